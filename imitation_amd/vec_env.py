@@ -1,0 +1,230 @@
+"""Host-side vectorised environment protocol + synthetic environments.
+
+Environment workers stay on host CPU (BASELINE.json north_star). This module provides
+the SB3 `VecEnv` surface the reference's trainer relies on:
+`num_envs, observation_space, action_space, reset(), step_async(), step_wait(), step()`
+with auto-reset semantics -- on `dones[i]` the returned `obs[i]` is the post-reset
+observation, `infos[i]["terminal_observation"]` holds the true last observation and
+`infos[i]["TimeLimit.truncated"]` flags time-limit endings (relied on by
+`rewards/reward_wrapper.py:100-104`, `data/rollout.py:161-167`).
+
+In addition to the dict-of-infos protocol, environments may implement the *array* fast
+path `step_wait_arrays()` which returns `(obs, rews, dones, next_obs_fixed, truncated)`
+without building `num_envs` Python dicts per step; the GPU rollout collector uses it
+when present and falls back to parsing `infos` otherwise.
+"""
+from __future__ import annotations
+
+import abc
+from typing import Any, Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from imitation_amd import spaces
+
+
+class VecEnv(abc.ABC):
+    """Abstract asynchronous vectorised environment (SB3 `VecEnv` surface)."""
+
+    def __init__(self, num_envs: int, observation_space: spaces.Space, action_space: spaces.Space):
+        self.num_envs = int(num_envs)
+        self.observation_space = observation_space
+        self.action_space = action_space
+
+    @abc.abstractmethod
+    def reset(self) -> np.ndarray:
+        ...
+
+    @abc.abstractmethod
+    def step_async(self, actions: np.ndarray) -> None:
+        ...
+
+    @abc.abstractmethod
+    def step_wait(self) -> Tuple[np.ndarray, np.ndarray, np.ndarray, List[Dict[str, Any]]]:
+        ...
+
+    def step(self, actions: np.ndarray):
+        self.step_async(actions)
+        return self.step_wait()
+
+    def close(self) -> None:
+        pass
+
+    def seed(self, seed: Optional[int] = None) -> Sequence[Optional[int]]:
+        return [seed] * self.num_envs
+
+    @property
+    def unwrapped(self) -> "VecEnv":
+        return self.venv.unwrapped if isinstance(self, VecEnvWrapper) else self
+
+    # SB3 API used by `BaseAlgorithm.set_env` checks; kept for duck-typing.
+    def env_is_wrapped(self, wrapper_class, indices=None):
+        return [False] * self.num_envs
+
+
+class VecEnvWrapper(VecEnv):
+    """Base wrapper: forwards everything to `venv` unless overridden."""
+
+    def __init__(self, venv: VecEnv, observation_space=None, action_space=None):
+        self.venv = venv
+        super().__init__(
+            venv.num_envs,
+            observation_space or venv.observation_space,
+            action_space or venv.action_space,
+        )
+
+    def step_async(self, actions):
+        self.venv.step_async(actions)
+
+    def reset(self):
+        return self.venv.reset()
+
+    def step_wait(self):
+        return self.venv.step_wait()
+
+    def close(self):
+        return self.venv.close()
+
+    def seed(self, seed=None):
+        return self.venv.seed(seed)
+
+    def __getattr__(self, name):
+        if name.startswith("_") or name == "venv":
+            raise AttributeError(name)
+        return getattr(self.venv, name)
+
+
+class ArrayVecEnv(VecEnv):
+    """VecEnv whose native step produces arrays; dict infos are derived from them."""
+
+    @abc.abstractmethod
+    def step_wait_arrays(self) -> Tuple[np.ndarray, np.ndarray, np.ndarray, np.ndarray, np.ndarray]:
+        """Returns `(obs, rews, dones, next_obs_fixed, truncated)`.
+
+        `obs` is post-auto-reset; `next_obs_fixed[i]` is the true successor observation
+        (== terminal observation where `dones[i]`, else `obs[i]`); `truncated[i]` is True
+        iff the episode ended by time limit."""
+
+    def step_wait(self):
+        obs, rews, dones, nxt, trunc = self.step_wait_arrays()
+        infos: List[Dict[str, Any]] = [{} for _ in range(self.num_envs)]
+        for i in np.flatnonzero(dones):
+            infos[i]["terminal_observation"] = nxt[i].copy()
+            infos[i]["TimeLimit.truncated"] = bool(trunc[i])
+        return obs, rews, dones, infos
+
+
+class SyntheticVecEnv(ArrayVecEnv):
+    """HalfCheetah-shaped synthetic control environment.
+
+    Dynamics `o' = 0.9*o + 0.1*tanh(W a) + 0.05*xi`, `W in R^{obs x act}`, `xi ~ N(0,1)`,
+    env reward 0 (optionally `-|a|^2`), fixed horizon with `TimeLimit.truncated=True`.
+    Discrete action spaces are embedded through a fixed table of `n` action vectors.
+    All randomness comes from a private `np.random.Generator` (never the global streams
+    the trainer's index draws use).
+    """
+
+    def __init__(
+        self,
+        num_envs: int = 1024,
+        obs_dim: int = 17,
+        act_dim: int = 6,
+        horizon: int = 1000,
+        seed: int = 0,
+        obs_dtype=np.float32,
+        n_discrete: Optional[int] = None,
+        stagger: bool = False,
+    ):
+        obs_space = spaces.Box(-np.inf, np.inf, (obs_dim,), obs_dtype)
+        if n_discrete is None:
+            act_space: spaces.Space = spaces.Box(-1.0, 1.0, (act_dim,), np.float32)
+        else:
+            act_space = spaces.Discrete(n_discrete)
+        super().__init__(num_envs, obs_space, act_space)
+        self.obs_dim, self.act_dim, self.horizon = obs_dim, act_dim, int(horizon)
+        self._seed0 = seed
+        self._rng = np.random.default_rng(seed)
+        wrng = np.random.default_rng(10_000 + seed)
+        self._W = wrng.standard_normal((act_dim, obs_dim)).astype(np.float64) / np.sqrt(act_dim)
+        self._table = (
+            wrng.uniform(-1, 1, (n_discrete, act_dim)) if n_discrete is not None else None
+        )
+        self._obs = np.zeros((num_envs, obs_dim), dtype=np.float64)
+        self._t = np.zeros(num_envs, dtype=np.int64)
+        self._stagger = stagger
+        self._actions: Optional[np.ndarray] = None
+
+    def _fresh(self, n: int) -> np.ndarray:
+        return 0.1 * self._rng.standard_normal((n, self.obs_dim))
+
+    def reset(self) -> np.ndarray:
+        self._obs = self._fresh(self.num_envs)
+        self._t[:] = 0
+        if self._stagger:
+            # Desynchronise episode ends across envs (keeps a fixed horizon per episode
+            # only when stagger=False; used by tests that want dones in every step).
+            self._t[:] = self._rng.integers(0, self.horizon, self.num_envs)
+        return self._obs.astype(self.observation_space.dtype)
+
+    def step_async(self, actions: np.ndarray) -> None:
+        self._actions = np.asarray(actions)
+
+    def step_wait_arrays(self):
+        a = self._actions
+        assert a is not None, "step_async must be called first"
+        self._actions = None
+        if self._table is not None:
+            a = self._table[np.asarray(a).reshape(-1).astype(np.int64)]
+        a = a.reshape(self.num_envs, self.act_dim).astype(np.float64)
+        nxt = 0.9 * self._obs + 0.1 * np.tanh(a @ self._W)
+        nxt += 0.05 * self._rng.standard_normal(nxt.shape)
+        self._t += 1
+        dones = self._t >= self.horizon
+        dt = self.observation_space.dtype
+        next_fixed = nxt.astype(dt)
+        n_done = int(dones.sum())
+        if n_done:
+            nxt[dones] = self._fresh(n_done)
+            self._t[dones] = 0
+        self._obs = nxt
+        obs = nxt.astype(dt)
+        rews = np.zeros(self.num_envs, dtype=np.float32)
+        return obs, rews, dones, next_fixed, dones.copy()
+
+
+class CountingVecEnv(ArrayVecEnv):
+    """Deterministic bookkeeping env in the spirit of the reference's `_CountingEnv`
+    (`tests/data/test_wrappers.py:14-74`): `obs = t`, `rew = 10 t`, per-env episode
+    lengths; terminal (not truncated) endings."""
+
+    def __init__(self, episode_lengths: Sequence[int], obs_dim: int = 1, act_dim: int = 1):
+        n = len(episode_lengths)
+        super().__init__(
+            n,
+            spaces.Box(-np.inf, np.inf, (obs_dim,), np.float32),
+            spaces.Box(-np.inf, np.inf, (act_dim,), np.float32),
+        )
+        self._lens = np.asarray(episode_lengths, dtype=np.int64)
+        self._t = np.zeros(n, dtype=np.int64)
+        self._obs_dim = obs_dim
+        self._actions = None
+
+    def _mk(self, t):
+        return np.repeat(t.astype(np.float32)[:, None], self._obs_dim, axis=1)
+
+    def reset(self):
+        self._t[:] = 0
+        return self._mk(self._t)
+
+    def step_async(self, actions):
+        self._actions = actions
+
+    def step_wait_arrays(self):
+        self._actions = None
+        self._t += 1
+        rews = (10.0 * self._t).astype(np.float32)
+        dones = self._t >= self._lens
+        next_fixed = self._mk(self._t)
+        self._t[dones] = 0
+        obs = self._mk(self._t)
+        return obs, rews, dones, next_fixed, np.zeros_like(dones)

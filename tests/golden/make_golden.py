@@ -1,0 +1,61 @@
+"""Generates the committed golden fixtures by running the REFERENCE's own code
+(`/root/reference/src/imitation`, imported unmodified under `oracle.ref_shim`) on the seeded
+cases of `tests/harness.py`. Runs only in the build container (the GPU box has no
+/root/reference). Usage: `python tests/golden/make_golden.py`.
+
+Outputs `tests/golden/<case>.npz`: replay-ring contents and indices, disc / policy
+parameters after training, per-update discriminator statistics, rollout-buffer arrays and
+reward predictions on fixed inputs.
+"""
+import os
+import sys
+import tempfile
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+
+from tests import harness  # noqa: E402
+
+
+def dump_sb3_fixture_layout():
+    """The one SB3 artefact on disk: state-dict layout + optimiser group of the fixture
+    `tests/testdata/expert_models/cartpole_0/policies/final/model.zip` (SB3 2.2.0a3)."""
+    import io
+    import json
+    import zipfile
+
+    import torch
+
+    z = zipfile.ZipFile("/root/reference/tests/testdata/expert_models/cartpole_0/policies/final/model.zip")
+    sd = torch.load(io.BytesIO(z.read("policy.pth")), map_location="cpu", weights_only=False)
+    opt = torch.load(io.BytesIO(z.read("policy.optimizer.pth")), map_location="cpu", weights_only=False)
+    pg = opt["param_groups"][0]
+    data = json.loads(z.read("data"))
+    keys = ["n_steps", "batch_size", "n_epochs", "gamma", "gae_lambda", "ent_coef", "vf_coef",
+            "max_grad_norm", "normalize_advantage", "target_kl"]
+    out = {
+        "sb3_version": z.read("_stable_baselines3_version").decode(),
+        "state_dict": {k: list(v.shape) for k, v in sd.items()},
+        "optimizer": {"betas": list(pg["betas"]), "eps": pg["eps"], "weight_decay": pg["weight_decay"],
+                      "n_params": len(pg["params"])},
+        "hyperparameter_fields": {k: data[k] for k in keys},
+    }
+    path = os.path.join(HERE, "sb3_fixture_layout.json")
+    with open(path, "w") as f:
+        json.dump(out, f, indent=1, sort_keys=True)
+    print("wrote", path)
+
+
+def main():
+    dump_sb3_fixture_layout()
+    for name in harness.CASES:
+        out = harness.run_case("reference", name, tempfile.mkdtemp())
+        path = os.path.join(HERE, f"{name}.npz")
+        np.savez_compressed(path, **out)
+        print(f"wrote {path}: {len(out)} arrays, {os.path.getsize(path)} bytes")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,195 @@
+"""Shared test harness: runs one seeded GAIL/AIRL case through an implementation
+(`reference` under the oracle shim, `oracle`, or the HIP product `hip`) and returns a flat
+dict of arrays that the parity tests compare.
+
+The three implementations expose the same constructor surface (that is the drop-in claim),
+so a case is a config dict + a namespace of classes.
+"""
+from __future__ import annotations
+
+import types as pytypes
+from typing import Any, Dict
+
+import numpy as np
+import torch as th
+
+from imitation_amd.vec_env import SyntheticVecEnv
+
+CASES: Dict[str, Dict[str, Any]] = {
+    # GAIL, Box actions, grad accumulation (minibatch 32 of 64), ring truncation + wrap
+    # (capacity 96 < 128 transitions/round), episodes ending mid-rollout (horizon 10, n_steps 16).
+    "gail_box": dict(algo="gail", n_envs=8, horizon=10, obs_dim=17, act_dim=6, n_discrete=None,
+                     n_steps=16, ppo_batch=32, n_epochs=2, ent_coef=0.1, disc_hid=(32, 32),
+                     demo_batch=64, demo_minibatch=32, n_disc=2, capacity=96, n_demo=500, rounds=3,
+                     norm_policy=True, norm_disc=True, obs_dtype="float32"),
+    # float64 observations (HalfCheetah-like dtype), wider disc, no input norm on the policy.
+    "gail_f64": dict(algo="gail", n_envs=4, horizon=7, obs_dim=5, act_dim=3, n_discrete=None,
+                     n_steps=8, ppo_batch=16, n_epochs=3, ent_coef=0.0, disc_hid=(64, 32),
+                     demo_batch=16, demo_minibatch=None, n_disc=3, capacity=None, n_demo=100, rounds=2,
+                     norm_policy=False, norm_disc=True, obs_dtype="float64"),
+    # Discrete actions (CartPole-shaped): one-hot action preprocessing, Categorical policy.
+    "gail_discrete": dict(algo="gail", n_envs=8, horizon=6, obs_dim=4, act_dim=2, n_discrete=2,
+                          n_steps=8, ppo_batch=16, n_epochs=2, ent_coef=0.01, disc_hid=(32, 32),
+                          demo_batch=32, demo_minibatch=None, n_disc=2, capacity=None, n_demo=200, rounds=2,
+                          norm_policy=True, norm_disc=True, obs_dtype="float32"),
+    # AIRL, shaped reward net, NormalizedRewardNet output norm (script default), use_next_state.
+    "airl_box": dict(algo="airl", n_envs=8, horizon=10, obs_dim=11, act_dim=3, n_discrete=None,
+                     n_steps=16, ppo_batch=32, n_epochs=2, ent_coef=0.0, disc_hid=(32,),
+                     demo_batch=64, demo_minibatch=None, n_disc=2, capacity=None, n_demo=300, rounds=2,
+                     norm_policy=True, norm_disc=True, obs_dtype="float32", normalize_output=True),
+}
+
+
+def make_demo_arrays(cfg, seed: int = 1) -> Dict[str, np.ndarray]:
+    rng = np.random.default_rng(seed)
+    n, od, ad = cfg["n_demo"], cfg["obs_dim"], cfg["act_dim"]
+    dt = np.dtype(cfg["obs_dtype"])
+    obs = rng.standard_normal((n, od)).astype(dt)
+    if cfg["n_discrete"] is None:
+        acts = rng.uniform(-1, 1, (n, ad)).astype(np.float32)
+    else:
+        acts = rng.integers(0, cfg["n_discrete"], n).astype(np.int64)
+    nxt = (0.9 * obs + 0.1 * rng.standard_normal((n, od))).astype(dt)
+    dones = np.zeros(n, dtype=bool)
+    dones[cfg["horizon"] - 1::cfg["horizon"]] = True
+    return dict(obs=obs, acts=acts, next_obs=nxt, dones=dones)
+
+
+def namespace(impl: str) -> pytypes.SimpleNamespace:
+    """Classes of one implementation under common names."""
+    if impl == "reference":
+        from oracle import ref_shim
+
+        ref_shim.install()
+        from imitation.algorithms.adversarial.airl import AIRL
+        from imitation.algorithms.adversarial.gail import GAIL
+        from imitation.data import types as rtypes
+        from imitation.policies.base import FeedForward32Policy, NormalizeFeaturesExtractor
+        from imitation.rewards import reward_nets as rn
+        from imitation.util import logger as rlog
+        from imitation.util.networks import RunningNorm
+        from oracle import sb3_restated as sb
+
+        def transitions(**kw):
+            n = len(kw["obs"])
+            return rtypes.Transitions(infos=np.array([{}] * n), **kw)
+
+        return pytypes.SimpleNamespace(
+            GAIL=GAIL, AIRL=AIRL, PPO=sb.PPO, FeedForward32Policy=FeedForward32Policy,
+            NormalizeFeaturesExtractor=NormalizeFeaturesExtractor, RunningNorm=RunningNorm,
+            BasicRewardNet=rn.BasicRewardNet, BasicShapedRewardNet=rn.BasicShapedRewardNet,
+            NormalizedRewardNet=rn.NormalizedRewardNet, Transitions=transitions,
+            configure_logger=lambda d: rlog.configure(d, []))
+    if impl == "oracle":
+        from oracle import imitation_restated as o
+        from oracle import sb3_restated as sb
+
+        return pytypes.SimpleNamespace(
+            GAIL=o.GAIL, AIRL=o.AIRL, PPO=sb.PPO, FeedForward32Policy=o.FeedForward32Policy,
+            NormalizeFeaturesExtractor=o.NormalizeFeaturesExtractor, RunningNorm=o.RunningNorm,
+            BasicRewardNet=o.BasicRewardNet, BasicShapedRewardNet=o.BasicShapedRewardNet,
+            NormalizedRewardNet=o.NormalizedRewardNet, Transitions=lambda **kw: o.Transitions(**kw),
+            configure_logger=lambda d: o.configure_logger(d, []))
+    if impl == "hip":
+        import imitation_amd as p
+
+        return pytypes.SimpleNamespace(
+            GAIL=p.GAIL, AIRL=p.AIRL, PPO=p.PPO, FeedForward32Policy=p.FeedForward32Policy,
+            NormalizeFeaturesExtractor=p.NormalizeFeaturesExtractor, RunningNorm=p.RunningNorm,
+            BasicRewardNet=p.BasicRewardNet, BasicShapedRewardNet=p.BasicShapedRewardNet,
+            NormalizedRewardNet=p.NormalizedRewardNet, Transitions=lambda **kw: p.Transitions(**kw),
+            configure_logger=lambda d: p.configure_logger(d, []))
+    raise ValueError(impl)
+
+
+def build_trainer(impl: str, cfg, log_dir: str, device: str = "cpu"):
+    ns = namespace(impl)
+    th.manual_seed(0)
+    np.random.seed(0)
+    venv = SyntheticVecEnv(num_envs=cfg["n_envs"], obs_dim=cfg["obs_dim"], act_dim=cfg["act_dim"],
+                           horizon=cfg["horizon"], seed=0, obs_dtype=np.dtype(cfg["obs_dtype"]),
+                           n_discrete=cfg["n_discrete"])
+    pk = {}
+    if cfg["norm_policy"]:
+        pk = dict(features_extractor_class=ns.NormalizeFeaturesExtractor,
+                  features_extractor_kwargs=dict(normalize_class=ns.RunningNorm))
+    algo = ns.PPO(ns.FeedForward32Policy, venv, n_steps=cfg["n_steps"], batch_size=cfg["ppo_batch"],
+                  n_epochs=cfg["n_epochs"], ent_coef=cfg["ent_coef"], seed=0, policy_kwargs=pk, device=device)
+    kw = dict(normalize_input_layer=ns.RunningNorm) if cfg["norm_disc"] else {}
+    if cfg["algo"] == "gail":
+        net = ns.BasicRewardNet(venv.observation_space, venv.action_space, hid_sizes=cfg["disc_hid"], **kw)
+        cls = ns.GAIL
+    else:
+        net = ns.BasicShapedRewardNet(venv.observation_space, venv.action_space,
+                                      reward_hid_sizes=cfg["disc_hid"], potential_hid_sizes=(32, 32),
+                                      use_next_state=True, **kw)
+        if cfg.get("normalize_output"):
+            net = ns.NormalizedRewardNet(net, ns.RunningNorm)
+        cls = ns.AIRL
+    demos = ns.Transitions(**make_demo_arrays(cfg))
+    trainer = cls(demonstrations=demos, demo_batch_size=cfg["demo_batch"], venv=venv, gen_algo=algo,
+                  reward_net=net, demo_minibatch_size=cfg["demo_minibatch"],
+                  n_disc_updates_per_round=cfg["n_disc"], gen_replay_buffer_capacity=cfg["capacity"],
+                  custom_logger=ns.configure_logger(log_dir), allow_variable_horizon=False)
+    return trainer, venv
+
+
+def _np(x):
+    if isinstance(x, th.Tensor):
+        return x.detach().cpu().numpy()
+    return np.asarray(x)
+
+
+def snapshot(trainer) -> Dict[str, np.ndarray]:
+    """State that must agree across implementations after a run."""
+    out: Dict[str, np.ndarray] = {}
+    for k, v in trainer._reward_net.state_dict().items():
+        out[f"disc/{k}"] = _np(v)
+    for k, v in trainer.gen_algo.policy.state_dict().items():
+        out[f"policy/{k}"] = _np(v)
+    buf = trainer._gen_replay_buffer
+    arrays = buf._buffer._arrays if hasattr(buf, "_buffer") else buf._arrays
+    for k in ("obs", "acts", "next_obs", "dones"):
+        out[f"replay/{k}"] = _np(arrays[k])
+    inner = buf._buffer if hasattr(buf, "_buffer") else buf
+    out["replay/_idx"] = np.asarray(inner._idx)
+    out["replay/_n_data"] = np.asarray(inner._n_data)
+    rb = trainer.gen_algo.rollout_buffer
+    for k in ("rewards", "values", "log_probs", "advantages", "returns", "actions", "observations"):
+        out[f"rollout/{k}"] = _np(getattr(rb, k)).reshape(-1)
+    out["counters"] = np.asarray([trainer._global_step, trainer._disc_step, trainer.gen_algo.num_timesteps])
+    return out
+
+
+def run_case(impl: str, name: str, log_dir: str, device: str = "cpu") -> Dict[str, np.ndarray]:
+    cfg = CASES[name]
+    trainer, venv = build_trainer(impl, cfg, log_dir, device)
+    stats = []
+    orig = trainer.train_disc
+
+    def recording_train_disc(**kw):
+        s = orig(**kw)
+        stats.append([float(s[k]) for k in sorted(s)])
+        return s
+
+    trainer.train_disc = recording_train_disc
+    trainer.train(cfg["rounds"] * cfg["n_envs"] * cfg["n_steps"])
+    out = snapshot(trainer)
+    out["disc_stats"] = np.asarray(stats, dtype=np.float64)
+    # one more reward query on fixed inputs through the public RewardFn surface
+    rng = np.random.default_rng(7)
+    n = 32
+    s = rng.standard_normal((n, cfg["obs_dim"])).astype(np.dtype(cfg["obs_dtype"]))
+    if cfg["n_discrete"] is None:
+        a = rng.uniform(-1, 1, (n, cfg["act_dim"])).astype(np.float32)
+    else:
+        a = rng.integers(0, cfg["n_discrete"], n)
+    ns_ = rng.standard_normal((n, cfg["obs_dim"])).astype(np.dtype(cfg["obs_dtype"]))
+    d = rng.random(n) < 0.2
+    out["reward_train_predict"] = _np(trainer.reward_train.predict(s, a, ns_, d))
+    out["reward_test_predict"] = _np(trainer.reward_test.predict(s, a, ns_, d))
+    return out
+
+
+# Keys whose values are integer/boolean bookkeeping and must match bit-exactly.
+EXACT_KEYS = ("replay/dones", "replay/_idx", "replay/_n_data", "counters")
