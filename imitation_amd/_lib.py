@@ -1,0 +1,118 @@
+"""ctypes binding of `libimitation_hip.so` (the C-ABI boundary, `include/imitation_hip.h`).
+
+PyTorch is used for device memory and streams only: tensors are passed as raw device
+pointers + sizes, the current HIP stream as `void*`. There is NO CPU fallback: if the shared
+library is missing or a call returns non-zero, a loud exception is raised.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import torch as th
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libimitation_hip.so")
+
+IA_MAX_LAYERS = 8
+ACT_NONE, ACT_RELU, ACT_TANH, ACT_SOFTPLUS = 0, 1, 2, 3
+GEMM_NT, GEMM_NN, GEMM_TN = 0, 1, 2
+
+
+class MlpDesc(C.Structure):
+    _fields_ = [("n_layers", C.c_int), ("dims", C.c_int * (IA_MAX_LAYERS + 1)), ("hidden_act", C.c_int)]
+
+
+class PolicyDesc(C.Structure):
+    _fields_ = [("obs_dim", C.c_int), ("act_dim", C.c_int), ("hidden", C.c_int), ("discrete", C.c_int),
+                ("has_norm", C.c_int), ("norm_eps", C.c_float)]
+
+
+class HipExtensionMissing(RuntimeError):
+    pass
+
+
+_P, _I, _L, _F, _D = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_double
+_SIGS = {
+    "ia_version": ([], C.c_int),
+    "ia_mlp_param_count": ([C.POINTER(MlpDesc)], C.c_int64),
+    "ia_mlp_hidden_floats_per_row": ([C.POINTER(MlpDesc)], C.c_int64),
+    "ia_gemm_f32": ([_I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _P, _I, _P, _I, _I, _P, _P], C.c_int),
+    "ia_mlp_forward": ([C.POINTER(MlpDesc), _P, _P, _I, _I, _P, _P, _I, _P], C.c_int),
+    "ia_mlp_backward": ([C.POINTER(MlpDesc), _P, _P, _I, _I, _P, _P, _P, _P, _I, _P, _P], C.c_int),
+    "ia_reduce_partials": ([_P, _I, _L, _F, _I, _P, _P], C.c_int),
+    "ia_adam_step": ([_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _F, _P], C.c_int),
+    "ia_running_norm_ws_floats": ([_I, _I], C.c_int64),
+    "ia_running_norm_update": ([_P, _I, _I, _I, _P, _P, _P, _P, _P], C.c_int),
+    "ia_running_norm_apply": ([_P, _I, _I, _I, _P, _P, _F, _P, _I, _P], C.c_int),
+    "ia_gather_concat": ([_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _I, _I, _P], C.c_int),
+    "ia_bce_logits": ([_P, _I, _I, _F, _P, _P, _P], C.c_int),
+    "ia_airl_logits": ([_P, _P, _P, _P, _P, _F, _I, _P, _P], C.c_int),
+    "ia_airl_route_grad": ([_P, _P, _F, _I, _P, _P, _P, _P], C.c_int),
+    "ia_gather_rows": ([_P, _P, _I, _I, _P, _P], C.c_int),
+    "ia_policy_param_count": ([C.POINTER(PolicyDesc)], C.c_int64),
+    "ia_policy_transpose": ([C.POINTER(PolicyDesc), _P, _P, _P], C.c_int),
+    "ia_policy_act": ([C.POINTER(PolicyDesc), _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P], C.c_int),
+    "ia_policy_evaluate": ([C.POINTER(PolicyDesc), _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P], C.c_int),
+    "ia_gae": ([_P, _P, _P, _P, _P, _I, _I, _F, _F, _P, _P, _P], C.c_int),
+    "ia_timeout_bootstrap": ([_P, _P, _P, _F, _L, _P], C.c_int),
+    "ia_ppo_ws_floats": ([C.POINTER(PolicyDesc), _I], C.c_int64),
+    "ia_ppo_minibatch": ([C.POINTER(PolicyDesc), _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F,
+                          _F, _F, _F, _P, _P, _F, _F, _F, _F, _F, _P, _P, _P], C.c_int),
+    "ia_ppo_epoch": ([C.POINTER(PolicyDesc), _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _F,
+                      _F, _F, _P, _P, _D, _D, _D, _F, _L, _P, _P, _P], C.c_int),
+}
+
+EXPORTED_SYMBOLS = tuple(_SIGS)
+_lib: Optional[C.CDLL] = None
+
+
+def load() -> C.CDLL:
+    """Loads the shared library (idempotent). Raises `HipExtensionMissing` when it was not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise HipExtensionMissing(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(make -C imitation_amd/csrc). The HIP path has no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (argtypes, restype) in _SIGS.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is missing
+        fn.argtypes = argtypes
+        fn.restype = restype
+    _lib = lib
+    return lib
+
+
+def ptr(t: Optional[th.Tensor]):
+    """Raw device pointer of a tensor (None -> NULL). The tensor must be contiguous."""
+    if t is None:
+        return None
+    assert t.is_contiguous(), "C-ABI expects contiguous buffers"
+    return t.data_ptr()
+
+
+def stream():
+    return th.cuda.current_stream().cuda_stream
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        raise RuntimeError(f"libimitation_hip: {what} failed with code {rc}")
+
+
+def call(name: str, *args) -> None:
+    lib = load()
+    check(getattr(lib, name)(*args), name)
+
+
+def mlp_desc(dims, hidden_act: int) -> MlpDesc:
+    d = MlpDesc()
+    assert 2 <= len(dims) <= IA_MAX_LAYERS + 1
+    d.n_layers = len(dims) - 1
+    for i, v in enumerate(dims):
+        d.dims[i] = int(v)
+    d.hidden_act = hidden_act
+    return d

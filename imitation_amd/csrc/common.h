@@ -1,0 +1,65 @@
+// Shared declarations for the gfx950 (MI355X / CDNA4) kernels of the GAIL/AIRL round.
+// Wave = 64 lanes; fp32 MFMA = v_mfma_f32_32x32x2_f32 (exact fp32 FMA chain, 157 TF peak).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define IA_OK 0
+#define IA_ERR_ARG (-1)
+#define IA_ERR_UNSUPPORTED (-2)
+
+#define IA_ACT_NONE 0
+#define IA_ACT_RELU 1
+#define IA_ACT_TANH 2
+#define IA_ACT_SOFTPLUS 3  // max(x,0)+log1p(exp(-|x|)) == -logsigmoid(-x)  (gail.py:75-83)
+
+#define IA_CHECK_LAUNCH()                         \
+  do {                                            \
+    hipError_t e__ = hipGetLastError();           \
+    if (e__ != hipSuccess) return (int)e__;       \
+  } while (0)
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// ---- GEMM (gemm.hip) -------------------------------------------------------------------
+enum { IA_GEMM_NT = 0, IA_GEMM_NN = 1, IA_GEMM_TN = 2 };
+
+struct IaGemm {
+  const float* A;
+  const float* B;
+  float* C;
+  int M, N, K;          // C is [M,N]; K is the reduction length
+  int lda, ldb, ldc;
+  const float* bias;    // NT: [N] added before the activation (may be null)
+  int act;              // NT: epilogue activation; NN: derivative kind applied with P
+  const float* P;       // NN: post-activation values of the layer whose input-grad this is
+  int ldp;
+  int splits;           // TN: number of K splits (grid.z)
+  int k_per_split;      // TN: rows of K handled by one split (multiple of 32)
+  long long c_split_stride;   // TN: elements between consecutive split slabs of C
+  float* dbias;               // TN: per-split column sums of A (bias gradient), may be null
+  long long dbias_split_stride;  // TN: elements between split slabs of dbias
+};
+
+int ia_launch_gemm(int mode, const IaGemm& g, hipStream_t stream);
+
+__device__ __forceinline__ float ia_softplus(float x) {
+  return fmaxf(x, 0.0f) + log1pf(expf(-fabsf(x)));
+}
+__device__ __forceinline__ float ia_apply_act(float x, int act) {
+  switch (act) {
+    case IA_ACT_RELU: return fmaxf(x, 0.0f);
+    case IA_ACT_TANH: return tanhf(x);
+    case IA_ACT_SOFTPLUS: return ia_softplus(x);
+    default: return x;
+  }
+}
+// derivative expressed through the POST-activation value p
+__device__ __forceinline__ float ia_act_grad_from_post(float p, int act) {
+  switch (act) {
+    case IA_ACT_RELU: return p > 0.0f ? 1.0f : 0.0f;
+    case IA_ACT_TANH: return 1.0f - p * p;
+    default: return 1.0f;
+  }
+}

@@ -1,0 +1,250 @@
+// fp32 MFMA GEMM for gfx950: the contraction engine behind every dense layer of the
+// discriminator / reward nets (forward, input-gradient and split-K weight-gradient forms).
+//
+//   NT : C[M,N] = act(A[M,K] . B[N,K]^T + bias)          -- Linear forward   (networks.py:262-277)
+//   NN : C[M,N] = (A[M,K] . B[K,N]) * act'(P[M,N])        -- grad wrt layer input
+//   TN : C_s[M,N] = A[Ks,M]^T . B[Ks,N]  per K-split s     -- grad wrt weights (+ column sums of A)
+//
+// One wave owns TM x TN tiles of v_mfma_f32_32x32x2_f32 (lane l feeds A[i=l&31][k=l>>5] and
+// B[k=l>>5][j=l&31]); operands are staged through LDS in whichever of two layouts makes the
+// fragment read bank-conflict free for ds_read_b32 (32 consecutive lanes -> 32 distinct banks):
+//   "MK": [row][BK+1]  (odd stride)  for operands that are k-contiguous in memory,
+//   "KM": [k][rows]                  for operands that are row-contiguous in memory.
+// Global->LDS goes through registers (float4 loads issued one chunk ahead, written to the
+// other LDS buffer after the MFMAs: one barrier per 32-deep K chunk).
+#include "common.h"
+
+namespace {
+
+constexpr int BK = 32;
+constexpr int LDP = BK + 1;
+
+__device__ __forceinline__ float4 load4_guard(const float* __restrict__ p, int n_valid, bool vec_ok) {
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (n_valid >= 4 && vec_ok) {
+    v = *reinterpret_cast<const float4*>(p);
+  } else if (n_valid > 0) {
+    v.x = p[0];
+    if (n_valid > 1) v.y = p[1];
+    if (n_valid > 2) v.z = p[2];
+    if (n_valid > 3) v.w = p[3];
+  }
+  return v;
+}
+
+// Tile loaders. ROWS = tile extent in the non-reduction index.
+template <int ROWS, int NT, bool KM>
+struct TileIO {
+  static constexpr int NV = ROWS * (BK / 4) / NT;  // float4 per thread
+  static_assert(ROWS * (BK / 4) % NT == 0, "tile not divisible among threads");
+
+  // src is [rows_total, K] (k contiguous) when !KM, or [K, rows_total] (row contiguous) when KM.
+  __device__ static void load(float4 (&r)[NV], const float* __restrict__ src, int ld, int row0, int rows_total,
+                              int k0, int k_end, bool vec_ok, int tid) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int f = tid + i * NT;
+      if (!KM) {
+        const int rr = f >> 3, kq = f & 7;
+        const int gr = row0 + rr, gk = k0 + kq * 4;
+        const int nv = (gr < rows_total) ? (k_end - gk) : 0;
+        r[i] = load4_guard(src + (long long)gr * ld + gk, nv, vec_ok);
+      } else {
+        constexpr int QPR = ROWS / 4;
+        const int kr = f / QPR, mq = f % QPR;
+        const int gk = k0 + kr, gm = row0 + mq * 4;
+        const int nv = (gk < k_end) ? (rows_total - gm) : 0;
+        r[i] = load4_guard(src + (long long)gk * ld + gm, nv, vec_ok);
+      }
+    }
+  }
+  __device__ static void store(const float4 (&r)[NV], float* __restrict__ S, int tid) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int f = tid + i * NT;
+      if (!KM) {
+        const int rr = f >> 3, kq = f & 7;
+        float* d = S + rr * LDP + kq * 4;
+        d[0] = r[i].x; d[1] = r[i].y; d[2] = r[i].z; d[3] = r[i].w;
+      } else {
+        constexpr int QPR = ROWS / 4;
+        const int kr = f / QPR, mq = f % QPR;
+        *reinterpret_cast<float4*>(S + kr * ROWS + mq * 4) = r[i];
+      }
+    }
+  }
+  __device__ __forceinline__ static float frag(const float* __restrict__ S, int i0, int kk, int li, int lh) {
+    return KM ? S[(kk + lh) * ROWS + i0 + li] : S[(i0 + li) * LDP + kk + lh];
+  }
+  static constexpr int ELEMS = KM ? BK * ROWS : ROWS * LDP;
+};
+
+template <int WM, int WN, int TM, int TN, int MODE>
+__global__ __launch_bounds__(WM* WN * 64) void ia_gemm_kernel(IaGemm g) {
+  constexpr int NT = WM * WN * 64;
+  constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+  using AIO = TileIO<BM, NT, MODE == IA_GEMM_TN>;
+  using BIO = TileIO<BN, NT, MODE != IA_GEMM_NT>;
+  constexpr int STAGE = AIO::ELEMS + BIO::ELEMS;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const int wm = wave / WN, wn = wave % WN;
+
+  // XCD-aware tile order: hardware places block b on XCD b%8; give each XCD a contiguous run
+  // of tiles so neighbouring column tiles (which share their A rows) hit the same L2.
+  const int tiles_n = (g.N + BN - 1) / BN;
+  const int nb = gridDim.x;
+  const int b = blockIdx.x;
+  const int q = nb >> 3, rmd = nb & 7, xcd = b & 7;
+  const int t = (xcd < rmd ? xcd * (q + 1) : rmd * (q + 1) + (xcd - rmd) * q) + (b >> 3);
+  const int bm0 = (t / tiles_n) * BM, bn0 = (t % tiles_n) * BN;
+
+  int k_begin = 0, k_end = g.K;
+  if (MODE == IA_GEMM_TN) {
+    k_begin = blockIdx.z * g.k_per_split;
+    k_end = min(g.K, k_begin + g.k_per_split);
+  }
+  const bool a_vec = (g.lda % 4 == 0) && ((reinterpret_cast<uintptr_t>(g.A) & 15) == 0);
+  const bool b_vec = (g.ldb % 4 == 0) && ((reinterpret_cast<uintptr_t>(g.B) & 15) == 0);
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  float4 ra[AIO::NV], rb[BIO::NV];
+  const int n_chunks = (k_end - k_begin + BK - 1) / BK;
+  const bool do_db = (MODE == IA_GEMM_TN) && (g.dbias != nullptr) && (bn0 == 0);
+  float dbacc = 0.f;
+
+  if (n_chunks > 0) {
+    AIO::load(ra, g.A, g.lda, bm0, g.M, k_begin, k_end, a_vec, tid);
+    BIO::load(rb, g.B, g.ldb, bn0, g.N, k_begin, k_end, b_vec, tid);
+    AIO::store(ra, smem, tid);
+    BIO::store(rb, smem + AIO::ELEMS, tid);
+  }
+  __syncthreads();
+
+  for (int c = 0; c < n_chunks; ++c) {
+    const float* As = smem + (c & 1) * STAGE;
+    const float* Bs = As + AIO::ELEMS;
+    const bool more = (c + 1 < n_chunks);
+    if (more) {
+      const int k0 = k_begin + (c + 1) * BK;
+      AIO::load(ra, g.A, g.lda, bm0, g.M, k0, k_end, a_vec, tid);
+      BIO::load(rb, g.B, g.ldb, bn0, g.N, k0, k_end, b_vec, tid);
+    }
+#pragma unroll 4
+    for (int kk = 0; kk < BK; kk += 2) {
+      float af[TM], bf[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) af[i] = AIO::frag(As, (wm * TM + i) * 32, kk, li, lh);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) bf[j] = BIO::frag(Bs, (wn * TN + j) * 32, kk, li, lh);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+    }
+    if (do_db && tid < BM) {
+#pragma unroll 8
+      for (int kk = 0; kk < BK; ++kk) dbacc += As[kk * BM + tid];
+    }
+    if (more) {
+      float* An = smem + ((c + 1) & 1) * STAGE;
+      AIO::store(ra, An, tid);
+      BIO::store(rb, An + AIO::ELEMS, tid);
+    }
+    __syncthreads();
+  }
+
+  float* C = g.C;
+  if (MODE == IA_GEMM_TN) C += (long long)blockIdx.z * g.c_split_stride;
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int col = bn0 + (wn * TN + j) * 32 + li;
+      const int rbase = bm0 + (wm * TM + i) * 32 + 4 * lh;
+      float bcol = 0.f;
+      if (MODE == IA_GEMM_NT && g.bias != nullptr && col < g.N) bcol = g.bias[col];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = rbase + (r & 3) + 8 * (r >> 2);
+        if (row < g.M && col < g.N) {
+          float v = acc[i][j][r];
+          if (MODE == IA_GEMM_NT) {
+            v = ia_apply_act(v + bcol, g.act);
+          } else if (MODE == IA_GEMM_NN) {
+            if (g.P != nullptr) v *= ia_act_grad_from_post(g.P[(long long)row * g.ldp + col], g.act);
+          }
+          C[(long long)row * g.ldc + col] = v;
+        }
+      }
+    }
+  }
+  if (do_db && tid < BM && bm0 + tid < g.M) g.dbias[(long long)blockIdx.z * g.dbias_split_stride + bm0 + tid] = dbacc;
+}
+
+template <int WM, int WN, int TM, int TN, int MODE>
+int launch_cfg(const IaGemm& g, hipStream_t stream) {
+  constexpr int NT = WM * WN * 64;
+  constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+  using AIO = TileIO<BM, NT, MODE == IA_GEMM_TN>;
+  using BIO = TileIO<BN, NT, MODE != IA_GEMM_NT>;
+  constexpr size_t smem = 2 * (AIO::ELEMS + BIO::ELEMS) * sizeof(float);
+  auto kern = ia_gemm_kernel<WM, WN, TM, TN, MODE>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  const int tiles = ((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN);
+  dim3 grid(tiles, 1, MODE == IA_GEMM_TN ? g.splits : 1);
+  hipLaunchKernelGGL(kern, grid, dim3(NT), smem, stream, g);
+  IA_CHECK_LAUNCH();
+  return IA_OK;
+}
+
+template <int MODE>
+int launch_mode(const IaGemm& g, hipStream_t stream) {
+  if (g.M <= 32 && g.N > 32) return launch_cfg<1, 4, 1, 1, MODE>(g, stream);  // 32 x 128
+  if (g.N <= 32) return launch_cfg<4, 1, 1, 1, MODE>(g, stream);              // 128 x 32
+  if (g.N <= 64 || g.M <= 64) return launch_cfg<2, 2, 1, 1, MODE>(g, stream); // 64 x 64
+  return launch_cfg<2, 2, 2, 2, MODE>(g, stream);                             // 128 x 128
+}
+
+}  // namespace
+
+int ia_launch_gemm(int mode, const IaGemm& g, hipStream_t stream) {
+  if (g.M <= 0 || g.N <= 0 || g.K < 0) return IA_ERR_ARG;
+  switch (mode) {
+    case IA_GEMM_NT: return launch_mode<IA_GEMM_NT>(g, stream);
+    case IA_GEMM_NN: return launch_mode<IA_GEMM_NN>(g, stream);
+    case IA_GEMM_TN: return launch_mode<IA_GEMM_TN>(g, stream);
+  }
+  return IA_ERR_ARG;
+}
+
+// C-ABI test/bench entry for the raw contraction (device pointers, row-major fp32).
+extern "C" int ia_gemm_f32(int mode, const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M,
+                           int N, int K, const float* bias, int act, const float* P, int ldp, int splits,
+                           float* dbias, void* stream) {
+  IaGemm g{};
+  g.A = A; g.B = B; g.C = C; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
+  g.bias = bias; g.act = act; g.P = P; g.ldp = ldp; g.dbias = dbias;
+  g.splits = splits > 0 ? splits : 1;
+  g.k_per_split = ((K + g.splits - 1) / g.splits + BK - 1) / BK * BK;
+  g.c_split_stride = (long long)M * ldc;
+  g.dbias_split_stride = M;
+  return ia_launch_gemm(mode, g, (hipStream_t)stream);
+}

@@ -1,0 +1,172 @@
+/* imitation_hip.h -- C ABI of libimitation_hip.so (gfx950 / MI355X).
+ *
+ * The reference (HumanCompatibleAI/imitation) is pure Python and has NO FFI boundary
+ * (SURVEY 8b); each entry point below therefore names the reference Python code whose
+ * arithmetic it replaces (paths relative to /root/reference/src/imitation/), and
+ * INTEGRATION.md shows the ctypes stub a maintainer would add on the reference side.
+ *
+ * Conventions: every pointer is a DEVICE pointer to row-major fp32 unless stated; `stream`
+ * is a hipStream_t passed as void*; all calls are asynchronous on that stream and return 0
+ * on success, a negative IA_ERR_* for bad arguments or a positive hipError_t.
+ * No call allocates, frees or synchronises.
+ */
+#ifndef IMITATION_HIP_H
+#define IMITATION_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define IA_MAX_LAYERS 8
+#define IA_ACT_NONE 0
+#define IA_ACT_RELU 1
+#define IA_ACT_TANH 2
+#define IA_ACT_SOFTPLUS 3
+
+/* Dense stack = util/networks.py:204-283 `build_mlp` without the optional input norm:
+ * Linear(dims[0],dims[1]) -act- ... Linear(dims[n-1],dims[n]).  Parameters live in ONE flat
+ * buffer in torch `parameters()` order: W0[dims1,dims0], b0[dims1], W1, b1, ...            */
+typedef struct {
+  int n_layers;
+  int dims[IA_MAX_LAYERS + 1];
+  int hidden_act;
+} ia_mlp_desc;
+
+int ia_version(void);
+int64_t ia_mlp_param_count(const ia_mlp_desc* d);
+/* floats of workspace per row needed for hidden activations (sum of hidden widths) */
+int64_t ia_mlp_hidden_floats_per_row(const ia_mlp_desc* d);
+
+/* Raw fp32 MFMA contraction (test / bench entry). mode 0: C=act(A.B^T+bias); 1: C=(A.B)*act'(P);
+ * 2: split-K C_s=A^T.B with optional column sums of A into dbias[splits][M]. */
+int ia_gemm_f32(int mode, const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N,
+                int K, const float* bias, int act, const float* P, int ldp, int splits, float* dbias,
+                void* stream);
+
+/* rewards/reward_nets.py:441-457 `BasicRewardNet.forward` after concat (+ gail.py:75-83 when
+ * out_act=IA_ACT_SOFTPLUS): out[R,dims[n]] = mlp(X). `hidden` receives the post-activation
+ * hidden layers ([R,dims1] then [R,dims2] ...; needed by ia_mlp_backward, may be scratch). */
+int ia_mlp_forward(const ia_mlp_desc* d, const float* params, const float* X, int ldx, int R, float* hidden,
+                   float* out, int out_act, void* stream);
+
+/* autograd of the above (what `loss.backward()` does at adversarial/common.py:369):
+ * per-split partial parameter gradients `partials[splits][param_count]`; optional dX[R,ldx].
+ * `dhidden` is scratch of the same size as `hidden`. */
+int ia_mlp_backward(const ia_mlp_desc* d, const float* params, const float* X, int ldx, int R,
+                    const float* hidden, const float* dOut, float* dhidden, float* partials, int splits,
+                    float* dX, void* stream);
+
+/* grads[i] (+)= scale * sum_s partials[s][i]  (gradient accumulation across minibatches,
+ * adversarial/common.py:352-369) */
+int ia_reduce_partials(const float* partials, int splits, int64_t n, float scale, int accumulate, float* grads,
+                       void* stream);
+
+/* torch.optim.Adam single-tensor step (adversarial/common.py:372; SB3 PPO optimiser):
+ * step_size = lr/(1-b1^t), bc2_sqrt = sqrt(1-b2^t) are computed by the caller in double. */
+int ia_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float beta1,
+                 float beta2, float eps, float weight_decay, float step_size, float bc2_sqrt, void* stream);
+
+/* util/networks.py:111-134 `RunningNorm.update_stats` (Chan et al.), count is int32 on device.
+ * ws: scratch of at least (2*D*blocks+...) floats, see ia_running_norm_ws_floats. */
+int64_t ia_running_norm_ws_floats(int R, int D);
+int ia_running_norm_update(const float* X, int ldx, int R, int D, float* mean, float* var, int32_t* count,
+                           float* ws, void* stream);
+/* util/networks.py:91: Y = (X-mean)/sqrt(var+eps); columns [D,ldy) of Y are zeroed. */
+int ia_running_norm_apply(const float* X, int ldx, int R, int D, const float* mean, const float* var, float eps,
+                          float* Y, int ldy, void* stream);
+
+/* adversarial/common.py:592-603 + rewards/reward_nets.py:52-118,441-457: gather rows (int64 idx,
+ * NULL = identity) from transition tables and concatenate [state|action|next_state|done] into
+ * X[row0+i, :] (fp32, zero padded to ldx). Discrete actions (act_i64 != NULL) are one-hot
+ * encoded with width act_dim. dones are bytes (0/1). */
+int ia_gather_concat(const float* obs, const float* act_f32, const int64_t* act_i64, const float* next_obs,
+                     const uint8_t* dones, const int64_t* idx, int n, int obs_dim, int act_dim, int use_state,
+                     int use_action, int use_next_state, int use_done, float* X, int ldx, int row0, void* stream);
+
+/* adversarial/common.py:360-368 + 27-92: BCE-with-logits over R rows whose first n_expert rows
+ * are labelled 1 and the rest 0; loss scaled by `scale` (= minibatch/batch); dlogits = dLoss/dlogit.
+ * stats[8] = {loss, n_correct, n_correct_expert, n_correct_gen, n_pred_gen, entropy_sum,
+ * n_expert, n_gen}. */
+int ia_bce_logits(const float* logits, int R, int n_expert, float scale, float* dlogits, float* stats,
+                  void* stream);
+
+/* adversarial/airl.py:118 + rewards/reward_nets.py:701-736:
+ * logits = g + gamma*(1-done)*h_next - h_cur - logp ; and the matching dOut routing. */
+int ia_airl_logits(const float* g, const float* h_cur, const float* h_next, const uint8_t* dones,
+                   const float* logp, float gamma, int R, float* logits, void* stream);
+int ia_airl_route_grad(const float* dlogits, const uint8_t* dones, float gamma, int R, float* dg, float* dh_cur,
+                       float* dh_next, void* stream);
+
+/* generic row gather: dst[i,:] = src[idx[i],:] (width floats) */
+int ia_gather_rows(const float* src, const int64_t* idx, int n, int width, float* dst, void* stream);
+
+/* ---- generator (policy / PPO) kernels: see policy section below (policy.hip) ---- */
+
+/* SB3 ActorCriticPolicy with net_arch=[H,H] tanh towers (policies/base.py:92-104), flat
+ * parameter order = torch parameters(): [log_std (Box only)], pi.W1,b1,W2,b2, vf.W1,b1,W2,b2,
+ * action_net.W,b, value_net.W,b. */
+typedef struct {
+  int obs_dim;
+  int act_dim;      /* Box: action dims; Discrete: number of actions */
+  int hidden;       /* 32 or 64 */
+  int discrete;     /* 0 Box / DiagGaussian, 1 Discrete / Categorical */
+  int has_norm;     /* NormalizeFeaturesExtractor(RunningNorm) in front (policies/base.py:123-149) */
+  float norm_eps;
+} ia_policy_desc;
+
+int64_t ia_policy_param_count(const ia_policy_desc* d);
+/* params_t = same flat layout with the four tower matrices stored [in][out] (kept in sync by
+ * ia_ppo_minibatch; call this after loading parameters from the host). */
+int ia_policy_transpose(const ia_policy_desc* d, const float* params, float* params_t, void* stream);
+
+/* [SB3 ActorCriticPolicy.forward] rollout step (collect_rollouts):
+ * Box: actions = mean + exp(log_std)*noise, clipped = clip(actions, low, high);
+ * Discrete: `noise` holds one uniform(0,1) per row, inverse-CDF sampling over softmax
+ * (actions / clipped are then fp32 action indices [n]). */
+int ia_policy_act(const ia_policy_desc* d, const float* params, const float* params_t, const float* norm_mean,
+                  const float* norm_var, const float* obs, int n, const float* noise, const float* low,
+                  const float* high, float* actions, float* clipped, float* values, float* logp, void* stream);
+
+/* [SB3 evaluate_actions / predict_values] without grad (adversarial/common.py:490-496): any of
+ * logp/values/entropy may be NULL. actions: fp32 [n,act_dim] (Box) or fp32 action index [n]. */
+int ia_policy_evaluate(const ia_policy_desc* d, const float* params, const float* params_t, const float* norm_mean,
+                       const float* norm_var, const float* obs, const float* actions, int n, float* logp,
+                       float* values, float* entropy, void* stream);
+
+/* [SB3 RolloutBuffer.compute_returns_and_advantage]: arrays are [T,n] fp32. */
+int ia_gae(const float* rewards, const float* values, const float* episode_starts, const float* last_values,
+           const float* last_dones, int T, int n, float gamma, float gae_lambda, float* advantages,
+           float* returns, void* stream);
+
+/* [SB3 collect_rollouts] rewards[i] += gamma * V(terminal_obs_i) where truncated[i]. */
+int ia_timeout_bootstrap(float* rewards, const float* terminal_values, const uint8_t* truncated, float gamma,
+                         int64_t n, void* stream);
+
+/* One PPO minibatch (SB3 PPO.train body): rows `idx` (int64 into the env-major
+ * flattened rollout, row = env*T+t) of time-major [T,n_envs,...] obs/actions/old_logp/advantages/
+ * returns. Three launches: (1) minibatch advantage mean/std (unbiased) + RunningNorm update of the
+ * policy's feature norm when in train mode; (2) forward, clipped-surrogate/value/entropy loss,
+ * backward, per-wave partial gradients; (3) fixed-order reduction, clip_grad_norm_, Adam, refresh
+ * of params_t. stats[8] = {pg_loss, value_loss, entropy_loss, approx_kl, clip_fraction, loss,
+ * grad_norm, clip_coef}. */
+int64_t ia_ppo_ws_floats(const ia_policy_desc* d, int batch);
+int ia_ppo_minibatch(const ia_policy_desc* d, float* params, float* params_t, float* norm_mean, float* norm_var,
+                     int32_t* norm_count, int update_norm, const float* obs, const float* actions,
+                     const float* old_logp, const float* advantages, const float* returns, const int64_t* idx,
+                     int batch, int T, int n_envs, int normalize_adv, float clip_range, float ent_coef,
+                     float vf_coef, float max_grad_norm, float* exp_avg, float* exp_avg_sq, float beta1,
+                     float beta2, float adam_eps, float step_size, float bc2_sqrt, float* ws, float* stats,
+                     void* stream);
+/* One PPO epoch = consecutive minibatches of the device-resident permutation `perm[T*n_envs]`
+ * (host-drawn np.random.permutation); stats is [n_minibatches][8] or NULL. */
+int ia_ppo_epoch(const ia_policy_desc* d, float* params, float* params_t, float* norm_mean, float* norm_var,
+                 int32_t* norm_count, int update_norm, const float* obs, const float* actions, const float* old_logp,
+                 const float* advantages, const float* returns, const int64_t* perm, int T, int n_envs,
+                 int batch_size, int normalize_adv, float clip_range, float ent_coef, float vf_coef,
+                 float max_grad_norm, float* exp_avg, float* exp_avg_sq, double lr, double beta1, double beta2,
+                 float adam_eps, int64_t adam_steps_done, float* ws, float* stats, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
