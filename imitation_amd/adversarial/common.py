@@ -1,0 +1,362 @@
+"""`AdversarialTrainer` -- the GAIL/AIRL round on MI355X behind the reference's constructor
+and `.train()` surface (`algorithms/adversarial/common.py:95-632`).
+
+What stays on the host, with the reference's exact RNG call sequence (=> bit-exact batch
+composition on identical seeds): the expert permutation (`ExpertIndexStream`), the replay
+indices (`np.random.randint` via `ReplayBuffer.sample_indices`), the label layout
+(`[expert_mb | gen_mb]`), ring-buffer positions, fixed-horizon check, step counters, logging.
+What runs in HBM through libimitation_hip.so: batch assembly (gather + concat + one-hot),
+RunningNorm updates, discriminator forward + BCE + backward (gradient accumulation over
+minibatches), Adam, train statistics, the policy log-prob pass, reward relabelling.
+"""
+from __future__ import annotations
+
+import abc
+import os
+from typing import Callable, Dict, Iterable, Mapping, Optional, Type
+
+import numpy as np
+import torch as th
+
+from imitation_amd import _lib as L
+from imitation_amd import buffer, data_types as dt
+from imitation_amd import logger as imit_logger
+from imitation_amd import networks, ppo, reward_nets, wrappers
+from imitation_amd.networks import HipAdam, TransitionTable, require_device
+from imitation_amd.policies import ActorCriticPolicy
+
+
+def compute_train_stats(disc_logits_expert_is_high: th.Tensor, labels_expert_is_one: th.Tensor,
+                        disc_loss: th.Tensor) -> Mapping[str, float]:
+    """`adversarial/common.py:27-92` for explicit logits/labels (device or host tensors)."""
+    logits = disc_logits_expert_is_high.detach().float().cpu()
+    labels = labels_expert_is_one.detach().cpu()
+    n = len(labels)
+    gen_true = labels == 0
+    gen_pred = logits < 0
+    correct = gen_pred == gen_true
+    n_gen = float(gen_true.sum())
+    n_exp = n - n_gen
+    p = th.sigmoid(logits)
+    ent = th.nn.functional.binary_cross_entropy_with_logits(logits, p, reduction="none").mean() if n else float("nan")
+    return _stats_dict(float(th.as_tensor(disc_loss).float().mean()), float(correct.sum()),
+                       float((correct & ~gen_true).sum()), float((correct & gen_true).sum()), float(gen_pred.sum()),
+                       float(ent) * n if n else float("nan"), n_exp, n_gen)
+
+
+def _stats_dict(loss, n_correct, n_correct_exp, n_correct_gen, n_pred_gen, ent_sum, n_exp, n_gen) -> Dict[str, float]:
+    n = n_exp + n_gen
+    return {
+        "disc_loss": float(loss),
+        "disc_acc": float(n_correct / n) if n > 0 else float("nan"),
+        "disc_acc_expert": float("nan") if n_exp < 1 else float(n_correct_exp / n_exp),
+        "disc_acc_gen": float(n_correct_gen / max(1.0, n_gen)),
+        "disc_entropy": float(ent_sum / n) if n > 0 else float("nan"),
+        "disc_proportion_expert_true": float(n_exp / n) if n > 0 else float("nan"),
+        "disc_proportion_expert_pred": float((n - n_pred_gen) / n) if n > 0 else float("nan"),
+        "n_expert": float(n_exp),
+        "n_generated": float(n_gen),
+    }
+
+
+def _upload_table(samples: Mapping, obs_shape, discrete: bool, device) -> TransitionTable:
+    """Explicit `expert_samples` / `gen_samples` dicts (`common.py:317-337,564-583`) -> device rows."""
+    def arr(k):
+        v = samples[k]
+        return v.detach().cpu().numpy() if isinstance(v, th.Tensor) else np.asarray(v)
+    n = len(arr("obs"))
+    f32 = lambda a: th.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).reshape(n, -1).to(device)
+    acts = arr("acts")
+    acts_d = (th.from_numpy(np.ascontiguousarray(acts, dtype=np.int64)).reshape(n).to(device) if discrete
+              else f32(acts))
+    return TransitionTable(f32(arr("obs")), acts_d, f32(arr("next_obs")),
+                           th.from_numpy(np.ascontiguousarray(arr("dones"), dtype=np.uint8)).to(device), discrete)
+
+
+class AdversarialTrainer(abc.ABC):
+    """Base class for adversarial imitation learning algorithms like GAIL and AIRL."""
+
+    def __init__(self, *, demonstrations, demo_batch_size: int, venv, gen_algo, reward_net: reward_nets.RewardNet,
+                 demo_minibatch_size: Optional[int] = None, n_disc_updates_per_round: int = 2, log_dir="output/",
+                 disc_opt_cls: Type = th.optim.Adam, disc_opt_kwargs: Optional[Mapping] = None,
+                 gen_train_timesteps: Optional[int] = None, gen_replay_buffer_capacity: Optional[int] = None,
+                 custom_logger: Optional[imit_logger.HierarchicalLogger] = None, init_tensorboard: bool = False,
+                 init_tensorboard_graph: bool = False, debug_use_ground_truth: bool = False,
+                 allow_variable_horizon: bool = False):
+        self.demo_batch_size = demo_batch_size
+        self.demo_minibatch_size = demo_minibatch_size or demo_batch_size
+        if self.demo_batch_size % self.demo_minibatch_size != 0:
+            raise ValueError("Batch size must be a multiple of minibatch size.")
+        self._logger = custom_logger or imit_logger.configure()
+        self.allow_variable_horizon = allow_variable_horizon
+        self._horizon = None
+        self.venv = venv
+        self.gen_algo = gen_algo
+        self._device = th.device(gen_algo.device)
+        require_device(self._device)
+        L.load()  # fail loudly here if the HIP extension is missing
+        self._discrete = hasattr(venv.action_space, "n")
+        self._expert_table: Optional[TransitionTable] = None
+        self._expert_stream: Optional[dt.ExpertIndexStream] = None
+        self._expert_batches = None
+        self.set_demonstrations(demonstrations)
+
+        self._global_step = 0
+        self._disc_step = 0
+        self.n_disc_updates_per_round = n_disc_updates_per_round
+        self.debug_use_ground_truth = debug_use_ground_truth
+        self._reward_net = reward_net.to(self._device)
+        self._log_dir = str(log_dir)
+        if init_tensorboard:
+            raise NotImplementedError("tensorboard is not installed in this image; use csv/json logger formats")
+        self._disc_opt_cls = disc_opt_cls
+        self._disc_opt_kwargs = dict(disc_opt_kwargs or {})
+        store = self._reward_net._store
+        if disc_opt_cls is th.optim.Adam:
+            self._disc_opt = HipAdam(store.flat, store.grad, **self._disc_opt_kwargs)
+            self._torch_opt_params = None
+        else:  # any other torch optimiser: steps device views of the same flat buffers
+            self._torch_opt_params = [p.requires_grad_(True) for p in self._reward_net.parameters()]
+            self._disc_opt = disc_opt_cls(self._torch_opt_params, **self._disc_opt_kwargs)
+
+        self.venv_buffering = wrappers.BufferingWrapper(self.venv)
+        if debug_use_ground_truth:
+            self.venv_wrapped = self.venv_buffering
+            self.gen_callback = None
+        else:
+            self.venv_wrapped = wrappers.RewardVecEnvWrapper(self.venv_buffering,
+                                                             reward_fn=self.reward_train.predict_processed)
+            self.gen_callback = self.venv_wrapped.make_log_callback()
+        self.venv_train = self.venv_wrapped
+        self.gen_algo.set_env(self.venv_train)
+        self.gen_algo.set_logger(self.logger)
+
+        if gen_train_timesteps is None:
+            gen_algo_env = self.gen_algo.get_env()
+            assert gen_algo_env is not None
+            self.gen_train_timesteps = gen_algo_env.num_envs
+            if isinstance(self.gen_algo, ppo.OnPolicyAlgorithm):
+                self.gen_train_timesteps *= self.gen_algo.n_steps
+        else:
+            self.gen_train_timesteps = gen_train_timesteps
+        if gen_replay_buffer_capacity is None:
+            gen_replay_buffer_capacity = self.gen_train_timesteps
+        self._gen_replay_buffer = buffer.ReplayBuffer(gen_replay_buffer_capacity, self.venv, device=self._device)
+
+        B = self.demo_batch_size
+        self._idx_host = th.zeros(2, B, dtype=th.int64).pin_memory()
+        self._idx_dev = th.zeros(2, B, dtype=th.int64, device=self._device)
+        self._stats_dev = th.zeros(8, device=self._device)
+        self._dlogits = th.zeros(2 * self.demo_minibatch_size, device=self._device)
+        self._logp = th.zeros(2 * self.demo_minibatch_size, device=self._device)
+        od = int(np.prod(venv.observation_space.shape))
+        ad = 1 if self._discrete else int(np.prod(venv.action_space.shape))
+        self._pol_obs = th.zeros(2 * self.demo_minibatch_size, od, device=self._device)
+        self._pol_act = th.zeros(2 * self.demo_minibatch_size, max(ad, 1), device=self._device)
+
+    # ---- properties ---------------------------------------------------------------------------
+    @property
+    def logger(self):
+        return self._logger
+
+    @logger.setter
+    def logger(self, value):
+        self._logger = value
+
+    @property
+    def policy(self):
+        policy = self.gen_algo.policy
+        assert policy is not None
+        return policy
+
+    @abc.abstractmethod
+    def logits_expert_is_high(self, state, action, next_state, done, log_policy_act_prob=None) -> th.Tensor:
+        """Discriminator logits, high = expert-like (`common.py:269-294`)."""
+
+    @property
+    @abc.abstractmethod
+    def reward_train(self) -> reward_nets.RewardNet:
+        """Reward used to train generator policy."""
+
+    @property
+    @abc.abstractmethod
+    def reward_test(self) -> reward_nets.RewardNet:
+        """Reward used to train policy at "test" time after adversarial training."""
+
+    _needs_logp = False  # AIRL sets True
+
+    # ---- demonstrations -------------------------------------------------------------------------
+    def set_demonstrations(self, demonstrations) -> None:
+        """`common.py:306-311`: device-resident expert table + the DataLoader-equivalent index stream."""
+        try:
+            demos = dt.as_transitions(demonstrations)
+        except TypeError:
+            if isinstance(demonstrations, Iterable):  # iterable of ready-made batches (`base.py:284-286`)
+                self._expert_table, self._expert_stream = None, None
+                self._expert_batches = _endless(demonstrations, self.demo_batch_size)
+                return
+            raise
+        self._expert_batches = None
+        self._expert_stream = dt.ExpertIndexStream(len(demos), self.demo_batch_size)
+        self._expert_table = _upload_table(dict(obs=demos.obs, acts=demos.acts, next_obs=demos.next_obs,
+                                                dones=demos.dones), None, self._discrete, self._device)
+
+    def _check_fixed_horizon(self, horizons: Iterable[int]) -> None:
+        """`algorithms/base.py:77-110`."""
+        if self.allow_variable_horizon:
+            return
+        hs = set(int(h) for h in horizons)
+        if self._horizon is not None:
+            hs.add(self._horizon)
+        if len(hs) > 1:
+            raise ValueError(f"Episodes of different length detected: {hs}. Variable horizon environments are "
+                             "discouraged -- termination conditions leak information about reward. If you are SURE "
+                             "you want to run imitation on a variable horizon task, then please pass in the flag: "
+                             "`allow_variable_horizon=True`.")
+        if len(hs) == 1:
+            self._horizon = hs.pop()
+
+    # ---- discriminator update (`common.py:317-389,521-632`) --------------------------------------
+    def _batch_sources(self, expert_samples, gen_samples):
+        """(expert_table, expert_idx_dev | None), (gen_table, gen_idx_dev | None) for one update."""
+        B = self.demo_batch_size
+        e_idx = g_idx = None
+        if expert_samples is None:
+            if self._expert_batches is not None:
+                expert_samples = next(self._expert_batches)
+            else:
+                self._idx_host[0].copy_(th.from_numpy(self._expert_stream.next_indices()))
+                e_idx = self._idx_dev[0]
+        if gen_samples is None:
+            if self._gen_replay_buffer.size() == 0:
+                raise RuntimeError("No generator samples for training. Call `train_gen()` first.")
+            self._idx_host[1].copy_(th.from_numpy(self._gen_replay_buffer.sample_indices(B)))
+            g_idx = self._idx_dev[1]
+        n_gen = B if gen_samples is None else len(gen_samples["obs"])
+        n_exp = B if expert_samples is None else len(expert_samples["obs"])
+        if not (n_gen == n_exp == B):
+            raise ValueError("Need to have exactly `demo_batch_size` number of expert and generator samples, each. "
+                             f"(n_gen={n_gen} n_expert={n_exp} demo_batch_size={B})")
+        if e_idx is not None or g_idx is not None:
+            self._idx_dev.copy_(self._idx_host, non_blocking=True)
+        obs_shape = self.venv.observation_space.shape
+        e_tab = self._expert_table if expert_samples is None else _upload_table(expert_samples, obs_shape,
+                                                                                self._discrete, self._device)
+        g_tab = self._gen_replay_buffer.table if gen_samples is None else _upload_table(gen_samples, obs_shape,
+                                                                                        self._discrete, self._device)
+        return (e_tab, e_idx), (g_tab, g_idx)
+
+    def _policy_pass(self, sources, mb: int) -> Optional[th.Tensor]:
+        """`common.py:606-615`: log pi(a|s) of the 2*mb rows under no_grad. For GAIL the value is
+        discarded (`gail.py:157`) but the call still updates a train-mode feature RunningNorm
+        (SURVEY App. C.2), so the statistics update is replayed even when logp is not needed."""
+        pol = self.policy
+        if not isinstance(pol, ActorCriticPolicy):
+            return None
+        has_norm = pol.features_extractor.normalize is not None
+        if not self._needs_logp and not (has_norm and pol.training):
+            return None
+        R = 2 * mb
+        row = 0
+        for table, idx, n in sources:
+            networks.gather_concat(table, idx, n, pol.obs_dim, pol.act_dim, (True, False, False, False),
+                                   self._pol_obs, pol.obs_dim, row)
+            if self._needs_logp:
+                if table.discrete:
+                    acts = table.acts if idx is None else table.acts[idx]
+                    self._pol_act[row:row + n, 0].copy_(acts.float())
+                else:
+                    L.call("ia_gather_concat", L.ptr(table.obs), L.ptr(table.acts), None, L.ptr(table.next_obs),
+                           L.ptr(table.dones), L.ptr(idx), n, pol.obs_dim, pol.act_dim, 0, 1, 0, 0,
+                           L.ptr(self._pol_act), pol.act_dim, row, L.stream())
+            row += n
+        if self._needs_logp:
+            pol.log_prob_rows(self._pol_obs[:R], self._pol_act[:R], self._logp)
+            return self._logp
+        pol.features_extractor.normalize.update_stats(self._pol_obs[:R])
+        return None
+
+    def train_disc(self, *, expert_samples: Optional[Mapping] = None,
+                   gen_samples: Optional[Mapping] = None) -> Mapping[str, float]:
+        with self.logger.accumulate_means("disc"):
+            (e_tab, e_idx), (g_tab, g_idx) = self._batch_sources(expert_samples, gen_samples)
+            B, mb = self.demo_batch_size, self.demo_minibatch_size
+            scale = mb / B
+            net = self._reward_net
+            first = True
+            for start in range(0, B, mb):
+                sl = lambda idx: None if idx is None else idx[start:start + mb]
+                e_src = (e_tab if e_idx is not None else _slice_table(e_tab, start, mb), sl(e_idx), mb)
+                g_src = (g_tab if g_idx is not None else _slice_table(g_tab, start, mb), sl(g_idx), mb)
+                sources = [e_src, g_src]
+                logp = self._policy_pass(sources, mb)
+                logits = net.disc_forward(sources, mb, logp)
+                L.call("ia_bce_logits", L.ptr(logits), 2 * mb, mb, scale, L.ptr(self._dlogits), L.ptr(self._stats_dev),
+                       L.stream())
+                net.disc_backward(self._dlogits, accumulate=not first)
+                first = False
+            if self._torch_opt_params is not None:
+                for p, (_, gview) in zip(self._torch_opt_params, _named_grads(net)):
+                    p.grad = gview
+            self._disc_opt.step()
+            self._disc_step += 1
+            self._last_disc_logits = logits
+            s = self._stats_dev.cpu().numpy()  # the one host sync of a discriminator update
+            train_stats = _stats_dict(*[float(x) for x in s])
+            self.logger.record("global_step", self._global_step)
+            for k, v in train_stats.items():
+                self.logger.record(k, v)
+            self.logger.dump(self._disc_step)
+        return train_stats
+
+    # ---- generator update (`common.py:391-425`) -------------------------------------------------
+    def train_gen(self, total_timesteps: Optional[int] = None, learn_kwargs: Optional[Mapping] = None) -> None:
+        if total_timesteps is None:
+            total_timesteps = self.gen_train_timesteps
+        if learn_kwargs is None:
+            learn_kwargs = {}
+        with self.logger.accumulate_means("gen"):
+            self.gen_algo.learn(total_timesteps=total_timesteps, reset_num_timesteps=False,
+                                callback=self.gen_callback, **learn_kwargs)
+            self._global_step += 1
+        gen_samples, ep_lens = self.venv_buffering.pop_transitions_and_lens()
+        self._check_fixed_horizon(ep_lens)
+        if gen_samples is not None:
+            self._gen_replay_buffer.store(gen_samples)
+
+    def train(self, total_timesteps: int, callback: Optional[Callable[[int], None]] = None) -> None:
+        """`common.py:427-461`."""
+        n_rounds = total_timesteps // self.gen_train_timesteps
+        assert n_rounds >= 1, ("No updates (need at least "
+                               f"{self.gen_train_timesteps} timesteps, have only "
+                               f"total_timesteps={total_timesteps})!")
+        for r in range(n_rounds):
+            self.train_gen(self.gen_train_timesteps)
+            for _ in range(self.n_disc_updates_per_round):
+                with networks.training(self.reward_train):
+                    self.train_disc()
+            if callback:
+                callback(r)
+            self.logger.dump(self._global_step)
+
+
+def _slice_table(t: TransitionTable, start: int, n: int) -> TransitionTable:
+    return TransitionTable(t.obs[start:start + n], t.acts[start:start + n], t.next_obs[start:start + n],
+                           t.dones[start:start + n], t.discrete)
+
+
+def _named_grads(net):
+    for prefix, s in net._named_stacks():
+        yield from s.named_grads(prefix)
+
+
+def _endless(batches, expected: int):
+    """`util.endless_iter` over user-supplied batch iterables with the size check of
+    `algorithms/base.py:185-223`."""
+    if iter(batches) is batches:
+        raise ValueError("endless_iter needs a non-iterator Iterable.")
+    while True:
+        for b in batches:
+            if len(b["obs"]) != expected or len(b["acts"]) != expected:
+                raise ValueError(f"Expected batch size {expected} != {len(b['obs'])} = len(batch['obs'])")
+            yield b

@@ -1,0 +1,58 @@
+"""Generative Adversarial Imitation Learning (`algorithms/adversarial/gail.py`)."""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch as th
+
+from imitation_amd import _lib as L
+from imitation_amd import reward_nets
+from imitation_amd.adversarial import common
+
+
+class RewardNetFromDiscriminatorLogit(reward_nets.RewardNet):
+    """`gail.py:14-83`: generator reward `-logsigmoid(-logit) = softplus(logit)`. The softplus is
+    fused into the last layer's epilogue of the discriminator forward when the base allows it."""
+
+    def __init__(self, base: reward_nets.RewardNet):
+        super().__init__(base.observation_space, base.action_space, base.normalize_images)
+        self.base = base
+        self._store = base._store
+
+    def _children(self):
+        return [self.base]
+
+    def _named_stacks(self):
+        return [(f"base.{p}", s) for p, s in self.base._named_stacks()]
+
+    def _named_norms(self):
+        return [(f"base.{p}", n) for p, n in self.base._named_norms()]
+
+    def _forward_table(self, sources, tag, out_act=L.ACT_NONE):
+        return self.base._forward_table(sources, tag, L.ACT_SOFTPLUS)
+
+
+class GAIL(common.AdversarialTrainer):
+    """`gail.py:86-168`."""
+
+    def __init__(self, *, demonstrations, demo_batch_size: int, venv, gen_algo, reward_net: reward_nets.RewardNet,
+                 **kwargs):
+        reward_net = reward_net.to(gen_algo.device)
+        self._processed_reward = RewardNetFromDiscriminatorLogit(reward_net)
+        super().__init__(demonstrations=demonstrations, demo_batch_size=demo_batch_size, venv=venv,
+                         gen_algo=gen_algo, reward_net=reward_net, **kwargs)
+
+    def logits_expert_is_high(self, state, action, next_state, done,
+                              log_policy_act_prob: Optional[th.Tensor] = None) -> th.Tensor:
+        del log_policy_act_prob
+        logits = self._reward_net(state, action, next_state, done)
+        assert logits.shape == state.shape[:1]
+        return logits
+
+    @property
+    def reward_train(self) -> reward_nets.RewardNet:
+        return self._processed_reward
+
+    @property
+    def reward_test(self) -> reward_nets.RewardNet:
+        return self._processed_reward

@@ -235,19 +235,19 @@ __global__ __launch_bounds__(1024) void bce_kernel(const float* __restrict__ log
 }
 
 __global__ void airl_logits_kernel(const float* __restrict__ g, const float* __restrict__ h_cur,
-                                   const float* __restrict__ h_next, const uint8_t* __restrict__ dones,
+                                   const float* __restrict__ h_next, const float* __restrict__ dones,
                                    const float* __restrict__ logp, float gamma, int R,
                                    float* __restrict__ logits) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= R) return;
   // reward_nets.py:727-733 order: base + gamma*((1-done)*new) - old ; then airl.py:118: - logp
-  const float new_shaping = (1.f - (dones[i] ? 1.f : 0.f)) * h_next[i];
+  const float new_shaping = (1.f - dones[i]) * h_next[i];
   float f = g[i] + gamma * new_shaping;
   f = f - h_cur[i];
   logits[i] = logp ? f - logp[i] : f;
 }
 
-__global__ void airl_route_kernel(const float* __restrict__ dlogits, const uint8_t* __restrict__ dones,
+__global__ void airl_route_kernel(const float* __restrict__ dlogits, const float* __restrict__ dones,
                                   float gamma, int R, float* __restrict__ dg, float* __restrict__ dh_cur,
                                   float* __restrict__ dh_next) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -255,7 +255,58 @@ __global__ void airl_route_kernel(const float* __restrict__ dlogits, const uint8
   const float d = dlogits[i];
   dg[i] = d;
   dh_cur[i] = -d;
-  dh_next[i] = gamma * (1.f - (dones[i] ? 1.f : 0.f)) * d;
+  dh_next[i] = gamma * (1.f - dones[i]) * d;
+}
+
+// rewards/reward_nets.py:660-669 applied once per env step t: normalise step t's n rewards with the
+// statistics accumulated over steps < t (eval-mode forward), THEN Chan-update them with those n
+// raw rewards. One block walks the T steps in order (the update is inherently sequential in t).
+__global__ __launch_bounds__(256) void reward_norm_seq_kernel(const float* __restrict__ raw, int T, int n, float eps,
+                                                               int update, float* __restrict__ mean,
+                                                               float* __restrict__ var, int32_t* __restrict__ count,
+                                                               float* __restrict__ out) {
+  __shared__ float red[256];
+  __shared__ float s_mean, s_var;
+  __shared__ int s_cnt;
+  const int tid = threadIdx.x;
+  if (tid == 0) { s_mean = *mean; s_var = *var; s_cnt = *count; }
+  __syncthreads();
+  for (int t = 0; t < T; ++t) {
+    const float m = s_mean, inv = 1.f / sqrtf(s_var + eps);
+    float sum = 0.f;
+    for (int i = tid; i < n; i += 256) {
+      const float r = raw[(long long)t * n + i];
+      out[(long long)t * n + i] = (r - m) * inv;
+      sum += r;
+    }
+    if (!update) continue;
+    red[tid] = sum;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if (tid < o) red[tid] += red[tid + o]; __syncthreads(); }
+    const float bmean = red[0] / (float)n;
+    __syncthreads();
+    float q = 0.f;
+    for (int i = tid; i < n; i += 256) {
+      const float dl = raw[(long long)t * n + i] - bmean;
+      q += dl * dl;
+    }
+    red[tid] = q;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if (tid < o) red[tid] += red[tid + o]; __syncthreads(); }
+    if (tid == 0) {
+      const float bvar = red[0] / (float)n;
+      const float fcount = (float)s_cnt, fn = (float)n, tot = (float)(s_cnt + n);
+      const float delta = bmean - s_mean;
+      s_mean = s_mean + delta * fn / tot;
+      float rv = s_var * fcount;
+      rv = rv + bvar * fn;
+      rv = rv + delta * delta * fcount * fn / tot;
+      s_var = rv / tot;
+      s_cnt += n;
+    }
+    __syncthreads();
+  }
+  if (tid == 0 && update) { *mean = s_mean; *var = s_var; *count = s_cnt; }
 }
 
 inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
@@ -419,7 +470,7 @@ int ia_bce_logits(const float* logits, int R, int n_expert, float scale, float* 
   return IA_OK;
 }
 
-int ia_airl_logits(const float* g, const float* h_cur, const float* h_next, const uint8_t* dones,
+int ia_airl_logits(const float* g, const float* h_cur, const float* h_next, const float* dones,
                    const float* logp, float gamma, int R, float* logits, void* stream) {
   if (R <= 0) return IA_ERR_ARG;
   hipLaunchKernelGGL(airl_logits_kernel, dim3(cdiv(R, 256)), dim3(256), 0, (hipStream_t)stream, g, h_cur, h_next,
@@ -428,11 +479,20 @@ int ia_airl_logits(const float* g, const float* h_cur, const float* h_next, cons
   return IA_OK;
 }
 
-int ia_airl_route_grad(const float* dlogits, const uint8_t* dones, float gamma, int R, float* dg, float* dh_cur,
+int ia_airl_route_grad(const float* dlogits, const float* dones, float gamma, int R, float* dg, float* dh_cur,
                        float* dh_next, void* stream) {
   if (R <= 0) return IA_ERR_ARG;
   hipLaunchKernelGGL(airl_route_kernel, dim3(cdiv(R, 256)), dim3(256), 0, (hipStream_t)stream, dlogits, dones,
                      gamma, R, dg, dh_cur, dh_next);
+  IA_CHECK_LAUNCH();
+  return IA_OK;
+}
+
+int ia_reward_norm_sequential(const float* raw, int T, int n, float eps, int update_stats, float* mean, float* var,
+                              int32_t* count, float* out, void* stream) {
+  if (T <= 0 || n <= 0) return IA_ERR_ARG;
+  hipLaunchKernelGGL(reward_norm_seq_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, raw, T, n, eps, update_stats,
+                     mean, var, count, out);
   IA_CHECK_LAUNCH();
   return IA_OK;
 }

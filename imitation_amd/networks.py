@@ -1,0 +1,326 @@
+"""Device-resident building blocks of the reward / discriminator networks.
+
+Host-side mirror of `util/networks.py` (`RunningNorm` `:98-134`, `build_mlp` `:204-283`,
+`training`/`evaluating` `:12-34`) whose arithmetic runs in libimitation_hip.so. Objects are
+light state holders: parameters live in one flat fp32 HBM buffer per network (torch
+`parameters()` order) so that one Adam launch / one all-reduce bucket covers a whole net.
+"""
+from __future__ import annotations
+
+import contextlib
+import ctypes as C
+from typing import Dict, Iterator, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch as th
+from torch import nn
+
+from imitation_amd import _lib as L
+
+
+def require_device(device: th.device) -> None:
+    if device.type != "cuda":
+        raise RuntimeError(
+            "imitation_amd computes on MI355X only (no CPU fallback): move the network / algorithm to "
+            f"'cuda' first (got device {device}).")
+
+
+@contextlib.contextmanager
+def training_mode(m, mode: bool):
+    old = m.training
+    m.train(mode)
+    try:
+        yield m
+    finally:
+        m.train(old)
+
+
+def training(m):
+    return training_mode(m, True)
+
+
+def evaluating(m):
+    return training_mode(m, False)
+
+
+class RunningNorm:
+    """`util/networks.py:47-134`: running mean / variance (Chan merge), int32 count.
+
+    In train mode `normalize` first updates the statistics with the batch, then normalises it
+    with the updated statistics (`networks.py:79-91`)."""
+
+    def __init__(self, num_features: int, eps: float = 1e-5):
+        self.num_features, self.eps = int(num_features), float(eps)
+        self.running_mean = th.zeros(num_features)
+        self.running_var = th.ones(num_features)
+        self.count = th.zeros((), dtype=th.int32)
+        self.training = True
+        self._ws: Optional[th.Tensor] = None
+
+    # -- nn.Module-like plumbing
+    def train(self, mode: bool = True):
+        self.training = mode
+        return self
+
+    def eval(self):
+        return self.train(False)
+
+    def to(self, device):
+        device = th.device(device)
+        self.running_mean = self.running_mean.to(device)
+        self.running_var = self.running_var.to(device)
+        self.count = self.count.to(device)
+        self._ws = None
+        return self
+
+    @property
+    def device(self) -> th.device:
+        return self.running_mean.device
+
+    def state_dict(self, prefix: str = "") -> Dict[str, th.Tensor]:
+        return {prefix + "running_mean": self.running_mean, prefix + "running_var": self.running_var,
+                prefix + "count": self.count}
+
+    def load_state_dict(self, sd, prefix: str = "") -> None:
+        self.running_mean.copy_(th.as_tensor(sd[prefix + "running_mean"]))
+        self.running_var.copy_(th.as_tensor(sd[prefix + "running_var"]))
+        self.count.copy_(th.as_tensor(sd[prefix + "count"]).to(th.int32))
+
+    def reset_running_stats(self) -> None:
+        self.running_mean.zero_()
+        self.running_var.fill_(1)
+        self.count.zero_()
+
+    # -- compute
+    def update_stats(self, x: th.Tensor, ldx: Optional[int] = None, rows: Optional[int] = None) -> None:
+        """`RunningNorm.update_stats` on a device batch `x[rows, ldx]` (first `num_features` columns)."""
+        require_device(self.device)
+        if x.dim() == 1:
+            x = x.reshape(-1, 1)
+        R = rows if rows is not None else x.shape[0]
+        ld = ldx if ldx is not None else x.shape[1]
+        need = int(L.load().ia_running_norm_ws_floats(R, self.num_features))
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = th.empty(need, device=self.device)
+        L.call("ia_running_norm_update", L.ptr(x), ld, R, self.num_features, L.ptr(self.running_mean),
+               L.ptr(self.running_var), L.ptr(self.count), L.ptr(self._ws), L.stream())
+
+    def apply(self, x: th.Tensor, out: th.Tensor, ldx: int, ldy: int, rows: int) -> None:
+        L.call("ia_running_norm_apply", L.ptr(x), ldx, rows, self.num_features, L.ptr(self.running_mean),
+               L.ptr(self.running_var), self.eps, L.ptr(out), ldy, L.stream())
+
+    def __call__(self, x: th.Tensor) -> th.Tensor:
+        """Module-style forward on a device tensor `[B, F]` (or `[B]` when F == 1)."""
+        require_device(self.device)
+        flat = x.reshape(x.shape[0], -1).contiguous().float()
+        if self.training:
+            self.update_stats(flat)
+        out = th.empty_like(flat)
+        self.apply(flat, out, flat.shape[1], flat.shape[1], flat.shape[0])
+        return out.reshape(x.shape)
+
+    forward = __call__
+
+
+_ACT_CODES = {nn.ReLU: L.ACT_RELU, nn.Tanh: L.ACT_TANH, None: L.ACT_NONE}
+
+
+def _round_up(v: int, m: int) -> int:
+    return (v + m - 1) // m * m
+
+
+class DenseStack:
+    """`build_mlp` (`util/networks.py:204-283`) on device: optional input `RunningNorm`, hidden
+    `Linear`+activation layers, final `Linear`. Initial weights are drawn by constructing
+    `torch.nn.Linear` layers on the host in the reference's order, so the torch global RNG is
+    consumed identically and seeds carry over."""
+
+    def __init__(self, in_size: int, hid_sizes: Sequence[int], out_size: int = 1, activation=nn.ReLU,
+                 dropout_prob: float = 0.0, squeeze_output: bool = False, flatten_input: bool = False,
+                 normalize_input_layer=None, name: Optional[str] = None):
+        if dropout_prob > 0.0:
+            raise NotImplementedError("dropout is off in every reference GAIL/AIRL config; not built for HIP")
+        if activation not in _ACT_CODES:
+            raise NotImplementedError(f"activation {activation} not supported on the HIP path (ReLU/Tanh)")
+        if squeeze_output and out_size != 1:
+            raise ValueError("squeeze_output is only applicable when out_size=1")
+        self.dims = [int(in_size), *[int(h) for h in hid_sizes], int(out_size)]
+        if len(self.dims) - 1 > L.IA_MAX_LAYERS:
+            raise NotImplementedError(f"at most {L.IA_MAX_LAYERS} Linear layers")
+        self.squeeze_output = squeeze_output
+        self.prefix = "" if name is None else f"{name}_"
+        self.norm: Optional[RunningNorm] = None
+        if normalize_input_layer is not None:
+            if normalize_input_layer is not RunningNorm:
+                raise NotImplementedError("only imitation_amd.RunningNorm is implemented as input normalisation")
+            self.norm = RunningNorm(in_size)
+        self.desc = L.mlp_desc(self.dims, _ACT_CODES[activation])
+        layers = [nn.Linear(self.dims[i], self.dims[i + 1]) for i in range(len(self.dims) - 1)]
+        self.n_params = sum(l.weight.numel() + l.bias.numel() for l in layers)
+        self._init_flat = th.cat([t.detach().reshape(-1) for l in layers for t in (l.weight, l.bias)])
+        self.flat: Optional[th.Tensor] = None        # view into the owner's flat parameter buffer
+        self.grad: Optional[th.Tensor] = None        # view into the owner's flat gradient buffer
+        self.ldx = _round_up(self.dims[0], 4)         # 16-byte aligned rows for the float4 tile loads
+        self.hidden_per_row = sum(self.dims[1:-1])
+        self.training = True
+        self._ws: Dict[Tuple[int, str], Dict[str, th.Tensor]] = {}
+
+    # -- parameter plumbing
+    def bind(self, flat: th.Tensor, grad: Optional[th.Tensor]) -> None:
+        self.flat, self.grad = flat, grad
+        self._ws = {}
+
+    def layer_names(self) -> List[str]:
+        n = len(self.dims) - 1
+        return [f"{self.prefix}dense{i}" for i in range(n - 1)] + [f"{self.prefix}dense_final"]
+
+    def named_parameters(self, prefix: str = "") -> Iterator[Tuple[str, th.Tensor]]:
+        o = 0
+        for name, (i, j) in zip(self.layer_names(), zip(self.dims[:-1], self.dims[1:])):
+            yield f"{prefix}{name}.weight", self.flat[o:o + i * j].view(j, i)
+            o += i * j
+            yield f"{prefix}{name}.bias", self.flat[o:o + j]
+            o += j
+
+    def named_grads(self, prefix: str = "") -> Iterator[Tuple[str, th.Tensor]]:
+        o = 0
+        for name, (i, j) in zip(self.layer_names(), zip(self.dims[:-1], self.dims[1:])):
+            yield f"{prefix}{name}.weight", self.grad[o:o + i * j].view(j, i)
+            o += i * j
+            yield f"{prefix}{name}.bias", self.grad[o:o + j]
+            o += j
+
+    def state_dict(self, prefix: str = "") -> Dict[str, th.Tensor]:
+        sd: Dict[str, th.Tensor] = {}
+        if self.norm is not None:
+            sd.update(self.norm.state_dict(f"{prefix}{self.prefix}normalize_input."))
+        sd.update(dict(self.named_parameters(prefix)))
+        return sd
+
+    def load_state_dict(self, sd, prefix: str = "") -> None:
+        if self.norm is not None:
+            self.norm.load_state_dict(sd, f"{prefix}{self.prefix}normalize_input.")
+        for k, v in self.named_parameters(prefix):
+            v.copy_(th.as_tensor(sd[k]))
+
+    def train(self, mode: bool = True):
+        self.training = mode
+        if self.norm is not None:
+            self.norm.train(mode)
+        return self
+
+    def to(self, device):
+        if self.norm is not None:
+            self.norm.to(device)
+        self._ws = {}
+        return self
+
+    # -- compute
+    def workspace(self, R: int, tag: str) -> Dict[str, th.Tensor]:
+        key = (R, tag)
+        ws = self._ws.get(key)
+        if ws is None:
+            dev = self.flat.device
+            ws = {
+                "X": th.zeros(R, self.ldx, device=dev),
+                "Xn": th.zeros(R, self.ldx, device=dev) if self.norm is not None else None,
+                "hidden": th.empty(max(1, R * self.hidden_per_row), device=dev),
+                "out": th.empty(R, self.dims[-1], device=dev),
+            }
+            self._ws[key] = ws
+        return ws
+
+    def train_workspace(self, R: int, tag: str) -> Dict[str, th.Tensor]:
+        ws = self.workspace(R, tag)
+        if "dhidden" not in ws:
+            dev = self.flat.device
+            ws["dhidden"] = th.empty(max(1, R * self.hidden_per_row), device=dev)
+            ws["splits"] = max(1, min(64, R // 256))
+            ws["partials"] = th.empty(ws["splits"], self.n_params, device=dev)
+        return ws
+
+    def forward_rows(self, ws: Dict[str, th.Tensor], R: int, out_act: int = L.ACT_NONE) -> th.Tensor:
+        """Runs the stack on `ws["X"][:R]` (already assembled). Returns `ws["out"]` `[R, out]`."""
+        x = ws["X"]
+        if self.norm is not None:
+            if self.training:
+                self.norm.update_stats(x, ldx=self.ldx, rows=R)
+            self.norm.apply(x, ws["Xn"], self.ldx, self.ldx, R)
+            x = ws["Xn"]
+        ws["_in"] = x
+        L.call("ia_mlp_forward", C.byref(self.desc), L.ptr(self.flat), L.ptr(x), self.ldx, R, L.ptr(ws["hidden"]),
+               L.ptr(ws["out"]), out_act, L.stream())
+        return ws["out"]
+
+    def backward_rows(self, ws: Dict[str, th.Tensor], R: int, d_out: th.Tensor, accumulate: bool,
+                      scale: float = 1.0) -> None:
+        """Back-propagates `d_out[R, out]` through the activations saved by `forward_rows` and
+        (accumulates) the parameter gradient into `self.grad`."""
+        L.call("ia_mlp_backward", C.byref(self.desc), L.ptr(self.flat), L.ptr(ws["_in"]), self.ldx, R,
+               L.ptr(ws["hidden"]), L.ptr(d_out), L.ptr(ws["dhidden"]), L.ptr(ws["partials"]), ws["splits"], None,
+               L.stream())
+        L.call("ia_reduce_partials", L.ptr(ws["partials"]), ws["splits"], self.n_params, scale, int(accumulate),
+               L.ptr(self.grad), L.stream())
+
+
+class TransitionTable:
+    """A set of row-aligned device arrays describing transitions (the expert demonstrations,
+    the generator replay ring, or a rollout): `obs/next_obs` fp32 `[N, obs_dim]`, `acts` fp32
+    `[N, act_dim]` (Box) or int64 `[N]` (Discrete), `dones` uint8 `[N]`."""
+
+    def __init__(self, obs: th.Tensor, acts: th.Tensor, next_obs: th.Tensor, dones: th.Tensor, discrete: bool):
+        self.obs, self.acts, self.next_obs, self.dones, self.discrete = obs, acts, next_obs, dones, discrete
+
+    def __len__(self) -> int:
+        return self.obs.shape[0]
+
+
+def gather_concat(table: TransitionTable, idx: Optional[th.Tensor], n: int, obs_dim: int, act_dim: int,
+                  flags: Tuple[bool, bool, bool, bool], X: th.Tensor, ldx: int, row0: int,
+                  state_from_next: bool = False) -> None:
+    """`adversarial/common.py:592-603` + `rewards/reward_nets.py:441-457`: X[row0:row0+n] =
+    [state | action (one-hot if discrete) | next_state | done] of rows `idx` of `table`."""
+    obs = table.next_obs if state_from_next else table.obs
+    L.call("ia_gather_concat", L.ptr(obs), None if table.discrete else L.ptr(table.acts),
+           L.ptr(table.acts) if table.discrete else None, L.ptr(table.next_obs), L.ptr(table.dones), L.ptr(idx), n,
+           obs_dim, act_dim, int(flags[0]), int(flags[1]), int(flags[2]), int(flags[3]), L.ptr(X), ldx, row0,
+           L.stream())
+
+
+class HipAdam:
+    """`torch.optim.Adam` (single param group) over one flat device buffer, stepping with the
+    fused HIP kernel. Mirrors the constructor kwargs and `state_dict` fields that matter."""
+
+    def __init__(self, flat: th.Tensor, grad: th.Tensor, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8,
+                 weight_decay: float = 0.0, amsgrad: bool = False, **unused):
+        if amsgrad:
+            raise NotImplementedError("amsgrad is not implemented on the HIP path")
+        self.flat, self.grad = flat, grad
+        self.param_groups = [dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay)]
+        self.exp_avg = th.zeros_like(flat)
+        self.exp_avg_sq = th.zeros_like(flat)
+        self.step_count = 0
+
+    def zero_grad(self, set_to_none: bool = False) -> None:
+        self.grad.zero_()
+
+    def step(self) -> None:
+        g = self.param_groups[0]
+        self.step_count += 1
+        b1, b2 = g["betas"]
+        bc1 = 1.0 - b1 ** self.step_count
+        bc2 = 1.0 - b2 ** self.step_count
+        L.call("ia_adam_step", L.ptr(self.flat), L.ptr(self.grad), L.ptr(self.exp_avg), L.ptr(self.exp_avg_sq),
+               self.flat.numel(), b1, b2, g["eps"], g["weight_decay"], g["lr"] / bc1, bc2 ** 0.5, L.stream())
+
+    def state_dict(self):
+        return {"state": {0: {"step": self.step_count, "exp_avg": self.exp_avg, "exp_avg_sq": self.exp_avg_sq}},
+                "param_groups": [dict(g, params=[0]) for g in self.param_groups]}
+
+    def load_state_dict(self, sd) -> None:
+        st = sd["state"][0]
+        self.step_count = int(st["step"])
+        self.exp_avg.copy_(st["exp_avg"])
+        self.exp_avg_sq.copy_(st["exp_avg_sq"])
+        for g, s in zip(self.param_groups, sd["param_groups"]):
+            g.update({k: v for k, v in s.items() if k != "params"})

@@ -1,0 +1,290 @@
+"""Actor-critic policy behind the SB3 `ActorCriticPolicy` surface the trainer touches
+(`adversarial/common.py:262-266,490-496`; `policies/base.py:92-149`), evaluated by the fused
+policy kernels of libimitation_hip.so.
+
+Supported architecture = what the reference's GAIL/AIRL configs use: Flatten or
+`NormalizeFeaturesExtractor(RunningNorm)` features, two separate tanh towers of equal width
+H in {32, 64} (`FeedForward32Policy` = [32, 32]; SB3 `MlpPolicy` default = [64, 64]),
+DiagGaussian (Box) or Categorical (Discrete) head. Parameters are ONE flat fp32 buffer in torch
+`parameters()` order (log_std, pi tower, vf tower, action_net, value_net) + a transposed
+shadow copy the kernels read their weight rows from.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import functools
+from typing import Dict, Iterator, List, Optional, Tuple
+
+import numpy as np
+import torch as th
+from torch import nn
+
+from imitation_amd import _lib as L
+from imitation_amd import spaces
+from imitation_amd.networks import HipAdam, RunningNorm, require_device
+
+
+class FlattenExtractor:
+    """[SB3 torch_layers.FlattenExtractor]."""
+
+    def __init__(self, observation_space):
+        self.features_dim = spaces.flatdim(observation_space)
+        self.normalize: Optional[RunningNorm] = None
+
+
+class NormalizeFeaturesExtractor(FlattenExtractor):
+    """`policies/base.py:123-149`: flatten then `normalize_class(features_dim)`."""
+
+    def __init__(self, observation_space, normalize_class=RunningNorm):
+        super().__init__(observation_space)
+        if normalize_class is not RunningNorm:
+            raise NotImplementedError("only imitation_amd.RunningNorm is implemented for feature normalisation")
+        self.normalize = normalize_class(self.features_dim)
+
+
+class ActorCriticPolicy:
+    def __init__(self, observation_space, action_space, lr_schedule, net_arch=None, activation_fn=nn.Tanh,
+                 ortho_init: bool = True, use_sde: bool = False, log_std_init: float = 0.0,
+                 squash_output: bool = False, features_extractor_class=FlattenExtractor,
+                 features_extractor_kwargs=None, share_features_extractor: bool = True, normalize_images: bool = True,
+                 optimizer_class=th.optim.Adam, optimizer_kwargs=None):
+        if use_sde or squash_output or not share_features_extractor:
+            raise NotImplementedError("gSDE / squashing / separate extractors are outside the reference's PPO path")
+        if activation_fn is not nn.Tanh:
+            raise NotImplementedError("policy towers are tanh (SB3 default) on the HIP path")
+        if optimizer_class is not th.optim.Adam:
+            raise NotImplementedError("the fused PPO step implements Adam (SB3 default)")
+        if net_arch is None:
+            net_arch = dict(pi=[64, 64], vf=[64, 64])
+        pi, vf = (net_arch["pi"], net_arch["vf"]) if isinstance(net_arch, dict) else (net_arch, net_arch)
+        if not (len(pi) == len(vf) == 2 and pi[0] == pi[1] == vf[0] == vf[1] and pi[0] in (32, 64)):
+            raise NotImplementedError(f"net_arch {net_arch}: the fused kernels cover two equal towers [H,H], H in (32,64)")
+        self.observation_space, self.action_space = observation_space, action_space
+        self.net_arch, self.hidden = net_arch, int(pi[0])
+        self.discrete = isinstance(action_space, spaces.Discrete)
+        self.obs_dim = spaces.flatdim(observation_space)
+        self.act_dim = action_space.n if self.discrete else int(np.prod(action_space.shape))
+        self.features_extractor = features_extractor_class(observation_space, **(features_extractor_kwargs or {}))
+        self.pi_features_extractor = self.vf_features_extractor = self.features_extractor
+        self.optimizer_kwargs = dict(optimizer_kwargs or {})
+        self.optimizer_kwargs.setdefault("eps", 1e-5)  # SB3 ActorCriticPolicy default for Adam
+        self.training = True
+        self._squash_output = False
+
+        # Host construction in SB3's order so the torch global RNG is consumed identically:
+        # pi tower, vf tower, action_net, log_std, value_net; then orthogonal re-initialisation.
+        H, D = self.hidden, self.obs_dim
+        pi_net = nn.Sequential(nn.Linear(D, H), nn.Tanh(), nn.Linear(H, H), nn.Tanh())
+        vf_net = nn.Sequential(nn.Linear(D, H), nn.Tanh(), nn.Linear(H, H), nn.Tanh())
+        action_net = nn.Linear(H, self.act_dim)
+        log_std = None if self.discrete else th.ones(self.act_dim) * log_std_init
+        value_net = nn.Linear(H, 1)
+        if ortho_init:
+            def init(m, gain):
+                if isinstance(m, nn.Linear):
+                    nn.init.orthogonal_(m.weight, gain=gain)
+                    m.bias.data.fill_(0.0)
+            for mod, gain in ((pi_net, np.sqrt(2)), (vf_net, np.sqrt(2)), (action_net, 0.01), (value_net, 1)):
+                mod.apply(functools.partial(init, gain=gain))
+        parts: List[th.Tensor] = [] if self.discrete else [log_std]
+        for lin in (pi_net[0], pi_net[2], vf_net[0], vf_net[2], action_net, value_net):
+            parts += [lin.weight.detach().reshape(-1), lin.bias.detach().reshape(-1)]
+        self._flat = th.cat(parts).contiguous()
+        self._flat_t: Optional[th.Tensor] = None
+        self.desc = L.PolicyDesc(self.obs_dim, self.act_dim, H, int(self.discrete),
+                                 int(self.features_extractor.normalize is not None),
+                                 self.features_extractor.normalize.eps if self.features_extractor.normalize else 1e-5)
+        self.optimizer: Optional[HipAdam] = None
+        self._lr0 = float(lr_schedule(1))
+        self._low = self._high = None
+
+    # ---- layout -------------------------------------------------------------------------
+    def _layout(self) -> List[Tuple[str, Tuple[int, ...]]]:
+        H, D, A = self.hidden, self.obs_dim, self.act_dim
+        lay = [] if self.discrete else [("log_std", (A,))]
+        for tower in ("policy_net", "value_net"):
+            lay += [(f"mlp_extractor.{tower}.0.weight", (H, D)), (f"mlp_extractor.{tower}.0.bias", (H,)),
+                    (f"mlp_extractor.{tower}.2.weight", (H, H)), (f"mlp_extractor.{tower}.2.bias", (H,))]
+        lay += [("action_net.weight", (A, H)), ("action_net.bias", (A,)), ("value_net.weight", (1, H)),
+                ("value_net.bias", (1,))]
+        return lay
+
+    def named_parameters(self) -> Iterator[Tuple[str, th.Tensor]]:
+        o = 0
+        for name, shape in self._layout():
+            n = int(np.prod(shape))
+            yield name, self._flat[o:o + n].view(shape)
+            o += n
+
+    def parameters(self) -> Iterator[th.Tensor]:
+        for _, p in self.named_parameters():
+            yield p
+
+    @property
+    def log_std(self) -> Optional[th.Tensor]:
+        return None if self.discrete else self._flat[: self.act_dim]
+
+    def state_dict(self) -> Dict[str, th.Tensor]:
+        sd: Dict[str, th.Tensor] = {}
+        named = dict(self.named_parameters())
+        if not self.discrete:
+            sd["log_std"] = named.pop("log_std")
+        rn = self.features_extractor.normalize
+        if rn is not None:  # SB3 registers the shared extractor under three names
+            for ext in ("features_extractor", "pi_features_extractor", "vf_features_extractor"):
+                sd.update(rn.state_dict(f"{ext}.normalize."))
+        sd.update(named)
+        return sd
+
+    def load_state_dict(self, sd) -> None:
+        for k, v in self.named_parameters():
+            v.copy_(th.as_tensor(sd[k]))
+        rn = self.features_extractor.normalize
+        if rn is not None:
+            rn.load_state_dict(sd, "features_extractor.normalize.")
+        self._sync_transposed()
+
+    # ---- module-like plumbing --------------------------------------------------------------
+    @property
+    def device(self) -> th.device:
+        return self._flat.device
+
+    @property
+    def squash_output(self) -> bool:
+        return self._squash_output
+
+    def to(self, device):
+        device = th.device(device)
+        self._flat = self._flat.to(device).contiguous()
+        if self.features_extractor.normalize is not None:
+            self.features_extractor.normalize.to(device)
+        if device.type == "cuda":
+            self._flat_t = th.empty_like(self._flat)
+            self._sync_transposed()
+            self.optimizer = HipAdam(self._flat, th.zeros_like(self._flat), lr=self._lr0, **self.optimizer_kwargs)
+            if not self.discrete:
+                self._low = th.as_tensor(self.action_space.low.reshape(-1), dtype=th.float32, device=device)
+                self._high = th.as_tensor(self.action_space.high.reshape(-1), dtype=th.float32, device=device)
+            else:
+                self._low = self._high = th.zeros(self.act_dim, device=device)
+        return self
+
+    def _sync_transposed(self) -> None:
+        if self._flat_t is not None:
+            L.call("ia_policy_transpose", C.byref(self.desc), L.ptr(self._flat), L.ptr(self._flat_t), L.stream())
+
+    def set_training_mode(self, mode: bool) -> None:
+        self.train(mode)
+
+    def train(self, mode: bool = True):
+        self.training = mode
+        if self.features_extractor.normalize is not None:
+            self.features_extractor.normalize.train(mode)
+        return self
+
+    def eval(self):
+        return self.train(False)
+
+    def _norm_ptrs(self):
+        rn = self.features_extractor.normalize
+        return (None, None) if rn is None else (L.ptr(rn.running_mean), L.ptr(rn.running_var))
+
+    def _obs_dev(self, obs) -> th.Tensor:
+        """Observation batch -> contiguous fp32 `[n, obs_dim]` on device ([SB3 preprocess_obs] Box: .float())."""
+        t = obs if isinstance(obs, th.Tensor) else th.as_tensor(np.ascontiguousarray(obs))
+        return t.to(self.device, th.float32).reshape(t.shape[0], -1).contiguous()
+
+    def _maybe_update_norm(self, obs_dev: th.Tensor) -> None:
+        rn = self.features_extractor.normalize
+        if rn is not None and self.training:  # train-mode forward updates before normalising (networks.py:81-87)
+            rn.update_stats(obs_dev)
+
+    # ---- SB3 API -----------------------------------------------------------------------------
+    def sample_noise(self, n: int) -> th.Tensor:
+        """Host draw from torch's global generator with the shape SB3's sampling uses
+        (`Normal.rsample` -> standard normal `[n, act_dim]`). Discrete heads use one U(0,1) per row for
+        inverse-CDF sampling (same distribution as `Categorical.sample`, different stream)."""
+        if self.discrete:
+            return th.rand(n)
+        return th.distributions.utils._standard_normal((n, self.act_dim), dtype=th.float32, device="cpu")
+
+    def act(self, obs_dev: th.Tensor, noise_dev: th.Tensor, actions: th.Tensor, clipped: th.Tensor,
+            values: th.Tensor, logp: th.Tensor) -> None:
+        """Device-to-device rollout step (no allocation): fills actions/clipped/values/logp."""
+        self._maybe_update_norm(obs_dev)
+        nm, nv = self._norm_ptrs()
+        L.call("ia_policy_act", C.byref(self.desc), L.ptr(self._flat), L.ptr(self._flat_t), nm, nv, L.ptr(obs_dev),
+               obs_dev.shape[0], L.ptr(noise_dev), L.ptr(self._low), L.ptr(self._high), L.ptr(actions),
+               L.ptr(clipped), L.ptr(values), L.ptr(logp), L.stream())
+
+    def forward(self, obs, deterministic: bool = False):
+        """[SB3 ActorCriticPolicy.forward] -> (actions, values, log_prob) device tensors."""
+        require_device(self.device)
+        o = self._obs_dev(obs)
+        n = o.shape[0]
+        noise = th.zeros(n, self.act_dim) if (deterministic and not self.discrete) else self.sample_noise(n)
+        aw = 1 if self.discrete else self.act_dim
+        acts, clip = th.empty(n, aw, device=self.device), th.empty(n, aw, device=self.device)
+        vals, logp = th.empty(n, device=self.device), th.empty(n, device=self.device)
+        self.act(o, noise.to(self.device), acts, clip, vals, logp)
+        if self.discrete:
+            acts = acts.reshape(n).long()
+        return acts.reshape((n, *self.action_space.shape)), vals.reshape(n, 1), logp
+
+    __call__ = forward
+
+    def evaluate_actions(self, obs, actions):
+        """[SB3 evaluate_actions] without autograd: (values [n,1], log_prob [n], entropy [n])."""
+        require_device(self.device)
+        o = self._obs_dev(obs)
+        n = o.shape[0]
+        a = actions if isinstance(actions, th.Tensor) else th.as_tensor(np.ascontiguousarray(actions))
+        a = a.to(self.device, th.float32).reshape(n, -1).contiguous()
+        self._maybe_update_norm(o)
+        nm, nv = self._norm_ptrs()
+        logp, vals, ent = (th.empty(n, device=self.device) for _ in range(3))
+        L.call("ia_policy_evaluate", C.byref(self.desc), L.ptr(self._flat), L.ptr(self._flat_t), nm, nv, L.ptr(o),
+               L.ptr(a), n, L.ptr(logp), L.ptr(vals), L.ptr(ent), L.stream())
+        return vals.reshape(n, 1), logp, ent
+
+    def log_prob_rows(self, obs_dev: th.Tensor, acts_dev: th.Tensor, out: th.Tensor) -> None:
+        """log pi(a|s) for device rows (train-mode norm update included), no allocation."""
+        self._maybe_update_norm(obs_dev)
+        nm, nv = self._norm_ptrs()
+        L.call("ia_policy_evaluate", C.byref(self.desc), L.ptr(self._flat), L.ptr(self._flat_t), nm, nv,
+               L.ptr(obs_dev), L.ptr(acts_dev), obs_dev.shape[0], L.ptr(out), None, None, L.stream())
+
+    def predict_values(self, obs) -> th.Tensor:
+        require_device(self.device)
+        o = self._obs_dev(obs)
+        self._maybe_update_norm(o)
+        vals = th.empty(o.shape[0], device=self.device)
+        self.values_rows(o, vals)
+        return vals.reshape(-1, 1)
+
+    def values_rows(self, obs_dev: th.Tensor, out: th.Tensor) -> None:
+        nm, nv = self._norm_ptrs()
+        L.call("ia_policy_evaluate", C.byref(self.desc), L.ptr(self._flat), L.ptr(self._flat_t), nm, nv,
+               L.ptr(obs_dev), None, obs_dev.shape[0], None, L.ptr(out), None, L.stream())
+
+    def predict(self, observation, state=None, episode_start=None, deterministic: bool = False):
+        """[SB3 BasePolicy.predict]: numpy in, clipped numpy actions out."""
+        self.set_training_mode(False)
+        obs = np.asarray(observation)
+        vectorized = obs.shape != tuple(self.observation_space.shape)
+        obs = obs.reshape((-1, *self.observation_space.shape))
+        if self.discrete and deterministic:
+            _, logp_all, _ = None, None, None
+            raise NotImplementedError("deterministic Categorical prediction is not built yet")
+        acts, _, _ = self.forward(obs, deterministic=deterministic)
+        acts = acts.cpu().numpy()
+        if not self.discrete:
+            acts = np.clip(acts, self.action_space.low, self.action_space.high)
+        return (acts if vectorized else acts[0]), state
+
+
+class FeedForward32Policy(ActorCriticPolicy):
+    """`policies/base.py:92-104`."""
+
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs, net_arch=[32, 32])

@@ -1,0 +1,407 @@
+"""PPO generator behind the SB3 `BaseAlgorithm` / `OnPolicyAlgorithm` surface the adversarial
+trainer touches (`adversarial/common.py:243-251,414-419`; SURVEY 8b "Generator protocol",
+App. A.3-A.7), running on MI355X:
+
+* `collect_rollouts`: per env step ONE fused policy kernel on the `[n_envs, obs]` observation
+  tensor (`ia_policy_act`), a 24 KB D2H of the clipped actions, the host VecEnv step, and an
+  async H2D of the next observations. Reward relabelling by the discriminator, the time-limit
+  value bootstrap, the final value estimate and GAE run once per rollout on the whole
+  `[T, n_envs]` tile (identical arithmetic: nothing they depend on changes inside a rollout).
+* `train`: host-drawn `np.random.permutation` per epoch (same global-RNG call sequence as SB3's
+  `RolloutBuffer.get`), all epochs enqueued back-to-back through `ia_ppo_epoch` with no host
+  synchronisation; statistics come back in one D2H at the end.
+"""
+from __future__ import annotations
+
+import collections
+import ctypes as C
+import random
+import sys
+import time
+from typing import Any, Dict, Optional
+
+import numpy as np
+import torch as th
+
+from imitation_amd import _lib as L
+from imitation_amd import logger as imit_logger
+from imitation_amd import policies as pol_mod
+from imitation_amd import spaces
+from imitation_amd.networks import TransitionTable, require_device
+from imitation_amd.wrappers import BufferingWrapper, RewardVecEnvWrapper, step_arrays
+
+
+def set_random_seed(seed: int) -> None:
+    """[SB3 utils.set_random_seed]."""
+    random.seed(seed)
+    np.random.seed(seed)
+    th.manual_seed(seed)
+
+
+def _schedule(v):
+    return v if callable(v) else (lambda _progress, _v=float(v): _v)
+
+
+class _NullCallback:
+    def init_callback(self, model): pass
+    def on_training_start(self, l, g): pass
+    def on_rollout_start(self): pass
+    def on_step(self): return True
+    def on_rollout_end(self): pass
+    def on_training_end(self): pass
+    def update_locals(self, l): pass
+
+
+class _CallbackList(_NullCallback):
+    def __init__(self, cbs):
+        self.cbs = list(cbs)
+
+    def init_callback(self, model):
+        for c in self.cbs: c.init_callback(model)
+
+    def on_training_start(self, l, g):
+        for c in self.cbs: c.on_training_start(l, g)
+
+    def on_rollout_start(self):
+        for c in self.cbs: c.on_rollout_start()
+
+    def on_step(self):
+        ok = True
+        for c in self.cbs: ok = c.on_step() and ok
+        return ok
+
+    def on_rollout_end(self):
+        for c in self.cbs: c.on_rollout_end()
+
+    def on_training_end(self):
+        for c in self.cbs: c.on_training_end()
+
+
+class RolloutBuffer:
+    """Device-resident `[T, n_envs, ...]` rollout tile (time-major, fp32) + the pinned host
+    staging the env loop writes into. Properties named like SB3's `RolloutBuffer` fields return
+    host copies in SB3's layout (post-`get()`: env-major flattened; `rewards`: `[T, n]`)."""
+
+    def __init__(self, T: int, n: int, obs_dim: int, act_width: int, device):
+        self.buffer_size, self.n_envs, self.obs_dim, self.act_width = T, n, obs_dim, act_width
+        f = lambda *s: th.zeros(*s, device=device)
+        self.obs = f(T + 1, n, obs_dim)
+        self.acts, self.clipped = f(T, n, act_width), f(T, n, act_width)
+        self.next_fixed = f(T, n, obs_dim)
+        self.dones = th.zeros(T, n, dtype=th.uint8, device=device)
+        self.trunc = th.zeros(T, n, dtype=th.uint8, device=device)
+        self.rew, self.val, self.logp, self.adv, self.ret, self.starts = (f(T, n) for _ in range(6))
+        self.term_val, self.last_val, self.last_done = f(T, n), f(n), f(n)
+        self.noise = f(n, max(act_width, 1))
+        pin = lambda *s, dtype=th.float32: th.zeros(*s, dtype=dtype).pin_memory()
+        self.h_obs, self.h_next = pin(T + 1, n, obs_dim), pin(T, n, obs_dim)
+        self.h_dones, self.h_trunc = pin(T, n, dtype=th.uint8), pin(T, n, dtype=th.uint8)
+        self.h_rew, self.h_starts = pin(T, n), pin(T, n)
+        self.h_clip, self.h_noise, self.h_last_done = pin(n, act_width), pin(n, max(act_width, 1)), pin(n)
+        self.full = False
+
+    def reset(self) -> None:
+        self.full = False
+
+    def _env_major(self, t: th.Tensor) -> np.ndarray:
+        a = t.detach().cpu().numpy()
+        return a.swapaxes(0, 1).reshape(self.buffer_size * self.n_envs, *a.shape[2:])
+
+    observations = property(lambda s: s._env_major(s.obs[: s.buffer_size]))
+    actions = property(lambda s: s._env_major(s.acts))
+    values = property(lambda s: s._env_major(s.val))
+    log_probs = property(lambda s: s._env_major(s.logp))
+    advantages = property(lambda s: s._env_major(s.adv))
+    returns = property(lambda s: s._env_major(s.ret))
+    rewards = property(lambda s: s.rew.detach().cpu().numpy())
+    episode_starts = property(lambda s: s.starts.detach().cpu().numpy())
+
+
+class OnPolicyAlgorithm:
+    """Marker base so `isinstance(gen_algo, OnPolicyAlgorithm)` (`common.py:250`) keeps its meaning."""
+
+
+class PPO(OnPolicyAlgorithm):
+    def __init__(self, policy, env, learning_rate=3e-4, n_steps: int = 2048, batch_size: int = 64, n_epochs: int = 10,
+                 gamma: float = 0.99, gae_lambda: float = 0.95, clip_range=0.2, clip_range_vf=None,
+                 normalize_advantage: bool = True, ent_coef: float = 0.0, vf_coef: float = 0.5,
+                 max_grad_norm: float = 0.5, use_sde: bool = False, sde_sample_freq: int = -1,
+                 target_kl: Optional[float] = None, stats_window_size: int = 100, tensorboard_log=None,
+                 policy_kwargs: Optional[Dict[str, Any]] = None, verbose: int = 0, seed: Optional[int] = None,
+                 device="auto", _init_setup_model: bool = True):
+        if use_sde or clip_range_vf is not None or target_kl is not None:
+            raise NotImplementedError("gSDE / value clipping / target_kl are off in every reference config")
+        if isinstance(policy, str):
+            policy = {"MlpPolicy": pol_mod.ActorCriticPolicy}[policy]
+        self.policy_class = policy
+        self.policy_kwargs = dict(policy_kwargs or {})
+        self.device = th.device("cuda" if device == "auto" else device)
+        self.learning_rate, self.n_steps, self.batch_size, self.n_epochs = learning_rate, n_steps, batch_size, n_epochs
+        self.gamma, self.gae_lambda, self.clip_range = gamma, gae_lambda, clip_range
+        self.normalize_advantage, self.ent_coef, self.vf_coef = normalize_advantage, ent_coef, vf_coef
+        self.max_grad_norm, self.seed, self.verbose = max_grad_norm, seed, verbose
+        self.num_timesteps = 0
+        self._total_timesteps = 0
+        self._num_timesteps_at_start = 0
+        self._n_updates = 0
+        self._current_progress_remaining = 1.0
+        self._last_obs = None
+        self._last_episode_starts = None
+        self._stats_window_size = stats_window_size
+        self.ep_info_buffer = None
+        self._logger: Optional[imit_logger.Logger] = None
+        self._custom_logger = False
+        self.start_time = 0
+        self.env = env
+        self.policy: Optional[pol_mod.ActorCriticPolicy] = None
+        self.rollout_buffer: Optional[RolloutBuffer] = None
+        if env is not None:
+            self.observation_space, self.action_space, self.n_envs = env.observation_space, env.action_space, env.num_envs
+        if normalize_advantage:
+            assert batch_size > 1, "`batch_size` must be greater than 1 (advantage normalisation)"
+        if _init_setup_model:
+            self._setup_model()
+
+    # ---- SB3 BaseAlgorithm surface ----------------------------------------------------------
+    def _setup_model(self) -> None:
+        self.lr_schedule = _schedule(self.learning_rate)
+        self.clip_range = _schedule(self.clip_range)
+        if self.seed is not None:
+            set_random_seed(self.seed)
+            self.action_space.seed(self.seed)
+            if self.env is not None:
+                self.env.seed(self.seed)
+        self.policy = self.policy_class(self.observation_space, self.action_space, self.lr_schedule,
+                                        **self.policy_kwargs).to(self.device)
+        self._alloc()
+
+    def _alloc(self) -> None:
+        if self.device.type != "cuda":
+            return
+        p = self.policy
+        self.rollout_buffer = RolloutBuffer(self.n_steps, self.n_envs, p.obs_dim, 1 if p.discrete else p.act_dim,
+                                            self.device)
+        total = self.n_steps * self.n_envs
+        self._n_mb = -(-total // self.batch_size)
+        self._ppo_ws = th.empty(int(L.load().ia_ppo_ws_floats(C.byref(p.desc), min(self.batch_size, total))),
+                                device=self.device)
+        self._perm_host = th.zeros(self.n_epochs, total, dtype=th.int64).pin_memory()
+        self._perm_dev = th.zeros(self.n_epochs, total, dtype=th.int64, device=self.device)
+        self._stats_dev = th.zeros(self.n_epochs, self._n_mb, 8, device=self.device)
+
+    @property
+    def logger(self):
+        return self._logger
+
+    def set_logger(self, logger) -> None:
+        self._logger = logger
+        self._custom_logger = True
+
+    def get_env(self):
+        return self.env
+
+    def set_env(self, env, force_reset: bool = True) -> None:
+        if env.num_envs != self.n_envs:
+            raise ValueError("The number of environments to be set is different from the number of environments in "
+                             f"the model: ({env.num_envs} != {self.n_envs})")
+        if env.observation_space != self.observation_space:
+            raise ValueError(f"Observation spaces do not match: {self.observation_space} != {env.observation_space}")
+        if env.action_space != self.action_space:
+            raise ValueError(f"Action spaces do not match: {self.action_space} != {env.action_space}")
+        if force_reset:
+            self._last_obs = None
+        self.env = env
+
+    def predict(self, observation, state=None, episode_start=None, deterministic: bool = False):
+        return self.policy.predict(observation, state, episode_start, deterministic)
+
+    def save(self, path) -> None:
+        th.save({"policy": {k: v.cpu() for k, v in self.policy.state_dict().items()},
+                 "optimizer": {"step": self.policy.optimizer.step_count,
+                               "exp_avg": self.policy.optimizer.exp_avg.cpu(),
+                               "exp_avg_sq": self.policy.optimizer.exp_avg_sq.cpu()},
+                 "num_timesteps": self.num_timesteps, "n_updates": self._n_updates}, path)
+
+    # ---- learn loop (App. A.3) ---------------------------------------------------------------
+    def _init_callback(self, callback):
+        if callback is None:
+            callback = _NullCallback()
+        elif isinstance(callback, (list, tuple)):
+            callback = _CallbackList(callback)
+        callback.init_callback(self)
+        return callback
+
+    def _setup_learn(self, total_timesteps: int, callback, reset_num_timesteps: bool):
+        self.start_time = time.time_ns()
+        if self.ep_info_buffer is None or reset_num_timesteps:
+            self.ep_info_buffer = collections.deque(maxlen=self._stats_window_size)
+        if reset_num_timesteps:
+            self.num_timesteps = 0
+        else:
+            total_timesteps += self.num_timesteps
+        self._total_timesteps = total_timesteps
+        self._num_timesteps_at_start = self.num_timesteps
+        if reset_num_timesteps or self._last_obs is None:
+            self._last_obs = self.env.reset()
+            self._last_episode_starts = np.ones((self.env.num_envs,), dtype=bool)
+        if not self._custom_logger and self._logger is None:
+            self._logger = imit_logger.Logger(None, [])
+        return total_timesteps, self._init_callback(callback)
+
+    def learn(self, total_timesteps: int, callback=None, log_interval: int = 1, tb_log_name: str = "PPO",
+              reset_num_timesteps: bool = True, progress_bar: bool = False):
+        require_device(self.device)
+        iteration = 0
+        total_timesteps, callback = self._setup_learn(total_timesteps, callback, reset_num_timesteps)
+        callback.on_training_start(locals(), globals())
+        while self.num_timesteps < total_timesteps:
+            if not self.collect_rollouts(self.env, callback, self.rollout_buffer, self.n_steps):
+                break
+            iteration += 1
+            self._current_progress_remaining = 1.0 - float(self.num_timesteps) / float(total_timesteps)
+            if log_interval is not None and iteration % log_interval == 0:
+                elapsed = max((time.time_ns() - self.start_time) / 1e9, sys.float_info.epsilon)
+                fps = int((self.num_timesteps - self._num_timesteps_at_start) / elapsed)
+                self.logger.record("time/iterations", iteration, exclude="tensorboard")
+                if len(self.ep_info_buffer) > 0 and len(self.ep_info_buffer[0]) > 0:
+                    self.logger.record("rollout/ep_rew_mean", float(np.mean([e["r"] for e in self.ep_info_buffer])))
+                    self.logger.record("rollout/ep_len_mean", float(np.mean([e["l"] for e in self.ep_info_buffer])))
+                self.logger.record("time/fps", fps)
+                self.logger.record("time/time_elapsed", int(elapsed), exclude="tensorboard")
+                self.logger.record("time/total_timesteps", self.num_timesteps, exclude="tensorboard")
+                self.logger.dump(step=self.num_timesteps)
+            self.train()
+        callback.on_training_end()
+        return self
+
+    # ---- rollout collection (App. A.4) --------------------------------------------------------
+    @staticmethod
+    def _unwrap(env):
+        """(reward_wrapper | None, buffering | None, innermost env to step)."""
+        rw = env if isinstance(env, RewardVecEnvWrapper) else None
+        inner = env.venv if rw is not None else env
+        bw = inner if isinstance(inner, BufferingWrapper) else None
+        base = inner.venv if bw is not None else inner
+        return rw, bw, base
+
+    def collect_rollouts(self, env, callback, rb: RolloutBuffer, n_rollout_steps: int) -> bool:
+        assert self._last_obs is not None, "No previous observation was provided"
+        from imitation_amd.reward_nets import RewardNet  # local import: avoid a cycle
+        pol = self.policy
+        pol.set_training_mode(False)
+        rb.reset()
+        callback.on_rollout_start()
+        rw, bw, base = self._unwrap(env)
+        fused_net = None
+        if rw is not None:
+            owner = getattr(rw.reward_fn, "__self__", None)
+            if isinstance(owner, RewardNet) and getattr(rw.reward_fn, "__name__", "") == "predict_processed":
+                fused_net = owner
+        T, n = rb.buffer_size, rb.n_envs
+        assert n_rollout_steps == T
+        stream = th.cuda.current_stream()
+        rb.h_obs[0].copy_(th.as_tensor(np.asarray(self._last_obs)).reshape(n, -1))
+        rb.obs[0].copy_(rb.h_obs[0], non_blocking=True)
+        starts = np.asarray(self._last_episode_starts, dtype=bool)
+        h_rew_np, h_dones_np, h_trunc_np = rb.h_rew.numpy(), rb.h_dones.numpy(), rb.h_trunc.numpy()
+        h_next_np, h_obs_np, h_starts_np = rb.h_next.numpy(), rb.h_obs.numpy(), rb.h_starts.numpy()
+        per_step_rews = []
+        for t in range(T):
+            rb.h_noise.copy_(pol.sample_noise(n).reshape(n, -1))
+            rb.noise.copy_(rb.h_noise, non_blocking=True)
+            pol.act(rb.obs[t], rb.noise, rb.acts[t], rb.clipped[t], rb.val[t], rb.logp[t])
+            rb.h_clip.copy_(rb.clipped[t], non_blocking=True)
+            stream.synchronize()
+            acts_np = rb.h_clip.numpy()
+            acts_np = acts_np.reshape(n).astype(np.int64) if pol.discrete else acts_np.reshape(
+                (n, *self.action_space.shape)).copy()
+            old_obs = self._last_obs
+            base.step_async(acts_np)
+            new_obs, env_rews, dones, nxt, trunc, infos = step_arrays(base)
+            self.num_timesteps += n
+            if not callback.on_step():
+                return False
+            if infos is not None:
+                for info in infos:
+                    if info.get("episode") is not None:
+                        self.ep_info_buffer.extend([info["episode"]])
+            if bw is not None:
+                bw.record_step(acts_np, new_obs, nxt, env_rews, dones)
+            h_obs_np[t + 1] = new_obs.reshape(n, -1)
+            h_next_np[t] = nxt.reshape(n, -1)
+            h_dones_np[t], h_trunc_np[t], h_starts_np[t] = dones, trunc, starts
+            if rw is not None and fused_net is None:  # arbitrary host reward function: per-step call
+                r = rw.reward_fn(old_obs, acts_np, nxt, np.array(dones))
+                per_step_rews.append(np.asarray(r, dtype=np.float32))
+                h_rew_np[t] = per_step_rews[-1]
+            else:
+                h_rew_np[t] = env_rews
+            rb.obs[t + 1].copy_(rb.h_obs[t + 1], non_blocking=True)
+            self._last_obs, starts = new_obs, np.asarray(dones, dtype=bool)
+        self._last_episode_starts = starts
+        rb.h_last_done.copy_(th.as_tensor(starts.astype(np.float32)))
+        for d, h in ((rb.next_fixed, rb.h_next), (rb.dones, rb.h_dones), (rb.trunc, rb.h_trunc),
+                     (rb.starts, rb.h_starts), (rb.last_done, rb.h_last_done)):
+            d.copy_(h, non_blocking=True)
+        if fused_net is not None:  # discriminator reward relabelling on the whole [T, n] tile
+            acts_tbl = rb.clipped.reshape(T * n).long() if pol.discrete else rb.clipped.reshape(T * n, -1)
+            table = TransitionTable(rb.obs[:T].reshape(T * n, -1), acts_tbl, rb.next_fixed.reshape(T * n, -1),
+                                    rb.dones.reshape(T * n), pol.discrete)
+            rb.rew.copy_(fused_net.predict_processed_rollout(table, T, n).reshape(T, n))
+        else:
+            rb.rew.copy_(rb.h_rew, non_blocking=True)
+        if rw is not None:
+            wrapped = rb.rew.cpu().numpy() if fused_net is not None else np.stack(per_step_rews)
+            rw.record_rewards(wrapped, h_dones_np.astype(bool), self._last_obs)
+        if h_trunc_np.any():  # rewards[i] += gamma * V(terminal_obs_i) for time-limit endings
+            pol.values_rows(rb.next_fixed.reshape(T * n, -1), rb.term_val.reshape(T * n))
+            L.call("ia_timeout_bootstrap", L.ptr(rb.rew), L.ptr(rb.term_val), L.ptr(rb.trunc), float(self.gamma),
+                   T * n, L.stream())
+        pol.values_rows(rb.obs[T], rb.last_val)
+        L.call("ia_gae", L.ptr(rb.rew), L.ptr(rb.val), L.ptr(rb.starts), L.ptr(rb.last_val), L.ptr(rb.last_done), T,
+               n, float(self.gamma), float(self.gae_lambda), L.ptr(rb.adv), L.ptr(rb.ret), L.stream())
+        rb.full = True
+        callback.on_rollout_end()
+        return True
+
+    # ---- PPO update (App. A.7) ----------------------------------------------------------------
+    def train(self) -> None:
+        pol, rb = self.policy, self.rollout_buffer
+        pol.set_training_mode(True)
+        lr = self.lr_schedule(self._current_progress_remaining)
+        self.logger.record("train/learning_rate", lr)
+        pol.optimizer.param_groups[0]["lr"] = lr
+        clip_range = self.clip_range(self._current_progress_remaining)
+        T, n = rb.buffer_size, rb.n_envs
+        perm = self._perm_host.numpy()
+        for e in range(self.n_epochs):  # one global-NumPy draw per epoch, as RolloutBuffer.get does
+            perm[e] = np.random.permutation(T * n)
+        self._perm_dev.copy_(self._perm_host, non_blocking=True)
+        rn = pol.features_extractor.normalize
+        g = pol.optimizer.param_groups[0]
+        for e in range(self.n_epochs):
+            L.call("ia_ppo_epoch", C.byref(pol.desc), L.ptr(pol._flat), L.ptr(pol._flat_t),
+                   L.ptr(rn.running_mean) if rn else None, L.ptr(rn.running_var) if rn else None,
+                   L.ptr(rn.count) if rn else None, int(rn is not None), L.ptr(rb.obs), L.ptr(rb.acts), L.ptr(rb.logp),
+                   L.ptr(rb.adv), L.ptr(rb.ret), L.ptr(self._perm_dev[e]), T, n, self.batch_size,
+                   int(self.normalize_advantage), float(clip_range), float(self.ent_coef), float(self.vf_coef),
+                   float(self.max_grad_norm), L.ptr(pol.optimizer.exp_avg), L.ptr(pol.optimizer.exp_avg_sq),
+                   float(lr), float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]), pol.optimizer.step_count,
+                   L.ptr(self._ppo_ws), L.ptr(self._stats_dev[e]), L.stream())
+            pol.optimizer.step_count += self._n_mb
+        self._n_updates += self.n_epochs
+        st = self._stats_dev.cpu().numpy()  # one synchronisation per train()
+        vals, rets = rb.val.cpu().numpy().reshape(-1), rb.ret.cpu().numpy().reshape(-1)
+        var_y = np.var(rets)
+        ev = np.nan if var_y == 0 else 1 - np.var(rets - vals) / var_y
+        self.logger.record("train/entropy_loss", float(st[..., 2].mean()))
+        self.logger.record("train/policy_gradient_loss", float(st[..., 0].mean()))
+        self.logger.record("train/value_loss", float(st[..., 1].mean()))
+        self.logger.record("train/approx_kl", float(st[-1, :, 3].mean()))
+        self.logger.record("train/clip_fraction", float(st[..., 4].mean()))
+        self.logger.record("train/loss", float(st[-1, -1, 5]))
+        self.logger.record("train/explained_variance", float(ev))
+        if not pol.discrete:
+            self.logger.record("train/std", float(th.exp(pol.log_std).mean().item()))
+        self.logger.record("train/n_updates", self._n_updates, exclude="tensorboard")
+        self.logger.record("train/clip_range", clip_range)

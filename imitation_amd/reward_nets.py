@@ -1,0 +1,427 @@
+"""Reward / discriminator networks behind the reference's `RewardNet` plugin API
+(`rewards/reward_nets.py`), computing on MI355X through libimitation_hip.so.
+
+Same constructors, same `forward / preprocess / predict_th / predict / predict_processed`
+surface, same `state_dict` keys (so checkpoints interchange with the reference), but the
+objects are plain state holders (not autograd modules): the discriminator update is driven
+by `AdversarialTrainer.train_disc` through `disc_forward` / `disc_backward`, which run the
+fused HIP forward+backward and accumulate into one flat gradient buffer.
+"""
+from __future__ import annotations
+
+import abc
+from typing import Callable, Dict, Iterator, List, Optional, Sequence, Tuple, Type
+
+import numpy as np
+import torch as th
+from torch import nn
+
+from imitation_amd import _lib as L
+from imitation_amd import spaces
+from imitation_amd.networks import (DenseStack, RunningNorm, TransitionTable, evaluating, gather_concat,
+                                    require_device)
+
+
+class ParamStore:
+    """All dense stacks of one reward-net tree share a flat parameter / gradient buffer."""
+
+    def __init__(self):
+        self.stacks: List[DenseStack] = []
+        self.flat: Optional[th.Tensor] = None
+        self.grad: Optional[th.Tensor] = None
+
+    def add(self, stack: DenseStack) -> None:
+        self.stacks.append(stack)
+        self.materialize(self.flat.device if self.flat is not None else th.device("cpu"))
+
+    def materialize(self, device) -> None:
+        device = th.device(device)
+        parts = []
+        for s in self.stacks:
+            parts.append(s.flat.detach().to(device) if s.flat is not None else s._init_flat.to(device))
+        self.flat = th.cat(parts).contiguous()
+        self.grad = th.zeros_like(self.flat)
+        o = 0
+        for s in self.stacks:
+            s.to(device)
+            s.bind(self.flat[o:o + s.n_params], self.grad[o:o + s.n_params])
+            o += s.n_params
+
+
+def preprocess_space(x: th.Tensor, space, normalize_images: bool = True) -> th.Tensor:
+    """[SB3 preprocess_obs] for the spaces on the path."""
+    if isinstance(space, spaces.Box):
+        x = x.float()
+        if normalize_images and space.dtype == np.uint8 and len(space.shape) == 3:
+            x = x / 255.0
+        return x
+    if isinstance(space, spaces.Discrete):
+        return th.nn.functional.one_hot(x.long(), num_classes=space.n).float()
+    raise NotImplementedError(f"Preprocessing not implemented for {space}")
+
+
+class RewardNet(abc.ABC):
+    """`rewards/reward_nets.py:16-224`."""
+
+    def __init__(self, observation_space, action_space, normalize_images: bool = True):
+        self.observation_space, self.action_space = observation_space, action_space
+        self.normalize_images = normalize_images
+        self.training = True
+        self._store: Optional[ParamStore] = None
+
+    # ---- module-like plumbing -----------------------------------------------------------
+    def _children(self) -> List["RewardNet"]:
+        return []
+
+    def _named_stacks(self) -> List[Tuple[str, DenseStack]]:
+        return []
+
+    def _named_norms(self) -> List[Tuple[str, RunningNorm]]:
+        return []
+
+    def train(self, mode: bool = True):
+        self.training = mode
+        for _, s in self._named_stacks():
+            s.train(mode)
+        for _, n in self._named_norms():
+            n.train(mode)
+        for c in self._children():
+            c.train(mode)
+        return self
+
+    def eval(self):
+        return self.train(False)
+
+    def to(self, device):
+        if self._store is not None:
+            self._store.materialize(device)
+        for _, n in self._named_norms():
+            n.to(device)
+        for c in self._children():
+            for _, n in c._named_norms():
+                n.to(device)
+        return self
+
+    @property
+    def device(self) -> th.device:
+        if self._store is not None and self._store.flat is not None:
+            return self._store.flat.device
+        return th.device("cpu")
+
+    @property
+    def dtype(self) -> th.dtype:
+        return th.float32
+
+    def named_parameters(self) -> Iterator[Tuple[str, th.Tensor]]:
+        for prefix, s in self._named_stacks():
+            yield from s.named_parameters(prefix)
+
+    def parameters(self) -> Iterator[th.Tensor]:
+        for _, p in self.named_parameters():
+            yield p
+
+    def state_dict(self) -> Dict[str, th.Tensor]:
+        sd: Dict[str, th.Tensor] = {}
+        for prefix, s in self._named_stacks():
+            sd.update(s.state_dict(prefix))
+        for prefix, n in self._named_norms():
+            sd.update(n.state_dict(prefix))
+        return sd
+
+    def load_state_dict(self, sd) -> None:
+        for prefix, s in self._named_stacks():
+            s.load_state_dict(sd, prefix)
+        for prefix, n in self._named_norms():
+            n.load_state_dict(sd, prefix)
+
+    # ---- reference API ------------------------------------------------------------------
+    def preprocess(self, state, action, next_state, done):
+        """`reward_nets.py:52-118`: to device, float / one-hot, done -> float32."""
+        dev = self.device
+        to = lambda a: th.as_tensor(np.ascontiguousarray(a) if isinstance(a, np.ndarray) else a).to(dev)
+        s = preprocess_space(to(state), self.observation_space, self.normalize_images)
+        a = preprocess_space(to(action), self.action_space, self.normalize_images)
+        ns = preprocess_space(to(next_state), self.observation_space, self.normalize_images)
+        d = to(done).to(th.float32)
+        assert s.shape == ns.shape and len(a) == len(s)
+        return s, a, ns, d
+
+    def _table_from_tensors(self, state, action, next_state, done) -> TransitionTable:
+        n = state.shape[0]
+        return TransitionTable(state.reshape(n, -1).float().contiguous(), action.reshape(n, -1).float().contiguous(),
+                               next_state.reshape(n, -1).float().contiguous(),
+                               (done.reshape(n) != 0).to(th.uint8).contiguous(), discrete=False)
+
+    def forward(self, state: th.Tensor, action: th.Tensor, next_state: th.Tensor, done: th.Tensor) -> th.Tensor:
+        """Rewards for preprocessed device tensors (`reward_nets.py:42-50`); no autograd graph."""
+        require_device(self.device)
+        table = self._table_from_tensors(state, action, next_state, done)
+        return self._forward_table([(table, None, len(table))], "fwd").clone()
+
+    __call__ = forward
+
+    @abc.abstractmethod
+    def _forward_table(self, sources, tag: str, out_act: int = L.ACT_NONE) -> th.Tensor:
+        """Rewards `[n]` for rows assembled from `sources = [(table, idx_or_None, n), ...]`."""
+
+    def predict_th(self, state, action, next_state, done) -> th.Tensor:
+        with evaluating(self):
+            rew = self.forward(*self.preprocess(state, action, next_state, done))
+        assert rew.shape == np.shape(state)[:1]
+        return rew
+
+    def predict(self, state, action, next_state, done) -> np.ndarray:
+        return self.predict_th(state, action, next_state, done).detach().cpu().numpy().flatten()
+
+    def predict_processed(self, state, action, next_state, done, **kwargs) -> np.ndarray:
+        del kwargs
+        return self.predict(state, action, next_state, done)
+
+    # ---- fused paths used by the trainer / rollout collector ----------------------------
+    def predict_processed_rollout(self, table: TransitionTable, T: int, n: int) -> th.Tensor:
+        """`predict_processed` for a whole rollout `[T*n]` rows (time-major), result on device.
+        Equivalent to calling `predict_processed` once per env step (`reward_wrapper.py:110-115`)
+        because nothing on this path changes between steps except output-norm statistics, which
+        `NormalizedRewardNet` replays sequentially."""
+        with evaluating(self):
+            return self._forward_table([(table, None, T * n)], "rollout")
+
+    def disc_forward(self, sources, mb_rows: int, logp: Optional[th.Tensor]) -> th.Tensor:
+        raise NotImplementedError(f"{type(self).__name__} cannot be trained as a discriminator on the HIP path")
+
+    def disc_backward(self, d_logits: th.Tensor, accumulate: bool) -> None:
+        raise NotImplementedError
+
+
+def _dims_of(space) -> int:
+    return spaces.flatdim(space)
+
+
+class BasicRewardNet(RewardNet):
+    """`rewards/reward_nets.py:383-457`: MLP over the concatenation of the enabled inputs."""
+
+    def __init__(self, observation_space, action_space, use_state: bool = True, use_action: bool = True,
+                 use_next_state: bool = False, use_done: bool = False, **kwargs):
+        super().__init__(observation_space, action_space)
+        self.use_state, self.use_action = use_state, use_action
+        self.use_next_state, self.use_done = use_next_state, use_done
+        self.obs_dim, self.act_dim = _dims_of(observation_space), _dims_of(action_space)
+        size = (self.obs_dim if use_state else 0) + (self.act_dim if use_action else 0) + \
+               (self.obs_dim if use_next_state else 0) + (1 if use_done else 0)
+        full = {"hid_sizes": (32, 32), **kwargs, "in_size": size, "out_size": 1, "squeeze_output": True}
+        self.mlp = DenseStack(**full)
+        self._store = ParamStore()
+        self._store.add(self.mlp)
+
+    @property
+    def flags(self):
+        return (self.use_state, self.use_action, self.use_next_state, self.use_done)
+
+    def _named_stacks(self):
+        return [("mlp.", self.mlp)]
+
+    def _assemble(self, sources, ws) -> int:
+        row = 0
+        for table, idx, n in sources:
+            # preprocessed tensors arrive one-hot already (discrete=False); raw tables may be int64
+            gather_concat(table, idx, n, self.obs_dim, self.act_dim, self.flags, ws["X"], self.mlp.ldx, row)
+            row += n
+        return row
+
+    def _forward_table(self, sources, tag, out_act=L.ACT_NONE):
+        R = sum(n for _, _, n in sources)
+        ws = self.mlp.workspace(R, tag)
+        self._assemble(sources, ws)
+        return self.mlp.forward_rows(ws, R, out_act).reshape(R)
+
+    def disc_forward(self, sources, mb_rows, logp):
+        R = sum(n for _, _, n in sources)
+        ws = self.mlp.train_workspace(R, "disc")
+        self._assemble(sources, ws)
+        self._disc_ws, self._disc_R = ws, R
+        return self.mlp.forward_rows(ws, R).reshape(R)
+
+    def disc_backward(self, d_logits, accumulate):
+        self.mlp.backward_rows(self._disc_ws, self._disc_R, d_logits, accumulate)
+
+
+class RewardNetWrapper(RewardNet):
+    """`rewards/reward_nets.py:227-272`."""
+
+    def __init__(self, base: RewardNet):
+        super().__init__(base.observation_space, base.action_space, base.normalize_images)
+        self._base = base
+        self._store = base._store
+
+    @property
+    def base(self) -> RewardNet:
+        return self._base
+
+    def _children(self):
+        return [self._base]
+
+    def _named_stacks(self):
+        return [(f"_base.{p}", s) for p, s in self._base._named_stacks()]
+
+    def _named_norms(self):
+        return [(f"_base.{p}", n) for p, n in self._base._named_norms()]
+
+    def preprocess(self, state, action, next_state, done):
+        return self.base.preprocess(state, action, next_state, done)
+
+
+class ForwardWrapper(RewardNetWrapper):
+    """`rewards/reward_nets.py:275-300`."""
+
+    def __init__(self, base: RewardNet):
+        super().__init__(base)
+        if isinstance(base, PredictProcessedWrapper):
+            raise ValueError("ForwardWrapper cannot be applied on top of PredictProcessedWrapper!")
+
+
+class PredictProcessedWrapper(RewardNetWrapper):
+    """`rewards/reward_nets.py:303-353`: forward / predict / predict_th pass through."""
+
+    def _forward_table(self, sources, tag, out_act=L.ACT_NONE):
+        return self.base._forward_table(sources, tag, out_act)
+
+    def predict(self, state, action, next_state, done):
+        return self.base.predict(state, action, next_state, done)
+
+    def predict_th(self, state, action, next_state, done):
+        return self.base.predict_th(state, action, next_state, done)
+
+    def disc_forward(self, sources, mb_rows, logp):
+        return self.base.disc_forward(sources, mb_rows, logp)
+
+    def disc_backward(self, d_logits, accumulate):
+        return self.base.disc_backward(d_logits, accumulate)
+
+
+class BasicPotentialMLP:
+    """`rewards/reward_nets.py:812-839`."""
+
+    def __init__(self, observation_space, hid_sizes: Sequence[int], **kwargs):
+        self.obs_dim = _dims_of(observation_space)
+        self._potential_net = DenseStack(in_size=self.obs_dim, hid_sizes=hid_sizes, squeeze_output=True,
+                                         flatten_input=True, **kwargs)
+
+
+class ShapedRewardNet(ForwardWrapper):
+    """`rewards/reward_nets.py:674-736`: f = base(s,a,s',d) + gamma*(1-d)*h(s') - h(s)."""
+
+    def __init__(self, base: RewardNet, potential, discount_factor: float):
+        super().__init__(base)
+        if not isinstance(base, BasicRewardNet) or not isinstance(potential, BasicPotentialMLP):
+            raise NotImplementedError("HIP ShapedRewardNet is built for BasicRewardNet + BasicPotentialMLP")
+        self.potential = potential
+        self.discount_factor = float(discount_factor)
+        self._store.add(potential._potential_net)
+        self._aux: Dict[int, Dict[str, th.Tensor]] = {}
+
+    def _named_stacks(self):
+        return super()._named_stacks() + [("potential._potential_net.", self.potential._potential_net)]
+
+    def to(self, device):
+        self._aux = {}
+        return super().to(device)
+
+    def _aux_ws(self, R: int) -> Dict[str, th.Tensor]:
+        ws = self._aux.get(R)
+        if ws is None:
+            dev = self.device
+            ws = {k: th.empty(R, device=dev) for k in ("dones", "logits", "dg", "dh_cur", "dh_next")}
+            ws["dones4"] = th.empty(R, 4, device=dev)
+            self._aux[R] = ws
+        return ws
+
+    def _shaped(self, sources, tag: str, train_ws: bool, logp: Optional[th.Tensor]) -> th.Tensor:
+        base, pot = self._base, self.potential._potential_net
+        R = sum(n for _, _, n in sources)
+        mk = (lambda s, t: s.train_workspace(R, t)) if train_ws else (lambda s, t: s.workspace(R, t))
+        wg, wn, wc = mk(base.mlp, tag), mk(pot, tag + "_next"), mk(pot, tag + "_cur")
+        aux = self._aux_ws(R)
+        row = 0
+        for table, idx, n in sources:
+            gather_concat(table, idx, n, base.obs_dim, base.act_dim, base.flags, wg["X"], base.mlp.ldx, row)
+            gather_concat(table, idx, n, base.obs_dim, base.act_dim, (True, False, False, False), wn["X"], pot.ldx,
+                          row, state_from_next=True)
+            gather_concat(table, idx, n, base.obs_dim, base.act_dim, (True, False, False, False), wc["X"], pot.ldx, row)
+            gather_concat(table, idx, n, base.obs_dim, base.act_dim, (False, False, False, True), aux["dones4"], 4, row)
+            row += n
+        # reference order (reward_nets.py:708-710): base, potential(next_state), potential(state)
+        g = base.mlp.forward_rows(wg, R)
+        h_next = pot.forward_rows(wn, R)
+        h_cur = pot.forward_rows(wc, R)
+        aux["dones"].copy_(aux["dones4"][:, 0])
+        L.call("ia_airl_logits", L.ptr(g), L.ptr(h_cur), L.ptr(h_next), L.ptr(aux["dones"]), L.ptr(logp),
+               self.discount_factor, R, L.ptr(aux["logits"]), L.stream())
+        self._last = (wg, wn, wc, aux, R)
+        return aux["logits"]
+
+    def _forward_table(self, sources, tag, out_act=L.ACT_NONE):
+        out = self._shaped(sources, tag, False, None)
+        if out_act == L.ACT_SOFTPLUS:
+            out = -th.nn.functional.logsigmoid(-out)
+        return out
+
+    def disc_forward(self, sources, mb_rows, logp):
+        if logp is None:
+            raise TypeError("Non-None `log_policy_act_prob` is required for this method.")
+        return self._shaped(sources, "disc", True, logp)
+
+    def disc_backward(self, d_logits, accumulate):
+        wg, wn, wc, aux, R = self._last
+        L.call("ia_airl_route_grad", L.ptr(d_logits), L.ptr(aux["dones"]), self.discount_factor, R, L.ptr(aux["dg"]),
+               L.ptr(aux["dh_cur"]), L.ptr(aux["dh_next"]), L.stream())
+        pot = self.potential._potential_net
+        self._base.mlp.backward_rows(wg, R, aux["dg"], accumulate)
+        pot.backward_rows(wn, R, aux["dh_next"], accumulate)
+        pot.backward_rows(wc, R, aux["dh_cur"], True)
+
+
+class BasicShapedRewardNet(ShapedRewardNet):
+    """`rewards/reward_nets.py:739-809`."""
+
+    def __init__(self, observation_space, action_space, *, reward_hid_sizes: Sequence[int] = (32,),
+                 potential_hid_sizes: Sequence[int] = (32, 32), use_state: bool = True, use_action: bool = True,
+                 use_next_state: bool = False, use_done: bool = False, discount_factor: float = 0.99, **kwargs):
+        base = BasicRewardNet(observation_space, action_space, use_state=use_state, use_action=use_action,
+                              use_next_state=use_next_state, use_done=use_done, hid_sizes=reward_hid_sizes, **kwargs)
+        pot = BasicPotentialMLP(observation_space, hid_sizes=potential_hid_sizes, **kwargs)
+        super().__init__(base, pot, discount_factor=discount_factor)
+
+
+class NormalizedRewardNet(PredictProcessedWrapper):
+    """`rewards/reward_nets.py:613-671`: normalises `predict_processed` with a running norm."""
+
+    def __init__(self, base: RewardNet, normalize_output_layer: Type):
+        super().__init__(base)
+        if normalize_output_layer is not RunningNorm:
+            raise NotImplementedError("only imitation_amd.RunningNorm is implemented as output normalisation")
+        self.normalize_output_layer = normalize_output_layer(1)
+
+    def _named_norms(self):
+        return super()._named_norms() + [("normalize_output_layer.", self.normalize_output_layer)]
+
+    def to(self, device):
+        self.normalize_output_layer.to(device)
+        return super().to(device)
+
+    def predict_processed(self, state, action, next_state, done, update_stats: bool = True, **kwargs) -> np.ndarray:
+        with evaluating(self):
+            raw = th.as_tensor(self.base.predict_processed(state, action, next_state, done, **kwargs),
+                               device=self.device)
+            rew = self.normalize_output_layer(raw.reshape(-1, 1)).reshape(-1).cpu().numpy().flatten()
+        if update_stats:
+            self.normalize_output_layer.update_stats(raw.reshape(-1, 1).contiguous())
+        assert rew.shape == np.shape(state)[:1]
+        return rew
+
+    def predict_processed_rollout(self, table, T, n, update_stats: bool = True):
+        raw = self.base.predict_processed_rollout(table, T, n).contiguous()
+        out = th.empty_like(raw)
+        nl = self.normalize_output_layer
+        L.call("ia_reward_norm_sequential", L.ptr(raw), T, n, nl.eps, int(update_stats), L.ptr(nl.running_mean),
+               L.ptr(nl.running_var), L.ptr(nl.count), L.ptr(out), L.stream())
+        return out

@@ -92,10 +92,16 @@ int ia_bce_logits(const float* logits, int R, int n_expert, float scale, float* 
 
 /* adversarial/airl.py:118 + rewards/reward_nets.py:701-736:
  * logits = g + gamma*(1-done)*h_next - h_cur - logp ; and the matching dOut routing. */
-int ia_airl_logits(const float* g, const float* h_cur, const float* h_next, const uint8_t* dones,
+int ia_airl_logits(const float* g, const float* h_cur, const float* h_next, const float* dones /*0/1 fp32*/,
                    const float* logp, float gamma, int R, float* logits, void* stream);
-int ia_airl_route_grad(const float* dlogits, const uint8_t* dones, float gamma, int R, float* dg, float* dh_cur,
+int ia_airl_route_grad(const float* dlogits, const float* dones, float gamma, int R, float* dg, float* dh_cur,
                        float* dh_next, void* stream);
+
+/* rewards/reward_nets.py:637-671 `NormalizedRewardNet.predict_processed` applied once per env
+ * step: out[t,:] = (raw[t,:]-mean)/sqrt(var+eps) with the statistics of steps < t, then (when
+ * update_stats) the Chan update with raw[t,:]. mean/var are 1-element buffers, count int32. */
+int ia_reward_norm_sequential(const float* raw, int T, int n, float eps, int update_stats, float* mean, float* var,
+                              int32_t* count, float* out, void* stream);
 
 /* generic row gather: dst[i,:] = src[idx[i],:] (width floats) */
 int ia_gather_rows(const float* src, const int64_t* idx, int n, int width, float* dst, void* stream);

@@ -1,0 +1,130 @@
+"""End-to-end parity (`-m gpu`): the HIP GAIL/AIRL trainer vs the golden vectors produced by the
+reference's own code (tests/golden/*.npz) and vs the oracle run live on the host CPU, on the
+same seeds / demos / synthetic env.
+
+Tolerances: integer bookkeeping (ring index, counters, done flags) bit-exact; every floating-
+point quantity (parameters after all optimiser steps, replay contents, rollout tensors, logged
+statistics, predicted rewards) within `rtol=2e-4, atol=5e-5` of the reference's CPU result --
+measured worst deviation on MI355X is 1e-5 (airl_box rollout returns); the reference's own
+accumulation-order tolerance is much looser (`atol=(1+k)*2e-4`, test_adversarial.py:340-343).
+"""
+import os
+
+import numpy as np
+import pytest
+import torch as th
+
+from tests import harness
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _need_gpu():
+    if not th.cuda.is_available():
+        pytest.skip("no GPU")
+
+
+def _k_steps(cfg):
+    ppo_steps = cfg["rounds"] * cfg["n_epochs"] * -(-cfg["n_envs"] * cfg["n_steps"] // cfg["ppo_batch"])
+    return ppo_steps + cfg["rounds"] * cfg["n_disc"]
+
+
+def _compare(got, gold, cfg, skip=()):
+    k = _k_steps(cfg)
+    atol, rtol = 5e-5, 2e-4
+    assert set(got) == set(gold), set(got) ^ set(gold)
+    worst = {}
+    for key in gold:
+        if any(key.startswith(s) for s in skip):
+            continue
+        x, y = np.asarray(got[key]), np.asarray(gold[key])
+        assert x.shape == y.shape, (key, x.shape, y.shape)
+        if key in harness.EXACT_KEYS or y.dtype.kind in "biu":
+            assert np.array_equal(x, y), key
+        else:
+            np.testing.assert_allclose(x.astype(np.float64), y.astype(np.float64), rtol=rtol, atol=atol,
+                                       equal_nan=True, err_msg=key)
+            worst[key] = float(np.nanmax(np.abs(x.astype(np.float64) - y.astype(np.float64)))) if x.size else 0.0
+    return worst
+
+
+@pytest.mark.parametrize("case", ["gail_box", "gail_f64", "airl_box"])
+def test_hip_trainer_matches_reference_golden(case, tmp_path):
+    cfg = harness.CASES[case]
+    gold = dict(np.load(os.path.join(GOLDEN, f"{case}.npz")))
+    got = harness.run_case("hip", case, str(tmp_path), device="cuda")
+    worst = _compare(got, gold, cfg)
+    print(case, "max abs deviation:", max(worst.values()), max(worst, key=worst.get))
+
+
+def test_hip_trainer_matches_live_oracle(tmp_path):
+    cfg = harness.CASES["gail_box"]
+    ref = harness.run_case("oracle", "gail_box", str(tmp_path / "o"))
+    got = harness.run_case("hip", "gail_box", str(tmp_path / "h"), device="cuda")
+    _compare(got, ref, cfg)
+
+
+def test_discrete_actions_structural(tmp_path):
+    """Categorical sampling uses inverse-CDF on a host U(0,1) draw (same distribution, different
+    stream than torch.multinomial), so trajectories are not comparable value-by-value; integer
+    bookkeeping, done layout and one-hot batch assembly still are."""
+    gold = dict(np.load(os.path.join(GOLDEN, "gail_discrete.npz")))
+    got = harness.run_case("hip", "gail_discrete", str(tmp_path), device="cuda")
+    for key in harness.EXACT_KEYS:
+        assert np.array_equal(got[key], gold[key]), key
+    assert got["replay/acts"].dtype == gold["replay/acts"].dtype
+    assert set(np.unique(got["replay/acts"])) <= {0, 1}
+    assert np.all(np.isfinite(got["disc_stats"]))
+    assert got["disc_stats"].shape == gold["disc_stats"].shape
+
+
+def test_disc_loss_decreases_and_error_contract(tmp_path):
+    """tests/algorithms/test_adversarial.py:155-170,256-282 against the HIP trainer."""
+    cfg = harness.CASES["gail_box"]
+    with pytest.raises(ValueError, match="multiple of minibatch"):
+        harness.build_trainer("hip", dict(cfg, demo_minibatch=5), str(tmp_path / "a"), "cuda")
+    tr, _ = harness.build_trainer("hip", cfg, str(tmp_path / "b"), "cuda")
+    with pytest.raises(RuntimeError, match="No generator samples"):
+        tr.train_disc()
+    with pytest.raises(AssertionError):
+        tr.train(1)
+    tr.train_gen()
+    bad = dict(obs=np.zeros((3, 17), np.float32), acts=np.zeros((3, 6), np.float32),
+               next_obs=np.zeros((3, 17), np.float32), dones=np.zeros(3, bool))
+    with pytest.raises(ValueError, match="exactly `demo_batch_size`"):
+        tr.train_disc(gen_samples=bad)
+    rng = np.random.default_rng(0)
+    mk = lambda: dict(obs=rng.standard_normal((64, 17)).astype(np.float32),
+                      acts=rng.uniform(-1, 1, (64, 6)).astype(np.float32),
+                      next_obs=rng.standard_normal((64, 17)).astype(np.float32), dones=np.zeros(64, bool))
+    e, g = mk(), mk()
+    losses = [tr.train_disc(expert_samples=e, gen_samples=g)["disc_loss"] for _ in range(4)]
+    assert losses[-1] < losses[0]
+
+
+def test_grad_accumulation_equivalence_hip(tmp_path):
+    """tests/algorithms/test_adversarial.py:285-343: minibatch 3 vs batch 6, 8 steps, on device."""
+    cfg = dict(harness.CASES["gail_box"], demo_batch=6, demo_minibatch=None, capacity=None, norm_disc=False)
+    a, _ = harness.build_trainer("hip", cfg, str(tmp_path / "a"), "cuda")
+    b, _ = harness.build_trainer("hip", dict(cfg, demo_minibatch=3), str(tmp_path / "b"), "cuda")
+    b._reward_net.load_state_dict(a._reward_net.state_dict())
+    rng = np.random.default_rng(0)
+    for step in range(8):
+        mk = lambda: dict(obs=rng.standard_normal((6, 17)).astype(np.float32),
+                          acts=rng.uniform(-1, 1, (6, 6)).astype(np.float32),
+                          next_obs=rng.standard_normal((6, 17)).astype(np.float32), dones=np.zeros(6, bool))
+        e, g = mk(), mk()
+        a.train_disc(expert_samples=e, gen_samples=g)
+        b.train_disc(expert_samples=e, gen_samples=g)
+        for pa, pb in zip(a._reward_net.parameters(), b._reward_net.parameters()):
+            assert th.allclose(pa, pb, atol=(1 + step) * 2e-4, rtol=(1 + step) * 1e-5)
+
+
+def test_missing_extension_fails_loudly(monkeypatch):
+    from imitation_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libimitation_hip.so")
+    with pytest.raises(_lib.HipExtensionMissing):
+        _lib.load()
