@@ -1,0 +1,232 @@
+#!/usr/bin/env python
+"""Headline benchmark: env-steps/sec of full GAIL rounds (generator rollout + PPO update +
+discriminator updates) on synthetic HalfCheetah-shaped data, BASELINE.json config[1].
+
+    python bench.py --gpus N --steps K --warmup W
+
+A "step" is ONE adversarial round (`AdversarialTrainer.train` body, reference
+`algorithms/adversarial/common.py:453-461`) at config P of SURVEY 8d: n_envs=1024 per GPU,
+n_steps=16 (16 384 transitions/round/GPU), obs 17 / act 6, disc BasicRewardNet 256x256 +
+RunningNorm, demo_batch_size 8192 (16 384-row disc updates), 16 disc updates/round, PPO
+FeedForward32Policy + NormalizeFeaturesExtractor, minibatch 1024, 10 epochs. Host env workers
+(NumPy) stay on the CPU. For N>1 it runs one rank per GPU (env-batch sharded: 1024 envs per
+rank, weak scaling) with RCCL gradient / moment all-reduces every optimiser step.
+
+Prints ONE JSON line (rank 0). Extra objects: `roofline` for the dominant kernel (the 128x128
+fp32-MFMA GEMM of the discriminator's 256x256 layer), measured with HIP events bracketing every
+launch on its stream during extra rounds right after the timed region; `cpu_baseline` = the
+oracle (CPU restatement of the reference round, torch CPU ops) timed on this box's host cores
+for one round of the same workload.
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import tempfile
+import time
+
+import numpy as np
+import torch as th
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+CFG_P = dict(n_envs=1024, n_steps=16, obs_dim=17, act_dim=6, horizon=1000, disc_hid=(256, 256),
+             demo_batch=8192, n_disc=16, ppo_batch=1024, n_epochs=10, ent_coef=0.1, lr=3e-4,
+             n_demo_traj=64)
+PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+DISC_FLOP_PER_UPDATE = 16384 * 418304  # 6.85 GFLOP per 16 384-row update
+
+
+def make_demos(cfg, seed=1):
+    """64 x 1000-step synthetic demonstrations from a fixed random tanh-linear expert."""
+    from imitation_amd.vec_env import SyntheticVecEnv
+    env = SyntheticVecEnv(num_envs=cfg["n_demo_traj"], obs_dim=cfg["obs_dim"], act_dim=cfg["act_dim"],
+                          horizon=cfg["horizon"], seed=seed)
+    rng = np.random.default_rng(seed)
+    We = rng.standard_normal((cfg["obs_dim"], cfg["act_dim"])).astype(np.float32)
+    obs = env.reset()
+    O, A, N, D = [], [], [], []
+    for _ in range(cfg["horizon"]):
+        act = np.tanh(obs @ We).astype(np.float32)
+        env.step_async(act)
+        nobs, _, dones, nxt, _ = env.step_wait_arrays()
+        O.append(obs); A.append(act); N.append(nxt); D.append(dones)
+        obs = nobs
+    # trajectory-major order like flatten_trajectories
+    st = lambda xs: np.stack(xs).swapaxes(0, 1).reshape(-1, *xs[0].shape[1:])
+    return dict(obs=st(O), acts=st(A), next_obs=st(N), dones=st(D))
+
+
+def build_trainer(ns, cfg, device, seed=0, dp=None):
+    from imitation_amd.vec_env import SyntheticVecEnv
+    th.manual_seed(seed)
+    np.random.seed(seed)
+    venv = SyntheticVecEnv(num_envs=cfg["n_envs"], obs_dim=cfg["obs_dim"], act_dim=cfg["act_dim"],
+                           horizon=cfg["horizon"], seed=seed)
+    pk = dict(features_extractor_class=ns.NormalizeFeaturesExtractor,
+              features_extractor_kwargs=dict(normalize_class=ns.RunningNorm))
+    algo = ns.PPO(ns.FeedForward32Policy, venv, n_steps=cfg["n_steps"], batch_size=cfg["ppo_batch"],
+                  n_epochs=cfg["n_epochs"], ent_coef=cfg["ent_coef"], learning_rate=cfg["lr"], seed=seed,
+                  policy_kwargs=pk, device=device)
+    net = ns.BasicRewardNet(venv.observation_space, venv.action_space, hid_sizes=cfg["disc_hid"],
+                            normalize_input_layer=ns.RunningNorm)
+    demos = ns.Transitions(**make_demos(cfg))
+    kw = {} if dp is None else dict(data_parallel=dp)
+    return ns.GAIL(demonstrations=demos, demo_batch_size=cfg["demo_batch"], venv=venv, gen_algo=algo,
+                   reward_net=net, n_disc_updates_per_round=cfg["n_disc"],
+                   gen_replay_buffer_capacity=cfg["n_envs"] * cfg["n_steps"],
+                   custom_logger=ns.configure_logger(tempfile.mkdtemp(prefix="bench-")), **kw)
+
+
+def hip_namespace():
+    import types
+    import imitation_amd as p
+    return types.SimpleNamespace(GAIL=p.GAIL, PPO=p.PPO, FeedForward32Policy=p.FeedForward32Policy,
+                                 NormalizeFeaturesExtractor=p.NormalizeFeaturesExtractor, RunningNorm=p.RunningNorm,
+                                 BasicRewardNet=p.BasicRewardNet, Transitions=lambda **kw: p.Transitions(**kw),
+                                 configure_logger=lambda d: p.configure_logger(d, []))
+
+
+def oracle_namespace():
+    import types
+    from oracle import imitation_restated as o
+    from oracle import sb3_restated as sb
+    return types.SimpleNamespace(GAIL=o.GAIL, PPO=sb.PPO, FeedForward32Policy=o.FeedForward32Policy,
+                                 NormalizeFeaturesExtractor=o.NormalizeFeaturesExtractor, RunningNorm=o.RunningNorm,
+                                 BasicRewardNet=o.BasicRewardNet, Transitions=lambda **kw: o.Transitions(**kw),
+                                 configure_logger=lambda d: o.configure_logger(d, []))
+
+
+def cpu_baseline(cfg):
+    """Oracle (kind="port") on the host cores: ONE full round of the same workload, timed after
+    construction (the first rollout pays one env reset; no separate warm-up to bound the cost)."""
+    threads = th.get_num_threads()
+    tr = build_trainer(oracle_namespace(), cfg, "cpu")
+    per_round = cfg["n_envs"] * cfg["n_steps"]
+    t0 = time.perf_counter()
+    tr.train(per_round)
+    dt = time.perf_counter() - t0
+    return {"value": per_round / dt, "unit": "env-steps/s", "cores": threads, "kind": "port",
+            "sample": f"1 round = {per_round} env-steps incl. 16 disc updates + 160 PPO minibatch steps, "
+                      f"{dt:.1f} s, torch threads={threads}, os.cpu_count()={os.cpu_count()}"}
+
+
+def gemm_roofline(trainer, cfg, rounds):
+    """Runs `rounds` more rounds with every GEMM launch bracketed by HIP events on its stream and
+    reports the kernel with the largest total time."""
+    from imitation_amd import _lib as L
+    lib = L.load()
+    lib.ia_prof_enable(1)
+    trainer.train(rounds * cfg["n_envs"] * cfg["n_steps"])
+    th.cuda.synchronize()
+    ms, fl = (C.c_double * 12)(), (C.c_double * 12)()
+    cnt = (C.c_longlong * 12)()
+    lib.ia_prof_collect(ms, fl, cnt)
+    lib.ia_prof_enable(0)
+    names = {0: "NT(fwd)", 1: "NN(dgrad)", 2: "TN(wgrad)"}
+    tiles = {0: "128x128", 1: "64x64", 2: "128x32", 3: "32x128"}
+    per = []
+    for k in range(12):
+        if cnt[k]:
+            per.append(dict(kernel=f"ia_gemm_kernel {names[k // 4]} tile {tiles[k % 4]}", launches=int(cnt[k]),
+                            avg_us=1e3 * ms[k] / cnt[k], tflops=fl[k] / (ms[k] * 1e-3) / 1e12, total_ms=ms[k]))
+    per.sort(key=lambda d: -d["total_ms"])
+    top = per[0]
+    traffic = None
+    pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(pmc):
+        try:
+            traffic = json.load(open(pmc)).get(top["kernel"])
+        except Exception:
+            traffic = None
+    all_ms, all_fl = sum(p["total_ms"] for p in per), sum(p["tflops"] * p["total_ms"] for p in per)
+    return {"bound": "mfma", "kernel": top["kernel"], "achieved": top["tflops"], "peak": PEAK_F32_MFMA_TFLOPS,
+            "unit": "TFLOP/s", "frac": top["tflops"] / PEAK_F32_MFMA_TFLOPS, "avg_launch_us": top["avg_us"],
+            "launches": top["launches"], "traffic": traffic,
+            "all_gemm_tflops": all_fl / all_ms if all_ms else None, "kernels": per[:6]}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--prof-rounds", type=int, default=2)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run)"
+    th.cuda.set_device(local_rank)
+    dp = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=th.device("cuda", local_rank))
+        from imitation_amd.distributed import DataParallel
+        dp = DataParallel()
+
+    cfg = dict(CFG_P)
+    per_round = cfg["n_envs"] * cfg["n_steps"]
+    # The HIP path's host side is sequential index bookkeeping; torch's intra-op thread pool only
+    # hurts it (torch.randperm(64000) -- the expert permutation, same values for any thread count
+    # -- takes 8 ms with 128 threads vs 0.7 ms with 1). The CPU baseline below gets all cores back.
+    host_threads = th.get_num_threads()
+    th.set_num_threads(1)
+    trainer = build_trainer(hip_namespace(), cfg, "cuda", seed=rank, dp=dp)
+    if args.warmup > 0:
+        trainer.train(args.warmup * per_round)
+
+    def barrier():
+        th.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            th.cuda.synchronize()
+
+    barrier()
+    t0 = time.perf_counter()
+    trainer.train(args.steps * per_round)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = th.tensor([dt], device="cuda", dtype=th.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    roof = gemm_roofline(trainer, cfg, args.prof_rounds) if rank == 0 else None
+    base = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        th.set_num_threads(host_threads)
+        base = cpu_baseline(cfg)
+    if world > 1:
+        dist.barrier()
+
+    if rank == 0:
+        value = world * args.steps * per_round / dt
+        out = {
+            "metric": "env-steps/sec (gen+disc round) GAIL HalfCheetah n_envs=1024",
+            "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "GAIL round, config P (BASELINE.json configs[1]): seals/HalfCheetah-shaped "
+                                   "obs17/act6 synthetic VecEnv, n_envs=1024/GPU x n_steps=16, disc BasicRewardNet "
+                                   "256x256+RunningNorm, demo_batch 8192, 16 disc updates/round, PPO 32x32 "
+                                   "minibatch 1024 x 10 epochs", "env_steps_per_round_per_gpu": per_round,
+                       "parallelism": f"dp{world}" if world > 1 else "single"},
+            "roofline": roof, "cpu_baseline": base,
+        }
+        if base:
+            out["speedup_vs_cpu_baseline"] = value / base["value"]
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

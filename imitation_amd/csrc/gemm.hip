@@ -193,6 +193,18 @@ __global__ __launch_bounds__(WM* WN * 64) void ia_gemm_kernel(IaGemm g) {
   if (do_db && tid < BM && bm0 + tid < g.M) g.dbias[(long long)blockIdx.z * g.dbias_split_stride + bm0 + tid] = dbacc;
 }
 
+// ---- optional per-launch timing with HIP events on the launch stream (bench.py roofline) ----
+struct ProfSlot { double ms; double flops; long long launches; };
+constexpr int PROF_KERNELS = 12;          // 3 modes x 4 tile configs
+constexpr int PROF_POOL = 8192;           // event pairs per collection window
+bool g_prof_on = false;
+hipEvent_t g_prof_ev[PROF_POOL][2];
+int g_prof_kid[PROF_POOL];
+double g_prof_fl[PROF_POOL];
+int g_prof_n = 0;
+bool g_prof_init = false;
+ProfSlot g_prof_acc[PROF_KERNELS];
+
 template <int WM, int WN, int TM, int TN, int MODE>
 int launch_cfg(const IaGemm& g, hipStream_t stream) {
   constexpr int NT = WM * WN * 64;
@@ -210,8 +222,17 @@ int launch_cfg(const IaGemm& g, hipStream_t stream) {
   }
   const int tiles = ((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN);
   dim3 grid(tiles, 1, MODE == IA_GEMM_TN ? g.splits : 1);
+  const bool prof = g_prof_on && g_prof_n < PROF_POOL;
+  if (prof) (void)hipEventRecord(g_prof_ev[g_prof_n][0], stream);
   hipLaunchKernelGGL(kern, grid, dim3(NT), smem, stream, g);
   IA_CHECK_LAUNCH();
+  if (prof) {
+    (void)hipEventRecord(g_prof_ev[g_prof_n][1], stream);
+    constexpr int cfg = (BM == 128 && BN == 128) ? 0 : (BM == 64 ? 1 : (BM == 128 ? 2 : 3));
+    g_prof_kid[g_prof_n] = MODE * 4 + cfg;
+    g_prof_fl[g_prof_n] = 2.0 * (double)g.M * (double)g.N * (double)g.K;
+    ++g_prof_n;
+  }
   return IA_OK;
 }
 
@@ -233,6 +254,38 @@ int ia_launch_gemm(int mode, const IaGemm& g, hipStream_t stream) {
     case IA_GEMM_TN: return launch_mode<IA_GEMM_TN>(g, stream);
   }
   return IA_ERR_ARG;
+}
+
+// Profiling window: ia_prof_enable(1) .. launches .. ia_prof_collect(ms, flops, launches) [12 each].
+// Kernel id = mode*4 + tile config {0:128x128, 1:64x64, 2:128x32, 3:32x128}.
+extern "C" int ia_prof_enable(int on) {
+  if (on && !g_prof_init) {
+    for (int i = 0; i < PROF_POOL; ++i)
+      for (int j = 0; j < 2; ++j)
+        if (hipEventCreate(&g_prof_ev[i][j]) != hipSuccess) return IA_ERR_ARG;
+    g_prof_init = true;
+  }
+  if (on) {
+    g_prof_n = 0;
+    for (int k = 0; k < PROF_KERNELS; ++k) g_prof_acc[k] = ProfSlot{0.0, 0.0, 0};
+  }
+  g_prof_on = on != 0;
+  return IA_OK;
+}
+
+extern "C" int ia_prof_collect(double* ms, double* flops, long long* launches) {
+  for (int i = 0; i < g_prof_n; ++i) {
+    if (hipEventSynchronize(g_prof_ev[i][1]) != hipSuccess) return IA_ERR_ARG;
+    float t = 0.f;
+    if (hipEventElapsedTime(&t, g_prof_ev[i][0], g_prof_ev[i][1]) != hipSuccess) return IA_ERR_ARG;
+    ProfSlot& a = g_prof_acc[g_prof_kid[i]];
+    a.ms += t; a.flops += g_prof_fl[i]; a.launches += 1;
+  }
+  g_prof_n = 0;
+  for (int k = 0; k < PROF_KERNELS; ++k) {
+    ms[k] = g_prof_acc[k].ms; flops[k] = g_prof_acc[k].flops; launches[k] = g_prof_acc[k].launches;
+  }
+  return IA_OK;
 }
 
 // C-ABI test/bench entry for the raw contraction (device pointers, row-major fp32).

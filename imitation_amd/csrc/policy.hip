@@ -68,6 +68,17 @@ struct Lds {
   static constexpr int total = aux + ROWS * AS + 64;  // +64: MFMA fragment reads may overrun a 17-wide tile
 };
 
+// Branch-free tanh: odd polynomial for |x| <= 0.1 (rel. error < 1e-9), 1 - 2/(exp(2|x|)+1) otherwise
+// (v_exp_f32 / v_rcp_f32: ~1 ulp each). libm's tanhf costs ~45 instructions and divergent branches.
+__device__ __forceinline__ float fast_tanh(float x) {
+  const float ax = fabsf(x);
+  const float x2 = x * x;
+  const float poly = x * (1.f + x2 * (-0.33333334f + x2 * (0.13333334f + x2 * -0.05396825f)));
+  const float e = __expf(2.f * ax);
+  const float big = copysignf(1.f - 2.f * __builtin_amdgcn_rcpf(e + 1.f), x);
+  return ax <= 0.1f ? poly : big;
+}
+
 // One tanh tower: a1 = tanh(W1 x + b1) -> LDS line, a2 = tanh(W2 a1 + b2) -> registers (+LDS).
 template <int H>
 __device__ __forceinline__ void tower_forward(const float* __restrict__ W1t, const float* __restrict__ b1,
@@ -82,7 +93,7 @@ __device__ __forceinline__ void tower_forward(const float* __restrict__ W1t, con
     for (int j = 0; j < H; ++j) acc[j] = fmaf(W1t[k * H + j], xk, acc[j]);
   }
 #pragma unroll
-  for (int j = 0; j < H; ++j) a1row[j] = tanhf(acc[j]);
+  for (int j = 0; j < H; ++j) a1row[j] = fast_tanh(acc[j]);
 #pragma unroll
   for (int j = 0; j < H; ++j) acc[j] = b2[j];
   for (int k = 0; k < H; ++k) {
@@ -92,7 +103,7 @@ __device__ __forceinline__ void tower_forward(const float* __restrict__ W1t, con
   }
 #pragma unroll
   for (int j = 0; j < H; ++j) {
-    a2[j] = tanhf(acc[j]);
+    a2[j] = fast_tanh(acc[j]);
     if (a2row) a2row[j] = a2[j];
   }
 }
@@ -297,6 +308,16 @@ __global__ void bootstrap_kernel(float* __restrict__ rewards, const float* __res
 }
 
 // --------------------------------------------------------------------------- PPO minibatch
+//
+// Two launches per minibatch:
+//   ppo_grad_kernel   : 64 rows per block, 8 waves: waves 0-3 run the policy tower, waves 4-7 the
+//                       value tower, each wave owning a quarter of every layer's outputs (so the
+//                       serial chain per wave is 4x shorter and each SIMD holds two waves);
+//                       weight gradients come from MFMA over the LDS activation tiles.
+//   ppo_apply_kernel  : one 1024-thread block: fixed-order slab reduction, clip_grad_norm_, Adam,
+//                       transposed-copy refresh, THEN the statistics of the NEXT minibatch
+//                       (advantage mean/std, feature RunningNorm update), so no separate
+//                       "prepare" launch is needed except for the first minibatch of an epoch.
 
 // ws layout (floats): [0..7] adv stats {mean, std}; [8..8+nblk*8) loss-stat partials;
 // then gradient slabs [nblk][P]; then reduced gradient [P].
@@ -321,76 +342,121 @@ __device__ __forceinline__ long long rollout_offset(long long flat, int T, int n
   return t * n_envs + env;
 }
 
-__global__ __launch_bounds__(256) void ppo_prepare_kernel(ia_policy_desc d, const float* __restrict__ obs,
-                                                          const float* __restrict__ adv,
-                                                          const int64_t* __restrict__ idx, int batch, int T,
-                                                          int n_envs, int update_norm, float* __restrict__ nm,
-                                                          float* __restrict__ nv, int32_t* __restrict__ ncount,
-                                                          float* __restrict__ advstat) {
-  __shared__ float red[256];
-  __shared__ float bc;
+constexpr int PREP_THREADS = 1024;
+constexpr int PREP_STAGE_FLOATS = 24576;            // 96 KB of staged observation rows
+constexpr int PREP_LDS_FLOATS = PREP_STAGE_FLOATS + 16 * 65 + 65 + 64;
+
+__device__ __forceinline__ float block_sum_1024(float v, float* red /*>=17 floats*/) {
+  for (int s = 32; s > 0; s >>= 1) v += __shfl_down(v, s, 64);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float t = 0.f;
+    for (int k = 0; k < 16; ++k) t += red[k];
+    red[16] = t;
+  }
+  __syncthreads();
+  return red[16];
+}
+
+// Minibatch statistics (SB3 PPO.train: advantage mean / unbiased std; train-mode RunningNorm
+// update of the feature extractor with the minibatch observations, util/networks.py:111-134).
+// Element-parallel gathers staged through LDS; all reductions in fixed order.
+__device__ void prepare_stats(const ia_policy_desc& d, const float* __restrict__ obs, const float* __restrict__ adv,
+                              const int64_t* __restrict__ idx, int batch, int T, int n_envs, int update_norm,
+                              float* __restrict__ nm, float* __restrict__ nv, int32_t* __restrict__ ncount,
+                              float* __restrict__ advstat, float* lds) {
   const int tid = threadIdx.x;
-  // minibatch advantage mean / unbiased std (two pass) -- PPO.train: (A-mean)/(std+1e-8)
+  float* stage = lds;
+  float* red = lds + PREP_STAGE_FLOATS;          // [16][65]
+  float* cmean = red + 16 * 65;                  // [65]
+  float* misc = cmean + 65;                      // [64]
   float s = 0.f;
-  for (int i = tid; i < batch; i += 256) s += adv[rollout_offset(idx[i], T, n_envs)];
-  red[tid] = s;
-  __syncthreads();
-  for (int o = 128; o > 0; o >>= 1) { if (tid < o) red[tid] += red[tid + o]; __syncthreads(); }
-  if (tid == 0) bc = red[0] / (float)batch;
-  __syncthreads();
-  const float mean = bc;
+  for (int i = tid; i < batch; i += PREP_THREADS) s += adv[rollout_offset(idx[i], T, n_envs)];
+  const float mean = block_sum_1024(s, misc) / (float)batch;
   float q = 0.f;
-  for (int i = tid; i < batch; i += 256) {
+  for (int i = tid; i < batch; i += PREP_THREADS) {
     const float dl = adv[rollout_offset(idx[i], T, n_envs)] - mean;
     q += dl * dl;
   }
-  __syncthreads();
-  red[tid] = q;
-  __syncthreads();
-  for (int o = 128; o > 0; o >>= 1) { if (tid < o) red[tid] += red[tid + o]; __syncthreads(); }
+  const float qq = block_sum_1024(q, misc);
   if (tid == 0) {
     advstat[0] = mean;
-    advstat[1] = batch > 1 ? sqrtf(red[0] / (float)(batch - 1)) : 0.f;
+    advstat[1] = batch > 1 ? sqrtf(qq / (float)(batch - 1)) : 0.f;
   }
   if (!(d.has_norm && update_norm)) return;
-  // RunningNorm.update_stats on the minibatch observations (train mode, util/networks.py:111-134)
-  const int D = d.obs_dim;
-  const int cl = tid & 63, rl = tid >> 6;  // 4 row lanes x 64 columns
-  __shared__ float r2[4][65];
-  float cs = 0.f;
-  if (cl < D)
-    for (int i = rl; i < batch; i += 4) cs += obs[rollout_offset(idx[i], T, n_envs) * D + cl];
-  r2[rl][cl] = cs;
-  __syncthreads();
-  float bmean = 0.f;
-  if (cl < D) bmean = (r2[0][cl] + r2[1][cl] + r2[2][cl] + r2[3][cl]) / (float)batch;
-  __syncthreads();
-  float cq = 0.f;
-  if (cl < D)
-    for (int i = rl; i < batch; i += 4) {
-      const float dl = obs[rollout_offset(idx[i], T, n_envs) * D + cl] - bmean;
-      cq += dl * dl;
+  const int D = d.obs_dim, DP = D | 1;
+  const int chunk_rows = min(batch, PREP_STAGE_FLOATS / DP);
+  const int col = tid & 63, rg = tid >> 6;
+  float n_acc = 0.f, m_acc = 0.f, M2 = 0.f;  // Chan accumulators, live in threads tid < D
+  for (int c0 = 0; c0 < batch; c0 += chunk_rows) {
+    const int rows = min(chunk_rows, batch - c0);
+    __syncthreads();
+    for (int e = tid; e < rows * D; e += PREP_THREADS) {
+      const int r = e / D, k = e - r * D;
+      stage[r * DP + k] = obs[rollout_offset(idx[c0 + r], T, n_envs) * D + k];
     }
-  r2[rl][cl] = cq;
-  __syncthreads();
+    __syncthreads();
+    float cs = 0.f;
+    if (col < D)
+      for (int r = rg; r < rows; r += 16) cs += stage[r * DP + col];
+    red[rg * 65 + col] = cs;
+    __syncthreads();
+    if (rg == 0 && col < D) {
+      float t = 0.f;
+      for (int g = 0; g < 16; ++g) t += red[g * 65 + col];
+      cmean[col] = t / (float)rows;
+    }
+    __syncthreads();
+    float cq = 0.f;
+    if (col < D) {
+      const float cm = cmean[col];
+      for (int r = rg; r < rows; r += 16) {
+        const float dl = stage[r * DP + col] - cm;
+        cq += dl * dl;
+      }
+    }
+    red[rg * 65 + col] = cq;
+    __syncthreads();
+    if (rg == 0 && col < D) {
+      float t = 0.f;
+      for (int g = 0; g < 16; ++g) t += red[g * 65 + col];
+      const float nb = (float)rows, mb = cmean[col];
+      const float tot = n_acc + nb, dlt = mb - m_acc;
+      M2 = M2 + t + dlt * dlt * n_acc * nb / tot;
+      m_acc = m_acc + dlt * nb / tot;
+      n_acc = tot;
+    }
+  }
   const int cnt = *ncount;
-  if (rl == 0 && cl < D) {
-    const float bvar = (r2[0][cl] + r2[1][cl] + r2[2][cl] + r2[3][cl]) / (float)batch;
+  __syncthreads();
+  if (rg == 0 && col < D) {
+    const float bmean = m_acc, bvar = M2 / (float)batch;
     const float fcount = (float)cnt, fn = (float)batch, tot = (float)(cnt + batch);
-    const float delta = bmean - nm[cl];
-    nm[cl] = nm[cl] + delta * fn / tot;
-    float rv = nv[cl] * fcount;
+    const float delta = bmean - nm[col];
+    nm[col] = nm[col] + delta * fn / tot;
+    float rv = nv[col] * fcount;
     rv = rv + bvar * fn;
     rv = rv + delta * delta * fcount * fn / tot;
-    nv[cl] = rv / tot;
+    nv[col] = rv / tot;
   }
-  __syncthreads();
   if (tid == 0) *ncount = cnt + batch;
 }
 
-// G[J][K] (+= over the wave's 64 rows) = sum_r U[r][j] * V[r][k], U/V are LDS tiles with odd
-// strides; written (not accumulated) to `dst` with leading dimension ldk. J,K multiples of 32
-// are handled tile by tile; `jmax`/`kmax` clip the store.
+__global__ __launch_bounds__(PREP_THREADS) void ppo_prepare_kernel(ia_policy_desc d, const float* __restrict__ obs,
+                                                                   const float* __restrict__ adv,
+                                                                   const int64_t* __restrict__ idx, int batch, int T,
+                                                                   int n_envs, int update_norm, float* __restrict__ nm,
+                                                                   float* __restrict__ nv, int32_t* __restrict__ ncount,
+                                                                   float* __restrict__ advstat) {
+  extern __shared__ float lds[];
+  prepare_stats(d, obs, adv, idx, batch, T, n_envs, update_norm, nm, nv, ncount, advstat, lds);
+}
+
+// G[J][K] = sum over the block's 64 rows of U[r][j] * V[r][k]; U/V are LDS tiles with odd strides
+// (fragment reads are bank-conflict free); result written (not accumulated) to `dst` with leading
+// dimension ldk, clipped to j<jmax, k<kmax. One wave, 32 MFMAs.
 __device__ __forceinline__ void mfma_outer_store(const float* U, int us, const float* V, int vs, int j0, int k0,
                                                  int jmax, int kmax, float* __restrict__ dst, int ldk, int lane) {
   const int li = lane & 31, lh = lane >> 5;
@@ -411,246 +477,302 @@ __device__ __forceinline__ void mfma_outer_store(const float* U, int us, const f
   }
 }
 
-template <int H>
-__device__ void tower_backward_and_grads(const float* __restrict__ W2, const float* __restrict__ W1, int D,
-                                         float (&dz2)[H] /* in: grad wrt a2 pre-tanh' ; used as scratch */,
-                                         const float (&a2)[H], float* lds, int tid, float* __restrict__ slab,
-                                         int oW1, int ob1, int oW2, int ob2) {
-  using L = Lds<H>;
-  float* a1row = lds + L::a1 + tid * L::HS;
-  float* dzrow = lds + L::dz + tid * L::HS;
-  // dz2 = da2 * (1 - a2^2)
-#pragma unroll
-  for (int j = 0; j < H; ++j) {
-    dz2[j] = dz2[j] * (1.f - a2[j] * a2[j]);
-    dzrow[j] = dz2[j];
-  }
-  __syncthreads();
-  // dW2[j][k] = sum_r dz2[r][j] a1[r][k] ; db2[j] = sum_r dz2[r][j]
-  for (int j0 = 0; j0 < H; j0 += 32)
-    for (int k0 = 0; k0 < H; k0 += 32)
-      mfma_outer_store(lds + L::dz, L::HS, lds + L::a1, L::HS, j0, k0, H, H, slab + oW2, H, tid);
-  if (tid < H) {
+__device__ __forceinline__ void column_sum_store(const float* tile, int stride, int ncols, float* __restrict__ dst,
+                                                 int lane) {
+  if (lane < ncols) {
     float s = 0.f;
-    for (int r = 0; r < ROWS; ++r) s += lds[L::dz + r * L::HS + tid];
-    slab[ob2 + tid] = s;
+#pragma unroll 8
+    for (int r = 0; r < ROWS; ++r) s += tile[r * stride + lane];
+    dst[lane] = s;
   }
-  // da1[k] = sum_j W2[j][k] dz2[j]  (rows of W2 are contiguous: scalar loads)
-  float da1[H];
-#pragma unroll
-  for (int k = 0; k < H; ++k) da1[k] = 0.f;
-  for (int j = 0; j < H; ++j) {
-    const float g = dzrow[j];
-#pragma unroll
-    for (int k = 0; k < H; ++k) da1[k] = fmaf(W2[j * H + k], g, da1[k]);
-  }
-  __syncthreads();
-#pragma unroll
-  for (int k = 0; k < H; ++k) {
-    const float a = a1row[k];
-    dzrow[k] = da1[k] * (1.f - a * a);  // dz1
-  }
-  __syncthreads();
-  // dW1[j][k] = sum_r dz1[r][j] x[r][k]
-  for (int j0 = 0; j0 < H; j0 += 32)
-    for (int k0 = 0; k0 < D; k0 += 32)
-      mfma_outer_store(lds + L::dz, L::HS, lds + L::x, L::XS, j0, k0, H, D, slab + oW1, D, tid);
-  if (tid < H) {
-    float s = 0.f;
-    for (int r = 0; r < ROWS; ++r) s += lds[L::dz + r * L::HS + tid];
-    slab[ob1 + tid] = s;
-  }
-  __syncthreads();
-  (void)W1;
 }
 
 template <int H>
-__global__ __launch_bounds__(ROWS) void ppo_grad_kernel(ia_policy_desc d, const float* __restrict__ P,
-                                                        const float* __restrict__ Pt, const float* __restrict__ nm,
-                                                        const float* __restrict__ nv, const float* __restrict__ obs,
-                                                        const float* __restrict__ actions,
-                                                        const float* __restrict__ old_logp,
-                                                        const float* __restrict__ adv, const float* __restrict__ ret,
-                                                        const int64_t* __restrict__ idx, int batch, int T, int n_envs,
-                                                        int normalize_adv, float clip, float ent_coef, float vf_coef,
-                                                        float* __restrict__ ws, int nblk) {
-  using L = Lds<H>;
+struct GLds {  // LDS carve-up of the 8-wave gradient kernel (floats)
+  static constexpr int XS = MAXD + 1, HS = H + 1, AS = MAXA + 1, MS = 5;
+  static constexpr int x = 0;
+  static constexpr int a1 = x + ROWS * XS;             // [2 towers][ROWS][HS]
+  static constexpr int a2 = a1 + 2 * ROWS * HS;
+  static constexpr int dz = a2 + 2 * ROWS * HS;
+  static constexpr int out = dz + 2 * ROWS * HS;
+  static constexpr int dout = out + ROWS * AS;
+  static constexpr int aux = dout + ROWS * AS;
+  static constexpr int misc = aux + ROWS * AS;         // [ROWS][MS]: 0 = value, 1 = dvalue
+  static constexpr int total = misc + ROWS * MS + 64;
+};
+
+template <int H>
+__global__ __launch_bounds__(512) void ppo_grad_kernel(ia_policy_desc d, const float* __restrict__ P,
+                                                       const float* __restrict__ Pt, const float* __restrict__ nm,
+                                                       const float* __restrict__ nv, const float* __restrict__ obs,
+                                                       const float* __restrict__ actions,
+                                                       const float* __restrict__ old_logp,
+                                                       const float* __restrict__ adv, const float* __restrict__ ret,
+                                                       const int64_t* __restrict__ idx, int batch, int T, int n_envs,
+                                                       int normalize_adv, float clip, float ent_coef, float vf_coef,
+                                                       float* __restrict__ ws, int nblk) {
+  using L = GLds<H>;
+  constexpr int HQ = H / 4;
   extern __shared__ float lds[];
-  const int tid = threadIdx.x, i = blockIdx.x * ROWS + tid;
-  const bool valid = i < batch;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tw = wv >> 2, q = wv & 3;          // tower (0 = policy, 1 = value), output quarter
   const int D = d.obs_dim, A = d.act_dim;
   const PolOff o = pol_offsets(D, A, H, d.discrete);
   const PpoWs w = ppo_ws(ws, nblk, o.total);
   float* slab = w.slabs + (long long)blockIdx.x * o.total;
-  const long long src = valid ? rollout_offset(idx[i], T, n_envs) : 0;
-  const int aw = d.discrete ? 1 : A;  // stored action width
-  float* xrow = lds + L::x + tid * L::XS;
-  float* a1row = lds + L::a1 + tid * L::HS;
-  float* a2row = lds + L::a2 + tid * L::HS;
-  float* outrow = lds + L::out + tid * L::AS;
-  float* doutrow = lds + L::dout + tid * L::AS;
-  // zero the padded feature columns the MFMA tiles may touch beyond D
-  for (int k = D; k < L::XS; ++k) xrow[k] = 0.f;
-  for (int a = 0; a < L::AS; ++a) doutrow[a] = 0.f;
-  load_features(d, obs + src * D, nm, nv, valid, xrow);
+  const int i0 = blockIdx.x * ROWS;
+  const int aw = d.discrete ? 1 : A;
   const float invB = 1.f / (float)batch;
 
-  // ---------------- policy tower ----------------
-  float a2[H];
-  tower_forward<H>(Pt + o.pW1, P + o.pb1, Pt + o.pW2, P + o.pb2, D, xrow, a1row, a2row, a2);
-  head_forward<H>(P + o.aW, P + o.ab, A, a2, outrow);
-  float logp = 0.f, entropy = 0.f;
-  float lse = 0.f;
-  int act_i = 0;
-  if (!d.discrete) {
-    for (int a = 0; a < A; ++a) {
-      const float ls = P[o.log_std + a];
-      logp += gauss_logp_term(actions[src * aw + a], outrow[a], ls);
-      entropy += 0.5f + LOG_SQRT_2PI + logf(expf(ls));
+  // ---- phase 0: cooperative, coalesced feature gather (+ normalisation) into LDS; clear pads
+  for (int e = tid; e < ROWS * L::XS; e += 512) {
+    const int r = e / L::XS, k = e - r * L::XS;
+    float v = 0.f;
+    if (k < D && i0 + r < batch) {
+      v = obs[rollout_offset(idx[i0 + r], T, n_envs) * D + k];
+      if (d.has_norm) v = (v - nm[k]) / sqrtf(nv[k] + d.norm_eps);
     }
-  } else {
-    float mx = outrow[0];
-    for (int a = 1; a < A; ++a) mx = fmaxf(mx, outrow[a]);
-    float se = 0.f;
-    for (int a = 0; a < A; ++a) se += expf(outrow[a] - mx);
-    lse = mx + logf(se);
-    act_i = (int)actions[src];
-    logp = outrow[act_i] - lse;
-    for (int a = 0; a < A; ++a) {
-      const float l = outrow[a] - lse;
-      entropy -= expf(l) * l;
-    }
+    lds[L::x + e] = v;
   }
-  float advn = adv[src];
-  if (normalize_adv && batch > 1) advn = (advn - w.advstat[0]) / (w.advstat[1] + 1e-8f);
-  const float log_ratio = logp - old_logp[src];
-  const float ratio = expf(log_ratio);
-  const float lo = 1.f - clip, hi = 1.f + clip;
-  const float pl1 = advn * ratio;
-  const float pl2 = advn * fminf(fmaxf(ratio, lo), hi);
-  // d(-mean(min(pl1,pl2)))/d ratio with torch's tie rule (equal -> half to each branch)
-  const float g1 = pl1 < pl2 ? 1.f : (pl1 == pl2 ? 0.5f : 0.f);
-  const float g2 = pl2 < pl1 ? 1.f : (pl1 == pl2 ? 0.5f : 0.f);
-  const float inrange = (ratio >= lo && ratio <= hi) ? 1.f : 0.f;
-  float dlogp = valid ? -invB * advn * (g1 + g2 * inrange) * ratio : 0.f;
+  for (int e = tid; e < ROWS * L::AS; e += 512) { lds[L::dout + e] = 0.f; lds[L::aux + e] = 0.f; lds[L::out + e] = 0.f; }
+  for (int e = tid; e < ROWS * L::MS; e += 512) lds[L::misc + e] = 0.f;
+  __syncthreads();
 
-  // d loss / d head outputs
-  float* auxrow = lds + L::aux + tid * L::AS;
-  if (!d.discrete) {
-    for (int a = 0; a < A; ++a) {
-      const float ls = P[o.log_std + a];
-      const float sd = expf(ls), var = sd * sd;
-      const float diff = actions[src * aw + a] - outrow[a];
-      doutrow[a] = dlogp * diff / var;
-      // d logp/d log_std = diff^2/var - 1 ; entropy_loss = -mean(entropy) -> -ent_coef/B per row
-      auxrow[a] = valid ? dlogp * (diff * diff / var - 1.f) - ent_coef * invB : 0.f;
-    }
-  } else {
-    for (int a = 0; a < A; ++a) {
-      const float l = outrow[a] - lse, p = expf(l);
-      const float dH = -p * (l + entropy);  // d entropy / d logit_a
-      float g = dlogp * ((a == act_i ? 1.f : 0.f) - p);
-      g += valid ? -ent_coef * invB * dH : 0.f;
-      doutrow[a] = g;
-    }
-  }
-  __syncthreads();
-  // head grads: dWa[a][k] = sum_r dout[r][a] a2[r][k]; dba[a] = sum_r dout[r][a]
-  for (int k0 = 0; k0 < H; k0 += 32)
-    mfma_outer_store(lds + L::dout, L::AS, lds + L::a2, L::HS, 0, k0, A, H, slab + o.aW, H, tid);
-  if (tid < A) {
-    float s = 0.f;
-    for (int r = 0; r < ROWS; ++r) s += lds[L::dout + r * L::AS + tid];
-    slab[o.ab + tid] = s;
-  }
-  if (!d.discrete) {
-    // log_std gradient: column sums of the per-row terms staged in the `aux` tile
-    if (tid < A) {
-      float s = 0.f;
-      for (int r = 0; r < ROWS; ++r) s += lds[L::aux + r * L::AS + tid];
-      slab[o.log_std + tid] = s;
-    }
-  }
-  // da2[k] = sum_a Wa[a][k] dout[a]
-  float da2[H];
-#pragma unroll
-  for (int k = 0; k < H; ++k) da2[k] = 0.f;
-  for (int a = 0; a < A; ++a) {
-    const float g = doutrow[a];
-#pragma unroll
-    for (int k = 0; k < H; ++k) da2[k] = fmaf(P[o.aW + a * H + k], g, da2[k]);
-  }
-  __syncthreads();
-  tower_backward_and_grads<H>(P + o.pW2, P + o.pW1, D, da2, a2, lds, tid, slab, o.pW1, o.pb1, o.pW2, o.pb2);
+  const int oW1 = tw ? o.vW1 : o.pW1, ob1 = tw ? o.vb1 : o.pb1, oW2 = tw ? o.vW2 : o.pW2, ob2 = tw ? o.vb2 : o.pb2;
+  const float* xrow = lds + L::x + lane * L::XS;
+  float* a1row = lds + L::a1 + (tw * ROWS + lane) * L::HS;
+  float* a2row = lds + L::a2 + (tw * ROWS + lane) * L::HS;
+  float* dzrow = lds + L::dz + (tw * ROWS + lane) * L::HS;
+  const int c0 = q * HQ;  // first output column owned by this wave
 
-  // ---------------- value tower ----------------
-  tower_forward<H>(Pt + o.vW1, P + o.vb1, Pt + o.vW2, P + o.vb2, D, xrow, a1row, a2row, a2);
-  float v = P[o.cb];
+  // ---- phase 1: layer 1 (quarter of the outputs)
+  {
+    float acc[HQ];
 #pragma unroll
-  for (int k = 0; k < H; ++k) v = fmaf(P[o.cW + k], a2[k], v);
-  const float verr = ret[src] - v;
-  const float dv = valid ? vf_coef * 2.f * (v - ret[src]) * invB : 0.f;  // F.mse_loss(returns, values)
-  for (int a = 0; a < L::AS; ++a) doutrow[a] = 0.f;
-  doutrow[0] = dv;
-  __syncthreads();
-  for (int k0 = 0; k0 < H; k0 += 32)
-    mfma_outer_store(lds + L::dout, L::AS, lds + L::a2, L::HS, 0, k0, 1, H, slab + o.cW, H, tid);
-  if (tid == 0) {
-    float s = 0.f;
-    for (int r = 0; r < ROWS; ++r) s += lds[L::dout + r * L::AS];
-    slab[o.cb] = s;
+    for (int j = 0; j < HQ; ++j) acc[j] = P[ob1 + c0 + j];
+    for (int k = 0; k < D; ++k) {
+      const float xk = xrow[k];
+#pragma unroll
+      for (int j = 0; j < HQ; ++j) acc[j] = fmaf(Pt[oW1 + k * H + c0 + j], xk, acc[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < HQ; ++j) a1row[c0 + j] = fast_tanh(acc[j]);
   }
-#pragma unroll
-  for (int k = 0; k < H; ++k) da2[k] = P[o.cW + k] * dv;
   __syncthreads();
-  tower_backward_and_grads<H>(P + o.vW2, P + o.vW1, D, da2, a2, lds, tid, slab, o.vW1, o.vb1, o.vW2, o.vb2);
-
-  // ---------------- loss statistics (SB3 logger values) ----------------
-  float st[6];
-  st[0] = valid ? -fminf(pl1, pl2) : 0.f;                                   // policy_gradient_loss
-  st[1] = valid ? verr * verr : 0.f;                                         // value_loss
-  st[2] = valid ? -entropy : 0.f;                                            // entropy_loss
-  st[3] = valid ? (expf(log_ratio) - 1.f) - log_ratio : 0.f;                 // approx_kl
-  st[4] = valid ? (fabsf(ratio - 1.f) > clip ? 1.f : 0.f) : 0.f;             // clip_fraction
-  st[5] = 0.f;
+  // ---- phase 2: layer 2
+  {
+    float acc[HQ];
 #pragma unroll
-  for (int k = 0; k < 6; ++k) {
-    float x = st[k];
+    for (int j = 0; j < HQ; ++j) acc[j] = P[ob2 + c0 + j];
+#pragma unroll 4
+    for (int k = 0; k < H; ++k) {
+      const float ak = a1row[k];
+#pragma unroll
+      for (int j = 0; j < HQ; ++j) acc[j] = fmaf(Pt[oW2 + k * H + c0 + j], ak, acc[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < HQ; ++j) a2row[c0 + j] = fast_tanh(acc[j]);
+  }
+  __syncthreads();
+  // ---- phase 3: heads
+  if (tw == 0) {
+    for (int a = q; a < A; a += 4) {
+      float s = P[o.ab + a];
+#pragma unroll 8
+      for (int k = 0; k < H; ++k) s = fmaf(P[o.aW + a * H + k], a2row[k], s);
+      lds[L::out + lane * L::AS + a] = s;
+    }
+  } else if (q == 0) {
+    float v = P[o.cb];
+#pragma unroll 8
+    for (int k = 0; k < H; ++k) v = fmaf(P[o.cW + k], a2row[k], v);
+    lds[L::misc + lane * L::MS + 0] = v;
+  }
+  __syncthreads();
+  // ---- phase 4: per-row losses (wave 0: policy terms, wave 4: value term)
+  const int i = i0 + lane;
+  const bool valid = i < batch;
+  if (wv == 0) {
+    const long long src = valid ? rollout_offset(idx[i], T, n_envs) : 0;
+    const float* outrow = lds + L::out + lane * L::AS;
+    float* doutrow = lds + L::dout + lane * L::AS;
+    float* auxrow = lds + L::aux + lane * L::AS;
+    float logp = 0.f, entropy = 0.f, lse = 0.f;
+    int act_i = 0;
+    if (!d.discrete) {
+      for (int a = 0; a < A; ++a) {
+        const float ls = P[o.log_std + a];
+        logp += gauss_logp_term(actions[src * aw + a], outrow[a], ls);
+        entropy += 0.5f + LOG_SQRT_2PI + logf(expf(ls));
+      }
+    } else {
+      float mx = outrow[0];
+      for (int a = 1; a < A; ++a) mx = fmaxf(mx, outrow[a]);
+      float se = 0.f;
+      for (int a = 0; a < A; ++a) se += expf(outrow[a] - mx);
+      lse = mx + logf(se);
+      act_i = (int)actions[src];
+      logp = outrow[act_i] - lse;
+      for (int a = 0; a < A; ++a) {
+        const float l = outrow[a] - lse;
+        entropy -= expf(l) * l;
+      }
+    }
+    float advn = adv[src];
+    if (normalize_adv && batch > 1) advn = (advn - w.advstat[0]) / (w.advstat[1] + 1e-8f);
+    const float log_ratio = logp - old_logp[src];
+    const float ratio = expf(log_ratio);
+    const float lo = 1.f - clip, hi = 1.f + clip;
+    const float pl1 = advn * ratio;
+    const float pl2 = advn * fminf(fmaxf(ratio, lo), hi);
+    // d(-mean(min(pl1,pl2)))/d ratio with torch's tie rule (equal -> half to each branch)
+    const float g1 = pl1 < pl2 ? 1.f : (pl1 == pl2 ? 0.5f : 0.f);
+    const float g2 = pl2 < pl1 ? 1.f : (pl1 == pl2 ? 0.5f : 0.f);
+    const float inrange = (ratio >= lo && ratio <= hi) ? 1.f : 0.f;
+    const float dlogp = valid ? -invB * advn * (g1 + g2 * inrange) * ratio : 0.f;
+    if (!d.discrete) {
+      for (int a = 0; a < A; ++a) {
+        const float ls = P[o.log_std + a];
+        const float sd = expf(ls), var = sd * sd;
+        const float diff = actions[src * aw + a] - outrow[a];
+        doutrow[a] = dlogp * diff / var;
+        // d logp/d log_std = diff^2/var - 1 ; entropy_loss = -mean(entropy) -> -ent_coef/B per row
+        auxrow[a] = valid ? dlogp * (diff * diff / var - 1.f) - ent_coef * invB : 0.f;
+      }
+    } else {
+      for (int a = 0; a < A; ++a) {
+        const float l = outrow[a] - lse, p = expf(l);
+        const float dH = -p * (l + entropy);  // d entropy / d logit_a
+        float g = dlogp * ((a == act_i ? 1.f : 0.f) - p);
+        g += valid ? -ent_coef * invB * dH : 0.f;
+        doutrow[a] = g;
+      }
+    }
+    float st[4];
+    st[0] = valid ? -fminf(pl1, pl2) : 0.f;                         // policy_gradient_loss
+    st[1] = valid ? -entropy : 0.f;                                  // entropy_loss
+    st[2] = valid ? (expf(log_ratio) - 1.f) - log_ratio : 0.f;       // approx_kl
+    st[3] = valid ? (fabsf(ratio - 1.f) > clip ? 1.f : 0.f) : 0.f;   // clip_fraction
+    const int slot[4] = {0, 2, 3, 4};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      float x = st[k];
+      for (int s = 32; s > 0; s >>= 1) x += __shfl_down(x, s, 64);
+      if (lane == 0) w.statpart[blockIdx.x * 8 + slot[k]] = x;
+    }
+  } else if (wv == 4) {
+    const long long src = valid ? rollout_offset(idx[i], T, n_envs) : 0;
+    const float v = lds[L::misc + lane * L::MS + 0];
+    const float verr = ret[src] - v;
+    lds[L::misc + lane * L::MS + 1] = valid ? vf_coef * 2.f * (v - ret[src]) * invB : 0.f;  // F.mse_loss
+    float x = valid ? verr * verr : 0.f;
     for (int s = 32; s > 0; s >>= 1) x += __shfl_down(x, s, 64);
-    if (tid == 0) w.statpart[blockIdx.x * 8 + k] = x;
+    if (lane == 0) w.statpart[blockIdx.x * 8 + 1] = x;
+  }
+  __syncthreads();
+  // ---- phase 5: d(a2) -> dz2 for this wave's quarter; head weight/bias gradients
+  if (tw == 0) {
+    float da2[HQ];
+#pragma unroll
+    for (int k = 0; k < HQ; ++k) da2[k] = 0.f;
+    const float* doutrow = lds + L::dout + lane * L::AS;
+    for (int a = 0; a < A; ++a) {
+      const float g = doutrow[a];
+#pragma unroll
+      for (int k = 0; k < HQ; ++k) da2[k] = fmaf(P[o.aW + a * H + c0 + k], g, da2[k]);
+    }
+#pragma unroll
+    for (int k = 0; k < HQ; ++k) {
+      const float a = a2row[c0 + k];
+      dzrow[c0 + k] = da2[k] * (1.f - a * a);
+    }
+    if (q * 32 < H)  // dWa[a][k] = sum_r dout[r][a] a2[r][k]
+      mfma_outer_store(lds + L::dout, L::AS, lds + L::a2, L::HS, 0, q * 32, A, H, slab + o.aW, H, lane);
+    if (q == 2) column_sum_store(lds + L::dout, L::AS, A, slab + o.ab, lane);
+    if (q == 3 && !d.discrete) column_sum_store(lds + L::aux, L::AS, A, slab + o.log_std, lane);
+  } else {
+    const float dv = lds[L::misc + lane * L::MS + 1];
+#pragma unroll
+    for (int k = 0; k < HQ; ++k) {
+      const float a = a2row[c0 + k];
+      dzrow[c0 + k] = P[o.cW + c0 + k] * dv * (1.f - a * a);
+    }
+    if (q * 32 < H)  // dcW[k] = sum_r dv[r] a2[r][k]   (U = misc column 1, only row j=0 stored)
+      mfma_outer_store(lds + L::misc + 1, L::MS, lds + L::a2 + ROWS * L::HS, L::HS, 0, q * 32, 1, H, slab + o.cW, H,
+                       lane);
+    if (q == 2 && lane == 0) {
+      float s = 0.f;
+      for (int r = 0; r < ROWS; ++r) s += lds[L::misc + r * L::MS + 1];
+      slab[o.cb] = s;
+    }
+  }
+  __syncthreads();
+  // ---- phase 6: dW2 / db2 from (dz2, a1); d(a1) -> dz1 (stored in the now-free a2 tile)
+  {
+    const float* dzt = lds + L::dz + tw * ROWS * L::HS;
+    const float* a1t = lds + L::a1 + tw * ROWS * L::HS;
+    constexpr int NT2 = (H / 32) * (H / 32);
+    if (q < NT2) {
+      const int j0 = (q / (H / 32)) * 32, k0 = (q % (H / 32)) * 32;
+      mfma_outer_store(dzt, L::HS, a1t, L::HS, j0, k0, H, H, slab + oW2, H, lane);
+    }
+    if (q == 3) column_sum_store(dzt, L::HS, H, slab + ob2, lane);
+    float da1[HQ];
+#pragma unroll
+    for (int k = 0; k < HQ; ++k) da1[k] = 0.f;
+#pragma unroll 4
+    for (int j = 0; j < H; ++j) {
+      const float g = dzrow[j];
+#pragma unroll
+      for (int k = 0; k < HQ; ++k) da1[k] = fmaf(P[oW2 + j * H + c0 + k], g, da1[k]);
+    }
+#pragma unroll
+    for (int k = 0; k < HQ; ++k) {
+      const float a = a1row[c0 + k];
+      a2row[c0 + k] = da1[k] * (1.f - a * a);  // dz1
+    }
+  }
+  __syncthreads();
+  // ---- phase 7: dW1 / db1 from (dz1, x)
+  {
+    const float* dz1 = lds + L::a2 + tw * ROWS * L::HS;
+    const int kt = (D + 31) / 32;
+    const int ntile = (H / 32) * kt;
+    for (int ti = q; ti < ntile; ti += 4)
+      mfma_outer_store(dz1, L::HS, lds + L::x, L::XS, (ti / kt) * 32, (ti % kt) * 32, H, D, slab + oW1, D, lane);
+    if (q == 3) column_sum_store(dz1, L::HS, H, slab + ob1, lane);
   }
 }
 
-__global__ __launch_bounds__(1024) void ppo_apply_kernel(ia_policy_desc d, float* __restrict__ P,
-                                                         float* __restrict__ Pt, float* __restrict__ m,
-                                                         float* __restrict__ v, float* __restrict__ ws, int nblk,
-                                                         int batch, float max_norm, float ent_coef, float vf_coef,
-                                                         float beta1, float beta2, float eps, float step_size,
-                                                         float bc2_sqrt, float* __restrict__ stats) {
-  __shared__ float red[16];
+__global__ __launch_bounds__(PREP_THREADS) void ppo_apply_kernel(
+    ia_policy_desc d, float* __restrict__ P, float* __restrict__ Pt, float* __restrict__ m, float* __restrict__ v,
+    float* __restrict__ ws, int nblk, int batch, float max_norm, float ent_coef, float vf_coef, float beta1,
+    float beta2, float eps, float step_size, float bc2_sqrt, float* __restrict__ stats,
+    // statistics of the NEXT minibatch (next_batch == 0: none)
+    const float* __restrict__ obs, const float* __restrict__ adv, const int64_t* __restrict__ next_idx, int next_batch,
+    int T, int n_envs, int update_norm, float* __restrict__ nm, float* __restrict__ nv,
+    int32_t* __restrict__ ncount) {
+  extern __shared__ float lds[];
   __shared__ float coef;
   const int H = d.hidden, D = d.obs_dim;
   const PolOff o = pol_offsets(D, d.act_dim, H, d.discrete);
   const PpoWs w = ppo_ws(ws, nblk, o.total);
   const int tid = threadIdx.x;
   float sq = 0.f;
-  for (int i = tid; i < o.total; i += blockDim.x) {
+  for (int i = tid; i < o.total; i += PREP_THREADS) {
     float g = 0.f;
-    for (int b = 0; b < nblk; ++b) g += w.slabs[(long long)b * o.total + i];
+    for (int b = 0; b < nblk; ++b) g += w.slabs[(long long)b * o.total + i];  // fixed order
     w.grad[i] = g;
     sq += g * g;
   }
-  for (int s = 32; s > 0; s >>= 1) sq += __shfl_down(sq, s, 64);
-  if ((tid & 63) == 0) red[tid >> 6] = sq;
-  __syncthreads();
+  const float total_sq = block_sum_1024(sq, lds);
   if (tid == 0) {
-    float t = 0.f;
-    for (int k = 0; k < (int)(blockDim.x >> 6); ++k) t += red[k];
-    const float total_norm = sqrtf(t);
+    const float total_norm = sqrtf(total_sq);
     // torch.nn.utils.clip_grad_norm_: coef = max_norm/(norm+1e-6), clamped to 1
     coef = fminf(max_norm / (total_norm + 1e-6f), 1.0f);
     if (stats) {
-      float st[6] = {0, 0, 0, 0, 0, 0};
+      float st[5] = {0, 0, 0, 0, 0};
       for (int b = 0; b < nblk; ++b)
         for (int k = 0; k < 5; ++k) st[k] += w.statpart[b * 8 + k];
       const float invB = 1.f / (float)batch;
@@ -663,7 +785,7 @@ __global__ __launch_bounds__(1024) void ppo_apply_kernel(ia_policy_desc d, float
   }
   __syncthreads();
   const float c = coef;
-  for (int i = tid; i < o.total; i += blockDim.x) {
+  for (int i = tid; i < o.total; i += PREP_THREADS) {
     const float g = w.grad[i] * c;
     float mi = m[i];
     mi = mi + (g - mi) * (1.f - beta1);
@@ -682,6 +804,10 @@ __global__ __launch_bounds__(1024) void ppo_apply_kernel(ia_policy_desc d, float
     };
     tr(o.pW1, H, D); tr(o.pW2, H, H); tr(o.vW1, H, D); tr(o.vW2, H, H);
     Pt[dst] = pn;
+  }
+  if (next_batch > 0) {
+    __syncthreads();
+    prepare_stats(d, obs, adv, next_idx, next_batch, T, n_envs, update_norm, nm, nv, ncount, w.advstat, lds);
   }
 }
 
@@ -781,6 +907,71 @@ int64_t ia_ppo_ws_floats(const ia_policy_desc* d, int batch) {
   return 8 + (int64_t)nblk * 8 + (int64_t)nblk * P + P;
 }
 
+}  // extern "C" (helpers below are C++)
+
+namespace {
+
+struct PpoArgs {
+  const ia_policy_desc* d;
+  float *params, *params_t, *norm_mean, *norm_var;
+  int32_t* norm_count;
+  int update_norm;
+  const float *obs, *actions, *old_logp, *advantages, *returns;
+  int T, n_envs, normalize_adv;
+  float clip_range, ent_coef, vf_coef, max_grad_norm;
+  float *exp_avg, *exp_avg_sq;
+  float beta1, beta2, adam_eps;
+  float* ws;
+  hipStream_t st;
+};
+
+int launch_prepare(const PpoArgs& a, const int64_t* idx, int batch) {
+  static bool attr = false;
+  const size_t bytes = PREP_LDS_FLOATS * sizeof(float);
+  if (!attr) { int rc = set_lds(ppo_prepare_kernel, bytes); if (rc) return rc; attr = true; }
+  const PolOff o = pol_offsets(a.d->obs_dim, a.d->act_dim, a.d->hidden, a.d->discrete);
+  const PpoWs w = ppo_ws(a.ws, cdiv(batch, ROWS), o.total);
+  hipLaunchKernelGGL(ppo_prepare_kernel, dim3(1), dim3(PREP_THREADS), bytes, a.st, *a.d, a.obs, a.advantages, idx,
+                     batch, a.T, a.n_envs, a.update_norm, a.norm_mean, a.norm_var, a.norm_count, w.advstat);
+  IA_CHECK_LAUNCH();
+  return IA_OK;
+}
+
+template <int H>
+int launch_grad(const PpoArgs& a, const int64_t* idx, int batch) {
+  static bool attr = false;
+  const size_t bytes = GLds<H>::total * sizeof(float);
+  if (!attr) { int rc = set_lds(ppo_grad_kernel<H>, bytes); if (rc) return rc; attr = true; }
+  const int nblk = cdiv(batch, ROWS);
+  hipLaunchKernelGGL(ppo_grad_kernel<H>, dim3(nblk), dim3(512), bytes, a.st, *a.d, a.params, a.params_t, a.norm_mean,
+                     a.norm_var, a.obs, a.actions, a.old_logp, a.advantages, a.returns, idx, batch, a.T, a.n_envs,
+                     a.normalize_adv, a.clip_range, a.ent_coef, a.vf_coef, a.ws, nblk);
+  IA_CHECK_LAUNCH();
+  return IA_OK;
+}
+
+// grad + apply for one minibatch whose statistics are already in ws; the apply kernel also
+// prepares minibatch `next_idx` (next_batch == 0: nothing follows). NOTE: both minibatches share
+// `ws`, whose slab region is sized by the LARGER batch; advstat sits at ws[0..7] for any size.
+int launch_minibatch(const PpoArgs& a, const int64_t* idx, int batch, float step_size, float bc2_sqrt, float* stats,
+                     const int64_t* next_idx, int next_batch) {
+  int rc = a.d->hidden == 32 ? launch_grad<32>(a, idx, batch) : launch_grad<64>(a, idx, batch);
+  if (rc) return rc;
+  static bool attr = false;
+  const size_t bytes = PREP_LDS_FLOATS * sizeof(float);
+  if (!attr) { rc = set_lds(ppo_apply_kernel, bytes); if (rc) return rc; attr = true; }
+  hipLaunchKernelGGL(ppo_apply_kernel, dim3(1), dim3(PREP_THREADS), bytes, a.st, *a.d, a.params, a.params_t, a.exp_avg,
+                     a.exp_avg_sq, a.ws, cdiv(batch, ROWS), batch, a.max_grad_norm, a.ent_coef, a.vf_coef, a.beta1,
+                     a.beta2, a.adam_eps, step_size, bc2_sqrt, stats, a.obs, a.advantages, next_idx, next_batch, a.T,
+                     a.n_envs, a.update_norm, a.norm_mean, a.norm_var, a.norm_count);
+  IA_CHECK_LAUNCH();
+  return IA_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
 int ia_ppo_minibatch(const ia_policy_desc* d, float* params, float* params_t, float* norm_mean, float* norm_var,
                      int32_t* norm_count, int update_norm, const float* obs, const float* actions,
                      const float* old_logp, const float* advantages, const float* returns, const int64_t* idx,
@@ -789,36 +980,18 @@ int ia_ppo_minibatch(const ia_policy_desc* d, float* params, float* params_t, fl
                      float beta2, float adam_eps, float step_size, float bc2_sqrt, float* ws, float* stats,
                      void* stream) {
   if (!pol_ok(d) || batch <= 0) return IA_ERR_ARG;
-  hipStream_t st = (hipStream_t)stream;
-  const int nblk = cdiv(batch, ROWS);
-  const PolOff o = pol_offsets(d->obs_dim, d->act_dim, d->hidden, d->discrete);
-  const PpoWs w = ppo_ws(ws, nblk, o.total);
-  hipLaunchKernelGGL(ppo_prepare_kernel, dim3(1), dim3(256), 0, st, *d, obs, advantages, idx, batch, T, n_envs,
-                     update_norm, norm_mean, norm_var, norm_count, w.advstat);
-  IA_CHECK_LAUNCH();
-  int rc;
-  if (d->hidden == 32) {
-    if ((rc = set_lds(ppo_grad_kernel<32>, lds_bytes<32>()))) return rc;
-    hipLaunchKernelGGL(ppo_grad_kernel<32>, dim3(nblk), dim3(ROWS), lds_bytes<32>(), st, *d, params, params_t,
-                       norm_mean, norm_var, obs, actions, old_logp, advantages, returns, idx, batch, T, n_envs,
-                       normalize_adv, clip_range, ent_coef, vf_coef, ws, nblk);
-  } else {
-    if ((rc = set_lds(ppo_grad_kernel<64>, lds_bytes<64>()))) return rc;
-    hipLaunchKernelGGL(ppo_grad_kernel<64>, dim3(nblk), dim3(ROWS), lds_bytes<64>(), st, *d, params, params_t,
-                       norm_mean, norm_var, obs, actions, old_logp, advantages, returns, idx, batch, T, n_envs,
-                       normalize_adv, clip_range, ent_coef, vf_coef, ws, nblk);
-  }
-  IA_CHECK_LAUNCH();
-  hipLaunchKernelGGL(ppo_apply_kernel, dim3(1), dim3(1024), 0, st, *d, params, params_t, exp_avg, exp_avg_sq, ws,
-                     nblk, batch, max_grad_norm, ent_coef, vf_coef, beta1, beta2, adam_eps, step_size, bc2_sqrt,
-                     stats);
-  IA_CHECK_LAUNCH();
-  return IA_OK;
+  PpoArgs a{d, params, params_t, norm_mean, norm_var, norm_count, update_norm, obs, actions, old_logp, advantages,
+            returns, T, n_envs, normalize_adv, clip_range, ent_coef, vf_coef, max_grad_norm, exp_avg, exp_avg_sq,
+            beta1, beta2, adam_eps, ws, (hipStream_t)stream};
+  int rc = launch_prepare(a, idx, batch);
+  if (rc) return rc;
+  return launch_minibatch(a, idx, batch, step_size, bc2_sqrt, stats, nullptr, 0);
 }
 
 // One full PPO epoch (SB3 PPO.train inner loop over RolloutBuffer.get): `perm` is the host-drawn
 // np.random.permutation(T*n_envs) already resident on the device; minibatches are consecutive
 // slices of it (the last one may be short). Adam's bias corrections are formed in double per step.
+// Launches: 1 prepare + 2 per minibatch.
 int ia_ppo_epoch(const ia_policy_desc* d, float* params, float* params_t, float* norm_mean, float* norm_var,
                  int32_t* norm_count, int update_norm, const float* obs, const float* actions, const float* old_logp,
                  const float* advantages, const float* returns, const int64_t* perm, int T, int n_envs,
@@ -826,19 +999,24 @@ int ia_ppo_epoch(const ia_policy_desc* d, float* params, float* params_t, float*
                  float max_grad_norm, float* exp_avg, float* exp_avg_sq, double lr, double beta1, double beta2,
                  float adam_eps, int64_t adam_steps_done, float* ws, float* stats, void* stream) {
   if (!pol_ok(d) || batch_size <= 0) return IA_ERR_ARG;
+  PpoArgs a{d, params, params_t, norm_mean, norm_var, norm_count, update_norm, obs, actions, old_logp, advantages,
+            returns, T, n_envs, normalize_adv, clip_range, ent_coef, vf_coef, max_grad_norm, exp_avg, exp_avg_sq,
+            (float)beta1, (float)beta2, adam_eps, ws, (hipStream_t)stream};
   const long long total = (long long)T * n_envs;
   int64_t step = adam_steps_done;
   int mb = 0;
+  auto size_at = [&](long long start) { return (int)((total - start) < batch_size ? (total - start) : batch_size); };
+  int rc = launch_prepare(a, perm, size_at(0));
+  if (rc) return rc;
   for (long long start = 0; start < total; start += batch_size, ++mb) {
-    const int b = (int)((total - start) < batch_size ? (total - start) : batch_size);
+    const int b = size_at(start);
+    const long long nstart = start + batch_size;
+    const int nb = nstart < total ? size_at(nstart) : 0;
     ++step;
     const double bc1 = 1.0 - pow(beta1, (double)step);
     const double bc2 = 1.0 - pow(beta2, (double)step);
-    int rc = ia_ppo_minibatch(d, params, params_t, norm_mean, norm_var, norm_count, update_norm, obs, actions,
-                              old_logp, advantages, returns, perm + start, b, T, n_envs, normalize_adv, clip_range,
-                              ent_coef, vf_coef, max_grad_norm, exp_avg, exp_avg_sq, (float)beta1, (float)beta2,
-                              adam_eps, (float)(lr / bc1), (float)sqrt(bc2), ws, stats ? stats + mb * 8 : nullptr,
-                              stream);
+    rc = launch_minibatch(a, perm + start, b, (float)(lr / bc1), (float)sqrt(bc2), stats ? stats + mb * 8 : nullptr,
+                          nb ? perm + nstart : nullptr, nb);
     if (rc) return rc;
   }
   return IA_OK;

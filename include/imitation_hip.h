@@ -43,6 +43,13 @@ int ia_gemm_f32(int mode, const float* A, int lda, const float* B, int ldb, floa
                 int K, const float* bias, int act, const float* P, int ldp, int splits, float* dbias,
                 void* stream);
 
+/* Measurement only (bench.py): when enabled every GEMM launch is bracketed by hipEvents on its
+ * launch stream; collect() returns per-kernel totals for the 12 kernels (id = mode*4 + tile
+ * config {0:128x128, 1:64x64, 2:128x32, 3:32x128}): elapsed ms, algorithmic flops (2*M*N*K),
+ * launch count. At most 8192 launches per window (later launches are not timed). */
+int ia_prof_enable(int on);
+int ia_prof_collect(double* ms, double* flops, long long* launches);
+
 /* rewards/reward_nets.py:441-457 `BasicRewardNet.forward` after concat (+ gail.py:75-83 when
  * out_act=IA_ACT_SOFTPLUS): out[R,dims[n]] = mlp(X). `hidden` receives the post-activation
  * hidden layers ([R,dims1] then [R,dims2] ...; needed by ia_mlp_backward, may be scratch). */

@@ -253,7 +253,7 @@ def test_airl_logits_and_grad_routing():
     dl = rnd(R, seed=11)
     logits.backward(dl)
     out = th.empty(R, device=DEV)
-    dd = dev(done.numpy().astype(np.uint8), th.uint8)
+    dd = dev(done.float())  # the AIRL kernels take 0/1 fp32 dones (as gathered by ia_gather_concat)
     L.call("ia_airl_logits", dptr(g.detach()), dptr(hc.detach()), dptr(hn.detach()), L.ptr(dd),
            dptr(lp), gamma, R, L.ptr(out), L.stream())
     th.testing.assert_close(out.cpu(), logits.detach(), rtol=1e-6, atol=1e-6)
