@@ -1,0 +1,229 @@
+"""CPU tests (`-m "not gpu"`) of the product's host logic: index streams, trajectory ordering,
+wrappers, logger, the C-ABI surface of the built library -- no compute calls."""
+import ctypes
+import itertools
+import os
+import re
+
+import numpy as np
+import pytest
+import torch as th
+
+import imitation_amd as p
+from imitation_amd import _lib
+from imitation_amd import data_types as dt
+from imitation_amd.vec_env import CountingVecEnv, SyntheticVecEnv
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    """include/imitation_hip.h <-> libimitation_hip.so <-> ctypes table agree."""
+    header = open(os.path.join(ROOT, "include", "imitation_hip.h")).read()
+    declared = set(re.findall(r"\b(ia_[a-z0-9_]+)\s*\(", header))
+    assert declared, "no declarations parsed"
+    assert os.path.exists(_lib.LIB_PATH), "run __graft_entry__.build() first"
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in the header but not exported"
+    assert declared == set(_lib.EXPORTED_SYMBOLS), declared ^ set(_lib.EXPORTED_SYMBOLS)
+    assert _lib.load().ia_version() >= 100
+
+
+def test_hip_path_refuses_cpu_device(tmp_path):
+    venv = SyntheticVecEnv(num_envs=2, obs_dim=3, act_dim=2, horizon=5)
+    algo = p.PPO(p.FeedForward32Policy, venv, n_steps=4, batch_size=4, device="cpu")
+    net = p.BasicRewardNet(venv.observation_space, venv.action_space)
+    demos = p.Transitions(obs=np.zeros((8, 3), np.float32), acts=np.zeros((8, 2), np.float32),
+                          next_obs=np.zeros((8, 3), np.float32), dones=np.zeros(8, bool))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        p.GAIL(demonstrations=demos, demo_batch_size=4, venv=venv, gen_algo=algo, reward_net=net,
+               custom_logger=p.configure_logger(str(tmp_path), []))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        net.predict(np.zeros((2, 3), np.float32), np.zeros((2, 2), np.float32), np.zeros((2, 3), np.float32),
+                    np.zeros(2, bool))
+
+
+@pytest.mark.parametrize("n,bs", [(103, 10), (64, 64), (500, 64), (26964, 1024)])
+def test_expert_index_stream_matches_torch_dataloader(n, bs):
+    """Same indices AND same global-RNG consumption as the reference's
+    endless_iter(DataLoader(shuffle=True, drop_last=True)) (algorithms/base.py:277-282, util.py:215-241)."""
+
+    class DS(th.utils.data.Dataset):
+        def __len__(self):
+            return n
+
+        def __getitem__(self, i):
+            return i
+
+    th.manual_seed(11)
+    dl = th.utils.data.DataLoader(DS(), batch_size=bs, shuffle=True, drop_last=True)
+    assert iter(dl) != dl                      # util.py:236 guard (creates an iterator)
+    next(iter(dl))                             # util.py:240 get_first_iter_element
+    it = itertools.chain.from_iterable(itertools.repeat(dl))
+    k = 3 * (n // bs) + 2
+    ref = [next(it).numpy() for _ in range(k)]
+    ref_post = th.rand(4)
+    th.manual_seed(11)
+    s = dt.ExpertIndexStream(n, bs)
+    got = [s.next_indices() for _ in range(k)]
+    post = th.rand(4)
+    for a, b in zip(ref, got):
+        assert np.array_equal(a, b)
+    assert th.equal(ref_post, post)
+    with pytest.raises(ValueError, match="smaller than batch size"):
+        dt.ExpertIndexStream(5, 10)
+    with pytest.raises(ValueError, match="must be positive"):
+        dt.ExpertIndexStream(5, 0)
+
+
+@pytest.mark.parametrize("lens,T", [((1,), 20), ((6, 5, 1, 2), 21), ((2, 2), 2), ((6, 5, 1, 2), 1), ((3, 7, 4), 16)])
+def test_buffering_wrapper_order_matches_oracle(lens, T):
+    """Array bookkeeping == the reference's per-env TrajectoryAccumulator semantics, including
+    the emission ORDER (completed episodes by completion, then partial fragments by env)."""
+    from oracle import imitation_restated as o
+    a, b = p.BufferingWrapper(CountingVecEnv(lens, obs_dim=2)), o.BufferingWrapper(CountingVecEnv(lens, obs_dim=2))
+    a.reset(), b.reset()
+    rng = np.random.default_rng(0)
+    for rep in range(2):  # two consecutive pops: fragments continue across pops
+        for _ in range(T):
+            acts = rng.standard_normal((len(lens), 1)).astype(np.float32)
+            a.step(acts), b.step(acts)
+        assert a.n_transitions == b.n_transitions
+        ta, la = a.pop_transitions_and_lens()
+        trajs, lb = b.pop_trajectories()
+        tb = o.flatten_trajectories(trajs)
+        for k in ("obs", "acts", "next_obs", "dones", "rews"):
+            assert np.array_equal(getattr(ta, k), getattr(tb, k)), (k, rep)
+        assert list(la) == list(lb)
+        assert a.n_transitions == 0
+    # trajectory view (API parity)
+    for _ in range(T):
+        acts = np.zeros((len(lens), 1), np.float32)
+        a.step(acts), b.step(acts)
+    tra, _ = a.pop_trajectories()
+    trb, _ = b.pop_trajectories()
+    assert len(tra) == len(trb)
+    for x, y in zip(tra, trb):
+        assert x.terminal == y.terminal and np.array_equal(x.obs, y.obs) and np.array_equal(x.acts, y.acts)
+    assert a.pop_trajectories() == ([], [])
+    with pytest.raises(RuntimeError, match="empty BufferingWrapper"):
+        a.pop_transitions()
+
+
+def test_buffering_wrapper_premature_reset():
+    """tests/data/test_wrappers.py:230-263."""
+    w = p.BufferingWrapper(CountingVecEnv((3, 3)))
+    w.reset()
+    w.reset()  # fine: nothing buffered
+    w.step(np.zeros((2, 1), np.float32))
+    with pytest.raises(RuntimeError, match="before samples were accessed"):
+        w.reset()
+    w.pop_transitions()
+    w.reset()
+
+
+def test_segment_order_random_done_patterns():
+    from oracle import imitation_restated as o
+    rng = np.random.default_rng(3)
+    for _ in range(20):
+        T, n = int(rng.integers(1, 12)), int(rng.integers(1, 9))
+        dones = rng.random((T, n)) < 0.3
+        order, _, _ = dt.segment_order(dones)
+        assert sorted(order.tolist()) == list(range(T * n))
+        # brute-force reference order
+        exp, last = [], [-1] * n
+        for t in range(T):
+            for e in range(n):
+                if dones[t, e]:
+                    exp += [s * n + e for s in range(last[e] + 1, t + 1)]
+                    last[e] = t
+        for e in range(n):
+            exp += [s * n + e for s in range(last[e] + 1, T)]
+        assert order.tolist() == exp
+
+
+def test_reward_wrapper_episode_returns_match_oracle():
+    from oracle import imitation_restated as o
+
+    def rfn(obs, acts, nxt, dones):
+        return (obs[:, 0] + 2 * nxt[:, 0] + acts[:, 0]).astype(np.float32)
+
+    lens = (3, 5, 2)
+    a = p.RewardVecEnvWrapper(p.BufferingWrapper(CountingVecEnv(lens)), rfn)
+    b = o.RewardVecEnvWrapper(o.BufferingWrapper(CountingVecEnv(lens)), rfn)
+    rng = np.random.default_rng(1)
+    for _ in range(17):
+        acts = rng.standard_normal((3, 1)).astype(np.float32)
+        ra, rb = a.step(acts), b.step(acts)
+        assert np.array_equal(ra[1], rb[1]) and np.array_equal(ra[2], rb[2])
+        assert [("terminal_observation" in i) for i in ra[3]] == [("terminal_observation" in i) for i in rb[3]]
+    assert list(a.episode_rewards) == list(b.episode_rewards)
+
+
+def test_hierarchical_logger_key_scheme(tmp_path):
+    """util/logger.py:71-119 docstring example."""
+    lg = p.configure_logger(str(tmp_path), ["csv"])
+    lg.record("loss", 1.0)
+    lg.dump(1)
+    with lg.accumulate_means("dataset"):
+        lg.record("entropy", 5.0)
+        lg.dump(100)
+        lg.record("entropy", 6.0)
+        lg.dump(200)
+        with pytest.raises(RuntimeError, match="Nested"):
+            with lg.accumulate_means("x"):
+                pass
+    assert lg.default_logger.name_to_value["mean/dataset/entropy"] == 5.5
+    lg.dump(1)
+    with lg.add_accumulate_prefix("foo"), lg.accumulate_means("bar"):
+        lg.record("biz", 42.0)
+        lg.dump(2000)
+    assert lg.default_logger.name_to_value["mean/foo/bar/biz"] == 42.0
+    assert os.path.exists(tmp_path / "raw" / "dataset" / "progress.csv")
+    assert os.path.exists(tmp_path / "raw" / "foo" / "bar" / "progress.csv")
+    rows = open(tmp_path / "raw" / "dataset" / "progress.csv").read().strip().split("\n")
+    assert rows[0] == "raw/dataset/entropy" and rows[1:] == ["5.0", "6.0"]
+
+
+def test_transitions_validation_and_legacy_npz(tmp_path):
+    with pytest.raises(ValueError, match="dones must be boolean"):
+        p.Transitions(obs=np.zeros((2, 1)), acts=np.zeros((2, 1)), next_obs=np.zeros((2, 1)), dones=np.zeros(2))
+    with pytest.raises(ValueError, match="same number of timesteps"):
+        p.Transitions(obs=np.zeros((2, 1)), acts=np.zeros((3, 1)), next_obs=np.zeros((2, 1)), dones=np.zeros(2, bool))
+    # legacy npz layout (data/serialize.py:50-67): obs has one more row per trajectory
+    obs = np.arange(7, dtype=np.float32)[:, None]
+    np.savez(tmp_path / "r.npz", obs=obs, acts=np.arange(5), rews=np.ones(5), infos=np.array([{}] * 5),
+             terminal=np.array([True, False]), indices=np.array([3]))
+    trajs = p.trajectories_from_legacy_npz(str(tmp_path / "r.npz"))
+    assert [len(t) for t in trajs] == [3, 2] and trajs[0].terminal and not trajs[1].terminal
+    flat = p.flatten_trajectories(trajs)
+    assert flat.dones.tolist() == [False, False, True, False, False]
+    assert np.array_equal(flat.next_obs[:, 0], [1, 2, 3, 5, 6])
+
+
+def test_policy_and_reward_net_init_match_oracle_rng():
+    """Host-side initialisation consumes torch's global RNG exactly like the oracle (and hence the
+    reference under the shim): identical initial parameters and identical RNG state afterwards."""
+    from oracle import imitation_restated as o
+    from oracle import sb3_restated as sb
+    venv = SyntheticVecEnv(num_envs=2, obs_dim=7, act_dim=3, horizon=5)
+    th.manual_seed(4)
+    po = sb.ActorCriticPolicy(venv.observation_space, venv.action_space, lambda _: 3e-4, net_arch=[32, 32],
+                              features_extractor_class=o.NormalizeFeaturesExtractor)
+    no = o.BasicShapedRewardNet(venv.observation_space, venv.action_space, normalize_input_layer=o.RunningNorm)
+    post_o = th.rand(3)
+    th.manual_seed(4)
+    pp = p.FeedForward32Policy(venv.observation_space, venv.action_space, lambda _: 3e-4,
+                               features_extractor_class=p.NormalizeFeaturesExtractor)
+    npn = p.BasicShapedRewardNet(venv.observation_space, venv.action_space, normalize_input_layer=p.RunningNorm)
+    post_p = th.rand(3)
+    assert th.equal(post_o, post_p)
+    sd_o, sd_p = po.state_dict(), pp.state_dict()
+    assert list(sd_o) == list(sd_p)
+    for k in sd_o:
+        assert th.equal(sd_o[k], sd_p[k].cpu()), k
+    sd_o, sd_p = no.state_dict(), npn.state_dict()
+    assert set(sd_o) == set(sd_p)
+    for k in sd_o:
+        assert th.equal(sd_o[k], sd_p[k].cpu()), k
