@@ -47,6 +47,8 @@ _SIGS = {
     "ia_adam_step": ([_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _F, _P], C.c_int),
     "ia_running_norm_ws_floats": ([_I, _I], C.c_int64),
     "ia_running_norm_update": ([_P, _I, _I, _I, _P, _P, _P, _P, _P], C.c_int),
+    "ia_running_norm_partial": ([_P, _I, _I, _I, _P, _P], C.c_int),
+    "ia_running_norm_merge": ([_P, _I, _I, _I, _P, _P, _P, _P], C.c_int),
     "ia_running_norm_apply": ([_P, _I, _I, _I, _P, _P, _F, _P, _I, _P], C.c_int),
     "ia_gather_concat": ([_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _I, _I, _P], C.c_int),
     "ia_bce_logits": ([_P, _I, _I, _F, _P, _P, _P], C.c_int),
@@ -63,6 +65,11 @@ _SIGS = {
     "ia_ppo_ws_floats": ([C.POINTER(PolicyDesc), _I], C.c_int64),
     "ia_ppo_minibatch": ([C.POINTER(PolicyDesc), _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F,
                           _F, _F, _F, _P, _P, _F, _F, _F, _F, _F, _P, _P, _P], C.c_int),
+    "ia_ppo_minibatch_grad": ([C.POINTER(PolicyDesc), _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I,
+                               _F, _F, _F, _P, _P], C.c_int),
+    "ia_ppo_grad_offset": ([C.POINTER(PolicyDesc), _I], C.c_int64),
+    "ia_ppo_minibatch_apply": ([C.POINTER(PolicyDesc), _P, _P, _I, _F, _F, _F, _P, _P, _F, _F, _F, _F, _F, _P, _P, _P],
+                               C.c_int),
     "ia_ppo_epoch": ([C.POINTER(PolicyDesc), _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _F,
                       _F, _F, _P, _P, _D, _D, _D, _F, _L, _P, _P, _P], C.c_int),
 }

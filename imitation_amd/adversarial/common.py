@@ -82,7 +82,7 @@ class AdversarialTrainer(abc.ABC):
                  gen_train_timesteps: Optional[int] = None, gen_replay_buffer_capacity: Optional[int] = None,
                  custom_logger: Optional[imit_logger.HierarchicalLogger] = None, init_tensorboard: bool = False,
                  init_tensorboard_graph: bool = False, debug_use_ground_truth: bool = False,
-                 allow_variable_horizon: bool = False):
+                 allow_variable_horizon: bool = False, data_parallel=None):
         self.demo_batch_size = demo_batch_size
         self.demo_minibatch_size = demo_minibatch_size or demo_batch_size
         if self.demo_batch_size % self.demo_minibatch_size != 0:
@@ -142,6 +142,21 @@ class AdversarialTrainer(abc.ABC):
         if gen_replay_buffer_capacity is None:
             gen_replay_buffer_capacity = self.gen_train_timesteps
         self._gen_replay_buffer = buffer.ReplayBuffer(gen_replay_buffer_capacity, self.venv, device=self._device)
+
+        # ---- data parallelism over env batches (extension; the reference is single-process) ----
+        self._dp = data_parallel
+        if self._dp is not None and self._dp.world > 1:
+            pol = self.gen_algo.policy
+            self.gen_algo.dp = self._dp
+            norms = [n for _, n in self.reward_train._named_norms()]
+            norms += [s.norm for _, s in self._reward_net._named_stacks() if s.norm is not None]
+            if pol.features_extractor.normalize is not None:
+                norms.append(pol.features_extractor.normalize)
+            for nrm in norms:
+                nrm.dp = self._dp
+            self._dp.broadcast_([store.flat, pol._flat] + [t for nrm in norms
+                                                           for t in (nrm.running_mean, nrm.running_var, nrm.count)])
+            pol._sync_transposed()
 
         B = self.demo_batch_size
         self._idx_host = th.zeros(2, B, dtype=th.int64).pin_memory()
@@ -295,6 +310,8 @@ class AdversarialTrainer(abc.ABC):
                        L.stream())
                 net.disc_backward(self._dlogits, accumulate=not first)
                 first = False
+            if self._dp is not None:  # one flat-bucket all-reduce per discriminator step
+                self._dp.allreduce_mean_(net._store.grad)
             if self._torch_opt_params is not None:
                 for p, (_, gview) in zip(self._torch_opt_params, _named_grads(net)):
                     p.grad = gview

@@ -105,15 +105,17 @@ __global__ __launch_bounds__(256) void rn_partial_kernel(const float* __restrict
   }
 }
 
-__global__ void rn_merge_kernel(const float* __restrict__ ws, int nblocks, int R, int D, float* __restrict__ mean,
-                                float* __restrict__ var, int32_t* __restrict__ count) {
+// `nblocks` slabs in groups of `bpg` (one group per data-parallel rank, each covering `rpg` rows);
+// R = total rows = groups * rpg.
+__global__ void rn_merge_kernel(const float* __restrict__ ws, int nblocks, int bpg, int rpg, int R, int D,
+                                float* __restrict__ mean, float* __restrict__ var, int32_t* __restrict__ count) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   const int cnt = *count;
   if (c < D) {
     // Chan merge of slab moments -> batch mean / biased variance
     float n_acc = 0.f, m_acc = 0.f, M2 = 0.f;
     for (int b = 0; b < nblocks; ++b) {
-      const float nb = (float)min(RN_ROWS_PER_BLOCK, R - b * RN_ROWS_PER_BLOCK);
+      const float nb = (float)min(RN_ROWS_PER_BLOCK, rpg - (b % bpg) * RN_ROWS_PER_BLOCK);
       const float mb = ws[((long long)b * 2 + 0) * D + c], qb = ws[((long long)b * 2 + 1) * D + c];
       const float tot = n_acc + nb;
       const float dlt = mb - m_acc;
@@ -432,8 +434,26 @@ int ia_running_norm_update(const float* X, int ldx, int R, int D, float* mean, f
   const int nb = cdiv(R, RN_ROWS_PER_BLOCK);
   hipLaunchKernelGGL(rn_partial_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, X, ldx, R, D, ws);
   IA_CHECK_LAUNCH();
-  hipLaunchKernelGGL(rn_merge_kernel, dim3(cdiv(D, 64)), dim3(64), 0, (hipStream_t)stream, ws, nb, R, D, mean, var,
-                     count);
+  hipLaunchKernelGGL(rn_merge_kernel, dim3(cdiv(D, 64)), dim3(64), 0, (hipStream_t)stream, ws, nb, nb, R, R, D, mean,
+                     var, count);
+  IA_CHECK_LAUNCH();
+  return IA_OK;
+}
+
+int ia_running_norm_partial(const float* X, int ldx, int R, int D, float* ws, void* stream) {
+  if (R <= 0 || D <= 0) return IA_ERR_ARG;
+  hipLaunchKernelGGL(rn_partial_kernel, dim3(cdiv(R, RN_ROWS_PER_BLOCK)), dim3(256), 0, (hipStream_t)stream, X, ldx, R,
+                     D, ws);
+  IA_CHECK_LAUNCH();
+  return IA_OK;
+}
+
+int ia_running_norm_merge(const float* ws_all, int groups, int rows_per_group, int D, float* mean, float* var,
+                          int32_t* count, void* stream) {
+  if (groups <= 0 || rows_per_group <= 0 || D <= 0) return IA_ERR_ARG;
+  const int bpg = cdiv(rows_per_group, RN_ROWS_PER_BLOCK);
+  hipLaunchKernelGGL(rn_merge_kernel, dim3(cdiv(D, 64)), dim3(64), 0, (hipStream_t)stream, ws_all, groups * bpg, bpg,
+                     rows_per_group, groups * rows_per_group, D, mean, var, count);
   IA_CHECK_LAUNCH();
   return IA_OK;
 }

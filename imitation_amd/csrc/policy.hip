@@ -752,7 +752,7 @@ __global__ __launch_bounds__(PREP_THREADS) void ppo_apply_kernel(
     // statistics of the NEXT minibatch (next_batch == 0: none)
     const float* __restrict__ obs, const float* __restrict__ adv, const int64_t* __restrict__ next_idx, int next_batch,
     int T, int n_envs, int update_norm, float* __restrict__ nm, float* __restrict__ nv,
-    int32_t* __restrict__ ncount) {
+    int32_t* __restrict__ ncount, int phases /* bit0: reduce slabs -> ws.grad, bit1: clip + Adam */) {
   extern __shared__ float lds[];
   __shared__ float coef;
   const int H = d.hidden, D = d.obs_dim;
@@ -761,11 +761,17 @@ __global__ __launch_bounds__(PREP_THREADS) void ppo_apply_kernel(
   const int tid = threadIdx.x;
   float sq = 0.f;
   for (int i = tid; i < o.total; i += PREP_THREADS) {
-    float g = 0.f;
-    for (int b = 0; b < nblk; ++b) g += w.slabs[(long long)b * o.total + i];  // fixed order
-    w.grad[i] = g;
+    float g;
+    if (phases & 1) {
+      g = 0.f;
+      for (int b = 0; b < nblk; ++b) g += w.slabs[(long long)b * o.total + i];  // fixed order
+      w.grad[i] = g;
+    } else {
+      g = w.grad[i];  // already reduced (and all-reduced across ranks) by the caller
+    }
     sq += g * g;
   }
+  if (!(phases & 2)) return;
   const float total_sq = block_sum_1024(sq, lds);
   if (tid == 0) {
     const float total_norm = sqrtf(total_sq);
@@ -963,7 +969,19 @@ int launch_minibatch(const PpoArgs& a, const int64_t* idx, int batch, float step
   hipLaunchKernelGGL(ppo_apply_kernel, dim3(1), dim3(PREP_THREADS), bytes, a.st, *a.d, a.params, a.params_t, a.exp_avg,
                      a.exp_avg_sq, a.ws, cdiv(batch, ROWS), batch, a.max_grad_norm, a.ent_coef, a.vf_coef, a.beta1,
                      a.beta2, a.adam_eps, step_size, bc2_sqrt, stats, a.obs, a.advantages, next_idx, next_batch, a.T,
-                     a.n_envs, a.update_norm, a.norm_mean, a.norm_var, a.norm_count);
+                     a.n_envs, a.update_norm, a.norm_mean, a.norm_var, a.norm_count, 3);
+  IA_CHECK_LAUNCH();
+  return IA_OK;
+}
+
+int launch_apply_phase(const PpoArgs& a, int batch, float step_size, float bc2_sqrt, float* stats, int phases) {
+  static bool attr = false;
+  const size_t bytes = PREP_LDS_FLOATS * sizeof(float);
+  if (!attr) { int rc = set_lds(ppo_apply_kernel, bytes); if (rc) return rc; attr = true; }
+  hipLaunchKernelGGL(ppo_apply_kernel, dim3(1), dim3(PREP_THREADS), bytes, a.st, *a.d, a.params, a.params_t, a.exp_avg,
+                     a.exp_avg_sq, a.ws, cdiv(batch, ROWS), batch, a.max_grad_norm, a.ent_coef, a.vf_coef, a.beta1,
+                     a.beta2, a.adam_eps, step_size, bc2_sqrt, stats, a.obs, a.advantages, nullptr, 0, a.T, a.n_envs, 0,
+                     a.norm_mean, a.norm_var, a.norm_count, phases);
   IA_CHECK_LAUNCH();
   return IA_OK;
 }
@@ -986,6 +1004,43 @@ int ia_ppo_minibatch(const ia_policy_desc* d, float* params, float* params_t, fl
   int rc = launch_prepare(a, idx, batch);
   if (rc) return rc;
   return launch_minibatch(a, idx, batch, step_size, bc2_sqrt, stats, nullptr, 0);
+}
+
+// Data-parallel split of a minibatch step (one rank per GPU): `_grad` = statistics + forward/backward
+// + fixed-order slab reduction into the flat gradient at ia_ppo_grad_ptr(); the caller all-reduces
+// that buffer over RCCL; `_apply` = clip_grad_norm_ + Adam on the reduced gradient.
+int ia_ppo_minibatch_grad(const ia_policy_desc* d, float* params, float* params_t, float* norm_mean, float* norm_var,
+                          int32_t* norm_count, int update_norm, const float* obs, const float* actions,
+                          const float* old_logp, const float* advantages, const float* returns, const int64_t* idx,
+                          int batch, int T, int n_envs, int normalize_adv, float clip_range, float ent_coef,
+                          float vf_coef, float* ws, void* stream) {
+  if (!pol_ok(d) || batch <= 0) return IA_ERR_ARG;
+  PpoArgs a{d, params, params_t, norm_mean, norm_var, norm_count, update_norm, obs, actions, old_logp, advantages,
+            returns, T, n_envs, normalize_adv, clip_range, ent_coef, vf_coef, 0.f, nullptr, nullptr, 0.f, 0.f, 0.f, ws,
+            (hipStream_t)stream};
+  int rc = launch_prepare(a, idx, batch);
+  if (rc) return rc;
+  rc = d->hidden == 32 ? launch_grad<32>(a, idx, batch) : launch_grad<64>(a, idx, batch);
+  if (rc) return rc;
+  return launch_apply_phase(a, batch, 0.f, 1.f, nullptr, 1);
+}
+
+int64_t ia_ppo_grad_offset(const ia_policy_desc* d, int batch) {
+  if (!pol_ok(d) || batch <= 0) return IA_ERR_ARG;
+  const int nblk = cdiv(batch, ROWS);
+  const int P = pol_offsets(d->obs_dim, d->act_dim, d->hidden, d->discrete).total;
+  return 8 + (int64_t)nblk * 8 + (int64_t)nblk * P;  // float offset of the reduced gradient inside ws
+}
+
+int ia_ppo_minibatch_apply(const ia_policy_desc* d, float* params, float* params_t, int batch, float ent_coef,
+                           float vf_coef, float max_grad_norm, float* exp_avg, float* exp_avg_sq, float beta1,
+                           float beta2, float adam_eps, float step_size, float bc2_sqrt, float* ws, float* stats,
+                           void* stream) {
+  if (!pol_ok(d) || batch <= 0) return IA_ERR_ARG;
+  PpoArgs a{d, params, params_t, nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, 0,
+            0.f, ent_coef, vf_coef, max_grad_norm, exp_avg, exp_avg_sq, beta1, beta2, adam_eps, ws,
+            (hipStream_t)stream};
+  return launch_apply_phase(a, batch, step_size, bc2_sqrt, stats, 2);
 }
 
 // One full PPO epoch (SB3 PPO.train inner loop over RolloutBuffer.get): `perm` is the host-drawn

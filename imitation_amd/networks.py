@@ -56,6 +56,7 @@ class RunningNorm:
         self.count = th.zeros((), dtype=th.int32)
         self.training = True
         self._ws: Optional[th.Tensor] = None
+        self.dp = None  # imitation_amd.distributed.DataParallel: merge moments across ranks
 
     # -- nn.Module-like plumbing
     def train(self, mode: bool = True):
@@ -100,8 +101,15 @@ class RunningNorm:
         R = rows if rows is not None else x.shape[0]
         ld = ldx if ldx is not None else x.shape[1]
         need = int(L.load().ia_running_norm_ws_floats(R, self.num_features))
-        if self._ws is None or self._ws.numel() < need:
+        if self._ws is None or self._ws.numel() != need:
             self._ws = th.empty(need, device=self.device)
+        if self.dp is not None and self.dp.world > 1:
+            # every rank contributes R rows: all-gather the slab moments, identical merge everywhere
+            L.call("ia_running_norm_partial", L.ptr(x), ld, R, self.num_features, L.ptr(self._ws), L.stream())
+            ws_all = self.dp.all_gather_flat(self._ws)
+            L.call("ia_running_norm_merge", L.ptr(ws_all), self.dp.world, R, self.num_features,
+                   L.ptr(self.running_mean), L.ptr(self.running_var), L.ptr(self.count), L.stream())
+            return
         L.call("ia_running_norm_update", L.ptr(x), ld, R, self.num_features, L.ptr(self.running_mean),
                L.ptr(self.running_var), L.ptr(self.count), L.ptr(self._ws), L.stream())
 

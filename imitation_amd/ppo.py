@@ -188,6 +188,8 @@ class PPO(OnPolicyAlgorithm):
         self._perm_host = th.zeros(self.n_epochs, total, dtype=th.int64).pin_memory()
         self._perm_dev = th.zeros(self.n_epochs, total, dtype=th.int64, device=self.device)
         self._stats_dev = th.zeros(self.n_epochs, self._n_mb, 8, device=self.device)
+        self.dp = None  # set by the trainer for data-parallel runs (imitation_amd.distributed.DataParallel)
+        self._dp_obs = th.zeros(min(self.batch_size, total), p.obs_dim, device=self.device)
 
     @property
     def logger(self):
@@ -364,6 +366,43 @@ class PPO(OnPolicyAlgorithm):
         callback.on_rollout_end()
         return True
 
+    def _train_data_parallel(self, perm: np.ndarray, lr: float, clip_range: float) -> None:
+        """Minibatch loop with one RCCL all-reduce of the flat policy gradient per optimiser step
+        (and a moment all-gather for the feature RunningNorm); replicas stay identical."""
+        pol, rb, dp = self.policy, self.rollout_buffer, self.dp
+        T, n = rb.buffer_size, rb.n_envs
+        total = T * n
+        rn = pol.features_extractor.normalize
+        g = pol.optimizer.param_groups[0]
+        b1, b2 = g["betas"]
+        P = pol._flat.numel()
+        offs_host = ((perm % T) * n + perm // T).astype(np.int64)  # time-major row of each permuted index
+        offs = th.from_numpy(offs_host).to(self.device)
+        obs_rows = rb.obs.reshape((T + 1) * n, -1)
+        for e in range(self.n_epochs):
+            for mb, start in enumerate(range(0, total, self.batch_size)):
+                b = min(self.batch_size, total - start)
+                idx = self._perm_dev[e, start:start + b]
+                if rn is not None:
+                    L.call("ia_gather_rows", L.ptr(obs_rows), L.ptr(offs[e, start:start + b]), b, pol.obs_dim,
+                           L.ptr(self._dp_obs), L.stream())
+                    rn.update_stats(self._dp_obs, ldx=pol.obs_dim, rows=b)
+                L.call("ia_ppo_minibatch_grad", C.byref(pol.desc), L.ptr(pol._flat), L.ptr(pol._flat_t),
+                       L.ptr(rn.running_mean) if rn else None, L.ptr(rn.running_var) if rn else None,
+                       L.ptr(rn.count) if rn else None, 0, L.ptr(rb.obs), L.ptr(rb.acts), L.ptr(rb.logp),
+                       L.ptr(rb.adv), L.ptr(rb.ret), L.ptr(idx), b, T, n, int(self.normalize_advantage),
+                       float(clip_range), float(self.ent_coef), float(self.vf_coef), L.ptr(self._ppo_ws), L.stream())
+                off = int(L.load().ia_ppo_grad_offset(C.byref(pol.desc), b))
+                dp.allreduce_mean_(self._ppo_ws[off:off + P])
+                pol.optimizer.step_count += 1
+                bc1 = 1.0 - b1 ** pol.optimizer.step_count
+                bc2 = 1.0 - b2 ** pol.optimizer.step_count
+                L.call("ia_ppo_minibatch_apply", C.byref(pol.desc), L.ptr(pol._flat), L.ptr(pol._flat_t), b,
+                       float(self.ent_coef), float(self.vf_coef), float(self.max_grad_norm),
+                       L.ptr(pol.optimizer.exp_avg), L.ptr(pol.optimizer.exp_avg_sq), float(b1), float(b2),
+                       float(g["eps"]), float(lr / bc1), float(bc2 ** 0.5), L.ptr(self._ppo_ws),
+                       L.ptr(self._stats_dev[e, mb]), L.stream())
+
     # ---- PPO update (App. A.7) ----------------------------------------------------------------
     def train(self) -> None:
         pol, rb = self.policy, self.rollout_buffer
@@ -379,7 +418,9 @@ class PPO(OnPolicyAlgorithm):
         self._perm_dev.copy_(self._perm_host, non_blocking=True)
         rn = pol.features_extractor.normalize
         g = pol.optimizer.param_groups[0]
-        for e in range(self.n_epochs):
+        if self.dp is not None and self.dp.world > 1:
+            self._train_data_parallel(perm, lr, clip_range)
+        for e in range(self.n_epochs if not (self.dp is not None and self.dp.world > 1) else 0):
             L.call("ia_ppo_epoch", C.byref(pol.desc), L.ptr(pol._flat), L.ptr(pol._flat_t),
                    L.ptr(rn.running_mean) if rn else None, L.ptr(rn.running_var) if rn else None,
                    L.ptr(rn.count) if rn else None, int(rn is not None), L.ptr(rb.obs), L.ptr(rb.acts), L.ptr(rb.logp),

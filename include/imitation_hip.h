@@ -78,6 +78,13 @@ int ia_adam_step(float* params, const float* grads, float* exp_avg, float* exp_a
 int64_t ia_running_norm_ws_floats(int R, int D);
 int ia_running_norm_update(const float* X, int ldx, int R, int D, float* mean, float* var, int32_t* count,
                            float* ws, void* stream);
+/* Data-parallel form of the update: `partial` writes per-slab (mean, M2) moments of the local
+ * batch into ws (ia_running_norm_ws_floats floats); after an all-gather of the ranks' ws buffers,
+ * `merge` Chan-merges all `groups` (ranks, `rows_per_group` rows each) and applies the reference
+ * update with the global batch -- every rank ends with identical statistics. */
+int ia_running_norm_partial(const float* X, int ldx, int R, int D, float* ws, void* stream);
+int ia_running_norm_merge(const float* ws_all, int groups, int rows_per_group, int D, float* mean, float* var,
+                          int32_t* count, void* stream);
 /* util/networks.py:91: Y = (X-mean)/sqrt(var+eps); columns [D,ldy) of Y are zeroed. */
 int ia_running_norm_apply(const float* X, int ldx, int R, int D, const float* mean, const float* var, float eps,
                           float* Y, int ldy, void* stream);
@@ -170,6 +177,19 @@ int ia_ppo_minibatch(const ia_policy_desc* d, float* params, float* params_t, fl
                      float vf_coef, float max_grad_norm, float* exp_avg, float* exp_avg_sq, float beta1,
                      float beta2, float adam_eps, float step_size, float bc2_sqrt, float* ws, float* stats,
                      void* stream);
+/* Data-parallel split (one rank per GPU): `_grad` leaves the rank's minibatch gradient (mean-loss
+ * gradient of its local rows) at ws + ia_ppo_grad_offset() floats; the caller all-reduces (mean)
+ * that flat bucket over RCCL; `_apply` then clips by the global norm and steps Adam. */
+int ia_ppo_minibatch_grad(const ia_policy_desc* d, float* params, float* params_t, float* norm_mean, float* norm_var,
+                          int32_t* norm_count, int update_norm, const float* obs, const float* actions,
+                          const float* old_logp, const float* advantages, const float* returns, const int64_t* idx,
+                          int batch, int T, int n_envs, int normalize_adv, float clip_range, float ent_coef,
+                          float vf_coef, float* ws, void* stream);
+int64_t ia_ppo_grad_offset(const ia_policy_desc* d, int batch);
+int ia_ppo_minibatch_apply(const ia_policy_desc* d, float* params, float* params_t, int batch, float ent_coef,
+                           float vf_coef, float max_grad_norm, float* exp_avg, float* exp_avg_sq, float beta1,
+                           float beta2, float adam_eps, float step_size, float bc2_sqrt, float* ws, float* stats,
+                           void* stream);
 /* One PPO epoch = consecutive minibatches of the device-resident permutation `perm[T*n_envs]`
  * (host-drawn np.random.permutation); stats is [n_minibatches][8] or NULL. */
 int ia_ppo_epoch(const ia_policy_desc* d, float* params, float* params_t, float* norm_mean, float* norm_var,
