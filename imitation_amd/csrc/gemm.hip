@@ -118,28 +118,27 @@ __global__ __launch_bounds__(WM* WN * 64) void ia_gemm_kernel(IaGemm g) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  float4 ra[AIO::NV], rb[BIO::NV];
+  // Two register stages: while chunk c is multiplied out of LDS, chunk c+1 sits in one register
+  // set (to be written to the other LDS buffer after the MFMAs) and chunk c+2 is in flight into
+  // the second set, so every global load has two chunk-times to land.
+  float4 ra0[AIO::NV], rb0[BIO::NV], ra1[AIO::NV], rb1[BIO::NV];
   const int n_chunks = (k_end - k_begin + BK - 1) / BK;
   const bool do_db = (MODE == IA_GEMM_TN) && (g.dbias != nullptr) && (bn0 == 0);
   float dbacc = 0.f;
 
-  if (n_chunks > 0) {
-    AIO::load(ra, g.A, g.lda, bm0, g.M, k_begin, k_end, a_vec, tid);
-    BIO::load(rb, g.B, g.ldb, bn0, g.N, k_begin, k_end, b_vec, tid);
-    AIO::store(ra, smem, tid);
-    BIO::store(rb, smem + AIO::ELEMS, tid);
-  }
-  __syncthreads();
-
-  for (int c = 0; c < n_chunks; ++c) {
+  auto gload = [&](float4 (&ra)[AIO::NV], float4 (&rb)[BIO::NV], int c) {
+    const int k0 = k_begin + c * BK;
+    AIO::load(ra, g.A, g.lda, bm0, g.M, k0, k_end, a_vec, tid);
+    BIO::load(rb, g.B, g.ldb, bn0, g.N, k0, k_end, b_vec, tid);
+  };
+  auto lstore = [&](const float4 (&ra)[AIO::NV], const float4 (&rb)[BIO::NV], int c) {
+    float* S = smem + (c & 1) * STAGE;
+    AIO::store(ra, S, tid);
+    BIO::store(rb, S + AIO::ELEMS, tid);
+  };
+  auto compute = [&](int c) {
     const float* As = smem + (c & 1) * STAGE;
     const float* Bs = As + AIO::ELEMS;
-    const bool more = (c + 1 < n_chunks);
-    if (more) {
-      const int k0 = k_begin + (c + 1) * BK;
-      AIO::load(ra, g.A, g.lda, bm0, g.M, k0, k_end, a_vec, tid);
-      BIO::load(rb, g.B, g.ldb, bn0, g.N, k0, k_end, b_vec, tid);
-    }
 #pragma unroll 4
     for (int kk = 0; kk < BK; kk += 2) {
       float af[TM], bf[TN];
@@ -157,11 +156,27 @@ __global__ __launch_bounds__(WM* WN * 64) void ia_gemm_kernel(IaGemm g) {
 #pragma unroll 8
       for (int kk = 0; kk < BK; ++kk) dbacc += As[kk * BM + tid];
     }
-    if (more) {
-      float* An = smem + ((c + 1) & 1) * STAGE;
-      AIO::store(ra, An, tid);
-      BIO::store(rb, An + AIO::ELEMS, tid);
-    }
+  };
+
+  if (n_chunks > 0) {
+    gload(ra0, rb0, 0);
+    lstore(ra0, rb0, 0);
+    if (n_chunks > 1) gload(ra1, rb1, 1);
+    if (n_chunks > 2) gload(ra0, rb0, 2);
+  }
+  __syncthreads();
+  // invariant at the top of an (odd c) iteration: set 1 holds chunk c ... handled by the 2x unroll:
+  // even c: set1 = chunk c+1 (landed), set0 = chunk c+2 (in flight)
+  // odd  c: set0 = chunk c+1 (landed), set1 = chunk c+2 (in flight)
+  for (int c = 0; c < n_chunks; c += 2) {
+    compute(c);
+    if (c + 1 < n_chunks) lstore(ra1, rb1, c + 1);
+    if (c + 3 < n_chunks) gload(ra1, rb1, c + 3);
+    __syncthreads();
+    if (c + 1 >= n_chunks) break;
+    compute(c + 1);
+    if (c + 2 < n_chunks) lstore(ra0, rb0, c + 2);
+    if (c + 4 < n_chunks) gload(ra0, rb0, c + 4);
     __syncthreads();
   }
 
@@ -228,7 +243,7 @@ int launch_cfg(const IaGemm& g, hipStream_t stream) {
   IA_CHECK_LAUNCH();
   if (prof) {
     (void)hipEventRecord(g_prof_ev[g_prof_n][1], stream);
-    constexpr int cfg = (BM == 128 && BN == 128) ? 0 : (BM == 64 ? 1 : (BM == 128 ? 2 : 3));
+    constexpr int cfg = (BM == 128 && BN == 128) ? 0 : ((BM == 64 && BN == 64) ? 1 : ((BM == 128 && BN == 32) ? 2 : 3));
     g_prof_kid[g_prof_n] = MODE * 4 + cfg;
     g_prof_fl[g_prof_n] = 2.0 * (double)g.M * (double)g.N * (double)g.K;
     ++g_prof_n;
@@ -236,12 +251,24 @@ int launch_cfg(const IaGemm& g, hipStream_t stream) {
   return IA_OK;
 }
 
+int g_force_cfg = -1;  // tuning override (ia_gemm_set_config)
+
 template <int MODE>
 int launch_mode(const IaGemm& g, hipStream_t stream) {
+  switch (g_force_cfg) {
+    case 0: return launch_cfg<2, 2, 2, 2, MODE>(g, stream);  // 128 x 128
+    case 1: return launch_cfg<2, 2, 1, 1, MODE>(g, stream);  // 64 x 64
+    case 2: return launch_cfg<4, 1, 1, 1, MODE>(g, stream);  // 128 x 32
+    case 3: return launch_cfg<1, 4, 1, 1, MODE>(g, stream);  // 32 x 128
+    case 4: return launch_cfg<2, 2, 1, 2, MODE>(g, stream);  // 64 x 128
+    case 5: return launch_cfg<2, 2, 2, 1, MODE>(g, stream);  // 128 x 64
+    default: break;
+  }
   if (g.M <= 32 && g.N > 32) return launch_cfg<1, 4, 1, 1, MODE>(g, stream);  // 32 x 128
   if (g.N <= 32) return launch_cfg<4, 1, 1, 1, MODE>(g, stream);              // 128 x 32
-  if (g.N <= 64 || g.M <= 64) return launch_cfg<2, 2, 1, 1, MODE>(g, stream); // 64 x 64
-  return launch_cfg<2, 2, 2, 2, MODE>(g, stream);                             // 128 x 128
+  // 64 x 64 (34 KB LDS, 4 workgroups per CU): this kernel is load-latency bound per workgroup, so
+  // residency beats tile size on every discriminator shape measured (tools/gemm_bench.py).
+  return launch_cfg<2, 2, 1, 1, MODE>(g, stream);
 }
 
 }  // namespace
@@ -255,6 +282,8 @@ int ia_launch_gemm(int mode, const IaGemm& g, hipStream_t stream) {
   }
   return IA_ERR_ARG;
 }
+
+extern "C" int ia_gemm_set_config(int cfg) { g_force_cfg = cfg; return IA_OK; }
 
 // Profiling window: ia_prof_enable(1) .. launches .. ia_prof_collect(ms, flops, launches) [12 each].
 // Kernel id = mode*4 + tile config {0:128x128, 1:64x64, 2:128x32, 3:32x128}.

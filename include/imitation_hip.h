@@ -47,6 +47,7 @@ int ia_gemm_f32(int mode, const float* A, int lda, const float* B, int ldb, floa
  * launch stream; collect() returns per-kernel totals for the 12 kernels (id = mode*4 + tile
  * config {0:128x128, 1:64x64, 2:128x32, 3:32x128}): elapsed ms, algorithmic flops (2*M*N*K),
  * launch count. At most 8192 launches per window (later launches are not timed). */
+int ia_gemm_set_config(int cfg); /* tuning: force a tile config (-1 = automatic selection) */
 int ia_prof_enable(int on);
 int ia_prof_collect(double* ms, double* flops, long long* launches);
 

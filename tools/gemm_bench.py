@@ -26,7 +26,10 @@ shapes = [  # (mode, M, N, K, splits, label)
     (0, 65536, 256, 256, 1, "fwd  L2 R=65536"),
 ]
 L.load()
-for mode, M, N, K, splits, label in shapes:
+cfgs = [int(c) for c in os.environ.get("GEMM_CFGS", "-1").split(",")]
+shapes = [(m, M, N, K, sp, f"cfg{c:2d} " + lab, c) for (m, M, N, K, sp, lab) in shapes for c in cfgs]
+for mode, M, N, K, splits, label, cfg in shapes:
+    L.load().ia_gemm_set_config(cfg)
     if mode == 0:
         A, B = th.randn(M, K, device=dev), th.randn(N, K, device=dev)
     elif mode == 1:
