@@ -158,7 +158,22 @@ class AdversarialTrainer(abc.ABC):
                                                            for t in (nrm.running_mean, nrm.running_var, nrm.count)])
             pol._sync_transposed()
 
+        # ---- GAIL only: the discriminator update never reads the policy, so inside `train()` the
+        # n_disc updates run on a second stream CONCURRENTLY with the PPO update of the same round
+        # (results unchanged: host RNG draws keep their program order; the policy-feature-norm
+        # side effect of `evaluate_actions` is replayed on the PPO stream after
+        # the PPO update, exactly where the reference executes it).
+        self._overlap = (not self._needs_logp and isinstance(self.gen_algo, ppo.PPO)
+                         and not (self._dp is not None and self._dp.world > 1))
+        self._disc_stream = th.cuda.Stream(device=self._device) if self._overlap else None
+        self._in_overlap = False
+        self._overlap_k = 0
+        self._quirk_pending = []
+
         B = self.demo_batch_size
+        nq = max(1, self.n_disc_updates_per_round)
+        self._quirk_idx_host = th.zeros(nq, 2, B, dtype=th.int64).pin_memory()
+        self._quirk_idx_dev = th.zeros(nq, 2, B, dtype=th.int64, device=self._device)
         self._idx_host = th.zeros(2, B, dtype=th.int64).pin_memory()
         self._idx_dev = th.zeros(2, B, dtype=th.int64, device=self._device)
         self._stats_dev = th.zeros(8, device=self._device)
@@ -236,24 +251,31 @@ class AdversarialTrainer(abc.ABC):
         """(expert_table, expert_idx_dev | None), (gen_table, gen_idx_dev | None) for one update."""
         B = self.demo_batch_size
         e_idx = g_idx = None
+        # inside an overlapped round every update gets its own (pinned, device) index rows so the
+        # deferred policy-norm replay can still read them after later updates were enqueued
+        k = self._overlap_k % self._quirk_idx_dev.shape[0] if self._in_overlap else None
+        idx_host = self._quirk_idx_host[k] if k is not None else self._idx_host
+        idx_dev = self._quirk_idx_dev[k] if k is not None else self._idx_dev
+        if self._in_overlap:
+            self._overlap_k += 1
         if expert_samples is None:
             if self._expert_batches is not None:
                 expert_samples = next(self._expert_batches)
             else:
-                self._idx_host[0].copy_(th.from_numpy(self._expert_stream.next_indices()))
-                e_idx = self._idx_dev[0]
+                idx_host[0].copy_(th.from_numpy(self._expert_stream.next_indices()))
+                e_idx = idx_dev[0]
         if gen_samples is None:
             if self._gen_replay_buffer.size() == 0:
                 raise RuntimeError("No generator samples for training. Call `train_gen()` first.")
-            self._idx_host[1].copy_(th.from_numpy(self._gen_replay_buffer.sample_indices(B)))
-            g_idx = self._idx_dev[1]
+            idx_host[1].copy_(th.from_numpy(self._gen_replay_buffer.sample_indices(B)))
+            g_idx = idx_dev[1]
         n_gen = B if gen_samples is None else len(gen_samples["obs"])
         n_exp = B if expert_samples is None else len(expert_samples["obs"])
         if not (n_gen == n_exp == B):
             raise ValueError("Need to have exactly `demo_batch_size` number of expert and generator samples, each. "
                              f"(n_gen={n_gen} n_expert={n_exp} demo_batch_size={B})")
         if e_idx is not None or g_idx is not None:
-            self._idx_dev.copy_(self._idx_host, non_blocking=True)
+            idx_dev.copy_(idx_host, non_blocking=True)
         obs_shape = self.venv.observation_space.shape
         e_tab = self._expert_table if expert_samples is None else _upload_table(expert_samples, obs_shape,
                                                                                 self._discrete, self._device)
@@ -270,6 +292,9 @@ class AdversarialTrainer(abc.ABC):
             return None
         has_norm = pol.features_extractor.normalize is not None
         if not self._needs_logp and not (has_norm and pol.training):
+            return None
+        if self._in_overlap:  # replayed later on the generator's stream (see `train`)
+            self._quirk_pending.append(list(sources))  # index views live in `_quirk_idx_dev` all round
             return None
         R = 2 * mb
         row = 0
@@ -339,7 +364,23 @@ class AdversarialTrainer(abc.ABC):
         gen_samples, ep_lens = self.venv_buffering.pop_transitions_and_lens()
         self._check_fixed_horizon(ep_lens)
         if gen_samples is not None:
-            self._gen_replay_buffer.store(gen_samples)
+            if self._in_overlap:  # the ring is only touched by the discriminator stream
+                with th.cuda.stream(self._disc_stream):
+                    self._gen_replay_buffer.store(gen_samples)
+            else:
+                self._gen_replay_buffer.store(gen_samples)
+
+    def _replay_policy_norm_updates(self) -> None:
+        """Deferred `_policy_pass` side effects, in order, on the current (generator) stream."""
+        pol = self.policy
+        for sources in self._quirk_pending:
+            row = 0
+            for table, idx, n in sources:
+                networks.gather_concat(table, idx, n, pol.obs_dim, pol.act_dim, (True, False, False, False),
+                                       self._pol_obs, pol.obs_dim, row)
+                row += n
+            pol.features_extractor.normalize.update_stats(self._pol_obs[:row])
+        self._quirk_pending = []
 
     def train(self, total_timesteps: int, callback: Optional[Callable[[int], None]] = None) -> None:
         """`common.py:427-461`."""
@@ -348,10 +389,27 @@ class AdversarialTrainer(abc.ABC):
                                f"{self.gen_train_timesteps} timesteps, have only "
                                f"total_timesteps={total_timesteps})!")
         for r in range(n_rounds):
-            self.train_gen(self.gen_train_timesteps)
-            for _ in range(self.n_disc_updates_per_round):
-                with networks.training(self.reward_train):
-                    self.train_disc()
+            if not self._overlap:
+                self.train_gen(self.gen_train_timesteps)
+                for _ in range(self.n_disc_updates_per_round):
+                    with networks.training(self.reward_train):
+                        self.train_disc()
+            else:
+                main = th.cuda.current_stream()
+                self._in_overlap, self.gen_algo.defer_train_stats, self._overlap_k = True, True, 0
+                try:
+                    self._disc_stream.wait_stream(main)
+                    self.train_gen(self.gen_train_timesteps)       # rollout; PPO update enqueued on `main`
+                    with th.cuda.stream(self._disc_stream):         # ... while the disc updates run here
+                        for _ in range(self.n_disc_updates_per_round):
+                            with networks.training(self.reward_train):
+                                self.train_disc()
+                    main.wait_stream(self._disc_stream)
+                    self._replay_policy_norm_updates()              # after the PPO update, in stream order
+                    with self.logger.accumulate_means("gen"):
+                        self.gen_algo.finalize_train()
+                finally:
+                    self._in_overlap, self.gen_algo.defer_train_stats = False, False
             if callback:
                 callback(r)
             self.logger.dump(self._global_step)

@@ -189,6 +189,10 @@ class PPO(OnPolicyAlgorithm):
         self._perm_dev = th.zeros(self.n_epochs, total, dtype=th.int64, device=self.device)
         self._stats_dev = th.zeros(self.n_epochs, self._n_mb, 8, device=self.device)
         self.dp = None  # set by the trainer for data-parallel runs (imitation_amd.distributed.DataParallel)
+        # When True, `train()` only ENQUEUES the update and returns; the caller overlaps other GPU
+        # work with it and later calls `finalize_train()` (one D2H of the statistics + logging).
+        self.defer_train_stats = False
+        self._pending_train = None
         self._dp_obs = th.zeros(min(self.batch_size, total), p.obs_dim, device=self.device)
 
     @property
@@ -431,6 +435,16 @@ class PPO(OnPolicyAlgorithm):
                    L.ptr(self._ppo_ws), L.ptr(self._stats_dev[e]), L.stream())
             pol.optimizer.step_count += self._n_mb
         self._n_updates += self.n_epochs
+        self._pending_train = clip_range
+        if not self.defer_train_stats:
+            self.finalize_train()
+
+    def finalize_train(self) -> None:
+        """Statistics read-back + logging of the last `train()` (SB3 PPO.train's logger block)."""
+        if self._pending_train is None:
+            return
+        clip_range, self._pending_train = self._pending_train, None
+        pol, rb = self.policy, self.rollout_buffer
         st = self._stats_dev.cpu().numpy()  # one synchronisation per train()
         vals, rets = rb.val.cpu().numpy().reshape(-1), rb.ret.cpu().numpy().reshape(-1)
         var_y = np.var(rets)
