@@ -63,11 +63,13 @@ _SIGS = {
     "ia_policy_evaluate": ([C.POINTER(PolicyDesc), _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P], C.c_int),
     "ia_gae": ([_P, _P, _P, _P, _P, _I, _I, _F, _F, _P, _P, _P], C.c_int),
     "ia_timeout_bootstrap": ([_P, _P, _P, _F, _L, _P], C.c_int),
-    "ia_ppo_ws_floats": ([C.POINTER(PolicyDesc), _I], C.c_int64),
+    "ia_ppo_ws_floats": ([C.POINTER(PolicyDesc), _I, _L], C.c_int64),
     "ia_ppo_minibatch": ([C.POINTER(PolicyDesc), _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F,
                           _F, _F, _F, _P, _P, _F, _F, _F, _F, _F, _P, _P, _P], C.c_int),
     "ia_ppo_minibatch_grad": ([C.POINTER(PolicyDesc), _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I,
                                _F, _F, _F, _P, _P], C.c_int),
+    "ia_ppo_debug_timing": ([_P], C.c_int),
+    "ia_ppo_force_valu": ([_I], C.c_int),
     "ia_ppo_grad_offset": ([C.POINTER(PolicyDesc), _I], C.c_int64),
     "ia_ppo_minibatch_apply": ([C.POINTER(PolicyDesc), _P, _P, _I, _F, _F, _F, _P, _P, _F, _F, _F, _F, _F, _P, _P, _P],
                                C.c_int),

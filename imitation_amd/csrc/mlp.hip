@@ -35,7 +35,15 @@ __global__ void reduce_partials_kernel(const float* __restrict__ partials, int s
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   float s = 0.f;
-  for (int k = 0; k < splits; ++k) s += partials[(long long)k * n + i];  // fixed order: deterministic
+  int k = 0;
+  for (; k + 8 <= splits; k += 8) {  // 8 independent loads in flight, then a fixed-order sum
+    float t[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) t[u] = partials[(long long)(k + u) * n + i];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s += t[u];
+  }
+  for (; k < splits; ++k) s += partials[(long long)k * n + i];  // fixed order: deterministic
   s *= scale;
   grads[i] = accumulate ? grads[i] + s : s;
 }
@@ -114,14 +122,26 @@ __global__ void rn_merge_kernel(const float* __restrict__ ws, int nblocks, int b
   if (c < D) {
     // Chan merge of slab moments -> batch mean / biased variance
     float n_acc = 0.f, m_acc = 0.f, M2 = 0.f;
-    for (int b = 0; b < nblocks; ++b) {
-      const float nb = (float)min(RN_ROWS_PER_BLOCK, rpg - (b % bpg) * RN_ROWS_PER_BLOCK);
-      const float mb = ws[((long long)b * 2 + 0) * D + c], qb = ws[((long long)b * 2 + 1) * D + c];
-      const float tot = n_acc + nb;
-      const float dlt = mb - m_acc;
-      M2 = M2 + qb + dlt * dlt * n_acc * nb / tot;
-      m_acc = m_acc + dlt * nb / tot;
-      n_acc = tot;
+    for (int b0 = 0; b0 < nblocks; b0 += 8) {  // slab moments are fetched 8 at a time (independent loads)
+      float mbv[8], qbv[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int b = min(b0 + u, nblocks - 1);
+        mbv[u] = ws[((long long)b * 2 + 0) * D + c];
+        qbv[u] = ws[((long long)b * 2 + 1) * D + c];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int b = b0 + u;
+        if (b < nblocks) {
+          const float nb = (float)min(RN_ROWS_PER_BLOCK, rpg - (b % bpg) * RN_ROWS_PER_BLOCK);
+          const float tot = n_acc + nb;
+          const float dlt = mbv[u] - m_acc;
+          M2 = M2 + qbv[u] + dlt * dlt * n_acc * nb / tot;
+          m_acc = m_acc + dlt * nb / tot;
+          n_acc = tot;
+        }
+      }
     }
     const float b_mean = m_acc, b_var = M2 / (float)R;
     // util/networks.py:123-134, same operation order

@@ -341,6 +341,31 @@ __device__ __forceinline__ long long rollout_offset(long long flat, int T, int n
   const long long env = flat / T, t = flat % T;
   return t * n_envs + env;
 }
+// Row i of a minibatch: through the permutation (idx != null) or already gathered (contiguous).
+__device__ __forceinline__ long long mb_row(const int64_t* __restrict__ idx, long long i, int T, int n_envs) {
+  return idx ? rollout_offset(idx[i], T, n_envs) : i;
+}
+
+// One coalesced pass per epoch: rows of the rollout tile in permuted order -> contiguous arrays,
+// so every minibatch kernel afterwards streams its rows without dependent index loads.
+__global__ void ppo_epoch_gather_kernel(const float* __restrict__ obs, const float* __restrict__ act,
+                                        const float* __restrict__ logp, const float* __restrict__ adv,
+                                        const float* __restrict__ ret, const int64_t* __restrict__ perm,
+                                        long long total, int T, int n_envs, int D, int aw, float* __restrict__ gobs,
+                                        float* __restrict__ gact, float* __restrict__ glogp, float* __restrict__ gadv,
+                                        float* __restrict__ gret) {
+  const int W = D + aw + 3;
+  const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= total * W) return;
+  const long long p = e / W;
+  const int c = (int)(e - p * W);
+  const long long src = rollout_offset(perm[p], T, n_envs);
+  if (c < D) gobs[p * D + c] = obs[src * D + c];
+  else if (c < D + aw) gact[p * aw + (c - D)] = act[src * aw + (c - D)];
+  else if (c == D + aw) glogp[p] = logp[src];
+  else if (c == D + aw + 1) gadv[p] = adv[src];
+  else gret[p] = ret[src];
+}
 
 constexpr int PREP_THREADS = 1024;
 constexpr int PREP_STAGE_FLOATS = 24576;            // 96 KB of staged observation rows
@@ -373,11 +398,11 @@ __device__ void prepare_stats(const ia_policy_desc& d, const float* __restrict__
   float* cmean = red + 16 * 65;                  // [65]
   float* misc = cmean + 65;                      // [64]
   float s = 0.f;
-  for (int i = tid; i < batch; i += PREP_THREADS) s += adv[rollout_offset(idx[i], T, n_envs)];
+  for (int i = tid; i < batch; i += PREP_THREADS) s += adv[mb_row(idx, i, T, n_envs)];
   const float mean = block_sum_1024(s, misc) / (float)batch;
   float q = 0.f;
   for (int i = tid; i < batch; i += PREP_THREADS) {
-    const float dl = adv[rollout_offset(idx[i], T, n_envs)] - mean;
+    const float dl = adv[mb_row(idx, i, T, n_envs)] - mean;
     q += dl * dl;
   }
   const float qq = block_sum_1024(q, misc);
@@ -395,7 +420,7 @@ __device__ void prepare_stats(const ia_policy_desc& d, const float* __restrict__
     __syncthreads();
     for (int e = tid; e < rows * D; e += PREP_THREADS) {
       const int r = e / D, k = e - r * D;
-      stage[r * DP + k] = obs[rollout_offset(idx[c0 + r], T, n_envs) * D + k];
+      stage[r * DP + k] = obs[mb_row(idx, c0 + r, T, n_envs) * D + k];
     }
     __syncthreads();
     float cs = 0.f;
@@ -489,7 +514,7 @@ __device__ __forceinline__ void column_sum_store(const float* tile, int stride, 
 
 template <int H>
 struct GLds {  // LDS carve-up of the 8-wave gradient kernel (floats)
-  static constexpr int XS = MAXD + 1, HS = H + 1, AS = MAXA + 1, MS = 5;
+  static constexpr int XS = MAXD + 1, HS = H + 1, AS = MAXA + 1, MS = 9;
   static constexpr int x = 0;
   static constexpr int a1 = x + ROWS * XS;             // [2 towers][ROWS][HS]
   static constexpr int a2 = a1 + 2 * ROWS * HS;
@@ -510,9 +535,11 @@ __global__ __launch_bounds__(512) void ppo_grad_kernel(ia_policy_desc d, const f
                                                        const float* __restrict__ adv, const float* __restrict__ ret,
                                                        const int64_t* __restrict__ idx, int batch, int T, int n_envs,
                                                        int normalize_adv, float clip, float ent_coef, float vf_coef,
-                                                       float* __restrict__ ws, int nblk) {
+                                                       float* __restrict__ ws, int nblk,
+                                                       long long* __restrict__ tstamp /* optional phase clocks */) {
   using L = GLds<H>;
   constexpr int HQ = H / 4;
+#define IA_TS(slot) do { if (tstamp && blockIdx.x == 0 && threadIdx.x == 0) tstamp[slot] = clock64(); } while (0)
   extern __shared__ float lds[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -525,12 +552,13 @@ __global__ __launch_bounds__(512) void ppo_grad_kernel(ia_policy_desc d, const f
   const int aw = d.discrete ? 1 : A;
   const float invB = 1.f / (float)batch;
 
+  IA_TS(0);
   // ---- phase 0: cooperative, coalesced feature gather (+ normalisation) into LDS; clear pads
   for (int e = tid; e < ROWS * L::XS; e += 512) {
     const int r = e / L::XS, k = e - r * L::XS;
     float v = 0.f;
     if (k < D && i0 + r < batch) {
-      v = obs[rollout_offset(idx[i0 + r], T, n_envs) * D + k];
+      v = obs[mb_row(idx, i0 + r, T, n_envs) * D + k];
       if (d.has_norm) v = (v - nm[k]) / sqrtf(nv[k] + d.norm_eps);
     }
     lds[L::x + e] = v;
@@ -546,11 +574,13 @@ __global__ __launch_bounds__(512) void ppo_grad_kernel(ia_policy_desc d, const f
   float* dzrow = lds + L::dz + (tw * ROWS + lane) * L::HS;
   const int c0 = q * HQ;  // first output column owned by this wave
 
+  IA_TS(1);
   // ---- phase 1: layer 1 (quarter of the outputs)
   {
     float acc[HQ];
 #pragma unroll
     for (int j = 0; j < HQ; ++j) acc[j] = P[ob1 + c0 + j];
+#pragma unroll 4
     for (int k = 0; k < D; ++k) {
       const float xk = xrow[k];
 #pragma unroll
@@ -560,6 +590,7 @@ __global__ __launch_bounds__(512) void ppo_grad_kernel(ia_policy_desc d, const f
     for (int j = 0; j < HQ; ++j) a1row[c0 + j] = fast_tanh(acc[j]);
   }
   __syncthreads();
+  IA_TS(2);
   // ---- phase 2: layer 2
   {
     float acc[HQ];
@@ -575,6 +606,7 @@ __global__ __launch_bounds__(512) void ppo_grad_kernel(ia_policy_desc d, const f
     for (int j = 0; j < HQ; ++j) a2row[c0 + j] = fast_tanh(acc[j]);
   }
   __syncthreads();
+  IA_TS(3);
   // ---- phase 3: heads
   if (tw == 0) {
     for (int a = q; a < A; a += 4) {
@@ -590,11 +622,12 @@ __global__ __launch_bounds__(512) void ppo_grad_kernel(ia_policy_desc d, const f
     lds[L::misc + lane * L::MS + 0] = v;
   }
   __syncthreads();
+  IA_TS(4);
   // ---- phase 4: per-row losses (wave 0: policy terms, wave 4: value term)
   const int i = i0 + lane;
   const bool valid = i < batch;
   if (wv == 0) {
-    const long long src = valid ? rollout_offset(idx[i], T, n_envs) : 0;
+    const long long src = valid ? mb_row(idx, i, T, n_envs) : 0;
     const float* outrow = lds + L::out + lane * L::AS;
     float* doutrow = lds + L::dout + lane * L::AS;
     float* auxrow = lds + L::aux + lane * L::AS;
@@ -662,7 +695,7 @@ __global__ __launch_bounds__(512) void ppo_grad_kernel(ia_policy_desc d, const f
       if (lane == 0) w.statpart[blockIdx.x * 8 + slot[k]] = x;
     }
   } else if (wv == 4) {
-    const long long src = valid ? rollout_offset(idx[i], T, n_envs) : 0;
+    const long long src = valid ? mb_row(idx, i, T, n_envs) : 0;
     const float v = lds[L::misc + lane * L::MS + 0];
     const float verr = ret[src] - v;
     lds[L::misc + lane * L::MS + 1] = valid ? vf_coef * 2.f * (v - ret[src]) * invB : 0.f;  // F.mse_loss
@@ -671,6 +704,7 @@ __global__ __launch_bounds__(512) void ppo_grad_kernel(ia_policy_desc d, const f
     if (lane == 0) w.statpart[blockIdx.x * 8 + 1] = x;
   }
   __syncthreads();
+  IA_TS(5);
   // ---- phase 5: d(a2) -> dz2 for this wave's quarter; head weight/bias gradients
   if (tw == 0) {
     float da2[HQ];
@@ -708,6 +742,7 @@ __global__ __launch_bounds__(512) void ppo_grad_kernel(ia_policy_desc d, const f
     }
   }
   __syncthreads();
+  IA_TS(6);
   // ---- phase 6: dW2 / db2 from (dz2, a1); d(a1) -> dz1 (stored in the now-free a2 tile)
   {
     const float* dzt = lds + L::dz + tw * ROWS * L::HS;
@@ -734,6 +769,7 @@ __global__ __launch_bounds__(512) void ppo_grad_kernel(ia_policy_desc d, const f
     }
   }
   __syncthreads();
+  IA_TS(7);
   // ---- phase 7: dW1 / db1 from (dz1, x)
   {
     const float* dz1 = lds + L::a2 + tw * ROWS * L::HS;
@@ -743,6 +779,397 @@ __global__ __launch_bounds__(512) void ppo_grad_kernel(ia_policy_desc d, const f
       mfma_outer_store(dz1, L::HS, lds + L::x, L::XS, (ti / kt) * 32, (ti % kt) * 32, H, D, slab + oW1, D, lane);
     if (q == 3) column_sum_store(dz1, L::HS, H, slab + ob1, lane);
   }
+  __syncthreads();
+  IA_TS(8);
+#undef IA_TS
+}
+
+// ---------------------------------------------------------------------------------------------
+// H = 32 specialisation built on v_mfma_f32_16x16x4_f32 (lane l: li = l&15, lk = l>>4; A[i=li][k=lk],
+// B[k=lk][j=li], C: col = li, rows = 4*lk + reg). 64 rows per block, 8 waves: waves 0-3 = policy
+// tower, 4-7 = value tower; wave q owns row-tile q (16 rows) of every layer output and one 16x16
+// tile of every weight gradient. All weight (B) fragments are fetched into VGPRs at kernel start, so
+// the layer chain only touches LDS (activations) and the matrix pipe: no dependent global or scalar
+// loads inside the phases.
+__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+__global__ __launch_bounds__(512) void ppo_grad_mfma32_kernel(
+    ia_policy_desc d, const float* __restrict__ P, const float* __restrict__ Pt, const float* __restrict__ nm,
+    const float* __restrict__ nv, const float* __restrict__ obs, const float* __restrict__ actions,
+    const float* __restrict__ old_logp, const float* __restrict__ adv, const float* __restrict__ ret,
+    const int64_t* __restrict__ idx, int batch, int T, int n_envs, int normalize_adv, float clip, float ent_coef,
+    float vf_coef, float* __restrict__ ws, int nblk, long long* __restrict__ tstamp) {
+  constexpr int H = 32;
+  using L = GLds<32>;
+#define IA_TS(slot) do { if (tstamp && blockIdx.x == 0 && threadIdx.x == 0) tstamp[slot] = clock64(); } while (0)
+  extern __shared__ float lds[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tw = wv >> 2, q = wv & 3;
+  const int li = lane & 15, lk = lane >> 4;
+  const int D = d.obs_dim, A = d.act_dim;
+  const PolOff o = pol_offsets(D, A, H, d.discrete);
+  const PpoWs w = ppo_ws(ws, nblk, o.total);
+  float* slab = w.slabs + (long long)blockIdx.x * o.total;
+  const int i0 = blockIdx.x * ROWS;
+  const int aw = d.discrete ? 1 : A;
+  const float invB = 1.f / (float)batch;
+  const int S1 = (D + 3) >> 2, SA = (A + 3) >> 2;
+
+  const int oW1 = tw ? o.vW1 : o.pW1, ob1 = tw ? o.vb1 : o.pb1, oW2 = tw ? o.vW2 : o.pW2, ob2 = tw ? o.vb2 : o.pb2;
+  IA_TS(0);
+
+  // ---- phase 0a: issue the feature-row loads FIRST (VMEM returns in order: the LDS stores below then
+  // only wait for these, while the weight fragments requested next keep streaming in behind them)
+  constexpr int NIT = (ROWS * L::XS + 511) / 512;
+  float xv[NIT], xm[NIT], xs_[NIT];
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int e = tid + it * 512;
+    const int r = e / L::XS, k = e - r * L::XS;
+    const bool ok = e < ROWS * L::XS && k < D && i0 + r < batch;
+    xv[it] = ok ? obs[mb_row(idx, i0 + r, T, n_envs) * D + k] : 0.f;
+    xm[it] = (ok && d.has_norm) ? nm[k] : 0.f;
+    xs_[it] = (ok && d.has_norm) ? nv[k] : 1.f - d.norm_eps;
+  }
+  // per-row scalars of the loss phase (wave 0: policy terms, wave 4: value term)
+  const int i = i0 + lane;
+  const bool valid = i < batch;
+  const long long src = valid ? mb_row(idx, i, T, n_envs) : 0;
+  float r_oldlp = 0.f, r_adv = 0.f, r_ret = 0.f, r_act[MAXA];
+#pragma unroll
+  for (int a = 0; a < MAXA; ++a) r_act[a] = 0.f;
+  if (wv == 0) {
+    r_oldlp = old_logp[src];
+    r_adv = adv[src];
+#pragma unroll
+    for (int a = 0; a < MAXA; ++a)
+      if (a < aw) r_act[a] = actions[src * aw + a];
+  }
+  if (wv == 4) r_ret = ret[src];
+  const float adv_mean = w.advstat[0], adv_std = w.advstat[1];
+
+  IA_TS(9);
+  // ---- parameters: ONE cooperative, coalesced 16-byte copy of both flat vectors (torch layout P and
+  // the transposed shadow copy Pt) into LDS; every weight fragment below is then an LDS read.
+  float* sP = lds + L::total;
+  float* sPt = sP + ((o.total + 3) & ~3);
+  {
+    const int n4 = (o.total + 3) >> 2;
+    const bool vec = ((reinterpret_cast<uintptr_t>(P) | reinterpret_cast<uintptr_t>(Pt)) & 15) == 0;
+    for (int e = tid; e < n4; e += 512) {
+      float4 v0, v1;
+      if (vec && 4 * e + 3 < o.total) {
+        v0 = reinterpret_cast<const float4*>(P)[e];
+        v1 = reinterpret_cast<const float4*>(Pt)[e];
+      } else {
+        float t0[4], t1[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int ii = min(4 * e + u, o.total - 1);
+          t0[u] = P[ii];
+          t1[u] = Pt[ii];
+        }
+        v0 = make_float4(t0[0], t0[1], t0[2], t0[3]);
+        v1 = make_float4(t1[0], t1[1], t1[2], t1[3]);
+      }
+      reinterpret_cast<float4*>(sP)[e] = v0;
+      reinterpret_cast<float4*>(sPt)[e] = v1;
+    }
+  }
+  IA_TS(10);
+  // ---- phase 0b: normalise + stage the feature rows in LDS; clear the small tiles
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int e = tid + it * 512;
+    if (e < ROWS * L::XS) lds[L::x + e] = (xv[it] - xm[it]) / sqrtf(xs_[it] + d.norm_eps);
+  }
+  for (int e = tid; e < ROWS * L::AS; e += 512) { lds[L::dout + e] = 0.f; lds[L::aux + e] = 0.f; lds[L::out + e] = 0.f; }
+  for (int e = tid; e < ROWS * L::MS; e += 512) lds[L::misc + e] = 0.f;
+  __syncthreads();
+
+  IA_TS(11);
+  // weight fragments (LDS -> VGPR): B[k = 4s+lk][j = c*16+li]
+  float bW1[16][2], bW2[8][2], bW2o[8][2], bHead[8], bDa2[4][2], b1v[2], b2v[2], cwv[2];
+#pragma unroll
+  for (int s = 0; s < 16; ++s) {
+    const int kk = 4 * s + lk;
+    bW1[s][0] = bW1[s][1] = 0.f;
+    if (s < S1) {  // wave-uniform: steps beyond the observation width issue no LDS reads
+#pragma unroll
+      for (int c = 0; c < 2; ++c) bW1[s][c] = kk < D ? sPt[oW1 + kk * H + c * 16 + li] : 0.f;
+    }
+  }
+#pragma unroll
+  for (int s = 0; s < 8; ++s) {
+    const int kk = 4 * s + lk;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      bW2[s][c] = sPt[oW2 + kk * H + c * 16 + li];   // W2^T[k][j]
+      bW2o[s][c] = sP[oW2 + kk * H + c * 16 + li];   // W2[j=k][k'] (row j contiguous)
+    }
+    bHead[s] = tw == 0 ? (li < A ? sP[o.aW + li * H + kk] : 0.f) : (li == 0 ? sP[o.cW + kk] : 0.f);
+  }
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    const int aa = 4 * s + lk;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) bDa2[s][c] = (tw == 0 && aa < A) ? sP[o.aW + aa * H + c * 16 + li] : 0.f;
+  }
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {
+    b1v[c] = sP[ob1 + c * 16 + li];
+    b2v[c] = sP[ob2 + c * 16 + li];
+    cwv[c] = sP[o.cW + c * 16 + li];
+  }
+  const float head_bias = tw == 0 ? (li < A ? sP[o.ab + li] : 0.f) : sP[o.cb];
+  // per-action Gaussian constants (wave-uniform): sd = exp(log_std), var = sd^2, log sd
+  float c_var[MAXA], c_logsd[MAXA];
+#pragma unroll
+  for (int a = 0; a < MAXA; ++a) {
+    c_var[a] = 1.f;
+    c_logsd[a] = 0.f;
+    if (wv == 0 && !d.discrete && a < A) {  // only the loss wave needs them
+      const float sd = expf(sP[o.log_std + a]);
+      c_var[a] = sd * sd;
+      c_logsd[a] = logf(sd);
+    }
+  }
+
+  float* a1t = lds + L::a1 + tw * ROWS * L::HS;
+  float* a2t = lds + L::a2 + tw * ROWS * L::HS;
+  float* dzt = lds + L::dz + tw * ROWS * L::HS;
+  const int arow = q * 16 + li;  // row whose A fragment this lane feeds
+  IA_TS(1);
+  // ---- phase 1: a1 = tanh(x W1^T + b1)
+  {
+    f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+    for (int s = 0; s < 16; ++s)
+      if (s < S1) {
+        const float a = lds[L::x + arow * L::XS + 4 * s + lk];
+        acc[0] = mfma16(a, bW1[s][0], acc[0]);
+        acc[1] = mfma16(a, bW1[s][1], acc[1]);
+      }
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) a1t[(q * 16 + lk * 4 + r) * L::HS + c * 16 + li] = fast_tanh(acc[c][r] + b1v[c]);
+  }
+  __syncthreads();
+  IA_TS(2);
+  // ---- phase 2: a2 = tanh(a1 W2^T + b2)
+  {
+    f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      const float a = a1t[arow * L::HS + 4 * s + lk];
+      acc[0] = mfma16(a, bW2[s][0], acc[0]);
+      acc[1] = mfma16(a, bW2[s][1], acc[1]);
+    }
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) a2t[(q * 16 + lk * 4 + r) * L::HS + c * 16 + li] = fast_tanh(acc[c][r] + b2v[c]);
+  }
+  __syncthreads();
+  IA_TS(3);
+  // ---- phase 3: heads (policy: action_net -> out[row][a]; value: value_net -> misc[row][0])
+  {
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < 8; ++s) acc = mfma16(a2t[arow * L::HS + 4 * s + lk], bHead[s], acc);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = q * 16 + lk * 4 + r;
+      if (tw == 0) { if (li < A) lds[L::out + row * L::AS + li] = acc[r] + head_bias; }
+      else if (li == 0) lds[L::misc + row * L::MS + 0] = acc[r] + head_bias;
+    }
+  }
+  __syncthreads();
+  IA_TS(4);
+  // ---- phase 4: per-row losses (wave 0: policy terms, wave 4: value term)
+  if (wv == 0) {
+    const float* outrow = lds + L::out + lane * L::AS;
+    float* doutrow = lds + L::dout + lane * L::AS;
+    float* auxrow = lds + L::aux + lane * L::AS;
+    float logp = 0.f, entropy = 0.f, lse = 0.f;
+    int act_i = 0;
+    if (!d.discrete) {
+#pragma unroll
+      for (int a = 0; a < MAXA; ++a)
+        if (a < A) {
+          const float diff = r_act[a] - outrow[a];
+          logp += -(diff * diff) / (2.f * c_var[a]) - c_logsd[a] - LOG_SQRT_2PI;
+          entropy += 0.5f + LOG_SQRT_2PI + c_logsd[a];
+        }
+    } else {
+      float mx = outrow[0];
+      for (int a = 1; a < A; ++a) mx = fmaxf(mx, outrow[a]);
+      float se = 0.f;
+      for (int a = 0; a < A; ++a) se += expf(outrow[a] - mx);
+      lse = mx + logf(se);
+      act_i = (int)r_act[0];
+      logp = outrow[act_i] - lse;
+      for (int a = 0; a < A; ++a) {
+        const float l = outrow[a] - lse;
+        entropy -= expf(l) * l;
+      }
+    }
+    float advn = r_adv;
+    if (normalize_adv && batch > 1) advn = (advn - adv_mean) / (adv_std + 1e-8f);
+    const float log_ratio = logp - r_oldlp;
+    const float ratio = expf(log_ratio);
+    const float lo = 1.f - clip, hi = 1.f + clip;
+    const float pl1 = advn * ratio;
+    const float pl2 = advn * fminf(fmaxf(ratio, lo), hi);
+    const float g1 = pl1 < pl2 ? 1.f : (pl1 == pl2 ? 0.5f : 0.f);
+    const float g2 = pl2 < pl1 ? 1.f : (pl1 == pl2 ? 0.5f : 0.f);
+    const float inrange = (ratio >= lo && ratio <= hi) ? 1.f : 0.f;
+    const float dlogp = valid ? -invB * advn * (g1 + g2 * inrange) * ratio : 0.f;
+    if (!d.discrete) {
+#pragma unroll
+      for (int a = 0; a < MAXA; ++a)
+        if (a < A) {
+          const float diff = r_act[a] - outrow[a];
+          doutrow[a] = dlogp * diff / c_var[a];
+          auxrow[a] = valid ? dlogp * (diff * diff / c_var[a] - 1.f) - ent_coef * invB : 0.f;
+        }
+    } else {
+      for (int a = 0; a < A; ++a) {
+        const float l = outrow[a] - lse, p = expf(l);
+        const float dH = -p * (l + entropy);
+        float g = dlogp * ((a == act_i ? 1.f : 0.f) - p);
+        g += valid ? -ent_coef * invB * dH : 0.f;
+        doutrow[a] = g;
+      }
+    }
+    // loss statistics: staged per row in the misc tile, summed by an idle wave in phase 5
+    float* mrow = lds + L::misc + lane * L::MS;
+    mrow[2] = valid ? -fminf(pl1, pl2) : 0.f;                           // policy_gradient_loss
+    mrow[3] = valid ? -entropy : 0.f;                                    // entropy_loss
+    mrow[4] = valid ? (expf(log_ratio) - 1.f) - log_ratio : 0.f;         // approx_kl
+    mrow[5] = valid ? (fabsf(ratio - 1.f) > clip ? 1.f : 0.f) : 0.f;     // clip_fraction
+  } else if (wv == 4) {
+    const float v = lds[L::misc + lane * L::MS + 0];
+    const float verr = r_ret - v;
+    lds[L::misc + lane * L::MS + 1] = valid ? vf_coef * 2.f * (v - r_ret) * invB : 0.f;
+    lds[L::misc + lane * L::MS + 6] = valid ? verr * verr : 0.f;        // value_loss
+  }
+  __syncthreads();
+  IA_TS(5);
+  // ---- phase 5: dz2 = d(a2) * (1 - a2^2); head weight / bias gradients
+  if (tw == 0) {
+    f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+      if (s < SA) {
+        const float a = lds[L::dout + arow * L::AS + 4 * s + lk];   // columns >= A are zero
+        acc[0] = mfma16(a, bDa2[s][0], acc[0]);
+        acc[1] = mfma16(a, bDa2[s][1], acc[1]);
+      }
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int e = (q * 16 + lk * 4 + r) * L::HS + c * 16 + li;
+        const float a = a2t[e];
+        dzt[e] = acc[c][r] * (1.f - a * a);
+      }
+    if (q < 2) {  // dWa[a][h] = sum_r dout[r][a] a2[r][h], tile of 16 h-columns per wave
+      f32x4 g = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s < 16; ++s)
+        g = mfma16(lds[L::dout + (4 * s + lk) * L::AS + li], a2t[(4 * s + lk) * L::HS + q * 16 + li], g);
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (lk * 4 + r < A) slab[o.aW + (lk * 4 + r) * H + q * 16 + li] = g[r];
+    }
+    if (q == 2) column_sum_store(lds + L::dout, L::AS, A, slab + o.ab, lane);
+    if (q == 3 && !d.discrete) column_sum_store(lds + L::aux, L::AS, A, slab + o.log_std, lane);
+  } else {
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = q * 16 + lk * 4 + r;
+        const int e = row * L::HS + c * 16 + li;
+        const float a = a2t[e];
+        dzt[e] = cwv[c] * lds[L::misc + row * L::MS + 1] * (1.f - a * a);
+      }
+    if (q < 2) {  // dcW[h] = sum_r dv[r] a2[r][h]  (only output row 0 is meaningful)
+      f32x4 g = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s < 16; ++s) {
+        const float a = li == 0 ? lds[L::misc + (4 * s + lk) * L::MS + 1] : 0.f;
+        g = mfma16(a, a2t[(4 * s + lk) * L::HS + q * 16 + li], g);
+      }
+      if (lk == 0) slab[o.cW + q * 16 + li] = g[0];
+    }
+    if (q == 2 && lane == 0) {
+      float s = 0.f;
+      for (int r = 0; r < ROWS; ++r) s += lds[L::misc + r * L::MS + 1];
+      slab[o.cb] = s;
+    }
+    if (q == 3 && lane < 5) {  // statpart slots {0 pg, 2 ent, 3 kl, 4 clip, 1 value} <- misc columns 2..6
+      float s = 0.f;
+#pragma unroll 8
+      for (int r = 0; r < ROWS; ++r) s += lds[L::misc + r * L::MS + 2 + lane];
+      const int slot = lane == 0 ? 0 : (lane == 4 ? 1 : lane + 1);
+      w.statpart[blockIdx.x * 8 + slot] = s;
+    }
+  }
+  __syncthreads();
+  IA_TS(6);
+  // ---- phase 6: dW2 (one 16x16 tile per wave), db2, and dz1 = (dz2 W2) * (1 - a1^2) -> a2 tile
+  {
+    const int jt = q >> 1, kt = q & 1;
+    f32x4 g = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < 16; ++s)
+      g = mfma16(dzt[(4 * s + lk) * L::HS + jt * 16 + li], a1t[(4 * s + lk) * L::HS + kt * 16 + li], g);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) slab[oW2 + (jt * 16 + lk * 4 + r) * H + kt * 16 + li] = g[r];
+    f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      const float a = dzt[arow * L::HS + 4 * s + lk];
+      acc[0] = mfma16(a, bW2o[s][0], acc[0]);
+      acc[1] = mfma16(a, bW2o[s][1], acc[1]);
+    }
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int e = (q * 16 + lk * 4 + r) * L::HS + c * 16 + li;
+        const float a = a1t[e];
+        a2t[e] = acc[c][r] * (1.f - a * a);   // dz1 (the a2 tile is free from here on)
+      }
+    if (q == 3) column_sum_store(dzt, L::HS, H, slab + ob2, lane);
+  }
+  __syncthreads();
+  IA_TS(7);
+  // ---- phase 7: dW1 tiles (dz1^T x), db1
+  {
+    const int KT = (D + 15) >> 4;
+    for (int ti = q; ti < 2 * KT; ti += 4) {
+      const int jt = ti / KT, kt = ti - jt * KT;
+      f32x4 g = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s < 16; ++s)
+        g = mfma16(a2t[(4 * s + lk) * L::HS + jt * 16 + li], lds[L::x + (4 * s + lk) * L::XS + kt * 16 + li], g);
+      const int col = kt * 16 + li;
+      if (col < D)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) slab[oW1 + (jt * 16 + lk * 4 + r) * D + col] = g[r];
+    }
+    if (q == 3) column_sum_store(a2t, L::HS, H, slab + ob1, lane);
+  }
+  __syncthreads();
+  IA_TS(8);
+#undef IA_TS
 }
 
 __global__ __launch_bounds__(PREP_THREADS) void ppo_apply_kernel(
@@ -764,7 +1191,15 @@ __global__ __launch_bounds__(PREP_THREADS) void ppo_apply_kernel(
     float g;
     if (phases & 1) {
       g = 0.f;
-      for (int b = 0; b < nblk; ++b) g += w.slabs[(long long)b * o.total + i];  // fixed order
+      int b = 0;
+      for (; b + 8 <= nblk; b += 8) {  // 8 independent loads in flight, then a fixed-order sum
+        float t[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t[u] = w.slabs[(long long)(b + u) * o.total + i];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) g += t[u];
+      }
+      for (; b < nblk; ++b) g += w.slabs[(long long)b * o.total + i];
       w.grad[i] = g;
     } else {
       g = w.grad[i];  // already reduced (and all-reduced across ranks) by the caller
@@ -906,16 +1341,35 @@ int ia_timeout_bootstrap(float* rewards, const float* terminal_values, const uin
   return IA_OK;
 }
 
-int64_t ia_ppo_ws_floats(const ia_policy_desc* d, int batch) {
-  if (!pol_ok(d) || batch <= 0) return IA_ERR_ARG;
+int64_t ia_ppo_ws_floats(const ia_policy_desc* d, int batch, int64_t gather_rows) {
+  if (!pol_ok(d) || batch <= 0 || gather_rows < batch) return IA_ERR_ARG;
   const int nblk = cdiv(batch, ROWS);
   const int P = pol_offsets(d->obs_dim, d->act_dim, d->hidden, d->discrete).total;
-  return 8 + (int64_t)nblk * 8 + (int64_t)nblk * P + P;
+  const int aw = d->discrete ? 1 : d->act_dim;
+  return 8 + (int64_t)nblk * 8 + (int64_t)nblk * P + P + gather_rows * (d->obs_dim + aw + 3);
 }
 
 }  // extern "C" (helpers below are C++)
 
 namespace {
+
+long long* g_tstamp = nullptr;  // debug: device buffer of >= 16 clocks (ia_ppo_debug_timing)
+
+struct Gathered {  // contiguous (permuted-order) copies of the minibatch rows, inside ws
+  float *obs, *act, *logp, *adv, *ret;
+};
+inline Gathered gathered_region(const ia_policy_desc* d, float* ws, int max_batch, long long rows) {
+  const int P = pol_offsets(d->obs_dim, d->act_dim, d->hidden, d->discrete).total;
+  const int nblk = cdiv(max_batch, ROWS);
+  const int aw = d->discrete ? 1 : d->act_dim;
+  Gathered g;
+  g.obs = ws + 8 + (long long)nblk * 8 + (long long)nblk * P + P;
+  g.act = g.obs + rows * d->obs_dim;
+  g.logp = g.act + rows * aw;
+  g.adv = g.logp + rows;
+  g.ret = g.adv + rows;
+  return g;
+}
 
 struct PpoArgs {
   const ia_policy_desc* d;
@@ -931,6 +1385,28 @@ struct PpoArgs {
   hipStream_t st;
 };
 
+int launch_gather(const PpoArgs& a, const int64_t* perm, long long rows, const Gathered& g) {
+  const int aw = a.d->discrete ? 1 : a.d->act_dim;
+  const long long elems = rows * (a.d->obs_dim + aw + 3);
+  hipLaunchKernelGGL(ppo_epoch_gather_kernel, dim3(cdiv(elems, 256)), dim3(256), 0, a.st, a.obs, a.actions, a.old_logp,
+                     a.advantages, a.returns, perm, rows, a.T, a.n_envs, a.d->obs_dim, aw, g.obs, g.act, g.logp, g.adv,
+                     g.ret);
+  IA_CHECK_LAUNCH();
+  return IA_OK;
+}
+
+// view of `a` whose row 0 is row `start` of the gathered arrays (kernels then run with idx == null)
+PpoArgs at_rows(const PpoArgs& a, const Gathered& g, long long start) {
+  const int aw = a.d->discrete ? 1 : a.d->act_dim;
+  PpoArgs v = a;
+  v.obs = g.obs + start * a.d->obs_dim;
+  v.actions = g.act + start * aw;
+  v.old_logp = g.logp + start;
+  v.advantages = g.adv + start;
+  v.returns = g.ret + start;
+  return v;
+}
+
 int launch_prepare(const PpoArgs& a, const int64_t* idx, int batch) {
   static bool attr = false;
   const size_t bytes = PREP_LDS_FLOATS * sizeof(float);
@@ -943,15 +1419,28 @@ int launch_prepare(const PpoArgs& a, const int64_t* idx, int batch) {
   return IA_OK;
 }
 
+bool g_ppo_valu = false;  // tuning/debug: force the VALU kernel for H = 32 as well
+
 template <int H>
 int launch_grad(const PpoArgs& a, const int64_t* idx, int batch) {
   static bool attr = false;
   const size_t bytes = GLds<H>::total * sizeof(float);
-  if (!attr) { int rc = set_lds(ppo_grad_kernel<H>, bytes); if (rc) return rc; attr = true; }
   const int nblk = cdiv(batch, ROWS);
+  if (H == 32 && !g_ppo_valu) {
+    const int P4 = (pol_offsets(a.d->obs_dim, a.d->act_dim, 32, a.d->discrete).total + 3) & ~3;
+    const size_t mbytes = (GLds<32>::total + 2 * P4) * sizeof(float);
+    int rc = set_lds(ppo_grad_mfma32_kernel, 160 * 1024);
+    if (rc) return rc;
+    hipLaunchKernelGGL(ppo_grad_mfma32_kernel, dim3(nblk), dim3(512), mbytes, a.st, *a.d, a.params, a.params_t,
+                       a.norm_mean, a.norm_var, a.obs, a.actions, a.old_logp, a.advantages, a.returns, idx, batch, a.T,
+                       a.n_envs, a.normalize_adv, a.clip_range, a.ent_coef, a.vf_coef, a.ws, nblk, g_tstamp);
+    IA_CHECK_LAUNCH();
+    return IA_OK;
+  }
+  if (!attr) { int rc = set_lds(ppo_grad_kernel<H>, bytes); if (rc) return rc; attr = true; }
   hipLaunchKernelGGL(ppo_grad_kernel<H>, dim3(nblk), dim3(512), bytes, a.st, *a.d, a.params, a.params_t, a.norm_mean,
                      a.norm_var, a.obs, a.actions, a.old_logp, a.advantages, a.returns, idx, batch, a.T, a.n_envs,
-                     a.normalize_adv, a.clip_range, a.ent_coef, a.vf_coef, a.ws, nblk);
+                     a.normalize_adv, a.clip_range, a.ent_coef, a.vf_coef, a.ws, nblk, g_tstamp);
   IA_CHECK_LAUNCH();
   return IA_OK;
 }
@@ -959,6 +1448,9 @@ int launch_grad(const PpoArgs& a, const int64_t* idx, int batch) {
 // grad + apply for one minibatch whose statistics are already in ws; the apply kernel also
 // prepares minibatch `next_idx` (next_batch == 0: nothing follows). NOTE: both minibatches share
 // `ws`, whose slab region is sized by the LARGER batch; advstat sits at ws[0..7] for any size.
+int launch_minibatch_next(const PpoArgs& a, int batch, float step_size, float bc2_sqrt, float* stats,
+                          const PpoArgs& nxt, int next_batch);
+
 int launch_minibatch(const PpoArgs& a, const int64_t* idx, int batch, float step_size, float bc2_sqrt, float* stats,
                      const int64_t* next_idx, int next_batch) {
   int rc = a.d->hidden == 32 ? launch_grad<32>(a, idx, batch) : launch_grad<64>(a, idx, batch);
@@ -969,6 +1461,22 @@ int launch_minibatch(const PpoArgs& a, const int64_t* idx, int batch, float step
   hipLaunchKernelGGL(ppo_apply_kernel, dim3(1), dim3(PREP_THREADS), bytes, a.st, *a.d, a.params, a.params_t, a.exp_avg,
                      a.exp_avg_sq, a.ws, cdiv(batch, ROWS), batch, a.max_grad_norm, a.ent_coef, a.vf_coef, a.beta1,
                      a.beta2, a.adam_eps, step_size, bc2_sqrt, stats, a.obs, a.advantages, next_idx, next_batch, a.T,
+                     a.n_envs, a.update_norm, a.norm_mean, a.norm_var, a.norm_count, 3);
+  IA_CHECK_LAUNCH();
+  return IA_OK;
+}
+
+// contiguous-rows form: `a` = this minibatch's rows, `nxt` = the next minibatch's rows (for its statistics)
+int launch_minibatch_next(const PpoArgs& a, int batch, float step_size, float bc2_sqrt, float* stats,
+                          const PpoArgs& nxt, int next_batch) {
+  int rc = a.d->hidden == 32 ? launch_grad<32>(a, nullptr, batch) : launch_grad<64>(a, nullptr, batch);
+  if (rc) return rc;
+  static bool attr = false;
+  const size_t bytes = PREP_LDS_FLOATS * sizeof(float);
+  if (!attr) { rc = set_lds(ppo_apply_kernel, bytes); if (rc) return rc; attr = true; }
+  hipLaunchKernelGGL(ppo_apply_kernel, dim3(1), dim3(PREP_THREADS), bytes, a.st, *a.d, a.params, a.params_t, a.exp_avg,
+                     a.exp_avg_sq, a.ws, cdiv(batch, ROWS), batch, a.max_grad_norm, a.ent_coef, a.vf_coef, a.beta1,
+                     a.beta2, a.adam_eps, step_size, bc2_sqrt, stats, nxt.obs, nxt.advantages, nullptr, next_batch, a.T,
                      a.n_envs, a.update_norm, a.norm_mean, a.norm_var, a.norm_count, 3);
   IA_CHECK_LAUNCH();
   return IA_OK;
@@ -1001,9 +1509,13 @@ int ia_ppo_minibatch(const ia_policy_desc* d, float* params, float* params_t, fl
   PpoArgs a{d, params, params_t, norm_mean, norm_var, norm_count, update_norm, obs, actions, old_logp, advantages,
             returns, T, n_envs, normalize_adv, clip_range, ent_coef, vf_coef, max_grad_norm, exp_avg, exp_avg_sq,
             beta1, beta2, adam_eps, ws, (hipStream_t)stream};
-  int rc = launch_prepare(a, idx, batch);
+  const Gathered g = gathered_region(d, ws, batch, batch);
+  int rc = launch_gather(a, idx, batch, g);
   if (rc) return rc;
-  return launch_minibatch(a, idx, batch, step_size, bc2_sqrt, stats, nullptr, 0);
+  const PpoArgs v = at_rows(a, g, 0);
+  rc = launch_prepare(v, nullptr, batch);
+  if (rc) return rc;
+  return launch_minibatch(v, nullptr, batch, step_size, bc2_sqrt, stats, nullptr, 0);
 }
 
 // Data-parallel split of a minibatch step (one rank per GPU): `_grad` = statistics + forward/backward
@@ -1018,11 +1530,25 @@ int ia_ppo_minibatch_grad(const ia_policy_desc* d, float* params, float* params_
   PpoArgs a{d, params, params_t, norm_mean, norm_var, norm_count, update_norm, obs, actions, old_logp, advantages,
             returns, T, n_envs, normalize_adv, clip_range, ent_coef, vf_coef, 0.f, nullptr, nullptr, 0.f, 0.f, 0.f, ws,
             (hipStream_t)stream};
-  int rc = launch_prepare(a, idx, batch);
+  const Gathered g = gathered_region(d, ws, batch, batch);
+  int rc = launch_gather(a, idx, batch, g);
   if (rc) return rc;
-  rc = d->hidden == 32 ? launch_grad<32>(a, idx, batch) : launch_grad<64>(a, idx, batch);
+  const PpoArgs v = at_rows(a, g, 0);
+  rc = launch_prepare(v, nullptr, batch);
   if (rc) return rc;
-  return launch_apply_phase(a, batch, 0.f, 1.f, nullptr, 1);
+  rc = d->hidden == 32 ? launch_grad<32>(v, nullptr, batch) : launch_grad<64>(v, nullptr, batch);
+  if (rc) return rc;
+  return launch_apply_phase(v, batch, 0.f, 1.f, nullptr, 1);
+}
+
+int ia_ppo_debug_timing(void* device_buffer_16xi64) {
+  g_tstamp = (long long*)device_buffer_16xi64;
+  return IA_OK;
+}
+
+int ia_ppo_force_valu(int on) {
+  g_ppo_valu = on != 0;
+  return IA_OK;
 }
 
 int64_t ia_ppo_grad_offset(const ia_policy_desc* d, int batch) {
@@ -1061,7 +1587,10 @@ int ia_ppo_epoch(const ia_policy_desc* d, float* params, float* params_t, float*
   int64_t step = adam_steps_done;
   int mb = 0;
   auto size_at = [&](long long start) { return (int)((total - start) < batch_size ? (total - start) : batch_size); };
-  int rc = launch_prepare(a, perm, size_at(0));
+  const Gathered g = gathered_region(d, ws, size_at(0), total);
+  int rc = launch_gather(a, perm, total, g);
+  if (rc) return rc;
+  rc = launch_prepare(at_rows(a, g, 0), nullptr, size_at(0));
   if (rc) return rc;
   for (long long start = 0; start < total; start += batch_size, ++mb) {
     const int b = size_at(start);
@@ -1070,8 +1599,10 @@ int ia_ppo_epoch(const ia_policy_desc* d, float* params, float* params_t, float*
     ++step;
     const double bc1 = 1.0 - pow(beta1, (double)step);
     const double bc2 = 1.0 - pow(beta2, (double)step);
-    rc = launch_minibatch(a, perm + start, b, (float)(lr / bc1), (float)sqrt(bc2), stats ? stats + mb * 8 : nullptr,
-                          nb ? perm + nstart : nullptr, nb);
+    // the apply kernel prepares the NEXT minibatch: hand it that minibatch's rows
+    PpoArgs v = at_rows(a, g, start);
+    rc = launch_minibatch_next(v, b, (float)(lr / bc1), (float)sqrt(bc2), stats ? stats + mb * 8 : nullptr,
+                               nb ? at_rows(a, g, nstart) : v, nb);
     if (rc) return rc;
   }
   return IA_OK;

@@ -183,7 +183,7 @@ class PPO(OnPolicyAlgorithm):
                                             self.device)
         total = self.n_steps * self.n_envs
         self._n_mb = -(-total // self.batch_size)
-        self._ppo_ws = th.empty(int(L.load().ia_ppo_ws_floats(C.byref(p.desc), min(self.batch_size, total))),
+        self._ppo_ws = th.empty(int(L.load().ia_ppo_ws_floats(C.byref(p.desc), min(self.batch_size, total), total)),
                                 device=self.device)
         self._perm_host = th.zeros(self.n_epochs, total, dtype=th.int64).pin_memory()
         self._perm_dev = th.zeros(self.n_epochs, total, dtype=th.int64, device=self.device)

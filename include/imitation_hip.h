@@ -170,7 +170,9 @@ int ia_timeout_bootstrap(float* rewards, const float* terminal_values, const uin
  * backward, per-wave partial gradients; (3) fixed-order reduction, clip_grad_norm_, Adam, refresh
  * of params_t. stats[8] = {pg_loss, value_loss, entropy_loss, approx_kl, clip_fraction, loss,
  * grad_norm, clip_coef}. */
-int64_t ia_ppo_ws_floats(const ia_policy_desc* d, int batch);
+/* gather_rows = rows gathered per call: `batch` for the single-minibatch entries, T*n_envs for
+ * ia_ppo_epoch (which copies the whole permuted epoch into contiguous rows first). */
+int64_t ia_ppo_ws_floats(const ia_policy_desc* d, int batch, int64_t gather_rows);
 int ia_ppo_minibatch(const ia_policy_desc* d, float* params, float* params_t, float* norm_mean, float* norm_var,
                      int32_t* norm_count, int update_norm, const float* obs, const float* actions,
                      const float* old_logp, const float* advantages, const float* returns, const int64_t* idx,
@@ -187,6 +189,12 @@ int ia_ppo_minibatch_grad(const ia_policy_desc* d, float* params, float* params_
                           int batch, int T, int n_envs, int normalize_adv, float clip_range, float ent_coef,
                           float vf_coef, float* ws, void* stream);
 int64_t ia_ppo_grad_offset(const ia_policy_desc* d, int batch);
+/* Debug/measurement: when set to a device buffer of 16 int64, block 0 of every ppo_grad launch
+ * stores the shader clock at its 9 phase boundaries (NULL switches it off). */
+int ia_ppo_debug_timing(void* device_buffer_16xi64);
+/* Tuning/tests: 1 = use the VALU (thread-per-row) gradient kernel also for hidden = 32 instead of
+ * the MFMA 16x16x4 one (hidden = 64 always uses the VALU kernel). */
+int ia_ppo_force_valu(int on);
 int ia_ppo_minibatch_apply(const ia_policy_desc* d, float* params, float* params_t, int batch, float ent_coef,
                            float vf_coef, float max_grad_norm, float* exp_avg, float* exp_avg_sq, float beta1,
                            float beta2, float adam_eps, float step_size, float bc2_sqrt, float* ws, float* stats,

@@ -388,7 +388,10 @@ def test_timeout_bootstrap():
 @pytest.mark.parametrize("D,A,H,discrete,norm,T,n,bs", [(17, 6, 32, False, True, 16, 64, 256),
                                                         (4, 2, 64, True, False, 8, 16, 50),
                                                         (11, 3, 32, False, False, 4, 32, 128),
-                                                        (5, 4, 64, False, True, 3, 7, 21)])
+                                                        (5, 4, 64, False, True, 3, 7, 21),
+                                                        (4, 3, 32, True, True, 8, 16, 40),
+                                                        (64, 16, 32, False, True, 4, 32, 64),
+                                                        (33, 1, 32, False, False, 2, 70, 140)])
 def test_ppo_epochs_match_oracle(D, A, H, discrete, norm, T, n, bs):
     """Two PPO epochs on a synthetic rollout: parameters, Adam state, RunningNorm state and the
     logged loss statistics against SB3-restated `PPO.train` on the same permutations."""
@@ -429,7 +432,7 @@ def test_ppo_epochs_match_oracle(D, A, H, discrete, norm, T, n, bs):
     np.random.seed(123)
     algo.train()  # oracle: 2 epochs
 
-    ws = th.empty(int(L.load().ia_ppo_ws_floats(C.byref(dp.d), bs)), device=DEV)
+    ws = th.empty(int(L.load().ia_ppo_ws_floats(C.byref(dp.d), bs, T * n)), device=DEV)
     n_mb = -(-T * n // bs)
     stats = th.zeros(2, n_mb, 8, device=DEV)
     for e in range(2):
