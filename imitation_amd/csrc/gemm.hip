@@ -93,18 +93,24 @@ __global__ __launch_bounds__(WM* WN * 64) void ia_gemm_kernel(IaGemm g) {
   const int li = lane & 31, lh = lane >> 5;
   const int wm = wave / WN, wn = wave % WN;
 
-  // XCD-aware tile order: hardware places block b on XCD b%8; give each XCD a contiguous run
-  // of tiles so neighbouring column tiles (which share their A rows) hit the same L2.
+  // XCD-aware block order: hardware places block b on XCD b%8. Give each XCD a CONTIGUOUS run of
+  // (split, tile) work items: column tiles that share an A row-block -- and, for split-K, all the
+  // tiles of one K-slab -- then run on the same XCD and are served by its L2 instead of being
+  // re-fetched into eight different L2s (PMC: 98 MB -> ~algorithmic for the 256x256 wgrad).
   const int tiles_n = (g.N + BN - 1) / BN;
+  const int tiles_m = (g.M + BM - 1) / BM;
+  const int tiles = tiles_m * tiles_n;
   const int nb = gridDim.x;
   const int b = blockIdx.x;
   const int q = nb >> 3, rmd = nb & 7, xcd = b & 7;
-  const int t = (xcd < rmd ? xcd * (q + 1) : rmd * (q + 1) + (xcd - rmd) * q) + (b >> 3);
+  const int lin = (xcd < rmd ? xcd * (q + 1) : rmd * (q + 1) + (xcd - rmd) * q) + (b >> 3);
+  const int split = lin / tiles;
+  const int t = lin - split * tiles;
   const int bm0 = (t / tiles_n) * BM, bn0 = (t % tiles_n) * BN;
 
   int k_begin = 0, k_end = g.K;
   if (MODE == IA_GEMM_TN) {
-    k_begin = blockIdx.z * g.k_per_split;
+    k_begin = split * g.k_per_split;
     k_end = min(g.K, k_begin + g.k_per_split);
   }
   const bool a_vec = (g.lda % 4 == 0) && ((reinterpret_cast<uintptr_t>(g.A) & 15) == 0);
@@ -181,7 +187,7 @@ __global__ __launch_bounds__(WM* WN * 64) void ia_gemm_kernel(IaGemm g) {
   }
 
   float* C = g.C;
-  if (MODE == IA_GEMM_TN) C += (long long)blockIdx.z * g.c_split_stride;
+  if (MODE == IA_GEMM_TN) C += (long long)split * g.c_split_stride;
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -205,7 +211,7 @@ __global__ __launch_bounds__(WM* WN * 64) void ia_gemm_kernel(IaGemm g) {
       }
     }
   }
-  if (do_db && tid < BM && bm0 + tid < g.M) g.dbias[(long long)blockIdx.z * g.dbias_split_stride + bm0 + tid] = dbacc;
+  if (do_db && tid < BM && bm0 + tid < g.M) g.dbias[(long long)split * g.dbias_split_stride + bm0 + tid] = dbacc;
 }
 
 // ---- optional per-launch timing with HIP events on the launch stream (bench.py roofline) ----
@@ -236,7 +242,7 @@ int launch_cfg(const IaGemm& g, hipStream_t stream) {
     attr_set = true;
   }
   const int tiles = ((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN);
-  dim3 grid(tiles, 1, MODE == IA_GEMM_TN ? g.splits : 1);
+  dim3 grid(tiles * (MODE == IA_GEMM_TN ? g.splits : 1));
   const bool prof = g_prof_on && g_prof_n < PROF_POOL;
   if (prof) (void)hipEventRecord(g_prof_ev[g_prof_n][0], stream);
   hipLaunchKernelGGL(kern, grid, dim3(NT), smem, stream, g);

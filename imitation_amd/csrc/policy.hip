@@ -1186,6 +1186,13 @@ __global__ __launch_bounds__(PREP_THREADS) void ppo_apply_kernel(
   const PolOff o = pol_offsets(D, d.act_dim, H, d.discrete);
   const PpoWs w = ppo_ws(ws, nblk, o.total);
   const int tid = threadIdx.x;
+  // Block 1 (when launched) computes the NEXT minibatch's statistics concurrently with block 0's
+  // reduce / clip / Adam: the two halves touch disjoint state (advstat + RunningNorm vs parameters).
+  if (blockIdx.x == 1) {
+    if (next_batch > 0)
+      prepare_stats(d, obs, adv, next_idx, next_batch, T, n_envs, update_norm, nm, nv, ncount, w.advstat, lds);
+    return;
+  }
   float sq = 0.f;
   for (int i = tid; i < o.total; i += PREP_THREADS) {
     float g;
@@ -1246,7 +1253,7 @@ __global__ __launch_bounds__(PREP_THREADS) void ppo_apply_kernel(
     tr(o.pW1, H, D); tr(o.pW2, H, H); tr(o.vW1, H, D); tr(o.vW2, H, H);
     Pt[dst] = pn;
   }
-  if (next_batch > 0) {
+  if (next_batch > 0 && gridDim.x == 1) {
     __syncthreads();
     prepare_stats(d, obs, adv, next_idx, next_batch, T, n_envs, update_norm, nm, nv, ncount, w.advstat, lds);
   }
@@ -1474,7 +1481,8 @@ int launch_minibatch_next(const PpoArgs& a, int batch, float step_size, float bc
   static bool attr = false;
   const size_t bytes = PREP_LDS_FLOATS * sizeof(float);
   if (!attr) { rc = set_lds(ppo_apply_kernel, bytes); if (rc) return rc; attr = true; }
-  hipLaunchKernelGGL(ppo_apply_kernel, dim3(1), dim3(PREP_THREADS), bytes, a.st, *a.d, a.params, a.params_t, a.exp_avg,
+  hipLaunchKernelGGL(ppo_apply_kernel, dim3(next_batch > 0 ? 2 : 1), dim3(PREP_THREADS), bytes, a.st, *a.d, a.params,
+                     a.params_t, a.exp_avg,
                      a.exp_avg_sq, a.ws, cdiv(batch, ROWS), batch, a.max_grad_norm, a.ent_coef, a.vf_coef, a.beta1,
                      a.beta2, a.adam_eps, step_size, bc2_sqrt, stats, nxt.obs, nxt.advantages, nullptr, next_batch, a.T,
                      a.n_envs, a.update_norm, a.norm_mean, a.norm_var, a.norm_count, 3);
