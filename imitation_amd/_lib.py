@@ -29,6 +29,24 @@ class PolicyDesc(C.Structure):
                 ("has_norm", C.c_int), ("norm_eps", C.c_float)]
 
 
+class DiscStepArgs(C.Structure):
+    """Mirror of `ia_disc_step_args` (include/imitation_hip.h)."""
+    _fields_ = ([("desc", C.POINTER(MlpDesc))] +
+                [(n, C.c_void_p) for n in ("params", "grads", "exp_avg", "exp_avg_sq", "norm_mean", "norm_var",
+                                           "norm_count")] +
+                [("norm_eps", C.c_float), ("update_norm", C.c_int)] +
+                [(n, C.c_void_p) for n in ("obs0", "act0_f32", "act0_i64", "next0", "done0", "idx0")] + [("n0", C.c_int)] +
+                [(n, C.c_void_p) for n in ("obs1", "act1_f32", "act1_i64", "next1", "done1", "idx1")] + [("n1", C.c_int)] +
+                [(n, C.c_int) for n in ("obs_dim", "act_dim", "use_state", "use_action", "use_next_state", "use_done",
+                                        "n_expert")] + [("loss_scale", C.c_float)] +
+                [("X", C.c_void_p), ("Xn", C.c_void_p), ("ldx", C.c_int)] +
+                [(n, C.c_void_p) for n in ("hidden", "dhidden", "logits", "dlogits", "partials")] + [("splits", C.c_int)] +
+                [(n, C.c_void_p) for n in ("rn_ws", "bce_ws", "stats")] +
+                [("accumulate", C.c_int), ("adam", C.c_int)] +
+                [(n, C.c_float) for n in ("beta1", "beta2", "adam_eps", "weight_decay", "step_size", "bc2_sqrt")] +
+                [(n, C.c_void_p) for n in ("pnorm_mean", "pnorm_var", "pnorm_count")] + [("pnorm_dim", C.c_int)])
+
+
 class HipExtensionMissing(RuntimeError):
     pass
 
@@ -49,10 +67,13 @@ _SIGS = {
     "ia_running_norm_ws_floats": ([_I, _I], C.c_int64),
     "ia_running_norm_update": ([_P, _I, _I, _I, _P, _P, _P, _P, _P], C.c_int),
     "ia_running_norm_partial": ([_P, _I, _I, _I, _P, _P], C.c_int),
-    "ia_running_norm_merge": ([_P, _I, _I, _I, _P, _P, _P, _P], C.c_int),
+    "ia_running_norm_merge": ([_P, _I, _I, _I, _I, _P, _P, _P, _P], C.c_int),
     "ia_running_norm_apply": ([_P, _I, _I, _I, _P, _P, _F, _P, _I, _P], C.c_int),
     "ia_gather_concat": ([_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _I, _I, _P], C.c_int),
-    "ia_bce_logits": ([_P, _I, _I, _F, _P, _P, _P], C.c_int),
+    "ia_bce_ws_floats": ([_I], C.c_int64),
+    "ia_bce_logits": ([_P, _I, _I, _F, _P, _P, _P, _P], C.c_int),
+    "ia_reduce_partials_adam": ([_P, _I, _L, _F, _P, _P, _P, _P, _F, _F, _F, _F, _F, _F, _P], C.c_int),
+    "ia_disc_step_basic": ([C.POINTER(DiscStepArgs), _P], C.c_int),
     "ia_airl_logits": ([_P, _P, _P, _P, _P, _F, _I, _P, _P], C.c_int),
     "ia_airl_route_grad": ([_P, _P, _F, _I, _P, _P, _P, _P], C.c_int),
     "ia_gather_rows": ([_P, _P, _I, _I, _P, _P], C.c_int),

@@ -169,6 +169,7 @@ class AdversarialTrainer(abc.ABC):
         self._in_overlap = False
         self._overlap_k = 0
         self._quirk_pending = []
+        self._quirk_slots = []
 
         B = self.demo_batch_size
         nq = max(1, self.n_disc_updates_per_round)
@@ -177,6 +178,7 @@ class AdversarialTrainer(abc.ABC):
         self._idx_host = th.zeros(2, B, dtype=th.int64).pin_memory()
         self._idx_dev = th.zeros(2, B, dtype=th.int64, device=self._device)
         self._stats_dev = th.zeros(8, device=self._device)
+        self._bce_ws = th.zeros(int(L.load().ia_bce_ws_floats(2 * self.demo_minibatch_size)), device=self._device)
         self._dlogits = th.zeros(2 * self.demo_minibatch_size, device=self._device)
         self._logp = th.zeros(2 * self.demo_minibatch_size, device=self._device)
         od = int(np.prod(venv.observation_space.shape))
@@ -324,23 +326,56 @@ class AdversarialTrainer(abc.ABC):
             scale = mb / B
             net = self._reward_net
             first = True
+            fused_step = False
+            # single minibatch, HIP Adam, no cross-rank exchange: reduce + Adam in one launch
+            single = self._dp is None or self._dp.world == 1
+            fuse_adam = self._disc_opt if (isinstance(self._disc_opt, HipAdam) and single) else None
+            basic = net
+            while isinstance(basic, reward_nets.PredictProcessedWrapper):
+                basic = basic.base
+            c_path = (isinstance(basic, reward_nets.BasicRewardNet) and not self._needs_logp and single
+                      and self._torch_opt_params is None)
+            pol = self.policy
+            prn = pol.features_extractor.normalize if isinstance(pol, ActorCriticPolicy) else None
             for start in range(0, B, mb):
                 sl = lambda idx: None if idx is None else idx[start:start + mb]
                 e_src = (e_tab if e_idx is not None else _slice_table(e_tab, start, mb), sl(e_idx), mb)
                 g_src = (g_tab if g_idx is not None else _slice_table(g_tab, start, mb), sl(g_idx), mb)
                 sources = [e_src, g_src]
-                logp = self._policy_pass(sources, mb)
-                logits = net.disc_forward(sources, mb, logp)
-                L.call("ia_bce_logits", L.ptr(logits), 2 * mb, mb, scale, L.ptr(self._dlogits), L.ptr(self._stats_dev),
-                       L.stream())
-                net.disc_backward(self._dlogits, accumulate=not first)
+                last = start + mb >= B
+                if c_path:
+                    # policy feature-norm side effect (App. C.2): when the discriminator's own input norm
+                    # updates on a state-first batch, its slab moments cover the observation columns and
+                    # are reused; otherwise the explicit pass below gathers the observations.
+                    reuse = (prn is not None and pol.training and basic.use_state and basic.mlp.norm is not None
+                             and basic.mlp.training)
+                    if prn is not None and pol.training and not reuse:
+                        self._policy_pass(sources, mb)
+                    inline = reuse and not self._in_overlap
+                    ws = basic.disc_step_c(sources, mb, scale, self._stats_dev, self._bce_ws, accumulate=not first,
+                                           adam=fuse_adam if last else None, pnorm=prn if inline else None,
+                                           pnorm_dim=pol.obs_dim if inline else 0)
+                    if reuse and self._in_overlap:  # replayed on the generator stream after the PPO update
+                        slot = self._quirk_moment_slot(ws["rn_ws"].numel())
+                        slot.copy_(ws["rn_ws"])
+                        self._quirk_pending.append((slot, 2 * mb, basic.mlp.dims[0]))
+                    logits = ws["out"].reshape(-1)
+                    fused_step = fused_step or (last and fuse_adam is not None)
+                else:
+                    logp = self._policy_pass(sources, mb)
+                    logits = net.disc_forward(sources, mb, logp)
+                    L.call("ia_bce_logits", L.ptr(logits), 2 * mb, mb, scale, L.ptr(self._dlogits),
+                           L.ptr(self._stats_dev), L.ptr(self._bce_ws), L.stream())
+                    fused_step = bool(net.disc_backward(self._dlogits, accumulate=not first,
+                                                        adam=fuse_adam if (B == mb) else None))
                 first = False
             if self._dp is not None:  # one flat-bucket all-reduce per discriminator step
                 self._dp.allreduce_mean_(net._store.grad)
             if self._torch_opt_params is not None:
                 for p, (_, gview) in zip(self._torch_opt_params, _named_grads(net)):
                     p.grad = gview
-            self._disc_opt.step()
+            if not fused_step:
+                self._disc_opt.step()
             self._disc_step += 1
             self._last_disc_logits = logits
             s = self._stats_dev.cpu().numpy()  # the one host sync of a discriminator update
@@ -370,10 +405,26 @@ class AdversarialTrainer(abc.ABC):
             else:
                 self._gen_replay_buffer.store(gen_samples)
 
+    def _quirk_moment_slot(self, numel: int) -> th.Tensor:
+        """Persistent per-update buffer for the slab moments replayed after the PPO update."""
+        k = len(self._quirk_pending)
+        while len(self._quirk_slots) <= k:
+            self._quirk_slots.append(th.empty(numel, device=self._device))
+        if self._quirk_slots[k].numel() != numel:
+            self._quirk_slots[k] = th.empty(numel, device=self._device)
+        return self._quirk_slots[k]
+
     def _replay_policy_norm_updates(self) -> None:
         """Deferred `_policy_pass` side effects, in order, on the current (generator) stream."""
         pol = self.policy
-        for sources in self._quirk_pending:
+        for item in self._quirk_pending:
+            if isinstance(item, tuple):  # (slab moments of the batch, rows, moment column count)
+                slot, rows, ld = item
+                rn = pol.features_extractor.normalize
+                L.call("ia_running_norm_merge", L.ptr(slot), 1, rows, pol.obs_dim, ld, L.ptr(rn.running_mean),
+                       L.ptr(rn.running_var), L.ptr(rn.count), L.stream())
+                continue
+            sources = item
             row = 0
             for table, idx, n in sources:
                 networks.gather_concat(table, idx, n, pol.obs_dim, pol.act_dim, (True, False, False, False),

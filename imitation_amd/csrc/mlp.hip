@@ -48,6 +48,37 @@ __global__ void reduce_partials_kernel(const float* __restrict__ partials, int s
   grads[i] = accumulate ? grads[i] + s : s;
 }
 
+// split-K slab reduction fused with the Adam step (single minibatch, single GPU): the reduced
+// gradient is also written out (it is the flat gradient the API exposes).
+__global__ void reduce_adam_kernel(const float* __restrict__ partials, int splits, long long n, float scale,
+                                   float* __restrict__ grads, float* __restrict__ p, float* __restrict__ m,
+                                   float* __restrict__ v, float beta1, float beta2, float eps, float wd,
+                                   float step_size, float bc2_sqrt) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float s = 0.f;
+  int k = 0;
+  for (; k + 8 <= splits; k += 8) {
+    float t[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) t[u] = partials[(long long)(k + u) * n + i];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s += t[u];
+  }
+  for (; k < splits; ++k) s += partials[(long long)k * n + i];
+  float grad = s * scale;
+  grads[i] = grad;
+  const float pi = p[i];
+  if (wd != 0.f) grad = grad + wd * pi;
+  float mi = m[i];
+  mi = mi + (grad - mi) * (1.f - beta1);
+  const float vi = v[i] * beta2 + (1.f - beta2) * grad * grad;
+  const float denom = sqrtf(vi) / bc2_sqrt + eps;
+  p[i] = pi - step_size * (mi / denom);
+  m[i] = mi;
+  v[i] = vi;
+}
+
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                             float* __restrict__ v, long long n, float beta1, float beta2, float eps, float wd,
                             float step_size, float bc2_sqrt) {
@@ -113,36 +144,38 @@ __global__ __launch_bounds__(256) void rn_partial_kernel(const float* __restrict
   }
 }
 
+// Chan combination of two (count, mean, M2) moment triples.
+__device__ __forceinline__ void chan_combine(float& n, float& m, float& M2, float nb, float mb, float qb) {
+  if (nb == 0.f) return;
+  const float tot = n + nb;
+  const float dlt = mb - m;
+  M2 = M2 + qb + dlt * dlt * n * nb / tot;
+  m = m + dlt * nb / tot;
+  n = tot;
+}
+
 // `nblocks` slabs in groups of `bpg` (one group per data-parallel rank, each covering `rpg` rows);
-// R = total rows = groups * rpg.
-__global__ void rn_merge_kernel(const float* __restrict__ ws, int nblocks, int bpg, int rpg, int R, int D,
-                                float* __restrict__ mean, float* __restrict__ var, int32_t* __restrict__ count) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+// R = total rows. One WAVE per column: lane l folds slabs l, l+64, ... sequentially, then a fixed
+// butterfly (xor 32,16,...,1) combines the 64 partial triples -> deterministic, ~3 us instead of a
+// 64-deep chain of dependent global loads. `ws_ld` = column count the slab moments were written with.
+__global__ __launch_bounds__(64) void rn_merge_kernel(const float* __restrict__ ws, int nblocks, int bpg, int rpg,
+                                                      int R, int D, int ws_ld, float* __restrict__ mean,
+                                                      float* __restrict__ var, int32_t* __restrict__ count,
+                                                      int bump_count) {
+  const int c = blockIdx.x, lane = threadIdx.x;
   const int cnt = *count;
-  if (c < D) {
-    // Chan merge of slab moments -> batch mean / biased variance
-    float n_acc = 0.f, m_acc = 0.f, M2 = 0.f;
-    for (int b0 = 0; b0 < nblocks; b0 += 8) {  // slab moments are fetched 8 at a time (independent loads)
-      float mbv[8], qbv[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int b = min(b0 + u, nblocks - 1);
-        mbv[u] = ws[((long long)b * 2 + 0) * D + c];
-        qbv[u] = ws[((long long)b * 2 + 1) * D + c];
-      }
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int b = b0 + u;
-        if (b < nblocks) {
-          const float nb = (float)min(RN_ROWS_PER_BLOCK, rpg - (b % bpg) * RN_ROWS_PER_BLOCK);
-          const float tot = n_acc + nb;
-          const float dlt = mbv[u] - m_acc;
-          M2 = M2 + qbv[u] + dlt * dlt * n_acc * nb / tot;
-          m_acc = m_acc + dlt * nb / tot;
-          n_acc = tot;
-        }
-      }
-    }
+  float n_acc = 0.f, m_acc = 0.f, M2 = 0.f;
+  for (int b = lane; b < nblocks; b += 64) {
+    const float nb = (float)min(RN_ROWS_PER_BLOCK, rpg - (b % bpg) * RN_ROWS_PER_BLOCK);
+    chan_combine(n_acc, m_acc, M2, nb, ws[((long long)b * 2 + 0) * ws_ld + c], ws[((long long)b * 2 + 1) * ws_ld + c]);
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    const float nb = __shfl_xor(n_acc, o, 64), mb = __shfl_xor(m_acc, o, 64), qb = __shfl_xor(M2, o, 64);
+    // both partners must compute the identical combination: order the pair by lane id
+    if ((lane & o) == 0) chan_combine(n_acc, m_acc, M2, nb, mb, qb);
+    else { float n2 = nb, m2 = mb, q2 = qb; chan_combine(n2, m2, q2, n_acc, m_acc, M2); n_acc = n2; m_acc = m2; M2 = q2; }
+  }
+  if (lane == 0) {
     const float b_mean = m_acc, b_var = M2 / (float)R;
     // util/networks.py:123-134, same operation order
     const float fcount = (float)cnt, fn = (float)R;
@@ -154,8 +187,13 @@ __global__ void rn_merge_kernel(const float* __restrict__ ws, int nblocks, int b
     rv = rv + delta * delta * fcount * fn / tot;
     var[c] = rv / tot;
   }
-  __syncthreads();
-  if (blockIdx.x == 0 && threadIdx.x == 0) *count = cnt + R;
+  // the count is bumped by a separate 1-thread launch-free path: the LAST column's wave does it after
+  // every column has read `cnt`... columns run in different blocks, so do it in a tiny follow-up kernel.
+  (void)bump_count;
+}
+
+__global__ void rn_count_kernel(int32_t* __restrict__ count, int R) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) *count += R;
 }
 
 __global__ void rn_apply_kernel(const float* __restrict__ X, int ldx, int R, int D, const float* __restrict__ mean,
@@ -211,32 +249,43 @@ __global__ void gather_rows_kernel(const float* __restrict__ src, const int64_t*
   dst[e] = src[idx[i] * width + c];
 }
 
-// BCE-with-logits, its gradient and the discriminator statistics in one pass by one block.
-__global__ __launch_bounds__(1024) void bce_kernel(const float* __restrict__ logits, int R, int n_expert,
-                                                   float scale, float* __restrict__ dlogits,
-                                                   float* __restrict__ stats) {
-  __shared__ float red[6][16];
-  float loss = 0.f, correct = 0.f, correct_e = 0.f, correct_g = 0.f, pred_gen = 0.f, ent = 0.f;
+// BCE-with-logits, its gradient and the discriminator statistics. Blocks of 256 threads own 1024
+// rows each and write 6 partial sums; the block that draws the last ticket folds the partials in
+// block order (deterministic) and resets the ticket. Hand-off per the gfx950 rules: plain stores ->
+// __syncthreads -> one-lane agent-scope release (+ explicit vmcnt(0)) -> relaxed ticket; last block:
+// one-lane agent-scope acquire -> __syncthreads -> plain loads.
+constexpr int BCE_ROWS_PER_BLOCK = 1024;
+
+__global__ __launch_bounds__(256) void bce_kernel(const float* __restrict__ logits, int R, int n_expert, float scale,
+                                                  float* __restrict__ dlogits, float* __restrict__ stats,
+                                                  float* __restrict__ part /*[nblk][8]*/,
+                                                  unsigned int* __restrict__ ticket) {
+  __shared__ float red[6][4];
+  __shared__ int is_last;
+  float vals[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};  // loss, correct, correct_e, correct_g, pred_gen, entropy
   const float inv = scale / (float)R;
-  for (int i = threadIdx.x; i < R; i += blockDim.x) {
-    const float x = logits[i];
-    const float y = i < n_expert ? 1.f : 0.f;
-    const float lse = log1pf(expf(-fabsf(x)));
-    // (1-y)*x - logsigmoid(x), logsigmoid(x) = min(x,0) - log1p(exp(-|x|))
-    loss += (1.f - y) * x - (fminf(x, 0.f) - lse);
-    const float p = 1.f / (1.f + expf(-x));
-    if (dlogits) dlogits[i] = (p - y) * inv;
-    const bool is_gen_pred = x < 0.f;
-    const bool is_gen_true = y == 0.f;
-    const bool ok = is_gen_pred == is_gen_true;
-    correct += ok ? 1.f : 0.f;
-    correct_e += (ok && !is_gen_true) ? 1.f : 0.f;
-    correct_g += (ok && is_gen_true) ? 1.f : 0.f;
-    pred_gen += is_gen_pred ? 1.f : 0.f;
-    // Bernoulli(logits=x).entropy() = BCEWithLogits(x, target=sigmoid(x))
-    ent += (1.f - p) * x - (fminf(x, 0.f) - lse);
+  const int r0 = blockIdx.x * BCE_ROWS_PER_BLOCK;
+#pragma unroll
+  for (int u = 0; u < BCE_ROWS_PER_BLOCK / 256; ++u) {
+    const int i = r0 + u * 256 + threadIdx.x;
+    if (i < R) {
+      const float x = logits[i];
+      const float y = i < n_expert ? 1.f : 0.f;
+      const float lse = log1pf(expf(-fabsf(x)));
+      // (1-y)*x - logsigmoid(x), logsigmoid(x) = min(x,0) - log1p(exp(-|x|))
+      vals[0] += (1.f - y) * x - (fminf(x, 0.f) - lse);
+      const float p = 1.f / (1.f + expf(-x));
+      if (dlogits) dlogits[i] = (p - y) * inv;
+      const bool is_gen_pred = x < 0.f, is_gen_true = y == 0.f;
+      const bool ok = is_gen_pred == is_gen_true;
+      vals[1] += ok ? 1.f : 0.f;
+      vals[2] += (ok && !is_gen_true) ? 1.f : 0.f;
+      vals[3] += (ok && is_gen_true) ? 1.f : 0.f;
+      vals[4] += is_gen_pred ? 1.f : 0.f;
+      // Bernoulli(logits=x).entropy() = BCEWithLogits(x, target=sigmoid(x))
+      vals[5] += (1.f - p) * x - (fminf(x, 0.f) - lse);
+    }
   }
-  float vals[6] = {loss, correct, correct_e, correct_g, pred_gen, ent};
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 #pragma unroll
   for (int k = 0; k < 6; ++k) {
@@ -245,15 +294,29 @@ __global__ __launch_bounds__(1024) void bce_kernel(const float* __restrict__ log
     if (lane == 0) red[k][wv] = v;
   }
   __syncthreads();
+  if (threadIdx.x < 6)
+    part[blockIdx.x * 8 + threadIdx.x] = red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] +
+                                         red[threadIdx.x][3];
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned int t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    is_last = (t == gridDim.x - 1);
+    if (is_last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  }
+  __syncthreads();
+  if (!is_last) return;
   if (threadIdx.x < 6) {
     float t = 0.f;
-    const int nw = blockDim.x >> 6;
-    for (int w = 0; w < nw; ++w) t += red[threadIdx.x][w];
+    for (unsigned int b = 0; b < gridDim.x; ++b) t += part[b * 8 + threadIdx.x];  // fixed block order
     if (threadIdx.x == 0) t = t / (float)R * scale;
     stats[threadIdx.x] = t;
   }
   if (threadIdx.x == 6) stats[6] = (float)n_expert;
   if (threadIdx.x == 7) stats[7] = (float)(R - n_expert);
+  if (threadIdx.x == 0) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 __global__ void airl_logits_kernel(const float* __restrict__ g, const float* __restrict__ h_cur,
@@ -435,6 +498,17 @@ int ia_reduce_partials(const float* partials, int splits, int64_t n, float scale
   return IA_OK;
 }
 
+int ia_reduce_partials_adam(const float* partials, int splits, int64_t n, float scale, float* grads, float* params,
+                            float* exp_avg, float* exp_avg_sq, float beta1, float beta2, float eps,
+                            float weight_decay, float step_size, float bc2_sqrt, void* stream) {
+  if (n <= 0 || splits < 1) return IA_ERR_ARG;
+  hipLaunchKernelGGL(reduce_adam_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, partials, splits,
+                     (long long)n, scale, grads, params, exp_avg, exp_avg_sq, beta1, beta2, eps, weight_decay, step_size,
+                     bc2_sqrt);
+  IA_CHECK_LAUNCH();
+  return IA_OK;
+}
+
 int ia_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float beta1,
                  float beta2, float eps, float weight_decay, float step_size, float bc2_sqrt, void* stream) {
   if (n <= 0) return IA_ERR_ARG;
@@ -454,8 +528,10 @@ int ia_running_norm_update(const float* X, int ldx, int R, int D, float* mean, f
   const int nb = cdiv(R, RN_ROWS_PER_BLOCK);
   hipLaunchKernelGGL(rn_partial_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, X, ldx, R, D, ws);
   IA_CHECK_LAUNCH();
-  hipLaunchKernelGGL(rn_merge_kernel, dim3(cdiv(D, 64)), dim3(64), 0, (hipStream_t)stream, ws, nb, nb, R, R, D, mean,
-                     var, count);
+  hipLaunchKernelGGL(rn_merge_kernel, dim3(D), dim3(64), 0, (hipStream_t)stream, ws, nb, nb, R, R, D, D, mean, var,
+                     count, 0);
+  IA_CHECK_LAUNCH();
+  hipLaunchKernelGGL(rn_count_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, count, R);
   IA_CHECK_LAUNCH();
   return IA_OK;
 }
@@ -468,12 +544,14 @@ int ia_running_norm_partial(const float* X, int ldx, int R, int D, float* ws, vo
   return IA_OK;
 }
 
-int ia_running_norm_merge(const float* ws_all, int groups, int rows_per_group, int D, float* mean, float* var,
-                          int32_t* count, void* stream) {
-  if (groups <= 0 || rows_per_group <= 0 || D <= 0) return IA_ERR_ARG;
+int ia_running_norm_merge(const float* ws_all, int groups, int rows_per_group, int D, int ws_ld, float* mean,
+                          float* var, int32_t* count, void* stream) {
+  if (groups <= 0 || rows_per_group <= 0 || D <= 0 || ws_ld < D) return IA_ERR_ARG;
   const int bpg = cdiv(rows_per_group, RN_ROWS_PER_BLOCK);
-  hipLaunchKernelGGL(rn_merge_kernel, dim3(cdiv(D, 64)), dim3(64), 0, (hipStream_t)stream, ws_all, groups * bpg, bpg,
-                     rows_per_group, groups * rows_per_group, D, mean, var, count);
+  hipLaunchKernelGGL(rn_merge_kernel, dim3(D), dim3(64), 0, (hipStream_t)stream, ws_all, groups * bpg, bpg,
+                     rows_per_group, groups * rows_per_group, D, ws_ld, mean, var, count, 0);
+  IA_CHECK_LAUNCH();
+  hipLaunchKernelGGL(rn_count_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, count, groups * rows_per_group);
   IA_CHECK_LAUNCH();
   return IA_OK;
 }
@@ -501,12 +579,63 @@ int ia_gather_concat(const float* obs, const float* act_f32, const int64_t* act_
   return IA_OK;
 }
 
-int ia_bce_logits(const float* logits, int R, int n_expert, float scale, float* dlogits, float* stats,
+int64_t ia_bce_ws_floats(int R) { return (int64_t)cdiv(R, BCE_ROWS_PER_BLOCK) * 8 + 8; }
+
+int ia_bce_logits(const float* logits, int R, int n_expert, float scale, float* dlogits, float* stats, float* ws,
                   void* stream) {
-  if (R <= 0 || n_expert < 0 || n_expert > R) return IA_ERR_ARG;
-  hipLaunchKernelGGL(bce_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, logits, R, n_expert, scale, dlogits,
-                     stats);
+  if (R <= 0 || n_expert < 0 || n_expert > R || !ws) return IA_ERR_ARG;
+  const int nblk = cdiv(R, BCE_ROWS_PER_BLOCK);
+  // ws: [nblk][8] partials followed by the ticket word (must be zero before the first call; the
+  // kernel leaves it at zero)
+  hipLaunchKernelGGL(bce_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, logits, R, n_expert, scale, dlogits,
+                     stats, ws, reinterpret_cast<unsigned int*>(ws + (long long)nblk * 8));
   IA_CHECK_LAUNCH();
+  return IA_OK;
+}
+
+int ia_disc_step_basic(const ia_disc_step_args* a, void* stream) {
+  if (!a || !desc_ok(a->desc) || a->n0 < 0 || a->n1 < 0 || a->n0 + a->n1 <= 0) return IA_ERR_ARG;
+  const int R = a->n0 + a->n1;
+  const int D = a->desc->dims[0];
+  int rc;
+  if (a->n0 > 0 &&
+      (rc = ia_gather_concat(a->obs0, a->act0_f32, a->act0_i64, a->next0, a->done0, a->idx0, a->n0, a->obs_dim,
+                             a->act_dim, a->use_state, a->use_action, a->use_next_state, a->use_done, a->X, a->ldx, 0,
+                             stream)))
+    return rc;
+  if (a->n1 > 0 &&
+      (rc = ia_gather_concat(a->obs1, a->act1_f32, a->act1_i64, a->next1, a->done1, a->idx1, a->n1, a->obs_dim,
+                             a->act_dim, a->use_state, a->use_action, a->use_next_state, a->use_done, a->X, a->ldx,
+                             a->n0, stream)))
+    return rc;
+  const float* in = a->X;
+  if (a->norm_mean) {
+    if (a->update_norm) {
+      if ((rc = ia_running_norm_partial(a->X, a->ldx, R, D, a->rn_ws, stream))) return rc;
+      if ((rc = ia_running_norm_merge(a->rn_ws, 1, R, D, D, a->norm_mean, a->norm_var, a->norm_count, stream)))
+        return rc;
+      if (a->pnorm_mean && a->pnorm_dim > 0 && a->pnorm_dim <= D &&
+          (rc = ia_running_norm_merge(a->rn_ws, 1, R, a->pnorm_dim, D, a->pnorm_mean, a->pnorm_var, a->pnorm_count,
+                                      stream)))
+        return rc;
+    }
+    if ((rc = ia_running_norm_apply(a->X, a->ldx, R, D, a->norm_mean, a->norm_var, a->norm_eps, a->Xn, a->ldx, stream)))
+      return rc;
+    in = a->Xn;
+  }
+  if ((rc = ia_mlp_forward(a->desc, a->params, in, a->ldx, R, a->hidden, a->logits, IA_ACT_NONE, stream))) return rc;
+  if ((rc = ia_bce_logits(a->logits, R, a->n_expert, a->loss_scale, a->dlogits, a->stats, a->bce_ws, stream))) return rc;
+  if ((rc = ia_mlp_backward(a->desc, a->params, in, a->ldx, R, a->hidden, a->dlogits, a->dhidden, a->partials, a->splits,
+                            nullptr, stream)))
+    return rc;
+  const int64_t P = ia_mlp_param_count(a->desc);
+  if (a->adam && !a->accumulate)
+    return ia_reduce_partials_adam(a->partials, a->splits, P, 1.0f, a->grads, a->params, a->exp_avg, a->exp_avg_sq,
+                                   a->beta1, a->beta2, a->adam_eps, a->weight_decay, a->step_size, a->bc2_sqrt, stream);
+  if ((rc = ia_reduce_partials(a->partials, a->splits, P, 1.0f, a->accumulate, a->grads, stream))) return rc;
+  if (a->adam)
+    return ia_adam_step(a->params, a->grads, a->exp_avg, a->exp_avg_sq, P, a->beta1, a->beta2, a->adam_eps,
+                        a->weight_decay, a->step_size, a->bc2_sqrt, stream);
   return IA_OK;
 }
 

@@ -107,7 +107,7 @@ class RunningNorm:
             # every rank contributes R rows: all-gather the slab moments, identical merge everywhere
             L.call("ia_running_norm_partial", L.ptr(x), ld, R, self.num_features, L.ptr(self._ws), L.stream())
             ws_all = self.dp.all_gather_flat(self._ws)
-            L.call("ia_running_norm_merge", L.ptr(ws_all), self.dp.world, R, self.num_features,
+            L.call("ia_running_norm_merge", L.ptr(ws_all), self.dp.world, R, self.num_features, self.num_features,
                    L.ptr(self.running_mean), L.ptr(self.running_var), L.ptr(self.count), L.stream())
             return
         L.call("ia_running_norm_update", L.ptr(x), ld, R, self.num_features, L.ptr(self.running_mean),
@@ -261,12 +261,18 @@ class DenseStack:
         return ws["out"]
 
     def backward_rows(self, ws: Dict[str, th.Tensor], R: int, d_out: th.Tensor, accumulate: bool,
-                      scale: float = 1.0) -> None:
+                      scale: float = 1.0, adam: Optional["HipAdam"] = None) -> None:
         """Back-propagates `d_out[R, out]` through the activations saved by `forward_rows` and
-        (accumulates) the parameter gradient into `self.grad`."""
+        (accumulates) the parameter gradient into `self.grad`. With `adam` (only when this stack IS
+        the whole optimised buffer and nothing is accumulated) the split-K reduction and the Adam step
+        run as one launch."""
         L.call("ia_mlp_backward", C.byref(self.desc), L.ptr(self.flat), L.ptr(ws["_in"]), self.ldx, R,
                L.ptr(ws["hidden"]), L.ptr(d_out), L.ptr(ws["dhidden"]), L.ptr(ws["partials"]), ws["splits"], None,
                L.stream())
+        if adam is not None:
+            assert not accumulate and adam.flat.data_ptr() == self.flat.data_ptr() and adam.flat.numel() == self.n_params
+            adam.fused_reduce_step(ws["partials"], ws["splits"], scale)
+            return
         L.call("ia_reduce_partials", L.ptr(ws["partials"]), ws["splits"], self.n_params, scale, int(accumulate),
                L.ptr(self.grad), L.stream())
 
@@ -320,6 +326,17 @@ class HipAdam:
         bc2 = 1.0 - b2 ** self.step_count
         L.call("ia_adam_step", L.ptr(self.flat), L.ptr(self.grad), L.ptr(self.exp_avg), L.ptr(self.exp_avg_sq),
                self.flat.numel(), b1, b2, g["eps"], g["weight_decay"], g["lr"] / bc1, bc2 ** 0.5, L.stream())
+
+    def fused_reduce_step(self, partials: th.Tensor, splits: int, scale: float) -> None:
+        """grad = scale * sum_s partials[s]; then the Adam step -- one launch."""
+        g = self.param_groups[0]
+        self.step_count += 1
+        b1, b2 = g["betas"]
+        bc1 = 1.0 - b1 ** self.step_count
+        bc2 = 1.0 - b2 ** self.step_count
+        L.call("ia_reduce_partials_adam", L.ptr(partials), splits, self.flat.numel(), scale, L.ptr(self.grad),
+               L.ptr(self.flat), L.ptr(self.exp_avg), L.ptr(self.exp_avg_sq), b1, b2, g["eps"], g["weight_decay"],
+               g["lr"] / bc1, bc2 ** 0.5, L.stream())
 
     def state_dict(self):
         return {"state": {0: {"step": self.step_count, "exp_avg": self.exp_avg, "exp_avg_sq": self.exp_avg_sq}},

@@ -189,7 +189,8 @@ class RewardNet(abc.ABC):
     def disc_forward(self, sources, mb_rows: int, logp: Optional[th.Tensor]) -> th.Tensor:
         raise NotImplementedError(f"{type(self).__name__} cannot be trained as a discriminator on the HIP path")
 
-    def disc_backward(self, d_logits: th.Tensor, accumulate: bool) -> None:
+    def disc_backward(self, d_logits: th.Tensor, accumulate: bool, adam=None) -> bool:
+        """Returns True when the optimiser step was fused into the backward (see `DenseStack`)."""
         raise NotImplementedError
 
 
@@ -241,8 +242,71 @@ class BasicRewardNet(RewardNet):
         self._disc_ws, self._disc_R = ws, R
         return self.mlp.forward_rows(ws, R).reshape(R)
 
-    def disc_backward(self, d_logits, accumulate):
-        self.mlp.backward_rows(self._disc_ws, self._disc_R, d_logits, accumulate)
+    def disc_backward(self, d_logits, accumulate, adam=None):
+        fuse = adam is not None and not accumulate and self._store.flat.numel() == self.mlp.n_params
+        self.mlp.backward_rows(self._disc_ws, self._disc_R, d_logits, accumulate, adam=adam if fuse else None)
+        return fuse
+
+    def disc_step_c(self, sources, n_expert: int, loss_scale: float, stats: th.Tensor, bce_ws: th.Tensor,
+                    accumulate: bool, adam=None, pnorm: Optional[RunningNorm] = None, pnorm_dim: int = 0):
+        """One discriminator minibatch through the single C entry `ia_disc_step_basic` (assemble ->
+        norm -> forward -> BCE -> backward -> reduce [-> Adam]): ONE host call instead of ~25.
+        Returns the workspace dict (logits in ws["out"], slab moments in ws["rn_ws"])."""
+        import ctypes as C
+        (t0, i0, n0), (t1, i1, n1) = sources
+        R = n0 + n1
+        mlp = self.mlp
+        ws = mlp.train_workspace(R, "disc")
+        if "dlogits" not in ws:
+            dev = mlp.flat.device
+            ws["dlogits"] = th.empty(R, device=dev)
+            ws["rn_ws"] = th.empty(max(1, int(L.load().ia_running_norm_ws_floats(R, mlp.dims[0]))), device=dev)
+            a = L.DiscStepArgs()
+            a.desc = C.pointer(mlp.desc)
+            a.obs_dim, a.act_dim = self.obs_dim, self.act_dim
+            a.use_state, a.use_action = int(self.use_state), int(self.use_action)
+            a.use_next_state, a.use_done = int(self.use_next_state), int(self.use_done)
+            a.X, a.Xn, a.ldx = L.ptr(ws["X"]), L.ptr(ws["Xn"]), mlp.ldx
+            a.hidden, a.dhidden = L.ptr(ws["hidden"]), L.ptr(ws["dhidden"])
+            a.logits, a.dlogits, a.partials = L.ptr(ws["out"]), L.ptr(ws["dlogits"]), L.ptr(ws["partials"])
+            a.splits, a.rn_ws = ws["splits"], L.ptr(ws["rn_ws"])
+            ws["args"] = a
+        a = ws["args"]
+        a.params, a.grads = L.ptr(mlp.flat), L.ptr(mlp.grad)
+        nrm = mlp.norm
+        a.norm_mean = L.ptr(nrm.running_mean) if nrm is not None else None
+        a.norm_var = L.ptr(nrm.running_var) if nrm is not None else None
+        a.norm_count = L.ptr(nrm.count) if nrm is not None else None
+        a.norm_eps = nrm.eps if nrm is not None else 0.0
+        a.update_norm = int(nrm is not None and mlp.training)
+        for k, (t, i, n) in enumerate(((t0, i0, n0), (t1, i1, n1))):
+            setattr(a, f"obs{k}", L.ptr(t.obs))
+            setattr(a, f"act{k}_f32", None if t.discrete else L.ptr(t.acts))
+            setattr(a, f"act{k}_i64", L.ptr(t.acts) if t.discrete else None)
+            setattr(a, f"next{k}", L.ptr(t.next_obs))
+            setattr(a, f"done{k}", L.ptr(t.dones))
+            setattr(a, f"idx{k}", L.ptr(i))
+            setattr(a, f"n{k}", n)
+        a.n_expert, a.loss_scale = n_expert, loss_scale
+        a.bce_ws, a.stats = L.ptr(bce_ws), L.ptr(stats)
+        a.accumulate = int(accumulate)
+        a.adam = 0
+        if adam is not None:
+            g = adam.param_groups[0]
+            adam.step_count += 1
+            b1, b2 = g["betas"]
+            a.adam = 1
+            a.exp_avg, a.exp_avg_sq = L.ptr(adam.exp_avg), L.ptr(adam.exp_avg_sq)
+            a.beta1, a.beta2, a.adam_eps, a.weight_decay = b1, b2, g["eps"], g["weight_decay"]
+            a.step_size = g["lr"] / (1.0 - b1 ** adam.step_count)
+            a.bc2_sqrt = (1.0 - b2 ** adam.step_count) ** 0.5
+        use_p = pnorm is not None and a.update_norm and self.use_state and 0 < pnorm_dim <= mlp.dims[0]
+        a.pnorm_mean = L.ptr(pnorm.running_mean) if use_p else None
+        a.pnorm_var = L.ptr(pnorm.running_var) if use_p else None
+        a.pnorm_count = L.ptr(pnorm.count) if use_p else None
+        a.pnorm_dim = pnorm_dim if use_p else 0
+        L.call("ia_disc_step_basic", C.byref(a), L.stream())
+        return ws
 
 
 class RewardNetWrapper(RewardNet):
@@ -294,8 +358,8 @@ class PredictProcessedWrapper(RewardNetWrapper):
     def disc_forward(self, sources, mb_rows, logp):
         return self.base.disc_forward(sources, mb_rows, logp)
 
-    def disc_backward(self, d_logits, accumulate):
-        return self.base.disc_backward(d_logits, accumulate)
+    def disc_backward(self, d_logits, accumulate, adam=None):
+        return self.base.disc_backward(d_logits, accumulate, adam)
 
 
 class BasicPotentialMLP:
@@ -370,7 +434,7 @@ class ShapedRewardNet(ForwardWrapper):
             raise TypeError("Non-None `log_policy_act_prob` is required for this method.")
         return self._shaped(sources, "disc", True, logp)
 
-    def disc_backward(self, d_logits, accumulate):
+    def disc_backward(self, d_logits, accumulate, adam=None):
         wg, wn, wc, aux, R = self._last
         L.call("ia_airl_route_grad", L.ptr(d_logits), L.ptr(aux["dones"]), self.discount_factor, R, L.ptr(aux["dg"]),
                L.ptr(aux["dh_cur"]), L.ptr(aux["dh_next"]), L.stream())
@@ -378,6 +442,7 @@ class ShapedRewardNet(ForwardWrapper):
         self._base.mlp.backward_rows(wg, R, aux["dg"], accumulate)
         pot.backward_rows(wn, R, aux["dh_next"], accumulate)
         pot.backward_rows(wc, R, aux["dh_cur"], True)
+        return False
 
 
 class BasicShapedRewardNet(ShapedRewardNet):

@@ -69,6 +69,12 @@ int ia_mlp_backward(const ia_mlp_desc* d, const float* params, const float* X, i
 int ia_reduce_partials(const float* partials, int splits, int64_t n, float scale, int accumulate, float* grads,
                        void* stream);
 
+/* ia_reduce_partials (accumulate = 0) fused with ia_adam_step: one launch per discriminator update
+ * when there is a single minibatch and no cross-rank all-reduce in between. */
+int ia_reduce_partials_adam(const float* partials, int splits, int64_t n, float scale, float* grads, float* params,
+                            float* exp_avg, float* exp_avg_sq, float beta1, float beta2, float eps,
+                            float weight_decay, float step_size, float bc2_sqrt, void* stream);
+
 /* torch.optim.Adam single-tensor step (adversarial/common.py:372; SB3 PPO optimiser):
  * step_size = lr/(1-b1^t), bc2_sqrt = sqrt(1-b2^t) are computed by the caller in double. */
 int ia_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float beta1,
@@ -82,10 +88,12 @@ int ia_running_norm_update(const float* X, int ldx, int R, int D, float* mean, f
 /* Data-parallel form of the update: `partial` writes per-slab (mean, M2) moments of the local
  * batch into ws (ia_running_norm_ws_floats floats); after an all-gather of the ranks' ws buffers,
  * `merge` Chan-merges all `groups` (ranks, `rows_per_group` rows each) and applies the reference
- * update with the global batch -- every rank ends with identical statistics. */
+ * update with the global batch -- every rank ends with identical statistics. `ws_ld` is the column
+ * count the moments were written with (>= D): a norm over the first D columns of a wider batch can
+ * reuse that batch's moments (GAIL: the policy's observation norm reuses the discriminator input's). */
 int ia_running_norm_partial(const float* X, int ldx, int R, int D, float* ws, void* stream);
-int ia_running_norm_merge(const float* ws_all, int groups, int rows_per_group, int D, float* mean, float* var,
-                          int32_t* count, void* stream);
+int ia_running_norm_merge(const float* ws_all, int groups, int rows_per_group, int D, int ws_ld, float* mean,
+                          float* var, int32_t* count, void* stream);
 /* util/networks.py:91: Y = (X-mean)/sqrt(var+eps); columns [D,ldy) of Y are zeroed. */
 int ia_running_norm_apply(const float* X, int ldx, int R, int D, const float* mean, const float* var, float eps,
                           float* Y, int ldy, void* stream);
@@ -102,8 +110,34 @@ int ia_gather_concat(const float* obs, const float* act_f32, const int64_t* act_
  * are labelled 1 and the rest 0; loss scaled by `scale` (= minibatch/batch); dlogits = dLoss/dlogit.
  * stats[8] = {loss, n_correct, n_correct_expert, n_correct_gen, n_pred_gen, entropy_sum,
  * n_expert, n_gen}. */
-int ia_bce_logits(const float* logits, int R, int n_expert, float scale, float* dlogits, float* stats,
+int64_t ia_bce_ws_floats(int R);
+/* ws: ia_bce_ws_floats(R) floats, zero-initialised once by the caller (the kernel restores the zero). */
+int ia_bce_logits(const float* logits, int R, int n_expert, float scale, float* dlogits, float* stats, float* ws,
                   void* stream);
+
+/* ONE call = one discriminator minibatch of adversarial/common.py:352-373 for a BasicRewardNet
+ * (GAIL): assemble [rows0 | rows1] from two transition tables, (train-mode) RunningNorm update +
+ * normalise, dense-stack forward, BCE-with-logits + statistics, backward, split-K reduction into the
+ * flat gradient (accumulate != 0: add to it), and when `adam` != 0 the Adam step fused into that
+ * reduction. Every pointer is device memory owned by the caller; nothing is allocated. */
+typedef struct {
+  const ia_mlp_desc* desc;
+  float* params; float* grads; float* exp_avg; float* exp_avg_sq;
+  float* norm_mean; float* norm_var; int32_t* norm_count; float norm_eps; int update_norm; /* mean NULL: no norm */
+  const float* obs0; const float* act0_f32; const int64_t* act0_i64; const float* next0; const uint8_t* done0;
+  const int64_t* idx0; int n0;
+  const float* obs1; const float* act1_f32; const int64_t* act1_i64; const float* next1; const uint8_t* done1;
+  const int64_t* idx1; int n1;
+  int obs_dim, act_dim, use_state, use_action, use_next_state, use_done;
+  int n_expert; float loss_scale;
+  float* X; float* Xn; int ldx; float* hidden; float* dhidden; float* logits; float* dlogits; float* partials;
+  int splits; float* rn_ws; float* bce_ws; float* stats;
+  int accumulate; int adam; float beta1, beta2, adam_eps, weight_decay, step_size, bc2_sqrt;
+  /* optional: a second RunningNorm over the first pnorm_dim columns updated with the SAME batch
+   * moments (the policy feature norm side effect); requires update_norm. */
+  float* pnorm_mean; float* pnorm_var; int32_t* pnorm_count; int pnorm_dim;
+} ia_disc_step_args;
+int ia_disc_step_basic(const ia_disc_step_args* a, void* stream);
 
 /* adversarial/airl.py:118 + rewards/reward_nets.py:701-736:
  * logits = g + gamma*(1-done)*h_next - h_cur - logp ; and the matching dOut routing. */

@@ -230,7 +230,9 @@ def test_bce_logits_and_stats(R, ne):
     loss.backward()
     ref = compute_train_stats(logits.detach(), labels.long(), loss.detach())
     dl, st = th.empty(R, device=DEV), th.empty(8, device=DEV)
-    L.call("ia_bce_logits", dptr(logits.detach()), R, ne, scale, L.ptr(dl), L.ptr(st), L.stream())
+    ws = th.zeros(int(L.load().ia_bce_ws_floats(R)), device=DEV)
+    for _ in range(2):  # twice: the ticket word must be back at zero after a call
+        L.call("ia_bce_logits", dptr(logits.detach()), R, ne, scale, L.ptr(dl), L.ptr(st), L.ptr(ws), L.stream())
     s = st.cpu().numpy()
     th.testing.assert_close(dl.cpu(), logits.grad, rtol=1e-5, atol=1e-9)
     assert abs(s[0] - ref["disc_loss"]) <= 1e-5 * max(1, abs(ref["disc_loss"]))
