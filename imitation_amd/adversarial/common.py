@@ -12,6 +12,7 @@ minibatches), Adam, train statistics, the policy log-prob pass, reward relabelli
 from __future__ import annotations
 
 import abc
+import contextlib
 import os
 from typing import Callable, Dict, Iterable, Mapping, Optional, Type
 
@@ -396,13 +397,23 @@ class AdversarialTrainer(abc.ABC):
             self.gen_algo.learn(total_timesteps=total_timesteps, reset_num_timesteps=False,
                                 callback=self.gen_callback, **learn_kwargs)
             self._global_step += 1
+        rb = getattr(self.gen_algo, "rollout_buffer", None)
+        device_rows = (isinstance(self.gen_algo, ppo.PPO) and rb is not None and rb.full
+                       and self.venv_buffering.n_transitions == rb.buffer_size * rb.n_envs)
+        store_ctx = th.cuda.stream(self._disc_stream) if self._in_overlap else contextlib.nullcontext()
+        if device_rows:
+            # the rollout tile is already in HBM: only the 8-byte row order crosses PCIe
+            order, ep_lens, _ = self.venv_buffering.pop_order_and_lens()
+            self._check_fixed_horizon(ep_lens)
+            if self._in_overlap:  # the gather reads the tile the generator stream finished BEFORE its PPO update
+                self._disc_stream.wait_event(self.gen_algo.rollout_done_event)
+            with store_ctx:
+                self._gen_replay_buffer.store_from_rollout(rb, order)
+            return
         gen_samples, ep_lens = self.venv_buffering.pop_transitions_and_lens()
         self._check_fixed_horizon(ep_lens)
         if gen_samples is not None:
-            if self._in_overlap:  # the ring is only touched by the discriminator stream
-                with th.cuda.stream(self._disc_stream):
-                    self._gen_replay_buffer.store(gen_samples)
-            else:
+            with store_ctx:  # in overlapped rounds the ring is only touched by the discriminator stream
                 self._gen_replay_buffer.store(gen_samples)
 
     def _quirk_moment_slot(self, numel: int) -> th.Tensor:

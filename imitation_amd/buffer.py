@@ -92,6 +92,47 @@ class ReplayBuffer:
         self._idx = (self._idx + n) % self.capacity
         self._n_data = min(self._n_data + n, self.capacity)
 
+    def store_from_rollout(self, rb, order: np.ndarray, truncate_ok: bool = True) -> None:
+        """`store` for transitions that already live in HBM (the PPO rollout tile `rb`): the rows
+        `order` (time-major offsets, reference emission order) are gathered device-to-device into
+        the ring; same index arithmetic as `store`."""
+        from imitation_amd import _lib as L
+        n = len(order)
+        if n == 0:
+            raise ValueError("Trying to store empty data.")
+        if n > self.capacity:
+            if not truncate_ok:
+                raise ValueError("Not enough capacity to store data.")
+            order = order[-self.capacity:]
+            n = self.capacity
+        order_dev = th.from_numpy(np.ascontiguousarray(order)).to(self.device)
+        T, ne = rb.buffer_size, rb.n_envs
+        od = self._obs.shape[1]
+        src_obs = rb.obs.reshape((T + 1) * ne, od)
+        src_next = rb.next_fixed.reshape(T * ne, od)
+        src_act = rb.clipped.reshape(T * ne, -1)
+        src_done = rb.dones.reshape(T * ne)
+
+        def put(lo: int, sel: th.Tensor) -> None:
+            m = sel.numel()
+            L.call("ia_gather_rows", L.ptr(src_obs), L.ptr(sel), m, od, L.ptr(self._obs[lo:lo + m]), L.stream())
+            L.call("ia_gather_rows", L.ptr(src_next), L.ptr(sel), m, od, L.ptr(self._next[lo:lo + m]), L.stream())
+            if self.discrete:
+                self._acts[lo:lo + m] = src_act[sel, 0].long()
+            else:
+                L.call("ia_gather_rows", L.ptr(src_act), L.ptr(sel), m, src_act.shape[1],
+                       L.ptr(self._acts[lo:lo + m]), L.stream())
+            self._dones[lo:lo + m] = src_done[sel]
+
+        if self._idx + n > self.capacity:
+            rem = self.capacity - self._idx
+            put(self._idx, order_dev[:rem].contiguous())
+            put(0, order_dev[rem:].contiguous())
+        else:
+            put(self._idx, order_dev)
+        self._idx = (self._idx + n) % self.capacity
+        self._n_data = min(self._n_data + n, self.capacity)
+
     def sample_indices(self, n_samples: int) -> np.ndarray:
         if self.size() == 0:
             raise ValueError("Buffer is empty")

@@ -367,6 +367,9 @@ class PPO(OnPolicyAlgorithm):
         L.call("ia_gae", L.ptr(rb.rew), L.ptr(rb.val), L.ptr(rb.starts), L.ptr(rb.last_val), L.ptr(rb.last_done), T,
                n, float(self.gamma), float(self.gae_lambda), L.ptr(rb.adv), L.ptr(rb.ret), L.stream())
         rb.full = True
+        # lets another stream consume the finished rollout tile without waiting for the PPO update
+        self.rollout_done_event = th.cuda.Event()
+        self.rollout_done_event.record()
         callback.on_rollout_end()
         return True
 

@@ -118,6 +118,19 @@ class BufferingWrapper(VecEnvWrapper):
         self.n_transitions = 0
         return trans, lens
 
+    def pop_order_and_lens(self):
+        """Device-friendly pop: `(order, ep_lens, T)` where `order` lists the time-major offsets
+        `t*n_envs + env` of the recorded steps in the reference's emission order; the caller gathers
+        the rows itself (the GPU collector already holds them in HBM). Clears the buffer."""
+        if self.n_transitions == 0:
+            return None, [], 0
+        dones = np.stack([st[4] for st in self._steps])
+        order, _, _ = dt.segment_order(dones)
+        lens, self._ep_lens = self._ep_lens, []
+        self._steps = []
+        self.n_transitions = 0
+        return order, lens, dones.shape[0]
+
     def pop_transitions(self) -> dt.TransitionsWithRew:
         if self.n_transitions == 0:
             raise RuntimeError("Called pop_transitions on an empty BufferingWrapper")
