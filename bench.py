@@ -199,7 +199,7 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 
-    roof = gemm_roofline(trainer, cfg, args.prof_rounds) if rank == 0 else None
+    roof = gemm_roofline(trainer, cfg, args.prof_rounds) if (rank == 0 and args.prof_rounds > 0) else None
     base = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         th.set_num_threads(host_threads)

@@ -397,11 +397,13 @@ __device__ void prepare_stats(const ia_policy_desc& d, const float* __restrict__
   float* red = lds + PREP_STAGE_FLOATS;          // [16][65]
   float* cmean = red + 16 * 65;                  // [65]
   float* misc = cmean + 65;                      // [64]
-  float s = 0.f;
-  for (int i = tid; i < batch; i += PREP_THREADS) s += adv[mb_row(idx, i, T, n_envs)];
+  // advantages: the first value of each thread stays in a register for the second pass
+  const float a0 = tid < batch ? adv[mb_row(idx, tid, T, n_envs)] : 0.f;
+  float s = a0;
+  for (int i = tid + PREP_THREADS; i < batch; i += PREP_THREADS) s += adv[mb_row(idx, i, T, n_envs)];
   const float mean = block_sum_1024(s, misc) / (float)batch;
-  float q = 0.f;
-  for (int i = tid; i < batch; i += PREP_THREADS) {
+  float q = tid < batch ? (a0 - mean) * (a0 - mean) : 0.f;
+  for (int i = tid + PREP_THREADS; i < batch; i += PREP_THREADS) {
     const float dl = adv[mb_row(idx, i, T, n_envs)] - mean;
     q += dl * dl;
   }
@@ -411,16 +413,35 @@ __device__ void prepare_stats(const ia_policy_desc& d, const float* __restrict__
     advstat[1] = batch > 1 ? sqrtf(qq / (float)(batch - 1)) : 0.f;
   }
   if (!(d.has_norm && update_norm)) return;
-  const int D = d.obs_dim, DP = D | 1;
+  const int D = d.obs_dim, DP = idx ? (D | 1) : D;  // column reads are conflict-free for any row stride
   const int chunk_rows = min(batch, PREP_STAGE_FLOATS / DP);
   const int col = tid & 63, rg = tid >> 6;
   float n_acc = 0.f, m_acc = 0.f, M2 = 0.f;  // Chan accumulators, live in threads tid < D
   for (int c0 = 0; c0 < batch; c0 += chunk_rows) {
     const int rows = min(chunk_rows, batch - c0);
     __syncthreads();
-    for (int e = tid; e < rows * D; e += PREP_THREADS) {
-      const int r = e / D, k = e - r * D;
-      stage[r * DP + k] = obs[mb_row(idx, c0 + r, T, n_envs) * D + k];
+    if (idx == nullptr) {
+      // contiguous rows: a straight linear copy (no index math), all loads of a thread issued
+      // before its first LDS store so they are in flight together
+      constexpr int MAXIT = PREP_STAGE_FLOATS / PREP_THREADS;
+      const float* __restrict__ srcp = obs + (long long)c0 * D;
+      const int nel = rows * D;
+      float v[MAXIT];
+#pragma unroll
+      for (int it = 0; it < MAXIT; ++it) {
+        const int e = tid + it * PREP_THREADS;
+        v[it] = e < nel ? srcp[e] : 0.f;
+      }
+#pragma unroll
+      for (int it = 0; it < MAXIT; ++it) {
+        const int e = tid + it * PREP_THREADS;
+        if (e < nel) stage[e] = v[it];
+      }
+    } else {
+      for (int e = tid; e < rows * D; e += PREP_THREADS) {
+        const int r = e / D, k = e - r * D;
+        stage[r * DP + k] = obs[mb_row(idx, c0 + r, T, n_envs) * D + k];
+      }
     }
     __syncthreads();
     float cs = 0.f;
@@ -1436,8 +1457,8 @@ int launch_grad(const PpoArgs& a, const int64_t* idx, int batch) {
   if (H == 32 && !g_ppo_valu) {
     const int P4 = (pol_offsets(a.d->obs_dim, a.d->act_dim, 32, a.d->discrete).total + 3) & ~3;
     const size_t mbytes = (GLds<32>::total + 2 * P4) * sizeof(float);
-    int rc = set_lds(ppo_grad_mfma32_kernel, 160 * 1024);
-    if (rc) return rc;
+    static bool attr2 = false;
+    if (!attr2) { int rc = set_lds(ppo_grad_mfma32_kernel, 160 * 1024); if (rc) return rc; attr2 = true; }
     hipLaunchKernelGGL(ppo_grad_mfma32_kernel, dim3(nblk), dim3(512), mbytes, a.st, *a.d, a.params, a.params_t,
                        a.norm_mean, a.norm_var, a.obs, a.actions, a.old_logp, a.advantages, a.returns, idx, batch, a.T,
                        a.n_envs, a.normalize_adv, a.clip_range, a.ent_coef, a.vf_coef, a.ws, nblk, g_tstamp);
