@@ -188,9 +188,15 @@ __global__ __launch_bounds__(ROWS) void policy_act_kernel(ia_policy_desc d, cons
     const float u = noise[row];
     float c = 0.f;
     int pick = A - 1;
-    for (int a = 0; a < A; ++a) {
-      c += expf(outrow[a] - lse);
-      if (u < c) { pick = a; break; }
+    if (u < 0.f) {  // mode of the Categorical ([SB3 CategoricalDistribution.mode] = argmax, first index on ties)
+      pick = 0;
+      for (int a = 1; a < A; ++a)
+        if (outrow[a] > outrow[pick]) pick = a;
+    } else {
+      for (int a = 0; a < A; ++a) {
+        c += expf(outrow[a] - lse);
+        if (u < c) { pick = a; break; }
+      }
     }
     actions[row] = (float)pick;
     clipped[row] = (float)pick;

@@ -222,7 +222,10 @@ class ActorCriticPolicy:
         require_device(self.device)
         o = self._obs_dev(obs)
         n = o.shape[0]
-        noise = th.zeros(n, self.act_dim) if (deterministic and not self.discrete) else self.sample_noise(n)
+        if deterministic:  # mode: zero Gaussian noise / negative uniform = argmax (no RNG draw, as in SB3)
+            noise = th.full((n,), -1.0) if self.discrete else th.zeros(n, self.act_dim)
+        else:
+            noise = self.sample_noise(n)
         aw = 1 if self.discrete else self.act_dim
         acts, clip = th.empty(n, aw, device=self.device), th.empty(n, aw, device=self.device)
         vals, logp = th.empty(n, device=self.device), th.empty(n, device=self.device)
@@ -273,9 +276,6 @@ class ActorCriticPolicy:
         obs = np.asarray(observation)
         vectorized = obs.shape != tuple(self.observation_space.shape)
         obs = obs.reshape((-1, *self.observation_space.shape))
-        if self.discrete and deterministic:
-            _, logp_all, _ = None, None, None
-            raise NotImplementedError("deterministic Categorical prediction is not built yet")
         acts, _, _ = self.forward(obs, deterministic=deterministic)
         acts = acts.cpu().numpy()
         if not self.discrete:

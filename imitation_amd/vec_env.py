@@ -118,7 +118,7 @@ class SyntheticVecEnv(ArrayVecEnv):
     """HalfCheetah-shaped synthetic control environment.
 
     Dynamics `o' = 0.9*o + 0.1*tanh(W a) + 0.05*xi`, `W in R^{obs x act}`, `xi ~ N(0,1)`,
-    env reward 0 (optionally `-|a|^2`), fixed horizon with `TimeLimit.truncated=True`.
+    env reward `-reward_scale*|a|^2` (0 by default), fixed horizon with `TimeLimit.truncated=True`.
     Discrete action spaces are embedded through a fixed table of `n` action vectors.
     All randomness comes from a private `np.random.Generator` (never the global streams
     the trainer's index draws use).
@@ -134,6 +134,7 @@ class SyntheticVecEnv(ArrayVecEnv):
         obs_dtype=np.float32,
         n_discrete: Optional[int] = None,
         stagger: bool = False,
+        reward_scale: float = 0.0,
     ):
         obs_space = spaces.Box(-np.inf, np.inf, (obs_dim,), obs_dtype)
         if n_discrete is None:
@@ -152,6 +153,7 @@ class SyntheticVecEnv(ArrayVecEnv):
         self._obs = np.zeros((num_envs, obs_dim), dtype=np.float64)
         self._t = np.zeros(num_envs, dtype=np.int64)
         self._stagger = stagger
+        self._reward_scale = float(reward_scale)
         self._actions: Optional[np.ndarray] = None
 
     def _fresh(self, n: int) -> np.ndarray:
@@ -188,7 +190,10 @@ class SyntheticVecEnv(ArrayVecEnv):
             self._t[dones] = 0
         self._obs = nxt
         obs = nxt.astype(dt)
-        rews = np.zeros(self.num_envs, dtype=np.float32)
+        if self._reward_scale:
+            rews = (-self._reward_scale * (a * a).sum(axis=1)).astype(np.float32)
+        else:
+            rews = np.zeros(self.num_envs, dtype=np.float32)
         return obs, rews, dones, next_fixed, dones.copy()
 
 

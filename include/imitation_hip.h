@@ -177,7 +177,8 @@ int ia_policy_transpose(const ia_policy_desc* d, const float* params, float* par
 /* [SB3 ActorCriticPolicy.forward] rollout step (collect_rollouts):
  * Box: actions = mean + exp(log_std)*noise, clipped = clip(actions, low, high);
  * Discrete: `noise` holds one uniform(0,1) per row, inverse-CDF sampling over softmax
- * (actions / clipped are then fp32 action indices [n]). */
+ * (actions / clipped are then fp32 action indices [n]); a negative entry selects the mode
+ * (argmax, first index on ties) for `predict(deterministic=True)`. */
 int ia_policy_act(const ia_policy_desc* d, const float* params, const float* params_t, const float* norm_mean,
                   const float* norm_var, const float* obs, int n, const float* noise, const float* low,
                   const float* high, float* actions, float* clipped, float* values, float* logp, void* stream);

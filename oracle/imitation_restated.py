@@ -253,6 +253,69 @@ class TrajectoryAccumulator:
         return out
 
 
+def make_sample_until(min_timesteps: Optional[int] = None, min_episodes: Optional[int] = None):
+    """data/rollout.py:193-272."""
+    if min_timesteps is None and min_episodes is None:
+        raise ValueError("At least one of min_timesteps and min_episodes needs to be non-None")
+    conds = []
+    if min_timesteps is not None:
+        if min_timesteps <= 0:
+            raise ValueError(f"min_timesteps={min_timesteps} if provided must be positive")
+        conds.append(lambda trajs: sum(len(t.obs) - 1 for t in trajs) >= min_timesteps)
+    if min_episodes is not None:
+        if min_episodes <= 0:
+            raise ValueError(f"min_episodes={min_episodes} if provided must be positive")
+        conds.append(lambda trajs: len(trajs) >= min_episodes)
+    return lambda trajs: all(c(trajs) for c in conds)
+
+
+def generate_trajectories(policy, venv, sample_until, rng: np.random.Generator,
+                          deterministic_policy: bool = False) -> List[TrajectoryWithRew]:
+    """data/rollout.py:382-506 (array observations). `policy`: None, an object with
+    `.predict` (SB3 algorithm / policy), or a callable `(obs, state, episode_start)`."""
+    if policy is None:
+        get_actions = lambda o, s, d: (np.stack([venv.action_space.sample() for _ in range(len(o))]), None)
+    elif hasattr(policy, "predict"):
+        get_actions = lambda o, s, d: policy.predict(o, state=s, episode_start=d, deterministic=deterministic_policy)
+    else:
+        get_actions = policy
+    trajectories: List[TrajectoryWithRew] = []
+    accum = TrajectoryAccumulator()
+    obs = venv.reset()
+    for i, o in enumerate(obs):
+        accum.add_step(dict(obs=o), i)                       # rollout.py:424-429
+    active = np.ones(venv.num_envs, dtype=bool)
+    state = None
+    dones = np.zeros(venv.num_envs, dtype=bool)
+    while np.any(active):
+        acts, state = get_actions(obs, state, dones)
+        obs, rews, dones, infos = venv.step(acts)
+        dones &= active                                      # rollout.py:454-456
+        trajectories.extend(accum.add_steps_and_auto_finish(acts, obs, rews, dones, infos))
+        if sample_until(trajectories):
+            active &= ~dones                                 # rollout.py:466-469
+    rng.shuffle(trajectories)
+    return trajectories
+
+
+def rollout_stats(trajectories) -> Dict[str, float]:
+    """data/rollout.py:509-560 (without Monitor infos)."""
+    out: Dict[str, float] = {"n_traj": len(trajectories)}
+    desc = {"return": np.asarray([sum(t.rews) for t in trajectories]),
+            "len": np.asarray([len(t.rews) for t in trajectories])}
+    for name, vals in desc.items():
+        for stat in ("min", "mean", "std", "max"):
+            out[f"{name}_{stat}"] = getattr(np, stat)(vals).item()
+    return out
+
+
+def discounted_sum(arr: np.ndarray, gamma: float):
+    """data/rollout.py:728-756."""
+    if gamma == 1.0:
+        return arr.sum(axis=0)
+    return np.polynomial.polynomial.polyval(gamma, arr)
+
+
 # -------------------------------------------------------------------- data/wrappers.py
 
 

@@ -55,6 +55,11 @@ def main():
         path = os.path.join(HERE, f"{name}.npz")
         np.savez_compressed(path, **out)
         print(f"wrote {path}: {len(out)} arrays, {os.path.getsize(path)} bytes")
+    for name in harness.ROLLOUT_CASES:   # data/rollout.py generate_trajectories run by the reference itself
+        out = harness.run_rollout_case("reference", name)
+        path = os.path.join(HERE, f"{name}.npz")
+        np.savez_compressed(path, **out)
+        print(f"wrote {path}: {len(out)} arrays, {os.path.getsize(path)} bytes")
 
 
 if __name__ == "__main__":

@@ -193,3 +193,78 @@ def run_case(impl: str, name: str, log_dir: str, device: str = "cpu") -> Dict[st
 
 # Keys whose values are integer/boolean bookkeeping and must match bit-exactly.
 EXACT_KEYS = ("replay/dones", "replay/_idx", "replay/_n_data", "counters")
+
+
+# --------------------------------------------------------------------------------------------
+# data/rollout.py cases: trajectory collection through each implementation.
+
+ROLLOUT_CASES: Dict[str, Dict[str, Any]] = {
+    # Plain callable policy: exercises episode bookkeeping, retirement of envs and the final
+    # shuffle only (bit-exact across implementations).
+    "rollout_callable": dict(kind="callable", n_envs=6, obs_dim=5, act_dim=3, horizon=7, n_discrete=None,
+                             min_timesteps=60, min_episodes=11),
+    # Freshly initialised FeedForward32Policy with RunningNorm features, stochastic actions.
+    "rollout_policy": dict(kind="policy", n_envs=8, obs_dim=9, act_dim=4, horizon=9, n_discrete=None,
+                           min_timesteps=100, min_episodes=None, deterministic=False),
+    # Discrete actions, deterministic (mode) prediction.
+    "rollout_discrete_det": dict(kind="policy", n_envs=5, obs_dim=4, act_dim=2, horizon=6, n_discrete=3,
+                                 min_timesteps=None, min_episodes=12, deterministic=True),
+}
+
+
+def rollout_namespace(impl: str):
+    if impl == "reference":
+        from oracle import ref_shim
+
+        ref_shim.install()
+        from imitation.data import rollout as r
+
+        return pytypes.SimpleNamespace(generate_trajectories=r.generate_trajectories,
+                                       make_sample_until=r.make_sample_until, rollout_stats=r.rollout_stats,
+                                       discounted_sum=r.discounted_sum)
+    if impl == "oracle":
+        from oracle import imitation_restated as o
+
+        return pytypes.SimpleNamespace(generate_trajectories=o.generate_trajectories,
+                                       make_sample_until=o.make_sample_until, rollout_stats=o.rollout_stats,
+                                       discounted_sum=o.discounted_sum)
+    from imitation_amd import rollout as r
+
+    return pytypes.SimpleNamespace(generate_trajectories=r.generate_trajectories,
+                                   make_sample_until=r.make_sample_until, rollout_stats=r.rollout_stats,
+                                   discounted_sum=r.discounted_sum)
+
+
+def run_rollout_case(impl: str, name: str, device: str = "cpu") -> Dict[str, np.ndarray]:
+    cfg = ROLLOUT_CASES[name]
+    ns, rns = namespace(impl), rollout_namespace(impl)
+    th.manual_seed(0)
+    np.random.seed(0)
+    venv = SyntheticVecEnv(num_envs=cfg["n_envs"], obs_dim=cfg["obs_dim"], act_dim=cfg["act_dim"],
+                           horizon=cfg["horizon"], seed=3, n_discrete=cfg["n_discrete"], stagger=True,
+                           reward_scale=1.0)
+    if cfg["kind"] == "callable":
+        W = np.random.default_rng(11).standard_normal((cfg["obs_dim"], cfg["act_dim"]))
+        policy = lambda obs, state, starts: (np.tanh(4.0 * obs @ W).astype(np.float32), None)  # noqa: E731
+        kw = {}
+    else:
+        pk = dict(features_extractor_class=ns.NormalizeFeaturesExtractor,
+                  features_extractor_kwargs=dict(normalize_class=ns.RunningNorm))
+        algo = ns.PPO(ns.FeedForward32Policy, venv, n_steps=8, batch_size=8, seed=0, policy_kwargs=pk, device=device)
+        # give the feature normaliser non-trivial statistics (one train-mode pass), then roll out in eval mode
+        warm = np.random.default_rng(12).standard_normal((64, cfg["obs_dim"])).astype(np.float32) * 0.3 + 0.1
+        algo.policy.set_training_mode(True)
+        algo.policy.predict_values(th.as_tensor(warm, device=device) if impl != "hip" else warm)
+        policy = algo
+        kw = dict(deterministic_policy=cfg["deterministic"])
+    until = rns.make_sample_until(min_timesteps=cfg["min_timesteps"], min_episodes=cfg["min_episodes"])
+    trajs = rns.generate_trajectories(policy, venv, until, rng=np.random.default_rng(5), **kw)
+    out = dict(lens=np.asarray([len(t.acts) for t in trajs]),
+               obs=np.concatenate([np.asarray(t.obs) for t in trajs]),
+               acts=np.concatenate([np.asarray(t.acts) for t in trajs]),
+               rews=np.concatenate([np.asarray(t.rews) for t in trajs]),
+               terminal=np.asarray([t.terminal for t in trajs]))
+    stats = rns.rollout_stats(trajs)
+    out["stats"] = np.asarray([stats[k] for k in sorted(stats)], dtype=np.float64)
+    out["disc_sum"] = np.asarray([rns.discounted_sum(np.asarray(t.rews, dtype=np.float64), 0.9) for t in trajs])
+    return out

@@ -1,0 +1,181 @@
+"""`data/rollout.py` row: trajectory collection with the device policy.
+
+CPU: the oracle restatement and the product's array bookkeeping against golden vectors
+produced by the reference's own `generate_trajectories`; host-side helpers.
+GPU: the product driving the HIP policy kernel through `.predict()` against the same goldens.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from imitation_amd import rollout
+from imitation_amd import data_types as dt
+from imitation_amd.vec_env import SyntheticVecEnv
+from oracle import ref_shim
+from tests import harness
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+EXACT = ("lens", "terminal")
+
+
+def _gold(case):
+    return dict(np.load(os.path.join(GOLDEN, f"{case}.npz")))
+
+
+@pytest.mark.parametrize("case", list(harness.ROLLOUT_CASES))
+def test_oracle_rollout_matches_golden(case):
+    gold, got = _gold(case), harness.run_rollout_case("oracle", case)
+    assert set(gold) == set(got)
+    for k in gold:
+        assert gold[k].shape == got[k].shape, k
+        if k in EXACT or harness.ROLLOUT_CASES[case]["kind"] == "callable":
+            assert np.array_equal(gold[k], got[k]), k
+        else:  # torch CPU policy forward: exact on the generating host, tight elsewhere
+            np.testing.assert_allclose(got[k], gold[k], rtol=1e-5, atol=1e-6, err_msg=k)
+
+
+@pytest.mark.reference
+@pytest.mark.skipif(not ref_shim.reference_available(), reason="/root/reference not present")
+@pytest.mark.parametrize("case", list(harness.ROLLOUT_CASES))
+def test_oracle_rollout_bit_identical_to_live_reference(case):
+    ref, got = harness.run_rollout_case("reference", case), harness.run_rollout_case("oracle", case)
+    for k in ref:
+        assert ref[k].dtype == got[k].dtype and np.array_equal(ref[k], got[k]), k
+
+
+def test_product_bookkeeping_bit_exact_vs_golden():
+    """Callable policy: everything but the policy itself (slicing, retirement of envs once
+    `sample_until` holds, emission order, the final shuffle) -- no GPU involved."""
+    gold, got = _gold("rollout_callable"), harness.run_rollout_case("hip", "rollout_callable")
+    for k in gold:
+        assert gold[k].dtype == got[k].dtype, k
+        assert np.array_equal(gold[k], got[k]), k
+
+
+def _env(**kw):
+    return SyntheticVecEnv(num_envs=4, obs_dim=3, act_dim=2, horizon=5, seed=1, stagger=True, reward_scale=1.0, **kw)
+
+
+def _zero_policy(obs, state, starts):
+    return np.zeros((len(obs), 2), np.float32), None
+
+
+def test_make_sample_until_contract():
+    """`data/rollout.py:226-272` argument errors and the AND of both conditions."""
+    with pytest.raises(ValueError, match="At least one"):
+        rollout.make_sample_until(None, None)
+    with pytest.raises(ValueError, match="min_timesteps=0"):
+        rollout.make_sample_until(min_timesteps=0)
+    with pytest.raises(ValueError, match="min_episodes=-1"):
+        rollout.make_sample_until(min_episodes=-1)
+    trajs = rollout.generate_trajectories(_zero_policy, _env(), rollout.make_sample_until(8, 3),
+                                          rng=np.random.default_rng(0))
+    until = rollout.make_sample_until(min_timesteps=8, min_episodes=3)
+    assert until(trajs) and not until(trajs[:2])
+    assert not rollout.make_sample_until(min_timesteps=10 ** 6)(trajs)
+
+
+def test_policy_to_callable_contract():
+    """`data/rollout.py:288-379`: None samples the action space; a callable refuses
+    `deterministic_policy=True`; anything else is a TypeError."""
+    env = _env()
+    acts, state = rollout.policy_to_callable(None, env)(env.reset(), None, None)
+    assert acts.shape == (4, 2) and state is None and env.action_space.contains(acts[0])
+    with pytest.raises(ValueError, match="deterministic_policy"):
+        rollout.policy_to_callable(_zero_policy, env, deterministic_policy=True)
+    with pytest.raises(TypeError, match="Policy must be None"):
+        rollout.policy_to_callable(3, env)
+
+
+def test_trajectories_are_unbiased_complete_episodes():
+    """Every returned trajectory is a whole episode (terminal, at most `horizon` steps); all
+    envs contribute; obs has one more row than acts (`data/rollout.py:478-505`)."""
+    env = _env()
+    trajs = rollout.generate_trajectories(_zero_policy, env, rollout.make_min_episodes(9),
+                                          rng=np.random.default_rng(2))
+    assert len(trajs) >= 9
+    for t in trajs:
+        assert t.terminal and 1 <= len(t) <= 5
+        assert t.obs.shape == (len(t) + 1, 3) and t.acts.shape == (len(t), 2) and t.rews.shape == (len(t),)
+        assert t.obs.dtype == np.float32 and t.infos is None
+    assert sum(len(t) == 5 for t in trajs) >= len(trajs) - 4   # only the staggered first episodes are short
+
+
+def test_rollout_stats_and_flatten_and_transitions():
+    env = _env()
+    pol = lambda o, s, d: (np.full((len(o), 2), 0.5, np.float32), None)  # noqa: E731
+    trajs = rollout.rollout(pol, env, rollout.make_min_timesteps(20), rng=np.random.default_rng(3), verbose=False)
+    st = rollout.rollout_stats(trajs)
+    assert st["n_traj"] == len(trajs) and isinstance(st["n_traj"], int)
+    lens = np.asarray([len(t) for t in trajs])
+    assert st["len_min"] == lens.min() and st["len_max"] == lens.max() and st["len_mean"] == lens.mean()
+    rets = np.asarray([sum(t.rews) for t in trajs])
+    assert st["return_mean"] == rets.mean() and st["return_std"] == rets.std()
+    assert set(st) == {"n_traj"} | {f"{a}_{b}" for a in ("return", "len") for b in ("min", "mean", "std", "max")}
+    flat = rollout.flatten_trajectories_with_rew(trajs)
+    assert isinstance(flat, dt.TransitionsWithRew) and len(flat) == lens.sum()
+    assert flat.dones.sum() == len(trajs) and np.array_equal(np.flatnonzero(flat.dones), np.cumsum(lens) - 1)
+    assert np.array_equal(flat.next_obs[:lens[0] - 1], flat.obs[1:lens[0]])
+    trans = rollout.generate_transitions(pol, _env(), 13, rng=np.random.default_rng(3))
+    assert len(trans) == 13 and trans.rews.shape == (13,)
+    more = rollout.generate_transitions(pol, _env(), 13, rng=np.random.default_rng(3), truncate=False)
+    assert len(more) >= 13 and np.array_equal(more.obs[:13], trans.obs)
+
+
+def test_discounted_sum_known_answers():
+    """`tests/data/test_rollout.py` style: matches the explicit sum, 1-D and 2-D, gamma = 1."""
+    r = np.random.default_rng(0).standard_normal((7, 3))
+    for g in (0.9, 0.5, 1.0):
+        want = sum(g ** t * r[t] for t in range(7))
+        np.testing.assert_allclose(rollout.discounted_sum(r, g), want, rtol=1e-12)
+        np.testing.assert_allclose(rollout.discounted_sum(r[:, 0], g), want[0], rtol=1e-12)
+
+
+def test_monitor_returns_are_reported_when_infos_carry_them():
+    t = dt.TrajectoryWithRew(obs=np.zeros((3, 1)), acts=np.zeros((2, 1)), rews=np.ones(2),
+                             infos=np.array([{}, {"episode": {"r": 7.5}}]), terminal=True)
+    st = rollout.rollout_stats([t, t])
+    assert st["monitor_return_len"] == 2 and st["monitor_return_mean"] == 7.5 and st["return_mean"] == 2.0
+
+
+# ------------------------------------------------------------------------------------- GPU
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["rollout_policy", "rollout_discrete_det"])
+def test_device_policy_rollout_matches_reference_golden(case):
+    """`.predict()` through the HIP policy kernel (eval mode, RunningNorm statistics frozen):
+    same episode structure and shuffle as the reference, observations / actions / rewards within
+    fp32 kernel-vs-torch tolerance (the dynamics are contractive: 0.9 per step)."""
+    gold, got = _gold(case), harness.run_rollout_case("hip", case, device="cuda")
+    assert set(gold) == set(got)
+    for k in gold:
+        assert gold[k].shape == got[k].shape, k
+        if k in EXACT or gold[k].dtype.kind in "iub":
+            assert np.array_equal(gold[k], got[k]), k
+        else:
+            np.testing.assert_allclose(got[k], gold[k], rtol=2e-4, atol=5e-5, err_msg=k)
+
+
+@pytest.mark.gpu
+def test_device_rollout_does_not_touch_policy_statistics():
+    """Eval-mode prediction: RunningNorm buffers and parameters are bit-identical before / after
+    (`util/networks.py:81-87` only updates in training mode; SB3 `predict` switches it off)."""
+    import torch as th
+
+    import imitation_amd as p
+
+    th.manual_seed(0)
+    env = SyntheticVecEnv(num_envs=16, obs_dim=6, act_dim=3, horizon=8, seed=0)
+    algo = p.PPO(p.FeedForward32Policy, env, n_steps=8, batch_size=16, seed=0, device="cuda",
+                 policy_kwargs=dict(features_extractor_class=p.NormalizeFeaturesExtractor,
+                                    features_extractor_kwargs=dict(normalize_class=p.RunningNorm)))
+    before = {k: v.detach().cpu().clone() for k, v in algo.policy.state_dict().items()}
+    trajs = rollout.rollout(algo, env, rollout.make_min_episodes(32), rng=np.random.default_rng(0), verbose=False)
+    assert len(trajs) >= 32 and all(len(t) == 8 for t in trajs)
+    after = algo.policy.state_dict()
+    for k in before:
+        assert th.equal(before[k], after[k].detach().cpu()), k
+    acts = np.concatenate([t.acts for t in trajs])
+    assert acts.min() >= -1.0 and acts.max() <= 1.0 and np.isfinite(acts).all()
