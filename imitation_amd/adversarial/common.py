@@ -179,6 +179,11 @@ class AdversarialTrainer(abc.ABC):
         self._idx_host = th.zeros(2, B, dtype=th.int64).pin_memory()
         self._idx_dev = th.zeros(2, B, dtype=th.int64, device=self._device)
         self._stats_dev = th.zeros(8, device=self._device)
+        # one statistics row per update of a round: `train()` enqueues all n_disc updates before it
+        # reads any of them back (the host prepares update k+1 while the GPU runs update k)
+        self._stats_ring = th.zeros(nq, 8, device=self._device)
+        self._stats_ring_host = th.zeros(nq, 8).pin_memory()
+        self._use_ring = False
         self._bce_ws = th.zeros(int(L.load().ia_bce_ws_floats(2 * self.demo_minibatch_size)), device=self._device)
         self._dlogits = th.zeros(2 * self.demo_minibatch_size, device=self._device)
         self._logp = th.zeros(2 * self.demo_minibatch_size, device=self._device)
@@ -256,10 +261,11 @@ class AdversarialTrainer(abc.ABC):
         e_idx = g_idx = None
         # inside an overlapped round every update gets its own (pinned, device) index rows so the
         # deferred policy-norm replay can still read them after later updates were enqueued
-        k = self._overlap_k % self._quirk_idx_dev.shape[0] if self._in_overlap else None
+        ring = self._in_overlap or self._use_ring
+        k = self._overlap_k % self._quirk_idx_dev.shape[0] if ring else None
         idx_host = self._quirk_idx_host[k] if k is not None else self._idx_host
         idx_dev = self._quirk_idx_dev[k] if k is not None else self._idx_dev
-        if self._in_overlap:
+        if ring:
             self._overlap_k += 1
         if expert_samples is None:
             if self._expert_batches is not None:
@@ -321,71 +327,112 @@ class AdversarialTrainer(abc.ABC):
 
     def train_disc(self, *, expert_samples: Optional[Mapping] = None,
                    gen_samples: Optional[Mapping] = None) -> Mapping[str, float]:
+        self._disc_update(expert_samples, gen_samples, self._stats_dev)
+        s = self._stats_dev.cpu().numpy()  # the one host sync of a discriminator update
+        return self._log_disc_stats(s, self._disc_step, self._global_step)
+
+    def _log_disc_stats(self, s, disc_step: int, global_step: int) -> Mapping[str, float]:
+        """`common.py:375-388`: the logging half of `train_disc` for one update's statistics row."""
         with self.logger.accumulate_means("disc"):
-            (e_tab, e_idx), (g_tab, g_idx) = self._batch_sources(expert_samples, gen_samples)
-            B, mb = self.demo_batch_size, self.demo_minibatch_size
-            scale = mb / B
-            net = self._reward_net
-            first = True
-            fused_step = False
-            # single minibatch, HIP Adam, no cross-rank exchange: reduce + Adam in one launch
-            single = self._dp is None or self._dp.world == 1
-            fuse_adam = self._disc_opt if (isinstance(self._disc_opt, HipAdam) and single) else None
-            basic = net
-            while isinstance(basic, reward_nets.PredictProcessedWrapper):
-                basic = basic.base
-            c_path = (isinstance(basic, reward_nets.BasicRewardNet) and not self._needs_logp and single
-                      and self._torch_opt_params is None)
-            pol = self.policy
-            prn = pol.features_extractor.normalize if isinstance(pol, ActorCriticPolicy) else None
-            for start in range(0, B, mb):
-                sl = lambda idx: None if idx is None else idx[start:start + mb]
-                e_src = (e_tab if e_idx is not None else _slice_table(e_tab, start, mb), sl(e_idx), mb)
-                g_src = (g_tab if g_idx is not None else _slice_table(g_tab, start, mb), sl(g_idx), mb)
-                sources = [e_src, g_src]
-                last = start + mb >= B
-                if c_path:
-                    # policy feature-norm side effect (App. C.2): when the discriminator's own input norm
-                    # updates on a state-first batch, its slab moments cover the observation columns and
-                    # are reused; otherwise the explicit pass below gathers the observations.
-                    reuse = (prn is not None and pol.training and basic.use_state and basic.mlp.norm is not None
-                             and basic.mlp.training)
-                    if prn is not None and pol.training and not reuse:
-                        self._policy_pass(sources, mb)
-                    inline = reuse and not self._in_overlap
-                    ws = basic.disc_step_c(sources, mb, scale, self._stats_dev, self._bce_ws, accumulate=not first,
-                                           adam=fuse_adam if last else None, pnorm=prn if inline else None,
-                                           pnorm_dim=pol.obs_dim if inline else 0)
-                    if reuse and self._in_overlap:  # replayed on the generator stream after the PPO update
-                        slot = self._quirk_moment_slot(ws["rn_ws"].numel())
-                        slot.copy_(ws["rn_ws"])
-                        self._quirk_pending.append((slot, 2 * mb, basic.mlp.dims[0]))
-                    logits = ws["out"].reshape(-1)
-                    fused_step = fused_step or (last and fuse_adam is not None)
-                else:
-                    logp = self._policy_pass(sources, mb)
-                    logits = net.disc_forward(sources, mb, logp)
-                    L.call("ia_bce_logits", L.ptr(logits), 2 * mb, mb, scale, L.ptr(self._dlogits),
-                           L.ptr(self._stats_dev), L.ptr(self._bce_ws), L.stream())
-                    fused_step = bool(net.disc_backward(self._dlogits, accumulate=not first,
-                                                        adam=fuse_adam if (B == mb) else None))
-                first = False
-            if self._dp is not None:  # one flat-bucket all-reduce per discriminator step
-                self._dp.allreduce_mean_(net._store.grad)
-            if self._torch_opt_params is not None:
-                for p, (_, gview) in zip(self._torch_opt_params, _named_grads(net)):
-                    p.grad = gview
-            if not fused_step:
-                self._disc_opt.step()
-            self._disc_step += 1
-            self._last_disc_logits = logits
-            s = self._stats_dev.cpu().numpy()  # the one host sync of a discriminator update
             train_stats = _stats_dict(*[float(x) for x in s])
-            self.logger.record("global_step", self._global_step)
+            self.logger.record("global_step", global_step)
             for k, v in train_stats.items():
                 self.logger.record(k, v)
-            self.logger.dump(self._disc_step)
+            self.logger.dump(disc_step)
         return train_stats
+
+    def _disc_round(self):
+        """Enqueues the n_disc updates of one round without reading their statistics back; returns
+        what `_finish_disc_round` needs to log them afterwards, in order. A `train_disc` replaced by
+        the user (subclass or instance attribute) is honoured: then the updates run one by one."""
+        n = self.n_disc_updates_per_round
+        if "train_disc" in self.__dict__ or type(self).train_disc is not AdversarialTrainer.train_disc:
+            for _ in range(n):
+                with networks.training(self.reward_train):
+                    self.train_disc()
+            return None
+        steps = []
+        self._use_ring = True
+        try:
+            for k in range(n):
+                with networks.training(self.reward_train):
+                    self._disc_update(None, None, self._stats_ring[k])
+                steps.append(self._disc_step)
+        finally:
+            self._use_ring = False
+        self._stats_ring_host.copy_(self._stats_ring, non_blocking=True)
+        done = th.cuda.Event()
+        done.record()
+        return done, steps, self._global_step
+
+    def _finish_disc_round(self, pending) -> None:
+        if pending is None:
+            return
+        done, steps, global_step = pending
+        done.synchronize()
+        rows = self._stats_ring_host.numpy()
+        for k, step in enumerate(steps):
+            self._log_disc_stats(rows[k], step, global_step)
+
+    def _disc_update(self, expert_samples, gen_samples, stats_dev: th.Tensor) -> None:
+        """Device half of `train_disc` (`common.py:317-374`); the 8 statistics land in `stats_dev`."""
+        (e_tab, e_idx), (g_tab, g_idx) = self._batch_sources(expert_samples, gen_samples)
+        B, mb = self.demo_batch_size, self.demo_minibatch_size
+        scale = mb / B
+        net = self._reward_net
+        first = True
+        fused_step = False
+        # single minibatch, HIP Adam, no cross-rank exchange: reduce + Adam in one launch
+        single = self._dp is None or self._dp.world == 1
+        fuse_adam = self._disc_opt if (isinstance(self._disc_opt, HipAdam) and single) else None
+        basic = net
+        while isinstance(basic, reward_nets.PredictProcessedWrapper):
+            basic = basic.base
+        c_path = (isinstance(basic, reward_nets.BasicRewardNet) and not self._needs_logp and single
+                  and self._torch_opt_params is None)
+        pol = self.policy
+        prn = pol.features_extractor.normalize if isinstance(pol, ActorCriticPolicy) else None
+        for start in range(0, B, mb):
+            sl = lambda idx: None if idx is None else idx[start:start + mb]
+            e_src = (e_tab if e_idx is not None else _slice_table(e_tab, start, mb), sl(e_idx), mb)
+            g_src = (g_tab if g_idx is not None else _slice_table(g_tab, start, mb), sl(g_idx), mb)
+            sources = [e_src, g_src]
+            last = start + mb >= B
+            if c_path:
+                # policy feature-norm side effect (App. C.2): when the discriminator's own input norm
+                # updates on a state-first batch, its slab moments cover the observation columns and
+                # are reused; otherwise the explicit pass below gathers the observations.
+                reuse = (prn is not None and pol.training and basic.use_state and basic.mlp.norm is not None
+                         and basic.mlp.training)
+                if prn is not None and pol.training and not reuse:
+                    self._policy_pass(sources, mb)
+                inline = reuse and not self._in_overlap
+                ws = basic.disc_step_c(sources, mb, scale, stats_dev, self._bce_ws, accumulate=not first,
+                                       adam=fuse_adam if last else None, pnorm=prn if inline else None,
+                                       pnorm_dim=pol.obs_dim if inline else 0)
+                if reuse and self._in_overlap:  # replayed on the generator stream after the PPO update
+                    slot = self._quirk_moment_slot(ws["rn_ws"].numel())
+                    slot.copy_(ws["rn_ws"])
+                    self._quirk_pending.append((slot, 2 * mb, basic.mlp.dims[0]))
+                logits = ws["out"].reshape(-1)
+                fused_step = fused_step or (last and fuse_adam is not None)
+            else:
+                logp = self._policy_pass(sources, mb)
+                logits = net.disc_forward(sources, mb, logp)
+                L.call("ia_bce_logits", L.ptr(logits), 2 * mb, mb, scale, L.ptr(self._dlogits),
+                       L.ptr(stats_dev), L.ptr(self._bce_ws), L.stream())
+                fused_step = bool(net.disc_backward(self._dlogits, accumulate=not first,
+                                                    adam=fuse_adam if (B == mb) else None))
+            first = False
+        if self._dp is not None:  # one flat-bucket all-reduce per discriminator step
+            self._dp.allreduce_mean_(net._store.grad)
+        if self._torch_opt_params is not None:
+            for p, (_, gview) in zip(self._torch_opt_params, _named_grads(net)):
+                p.grad = gview
+        if not fused_step:
+            self._disc_opt.step()
+        self._disc_step += 1
+        self._last_disc_logits = logits
 
     # ---- generator update (`common.py:391-425`) -------------------------------------------------
     def train_gen(self, total_timesteps: Optional[int] = None, learn_kwargs: Optional[Mapping] = None) -> None:
@@ -453,9 +500,8 @@ class AdversarialTrainer(abc.ABC):
         for r in range(n_rounds):
             if not self._overlap:
                 self.train_gen(self.gen_train_timesteps)
-                for _ in range(self.n_disc_updates_per_round):
-                    with networks.training(self.reward_train):
-                        self.train_disc()
+                self._overlap_k = 0
+                self._finish_disc_round(self._disc_round())
             else:
                 main = th.cuda.current_stream()
                 self._in_overlap, self.gen_algo.defer_train_stats, self._overlap_k = True, True, 0
@@ -463,11 +509,10 @@ class AdversarialTrainer(abc.ABC):
                     self._disc_stream.wait_stream(main)
                     self.train_gen(self.gen_train_timesteps)       # rollout; PPO update enqueued on `main`
                     with th.cuda.stream(self._disc_stream):         # ... while the disc updates run here
-                        for _ in range(self.n_disc_updates_per_round):
-                            with networks.training(self.reward_train):
-                                self.train_disc()
+                        pending = self._disc_round()
                     main.wait_stream(self._disc_stream)
                     self._replay_policy_norm_updates()              # after the PPO update, in stream order
+                    self._finish_disc_round(pending)
                     with self.logger.accumulate_means("gen"):
                         self.gen_algo.finalize_train()
                 finally:

@@ -19,10 +19,14 @@ namespace {
 constexpr int BK = 32;
 constexpr int LDP = BK + 1;
 
-__device__ __forceinline__ float4 load4_guard(const float* __restrict__ p, int n_valid, bool vec_ok) {
-  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+// Register staging uses a first-class 4-wide vector (not the float4 struct): aggregate copies of
+// struct elements into LDS keep the staging arrays in scratch memory.
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ f4 load4_guard(const float* __restrict__ p, int n_valid, bool vec_ok) {
+  f4 v = {0.f, 0.f, 0.f, 0.f};
   if (n_valid >= 4 && vec_ok) {
-    v = *reinterpret_cast<const float4*>(p);
+    v = *reinterpret_cast<const f4*>(p);
   } else if (n_valid > 0) {
     v.x = p[0];
     if (n_valid > 1) v.y = p[1];
@@ -39,7 +43,7 @@ struct TileIO {
   static_assert(ROWS * (BK / 4) % NT == 0, "tile not divisible among threads");
 
   // src is [rows_total, K] (k contiguous) when !KM, or [K, rows_total] (row contiguous) when KM.
-  __device__ static void load(float4 (&r)[NV], const float* __restrict__ src, int ld, int row0, int rows_total,
+  __device__ static void load(f4 (&r)[NV], const float* __restrict__ src, int ld, int row0, int rows_total,
                               int k0, int k_end, bool vec_ok, int tid) {
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
@@ -58,7 +62,27 @@ struct TileIO {
       }
     }
   }
-  __device__ static void store(const float4 (&r)[NV], float* __restrict__ S, int tid) {
+  // Interior tiles (whole tile in range, K range a multiple of BK, 16-byte aligned rows): plain
+  // float4 loads in straight-line code, so the compiler can keep them in flight behind counted
+  // `s_waitcnt vmcnt(N)` instead of draining the queue around every guarded load.
+  __device__ __forceinline__ static const float* fast_base(const float* __restrict__ src, int ld, int row0, int tid) {
+    if (!KM) return src + (long long)(row0 + (tid >> 3)) * ld + (tid & 7) * 4;
+    constexpr int QPR = ROWS / 4;
+    return src + (long long)(tid / QPR) * ld + row0 + (tid % QPR) * 4;
+  }
+  __device__ __forceinline__ static void load_fast(f4 (&r)[NV], const float* __restrict__ base, int ld, int k0) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      if (!KM) {
+        r[i] = *reinterpret_cast<const f4*>(base + (long long)(i * (NT / 8)) * ld + k0);
+      } else {
+        constexpr int QPR = ROWS / 4;
+        static_assert(NT % QPR == 0, "thread count must be a multiple of quads per row");
+        r[i] = *reinterpret_cast<const f4*>(base + (long long)(k0 + i * (NT / QPR)) * ld);
+      }
+    }
+  }
+  __device__ static void store(const f4 (&r)[NV], float* __restrict__ S, int tid) {
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       const int f = tid + i * NT;
@@ -69,7 +93,7 @@ struct TileIO {
       } else {
         constexpr int QPR = ROWS / 4;
         const int kr = f / QPR, mq = f % QPR;
-        *reinterpret_cast<float4*>(S + kr * ROWS + mq * 4) = r[i];
+        *reinterpret_cast<f4*>(S + kr * ROWS + mq * 4) = r[i];
       }
     }
   }
@@ -79,42 +103,26 @@ struct TileIO {
   static constexpr int ELEMS = KM ? BK * ROWS : ROWS * LDP;
 };
 
-template <int WM, int WN, int TM, int TN, int MODE>
-__global__ __launch_bounds__(WM* WN * 64) void ia_gemm_kernel(IaGemm g) {
+// Tile coordinates of one workgroup.
+struct TileCtx {
+  int bm0, bn0, split, k_begin, k_end;
+  bool a_vec, b_vec;
+};
+
+// K loop + epilogue of one output tile. FAST = interior tile (see TileIO::load_fast).
+template <int WM, int WN, int TM, int TN, int MODE, bool FAST>
+__device__ __forceinline__ void gemm_tile(const IaGemm& g, const TileCtx& tc, float* __restrict__ smem) {
   constexpr int NT = WM * WN * 64;
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
   using AIO = TileIO<BM, NT, MODE == IA_GEMM_TN>;
   using BIO = TileIO<BN, NT, MODE != IA_GEMM_NT>;
   constexpr int STAGE = AIO::ELEMS + BIO::ELEMS;
-  extern __shared__ __attribute__((aligned(16))) float smem[];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, lh = lane >> 5;
   const int wm = wave / WN, wn = wave % WN;
-
-  // XCD-aware block order: hardware places block b on XCD b%8. Give each XCD a CONTIGUOUS run of
-  // (split, tile) work items: column tiles that share an A row-block -- and, for split-K, all the
-  // tiles of one K-slab -- then run on the same XCD and are served by its L2 instead of being
-  // re-fetched into eight different L2s (PMC: 98 MB -> ~algorithmic for the 256x256 wgrad).
-  const int tiles_n = (g.N + BN - 1) / BN;
-  const int tiles_m = (g.M + BM - 1) / BM;
-  const int tiles = tiles_m * tiles_n;
-  const int nb = gridDim.x;
-  const int b = blockIdx.x;
-  const int q = nb >> 3, rmd = nb & 7, xcd = b & 7;
-  const int lin = (xcd < rmd ? xcd * (q + 1) : rmd * (q + 1) + (xcd - rmd) * q) + (b >> 3);
-  const int split = lin / tiles;
-  const int t = lin - split * tiles;
-  const int bm0 = (t / tiles_n) * BM, bn0 = (t % tiles_n) * BN;
-
-  int k_begin = 0, k_end = g.K;
-  if (MODE == IA_GEMM_TN) {
-    k_begin = split * g.k_per_split;
-    k_end = min(g.K, k_begin + g.k_per_split);
-  }
-  const bool a_vec = (g.lda % 4 == 0) && ((reinterpret_cast<uintptr_t>(g.A) & 15) == 0);
-  const bool b_vec = (g.ldb % 4 == 0) && ((reinterpret_cast<uintptr_t>(g.B) & 15) == 0);
+  const int bm0 = tc.bm0, bn0 = tc.bn0, k_begin = tc.k_begin, k_end = tc.k_end;
 
   f32x16 acc[TM][TN];
 #pragma unroll
@@ -127,17 +135,24 @@ __global__ __launch_bounds__(WM* WN * 64) void ia_gemm_kernel(IaGemm g) {
   // Two register stages: while chunk c is multiplied out of LDS, chunk c+1 sits in one register
   // set (to be written to the other LDS buffer after the MFMAs) and chunk c+2 is in flight into
   // the second set, so every global load has two chunk-times to land.
-  float4 ra0[AIO::NV], rb0[BIO::NV], ra1[AIO::NV], rb1[BIO::NV];
+  f4 ra0[AIO::NV], rb0[BIO::NV], ra1[AIO::NV], rb1[BIO::NV];
   const int n_chunks = (k_end - k_begin + BK - 1) / BK;
   const bool do_db = (MODE == IA_GEMM_TN) && (g.dbias != nullptr) && (bn0 == 0);
   float dbacc = 0.f;
 
-  auto gload = [&](float4 (&ra)[AIO::NV], float4 (&rb)[BIO::NV], int c) {
+  const float* fa = AIO::fast_base(g.A, g.lda, bm0, tid);
+  const float* fb = BIO::fast_base(g.B, g.ldb, bn0, tid);
+  auto gload = [&](f4 (&ra)[AIO::NV], f4 (&rb)[BIO::NV], int c) {
     const int k0 = k_begin + c * BK;
-    AIO::load(ra, g.A, g.lda, bm0, g.M, k0, k_end, a_vec, tid);
-    BIO::load(rb, g.B, g.ldb, bn0, g.N, k0, k_end, b_vec, tid);
+    if (FAST) {
+      AIO::load_fast(ra, fa, g.lda, k0);
+      BIO::load_fast(rb, fb, g.ldb, k0);
+    } else {
+      AIO::load(ra, g.A, g.lda, bm0, g.M, k0, k_end, tc.a_vec, tid);
+      BIO::load(rb, g.B, g.ldb, bn0, g.N, k0, k_end, tc.b_vec, tid);
+    }
   };
-  auto lstore = [&](const float4 (&ra)[AIO::NV], const float4 (&rb)[BIO::NV], int c) {
+  auto lstore = [&](const f4 (&ra)[AIO::NV], const f4 (&rb)[BIO::NV], int c) {
     float* S = smem + (c & 1) * STAGE;
     AIO::store(ra, S, tid);
     BIO::store(rb, S + AIO::ELEMS, tid);
@@ -145,18 +160,33 @@ __global__ __launch_bounds__(WM* WN * 64) void ia_gemm_kernel(IaGemm g) {
   auto compute = [&](int c) {
     const float* As = smem + (c & 1) * STAGE;
     const float* Bs = As + AIO::ELEMS;
-#pragma unroll 4
-    for (int kk = 0; kk < BK; kk += 2) {
-      float af[TM], bf[TN];
+    // Fragment reads run one stage (Q k-steps) ahead of the MFMAs that consume them, pinned with
+    // scheduling barriers: left alone, the scheduler sinks every ds_read next to its MFMA and each
+    // k-step then waits a full LDS round trip.
+    constexpr int Q = 4, NQ = BK / 2 / Q;
+    float af[2][Q][TM], bf[2][Q][TN];
+    auto rd = [&](int q) {
 #pragma unroll
-      for (int i = 0; i < TM; ++i) af[i] = AIO::frag(As, (wm * TM + i) * 32, kk, li, lh);
+      for (int s = 0; s < Q; ++s) {
 #pragma unroll
-      for (int j = 0; j < TN; ++j) bf[j] = BIO::frag(Bs, (wn * TN + j) * 32, kk, li, lh);
+        for (int i = 0; i < TM; ++i) af[q & 1][s][i] = AIO::frag(As, (wm * TM + i) * 32, 2 * (q * Q + s), li, lh);
 #pragma unroll
-      for (int i = 0; i < TM; ++i)
+        for (int j = 0; j < TN; ++j) bf[q & 1][s][j] = BIO::frag(Bs, (wn * TN + j) * 32, 2 * (q * Q + s), li, lh);
+      }
+    };
+    rd(0);
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+    for (int q = 0; q < NQ; ++q) {
+      if (q + 1 < NQ) rd(q + 1);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int s = 0; s < Q; ++s)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[q & 1][s][i], bf[q & 1][s][j], acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
     }
     if (do_db && tid < BM) {
 #pragma unroll 8
@@ -171,10 +201,35 @@ __global__ __launch_bounds__(WM* WN * 64) void ia_gemm_kernel(IaGemm g) {
     if (n_chunks > 2) gload(ra0, rb0, 2);
   }
   __syncthreads();
-  // invariant at the top of an (odd c) iteration: set 1 holds chunk c ... handled by the 2x unroll:
-  // even c: set1 = chunk c+1 (landed), set0 = chunk c+2 (in flight)
-  // odd  c: set0 = chunk c+1 (landed), set1 = chunk c+2 (in flight)
-  for (int c = 0; c < n_chunks; c += 2) {
+  // even c: set1 = chunk c+1 (landed), set0 = chunk c+2 (in flight); odd c: the sets swap roles.
+  int c = 0;
+  // Steady state: every load is unconditional, so the waits before the LDS stores are counted
+  // (`vmcnt(N)` with the younger set still in flight) rather than full drains.
+  for (; c + 4 < n_chunks; c += 2) {
+    compute(c);
+    lstore(ra1, rb1, c + 1);
+    gload(ra1, rb1, c + 3);
+    __syncthreads();
+    compute(c + 1);
+    lstore(ra0, rb0, c + 2);
+    gload(ra0, rb0, c + 4);
+    __syncthreads();
+  }
+  // NN epilogue operand (post-activation values for act'): on interior tiles request it before
+  // the tail chunks so the 16 loads per tile land behind the remaining MFMAs.
+  constexpr bool PREP = FAST && MODE == IA_GEMM_NN && TM * TN <= 2;
+  float pv[PREP ? TM : 1][PREP ? TN : 1][16];
+  if (PREP && g.P != nullptr) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const float* pp = g.P + (long long)(bm0 + (wm * TM + i) * 32 + 4 * lh) * g.ldp + bn0 + (wn * TN + j) * 32 + li;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) pv[i][j][r] = pp[(long long)((r & 3) + 8 * (r >> 2)) * g.ldp];
+      }
+  }
+  for (; c < n_chunks; c += 2) {  // tail (at most four chunks)
     compute(c);
     if (c + 1 < n_chunks) lstore(ra1, rb1, c + 1);
     if (c + 3 < n_chunks) gload(ra1, rb1, c + 3);
@@ -182,12 +237,11 @@ __global__ __launch_bounds__(WM* WN * 64) void ia_gemm_kernel(IaGemm g) {
     if (c + 1 >= n_chunks) break;
     compute(c + 1);
     if (c + 2 < n_chunks) lstore(ra0, rb0, c + 2);
-    if (c + 4 < n_chunks) gload(ra0, rb0, c + 4);
     __syncthreads();
   }
 
   float* C = g.C;
-  if (MODE == IA_GEMM_TN) C += (long long)split * g.c_split_stride;
+  if (MODE == IA_GEMM_TN) C += (long long)tc.split * g.c_split_stride;
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -195,23 +249,63 @@ __global__ __launch_bounds__(WM* WN * 64) void ia_gemm_kernel(IaGemm g) {
       const int col = bn0 + (wn * TN + j) * 32 + li;
       const int rbase = bm0 + (wm * TM + i) * 32 + 4 * lh;
       float bcol = 0.f;
-      if (MODE == IA_GEMM_NT && g.bias != nullptr && col < g.N) bcol = g.bias[col];
+      if (MODE == IA_GEMM_NT && g.bias != nullptr && (FAST || col < g.N)) bcol = g.bias[col];
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = rbase + (r & 3) + 8 * (r >> 2);
-        if (row < g.M && col < g.N) {
+        if (FAST || (row < g.M && col < g.N)) {
           float v = acc[i][j][r];
           if (MODE == IA_GEMM_NT) {
             v = ia_apply_act(v + bcol, g.act);
           } else if (MODE == IA_GEMM_NN) {
-            if (g.P != nullptr) v *= ia_act_grad_from_post(g.P[(long long)row * g.ldp + col], g.act);
+            if (g.P != nullptr)
+              v *= ia_act_grad_from_post(PREP ? pv[PREP ? i : 0][PREP ? j : 0][r] : g.P[(long long)row * g.ldp + col], g.act);
           }
           C[(long long)row * g.ldc + col] = v;
         }
       }
     }
   }
-  if (do_db && tid < BM && bm0 + tid < g.M) g.dbias[(long long)split * g.dbias_split_stride + bm0 + tid] = dbacc;
+  if (do_db && tid < BM && bm0 + tid < g.M) g.dbias[(long long)tc.split * g.dbias_split_stride + bm0 + tid] = dbacc;
+}
+
+template <int WM, int WN, int TM, int TN, int MODE>
+__global__ __launch_bounds__(WM* WN * 64) void ia_gemm_kernel(IaGemm g) {
+  constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+
+  // XCD-aware block order: hardware places block b on XCD b%8. Give each XCD a CONTIGUOUS run of
+  // (split, tile) work items: column tiles that share an A row-block -- and, for split-K, all the
+  // tiles of one K-slab -- then run on the same XCD and are served by its L2 instead of being
+  // re-fetched into eight different L2s (PMC: 98 MB -> ~algorithmic for the 256x256 wgrad).
+  const int tiles_n = (g.N + BN - 1) / BN;
+  const int tiles_m = (g.M + BM - 1) / BM;
+  const int tiles = tiles_m * tiles_n;
+  const int nb = gridDim.x;
+  const int b = blockIdx.x;
+  const int q = nb >> 3, rmd = nb & 7, xcd = b & 7;
+  const int lin = (xcd < rmd ? xcd * (q + 1) : rmd * (q + 1) + (xcd - rmd) * q) + (b >> 3);
+  TileCtx tc;
+  tc.split = lin / tiles;
+  const int t = lin - tc.split * tiles;
+  tc.bm0 = (t / tiles_n) * BM;
+  tc.bn0 = (t % tiles_n) * BN;
+  tc.k_begin = 0;
+  tc.k_end = g.K;
+  if (MODE == IA_GEMM_TN) {
+    tc.k_begin = tc.split * g.k_per_split;
+    tc.k_end = min(g.K, tc.k_begin + g.k_per_split);
+  }
+  tc.a_vec = (g.lda % 4 == 0) && ((reinterpret_cast<uintptr_t>(g.A) & 15) == 0);
+  tc.b_vec = (g.ldb % 4 == 0) && ((reinterpret_cast<uintptr_t>(g.B) & 15) == 0);
+  // Block-uniform choice of the unguarded path: whole tile in range, full K chunks, aligned rows.
+  const bool fast = tc.a_vec && tc.b_vec && (tc.bm0 + BM <= g.M) && (tc.bn0 + BN <= g.N) &&
+                    (tc.k_end > tc.k_begin) && ((tc.k_end - tc.k_begin) % BK == 0);
+  if (fast) {
+    gemm_tile<WM, WN, TM, TN, MODE, true>(g, tc, smem);
+  } else {
+    gemm_tile<WM, WN, TM, TN, MODE, false>(g, tc, smem);
+  }
 }
 
 // ---- optional per-launch timing with HIP events on the launch stream (bench.py roofline) ----

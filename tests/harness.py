@@ -161,18 +161,30 @@ def snapshot(trainer) -> Dict[str, np.ndarray]:
     return out
 
 
-def run_case(impl: str, name: str, log_dir: str, device: str = "cpu") -> Dict[str, np.ndarray]:
+def run_case(impl: str, name: str, log_dir: str, device: str = "cpu", sync_disc: bool = False) -> Dict[str, np.ndarray]:
     cfg = CASES[name]
     trainer, venv = build_trainer(impl, cfg, log_dir, device)
     stats = []
-    orig = trainer.train_disc
+    if hasattr(trainer, "_log_disc_stats") and not sync_disc:
+        # product: record where the statistics are logged, so `train()` keeps its own schedule
+        # (all updates of a round enqueued before any statistics are read back)
+        orig_log = trainer._log_disc_stats
 
-    def recording_train_disc(**kw):
-        s = orig(**kw)
-        stats.append([float(s[k]) for k in sorted(s)])
-        return s
+        def recording_log(*a, **kw):
+            s = orig_log(*a, **kw)
+            stats.append([float(s[k]) for k in sorted(s)])
+            return s
 
-    trainer.train_disc = recording_train_disc
+        trainer._log_disc_stats = recording_log
+    else:
+        orig = trainer.train_disc
+
+        def recording_train_disc(**kw):
+            s = orig(**kw)
+            stats.append([float(s[k]) for k in sorted(s)])
+            return s
+
+        trainer.train_disc = recording_train_disc  # a replaced train_disc is called once per update
     trainer.train(cfg["rounds"] * cfg["n_envs"] * cfg["n_steps"])
     out = snapshot(trainer)
     out["disc_stats"] = np.asarray(stats, dtype=np.float64)

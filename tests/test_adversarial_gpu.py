@@ -66,6 +66,19 @@ def test_hip_trainer_matches_live_oracle(tmp_path):
     _compare(got, ref, cfg)
 
 
+@pytest.mark.parametrize("case", ["gail_box", "airl_box"])
+def test_deferred_statistics_schedule_is_bit_identical(case, tmp_path):
+    """`train()` enqueues a round's discriminator updates before reading any statistics back; a
+    user-replaced `train_disc` is called (and synchronised) once per update. Same kernels, same
+    order on each stream => every array, and every logged statistic, must agree bit for bit."""
+    a = harness.run_case("hip", case, str(tmp_path / "a"), device="cuda")
+    b = harness.run_case("hip", case, str(tmp_path / "b"), device="cuda", sync_disc=True)
+    assert set(a) == set(b)
+    for k in a:
+        assert np.array_equal(np.asarray(a[k]), np.asarray(b[k]), equal_nan=True), k
+    assert len(a["disc_stats"]) == harness.CASES[case]["rounds"] * harness.CASES[case]["n_disc"]
+
+
 def test_discrete_actions_structural(tmp_path):
     """Categorical sampling uses inverse-CDF on a host U(0,1) draw (same distribution, different
     stream than torch.multinomial), so trajectories are not comparable value-by-value; integer
