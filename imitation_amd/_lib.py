@@ -54,6 +54,7 @@ class HipExtensionMissing(RuntimeError):
 _P, _I, _L, _F, _D = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_double
 _SIGS = {
     "ia_version": ([], C.c_int),
+    "ia_host_mt19937_permutations": ([_P, C.POINTER(C.c_int), _L, _I, _P], C.c_int),
     "ia_mlp_param_count": ([C.POINTER(MlpDesc)], C.c_int64),
     "ia_mlp_hidden_floats_per_row": ([C.POINTER(MlpDesc)], C.c_int64),
     "ia_gemm_f32": ([_I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _P, _I, _P, _I, _I, _P, _P], C.c_int),
@@ -96,6 +97,10 @@ _SIGS = {
                                C.c_int),
     "ia_ppo_epoch": ([C.POINTER(PolicyDesc), _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _F,
                       _F, _F, _P, _P, _D, _D, _D, _F, _L, _P, _P, _P], C.c_int),
+    "ia_ppo_update_ws_floats": ([C.POINTER(PolicyDesc), _I], C.c_int64),
+    "ia_ppo_update_xcd_pack": ([_I], C.c_int),
+    "ia_ppo_update": ([C.POINTER(PolicyDesc), _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F,
+                       _F, _F, _F, _P, _P, _D, _D, _D, _F, _L, _P, _P, _P], C.c_int),
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGS)

@@ -1,0 +1,72 @@
+// Host-side helpers of the C ABI (no device code): index draws that must reproduce NumPy's
+// legacy global generator bit for bit, runnable off the Python thread (ctypes drops the GIL).
+#include <cstdint>
+
+#include "common.h"
+
+namespace {
+
+constexpr int MT_N = 624, MT_M = 397;
+
+inline void mt_refill(uint32_t* key) {
+  constexpr uint32_t A = 0x9908b0dfu, UP = 0x80000000u, LO = 0x7fffffffu;
+  int i = 0;
+  for (; i < MT_N - MT_M; ++i) {
+    const uint32_t y = (key[i] & UP) | (key[i + 1] & LO);
+    key[i] = key[i + MT_M] ^ (y >> 1) ^ (-(int32_t)(y & 1) & A);
+  }
+  for (; i < MT_N - 1; ++i) {
+    const uint32_t y = (key[i] & UP) | (key[i + 1] & LO);
+    key[i] = key[i + (MT_M - MT_N)] ^ (y >> 1) ^ (-(int32_t)(y & 1) & A);
+  }
+  const uint32_t y = (key[MT_N - 1] & UP) | (key[0] & LO);
+  key[MT_N - 1] = key[MT_M - 1] ^ (y >> 1) ^ (-(int32_t)(y & 1) & A);
+}
+
+inline uint32_t mt_next32(uint32_t* key, int& pos) {
+  if (pos == MT_N) {
+    mt_refill(key);
+    pos = 0;
+  }
+  uint32_t y = key[pos++];
+  y ^= y >> 11;
+  y ^= (y << 7) & 0x9d2c5680u;
+  y ^= (y << 15) & 0xefc60000u;
+  y ^= y >> 18;
+  return y;
+}
+
+// NumPy legacy `random_interval`: masked rejection on 32-bit draws (max < 2^32 here).
+inline uint64_t legacy_interval(uint32_t* key, int& pos, uint64_t max) {
+  if (max == 0) return 0;
+  uint64_t mask = max;
+  mask |= mask >> 1; mask |= mask >> 2; mask |= mask >> 4; mask |= mask >> 8; mask |= mask >> 16; mask |= mask >> 32;
+  uint64_t v;
+  while ((v = (mt_next32(key, pos) & mask)) > max) {}
+  return v;
+}
+
+}  // namespace
+
+// `count` consecutive `np.random.permutation(n)` draws of the legacy MT19937 RandomState whose
+// state is (key[624], *pos): out[c*n .. c*n+n) = arange(n) shuffled by the legacy Fisher-Yates
+// loop (`for i in n-1..1: j = random_interval(i); swap(x[i], x[j])`). key / pos are advanced in
+// place exactly as NumPy would have ([SB3 RolloutBuffer.get] draws one per PPO epoch).
+extern "C" int ia_host_mt19937_permutations(uint32_t* key, int* pos, int64_t n, int count, int64_t* out) {
+  if (key == nullptr || pos == nullptr || out == nullptr || n < 0 || count < 0 || *pos < 0 || *pos > MT_N ||
+      n > 0xffffffffLL)
+    return IA_ERR_ARG;
+  int p = *pos;
+  for (int c = 0; c < count; ++c) {
+    int64_t* x = out + (int64_t)c * n;
+    for (int64_t i = 0; i < n; ++i) x[i] = i;
+    for (int64_t i = n - 1; i >= 1; --i) {
+      const int64_t j = (int64_t)legacy_interval(key, p, (uint64_t)i);
+      const int64_t t = x[i];
+      x[i] = x[j];
+      x[j] = t;
+    }
+  }
+  *pos = p;
+  return IA_OK;
+}

@@ -377,24 +377,28 @@ constexpr int PREP_THREADS = 1024;
 constexpr int PREP_STAGE_FLOATS = 24576;            // 96 KB of staged observation rows
 constexpr int PREP_LDS_FLOATS = PREP_STAGE_FLOATS + 16 * 65 + 65 + 64;
 
-__device__ __forceinline__ float block_sum_1024(float v, float* red /*>=17 floats*/) {
+template <int NT>
+__device__ __forceinline__ float block_sum(float v, float* red /*>=17 floats*/) {
   for (int s = 32; s > 0; s >>= 1) v += __shfl_down(v, s, 64);
   __syncthreads();
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
   __syncthreads();
   if (threadIdx.x == 0) {
     float t = 0.f;
-    for (int k = 0; k < 16; ++k) t += red[k];
+    for (int k = 0; k < NT / 64; ++k) t += red[k];
     red[16] = t;
   }
   __syncthreads();
   return red[16];
 }
+__device__ __forceinline__ float block_sum_1024(float v, float* red) { return block_sum<1024>(v, red); }
 
 // Minibatch statistics (SB3 PPO.train: advantage mean / unbiased std; train-mode RunningNorm
 // update of the feature extractor with the minibatch observations, util/networks.py:111-134).
 // Element-parallel gathers staged through LDS; all reductions in fixed order.
-__device__ void prepare_stats(const ia_policy_desc& d, const float* __restrict__ obs, const float* __restrict__ adv,
+// NT = threads of the calling block (1024: prepare / apply kernels, 512: the persistent update).
+template <int NT>
+__device__ void prepare_stats_t(const ia_policy_desc& d, const float* __restrict__ obs, const float* __restrict__ adv,
                               const int64_t* __restrict__ idx, int batch, int T, int n_envs, int update_norm,
                               float* __restrict__ nm, float* __restrict__ nv, int32_t* __restrict__ ncount,
                               float* __restrict__ advstat, float* lds) {
@@ -406,14 +410,14 @@ __device__ void prepare_stats(const ia_policy_desc& d, const float* __restrict__
   // advantages: the first value of each thread stays in a register for the second pass
   const float a0 = tid < batch ? adv[mb_row(idx, tid, T, n_envs)] : 0.f;
   float s = a0;
-  for (int i = tid + PREP_THREADS; i < batch; i += PREP_THREADS) s += adv[mb_row(idx, i, T, n_envs)];
-  const float mean = block_sum_1024(s, misc) / (float)batch;
+  for (int i = tid + NT; i < batch; i += NT) s += adv[mb_row(idx, i, T, n_envs)];
+  const float mean = block_sum<NT>(s, misc) / (float)batch;
   float q = tid < batch ? (a0 - mean) * (a0 - mean) : 0.f;
-  for (int i = tid + PREP_THREADS; i < batch; i += PREP_THREADS) {
+  for (int i = tid + NT; i < batch; i += NT) {
     const float dl = adv[mb_row(idx, i, T, n_envs)] - mean;
     q += dl * dl;
   }
-  const float qq = block_sum_1024(q, misc);
+  const float qq = block_sum<NT>(q, misc);
   if (tid == 0) {
     advstat[0] = mean;
     advstat[1] = batch > 1 ? sqrtf(qq / (float)(batch - 1)) : 0.f;
@@ -426,25 +430,25 @@ __device__ void prepare_stats(const ia_policy_desc& d, const float* __restrict__
   for (int c0 = 0; c0 < batch; c0 += chunk_rows) {
     const int rows = min(chunk_rows, batch - c0);
     __syncthreads();
-    if (idx == nullptr) {
+    if (idx == nullptr && NT == 1024) {
       // contiguous rows: a straight linear copy (no index math), all loads of a thread issued
       // before its first LDS store so they are in flight together
-      constexpr int MAXIT = PREP_STAGE_FLOATS / PREP_THREADS;
+      constexpr int MAXIT = PREP_STAGE_FLOATS / NT;
       const float* __restrict__ srcp = obs + (long long)c0 * D;
       const int nel = rows * D;
       float v[MAXIT];
 #pragma unroll
       for (int it = 0; it < MAXIT; ++it) {
-        const int e = tid + it * PREP_THREADS;
+        const int e = tid + it * NT;
         v[it] = e < nel ? srcp[e] : 0.f;
       }
 #pragma unroll
       for (int it = 0; it < MAXIT; ++it) {
-        const int e = tid + it * PREP_THREADS;
+        const int e = tid + it * NT;
         if (e < nel) stage[e] = v[it];
       }
     } else {
-      for (int e = tid; e < rows * D; e += PREP_THREADS) {
+      for (int e = tid; e < rows * D; e += NT) {
         const int r = e / D, k = e - r * D;
         stage[r * DP + k] = obs[mb_row(idx, c0 + r, T, n_envs) * D + k];
       }
@@ -452,19 +456,19 @@ __device__ void prepare_stats(const ia_policy_desc& d, const float* __restrict__
     __syncthreads();
     float cs = 0.f;
     if (col < D)
-      for (int r = rg; r < rows; r += 16) cs += stage[r * DP + col];
+      for (int r = rg; r < rows; r += NT / 64) cs += stage[r * DP + col];
     red[rg * 65 + col] = cs;
     __syncthreads();
     if (rg == 0 && col < D) {
       float t = 0.f;
-      for (int g = 0; g < 16; ++g) t += red[g * 65 + col];
+      for (int g = 0; g < NT / 64; ++g) t += red[g * 65 + col];
       cmean[col] = t / (float)rows;
     }
     __syncthreads();
     float cq = 0.f;
     if (col < D) {
       const float cm = cmean[col];
-      for (int r = rg; r < rows; r += 16) {
+      for (int r = rg; r < rows; r += NT / 64) {
         const float dl = stage[r * DP + col] - cm;
         cq += dl * dl;
       }
@@ -473,7 +477,7 @@ __device__ void prepare_stats(const ia_policy_desc& d, const float* __restrict__
     __syncthreads();
     if (rg == 0 && col < D) {
       float t = 0.f;
-      for (int g = 0; g < 16; ++g) t += red[g * 65 + col];
+      for (int g = 0; g < NT / 64; ++g) t += red[g * 65 + col];
       const float nb = (float)rows, mb = cmean[col];
       const float tot = n_acc + nb, dlt = mb - m_acc;
       M2 = M2 + t + dlt * dlt * n_acc * nb / tot;
@@ -494,6 +498,13 @@ __device__ void prepare_stats(const ia_policy_desc& d, const float* __restrict__
     nv[col] = rv / tot;
   }
   if (tid == 0) *ncount = cnt + batch;
+}
+
+__device__ void prepare_stats(const ia_policy_desc& d, const float* __restrict__ obs, const float* __restrict__ adv,
+                              const int64_t* __restrict__ idx, int batch, int T, int n_envs, int update_norm,
+                              float* __restrict__ nm, float* __restrict__ nv, int32_t* __restrict__ ncount,
+                              float* __restrict__ advstat, float* lds) {
+  prepare_stats_t<PREP_THREADS>(d, obs, adv, idx, batch, T, n_envs, update_norm, nm, nv, ncount, advstat, lds);
 }
 
 __global__ __launch_bounds__(PREP_THREADS) void ppo_prepare_kernel(ia_policy_desc d, const float* __restrict__ obs,
@@ -822,25 +833,55 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
-__global__ __launch_bounds__(512) void ppo_grad_mfma32_kernel(
-    ia_policy_desc d, const float* __restrict__ P, const float* __restrict__ Pt, const float* __restrict__ nm,
-    const float* __restrict__ nv, const float* __restrict__ obs, const float* __restrict__ actions,
-    const float* __restrict__ old_logp, const float* __restrict__ adv, const float* __restrict__ ret,
-    const int64_t* __restrict__ idx, int batch, int T, int n_envs, int normalize_adv, float clip, float ent_coef,
-    float vf_coef, float* __restrict__ ws, int nblk, long long* __restrict__ tstamp) {
+// Rows of one minibatch as the kernels address them.
+struct MbRows {
+  const float *obs, *actions, *old_logp, *adv, *ret;
+  const int64_t* idx;   // permutation slice (null: rows already gathered, contiguous)
+  int batch, T, n_envs;
+};
+
+// One minibatch of block `vblk` (64 rows): forward, losses, backward; gradient partials -> `slab`,
+// loss-statistic partials -> `statpart[0..4]`. LOAD_PARAMS: copy the flat parameter vectors into LDS
+// first (one launch per minibatch); otherwise they are already resident there (persistent kernel).
+// STAGED: the block's raw feature rows and per-row scalars were prefetched into the LDS staging
+// area `stg` (layout UpdStage) instead of being gathered from global memory here.
+struct UpdStage {
+  static constexpr int x = 0;                                   // [ROWS][XS] raw observations (0 where unused)
+  static constexpr int oldlp = ROWS * (MAXD + 1);               // [ROWS]
+  static constexpr int adv = oldlp + ROWS, ret = adv + ROWS;    // [ROWS] each
+  static constexpr int src = ret + ROWS;                        // [ROWS] row offset into the rollout tile (as float bits)
+  static constexpr int nxt = src + ROWS;                        // [ROWS] row offsets of the minibatch being prefetched
+  static constexpr int ring = nxt + ROWS;                       // [UPD_RS_] copy of the minibatch's statistics-ring slot
+  static constexpr int total = ring + 2 * MAXD + 8;
+};
+template <bool LOAD_PARAMS, bool STAGED = false>
+__device__ __forceinline__ void mfma32_minibatch(
+    const ia_policy_desc& d, const float* __restrict__ P, const float* __restrict__ Pt, const float* __restrict__ nm,
+    const float* __restrict__ nv, const float adv_mean, const float adv_std, const MbRows rows, const int vblk,
+    const int normalize_adv, const float clip, const float ent_coef, const float vf_coef, float* __restrict__ slab,
+    float* __restrict__ statpart, float* __restrict__ lds_in, long long* __restrict__ tstamp,
+    const float* __restrict__ stg = nullptr, const int opaque_zero = 0) {
+  // `opaque_zero` is 0 at run time but unknown to the compiler (the persistent kernel re-makes it
+  // every step): thread ids and LDS addresses derived from it are not loop-invariant, so nothing
+  // of this body is hoisted out of the step loop and kept alive across it.
+  float* __restrict__ lds = lds_in + opaque_zero;
+  const float* __restrict__ obs = rows.obs;
+  const float* __restrict__ actions = rows.actions;
+  const float* __restrict__ old_logp = rows.old_logp;
+  const float* __restrict__ adv = rows.adv;
+  const float* __restrict__ ret = rows.ret;
+  const int64_t* __restrict__ idx = rows.idx;
+  const int batch = rows.batch, T = rows.T, n_envs = rows.n_envs;
   constexpr int H = 32;
   using L = GLds<32>;
-#define IA_TS(slot) do { if (tstamp && blockIdx.x == 0 && threadIdx.x == 0) tstamp[slot] = clock64(); } while (0)
-  extern __shared__ float lds[];
-  const int tid = threadIdx.x, lane = tid & 63;
+#define IA_TS(slot) do { if (tstamp && vblk == 0 && threadIdx.x == 0) tstamp[slot] = clock64(); } while (0)
+  const int tid = threadIdx.x + opaque_zero, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int tw = wv >> 2, q = wv & 3;
   const int li = lane & 15, lk = lane >> 4;
   const int D = d.obs_dim, A = d.act_dim;
   const PolOff o = pol_offsets(D, A, H, d.discrete);
-  const PpoWs w = ppo_ws(ws, nblk, o.total);
-  float* slab = w.slabs + (long long)blockIdx.x * o.total;
-  const int i0 = blockIdx.x * ROWS;
+  const int i0 = vblk * ROWS;
   const int aw = d.discrete ? 1 : A;
   const float invB = 1.f / (float)batch;
   const int S1 = (D + 3) >> 2, SA = (A + 3) >> 2;
@@ -857,33 +898,43 @@ __global__ __launch_bounds__(512) void ppo_grad_mfma32_kernel(
     const int e = tid + it * 512;
     const int r = e / L::XS, k = e - r * L::XS;
     const bool ok = e < ROWS * L::XS && k < D && i0 + r < batch;
-    xv[it] = ok ? obs[mb_row(idx, i0 + r, T, n_envs) * D + k] : 0.f;
-    xm[it] = (ok && d.has_norm) ? nm[k] : 0.f;
-    xs_[it] = (ok && d.has_norm) ? nv[k] : 1.f - d.norm_eps;
+    if (STAGED) xv[it] = ok ? stg[UpdStage::x + e] : 0.f;  // (unused slots hold clamped-address data)
+    else xv[it] = ok ? obs[mb_row(idx, i0 + r, T, n_envs) * D + k] : 0.f;
+    if (STAGED) {  // nm / nv always point at a full ring slot here: unconditional loads, masked afterwards
+      // (a guarded load costs a branch and a wait each, which serialises the nine of them)
+      // (arithmetic masking, not a select: a select lets the compiler sink the loads back under the branch)
+      const int kc = min(k, MAXD - 1);
+      const float mv = nm[kc], vv = nv[kc];
+      const float msk = (ok && d.has_norm) ? 1.f : 0.f;
+      xm[it] = mv * msk;
+      xs_[it] = vv * msk + (1.f - msk) * (1.f - d.norm_eps);
+    } else {
+      xm[it] = (ok && d.has_norm) ? nm[k] : 0.f;
+      xs_[it] = (ok && d.has_norm) ? nv[k] : 1.f - d.norm_eps;
+    }
   }
   // per-row scalars of the loss phase (wave 0: policy terms, wave 4: value term)
   const int i = i0 + lane;
   const bool valid = i < batch;
-  const long long src = valid ? mb_row(idx, i, T, n_envs) : 0;
+  const long long src = !valid ? 0 : (STAGED ? (long long)__float_as_int(stg[UpdStage::src + lane]) : mb_row(idx, i, T, n_envs));
   float r_oldlp = 0.f, r_adv = 0.f, r_ret = 0.f, r_act[MAXA];
 #pragma unroll
   for (int a = 0; a < MAXA; ++a) r_act[a] = 0.f;
   if (wv == 0) {
-    r_oldlp = old_logp[src];
-    r_adv = adv[src];
+    r_oldlp = STAGED ? stg[UpdStage::oldlp + lane] : old_logp[src];
+    r_adv = STAGED ? stg[UpdStage::adv + lane] : adv[src];
 #pragma unroll
     for (int a = 0; a < MAXA; ++a)
-      if (a < aw) r_act[a] = actions[src * aw + a];
+      if (a < aw) r_act[a] = actions[src * aw + a];  // consumed in phase 4: the latency hides behind phases 1-3
   }
-  if (wv == 4) r_ret = ret[src];
-  const float adv_mean = w.advstat[0], adv_std = w.advstat[1];
+  if (wv == 4) r_ret = STAGED ? stg[UpdStage::ret + lane] : ret[src];
 
   IA_TS(9);
   // ---- parameters: ONE cooperative, coalesced 16-byte copy of both flat vectors (torch layout P and
   // the transposed shadow copy Pt) into LDS; every weight fragment below is then an LDS read.
   float* sP = lds + L::total;
   float* sPt = sP + ((o.total + 3) & ~3);
-  {
+  if (LOAD_PARAMS) {
     const int n4 = (o.total + 3) >> 2;
     const bool vec = ((reinterpret_cast<uintptr_t>(P) | reinterpret_cast<uintptr_t>(Pt)) & 15) == 0;
     for (int e = tid; e < n4; e += 512) {
@@ -908,14 +959,19 @@ __global__ __launch_bounds__(512) void ppo_grad_mfma32_kernel(
   }
   IA_TS(10);
   // ---- phase 0b: normalise + stage the feature rows in LDS; clear the small tiles
+  auto stage_rows = [&]() {
 #pragma unroll
-  for (int it = 0; it < NIT; ++it) {
-    const int e = tid + it * 512;
-    if (e < ROWS * L::XS) lds[L::x + e] = (xv[it] - xm[it]) / sqrtf(xs_[it] + d.norm_eps);
-  }
-  for (int e = tid; e < ROWS * L::AS; e += 512) { lds[L::dout + e] = 0.f; lds[L::aux + e] = 0.f; lds[L::out + e] = 0.f; }
-  for (int e = tid; e < ROWS * L::MS; e += 512) lds[L::misc + e] = 0.f;
-  __syncthreads();
+    for (int it = 0; it < NIT; ++it) {
+      const int e = tid + it * 512;
+      if (e < ROWS * L::XS) lds[L::x + e] = (xv[it] - xm[it]) / sqrtf(xs_[it] + d.norm_eps);
+    }
+    for (int e = tid; e < ROWS * L::AS; e += 512) { lds[L::dout + e] = 0.f; lds[L::aux + e] = 0.f; lds[L::out + e] = 0.f; }
+    for (int e = tid; e < ROWS * L::MS; e += 512) lds[L::misc + e] = 0.f;
+    __syncthreads();
+  };
+  // With the parameters already resident in LDS the fragment reads below do not depend on this
+  // barrier, so the staging (which waits for the normaliser statistics, a global load) goes after them.
+  if (LOAD_PARAMS) stage_rows();
 
   IA_TS(11);
   // weight fragments (LDS -> VGPR): B[k = 4s+lk][j = c*16+li]
@@ -965,6 +1021,7 @@ __global__ __launch_bounds__(512) void ppo_grad_mfma32_kernel(
     }
   }
 
+  if (!LOAD_PARAMS) stage_rows();
   float* a1t = lds + L::a1 + tw * ROWS * L::HS;
   float* a2t = lds + L::a2 + tw * ROWS * L::HS;
   float* dzt = lds + L::dz + tw * ROWS * L::HS;
@@ -1145,7 +1202,7 @@ __global__ __launch_bounds__(512) void ppo_grad_mfma32_kernel(
 #pragma unroll 8
       for (int r = 0; r < ROWS; ++r) s += lds[L::misc + r * L::MS + 2 + lane];
       const int slot = lane == 0 ? 0 : (lane == 4 ? 1 : lane + 1);
-      w.statpart[blockIdx.x * 8 + slot] = s;
+      statpart[slot] = s;
     }
   }
   __syncthreads();
@@ -1197,6 +1254,21 @@ __global__ __launch_bounds__(512) void ppo_grad_mfma32_kernel(
   __syncthreads();
   IA_TS(8);
 #undef IA_TS
+}
+
+
+__global__ __launch_bounds__(512) void ppo_grad_mfma32_kernel(
+    ia_policy_desc d, const float* __restrict__ P, const float* __restrict__ Pt, const float* __restrict__ nm,
+    const float* __restrict__ nv, const float* __restrict__ obs, const float* __restrict__ actions,
+    const float* __restrict__ old_logp, const float* __restrict__ adv, const float* __restrict__ ret,
+    const int64_t* __restrict__ idx, int batch, int T, int n_envs, int normalize_adv, float clip, float ent_coef,
+    float vf_coef, float* __restrict__ ws, int nblk, long long* __restrict__ tstamp) {
+  extern __shared__ float lds[];
+  const PolOff o = pol_offsets(d.obs_dim, d.act_dim, 32, d.discrete);
+  const PpoWs w = ppo_ws(ws, nblk, o.total);
+  const MbRows rows{obs, actions, old_logp, adv, ret, idx, batch, T, n_envs};
+  mfma32_minibatch<true>(d, P, Pt, nm, nv, w.advstat[0], w.advstat[1], rows, blockIdx.x, normalize_adv, clip, ent_coef,
+                         vf_coef, w.slabs + (long long)blockIdx.x * o.total, w.statpart + blockIdx.x * 8, lds, tstamp);
 }
 
 __global__ __launch_bounds__(PREP_THREADS) void ppo_apply_kernel(
@@ -1283,6 +1355,439 @@ __global__ __launch_bounds__(PREP_THREADS) void ppo_apply_kernel(
   if (next_batch > 0 && gridDim.x == 1) {
     __syncthreads();
     prepare_stats(d, obs, adv, next_idx, next_batch, T, n_envs, update_norm, nm, nv, ncount, w.advstat, lds);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Persistent PPO update (H = 32): ALL minibatch steps of a `PPO.train` call in one launch.
+//
+//   grid = nblk gradient blocks (64 rows each) + 1 statistics block, 512 threads, all co-resident.
+//   Parameters live in LDS (sP torch layout, sPt transposed towers) and Adam's m, v in registers of
+//   EVERY gradient block: after one grid barrier per step each block reduces the nblk gradient
+//   slabs in the same fixed order and applies the same clip + Adam update to its own copy, so no
+//   block ever waits for a parameter broadcast. Slabs are double-buffered by step parity: a block
+//   can only reach the writes of step s+1 after its reads of step s-1's slabs (program order), and
+//   readers of step s finish before anyone passes barrier s+1.
+//   The statistics block runs AHEAD of the gradient chain -- advantage mean/std and the train-mode
+//   feature RunningNorm update of every minibatch depend on the data only -- and publishes them
+//   through a small ring (flag = steps published; back-pressure from the barrier counter).
+// Cross-block visibility: writers fence (agent scope) before the counter increment, readers after
+// the spin (same pattern as the BCE last-block reduction). Spins are bounded: on timeout an error
+// word is set and every block leaves the kernel.
+// Instance for the persistent kernel (parameters resident in LDS, rows staged in LDS). Inlined with
+// the opaque zero below; an out-of-line call measured 4 us per step slower (callee-saved spills).
+__device__ __forceinline__ void mfma32_minibatch_resident(
+    const ia_policy_desc& d, const float* __restrict__ nm, const float* __restrict__ nv, const float adv_mean,
+    const float adv_std, const MbRows& rows, const int vblk, const int normalize_adv, const float clip,
+    const float ent_coef, const float vf_coef, float* __restrict__ slab, float* __restrict__ statpart,
+    float* __restrict__ lds, const float* __restrict__ stg, const int opaque_zero, long long* __restrict__ tstamp) {
+  mfma32_minibatch<false, true>(d, nullptr, nullptr, nm, nv, adv_mean, adv_std, rows, vblk, normalize_adv, clip,
+                                ent_coef, vf_coef, slab, statpart, lds, tstamp, stg + opaque_zero, opaque_zero);
+}
+
+constexpr int UPD_RING = 4;
+constexpr int UPD_MAX_STEPS = 2048;                // optimiser steps per launch (Adam scalar tables in ws)
+constexpr int UPD_NPT = 8;                        // parameters per thread (<= 4096 parameters)
+constexpr int UPD_RS = 2 * MAXD + 8;              // ring slot: mean[MAXD], var[MAXD], adv mean, adv std
+constexpr int UPD_CTRL = 16;                      // control words: 0 arrivals, 1 steps published, 8 error (sticky)
+constexpr int UPD_SD = 8;                         // depth of the loss-statistic partial ring (> UPD_RING + 2)
+struct UpdSched {
+  int n_steps, first, n_mb, batch_size;
+  long long total;
+};
+struct UpdWs {
+  unsigned* ctrl;
+  float *tab;   // [2][UPD_MAX_STEPS]: Adam step size lr/(1-b1^t) and sqrt(1-b2^t) per step (host doubles)
+  float *ring, *normcoef, *statpart, *slabs;   // normcoef: [UPD_SD][2] gradient norm, clip coefficient
+  int P4;
+};
+__host__ __device__ inline UpdWs upd_ws(float* ws, int nblk, int P) {
+  UpdWs w;
+  w.P4 = (P + 3) & ~3;
+  w.ctrl = reinterpret_cast<unsigned*>(ws);
+  w.tab = ws + UPD_CTRL;
+  w.ring = w.tab + 2 * UPD_MAX_STEPS;
+  w.normcoef = w.ring + UPD_RING * UPD_RS;
+  w.statpart = w.normcoef + UPD_SD * 2;
+  w.slabs = w.statpart + UPD_SD * nblk * 8;
+  return w;
+}
+
+__device__ __forceinline__ bool spin_until(unsigned* p, unsigned target, unsigned* err) {
+  unsigned it = 0;
+  while (__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+    __builtin_amdgcn_s_sleep(2);
+    if (++it > (1u << 24)) {
+      __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      return false;
+    }
+    if ((it & 255u) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return false;
+  }
+  return true;
+}
+
+__global__ __launch_bounds__(512) void ppo_update_persistent_kernel(
+    ia_policy_desc d, float* __restrict__ P, float* __restrict__ Pt, float* __restrict__ m, float* __restrict__ v,
+    float* __restrict__ nm, float* __restrict__ nv, int32_t* __restrict__ ncount, int update_norm,
+    const float* __restrict__ obs, const float* __restrict__ actions, const float* __restrict__ old_logp,
+    const float* __restrict__ adv, const float* __restrict__ ret, const int64_t* __restrict__ perm, int T, int n_envs,
+    int normalize_adv, float clip, float ent_coef, float vf_coef, float max_norm, float beta1, float beta2, float eps,
+    float* __restrict__ ws, int nblk, float* __restrict__ stats, UpdSched sch, int xcd_pack,
+    long long* __restrict__ tstamp /* debug: [0..3] += 100 MHz ticks in {stat wait, minibatch, barrier, update} */) {
+  constexpr int H = 32;
+  using L = GLds<32>;
+  extern __shared__ float lds[];
+  __shared__ int s_ok, s_pub;
+  long long tacc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  long long tprev = 0;
+#define UPD_TS(k) do { if (tstamp && tid == 0) { const long long tn = wall_clock64(); tacc[k] += tn - tprev; tprev = tn; } } while (0)
+  // xcd_pack: the launch has 8x the blocks and only every 8th works, so that all working blocks sit
+  // on one XCD (hardware deals consecutive block ids round-robin over the 8 XCDs) and share its L2.
+  if (xcd_pack && (blockIdx.x & 7)) return;
+  const int vb = xcd_pack ? blockIdx.x >> 3 : blockIdx.x;
+  const int tid = threadIdx.x;
+  const int D = d.obs_dim;
+  const PolOff o = pol_offsets(D, d.act_dim, H, d.discrete);
+  const UpdWs w = upd_ws(ws, nblk, o.total);
+  unsigned* arrivals = w.ctrl + 0;
+  unsigned* published = w.ctrl + 1;
+  unsigned* err = w.ctrl + 8;
+
+  // schedule scalars in registers; the per-step tables are read straight from the kernel arguments
+  const int sch_first = sch.first, sch_nmb = sch.n_mb, sch_bs = sch.batch_size, n_steps = sch.n_steps;
+  const long long sch_total = sch.total;
+  auto rows_of = [=](int s) {
+    const int gs = sch_first + s;
+    const int e = gs / sch_nmb, mb = gs - e * sch_nmb;
+    const long long start = (long long)mb * sch_bs;
+    const long long left = sch_total - start;
+    MbRows r{obs, actions, old_logp, adv, ret, perm + (long long)e * sch_total + start,
+             (int)(left < sch_bs ? left : sch_bs), T, n_envs};
+    return r;
+  };
+
+  // Loss statistics of step q: sum of the per-block partials in block order, written by one wave.
+  auto write_loss_stats = [&](int q, float total_norm, float coef) {
+    if (tid < 64 && stats) {
+      const int ln = tid & 63;
+      const float* sb = w.statpart + (q % UPD_SD) * nblk * 8;
+      float st = 0.f;
+      if (ln < 5) {
+        int b = 0;
+        for (; b + 8 <= nblk; b += 8) {
+          float t[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) t[u] = sb[(b + u) * 8 + ln];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) st += t[u];
+        }
+        for (; b < nblk; ++b) st += sb[b * 8 + ln];
+        st *= 1.f / (float)rows_of(q).batch;
+      }
+      const float st0 = __shfl(st, 0, 64), st1 = __shfl(st, 1, 64), st2 = __shfl(st, 2, 64);
+      float* so = stats + (long long)(sch_first + q) * 8;
+      if (ln < 5) so[ln] = st;
+      if (ln == 5) so[5] = st0 + ent_coef * st2 + vf_coef * st1;
+      if (ln == 6) so[6] = total_norm;
+      if (ln == 7) so[7] = coef;
+    }
+  };
+
+  if (vb == nblk) {  // ---------------- statistics block
+    // It also writes the loss statistics of finished steps (all but the last one of the launch):
+    // step q's partials and its (norm, coef) pair are published by barrier q+1's release fences.
+    int q = 0;
+    auto drain = [&](int upto /* exclusive */) {
+      for (; q < upto; ++q)
+        write_loss_stats(q, *reinterpret_cast<const volatile float*>(w.normcoef + (q % UPD_SD) * 2),
+                         *reinterpret_cast<const volatile float*>(w.normcoef + (q % UPD_SD) * 2 + 1));
+    };
+    for (int s = 0; s < n_steps; ++s) {
+      if (s >= UPD_RING) {  // the slot is free once every gradient block has arrived at barrier s - RING
+        if (tid == 0) {
+          s_ok = spin_until(arrivals, (unsigned)(s - UPD_RING + 1) * nblk, err);
+          __threadfence();
+        }
+        __syncthreads();
+        if (!s_ok) return;
+        drain(s - UPD_RING);  // barriers 0 .. s-RING complete => steps 0 .. s-RING-1 fully published
+      }
+      const MbRows r = rows_of(s);
+      float* slot = w.ring + (s % UPD_RING) * UPD_RS;
+      prepare_stats_t<512>(d, r.obs, r.adv, r.idx, r.batch, T, n_envs, update_norm, nm, nv, ncount, slot + 2 * MAXD, lds);
+      __syncthreads();
+      if (d.has_norm && tid < D) {
+        slot[tid] = nm[tid];
+        slot[MAXD + tid] = nv[tid];
+      }
+      __syncthreads();
+      if (tid == 0) {
+        __threadfence();
+        __hip_atomic_store(published, (unsigned)(s + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+    if (tid == 0) {
+      s_ok = spin_until(arrivals, (unsigned)n_steps * nblk, err);
+      __threadfence();
+    }
+    __syncthreads();
+    if (!s_ok) return;
+    drain(n_steps - 1);  // the last step's statistics are written by gradient block 0 itself
+    return;
+  }
+  if (vb > nblk) return;
+
+  // ---------------- gradient blocks
+  float* sP = lds + L::total;
+  float* sPt = sP + w.P4;
+  float* stg = sPt + w.P4;                    // UpdStage: the NEXT minibatch's rows of this block
+  int* dstT = reinterpret_cast<int*>(stg + UpdStage::total);  // [P4] index of parameter i in the transposed copy
+  float* red = lds + L::misc + ROWS * L::MS;  // 64 spare floats behind the misc tile
+  const int lane = tid & 63;
+  const int aw = d.discrete ? 1 : d.act_dim;
+  float rm[UPD_NPT], rv[UPD_NPT];
+#pragma unroll
+  for (int k = 0; k < UPD_NPT; ++k) {
+    const int i = tid + k * 512;
+    rm[k] = rv[k] = 0.f;
+    if (i < o.total) {
+      sP[i] = P[i];
+      sPt[i] = Pt[i];
+      rm[k] = m[i];
+      rv[k] = v[i];
+      int dst = i;
+      auto tr = [&](int base, int rows, int cols) {
+        if (i >= base && i < base + rows * cols) {
+          const int rr = (i - base) / cols, cc = (i - base) % cols;
+          dst = base + cc * rows + rr;
+        }
+      };
+      tr(o.pW1, H, D); tr(o.pW2, H, H); tr(o.vW1, H, D); tr(o.vW2, H, H);
+      dstT[i] = dst;
+    }
+  }
+  // Row prefetch: the gathers of step s+1 (two dependent global loads per element) are issued
+  // before the grid barrier of step s and land in registers behind the barrier wait and the
+  // update; they are parked in the LDS staging area just before step s+1 starts.
+  constexpr int NIT = (ROWS * L::XS + 511) / 512;
+  // (i) one step ahead of (ii): wave 7 resolves permutation entry -> rollout-tile row offset for the
+  // block's 64 rows of minibatch s (a dependent global load plus a division) and leaves them in LDS;
+  // any later block barrier publishes them. (ii) every thread then issues its row gathers at once.
+  auto prefetch_resolve = [&](int s) {
+    if (tid >= 448) {
+      const MbRows r = rows_of(s);
+      const int i0 = vb * ROWS;
+      int src = 0;
+      if (i0 + lane < r.batch) {
+        const long long flat = r.idx[i0 + lane];
+        if (sch_total < (1ll << 31)) {  // 32-bit divide (the 64-bit one is a long software sequence)
+          const unsigned f = (unsigned)flat, env = f / (unsigned)T, t = f - env * (unsigned)T;
+          src = (int)(t * (unsigned)n_envs + env);
+        } else {
+          src = (int)rollout_offset(flat, T, n_envs);
+        }
+      }
+      reinterpret_cast<int*>(stg)[UpdStage::nxt + lane] = src;
+    }
+  };
+  // (ii) global -> LDS directly (no staging registers to keep alive across the update): each wave
+  // instruction drops its 64 dwords at a wave-uniform LDS base + 4*lane, which is exactly the
+  // linear staging order e = it*512 + wave*64 + lane. Addresses are clamped to valid rows/columns;
+  // slots outside the observation width or the batch are masked when the stage is read.
+  typedef __attribute__((address_space(3))) void* lds_void_p;
+  typedef __attribute__((address_space(1))) const void* glb_void_p;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  auto prefetch_issue = [&](int s) {
+    const MbRows r = rows_of(s);
+    const int* nxt = reinterpret_cast<const int*>(stg) + UpdStage::nxt;
+    if (wave == 0) {
+      const int src = nxt[lane];
+      __builtin_amdgcn_global_load_lds((glb_void_p)(r.old_logp + src), (lds_void_p)(stg + UpdStage::oldlp), 4, 0, 0);
+      __builtin_amdgcn_global_load_lds((glb_void_p)(r.adv + src), (lds_void_p)(stg + UpdStage::adv), 4, 0, 0);
+      __builtin_amdgcn_global_load_lds((glb_void_p)(r.ret + src), (lds_void_p)(stg + UpdStage::ret), 4, 0, 0);
+    }
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int e0 = it * 512 + wave * 64;  // wave-uniform
+      if (e0 < ROWS * L::XS) {
+        const int e = min(e0 + lane, ROWS * L::XS - 1);
+        const int rr = e / L::XS, k = e - rr * L::XS;
+        const int src = nxt[rr];
+        __builtin_amdgcn_global_load_lds((glb_void_p)(r.obs + (long long)src * D + min(k, D - 1)),
+                                         (lds_void_p)(stg + UpdStage::x + e0), 4, 0, 0);
+      }
+    }
+  };
+  auto prefetch_park = [&]() {  // row offsets of the staged minibatch (its action loads use them)
+    if (wave == 0) stg[UpdStage::src + lane] = stg[UpdStage::nxt + lane];
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the LDS-direct loads have landed
+  };
+  if (n_steps > 0) {
+    prefetch_resolve(0);
+    __syncthreads();
+    prefetch_issue(0);
+    prefetch_park();
+  }
+  __syncthreads();
+
+  // The statistics-ring slot of step s+1 is normally published long before step s ends: it is then
+  // copied into LDS behind barrier s (whose acquire fence covers it) and step s+1 starts without a
+  // wait, a fence or a dependent global load. `have_ring`: the LDS copy holds this step's slot.
+  bool have_ring = false;
+  float pf_r[3] = {0.f, 0.f, 0.f};
+  if (tstamp && tid == 0) tprev = wall_clock64();
+  for (int s = 0; s < n_steps; ++s) {
+    const MbRows r = rows_of(s);
+    const float* slot = w.ring + (s % UPD_RING) * UPD_RS;
+    float adv_mean, adv_std;
+    if (!have_ring) {
+      if (tid == 0) {
+        s_ok = spin_until(published, (unsigned)(s + 1), err);
+        __threadfence();
+      }
+      __syncthreads();
+      if (!s_ok) return;
+      adv_mean = *reinterpret_cast<const volatile float*>(slot + 2 * MAXD);
+      adv_std = *reinterpret_cast<const volatile float*>(slot + 2 * MAXD + 1);
+    } else {
+      slot = stg + UpdStage::ring;
+      adv_mean = slot[2 * MAXD];
+      adv_std = slot[2 * MAXD + 1];
+    }
+    UPD_TS(0);
+    if (s + 1 < n_steps) prefetch_resolve(s + 1);  // published by the block barriers inside the minibatch
+    float* slab_base = w.slabs + (long long)(s & 1) * nblk * w.P4;
+    float* stat_base = w.statpart + (s % UPD_SD) * nblk * 8;
+    int oz;
+    asm volatile("s_mov_b32 %0, 0" : "=s"(oz));
+    mfma32_minibatch_resident(d, slot, slot + MAXD, adv_mean, adv_std, r, vb, normalize_adv, clip, ent_coef, vf_coef,
+                              slab_base + (long long)vb * w.P4, stat_base + vb * 8, lds, stg, oz,
+                              tstamp ? tstamp + 16 : nullptr);
+    // (the minibatch ends with a block barrier: every slab store of this block has been issued)
+    UPD_TS(1);
+    if (tid == 0) {  // arrive first; the prefetch below overlaps the wait for the other blocks
+      __threadfence();
+      UPD_TS(7);
+      __hip_atomic_fetch_add(arrivals, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    UPD_TS(8);
+    if (s + 1 < n_steps) prefetch_issue(s + 1);
+    UPD_TS(9);
+    if (tid == 0) {
+      s_ok = spin_until(arrivals, (unsigned)(s + 1) * nblk, err);
+      s_pub = (int)__hip_atomic_load(published, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      UPD_TS(10);
+      __threadfence();
+      UPD_TS(11);
+    }
+    __syncthreads();
+    if (!s_ok) return;
+    have_ring = (s + 1 < n_steps) && (s_pub >= s + 2);
+    if (have_ring) {  // issue now, park with the rows after the update
+      const float* nslot = w.ring + ((s + 1) % UPD_RING) * UPD_RS;
+      if (tid < MAXD) {
+        pf_r[0] = nslot[tid];
+        pf_r[1] = nslot[MAXD + tid];
+      }
+      if (tid < 8) pf_r[2] = nslot[2 * MAXD + tid];
+    }
+    UPD_TS(2);
+
+    // reduce the slabs (fixed order b = 0..nblk-1 per parameter), global norm, clip, Adam --
+    // identical in every block. All loads of a group of 8 slabs are in flight together.
+    float g[UPD_NPT];
+    float sq = 0.f;
+#pragma unroll
+    for (int k = 0; k < UPD_NPT; ++k) g[k] = 0.f;
+    {
+      constexpr int KH = UPD_NPT / 2;  // 4 parameters x 8 slabs = 32 loads in flight per thread
+      int b = 0;
+      for (; b + 8 <= nblk; b += 8) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          float t[KH][8];
+#pragma unroll
+          for (int k = 0; k < KH; ++k) {
+            // clamped index: every load is unconditional (a guarded load costs a branch and a full
+            // wait each, which serialises the whole batch); lanes past the end are discarded below
+            const int i = min(tid + (h * KH + k) * 512, o.total - 1);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) t[k][u] = slab_base[(long long)(b + u) * w.P4 + i];
+          }
+#pragma unroll
+          for (int k = 0; k < KH; ++k)
+#pragma unroll
+            for (int u = 0; u < 8; ++u) g[h * KH + k] += t[k][u];
+        }
+      }
+      for (; b < nblk; ++b) {
+#pragma unroll
+        for (int k = 0; k < UPD_NPT; ++k) g[k] += slab_base[(long long)b * w.P4 + min(tid + k * 512, o.total - 1)];
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < UPD_NPT; ++k) {
+      if (tid + k * 512 >= o.total) g[k] = 0.f;
+      sq += g[k] * g[k];
+    }
+    UPD_TS(4);
+    const float total_sq = block_sum<512>(sq, red);
+    UPD_TS(5);
+    const float total_norm = sqrtf(total_sq);
+    const float coef = fminf(max_norm / (total_norm + 1e-6f), 1.0f);  // torch clip_grad_norm_
+    if (vb == 0) {
+      if (s + 1 < n_steps) {  // the statistics block writes this step's loss statistics later
+        if (tid == 0) {
+          w.normcoef[(s % UPD_SD) * 2] = total_norm;
+          w.normcoef[(s % UPD_SD) * 2 + 1] = coef;
+        }
+      } else {
+        write_loss_stats(s, total_norm, coef);
+      }
+    }
+    const float step_size = w.tab[s], bc2_sqrt = w.tab[UPD_MAX_STEPS + s];
+#pragma unroll
+    for (int k = 0; k < UPD_NPT; ++k) {
+      const int i = tid + k * 512;
+      if (i < o.total) {
+        const float gi = g[k] * coef;
+        float mi = rm[k];
+        mi = mi + (gi - mi) * (1.f - beta1);
+        const float vi = rv[k] * beta2 + (1.f - beta2) * gi * gi;
+        const float denom = sqrtf(vi) / bc2_sqrt + eps;
+        const float pn = sP[i] - step_size * (mi / denom);
+        rm[k] = mi;
+        rv[k] = vi;
+        sP[i] = pn;
+        sPt[dstT[i]] = pn;
+      }
+    }
+    UPD_TS(6);
+    if (s + 1 < n_steps) prefetch_park();
+    if (have_ring) {
+      if (tid < MAXD) {
+        stg[UpdStage::ring + tid] = pf_r[0];
+        stg[UpdStage::ring + MAXD + tid] = pf_r[1];
+      }
+      if (tid < 8) stg[UpdStage::ring + 2 * MAXD + tid] = pf_r[2];
+    }
+    __syncthreads();
+    UPD_TS(3);
+  }
+#undef UPD_TS
+  if (tstamp && vb == 0 && tid == 0)
+    for (int k = 0; k < 12; ++k) tstamp[k] += tacc[k];
+  if (vb == 0) {
+#pragma unroll
+    for (int k = 0; k < UPD_NPT; ++k) {
+      const int i = tid + k * 512;
+      if (i < o.total) {
+        P[i] = sP[i];
+        Pt[i] = sPt[i];
+        m[i] = rm[k];
+        v[i] = rv[k];
+      }
+    }
   }
 }
 
@@ -1639,6 +2144,91 @@ int ia_ppo_epoch(const ia_policy_desc* d, float* params, float* params_t, float*
     rc = launch_minibatch_next(v, b, (float)(lr / bc1), (float)sqrt(bc2), stats ? stats + mb * 8 : nullptr,
                                nb ? at_rows(a, g, nstart) : v, nb);
     if (rc) return rc;
+  }
+  return IA_OK;
+}
+
+
+// Workspace of ia_ppo_update in floats; 0 when the persistent kernel does not cover the shape
+// (the caller then runs ia_ppo_epoch per epoch).
+int64_t ia_ppo_update_ws_floats(const ia_policy_desc* d, int batch_size) {
+  if (!pol_ok(d) || batch_size <= 0) return IA_ERR_ARG;
+  const int P = pol_offsets(d->obs_dim, d->act_dim, d->hidden, d->discrete).total;
+  const int nblk = cdiv(batch_size, ROWS);
+  if (d->hidden != 32 || P > UPD_NPT * 512 || nblk > 30 || g_ppo_valu) return 0;
+  const int P4 = (P + 3) & ~3;
+  return UPD_CTRL + 2 * UPD_MAX_STEPS + UPD_RING * UPD_RS + UPD_SD * 2 + UPD_SD * (int64_t)nblk * 8 +
+         2 * (int64_t)nblk * P4;
+}
+
+bool g_upd_xcd_pack = false;
+constexpr int HOST_TAB_SLOTS = 8;
+struct HostTab { float* buf = nullptr; hipEvent_t done; };
+HostTab g_host_tab[HOST_TAB_SLOTS];
+int g_host_tab_next = 0;
+int ia_ppo_update_xcd_pack(int on) { g_upd_xcd_pack = on != 0; return IA_OK; }
+
+// A whole PPO.train: n_epochs passes over consecutive minibatches of perm[e][T*n_envs] (SB3
+// RolloutBuffer.get order), in ONE persistent launch per <= UPD_MAX_STEPS optimiser steps.
+// stats: [n_epochs * n_minibatches][8] or NULL. ws must be zero-initialised once by the caller;
+// word 8 of it is a sticky error flag (non-zero: a grid wait timed out, results invalid).
+int ia_ppo_update(const ia_policy_desc* d, float* params, float* params_t, float* norm_mean, float* norm_var,
+                  int32_t* norm_count, int update_norm, const float* obs, const float* actions, const float* old_logp,
+                  const float* advantages, const float* returns, const int64_t* perm, int n_epochs, int T, int n_envs,
+                  int batch_size, int normalize_adv, float clip_range, float ent_coef, float vf_coef,
+                  float max_grad_norm, float* exp_avg, float* exp_avg_sq, double lr, double beta1, double beta2,
+                  float adam_eps, int64_t adam_steps_done, float* ws, float* stats, void* stream) {
+  if (!pol_ok(d) || batch_size <= 0 || n_epochs <= 0 || ia_ppo_update_ws_floats(d, batch_size) <= 0) return IA_ERR_ARG;
+  const long long total = (long long)T * n_envs;
+  const int n_mb = cdiv(total, batch_size);
+  const int nblk = cdiv(batch_size, ROWS);
+  const int P = pol_offsets(d->obs_dim, d->act_dim, 32, d->discrete).total;
+  const int P4 = (P + 3) & ~3;
+  const size_t grad_bytes = (GLds<32>::total + 3 * P4 + UpdStage::total) * sizeof(float);
+  const size_t prep_bytes = PREP_LDS_FLOATS * sizeof(float);
+  const size_t bytes = grad_bytes > prep_bytes ? grad_bytes : prep_bytes;
+  static size_t attr_bytes = 0;
+  if (bytes > attr_bytes) { int rc = set_lds(ppo_update_persistent_kernel, bytes); if (rc) return rc; attr_bytes = bytes; }
+  hipStream_t st = (hipStream_t)stream;
+  const int steps_total = n_epochs * n_mb;
+  int64_t step = adam_steps_done;
+  for (int first = 0; first < steps_total; first += UPD_MAX_STEPS) {
+    UpdSched sch;
+    sch.n_steps = steps_total - first < UPD_MAX_STEPS ? steps_total - first : UPD_MAX_STEPS;
+    sch.first = first; sch.n_mb = n_mb; sch.batch_size = batch_size; sch.total = total;
+    // Adam's per-step scalars, formed in double on the host exactly as torch.optim.Adam does, staged
+    // through a small ring of pinned buffers (a slot is reused only after its copy has completed).
+    HostTab& ht = g_host_tab[g_host_tab_next];
+    g_host_tab_next = (g_host_tab_next + 1) % HOST_TAB_SLOTS;
+    if (ht.buf == nullptr) {
+      hipError_t e0 = hipHostMalloc(reinterpret_cast<void**>(&ht.buf), 2 * UPD_MAX_STEPS * sizeof(float), 0);
+      if (e0 != hipSuccess) return (int)e0;
+      e0 = hipEventCreateWithFlags(&ht.done, hipEventDisableTiming);
+      if (e0 != hipSuccess) return (int)e0;
+    } else {
+      hipError_t e0 = hipEventSynchronize(ht.done);
+      if (e0 != hipSuccess) return (int)e0;
+    }
+    for (int s = 0; s < sch.n_steps; ++s) {
+      ++step;
+      const double bc1 = 1.0 - pow(beta1, (double)step);
+      const double bc2 = 1.0 - pow(beta2, (double)step);
+      ht.buf[s] = (float)(lr / bc1);
+      ht.buf[UPD_MAX_STEPS + s] = (float)sqrt(bc2);
+    }
+    const UpdWs uw = upd_ws(ws, nblk, P);
+    hipError_t ec = hipMemcpyAsync(uw.tab, ht.buf, 2 * UPD_MAX_STEPS * sizeof(float), hipMemcpyHostToDevice, st);
+    if (ec != hipSuccess) return (int)ec;
+    ec = hipEventRecord(ht.done, st);
+    if (ec != hipSuccess) return (int)ec;
+    hipError_t e = hipMemsetAsync(ws, 0, 8 * sizeof(unsigned), st);  // arrivals / published (error word stays)
+    if (e != hipSuccess) return (int)e;
+    const int grid = (nblk + 1) * (g_upd_xcd_pack ? 8 : 1);
+    hipLaunchKernelGGL(ppo_update_persistent_kernel, dim3(grid), dim3(512), bytes, st, *d, params, params_t, exp_avg,
+                       exp_avg_sq, norm_mean, norm_var, norm_count, update_norm, obs, actions, old_logp, advantages,
+                       returns, perm, T, n_envs, normalize_adv, clip_range, ent_coef, vf_coef, max_grad_norm,
+                       (float)beta1, (float)beta2, adam_eps, ws, nblk, stats, sch, g_upd_xcd_pack ? 1 : 0, g_tstamp);
+    IA_CHECK_LAUNCH();
   }
   return IA_OK;
 }

@@ -17,6 +17,7 @@ import collections
 import ctypes as C
 import random
 import sys
+import threading
 import time
 from typing import Any, Dict, Optional
 
@@ -75,6 +76,64 @@ class _CallbackList(_NullCallback):
 
     def on_training_end(self):
         for c in self.cbs: c.on_training_end()
+
+
+class _PermutationPredraw:
+    """Draws the `n_epochs` minibatch permutations of the NEXT PPO update while the rollout is
+    still stepping the environments, on a private copy of the state of NumPy's global generator
+    (`ia_host_mt19937_permutations`: the legacy MT19937 Fisher-Yates draw, bit for bit, in C --
+    ctypes releases the GIL, so the helper thread does not slow the rollout down).
+
+    SB3 draws them from the global generator at the start of `PPO.train` (`RolloutBuffer.get`), i.e.
+    right after the rollout. The copy is only adopted if, at that point, the global generator is
+    still in the state it was copied from (nobody -- e.g. an environment -- drew from it during the
+    rollout); the global state then jumps to the copy's post-draw state, which is exactly what
+    drawing in place would have produced. Otherwise the speculation is dropped and the permutations
+    are drawn in place. Either way values and generator state equal the reference's."""
+
+    def __init__(self, n_epochs: int, size: int):
+        self.n_epochs, self.size = n_epochs, size
+        self._thread: Optional[threading.Thread] = None
+        self._state0 = None
+        self._key: Optional[np.ndarray] = None
+        self._pos = C.c_int(0)
+        self._rc = 0
+        self._out: Optional[np.ndarray] = None
+
+    @staticmethod
+    def _same(a, b) -> bool:
+        return a[0] == b[0] and a[2:] == b[2:] and np.array_equal(a[1], b[1])
+
+    def start(self, out: np.ndarray) -> None:
+        assert out.dtype == np.int64 and out.flags.c_contiguous and out.shape == (self.n_epochs, self.size)
+        st = np.random.get_state()
+        if st[0] != "MT19937":
+            self._thread = None
+            return
+        self._state0 = st
+        self._key = np.ascontiguousarray(st[1], dtype=np.uint32).copy()
+        self._pos = C.c_int(int(st[2]))
+        self._out = out
+        lib = L.load()
+
+        def work():
+            self._rc = lib.ia_host_mt19937_permutations(self._key.ctypes.data, C.byref(self._pos), self.size,
+                                                        self.n_epochs, out.ctypes.data)
+
+        self._thread = threading.Thread(target=work, daemon=True)
+        self._thread.start()
+
+    def finish(self, out: np.ndarray) -> bool:
+        """True if `out` now holds the permutations and the global generator has advanced past them."""
+        t, self._thread = self._thread, None
+        if t is None:
+            return False
+        t.join()
+        if self._rc != 0 or out is not self._out or not self._same(np.random.get_state(), self._state0):
+            return False
+        s0 = self._state0
+        np.random.set_state((s0[0], self._key, int(self._pos.value), s0[3], s0[4]))
+        return True
 
 
 class RolloutBuffer:
@@ -187,7 +246,12 @@ class PPO(OnPolicyAlgorithm):
                                 device=self.device)
         self._perm_host = th.zeros(self.n_epochs, total, dtype=th.int64).pin_memory()
         self._perm_dev = th.zeros(self.n_epochs, total, dtype=th.int64, device=self.device)
+        self._perm_np = self._perm_host.numpy()
+        self._predraw = _PermutationPredraw(self.n_epochs, total)
         self._stats_dev = th.zeros(self.n_epochs, self._n_mb, 8, device=self.device)
+        n_upd = int(L.load().ia_ppo_update_ws_floats(C.byref(p.desc), min(self.batch_size, total)))
+        # persistent whole-update kernel (hidden = 32); None -> one ia_ppo_epoch call per epoch
+        self._upd_ws = th.zeros(n_upd, device=self.device) if n_upd > 0 else None
         self.dp = None  # set by the trainer for data-parallel runs (imitation_amd.distributed.DataParallel)
         # When True, `train()` only ENQUEUES the update and returns; the caller overlaps other GPU
         # work with it and later calls `finalize_train()` (one D2H of the statistics + logging).
@@ -305,6 +369,7 @@ class PPO(OnPolicyAlgorithm):
                 fused_net = owner
         T, n = rb.buffer_size, rb.n_envs
         assert n_rollout_steps == T
+        self._predraw.start(self._perm_np)  # consumed by the `train()` that follows
         stream = th.cuda.current_stream()
         rb.h_obs[0].copy_(th.as_tensor(np.asarray(self._last_obs)).reshape(n, -1))
         rb.obs[0].copy_(rb.h_obs[0], non_blocking=True)
@@ -419,15 +484,27 @@ class PPO(OnPolicyAlgorithm):
         pol.optimizer.param_groups[0]["lr"] = lr
         clip_range = self.clip_range(self._current_progress_remaining)
         T, n = rb.buffer_size, rb.n_envs
-        perm = self._perm_host.numpy()
-        for e in range(self.n_epochs):  # one global-NumPy draw per epoch, as RolloutBuffer.get does
-            perm[e] = np.random.permutation(T * n)
+        perm = self._perm_np
+        if not self._predraw.finish(perm):
+            for e in range(self.n_epochs):  # one global-NumPy draw per epoch, as RolloutBuffer.get does
+                perm[e] = np.random.permutation(T * n)
         self._perm_dev.copy_(self._perm_host, non_blocking=True)
         rn = pol.features_extractor.normalize
         g = pol.optimizer.param_groups[0]
         if self.dp is not None and self.dp.world > 1:
             self._train_data_parallel(perm, lr, clip_range)
-        for e in range(self.n_epochs if not (self.dp is not None and self.dp.world > 1) else 0):
+        single = not (self.dp is not None and self.dp.world > 1)
+        if single and self._upd_ws is not None:
+            L.call("ia_ppo_update", C.byref(pol.desc), L.ptr(pol._flat), L.ptr(pol._flat_t),
+                   L.ptr(rn.running_mean) if rn else None, L.ptr(rn.running_var) if rn else None,
+                   L.ptr(rn.count) if rn else None, int(rn is not None), L.ptr(rb.obs), L.ptr(rb.acts), L.ptr(rb.logp),
+                   L.ptr(rb.adv), L.ptr(rb.ret), L.ptr(self._perm_dev), self.n_epochs, T, n, min(self.batch_size, T * n),
+                   int(self.normalize_advantage), float(clip_range), float(self.ent_coef), float(self.vf_coef),
+                   float(self.max_grad_norm), L.ptr(pol.optimizer.exp_avg), L.ptr(pol.optimizer.exp_avg_sq),
+                   float(lr), float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]), pol.optimizer.step_count,
+                   L.ptr(self._upd_ws), L.ptr(self._stats_dev), L.stream())
+            pol.optimizer.step_count += self.n_epochs * self._n_mb
+        for e in range(self.n_epochs if (single and self._upd_ws is None) else 0):
             L.call("ia_ppo_epoch", C.byref(pol.desc), L.ptr(pol._flat), L.ptr(pol._flat_t),
                    L.ptr(rn.running_mean) if rn else None, L.ptr(rn.running_var) if rn else None,
                    L.ptr(rn.count) if rn else None, int(rn is not None), L.ptr(rb.obs), L.ptr(rb.acts), L.ptr(rb.logp),
@@ -449,6 +526,9 @@ class PPO(OnPolicyAlgorithm):
         clip_range, self._pending_train = self._pending_train, None
         pol, rb = self.policy, self.rollout_buffer
         st = self._stats_dev.cpu().numpy()  # one synchronisation per train()
+        if self._upd_ws is not None and int(self._upd_ws[8:9].view(th.int32).item()) != 0:
+            raise RuntimeError("ia_ppo_update: a grid-wide wait timed out inside the persistent PPO kernel; "
+                               "the parameters of this update are invalid")
         vals, rets = rb.val.cpu().numpy().reshape(-1), rb.ret.cpu().numpy().reshape(-1)
         var_y = np.var(rets)
         ev = np.nan if var_y == 0 else 1 - np.var(rets - vals) / var_y

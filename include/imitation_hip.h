@@ -33,6 +33,12 @@ typedef struct {
 } ia_mlp_desc;
 
 int ia_version(void);
+
+/* HOST helper (no device work): `count` consecutive `np.random.permutation(n)` draws of NumPy's
+ * legacy MT19937 global generator, bit for bit, advancing (key[624], *pos) in place -- the
+ * per-epoch minibatch order of [SB3 RolloutBuffer.get] (adversarial/common.py:391-403 -> PPO.train).
+ * Lets the host draw them off the Python thread while the rollout runs. out: int64 [count, n]. */
+int ia_host_mt19937_permutations(uint32_t* key, int* pos, int64_t n, int count, int64_t* out);
 int64_t ia_mlp_param_count(const ia_mlp_desc* d);
 /* floats of workspace per row needed for hidden activations (sum of hidden widths) */
 int64_t ia_mlp_hidden_floats_per_row(const ia_mlp_desc* d);
@@ -224,8 +230,9 @@ int ia_ppo_minibatch_grad(const ia_policy_desc* d, float* params, float* params_
                           int batch, int T, int n_envs, int normalize_adv, float clip_range, float ent_coef,
                           float vf_coef, float* ws, void* stream);
 int64_t ia_ppo_grad_offset(const ia_policy_desc* d, int batch);
-/* Debug/measurement: when set to a device buffer of 16 int64, block 0 of every ppo_grad launch
- * stores the shader clock at its 9 phase boundaries (NULL switches it off). */
+/* Debug/measurement: when set to a device buffer of 32 int64, block 0 of every ppo_grad launch
+ * stores the shader clock at its phase boundaries in [0..11]; ia_ppo_update accumulates 100 MHz ticks
+ * per step phase in [0..7] and stores the last step's phase clocks in [16..27] (NULL switches it off). */
 int ia_ppo_debug_timing(void* device_buffer_16xi64);
 /* Tuning/tests: 1 = use the VALU (thread-per-row) gradient kernel also for hidden = 32 instead of
  * the MFMA 16x16x4 one (hidden = 64 always uses the VALU kernel). */
@@ -242,6 +249,25 @@ int ia_ppo_epoch(const ia_policy_desc* d, float* params, float* params_t, float*
                  int batch_size, int normalize_adv, float clip_range, float ent_coef, float vf_coef,
                  float max_grad_norm, float* exp_avg, float* exp_avg_sq, double lr, double beta1, double beta2,
                  float adam_eps, int64_t adam_steps_done, float* ws, float* stats, void* stream);
+
+/* A whole [SB3 PPO.train]: n_epochs passes over consecutive minibatches of perm[n_epochs][T*n_envs]
+ * in ONE persistent launch (hidden = 32): nblk gradient blocks keep the parameters in LDS and
+ * Adam's moments in registers, meet at one grid barrier per optimiser step, reduce the gradient
+ * slabs redundantly in fixed order and apply identical clip + Adam updates; a further block runs
+ * ahead computing each minibatch's advantage statistics and train-mode RunningNorm update.
+ * ia_ppo_update_ws_floats returns 0 when the shape is not covered (use ia_ppo_epoch per epoch);
+ * ws must be zeroed once by the caller, word 8 of it is a sticky error flag (a bounded grid wait
+ * timed out: results invalid). stats: [n_epochs*n_minibatches][8] or NULL.
+ * ia_ppo_update_xcd_pack(1) launches 8x the blocks so the working ones share one XCD (default 0:
+ * spread over all XCDs, which measured faster). */
+int64_t ia_ppo_update_ws_floats(const ia_policy_desc* d, int batch_size);
+int ia_ppo_update_xcd_pack(int on);
+int ia_ppo_update(const ia_policy_desc* d, float* params, float* params_t, float* norm_mean, float* norm_var,
+                  int32_t* norm_count, int update_norm, const float* obs, const float* actions, const float* old_logp,
+                  const float* advantages, const float* returns, const int64_t* perm, int n_epochs, int T, int n_envs,
+                  int batch_size, int normalize_adv, float clip_range, float ent_coef, float vf_coef,
+                  float max_grad_norm, float* exp_avg, float* exp_avg_sq, double lr, double beta1, double beta2,
+                  float adam_eps, int64_t adam_steps_done, float* ws, float* stats, void* stream);
 
 #ifdef __cplusplus
 }

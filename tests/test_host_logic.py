@@ -227,3 +227,51 @@ def test_policy_and_reward_net_init_match_oracle_rng():
     assert set(sd_o) == set(sd_p)
     for k in sd_o:
         assert th.equal(sd_o[k], sd_p[k].cpu()), k
+
+
+def test_permutation_predraw_equals_in_place_draws():
+    """The PPO minibatch permutations are drawn during the rollout on a copy of NumPy's global
+    generator and adopted only if the global generator was not used meanwhile: values AND the
+    generator's post-state must equal drawing in place ([SB3 RolloutBuffer.get] order)."""
+    from imitation_amd.ppo import _PermutationPredraw
+
+    np.random.seed(3)
+    ref = [np.random.permutation(1000) for _ in range(4)]
+    ref_next = np.random.randint(10 ** 6)
+    np.random.seed(3)
+    out = np.zeros((4, 1000), dtype=np.int64)
+    p = _PermutationPredraw(4, 1000)
+    p.start(out)
+    assert p.finish(out)
+    assert all(np.array_equal(out[e], ref[e]) for e in range(4))
+    assert np.random.randint(10 ** 6) == ref_next
+    # a foreign draw during the speculation window: dropped, global state untouched by us
+    np.random.seed(3)
+    np.random.rand()
+    want = np.random.rand()
+    np.random.seed(3)
+    p.start(out)
+    np.random.rand()
+    assert not p.finish(out)
+    assert np.random.rand() == want
+    assert not p.finish(out)  # nothing pending
+
+
+@pytest.mark.parametrize("n,count,seed", [(1, 3, 0), (2, 5, 1), (17, 7, 2), (16384, 10, 3), (65537, 2, 4)])
+def test_host_mt19937_permutations_bit_exact(n, count, seed):
+    """C-ABI host helper vs `np.random.permutation`: values, and the generator state afterwards
+    (key block and position), across several state refills and mask widths."""
+    import ctypes as C
+
+    from imitation_amd import _lib as L
+
+    np.random.seed(seed)
+    np.random.rand(seed)  # odd starting position
+    st = np.random.get_state()
+    want = np.stack([np.random.permutation(n) for _ in range(count)])
+    after = np.random.get_state()
+    key, pos = st[1].copy(), C.c_int(int(st[2]))
+    out = np.empty((count, n), dtype=np.int64)
+    assert L.load().ia_host_mt19937_permutations(key.ctypes.data, C.byref(pos), n, count, out.ctypes.data) == 0
+    assert np.array_equal(out, want)
+    assert pos.value == after[2] and np.array_equal(key, after[1])

@@ -394,9 +394,14 @@ def test_timeout_bootstrap():
                                                         (4, 3, 32, True, True, 8, 16, 40),
                                                         (64, 16, 32, False, True, 4, 32, 64),
                                                         (33, 1, 32, False, False, 2, 70, 140)])
-def test_ppo_epochs_match_oracle(D, A, H, discrete, norm, T, n, bs):
+@pytest.mark.parametrize("path", ["epoch", "update", "update_spread"])
+def test_ppo_epochs_match_oracle(D, A, H, discrete, norm, T, n, bs, path):
     """Two PPO epochs on a synthetic rollout: parameters, Adam state, RunningNorm state and the
-    logged loss statistics against SB3-restated `PPO.train` on the same permutations."""
+    logged loss statistics against SB3-restated `PPO.train` on the same permutations -- through
+    one `ia_ppo_epoch` call per epoch, and through the single persistent `ia_ppo_update` launch
+    (working blocks packed on one XCD, or spread over all of them)."""
+    if path != "epoch" and H != 32:
+        pytest.skip("the persistent update covers hidden = 32")
     from imitation_amd import spaces
     from oracle import imitation_restated as o
     from oracle import sb3_restated as sb
@@ -437,11 +442,28 @@ def test_ppo_epochs_match_oracle(D, A, H, discrete, norm, T, n, bs):
     ws = th.empty(int(L.load().ia_ppo_ws_floats(C.byref(dp.d), bs, T * n)), device=DEV)
     n_mb = -(-T * n // bs)
     stats = th.zeros(2, n_mb, 8, device=DEV)
-    for e in range(2):
-        L.call("ia_ppo_epoch", C.byref(dp.d), L.ptr(dp.P), L.ptr(dp.Pt), L.ptr(dp.nm), L.ptr(dp.nv), L.ptr(dp.nc),
-               int(norm), L.ptr(d_obs), L.ptr(d_act), L.ptr(d_lp), L.ptr(d_adv), L.ptr(d_ret),
-               dptr(perms[e], th.int64), T, n, bs, 1, 0.2, 0.05, 0.5, 0.5, L.ptr(dp.m), L.ptr(dp.v), 3e-4, 0.9,
-               0.999, 1e-5, e * n_mb, L.ptr(ws), L.ptr(stats[e]), L.stream())
+    if path == "epoch":
+        for e in range(2):
+            L.call("ia_ppo_epoch", C.byref(dp.d), L.ptr(dp.P), L.ptr(dp.Pt), L.ptr(dp.nm), L.ptr(dp.nv), L.ptr(dp.nc),
+                   int(norm), L.ptr(d_obs), L.ptr(d_act), L.ptr(d_lp), L.ptr(d_adv), L.ptr(d_ret),
+                   dptr(perms[e], th.int64), T, n, bs, 1, 0.2, 0.05, 0.5, 0.5, L.ptr(dp.m), L.ptr(dp.v), 3e-4, 0.9,
+                   0.999, 1e-5, e * n_mb, L.ptr(ws), L.ptr(stats[e]), L.stream())
+    else:
+        nws = int(L.load().ia_ppo_update_ws_floats(C.byref(dp.d), bs))
+        if nws == 0:
+            pytest.skip("shape not covered by the persistent kernel (more than 4096 parameters)")
+        uws = th.zeros(nws, device=DEV)
+        d_perm = th.as_tensor(np.stack(perms)).to(DEV)
+        L.load().ia_ppo_update_xcd_pack(1 if path == "update" else 0)
+        try:
+            L.call("ia_ppo_update", C.byref(dp.d), L.ptr(dp.P), L.ptr(dp.Pt), L.ptr(dp.nm), L.ptr(dp.nv), L.ptr(dp.nc),
+                   int(norm), L.ptr(d_obs), L.ptr(d_act), L.ptr(d_lp), L.ptr(d_adv), L.ptr(d_ret), L.ptr(d_perm), 2, T,
+                   n, bs, 1, 0.2, 0.05, 0.5, 0.5, L.ptr(dp.m), L.ptr(dp.v), 3e-4, 0.9, 0.999, 1e-5, 0, L.ptr(uws),
+                   L.ptr(stats), L.stream())
+            th.cuda.synchronize()
+        finally:
+            L.load().ia_ppo_update_xcd_pack(0)
+        assert int(uws[8:9].view(th.int32).item()) == 0, "grid wait timed out"
     th.cuda.synchronize()
     flat_ref = th.cat([p.detach().reshape(-1) for p in pol_ref.parameters()])
     k = 2 * n_mb  # optimiser steps taken; tolerance scaled as the reference's own test does

@@ -1,0 +1,46 @@
+"""Where the persistent PPO update (ia_ppo_update) spends its time at config P: block 0 accumulates
+100 MHz ticks per phase {wait for statistics, minibatch fwd/bwd, grid barrier, reduce+clip+Adam}.
+Usage: python tools/ppo_update_timing.py [xcd_pack 0|1]"""
+import os
+import sys
+import time
+
+import torch as th
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402
+from imitation_amd import _lib as L  # noqa: E402
+
+pack = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+th.set_num_threads(1)
+cfg = dict(bench.CFG_P)
+tr = bench.build_trainer(bench.hip_namespace(), cfg, "cuda")
+per_round = cfg["n_envs"] * cfg["n_steps"]
+tr.train(2 * per_round)
+th.cuda.synchronize()
+algo = tr.gen_algo
+algo.defer_train_stats = True
+L.load().ia_ppo_update_xcd_pack(pack)
+buf = th.zeros(32, dtype=th.int64, device="cuda")
+L.load().ia_ppo_debug_timing(buf.data_ptr())
+for rep in range(3):
+    buf.zero_()
+    th.cuda.synchronize()
+    t = time.perf_counter()
+    algo.train()
+    th.cuda.synchronize()
+    d = time.perf_counter() - t
+    steps = algo.n_epochs * algo._n_mb
+    ticks = buf.cpu().numpy()[:12]
+    names = ("wait statistics", "minibatch fwd/bwd", "grid barrier", "park+sync", "slab reduce", "norm (block sum)", "stats+Adam", "release fence", "atomic add", "prefetch issue", "spin", "acquire fence")
+    print(f"xcd_pack={pack}: train() {1e3 * d:.2f} ms for {steps} steps; per step: " +
+          ", ".join(f"{n} {t_ / 100.0 / steps:.2f} us" for n, t_ in zip(names, ticks)))
+t = buf.cpu().numpy()[16:28]
+import numpy as np  # noqa: E402
+d = np.diff(t[:9])
+names = ["0 stage/fragments", "1 layer1", "2 layer2", "3 heads", "4 loss", "5 head grads/dz2", "6 dW2/da1", "7 dW1"]
+print("shader clocks per minibatch phase (last step, block 0):")
+for n_, v in zip(names, d):
+    print(f"  {n_:18s} {v:8d} clk  ~{v / 2.4e3:6.2f} us @2.4GHz")
+print("  phase0 detail: ->row loads", t[9] - t[0], " ->params", t[10] - t[9], " ->staged+sync", t[11] - t[10], " ->fragments", t[1] - t[11])
+L.load().ia_ppo_debug_timing(None)

@@ -1,0 +1,74 @@
+"""Host and device timeline of overlapped GAIL rounds at config P: when the host finishes each
+enqueue step, and when each stream finishes its work (HIP events), relative to the round start.
+Usage: python tools/round_timeline.py [rounds]"""
+import os
+import sys
+import time
+
+import torch as th
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402
+
+rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 5
+th.set_num_threads(1)
+cfg = dict(bench.CFG_P)
+tr = bench.build_trainer(bench.hip_namespace(), cfg, "cuda")
+per_round = cfg["n_envs"] * cfg["n_steps"]
+tr.train(3 * per_round)
+th.cuda.synchronize()
+algo = tr.gen_algo
+marks = []
+t0 = [0.0]
+ev0 = [None]
+dev_marks = []
+
+
+def host_mark(name):
+    marks.append((name, 1e3 * (time.perf_counter() - t0[0])))
+
+
+def dev_mark(name, stream=None):
+    e = th.cuda.Event(enable_timing=True)
+    e.record(stream if stream is not None else th.cuda.current_stream())
+    dev_marks.append((name, e))
+
+
+def wrap(obj, attr, name, dev=False, stream_of=None):
+    orig = getattr(obj, attr)
+
+    def f(*a, **k):
+        r = orig(*a, **k)
+        host_mark(name)
+        if dev:
+            dev_mark(name)
+        return r
+
+    setattr(obj, attr, f)
+
+
+wrap(algo, "collect_rollouts", "collect_rollouts returned", dev=True)
+wrap(algo, "train", "ppo train enqueued", dev=True)
+wrap(tr, "_disc_round", "disc round enqueued", dev=True)
+wrap(tr, "_replay_policy_norm_updates", "norm replay enqueued", dev=True)
+wrap(tr, "_finish_disc_round", "disc stats logged")
+wrap(algo, "finalize_train", "ppo stats logged")
+tot = {}
+for r in range(rounds):
+    marks.clear()
+    dev_marks.clear()
+    th.cuda.synchronize()
+    t0[0] = time.perf_counter()
+    s = th.cuda.Event(enable_timing=True)
+    s.record()
+    tr.train(per_round)
+    host_mark("round returned")
+    th.cuda.synchronize()
+    host_mark("device idle")
+    if r == rounds - 1:
+        print("host timeline (ms since round start):")
+        for n, t in marks:
+            print(f"  {t:8.2f}  {n}")
+        print("device timeline (ms since round start, completion of the work enqueued up to that point on that stream):")
+        for n, e in dev_marks:
+            print(f"  {s.elapsed_time(e):8.2f}  {n}")
