@@ -248,6 +248,7 @@ class PPO(OnPolicyAlgorithm):
         self._perm_dev = th.zeros(self.n_epochs, total, dtype=th.int64, device=self.device)
         self._perm_np = self._perm_host.numpy()
         self._predraw = _PermutationPredraw(self.n_epochs, total)
+        self.update_events = None  # optional (start, end) torch events around the persistent update launch
         self._stats_dev = th.zeros(self.n_epochs, self._n_mb, 8, device=self.device)
         n_upd = int(L.load().ia_ppo_update_ws_floats(C.byref(p.desc), min(self.batch_size, total)))
         # persistent whole-update kernel (hidden = 32); None -> one ia_ppo_epoch call per epoch
@@ -495,6 +496,8 @@ class PPO(OnPolicyAlgorithm):
             self._train_data_parallel(perm, lr, clip_range)
         single = not (self.dp is not None and self.dp.world > 1)
         if single and self._upd_ws is not None:
+            if self.update_events is not None:  # measurement hook (bench.py): events on the launch stream
+                self.update_events[0].record()
             L.call("ia_ppo_update", C.byref(pol.desc), L.ptr(pol._flat), L.ptr(pol._flat_t),
                    L.ptr(rn.running_mean) if rn else None, L.ptr(rn.running_var) if rn else None,
                    L.ptr(rn.count) if rn else None, int(rn is not None), L.ptr(rb.obs), L.ptr(rb.acts), L.ptr(rb.logp),
@@ -503,6 +506,8 @@ class PPO(OnPolicyAlgorithm):
                    float(self.max_grad_norm), L.ptr(pol.optimizer.exp_avg), L.ptr(pol.optimizer.exp_avg_sq),
                    float(lr), float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]), pol.optimizer.step_count,
                    L.ptr(self._upd_ws), L.ptr(self._stats_dev), L.stream())
+            if self.update_events is not None:
+                self.update_events[1].record()
             pol.optimizer.step_count += self.n_epochs * self._n_mb
         for e in range(self.n_epochs if (single and self._upd_ws is None) else 0):
             L.call("ia_ppo_epoch", C.byref(pol.desc), L.ptr(pol._flat), L.ptr(pol._flat_t),
