@@ -417,6 +417,107 @@ int64_t ia_mlp_hidden_floats_per_row(const ia_mlp_desc* d) {
   return s;
 }
 
+}  // extern "C" (kernels of the single-output layer follow)
+
+namespace {
+
+// Single-output Linear (the logit / reward / potential head, out_size = 1): a GEMM tile would leave
+// 127 of 128 MFMA columns idle and re-launch for an elementwise amount of work, so it runs as a
+// streaming row-dot: one wave per row, 16-byte loads, butterfly reduction.
+//   out[r] = act(dot(in[r, :K], w) + b)
+__global__ __launch_bounds__(256) void rowdot_kernel(const float* __restrict__ in, int ldin, const float* __restrict__ w,
+                                                     const float* __restrict__ b, int R, int K, int act,
+                                                     float* __restrict__ out) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int waves = gridDim.x * 4;
+  const bool vec = (K % 4 == 0) && (ldin % 4 == 0) && ((reinterpret_cast<uintptr_t>(in) & 15) == 0) &&
+                   ((reinterpret_cast<uintptr_t>(w) & 15) == 0);
+  for (int r = blockIdx.x * 4 + wave; r < R; r += waves) {
+    const float* row = in + (long long)r * ldin;
+    float acc = 0.f;
+    if (vec) {
+      for (int k = lane * 4; k < K; k += 256) {
+        const float4 x = *reinterpret_cast<const float4*>(row + k);
+        const float4 ww = *reinterpret_cast<const float4*>(w + k);
+        acc += x.x * ww.x + x.y * ww.y + x.z * ww.z + x.w * ww.w;
+      }
+    } else {
+      for (int k = lane; k < K; k += 64) acc += row[k] * w[k];
+    }
+    for (int s = 32; s > 0; s >>= 1) acc += __shfl_xor(acc, s, 64);
+    if (lane == 0) out[r] = ia_apply_act(acc + (b ? b[0] : 0.f), act);
+  }
+}
+
+// Backward of that layer in ONE pass over the previous activations H[R, N] (post-activation):
+//   dIn[r, c]   = dY[r] * w[c] * act'(H[r, c])                      (input gradient, written to dhidden)
+//   dW_s[c]     = sum_{r in slab s} dY[r] * H[r, c]                 (weight-gradient partial of K-slab s)
+//   db_s        = sum_{r in slab s} dY[r]
+// grid = (column chunks of 64, splits); block = 16 column quads x 16 row groups.
+__global__ __launch_bounds__(256) void single_out_backward_kernel(const float* __restrict__ dY, const float* __restrict__ H,
+                                                                  int ldh, const float* __restrict__ w, int R, int N,
+                                                                  int rows_per_split, int act, float* __restrict__ dIn,
+                                                                  int ldd, float* __restrict__ dW, float* __restrict__ db,
+                                                                  long long split_stride) {
+  __shared__ float red[16][65];
+  __shared__ float redb[16];
+  const int cq = threadIdx.x & 15, rg = threadIdx.x >> 4;
+  const int c0 = blockIdx.x * 64 + cq * 4;
+  const int split = blockIdx.y;
+  const int r0 = split * rows_per_split, r1 = min(R, r0 + rows_per_split);
+  const bool vec = (N % 4 == 0) && (ldh % 4 == 0) && (ldd % 4 == 0) && c0 + 3 < N;
+  float wv[4], acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int j = 0; j < 4; ++j) wv[j] = c0 + j < N ? w[c0 + j] : 0.f;
+  float bacc = 0.f;
+  for (int r = r0 + rg; r < r1; r += 16) {
+    const float g = dY[r];
+    bacc += g;
+    float h[4];
+    if (vec) {
+      const float4 t = *reinterpret_cast<const float4*>(H + (long long)r * ldh + c0);
+      h[0] = t.x; h[1] = t.y; h[2] = t.z; h[3] = t.w;
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) h[j] = c0 + j < N ? H[(long long)r * ldh + c0 + j] : 0.f;
+    }
+    float o[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      acc[j] += g * h[j];
+      o[j] = g * wv[j] * ia_act_grad_from_post(h[j], act);
+    }
+    if (vec) {
+      *reinterpret_cast<float4*>(dIn + (long long)r * ldd + c0) = make_float4(o[0], o[1], o[2], o[3]);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (c0 + j < N) dIn[(long long)r * ldd + c0 + j] = o[j];
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) red[rg][cq * 4 + j] = acc[j];
+  if (cq == 0) redb[rg] = bacc;
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    const int c = blockIdx.x * 64 + threadIdx.x;
+    float t = 0.f;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) t += red[g][threadIdx.x];
+    if (c < N) dW[(long long)split * split_stride + c] = t;
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 64 && db != nullptr) {
+    float t = 0.f;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) t += redb[g];
+    db[(long long)split * split_stride] = t;
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
 int ia_mlp_forward(const ia_mlp_desc* d, const float* params, const float* X, int ldx, int R, float* hidden,
                    float* out, int out_act, void* stream) {
   if (!desc_ok(d) || R <= 0) return IA_ERR_ARG;
@@ -435,7 +536,15 @@ int ia_mlp_forward(const ia_mlp_desc* d, const float* params, const float* X, in
     g.M = R; g.N = d->dims[l + 1]; g.K = d->dims[l];
     g.C = last ? out : hp; g.ldc = d->dims[l + 1];
     g.act = last ? out_act : d->hidden_act;
-    int rc = ia_launch_gemm(IA_GEMM_NT, g, (hipStream_t)stream);
+    int rc = IA_OK;
+    if (g.N == 1 && l > 0) {  // single-output head: streaming row-dot instead of a GEMM tile
+      const int blocks = R / 4 < 2048 ? (R + 3) / 4 : 2048;
+      hipLaunchKernelGGL(rowdot_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, g.A, g.lda, g.B, g.bias, R,
+                         g.K, g.act, g.C);
+      IA_CHECK_LAUNCH();
+    } else {
+      rc = ia_launch_gemm(IA_GEMM_NT, g, (hipStream_t)stream);
+    }
     if (rc) return rc;
     if (!last) {
       in = hp; ldin = d->dims[l + 1];
@@ -461,6 +570,14 @@ int ia_mlp_backward(const ia_mlp_desc* d, const float* params, const float* X, i
     const float* dY = (l == d->n_layers - 1) ? dOut : dhidden + hoff[l];
     const float* in = (l == 0) ? X : hidden + hoff[l - 1];
     const int ldin = (l == 0) ? ldx : d->dims[l];
+    if (d->dims[l + 1] == 1 && l > 0) {  // single-output head: dW/db partials and dIn in one pass
+      const int N = d->dims[l];
+      hipLaunchKernelGGL(single_out_backward_kernel, dim3((N + 63) / 64, splits), dim3(256), 0, (hipStream_t)stream, dY,
+                         in, ldin, params + off[l].w, R, N, kps, d->hidden_act, dhidden + hoff[l - 1], N,
+                         partials + off[l].w, partials + off[l].b, tot);
+      IA_CHECK_LAUNCH();
+      continue;
+    }
     IaGemm w{};  // dW_l[dims(l+1), dims(l)] = dY^T . in   (+ db_l = column sums of dY)
     w.A = dY; w.lda = d->dims[l + 1];
     w.B = in; w.ldb = ldin;
