@@ -103,5 +103,14 @@ def install() -> None:
 
         torch.utils.tensorboard = _mod("torch.utils.tensorboard", SummaryWriter=_SummaryWriter)
 
+    try:
+        import jsonpickle  # noqa: F401
+    except Exception:
+        # `data/huggingface_utils.py:5` imports jsonpickle (absent here) to encode per-step info dicts.
+        # For dicts of JSON types its text equals json's, which is all the serialisation tests write.
+        import json
+
+        _mod("jsonpickle", encode=lambda o, **k: json.dumps(o), decode=lambda s, **k: json.loads(s))
+
     if REFERENCE_SRC not in sys.path:
         sys.path.insert(0, REFERENCE_SRC)

@@ -48,6 +48,30 @@ def dump_sb3_fixture_layout():
     print("wrote", path)
 
 
+def dump_hf_rollouts():
+    """HuggingFace-dataset directories written by the reference's own `serialize.save` (under the shim,
+    whose `jsonpickle` stand-in equals jsonpickle on these JSON-typed infos) from the seeded
+    trajectories of tests/test_serialize.py."""
+    import shutil
+
+    from oracle import ref_shim
+
+    ref_shim.install()
+    from imitation.data import serialize as rser
+    from imitation.data import types as rtypes
+
+    from tests.test_serialize import seeded_trajectories
+
+    for name, with_infos in (("hf_rollout", False), ("hf_rollout_infos", True)):
+        trajs = [rtypes.TrajectoryWithRew(obs=t.obs, acts=t.acts, rews=t.rews,
+                                          infos=np.array(list(t.infos)) if t.infos is not None else None,
+                                          terminal=t.terminal) for t in seeded_trajectories(with_infos)]
+        path = os.path.join(HERE, name)
+        shutil.rmtree(path, ignore_errors=True)
+        rser.save(path, trajs)
+        print("wrote", path, sorted(os.listdir(path)))
+
+
 def main():
     dump_sb3_fixture_layout()
     for name in harness.CASES:
@@ -55,6 +79,7 @@ def main():
         path = os.path.join(HERE, f"{name}.npz")
         np.savez_compressed(path, **out)
         print(f"wrote {path}: {len(out)} arrays, {os.path.getsize(path)} bytes")
+    dump_hf_rollouts()
     for name in harness.ROLLOUT_CASES:   # data/rollout.py generate_trajectories run by the reference itself
         out = harness.run_rollout_case("reference", name)
         path = os.path.join(HERE, f"{name}.npz")
