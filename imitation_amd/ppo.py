@@ -287,11 +287,17 @@ class PPO(OnPolicyAlgorithm):
         return self.policy.predict(observation, state, episode_start, deterministic)
 
     def save(self, path) -> None:
-        th.save({"policy": {k: v.cpu() for k, v in self.policy.state_dict().items()},
-                 "optimizer": {"step": self.policy.optimizer.step_count,
-                               "exp_avg": self.policy.optimizer.exp_avg.cpu(),
-                               "exp_avg_sq": self.policy.optimizer.exp_avg_sq.cpu()},
-                 "num_timesteps": self.num_timesteps, "n_updates": self._n_updates}, path)
+        """[SB3 BaseAlgorithm.save]: a zip with SB3's member layout (`checkpoint.save_policy_zip`)."""
+        from imitation_amd import checkpoint
+
+        path = str(path)
+        checkpoint.save_policy_zip(path if path.endswith(".zip") else path + ".zip", self)
+
+    def load_parameters(self, path, load_optimizer: bool = True):
+        """Policy (+ Adam state) from an SB3-layout zip into this model; returns its `data` dict."""
+        from imitation_amd import checkpoint
+
+        return checkpoint.load_policy_zip(path, self, load_optimizer=load_optimizer)
 
     # ---- learn loop (App. A.3) ---------------------------------------------------------------
     def _init_callback(self, callback):

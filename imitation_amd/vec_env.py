@@ -159,6 +159,15 @@ class SyntheticVecEnv(ArrayVecEnv):
     def _fresh(self, n: int) -> np.ndarray:
         return 0.1 * self._rng.standard_normal((n, self.obs_dim))
 
+    def get_state(self):
+        """Everything `step` depends on (used by `checkpoint.save_checkpoint`)."""
+        return {"rng": self._rng.bit_generator.state, "obs": self._obs.copy(), "t": self._t.copy()}
+
+    def set_state(self, state) -> None:
+        self._rng.bit_generator.state = state["rng"]
+        self._obs, self._t = state["obs"].copy(), state["t"].copy()
+        self._actions = None
+
     def reset(self) -> np.ndarray:
         self._obs = self._fresh(self.num_envs)
         self._t[:] = 0

@@ -48,6 +48,35 @@ def dump_sb3_fixture_layout():
     print("wrote", path)
 
 
+def dump_sb3_expert_policy():
+    """State dict of the reference's SB3-trained CartPole expert (`policy.pth` of the fixture zip) as
+    plain arrays + its predictions on fixed observations computed by the SB3-restated torch policy."""
+    import io
+    import zipfile
+
+    import torch
+
+    from imitation_amd import spaces
+    from oracle import sb3_restated as sb
+
+    z = zipfile.ZipFile("/root/reference/tests/testdata/expert_models/cartpole_0/policies/final/model.zip")
+    sd = torch.load(io.BytesIO(z.read("policy.pth")), map_location="cpu", weights_only=False)
+    os_, as_ = spaces.Box(-np.inf, np.inf, (4,), np.float32), spaces.Discrete(2)
+    pol = sb.ActorCriticPolicy(os_, as_, sb.constant_fn(3e-4))   # SB3 MlpPolicy default: 64x64 tanh
+    pol.load_state_dict(sd)
+    pol.set_training_mode(False)
+    obs = np.random.default_rng(9).uniform(-1.5, 1.5, (256, 4)).astype(np.float32)
+    with torch.no_grad():
+        t = torch.as_tensor(obs)
+        acts = pol._predict(t, deterministic=True)
+        vals, logp, ent = pol.evaluate_actions(t, acts)
+    out = {f"sd/{k}": v.numpy() for k, v in sd.items()}
+    out.update(obs=obs, acts=acts.numpy(), values=vals.numpy().reshape(-1), logp=logp.numpy(), entropy=ent.numpy())
+    path = os.path.join(HERE, "sb3_cartpole_expert.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, os.path.getsize(path), "bytes; action histogram", np.bincount(acts.numpy()))
+
+
 def dump_hf_rollouts():
     """HuggingFace-dataset directories written by the reference's own `serialize.save` (under the shim,
     whose `jsonpickle` stand-in equals jsonpickle on these JSON-typed infos) from the seeded
@@ -80,6 +109,7 @@ def main():
         np.savez_compressed(path, **out)
         print(f"wrote {path}: {len(out)} arrays, {os.path.getsize(path)} bytes")
     dump_hf_rollouts()
+    dump_sb3_expert_policy()
     for name in harness.ROLLOUT_CASES:   # data/rollout.py generate_trajectories run by the reference itself
         out = harness.run_rollout_case("reference", name)
         path = os.path.join(HERE, f"{name}.npz")
