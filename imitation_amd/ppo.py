@@ -259,6 +259,8 @@ class PPO(OnPolicyAlgorithm):
         self.defer_train_stats = False
         self._pending_train = None
         self._dp_obs = th.zeros(min(self.batch_size, total), p.obs_dim, device=self.device)
+        self._dp_ws_pre = None
+        self.dp_batch_moments = True  # False: exchange the feature-norm moments once per minibatch (tests)
 
     @property
     def logger(self):
@@ -458,11 +460,32 @@ class PPO(OnPolicyAlgorithm):
         offs_host = ((perm % T) * n + perm // T).astype(np.int64)  # time-major row of each permuted index
         offs = th.from_numpy(offs_host).to(self.device)
         obs_rows = rb.obs.reshape((T + 1) * n, -1)
+        # The feature-RunningNorm update of a minibatch depends on the data only, so the slab moments of
+        # ALL minibatches of this update are formed first and exchanged in ONE all-gather; the per-step
+        # loop then merges them locally (same partial / merge kernels and order as the per-minibatch
+        # exchange, hence the same statistics) and keeps a single collective per optimiser step.
+        pre = None
+        if rn is not None and total % self.batch_size == 0 and self.dp_batch_moments:
+            bsz, steps = self.batch_size, self.n_epochs * self._n_mb
+            need = int(L.load().ia_running_norm_ws_floats(bsz, pol.obs_dim))
+            if self._dp_ws_pre is None or self._dp_ws_pre.numel() != steps * need:
+                self._dp_ws_pre = th.empty(steps, need, device=self.device)
+            for e in range(self.n_epochs):
+                for mb, start in enumerate(range(0, total, bsz)):
+                    L.call("ia_gather_rows", L.ptr(obs_rows), L.ptr(offs[e, start:start + bsz]), bsz, pol.obs_dim,
+                           L.ptr(self._dp_obs), L.stream())
+                    L.call("ia_running_norm_partial", L.ptr(self._dp_obs), pol.obs_dim, bsz, pol.obs_dim,
+                           L.ptr(self._dp_ws_pre[e * self._n_mb + mb]), L.stream())
+            gathered = dp.all_gather_flat(self._dp_ws_pre.reshape(-1))
+            pre = gathered.view(dp.world, steps, need).permute(1, 0, 2).contiguous()   # [step][rank][ws]
         for e in range(self.n_epochs):
             for mb, start in enumerate(range(0, total, self.batch_size)):
                 b = min(self.batch_size, total - start)
                 idx = self._perm_dev[e, start:start + b]
-                if rn is not None:
+                if pre is not None:
+                    L.call("ia_running_norm_merge", L.ptr(pre[e * self._n_mb + mb]), dp.world, b, pol.obs_dim,
+                           pol.obs_dim, L.ptr(rn.running_mean), L.ptr(rn.running_var), L.ptr(rn.count), L.stream())
+                elif rn is not None:
                     L.call("ia_gather_rows", L.ptr(obs_rows), L.ptr(offs[e, start:start + b]), b, pol.obs_dim,
                            L.ptr(self._dp_obs), L.stream())
                     rn.update_stats(self._dp_obs, ldx=pol.obs_dim, rows=b)
