@@ -401,20 +401,32 @@ template <int NT>
 __device__ void prepare_stats_t(const ia_policy_desc& d, const float* __restrict__ obs, const float* __restrict__ adv,
                               const int64_t* __restrict__ idx, int batch, int T, int n_envs, int update_norm,
                               float* __restrict__ nm, float* __restrict__ nv, int32_t* __restrict__ ncount,
-                              float* __restrict__ advstat, float* lds) {
+                              float* __restrict__ advstat, float* lds, int* __restrict__ rowoff = nullptr) {
   const int tid = threadIdx.x;
   float* stage = lds;
   float* red = lds + PREP_STAGE_FLOATS;          // [16][65]
   float* cmean = red + 16 * 65;                  // [65]
   float* misc = cmean + 65;                      // [64]
+  // `rowoff` (LDS, >= batch ints; T*n_envs < 2^31): every row's permutation entry is resolved to its
+  // tile offset ONCE (one 32-bit divide per row) instead of once per gathered element with 64-bit
+  // divides -- the per-element form made the statistics block slower than the gradient chain.
+  const bool pre = rowoff != nullptr && idx != nullptr;
+  if (pre) {
+    for (int i = tid; i < batch; i += NT) {
+      const unsigned f = (unsigned)idx[i], env = f / (unsigned)T, t = f - env * (unsigned)T;
+      rowoff[i] = (int)(t * (unsigned)n_envs + env);
+    }
+    __syncthreads();
+  }
+  auto src_row = [&](int i) -> long long { return pre ? (long long)rowoff[i] : mb_row(idx, i, T, n_envs); };
   // advantages: the first value of each thread stays in a register for the second pass
-  const float a0 = tid < batch ? adv[mb_row(idx, tid, T, n_envs)] : 0.f;
+  const float a0 = tid < batch ? adv[src_row(tid)] : 0.f;
   float s = a0;
-  for (int i = tid + NT; i < batch; i += NT) s += adv[mb_row(idx, i, T, n_envs)];
+  for (int i = tid + NT; i < batch; i += NT) s += adv[src_row(i)];
   const float mean = block_sum<NT>(s, misc) / (float)batch;
   float q = tid < batch ? (a0 - mean) * (a0 - mean) : 0.f;
   for (int i = tid + NT; i < batch; i += NT) {
-    const float dl = adv[mb_row(idx, i, T, n_envs)] - mean;
+    const float dl = adv[src_row(i)] - mean;
     q += dl * dl;
   }
   const float qq = block_sum<NT>(q, misc);
@@ -450,7 +462,7 @@ __device__ void prepare_stats_t(const ia_policy_desc& d, const float* __restrict
     } else {
       for (int e = tid; e < rows * D; e += NT) {
         const int r = e / D, k = e - r * D;
-        stage[r * DP + k] = obs[mb_row(idx, c0 + r, T, n_envs) * D + k];
+        stage[r * DP + k] = obs[src_row(c0 + r) * D + k];
       }
     }
     __syncthreads();
@@ -1374,6 +1386,430 @@ __global__ __launch_bounds__(PREP_THREADS) void ppo_apply_kernel(
 // Cross-block visibility: writers fence (agent scope) before the counter increment, readers after
 // the spin (same pattern as the BCE last-block reduction). Spins are bounded: on timeout an error
 // word is set and every block leaves the kernel.
+// ---------------------------------------------------------------------------------------------
+// Minibatch body of the persistent kernel, re-phased around data locality: wave (tower, q) owns rows
+// q*16 .. q*16+15 of the block for the WHOLE forward / loss / backward-activation chain
+//     x -> a1 -> a2 -> head -> per-row loss -> d(head) -> dz2 -> dz1
+// (every hand-off is an LDS write read back by the same wave: wave-scope ordering, no block barrier),
+// then ONE block barrier, then all weight-gradient tiles, bias column sums and loss-statistic sums --
+// the only parts that contract over all 64 rows -- run independently per wave. Three block barriers
+// per minibatch instead of eight. Parameters are resident in LDS (sP / sPt), rows are staged (stg).
+struct CLds {  // LDS carve-up (floats): activations of both towers plus separate dz2 / dz1 tiles
+  static constexpr int XS = MAXD + 1, HS = 33, AS = MAXA + 1, MS = 9;
+  static constexpr int x = 0;
+  static constexpr int a1 = x + ROWS * XS;             // [2 towers][ROWS][HS]
+  static constexpr int a2 = a1 + 2 * ROWS * HS;
+  static constexpr int dz2 = a2 + 2 * ROWS * HS;
+  static constexpr int dz1 = dz2 + 2 * ROWS * HS;
+  static constexpr int out = dz1 + 2 * ROWS * HS;
+  static constexpr int dout = out + ROWS * AS;
+  static constexpr int aux = dout + ROWS * AS;
+  static constexpr int misc = aux + ROWS * AS;         // [ROWS][MS]: 0 value, 1 dvalue, 2..6 loss statistics
+  static constexpr int total = misc + ROWS * MS + 64;
+};
+
+__device__ __forceinline__ void wave_sync_lds() {
+  // same-wave LDS hand-off: DS operations of one wave execute in issue order; this only stops the
+  // compiler from moving the reads above the writes
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
+__device__ __forceinline__ void mfma32_minibatch_chain(
+    const ia_policy_desc& d, const float* __restrict__ nm, const float* __restrict__ nv, const float adv_mean,
+    const float adv_std, const MbRows rows, const int vblk, const int normalize_adv, const float clip,
+    const float ent_coef, const float vf_coef, float* __restrict__ slab, float* __restrict__ statpart,
+    float* __restrict__ lds_in, const float* __restrict__ sP_in, const float* __restrict__ stg_in,
+    const int opaque_zero, long long* __restrict__ tstamp) {
+  float* __restrict__ lds = lds_in + opaque_zero;
+  const float* __restrict__ stg = stg_in + opaque_zero;
+  const float* __restrict__ actions = rows.actions;
+  const int batch = rows.batch;
+  constexpr int H = 32;
+  using L = CLds;
+#define IA_TS(slot) do { if (tstamp && vblk == 0 && threadIdx.x == 0) tstamp[slot] = clock64(); } while (0)
+  const int tid = threadIdx.x + opaque_zero, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tw = wv >> 2, q = wv & 3;
+  const int li = lane & 15, lk = lane >> 4;
+  const int D = d.obs_dim, A = d.act_dim;
+  const PolOff o = pol_offsets(D, A, H, d.discrete);
+  const int i0 = vblk * ROWS;
+  const int aw = d.discrete ? 1 : A;
+  const float invB = 1.f / (float)batch;
+  const int S1 = (D + 3) >> 2, SA = (A + 3) >> 2;
+  const int oW1 = tw ? o.vW1 : o.pW1, ob1 = tw ? o.vb1 : o.pb1, oW2 = tw ? o.vW2 : o.pW2, ob2 = tw ? o.vb2 : o.pb2;
+  const float* __restrict__ sP = sP_in + opaque_zero;
+  const float* __restrict__ sPt = sP + ((o.total + 3) & ~3);
+  IA_TS(0);
+
+  // ---- per-row scalars of the loss: lanes 0..15 of every wave own row q*16 + lane of their tower's loss
+  const int lrow = q * 16 + (lane & 15);            // local row of this lane in the loss phase
+  const bool loss_lane = lane < 16;
+  const bool valid = (i0 + lrow) < batch;
+  float r_oldlp = 0.f, r_adv = 0.f, r_ret = 0.f, r_act[MAXA];
+#pragma unroll
+  for (int a = 0; a < MAXA; ++a) r_act[a] = 0.f;
+  if (loss_lane) {
+    if (tw == 0) {
+      const long long src = valid ? (long long)__float_as_int(stg[UpdStage::src + lrow]) : 0;
+      r_oldlp = stg[UpdStage::oldlp + lrow];
+      r_adv = stg[UpdStage::adv + lrow];
+#pragma unroll
+      for (int a = 0; a < MAXA; ++a)
+        if (a < aw) r_act[a] = actions[src * aw + a];   // consumed after three layers: latency hidden
+    } else {
+      r_ret = stg[UpdStage::ret + lrow];
+    }
+  }
+
+  // ---- stage this wave's 16 feature rows (normalised) into the x tile; clear its rows of the small tiles
+  {
+    const int rbase = q * 16;
+    // both towers read x: tower 0 waves stage even columns chunks, tower 1 waves the odd ones
+    for (int e = lane + 64 * tw; e < 16 * L::XS; e += 128) {
+      const int r = e / L::XS, k = e - r * L::XS;
+      const bool ok = k < D && (i0 + rbase + r) < batch;
+      const int kc = min(k, MAXD - 1);
+      const float msk = (ok && d.has_norm) ? 1.f : 0.f;
+      const float mean = nm[kc] * msk, var = nv[kc] * msk + (1.f - msk) * (1.f - d.norm_eps);
+      const float raw = ok ? stg[UpdStage::x + (rbase + r) * L::XS + k] : 0.f;
+      lds[L::x + (rbase + r) * L::XS + k] = (raw - mean) / sqrtf(var + d.norm_eps);
+    }
+    if (tw == 0) {
+      for (int e = lane; e < 16 * L::AS; e += 64) {
+        lds[L::dout + rbase * L::AS + e] = 0.f;
+        lds[L::aux + rbase * L::AS + e] = 0.f;
+        lds[L::out + rbase * L::AS + e] = 0.f;
+      }
+    } else {
+      for (int e = lane; e < 16 * L::MS; e += 64) lds[L::misc + rbase * L::MS + e] = 0.f;
+    }
+  }
+  // weight fragments (LDS -> VGPR): B[k = 4s+lk][j = c*16+li]
+  float bW1[16][2], bW2[8][2], bW2o[8][2], bHead[8], bDa2[4][2], b1v[2], b2v[2], cwv[2];
+#pragma unroll
+  for (int s = 0; s < 16; ++s) {
+    const int kk = 4 * s + lk;
+    bW1[s][0] = bW1[s][1] = 0.f;
+    if (s < S1) {
+#pragma unroll
+      for (int c = 0; c < 2; ++c) bW1[s][c] = kk < D ? sPt[oW1 + kk * H + c * 16 + li] : 0.f;
+    }
+  }
+#pragma unroll
+  for (int s = 0; s < 8; ++s) {
+    const int kk = 4 * s + lk;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      bW2[s][c] = sPt[oW2 + kk * H + c * 16 + li];
+      bW2o[s][c] = sP[oW2 + kk * H + c * 16 + li];
+    }
+    bHead[s] = tw == 0 ? (li < A ? sP[o.aW + li * H + kk] : 0.f) : (li == 0 ? sP[o.cW + kk] : 0.f);
+  }
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    const int aa = 4 * s + lk;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) bDa2[s][c] = (tw == 0 && aa < A) ? sP[o.aW + aa * H + c * 16 + li] : 0.f;
+  }
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {
+    b1v[c] = sP[ob1 + c * 16 + li];
+    b2v[c] = sP[ob2 + c * 16 + li];
+    cwv[c] = sP[o.cW + c * 16 + li];
+  }
+  const float head_bias = tw == 0 ? (li < A ? sP[o.ab + li] : 0.f) : sP[o.cb];
+  float c_var[MAXA], c_logsd[MAXA];
+#pragma unroll
+  for (int a = 0; a < MAXA; ++a) {
+    c_var[a] = 1.f;
+    c_logsd[a] = 0.f;
+    if (tw == 0 && !d.discrete && a < A) {
+      const float sd = expf(sP[o.log_std + a]);
+      c_var[a] = sd * sd;
+      c_logsd[a] = logf(sd);
+    }
+  }
+  // the x rows of this wave were written by the two waves (tower 0 / tower 1) that share q
+  __syncthreads();
+  IA_TS(1);
+
+  float* a1t = lds + L::a1 + tw * ROWS * L::HS;
+  float* a2t = lds + L::a2 + tw * ROWS * L::HS;
+  float* dz2t = lds + L::dz2 + tw * ROWS * L::HS;
+  float* dz1t = lds + L::dz1 + tw * ROWS * L::HS;
+  const int arow = q * 16 + li;  // row whose A fragment this lane feeds
+  // ---- a1 = tanh(x W1^T + b1)
+  {
+    f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+    for (int s = 0; s < 16; ++s)
+      if (s < S1) {
+        const float a = lds[L::x + arow * L::XS + 4 * s + lk];
+        acc[0] = mfma16(a, bW1[s][0], acc[0]);
+        acc[1] = mfma16(a, bW1[s][1], acc[1]);
+      }
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) a1t[(q * 16 + lk * 4 + r) * L::HS + c * 16 + li] = fast_tanh(acc[c][r] + b1v[c]);
+  }
+  wave_sync_lds();
+  IA_TS(2);
+  // ---- a2 = tanh(a1 W2^T + b2)
+  {
+    f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      const float a = a1t[arow * L::HS + 4 * s + lk];
+      acc[0] = mfma16(a, bW2[s][0], acc[0]);
+      acc[1] = mfma16(a, bW2[s][1], acc[1]);
+    }
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) a2t[(q * 16 + lk * 4 + r) * L::HS + c * 16 + li] = fast_tanh(acc[c][r] + b2v[c]);
+  }
+  wave_sync_lds();
+  IA_TS(3);
+  // ---- heads (policy: action_net -> out[row][a]; value: value_net -> misc[row][0])
+  {
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < 8; ++s) acc = mfma16(a2t[arow * L::HS + 4 * s + lk], bHead[s], acc);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = q * 16 + lk * 4 + r;
+      if (tw == 0) { if (li < A) lds[L::out + row * L::AS + li] = acc[r] + head_bias; }
+      else if (li == 0) lds[L::misc + row * L::MS + 0] = acc[r] + head_bias;
+    }
+  }
+  wave_sync_lds();
+  IA_TS(4);
+  // ---- per-row losses of this wave's 16 rows (lanes 0..15)
+  if (loss_lane) {
+    if (tw == 0) {
+      const float* outrow = lds + L::out + lrow * L::AS;
+      float* doutrow = lds + L::dout + lrow * L::AS;
+      float* auxrow = lds + L::aux + lrow * L::AS;
+      float logp = 0.f, entropy = 0.f, lse = 0.f;
+      int act_i = 0;
+      if (!d.discrete) {
+#pragma unroll
+        for (int a = 0; a < MAXA; ++a)
+          if (a < A) {
+            const float diff = r_act[a] - outrow[a];
+            logp += -(diff * diff) / (2.f * c_var[a]) - c_logsd[a] - LOG_SQRT_2PI;
+            entropy += 0.5f + LOG_SQRT_2PI + c_logsd[a];
+          }
+      } else {
+        float mx = outrow[0];
+        for (int a = 1; a < A; ++a) mx = fmaxf(mx, outrow[a]);
+        float se = 0.f;
+        for (int a = 0; a < A; ++a) se += expf(outrow[a] - mx);
+        lse = mx + logf(se);
+        act_i = (int)r_act[0];
+        logp = outrow[act_i] - lse;
+        for (int a = 0; a < A; ++a) {
+          const float l = outrow[a] - lse;
+          entropy -= expf(l) * l;
+        }
+      }
+      float advn = r_adv;
+      if (normalize_adv && batch > 1) advn = (advn - adv_mean) / (adv_std + 1e-8f);
+      const float log_ratio = logp - r_oldlp;
+      const float ratio = expf(log_ratio);
+      const float lo = 1.f - clip, hi = 1.f + clip;
+      const float pl1 = advn * ratio;
+      const float pl2 = advn * fminf(fmaxf(ratio, lo), hi);
+      const float g1 = pl1 < pl2 ? 1.f : (pl1 == pl2 ? 0.5f : 0.f);
+      const float g2 = pl2 < pl1 ? 1.f : (pl1 == pl2 ? 0.5f : 0.f);
+      const float inrange = (ratio >= lo && ratio <= hi) ? 1.f : 0.f;
+      const float dlogp = valid ? -invB * advn * (g1 + g2 * inrange) * ratio : 0.f;
+      if (!d.discrete) {
+#pragma unroll
+        for (int a = 0; a < MAXA; ++a)
+          if (a < A) {
+            const float diff = r_act[a] - outrow[a];
+            doutrow[a] = dlogp * diff / c_var[a];
+            auxrow[a] = valid ? dlogp * (diff * diff / c_var[a] - 1.f) - ent_coef * invB : 0.f;
+          }
+      } else {
+        for (int a = 0; a < A; ++a) {
+          const float l = outrow[a] - lse, p = expf(l);
+          const float dH = -p * (l + entropy);
+          float g = dlogp * ((a == act_i ? 1.f : 0.f) - p);
+          g += valid ? -ent_coef * invB * dH : 0.f;
+          doutrow[a] = g;
+        }
+      }
+      float* mrow = lds + L::misc + lrow * L::MS;
+      mrow[2] = valid ? -fminf(pl1, pl2) : 0.f;                           // policy_gradient_loss
+      mrow[3] = valid ? -entropy : 0.f;                                    // entropy_loss
+      mrow[4] = valid ? (expf(log_ratio) - 1.f) - log_ratio : 0.f;         // approx_kl
+      mrow[5] = valid ? (fabsf(ratio - 1.f) > clip ? 1.f : 0.f) : 0.f;     // clip_fraction
+    } else {
+      const float v = lds[L::misc + lrow * L::MS + 0];
+      const float verr = r_ret - v;
+      lds[L::misc + lrow * L::MS + 1] = valid ? vf_coef * 2.f * (v - r_ret) * invB : 0.f;
+      lds[L::misc + lrow * L::MS + 6] = valid ? verr * verr : 0.f;        // value_loss
+    }
+  }
+  wave_sync_lds();
+  IA_TS(5);
+  // ---- dz2 = d(a2) * (1 - a2^2) for this wave's rows
+  if (tw == 0) {
+    f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+      if (s < SA) {
+        const float a = lds[L::dout + arow * L::AS + 4 * s + lk];   // columns >= A are zero
+        acc[0] = mfma16(a, bDa2[s][0], acc[0]);
+        acc[1] = mfma16(a, bDa2[s][1], acc[1]);
+      }
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int e = (q * 16 + lk * 4 + r) * L::HS + c * 16 + li;
+        const float a = a2t[e];
+        dz2t[e] = acc[c][r] * (1.f - a * a);
+      }
+  } else {
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = q * 16 + lk * 4 + r;
+        const int e = row * L::HS + c * 16 + li;
+        const float a = a2t[e];
+        dz2t[e] = cwv[c] * lds[L::misc + row * L::MS + 1] * (1.f - a * a);
+      }
+  }
+  wave_sync_lds();
+  // ---- dz1 = (dz2 W2) * (1 - a1^2) for this wave's rows
+  {
+    f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      const float a = dz2t[arow * L::HS + 4 * s + lk];
+      acc[0] = mfma16(a, bW2o[s][0], acc[0]);
+      acc[1] = mfma16(a, bW2o[s][1], acc[1]);
+    }
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int e = (q * 16 + lk * 4 + r) * L::HS + c * 16 + li;
+        const float a = a1t[e];
+        dz1t[e] = acc[c][r] * (1.f - a * a);
+      }
+  }
+  __syncthreads();   // every row's activations and activation gradients are in LDS
+  IA_TS(6);
+
+  // ---- gradient tiles: contractions over all 64 rows, independent per wave. Every tile requests its
+  // 32 LDS operands first and then runs its 16 dependent MFMAs (the compiler otherwise pairs each
+  // MFMA with its two reads and exposes an LDS round trip per step).
+  auto outer16 = [&](const float* __restrict__ U, int us, int ucol, const float* __restrict__ V, int vs, int vcol) {
+    float u[16], v[16];
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      u[s] = U[(4 * s + lk) * us + ucol];
+      v[s] = V[(4 * s + lk) * vs + vcol];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    f32x4 g = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < 16; ++s) g = mfma16(u[s], v[s], g);
+    return g;
+  };
+  // a column sum over the 64 rows with four lanes per column (16 rows each) and a cross-lane add
+  auto colsum64 = [&](const float* __restrict__ tile, int stride, int ncols, float* __restrict__ dst) {
+    const int c = lane & 15, part = lane >> 4;
+    float s = 0.f;
+    if (c < ncols) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s += tile[(part * 16 + r) * stride + c];
+    }
+    s += __shfl_xor(s, 16, 64);
+    s += __shfl_xor(s, 32, 64);
+    if (lane < ncols && lane < 16) dst[lane] = s;
+  };
+  auto colsum64_wide = [&](const float* __restrict__ tile, int stride, float* __restrict__ dst) {  // 32 columns
+    const int c = lane & 31, part = lane >> 5;
+    float s = 0.f;
+#pragma unroll
+    for (int r = 0; r < 32; ++r) s += tile[(part * 32 + r) * stride + c];
+    s += __shfl_xor(s, 32, 64);
+    if (lane < 32) dst[lane] = s;
+  };
+  if (tw == 0) {
+    if (q < 2) {  // dWa[a][h] = sum_r dout[r][a] a2[r][h], 16 h-columns per wave
+      const f32x4 g = outer16(lds + L::dout, L::AS, li, a2t, L::HS, q * 16 + li);
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (lk * 4 + r < A) slab[o.aW + (lk * 4 + r) * H + q * 16 + li] = g[r];
+    }
+    if (q == 2) colsum64(lds + L::dout, L::AS, A, slab + o.ab);
+    if (q == 3 && !d.discrete) colsum64(lds + L::aux, L::AS, A, slab + o.log_std);
+  } else {
+    if (q < 2) {  // dcW[h] = sum_r dv[r] a2[r][h]  (only output row 0 is meaningful)
+      float u[16], v[16];
+#pragma unroll
+      for (int s = 0; s < 16; ++s) {
+        u[s] = li == 0 ? lds[L::misc + (4 * s + lk) * L::MS + 1] : 0.f;
+        v[s] = a2t[(4 * s + lk) * L::HS + q * 16 + li];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      f32x4 g = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s < 16; ++s) g = mfma16(u[s], v[s], g);
+      if (lk == 0) slab[o.cW + q * 16 + li] = g[0];
+    }
+    if (q == 2) {  // cb = sum_r dv[r]; statpart slots {0 pg, 2 ent, 3 kl, 4 clip, 1 value} <- misc columns 2..6
+      // columns 1..6 of the misc tile summed together: lane c < 6 handles column 1 + c
+      const int c = lane & 15, part = lane >> 4;
+      float sm = 0.f;
+      if (c < 6) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sm += lds[L::misc + (part * 16 + r) * L::MS + 1 + c];
+      }
+      sm += __shfl_xor(sm, 16, 64);
+      sm += __shfl_xor(sm, 32, 64);
+      if (lane == 0) slab[o.cb] = sm;
+      if (lane >= 1 && lane < 6) {
+        const int m = lane - 1;                      // misc column 2 + m
+        const int slot = m == 0 ? 0 : (m == 4 ? 1 : m + 1);
+        statpart[slot] = sm;
+      }
+    }
+  }
+  {  // dW2 (one 16x16 tile per wave), db2
+    const int jt = q >> 1, kt = q & 1;
+    const f32x4 g = outer16(dz2t, L::HS, jt * 16 + li, a1t, L::HS, kt * 16 + li);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) slab[oW2 + (jt * 16 + lk * 4 + r) * H + kt * 16 + li] = g[r];
+    if (q == 3) colsum64_wide(dz2t, L::HS, slab + ob2);
+  }
+  {  // dW1 tiles (dz1^T x), db1
+    const int KT = (D + 15) >> 4;
+    for (int ti = q; ti < 2 * KT; ti += 4) {
+      const int jt = ti / KT, kt = ti - jt * KT;
+      const f32x4 g = outer16(dz1t, L::HS, jt * 16 + li, lds + L::x, L::XS, kt * 16 + li);
+      const int col = kt * 16 + li;
+      if (col < D)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) slab[oW1 + (jt * 16 + lk * 4 + r) * D + col] = g[r];
+    }
+    if (q == 2) colsum64_wide(dz1t, L::HS, slab + ob1);
+  }
+  __syncthreads();
+  IA_TS(8);
+#undef IA_TS
+}
+
 // Instance for the persistent kernel (parameters resident in LDS, rows staged in LDS). Inlined with
 // the opaque zero below; an out-of-line call measured 4 us per step slower (callee-saved spills).
 __device__ __forceinline__ void mfma32_minibatch_resident(
@@ -1435,7 +1871,7 @@ __global__ __launch_bounds__(512) void ppo_update_persistent_kernel(
     float* __restrict__ ws, int nblk, float* __restrict__ stats, UpdSched sch, int xcd_pack,
     long long* __restrict__ tstamp /* debug: [0..3] += 100 MHz ticks in {stat wait, minibatch, barrier, update} */) {
   constexpr int H = 32;
-  using L = GLds<32>;
+  using L = CLds;
   extern __shared__ float lds[];
   __shared__ int s_ok, s_pub;
   long long tacc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -1514,7 +1950,8 @@ __global__ __launch_bounds__(512) void ppo_update_persistent_kernel(
       }
       const MbRows r = rows_of(s);
       float* slot = w.ring + (s % UPD_RING) * UPD_RS;
-      prepare_stats_t<512>(d, r.obs, r.adv, r.idx, r.batch, T, n_envs, update_norm, nm, nv, ncount, slot + 2 * MAXD, lds);
+      prepare_stats_t<512>(d, r.obs, r.adv, r.idx, r.batch, T, n_envs, update_norm, nm, nv, ncount, slot + 2 * MAXD, lds,
+                           sch_total < (1ll << 31) ? reinterpret_cast<int*>(lds + PREP_LDS_FLOATS) : nullptr);
       __syncthreads();
       if (d.has_norm && tid < D) {
         slot[tid] = nm[tid];
@@ -1541,7 +1978,7 @@ __global__ __launch_bounds__(512) void ppo_update_persistent_kernel(
   float* sP = lds + L::total;
   float* sPt = sP + w.P4;
   float* stg = sPt + w.P4;                    // UpdStage: the NEXT minibatch's rows of this block
-  int* dstT = reinterpret_cast<int*>(stg + UpdStage::total);  // [P4] index of parameter i in the transposed copy
+  unsigned short* dstT = reinterpret_cast<unsigned short*>(stg + UpdStage::total);  // [P4] index of parameter i in the transposed copy
   float* red = lds + L::misc + ROWS * L::MS;  // 64 spare floats behind the misc tile
   const int lane = tid & 63;
   const int aw = d.discrete ? 1 : d.act_dim;
@@ -1563,7 +2000,7 @@ __global__ __launch_bounds__(512) void ppo_update_persistent_kernel(
         }
       };
       tr(o.pW1, H, D); tr(o.pW2, H, H); tr(o.vW1, H, D); tr(o.vW2, H, H);
-      dstT[i] = dst;
+      dstT[i] = (unsigned short)dst;
     }
   }
   // Row prefetch: the gathers of step s+1 (two dependent global loads per element) are issued
@@ -1660,9 +2097,9 @@ __global__ __launch_bounds__(512) void ppo_update_persistent_kernel(
     float* stat_base = w.statpart + (s % UPD_SD) * nblk * 8;
     int oz;
     asm volatile("s_mov_b32 %0, 0" : "=s"(oz));
-    mfma32_minibatch_resident(d, slot, slot + MAXD, adv_mean, adv_std, r, vb, normalize_adv, clip, ent_coef, vf_coef,
-                              slab_base + (long long)vb * w.P4, stat_base + vb * 8, lds, stg, oz,
-                              tstamp ? tstamp + 16 : nullptr);
+    mfma32_minibatch_chain(d, slot, slot + MAXD, adv_mean, adv_std, r, vb, normalize_adv, clip, ent_coef, vf_coef,
+                           slab_base + (long long)vb * w.P4, stat_base + vb * 8, lds, sP, stg, oz,
+                           tstamp ? tstamp + 16 : nullptr);
     // (the minibatch ends with a block barrier: every slab store of this block has been issued)
     UPD_TS(1);
     if (tid == 0) {  // arrive first; the prefetch below overlaps the wait for the other blocks
@@ -2184,8 +2621,8 @@ int ia_ppo_update(const ia_policy_desc* d, float* params, float* params_t, float
   const int nblk = cdiv(batch_size, ROWS);
   const int P = pol_offsets(d->obs_dim, d->act_dim, 32, d->discrete).total;
   const int P4 = (P + 3) & ~3;
-  const size_t grad_bytes = (GLds<32>::total + 3 * P4 + UpdStage::total) * sizeof(float);
-  const size_t prep_bytes = PREP_LDS_FLOATS * sizeof(float);
+  const size_t grad_bytes = (CLds::total + 2 * P4 + UpdStage::total) * sizeof(float) + P4 * sizeof(unsigned short);
+  const size_t prep_bytes = (PREP_LDS_FLOATS + (size_t)nblk * ROWS) * sizeof(float);  // + row offsets
   const size_t bytes = grad_bytes > prep_bytes ? grad_bytes : prep_bytes;
   static size_t attr_bytes = 0;
   if (bytes > attr_bytes) { int rc = set_lds(ppo_update_persistent_kernel, bytes); if (rc) return rc; attr_bytes = bytes; }
