@@ -169,6 +169,11 @@ class AdversarialTrainer(abc.ABC):
         self._disc_stream = th.cuda.Stream(device=self._device) if self._overlap else None
         self._in_overlap = False
         self._overlap_k = 0
+        self._quirk_ready = None
+        self._quirk_seq = None
+        # GAIL only: let round r's discriminator updates run behind round r+1's environment stepping
+        # (`_train_pipelined`); off -> every round is completed before the next one starts
+        self.pipeline_rounds = True
         self._quirk_pending = []
         self._quirk_slots = []
 
@@ -341,7 +346,7 @@ class AdversarialTrainer(abc.ABC):
             self.logger.dump(disc_step)
         return train_stats
 
-    def _disc_round(self):
+    def _disc_round(self, prepass: bool = False, after=None):
         """Enqueues the n_disc updates of one round without reading their statistics back; returns
         what `_finish_disc_round` needs to log them afterwards, in order. A `train_disc` replaced by
         the user (subclass or instance attribute) is honoured: then the updates run one by one."""
@@ -354,10 +359,24 @@ class AdversarialTrainer(abc.ABC):
         steps = []
         self._use_ring = True
         try:
-            for k in range(n):
-                with networks.training(self.reward_train):
-                    self._disc_update(None, None, self._stats_ring[k])
-                steps.append(self._disc_step)
+            if prepass:
+                # all host index draws of the round first (same order as one per update), then the
+                # policy feature-norm moments of every update's batch, then the updates themselves
+                drawn = [self._batch_sources(None, None) for _ in range(n)]
+                did = self._quirk_prepass(drawn)
+                self._quirk_ready = th.cuda.Event()
+                self._quirk_ready.record()
+                if after is not None:   # the updates themselves are held back (see `_train_pipelined`)
+                    th.cuda.current_stream().wait_event(after)
+                for k in range(n):
+                    with networks.training(self.reward_train):
+                        self._disc_update(None, None, self._stats_ring[k], drawn=drawn[k], quirk_done=did)
+                    steps.append(self._disc_step)
+            else:
+                for k in range(n):
+                    with networks.training(self.reward_train):
+                        self._disc_update(None, None, self._stats_ring[k])
+                    steps.append(self._disc_step)
         finally:
             self._use_ring = False
         self._stats_ring_host.copy_(self._stats_ring, non_blocking=True)
@@ -374,9 +393,13 @@ class AdversarialTrainer(abc.ABC):
         for k, step in enumerate(steps):
             self._log_disc_stats(rows[k], step, global_step)
 
-    def _disc_update(self, expert_samples, gen_samples, stats_dev: th.Tensor) -> None:
-        """Device half of `train_disc` (`common.py:317-374`); the 8 statistics land in `stats_dev`."""
-        (e_tab, e_idx), (g_tab, g_idx) = self._batch_sources(expert_samples, gen_samples)
+    def _disc_update(self, expert_samples, gen_samples, stats_dev: th.Tensor, drawn=None,
+                     quirk_done: bool = False) -> None:
+        """Device half of `train_disc` (`common.py:317-374`); the 8 statistics land in `stats_dev`.
+        `drawn`: batch sources already drawn by `_batch_sources`; `quirk_done`: the policy feature-norm
+        side effect of this update was already captured by `_quirk_prepass`."""
+        (e_tab, e_idx), (g_tab, g_idx) = drawn if drawn is not None else self._batch_sources(expert_samples,
+                                                                                               gen_samples)
         B, mb = self.demo_batch_size, self.demo_minibatch_size
         scale = mb / B
         net = self._reward_net
@@ -403,8 +426,8 @@ class AdversarialTrainer(abc.ABC):
                 # updates on a state-first batch, its slab moments cover the observation columns and
                 # are reused; otherwise the explicit pass below gathers the observations.
                 reuse = (prn is not None and pol.training and basic.use_state and basic.mlp.norm is not None
-                         and basic.mlp.training)
-                if prn is not None and pol.training and not reuse:
+                         and basic.mlp.training and not quirk_done)
+                if prn is not None and pol.training and not reuse and not quirk_done:
                     self._policy_pass(sources, mb)
                 inline = reuse and not self._in_overlap
                 ws = basic.disc_step_c(sources, mb, scale, stats_dev, self._bce_ws, accumulate=not first,
@@ -417,7 +440,7 @@ class AdversarialTrainer(abc.ABC):
                 logits = ws["out"].reshape(-1)
                 fused_step = fused_step or (last and fuse_adam is not None)
             else:
-                logp = self._policy_pass(sources, mb)
+                logp = None if (quirk_done and not self._needs_logp) else self._policy_pass(sources, mb)
                 logits = net.disc_forward(sources, mb, logp)
                 L.call("ia_bce_logits", L.ptr(logits), 2 * mb, mb, scale, L.ptr(self._dlogits),
                        L.ptr(stats_dev), L.ptr(self._bce_ws), L.stream())
@@ -472,10 +495,49 @@ class AdversarialTrainer(abc.ABC):
             self._quirk_slots[k] = th.empty(numel, device=self._device)
         return self._quirk_slots[k]
 
+    def _quirk_prepass(self, drawn) -> bool:
+        """Slab moments of the observation columns of every (update, minibatch) batch of a round, on the
+        current (discriminator) stream, queued for `_replay_policy_norm_updates`. They depend on the
+        sampled rows only, so they can be taken before -- and independently of -- the updates, which
+        lets the generator stream run ahead of the discriminator stream (see `train`). Returns whether
+        the side effect applies at all (train-mode policy with a feature RunningNorm)."""
+        pol = self.policy
+        if not isinstance(pol, ActorCriticPolicy):
+            return False
+        rn = pol.features_extractor.normalize
+        if rn is None or not pol.training:
+            return False
+        B, mb = self.demo_batch_size, self.demo_minibatch_size
+        need = int(L.load().ia_running_norm_ws_floats(2 * mb, pol.obs_dim))
+        n_items = len(drawn) * len(range(0, B, mb))
+        if self._quirk_seq is None or self._quirk_seq.shape != (n_items, need):
+            self._quirk_seq = th.empty(n_items, need, device=self._device)
+        k = 0
+        for (e_tab, e_idx), (g_tab, g_idx) in drawn:
+            for start in range(0, B, mb):
+                row = 0
+                for tab, idx in ((e_tab, e_idx), (g_tab, g_idx)):
+                    t = tab if idx is not None else _slice_table(tab, start, mb)
+                    i = None if idx is None else idx[start:start + mb]
+                    networks.gather_concat(t, i, mb, pol.obs_dim, pol.act_dim, (True, False, False, False),
+                                           self._pol_obs, pol.obs_dim, row)
+                    row += mb
+                L.call("ia_running_norm_partial", L.ptr(self._pol_obs), pol.obs_dim, 2 * mb, pol.obs_dim,
+                       L.ptr(self._quirk_seq[k]), L.stream())
+                k += 1
+        self._quirk_pending.append(("seq", n_items, need, 2 * mb, pol.obs_dim))
+        return True
+
     def _replay_policy_norm_updates(self) -> None:
         """Deferred `_policy_pass` side effects, in order, on the current (generator) stream."""
         pol = self.policy
         for item in self._quirk_pending:
+            if isinstance(item, tuple) and item[0] == "seq":  # all updates of a round, one launch, in order
+                _, n_items, stride, rows, ld = item
+                rn = pol.features_extractor.normalize
+                L.call("ia_running_norm_merge_seq", L.ptr(self._quirk_seq), n_items, stride, rows, pol.obs_dim, ld,
+                       L.ptr(rn.running_mean), L.ptr(rn.running_var), L.ptr(rn.count), L.stream())
+                continue
             if isinstance(item, tuple):  # (slab moments of the batch, rows, moment column count)
                 slot, rows, ld = item
                 rn = pol.features_extractor.normalize
@@ -497,6 +559,10 @@ class AdversarialTrainer(abc.ABC):
         assert n_rounds >= 1, ("No updates (need at least "
                                f"{self.gen_train_timesteps} timesteps, have only "
                                f"total_timesteps={total_timesteps})!")
+        own_disc = "train_disc" not in self.__dict__ and type(self).train_disc is AdversarialTrainer.train_disc
+        if self._overlap and callback is None and self.pipeline_rounds and own_disc:
+            self._train_pipelined(n_rounds)
+            return
         for r in range(n_rounds):
             if not self._overlap:
                 self.train_gen(self.gen_train_timesteps)
@@ -520,6 +586,60 @@ class AdversarialTrainer(abc.ABC):
             if callback:
                 callback(r)
             self.logger.dump(self._global_step)
+
+    def _train_pipelined(self, n_rounds: int) -> None:
+        """GAIL rounds with the discriminator updates of round r running BEHIND the environment stepping
+        of round r+1 (the GPU is almost idle while the host steps the environments):
+
+            main : rollout r | PPO r ............ | norm replay | rollout r+1 (act kernels) ... | relabel r+1 | PPO r+1
+            disc :           | ring store, moment pre-pass r |  | 16 updates r ................ |
+
+        Dependencies are exactly the reference's: the policy of rollout r+1 needs PPO r and the
+        feature-norm side effects of round r's updates (the pre-pass + replay); the first use of the
+        discriminator in round r+1 is the reward relabelling after the last env step, which waits for
+        round r's updates (`PPO.before_relabel`). Round r's statistics are read back and logged at that
+        point -- into the log rows of round r, via `logger.replaying` -- or at the end of `train()`.
+        Every value, every RNG draw and every log row equals the strictly sequential schedule
+        (`test_pipelined_rounds_are_bit_identical`)."""
+        algo = self.gen_algo
+        main = th.cuda.current_stream()
+        self._disc_stream.wait_stream(main)
+        previous = []  # at most one round in flight: (disc handle, done event, root-log stash, global step)
+
+        def drain():
+            if not previous:
+                return
+            pend, done, stash, gstep = previous.pop()
+            done.synchronize()
+            main.wait_event(done)
+            with self.logger.replaying(stash):
+                self._finish_disc_round(pend)
+                with self.logger.accumulate_means("gen"):
+                    algo.finalize_train()
+                self.logger.dump(gstep)
+
+        self._in_overlap, algo.defer_train_stats = True, True
+        algo.before_relabel = drain
+        try:
+            for _ in range(n_rounds):
+                self._overlap_k = 0
+                self.train_gen(self.gen_train_timesteps)          # drains the previous round before relabelling
+                ppo_done = th.cuda.Event()
+                ppo_done.record()
+                with th.cuda.stream(self._disc_stream):
+                    # ring store and moment pre-pass run beside the PPO update; the 16 updates wait for it,
+                    # so they execute while the host steps the environments of the next round instead of
+                    # competing with the latency-bound PPO chain for the memory system
+                    pend = self._disc_round(prepass=True, after=ppo_done)
+                    done = th.cuda.Event()
+                    done.record()
+                main.wait_event(self._quirk_ready)
+                self._replay_policy_norm_updates()                 # behind the PPO update, ahead of the next rollout
+                previous.append((pend, done, self.logger.detach_pending(), self._global_step))
+            drain()
+            main.wait_stream(self._disc_stream)
+        finally:
+            self._in_overlap, algo.defer_train_stats, algo.before_relabel = False, False, None
 
 
 def _slice_table(t: TransitionTable, start: int, n: int) -> TransitionTable:

@@ -192,6 +192,45 @@ __global__ __launch_bounds__(64) void rn_merge_kernel(const float* __restrict__ 
   (void)bump_count;
 }
 
+// `n_seq` CONSECUTIVE updates (each the merge above of one batch's slab moments, `seq_stride` floats
+// apart) applied in order by one launch: the replay of the deferred policy feature-norm updates of a
+// round. Same arithmetic per update as rn_merge_kernel; the count seen by update k is cnt0 + k*R.
+__global__ __launch_bounds__(64) void rn_merge_seq_kernel(const float* __restrict__ ws_seq, int n_seq,
+                                                          long long seq_stride, int nblocks, int R, int D, int ws_ld,
+                                                          float* __restrict__ mean, float* __restrict__ var,
+                                                          const int32_t* __restrict__ count) {
+  const int c = blockIdx.x, lane = threadIdx.x;
+  int cnt = *count;
+  float mc = mean[c], vc = var[c];
+  for (int k = 0; k < n_seq; ++k) {
+    const float* ws = ws_seq + (long long)k * seq_stride;
+    float n_acc = 0.f, m_acc = 0.f, M2 = 0.f;
+    for (int b = lane; b < nblocks; b += 64) {
+      const float nb = (float)min(RN_ROWS_PER_BLOCK, R - b * RN_ROWS_PER_BLOCK);
+      chan_combine(n_acc, m_acc, M2, nb, ws[((long long)b * 2 + 0) * ws_ld + c], ws[((long long)b * 2 + 1) * ws_ld + c]);
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+      const float nb = __shfl_xor(n_acc, o, 64), mb = __shfl_xor(m_acc, o, 64), qb = __shfl_xor(M2, o, 64);
+      if ((lane & o) == 0) chan_combine(n_acc, m_acc, M2, nb, mb, qb);
+      else { float n2 = nb, m2 = mb, q2 = qb; chan_combine(n2, m2, q2, n_acc, m_acc, M2); n_acc = n2; m_acc = m2; M2 = q2; }
+    }
+    const float b_mean = __shfl(m_acc, 0, 64), b_var = __shfl(M2, 0, 64) / (float)R;
+    const float fcount = (float)cnt, fn = (float)R;
+    const float tot = (float)(cnt + R);
+    const float delta = b_mean - mc;
+    mc = mc + delta * fn / tot;
+    float rv = vc * fcount;
+    rv = rv + b_var * fn;
+    rv = rv + delta * delta * fcount * fn / tot;
+    vc = rv / tot;
+    cnt += R;
+  }
+  if (lane == 0) {
+    mean[c] = mc;
+    var[c] = vc;
+  }
+}
+
 __global__ void rn_count_kernel(int32_t* __restrict__ count, int R) {
   if (threadIdx.x == 0 && blockIdx.x == 0) *count += R;
 }
@@ -669,6 +708,18 @@ int ia_running_norm_merge(const float* ws_all, int groups, int rows_per_group, i
                      rows_per_group, groups * rows_per_group, D, ws_ld, mean, var, count, 0);
   IA_CHECK_LAUNCH();
   hipLaunchKernelGGL(rn_count_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, count, groups * rows_per_group);
+  IA_CHECK_LAUNCH();
+  return IA_OK;
+}
+
+int ia_running_norm_merge_seq(const float* ws_seq, int n_seq, int64_t seq_stride, int rows, int D, int ws_ld,
+                              float* mean, float* var, int32_t* count, void* stream) {
+  if (n_seq <= 0 || rows <= 0 || D <= 0 || ws_ld < D) return IA_ERR_ARG;
+  const int nb = cdiv(rows, RN_ROWS_PER_BLOCK);
+  hipLaunchKernelGGL(rn_merge_seq_kernel, dim3(D), dim3(64), 0, (hipStream_t)stream, ws_seq, n_seq,
+                     (long long)seq_stride, nb, rows, D, ws_ld, mean, var, count);
+  IA_CHECK_LAUNCH();
+  hipLaunchKernelGGL(rn_count_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, count, n_seq * rows);
   IA_CHECK_LAUNCH();
   return IA_OK;
 }

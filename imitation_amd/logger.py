@@ -213,6 +213,35 @@ class HierarchicalLogger(Logger):
         finally:
             self.current_logger, self._name = None, None
 
+    # ---- deferred rounds (imitation_amd extension) --------------------------------------------------
+    # A trainer that lets round r's device work finish in the background while round r+1 already
+    # records its first values parks round r's still-undumped root entries in a stash and later
+    # replays the rest of round r's logging into it -- from INSIDE round r+1's own context -- so that
+    # every file receives exactly the rows, in exactly the order, of the strictly sequential schedule.
+    def detach_pending(self):
+        """Moves the root logger's undumped entries out (the root starts empty again)."""
+        d = self.default_logger
+        stash = (d.name_to_value, d.name_to_count, d.name_to_excluded)
+        d.name_to_value = collections.defaultdict(float)
+        d.name_to_count = collections.defaultdict(int)
+        d.name_to_excluded = {}
+        return stash
+
+    @contextlib.contextmanager
+    def replaying(self, stash):
+        """Temporarily leaves any active `accumulate_means` context and swaps the stashed root entries
+        in; on exit the interrupted context and the current entries are back."""
+        d = self.default_logger
+        saved_ctx = (self.current_logger, self._name, self._key_prefixes, self._accumulate_prefixes)
+        saved_maps = (d.name_to_value, d.name_to_count, d.name_to_excluded)
+        self.current_logger, self._name, self._key_prefixes, self._accumulate_prefixes = None, None, [], []
+        d.name_to_value, d.name_to_count, d.name_to_excluded = stash
+        try:
+            yield
+        finally:
+            d.name_to_value, d.name_to_count, d.name_to_excluded = saved_maps
+            self.current_logger, self._name, self._key_prefixes, self._accumulate_prefixes = saved_ctx
+
     def record(self, key, val, exclude=None):
         if self.current_logger is None:
             self.default_logger.record(key, val, exclude)

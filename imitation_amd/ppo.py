@@ -258,8 +258,12 @@ class PPO(OnPolicyAlgorithm):
         # work with it and later calls `finalize_train()` (one D2H of the statistics + logging).
         self.defer_train_stats = False
         self._pending_train = None
+        # called (if set) after the last env step of a rollout and before the reward relabelling -- the
+        # first point of a rollout that depends on the discriminator (see AdversarialTrainer.train)
+        self.before_relabel = None
         self._dp_obs = th.zeros(min(self.batch_size, total), p.obs_dim, device=self.device)
         self._dp_ws_pre = None
+        self._fin_val = self._fin_ret = None
         self.dp_batch_moments = True  # False: exchange the feature-norm moments once per minibatch (tests)
 
     @property
@@ -423,6 +427,8 @@ class PPO(OnPolicyAlgorithm):
         for d, h in ((rb.next_fixed, rb.h_next), (rb.dones, rb.h_dones), (rb.trunc, rb.h_trunc),
                      (rb.starts, rb.h_starts), (rb.last_done, rb.h_last_done)):
             d.copy_(h, non_blocking=True)
+        if self.before_relabel is not None:
+            self.before_relabel()
         if fused_net is not None:  # discriminator reward relabelling on the whole [T, n] tile
             acts_tbl = rb.clipped.reshape(T * n).long() if pol.discrete else rb.clipped.reshape(T * n, -1)
             table = TransitionTable(rb.obs[:T].reshape(T * n, -1), acts_tbl, rb.next_fixed.reshape(T * n, -1),
@@ -550,6 +556,11 @@ class PPO(OnPolicyAlgorithm):
             pol.optimizer.step_count += self._n_mb
         self._n_updates += self.n_epochs
         self._pending_train = clip_range
+        if self.defer_train_stats:  # the tile is reused by the next rollout before the statistics are read
+            if self._fin_val is None:
+                self._fin_val, self._fin_ret = th.empty_like(rb.val), th.empty_like(rb.ret)
+            self._fin_val.copy_(rb.val)
+            self._fin_ret.copy_(rb.ret)
         if not self.defer_train_stats:
             self.finalize_train()
 
@@ -563,7 +574,9 @@ class PPO(OnPolicyAlgorithm):
         if self._upd_ws is not None and int(self._upd_ws[8:9].view(th.int32).item()) != 0:
             raise RuntimeError("ia_ppo_update: a grid-wide wait timed out inside the persistent PPO kernel; "
                                "the parameters of this update are invalid")
-        vals, rets = rb.val.cpu().numpy().reshape(-1), rb.ret.cpu().numpy().reshape(-1)
+        deferred = self.defer_train_stats and self._fin_val is not None
+        vals = (self._fin_val if deferred else rb.val).cpu().numpy().reshape(-1)
+        rets = (self._fin_ret if deferred else rb.ret).cpu().numpy().reshape(-1)
         var_y = np.var(rets)
         ev = np.nan if var_y == 0 else 1 - np.var(rets - vals) / var_y
         self.logger.record("train/entropy_loss", float(st[..., 2].mean()))

@@ -161,9 +161,12 @@ def snapshot(trainer) -> Dict[str, np.ndarray]:
     return out
 
 
-def run_case(impl: str, name: str, log_dir: str, device: str = "cpu", sync_disc: bool = False) -> Dict[str, np.ndarray]:
+def run_case(impl: str, name: str, log_dir: str, device: str = "cpu", sync_disc: bool = False,
+             pipeline: bool = True) -> Dict[str, np.ndarray]:
     cfg = CASES[name]
     trainer, venv = build_trainer(impl, cfg, log_dir, device)
+    if hasattr(trainer, "pipeline_rounds"):
+        trainer.pipeline_rounds = pipeline
     stats = []
     if hasattr(trainer, "_log_disc_stats") and not sync_disc:
         # product: record where the statistics are logged, so `train()` keeps its own schedule

@@ -79,6 +79,43 @@ def test_deferred_statistics_schedule_is_bit_identical(case, tmp_path):
     assert len(a["disc_stats"]) == harness.CASES[case]["rounds"] * harness.CASES[case]["n_disc"]
 
 
+def _csv_rows(path):
+    import csv
+
+    with open(path) as f:
+        rows = list(csv.DictReader(f))
+    return [{k: v for k, v in r.items() if not k.startswith(("time/", "mean/gen/time/", "raw/gen/time/"))} for r in rows]
+
+
+def test_pipelined_rounds_are_bit_identical(tmp_path):
+    """Round r's discriminator updates run behind round r+1's environment stepping (GAIL). Every
+    array, every logged statistic and every row of every log file must equal the schedule that
+    completes each round before the next one starts."""
+    import glob
+
+    import imitation_amd as p
+
+    outs, logs = {}, {}
+    for mode in (True, False):
+        cfg = harness.CASES["gail_box"]
+        d = str(tmp_path / f"log_{mode}")
+        tr, _ = harness.build_trainer("hip", cfg, d, device="cuda")
+        tr._logger = p.configure_logger(d, ["csv"])
+        tr.gen_algo.set_logger(tr.logger)
+        tr.pipeline_rounds = mode
+        tr.train(4 * cfg["n_envs"] * cfg["n_steps"])
+        outs[mode] = harness.snapshot(tr)
+        tr.logger.close()
+        logs[mode] = {os.path.relpath(f, d): _csv_rows(f) for f in sorted(glob.glob(os.path.join(d, "**", "*.csv"),
+                                                                                recursive=True))}
+    for k in outs[True]:
+        assert np.array_equal(np.asarray(outs[True][k]), np.asarray(outs[False][k]), equal_nan=True), k
+    assert set(logs[True]) == set(logs[False]) and len(logs[True]) == 3      # root, raw/gen, raw/disc
+    for f in logs[True]:
+        assert logs[True][f] == logs[False][f], f
+    assert len(logs[True]["progress.csv"]) == 4
+
+
 def test_discrete_actions_structural(tmp_path):
     """Categorical sampling uses inverse-CDF on a host U(0,1) draw (same distribution, different
     stream than torch.multinomial), so trajectories are not comparable value-by-value; integer

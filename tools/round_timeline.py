@@ -51,24 +51,34 @@ wrap(algo, "collect_rollouts", "collect_rollouts returned", dev=True)
 wrap(algo, "train", "ppo train enqueued", dev=True)
 wrap(tr, "_disc_round", "disc round enqueued", dev=True)
 wrap(tr, "_replay_policy_norm_updates", "norm replay enqueued", dev=True)
-wrap(tr, "_finish_disc_round", "disc stats logged")
+_orig_fin = tr._finish_disc_round
+
+
+def _fin(p):
+    host_mark("  drain starts (disc r-1 done event waited)")
+    r = _orig_fin(p)
+    host_mark("disc stats logged")
+    return r
+
+
+tr._finish_disc_round = _fin
 wrap(algo, "finalize_train", "ppo stats logged")
-tot = {}
-for r in range(rounds):
-    marks.clear()
-    dev_marks.clear()
-    th.cuda.synchronize()
-    t0[0] = time.perf_counter()
-    s = th.cuda.Event(enable_timing=True)
-    s.record()
-    tr.train(per_round)
-    host_mark("round returned")
-    th.cuda.synchronize()
-    host_mark("device idle")
-    if r == rounds - 1:
-        print("host timeline (ms since round start):")
-        for n, t in marks:
-            print(f"  {t:8.2f}  {n}")
-        print("device timeline (ms since round start, completion of the work enqueued up to that point on that stream):")
-        for n, e in dev_marks:
-            print(f"  {s.elapsed_time(e):8.2f}  {n}")
+# multi-round call: rounds overlap (the discriminator updates of round r run behind the environment
+# stepping of round r+1), so print absolute host / device times of everything in one train() call
+marks.clear()
+dev_marks.clear()
+th.cuda.synchronize()
+t0[0] = time.perf_counter()
+s = th.cuda.Event(enable_timing=True)
+s.record()
+tr.train(rounds * per_round)
+host_mark("train() returned")
+th.cuda.synchronize()
+host_mark("device idle")
+print(f"{rounds} rounds in one train() call: {marks[-1][1] / rounds:.2f} ms/round")
+print("host timeline (ms):")
+for n, t in marks:
+    print(f"  {t:8.2f}  {n}")
+print("device timeline (ms; completion of the work enqueued up to that point on that stream):")
+for n, e in dev_marks:
+    print(f"  {s.elapsed_time(e):8.2f}  {n}")
