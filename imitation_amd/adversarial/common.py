@@ -596,9 +596,10 @@ class AdversarialTrainer(abc.ABC):
 
         Dependencies are exactly the reference's: the policy of rollout r+1 needs PPO r and the
         feature-norm side effects of round r's updates (the pre-pass + replay); the first use of the
-        discriminator in round r+1 is the reward relabelling after the last env step, which waits for
-        round r's updates (`PPO.before_relabel`). Round r's statistics are read back and logged at that
-        point -- into the log rows of round r, via `logger.replaying` -- or at the end of `train()`.
+        discriminator in round r+1 is the reward relabelling after the last env step, whose kernels wait
+        for round r's updates (`PPO.before_relabel`). Round r's statistics are read back and logged right
+        after PPO r+1 has been enqueued (`PPO.enqueue_first` / `after_enqueue`: nothing on the host delays
+        a launch) -- into the log rows of round r, via `logger.replaying` -- or at the end of `train()`.
         Every value, every RNG draw and every log row equals the strictly sequential schedule
         (`test_pipelined_rounds_are_bit_identical`)."""
         algo = self.gen_algo
@@ -606,20 +607,25 @@ class AdversarialTrainer(abc.ABC):
         self._disc_stream.wait_stream(main)
         previous = []  # at most one round in flight: (disc handle, done event, root-log stash, global step)
 
-        def drain():
+        def gate():  # device side only: the relabelling kernels wait for the previous round's updates
+            if previous:
+                main.wait_event(previous[-1][1])
+
+        def drain():  # host side: read the previous round's statistics back and write its log rows
             if not previous:
                 return
-            pend, done, stash, gstep = previous.pop()
+            pend, done, stash, gstep, train_rec = previous.pop()
             done.synchronize()
-            main.wait_event(done)
             with self.logger.replaying(stash):
                 self._finish_disc_round(pend)
                 with self.logger.accumulate_means("gen"):
+                    algo._pending_train, keep = train_rec, algo._pending_train
                     algo.finalize_train()
+                    algo._pending_train = keep
                 self.logger.dump(gstep)
 
         self._in_overlap, algo.defer_train_stats = True, True
-        algo.before_relabel = drain
+        algo.before_relabel, algo.after_enqueue, algo.enqueue_first = gate, drain, True
         try:
             for _ in range(n_rounds):
                 self._overlap_k = 0
@@ -635,11 +641,13 @@ class AdversarialTrainer(abc.ABC):
                     done.record()
                 main.wait_event(self._quirk_ready)
                 self._replay_policy_norm_updates()                 # behind the PPO update, ahead of the next rollout
-                previous.append((pend, done, self.logger.detach_pending(), self._global_step))
+                train_rec, algo._pending_train = algo._pending_train, None
+                previous.append((pend, done, self.logger.detach_pending(), self._global_step, train_rec))
             drain()
             main.wait_stream(self._disc_stream)
         finally:
-            self._in_overlap, algo.defer_train_stats, algo.before_relabel = False, False, None
+            self._in_overlap, algo.defer_train_stats = False, False
+            algo.before_relabel, algo.after_enqueue, algo.enqueue_first = None, None, False
 
 
 def _slice_table(t: TransitionTable, start: int, n: int) -> TransitionTable:

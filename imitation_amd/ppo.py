@@ -136,6 +136,37 @@ class _PermutationPredraw:
         return True
 
 
+class _TrainRecord:
+    """Everything `finalize_train` reads about ONE `PPO.train`, kept apart from the live buffers so it can
+    be read back after the next rollout -- or even the next PPO update -- has been enqueued: loss
+    statistics (written by the kernels directly), value / return tiles, log_std, the error word.
+    Read-back goes through a side stream, so it never queues behind a running PPO update."""
+
+    def __init__(self, stats_like: th.Tensor, val_like: th.Tensor, log_std: Optional[th.Tensor]):
+        dev = stats_like.device
+        self.stats = th.zeros_like(stats_like)
+        self.val, self.ret = th.empty_like(val_like), th.empty_like(val_like)
+        self.log_std = None if log_std is None else th.empty_like(log_std)
+        self.err = th.zeros(1, dtype=th.int32, device=dev)
+        pin = lambda t: th.empty(t.shape, dtype=t.dtype).pin_memory()
+        self.h_stats, self.h_val, self.h_ret, self.h_err = pin(self.stats), pin(self.val), pin(self.ret), pin(self.err)
+        self.h_log_std = None if log_std is None else pin(self.log_std)
+        self.ready = th.cuda.Event()
+        self.clip_range = 0.0
+        self.n_updates = 0
+
+    def read_back(self, stream: th.cuda.Stream) -> None:
+        with th.cuda.stream(stream):
+            stream.wait_event(self.ready)
+            self.h_stats.copy_(self.stats, non_blocking=True)
+            self.h_val.copy_(self.val, non_blocking=True)
+            self.h_ret.copy_(self.ret, non_blocking=True)
+            self.h_err.copy_(self.err, non_blocking=True)
+            if self.log_std is not None:
+                self.h_log_std.copy_(self.log_std, non_blocking=True)
+        stream.synchronize()
+
+
 class RolloutBuffer:
     """Device-resident `[T, n_envs, ...]` rollout tile (time-major, fp32) + the pinned host
     staging the env loop writes into. Properties named like SB3's `RolloutBuffer` fields return
@@ -261,9 +292,17 @@ class PPO(OnPolicyAlgorithm):
         # called (if set) after the last env step of a rollout and before the reward relabelling -- the
         # first point of a rollout that depends on the discriminator (see AdversarialTrainer.train)
         self.before_relabel = None
+        # `enqueue_first`: inside `learn`, enqueue the PPO update BEFORE the iteration's host-side logging
+        # (then call `after_enqueue`, then log) so that nothing on the host delays the launch; the records
+        # are made in the same order as always. Set by the pipelined adversarial trainer.
+        self.enqueue_first = False
+        self.after_enqueue = None
+        self._post_enqueue_work = []
         self._dp_obs = th.zeros(min(self.batch_size, total), p.obs_dim, device=self.device)
         self._dp_ws_pre = None
-        self._fin_val = self._fin_ret = None
+        self._records = None
+        self._rec_i = 0
+        self._fin_stream = None
         self.dp_batch_moments = True  # False: exchange the feature-norm moments once per minibatch (tests)
 
     @property
@@ -342,6 +381,14 @@ class PPO(OnPolicyAlgorithm):
                 break
             iteration += 1
             self._current_progress_remaining = 1.0 - float(self.num_timesteps) / float(total_timesteps)
+            lr_later = None
+            if self.enqueue_first:
+                lr_later = self.train(record_lr=False)
+                for work in self._post_enqueue_work:
+                    work()
+                self._post_enqueue_work = []
+                if self.after_enqueue is not None:
+                    self.after_enqueue()
             if log_interval is not None and iteration % log_interval == 0:
                 elapsed = max((time.time_ns() - self.start_time) / 1e9, sys.float_info.epsilon)
                 fps = int((self.num_timesteps - self._num_timesteps_at_start) / elapsed)
@@ -353,7 +400,10 @@ class PPO(OnPolicyAlgorithm):
                 self.logger.record("time/time_elapsed", int(elapsed), exclude="tensorboard")
                 self.logger.record("time/total_timesteps", self.num_timesteps, exclude="tensorboard")
                 self.logger.dump(step=self.num_timesteps)
-            self.train()
+            if lr_later is None:
+                self.train()
+            else:  # what `train()` records before it enqueues anything
+                self.logger.record("train/learning_rate", lr_later)
         callback.on_training_end()
         return self
 
@@ -437,8 +487,22 @@ class PPO(OnPolicyAlgorithm):
         else:
             rb.rew.copy_(rb.h_rew, non_blocking=True)
         if rw is not None:
-            wrapped = rb.rew.cpu().numpy() if fused_net is not None else np.stack(per_step_rews)
-            rw.record_rewards(wrapped, h_dones_np.astype(bool), self._last_obs)
+            if fused_net is not None and self.enqueue_first:
+                # episode-return bookkeeping needs the relabelled rewards on the host but nothing on the
+                # device needs it: copy now, consume after the PPO update has been enqueued
+                rb.h_rew.copy_(rb.rew, non_blocking=True)
+                copied = th.cuda.Event()
+                copied.record()
+                last_obs, dones_host = self._last_obs, h_dones_np.astype(bool)
+
+                def bookkeeping():
+                    copied.synchronize()
+                    rw.record_rewards(rb.h_rew.numpy().copy(), dones_host, last_obs)
+
+                self._post_enqueue_work.append(bookkeeping)
+            else:
+                wrapped = rb.rew.cpu().numpy() if fused_net is not None else np.stack(per_step_rews)
+                rw.record_rewards(wrapped, h_dones_np.astype(bool), self._last_obs)
         if h_trunc_np.any():  # rewards[i] += gamma * V(terminal_obs_i) for time-limit endings
             pol.values_rows(rb.next_fixed.reshape(T * n, -1), rb.term_val.reshape(T * n))
             L.call("ia_timeout_bootstrap", L.ptr(rb.rew), L.ptr(rb.term_val), L.ptr(rb.trunc), float(self.gamma),
@@ -512,11 +576,12 @@ class PPO(OnPolicyAlgorithm):
                        L.ptr(self._stats_dev[e, mb]), L.stream())
 
     # ---- PPO update (App. A.7) ----------------------------------------------------------------
-    def train(self) -> None:
+    def train(self, record_lr: bool = True):
         pol, rb = self.policy, self.rollout_buffer
         pol.set_training_mode(True)
         lr = self.lr_schedule(self._current_progress_remaining)
-        self.logger.record("train/learning_rate", lr)
+        if record_lr:
+            self.logger.record("train/learning_rate", lr)
         pol.optimizer.param_groups[0]["lr"] = lr
         clip_range = self.clip_range(self._current_progress_remaining)
         T, n = rb.buffer_size, rb.n_envs
@@ -527,6 +592,16 @@ class PPO(OnPolicyAlgorithm):
         self._perm_dev.copy_(self._perm_host, non_blocking=True)
         rn = pol.features_extractor.normalize
         g = pol.optimizer.param_groups[0]
+        rec = None
+        if self.defer_train_stats:
+            if self._records is None:
+                self._records = [_TrainRecord(self._stats_dev, rb.val, pol.log_std) for _ in range(2)]
+                self._fin_stream = th.cuda.Stream(device=self.device)
+            rec = self._records[self._rec_i % 2]
+            self._rec_i += 1
+            rec.val.copy_(rb.val)   # the tile is reused by the next rollout before the statistics are read
+            rec.ret.copy_(rb.ret)
+        stats_dev = rec.stats if rec is not None else self._stats_dev
         if self.dp is not None and self.dp.world > 1:
             self._train_data_parallel(perm, lr, clip_range)
         single = not (self.dp is not None and self.dp.world > 1)
@@ -540,7 +615,7 @@ class PPO(OnPolicyAlgorithm):
                    int(self.normalize_advantage), float(clip_range), float(self.ent_coef), float(self.vf_coef),
                    float(self.max_grad_norm), L.ptr(pol.optimizer.exp_avg), L.ptr(pol.optimizer.exp_avg_sq),
                    float(lr), float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]), pol.optimizer.step_count,
-                   L.ptr(self._upd_ws), L.ptr(self._stats_dev), L.stream())
+                   L.ptr(self._upd_ws), L.ptr(stats_dev), L.stream())
             if self.update_events is not None:
                 self.update_events[1].record()
             pol.optimizer.step_count += self.n_epochs * self._n_mb
@@ -552,31 +627,45 @@ class PPO(OnPolicyAlgorithm):
                    int(self.normalize_advantage), float(clip_range), float(self.ent_coef), float(self.vf_coef),
                    float(self.max_grad_norm), L.ptr(pol.optimizer.exp_avg), L.ptr(pol.optimizer.exp_avg_sq),
                    float(lr), float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]), pol.optimizer.step_count,
-                   L.ptr(self._ppo_ws), L.ptr(self._stats_dev[e]), L.stream())
+                   L.ptr(self._ppo_ws), L.ptr(stats_dev[e]), L.stream())
             pol.optimizer.step_count += self._n_mb
         self._n_updates += self.n_epochs
-        self._pending_train = clip_range
-        if self.defer_train_stats:  # the tile is reused by the next rollout before the statistics are read
-            if self._fin_val is None:
-                self._fin_val, self._fin_ret = th.empty_like(rb.val), th.empty_like(rb.ret)
-            self._fin_val.copy_(rb.val)
-            self._fin_ret.copy_(rb.ret)
-        if not self.defer_train_stats:
+        if rec is not None:
+            if self.dp is not None and self.dp.world > 1:   # that path wrote the shared statistics tile
+                rec.stats.copy_(self._stats_dev)
+            if rec.log_std is not None:
+                rec.log_std.copy_(pol.log_std)
+            if self._upd_ws is not None:
+                rec.err.copy_(self._upd_ws[8:9].view(th.int32))
+            rec.ready.record()
+            rec.clip_range, rec.n_updates = clip_range, self._n_updates
+            self._pending_train = rec
+        else:
+            self._pending_train = clip_range
             self.finalize_train()
+        return lr
 
     def finalize_train(self) -> None:
         """Statistics read-back + logging of the last `train()` (SB3 PPO.train's logger block)."""
         if self._pending_train is None:
             return
-        clip_range, self._pending_train = self._pending_train, None
+        pending, self._pending_train = self._pending_train, None
         pol, rb = self.policy, self.rollout_buffer
-        st = self._stats_dev.cpu().numpy()  # one synchronisation per train()
-        if self._upd_ws is not None and int(self._upd_ws[8:9].view(th.int32).item()) != 0:
+        if isinstance(pending, _TrainRecord):
+            pending.read_back(self._fin_stream)
+            clip_range, n_updates = pending.clip_range, pending.n_updates
+            st, err = pending.h_stats.numpy(), int(pending.h_err.item())
+            vals, rets = pending.h_val.numpy().reshape(-1), pending.h_ret.numpy().reshape(-1)
+            std = None if pending.h_log_std is None else float(th.exp(pending.h_log_std).mean().item())
+        else:
+            clip_range, n_updates = pending, self._n_updates
+            st = self._stats_dev.cpu().numpy()  # one synchronisation per train()
+            err = 0 if self._upd_ws is None else int(self._upd_ws[8:9].view(th.int32).item())
+            vals, rets = rb.val.cpu().numpy().reshape(-1), rb.ret.cpu().numpy().reshape(-1)
+            std = None if pol.discrete else float(th.exp(pol.log_std).mean().item())
+        if err != 0:
             raise RuntimeError("ia_ppo_update: a grid-wide wait timed out inside the persistent PPO kernel; "
                                "the parameters of this update are invalid")
-        deferred = self.defer_train_stats and self._fin_val is not None
-        vals = (self._fin_val if deferred else rb.val).cpu().numpy().reshape(-1)
-        rets = (self._fin_ret if deferred else rb.ret).cpu().numpy().reshape(-1)
         var_y = np.var(rets)
         ev = np.nan if var_y == 0 else 1 - np.var(rets - vals) / var_y
         self.logger.record("train/entropy_loss", float(st[..., 2].mean()))
@@ -586,7 +675,7 @@ class PPO(OnPolicyAlgorithm):
         self.logger.record("train/clip_fraction", float(st[..., 4].mean()))
         self.logger.record("train/loss", float(st[-1, -1, 5]))
         self.logger.record("train/explained_variance", float(ev))
-        if not pol.discrete:
-            self.logger.record("train/std", float(th.exp(pol.log_std).mean().item()))
-        self.logger.record("train/n_updates", self._n_updates, exclude="tensorboard")
+        if std is not None:
+            self.logger.record("train/std", std)
+        self.logger.record("train/n_updates", n_updates, exclude="tensorboard")
         self.logger.record("train/clip_range", clip_range)
