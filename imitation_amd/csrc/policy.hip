@@ -1810,6 +1810,156 @@ __device__ __forceinline__ void mfma32_minibatch_chain(
 #undef IA_TS
 }
 
+// ---------------------------------------------------------------------------------------------
+// Rollout step on the matrix pipe (hidden = 32): the forward half of the chain above for 64 rows per
+// block -- wave (tower, q) takes rows q*16 .. q*16+15 through both layers and its head without block
+// barriers after the feature staging -- then lanes 0..15 of the policy waves sample / clip / score
+// their row exactly as the thread-per-row kernel does (same expression order), value waves store V.
+struct ALds {
+  static constexpr int XS = MAXD + 1, HS = 33, AS = MAXA + 1;
+  static constexpr int x = 0;
+  static constexpr int a1 = x + ROWS * XS;       // [2][ROWS][HS]
+  static constexpr int a2 = a1 + 2 * ROWS * HS;
+  static constexpr int out = a2 + 2 * ROWS * HS; // [ROWS][AS]
+  static constexpr int total = out + ROWS * AS;
+};
+
+__global__ __launch_bounds__(512) void policy_act_mfma32_kernel(
+    ia_policy_desc d, const float* __restrict__ P, const float* __restrict__ Pt, const float* __restrict__ nm,
+    const float* __restrict__ nv, const float* __restrict__ obs, int n, const float* __restrict__ noise,
+    const float* __restrict__ low, const float* __restrict__ high, float* __restrict__ actions,
+    float* __restrict__ clipped, float* __restrict__ values, float* __restrict__ logp) {
+  constexpr int H = 32;
+  using L = ALds;
+  extern __shared__ float lds[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tw = wv >> 2, q = wv & 3;
+  const int li = lane & 15, lk = lane >> 4;
+  const int D = d.obs_dim, A = d.act_dim;
+  const PolOff o = pol_offsets(D, A, H, d.discrete);
+  const int i0 = blockIdx.x * ROWS;
+  const int S1 = (D + 3) >> 2;
+  const int oW1 = tw ? o.vW1 : o.pW1, ob1 = tw ? o.vb1 : o.pb1, oW2 = tw ? o.vW2 : o.pW2, ob2 = tw ? o.vb2 : o.pb2;
+  // stage the block's feature rows (normalised); unconditional loads from clamped addresses
+  for (int e = tid; e < ROWS * L::XS; e += 512) {
+    const int r = e / L::XS, k = e - r * L::XS;
+    const bool ok = k < D && (i0 + r) < n;
+    const int kc = min(k, D - 1);
+    const float raw = obs[(long long)min(i0 + r, n - 1) * D + kc];
+    float v = raw;
+    if (d.has_norm) v = (raw - nm[kc]) / sqrtf(nv[kc] + d.norm_eps);
+    lds[L::x + e] = ok ? v : 0.f;
+  }
+  // weight fragments straight from global memory (L2-resident, 14 KB): B[k = 4s+lk][j = c*16+li]
+  float bW1[16][2], bW2[8][2], bHead[8], b1v[2], b2v[2];
+#pragma unroll
+  for (int s = 0; s < 16; ++s) {
+    const int kk = min(4 * s + lk, D - 1);
+    const float m = (s < S1 && 4 * s + lk < D) ? 1.f : 0.f;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) bW1[s][c] = s < S1 ? Pt[oW1 + kk * H + c * 16 + li] * m : 0.f;
+  }
+#pragma unroll
+  for (int s = 0; s < 8; ++s) {
+    const int kk = 4 * s + lk;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) bW2[s][c] = Pt[oW2 + kk * H + c * 16 + li];
+    const float hv = P[(tw == 0 ? o.aW + min(li, A - 1) * H : o.cW) + kk];
+    bHead[s] = tw == 0 ? (li < A ? hv : 0.f) : (li == 0 ? hv : 0.f);
+  }
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {
+    b1v[c] = P[ob1 + c * 16 + li];
+    b2v[c] = P[ob2 + c * 16 + li];
+  }
+  const float head_bias = tw == 0 ? P[o.ab + min(li, A - 1)] : P[o.cb];
+  __syncthreads();
+
+  float* a1t = lds + L::a1 + tw * ROWS * L::HS;
+  float* a2t = lds + L::a2 + tw * ROWS * L::HS;
+  const int arow = q * 16 + li;
+  {
+    f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+    for (int s = 0; s < 16; ++s)
+      if (s < S1) {
+        const float a = lds[L::x + arow * L::XS + 4 * s + lk];
+        acc[0] = mfma16(a, bW1[s][0], acc[0]);
+        acc[1] = mfma16(a, bW1[s][1], acc[1]);
+      }
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) a1t[(q * 16 + lk * 4 + r) * L::HS + c * 16 + li] = fast_tanh(acc[c][r] + b1v[c]);
+  }
+  wave_sync_lds();
+  {
+    f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      const float a = a1t[arow * L::HS + 4 * s + lk];
+      acc[0] = mfma16(a, bW2[s][0], acc[0]);
+      acc[1] = mfma16(a, bW2[s][1], acc[1]);
+    }
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) a2t[(q * 16 + lk * 4 + r) * L::HS + c * 16 + li] = fast_tanh(acc[c][r] + b2v[c]);
+  }
+  wave_sync_lds();
+  {
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < 8; ++s) acc = mfma16(a2t[arow * L::HS + 4 * s + lk], bHead[s], acc);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int rr = q * 16 + lk * 4 + r;
+      if (tw == 0) { if (li < A) lds[L::out + rr * L::AS + li] = acc[r] + head_bias; }
+      else if (li == 0 && i0 + rr < n) values[i0 + rr] = acc[r] + head_bias;
+    }
+  }
+  if (tw != 0) return;
+  wave_sync_lds();
+  const int row = i0 + q * 16 + lane;
+  if (lane >= 16 || row >= n) return;
+  const float* outrow = lds + L::out + (q * 16 + lane) * L::AS;
+  if (!d.discrete) {
+    float lp = 0.f;
+    for (int a = 0; a < A; ++a) {
+      const float ls = P[o.log_std + a];
+      const float mu = outrow[a];
+      const float act = __fadd_rn(mu, __fmul_rn(noise[(long long)row * A + a], expf(ls)));  // Normal.rsample
+      actions[(long long)row * A + a] = act;
+      clipped[(long long)row * A + a] = fminf(fmaxf(act, low[a]), high[a]);
+      lp += gauss_logp_term(act, mu, ls);
+    }
+    logp[row] = lp;
+  } else {
+    float mx = outrow[0];
+    for (int a = 1; a < A; ++a) mx = fmaxf(mx, outrow[a]);
+    float se = 0.f;
+    for (int a = 0; a < A; ++a) se += expf(outrow[a] - mx);
+    const float lse = mx + logf(se);
+    const float u = noise[row];
+    float c = 0.f;
+    int pick = A - 1;
+    if (u < 0.f) {  // mode of the Categorical (argmax, first index on ties)
+      pick = 0;
+      for (int a = 1; a < A; ++a)
+        if (outrow[a] > outrow[pick]) pick = a;
+    } else {
+      for (int a = 0; a < A; ++a) {
+        c += expf(outrow[a] - lse);
+        if (u < c) { pick = a; break; }
+      }
+    }
+    actions[row] = (float)pick;
+    clipped[row] = (float)pick;
+    logp[row] = outrow[pick] - lse;
+  }
+}
+
 // Instance for the persistent kernel (parameters resident in LDS, rows staged in LDS). Inlined with
 // the opaque zero below; an out-of-line call measured 4 us per step slower (callee-saved spills).
 __device__ __forceinline__ void mfma32_minibatch_resident(
@@ -2240,6 +2390,7 @@ int set_lds(K kern, size_t bytes) {
   return e == hipSuccess ? IA_OK : (int)e;
 }
 
+bool g_ppo_valu = false;  // tuning/debug: force the VALU kernels for H = 32 as well
 }  // namespace
 
 extern "C" {
@@ -2261,7 +2412,13 @@ int ia_policy_act(const ia_policy_desc* d, const float* params, const float* par
                   const float* high, float* actions, float* clipped, float* values, float* logp, void* stream) {
   if (!pol_ok(d) || n <= 0) return IA_ERR_ARG;
   int rc;
-  if (d->hidden == 32) {
+  if (d->hidden == 32 && !g_ppo_valu) {
+    static bool attr = false;
+    const size_t bytes = ALds::total * sizeof(float);
+    if (!attr) { if ((rc = set_lds(policy_act_mfma32_kernel, bytes))) return rc; attr = true; }
+    hipLaunchKernelGGL(policy_act_mfma32_kernel, dim3(cdiv(n, ROWS)), dim3(512), bytes, (hipStream_t)stream, *d, params,
+                       params_t, norm_mean, norm_var, obs, n, noise, low, high, actions, clipped, values, logp);
+  } else if (d->hidden == 32) {
     if ((rc = set_lds(policy_act_kernel<32>, lds_bytes<32>()))) return rc;
     hipLaunchKernelGGL(policy_act_kernel<32>, dim3(cdiv(n, ROWS)), dim3(ROWS), lds_bytes<32>(), (hipStream_t)stream,
                        *d, params, params_t, norm_mean, norm_var, obs, n, noise, low, high, actions, clipped, values,
@@ -2395,7 +2552,6 @@ int launch_prepare(const PpoArgs& a, const int64_t* idx, int batch) {
   return IA_OK;
 }
 
-bool g_ppo_valu = false;  // tuning/debug: force the VALU kernel for H = 32 as well
 
 template <int H>
 int launch_grad(const PpoArgs& a, const int64_t* idx, int batch) {

@@ -239,8 +239,8 @@ int64_t ia_ppo_grad_offset(const ia_policy_desc* d, int batch);
  * stores the shader clock at its phase boundaries in [0..11]; ia_ppo_update accumulates 100 MHz ticks
  * per step phase in [0..7] and stores the last step's phase clocks in [16..27] (NULL switches it off). */
 int ia_ppo_debug_timing(void* device_buffer_16xi64);
-/* Tuning/tests: 1 = use the VALU (thread-per-row) gradient kernel also for hidden = 32 instead of
- * the MFMA 16x16x4 one (hidden = 64 always uses the VALU kernel). */
+/* Tuning/tests: 1 = use the VALU (thread-per-row) gradient and rollout-step kernels also for
+ * hidden = 32 instead of the MFMA 16x16x4 ones (hidden = 64 always uses the VALU kernels). */
 int ia_ppo_force_valu(int on);
 int ia_ppo_minibatch_apply(const ia_policy_desc* d, float* params, float* params_t, int batch, float ent_coef,
                            float vf_coef, float max_grad_norm, float* exp_avg, float* exp_avg_sq, float beta1,
