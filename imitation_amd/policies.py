@@ -208,6 +208,42 @@ class ActorCriticPolicy:
             return th.rand(n)
         return th.distributions.utils._standard_normal((n, self.act_dim), dtype=th.float32, device="cpu")
 
+    def draw_noise_into(self, out: th.Tensor) -> None:
+        """`sample_noise` straight into a (pinned) contiguous host buffer: the same generator
+        consumption as `torch.empty(shape).normal_()` / `.uniform_()` on a fresh tensor, minus the
+        allocation and the copy."""
+        if self.discrete:
+            out.uniform_()
+        else:
+            out.normal_()
+
+    def make_act_step(self, obs_tile: th.Tensor, noise_dev: th.Tensor, acts: th.Tensor, clipped: th.Tensor,
+                      val: th.Tensor, logp: th.Tensor):
+        """Rollout-step launcher over time-major tiles `[T(+1), n, ...]` with every pointer resolved once:
+        `step(t)` is one ctypes call (eval mode: no statistics update). Used by `PPO.collect_rollouts`."""
+        assert not (self.training and self.features_extractor.normalize is not None), \
+            "the rollout step runs in eval mode (a train-mode forward would update the feature statistics)"
+        lib, desc = L.load(), C.byref(self.desc)
+        fn = lib.ia_policy_act
+        n = obs_tile.shape[1]
+        nm, nv = self._norm_ptrs()
+        P, Pt = L.ptr(self._flat), L.ptr(self._flat_t)
+        low, high, noise = L.ptr(self._low), L.ptr(self._high), L.ptr(noise_dev)
+        b_obs, s_obs = obs_tile.data_ptr(), obs_tile.stride(0) * 4
+        b_act, s_act = acts.data_ptr(), acts.stride(0) * 4
+        b_clip, s_clip = clipped.data_ptr(), clipped.stride(0) * 4
+        b_val, s_val = val.data_ptr(), val.stride(0) * 4
+        b_lp, s_lp = logp.data_ptr(), logp.stride(0) * 4
+        stream = L.stream()
+
+        def step(t: int) -> None:
+            rc = fn(desc, P, Pt, nm, nv, b_obs + t * s_obs, n, noise, low, high, b_act + t * s_act, b_clip + t * s_clip,
+                    b_val + t * s_val, b_lp + t * s_lp, stream)
+            if rc != 0:
+                L.check(rc, "ia_policy_act")
+
+        return step
+
     def act(self, obs_dev: th.Tensor, noise_dev: th.Tensor, actions: th.Tensor, clipped: th.Tensor,
             values: th.Tensor, logp: th.Tensor) -> None:
         """Device-to-device rollout step (no allocation): fills actions/clipped/values/logp."""

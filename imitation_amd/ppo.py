@@ -298,6 +298,7 @@ class PPO(OnPolicyAlgorithm):
         self.enqueue_first = False
         self.after_enqueue = None
         self._post_enqueue_work = []
+        self.rollout_profile = None
         self._dp_obs = th.zeros(min(self.batch_size, total), p.obs_dim, device=self.device)
         self._dp_ws_pre = None
         self._records = None
@@ -440,18 +441,31 @@ class PPO(OnPolicyAlgorithm):
         h_rew_np, h_dones_np, h_trunc_np = rb.h_rew.numpy(), rb.h_dones.numpy(), rb.h_trunc.numpy()
         h_next_np, h_obs_np, h_starts_np = rb.h_next.numpy(), rb.h_obs.numpy(), rb.h_starts.numpy()
         per_step_rews = []
+        prof = self.rollout_profile  # optional dict of per-section host seconds (tools/rollout_sections.py)
+        tick = time.perf_counter
+        act_step = pol.make_act_step(rb.obs, rb.noise, rb.acts, rb.clipped, rb.val, rb.logp)  # eval mode: no norm update
         for t in range(T):
-            rb.h_noise.copy_(pol.sample_noise(n).reshape(n, -1))
+            t0 = tick() if prof is not None else 0.0
+            pol.draw_noise_into(rb.h_noise)
             rb.noise.copy_(rb.h_noise, non_blocking=True)
-            pol.act(rb.obs[t], rb.noise, rb.acts[t], rb.clipped[t], rb.val[t], rb.logp[t])
+            t1 = tick() if prof is not None else 0.0
+            act_step(t)
             rb.h_clip.copy_(rb.clipped[t], non_blocking=True)
+            t2 = tick() if prof is not None else 0.0
             stream.synchronize()
+            t3 = tick() if prof is not None else 0.0
             acts_np = rb.h_clip.numpy()
             acts_np = acts_np.reshape(n).astype(np.int64) if pol.discrete else acts_np.reshape(
                 (n, *self.action_space.shape)).copy()
             old_obs = self._last_obs
             base.step_async(acts_np)
             new_obs, env_rews, dones, nxt, trunc, infos = step_arrays(base)
+            if prof is not None:
+                t4 = tick()
+                for k, v in (("noise draw + H2D", t1 - t0), ("act launch + D2H enqueue", t2 - t1),
+                             ("wait for the device", t3 - t2), ("env step", t4 - t3)):
+                    prof[k] = prof.get(k, 0.0) + v
+                prof["_t_book"] = t4
             self.num_timesteps += n
             if not callback.on_step():
                 return False
@@ -472,6 +486,8 @@ class PPO(OnPolicyAlgorithm):
                 h_rew_np[t] = env_rews
             rb.obs[t + 1].copy_(rb.h_obs[t + 1], non_blocking=True)
             self._last_obs, starts = new_obs, np.asarray(dones, dtype=bool)
+            if prof is not None:
+                prof["bookkeeping + obs H2D"] = prof.get("bookkeeping + obs H2D", 0.0) + tick() - prof.pop("_t_book")
         self._last_episode_starts = starts
         rb.h_last_done.copy_(th.as_tensor(starts.astype(np.float32)))
         for d, h in ((rb.next_fixed, rb.h_next), (rb.dones, rb.h_dones), (rb.trunc, rb.h_trunc),

@@ -1,0 +1,26 @@
+"""Host-side sections of the rollout loop at config P (seconds accumulated over the 16 steps of each
+rollout inside pipelined training). Usage: python tools/rollout_sections.py [rounds]"""
+import os
+import sys
+
+import torch as th
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402
+
+rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 10
+th.set_num_threads(1)
+cfg = dict(bench.CFG_P)
+tr = bench.build_trainer(bench.hip_namespace(), cfg, "cuda")
+per_round = cfg["n_envs"] * cfg["n_steps"]
+tr.train(3 * per_round)
+th.cuda.synchronize()
+tr.gen_algo.rollout_profile = {}
+tr.train(rounds * per_round)
+th.cuda.synchronize()
+prof = tr.gen_algo.rollout_profile
+tot = sum(prof.values())
+print(f"per rollout (16 steps), average over {rounds} rounds:")
+for k, v in sorted(prof.items(), key=lambda kv: -kv[1]):
+    print(f"  {k:28s} {1e3 * v / rounds:7.3f} ms   {1e6 * v / rounds / cfg['n_steps']:7.1f} us/step")
+print(f"  {'sum':28s} {1e3 * tot / rounds:7.3f} ms")
