@@ -1466,15 +1466,27 @@ __device__ __forceinline__ void mfma32_minibatch_chain(
   // ---- stage this wave's 16 feature rows (normalised) into the x tile; clear its rows of the small tiles
   {
     const int rbase = q * 16;
-    // both towers read x: tower 0 waves stage even columns chunks, tower 1 waves the odd ones
-    for (int e = lane + 64 * tw; e < 16 * L::XS; e += 128) {
-      const int r = e / L::XS, k = e - r * L::XS;
-      const bool ok = k < D && (i0 + rbase + r) < batch;
-      const int kc = min(k, MAXD - 1);
+    // the two waves that share q (tower 0 / tower 1) stage the 16 rows together: lane l of the 128
+    // takes row l/8 and the eight columns l%8 + 8j -- no integer division, and all 24 loads of a lane
+    // (raw value, mean, variance per column) are independent and in flight together
+    const int l128 = lane + 64 * tw;
+    const int r = l128 >> 3, cb = l128 & 7;
+    const bool rok = (i0 + rbase + r) < batch;
+    float raw[8], mu[8], vr[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int k = cb + 8 * j;
+      raw[j] = stg[UpdStage::x + (rbase + r) * L::XS + k];
+      mu[j] = nm[k];          // slot arrays hold MAXD entries each
+      vr[j] = nv[k];
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int k = cb + 8 * j;
+      const bool ok = rok && k < D;
       const float msk = (ok && d.has_norm) ? 1.f : 0.f;
-      const float mean = nm[kc] * msk, var = nv[kc] * msk + (1.f - msk) * (1.f - d.norm_eps);
-      const float raw = ok ? stg[UpdStage::x + (rbase + r) * L::XS + k] : 0.f;
-      lds[L::x + (rbase + r) * L::XS + k] = (raw - mean) / sqrtf(var + d.norm_eps);
+      const float mean = mu[j] * msk, var = vr[j] * msk + (1.f - msk) * (1.f - d.norm_eps);
+      lds[L::x + (rbase + r) * L::XS + k] = ok ? (raw[j] - mean) / sqrtf(var + d.norm_eps) : 0.f;
     }
     if (tw == 0) {
       for (int e = lane; e < 16 * L::AS; e += 64) {
@@ -1520,14 +1532,16 @@ __device__ __forceinline__ void mfma32_minibatch_chain(
     cwv[c] = sP[o.cW + c * 16 + li];
   }
   const float head_bias = tw == 0 ? (li < A ? sP[o.ab + li] : 0.f) : sP[o.cb];
-  float c_var[MAXA], c_logsd[MAXA];
+  // per-action Gaussian constants; the reciprocal variance turns the ~3 IEEE divisions per action and
+  // row of the loss into multiplications (<= 1 ulp away from dividing)
+  float c_ivar[MAXA], c_logsd[MAXA];
 #pragma unroll
   for (int a = 0; a < MAXA; ++a) {
-    c_var[a] = 1.f;
+    c_ivar[a] = 1.f;
     c_logsd[a] = 0.f;
     if (tw == 0 && !d.discrete && a < A) {
       const float sd = expf(sP[o.log_std + a]);
-      c_var[a] = sd * sd;
+      c_ivar[a] = 1.f / (sd * sd);
       c_logsd[a] = logf(sd);
     }
   }
@@ -1600,7 +1614,7 @@ __device__ __forceinline__ void mfma32_minibatch_chain(
         for (int a = 0; a < MAXA; ++a)
           if (a < A) {
             const float diff = r_act[a] - outrow[a];
-            logp += -(diff * diff) / (2.f * c_var[a]) - c_logsd[a] - LOG_SQRT_2PI;
+            logp += -(diff * diff) * (0.5f * c_ivar[a]) - c_logsd[a] - LOG_SQRT_2PI;
             entropy += 0.5f + LOG_SQRT_2PI + c_logsd[a];
           }
       } else {
@@ -1632,8 +1646,8 @@ __device__ __forceinline__ void mfma32_minibatch_chain(
         for (int a = 0; a < MAXA; ++a)
           if (a < A) {
             const float diff = r_act[a] - outrow[a];
-            doutrow[a] = dlogp * diff / c_var[a];
-            auxrow[a] = valid ? dlogp * (diff * diff / c_var[a] - 1.f) - ent_coef * invB : 0.f;
+            doutrow[a] = dlogp * diff * c_ivar[a];
+            auxrow[a] = valid ? dlogp * (diff * diff * c_ivar[a] - 1.f) - ent_coef * invB : 0.f;
           }
       } else {
         for (int a = 0; a < A; ++a) {
@@ -1647,7 +1661,7 @@ __device__ __forceinline__ void mfma32_minibatch_chain(
       float* mrow = lds + L::misc + lrow * L::MS;
       mrow[2] = valid ? -fminf(pl1, pl2) : 0.f;                           // policy_gradient_loss
       mrow[3] = valid ? -entropy : 0.f;                                    // entropy_loss
-      mrow[4] = valid ? (expf(log_ratio) - 1.f) - log_ratio : 0.f;         // approx_kl
+      mrow[4] = valid ? (ratio - 1.f) - log_ratio : 0.f;                   // approx_kl
       mrow[5] = valid ? (fabsf(ratio - 1.f) > clip ? 1.f : 0.f) : 0.f;     // clip_fraction
     } else {
       const float v = lds[L::misc + lrow * L::MS + 0];
