@@ -852,11 +852,8 @@ struct MbRows {
   int batch, T, n_envs;
 };
 
-// One minibatch of block `vblk` (64 rows): forward, losses, backward; gradient partials -> `slab`,
-// loss-statistic partials -> `statpart[0..4]`. LOAD_PARAMS: copy the flat parameter vectors into LDS
-// first (one launch per minibatch); otherwise they are already resident there (persistent kernel).
-// STAGED: the block's raw feature rows and per-row scalars were prefetched into the LDS staging
-// area `stg` (layout UpdStage) instead of being gathered from global memory here.
+// LDS staging area of the persistent kernel: the block's raw feature rows and per-row scalars of the
+// NEXT minibatch (prefetched), plus a copy of its statistics-ring slot.
 struct UpdStage {
   static constexpr int x = 0;                                   // [ROWS][XS] raw observations (0 where unused)
   static constexpr int oldlp = ROWS * (MAXD + 1);               // [ROWS]
@@ -866,17 +863,16 @@ struct UpdStage {
   static constexpr int ring = nxt + ROWS;                       // [UPD_RS_] copy of the minibatch's statistics-ring slot
   static constexpr int total = ring + 2 * MAXD + 8;
 };
-template <bool LOAD_PARAMS, bool STAGED = false>
+// One minibatch of block `vblk` (64 rows), one launch per minibatch (`ia_ppo_minibatch*`, `ia_ppo_epoch`:
+// hidden = 32 without the persistent kernel, i.e. data-parallel runs): forward, losses, backward;
+// gradient partials -> `slab`, loss-statistic partials -> `statpart[0..4]`. LOAD_PARAMS: copy the flat
+// parameter vectors into LDS first.
+template <bool LOAD_PARAMS>
 __device__ __forceinline__ void mfma32_minibatch(
     const ia_policy_desc& d, const float* __restrict__ P, const float* __restrict__ Pt, const float* __restrict__ nm,
     const float* __restrict__ nv, const float adv_mean, const float adv_std, const MbRows rows, const int vblk,
     const int normalize_adv, const float clip, const float ent_coef, const float vf_coef, float* __restrict__ slab,
-    float* __restrict__ statpart, float* __restrict__ lds_in, long long* __restrict__ tstamp,
-    const float* __restrict__ stg = nullptr, const int opaque_zero = 0) {
-  // `opaque_zero` is 0 at run time but unknown to the compiler (the persistent kernel re-makes it
-  // every step): thread ids and LDS addresses derived from it are not loop-invariant, so nothing
-  // of this body is hoisted out of the step loop and kept alive across it.
-  float* __restrict__ lds = lds_in + opaque_zero;
+    float* __restrict__ statpart, float* __restrict__ lds, long long* __restrict__ tstamp) {
   const float* __restrict__ obs = rows.obs;
   const float* __restrict__ actions = rows.actions;
   const float* __restrict__ old_logp = rows.old_logp;
@@ -887,7 +883,7 @@ __device__ __forceinline__ void mfma32_minibatch(
   constexpr int H = 32;
   using L = GLds<32>;
 #define IA_TS(slot) do { if (tstamp && vblk == 0 && threadIdx.x == 0) tstamp[slot] = clock64(); } while (0)
-  const int tid = threadIdx.x + opaque_zero, lane = tid & 63;
+  const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int tw = wv >> 2, q = wv & 3;
   const int li = lane & 15, lk = lane >> 4;
@@ -910,36 +906,25 @@ __device__ __forceinline__ void mfma32_minibatch(
     const int e = tid + it * 512;
     const int r = e / L::XS, k = e - r * L::XS;
     const bool ok = e < ROWS * L::XS && k < D && i0 + r < batch;
-    if (STAGED) xv[it] = ok ? stg[UpdStage::x + e] : 0.f;  // (unused slots hold clamped-address data)
-    else xv[it] = ok ? obs[mb_row(idx, i0 + r, T, n_envs) * D + k] : 0.f;
-    if (STAGED) {  // nm / nv always point at a full ring slot here: unconditional loads, masked afterwards
-      // (a guarded load costs a branch and a wait each, which serialises the nine of them)
-      // (arithmetic masking, not a select: a select lets the compiler sink the loads back under the branch)
-      const int kc = min(k, MAXD - 1);
-      const float mv = nm[kc], vv = nv[kc];
-      const float msk = (ok && d.has_norm) ? 1.f : 0.f;
-      xm[it] = mv * msk;
-      xs_[it] = vv * msk + (1.f - msk) * (1.f - d.norm_eps);
-    } else {
-      xm[it] = (ok && d.has_norm) ? nm[k] : 0.f;
-      xs_[it] = (ok && d.has_norm) ? nv[k] : 1.f - d.norm_eps;
-    }
+    xv[it] = ok ? obs[mb_row(idx, i0 + r, T, n_envs) * D + k] : 0.f;
+    xm[it] = (ok && d.has_norm) ? nm[k] : 0.f;
+    xs_[it] = (ok && d.has_norm) ? nv[k] : 1.f - d.norm_eps;
   }
   // per-row scalars of the loss phase (wave 0: policy terms, wave 4: value term)
   const int i = i0 + lane;
   const bool valid = i < batch;
-  const long long src = !valid ? 0 : (STAGED ? (long long)__float_as_int(stg[UpdStage::src + lane]) : mb_row(idx, i, T, n_envs));
+  const long long src = valid ? mb_row(idx, i, T, n_envs) : 0;
   float r_oldlp = 0.f, r_adv = 0.f, r_ret = 0.f, r_act[MAXA];
 #pragma unroll
   for (int a = 0; a < MAXA; ++a) r_act[a] = 0.f;
   if (wv == 0) {
-    r_oldlp = STAGED ? stg[UpdStage::oldlp + lane] : old_logp[src];
-    r_adv = STAGED ? stg[UpdStage::adv + lane] : adv[src];
+    r_oldlp = old_logp[src];
+    r_adv = adv[src];
 #pragma unroll
     for (int a = 0; a < MAXA; ++a)
       if (a < aw) r_act[a] = actions[src * aw + a];  // consumed in phase 4: the latency hides behind phases 1-3
   }
-  if (wv == 4) r_ret = STAGED ? stg[UpdStage::ret + lane] : ret[src];
+  if (wv == 4) r_ret = ret[src];
 
   IA_TS(9);
   // ---- parameters: ONE cooperative, coalesced 16-byte copy of both flat vectors (torch layout P and
@@ -1974,17 +1959,6 @@ __global__ __launch_bounds__(512) void policy_act_mfma32_kernel(
   }
 }
 
-// Instance for the persistent kernel (parameters resident in LDS, rows staged in LDS). Inlined with
-// the opaque zero below; an out-of-line call measured 4 us per step slower (callee-saved spills).
-__device__ __forceinline__ void mfma32_minibatch_resident(
-    const ia_policy_desc& d, const float* __restrict__ nm, const float* __restrict__ nv, const float adv_mean,
-    const float adv_std, const MbRows& rows, const int vblk, const int normalize_adv, const float clip,
-    const float ent_coef, const float vf_coef, float* __restrict__ slab, float* __restrict__ statpart,
-    float* __restrict__ lds, const float* __restrict__ stg, const int opaque_zero, long long* __restrict__ tstamp) {
-  mfma32_minibatch<false, true>(d, nullptr, nullptr, nm, nv, adv_mean, adv_std, rows, vblk, normalize_adv, clip,
-                                ent_coef, vf_coef, slab, statpart, lds, tstamp, stg + opaque_zero, opaque_zero);
-}
-
 constexpr int UPD_RING = 4;
 constexpr int UPD_MAX_STEPS = 2048;                // optimiser steps per launch (Adam scalar tables in ws)
 constexpr int UPD_NPT = 8;                        // parameters per thread (<= 4096 parameters)
@@ -2145,7 +2119,6 @@ __global__ __launch_bounds__(512) void ppo_update_persistent_kernel(
   unsigned short* dstT = reinterpret_cast<unsigned short*>(stg + UpdStage::total);  // [P4] index of parameter i in the transposed copy
   float* red = lds + L::misc + ROWS * L::MS;  // 64 spare floats behind the misc tile
   const int lane = tid & 63;
-  const int aw = d.discrete ? 1 : d.act_dim;
   float rm[UPD_NPT], rv[UPD_NPT];
 #pragma unroll
   for (int k = 0; k < UPD_NPT; ++k) {
@@ -2256,6 +2229,8 @@ __global__ __launch_bounds__(512) void ppo_update_persistent_kernel(
       adv_std = slot[2 * MAXD + 1];
     }
     UPD_TS(0);
+    // Adam's scalars of this step: requested now (a global load), consumed after the grid barrier
+    const float step_size = w.tab[s], bc2_sqrt = w.tab[UPD_MAX_STEPS + s];
     if (s + 1 < n_steps) prefetch_resolve(s + 1);  // published by the block barriers inside the minibatch
     float* slab_base = w.slabs + (long long)(s & 1) * nblk * w.P4;
     float* stat_base = w.statpart + (s % UPD_SD) * nblk * 8;
@@ -2346,7 +2321,6 @@ __global__ __launch_bounds__(512) void ppo_update_persistent_kernel(
         write_loss_stats(s, total_norm, coef);
       }
     }
-    const float step_size = w.tab[s], bc2_sqrt = w.tab[UPD_MAX_STEPS + s];
 #pragma unroll
     for (int k = 0; k < UPD_NPT; ++k) {
       const int i = tid + k * 512;
