@@ -164,13 +164,17 @@ class AdversarialTrainer(abc.ABC):
         # (results unchanged: host RNG draws keep their program order; the policy-feature-norm
         # side effect of `evaluate_actions` is replayed on the PPO stream after
         # the PPO update, exactly where the reference executes it).
+        # Data-parallel runs keep it when the PPO update needs no per-step collective (global-minibatch
+        # update): then only one stream at a time has collectives in flight, in the same order on all ranks.
+        dp_many = self._dp is not None and self._dp.world > 1
         self._overlap = (not self._needs_logp and isinstance(self.gen_algo, ppo.PPO)
-                         and not (self._dp is not None and self._dp.world > 1))
+                         and (not dp_many or self.gen_algo._dp_global()))
         self._disc_stream = th.cuda.Stream(device=self._device) if self._overlap else None
         self._in_overlap = False
         self._overlap_k = 0
         self._quirk_ready = None
         self._quirk_seq = None
+        self._quirk_seq_merged = None
         # GAIL only: let round r's discriminator updates run behind round r+1's environment stepping
         # (`_train_pipelined`); off -> every round is completed before the next one starts
         self.pipeline_rounds = True
@@ -525,7 +529,16 @@ class AdversarialTrainer(abc.ABC):
                 L.call("ia_running_norm_partial", L.ptr(self._pol_obs), pol.obs_dim, 2 * mb, pol.obs_dim,
                        L.ptr(self._quirk_seq[k]), L.stream())
                 k += 1
-        self._quirk_pending.append(("seq", n_items, need, 2 * mb, pol.obs_dim))
+        groups, seq, stride = 1, self._quirk_seq, need
+        if self._dp is not None and self._dp.world > 1:
+            # every rank contributes its own batches: ONE all-gather of the round's moments, laid out
+            # [update][rank][moments] so that each update merges world x 2*mb rows like a single process
+            groups = self._dp.world
+            allm = self._dp.all_gather_flat(self._quirk_seq.reshape(-1))
+            seq = allm.view(groups, n_items, need).permute(1, 0, 2).contiguous()
+            stride = groups * need
+        self._quirk_seq_merged = seq
+        self._quirk_pending.append(("seq", n_items, stride, groups, 2 * mb, pol.obs_dim))
         return True
 
     def _replay_policy_norm_updates(self) -> None:
@@ -533,9 +546,10 @@ class AdversarialTrainer(abc.ABC):
         pol = self.policy
         for item in self._quirk_pending:
             if isinstance(item, tuple) and item[0] == "seq":  # all updates of a round, one launch, in order
-                _, n_items, stride, rows, ld = item
+                _, n_items, stride, groups, rows, ld = item
                 rn = pol.features_extractor.normalize
-                L.call("ia_running_norm_merge_seq", L.ptr(self._quirk_seq), n_items, stride, rows, pol.obs_dim, ld,
+                L.call("ia_running_norm_merge_seq", L.ptr(self._quirk_seq_merged), n_items, stride, groups, rows,
+                       pol.obs_dim, ld,
                        L.ptr(rn.running_mean), L.ptr(rn.running_var), L.ptr(rn.count), L.stream())
                 continue
             if isinstance(item, tuple):  # (slab moments of the batch, rows, moment column count)

@@ -196,9 +196,9 @@ __global__ __launch_bounds__(64) void rn_merge_kernel(const float* __restrict__ 
 // apart) applied in order by one launch: the replay of the deferred policy feature-norm updates of a
 // round. Same arithmetic per update as rn_merge_kernel; the count seen by update k is cnt0 + k*R.
 __global__ __launch_bounds__(64) void rn_merge_seq_kernel(const float* __restrict__ ws_seq, int n_seq,
-                                                          long long seq_stride, int nblocks, int R, int D, int ws_ld,
-                                                          float* __restrict__ mean, float* __restrict__ var,
-                                                          const int32_t* __restrict__ count) {
+                                                          long long seq_stride, int nblocks, int bpg, int rpg, int R,
+                                                          int D, int ws_ld, float* __restrict__ mean,
+                                                          float* __restrict__ var, const int32_t* __restrict__ count) {
   const int c = blockIdx.x, lane = threadIdx.x;
   int cnt = *count;
   float mc = mean[c], vc = var[c];
@@ -206,7 +206,7 @@ __global__ __launch_bounds__(64) void rn_merge_seq_kernel(const float* __restric
     const float* ws = ws_seq + (long long)k * seq_stride;
     float n_acc = 0.f, m_acc = 0.f, M2 = 0.f;
     for (int b = lane; b < nblocks; b += 64) {
-      const float nb = (float)min(RN_ROWS_PER_BLOCK, R - b * RN_ROWS_PER_BLOCK);
+      const float nb = (float)min(RN_ROWS_PER_BLOCK, rpg - (b % bpg) * RN_ROWS_PER_BLOCK);
       chan_combine(n_acc, m_acc, M2, nb, ws[((long long)b * 2 + 0) * ws_ld + c], ws[((long long)b * 2 + 1) * ws_ld + c]);
     }
     for (int o = 32; o > 0; o >>= 1) {
@@ -712,12 +712,13 @@ int ia_running_norm_merge(const float* ws_all, int groups, int rows_per_group, i
   return IA_OK;
 }
 
-int ia_running_norm_merge_seq(const float* ws_seq, int n_seq, int64_t seq_stride, int rows, int D, int ws_ld,
-                              float* mean, float* var, int32_t* count, void* stream) {
-  if (n_seq <= 0 || rows <= 0 || D <= 0 || ws_ld < D) return IA_ERR_ARG;
-  const int nb = cdiv(rows, RN_ROWS_PER_BLOCK);
+int ia_running_norm_merge_seq(const float* ws_seq, int n_seq, int64_t seq_stride, int groups, int rows_per_group,
+                              int D, int ws_ld, float* mean, float* var, int32_t* count, void* stream) {
+  if (n_seq <= 0 || groups <= 0 || rows_per_group <= 0 || D <= 0 || ws_ld < D) return IA_ERR_ARG;
+  const int bpg = cdiv(rows_per_group, RN_ROWS_PER_BLOCK);
+  const int rows = groups * rows_per_group;
   hipLaunchKernelGGL(rn_merge_seq_kernel, dim3(D), dim3(64), 0, (hipStream_t)stream, ws_seq, n_seq,
-                     (long long)seq_stride, nb, rows, D, ws_ld, mean, var, count);
+                     (long long)seq_stride, groups * bpg, bpg, rows_per_group, rows, D, ws_ld, mean, var, count);
   IA_CHECK_LAUNCH();
   hipLaunchKernelGGL(rn_count_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, count, n_seq * rows);
   IA_CHECK_LAUNCH();

@@ -401,7 +401,11 @@ template <int NT>
 __device__ void prepare_stats_t(const ia_policy_desc& d, const float* __restrict__ obs, const float* __restrict__ adv,
                               const int64_t* __restrict__ idx, int batch, int T, int n_envs, int update_norm,
                               float* __restrict__ nm, float* __restrict__ nv, int32_t* __restrict__ ncount,
-                              float* __restrict__ advstat, float* lds, int* __restrict__ rowoff = nullptr) {
+                              float* __restrict__ advstat, float* lds, int* __restrict__ rowoff = nullptr,
+                              float* __restrict__ partial = nullptr) {
+  // `partial` (slices of a large minibatch, see the persistent kernel): instead of updating the running
+  // statistics, leave this slice's raw moments -- column means [MAXD], column sums of squared deviations
+  // [MAXD], advantage mean, advantage sum of squared deviations, row count -- for a later ordered merge.
   const int tid = threadIdx.x;
   float* stage = lds;
   float* red = lds + PREP_STAGE_FLOATS;          // [16][65]
@@ -431,8 +435,14 @@ __device__ void prepare_stats_t(const ia_policy_desc& d, const float* __restrict
   }
   const float qq = block_sum<NT>(q, misc);
   if (tid == 0) {
-    advstat[0] = mean;
-    advstat[1] = batch > 1 ? sqrtf(qq / (float)(batch - 1)) : 0.f;
+    if (partial != nullptr) {
+      partial[2 * MAXD + 0] = mean;
+      partial[2 * MAXD + 1] = qq;
+      partial[2 * MAXD + 2] = (float)batch;
+    } else {
+      advstat[0] = mean;
+      advstat[1] = batch > 1 ? sqrtf(qq / (float)(batch - 1)) : 0.f;
+    }
   }
   if (!(d.has_norm && update_norm)) return;
   const int D = d.obs_dim, DP = idx ? (D | 1) : D;  // column reads are conflict-free for any row stride
@@ -496,6 +506,13 @@ __device__ void prepare_stats_t(const ia_policy_desc& d, const float* __restrict
       m_acc = m_acc + dlt * nb / tot;
       n_acc = tot;
     }
+  }
+  if (partial != nullptr) {
+    if (rg == 0 && col < D) {
+      partial[col] = m_acc;
+      partial[MAXD + col] = M2;
+    }
+    return;
   }
   const int cnt = *ncount;
   __syncthreads();
@@ -1963,8 +1980,15 @@ constexpr int UPD_RING = 4;
 constexpr int UPD_MAX_STEPS = 2048;                // optimiser steps per launch (Adam scalar tables in ws)
 constexpr int UPD_NPT = 8;                        // parameters per thread (<= 4096 parameters)
 constexpr int UPD_RS = 2 * MAXD + 8;              // ring slot: mean[MAXD], var[MAXD], adv mean, adv std
-constexpr int UPD_CTRL = 16;                      // control words: 0 arrivals, 1 steps published, 8 error (sticky)
+constexpr int UPD_CTRL = 64;                      // control words: 0 arrivals, 1 steps published, 2 second-level
+                                                  // arrivals, 8 error (sticky), 16.. steps sliced per slicer
+constexpr int UPD_SLICE = 512;                    // rows per statistics slice (minibatches > 1024 rows)
+constexpr int UPD_SLICES_MAX = 32;                // => minibatches up to 16 384 rows
+constexpr int UPD_PRS = 2 * MAXD + 4;             // slice partial: mean[MAXD], M2[MAXD], adv mean, adv M2, rows
 constexpr int UPD_SD = 8;                         // depth of the loss-statistic partial ring (> UPD_RING + 2)
+constexpr int UPD_GROUP = 16;                     // slabs summed per first-level group
+constexpr int UPD_GROUPS_MAX = 16;                // => up to 256 gradient blocks (16 384-row minibatches)
+constexpr int UPD_NBLK_MAX = 192;                 // co-residency: nblk + 1 workgroups on 256 CUs
 struct UpdSched {
   int n_steps, first, n_mb, batch_size;
   long long total;
@@ -1973,6 +1997,8 @@ struct UpdWs {
   unsigned* ctrl;
   float *tab;   // [2][UPD_MAX_STEPS]: Adam step size lr/(1-b1^t) and sqrt(1-b2^t) per step (host doubles)
   float *ring, *normcoef, *statpart, *slabs;   // normcoef: [UPD_SD][2] gradient norm, clip coefficient
+  float *partials;                             // [2][UPD_GROUPS_MAX][P4]: first reduction level when nblk > UPD_GROUP
+  float *pring;                                // [UPD_RING][UPD_SLICES_MAX][UPD_PRS]: statistics slice partials
   int P4;
 };
 __host__ __device__ inline UpdWs upd_ws(float* ws, int nblk, int P) {
@@ -1984,6 +2010,8 @@ __host__ __device__ inline UpdWs upd_ws(float* ws, int nblk, int P) {
   w.normcoef = w.ring + UPD_RING * UPD_RS;
   w.statpart = w.normcoef + UPD_SD * 2;
   w.slabs = w.statpart + UPD_SD * nblk * 8;
+  w.partials = w.slabs + 2 * (long long)nblk * w.P4;
+  w.pring = w.partials + 2 * (long long)UPD_GROUPS_MAX * w.P4;
   return w;
 }
 
@@ -2006,7 +2034,7 @@ __global__ __launch_bounds__(512) void ppo_update_persistent_kernel(
     const float* __restrict__ obs, const float* __restrict__ actions, const float* __restrict__ old_logp,
     const float* __restrict__ adv, const float* __restrict__ ret, const int64_t* __restrict__ perm, int T, int n_envs,
     int normalize_adv, float clip, float ent_coef, float vf_coef, float max_norm, float beta1, float beta2, float eps,
-    float* __restrict__ ws, int nblk, float* __restrict__ stats, UpdSched sch, int xcd_pack,
+    float* __restrict__ ws, int nblk, int n_slices, float* __restrict__ stats, UpdSched sch, int xcd_pack,
     long long* __restrict__ tstamp /* debug: [0..3] += 100 MHz ticks in {stat wait, minibatch, barrier, update} */) {
   constexpr int H = 32;
   using L = CLds;
@@ -2025,6 +2053,8 @@ __global__ __launch_bounds__(512) void ppo_update_persistent_kernel(
   const UpdWs w = upd_ws(ws, nblk, o.total);
   unsigned* arrivals = w.ctrl + 0;
   unsigned* published = w.ctrl + 1;
+  unsigned* arrivals2 = w.ctrl + 2;   // second-level barrier (group leaders only)
+  unsigned* sliced = w.ctrl + 16;     // [n_slices] steps whose partial moments slicer j has written
   unsigned* err = w.ctrl + 8;
 
   // schedule scalars in registers; the per-step tables are read straight from the kernel arguments
@@ -2088,8 +2118,54 @@ __global__ __launch_bounds__(512) void ppo_update_persistent_kernel(
       }
       const MbRows r = rows_of(s);
       float* slot = w.ring + (s % UPD_RING) * UPD_RS;
-      prepare_stats_t<512>(d, r.obs, r.adv, r.idx, r.batch, T, n_envs, update_norm, nm, nv, ncount, slot + 2 * MAXD, lds,
-                           sch_total < (1ll << 31) ? reinterpret_cast<int*>(lds + PREP_LDS_FLOATS) : nullptr);
+      if (n_slices == 0) {
+        prepare_stats_t<512>(d, r.obs, r.adv, r.idx, r.batch, T, n_envs, update_norm, nm, nv, ncount, slot + 2 * MAXD,
+                             lds, sch_total < (1ll << 31) ? reinterpret_cast<int*>(lds + PREP_LDS_FLOATS) : nullptr);
+      } else {
+        // large minibatch: the slicer blocks left per-slice moments; merge them in slice order (Chan),
+        // then the same running update / advantage statistics as the one-block form
+        const int ns = (r.batch + UPD_SLICE - 1) / UPD_SLICE;
+        if (tid == 0) {
+          int ok = 1;
+          for (int j = 0; j < ns && ok; ++j) ok = spin_until(sliced + j, (unsigned)(s + 1), err);
+          s_ok = ok;
+          __threadfence();
+        }
+        __syncthreads();
+        if (!s_ok) return;
+        const float* pr = w.pring + (long long)(s % UPD_RING) * UPD_SLICES_MAX * UPD_PRS;
+        const bool norm_on = d.has_norm && update_norm;
+        if (tid <= D) {
+          const int c = tid;  // columns 0..D-1: features; D: advantages
+          float n_acc = 0.f, m_acc = 0.f, M2 = 0.f;
+          for (int j = 0; j < ns; ++j) {
+            const float* pj = pr + j * UPD_PRS;
+            const float nb = pj[2 * MAXD + 2];
+            const float mb = c < D ? pj[c] : pj[2 * MAXD + 0];
+            const float qb = c < D ? pj[MAXD + c] : pj[2 * MAXD + 1];
+            const float tot = n_acc + nb, dlt = mb - m_acc;
+            M2 = M2 + qb + dlt * dlt * n_acc * nb / tot;
+            m_acc = m_acc + dlt * nb / tot;
+            n_acc = tot;
+          }
+          if (c == D) {
+            slot[2 * MAXD + 0] = m_acc;
+            slot[2 * MAXD + 1] = r.batch > 1 ? sqrtf(M2 / (float)(r.batch - 1)) : 0.f;
+          } else if (norm_on) {
+            const int cnt = *ncount;
+            const float bmean = m_acc, bvar = M2 / (float)r.batch;
+            const float fcount = (float)cnt, fn = (float)r.batch, tot = (float)(cnt + r.batch);
+            const float delta = bmean - nm[c];
+            nm[c] = nm[c] + delta * fn / tot;
+            float rvv = nv[c] * fcount;
+            rvv = rvv + bvar * fn;
+            rvv = rvv + delta * delta * fcount * fn / tot;
+            nv[c] = rvv / tot;
+          }
+        }
+        __syncthreads();
+        if (tid == 0 && norm_on) *ncount = *ncount + r.batch;
+      }
       __syncthreads();
       if (d.has_norm && tid < D) {
         slot[tid] = nm[tid];
@@ -2110,7 +2186,31 @@ __global__ __launch_bounds__(512) void ppo_update_persistent_kernel(
     drain(n_steps - 1);  // the last step's statistics are written by gradient block 0 itself
     return;
   }
-  if (vb > nblk) return;
+  if (vb > nblk) {  // ---------------- statistics slicers (large minibatches only)
+    const int j = vb - nblk - 1;
+    if (j >= n_slices) return;
+    for (int s = 0; s < n_steps; ++s) {
+      const MbRows r = rows_of(s);
+      const int r0 = j * UPD_SLICE;
+      const int nr = min(UPD_SLICE, r.batch - r0);
+      if (s >= UPD_RING) {  // the partial slot is free once the merger has published step s - RING
+        if (tid == 0) s_ok = spin_until(published, (unsigned)(s - UPD_RING + 1), err);
+        __syncthreads();
+        if (!s_ok) return;
+      }
+      if (nr > 0) {
+        float* pj = w.pring + ((long long)(s % UPD_RING) * UPD_SLICES_MAX + j) * UPD_PRS;
+        prepare_stats_t<512>(d, r.obs, r.adv, r.idx + r0, nr, T, n_envs, update_norm, nullptr, nullptr, nullptr, nullptr,
+                             lds, reinterpret_cast<int*>(lds + PREP_LDS_FLOATS), pj);
+      }
+      __syncthreads();
+      if (tid == 0) {
+        __threadfence();
+        __hip_atomic_store(sliced + j, (unsigned)(s + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+    return;
+  }
 
   // ---------------- gradient blocks
   float* sP = lds + L::total;
@@ -2269,16 +2369,20 @@ __global__ __launch_bounds__(512) void ppo_update_persistent_kernel(
     }
     UPD_TS(2);
 
-    // reduce the slabs (fixed order b = 0..nblk-1 per parameter), global norm, clip, Adam --
-    // identical in every block. All loads of a group of 8 slabs are in flight together.
+    // reduce the slabs in fixed order, global norm, clip, Adam -- identical in every block. Up to
+    // UPD_GROUP blocks: every block sums all slabs itself. More (large global minibatches, e.g. the
+    // data-parallel update on the all-gathered rollout): two levels -- block g < ngrp sums the slabs of
+    // group g into a partial, one more grid barrier among the leaders' arrivals, then every block sums
+    // the ngrp partials -- so a block never reads more than 16 vectors (128 slabs each would be 230 MB
+    // of reads per step over all blocks).
     float g[UPD_NPT];
     float sq = 0.f;
+    auto sum_vectors = [&](const float* __restrict__ base, int nsrc) {
 #pragma unroll
-    for (int k = 0; k < UPD_NPT; ++k) g[k] = 0.f;
-    {
-      constexpr int KH = UPD_NPT / 2;  // 4 parameters x 8 slabs = 32 loads in flight per thread
+      for (int k = 0; k < UPD_NPT; ++k) g[k] = 0.f;
+      constexpr int KH = UPD_NPT / 2;  // 4 parameters x 8 vectors = 32 loads in flight per thread
       int b = 0;
-      for (; b + 8 <= nblk; b += 8) {
+      for (; b + 8 <= nsrc; b += 8) {
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
           float t[KH][8];
@@ -2288,7 +2392,7 @@ __global__ __launch_bounds__(512) void ppo_update_persistent_kernel(
             // wait each, which serialises the whole batch); lanes past the end are discarded below
             const int i = min(tid + (h * KH + k) * 512, o.total - 1);
 #pragma unroll
-            for (int u = 0; u < 8; ++u) t[k][u] = slab_base[(long long)(b + u) * w.P4 + i];
+            for (int u = 0; u < 8; ++u) t[k][u] = base[(long long)(b + u) * w.P4 + i];
           }
 #pragma unroll
           for (int k = 0; k < KH; ++k)
@@ -2296,10 +2400,37 @@ __global__ __launch_bounds__(512) void ppo_update_persistent_kernel(
             for (int u = 0; u < 8; ++u) g[h * KH + k] += t[k][u];
         }
       }
-      for (; b < nblk; ++b) {
+      for (; b < nsrc; ++b) {
 #pragma unroll
-        for (int k = 0; k < UPD_NPT; ++k) g[k] += slab_base[(long long)b * w.P4 + min(tid + k * 512, o.total - 1)];
+        for (int k = 0; k < UPD_NPT; ++k) g[k] += base[(long long)b * w.P4 + min(tid + k * 512, o.total - 1)];
       }
+    };
+    if (nblk <= UPD_GROUP) {
+      sum_vectors(slab_base, nblk);
+    } else {
+      const int ngrp = (nblk + UPD_GROUP - 1) / UPD_GROUP;
+      float* part_base = w.partials + (long long)(s & 1) * UPD_GROUPS_MAX * w.P4;
+      if (vb < ngrp) {
+        const int first = vb * UPD_GROUP;
+        sum_vectors(slab_base + (long long)first * w.P4, min(UPD_GROUP, nblk - first));
+#pragma unroll
+        for (int k = 0; k < UPD_NPT; ++k) {
+          const int i = tid + k * 512;
+          if (i < o.total) part_base[(long long)vb * w.P4 + i] = g[k];
+        }
+      }
+      __syncthreads();
+      if (tid == 0) {
+        if (vb < ngrp) {
+          __threadfence();
+          __hip_atomic_fetch_add(arrivals2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        s_ok = spin_until(arrivals2, (unsigned)(s + 1) * ngrp, err);
+        __threadfence();
+      }
+      __syncthreads();
+      if (!s_ok) return;
+      sum_vectors(part_base, ngrp);
     }
 #pragma unroll
     for (int k = 0; k < UPD_NPT; ++k) {
@@ -2736,10 +2867,12 @@ int64_t ia_ppo_update_ws_floats(const ia_policy_desc* d, int batch_size) {
   if (!pol_ok(d) || batch_size <= 0) return IA_ERR_ARG;
   const int P = pol_offsets(d->obs_dim, d->act_dim, d->hidden, d->discrete).total;
   const int nblk = cdiv(batch_size, ROWS);
-  if (d->hidden != 32 || P > UPD_NPT * 512 || nblk > 30 || g_ppo_valu) return 0;
+  if (d->hidden != 32 || P > UPD_NPT * 512 || nblk > UPD_NBLK_MAX || cdiv(batch_size, UPD_SLICE) > UPD_SLICES_MAX ||
+      g_ppo_valu)
+    return 0;
   const int P4 = (P + 3) & ~3;
   return UPD_CTRL + 2 * UPD_MAX_STEPS + UPD_RING * UPD_RS + UPD_SD * 2 + UPD_SD * (int64_t)nblk * 8 +
-         2 * (int64_t)nblk * P4;
+         2 * (int64_t)nblk * P4 + 2 * (int64_t)UPD_GROUPS_MAX * P4 + (int64_t)UPD_RING * UPD_SLICES_MAX * UPD_PRS;
 }
 
 bool g_upd_xcd_pack = false;
@@ -2804,11 +2937,17 @@ int ia_ppo_update(const ia_policy_desc* d, float* params, float* params_t, float
     if (ec != hipSuccess) return (int)ec;
     hipError_t e = hipMemsetAsync(ws, 0, 8 * sizeof(unsigned), st);  // arrivals / published (error word stays)
     if (e != hipSuccess) return (int)e;
-    const int grid = (nblk + 1) * (g_upd_xcd_pack ? 8 : 1);
+    e = hipMemsetAsync(ws + 16, 0, (UPD_CTRL - 16) * sizeof(unsigned), st);  // per-slicer progress
+    if (e != hipSuccess) return (int)e;
+    // packing onto one XCD only works while all workgroups fit its 32 CUs (each takes a whole CU's LDS)
+    // minibatches beyond 1024 rows: their statistics are cut into UPD_SLICE-row slices, one extra block each
+    const int n_slices = (batch_size > 1024 && total < (1ll << 31)) ? cdiv(batch_size, UPD_SLICE) : 0;
+    const bool pack = g_upd_xcd_pack && nblk + 1 + n_slices <= 32;
+    const int grid = (nblk + 1 + n_slices) * (pack ? 8 : 1);
     hipLaunchKernelGGL(ppo_update_persistent_kernel, dim3(grid), dim3(512), bytes, st, *d, params, params_t, exp_avg,
                        exp_avg_sq, norm_mean, norm_var, norm_count, update_norm, obs, actions, old_logp, advantages,
                        returns, perm, T, n_envs, normalize_adv, clip_range, ent_coef, vf_coef, max_grad_norm,
-                       (float)beta1, (float)beta2, adam_eps, ws, nblk, stats, sch, g_upd_xcd_pack ? 1 : 0, g_tstamp);
+                       (float)beta1, (float)beta2, adam_eps, ws, nblk, n_slices, stats, sch, pack ? 1 : 0, g_tstamp);
     IA_CHECK_LAUNCH();
   }
   return IA_OK;

@@ -54,6 +54,18 @@ class DataParallel:
                 else:
                     dist.broadcast(t, src=src, group=self.group)
 
+    def shared_seed(self) -> int:
+        """One random 31-bit integer agreed on by every rank (drawn by rank 0)."""
+        t = th.randint(0, 2 ** 31 - 1, (1,), dtype=th.int64)
+        if self.world > 1:
+            dist.broadcast(t, src=0, group=self.group) if self._stage else self._bcast_dev(t)
+        return int(t.item())
+
+    def _bcast_dev(self, t: th.Tensor) -> None:
+        d = t.cuda()
+        dist.broadcast(d, src=0, group=self.group)
+        t.copy_(d.cpu())
+
     def all_gather_flat(self, local: th.Tensor) -> th.Tensor:
         """Concatenation of every rank's (equally sized) 1-D buffer, in rank order."""
         if self.world == 1:

@@ -136,6 +136,40 @@ class _PermutationPredraw:
         return True
 
 
+class _SharedPermutations:
+    """Minibatch permutations of the data-parallel PPO update over the all-gathered rollout: every rank
+    must use the SAME permutations, so they come from generators seeded identically on all ranks
+    (`[shared seed, update index, epoch]`), one per epoch, drawn concurrently by helper threads through
+    `ia_host_mt19937_permutations` (no GIL) while the rollout runs."""
+
+    def __init__(self, seed: int, n_epochs: int, size: int):
+        self.seed, self.n_epochs, self.size = int(seed), n_epochs, size
+        self.update = 0
+        self._threads = []
+
+    def start(self, out: np.ndarray) -> None:
+        assert out.dtype == np.int64 and out.flags.c_contiguous and out.shape == (self.n_epochs, self.size)
+        lib = L.load()
+        self._threads = []
+        for e in range(self.n_epochs):
+            st = np.random.RandomState([self.seed, self.update, e]).get_state()
+            key, pos = np.ascontiguousarray(st[1], dtype=np.uint32).copy(), C.c_int(int(st[2]))
+
+            def work(key=key, pos=pos, e=e):
+                rc = lib.ia_host_mt19937_permutations(key.ctypes.data, C.byref(pos), self.size, 1, out[e].ctypes.data)
+                assert rc == 0
+
+            t = threading.Thread(target=work, daemon=True)
+            t.start()
+            self._threads.append(t)
+        self.update += 1
+
+    def finish(self) -> None:
+        for t in self._threads:
+            t.join()
+        self._threads = []
+
+
 class _TrainRecord:
     """Everything `finalize_train` reads about ONE `PPO.train`, kept apart from the live buffers so it can
     be read back after the next rollout -- or even the next PPO update -- has been enqueued: loss
@@ -301,10 +335,12 @@ class PPO(OnPolicyAlgorithm):
         self.rollout_profile = None
         self._dp_obs = th.zeros(min(self.batch_size, total), p.obs_dim, device=self.device)
         self._dp_ws_pre = None
+        self._dpg = None   # lazily built state of the global-minibatch data-parallel update
         self._records = None
         self._rec_i = 0
         self._fin_stream = None
         self.dp_batch_moments = True  # False: exchange the feature-norm moments once per minibatch (tests)
+        self.dp_global_minibatch = True  # False: per-minibatch gradient all-reduce (`_train_data_parallel`)
 
     @property
     def logger(self):
@@ -433,7 +469,10 @@ class PPO(OnPolicyAlgorithm):
                 fused_net = owner
         T, n = rb.buffer_size, rb.n_envs
         assert n_rollout_steps == T
-        self._predraw.start(self._perm_np)  # consumed by the `train()` that follows
+        if self._dp_global():
+            self._dpg["perms"].start(self._dpg["perm_np"])   # shared across ranks; consumed by the next train()
+        else:
+            self._predraw.start(self._perm_np)  # consumed by the `train()` that follows
         stream = th.cuda.current_stream()
         rb.h_obs[0].copy_(th.as_tensor(np.asarray(self._last_obs)).reshape(n, -1))
         rb.obs[0].copy_(rb.h_obs[0], non_blocking=True)
@@ -533,6 +572,67 @@ class PPO(OnPolicyAlgorithm):
         callback.on_rollout_end()
         return True
 
+    def _dp_global(self) -> bool:
+        """Data-parallel PPO on the all-gathered rollout (see `_train_dp_global`); builds its state on
+        first use. False: single process, or a shape the persistent kernel does not cover (then the
+        per-minibatch all-reduce path `_train_data_parallel` runs)."""
+        dp = self.dp
+        if dp is None or dp.world <= 1 or not self.dp_global_minibatch:
+            return False
+        if self._dpg is None:
+            pol, rb = self.policy, self.rollout_buffer
+            T, n, W = rb.buffer_size, rb.n_envs, dp.world
+            aw = 1 if pol.discrete else pol.act_dim
+            bg = min(W * self.batch_size, W * T * n)
+            n_ws = int(L.load().ia_ppo_update_ws_floats(C.byref(pol.desc), bg))
+            if n_ws <= 0:
+                self._dpg = False
+            else:
+                dev, cols = self.device, pol.obs_dim + aw + 3
+                perm_host = th.zeros(self.n_epochs, W * T * n, dtype=th.int64).pin_memory()
+                self._dpg = dict(
+                    W=W, aw=aw, cols=cols, batch=bg, ws=th.zeros(n_ws, device=dev),
+                    send=th.empty(T, n, cols, device=dev),
+                    obs=th.empty(T, W * n, pol.obs_dim, device=dev), acts=th.empty(T, W * n, aw, device=dev),
+                    logp=th.empty(T, W * n, device=dev), adv=th.empty(T, W * n, device=dev),
+                    ret=th.empty(T, W * n, device=dev), perm_host=perm_host, perm_np=perm_host.numpy(),
+                    perm_dev=th.zeros(self.n_epochs, W * T * n, dtype=th.int64, device=dev),
+                    perms=_SharedPermutations(dp.shared_seed(), self.n_epochs, W * T * n))
+        return bool(self._dpg)
+
+    def _train_dp_global(self, g, lr: float, clip_range: float, stats_dev: th.Tensor) -> None:
+        """Data-parallel PPO update with NO per-step collective: ONE all-gather of the round's rollout
+        shards (obs, actions, log-probs, advantages, returns; 1.8 MB per rank at config P), then every
+        rank runs the identical persistent update on the global tile `[T, world*n_envs]` -- minibatches
+        of world x batch_size rows, permutations shared by construction, deterministic kernels, hence
+        bit-identical replicas. The PPO update is a latency-bound chain of dependent optimiser steps
+        whose per-step time barely depends on the minibatch size (more 64-row workgroups, a two-level
+        slab reduction), so replicating it costs far less than 160 latency-bound all-reduces per round
+        would; the throughput-bound parts (rollout, discriminator) stay sharded."""
+        pol, rb, dp = self.policy, self.rollout_buffer, self.dp
+        T, n, W, D, aw = rb.buffer_size, rb.n_envs, g["W"], pol.obs_dim, g["aw"]
+        send = g["send"]
+        send[..., :D] = rb.obs[:T]
+        send[..., D:D + aw] = rb.acts
+        send[..., D + aw], send[..., D + aw + 1], send[..., D + aw + 2] = rb.logp, rb.adv, rb.ret
+        allr = dp.all_gather_flat(send.reshape(-1)).view(W, T, n, g["cols"]).permute(1, 0, 2, 3).reshape(T, W * n, -1)
+        g["obs"].copy_(allr[..., :D])
+        g["acts"].copy_(allr[..., D:D + aw])
+        g["logp"].copy_(allr[..., D + aw]); g["adv"].copy_(allr[..., D + aw + 1]); g["ret"].copy_(allr[..., D + aw + 2])
+        g["perms"].finish()
+        g["perm_dev"].copy_(g["perm_host"], non_blocking=True)
+        rn = pol.features_extractor.normalize
+        og = pol.optimizer.param_groups[0]
+        L.call("ia_ppo_update", C.byref(pol.desc), L.ptr(pol._flat), L.ptr(pol._flat_t),
+               L.ptr(rn.running_mean) if rn else None, L.ptr(rn.running_var) if rn else None,
+               L.ptr(rn.count) if rn else None, int(rn is not None), L.ptr(g["obs"]), L.ptr(g["acts"]), L.ptr(g["logp"]),
+               L.ptr(g["adv"]), L.ptr(g["ret"]), L.ptr(g["perm_dev"]), self.n_epochs, T, W * n, g["batch"],
+               int(self.normalize_advantage), float(clip_range), float(self.ent_coef), float(self.vf_coef),
+               float(self.max_grad_norm), L.ptr(pol.optimizer.exp_avg), L.ptr(pol.optimizer.exp_avg_sq),
+               float(lr), float(og["betas"][0]), float(og["betas"][1]), float(og["eps"]), pol.optimizer.step_count,
+               L.ptr(g["ws"]), L.ptr(stats_dev), L.stream())
+        pol.optimizer.step_count += self.n_epochs * self._n_mb
+
     def _train_data_parallel(self, perm: np.ndarray, lr: float, clip_range: float) -> None:
         """Minibatch loop with one RCCL all-reduce of the flat policy gradient per optimiser step
         (and a moment all-gather for the feature RunningNorm); replicas stay identical."""
@@ -601,11 +701,13 @@ class PPO(OnPolicyAlgorithm):
         pol.optimizer.param_groups[0]["lr"] = lr
         clip_range = self.clip_range(self._current_progress_remaining)
         T, n = rb.buffer_size, rb.n_envs
+        dpg = self._dpg if self._dp_global() else None
         perm = self._perm_np
-        if not self._predraw.finish(perm):
-            for e in range(self.n_epochs):  # one global-NumPy draw per epoch, as RolloutBuffer.get does
-                perm[e] = np.random.permutation(T * n)
-        self._perm_dev.copy_(self._perm_host, non_blocking=True)
+        if dpg is None:
+            if not self._predraw.finish(perm):
+                for e in range(self.n_epochs):  # one global-NumPy draw per epoch, as RolloutBuffer.get does
+                    perm[e] = np.random.permutation(T * n)
+            self._perm_dev.copy_(self._perm_host, non_blocking=True)
         rn = pol.features_extractor.normalize
         g = pol.optimizer.param_groups[0]
         rec = None
@@ -618,7 +720,9 @@ class PPO(OnPolicyAlgorithm):
             rec.val.copy_(rb.val)   # the tile is reused by the next rollout before the statistics are read
             rec.ret.copy_(rb.ret)
         stats_dev = rec.stats if rec is not None else self._stats_dev
-        if self.dp is not None and self.dp.world > 1:
+        if dpg is not None:
+            self._train_dp_global(dpg, lr, clip_range, stats_dev)
+        elif self.dp is not None and self.dp.world > 1:
             self._train_data_parallel(perm, lr, clip_range)
         single = not (self.dp is not None and self.dp.world > 1)
         if single and self._upd_ws is not None:
@@ -647,7 +751,7 @@ class PPO(OnPolicyAlgorithm):
             pol.optimizer.step_count += self._n_mb
         self._n_updates += self.n_epochs
         if rec is not None:
-            if self.dp is not None and self.dp.world > 1:   # that path wrote the shared statistics tile
+            if self.dp is not None and self.dp.world > 1 and dpg is None:   # that path wrote the shared statistics tile
                 rec.stats.copy_(self._stats_dev)
             if rec.log_std is not None:
                 rec.log_std.copy_(pol.log_std)

@@ -100,11 +100,11 @@ int ia_running_norm_update(const float* X, int ldx, int R, int D, float* mean, f
 int ia_running_norm_partial(const float* X, int ldx, int R, int D, float* ws, void* stream);
 int ia_running_norm_merge(const float* ws_all, int groups, int rows_per_group, int D, int ws_ld, float* mean,
                           float* var, int32_t* count, void* stream);
-/* n_seq consecutive ia_running_norm_merge updates (one group of `rows` rows each, moments `seq_stride`
- * floats apart) in order, in one launch: the deferred policy feature-norm updates of a round
- * (adversarial/common.py:606-615 side effect). */
-int ia_running_norm_merge_seq(const float* ws_seq, int n_seq, int64_t seq_stride, int rows, int D, int ws_ld,
-                              float* mean, float* var, int32_t* count, void* stream);
+/* n_seq consecutive ia_running_norm_merge updates (`groups` x `rows_per_group` rows each, moments
+ * `seq_stride` floats apart) in order, in one launch: the deferred policy feature-norm updates of a
+ * round (adversarial/common.py:606-615 side effect). */
+int ia_running_norm_merge_seq(const float* ws_seq, int n_seq, int64_t seq_stride, int groups, int rows_per_group,
+                              int D, int ws_ld, float* mean, float* var, int32_t* count, void* stream);
 /* util/networks.py:91: Y = (X-mean)/sqrt(var+eps); columns [D,ldy) of Y are zeroed. */
 int ia_running_norm_apply(const float* X, int ldx, int R, int D, const float* mean, const float* var, float eps,
                           float* Y, int ldy, void* stream);

@@ -69,7 +69,7 @@ def _gpu_worker(rank, world, port, out_dir):
     cfg = dict(harness.CASES["gail_box"], rounds=2)
     from imitation_amd.vec_env import SyntheticVecEnv
 
-    def run(batch_moments: bool):
+    def run(batch_moments: bool, global_mb: bool = False, pipeline: bool = True):
         th.manual_seed(100 + rank)      # different initial weights per rank: the broadcast must fix that
         np.random.seed(100 + rank)
         venv = SyntheticVecEnv(num_envs=cfg["n_envs"], obs_dim=17, act_dim=6, horizon=cfg["horizon"], seed=rank)
@@ -78,20 +78,30 @@ def _gpu_worker(rank, world, port, out_dir):
         algo = p.PPO(p.FeedForward32Policy, venv, n_steps=cfg["n_steps"], batch_size=cfg["ppo_batch"], n_epochs=2,
                      ent_coef=0.1, policy_kwargs=pk, device="cuda")
         algo.dp_batch_moments = batch_moments
+        algo.dp_global_minibatch = global_mb
         net = p.BasicRewardNet(venv.observation_space, venv.action_space, hid_sizes=(32, 32),
                                normalize_input_layer=p.RunningNorm)
         demos = p.Transitions(**harness.make_demo_arrays(cfg, seed=1 + rank))
         tr = p.GAIL(demonstrations=demos, demo_batch_size=64, venv=venv, gen_algo=algo, reward_net=net,
                     n_disc_updates_per_round=2, custom_logger=p.configure_logger(tempfile.mkdtemp(), []),
                     data_parallel=DataParallel())
-        tr.train(cfg["rounds"] * cfg["n_envs"] * cfg["n_steps"])
+        tr.pipeline_rounds = pipeline
+        tr.train((cfg["rounds"] + 1) * cfg["n_envs"] * cfg["n_steps"] if global_mb else
+                 cfg["rounds"] * cfg["n_envs"] * cfg["n_steps"])
         th.cuda.synchronize()
         sd = {f"disc/{k}": v.cpu() for k, v in tr._reward_net.state_dict().items()}
         sd.update({f"pol/{k}": v.cpu() for k, v in algo.policy.state_dict().items()})
+        if global_mb:  # the gathered tile of the last update and this rank's own shard of it
+            g, rb = algo._dpg, algo.rollout_buffer
+            sd["tile/obs_global"], sd["tile/adv_global"] = g["obs"].cpu(), g["adv"].cpu()
+            sd["tile/obs_local"], sd["tile/adv_local"] = rb.obs[: rb.buffer_size].cpu(), rb.adv.cpu()
+            sd["tile/perm"] = g["perm_dev"].cpu()
         return sd
 
     th.save(run(True), os.path.join(out_dir, f"state{rank}.pt"))
     th.save(run(False), os.path.join(out_dir, f"state{rank}_per_minibatch.pt"))
+    th.save(run(True, global_mb=True), os.path.join(out_dir, f"state{rank}_global.pt"))
+    th.save(run(True, global_mb=True, pipeline=False), os.path.join(out_dir, f"state{rank}_global_seq.pt"))
     dist.destroy_process_group()
 
 
@@ -109,5 +119,24 @@ def test_two_ranks_one_gpu_replicas_identical(tmp_path):
     c = th.load(tmp_path / "state0_per_minibatch.pt")
     for k in a:
         assert th.equal(a[k], c[k]), k
+    # global-minibatch update (no per-step collective): replicas identical, every rank holds the same
+    # gathered tile [T, world*n] = [rank 0 envs | rank 1 envs], and the same permutations
+    g0, g1 = th.load(tmp_path / "state0_global.pt"), th.load(tmp_path / "state1_global.pt")
+    for k in g0:
+        if not k.startswith("tile/") or k.endswith("_global") or k == "tile/perm":
+            assert th.equal(g0[k], g1[k]), k
+    n = g0["tile/obs_local"].shape[1]
+    assert th.equal(g0["tile/obs_global"][:, :n], g0["tile/obs_local"]) and th.equal(g0["tile/obs_global"][:, n:],
+                                                                                      g1["tile/obs_local"])
+    assert th.equal(g0["tile/adv_global"][:, n:], g1["tile/adv_local"])
+    perm = g0["tile/perm"]
+    assert perm.shape[1] == 2 * g0["tile/adv_local"].numel() and th.equal(perm.sort(dim=1).values[0],
+                                                                           th.arange(perm.shape[1]))
+    assert not th.equal(g0["pol/action_net.weight"], a["pol/action_net.weight"])   # it did train differently
+    # rounds pipelined across the rollout (discriminator collectives behind the env stepping) == sequential
+    q0 = th.load(tmp_path / "state0_global_seq.pt")
+    for k in g0:
+        assert th.equal(g0[k], q0[k]), k
     # every rank contributed: disc input norm saw world * (2 rounds * 2 updates * 128 rows)
     assert int(a["disc/mlp.normalize_input.count"]) == 2 * 2 * 2 * 128
+    assert int(g0["disc/mlp.normalize_input.count"]) == 2 * 3 * 2 * 128

@@ -393,7 +393,11 @@ def test_timeout_bootstrap():
                                                         (5, 4, 64, False, True, 3, 7, 21),
                                                         (4, 3, 32, True, True, 8, 16, 40),
                                                         (64, 16, 32, False, True, 4, 32, 64),
-                                                        (33, 1, 32, False, False, 2, 70, 140)])
+                                                        (33, 1, 32, False, False, 2, 70, 140),
+                                                        # large (data-parallel-sized) minibatches: 32 / 128
+                                                        # gradient blocks, two-level slab reduction
+                                                        (17, 6, 32, False, True, 16, 256, 2048),
+                                                        (17, 6, 32, False, True, 8, 2048, 8192)])
 @pytest.mark.parametrize("path", ["epoch", "update", "update_spread"])
 def test_ppo_epochs_match_oracle(D, A, H, discrete, norm, T, n, bs, path):
     """Two PPO epochs on a synthetic rollout: parameters, Adam state, RunningNorm state and the

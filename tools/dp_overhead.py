@@ -13,7 +13,10 @@ import bench  # noqa: E402
 
 
 class NullDP:
-    world, rank = 2, 0
+    rank = 0
+
+    def __init__(self, world):
+        self.world = world
 
     def allreduce_mean_(self, flat):
         return flat
@@ -22,18 +25,24 @@ class NullDP:
         pass
 
     def all_gather_flat(self, local):
-        return th.cat([local, local])
+        return th.cat([local] * self.world)
+
+    def shared_seed(self):
+        return 1234
 
 
 th.set_num_threads(1)
 cfg = dict(bench.CFG_P)
 per_round = cfg["n_envs"] * cfg["n_steps"]
-for name, dp in (("single", None), ("dp-path, null collectives", NullDP())):
+for name, dp, glob in (("single", None, True), ("dp 2, per-minibatch all-reduce path", NullDP(2), False),
+                       ("dp 2, global-minibatch update", NullDP(2), True),
+                       ("dp 8, global-minibatch update", NullDP(8), True)):
     tr = bench.build_trainer(bench.hip_namespace(), cfg, "cuda", seed=0, dp=dp)
+    tr.gen_algo.dp_global_minibatch = glob
     tr.train(3 * per_round)
     th.cuda.synchronize()
     t = time.perf_counter()
     tr.train(10 * per_round)
     th.cuda.synchronize()
     dt = (time.perf_counter() - t) / 10
-    print(f"{name:28s} {1e3 * dt:7.2f} ms/round  {per_round / dt / 1e3:8.1f} k env-steps/s per GPU")
+    print(f"{name:38s} {1e3 * dt:7.2f} ms/round  {per_round / dt / 1e3:8.1f} k env-steps/s per GPU")
