@@ -157,7 +157,8 @@ def gemm_roofline(trainer, cfg, rounds):
         D, A, H = cfg["obs_dim"], cfg["act_dim"], 32
         per_row = 6.0 * ((D * H + H * H + H * A) + (D * H + H * H + H))
         steps = algo.n_epochs * algo._n_mb
-        fl_ppo = per_row * min(algo.batch_size, cfg["n_envs"] * cfg["n_steps"]) * steps
+        world = getattr(getattr(algo, "dp", None), "world", 1)   # the data-parallel update runs on the gathered tile
+        fl_ppo = per_row * world * min(algo.batch_size, cfg["n_envs"] * cfg["n_steps"]) * steps
         avg = sum(ppo_ms) / len(ppo_ms)
         ppo = {"kernel": "ppo_update_persistent_kernel (whole PPO.train, one launch)", "bound": "latency",
                "avg_launch_us": 1e3 * avg, "optimizer_steps_per_launch": steps, "us_per_step": 1e3 * avg / steps,
@@ -185,12 +186,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", 1))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run)"
-    th.cuda.set_device(local_rank)
+    # Test hook for boxes with fewer GPUs than ranks (not a benchmark mode): IA_BENCH_SHARE_GPU=1 puts
+    # every rank on cuda:0 and moves the collectives through gloo (RCCL refuses two ranks on one GPU).
+    share = os.environ.get("IA_BENCH_SHARE_GPU") == "1"
+    th.cuda.set_device(0 if share else local_rank)
     dp = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=th.device("cuda", local_rank))
+        if share:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=th.device("cuda", local_rank))
         from imitation_amd.distributed import DataParallel
         dp = DataParallel()
 
@@ -221,7 +228,11 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 
-    roof = gemm_roofline(trainer, cfg, args.prof_rounds) if (rank == 0 and args.prof_rounds > 0) else None
+    # the profiled rounds are training rounds too: under data parallelism EVERY rank must take part in
+    # their collectives (only rank 0's measurement is reported)
+    roof = gemm_roofline(trainer, cfg, args.prof_rounds) if args.prof_rounds > 0 else None
+    if rank != 0:
+        roof = None
     base = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         th.set_num_threads(host_threads)

@@ -623,6 +623,8 @@ class PPO(OnPolicyAlgorithm):
         g["perm_dev"].copy_(g["perm_host"], non_blocking=True)
         rn = pol.features_extractor.normalize
         og = pol.optimizer.param_groups[0]
+        if self.update_events is not None:
+            self.update_events[0].record()
         L.call("ia_ppo_update", C.byref(pol.desc), L.ptr(pol._flat), L.ptr(pol._flat_t),
                L.ptr(rn.running_mean) if rn else None, L.ptr(rn.running_var) if rn else None,
                L.ptr(rn.count) if rn else None, int(rn is not None), L.ptr(g["obs"]), L.ptr(g["acts"]), L.ptr(g["logp"]),
@@ -631,6 +633,8 @@ class PPO(OnPolicyAlgorithm):
                float(self.max_grad_norm), L.ptr(pol.optimizer.exp_avg), L.ptr(pol.optimizer.exp_avg_sq),
                float(lr), float(og["betas"][0]), float(og["betas"][1]), float(og["eps"]), pol.optimizer.step_count,
                L.ptr(g["ws"]), L.ptr(stats_dev), L.stream())
+        if self.update_events is not None:
+            self.update_events[1].record()
         pol.optimizer.step_count += self.n_epochs * self._n_mb
 
     def _train_data_parallel(self, perm: np.ndarray, lr: float, clip_range: float) -> None:
