@@ -1978,7 +1978,9 @@ __global__ __launch_bounds__(512) void policy_act_mfma32_kernel(
 
 constexpr int UPD_RING = 4;
 constexpr int UPD_MAX_STEPS = 2048;                // optimiser steps per launch (Adam scalar tables in ws)
-constexpr int UPD_NPT = 8;                        // parameters per thread (<= 4096 parameters)
+constexpr int UPD_NPT = 8;                        // parameters per thread: 8 (<= 4096 parameters) or, for wider
+constexpr int UPD_NPT_WIDE = 9;                   // observation/action spaces (Ant-shaped: 4209), 9 -- as many as the
+                                                  // LDS-resident parameter copies allow next to the minibatch tiles
 constexpr int UPD_RS = 2 * MAXD + 8;              // ring slot: mean[MAXD], var[MAXD], adv mean, adv std
 constexpr int UPD_CTRL = 64;                      // control words: 0 arrivals, 1 steps published, 2 second-level
                                                   // arrivals, 8 error (sticky), 16.. steps sliced per slicer
@@ -2028,6 +2030,7 @@ __device__ __forceinline__ bool spin_until(unsigned* p, unsigned target, unsigne
   return true;
 }
 
+template <int NPT>
 __global__ __launch_bounds__(512) void ppo_update_persistent_kernel(
     ia_policy_desc d, float* __restrict__ P, float* __restrict__ Pt, float* __restrict__ m, float* __restrict__ v,
     float* __restrict__ nm, float* __restrict__ nv, int32_t* __restrict__ ncount, int update_norm,
@@ -2219,9 +2222,9 @@ __global__ __launch_bounds__(512) void ppo_update_persistent_kernel(
   unsigned short* dstT = reinterpret_cast<unsigned short*>(stg + UpdStage::total);  // [P4] index of parameter i in the transposed copy
   float* red = lds + L::misc + ROWS * L::MS;  // 64 spare floats behind the misc tile
   const int lane = tid & 63;
-  float rm[UPD_NPT], rv[UPD_NPT];
+  float rm[NPT], rv[NPT];
 #pragma unroll
-  for (int k = 0; k < UPD_NPT; ++k) {
+  for (int k = 0; k < NPT; ++k) {
     const int i = tid + k * 512;
     rm[k] = rv[k] = 0.f;
     if (i < o.total) {
@@ -2375,19 +2378,20 @@ __global__ __launch_bounds__(512) void ppo_update_persistent_kernel(
     // group g into a partial, one more grid barrier among the leaders' arrivals, then every block sums
     // the ngrp partials -- so a block never reads more than 16 vectors (128 slabs each would be 230 MB
     // of reads per step over all blocks).
-    float g[UPD_NPT];
+    float g[NPT];
     float sq = 0.f;
     auto sum_vectors = [&](const float* __restrict__ base, int nsrc) {
 #pragma unroll
-      for (int k = 0; k < UPD_NPT; ++k) g[k] = 0.f;
-      constexpr int KH = UPD_NPT / 2;  // 4 parameters x 8 vectors = 32 loads in flight per thread
+      for (int k = 0; k < NPT; ++k) g[k] = 0.f;
+      constexpr int KH = 4;  // 4 parameters x 8 vectors = 32 loads in flight per thread
       int b = 0;
       for (; b + 8 <= nsrc; b += 8) {
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
+        for (int h = 0; h < (NPT + KH - 1) / KH; ++h) {
           float t[KH][8];
 #pragma unroll
           for (int k = 0; k < KH; ++k) {
+            if (h * KH + k >= NPT) continue;  // (resolved at compile time)
             // clamped index: every load is unconditional (a guarded load costs a branch and a full
             // wait each, which serialises the whole batch); lanes past the end are discarded below
             const int i = min(tid + (h * KH + k) * 512, o.total - 1);
@@ -2395,14 +2399,16 @@ __global__ __launch_bounds__(512) void ppo_update_persistent_kernel(
             for (int u = 0; u < 8; ++u) t[k][u] = base[(long long)(b + u) * w.P4 + i];
           }
 #pragma unroll
-          for (int k = 0; k < KH; ++k)
+          for (int k = 0; k < KH; ++k) {
+            if (h * KH + k >= NPT) continue;
 #pragma unroll
             for (int u = 0; u < 8; ++u) g[h * KH + k] += t[k][u];
+          }
         }
       }
       for (; b < nsrc; ++b) {
 #pragma unroll
-        for (int k = 0; k < UPD_NPT; ++k) g[k] += base[(long long)b * w.P4 + min(tid + k * 512, o.total - 1)];
+        for (int k = 0; k < NPT; ++k) g[k] += base[(long long)b * w.P4 + min(tid + k * 512, o.total - 1)];
       }
     };
     if (nblk <= UPD_GROUP) {
@@ -2414,7 +2420,7 @@ __global__ __launch_bounds__(512) void ppo_update_persistent_kernel(
         const int first = vb * UPD_GROUP;
         sum_vectors(slab_base + (long long)first * w.P4, min(UPD_GROUP, nblk - first));
 #pragma unroll
-        for (int k = 0; k < UPD_NPT; ++k) {
+        for (int k = 0; k < NPT; ++k) {
           const int i = tid + k * 512;
           if (i < o.total) part_base[(long long)vb * w.P4 + i] = g[k];
         }
@@ -2433,7 +2439,7 @@ __global__ __launch_bounds__(512) void ppo_update_persistent_kernel(
       sum_vectors(part_base, ngrp);
     }
 #pragma unroll
-    for (int k = 0; k < UPD_NPT; ++k) {
+    for (int k = 0; k < NPT; ++k) {
       if (tid + k * 512 >= o.total) g[k] = 0.f;
       sq += g[k] * g[k];
     }
@@ -2453,7 +2459,7 @@ __global__ __launch_bounds__(512) void ppo_update_persistent_kernel(
       }
     }
 #pragma unroll
-    for (int k = 0; k < UPD_NPT; ++k) {
+    for (int k = 0; k < NPT; ++k) {
       const int i = tid + k * 512;
       if (i < o.total) {
         const float gi = g[k] * coef;
@@ -2485,7 +2491,7 @@ __global__ __launch_bounds__(512) void ppo_update_persistent_kernel(
     for (int k = 0; k < 12; ++k) tstamp[k] += tacc[k];
   if (vb == 0) {
 #pragma unroll
-    for (int k = 0; k < UPD_NPT; ++k) {
+    for (int k = 0; k < NPT; ++k) {
       const int i = tid + k * 512;
       if (i < o.total) {
         P[i] = sP[i];
@@ -2861,16 +2867,21 @@ int ia_ppo_epoch(const ia_policy_desc* d, float* params, float* params_t, float*
 }
 
 
+// LDS of a gradient block: minibatch tiles, both parameter copies, the staged next minibatch, the transpose map
+inline size_t upd_grad_lds_bytes(int P4) {
+  return (CLds::total + 2 * (size_t)P4 + UpdStage::total) * sizeof(float) + P4 * sizeof(unsigned short);
+}
+
 // Workspace of ia_ppo_update in floats; 0 when the persistent kernel does not cover the shape
 // (the caller then runs ia_ppo_epoch per epoch).
 int64_t ia_ppo_update_ws_floats(const ia_policy_desc* d, int batch_size) {
   if (!pol_ok(d) || batch_size <= 0) return IA_ERR_ARG;
   const int P = pol_offsets(d->obs_dim, d->act_dim, d->hidden, d->discrete).total;
   const int nblk = cdiv(batch_size, ROWS);
-  if (d->hidden != 32 || P > UPD_NPT * 512 || nblk > UPD_NBLK_MAX || cdiv(batch_size, UPD_SLICE) > UPD_SLICES_MAX ||
-      g_ppo_valu)
-    return 0;
   const int P4 = (P + 3) & ~3;
+  if (d->hidden != 32 || P > UPD_NPT_WIDE * 512 || upd_grad_lds_bytes(P4) > 160 * 1024 || nblk > UPD_NBLK_MAX ||
+      cdiv(batch_size, UPD_SLICE) > UPD_SLICES_MAX || g_ppo_valu)
+    return 0;
   return UPD_CTRL + 2 * UPD_MAX_STEPS + UPD_RING * UPD_RS + UPD_SD * 2 + UPD_SD * (int64_t)nblk * 8 +
          2 * (int64_t)nblk * P4 + 2 * (int64_t)UPD_GROUPS_MAX * P4 + (int64_t)UPD_RING * UPD_SLICES_MAX * UPD_PRS;
 }
@@ -2898,11 +2909,17 @@ int ia_ppo_update(const ia_policy_desc* d, float* params, float* params_t, float
   const int nblk = cdiv(batch_size, ROWS);
   const int P = pol_offsets(d->obs_dim, d->act_dim, 32, d->discrete).total;
   const int P4 = (P + 3) & ~3;
-  const size_t grad_bytes = (CLds::total + 2 * P4 + UpdStage::total) * sizeof(float) + P4 * sizeof(unsigned short);
+  const size_t grad_bytes = upd_grad_lds_bytes(P4);
   const size_t prep_bytes = (PREP_LDS_FLOATS + (size_t)nblk * ROWS) * sizeof(float);  // + row offsets
   const size_t bytes = grad_bytes > prep_bytes ? grad_bytes : prep_bytes;
-  static size_t attr_bytes = 0;
-  if (bytes > attr_bytes) { int rc = set_lds(ppo_update_persistent_kernel, bytes); if (rc) return rc; attr_bytes = bytes; }
+  const bool wide = P > UPD_NPT * 512;
+  static size_t attr_bytes[2] = {0, 0};
+  if (bytes > attr_bytes[wide]) {
+    const int rc = wide ? set_lds(ppo_update_persistent_kernel<UPD_NPT_WIDE>, bytes)
+                        : set_lds(ppo_update_persistent_kernel<UPD_NPT>, bytes);
+    if (rc) return rc;
+    attr_bytes[wide] = bytes;
+  }
   hipStream_t st = (hipStream_t)stream;
   const int steps_total = n_epochs * n_mb;
   int64_t step = adam_steps_done;
@@ -2944,7 +2961,8 @@ int ia_ppo_update(const ia_policy_desc* d, float* params, float* params_t, float
     const int n_slices = (batch_size > 1024 && total < (1ll << 31)) ? cdiv(batch_size, UPD_SLICE) : 0;
     const bool pack = g_upd_xcd_pack && nblk + 1 + n_slices <= 32;
     const int grid = (nblk + 1 + n_slices) * (pack ? 8 : 1);
-    hipLaunchKernelGGL(ppo_update_persistent_kernel, dim3(grid), dim3(512), bytes, st, *d, params, params_t, exp_avg,
+    auto kernel = wide ? ppo_update_persistent_kernel<UPD_NPT_WIDE> : ppo_update_persistent_kernel<UPD_NPT>;
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(512), bytes, st, *d, params, params_t, exp_avg,
                        exp_avg_sq, norm_mean, norm_var, norm_count, update_norm, obs, actions, old_logp, advantages,
                        returns, perm, T, n_envs, normalize_adv, clip_range, ent_coef, vf_coef, max_grad_norm,
                        (float)beta1, (float)beta2, adam_eps, ws, nblk, n_slices, stats, sch, pack ? 1 : 0, g_tstamp);

@@ -221,7 +221,7 @@ class RolloutBuffer:
         self.h_obs, self.h_next = pin(T + 1, n, obs_dim), pin(T, n, obs_dim)
         self.h_dones, self.h_trunc = pin(T, n, dtype=th.uint8), pin(T, n, dtype=th.uint8)
         self.h_rew, self.h_starts = pin(T, n), pin(T, n)
-        self.h_clip, self.h_noise, self.h_last_done = pin(n, act_width), pin(n, max(act_width, 1)), pin(n)
+        self.h_clip, self.h_noise, self.h_last_done = pin(T, n, act_width), pin(n, max(act_width, 1)), pin(n)
         self.full = False
 
     def reset(self) -> None:
@@ -332,6 +332,7 @@ class PPO(OnPolicyAlgorithm):
         self.enqueue_first = False
         self.after_enqueue = None
         self._post_enqueue_work = []
+        self._act_stream = None
         self.rollout_profile = None
         self._dp_obs = th.zeros(min(self.batch_size, total), p.obs_dim, device=self.device)
         self._dp_ws_pre = None
@@ -475,25 +476,36 @@ class PPO(OnPolicyAlgorithm):
             self._predraw.start(self._perm_np)  # consumed by the `train()` that follows
         stream = th.cuda.current_stream()
         rb.h_obs[0].copy_(th.as_tensor(np.asarray(self._last_obs)).reshape(n, -1))
-        rb.obs[0].copy_(rb.h_obs[0], non_blocking=True)
         starts = np.asarray(self._last_episode_starts, dtype=bool)
         h_rew_np, h_dones_np, h_trunc_np = rb.h_rew.numpy(), rb.h_dones.numpy(), rb.h_trunc.numpy()
         h_next_np, h_obs_np, h_starts_np = rb.h_next.numpy(), rb.h_obs.numpy(), rb.h_starts.numpy()
         per_step_rews = []
         prof = self.rollout_profile  # optional dict of per-section host seconds (tools/rollout_sections.py)
         tick = time.perf_counter
-        act_step = pol.make_act_step(rb.obs, rb.noise, rb.acts, rb.clipped, rb.val, rb.logp)  # eval mode: no norm update
+        # The per-step exchange with the host env workers goes through pinned (device-mapped) host
+        # memory directly: the act kernel reads this step's observations and noise from it and writes
+        # the clipped actions into it, so a step is ONE launch + ONE wait -- no copy-engine hops in the
+        # latency chain. The device copies of the observation / clipped-action tiles (needed from the
+        # reward relabelling on) are filled by two bulk copies after the last step.
+        # The act kernels run on their own HIGH-PRIORITY stream: while the host steps the environments the
+        # device works through the previous round's discriminator updates (pipelined rounds), whose GEMMs
+        # fill every CU; with equal priority each 15 us act kernel queued behind them for ~60 us.
+        if self._act_stream is None:
+            self._act_stream = th.cuda.Stream(device=self.device, priority=-1)
+        act_stream = self._act_stream
+        act_stream.wait_stream(stream)     # parameters / statistics written by the previous update
+        with th.cuda.stream(act_stream):
+            act_step = pol.make_act_step(rb.h_obs, rb.h_noise, rb.acts, rb.h_clip, rb.val, rb.logp)  # eval mode: no norm update
+        h_clip_np = rb.h_clip.numpy()
         for t in range(T):
             t0 = tick() if prof is not None else 0.0
             pol.draw_noise_into(rb.h_noise)
-            rb.noise.copy_(rb.h_noise, non_blocking=True)
             t1 = tick() if prof is not None else 0.0
             act_step(t)
-            rb.h_clip.copy_(rb.clipped[t], non_blocking=True)
             t2 = tick() if prof is not None else 0.0
-            stream.synchronize()
+            act_stream.synchronize()       # (so everything the act kernels wrote is complete before `stream` reads it)
             t3 = tick() if prof is not None else 0.0
-            acts_np = rb.h_clip.numpy()
+            acts_np = h_clip_np[t]
             acts_np = acts_np.reshape(n).astype(np.int64) if pol.discrete else acts_np.reshape(
                 (n, *self.action_space.shape)).copy()
             old_obs = self._last_obs
@@ -501,8 +513,8 @@ class PPO(OnPolicyAlgorithm):
             new_obs, env_rews, dones, nxt, trunc, infos = step_arrays(base)
             if prof is not None:
                 t4 = tick()
-                for k, v in (("noise draw + H2D", t1 - t0), ("act launch + D2H enqueue", t2 - t1),
-                             ("wait for the device", t3 - t2), ("env step", t4 - t3)):
+                for k, v in (("noise draw", t1 - t0), ("act launch", t2 - t1),
+                             ("wait for the device" if t else "wait for the device, step 0 (previous update)", t3 - t2), ("env step", t4 - t3)):
                     prof[k] = prof.get(k, 0.0) + v
                 prof["_t_book"] = t4
             self.num_timesteps += n
@@ -523,14 +535,13 @@ class PPO(OnPolicyAlgorithm):
                 h_rew_np[t] = per_step_rews[-1]
             else:
                 h_rew_np[t] = env_rews
-            rb.obs[t + 1].copy_(rb.h_obs[t + 1], non_blocking=True)
             self._last_obs, starts = new_obs, np.asarray(dones, dtype=bool)
             if prof is not None:
-                prof["bookkeeping + obs H2D"] = prof.get("bookkeeping + obs H2D", 0.0) + tick() - prof.pop("_t_book")
+                prof["bookkeeping"] = prof.get("bookkeeping", 0.0) + tick() - prof.pop("_t_book")
         self._last_episode_starts = starts
         rb.h_last_done.copy_(th.as_tensor(starts.astype(np.float32)))
-        for d, h in ((rb.next_fixed, rb.h_next), (rb.dones, rb.h_dones), (rb.trunc, rb.h_trunc),
-                     (rb.starts, rb.h_starts), (rb.last_done, rb.h_last_done)):
+        for d, h in ((rb.obs, rb.h_obs), (rb.clipped, rb.h_clip), (rb.next_fixed, rb.h_next), (rb.dones, rb.h_dones),
+                     (rb.trunc, rb.h_trunc), (rb.starts, rb.h_starts), (rb.last_done, rb.h_last_done)):
             d.copy_(h, non_blocking=True)
         if self.before_relabel is not None:
             self.before_relabel()

@@ -394,6 +394,9 @@ def test_timeout_bootstrap():
                                                         (4, 3, 32, True, True, 8, 16, 40),
                                                         (64, 16, 32, False, True, 4, 32, 64),
                                                         (33, 1, 32, False, False, 2, 70, 140),
+                                                        # Ant-shaped (BASELINE config 3): 4209 parameters, the
+                                                        # 9-parameters-per-thread build of the persistent kernel
+                                                        (27, 8, 32, False, True, 8, 64, 256),
                                                         # large (data-parallel-sized) minibatches: 32 / 128
                                                         # gradient blocks, two-level slab reduction
                                                         (17, 6, 32, False, True, 16, 256, 2048),
@@ -455,7 +458,7 @@ def test_ppo_epochs_match_oracle(D, A, H, discrete, norm, T, n, bs, path):
     else:
         nws = int(L.load().ia_ppo_update_ws_floats(C.byref(dp.d), bs))
         if nws == 0:
-            pytest.skip("shape not covered by the persistent kernel (more than 4096 parameters)")
+            pytest.skip("shape not covered by the persistent kernel (parameter copies do not fit LDS)")
         uws = th.zeros(nws, device=DEV)
         d_perm = th.as_tensor(np.stack(perms)).to(DEV)
         L.load().ia_ppo_update_xcd_pack(1 if path == "update" else 0)

@@ -1,5 +1,5 @@
 """Runs the other BASELINE.json / SURVEY 8d configurations through the HIP trainer for a few rounds:
-sanity (finite statistics, counters) + throughput. Usage: python tools/variants.py [rounds]"""
+sanity (finite statistics, counters) + throughput. Usage: python tools/variants.py [rounds] [names]"""
 import os, sys, tempfile, time
 import numpy as np, torch as th
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -7,6 +7,7 @@ import imitation_amd as p
 from imitation_amd.vec_env import SyntheticVecEnv
 
 rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 4
+only = set(sys.argv[2].split(",")) if len(sys.argv) > 2 else None   # e.g. "P,3b"
 th.set_num_threads(1)
 
 
@@ -19,6 +20,8 @@ def demos(n, od, ad, discrete, seed=1):
 
 def run(name, algo_name, n_envs, n_steps, od, ad, horizon, ppo_batch, n_epochs, demo_batch, n_disc, capacity,
         disc_kw, discrete=False, gamma=0.99, gae=0.95, clip=0.2, minib=None, normalize_output=False):
+    if only is not None and name.split()[0] not in only:
+        return True
     th.manual_seed(0); np.random.seed(0)
     venv = SyntheticVecEnv(num_envs=n_envs, obs_dim=od, act_dim=ad, horizon=horizon, seed=0,
                            n_discrete=ad if discrete else None)
@@ -37,15 +40,13 @@ def run(name, algo_name, n_envs, n_steps, od, ad, horizon, ppo_batch, n_epochs, 
              demo_minibatch_size=minib, venv=venv, gen_algo=algo, reward_net=net, n_disc_updates_per_round=n_disc,
              gen_replay_buffer_capacity=capacity, custom_logger=p.configure_logger(tempfile.mkdtemp(), []))
     per = n_envs * n_steps
-    stats = []
-    orig = tr.train_disc
-    tr.train_disc = lambda **k: (stats.append(orig(**k)), stats[-1])[1]
     tr.train(per)  # warm-up round
     th.cuda.synchronize(); t0 = time.perf_counter()
-    tr.train(rounds * per)
+    tr.train(rounds * per)   # (no hook on train_disc: an overridden train_disc switches round pipelining off)
     th.cuda.synchronize(); dt = time.perf_counter() - t0
-    last = stats[-1]
-    ok = all(np.isfinite(v) for k, v in last.items()) and tr._disc_step == (rounds + 1) * n_disc
+    ok = tr._disc_step == (rounds + 1) * n_disc
+    last = tr.train_disc()
+    ok = ok and all(np.isfinite(v) for k, v in last.items())
     sd = tr.gen_algo.policy.state_dict()
     ok = ok and all(bool(th.isfinite(v.float()).all()) for v in sd.values())
     print(f"{name:34s} {rounds * per / dt / 1e3:9.1f} k env-steps/s  {1e3 * dt / rounds:8.2f} ms/round  "
