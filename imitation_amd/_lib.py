@@ -55,6 +55,7 @@ _P, _I, _L, _F, _D = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_double
 _SIGS = {
     "ia_version": ([], C.c_int),
     "ia_host_mt19937_permutations": ([_P, C.POINTER(C.c_int), _L, _I, _P], C.c_int),
+    "ia_host_mt19937_seeded_permutations": ([_P, _I, _L, _I, _P], C.c_int),
     "ia_mlp_param_count": ([C.POINTER(MlpDesc)], C.c_int64),
     "ia_mlp_hidden_floats_per_row": ([C.POINTER(MlpDesc)], C.c_int64),
     "ia_gemm_f32": ([_I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _P, _I, _P, _I, _I, _P, _P], C.c_int),
@@ -136,6 +137,21 @@ def ptr(t: Optional[th.Tensor]):
 
 def stream():
     return th.cuda.current_stream().cuda_stream
+
+
+_side_streams: dict = {}
+
+
+def side_stream(device, name: str, priority: int = 0) -> "th.cuda.Stream":
+    """The process-wide side stream `name` of `device` (created on first use). Trainers share them instead
+    of creating their own: HIP multiplexes streams onto a handful of hardware queues in creation order, so
+    every additional stream risks landing on the queue of one it is supposed to overlap with (a second
+    trainer built in the same process ran 30 % slower that way)."""
+    dev = th.device(device)
+    key = (dev.index if dev.index is not None else th.cuda.current_device(), name)
+    if key not in _side_streams:
+        _side_streams[key] = th.cuda.Stream(device=dev, priority=priority)
+    return _side_streams[key]
 
 
 def check(rc: int, what: str) -> None:

@@ -169,7 +169,7 @@ class AdversarialTrainer(abc.ABC):
         dp_many = self._dp is not None and self._dp.world > 1
         self._overlap = (not self._needs_logp and isinstance(self.gen_algo, ppo.PPO)
                          and (not dp_many or self.gen_algo._dp_global()))
-        self._disc_stream = th.cuda.Stream(device=self._device) if self._overlap else None
+        self._disc_stream = L.side_stream(self._device, "disc") if self._overlap else None
         self._in_overlap = False
         self._overlap_k = 0
         self._quirk_ready = None

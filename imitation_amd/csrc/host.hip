@@ -1,6 +1,8 @@
 // Host-side helpers of the C ABI (no device code): index draws that must reproduce NumPy's
 // legacy global generator bit for bit, runnable off the Python thread (ctypes drops the GIL).
 #include <cstdint>
+#include <thread>
+#include <vector>
 
 #include "common.h"
 
@@ -46,7 +48,55 @@ inline uint64_t legacy_interval(uint32_t* key, int& pos, uint64_t max) {
   return v;
 }
 
+// MT19937 `init_by_array` (Matsumoto & Nishimura's published seeding routine; what
+// `np.random.RandomState(seed_array)` runs on the uint32 words of the array). Leaves pos = 624.
+inline void mt_init_by_array(const uint32_t* init, int len, uint32_t* mt) {
+  mt[0] = 19650218u;
+  for (int i = 1; i < MT_N; ++i) mt[i] = 1812433253u * (mt[i - 1] ^ (mt[i - 1] >> 30)) + (uint32_t)i;
+  int i = 1, j = 0;
+  for (int k = MT_N > len ? MT_N : len; k; --k) {
+    mt[i] = (mt[i] ^ ((mt[i - 1] ^ (mt[i - 1] >> 30)) * 1664525u)) + init[j] + (uint32_t)j;
+    if (++i >= MT_N) { mt[0] = mt[MT_N - 1]; i = 1; }
+    if (++j >= len) j = 0;
+  }
+  for (int k = MT_N - 1; k; --k) {
+    mt[i] = (mt[i] ^ ((mt[i - 1] ^ (mt[i - 1] >> 30)) * 1566083941u)) - (uint32_t)i;
+    if (++i >= MT_N) { mt[0] = mt[MT_N - 1]; i = 1; }
+  }
+  mt[0] = 0x80000000u;
+}
+
+inline void legacy_permutation(uint32_t* key, int& p, int64_t n, int64_t* x) {
+  for (int64_t i = 0; i < n; ++i) x[i] = i;
+  for (int64_t i = n - 1; i >= 1; --i) {
+    const int64_t j = (int64_t)legacy_interval(key, p, (uint64_t)i);
+    const int64_t t = x[i];
+    x[i] = x[j];
+    x[j] = t;
+  }
+}
+
 }  // namespace
+
+// `count` independent permutations, out[c] = np.random.RandomState(seeds[c, :seed_len]).permutation(n),
+// each drawn by its own host thread (the data-parallel PPO update: every rank derives the same
+// per-epoch minibatch order from a shared seed while its rollout runs).
+extern "C" int ia_host_mt19937_seeded_permutations(const uint32_t* seeds, int seed_len, int64_t n, int count,
+                                                   int64_t* out) {
+  if (seeds == nullptr || out == nullptr || seed_len <= 0 || n < 0 || count < 0 || n > 0xffffffffLL) return IA_ERR_ARG;
+  auto one = [=](int c) {
+    uint32_t key[MT_N];
+    mt_init_by_array(seeds + (int64_t)c * seed_len, seed_len, key);
+    int pos = MT_N;
+    legacy_permutation(key, pos, n, out + (int64_t)c * n);
+  };
+  std::vector<std::thread> workers;
+  workers.reserve(count > 1 ? count - 1 : 0);
+  for (int c = 1; c < count; ++c) workers.emplace_back(one, c);
+  if (count > 0) one(0);
+  for (auto& t : workers) t.join();
+  return IA_OK;
+}
 
 // `count` consecutive `np.random.permutation(n)` draws of the legacy MT19937 RandomState whose
 // state is (key[624], *pos): out[c*n .. c*n+n) = arange(n) shuffled by the legacy Fisher-Yates
@@ -57,16 +107,7 @@ extern "C" int ia_host_mt19937_permutations(uint32_t* key, int* pos, int64_t n, 
       n > 0xffffffffLL)
     return IA_ERR_ARG;
   int p = *pos;
-  for (int c = 0; c < count; ++c) {
-    int64_t* x = out + (int64_t)c * n;
-    for (int64_t i = 0; i < n; ++i) x[i] = i;
-    for (int64_t i = n - 1; i >= 1; --i) {
-      const int64_t j = (int64_t)legacy_interval(key, p, (uint64_t)i);
-      const int64_t t = x[i];
-      x[i] = x[j];
-      x[j] = t;
-    }
-  }
+  for (int c = 0; c < count; ++c) legacy_permutation(key, p, n, out + (int64_t)c * n);
   *pos = p;
   return IA_OK;
 }

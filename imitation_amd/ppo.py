@@ -78,6 +78,33 @@ class _CallbackList(_NullCallback):
         for c in self.cbs: c.on_training_end()
 
 
+class _HostHelper:
+    """One persistent daemon thread for the GIL-free C helpers that run beside the rollout (no thread
+    creation per round). `submit(fn)` returns an event that is set when `fn()` has returned."""
+
+    _queue: Optional["queue.SimpleQueue"] = None
+
+    @classmethod
+    def submit(cls, fn) -> threading.Event:
+        if cls._queue is None:
+            import queue
+
+            cls._queue = queue.SimpleQueue()
+
+            def serve(q=cls._queue):
+                while True:
+                    job, done = q.get()
+                    try:
+                        job()
+                    finally:
+                        done.set()
+
+            threading.Thread(target=serve, daemon=True, name="imitation_amd-host-helper").start()
+        done = threading.Event()
+        cls._queue.put((fn, done))
+        return done
+
+
 class _PermutationPredraw:
     """Draws the `n_epochs` minibatch permutations of the NEXT PPO update while the rollout is
     still stepping the environments, on a private copy of the state of NumPy's global generator
@@ -93,7 +120,7 @@ class _PermutationPredraw:
 
     def __init__(self, n_epochs: int, size: int):
         self.n_epochs, self.size = n_epochs, size
-        self._thread: Optional[threading.Thread] = None
+        self._thread: Optional[threading.Event] = None
         self._state0 = None
         self._key: Optional[np.ndarray] = None
         self._pos = C.c_int(0)
@@ -120,15 +147,14 @@ class _PermutationPredraw:
             self._rc = lib.ia_host_mt19937_permutations(self._key.ctypes.data, C.byref(self._pos), self.size,
                                                         self.n_epochs, out.ctypes.data)
 
-        self._thread = threading.Thread(target=work, daemon=True)
-        self._thread.start()
+        self._thread = _HostHelper.submit(work)
 
     def finish(self, out: np.ndarray) -> bool:
         """True if `out` now holds the permutations and the global generator has advanced past them."""
         t, self._thread = self._thread, None
         if t is None:
             return False
-        t.join()
+        t.wait()
         if self._rc != 0 or out is not self._out or not self._same(np.random.get_state(), self._state0):
             return False
         s0 = self._state0
@@ -139,8 +165,8 @@ class _PermutationPredraw:
 class _SharedPermutations:
     """Minibatch permutations of the data-parallel PPO update over the all-gathered rollout: every rank
     must use the SAME permutations, so they come from generators seeded identically on all ranks
-    (`[shared seed, update index, epoch]`), one per epoch, drawn concurrently by helper threads through
-    `ia_host_mt19937_permutations` (no GIL) while the rollout runs."""
+    (`[shared seed, update index, epoch]`), one per epoch, drawn concurrently by host threads inside
+    `ia_host_mt19937_seeded_permutations` (no GIL) while the rollout runs."""
 
     def __init__(self, seed: int, n_epochs: int, size: int):
         self.seed, self.n_epochs, self.size = int(seed), n_epochs, size
@@ -150,24 +176,21 @@ class _SharedPermutations:
     def start(self, out: np.ndarray) -> None:
         assert out.dtype == np.int64 and out.flags.c_contiguous and out.shape == (self.n_epochs, self.size)
         lib = L.load()
-        self._threads = []
-        for e in range(self.n_epochs):
-            st = np.random.RandomState([self.seed, self.update, e]).get_state()
-            key, pos = np.ascontiguousarray(st[1], dtype=np.uint32).copy(), C.c_int(int(st[2]))
+        seeds = np.array([[self.seed, self.update, e] for e in range(self.n_epochs)], dtype=np.uint32)
 
-            def work(key=key, pos=pos, e=e):
-                rc = lib.ia_host_mt19937_permutations(key.ctypes.data, C.byref(pos), self.size, 1, out[e].ctypes.data)
-                assert rc == 0
+        def work():  # one ctypes call (no GIL); the library fans out one host thread per epoch
+            self._rc = lib.ia_host_mt19937_seeded_permutations(seeds.ctypes.data, 3, self.size, self.n_epochs,
+                                                                 out.ctypes.data)
 
-            t = threading.Thread(target=work, daemon=True)
-            t.start()
-            self._threads.append(t)
+        self._rc = 0
+        self._threads = [_HostHelper.submit(work)]
         self.update += 1
 
     def finish(self) -> None:
         for t in self._threads:
-            t.join()
+            t.wait()
         self._threads = []
+        L.check(self._rc, "ia_host_mt19937_seeded_permutations")
 
 
 class _TrainRecord:
@@ -491,7 +514,7 @@ class PPO(OnPolicyAlgorithm):
         # device works through the previous round's discriminator updates (pipelined rounds), whose GEMMs
         # fill every CU; with equal priority each 15 us act kernel queued behind them for ~60 us.
         if self._act_stream is None:
-            self._act_stream = th.cuda.Stream(device=self.device, priority=-1)
+            self._act_stream = L.side_stream(self.device, "act", priority=-1)
         act_stream = self._act_stream
         act_stream.wait_stream(stream)     # parameters / statistics written by the previous update
         with th.cuda.stream(act_stream):
@@ -729,7 +752,7 @@ class PPO(OnPolicyAlgorithm):
         if self.defer_train_stats:
             if self._records is None:
                 self._records = [_TrainRecord(self._stats_dev, rb.val, pol.log_std) for _ in range(2)]
-                self._fin_stream = th.cuda.Stream(device=self.device)
+                self._fin_stream = L.side_stream(self.device, "readback")
             rec = self._records[self._rec_i % 2]
             self._rec_i += 1
             rec.val.copy_(rb.val)   # the tile is reused by the next rollout before the statistics are read

@@ -39,6 +39,10 @@ int ia_version(void);
  * per-epoch minibatch order of [SB3 RolloutBuffer.get] (adversarial/common.py:391-403 -> PPO.train).
  * Lets the host draw them off the Python thread while the rollout runs. out: int64 [count, n]. */
 int ia_host_mt19937_permutations(uint32_t* key, int* pos, int64_t n, int count, int64_t* out);
+/* HOST helper: out[c] = np.random.RandomState(seeds[c, 0:seed_len]).permutation(n) for c < count, each on
+ * its own host thread. No reference counterpart (the reference is single-process): the shared-seed
+ * minibatch order of the data-parallel PPO update. seeds: uint32 [count, seed_len]. */
+int ia_host_mt19937_seeded_permutations(const uint32_t* seeds, int seed_len, int64_t n, int count, int64_t* out);
 int64_t ia_mlp_param_count(const ia_mlp_desc* d);
 /* floats of workspace per row needed for hidden activations (sum of hidden widths) */
 int64_t ia_mlp_hidden_floats_per_row(const ia_mlp_desc* d);

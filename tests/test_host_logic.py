@@ -275,3 +275,16 @@ def test_host_mt19937_permutations_bit_exact(n, count, seed):
     assert L.load().ia_host_mt19937_permutations(key.ctypes.data, C.byref(pos), n, count, out.ctypes.data) == 0
     assert np.array_equal(out, want)
     assert pos.value == after[2] and np.array_equal(key, after[1])
+
+
+@pytest.mark.parametrize("n,count,seed_len", [(1, 1, 1), (1000, 5, 3), (70000, 3, 3), (17, 4, 700)])
+def test_host_mt19937_seeded_permutations_bit_exact(n, count, seed_len):
+    """C-ABI host helper vs `np.random.RandomState(seed_words).permutation(n)` (array seeding shorter and
+    longer than the 624-word state; one host thread per permutation)."""
+    from imitation_amd import _lib as L
+
+    seeds = np.random.default_rng(n).integers(0, 2 ** 32, (count, seed_len), dtype=np.uint64).astype(np.uint32)
+    out = np.full((count, n), -1, dtype=np.int64)
+    assert L.load().ia_host_mt19937_seeded_permutations(seeds.ctypes.data, seed_len, n, count, out.ctypes.data) == 0
+    for c in range(count):
+        assert np.array_equal(out[c], np.random.RandomState(seeds[c]).permutation(n))

@@ -34,9 +34,12 @@ class NullDP:
 th.set_num_threads(1)
 cfg = dict(bench.CFG_P)
 per_round = cfg["n_envs"] * cfg["n_steps"]
+only = sys.argv[1] if len(sys.argv) > 1 else None   # substring of the case name, e.g. "dp 8"
 for name, dp, glob in (("single", None, True), ("dp 2, per-minibatch all-reduce path", NullDP(2), False),
                        ("dp 2, global-minibatch update", NullDP(2), True),
                        ("dp 8, global-minibatch update", NullDP(8), True)):
+    if only is not None and only not in name:
+        continue
     tr = bench.build_trainer(bench.hip_namespace(), cfg, "cuda", seed=0, dp=dp)
     tr.gen_algo.dp_global_minibatch = glob
     tr.train(3 * per_round)

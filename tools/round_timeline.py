@@ -1,6 +1,6 @@
 """Host and device timeline of overlapped GAIL rounds at config P: when the host finishes each
 enqueue step, and when each stream finishes its work (HIP events), relative to the round start.
-Usage: python tools/round_timeline.py [rounds]"""
+Usage: python tools/round_timeline.py [rounds] [world]"""
 import os
 import sys
 import time
@@ -13,7 +13,29 @@ import bench  # noqa: E402
 rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 5
 th.set_num_threads(1)
 cfg = dict(bench.CFG_P)
-tr = bench.build_trainer(bench.hip_namespace(), cfg, "cuda")
+world = int(sys.argv[2]) if len(sys.argv) > 2 else 1   # > 1: data-parallel code path with stand-in collectives
+dp = None
+if world > 1:
+    class NullDP:  # all-reduce = identity, all-gather = the local buffer repeated (see tools/dp_overhead.py)
+        rank = 0
+
+        def __init__(self, w):
+            self.world = w
+
+        def allreduce_mean_(self, flat):
+            return flat
+
+        def broadcast_(self, tensors, src=0):
+            pass
+
+        def all_gather_flat(self, local):
+            return th.cat([local] * self.world)
+
+        def shared_seed(self):
+            return 1234
+
+    dp = NullDP(world)
+tr = bench.build_trainer(bench.hip_namespace(), cfg, "cuda", seed=0, dp=dp)
 per_round = cfg["n_envs"] * cfg["n_steps"]
 tr.train(3 * per_round)
 th.cuda.synchronize()
