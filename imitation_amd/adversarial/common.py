@@ -167,14 +167,21 @@ class AdversarialTrainer(abc.ABC):
         # Data-parallel runs keep it when the PPO update needs no per-step collective (global-minibatch
         # update): then only one stream at a time has collectives in flight, in the same order on all ranks.
         dp_many = self._dp is not None and self._dp.world > 1
-        self._overlap = (not self._needs_logp and isinstance(self.gen_algo, ppo.PPO)
+        self._overlap = (isinstance(self.gen_algo, ppo.PPO) and isinstance(self.policy, ActorCriticPolicy)
                          and (not dp_many or self.gen_algo._dp_global()))
+        # AIRL's updates read log pi(a|s) of the policy PPO has just updated: they cannot run beside that
+        # PPO update, only behind the next rollout (`_train_pipelined`), with the feature statistics each
+        # update's own `evaluate_actions` would have seen taken from the merge snapshots.
+        self._overlap_beside_ppo = self._overlap and not self._needs_logp
         self._disc_stream = L.side_stream(self._device, "disc") if self._overlap else None
         self._in_overlap = False
         self._overlap_k = 0
         self._quirk_ready = None
         self._quirk_seq = None
         self._quirk_seq_merged = None
+        self._quirk_snap = None
+        self._quirk_snap_buf = None
+        self._quirk_item = 0
         # GAIL only: let round r's discriminator updates run behind round r+1's environment stepping
         # (`_train_pipelined`); off -> every round is completed before the next one starts
         self.pipeline_rounds = True
@@ -311,9 +318,14 @@ class AdversarialTrainer(abc.ABC):
         has_norm = pol.features_extractor.normalize is not None
         if not self._needs_logp and not (has_norm and pol.training):
             return None
-        if self._in_overlap:  # replayed later on the generator's stream (see `train`)
-            self._quirk_pending.append(list(sources))  # index views live in `_quirk_idx_dev` all round
-            return None
+        snapshot = None
+        if self._in_overlap:
+            if not self._needs_logp:  # replayed later on the generator's stream (see `train`)
+                self._quirk_pending.append(list(sources))  # index views live in `_quirk_idx_dev` all round
+                return None
+            if self._quirk_snap is not None:  # statistics after THIS item's update (already merged, in order)
+                snapshot = self._quirk_snap[self._quirk_item]
+                self._quirk_item += 1
         R = 2 * mb
         row = 0
         for table, idx, n in sources:
@@ -329,7 +341,7 @@ class AdversarialTrainer(abc.ABC):
                            L.ptr(self._pol_act), pol.act_dim, row, L.stream())
             row += n
         if self._needs_logp:
-            pol.log_prob_rows(self._pol_obs[:R], self._pol_act[:R], self._logp)
+            pol.log_prob_rows(self._pol_obs[:R], self._pol_act[:R], self._logp, norm_snapshot=snapshot)
             return self._logp
         pol.features_extractor.normalize.update_stats(self._pol_obs[:R])
         return None
@@ -368,10 +380,20 @@ class AdversarialTrainer(abc.ABC):
                 # policy feature-norm moments of every update's batch, then the updates themselves
                 drawn = [self._batch_sources(None, None) for _ in range(n)]
                 did = self._quirk_prepass(drawn)
-                self._quirk_ready = th.cuda.Event()
-                self._quirk_ready.record()
-                if after is not None:   # the updates themselves are held back (see `_train_pipelined`)
-                    th.cuda.current_stream().wait_event(after)
+                if self._needs_logp:
+                    # AIRL: the merge runs here, behind the PPO update, and leaves the statistics each
+                    # update's own forward pass sees (`_policy_pass`); the next rollout waits for it
+                    if after is not None:
+                        th.cuda.current_stream().wait_event(after)
+                    self._quirk_item = 0
+                    self._replay_policy_norm_updates(snapshots=did)
+                    self._quirk_ready = th.cuda.Event()
+                    self._quirk_ready.record()
+                else:
+                    self._quirk_ready = th.cuda.Event()
+                    self._quirk_ready.record()
+                    if after is not None:   # the updates themselves are held back (see `_train_pipelined`)
+                        th.cuda.current_stream().wait_event(after)
                 for k in range(n):
                     with networks.training(self.reward_train):
                         self._disc_update(None, None, self._stats_ring[k], drawn=drawn[k], quirk_done=did)
@@ -541,16 +563,23 @@ class AdversarialTrainer(abc.ABC):
         self._quirk_pending.append(("seq", n_items, stride, groups, 2 * mb, pol.obs_dim))
         return True
 
-    def _replay_policy_norm_updates(self) -> None:
-        """Deferred `_policy_pass` side effects, in order, on the current (generator) stream."""
+    def _replay_policy_norm_updates(self, snapshots: bool = False) -> None:
+        """Deferred `_policy_pass` side effects, in order, on the current stream. `snapshots`: also keep
+        the statistics after every single update (`_quirk_snap`, read by AIRL's `_policy_pass`)."""
         pol = self.policy
+        self._quirk_snap = None
         for item in self._quirk_pending:
             if isinstance(item, tuple) and item[0] == "seq":  # all updates of a round, one launch, in order
                 _, n_items, stride, groups, rows, ld = item
                 rn = pol.features_extractor.normalize
+                snap = None
+                if snapshots:
+                    if self._quirk_snap_buf is None or self._quirk_snap_buf.shape[0] != n_items:
+                        self._quirk_snap_buf = th.empty(n_items, 2, pol.obs_dim, device=self._device)
+                    snap = self._quirk_snap = self._quirk_snap_buf
                 L.call("ia_running_norm_merge_seq", L.ptr(self._quirk_seq_merged), n_items, stride, groups, rows,
                        pol.obs_dim, ld,
-                       L.ptr(rn.running_mean), L.ptr(rn.running_var), L.ptr(rn.count), L.stream())
+                       L.ptr(rn.running_mean), L.ptr(rn.running_var), L.ptr(rn.count), L.ptr(snap), L.stream())
                 continue
             if isinstance(item, tuple):  # (slab moments of the batch, rows, moment column count)
                 slot, rows, ld = item
@@ -578,7 +607,7 @@ class AdversarialTrainer(abc.ABC):
             self._train_pipelined(n_rounds)
             return
         for r in range(n_rounds):
-            if not self._overlap:
+            if not self._overlap_beside_ppo:
                 self.train_gen(self.gen_train_timesteps)
                 self._overlap_k = 0
                 self._finish_disc_round(self._disc_round())

@@ -198,7 +198,8 @@ __global__ __launch_bounds__(64) void rn_merge_kernel(const float* __restrict__ 
 __global__ __launch_bounds__(64) void rn_merge_seq_kernel(const float* __restrict__ ws_seq, int n_seq,
                                                           long long seq_stride, int nblocks, int bpg, int rpg, int R,
                                                           int D, int ws_ld, float* __restrict__ mean,
-                                                          float* __restrict__ var, const int32_t* __restrict__ count) {
+                                                          float* __restrict__ var, const int32_t* __restrict__ count,
+                                                          float* __restrict__ snapshots) {
   const int c = blockIdx.x, lane = threadIdx.x;
   int cnt = *count;
   float mc = mean[c], vc = var[c];
@@ -224,6 +225,10 @@ __global__ __launch_bounds__(64) void rn_merge_seq_kernel(const float* __restric
     rv = rv + delta * delta * fcount * fn / tot;
     vc = rv / tot;
     cnt += R;
+    if (snapshots != nullptr && lane == 0) {  // statistics as update k's own forward pass sees them
+      snapshots[((long long)k * 2 + 0) * D + c] = mc;
+      snapshots[((long long)k * 2 + 1) * D + c] = vc;
+    }
   }
   if (lane == 0) {
     mean[c] = mc;
@@ -713,12 +718,14 @@ int ia_running_norm_merge(const float* ws_all, int groups, int rows_per_group, i
 }
 
 int ia_running_norm_merge_seq(const float* ws_seq, int n_seq, int64_t seq_stride, int groups, int rows_per_group,
-                              int D, int ws_ld, float* mean, float* var, int32_t* count, void* stream) {
+                              int D, int ws_ld, float* mean, float* var, int32_t* count, float* snapshots,
+                              void* stream) {
   if (n_seq <= 0 || groups <= 0 || rows_per_group <= 0 || D <= 0 || ws_ld < D) return IA_ERR_ARG;
   const int bpg = cdiv(rows_per_group, RN_ROWS_PER_BLOCK);
   const int rows = groups * rows_per_group;
   hipLaunchKernelGGL(rn_merge_seq_kernel, dim3(D), dim3(64), 0, (hipStream_t)stream, ws_seq, n_seq,
-                     (long long)seq_stride, groups * bpg, bpg, rows_per_group, rows, D, ws_ld, mean, var, count);
+                     (long long)seq_stride, groups * bpg, bpg, rows_per_group, rows, D, ws_ld, mean, var, count,
+                     snapshots);
   IA_CHECK_LAUNCH();
   hipLaunchKernelGGL(rn_count_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, count, n_seq * rows);
   IA_CHECK_LAUNCH();

@@ -286,10 +286,18 @@ class ActorCriticPolicy:
                L.ptr(a), n, L.ptr(logp), L.ptr(vals), L.ptr(ent), L.stream())
         return vals.reshape(n, 1), logp, ent
 
-    def log_prob_rows(self, obs_dev: th.Tensor, acts_dev: th.Tensor, out: th.Tensor) -> None:
-        """log pi(a|s) for device rows (train-mode norm update included), no allocation."""
-        self._maybe_update_norm(obs_dev)
-        nm, nv = self._norm_ptrs()
+    def log_prob_rows(self, obs_dev: th.Tensor, acts_dev: th.Tensor, out: th.Tensor,
+                      norm_snapshot: Optional[th.Tensor] = None) -> None:
+        """log pi(a|s) for device rows (train-mode norm update included), no allocation.
+        `norm_snapshot` `[2, obs_dim]` (mean, var): normalise with these statistics and leave the live ones
+        alone -- the train-mode update this call would have made was already applied elsewhere
+        (`ia_running_norm_merge_seq` snapshots, pipelined AIRL rounds)."""
+        if norm_snapshot is None:
+            self._maybe_update_norm(obs_dev)
+            nm, nv = self._norm_ptrs()
+        else:
+            assert norm_snapshot.is_contiguous() and norm_snapshot.shape == (2, self.obs_dim)
+            nm, nv = norm_snapshot.data_ptr(), norm_snapshot.data_ptr() + 4 * self.obs_dim
         L.call("ia_policy_evaluate", C.byref(self.desc), L.ptr(self._flat), L.ptr(self._flat_t), nm, nv,
                L.ptr(obs_dev), L.ptr(acts_dev), obs_dev.shape[0], L.ptr(out), None, None, L.stream())
 

@@ -820,7 +820,7 @@ class PPO(OnPolicyAlgorithm):
             st = self._stats_dev.cpu().numpy()  # one synchronisation per train()
             err = 0 if self._upd_ws is None else int(self._upd_ws[8:9].view(th.int32).item())
             vals, rets = rb.val.cpu().numpy().reshape(-1), rb.ret.cpu().numpy().reshape(-1)
-            std = None if pol.discrete else float(th.exp(pol.log_std).mean().item())
+            std = None if pol.discrete else float(th.exp(pol.log_std.cpu()).mean().item())  # host exp, as on every schedule
         if err != 0:
             raise RuntimeError("ia_ppo_update: a grid-wide wait timed out inside the persistent PPO kernel; "
                                "the parameters of this update are invalid")

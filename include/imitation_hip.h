@@ -106,9 +106,12 @@ int ia_running_norm_merge(const float* ws_all, int groups, int rows_per_group, i
                           float* var, int32_t* count, void* stream);
 /* n_seq consecutive ia_running_norm_merge updates (`groups` x `rows_per_group` rows each, moments
  * `seq_stride` floats apart) in order, in one launch: the deferred policy feature-norm updates of a
- * round (adversarial/common.py:606-615 side effect). */
+ * round (adversarial/common.py:606-615 side effect). snapshots (nullable): float
+ * [n_seq][2][D], the (mean, var) after each update -- what update k's own `evaluate_actions` normalises
+ * with (util/networks.py:79-91: update, then normalise), for AIRL's log pi(a|s) (airl.py:99-119). */
 int ia_running_norm_merge_seq(const float* ws_seq, int n_seq, int64_t seq_stride, int groups, int rows_per_group,
-                              int D, int ws_ld, float* mean, float* var, int32_t* count, void* stream);
+                              int D, int ws_ld, float* mean, float* var, int32_t* count, float* snapshots,
+                              void* stream);
 /* util/networks.py:91: Y = (X-mean)/sqrt(var+eps); columns [D,ldy) of Y are zeroed. */
 int ia_running_norm_apply(const float* X, int ldx, int R, int D, const float* mean, const float* var, float eps,
                           float* Y, int ldy, void* stream);

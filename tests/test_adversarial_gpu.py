@@ -87,22 +87,25 @@ def _csv_rows(path):
     return [{k: v for k, v in r.items() if not k.startswith(("time/", "mean/gen/time/", "raw/gen/time/"))} for r in rows]
 
 
-def test_pipelined_rounds_are_bit_identical(tmp_path):
-    """Round r's discriminator updates run behind round r+1's environment stepping (GAIL). Every
-    array, every logged statistic and every row of every log file must equal the schedule that
-    completes each round before the next one starts."""
+@pytest.mark.parametrize("case", ["gail_box", "airl_box"])
+def test_pipelined_rounds_are_bit_identical(tmp_path, case):
+    """Round r's discriminator updates run behind round r+1's environment stepping (GAIL; AIRL with the
+    per-update feature statistics taken from the merge snapshots). Every array, every logged statistic
+    and every row of every log file must equal the schedule that completes each round before the next
+    one starts."""
     import glob
 
     import imitation_amd as p
 
     outs, logs = {}, {}
     for mode in (True, False):
-        cfg = harness.CASES["gail_box"]
+        cfg = harness.CASES[case]
         d = str(tmp_path / f"log_{mode}")
         tr, _ = harness.build_trainer("hip", cfg, d, device="cuda")
         tr._logger = p.configure_logger(d, ["csv"])
         tr.gen_algo.set_logger(tr.logger)
         tr.pipeline_rounds = mode
+        assert tr._overlap, "the overlapped schedules must be available for this case"
         tr.train(4 * cfg["n_envs"] * cfg["n_steps"])
         outs[mode] = harness.snapshot(tr)
         tr.logger.close()
