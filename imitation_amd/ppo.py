@@ -25,6 +25,7 @@ import numpy as np
 import torch as th
 
 from imitation_amd import _lib as L
+from imitation_amd.host_worker import HostWorker
 from imitation_amd import logger as imit_logger
 from imitation_amd import policies as pol_mod
 from imitation_amd import spaces
@@ -78,33 +79,6 @@ class _CallbackList(_NullCallback):
         for c in self.cbs: c.on_training_end()
 
 
-class _HostHelper:
-    """One persistent daemon thread for the GIL-free C helpers that run beside the rollout (no thread
-    creation per round). `submit(fn)` returns an event that is set when `fn()` has returned."""
-
-    _queue: Optional["queue.SimpleQueue"] = None
-
-    @classmethod
-    def submit(cls, fn) -> threading.Event:
-        if cls._queue is None:
-            import queue
-
-            cls._queue = queue.SimpleQueue()
-
-            def serve(q=cls._queue):
-                while True:
-                    job, done = q.get()
-                    try:
-                        job()
-                    finally:
-                        done.set()
-
-            threading.Thread(target=serve, daemon=True, name="imitation_amd-host-helper").start()
-        done = threading.Event()
-        cls._queue.put((fn, done))
-        return done
-
-
 class _PermutationPredraw:
     """Draws the `n_epochs` minibatch permutations of the NEXT PPO update while the rollout is
     still stepping the environments, on a private copy of the state of NumPy's global generator
@@ -147,7 +121,7 @@ class _PermutationPredraw:
             self._rc = lib.ia_host_mt19937_permutations(self._key.ctypes.data, C.byref(self._pos), self.size,
                                                         self.n_epochs, out.ctypes.data)
 
-        self._thread = _HostHelper.submit(work)
+        self._thread = HostWorker.named("permutations").submit(work)
 
     def finish(self, out: np.ndarray) -> bool:
         """True if `out` now holds the permutations and the global generator has advanced past them."""
@@ -183,7 +157,7 @@ class _SharedPermutations:
                                                                  out.ctypes.data)
 
         self._rc = 0
-        self._threads = [_HostHelper.submit(work)]
+        self._threads = [HostWorker.named("permutations").submit(work)]
         self.update += 1
 
     def finish(self) -> None:

@@ -16,6 +16,8 @@ when present and falls back to parsing `infos` otherwise.
 from __future__ import annotations
 
 import abc
+import os
+import weakref
 from typing import Any, Dict, List, Optional, Sequence, Tuple
 
 import numpy as np
@@ -94,6 +96,31 @@ class VecEnvWrapper(VecEnv):
         return getattr(self.venv, name)
 
 
+_ENV_NOISE_LIB: List[Any] = []
+
+
+def _env_noise_lib():
+    """ctypes handle of libimitation_envnoise.so (built next to libimitation_hip.so), or None."""
+    if not _ENV_NOISE_LIB:
+        import ctypes as C
+
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libimitation_envnoise.so")
+        lib = None
+        if os.path.exists(path):
+            lib = C.CDLL(path)
+            lib.ia_env_noise_create.argtypes, lib.ia_env_noise_create.restype = [], C.c_void_p
+            lib.ia_env_noise_post.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p]
+            lib.ia_env_noise_post.restype = C.c_int
+            lib.ia_env_noise_wait.argtypes, lib.ia_env_noise_wait.restype = [C.c_void_p], C.c_int
+            lib.ia_env_noise_destroy.argtypes, lib.ia_env_noise_destroy.restype = [C.c_void_p], None
+        _ENV_NOISE_LIB.append(lib)
+    return _ENV_NOISE_LIB[0]
+
+
+def _destroy_worker(lib, worker, *keep_alive) -> None:
+    lib.ia_env_noise_destroy(worker)
+
+
 class ArrayVecEnv(VecEnv):
     """VecEnv whose native step produces arrays; dict infos are derived from them."""
 
@@ -135,6 +162,7 @@ class SyntheticVecEnv(ArrayVecEnv):
         n_discrete: Optional[int] = None,
         stagger: bool = False,
         reward_scale: float = 0.0,
+        prefetch_noise: bool = True,
     ):
         obs_space = spaces.Box(-np.inf, np.inf, (obs_dim,), obs_dtype)
         if n_discrete is None:
@@ -155,26 +183,72 @@ class SyntheticVecEnv(ArrayVecEnv):
         self._stagger = stagger
         self._reward_scale = float(reward_scale)
         self._actions: Optional[np.ndarray] = None
+        # The generator draws of the NEXT step (process noise, then the fresh observations of the
+        # environments whose episode ends in it -- known in advance, the horizon is fixed) do not depend
+        # on the actions: a helper thread of libimitation_envnoise.so fills them through NumPy's own
+        # `random_standard_normal_fill` while the policy step of that transition runs on the device, as a
+        # subprocess env worker would overlap with the learner. Same stream, same order, same values as
+        # drawing inside the step (the helper is optional: without the library the step draws inline).
+        self._helper = _env_noise_lib() if (prefetch_noise and os.environ.get("IA_ENV_PREFETCH", "1") != "0") else None
+        self._xi = np.empty((num_envs, obs_dim), dtype=np.float64)
+        self._fresh_buf = np.empty((num_envs, obs_dim), dtype=np.float64)
+        self._pending = None  # (generator state before the draws, n_done)
+        self._worker = self._bitgen_addr = 0
+        if self._helper is not None:
+            self._bitgen_addr = int(self._rng.bit_generator.ctypes.bit_generator.value)
+            self._worker = self._helper.ia_env_noise_create()
+            # the worker may still be filling these buffers from this generator when the env goes away:
+            # the finaliser keeps them alive until the thread has been joined
+            weakref.finalize(self, _destroy_worker, self._helper, self._worker, self._rng, self._xi, self._fresh_buf)
 
     def _fresh(self, n: int) -> np.ndarray:
         return 0.1 * self._rng.standard_normal((n, self.obs_dim))
 
+    def _plan_next_draws(self) -> None:
+        if self._helper is None:
+            return
+        n_done = int(np.count_nonzero(self._t + 1 >= self.horizon))
+        state0 = self._rng.bit_generator.state
+        rc = self._helper.ia_env_noise_post(self._worker, self._bitgen_addr, self._xi.size, self._xi.ctypes.data,
+                                            n_done * self.obs_dim, self._fresh_buf.ctypes.data)
+        assert rc == 0, rc
+        self._pending = (state0, n_done)
+
+    def _collect_planned_draws(self):
+        """-> (xi, fresh or None) of the planned step; the buffers are reused by the next plan."""
+        _, n_done = self._pending
+        self._pending = None
+        rc = self._helper.ia_env_noise_wait(self._worker)
+        assert rc == 0, rc
+        return self._xi, (0.1 * self._fresh_buf[:n_done] if n_done else None), n_done
+
+    def _cancel_planned_draws(self) -> None:
+        """Back to the generator state in which nothing of the next step has been drawn."""
+        if self._pending is not None:
+            state0 = self._pending[0]
+            self._collect_planned_draws()
+            self._rng.bit_generator.state = state0
+
     def get_state(self):
         """Everything `step` depends on (used by `checkpoint.save_checkpoint`)."""
-        return {"rng": self._rng.bit_generator.state, "obs": self._obs.copy(), "t": self._t.copy()}
+        rng = self._pending[0] if self._pending is not None else self._rng.bit_generator.state
+        return {"rng": rng, "obs": self._obs.copy(), "t": self._t.copy()}
 
     def set_state(self, state) -> None:
+        self._cancel_planned_draws()
         self._rng.bit_generator.state = state["rng"]
         self._obs, self._t = state["obs"].copy(), state["t"].copy()
         self._actions = None
 
     def reset(self) -> np.ndarray:
+        self._cancel_planned_draws()
         self._obs = self._fresh(self.num_envs)
         self._t[:] = 0
         if self._stagger:
             # Desynchronise episode ends across envs (keeps a fixed horizon per episode
             # only when stagger=False; used by tests that want dones in every step).
             self._t[:] = self._rng.integers(0, self.horizon, self.num_envs)
+        self._plan_next_draws()
         return self._obs.astype(self.observation_space.dtype)
 
     def step_async(self, actions: np.ndarray) -> None:
@@ -188,17 +262,24 @@ class SyntheticVecEnv(ArrayVecEnv):
             a = self._table[np.asarray(a).reshape(-1).astype(np.int64)]
         a = a.reshape(self.num_envs, self.act_dim).astype(np.float64)
         nxt = 0.9 * self._obs + 0.1 * np.tanh(a @ self._W)
-        nxt += 0.05 * self._rng.standard_normal(nxt.shape)
+        fresh = None
+        if self._pending is not None:
+            xi, fresh, planned = self._collect_planned_draws()
+        else:
+            xi, planned = self._rng.standard_normal(nxt.shape), -1
+        nxt += 0.05 * xi
         self._t += 1
         dones = self._t >= self.horizon
         dt = self.observation_space.dtype
         next_fixed = nxt.astype(dt)
         n_done = int(dones.sum())
         if n_done:
-            nxt[dones] = self._fresh(n_done)
+            assert planned in (-1, n_done)
+            nxt[dones] = fresh if fresh is not None else self._fresh(n_done)
             self._t[dones] = 0
         self._obs = nxt
         obs = nxt.astype(dt)
+        self._plan_next_draws()
         if self._reward_scale:
             rews = (-self._reward_scale * (a * a).sum(axis=1)).astype(np.float32)
         else:
