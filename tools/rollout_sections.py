@@ -24,3 +24,14 @@ print(f"per rollout (16 steps), average over {rounds} rounds:")
 for k, v in sorted(prof.items(), key=lambda kv: -kv[1]):
     print(f"  {k:28s} {1e3 * v / rounds:7.3f} ms   {1e6 * v / rounds / cfg['n_steps']:7.1f} us/step")
 print(f"  {'sum':28s} {1e3 * tot / rounds:7.3f} ms")
+
+env = tr.venv  # helper-thread diagnostics of the synthetic env (if the prefetch helper is active)
+while not hasattr(env, "_worker") and hasattr(env, "venv"):
+    env = env.venv
+if getattr(env, "_worker", 0):
+    import ctypes as C
+    out = (C.c_int64 * 4)()
+    env._helper.ia_env_noise_stats.argtypes = [C.c_void_p, C.c_void_p]
+    env._helper.ia_env_noise_stats(env._worker, out)
+    print(f"  env noise helper: {out[0] / max(out[1], 1) / 1e3:.1f} us per fill over {out[1]} fills, helper on cpu {out[2]}, "
+          f"main thread on cpu {out[3]}")

@@ -40,11 +40,11 @@ def run(name, algo_name, n_envs, n_steps, od, ad, horizon, ppo_batch, n_epochs, 
              demo_minibatch_size=minib, venv=venv, gen_algo=algo, reward_net=net, n_disc_updates_per_round=n_disc,
              gen_replay_buffer_capacity=capacity, custom_logger=p.configure_logger(tempfile.mkdtemp(), []))
     per = n_envs * n_steps
-    tr.train(per)  # warm-up round
+    tr.train(3 * per)  # warm-up rounds (lazily created pinned buffers / streams appear during the first three)
     th.cuda.synchronize(); t0 = time.perf_counter()
     tr.train(rounds * per)   # (no hook on train_disc: an overridden train_disc switches round pipelining off)
     th.cuda.synchronize(); dt = time.perf_counter() - t0
-    ok = tr._disc_step == (rounds + 1) * n_disc
+    ok = tr._disc_step == (rounds + 3) * n_disc
     last = tr.train_disc()
     ok = ok and all(np.isfinite(v) for k, v in last.items())
     sd = tr.gen_algo.policy.state_dict()
