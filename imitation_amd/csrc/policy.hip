@@ -2109,6 +2109,8 @@ __global__ __launch_bounds__(512) void ppo_update_persistent_kernel(
         write_loss_stats(q, *reinterpret_cast<const volatile float*>(w.normcoef + (q % UPD_SD) * 2),
                          *reinterpret_cast<const volatile float*>(w.normcoef + (q % UPD_SD) * 2 + 1));
     };
+    long long sb_acc[3] = {0, 0, 0}, sb_prev = tstamp ? wall_clock64() : 0;
+#define SB_TS(k) do { if (tstamp && tid == 0) { const long long tn = wall_clock64(); sb_acc[k] += tn - sb_prev; sb_prev = tn; } } while (0)
     for (int s = 0; s < n_steps; ++s) {
       if (s >= UPD_RING) {  // the slot is free once every gradient block has arrived at barrier s - RING
         if (tid == 0) {
@@ -2117,7 +2119,9 @@ __global__ __launch_bounds__(512) void ppo_update_persistent_kernel(
         }
         __syncthreads();
         if (!s_ok) return;
+        SB_TS(0);
         drain(s - UPD_RING);  // barriers 0 .. s-RING complete => steps 0 .. s-RING-1 fully published
+        SB_TS(1);
       }
       const MbRows r = rows_of(s);
       float* slot = w.ring + (s % UPD_RING) * UPD_RS;
@@ -2179,7 +2183,10 @@ __global__ __launch_bounds__(512) void ppo_update_persistent_kernel(
         __threadfence();
         __hip_atomic_store(published, (unsigned)(s + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
+      SB_TS(2);
     }
+    if (tstamp && tid == 0) { tstamp[12] += sb_acc[0]; tstamp[13] += sb_acc[1]; tstamp[14] += sb_acc[2]; }
+#undef SB_TS
     if (tid == 0) {
       s_ok = spin_until(arrivals, (unsigned)n_steps * nblk, err);
       __threadfence();
@@ -2957,8 +2964,11 @@ int ia_ppo_update(const ia_policy_desc* d, float* params, float* params_t, float
     e = hipMemsetAsync(ws + 16, 0, (UPD_CTRL - 16) * sizeof(unsigned), st);  // per-slicer progress
     if (e != hipSuccess) return (int)e;
     // packing onto one XCD only works while all workgroups fit its 32 CUs (each takes a whole CU's LDS)
-    // minibatches beyond 1024 rows: their statistics are cut into UPD_SLICE-row slices, one extra block each
-    const int n_slices = (batch_size > 1024 && total < (1ll << 31)) ? cdiv(batch_size, UPD_SLICE) : 0;
+    // minibatches beyond UPD_SLICE rows: their statistics are cut into UPD_SLICE-row slices, one extra block
+    // each, merged in order by the statistics block. (One block needs 22 us for the gathered moments of a
+    // 1024-row minibatch -- as long as a whole gradient step, so the chain kept waiting 1-2 us per step for
+    // it; two slices + merge take ~14 us and the ring runs ahead again.)
+    const int n_slices = (batch_size > UPD_SLICE && total < (1ll << 31)) ? cdiv(batch_size, UPD_SLICE) : 0;
     const bool pack = g_upd_xcd_pack && nblk + 1 + n_slices <= 32;
     const int grid = (nblk + 1 + n_slices) * (pack ? 8 : 1);
     auto kernel = wide ? ppo_update_persistent_kernel<UPD_NPT_WIDE> : ppo_update_persistent_kernel<UPD_NPT>;

@@ -33,6 +33,10 @@ for rep in range(3):
     steps = algo.n_epochs * algo._n_mb
     ticks = buf.cpu().numpy()[:12]
     names = ("wait statistics", "minibatch fwd/bwd", "grid barrier", "park+sync", "slab reduce", "norm (block sum)", "stats+Adam", "release fence", "atomic add", "prefetch issue", "spin", "acquire fence")
+    sb = buf.cpu().numpy()[12:15]
+    print("statistics block per step: " + ", ".join(f"{n} {t_ / 100.0 / steps:.2f} us" for n, t_ in
+                                                      zip(("wait for a free ring slot", "loss statistics of finished steps",
+                                                           "minibatch statistics + publish"), sb)))
     print(f"xcd_pack={pack}: train() {1e3 * d:.2f} ms for {steps} steps; per step: " +
           ", ".join(f"{n} {t_ / 100.0 / steps:.2f} us" for n, t_ in zip(names, ticks)))
 t = buf.cpu().numpy()[16:28]
