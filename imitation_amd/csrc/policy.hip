@@ -383,13 +383,10 @@ __device__ __forceinline__ float block_sum(float v, float* red /*>=17 floats*/) 
   __syncthreads();
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
   __syncthreads();
-  if (threadIdx.x == 0) {
-    float t = 0.f;
-    for (int k = 0; k < NT / 64; ++k) t += red[k];
-    red[16] = t;
-  }
-  __syncthreads();
-  return red[16];
+  float t = 0.f;  // every thread adds the wave sums in the same order: same value everywhere, no third barrier
+#pragma unroll
+  for (int k = 0; k < NT / 64; ++k) t += red[k];
+  return t;
 }
 __device__ __forceinline__ float block_sum_1024(float v, float* red) { return block_sum<1024>(v, red); }
 
