@@ -179,12 +179,23 @@ class AdversarialTrainer(abc.ABC):
         self._quirk_ready = None
         self._quirk_seq = None
         self._quirk_seq_merged = None
+        self._disc_t0 = None
+        self._disc_timing = None
         self._quirk_snap = None
         self._quirk_snap_buf = None
         self._quirk_item = 0
         # GAIL only: let round r's discriminator updates run behind round r+1's environment stepping
         # (`_train_pipelined`); off -> every round is completed before the next one starts
         self.pipeline_rounds = True
+        # GAIL, pipelined rounds: True = hold the discriminator updates of round r back until PPO r has
+        # finished (they then run behind rollout r+1 and the latency-bound PPO chain has the device to
+        # itself); False = start them beside PPO r (it gets ~10 % slower, but nothing waits for them at the
+        # end of a short rollout); None = decide per round from measurements: behind while the updates fit
+        # into the rollout's host time, beside otherwise. Pure scheduling: values are identical either way.
+        # AIRL's updates read the updated policy and always wait.
+        self.disc_behind_ppo: Optional[bool] = None
+        self._disc_ms_behind = None   # device time of a round's updates, measured while they ran alone
+        self._disc_mode_behind = True
         self._quirk_pending = []
         self._quirk_slots = []
 
@@ -394,6 +405,8 @@ class AdversarialTrainer(abc.ABC):
                     self._quirk_ready.record()
                     if after is not None:   # the updates themselves are held back (see `_train_pipelined`)
                         th.cuda.current_stream().wait_event(after)
+                    self._disc_t0 = th.cuda.Event(enable_timing=True)
+                    self._disc_t0.record()
                 for k in range(n):
                     with networks.training(self.reward_train):
                         self._disc_update(None, None, self._stats_ring[k], drawn=drawn[k], quirk_done=did)
@@ -630,6 +643,21 @@ class AdversarialTrainer(abc.ABC):
                 callback(r)
             self.logger.dump(self._global_step)
 
+    def _choose_disc_behind_ppo(self) -> bool:
+        if self._needs_logp:
+            return True
+        if self.disc_behind_ppo is not None:
+            return bool(self.disc_behind_ppo)
+        t = getattr(self, "_disc_timing", None)
+        if t is not None and t[0] is not None and t[2] and t[1].query():  # a finished round measured while alone
+            self._disc_ms_behind = t[0].elapsed_time(t[1])
+        window = self.gen_algo.rollout_window_ms
+        if self._disc_ms_behind is not None and window is not None:
+            # hysteresis: switching costs nothing, but do not flap around the break-even point
+            fits = self._disc_ms_behind < (0.95 if self._disc_mode_behind else 0.8) * window
+            self._disc_mode_behind = fits
+        return self._disc_mode_behind
+
     def _train_pipelined(self, n_rounds: int) -> None:
         """GAIL rounds with the discriminator updates of round r running BEHIND the environment stepping
         of round r+1 (the GPU is almost idle while the host steps the environments):
@@ -679,9 +707,11 @@ class AdversarialTrainer(abc.ABC):
                     # ring store and moment pre-pass run beside the PPO update; the 16 updates wait for it,
                     # so they execute while the host steps the environments of the next round instead of
                     # competing with the latency-bound PPO chain for the memory system
-                    pend = self._disc_round(prepass=True, after=ppo_done)
-                    done = th.cuda.Event()
+                    behind = self._choose_disc_behind_ppo()
+                    pend = self._disc_round(prepass=True, after=ppo_done if behind else None)
+                    done = th.cuda.Event(enable_timing=True)
                     done.record()
+                    self._disc_timing = (self._disc_t0, done, behind)
                 main.wait_event(self._quirk_ready)
                 self._replay_policy_norm_updates()                 # behind the PPO update, ahead of the next rollout
                 train_rec, algo._pending_train = algo._pending_train, None

@@ -28,8 +28,12 @@ namespace {
 struct Worker {
   std::atomic<int> state{0};  // 0 idle, 1 job posted, 2 job done, 3 exit requested
   bitgen_t* bg = nullptr;
-  int64_t n_a = 0, n_b = 0;
+  // a job = n_steps consecutive env steps: step j draws a[j*stride .. +n_a) and then b[j*stride .. +n_b[j])
+  int n_steps = 0;
+  int64_t n_a = 0, stride = 0;
+  const int64_t* n_b = nullptr;
   double *a = nullptr, *b = nullptr;
+  std::atomic<int> steps_done{0};  // of the current job
   std::mutex m;
   std::condition_variable cv;
   std::thread th;
@@ -58,8 +62,11 @@ struct Worker {
       }
       if (s == 3) return;
       const auto f0 = std::chrono::steady_clock::now();
-      random_standard_normal_fill(bg, (intptr_t)n_a, a);               // process noise first ...
-      if (n_b > 0) random_standard_normal_fill(bg, (intptr_t)n_b, b);  // ... then the reset observations
+      for (int j = 0; j < n_steps; ++j) {
+        random_standard_normal_fill(bg, (intptr_t)n_a, a + j * stride);                      // process noise first ...
+        if (n_b[j] > 0) random_standard_normal_fill(bg, (intptr_t)n_b[j], b + j * stride);  // ... then the reset observations
+        steps_done.store(j + 1, std::memory_order_release);
+      }
       fill_ns += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - f0).count();
       ++fills;
       cpu = sched_getcpu();
@@ -126,24 +133,35 @@ extern "C" void* ia_env_noise_create(void) {
   return w;
 }
 
-// Post one job: a[0..n_a) then b[0..n_b) from generator `bitgen` (address of its bitgen_t). One job at a
-// time; the caller must not touch the generator or the buffers until ia_env_noise_wait() has returned.
-extern "C" int ia_env_noise_post(void* handle, void* bitgen, int64_t n_a, double* a, int64_t n_b, double* b) {
+// Post one job of n_steps env steps: step j fills a[j*stride .. +n_a) and then b[j*stride .. +n_b[j]) from
+// generator `bitgen` (address of its bitgen_t), in that order. One job at a time; the caller must not touch
+// the generator, the buffers or n_b until ia_env_noise_finish() has returned.
+extern "C" int ia_env_noise_post(void* handle, void* bitgen, int n_steps, int64_t n_a, int64_t stride, double* a,
+                                 const int64_t* n_b, double* b) {
   Worker* w = static_cast<Worker*>(handle);
-  if (w == nullptr || bitgen == nullptr || n_a < 0 || n_b < 0 || (n_a > 0 && a == nullptr) ||
-      (n_b > 0 && b == nullptr))
+  if (w == nullptr || bitgen == nullptr || n_steps <= 0 || n_a < 0 || stride < n_a || a == nullptr ||
+      n_b == nullptr || b == nullptr)
     return 1;
   if (w->state.load(std::memory_order_acquire) != 0) return 2;  // previous job not collected
   const int cpu = sched_getcpu();
   if (cpu >= 0 && cpu != w->main_cpu) place_near(w, cpu);
   w->bg = static_cast<bitgen_t*>(bitgen);
-  w->n_a = n_a; w->a = a; w->n_b = n_b; w->b = b;
+  w->n_steps = n_steps; w->n_a = n_a; w->stride = stride; w->a = a; w->n_b = n_b; w->b = b;
+  w->steps_done.store(0, std::memory_order_release);
   w->signal(1);
   return 0;
 }
 
-// Blocks (spinning: the fill is normally finished already) until the posted job is done.
-extern "C" int ia_env_noise_wait(void* handle) {
+// Blocks (spinning: the fill is normally finished already) until step j of the posted job has been drawn.
+extern "C" int ia_env_noise_wait_step(void* handle, int j) {
+  Worker* w = static_cast<Worker*>(handle);
+  if (w == nullptr || w->state.load(std::memory_order_acquire) == 0 || j < 0 || j >= w->n_steps) return 1;
+  while (w->steps_done.load(std::memory_order_acquire) <= j) __builtin_ia32_pause();
+  return 0;
+}
+
+// Blocks until the whole posted job is done and marks the worker idle again.
+extern "C" int ia_env_noise_finish(void* handle) {
   Worker* w = static_cast<Worker*>(handle);
   if (w == nullptr || w->state.load(std::memory_order_acquire) == 0) return 1;  // nothing posted
   while (w->state.load(std::memory_order_acquire) != 2) __builtin_ia32_pause();
@@ -155,7 +173,7 @@ extern "C" int ia_env_noise_wait(void* handle) {
 extern "C" void ia_env_noise_destroy(void* handle) {
   Worker* w = static_cast<Worker*>(handle);
   if (w == nullptr) return;
-  if (w->state.load(std::memory_order_acquire) != 0) ia_env_noise_wait(handle);
+  if (w->state.load(std::memory_order_acquire) != 0) ia_env_noise_finish(handle);
   w->signal(3);
   w->th.join();
   delete w;

@@ -330,6 +330,7 @@ class PPO(OnPolicyAlgorithm):
         self.after_enqueue = None
         self._post_enqueue_work = []
         self._act_stream = None
+        self.rollout_window_ms = None
         self.rollout_profile = None
         self._dp_obs = th.zeros(min(self.batch_size, total), p.obs_dim, device=self.device)
         self._dp_ws_pre = None
@@ -467,6 +468,8 @@ class PPO(OnPolicyAlgorithm):
                 fused_net = owner
         T, n = rb.buffer_size, rb.n_envs
         assert n_rollout_steps == T
+        if hasattr(base, "set_lookahead"):  # host env that can draw its noise one rollout ahead (SyntheticVecEnv)
+            base.set_lookahead(T)
         if self._dp_global():
             self._dpg["perms"].start(self._dpg["perm_np"])   # shared across ranks; consumed by the next train()
         else:
@@ -501,6 +504,8 @@ class PPO(OnPolicyAlgorithm):
             act_step(t)
             t2 = tick() if prof is not None else 0.0
             act_stream.synchronize()       # (so everything the act kernels wrote is complete before `stream` reads it)
+            if t == 0:
+                t_first_step = tick()      # the previous update has finished: the device is free from here on
             t3 = tick() if prof is not None else 0.0
             acts_np = h_clip_np[t]
             acts_np = acts_np.reshape(n).astype(np.int64) if pol.discrete else acts_np.reshape(
@@ -540,6 +545,9 @@ class PPO(OnPolicyAlgorithm):
         for d, h in ((rb.obs, rb.h_obs), (rb.clipped, rb.h_clip), (rb.next_fixed, rb.h_next), (rb.dones, rb.h_dones),
                      (rb.trunc, rb.h_trunc), (rb.starts, rb.h_starts), (rb.last_done, rb.h_last_done)):
             d.copy_(h, non_blocking=True)
+        # host time the device had to itself for other streams' work during this rollout (see
+        # `AdversarialTrainer._train_pipelined`: where the discriminator updates are scheduled)
+        self.rollout_window_ms = 1e3 * (tick() - t_first_step)
         if self.before_relabel is not None:
             self.before_relabel()
         if fused_net is not None:  # discriminator reward relabelling on the whole [T, n] tile

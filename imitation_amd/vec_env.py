@@ -109,9 +109,11 @@ def _env_noise_lib():
         if os.path.exists(path):
             lib = C.CDLL(path)
             lib.ia_env_noise_create.argtypes, lib.ia_env_noise_create.restype = [], C.c_void_p
-            lib.ia_env_noise_post.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p]
+            lib.ia_env_noise_post.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_int64, C.c_void_p,
+                                              C.c_void_p, C.c_void_p]
             lib.ia_env_noise_post.restype = C.c_int
-            lib.ia_env_noise_wait.argtypes, lib.ia_env_noise_wait.restype = [C.c_void_p], C.c_int
+            lib.ia_env_noise_wait_step.argtypes, lib.ia_env_noise_wait_step.restype = [C.c_void_p, C.c_int], C.c_int
+            lib.ia_env_noise_finish.argtypes, lib.ia_env_noise_finish.restype = [C.c_void_p], C.c_int
             lib.ia_env_noise_destroy.argtypes, lib.ia_env_noise_destroy.restype = [C.c_void_p], None
         _ENV_NOISE_LIB.append(lib)
     return _ENV_NOISE_LIB[0]
@@ -183,55 +185,98 @@ class SyntheticVecEnv(ArrayVecEnv):
         self._stagger = stagger
         self._reward_scale = float(reward_scale)
         self._actions: Optional[np.ndarray] = None
-        # The generator draws of the NEXT step (process noise, then the fresh observations of the
-        # environments whose episode ends in it -- known in advance, the horizon is fixed) do not depend
-        # on the actions: a helper thread of libimitation_envnoise.so fills them through NumPy's own
-        # `random_standard_normal_fill` while the policy step of that transition runs on the device, as a
-        # subprocess env worker would overlap with the learner. Same stream, same order, same values as
-        # drawing inside the step (the helper is optional: without the library the step draws inline).
+        # The generator draws of the NEXT steps (process noise, then the fresh observations of the
+        # environments whose episode ends in that step -- known in advance, the horizon is fixed) do not
+        # depend on the actions: a helper thread of libimitation_envnoise.so fills them through NumPy's
+        # own `random_standard_normal_fill`, `lookahead` steps per job, while the learner is busy (the
+        # policy step of a transition, or -- with `lookahead` = rollout length, set by `PPO` -- the whole
+        # generator update between two rollouts), as subprocess env workers would overlap with the
+        # learner. Same stream, same order, same values as drawing inside the step (the helper is
+        # optional: without the library the step draws inline).
         self._helper = _env_noise_lib() if (prefetch_noise and os.environ.get("IA_ENV_PREFETCH", "1") != "0") else None
-        self._xi = np.empty((num_envs, obs_dim), dtype=np.float64)
-        self._fresh_buf = np.empty((num_envs, obs_dim), dtype=np.float64)
-        self._pending = None  # (generator state before the draws, n_done)
+        self.lookahead = 1   # env steps per helper job (buffers grow on demand)
+        self._xi = self._fresh_buf = self._n_fresh = None
+        self._pending = None  # [generator state before the job's draws, n_done per step, steps consumed]
         self._worker = self._bitgen_addr = 0
         if self._helper is not None:
             self._bitgen_addr = int(self._rng.bit_generator.ctypes.bit_generator.value)
             self._worker = self._helper.ia_env_noise_create()
-            # the worker may still be filling these buffers from this generator when the env goes away:
-            # the finaliser keeps them alive until the thread has been joined
-            weakref.finalize(self, _destroy_worker, self._helper, self._worker, self._rng, self._xi, self._fresh_buf)
+            # the worker may still be drawing from this generator into the job buffers when the env goes
+            # away: the finaliser keeps both alive until the thread has been joined
+            self._keep = []
+            weakref.finalize(self, _destroy_worker, self._helper, self._worker, self._rng, self._keep)
 
     def _fresh(self, n: int) -> np.ndarray:
         return 0.1 * self._rng.standard_normal((n, self.obs_dim))
 
     def _plan_next_draws(self) -> None:
-        if self._helper is None:
+        """Posts the draws of the next `lookahead` steps (only when no job is outstanding)."""
+        if self._helper is None or self._pending is not None:
             return
-        n_done = int(np.count_nonzero(self._t + 1 >= self.horizon))
+        K, n, D = max(1, int(self.lookahead)), self.num_envs, self.obs_dim
+        if self._xi is None or self._xi.shape[0] != K:
+            self._xi, self._fresh_buf = np.empty((K, n, D)), np.empty((K, n, D))
+            self._n_fresh = np.zeros(K, dtype=np.int64)
+            self._keep[:] = [self._xi, self._fresh_buf, self._n_fresh]
+        t = self._t.copy()
+        n_done = []
+        for j in range(K):  # episode ends of the next K steps (fixed horizon: independent of the actions)
+            t += 1
+            ends = t >= self.horizon
+            n_done.append(int(np.count_nonzero(ends)))
+            t[ends] = 0
+        self._n_fresh[:] = np.asarray(n_done) * D
         state0 = self._rng.bit_generator.state
-        rc = self._helper.ia_env_noise_post(self._worker, self._bitgen_addr, self._xi.size, self._xi.ctypes.data,
-                                            n_done * self.obs_dim, self._fresh_buf.ctypes.data)
+        rc = self._helper.ia_env_noise_post(self._worker, self._bitgen_addr, K, n * D, n * D, self._xi.ctypes.data,
+                                            self._n_fresh.ctypes.data, self._fresh_buf.ctypes.data)
         assert rc == 0, rc
-        self._pending = (state0, n_done)
+        self._pending = [state0, n_done, 0]
 
-    def _collect_planned_draws(self):
-        """-> (xi, fresh or None) of the planned step; the buffers are reused by the next plan."""
-        _, n_done = self._pending
-        self._pending = None
-        rc = self._helper.ia_env_noise_wait(self._worker)
+    def set_lookahead(self, steps: int) -> None:
+        """Draw-ahead horizon = the learner's rollout length: the job that is posted at the end of a
+        rollout's last step then covers exactly the next rollout and is filled during the generator
+        update in between. Re-plans from the current position."""
+        if int(steps) != self.lookahead:
+            self._cancel_planned_draws()
+            self.lookahead = int(steps)
+            self._plan_next_draws()
+
+    def _take_planned_draws(self):
+        """-> (xi, fresh or None, n_done) of the next step of the outstanding job."""
+        _, n_done, j = self._pending
+        rc = self._helper.ia_env_noise_wait_step(self._worker, j)
         assert rc == 0, rc
-        return self._xi, (0.1 * self._fresh_buf[:n_done] if n_done else None), n_done
+        out = (self._xi[j], (0.1 * self._fresh_buf[j, :n_done[j]] if n_done[j] else None), n_done[j])
+        self._pending[2] = j + 1
+        if j + 1 == len(n_done):   # job used up (the views above stay valid until the next post)
+            rc = self._helper.ia_env_noise_finish(self._worker)
+            assert rc == 0, rc
+            self._pending = None
+        return out
+
+    def _state_at_cursor(self):
+        """Generator state as if exactly the consumed steps of the outstanding job had been drawn."""
+        state0, n_done, used = self._pending
+        g = np.random.Generator(type(self._rng.bit_generator)())
+        g.bit_generator.state = state0
+        for j in range(used):
+            g.standard_normal((self.num_envs, self.obs_dim))
+            if n_done[j]:
+                g.standard_normal((n_done[j], self.obs_dim))
+        return g.bit_generator.state
 
     def _cancel_planned_draws(self) -> None:
-        """Back to the generator state in which nothing of the next step has been drawn."""
+        """Drops the draws that were made ahead: the generator is back where inline draws would have left it."""
         if self._pending is not None:
-            state0 = self._pending[0]
-            self._collect_planned_draws()
-            self._rng.bit_generator.state = state0
+            cursor = self._state_at_cursor()
+            rc = self._helper.ia_env_noise_finish(self._worker)
+            assert rc == 0, rc
+            self._rng.bit_generator.state = cursor
+            self._pending = None
 
     def get_state(self):
         """Everything `step` depends on (used by `checkpoint.save_checkpoint`)."""
-        rng = self._pending[0] if self._pending is not None else self._rng.bit_generator.state
+        rng = self._state_at_cursor() if self._pending is not None else self._rng.bit_generator.state
         return {"rng": rng, "obs": self._obs.copy(), "t": self._t.copy()}
 
     def set_state(self, state) -> None:
@@ -264,7 +309,7 @@ class SyntheticVecEnv(ArrayVecEnv):
         nxt = 0.9 * self._obs + 0.1 * np.tanh(a @ self._W)
         fresh = None
         if self._pending is not None:
-            xi, fresh, planned = self._collect_planned_draws()
+            xi, fresh, planned = self._take_planned_draws()
         else:
             xi, planned = self._rng.standard_normal(nxt.shape), -1
         nxt += 0.05 * xi
