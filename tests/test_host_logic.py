@@ -288,3 +288,60 @@ def test_host_mt19937_seeded_permutations_bit_exact(n, count, seed_len):
     assert L.load().ia_host_mt19937_seeded_permutations(seeds.ctypes.data, seed_len, n, count, out.ctypes.data) == 0
     for c in range(count):
         assert np.array_equal(out[c], np.random.RandomState(seeds[c]).permutation(n))
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(stagger=True, horizon=13), dict(horizon=7)])
+@pytest.mark.parametrize("lookahead", [1, 5, 16])
+def test_env_draw_ahead_is_value_identical(kw, lookahead):
+    """`SyntheticVecEnv` draws the next steps' generator noise on a helper thread (one step or a whole
+    rollout ahead): observations, successor observations and dones must equal the inline draws, across
+    episode ends, `reset()`, a `get_state`/`set_state` round trip mid-job and a change of the horizon."""
+    from imitation_amd import vec_env
+
+    if vec_env._env_noise_lib() is None:
+        pytest.skip("libimitation_envnoise.so not built")
+
+    def run(prefetch):
+        env = SyntheticVecEnv(64, 17, 6, kw.get("horizon", 1000), 0, stagger=kw.get("stagger", False),
+                              prefetch_noise=prefetch)
+        assert (env._helper is not None) == prefetch
+        if prefetch:
+            env.set_lookahead(lookahead)
+        out = [env.reset()]
+        rng = np.random.default_rng(5)
+        for i in range(60):
+            env.step_async(rng.uniform(-1, 1, (64, 6)).astype(np.float32))
+            o = env.step_wait_arrays()
+            out += [o[0], o[3], o[2]]
+            if i in (20, 27):
+                st = env.get_state()
+                if i == 27:
+                    env.set_state(st)
+            if i == 33:
+                out.append(env.reset())
+            if i == 45 and prefetch:
+                env.set_lookahead(3)
+        return out
+
+    a, b = run(True), run(False)
+    assert len(a) == len(b) and all(np.array_equal(x, y) for x, y in zip(a, b))
+
+
+def test_env_state_mid_job_continues_in_another_env():
+    """`get_state()` taken while a multi-step draw-ahead job is partly consumed restores, in an env
+    without the helper, exactly the continuation (what `checkpoint.save_checkpoint` relies on)."""
+    e1 = SyntheticVecEnv(32, 5, 3, 9, 1)
+    e1.set_lookahead(8)
+    e1.reset()
+    acts = np.zeros((32, 3), np.float32)
+    for _ in range(5):
+        e1.step_async(acts)
+        e1.step_wait_arrays()
+    st = e1.get_state()
+    e2 = SyntheticVecEnv(32, 5, 3, 9, 7, prefetch_noise=False)
+    e2.reset()
+    e2.set_state(st)
+    for _ in range(20):
+        e1.step_async(acts)
+        e2.step_async(acts)
+        assert all(np.array_equal(x, y) for x, y in zip(e1.step_wait_arrays(), e2.step_wait_arrays()))
