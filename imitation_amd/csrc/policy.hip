@@ -1451,17 +1451,19 @@ __device__ __forceinline__ void mfma32_minibatch_chain(
   for (int a = 0; a < MAXA; ++a) r_act[a] = 0.f;
   if (loss_lane) {
     if (tw == 0) {
-      const long long src = valid ? (long long)__float_as_int(stg[UpdStage::src + lrow]) : 0;
+      const int src_raw = __float_as_int(stg[UpdStage::src + lrow]);   // (unconditional read, masked afterwards)
+      const long long src = valid ? (long long)src_raw : 0;
       r_oldlp = stg[UpdStage::oldlp + lrow];
       r_adv = stg[UpdStage::adv + lrow];
 #pragma unroll
-      for (int a = 0; a < MAXA; ++a)
-        if (a < aw) r_act[a] = actions[src * aw + a];   // consumed after three layers: latency hidden
+      for (int a = 0; a < MAXA; ++a)   // unconditional, clamped (same cache line); consumed after three layers
+        r_act[a] = actions[src * aw + min(a, aw - 1)];
     } else {
       r_ret = stg[UpdStage::ret + lrow];
     }
   }
 
+  IA_TS(9);
   // ---- stage this wave's 16 feature rows (normalised) into the x tile; clear its rows of the small tiles
   {
     const int rbase = q * 16;
@@ -1497,17 +1499,25 @@ __device__ __forceinline__ void mfma32_minibatch_chain(
       for (int e = lane; e < 16 * L::MS; e += 64) lds[L::misc + rbase * L::MS + e] = 0.f;
     }
   }
-  // weight fragments (LDS -> VGPR): B[k = 4s+lk][j = c*16+li]
+  IA_TS(10);
+  // weight fragments (LDS -> VGPR): B[k = 4s+lk][j = c*16+li]. ALL reads first -- unconditional, at clamped
+  // addresses, grouped behind at most four wave-uniform branches -- then the masks: a guarded read (or a
+  // select right behind its read) costs a branch and a full `lgkmcnt(0)` wait each, which made these ~70
+  // reads a chain of ~50 serial LDS round trips.
   float bW1[16][2], bW2[8][2], bW2o[8][2], bHead[8], bDa2[4][2], b1v[2], b2v[2], cwv[2];
 #pragma unroll
-  for (int s = 0; s < 16; ++s) {
-    const int kk = 4 * s + lk;
-    bW1[s][0] = bW1[s][1] = 0.f;
-    if (s < S1) {
+  for (int g = 0; g < 4; ++g) {
+    if (4 * g < S1) {
 #pragma unroll
-      for (int c = 0; c < 2; ++c) bW1[s][c] = kk < D ? sPt[oW1 + kk * H + c * 16 + li] : 0.f;
+      for (int s = 4 * g; s < 4 * g + 4; ++s)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) bW1[s][c] = sPt[oW1 + min(4 * s + lk, D - 1) * H + c * 16 + li];
+    } else {
+#pragma unroll
+      for (int s = 4 * g; s < 4 * g + 4; ++s) bW1[s][0] = bW1[s][1] = 0.f;
     }
   }
+  const int head_base = tw == 0 ? o.aW + min(li, A - 1) * H : o.cW;
 #pragma unroll
   for (int s = 0; s < 8; ++s) {
     const int kk = 4 * s + lk;
@@ -1516,34 +1526,53 @@ __device__ __forceinline__ void mfma32_minibatch_chain(
       bW2[s][c] = sPt[oW2 + kk * H + c * 16 + li];
       bW2o[s][c] = sP[oW2 + kk * H + c * 16 + li];
     }
-    bHead[s] = tw == 0 ? (li < A ? sP[o.aW + li * H + kk] : 0.f) : (li == 0 ? sP[o.cW + kk] : 0.f);
+    bHead[s] = sP[head_base + kk];
   }
 #pragma unroll
-  for (int s = 0; s < 4; ++s) {
-    const int aa = 4 * s + lk;
+  for (int s = 0; s < 4; ++s)
 #pragma unroll
-    for (int c = 0; c < 2; ++c) bDa2[s][c] = (tw == 0 && aa < A) ? sP[o.aW + aa * H + c * 16 + li] : 0.f;
-  }
+    for (int c = 0; c < 2; ++c) bDa2[s][c] = sP[o.aW + min(4 * s + lk, A - 1) * H + c * 16 + li];
 #pragma unroll
   for (int c = 0; c < 2; ++c) {
     b1v[c] = sP[ob1 + c * 16 + li];
     b2v[c] = sP[ob2 + c * 16 + li];
     cwv[c] = sP[o.cW + c * 16 + li];
   }
-  const float head_bias = tw == 0 ? (li < A ? sP[o.ab + li] : 0.f) : sP[o.cb];
-  // per-action Gaussian constants; the reciprocal variance turns the ~3 IEEE divisions per action and
-  // row of the loss into multiplications (<= 1 ulp away from dividing)
-  float c_ivar[MAXA], c_logsd[MAXA];
+  float head_bias = sP[tw == 0 ? o.ab + min(li, A - 1) : o.cb];
+  float my_sd = sP[o.log_std + min(lane, A - 1)];
+  __builtin_amdgcn_sched_barrier(0);   // every read above is issued before the first value is touched
 #pragma unroll
-  for (int a = 0; a < MAXA; ++a) {
-    c_ivar[a] = 1.f;
-    c_logsd[a] = 0.f;
-    if (tw == 0 && !d.discrete && a < A) {
-      const float sd = expf(sP[o.log_std + a]);
-      c_ivar[a] = 1.f / (sd * sd);
-      c_logsd[a] = logf(sd);
+  for (int s = 0; s < 16; ++s)
+#pragma unroll
+    for (int c = 0; c < 2; ++c) bW1[s][c] = (4 * s + lk < D) ? bW1[s][c] : 0.f;
+  {
+    const bool head_on = tw == 0 ? li < A : li == 0;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) bHead[s] = head_on ? bHead[s] : 0.f;
+  }
+#pragma unroll
+  for (int s = 0; s < 4; ++s)
+#pragma unroll
+    for (int c = 0; c < 2; ++c) bDa2[s][c] = (tw == 0 && 4 * s + lk < A) ? bDa2[s][c] : 0.f;
+  head_bias = (tw == 0 && li >= A) ? 0.f : head_bias;
+  // per-action Gaussian constants; the reciprocal variance turns the ~3 IEEE divisions per action and
+  // row of the loss into multiplications (<= 1 ulp away from dividing). Lane a computes action a's pair
+  // once (exp, division, log); every lane then picks the MAXA pairs up from the wave.
+  float c_ivar[MAXA], c_logsd[MAXA];
+  {
+    float my_ivar = 1.f, my_logsd = 0.f;
+    if (tw == 0 && !d.discrete) {
+      const float sd = expf(my_sd);
+      my_ivar = lane < A ? 1.f / (sd * sd) : 1.f;
+      my_logsd = lane < A ? logf(sd) : 0.f;
+    }
+#pragma unroll
+    for (int a = 0; a < MAXA; ++a) {
+      c_ivar[a] = __shfl(my_ivar, a, 64);
+      c_logsd[a] = __shfl(my_logsd, a, 64);
     }
   }
+  IA_TS(11);
   // the x rows of this wave were written by the two waves (tower 0 / tower 1) that share q
   __syncthreads();
   IA_TS(1);
@@ -1556,12 +1585,20 @@ __device__ __forceinline__ void mfma32_minibatch_chain(
   // ---- a1 = tanh(x W1^T + b1)
   {
     f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    // A fragments in batches of four k-steps (one wave-uniform branch and one LDS wait per batch instead of
+    // one per k-step); columns >= D of the x tile are zero
 #pragma unroll
-    for (int s = 0; s < 16; ++s)
-      if (s < S1) {
-        const float a = lds[L::x + arow * L::XS + 4 * s + lk];
-        acc[0] = mfma16(a, bW1[s][0], acc[0]);
-        acc[1] = mfma16(a, bW1[s][1], acc[1]);
+    for (int g = 0; g < 4; ++g)
+      if (4 * g < S1) {
+        float xa[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) xa[u] = lds[L::x + arow * L::XS + 4 * (4 * g + u) + lk];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          acc[0] = mfma16(xa[u], bW1[4 * g + u][0], acc[0]);
+          acc[1] = mfma16(xa[u], bW1[4 * g + u][1], acc[1]);
+        }
       }
 #pragma unroll
     for (int c = 0; c < 2; ++c)
@@ -1573,11 +1610,14 @@ __device__ __forceinline__ void mfma32_minibatch_chain(
   // ---- a2 = tanh(a1 W2^T + b2)
   {
     f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    float aa[8];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) aa[s] = a1t[arow * L::HS + 4 * s + lk];
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int s = 0; s < 8; ++s) {
-      const float a = a1t[arow * L::HS + 4 * s + lk];
-      acc[0] = mfma16(a, bW2[s][0], acc[0]);
-      acc[1] = mfma16(a, bW2[s][1], acc[1]);
+      acc[0] = mfma16(aa[s], bW2[s][0], acc[0]);
+      acc[1] = mfma16(aa[s], bW2[s][1], acc[1]);
     }
 #pragma unroll
     for (int c = 0; c < 2; ++c)
@@ -1589,8 +1629,12 @@ __device__ __forceinline__ void mfma32_minibatch_chain(
   // ---- heads (policy: action_net -> out[row][a]; value: value_net -> misc[row][0])
   {
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    float aa[8];
 #pragma unroll
-    for (int s = 0; s < 8; ++s) acc = mfma16(a2t[arow * L::HS + 4 * s + lk], bHead[s], acc);
+    for (int s = 0; s < 8; ++s) aa[s] = a2t[arow * L::HS + 4 * s + lk];
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int s = 0; s < 8; ++s) acc = mfma16(aa[s], bHead[s], acc);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int row = q * 16 + lk * 4 + r;
@@ -1608,11 +1652,15 @@ __device__ __forceinline__ void mfma32_minibatch_chain(
       float* auxrow = lds + L::aux + lrow * L::AS;
       float logp = 0.f, entropy = 0.f, lse = 0.f;
       int act_i = 0;
+      float o_[MAXA];  // the row's head outputs, read in one batch (a read inside `if (a < A)` is a branch + a wait each)
+#pragma unroll
+      for (int a = 0; a < MAXA; ++a) o_[a] = outrow[a];
+      __builtin_amdgcn_sched_barrier(0);
       if (!d.discrete) {
 #pragma unroll
         for (int a = 0; a < MAXA; ++a)
           if (a < A) {
-            const float diff = r_act[a] - outrow[a];
+            const float diff = r_act[a] - o_[a];
             logp += -(diff * diff) * (0.5f * c_ivar[a]) - c_logsd[a] - LOG_SQRT_2PI;
             entropy += 0.5f + LOG_SQRT_2PI + c_logsd[a];
           }
@@ -1644,7 +1692,7 @@ __device__ __forceinline__ void mfma32_minibatch_chain(
 #pragma unroll
         for (int a = 0; a < MAXA; ++a)
           if (a < A) {
-            const float diff = r_act[a] - outrow[a];
+            const float diff = r_act[a] - o_[a];
             doutrow[a] = dlogp * diff * c_ivar[a];
             auxrow[a] = valid ? dlogp * (diff * diff * c_ivar[a] - 1.f) - ent_coef * invB : 0.f;
           }
@@ -1674,50 +1722,62 @@ __device__ __forceinline__ void mfma32_minibatch_chain(
   // ---- dz2 = d(a2) * (1 - a2^2) for this wave's rows
   if (tw == 0) {
     f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    float da[4], act[2][4];   // all operands of this phase in one batch (columns >= A of dout are zero)
+#pragma unroll
+    for (int s = 0; s < 4; ++s) da[s] = lds[L::dout + arow * L::AS + 4 * s + lk];
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) act[c][r] = a2t[(q * 16 + lk * 4 + r) * L::HS + c * 16 + li];
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int s = 0; s < 4; ++s)
       if (s < SA) {
-        const float a = lds[L::dout + arow * L::AS + 4 * s + lk];   // columns >= A are zero
-        acc[0] = mfma16(a, bDa2[s][0], acc[0]);
-        acc[1] = mfma16(a, bDa2[s][1], acc[1]);
+        acc[0] = mfma16(da[s], bDa2[s][0], acc[0]);
+        acc[1] = mfma16(da[s], bDa2[s][1], acc[1]);
       }
 #pragma unroll
     for (int c = 0; c < 2; ++c)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int e = (q * 16 + lk * 4 + r) * L::HS + c * 16 + li;
-        const float a = a2t[e];
-        dz2t[e] = acc[c][r] * (1.f - a * a);
-      }
+      for (int r = 0; r < 4; ++r)
+        dz2t[(q * 16 + lk * 4 + r) * L::HS + c * 16 + li] = acc[c][r] * (1.f - act[c][r] * act[c][r]);
   } else {
+    float act[2][4], dv[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      dv[r] = lds[L::misc + (q * 16 + lk * 4 + r) * L::MS + 1];
+#pragma unroll
+      for (int c = 0; c < 2; ++c) act[c][r] = a2t[(q * 16 + lk * 4 + r) * L::HS + c * 16 + li];
+    }
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int c = 0; c < 2; ++c)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = q * 16 + lk * 4 + r;
-        const int e = row * L::HS + c * 16 + li;
-        const float a = a2t[e];
-        dz2t[e] = cwv[c] * lds[L::misc + row * L::MS + 1] * (1.f - a * a);
-      }
+      for (int r = 0; r < 4; ++r)
+        dz2t[(q * 16 + lk * 4 + r) * L::HS + c * 16 + li] = cwv[c] * dv[r] * (1.f - act[c][r] * act[c][r]);
   }
   wave_sync_lds();
   // ---- dz1 = (dz2 W2) * (1 - a1^2) for this wave's rows
   {
     f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    float dd[8], act[2][4];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) dd[s] = dz2t[arow * L::HS + 4 * s + lk];
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) act[c][r] = a1t[(q * 16 + lk * 4 + r) * L::HS + c * 16 + li];
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int s = 0; s < 8; ++s) {
-      const float a = dz2t[arow * L::HS + 4 * s + lk];
-      acc[0] = mfma16(a, bW2o[s][0], acc[0]);
-      acc[1] = mfma16(a, bW2o[s][1], acc[1]);
+      acc[0] = mfma16(dd[s], bW2o[s][0], acc[0]);
+      acc[1] = mfma16(dd[s], bW2o[s][1], acc[1]);
     }
 #pragma unroll
     for (int c = 0; c < 2; ++c)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int e = (q * 16 + lk * 4 + r) * L::HS + c * 16 + li;
-        const float a = a1t[e];
-        dz1t[e] = acc[c][r] * (1.f - a * a);
-      }
+      for (int r = 0; r < 4; ++r)
+        dz1t[(q * 16 + lk * 4 + r) * L::HS + c * 16 + li] = acc[c][r] * (1.f - act[c][r] * act[c][r]);
   }
   __syncthreads();   // every row's activations and activation gradients are in LDS
   IA_TS(6);
@@ -1772,13 +1832,13 @@ __device__ __forceinline__ void mfma32_minibatch_chain(
       float u[16], v[16];
 #pragma unroll
       for (int s = 0; s < 16; ++s) {
-        u[s] = li == 0 ? lds[L::misc + (4 * s + lk) * L::MS + 1] : 0.f;
+        u[s] = lds[L::misc + (4 * s + lk) * L::MS + 1];   // (unconditional; masked behind the barrier)
         v[s] = a2t[(4 * s + lk) * L::HS + q * 16 + li];
       }
       __builtin_amdgcn_sched_barrier(0);
       f32x4 g = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int s = 0; s < 16; ++s) g = mfma16(u[s], v[s], g);
+      for (int s = 0; s < 16; ++s) g = mfma16(li == 0 ? u[s] : 0.f, v[s], g);
       if (lk == 0) slab[o.cW + q * 16 + li] = g[0];
     }
     if (q == 2) {  // cb = sum_r dv[r]; statpart slots {0 pg, 2 ent, 3 kl, 4 clip, 1 value} <- misc columns 2..6

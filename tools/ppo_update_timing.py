@@ -46,5 +46,6 @@ names = ["0 stage/fragments", "1 layer1", "2 layer2", "3 heads", "4 loss", "5 he
 print("shader clocks per minibatch phase (last step, block 0):")
 for n_, v in zip(names, d):
     print(f"  {n_:18s} {v:8d} clk  ~{v / 2.4e3:6.2f} us @2.4GHz")
-print("  phase0 detail: ->row loads", t[9] - t[0], " ->params", t[10] - t[9], " ->staged+sync", t[11] - t[10], " ->fragments", t[1] - t[11])
+print(f"  phase 0 detail (clk): loss scalars / action loads issued {t[9] - t[0]}, rows normalised into the x tile "
+      f"{t[10] - t[9]}, weight fragments LDS->VGPR + Gaussian constants {t[11] - t[10]}, block barrier {t[1] - t[11]}")
 L.load().ia_ppo_debug_timing(None)
