@@ -1914,39 +1914,88 @@ __global__ __launch_bounds__(512) void policy_act_mfma32_kernel(
   const int i0 = blockIdx.x * ROWS;
   const int S1 = (D + 3) >> 2;
   const int oW1 = tw ? o.vW1 : o.pW1, ob1 = tw ? o.vb1 : o.pb1, oW2 = tw ? o.vW2 : o.pW2, ob2 = tw ? o.vb2 : o.pb2;
-  // stage the block's feature rows (normalised); unconditional loads from clamped addresses
-  for (int e = tid; e < ROWS * L::XS; e += 512) {
-    const int r = e / L::XS, k = e - r * L::XS;
-    const bool ok = k < D && (i0 + r) < n;
-    const int kc = min(k, D - 1);
-    const float raw = obs[(long long)min(i0 + r, n - 1) * D + kc];
-    float v = raw;
-    if (d.has_norm) v = (raw - nm[kc]) / sqrtf(nv[kc] + d.norm_eps);
-    lds[L::x + e] = ok ? v : 0.f;
+  // The observations and the noise may live in device-mapped HOST memory (the rollout step of `PPO`): a load
+  // is then a PCIe round trip of ~2 us, so every one of them is issued up front -- the block's ROWS x D
+  // observation elements (contiguous rows, <= NOBS loads per thread) and, for the lanes that sample, the
+  // row's noise -- and consumed later.
+  constexpr int NOBS = (ROWS * MAXD + 511) / 512;
+  float raw[NOBS], nrm_m[NOBS], nrm_v[NOBS];
+  const int n_real = ROWS * D;
+#pragma unroll
+  for (int j = 0; j < NOBS; ++j) {
+    const int e = min(tid + 512 * j, n_real - 1);
+    const int r = e / D, k = e - r * D;
+    raw[j] = obs[(long long)min(i0 + r, n - 1) * D + k];
+    nrm_m[j] = d.has_norm ? nm[k] : 0.f;
+    nrm_v[j] = d.has_norm ? nv[k] : 1.f - d.norm_eps;
+  }
+  const int srow = i0 + q * 16 + (lane & 15);        // row this lane samples for (tower 0, lanes 0..15)
+  float r_noise[MAXA];
+#pragma unroll
+  for (int a2 = 0; a2 < MAXA; ++a2) r_noise[a2] = 0.f;
+  if (tw == 0 && lane < 16) {
+    const long long nrow = (long long)min(srow, n - 1) * (d.discrete ? 1 : A);
+#pragma unroll
+    for (int a2 = 0; a2 < MAXA; ++a2) r_noise[a2] = noise[nrow + (d.discrete ? 0 : min(a2, A - 1))];
+  }
+  for (int e = tid; e < ROWS * L::XS; e += 512) lds[L::x + e] = 0.f;   // padding columns / rows
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < NOBS; ++j) {
+    const int e = tid + 512 * j;
+    if (e < n_real) {
+      const int r = e / D, k = e - r * D;
+      const float v = d.has_norm ? (raw[j] - nrm_m[j]) / sqrtf(nrm_v[j] + d.norm_eps) : raw[j];
+      lds[L::x + r * L::XS + k] = (i0 + r) < n ? v : 0.f;
+    }
   }
   // weight fragments straight from global memory (L2-resident, 14 KB): B[k = 4s+lk][j = c*16+li]
   float bW1[16][2], bW2[8][2], bHead[8], b1v[2], b2v[2];
+  // (all loads first, unconditional at clamped addresses, behind at most four wave-uniform branches; masks after)
 #pragma unroll
-  for (int s = 0; s < 16; ++s) {
-    const int kk = min(4 * s + lk, D - 1);
-    const float m = (s < S1 && 4 * s + lk < D) ? 1.f : 0.f;
+  for (int g = 0; g < 4; ++g) {
+    if (4 * g < S1) {
 #pragma unroll
-    for (int c = 0; c < 2; ++c) bW1[s][c] = s < S1 ? Pt[oW1 + kk * H + c * 16 + li] * m : 0.f;
+      for (int s = 4 * g; s < 4 * g + 4; ++s)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) bW1[s][c] = Pt[oW1 + min(4 * s + lk, D - 1) * H + c * 16 + li];
+    } else {
+#pragma unroll
+      for (int s = 4 * g; s < 4 * g + 4; ++s) bW1[s][0] = bW1[s][1] = 0.f;
+    }
   }
+  const int head_base = tw == 0 ? o.aW + min(li, A - 1) * H : o.cW;
 #pragma unroll
   for (int s = 0; s < 8; ++s) {
     const int kk = 4 * s + lk;
 #pragma unroll
     for (int c = 0; c < 2; ++c) bW2[s][c] = Pt[oW2 + kk * H + c * 16 + li];
-    const float hv = P[(tw == 0 ? o.aW + min(li, A - 1) * H : o.cW) + kk];
-    bHead[s] = tw == 0 ? (li < A ? hv : 0.f) : (li == 0 ? hv : 0.f);
+    bHead[s] = P[head_base + kk];
   }
 #pragma unroll
   for (int c = 0; c < 2; ++c) {
     b1v[c] = P[ob1 + c * 16 + li];
     b2v[c] = P[ob2 + c * 16 + li];
   }
-  const float head_bias = tw == 0 ? P[o.ab + min(li, A - 1)] : P[o.cb];
+  const float head_bias = P[tw == 0 ? o.ab + min(li, A - 1) : o.cb];
+  float r_ls[MAXA], r_low[MAXA], r_high[MAXA];   // per-action constants of the sampling lanes
+#pragma unroll
+  for (int a2 = 0; a2 < MAXA; ++a2) {
+    const int ac = min(a2, A - 1);
+    r_ls[a2] = d.discrete ? 0.f : P[o.log_std + ac];
+    r_low[a2] = d.discrete ? 0.f : low[ac];
+    r_high[a2] = d.discrete ? 0.f : high[ac];
+  }
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int s = 0; s < 16; ++s)
+#pragma unroll
+    for (int c = 0; c < 2; ++c) bW1[s][c] = (4 * s + lk < D) ? bW1[s][c] : 0.f;
+  {
+    const bool head_on = tw == 0 ? li < A : li == 0;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) bHead[s] = head_on ? bHead[s] : 0.f;
+  }
   __syncthreads();
 
   float* a1t = lds + L::a1 + tw * ROWS * L::HS;
@@ -1999,14 +2048,16 @@ __global__ __launch_bounds__(512) void policy_act_mfma32_kernel(
   const float* outrow = lds + L::out + (q * 16 + lane) * L::AS;
   if (!d.discrete) {
     float lp = 0.f;
-    for (int a = 0; a < A; ++a) {
-      const float ls = P[o.log_std + a];
-      const float mu = outrow[a];
-      const float act = __fadd_rn(mu, __fmul_rn(noise[(long long)row * A + a], expf(ls)));  // Normal.rsample
-      actions[(long long)row * A + a] = act;
-      clipped[(long long)row * A + a] = fminf(fmaxf(act, low[a]), high[a]);
-      lp += gauss_logp_term(act, mu, ls);
-    }
+#pragma unroll
+    for (int a = 0; a < MAXA; ++a)
+      if (a < A) {
+        const float ls = r_ls[a];
+        const float mu = outrow[a];
+        const float act = __fadd_rn(mu, __fmul_rn(r_noise[a], expf(ls)));  // Normal.rsample
+        actions[(long long)row * A + a] = act;
+        clipped[(long long)row * A + a] = fminf(fmaxf(act, r_low[a]), r_high[a]);
+        lp += gauss_logp_term(act, mu, ls);
+      }
     logp[row] = lp;
   } else {
     float mx = outrow[0];
@@ -2014,7 +2065,7 @@ __global__ __launch_bounds__(512) void policy_act_mfma32_kernel(
     float se = 0.f;
     for (int a = 0; a < A; ++a) se += expf(outrow[a] - mx);
     const float lse = mx + logf(se);
-    const float u = noise[row];
+    const float u = r_noise[0];
     float c = 0.f;
     int pick = A - 1;
     if (u < 0.f) {  // mode of the Categorical (argmax, first index on ties)
