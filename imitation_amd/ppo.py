@@ -206,20 +206,36 @@ class RolloutBuffer:
     def __init__(self, T: int, n: int, obs_dim: int, act_width: int, device):
         self.buffer_size, self.n_envs, self.obs_dim, self.act_width = T, n, obs_dim, act_width
         f = lambda *s: th.zeros(*s, device=device)
-        self.obs = f(T + 1, n, obs_dim)
-        self.acts, self.clipped = f(T, n, act_width), f(T, n, act_width)
-        self.next_fixed = f(T, n, obs_dim)
-        self.dones = th.zeros(T, n, dtype=th.uint8, device=device)
-        self.trunc = th.zeros(T, n, dtype=th.uint8, device=device)
-        self.rew, self.val, self.logp, self.adv, self.ret, self.starts = (f(T, n) for _ in range(6))
-        self.term_val, self.last_val, self.last_done = f(T, n), f(n), f(n)
+        # Everything the env loop produces on the host goes to the device in ONE copy after the last step:
+        # the host-written tiles are views into one pinned block, their device twins views into one device
+        # block with the same layout (seven separate copies cost ~10 us of copy-engine latency each, on the
+        # critical path between the last env step and the PPO update).
+        spec = [("obs", (T + 1, n, obs_dim), th.float32), ("clipped", (T, n, act_width), th.float32),
+                ("next_fixed", (T, n, obs_dim), th.float32), ("starts", (T, n), th.float32),
+                ("last_done", (n,), th.float32), ("dones", (T, n), th.uint8), ("trunc", (T, n), th.uint8)]
+        nbytes = sum(-(-int(np.prod(shape)) * th.empty(0, dtype=dt).element_size() // 256) * 256 for _, shape, dt in spec)
+        self._dev_block = th.zeros(nbytes, dtype=th.uint8, device=device)
+        self._host_block = th.zeros(nbytes, dtype=th.uint8).pin_memory()
+        off = 0
+        host_names = dict(obs="h_obs", clipped="h_clip", next_fixed="h_next", starts="h_starts",
+                          last_done="h_last_done", dones="h_dones", trunc="h_trunc")
+        for name, shape, dt in spec:
+            size = int(np.prod(shape)) * th.empty(0, dtype=dt).element_size()
+            setattr(self, name, self._dev_block[off:off + size].view(dt).view(*shape))
+            setattr(self, host_names[name], self._host_block[off:off + size].view(dt).view(*shape))
+            off += -(-size // 256) * 256
+        self.acts = f(T, n, act_width)
+        self.rew, self.val, self.logp, self.adv, self.ret = (f(T, n) for _ in range(5))
+        self.term_val, self.last_val = f(T, n), f(n)
         self.noise = f(n, max(act_width, 1))
         pin = lambda *s, dtype=th.float32: th.zeros(*s, dtype=dtype).pin_memory()
-        self.h_obs, self.h_next = pin(T + 1, n, obs_dim), pin(T, n, obs_dim)
-        self.h_dones, self.h_trunc = pin(T, n, dtype=th.uint8), pin(T, n, dtype=th.uint8)
-        self.h_rew, self.h_starts = pin(T, n), pin(T, n)
-        self.h_clip, self.h_noise, self.h_last_done = pin(T, n, act_width), pin(n, max(act_width, 1)), pin(n)
+        self.h_rew = pin(T, n)
+        self.h_noise = pin(n, max(act_width, 1))
         self.full = False
+
+    def upload_host_tiles(self) -> None:
+        """One H2D copy of everything the env loop wrote on the host (current stream)."""
+        self._dev_block.copy_(self._host_block, non_blocking=True)
 
     def reset(self) -> None:
         self.full = False
@@ -541,10 +557,11 @@ class PPO(OnPolicyAlgorithm):
             if prof is not None:
                 prof["bookkeeping"] = prof.get("bookkeeping", 0.0) + tick() - prof.pop("_t_book")
         self._last_episode_starts = starts
+        if self.update_events is not None:  # tools: device time from the last env step to the start of the update
+            self.tail_event = th.cuda.Event(enable_timing=True)
+            self.tail_event.record()
         rb.h_last_done.copy_(th.as_tensor(starts.astype(np.float32)))
-        for d, h in ((rb.obs, rb.h_obs), (rb.clipped, rb.h_clip), (rb.next_fixed, rb.h_next), (rb.dones, rb.h_dones),
-                     (rb.trunc, rb.h_trunc), (rb.starts, rb.h_starts), (rb.last_done, rb.h_last_done)):
-            d.copy_(h, non_blocking=True)
+        rb.upload_host_tiles()
         # host time the device had to itself for other streams' work during this rollout (see
         # `AdversarialTrainer._train_pipelined`: where the discriminator updates are scheduled)
         self.rollout_window_ms = 1e3 * (tick() - t_first_step)

@@ -25,6 +25,17 @@ for k, v in sorted(prof.items(), key=lambda kv: -kv[1]):
     print(f"  {k:28s} {1e3 * v / rounds:7.3f} ms   {1e6 * v / rounds / cfg['n_steps']:7.1f} us/step")
 print(f"  {'sum':28s} {1e3 * tot / rounds:7.3f} ms")
 
+# device time between the last env step and the start of the PPO update (copies, relabel, GAE, launch)
+algo = tr.gen_algo
+tails = []
+for _ in range(5):
+    algo.update_events = (th.cuda.Event(enable_timing=True), th.cuda.Event(enable_timing=True))
+    tr.train(per_round)
+    th.cuda.synchronize()
+    tails.append((algo.tail_event.elapsed_time(algo.update_events[0]), algo.update_events[0].elapsed_time(algo.update_events[1])))
+algo.update_events = None
+print("  last env step -> PPO update starts (ms):", ", ".join(f"{a:.3f}" for a, _ in tails),
+      "| PPO update (ms):", ", ".join(f"{b:.3f}" for _, b in tails))
 env = tr.venv  # helper-thread diagnostics of the synthetic env (if the prefetch helper is active)
 while not hasattr(env, "_worker") and hasattr(env, "venv"):
     env = env.venv
