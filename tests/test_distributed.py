@@ -69,7 +69,7 @@ def _gpu_worker(rank, world, port, out_dir):
     cfg = dict(harness.CASES["gail_box"], rounds=2)
     from imitation_amd.vec_env import SyntheticVecEnv
 
-    def run(batch_moments: bool, global_mb: bool = False, pipeline: bool = True):
+    def run(batch_moments: bool, global_mb: bool = False, pipeline: bool = True, airl: bool = False):
         th.manual_seed(100 + rank)      # different initial weights per rank: the broadcast must fix that
         np.random.seed(100 + rank)
         venv = SyntheticVecEnv(num_envs=cfg["n_envs"], obs_dim=17, act_dim=6, horizon=cfg["horizon"], seed=rank)
@@ -79,12 +79,18 @@ def _gpu_worker(rank, world, port, out_dir):
                      ent_coef=0.1, policy_kwargs=pk, device="cuda")
         algo.dp_batch_moments = batch_moments
         algo.dp_global_minibatch = global_mb
-        net = p.BasicRewardNet(venv.observation_space, venv.action_space, hid_sizes=(32, 32),
-                               normalize_input_layer=p.RunningNorm)
+        if airl:
+            net = p.BasicShapedRewardNet(venv.observation_space, venv.action_space, reward_hid_sizes=(32,),
+                                         potential_hid_sizes=(32, 32), use_next_state=True,
+                                         normalize_input_layer=p.RunningNorm)
+        else:
+            net = p.BasicRewardNet(venv.observation_space, venv.action_space, hid_sizes=(32, 32),
+                                   normalize_input_layer=p.RunningNorm)
         demos = p.Transitions(**harness.make_demo_arrays(cfg, seed=1 + rank))
-        tr = p.GAIL(demonstrations=demos, demo_batch_size=64, venv=venv, gen_algo=algo, reward_net=net,
-                    n_disc_updates_per_round=2, custom_logger=p.configure_logger(tempfile.mkdtemp(), []),
-                    data_parallel=DataParallel())
+        tr = (p.AIRL if airl else p.GAIL)(
+            demonstrations=demos, demo_batch_size=64, venv=venv, gen_algo=algo, reward_net=net,
+            n_disc_updates_per_round=2, custom_logger=p.configure_logger(tempfile.mkdtemp(), []),
+            data_parallel=DataParallel())
         tr.pipeline_rounds = pipeline
         tr.train((cfg["rounds"] + 1) * cfg["n_envs"] * cfg["n_steps"] if global_mb else
                  cfg["rounds"] * cfg["n_envs"] * cfg["n_steps"])
@@ -102,6 +108,8 @@ def _gpu_worker(rank, world, port, out_dir):
     th.save(run(False), os.path.join(out_dir, f"state{rank}_per_minibatch.pt"))
     th.save(run(True, global_mb=True), os.path.join(out_dir, f"state{rank}_global.pt"))
     th.save(run(True, global_mb=True, pipeline=False), os.path.join(out_dir, f"state{rank}_global_seq.pt"))
+    th.save(run(True, global_mb=True, airl=True), os.path.join(out_dir, f"state{rank}_airl.pt"))
+    th.save(run(True, global_mb=True, pipeline=False, airl=True), os.path.join(out_dir, f"state{rank}_airl_seq.pt"))
     dist.destroy_process_group()
 
 
@@ -137,6 +145,13 @@ def test_two_ranks_one_gpu_replicas_identical(tmp_path):
     q0 = th.load(tmp_path / "state0_global_seq.pt")
     for k in g0:
         assert th.equal(g0[k], q0[k]), k
+    # AIRL under data parallelism: per-update feature statistics from the (all-gathered) merge snapshots;
+    # replicas identical, pipelined == sequential
+    r0, r1, rs = (th.load(tmp_path / f) for f in ("state0_airl.pt", "state1_airl.pt", "state0_airl_seq.pt"))
+    for k in r0:
+        if not k.startswith("tile/") or k.endswith("_global") or k == "tile/perm":
+            assert th.equal(r0[k], r1[k]), k
+        assert th.equal(r0[k], rs[k]), k
     # every rank contributed: disc input norm saw world * (2 rounds * 2 updates * 128 rows)
     assert int(a["disc/mlp.normalize_input.count"]) == 2 * 2 * 2 * 128
     assert int(g0["disc/mlp.normalize_input.count"]) == 2 * 3 * 2 * 128
