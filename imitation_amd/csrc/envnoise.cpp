@@ -31,6 +31,7 @@ struct Worker {
   // a job = n_steps consecutive env steps: step j draws a[j*stride .. +n_a) and then b[j*stride .. +n_b[j])
   int n_steps = 0;
   int64_t n_a = 0, stride = 0;
+  double a_scale = 1.0, b_scale = 1.0;  // the draws are stored already multiplied by these (one IEEE multiply each)
   const int64_t* n_b = nullptr;
   double *a = nullptr, *b = nullptr;
   std::atomic<int> steps_done{0};  // of the current job
@@ -63,8 +64,12 @@ struct Worker {
       if (s == 3) return;
       const auto f0 = std::chrono::steady_clock::now();
       for (int j = 0; j < n_steps; ++j) {
-        random_standard_normal_fill(bg, (intptr_t)n_a, a + j * stride);                      // process noise first ...
-        if (n_b[j] > 0) random_standard_normal_fill(bg, (intptr_t)n_b[j], b + j * stride);  // ... then the reset observations
+        double* aj = a + j * stride;
+        double* bj = b + j * stride;
+        random_standard_normal_fill(bg, (intptr_t)n_a, aj);                      // process noise first ...
+        if (n_b[j] > 0) random_standard_normal_fill(bg, (intptr_t)n_b[j], bj);  // ... then the reset observations
+        for (int64_t i = 0; i < n_a; ++i) aj[i] = a_scale * aj[i];
+        for (int64_t i = 0; i < n_b[j]; ++i) bj[i] = b_scale * bj[i];
         steps_done.store(j + 1, std::memory_order_release);
       }
       fill_ns += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - f0).count();
@@ -134,10 +139,10 @@ extern "C" void* ia_env_noise_create(void) {
 }
 
 // Post one job of n_steps env steps: step j fills a[j*stride .. +n_a) and then b[j*stride .. +n_b[j]) from
-// generator `bitgen` (address of its bitgen_t), in that order. One job at a time; the caller must not touch
+// generator `bitgen` (address of its bitgen_t), in that order, and stores them multiplied by a_scale / b_scale. One job at a time; the caller must not touch
 // the generator, the buffers or n_b until ia_env_noise_finish() has returned.
 extern "C" int ia_env_noise_post(void* handle, void* bitgen, int n_steps, int64_t n_a, int64_t stride, double* a,
-                                 const int64_t* n_b, double* b) {
+                                 const int64_t* n_b, double* b, double a_scale, double b_scale) {
   Worker* w = static_cast<Worker*>(handle);
   if (w == nullptr || bitgen == nullptr || n_steps <= 0 || n_a < 0 || stride < n_a || a == nullptr ||
       n_b == nullptr || b == nullptr)
@@ -147,6 +152,7 @@ extern "C" int ia_env_noise_post(void* handle, void* bitgen, int n_steps, int64_
   if (cpu >= 0 && cpu != w->main_cpu) place_near(w, cpu);
   w->bg = static_cast<bitgen_t*>(bitgen);
   w->n_steps = n_steps; w->n_a = n_a; w->stride = stride; w->a = a; w->n_b = n_b; w->b = b;
+  w->a_scale = a_scale; w->b_scale = b_scale;
   w->steps_done.store(0, std::memory_order_release);
   w->signal(1);
   return 0;

@@ -110,7 +110,7 @@ def _env_noise_lib():
             lib = C.CDLL(path)
             lib.ia_env_noise_create.argtypes, lib.ia_env_noise_create.restype = [], C.c_void_p
             lib.ia_env_noise_post.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_int64, C.c_void_p,
-                                              C.c_void_p, C.c_void_p]
+                                              C.c_void_p, C.c_void_p, C.c_double, C.c_double]
             lib.ia_env_noise_post.restype = C.c_int
             lib.ia_env_noise_wait_step.argtypes, lib.ia_env_noise_wait_step.restype = [C.c_void_p, C.c_int], C.c_int
             lib.ia_env_noise_finish.argtypes, lib.ia_env_noise_finish.restype = [C.c_void_p], C.c_int
@@ -228,7 +228,7 @@ class SyntheticVecEnv(ArrayVecEnv):
         self._n_fresh[:] = np.asarray(n_done) * D
         state0 = self._rng.bit_generator.state
         rc = self._helper.ia_env_noise_post(self._worker, self._bitgen_addr, K, n * D, n * D, self._xi.ctypes.data,
-                                            self._n_fresh.ctypes.data, self._fresh_buf.ctypes.data)
+                                            self._n_fresh.ctypes.data, self._fresh_buf.ctypes.data, 0.05, 0.1)
         assert rc == 0, rc
         self._pending = [state0, n_done, 0]
 
@@ -242,11 +242,12 @@ class SyntheticVecEnv(ArrayVecEnv):
             self._plan_next_draws()
 
     def _take_planned_draws(self):
-        """-> (xi, fresh or None, n_done) of the next step of the outstanding job."""
+        """-> (0.05 * xi, 0.1 * fresh-draws or None, n_done) of the next step of the outstanding job (the helper
+        stores the draws already scaled: the same single IEEE multiply NumPy would do)."""
         _, n_done, j = self._pending
         rc = self._helper.ia_env_noise_wait_step(self._worker, j)
         assert rc == 0, rc
-        out = (self._xi[j], (0.1 * self._fresh_buf[j, :n_done[j]] if n_done[j] else None), n_done[j])
+        out = (self._xi[j], (self._fresh_buf[j, :n_done[j]] if n_done[j] else None), n_done[j])
         self._pending[2] = j + 1
         if j + 1 == len(n_done):   # job used up (the views above stay valid until the next post)
             rc = self._helper.ia_env_noise_finish(self._worker)
@@ -309,10 +310,10 @@ class SyntheticVecEnv(ArrayVecEnv):
         nxt = 0.9 * self._obs + 0.1 * np.tanh(a @ self._W)
         fresh = None
         if self._pending is not None:
-            xi, fresh, planned = self._take_planned_draws()
+            sxi, fresh, planned = self._take_planned_draws()
         else:
-            xi, planned = self._rng.standard_normal(nxt.shape), -1
-        nxt += 0.05 * xi
+            sxi, planned = 0.05 * self._rng.standard_normal(nxt.shape), -1
+        nxt += sxi
         self._t += 1
         dones = self._t >= self.horizon
         dt = self.observation_space.dtype
