@@ -222,3 +222,39 @@ def test_full_size_config_p_matches_live_oracle():
     assert int(ref["counters"][2]) == 2 * per_round
     top = sorted(worst.items(), key=lambda kv: -kv[1])[:3]
     print("config P, 2 rounds, largest absolute deviations from the oracle:", top)
+
+
+def test_full_size_airl_ant_matches_live_oracle(tmp_path):
+    """BASELINE.json configs[2] shape at full width (AIRL, 1 024 Ant-shaped envs obs 27 / act 8,
+    `BasicShapedRewardNet` + `NormalizedRewardNet`, 8 192-row demo batches, 16 updates per round, PPO
+    minibatch 1 024 x 10 epochs): one round of the HIP trainer (pipelined AIRL schedule, 9-parameters-per-
+    thread persistent PPO update) against the CPU oracle. Same tolerance rule as the config-P test."""
+    cfg = dict(algo="airl", n_envs=1024, horizon=1000, obs_dim=27, act_dim=8, n_discrete=None, n_steps=16,
+               ppo_batch=1024, n_epochs=10, ent_coef=0.01, disc_hid=(32,), demo_batch=8192, demo_minibatch=None,
+               n_disc=16, capacity=16384, n_demo=32768, rounds=1, norm_policy=True, norm_disc=True,
+               obs_dtype="float32", normalize_output=True)
+    outs = {}
+    for impl in ("oracle", "hip"):
+        threads = th.get_num_threads()
+        th.set_num_threads(8 if impl == "oracle" else 1)
+        try:
+            tr, _ = harness.build_trainer(impl, cfg, str(tmp_path / impl), "cpu" if impl == "oracle" else "cuda")
+            tr.train(cfg["n_envs"] * cfg["n_steps"])
+            outs[impl] = harness.snapshot(tr)
+        finally:
+            th.set_num_threads(threads)
+    ref, got = outs["oracle"], outs["hip"]
+    assert set(ref) == set(got)
+    k_steps = 16 + 160
+    worst = {}
+    for key in ref:
+        x, y = np.asarray(got[key]), np.asarray(ref[key])
+        assert x.shape == y.shape, key
+        if key in harness.EXACT_KEYS or y.dtype.kind in "biu":
+            assert np.array_equal(x, y), key
+        else:
+            np.testing.assert_allclose(x.astype(np.float64), y.astype(np.float64), rtol=2e-4,
+                                       atol=5e-5 + k_steps * 1e-5, equal_nan=True, err_msg=key)
+            worst[key] = float(np.nanmax(np.abs(x.astype(np.float64) - y.astype(np.float64)))) if x.size else 0.0
+    print("AIRL Ant-shaped, 1 round, largest absolute deviations from the oracle:",
+          sorted(worst.items(), key=lambda kv: -kv[1])[:3])
