@@ -998,3 +998,132 @@ class AIRL(AdversarialTrainer):
         while isinstance(net, RewardNetWrapper):
             net = net.base
         return net
+
+
+# ------------------------------------------------------------------- algorithms/bc.py
+# SURVEY 8(f) row 4, first slice: the supervised BC step on the actor-critic MLP policies of the path.
+
+
+def bc_loss(policy, obs: th.Tensor, acts: th.Tensor, ent_weight: float, l2_weight: float) -> Dict[str, th.Tensor]:
+    """`BehaviorCloningLossCalculator.__call__` (algorithms/bc.py:100-156)."""
+    _, log_prob, entropy = policy.evaluate_actions(obs, acts)
+    prob_true_act = th.exp(log_prob).mean()
+    log_prob = log_prob.mean()
+    entropy = entropy.mean() if entropy is not None else None
+    l2_norm = sum(th.sum(th.square(w)) for w in policy.parameters()) / 2
+    ent_loss = -ent_weight * (entropy if entropy is not None else th.zeros(1))
+    neglogp = -log_prob
+    l2_loss = l2_weight * l2_norm
+    loss = neglogp + ent_loss + l2_loss
+    return dict(neglogp=neglogp, entropy=entropy, ent_loss=ent_loss, prob_true_act=prob_true_act, l2_norm=l2_norm,
+                l2_loss=l2_loss, loss=loss)
+
+
+class BC:
+    """algorithms/bc.py:268-510 (`BC.__init__`, `set_demonstrations`, `train`) without the progress bar
+    and the optional rollout statistics (`log_rollouts_venv=None`)."""
+
+    def __init__(self, *, observation_space, action_space, rng: np.random.Generator, policy=None, demonstrations=None,
+                 batch_size: int = 32, minibatch_size: Optional[int] = None, optimizer_cls=th.optim.Adam,
+                 optimizer_kwargs: Optional[Mapping[str, Any]] = None, ent_weight: float = 1e-3,
+                 l2_weight: float = 0.0, device="auto", custom_logger=None):
+        self._demo_data_loader = None
+        self.batch_size = batch_size
+        self.minibatch_size = minibatch_size or batch_size
+        if self.batch_size % self.minibatch_size != 0:
+            raise ValueError("Batch size must be a multiple of minibatch size.")
+        self.logger = custom_logger or configure_logger()
+        if demonstrations is not None:
+            self.set_demonstrations(demonstrations)
+        self.action_space, self.observation_space, self.rng = action_space, observation_space, rng
+        if policy is None:
+            policy = FeedForward32Policy(observation_space=observation_space, action_space=action_space,
+                                         lr_schedule=lambda _: th.finfo(th.float32).max,
+                                         features_extractor_class=sb.FlattenExtractor)
+        self._policy = policy.to(sb.get_device(device))
+        assert self.policy.observation_space == self.observation_space
+        assert self.policy.action_space == self.action_space
+        if optimizer_kwargs and "weight_decay" in optimizer_kwargs:
+            raise ValueError("Use the parameter l2_weight instead of weight_decay.")
+        self.optimizer = optimizer_cls(self.policy.parameters(), **(optimizer_kwargs or {}))
+        self.ent_weight, self.l2_weight = ent_weight, l2_weight
+        self._tensorboard_step = 0
+        self._current_epoch = 0
+
+    @property
+    def policy(self):
+        return self._policy
+
+    def set_demonstrations(self, demonstrations) -> None:
+        self._demo_data_loader = make_data_loader(demonstrations, self.minibatch_size)
+
+    def _batches(self, n_epochs, n_minibatches, on_epoch_end):
+        """`BatchIteratorWithEpochEndCallback.__iter__` (bc.py:59-78)."""
+        if (n_epochs is None) == (n_minibatches is None):
+            raise ValueError("Must provide exactly one of `n_epochs` and `n_batches` arguments.")
+        epoch, seen = 0, 0
+        while True:
+            some = False
+            for batch in self._demo_data_loader:   # one DataLoader iterator per epoch
+                some = True
+                yield batch
+                seen += 1
+                if n_minibatches is not None and seen >= n_minibatches:
+                    return
+            if not some:
+                raise AssertionError(f"no data in epoch {epoch}")
+            epoch += 1
+            on_epoch_end(epoch - 1)
+            if n_epochs is not None and epoch >= n_epochs:
+                return
+
+    def _log_batch(self, batch_num, batch_size, num_samples_so_far, metrics) -> None:
+        """`BCLogger.log_batch` (bc.py:223-242) with empty rollout statistics."""
+        self.logger.record("batch_size", batch_size)
+        self.logger.record("bc/epoch", self._current_epoch)
+        self.logger.record("bc/batch", batch_num)
+        self.logger.record("bc/samples_so_far", num_samples_so_far)
+        for k, v in metrics.items():
+            self.logger.record(f"bc/{k}", float(v) if v is not None else None)
+        self.logger.dump(self._tensorboard_step)
+        self._tensorboard_step += 1
+
+    def train(self, *, n_epochs: Optional[int] = None, n_batches: Optional[int] = None, on_epoch_end=None,
+              on_batch_end=None, log_interval: int = 500, progress_bar: bool = False,
+              reset_tensorboard: bool = False) -> None:
+        if reset_tensorboard:
+            self._tensorboard_step = 0
+        self._current_epoch = 0
+
+        def _on_epoch_end(epoch_number: int):
+            self._current_epoch = epoch_number + 1
+            if on_epoch_end is not None:
+                on_epoch_end()
+
+        mini_per_batch = self.batch_size // self.minibatch_size
+        n_minibatches = n_batches * mini_per_batch if n_batches is not None else None
+        assert self._demo_data_loader is not None
+        num_samples_so_far, batch_num, metrics, minibatch_size = 0, 0, None, 0
+
+        def process_batch():
+            self.optimizer.step()
+            self.optimizer.zero_grad()
+            if batch_num % log_interval == 0:
+                self._log_batch(batch_num, minibatch_size, num_samples_so_far, metrics)
+            if on_batch_end is not None:
+                on_batch_end()
+
+        self.optimizer.zero_grad()
+        for num_batches, batch in enumerate(self._batches(n_epochs, n_minibatches, _on_epoch_end)):
+            minibatch_size = len(batch["obs"])
+            num_samples_so_far += minibatch_size
+            obs = safe_to_tensor(batch["obs"], device=self.policy.device)
+            acts = safe_to_tensor(batch["acts"], device=self.policy.device)
+            metrics = bc_loss(self.policy, obs, acts, self.ent_weight, self.l2_weight)
+            (metrics["loss"] * minibatch_size / self.batch_size).backward()
+            batch_num = num_batches * self.minibatch_size // self.batch_size
+            if num_samples_so_far % self.batch_size == 0:
+                process_batch()
+        if num_samples_so_far % self.batch_size != 0:
+            batch_num += 1
+            process_batch()

@@ -81,9 +81,11 @@ def install() -> None:
                             CallbackList=sb.CallbackList)
     common.monitor = _mod("stable_baselines3.common.monitor", Monitor=_Monitor)
     common.utils = _mod("stable_baselines3.common.utils", check_for_correct_spaces=sb.check_for_correct_spaces,
-                        set_random_seed=sb.set_random_seed, obs_as_tensor=sb.obs_as_tensor)
+                        set_random_seed=sb.set_random_seed, obs_as_tensor=sb.obs_as_tensor,
+                        get_device=sb.get_device)
     common.torch_layers = _mod("stable_baselines3.common.torch_layers", FlattenExtractor=sb.FlattenExtractor,
-                               BaseFeaturesExtractor=sb.BaseFeaturesExtractor, MlpExtractor=sb.MlpExtractor)
+                               BaseFeaturesExtractor=sb.BaseFeaturesExtractor, MlpExtractor=sb.MlpExtractor,
+                               CombinedExtractor=sb.CombinedExtractor)
     sac = _mod("stable_baselines3.sac")
     sac.policies = _mod("stable_baselines3.sac.policies", SACPolicy=sb.SACPolicy)
     ppo = _mod("stable_baselines3.ppo", PPO=sb.PPO)

@@ -46,6 +46,13 @@ def set_random_seed(seed: int) -> None:
     th.manual_seed(seed)
 
 
+def get_device(device="auto") -> th.device:
+    """[SB3 utils.get_device]: "auto" -> cuda if available else cpu. The oracle is the CPU path."""
+    if isinstance(device, th.device):
+        return device
+    return th.device("cpu" if device in ("auto", "cpu") else device)
+
+
 def obs_as_tensor(obs: np.ndarray, device) -> th.Tensor:
     return th.as_tensor(obs, device=device)
 
@@ -455,6 +462,14 @@ class FlattenExtractor(BaseFeaturesExtractor):
 
     def forward(self, observations: th.Tensor) -> th.Tensor:
         return self.flatten(observations)
+
+
+class CombinedExtractor(BaseFeaturesExtractor):
+    """[SB3 torch_layers.CombinedExtractor] is for Dict observation spaces, which the path never uses;
+    the name exists because `algorithms/bc.py:342-346` refers to it."""
+
+    def __init__(self, observation_space, *a, **k):
+        raise NotImplementedError("Dict observation spaces are outside the restated path")
 
 
 class MlpExtractor(nn.Module):

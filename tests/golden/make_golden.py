@@ -115,7 +115,20 @@ def main():
         path = os.path.join(HERE, f"{name}.npz")
         np.savez_compressed(path, **out)
         print(f"wrote {path}: {len(out)} arrays, {os.path.getsize(path)} bytes")
+    dump_bc()
+
+
+def dump_bc():
+    """`algorithms/bc.py` (BC.__init__ / train, BehaviorCloningLossCalculator) run by the reference itself."""
+    for name in harness.BC_CASES:
+        out = harness.run_bc_case("reference", name, tempfile.mkdtemp())
+        path = os.path.join(HERE, f"{name}.npz")
+        np.savez_compressed(path, **out)
+        print(f"wrote {path}: {len(out)} arrays, {os.path.getsize(path)} bytes")
 
 
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "bc":
+        dump_bc()
+    else:
+        main()

@@ -283,3 +283,87 @@ def run_rollout_case(impl: str, name: str, device: str = "cpu") -> Dict[str, np.
     out["stats"] = np.asarray([stats[k] for k in sorted(stats)], dtype=np.float64)
     out["disc_sum"] = np.asarray([rns.discounted_sum(np.asarray(t.rews, dtype=np.float64), 0.9) for t in trajs])
     return out
+
+
+# ----------------------------------------------------------------------------------------------
+# Behavioural cloning (MLP slice): seeded cases shared by the golden generator
+# (reference `algorithms/bc.py` under the shim), the oracle pin and the HIP parity test.
+BC_CASES: Dict[str, Dict[str, Any]] = {
+    # default policy (FeedForward32Policy, Flatten features), Box actions, two epochs + drop_last remainder
+    "bc_box": dict(obs_dim=5, act_dim=3, n_discrete=None, n_demo=200, batch_size=32, ent_weight=1e-3,
+                   train=dict(n_epochs=2), norm_policy=False, log_interval=3),
+    # Discrete actions, n_batches that stops inside the second epoch, larger entropy weight
+    "bc_discrete": dict(obs_dim=4, act_dim=2, n_discrete=2, n_demo=150, batch_size=16, ent_weight=1e-2,
+                        train=dict(n_batches=13), norm_policy=False, log_interval=4),
+    # train-mode NormalizeFeaturesExtractor(RunningNorm): `evaluate_actions` updates the statistics every batch
+    "bc_norm": dict(obs_dim=7, act_dim=2, n_discrete=None, n_demo=128, batch_size=64, ent_weight=1e-3,
+                    train=dict(n_epochs=3), norm_policy=True, log_interval=1),
+}
+
+
+def bc_namespace(impl: str) -> pytypes.SimpleNamespace:
+    if impl == "reference":
+        ns = namespace("reference")
+        from imitation.algorithms import bc as rbc
+
+        ns.BC = rbc.BC
+        return ns
+    if impl == "oracle":
+        ns = namespace("oracle")
+        from oracle import imitation_restated as o
+
+        ns.BC = o.BC
+        return ns
+    ns = namespace("hip")
+    import imitation_amd as p
+
+    ns.BC = p.bc.BC
+    return ns
+
+
+def run_bc_case(impl: str, name: str, log_dir: str, device: str = "cpu") -> Dict[str, np.ndarray]:
+    """Trains BC on seeded synthetic demonstrations; returns the policy state and every logged row."""
+    from imitation_amd import spaces
+
+    cfg = BC_CASES[name]
+    ns = bc_namespace(impl)
+    th.manual_seed(0)
+    np.random.seed(0)
+    rng = np.random.default_rng(3)
+    n, od, ad = cfg["n_demo"], cfg["obs_dim"], cfg["act_dim"]
+    obs = rng.standard_normal((n, od)).astype(np.float32)
+    if cfg["n_discrete"] is None:
+        acts = np.tanh(obs[:, :ad] + 0.1 * rng.standard_normal((n, ad))).astype(np.float32)
+        act_space = spaces.Box(-1.0, 1.0, (ad,), np.float32)
+    else:
+        acts = (obs[:, 0] > 0).astype(np.int64)
+        act_space = spaces.Discrete(cfg["n_discrete"])
+    obs_space = spaces.Box(-np.inf, np.inf, (od,), np.float32)
+    demos = ns.Transitions(obs=obs, acts=acts, next_obs=obs.copy(), dones=np.zeros(n, dtype=bool))
+    policy = None
+    if cfg["norm_policy"]:
+        policy = ns.FeedForward32Policy(observation_space=obs_space, action_space=act_space,
+                                        lr_schedule=lambda _: 1.0,
+                                        features_extractor_class=ns.NormalizeFeaturesExtractor,
+                                        features_extractor_kwargs=dict(normalize_class=ns.RunningNorm))
+    logger = ns.configure_logger(log_dir)
+    rows = []
+    orig_dump = logger.dump
+
+    def dump(step=0):
+        kv = dict(logger.name_to_value) if hasattr(logger, "name_to_value") else {}
+        if not kv and hasattr(logger, "default_logger"):
+            kv = dict(logger.default_logger.name_to_value)
+        rows.append([float(kv[k]) for k in sorted(kv) if k.startswith("bc/") or k == "batch_size"])
+        return orig_dump(step)
+
+    logger.dump = dump
+    kw = dict(device=device) if impl == "hip" else {}
+    trainer = ns.BC(observation_space=obs_space, action_space=act_space, rng=np.random.default_rng(0), policy=policy,
+                    demonstrations=demos, batch_size=cfg["batch_size"], ent_weight=cfg["ent_weight"],
+                    custom_logger=logger, **kw)
+    trainer.train(log_interval=cfg["log_interval"], progress_bar=False, **cfg["train"])
+    out = {f"policy/{k}": _np(v) for k, v in trainer.policy.state_dict().items()}
+    out["log_rows"] = np.asarray(rows, dtype=np.float64)
+    out["torch_rng_after"] = th.get_rng_state().numpy().copy()   # the loader consumed the global generator identically
+    return out

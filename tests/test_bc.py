@@ -1,0 +1,56 @@
+"""Behavioural cloning (MLP-policy slice): the oracle's restatement of
+`algorithms/bc.py` against golden fixtures produced by the reference itself (and against the live
+reference where /root/reference exists); the HIP trainer against the same fixtures (`-m gpu`)."""
+import os
+
+import numpy as np
+import pytest
+import torch as th
+
+from oracle import ref_shim
+from tests import harness
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _gold(case):
+    return dict(np.load(os.path.join(GOLDEN, f"{case}.npz")))
+
+
+@pytest.mark.parametrize("case", list(harness.BC_CASES))
+def test_oracle_bc_matches_golden(case, tmp_path):
+    gold, got = _gold(case), harness.run_bc_case("oracle", case, str(tmp_path))
+    assert set(gold) == set(got)
+    assert np.array_equal(gold["torch_rng_after"], got["torch_rng_after"])   # same DataLoader draws
+    assert gold["log_rows"].shape == got["log_rows"].shape
+    for k in gold:
+        if k != "torch_rng_after":  # torch CPU autograd: exact on the generating host, tight elsewhere
+            np.testing.assert_allclose(got[k], gold[k], rtol=1e-5, atol=1e-6, err_msg=k)
+
+
+@pytest.mark.reference
+@pytest.mark.skipif(not ref_shim.reference_available(), reason="/root/reference not present")
+@pytest.mark.parametrize("case", list(harness.BC_CASES))
+def test_oracle_bc_bit_identical_to_live_reference(case, tmp_path):
+    ref = harness.run_bc_case("reference", case, str(tmp_path / "r"))
+    got = harness.run_bc_case("oracle", case, str(tmp_path / "o"))
+    for k in ref:
+        assert ref[k].dtype == got[k].dtype and np.array_equal(ref[k], got[k], equal_nan=True), k
+
+
+def test_bc_argument_contract(tmp_path):
+    """bc.py:47-57,325-327: exactly one of n_epochs / n_batches; batch size a multiple of the minibatch size."""
+    from imitation_amd import spaces
+    from oracle import imitation_restated as o
+
+    osp, asp = spaces.Box(-np.inf, np.inf, (3,), np.float32), spaces.Box(-1, 1, (2,), np.float32)
+    demos = o.Transitions(obs=np.zeros((40, 3), np.float32), acts=np.zeros((40, 2), np.float32),
+                          next_obs=np.zeros((40, 3), np.float32), dones=np.zeros(40, bool))
+    with pytest.raises(ValueError, match="multiple of minibatch"):
+        o.BC(observation_space=osp, action_space=asp, rng=np.random.default_rng(0), batch_size=32, minibatch_size=5)
+    t = o.BC(observation_space=osp, action_space=asp, rng=np.random.default_rng(0), demonstrations=demos, batch_size=8,
+             custom_logger=o.configure_logger(str(tmp_path), []))
+    with pytest.raises(ValueError, match="exactly one"):
+        t.train()
+    with pytest.raises(ValueError, match="exactly one"):
+        t.train(n_epochs=1, n_batches=1)
