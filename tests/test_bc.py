@@ -54,3 +54,29 @@ def test_bc_argument_contract(tmp_path):
         t.train()
     with pytest.raises(ValueError, match="exactly one"):
         t.train(n_epochs=1, n_batches=1)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", list(harness.BC_CASES))
+def test_hip_bc_matches_reference_golden(case, tmp_path):
+    """The HIP BC trainer (policy kernels through the C ABI) against the reference's own run: identical batch
+    order (torch generator post-state bit-equal), identical log schedule, parameters and every logged metric
+    within the tolerance of the adversarial end-to-end tests."""
+    if not th.cuda.is_available():
+        pytest.skip("no GPU")
+    gold, got = _gold(case), harness.run_bc_case("hip", case, str(tmp_path), device="cuda")
+    assert set(gold) == set(got), set(gold) ^ set(got)
+    assert np.array_equal(gold["torch_rng_after"], got["torch_rng_after"])
+    assert gold["log_rows"].shape == got["log_rows"].shape
+    worst = 0.0
+    for k in gold:
+        if k == "torch_rng_after":
+            continue
+        x, y = np.asarray(got[k], dtype=np.float64), np.asarray(gold[k], dtype=np.float64)
+        assert x.shape == y.shape, k
+        if y.dtype.kind in "biu" or k.endswith("count"):
+            assert np.array_equal(x, y), k
+        else:
+            np.testing.assert_allclose(x, y, rtol=2e-4, atol=5e-5, err_msg=k)
+            worst = max(worst, float(np.max(np.abs(x - y))) if x.size else 0.0)
+    print(case, "max abs deviation from the reference:", worst)
