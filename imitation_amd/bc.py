@@ -63,12 +63,8 @@ class BC:
         self.minibatch_size = minibatch_size or batch_size
         if self.batch_size % self.minibatch_size != 0:
             raise ValueError("Batch size must be a multiple of minibatch size.")
-        if self.minibatch_size != self.batch_size:
-            raise NotImplementedError("gradient accumulation over minibatches is not built for BC yet")
         if optimizer_cls is not th.optim.Adam:
             raise NotImplementedError("the fused policy step implements Adam (the reference's default)")
-        if l2_weight != 0.0:
-            raise NotImplementedError("l2_weight != 0 is not built yet (the reference's default is 0.0)")
         optimizer_kwargs = dict(optimizer_kwargs or {})
         if "weight_decay" in optimizer_kwargs:
             raise ValueError("Use the parameter l2_weight instead of weight_decay.")
@@ -95,11 +91,16 @@ class BC:
         flat = self.policy._flat
         self._exp_avg, self._exp_avg_sq = th.zeros_like(flat), th.zeros_like(flat)
         self._steps = 0
-        B = self.batch_size
+        B = self.minibatch_size
         self._ws = th.zeros(int(L.load().ia_ppo_ws_floats(C.byref(self.policy.desc), B, B)), device=self._device)
         self._stats = th.zeros(8, device=self._device)
         self._ones, self._zeros = th.ones(B, device=self._device), th.zeros(B, device=self._device)
         self._rows = th.arange(B, dtype=th.int64, device=self._device)
+        # gradient accumulation over minibatches and / or an L2 term: gradient and update as two launches
+        # with the accumulated flat gradient in between; otherwise one fused launch per batch
+        self._fused = self.minibatch_size == self.batch_size and self.l2_weight == 0.0
+        self._grad_off = int(L.load().ia_ppo_grad_offset(C.byref(self.policy.desc), B))
+        self._acc = th.zeros_like(flat)
         self._tensorboard_step = 0
         self._current_epoch = 0
 
@@ -141,6 +142,39 @@ class BC:
                self.lr / bc1, math.sqrt(bc2), L.ptr(self._ws), L.ptr(self._stats), L.stream())
         return logp, ent
 
+    def _accumulate(self, idx: np.ndarray):
+        """Gradient of one minibatch's share of the batch loss (`loss * minibatch_size / batch_size`,
+        bc.py:494-499) added to the accumulator; -> (log_prob, entropy) of the minibatch."""
+        pol = self.policy
+        i = th.as_tensor(idx).to(self._device, non_blocking=True)
+        obs, acts = self._demo_obs.index_select(0, i), self._demo_acts.index_select(0, i)
+        _, logp, ent = pol.evaluate_actions(obs, acts)
+        share = len(idx) / self.batch_size
+        rn = pol.features_extractor.normalize
+        B = len(idx)
+        P = pol._flat.numel()
+        L.call("ia_ppo_minibatch_grad", C.byref(pol.desc), L.ptr(pol._flat), L.ptr(pol._flat_t),
+               L.ptr(rn.running_mean) if rn else None, L.ptr(rn.running_var) if rn else None,
+               L.ptr(rn.count) if rn else None, 0, L.ptr(obs), L.ptr(acts), L.ptr(logp),
+               L.ptr(self._ones * share), L.ptr(self._zeros), L.ptr(self._rows), B, 1, B, 0, 0.2,
+               self.ent_weight * share, 0.0, L.ptr(self._ws), L.stream())
+        self._acc += self._ws[self._grad_off:self._grad_off + P]
+        if self.l2_weight:
+            self._acc.add_(pol._flat, alpha=self.l2_weight * share)   # d/dw of l2_weight * sum(w^2) / 2, this share
+        return logp, ent
+
+    def _apply_accumulated(self) -> None:
+        pol = self.policy
+        self._steps += 1
+        bc1 = 1.0 - self.betas[0] ** self._steps
+        bc2 = 1.0 - self.betas[1] ** self._steps
+        P = pol._flat.numel()
+        self._ws[self._grad_off:self._grad_off + P].copy_(self._acc)
+        L.call("ia_ppo_minibatch_apply", C.byref(pol.desc), L.ptr(pol._flat), L.ptr(pol._flat_t), self.minibatch_size,
+               self.ent_weight, 0.0, 3.0e38, L.ptr(self._exp_avg), L.ptr(self._exp_avg_sq), self.betas[0],
+               self.betas[1], self.eps, self.lr / bc1, math.sqrt(bc2), L.ptr(self._ws), L.ptr(self._stats), L.stream())
+        self._acc.zero_()
+
     def _metrics(self, logp: th.Tensor, ent: th.Tensor, l2_norm: th.Tensor) -> Dict[str, float]:
         """`BehaviorCloningLossCalculator` (bc.py:138-156) from the per-row outputs; one read-back."""
         v = th.stack([logp.mean(), ent.mean(), th.exp(logp).mean(), l2_norm]).cpu().numpy().astype(np.float32)
@@ -179,32 +213,48 @@ class BC:
             self._tensorboard_step = 0
         self._current_epoch = 0
         num_samples_so_far = 0
+        n_minibatches = n_batches * (self.batch_size // self.minibatch_size) if n_batches is not None else None
+        seen = 0          # minibatches so far
         batch_num = 0
         epoch = 0
-        while True:
+        last = None       # (log_prob, entropy, l2_norm) of the last minibatch: what the reference logs
+
+        def process_batch():
+            if not self._fused:
+                self._apply_accumulated()
+            if batch_num % log_interval == 0:
+                stats: Mapping[str, float] = {}
+                if log_rollouts_venv is not None and log_rollouts_n_episodes > 0:
+                    from imitation_amd import rollout
+
+                    trajs = rollout.generate_trajectories(self.policy, log_rollouts_venv,
+                                                          rollout.make_min_episodes(log_rollouts_n_episodes),
+                                                          rng=self.rng)
+                    stats = rollout.rollout_stats(trajs)
+                self._log_batch(batch_num, self.minibatch_size, num_samples_so_far, self._metrics(*last), stats)
+            if on_batch_end is not None:
+                on_batch_end()
+
+        done = False
+        while not done:
             some = False
             for idx in self._stream.epoch():
                 some = True
-                # metrics are those of the batch before its update; l2 of the parameters likewise
-                want_log = batch_num % log_interval == 0
-                l2_norm = (self.policy._flat.square().sum() / 2) if want_log else None
-                logp, ent = self._step(idx)
+                # metrics are those of the minibatch before the update; l2 of the parameters likewise
+                batch_num = seen * self.minibatch_size // self.batch_size
+                will_log = batch_num % log_interval == 0
+                l2_norm = (self.policy._flat.square().sum() / 2) if will_log else None
+                logp, ent = self._step(idx) if self._fused else self._accumulate(idx)
+                last = (logp, ent, l2_norm)
                 num_samples_so_far += len(idx)
-                if want_log:
-                    stats: Mapping[str, float] = {}
-                    if log_rollouts_venv is not None and log_rollouts_n_episodes > 0:
-                        from imitation_amd import rollout
-
-                        trajs = rollout.generate_trajectories(self.policy, log_rollouts_venv,
-                                                              rollout.make_min_episodes(log_rollouts_n_episodes),
-                                                              rng=self.rng)
-                        stats = rollout.rollout_stats(trajs)
-                    self._log_batch(batch_num, len(idx), num_samples_so_far, self._metrics(logp, ent, l2_norm), stats)
-                if on_batch_end is not None:
-                    on_batch_end()
-                batch_num += 1
-                if n_batches is not None and batch_num >= n_batches:
-                    return
+                seen += 1
+                if num_samples_so_far % self.batch_size == 0:
+                    process_batch()
+                if n_minibatches is not None and seen >= n_minibatches:
+                    done = True
+                    break
+            if done:
+                break
             if not some:
                 raise AssertionError(f"Data loader returned no data during epoch {epoch} -- did it reset correctly?")
             self._current_epoch = epoch + 1
@@ -212,4 +262,9 @@ class BC:
                 on_epoch_end()
             epoch += 1
             if n_epochs is not None and epoch >= n_epochs:
-                return
+                break
+        if num_samples_so_far % self.batch_size != 0:   # an incomplete last batch still steps (bc.py:505-508)
+            batch_num += 1
+            if last[2] is None:
+                last = (last[0], last[1], self.policy._flat.square().sum() / 2)
+            process_batch()

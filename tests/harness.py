@@ -298,6 +298,9 @@ BC_CASES: Dict[str, Dict[str, Any]] = {
     # train-mode NormalizeFeaturesExtractor(RunningNorm): `evaluate_actions` updates the statistics every batch
     "bc_norm": dict(obs_dim=7, act_dim=2, n_discrete=None, n_demo=128, batch_size=64, ent_weight=1e-3,
                     train=dict(n_epochs=3), norm_policy=True, log_interval=1),
+    # gradient accumulation (minibatch 8 of 24; batches straddle epoch ends; incomplete last batch) + L2 term
+    "bc_accum_l2": dict(obs_dim=6, act_dim=2, n_discrete=None, n_demo=100, batch_size=24, minibatch_size=8,
+                        ent_weight=1e-3, l2_weight=1e-2, train=dict(n_epochs=2), norm_policy=False, log_interval=2),
 }
 
 
@@ -361,6 +364,7 @@ def run_bc_case(impl: str, name: str, log_dir: str, device: str = "cpu") -> Dict
     kw = dict(device=device) if impl == "hip" else {}
     trainer = ns.BC(observation_space=obs_space, action_space=act_space, rng=np.random.default_rng(0), policy=policy,
                     demonstrations=demos, batch_size=cfg["batch_size"], ent_weight=cfg["ent_weight"],
+                    minibatch_size=cfg.get("minibatch_size"), l2_weight=cfg.get("l2_weight", 0.0),
                     custom_logger=logger, **kw)
     trainer.train(log_interval=cfg["log_interval"], progress_bar=False, **cfg["train"])
     out = {f"policy/{k}": _np(v) for k, v in trainer.policy.state_dict().items()}
