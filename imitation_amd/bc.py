@@ -13,6 +13,8 @@ One optimiser step = one pass of the policy kernels over a batch of expert rows:
      `evaluate_actions`' values are discarded); no gradient clipping; Adam with the reference's defaults.
 Index decisions stay on the host with the reference's RNG call sequence (one `DataLoader` iterator per
 epoch: a base-seed draw, a sampler-seed draw and a `randperm` from torch's global generator).
+The four logged means (log-prob, entropy, exp(log-prob), sum of squared parameters) and the flat-gradient
+accumulation across minibatches are small torch reductions / axpys on the device tensors.
 """
 from __future__ import annotations
 
@@ -121,13 +123,23 @@ class BC:
         self._stream = _EpochIndexStream(n, self.minibatch_size)
         self._demo_obs = th.as_tensor(np.ascontiguousarray(obs.reshape(n, -1))).to(self._device, th.float32)
         self._demo_acts = th.as_tensor(np.ascontiguousarray(acts.reshape(n, -1))).to(self._device, th.float32)
+        self._obs_b = th.empty(self.minibatch_size, self._demo_obs.shape[1], device=self._device)
+        self._acts_b = th.empty(self.minibatch_size, self._demo_acts.shape[1], device=self._device)
+
+    def _gather(self, idx: np.ndarray):
+        """Expert rows `idx` of the device-resident demonstration table -> (obs [B, D], acts [B, A])."""
+        B = len(idx)
+        i = th.as_tensor(idx).to(self._device, non_blocking=True)
+        obs, acts = self._obs_b[:B], self._acts_b[:B]
+        L.call("ia_gather_rows", L.ptr(self._demo_obs), L.ptr(i), B, self._demo_obs.shape[1], L.ptr(obs), L.stream())
+        L.call("ia_gather_rows", L.ptr(self._demo_acts), L.ptr(i), B, self._demo_acts.shape[1], L.ptr(acts), L.stream())
+        return obs, acts
 
     # ---- one optimiser step ---------------------------------------------------------------------------
     def _step(self, idx: np.ndarray):
         """-> (log_prob [B], entropy [B]) of the batch BEFORE the update (what the reference logs)."""
         pol = self.policy
-        i = th.as_tensor(idx).to(self._device, non_blocking=True)
-        obs, acts = self._demo_obs.index_select(0, i), self._demo_acts.index_select(0, i)
+        obs, acts = self._gather(idx)
         _, logp, ent = pol.evaluate_actions(obs, acts)
         self._steps += 1
         bc1 = 1.0 - self.betas[0] ** self._steps
@@ -146,8 +158,7 @@ class BC:
         """Gradient of one minibatch's share of the batch loss (`loss * minibatch_size / batch_size`,
         bc.py:494-499) added to the accumulator; -> (log_prob, entropy) of the minibatch."""
         pol = self.policy
-        i = th.as_tensor(idx).to(self._device, non_blocking=True)
-        obs, acts = self._demo_obs.index_select(0, i), self._demo_acts.index_select(0, i)
+        obs, acts = self._gather(idx)
         _, logp, ent = pol.evaluate_actions(obs, acts)
         share = len(idx) / self.batch_size
         rn = pol.features_extractor.normalize
