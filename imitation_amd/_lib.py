@@ -56,6 +56,10 @@ _SIGS = {
     "ia_version": ([], C.c_int),
     "ia_host_mt19937_permutations": ([_P, C.POINTER(C.c_int), _L, _I, _P], C.c_int),
     "ia_host_mt19937_seeded_permutations": ([_P, _I, _L, _I, _P], C.c_int),
+    "ia_im2col_u8_nchw": ([_P, _I, _I, _I, _I, _I, _I, _I, _F, _P, _P], C.c_int),
+    "ia_im2col_f32_nhwc": ([_P, _I, _I, _I, _I, _I, _I, _I, _P, _P], C.c_int),
+    "ia_col2im_nhwc": ([_P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P], C.c_int),
+    "ia_categorical_loss": ([_P, _I, _P, _I, _I, _F, _F, _P, _P, _P, _P], C.c_int),
     "ia_mlp_param_count": ([C.POINTER(MlpDesc)], C.c_int64),
     "ia_mlp_hidden_floats_per_row": ([C.POINTER(MlpDesc)], C.c_int64),
     "ia_gemm_f32": ([_I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _P, _I, _P, _I, _I, _P, _P], C.c_int),

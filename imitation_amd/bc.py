@@ -93,16 +93,22 @@ class BC:
         flat = self.policy._flat
         self._exp_avg, self._exp_avg_sq = th.zeros_like(flat), th.zeros_like(flat)
         self._steps = 0
-        B = self.minibatch_size
-        self._ws = th.zeros(int(L.load().ia_ppo_ws_floats(C.byref(self.policy.desc), B, B)), device=self._device)
-        self._stats = th.zeros(8, device=self._device)
-        self._ones, self._zeros = th.ones(B, device=self._device), th.zeros(B, device=self._device)
-        self._rows = th.arange(B, dtype=th.int64, device=self._device)
-        # gradient accumulation over minibatches and / or an L2 term: gradient and update as two launches
-        # with the accumulated flat gradient in between; otherwise one fused launch per batch
-        self._fused = self.minibatch_size == self.batch_size and self.l2_weight == 0.0
-        self._grad_off = int(L.load().ia_ppo_grad_offset(C.byref(self.policy.desc), B))
         self._acc = th.zeros_like(flat)
+        B = self.minibatch_size
+        from imitation_amd.cnn_policy import ActorCriticCnnPolicy
+
+        self._image = isinstance(self.policy, ActorCriticCnnPolicy)
+        if self._image:   # convolution stack: explicit forward / backward launches, then Adam on the flat buffer
+            self._fused = False
+        else:
+            self._ws = th.zeros(int(L.load().ia_ppo_ws_floats(C.byref(self.policy.desc), B, B)), device=self._device)
+            self._stats = th.zeros(8, device=self._device)
+            self._ones, self._zeros = th.ones(B, device=self._device), th.zeros(B, device=self._device)
+            self._rows = th.arange(B, dtype=th.int64, device=self._device)
+            # gradient accumulation over minibatches and / or an L2 term: gradient and update as two launches
+            # with the accumulated flat gradient in between; otherwise one fused launch per batch
+            self._fused = self.minibatch_size == self.batch_size and self.l2_weight == 0.0
+            self._grad_off = int(L.load().ia_ppo_grad_offset(C.byref(self.policy.desc), B))
         self._tensorboard_step = 0
         self._current_epoch = 0
 
@@ -121,16 +127,32 @@ class BC:
         obs, acts = np.asarray(demonstrations.obs), np.asarray(demonstrations.acts)
         n = len(obs)
         self._stream = _EpochIndexStream(n, self.minibatch_size)
-        self._demo_obs = th.as_tensor(np.ascontiguousarray(obs.reshape(n, -1))).to(self._device, th.float32)
+        self._demo_host = (obs, acts)
+        self._demo_obs = None      # device tables are laid out for the policy: uploaded on first use
+
+    def _upload(self) -> None:
+        obs, acts = self._demo_host
+        n = len(obs)
+        if self._image:   # frames stay uint8 [N, C, H, W]; the policy applies x / 255 while building its columns
+            self._demo_obs = th.as_tensor(np.ascontiguousarray(obs)).to(self._device)
+        else:
+            self._demo_obs = th.as_tensor(np.ascontiguousarray(obs.reshape(n, -1))).to(self._device, th.float32)
+            self._obs_b = th.empty(self.minibatch_size, self._demo_obs.shape[1], device=self._device)
         self._demo_acts = th.as_tensor(np.ascontiguousarray(acts.reshape(n, -1))).to(self._device, th.float32)
-        self._obs_b = th.empty(self.minibatch_size, self._demo_obs.shape[1], device=self._device)
         self._acts_b = th.empty(self.minibatch_size, self._demo_acts.shape[1], device=self._device)
 
     def _gather(self, idx: np.ndarray):
         """Expert rows `idx` of the device-resident demonstration table -> (obs [B, D], acts [B, A])."""
         B = len(idx)
+        if self._demo_obs is None:
+            self._upload()
         i = th.as_tensor(idx).to(self._device, non_blocking=True)
-        obs, acts = self._obs_b[:B], self._acts_b[:B]
+        acts = self._acts_b[:B]
+        if self._image:   # uint8 frames: a byte gather (data movement only)
+            obs = self._demo_obs.index_select(0, i)
+            L.call("ia_gather_rows", L.ptr(self._demo_acts), L.ptr(i), B, self._demo_acts.shape[1], L.ptr(acts), L.stream())
+            return obs, acts
+        obs = self._obs_b[:B]
         L.call("ia_gather_rows", L.ptr(self._demo_obs), L.ptr(i), B, self._demo_obs.shape[1], L.ptr(obs), L.stream())
         L.call("ia_gather_rows", L.ptr(self._demo_acts), L.ptr(i), B, self._demo_acts.shape[1], L.ptr(acts), L.stream())
         return obs, acts
@@ -159,8 +181,16 @@ class BC:
         bc.py:494-499) added to the accumulator; -> (log_prob, entropy) of the minibatch."""
         pol = self.policy
         obs, acts = self._gather(idx)
-        _, logp, ent = pol.evaluate_actions(obs, acts)
         share = len(idx) / self.batch_size
+        if self._image:
+            B = len(idx)
+            _, logp, ent = pol.evaluate_actions(obs, acts, logp_coef=-share / B, ent_coef=-self.ent_weight * share / B,
+                                                want_grad=True)
+            pol.backward(B, self._acc)
+            if self.l2_weight:
+                self._acc.add_(pol._flat, alpha=self.l2_weight * share)
+            return logp, ent
+        _, logp, ent = pol.evaluate_actions(obs, acts)
         rn = pol.features_extractor.normalize
         B = len(idx)
         P = pol._flat.numel()
@@ -180,6 +210,11 @@ class BC:
         bc1 = 1.0 - self.betas[0] ** self._steps
         bc2 = 1.0 - self.betas[1] ** self._steps
         P = pol._flat.numel()
+        if self._image:
+            L.call("ia_adam_step", L.ptr(pol._flat), L.ptr(self._acc), L.ptr(self._exp_avg), L.ptr(self._exp_avg_sq), P,
+                   self.betas[0], self.betas[1], self.eps, 0.0, self.lr / bc1, math.sqrt(bc2), L.stream())
+            self._acc.zero_()
+            return
         self._ws[self._grad_off:self._grad_off + P].copy_(self._acc)
         L.call("ia_ppo_minibatch_apply", C.byref(pol.desc), L.ptr(pol._flat), L.ptr(pol._flat_t), self.minibatch_size,
                self.ent_weight, 0.0, 3.0e38, L.ptr(self._exp_avg), L.ptr(self._exp_avg_sq), self.betas[0],

@@ -1,0 +1,162 @@
+// Image path of the BC step (BASELINE config 4: NatureCNN on [C,H,W] uint8 frames):
+// convolutions as im2col + the fp32 MFMA GEMMs of gemm.hip (activations NHWC, weights in torch's
+// [Cout, Cin*KH*KW] layout = the GEMM's B operand as stored), their input gradient as a GEMM + a gather-
+// form col2im (each input element sums the windows that cover it: no atomics, fixed order), and the
+// Categorical head (log-prob of the expert action, entropy, gradient of the BC loss w.r.t. the logits).
+// First version: explicit column buffers in HBM (288 GB: batch 4096 x 84x84x4 needs 1.7 GB for the first
+// layer) -- every kernel here is a streaming gather bound by HBM; the flops are in the GEMMs.
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "common.h"
+
+namespace {
+
+inline int cdiv_ll(long long a, long long b) { return (int)((a + b - 1) / b); }
+
+// col[m = (b, oh, ow)][k = (c, i, j)] = x[b, c, oh*S+i, ow*S+j] * scale     (x: uint8, channel-first)
+__global__ void im2col_u8_nchw_kernel(const uint8_t* __restrict__ x, int C, int H, int W, int KH, int KW, int S,
+                                      int OH, int OW, float scale, float* __restrict__ col, long long total) {
+  const int K = C * KH * KW;
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+    const long long m = e / K;
+    const int k = (int)(e - m * K);
+    const int p = (int)(m % (OH * OW));
+    const long long b = m / (OH * OW);
+    const int oh = p / OW, ow = p - oh * OW;
+    const int c = k / (KH * KW), r = k - c * (KH * KW);
+    const int i = r / KW, j = r - i * KW;
+    col[e] = (float)x[((b * C + c) * H + oh * S + i) * W + ow * S + j] * scale;
+  }
+}
+
+// col[m = (b, oh, ow)][k = (c, i, j)] = x[b, oh*S+i, ow*S+j, c]              (x: fp32, channel-last)
+__global__ void im2col_f32_nhwc_kernel(const float* __restrict__ x, int C, int H, int W, int KH, int KW, int S,
+                                       int OH, int OW, float* __restrict__ col, long long total) {
+  const int K = C * KH * KW;
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+    const long long m = e / K;
+    const int k = (int)(e - m * K);
+    const int p = (int)(m % (OH * OW));
+    const long long b = m / (OH * OW);
+    const int oh = p / OW, ow = p - oh * OW;
+    const int c = k / (KH * KW), r = k - c * (KH * KW);
+    const int i = r / KW, j = r - i * KW;
+    col[e] = x[((b * H + oh * S + i) * W + ow * S + j) * C + c];
+  }
+}
+
+// dx[b, h, w, c] = sum over the windows (oh, ow, i, j) with oh*S+i == h, ow*S+j == w of dcol[(b,oh,ow)][(c,i,j)],
+// in (i, j) order; multiplied by [mask[b,h,w,c] > 0] when a mask (the ReLU output of that layer) is given.
+__global__ void col2im_nhwc_kernel(const float* __restrict__ dcol, int C, int H, int W, int KH, int KW, int S, int OH,
+                                   int OW, const float* __restrict__ mask, float* __restrict__ dx, long long total) {
+  const int K = C * KH * KW;
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(e % C);
+    const long long t = e / C;
+    const int w = (int)(t % W);
+    const long long t2 = t / W;
+    const int h = (int)(t2 % H);
+    const long long b = t2 / H;
+    float s = 0.f;
+    for (int i = 0; i < KH; ++i) {
+      const int hh = h - i;
+      if (hh < 0 || hh % S != 0) continue;
+      const int oh = hh / S;
+      if (oh >= OH) continue;
+      for (int j = 0; j < KW; ++j) {
+        const int ww = w - j;
+        if (ww < 0 || ww % S != 0) continue;
+        const int ow = ww / S;
+        if (ow >= OW) continue;
+        s += dcol[((b * OH + oh) * OW + ow) * (long long)K + (c * KH + i) * KW + j];
+      }
+    }
+    if (mask != nullptr && !(mask[e] > 0.f)) s = 0.f;
+    dx[e] = s;
+  }
+}
+
+// One row per lane. logits [B][ldl]; act = expert action index (fp32). log-softmax z, p = exp(z):
+//   logp = z[act], H = -sum_k p_k z_k  (torch Categorical.log_prob / .entropy),
+//   dlogits_k = c_lp * ([k == act] - p_k) + c_ent * (-p_k (z_k + H))     (= d(c_lp*logp + c_ent*H)/dlogit_k)
+__global__ void categorical_loss_kernel(const float* __restrict__ logits, int ldl, const float* __restrict__ act, int B,
+                                        int A, float c_lp, float c_ent, float* __restrict__ logp,
+                                        float* __restrict__ entropy, float* __restrict__ dlogits) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= B) return;
+  const float* row = logits + (long long)r * ldl;
+  float mx = row[0];
+  for (int k = 1; k < A; ++k) mx = fmaxf(mx, row[k]);
+  float se = 0.f;
+  for (int k = 0; k < A; ++k) se += expf(row[k] - mx);
+  const float lse = mx + logf(se);
+  const int a = (int)act[r];
+  float H = 0.f;
+  for (int k = 0; k < A; ++k) {
+    const float z = row[k] - lse;
+    H -= expf(z) * z;
+  }
+  logp[r] = row[a] - lse;
+  entropy[r] = H;
+  if (dlogits != nullptr) {
+    float* drow = dlogits + (long long)r * ldl;
+    for (int k = 0; k < A; ++k) {
+      const float z = row[k] - lse, p = expf(z);
+      drow[k] = c_lp * ((k == a ? 1.f : 0.f) - p) + c_ent * (-p * (z + H));
+    }
+  }
+}
+
+inline dim3 stream_grid(long long total) {
+  const long long blocks = (total + 255) / 256;
+  return dim3((unsigned)(blocks < 65536 * 4 ? (blocks > 0 ? blocks : 1) : 65536 * 4));
+}
+
+}  // namespace
+
+extern "C" {
+
+int ia_im2col_u8_nchw(const uint8_t* x, int B, int C, int H, int W, int KH, int KW, int S, float scale, float* col,
+                      void* stream) {
+  if (!x || !col || B <= 0 || C <= 0 || KH <= 0 || KW <= 0 || S <= 0 || H < KH || W < KW) return IA_ERR_ARG;
+  const int OH = (H - KH) / S + 1, OW = (W - KW) / S + 1;
+  const long long total = (long long)B * OH * OW * C * KH * KW;
+  hipLaunchKernelGGL(im2col_u8_nchw_kernel, stream_grid(total), dim3(256), 0, (hipStream_t)stream, x, C, H, W, KH, KW,
+                     S, OH, OW, scale, col, total);
+  IA_CHECK_LAUNCH();
+  return IA_OK;
+}
+
+int ia_im2col_f32_nhwc(const float* x, int B, int H, int W, int C, int KH, int KW, int S, float* col, void* stream) {
+  if (!x || !col || B <= 0 || C <= 0 || KH <= 0 || KW <= 0 || S <= 0 || H < KH || W < KW) return IA_ERR_ARG;
+  const int OH = (H - KH) / S + 1, OW = (W - KW) / S + 1;
+  const long long total = (long long)B * OH * OW * C * KH * KW;
+  hipLaunchKernelGGL(im2col_f32_nhwc_kernel, stream_grid(total), dim3(256), 0, (hipStream_t)stream, x, C, H, W, KH, KW,
+                     S, OH, OW, col, total);
+  IA_CHECK_LAUNCH();
+  return IA_OK;
+}
+
+int ia_col2im_nhwc(const float* dcol, int B, int H, int W, int C, int KH, int KW, int S, const float* relu_mask,
+                   float* dx, void* stream) {
+  if (!dcol || !dx || B <= 0 || C <= 0 || KH <= 0 || KW <= 0 || S <= 0 || H < KH || W < KW) return IA_ERR_ARG;
+  const int OH = (H - KH) / S + 1, OW = (W - KW) / S + 1;
+  const long long total = (long long)B * H * W * C;
+  hipLaunchKernelGGL(col2im_nhwc_kernel, stream_grid(total), dim3(256), 0, (hipStream_t)stream, dcol, C, H, W, KH, KW,
+                     S, OH, OW, relu_mask, dx, total);
+  IA_CHECK_LAUNCH();
+  return IA_OK;
+}
+
+int ia_categorical_loss(const float* logits, int ldl, const float* actions, int B, int A, float logp_coef,
+                        float ent_coef, float* logp, float* entropy, float* dlogits, void* stream) {
+  if (!logits || !actions || !logp || !entropy || B <= 0 || A <= 0 || ldl < A) return IA_ERR_ARG;
+  hipLaunchKernelGGL(categorical_loss_kernel, dim3(cdiv_ll(B, 128)), dim3(128), 0, (hipStream_t)stream, logits, ldl,
+                     actions, B, A, logp_coef, ent_coef, logp, entropy, dlogits);
+  IA_CHECK_LAUNCH();
+  return IA_OK;
+}
+
+}  // extern "C"

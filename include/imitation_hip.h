@@ -253,6 +253,23 @@ int ia_ppo_minibatch_apply(const ia_policy_desc* d, float* params, float* params
                            float vf_coef, float max_grad_norm, float* exp_avg, float* exp_avg_sq, float beta1,
                            float beta2, float adam_eps, float step_size, float bc2_sqrt, float* ws, float* stats,
                            void* stream);
+/* ---- image policies (SB3 NatureCNN / ActorCriticCnnPolicy; algorithms/bc.py:94-156 with BASELINE config 4) ----
+ * Convolution = im2col + ia_gemm_f32 (mode 0, weights [Cout, Cin*KH*KW] as torch stores them); activations
+ * are channel-last [B, H, W, C]; column index k = (c*KH + i)*KW + j, row m = (b*OH + oh)*OW + ow.
+ * `_u8_nchw`: the policy's input frames, uint8 channel-first ([SB3 preprocess_obs]: x / 255 -> scale). */
+int ia_im2col_u8_nchw(const uint8_t* x, int B, int C, int H, int W, int KH, int KW, int S, float scale, float* col,
+                      void* stream);
+int ia_im2col_f32_nhwc(const float* x, int B, int H, int W, int C, int KH, int KW, int S, float* col, void* stream);
+/* Input gradient of a convolution from its column gradient (gather form, fixed order, no atomics);
+ * relu_mask (nullable) = that input's own post-ReLU value: the gradient is zeroed where it is <= 0. */
+int ia_col2im_nhwc(const float* dcol, int B, int H, int W, int C, int KH, int KW, int S, const float* relu_mask,
+                   float* dx, void* stream);
+/* Categorical head ([SB3 CategoricalDistribution] log_prob / entropy of torch.distributions.Categorical):
+ * logp[r] = log_softmax(logits[r])[action r], entropy[r]; dlogits (nullable) = gradient of
+ * logp_coef*logp + ent_coef*entropy per row (BC: -share/B and -ent_weight*share/B, bc.py:138-156,494-499). */
+int ia_categorical_loss(const float* logits, int ldl, const float* actions, int B, int A, float logp_coef,
+                        float ent_coef, float* logp, float* entropy, float* dlogits, void* stream);
+
 /* One PPO epoch = consecutive minibatches of the device-resident permutation `perm[T*n_envs]`
  * (host-drawn np.random.permutation); stats is [n_minibatches][8] or NULL. */
 int ia_ppo_epoch(const ia_policy_desc* d, float* params, float* params_t, float* norm_mean, float* norm_var,

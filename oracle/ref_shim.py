@@ -67,7 +67,7 @@ def install() -> None:
     common.on_policy_algorithm = _mod("stable_baselines3.common.on_policy_algorithm",
                                       OnPolicyAlgorithm=sb.OnPolicyAlgorithm)
     common.policies = _mod("stable_baselines3.common.policies", BasePolicy=sb.BasePolicy,
-                           ActorCriticPolicy=sb.ActorCriticPolicy)
+                           ActorCriticPolicy=sb.ActorCriticPolicy, ActorCriticCnnPolicy=sb.ActorCriticCnnPolicy)
     common.distributions = _mod("stable_baselines3.common.distributions",
                                 DiagGaussianDistribution=sb.DiagGaussianDistribution,
                                 SquashedDiagGaussianDistribution=sb.SquashedDiagGaussianDistribution,
@@ -85,7 +85,7 @@ def install() -> None:
                         get_device=sb.get_device)
     common.torch_layers = _mod("stable_baselines3.common.torch_layers", FlattenExtractor=sb.FlattenExtractor,
                                BaseFeaturesExtractor=sb.BaseFeaturesExtractor, MlpExtractor=sb.MlpExtractor,
-                               CombinedExtractor=sb.CombinedExtractor)
+                               CombinedExtractor=sb.CombinedExtractor, NatureCNN=sb.NatureCNN)
     sac = _mod("stable_baselines3.sac")
     sac.policies = _mod("stable_baselines3.sac.policies", SACPolicy=sb.SACPolicy)
     ppo = _mod("stable_baselines3.ppo", PPO=sb.PPO)

@@ -464,6 +464,28 @@ class FlattenExtractor(BaseFeaturesExtractor):
         return self.flatten(observations)
 
 
+class NatureCNN(BaseFeaturesExtractor):
+    """[SB3 torch_layers.NatureCNN] (Mnih et al. 2015): Conv(C,32,8,4)-ReLU-Conv(32,64,4,2)-ReLU-
+    Conv(64,64,3,1)-ReLU-Flatten, Linear(n_flatten, features_dim)-ReLU; channel-first uint8 images.
+    Parity unpinned (SB3 is absent); BASELINE config 4 / SURVEY 8f row 4."""
+
+    def __init__(self, observation_space, features_dim: int = 512, normalized_image: bool = False):
+        assert isinstance(observation_space, spaces.Box)
+        super().__init__(observation_space, features_dim)
+        assert is_image_space(observation_space), "NatureCNN is for uint8 image spaces [C, H, W]"
+        n_input_channels = observation_space.shape[0]
+        self.cnn = nn.Sequential(
+            nn.Conv2d(n_input_channels, 32, kernel_size=8, stride=4, padding=0), nn.ReLU(),
+            nn.Conv2d(32, 64, kernel_size=4, stride=2, padding=0), nn.ReLU(),
+            nn.Conv2d(64, 64, kernel_size=3, stride=1, padding=0), nn.ReLU(), nn.Flatten())
+        with th.no_grad():
+            n_flatten = self.cnn(th.zeros(1, *observation_space.shape)).shape[1]
+        self.linear = nn.Sequential(nn.Linear(n_flatten, features_dim), nn.ReLU())
+
+    def forward(self, observations: th.Tensor) -> th.Tensor:
+        return self.linear(self.cnn(observations))
+
+
 class CombinedExtractor(BaseFeaturesExtractor):
     """[SB3 torch_layers.CombinedExtractor] is for Dict observation spaces, which the path never uses;
     the name exists because `algorithms/bc.py:342-346` refers to it."""
@@ -648,6 +670,18 @@ class ActorCriticPolicy(BasePolicy):
     def predict_values(self, obs: th.Tensor) -> th.Tensor:
         features = self.extract_features(obs, self.vf_features_extractor)
         return self.value_net(self.mlp_extractor.forward_critic(features))
+
+
+class ActorCriticCnnPolicy(ActorCriticPolicy):
+    """[SB3 policies.ActorCriticCnnPolicy]: NatureCNN features, no further hidden layers (`net_arch=[]`
+    is SB3's default for the NatureCNN extractor), heads straight on the 512 features."""
+
+    def __init__(self, observation_space, action_space, lr_schedule, net_arch=None, activation_fn=nn.Tanh,
+                 features_extractor_class=NatureCNN, **kwargs):
+        if net_arch is None and features_extractor_class is NatureCNN:
+            net_arch = []
+        super().__init__(observation_space, action_space, lr_schedule, net_arch=net_arch, activation_fn=activation_fn,
+                         features_extractor_class=features_extractor_class, **kwargs)
 
 
 class SACPolicy(BasePolicy):

@@ -299,6 +299,10 @@ BC_CASES: Dict[str, Dict[str, Any]] = {
     "bc_norm": dict(obs_dim=7, act_dim=2, n_discrete=None, n_demo=128, batch_size=64, ent_weight=1e-3,
                     train=dict(n_epochs=3), norm_policy=True, log_interval=1),
     # gradient accumulation (minibatch 8 of 24; batches straddle epoch ends; incomplete last batch) + L2 term
+    # image observations (uint8 [C, H, W]) through the NatureCNN actor-critic policy (BASELINE config 4 shape,
+    # scaled down: 4 x 36 x 36 is the smallest image the 8/4 - 4/2 - 3/1 convolution stack accepts), Discrete(6)
+    "bc_cnn": dict(image=(4, 36, 36), obs_dim=None, act_dim=6, n_discrete=6, n_demo=96, batch_size=32,
+                   ent_weight=1e-3, train=dict(n_epochs=2), norm_policy=False, log_interval=2),
     "bc_accum_l2": dict(obs_dim=6, act_dim=2, n_discrete=None, n_demo=100, batch_size=24, minibatch_size=8,
                         ent_weight=1e-3, l2_weight=1e-2, train=dict(n_epochs=2), norm_policy=False, log_interval=2),
 }
@@ -308,19 +312,22 @@ def bc_namespace(impl: str) -> pytypes.SimpleNamespace:
     if impl == "reference":
         ns = namespace("reference")
         from imitation.algorithms import bc as rbc
+        from oracle import sb3_restated as sb
 
-        ns.BC = rbc.BC
+        ns.BC, ns.ActorCriticCnnPolicy = rbc.BC, sb.ActorCriticCnnPolicy
         return ns
     if impl == "oracle":
         ns = namespace("oracle")
         from oracle import imitation_restated as o
+        from oracle import sb3_restated as sb
 
-        ns.BC = o.BC
+        ns.BC, ns.ActorCriticCnnPolicy = o.BC, sb.ActorCriticCnnPolicy
         return ns
     ns = namespace("hip")
     import imitation_amd as p
 
     ns.BC = p.bc.BC
+    ns.ActorCriticCnnPolicy = getattr(getattr(p, "cnn_policy", None), "ActorCriticCnnPolicy", None)
     return ns
 
 
@@ -334,16 +341,24 @@ def run_bc_case(impl: str, name: str, log_dir: str, device: str = "cpu") -> Dict
     np.random.seed(0)
     rng = np.random.default_rng(3)
     n, od, ad = cfg["n_demo"], cfg["obs_dim"], cfg["act_dim"]
-    obs = rng.standard_normal((n, od)).astype(np.float32)
-    if cfg["n_discrete"] is None:
-        acts = np.tanh(obs[:, :ad] + 0.1 * rng.standard_normal((n, ad))).astype(np.float32)
-        act_space = spaces.Box(-1.0, 1.0, (ad,), np.float32)
-    else:
-        acts = (obs[:, 0] > 0).astype(np.int64)
-        act_space = spaces.Discrete(cfg["n_discrete"])
-    obs_space = spaces.Box(-np.inf, np.inf, (od,), np.float32)
-    demos = ns.Transitions(obs=obs, acts=acts, next_obs=obs.copy(), dones=np.zeros(n, dtype=bool))
     policy = None
+    if cfg.get("image"):
+        obs = rng.integers(0, 256, (n, *cfg["image"]), dtype=np.uint8)
+        acts = (obs.reshape(n, -1)[:, :7].sum(axis=1) % cfg["n_discrete"]).astype(np.int64)
+        act_space = spaces.Discrete(cfg["n_discrete"])
+        obs_space = spaces.Box(0, 255, cfg["image"], np.uint8)
+        policy = ns.ActorCriticCnnPolicy(observation_space=obs_space, action_space=act_space,
+                                         lr_schedule=lambda _: 1.0)
+    else:
+        obs = rng.standard_normal((n, od)).astype(np.float32)
+        if cfg["n_discrete"] is None:
+            acts = np.tanh(obs[:, :ad] + 0.1 * rng.standard_normal((n, ad))).astype(np.float32)
+            act_space = spaces.Box(-1.0, 1.0, (ad,), np.float32)
+        else:
+            acts = (obs[:, 0] > 0).astype(np.int64)
+            act_space = spaces.Discrete(cfg["n_discrete"])
+        obs_space = spaces.Box(-np.inf, np.inf, (od,), np.float32)
+    demos = ns.Transitions(obs=obs, acts=acts, next_obs=obs.copy(), dones=np.zeros(n, dtype=bool))
     if cfg["norm_policy"]:
         policy = ns.FeedForward32Policy(observation_space=obs_space, action_space=act_space,
                                         lr_schedule=lambda _: 1.0,

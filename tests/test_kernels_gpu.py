@@ -492,3 +492,43 @@ def test_ppo_epochs_match_oracle(D, A, H, discrete, norm, T, n, bs, path):
     Pt2 = th.empty_like(dp.P)
     L.call("ia_policy_transpose", C.byref(dp.d), L.ptr(dp.P), L.ptr(Pt2), L.stream())
     assert th.equal(Pt2, dp.Pt)
+
+
+@pytest.mark.parametrize("shape,B,A", [((4, 36, 36), 8, 6), ((3, 44, 52), 5, 4), ((1, 36, 40), 33, 18)])
+def test_cnn_policy_forward_and_gradient_match_torch(shape, B, A):
+    """NatureCNN actor-critic policy on the HIP path (im2col + MFMA GEMMs, col2im, Categorical head) against
+    the SB3-restated torch policy with the same weights: values / log-probs / entropies, and the gradient of
+    `c_lp * sum(logp) + c_ent * sum(entropy)` w.r.t. every parameter against torch autograd."""
+    from imitation_amd import spaces
+    from imitation_amd.cnn_policy import ActorCriticCnnPolicy
+    from oracle import sb3_restated as sb
+
+    osp, asp = spaces.Box(0, 255, shape, np.uint8), spaces.Discrete(A)
+    th.manual_seed(5)
+    ref = sb.ActorCriticCnnPolicy(osp, asp, lambda _: 1.0)
+    pol = ActorCriticCnnPolicy(osp, asp, lambda _: 1.0).to(DEV)
+    pol.load_state_dict(ref.state_dict())
+    for k, v in ref.state_dict().items():                      # layout round trip (linear.0 columns are permuted)
+        assert th.equal(pol.state_dict()[k].cpu(), v), k
+    rng = np.random.default_rng(1)
+    obs = rng.integers(0, 256, (B, *shape), dtype=np.uint8)
+    acts = rng.integers(0, A, B)
+    c_lp, c_ent = -0.7 / B, -0.01 / B
+    vals, logp, ent = pol.evaluate_actions(obs, acts, logp_coef=c_lp, ent_coef=c_ent, want_grad=True)
+    grad = th.zeros_like(pol._flat)
+    pol.backward(B, grad)
+    rv, rl, re = ref.evaluate_actions(th.as_tensor(obs), th.as_tensor(acts))
+    (c_lp * rl.sum() + c_ent * re.sum()).backward()
+    th.testing.assert_close(logp.cpu(), rl.detach(), rtol=2e-5, atol=2e-5)
+    th.testing.assert_close(ent.cpu(), re.detach(), rtol=2e-5, atol=2e-5)
+    th.testing.assert_close(vals.cpu(), rv.detach(), rtol=2e-5, atol=2e-5)
+    named = dict(ref.named_parameters())
+    for i, name in enumerate(pol._names):
+        if name == "value_net":
+            continue   # no gradient reaches the value head from this loss (torch leaves .grad None)
+        o, n, ob, nb = pol._offsets[i]
+        gw = pol._to_torch_layout(i, grad[o:o + n]).reshape(pol._shapes[i]).cpu()
+        rw, rb = named[f"{name}.weight"].grad, named[f"{name}.bias"].grad
+        scale = float(rw.abs().max()) + 1e-12
+        assert float((gw - rw).abs().max()) <= 2e-5 * scale + 1e-8, (name, float((gw - rw).abs().max()), scale)
+        assert float((grad[ob:ob + nb].cpu() - rb).abs().max()) <= 2e-5 * (float(rb.abs().max()) + 1e-12) + 1e-8, name
