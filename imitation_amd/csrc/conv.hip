@@ -15,35 +15,101 @@ namespace {
 
 inline int cdiv_ll(long long a, long long b) { return (int)((a + b - 1) / b); }
 
-// col[m = (b, oh, ow)][k = (c, i, j)] = x[b, c, oh*S+i, ow*S+j] * scale     (x: uint8, channel-first)
-__global__ void im2col_u8_nchw_kernel(const uint8_t* __restrict__ x, int C, int H, int W, int KH, int KW, int S,
-                                      int OH, int OW, float scale, float* __restrict__ col, long long total) {
+// Both im2col kernels: a block walks IM2COL_ROWS consecutive rows m = (b, oh, ow); the row -> input base
+// address arithmetic is wave-uniform (scalar unit), every thread keeps the input offsets of its own
+// columns k = tid + 256 t in registers (c, i, j resolved once), so an element costs one add, one load and
+// one coalesced store (the first version spent its time in per-element 64-bit divisions: 1.1 TB/s).
+constexpr int IM2COL_ROWS = 16;
+constexpr int IM2COL_KPT = 4;   // columns per thread: K <= 1024
+
+// col[m][k = (c, i, j)] = x[b, c, oh*S+i, ow*S+j] * scale     (x: uint8, channel-first)
+__global__ __launch_bounds__(256) void im2col_u8_nchw_kernel(const uint8_t* __restrict__ x, int C, int H, int W, int KH,
+                                                             int KW, int S, int OH, int OW, float scale,
+                                                             float* __restrict__ col, long long M) {
   const int K = C * KH * KW;
-  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
-    const long long m = e / K;
-    const int k = (int)(e - m * K);
+  int koff[IM2COL_KPT];
+#pragma unroll
+  for (int t = 0; t < IM2COL_KPT; ++t) {
+    const int k = min((int)threadIdx.x + 256 * t, K - 1);
+    const int c = k / (KH * KW), r = k - c * (KH * KW);
+    const int i = r / KW, j = r - i * KW;
+    koff[t] = (c * H + i) * W + j;
+  }
+  const long long m0 = (long long)blockIdx.x * IM2COL_ROWS;
+  for (int rr = 0; rr < IM2COL_ROWS; ++rr) {
+    const long long m = m0 + rr;
+    if (m >= M) return;
     const int p = (int)(m % (OH * OW));
     const long long b = m / (OH * OW);
     const int oh = p / OW, ow = p - oh * OW;
-    const int c = k / (KH * KW), r = k - c * (KH * KW);
-    const int i = r / KW, j = r - i * KW;
-    col[e] = (float)x[((b * C + c) * H + oh * S + i) * W + ow * S + j] * scale;
+    const uint8_t* src = x + (b * C * H + oh * S) * W + ow * S;
+    float* dst = col + m * K;
+#pragma unroll
+    for (int t = 0; t < IM2COL_KPT; ++t) {
+      const int k = threadIdx.x + 256 * t;
+      if (k < K) dst[k] = (float)src[koff[t]] * scale;
+    }
   }
 }
 
-// col[m = (b, oh, ow)][k = (c, i, j)] = x[b, oh*S+i, ow*S+j, c]              (x: fp32, channel-last)
-__global__ void im2col_f32_nhwc_kernel(const float* __restrict__ x, int C, int H, int W, int KH, int KW, int S,
-                                       int OH, int OW, float* __restrict__ col, long long total) {
-  const int K = C * KH * KW;
-  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
-    const long long m = e / K;
-    const int k = (int)(e - m * K);
+// KW == 8 with 4-byte aligned windows (NatureCNN's first layer: 8x8, stride 4, W % 4 == 0): a thread owns one
+// (c, i) pair of a row = 8 consecutive bytes in, 8 consecutive floats out (two dword loads, two 16-byte
+// stores); 256 threads cover 256 / (C*KH) rows at a time.
+__global__ __launch_bounds__(256) void im2col_u8_nchw_kw8_kernel(const uint8_t* __restrict__ x, int C, int H, int W,
+                                                                 int KH, int S, int OH, int OW, float scale,
+                                                                 float* __restrict__ col, long long M, int rows_per_pass) {
+  const int CI = C * KH;                       // (c, i) pairs per row; K = CI * 8
+  const int sub = threadIdx.x / CI, ci = threadIdx.x - sub * CI;
+  if (sub >= rows_per_pass) return;
+  const int c = ci / KH, i = ci - c * KH;
+  const int koff = (c * H + i) * W;
+  typedef float f4v __attribute__((ext_vector_type(4)));
+  const long long m0 = (long long)blockIdx.x * IM2COL_ROWS * rows_per_pass;
+  for (int rr = 0; rr < IM2COL_ROWS; ++rr) {
+    const long long m = m0 + (long long)rr * rows_per_pass + sub;
+    if (m >= M) return;
     const int p = (int)(m % (OH * OW));
     const long long b = m / (OH * OW);
     const int oh = p / OW, ow = p - oh * OW;
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(x + (b * C * H + oh * S) * W + ow * S + koff);
+    const uint32_t lo = src[0], hi = src[1];
+    f4v a = {(float)(lo & 255u) * scale, (float)((lo >> 8) & 255u) * scale, (float)((lo >> 16) & 255u) * scale,
+             (float)(lo >> 24) * scale};
+    f4v bq = {(float)(hi & 255u) * scale, (float)((hi >> 8) & 255u) * scale, (float)((hi >> 16) & 255u) * scale,
+              (float)(hi >> 24) * scale};
+    f4v* dst = reinterpret_cast<f4v*>(col + m * (CI * 8) + ci * 8);
+    dst[0] = a;
+    dst[1] = bq;
+  }
+}
+
+// col[m][k = (c, i, j)] = x[b, oh*S+i, ow*S+j, c]              (x: fp32, channel-last)
+__global__ __launch_bounds__(256) void im2col_f32_nhwc_kernel(const float* __restrict__ x, int C, int H, int W, int KH,
+                                                              int KW, int S, int OH, int OW, float* __restrict__ col,
+                                                              long long M) {
+  const int K = C * KH * KW;
+  int koff[IM2COL_KPT];
+#pragma unroll
+  for (int t = 0; t < IM2COL_KPT; ++t) {
+    const int k = min((int)threadIdx.x + 256 * t, K - 1);
     const int c = k / (KH * KW), r = k - c * (KH * KW);
     const int i = r / KW, j = r - i * KW;
-    col[e] = x[((b * H + oh * S + i) * W + ow * S + j) * C + c];
+    koff[t] = (i * W + j) * C + c;
+  }
+  const long long m0 = (long long)blockIdx.x * IM2COL_ROWS;
+  for (int rr = 0; rr < IM2COL_ROWS; ++rr) {
+    const long long m = m0 + rr;
+    if (m >= M) return;
+    const int p = (int)(m % (OH * OW));
+    const long long b = m / (OH * OW);
+    const int oh = p / OW, ow = p - oh * OW;
+    const float* src = x + ((b * H + oh * S) * W + ow * S) * C;
+    float* dst = col + m * K;
+#pragma unroll
+    for (int t = 0; t < IM2COL_KPT; ++t) {
+      const int k = threadIdx.x + 256 * t;
+      if (k < K) dst[k] = src[koff[t]];
+    }
   }
 }
 
@@ -122,9 +188,18 @@ int ia_im2col_u8_nchw(const uint8_t* x, int B, int C, int H, int W, int KH, int 
                       void* stream) {
   if (!x || !col || B <= 0 || C <= 0 || KH <= 0 || KW <= 0 || S <= 0 || H < KH || W < KW) return IA_ERR_ARG;
   const int OH = (H - KH) / S + 1, OW = (W - KW) / S + 1;
-  const long long total = (long long)B * OH * OW * C * KH * KW;
-  hipLaunchKernelGGL(im2col_u8_nchw_kernel, stream_grid(total), dim3(256), 0, (hipStream_t)stream, x, C, H, W, KH, KW,
-                     S, OH, OW, scale, col, total);
+  if (C * KH * KW > 256 * IM2COL_KPT) return IA_ERR_ARG;
+  const long long M = (long long)B * OH * OW;
+  if (KW == 8 && S % 4 == 0 && W % 4 == 0 && C * KH <= 256 && (reinterpret_cast<uintptr_t>(x) & 3) == 0) {
+    const int rpp = 256 / (C * KH);
+    const long long per_block = (long long)IM2COL_ROWS * rpp;
+    hipLaunchKernelGGL(im2col_u8_nchw_kw8_kernel, dim3((unsigned)((M + per_block - 1) / per_block)), dim3(256), 0,
+                       (hipStream_t)stream, x, C, H, W, KH, S, OH, OW, scale, col, M, rpp);
+    IA_CHECK_LAUNCH();
+    return IA_OK;
+  }
+  hipLaunchKernelGGL(im2col_u8_nchw_kernel, dim3((unsigned)((M + IM2COL_ROWS - 1) / IM2COL_ROWS)), dim3(256), 0,
+                     (hipStream_t)stream, x, C, H, W, KH, KW, S, OH, OW, scale, col, M);
   IA_CHECK_LAUNCH();
   return IA_OK;
 }
@@ -132,9 +207,10 @@ int ia_im2col_u8_nchw(const uint8_t* x, int B, int C, int H, int W, int KH, int 
 int ia_im2col_f32_nhwc(const float* x, int B, int H, int W, int C, int KH, int KW, int S, float* col, void* stream) {
   if (!x || !col || B <= 0 || C <= 0 || KH <= 0 || KW <= 0 || S <= 0 || H < KH || W < KW) return IA_ERR_ARG;
   const int OH = (H - KH) / S + 1, OW = (W - KW) / S + 1;
-  const long long total = (long long)B * OH * OW * C * KH * KW;
-  hipLaunchKernelGGL(im2col_f32_nhwc_kernel, stream_grid(total), dim3(256), 0, (hipStream_t)stream, x, C, H, W, KH, KW,
-                     S, OH, OW, col, total);
+  if (C * KH * KW > 256 * IM2COL_KPT) return IA_ERR_ARG;
+  const long long M = (long long)B * OH * OW;
+  hipLaunchKernelGGL(im2col_f32_nhwc_kernel, dim3((unsigned)((M + IM2COL_ROWS - 1) / IM2COL_ROWS)), dim3(256), 0,
+                     (hipStream_t)stream, x, C, H, W, KH, KW, S, OH, OW, col, M);
   IA_CHECK_LAUNCH();
   return IA_OK;
 }
