@@ -4,10 +4,11 @@ NatureCNN features (Conv 8/4 - ReLU - Conv 4/2 - ReLU - Conv 3/1 - ReLU - Flatte
 further hidden layers, a Categorical action head and a value head.
 
 Device layout: ONE flat fp32 parameter buffer in torch `parameters()` order (cnn.0 w,b, cnn.2 w,b, cnn.4 w,b,
-linear.0 w,b, action_net w,b, value_net w,b). Convolution weights are used as stored ([Cout, Cin*KH*KW] is the
-GEMM's B operand); activations are channel-last, so the columns of `linear.0.weight` are kept in (h, w, c)
-order on the device and permuted to torch's (c, h, w) in `state_dict()` / `load_state_dict()` -- Adam and
-the L2 term are element-wise, so nothing else notices. A convolution is `ia_im2col_*` + `ia_gemm_f32`; its
+linear.0 w,b, action_net w,b, value_net w,b). A weight matrix [Cout, K] is the GEMM's B operand as stored;
+activations are channel-last, so on the device cnn.2 / cnn.4 are kept as [Cout, KH, KW, Cin] and the columns
+of `linear.0.weight` in (h, w, c) order -- both sides of every im2col / col2im copy are then contiguous runs --
+and permuted to torch's layouts in `state_dict()` / `load_state_dict()`; Adam and the L2 term are
+element-wise, so nothing else notices. A convolution is `ia_im2col_*` + `ia_gemm_f32`; its
 weight gradient the split-K TN GEMM on the kept column buffer; its input gradient an NN GEMM + `ia_col2im_nhwc`.
 
 Scope of this first version: what the BC step needs (`evaluate_actions`, the loss gradient, Adam) plus a
@@ -108,12 +109,17 @@ class ActorCriticCnnPolicy:
 
     # ---- layouts ---------------------------------------------------------------------------------------
     def _to_device_layout(self, i: int, w: th.Tensor) -> th.Tensor:
+        if i in (1, 2):  # cnn.2 / cnn.4: [Cout, Cin, KH, KW] -> [Cout, KH, KW, Cin] (column order of the NHWC im2col)
+            return w.reshape(self._shapes[i]).permute(0, 2, 3, 1).contiguous()
         if i == 3:  # linear.0: columns (c, h, w) -> (h, w, c)
             Hh, Ww, Cc = self._last_hw_c
             return w.reshape(w.shape[0], Cc, Hh, Ww).permute(0, 2, 3, 1).reshape(w.shape[0], -1).contiguous()
         return w.contiguous()
 
     def _to_torch_layout(self, i: int, w: th.Tensor) -> th.Tensor:
+        if i in (1, 2):
+            co, ci, kh, kw = self._shapes[i]
+            return w.reshape(co, kh, kw, ci).permute(0, 3, 1, 2).contiguous()
         if i == 3:
             Hh, Ww, Cc = self._last_hw_c
             n_out = self._shapes[3][0]

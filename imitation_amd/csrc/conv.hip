@@ -83,7 +83,9 @@ __global__ __launch_bounds__(256) void im2col_u8_nchw_kw8_kernel(const uint8_t* 
   }
 }
 
-// col[m][k = (c, i, j)] = x[b, oh*S+i, ow*S+j, c]              (x: fp32, channel-last)
+// col[m][k = (i, j, c)] = x[b, oh*S+i, ow*S+j, c]              (x: fp32, channel-last)
+// Column order (i, j, c) -- the weights of these layers are kept as [Cout, KH, KW, Cin] on the device -- so a
+// row is KH runs of KW*C contiguous input floats: reads and writes are both coalesced.
 __global__ __launch_bounds__(256) void im2col_f32_nhwc_kernel(const float* __restrict__ x, int C, int H, int W, int KH,
                                                               int KW, int S, int OH, int OW, float* __restrict__ col,
                                                               long long M) {
@@ -92,9 +94,8 @@ __global__ __launch_bounds__(256) void im2col_f32_nhwc_kernel(const float* __res
 #pragma unroll
   for (int t = 0; t < IM2COL_KPT; ++t) {
     const int k = min((int)threadIdx.x + 256 * t, K - 1);
-    const int c = k / (KH * KW), r = k - c * (KH * KW);
-    const int i = r / KW, j = r - i * KW;
-    koff[t] = (i * W + j) * C + c;
+    const int i = k / (KW * C), r = k - i * (KW * C);
+    koff[t] = i * W * C + r;
   }
   const long long m0 = (long long)blockIdx.x * IM2COL_ROWS;
   for (int rr = 0; rr < IM2COL_ROWS; ++rr) {
@@ -113,8 +114,9 @@ __global__ __launch_bounds__(256) void im2col_f32_nhwc_kernel(const float* __res
   }
 }
 
-// dx[b, h, w, c] = sum over the windows (oh, ow, i, j) with oh*S+i == h, ow*S+j == w of dcol[(b,oh,ow)][(c,i,j)],
+// dx[b, h, w, c] = sum over the windows (oh, ow, i, j) with oh*S+i == h, ow*S+j == w of dcol[(b,oh,ow)][(i,j,c)],
 // in (i, j) order; multiplied by [mask[b,h,w,c] > 0] when a mask (the ReLU output of that layer) is given.
+// (Consecutive threads = consecutive c: every read of a window is a contiguous run of C floats.)
 __global__ void col2im_nhwc_kernel(const float* __restrict__ dcol, int C, int H, int W, int KH, int KW, int S, int OH,
                                    int OW, const float* __restrict__ mask, float* __restrict__ dx, long long total) {
   const int K = C * KH * KW;
@@ -125,18 +127,16 @@ __global__ void col2im_nhwc_kernel(const float* __restrict__ dcol, int C, int H,
     const long long t2 = t / W;
     const int h = (int)(t2 % H);
     const long long b = t2 / H;
+    // windows covering (h, w): oh in [ceil((h-KH+1)/S), floor(h/S)] n [0, OH), likewise ow -- at most
+    // ceil(KH/S) x ceil(KW/S) terms, visited in decreasing (oh, ow) = increasing (i, j) order
     float s = 0.f;
-    for (int i = 0; i < KH; ++i) {
-      const int hh = h - i;
-      if (hh < 0 || hh % S != 0) continue;
-      const int oh = hh / S;
-      if (oh >= OH) continue;
-      for (int j = 0; j < KW; ++j) {
-        const int ww = w - j;
-        if (ww < 0 || ww % S != 0) continue;
-        const int ow = ww / S;
-        if (ow >= OW) continue;
-        s += dcol[((b * OH + oh) * OW + ow) * (long long)K + (c * KH + i) * KW + j];
+    const int oh_hi = min(h / S, OH - 1), oh_lo = max(0, (h - KH + S) / S);
+    const int ow_hi = min(w / S, OW - 1), ow_lo = max(0, (w - KW + S) / S);
+    for (int oh = oh_hi; oh >= oh_lo; --oh) {
+      const int i = h - oh * S;
+      for (int ow = ow_hi; ow >= ow_lo; --ow) {
+        const int j = w - ow * S;
+        s += dcol[((b * OH + oh) * OW + ow) * (long long)K + (i * KW + j) * C + c];
       }
     }
     if (mask != nullptr && !(mask[e] > 0.f)) s = 0.f;

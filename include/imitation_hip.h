@@ -255,8 +255,10 @@ int ia_ppo_minibatch_apply(const ia_policy_desc* d, float* params, float* params
                            void* stream);
 /* ---- image policies (SB3 NatureCNN / ActorCriticCnnPolicy; algorithms/bc.py:94-156 with BASELINE config 4) ----
  * Convolution = im2col + ia_gemm_f32 (mode 0, weights [Cout, Cin*KH*KW] as torch stores them); activations
- * are channel-last [B, H, W, C]; column index k = (c*KH + i)*KW + j, row m = (b*OH + oh)*OW + ow.
- * `_u8_nchw`: the policy's input frames, uint8 channel-first ([SB3 preprocess_obs]: x / 255 -> scale). */
+ * are channel-last [B, H, W, C]; row m = (b*OH + oh)*OW + ow. `_u8_nchw`: the policy's input frames, uint8
+ * channel-first ([SB3 preprocess_obs]: x / 255 -> scale), column index k = (c*KH + i)*KW + j (torch's weight
+ * layout as stored). `_f32_nhwc` / `ia_col2im_nhwc`: column index k = (i*KW + j)*C + c, i.e. weights kept as
+ * [Cout, KH, KW, Cin] (both sides of the copy are then contiguous runs). */
 int ia_im2col_u8_nchw(const uint8_t* x, int B, int C, int H, int W, int KH, int KW, int S, float scale, float* col,
                       void* stream);
 int ia_im2col_f32_nhwc(const float* x, int B, int H, int W, int C, int KH, int KW, int S, float* col, void* stream);
