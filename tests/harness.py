@@ -382,7 +382,8 @@ def run_bc_case(impl: str, name: str, log_dir: str, device: str = "cpu") -> Dict
                     minibatch_size=cfg.get("minibatch_size"), l2_weight=cfg.get("l2_weight", 0.0),
                     custom_logger=logger, **kw)
     trainer.train(log_interval=cfg["log_interval"], progress_bar=False, **cfg["train"])
-    out = {f"policy/{k}": _np(v) for k, v in trainer.policy.state_dict().items()}
+    out = {f"policy/{k}": _np(v) for k, v in trainer.policy.state_dict().items()
+           if not (cfg.get("image") and k.startswith(("pi_features_extractor.", "vf_features_extractor.")))}  # aliases
     out["log_rows"] = np.asarray(rows, dtype=np.float64)
     out["torch_rng_after"] = th.get_rng_state().numpy().copy()   # the loader consumed the global generator identically
     return out
