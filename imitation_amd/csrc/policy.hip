@@ -1897,6 +1897,10 @@ struct ALds {
   static constexpr int total = out + ROWS * AS;
 };
 
+// EVAL = false: the rollout step (sample from `noise`, clip, log-prob of the sample).
+// EVAL = true: [SB3 evaluate_actions] -- `noise` holds the GIVEN actions, `clipped` receives the entropy;
+// `logp`, `values` and the entropy output may each be NULL (`ia_policy_evaluate`, hidden = 32).
+template <bool EVAL>
 __global__ __launch_bounds__(512) void policy_act_mfma32_kernel(
     ia_policy_desc d, const float* __restrict__ P, const float* __restrict__ Pt, const float* __restrict__ nm,
     const float* __restrict__ nv, const float* __restrict__ obs, int n, const float* __restrict__ noise,
@@ -1933,7 +1937,7 @@ __global__ __launch_bounds__(512) void policy_act_mfma32_kernel(
   float r_noise[MAXA];
 #pragma unroll
   for (int a2 = 0; a2 < MAXA; ++a2) r_noise[a2] = 0.f;
-  if (tw == 0 && lane < 16) {
+  if (tw == 0 && lane < 16 && noise != nullptr) {
     const long long nrow = (long long)min(srow, n - 1) * (d.discrete ? 1 : A);
 #pragma unroll
     for (int a2 = 0; a2 < MAXA; ++a2) r_noise[a2] = noise[nrow + (d.discrete ? 0 : min(a2, A - 1))];
@@ -1983,8 +1987,8 @@ __global__ __launch_bounds__(512) void policy_act_mfma32_kernel(
   for (int a2 = 0; a2 < MAXA; ++a2) {
     const int ac = min(a2, A - 1);
     r_ls[a2] = d.discrete ? 0.f : P[o.log_std + ac];
-    r_low[a2] = d.discrete ? 0.f : low[ac];
-    r_high[a2] = d.discrete ? 0.f : high[ac];
+    r_low[a2] = (EVAL || d.discrete) ? 0.f : low[ac];
+    r_high[a2] = (EVAL || d.discrete) ? 0.f : high[ac];
   }
   __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -2038,7 +2042,7 @@ __global__ __launch_bounds__(512) void policy_act_mfma32_kernel(
     for (int r = 0; r < 4; ++r) {
       const int rr = q * 16 + lk * 4 + r;
       if (tw == 0) { if (li < A) lds[L::out + rr * L::AS + li] = acc[r] + head_bias; }
-      else if (li == 0 && i0 + rr < n) values[i0 + rr] = acc[r] + head_bias;
+      else if (li == 0 && i0 + rr < n && values != nullptr) values[i0 + rr] = acc[r] + head_bias;
     }
   }
   if (tw != 0) return;
@@ -2046,6 +2050,34 @@ __global__ __launch_bounds__(512) void policy_act_mfma32_kernel(
   const int row = i0 + q * 16 + lane;
   if (lane >= 16 || row >= n) return;
   const float* outrow = lds + L::out + (q * 16 + lane) * L::AS;
+  if constexpr (EVAL) {
+    float* entropy = clipped;
+    if (!d.discrete) {
+      float lp = 0.f, en = 0.f;
+#pragma unroll
+      for (int a = 0; a < MAXA; ++a)
+        if (a < A) {
+          lp += gauss_logp_term(r_noise[a], outrow[a], r_ls[a]);
+          en += 0.5f + LOG_SQRT_2PI + logf(expf(r_ls[a]));  // Normal.entropy: 0.5 + 0.5*log(2*pi) + log(scale)
+        }
+      if (logp != nullptr) logp[row] = lp;
+      if (entropy != nullptr) entropy[row] = en;
+    } else {
+      float mx = outrow[0];
+      for (int a = 1; a < A; ++a) mx = fmaxf(mx, outrow[a]);
+      float se = 0.f;
+      for (int a = 0; a < A; ++a) se += expf(outrow[a] - mx);
+      const float lse = mx + logf(se);
+      float en = 0.f;
+      for (int a = 0; a < A; ++a) {
+        const float l = outrow[a] - lse;
+        en -= expf(l) * l;
+      }
+      if (logp != nullptr) logp[row] = outrow[(int)r_noise[0]] - lse;
+      if (entropy != nullptr) entropy[row] = en;
+    }
+    return;
+  }
   if (!d.discrete) {
     float lp = 0.f;
 #pragma unroll
@@ -2655,9 +2687,9 @@ int ia_policy_act(const ia_policy_desc* d, const float* params, const float* par
   if (d->hidden == 32 && !g_ppo_valu) {
     static bool attr = false;
     const size_t bytes = ALds::total * sizeof(float);
-    if (!attr) { if ((rc = set_lds(policy_act_mfma32_kernel, bytes))) return rc; attr = true; }
-    hipLaunchKernelGGL(policy_act_mfma32_kernel, dim3(cdiv(n, ROWS)), dim3(512), bytes, (hipStream_t)stream, *d, params,
-                       params_t, norm_mean, norm_var, obs, n, noise, low, high, actions, clipped, values, logp);
+    if (!attr) { if ((rc = set_lds(policy_act_mfma32_kernel<false>, bytes))) return rc; attr = true; }
+    hipLaunchKernelGGL(policy_act_mfma32_kernel<false>, dim3(cdiv(n, ROWS)), dim3(512), bytes, (hipStream_t)stream, *d,
+                       params, params_t, norm_mean, norm_var, obs, n, noise, low, high, actions, clipped, values, logp);
   } else if (d->hidden == 32) {
     if ((rc = set_lds(policy_act_kernel<32>, lds_bytes<32>()))) return rc;
     hipLaunchKernelGGL(policy_act_kernel<32>, dim3(cdiv(n, ROWS)), dim3(ROWS), lds_bytes<32>(), (hipStream_t)stream,
@@ -2678,7 +2710,14 @@ int ia_policy_evaluate(const ia_policy_desc* d, const float* params, const float
                        float* values, float* entropy, void* stream) {
   if (!pol_ok(d) || n <= 0) return IA_ERR_ARG;
   int rc;
-  if (d->hidden == 32) {
+  if (d->hidden == 32 && !g_ppo_valu && (actions != nullptr || logp == nullptr)) {
+    static bool attr = false;   // the MFMA layer chain of the rollout step, given actions instead of sampling
+    const size_t bytes = ALds::total * sizeof(float);
+    if (!attr) { if ((rc = set_lds(policy_act_mfma32_kernel<true>, bytes))) return rc; attr = true; }
+    hipLaunchKernelGGL(policy_act_mfma32_kernel<true>, dim3(cdiv(n, ROWS)), dim3(512), bytes, (hipStream_t)stream, *d,
+                       params, params_t, norm_mean, norm_var, obs, n, actions, (const float*)nullptr,
+                       (const float*)nullptr, (float*)nullptr, entropy, values, logp);
+  } else if (d->hidden == 32) {
     if ((rc = set_lds(policy_eval_kernel<32>, lds_bytes<32>()))) return rc;
     hipLaunchKernelGGL(policy_eval_kernel<32>, dim3(cdiv(n, ROWS)), dim3(ROWS), lds_bytes<32>(),
                        (hipStream_t)stream, *d, params, params_t, norm_mean, norm_var, obs, actions, n, logp, values,
