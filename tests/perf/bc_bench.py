@@ -1,6 +1,6 @@
 """BC supervised step with the NatureCNN policy at BASELINE config 4's shape (84x84x4 uint8 frames, batch 4096,
 Discrete(6)): samples/s of `imitation_amd.bc.BC` on the GPU next to the CPU oracle (torch CPU, same policy and
-loss) on a bounded sample. Usage: python tools/bc_bench.py [batch] [steps]"""
+loss) on a bounded sample. Usage: python tests/perf/bc_bench.py [batch] [steps]"""
 import os
 import sys
 import tempfile
@@ -9,7 +9,7 @@ import time
 import numpy as np
 import torch as th
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import imitation_amd as p  # noqa: E402
 from imitation_amd import spaces  # noqa: E402
 

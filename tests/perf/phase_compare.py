@@ -4,7 +4,7 @@
 for the HIP trainer (phases run back to back with a device sync after each, i.e. WITHOUT the overlap
 of the real schedule), the CPU oracle (1 torch thread and all cores) and -- where /root/reference
 exists (not on the GPU box) -- the reference's own modules under the import shim.
-Usage: python tools/phase_compare.py hip|oracle|reference [torch threads]"""
+Usage: python tests/perf/phase_compare.py hip|oracle|reference [torch threads]"""
 import os
 import sys
 import time
@@ -12,7 +12,7 @@ import time
 import numpy as np
 import torch as th
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import bench  # noqa: E402
 from tests import harness  # noqa: E402
