@@ -667,6 +667,69 @@ class BasicRewardNet(RewardNet):
         return out
 
 
+def build_cnn(in_channels: int, hid_channels: Iterable[int], out_size: int = 1, activation=nn.ReLU,
+              kernel_size: int = 3, stride: int = 1, padding="same", squeeze_output: bool = False) -> nn.Module:
+    """util/networks.py:286-357 without the name prefix and dropout (both unused on the path): `conv{i}` +
+    activation per hidden layer, AdaptiveAvgPool2d(1), Flatten, `dense_final`."""
+    layers: Dict[str, nn.Module] = collections.OrderedDict()
+    prev = in_channels
+    for i, n_channels in enumerate(hid_channels):
+        layers[f"conv{i}"] = nn.Conv2d(prev, n_channels, kernel_size, stride=stride, padding=padding)
+        prev = n_channels
+        if activation:
+            layers[f"act{i}"] = activation()
+    layers["avg_pool"] = nn.AdaptiveAvgPool2d(1)
+    layers["flatten"] = nn.Flatten()
+    layers["dense_final"] = nn.Linear(prev, out_size)
+    if squeeze_output:
+        if out_size != 1:
+            raise ValueError("squeeze_output is only applicable when out_size=1")
+        layers["squeeze"] = _Squeeze()
+    return nn.Sequential(layers)
+
+
+class CnnRewardNet(RewardNet):
+    """rewards/reward_nets.py:460-597: image states (h, w, c unless `hwc_format=False`),
+    one output per Discrete action (x2 with `use_done`), picked by the one-hot action / done."""
+
+    def __init__(self, observation_space, action_space, use_state: bool = True, use_action: bool = True,
+                 use_next_state: bool = False, use_done: bool = False, hwc_format: bool = True, **kwargs):
+        super().__init__(observation_space, action_space)
+        self.use_state, self.use_action, self.use_next_state, self.use_done = use_state, use_action, use_next_state, use_done
+        self.hwc_format = hwc_format
+        if not (use_state or use_next_state):
+            raise ValueError("CnnRewardNet must take current or next state as input.")
+        if not sb.is_image_space(observation_space):
+            raise ValueError("CnnRewardNet requires observations to be images.")
+        if use_action and not isinstance(action_space, spaces.Discrete):
+            raise ValueError("CnnRewardNet can only use Discrete action spaces.")
+        n_ch = observation_space.shape[-1] if hwc_format else observation_space.shape[0]
+        input_size = n_ch * (int(use_state) + int(use_next_state))
+        output_size = int(action_space.n) if use_action else 1
+        if use_done:
+            output_size *= 2
+        full = {"hid_channels": (32, 32), **kwargs, "in_channels": input_size, "out_size": output_size,
+                "squeeze_output": output_size == 1}
+        self.cnn = build_cnn(**full)
+
+    def forward(self, state, action, next_state, done):
+        tr = (lambda t: th.permute(t, (0, 3, 1, 2))) if self.hwc_format else (lambda t: t)
+        inputs = []
+        if self.use_state:
+            inputs.append(tr(state))
+        if self.use_next_state:
+            inputs.append(tr(next_state))
+        outputs = self.cnn(th.cat(inputs, dim=1))
+        if self.use_action and not self.use_done:
+            return th.sum(outputs * action, dim=1)
+        if self.use_action and self.use_done:
+            full_acts = th.cat((action * (1 - done[:, None]), action * done[:, None]), dim=1)
+            return th.sum(outputs * full_acts, dim=1)
+        if self.use_done:
+            return th.sum(outputs * nn.functional.one_hot(done.long(), num_classes=2), dim=1)
+        return outputs
+
+
 class RewardNetWrapper(RewardNet):
     """rewards/reward_nets.py:227-272."""
 

@@ -116,6 +116,7 @@ def main():
         np.savez_compressed(path, **out)
         print(f"wrote {path}: {len(out)} arrays, {os.path.getsize(path)} bytes")
     dump_bc()
+    dump_cnn_reward_net()
 
 
 def dump_bc():
@@ -127,8 +128,34 @@ def dump_bc():
         print(f"wrote {path}: {len(out)} arrays, {os.path.getsize(path)} bytes")
 
 
+def dump_cnn_reward_net():
+    """`CnnRewardNet` of the reference (state + next state + done variant): parameters and predictions."""
+    import torch
+
+    from imitation_amd import spaces
+    from oracle import ref_shim
+
+    ref_shim.install()
+    from imitation.rewards import reward_nets as rrn
+
+    osp, asp = spaces.Box(0, 255, (12, 10, 3), np.uint8), spaces.Discrete(5)
+    torch.manual_seed(3)
+    net = rrn.CnnRewardNet(osp, asp, use_next_state=True, use_done=True)
+    rng = np.random.default_rng(0)
+    obs = rng.integers(0, 256, (7, 12, 10, 3), dtype=np.uint8)
+    nxt = rng.integers(0, 256, (7, 12, 10, 3), dtype=np.uint8)
+    acts, dones = rng.integers(0, 5, 7), rng.random(7) < 0.5
+    out = {f"sd/{k}": v.numpy() for k, v in net.state_dict().items()}
+    out.update(obs=obs, next_obs=nxt, acts=acts, dones=dones, rews=net.predict_processed(obs, acts, nxt, dones))
+    path = os.path.join(HERE, "cnn_reward_net.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, os.path.getsize(path), "bytes")
+
+
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "bc":
+    if len(sys.argv) > 1 and sys.argv[1] == "cnn_reward":
+        dump_cnn_reward_net()
+    elif len(sys.argv) > 1 and sys.argv[1] == "bc":
         dump_bc()
     else:
         main()

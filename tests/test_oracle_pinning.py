@@ -213,3 +213,52 @@ def test_trainer_error_contract(tmp_path):
     at, _ = harness.build_trainer("oracle", harness.CASES["airl_box"], str(tmp_path / "c"))
     with pytest.raises(TypeError):
         at.logits_expert_is_high(th.zeros(2, 11), th.zeros(2, 3), th.zeros(2, 11), th.zeros(2), None)
+
+
+@pytest.mark.reference
+@pytest.mark.skipif(not ref_shim.reference_available(), reason="/root/reference not present")
+@pytest.mark.parametrize("kw", [dict(), dict(use_next_state=True, use_done=True), dict(use_action=False),
+                                dict(use_action=False, use_done=True, hwc_format=False, hid_channels=(8,))])
+def test_cnn_reward_net_bit_identical_to_live_reference(kw):
+    """`CnnRewardNet` / `build_cnn` (rewards/reward_nets.py:460-610, util/networks.py:286-357): same parameters
+    from the same seed, same forward values, same `predict_processed` on uint8 frames, same errors."""
+    ref_shim.install()
+    from imitation.rewards import reward_nets as rrn
+
+    from imitation_amd import spaces
+    from oracle import imitation_restated as o
+
+    hwc = kw.get("hwc_format", True)
+    shape = (12, 10, 3) if hwc else (3, 12, 10)
+    osp, asp = spaces.Box(0, 255, shape, np.uint8), spaces.Discrete(5)
+    th.manual_seed(3)
+    a = rrn.CnnRewardNet(osp, asp, **kw)
+    th.manual_seed(3)
+    b = o.CnnRewardNet(osp, asp, **kw)
+    sa, sb_ = a.state_dict(), b.state_dict()
+    assert list(sa) == list(sb_) and all(th.equal(sa[k], sb_[k]) for k in sa)
+    rng = np.random.default_rng(0)
+    obs = rng.integers(0, 256, (7, *shape), dtype=np.uint8)
+    nxt = rng.integers(0, 256, (7, *shape), dtype=np.uint8)
+    acts, dones = rng.integers(0, 5, 7), rng.random(7) < 0.5
+    assert np.array_equal(a.predict_processed(obs, acts, nxt, dones), b.predict_processed(obs, acts, nxt, dones))
+    for net in (rrn.CnnRewardNet, o.CnnRewardNet):
+        with pytest.raises(ValueError, match="current or next state"):
+            net(osp, asp, use_state=False, use_next_state=False)
+        with pytest.raises(ValueError, match="to be images"):
+            net(spaces.Box(-1, 1, (4,), np.float32), asp)
+        with pytest.raises(ValueError, match="Discrete action"):
+            net(osp, spaces.Box(-1, 1, (2,), np.float32))
+
+
+def test_cnn_reward_net_matches_golden():
+    """The oracle's `CnnRewardNet` with the reference's parameters reproduces the reference's predictions
+    (tests/golden/cnn_reward_net.npz, generated by the reference itself)."""
+    from imitation_amd import spaces
+
+    g = dict(np.load(os.path.join(os.path.dirname(__file__), "golden", "cnn_reward_net.npz")))
+    net = o.CnnRewardNet(spaces.Box(0, 255, (12, 10, 3), np.uint8), spaces.Discrete(5), use_next_state=True,
+                         use_done=True)
+    net.load_state_dict({k[3:]: th.as_tensor(v) for k, v in g.items() if k.startswith("sd/")})
+    got = net.predict_processed(g["obs"], g["acts"], g["next_obs"], g["dones"])
+    np.testing.assert_allclose(got, g["rews"], rtol=1e-5, atol=1e-6)
