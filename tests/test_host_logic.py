@@ -345,3 +345,34 @@ def test_env_state_mid_job_continues_in_another_env():
         e1.step_async(acts)
         e2.step_async(acts)
         assert all(np.array_equal(x, y) for x, y in zip(e1.step_wait_arrays(), e2.step_wait_arrays()))
+
+
+@pytest.mark.parametrize("shape,A", [((4, 36, 36), 6), ((3, 44, 52), 4)])
+def test_cnn_policy_host_construction_matches_sb3_restated(shape, A):
+    """`cnn_policy.ActorCriticCnnPolicy` is built on the host in SB3's order: same draws from torch's global
+    generator, same initial parameters under SB3's state-dict keys (the device keeps cnn.2 / cnn.4 / linear.0 in
+    channel-last order; `state_dict()` / `load_state_dict()` convert), and a load -> state_dict round trip."""
+    from imitation_amd import spaces
+    from imitation_amd.cnn_policy import ActorCriticCnnPolicy
+    from oracle import sb3_restated as sb
+
+    osp, asp = spaces.Box(0, 255, shape, np.uint8), spaces.Discrete(A)
+    th.manual_seed(11)
+    ref = sb.ActorCriticCnnPolicy(osp, asp, lambda _: 1.0)
+    after_ref = th.get_rng_state()
+    th.manual_seed(11)
+    pol = ActorCriticCnnPolicy(osp, asp, lambda _: 1.0)
+    assert th.equal(th.get_rng_state(), after_ref)
+    sd, rsd = pol.state_dict(), ref.state_dict()
+    assert list(sd) == list(rsd)
+    for k in rsd:
+        assert sd[k].shape == rsd[k].shape and th.equal(sd[k], rsd[k]), k
+    th.manual_seed(12)
+    other = sb.ActorCriticCnnPolicy(osp, asp, lambda _: 1.0).state_dict()
+    pol.load_state_dict(other)
+    for k in other:
+        assert th.equal(pol.state_dict()[k], other[k]), k
+    with pytest.raises(ValueError, match="too small"):
+        ActorCriticCnnPolicy(spaces.Box(0, 255, (4, 20, 20), np.uint8), asp, lambda _: 1.0)
+    with pytest.raises(NotImplementedError):
+        ActorCriticCnnPolicy(osp, spaces.Box(-1, 1, (2,), np.float32), lambda _: 1.0)
