@@ -1,0 +1,861 @@
+// Fused discriminator update for BasicRewardNet-shaped stacks  D -> H -> H -> 1  (ReLU, H in {128, 256},
+// D <= 24): adversarial/common.py:352-373 (one minibatch of train_disc) in FIVE launches instead of 16,
+// with the hidden activations of a 64-row tile chained through LDS instead of round-tripping HBM.
+//
+//   K1 assemble : gather + concat (+ one-hot) of [expert | generator] rows -> X, RunningNorm slab moments
+//                 from the LDS copy of the slab, last-block Chan merge (util/networks.py:111-134); spare
+//                 blocks transpose W2 -> W2T ([in][out]) so that both big layers stream contiguous K chunks
+//   K2 forward  : per 64-row tile: normalise x on load, layer 1 (K = D) on MFMA -> h1 in LDS (+ HBM, for
+//                 the weight gradients), layer 2 (K = H) with A = the LDS tile and B = W2T streamed through a
+//                 3-stage LDS ring, logit layer + BCE-with-logits + its gradient + the 8 statistics partials
+//                 + dW3/db3 partials + dh2 = dlogit * w3 * relu'(h2), all in the epilogue (h2 never leaves
+//                 the registers)
+//   K3 backward : per 64-row tile: dh1 = (dh2 . W2) * relu'(h1) with A = dh2 chunks and B = W2 chunks
+//                 through LDS rings, then dW1/db1 partials = dh1^T . xn from the LDS tile (dh1 never
+//                 reaches HBM)
+//   K4 wgrad 2  : dW2/db2 = split-K TN GEMM over (dh2, h1)                      (gemm.hip)
+//   K5 reduce   : fixed-order slab reduction of the three partial sets, gradient (accumulation), Adam,
+//                 and the statistics row
+// fp32 throughout (v_mfma_f32_32x32x2_f32: exact fp32 FMA chains). Deterministic: every reduction has a
+// fixed order.
+#include "common.h"
+#include "rn_common.h"
+#include "../../include/imitation_hip.h"
+
+namespace {
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+constexpr int FB_M = 64;     // rows per workgroup tile
+constexpr int FB_K = 16;     // K chunk of the streamed operand
+constexpr int FB_NT = 512;   // threads per workgroup: 8 waves = 2 (rows) x 4 (columns)
+constexpr int XP = 25;       // padded row length of the x tile / W1 in LDS (D <= 24), odd -> conflict-free
+constexpr int XP3 = 33;      // x tile as a 32-wide B operand (K3)
+constexpr int A_LD = FB_K + 1;
+
+__device__ __forceinline__ int rowoff(int r) { return (r & 3) + 8 * (r >> 2); }
+// phase clock of (block 0, thread 0) into dbg[slot] when measurement is switched on (scalar branch otherwise)
+#define FUSED_STAMP(a, slot)                                                                     \
+  do {                                                                                           \
+    if ((a).dbg != nullptr && blockIdx.x == 0 && threadIdx.x == 0) (a).dbg[slot] = __builtin_readcyclecounter(); \
+  } while (0)
+
+struct FusedArgs {
+  const float* X; int ldx; int R; int D;
+  const float* mean; const float* var; float eps;     // mean == nullptr: no input normalisation
+  const float* params;                                 // W1[H,D] b1[H] W2[H,H] b2[H] W3[H] b3[1]
+  const float* W2T;                                    // [in][out]
+  float* h1; float* dh2;                               // [R,H] each
+  float* logits; float* dlogits; int n_expert; float loss_scale;
+  float* part;                                         // [tiles][8] statistics partials
+  float* P1; float* P3;                                // per-tile partial slabs: [tiles][H*D+H], [tiles][H+1]
+  long long* dbg;                                      // measurement only (ia_disc_fused_debug_timing): phase clocks of block 0
+};
+
+// x tile of rows [row0, row0+64): raw X normalised on the fly -> xs[row][ld], columns >= D and rows >= R zero.
+// (X - mean) / sqrt(var + eps): util/networks.py:91 as ia_running_norm_apply computes it.
+__device__ __forceinline__ void load_x_tile(const FusedArgs& a, int row0, float* __restrict__ xs, int ld, int tid) {
+  const int quads = a.ldx >> 2;
+  if (tid < FB_M * quads) {
+    const int row = tid / quads, q = tid - row * quads;
+    const int gi = row0 + row;
+    const f4 v = *reinterpret_cast<const f4*>(a.X + (long long)min(gi, a.R - 1) * a.ldx + 4 * q);
+    const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int c = 4 * q + j;
+      float x = vv[j];
+      if (a.mean != nullptr) {
+        const int cc = min(c, a.D - 1);
+        x = (x - a.mean[cc]) / sqrtf(a.var[cc] + a.eps);
+      }
+      xs[row * ld + c] = (gi < a.R && c < a.D) ? x : 0.f;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------- K2
+template <int H>
+__global__ __launch_bounds__(FB_NT) void disc_fwd_kernel(FusedArgs a) {
+  constexpr int TN = H / 128;          // 32-column MFMA tiles per wave
+  constexpr int WC = TN * 32;          // columns per wave
+  constexpr int LDH = H + 1;
+  constexpr int NCH = H / FB_K;
+  constexpr int BST = FB_K * H;        // floats per B stage
+  constexpr int BV = BST / 4 / FB_NT;  // float4 per thread per B chunk
+  static_assert(BST % (4 * FB_NT) == 0, "B chunk must divide among the threads");
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* xs = smem;                    // [64][XP]
+  float* w1s = xs + FB_M * XP;         // [H][XP]
+  float* h1s = w1s + H * XP;           // [64][LDH]
+  float* bs = h1s + FB_M * LDH;        // 3 x [FB_K][H]
+  float* red = bs + 3 * BST;           // [4][64] logit partials per column group
+  float* dls = red + 4 * FB_M;         // [64] dlogit of the tile's rows
+  float* w3red = dls + FB_M;           // [2][H] dW3 partials per row group
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const int wm = wave >> 2, wn = wave & 3;
+  const int row0 = blockIdx.x * FB_M;
+  const int D = a.D;
+  const float* W1 = a.params;
+  const float* b1 = W1 + (long long)H * D;
+  const float* b2 = b1 + H + (long long)H * H;
+  const float* w3 = b2 + H;
+  const float* b3 = w3 + H;
+
+  // ---- prologue: everything this tile needs first is requested up front (clamped, unconditional loads)
+  FUSED_STAMP(a, 0);
+  f4 rb[BV];
+  auto bload = [&](int c) {
+#pragma unroll
+    for (int i = 0; i < BV; ++i)
+      rb[i] = *reinterpret_cast<const f4*>(a.W2T + (long long)c * BST + (long long)(tid + i * FB_NT) * 4);
+  };
+  auto bstore = [&](int c) {
+    float* S = bs + (c % 3) * BST;
+#pragma unroll
+    for (int i = 0; i < BV; ++i) *reinterpret_cast<f4*>(S + (tid + i * FB_NT) * 4) = rb[i];
+  };
+  constexpr int W1V = (H * 24 + FB_NT - 1) / FB_NT;
+  float w1v[W1V];
+  const int n_w1 = H * D;
+#pragma unroll
+  for (int i = 0; i < W1V; ++i) w1v[i] = W1[min(tid + i * FB_NT, n_w1 - 1)];
+  float b1v[TN], b2v[TN], w3v[TN];
+#pragma unroll
+  for (int t = 0; t < TN; ++t) {
+    const int col = wn * WC + t * 32 + li;
+    b1v[t] = b1[col]; b2v[t] = b2[col]; w3v[t] = w3[col];
+  }
+  const float b3v = b3[0];
+  load_x_tile(a, row0, xs, XP, tid);
+  for (int e = tid; e < FB_M * (24 - a.ldx); e += FB_NT) {  // columns [ldx, 24) of the K = 24 operand
+    const int w = 24 - a.ldx;
+    const int row = e / w;
+    xs[row * XP + a.ldx + e - row * w] = 0.f;
+  }
+  bload(0);
+  // W1 -> LDS as the NT B operand [n][XP]; k in [D, 24) zero
+#pragma unroll
+  for (int i = 0; i < W1V; ++i) {
+    const int e = tid + i * FB_NT;
+    if (e < n_w1) {
+      const int n = e / D, k = e - n * D;
+      w1s[n * XP + k] = w1v[i];
+    }
+  }
+  for (int e = tid; e < H * (24 - D); e += FB_NT) {
+    const int n = e / (24 - D), k = D + e - n * (24 - D);
+    w1s[n * XP + k] = 0.f;
+  }
+  bstore(0);
+  bload(1);
+  __syncthreads();
+  FUSED_STAMP(a, 1);
+
+  // ---- layer 1: h1 = relu(xn . W1^T + b1), K = 24
+  f32x16 acc[TN];
+#pragma unroll
+  for (int t = 0; t < TN; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+  {
+    float af[12], bf[12][TN];
+#pragma unroll
+    for (int ks = 0; ks < 12; ++ks) {
+      af[ks] = xs[(wm * 32 + li) * XP + 2 * ks + lh];
+#pragma unroll
+      for (int t = 0; t < TN; ++t) bf[ks][t] = w1s[(wn * WC + t * 32 + li) * XP + 2 * ks + lh];
+    }
+#pragma unroll
+    for (int ks = 0; ks < 12; ++ks)
+#pragma unroll
+      for (int t = 0; t < TN; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[ks], bf[ks][t], acc[t], 0, 0, 0);
+  }
+  FUSED_STAMP(a, 2);
+  bstore(1);
+  bload(2);
+#pragma unroll
+  for (int t = 0; t < TN; ++t) {
+    const int col = wn * WC + t * 32 + li;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = wm * 32 + 4 * lh + rowoff(r);
+      const float v = fmaxf(acc[t][r] + b1v[t], 0.f);
+      h1s[row * LDH + col] = v;
+      if (row0 + row < a.R) a.h1[(long long)(row0 + row) * H + col] = v;
+      acc[t][r] = 0.f;
+    }
+  }
+  __syncthreads();
+  FUSED_STAMP(a, 3);
+
+  // ---- layer 2: h2 = relu(h1 . W2^T + b2): A = the LDS tile, B = W2T chunks through a 3-stage ring.
+  // At the top of iteration c: stage c%3 and (c+1)%3 are complete (barriers c-2, c-1), the registers hold
+  // chunk c+2, which goes to stage (c+2)%3 == (c-1)%3 -- last read in iteration c-1, before barrier c-1.
+  auto compute = [&](int c) {
+    const float* Bs = bs + (c % 3) * BST;
+    const float* Ar = h1s + (wm * 32 + li) * LDH + c * FB_K + lh;
+    constexpr int Q = 4;
+    float af[2][Q], bf[2][Q][TN];
+    auto rd = [&](int q) {
+#pragma unroll
+      for (int s = 0; s < Q; ++s) {
+        const int ks = q * Q + s;
+        af[q & 1][s] = Ar[2 * ks];
+#pragma unroll
+        for (int t = 0; t < TN; ++t) bf[q & 1][s][t] = Bs[(2 * ks + lh) * H + wn * WC + t * 32 + li];
+      }
+    };
+    rd(0);
+#pragma unroll
+    for (int q = 0; q < FB_K / 2 / Q; ++q) {
+      if (q + 1 < FB_K / 2 / Q) rd(q + 1);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int s = 0; s < Q; ++s)
+#pragma unroll
+        for (int t = 0; t < TN; ++t)
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[q & 1][s], bf[q & 1][s][t], acc[t], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  for (int c = 0; c < NCH; ++c) {
+    compute(c);
+    if (c + 2 < NCH) bstore(c + 2);
+    if (c + 3 < NCH) bload(c + 3);
+    __syncthreads();
+  }
+  FUSED_STAMP(a, 4);
+
+  // ---- epilogue: logit, BCE, dlogit, statistics, dW3/db3 partials, dh2
+  float h2[TN][16];
+  float p[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    float s = 0.f;
+#pragma unroll
+    for (int t = 0; t < TN; ++t) {
+      h2[t][r] = fmaxf(acc[t][r] + b2v[t], 0.f);
+      s += h2[t][r] * w3v[t];
+    }
+    p[r] = s;
+  }
+#pragma unroll
+  for (int o = 16; o > 0; o >>= 1)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) p[r] += __shfl_xor(p[r], o, 64);
+  if (li == 0) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[wn * FB_M + wm * 32 + 4 * lh + rowoff(r)] = p[r];
+  }
+  __syncthreads();
+  FUSED_STAMP(a, 5);
+  if (tid < FB_M) {  // wave 0: one row per lane
+    const int gi = row0 + tid;
+    const bool valid = gi < a.R;
+    const float x = ((red[tid] + red[FB_M + tid]) + red[2 * FB_M + tid]) + red[3 * FB_M + tid] + b3v;
+    // adversarial/common.py:360-368 + 27-92, the arithmetic of bce_kernel (mlp.hip)
+    const float y = gi < a.n_expert ? 1.f : 0.f;
+    const float lse = log1pf(expf(-fabsf(x)));
+    const float pr = 1.f / (1.f + expf(-x));
+    const float inv = a.loss_scale / (float)a.R;
+    const float dl = valid ? (pr - y) * inv : 0.f;
+    dls[tid] = dl;
+    if (valid) {
+      a.logits[gi] = x;
+      if (a.dlogits) a.dlogits[gi] = dl;
+    }
+    const bool is_gen_pred = x < 0.f, is_gen_true = y == 0.f;
+    const bool ok = is_gen_pred == is_gen_true;
+    float vals[7];
+    vals[0] = valid ? (1.f - y) * x - (fminf(x, 0.f) - lse) : 0.f;
+    vals[1] = (valid && ok) ? 1.f : 0.f;
+    vals[2] = (valid && ok && !is_gen_true) ? 1.f : 0.f;
+    vals[3] = (valid && ok && is_gen_true) ? 1.f : 0.f;
+    vals[4] = (valid && is_gen_pred) ? 1.f : 0.f;
+    vals[5] = valid ? (1.f - pr) * x - (fminf(x, 0.f) - lse) : 0.f;
+    vals[6] = dl;  // db3 partial
+#pragma unroll
+    for (int k = 0; k < 7; ++k) {
+      float v = vals[k];
+      for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+      vals[k] = v;
+    }
+    if (tid == 0) {
+#pragma unroll
+      for (int k = 0; k < 6; ++k) a.part[(long long)blockIdx.x * 8 + k] = vals[k];
+      a.P3[(long long)blockIdx.x * (H + 1) + H] = vals[6];
+    }
+  }
+  __syncthreads();
+  FUSED_STAMP(a, 6);
+  float dlr[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) dlr[r] = dls[wm * 32 + 4 * lh + rowoff(r)];
+#pragma unroll
+  for (int t = 0; t < TN; ++t) {
+    const int col = wn * WC + t * 32 + li;
+    float s = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = wm * 32 + 4 * lh + rowoff(r);
+      s += dlr[r] * h2[t][r];
+      if (row0 + row < a.R) a.dh2[(long long)(row0 + row) * H + col] = h2[t][r] > 0.f ? dlr[r] * w3v[t] : 0.f;
+    }
+    s += __shfl_xor(s, 32, 64);
+    if (lh == 0) w3red[wm * H + col] = s;
+  }
+  __syncthreads();
+  if (tid < H) a.P3[(long long)blockIdx.x * (H + 1) + tid] = w3red[tid] + w3red[H + tid];
+  FUSED_STAMP(a, 7);
+}
+
+// ------------------------------------------------------------------------------------------- K3
+template <int H>
+__global__ __launch_bounds__(FB_NT) void disc_bwd_kernel(FusedArgs a) {
+  constexpr int TN = H / 128;
+  constexpr int WC = TN * 32;
+  constexpr int LDH = H + 1;
+  constexpr int NCH = H / FB_K;
+  constexpr int BST = FB_K * H;
+  constexpr int BV = BST / 4 / FB_NT;
+  constexpr int AST = FB_M * A_LD;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* xs = smem;                    // [64][XP3]
+  float* d1s = xs + FB_M * XP3;        // [64][LDH]  dh1 tile
+  float* bs = d1s + FB_M * LDH;        // 3 x [FB_K][H]   W2 chunks (k = out unit, n = in unit)
+  float* as = bs + 3 * BST;            // 3 x [64][A_LD]  dh2 chunks
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const int wm = wave >> 2, wn = wave & 3;
+  const int row0 = blockIdx.x * FB_M;
+  const int D = a.D;
+  const float* W2 = a.params + (long long)H * D + H;
+
+  FUSED_STAMP(a, 8);
+  f4 rb[BV], ra;
+  const int arow = tid >> 2, aq = tid & 3;
+  const bool a_thread = tid < FB_M * 4;
+  const float* abase = a.dh2 + (long long)min(row0 + arow, a.R - 1) * H + aq * 4;
+  const bool a_valid = a_thread && (row0 + arow < a.R);
+  auto gload = [&](int c) {
+#pragma unroll
+    for (int i = 0; i < BV; ++i)
+      rb[i] = *reinterpret_cast<const f4*>(W2 + (long long)c * BST + (long long)(tid + i * FB_NT) * 4);
+    if (a_thread) ra = *reinterpret_cast<const f4*>(abase + c * FB_K);
+  };
+  auto lstore = [&](int c) {
+    float* S = bs + (c % 3) * BST;
+#pragma unroll
+    for (int i = 0; i < BV; ++i) *reinterpret_cast<f4*>(S + (tid + i * FB_NT) * 4) = rb[i];
+    if (a_thread) {
+      float* d = as + (c % 3) * AST + arow * A_LD + aq * 4;
+      d[0] = a_valid ? ra.x : 0.f; d[1] = a_valid ? ra.y : 0.f; d[2] = a_valid ? ra.z : 0.f; d[3] = a_valid ? ra.w : 0.f;
+    }
+  };
+  gload(0);
+  load_x_tile(a, row0, xs, XP3, tid);
+  for (int e = tid; e < FB_M * (XP3 - 1 - a.ldx); e += FB_NT) {  // columns [ldx, 32) of the B operand
+    const int w = XP3 - 1 - a.ldx;
+    const int row = e / w, c = a.ldx + e - row * w;
+    xs[row * XP3 + c] = 0.f;
+  }
+  lstore(0);
+  gload(1);
+  lstore(1);
+  gload(2);
+  __syncthreads();
+  FUSED_STAMP(a, 9);
+
+  f32x16 acc[TN];
+#pragma unroll
+  for (int t = 0; t < TN; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+  auto compute = [&](int c) {
+    const float* Bs = bs + (c % 3) * BST;
+    const float* Ar = as + (c % 3) * AST + (wm * 32 + li) * A_LD + lh;
+    constexpr int Q = 4;
+    float af[2][Q], bf[2][Q][TN];
+    auto rd = [&](int q) {
+#pragma unroll
+      for (int s = 0; s < Q; ++s) {
+        const int ks = q * Q + s;
+        af[q & 1][s] = Ar[2 * ks];
+#pragma unroll
+        for (int t = 0; t < TN; ++t) bf[q & 1][s][t] = Bs[(2 * ks + lh) * H + wn * WC + t * 32 + li];
+      }
+    };
+    rd(0);
+#pragma unroll
+    for (int q = 0; q < FB_K / 2 / Q; ++q) {
+      if (q + 1 < FB_K / 2 / Q) rd(q + 1);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int s = 0; s < Q; ++s)
+#pragma unroll
+        for (int t = 0; t < TN; ++t)
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[q & 1][s], bf[q & 1][s][t], acc[t], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  // the tile's own h1 values (relu mask), requested before the last chunks so they land behind the MFMAs
+  float pv[TN][16];
+  for (int c = 0; c < NCH; ++c) {
+    if (c == NCH - 2) {
+#pragma unroll
+      for (int t = 0; t < TN; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = min(row0 + wm * 32 + 4 * lh + rowoff(r), a.R - 1);
+          pv[t][r] = a.h1[(long long)row * H + wn * WC + t * 32 + li];
+        }
+    }
+    compute(c);
+    if (c + 2 < NCH) lstore(c + 2);
+    if (c + 3 < NCH) gload(c + 3);
+    __syncthreads();
+  }
+  FUSED_STAMP(a, 10);
+#pragma unroll
+  for (int t = 0; t < TN; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+      d1s[(wm * 32 + 4 * lh + rowoff(r)) * LDH + wn * WC + t * 32 + li] = pv[t][r] > 0.f ? acc[t][r] : 0.f;
+  __syncthreads();
+  FUSED_STAMP(a, 11);
+
+  // ---- dW1 partial [H, D] = dh1^T . xn over the tile's 64 rows (wave w owns hidden units 32w..32w+31);
+  //      db1 partial = column sums of dh1
+  const long long n1 = (long long)H * D + H;
+  float* P1 = a.P1 + (long long)blockIdx.x * n1;
+  if (wave < H / 32) {
+    f32x16 acc1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc1[r] = 0.f;
+    constexpr int Q = 8;
+    float af[2][Q], bf[2][Q];
+    auto rd = [&](int q) {
+#pragma unroll
+      for (int s = 0; s < Q; ++s) {
+        const int k = 2 * (q * Q + s) + lh;
+        af[q & 1][s] = d1s[k * LDH + wave * 32 + li];
+        bf[q & 1][s] = xs[k * XP3 + li];
+      }
+    };
+    rd(0);
+#pragma unroll
+    for (int q = 0; q < FB_M / 2 / Q; ++q) {
+      if (q + 1 < FB_M / 2 / Q) rd(q + 1);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int s = 0; s < Q; ++s) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(af[q & 1][s], bf[q & 1][s], acc1, 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (li < D) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) P1[(long long)(wave * 32 + 4 * lh + rowoff(r)) * D + li] = acc1[r];
+    }
+  }
+  if (tid >= FB_NT - H) {  // the last H threads: bias gradient (the first waves are busy with the MFMAs)
+    const int c = tid - (FB_NT - H);
+    float s = 0.f;
+#pragma unroll 8
+    for (int row = 0; row < FB_M; ++row) s += d1s[row * LDH + c];
+    P1[(long long)H * D + c] = s;
+  }
+  FUSED_STAMP(a, 12);
+}
+
+// ------------------------------------------------------------------------------------------- K1
+struct AssembleArgs {
+  const float* obs[2]; const float* act_f32[2]; const int64_t* act_i64[2]; const float* next[2];
+  const uint8_t* done[2]; const int64_t* idx[2]; int n[2];
+  int obs_dim, act_dim, use_state, use_action, use_next, use_done;
+  float* X; int ldx; int R; int D;
+  int update_norm;                       // slab moments + merge
+  float* rn_ws;                          // [slabs][2][D]
+  float* mean; float* var; int32_t* count;
+  float* pmean; float* pvar; int32_t* pcount; int pdim;   // second norm over the first pdim columns
+  unsigned int* ticket;
+  const float* W2; float* W2T; int H;    // transposer blocks (blockIdx >= slabs); W2T == nullptr: none
+};
+
+constexpr int AS_NT = 1024;
+
+__global__ __launch_bounds__(AS_NT) void disc_assemble_kernel(AssembleArgs a) {
+  __shared__ __attribute__((aligned(16))) float xt[RN_ROWS_PER_BLOCK * 24];  // the slab, X's own layout (ldx <= 24)
+  __shared__ float red[8][33];
+  __shared__ int s_last;
+  const int tid = threadIdx.x;
+  const int slabs = (a.R + RN_ROWS_PER_BLOCK - 1) / RN_ROWS_PER_BLOCK;
+  if ((int)blockIdx.x >= slabs) {
+    // ---- W2 [H][H] -> W2T, one 64x64 tile per block through LDS (stride 65)
+    float* tt = xt;  // 64*65 = 4160 floats <= 6144
+    const int tb = blockIdx.x - slabs, tpr = a.H / 64;
+    const int r0 = (tb / tpr) * 64, c0 = (tb % tpr) * 64;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int e = tid + i * AS_NT, r = e >> 6, c = e & 63;
+      tt[r * 65 + c] = a.W2[(long long)(r0 + r) * a.H + c0 + c];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int e = tid + i * AS_NT, r = e >> 6, c = e & 63;
+      a.W2T[(long long)(c0 + r) * a.H + r0 + c] = tt[c * 65 + r];
+    }
+    return;
+  }
+  const int r0 = blockIdx.x * RN_ROWS_PER_BLOCK;
+  const int rows = min(RN_ROWS_PER_BLOCK, a.R - r0);
+  const int ldx = a.ldx, D = a.D;
+  {
+    // four threads per row; thread q takes columns q, q+4, ... (adversarial/common.py:592-603 +
+    // rewards/reward_nets.py:441-457, the element rule of gather_concat_kernel). Every load is
+    // unconditional at a clamped address so that the batch is in flight at once.
+    const int row = tid >> 2, q = tid & 3;
+    const int gi = min(r0 + row, a.R - 1);
+    const int s = gi >= a.n[0] ? 1 : 0;
+    const int li = gi - (s ? a.n[0] : 0);
+    const long long src = a.idx[s] ? a.idx[s][li] : (long long)li;
+    const long long av = a.act_i64[s] ? a.act_i64[s][src] : 0;
+    const float dn = (a.use_done && a.done[s][src]) ? 1.f : 0.f;
+    constexpr int NC = 6;  // columns per thread (ldx <= 24)
+    float v[NC];
+    int kind[NC], oo[NC];
+#pragma unroll
+    for (int j = 0; j < NC; ++j) {
+      const int c = min(q + 4 * j, ldx - 1);
+      int o = c, k = 0;  // 0 zero, 1 f32 load, 2 one-hot, 3 done
+      const float* p = a.obs[s];
+      if (a.use_state) {
+        if (o < a.obs_dim) { k = 1; p = a.obs[s] + src * a.obs_dim + o; }
+        o -= a.obs_dim;
+      }
+      if (k == 0 && a.use_action) {
+        if (o >= 0 && o < a.act_dim) {
+          if (a.act_i64[s]) { k = 2; }
+          else { k = 1; p = a.act_f32[s] + src * a.act_dim + o; }
+        }
+        if (k == 0) o -= a.act_dim;
+      }
+      if (k == 0 && a.use_next) {
+        if (o >= 0 && o < a.obs_dim) { k = 1; p = a.next[s] + src * a.obs_dim + o; }
+        if (k == 0) o -= a.obs_dim;
+      }
+      if (k == 0 && a.use_done && o == 0) k = 3;
+      kind[j] = k; oo[j] = o;
+      v[j] = *p;
+    }
+#pragma unroll
+    for (int j = 0; j < NC; ++j) {
+      const int c = q + 4 * j;
+      if (c < ldx) {
+        float x = 0.f;
+        if (kind[j] == 1) x = v[j];
+        else if (kind[j] == 2) x = (av == oo[j]) ? 1.f : 0.f;
+        else if (kind[j] == 3) x = dn;
+        xt[row * ldx + c] = (r0 + row < a.R) ? x : 0.f;
+      }
+    }
+  }
+  __syncthreads();
+  // the slab in LDS has X's own layout: coalesced 16-byte copy out
+  for (int e = tid; e < rows * ldx / 4; e += AS_NT)
+    reinterpret_cast<f4*>(a.X + (long long)r0 * ldx)[e] = reinterpret_cast<const f4*>(xt)[e];
+  if (!a.update_norm) return;
+
+  // ---- slab moments: the arithmetic (and summation order) of rn_partial_kernel, reading the LDS copy
+  {
+    const bool act = tid < 256;
+    const int cl = tid & 31, rl = (tid >> 5) & 7;
+    constexpr int RPT = RN_ROWS_PER_BLOCK / 8;
+    for (int c0 = 0; c0 < D; c0 += 32) {
+      const int c = c0 + cl;
+      float v[RPT];
+      float mean = 0.f;
+      if (act) {
+#pragma unroll
+        for (int k = 0; k < RPT; ++k) v[k] = xt[min(rl + 8 * k, rows - 1) * ldx + min(c, D - 1)];
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < RPT; ++k) s += (c < D && rl + 8 * k < rows) ? v[k] : 0.f;
+        red[rl][cl] = s;
+      }
+      __syncthreads();
+      if (act && rl == 0) {
+        float t = 0.f;
+        for (int k = 0; k < 8; ++k) t += red[k][cl];
+        red[0][cl] = t / (float)rows;
+      }
+      __syncthreads();
+      if (act) mean = red[0][cl];
+      __syncthreads();
+      if (act) {
+        float q = 0.f;
+#pragma unroll
+        for (int k = 0; k < RPT; ++k) {
+          const float dlt = v[k] - mean;
+          q += (c < D && rl + 8 * k < rows) ? dlt * dlt : 0.f;
+        }
+        red[rl][cl] = q;
+      }
+      __syncthreads();
+      if (act && rl == 0 && c < D) {
+        float t = 0.f;
+        for (int k = 0; k < 8; ++k) t += red[k][cl];
+        a.rn_ws[((long long)blockIdx.x * 2 + 0) * D + c] = mean;
+        a.rn_ws[((long long)blockIdx.x * 2 + 1) * D + c] = t;  // M2 of the slab
+      }
+      __syncthreads();
+    }
+  }
+  if (a.mean == nullptr) return;
+  // ---- last slab block merges (util/networks.py:111-134). Hand-off per the gfx950 rules: plain stores ->
+  // __syncthreads -> one-lane agent-scope release (+ explicit vmcnt(0)) -> relaxed ticket; last block:
+  // one-lane agent-scope acquire -> __syncthreads -> plain loads.
+  if (tid == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned int t = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_last = (t == (unsigned int)slabs - 1u);
+    if (s_last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  }
+  __syncthreads();
+  if (!s_last) return;
+  const int cnt = *a.count;
+  const int pcnt = a.pcount ? *a.pcount : 0;
+  __syncthreads();
+  const int lane = tid & 63, wave = tid >> 6;
+  const int pdim = a.pmean ? a.pdim : 0;
+  for (int job = wave; job < D + pdim; job += AS_NT / 64) {
+    const bool isp = job >= D;
+    const int c = isp ? job - D : job;
+    float b_mean, b_M2;
+    rn_wave_batch_moments(a.rn_ws, slabs, slabs, a.R, D, c, lane, b_mean, b_M2);
+    if (lane == 0) {
+      float* mp = isp ? a.pmean : a.mean;
+      float* vp = isp ? a.pvar : a.var;
+      float mc = mp[c], vc = vp[c];
+      rn_absorb(mc, vc, isp ? pcnt : cnt, a.R, b_mean, b_M2 / (float)a.R);
+      mp[c] = mc;
+      vp[c] = vc;
+    }
+  }
+  if (tid == 0) {
+    *a.count = rn_count_add(cnt, a.R);
+    if (pdim > 0) *a.pcount = rn_count_add(pcnt, a.R);
+    __hip_atomic_store(a.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+// ------------------------------------------------------------------------------------------- K5
+struct ReduceArgs {
+  const float* src[3]; long long stride[3]; int cnt[3]; long long seg_end[3];   // W1b1 | W2b2 | W3b3
+  long long n; int accumulate; float* grads;
+  int adam; float* p; float* m; float* v; float beta1, beta2, eps, wd, step_size, bc2_sqrt;
+  const float* part; int tiles; int R; int n_expert; float loss_scale; float* stats;
+};
+
+// 64 parameters per block; wave q folds quarter q of the element's slabs in slab order, the four quarter
+// sums are combined in fixed order -> deterministic. The last block folds the statistics partials.
+__global__ __launch_bounds__(256) void disc_reduce_kernel(ReduceArgs a) {
+  __shared__ float red[4][64];
+  const int tid = threadIdx.x, lane = tid & 63, q = tid >> 6;
+  if (blockIdx.x == gridDim.x - 1) {
+    float vals[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int t = tid; t < a.tiles; t += 256) {
+#pragma unroll
+      for (int k = 0; k < 6; ++k) vals[k] += a.part[(long long)t * 8 + k];
+    }
+    __shared__ float sred[6][4];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      float v = vals[k];
+      for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+      if (lane == 0) sred[k][q] = v;
+    }
+    __syncthreads();
+    if (tid < 6) {
+      float t = ((sred[tid][0] + sred[tid][1]) + sred[tid][2]) + sred[tid][3];
+      if (tid == 0) t = t / (float)a.R * a.loss_scale;
+      a.stats[tid] = t;
+    }
+    if (tid == 6) a.stats[6] = (float)a.n_expert;
+    if (tid == 7) a.stats[7] = (float)(a.R - a.n_expert);
+    return;
+  }
+  const long long i = (long long)blockIdx.x * 64 + lane;
+  const long long ic = i < a.n ? i : a.n - 1;
+  const int seg = ic < a.seg_end[0] ? 0 : (ic < a.seg_end[1] ? 1 : 2);
+  const long long base = seg == 0 ? 0 : a.seg_end[seg - 1];
+  const float* src = a.src[seg] + (ic - base);
+  const long long st = a.stride[seg];
+  const int cnt = a.cnt[seg];
+  const int lo = (int)((long long)q * cnt / 4), hi = (int)((long long)(q + 1) * cnt / 4);
+  float s = 0.f;
+  int k = lo;
+  for (; k + 8 <= hi; k += 8) {
+    float t[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) t[u] = src[(long long)(k + u) * st];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s += t[u];
+  }
+  for (; k < hi; ++k) s += src[(long long)k * st];
+  red[q][lane] = s;
+  __syncthreads();
+  if (q != 0 || i >= a.n) return;
+  float grad = ((red[0][lane] + red[1][lane]) + red[2][lane]) + red[3][lane];
+  if (a.accumulate) grad = a.grads[i] + grad;
+  a.grads[i] = grad;
+  if (!a.adam) return;
+  // torch/optim/adam.py _single_tensor_adam: lerp, mul+addcmul, sqrt/bc2_sqrt + eps, addcdiv
+  const float pi = a.p[i];
+  if (a.wd != 0.f) grad = grad + a.wd * pi;
+  float mi = a.m[i];
+  mi = mi + (grad - mi) * (1.f - a.beta1);
+  const float vi = a.v[i] * a.beta2 + (1.f - a.beta2) * grad * grad;
+  const float denom = sqrtf(vi) / a.bc2_sqrt + a.eps;
+  a.p[i] = pi - a.step_size * (mi / denom);
+  a.m[i] = mi;
+  a.v[i] = vi;
+}
+
+inline int cdivi(long long a, long long b) { return (int)((a + b - 1) / b); }
+
+inline bool fused_shape_ok(const ia_mlp_desc* d, int ldx) {
+  if (!d || d->n_layers != 3 || d->hidden_act != IA_ACT_RELU) return false;
+  const int D = d->dims[0], H = d->dims[1];
+  if (d->dims[2] != H || d->dims[3] != 1) return false;
+  if (H != 128 && H != 256) return false;
+  return D >= 1 && D <= 24 && ldx >= D && ldx <= 24 && ldx % 4 == 0;
+}
+
+struct FusedWs { float* P1; float* P3; float* part; float* W2T; unsigned int* ticket; long long total; };
+
+inline FusedWs fused_ws_layout(const ia_mlp_desc* d, int R, float* base) {
+  const long long D = d->dims[0], H = d->dims[1];
+  const long long tiles = cdivi(R, FB_M);
+  FusedWs w;
+  long long o = 0;
+  w.P1 = base + o; o += tiles * (H * D + H);
+  w.P3 = base + o; o += tiles * (H + 1);
+  w.part = base + o; o += tiles * 8;
+  o = (o + 3) / 4 * 4;                     // 16-byte aligned W2T rows
+  w.W2T = base + o; o += H * H;
+  w.ticket = reinterpret_cast<unsigned int*>(base + o); o += 4;
+  w.total = o;
+  return w;
+}
+
+template <int H>
+int launch_fused_tiles(const FusedArgs& fa, int tiles, hipStream_t stream) {
+  constexpr size_t smem_f = sizeof(float) * (FB_M * XP + H * XP + FB_M * (H + 1) + 3 * FB_K * H + 4 * FB_M + FB_M + 2 * H);
+  constexpr size_t smem_b = sizeof(float) * (FB_M * XP3 + FB_M * (H + 1) + 3 * FB_K * H + 3 * FB_M * A_LD);
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(disc_fwd_kernel<H>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_f);
+    if (e != hipSuccess) return (int)e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(disc_bwd_kernel<H>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_b);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(disc_fwd_kernel<H>, dim3(tiles), dim3(FB_NT), smem_f, stream, fa);
+  IA_CHECK_LAUNCH();
+  hipLaunchKernelGGL(disc_bwd_kernel<H>, dim3(tiles), dim3(FB_NT), smem_b, stream, fa);
+  IA_CHECK_LAUNCH();
+  return IA_OK;
+}
+
+}  // namespace
+
+namespace { long long* g_fused_dbg = nullptr; }
+extern "C" int ia_disc_fused_debug_timing(void* device_buffer_16xi64) {
+  g_fused_dbg = static_cast<long long*>(device_buffer_16xi64);
+  return IA_OK;
+}
+
+extern "C" int64_t ia_disc_fused_ws_floats(const ia_mlp_desc* d, int R, int ldx) {
+  if (R <= 0 || !fused_shape_ok(d, ldx)) return 0;
+  return fused_ws_layout(d, R, nullptr).total;
+}
+
+// The fused form of ia_disc_step_basic (mlp.hip dispatches here when a->fused_ws is set and the shape
+// qualifies). Same contract, same outputs (logits, dlogits, stats, rn_ws slab moments, grads / Adam).
+int ia_disc_step_fused(const ia_disc_step_args* a, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  const ia_mlp_desc* d = a->desc;
+  const int R = a->n0 + a->n1, D = d->dims[0], H = d->dims[1];
+  if (!fused_shape_ok(d, a->ldx) || !a->fused_ws) return IA_ERR_UNSUPPORTED;
+  const FusedWs w = fused_ws_layout(d, R, a->fused_ws);
+  const int tiles = cdivi(R, FB_M), slabs = cdivi(R, RN_ROWS_PER_BLOCK);
+  const long long nW1 = (long long)H * D, n1 = nW1 + H, n2 = (long long)H * H + H, n3 = H + 1, tot = n1 + n2 + n3;
+
+  AssembleArgs as{};
+  as.obs[0] = a->obs0; as.act_f32[0] = a->act0_f32; as.act_i64[0] = a->act0_i64; as.next[0] = a->next0;
+  as.done[0] = a->done0; as.idx[0] = a->idx0; as.n[0] = a->n0;
+  as.obs[1] = a->obs1; as.act_f32[1] = a->act1_f32; as.act_i64[1] = a->act1_i64; as.next[1] = a->next1;
+  as.done[1] = a->done1; as.idx[1] = a->idx1; as.n[1] = a->n1;
+  if (a->n0 == 0) { as.obs[0] = a->obs1; as.next[0] = a->next1; as.done[0] = a->done1; }
+  if (a->n1 == 0) { as.obs[1] = a->obs0; as.next[1] = a->next0; as.done[1] = a->done0; }
+  as.obs_dim = a->obs_dim; as.act_dim = a->act_dim; as.use_state = a->use_state; as.use_action = a->use_action;
+  as.use_next = a->use_next_state; as.use_done = a->use_done;
+  as.X = a->X; as.ldx = a->ldx; as.R = R; as.D = D;
+  as.update_norm = (a->norm_mean != nullptr && a->update_norm) ? 1 : 0;
+  as.rn_ws = a->rn_ws; as.mean = a->norm_mean; as.var = a->norm_var; as.count = a->norm_count;
+  const bool use_p = as.update_norm && a->pnorm_mean && a->pnorm_dim > 0 && a->pnorm_dim <= D;
+  as.pmean = use_p ? a->pnorm_mean : nullptr; as.pvar = a->pnorm_var; as.pcount = use_p ? a->pnorm_count : nullptr;
+  as.pdim = use_p ? a->pnorm_dim : 0;
+  as.ticket = w.ticket;
+  as.W2 = a->params + n1; as.W2T = w.W2T; as.H = H;
+  hipLaunchKernelGGL(disc_assemble_kernel, dim3(slabs + (H / 64) * (H / 64)), dim3(AS_NT), 0, stream, as);
+  IA_CHECK_LAUNCH();
+
+  FusedArgs fa{};
+  fa.X = a->X; fa.ldx = a->ldx; fa.R = R; fa.D = D;
+  fa.mean = a->norm_mean; fa.var = a->norm_var; fa.eps = a->norm_eps;
+  fa.params = a->params; fa.W2T = w.W2T;
+  fa.h1 = a->hidden; fa.dh2 = a->hidden + (long long)R * H;
+  fa.logits = a->logits; fa.dlogits = a->dlogits; fa.n_expert = a->n_expert; fa.loss_scale = a->loss_scale;
+  fa.part = w.part; fa.P1 = w.P1; fa.P3 = w.P3;
+  fa.dbg = g_fused_dbg;
+  int rc = H == 256 ? launch_fused_tiles<256>(fa, tiles, stream) : launch_fused_tiles<128>(fa, tiles, stream);
+  if (rc) return rc;
+
+  // dW2 [H,H] = dh2^T . h1 (+ db2 = column sums of dh2), split-K slabs inside `partials` ([splits][tot])
+  const int splits = a->splits;
+  const int kps = (((R + splits - 1) / splits) + 31) / 32 * 32;
+  IaGemm g{};
+  g.A = fa.dh2; g.lda = H;
+  g.B = fa.h1; g.ldb = H;
+  g.M = H; g.N = H; g.K = R;
+  g.C = a->partials + n1; g.ldc = H;
+  g.splits = splits; g.k_per_split = kps; g.c_split_stride = tot;
+  g.dbias = a->partials + n1 + (long long)H * H; g.dbias_split_stride = tot;
+  if ((rc = ia_launch_gemm(IA_GEMM_TN, g, stream))) return rc;
+
+  ReduceArgs ra{};
+  ra.src[0] = w.P1; ra.stride[0] = n1; ra.cnt[0] = tiles; ra.seg_end[0] = n1;
+  ra.src[1] = a->partials + n1; ra.stride[1] = tot; ra.cnt[1] = splits; ra.seg_end[1] = n1 + n2;
+  ra.src[2] = w.P3; ra.stride[2] = n3; ra.cnt[2] = tiles; ra.seg_end[2] = tot;
+  ra.n = tot; ra.accumulate = a->accumulate; ra.grads = a->grads;
+  ra.adam = (a->adam && !a->accumulate) ? 1 : 0;
+  ra.p = a->params; ra.m = a->exp_avg; ra.v = a->exp_avg_sq;
+  ra.beta1 = a->beta1; ra.beta2 = a->beta2; ra.eps = a->adam_eps; ra.wd = a->weight_decay;
+  ra.step_size = a->step_size; ra.bc2_sqrt = a->bc2_sqrt;
+  ra.part = w.part; ra.tiles = tiles; ra.R = R; ra.n_expert = a->n_expert; ra.loss_scale = a->loss_scale;
+  ra.stats = a->stats;
+  hipLaunchKernelGGL(disc_reduce_kernel, dim3(cdivi(tot, 64) + 1), dim3(256), 0, stream, ra);
+  IA_CHECK_LAUNCH();
+  if (a->adam && a->accumulate)
+    return ia_adam_step(a->params, a->grads, a->exp_avg, a->exp_avg_sq, tot, a->beta1, a->beta2, a->adam_eps,
+                        a->weight_decay, a->step_size, a->bc2_sqrt, stream_);
+  return IA_OK;
+}

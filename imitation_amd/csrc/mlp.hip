@@ -2,6 +2,7 @@
 // HBM-bound helpers of the discriminator update: RunningNorm (Chan merge), gather+concat
 // batch assembly, BCE-with-logits + train statistics, split-K partial reduction, Adam.
 #include "common.h"
+#include "rn_common.h"
 #include "../../include/imitation_hip.h"
 
 namespace {
@@ -100,8 +101,6 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
 // RunningNorm statistics. Stage 1: each block owns a contiguous slab of rows and produces, per
 // column, (mean_b, M2_b) by a two-pass over its slab (rows are re-read from L2). Stage 2: one
 // block Chan-merges the slabs in slab order and applies the reference's update formula.
-constexpr int RN_ROWS_PER_BLOCK = 256;
-
 __global__ __launch_bounds__(256) void rn_partial_kernel(const float* __restrict__ X, int ldx, int R, int D,
                                                          float* __restrict__ ws) {
   // threads: 256 = 8 row-lanes x 32 column-lanes; loops over columns in steps of 32
@@ -152,52 +151,23 @@ __global__ __launch_bounds__(256) void rn_partial_kernel(const float* __restrict
   }
 }
 
-// Chan combination of two (count, mean, M2) moment triples.
-__device__ __forceinline__ void chan_combine(float& n, float& m, float& M2, float nb, float mb, float qb) {
-  if (nb == 0.f) return;
-  const float tot = n + nb;
-  const float dlt = mb - m;
-  M2 = M2 + qb + dlt * dlt * n * nb / tot;
-  m = m + dlt * nb / tot;
-  n = tot;
-}
-
 // `nblocks` slabs in groups of `bpg` (one group per data-parallel rank, each covering `rpg` rows);
-// R = total rows. One WAVE per column: lane l folds slabs l, l+64, ... sequentially, then a fixed
-// butterfly (xor 32,16,...,1) combines the 64 partial triples -> deterministic, ~3 us instead of a
-// 64-deep chain of dependent global loads. `ws_ld` = column count the slab moments were written with.
+// R = total rows. One WAVE per column (rn_common.h). `ws_ld` = column count the slab moments were
+// written with.
 __global__ __launch_bounds__(64) void rn_merge_kernel(const float* __restrict__ ws, int nblocks, int bpg, int rpg,
                                                       int R, int D, int ws_ld, float* __restrict__ mean,
-                                                      float* __restrict__ var, int32_t* __restrict__ count,
-                                                      int bump_count) {
+                                                      float* __restrict__ var, const int32_t* __restrict__ count) {
   const int c = blockIdx.x, lane = threadIdx.x;
   const int cnt = *count;
-  float n_acc = 0.f, m_acc = 0.f, M2 = 0.f;
-  for (int b = lane; b < nblocks; b += 64) {
-    const float nb = (float)min(RN_ROWS_PER_BLOCK, rpg - (b % bpg) * RN_ROWS_PER_BLOCK);
-    chan_combine(n_acc, m_acc, M2, nb, ws[((long long)b * 2 + 0) * ws_ld + c], ws[((long long)b * 2 + 1) * ws_ld + c]);
-  }
-  for (int o = 32; o > 0; o >>= 1) {
-    const float nb = __shfl_xor(n_acc, o, 64), mb = __shfl_xor(m_acc, o, 64), qb = __shfl_xor(M2, o, 64);
-    // both partners must compute the identical combination: order the pair by lane id
-    if ((lane & o) == 0) chan_combine(n_acc, m_acc, M2, nb, mb, qb);
-    else { float n2 = nb, m2 = mb, q2 = qb; chan_combine(n2, m2, q2, n_acc, m_acc, M2); n_acc = n2; m_acc = m2; M2 = q2; }
-  }
+  float b_mean, b_M2;
+  rn_wave_batch_moments(ws, nblocks, bpg, rpg, ws_ld, c, lane, b_mean, b_M2);
   if (lane == 0) {
-    const float b_mean = m_acc, b_var = M2 / (float)R;
-    // util/networks.py:123-134, same operation order
-    const float fcount = (float)cnt, fn = (float)R;
-    const float tot = (float)(cnt + R);
-    const float delta = b_mean - mean[c];
-    mean[c] = mean[c] + delta * fn / tot;
-    float rv = var[c] * fcount;
-    rv = rv + b_var * fn;
-    rv = rv + delta * delta * fcount * fn / tot;
-    var[c] = rv / tot;
+    float mc = mean[c], vc = var[c];
+    rn_absorb(mc, vc, cnt, R, b_mean, b_M2 / (float)R);
+    mean[c] = mc;
+    var[c] = vc;
   }
-  // the count is bumped by a separate 1-thread launch-free path: the LAST column's wave does it after
-  // every column has read `cnt`... columns run in different blocks, so do it in a tiny follow-up kernel.
-  (void)bump_count;
+  // the count is bumped by a tiny follow-up kernel: columns run in different blocks and all read `cnt`
 }
 
 // `n_seq` CONSECUTIVE updates (each the merge above of one batch's slab moments, `seq_stride` floats
@@ -212,27 +182,10 @@ __global__ __launch_bounds__(64) void rn_merge_seq_kernel(const float* __restric
   int cnt = *count;
   float mc = mean[c], vc = var[c];
   for (int k = 0; k < n_seq; ++k) {
-    const float* ws = ws_seq + (long long)k * seq_stride;
-    float n_acc = 0.f, m_acc = 0.f, M2 = 0.f;
-    for (int b = lane; b < nblocks; b += 64) {
-      const float nb = (float)min(RN_ROWS_PER_BLOCK, rpg - (b % bpg) * RN_ROWS_PER_BLOCK);
-      chan_combine(n_acc, m_acc, M2, nb, ws[((long long)b * 2 + 0) * ws_ld + c], ws[((long long)b * 2 + 1) * ws_ld + c]);
-    }
-    for (int o = 32; o > 0; o >>= 1) {
-      const float nb = __shfl_xor(n_acc, o, 64), mb = __shfl_xor(m_acc, o, 64), qb = __shfl_xor(M2, o, 64);
-      if ((lane & o) == 0) chan_combine(n_acc, m_acc, M2, nb, mb, qb);
-      else { float n2 = nb, m2 = mb, q2 = qb; chan_combine(n2, m2, q2, n_acc, m_acc, M2); n_acc = n2; m_acc = m2; M2 = q2; }
-    }
-    const float b_mean = __shfl(m_acc, 0, 64), b_var = __shfl(M2, 0, 64) / (float)R;
-    const float fcount = (float)cnt, fn = (float)R;
-    const float tot = (float)(cnt + R);
-    const float delta = b_mean - mc;
-    mc = mc + delta * fn / tot;
-    float rv = vc * fcount;
-    rv = rv + b_var * fn;
-    rv = rv + delta * delta * fcount * fn / tot;
-    vc = rv / tot;
-    cnt += R;
+    float b_mean, b_M2;
+    rn_wave_batch_moments(ws_seq + (long long)k * seq_stride, nblocks, bpg, rpg, ws_ld, c, lane, b_mean, b_M2);
+    rn_absorb(mc, vc, cnt, R, b_mean, b_M2 / (float)R);
+    cnt = rn_count_add(cnt, R);
     if (snapshots != nullptr && lane == 0) {  // statistics as update k's own forward pass sees them
       snapshots[((long long)k * 2 + 0) * D + c] = mc;
       snapshots[((long long)k * 2 + 1) * D + c] = vc;
@@ -244,8 +197,8 @@ __global__ __launch_bounds__(64) void rn_merge_seq_kernel(const float* __restric
   }
 }
 
-__global__ void rn_count_kernel(int32_t* __restrict__ count, int R) {
-  if (threadIdx.x == 0 && blockIdx.x == 0) *count += R;
+__global__ void rn_count_kernel(int32_t* __restrict__ count, long long R) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) *count = rn_count_add(*count, R);
 }
 
 __global__ void rn_apply_kernel(const float* __restrict__ X, int ldx, int R, int D, const float* __restrict__ mean,
@@ -432,14 +385,11 @@ __global__ __launch_bounds__(256) void reward_norm_seq_kernel(const float* __res
     for (int o = 128; o > 0; o >>= 1) { if (tid < o) red[tid] += red[tid + o]; __syncthreads(); }
     if (tid == 0) {
       const float bvar = red[0] / (float)n;
-      const float fcount = (float)s_cnt, fn = (float)n, tot = (float)(s_cnt + n);
-      const float delta = bmean - s_mean;
-      s_mean = s_mean + delta * fn / tot;
-      float rv = s_var * fcount;
-      rv = rv + bvar * fn;
-      rv = rv + delta * delta * fcount * fn / tot;
-      s_var = rv / tot;
-      s_cnt += n;
+      float mc = s_mean, vc = s_var;
+      rn_absorb(mc, vc, s_cnt, n, bmean, bvar);
+      s_mean = mc;
+      s_var = vc;
+      s_cnt = rn_count_add(s_cnt, n);
     }
     __syncthreads();
   }
@@ -449,6 +399,8 @@ __global__ __launch_bounds__(256) void reward_norm_seq_kernel(const float* __res
 inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 
 }  // namespace
+
+int ia_disc_step_fused(const ia_disc_step_args* a, void* stream);  // disc_fused.hip
 
 extern "C" {
 
@@ -698,9 +650,9 @@ int ia_running_norm_update(const float* X, int ldx, int R, int D, float* mean, f
   hipLaunchKernelGGL(rn_partial_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, X, ldx, R, D, ws);
   IA_CHECK_LAUNCH();
   hipLaunchKernelGGL(rn_merge_kernel, dim3(D), dim3(64), 0, (hipStream_t)stream, ws, nb, nb, R, R, D, D, mean, var,
-                     count, 0);
+                     count);
   IA_CHECK_LAUNCH();
-  hipLaunchKernelGGL(rn_count_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, count, R);
+  hipLaunchKernelGGL(rn_count_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, count, (long long)R);
   IA_CHECK_LAUNCH();
   return IA_OK;
 }
@@ -718,9 +670,9 @@ int ia_running_norm_merge(const float* ws_all, int groups, int rows_per_group, i
   if (groups <= 0 || rows_per_group <= 0 || D <= 0 || ws_ld < D) return IA_ERR_ARG;
   const int bpg = cdiv(rows_per_group, RN_ROWS_PER_BLOCK);
   hipLaunchKernelGGL(rn_merge_kernel, dim3(D), dim3(64), 0, (hipStream_t)stream, ws_all, groups * bpg, bpg,
-                     rows_per_group, groups * rows_per_group, D, ws_ld, mean, var, count, 0);
+                     rows_per_group, groups * rows_per_group, D, ws_ld, mean, var, count);
   IA_CHECK_LAUNCH();
-  hipLaunchKernelGGL(rn_count_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, count, groups * rows_per_group);
+  hipLaunchKernelGGL(rn_count_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, count, (long long)groups * rows_per_group);
   IA_CHECK_LAUNCH();
   return IA_OK;
 }
@@ -735,7 +687,7 @@ int ia_running_norm_merge_seq(const float* ws_seq, int n_seq, int64_t seq_stride
                      (long long)seq_stride, groups * bpg, bpg, rows_per_group, rows, D, ws_ld, mean, var, count,
                      snapshots);
   IA_CHECK_LAUNCH();
-  hipLaunchKernelGGL(rn_count_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, count, n_seq * rows);
+  hipLaunchKernelGGL(rn_count_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, count, (long long)n_seq * rows);
   IA_CHECK_LAUNCH();
   return IA_OK;
 }
@@ -779,6 +731,9 @@ int ia_bce_logits(const float* logits, int R, int n_expert, float scale, float* 
 
 int ia_disc_step_basic(const ia_disc_step_args* a, void* stream) {
   if (!a || !desc_ok(a->desc) || a->n0 < 0 || a->n1 < 0 || a->n0 + a->n1 <= 0) return IA_ERR_ARG;
+  // D -> H -> H -> 1 ReLU stacks with a fused workspace take the five-launch path (disc_fused.hip)
+  if (a->fused_ws != nullptr && ia_disc_fused_ws_floats(a->desc, a->n0 + a->n1, a->ldx) > 0)
+    return ia_disc_step_fused(a, stream);
   const int R = a->n0 + a->n1;
   const int D = a->desc->dims[0];
   int rc;

@@ -22,6 +22,10 @@ from imitation_amd.networks import (DenseStack, RunningNorm, TransitionTable, ev
                                     require_device)
 
 
+# tuning / tests: False forces the general (unfused) discriminator update even where the fused one applies
+FUSED_DISC_STEP = True
+
+
 class ParamStore:
     """All dense stacks of one reward-net tree share a flat parameter / gradient buffer."""
 
@@ -270,6 +274,10 @@ class BasicRewardNet(RewardNet):
             a.hidden, a.dhidden = L.ptr(ws["hidden"]), L.ptr(ws["dhidden"])
             a.logits, a.dlogits, a.partials = L.ptr(ws["out"]), L.ptr(ws["dlogits"]), L.ptr(ws["partials"])
             a.splits, a.rn_ws = ws["splits"], L.ptr(ws["rn_ws"])
+            # D -> H -> H -> 1 stacks: workspace of the five-launch fused update (0 floats: general path)
+            nf = 0 if FUSED_DISC_STEP is False else int(L.load().ia_disc_fused_ws_floats(C.byref(mlp.desc), R, mlp.ldx))
+            ws["fused_ws"] = th.zeros(nf, device=dev) if nf > 0 else None
+            a.fused_ws = L.ptr(ws["fused_ws"])
             ws["args"] = a
         a = ws["args"]
         a.params, a.grads = L.ptr(mlp.flat), L.ptr(mlp.grad)

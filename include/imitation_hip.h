@@ -154,8 +154,19 @@ typedef struct {
   /* optional: a second RunningNorm over the first pnorm_dim columns updated with the SAME batch
    * moments (the policy feature norm side effect); requires update_norm. */
   float* pnorm_mean; float* pnorm_var; int32_t* pnorm_count; int pnorm_dim;
+  /* optional: ia_disc_fused_ws_floats(desc, n0+n1, ldx) floats, ZEROED once by the caller. When set and the
+   * stack is D -> H -> H -> 1 with ReLU, H in {128, 256}, D <= 24, the update runs as five fused launches
+   * (assemble+moments+merge | forward+BCE+head gradient per 64-row tile | input gradient + first-layer weight
+   * gradient per tile | second-layer weight gradient | slab reduction + Adam + statistics): the hidden
+   * activations of a tile stay in LDS; `hidden` then holds h1 and dh2, `Xn` / `dhidden` are not touched. */
+  float* fused_ws;
 } ia_disc_step_args;
 int ia_disc_step_basic(const ia_disc_step_args* a, void* stream);
+/* 0 when the fused path does not cover the shape (the call then runs the general path). */
+int64_t ia_disc_fused_ws_floats(const ia_mlp_desc* d, int R, int ldx);
+/* Measurement only: when set to a device buffer of 16 int64, block 0 of the fused forward / backward tile
+ * kernels stores the shader clock at its phase boundaries in [0..7] / [8..12] (NULL switches it off). */
+int ia_disc_fused_debug_timing(void* device_buffer_16xi64);
 
 /* adversarial/airl.py:118 + rewards/reward_nets.py:701-736:
  * logits = g + gamma*(1-done)*h_next - h_cur - logp ; and the matching dOut routing. */
