@@ -45,7 +45,9 @@ struct FusedArgs {
   const float* mean; const float* var; float eps;     // mean == nullptr: no input normalisation
   const float* params;                                 // W1[H,D] b1[H] W2[H,H] b2[H] W3[H] b3[1]
   const float* W2T;                                    // [in][out]
+  const float* W1P;                                    // [H][XP]: W1 rows zero-padded to the LDS row length
   float* h1; float* dh2;                               // [R,H] each
+  unsigned long long* h1mask;                          // [tiles][8 waves][TN*16]: ballot(h1 > 0) per accumulator register
   float* logits; float* dlogits; int n_expert; float loss_scale;
   float* part;                                         // [tiles][8] statistics partials
   float* P1; float* P3;                                // per-tile partial slabs: [tiles][H*D+H], [tiles][H+1]
@@ -75,6 +77,66 @@ __device__ __forceinline__ void load_x_tile(const FusedArgs& a, int row0, float*
 }
 
 // ------------------------------------------------------------------------------------------- K2
+// Cross-lane sums by halving butterflies: N values per lane, summed across a group of lanes; every step
+// trades half of the values with the partner lane, so N values cost N - 1 + log2(lanes / N) exchanges instead
+// of N * log2(lanes). Fixed order -> deterministic.
+// reduce16_in_half: 16 values across the 32 lanes of a wave half; lane `l` ends with the total of value
+// index ((l>>4)&1)*8 + ((l>>3)&1)*4 + ((l>>2)&1)*2 + ((l>>1)&1) (lanes l and l^1 hold the same one).
+template <int N, int O>
+__device__ __forceinline__ void halve_step(float* __restrict__ v, int lane) {
+  const bool up = (lane & O) != 0;
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    const float send = up ? v[i] : v[i + N];
+    const float keep = up ? v[i + N] : v[i];
+    v[i] = keep + __shfl_xor(send, O, 64);
+  }
+}
+__device__ __forceinline__ float reduce16_in_half(float (&v)[16], int lane) {
+  halve_step<8, 16>(v, lane);
+  halve_step<4, 8>(v, lane);
+  halve_step<2, 4>(v, lane);
+  halve_step<1, 2>(v, lane);
+  return v[0] + __shfl_xor(v[0], 1, 64);
+}
+// reduce8_in_wave: 8 values across the 64 lanes of a wave; lane 8k ends with the total of value index k.
+__device__ __forceinline__ float reduce8_in_wave(float (&v)[8], int lane) {
+  halve_step<4, 32>(v, lane);
+  halve_step<2, 16>(v, lane);
+  halve_step<1, 8>(v, lane);
+  float t = v[0];
+  t += __shfl_xor(t, 4, 64);
+  t += __shfl_xor(t, 2, 64);
+  t += __shfl_xor(t, 1, 64);
+  return t;
+}
+
+// LDS ring pipeline shared by K2 / K3: chunk c is multiplied out of stage c%3 in two halves of Q k-steps;
+// the fragments of a half are requested one half ahead (also across the chunk barrier: stage (c+1)%3 has
+// been complete since barrier c-1), the next-but-one chunk goes from registers to LDS between the halves.
+template <int H, int TN, class ARow>
+struct RingMma {
+  static constexpr int Q = FB_K / 4;  // k-steps per half
+  float af[2][Q], bf[2][Q][TN];
+  // a_at(c, ks) -> the lane's A fragment of k-step ks of chunk c; Bs = stage base + lane column offset
+  __device__ __forceinline__ void rd(const ARow& a_at, const float* __restrict__ Bs, int c, int half, int lh) {
+#pragma unroll
+    for (int s = 0; s < Q; ++s) {
+      const int ks = half * Q + s;
+      af[half][s] = a_at(c, ks);
+#pragma unroll
+      for (int t = 0; t < TN; ++t) bf[half][s][t] = Bs[(2 * ks + lh) * H + t * 32];
+    }
+  }
+  __device__ __forceinline__ void mma(f32x16 (&acc)[TN], int half) {
+#pragma unroll
+    for (int s = 0; s < Q; ++s)
+#pragma unroll
+      for (int t = 0; t < TN; ++t)
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[half][s], bf[half][s][t], acc[t], 0, 0, 0);
+  }
+};
+
 template <int H>
 __global__ __launch_bounds__(FB_NT) void disc_fwd_kernel(FusedArgs a) {
   constexpr int TN = H / 128;          // 32-column MFMA tiles per wave
@@ -85,13 +147,14 @@ __global__ __launch_bounds__(FB_NT) void disc_fwd_kernel(FusedArgs a) {
   constexpr int BV = BST / 4 / FB_NT;  // float4 per thread per B chunk
   static_assert(BST % (4 * FB_NT) == 0, "B chunk must divide among the threads");
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* xs = smem;                    // [64][XP]
-  float* w1s = xs + FB_M * XP;         // [H][XP]
-  float* h1s = w1s + H * XP;           // [64][LDH]
-  float* bs = h1s + FB_M * LDH;        // 3 x [FB_K][H]
+  float* h1s = smem;                   // [64][LDH]
+  float* bs = h1s + FB_M * LDH;        // 3 x [FB_K][H]; stages 1, 2 hold the W1 image [H][XP] during layer 1
   float* red = bs + 3 * BST;           // [4][64] logit partials per column group
   float* dls = red + 4 * FB_M;         // [64] dlogit of the tile's rows
   float* w3red = dls + FB_M;           // [2][H] dW3 partials per row group
+  float* xs = w3red + 2 * H;           // [64][XP]
+  float* w1s = bs + BST;
+  static_assert(H * XP <= 2 * BST, "W1 image must fit into ring stages 1 and 2");
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, lh = lane >> 5;
@@ -104,7 +167,7 @@ __global__ __launch_bounds__(FB_NT) void disc_fwd_kernel(FusedArgs a) {
   const float* w3 = b2 + H;
   const float* b3 = w3 + H;
 
-  // ---- prologue: everything this tile needs first is requested up front (clamped, unconditional loads)
+  // ---- prologue: every first-use operand is requested up front (coalesced 16-byte copies)
   FUSED_STAMP(a, 0);
   f4 rb[BV];
   auto bload = [&](int c) {
@@ -117,11 +180,12 @@ __global__ __launch_bounds__(FB_NT) void disc_fwd_kernel(FusedArgs a) {
 #pragma unroll
     for (int i = 0; i < BV; ++i) *reinterpret_cast<f4*>(S + (tid + i * FB_NT) * 4) = rb[i];
   };
-  constexpr int W1V = (H * 24 + FB_NT - 1) / FB_NT;
-  float w1v[W1V];
-  const int n_w1 = H * D;
+  constexpr int W1Q = H * XP / 4;                      // float4 of the W1 image
+  constexpr int W1V = (W1Q + FB_NT - 1) / FB_NT;
+  static_assert((H * XP) % 4 == 0, "W1 image is copied in 16-byte pieces");
+  f4 w1v[W1V];
 #pragma unroll
-  for (int i = 0; i < W1V; ++i) w1v[i] = W1[min(tid + i * FB_NT, n_w1 - 1)];
+  for (int i = 0; i < W1V; ++i) w1v[i] = reinterpret_cast<const f4*>(a.W1P)[min(tid + i * FB_NT, W1Q - 1)];
   float b1v[TN], b2v[TN], w3v[TN];
 #pragma unroll
   for (int t = 0; t < TN; ++t) {
@@ -136,19 +200,9 @@ __global__ __launch_bounds__(FB_NT) void disc_fwd_kernel(FusedArgs a) {
     xs[row * XP + a.ldx + e - row * w] = 0.f;
   }
   bload(0);
-  // W1 -> LDS as the NT B operand [n][XP]; k in [D, 24) zero
 #pragma unroll
-  for (int i = 0; i < W1V; ++i) {
-    const int e = tid + i * FB_NT;
-    if (e < n_w1) {
-      const int n = e / D, k = e - n * D;
-      w1s[n * XP + k] = w1v[i];
-    }
-  }
-  for (int e = tid; e < H * (24 - D); e += FB_NT) {
-    const int n = e / (24 - D), k = D + e - n * (24 - D);
-    w1s[n * XP + k] = 0.f;
-  }
+  for (int i = 0; i < W1V; ++i)
+    if (tid + i * FB_NT < W1Q) reinterpret_cast<f4*>(w1s)[tid + i * FB_NT] = w1v[i];
   bstore(0);
   bload(1);
   __syncthreads();
@@ -174,8 +228,6 @@ __global__ __launch_bounds__(FB_NT) void disc_fwd_kernel(FusedArgs a) {
       for (int t = 0; t < TN; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[ks], bf[ks][t], acc[t], 0, 0, 0);
   }
   FUSED_STAMP(a, 2);
-  bstore(1);
-  bload(2);
 #pragma unroll
   for (int t = 0; t < TN; ++t) {
     const int col = wn * WC + t * 32 + li;
@@ -184,48 +236,56 @@ __global__ __launch_bounds__(FB_NT) void disc_fwd_kernel(FusedArgs a) {
       const int row = wm * 32 + 4 * lh + rowoff(r);
       const float v = fmaxf(acc[t][r] + b1v[t], 0.f);
       h1s[row * LDH + col] = v;
-      if (row0 + row < a.R) a.h1[(long long)(row0 + row) * H + col] = v;
+      // relu'(h1) for the backward tile kernel: one 64-bit ballot per accumulator register instead of a
+      // 64 KB re-read of the tile
+      const unsigned long long m = __ballot(v > 0.f);
+      if (lane == 0) a.h1mask[((long long)blockIdx.x * 8 + wave) * (TN * 16) + t * 16 + r] = m;
       acc[t][r] = 0.f;
     }
   }
+  __syncthreads();   // every wave is done with the W1 image: stages 1, 2 are the ring's from here on
+  bstore(1);
+  bload(2);
   __syncthreads();
   FUSED_STAMP(a, 3);
 
   // ---- layer 2: h2 = relu(h1 . W2^T + b2): A = the LDS tile, B = W2T chunks through a 3-stage ring.
-  // At the top of iteration c: stage c%3 and (c+1)%3 are complete (barriers c-2, c-1), the registers hold
+  // At the top of iteration c: stages c%3 and (c+1)%3 are complete (barriers c-2, c-1), the registers hold
   // chunk c+2, which goes to stage (c+2)%3 == (c-1)%3 -- last read in iteration c-1, before barrier c-1.
-  auto compute = [&](int c) {
-    const float* Bs = bs + (c % 3) * BST;
-    const float* Ar = h1s + (wm * 32 + li) * LDH + c * FB_K + lh;
-    constexpr int Q = 4;
-    float af[2][Q], bf[2][Q][TN];
-    auto rd = [&](int q) {
+  {
+    const float* Ar = h1s + (wm * 32 + li) * LDH + lh;
+    auto a_at = [&](int c, int ks) { return Ar[c * FB_K + 2 * ks]; };
+    RingMma<H, TN, decltype(a_at)> pipe;
+    const int boff = wn * WC + li;
+    pipe.rd(a_at, bs + boff, 0, 0, lh);
+    // the tile's h1 goes out to HBM (for the weight gradients) in 16 slices, one per chunk, read back from
+    // LDS row-major: 256-byte coalesced stores trickling beside the MFMAs instead of one 16.8 MB burst of
+    // all workgroups at once
+    constexpr int HQ = FB_M * H / NCH / 4;   // 16-byte pieces per chunk (256: the first four waves store one each)
+    static_assert(HQ <= FB_NT, "one 16-byte piece per thread and chunk at most");
 #pragma unroll
-      for (int s = 0; s < Q; ++s) {
-        const int ks = q * Q + s;
-        af[q & 1][s] = Ar[2 * ks];
-#pragma unroll
-        for (int t = 0; t < TN; ++t) bf[q & 1][s][t] = Bs[(2 * ks + lh) * H + wn * WC + t * 32 + li];
+    for (int c = 0; c < NCH; ++c) {
+      const float* Bs = bs + (c % 3) * BST + boff;
+      pipe.rd(a_at, Bs, c, 1, lh);
+      f4 hv;
+      const int e4 = c * HQ + min(tid, HQ - 1);
+      const int hrow = e4 / (H / 4), hcol = (e4 % (H / 4)) * 4;
+      {
+        const float* hp = h1s + hrow * LDH + hcol;
+        hv.x = hp[0]; hv.y = hp[1]; hv.z = hp[2]; hv.w = hp[3];
       }
-    };
-    rd(0);
-#pragma unroll
-    for (int q = 0; q < FB_K / 2 / Q; ++q) {
-      if (q + 1 < FB_K / 2 / Q) rd(q + 1);
       __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int s = 0; s < Q; ++s)
-#pragma unroll
-        for (int t = 0; t < TN; ++t)
-          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[q & 1][s], bf[q & 1][s][t], acc[t], 0, 0, 0);
+      pipe.mma(acc, 0);
       __builtin_amdgcn_sched_barrier(0);
+      if (tid < HQ && row0 + hrow < a.R) *reinterpret_cast<f4*>(a.h1 + (long long)(row0 + hrow) * H + hcol) = hv;
+      if (c + 2 < NCH) bstore(c + 2);
+      if (c + 3 < NCH) bload(c + 3);
+      __builtin_amdgcn_sched_barrier(0);
+      pipe.mma(acc, 1);
+      __builtin_amdgcn_sched_barrier(0);
+      if (c + 1 < NCH) pipe.rd(a_at, bs + ((c + 1) % 3) * BST + boff, c + 1, 0, lh);
+      __syncthreads();
     }
-  };
-  for (int c = 0; c < NCH; ++c) {
-    compute(c);
-    if (c + 2 < NCH) bstore(c + 2);
-    if (c + 3 < NCH) bload(c + 3);
-    __syncthreads();
   }
   FUSED_STAMP(a, 4);
 
@@ -242,13 +302,10 @@ __global__ __launch_bounds__(FB_NT) void disc_fwd_kernel(FusedArgs a) {
     }
     p[r] = s;
   }
-#pragma unroll
-  for (int o = 16; o > 0; o >>= 1)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) p[r] += __shfl_xor(p[r], o, 64);
-  if (li == 0) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) red[wn * FB_M + wm * 32 + 4 * lh + rowoff(r)] = p[r];
+  {
+    const float tot = reduce16_in_half(p, lane);
+    const int r = ((lane >> 4) & 1) * 8 + ((lane >> 3) & 1) * 4 + ((lane >> 2) & 1) * 2 + ((lane >> 1) & 1);
+    if ((lane & 1) == 0) red[wn * FB_M + wm * 32 + 4 * lh + rowoff(r)] = tot;
   }
   __syncthreads();
   FUSED_STAMP(a, 5);
@@ -269,7 +326,7 @@ __global__ __launch_bounds__(FB_NT) void disc_fwd_kernel(FusedArgs a) {
     }
     const bool is_gen_pred = x < 0.f, is_gen_true = y == 0.f;
     const bool ok = is_gen_pred == is_gen_true;
-    float vals[7];
+    float vals[8];
     vals[0] = valid ? (1.f - y) * x - (fminf(x, 0.f) - lse) : 0.f;
     vals[1] = (valid && ok) ? 1.f : 0.f;
     vals[2] = (valid && ok && !is_gen_true) ? 1.f : 0.f;
@@ -277,16 +334,12 @@ __global__ __launch_bounds__(FB_NT) void disc_fwd_kernel(FusedArgs a) {
     vals[4] = (valid && is_gen_pred) ? 1.f : 0.f;
     vals[5] = valid ? (1.f - pr) * x - (fminf(x, 0.f) - lse) : 0.f;
     vals[6] = dl;  // db3 partial
-#pragma unroll
-    for (int k = 0; k < 7; ++k) {
-      float v = vals[k];
-      for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
-      vals[k] = v;
-    }
-    if (tid == 0) {
-#pragma unroll
-      for (int k = 0; k < 6; ++k) a.part[(long long)blockIdx.x * 8 + k] = vals[k];
-      a.P3[(long long)blockIdx.x * (H + 1) + H] = vals[6];
+    vals[7] = 0.f;
+    const float tot = reduce8_in_wave(vals, lane);
+    const int k = lane >> 3;
+    if ((lane & 7) == 0) {
+      if (k < 6) a.part[(long long)blockIdx.x * 8 + k] = tot;
+      else if (k == 6) a.P3[(long long)blockIdx.x * (H + 1) + H] = tot;
     }
   }
   __syncthreads();
@@ -302,13 +355,23 @@ __global__ __launch_bounds__(FB_NT) void disc_fwd_kernel(FusedArgs a) {
     for (int r = 0; r < 16; ++r) {
       const int row = wm * 32 + 4 * lh + rowoff(r);
       s += dlr[r] * h2[t][r];
-      if (row0 + row < a.R) a.dh2[(long long)(row0 + row) * H + col] = h2[t][r] > 0.f ? dlr[r] * w3v[t] : 0.f;
+      h1s[row * LDH + col] = h2[t][r] > 0.f ? dlr[r] * w3v[t] : 0.f;   // dh2 (the h1 tile is dead by now)
     }
     s += __shfl_xor(s, 32, 64);
     if (lh == 0) w3red[wm * H + col] = s;
   }
   __syncthreads();
   if (tid < H) a.P3[(long long)blockIdx.x * (H + 1) + tid] = w3red[tid] + w3red[H + tid];
+  // dh2 tile -> HBM row-major in 16-byte stores (a dword-per-lane epilogue is store-issue bound)
+#pragma unroll
+  for (int i = 0; i < FB_M * H / 4 / FB_NT; ++i) {
+    const int e4 = tid + i * FB_NT;
+    const int row = e4 / (H / 4), c4 = (e4 % (H / 4)) * 4;
+    const float* hp = h1s + row * LDH + c4;
+    f4 v;
+    v.x = hp[0]; v.y = hp[1]; v.z = hp[2]; v.w = hp[3];
+    if (row0 + row < a.R) *reinterpret_cast<f4*>(a.dh2 + (long long)(row0 + row) * H + c4) = v;
+  }
   FUSED_STAMP(a, 7);
 }
 
@@ -323,7 +386,7 @@ __global__ __launch_bounds__(FB_NT) void disc_bwd_kernel(FusedArgs a) {
   constexpr int BV = BST / 4 / FB_NT;
   constexpr int AST = FB_M * A_LD;
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* xs = smem;                    // [64][XP3]
+  float* xs = smem;                    // [64][XP3]: xn | 1 | 0 ... (the ones column makes db1 a column of dW1)
   float* d1s = xs + FB_M * XP3;        // [64][LDH]  dh1 tile
   float* bs = d1s + FB_M * LDH;        // 3 x [FB_K][H]   W2 chunks (k = out unit, n = in unit)
   float* as = bs + 3 * BST;            // 3 x [64][A_LD]  dh2 chunks
@@ -357,6 +420,11 @@ __global__ __launch_bounds__(FB_NT) void disc_bwd_kernel(FusedArgs a) {
     }
   };
   gload(0);
+  f4 rb1[BV], ra1;   // chunk 1 requested right behind chunk 0 (one cold round trip, not two)
+#pragma unroll
+  for (int i = 0; i < BV; ++i)
+    rb1[i] = *reinterpret_cast<const f4*>(W2 + (long long)BST + (long long)(tid + i * FB_NT) * 4);
+  if (a_thread) ra1 = *reinterpret_cast<const f4*>(abase + FB_K);
   load_x_tile(a, row0, xs, XP3, tid);
   for (int e = tid; e < FB_M * (XP3 - 1 - a.ldx); e += FB_NT) {  // columns [ldx, 32) of the B operand
     const int w = XP3 - 1 - a.ldx;
@@ -364,10 +432,13 @@ __global__ __launch_bounds__(FB_NT) void disc_bwd_kernel(FusedArgs a) {
     xs[row * XP3 + c] = 0.f;
   }
   lstore(0);
-  gload(1);
+#pragma unroll
+  for (int i = 0; i < BV; ++i) rb[i] = rb1[i];
+  ra = ra1;
   lstore(1);
   gload(2);
   __syncthreads();
+  if (tid < FB_M) xs[tid * XP3 + D] = 1.f;  // after the tile writes above (column D < 32 is a zero column there)
   FUSED_STAMP(a, 9);
 
   f32x16 acc[TN];
@@ -375,61 +446,48 @@ __global__ __launch_bounds__(FB_NT) void disc_bwd_kernel(FusedArgs a) {
   for (int t = 0; t < TN; ++t)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-  auto compute = [&](int c) {
-    const float* Bs = bs + (c % 3) * BST;
-    const float* Ar = as + (c % 3) * AST + (wm * 32 + li) * A_LD + lh;
-    constexpr int Q = 4;
-    float af[2][Q], bf[2][Q][TN];
-    auto rd = [&](int q) {
+  // relu'(h1) of the tile: the forward kernel's ballots, same (wave, tile, register) decomposition
+  unsigned long long hm[TN][16];
+  {
+    const unsigned long long* mp = a.h1mask + ((long long)blockIdx.x * 8 + __builtin_amdgcn_readfirstlane(wave)) * (TN * 16);
 #pragma unroll
-      for (int s = 0; s < Q; ++s) {
-        const int ks = q * Q + s;
-        af[q & 1][s] = Ar[2 * ks];
+    for (int t = 0; t < TN; ++t)
 #pragma unroll
-        for (int t = 0; t < TN; ++t) bf[q & 1][s][t] = Bs[(2 * ks + lh) * H + wn * WC + t * 32 + li];
-      }
-    };
-    rd(0);
+      for (int r = 0; r < 16; ++r) hm[t][r] = mp[t * 16 + r];
+  }
+  {
+    const float* Ab = as + (wm * 32 + li) * A_LD + lh;
+    auto a_at = [&](int c, int ks) { return Ab[(c % 3) * AST + 2 * ks]; };
+    RingMma<H, TN, decltype(a_at)> pipe;
+    const int boff = wn * WC + li;
+    pipe.rd(a_at, bs + boff, 0, 0, lh);
 #pragma unroll
-    for (int q = 0; q < FB_K / 2 / Q; ++q) {
-      if (q + 1 < FB_K / 2 / Q) rd(q + 1);
+    for (int c = 0; c < NCH; ++c) {
+      const float* Bs = bs + (c % 3) * BST + boff;
+      pipe.rd(a_at, Bs, c, 1, lh);
       __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int s = 0; s < Q; ++s)
-#pragma unroll
-        for (int t = 0; t < TN; ++t)
-          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[q & 1][s], bf[q & 1][s][t], acc[t], 0, 0, 0);
+      pipe.mma(acc, 0);
       __builtin_amdgcn_sched_barrier(0);
+      if (c + 2 < NCH) lstore(c + 2);
+      if (c + 3 < NCH) gload(c + 3);
+      __builtin_amdgcn_sched_barrier(0);
+      pipe.mma(acc, 1);
+      __builtin_amdgcn_sched_barrier(0);
+      if (c + 1 < NCH) pipe.rd(a_at, bs + ((c + 1) % 3) * BST + boff, c + 1, 0, lh);
+      __syncthreads();
     }
-  };
-  // the tile's own h1 values (relu mask), requested before the last chunks so they land behind the MFMAs
-  float pv[TN][16];
-  for (int c = 0; c < NCH; ++c) {
-    if (c == NCH - 2) {
-#pragma unroll
-      for (int t = 0; t < TN; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = min(row0 + wm * 32 + 4 * lh + rowoff(r), a.R - 1);
-          pv[t][r] = a.h1[(long long)row * H + wn * WC + t * 32 + li];
-        }
-    }
-    compute(c);
-    if (c + 2 < NCH) lstore(c + 2);
-    if (c + 3 < NCH) gload(c + 3);
-    __syncthreads();
   }
   FUSED_STAMP(a, 10);
 #pragma unroll
   for (int t = 0; t < TN; ++t)
 #pragma unroll
     for (int r = 0; r < 16; ++r)
-      d1s[(wm * 32 + 4 * lh + rowoff(r)) * LDH + wn * WC + t * 32 + li] = pv[t][r] > 0.f ? acc[t][r] : 0.f;
+      d1s[(wm * 32 + 4 * lh + rowoff(r)) * LDH + wn * WC + t * 32 + li] = ((hm[t][r] >> lane) & 1ull) ? acc[t][r] : 0.f;
   __syncthreads();
   FUSED_STAMP(a, 11);
 
-  // ---- dW1 partial [H, D] = dh1^T . xn over the tile's 64 rows (wave w owns hidden units 32w..32w+31);
-  //      db1 partial = column sums of dh1
+  // ---- [dW1 | db1] partial [H, D + 1] = dh1^T . [xn | 1] over the tile's 64 rows (wave w owns hidden
+  //      units 32w..32w+31)
   const long long n1 = (long long)H * D + H;
   float* P1 = a.P1 + (long long)blockIdx.x * n1;
   if (wave < H / 32) {
@@ -455,17 +513,13 @@ __global__ __launch_bounds__(FB_NT) void disc_bwd_kernel(FusedArgs a) {
       for (int s = 0; s < Q; ++s) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(af[q & 1][s], bf[q & 1][s], acc1, 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
     }
-    if (li < D) {
+    if (li <= D) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) P1[(long long)(wave * 32 + 4 * lh + rowoff(r)) * D + li] = acc1[r];
+      for (int r = 0; r < 16; ++r) {
+        const int i = wave * 32 + 4 * lh + rowoff(r);
+        P1[li < D ? (long long)i * D + li : (long long)H * D + i] = acc1[r];
+      }
     }
-  }
-  if (tid >= FB_NT - H) {  // the last H threads: bias gradient (the first waves are busy with the MFMAs)
-    const int c = tid - (FB_NT - H);
-    float s = 0.f;
-#pragma unroll 8
-    for (int row = 0; row < FB_M; ++row) s += d1s[row * LDH + c];
-    P1[(long long)H * D + c] = s;
   }
   FUSED_STAMP(a, 12);
 }
@@ -481,7 +535,8 @@ struct AssembleArgs {
   float* mean; float* var; int32_t* count;
   float* pmean; float* pvar; int32_t* pcount; int pdim;   // second norm over the first pdim columns
   unsigned int* ticket;
-  const float* W2; float* W2T; int H;    // transposer blocks (blockIdx >= slabs); W2T == nullptr: none
+  const float* W2; float* W2T; int H;    // transposer blocks (blockIdx >= slabs)
+  const float* W1; float* W1P;           // last block: W1 [H][D] -> [H][XP], zero padded
 };
 
 constexpr int AS_NT = 1024;
@@ -492,6 +547,13 @@ __global__ __launch_bounds__(AS_NT) void disc_assemble_kernel(AssembleArgs a) {
   __shared__ int s_last;
   const int tid = threadIdx.x;
   const int slabs = (a.R + RN_ROWS_PER_BLOCK - 1) / RN_ROWS_PER_BLOCK;
+  if (blockIdx.x == gridDim.x - 1) {
+    for (int e = tid; e < a.H * XP; e += AS_NT) {
+      const int n = e / XP, k = e - n * XP;
+      a.W1P[e] = k < a.D ? a.W1[n * a.D + k] : 0.f;
+    }
+    return;
+  }
   if ((int)blockIdx.x >= slabs) {
     // ---- W2 [H][H] -> W2T, one 64x64 tile per block through LDS (stride 65)
     float* tt = xt;  // 64*65 = 4160 floats <= 6144
@@ -736,7 +798,7 @@ inline bool fused_shape_ok(const ia_mlp_desc* d, int ldx) {
   return D >= 1 && D <= 24 && ldx >= D && ldx <= 24 && ldx % 4 == 0;
 }
 
-struct FusedWs { float* P1; float* P3; float* part; float* W2T; unsigned int* ticket; long long total; };
+struct FusedWs { float* P1; float* P3; float* part; float* W2T; float* W1P; unsigned long long* h1mask; unsigned int* ticket; long long total; };
 
 inline FusedWs fused_ws_layout(const ia_mlp_desc* d, int R, float* base) {
   const long long D = d->dims[0], H = d->dims[1];
@@ -748,6 +810,8 @@ inline FusedWs fused_ws_layout(const ia_mlp_desc* d, int R, float* base) {
   w.part = base + o; o += tiles * 8;
   o = (o + 3) / 4 * 4;                     // 16-byte aligned W2T rows
   w.W2T = base + o; o += H * H;
+  w.W1P = base + o; o += H * XP;
+  w.h1mask = reinterpret_cast<unsigned long long*>(base + o); o += tiles * 8 * (H / 128) * 16 * 2;
   w.ticket = reinterpret_cast<unsigned int*>(base + o); o += 4;
   w.total = o;
   return w;
@@ -755,7 +819,7 @@ inline FusedWs fused_ws_layout(const ia_mlp_desc* d, int R, float* base) {
 
 template <int H>
 int launch_fused_tiles(const FusedArgs& fa, int tiles, hipStream_t stream) {
-  constexpr size_t smem_f = sizeof(float) * (FB_M * XP + H * XP + FB_M * (H + 1) + 3 * FB_K * H + 4 * FB_M + FB_M + 2 * H);
+  constexpr size_t smem_f = sizeof(float) * (FB_M * (H + 1) + 3 * FB_K * H + 4 * FB_M + FB_M + 2 * H + FB_M * XP);
   constexpr size_t smem_b = sizeof(float) * (FB_M * XP3 + FB_M * (H + 1) + 3 * FB_K * H + 3 * FB_M * A_LD);
   static bool attr_set = false;
   if (!attr_set) {
@@ -815,14 +879,16 @@ int ia_disc_step_fused(const ia_disc_step_args* a, void* stream_) {
   as.pdim = use_p ? a->pnorm_dim : 0;
   as.ticket = w.ticket;
   as.W2 = a->params + n1; as.W2T = w.W2T; as.H = H;
-  hipLaunchKernelGGL(disc_assemble_kernel, dim3(slabs + (H / 64) * (H / 64)), dim3(AS_NT), 0, stream, as);
+  as.W1 = a->params; as.W1P = w.W1P;
+  hipLaunchKernelGGL(disc_assemble_kernel, dim3(slabs + (H / 64) * (H / 64) + 1), dim3(AS_NT), 0, stream, as);
   IA_CHECK_LAUNCH();
 
   FusedArgs fa{};
   fa.X = a->X; fa.ldx = a->ldx; fa.R = R; fa.D = D;
   fa.mean = a->norm_mean; fa.var = a->norm_var; fa.eps = a->norm_eps;
-  fa.params = a->params; fa.W2T = w.W2T;
+  fa.params = a->params; fa.W2T = w.W2T; fa.W1P = w.W1P;
   fa.h1 = a->hidden; fa.dh2 = a->hidden + (long long)R * H;
+  fa.h1mask = w.h1mask;
   fa.logits = a->logits; fa.dlogits = a->dlogits; fa.n_expert = a->n_expert; fa.loss_scale = a->loss_scale;
   fa.part = w.part; fa.P1 = w.P1; fa.P3 = w.P3;
   fa.dbg = g_fused_dbg;
