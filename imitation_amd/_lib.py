@@ -92,6 +92,7 @@ _SIGS = {
     "ia_policy_transpose": ([C.POINTER(PolicyDesc), _P, _P, _P], C.c_int),
     "ia_policy_act": ([C.POINTER(PolicyDesc), _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P], C.c_int),
     "ia_policy_evaluate": ([C.POINTER(PolicyDesc), _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P], C.c_int),
+    "ia_policy_logits": ([C.POINTER(PolicyDesc), _P, _P, _P, _P, _P, _I, _P, _P, _P], C.c_int),
     "ia_gae": ([_P, _P, _P, _P, _P, _I, _I, _F, _F, _P, _P, _P], C.c_int),
     "ia_timeout_bootstrap": ([_P, _P, _P, _F, _L, _P], C.c_int),
     "ia_ppo_ws_floats": ([C.POINTER(PolicyDesc), _I, _L], C.c_int64),

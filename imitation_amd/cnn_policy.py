@@ -266,18 +266,16 @@ class ActorCriticCnnPolicy:
 
     # ---- acting --------------------------------------------------------------------------------------------
     def predict(self, observation, state=None, episode_start=None, deterministic: bool = False):
-        """[SB3 BasePolicy.predict]. The mode is the first argmax; sampling is inverse-CDF on one host U(0,1) per
-        row (same distribution as `Categorical.sample`, different stream -- as for the MLP policies)."""
+        """[SB3 BasePolicy.predict]. The mode is the first argmax; sampling is [SB3 CategoricalDistribution.sample]
+        itself on the host (`torch.distributions.Categorical(logits).sample()`: torch.multinomial on the global
+        generator, the reference's stream -- as for the MLP policies)."""
         obs = np.asarray(observation)
         vectorized = obs.shape != tuple(self.observation_space.shape)
         d = self._forward(self._obs_u8(obs))
-        logits = d["logits"].cpu().numpy().astype(np.float64)
+        logits = d["logits"].float().cpu()
         if deterministic:
-            acts = logits.argmax(axis=1)
+            acts = logits.numpy().argmax(axis=1)
         else:
-            p = np.exp(logits - logits.max(axis=1, keepdims=True))
-            cdf = np.cumsum(p / p.sum(axis=1, keepdims=True), axis=1)
-            u = th.rand(len(logits)).numpy().astype(np.float64)[:, None]
-            acts = np.minimum((u >= cdf).sum(axis=1), self.n_actions - 1)
+            acts = th.distributions.Categorical(logits=logits).sample().numpy()
         acts = acts.astype(np.int64)
         return (acts if vectorized else acts[0]), state

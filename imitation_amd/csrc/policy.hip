@@ -259,6 +259,39 @@ __global__ __launch_bounds__(ROWS) void policy_eval_kernel(ia_policy_desc d, con
   }
 }
 
+// Raw head outputs: action_net(latent_pi) (Categorical logits / Gaussian means) and the value head, for
+// callers that sample on the host with the reference's own RNG call ([SB3 CategoricalDistribution.sample] =
+// torch.multinomial on torch's global CPU generator). Thread per row.
+template <int H>
+__global__ __launch_bounds__(ROWS) void policy_logits_kernel(ia_policy_desc d, const float* __restrict__ P,
+                                                             const float* __restrict__ Pt, const float* __restrict__ nm,
+                                                             const float* __restrict__ nv, const float* __restrict__ obs,
+                                                             int n, float* __restrict__ logits,
+                                                             float* __restrict__ values) {
+  using L = Lds<H>;
+  extern __shared__ float lds[];
+  const int tid = threadIdx.x, row = blockIdx.x * ROWS + tid;
+  const bool valid = row < n;
+  const int D = d.obs_dim, A = d.act_dim;
+  const PolOff o = pol_offsets(D, A, H, d.discrete);
+  float* xrow = lds + L::x + tid * L::XS;
+  float* a1row = lds + L::a1 + tid * L::HS;
+  float* outrow = lds + L::out + tid * L::AS;
+  load_features(d, obs + (long long)(valid ? row : 0) * D, nm, nv, valid, xrow);
+  float a2[H];
+  tower_forward<H>(Pt + o.pW1, P + o.pb1, Pt + o.pW2, P + o.pb2, D, xrow, a1row, nullptr, a2);
+  head_forward<H>(P + o.aW, P + o.ab, A, a2, outrow);
+  if (valid)
+    for (int a = 0; a < A; ++a) logits[(long long)row * A + a] = outrow[a];
+  if (values) {
+    tower_forward<H>(Pt + o.vW1, P + o.vb1, Pt + o.vW2, P + o.vb2, D, xrow, a1row, nullptr, a2);
+    float v = P[o.cb];
+#pragma unroll
+    for (int k = 0; k < H; ++k) v = fmaf(P[o.cW + k], a2[k], v);
+    if (valid) values[row] = v;
+  }
+}
+
 __global__ void transpose_params_kernel(ia_policy_desc d, const float* __restrict__ P, float* __restrict__ Pt) {
   const int H = d.hidden, D = d.obs_dim;
   const PolOff o = pol_offsets(D, d.act_dim, H, d.discrete);
@@ -2731,6 +2764,23 @@ int ia_policy_evaluate(const ia_policy_desc* d, const float* params, const float
     hipLaunchKernelGGL(policy_eval_kernel<64>, dim3(cdiv(n, ROWS)), dim3(ROWS), lds_bytes<64>(),
                        (hipStream_t)stream, *d, params, params_t, norm_mean, norm_var, obs, actions, n, logp, values,
                        entropy);
+  }
+  IA_CHECK_LAUNCH();
+  return IA_OK;
+}
+
+int ia_policy_logits(const ia_policy_desc* d, const float* params, const float* params_t, const float* norm_mean,
+                     const float* norm_var, const float* obs, int n, float* logits, float* values, void* stream) {
+  if (!pol_ok(d) || n <= 0 || !logits) return IA_ERR_ARG;
+  int rc;
+  if (d->hidden == 32) {
+    if ((rc = set_lds(policy_logits_kernel<32>, lds_bytes<32>()))) return rc;
+    hipLaunchKernelGGL(policy_logits_kernel<32>, dim3(cdiv(n, ROWS)), dim3(ROWS), lds_bytes<32>(),
+                       (hipStream_t)stream, *d, params, params_t, norm_mean, norm_var, obs, n, logits, values);
+  } else {
+    if ((rc = set_lds(policy_logits_kernel<64>, lds_bytes<64>()))) return rc;
+    hipLaunchKernelGGL(policy_logits_kernel<64>, dim3(cdiv(n, ROWS)), dim3(ROWS), lds_bytes<64>(),
+                       (hipStream_t)stream, *d, params, params_t, norm_mean, norm_var, obs, n, logits, values);
   }
   IA_CHECK_LAUNCH();
   return IA_OK;

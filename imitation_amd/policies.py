@@ -70,6 +70,12 @@ class ActorCriticPolicy:
         self.optimizer_kwargs.setdefault("eps", 1e-5)  # SB3 ActorCriticPolicy default for Adam
         self.training = True
         self._squash_output = False
+        # Discrete heads: "multinomial" = [SB3 CategoricalDistribution.sample] itself on the host -- the head's
+        # logits come back from the device and `torch.distributions.Categorical(logits).sample()` consumes
+        # torch's global CPU generator exactly as the reference does (identical seeds => identical actions);
+        # "inverse_cdf" = one host U(0,1) per row, sampled inside the rollout kernel (same distribution,
+        # different stream, one launch + no logits round trip per step).
+        self.discrete_sampling = "multinomial"
 
         # Host construction in SB3's order so the torch global RNG is consumed identically:
         # pi tower, vf tower, action_net, log_std, value_net; then orthogonal re-initialisation.
@@ -244,6 +250,42 @@ class ActorCriticPolicy:
 
         return step
 
+    @property
+    def samples_on_host(self) -> bool:
+        """Discrete head sampled by torch.multinomial on the host (the reference's RNG stream)."""
+        return self.discrete and self.discrete_sampling == "multinomial"
+
+    def make_multinomial_step(self, obs_tile: th.Tensor, h_logits: th.Tensor, h_clip: th.Tensor, val: th.Tensor,
+                              h_logp: th.Tensor):
+        """Rollout-step launcher for Discrete heads on the reference's sampling stream: `step(t)` = one launch
+        (logits of the step's observations straight into pinned host memory + values), one wait, then
+        [SB3 CategoricalDistribution] `sample()` / `log_prob()` on the host exactly as the reference composes
+        them (`torch.distributions.Categorical(logits=...)`: `torch.multinomial` on the global generator).
+        Actions land in `h_clip[t]` (fp32 indices), log-probs in `h_logp[t]` (both pinned host tiles)."""
+        assert self.discrete and not (self.training and self.features_extractor.normalize is not None)
+        lib, desc = L.load(), C.byref(self.desc)
+        fn = lib.ia_policy_logits
+        n = obs_tile.shape[1]
+        nm, nv = self._norm_ptrs()
+        P, Pt = L.ptr(self._flat), L.ptr(self._flat_t)
+        b_obs, s_obs = obs_tile.data_ptr(), obs_tile.stride(0) * 4
+        b_val, s_val = val.data_ptr(), val.stride(0) * 4
+        lg = h_logits.data_ptr()
+        stream_obj = th.cuda.current_stream()
+        stream = stream_obj.cuda_stream
+
+        def step(t: int) -> None:
+            rc = fn(desc, P, Pt, nm, nv, b_obs + t * s_obs, n, lg, b_val + t * s_val, stream)
+            if rc != 0:
+                L.check(rc, "ia_policy_logits")
+            stream_obj.synchronize()
+            dist = th.distributions.Categorical(logits=h_logits)
+            a = dist.sample()
+            h_logp[t].copy_(dist.log_prob(a))
+            h_clip[t].copy_(a.reshape(n, 1))
+
+        return step
+
     def act(self, obs_dev: th.Tensor, noise_dev: th.Tensor, actions: th.Tensor, clipped: th.Tensor,
             values: th.Tensor, logp: th.Tensor) -> None:
         """Device-to-device rollout step (no allocation): fills actions/clipped/values/logp."""
@@ -258,6 +300,16 @@ class ActorCriticPolicy:
         require_device(self.device)
         o = self._obs_dev(obs)
         n = o.shape[0]
+        if self.samples_on_host and not deterministic:
+            self._maybe_update_norm(o)
+            nm, nv = self._norm_ptrs()
+            logits, vals = th.empty(n, self.act_dim, device=self.device), th.empty(n, device=self.device)
+            L.call("ia_policy_logits", C.byref(self.desc), L.ptr(self._flat), L.ptr(self._flat_t), nm, nv, L.ptr(o), n,
+                   L.ptr(logits), L.ptr(vals), L.stream())
+            dist = th.distributions.Categorical(logits=logits.cpu())
+            a = dist.sample()
+            return (a.to(self.device).reshape((n, *self.action_space.shape)), vals.reshape(n, 1),
+                    dist.log_prob(a).to(self.device))
         if deterministic:  # mode: zero Gaussian noise / negative uniform = argmax (no RNG draw, as in SB3)
             noise = th.full((n,), -1.0) if self.discrete else th.zeros(n, self.act_dim)
         else:

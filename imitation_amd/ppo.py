@@ -233,6 +233,12 @@ class RolloutBuffer:
         self.h_noise = pin(n, max(act_width, 1))
         self.full = False
 
+    def ensure_host_sampling_tiles(self, n_actions: int) -> None:
+        """Pinned tiles of the host-sampled Discrete rollout step (`ActorCriticPolicy.make_multinomial_step`)."""
+        if getattr(self, "h_logits", None) is None or self.h_logits.shape[1] != n_actions:
+            self.h_logits = th.zeros(self.n_envs, n_actions).pin_memory()
+            self.h_logp = th.zeros(self.buffer_size, self.n_envs).pin_memory()
+
     def upload_host_tiles(self) -> None:
         """One H2D copy of everything the env loop wrote on the host (current stream)."""
         self._dev_block.copy_(self._host_block, non_blocking=True)
@@ -510,12 +516,18 @@ class PPO(OnPolicyAlgorithm):
             self._act_stream = L.side_stream(self.device, "act", priority=-1)
         act_stream = self._act_stream
         act_stream.wait_stream(stream)     # parameters / statistics written by the previous update
+        host_sampling = pol.samples_on_host  # Discrete head on the reference's torch.multinomial stream
         with th.cuda.stream(act_stream):
-            act_step = pol.make_act_step(rb.h_obs, rb.h_noise, rb.acts, rb.h_clip, rb.val, rb.logp)  # eval mode: no norm update
+            if host_sampling:
+                rb.ensure_host_sampling_tiles(pol.act_dim)
+                act_step = pol.make_multinomial_step(rb.h_obs, rb.h_logits, rb.h_clip, rb.val, rb.h_logp)
+            else:
+                act_step = pol.make_act_step(rb.h_obs, rb.h_noise, rb.acts, rb.h_clip, rb.val, rb.logp)  # eval mode: no norm update
         h_clip_np = rb.h_clip.numpy()
         for t in range(T):
             t0 = tick() if prof is not None else 0.0
-            pol.draw_noise_into(rb.h_noise)
+            if not host_sampling:
+                pol.draw_noise_into(rb.h_noise)
             t1 = tick() if prof is not None else 0.0
             act_step(t)
             t2 = tick() if prof is not None else 0.0
@@ -562,6 +574,9 @@ class PPO(OnPolicyAlgorithm):
             self.tail_event.record()
         rb.h_last_done.copy_(th.as_tensor(starts.astype(np.float32)))
         rb.upload_host_tiles()
+        if host_sampling:  # actions (= the clipped tile for Discrete heads) and log-probs were produced on the host
+            rb.acts.copy_(rb.clipped)
+            rb.logp.copy_(rb.h_logp, non_blocking=True)
         # host time the device had to itself for other streams' work during this rollout (see
         # `AdversarialTrainer._train_pipelined`: where the discriminator updates are scheduled)
         self.rollout_window_ms = 1e3 * (tick() - t_first_step)

@@ -218,6 +218,13 @@ int ia_policy_evaluate(const ia_policy_desc* d, const float* params, const float
                        const float* norm_var, const float* obs, const float* actions, int n, float* logp,
                        float* values, float* entropy, void* stream);
 
+/* Head outputs only: logits[n, act_dim] = action_net(latent_pi) (Categorical logits / Gaussian means) and,
+ * when values != NULL, the value head. For host-side sampling with the reference's own RNG call:
+ * [SB3 CategoricalDistribution.sample] = torch.multinomial on torch's global CPU generator
+ * (adversarial/common.py:414-419 -> collect_rollouts). */
+int ia_policy_logits(const ia_policy_desc* d, const float* params, const float* params_t, const float* norm_mean,
+                     const float* norm_var, const float* obs, int n, float* logits, float* values, void* stream);
+
 /* [SB3 RolloutBuffer.compute_returns_and_advantage]: arrays are [T,n] fp32. */
 int ia_gae(const float* rewards, const float* values, const float* episode_starts, const float* last_values,
            const float* last_dones, int T, int n, float gamma, float gae_lambda, float* advantages,

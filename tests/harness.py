@@ -162,9 +162,11 @@ def snapshot(trainer) -> Dict[str, np.ndarray]:
 
 
 def run_case(impl: str, name: str, log_dir: str, device: str = "cpu", sync_disc: bool = False,
-             pipeline: bool = True) -> Dict[str, np.ndarray]:
+             pipeline: bool = True, discrete_sampling: str = None) -> Dict[str, np.ndarray]:
     cfg = CASES[name]
     trainer, venv = build_trainer(impl, cfg, log_dir, device)
+    if discrete_sampling is not None:  # product only: "inverse_cdf" = the in-kernel fast sampler
+        trainer.gen_algo.policy.discrete_sampling = discrete_sampling
     if hasattr(trainer, "pipeline_rounds"):
         trainer.pipeline_rounds = pipeline
     stats = []
@@ -224,6 +226,9 @@ ROLLOUT_CASES: Dict[str, Dict[str, Any]] = {
     # Discrete actions, deterministic (mode) prediction.
     "rollout_discrete_det": dict(kind="policy", n_envs=5, obs_dim=4, act_dim=2, horizon=6, n_discrete=3,
                                  min_timesteps=None, min_episodes=12, deterministic=True),
+    # Discrete actions SAMPLED ([SB3 CategoricalDistribution.sample] = torch.multinomial on the global generator).
+    "rollout_discrete_sto": dict(kind="policy", n_envs=6, obs_dim=5, act_dim=2, horizon=7, n_discrete=4,
+                                 min_timesteps=90, min_episodes=None, deterministic=False),
 }
 
 

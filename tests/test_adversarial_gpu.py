@@ -50,7 +50,7 @@ def _compare(got, gold, cfg, skip=()):
     return worst
 
 
-@pytest.mark.parametrize("case", ["gail_box", "gail_f64", "airl_box"])
+@pytest.mark.parametrize("case", ["gail_box", "gail_f64", "gail_discrete", "airl_box"])
 def test_hip_trainer_matches_reference_golden(case, tmp_path):
     cfg = harness.CASES[case]
     gold = dict(np.load(os.path.join(GOLDEN, f"{case}.npz")))
@@ -119,12 +119,14 @@ def test_pipelined_rounds_are_bit_identical(tmp_path, case):
     assert len(logs[True]["progress.csv"]) == 4
 
 
-def test_discrete_actions_structural(tmp_path):
-    """Categorical sampling uses inverse-CDF on a host U(0,1) draw (same distribution, different
-    stream than torch.multinomial), so trajectories are not comparable value-by-value; integer
-    bookkeeping, done layout and one-hot batch assembly still are."""
+def test_discrete_actions_fast_sampler_structural(tmp_path):
+    """Discrete heads default to the reference's own sampling call (torch.multinomial on the global
+    generator: `gail_discrete` is compared value by value above). The opt-in in-kernel sampler
+    (`policy.discrete_sampling = "inverse_cdf"`: one host U(0,1) per row, same distribution, different
+    stream) cannot be compared value by value; integer bookkeeping, done layout and one-hot batch
+    assembly still are."""
     gold = dict(np.load(os.path.join(GOLDEN, "gail_discrete.npz")))
-    got = harness.run_case("hip", "gail_discrete", str(tmp_path), device="cuda")
+    got = harness.run_case("hip", "gail_discrete", str(tmp_path), device="cuda", discrete_sampling="inverse_cdf")
     for key in harness.EXACT_KEYS:
         assert np.array_equal(got[key], gold[key]), key
     assert got["replay/acts"].dtype == gold["replay/acts"].dtype

@@ -76,16 +76,6 @@ def test_hip_bc_matches_reference_golden(case, tmp_path):
         assert x.shape == y.shape, k
         if y.dtype.kind in "biu" or k.endswith("count"):
             assert np.array_equal(x, y), k
-        elif harness.BC_CASES[case].get("image") and k.startswith("policy/"):
-            # Adam's first steps move a parameter by ~lr whatever the size of its gradient (m / sqrt(v) = +-1),
-            # so the handful of convolution weights whose gradient is at rounding level (pixels that barely
-            # matter) may go the other way: bound them by the total travel, hold all the others to the usual
-            # tolerance. The gradients themselves are checked to 2e-5 relative against torch autograd in
-            # test_kernels_gpu.py::test_cnn_policy_forward_and_gradient_match_torch.
-            close = np.isclose(x, y, rtol=2e-4, atol=5e-5)
-            assert close.mean() >= 0.97, (k, close.mean())
-            n_updates = len(gold["log_rows"]) * harness.BC_CASES[case]["log_interval"]
-            assert np.max(np.abs(x - y)) <= n_updates * 1e-3, k
         else:
             np.testing.assert_allclose(x, y, rtol=2e-4, atol=5e-5, err_msg=k)
             worst = max(worst, float(np.max(np.abs(x - y))) if x.size else 0.0)

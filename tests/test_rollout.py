@@ -143,7 +143,7 @@ def test_monitor_returns_are_reported_when_infos_carry_them():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("case", ["rollout_policy", "rollout_discrete_det"])
+@pytest.mark.parametrize("case", ["rollout_policy", "rollout_discrete_det", "rollout_discrete_sto"])
 def test_device_policy_rollout_matches_reference_golden(case):
     """`.predict()` through the HIP policy kernel (eval mode, RunningNorm statistics frozen):
     same episode structure and shuffle as the reference, observations / actions / rewards within
