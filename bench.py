@@ -12,11 +12,13 @@ FeedForward32Policy + NormalizeFeaturesExtractor, minibatch 1024, 10 epochs. Hos
 (NumPy) stay on the CPU. For N>1 it runs one rank per GPU (env-batch sharded: 1024 envs per
 rank, weak scaling) with RCCL gradient / moment all-reduces every optimiser step.
 
-Prints ONE JSON line (rank 0). Extra objects: `roofline` for the dominant kernel (the 128x128
-fp32-MFMA GEMM of the discriminator's 256x256 layer), measured with HIP events bracketing every
-launch on its stream during extra rounds right after the timed region; `cpu_baseline` = the
-oracle (CPU restatement of the reference round, torch CPU ops) timed on this box's host cores
-for one round of the same workload.
+Prints ONE JSON line (rank 0). Extra objects: `roofline` for the kernel with the largest share of GPU
+time (the persistent PPO update: a latency chain, so its figure of merit is us_per_step), with the whole
+discriminator update (`disc_update`, the throughput kernel family SURVEY 8d's roofline target is about)
+and the GEMM family (`gemm`) as siblings, all measured with HIP events on the launch streams right
+after the timed region; `variants` = SURVEY 8d's other configurations through the same trainer;
+`cpu_baseline` = the oracle (CPU restatement of the reference round, torch CPU ops) timed on this box's
+host cores for a few rounds of the same workload.
 """
 from __future__ import annotations
 
@@ -128,9 +130,61 @@ def cpu_baseline(cfg, host_threads):
                            "sample": f"{one[0]} round, {one[1]:.1f} s, torch threads=1"}}
 
 
+def _pmc_traffic():
+    pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        return json.load(open(pmc)) if os.path.exists(pmc) else {}
+    except Exception:
+        return {}
+
+
+def disc_update_timing(trainer, cfg):
+    """One round's worth of discriminator updates (n_disc x `ia_disc_step_basic`) ALONE on the stream, bracketed
+    by HIP events on that stream: the whole-update number SURVEY 8d's roofline target is about
+    (6.85 GFLOP per 16 384-row update against the fp32-MFMA peak; 3.6 MB algorithmic bytes against HBM)."""
+    from imitation_amd import networks
+    n = trainer.n_disc_updates_per_round
+    th.cuda.synchronize()
+    best = None
+    for _ in range(3):
+        # all host index draws (and their uploads) first, as the pipelined trainer does, so that the timed region
+        # holds nothing but the updates' own launches
+        trainer._use_ring, trainer._overlap_k = True, 0
+        try:
+            drawn = [trainer._batch_sources(None, None) for _ in range(n)]
+            th.cuda.synchronize()
+            e0, e1 = th.cuda.Event(enable_timing=True), th.cuda.Event(enable_timing=True)
+            e0.record()
+            for k in range(n):
+                with networks.training(trainer.reward_train):
+                    trainer._disc_update(None, None, trainer._stats_ring[k], drawn=drawn[k], quirk_done=True)
+            e1.record()
+        finally:
+            trainer._use_ring = False
+        th.cuda.synchronize()
+        us = 1e3 * e0.elapsed_time(e1) / n
+        best = us if best is None else min(best, us)
+    R = 2 * cfg["demo_batch"]
+    D, (H1, H2) = cfg["obs_dim"] + cfg["act_dim"], cfg["disc_hid"]
+    flop = R * (2.0 * (D * H1 + H1 * H2 + H2) * 2 + 2.0 * (H1 * H2 + H2))   # fwd + wgrad + dgrad (SURVEY 8d)
+    n_par = D * H1 + H1 + H1 * H2 + H2 + H2 + 1
+    alg_bytes = R * (D * 4 + 4) + 7 * 4 * n_par                            # rows in, logit out, parameter/Adam traffic
+    tf = flop / (best * 1e-6) / 1e12
+    return {"kernel": "discriminator update (ia_disc_step_basic: assemble+moments+merge | tile forward+BCE+head "
+                      "gradient | tile dgrad+first-layer wgrad | split-K wgrad | slab reduce+Adam+statistics)",
+            "bound": "mfma", "us": best, "launches_per_update": 5, "rows": R, "flop": flop,
+            "achieved": tf, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": tf / PEAK_F32_MFMA_TFLOPS,
+            "algorithmic_bytes": alg_bytes, "achieved_hbm_gbs": alg_bytes / (best * 1e-6) / 1e9,
+            "frac_hbm": alg_bytes / (best * 1e-6) / 8e12,
+            "traffic": _pmc_traffic().get("disc_update_fused"),
+            "note": "compute-bound (arithmetic intensity ~1900 flop/B fused): the fp32-MFMA fraction binds, the HBM "
+                    "fraction is reported for completeness; measured alone, best of 3 rounds of n_disc updates"}
+
+
 def gemm_roofline(trainer, cfg, rounds):
-    """Runs `rounds` more rounds with every GEMM launch bracketed by HIP events on its stream and
-    reports the kernel with the largest total time."""
+    """Runs `rounds` more rounds with every GEMM launch and the persistent PPO launch bracketed by HIP events on
+    their streams. The top-level record names the kernel with the LARGEST share of GPU time (the persistent PPO
+    update: a latency chain); the discriminator update as a whole and the GEMM family are siblings."""
     from imitation_amd import _lib as L
     lib = L.load()
     lib.ia_prof_enable(1)
@@ -155,15 +209,16 @@ def gemm_roofline(trainer, cfg, rounds):
             per.append(dict(kernel=f"ia_gemm_kernel {names[k // 4]} tile {tiles[k % 4]}", launches=int(cnt[k]),
                             avg_us=1e3 * ms[k] / cnt[k], tflops=fl[k] / (ms[k] * 1e-3) / 1e12, total_ms=ms[k]))
     per.sort(key=lambda d: -d["total_ms"])
-    top = per[0]
-    traffic = None
-    pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if os.path.exists(pmc):
-        try:
-            traffic = json.load(open(pmc)).get(top["kernel"])
-        except Exception:
-            traffic = None
-    all_ms, all_fl = sum(p["total_ms"] for p in per), sum(p["tflops"] * p["total_ms"] for p in per)
+    gemm = None
+    if per:
+        top = per[0]
+        all_ms, all_fl = sum(p["total_ms"] for p in per), sum(p["tflops"] * p["total_ms"] for p in per)
+        gemm = {"bound": "mfma", "kernel": top["kernel"], "achieved": top["tflops"], "peak": PEAK_F32_MFMA_TFLOPS,
+                "unit": "TFLOP/s", "frac": top["tflops"] / PEAK_F32_MFMA_TFLOPS, "avg_launch_us": top["avg_us"],
+                "launches": top["launches"], "traffic": _pmc_traffic().get(top["kernel"]),
+                "all_gemm_tflops": all_fl / all_ms if all_ms else None, "kernels": per[:6],
+                "note": "measured inside training rounds, i.e. BESIDE the persistent PPO kernel and the act kernels"}
+    disc = disc_update_timing(trainer, cfg)
     ppo = None
     if ppo_ms:
         # forward + backward of both 32x32 towers ~ 3 x 2 x (weights touched) flops per row and step
@@ -171,19 +226,81 @@ def gemm_roofline(trainer, cfg, rounds):
         per_row = 6.0 * ((D * H + H * H + H * A) + (D * H + H * H + H))
         steps = algo.n_epochs * algo._n_mb
         world = getattr(getattr(algo, "dp", None), "world", 1)   # the data-parallel update runs on the gathered tile
-        fl_ppo = per_row * world * min(algo.batch_size, cfg["n_envs"] * cfg["n_steps"]) * steps
+        rows = world * min(algo.batch_size, cfg["n_envs"] * cfg["n_steps"])
+        fl_ppo = per_row * rows * steps
         avg = sum(ppo_ms) / len(ppo_ms)
+        disc_ms_round = disc["us"] * 1e-3 * trainer.n_disc_updates_per_round
         ppo = {"kernel": "ppo_update_persistent_kernel (whole PPO.train, one launch)", "bound": "latency",
                "avg_launch_us": 1e3 * avg, "optimizer_steps_per_launch": steps, "us_per_step": 1e3 * avg / steps,
                "achieved": fl_ppo / (avg * 1e-3) / 1e12, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-               "frac": fl_ppo / (avg * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS,
-               "note": "largest single kernel by time; a chain of dependent 1024-row optimiser steps on "
-                       "nblk+1 = 17 workgroups (the reference's minibatch semantics), not a throughput kernel; "
-                       "97% of the round's flops are in the GEMM family reported under `roofline`"}
-    return {"bound": "mfma", "kernel": top["kernel"], "achieved": top["tflops"], "peak": PEAK_F32_MFMA_TFLOPS,
-            "unit": "TFLOP/s", "frac": top["tflops"] / PEAK_F32_MFMA_TFLOPS, "avg_launch_us": top["avg_us"],
-            "launches": top["launches"], "traffic": traffic,
-            "all_gemm_tflops": all_fl / all_ms if all_ms else None, "kernels": per[:6], "ppo_update": ppo}
+               "frac": fl_ppo / (avg * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+               "share_of_gpu_time": avg / (avg + disc_ms_round),
+               "algorithmic_bytes_per_launch": steps * rows * (D + A + 4) * 4.0,
+               "note": "largest kernel by GPU time: a chain of dependent 1024-row optimiser steps on nblk+3 workgroups "
+                       "(the reference's minibatch semantics), bound by per-step latency (grid barrier, slab reduce, "
+                       "Adam), not by MFMA or HBM throughput: read us_per_step, not frac. The throughput kernels are "
+                       "under `disc_update` (whole discriminator update) and `gemm`"}
+    top = dict(ppo) if ppo is not None else dict(disc)
+    top["disc_update"] = disc
+    top["gemm"] = gemm
+    top["ppo_update"] = ppo
+    return top
+
+
+# ---- the other BASELINE.json / SURVEY 8d configurations, driver-timed under `variants` -----------------
+VARIANTS = {
+    # name: (algo, n_envs, n_steps, obs, act, ppo_batch, n_epochs, demo_batch, n_disc, capacity, net kwargs, extras)
+    "H_horizon_1024x1000": ("gail", 1024, 1000, 17, 6, 1024, 2, 8192, 4, 16384, dict(hid_sizes=(256, 256)), {}),
+    "T_tuned_1024x4_mb64": ("gail", 1024, 4, 17, 6, 64, 5, 8192, 8, 512, dict(hid_sizes=(256, 256)),
+                            dict(gamma=0.95, clip_range=0.1)),
+    "3_airl_ant_1024x16": ("airl", 1024, 16, 27, 8, 1024, 10, 8192, 16, 16384,
+                           dict(reward_hid_sizes=(32,), potential_hid_sizes=(32, 32)), dict(normalize_output=True)),
+    "1_cartpole_8x256_mlp64": ("gail", 8, 256, 4, 2, 64, 5, 1024, 4, 2048, dict(hid_sizes=(32, 32)),
+                               dict(discrete=True, mlp64=True, gamma=0.95)),
+}
+
+
+def run_variant(name, rounds=4, warm=3):
+    import imitation_amd as p
+    from imitation_amd.vec_env import SyntheticVecEnv
+    algo_name, n_envs, n_steps, od, ad, ppo_batch, n_epochs, demo_batch, n_disc, capacity, net_kw, ex = VARIANTS[name]
+    discrete = ex.get("discrete", False)
+    th.manual_seed(0)
+    np.random.seed(0)
+    venv = SyntheticVecEnv(num_envs=n_envs, obs_dim=od, act_dim=ad, horizon=1000 if n_envs > 8 else 500, seed=0,
+                           n_discrete=ad if discrete else None)
+    pk = dict(features_extractor_class=p.NormalizeFeaturesExtractor,
+              features_extractor_kwargs=dict(normalize_class=p.RunningNorm))
+    policy = p.ActorCriticPolicy if ex.get("mlp64") else p.FeedForward32Policy   # SB3 MlpPolicy default = 64 x 64
+    algo = p.PPO(policy, venv, n_steps=n_steps, batch_size=ppo_batch, n_epochs=n_epochs, ent_coef=0.01,
+                 gamma=ex.get("gamma", 0.99), clip_range=ex.get("clip_range", 0.2), seed=0,
+                 policy_kwargs={} if ex.get("mlp64") else pk, device="cuda")
+    if algo_name == "gail":
+        net = p.BasicRewardNet(venv.observation_space, venv.action_space, normalize_input_layer=p.RunningNorm, **net_kw)
+        cls = p.GAIL
+    else:
+        net = p.BasicShapedRewardNet(venv.observation_space, venv.action_space, normalize_input_layer=p.RunningNorm, **net_kw)
+        if ex.get("normalize_output"):
+            net = p.NormalizedRewardNet(net, p.RunningNorm)
+        cls = p.AIRL
+    rng = np.random.default_rng(1)
+    n = max(4 * demo_batch, 20000)
+    obs = rng.standard_normal((n, od)).astype(np.float32)
+    acts = rng.integers(0, ad, n).astype(np.int64) if discrete else rng.uniform(-1, 1, (n, ad)).astype(np.float32)
+    demos = p.Transitions(obs=obs, acts=acts, next_obs=(0.9 * obs).astype(np.float32), dones=np.zeros(n, bool))
+    tr = cls(demonstrations=demos, demo_batch_size=demo_batch, venv=venv, gen_algo=algo, reward_net=net,
+             n_disc_updates_per_round=n_disc, gen_replay_buffer_capacity=capacity,
+             custom_logger=p.configure_logger(tempfile.mkdtemp(prefix="bench-var-"), []))
+    per = n_envs * n_steps
+    tr.train(warm * per)
+    th.cuda.synchronize()
+    t0 = time.perf_counter()
+    tr.train(rounds * per)
+    th.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    finite = all(bool(th.isfinite(v.float()).all()) for v in tr.gen_algo.policy.state_dict().values())
+    return {"env_steps_per_s": rounds * per / dt, "ms_per_round": 1e3 * dt / rounds, "rounds": rounds,
+            "env_steps_per_round": per, "finite": finite}
 
 
 def main():
@@ -193,6 +310,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--prof-rounds", type=int, default=2)
+    ap.add_argument("--no-variants", action="store_true")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", 0))
@@ -246,6 +364,15 @@ def main():
     roof = gemm_roofline(trainer, cfg, args.prof_rounds) if args.prof_rounds > 0 else None
     if rank != 0:
         roof = None
+    variants = None
+    if rank == 0 and world == 1 and not args.no_variants:
+        # SURVEY 8d's other configurations through the same trainer (a few rounds each, after the timed region)
+        variants = {}
+        for name in VARIANTS:
+            try:
+                variants[name] = run_variant(name)
+            except Exception as e:  # a variant must never take the headline down with it
+                variants[name] = {"error": f"{type(e).__name__}: {e}"}
     base = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         base = cpu_baseline(cfg, host_threads)
@@ -265,6 +392,11 @@ def main():
                                    "minibatch 1024 x 10 epochs", "env_steps_per_round_per_gpu": per_round,
                        "parallelism": f"dp{world}" if world > 1 else "single"},
             "roofline": roof, "cpu_baseline": base,
+            # siblings of `roofline` repeated at the top level (a parser that keeps only roofline's scalar fields
+            # still sees them): the whole discriminator update and the GEMM family
+            "roofline_disc_update": roof.get("disc_update") if roof else None,
+            "roofline_gemm": roof.get("gemm") if roof else None,
+            "variants": variants,
         }
         if base:
             out["speedup_vs_cpu_baseline"] = value / base["value"]

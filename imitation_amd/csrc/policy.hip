@@ -15,6 +15,7 @@
 //  * per-wave partial gradients go to a slab; a single-block kernel reduces the slabs in fixed
 //    order (deterministic), applies clip_grad_norm_ + Adam and refreshes the transposed copies.
 #include "common.h"
+#include "rn_common.h"
 #include "../../include/imitation_hip.h"
 
 namespace {
@@ -548,7 +549,7 @@ __device__ void prepare_stats_t(const ia_policy_desc& d, const float* __restrict
   __syncthreads();
   if (rg == 0 && col < D) {
     const float bmean = m_acc, bvar = M2 / (float)batch;
-    const float fcount = (float)cnt, fn = (float)batch, tot = (float)(cnt + batch);
+    const float fcount = (float)cnt, fn = (float)batch, tot = (float)((long long)cnt + batch);
     const float delta = bmean - nm[col];
     nm[col] = nm[col] + delta * fn / tot;
     float rv = nv[col] * fcount;
@@ -556,7 +557,7 @@ __device__ void prepare_stats_t(const ia_policy_desc& d, const float* __restrict
     rv = rv + delta * delta * fcount * fn / tot;
     nv[col] = rv / tot;
   }
-  if (tid == 0) *ncount = cnt + batch;
+  if (tid == 0) *ncount = rn_count_add(cnt, batch);  // saturates at INT32_MAX (rn_common.h)
 }
 
 __device__ void prepare_stats(const ia_policy_desc& d, const float* __restrict__ obs, const float* __restrict__ adv,
@@ -2203,7 +2204,9 @@ __device__ __forceinline__ bool spin_until(unsigned* p, unsigned target, unsigne
   return true;
 }
 
-template <int NPT>
+// TIMING = false (production): the phase-clock accumulators (24 VGPRs of `tacc` alone) and every stamp are
+// compiled out -- the measurement build is a separate instantiation picked only while ia_ppo_debug_timing is on.
+template <int NPT, bool TIMING>
 __global__ __launch_bounds__(512) void ppo_update_persistent_kernel(
     ia_policy_desc d, float* __restrict__ P, float* __restrict__ Pt, float* __restrict__ m, float* __restrict__ v,
     float* __restrict__ nm, float* __restrict__ nv, int32_t* __restrict__ ncount, int update_norm,
@@ -2216,6 +2219,7 @@ __global__ __launch_bounds__(512) void ppo_update_persistent_kernel(
   using L = CLds;
   extern __shared__ float lds[];
   __shared__ int s_ok, s_pub;
+  if (!TIMING) tstamp = nullptr;
   long long tacc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   long long tprev = 0;
 #define UPD_TS(k) do { if (tstamp && tid == 0) { const long long tn = wall_clock64(); tacc[k] += tn - tprev; tprev = tn; } } while (0)
@@ -2334,7 +2338,7 @@ __global__ __launch_bounds__(512) void ppo_update_persistent_kernel(
           } else if (norm_on) {
             const int cnt = *ncount;
             const float bmean = m_acc, bvar = M2 / (float)r.batch;
-            const float fcount = (float)cnt, fn = (float)r.batch, tot = (float)(cnt + r.batch);
+            const float fcount = (float)cnt, fn = (float)r.batch, tot = (float)((long long)cnt + r.batch);
             const float delta = bmean - nm[c];
             nm[c] = nm[c] + delta * fn / tot;
             float rvv = nv[c] * fcount;
@@ -2344,7 +2348,7 @@ __global__ __launch_bounds__(512) void ppo_update_persistent_kernel(
           }
         }
         __syncthreads();
-        if (tid == 0 && norm_on) *ncount = *ncount + r.batch;
+        if (tid == 0 && norm_on) *ncount = rn_count_add(*ncount, r.batch);
       }
       __syncthreads();
       if (d.has_norm && tid < D) {
@@ -3121,12 +3125,14 @@ int ia_ppo_update(const ia_policy_desc* d, float* params, float* params_t, float
   const size_t prep_bytes = (PREP_LDS_FLOATS + (size_t)nblk * ROWS) * sizeof(float);  // + row offsets
   const size_t bytes = grad_bytes > prep_bytes ? grad_bytes : prep_bytes;
   const bool wide = P > UPD_NPT * 512;
-  static size_t attr_bytes[2] = {0, 0};
-  if (bytes > attr_bytes[wide]) {
-    const int rc = wide ? set_lds(ppo_update_persistent_kernel<UPD_NPT_WIDE>, bytes)
-                        : set_lds(ppo_update_persistent_kernel<UPD_NPT>, bytes);
+  const bool timing = g_tstamp != nullptr;
+  auto kernel = wide ? (timing ? ppo_update_persistent_kernel<UPD_NPT_WIDE, true> : ppo_update_persistent_kernel<UPD_NPT_WIDE, false>)
+                     : (timing ? ppo_update_persistent_kernel<UPD_NPT, true> : ppo_update_persistent_kernel<UPD_NPT, false>);
+  static size_t attr_bytes[4] = {0, 0, 0, 0};
+  if (bytes > attr_bytes[wide * 2 + timing]) {
+    const int rc = set_lds(kernel, bytes);
     if (rc) return rc;
-    attr_bytes[wide] = bytes;
+    attr_bytes[wide * 2 + timing] = bytes;
   }
   hipStream_t st = (hipStream_t)stream;
   const int steps_total = n_epochs * n_mb;
@@ -3172,7 +3178,6 @@ int ia_ppo_update(const ia_policy_desc* d, float* params, float* params_t, float
     const int n_slices = (batch_size > UPD_SLICE && total < (1ll << 31)) ? cdiv(batch_size, UPD_SLICE) : 0;
     const bool pack = g_upd_xcd_pack && nblk + 1 + n_slices <= 32;
     const int grid = (nblk + 1 + n_slices) * (pack ? 8 : 1);
-    auto kernel = wide ? ppo_update_persistent_kernel<UPD_NPT_WIDE> : ppo_update_persistent_kernel<UPD_NPT>;
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(512), bytes, st, *d, params, params_t, exp_avg,
                        exp_avg_sq, norm_mean, norm_var, norm_count, update_norm, obs, actions, old_logp, advantages,
                        returns, perm, T, n_envs, normalize_adv, clip_range, ent_coef, vf_coef, max_grad_norm,

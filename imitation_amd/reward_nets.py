@@ -278,6 +278,8 @@ class BasicRewardNet(RewardNet):
             nf = 0 if FUSED_DISC_STEP is False else int(L.load().ia_disc_fused_ws_floats(C.byref(mlp.desc), R, mlp.ldx))
             ws["fused_ws"] = th.zeros(nf, device=dev) if nf > 0 else None
             a.fused_ws = L.ptr(ws["fused_ws"])
+            if nf > 0:  # 32 K-splits of the second layer's weight gradient: half the partial-slab traffic of 64
+                a.splits = min(ws["splits"], 32)
             ws["args"] = a
         a = ws["args"]
         a.params, a.grads = L.ptr(mlp.flat), L.ptr(mlp.grad)
