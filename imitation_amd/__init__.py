@@ -21,7 +21,7 @@ from imitation_amd.wrappers import BufferingWrapper, RewardVecEnvWrapper  # noqa
 from imitation_amd.adversarial.common import AdversarialTrainer, compute_train_stats  # noqa: F401
 from imitation_amd.adversarial.gail import GAIL, RewardNetFromDiscriminatorLogit  # noqa: F401
 from imitation_amd.adversarial.airl import AIRL  # noqa: F401
-from imitation_amd import bc, checkpoint, cnn_policy, rollout, serialize  # noqa: F401
+from imitation_amd import bc, checkpoint, cnn_policy, modules, ops, rollout, serialize  # noqa: F401
 
 
 def configure_logger(folder=None, format_strs=None):

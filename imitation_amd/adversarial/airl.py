@@ -37,6 +37,6 @@ class AIRL(common.AdversarialTrainer):
     @property
     def reward_test(self) -> reward_nets.RewardNet:
         net = self._reward_net
-        while isinstance(net, reward_nets.RewardNetWrapper):
+        while isinstance(net, reward_nets.RewardNetWrapper) or (isinstance(net, th.nn.Module) and hasattr(net, "base")):
             net = net.base
         return net

@@ -19,6 +19,8 @@ from typing import Callable, Dict, Iterable, Mapping, Optional, Type
 import numpy as np
 import torch as th
 
+from torch import nn
+
 from imitation_amd import _lib as L
 from imitation_amd import buffer, data_types as dt
 from imitation_amd import logger as imit_logger
@@ -112,8 +114,20 @@ class AdversarialTrainer(abc.ABC):
             raise NotImplementedError("tensorboard is not installed in this image; use csv/json logger formats")
         self._disc_opt_cls = disc_opt_cls
         self._disc_opt_kwargs = dict(disc_opt_kwargs or {})
-        store = self._reward_net._store
-        if disc_opt_cls is th.optim.Adam:
+        # An `nn.Module` reward net (imitation_amd.modules, or any user subclass of its `RewardNet`): the
+        # reference's plugin contract -- autograd graph through `forward`, `loss.backward()`, a torch optimiser
+        # over its parameters (`common.py:218-221,353-372`); the contractions run in the HIP custom ops.
+        self._module_net = isinstance(self._reward_net, nn.Module)
+        store = None if self._module_net else self._reward_net._store
+        if self._module_net:
+            from imitation_amd import ops
+            if data_parallel is not None and data_parallel.world > 1:
+                raise NotImplementedError("data parallelism is built for the fused state-holder reward nets")
+            params = [p_ for p_ in self._reward_net.parameters() if p_.requires_grad]
+            self._disc_opt = (ops.HipAdam(params, **self._disc_opt_kwargs) if disc_opt_cls is th.optim.Adam
+                              else disc_opt_cls(params, **self._disc_opt_kwargs))
+            self._torch_opt_params = None
+        elif disc_opt_cls is th.optim.Adam:
             self._disc_opt = HipAdam(store.flat, store.grad, **self._disc_opt_kwargs)
             self._torch_opt_params = None
         else:  # any other torch optimiser: steps device views of the same flat buffers
@@ -168,7 +182,7 @@ class AdversarialTrainer(abc.ABC):
         # update): then only one stream at a time has collectives in flight, in the same order on all ranks.
         dp_many = self._dp is not None and self._dp.world > 1
         self._overlap = (isinstance(self.gen_algo, ppo.PPO) and isinstance(self.policy, ActorCriticPolicy)
-                         and (not dp_many or self.gen_algo._dp_global()))
+                         and (not dp_many or self.gen_algo._dp_global()) and not self._module_net)
         # AIRL's updates read log pi(a|s) of the policy PPO has just updated: they cannot run beside that
         # PPO update, only behind the next rollout (`_train_pipelined`), with the feature statistics each
         # update's own `evaluate_actions` would have seen taken from the merge snapshots.
@@ -439,6 +453,9 @@ class AdversarialTrainer(abc.ABC):
         side effect of this update was already captured by `_quirk_prepass`."""
         (e_tab, e_idx), (g_tab, g_idx) = drawn if drawn is not None else self._batch_sources(expert_samples,
                                                                                                gen_samples)
+        if self._module_net:
+            self._disc_update_module((e_tab, e_idx), (g_tab, g_idx), stats_dev, quirk_done)
+            return
         B, mb = self.demo_batch_size, self.demo_minibatch_size
         scale = mb / B
         net = self._reward_net
@@ -495,6 +512,48 @@ class AdversarialTrainer(abc.ABC):
             self._disc_opt.step()
         self._disc_step += 1
         self._last_disc_logits = logits
+
+    def _module_batch(self, sources):
+        """`common.py:564-603` for the autograd path: [expert | generator] rows of one minibatch as preprocessed
+        device tensors (observations in their space's shape, one-hot actions for Discrete spaces, done as fp32)."""
+        from imitation_amd import ops
+        cols = {"obs": [], "acts": [], "next_obs": [], "dones": []}
+        for table, idx, n in sources:
+            for k, t in (("obs", table.obs), ("next_obs", table.next_obs)):
+                cols[k].append(ops.gather_rows(t, idx) if idx is not None else t[:n])
+            a = table.acts[idx] if idx is not None else table.acts[:n]
+            if table.discrete:
+                a = th.nn.functional.one_hot(a.long(), num_classes=self.venv.action_space.n).float()
+            cols["acts"].append(a.float())
+            d = table.dones[idx] if idx is not None else table.dones[:n]
+            cols["dones"].append(d.to(th.float32))
+        cat = {k: th.cat(v) for k, v in cols.items()}
+        shp = tuple(self.venv.observation_space.shape)
+        return (cat["obs"].reshape(-1, *shp), cat["acts"], cat["next_obs"].reshape(-1, *shp), cat["dones"])
+
+    def _disc_update_module(self, e_src, g_src, stats_dev: th.Tensor, quirk_done: bool) -> None:
+        """`train_disc` (`common.py:317-374`) for an `nn.Module` reward net: zero_grad, per minibatch
+        `logits_expert_is_high` -> BCE-with-logits (scaled by minibatch / batch) -> `backward()`, then the
+        optimiser step. Forward, backward, loss and Adam all run in the HIP custom ops."""
+        from imitation_amd import ops
+        (e_tab, e_idx), (g_tab, g_idx) = e_src, g_src
+        B, mb = self.demo_batch_size, self.demo_minibatch_size
+        self._disc_opt.zero_grad()
+        stats = None
+        for start in range(0, B, mb):
+            sl = lambda idx: None if idx is None else idx[start:start + mb]
+            sources = [(e_tab if e_idx is not None else _slice_table(e_tab, start, mb), sl(e_idx), mb),
+                       (g_tab if g_idx is not None else _slice_table(g_tab, start, mb), sl(g_idx), mb)]
+            logp = None if (quirk_done and not self._needs_logp) else self._policy_pass(sources, mb)
+            state, action, next_state, done = self._module_batch(sources)
+            logits = self.logits_expert_is_high(state, action, next_state, done,
+                                                None if logp is None else logp[:2 * mb].clone())
+            loss, stats = ops.bce_expert_first(logits, mb, mb / B)
+            loss.backward()
+        self._disc_opt.step()
+        stats_dev.copy_(stats)
+        self._disc_step += 1
+        self._last_disc_logits = logits.detach()
 
     # ---- generator update (`common.py:391-425`) -------------------------------------------------
     def train_gen(self, total_timesteps: Optional[int] = None, learn_kwargs: Optional[Mapping] = None) -> None:

@@ -38,7 +38,11 @@ class GAIL(common.AdversarialTrainer):
     def __init__(self, *, demonstrations, demo_batch_size: int, venv, gen_algo, reward_net: reward_nets.RewardNet,
                  **kwargs):
         reward_net = reward_net.to(gen_algo.device)
-        self._processed_reward = RewardNetFromDiscriminatorLogit(reward_net)
+        if isinstance(reward_net, th.nn.Module):  # autograd-capable plugin net (imitation_amd.modules)
+            from imitation_amd import modules
+            self._processed_reward = modules.RewardNetFromDiscriminatorLogit(reward_net)
+        else:
+            self._processed_reward = RewardNetFromDiscriminatorLogit(reward_net)
         super().__init__(demonstrations=demonstrations, demo_batch_size=demo_batch_size, venv=venv,
                          gen_algo=gen_algo, reward_net=reward_net, **kwargs)
 

@@ -1,0 +1,320 @@
+"""`nn.Module` reward networks on the HIP custom ops (`imitation_amd.ops`): the reference's reward-net
+PLUGIN contract (`rewards/reward_nets.py:16-224`) -- `forward(state, action, next_state, done)` carries an
+autograd graph, `AdversarialTrainer.train_disc` trains it with `loss.backward()`
+(`algorithms/adversarial/common.py:353-372`) -- with the forward / backward arithmetic in libimitation_hip.so.
+
+`BasicRewardNet` here has the reference's module tree and `state_dict` keys (`mlp.normalize_input.*`,
+`mlp.dense0.*`, ..., `mlp.dense_final.*`), so checkpoints interchange with the reference and with the
+fused state-holder nets of `imitation_amd.reward_nets` (same keys). User-defined reward nets subclass
+`RewardNet` below and compose `Mlp` / `RunningNorm` / any differentiable torch-on-ROCm op in `forward`.
+
+The state-holder nets (`imitation_amd.reward_nets`) remain the fast path: one fused C call per update.
+"""
+from __future__ import annotations
+
+import abc
+import collections
+from typing import Iterable, Optional, Sequence, Tuple, Type
+
+import numpy as np
+import torch as th
+from torch import nn
+
+from imitation_amd import ops, spaces
+from imitation_amd.reward_nets import preprocess_space
+
+
+class RunningNorm(nn.Module):
+    """`util/networks.py:47-134`: buffers `running_mean`, `running_var`, int32 `count`; a train-mode forward
+    first merges the batch into the statistics (Chan), then normalises with them."""
+
+    def __init__(self, num_features: int, eps: float = 1e-5):
+        super().__init__()
+        self.eps = eps
+        self.register_buffer("running_mean", th.zeros(num_features))
+        self.register_buffer("running_var", th.ones(num_features))
+        self.register_buffer("count", th.zeros((), dtype=th.int32))
+
+    def reset_running_stats(self) -> None:
+        self.running_mean.zero_()
+        self.running_var.fill_(1)
+        self.count.zero_()
+
+    def update_stats(self, batch: th.Tensor) -> None:
+        th.ops.imitation_amd.running_norm_update(batch.detach().reshape(batch.shape[0], -1).float().contiguous(),
+                                                 self.running_mean, self.running_var, self.count)
+
+    def forward(self, x: th.Tensor) -> th.Tensor:
+        flat = x.reshape(x.shape[0], -1)
+        if self.training:
+            with th.no_grad():
+                self.update_stats(flat)
+        return ops.running_norm_apply_fn(flat, self.running_mean, self.running_var, self.eps).reshape(x.shape)
+
+
+_ACTS = {nn.ReLU: ops.ACT_RELU, nn.Tanh: ops.ACT_TANH}
+
+
+class Mlp(nn.Module):
+    """`build_mlp` (`util/networks.py:204-283`): children named as the reference names them (`normalize_input`,
+    `dense{i}`, `dense_final`), ordinary `nn.Linear` parameters (so any torch optimiser and the reference's
+    `state_dict` keys apply); `forward` packs them into the flat vector the `imitation_amd::mlp_*` ops take and
+    autograd routes the flat gradient back to the individual parameters."""
+
+    def __init__(self, in_size: int, hid_sizes: Iterable[int], out_size: int = 1, name: Optional[str] = None,
+                 activation: Type[nn.Module] = nn.ReLU, dropout_prob: float = 0.0, squeeze_output: bool = False,
+                 flatten_input: bool = False, normalize_input_layer: Optional[Type[nn.Module]] = None):
+        super().__init__()
+        if dropout_prob > 0.0:
+            raise NotImplementedError("dropout is off in every reference GAIL/AIRL config; not built for HIP")
+        if activation not in _ACTS:
+            raise NotImplementedError(f"activation {activation} not supported on the HIP path (ReLU/Tanh)")
+        if squeeze_output and out_size != 1:
+            raise ValueError("squeeze_output is only applicable when out_size=1")
+        prefix = "" if name is None else f"{name}_"
+        self.dims = [int(in_size), *[int(h) for h in hid_sizes], int(out_size)]
+        self.act = _ACTS[activation]
+        self.squeeze_output, self.flatten_input = squeeze_output, flatten_input
+        self._norm_name = None
+        if normalize_input_layer:
+            try:
+                layer = normalize_input_layer(in_size)
+            except TypeError as exc:
+                raise ValueError(f"normalize_input_layer={normalize_input_layer} is not a valid normalization layer "
+                                 "type accepting only one argument (in_size).") from exc
+            self._norm_name = f"{prefix}normalize_input"
+            self.add_module(self._norm_name, layer)
+        self._dense = []
+        for i in range(len(self.dims) - 2):
+            self._dense.append(f"{prefix}dense{i}")
+            self.add_module(self._dense[-1], nn.Linear(self.dims[i], self.dims[i + 1]))
+        self._dense.append(f"{prefix}dense_final")
+        self.add_module(self._dense[-1], nn.Linear(self.dims[-2], self.dims[-1]))
+
+    def flat_parameters(self) -> th.Tensor:
+        parts = []
+        for n in self._dense:
+            lin = getattr(self, n)
+            parts += [lin.weight.reshape(-1), lin.bias.reshape(-1)]
+        return th.cat(parts)
+
+    def forward(self, x: th.Tensor) -> th.Tensor:
+        if self.flatten_input:
+            x = x.reshape(x.shape[0], -1)
+        if self._norm_name is not None:
+            x = getattr(self, self._norm_name)(x)
+        out = ops.mlp(x, self.flat_parameters(), self.dims, self.act)
+        return out.squeeze(-1) if self.squeeze_output else out
+
+
+class RewardNet(nn.Module, abc.ABC):
+    """`rewards/reward_nets.py:16-224`, verbatim contract: `forward` on preprocessed device tensors (with
+    grad), `preprocess` (numpy -> device tensors, one-hot / float), `predict_th`, `predict`,
+    `predict_processed`, `device`, `dtype`."""
+
+    def __init__(self, observation_space, action_space, normalize_images: bool = True):
+        super().__init__()
+        self.observation_space, self.action_space = observation_space, action_space
+        self.normalize_images = normalize_images
+
+    @abc.abstractmethod
+    def forward(self, state: th.Tensor, action: th.Tensor, next_state: th.Tensor, done: th.Tensor) -> th.Tensor:
+        """Rewards `[B]` for preprocessed tensors."""
+
+    def preprocess(self, state, action, next_state, done) -> Tuple[th.Tensor, th.Tensor, th.Tensor, th.Tensor]:
+        dev = self.device
+        to = lambda a: th.as_tensor(np.ascontiguousarray(a) if isinstance(a, np.ndarray) else a).to(dev)
+        s = preprocess_space(to(state), self.observation_space, self.normalize_images)
+        a = preprocess_space(to(action), self.action_space, self.normalize_images)
+        ns = preprocess_space(to(next_state), self.observation_space, self.normalize_images)
+        d = to(done).to(th.float32)
+        assert s.shape == ns.shape and len(a) == len(s)
+        return s, a, ns, d
+
+    def predict_th(self, state, action, next_state, done) -> th.Tensor:
+        was = self.training
+        self.eval()
+        try:
+            with th.no_grad():
+                rew = self(*self.preprocess(state, action, next_state, done))
+        finally:
+            self.train(was)
+        assert rew.shape == np.shape(state)[:1]
+        return rew
+
+    def predict(self, state, action, next_state, done) -> np.ndarray:
+        return self.predict_th(state, action, next_state, done).detach().cpu().numpy().flatten()
+
+    def predict_processed(self, state, action, next_state, done, **kwargs) -> np.ndarray:
+        del kwargs
+        return self.predict(state, action, next_state, done)
+
+    @property
+    def device(self) -> th.device:
+        try:
+            return next(self.parameters()).device
+        except StopIteration:
+            return th.device("cpu")
+
+    @property
+    def dtype(self) -> th.dtype:
+        try:
+            return next(self.parameters()).dtype
+        except StopIteration:
+            return th.get_default_dtype()
+
+
+class BasicRewardNet(RewardNet):
+    """`rewards/reward_nets.py:383-457`: MLP over the concatenation of the enabled, flattened inputs."""
+
+    def __init__(self, observation_space, action_space, use_state: bool = True, use_action: bool = True,
+                 use_next_state: bool = False, use_done: bool = False, **kwargs):
+        super().__init__(observation_space, action_space)
+        size = 0
+        self.use_state, self.use_action = use_state, use_action
+        self.use_next_state, self.use_done = use_next_state, use_done
+        if use_state:
+            size += spaces.flatdim(observation_space)
+        if use_action:
+            size += spaces.flatdim(action_space)
+        if use_next_state:
+            size += spaces.flatdim(observation_space)
+        if use_done:
+            size += 1
+        full = {"hid_sizes": (32, 32), **kwargs, "in_size": size, "out_size": 1, "squeeze_output": True}
+        self.mlp = Mlp(**full)
+
+    def forward(self, state, action, next_state, done):
+        n = state.shape[0]
+        picked = ((self.use_state, state), (self.use_action, action), (self.use_next_state, next_state),
+                  (self.use_done, done))
+        row = th.cat([t.reshape(n, -1).float() for on, t in picked if on], dim=1)
+        rew = self.mlp(row)
+        assert rew.shape == (n,)
+        return rew
+
+
+class BasicPotentialMLP(nn.Module):
+    """`rewards/reward_nets.py:812-839`."""
+
+    def __init__(self, observation_space, hid_sizes: Sequence[int], **kwargs):
+        super().__init__()
+        self._potential_net = Mlp(in_size=spaces.flatdim(observation_space), hid_sizes=hid_sizes, squeeze_output=True,
+                                  flatten_input=True, **kwargs)
+
+    def forward(self, state: th.Tensor) -> th.Tensor:
+        return self._potential_net(state)
+
+
+class ShapedRewardNet(RewardNet):
+    """`rewards/reward_nets.py:674-736`: `base(s, a, s', d) + gamma * (1 - d) * potential(s') - potential(s)`,
+    composed by autograd from the two sub-modules."""
+
+    def __init__(self, base: RewardNet, potential: nn.Module, discount_factor: float):
+        super().__init__(base.observation_space, base.action_space, base.normalize_images)
+        self._base = base
+        self.potential = potential
+        self.discount_factor = discount_factor
+
+    @property
+    def base(self) -> RewardNet:
+        return self._base
+
+    def forward(self, state, action, next_state, done):
+        g = self._base(state, action, next_state, done)
+        h_next, h_cur = self.potential(next_state).reshape(-1), self.potential(state).reshape(-1)
+        alive = 1 - done.float()                     # no bootstrapping through a true episode end
+        shaped = g + self.discount_factor * (alive * h_next)   # same association as the reference (`:727-733`)
+        shaped = shaped - h_cur
+        assert shaped.shape == state.shape[:1]
+        return shaped
+
+
+class BasicShapedRewardNet(ShapedRewardNet):
+    """`rewards/reward_nets.py:739-809`."""
+
+    def __init__(self, observation_space, action_space, *, reward_hid_sizes: Sequence[int] = (32,),
+                 potential_hid_sizes: Sequence[int] = (32, 32), use_state: bool = True, use_action: bool = True,
+                 use_next_state: bool = False, use_done: bool = False, discount_factor: float = 0.99, **kwargs):
+        base = BasicRewardNet(observation_space, action_space, use_state=use_state, use_action=use_action,
+                              use_next_state=use_next_state, use_done=use_done, hid_sizes=reward_hid_sizes, **kwargs)
+        pot = BasicPotentialMLP(observation_space, hid_sizes=potential_hid_sizes, **kwargs)
+        super().__init__(base, pot, discount_factor=discount_factor)
+
+
+class RewardNetWrapper(RewardNet):
+    """`rewards/reward_nets.py:227-272`."""
+
+    def __init__(self, base: RewardNet):
+        super().__init__(base.observation_space, base.action_space, base.normalize_images)
+        self._base = base
+
+    @property
+    def base(self) -> RewardNet:
+        return self._base
+
+    @property
+    def device(self) -> th.device:
+        return self.base.device
+
+    @property
+    def dtype(self) -> th.dtype:
+        return self.base.dtype
+
+    def preprocess(self, state, action, next_state, done):
+        return self.base.preprocess(state, action, next_state, done)
+
+
+class PredictProcessedWrapper(RewardNetWrapper):
+    """`rewards/reward_nets.py:303-353`: `forward` / `predict` / `predict_th` pass through to the base."""
+
+    def forward(self, state, action, next_state, done):
+        return self.base.forward(state, action, next_state, done)
+
+    def predict(self, state, action, next_state, done):
+        return self.base.predict(state, action, next_state, done)
+
+    def predict_th(self, state, action, next_state, done):
+        return self.base.predict_th(state, action, next_state, done)
+
+
+class NormalizedRewardNet(PredictProcessedWrapper):
+    """`rewards/reward_nets.py:613-671`: `predict_processed` normalised by a running norm of the raw rewards
+    (statistics of the calls so far; updated AFTER normalising when `update_stats`)."""
+
+    def __init__(self, base: RewardNet, normalize_output_layer: Type[nn.Module]):
+        super().__init__(base=base)
+        self.normalize_output_layer = normalize_output_layer(1)
+
+    def predict_processed(self, state, action, next_state, done, update_stats: bool = True, **kwargs) -> np.ndarray:
+        was = self.training
+        self.eval()
+        try:
+            with th.no_grad():
+                raw = th.as_tensor(self.base.predict_processed(state, action, next_state, done, **kwargs),
+                                   device=self.device)
+                rew = self.normalize_output_layer(raw.reshape(-1, 1)).reshape(-1).cpu().numpy().flatten()
+            if update_stats:
+                with th.no_grad():
+                    self.normalize_output_layer.update_stats(raw.reshape(-1, 1))
+        finally:
+            self.train(was)
+        assert rew.shape == np.shape(state)[:1]
+        return rew
+
+
+class RewardNetFromDiscriminatorLogit(RewardNet):
+    """`adversarial/gail.py:14-83`: generator reward `-logsigmoid(-logit)` of a discriminator-logit net."""
+
+    def __init__(self, base: RewardNet):
+        super().__init__(base.observation_space, base.action_space, base.normalize_images)
+        self.base = base
+
+    def forward(self, state, action, next_state, done):
+        logits = self.base.forward(state, action, next_state, done)
+        return -th.nn.functional.logsigmoid(-logits)
+
+
+def build_mlp(*args, **kwargs) -> Mlp:
+    """`util/networks.py:204-283` signature."""
+    return Mlp(*args, **kwargs)

@@ -1,0 +1,252 @@
+"""PyTorch-ROCm custom ops over the C ABI (`include/imitation_hip.h`): the operator boundary the
+reference's reward-net plugin API sits on (`rewards/reward_nets.py:16-50`: a `RewardNet` is an
+`nn.Module` whose `forward` carries an autograd graph, trained by `loss.backward()` at
+`algorithms/adversarial/common.py:353-369`).
+
+Two layers:
+
+* `torch.library` ops `imitation_amd::*` -- thin, stateless wrappers of the HIP kernels (device tensors in,
+  device tensors out, launched on the current HIP stream; CUDA/ROCm device only: there is no CPU
+  implementation, calling them with CPU tensors raises);
+* `torch.autograd.Function`s on top (`mlp`, `running_norm_apply`, `bce_expert_first`) so that an
+  `nn.Module` built from them (`imitation_amd.modules`) trains through `loss.backward()` with every
+  forward / backward contraction running in libimitation_hip.so.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Optional, Sequence, Tuple
+
+import torch as th
+from torch import Tensor
+
+from imitation_amd import _lib as L
+
+ACT_NONE, ACT_RELU, ACT_TANH = L.ACT_NONE, L.ACT_RELU, L.ACT_TANH
+
+
+def _dev(t: Tensor, what: str) -> Tensor:
+    if not t.is_cuda:
+        raise RuntimeError(f"imitation_amd ops compute on MI355X only (no CPU fallback): `{what}` is on {t.device}")
+    return t.contiguous().float() if (t.dtype != th.float32 or not t.is_contiguous()) else t
+
+
+def _desc(dims: Sequence[int], act: int) -> L.MlpDesc:
+    return L.mlp_desc([int(d) for d in dims], int(act))
+
+
+def _splits(R: int) -> int:
+    return max(1, min(64, R // 256))
+
+
+# ------------------------------------------------------------------------------------ torch.library ops
+
+@th.library.custom_op("imitation_amd::mlp_forward", mutates_args=(), device_types="cuda")
+def mlp_forward(x: Tensor, flat: Tensor, dims: List[int], act: int, out_act: int) -> Tuple[Tensor, Tensor]:
+    """`build_mlp` stack (`util/networks.py:204-283`, no input norm) on rows `x[R, dims[0]]` with the flat
+    parameter vector `flat` (torch `parameters()` order W0, b0, W1, b1, ...). Returns `(out[R, dims[-1]],
+    hidden)` where `hidden` holds the post-activation hidden layers the backward needs."""
+    x, flat = _dev(x, "x"), _dev(flat, "flat")
+    R = x.shape[0]
+    d = _desc(dims, act)
+    hidden = th.empty(max(1, R * sum(dims[1:-1])), device=x.device)
+    out = th.empty(R, dims[-1], device=x.device)
+    L.call("ia_mlp_forward", C.byref(d), L.ptr(flat), L.ptr(x), x.shape[1], R, L.ptr(hidden), L.ptr(out), out_act,
+           L.stream())
+    return out, hidden
+
+
+@mlp_forward.register_fake
+def _(x, flat, dims, act, out_act):
+    R = x.shape[0]
+    return x.new_empty(R, dims[-1]), x.new_empty(max(1, R * sum(dims[1:-1])))
+
+
+@th.library.custom_op("imitation_amd::mlp_backward", mutates_args=(), device_types="cuda")
+def mlp_backward(x: Tensor, flat: Tensor, hidden: Tensor, dout: Tensor, dims: List[int], act: int) -> Tuple[Tensor, Tensor]:
+    """Autograd of `mlp_forward` for `dout[R, dims[-1]]` (gradient at the pre-activation output): returns
+    `(dflat, dx)` -- the flat parameter gradient (split-K slabs reduced in fixed order: deterministic) and
+    the input gradient `[R, dims[0]]`."""
+    x, flat, hidden, dout = _dev(x, "x"), _dev(flat, "flat"), _dev(hidden, "hidden"), _dev(dout, "dout")
+    R = x.shape[0]
+    d = _desc(dims, act)
+    splits = _splits(R)
+    n = flat.numel()
+    partials = th.empty(splits, n, device=x.device)
+    dhidden = th.empty_like(hidden)
+    dx = th.empty_like(x)
+    L.call("ia_mlp_backward", C.byref(d), L.ptr(flat), L.ptr(x), x.shape[1], R, L.ptr(hidden), L.ptr(dout),
+           L.ptr(dhidden), L.ptr(partials), splits, L.ptr(dx), L.stream())
+    dflat = th.empty(n, device=x.device)
+    L.call("ia_reduce_partials", L.ptr(partials), splits, n, 1.0, 0, L.ptr(dflat), L.stream())
+    return dflat, dx
+
+
+@mlp_backward.register_fake
+def _(x, flat, hidden, dout, dims, act):
+    return th.empty_like(flat), th.empty_like(x)
+
+
+@th.library.custom_op("imitation_amd::running_norm_update", mutates_args=("mean", "var", "count"), device_types="cuda")
+def running_norm_update(x: Tensor, mean: Tensor, var: Tensor, count: Tensor) -> None:
+    """`RunningNorm.update_stats` (`util/networks.py:111-134`, Chan merge; `count` int32) with batch `x[R, F]`."""
+    x = _dev(x, "x")
+    R, F = x.shape
+    ws = th.empty(int(L.load().ia_running_norm_ws_floats(R, F)), device=x.device)
+    L.call("ia_running_norm_update", L.ptr(x), F, R, F, L.ptr(mean), L.ptr(var), L.ptr(count), L.ptr(ws), L.stream())
+
+
+@th.library.custom_op("imitation_amd::running_norm_apply", mutates_args=(), device_types="cuda")
+def running_norm_apply(x: Tensor, mean: Tensor, var: Tensor, eps: float) -> Tensor:
+    """`(x - mean) / sqrt(var + eps)` (`util/networks.py:91`) on `x[R, F]`."""
+    x = _dev(x, "x")
+    R, F = x.shape
+    y = th.empty_like(x)
+    L.call("ia_running_norm_apply", L.ptr(x), F, R, F, L.ptr(_dev(mean, "mean")), L.ptr(_dev(var, "var")), float(eps),
+           L.ptr(y), F, L.stream())
+    return y
+
+
+@running_norm_apply.register_fake
+def _(x, mean, var, eps):
+    return th.empty_like(x)
+
+
+@th.library.custom_op("imitation_amd::bce_expert_first", mutates_args=(), device_types="cuda")
+def bce_expert_first_raw(logits: Tensor, n_expert: int, scale: float) -> Tuple[Tensor, Tensor]:
+    """`adversarial/common.py:360-368` + `27-92`: BCE-with-logits over `logits[R]` whose first `n_expert` rows are
+    labelled 1 (expert) and the rest 0, mean loss scaled by `scale`. Returns `(stats[8], dlogits[R])`:
+    stats = {loss, n_correct, n_correct_expert, n_correct_gen, n_pred_gen, entropy_sum, n_expert, n_gen},
+    dlogits = d loss / d logits."""
+    logits = _dev(logits, "logits").reshape(-1)
+    R = logits.numel()
+    ws = th.zeros(int(L.load().ia_bce_ws_floats(R)), device=logits.device)
+    stats = th.empty(8, device=logits.device)
+    dlogits = th.empty(R, device=logits.device)
+    L.call("ia_bce_logits", L.ptr(logits), R, int(n_expert), float(scale), L.ptr(dlogits), L.ptr(stats), L.ptr(ws),
+           L.stream())
+    return stats, dlogits
+
+
+@bce_expert_first_raw.register_fake
+def _(logits, n_expert, scale):
+    return logits.new_empty(8), logits.new_empty(logits.numel())
+
+
+@th.library.custom_op("imitation_amd::gather_rows", mutates_args=(), device_types="cuda")
+def gather_rows(src: Tensor, idx: Tensor) -> Tensor:
+    """`src[idx]` for a row-major fp32 table `src[N, W]` and int64 `idx[n]` (batch assembly, `common.py:564-603`)."""
+    src = _dev(src, "src")
+    flat = src.reshape(src.shape[0], -1)
+    out = th.empty(idx.numel(), flat.shape[1], device=src.device)
+    L.call("ia_gather_rows", L.ptr(flat), L.ptr(idx.contiguous()), idx.numel(), flat.shape[1], L.ptr(out), L.stream())
+    return out.reshape(idx.numel(), *src.shape[1:])
+
+
+@gather_rows.register_fake
+def _(src, idx):
+    return src.new_empty(idx.numel(), *src.shape[1:])
+
+
+@th.library.custom_op("imitation_amd::adam_step", mutates_args=("p", "m", "v"), device_types="cuda")
+def adam_step(p: Tensor, g: Tensor, m: Tensor, v: Tensor, beta1: float, beta2: float, eps: float, weight_decay: float,
+              step_size: float, bc2_sqrt: float) -> None:
+    """`torch.optim.Adam` single-tensor step on contiguous fp32 buffers (`step_size = lr / (1 - b1^t)`,
+    `bc2_sqrt = sqrt(1 - b2^t)` formed by the caller in double, as torch does)."""
+    L.call("ia_adam_step", L.ptr(p), L.ptr(_dev(g, "g")), L.ptr(m), L.ptr(v), p.numel(), beta1, beta2, eps, weight_decay,
+           step_size, bc2_sqrt, L.stream())
+
+
+# ------------------------------------------------------------------------------------ autograd functions
+
+class _Mlp(th.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, flat, dims, act):
+        out, hidden = th.ops.imitation_amd.mlp_forward(x, flat, list(dims), act, ACT_NONE)
+        ctx.save_for_backward(x, flat, hidden)
+        ctx.dims, ctx.act = list(dims), act
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, flat, hidden = ctx.saved_tensors
+        dflat, dx = th.ops.imitation_amd.mlp_backward(x, flat, hidden, dout.contiguous(), ctx.dims, ctx.act)
+        return (dx if ctx.needs_input_grad[0] else None), (dflat if ctx.needs_input_grad[1] else None), None, None
+
+
+def mlp(x: Tensor, flat: Tensor, dims: Sequence[int], act: int = ACT_RELU) -> Tensor:
+    """Differentiable dense stack: `out[R, dims[-1]]`; gradients flow to `x` and to `flat`."""
+    return _Mlp.apply(_dev(x, "x"), _dev(flat, "flat"), tuple(int(d) for d in dims), int(act))
+
+
+class _NormApply(th.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, mean, var, eps):
+        ctx.save_for_backward(var)
+        ctx.eps = eps
+        return th.ops.imitation_amd.running_norm_apply(x, mean, var, eps)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (var,) = ctx.saved_tensors
+        # d/dx (x - mean) / sqrt(var + eps) with the statistics held constant (they are buffers, `networks.py:72-77`)
+        return th.ops.imitation_amd.running_norm_apply(dy.contiguous(), th.zeros_like(var), var, ctx.eps), None, None, None
+
+
+def running_norm_apply_fn(x: Tensor, mean: Tensor, var: Tensor, eps: float) -> Tensor:
+    return _NormApply.apply(_dev(x, "x"), mean, var, float(eps))
+
+
+class _Bce(th.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, n_expert, scale):
+        stats, dlogits = th.ops.imitation_amd.bce_expert_first(logits, n_expert, scale)
+        ctx.save_for_backward(dlogits)
+        ctx.shape = logits.shape
+        ctx.mark_non_differentiable(stats)
+        return stats[0].clone(), stats
+
+    @staticmethod
+    def backward(ctx, dloss, _dstats):
+        (dlogits,) = ctx.saved_tensors
+        return (dlogits * dloss).reshape(ctx.shape), None, None
+
+
+def bce_expert_first(logits: Tensor, n_expert: int, scale: float = 1.0) -> Tuple[Tensor, Tensor]:
+    """Differentiable `binary_cross_entropy_with_logits(logits, [1]*n_expert + [0]*(R - n_expert)) * scale`
+    plus the statistics row of `compute_train_stats` (not differentiable). Returns `(loss, stats[8])`."""
+    return _Bce.apply(_dev(logits, "logits"), int(n_expert), float(scale))
+
+
+# ------------------------------------------------------------------------------------ optimiser
+
+class HipAdam(th.optim.Optimizer):
+    """`torch.optim.Adam` (no amsgrad) over ordinary `nn.Parameter`s, each step one `imitation_amd::adam_step`
+    launch per parameter tensor. What `AdversarialTrainer` builds for an `nn.Module` reward net when
+    `disc_opt_cls` is `torch.optim.Adam` (`adversarial/common.py:218-221`)."""
+
+    def __init__(self, params, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.0,
+                 amsgrad: bool = False):
+        if amsgrad:
+            raise NotImplementedError("amsgrad is not implemented on the HIP path")
+        super().__init__(params, dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay))
+
+    @th.no_grad()
+    def step(self, closure=None):
+        loss = closure() if closure is not None else None
+        for group in self.param_groups:
+            b1, b2 = group["betas"]
+            for p in group["params"]:
+                if p.grad is None:
+                    continue
+                st = self.state[p]
+                if not st:
+                    st["step"] = 0
+                    st["exp_avg"] = th.zeros_like(p, memory_format=th.contiguous_format)
+                    st["exp_avg_sq"] = th.zeros_like(p, memory_format=th.contiguous_format)
+                st["step"] += 1
+                t = st["step"]
+                th.ops.imitation_amd.adam_step(p.data, p.grad.contiguous(), st["exp_avg"], st["exp_avg_sq"], b1, b2,
+                                               group["eps"], group["weight_decay"], group["lr"] / (1.0 - b1 ** t),
+                                               (1.0 - b2 ** t) ** 0.5)
+        return loss

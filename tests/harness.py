@@ -102,8 +102,16 @@ def namespace(impl: str) -> pytypes.SimpleNamespace:
     raise ValueError(impl)
 
 
-def build_trainer(impl: str, cfg, log_dir: str, device: str = "cpu"):
+def build_trainer(impl: str, cfg, log_dir: str, device: str = "cpu", module_net: bool = False):
     ns = namespace(impl)
+    if module_net:  # product only: the autograd-capable nn.Module reward nets on the HIP custom ops
+        from imitation_amd import modules as m
+
+        ns.BasicRewardNet, ns.BasicShapedRewardNet, ns.NormalizedRewardNet = (m.BasicRewardNet, m.BasicShapedRewardNet,
+                                                                             m.NormalizedRewardNet)
+        disc_norm = m.RunningNorm
+    else:
+        disc_norm = ns.RunningNorm
     th.manual_seed(0)
     np.random.seed(0)
     venv = SyntheticVecEnv(num_envs=cfg["n_envs"], obs_dim=cfg["obs_dim"], act_dim=cfg["act_dim"],
@@ -115,7 +123,7 @@ def build_trainer(impl: str, cfg, log_dir: str, device: str = "cpu"):
                   features_extractor_kwargs=dict(normalize_class=ns.RunningNorm))
     algo = ns.PPO(ns.FeedForward32Policy, venv, n_steps=cfg["n_steps"], batch_size=cfg["ppo_batch"],
                   n_epochs=cfg["n_epochs"], ent_coef=cfg["ent_coef"], seed=0, policy_kwargs=pk, device=device)
-    kw = dict(normalize_input_layer=ns.RunningNorm) if cfg["norm_disc"] else {}
+    kw = dict(normalize_input_layer=disc_norm) if cfg["norm_disc"] else {}
     if cfg["algo"] == "gail":
         net = ns.BasicRewardNet(venv.observation_space, venv.action_space, hid_sizes=cfg["disc_hid"], **kw)
         cls = ns.GAIL
@@ -124,7 +132,7 @@ def build_trainer(impl: str, cfg, log_dir: str, device: str = "cpu"):
                                       reward_hid_sizes=cfg["disc_hid"], potential_hid_sizes=(32, 32),
                                       use_next_state=True, **kw)
         if cfg.get("normalize_output"):
-            net = ns.NormalizedRewardNet(net, ns.RunningNorm)
+            net = ns.NormalizedRewardNet(net, disc_norm)
         cls = ns.AIRL
     demos = ns.Transitions(**make_demo_arrays(cfg))
     trainer = cls(demonstrations=demos, demo_batch_size=cfg["demo_batch"], venv=venv, gen_algo=algo,
@@ -162,9 +170,9 @@ def snapshot(trainer) -> Dict[str, np.ndarray]:
 
 
 def run_case(impl: str, name: str, log_dir: str, device: str = "cpu", sync_disc: bool = False,
-             pipeline: bool = True, discrete_sampling: str = None) -> Dict[str, np.ndarray]:
+             pipeline: bool = True, discrete_sampling: str = None, module_net: bool = False) -> Dict[str, np.ndarray]:
     cfg = CASES[name]
-    trainer, venv = build_trainer(impl, cfg, log_dir, device)
+    trainer, venv = build_trainer(impl, cfg, log_dir, device, module_net=module_net)
     if discrete_sampling is not None:  # product only: "inverse_cdf" = the in-kernel fast sampler
         trainer.gen_algo.policy.discrete_sampling = discrete_sampling
     if hasattr(trainer, "pipeline_rounds"):

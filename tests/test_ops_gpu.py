@@ -1,0 +1,219 @@
+"""The PyTorch-ROCm custom-op boundary (`imitation_amd.ops`, `imitation_amd.modules`), `-m gpu`:
+the `imitation_amd::*` torch.library ops and their autograd functions against torch's own autograd
+(float64) on the same inputs, and `nn.Module` reward nets trained by `loss.backward()` through them
+against (a) the fused state-holder path and (b) the reference's golden runs.
+
+Tolerances: op-level `rtol 2e-5, atol 2e-5 * sqrt(K)` (fp32 MFMA FMA chains vs float64); end-to-end
+the adversarial tests' `rtol 2e-4 / atol 5e-5`."""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch as th
+
+from tests import harness
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+DEV = "cuda"
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _need_gpu():
+    if not th.cuda.is_available():
+        pytest.skip("no GPU")
+
+
+def test_ops_are_registered_with_torch_library():
+    from imitation_amd import ops  # noqa: F401
+
+    for name in ("mlp_forward", "mlp_backward", "running_norm_update", "running_norm_apply", "bce_expert_first",
+                 "gather_rows", "adam_step"):
+        assert hasattr(th.ops.imitation_amd, name), name
+    with pytest.raises((NotImplementedError, RuntimeError)):   # no CPU kernels: fails loudly
+        th.ops.imitation_amd.running_norm_apply(th.zeros(4, 3), th.zeros(3), th.ones(3), 1e-5)
+
+
+@pytest.mark.parametrize("dims,act,R", [((23, 256, 256, 1), "relu", 4096), ((6, 32, 32, 1), "tanh", 333),
+                                        ((11, 64, 3), "relu", 100)])
+def test_mlp_autograd_matches_torch(dims, act, R):
+    from imitation_amd import ops
+
+    g = th.Generator().manual_seed(0)
+    n = sum(i * j + j for i, j in zip(dims[:-1], dims[1:]))
+    flat = (th.randn(n, generator=g) * 0.2)
+    x = th.randn(R, dims[0], generator=g)
+    w_out = th.randn(R, dims[-1], generator=g)
+    # torch float64 reference
+    xr, fr = x.double().requires_grad_(True), flat.double().requires_grad_(True)
+    h, o = xr, 0
+    fn = th.relu if act == "relu" else th.tanh
+    for li, (i, j) in enumerate(zip(dims[:-1], dims[1:])):
+        W = fr[o:o + i * j].view(j, i); o += i * j
+        b = fr[o:o + j]; o += j
+        h = h @ W.T + b
+        if li < len(dims) - 2:
+            h = fn(h)
+    (h * w_out.double()).sum().backward()
+    # HIP
+    xd, fd = x.to(DEV).requires_grad_(True), flat.to(DEV).requires_grad_(True)
+    out = ops.mlp(xd, fd, dims, ops.ACT_RELU if act == "relu" else ops.ACT_TANH)
+    (out * w_out.to(DEV)).sum().backward()
+    K = max(dims)
+    tol = dict(rtol=2e-5, atol=2e-5 * math.sqrt(K))
+    th.testing.assert_close(out.detach().cpu().double(), h.detach(), rtol=2e-5, atol=2e-5 * math.sqrt(K))
+    th.testing.assert_close(xd.grad.cpu().double(), xr.grad, **tol)
+    th.testing.assert_close(fd.grad.cpu().double(), fr.grad, rtol=3e-5, atol=3e-5 * math.sqrt(R))
+
+
+def test_running_norm_module_and_bce_match_torch():
+    from imitation_amd import modules, ops
+
+    g = th.Generator().manual_seed(1)
+    rn = modules.RunningNorm(7).to(DEV)
+    mean, M2, cnt = th.zeros(7, dtype=th.float64), th.zeros(7, dtype=th.float64), 0
+    allx = []
+    for k in range(3):
+        x = th.randn(50 + 13 * k, 7, generator=g) * (1 + k) + k
+        allx.append(x)
+        xd = x.to(DEV).requires_grad_(True)
+        y = rn(xd)                                           # train mode: update, then normalise
+        cat = th.cat(allx).double()
+        mu, var = cat.mean(0), cat.var(0, unbiased=False)
+        th.testing.assert_close(rn.running_mean.cpu().double(), mu, rtol=1e-5, atol=1e-5)
+        th.testing.assert_close(rn.running_var.cpu().double(), var, rtol=1e-5, atol=1e-5)
+        assert int(rn.count) == len(cat)
+        th.testing.assert_close(y.detach().cpu().double(), (x.double() - mu) / th.sqrt(var + 1e-5), rtol=1e-4, atol=1e-5)
+        y.sum().backward()                                   # statistics are constants for autograd
+        th.testing.assert_close(xd.grad.cpu().double(), (1 / th.sqrt(var + 1e-5)).expand(len(x), 7), rtol=1e-5, atol=1e-6)
+    rn.eval()
+    before = rn.running_mean.clone()
+    rn(th.randn(5, 7, device=DEV))
+    assert th.equal(before, rn.running_mean)
+    # BCE with the [expert | generator] label layout
+    logits = th.randn(301, generator=g) * 3
+    ne = 120
+    ld = logits.to(DEV).requires_grad_(True)
+    loss, stats = ops.bce_expert_first(ld, ne, 0.5)
+    (loss * 2.0).backward()
+    lr = logits.double().requires_grad_(True)
+    y = th.cat([th.ones(ne), th.zeros(301 - ne)]).double()
+    ref = th.nn.functional.binary_cross_entropy_with_logits(lr, y) * 0.5
+    (ref * 2.0).backward()
+    th.testing.assert_close(loss.cpu().double(), ref.detach(), rtol=1e-5, atol=1e-6)
+    th.testing.assert_close(ld.grad.cpu().double(), lr.grad, rtol=1e-5, atol=1e-8)
+    s = stats.cpu().numpy()
+    pred_gen = (logits < 0).numpy()
+    assert s[4] == pred_gen.sum() and s[6] == ne and s[7] == 301 - ne
+    assert s[1] == (pred_gen == (y.numpy() == 0)).sum()
+
+
+def test_hip_adam_optimizer_matches_torch_adam():
+    from imitation_amd import ops
+
+    th.manual_seed(0)
+    ps = [th.randn(17, 5), th.randn(5)]
+    a = [p.clone().to(DEV).requires_grad_(True) for p in ps]
+    b = [p.clone().double().requires_grad_(True) for p in ps]
+    oa, ob = ops.HipAdam(a, lr=3e-3, weight_decay=1e-2), th.optim.Adam(b, lr=3e-3, weight_decay=1e-2)
+    for k in range(5):
+        for opt, params in ((oa, a), (ob, b)):
+            opt.zero_grad()
+            loss = sum(((p * (k + 1)).sin() ** 2).sum() for p in params)
+            loss.backward()
+            opt.step()
+    for x, y in zip(a, b):
+        th.testing.assert_close(x.detach().cpu().double(), y.detach(), rtol=1e-5, atol=1e-6)
+
+
+def test_module_reward_net_train_disc_matches_fused_path(tmp_path):
+    """One `train_gen` + several `train_disc` through `modules.BasicRewardNet` (loss.backward() on the custom ops,
+    `ops.HipAdam`) against the fused `ia_disc_step_basic` path on the same seeds: identical batches (host RNG
+    order), statistics / parameters / norm buffers within the end-to-end tolerance; state dicts interchange."""
+    cfg = dict(harness.CASES["gail_box"], demo_minibatch=None)
+    outs = {}
+    for module_net in (False, True):
+        tr, _ = harness.build_trainer("hip", cfg, str(tmp_path / f"m{module_net}"), device="cuda", module_net=module_net)
+        assert tr._module_net == module_net
+        tr.train_gen()
+        stats = [tr.train_disc() for _ in range(4)]
+        sd = {k: v.detach().cpu().numpy().copy() for k, v in tr._reward_net.state_dict().items()}
+        outs[module_net] = (stats, sd, tr)
+    (sa, da, ta), (sb, db, tb) = outs[False], outs[True]
+    assert set(da) == set(db)
+    for k in da:
+        if k.endswith("count"):
+            assert np.array_equal(da[k], db[k]), k
+        else:
+            np.testing.assert_allclose(db[k], da[k], rtol=2e-4, atol=5e-5, err_msg=k)
+    for x, y in zip(sa, sb):
+        for k in x:
+            np.testing.assert_allclose(y[k], x[k], rtol=2e-4, atol=5e-5, err_msg=k)
+    # interchange: the module's state dict loads into the state-holder net and vice versa
+    ta._reward_net.load_state_dict(tb._reward_net.state_dict())
+    tb._reward_net.load_state_dict({k: th.as_tensor(v) for k, v in da.items()})
+    # the public RewardFn surface agrees
+    rng = np.random.default_rng(3)
+    s = rng.standard_normal((16, cfg["obs_dim"])).astype(np.float32)
+    a = rng.uniform(-1, 1, (16, cfg["act_dim"])).astype(np.float32)
+    tb._reward_net.load_state_dict(ta._reward_net.state_dict())
+    np.testing.assert_allclose(tb.reward_train.predict_processed(s, a, s, np.zeros(16, bool)),
+                               ta.reward_train.predict_processed(s, a, s, np.zeros(16, bool)), rtol=2e-4, atol=5e-5)
+
+
+@pytest.mark.parametrize("case", ["gail_box", "gail_discrete", "airl_box"])
+def test_module_reward_net_trainer_matches_reference_golden(case, tmp_path):
+    """Full GAIL / AIRL runs with `nn.Module` reward nets (autograd through the HIP ops, gradient accumulation
+    over minibatches by repeated `backward()`, per-step `predict_processed` relabelling) against the
+    reference's own golden runs -- the same comparison the fused path passes."""
+    cfg = harness.CASES[case]
+    gold = dict(np.load(os.path.join(GOLDEN, f"{case}.npz")))
+    got = harness.run_case("hip", case, str(tmp_path), device="cuda", module_net=True)
+    assert set(got) == set(gold), set(got) ^ set(gold)
+    for key in gold:
+        x, y = np.asarray(got[key]), np.asarray(gold[key])
+        assert x.shape == y.shape, (key, x.shape, y.shape)
+        if key in harness.EXACT_KEYS or y.dtype.kind in "biu":
+            assert np.array_equal(x, y), key
+        else:
+            np.testing.assert_allclose(x.astype(np.float64), y.astype(np.float64), rtol=2e-4, atol=5e-5,
+                                       equal_nan=True, err_msg=key)
+
+
+def test_user_defined_reward_net_plugs_in(tmp_path):
+    """A reward net the framework has never seen -- a user's `modules.RewardNet` subclass mixing an HIP-op MLP
+    with plain torch-on-ROCm ops -- trains through `GAIL.train()`: the plugin contract of
+    `rewards/reward_nets.py:16-50`."""
+    import imitation_amd as p
+    from imitation_amd import modules
+
+    class TwoHeadNet(modules.RewardNet):
+        def __init__(self, osp, asp):
+            super().__init__(osp, asp)
+            d = int(np.prod(osp.shape)) + int(np.prod(asp.shape))
+            self.trunk = modules.Mlp(d, (32,), out_size=8)
+            self.head = th.nn.Linear(8, 1)   # ordinary torch layer: rocBLAS-free tiny matvec via autograd
+
+        def forward(self, state, action, next_state, done):
+            z = th.tanh(self.trunk(th.cat([state.flatten(1), action.flatten(1)], 1)))
+            return self.head(z).squeeze(-1) - 0.1 * done
+
+    cfg = harness.CASES["gail_box"]
+    th.manual_seed(0)
+    np.random.seed(0)
+    from imitation_amd.vec_env import SyntheticVecEnv
+    venv = SyntheticVecEnv(num_envs=8, obs_dim=cfg["obs_dim"], act_dim=cfg["act_dim"], horizon=10, seed=0)
+    algo = p.PPO(p.FeedForward32Policy, venv, n_steps=16, batch_size=32, n_epochs=2, seed=0, device="cuda")
+    net = TwoHeadNet(venv.observation_space, venv.action_space)
+    tr = p.GAIL(demonstrations=p.Transitions(**harness.make_demo_arrays(cfg)), demo_batch_size=64, venv=venv,
+                gen_algo=algo, reward_net=net, n_disc_updates_per_round=3, disc_opt_cls=th.optim.SGD,
+                disc_opt_kwargs=dict(lr=0.05), custom_logger=p.configure_logger(str(tmp_path), []))
+    before = {k: v.detach().clone() for k, v in net.state_dict().items()}
+    tr.train(3 * 8 * 16)
+    after = net.state_dict()
+    assert all(th.isfinite(v).all() for v in after.values())
+    assert any(not th.equal(before[k], after[k]) for k in before), "the optimiser never moved the plugged-in net"
+    assert tr._disc_step == 9
+    losses = [tr.train_disc()["disc_loss"] for _ in range(30)]
+    assert np.mean(losses[-5:]) < np.mean(losses[:5])
