@@ -18,6 +18,7 @@ LIB_PATH = os.path.join(_HERE, "libimitation_hip.so")
 IA_MAX_LAYERS = 8
 ACT_NONE, ACT_RELU, ACT_TANH, ACT_SOFTPLUS = 0, 1, 2, 3
 GEMM_NT, GEMM_NN, GEMM_TN = 0, 1, 2
+ERR_ARG, ERR_UNSUPPORTED = -1, -2
 
 
 class MlpDesc(C.Structure):
@@ -109,6 +110,7 @@ _SIGS = {
                       _F, _F, _P, _P, _D, _D, _D, _F, _L, _P, _P, _P], C.c_int),
     "ia_ppo_update_ws_floats": ([C.POINTER(PolicyDesc), _I], C.c_int64),
     "ia_ppo_update_xcd_pack": ([_I], C.c_int),
+    "ia_ppo_update_assume_cus": ([_I], C.c_int),
     "ia_ppo_update": ([C.POINTER(PolicyDesc), _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F,
                        _F, _F, _F, _P, _P, _D, _D, _D, _F, _L, _P, _P, _P], C.c_int),
 }

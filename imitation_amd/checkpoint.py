@@ -135,7 +135,12 @@ def load_policy_zip(path, algo_or_policy, load_optimizer: bool = True) -> Dict[s
     return data
 
 
-def save_reward_net(path, net: reward_nets.RewardNet) -> None:
+def save_reward_net(path, net) -> None:
+    if isinstance(net, th.nn.Module):
+        # an `nn.Module` reward net (imitation_amd.modules) is written the way the reference writes its own:
+        # `th.save(module, path)` (`scripts/train_adversarial.py:25-35`), readable by `th.load` + `.predict*`
+        th.save(net, str(path))
+        return
     chain, n = [], net
     while n is not None:
         chain.append(type(n).__name__)
@@ -143,8 +148,10 @@ def save_reward_net(path, net: reward_nets.RewardNet) -> None:
     th.save({"class": chain[0], "wrapper_chain": chain, "state_dict": _cpu(net.state_dict())}, str(path))
 
 
-def load_reward_net(path, net: reward_nets.RewardNet) -> None:
+def load_reward_net(path, net) -> None:
     blob = th.load(str(path), map_location="cpu", weights_only=False)
+    if isinstance(blob, th.nn.Module):
+        blob = blob.state_dict()
     net.load_state_dict(blob["state_dict"] if isinstance(blob, dict) and "state_dict" in blob else blob)
 
 
@@ -175,6 +182,16 @@ def _set_env_state(venv, state) -> None:
         base.set_state(state)
 
 
+def _cpu_nested(x):
+    if isinstance(x, th.Tensor):
+        return x.detach().cpu()
+    if isinstance(x, dict):
+        return {k: _cpu_nested(v) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return type(x)(_cpu_nested(v) for v in x)
+    return x
+
+
 def save_checkpoint(trainer, path) -> None:
     """Complete training state at a round boundary (call between `train()` calls)."""
     algo = trainer.gen_algo
@@ -186,7 +203,10 @@ def save_checkpoint(trainer, path) -> None:
     blob = {
         "format": 1,
         "reward_net": _cpu(net.state_dict()),
-        "disc_opt": {"step": opt.step_count, "exp_avg": opt.exp_avg.cpu(), "exp_avg_sq": opt.exp_avg_sq.cpu()},
+        # the fused flat-buffer Adam keeps (step, exp_avg, exp_avg_sq); any torch optimiser (a `disc_opt_cls` other than
+        # Adam, or the optimiser of an `nn.Module` reward net) goes through its own state_dict
+        "disc_opt": ({"step": opt.step_count, "exp_avg": opt.exp_avg.cpu(), "exp_avg_sq": opt.exp_avg_sq.cpu()}
+                     if hasattr(opt, "step_count") else {"torch_state_dict": _cpu_nested(opt.state_dict())}),
         "policy": _cpu(algo.policy.state_dict()),
         "policy_opt": {"step": algo.policy.optimizer.step_count, "exp_avg": algo.policy.optimizer.exp_avg.cpu(),
                        "exp_avg_sq": algo.policy.optimizer.exp_avg_sq.cpu()},
@@ -224,9 +244,12 @@ def load_checkpoint(trainer, path) -> None:
     dev = trainer._device
     trainer._reward_net.load_state_dict(blob["reward_net"])
     o = trainer._disc_opt
-    o.step_count = int(blob["disc_opt"]["step"])
-    o.exp_avg.copy_(blob["disc_opt"]["exp_avg"].to(dev))
-    o.exp_avg_sq.copy_(blob["disc_opt"]["exp_avg_sq"].to(dev))
+    if "torch_state_dict" in blob["disc_opt"]:
+        o.load_state_dict(blob["disc_opt"]["torch_state_dict"])  # torch moves the state to the parameters' device
+    else:
+        o.step_count = int(blob["disc_opt"]["step"])
+        o.exp_avg.copy_(blob["disc_opt"]["exp_avg"].to(dev))
+        o.exp_avg_sq.copy_(blob["disc_opt"]["exp_avg_sq"].to(dev))
     algo.policy.load_state_dict(blob["policy"])
     po = algo.policy.optimizer
     po.step_count = int(blob["policy_opt"]["step"])

@@ -3104,6 +3104,8 @@ struct HostTab { float* buf = nullptr; hipEvent_t done; };
 HostTab g_host_tab[HOST_TAB_SLOTS];
 int g_host_tab_next = 0;
 int ia_ppo_update_xcd_pack(int on) { g_upd_xcd_pack = on != 0; return IA_OK; }
+int g_upd_assume_cus = 0;
+int ia_ppo_update_assume_cus(int n) { g_upd_assume_cus = n; return IA_OK; }
 
 // A whole PPO.train: n_epochs passes over consecutive minibatches of perm[e][T*n_envs] (SB3
 // RolloutBuffer.get order), in ONE persistent launch per <= UPD_MAX_STEPS optimiser steps.
@@ -3178,6 +3180,31 @@ int ia_ppo_update(const ia_policy_desc* d, float* params, float* params_t, float
     const int n_slices = (batch_size > UPD_SLICE && total < (1ll << 31)) ? cdiv(batch_size, UPD_SLICE) : 0;
     const bool pack = g_upd_xcd_pack && nblk + 1 + n_slices <= 32;
     const int grid = (nblk + 1 + n_slices) * (pack ? 8 : 1);
+    {
+      // The grid barriers inside need every workgroup resident at once. A plain launch performs no such check
+      // (and a cooperative launch costs +15-19 us per launch, MI355X_MICROARCH.md "coop-launch"), so the same
+      // test is made here: workgroups per CU by the occupancy query (LDS-bound: one) times the CU count.
+      // Not enough room -> IA_ERR_UNSUPPORTED, the caller runs ia_ppo_epoch (two launches per minibatch).
+      static int dev_cus = 0, per_cu[4] = {-1, -1, -1, -1};
+      static size_t per_cu_bytes[4] = {0, 0, 0, 0};
+      const int vi = wide * 2 + timing;
+      if (dev_cus == 0) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess ||
+            hipDeviceGetAttribute(&dev_cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+          return IA_ERR_ARG;
+      }
+      const int cu_count = g_upd_assume_cus > 0 ? g_upd_assume_cus : dev_cus;
+      if (per_cu[vi] < 0 || per_cu_bytes[vi] != bytes) {
+        int nb = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(kernel), 512, bytes) !=
+            hipSuccess)
+          return IA_ERR_ARG;
+        per_cu[vi] = nb;
+        per_cu_bytes[vi] = bytes;
+      }
+      if ((long long)per_cu[vi] * cu_count < (pack ? grid / 8 : grid)) return IA_ERR_UNSUPPORTED;
+    }
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(512), bytes, st, *d, params, params_t, exp_avg,
                        exp_avg_sq, norm_mean, norm_var, norm_count, update_norm, obs, actions, old_logp, advantages,
                        returns, perm, T, n_envs, normalize_adv, clip_range, ent_coef, vf_coef, max_grad_norm,

@@ -342,6 +342,7 @@ class PPO(OnPolicyAlgorithm):
         # work with it and later calls `finalize_train()` (one D2H of the statistics + logging).
         self.defer_train_stats = False
         self._pending_train = None
+        self._h_upd_err, self._upd_err_pending = None, False
         # called (if set) after the last env step of a rollout and before the reward relabelling -- the
         # first point of a rollout that depends on the discriminator (see AdversarialTrainer.train)
         self.before_relabel = None
@@ -534,6 +535,7 @@ class PPO(OnPolicyAlgorithm):
             act_stream.synchronize()       # (so everything the act kernels wrote is complete before `stream` reads it)
             if t == 0:
                 t_first_step = tick()      # the previous update has finished: the device is free from here on
+                self._check_update_error()
             t3 = tick() if prof is not None else 0.0
             acts_np = h_clip_np[t]
             acts_np = acts_np.reshape(n).astype(np.int64) if pol.discrete else acts_np.reshape(
@@ -746,6 +748,10 @@ class PPO(OnPolicyAlgorithm):
     # ---- PPO update (App. A.7) ----------------------------------------------------------------
     def train(self, record_lr: bool = True):
         pol, rb = self.policy, self.rollout_buffer
+        if self._pending_train is not None:
+            # a deferred record nobody has collected yet (`learn` spanning several iterations inside one
+            # `train_gen`): log it now, in order, instead of overwriting it (the reference logs every iteration)
+            self.finalize_train()
         pol.set_training_mode(True)
         lr = self.lr_schedule(self._current_progress_remaining)
         if record_lr:
@@ -780,17 +786,30 @@ class PPO(OnPolicyAlgorithm):
         if single and self._upd_ws is not None:
             if self.update_events is not None:  # measurement hook (bench.py): events on the launch stream
                 self.update_events[0].record()
-            L.call("ia_ppo_update", C.byref(pol.desc), L.ptr(pol._flat), L.ptr(pol._flat_t),
-                   L.ptr(rn.running_mean) if rn else None, L.ptr(rn.running_var) if rn else None,
-                   L.ptr(rn.count) if rn else None, int(rn is not None), L.ptr(rb.obs), L.ptr(rb.acts), L.ptr(rb.logp),
-                   L.ptr(rb.adv), L.ptr(rb.ret), L.ptr(self._perm_dev), self.n_epochs, T, n, min(self.batch_size, T * n),
-                   int(self.normalize_advantage), float(clip_range), float(self.ent_coef), float(self.vf_coef),
-                   float(self.max_grad_norm), L.ptr(pol.optimizer.exp_avg), L.ptr(pol.optimizer.exp_avg_sq),
-                   float(lr), float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]), pol.optimizer.step_count,
-                   L.ptr(self._upd_ws), L.ptr(stats_dev), L.stream())
-            if self.update_events is not None:
-                self.update_events[1].record()
-            pol.optimizer.step_count += self.n_epochs * self._n_mb
+            rc = L.load().ia_ppo_update(
+                C.byref(pol.desc), L.ptr(pol._flat), L.ptr(pol._flat_t),
+                L.ptr(rn.running_mean) if rn else None, L.ptr(rn.running_var) if rn else None,
+                L.ptr(rn.count) if rn else None, int(rn is not None), L.ptr(rb.obs), L.ptr(rb.acts), L.ptr(rb.logp),
+                L.ptr(rb.adv), L.ptr(rb.ret), L.ptr(self._perm_dev), self.n_epochs, T, n, min(self.batch_size, T * n),
+                int(self.normalize_advantage), float(clip_range), float(self.ent_coef), float(self.vf_coef),
+                float(self.max_grad_norm), L.ptr(pol.optimizer.exp_avg), L.ptr(pol.optimizer.exp_avg_sq),
+                float(lr), float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]), pol.optimizer.step_count,
+                L.ptr(self._upd_ws), L.ptr(stats_dev), L.stream())
+            if rc == L.ERR_UNSUPPORTED:
+                # not every workgroup of the persistent kernel would be resident at once on this device (its grid
+                # barriers need that): nothing was launched; this and all later updates take the per-epoch kernels
+                self._upd_ws = None
+            else:
+                L.check(rc, "ia_ppo_update")
+                if self.update_events is not None:
+                    self.update_events[1].record()
+                pol.optimizer.step_count += self.n_epochs * self._n_mb
+                # sticky error word of the launch -> pinned host word, checked before the next rollout acts on the
+                # updated parameters (`_check_update_error`)
+                if self._h_upd_err is None:
+                    self._h_upd_err = th.zeros(1, dtype=th.int32).pin_memory()
+                self._h_upd_err.copy_(self._upd_ws[8:9].view(th.int32), non_blocking=True)
+                self._upd_err_pending = True
         for e in range(self.n_epochs if (single and self._upd_ws is None) else 0):
             L.call("ia_ppo_epoch", C.byref(pol.desc), L.ptr(pol._flat), L.ptr(pol._flat_t),
                    L.ptr(rn.running_mean) if rn else None, L.ptr(rn.running_var) if rn else None,
@@ -816,6 +835,17 @@ class PPO(OnPolicyAlgorithm):
             self._pending_train = clip_range
             self.finalize_train()
         return lr
+
+    def _check_update_error(self) -> None:
+        """After a synchronisation that covers the last `ia_ppo_update`: raise (and clear the sticky device word)
+        if a grid-wide wait inside it timed out -- BEFORE a rollout acts on parameters it left half-updated."""
+        if not self._upd_err_pending:
+            return
+        self._upd_err_pending = False
+        if int(self._h_upd_err[0]) != 0:
+            self._upd_ws[8:9].zero_()
+            raise RuntimeError("ia_ppo_update: a grid-wide wait timed out inside the persistent PPO kernel (its "
+                               "workgroups were not co-resident); the parameters of this update are invalid")
 
     def finalize_train(self) -> None:
         """Statistics read-back + logging of the last `train()` (SB3 PPO.train's logger block)."""

@@ -125,9 +125,11 @@ class _StepLog:
     def cut(self, first_obs, s: int, e: int, env: int, terminal: bool) -> dt.TrajectoryWithRew:
         """Steps s..e (inclusive) of `env` as one trajectory starting from `first_obs`."""
         obs = np.concatenate([first_obs[None], self.nxt[s:e + 1, env]])
+        # per trajectory: Monitor-style wrappers report content ('episode', 'rollout') on the done step only, so a
+        # step's list may be missing (nothing beyond what the trajectory already encodes) -- those steps get {}
         infos = None
-        if self.infos[s] is not None:
-            infos = np.array([self.infos[t][env] for t in range(s, e + 1)])
+        if any(self.infos[t] is not None for t in range(s, e + 1)):
+            infos = np.array([self.infos[t][env] if self.infos[t] is not None else {} for t in range(s, e + 1)])
         return dt.TrajectoryWithRew(obs=obs, acts=self.acts[s:e + 1, env].copy(),
                                     rews=self.rews[s:e + 1, env].astype(np.float64 if not np.issubdtype(
                                         self.rews.dtype, np.floating) else self.rews.dtype), infos=infos,

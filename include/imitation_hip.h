@@ -311,6 +311,10 @@ int ia_ppo_epoch(const ia_policy_desc* d, float* params, float* params_t, float*
  * spread over all XCDs, which measured faster). */
 int64_t ia_ppo_update_ws_floats(const ia_policy_desc* d, int batch_size);
 int ia_ppo_update_xcd_pack(int on);
+/* ia_ppo_update returns IA_ERR_UNSUPPORTED (-2) without launching when its workgroups (which meet at grid
+ * barriers) would not all be resident at once: occupancy query x compute units < grid. Tests: pretend the
+ * device has n compute units (0 = ask the device). */
+int ia_ppo_update_assume_cus(int n);
 int ia_ppo_update(const ia_policy_desc* d, float* params, float* params_t, float* norm_mean, float* norm_var,
                   int32_t* norm_count, int update_norm, const float* obs, const float* actions, const float* old_logp,
                   const float* advantages, const float* returns, const int64_t* perm, int n_epochs, int T, int n_envs,

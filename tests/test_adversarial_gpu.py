@@ -119,6 +119,33 @@ def test_pipelined_rounds_are_bit_identical(tmp_path, case):
     assert len(logs[True]["progress.csv"]) == 4
 
 
+def test_persistent_update_refuses_a_grid_that_cannot_be_resident(tmp_path):
+    """`ia_ppo_update` meets at grid barriers, so every workgroup must be resident at once. The entry point checks
+    occupancy x compute units against its grid and returns IA_ERR_UNSUPPORTED instead of launching; `PPO.train` then
+    takes the per-epoch kernels for good. Provoked by pretending the device has ONE compute unit: the run must
+    still match the reference golden (round-1 advisor finding: no residency check before a spinning barrier)."""
+    from imitation_amd import _lib as L
+
+    cfg = harness.CASES["gail_box"]
+    gold = dict(np.load(os.path.join(GOLDEN, "gail_box.npz")))
+    L.load().ia_ppo_update_assume_cus(1)
+    try:
+        tr, _ = harness.build_trainer("hip", cfg, str(tmp_path), device="cuda")
+        assert tr.gen_algo._upd_ws is not None, "the persistent kernel covers this shape"
+        tr.train(cfg["rounds"] * cfg["n_envs"] * cfg["n_steps"])
+        assert tr.gen_algo._upd_ws is None, "ia_ppo_update must have refused the launch"
+        got = harness.snapshot(tr)
+    finally:
+        L.load().ia_ppo_update_assume_cus(0)
+    for key in got:
+        x, y = np.asarray(got[key]), np.asarray(gold[key])
+        if key in harness.EXACT_KEYS or y.dtype.kind in "biu":
+            assert np.array_equal(x, y), key
+        else:
+            np.testing.assert_allclose(x.astype(np.float64), y.astype(np.float64), rtol=2e-4, atol=5e-5,
+                                       equal_nan=True, err_msg=key)
+
+
 def test_discrete_actions_fast_sampler_structural(tmp_path):
     """Discrete heads default to the reference's own sampling call (torch.multinomial on the global
     generator: `gail_discrete` is compared value by value above). The opt-in in-kernel sampler

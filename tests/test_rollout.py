@@ -139,6 +139,54 @@ def test_monitor_returns_are_reported_when_infos_carry_them():
     assert st["monitor_return_len"] == 2 and st["monitor_return_mean"] == 7.5 and st["return_mean"] == 2.0
 
 
+def test_monitor_infos_only_on_done_steps_with_unequal_episode_lengths():
+    """A generic VecEnv whose Monitor-style wrapper reports `episode` on the done step only, episodes of lengths
+    3 and 4 running side by side (round-1 advisor finding: the infos of a trajectory were taken from its FIRST step
+    alone -- dropped when that step had none, a TypeError when a later step had none)."""
+    from imitation_amd import spaces
+    from imitation_amd.vec_env import VecEnv
+
+    class MonitoredEnv(VecEnv):
+        lens = (3, 4)
+
+        def __init__(self):
+            super().__init__(2, spaces.Box(-1, 1, (2,)), spaces.Box(-1, 1, (1,)))
+            self.t = np.zeros(2, dtype=int)
+            self.ret = np.zeros(2)
+
+        def reset(self):
+            self.t[:], self.ret[:] = 0, 0
+            return np.zeros((2, 2), np.float32)
+
+        def step_async(self, actions):
+            self._a = actions
+
+        def step_wait(self):
+            self.t += 1
+            rews = np.asarray([1.0, 2.0])
+            self.ret += rews
+            obs = np.stack([np.full(2, self.t[i], np.float32) for i in range(2)])
+            dones = np.asarray([self.t[i] == self.lens[i] for i in range(2)])
+            infos = [{}, {}]
+            for i in np.flatnonzero(dones):
+                infos[i] = {"terminal_observation": obs[i].copy(), "episode": {"r": float(self.ret[i]), "l": int(self.t[i])}}
+                obs[i] = 0
+                self.t[i], self.ret[i] = 0, 0
+            return obs, rews, dones, infos
+
+    policy = lambda obs, state, starts: (np.zeros((2, 1), np.float32), None)  # noqa: E731
+    trajs = rollout.generate_trajectories(policy, MonitoredEnv(), rollout.make_sample_until(min_episodes=5),
+                                          rng=np.random.default_rng(0))
+    assert len(trajs) >= 5
+    for t in trajs:
+        assert t.infos is not None and len(t.infos) == len(t.acts)
+        assert all(i == {} for i in t.infos[:-1])
+        assert t.infos[-1]["episode"]["l"] == len(t.acts) and len(t.acts) in (3, 4)
+        assert t.infos[-1]["episode"]["r"] == float(sum(t.rews))
+    st = rollout.rollout_stats(trajs)
+    assert st["monitor_return_min"] == 3.0 and st["monitor_return_max"] == 8.0
+
+
 # ------------------------------------------------------------------------------------- GPU
 
 
