@@ -31,10 +31,13 @@ class DataParallel:
         # `gloo` (CPU tests, or several ranks sharing one GPU in the single-GPU test) moves device
         # buffers through the host; `nccl` (= RCCL) works on them in place over xGMI.
         self._stage = dist.get_backend(group) == "gloo"
+        # collectives are issued from this world size on (a single rank needs none; tests lower it to 1 so that
+        # the RCCL branches execute on a one-GPU box)
+        self._min_world = 2
 
     def allreduce_mean_(self, flat: th.Tensor) -> th.Tensor:
         """In-place mean over ranks of one flat bucket."""
-        if self.world > 1:
+        if self.world >= self._min_world:
             if self._stage and flat.is_cuda:
                 h = flat.cpu()
                 dist.all_reduce(h, op=dist.ReduceOp.SUM, group=self.group)
@@ -45,7 +48,7 @@ class DataParallel:
         return flat
 
     def broadcast_(self, tensors: List[th.Tensor], src: int = 0) -> None:
-        if self.world > 1:
+        if self.world >= self._min_world:
             for t in tensors:
                 if self._stage and t.is_cuda:
                     h = t.cpu()
@@ -55,20 +58,18 @@ class DataParallel:
                     dist.broadcast(t, src=src, group=self.group)
 
     def shared_seed(self) -> int:
-        """One random 31-bit integer agreed on by every rank (drawn by rank 0)."""
+        """One random 31-bit integer agreed on by every rank (drawn by rank 0). The value travels in a tensor on
+        the backend's own device -- host memory for gloo, device memory for RCCL (which has no CPU collectives)."""
         t = th.randint(0, 2 ** 31 - 1, (1,), dtype=th.int64)
-        if self.world > 1:
-            dist.broadcast(t, src=0, group=self.group) if self._stage else self._bcast_dev(t)
+        if self.world >= self._min_world:
+            buf = t if self._stage else t.cuda()
+            dist.broadcast(buf, src=0, group=self.group)
+            t = buf.cpu()
         return int(t.item())
-
-    def _bcast_dev(self, t: th.Tensor) -> None:
-        d = t.cuda()
-        dist.broadcast(d, src=0, group=self.group)
-        t.copy_(d.cpu())
 
     def all_gather_flat(self, local: th.Tensor) -> th.Tensor:
         """Concatenation of every rank's (equally sized) 1-D buffer, in rank order."""
-        if self.world == 1:
+        if self.world < self._min_world:
             return local
         if self._stage:
             parts = [th.empty(local.numel(), dtype=local.dtype) for _ in range(self.world)]

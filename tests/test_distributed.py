@@ -155,3 +155,199 @@ def test_two_ranks_one_gpu_replicas_identical(tmp_path):
     # every rank contributed: disc input norm saw world * (2 rounds * 2 updates * 128 rows)
     assert int(a["disc/mlp.normalize_input.count"]) == 2 * 2 * 2 * 128
     assert int(g0["disc/mlp.normalize_input.count"]) == 2 * 3 * 2 * 128
+
+
+# ---------------------------------------------------------------------------------------------------
+# What single-process run does a world-W run equal?
+#   PPO   : n_envs' = W * n_envs (the env batches side by side, rank order), batch_size' = W * batch_size,
+#           the data-parallel run's own permutation stream -- [SB3 PPO.train] on that rollout;
+#   disc  : demo_batch_size' = W * demo_batch_size with expert / generator batches = the ranks' batches
+#           concatenated -- `train_disc` on that batch (mean-reduced BCE: the rank-mean of per-rank mean
+#           gradients IS the gradient of the global mean; moments merged over all rows).
+
+def _equiv_worker(rank, world, port, out_dir):
+    _init(rank, world, port)
+    th.cuda.set_device(0)
+    th.set_num_threads(1)
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import imitation_amd as p
+    from imitation_amd.distributed import DataParallel
+    from imitation_amd.vec_env import SyntheticVecEnv
+    from tests import harness
+    cfg = harness.CASES["gail_box"]
+    th.manual_seed(100 + rank)
+    np.random.seed(100 + rank)
+    venv = SyntheticVecEnv(num_envs=cfg["n_envs"], obs_dim=17, act_dim=6, horizon=cfg["horizon"], seed=rank)
+    pk = dict(features_extractor_class=p.NormalizeFeaturesExtractor,
+              features_extractor_kwargs=dict(normalize_class=p.RunningNorm))
+    algo = p.PPO(p.FeedForward32Policy, venv, n_steps=cfg["n_steps"], batch_size=cfg["ppo_batch"], n_epochs=2,
+                 ent_coef=0.1, policy_kwargs=pk, device="cuda")
+    algo.dp_global_minibatch = True
+    net = p.BasicRewardNet(venv.observation_space, venv.action_space, hid_sizes=(32, 32),
+                           normalize_input_layer=p.RunningNorm)
+    demos = p.Transitions(**harness.make_demo_arrays(cfg, seed=1 + rank))
+    tr = p.GAIL(demonstrations=demos, demo_batch_size=64, venv=venv, gen_algo=algo, reward_net=net,
+                n_disc_updates_per_round=2, custom_logger=p.configure_logger(tempfile.mkdtemp(), []),
+                data_parallel=DataParallel())
+    tr.pipeline_rounds = False
+    out = {}
+    # ---- discriminator: three updates on explicit per-rank batches
+    cpu = lambda sd: {k: v.detach().cpu().clone() for k, v in sd.items()}
+    out["disc_pre"] = cpu(tr._reward_net.state_dict())
+    rng = np.random.default_rng(200 + rank)
+    out["batches"] = []
+    for _ in range(3):
+        mk = lambda: dict(obs=rng.standard_normal((64, 17)).astype(np.float32),
+                          acts=rng.uniform(-1, 1, (64, 6)).astype(np.float32),
+                          next_obs=rng.standard_normal((64, 17)).astype(np.float32), dones=rng.random(64) < 0.1)
+        e, g = mk(), mk()
+        out["batches"].append((e, g))
+        tr.train_disc(expert_samples=e, gen_samples=g)
+    out["disc_post"] = cpu(tr._reward_net.state_dict())
+    out["pol_norm_post_disc"] = cpu(algo.policy.features_extractor.normalize.state_dict())
+    # ---- generator: one rollout + the data-parallel PPO update on the gathered tile
+    orig_train = algo.train
+
+    def hooked(*a, **k):
+        th.cuda.synchronize()
+        out["pol_pre"] = cpu(algo.policy.state_dict())
+        return orig_train(*a, **k)
+
+    algo.train = hooked
+    tr.train_gen()
+    th.cuda.synchronize()
+    out["pol_post"] = cpu(algo.policy.state_dict())
+    g = algo._dpg
+    out["tile"] = {k: g[k].cpu().clone() for k in ("obs", "acts", "logp", "adv", "ret")}
+    out["perm"] = g["perm_dev"].cpu().clone()
+    out["hyper"] = dict(T=cfg["n_steps"], n=cfg["n_envs"], bs=cfg["ppo_batch"], n_epochs=2, ent_coef=0.1)
+    th.save(out, os.path.join(out_dir, f"equiv{rank}.pt"))
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_world_two_equals_single_process_on_the_concatenated_batch(tmp_path):
+    if not th.cuda.is_available():
+        pytest.skip("no GPU")
+    port = _free_port()
+    mp.spawn(_equiv_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0 = th.load(tmp_path / "equiv0.pt", weights_only=False)
+    r1 = th.load(tmp_path / "equiv1.pt", weights_only=False)
+    for k in r0["disc_post"]:
+        assert th.equal(r0["disc_post"][k], r1["disc_post"][k]), k
+    for k in r0["pol_post"]:
+        assert th.equal(r0["pol_post"][k], r1["pol_post"][k]), k
+
+    # ---- (1) PPO: world 2 == [SB3 PPO.train] restated, single process, on the side-by-side env batch with
+    #          batch_size 2 x 32 and the data-parallel run's permutations
+    from imitation_amd import spaces
+    from oracle import imitation_restated as o
+    from oracle import sb3_restated as sb
+    h = r0["hyper"]
+    T, n2, D, A = h["T"], 2 * h["n"], 17, 6
+    os_, as_ = spaces.Box(-np.inf, np.inf, (D,), np.float32), spaces.Box(-1, 1, (A,), np.float32)
+    pol = sb.ActorCriticPolicy(os_, as_, lambda _: 3e-4, net_arch=[32, 32], features_extractor_class=o.NormalizeFeaturesExtractor)
+    pol.load_state_dict(r0["pol_pre"])
+    algo = sb.PPO(sb.ActorCriticPolicy, None, n_steps=T, batch_size=2 * h["bs"], n_epochs=h["n_epochs"],
+                  ent_coef=h["ent_coef"], _init_setup_model=False)
+    algo.observation_space, algo.action_space, algo.n_envs = os_, as_, n2
+    algo.policy = pol
+    algo.lr_schedule, algo.clip_range = sb.constant_fn(3e-4), sb.constant_fn(0.2)
+    algo._logger = sb.Logger(None, [])
+    buf = sb.RolloutBuffer(T, os_, as_, gamma=0.99, gae_lambda=0.95, n_envs=n2)
+    t = r0["tile"]
+    buf.observations[:] = t["obs"].numpy()
+    buf.actions[:] = t["acts"].numpy()
+    buf.log_probs[:] = t["logp"].numpy()
+    buf.advantages[:] = t["adv"].numpy()
+    buf.returns[:] = t["ret"].numpy()
+    buf.values[:] = buf.returns - buf.advantages
+    buf.full = True
+    algo.rollout_buffer = buf
+    perms = [p_.numpy() for p_ in r0["perm"]]
+    real = np.random.permutation
+    it = iter(perms)
+    np.random.permutation = lambda n_: next(it)        # the shared-seed stream of the data-parallel run
+    try:
+        algo.train()
+    finally:
+        np.random.permutation = real
+    k = h["n_epochs"] * (T * n2 // (2 * h["bs"]))
+    for name, ref in pol.state_dict().items():
+        got = r0["pol_post"][name]
+        if name.endswith("count"):
+            assert int(got) == int(ref), name
+        else:
+            th.testing.assert_close(got.float(), ref.float(), rtol=(1 + k) * 1e-5, atol=(1 + k) * 2e-6, msg=name)
+
+    # ---- (2) discriminator: world 2 == one process with demo_batch_size 2 x 64 on the concatenated batches
+    import imitation_amd as p
+    from imitation_amd.vec_env import SyntheticVecEnv
+    from tests import harness
+    cfg = harness.CASES["gail_box"]
+    th.manual_seed(100)
+    np.random.seed(100)   # rank 0's construction seeds: its initial weights are what the broadcast spread
+    venv = SyntheticVecEnv(num_envs=cfg["n_envs"], obs_dim=17, act_dim=6, horizon=cfg["horizon"], seed=0)
+    pk = dict(features_extractor_class=p.NormalizeFeaturesExtractor,
+              features_extractor_kwargs=dict(normalize_class=p.RunningNorm))
+    a1 = p.PPO(p.FeedForward32Policy, venv, n_steps=cfg["n_steps"], batch_size=cfg["ppo_batch"], n_epochs=2,
+               ent_coef=0.1, policy_kwargs=pk, device="cuda")
+    net = p.BasicRewardNet(venv.observation_space, venv.action_space, hid_sizes=(32, 32),
+                           normalize_input_layer=p.RunningNorm)
+    tr = p.GAIL(demonstrations=p.Transitions(**harness.make_demo_arrays(cfg, seed=1)), demo_batch_size=128, venv=venv,
+                gen_algo=a1, reward_net=net, n_disc_updates_per_round=2,
+                custom_logger=p.configure_logger(str(tmp_path / "single"), []))
+    for kk, v in tr._reward_net.state_dict().items():
+        assert th.equal(v.cpu(), r0["disc_pre"][kk]), kk          # same starting point
+    cat = lambda a, b: {kk: np.concatenate([a[kk], b[kk]]) for kk in a}
+    for (e0, g0), (e1, g1) in zip(r0["batches"], r1["batches"]):
+        tr.train_disc(expert_samples=cat(e0, e1), gen_samples=cat(g0, g1))
+    for kk, v in tr._reward_net.state_dict().items():
+        if kk.endswith("count"):
+            assert int(v) == int(r0["disc_post"][kk]), kk
+        else:
+            th.testing.assert_close(r0["disc_post"][kk], v.cpu(), rtol=2e-4, atol=5e-5, msg=kk)
+    rn = a1.policy.features_extractor.normalize.state_dict()
+    for kk, v in rn.items():   # the policy-feature-norm side effect of the updates (App. C.2) merges over all rows too
+        if kk.endswith("count"):
+            assert int(v) == int(r0["pol_norm_post_disc"][kk]), kk
+        else:
+            th.testing.assert_close(r0["pol_norm_post_disc"][kk], v.cpu(), rtol=2e-4, atol=5e-5, msg=kk)
+
+
+def _rccl_worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    th.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=th.device("cuda", 0))
+    from imitation_amd.distributed import DataParallel
+    dp = DataParallel()
+    assert not dp._stage, "nccl (= RCCL) works on device buffers in place"
+    dp._min_world = 1                     # issue the collectives although one rank needs none
+    flat = th.arange(1000, dtype=th.float32, device="cuda")
+    ref = flat.clone()
+    dp.allreduce_mean_(flat)
+    assert th.equal(flat, ref)
+    g = dp.all_gather_flat(ref)
+    assert g.is_cuda and th.equal(g, ref)
+    t = th.full((7,), 3.0, device="cuda")
+    dp.broadcast_([t])
+    assert th.all(t == 3.0)
+    s = dp.shared_seed()
+    assert 0 <= s < 2 ** 31
+    th.cuda.synchronize()
+    open(os.path.join(out_dir, "rccl_ok"), "w").write("ok")
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_rccl_branches_execute_on_one_gpu(tmp_path):
+    """Backend `nccl` (= RCCL on ROCm) with a world of one on the box's single GPU: every `DataParallel` method
+    goes through its device-buffer branch (all_reduce, all_gather_into_tensor, broadcast, the shared seed on a
+    device tensor) -- the code the 8-GPU run executes, minus the second peer."""
+    if not th.cuda.is_available():
+        pytest.skip("no GPU")
+    port = _free_port()
+    mp.spawn(_rccl_worker, args=(1, port, str(tmp_path)), nprocs=1, join=True)
+    assert os.path.exists(tmp_path / "rccl_ok")
