@@ -61,6 +61,11 @@ _SIGS = {
     "ia_im2col_u8_nchw": ([_P, _I, _I, _I, _I, _I, _I, _I, _F, _P, _P], C.c_int),
     "ia_im2col_f32_nhwc": ([_P, _I, _I, _I, _I, _I, _I, _I, _P, _P], C.c_int),
     "ia_col2im_nhwc": ([_P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P], C.c_int),
+    "ia_im2col_f32_nhwc_pad": ([_P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P], C.c_int),
+    "ia_col2im_nhwc_pad": ([_P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P], C.c_int),
+    "ia_relu_backward": ([_P, _P, _L, _P, _P], C.c_int),
+    "ia_avgpool_nhwc": ([_P, _I, _I, _I, _P, _P], C.c_int),
+    "ia_avgpool_nhwc_backward": ([_P, _I, _I, _I, _P, _P], C.c_int),
     "ia_categorical_loss": ([_P, _I, _P, _I, _I, _F, _F, _P, _P, _P, _P], C.c_int),
     "ia_mlp_param_count": ([C.POINTER(MlpDesc)], C.c_int64),
     "ia_mlp_hidden_floats_per_row": ([C.POINTER(MlpDesc)], C.c_int64),

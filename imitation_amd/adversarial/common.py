@@ -528,8 +528,11 @@ class AdversarialTrainer(abc.ABC):
             d = table.dones[idx] if idx is not None else table.dones[:n]
             cols["dones"].append(d.to(th.float32))
         cat = {k: th.cat(v) for k, v in cols.items()}
-        shp = tuple(self.venv.observation_space.shape)
-        return (cat["obs"].reshape(-1, *shp), cat["acts"], cat["next_obs"].reshape(-1, *shp), cat["dones"])
+        osp = self.venv.observation_space
+        norm = getattr(self._reward_net, "normalize_images", True)
+        # [SB3 preprocess_obs] (`rewards/reward_nets.py:90-110`): image spaces are scaled by 1 / 255, others are float
+        img = lambda t: reward_nets.preprocess_space(t.reshape(-1, *osp.shape), osp, norm)
+        return img(cat["obs"]), cat["acts"], img(cat["next_obs"]), cat["dones"]
 
     def _disc_update_module(self, e_src, g_src, stats_dev: th.Tensor, quirk_done: bool) -> None:
         """`train_disc` (`common.py:317-374`) for an `nn.Module` reward net: zero_grad, per minibatch

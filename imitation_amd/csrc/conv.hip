@@ -175,6 +175,81 @@ __global__ void categorical_loss_kernel(const float* __restrict__ logits, int ld
   }
 }
 
+// ---- padded convolutions of the reward CNN (util/networks.py:286-357 `build_cnn`: Conv2d(k, stride, padding) -
+// ReLU ..., AdaptiveAvgPool2d(1), Linear). Same im2col / GEMM / col2im scheme with a zero border of P pixels
+// resolved in the index arithmetic (no padded copy of the activations).
+
+// col[m = (b, oh, ow)][k = (i, j, c)] = x[b, oh*S + i - P, ow*S + j - P, c] (0 outside the image); x channel-last
+__global__ void im2col_f32_nhwc_pad_kernel(const float* __restrict__ x, int C, int H, int W, int KH, int KW, int S,
+                                           int P, int OH, int OW, float* __restrict__ col, long long total) {
+  const int K = C * KH * KW;
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+    const int k = (int)(e % K);
+    const long long m = e / K;
+    const int c = k % C, ij = k / C;
+    const int i = ij / KW, j = ij - i * KW;
+    const int p = (int)(m % ((long long)OH * OW));
+    const long long b = m / ((long long)OH * OW);
+    const int oh = p / OW, ow = p - oh * OW;
+    const int h = oh * S + i - P, w = ow * S + j - P;
+    col[e] = (h >= 0 && h < H && w >= 0 && w < W) ? x[((b * H + h) * W + w) * C + c] : 0.f;
+  }
+}
+
+// dx[b, h, w, c] = sum over the windows (oh, ow, i, j) with oh*S + i - P == h, ow*S + j - P == w, in (i, j) order
+__global__ void col2im_nhwc_pad_kernel(const float* __restrict__ dcol, int C, int H, int W, int KH, int KW, int S,
+                                       int P, int OH, int OW, float* __restrict__ dx, long long total) {
+  const int K = C * KH * KW;
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(e % C);
+    const long long t = e / C;
+    const int w = (int)(t % W);
+    const long long t2 = t / W;
+    const int h = (int)(t2 % H);
+    const long long b = t2 / H;
+    const int hp = h + P, wp = w + P;   // position in the (virtually) padded image
+    float s = 0.f;
+    const int oh_hi = min(hp / S, OH - 1), oh_lo = max(0, (hp - KH + S) / S);
+    const int ow_hi = min(wp / S, OW - 1), ow_lo = max(0, (wp - KW + S) / S);
+    for (int oh = oh_hi; oh >= oh_lo; --oh) {
+      const int i = hp - oh * S;
+      for (int ow = ow_hi; ow >= ow_lo; --ow) {
+        const int j = wp - ow * S;
+        s += dcol[((b * OH + oh) * OW + ow) * (long long)K + (i * KW + j) * C + c];
+      }
+    }
+    dx[e] = s;
+  }
+}
+
+__global__ void relu_backward_kernel(const float* __restrict__ dy, const float* __restrict__ y, long long n,
+                                     float* __restrict__ out) {
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long long)gridDim.x * blockDim.x)
+    out[e] = y[e] > 0.f ? dy[e] : 0.f;
+}
+
+// out[b, c] = mean over the HW positions of y[b, :, c] (AdaptiveAvgPool2d(1) on channel-last activations): one
+// block per image, threads over channels (consecutive c: coalesced rows), positions summed in order.
+__global__ __launch_bounds__(256) void avgpool_nhwc_kernel(const float* __restrict__ y, int HW, int C,
+                                                           float* __restrict__ out) {
+  const long long b = blockIdx.x;
+  for (int c = threadIdx.x; c < C; c += 256) {
+    const float* src = y + b * HW * C + c;
+    float s = 0.f;
+    for (int p = 0; p < HW; ++p) s += src[(long long)p * C];
+    out[b * C + c] = s / (float)HW;
+  }
+}
+
+__global__ void avgpool_nhwc_backward_kernel(const float* __restrict__ dout, int HW, int C, float* __restrict__ dy,
+                                             long long total) {
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(e % C);
+    const long long b = e / ((long long)HW * C);
+    dy[e] = dout[b * C + c] / (float)HW;
+  }
+}
+
 inline dim3 stream_grid(long long total) {
   const long long blocks = (total + 255) / 256;
   return dim3((unsigned)(blocks < 65536 * 4 ? (blocks > 0 ? blocks : 1) : 65536 * 4));
@@ -222,6 +297,53 @@ int ia_col2im_nhwc(const float* dcol, int B, int H, int W, int C, int KH, int KW
   const long long total = (long long)B * H * W * C;
   hipLaunchKernelGGL(col2im_nhwc_kernel, stream_grid(total), dim3(256), 0, (hipStream_t)stream, dcol, C, H, W, KH, KW,
                      S, OH, OW, relu_mask, dx, total);
+  IA_CHECK_LAUNCH();
+  return IA_OK;
+}
+
+int ia_im2col_f32_nhwc_pad(const float* x, int B, int H, int W, int C, int KH, int KW, int S, int P, float* col,
+                           void* stream) {
+  if (!x || !col || B <= 0 || C <= 0 || KH <= 0 || KW <= 0 || S <= 0 || P < 0 || H + 2 * P < KH || W + 2 * P < KW)
+    return IA_ERR_ARG;
+  const int OH = (H + 2 * P - KH) / S + 1, OW = (W + 2 * P - KW) / S + 1;
+  const long long total = (long long)B * OH * OW * C * KH * KW;
+  hipLaunchKernelGGL(im2col_f32_nhwc_pad_kernel, stream_grid(total), dim3(256), 0, (hipStream_t)stream, x, C, H, W, KH,
+                     KW, S, P, OH, OW, col, total);
+  IA_CHECK_LAUNCH();
+  return IA_OK;
+}
+
+int ia_col2im_nhwc_pad(const float* dcol, int B, int H, int W, int C, int KH, int KW, int S, int P, float* dx,
+                       void* stream) {
+  if (!dcol || !dx || B <= 0 || C <= 0 || KH <= 0 || KW <= 0 || S <= 0 || P < 0 || H + 2 * P < KH || W + 2 * P < KW)
+    return IA_ERR_ARG;
+  const int OH = (H + 2 * P - KH) / S + 1, OW = (W + 2 * P - KW) / S + 1;
+  const long long total = (long long)B * H * W * C;
+  hipLaunchKernelGGL(col2im_nhwc_pad_kernel, stream_grid(total), dim3(256), 0, (hipStream_t)stream, dcol, C, H, W, KH,
+                     KW, S, P, OH, OW, dx, total);
+  IA_CHECK_LAUNCH();
+  return IA_OK;
+}
+
+int ia_relu_backward(const float* dy, const float* y, int64_t n, float* out, void* stream) {
+  if (!dy || !y || !out || n <= 0) return IA_ERR_ARG;
+  hipLaunchKernelGGL(relu_backward_kernel, stream_grid(n), dim3(256), 0, (hipStream_t)stream, dy, y, (long long)n, out);
+  IA_CHECK_LAUNCH();
+  return IA_OK;
+}
+
+int ia_avgpool_nhwc(const float* y, int B, int HW, int C, float* out, void* stream) {
+  if (!y || !out || B <= 0 || HW <= 0 || C <= 0) return IA_ERR_ARG;
+  hipLaunchKernelGGL(avgpool_nhwc_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, y, HW, C, out);
+  IA_CHECK_LAUNCH();
+  return IA_OK;
+}
+
+int ia_avgpool_nhwc_backward(const float* dout, int B, int HW, int C, float* dy, void* stream) {
+  if (!dout || !dy || B <= 0 || HW <= 0 || C <= 0) return IA_ERR_ARG;
+  const long long total = (long long)B * HW * C;
+  hipLaunchKernelGGL(avgpool_nhwc_backward_kernel, stream_grid(total), dim3(256), 0, (hipStream_t)stream, dout, HW, C,
+                     dy, total);
   IA_CHECK_LAUNCH();
   return IA_OK;
 }

@@ -194,6 +194,102 @@ class BasicRewardNet(RewardNet):
         return rew
 
 
+class Cnn(nn.Module):
+    """`build_cnn` (`util/networks.py:286-357`): `Conv2d(kernel_size, stride, padding) - activation` per hidden
+    channel count, `AdaptiveAvgPool2d(1)`, `Flatten`, `Linear(out_size)`. Children carry the reference's names
+    (`conv{i}`, `dense_final`) and torch's parameter layouts ([Cout, Cin, KH, KW]); `forward` takes channel-FIRST
+    input like the reference's, runs channel-last internally (im2col + MFMA GEMM per layer) and permutes the
+    weights on the fly."""
+
+    def __init__(self, in_channels: int, hid_channels: Iterable[int], out_size: int = 1, name: Optional[str] = None,
+                 activation: Type[nn.Module] = nn.ReLU, kernel_size: int = 3, stride: int = 1, padding="same",
+                 dropout_prob: float = 0.0, squeeze_output: bool = False):
+        super().__init__()
+        if dropout_prob > 0.0:
+            raise NotImplementedError("dropout is not built for HIP")
+        if activation is not nn.ReLU:
+            raise NotImplementedError("the HIP convolution fuses ReLU (the reference's default)")
+        if squeeze_output and out_size != 1:
+            raise ValueError("squeeze_output is only applicable when out_size=1")
+        if padding == "same":
+            if stride != 1 or kernel_size % 2 == 0:
+                raise ValueError("padding='same' needs stride 1 and an odd kernel (as torch.nn.Conv2d does)")
+            pad = kernel_size // 2
+        else:
+            pad = int(padding)
+        prefix = "" if name is None else f"{name}_"
+        self.stride, self.pad, self.squeeze_output = int(stride), pad, squeeze_output
+        self._convs = []
+        prev = int(in_channels)
+        for i, ch in enumerate(hid_channels):
+            self._convs.append(f"{prefix}conv{i}")
+            self.add_module(self._convs[-1], nn.Conv2d(prev, int(ch), kernel_size, stride=stride, padding=padding))
+            prev = int(ch)
+        self._final = f"{prefix}dense_final"
+        self.add_module(self._final, nn.Linear(prev, int(out_size)))
+        self.dims_final = [prev, int(out_size)]
+
+    def forward(self, x: th.Tensor) -> th.Tensor:
+        h = x.permute(0, 2, 3, 1).contiguous()                  # [B, C, H, W] -> channel-last
+        for n in self._convs:
+            conv = getattr(self, n)
+            h = ops.conv2d_nhwc(h, conv.weight.permute(0, 2, 3, 1).contiguous(), conv.bias, self.stride, self.pad, relu=True)
+        pooled = ops.avgpool_nhwc_fn(h)
+        fin = getattr(self, self._final)
+        out = ops.mlp(pooled, th.cat([fin.weight.reshape(-1), fin.bias.reshape(-1)]), self.dims_final, ops.ACT_NONE)
+        return out.squeeze(-1) if self.squeeze_output else out
+
+
+def build_cnn(*args, **kwargs) -> Cnn:
+    """`util/networks.py:286-357` signature."""
+    return Cnn(*args, **kwargs)
+
+
+def _is_image_space(space) -> bool:
+    return (isinstance(space, spaces.Box) and len(space.shape) == 3 and space.dtype == np.uint8
+            and bool(np.all(space.low == 0) and np.all(space.high == 255)))
+
+
+class CnnRewardNet(RewardNet):
+    """`rewards/reward_nets.py:460-610`: a CNN over the (channel-concatenated) image state / next state whose output
+    has one entry per discrete action (two per action when `use_done`); the reward is the entry the one-hot action
+    (and the done flag) selects."""
+
+    def __init__(self, observation_space, action_space, use_state: bool = True, use_action: bool = True,
+                 use_next_state: bool = False, use_done: bool = False, hwc_format: bool = True, **kwargs):
+        super().__init__(observation_space, action_space)
+        self.use_state, self.use_action = use_state, use_action
+        self.use_next_state, self.use_done, self.hwc_format = use_next_state, use_done, hwc_format
+        if not (use_state or use_next_state):
+            raise ValueError("CnnRewardNet must take current or next state as input.")
+        if not _is_image_space(observation_space):
+            raise ValueError("CnnRewardNet requires observations to be images.")
+        if use_action and not isinstance(action_space, spaces.Discrete):
+            raise ValueError("CnnRewardNet can only use Discrete action spaces.")
+        ch = observation_space.shape[-1] if hwc_format else observation_space.shape[0]
+        n_in = ch * (int(use_state) + int(use_next_state))
+        n_out = (int(action_space.n) if use_action else 1) * (2 if use_done else 1)
+        full = {"hid_channels": (32, 32), **kwargs, "in_channels": n_in, "out_size": n_out, "squeeze_output": n_out == 1}
+        self.cnn = Cnn(**full)
+
+    def forward(self, state, action, next_state, done):
+        images = [t for on, t in ((self.use_state, state), (self.use_next_state, next_state)) if on]
+        if self.hwc_format:   # [B, H, W, C] frames: channel-first for the CNN's input contract
+            images = [t.permute(0, 3, 1, 2) for t in images]
+        out = self.cnn(th.cat(images, dim=1))
+        if not self.use_action and not self.use_done:
+            return out
+        n = state.shape[0]
+        if self.use_action:
+            sel = action.reshape(n, -1).float()
+            if self.use_done:   # first half of the outputs: done = False, second half: done = True
+                d = done.reshape(n, 1).float()
+                sel = th.cat([sel * (1 - d), sel * d], dim=1)
+        else:
+            sel = nn.functional.one_hot(done.long(), num_classes=2).float()
+        return (out * sel).sum(dim=1)
+
+
 class BasicPotentialMLP(nn.Module):
     """`rewards/reward_nets.py:812-839`."""
 

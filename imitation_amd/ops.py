@@ -157,7 +157,136 @@ def adam_step(p: Tensor, g: Tensor, m: Tensor, v: Tensor, beta1: float, beta2: f
            step_size, bc2_sqrt, L.stream())
 
 
+@th.library.custom_op("imitation_amd::conv2d_nhwc_forward", mutates_args=(), device_types="cuda")
+def conv2d_nhwc_forward(x: Tensor, w: Tensor, b: Tensor, stride: int, pad: int, relu: bool) -> Tuple[Tensor, Tensor]:
+    """Convolution of channel-last activations `x[B, H, W, Cin]` with `w[Cout, KH, KW, Cin]`, bias `b[Cout]`, zero
+    padding `pad`, optional fused ReLU: im2col (border resolved in the index arithmetic) + the fp32 MFMA GEMM.
+    Returns `(y[B, OH, OW, Cout], col)`; `col` is kept for the weight gradient."""
+    x, w, b = _dev(x, "x"), _dev(w, "w"), _dev(b, "b")
+    B, H, W, Cin = x.shape
+    Cout, KH, KW, _ = w.shape
+    OH, OW = (H + 2 * pad - KH) // stride + 1, (W + 2 * pad - KW) // stride + 1
+    K, M = KH * KW * Cin, B * OH * OW
+    col = th.empty(M, K, device=x.device)
+    L.call("ia_im2col_f32_nhwc_pad", L.ptr(x), B, H, W, Cin, KH, KW, stride, pad, L.ptr(col), L.stream())
+    y = th.empty(B, OH, OW, Cout, device=x.device)
+    L.call("ia_gemm_f32", L.GEMM_NT, L.ptr(col), K, L.ptr(w), K, L.ptr(y), Cout, M, Cout, K, L.ptr(b),
+           ACT_RELU if relu else ACT_NONE, None, 0, 1, None, L.stream())
+    return y, col
+
+
+@conv2d_nhwc_forward.register_fake
+def _(x, w, b, stride, pad, relu):
+    B, H, W, Cin = x.shape
+    Cout, KH, KW, _ = w.shape
+    OH, OW = (H + 2 * pad - KH) // stride + 1, (W + 2 * pad - KW) // stride + 1
+    return x.new_empty(B, OH, OW, Cout), x.new_empty(B * OH * OW, KH * KW * Cin)
+
+
+@th.library.custom_op("imitation_amd::conv2d_nhwc_backward", mutates_args=(), device_types="cuda")
+def conv2d_nhwc_backward(dy: Tensor, y: Tensor, col: Tensor, w: Tensor, in_h: int, in_w: int, stride: int, pad: int,
+                         relu: bool, need_dx: bool) -> Tuple[Tensor, Tensor, Tensor]:
+    """Backward of `conv2d_nhwc_forward`: `(dx[B, H, W, Cin] (zeros when not needed), dw, db)`. ReLU backward from
+    the saved output, weight gradient = split-K TN GEMM on the kept columns (slabs reduced in fixed order), input
+    gradient = NN GEMM + gather-form col2im."""
+    dy, y, col, w = _dev(dy, "dy"), _dev(y, "y"), _dev(col, "col"), _dev(w, "w")
+    B, OH, OW, Cout = y.shape
+    _, KH, KW, Cin = w.shape
+    K, M = KH * KW * Cin, B * OH * OW
+    dz = dy
+    if relu:
+        dz = th.empty_like(dy)
+        L.call("ia_relu_backward", L.ptr(dy), L.ptr(y), dy.numel(), L.ptr(dz), L.stream())
+    splits = int(min(64, max(1, M // 2048)))
+    part = th.empty(splits, Cout, K, device=dy.device)
+    dbp = th.empty(splits, Cout, device=dy.device)
+    L.call("ia_gemm_f32", L.GEMM_TN, L.ptr(dz), Cout, L.ptr(col), K, L.ptr(part), K, Cout, K, M, None, 0, None, 0,
+           splits, L.ptr(dbp), L.stream())
+    dw, db = th.empty(Cout, KH, KW, Cin, device=dy.device), th.empty(Cout, device=dy.device)
+    L.call("ia_reduce_partials", L.ptr(part), splits, Cout * K, 1.0, 0, L.ptr(dw), L.stream())
+    L.call("ia_reduce_partials", L.ptr(dbp), splits, Cout, 1.0, 0, L.ptr(db), L.stream())
+    dx = th.zeros(B, in_h, in_w, Cin, device=dy.device) if not need_dx else th.empty(B, in_h, in_w, Cin, device=dy.device)
+    if need_dx:
+        dcol = th.empty(M, K, device=dy.device)
+        L.call("ia_gemm_f32", L.GEMM_NN, L.ptr(dz), Cout, L.ptr(w), K, L.ptr(dcol), K, M, K, Cout, None, 0, None, 0, 1,
+               None, L.stream())
+        L.call("ia_col2im_nhwc_pad", L.ptr(dcol), B, in_h, in_w, Cin, KH, KW, stride, pad, L.ptr(dx), L.stream())
+    return dx, dw, db
+
+
+@conv2d_nhwc_backward.register_fake
+def _(dy, y, col, w, in_h, in_w, stride, pad, relu, need_dx):
+    B = y.shape[0]
+    return y.new_empty(B, in_h, in_w, w.shape[3]), th.empty_like(w), y.new_empty(w.shape[0])
+
+
+@th.library.custom_op("imitation_amd::avgpool_nhwc", mutates_args=(), device_types="cuda")
+def avgpool_nhwc(y: Tensor) -> Tensor:
+    """`nn.AdaptiveAvgPool2d(1)` + flatten on channel-last `y[B, H, W, C]` -> `[B, C]`."""
+    y = _dev(y, "y")
+    B, H, W, Cc = y.shape
+    out = th.empty(B, Cc, device=y.device)
+    L.call("ia_avgpool_nhwc", L.ptr(y), B, H * W, Cc, L.ptr(out), L.stream())
+    return out
+
+
+@avgpool_nhwc.register_fake
+def _(y):
+    return y.new_empty(y.shape[0], y.shape[3])
+
+
+@th.library.custom_op("imitation_amd::avgpool_nhwc_backward", mutates_args=(), device_types="cuda")
+def avgpool_nhwc_backward(dout: Tensor, h: int, w: int) -> Tensor:
+    dout = _dev(dout, "dout")
+    B, Cc = dout.shape
+    dy = th.empty(B, h, w, Cc, device=dout.device)
+    L.call("ia_avgpool_nhwc_backward", L.ptr(dout), B, h * w, Cc, L.ptr(dy), L.stream())
+    return dy
+
+
+@avgpool_nhwc_backward.register_fake
+def _(dout, h, w):
+    return dout.new_empty(dout.shape[0], h, w, dout.shape[1])
+
+
 # ------------------------------------------------------------------------------------ autograd functions
+
+class _Conv(th.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, b, stride, pad, relu):
+        y, col = th.ops.imitation_amd.conv2d_nhwc_forward(x, w, b, stride, pad, relu)
+        ctx.save_for_backward(y, col, w)
+        ctx.cfg = (x.shape[1], x.shape[2], stride, pad, relu)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        y, col, w = ctx.saved_tensors
+        in_h, in_w, stride, pad, relu = ctx.cfg
+        dx, dw, db = th.ops.imitation_amd.conv2d_nhwc_backward(dy.contiguous(), y, col, w, in_h, in_w, stride, pad, relu,
+                                                               bool(ctx.needs_input_grad[0]))
+        return (dx if ctx.needs_input_grad[0] else None), dw, db, None, None, None
+
+
+def conv2d_nhwc(x: Tensor, w: Tensor, b: Tensor, stride: int = 1, pad: int = 0, relu: bool = False) -> Tensor:
+    """Differentiable channel-last convolution (+ fused ReLU): `x[B, H, W, Cin]`, `w[Cout, KH, KW, Cin]`."""
+    return _Conv.apply(_dev(x, "x"), w, b, int(stride), int(pad), bool(relu))
+
+
+class _AvgPool(th.autograd.Function):
+    @staticmethod
+    def forward(ctx, y):
+        ctx.hw = (y.shape[1], y.shape[2])
+        return th.ops.imitation_amd.avgpool_nhwc(y)
+
+    @staticmethod
+    def backward(ctx, dout):
+        return th.ops.imitation_amd.avgpool_nhwc_backward(dout.contiguous(), *ctx.hw)
+
+
+def avgpool_nhwc_fn(y: Tensor) -> Tensor:
+    return _AvgPool.apply(_dev(y, "y"))
+
 
 class _Mlp(th.autograd.Function):
     @staticmethod

@@ -284,6 +284,18 @@ int ia_im2col_f32_nhwc(const float* x, int B, int H, int W, int C, int KH, int K
  * relu_mask (nullable) = that input's own post-ReLU value: the gradient is zeroed where it is <= 0. */
 int ia_col2im_nhwc(const float* dcol, int B, int H, int W, int C, int KH, int KW, int S, const float* relu_mask,
                    float* dx, void* stream);
+/* Padded convolutions of the reward CNN (util/networks.py:286-357 `build_cnn`, rewards/reward_nets.py:460-610
+ * `CnnRewardNet`): im2col / col2im with a zero border of P pixels resolved in the index arithmetic (column index
+ * k = (i*KW + j)*C + c, activations channel-last); OH = (H + 2P - KH)/S + 1. */
+int ia_im2col_f32_nhwc_pad(const float* x, int B, int H, int W, int C, int KH, int KW, int S, int P, float* col,
+                           void* stream);
+int ia_col2im_nhwc_pad(const float* dcol, int B, int H, int W, int C, int KH, int KW, int S, int P, float* dx,
+                       void* stream);
+/* out = y > 0 ? dy : 0 (ReLU backward from the post-activation value). */
+int ia_relu_backward(const float* dy, const float* y, int64_t n, float* out, void* stream);
+/* nn.AdaptiveAvgPool2d(1) on channel-last activations y[B, HW, C] -> out[B, C], and its backward (dy = dout / HW). */
+int ia_avgpool_nhwc(const float* y, int B, int HW, int C, float* out, void* stream);
+int ia_avgpool_nhwc_backward(const float* dout, int B, int HW, int C, float* dy, void* stream);
 /* Categorical head ([SB3 CategoricalDistribution] log_prob / entropy of torch.distributions.Categorical):
  * logp[r] = log_softmax(logits[r])[action r], entropy[r]; dlogits (nullable) = gradient of
  * logp_coef*logp + ent_coef*entropy per row (BC: -share/B and -ent_weight*share/B, bc.py:138-156,494-499). */

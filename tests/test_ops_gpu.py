@@ -217,3 +217,76 @@ def test_user_defined_reward_net_plugs_in(tmp_path):
     assert tr._disc_step == 9
     losses = [tr.train_disc()["disc_loss"] for _ in range(30)]
     assert np.mean(losses[-5:]) < np.mean(losses[:5])
+
+
+def test_cnn_reward_net_matches_reference_golden_and_torch_autograd():
+    """`modules.CnnRewardNet` (padded 3x3 convolutions as im2col + MFMA GEMM, global average pool, linear head,
+    one-hot action / done selection) against (a) the reference's own `CnnRewardNet` outputs for the same weights
+    (`tests/golden/cnn_reward_net.npz`, made by the reference under the shim) and (b) torch autograd (float64
+    `nn.Conv2d` stack) for every parameter gradient and the input gradient."""
+    from imitation_amd import modules, ops, spaces
+
+    g = np.load(os.path.join(GOLDEN, "cnn_reward_net.npz"))
+    osp, asp = spaces.Box(0, 255, (12, 10, 3), np.uint8), spaces.Discrete(5)
+    net = modules.CnnRewardNet(osp, asp, use_next_state=True, use_done=True).to(DEV)
+    net.load_state_dict({k[3:]: th.as_tensor(g[k]) for k in g.files if k.startswith("sd/")})
+    rews = net.predict_processed(g["obs"], g["acts"], g["next_obs"], g["dones"])
+    np.testing.assert_allclose(rews, g["rews"], rtol=2e-5, atol=2e-6)
+
+    # (b) gradients of a generic stack: 5 -> 16 -> 8 channels, 4 outputs, 9 x 7 images, batch 6
+    th.manual_seed(0)
+    cnn = modules.Cnn(5, (16, 8), out_size=4).to(DEV)
+    x = th.randn(6, 5, 9, 7)
+    wsum = th.randn(6, 4)
+    ref = th.nn.Sequential(th.nn.Conv2d(5, 16, 3, padding="same"), th.nn.ReLU(), th.nn.Conv2d(16, 8, 3, padding="same"),
+                           th.nn.ReLU(), th.nn.AdaptiveAvgPool2d(1), th.nn.Flatten(), th.nn.Linear(8, 4)).double()
+    sd = cnn.state_dict()
+    with th.no_grad():
+        for src, dst in (("conv0", ref[0]), ("conv1", ref[2]), ("dense_final", ref[6])):
+            dst.weight.copy_(sd[f"{src}.weight"].double().cpu())
+            dst.bias.copy_(sd[f"{src}.bias"].double().cpu())
+    xr = x.double().requires_grad_(True)
+    (ref(xr) * wsum.double()).sum().backward()
+    xd = x.to(DEV).requires_grad_(True)
+    out = cnn(xd)
+    (out * wsum.to(DEV)).sum().backward()
+    th.testing.assert_close(out.detach().cpu().double(), ref(x.double()).detach(), rtol=2e-5, atol=2e-5)
+    th.testing.assert_close(xd.grad.cpu().double(), xr.grad, rtol=5e-5, atol=2e-5)
+    for src, dst in (("conv0", ref[0]), ("conv1", ref[2]), ("dense_final", ref[6])):
+        th.testing.assert_close(getattr(cnn, src).weight.grad.cpu().double(), dst.weight.grad, rtol=5e-5, atol=5e-5)
+        th.testing.assert_close(getattr(cnn, src).bias.grad.cpu().double(), dst.bias.grad, rtol=5e-5, atol=5e-5)
+
+
+def test_gail_discriminator_on_image_observations_trains(tmp_path):
+    """`train_disc` of a GAIL trainer whose reward net is the image `CnnRewardNet` (explicit expert / generator
+    image batches, uint8 frames): loss.backward() through the convolution ops, discriminator loss decreases
+    (`tests/algorithms/test_adversarial.py:256-282` of the reference, on images)."""
+    import imitation_amd as p
+    from imitation_amd import modules, spaces
+    from imitation_amd.vec_env import SyntheticVecEnv
+
+    th.manual_seed(0)
+    np.random.seed(0)
+    osp, asp = spaces.Box(0, 255, (10, 10, 2), np.uint8), spaces.Discrete(3)
+
+    class ImageEnv(SyntheticVecEnv):   # only the spaces matter here: train_disc gets explicit samples
+        pass
+
+    venv = SyntheticVecEnv(num_envs=4, obs_dim=8, act_dim=3, horizon=5, seed=0, n_discrete=3)
+    venv.observation_space = osp
+    rng = np.random.default_rng(0)
+
+    def batch(bright):
+        obs = rng.integers(0, 128, (32, 10, 10, 2)).astype(np.uint8) + (100 if bright else 0)
+        return dict(obs=obs, acts=rng.integers(0, 3, 32), next_obs=obs.copy(), dones=np.zeros(32, bool))
+
+    algo = p.PPO(p.FeedForward32Policy, SyntheticVecEnv(num_envs=4, obs_dim=8, act_dim=3, horizon=5, seed=0, n_discrete=3),
+                 n_steps=4, batch_size=8, seed=0, device="cuda")
+    net = modules.CnnRewardNet(osp, asp, hid_channels=(8, 8))
+    demos = p.Transitions(obs=np.zeros((64, 8), np.float32), acts=np.zeros(64, np.int64),
+                          next_obs=np.zeros((64, 8), np.float32), dones=np.zeros(64, bool))
+    tr = p.GAIL(demonstrations=demos, demo_batch_size=32, venv=algo.get_env(), gen_algo=algo, reward_net=net,
+                custom_logger=p.configure_logger(str(tmp_path), []))
+    tr.venv = venv   # spaces of the image task for batch assembly (one-hot width, observation shape)
+    losses = [tr.train_disc(expert_samples=batch(True), gen_samples=batch(False))["disc_loss"] for _ in range(25)]
+    assert np.isfinite(losses).all() and np.mean(losses[-5:]) < 0.7 * np.mean(losses[:5]), losses
