@@ -46,7 +46,7 @@ class DiscStepArgs(C.Structure):
                 [("accumulate", C.c_int), ("adam", C.c_int)] +
                 [(n, C.c_float) for n in ("beta1", "beta2", "adam_eps", "weight_decay", "step_size", "bc2_sqrt")] +
                 [(n, C.c_void_p) for n in ("pnorm_mean", "pnorm_var", "pnorm_count")] + [("pnorm_dim", C.c_int)] +
-                [("fused_ws", C.c_void_p)])
+                [("fused_ws", C.c_void_p), ("pre_assembled", C.c_int)])
 
 
 class HipExtensionMissing(RuntimeError):
@@ -90,6 +90,8 @@ _SIGS = {
     "ia_disc_step_basic": ([C.POINTER(DiscStepArgs), _P], C.c_int),
     "ia_disc_fused_ws_floats": ([C.POINTER(MlpDesc), _I, _I], C.c_int64),
     "ia_disc_fused_debug_timing": ([_P], C.c_int),
+    "ia_disc_assemble_round": ([C.POINTER(DiscStepArgs), _I, _L, _L, _L, _P], C.c_int),
+    "ia_disc_fused_prepare": ([C.POINTER(MlpDesc), _P, _I, _I, _P, _P], C.c_int),
     "ia_airl_logits": ([_P, _P, _P, _P, _P, _F, _I, _P, _P], C.c_int),
     "ia_airl_route_grad": ([_P, _P, _F, _I, _P, _P, _P, _P], C.c_int),
     "ia_gather_rows": ([_P, _P, _I, _I, _P, _P], C.c_int),

@@ -404,7 +404,8 @@ class AdversarialTrainer(abc.ABC):
                 # all host index draws of the round first (same order as one per update), then the
                 # policy feature-norm moments of every update's batch, then the updates themselves
                 drawn = [self._batch_sources(None, None) for _ in range(n)]
-                did = self._quirk_prepass(drawn)
+                round_ws = self._assemble_round(drawn)   # fused shapes: ONE launch assembles all n batches
+                did = self._quirk_prepass(drawn, round_ws)
                 if self._needs_logp:
                     # AIRL: the merge runs here, behind the PPO update, and leaves the statistics each
                     # update's own forward pass sees (`_policy_pass`); the next rollout waits for it
@@ -423,7 +424,8 @@ class AdversarialTrainer(abc.ABC):
                     self._disc_t0.record()
                 for k in range(n):
                     with networks.training(self.reward_train):
-                        self._disc_update(None, None, self._stats_ring[k], drawn=drawn[k], quirk_done=did)
+                        self._disc_update(None, None, self._stats_ring[k], drawn=drawn[k], quirk_done=did,
+                                          pre=None if round_ws is None else (round_ws, k))
                     steps.append(self._disc_step)
             else:
                 for k in range(n):
@@ -446,8 +448,26 @@ class AdversarialTrainer(abc.ABC):
         for k, step in enumerate(steps):
             self._log_disc_stats(rows[k], step, global_step)
 
+    def _assemble_round(self, drawn):
+        """Round-level batch assembly for the fused discriminator path (`BasicRewardNet.assemble_round`): every
+        update's rows gathered by one launch, the input-norm updates applied in order by one more. None when it
+        does not apply (other nets / shapes, gradient accumulation, data parallelism, explicit samples)."""
+        net = self._reward_net
+        while isinstance(net, reward_nets.PredictProcessedWrapper):
+            net = net.base
+        single = self._dp is None or self._dp.world == 1
+        if (self._module_net or not isinstance(net, reward_nets.BasicRewardNet) or self._needs_logp or not single
+                or self._torch_opt_params is not None or self.demo_minibatch_size != self.demo_batch_size
+                or not isinstance(self._disc_opt, HipAdam) or len(drawn) > self._quirk_idx_dev.shape[0]):
+            return None
+        (e_tab, e_idx), (g_tab, g_idx) = drawn[0]
+        if e_idx is None or g_idx is None:
+            return None
+        with networks.training(self.reward_train):
+            return net.assemble_round(e_tab, g_tab, self._quirk_idx_dev[:len(drawn)], len(drawn), self.demo_batch_size)
+
     def _disc_update(self, expert_samples, gen_samples, stats_dev: th.Tensor, drawn=None,
-                     quirk_done: bool = False) -> None:
+                     quirk_done: bool = False, pre=None) -> None:
         """Device half of `train_disc` (`common.py:317-374`); the 8 statistics land in `stats_dev`.
         `drawn`: batch sources already drawn by `_batch_sources`; `quirk_done`: the policy feature-norm
         side effect of this update was already captured by `_quirk_prepass`."""
@@ -488,7 +508,7 @@ class AdversarialTrainer(abc.ABC):
                 inline = reuse and not self._in_overlap
                 ws = basic.disc_step_c(sources, mb, scale, stats_dev, self._bce_ws, accumulate=not first,
                                        adam=fuse_adam if last else None, pnorm=prn if inline else None,
-                                       pnorm_dim=pol.obs_dim if inline else 0)
+                                       pnorm_dim=pol.obs_dim if inline else 0, pre=pre)
                 if reuse and self._in_overlap:  # replayed on the generator stream after the PPO update
                     slot = self._quirk_moment_slot(ws["rn_ws"].numel())
                     slot.copy_(ws["rn_ws"])
@@ -596,7 +616,7 @@ class AdversarialTrainer(abc.ABC):
             self._quirk_slots[k] = th.empty(numel, device=self._device)
         return self._quirk_slots[k]
 
-    def _quirk_prepass(self, drawn) -> bool:
+    def _quirk_prepass(self, drawn, round_ws=None) -> bool:
         """Slab moments of the observation columns of every (update, minibatch) batch of a round, on the
         current (discriminator) stream, queued for `_replay_policy_norm_updates`. They depend on the
         sampled rows only, so they can be taken before -- and independently of -- the updates, which
@@ -609,6 +629,17 @@ class AdversarialTrainer(abc.ABC):
         if rn is None or not pol.training:
             return False
         B, mb = self.demo_batch_size, self.demo_minibatch_size
+        basic = self._reward_net
+        while isinstance(basic, reward_nets.PredictProcessedWrapper):
+            basic = basic.base
+        if (round_ws is not None and round_ws.get("has_moments") and getattr(basic, "use_state", False)
+                and pol.obs_dim <= basic.mlp.dims[0]):
+            # the discriminator batches start with the observation columns and their slab moments were just taken
+            # by the round assembly: the policy-feature-norm side effect (App. C.2) merges the same moments
+            # (first obs_dim of D columns) -- no second gather
+            self._quirk_seq_merged = round_ws["rn_all"]
+            self._quirk_pending.append(("seq", len(drawn), round_ws["need"], 1, 2 * mb, basic.mlp.dims[0]))
+            return True
         need = int(L.load().ia_running_norm_ws_floats(2 * mb, pol.obs_dim))
         n_items = len(drawn) * len(range(0, B, mb))
         if self._quirk_seq is None or self._quirk_seq.shape != (n_items, need):

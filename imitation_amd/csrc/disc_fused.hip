@@ -537,6 +537,8 @@ struct AssembleArgs {
   unsigned int* ticket;
   const float* W2; float* W2T; int H;    // transposer blocks (blockIdx >= slabs)
   const float* W1; float* W1P;           // last block: W1 [H][D] -> [H][XP], zero padded
+  // a whole round in one launch: blockIdx.y = update k; its index rows / X / slab moments sit k strides further
+  long long idx_stride, x_stride, rn_stride;
 };
 
 constexpr int AS_NT = 1024;
@@ -547,7 +549,14 @@ __global__ __launch_bounds__(AS_NT) void disc_assemble_kernel(AssembleArgs a) {
   __shared__ int s_last;
   const int tid = threadIdx.x;
   const int slabs = (a.R + RN_ROWS_PER_BLOCK - 1) / RN_ROWS_PER_BLOCK;
-  if (blockIdx.x == gridDim.x - 1) {
+  if (blockIdx.y > 0) {
+    const long long k = blockIdx.y;
+    if (a.idx[0]) a.idx[0] += k * a.idx_stride;
+    if (a.idx[1]) a.idx[1] += k * a.idx_stride;
+    a.X += k * a.x_stride;
+    a.rn_ws += k * a.rn_stride;
+  }
+  if (a.W1P != nullptr && blockIdx.x == gridDim.x - 1) {
     for (int e = tid; e < a.H * XP; e += AS_NT) {
       const int n = e / XP, k = e - n * XP;
       a.W1P[e] = k < a.D ? a.W1[n * a.D + k] : 0.f;
@@ -721,6 +730,7 @@ struct ReduceArgs {
   long long n; int accumulate; float* grads;
   int adam; float* p; float* m; float* v; float beta1, beta2, eps, wd, step_size, bc2_sqrt;
   const float* part; int tiles; int R; int n_expert; float loss_scale; float* stats;
+  float* W2T; float* W1P; int H; int D;   // images of W2 / W1 the tile kernels read: refreshed with the Adam step
 };
 
 // 64 parameters per block; wave q folds quarter q of the element's slabs in slab order, the four quarter
@@ -783,9 +793,19 @@ __global__ __launch_bounds__(256) void disc_reduce_kernel(ReduceArgs a) {
   mi = mi + (grad - mi) * (1.f - a.beta1);
   const float vi = a.v[i] * a.beta2 + (1.f - a.beta2) * grad * grad;
   const float denom = sqrtf(vi) / a.bc2_sqrt + a.eps;
-  a.p[i] = pi - a.step_size * (mi / denom);
+  const float pn = pi - a.step_size * (mi / denom);
+  a.p[i] = pn;
   a.m[i] = mi;
   a.v[i] = vi;
+  // the next update may skip the assemble launch (pre-assembled rounds): W2T / the padded W1 image follow here
+  const long long nW1 = (long long)a.H * a.D, n1 = nW1 + a.H;
+  if (i < nW1) {
+    const int n = (int)(i / a.D), k = (int)(i - (long long)n * a.D);
+    a.W1P[n * XP + k] = pn;
+  } else if (i >= n1 && i < n1 + (long long)a.H * a.H) {
+    const int j = (int)(i - n1), r = j / a.H, c = j - r * a.H;
+    a.W2T[(long long)c * a.H + r] = pn;
+  }
 }
 
 inline int cdivi(long long a, long long b) { return (int)((a + b - 1) / b); }
@@ -851,6 +871,54 @@ extern "C" int64_t ia_disc_fused_ws_floats(const ia_mlp_desc* d, int R, int ldx)
   return fused_ws_layout(d, R, nullptr).total;
 }
 
+namespace {
+void fill_assemble_sources(AssembleArgs& as, const ia_disc_step_args* a) {
+  as.obs[0] = a->obs0; as.act_f32[0] = a->act0_f32; as.act_i64[0] = a->act0_i64; as.next[0] = a->next0;
+  as.done[0] = a->done0; as.idx[0] = a->idx0; as.n[0] = a->n0;
+  as.obs[1] = a->obs1; as.act_f32[1] = a->act1_f32; as.act_i64[1] = a->act1_i64; as.next[1] = a->next1;
+  as.done[1] = a->done1; as.idx[1] = a->idx1; as.n[1] = a->n1;
+  if (a->n0 == 0) { as.obs[0] = a->obs1; as.next[0] = a->next1; as.done[0] = a->done1; }
+  if (a->n1 == 0) { as.obs[1] = a->obs0; as.next[1] = a->next0; as.done[1] = a->done0; }
+  as.obs_dim = a->obs_dim; as.act_dim = a->act_dim; as.use_state = a->use_state; as.use_action = a->use_action;
+  as.use_next = a->use_next_state; as.use_done = a->use_done;
+}
+}  // namespace
+
+// A whole round's batch assembly in ONE launch: update k (blockIdx.y) gathers rows idx0 + k*idx_stride /
+// idx1 + k*idx_stride of the two tables into X + k*x_stride and leaves its RunningNorm slab moments at
+// rn_ws + k*rn_stride (no merge: ia_running_norm_merge_seq applies them in order and keeps per-update snapshots).
+extern "C" int ia_disc_assemble_round(const ia_disc_step_args* a, int n_updates, int64_t idx_stride, int64_t x_stride,
+                                      int64_t rn_stride, void* stream) {
+  if (!a || n_updates <= 0 || !fused_shape_ok(a->desc, a->ldx) || a->n0 + a->n1 <= 0) return IA_ERR_ARG;
+  AssembleArgs as{};
+  fill_assemble_sources(as, a);
+  const int R = a->n0 + a->n1;
+  as.X = a->X; as.ldx = a->ldx; as.R = R; as.D = a->desc->dims[0];
+  as.update_norm = a->rn_ws != nullptr;
+  as.rn_ws = a->rn_ws; as.mean = nullptr;
+  as.idx_stride = idx_stride; as.x_stride = x_stride; as.rn_stride = rn_stride;
+  hipLaunchKernelGGL(disc_assemble_kernel, dim3(cdivi(R, RN_ROWS_PER_BLOCK), n_updates), dim3(AS_NT), 0,
+                     (hipStream_t)stream, as);
+  IA_CHECK_LAUNCH();
+  return IA_OK;
+}
+
+// W2T and the padded W1 image of the CURRENT parameters into the fused workspace (once before a batch of
+// pre-assembled updates; the updates' own Adam steps keep them current).
+extern "C" int ia_disc_fused_prepare(const ia_mlp_desc* d, const float* params, int R, int ldx, float* fused_ws,
+                                     void* stream) {
+  if (!fused_shape_ok(d, ldx) || !fused_ws || R <= 0) return IA_ERR_ARG;
+  const int D = d->dims[0], H = d->dims[1];
+  const FusedWs w = fused_ws_layout(d, R, fused_ws);
+  AssembleArgs as{};
+  as.R = 0; as.D = D; as.ldx = ldx; as.H = H;
+  as.W2 = params + (long long)H * D + H; as.W2T = w.W2T;
+  as.W1 = params; as.W1P = w.W1P;
+  hipLaunchKernelGGL(disc_assemble_kernel, dim3((H / 64) * (H / 64) + 1), dim3(AS_NT), 0, (hipStream_t)stream, as);
+  IA_CHECK_LAUNCH();
+  return IA_OK;
+}
+
 // The fused form of ia_disc_step_basic (mlp.hip dispatches here when a->fused_ws is set and the shape
 // qualifies). Same contract, same outputs (logits, dlogits, stats, rn_ws slab moments, grads / Adam).
 int ia_disc_step_fused(const ia_disc_step_args* a, void* stream_) {
@@ -863,14 +931,7 @@ int ia_disc_step_fused(const ia_disc_step_args* a, void* stream_) {
   const long long nW1 = (long long)H * D, n1 = nW1 + H, n2 = (long long)H * H + H, n3 = H + 1, tot = n1 + n2 + n3;
 
   AssembleArgs as{};
-  as.obs[0] = a->obs0; as.act_f32[0] = a->act0_f32; as.act_i64[0] = a->act0_i64; as.next[0] = a->next0;
-  as.done[0] = a->done0; as.idx[0] = a->idx0; as.n[0] = a->n0;
-  as.obs[1] = a->obs1; as.act_f32[1] = a->act1_f32; as.act_i64[1] = a->act1_i64; as.next[1] = a->next1;
-  as.done[1] = a->done1; as.idx[1] = a->idx1; as.n[1] = a->n1;
-  if (a->n0 == 0) { as.obs[0] = a->obs1; as.next[0] = a->next1; as.done[0] = a->done1; }
-  if (a->n1 == 0) { as.obs[1] = a->obs0; as.next[1] = a->next0; as.done[1] = a->done0; }
-  as.obs_dim = a->obs_dim; as.act_dim = a->act_dim; as.use_state = a->use_state; as.use_action = a->use_action;
-  as.use_next = a->use_next_state; as.use_done = a->use_done;
+  fill_assemble_sources(as, a);
   as.X = a->X; as.ldx = a->ldx; as.R = R; as.D = D;
   as.update_norm = (a->norm_mean != nullptr && a->update_norm) ? 1 : 0;
   as.rn_ws = a->rn_ws; as.mean = a->norm_mean; as.var = a->norm_var; as.count = a->norm_count;
@@ -880,8 +941,11 @@ int ia_disc_step_fused(const ia_disc_step_args* a, void* stream_) {
   as.ticket = w.ticket;
   as.W2 = a->params + n1; as.W2T = w.W2T; as.H = H;
   as.W1 = a->params; as.W1P = w.W1P;
-  hipLaunchKernelGGL(disc_assemble_kernel, dim3(slabs + (H / 64) * (H / 64) + 1), dim3(AS_NT), 0, stream, as);
-  IA_CHECK_LAUNCH();
+  if (!a->pre_assembled) {   // (pre-assembled: X / slab moments come from ia_disc_assemble_round, the statistics to
+                             //  normalise with from the caller, W2T / W1P from ia_disc_fused_prepare + the Adam steps)
+    hipLaunchKernelGGL(disc_assemble_kernel, dim3(slabs + (H / 64) * (H / 64) + 1), dim3(AS_NT), 0, stream, as);
+    IA_CHECK_LAUNCH();
+  }
 
   FusedArgs fa{};
   fa.X = a->X; fa.ldx = a->ldx; fa.R = R; fa.D = D;
@@ -918,6 +982,7 @@ int ia_disc_step_fused(const ia_disc_step_args* a, void* stream_) {
   ra.step_size = a->step_size; ra.bc2_sqrt = a->bc2_sqrt;
   ra.part = w.part; ra.tiles = tiles; ra.R = R; ra.n_expert = a->n_expert; ra.loss_scale = a->loss_scale;
   ra.stats = a->stats;
+  ra.W2T = w.W2T; ra.W1P = w.W1P; ra.H = H; ra.D = D;
   hipLaunchKernelGGL(disc_reduce_kernel, dim3(cdivi(tot, 64) + 1), dim3(256), 0, stream, ra);
   IA_CHECK_LAUNCH();
   if (a->adam && a->accumulate)

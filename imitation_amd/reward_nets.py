@@ -251,14 +251,52 @@ class BasicRewardNet(RewardNet):
         self.mlp.backward_rows(self._disc_ws, self._disc_R, d_logits, accumulate, adam=adam if fuse else None)
         return fuse
 
-    def disc_step_c(self, sources, n_expert: int, loss_scale: float, stats: th.Tensor, bce_ws: th.Tensor,
-                    accumulate: bool, adam=None, pnorm: Optional[RunningNorm] = None, pnorm_dim: int = 0):
-        """One discriminator minibatch through the single C entry `ia_disc_step_basic` (assemble ->
-        norm -> forward -> BCE -> backward -> reduce [-> Adam]): ONE host call instead of ~25.
-        Returns the workspace dict (logits in ws["out"], slab moments in ws["rn_ws"])."""
+    def assemble_round(self, e_tab: TransitionTable, g_tab: TransitionTable, idx_all: th.Tensor, n_updates: int,
+                       mb: int) -> Optional[Dict[str, th.Tensor]]:
+        """Batch assembly of a whole round's discriminator updates in ONE launch (fused shapes only; returns None
+        otherwise): update k gathers expert rows `idx_all[k, 0]` and generator rows `idx_all[k, 1]` into its own
+        X and leaves its RunningNorm slab moments; one `ia_running_norm_merge_seq` launch then applies the n
+        updates of the input norm in order and keeps the statistics AFTER each one -- what update k's own forward
+        normalises with (`util/networks.py:79-91`). The updates themselves (`disc_step_c(..., pre=(ws, k))`) are
+        four launches each."""
         import ctypes as C
-        (t0, i0, n0), (t1, i1, n1) = sources
-        R = n0 + n1
+        mlp, R = self.mlp, 2 * mb
+        if FUSED_DISC_STEP is False or int(L.load().ia_disc_fused_ws_floats(C.byref(mlp.desc), R, mlp.ldx)) <= 0:
+            return None
+        if idx_all.shape[1:] != (2, mb) or not idx_all.is_contiguous():
+            return None
+        dev, D = mlp.flat.device, mlp.dims[0]
+        key = ("round", n_updates, R)
+        rw = mlp._ws.get(key)
+        if rw is None:
+            need = int(L.load().ia_running_norm_ws_floats(R, D))
+            rw = {"X_all": th.zeros(n_updates, R, mlp.ldx, device=dev), "rn_all": th.empty(n_updates, need, device=dev),
+                  "snap": th.empty(n_updates, 2, D, device=dev), "need": need}
+            mlp._ws[key] = rw
+        ws = self._step_workspace(R)
+        a = ws["args"]
+        for k, t in enumerate((e_tab, g_tab)):
+            setattr(a, f"obs{k}", L.ptr(t.obs))
+            setattr(a, f"act{k}_f32", None if t.discrete else L.ptr(t.acts))
+            setattr(a, f"act{k}_i64", L.ptr(t.acts) if t.discrete else None)
+            setattr(a, f"next{k}", L.ptr(t.next_obs))
+            setattr(a, f"done{k}", L.ptr(t.dones))
+            setattr(a, f"idx{k}", idx_all[0, k].data_ptr())
+            setattr(a, f"n{k}", mb)
+        nrm = mlp.norm
+        update = nrm is not None and mlp.training
+        a.X, a.rn_ws = L.ptr(rw["X_all"]), (L.ptr(rw["rn_all"]) if update else None)
+        L.call("ia_disc_assemble_round", C.byref(a), n_updates, 2 * mb, R * mlp.ldx, rw["need"], L.stream())
+        a.X, a.rn_ws = L.ptr(ws["X"]), L.ptr(ws["rn_ws"])
+        rw["has_moments"] = update
+        if update:
+            L.call("ia_running_norm_merge_seq", L.ptr(rw["rn_all"]), n_updates, rw["need"], 1, R, D, D,
+                   L.ptr(nrm.running_mean), L.ptr(nrm.running_var), L.ptr(nrm.count), L.ptr(rw["snap"]), L.stream())
+        L.call("ia_disc_fused_prepare", C.byref(mlp.desc), L.ptr(mlp.flat), R, mlp.ldx, L.ptr(ws["fused_ws"]), L.stream())
+        return rw
+
+    def _step_workspace(self, R: int) -> Dict[str, th.Tensor]:
+        import ctypes as C
         mlp = self.mlp
         ws = mlp.train_workspace(R, "disc")
         if "dlogits" not in ws:
@@ -281,6 +319,18 @@ class BasicRewardNet(RewardNet):
             if nf > 0:  # 32 K-splits of the second layer's weight gradient: half the partial-slab traffic of 64
                 a.splits = min(ws["splits"], 32)
             ws["args"] = a
+        return ws
+
+    def disc_step_c(self, sources, n_expert: int, loss_scale: float, stats: th.Tensor, bce_ws: th.Tensor,
+                    accumulate: bool, adam=None, pnorm: Optional[RunningNorm] = None, pnorm_dim: int = 0, pre=None):
+        """One discriminator minibatch through the single C entry `ia_disc_step_basic` (assemble ->
+        norm -> forward -> BCE -> backward -> reduce [-> Adam]): ONE host call instead of ~25.
+        Returns the workspace dict (logits in ws["out"], slab moments in ws["rn_ws"])."""
+        import ctypes as C
+        (t0, i0, n0), (t1, i1, n1) = sources
+        R = n0 + n1
+        mlp = self.mlp
+        ws = self._step_workspace(R)
         a = ws["args"]
         a.params, a.grads = L.ptr(mlp.flat), L.ptr(mlp.grad)
         nrm = mlp.norm
@@ -289,7 +339,17 @@ class BasicRewardNet(RewardNet):
         a.norm_count = L.ptr(nrm.count) if nrm is not None else None
         a.norm_eps = nrm.eps if nrm is not None else 0.0
         a.update_norm = int(nrm is not None and mlp.training)
-        for k, (t, i, n) in enumerate(((t0, i0, n0), (t1, i1, n1))):
+        a.pre_assembled = 0
+        a.X, a.rn_ws = L.ptr(ws["X"]), L.ptr(ws["rn_ws"])
+        a.n0, a.n1 = n0, n1
+        if pre is not None:   # (round workspace of `assemble_round`, update number): rows and statistics are ready
+            rw, k = pre
+            a.pre_assembled, a.update_norm = 1, 0
+            a.X = rw["X_all"][k].data_ptr()
+            if rw["has_moments"]:
+                a.rn_ws = rw["rn_all"][k].data_ptr()
+                a.norm_mean, a.norm_var = rw["snap"][k, 0].data_ptr(), rw["snap"][k, 1].data_ptr()
+        for k, (t, i, n) in enumerate(((t0, i0, n0), (t1, i1, n1)) if pre is None else ()):  # (pre-assembled: unused)
             setattr(a, f"obs{k}", L.ptr(t.obs))
             setattr(a, f"act{k}_f32", None if t.discrete else L.ptr(t.acts))
             setattr(a, f"act{k}_i64", L.ptr(t.acts) if t.discrete else None)

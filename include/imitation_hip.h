@@ -160,10 +160,23 @@ typedef struct {
    * gradient per tile | second-layer weight gradient | slab reduction + Adam + statistics): the hidden
    * activations of a tile stay in LDS; `hidden` then holds h1 and dh2, `Xn` / `dhidden` are not touched. */
   float* fused_ws;
+  /* fused path only: X and rn_ws already hold this update's assembled rows / slab moments
+   * (ia_disc_assemble_round), norm_mean / norm_var are the statistics to normalise with (update_norm must be 0),
+   * and fused_ws holds current W2T / W1 images (ia_disc_fused_prepare once, then kept by the Adam steps):
+   * the update is four launches. */
+  int pre_assembled;
 } ia_disc_step_args;
 int ia_disc_step_basic(const ia_disc_step_args* a, void* stream);
 /* 0 when the fused path does not cover the shape (the call then runs the general path). */
 int64_t ia_disc_fused_ws_floats(const ia_mlp_desc* d, int R, int ldx);
+/* A whole round's batch assembly in ONE launch (fused shapes): for k < n_updates, rows idx0 + k*idx_stride /
+ * idx1 + k*idx_stride of a's two tables -> X + k*x_stride, RunningNorm slab moments -> rn_ws + k*rn_stride
+ * (strides in elements; no statistics are touched: apply them with ia_running_norm_merge_seq, whose snapshots
+ * are what update k normalises with -- util/networks.py:79-91 update-then-normalise, one update at a time). */
+int ia_disc_assemble_round(const ia_disc_step_args* a, int n_updates, int64_t idx_stride, int64_t x_stride,
+                           int64_t rn_stride, void* stream);
+/* W2T / padded W1 images of the CURRENT parameters into fused_ws (before a batch of pre_assembled updates). */
+int ia_disc_fused_prepare(const ia_mlp_desc* d, const float* params, int R, int ldx, float* fused_ws, void* stream);
 /* Measurement only: when set to a device buffer of 16 int64, block 0 of the fused forward / backward tile
  * kernels stores the shader clock at its phase boundaries in [0..7] / [8..12] (NULL switches it off). */
 int ia_disc_fused_debug_timing(void* device_buffer_16xi64);

@@ -157,6 +157,10 @@ if __name__ == "__main__":
         dump_cnn_reward_net()
     elif len(sys.argv) > 1 and sys.argv[1] == "bc":
         dump_bc()
+    elif len(sys.argv) > 2 and sys.argv[1] == "case":      # one training case: make_golden.py case <name>
+        out = harness.run_case("reference", sys.argv[2], tempfile.mkdtemp())
+        np.savez_compressed(os.path.join(HERE, f"{sys.argv[2]}.npz"), **out)
+        print("wrote", sys.argv[2], len(out), "arrays")
     elif len(sys.argv) > 2 and sys.argv[1] == "rollout":   # one rollout case: make_golden.py rollout <name>
         out = harness.run_rollout_case("reference", sys.argv[2])
         np.savez_compressed(os.path.join(HERE, f"{sys.argv[2]}.npz"), **out)

@@ -32,6 +32,26 @@ CASES: Dict[str, Dict[str, Any]] = {
                           n_steps=8, ppo_batch=16, n_epochs=2, ent_coef=0.01, disc_hid=(32, 32),
                           demo_batch=32, demo_minibatch=None, n_disc=2, capacity=None, n_demo=200, rounds=2,
                           norm_policy=True, norm_disc=True, obs_dtype="float32"),
+    # the fused five-launch discriminator update (D -> H -> H -> 1, H = 128) and, in pipelined rounds, the
+    # one-launch round assembly + pre-assembled four-launch updates
+    "gail_fused": dict(algo="gail", n_envs=8, horizon=10, obs_dim=17, act_dim=6, n_discrete=None,
+                       n_steps=16, ppo_batch=32, n_epochs=2, ent_coef=0.1, disc_hid=(128, 128),
+                       demo_batch=192, demo_minibatch=None, n_disc=3, capacity=None, n_demo=500, rounds=3,
+                       norm_policy=True, norm_disc=True, obs_dtype="float32"),
+    # SURVEY 8d variant H ("horizon" rollouts: n_steps far beyond the episode length -- long GAE scans, many episodes
+    # completing inside one rollout, the replay ring holding a whole long rollout) at reduced width.
+    "gail_horizon": dict(algo="gail", n_envs=4, horizon=25, obs_dim=17, act_dim=6, n_discrete=None,
+                         n_steps=200, ppo_batch=100, n_epochs=2, ent_coef=0.1, disc_hid=(32, 32),
+                         demo_batch=128, demo_minibatch=None, n_disc=2, capacity=None, n_demo=600, rounds=2,
+                         norm_policy=True, norm_disc=True, obs_dtype="float32"),
+    # SURVEY 8d variant T (tuned_hps/gail_seals_half_cheetah_best_hp_eval.json shape): rounds of n_steps = 4, PPO
+    # minibatch 1/8 of the rollout x 5 epochs, gamma 0.95, clip 0.1, replay capacity SMALLER than a round
+    # (truncation on every store) and demo batches larger than the ring (heavy sampling with replacement).
+    "gail_tuned": dict(algo="gail", n_envs=16, horizon=6, obs_dim=17, act_dim=6, n_discrete=None,
+                       n_steps=4, ppo_batch=8, n_epochs=5, ent_coef=0.0, disc_hid=(32, 32),
+                       demo_batch=128, demo_minibatch=None, n_disc=4, capacity=32, n_demo=500, rounds=4,
+                       norm_policy=True, norm_disc=True, obs_dtype="float32",
+                       ppo_kwargs=dict(gamma=0.95, clip_range=0.1, gae_lambda=0.9)),
     # AIRL, shaped reward net, NormalizedRewardNet output norm (script default), use_next_state.
     "airl_box": dict(algo="airl", n_envs=8, horizon=10, obs_dim=11, act_dim=3, n_discrete=None,
                      n_steps=16, ppo_batch=32, n_epochs=2, ent_coef=0.0, disc_hid=(32,),
@@ -122,7 +142,8 @@ def build_trainer(impl: str, cfg, log_dir: str, device: str = "cpu", module_net:
         pk = dict(features_extractor_class=ns.NormalizeFeaturesExtractor,
                   features_extractor_kwargs=dict(normalize_class=ns.RunningNorm))
     algo = ns.PPO(ns.FeedForward32Policy, venv, n_steps=cfg["n_steps"], batch_size=cfg["ppo_batch"],
-                  n_epochs=cfg["n_epochs"], ent_coef=cfg["ent_coef"], seed=0, policy_kwargs=pk, device=device)
+                  n_epochs=cfg["n_epochs"], ent_coef=cfg["ent_coef"], seed=0, policy_kwargs=pk, device=device,
+                  **cfg.get("ppo_kwargs", {}))
     kw = dict(normalize_input_layer=disc_norm) if cfg["norm_disc"] else {}
     if cfg["algo"] == "gail":
         net = ns.BasicRewardNet(venv.observation_space, venv.action_space, hid_sizes=cfg["disc_hid"], **kw)
