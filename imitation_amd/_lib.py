@@ -90,6 +90,7 @@ _SIGS = {
     "ia_disc_step_basic": ([C.POINTER(DiscStepArgs), _P], C.c_int),
     "ia_disc_fused_ws_floats": ([C.POINTER(MlpDesc), _I, _I], C.c_int64),
     "ia_disc_fused_debug_timing": ([_P], C.c_int),
+    "ia_disc_fused_tile_rows": ([_I], C.c_int),
     "ia_disc_assemble_round": ([C.POINTER(DiscStepArgs), _I, _L, _L, _L, _P], C.c_int),
     "ia_disc_fused_prepare": ([C.POINTER(MlpDesc), _P, _I, _I, _P, _P], C.c_int),
     "ia_airl_logits": ([_P, _P, _P, _P, _P, _F, _I, _P, _P], C.c_int),

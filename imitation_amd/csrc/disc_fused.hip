@@ -26,9 +26,13 @@ namespace {
 
 typedef float f4 __attribute__((ext_vector_type(4)));
 
-constexpr int FB_M = 64;     // rows per workgroup tile
+// Tile kernels (K2, K3) are templated on BM = rows per workgroup: 4 waves per 32 rows, each wave 32 rows x H/4
+// columns. BM = 64 (512 threads, one workgroup per CU) is the default. BM = 32 (256 threads, <= 75 KB LDS) puts two
+// workgroups on a CU -- measured no faster at R = 16 384 (116 vs 107 us per update): all 512 workgroups start
+// together and run in lockstep, so their prologues / epilogues coincide instead of hiding behind each other's
+// MFMA loop, and every workgroup streams all of W2 through LDS (twice the ring traffic per CU).
 constexpr int FB_K = 16;     // K chunk of the streamed operand
-constexpr int FB_NT = 512;   // threads per workgroup: 8 waves = 2 (rows) x 4 (columns)
+constexpr int NS = 2;        // ring stages
 constexpr int XP = 25;       // padded row length of the x tile / W1 in LDS (D <= 24), odd -> conflict-free
 constexpr int XP3 = 33;      // x tile as a 32-wide B operand (K3)
 constexpr int A_LD = FB_K + 1;
@@ -56,9 +60,10 @@ struct FusedArgs {
 
 // x tile of rows [row0, row0+64): raw X normalised on the fly -> xs[row][ld], columns >= D and rows >= R zero.
 // (X - mean) / sqrt(var + eps): util/networks.py:91 as ia_running_norm_apply computes it.
+template <int BM>
 __device__ __forceinline__ void load_x_tile(const FusedArgs& a, int row0, float* __restrict__ xs, int ld, int tid) {
   const int quads = a.ldx >> 2;
-  if (tid < FB_M * quads) {
+  if (tid < BM * quads) {
     const int row = tid / quads, q = tid - row * quads;
     const int gi = row0 + row;
     const f4 v = *reinterpret_cast<const f4*>(a.X + (long long)min(gi, a.R - 1) * a.ldx + 4 * q);
@@ -111,55 +116,51 @@ __device__ __forceinline__ float reduce8_in_wave(float (&v)[8], int lane) {
   return t;
 }
 
-// LDS ring pipeline shared by K2 / K3: chunk c is multiplied out of stage c%3 in two halves of Q k-steps;
-// the fragments of a half are requested one half ahead (also across the chunk barrier: stage (c+1)%3 has
-// been complete since barrier c-1), the next-but-one chunk goes from registers to LDS between the halves.
-template <int H, int TN, class ARow>
-struct RingMma {
-  static constexpr int Q = FB_K / 4;  // k-steps per half
-  float af[2][Q], bf[2][Q][TN];
-  // a_at(c, ks) -> the lane's A fragment of k-step ks of chunk c; Bs = stage base + lane column offset
-  __device__ __forceinline__ void rd(const ARow& a_at, const float* __restrict__ Bs, int c, int half, int lh) {
+// One K chunk (FB_K = 16 deep) of a wave's 32 x (TN*32) tile: all fragments of the chunk are requested, then the
+// MFMAs issue (with two workgroups per CU the other workgroup's waves fill this wave's LDS round trip).
+// a_at(ks) = the lane's A fragment of k-step ks; Bs = chunk base + lane column.
+template <int H, int TN, class AAt>
+__device__ __forceinline__ void chunk_mma(f32x16 (&acc)[TN], const AAt& a_at, const float* __restrict__ Bs, int lh) {
+  constexpr int KS = FB_K / 2;
+  float af[KS], bf[KS][TN];
 #pragma unroll
-    for (int s = 0; s < Q; ++s) {
-      const int ks = half * Q + s;
-      af[half][s] = a_at(c, ks);
+  for (int ks = 0; ks < KS; ++ks) {
+    af[ks] = a_at(ks);
 #pragma unroll
-      for (int t = 0; t < TN; ++t) bf[half][s][t] = Bs[(2 * ks + lh) * H + t * 32];
-    }
+    for (int t = 0; t < TN; ++t) bf[ks][t] = Bs[(2 * ks + lh) * H + t * 32];
   }
-  __device__ __forceinline__ void mma(f32x16 (&acc)[TN], int half) {
+  __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int s = 0; s < Q; ++s)
+  for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
-      for (int t = 0; t < TN; ++t)
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[half][s], bf[half][s][t], acc[t], 0, 0, 0);
-  }
-};
+    for (int t = 0; t < TN; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[ks], bf[ks][t], acc[t], 0, 0, 0);
+  __builtin_amdgcn_sched_barrier(0);
+}
 
-template <int H>
-__global__ __launch_bounds__(FB_NT) void disc_fwd_kernel(FusedArgs a) {
+template <int H, int BM>
+__global__ __launch_bounds__(BM * 8) void disc_fwd_kernel(FusedArgs a) {
+  constexpr int NT = BM * 8, NW = NT / 64;
   constexpr int TN = H / 128;          // 32-column MFMA tiles per wave
   constexpr int WC = TN * 32;          // columns per wave
   constexpr int LDH = H + 1;
   constexpr int NCH = H / FB_K;
   constexpr int BST = FB_K * H;        // floats per B stage
-  constexpr int BV = BST / 4 / FB_NT;  // float4 per thread per B chunk
-  static_assert(BST % (4 * FB_NT) == 0, "B chunk must divide among the threads");
+  constexpr int BV = BST / 4 / NT;     // float4 per thread per B chunk
+  static_assert(BST % (4 * NT) == 0, "B chunk must divide among the threads");
+  static_assert(H * XP <= NS * BST, "the W1 image borrows the ring during layer 1");
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* h1s = smem;                   // [64][LDH]
-  float* bs = h1s + FB_M * LDH;        // 3 x [FB_K][H]; stages 1, 2 hold the W1 image [H][XP] during layer 1
-  float* red = bs + 3 * BST;           // [4][64] logit partials per column group
-  float* dls = red + 4 * FB_M;         // [64] dlogit of the tile's rows
-  float* w3red = dls + FB_M;           // [2][H] dW3 partials per row group
-  float* xs = w3red + 2 * H;           // [64][XP]
-  float* w1s = bs + BST;
-  static_assert(H * XP <= 2 * BST, "W1 image must fit into ring stages 1 and 2");
+  float* h1s = smem;                   // [BM][LDH]   h1 tile, later the dh2 tile
+  float* bs = h1s + BM * LDH;          // NS x [FB_K][H] ring; holds the W1 image [H][XP] during layer 1
+  float* red = bs + NS * BST;          // [4][BM] logit partials per column group
+  float* dls = red + 4 * BM;           // [BM] dlogit of the tile's rows
+  float* w3red = dls + BM;             // [BM/32][H] dW3 partials per row group
+  float* xs = w3red + (BM / 32) * H;   // [BM][XP]
+  float* w1s = bs;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, lh = lane >> 5;
   const int wm = wave >> 2, wn = wave & 3;
-  const int row0 = blockIdx.x * FB_M;
+  const int row0 = blockIdx.x * BM;
   const int D = a.D;
   const float* W1 = a.params;
   const float* b1 = W1 + (long long)H * D;
@@ -173,19 +174,19 @@ __global__ __launch_bounds__(FB_NT) void disc_fwd_kernel(FusedArgs a) {
   auto bload = [&](int c) {
 #pragma unroll
     for (int i = 0; i < BV; ++i)
-      rb[i] = *reinterpret_cast<const f4*>(a.W2T + (long long)c * BST + (long long)(tid + i * FB_NT) * 4);
+      rb[i] = *reinterpret_cast<const f4*>(a.W2T + (long long)c * BST + (long long)(tid + i * NT) * 4);
   };
   auto bstore = [&](int c) {
-    float* S = bs + (c % 3) * BST;
+    float* S = bs + (c % NS) * BST;
 #pragma unroll
-    for (int i = 0; i < BV; ++i) *reinterpret_cast<f4*>(S + (tid + i * FB_NT) * 4) = rb[i];
+    for (int i = 0; i < BV; ++i) *reinterpret_cast<f4*>(S + (tid + i * NT) * 4) = rb[i];
   };
   constexpr int W1Q = H * XP / 4;                      // float4 of the W1 image
-  constexpr int W1V = (W1Q + FB_NT - 1) / FB_NT;
+  constexpr int W1V = (W1Q + NT - 1) / NT;
   static_assert((H * XP) % 4 == 0, "W1 image is copied in 16-byte pieces");
   f4 w1v[W1V];
 #pragma unroll
-  for (int i = 0; i < W1V; ++i) w1v[i] = reinterpret_cast<const f4*>(a.W1P)[min(tid + i * FB_NT, W1Q - 1)];
+  for (int i = 0; i < W1V; ++i) w1v[i] = reinterpret_cast<const f4*>(a.W1P)[min(tid + i * NT, W1Q - 1)];
   float b1v[TN], b2v[TN], w3v[TN];
 #pragma unroll
   for (int t = 0; t < TN; ++t) {
@@ -193,18 +194,16 @@ __global__ __launch_bounds__(FB_NT) void disc_fwd_kernel(FusedArgs a) {
     b1v[t] = b1[col]; b2v[t] = b2[col]; w3v[t] = w3[col];
   }
   const float b3v = b3[0];
-  load_x_tile(a, row0, xs, XP, tid);
-  for (int e = tid; e < FB_M * (24 - a.ldx); e += FB_NT) {  // columns [ldx, 24) of the K = 24 operand
+  load_x_tile<BM>(a, row0, xs, XP, tid);
+  for (int e = tid; e < BM * (24 - a.ldx); e += NT) {  // columns [ldx, 24) of the K = 24 operand
     const int w = 24 - a.ldx;
     const int row = e / w;
     xs[row * XP + a.ldx + e - row * w] = 0.f;
   }
-  bload(0);
+  bload(0);                                            // stays in registers until layer 1 is done with the ring
 #pragma unroll
   for (int i = 0; i < W1V; ++i)
-    if (tid + i * FB_NT < W1Q) reinterpret_cast<f4*>(w1s)[tid + i * FB_NT] = w1v[i];
-  bstore(0);
-  bload(1);
+    if (tid + i * NT < W1Q) reinterpret_cast<f4*>(w1s)[tid + i * NT] = w1v[i];
   __syncthreads();
   FUSED_STAMP(a, 1);
 
@@ -228,6 +227,7 @@ __global__ __launch_bounds__(FB_NT) void disc_fwd_kernel(FusedArgs a) {
       for (int t = 0; t < TN; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[ks], bf[ks][t], acc[t], 0, 0, 0);
   }
   FUSED_STAMP(a, 2);
+  unsigned long long mword = 0ull;
 #pragma unroll
   for (int t = 0; t < TN; ++t) {
     const int col = wn * WC + t * 32 + li;
@@ -237,36 +237,33 @@ __global__ __launch_bounds__(FB_NT) void disc_fwd_kernel(FusedArgs a) {
       const float v = fmaxf(acc[t][r] + b1v[t], 0.f);
       h1s[row * LDH + col] = v;
       // relu'(h1) for the backward tile kernel: one 64-bit ballot per accumulator register instead of a
-      // 64 KB re-read of the tile
+      // re-read of the tile; lane (t*16 + r) keeps word (t, r) -> ONE coalesced store per wave below
       const unsigned long long m = __ballot(v > 0.f);
-      if (lane == 0) a.h1mask[((long long)blockIdx.x * 8 + wave) * (TN * 16) + t * 16 + r] = m;
+      if (lane == t * 16 + r) mword = m;
       acc[t][r] = 0.f;
     }
   }
-  __syncthreads();   // every wave is done with the W1 image: stages 1, 2 are the ring's from here on
-  bstore(1);
-  bload(2);
+  if (lane < TN * 16) a.h1mask[((long long)blockIdx.x * NW + wave) * (TN * 16) + lane] = mword;
+  __syncthreads();   // every wave is done with the W1 image: the ring is the ring from here on
+  bstore(0);
+  if (NCH > 1) bload(1);
   __syncthreads();
   FUSED_STAMP(a, 3);
 
-  // ---- layer 2: h2 = relu(h1 . W2^T + b2): A = the LDS tile, B = W2T chunks through a 3-stage ring.
-  // At the top of iteration c: stages c%3 and (c+1)%3 are complete (barriers c-2, c-1), the registers hold
-  // chunk c+2, which goes to stage (c+2)%3 == (c-1)%3 -- last read in iteration c-1, before barrier c-1.
+  // ---- layer 2: h2 = relu(h1 . W2^T + b2): A = the LDS tile, B = W2T chunks through the ring. Iteration c: the
+  // registers (chunk c+1) go to stage (c+1)%2 -- last read in iteration c-1, before barrier c-1 --, chunk c+2 is
+  // requested, chunk c is multiplied out of stage c%2 (complete since barrier c-1), barrier c.
   {
     const float* Ar = h1s + (wm * 32 + li) * LDH + lh;
-    auto a_at = [&](int c, int ks) { return Ar[c * FB_K + 2 * ks]; };
-    RingMma<H, TN, decltype(a_at)> pipe;
     const int boff = wn * WC + li;
-    pipe.rd(a_at, bs + boff, 0, 0, lh);
-    // the tile's h1 goes out to HBM (for the weight gradients) in 16 slices, one per chunk, read back from
-    // LDS row-major: 256-byte coalesced stores trickling beside the MFMAs instead of one 16.8 MB burst of
-    // all workgroups at once
-    constexpr int HQ = FB_M * H / NCH / 4;   // 16-byte pieces per chunk (256: the first four waves store one each)
-    static_assert(HQ <= FB_NT, "one 16-byte piece per thread and chunk at most");
+    // the tile's h1 goes out to HBM (for the weight gradients) in slices, one per chunk, read back from LDS
+    // row-major: 16-byte coalesced stores trickling beside the MFMAs instead of one burst of all workgroups
+    constexpr int HQ = BM * H / NCH / 4;     // 16-byte pieces per chunk
+    static_assert(HQ <= NT, "one 16-byte piece per thread and chunk at most");
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
-      const float* Bs = bs + (c % 3) * BST + boff;
-      pipe.rd(a_at, Bs, c, 1, lh);
+      if (c + 1 < NCH) bstore(c + 1);
+      if (c + 2 < NCH) bload(c + 2);
       f4 hv;
       const int e4 = c * HQ + min(tid, HQ - 1);
       const int hrow = e4 / (H / 4), hcol = (e4 % (H / 4)) * 4;
@@ -274,16 +271,9 @@ __global__ __launch_bounds__(FB_NT) void disc_fwd_kernel(FusedArgs a) {
         const float* hp = h1s + hrow * LDH + hcol;
         hv.x = hp[0]; hv.y = hp[1]; hv.z = hp[2]; hv.w = hp[3];
       }
-      __builtin_amdgcn_sched_barrier(0);
-      pipe.mma(acc, 0);
-      __builtin_amdgcn_sched_barrier(0);
+      auto a_at = [&](int ks) { return Ar[c * FB_K + 2 * ks]; };
+      chunk_mma<H, TN>(acc, a_at, bs + (c % NS) * BST + boff, lh);
       if (tid < HQ && row0 + hrow < a.R) *reinterpret_cast<f4*>(a.h1 + (long long)(row0 + hrow) * H + hcol) = hv;
-      if (c + 2 < NCH) bstore(c + 2);
-      if (c + 3 < NCH) bload(c + 3);
-      __builtin_amdgcn_sched_barrier(0);
-      pipe.mma(acc, 1);
-      __builtin_amdgcn_sched_barrier(0);
-      if (c + 1 < NCH) pipe.rd(a_at, bs + ((c + 1) % 3) * BST + boff, c + 1, 0, lh);
       __syncthreads();
     }
   }
@@ -305,21 +295,22 @@ __global__ __launch_bounds__(FB_NT) void disc_fwd_kernel(FusedArgs a) {
   {
     const float tot = reduce16_in_half(p, lane);
     const int r = ((lane >> 4) & 1) * 8 + ((lane >> 3) & 1) * 4 + ((lane >> 2) & 1) * 2 + ((lane >> 1) & 1);
-    if ((lane & 1) == 0) red[wn * FB_M + wm * 32 + 4 * lh + rowoff(r)] = tot;
+    if ((lane & 1) == 0) red[wn * BM + wm * 32 + 4 * lh + rowoff(r)] = tot;
   }
   __syncthreads();
   FUSED_STAMP(a, 5);
-  if (tid < FB_M) {  // wave 0: one row per lane
-    const int gi = row0 + tid;
-    const bool valid = gi < a.R;
-    const float x = ((red[tid] + red[FB_M + tid]) + red[2 * FB_M + tid]) + red[3 * FB_M + tid] + b3v;
+  if (wave == 0) {  // one row per lane (lanes >= BM idle but take part in the reduction)
+    const int row = min(lane, BM - 1);
+    const int gi = row0 + row;
+    const bool valid = lane < BM && gi < a.R;
+    const float x = ((red[row] + red[BM + row]) + red[2 * BM + row]) + red[3 * BM + row] + b3v;
     // adversarial/common.py:360-368 + 27-92, the arithmetic of bce_kernel (mlp.hip)
     const float y = gi < a.n_expert ? 1.f : 0.f;
     const float lse = log1pf(expf(-fabsf(x)));
     const float pr = 1.f / (1.f + expf(-x));
     const float inv = a.loss_scale / (float)a.R;
     const float dl = valid ? (pr - y) * inv : 0.f;
-    dls[tid] = dl;
+    if (lane < BM) dls[lane] = dl;
     if (valid) {
       a.logits[gi] = x;
       if (a.dlogits) a.dlogits[gi] = dl;
@@ -361,11 +352,16 @@ __global__ __launch_bounds__(FB_NT) void disc_fwd_kernel(FusedArgs a) {
     if (lh == 0) w3red[wm * H + col] = s;
   }
   __syncthreads();
-  if (tid < H) a.P3[(long long)blockIdx.x * (H + 1) + tid] = w3red[tid] + w3red[H + tid];
+  if (tid < H) {
+    float s = w3red[tid];
+#pragma unroll
+    for (int g = 1; g < BM / 32; ++g) s += w3red[g * H + tid];
+    a.P3[(long long)blockIdx.x * (H + 1) + tid] = s;
+  }
   // dh2 tile -> HBM row-major in 16-byte stores (a dword-per-lane epilogue is store-issue bound)
 #pragma unroll
-  for (int i = 0; i < FB_M * H / 4 / FB_NT; ++i) {
-    const int e4 = tid + i * FB_NT;
+  for (int i = 0; i < BM * H / 4 / NT; ++i) {
+    const int e4 = tid + i * NT;
     const int row = e4 / (H / 4), c4 = (e4 % (H / 4)) * 4;
     const float* hp = h1s + row * LDH + c4;
     f4 v;
@@ -376,69 +372,65 @@ __global__ __launch_bounds__(FB_NT) void disc_fwd_kernel(FusedArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------- K3
-template <int H>
-__global__ __launch_bounds__(FB_NT) void disc_bwd_kernel(FusedArgs a) {
+template <int H, int BM>
+__global__ __launch_bounds__(BM * 8) void disc_bwd_kernel(FusedArgs a) {
+  constexpr int NT = BM * 8, NW = NT / 64;
   constexpr int TN = H / 128;
   constexpr int WC = TN * 32;
   constexpr int LDH = H + 1;
   constexpr int NCH = H / FB_K;
   constexpr int BST = FB_K * H;
-  constexpr int BV = BST / 4 / FB_NT;
-  constexpr int AST = FB_M * A_LD;
+  constexpr int BV = BST / 4 / NT;
+  constexpr int AST = BM * A_LD;
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* xs = smem;                    // [64][XP3]: xn | 1 | 0 ... (the ones column makes db1 a column of dW1)
-  float* d1s = xs + FB_M * XP3;        // [64][LDH]  dh1 tile
-  float* bs = d1s + FB_M * LDH;        // 3 x [FB_K][H]   W2 chunks (k = out unit, n = in unit)
-  float* as = bs + 3 * BST;            // 3 x [64][A_LD]  dh2 chunks
+  float* xs = smem;                    // [BM][XP3]: xn | 1 | 0 ... (the ones column makes db1 a column of dW1)
+  float* d1s = xs + BM * XP3;          // [BM][LDH]  dh1 tile
+  float* bs = d1s + BM * LDH;          // NS x [FB_K][H]  W2 chunks (k = out unit, n = in unit); later the P1 slab image
+  float* as = bs + NS * BST;           // NS x [BM][A_LD]  dh2 chunks
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, lh = lane >> 5;
   const int wm = wave >> 2, wn = wave & 3;
-  const int row0 = blockIdx.x * FB_M;
+  const int row0 = blockIdx.x * BM;
   const int D = a.D;
   const float* W2 = a.params + (long long)H * D + H;
 
   FUSED_STAMP(a, 8);
   f4 rb[BV], ra;
   const int arow = tid >> 2, aq = tid & 3;
-  const bool a_thread = tid < FB_M * 4;
+  const bool a_thread = tid < BM * 4;
   const float* abase = a.dh2 + (long long)min(row0 + arow, a.R - 1) * H + aq * 4;
   const bool a_valid = a_thread && (row0 + arow < a.R);
   auto gload = [&](int c) {
 #pragma unroll
     for (int i = 0; i < BV; ++i)
-      rb[i] = *reinterpret_cast<const f4*>(W2 + (long long)c * BST + (long long)(tid + i * FB_NT) * 4);
+      rb[i] = *reinterpret_cast<const f4*>(W2 + (long long)c * BST + (long long)(tid + i * NT) * 4);
     if (a_thread) ra = *reinterpret_cast<const f4*>(abase + c * FB_K);
   };
   auto lstore = [&](int c) {
-    float* S = bs + (c % 3) * BST;
+    float* S = bs + (c % NS) * BST;
 #pragma unroll
-    for (int i = 0; i < BV; ++i) *reinterpret_cast<f4*>(S + (tid + i * FB_NT) * 4) = rb[i];
+    for (int i = 0; i < BV; ++i) *reinterpret_cast<f4*>(S + (tid + i * NT) * 4) = rb[i];
     if (a_thread) {
-      float* d = as + (c % 3) * AST + arow * A_LD + aq * 4;
+      float* d = as + (c % NS) * AST + arow * A_LD + aq * 4;
       d[0] = a_valid ? ra.x : 0.f; d[1] = a_valid ? ra.y : 0.f; d[2] = a_valid ? ra.z : 0.f; d[3] = a_valid ? ra.w : 0.f;
     }
   };
   gload(0);
-  f4 rb1[BV], ra1;   // chunk 1 requested right behind chunk 0 (one cold round trip, not two)
-#pragma unroll
-  for (int i = 0; i < BV; ++i)
-    rb1[i] = *reinterpret_cast<const f4*>(W2 + (long long)BST + (long long)(tid + i * FB_NT) * 4);
-  if (a_thread) ra1 = *reinterpret_cast<const f4*>(abase + FB_K);
-  load_x_tile(a, row0, xs, XP3, tid);
-  for (int e = tid; e < FB_M * (XP3 - 1 - a.ldx); e += FB_NT) {  // columns [ldx, 32) of the B operand
+  // relu'(h1) of the tile: the forward kernel's ballots, same (wave, tile, register) decomposition
+  // (lane l < TN*16 holds word l: one coalesced load; word (t, r) is broadcast with readlane where it is used)
+  const unsigned long long hmw = a.h1mask[((long long)blockIdx.x * NW + wave) * (TN * 16) + min(lane, TN * 16 - 1)];
+  const unsigned int hm_lo = (unsigned int)hmw, hm_hi = (unsigned int)(hmw >> 32);
+  load_x_tile<BM>(a, row0, xs, XP3, tid);
+  for (int e = tid; e < BM * (XP3 - 1 - a.ldx); e += NT) {  // columns [ldx, 32) of the B operand
     const int w = XP3 - 1 - a.ldx;
     const int row = e / w, c = a.ldx + e - row * w;
     xs[row * XP3 + c] = 0.f;
   }
   lstore(0);
-#pragma unroll
-  for (int i = 0; i < BV; ++i) rb[i] = rb1[i];
-  ra = ra1;
-  lstore(1);
-  gload(2);
+  if (NCH > 1) gload(1);
   __syncthreads();
-  if (tid < FB_M) xs[tid * XP3 + D] = 1.f;  // after the tile writes above (column D < 32 is a zero column there)
+  if (tid < BM) xs[tid * XP3 + D] = 1.f;  // after the tile writes above (column D < 32 is a zero column there)
   FUSED_STAMP(a, 9);
 
   f32x16 acc[TN];
@@ -446,34 +438,15 @@ __global__ __launch_bounds__(FB_NT) void disc_bwd_kernel(FusedArgs a) {
   for (int t = 0; t < TN; ++t)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-  // relu'(h1) of the tile: the forward kernel's ballots, same (wave, tile, register) decomposition
-  unsigned long long hm[TN][16];
-  {
-    const unsigned long long* mp = a.h1mask + ((long long)blockIdx.x * 8 + __builtin_amdgcn_readfirstlane(wave)) * (TN * 16);
-#pragma unroll
-    for (int t = 0; t < TN; ++t)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) hm[t][r] = mp[t * 16 + r];
-  }
   {
     const float* Ab = as + (wm * 32 + li) * A_LD + lh;
-    auto a_at = [&](int c, int ks) { return Ab[(c % 3) * AST + 2 * ks]; };
-    RingMma<H, TN, decltype(a_at)> pipe;
     const int boff = wn * WC + li;
-    pipe.rd(a_at, bs + boff, 0, 0, lh);
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
-      const float* Bs = bs + (c % 3) * BST + boff;
-      pipe.rd(a_at, Bs, c, 1, lh);
-      __builtin_amdgcn_sched_barrier(0);
-      pipe.mma(acc, 0);
-      __builtin_amdgcn_sched_barrier(0);
-      if (c + 2 < NCH) lstore(c + 2);
-      if (c + 3 < NCH) gload(c + 3);
-      __builtin_amdgcn_sched_barrier(0);
-      pipe.mma(acc, 1);
-      __builtin_amdgcn_sched_barrier(0);
-      if (c + 1 < NCH) pipe.rd(a_at, bs + ((c + 1) % 3) * BST + boff, c + 1, 0, lh);
+      if (c + 1 < NCH) lstore(c + 1);
+      if (c + 2 < NCH) gload(c + 2);
+      auto a_at = [&](int ks) { return Ab[(c % NS) * AST + 2 * ks]; };
+      chunk_mma<H, TN>(acc, a_at, bs + (c % NS) * BST + boff, lh);
       __syncthreads();
     }
   }
@@ -481,46 +454,43 @@ __global__ __launch_bounds__(FB_NT) void disc_bwd_kernel(FusedArgs a) {
 #pragma unroll
   for (int t = 0; t < TN; ++t)
 #pragma unroll
-    for (int r = 0; r < 16; ++r)
-      d1s[(wm * 32 + 4 * lh + rowoff(r)) * LDH + wn * WC + t * 32 + li] = ((hm[t][r] >> lane) & 1ull) ? acc[t][r] : 0.f;
+    for (int r = 0; r < 16; ++r) {
+      const unsigned int wlo = __builtin_amdgcn_readlane(hm_lo, t * 16 + r), whi = __builtin_amdgcn_readlane(hm_hi, t * 16 + r);
+      const bool on = (((lh ? whi : wlo) >> li) & 1u) != 0u;
+      d1s[(wm * 32 + 4 * lh + rowoff(r)) * LDH + wn * WC + t * 32 + li] = on ? acc[t][r] : 0.f;
+    }
   __syncthreads();
   FUSED_STAMP(a, 11);
 
-  // ---- [dW1 | db1] partial [H, D + 1] = dh1^T . [xn | 1] over the tile's 64 rows (wave w owns hidden
-  //      units 32w..32w+31)
+  // ---- [dW1 | db1] partial [H, D + 1] = dh1^T . [xn | 1] over the tile's BM rows: one 32-unit M tile per wave
+  //      and pass; the slab image [W1 grad [H][D] | b1 grad [H]] is assembled in LDS (the ring is free by now) ...
   const long long n1 = (long long)H * D + H;
   float* P1 = a.P1 + (long long)blockIdx.x * n1;
-  if (wave < H / 32) {
+  for (int mt = wave; mt < H / 32; mt += NW) {
     f32x16 acc1;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc1[r] = 0.f;
-    constexpr int Q = 8;
-    float af[2][Q], bf[2][Q];
-    auto rd = [&](int q) {
+    float af[BM / 2], bf[BM / 2];
 #pragma unroll
-      for (int s = 0; s < Q; ++s) {
-        const int k = 2 * (q * Q + s) + lh;
-        af[q & 1][s] = d1s[k * LDH + wave * 32 + li];
-        bf[q & 1][s] = xs[k * XP3 + li];
-      }
-    };
-    rd(0);
-#pragma unroll
-    for (int q = 0; q < FB_M / 2 / Q; ++q) {
-      if (q + 1 < FB_M / 2 / Q) rd(q + 1);
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int s = 0; s < Q; ++s) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(af[q & 1][s], bf[q & 1][s], acc1, 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
+    for (int s = 0; s < BM / 2; ++s) {
+      const int k = 2 * s + lh;
+      af[s] = d1s[k * LDH + mt * 32 + li];
+      bf[s] = xs[k * XP3 + li];
     }
+#pragma unroll
+    for (int s = 0; s < BM / 2; ++s) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(af[s], bf[s], acc1, 0, 0, 0);
     if (li <= D) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int i = wave * 32 + 4 * lh + rowoff(r);
-        P1[li < D ? (long long)i * D + li : (long long)H * D + i] = acc1[r];
+        const int i = mt * 32 + 4 * lh + rowoff(r);
+        bs[li < D ? i * D + li : H * D + i] = acc1[r];
       }
     }
   }
+  __syncthreads();
+  // ... and leaves in 16-byte coalesced stores (a dword-per-lane store of 23-float rows is store-issue bound)
+  for (int e = tid; e < (int)(n1 / 4); e += NT)
+    reinterpret_cast<f4*>(P1)[e] = reinterpret_cast<const f4*>(bs)[e];
   FUSED_STAMP(a, 12);
 }
 
@@ -822,7 +792,7 @@ struct FusedWs { float* P1; float* P3; float* part; float* W2T; float* W1P; unsi
 
 inline FusedWs fused_ws_layout(const ia_mlp_desc* d, int R, float* base) {
   const long long D = d->dims[0], H = d->dims[1];
-  const long long tiles = cdivi(R, FB_M);
+  const long long tiles = cdivi(R, 32);   // sized for 32-row tiles (64-row tiles use half of it)
   FusedWs w;
   long long o = 0;
   w.P1 = base + o; o += tiles * (H * D + H);
@@ -831,29 +801,32 @@ inline FusedWs fused_ws_layout(const ia_mlp_desc* d, int R, float* base) {
   o = (o + 3) / 4 * 4;                     // 16-byte aligned W2T rows
   w.W2T = base + o; o += H * H;
   w.W1P = base + o; o += H * XP;
-  w.h1mask = reinterpret_cast<unsigned long long*>(base + o); o += tiles * 8 * (H / 128) * 16 * 2;
+  w.h1mask = reinterpret_cast<unsigned long long*>(base + o); o += tiles * 4 * (H / 128) * 16 * 2;
   w.ticket = reinterpret_cast<unsigned int*>(base + o); o += 4;
   w.total = o;
   return w;
 }
 
-template <int H>
-int launch_fused_tiles(const FusedArgs& fa, int tiles, hipStream_t stream) {
-  constexpr size_t smem_f = sizeof(float) * (FB_M * (H + 1) + 3 * FB_K * H + 4 * FB_M + FB_M + 2 * H + FB_M * XP);
-  constexpr size_t smem_b = sizeof(float) * (FB_M * XP3 + FB_M * (H + 1) + 3 * FB_K * H + 3 * FB_M * A_LD);
+int g_fused_bm = 64;   // rows per tile workgroup (tuning: ia_disc_fused_tile_rows)
+
+template <int H, int BM>
+int launch_fused_tiles(const FusedArgs& fa, int R, hipStream_t stream) {
+  constexpr size_t smem_f = sizeof(float) * (BM * (H + 1) + NS * FB_K * H + 4 * BM + BM + (BM / 32) * H + BM * XP);
+  constexpr size_t smem_b = sizeof(float) * (BM * XP3 + BM * (H + 1) + NS * FB_K * H + NS * BM * A_LD);
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(disc_fwd_kernel<H>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(disc_fwd_kernel<H, BM>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_f);
     if (e != hipSuccess) return (int)e;
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(disc_bwd_kernel<H>),
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(disc_bwd_kernel<H, BM>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_b);
     if (e != hipSuccess) return (int)e;
     attr_set = true;
   }
-  hipLaunchKernelGGL(disc_fwd_kernel<H>, dim3(tiles), dim3(FB_NT), smem_f, stream, fa);
+  const int tiles = cdivi(R, BM);
+  hipLaunchKernelGGL((disc_fwd_kernel<H, BM>), dim3(tiles), dim3(BM * 8), smem_f, stream, fa);
   IA_CHECK_LAUNCH();
-  hipLaunchKernelGGL(disc_bwd_kernel<H>, dim3(tiles), dim3(FB_NT), smem_b, stream, fa);
+  hipLaunchKernelGGL((disc_bwd_kernel<H, BM>), dim3(tiles), dim3(BM * 8), smem_b, stream, fa);
   IA_CHECK_LAUNCH();
   return IA_OK;
 }
@@ -861,6 +834,7 @@ int launch_fused_tiles(const FusedArgs& fa, int tiles, hipStream_t stream) {
 }  // namespace
 
 namespace { long long* g_fused_dbg = nullptr; }
+extern "C" int ia_disc_fused_tile_rows(int rows) { g_fused_bm = rows == 32 ? 32 : 64; return IA_OK; }
 extern "C" int ia_disc_fused_debug_timing(void* device_buffer_16xi64) {
   g_fused_dbg = static_cast<long long*>(device_buffer_16xi64);
   return IA_OK;
@@ -927,7 +901,8 @@ int ia_disc_step_fused(const ia_disc_step_args* a, void* stream_) {
   const int R = a->n0 + a->n1, D = d->dims[0], H = d->dims[1];
   if (!fused_shape_ok(d, a->ldx) || !a->fused_ws) return IA_ERR_UNSUPPORTED;
   const FusedWs w = fused_ws_layout(d, R, a->fused_ws);
-  const int tiles = cdivi(R, FB_M), slabs = cdivi(R, RN_ROWS_PER_BLOCK);
+  const int bm = g_fused_bm == 64 ? 64 : 32;
+  const int tiles = cdivi(R, bm), slabs = cdivi(R, RN_ROWS_PER_BLOCK);
   const long long nW1 = (long long)H * D, n1 = nW1 + H, n2 = (long long)H * H + H, n3 = H + 1, tot = n1 + n2 + n3;
 
   AssembleArgs as{};
@@ -956,7 +931,9 @@ int ia_disc_step_fused(const ia_disc_step_args* a, void* stream_) {
   fa.logits = a->logits; fa.dlogits = a->dlogits; fa.n_expert = a->n_expert; fa.loss_scale = a->loss_scale;
   fa.part = w.part; fa.P1 = w.P1; fa.P3 = w.P3;
   fa.dbg = g_fused_dbg;
-  int rc = H == 256 ? launch_fused_tiles<256>(fa, tiles, stream) : launch_fused_tiles<128>(fa, tiles, stream);
+  int rc;
+  if (bm == 64) rc = H == 256 ? launch_fused_tiles<256, 64>(fa, R, stream) : launch_fused_tiles<128, 64>(fa, R, stream);
+  else rc = H == 256 ? launch_fused_tiles<256, 32>(fa, R, stream) : launch_fused_tiles<128, 32>(fa, R, stream);
   if (rc) return rc;
 
   // dW2 [H,H] = dh2^T . h1 (+ db2 = column sums of dh2), split-K slabs inside `partials` ([splits][tot])

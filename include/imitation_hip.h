@@ -180,6 +180,9 @@ int ia_disc_fused_prepare(const ia_mlp_desc* d, const float* params, int R, int 
 /* Measurement only: when set to a device buffer of 16 int64, block 0 of the fused forward / backward tile
  * kernels stores the shader clock at its phase boundaries in [0..7] / [8..12] (NULL switches it off). */
 int ia_disc_fused_debug_timing(void* device_buffer_16xi64);
+/* Tuning: rows per workgroup of the fused tile kernels, 64 (default: one 512-thread workgroup per CU) or 32
+ * (two 256-thread workgroups per CU). */
+int ia_disc_fused_tile_rows(int rows);
 
 /* adversarial/airl.py:118 + rewards/reward_nets.py:701-736:
  * logits = g + gamma*(1-done)*h_next - h_cur - logp ; and the matching dOut routing. */

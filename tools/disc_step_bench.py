@@ -43,6 +43,8 @@ def step(net, opt, e, g, ie, ig, stats, bce_ws, adam=True):
                                adam=opt if adam else None)
 
 
+if os.environ.get("TILE_ROWS"):
+    L.load().ia_disc_fused_tile_rows(int(os.environ["TILE_ROWS"]))
 e, g = tables(1)
 gi = th.Generator().manual_seed(2)
 ie = th.randint(0, NE, (mb,), generator=gi).to(dev)
