@@ -85,12 +85,18 @@ class AdversarialTrainer(abc.ABC):
                  gen_train_timesteps: Optional[int] = None, gen_replay_buffer_capacity: Optional[int] = None,
                  custom_logger: Optional[imit_logger.HierarchicalLogger] = None, init_tensorboard: bool = False,
                  init_tensorboard_graph: bool = False, debug_use_ground_truth: bool = False,
-                 allow_variable_horizon: bool = False, data_parallel=None):
+                 allow_variable_horizon: bool = False, data_parallel=None, disc_grad_penalty_coef: float = 0.0,
+                 disc_grad_penalty_target: float = 1.0):
         self.demo_batch_size = demo_batch_size
         self.demo_minibatch_size = demo_minibatch_size or demo_batch_size
         if self.demo_batch_size % self.demo_minibatch_size != 0:
             raise ValueError("Batch size must be a multiple of minibatch size.")
         self._logger = custom_logger or imit_logger.configure()
+        # OPT-IN extension, default off (imitation_amd/grad_penalty.py): coef * E[(|grad_x D(x_hat)| - target)^2] on
+        # interpolates of the expert / generator rows, added to the BCE gradient. Not in the reference.
+        self.disc_grad_penalty_coef = float(disc_grad_penalty_coef)
+        self.disc_grad_penalty_target = float(disc_grad_penalty_target)
+        self.last_grad_penalty: Optional[th.Tensor] = None   # mean (|grad D| - target)^2 of the last minibatch (device)
         self.allow_variable_horizon = allow_variable_horizon
         self._horizon = None
         self.venv = venv
@@ -457,6 +463,7 @@ class AdversarialTrainer(abc.ABC):
             net = net.base
         single = self._dp is None or self._dp.world == 1
         if (self._module_net or not isinstance(net, reward_nets.BasicRewardNet) or self._needs_logp or not single
+                or self.disc_grad_penalty_coef > 0.0
                 or self._torch_opt_params is not None or self.demo_minibatch_size != self.demo_batch_size
                 or not isinstance(self._disc_opt, HipAdam) or len(drawn) > self._quirk_idx_dev.shape[0]):
             return None
@@ -506,16 +513,22 @@ class AdversarialTrainer(abc.ABC):
                 if prn is not None and pol.training and not reuse and not quirk_done:
                     self._policy_pass(sources, mb)
                 inline = reuse and not self._in_overlap
+                gp = self.disc_grad_penalty_coef > 0.0
                 ws = basic.disc_step_c(sources, mb, scale, stats_dev, self._bce_ws, accumulate=not first,
-                                       adam=fuse_adam if last else None, pnorm=prn if inline else None,
+                                       adam=fuse_adam if (last and not gp) else None, pnorm=prn if inline else None,
                                        pnorm_dim=pol.obs_dim if inline else 0, pre=pre)
+                if gp:
+                    self._add_grad_penalty(basic.mlp, ws["X_used"], ws["norm_used"], mb, scale)
                 if reuse and self._in_overlap:  # replayed on the generator stream after the PPO update
                     slot = self._quirk_moment_slot(ws["rn_ws"].numel())
                     slot.copy_(ws["rn_ws"])
                     self._quirk_pending.append((slot, 2 * mb, basic.mlp.dims[0]))
                 logits = ws["out"].reshape(-1)
-                fused_step = fused_step or (last and fuse_adam is not None)
+                fused_step = fused_step or (last and fuse_adam is not None and not gp)
             else:
+                if self.disc_grad_penalty_coef > 0.0:
+                    raise NotImplementedError("disc_grad_penalty_coef > 0 is implemented for BasicRewardNet "
+                                              "discriminators (GAIL; state-holder or imitation_amd.modules net)")
                 logp = None if (quirk_done and not self._needs_logp) else self._policy_pass(sources, mb)
                 logits = net.disc_forward(sources, mb, logp)
                 L.call("ia_bce_logits", L.ptr(logits), 2 * mb, mb, scale, L.ptr(self._dlogits),
@@ -532,6 +545,18 @@ class AdversarialTrainer(abc.ABC):
             self._disc_opt.step()
         self._disc_step += 1
         self._last_disc_logits = logits
+
+    def _add_grad_penalty(self, mlp, X: th.Tensor, norm, mb: int, scale: float) -> None:
+        """Adds the gradient-penalty parameter gradient of one minibatch (`X[2*mb, ldx]` = [expert | generator] rows
+        as assembled, `norm` = the (mean, var, eps) its forward normalised with, or None) to the flat gradient."""
+        from imitation_amd import grad_penalty
+        e = th.rand(mb).to(self._device)      # interpolation weights: torch's global CPU generator (only when enabled)
+        mean, var, eps = norm if norm is not None else (None, None, 0.0)
+        pen, g = grad_penalty.penalty_and_param_grad(mlp.flat, mlp.dims, mlp.desc.hidden_act, X, mlp.ldx, mb, e, mean,
+                                                     var, eps, self.disc_grad_penalty_coef * scale,
+                                                     self.disc_grad_penalty_target)
+        L.call("ia_reduce_partials", L.ptr(g), 1, g.numel(), 1.0, 1, L.ptr(mlp.grad), L.stream())
+        self.last_grad_penalty = pen
 
     def _module_batch(self, sources):
         """`common.py:564-603` for the autograd path: [expert | generator] rows of one minibatch as preprocessed
@@ -573,10 +598,29 @@ class AdversarialTrainer(abc.ABC):
                                                 None if logp is None else logp[:2 * mb].clone())
             loss, stats = ops.bce_expert_first(logits, mb, mb / B)
             loss.backward()
+            if self.disc_grad_penalty_coef > 0.0:
+                self._module_grad_penalty(state, action, next_state, done, mb, mb / B)
         self._disc_opt.step()
         stats_dev.copy_(stats)
         self._disc_step += 1
         self._last_disc_logits = logits.detach()
+
+    def _module_grad_penalty(self, state, action, next_state, done, mb: int, scale: float) -> None:
+        from imitation_amd import grad_penalty, modules
+        net = self._reward_net
+        if not (isinstance(net, modules.BasicRewardNet) and not self._needs_logp):
+            raise NotImplementedError("disc_grad_penalty_coef > 0 is implemented for BasicRewardNet discriminators")
+        mlp = net.mlp
+        with th.no_grad():
+            X = net.concat_inputs(state, action, next_state, done).contiguous()
+            nrm = getattr(mlp, mlp._norm_name) if mlp._norm_name is not None else None
+            e = th.rand(mb).to(self._device)
+            pen, g = grad_penalty.penalty_and_param_grad(
+                mlp.flat_parameters().contiguous(), mlp.dims, mlp.act, X, X.shape[1], mb, e,
+                None if nrm is None else nrm.running_mean, None if nrm is None else nrm.running_var,
+                0.0 if nrm is None else nrm.eps, self.disc_grad_penalty_coef * scale, self.disc_grad_penalty_target)
+            mlp.add_flat_grad(g)
+        self.last_grad_penalty = pen
 
     # ---- generator update (`common.py:391-425`) -------------------------------------------------
     def train_gen(self, total_timesteps: Optional[int] = None, learn_kwargs: Optional[Mapping] = None) -> None:

@@ -410,6 +410,54 @@ __global__ __launch_bounds__(256) void reward_norm_seq_kernel(const float* __res
   if (tid == 0 && update) { *mean = s_mean; *var = s_var; *count = s_cnt; }
 }
 
+// ---- gradient penalty (opt-in extension; BASELINE.json config 3 names it, the reference has none: SURVEY M1) ----
+// x_hat = e * x_expert + (1 - e) * x_gen per row pair, then the input normalisation with FROZEN statistics:
+// Xn[r, c] = (x_hat - mean[c]) / sqrt(var[c] + eps)  (mean == nullptr: x_hat itself); columns [D, ld) zero.
+__global__ void gp_interpolate_kernel(const float* __restrict__ X, int ldx, int B, int D, const float* __restrict__ e,
+                                      const float* __restrict__ mean, const float* __restrict__ var, float eps,
+                                      float* __restrict__ Xn, int ld) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long long)B * ld) return;
+  const int c = (int)(i % ld);
+  const long long r = i / ld;
+  float v = 0.f;
+  if (c < D) {
+    const float w = e[r];
+    v = w * X[r * ldx + c] + (1.f - w) * X[(r + B) * ldx + c];
+    if (mean != nullptr) v = (v - mean[c]) / sqrtf(var[c] + eps);
+  }
+  Xn[i] = v;
+}
+
+// Per row: g = gn / sigma (gradient w.r.t. the un-normalised input), n = |g|_2, penalty (n - target)^2,
+// Cn = d(coef / B * sum penalty) / d gn = coef / B * 2 (n - target) / n * g / sigma. One wave per row (lanes stride
+// the columns); pen[r] = (n - target)^2.
+__global__ __launch_bounds__(256) void gp_row_coeffs_kernel(const float* __restrict__ gn, int ld, int B, int D,
+                                                            const float* __restrict__ var, float eps, float coef,
+                                                            float target, float* __restrict__ Cn, float* __restrict__ pen) {
+  const int lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= B) return;
+  float sq = 0.f;
+  for (int c = lane; c < D; c += 64) {
+    const float inv = var ? 1.f / sqrtf(var[c] + eps) : 1.f;
+    const float g = gn[(long long)r * ld + c] * inv;
+    sq += g * g;
+  }
+  for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o, 64);
+  const float n = sqrtf(sq);
+  const float k = n > 0.f ? coef / (float)B * 2.f * (n - target) / n : 0.f;
+  for (int c = lane; c < ld; c += 64) {
+    float v = 0.f;
+    if (c < D) {
+      const float inv = var ? 1.f / sqrtf(var[c] + eps) : 1.f;
+      v = k * gn[(long long)r * ld + c] * inv * inv;
+    }
+    Cn[(long long)r * ld + c] = v;
+  }
+  if (lane == 0) pen[r] = (n - target) * (n - target);
+}
+
 inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 
 }  // namespace
@@ -789,6 +837,24 @@ int ia_disc_step_basic(const ia_disc_step_args* a, void* stream) {
   if (a->adam)
     return ia_adam_step(a->params, a->grads, a->exp_avg, a->exp_avg_sq, P, a->beta1, a->beta2, a->adam_eps,
                         a->weight_decay, a->step_size, a->bc2_sqrt, stream);
+  return IA_OK;
+}
+
+int ia_gp_interpolate(const float* X, int ldx, int B, int D, const float* e, const float* mean, const float* var,
+                      float eps, float* Xn, int ld, void* stream) {
+  if (!X || !e || !Xn || B <= 0 || D <= 0 || ld < D) return IA_ERR_ARG;
+  hipLaunchKernelGGL(gp_interpolate_kernel, dim3(cdiv((long long)B * ld, 256)), dim3(256), 0, (hipStream_t)stream, X,
+                     ldx, B, D, e, mean, var, eps, Xn, ld);
+  IA_CHECK_LAUNCH();
+  return IA_OK;
+}
+
+int ia_gp_row_coeffs(const float* gn, int ld, int B, int D, const float* var, float eps, float coef, float target,
+                     float* Cn, float* pen, void* stream) {
+  if (!gn || !Cn || !pen || B <= 0 || D <= 0 || ld < D) return IA_ERR_ARG;
+  hipLaunchKernelGGL(gp_row_coeffs_kernel, dim3(cdiv(B, 4)), dim3(256), 0, (hipStream_t)stream, gn, ld, B, D, var, eps,
+                     coef, target, Cn, pen);
+  IA_CHECK_LAUNCH();
   return IA_OK;
 }
 

@@ -98,6 +98,16 @@ class Mlp(nn.Module):
             parts += [lin.weight.reshape(-1), lin.bias.reshape(-1)]
         return th.cat(parts)
 
+    def add_flat_grad(self, gflat: th.Tensor) -> None:
+        """Adds a gradient given in the flat layout of `flat_parameters()` to the individual `.grad`s."""
+        o = 0
+        for n in self._dense:
+            lin = getattr(self, n)
+            for p_ in (lin.weight, lin.bias):
+                piece = gflat[o:o + p_.numel()].view_as(p_)
+                p_.grad = piece.clone() if p_.grad is None else p_.grad.add_(piece)
+                o += p_.numel()
+
     def forward(self, x: th.Tensor) -> th.Tensor:
         if self.flatten_input:
             x = x.reshape(x.shape[0], -1)
@@ -184,11 +194,15 @@ class BasicRewardNet(RewardNet):
         full = {"hid_sizes": (32, 32), **kwargs, "in_size": size, "out_size": 1, "squeeze_output": True}
         self.mlp = Mlp(**full)
 
-    def forward(self, state, action, next_state, done):
+    def concat_inputs(self, state, action, next_state, done) -> th.Tensor:
         n = state.shape[0]
         picked = ((self.use_state, state), (self.use_action, action), (self.use_next_state, next_state),
                   (self.use_done, done))
-        row = th.cat([t.reshape(n, -1).float() for on, t in picked if on], dim=1)
+        return th.cat([t.reshape(n, -1).float() for on, t in picked if on], dim=1)
+
+    def forward(self, state, action, next_state, done):
+        n = state.shape[0]
+        row = self.concat_inputs(state, action, next_state, done)
         rew = self.mlp(row)
         assert rew.shape == (n,)
         return rew

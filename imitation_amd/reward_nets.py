@@ -376,6 +376,14 @@ class BasicRewardNet(RewardNet):
         a.pnorm_count = L.ptr(pnorm.count) if use_p else None
         a.pnorm_dim = pnorm_dim if use_p else 0
         L.call("ia_disc_step_basic", C.byref(a), L.stream())
+        # what this step read / normalised with (the opt-in gradient penalty evaluates the net at the same point)
+        ws["X_used"] = ws["X"] if pre is None else pre[0]["X_all"][pre[1]]
+        if nrm is None:
+            ws["norm_used"] = None
+        elif pre is not None and pre[0]["has_moments"]:
+            ws["norm_used"] = (pre[0]["snap"][pre[1], 0], pre[0]["snap"][pre[1], 1], nrm.eps)
+        else:
+            ws["norm_used"] = (nrm.running_mean, nrm.running_var, nrm.eps)
         return ws
 
 

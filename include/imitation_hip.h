@@ -184,6 +184,17 @@ int ia_disc_fused_debug_timing(void* device_buffer_16xi64);
  * (two 256-thread workgroups per CU). */
 int ia_disc_fused_tile_rows(int rows);
 
+/* Gradient penalty on the discriminator (OPT-IN extension, default off: BASELINE.json config 3 / the north star name
+ * it, the reference has none -- SURVEY M1): E[(|grad_x D(x_hat)|_2 - target)^2] at x_hat = e x_expert + (1-e) x_gen.
+ * `ia_gp_interpolate`: rows r < B of X ([expert | generator], 2B rows) -> normalised interpolates Xn[B, ld]
+ * (statistics frozen; mean NULL: none). `ia_gp_row_coeffs`: from gn = dD/dXn (ia_mlp_backward with dOut = 1) the
+ * per-row penalty pen[B] and Cn = d(coef/B * sum pen)/d gn [B, ld]; the parameter gradient follows from Cn with
+ * ia_gemm_f32 calls (ReLU stacks: the masks are locally constant), see imitation_amd/grad_penalty.py. */
+int ia_gp_interpolate(const float* X, int ldx, int B, int D, const float* e, const float* mean, const float* var,
+                      float eps, float* Xn, int ld, void* stream);
+int ia_gp_row_coeffs(const float* gn, int ld, int B, int D, const float* var, float eps, float coef, float target,
+                     float* Cn, float* pen, void* stream);
+
 /* adversarial/airl.py:118 + rewards/reward_nets.py:701-736:
  * logits = g + gamma*(1-done)*h_next - h_cur - logp ; and the matching dOut routing. */
 int ia_airl_logits(const float* g, const float* h_cur, const float* h_next, const float* dones /*0/1 fp32*/,
