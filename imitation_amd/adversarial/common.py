@@ -643,7 +643,7 @@ class AdversarialTrainer(abc.ABC):
             if self._in_overlap:  # the gather reads the tile the generator stream finished BEFORE its PPO update
                 self._disc_stream.wait_event(self.gen_algo.rollout_done_event)
             with store_ctx:
-                self._gen_replay_buffer.store_from_rollout(rb, order)
+                self._gen_replay_buffer.store_from_rollout(rb, order, infos=self.venv_buffering.last_infos)
             return
         gen_samples, ep_lens = self.venv_buffering.pop_transitions_and_lens()
         self._check_fixed_horizon(ep_lens)

@@ -1,7 +1,8 @@
 """Generator replay ring resident in HBM (`data/buffer.py:30-416`).
 
-FIFO ring over `obs, acts, next_obs, dones` (the reference also keeps `infos` objects and
-drops `rews`, `buffer.py:316-329,409-412`). All index arithmetic stays on the host and follows
+FIFO ring over `obs, acts, next_obs, dones` in HBM plus `infos` objects in a host-side ring at the same
+positions (`rews` are dropped, `buffer.py:316-329,409-412`); the host ring exists only once some stored
+transition carried a non-empty info dict (array envs never allocate it: `sample` then returns `{}`s). All index arithmetic stays on the host and follows
 the reference exactly -- `store` splits at the wrap point (`:184-192`), `_idx=(idx+n)%cap`,
 `_n_data=min(n_data+n,cap)` (`:208-214`), over-capacity stores keep only the LAST `capacity`
 rows (`:174-178`), `sample` draws `np.random.randint(size, size=n)` from the GLOBAL NumPy
@@ -43,6 +44,7 @@ class ReplayBuffer:
         self._acts = (th.zeros(self.capacity, dtype=th.int64, device=self.device) if self.discrete
                       else th.zeros(self.capacity, ad, device=self.device))
         self._dones = th.zeros(self.capacity, dtype=th.uint8, device=self.device)
+        self._infos: Optional[np.ndarray] = None   # host ring of info dicts, allocated on first use
         self._n_data = 0
         self._idx = 0
         self.table = TransitionTable(self._obs, self._acts, self._next, self._dones, self.discrete)
@@ -70,9 +72,24 @@ class ReplayBuffer:
             self._acts[lo:hi].copy_(th.from_numpy(np.ascontiguousarray(acts, dtype=np.float32)).reshape(len(obs), -1))
         self._dones[lo:hi].copy_(th.from_numpy(np.ascontiguousarray(dones, dtype=np.uint8)))
 
+    def _put_infos(self, lo: int, infos, m: int) -> None:
+        """Host ring of `infos` (`buffer.py:316-329` stores them like any other key)."""
+        if infos is None and self._infos is None:
+            return
+        if self._infos is None:
+            self._infos = np.array([{} for _ in range(self.capacity)], dtype=object)
+        self._infos[lo:lo + m] = [{} for _ in range(m)] if infos is None else list(infos)
+
+    @staticmethod
+    def _meaningful(infos) -> Optional[np.ndarray]:
+        if infos is None:
+            return None
+        return np.asarray(infos, dtype=object) if any(len(i) for i in infos) else None
+
     def store(self, transitions, truncate_ok: bool = True) -> None:
         obs, acts = np.asarray(transitions.obs), np.asarray(transitions.acts)
         nxt, dones = np.asarray(transitions.next_obs), np.asarray(transitions.dones)
+        infos = self._meaningful(getattr(transitions, "infos", None))
         n = len(obs)
         if n == 0:
             raise ValueError("Trying to store empty data.")
@@ -82,17 +99,21 @@ class ReplayBuffer:
             if not truncate_ok:
                 raise ValueError("Not enough capacity to store data.")
             obs, acts, nxt, dones = (a[-self.capacity:] for a in (obs, acts, nxt, dones))
+            infos = None if infos is None else infos[-self.capacity:]
             n = self.capacity
         if self._idx + n > self.capacity:
             rem = self.capacity - self._idx
             self._put(self._idx, obs[:rem], acts[:rem], nxt[:rem], dones[:rem])
             self._put(0, obs[rem:], acts[rem:], nxt[rem:], dones[rem:])
+            self._put_infos(self._idx, None if infos is None else infos[:rem], rem)
+            self._put_infos(0, None if infos is None else infos[rem:], n - rem)
         else:
             self._put(self._idx, obs, acts, nxt, dones)
+            self._put_infos(self._idx, infos, n)
         self._idx = (self._idx + n) % self.capacity
         self._n_data = min(self._n_data + n, self.capacity)
 
-    def store_from_rollout(self, rb, order: np.ndarray, truncate_ok: bool = True) -> None:
+    def store_from_rollout(self, rb, order: np.ndarray, truncate_ok: bool = True, infos=None) -> None:
         """`store` for transitions that already live in HBM (the PPO rollout tile `rb`): the rows
         `order` (time-major offsets, reference emission order) are gathered device-to-device into
         the ring; same index arithmetic as `store`."""
@@ -104,7 +125,9 @@ class ReplayBuffer:
             if not truncate_ok:
                 raise ValueError("Not enough capacity to store data.")
             order = order[-self.capacity:]
+            infos = None if infos is None else infos[-self.capacity:]
             n = self.capacity
+        infos = self._meaningful(infos)
         order_dev = th.from_numpy(np.ascontiguousarray(order)).to(self.device)
         T, ne = rb.buffer_size, rb.n_envs
         od = self._obs.shape[1]
@@ -128,8 +151,11 @@ class ReplayBuffer:
             rem = self.capacity - self._idx
             put(self._idx, order_dev[:rem].contiguous())
             put(0, order_dev[rem:].contiguous())
+            self._put_infos(self._idx, None if infos is None else infos[:rem], rem)
+            self._put_infos(0, None if infos is None else infos[rem:], n - rem)
         else:
             put(self._idx, order_dev)
+            self._put_infos(self._idx, infos, n)
         self._idx = (self._idx + n) % self.capacity
         self._n_data = min(self._n_data + n, self.capacity)
 
@@ -143,7 +169,7 @@ class ReplayBuffer:
         ind = self.sample_indices(n_samples)
         arr = self._arrays
         return dt.Transitions(obs=arr["obs"][ind], acts=arr["acts"][ind], next_obs=arr["next_obs"][ind],
-                              dones=arr["dones"][ind])
+                              dones=arr["dones"][ind], infos=None if self._infos is None else self._infos[ind])
 
     @property
     def _arrays(self) -> Dict[str, np.ndarray]:

@@ -65,13 +65,17 @@ class Mlp(nn.Module):
                  activation: Type[nn.Module] = nn.ReLU, dropout_prob: float = 0.0, squeeze_output: bool = False,
                  flatten_input: bool = False, normalize_input_layer: Optional[Type[nn.Module]] = None):
         super().__init__()
-        if dropout_prob > 0.0:
-            raise NotImplementedError("dropout is off in every reference GAIL/AIRL config; not built for HIP")
         if activation not in _ACTS:
             raise NotImplementedError(f"activation {activation} not supported on the HIP path (ReLU/Tanh)")
         if squeeze_output and out_size != 1:
             raise ValueError("squeeze_output is only applicable when out_size=1")
         prefix = "" if name is None else f"{name}_"
+        # dropout (`util/networks.py:270-271`, off in every reference GAIL/AIRL config): the stack then runs layer
+        # by layer -- each Linear on the HIP op, activation + `nn.Dropout` in between (the mask comes from the
+        # DEVICE generator, so dropout runs are not seed-comparable with the reference's CPU masks)
+        self.dropout_prob = float(dropout_prob)
+        self._activation = activation() if dropout_prob > 0.0 else None
+        self._dropout = nn.Dropout(dropout_prob) if dropout_prob > 0.0 else None
         self.dims = [int(in_size), *[int(h) for h in hid_sizes], int(out_size)]
         self.act = _ACTS[activation]
         self.squeeze_output, self.flatten_input = squeeze_output, flatten_input
@@ -113,7 +117,16 @@ class Mlp(nn.Module):
             x = x.reshape(x.shape[0], -1)
         if self._norm_name is not None:
             x = getattr(self, self._norm_name)(x)
-        out = ops.mlp(x, self.flat_parameters(), self.dims, self.act)
+        if self._dropout is None:
+            out = ops.mlp(x, self.flat_parameters(), self.dims, self.act)
+        else:
+            out = x
+            for k, n in enumerate(self._dense):
+                lin = getattr(self, n)
+                out = ops.mlp(out, th.cat([lin.weight.reshape(-1), lin.bias.reshape(-1)]),
+                              [lin.in_features, lin.out_features], ops.ACT_NONE)
+                if k < len(self._dense) - 1:
+                    out = self._dropout(self._activation(out))
         return out.squeeze(-1) if self.squeeze_output else out
 
 

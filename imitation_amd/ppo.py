@@ -557,7 +557,7 @@ class PPO(OnPolicyAlgorithm):
                     if info.get("episode") is not None:
                         self.ep_info_buffer.extend([info["episode"]])
             if bw is not None:
-                bw.record_step(acts_np, new_obs, nxt, env_rews, dones)
+                bw.record_step(acts_np, new_obs, nxt, env_rews, dones, infos)
             h_obs_np[t + 1] = new_obs.reshape(n, -1)
             h_next_np[t] = nxt.reshape(n, -1)
             h_dones_np[t], h_trunc_np[t], h_starts_np[t] = dones, trunc, starts

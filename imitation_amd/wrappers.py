@@ -45,6 +45,14 @@ def infos_from_arrays(dones, nxt, trunc) -> List[Dict[str, Any]]:
     return infos
 
 
+def _infos_have_content(infos) -> bool:
+    for info in infos:
+        for k in info:
+            if k not in ("terminal_observation", "TimeLimit.truncated"):
+                return True
+    return False
+
+
 class BufferingWrapper(VecEnvWrapper):
     """Saves transitions of the underlying VecEnv; `pop_*` return them in the reference's order."""
 
@@ -57,6 +65,10 @@ class BufferingWrapper(VecEnvWrapper):
         self._timesteps: Optional[np.ndarray] = None
         self.n_transitions: Optional[int] = None
         self._steps: List[Tuple[np.ndarray, ...]] = []   # (obs_before, acts, next_fixed, rews, dones)
+        # per step: the env's info dicts when they carry more than what the arrays already encode
+        # (terminal_observation / TimeLimit.truncated), else None -- array envs never pay for dict lists
+        self._infos: List[Optional[list]] = []
+        self.last_infos: Optional[np.ndarray] = None     # infos of the last pop, in its emission order (or None)
         self._ep_lens: List[int] = []
 
     def reset(self, **kwargs):
@@ -66,7 +78,7 @@ class BufferingWrapper(VecEnvWrapper):
         self.n_transitions = 0
         obs = self.venv.reset(**kwargs)
         self._last_obs = obs
-        self._steps = []
+        self._steps, self._infos = [], []
         self._timesteps = np.zeros((len(obs),), dtype=int)
         return obs
 
@@ -81,15 +93,16 @@ class BufferingWrapper(VecEnvWrapper):
         assert self._saved_acts is not None
         acts, self._saved_acts = self._saved_acts, None
         obs, rews, dones, nxt, trunc, infos = step_arrays(self.venv)
-        self.record_step(acts, obs, nxt, rews, dones)
+        self.record_step(acts, obs, nxt, rews, dones, infos)
         if infos is None:
             infos = infos_from_arrays(dones, nxt, trunc)
         return obs, rews, dones, infos
 
-    def record_step(self, acts, new_obs, next_fixed, rews, dones) -> None:
+    def record_step(self, acts, new_obs, next_fixed, rews, dones, infos=None) -> None:
         """State update of one `step_wait` given the step's arrays (`wrappers.py:69-91`)."""
         dones = np.asarray(dones, dtype=bool)
         self._steps.append((self._last_obs, np.array(acts, copy=True), next_fixed, np.asarray(rews), dones))
+        self._infos.append(list(infos) if infos is not None and _infos_have_content(infos) else None)
         self._last_obs = new_obs
         self.n_transitions += self.num_envs
         self._timesteps += 1
@@ -101,6 +114,14 @@ class BufferingWrapper(VecEnvWrapper):
         obs, acts, nxt, rews, dones = (np.stack(x) for x in zip(*self._steps))
         return obs, acts, nxt, rews, dones
 
+    def _infos_in_order(self, order: np.ndarray, n: int) -> Optional[np.ndarray]:
+        """`infos` of the recorded steps in emission order (time-major offsets `t*n + env`), `{}` where a step had
+        none; None when no step of the round carried any (`data/wrappers.py:69-91` keeps every step's dict)."""
+        if not any(i is not None for i in self._infos):
+            return None
+        return np.array([self._infos[o // n][o % n] if self._infos[o // n] is not None else {} for o in order],
+                        dtype=object)
+
     def pop_transitions_and_lens(self) -> Tuple[Optional[dt.TransitionsWithRew], List[int]]:
         """Fast path of `pop_trajectories` + `flatten_trajectories_with_rew`
         (`adversarial/common.py:422-424`): the same rows in the same order, built with one gather."""
@@ -110,11 +131,13 @@ class BufferingWrapper(VecEnvWrapper):
         T, n = dones.shape
         order, _, _ = dt.segment_order(dones)
         flat = lambda a: a.reshape(T * n, *a.shape[2:])[order]
+        self.last_infos = self._infos_in_order(order, n)
         trans = dt.TransitionsWithRew(obs=flat(obs), acts=flat(acts), next_obs=flat(nxt), dones=flat(dones),
+                                      infos=self.last_infos,
                                       rews=flat(rews).astype(np.float64, copy=False)
                                       if not np.issubdtype(rews.dtype, np.floating) else flat(rews))
         lens, self._ep_lens = self._ep_lens, []
-        self._steps = []
+        self._steps, self._infos = [], []
         self.n_transitions = 0
         return trans, lens
 
@@ -126,8 +149,9 @@ class BufferingWrapper(VecEnvWrapper):
             return None, [], 0
         dones = np.stack([st[4] for st in self._steps])
         order, _, _ = dt.segment_order(dones)
+        self.last_infos = self._infos_in_order(order, dones.shape[1])
         lens, self._ep_lens = self._ep_lens, []
-        self._steps = []
+        self._steps, self._infos = [], []
         self.n_transitions = 0
         return order, lens, dones.shape[0]
 
@@ -146,18 +170,28 @@ class BufferingWrapper(VecEnvWrapper):
         trajs: List[dt.TrajectoryWithRew] = []
         t_idx, e_idx = np.nonzero(dones)
         last = np.full(n, -1)
+        have = any(i is not None for i in self._infos)
+
+        def infos_of(s: int, t: int, e: int):   # steps s..t (inclusive) of env e
+            if not have:
+                return None
+            return np.array([self._infos[k][e] if self._infos[k] is not None else {} for k in range(s, t + 1)],
+                            dtype=object)
+
         for t, e in zip(t_idx, e_idx):
             s = last[e] + 1
             trajs.append(dt.TrajectoryWithRew(obs=np.concatenate([obs[s:t + 1, e], nxt[t:t + 1, e]]),
-                                              acts=acts[s:t + 1, e], rews=rews[s:t + 1, e], infos=None, terminal=True))
+                                              acts=acts[s:t + 1, e], rews=rews[s:t + 1, e], infos=infos_of(s, t, e),
+                                              terminal=True))
             last[e] = t
         for e in range(n):
             s = last[e] + 1
             if s <= T - 1:
                 trajs.append(dt.TrajectoryWithRew(obs=np.concatenate([obs[s:T, e], nxt[T - 1:T, e]]),
-                                                  acts=acts[s:T, e], rews=rews[s:T, e], infos=None, terminal=False))
+                                                  acts=acts[s:T, e], rews=rews[s:T, e], infos=infos_of(s, T - 1, e),
+                                                  terminal=False))
         lens, self._ep_lens = self._ep_lens, []
-        self._steps = []
+        self._steps, self._infos = [], []
         self.n_transitions = 0
         return trajs, lens
 

@@ -32,6 +32,14 @@ CASES: Dict[str, Dict[str, Any]] = {
                           n_steps=8, ppo_batch=16, n_epochs=2, ent_coef=0.01, disc_hid=(32, 32),
                           demo_batch=32, demo_minibatch=None, n_disc=2, capacity=None, n_demo=200, rounds=2,
                           norm_policy=True, norm_disc=True, obs_dtype="float32"),
+    # BASELINE config 1 in its canonical library form (docs/algorithms/gail.rst:36-91), scaled down: 8 envs, Discrete
+    # actions, SB3 `MlpPolicy` (two 64-wide tanh towers, no feature norm), PPO minibatch 64-style (a quarter of
+    # the rollout) x 5 epochs, gamma 0.95, lr 4e-4, ent_coef 0, replay capacity smaller than a round.
+    "gail_cartpole": dict(algo="gail", n_envs=8, horizon=9, obs_dim=4, act_dim=2, n_discrete=2,
+                          n_steps=16, ppo_batch=32, n_epochs=5, ent_coef=0.0, disc_hid=(32, 32),
+                          demo_batch=64, demo_minibatch=None, n_disc=4, capacity=64, n_demo=300, rounds=3,
+                          norm_policy=False, norm_disc=True, obs_dtype="float32", policy="mlp64",
+                          ppo_kwargs=dict(gamma=0.95, learning_rate=4e-4)),
     # the fused five-launch discriminator update (D -> H -> H -> 1, H = 128) and, in pipelined rounds, the
     # one-launch round assembly + pre-assembled four-launch updates
     "gail_fused": dict(algo="gail", n_envs=8, horizon=10, obs_dim=17, act_dim=6, n_discrete=None,
@@ -96,6 +104,7 @@ def namespace(impl: str) -> pytypes.SimpleNamespace:
 
         return pytypes.SimpleNamespace(
             GAIL=GAIL, AIRL=AIRL, PPO=sb.PPO, FeedForward32Policy=FeedForward32Policy,
+            ActorCriticPolicy=sb.ActorCriticPolicy,
             NormalizeFeaturesExtractor=NormalizeFeaturesExtractor, RunningNorm=RunningNorm,
             BasicRewardNet=rn.BasicRewardNet, BasicShapedRewardNet=rn.BasicShapedRewardNet,
             NormalizedRewardNet=rn.NormalizedRewardNet, Transitions=transitions,
@@ -106,6 +115,7 @@ def namespace(impl: str) -> pytypes.SimpleNamespace:
 
         return pytypes.SimpleNamespace(
             GAIL=o.GAIL, AIRL=o.AIRL, PPO=sb.PPO, FeedForward32Policy=o.FeedForward32Policy,
+            ActorCriticPolicy=sb.ActorCriticPolicy,
             NormalizeFeaturesExtractor=o.NormalizeFeaturesExtractor, RunningNorm=o.RunningNorm,
             BasicRewardNet=o.BasicRewardNet, BasicShapedRewardNet=o.BasicShapedRewardNet,
             NormalizedRewardNet=o.NormalizedRewardNet, Transitions=lambda **kw: o.Transitions(**kw),
@@ -115,6 +125,7 @@ def namespace(impl: str) -> pytypes.SimpleNamespace:
 
         return pytypes.SimpleNamespace(
             GAIL=p.GAIL, AIRL=p.AIRL, PPO=p.PPO, FeedForward32Policy=p.FeedForward32Policy,
+            ActorCriticPolicy=p.ActorCriticPolicy,
             NormalizeFeaturesExtractor=p.NormalizeFeaturesExtractor, RunningNorm=p.RunningNorm,
             BasicRewardNet=p.BasicRewardNet, BasicShapedRewardNet=p.BasicShapedRewardNet,
             NormalizedRewardNet=p.NormalizedRewardNet, Transitions=lambda **kw: p.Transitions(**kw),
@@ -141,7 +152,8 @@ def build_trainer(impl: str, cfg, log_dir: str, device: str = "cpu", module_net:
     if cfg["norm_policy"]:
         pk = dict(features_extractor_class=ns.NormalizeFeaturesExtractor,
                   features_extractor_kwargs=dict(normalize_class=ns.RunningNorm))
-    algo = ns.PPO(ns.FeedForward32Policy, venv, n_steps=cfg["n_steps"], batch_size=cfg["ppo_batch"],
+    policy_cls = ns.ActorCriticPolicy if cfg.get("policy") == "mlp64" else ns.FeedForward32Policy  # SB3 MlpPolicy
+    algo = ns.PPO(policy_cls, venv, n_steps=cfg["n_steps"], batch_size=cfg["ppo_batch"],
                   n_epochs=cfg["n_epochs"], ent_coef=cfg["ent_coef"], seed=0, policy_kwargs=pk, device=device,
                   **cfg.get("ppo_kwargs", {}))
     kw = dict(normalize_input_layer=disc_norm) if cfg["norm_disc"] else {}

@@ -51,7 +51,7 @@ def _compare(got, gold, cfg, skip=()):
 
 
 @pytest.mark.parametrize("case", ["gail_box", "gail_f64", "gail_discrete", "airl_box", "gail_horizon", "gail_tuned",
-                                  "gail_fused"])
+                                  "gail_fused", "gail_cartpole"])
 def test_hip_trainer_matches_reference_golden(case, tmp_path):
     cfg = harness.CASES[case]
     gold = dict(np.load(os.path.join(GOLDEN, f"{case}.npz")))

@@ -290,3 +290,22 @@ def test_gail_discriminator_on_image_observations_trains(tmp_path):
     tr.venv = venv   # spaces of the image task for batch assembly (one-hot width, observation shape)
     losses = [tr.train_disc(expert_samples=batch(True), gen_samples=batch(False))["disc_loss"] for _ in range(60)]
     assert np.isfinite(losses).all() and np.mean(losses[-5:]) < 0.8 * np.mean(losses[:5]), losses
+
+
+def test_mlp_module_with_dropout_runs_layer_by_layer():
+    """`build_mlp(dropout_prob > 0)` (`util/networks.py:210,270-271`): eval mode equals the dropout-free stack,
+    train mode drops units (different outputs for the same input) and trains through `backward()`."""
+    from imitation_amd import modules
+
+    th.manual_seed(0)
+    net = modules.Mlp(7, (32, 32), out_size=1, dropout_prob=0.5, squeeze_output=True).to(DEV)
+    ref = modules.Mlp(7, (32, 32), out_size=1, squeeze_output=True).to(DEV)
+    ref.load_state_dict(net.state_dict())
+    x = th.randn(64, 7, device=DEV)
+    net.eval()
+    th.testing.assert_close(net(x), ref(x), rtol=1e-5, atol=1e-6)
+    net.train()
+    a, b = net(x), net(x)
+    assert not th.allclose(a, b)
+    a.sum().backward()
+    assert all(p_.grad is not None and th.isfinite(p_.grad).all() for p_ in net.parameters())
