@@ -2,10 +2,11 @@
 (`adversarial/common.py:262-266,490-496`; `policies/base.py:92-149`), evaluated by the fused
 policy kernels of libimitation_hip.so.
 
-Supported architecture = what the reference's GAIL/AIRL configs use: Flatten or
+Fused architecture = what the reference's GAIL/AIRL configs use: Flatten or
 `NormalizeFeaturesExtractor(RunningNorm)` features, two separate tanh towers of equal width
 H in {32, 64} (`FeedForward32Policy` = [32, 32]; SB3 `MlpPolicy` default = [64, 64]),
-DiagGaussian (Box) or Categorical (Discrete) head. Parameters are ONE flat fp32 buffer in torch
+DiagGaussian (Box) or Categorical (Discrete) head. Any other `net_arch` (deeper, unequal, `dict(pi=..., vf=...)`,
+ReLU towers) keeps this class's surface but executes on the generic MLP stacks: `general_policy.GeneralTowers`. Parameters are ONE flat fp32 buffer in torch
 `parameters()` order (log_std, pi tower, vf tower, action_net, value_net) + a transposed
 shadow copy the kernels read their weight rows from.
 """
@@ -43,6 +44,8 @@ class NormalizeFeaturesExtractor(FlattenExtractor):
 
 
 class ActorCriticPolicy:
+    fused = True   # False once `general_policy.adopt` re-classed the instance (towers outside the fused kernels)
+
     def __init__(self, observation_space, action_space, lr_schedule, net_arch=None, activation_fn=nn.Tanh,
                  ortho_init: bool = True, use_sde: bool = False, log_std_init: float = 0.0,
                  squash_output: bool = False, features_extractor_class=FlattenExtractor,
@@ -50,17 +53,18 @@ class ActorCriticPolicy:
                  optimizer_class=th.optim.Adam, optimizer_kwargs=None):
         if use_sde or squash_output or not share_features_extractor:
             raise NotImplementedError("gSDE / squashing / separate extractors are outside the reference's PPO path")
-        if activation_fn is not nn.Tanh:
-            raise NotImplementedError("policy towers are tanh (SB3 default) on the HIP path")
         if optimizer_class is not th.optim.Adam:
-            raise NotImplementedError("the fused PPO step implements Adam (SB3 default)")
+            raise NotImplementedError("the PPO step implements Adam (SB3 default)")
         if net_arch is None:
             net_arch = dict(pi=[64, 64], vf=[64, 64])
-        pi, vf = (net_arch["pi"], net_arch["vf"]) if isinstance(net_arch, dict) else (net_arch, net_arch)
-        if not (len(pi) == len(vf) == 2 and pi[0] == pi[1] == vf[0] == vf[1] and pi[0] in (32, 64)):
-            raise NotImplementedError(f"net_arch {net_arch}: the fused kernels cover two equal towers [H,H], H in (32,64)")
+        if isinstance(net_arch, dict):   # [SB3 MlpExtractor]: a missing key = no hidden layer in that tower
+            pi, vf = list(net_arch.get("pi", [])), list(net_arch.get("vf", []))
+        else:
+            pi, vf = list(net_arch), list(net_arch)
+        from imitation_amd import general_policy
+        fused = general_policy.fused_arch(pi, vf, activation_fn)
         self.observation_space, self.action_space = observation_space, action_space
-        self.net_arch, self.hidden = net_arch, int(pi[0])
+        self.net_arch, self.hidden = net_arch, (int(pi[0]) if fused else None)
         self.discrete = isinstance(action_space, spaces.Discrete)
         self.obs_dim = spaces.flatdim(observation_space)
         self.act_dim = action_space.n if self.discrete else int(np.prod(action_space.shape))
@@ -76,6 +80,13 @@ class ActorCriticPolicy:
         # "inverse_cdf" = one host U(0,1) per row, sampled inside the rollout kernel (same distribution,
         # different stream, one launch + no logits round trip per step).
         self.discrete_sampling = "multinomial"
+        self._lr0 = float(lr_schedule(1))
+        self._low = self._high = None
+        self.optimizer: Optional[HipAdam] = None
+        if not fused:
+            # any other `net_arch` / ReLU towers: same parameters and API, executed on the generic MLP stacks
+            general_policy.adopt(self, pi, vf, activation_fn, ortho_init, log_std_init)
+            return
 
         # Host construction in SB3's order so the torch global RNG is consumed identically:
         # pi tower, vf tower, action_net, log_std, value_net; then orthogonal re-initialisation.
@@ -100,9 +111,6 @@ class ActorCriticPolicy:
         self.desc = L.PolicyDesc(self.obs_dim, self.act_dim, H, int(self.discrete),
                                  int(self.features_extractor.normalize is not None),
                                  self.features_extractor.normalize.eps if self.features_extractor.normalize else 1e-5)
-        self.optimizer: Optional[HipAdam] = None
-        self._lr0 = float(lr_schedule(1))
-        self._low = self._high = None
 
     # ---- layout -------------------------------------------------------------------------
     def _layout(self) -> List[Tuple[str, Tuple[int, ...]]]:

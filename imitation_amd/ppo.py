@@ -326,15 +326,16 @@ class PPO(OnPolicyAlgorithm):
                                             self.device)
         total = self.n_steps * self.n_envs
         self._n_mb = -(-total // self.batch_size)
+        # policies outside the fused kernels' shapes (`general_policy.GeneralTowers`) run their own minibatch loop
         self._ppo_ws = th.empty(int(L.load().ia_ppo_ws_floats(C.byref(p.desc), min(self.batch_size, total), total)),
-                                device=self.device)
+                                device=self.device) if p.fused else None
         self._perm_host = th.zeros(self.n_epochs, total, dtype=th.int64).pin_memory()
         self._perm_dev = th.zeros(self.n_epochs, total, dtype=th.int64, device=self.device)
         self._perm_np = self._perm_host.numpy()
         self._predraw = _PermutationPredraw(self.n_epochs, total)
         self.update_events = None  # optional (start, end) torch events around the persistent update launch
         self._stats_dev = th.zeros(self.n_epochs, self._n_mb, 8, device=self.device)
-        n_upd = int(L.load().ia_ppo_update_ws_floats(C.byref(p.desc), min(self.batch_size, total)))
+        n_upd = int(L.load().ia_ppo_update_ws_floats(C.byref(p.desc), min(self.batch_size, total))) if p.fused else 0
         # persistent whole-update kernel (hidden = 32); None -> one ia_ppo_epoch call per epoch
         self._upd_ws = th.zeros(n_upd, device=self.device) if n_upd > 0 else None
         self.dp = None  # set by the trainer for data-parallel runs (imitation_amd.distributed.DataParallel)
@@ -627,7 +628,7 @@ class PPO(OnPolicyAlgorithm):
         first use. False: single process, or a shape the persistent kernel does not cover (then the
         per-minibatch all-reduce path `_train_data_parallel` runs)."""
         dp = self.dp
-        if dp is None or dp.world <= 1 or not self.dp_global_minibatch:
+        if dp is None or dp.world <= 1 or not self.dp_global_minibatch or not self.policy.fused:
             return False
         if self._dpg is None:
             pol, rb = self.policy, self.rollout_buffer
@@ -778,11 +779,17 @@ class PPO(OnPolicyAlgorithm):
             rec.val.copy_(rb.val)   # the tile is reused by the next rollout before the statistics are read
             rec.ret.copy_(rb.ret)
         stats_dev = rec.stats if rec is not None else self._stats_dev
-        if dpg is not None:
+        if not pol.fused:
+            # general towers: [SB3 PPO.train]'s minibatch loop on the generic stacks (one gradient all-reduce per
+            # optimiser step when data-parallel; the feature RunningNorm exchanges its moments itself)
+            sd = self._stats_dev if (rec is not None and self.dp is not None and self.dp.world > 1) else stats_dev
+            pol.ppo_update(rb, self._perm_dev, self.n_epochs, self.batch_size, self.normalize_advantage, clip_range,
+                           self.ent_coef, self.vf_coef, self.max_grad_norm, sd, dp=self.dp)
+        elif dpg is not None:
             self._train_dp_global(dpg, lr, clip_range, stats_dev)
         elif self.dp is not None and self.dp.world > 1:
             self._train_data_parallel(perm, lr, clip_range)
-        single = not (self.dp is not None and self.dp.world > 1)
+        single = pol.fused and not (self.dp is not None and self.dp.world > 1)
         if single and self._upd_ws is not None:
             if self.update_events is not None:  # measurement hook (bench.py): events on the launch stream
                 self.update_events[0].record()

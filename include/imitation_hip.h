@@ -329,6 +329,30 @@ int ia_avgpool_nhwc_backward(const float* dout, int B, int HW, int C, float* dy,
 int ia_categorical_loss(const float* logits, int ldl, const float* actions, int B, int A, float logp_coef,
                         float ent_coef, float* logp, float* entropy, float* dlogits, void* stream);
 
+/* ---- actor-critic heads + PPO loss for towers of ANY shape (csrc/ppo_general.hip) -------------------------------
+ * Policies whose `net_arch` the fused kernels above do not cover run their towers on ia_mlp_forward/_backward and
+ * take the pieces between them from here ([SB3 distributions.py] DiagGaussianDistribution / CategoricalDistribution,
+ * [SB3 ppo.py] PPO.train loss; reference call sites: adversarial/common.py:490-496, data/rollout.py:288-379).
+ * ia_gauss_act: actions = mean + exp(log_std) * noise, clipped to [low, high] (clipped/logp nullable),
+ * logp = Normal(mean, exp(log_std)).log_prob(actions).sum(-1). ia_gauss_eval: logp / entropy of given actions. */
+int ia_gauss_act(const float* mean, const float* log_std, const float* noise, const float* low, const float* high, int n,
+                 int A, float* actions, float* clipped, float* logp, void* stream);
+int ia_gauss_eval(const float* mean, const float* log_std, const float* actions, int n, int A, float* logp, float* entropy,
+                  void* stream);
+/* out2 = (mean, unbiased std) of x[n] -- the minibatch advantage normalisation of PPO.train; one block, fixed order */
+int ia_adv_moments(const float* x, int n, float* out2, void* stream);
+/* torch.nn.utils.clip_grad_norm_ on one flat gradient (in place); norm_out (nullable) receives the total norm */
+int ia_clip_grad_norm(float* grad, long long n, float max_norm, float* norm_out, void* stream);
+/* One PPO minibatch at the heads: `out` = Gaussian means or Categorical logits [B, A] (A <= 64), `actions` [B, A]
+ * (Box) or [B] fp32 indices (Discrete), adv_ms = ia_adv_moments of `adv` or NULL (no normalisation).
+ * Writes d loss / d out, d loss / d values, d loss / d log_std (Box) and stats[8] = {policy_gradient_loss,
+ * value_loss, entropy_loss, approx_kl, clip_fraction, loss, 0, 0}; ws: ia_ppo_head_loss_ws_floats(B) floats. */
+long long ia_ppo_head_loss_ws_floats(int B);
+int ia_ppo_head_loss(int discrete, const float* out, const float* log_std, const float* values, const float* actions,
+                     const float* old_logp, const float* adv, const float* ret, const float* adv_ms, int B, int A,
+                     float clip_range, float ent_coef, float vf_coef, float* d_out, float* d_values, float* dlog_std,
+                     float* ws, float* stats, void* stream);
+
 /* One PPO epoch = consecutive minibatches of the device-resident permutation `perm[T*n_envs]`
  * (host-drawn np.random.permutation); stats is [n_minibatches][8] or NULL. */
 int ia_ppo_epoch(const ia_policy_desc* d, float* params, float* params_t, float* norm_mean, float* norm_var,

@@ -60,6 +60,26 @@ CASES: Dict[str, Dict[str, Any]] = {
                        demo_batch=128, demo_minibatch=None, n_disc=4, capacity=32, n_demo=500, rounds=4,
                        norm_policy=True, norm_disc=True, obs_dtype="float32",
                        ppo_kwargs=dict(gamma=0.95, clip_range=0.1, gae_lambda=0.9)),
+    # Policy towers outside the reference configs' [H, H] shapes (any SB3 `net_arch`): unequal pi / vf
+    # towers of different depth behind the feature RunningNorm, Box actions.
+    "gail_towers": dict(algo="gail", n_envs=8, horizon=10, obs_dim=17, act_dim=6, n_discrete=None,
+                        n_steps=16, ppo_batch=32, n_epochs=3, ent_coef=0.05, disc_hid=(32, 32),
+                        demo_batch=64, demo_minibatch=None, n_disc=2, capacity=None, n_demo=400, rounds=3,
+                        norm_policy=True, norm_disc=True, obs_dtype="float32", policy="mlp64",
+                        policy_kwargs=dict(net_arch=dict(pi=[48, 24], vf=[40, 40, 16]))),
+    # Discrete head on a one-layer pi tower and NO vf tower (value_net reads the features), ReLU; remainder minibatch
+    # (rollout of 40 rows in minibatches of 16).
+    "gail_discrete_towers": dict(algo="gail", n_envs=5, horizon=6, obs_dim=4, act_dim=3, n_discrete=3,
+                                 n_steps=8, ppo_batch=16, n_epochs=2, ent_coef=0.01, disc_hid=(32, 32),
+                                 demo_batch=20, demo_minibatch=None, n_disc=2, capacity=None, n_demo=200, rounds=2,
+                                 norm_policy=False, norm_disc=True, obs_dtype="float32", policy="mlp64",
+                                 policy_kwargs=dict(net_arch=dict(pi=[24], vf=[]), activation_fn="relu")),
+    # AIRL (log pi of the generator inside the discriminator logit) on three-layer ReLU towers.
+    "airl_towers": dict(algo="airl", n_envs=8, horizon=10, obs_dim=11, act_dim=3, n_discrete=None,
+                        n_steps=16, ppo_batch=64, n_epochs=2, ent_coef=0.0, disc_hid=(32,),
+                        demo_batch=64, demo_minibatch=None, n_disc=2, capacity=None, n_demo=300, rounds=2,
+                        norm_policy=True, norm_disc=True, obs_dtype="float32", normalize_output=True, policy="mlp64",
+                        policy_kwargs=dict(net_arch=[64, 48, 32], activation_fn="relu")),
     # AIRL, shaped reward net, NormalizedRewardNet output norm (script default), use_next_state.
     "airl_box": dict(algo="airl", n_envs=8, horizon=10, obs_dim=11, act_dim=3, n_discrete=None,
                      n_steps=16, ppo_batch=32, n_epochs=2, ent_coef=0.0, disc_hid=(32,),
@@ -153,6 +173,10 @@ def build_trainer(impl: str, cfg, log_dir: str, device: str = "cpu", module_net:
         pk = dict(features_extractor_class=ns.NormalizeFeaturesExtractor,
                   features_extractor_kwargs=dict(normalize_class=ns.RunningNorm))
     policy_cls = ns.ActorCriticPolicy if cfg.get("policy") == "mlp64" else ns.FeedForward32Policy  # SB3 MlpPolicy
+    extra = dict(cfg.get("policy_kwargs", {}))
+    if "activation_fn" in extra:
+        extra["activation_fn"] = {"relu": th.nn.ReLU, "tanh": th.nn.Tanh}[extra["activation_fn"]]
+    pk = dict(pk, **extra)
     algo = ns.PPO(policy_cls, venv, n_steps=cfg["n_steps"], batch_size=cfg["ppo_batch"],
                   n_epochs=cfg["n_epochs"], ent_coef=cfg["ent_coef"], seed=0, policy_kwargs=pk, device=device,
                   **cfg.get("ppo_kwargs", {}))

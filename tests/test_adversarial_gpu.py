@@ -51,7 +51,8 @@ def _compare(got, gold, cfg, skip=()):
 
 
 @pytest.mark.parametrize("case", ["gail_box", "gail_f64", "gail_discrete", "airl_box", "gail_horizon", "gail_tuned",
-                                  "gail_fused", "gail_cartpole"])
+                                  "gail_fused", "gail_cartpole", "gail_towers", "gail_discrete_towers",
+                                  "airl_towers"])
 def test_hip_trainer_matches_reference_golden(case, tmp_path):
     cfg = harness.CASES[case]
     gold = dict(np.load(os.path.join(GOLDEN, f"{case}.npz")))

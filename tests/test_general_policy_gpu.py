@@ -1,0 +1,177 @@
+"""General-tower actor-critic policies (`imitation_amd/general_policy.py`, `csrc/ppo_general.hip`): the head kernels
+against torch (float64 autograd of [SB3 ppo.py] PPO.train's loss), and policy-level agreement of a general-tower
+policy with the fused kernels on a shape both cover. The end-to-end evidence is the reference's golden runs
+`gail_towers`, `gail_discrete_towers`, `airl_towers` (tests/test_adversarial_gpu.py)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch as th
+from torch import nn
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True)
+def _need_gpu():
+    if not th.cuda.is_available():
+        pytest.skip("no GPU")
+
+
+def _torch_loss(discrete, out, log_std, values, actions, old, adv, ret, normalize, clip, ent_coef, vf_coef):
+    """[SB3 ppo.py] PPO.train loss of one minibatch in float64 with autograd."""
+    if normalize:
+        adv = (adv - adv.mean()) / (adv.std() + 1e-8)
+    if discrete:
+        dist = th.distributions.Categorical(logits=out)
+        logp, ent = dist.log_prob(actions.long()), dist.entropy()
+    else:
+        dist = th.distributions.Normal(out, th.ones_like(out) * log_std.exp())
+        logp, ent = dist.log_prob(actions).sum(1), dist.entropy().sum(1)
+    ratio = th.exp(logp - old)
+    pl1, pl2 = adv * ratio, adv * th.clamp(ratio, 1 - clip, 1 + clip)
+    pg = -th.min(pl1, pl2).mean()
+    vl = th.nn.functional.mse_loss(ret, values)
+    el = -ent.mean()
+    loss = pg + ent_coef * el + vf_coef * vl
+    with th.no_grad():
+        lr = logp - old
+        kl = ((th.exp(lr) - 1) - lr).mean()
+        cf = ((ratio - 1).abs() > clip).double().mean()
+    return loss, th.stack([pg, vl, el, kl, cf, loss]).detach()
+
+
+@pytest.mark.parametrize("discrete,B,A,normalize", [(False, 700, 6, True), (False, 33, 1, False), (True, 515, 5, True),
+                                                    (True, 7, 2, True)])
+def test_head_loss_matches_torch_autograd(discrete, B, A, normalize):
+    from imitation_amd import _lib as L
+    g = th.Generator().manual_seed(B + A)
+    out = th.randn(B, A, generator=g, dtype=th.float64)
+    log_std = th.randn(A, generator=g, dtype=th.float64) * 0.3
+    values, ret = th.randn(B, generator=g, dtype=th.float64), th.randn(B, generator=g, dtype=th.float64)
+    adv = th.randn(B, generator=g, dtype=th.float64) * 2 + 0.3
+    if discrete:
+        actions = th.randint(0, A, (B,), generator=g).double()
+        old = th.distributions.Categorical(logits=out).log_prob(actions.long()) + 0.3 * th.randn(B, generator=g, dtype=th.float64)
+    else:
+        actions = out + th.randn(B, A, generator=g, dtype=th.float64)
+        old = (th.distributions.Normal(out, log_std.exp().expand_as(out)).log_prob(actions).sum(1)
+               + 0.3 * th.randn(B, generator=g, dtype=th.float64))
+    clip, ent_coef, vf_coef = 0.2, 0.03, 0.5
+    o, ls, v = out.clone().requires_grad_(), log_std.clone().requires_grad_(), values.clone().requires_grad_()
+    loss, st_ref = _torch_loss(discrete, o, ls, v, actions, old, adv, ret, normalize, clip, ent_coef, vf_coef)
+    loss.backward()
+
+    dev = "cuda"
+    f = lambda t: t.float().to(dev).contiguous()  # noqa: E731
+    d_out, d_val, dls = th.empty(B, A, device=dev), th.empty(B, device=dev), th.zeros(A, device=dev)
+    ms, stats = th.empty(2, device=dev), th.empty(8, device=dev)
+    ws = th.empty(int(L.load().ia_ppo_head_loss_ws_floats(B)), device=dev)
+    adv_d = f(adv)
+    if normalize:
+        L.call("ia_adv_moments", L.ptr(adv_d), B, L.ptr(ms), L.stream())
+        np.testing.assert_allclose(ms.cpu().numpy(), [adv.mean().item(), adv.std().item()], rtol=1e-5)
+    out_d, ls_d, val_d, act_d, old_d, ret_d = f(out), f(log_std), f(values), f(actions), f(old), f(ret)  # (kept alive)
+    L.call("ia_ppo_head_loss", int(discrete), L.ptr(out_d), L.ptr(ls_d), L.ptr(val_d), L.ptr(act_d),
+           L.ptr(old_d), L.ptr(adv_d), L.ptr(ret_d), L.ptr(ms) if normalize else None, B, A, clip, ent_coef, vf_coef,
+           L.ptr(d_out), L.ptr(d_val), None if discrete else L.ptr(dls), L.ptr(ws), L.ptr(stats), L.stream())
+    tol = dict(rtol=2e-4, atol=2e-6)
+    np.testing.assert_allclose(d_out.cpu().double().numpy(), o.grad.numpy(), **tol)
+    np.testing.assert_allclose(d_val.cpu().double().numpy(), v.grad.numpy(), **tol)
+    if not discrete:
+        np.testing.assert_allclose(dls.cpu().double().numpy(), ls.grad.numpy(), rtol=5e-4, atol=1e-5)
+    np.testing.assert_allclose(stats[:6].cpu().double().numpy(), st_ref.numpy(), rtol=2e-4, atol=1e-5)
+
+
+def test_gauss_act_and_clip_grad_norm():
+    from imitation_amd import _lib as L
+    n, A = 300, 4
+    g = th.Generator().manual_seed(1)
+    mean, noise = th.randn(n, A, generator=g), th.randn(n, A, generator=g)
+    log_std = th.tensor([0.1, -0.4, 0.0, 0.7])
+    low, high = -th.ones(A) * 0.8, th.ones(A) * 1.1
+    d = lambda t: t.cuda().contiguous()  # noqa: E731
+    acts, clip, lp = th.empty(n, A, device="cuda"), th.empty(n, A, device="cuda"), th.empty(n, device="cuda")
+    mean_d, ls_d, noise_d, low_d, high_d = d(mean), d(log_std), d(noise), d(low), d(high)
+    L.call("ia_gauss_act", L.ptr(mean_d), L.ptr(ls_d), L.ptr(noise_d), L.ptr(low_d), L.ptr(high_d), n, A,
+           L.ptr(acts), L.ptr(clip), L.ptr(lp), L.stream())
+    ref = mean + log_std.exp() * noise
+    dist = th.distributions.Normal(mean, log_std.exp().expand_as(mean))
+    np.testing.assert_allclose(acts.cpu().numpy(), ref.numpy(), rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(clip.cpu().numpy(), th.max(th.min(ref, high), low).numpy(), rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(lp.cpu().numpy(), dist.log_prob(ref).sum(1).numpy(), rtol=1e-5, atol=1e-5)
+    ent, lp2 = th.empty(n, device="cuda"), th.empty(n, device="cuda")
+    L.call("ia_gauss_eval", L.ptr(mean_d), L.ptr(ls_d), L.ptr(acts), n, A, L.ptr(lp2), L.ptr(ent), L.stream())
+    np.testing.assert_allclose(lp2.cpu().numpy(), lp.cpu().numpy(), rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(ent.cpu().numpy(), dist.entropy().sum(1).numpy(), rtol=1e-6)
+
+    for scale in (0.01, 10.0):   # below / above the clipping threshold
+        gr = th.randn(5000, generator=g) * scale
+        gd, norm = d(gr), th.empty(1, device="cuda")
+        L.call("ia_clip_grad_norm", L.ptr(gd), gd.numel(), 0.5, L.ptr(norm), L.stream())
+        p = nn.Parameter(th.zeros(5000))
+        p.grad = gr.clone()
+        total = th.nn.utils.clip_grad_norm_([p], 0.5)
+        np.testing.assert_allclose(norm.item(), total.item(), rtol=1e-5)
+        np.testing.assert_allclose(gd.cpu().numpy(), p.grad.numpy(), rtol=1e-5, atol=1e-9)
+
+
+@pytest.mark.parametrize("discrete", [False, True])
+def test_general_towers_agree_with_fused_kernels_on_a_shared_shape(discrete):
+    """[32, 32] tanh towers run on the fused kernels; forced through `general_policy.adopt` the SAME parameters must
+    give the same actions / values / log-probs and the same PPO update (both follow [SB3 PPO.train])."""
+    import imitation_amd as ia
+    from imitation_amd import general_policy, spaces
+    from imitation_amd.vec_env import SyntheticVecEnv
+
+    def make(general):
+        th.manual_seed(3)
+        np.random.seed(3)
+        venv = SyntheticVecEnv(num_envs=8, obs_dim=7, act_dim=3, horizon=9, seed=0, n_discrete=3 if discrete else None)
+        if general:
+            orig = general_policy.fused_arch
+            general_policy.fused_arch = lambda *a: False
+        try:
+            algo = ia.PPO(ia.FeedForward32Policy, venv, n_steps=16, batch_size=32, n_epochs=2, ent_coef=0.02, seed=0,
+                          policy_kwargs=dict(features_extractor_class=ia.NormalizeFeaturesExtractor,
+                                             features_extractor_kwargs=dict(normalize_class=ia.RunningNorm)),
+                          device="cuda")
+        finally:
+            if general:
+                general_policy.fused_arch = orig
+        return algo
+
+    a, b = make(False), make(True)
+    assert a.policy.fused and not b.policy.fused
+    assert th.equal(a.policy._flat, b.policy._flat)
+    assert list(a.policy.state_dict()) == list(b.policy.state_dict())
+    for algo in (a, b):   # same global torch / NumPy streams (action noise, minibatch permutations) for both runs
+        th.manual_seed(11)
+        np.random.seed(11)
+        algo.learn(16 * 8 * 3)
+    for k, v in a.policy.state_dict().items():
+        np.testing.assert_allclose(b.policy.state_dict()[k].cpu().numpy(), v.cpu().numpy(), rtol=2e-4, atol=2e-5, err_msg=k)
+    obs = np.random.default_rng(0).standard_normal((50, 7)).astype(np.float32)
+    acts = a.policy.predict(obs, deterministic=True)[0]
+    np.testing.assert_allclose(b.policy.predict(obs, deterministic=True)[0], acts, rtol=1e-3, atol=1e-4)
+    va, lpa, ea = a.policy.evaluate_actions(obs, acts)
+    vb, lpb, eb = b.policy.evaluate_actions(obs, acts)
+    for x, y in ((va, vb), (lpa, lpb), (ea, eb)):
+        np.testing.assert_allclose(y.cpu().numpy(), x.cpu().numpy(), rtol=1e-3, atol=1e-4)
+
+
+def test_general_towers_state_dict_checkpoint_and_bc_guard(tmp_path):
+    import imitation_amd as ia
+    from imitation_amd import bc, spaces
+    osp = spaces.Box(-np.ones(5, dtype=np.float32), np.ones(5, dtype=np.float32))
+    asp = spaces.Box(-np.ones(2, dtype=np.float32), np.ones(2, dtype=np.float32))
+    th.manual_seed(0)
+    p = ia.ActorCriticPolicy(osp, asp, lambda _: 1e-3, net_arch=dict(pi=[16, 8, 8], vf=[12]), activation_fn=nn.ReLU).to("cuda")
+    assert list(p.state_dict())[:3] == ["log_std", "mlp_extractor.policy_net.0.weight", "mlp_extractor.policy_net.0.bias"]
+    assert "mlp_extractor.policy_net.4.weight" in p.state_dict() and p.state_dict()["value_net.weight"].shape == (1, 12)
+    q = ia.ActorCriticPolicy(osp, asp, lambda _: 1e-3, net_arch=dict(pi=[16, 8, 8], vf=[12]), activation_fn=nn.ReLU).to("cuda")
+    q.load_state_dict(p.state_dict())
+    obs = np.random.default_rng(1).standard_normal((9, 5)).astype(np.float32)
+    np.testing.assert_array_equal(q.predict(obs, deterministic=True)[0], p.predict(obs, deterministic=True)[0])
+    with pytest.raises(NotImplementedError):
+        bc.BC(observation_space=osp, action_space=asp, rng=np.random.default_rng(0), policy=p)
