@@ -909,7 +909,8 @@ struct UpdStage {
   static constexpr int src = ret + ROWS;                        // [ROWS] row offset into the rollout tile (as float bits)
   static constexpr int nxt = src + ROWS;                        // [ROWS] row offsets of the minibatch being prefetched
   static constexpr int ring = nxt + ROWS;                       // [UPD_RS_] copy of the minibatch's statistics-ring slot
-  static constexpr int total = ring + 2 * MAXD + 8;
+  static constexpr int act = ring + 2 * MAXD + 8;               // [ROWS][aw] the rows' actions, row-major, aw <= MAXA
+  __host__ __device__ static constexpr int total(int aw) { return act + ROWS * aw; }
 };
 // One minibatch of block `vblk` (64 rows), one launch per minibatch (`ia_ppo_minibatch*`, `ia_ppo_epoch`:
 // hidden = 32 without the persistent kernel, i.e. data-parallel runs): forward, losses, backward;
@@ -1448,6 +1449,7 @@ __device__ __forceinline__ void wave_sync_lds() {
   __builtin_amdgcn_wave_barrier();
 }
 
+// (`nv` = 1/sqrt(running_var + eps) per column, as the statistics block publishes it)
 __device__ __forceinline__ void mfma32_minibatch_chain(
     const ia_policy_desc& d, const float* __restrict__ nm, const float* __restrict__ nv, const float adv_mean,
     const float adv_std, const MbRows rows, const int vblk, const int normalize_adv, const float clip,
@@ -1456,7 +1458,6 @@ __device__ __forceinline__ void mfma32_minibatch_chain(
     const int opaque_zero, long long* __restrict__ tstamp) {
   float* __restrict__ lds = lds_in + opaque_zero;
   const float* __restrict__ stg = stg_in + opaque_zero;
-  const float* __restrict__ actions = rows.actions;
   const int batch = rows.batch;
   constexpr int H = 32;
   using L = CLds;
@@ -1485,13 +1486,11 @@ __device__ __forceinline__ void mfma32_minibatch_chain(
   for (int a = 0; a < MAXA; ++a) r_act[a] = 0.f;
   if (loss_lane) {
     if (tw == 0) {
-      const int src_raw = __float_as_int(stg[UpdStage::src + lrow]);   // (unconditional read, masked afterwards)
-      const long long src = valid ? (long long)src_raw : 0;
       r_oldlp = stg[UpdStage::oldlp + lrow];
       r_adv = stg[UpdStage::adv + lrow];
 #pragma unroll
-      for (int a = 0; a < MAXA; ++a)   // unconditional, clamped (same cache line); consumed after three layers
-        r_act[a] = actions[src * aw + min(a, aw - 1)];
+      for (int a = 0; a < MAXA; ++a)   // staged by the prefetch (LDS-direct loads); unconditional, clamped
+        r_act[a] = stg[UpdStage::act + lrow * aw + min(a, aw - 1)];
     } else {
       r_ret = stg[UpdStage::ret + lrow];
     }
@@ -1519,9 +1518,8 @@ __device__ __forceinline__ void mfma32_minibatch_chain(
     for (int j = 0; j < 8; ++j) {
       const int k = cb + 8 * j;
       const bool ok = rok && k < D;
-      const float msk = (ok && d.has_norm) ? 1.f : 0.f;
-      const float mean = mu[j] * msk, var = vr[j] * msk + (1.f - msk) * (1.f - d.norm_eps);
-      lds[L::x + (rbase + r) * L::XS + k] = ok ? (raw[j] - mean) / sqrtf(var + d.norm_eps) : 0.f;
+      const bool nrm = ok && d.has_norm;          // (`nv` carries 1/sqrt(var + eps), see the statistics block)
+      lds[L::x + (rbase + r) * L::XS + k] = ok ? (nrm ? (raw[j] - mu[j]) * vr[j] : raw[j]) : 0.f;
     }
     if (tw == 0) {
       for (int e = lane; e < 16 * L::AS; e += 64) {
@@ -2352,8 +2350,11 @@ __global__ __launch_bounds__(512) void ppo_update_persistent_kernel(
       }
       __syncthreads();
       if (d.has_norm && tid < D) {
+        // mean and 1/sqrt(var + eps): the square root and the division are done ONCE per column here (this block runs
+        // ahead of the chain) instead of once per element in every gradient block (8 IEEE sqrt + 8 IEEE divisions per
+        // lane on the chain's critical path); the product is within 1 ulp of the quotient `networks.py:91` forms
         slot[tid] = nm[tid];
-        slot[MAXD + tid] = nv[tid];
+        slot[MAXD + tid] = 1.f / sqrtf(nv[tid] + d.norm_eps);
       }
       __syncthreads();
       if (tid == 0) {
@@ -2403,7 +2404,7 @@ __global__ __launch_bounds__(512) void ppo_update_persistent_kernel(
   float* sP = lds + L::total;
   float* sPt = sP + w.P4;
   float* stg = sPt + w.P4;                    // UpdStage: the NEXT minibatch's rows of this block
-  unsigned short* dstT = reinterpret_cast<unsigned short*>(stg + UpdStage::total);  // [P4] index of parameter i in the transposed copy
+  unsigned short* dstT = reinterpret_cast<unsigned short*>(stg + UpdStage::total(d.discrete ? 1 : d.act_dim));  // [P4] index of parameter i in the transposed copy
   float* red = lds + L::misc + ROWS * L::MS;  // 64 spare floats behind the misc tile
   const int lane = tid & 63;
   float rm[NPT], rv[NPT];
@@ -2458,25 +2459,55 @@ __global__ __launch_bounds__(512) void ppo_update_persistent_kernel(
   typedef __attribute__((address_space(3))) void* lds_void_p;
   typedef __attribute__((address_space(1))) const void* glb_void_p;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  auto prefetch_issue = [&](int s) {
+  // Every row offset is read from LDS BEFORE the first LDS-direct load is issued: the compiler orders an LDS read
+  // that follows a `global_load_lds` behind `s_waitcnt vmcnt(0)` (the DMA might alias it), which made the nine
+  // gathers of a wave nine serial round trips to memory (3.6 us per step on the barrier path). `zero` is an opaque
+  // 0 refreshed every step, so the element -> (row, column) arithmetic is redone here (a dozen VALU operations)
+  // instead of being hoisted out of the step loop into 27 spilled registers.
+  auto prefetch_issue = [&](int s, int zero) {
     const MbRows r = rows_of(s);
     const int* nxt = reinterpret_cast<const int*>(stg) + UpdStage::nxt;
+    int src0 = 0;
+    if (wave == 0) src0 = nxt[lane];
+    int srcs[NIT], cols[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int e0 = it * 512 + wave * 64 + zero;  // wave-uniform
+      const int e = min(e0 + lane, ROWS * L::XS - 1);
+      const int rr = e / L::XS;
+      cols[it] = min(e - rr * L::XS, D - 1);
+      srcs[it] = nxt[rr];
+    }
+    // actions: element e = row * aw + column of the block's [ROWS][aw] tile, 512 elements per pass
+    const int aw_ = d.discrete ? 1 : d.act_dim;
+    constexpr int NAT = ROWS * MAXA / 512;
+    int asrc[NAT], acol[NAT];
+#pragma unroll
+    for (int it = 0; it < NAT; ++it) {
+      const int e = min(it * 512 + wave * 64 + zero + lane, ROWS * aw_ - 1);
+      const int rr = e / aw_;
+      acol[it] = e - rr * aw_;
+      asrc[it] = nxt[rr];
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int it = 0; it < NAT; ++it) {
+      const int e0 = it * 512 + wave * 64;  // wave-uniform
+      if (e0 < ROWS * aw_)
+        __builtin_amdgcn_global_load_lds((glb_void_p)(r.actions + (long long)asrc[it] * aw_ + acol[it]),
+                                         (lds_void_p)(stg + UpdStage::act + e0), 4, 0, 0);
+    }
     if (wave == 0) {
-      const int src = nxt[lane];
-      __builtin_amdgcn_global_load_lds((glb_void_p)(r.old_logp + src), (lds_void_p)(stg + UpdStage::oldlp), 4, 0, 0);
-      __builtin_amdgcn_global_load_lds((glb_void_p)(r.adv + src), (lds_void_p)(stg + UpdStage::adv), 4, 0, 0);
-      __builtin_amdgcn_global_load_lds((glb_void_p)(r.ret + src), (lds_void_p)(stg + UpdStage::ret), 4, 0, 0);
+      __builtin_amdgcn_global_load_lds((glb_void_p)(r.old_logp + src0), (lds_void_p)(stg + UpdStage::oldlp), 4, 0, 0);
+      __builtin_amdgcn_global_load_lds((glb_void_p)(r.adv + src0), (lds_void_p)(stg + UpdStage::adv), 4, 0, 0);
+      __builtin_amdgcn_global_load_lds((glb_void_p)(r.ret + src0), (lds_void_p)(stg + UpdStage::ret), 4, 0, 0);
     }
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
       const int e0 = it * 512 + wave * 64;  // wave-uniform
-      if (e0 < ROWS * L::XS) {
-        const int e = min(e0 + lane, ROWS * L::XS - 1);
-        const int rr = e / L::XS, k = e - rr * L::XS;
-        const int src = nxt[rr];
-        __builtin_amdgcn_global_load_lds((glb_void_p)(r.obs + (long long)src * D + min(k, D - 1)),
+      if (e0 < ROWS * L::XS)
+        __builtin_amdgcn_global_load_lds((glb_void_p)(r.obs + (long long)srcs[it] * D + cols[it]),
                                          (lds_void_p)(stg + UpdStage::x + e0), 4, 0, 0);
-      }
     }
   };
   auto prefetch_park = [&]() {  // row offsets of the staged minibatch (its action loads use them)
@@ -2486,7 +2517,7 @@ __global__ __launch_bounds__(512) void ppo_update_persistent_kernel(
   if (n_steps > 0) {
     prefetch_resolve(0);
     __syncthreads();
-    prefetch_issue(0);
+    prefetch_issue(0, 0);
     prefetch_park();
   }
   __syncthreads();
@@ -2534,7 +2565,11 @@ __global__ __launch_bounds__(512) void ppo_update_persistent_kernel(
       __hip_atomic_fetch_add(arrivals, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     UPD_TS(8);
-    if (s + 1 < n_steps) prefetch_issue(s + 1);
+    if (s + 1 < n_steps) {
+      int pz;
+      asm volatile("s_mov_b32 %0, 0" : "=s"(pz));
+      prefetch_issue(s + 1, pz);
+    }
     UPD_TS(9);
     if (tid == 0) {
       s_ok = spin_until(arrivals, (unsigned)(s + 1) * nblk, err);
@@ -3080,8 +3115,8 @@ int ia_ppo_epoch(const ia_policy_desc* d, float* params, float* params_t, float*
 
 
 // LDS of a gradient block: minibatch tiles, both parameter copies, the staged next minibatch, the transpose map
-inline size_t upd_grad_lds_bytes(int P4) {
-  return (CLds::total + 2 * (size_t)P4 + UpdStage::total) * sizeof(float) + P4 * sizeof(unsigned short);
+inline size_t upd_grad_lds_bytes(int P4, int aw) {
+  return (CLds::total + 2 * (size_t)P4 + UpdStage::total(aw)) * sizeof(float) + P4 * sizeof(unsigned short);
 }
 
 // Workspace of ia_ppo_update in floats; 0 when the persistent kernel does not cover the shape
@@ -3091,7 +3126,7 @@ int64_t ia_ppo_update_ws_floats(const ia_policy_desc* d, int batch_size) {
   const int P = pol_offsets(d->obs_dim, d->act_dim, d->hidden, d->discrete).total;
   const int nblk = cdiv(batch_size, ROWS);
   const int P4 = (P + 3) & ~3;
-  if (d->hidden != 32 || P > UPD_NPT_WIDE * 512 || upd_grad_lds_bytes(P4) > 160 * 1024 || nblk > UPD_NBLK_MAX ||
+  if (d->hidden != 32 || P > UPD_NPT_WIDE * 512 || upd_grad_lds_bytes(P4, d->discrete ? 1 : d->act_dim) > 160 * 1024 || nblk > UPD_NBLK_MAX ||
       cdiv(batch_size, UPD_SLICE) > UPD_SLICES_MAX || g_ppo_valu)
     return 0;
   return UPD_CTRL + 2 * UPD_MAX_STEPS + UPD_RING * UPD_RS + UPD_SD * 2 + UPD_SD * (int64_t)nblk * 8 +
@@ -3123,7 +3158,7 @@ int ia_ppo_update(const ia_policy_desc* d, float* params, float* params_t, float
   const int nblk = cdiv(batch_size, ROWS);
   const int P = pol_offsets(d->obs_dim, d->act_dim, 32, d->discrete).total;
   const int P4 = (P + 3) & ~3;
-  const size_t grad_bytes = upd_grad_lds_bytes(P4);
+  const size_t grad_bytes = upd_grad_lds_bytes(P4, d->discrete ? 1 : d->act_dim);
   const size_t prep_bytes = (PREP_LDS_FLOATS + (size_t)nblk * ROWS) * sizeof(float);  // + row offsets
   const size_t bytes = grad_bytes > prep_bytes ? grad_bytes : prep_bytes;
   const bool wide = P > UPD_NPT * 512;

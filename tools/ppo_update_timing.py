@@ -41,8 +41,9 @@ for rep in range(3):
           ", ".join(f"{n} {t_ / 100.0 / steps:.2f} us" for n, t_ in zip(names, ticks)))
 t = buf.cpu().numpy()[16:28]
 import numpy as np  # noqa: E402
-d = np.diff(t[:9])
-names = ["0 stage/fragments", "1 layer1", "2 layer2", "3 heads", "4 loss", "5 head grads/dz2", "6 dW2/da1", "7 dW1"]
+d = np.diff(np.concatenate([t[:7], t[8:9]]))   # (slot 7 is not stamped: the gradient tiles are one phase)
+names = ["0 stage/fragments", "1 layer1", "2 layer2", "3 heads", "4 loss", "5 head grads, dz2, dz1 + barrier",
+         "6 gradient tiles (dW*, db*, statistics) + barrier"]
 print("shader clocks per minibatch phase (last step, block 0):")
 for n_, v in zip(names, d):
     print(f"  {n_:18s} {v:8d} clk  ~{v / 2.4e3:6.2f} us @2.4GHz")
