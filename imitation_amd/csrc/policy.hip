@@ -1554,16 +1554,9 @@ __device__ __forceinline__ void mfma32_minibatch_chain(
   for (int s = 0; s < 8; ++s) {
     const int kk = 4 * s + lk;
 #pragma unroll
-    for (int c = 0; c < 2; ++c) {
-      bW2[s][c] = sPt[oW2 + kk * H + c * 16 + li];
-      bW2o[s][c] = sP[oW2 + kk * H + c * 16 + li];
-    }
+    for (int c = 0; c < 2; ++c) bW2[s][c] = sPt[oW2 + kk * H + c * 16 + li];
     bHead[s] = sP[head_base + kk];
   }
-#pragma unroll
-  for (int s = 0; s < 4; ++s)
-#pragma unroll
-    for (int c = 0; c < 2; ++c) bDa2[s][c] = sP[o.aW + min(4 * s + lk, A - 1) * H + c * 16 + li];
 #pragma unroll
   for (int c = 0; c < 2; ++c) {
     b1v[c] = sP[ob1 + c * 16 + li];
@@ -1582,10 +1575,6 @@ __device__ __forceinline__ void mfma32_minibatch_chain(
 #pragma unroll
     for (int s = 0; s < 8; ++s) bHead[s] = head_on ? bHead[s] : 0.f;
   }
-#pragma unroll
-  for (int s = 0; s < 4; ++s)
-#pragma unroll
-    for (int c = 0; c < 2; ++c) bDa2[s][c] = (tw == 0 && 4 * s + lk < A) ? bDa2[s][c] : 0.f;
   head_bias = (tw == 0 && li >= A) ? 0.f : head_bias;
   // per-action Gaussian constants; the reciprocal variance turns the ~3 IEEE divisions per action and
   // row of the loss into multiplications (<= 1 ulp away from dividing). Lane a computes action a's pair
@@ -1598,10 +1587,11 @@ __device__ __forceinline__ void mfma32_minibatch_chain(
       my_ivar = lane < A ? 1.f / (sd * sd) : 1.f;
       my_logsd = lane < A ? logf(sd) : 0.f;
     }
+    // wave-uniform: kept in scalar registers (as 32 vector registers they pushed the step loop into scratch)
 #pragma unroll
     for (int a = 0; a < MAXA; ++a) {
-      c_ivar[a] = __shfl(my_ivar, a, 64);
-      c_logsd[a] = __shfl(my_logsd, a, 64);
+      c_ivar[a] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_ivar), a));
+      c_logsd[a] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_logsd), a));
     }
   }
   IA_TS(11);
@@ -1676,6 +1666,16 @@ __device__ __forceinline__ void mfma32_minibatch_chain(
   }
   wave_sync_lds();
   IA_TS(4);
+  // backward weight fragments (W2 in torch orientation, action_net rows): requested here, behind the forward pass
+  // (24 registers less across it), and landed by the time the loss phase below is through
+#pragma unroll
+  for (int s = 0; s < 8; ++s)
+#pragma unroll
+    for (int c = 0; c < 2; ++c) bW2o[s][c] = sP[oW2 + (4 * s + lk) * H + c * 16 + li];
+#pragma unroll
+  for (int s = 0; s < 4; ++s)
+#pragma unroll
+    for (int c = 0; c < 2; ++c) bDa2[s][c] = sP[o.aW + min(4 * s + lk, A - 1) * H + c * 16 + li];
   // ---- per-row losses of this wave's 16 rows (lanes 0..15)
   if (loss_lane) {
     if (tw == 0) {
@@ -1765,8 +1765,9 @@ __device__ __forceinline__ void mfma32_minibatch_chain(
 #pragma unroll
     for (int s = 0; s < 4; ++s)
       if (s < SA) {
-        acc[0] = mfma16(da[s], bDa2[s][0], acc[0]);
-        acc[1] = mfma16(da[s], bDa2[s][1], acc[1]);
+        const bool on = 4 * s + lk < A;
+        acc[0] = mfma16(da[s], on ? bDa2[s][0] : 0.f, acc[0]);
+        acc[1] = mfma16(da[s], on ? bDa2[s][1] : 0.f, acc[1]);
       }
 #pragma unroll
     for (int c = 0; c < 2; ++c)
