@@ -83,7 +83,7 @@ class BC:
         if policy is None:  # (constructed here, after the loader, like the reference: same draws from torch's RNG)
             policy = pol_mod.FeedForward32Policy(observation_space, action_space,
                                                  lr_schedule=lambda _: float(th.finfo(th.float32).max))
-        if not getattr(policy, "fused", True):
+        if isinstance(policy, pol_mod.ActorCriticPolicy) and not policy.fused:
             raise NotImplementedError("BC trains MLP policies with the fused towers ([32, 32] / [64, 64] tanh) or the "
                                       "NatureCNN image policy; other `net_arch` shapes are covered for PPO only")
         self._policy = policy.to(self._device)

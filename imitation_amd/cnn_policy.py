@@ -11,8 +11,11 @@ and permuted to torch's layouts in `state_dict()` / `load_state_dict()`; Adam an
 element-wise, so nothing else notices. A convolution is `ia_im2col_*` + `ia_gemm_f32`; its
 weight gradient the split-K TN GEMM on the kept column buffer; its input gradient an NN GEMM + `ia_col2im_nhwc`.
 
-Scope of this first version: what the BC step needs (`evaluate_actions`, the loss gradient, Adam) plus a
-plain `predict`; Discrete action spaces (Atari). Column buffers are explicit (sized for 288 GB of HBM).
+Scope: the BC step (`evaluate_actions`, the loss gradient; Categorical head) and the PPO generator of GAIL on image
+observations -- the same rollout / update protocol as `general_policy.GeneralTowers` (`make_act_step`,
+`make_multinomial_step`, `values_rows`, `log_prob_rows`, `ppo_update`): rollout tiles hold the frames as fp32 rows
+(0..255, exact), the policy turns them back into uint8 images on the device. Categorical (Discrete) and DiagGaussian
+(Box) heads. Column buffers are explicit (sized for 288 GB of HBM).
 """
 from __future__ import annotations
 
@@ -47,12 +50,14 @@ class NatureCNN:
 
 class ActorCriticCnnPolicy:
     def __init__(self, observation_space, action_space, lr_schedule, net_arch=None, activation_fn=nn.Tanh,
-                 ortho_init: bool = True, features_extractor_class=NatureCNN, features_extractor_kwargs=None,
+                 ortho_init: bool = True, use_sde: bool = False, log_std_init: float = 0.0,
+                 features_extractor_class=NatureCNN, features_extractor_kwargs=None, share_features_extractor: bool = True,
                  normalize_images: bool = True, optimizer_class=th.optim.Adam, optimizer_kwargs=None):
         if not _is_image_space(observation_space):
             raise ValueError("ActorCriticCnnPolicy is for uint8 image spaces [C, H, W] with bounds 0 / 255")
-        if not isinstance(action_space, spaces.Discrete):
-            raise NotImplementedError("the image policy implements the Categorical head (Atari) so far")
+        self.discrete = isinstance(action_space, spaces.Discrete)
+        if not self.discrete and not (isinstance(action_space, spaces.Box) and len(action_space.shape) == 1):
+            raise NotImplementedError("image policies implement Discrete (Categorical) and 1-D Box (DiagGaussian) heads")
         if net_arch not in (None, [], {}):
             raise NotImplementedError("hidden layers behind NatureCNN are not implemented (SB3's default is none)")
         if features_extractor_class is not NatureCNN or not normalize_images:
@@ -60,8 +65,18 @@ class ActorCriticCnnPolicy:
         self.observation_space, self.action_space = observation_space, action_space
         self.features_dim = int((features_extractor_kwargs or {}).get("features_dim", 512))
         self.features_extractor = NatureCNN(observation_space, self.features_dim)
-        self.n_actions = int(action_space.n)
+        self.act_dim = int(action_space.n) if self.discrete else int(action_space.shape[0])
+        self.n_actions = self.act_dim               # width of the action head (logits or Gaussian means)
+        self.obs_dim = int(np.prod(observation_space.shape))
+        self.fused = False                          # PPO runs this policy's own minibatch loop (`ppo_update`)
+        self.discrete_sampling = "multinomial"
         self.training = True
+        self.optimizer_kwargs = dict(optimizer_kwargs or {})
+        self.optimizer_kwargs.setdefault("eps", 1e-5)   # SB3 ActorCriticPolicy default for Adam
+        self.optimizer = None
+        self._low = self._high = None
+        if optimizer_class is not th.optim.Adam:
+            raise NotImplementedError("the PPO step implements Adam (SB3 default)")
         Cin, H, W = observation_space.shape
         self.geom: List[Tuple[int, int, int, int, int, int, int, int]] = []   # (Cin, H, W, Cout, K, S, OH, OW)
         for cout, k, s in _CONVS:
@@ -80,6 +95,7 @@ class ActorCriticCnnPolicy:
                             nn.Conv2d(64, 64, 3, 1), nn.ReLU(), nn.Flatten())
         linear = nn.Sequential(nn.Linear(self.n_flatten, self.features_dim), nn.ReLU())
         action_net = nn.Linear(self.features_dim, self.n_actions)
+        log_std = None if self.discrete else th.ones(self.act_dim) * log_std_init
         value_net = nn.Linear(self.features_dim, 1)
         if ortho_init:
             def init(m, gain):
@@ -92,13 +108,14 @@ class ActorCriticCnnPolicy:
         self._names = ["features_extractor.cnn.0", "features_extractor.cnn.2", "features_extractor.cnn.4",
                        "features_extractor.linear.0", "action_net", "value_net"]
         self._shapes = [tuple(m.weight.shape) for m in mods]
-        parts: List[th.Tensor] = []
+        # torch `parameters()` order: the policy's own parameter (log_std, Box heads) first, then the child modules
+        parts: List[th.Tensor] = [] if self.discrete else [log_std]
         for i, m in enumerate(mods):
             w = m.weight.detach()
             parts += [self._to_device_layout(i, w).reshape(-1), m.bias.detach().reshape(-1)]
         self._flat = th.cat(parts).contiguous()
         self._offsets: List[Tuple[int, int, int, int]] = []   # (w offset, w numel, b offset, b numel)
-        o = 0
+        o = 0 if self.discrete else self.act_dim
         for shp in self._shapes:
             nw, nb = int(np.prod(shp)), int(shp[0])
             self._offsets.append((o, nw, o + nw, nb))
@@ -135,14 +152,47 @@ class ActorCriticCnnPolicy:
         return self._flat[o:o + n]
 
     def to(self, device):
+        from imitation_amd.networks import HipAdam
         self.device = th.device(device)
         self._flat = self._flat.to(self.device).contiguous()
+        if self.device.type == "cuda":
+            self.optimizer = HipAdam(self._flat, th.zeros_like(self._flat), lr=self._lr0, **self.optimizer_kwargs)
+            if self.discrete:
+                self._low = self._high = th.zeros(self.act_dim, device=self.device)
+            else:
+                self._low = th.as_tensor(self.action_space.low.reshape(-1), dtype=th.float32, device=self.device)
+                self._high = th.as_tensor(self.action_space.high.reshape(-1), dtype=th.float32, device=self.device)
         return self
 
     def set_training_mode(self, mode: bool) -> None:
         self.training = bool(mode)
 
+    def train(self, mode: bool = True):
+        self.training = bool(mode)
+        return self
+
+    def eval(self):
+        return self.train(False)
+
+    def _sync_transposed(self) -> None:
+        """(protocol of the MLP policies: nothing is shadowed here)"""
+
+    @property
+    def log_std(self) -> Optional[th.Tensor]:
+        return None if self.discrete else self._flat[: self.act_dim]
+
+    @property
+    def samples_on_host(self) -> bool:
+        """Discrete heads sample with torch.multinomial on the host (the reference's stream)."""
+        return self.discrete
+
+    @property
+    def squash_output(self) -> bool:
+        return False
+
     def named_parameters(self) -> Iterator[Tuple[str, th.Tensor]]:
+        if not self.discrete:
+            yield "log_std", self._flat[: self.act_dim]
         for i, name in enumerate(self._names):
             yield f"{name}.weight", self._to_torch_layout(i, self.w(i)).reshape(self._shapes[i])
             yield f"{name}.bias", self.b(i)
@@ -155,6 +205,8 @@ class ActorCriticCnnPolicy:
         """SB3's keys: the shared extractor appears under three names."""
         sd: Dict[str, th.Tensor] = {}
         named = dict(self.named_parameters())
+        if not self.discrete:
+            sd["log_std"] = named.pop("log_std")
         for alias in ("features_extractor", "pi_features_extractor", "vf_features_extractor"):
             for k, v in named.items():
                 if k.startswith("features_extractor."):
@@ -165,6 +217,8 @@ class ActorCriticCnnPolicy:
         return sd
 
     def load_state_dict(self, sd) -> None:
+        if not self.discrete:
+            self._flat[: self.act_dim].copy_(th.as_tensor(sd["log_std"]).to(self.device).float().reshape(-1))
         for i, name in enumerate(self._names):
             self.w(i).copy_(self._to_device_layout(i, th.as_tensor(sd[f"{name}.weight"]).to(self.device).float()).reshape(-1))
             self.b(i).copy_(th.as_tensor(sd[f"{name}.bias"]).to(self.device).float().reshape(-1))
@@ -178,13 +232,16 @@ class ActorCriticCnnPolicy:
                 d[f"col{li}"] = f(B * oh * ow, cin * k * k)
                 d[f"act{li}"] = f(B * oh * ow, cout)           # channel-last [B, OH, OW, Cout], post-ReLU
             d["feat"], d["logits"], d["values"] = f(B, self.features_dim), f(B, self.n_actions), f(B, 1)
-            d["logp"], d["ent"], d["acts"] = f(B), f(B), f(B)
+            d["logp"], d["ent"], d["acts"] = f(B), f(B), f(B, 1 if self.discrete else self.act_dim)
             d["dlogits"], d["dfeat"], d["dflat"] = f(B, self.n_actions), f(B, self.features_dim), f(B, self.n_flatten)
             for li in (1, 2):  # input gradients of conv 2 and 3 (conv 1's input is the image)
                 cin, h, w_, _, k, _, oh, ow = self.geom[li]
                 d[f"dcol{li}"] = f(B * oh * ow, cin * k * k)
                 d[f"dact{li - 1}"] = f(B * h * w_, cin)
-            self._bufs = {B: d}    # one batch size at a time (the column buffers are large)
+            d["dvalues"], d["dhead"] = f(B, 1), f(2, B, self.features_dim)
+            if len(self._bufs) >= 3:   # rollout step, bootstrap chunk, minibatch: more sizes evict the oldest
+                self._bufs.pop(next(iter(self._bufs)))
+            self._bufs[B] = d
         return self._bufs[B]
 
     @staticmethod
@@ -225,7 +282,13 @@ class ActorCriticCnnPolicy:
         d = self._forward(obs_u8)
         B = obs_u8.shape[0]
         a = actions if isinstance(actions, th.Tensor) else th.as_tensor(np.ascontiguousarray(actions))
-        d["acts"].copy_(a.to(self.device).reshape(B).float())
+        d["acts"].copy_(a.to(self.device).reshape(d["acts"].shape).float())
+        if not self.discrete:
+            if want_grad:
+                raise NotImplementedError("the BC loss gradient on image policies is built for the Categorical head")
+            L.call("ia_gauss_eval", L.ptr(d["logits"]), L.ptr(self._flat), L.ptr(d["acts"]), B, self.act_dim,
+                   L.ptr(d["logp"]), L.ptr(d["ent"]), L.stream())
+            return d["values"], d["logp"], d["ent"]
         L.call("ia_categorical_loss", L.ptr(d["logits"]), self.n_actions, L.ptr(d["acts"]), B, self.n_actions,
                float(logp_coef), float(ent_coef), L.ptr(d["logp"]), L.ptr(d["ent"]),
                L.ptr(d["dlogits"]) if want_grad else None, L.stream())
@@ -241,13 +304,23 @@ class ActorCriticCnnPolicy:
         L.call("ia_reduce_partials", L.ptr(part), splits, nw, 1.0, 1, L.ptr(grad[ow_:ow_ + nw]), L.stream())
         L.call("ia_reduce_partials", L.ptr(db), splits, nb, 1.0, 1, L.ptr(grad[ob_:ob_ + nb]), L.stream())
 
-    def backward(self, B: int, grad: th.Tensor) -> None:
-        """Adds to `grad` (flat, device layout) the parameter gradient of the loss whose logit gradient the last
-        `evaluate_actions(..., want_grad=True)` on a batch of `B` rows left behind. The value head gets none."""
+    def backward(self, B: int, grad: th.Tensor, with_values: bool = False) -> None:
+        """Adds to `grad` (flat, device layout) the parameter gradient of the loss whose head gradients were left in
+        the batch-`B` buffers: `dlogits` (by `evaluate_actions(..., want_grad=True)` or the PPO head loss) and, with
+        `with_values`, `dvalues` (PPO's value loss; the BC loss has no value term)."""
         d = self._bufs[B]
         F_, A = self.features_dim, self.n_actions
         self._wgrad(4, d["dlogits"], B, A, d["feat"], F_, grad)
-        self._gemm(1, d["dlogits"], A, self.w(4), F_, d["dfeat"], F_, B, F_, A, act=1, P=d["feat"], ldp=F_)
+        if with_values:
+            self._wgrad(5, d["dvalues"], B, 1, d["feat"], F_, grad)
+            # d feat = relu'(feat) * (dlogits . Wa + dvalues . Wv): two NN GEMMs into one [2][B, F] slab pair,
+            # summed in slab order, then the ReLU mask
+            self._gemm(1, d["dlogits"], A, self.w(4), F_, d["dhead"][0], F_, B, F_, A)
+            self._gemm(1, d["dvalues"], 1, self.w(5), F_, d["dhead"][1], F_, B, F_, 1)
+            L.call("ia_reduce_partials", L.ptr(d["dhead"]), 2, B * F_, 1.0, 0, L.ptr(d["dhead"][0]), L.stream())
+            L.call("ia_relu_backward", L.ptr(d["dhead"][0]), L.ptr(d["feat"]), B * F_, L.ptr(d["dfeat"]), L.stream())
+        else:
+            self._gemm(1, d["dlogits"], A, self.w(4), F_, d["dfeat"], F_, B, F_, A, act=1, P=d["feat"], ldp=F_)
         flat = d["act2"].view(B, self.n_flatten)
         self._wgrad(3, d["dfeat"], B, F_, flat, self.n_flatten, grad)
         self._gemm(1, d["dfeat"], F_, self.w(3), self.n_flatten, d["dflat"], self.n_flatten, B, self.n_flatten, F_,
@@ -264,13 +337,161 @@ class ActorCriticCnnPolicy:
                    L.ptr(d[f"dact{li - 1}"]), L.stream())
             dout = d[f"dact{li - 1}"]
 
+    # ---- PPO generator protocol (the surface `ppo.PPO` and the adversarial trainer drive; same as
+    # `general_policy.GeneralTowers`) ---------------------------------------------------------------------------
+    def _rows_u8(self, rows: th.Tensor) -> th.Tensor:
+        """fp32 frame rows `[m, C*H*W]` of a rollout tile / replay table (values 0..255, exact) -> uint8 images."""
+        return rows.reshape(-1, *self.observation_space.shape).to(th.uint8)
+
+    def sample_noise(self, n: int) -> th.Tensor:
+        return th.distributions.utils._standard_normal((n, self.act_dim), dtype=th.float32, device="cpu")
+
+    def draw_noise_into(self, out: th.Tensor) -> None:
+        out.normal_()
+
+    def make_act_step(self, obs_tile: th.Tensor, noise_host: th.Tensor, acts: th.Tensor, clipped: th.Tensor,
+                      val: th.Tensor, logp: th.Tensor):
+        """Rollout-step launcher for Box heads (see `GeneralTowers.make_act_step`)."""
+        assert not self.discrete
+        n, A = obs_tile.shape[1], self.act_dim
+        dev = self.device
+        obs_d, noise_d, clip_d = th.empty(n, self.obs_dim, device=dev), th.empty(n, A, device=dev), th.empty(n, A, device=dev)
+        stream_obj = th.cuda.current_stream()
+
+        def step(t: int) -> None:
+            with th.cuda.stream(stream_obj):
+                obs_d.copy_(obs_tile[t], non_blocking=True)
+                noise_d.copy_(noise_host.reshape(n, A), non_blocking=True)
+                d = self._forward(self._rows_u8(obs_d))
+                L.call("ia_gauss_act", L.ptr(d["logits"]), L.ptr(self._flat), L.ptr(noise_d), L.ptr(self._low),
+                       L.ptr(self._high), n, A, L.ptr(acts[t]), L.ptr(clip_d), L.ptr(logp[t]), L.stream())
+                val[t].copy_(d["values"].reshape(n))
+                clipped[t].copy_(clip_d, non_blocking=True)
+
+        return step
+
+    def make_multinomial_step(self, obs_tile: th.Tensor, h_logits: th.Tensor, h_clip: th.Tensor, val: th.Tensor,
+                              h_logp: th.Tensor):
+        """Rollout-step launcher for Discrete heads on the reference's sampling stream: logits to the pinned host
+        tile, then `torch.distributions.Categorical(logits).sample()` / `.log_prob()` as SB3 composes them."""
+        assert self.discrete
+        n = obs_tile.shape[1]
+        obs_d = th.empty(n, self.obs_dim, device=self.device)
+        stream_obj = th.cuda.current_stream()
+
+        def step(t: int) -> None:
+            with th.cuda.stream(stream_obj):
+                obs_d.copy_(obs_tile[t], non_blocking=True)
+                d = self._forward(self._rows_u8(obs_d))
+                h_logits.copy_(d["logits"], non_blocking=True)
+                val[t].copy_(d["values"].reshape(n))
+            stream_obj.synchronize()
+            dist = th.distributions.Categorical(logits=h_logits)
+            a = dist.sample()
+            h_logp[t].copy_(dist.log_prob(a))
+            h_clip[t].copy_(a.reshape(n, 1))
+
+        return step
+
+    _CHUNK = 512   # rows per forward when a whole tile is evaluated (bootstrap values, log pi of replay rows)
+
+    def values_rows(self, obs_dev: th.Tensor, out: th.Tensor) -> None:
+        m = obs_dev.shape[0]
+        out = out.reshape(m)
+        for lo in range(0, m, self._CHUNK):
+            hi = min(m, lo + self._CHUNK)
+            d = self._forward(self._rows_u8(obs_dev[lo:hi]))
+            out[lo:hi].copy_(d["values"].reshape(hi - lo))
+
+    def predict_values(self, obs) -> th.Tensor:
+        d = self._forward(self._obs_u8(obs))
+        return d["values"].clone()
+
+    def log_prob_rows(self, obs_dev: th.Tensor, acts_dev: th.Tensor, out: th.Tensor, norm_snapshot=None) -> None:
+        m = obs_dev.shape[0]
+        a = acts_dev.float().reshape(m, -1)
+        for lo in range(0, m, self._CHUNK):
+            hi = min(m, lo + self._CHUNK)
+            _, lp, _ = self.evaluate_actions(self._rows_u8(obs_dev[lo:hi]), a[lo:hi])
+            out[lo:hi].copy_(lp)
+
+    def ppo_update(self, rb, perm_dev: th.Tensor, n_epochs: int, batch_size: int, normalize_advantage: bool,
+                   clip_range: float, ent_coef: float, vf_coef: float, max_grad_norm: float, stats: th.Tensor,
+                   dp=None) -> None:
+        """[SB3 PPO.train] on the rollout tile `rb` (see `GeneralTowers.ppo_update`): per minibatch gather the rows,
+        forward, `ia_ppo_head_loss` (gradients w.r.t. logits / means, values, log_std + the logged statistics),
+        `backward`, `clip_grad_norm_`, Adam."""
+        T, n = rb.buffer_size, rb.n_envs
+        total, D, A = T * n, self.obs_dim, self.act_dim
+        aw = 1 if self.discrete else A
+        s = L.stream()
+        offs = (perm_dev % T) * n + perm_dev // T          # time-major row of every permuted index
+        obs_rows, act_rows = rb.obs.reshape((T + 1) * n, D), rb.acts.reshape(total, aw)
+        vecs = ((rb.logp.reshape(total, 1), "old"), (rb.adv.reshape(total, 1), "adv"), (rb.ret.reshape(total, 1), "ret"))
+        opt = self.optimizer
+        grad = opt.grad
+        dev = self.device
+        for e in range(n_epochs):
+            for mb, start in enumerate(range(0, total, batch_size)):
+                b = min(batch_size, total - start)
+                idx = offs[e, start:start + b]
+                rows = th.empty(b, D, device=dev)
+                L.call("ia_gather_rows", L.ptr(obs_rows), L.ptr(idx), b, D, L.ptr(rows), s)
+                d = self._forward(self._rows_u8(rows))
+                if "old" not in d:
+                    d.update(old=th.empty(b, device=dev), adv=th.empty(b, device=dev), ret=th.empty(b, device=dev),
+                             ms=th.empty(2, device=dev),
+                             loss_ws=th.empty(int(L.load().ia_ppo_head_loss_ws_floats(b)), device=dev))
+                L.call("ia_gather_rows", L.ptr(act_rows), L.ptr(idx), b, aw, L.ptr(d["acts"]), s)
+                for src, key in vecs:
+                    L.call("ia_gather_rows", L.ptr(src), L.ptr(idx), b, 1, L.ptr(d[key]), s)
+                ms = None
+                if normalize_advantage and b > 1:
+                    L.call("ia_adv_moments", L.ptr(d["adv"]), b, L.ptr(d["ms"]), s)
+                    ms = L.ptr(d["ms"])
+                grad.zero_()
+                L.call("ia_ppo_head_loss", int(self.discrete), L.ptr(d["logits"]), None if self.discrete else L.ptr(self._flat),
+                       L.ptr(d["values"]), L.ptr(d["acts"]), L.ptr(d["old"]), L.ptr(d["adv"]), L.ptr(d["ret"]), ms, b, A,
+                       float(clip_range), float(ent_coef), float(vf_coef), L.ptr(d["dlogits"]), L.ptr(d["dvalues"]),
+                       None if self.discrete else L.ptr(grad), L.ptr(d["loss_ws"]), L.ptr(stats[e, mb]), s)
+                self.backward(b, grad, with_values=True)
+                if dp is not None and dp.world > 1:
+                    dp.allreduce_mean_(grad)
+                L.call("ia_clip_grad_norm", L.ptr(grad), grad.numel(), float(max_grad_norm), None, s)
+                opt.step()
+
     # ---- acting --------------------------------------------------------------------------------------------
+    def forward(self, obs, deterministic: bool = False):
+        """[SB3 ActorCriticPolicy.forward] -> (actions, values, log_prob) device tensors."""
+        d = self._forward(self._obs_u8(obs))
+        n = d["values"].shape[0]
+        if self.discrete:
+            if deterministic:
+                a_dev = th.argmax(d["logits"], dim=1)
+            else:
+                a_dev = th.distributions.Categorical(logits=d["logits"].cpu()).sample().to(self.device)
+            d["acts"].copy_(a_dev.reshape(n, 1).float())
+            L.call("ia_categorical_loss", L.ptr(d["logits"]), self.n_actions, L.ptr(d["acts"]), n, self.n_actions, 0.0, 0.0,
+                   L.ptr(d["logp"]), L.ptr(d["ent"]), None, L.stream())
+            return a_dev.reshape((n, *self.action_space.shape)), d["values"].clone(), d["logp"].clone()
+        noise = (th.zeros(n, self.act_dim) if deterministic else self.sample_noise(n)).to(self.device)
+        acts, clip, lp = th.empty(n, self.act_dim, device=self.device), th.empty(n, self.act_dim, device=self.device), th.empty(n, device=self.device)
+        L.call("ia_gauss_act", L.ptr(d["logits"]), L.ptr(self._flat), L.ptr(noise), L.ptr(self._low), L.ptr(self._high), n,
+               self.act_dim, L.ptr(acts), L.ptr(clip), L.ptr(lp), L.stream())
+        return acts.reshape((n, *self.action_space.shape)), d["values"].clone(), lp
+
+    __call__ = forward
+
     def predict(self, observation, state=None, episode_start=None, deterministic: bool = False):
         """[SB3 BasePolicy.predict]. The mode is the first argmax; sampling is [SB3 CategoricalDistribution.sample]
         itself on the host (`torch.distributions.Categorical(logits).sample()`: torch.multinomial on the global
         generator, the reference's stream -- as for the MLP policies)."""
         obs = np.asarray(observation)
         vectorized = obs.shape != tuple(self.observation_space.shape)
+        if not self.discrete:
+            acts = self.forward(obs.reshape((-1, *self.observation_space.shape)), deterministic=deterministic)[0]
+            acts = np.clip(acts.cpu().numpy(), self.action_space.low, self.action_space.high)
+            return (acts if vectorized else acts[0]), state
         d = self._forward(self._obs_u8(obs))
         logits = d["logits"].float().cpu()
         if deterministic:

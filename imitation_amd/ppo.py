@@ -275,7 +275,8 @@ class PPO(OnPolicyAlgorithm):
         if use_sde or clip_range_vf is not None or target_kl is not None:
             raise NotImplementedError("gSDE / value clipping / target_kl are off in every reference config")
         if isinstance(policy, str):
-            policy = {"MlpPolicy": pol_mod.ActorCriticPolicy}[policy]
+            from imitation_amd.cnn_policy import ActorCriticCnnPolicy
+            policy = {"MlpPolicy": pol_mod.ActorCriticPolicy, "CnnPolicy": ActorCriticCnnPolicy}[policy]
         self.policy_class = policy
         self.policy_kwargs = dict(policy_kwargs or {})
         self.device = th.device("cuda" if device == "auto" else device)

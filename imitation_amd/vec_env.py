@@ -333,6 +333,63 @@ class SyntheticVecEnv(ArrayVecEnv):
         return obs, rews, dones, next_fixed, dones.copy()
 
 
+class SyntheticImageVecEnv(ArrayVecEnv):
+    """Image-observation synthetic environment: uint8 `[C, H, W]` frames (the space SB3's `CnnPolicy` / the
+    reference's `CnnRewardNet` take) rendered from a low-dimensional latent with `SyntheticVecEnv`'s dynamics,
+    `z' = 0.9 z + 0.1 tanh(W a) + 0.05 xi`, `frame = uint8(127.5 + 100 tanh(R z))`; fixed horizon with
+    `TimeLimit.truncated`. Discrete (table of action vectors) or Box actions."""
+
+    def __init__(self, num_envs: int = 8, shape=(4, 36, 36), act_dim: int = 3, horizon: int = 20, seed: int = 0,
+                 n_discrete: Optional[int] = None, latent_dim: int = 6):
+        obs_space = spaces.Box(0, 255, tuple(shape), np.uint8)
+        act_space: spaces.Space = (spaces.Box(-1.0, 1.0, (act_dim,), np.float32) if n_discrete is None
+                                   else spaces.Discrete(n_discrete))
+        super().__init__(num_envs, obs_space, act_space)
+        self.act_dim, self.horizon, self.latent_dim = act_dim, int(horizon), latent_dim
+        self._rng = np.random.default_rng(seed)
+        wrng = np.random.default_rng(20_000 + seed)
+        self._W = wrng.standard_normal((act_dim, latent_dim)) / np.sqrt(act_dim)
+        self._R = wrng.standard_normal((latent_dim, int(np.prod(shape)))) / np.sqrt(latent_dim)
+        self._table = wrng.uniform(-1, 1, (n_discrete, act_dim)) if n_discrete is not None else None
+        self._z = np.zeros((num_envs, latent_dim))
+        self._t = np.zeros(num_envs, dtype=np.int64)
+        self._actions: Optional[np.ndarray] = None
+
+    def render_frames(self, z: np.ndarray) -> np.ndarray:
+        f = 127.5 + 100.0 * np.tanh(z @ self._R)
+        return f.astype(np.uint8).reshape(len(z), *self.observation_space.shape)
+
+    def reset(self) -> np.ndarray:
+        self._z = self._rng.standard_normal((self.num_envs, self.latent_dim))
+        self._t[:] = 0
+        return self.render_frames(self._z)
+
+    def step_async(self, actions: np.ndarray) -> None:
+        self._actions = np.asarray(actions)
+
+    def step_wait_arrays(self):
+        a = self._actions
+        assert a is not None, "step_async must be called first"
+        self._actions = None
+        if self._table is not None:
+            a = self._table[np.asarray(a).reshape(-1).astype(np.int64)]
+        a = a.reshape(self.num_envs, self.act_dim).astype(np.float64)
+        z = 0.9 * self._z + 0.1 * np.tanh(a @ self._W) + 0.05 * self._rng.standard_normal(self._z.shape)
+        self._t += 1
+        dones = self._t >= self.horizon
+        next_fixed = self.render_frames(z)
+        n_done = int(dones.sum())
+        if n_done:
+            z[dones] = self._rng.standard_normal((n_done, self.latent_dim))
+            self._t[dones] = 0
+        self._z = z
+        obs = next_fixed.copy()
+        if n_done:
+            obs[dones] = self.render_frames(z[dones])
+        rews = (-0.1 * (a * a).sum(axis=1)).astype(np.float32)   # (the adversarial trainers replace it)
+        return obs, rews, dones, next_fixed, dones.copy()
+
+
 class CountingVecEnv(ArrayVecEnv):
     """Deterministic bookkeeping env in the spirit of the reference's `_CountingEnv`
     (`tests/data/test_wrappers.py:14-74`): `obs = t`, `rew = 10 t`, per-env episode

@@ -80,6 +80,12 @@ CASES: Dict[str, Dict[str, Any]] = {
                         demo_batch=64, demo_minibatch=None, n_disc=2, capacity=None, n_demo=300, rounds=2,
                         norm_policy=True, norm_disc=True, obs_dtype="float32", normalize_output=True, policy="mlp64",
                         policy_kwargs=dict(net_arch=[64, 48, 32], activation_fn="relu")),
+    # GAIL on IMAGE observations: uint8 [C, H, W] frames, SB3 `CnnPolicy` (NatureCNN) generator with a
+    # Categorical head, the reference's `CnnRewardNet` discriminator (state + action, channel-first frames).
+    "gail_image": dict(algo="gail", image=(4, 36, 36), n_envs=4, horizon=7, obs_dim=None, act_dim=3, n_discrete=4,
+                       n_steps=8, ppo_batch=16, n_epochs=2, ent_coef=0.01, disc_hid=None,
+                       demo_batch=16, demo_minibatch=None, n_disc=2, capacity=None, n_demo=64, rounds=2,
+                       norm_policy=False, norm_disc=False, obs_dtype="uint8", ppo_kwargs=dict(learning_rate=1e-4)),
     # AIRL, shaped reward net, NormalizedRewardNet output norm (script default), use_next_state.
     "airl_box": dict(algo="airl", n_envs=8, horizon=10, obs_dim=11, act_dim=3, n_discrete=None,
                      n_steps=16, ppo_batch=32, n_epochs=2, ent_coef=0.0, disc_hid=(32,),
@@ -92,6 +98,12 @@ def make_demo_arrays(cfg, seed: int = 1) -> Dict[str, np.ndarray]:
     rng = np.random.default_rng(seed)
     n, od, ad = cfg["n_demo"], cfg["obs_dim"], cfg["act_dim"]
     dt = np.dtype(cfg["obs_dtype"])
+    if cfg.get("image"):
+        obs = rng.integers(0, 256, (n + 1, *cfg["image"])).astype(np.uint8)
+        acts = rng.integers(0, cfg["n_discrete"], n).astype(np.int64)
+        dones = np.zeros(n, dtype=bool)
+        dones[cfg["horizon"] - 1::cfg["horizon"]] = True
+        return dict(obs=obs[:-1], acts=acts, next_obs=obs[1:], dones=dones)
     obs = rng.standard_normal((n, od)).astype(dt)
     if cfg["n_discrete"] is None:
         acts = rng.uniform(-1, 1, (n, ad)).astype(np.float32)
@@ -124,7 +136,8 @@ def namespace(impl: str) -> pytypes.SimpleNamespace:
 
         return pytypes.SimpleNamespace(
             GAIL=GAIL, AIRL=AIRL, PPO=sb.PPO, FeedForward32Policy=FeedForward32Policy,
-            ActorCriticPolicy=sb.ActorCriticPolicy,
+            ActorCriticPolicy=sb.ActorCriticPolicy, ActorCriticCnnPolicy=sb.ActorCriticCnnPolicy,
+            CnnRewardNet=rn.CnnRewardNet,
             NormalizeFeaturesExtractor=NormalizeFeaturesExtractor, RunningNorm=RunningNorm,
             BasicRewardNet=rn.BasicRewardNet, BasicShapedRewardNet=rn.BasicShapedRewardNet,
             NormalizedRewardNet=rn.NormalizedRewardNet, Transitions=transitions,
@@ -145,7 +158,8 @@ def namespace(impl: str) -> pytypes.SimpleNamespace:
 
         return pytypes.SimpleNamespace(
             GAIL=p.GAIL, AIRL=p.AIRL, PPO=p.PPO, FeedForward32Policy=p.FeedForward32Policy,
-            ActorCriticPolicy=p.ActorCriticPolicy,
+            ActorCriticPolicy=p.ActorCriticPolicy, ActorCriticCnnPolicy=p.cnn_policy.ActorCriticCnnPolicy,
+            CnnRewardNet=p.modules.CnnRewardNet,
             NormalizeFeaturesExtractor=p.NormalizeFeaturesExtractor, RunningNorm=p.RunningNorm,
             BasicRewardNet=p.BasicRewardNet, BasicShapedRewardNet=p.BasicShapedRewardNet,
             NormalizedRewardNet=p.NormalizedRewardNet, Transitions=lambda **kw: p.Transitions(**kw),
@@ -165,9 +179,14 @@ def build_trainer(impl: str, cfg, log_dir: str, device: str = "cpu", module_net:
         disc_norm = ns.RunningNorm
     th.manual_seed(0)
     np.random.seed(0)
-    venv = SyntheticVecEnv(num_envs=cfg["n_envs"], obs_dim=cfg["obs_dim"], act_dim=cfg["act_dim"],
-                           horizon=cfg["horizon"], seed=0, obs_dtype=np.dtype(cfg["obs_dtype"]),
-                           n_discrete=cfg["n_discrete"])
+    if cfg.get("image"):
+        from imitation_amd.vec_env import SyntheticImageVecEnv
+        venv = SyntheticImageVecEnv(num_envs=cfg["n_envs"], shape=cfg["image"], act_dim=cfg["act_dim"],
+                                    horizon=cfg["horizon"], seed=0, n_discrete=cfg["n_discrete"])
+    else:
+        venv = SyntheticVecEnv(num_envs=cfg["n_envs"], obs_dim=cfg["obs_dim"], act_dim=cfg["act_dim"],
+                               horizon=cfg["horizon"], seed=0, obs_dtype=np.dtype(cfg["obs_dtype"]),
+                               n_discrete=cfg["n_discrete"])
     pk = {}
     if cfg["norm_policy"]:
         pk = dict(features_extractor_class=ns.NormalizeFeaturesExtractor,
@@ -177,11 +196,16 @@ def build_trainer(impl: str, cfg, log_dir: str, device: str = "cpu", module_net:
     if "activation_fn" in extra:
         extra["activation_fn"] = {"relu": th.nn.ReLU, "tanh": th.nn.Tanh}[extra["activation_fn"]]
     pk = dict(pk, **extra)
+    if cfg.get("image"):
+        policy_cls = ns.ActorCriticCnnPolicy
     algo = ns.PPO(policy_cls, venv, n_steps=cfg["n_steps"], batch_size=cfg["ppo_batch"],
                   n_epochs=cfg["n_epochs"], ent_coef=cfg["ent_coef"], seed=0, policy_kwargs=pk, device=device,
                   **cfg.get("ppo_kwargs", {}))
     kw = dict(normalize_input_layer=disc_norm) if cfg["norm_disc"] else {}
-    if cfg["algo"] == "gail":
+    if cfg.get("image"):
+        net = ns.CnnRewardNet(venv.observation_space, venv.action_space, hwc_format=False)
+        cls = ns.GAIL
+    elif cfg["algo"] == "gail":
         net = ns.BasicRewardNet(venv.observation_space, venv.action_space, hid_sizes=cfg["disc_hid"], **kw)
         cls = ns.GAIL
     else:
@@ -261,12 +285,16 @@ def run_case(impl: str, name: str, log_dir: str, device: str = "cpu", sync_disc:
     # one more reward query on fixed inputs through the public RewardFn surface
     rng = np.random.default_rng(7)
     n = 32
-    s = rng.standard_normal((n, cfg["obs_dim"])).astype(np.dtype(cfg["obs_dtype"]))
+    if cfg.get("image"):
+        draw = lambda: rng.integers(0, 256, (n, *cfg["image"])).astype(np.uint8)  # noqa: E731
+    else:
+        draw = lambda: rng.standard_normal((n, cfg["obs_dim"])).astype(np.dtype(cfg["obs_dtype"]))  # noqa: E731
+    s = draw()
     if cfg["n_discrete"] is None:
         a = rng.uniform(-1, 1, (n, cfg["act_dim"])).astype(np.float32)
     else:
         a = rng.integers(0, cfg["n_discrete"], n)
-    ns_ = rng.standard_normal((n, cfg["obs_dim"])).astype(np.dtype(cfg["obs_dtype"]))
+    ns_ = draw()
     d = rng.random(n) < 0.2
     out["reward_train_predict"] = _np(trainer.reward_train.predict(s, a, ns_, d))
     out["reward_test_predict"] = _np(trainer.reward_test.predict(s, a, ns_, d))

@@ -31,7 +31,11 @@ def _k_steps(cfg):
     return ppo_steps + cfg["rounds"] * cfg["n_disc"]
 
 
-def _compare(got, gold, cfg, skip=()):
+def _compare(got, gold, cfg, skip=(), adam_outliers=None):
+    """`adam_outliers=(fraction, bound)`: per array, at most `fraction` of the entries may miss the tolerance, by no
+    more than `bound` -- for convolutional nets, whose weight gradients have entries near zero: Adam's first steps
+    move a weight by ~lr * g / |g|, so an entry whose gradient is at rounding level can take a different step
+    (observed: 1 of 9216 `conv1` weights off by 1.5e-4 after 4 updates at lr 1e-3; bound = steps x lr)."""
     k = _k_steps(cfg)
     atol, rtol = 5e-5, 2e-4
     assert set(got) == set(gold), set(got) ^ set(gold)
@@ -43,6 +47,12 @@ def _compare(got, gold, cfg, skip=()):
         assert x.shape == y.shape, (key, x.shape, y.shape)
         if key in harness.EXACT_KEYS or y.dtype.kind in "biu":
             assert np.array_equal(x, y), key
+        elif adam_outliers is not None and x.size:
+            err = np.abs(x.astype(np.float64) - y.astype(np.float64))
+            bad = err > atol + rtol * np.abs(y.astype(np.float64))
+            assert bad.mean() <= adam_outliers[0] and (not bad.any() or err[bad].max() <= adam_outliers[1]), \
+                (key, float(bad.mean()), float(err.max()))
+            worst[key] = float(err.max())
         else:
             np.testing.assert_allclose(x.astype(np.float64), y.astype(np.float64), rtol=rtol, atol=atol,
                                        equal_nan=True, err_msg=key)
@@ -52,12 +62,13 @@ def _compare(got, gold, cfg, skip=()):
 
 @pytest.mark.parametrize("case", ["gail_box", "gail_f64", "gail_discrete", "airl_box", "gail_horizon", "gail_tuned",
                                   "gail_fused", "gail_cartpole", "gail_towers", "gail_discrete_towers",
-                                  "airl_towers"])
+                                  "airl_towers", "gail_image"])
 def test_hip_trainer_matches_reference_golden(case, tmp_path):
     cfg = harness.CASES[case]
     gold = dict(np.load(os.path.join(GOLDEN, f"{case}.npz")))
     got = harness.run_case("hip", case, str(tmp_path), device="cuda")
-    worst = _compare(got, gold, cfg)
+    # image nets: <= 0.1 % of an array's entries may take a different early Adam step (bounded by 4 steps x lr 1e-3)
+    worst = _compare(got, gold, cfg, adam_outliers=(1e-3, 4e-3) if cfg.get("image") else None)
     print(case, "max abs deviation:", max(worst.values()), max(worst, key=worst.get))
 
 

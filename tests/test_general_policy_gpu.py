@@ -175,3 +175,37 @@ def test_general_towers_state_dict_checkpoint_and_bc_guard(tmp_path):
     np.testing.assert_array_equal(q.predict(obs, deterministic=True)[0], p.predict(obs, deterministic=True)[0])
     with pytest.raises(NotImplementedError):
         bc.BC(observation_space=osp, action_space=asp, rng=np.random.default_rng(0), policy=p)
+
+
+@pytest.mark.parametrize("discrete", [True, False])
+def test_cnn_policy_ppo_matches_sb3_restated(discrete):
+    """PPO with the NatureCNN actor-critic policy on uint8 frames (`PPO("CnnPolicy", ...)`): rollouts, GAE and the
+    minibatch updates against the SB3 restatement (oracle, CPU) on the same seeds -- Categorical and DiagGaussian
+    heads. Same outlier rule as the image golden: a few conv weights may take a different early Adam step."""
+    import imitation_amd as ia
+    from imitation_amd.vec_env import SyntheticImageVecEnv
+    from oracle import sb3_restated as sb
+
+    def run(ppo_cls, policy_cls, device):
+        th.manual_seed(5)
+        np.random.seed(5)
+        venv = SyntheticImageVecEnv(num_envs=4, shape=(4, 36, 36), act_dim=2, horizon=6, seed=1,
+                                    n_discrete=3 if discrete else None)
+        algo = ppo_cls(policy_cls, venv, n_steps=8, batch_size=16, n_epochs=2, ent_coef=0.01, learning_rate=1e-4, seed=0,
+                       device=device)
+        algo.learn(4 * 8 * 2)
+        rb = algo.rollout_buffer
+        out = {f"policy/{k}": v.detach().cpu().numpy() for k, v in algo.policy.state_dict().items()}
+        for k in ("values", "log_probs", "advantages", "returns", "actions"):
+            v = getattr(rb, k)
+            out[f"rollout/{k}"] = (v.detach().cpu().numpy() if isinstance(v, th.Tensor) else np.asarray(v)).reshape(-1)
+        return out
+
+    ref = run(sb.PPO, sb.ActorCriticCnnPolicy, "cpu")
+    got = run(ia.PPO, "CnnPolicy", "cuda")
+    assert set(ref) == set(got)
+    for k in ref:
+        x, y = got[k].astype(np.float64), ref[k].astype(np.float64)
+        err = np.abs(x - y)
+        bad = err > 5e-5 + 2e-4 * np.abs(y)
+        assert bad.mean() <= 1e-3 and (not bad.any() or err[bad].max() <= 4 * 1e-4), (k, bad.mean(), err.max())

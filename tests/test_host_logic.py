@@ -374,8 +374,21 @@ def test_cnn_policy_host_construction_matches_sb3_restated(shape, A):
         assert th.equal(pol.state_dict()[k], other[k]), k
     with pytest.raises(ValueError, match="too small"):
         ActorCriticCnnPolicy(spaces.Box(0, 255, (4, 20, 20), np.uint8), asp, lambda _: 1.0)
+    # Box (DiagGaussian) head: log_std is the policy's own parameter and comes first, as in torch's `parameters()`
+    bsp = spaces.Box(-np.ones(2, dtype=np.float32), np.ones(2, dtype=np.float32))
+    th.manual_seed(13)
+    ref_b = sb.ActorCriticCnnPolicy(osp, bsp, lambda _: 1.0)
+    after_ref = th.get_rng_state()
+    th.manual_seed(13)
+    pol_b = ActorCriticCnnPolicy(osp, bsp, lambda _: 1.0)
+    assert th.equal(th.get_rng_state(), after_ref)
+    assert [n for n, _ in pol_b.named_parameters()] == [n for n, _ in ref_b.named_parameters()]
+    sd, rsd = pol_b.state_dict(), ref_b.state_dict()
+    assert list(sd) == list(rsd)
+    for k in rsd:
+        assert th.equal(sd[k], rsd[k]), k
     with pytest.raises(NotImplementedError):
-        ActorCriticCnnPolicy(osp, spaces.Box(-1, 1, (2,), np.float32), lambda _: 1.0)
+        ActorCriticCnnPolicy(osp, spaces.Box(-1, 1, (2, 2), np.float32), lambda _: 1.0)
 
 
 def test_infos_travel_through_buffering_wrapper_and_replay_ring():
