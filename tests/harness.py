@@ -148,7 +148,8 @@ def namespace(impl: str) -> pytypes.SimpleNamespace:
 
         return pytypes.SimpleNamespace(
             GAIL=o.GAIL, AIRL=o.AIRL, PPO=sb.PPO, FeedForward32Policy=o.FeedForward32Policy,
-            ActorCriticPolicy=sb.ActorCriticPolicy,
+            ActorCriticPolicy=sb.ActorCriticPolicy, ActorCriticCnnPolicy=sb.ActorCriticCnnPolicy,
+            CnnRewardNet=o.CnnRewardNet,
             NormalizeFeaturesExtractor=o.NormalizeFeaturesExtractor, RunningNorm=o.RunningNorm,
             BasicRewardNet=o.BasicRewardNet, BasicShapedRewardNet=o.BasicShapedRewardNet,
             NormalizedRewardNet=o.NormalizedRewardNet, Transitions=lambda **kw: o.Transitions(**kw),
