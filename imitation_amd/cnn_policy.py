@@ -87,6 +87,10 @@ class ActorCriticCnnPolicy:
             Cin, H, W = cout, oh, ow
         self.n_flatten = Cin * H * W
         self._last_hw_c = (H, W, Cin)
+        # first layer straight from the uint8 frames (implicit GEMM, csrc/conv1_implicit.hip) when the shape is the
+        # standard 4-frame stack; otherwise im2col + GEMM like the other layers. `implicit_conv1 = False` forces the
+        # explicit path (tests compare the two).
+        self.implicit_conv1: Optional[bool] = None   # resolved on the device (`to`)
         # Host construction in SB3's order so that torch's global generator is consumed identically:
         # the three convolutions, the linear layer, action_net, value_net; then orthogonal re-initialisation
         # (features extractor sqrt(2), action_net 0.01, value_net 1).
@@ -156,6 +160,9 @@ class ActorCriticCnnPolicy:
         self.device = th.device(device)
         self._flat = self._flat.to(self.device).contiguous()
         if self.device.type == "cuda":
+            if self.implicit_conv1 is None:
+                c0, h0, w0 = self.observation_space.shape
+                self.implicit_conv1 = bool(L.load().ia_conv1_u8_implicit_ok(c0, h0, w0, 8, 8, 4, 32))
             self.optimizer = HipAdam(self._flat, th.zeros_like(self._flat), lr=self._lr0, **self.optimizer_kwargs)
             if self.discrete:
                 self._low = self._high = th.zeros(self.act_dim, device=self.device)
@@ -229,7 +236,11 @@ class ActorCriticCnnPolicy:
             f = lambda *s: th.empty(*s, device=self.device)
             d: Dict[str, th.Tensor] = {}
             for li, (cin, _, _, cout, k, _, oh, ow) in enumerate(self.geom):
-                d[f"col{li}"] = f(B * oh * ow, cin * k * k)
+                if li == 0 and self.implicit_conv1:   # no column buffer: workspaces of the implicit first layer
+                    d["c1_ws"] = f(128 * 64)
+                    d["c1_wg"] = f(int(L.load().ia_conv1_u8_wgrad_ws_floats(B)))
+                else:
+                    d[f"col{li}"] = f(B * oh * ow, cin * k * k)
                 d[f"act{li}"] = f(B * oh * ow, cout)           # channel-last [B, OH, OW, Cout], post-ReLU
             d["feat"], d["logits"], d["values"] = f(B, self.features_dim), f(B, self.n_actions), f(B, 1)
             d["logp"], d["ent"], d["acts"] = f(B), f(B), f(B, 1 if self.discrete else self.act_dim)
@@ -261,8 +272,15 @@ class ActorCriticCnnPolicy:
         d = self._buffers(B)
         C0, H0, W0 = self.observation_space.shape
         _, _, _, _, k, s, _, _ = self.geom[0]
-        L.call("ia_im2col_u8_nchw", L.ptr(obs_u8), B, C0, H0, W0, k, k, s, 1.0 / 255.0, L.ptr(d["col0"]), L.stream())
+        d["obs_u8"] = obs_u8   # (the implicit weight gradient reads the frames again)
+        if self.implicit_conv1:
+            L.call("ia_conv1_u8_forward", L.ptr(obs_u8), B, H0, W0, L.ptr(self.w(0)), L.ptr(self.b(0)), 1.0 / 255.0,
+                   L.ptr(d["c1_ws"]), L.ptr(d["act0"]), L.stream())
+        else:
+            L.call("ia_im2col_u8_nchw", L.ptr(obs_u8), B, C0, H0, W0, k, k, s, 1.0 / 255.0, L.ptr(d["col0"]), L.stream())
         for li, (cin, h, w_, cout, k, s, oh, ow) in enumerate(self.geom):
+            if li == 0 and self.implicit_conv1:
+                continue
             if li > 0:
                 L.call("ia_im2col_f32_nhwc", L.ptr(d[f"act{li - 1}"]), B, h, w_, cin, k, k, s, L.ptr(d[f"col{li}"]), L.stream())
             K = cin * k * k
@@ -329,6 +347,11 @@ class ActorCriticCnnPolicy:
         for li in (2, 1, 0):
             cin, h, w_, cout, k, s, oh, ow = self.geom[li]
             K, rows = cin * k * k, B * oh * ow
+            if li == 0 and self.implicit_conv1:
+                ow_, nw, ob_, nb = self._offsets[0]
+                L.call("ia_conv1_u8_wgrad", L.ptr(d["obs_u8"]), B, h, w_, L.ptr(dout), 1.0 / 255.0, L.ptr(d["c1_wg"]), 1,
+                       L.ptr(grad[ow_:ow_ + nw]), L.ptr(grad[ob_:ob_ + nb]), L.stream())
+                break
             self._wgrad(li, dout, rows, cout, d[f"col{li}"], K, grad)
             if li == 0:
                 break

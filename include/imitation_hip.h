@@ -323,6 +323,18 @@ int ia_relu_backward(const float* dy, const float* y, int64_t n, float* out, voi
 /* nn.AdaptiveAvgPool2d(1) on channel-last activations y[B, HW, C] -> out[B, C], and its backward (dy = dout / HW). */
 int ia_avgpool_nhwc(const float* y, int B, int HW, int C, float* out, void* stream);
 int ia_avgpool_nhwc_backward(const float* dout, int B, int HW, int C, float* dy, void* stream);
+/* ---- NatureCNN's first layer as an implicit GEMM (csrc/conv1_implicit.hip): Conv2d(4, 32, 8, stride 4) on uint8
+ * [B, 4, H, W] frames with x * scale folded in ([SB3 torch_layers.NatureCNN] cnn.0 + [SB3 preprocess_obs]); no column
+ * buffer. `ia_conv1_u8_implicit_ok`: 1 when the shape is covered (4 channels, 8x8 / 4, 32 filters, W % 4 == 0, image
+ * fits the LDS budget), else use ia_im2col_u8_nchw + ia_gemm_f32. forward: out[B*OH*OW, 32] = relu(conv + bias),
+ * ws = 8192 floats. wgrad: dW[32, 256] / db[32] (=, or += with `accumulate`) from dout[B*OH*OW, 32] (already masked
+ * by the ReLU), ws = ia_conv1_u8_wgrad_ws_floats(B) floats; per-workgroup partials are summed in workgroup order. */
+int ia_conv1_u8_implicit_ok(int C, int H, int W, int KH, int KW, int S, int Cout);
+int ia_conv1_u8_forward(const uint8_t* x, int B, int H, int W, const float* weight, const float* bias, float scale,
+                        float* ws, float* out, void* stream);
+long long ia_conv1_u8_wgrad_ws_floats(int B);
+int ia_conv1_u8_wgrad(const uint8_t* x, int B, int H, int W, const float* dout, float scale, float* ws, int accumulate,
+                      float* dW, float* db, void* stream);
 /* Categorical head ([SB3 CategoricalDistribution] log_prob / entropy of torch.distributions.Categorical):
  * logp[r] = log_softmax(logits[r])[action r], entropy[r]; dlogits (nullable) = gradient of
  * logp_coef*logp + ent_coef*entropy per row (BC: -share/B and -ent_weight*share/B, bc.py:138-156,494-499). */

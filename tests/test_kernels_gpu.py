@@ -494,7 +494,8 @@ def test_ppo_epochs_match_oracle(D, A, H, discrete, norm, T, n, bs, path):
     assert th.equal(Pt2, dp.Pt)
 
 
-@pytest.mark.parametrize("shape,B,A", [((4, 36, 36), 8, 6), ((3, 44, 52), 5, 4), ((1, 36, 40), 33, 18)])
+@pytest.mark.parametrize("shape,B,A", [((4, 36, 36), 8, 6), ((3, 44, 52), 5, 4), ((1, 36, 40), 33, 18),
+                                       ((4, 84, 84), 5, 6), ((4, 44, 60), 3, 4)])
 def test_cnn_policy_forward_and_gradient_match_torch(shape, B, A):
     """NatureCNN actor-critic policy on the HIP path (im2col + MFMA GEMMs, col2im, Categorical head) against
     the SB3-restated torch policy with the same weights: values / log-probs / entropies, and the gradient of
@@ -532,3 +533,31 @@ def test_cnn_policy_forward_and_gradient_match_torch(shape, B, A):
         scale = float(rw.abs().max()) + 1e-12
         assert float((gw - rw).abs().max()) <= 2e-5 * scale + 1e-8, (name, float((gw - rw).abs().max()), scale)
         assert float((grad[ob:ob + nb].cpu() - rb).abs().max()) <= 2e-5 * (float(rb.abs().max()) + 1e-12) + 1e-8, name
+
+
+@pytest.mark.parametrize("shape,B", [((4, 84, 84), 7), ((4, 36, 36), 19), ((4, 44, 60), 4)])
+def test_implicit_first_layer_equals_the_column_buffer_path(shape, B):
+    """`csrc/conv1_implicit.hip` (A operand formed from the uint8 frames in LDS, no column buffer) against the
+    explicit im2col + GEMM path of the same policy: activations of the first layer and the gradient of every parameter
+    (the two paths sum the same products in different orders: tolerance 2e-5 of the array's scale)."""
+    from imitation_amd import spaces
+    from imitation_amd.cnn_policy import ActorCriticCnnPolicy
+
+    osp, asp = spaces.Box(0, 255, shape, np.uint8), spaces.Discrete(5)
+    th.manual_seed(2)
+    pol = ActorCriticCnnPolicy(osp, asp, lambda _: 1.0).to(DEV)
+    assert pol.implicit_conv1, "this shape is covered by the implicit kernels"
+    rng = np.random.default_rng(3)
+    obs = rng.integers(0, 256, (B, *shape), dtype=np.uint8)
+    acts = rng.integers(0, 5, B)
+    res = {}
+    for implicit in (True, False):
+        pol.implicit_conv1 = implicit
+        pol._bufs = {}
+        vals, logp, _ = pol.evaluate_actions(obs, acts, logp_coef=-0.5 / B, ent_coef=-0.02 / B, want_grad=True)
+        grad = th.zeros_like(pol._flat)
+        pol.backward(B, grad)
+        res[implicit] = (pol._bufs[B]["act0"].clone(), vals.clone(), logp.clone(), grad)
+    for x, y in zip(res[True], res[False]):
+        scale = float(y.abs().max()) + 1e-12
+        assert float((x - y).abs().max()) <= 2e-5 * scale + 1e-8, (float((x - y).abs().max()), scale)
