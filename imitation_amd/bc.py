@@ -83,9 +83,6 @@ class BC:
         if policy is None:  # (constructed here, after the loader, like the reference: same draws from torch's RNG)
             policy = pol_mod.FeedForward32Policy(observation_space, action_space,
                                                  lr_schedule=lambda _: float(th.finfo(th.float32).max))
-        if isinstance(policy, pol_mod.ActorCriticPolicy) and not policy.fused:
-            raise NotImplementedError("BC trains MLP policies with the fused towers ([32, 32] / [64, 64] tanh) or the "
-                                      "NatureCNN image policy; other `net_arch` shapes are covered for PPO only")
         self._policy = policy.to(self._device)
         assert self.policy.observation_space == self.observation_space
         assert self.policy.action_space == self.action_space
@@ -101,7 +98,10 @@ class BC:
         from imitation_amd.cnn_policy import ActorCriticCnnPolicy
 
         self._image = isinstance(self.policy, ActorCriticCnnPolicy)
-        if self._image:   # convolution stack: explicit forward / backward launches, then Adam on the flat buffer
+        # explicit forward / backward launches (`evaluate_actions(..., want_grad=True)` + `backward`), then Adam on the
+        # flat buffer: the convolution stack and MLP policies outside the fused kernels' shapes (any `net_arch`)
+        self._explicit = self._image or not getattr(self.policy, "fused", True)
+        if self._explicit:
             self._fused = False
         else:
             self._ws = th.zeros(int(L.load().ia_ppo_ws_floats(C.byref(self.policy.desc), B, B)), device=self._device)
@@ -185,7 +185,7 @@ class BC:
         pol = self.policy
         obs, acts = self._gather(idx)
         share = len(idx) / self.batch_size
-        if self._image:
+        if self._explicit:
             B = len(idx)
             _, logp, ent = pol.evaluate_actions(obs, acts, logp_coef=-share / B, ent_coef=-self.ent_weight * share / B,
                                                 want_grad=True)
@@ -213,10 +213,11 @@ class BC:
         bc1 = 1.0 - self.betas[0] ** self._steps
         bc2 = 1.0 - self.betas[1] ** self._steps
         P = pol._flat.numel()
-        if self._image:
+        if self._explicit:
             L.call("ia_adam_step", L.ptr(pol._flat), L.ptr(self._acc), L.ptr(self._exp_avg), L.ptr(self._exp_avg_sq), P,
                    self.betas[0], self.betas[1], self.eps, 0.0, self.lr / bc1, math.sqrt(bc2), L.stream())
             self._acc.zero_()
+            pol._sync_transposed()   # (policies that shadow their parameters refresh the copies)
             return
         self._ws[self._grad_off:self._grad_off + P].copy_(self._acc)
         L.call("ia_ppo_minibatch_apply", C.byref(pol.desc), L.ptr(pol._flat), L.ptr(pol._flat_t), self.minibatch_size,

@@ -302,10 +302,15 @@ class ActorCriticCnnPolicy:
         a = actions if isinstance(actions, th.Tensor) else th.as_tensor(np.ascontiguousarray(actions))
         d["acts"].copy_(a.to(self.device).reshape(d["acts"].shape).float())
         if not self.discrete:
-            if want_grad:
-                raise NotImplementedError("the BC loss gradient on image policies is built for the Categorical head")
             L.call("ia_gauss_eval", L.ptr(d["logits"]), L.ptr(self._flat), L.ptr(d["acts"]), B, self.act_dim,
                    L.ptr(d["logp"]), L.ptr(d["ent"]), L.stream())
+            if want_grad:   # Gaussian head: the head-loss kernel forms the gradient (see `head_grad_of_coefficients`)
+                from imitation_amd.general_policy import head_grad_of_coefficients
+                hw = d.setdefault("bc_ws", {})
+                head_grad_of_coefficients(False, d["logits"], L.ptr(self._flat), d["values"], d["acts"], d["logp"], B,
+                                          self.act_dim, logp_coef, ent_coef, hw)
+                d["dlogits"].copy_(hw["d_out"])
+                d["dls_pending"] = hw["dls"]
             return d["values"], d["logp"], d["ent"]
         L.call("ia_categorical_loss", L.ptr(d["logits"]), self.n_actions, L.ptr(d["acts"]), B, self.n_actions,
                float(logp_coef), float(ent_coef), L.ptr(d["logp"]), L.ptr(d["ent"]),
@@ -328,6 +333,9 @@ class ActorCriticCnnPolicy:
         `with_values`, `dvalues` (PPO's value loss; the BC loss has no value term)."""
         d = self._bufs[B]
         F_, A = self.features_dim, self.n_actions
+        if d.get("dls_pending") is not None:   # log_std gradient of a Box-head BC step
+            L.call("ia_reduce_partials", L.ptr(d["dls_pending"]), 1, A, 1.0, 1, L.ptr(grad), L.stream())
+            d["dls_pending"] = None
         self._wgrad(4, d["dlogits"], B, A, d["feat"], F_, grad)
         if with_values:
             self._wgrad(5, d["dvalues"], B, 1, d["feat"], F_, grad)

@@ -36,6 +36,26 @@ def fused_arch(pi, vf, activation_fn) -> bool:
             and pi[0] in (32, 64))
 
 
+def head_grad_of_coefficients(discrete: bool, out: th.Tensor, log_std_ptr, values: th.Tensor, acts: th.Tensor,
+                              logp: th.Tensor, n: int, A: int, logp_coef: float, ent_coef: float, ws) -> None:
+    """d/d(head outputs, log_std) of `logp_coef * sum(log_prob) + ent_coef * sum(entropy)` (the BC loss terms) through
+    `ia_ppo_head_loss`: with old log-probs = current ones the ratio is 1 and the clipped surrogate's gradient is
+    `-adv / n` per row, so `adv = -logp_coef * n`, PPO's `ent_coef = -ent_coef * n`, `vf_coef = 0`, no clipping, no
+    advantage normalisation give exactly that gradient for Categorical and DiagGaussian heads alike. Results land in
+    `ws["d_out"]` (`[n, A]`) and, for Box heads, `ws["dls"]` (`[A]`)."""
+    dev = out.device
+    for k, shape in (("d_out", (n, A)), ("d_val", (n, 1)), ("adv", (n,)), ("ret", (n,)), ("dls", (max(A, 1),))):
+        if k not in ws or ws[k].shape != shape:
+            ws[k] = th.empty(*shape, device=dev)
+    if "loss_ws" not in ws:
+        ws["loss_ws"] = th.empty(int(L.load().ia_ppo_head_loss_ws_floats(n)), device=dev)
+    ws["adv"].fill_(-float(logp_coef) * n)
+    ws["ret"].zero_()   # (enters only the value-loss terms, which carry coefficient 0)
+    L.call("ia_ppo_head_loss", int(discrete), L.ptr(out), log_std_ptr, L.ptr(values), L.ptr(acts), L.ptr(logp), L.ptr(ws["adv"]),
+           L.ptr(ws["ret"]), None, n, A, 1.0e30, -float(ent_coef) * n, 0.0, L.ptr(ws["d_out"]), L.ptr(ws["d_val"]),
+           None if discrete else L.ptr(ws["dls"]), L.ptr(ws["loss_ws"]), None, L.stream())
+
+
 def adopt(policy, pi, vf, activation_fn, ortho_init: bool, log_std_init: float) -> None:
     """Re-class `policy` (an `ActorCriticPolicy` whose common attributes are set) to the general-tower execution,
     keeping the user's class in the MRO, and build its parameters."""
@@ -295,19 +315,38 @@ class GeneralTowers:
             L.call("ia_gauss_eval", L.ptr(ws["out"]), self._log_std_ptr(), L.ptr(a), n, self.act_dim, L.ptr(logp),
                    L.ptr(entropy), L.stream())
 
-    def evaluate_actions(self, obs, actions):
-        """[SB3 evaluate_actions] without autograd: (values [n,1], log_prob [n], entropy [n])."""
+    def evaluate_actions(self, obs, actions, logp_coef: float = 0.0, ent_coef: float = 0.0, want_grad: bool = False):
+        """[SB3 evaluate_actions] without autograd: (values [n,1], log_prob [n], entropy [n]). With `want_grad` (the BC
+        step, `bc.py:138-156`), the gradient of `logp_coef * sum(log_prob) + ent_coef * sum(entropy)` w.r.t. the head
+        outputs and log_std is left for `backward()`."""
         require_device(self.device)
         o = self._obs_dev(obs)
         n = o.shape[0]
         a = actions if isinstance(actions, th.Tensor) else th.as_tensor(np.ascontiguousarray(actions))
         a = a.to(self.device, th.float32).reshape(n, -1).contiguous()
         self._maybe_update_norm(o)
-        ws = self._buffers("eval", n)
+        ws = self._buffers("train" if want_grad else "eval", n)
         self._run(o, n, ws)
         logp, ent = th.empty(n, device=self.device), th.empty(n, device=self.device)
         self._head_eval(ws, a, n, logp, ent)
+        if want_grad:
+            head_grad_of_coefficients(self.discrete, ws["out"], self._log_std_ptr(), ws["val"], a, logp, n, self.act_dim,
+                                      logp_coef, ent_coef, ws)
         return ws["val"].clone(), logp, ent
+
+    def backward(self, B: int, grad: th.Tensor) -> None:
+        """Adds to `grad` (flat) the parameter gradient of the loss whose head gradient the last
+        `evaluate_actions(..., want_grad=True)` on `B` rows left behind (no value term: the vf stack gets none)."""
+        ws = self._buffers("train", B)
+        s, sp, P = L.stream(), ws["splits"], self._pi_stack.numel()
+        part = ws["part"].reshape(-1)[: sp * P]
+        L.call("ia_mlp_backward", C.byref(self._desc_pi), L.ptr(self._pi_stack), L.ptr(ws["x"]), self.obs_dim, B,
+               L.ptr(ws["hid_pi"]), L.ptr(ws["d_out"]), L.ptr(ws["dhid"]), L.ptr(part), sp, None, s)
+        L.call("ia_reduce_partials", L.ptr(part), sp, P, 1.0, 0, L.ptr(self._g_pi), s)
+        for (o0, n0), lo in (((self._o_pi, self._n_pi), 0), ((self._o_an, self._n_an), self._n_pi)):
+            L.call("ia_reduce_partials", L.ptr(self._g_pi[lo:lo + n0]), 1, n0, 1.0, 1, L.ptr(grad[o0:o0 + n0]), s)
+        if not self.discrete:
+            L.call("ia_reduce_partials", L.ptr(ws["dls"]), 1, self.act_dim, 1.0, 1, L.ptr(grad), s)
 
     def log_prob_rows(self, obs_dev: th.Tensor, acts_dev: th.Tensor, out: th.Tensor,
                       norm_snapshot: Optional[th.Tensor] = None) -> None:

@@ -153,7 +153,11 @@ def dump_cnn_reward_net():
 
 
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "cnn_reward":
+    if len(sys.argv) > 2 and sys.argv[1] == "bc":        # one BC case: make_golden.py bc <name>
+        out = harness.run_bc_case("reference", sys.argv[2], tempfile.mkdtemp())
+        np.savez_compressed(os.path.join(HERE, f"{sys.argv[2]}.npz"), **out)
+        print("wrote", sys.argv[2], len(out), "arrays")
+    elif len(sys.argv) > 1 and sys.argv[1] == "cnn_reward":
         dump_cnn_reward_net()
     elif len(sys.argv) > 1 and sys.argv[1] == "bc":
         dump_bc()

@@ -402,6 +402,17 @@ BC_CASES: Dict[str, Dict[str, Any]] = {
     # scaled down: 4 x 36 x 36 is the smallest image the 8/4 - 4/2 - 3/1 convolution stack accepts), Discrete(6)
     "bc_cnn": dict(image=(4, 36, 36), obs_dim=None, act_dim=6, n_discrete=6, n_demo=96, batch_size=32,
                    ent_weight=1e-3, train=dict(n_epochs=2), norm_policy=False, log_interval=2),
+    # MLP policies outside the fused kernels' shapes (any SB3 `net_arch`): unequal ReLU towers behind the feature
+    # RunningNorm, Box actions, gradient accumulation + L2; and a Discrete head on a single tanh layer
+    "bc_towers": dict(obs_dim=7, act_dim=3, n_discrete=None, n_demo=120, batch_size=24, minibatch_size=12,
+                      ent_weight=1e-3, l2_weight=1e-2, train=dict(n_epochs=2), norm_policy=True, log_interval=2,
+                      policy_kwargs=dict(net_arch=dict(pi=[48, 24], vf=[16]), activation_fn="relu")),
+    "bc_towers_discrete": dict(obs_dim=5, act_dim=3, n_discrete=3, n_demo=90, batch_size=16, ent_weight=1e-2,
+                               train=dict(n_epochs=2), norm_policy=False, log_interval=2,
+                               policy_kwargs=dict(net_arch=[40])),
+    # DiagGaussian head on the NatureCNN policy
+    "bc_cnn_box": dict(image=(4, 36, 36), obs_dim=None, act_dim=2, n_discrete=None, n_demo=64, batch_size=32,
+                       ent_weight=1e-3, train=dict(n_epochs=2), norm_policy=False, log_interval=1),
     "bc_accum_l2": dict(obs_dim=6, act_dim=2, n_discrete=None, n_demo=100, batch_size=24, minibatch_size=8,
                         ent_weight=1e-3, l2_weight=1e-2, train=dict(n_epochs=2), norm_policy=False, log_interval=2),
 }
@@ -443,8 +454,12 @@ def run_bc_case(impl: str, name: str, log_dir: str, device: str = "cpu") -> Dict
     policy = None
     if cfg.get("image"):
         obs = rng.integers(0, 256, (n, *cfg["image"]), dtype=np.uint8)
-        acts = (obs.reshape(n, -1)[:, :7].sum(axis=1) % cfg["n_discrete"]).astype(np.int64)
-        act_space = spaces.Discrete(cfg["n_discrete"])
+        if cfg["n_discrete"] is None:
+            acts = np.tanh(obs.reshape(n, -1)[:, :ad] / 128.0 - 1.0 + 0.1 * rng.standard_normal((n, ad))).astype(np.float32)
+            act_space = spaces.Box(-1.0, 1.0, (ad,), np.float32)
+        else:
+            acts = (obs.reshape(n, -1)[:, :7].sum(axis=1) % cfg["n_discrete"]).astype(np.int64)
+            act_space = spaces.Discrete(cfg["n_discrete"])
         obs_space = spaces.Box(0, 255, cfg["image"], np.uint8)
         policy = ns.ActorCriticCnnPolicy(observation_space=obs_space, action_space=act_space,
                                          lr_schedule=lambda _: 1.0)
@@ -458,11 +473,14 @@ def run_bc_case(impl: str, name: str, log_dir: str, device: str = "cpu") -> Dict
             act_space = spaces.Discrete(cfg["n_discrete"])
         obs_space = spaces.Box(-np.inf, np.inf, (od,), np.float32)
     demos = ns.Transitions(obs=obs, acts=acts, next_obs=obs.copy(), dones=np.zeros(n, dtype=bool))
-    if cfg["norm_policy"]:
-        policy = ns.FeedForward32Policy(observation_space=obs_space, action_space=act_space,
-                                        lr_schedule=lambda _: 1.0,
-                                        features_extractor_class=ns.NormalizeFeaturesExtractor,
-                                        features_extractor_kwargs=dict(normalize_class=ns.RunningNorm))
+    extra = dict(cfg.get("policy_kwargs", {}))
+    if "activation_fn" in extra:
+        extra["activation_fn"] = {"relu": th.nn.ReLU, "tanh": th.nn.Tanh}[extra["activation_fn"]]
+    if cfg["norm_policy"] or extra:
+        nk = (dict(features_extractor_class=ns.NormalizeFeaturesExtractor,
+                   features_extractor_kwargs=dict(normalize_class=ns.RunningNorm)) if cfg["norm_policy"] else {})
+        pcls = ns.ActorCriticPolicy if extra else ns.FeedForward32Policy
+        policy = pcls(observation_space=obs_space, action_space=act_space, lr_schedule=lambda _: 1.0, **nk, **extra)
     logger = ns.configure_logger(log_dir)
     rows = []
     orig_dump = logger.dump

@@ -57,3 +57,14 @@ for rep in range(2):
     print(f"world {world}: train() host {1e3 * h:.2f} ms, device idle after {1e3 * d:.2f} ms, {steps} steps; per step: " +
           ", ".join(f"{n} {t_ / 100.0 / steps:.2f}" for n, t_ in zip(names, ticks)))
 L.load().ia_ppo_debug_timing(None)
+# production instantiation (no phase clocks): HIP events around the launch
+algo.update_events = (th.cuda.Event(enable_timing=True), th.cuda.Event(enable_timing=True))
+ms = []
+for rep in range(6):
+    algo._dpg["perms"].start(algo._dpg["perm_np"])
+    algo.train()
+    th.cuda.synchronize()
+    ms.append(algo.update_events[0].elapsed_time(algo.update_events[1]))
+steps = algo.n_epochs * algo._n_mb
+print(f"world {world}: production ia_ppo_update on the gathered tile: median {sorted(ms)[len(ms) // 2]:.3f} ms = "
+      f"{1e3 * sorted(ms)[len(ms) // 2] / steps:.2f} us/step")
