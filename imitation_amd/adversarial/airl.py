@@ -7,9 +7,10 @@ import torch as th
 
 from imitation_amd import reward_nets
 from imitation_amd.adversarial import common
+from imitation_amd.cnn_policy import ActorCriticCnnPolicy
 from imitation_amd.policies import ActorCriticPolicy
 
-STOCHASTIC_POLICIES = (ActorCriticPolicy,)
+STOCHASTIC_POLICIES = (ActorCriticPolicy, ActorCriticCnnPolicy)   # (`airl.py:11`: SAC / actor-critic policies)
 
 
 class AIRL(common.AdversarialTrainer):

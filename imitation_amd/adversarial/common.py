@@ -344,7 +344,7 @@ class AdversarialTrainer(abc.ABC):
         discarded (`gail.py:157`) but the call still updates a train-mode feature RunningNorm
         (SURVEY App. C.2), so the statistics update is replayed even when logp is not needed."""
         pol = self.policy
-        if not isinstance(pol, ActorCriticPolicy):
+        if not hasattr(pol, "log_prob_rows"):   # (MLP and image actor-critic policies both provide it)
             return None
         has_norm = pol.features_extractor.normalize is not None
         if not self._needs_logp and not (has_norm and pol.training):

@@ -86,6 +86,11 @@ CASES: Dict[str, Dict[str, Any]] = {
                        n_steps=8, ppo_batch=16, n_epochs=2, ent_coef=0.01, disc_hid=None,
                        demo_batch=16, demo_minibatch=None, n_disc=2, capacity=None, n_demo=64, rounds=2,
                        norm_policy=False, norm_disc=False, obs_dtype="uint8", ppo_kwargs=dict(learning_rate=1e-4)),
+    # AIRL on image observations: log pi(a|s) of the NatureCNN policy inside the discriminator logit
+    "airl_image": dict(algo="airl", image=(4, 36, 36), n_envs=4, horizon=7, obs_dim=None, act_dim=3, n_discrete=3,
+                       n_steps=8, ppo_batch=16, n_epochs=2, ent_coef=0.01, disc_hid=None,
+                       demo_batch=16, demo_minibatch=8, n_disc=2, capacity=None, n_demo=64, rounds=2,
+                       norm_policy=False, norm_disc=False, obs_dtype="uint8", ppo_kwargs=dict(learning_rate=1e-4)),
     # AIRL, shaped reward net, NormalizedRewardNet output norm (script default), use_next_state.
     "airl_box": dict(algo="airl", n_envs=8, horizon=10, obs_dim=11, act_dim=3, n_discrete=None,
                      n_steps=16, ppo_batch=32, n_epochs=2, ent_coef=0.0, disc_hid=(32,),
@@ -205,7 +210,7 @@ def build_trainer(impl: str, cfg, log_dir: str, device: str = "cpu", module_net:
     kw = dict(normalize_input_layer=disc_norm) if cfg["norm_disc"] else {}
     if cfg.get("image"):
         net = ns.CnnRewardNet(venv.observation_space, venv.action_space, hwc_format=False)
-        cls = ns.GAIL
+        cls = ns.GAIL if cfg["algo"] == "gail" else ns.AIRL
     elif cfg["algo"] == "gail":
         net = ns.BasicRewardNet(venv.observation_space, venv.action_space, hid_sizes=cfg["disc_hid"], **kw)
         cls = ns.GAIL
