@@ -238,7 +238,8 @@ def gemm_roofline(trainer, cfg, rounds):
         ppo = {"kernel": "ppo_update_persistent_kernel (whole PPO.train, one launch)", "bound": "latency",
                "avg_launch_us": 1e3 * avg, "optimizer_steps_per_launch": steps, "us_per_step": 1e3 * avg / steps,
                "achieved": fl_ppo / (avg * 1e-3) / 1e12, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-               "frac": fl_ppo / (avg * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+               "frac": fl_ppo / (avg * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS,
+               "traffic": _pmc_traffic().get("ppo_update_persistent_kernel"),
                "share_of_gpu_time": avg / (avg + disc_ms_round),
                "algorithmic_bytes_per_launch": steps * rows * (D + A + 4) * 4.0,
                "note": "largest kernel by GPU time: a chain of dependent 1024-row optimiser steps on nblk+3 workgroups "
