@@ -2252,7 +2252,9 @@ __global__ __launch_bounds__(512) void ppo_update_persistent_kernel(
   // Loss statistics of step q: sum of the per-block partials in block order, written by one wave.
   auto write_loss_stats = [&](int q, float total_norm, float coef) {
     if (tid < 64 && stats) {
-      const int ln = tid & 63;
+      int wz;   // opaque zero: lane index and row addresses of this rarely taken branch are formed here, not kept alive
+      asm volatile("s_mov_b32 %0, 0" : "=s"(wz));
+      const int ln = (tid + wz) & 63;
       const float* sb = w.statpart + (q % UPD_SD) * nblk * 8;
       float st = 0.f;
       if (ln < 5) {
@@ -2406,7 +2408,7 @@ __global__ __launch_bounds__(512) void ppo_update_persistent_kernel(
   float* sPt = sP + w.P4;
   float* stg = sPt + w.P4;                    // UpdStage: the NEXT minibatch's rows of this block
   unsigned short* dstT = reinterpret_cast<unsigned short*>(stg + UpdStage::total(d.discrete ? 1 : d.act_dim));  // [P4] index of parameter i in the transposed copy
-  float* red = lds + L::misc + ROWS * L::MS;  // 64 spare floats behind the misc tile
+  // (64 spare floats behind the misc tile, lds + L::misc + ROWS * L::MS, are the block reductions' scratch)
   const int lane = tid & 63;
   float rm[NPT], rv[NPT];
 #pragma unroll
@@ -2438,13 +2440,16 @@ __global__ __launch_bounds__(512) void ppo_update_persistent_kernel(
   // any later block barrier publishes them. (ii) every thread then issues its row gathers at once.
   auto prefetch_resolve = [&](int s) {
     if (tid >= 448) {
+      int tz;   // opaque zero: the reciprocal of T behind `f / T` is re-derived per step instead of being spilled
+      asm volatile("s_mov_b32 %0, 0" : "=s"(tz));
+      const unsigned Tq = (unsigned)(T + tz);
       const MbRows r = rows_of(s);
       const int i0 = vb * ROWS;
       int src = 0;
       if (i0 + lane < r.batch) {
         const long long flat = r.idx[i0 + lane];
         if (sch_total < (1ll << 31)) {  // 32-bit divide (the 64-bit one is a long software sequence)
-          const unsigned f = (unsigned)flat, env = f / (unsigned)T, t = f - env * (unsigned)T;
+          const unsigned f = (unsigned)flat, env = f / Tq, t = f - env * Tq;
           src = (int)(t * (unsigned)n_envs + env);
         } else {
           src = (int)rollout_offset(flat, T, n_envs);
@@ -2668,7 +2673,9 @@ __global__ __launch_bounds__(512) void ppo_update_persistent_kernel(
       sq += g[k] * g[k];
     }
     UPD_TS(4);
-    const float total_sq = block_sum<512>(sq, red);
+    int rz;   // opaque zero: the reduction scratch address is re-formed here instead of living in a (spilled) register
+    asm volatile("s_mov_b32 %0, 0" : "=s"(rz));
+    const float total_sq = block_sum<512>(sq, lds + L::misc + ROWS * L::MS + rz);
     UPD_TS(5);
     const float total_norm = sqrtf(total_sq);
     const float coef = fminf(max_norm / (total_norm + 1e-6f), 1.0f);  // torch clip_grad_norm_
