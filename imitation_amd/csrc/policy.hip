@@ -1477,23 +1477,22 @@ __device__ __forceinline__ void mfma32_minibatch_chain(
   const float* __restrict__ sPt = sP + ((o.total + 3) & ~3);
   IA_TS(0);
 
-  // ---- per-row scalars of the loss: lanes 0..15 of every wave own row q*16 + lane of their tower's loss
-  const int lrow = q * 16 + (lane & 15);            // local row of this lane in the loss phase
-  const bool loss_lane = lane < 16;
+  // ---- per-row scalars of the loss. Policy waves (tw = 0): FOUR lanes per row -- lane = 4 * (row - 16 q) + part, part
+  // owns actions part, part + 4, part + 8, part + 12 (MAXA = 16) -- so the per-action work of a row is four
+  // iterations on 64 lanes instead of sixteen on 16 (the sums over actions are finished with two quad shuffles).
+  // Value waves (tw = 1): lanes 0..15 own row q*16 + lane.
+  const int part = lane & 3;
+  const int lrow = tw == 0 ? q * 16 + (lane >> 2) : q * 16 + (lane & 15);   // local row of this lane in the loss phase
+  const bool loss_lane = tw == 0 || lane < 16;
   const bool valid = (i0 + lrow) < batch;
-  float r_oldlp = 0.f, r_adv = 0.f, r_ret = 0.f, r_act[MAXA];
+  float r_oldlp = 0.f, r_adv = 0.f, r_ret = 0.f, r_act[4] = {0.f, 0.f, 0.f, 0.f};
+  if (tw == 0) {   // staged by the prefetch (LDS-direct loads); unconditional, clamped
+    r_oldlp = stg[UpdStage::oldlp + lrow];
+    r_adv = stg[UpdStage::adv + lrow];
 #pragma unroll
-  for (int a = 0; a < MAXA; ++a) r_act[a] = 0.f;
-  if (loss_lane) {
-    if (tw == 0) {
-      r_oldlp = stg[UpdStage::oldlp + lrow];
-      r_adv = stg[UpdStage::adv + lrow];
-#pragma unroll
-      for (int a = 0; a < MAXA; ++a)   // staged by the prefetch (LDS-direct loads); unconditional, clamped
-        r_act[a] = stg[UpdStage::act + lrow * aw + min(a, aw - 1)];
-    } else {
-      r_ret = stg[UpdStage::ret + lrow];
-    }
+    for (int j = 0; j < 4; ++j) r_act[j] = stg[UpdStage::act + lrow * aw + min(part + 4 * j, aw - 1)];
+  } else if (loss_lane) {
+    r_ret = stg[UpdStage::ret + lrow];
   }
 
   IA_TS(9);
@@ -1579,7 +1578,7 @@ __device__ __forceinline__ void mfma32_minibatch_chain(
   // per-action Gaussian constants; the reciprocal variance turns the ~3 IEEE divisions per action and
   // row of the loss into multiplications (<= 1 ulp away from dividing). Lane a computes action a's pair
   // once (exp, division, log); every lane then picks the MAXA pairs up from the wave.
-  float c_ivar[MAXA], c_logsd[MAXA];
+  float c_ivar[4], c_logsd[4];   // of this lane's actions part + 4 j
   {
     float my_ivar = 1.f, my_logsd = 0.f;
     if (tw == 0 && !d.discrete) {
@@ -1587,11 +1586,10 @@ __device__ __forceinline__ void mfma32_minibatch_chain(
       my_ivar = lane < A ? 1.f / (sd * sd) : 1.f;
       my_logsd = lane < A ? logf(sd) : 0.f;
     }
-    // wave-uniform: kept in scalar registers (as 32 vector registers they pushed the step loop into scratch)
 #pragma unroll
-    for (int a = 0; a < MAXA; ++a) {
-      c_ivar[a] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_ivar), a));
-      c_logsd[a] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_logsd), a));
+    for (int j = 0; j < 4; ++j) {
+      c_ivar[j] = __shfl(my_ivar, part + 4 * j, 64);
+      c_logsd[j] = __shfl(my_logsd, part + 4 * j, 64);
     }
   }
   IA_TS(11);
@@ -1676,7 +1674,7 @@ __device__ __forceinline__ void mfma32_minibatch_chain(
   for (int s = 0; s < 4; ++s)
 #pragma unroll
     for (int c = 0; c < 2; ++c) bDa2[s][c] = sP[o.aW + min(4 * s + lk, A - 1) * H + c * 16 + li];
-  // ---- per-row losses of this wave's 16 rows (lanes 0..15)
+  // ---- per-row losses of this wave's 16 rows (policy waves: four lanes per row; value waves: lanes 0..15)
   if (loss_lane) {
     if (tw == 0) {
       const float* outrow = lds + L::out + lrow * L::AS;
@@ -1684,31 +1682,50 @@ __device__ __forceinline__ void mfma32_minibatch_chain(
       float* auxrow = lds + L::aux + lrow * L::AS;
       float logp = 0.f, entropy = 0.f, lse = 0.f;
       int act_i = 0;
-      float o_[MAXA];  // the row's head outputs, read in one batch (a read inside `if (a < A)` is a branch + a wait each)
+      float o_[4];   // the head outputs of this lane's actions, read in one batch (columns >= A hold zeros)
 #pragma unroll
-      for (int a = 0; a < MAXA; ++a) o_[a] = outrow[a];
+      for (int j = 0; j < 4; ++j) o_[j] = outrow[part + 4 * j];
+      if (d.discrete) act_i = (int)r_act[0];
+      const float o_act = outrow[act_i];
       __builtin_amdgcn_sched_barrier(0);
+      IA_TS(12);
+      auto quad_sum = [](float v) {
+        v += __shfl_xor(v, 1, 64);
+        v += __shfl_xor(v, 2, 64);
+        return v;
+      };
       if (!d.discrete) {
 #pragma unroll
-        for (int a = 0; a < MAXA; ++a)
-          if (a < A) {
-            const float diff = r_act[a] - o_[a];
-            logp += -(diff * diff) * (0.5f * c_ivar[a]) - c_logsd[a] - LOG_SQRT_2PI;
-            entropy += 0.5f + LOG_SQRT_2PI + c_logsd[a];
+        for (int j = 0; j < 4; ++j)
+          if (part + 4 * j < A) {
+            const float diff = r_act[j] - o_[j];
+            logp += -(diff * diff) * (0.5f * c_ivar[j]) - c_logsd[j] - LOG_SQRT_2PI;
+            entropy += 0.5f + LOG_SQRT_2PI + c_logsd[j];
           }
+        logp = quad_sum(logp);
+        entropy = quad_sum(entropy);
       } else {
-        float mx = outrow[0];
-        for (int a = 1; a < A; ++a) mx = fmaxf(mx, outrow[a]);
+        float mx = -3.0e38f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (part + 4 * j < A) mx = fmaxf(mx, o_[j]);
+        mx = fmaxf(mx, __shfl_xor(mx, 1, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 2, 64));
         float se = 0.f;
-        for (int a = 0; a < A; ++a) se += expf(outrow[a] - mx);
-        lse = mx + logf(se);
-        act_i = (int)r_act[0];
-        logp = outrow[act_i] - lse;
-        for (int a = 0; a < A; ++a) {
-          const float l = outrow[a] - lse;
-          entropy -= expf(l) * l;
-        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (part + 4 * j < A) se += expf(o_[j] - mx);
+        lse = mx + logf(quad_sum(se));
+        logp = o_act - lse;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (part + 4 * j < A) {
+            const float l = o_[j] - lse;
+            entropy -= expf(l) * l;
+          }
+        entropy = quad_sum(entropy);
       }
+      IA_TS(13);
       float advn = r_adv;
       if (normalize_adv && batch > 1) advn = (advn - adv_mean) / (adv_std + 1e-8f);
       const float log_ratio = logp - r_oldlp;
@@ -1720,28 +1737,34 @@ __device__ __forceinline__ void mfma32_minibatch_chain(
       const float g2 = pl2 < pl1 ? 1.f : (pl1 == pl2 ? 0.5f : 0.f);
       const float inrange = (ratio >= lo && ratio <= hi) ? 1.f : 0.f;
       const float dlogp = valid ? -invB * advn * (g1 + g2 * inrange) * ratio : 0.f;
+      IA_TS(14);
       if (!d.discrete) {
 #pragma unroll
-        for (int a = 0; a < MAXA; ++a)
-          if (a < A) {
-            const float diff = r_act[a] - o_[a];
-            doutrow[a] = dlogp * diff * c_ivar[a];
-            auxrow[a] = valid ? dlogp * (diff * diff * c_ivar[a] - 1.f) - ent_coef * invB : 0.f;
+        for (int j = 0; j < 4; ++j)
+          if (part + 4 * j < A) {
+            const float diff = r_act[j] - o_[j];
+            doutrow[part + 4 * j] = dlogp * diff * c_ivar[j];
+            auxrow[part + 4 * j] = valid ? dlogp * (diff * diff * c_ivar[j] - 1.f) - ent_coef * invB : 0.f;
           }
       } else {
-        for (int a = 0; a < A; ++a) {
-          const float l = outrow[a] - lse, p = expf(l);
-          const float dH = -p * (l + entropy);
-          float g = dlogp * ((a == act_i ? 1.f : 0.f) - p);
-          g += valid ? -ent_coef * invB * dH : 0.f;
-          doutrow[a] = g;
-        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (part + 4 * j < A) {
+            const float l = o_[j] - lse, p = expf(l);
+            const float dH = -p * (l + entropy);
+            float g = dlogp * ((part + 4 * j == act_i ? 1.f : 0.f) - p);
+            g += valid ? -ent_coef * invB * dH : 0.f;
+            doutrow[part + 4 * j] = g;
+          }
       }
-      float* mrow = lds + L::misc + lrow * L::MS;
-      mrow[2] = valid ? -fminf(pl1, pl2) : 0.f;                           // policy_gradient_loss
-      mrow[3] = valid ? -entropy : 0.f;                                    // entropy_loss
-      mrow[4] = valid ? (ratio - 1.f) - log_ratio : 0.f;                   // approx_kl
-      mrow[5] = valid ? (fabsf(ratio - 1.f) > clip ? 1.f : 0.f) : 0.f;     // clip_fraction
+      if (part == 0) {
+        float* mrow = lds + L::misc + lrow * L::MS;
+        mrow[2] = valid ? -fminf(pl1, pl2) : 0.f;                           // policy_gradient_loss
+        mrow[3] = valid ? -entropy : 0.f;                                    // entropy_loss
+        mrow[4] = valid ? (ratio - 1.f) - log_ratio : 0.f;                   // approx_kl
+        mrow[5] = valid ? (fabsf(ratio - 1.f) > clip ? 1.f : 0.f) : 0.f;     // clip_fraction
+      }
+      IA_TS(15);
     } else {
       const float v = lds[L::misc + lrow * L::MS + 0];
       const float verr = r_ret - v;

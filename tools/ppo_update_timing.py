@@ -39,7 +39,7 @@ for rep in range(3):
                                                            "minibatch statistics + publish"), sb)))
     print(f"xcd_pack={pack}: train() {1e3 * d:.2f} ms for {steps} steps; per step: " +
           ", ".join(f"{n} {t_ / 100.0 / steps:.2f} us" for n, t_ in zip(names, ticks)))
-t = buf.cpu().numpy()[16:28]
+t = buf.cpu().numpy()[16:32]
 import numpy as np  # noqa: E402
 d = np.diff(np.concatenate([t[:7], t[8:9]]))   # (slot 7 is not stamped: the gradient tiles are one phase)
 names = ["0 stage/fragments", "1 layer1", "2 layer2", "3 heads", "4 loss", "5 head grads, dz2, dz1 + barrier",
@@ -47,6 +47,9 @@ names = ["0 stage/fragments", "1 layer1", "2 layer2", "3 heads", "4 loss", "5 he
 print("shader clocks per minibatch phase (last step, block 0):")
 for n_, v in zip(names, d):
     print(f"  {n_:18s} {v:8d} clk  ~{v / 2.4e3:6.2f} us @2.4GHz")
+print(f"  loss detail (clk): fragment requests + head outputs read {t[12] - t[4]}, log-prob / entropy over the actions "
+      f"{t[13] - t[12]}, ratio / surrogate / d log-prob {t[14] - t[13]}, head gradients + statistics written {t[15] - t[14]}, "
+      f"to the end of the phase {t[5] - t[15]}")
 print(f"  phase 0 detail (clk): loss scalars / action loads issued {t[9] - t[0]}, rows normalised into the x tile "
       f"{t[10] - t[9]}, weight fragments LDS->VGPR + Gaussian constants {t[11] - t[10]}, block barrier {t[1] - t[11]}")
 L.load().ia_ppo_debug_timing(None)
