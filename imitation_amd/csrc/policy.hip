@@ -1499,26 +1499,28 @@ __device__ __forceinline__ void mfma32_minibatch_chain(
   // ---- stage this wave's 16 feature rows (normalised) into the x tile; clear its rows of the small tiles
   {
     const int rbase = q * 16;
-    // the two waves that share q (tower 0 / tower 1) stage the 16 rows together: lane l of the 128
-    // takes row l/8 and the eight columns l%8 + 8j -- no integer division, and all 24 loads of a lane
-    // (raw value, mean, variance per column) are independent and in flight together
+    // the two waves that share q (tower 0 / tower 1) stage the 16 rows together, four consecutive columns per lane
+    // and only the 4 * S1 columns the first layer reads with non-zero weights (the caller cleared the tile once: the
+    // columns beyond are never written). Group g = row * S1 + column group; the row comes from a multiply-shift
+    // (S1 <= 16, g < 256). All 12 loads of a group (raw value, mean, 1 / std) are in flight together.
     const int l128 = lane + 64 * tw;
-    const int r = l128 >> 3, cb = l128 & 7;
-    const bool rok = (i0 + rbase + r) < batch;
-    float raw[8], mu[8], vr[8];
+    const int s1r = (65536 + S1 - 1) / S1;   // wave-uniform
+    for (int g = l128; g < 16 * S1; g += 128) {
+      const int r = (g * s1r) >> 16, k0 = (g - r * S1) * 4;
+      const bool rok = (i0 + rbase + r) < batch;
+      float raw[4], mu[4], vr[4];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int k = cb + 8 * j;
-      raw[j] = stg[UpdStage::x + (rbase + r) * L::XS + k];
-      mu[j] = nm[k];          // slot arrays hold MAXD entries each
-      vr[j] = nv[k];
-    }
+      for (int j = 0; j < 4; ++j) {
+        raw[j] = stg[UpdStage::x + (rbase + r) * L::XS + k0 + j];
+        mu[j] = nm[k0 + j];          // slot arrays hold MAXD entries each
+        vr[j] = nv[k0 + j];
+      }
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int k = cb + 8 * j;
-      const bool ok = rok && k < D;
-      const bool nrm = ok && d.has_norm;          // (`nv` carries 1/sqrt(var + eps), see the statistics block)
-      lds[L::x + (rbase + r) * L::XS + k] = ok ? (nrm ? (raw[j] - mu[j]) * vr[j] : raw[j]) : 0.f;
+      for (int j = 0; j < 4; ++j) {
+        const bool ok = rok && k0 + j < D;
+        const bool nrm = ok && d.has_norm;          // (`nv` carries 1/sqrt(var + eps), see the statistics block)
+        lds[L::x + (rbase + r) * L::XS + k0 + j] = ok ? (nrm ? (raw[j] - mu[j]) * vr[j] : raw[j]) : 0.f;
+      }
     }
     if (tw == 0) {
       for (int e = lane; e < 16 * L::AS; e += 64) {
@@ -2543,6 +2545,7 @@ __global__ __launch_bounds__(512) void ppo_update_persistent_kernel(
     if (wave == 0) stg[UpdStage::src + lane] = stg[UpdStage::nxt + lane];
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the LDS-direct loads have landed
   };
+  for (int e = tid; e < ROWS * L::XS; e += 512) lds[L::x + e] = 0.f;   // (the chain only rewrites the columns it uses)
   if (n_steps > 0) {
     prefetch_resolve(0);
     __syncthreads();
@@ -2568,13 +2571,15 @@ __global__ __launch_bounds__(512) void ppo_update_persistent_kernel(
       }
       __syncthreads();
       if (!s_ok) return;
-      adv_mean = *reinterpret_cast<const volatile float*>(slot + 2 * MAXD);
-      adv_std = *reinterpret_cast<const volatile float*>(slot + 2 * MAXD + 1);
-    } else {
-      slot = stg + UpdStage::ring;
-      adv_mean = slot[2 * MAXD];
-      adv_std = slot[2 * MAXD + 1];
+      // (rare: the statistics block had not published this slot when the previous barrier was passed) copy it into
+      // the LDS slot too, so that the chain below ALWAYS reads its statistics through LDS addresses -- a pointer that
+      // may be global or LDS compiles to flat loads, 16 of them per lane in the staging phase
+      if (tid < 2 * MAXD + 8) stg[UpdStage::ring + tid] = *reinterpret_cast<const volatile float*>(slot + tid);
+      __syncthreads();
     }
+    slot = stg + UpdStage::ring;
+    adv_mean = slot[2 * MAXD];
+    adv_std = slot[2 * MAXD + 1];
     UPD_TS(0);
     // Adam's scalars of this step: requested now (a global load), consumed after the grid barrier
     const float step_size = w.tab[s], bc2_sqrt = w.tab[UPD_MAX_STEPS + s];
