@@ -392,7 +392,7 @@ class ActorCriticCnnPolicy:
         def step(t: int) -> None:
             with th.cuda.stream(stream_obj):
                 obs_d.copy_(obs_tile[t], non_blocking=True)
-                noise_d.copy_(noise_host.reshape(n, A), non_blocking=True)
+                noise_d.copy_((noise_host[t] if noise_host.dim() == 3 else noise_host).reshape(n, A), non_blocking=True)
                 d = self._forward(self._rows_u8(obs_d))
                 L.call("ia_gauss_act", L.ptr(d["logits"]), L.ptr(self._flat), L.ptr(noise_d), L.ptr(self._low),
                        L.ptr(self._high), n, A, L.ptr(acts[t]), L.ptr(clip_d), L.ptr(logp[t]), L.stream())

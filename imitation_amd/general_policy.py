@@ -237,7 +237,7 @@ class GeneralTowers:
         def step(t: int) -> None:
             with th.cuda.stream(stream_obj):
                 ws["obs"].copy_(obs_tile[t], non_blocking=True)
-                ws["noise"].copy_(noise_host.reshape(n, A), non_blocking=True)
+                ws["noise"].copy_((noise_host[t] if noise_host.dim() == 3 else noise_host).reshape(n, A), non_blocking=True)
                 self._run(ws["obs"], n, ws)
                 L.call("ia_gauss_act", L.ptr(ws["out"]), self._log_std_ptr(), L.ptr(ws["noise"]), L.ptr(self._low),
                        L.ptr(self._high), n, A, L.ptr(acts[t]), L.ptr(ws["clip"]), L.ptr(logp[t]), L.stream())

@@ -242,7 +242,9 @@ class ActorCriticPolicy:
         n = obs_tile.shape[1]
         nm, nv = self._norm_ptrs()
         P, Pt = L.ptr(self._flat), L.ptr(self._flat_t)
-        low, high, noise = L.ptr(self._low), L.ptr(self._high), L.ptr(noise_dev)
+        low, high = L.ptr(self._low), L.ptr(self._high)
+        # `noise_dev`: one [n, A] tile refilled before every step, or [T, n, A] with the whole rollout's draws
+        b_noise, s_noise = noise_dev.data_ptr(), (noise_dev.stride(0) * 4 if noise_dev.dim() == 3 else 0)
         b_obs, s_obs = obs_tile.data_ptr(), obs_tile.stride(0) * 4
         b_act, s_act = acts.data_ptr(), acts.stride(0) * 4
         b_clip, s_clip = clipped.data_ptr(), clipped.stride(0) * 4
@@ -251,7 +253,8 @@ class ActorCriticPolicy:
         stream = L.stream()
 
         def step(t: int) -> None:
-            rc = fn(desc, P, Pt, nm, nv, b_obs + t * s_obs, n, noise, low, high, b_act + t * s_act, b_clip + t * s_clip,
+            rc = fn(desc, P, Pt, nm, nv, b_obs + t * s_obs, n, b_noise + t * s_noise, low, high, b_act + t * s_act,
+                    b_clip + t * s_clip,
                     b_val + t * s_val, b_lp + t * s_lp, stream)
             if rc != 0:
                 L.check(rc, "ia_policy_act")

@@ -16,6 +16,7 @@ from __future__ import annotations
 import collections
 import ctypes as C
 import random
+import os
 import sys
 import threading
 import time
@@ -231,6 +232,7 @@ class RolloutBuffer:
         pin = lambda *s, dtype=th.float32: th.zeros(*s, dtype=dtype).pin_memory()
         self.h_rew = pin(T, n)
         self.h_noise = pin(n, max(act_width, 1))
+        self.h_noise_tile = None   # [T, n, act_width] pinned: a whole rollout's policy noise in one draw (PPO.predraw_noise)
         self.full = False
 
     def ensure_host_sampling_tiles(self, n_actions: int) -> None:
@@ -355,6 +357,7 @@ class PPO(OnPolicyAlgorithm):
         self.after_enqueue = None
         self._post_enqueue_work = []
         self._act_stream = None
+        self.predraw_noise = os.environ.get("IA_PREDRAW_NOISE", "1") != "0"   # see `collect_rollouts`
         self.rollout_window_ms = None
         self.rollout_profile = None
         self._dp_obs = th.zeros(min(self.batch_size, total), p.obs_dim, device=self.device)
@@ -520,16 +523,32 @@ class PPO(OnPolicyAlgorithm):
         act_stream = self._act_stream
         act_stream.wait_stream(stream)     # parameters / statistics written by the previous update
         host_sampling = pol.samples_on_host  # Discrete head on the reference's torch.multinomial stream
+        predrawn = False
         with th.cuda.stream(act_stream):
             if host_sampling:
                 rb.ensure_host_sampling_tiles(pol.act_dim)
                 act_step = pol.make_multinomial_step(rb.h_obs, rb.h_logits, rb.h_clip, rb.val, rb.h_logp)
             else:
-                act_step = pol.make_act_step(rb.h_obs, rb.h_noise, rb.acts, rb.h_clip, rb.val, rb.logp)  # eval mode: no norm update
+                # The rollout's T Gaussian noise tiles in ONE draw at its start, when that is the same stream:
+                # `normal_()` on a contiguous [T, n, A] tensor consumes torch's generator exactly as T draws of
+                # [n, A] do if n * A is a multiple of 16 (its vectorised path fills whole 16-element blocks;
+                # `tests/test_host_logic.py`) and nothing else reads that generator between the steps (no env of
+                # the path does; set `predraw_noise = False` for in-process envs that use torch's global RNG).
+                # The draw lands where the host waits for the previous PPO update anyway; 15 x 13 us per round
+                # leave the step loop.
+                width = rb.h_noise.shape[1]
+                noise_tile = rb.h_noise
+                if self.predraw_noise and not pol.discrete and (n * width) % 16 == 0:
+                    if rb.h_noise_tile is None:
+                        rb.h_noise_tile = th.zeros(T, n, width).pin_memory()
+                    noise_tile = rb.h_noise_tile
+                    pol.draw_noise_into(noise_tile)
+                predrawn = noise_tile.dim() == 3
+                act_step = pol.make_act_step(rb.h_obs, noise_tile, rb.acts, rb.h_clip, rb.val, rb.logp)  # eval mode: no norm update
         h_clip_np = rb.h_clip.numpy()
         for t in range(T):
             t0 = tick() if prof is not None else 0.0
-            if not host_sampling:
+            if not host_sampling and not predrawn:
                 pol.draw_noise_into(rb.h_noise)
             t1 = tick() if prof is not None else 0.0
             act_step(t)

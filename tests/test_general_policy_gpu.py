@@ -160,7 +160,7 @@ def test_general_towers_agree_with_fused_kernels_on_a_shared_shape(discrete):
         np.testing.assert_allclose(y.cpu().numpy(), x.cpu().numpy(), rtol=1e-3, atol=1e-4)
 
 
-def test_general_towers_state_dict_checkpoint_and_bc_guard(tmp_path):
+def test_general_towers_state_dict_checkpoint_and_bc(tmp_path):
     import imitation_amd as ia
     from imitation_amd import bc, spaces
     osp = spaces.Box(-np.ones(5, dtype=np.float32), np.ones(5, dtype=np.float32))
@@ -173,8 +173,9 @@ def test_general_towers_state_dict_checkpoint_and_bc_guard(tmp_path):
     q.load_state_dict(p.state_dict())
     obs = np.random.default_rng(1).standard_normal((9, 5)).astype(np.float32)
     np.testing.assert_array_equal(q.predict(obs, deterministic=True)[0], p.predict(obs, deterministic=True)[0])
-    with pytest.raises(NotImplementedError):
-        bc.BC(observation_space=osp, action_space=asp, rng=np.random.default_rng(0), policy=p)
+    # BC accepts general-tower policies (explicit forward / head-gradient / backward launches; goldens in test_bc.py)
+    trainer = bc.BC(observation_space=osp, action_space=asp, rng=np.random.default_rng(0), policy=p)
+    assert trainer._explicit and not trainer._fused
 
 
 @pytest.mark.parametrize("discrete", [True, False])

@@ -444,3 +444,16 @@ def test_infos_travel_through_buffering_wrapper_and_replay_ring():
     plain.store(dt.Transitions(obs=np.zeros((3, 3), np.float32), acts=np.zeros((3, 1), np.float32),
                                next_obs=np.zeros((3, 3), np.float32), dones=np.zeros(3, bool)))
     assert plain._infos is None and all(i == {} for i in plain.sample(2).infos)
+
+
+@pytest.mark.parametrize("n,A,T", [(1024, 6, 16), (8, 6, 5), (16, 3, 4)])
+def test_one_rollout_noise_draw_equals_per_step_draws(n, A, T):
+    """`PPO.collect_rollouts` draws a rollout's T Gaussian noise tiles in one `normal_()` call when n * A is a multiple
+    of 16: torch's vectorised CPU path consumes the generator block-wise, so the values AND the generator's state
+    afterwards equal T per-step draws (the reference's sequence)."""
+    th.manual_seed(3)
+    seq = th.stack([th.empty(n, A).normal_() for _ in range(T)])
+    post_seq = th.get_rng_state()
+    th.manual_seed(3)
+    one = th.empty(T, n, A).normal_()
+    assert th.equal(seq, one) and th.equal(post_seq, th.get_rng_state())
