@@ -2180,8 +2180,11 @@ constexpr int UPD_NPT = 8;                        // parameters per thread: 8 (<
 constexpr int UPD_NPT_WIDE = 9;                   // observation/action spaces (Ant-shaped: 4209), 9 -- as many as the
                                                   // LDS-resident parameter copies allow next to the minibatch tiles
 constexpr int UPD_RS = 2 * MAXD + 8;              // ring slot: mean[MAXD], var[MAXD], adv mean, adv std
-constexpr int UPD_CTRL = 64;                      // control words: 0 arrivals, 1 steps published, 2 second-level
-                                                  // arrivals, 8 error (sticky), 16.. steps sliced per slicer
+constexpr int UPD_CTRL = 192;                     // control words: 1 steps published, 2 second-level arrivals,
+                                                  // 8 error (sticky), 16..47 steps sliced per slicer,
+                                                  // 64 + 16 i (i < 8): arrival counters of the grid barrier
+constexpr int UPD_ARR = 8;                        // workgroup v arrives on counter v % 8 (one cache line each): 128
+                                                  // workgroups adding to ONE word serialise at its memory channel
 constexpr int UPD_SLICE = 512;                    // rows per statistics slice (minibatches > 1024 rows)
 constexpr int UPD_SLICES_MAX = 32;                // => minibatches up to 16 384 rows
 constexpr int UPD_PRS = 2 * MAXD + 4;             // slice partial: mean[MAXD], M2[MAXD], adv mean, adv M2, rows
@@ -2213,6 +2216,26 @@ __host__ __device__ inline UpdWs upd_ws(float* ws, int nblk, int P) {
   w.partials = w.slabs + 2 * (long long)nblk * w.P4;
   w.pring = w.partials + 2 * (long long)UPD_GROUPS_MAX * w.P4;
   return w;
+}
+
+// Grid-barrier wait on the UPD_ARR arrival counters, called by ALL lanes of one wave: lane i < UPD_ARR polls counter i
+// until it has seen `steps` arrivals of each of its workgroups (those with index % UPD_ARR == i). Bounded like spin_until.
+__device__ __forceinline__ bool spin_arrivals(unsigned* arr, unsigned steps, int nblk, unsigned* err) {
+  const int lane = threadIdx.x & 63;
+  const unsigned mine = lane < UPD_ARR ? (unsigned)((nblk - lane + UPD_ARR - 1) / UPD_ARR) : 0u;
+  const unsigned target = steps * mine;
+  unsigned* p = arr + 16 * (lane < UPD_ARR ? lane : 0);
+  unsigned it = 0;
+  for (;;) {
+    const bool ok = lane >= UPD_ARR || __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target;
+    if (__all(ok)) return true;
+    __builtin_amdgcn_s_sleep(2);
+    if (++it > (1u << 24)) {
+      if (lane == 0) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      return false;
+    }
+    if ((it & 255u) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return false;
+  }
 }
 
 __device__ __forceinline__ bool spin_until(unsigned* p, unsigned target, unsigned* err) {
@@ -2255,7 +2278,7 @@ __global__ __launch_bounds__(512) void ppo_update_persistent_kernel(
   const int D = d.obs_dim;
   const PolOff o = pol_offsets(D, d.act_dim, H, d.discrete);
   const UpdWs w = upd_ws(ws, nblk, o.total);
-  unsigned* arrivals = w.ctrl + 0;
+  unsigned* arrivals = w.ctrl + 64;   // UPD_ARR counters, 16 words apart
   unsigned* published = w.ctrl + 1;
   unsigned* arrivals2 = w.ctrl + 2;   // second-level barrier (group leaders only)
   unsigned* sliced = w.ctrl + 16;     // [n_slices] steps whose partial moments slicer j has written
@@ -2316,9 +2339,12 @@ __global__ __launch_bounds__(512) void ppo_update_persistent_kernel(
 #define SB_TS(k) do { if (tstamp && tid == 0) { const long long tn = wall_clock64(); sb_acc[k] += tn - sb_prev; sb_prev = tn; } } while (0)
     for (int s = 0; s < n_steps; ++s) {
       if (s >= UPD_RING) {  // the slot is free once every gradient block has arrived at barrier s - RING
-        if (tid == 0) {
-          s_ok = spin_until(arrivals, (unsigned)(s - UPD_RING + 1) * nblk, err);
-          __threadfence();
+        if (tid < 64) {
+          const bool ok = spin_arrivals(arrivals, (unsigned)(s - UPD_RING + 1), nblk, err);
+          if (tid == 0) {
+            s_ok = ok;
+            __threadfence();
+          }
         }
         __syncthreads();
         if (!s_ok) return;
@@ -2393,9 +2419,12 @@ __global__ __launch_bounds__(512) void ppo_update_persistent_kernel(
     }
     if (tstamp && tid == 0) { tstamp[12] += sb_acc[0]; tstamp[13] += sb_acc[1]; tstamp[14] += sb_acc[2]; }
 #undef SB_TS
-    if (tid == 0) {
-      s_ok = spin_until(arrivals, (unsigned)n_steps * nblk, err);
-      __threadfence();
+    if (tid < 64) {
+      const bool ok = spin_arrivals(arrivals, (unsigned)n_steps, nblk, err);
+      if (tid == 0) {
+        s_ok = ok;
+        __threadfence();
+      }
     }
     __syncthreads();
     if (!s_ok) return;
@@ -2596,7 +2625,7 @@ __global__ __launch_bounds__(512) void ppo_update_persistent_kernel(
     if (tid == 0) {  // arrive first; the prefetch below overlaps the wait for the other blocks
       __threadfence();
       UPD_TS(7);
-      __hip_atomic_fetch_add(arrivals, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_fetch_add(arrivals + 16 * (vb & (UPD_ARR - 1)), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     UPD_TS(8);
     if (s + 1 < n_steps) {
@@ -2605,12 +2634,15 @@ __global__ __launch_bounds__(512) void ppo_update_persistent_kernel(
       prefetch_issue(s + 1, pz);
     }
     UPD_TS(9);
-    if (tid == 0) {
-      s_ok = spin_until(arrivals, (unsigned)(s + 1) * nblk, err);
-      s_pub = (int)__hip_atomic_load(published, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      UPD_TS(10);
-      __threadfence();
-      UPD_TS(11);
+    if (tid < 64) {
+      const bool ok = spin_arrivals(arrivals, (unsigned)(s + 1), nblk, err);
+      if (tid == 0) {
+        s_ok = ok;
+        s_pub = (int)__hip_atomic_load(published, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        UPD_TS(10);
+        __threadfence();
+        UPD_TS(11);
+      }
     }
     __syncthreads();
     if (!s_ok) return;
@@ -3239,9 +3271,9 @@ int ia_ppo_update(const ia_policy_desc* d, float* params, float* params_t, float
     if (ec != hipSuccess) return (int)ec;
     ec = hipEventRecord(ht.done, st);
     if (ec != hipSuccess) return (int)ec;
-    hipError_t e = hipMemsetAsync(ws, 0, 8 * sizeof(unsigned), st);  // arrivals / published (error word stays)
+    hipError_t e = hipMemsetAsync(ws, 0, 8 * sizeof(unsigned), st);  // published / second-level arrivals (error word stays)
     if (e != hipSuccess) return (int)e;
-    e = hipMemsetAsync(ws + 16, 0, (UPD_CTRL - 16) * sizeof(unsigned), st);  // per-slicer progress
+    e = hipMemsetAsync(ws + 16, 0, (UPD_CTRL - 16) * sizeof(unsigned), st);  // per-slicer progress, arrival counters
     if (e != hipSuccess) return (int)e;
     // packing onto one XCD only works while all workgroups fit its 32 CUs (each takes a whole CU's LDS)
     // minibatches beyond UPD_SLICE rows: their statistics are cut into UPD_SLICE-row slices, one extra block
