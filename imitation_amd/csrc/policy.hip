@@ -1442,6 +1442,12 @@ struct CLds {  // LDS carve-up (floats): activations of both towers plus separat
   static constexpr int total = misc + ROWS * MS + 64;
 };
 
+// Gradient-slab store of the persistent kernel: write-through (system-scope relaxed store = global_store sc0 sc1), so
+// the agent-scope release fence before the grid barrier finds no dirty L2 lines of the slab left to write back.
+__device__ __forceinline__ void slab_store(float* p, float v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 __device__ __forceinline__ void wave_sync_lds() {
   // same-wave LDS hand-off: DS operations of one wave execute in issue order; this only stops the
   // compiler from moving the reads above the writes
@@ -1866,7 +1872,7 @@ __device__ __forceinline__ void mfma32_minibatch_chain(
     }
     s += __shfl_xor(s, 16, 64);
     s += __shfl_xor(s, 32, 64);
-    if (lane < ncols && lane < 16) dst[lane] = s;
+    if (lane < ncols && lane < 16) slab_store(dst + lane, s);
   };
   auto colsum64_wide = [&](const float* __restrict__ tile, int stride, float* __restrict__ dst) {  // 32 columns
     const int c = lane & 31, part = lane >> 5;
@@ -1874,14 +1880,14 @@ __device__ __forceinline__ void mfma32_minibatch_chain(
 #pragma unroll
     for (int r = 0; r < 32; ++r) s += tile[(part * 32 + r) * stride + c];
     s += __shfl_xor(s, 32, 64);
-    if (lane < 32) dst[lane] = s;
+    if (lane < 32) slab_store(dst + lane, s);
   };
   if (tw == 0) {
     if (q < 2) {  // dWa[a][h] = sum_r dout[r][a] a2[r][h], 16 h-columns per wave
       const f32x4 g = outer16(lds + L::dout, L::AS, li, a2t, L::HS, q * 16 + li);
 #pragma unroll
       for (int r = 0; r < 4; ++r)
-        if (lk * 4 + r < A) slab[o.aW + (lk * 4 + r) * H + q * 16 + li] = g[r];
+        if (lk * 4 + r < A) slab_store(slab + (o.aW + (lk * 4 + r) * H + q * 16 + li), g[r]);
     }
     if (q == 2) colsum64(lds + L::dout, L::AS, A, slab + o.ab);
     if (q == 3 && !d.discrete) colsum64(lds + L::aux, L::AS, A, slab + o.log_std);
@@ -1897,7 +1903,7 @@ __device__ __forceinline__ void mfma32_minibatch_chain(
       f32x4 g = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int s = 0; s < 16; ++s) g = mfma16(li == 0 ? u[s] : 0.f, v[s], g);
-      if (lk == 0) slab[o.cW + q * 16 + li] = g[0];
+      if (lk == 0) slab_store(slab + (o.cW + q * 16 + li), g[0]);
     }
     if (q == 2) {  // cb = sum_r dv[r]; statpart slots {0 pg, 2 ent, 3 kl, 4 clip, 1 value} <- misc columns 2..6
       // columns 1..6 of the misc tile summed together: lane c < 6 handles column 1 + c
@@ -1909,7 +1915,7 @@ __device__ __forceinline__ void mfma32_minibatch_chain(
       }
       sm += __shfl_xor(sm, 16, 64);
       sm += __shfl_xor(sm, 32, 64);
-      if (lane == 0) slab[o.cb] = sm;
+      if (lane == 0) slab_store(slab + (o.cb), sm);
       if (lane >= 1 && lane < 6) {
         const int m = lane - 1;                      // misc column 2 + m
         const int slot = m == 0 ? 0 : (m == 4 ? 1 : m + 1);
@@ -1921,7 +1927,7 @@ __device__ __forceinline__ void mfma32_minibatch_chain(
     const int jt = q >> 1, kt = q & 1;
     const f32x4 g = outer16(dz2t, L::HS, jt * 16 + li, a1t, L::HS, kt * 16 + li);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) slab[oW2 + (jt * 16 + lk * 4 + r) * H + kt * 16 + li] = g[r];
+    for (int r = 0; r < 4; ++r) slab_store(slab + (oW2 + (jt * 16 + lk * 4 + r) * H + kt * 16 + li), g[r]);
     if (q == 3) colsum64_wide(dz2t, L::HS, slab + ob2);
   }
   {  // dW1 tiles (dz1^T x), db1
@@ -1932,7 +1938,7 @@ __device__ __forceinline__ void mfma32_minibatch_chain(
       const int col = kt * 16 + li;
       if (col < D)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) slab[oW1 + (jt * 16 + lk * 4 + r) * D + col] = g[r];
+        for (int r = 0; r < 4; ++r) slab_store(slab + (oW1 + (jt * 16 + lk * 4 + r) * D + col), g[r]);
     }
     if (q == 2) colsum64_wide(dz1t, L::HS, slab + ob1);
   }
@@ -2711,7 +2717,7 @@ __global__ __launch_bounds__(512) void ppo_update_persistent_kernel(
 #pragma unroll
         for (int k = 0; k < NPT; ++k) {
           const int i = tid + k * 512;
-          if (i < o.total) part_base[(long long)vb * w.P4 + i] = g[k];
+          if (i < o.total) slab_store(part_base + (long long)vb * w.P4 + i, g[k]);
         }
       }
       __syncthreads();
