@@ -263,12 +263,52 @@ VARIANTS = {
                            dict(reward_hid_sizes=(32,), potential_hid_sizes=(32, 32)), dict(normalize_output=True)),
     "1_cartpole_8x256_mlp64": ("gail", 8, 256, 4, 2, 64, 5, 1024, 4, 2048, dict(hid_sizes=(32, 32)),
                                dict(discrete=True, mlp64=True, gamma=0.95)),
+    # policy towers outside the fused kernels' shapes (any SB3 `net_arch`): the general minibatch loop
+    "towers_1024x16_pi128x64_vf256": ("gail", 1024, 16, 17, 6, 2048, 4, 8192, 4, 16384, dict(hid_sizes=(256, 256)),
+                                      dict(net_arch=dict(pi=[128, 64], vf=[256]))),
+    # GAIL on uint8 image observations: CnnPolicy generator + CnnRewardNet discriminator (run_image_variant)
+    "image_gail_64x16_cnn": None,
 }
+
+
+def run_image_variant(rounds=3, warm=2):
+    """GAIL on image observations end to end: uint8 [4, 84, 84] frames, `PPO("CnnPolicy")` generator
+    (NatureCNN, Categorical head), `modules.CnnRewardNet` discriminator trained through the operator boundary."""
+    import imitation_amd as p
+    from imitation_amd.vec_env import SyntheticImageVecEnv
+    n_envs, n_steps, shape, n_act = 64, 16, (4, 84, 84), 6
+    th.manual_seed(0)
+    np.random.seed(0)
+    venv = SyntheticImageVecEnv(num_envs=n_envs, shape=shape, act_dim=3, horizon=500, seed=0, n_discrete=n_act)
+    algo = p.PPO("CnnPolicy", venv, n_steps=n_steps, batch_size=256, n_epochs=4, ent_coef=0.01, learning_rate=1e-4, seed=0,
+                 device="cuda")
+    net = p.modules.CnnRewardNet(venv.observation_space, venv.action_space, hwc_format=False)
+    rng = np.random.default_rng(1)
+    n = 2048
+    frames = rng.integers(0, 256, (n + 1, *shape)).astype(np.uint8)
+    demos = p.Transitions(obs=frames[:-1], acts=rng.integers(0, n_act, n).astype(np.int64), next_obs=frames[1:],
+                          dones=np.zeros(n, bool))
+    tr = p.GAIL(demonstrations=demos, demo_batch_size=512, venv=venv, gen_algo=algo, reward_net=net,
+                n_disc_updates_per_round=2, custom_logger=p.configure_logger(tempfile.mkdtemp(prefix="bench-var-"), []))
+    per = n_envs * n_steps
+    tr.train(warm * per)
+    th.cuda.synchronize()
+    t0 = time.perf_counter()
+    tr.train(rounds * per)
+    th.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    finite = all(bool(th.isfinite(v.float()).all()) for v in tr.gen_algo.policy.state_dict().values())
+    return {"env_steps_per_s": rounds * per / dt, "ms_per_round": 1e3 * dt / rounds, "rounds": rounds,
+            "env_steps_per_round": per, "finite": finite,
+            "config": "GAIL, 64 envs x 16 steps of uint8 4x84x84 frames, CnnPolicy (NatureCNN) + CnnRewardNet, PPO "
+                      "minibatch 256 x 4 epochs, demo batch 512 x 2 updates"}
 
 
 def run_variant(name, rounds=4, warm=3):
     import imitation_amd as p
     from imitation_amd.vec_env import SyntheticVecEnv
+    if name == "image_gail_64x16_cnn":
+        return run_image_variant()
     algo_name, n_envs, n_steps, od, ad, ppo_batch, n_epochs, demo_batch, n_disc, capacity, net_kw, ex = VARIANTS[name]
     discrete = ex.get("discrete", False)
     th.manual_seed(0)
@@ -277,7 +317,9 @@ def run_variant(name, rounds=4, warm=3):
                            n_discrete=ad if discrete else None)
     pk = dict(features_extractor_class=p.NormalizeFeaturesExtractor,
               features_extractor_kwargs=dict(normalize_class=p.RunningNorm))
-    policy = p.ActorCriticPolicy if ex.get("mlp64") else p.FeedForward32Policy   # SB3 MlpPolicy default = 64 x 64
+    policy = p.ActorCriticPolicy if (ex.get("mlp64") or ex.get("net_arch")) else p.FeedForward32Policy   # SB3 MlpPolicy default = 64 x 64
+    if ex.get("net_arch"):
+        pk = dict(pk, net_arch=ex["net_arch"])
     algo = p.PPO(policy, venv, n_steps=n_steps, batch_size=ppo_batch, n_epochs=n_epochs, ent_coef=0.01,
                  gamma=ex.get("gamma", 0.99), clip_range=ex.get("clip_range", 0.2), seed=0,
                  policy_kwargs={} if ex.get("mlp64") else pk, device="cuda")

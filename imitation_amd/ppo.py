@@ -494,6 +494,15 @@ class PPO(OnPolicyAlgorithm):
             owner = getattr(rw.reward_fn, "__self__", None)
             if isinstance(owner, RewardNet) and getattr(rw.reward_fn, "__name__", "") == "predict_processed":
                 fused_net = owner
+        # an `nn.Module` reward net (operator boundary) whose prediction does not depend on the call sequence (no
+        # NormalizedRewardNet statistics update per call): relabel the whole tile behind the last step, in chunks,
+        # instead of one host round trip per environment step
+        module_net = None
+        if rw is not None and fused_net is None:
+            from imitation_amd import modules as _modules
+            if (isinstance(owner, _modules.RewardNet) and getattr(rw.reward_fn, "__name__", "") == "predict_processed"
+                    and not any(isinstance(m_, _modules.NormalizedRewardNet) for m_ in owner.modules())):
+                module_net = owner
         T, n = rb.buffer_size, rb.n_envs
         assert n_rollout_steps == T
         if hasattr(base, "set_lookahead"):  # host env that can draw its noise one rollout ahead (SyntheticVecEnv)
@@ -582,7 +591,7 @@ class PPO(OnPolicyAlgorithm):
             h_obs_np[t + 1] = new_obs.reshape(n, -1)
             h_next_np[t] = nxt.reshape(n, -1)
             h_dones_np[t], h_trunc_np[t], h_starts_np[t] = dones, trunc, starts
-            if rw is not None and fused_net is None:  # arbitrary host reward function: per-step call
+            if rw is not None and fused_net is None and module_net is None:  # arbitrary host reward function: per-step call
                 r = rw.reward_fn(old_obs, acts_np, nxt, np.array(dones))
                 per_step_rews.append(np.asarray(r, dtype=np.float32))
                 h_rew_np[t] = per_step_rews[-1]
@@ -610,6 +619,14 @@ class PPO(OnPolicyAlgorithm):
             table = TransitionTable(rb.obs[:T].reshape(T * n, -1), acts_tbl, rb.next_fixed.reshape(T * n, -1),
                                     rb.dones.reshape(T * n), pol.discrete)
             rb.rew.copy_(fused_net.predict_processed_rollout(table, T, n).reshape(T, n))
+        elif module_net is not None:
+            osp = self.observation_space
+            S, NS = rb.obs[:T].reshape(T * n, *osp.shape), rb.next_fixed.reshape(T * n, *osp.shape)
+            A_ = rb.clipped.reshape(T * n).long() if pol.discrete else rb.clipped.reshape((T * n, *self.action_space.shape))
+            D_, out = rb.dones.reshape(T * n), rb.rew.view(-1)
+            for lo in range(0, T * n, 256):
+                hi = min(T * n, lo + 256)
+                out[lo:hi] = module_net.predict_th(S[lo:hi], A_[lo:hi], NS[lo:hi], D_[lo:hi])
         else:
             rb.rew.copy_(rb.h_rew, non_blocking=True)
         if rw is not None:
@@ -627,7 +644,8 @@ class PPO(OnPolicyAlgorithm):
 
                 self._post_enqueue_work.append(bookkeeping)
             else:
-                wrapped = rb.rew.cpu().numpy() if fused_net is not None else np.stack(per_step_rews)
+                wrapped = (rb.rew.cpu().numpy() if (fused_net is not None or module_net is not None)
+                           else np.stack(per_step_rews))
                 rw.record_rewards(wrapped, h_dones_np.astype(bool), self._last_obs)
         if h_trunc_np.any():  # rewards[i] += gamma * V(terminal_obs_i) for time-limit endings
             pol.values_rows(rb.next_fixed.reshape(T * n, -1), rb.term_val.reshape(T * n))
