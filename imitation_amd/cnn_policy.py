@@ -91,6 +91,10 @@ class ActorCriticCnnPolicy:
         # standard 4-frame stack; otherwise im2col + GEMM like the other layers. `implicit_conv1 = False` forces the
         # explicit path (tests compare the two).
         self.implicit_conv1: Optional[bool] = None   # resolved on the device (`to`)
+        # layers 2 and 3: the GEMMs read their [rows, KH*KW*Cin] operand as an implicit im2col view of the channel-last
+        # activations (`ia_gemm_f32_im2col`: forward and weight gradient; no column buffer) when Cin % 4 == 0 and
+        # (KW*Cin) % 32 == 0 -- true for NatureCNN (4 x 32 and 3 x 64). False: explicit im2col + GEMM (tests).
+        self.implicit_convs = all(g[0] % 4 == 0 and (g[4] * g[0]) % 32 == 0 for g in self.geom[1:])
         # Host construction in SB3's order so that torch's global generator is consumed identically:
         # the three convolutions, the linear layer, action_net, value_net; then orthogonal re-initialisation
         # (features extractor sqrt(2), action_net 0.01, value_net 1).
@@ -239,6 +243,8 @@ class ActorCriticCnnPolicy:
                 if li == 0 and self.implicit_conv1:   # no column buffer: workspaces of the implicit first layer
                     d["c1_ws"] = f(128 * 64)
                     d["c1_wg"] = f(int(L.load().ia_conv1_u8_wgrad_ws_floats(B)))
+                elif li > 0 and self.implicit_convs:
+                    pass                               # (the GEMMs read the activations through the im2col view)
                 else:
                     d[f"col{li}"] = f(B * oh * ow, cin * k * k)
                 d[f"act{li}"] = f(B * oh * ow, cout)           # channel-last [B, OH, OW, Cout], post-ReLU
@@ -281,9 +287,13 @@ class ActorCriticCnnPolicy:
         for li, (cin, h, w_, cout, k, s, oh, ow) in enumerate(self.geom):
             if li == 0 and self.implicit_conv1:
                 continue
+            K = cin * k * k
+            if li > 0 and self.implicit_convs:
+                L.call("ia_gemm_f32_im2col", 0, L.ptr(d[f"act{li - 1}"]), K, L.ptr(self.w(li)), K, L.ptr(d[f"act{li}"]), cout,
+                       B * oh * ow, cout, K, L.ptr(self.b(li)), 1, 1, None, h, w_, cin, k, k, s, L.stream())
+                continue
             if li > 0:
                 L.call("ia_im2col_f32_nhwc", L.ptr(d[f"act{li - 1}"]), B, h, w_, cin, k, k, s, L.ptr(d[f"col{li}"]), L.stream())
-            K = cin * k * k
             self._gemm(0, d[f"col{li}"], K, self.w(li), K, d[f"act{li}"], cout, B * oh * ow, cout, K, bias=self.b(li), act=1)
         flat = d["act2"].view(B, self.n_flatten)     # (h, w, c) order: linear.0's columns are stored to match
         self._gemm(0, flat, self.n_flatten, self.w(3), self.n_flatten, d["feat"], self.features_dim, B, self.features_dim,
@@ -317,12 +327,20 @@ class ActorCriticCnnPolicy:
                L.ptr(d["dlogits"]) if want_grad else None, L.stream())
         return d["values"], d["logp"], d["ent"]
 
-    def _wgrad(self, li: int, dout: th.Tensor, rows: int, n_out: int, inp: th.Tensor, K: int, grad: th.Tensor) -> None:
-        """grad[w_li] += dout^T . inp ; grad[b_li] += column sums of dout   (split-K TN GEMM + ordered reduction)."""
+    def _wgrad(self, li: int, dout: th.Tensor, rows: int, n_out: int, inp: th.Tensor, K: int, grad: th.Tensor,
+               im=None) -> None:
+        """grad[w_li] += dout^T . inp ; grad[b_li] += column sums of dout   (split-K TN GEMM + ordered reduction).
+        `im = (H, W, Cin, k, stride)`: `inp` is the layer's channel-last INPUT and the [rows, K] operand its implicit
+        im2col view."""
         splits = int(min(64, max(1, rows // 2048)))
         part = th.empty(splits, n_out, K, device=self.device)
         db = th.empty(splits, n_out, device=self.device)
-        self._gemm(2, dout, n_out, inp, K, part, K, n_out, K, rows, splits=splits, dbias=db)
+        if im is not None:
+            h, w_, cin, k, s = im
+            L.call("ia_gemm_f32_im2col", 2, L.ptr(dout), n_out, L.ptr(inp), K, L.ptr(part), K, n_out, K, rows, None, 0,
+                   splits, L.ptr(db), h, w_, cin, k, k, s, L.stream())
+        else:
+            self._gemm(2, dout, n_out, inp, K, part, K, n_out, K, rows, splits=splits, dbias=db)
         ow_, nw, ob_, nb = self._offsets[li]
         L.call("ia_reduce_partials", L.ptr(part), splits, nw, 1.0, 1, L.ptr(grad[ow_:ow_ + nw]), L.stream())
         L.call("ia_reduce_partials", L.ptr(db), splits, nb, 1.0, 1, L.ptr(grad[ob_:ob_ + nb]), L.stream())
@@ -360,7 +378,10 @@ class ActorCriticCnnPolicy:
                 L.call("ia_conv1_u8_wgrad", L.ptr(d["obs_u8"]), B, h, w_, L.ptr(dout), 1.0 / 255.0, L.ptr(d["c1_wg"]), 1,
                        L.ptr(grad[ow_:ow_ + nw]), L.ptr(grad[ob_:ob_ + nb]), L.stream())
                 break
-            self._wgrad(li, dout, rows, cout, d[f"col{li}"], K, grad)
+            if li > 0 and self.implicit_convs:
+                self._wgrad(li, dout, rows, cout, d[f"act{li - 1}"], K, grad, im=(h, w_, cin, k, s))
+            else:
+                self._wgrad(li, dout, rows, cout, d[f"col{li}"], K, grad)
             if li == 0:
                 break
             self._gemm(1, dout, cout, self.w(li), K, d[f"dcol{li}"], K, rows, K, cout)

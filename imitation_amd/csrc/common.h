@@ -25,7 +25,18 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // ---- GEMM (gemm.hip) -------------------------------------------------------------------
 enum { IA_GEMM_NT = 0, IA_GEMM_NN = 1, IA_GEMM_TN = 2 };
 
+// Implicit im2col view of a channel-last activation tensor x[B, H, W, C] (no column buffer): row m = (b, oh, ow),
+// column k = (i, j, c) -> x[b, oh*S + i, ow*S + j, c]. A kernel row (fixed i) is one contiguous run of `seg` = KW*C
+// floats; divisions go through precomputed reciprocals (`m*`: ceil(2^32 / d), exact for the index ranges here).
+struct IaIm {
+  int on;                       // 0: the operand is a plain matrix
+  int OW, OHW, W, C, S, HWC;    // output width, output pixels per image, input width / channels / stride, H*W*C
+  int seg, rstride;             // KW*C, W*C
+  unsigned mOW, mOHW, mseg;
+};
+
 struct IaGemm {
+  IaIm im;              // NT: A is the view; TN: B is (the k-contiguous [rows, K] operand of the convolution)
   const float* A;
   const float* B;
   float* C;

@@ -36,6 +36,17 @@ __device__ __forceinline__ f4 load4_guard(const float* __restrict__ p, int n_val
   return v;
 }
 
+__device__ __forceinline__ int im_div(int n, int d, unsigned magic) { return d == 1 ? n : (int)__umulhi((unsigned)n, magic); }
+__device__ __forceinline__ int im_rowoff(const IaIm& im, int m) {
+  const int b = im_div(m, im.OHW, im.mOHW), p = m - b * im.OHW;
+  const int oh = im_div(p, im.OW, im.mOW), ow = p - oh * im.OW;
+  return b * im.HWC + (oh * im.S * im.W + ow * im.S) * im.C;
+}
+__device__ __forceinline__ int im_kmap(const IaIm& im, int k) {
+  const int i = im_div(k, im.seg, im.mseg);
+  return i * im.rstride + (k - i * im.seg);
+}
+
 // Tile loaders. ROWS = tile extent in the non-reduction index.
 template <int ROWS, int NT, bool KM>
 struct TileIO {
@@ -82,6 +93,50 @@ struct TileIO {
       }
     }
   }
+  // ---- the same two loaders for an operand given as an implicit im2col view (IaIm): element (row, k) of the
+  // [rows_total, K] matrix lives at src + im_rowoff(row) + im_kmap(k); quads of four consecutive k never straddle a
+  // kernel row (seg % 4 == 0). !KM: rows are the tile rows; KM: the reduction index walks the rows of the view.
+  __device__ static void load_im(f4 (&r)[NV], const float* __restrict__ src, const IaIm& im, int row0, int rows_total,
+                                 int k0, int k_end, int tid) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int f = tid + i * NT;
+      f4 v = {0.f, 0.f, 0.f, 0.f};
+      if (!KM) {
+        const int rr = f >> 3, kq = f & 7;
+        const int gr = row0 + rr, gk = k0 + kq * 4;
+        if (gr < rows_total && gk + 4 <= k_end) v = *reinterpret_cast<const f4*>(src + im_rowoff(im, gr) + im_kmap(im, gk));
+      } else {
+        constexpr int QPR = ROWS / 4;
+        const int kr = f / QPR, mq = f % QPR;
+        const int gk = k0 + kr, gm = row0 + mq * 4;
+        if (gk < k_end && gm + 4 <= rows_total) v = *reinterpret_cast<const f4*>(src + im_rowoff(im, gk) + im_kmap(im, gm));
+      }
+      r[i] = v;
+    }
+  }
+  // interior tiles: !KM -> `off[i]` = row offsets of this thread's NV rows (+ its k quad), fixed for the tile;
+  // KM -> `off[0]` = im_kmap of this thread's column quad, the row offsets follow the reduction index
+  __device__ __forceinline__ static void fast_init_im(int (&off)[NV], const IaIm& im, int row0, int tid) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      if (!KM) off[i] = im_rowoff(im, row0 + (tid >> 3) + i * (NT / 8)) + (tid & 7) * 4;
+      else off[i] = im_kmap(im, row0 + (tid % (ROWS / 4)) * 4);
+    }
+  }
+  __device__ __forceinline__ static void load_fast_im(f4 (&r)[NV], const float* __restrict__ src, const IaIm& im,
+                                                      const int (&off)[NV], int k0, int tid) {
+    if (!KM) {
+      const int kb = im_kmap(im, k0);   // block-uniform: a 32-deep chunk lies inside one kernel row (seg % 32 == 0)
+#pragma unroll
+      for (int i = 0; i < NV; ++i) r[i] = *reinterpret_cast<const f4*>(src + off[i] + kb);
+    } else {
+      constexpr int QPR = ROWS / 4;
+#pragma unroll
+      for (int i = 0; i < NV; ++i)
+        r[i] = *reinterpret_cast<const f4*>(src + im_rowoff(im, k0 + tid / QPR + i * (NT / QPR)) + off[0]);
+    }
+  }
   __device__ static void store(const f4 (&r)[NV], float* __restrict__ S, int tid) {
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
@@ -110,7 +165,7 @@ struct TileCtx {
 };
 
 // K loop + epilogue of one output tile. FAST = interior tile (see TileIO::load_fast).
-template <int WM, int WN, int TM, int TN, int MODE, bool FAST>
+template <int WM, int WN, int TM, int TN, int MODE, bool FAST, bool IM>
 __device__ __forceinline__ void gemm_tile(const IaGemm& g, const TileCtx& tc, float* __restrict__ smem) {
   constexpr int NT = WM * WN * 64;
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
@@ -140,16 +195,24 @@ __device__ __forceinline__ void gemm_tile(const IaGemm& g, const TileCtx& tc, fl
   const bool do_db = (MODE == IA_GEMM_TN) && (g.dbias != nullptr) && (bn0 == 0);
   float dbacc = 0.f;
 
+  constexpr bool IM_A = IM && MODE == IA_GEMM_NT, IM_B = IM && MODE == IA_GEMM_TN;
   const float* fa = AIO::fast_base(g.A, g.lda, bm0, tid);
   const float* fb = BIO::fast_base(g.B, g.ldb, bn0, tid);
+  int ima[AIO::NV], imb[BIO::NV];
+  if (FAST && IM_A) AIO::fast_init_im(ima, g.im, bm0, tid);
+  if (FAST && IM_B) BIO::fast_init_im(imb, g.im, bn0, tid);
   auto gload = [&](f4 (&ra)[AIO::NV], f4 (&rb)[BIO::NV], int c) {
     const int k0 = k_begin + c * BK;
     if (FAST) {
-      AIO::load_fast(ra, fa, g.lda, k0);
-      BIO::load_fast(rb, fb, g.ldb, k0);
+      if (IM_A) AIO::load_fast_im(ra, g.A, g.im, ima, k0, tid);
+      else AIO::load_fast(ra, fa, g.lda, k0);
+      if (IM_B) BIO::load_fast_im(rb, g.B, g.im, imb, k0, tid);
+      else BIO::load_fast(rb, fb, g.ldb, k0);
     } else {
-      AIO::load(ra, g.A, g.lda, bm0, g.M, k0, k_end, tc.a_vec, tid);
-      BIO::load(rb, g.B, g.ldb, bn0, g.N, k0, k_end, tc.b_vec, tid);
+      if (IM_A) AIO::load_im(ra, g.A, g.im, bm0, g.M, k0, k_end, tid);
+      else AIO::load(ra, g.A, g.lda, bm0, g.M, k0, k_end, tc.a_vec, tid);
+      if (IM_B) BIO::load_im(rb, g.B, g.im, bn0, g.N, k0, k_end, tid);
+      else BIO::load(rb, g.B, g.ldb, bn0, g.N, k0, k_end, tc.b_vec, tid);
     }
   };
   auto lstore = [&](const f4 (&ra)[AIO::NV], const f4 (&rb)[BIO::NV], int c) {
@@ -269,7 +332,7 @@ __device__ __forceinline__ void gemm_tile(const IaGemm& g, const TileCtx& tc, fl
   if (do_db && tid < BM && bm0 + tid < g.M) g.dbias[(long long)tc.split * g.dbias_split_stride + bm0 + tid] = dbacc;
 }
 
-template <int WM, int WN, int TM, int TN, int MODE>
+template <int WM, int WN, int TM, int TN, int MODE, bool IM = false>
 __global__ __launch_bounds__(WM* WN * 64) void ia_gemm_kernel(IaGemm g) {
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -302,9 +365,9 @@ __global__ __launch_bounds__(WM* WN * 64) void ia_gemm_kernel(IaGemm g) {
   const bool fast = tc.a_vec && tc.b_vec && (tc.bm0 + BM <= g.M) && (tc.bn0 + BN <= g.N) &&
                     (tc.k_end > tc.k_begin) && ((tc.k_end - tc.k_begin) % BK == 0);
   if (fast) {
-    gemm_tile<WM, WN, TM, TN, MODE, true>(g, tc, smem);
+    gemm_tile<WM, WN, TM, TN, MODE, true, IM>(g, tc, smem);
   } else {
-    gemm_tile<WM, WN, TM, TN, MODE, false>(g, tc, smem);
+    gemm_tile<WM, WN, TM, TN, MODE, false, IM>(g, tc, smem);
   }
 }
 
@@ -320,14 +383,14 @@ int g_prof_n = 0;
 bool g_prof_init = false;
 ProfSlot g_prof_acc[PROF_KERNELS];
 
-template <int WM, int WN, int TM, int TN, int MODE>
+template <int WM, int WN, int TM, int TN, int MODE, bool IM = false>
 int launch_cfg(const IaGemm& g, hipStream_t stream) {
   constexpr int NT = WM * WN * 64;
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
   using AIO = TileIO<BM, NT, MODE == IA_GEMM_TN>;
   using BIO = TileIO<BN, NT, MODE != IA_GEMM_NT>;
   constexpr size_t smem = 2 * (AIO::ELEMS + BIO::ELEMS) * sizeof(float);
-  auto kern = ia_gemm_kernel<WM, WN, TM, TN, MODE>;
+  auto kern = ia_gemm_kernel<WM, WN, TM, TN, MODE, IM>;
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -375,6 +438,11 @@ int launch_mode(const IaGemm& g, hipStream_t stream) {
 
 int ia_launch_gemm(int mode, const IaGemm& g, hipStream_t stream) {
   if (g.M <= 0 || g.N <= 0 || g.K < 0) return IA_ERR_ARG;
+  if (g.im.on) {   // convolution forms: 64 x 64 tiles (the shapes of the NatureCNN layers 2 and 3)
+    if (mode == IA_GEMM_NT) return launch_cfg<2, 2, 1, 1, IA_GEMM_NT, true>(g, stream);
+    if (mode == IA_GEMM_TN) return launch_cfg<2, 2, 1, 1, IA_GEMM_TN, true>(g, stream);
+    return IA_ERR_ARG;
+  }
   switch (mode) {
     case IA_GEMM_NT: return launch_mode<IA_GEMM_NT>(g, stream);
     case IA_GEMM_NN: return launch_mode<IA_GEMM_NN>(g, stream);
@@ -424,6 +492,33 @@ extern "C" int ia_gemm_f32(int mode, const float* A, int lda, const float* B, in
   IaGemm g{};
   g.A = A; g.B = B; g.C = C; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
   g.bias = bias; g.act = act; g.P = P; g.ldp = ldp; g.dbias = dbias;
+  g.splits = splits > 0 ? splits : 1;
+  g.k_per_split = ((K + g.splits - 1) / g.splits + BK - 1) / BK * BK;
+  g.c_split_stride = (long long)M * ldc;
+  g.dbias_split_stride = M;
+  return ia_launch_gemm(mode, g, (hipStream_t)stream);
+}
+
+// ia_gemm_f32 with the k-contiguous [rows, KH*KW*Cin] operand of a convolution given IMPLICITLY as the im2col view of
+// the channel-last activation tensor x[Bn, H, W, Cin] (no column buffer is ever written or read):
+//   NT: C[M, N] = act(view(x)[M, K] . Wt[N, K]^T + bias)    M = Bn*OH*OW rows, K = KH*KW*Cin   (convolution forward)
+//   TN: C_s[M, N] = dout[Ks, M]^T . view(x)[Ks, N]           M = Cout, N = KH*KW*Cin, Ks = rows (weight gradient)
+// Requirements: Cin % 4 == 0 and (KW*Cin) % 32 == 0 (a 32-deep K chunk stays inside one kernel row).
+extern "C" int ia_gemm_f32_im2col(int mode, const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M,
+                                  int N, int K, const float* bias, int act, int splits, float* dbias, int H, int W,
+                                  int Cin, int KH, int KW, int S, void* stream) {
+  if (H < KH || W < KW || S <= 0 || Cin % 4 != 0 || (KW * Cin) % 32 != 0) return IA_ERR_ARG;
+  const int OH = (H - KH) / S + 1, OW = (W - KW) / S + 1;
+  auto magic = [](int d) { return d <= 1 ? 0u : (unsigned)((0x100000000ull + (unsigned long long)d - 1) / (unsigned long long)d); };
+  IaGemm g{};
+  g.im.on = 1; g.im.OW = OW; g.im.OHW = OH * OW; g.im.W = W; g.im.C = Cin; g.im.S = S; g.im.HWC = H * W * Cin;
+  g.im.seg = KW * Cin; g.im.rstride = W * Cin;
+  g.im.mOW = magic(OW); g.im.mOHW = magic(OH * OW); g.im.mseg = magic(KW * Cin);
+  const long long rows = mode == IA_GEMM_NT ? M : K;
+  if (rows % g.im.OHW != 0 || (mode == IA_GEMM_NT ? K : N) != KH * KW * Cin) return IA_ERR_ARG;
+  if ((rows / g.im.OHW) * (long long)g.im.HWC >= (1ll << 31)) return IA_ERR_UNSUPPORTED;   // 32-bit element offsets
+  g.A = A; g.B = B; g.C = C; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
+  g.bias = bias; g.act = act; g.dbias = dbias;
   g.splits = splits > 0 ? splits : 1;
   g.k_per_split = ((K + g.splits - 1) / g.splits + BK - 1) / BK * BK;
   g.c_split_stride = (long long)M * ldc;

@@ -323,6 +323,15 @@ int ia_relu_backward(const float* dy, const float* y, int64_t n, float* out, voi
 /* nn.AdaptiveAvgPool2d(1) on channel-last activations y[B, HW, C] -> out[B, C], and its backward (dy = dout / HW). */
 int ia_avgpool_nhwc(const float* y, int B, int HW, int C, float* out, void* stream);
 int ia_avgpool_nhwc_backward(const float* dout, int B, int HW, int C, float* dy, void* stream);
+/* ia_gemm_f32 with the [rows, KH*KW*Cin] operand of a convolution given implicitly as the im2col view of the
+ * channel-last activation tensor x[Bn, H, W, Cin] (`torch.nn.Conv2d` forward / weight gradient without a column
+ * buffer; [SB3 torch_layers.NatureCNN] cnn.2 / cnn.4). mode 0 (NT): A = x, C[M = Bn*OH*OW, N = Cout] =
+ * act(view . B[N, K]^T + bias); mode 2 (TN): A = dout[rows, M = Cout], B = x, C_s[M, N = KH*KW*Cin] per K split
+ * (+ dbias = column sums of dout). Needs Cin % 4 == 0 and (KW*Cin) % 32 == 0. */
+int ia_gemm_f32_im2col(int mode, const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N,
+                       int K, const float* bias, int act, int splits, float* dbias, int H, int W, int Cin, int KH, int KW,
+                       int S, void* stream);
+
 /* ---- NatureCNN's first layer as an implicit GEMM (csrc/conv1_implicit.hip): Conv2d(4, 32, 8, stride 4) on uint8
  * [B, 4, H, W] frames with x * scale folded in ([SB3 torch_layers.NatureCNN] cnn.0 + [SB3 preprocess_obs]); no column
  * buffer. `ia_conv1_u8_implicit_ok`: 1 when the shape is covered (4 channels, 8x8 / 4, 32 filters, W % 4 == 0, image

@@ -537,7 +537,8 @@ def test_cnn_policy_forward_and_gradient_match_torch(shape, B, A):
 
 @pytest.mark.parametrize("shape,B", [((4, 84, 84), 7), ((4, 36, 36), 19), ((4, 44, 60), 4)])
 def test_implicit_first_layer_equals_the_column_buffer_path(shape, B):
-    """`csrc/conv1_implicit.hip` (A operand formed from the uint8 frames in LDS, no column buffer) against the
+    """`csrc/conv1_implicit.hip` (A operand formed from the uint8 frames in LDS) and `ia_gemm_f32_im2col` (layers 2 / 3:
+    the GEMM reads its operand through the im2col view of the activations) -- no column buffers -- against the
     explicit im2col + GEMM path of the same policy: activations of the first layer and the gradient of every parameter
     (the two paths sum the same products in different orders: tolerance 2e-5 of the array's scale)."""
     from imitation_amd import spaces
@@ -550,9 +551,10 @@ def test_implicit_first_layer_equals_the_column_buffer_path(shape, B):
     rng = np.random.default_rng(3)
     obs = rng.integers(0, 256, (B, *shape), dtype=np.uint8)
     acts = rng.integers(0, 5, B)
+    assert pol.implicit_convs, "NatureCNN's layers 2 and 3 are covered by the implicit-im2col GEMMs"
     res = {}
     for implicit in (True, False):
-        pol.implicit_conv1 = implicit
+        pol.implicit_conv1 = pol.implicit_convs = implicit
         pol._bufs = {}
         vals, logp, _ = pol.evaluate_actions(obs, acts, logp_coef=-0.5 / B, ent_coef=-0.02 / B, want_grad=True)
         grad = th.zeros_like(pol._flat)
