@@ -144,6 +144,38 @@ __global__ void col2im_nhwc_kernel(const float* __restrict__ dcol, int C, int H,
   }
 }
 
+// The same for C % 4 == 0 and fewer than 2^31 channel quads: a thread owns FOUR consecutive channels of one input pixel
+// (16-byte loads and stores, a quarter of the memory instructions) and decodes its pixel with 32-bit arithmetic (the
+// element-per-thread form above spends four 64-bit divisions per element).
+__global__ __launch_bounds__(256) void col2im_nhwc_v4_kernel(const float* __restrict__ dcol, int C, int H, int W, int KH,
+                                                             int KW, int S, int OH, int OW, const float* __restrict__ mask,
+                                                             float* __restrict__ dx, int total4) {
+  const int K = C * KH * KW, q = C >> 2;
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total4; e += gridDim.x * blockDim.x) {
+    const int t = e / q, cq = e - t * q;
+    const int t2 = t / W, w = t - t2 * W;
+    const int b = t2 / H, h = t2 - b * H;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    const int oh_hi = min(h / S, OH - 1), oh_lo = max(0, (h - KH + S) / S);
+    const int ow_hi = min(w / S, OW - 1), ow_lo = max(0, (w - KW + S) / S);
+    for (int oh = oh_hi; oh >= oh_lo; --oh) {
+      const int i = h - oh * S;
+      for (int ow = ow_hi; ow >= ow_lo; --ow) {
+        const int j = w - ow * S;
+        s += *reinterpret_cast<const f32x4*>(dcol + ((long long)(b * OH + oh) * OW + ow) * K + (i * KW + j) * C + cq * 4);
+      }
+    }
+    if (mask != nullptr) {
+      const f32x4 m = *reinterpret_cast<const f32x4*>(mask + (long long)e * 4);
+      s.x = m.x > 0.f ? s.x : 0.f;
+      s.y = m.y > 0.f ? s.y : 0.f;
+      s.z = m.z > 0.f ? s.z : 0.f;
+      s.w = m.w > 0.f ? s.w : 0.f;
+    }
+    *reinterpret_cast<f32x4*>(dx + (long long)e * 4) = s;
+  }
+}
+
 // One row per lane. logits [B][ldl]; act = expert action index (fp32). log-softmax z, p = exp(z):
 //   logp = z[act], H = -sum_k p_k z_k  (torch Categorical.log_prob / .entropy),
 //   dlogits_k = c_lp * ([k == act] - p_k) + c_ent * (-p_k (z_k + H))     (= d(c_lp*logp + c_ent*H)/dlogit_k)
@@ -295,6 +327,14 @@ int ia_col2im_nhwc(const float* dcol, int B, int H, int W, int C, int KH, int KW
   if (!dcol || !dx || B <= 0 || C <= 0 || KH <= 0 || KW <= 0 || S <= 0 || H < KH || W < KW) return IA_ERR_ARG;
   const int OH = (H - KH) / S + 1, OW = (W - KW) / S + 1;
   const long long total = (long long)B * H * W * C;
+  const bool aligned = ((reinterpret_cast<uintptr_t>(dcol) | reinterpret_cast<uintptr_t>(dx) |
+                         reinterpret_cast<uintptr_t>(relu_mask)) & 15) == 0;
+  if (C % 4 == 0 && total / 4 < (1ll << 31) && aligned) {
+    hipLaunchKernelGGL(col2im_nhwc_v4_kernel, stream_grid(total / 4), dim3(256), 0, (hipStream_t)stream, dcol, C, H, W, KH,
+                       KW, S, OH, OW, relu_mask, dx, (int)(total / 4));
+    IA_CHECK_LAUNCH();
+    return IA_OK;
+  }
   hipLaunchKernelGGL(col2im_nhwc_kernel, stream_grid(total), dim3(256), 0, (hipStream_t)stream, dcol, C, H, W, KH, KW,
                      S, OH, OW, relu_mask, dx, total);
   IA_CHECK_LAUNCH();
