@@ -903,7 +903,7 @@ struct MbRows {
 // LDS staging area of the persistent kernel: the block's raw feature rows and per-row scalars of the
 // NEXT minibatch (prefetched), plus a copy of its statistics-ring slot.
 struct UpdStage {
-  static constexpr int x = 0;                                   // [ROWS][XS] raw observations (0 where unused)
+  static constexpr int x = 0;                                   // [ROWS][D] raw observations, rows packed (room for D = MAXD + 1)
   static constexpr int oldlp = ROWS * (MAXD + 1);               // [ROWS]
   static constexpr int adv = oldlp + ROWS, ret = adv + ROWS;    // [ROWS] each
   static constexpr int src = ret + ROWS;                        // [ROWS] row offset into the rollout tile (as float bits)
@@ -1517,7 +1517,7 @@ __device__ __forceinline__ void mfma32_minibatch_chain(
       float raw[4], mu[4], vr[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        raw[j] = stg[UpdStage::x + (rbase + r) * L::XS + k0 + j];
+        raw[j] = stg[UpdStage::x + (rbase + r) * D + k0 + j];   // (packed rows; columns >= D are masked below)
         mu[j] = nm[k0 + j];          // slot arrays hold MAXD entries each
         vr[j] = nv[k0 + j];
       }
@@ -2535,13 +2535,16 @@ __global__ __launch_bounds__(512) void ppo_update_persistent_kernel(
     const int* nxt = reinterpret_cast<const int*>(stg) + UpdStage::nxt;
     int src0 = 0;
     if (wave == 0) src0 = nxt[lane];
+    // observations: staged PACKED, element e = row * D + column (only the D columns that exist: at D = 17 three
+    // 512-element passes instead of the nine a 65-wide row stride took); row = e / D by reciprocal multiplication
     int srcs[NIT], cols[NIT];
+    const unsigned rcpD = (unsigned)((0x100000000ull + (unsigned)D - 1) / (unsigned)D);   // wave-uniform
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
       const int e0 = it * 512 + wave * 64 + zero;  // wave-uniform
-      const int e = min(e0 + lane, ROWS * L::XS - 1);
-      const int rr = e / L::XS;
-      cols[it] = min(e - rr * L::XS, D - 1);
+      const int e = min(e0 + lane, ROWS * D - 1);
+      const int rr = D == 1 ? e : (int)__umulhi((unsigned)e, rcpD);
+      cols[it] = e - rr * D;
       srcs[it] = nxt[rr];
     }
     // actions: element e = row * aw + column of the block's [ROWS][aw] tile, 512 elements per pass
@@ -2571,7 +2574,7 @@ __global__ __launch_bounds__(512) void ppo_update_persistent_kernel(
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
       const int e0 = it * 512 + wave * 64;  // wave-uniform
-      if (e0 < ROWS * L::XS)
+      if (e0 < ROWS * D)
         __builtin_amdgcn_global_load_lds((glb_void_p)(r.obs + (long long)srcs[it] * D + cols[it]),
                                          (lds_void_p)(stg + UpdStage::x + e0), 4, 0, 0);
     }
