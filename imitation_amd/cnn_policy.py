@@ -95,6 +95,11 @@ class ActorCriticCnnPolicy:
         # activations (`ia_gemm_f32_im2col`: forward and weight gradient; no column buffer) when Cin % 4 == 0 and
         # (KW*Cin) % 32 == 0 -- true for NatureCNN (4 x 32 and 3 x 64). False: explicit im2col + GEMM (tests).
         self.implicit_convs = all(g[0] % 4 == 0 and (g[4] * g[0]) % 32 == 0 for g in self.geom[1:])
+        # input gradients of layers 2 / 3 as implicit transposed convolutions (`_dgrad_implicit`: no `dcol` buffers,
+        # 1.1 GB less at batch 4096) -- measured 0.2 ms per step SLOWER than the NN GEMM + col2im pair at that batch (the
+        # stride-2 layer splits into four 32-column GEMMs), so it is opt-in for memory-bound batch sizes
+        self.implicit_dgrad = False
+        self._dgrad_idx: Dict[int, th.Tensor] = {}
         # Host construction in SB3's order so that torch's global generator is consumed identically:
         # the three convolutions, the linear layer, action_net, value_net; then orthogonal re-initialisation
         # (features extractor sqrt(2), action_net 0.01, value_net 1).
@@ -253,8 +258,7 @@ class ActorCriticCnnPolicy:
             d["dlogits"], d["dfeat"], d["dflat"] = f(B, self.n_actions), f(B, self.features_dim), f(B, self.n_flatten)
             for li in (1, 2):  # input gradients of conv 2 and 3 (conv 1's input is the image)
                 cin, h, w_, _, k, _, oh, ow = self.geom[li]
-                d[f"dcol{li}"] = f(B * oh * ow, cin * k * k)
-                d[f"dact{li - 1}"] = f(B * h * w_, cin)
+                d[f"dact{li - 1}"] = f(B * h * w_, cin)      # (`dcol{li}` only exists on the explicit path: `_dcol`)
             d["dvalues"], d["dhead"] = f(B, 1), f(2, B, self.features_dim)
             if len(self._bufs) >= 3:   # rollout step, bootstrap chunk, minibatch: more sizes evict the oldest
                 self._bufs.pop(next(iter(self._bufs)))
@@ -345,6 +349,41 @@ class ActorCriticCnnPolicy:
         L.call("ia_reduce_partials", L.ptr(part), splits, nw, 1.0, 1, L.ptr(grad[ow_:ow_ + nw]), L.stream())
         L.call("ia_reduce_partials", L.ptr(db), splits, nb, 1.0, 1, L.ptr(grad[ob_:ob_ + nb]), L.stream())
 
+    def _dcol(self, d, li: int, rows: int, K: int) -> th.Tensor:
+        """Column-gradient buffer of the explicit input-gradient path (allocated on first use)."""
+        if f"dcol{li}" not in d:
+            d[f"dcol{li}"] = th.empty(rows, K, device=self.device)
+        return d[f"dcol{li}"]
+
+    def _dgrad_implicit(self, li: int, dout: th.Tensor, B: int, d) -> None:
+        """d loss / d input of convolution `li` (then the ReLU mask of the layer below) as implicit GEMMs over `dout`
+        [B, OH, OW, Cout]: dX[y, x, c] = sum_{i,j,co} dout[(y-i)/S, (x-j)/S, co] W[co, i, j, c] over the taps with
+        S | y-i, S | x-j. For the input pixels of one sub-pixel class (py, px) = (y % S, x % S) that is a stride-1
+        convolution of `dout`, zero-padded by k/S - 1, with the k/S x k/S kernel Wd[c, ti, tj, co] =
+        W[co, py + S (k/S-1-ti), px + S (k/S-1-tj), c]; `ia_gemm_f32_im2col_pad` reads its operand through that padded
+        view and scatters the class's rows into the input grid. No `dcol` buffer, no col2im."""
+        cin, h, w_, cout, k, s, oh, ow = self.geom[li]
+        kt = k // s
+        dact = d[f"dact{li - 1}"]
+        Kd = kt * kt * cout
+        if li not in self._dgrad_idx:   # gather index of all classes' rearranged weights (geometry only): one launch per step
+            base = th.arange(cout * k * k * cin).view(cout, k, k, cin)        # device layout [Cout, KH, KW, Cin]
+            blocks = []
+            for py in range(s):
+                for px in range(s):
+                    ii = th.as_tensor([py + s * (kt - 1 - t) for t in range(kt)])
+                    jj = th.as_tensor([px + s * (kt - 1 - t) for t in range(kt)])
+                    blocks.append(base.index_select(1, ii).index_select(2, jj).permute(3, 1, 2, 0).reshape(-1))
+            self._dgrad_idx[li] = th.cat(blocks).to(self.device)
+        Wd_all = self.w(li).index_select(0, self._dgrad_idx[li]).view(s * s, cin, Kd)
+        for py in range(s):
+            for px in range(s):
+                Wd = Wd_all[py * s + px]
+                gh, gw = oh + kt - 1, ow + kt - 1                 # input pixels of this class per image
+                cmap = (C.c_int * 5)(s, py, px, h, w_) if s > 1 else None
+                L.call("ia_gemm_f32_im2col_pad", 0, L.ptr(dout), Kd, L.ptr(Wd), Kd, L.ptr(dact), cin, B * gh * gw, cin, Kd,
+                       None, 0, 1, None, oh, ow, cout, kt, kt, 1, kt - 1, cmap, L.ptr(d[f"act{li - 1}"]), L.stream())
+
     def backward(self, B: int, grad: th.Tensor, with_values: bool = False) -> None:
         """Adds to `grad` (flat, device layout) the parameter gradient of the loss whose head gradients were left in
         the batch-`B` buffers: `dlogits` (by `evaluate_actions(..., want_grad=True)` or the PPO head loss) and, with
@@ -384,9 +423,12 @@ class ActorCriticCnnPolicy:
                 self._wgrad(li, dout, rows, cout, d[f"col{li}"], K, grad)
             if li == 0:
                 break
-            self._gemm(1, dout, cout, self.w(li), K, d[f"dcol{li}"], K, rows, K, cout)
-            L.call("ia_col2im_nhwc", L.ptr(d[f"dcol{li}"]), B, h, w_, cin, k, k, s, L.ptr(d[f"act{li - 1}"]),
-                   L.ptr(d[f"dact{li - 1}"]), L.stream())
+            if self.implicit_dgrad and k % s == 0 and ((k // s) * cout) % 32 == 0 and cout % 4 == 0:
+                self._dgrad_implicit(li, dout, B, d)
+            else:
+                self._gemm(1, dout, cout, self.w(li), K, self._dcol(d, li, rows, K), K, rows, K, cout)
+                L.call("ia_col2im_nhwc", L.ptr(d[f"dcol{li}"]), B, h, w_, cin, k, k, s, L.ptr(d[f"act{li - 1}"]),
+                       L.ptr(d[f"dact{li - 1}"]), L.stream())
             dout = d[f"dact{li - 1}"]
 
     # ---- PPO generator protocol (the surface `ppo.PPO` and the adversarial trainer drive; same as

@@ -33,6 +33,12 @@ struct IaIm {
   int OW, OHW, W, C, S, HWC;    // output width, output pixels per image, input width / channels / stride, H*W*C
   int seg, rstride;             // KW*C, W*C
   unsigned mOW, mOHW, mseg;
+  int pad, H;                   // zero padding on every side (taps outside the image read as 0), input height
+  unsigned mC;                  // ceil(2^32 / C)
+  // optional scatter of the OUTPUT rows (NT): row m = (b, y', x') of a cm_OW-wide grid with cm_OHW cells per image
+  // goes to row b*cm_HW + (y'*cm_S + cm_py)*cm_W + x'*cm_S + cm_px of C (transposed convolution by sub-pixel classes)
+  int cm_on, cm_OW, cm_OHW, cm_S, cm_py, cm_px, cm_W, cm_HW;
+  unsigned cm_mOW, cm_mOHW;
 };
 
 struct IaGemm {

@@ -47,6 +47,31 @@ __device__ __forceinline__ int im_kmap(const IaIm& im, int k) {
   return i * im.rstride + (k - i * im.seg);
 }
 
+// Padded view: element offset of (row m, column k) with the tap clamped into the image, and whether it is inside
+__device__ __forceinline__ int im_addr_pad(const IaIm& im, int m, int k, bool& valid) {
+  const int b = im_div(m, im.OHW, im.mOHW), p = m - b * im.OHW;
+  const int oh = im_div(p, im.OW, im.mOW), ow = p - oh * im.OW;
+  const int i = im_div(k, im.seg, im.mseg), r = k - i * im.seg;
+  const int j = im_div(r, im.C, im.mC), c = r - j * im.C;
+  const int y = oh * im.S - im.pad + i, x = ow * im.S - im.pad + j;
+  valid = (unsigned)y < (unsigned)im.H && (unsigned)x < (unsigned)im.W;
+  const int yc = min(max(y, 0), im.H - 1), xc = min(max(x, 0), im.W - 1);
+  return b * im.HWC + (yc * im.W + xc) * im.C + c;
+}
+__device__ __forceinline__ f4 im_load_pad(const float* __restrict__ src, const IaIm& im, int m, int k) {
+  bool valid;
+  const int off = im_addr_pad(im, m, k, valid);
+  const f4 v = *reinterpret_cast<const f4*>(src + off);   // (unconditional, clamped address; masked below)
+  const f4 z = {0.f, 0.f, 0.f, 0.f};
+  return valid ? v : z;
+}
+__device__ __forceinline__ long long im_crow(const IaIm& im, int m) {
+  if (!im.cm_on) return m;
+  const int b = im_div(m, im.cm_OHW, im.cm_mOHW), p = m - b * im.cm_OHW;
+  const int yy = im_div(p, im.cm_OW, im.cm_mOW), xx = p - yy * im.cm_OW;
+  return (long long)b * im.cm_HW + (yy * im.cm_S + im.cm_py) * im.cm_W + xx * im.cm_S + im.cm_px;
+}
+
 // Tile loaders. ROWS = tile extent in the non-reduction index.
 template <int ROWS, int NT, bool KM>
 struct TileIO {
@@ -105,12 +130,14 @@ struct TileIO {
       if (!KM) {
         const int rr = f >> 3, kq = f & 7;
         const int gr = row0 + rr, gk = k0 + kq * 4;
-        if (gr < rows_total && gk + 4 <= k_end) v = *reinterpret_cast<const f4*>(src + im_rowoff(im, gr) + im_kmap(im, gk));
+        if (gr < rows_total && gk + 4 <= k_end)
+          v = im.pad ? im_load_pad(src, im, gr, gk) : *reinterpret_cast<const f4*>(src + im_rowoff(im, gr) + im_kmap(im, gk));
       } else {
         constexpr int QPR = ROWS / 4;
         const int kr = f / QPR, mq = f % QPR;
         const int gk = k0 + kr, gm = row0 + mq * 4;
-        if (gk < k_end && gm + 4 <= rows_total) v = *reinterpret_cast<const f4*>(src + im_rowoff(im, gk) + im_kmap(im, gm));
+        if (gk < k_end && gm + 4 <= rows_total)
+          v = im.pad ? im_load_pad(src, im, gk, gm) : *reinterpret_cast<const f4*>(src + im_rowoff(im, gk) + im_kmap(im, gm));
       }
       r[i] = v;
     }
@@ -135,6 +162,48 @@ struct TileIO {
 #pragma unroll
       for (int i = 0; i < NV; ++i)
         r[i] = *reinterpret_cast<const f4*>(src + im_rowoff(im, k0 + tid / QPR + i * (NT / QPR)) + off[0]);
+    }
+  }
+  // interior tiles of a PADDED view. !KM: the NV rows of a thread are fixed for the tile -- their image base and
+  // top-left tap (y0, x0) are decoded once (`fast_init_pad`), a load then needs the chunk's kernel row (uniform) and
+  // the thread's tap column. KM: every load decodes its row. Loads are unconditional at clamped addresses, then masked.
+  struct PadRow { int base, y0, x0; };
+  __device__ __forceinline__ static void fast_init_pad(PadRow (&pr)[NV], const IaIm& im, int row0, int tid) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int m = row0 + (tid >> 3) + i * (NT / 8);
+      const int b = im_div(m, im.OHW, im.mOHW), p = m - b * im.OHW;
+      const int oh = im_div(p, im.OW, im.mOW), ow = p - oh * im.OW;
+      pr[i].base = b * im.HWC;
+      pr[i].y0 = oh * im.S - im.pad;
+      pr[i].x0 = ow * im.S - im.pad;
+    }
+  }
+  __device__ __forceinline__ static void load_fast_im_pad_rows(f4 (&r)[NV], const float* __restrict__ src, const IaIm& im,
+                                                               const PadRow (&pr)[NV], int k0, int tid) {
+    const int ki = im_div(k0, im.seg, im.mseg);            // kernel row of this chunk (block-uniform)
+    const int rr = k0 - ki * im.seg + (tid & 7) * 4;       // position inside the kernel row: tap column * C + channel
+    const int j = im_div(rr, im.C, im.mC), c = rr - j * im.C;
+    const f4 z = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int y = pr[i].y0 + ki, x = pr[i].x0 + j;
+      const bool valid = (unsigned)y < (unsigned)im.H && (unsigned)x < (unsigned)im.W;
+      const int yc = min(max(y, 0), im.H - 1), xc = min(max(x, 0), im.W - 1);
+      const f4 v = *reinterpret_cast<const f4*>(src + pr[i].base + (yc * im.W + xc) * im.C + c);
+      r[i] = valid ? v : z;
+    }
+  }
+  __device__ __forceinline__ static void load_fast_im_pad(f4 (&r)[NV], const float* __restrict__ src, const IaIm& im,
+                                                          int row0, int k0, int tid) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      if (!KM) {
+        r[i] = im_load_pad(src, im, row0 + (tid >> 3) + i * (NT / 8), k0 + (tid & 7) * 4);
+      } else {
+        constexpr int QPR = ROWS / 4;
+        r[i] = im_load_pad(src, im, k0 + tid / QPR + i * (NT / QPR), row0 + (tid % QPR) * 4);
+      }
     }
   }
   __device__ static void store(const f4 (&r)[NV], float* __restrict__ S, int tid) {
@@ -199,15 +268,27 @@ __device__ __forceinline__ void gemm_tile(const IaGemm& g, const TileCtx& tc, fl
   const float* fa = AIO::fast_base(g.A, g.lda, bm0, tid);
   const float* fb = BIO::fast_base(g.B, g.ldb, bn0, tid);
   int ima[AIO::NV], imb[BIO::NV];
-  if (FAST && IM_A) AIO::fast_init_im(ima, g.im, bm0, tid);
+  typename AIO::PadRow pra[AIO::NV];
+  if (FAST && IM_A) {
+    if (g.im.pad) AIO::fast_init_pad(pra, g.im, bm0, tid);
+    else AIO::fast_init_im(ima, g.im, bm0, tid);
+  }
   if (FAST && IM_B) BIO::fast_init_im(imb, g.im, bn0, tid);
   auto gload = [&](f4 (&ra)[AIO::NV], f4 (&rb)[BIO::NV], int c) {
     const int k0 = k_begin + c * BK;
     if (FAST) {
-      if (IM_A) AIO::load_fast_im(ra, g.A, g.im, ima, k0, tid);
-      else AIO::load_fast(ra, fa, g.lda, k0);
-      if (IM_B) BIO::load_fast_im(rb, g.B, g.im, imb, k0, tid);
-      else BIO::load_fast(rb, fb, g.ldb, k0);
+      if (IM_A) {
+        if (g.im.pad) AIO::load_fast_im_pad_rows(ra, g.A, g.im, pra, k0, tid);
+        else AIO::load_fast_im(ra, g.A, g.im, ima, k0, tid);
+      } else {
+        AIO::load_fast(ra, fa, g.lda, k0);
+      }
+      if (IM_B) {
+        if (g.im.pad) BIO::load_fast_im_pad(rb, g.B, g.im, bn0, k0, tid);
+        else BIO::load_fast_im(rb, g.B, g.im, imb, k0, tid);
+      } else {
+        BIO::load_fast(rb, fb, g.ldb, k0);
+      }
     } else {
       if (IM_A) AIO::load_im(ra, g.A, g.im, bm0, g.M, k0, k_end, tid);
       else AIO::load(ra, g.A, g.lda, bm0, g.M, k0, k_end, tc.a_vec, tid);
@@ -324,7 +405,13 @@ __device__ __forceinline__ void gemm_tile(const IaGemm& g, const TileCtx& tc, fl
             if (g.P != nullptr)
               v *= ia_act_grad_from_post(PREP ? pv[PREP ? i : 0][PREP ? j : 0][r] : g.P[(long long)row * g.ldp + col], g.act);
           }
-          C[(long long)row * g.ldc + col] = v;
+          if (IM) {   // implicit-view forms: optional output-row scatter and ReLU mask of the tensor being written to
+            const long long crow = im_crow(g.im, row);
+            if (MODE == IA_GEMM_NT && g.P != nullptr && !(g.P[crow * g.ldp + col] > 0.f)) v = 0.f;
+            C[crow * g.ldc + col] = v;
+          } else {
+            C[(long long)row * g.ldc + col] = v;
+          }
         }
       }
     }
@@ -439,6 +526,7 @@ int launch_mode(const IaGemm& g, hipStream_t stream) {
 int ia_launch_gemm(int mode, const IaGemm& g, hipStream_t stream) {
   if (g.M <= 0 || g.N <= 0 || g.K < 0) return IA_ERR_ARG;
   if (g.im.on) {   // convolution forms: 64 x 64 tiles (the shapes of the NatureCNN layers 2 and 3)
+    if (mode == IA_GEMM_NT && g.N <= 32) return launch_cfg<4, 1, 1, 1, IA_GEMM_NT, true>(g, stream);   // 128 x 32
     if (mode == IA_GEMM_NT) return launch_cfg<2, 2, 1, 1, IA_GEMM_NT, true>(g, stream);
     if (mode == IA_GEMM_TN) return launch_cfg<2, 2, 1, 1, IA_GEMM_TN, true>(g, stream);
     return IA_ERR_ARG;
@@ -504,24 +592,58 @@ extern "C" int ia_gemm_f32(int mode, const float* A, int lda, const float* B, in
 //   NT: C[M, N] = act(view(x)[M, K] . Wt[N, K]^T + bias)    M = Bn*OH*OW rows, K = KH*KW*Cin   (convolution forward)
 //   TN: C_s[M, N] = dout[Ks, M]^T . view(x)[Ks, N]           M = Cout, N = KH*KW*Cin, Ks = rows (weight gradient)
 // Requirements: Cin % 4 == 0 and (KW*Cin) % 32 == 0 (a 32-deep K chunk stays inside one kernel row).
+namespace {
+int gemm_im2col(int mode, const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N, int K,
+                const float* bias, int act, int splits, float* dbias, int H, int W, int Cin, int KH, int KW, int S, int P,
+                const int* cmap, const float* relu_mask, void* stream);
+}
 extern "C" int ia_gemm_f32_im2col(int mode, const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M,
                                   int N, int K, const float* bias, int act, int splits, float* dbias, int H, int W,
                                   int Cin, int KH, int KW, int S, void* stream) {
-  if (H < KH || W < KW || S <= 0 || Cin % 4 != 0 || (KW * Cin) % 32 != 0) return IA_ERR_ARG;
-  const int OH = (H - KH) / S + 1, OW = (W - KW) / S + 1;
+  return gemm_im2col(mode, A, lda, B, ldb, C, ldc, M, N, K, bias, act, splits, dbias, H, W, Cin, KH, KW, S, 0, nullptr, nullptr,
+                     stream);
+}
+// The same with zero padding P on every side of the image (taps outside read as 0) and, for mode NT, an optional scatter
+// of the output rows: cmap = {S_out, py, px, H_out, W_out} sends row (b, y', x') of the [OH, OW] output grid to row
+// (b, y'*S_out + py, x'*S_out + px) of a [H_out, W_out] grid in C -- the input gradient of a strided convolution is one
+// such padded stride-1 convolution over dout per sub-pixel class (py, px). cmap = NULL: rows in place.
+// relu_mask (mode NT, nullable): a tensor laid out like C; outputs are zeroed where it is <= 0 (the ReLU of the layer below).
+extern "C" int ia_gemm_f32_im2col_pad(int mode, const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M,
+                                      int N, int K, const float* bias, int act, int splits, float* dbias, int H, int W,
+                                      int Cin, int KH, int KW, int S, int P, const int* cmap, const float* relu_mask,
+                                      void* stream) {
+  if (P < 0) return IA_ERR_ARG;
+  return gemm_im2col(mode, A, lda, B, ldb, C, ldc, M, N, K, bias, act, splits, dbias, H, W, Cin, KH, KW, S, P, cmap, relu_mask,
+                     stream);
+}
+namespace {
+int gemm_im2col(int mode, const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N, int K,
+                const float* bias, int act, int splits, float* dbias, int H, int W, int Cin, int KH, int KW, int S, int P,
+                const int* cmap, const float* relu_mask, void* stream) {
+  if (H + 2 * P < KH || W + 2 * P < KW || S <= 0 || Cin % 4 != 0 || (KW * Cin) % 32 != 0) return IA_ERR_ARG;
+  const int OH = (H + 2 * P - KH) / S + 1, OW = (W + 2 * P - KW) / S + 1;
   auto magic = [](int d) { return d <= 1 ? 0u : (unsigned)((0x100000000ull + (unsigned long long)d - 1) / (unsigned long long)d); };
   IaGemm g{};
   g.im.on = 1; g.im.OW = OW; g.im.OHW = OH * OW; g.im.W = W; g.im.C = Cin; g.im.S = S; g.im.HWC = H * W * Cin;
   g.im.seg = KW * Cin; g.im.rstride = W * Cin;
   g.im.mOW = magic(OW); g.im.mOHW = magic(OH * OW); g.im.mseg = magic(KW * Cin);
+  g.im.pad = P; g.im.H = H; g.im.mC = magic(Cin);
+  if (cmap != nullptr) {
+    if (mode != IA_GEMM_NT || cmap[0] <= 0) return IA_ERR_ARG;
+    g.im.cm_on = 1; g.im.cm_OW = OW; g.im.cm_OHW = OH * OW; g.im.cm_S = cmap[0]; g.im.cm_py = cmap[1]; g.im.cm_px = cmap[2];
+    g.im.cm_W = cmap[4]; g.im.cm_HW = cmap[3] * cmap[4];
+    g.im.cm_mOW = g.im.mOW; g.im.cm_mOHW = g.im.mOHW;
+  }
   const long long rows = mode == IA_GEMM_NT ? M : K;
   if (rows % g.im.OHW != 0 || (mode == IA_GEMM_NT ? K : N) != KH * KW * Cin) return IA_ERR_ARG;
   if ((rows / g.im.OHW) * (long long)g.im.HWC >= (1ll << 31)) return IA_ERR_UNSUPPORTED;   // 32-bit element offsets
   g.A = A; g.B = B; g.C = C; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
   g.bias = bias; g.act = act; g.dbias = dbias;
+  g.P = relu_mask; g.ldp = ldc;
   g.splits = splits > 0 ? splits : 1;
   g.k_per_split = ((K + g.splits - 1) / g.splits + BK - 1) / BK * BK;
   g.c_split_stride = (long long)M * ldc;
   g.dbias_split_stride = M;
   return ia_launch_gemm(mode, g, (hipStream_t)stream);
 }
+}  // namespace

@@ -332,6 +332,17 @@ int ia_gemm_f32_im2col(int mode, const float* A, int lda, const float* B, int ld
                        int K, const float* bias, int act, int splits, float* dbias, int H, int W, int Cin, int KH, int KW,
                        int S, void* stream);
 
+/* The same view with zero padding P on every side (taps outside the image read as 0) and, for mode 0, an optional
+ * scatter of the output rows: cmap = {S_out, py, px, H_out, W_out} (HOST pointer to 5 ints) writes row (b, y', x') of
+ * the [OH, OW] output grid to row (b, y'*S_out + py, x'*S_out + px) of a [H_out, W_out] grid in C. With these the
+ * INPUT gradient of a convolution is again an implicit GEMM over dout (`torch.nn.Conv2d` backward w.r.t. its input):
+ * one padded stride-1 convolution with the flipped / transposed weights per sub-pixel class (py, px) of the stride --
+ * no `dcol` buffer, no col2im; `relu_mask` (nullable, laid out like C) zeroes the outputs where the layer below's ReLU
+ * output is <= 0. Also serves padded ("same") convolutions (`util/networks.py:286-357` build_cnn). */
+int ia_gemm_f32_im2col_pad(int mode, const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N,
+                           int K, const float* bias, int act, int splits, float* dbias, int H, int W, int Cin, int KH,
+                           int KW, int S, int P, const int* cmap, const float* relu_mask, void* stream);
+
 /* ---- NatureCNN's first layer as an implicit GEMM (csrc/conv1_implicit.hip): Conv2d(4, 32, 8, stride 4) on uint8
  * [B, 4, H, W] frames with x * scale folded in ([SB3 torch_layers.NatureCNN] cnn.0 + [SB3 preprocess_obs]); no column
  * buffer. `ia_conv1_u8_implicit_ok`: 1 when the shape is covered (4 channels, 8x8 / 4, 32 filters, W % 4 == 0, image

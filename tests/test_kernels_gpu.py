@@ -553,13 +553,16 @@ def test_implicit_first_layer_equals_the_column_buffer_path(shape, B):
     acts = rng.integers(0, 5, B)
     assert pol.implicit_convs, "NatureCNN's layers 2 and 3 are covered by the implicit-im2col GEMMs"
     res = {}
-    for implicit in (True, False):
-        pol.implicit_conv1 = pol.implicit_convs = implicit
+    for mode in ("implicit", "implicit+dgrad", "explicit"):   # (+dgrad: input gradients as implicit transposed convolutions)
+        pol.implicit_conv1 = pol.implicit_convs = mode != "explicit"
+        pol.implicit_dgrad = mode == "implicit+dgrad"
         pol._bufs = {}
         vals, logp, _ = pol.evaluate_actions(obs, acts, logp_coef=-0.5 / B, ent_coef=-0.02 / B, want_grad=True)
         grad = th.zeros_like(pol._flat)
         pol.backward(B, grad)
-        res[implicit] = (pol._bufs[B]["act0"].clone(), vals.clone(), logp.clone(), grad)
-    for x, y in zip(res[True], res[False]):
-        scale = float(y.abs().max()) + 1e-12
-        assert float((x - y).abs().max()) <= 2e-5 * scale + 1e-8, (float((x - y).abs().max()), scale)
+        assert ("dcol1" in pol._bufs[B]) == (mode != "implicit+dgrad")
+        res[mode] = (pol._bufs[B]["act0"].clone(), vals.clone(), logp.clone(), grad)
+    for mode in ("implicit", "implicit+dgrad"):
+        for x, y in zip(res[mode], res["explicit"]):
+            scale = float(y.abs().max()) + 1e-12
+            assert float((x - y).abs().max()) <= 2e-5 * scale + 1e-8, (mode, float((x - y).abs().max()), scale)
