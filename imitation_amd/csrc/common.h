@@ -27,18 +27,18 @@ enum { IA_GEMM_NT = 0, IA_GEMM_NN = 1, IA_GEMM_TN = 2 };
 
 // Implicit im2col view of a channel-last activation tensor x[B, H, W, C] (no column buffer): row m = (b, oh, ow),
 // column k = (i, j, c) -> x[b, oh*S + i, ow*S + j, c]. A kernel row (fixed i) is one contiguous run of `seg` = KW*C
-// floats; divisions go through precomputed reciprocals (`m*`: ceil(2^32 / d), exact for the index ranges here).
+// floats; divisions go through precomputed 64-bit reciprocals (`m*`), exact for every 32-bit index.
 struct IaIm {
   int on;                       // 0: the operand is a plain matrix
   int OW, OHW, W, C, S, HWC;    // output width, output pixels per image, input width / channels / stride, H*W*C
   int seg, rstride;             // KW*C, W*C
-  unsigned mOW, mOHW, mseg;
+  unsigned long long mOW, mOHW, mseg;   // floor((2^64 - 1) / d) + 1: __umul64hi(n, m) == n / d for every 32-bit n
   int pad, H;                   // zero padding on every side (taps outside the image read as 0), input height
-  unsigned mC;                  // ceil(2^32 / C)
+  unsigned long long mC;
   // optional scatter of the OUTPUT rows (NT): row m = (b, y', x') of a cm_OW-wide grid with cm_OHW cells per image
   // goes to row b*cm_HW + (y'*cm_S + cm_py)*cm_W + x'*cm_S + cm_px of C (transposed convolution by sub-pixel classes)
   int cm_on, cm_OW, cm_OHW, cm_S, cm_py, cm_px, cm_W, cm_HW;
-  unsigned cm_mOW, cm_mOHW;
+  unsigned long long cm_mOW, cm_mOHW;
 };
 
 struct IaGemm {

@@ -36,7 +36,9 @@ __device__ __forceinline__ f4 load4_guard(const float* __restrict__ p, int n_val
   return v;
 }
 
-__device__ __forceinline__ int im_div(int n, int d, unsigned magic) { return d == 1 ? n : (int)__umulhi((unsigned)n, magic); }
+__device__ __forceinline__ int im_div(int n, int d, unsigned long long magic) {
+  return d == 1 ? n : (int)__umul64hi((unsigned long long)(unsigned)n, magic);
+}
 __device__ __forceinline__ int im_rowoff(const IaIm& im, int m) {
   const int b = im_div(m, im.OHW, im.mOHW), p = m - b * im.OHW;
   const int oh = im_div(p, im.OW, im.mOW), ow = p - oh * im.OW;
@@ -622,7 +624,7 @@ int gemm_im2col(int mode, const float* A, int lda, const float* B, int ldb, floa
                 const int* cmap, const float* relu_mask, void* stream) {
   if (H + 2 * P < KH || W + 2 * P < KW || S <= 0 || Cin % 4 != 0 || (KW * Cin) % 32 != 0) return IA_ERR_ARG;
   const int OH = (H + 2 * P - KH) / S + 1, OW = (W + 2 * P - KW) / S + 1;
-  auto magic = [](int d) { return d <= 1 ? 0u : (unsigned)((0x100000000ull + (unsigned long long)d - 1) / (unsigned long long)d); };
+  auto magic = [](int d) { return d <= 1 ? 0ull : (~0ull / (unsigned long long)d) + 1ull; };
   IaGemm g{};
   g.im.on = 1; g.im.OW = OW; g.im.OHW = OH * OW; g.im.W = W; g.im.C = Cin; g.im.S = S; g.im.HWC = H * W * Cin;
   g.im.seg = KW * Cin; g.im.rstride = W * Cin;

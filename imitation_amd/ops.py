@@ -157,6 +157,12 @@ def adam_step(p: Tensor, g: Tensor, m: Tensor, v: Tensor, beta1: float, beta2: f
            step_size, bc2_sqrt, L.stream())
 
 
+def conv_is_implicit(cin: int, kw: int, x_numel: int) -> bool:
+    """Shapes whose convolution GEMMs read the activations through the implicit im2col view (`ia_gemm_f32_im2col_pad`):
+    channel quads, a 32-deep K chunk inside one kernel row, 32-bit element offsets."""
+    return cin % 4 == 0 and (kw * cin) % 32 == 0 and x_numel < 2 ** 31
+
+
 @th.library.custom_op("imitation_amd::conv2d_nhwc_forward", mutates_args=(), device_types="cuda")
 def conv2d_nhwc_forward(x: Tensor, w: Tensor, b: Tensor, stride: int, pad: int, relu: bool) -> Tuple[Tensor, Tensor]:
     """Convolution of channel-last activations `x[B, H, W, Cin]` with `w[Cout, KH, KW, Cin]`, bias `b[Cout]`, zero
@@ -167,9 +173,15 @@ def conv2d_nhwc_forward(x: Tensor, w: Tensor, b: Tensor, stride: int, pad: int, 
     Cout, KH, KW, _ = w.shape
     OH, OW = (H + 2 * pad - KH) // stride + 1, (W + 2 * pad - KW) // stride + 1
     K, M = KH * KW * Cin, B * OH * OW
+    y = th.empty(B, OH, OW, Cout, device=x.device)
+    if conv_is_implicit(Cin, KW, B * H * W * Cin):
+        # the GEMM reads its operand through the padded im2col view of `x`: no column buffer (`col` comes back empty;
+        # the backward op takes `x` instead)
+        L.call("ia_gemm_f32_im2col_pad", L.GEMM_NT, L.ptr(x), K, L.ptr(w), K, L.ptr(y), Cout, M, Cout, K, L.ptr(b),
+               ACT_RELU if relu else ACT_NONE, 1, None, H, W, Cin, KH, KW, stride, pad, None, None, L.stream())
+        return y, th.empty(0, K, device=x.device)
     col = th.empty(M, K, device=x.device)
     L.call("ia_im2col_f32_nhwc_pad", L.ptr(x), B, H, W, Cin, KH, KW, stride, pad, L.ptr(col), L.stream())
-    y = th.empty(B, OH, OW, Cout, device=x.device)
     L.call("ia_gemm_f32", L.GEMM_NT, L.ptr(col), K, L.ptr(w), K, L.ptr(y), Cout, M, Cout, K, L.ptr(b),
            ACT_RELU if relu else ACT_NONE, None, 0, 1, None, L.stream())
     return y, col
@@ -180,16 +192,18 @@ def _(x, w, b, stride, pad, relu):
     B, H, W, Cin = x.shape
     Cout, KH, KW, _ = w.shape
     OH, OW = (H + 2 * pad - KH) // stride + 1, (W + 2 * pad - KW) // stride + 1
-    return x.new_empty(B, OH, OW, Cout), x.new_empty(B * OH * OW, KH * KW * Cin)
+    rows = 0 if conv_is_implicit(Cin, KW, B * H * W * Cin) else B * OH * OW
+    return x.new_empty(B, OH, OW, Cout), x.new_empty(rows, KH * KW * Cin)
 
 
 @th.library.custom_op("imitation_amd::conv2d_nhwc_backward", mutates_args=(), device_types="cuda")
-def conv2d_nhwc_backward(dy: Tensor, y: Tensor, col: Tensor, w: Tensor, in_h: int, in_w: int, stride: int, pad: int,
-                         relu: bool, need_dx: bool) -> Tuple[Tensor, Tensor, Tensor]:
+def conv2d_nhwc_backward(dy: Tensor, y: Tensor, col: Tensor, x: Tensor, w: Tensor, in_h: int, in_w: int, stride: int,
+                         pad: int, relu: bool, need_dx: bool) -> Tuple[Tensor, Tensor, Tensor]:
     """Backward of `conv2d_nhwc_forward`: `(dx[B, H, W, Cin] (zeros when not needed), dw, db)`. ReLU backward from
-    the saved output, weight gradient = split-K TN GEMM on the kept columns (slabs reduced in fixed order), input
-    gradient = NN GEMM + gather-form col2im."""
-    dy, y, col, w = _dev(dy, "dy"), _dev(y, "y"), _dev(col, "col"), _dev(w, "w")
+    the saved output, weight gradient = split-K TN GEMM on the kept columns -- or, when the forward ran without a
+    column buffer (`col` empty), on the implicit view of the input `x` -- slabs reduced in fixed order; input gradient =
+    NN GEMM + gather-form col2im."""
+    dy, y, col, x, w = _dev(dy, "dy"), _dev(y, "y"), _dev(col, "col"), _dev(x, "x"), _dev(w, "w")
     B, OH, OW, Cout = y.shape
     _, KH, KW, Cin = w.shape
     K, M = KH * KW * Cin, B * OH * OW
@@ -200,8 +214,12 @@ def conv2d_nhwc_backward(dy: Tensor, y: Tensor, col: Tensor, w: Tensor, in_h: in
     splits = int(min(64, max(1, M // 2048)))
     part = th.empty(splits, Cout, K, device=dy.device)
     dbp = th.empty(splits, Cout, device=dy.device)
-    L.call("ia_gemm_f32", L.GEMM_TN, L.ptr(dz), Cout, L.ptr(col), K, L.ptr(part), K, Cout, K, M, None, 0, None, 0,
-           splits, L.ptr(dbp), L.stream())
+    if col.shape[0] == 0:
+        L.call("ia_gemm_f32_im2col_pad", L.GEMM_TN, L.ptr(dz), Cout, L.ptr(x), K, L.ptr(part), K, Cout, K, M, None, 0,
+               splits, L.ptr(dbp), in_h, in_w, Cin, KH, KW, stride, pad, None, None, L.stream())
+    else:
+        L.call("ia_gemm_f32", L.GEMM_TN, L.ptr(dz), Cout, L.ptr(col), K, L.ptr(part), K, Cout, K, M, None, 0, None, 0,
+               splits, L.ptr(dbp), L.stream())
     dw, db = th.empty(Cout, KH, KW, Cin, device=dy.device), th.empty(Cout, device=dy.device)
     L.call("ia_reduce_partials", L.ptr(part), splits, Cout * K, 1.0, 0, L.ptr(dw), L.stream())
     L.call("ia_reduce_partials", L.ptr(dbp), splits, Cout, 1.0, 0, L.ptr(db), L.stream())
@@ -215,7 +233,7 @@ def conv2d_nhwc_backward(dy: Tensor, y: Tensor, col: Tensor, w: Tensor, in_h: in
 
 
 @conv2d_nhwc_backward.register_fake
-def _(dy, y, col, w, in_h, in_w, stride, pad, relu, need_dx):
+def _(dy, y, col, x, w, in_h, in_w, stride, pad, relu, need_dx):
     B = y.shape[0]
     return y.new_empty(B, in_h, in_w, w.shape[3]), th.empty_like(w), y.new_empty(w.shape[0])
 
@@ -255,16 +273,16 @@ class _Conv(th.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, b, stride, pad, relu):
         y, col = th.ops.imitation_amd.conv2d_nhwc_forward(x, w, b, stride, pad, relu)
-        ctx.save_for_backward(y, col, w)
+        ctx.save_for_backward(y, col, x, w)
         ctx.cfg = (x.shape[1], x.shape[2], stride, pad, relu)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        y, col, w = ctx.saved_tensors
+        y, col, x, w = ctx.saved_tensors
         in_h, in_w, stride, pad, relu = ctx.cfg
-        dx, dw, db = th.ops.imitation_amd.conv2d_nhwc_backward(dy.contiguous(), y, col, w, in_h, in_w, stride, pad, relu,
-                                                               bool(ctx.needs_input_grad[0]))
+        dx, dw, db = th.ops.imitation_amd.conv2d_nhwc_backward(dy.contiguous(), y, col, x, w, in_h, in_w, stride, pad,
+                                                               relu, bool(ctx.needs_input_grad[0]))
         return (dx if ctx.needs_input_grad[0] else None), dw, db, None, None, None
 
 

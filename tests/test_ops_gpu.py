@@ -309,3 +309,30 @@ def test_mlp_module_with_dropout_runs_layer_by_layer():
     assert not th.allclose(a, b)
     a.sum().backward()
     assert all(p_.grad is not None and th.isfinite(p_.grad).all() for p_ in net.parameters())
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout,k,s,p,relu", [
+    (96, 84, 84, 32, 32, 3, 1, 1, True),     # 677 376 output rows: the view's row decode must be exact far past 2^16 rows
+    (5, 20, 20, 32, 64, 4, 2, 0, True),      # NatureCNN layer 2 geometry
+    (3, 9, 11, 64, 64, 3, 1, 1, False),      # non-square, padded
+    (4, 12, 12, 4, 16, 3, 1, 1, True),       # Cin = 4: (KW * Cin) % 32 != 0 -> explicit column buffer path
+])
+def test_conv2d_nhwc_op_matches_torch(B, H, W, Cin, Cout, k, s, p, relu):
+    """`ops.conv2d_nhwc` (implicit im2col view when Cin % 4 == 0 and KW*Cin % 32 == 0, explicit column buffer otherwise)
+    against `torch.nn.functional.conv2d` autograd: output, input gradient, weight and bias gradients."""
+    from imitation_amd import ops
+    g = th.Generator().manual_seed(B + Cin)
+    x = th.randn(B, H, W, Cin, generator=g).cuda().requires_grad_()
+    w = (th.randn(Cout, k, k, Cin, generator=g) / np.sqrt(k * k * Cin)).cuda().requires_grad_()
+    b = (0.1 * th.randn(Cout, generator=g)).cuda().requires_grad_()
+    assert ops.conv_is_implicit(Cin, k, x.numel()) == (Cin % 4 == 0 and (k * Cin) % 32 == 0)
+    y = ops.conv2d_nhwc(x, w, b, stride=s, pad=p, relu=relu)
+    up = th.randn(y.shape, generator=g).cuda()
+    (y * up).sum().backward()
+    xr, wr, br = (t.detach().clone().requires_grad_() for t in (x, w, b))
+    yr = th.nn.functional.conv2d(xr.permute(0, 3, 1, 2), wr.permute(0, 3, 1, 2), br, stride=s, padding=p)
+    yr = (th.relu(yr) if relu else yr).permute(0, 2, 3, 1)
+    (yr * up).sum().backward()
+    for name, a_, r_ in (("y", y, yr), ("dx", x.grad, xr.grad), ("dw", w.grad, wr.grad), ("db", b.grad, br.grad)):
+        scale = float(r_.abs().max()) + 1e-12
+        assert float((a_ - r_).abs().max()) <= 5e-5 * scale, (name, float((a_ - r_).abs().max()), scale)
