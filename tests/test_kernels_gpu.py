@@ -394,6 +394,9 @@ def test_timeout_bootstrap():
                                                         (4, 3, 32, True, True, 8, 16, 40),
                                                         (64, 16, 32, False, True, 4, 32, 64),
                                                         (33, 1, 32, False, False, 2, 70, 140),
+                                                        # Discrete head with 13 actions: every lane of a row's quad
+                                                        # owns several of them in the loss phase
+                                                        (20, 13, 32, True, True, 4, 32, 96),
                                                         # Ant-shaped (BASELINE config 3): 4209 parameters, the
                                                         # 9-parameters-per-thread build of the persistent kernel
                                                         (27, 8, 32, False, True, 8, 64, 256),
