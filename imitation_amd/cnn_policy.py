@@ -96,9 +96,9 @@ class ActorCriticCnnPolicy:
         # (KW*Cin) % 32 == 0 -- true for NatureCNN (4 x 32 and 3 x 64). False: explicit im2col + GEMM (tests).
         self.implicit_convs = all(g[0] % 4 == 0 and (g[4] * g[0]) % 32 == 0 for g in self.geom[1:])
         # input gradients of layers 2 / 3 as implicit transposed convolutions (`_dgrad_implicit`: no `dcol` buffers,
-        # 1.1 GB less at batch 4096) -- measured 0.2 ms per step SLOWER than the NN GEMM + col2im pair at that batch (the
-        # stride-2 layer splits into four 32-column GEMMs), so it is opt-in for memory-bound batch sizes
-        self.implicit_dgrad = False
+        # 1.1 GB less at batch 4096; on par with the NN GEMM + col2im pair in time: 2.82 against 2.87 ms per BC step).
+        # False: the explicit pair (tests compare the two).
+        self.implicit_dgrad = True
         self._dgrad_idx: Dict[int, th.Tensor] = {}
         # Host construction in SB3's order so that torch's global generator is consumed identically:
         # the three convolutions, the linear layer, action_net, value_net; then orthogonal re-initialisation
@@ -375,14 +375,13 @@ class ActorCriticCnnPolicy:
                     jj = th.as_tensor([px + s * (kt - 1 - t) for t in range(kt)])
                     blocks.append(base.index_select(1, ii).index_select(2, jj).permute(3, 1, 2, 0).reshape(-1))
             self._dgrad_idx[li] = th.cat(blocks).to(self.device)
-        Wd_all = self.w(li).index_select(0, self._dgrad_idx[li]).view(s * s, cin, Kd)
-        for py in range(s):
-            for px in range(s):
-                Wd = Wd_all[py * s + px]
-                gh, gw = oh + kt - 1, ow + kt - 1                 # input pixels of this class per image
-                cmap = (C.c_int * 5)(s, py, px, h, w_) if s > 1 else None
-                L.call("ia_gemm_f32_im2col_pad", 0, L.ptr(dout), Kd, L.ptr(Wd), Kd, L.ptr(dact), cin, B * gh * gw, cin, Kd,
-                       None, 0, 1, None, oh, ow, cout, kt, kt, 1, kt - 1, cmap, L.ptr(d[f"act{li - 1}"]), L.stream())
+        # every class reads the SAME padded view of `dout` (only the weights differ): one GEMM with the classes side by
+        # side along the columns, rows scattered by (class, pixel) in the epilogue
+        Wd_all = self.w(li).index_select(0, self._dgrad_idx[li])              # [s*s*cin, Kd], class-major rows
+        gh, gw = oh + kt - 1, ow + kt - 1                                     # input pixels of one class per image
+        cmap = (C.c_int * 5)(s, -1, -1, h, w_) if s > 1 else None
+        L.call("ia_gemm_f32_im2col_pad", 0, L.ptr(dout), Kd, L.ptr(Wd_all), Kd, L.ptr(dact), cin, B * gh * gw, s * s * cin, Kd,
+               None, 0, 1, None, oh, ow, cout, kt, kt, 1, kt - 1, cmap, L.ptr(d[f"act{li - 1}"]), L.stream())
 
     def backward(self, B: int, grad: th.Tensor, with_values: bool = False) -> None:
         """Adds to `grad` (flat, device layout) the parameter gradient of the loss whose head gradients were left in

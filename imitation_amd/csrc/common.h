@@ -37,8 +37,9 @@ struct IaIm {
   unsigned long long mC;
   // optional scatter of the OUTPUT rows (NT): row m = (b, y', x') of a cm_OW-wide grid with cm_OHW cells per image
   // goes to row b*cm_HW + (y'*cm_S + cm_py)*cm_W + x'*cm_S + cm_px of C (transposed convolution by sub-pixel classes)
-  int cm_on, cm_OW, cm_OHW, cm_S, cm_py, cm_px, cm_W, cm_HW;
-  unsigned long long cm_mOW, cm_mOHW;
+  // cm_on == 2: all cm_S^2 classes in ONE GEMM -- output column = class * cm_C + channel, class = py * cm_S + px
+  int cm_on, cm_OW, cm_OHW, cm_S, cm_py, cm_px, cm_W, cm_HW, cm_C;
+  unsigned long long cm_mOW, cm_mOHW, cm_mC;
 };
 
 struct IaGemm {

@@ -67,11 +67,11 @@ __device__ __forceinline__ f4 im_load_pad(const float* __restrict__ src, const I
   const f4 z = {0.f, 0.f, 0.f, 0.f};
   return valid ? v : z;
 }
-__device__ __forceinline__ long long im_crow(const IaIm& im, int m) {
+__device__ __forceinline__ long long im_crow(const IaIm& im, int m, int py, int px) {
   if (!im.cm_on) return m;
   const int b = im_div(m, im.cm_OHW, im.cm_mOHW), p = m - b * im.cm_OHW;
   const int yy = im_div(p, im.cm_OW, im.cm_mOW), xx = p - yy * im.cm_OW;
-  return (long long)b * im.cm_HW + (yy * im.cm_S + im.cm_py) * im.cm_W + xx * im.cm_S + im.cm_px;
+  return (long long)b * im.cm_HW + (yy * im.cm_S + py) * im.cm_W + xx * im.cm_S + px;
 }
 
 // Tile loaders. ROWS = tile extent in the non-reduction index.
@@ -386,6 +386,20 @@ __device__ __forceinline__ void gemm_tile(const IaGemm& g, const TileCtx& tc, fl
     __syncthreads();
   }
 
+  // scattered output rows (transposed-convolution forms): the class-independent part of every tile row's target row is
+  // decoded ONCE per tile into LDS (two reciprocal divisions per row instead of per output element)
+  int* rowmap = reinterpret_cast<int*>(smem);
+  const bool scatter = IM && MODE == IA_GEMM_NT && g.im.cm_on != 0;
+  if (scatter) {
+    __syncthreads();   // the last chunk's fragments have been read
+    if (tid < BM) {
+      const int m = min(bm0 + tid, g.M - 1);
+      const int b = im_div(m, g.im.cm_OHW, g.im.cm_mOHW), p = m - b * g.im.cm_OHW;
+      const int yy = im_div(p, g.im.cm_OW, g.im.cm_mOW), xx = p - yy * g.im.cm_OW;
+      rowmap[tid] = b * g.im.cm_HW + yy * g.im.cm_S * g.im.cm_W + xx * g.im.cm_S;
+    }
+    __syncthreads();
+  }
   float* C = g.C;
   if (MODE == IA_GEMM_TN) C += (long long)tc.split * g.c_split_stride;
 #pragma unroll
@@ -408,9 +422,16 @@ __device__ __forceinline__ void gemm_tile(const IaGemm& g, const TileCtx& tc, fl
               v *= ia_act_grad_from_post(PREP ? pv[PREP ? i : 0][PREP ? j : 0][r] : g.P[(long long)row * g.ldp + col], g.act);
           }
           if (IM) {   // implicit-view forms: optional output-row scatter and ReLU mask of the tensor being written to
-            const long long crow = im_crow(g.im, row);
-            if (MODE == IA_GEMM_NT && g.P != nullptr && !(g.P[crow * g.ldp + col] > 0.f)) v = 0.f;
-            C[crow * g.ldc + col] = v;
+            int py = g.im.cm_py, px = g.im.cm_px, ccol = col;
+            if (g.im.cm_on == 2) {   // sub-pixel classes fused along the columns: class = col / cm_C
+              const int cls = im_div(col, g.im.cm_C, g.im.cm_mC);
+              ccol = col - cls * g.im.cm_C;
+              py = im_div(cls, g.im.cm_S, ~0ull / (unsigned long long)g.im.cm_S + 1ull);
+              px = cls - py * g.im.cm_S;
+            }
+            const long long crow = scatter ? (long long)rowmap[row - bm0] + py * g.im.cm_W + px : (long long)row;
+            if (MODE == IA_GEMM_NT && g.P != nullptr && !(g.P[crow * g.ldp + ccol] > 0.f)) v = 0.f;
+            C[crow * g.ldc + ccol] = v;
           } else {
             C[(long long)row * g.ldc + col] = v;
           }
@@ -635,6 +656,11 @@ int gemm_im2col(int mode, const float* A, int lda, const float* B, int ldb, floa
     g.im.cm_on = 1; g.im.cm_OW = OW; g.im.cm_OHW = OH * OW; g.im.cm_S = cmap[0]; g.im.cm_py = cmap[1]; g.im.cm_px = cmap[2];
     g.im.cm_W = cmap[4]; g.im.cm_HW = cmap[3] * cmap[4];
     g.im.cm_mOW = g.im.mOW; g.im.cm_mOHW = g.im.mOHW;
+    if (cmap[1] < 0) {   // py < 0: all S_out^2 classes at once, N = S_out^2 * (channels per class)
+      if (N % (cmap[0] * cmap[0]) != 0) return IA_ERR_ARG;
+      g.im.cm_on = 2; g.im.cm_C = N / (cmap[0] * cmap[0]); g.im.cm_mC = magic(g.im.cm_C);
+      ldc = g.im.cm_C;
+    }
   }
   const long long rows = mode == IA_GEMM_NT ? M : K;
   if (rows % g.im.OHW != 0 || (mode == IA_GEMM_NT ? K : N) != KH * KW * Cin) return IA_ERR_ARG;

@@ -334,7 +334,9 @@ int ia_gemm_f32_im2col(int mode, const float* A, int lda, const float* B, int ld
 
 /* The same view with zero padding P on every side (taps outside the image read as 0) and, for mode 0, an optional
  * scatter of the output rows: cmap = {S_out, py, px, H_out, W_out} (HOST pointer to 5 ints) writes row (b, y', x') of
- * the [OH, OW] output grid to row (b, y'*S_out + py, x'*S_out + px) of a [H_out, W_out] grid in C. With these the
+ * the [OH, OW] output grid to row (b, y'*S_out + py, x'*S_out + px) of a [H_out, W_out] grid in C; py < 0: all
+ * S_out^2 classes in one GEMM (they share the view): N = S_out^2 * Cc, column class*Cc + c goes to channel c of the
+ * class's row, C has Cc columns. With these the
  * INPUT gradient of a convolution is again an implicit GEMM over dout (`torch.nn.Conv2d` backward w.r.t. its input):
  * one padded stride-1 convolution with the flipped / transposed weights per sub-pixel class (py, px) of the stride --
  * no `dcol` buffer, no col2im; `relu_mask` (nullable, laid out like C) zeroes the outputs where the layer below's ReLU
