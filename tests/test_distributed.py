@@ -69,14 +69,17 @@ def _gpu_worker(rank, world, port, out_dir):
     cfg = dict(harness.CASES["gail_box"], rounds=2)
     from imitation_amd.vec_env import SyntheticVecEnv
 
-    def run(batch_moments: bool, global_mb: bool = False, pipeline: bool = True, airl: bool = False):
+    def run(batch_moments: bool, global_mb: bool = False, pipeline: bool = True, airl: bool = False,
+            general: bool = False):
         th.manual_seed(100 + rank)      # different initial weights per rank: the broadcast must fix that
         np.random.seed(100 + rank)
         venv = SyntheticVecEnv(num_envs=cfg["n_envs"], obs_dim=17, act_dim=6, horizon=cfg["horizon"], seed=rank)
         pk = dict(features_extractor_class=p.NormalizeFeaturesExtractor,
                   features_extractor_kwargs=dict(normalize_class=p.RunningNorm))
-        algo = p.PPO(p.FeedForward32Policy, venv, n_steps=cfg["n_steps"], batch_size=cfg["ppo_batch"], n_epochs=2,
-                     ent_coef=0.1, policy_kwargs=pk, device="cuda")
+        if general:   # towers outside the fused kernels' shapes: the general minibatch loop, one gradient all-reduce per step
+            pk = dict(pk, net_arch=dict(pi=[24], vf=[16, 16]))
+        algo = p.PPO(p.ActorCriticPolicy if general else p.FeedForward32Policy, venv, n_steps=cfg["n_steps"],
+                     batch_size=cfg["ppo_batch"], n_epochs=2, ent_coef=0.1, policy_kwargs=pk, device="cuda")
         algo.dp_batch_moments = batch_moments
         algo.dp_global_minibatch = global_mb
         if airl:
@@ -110,6 +113,7 @@ def _gpu_worker(rank, world, port, out_dir):
     th.save(run(True, global_mb=True, pipeline=False), os.path.join(out_dir, f"state{rank}_global_seq.pt"))
     th.save(run(True, global_mb=True, airl=True), os.path.join(out_dir, f"state{rank}_airl.pt"))
     th.save(run(True, global_mb=True, pipeline=False, airl=True), os.path.join(out_dir, f"state{rank}_airl_seq.pt"))
+    th.save(run(True, general=True), os.path.join(out_dir, f"state{rank}_general.pt"))
     dist.destroy_process_group()
 
 
@@ -152,6 +156,13 @@ def test_two_ranks_one_gpu_replicas_identical(tmp_path):
         if not k.startswith("tile/") or k.endswith("_global") or k == "tile/perm":
             assert th.equal(r0[k], r1[k]), k
         assert th.equal(r0[k], rs[k]), k
+    # general-tower policies (any `net_arch`) under data parallelism: gradient all-reduce per optimiser step, feature
+    # statistics merged across ranks -> identical replicas, and the policy did train
+    t0, t1 = th.load(tmp_path / "state0_general.pt"), th.load(tmp_path / "state1_general.pt")
+    assert "pol/mlp_extractor.value_net.2.weight" in t0
+    for k in t0:
+        assert th.equal(t0[k], t1[k]), k
+    assert all(bool(th.isfinite(v.float()).all()) for v in t0.values())
     # every rank contributed: disc input norm saw world * (2 rounds * 2 updates * 128 rows)
     assert int(a["disc/mlp.normalize_input.count"]) == 2 * 2 * 2 * 128
     assert int(g0["disc/mlp.normalize_input.count"]) == 2 * 3 * 2 * 128
