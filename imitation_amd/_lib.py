@@ -70,6 +70,10 @@ _SIGS = {
     "ia_gemm_f32_im2col": ([_I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _P, _I, _I, _P, _I, _I, _I, _I, _I, _I, _P], C.c_int),
     "ia_gemm_f32_im2col_pad": ([_I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _P, _I, _I, _P, _I, _I, _I, _I, _I, _I, _I,
                                C.POINTER(C.c_int), _P, _P], C.c_int),
+    "ia_airl_fused_ok": ([_I, _I, _I, _I, _I], C.c_int),
+    "ia_airl_fused_slabs": ([_I], C.c_int),
+    "ia_airl_step_shaped": ([_P, _I, _I, _P, _P, _I, _I, _P, _P, _P, _P, _F, _P, _P, _P, _P, _F, _P, _P, _F, _F, _I, _I,
+                            _P, _I, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P], C.c_int),
     "ia_conv1_u8_implicit_ok": ([_I, _I, _I, _I, _I, _I, _I], C.c_int),
     "ia_conv1_u8_forward": ([_P, _I, _I, _I, _P, _P, _F, _P, _P, _P], C.c_int),
     "ia_conv1_u8_wgrad_ws_floats": ([_I], C.c_longlong),

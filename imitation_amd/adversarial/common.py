@@ -530,11 +530,17 @@ class AdversarialTrainer(abc.ABC):
                     raise NotImplementedError("disc_grad_penalty_coef > 0 is implemented for BasicRewardNet "
                                               "discriminators (GAIL; state-holder or imitation_amd.modules net)")
                 logp = None if (quirk_done and not self._needs_logp) else self._policy_pass(sources, mb)
-                logits = net.disc_forward(sources, mb, logp)
-                L.call("ia_bce_logits", L.ptr(logits), 2 * mb, mb, scale, L.ptr(self._dlogits),
-                       L.ptr(stats_dev), L.ptr(self._bce_ws), L.stream())
-                fused_step = bool(net.disc_backward(self._dlogits, accumulate=not first,
-                                                    adam=fuse_adam if (B == mb) else None))
+                if (isinstance(basic, reward_nets.ShapedRewardNet) and B == mb and fuse_adam is not None
+                        and logp is not None and basic.fused_step_ok()):
+                    # AIRL's default shaped net: forward, BCE, backward, reduction + Adam in five launches
+                    logits = basic.disc_step_fused(sources, logp, scale, stats_dev, fuse_adam)
+                    fused_step = True
+                else:
+                    logits = net.disc_forward(sources, mb, logp)
+                    L.call("ia_bce_logits", L.ptr(logits), 2 * mb, mb, scale, L.ptr(self._dlogits),
+                           L.ptr(stats_dev), L.ptr(self._bce_ws), L.stream())
+                    fused_step = bool(net.disc_backward(self._dlogits, accumulate=not first,
+                                                        adam=fuse_adam if (B == mb) else None))
             first = False
         if self._dp is not None:  # one flat-bucket all-reduce per discriminator step
             self._dp.allreduce_mean_(net._store.grad)

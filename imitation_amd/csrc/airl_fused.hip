@@ -1,0 +1,418 @@
+// One AIRL discriminator update for the scripts' default shaped reward net (adversarial/airl.py:99-132,
+// rewards/reward_nets.py:674-809: BasicShapedRewardNet = reward MLP D_b -> 32 -> 1 on [s | a | s' | done] plus potential
+// MLP D_p -> 32 -> 32 -> 1 evaluated on s' and on s, ReLU) without the ~40 launches of the generic stack path
+// (three dense stacks forward and backward through the GEMM family, row-dot heads, logit / BCE / routing kernels --
+// each 2-15 us for nets this small: 380 us per update, profiles/r02_airl_kernel_stats.md).
+//
+//   airl_rows_kernel: ONE pass over the 2 x minibatch rows on the matrix cores. A wave owns 32 rows and computes every
+//     layer TRANSPOSED (H^T = W . X^T, v_mfma_f32_32x32x2_f32): the accumulator of one layer -- lane = row, registers =
+//     16 of the 32 features -- is, element by element, the B operand of the next layer's MFMAs (the contraction index
+//     is simply visited in the accumulator's feature order, with the weight fragments pre-permuted to match in LDS),
+//     so activations and deltas never leave the registers between layers:
+//     normalise the three inputs (statistics as given: the caller has applied the train-mode updates, potential:
+//     after the next-state batch for h(s'), after the state batch for h(s), util/networks.py:79-91),
+//     forward the three stacks, logits = g + gamma (1 - done) h(s') - h(s) - log pi  (reward_nets.py:727-733, airl.py:118),
+//     BCE-with-logits + its statistics (common.py:27-92, 360-368; same sums as bce_kernel), d logits routed to the three
+//     outputs, deltas back through the ReLU layers (W2^T . delta^T is one more MFMA chain).
+//     It writes what the weight gradients contract over the rows: normalised inputs, first hidden activations of the
+//     potential and the hidden-layer deltas; the 1-wide output layers' gradients are reduced inside the workgroup
+//     (transpose-and-halve butterflies: 16 shuffles for 16 sums) and stored as this workgroup's slab of the split-K
+//     partial buffer.
+//   The three hidden-layer weight gradients are then the existing split-K TN GEMMs (one slab per 128 rows) and
+//   ia_reduce_partials_adam finishes: 1 + 3 + 1 launches behind the batch assembly and the statistics updates.
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "common.h"
+
+namespace {
+
+constexpr int AH = 32;              // hidden width of all three stacks
+constexpr int A_WAVES = 4;
+constexpr int A_THREADS = 64 * A_WAVES;
+constexpr int A_ROWS = 32 * A_WAVES;    // rows per workgroup = rows per split-K slab of the weight-gradient GEMMs
+constexpr int A_CH = 8;                 // input chunks of 8 columns a stack's first layer may have
+constexpr int A_D_MAX = 8 * A_CH;
+
+struct AirlArgs {
+  const float *Xb, *Sn, *Sc;        // [R, ldb] base inputs, [R, ldp] next / current observations (raw)
+  int ldb, Db, ldp, Dp;
+  const float *dones, *logp;        // [R]
+  const float *bmean, *bvar;        // base input norm (null: none)
+  const float *pmeanA, *pvarA;      // potential norm after the next-state update (null: none)
+  const float *pmeanB, *pvarB;      // ... after the current-state update
+  float beps, peps;
+  const float *Pb, *Pp;             // flat parameters: base [W1 32xDb | b1 | wout 32 | bout], potential [W1 32xDp | b1 | W2 | b2 | wout | bout]
+  float gamma, scale;
+  int R, n_expert;
+  float *Ab; int ldab;              // [R, ldab] normalised base inputs
+  float *Db1;                       // [R, 32]
+  float *Ap; int ldap;              // [2R, ldap] normalised potential inputs: rows r (next) and R + r (current)
+  float *H1, *Dp1, *Dp2;            // [2R, 32] each
+  float *part; long long part_stride;   // split-K partial buffer [slabs][part_stride]; this kernel fills the output layers
+  int off_b_wout, off_b_bout, off_p_wout, off_p_bout;   // their offsets inside a slab
+  float *logits, *stats, *bce_part;
+  unsigned *ticket;
+};
+
+__device__ __forceinline__ f32x16 mfma(float a, float b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+
+// Accumulator element j of a lane in half h (= lane >> 5) is feature 8 (j / 4) + 4 h + j % 4 of row lane & 31: four
+// runs of four consecutive features, so per-feature vectors and row-major stores go by float4.
+__device__ __forceinline__ f32x16 per_feature(const float* __restrict__ v, int half) {
+  f32x16 r;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const f32x4 t = *reinterpret_cast<const f32x4*>(v + 8 * q + 4 * half);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) r[4 * q + u] = t[u];
+  }
+  return r;
+}
+
+__device__ __forceinline__ void store_features(float* __restrict__ row32, const f32x16& v, int half) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    f32x4 t;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) t[u] = v[4 * q + u];
+    *reinterpret_cast<f32x4*>(row32 + 8 * q + 4 * half) = t;
+  }
+}
+
+// Sums of 16 per-lane values over the 32 lanes of a half: every step trades half of the values with the partner
+// lane and adds, so 8 + 4 + 2 + 1 + 1 shuffles do the work of 16 butterflies. Lane l ends up with the sum of element
+// 8 b4 + 4 b3 + 2 b2 + b1 (bits of l); the pair (l, l ^ 1) holds the same one. Fixed order: deterministic.
+__device__ __forceinline__ float half_sums16(const f32x16& p, int lane) {
+  float a8[8], a4[4], a2[2];
+  bool b = (lane & 16) != 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) a8[i] = (b ? p[i + 8] : p[i]) + __shfl_xor(b ? p[i] : p[i + 8], 16, 64);
+  b = (lane & 8) != 0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) a4[i] = (b ? a8[i + 4] : a8[i]) + __shfl_xor(b ? a8[i] : a8[i + 4], 8, 64);
+  b = (lane & 4) != 0;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) a2[i] = (b ? a4[i + 2] : a4[i]) + __shfl_xor(b ? a4[i] : a4[i + 2], 4, 64);
+  b = (lane & 2) != 0;
+  float a1 = (b ? a2[1] : a2[0]) + __shfl_xor(b ? a2[0] : a2[1], 2, 64);
+  a1 += __shfl_xor(a1, 1, 64);
+  return a1;
+}
+
+// All chunks of one input row, issued up front (the kernel's only HBM-latency exposure): chunk q of a lane in half h is
+// columns 8 q + 4 h .. + 3.
+__device__ __forceinline__ void load_row(const float* __restrict__ xrow, int ld, int chunks, int half, f32x4 (&raw)[A_CH]) {
+#pragma unroll
+  for (int q = 0; q < A_CH; ++q) {
+    raw[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (q < chunks) {
+      const int k0 = 8 * q + 4 * half;
+      const f32x4 v = *reinterpret_cast<const f32x4*>(xrow + min(k0, ld - 4));
+      if (k0 < ld) raw[q] = v;
+    }
+  }
+}
+
+// First layer of a stack for the wave's 32 rows: normalise, store the normalised rows, relu(b1 + W1 xn) transposed.
+__device__ __forceinline__ f32x16 first_layer(const f32x4 (&raw)[A_CH], int chunks, const float* __restrict__ mean,
+                                              const float* __restrict__ istd, const f32x4* __restrict__ wf,
+                                              const float* __restrict__ b1, float* __restrict__ xn_out, int ldo,
+                                              bool live, int half) {
+  f32x16 acc = per_feature(b1, half);
+#pragma unroll
+  for (int q = 0; q < A_CH; ++q) {
+    if (q < chunks) {
+      const int k0 = 8 * q + 4 * half;
+      const f32x4 m = *reinterpret_cast<const f32x4*>(mean + k0);
+      const f32x4 is = *reinterpret_cast<const f32x4*>(istd + k0);
+      const f32x4 w = wf[q * 64];
+      const f32x4 xn = (raw[q] - m) * is;          // (columns past the input width: istd = 0)
+      if (live && k0 < ldo) *reinterpret_cast<f32x4*>(xn_out + k0) = xn;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) acc = mfma(w[u], xn[u], acc);
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 16; ++j) acc[j] = fmaxf(acc[j], 0.f);
+  return acc;
+}
+
+// acc0 + W . v for a 32 x 32 layer whose A fragments `wf` follow the accumulator's feature order
+__device__ __forceinline__ f32x16 chain32(f32x16 acc, const f32x16& v, const f32x4* __restrict__ wf) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const f32x4 w = wf[q * 64];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) acc = mfma(w[u], v[4 * q + u], acc);
+  }
+  return acc;
+}
+
+__device__ __forceinline__ float dot_features(const f32x16& h, const f32x16& w) {
+  float s = 0.f;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) s += h[j] * w[j];
+  return s + __shfl_xor(s, 32, 64);
+}
+
+struct AirlLds {
+  f32x4 bW1f[A_CH * 64], pW1f[A_CH * 64], W2f[4 * 64], W2tf[4 * 64];
+  float vec[5 * AH + 4];            // b_b1, b_wout, p_b1, p_b2, p_wout, then bout_b, bout_p
+  float bmean[A_D_MAX], bistd[A_D_MAX], pmA[A_D_MAX], piA[A_D_MAX], pmB[A_D_MAX], piB[A_D_MAX];
+  float red[A_WAVES][72];
+  int is_last;
+};
+
+__global__ __launch_bounds__(A_THREADS) void airl_rows_kernel(AirlArgs a) {
+  __shared__ __attribute__((aligned(16))) AirlLds S;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int half = lane >> 5;
+  const int Cb = (a.Db + 7) >> 3, Cp = (a.Dp + 7) >> 3;
+  const int r = blockIdx.x * A_ROWS + wave * 32 + (lane & 31);
+  const bool live = r < a.R;
+  const int rr = live ? r : a.R - 1;             // (rows past the end recompute the last one; nothing of theirs is stored or summed)
+  f32x4 rawb[A_CH], rawn[A_CH], rawc[A_CH];
+  load_row(a.Xb + (long long)rr * a.ldb, a.ldb, Cb, half, rawb);
+  load_row(a.Sn + (long long)rr * a.ldp, a.ldp, Cp, half, rawn);
+  load_row(a.Sc + (long long)rr * a.ldp, a.ldp, Cp, half, rawc);
+  const float done = a.dones[rr], lp = a.logp[rr];
+
+  const float* Pb = a.Pb;
+  const float* Pp = a.Pp;
+  const int ob_b1 = AH * a.Db, ob_wout = ob_b1 + AH, ob_bout = ob_wout + AH;
+  const int op_b1 = AH * a.Dp, op_W2 = op_b1 + AH, op_b2 = op_W2 + AH * AH, op_wout = op_b2 + AH, op_bout = op_wout + AH;
+  // weight fragments: entry (q, lane) = the four A values A[m = lane & 31][k = 8 q + 4 (lane >> 5) + u]
+  for (int e = tid; e < Cb * 64; e += A_THREADS) {
+    const int m = e & 31, k0 = 8 * (e >> 6) + 4 * ((e >> 5) & 1);
+    f32x4 w;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) w[u] = k0 + u < a.Db ? Pb[m * a.Db + k0 + u] : 0.f;
+    S.bW1f[e] = w;
+  }
+  for (int e = tid; e < Cp * 64; e += A_THREADS) {
+    const int m = e & 31, k0 = 8 * (e >> 6) + 4 * ((e >> 5) & 1);
+    f32x4 w;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) w[u] = k0 + u < a.Dp ? Pp[m * a.Dp + k0 + u] : 0.f;
+    S.pW1f[e] = w;
+  }
+  for (int e = tid; e < 4 * 64; e += A_THREADS) {
+    const int m = e & 31, k0 = 8 * (e >> 6) + 4 * ((e >> 5) & 1);
+    f32x4 w, wt;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      w[u] = Pp[op_W2 + m * AH + k0 + u];          // forward:  A[m = out][k = in]
+      wt[u] = Pp[op_W2 + (k0 + u) * AH + m];       // backward: A[m = in][k = out]
+    }
+    S.W2f[e] = w;
+    S.W2tf[e] = wt;
+  }
+  if (tid < AH) {
+    S.vec[tid] = Pb[ob_b1 + tid];
+    S.vec[AH + tid] = Pb[ob_wout + tid];
+    S.vec[2 * AH + tid] = Pp[op_b1 + tid];
+    S.vec[3 * AH + tid] = Pp[op_b2 + tid];
+    S.vec[4 * AH + tid] = Pp[op_wout + tid];
+  }
+  if (tid == 0) {
+    S.vec[5 * AH] = Pb[ob_bout];
+    S.vec[5 * AH + 1] = Pp[op_bout];
+  }
+  if (tid < A_D_MAX) {
+    const int k = tid;
+    const bool inb = k < a.Db, inp = k < a.Dp;
+    S.bmean[k] = (inb && a.bmean) ? a.bmean[k] : 0.f;
+    S.bistd[k] = inb ? (a.bmean ? 1.f / sqrtf(a.bvar[k] + a.beps) : 1.f) : 0.f;
+    S.pmA[k] = (inp && a.pmeanA) ? a.pmeanA[k] : 0.f;
+    S.piA[k] = inp ? (a.pmeanA ? 1.f / sqrtf(a.pvarA[k] + a.peps) : 1.f) : 0.f;
+    S.pmB[k] = (inp && a.pmeanA) ? a.pmeanB[k] : 0.f;
+    S.piB[k] = inp ? (a.pmeanA ? 1.f / sqrtf(a.pvarB[k] + a.peps) : 1.f) : 0.f;
+  }
+  __syncthreads();
+
+  const float* b_b1 = S.vec;
+  const float* p_b1 = S.vec + 2 * AH;
+  const f32x16 b_wout = per_feature(S.vec + AH, half), p_wout = per_feature(S.vec + 4 * AH, half);
+  const f32x16 p_b2 = per_feature(S.vec + 3 * AH, half);
+  const f32x4* bW1f = S.bW1f + lane;
+  const f32x4* pW1f = S.pW1f + lane;
+  const f32x4* W2f = S.W2f + lane;
+  const f32x4* W2tf = S.W2tf + lane;
+
+  // forward (reference order: base, potential(next_state), potential(state))
+  const f32x16 hb = first_layer(rawb, Cb, S.bmean, S.bistd, bW1f, b_b1, a.Ab + (long long)rr * a.ldab, a.ldab, live, half);
+  const float g = S.vec[5 * AH] + dot_features(hb, b_wout);
+  const f32x16 h1n = first_layer(rawn, Cp, S.pmA, S.piA, pW1f, p_b1, a.Ap + (long long)rr * a.ldap, a.ldap, live, half);
+  f32x16 h2n = chain32(p_b2, h1n, W2f);
+  const f32x16 h1c = first_layer(rawc, Cp, S.pmB, S.piB, pW1f, p_b1, a.Ap + (long long)(a.R + rr) * a.ldap, a.ldap, live, half);
+  f32x16 h2c = chain32(p_b2, h1c, W2f);
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    h2n[j] = fmaxf(h2n[j], 0.f);
+    h2c[j] = fmaxf(h2c[j], 0.f);
+  }
+  const float h_next = S.vec[5 * AH + 1] + dot_features(h2n, p_wout);
+  const float h_cur = S.vec[5 * AH + 1] + dot_features(h2c, p_wout);
+
+  // logits (reward_nets.py:727-733 order, then airl.py:118) and BCE (bce_kernel's expressions); both halves hold them
+  float f = g + a.gamma * ((1.f - done) * h_next);
+  f = f - h_cur;
+  const float x = f - lp;
+  const float y = rr < a.n_expert ? 1.f : 0.f;
+  const float lse = log1pf(expf(-fabsf(x)));
+  const float p = 1.f / (1.f + expf(-x));
+  const float dlog = live ? (p - y) * (a.scale / (float)a.R) : 0.f;
+  const float dg = dlog, dhn = a.gamma * (1.f - done) * dlog, dhc = -dlog;
+  f32x16 sc;                                     // scalars to sum over the rows: elements 0..7
+#pragma unroll
+  for (int j = 0; j < 16; ++j) sc[j] = 0.f;
+  if (live) {
+    if (half == 0) a.logits[r] = x;
+    const bool is_gen_pred = x < 0.f, is_gen_true = y == 0.f, ok = is_gen_pred == is_gen_true;
+    sc[0] = (1.f - y) * x - (fminf(x, 0.f) - lse);
+    sc[1] = ok ? 1.f : 0.f;
+    sc[2] = (ok && !is_gen_true) ? 1.f : 0.f;
+    sc[3] = (ok && is_gen_true) ? 1.f : 0.f;
+    sc[4] = is_gen_pred ? 1.f : 0.f;
+    sc[5] = (1.f - p) * x - (fminf(x, 0.f) - lse);
+    sc[6] = dg;                                  // d bout of the base stack
+    sc[7] = dhn + dhc;                           // d bout of the potential
+  }
+
+  // backward: deltas of the hidden layers for the TN GEMMs, output-layer gradients reduced here
+  f32x16 gb, gp, t;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    gb[j] = dg * hb[j];
+    gp[j] = dhn * h2n[j] + dhc * h2c[j];
+    t[j] = hb[j] > 0.f ? dg * b_wout[j] : 0.f;
+  }
+  if (live) store_features(a.Db1 + (long long)rr * AH, t, half);
+  auto pot_back = [&](const f32x16& h1, const f32x16& h2, float dh, long long row) {
+    f32x16 d2, z;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      d2[j] = h2[j] > 0.f ? dh * p_wout[j] : 0.f;
+      z[j] = 0.f;
+    }
+    f32x16 d1 = chain32(z, d2, W2tf);
+#pragma unroll
+    for (int j = 0; j < 16; ++j) d1[j] = h1[j] > 0.f ? d1[j] : 0.f;
+    if (live) {
+      store_features(a.Dp2 + row * AH, d2, half);
+      store_features(a.Dp1 + row * AH, d1, half);
+      store_features(a.H1 + row * AH, h1, half);
+    }
+  };
+  pot_back(h1n, h2n, dhn, (long long)rr);
+  pot_back(h1c, h2c, dhc, (long long)(a.R + rr));
+  const float s_b = half_sums16(gb, lane), s_p = half_sums16(gp, lane), s_s = half_sums16(sc, lane);
+  {
+    const int j = ((lane >> 4) & 1) * 8 + ((lane >> 3) & 1) * 4 + ((lane >> 2) & 1) * 2 + ((lane >> 1) & 1);
+    const int feat = 8 * (j >> 2) + 4 * half + (j & 3);
+    if ((lane & 1) == 0) {
+      S.red[wave][feat] = s_b;
+      S.red[wave][AH + feat] = s_p;
+      if (half == 0 && j < 8) S.red[wave][2 * AH + j] = s_s;
+    }
+  }
+  __syncthreads();
+  if (tid < 72) {
+    float tsum = S.red[0][tid];
+#pragma unroll
+    for (int w = 1; w < A_WAVES; ++w) tsum += S.red[w][tid];
+    float* slab = a.part + (long long)blockIdx.x * a.part_stride;
+    if (tid < AH) slab[a.off_b_wout + tid] = tsum;
+    else if (tid < 2 * AH) slab[a.off_p_wout + tid - AH] = tsum;
+    else if (tid < 2 * AH + 6) a.bce_part[blockIdx.x * 8 + tid - 2 * AH] = tsum;
+    else if (tid == 2 * AH + 6) slab[a.off_b_bout] = tsum;
+    else slab[a.off_p_bout] = tsum;
+  }
+  // statistics: the workgroup that draws the last ticket folds the partials in workgroup order (bce_kernel's hand-off)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (tid == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned tk = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    S.is_last = (tk == gridDim.x - 1);
+    if (S.is_last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  }
+  __syncthreads();
+  if (!S.is_last) return;
+  if (tid < 6) {
+    float tsum = 0.f;
+    for (unsigned b = 0; b < gridDim.x; ++b) tsum += a.bce_part[b * 8 + tid];
+    if (tid == 0) tsum = tsum / (float)a.R * a.scale;
+    a.stats[tid] = tsum;
+  }
+  if (tid == 6) a.stats[6] = (float)a.n_expert;
+  if (tid == 7) a.stats[7] = (float)(a.R - a.n_expert);
+  if (tid == 0) __hip_atomic_store(a.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+}  // namespace
+
+extern "C" {
+
+/* Geometry the fused AIRL update covers: reward MLP Db -> 32 -> 1, potential MLP Dp -> 32 -> 32 -> 1 (ReLU). */
+int ia_airl_fused_ok(int Db, int Dp, int hb, int hp1, int hp2) {
+  return (hb == AH && hp1 == AH && hp2 == AH && Db >= 1 && Db <= A_D_MAX && Dp >= 1 && Dp <= A_D_MAX) ? 1 : 0;
+}
+
+/* Slabs of the split-K partial buffer (= workgroups of the rows kernel) an update of R rows uses. */
+int ia_airl_fused_slabs(int R) { return R > 0 ? (R + A_ROWS - 1) / A_ROWS : 0; }
+
+/* One discriminator update, device half: rows kernel + the three hidden-layer weight-gradient GEMMs; the caller then
+ * reduces `partials` ([ia_airl_fused_slabs(R)][n_params], base stack's parameters first) -- e.g. ia_reduce_partials_adam.
+ * Inputs: assembled raw batches Xb[R, ldb] / Sn, Sc[R, ldp] ([expert | generator] rows), dones, log pi; statistics
+ * as the train-mode updates left them (nullable: no input norm); flat parameters of the two stacks. Workspaces:
+ * Ab[R, ldab], Db1[R, 32], Ap[2R, ldap], H1 / Dp1 / Dp2 [2R, 32], bce_part [slabs * 8], ticket (zeroed once). */
+int ia_airl_step_shaped(const float* Xb, int ldb, int Db, const float* Sn, const float* Sc, int ldp, int Dp,
+                        const float* dones, const float* logp, const float* bmean, const float* bvar, float beps,
+                        const float* pmeanA, const float* pvarA, const float* pmeanB, const float* pvarB, float peps,
+                        const float* params_base, const float* params_pot, float gamma, float scale, int R, int n_expert,
+                        float* Ab, int ldab, float* Db1, float* Ap, int ldap, float* H1, float* Dp1, float* Dp2,
+                        float* partials, float* logits, float* stats, float* bce_part, unsigned* ticket, void* stream) {
+  if (!Xb || !Sn || !Sc || !dones || !logp || !params_base || !params_pot || !Ab || !Db1 || !Ap || !H1 || !Dp1 || !Dp2 ||
+      !partials || !logits || !stats || !bce_part || !ticket || R <= 0 || n_expert < 0 || n_expert > R)
+    return IA_ERR_ARG;
+  if (!ia_airl_fused_ok(Db, Dp, AH, AH, AH) || ldb % 4 || ldp % 4 || ldab % 4 || ldap % 4 || ldb < Db || ldp < Dp ||
+      ldab < ((Db + 3) & ~3) || ldap < ((Dp + 3) & ~3))
+    return IA_ERR_UNSUPPORTED;
+  const int nb = AH * Db + AH + AH + 1, np = AH * Dp + AH + AH * AH + AH + AH + 1;
+  const long long ptot = (long long)nb + np;
+  const int nblk = ia_airl_fused_slabs(R);
+  AirlArgs a{};
+  a.Xb = Xb; a.Sn = Sn; a.Sc = Sc; a.ldb = ldb; a.Db = Db; a.ldp = ldp; a.Dp = Dp; a.dones = dones; a.logp = logp;
+  a.bmean = bmean; a.bvar = bvar; a.pmeanA = pmeanA; a.pvarA = pvarA; a.pmeanB = pmeanB; a.pvarB = pvarB;
+  a.beps = beps; a.peps = peps; a.Pb = params_base; a.Pp = params_pot; a.gamma = gamma; a.scale = scale; a.R = R;
+  a.n_expert = n_expert; a.Ab = Ab; a.ldab = ldab; a.Db1 = Db1; a.Ap = Ap; a.ldap = ldap; a.H1 = H1; a.Dp1 = Dp1; a.Dp2 = Dp2;
+  a.part = partials; a.part_stride = ptot;
+  a.off_b_wout = AH * Db + AH; a.off_b_bout = a.off_b_wout + AH;
+  a.off_p_wout = nb + AH * Dp + AH + AH * AH + AH; a.off_p_bout = a.off_p_wout + AH;
+  a.logits = logits; a.stats = stats; a.bce_part = bce_part; a.ticket = ticket;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(airl_rows_kernel, dim3(nblk), dim3(A_THREADS), 0, st, a);
+  IA_CHECK_LAUNCH();
+  // hidden-layer weight gradients: dW = delta^T . input over the rows, one split-K slab per 128 (256) rows; bias
+  // gradients = column sums of delta. Slab s of `partials` is what workgroup s of the rows kernel wrote into.
+  auto wgrad = [&](const float* delta, const float* in, int ldin, int N, int K, long long w_off, long long b_off) {
+    IaGemm w{};
+    w.A = delta; w.lda = AH; w.B = in; w.ldb = ldin; w.M = AH; w.N = N; w.K = K;
+    w.C = partials + w_off; w.ldc = N; w.splits = nblk; w.k_per_split = ((K + nblk - 1) / nblk + 31) / 32 * 32;
+    w.c_split_stride = ptot; w.dbias = partials + b_off; w.dbias_split_stride = ptot;
+    return ia_launch_gemm(IA_GEMM_TN, w, st);
+  };
+  int rc = wgrad(Db1, Ab, ldab, Db, R, 0, (long long)AH * Db);
+  if (rc) return rc;
+  rc = wgrad(Dp1, Ap, ldap, Dp, 2 * R, nb, (long long)nb + AH * Dp);
+  if (rc) return rc;
+  return wgrad(Dp2, H1, AH, AH, 2 * R, (long long)nb + AH * Dp + AH, (long long)nb + AH * Dp + AH + AH * AH);
+}
+
+}  // extern "C"

@@ -24,6 +24,7 @@ from imitation_amd.networks import (DenseStack, RunningNorm, TransitionTable, ev
 
 # tuning / tests: False forces the general (unfused) discriminator update even where the fused one applies
 FUSED_DISC_STEP = True
+FUSED_AIRL_STEP = True    # shaped reward nets of the default geometry take `ShapedRewardNet.disc_step_fused` (tests flip it)
 
 
 class ParamStore:
@@ -511,6 +512,74 @@ class ShapedRewardNet(ForwardWrapper):
         if logp is None:
             raise TypeError("Non-None `log_policy_act_prob` is required for this method.")
         return self._shaped(sources, "disc", True, logp)
+
+    # ---- fused update (csrc/airl_fused.hip): the scripts' default geometry in 5 launches behind the batch assembly
+    def fused_step_ok(self) -> bool:
+        base, pot = self._base.mlp, self.potential._potential_net
+        if len(base.dims) != 3 or len(pot.dims) != 4 or base.dims[-1] != 1 or pot.dims[-1] != 1:
+            return False
+        if base.desc.hidden_act != L.ACT_RELU or pot.desc.hidden_act != L.ACT_RELU or not FUSED_AIRL_STEP:
+            return False
+        return bool(L.load().ia_airl_fused_ok(base.dims[0], pot.dims[0], base.dims[1], pot.dims[1], pot.dims[2]))
+
+    def disc_step_fused(self, sources, logp: th.Tensor, scale: float, stats_dev: th.Tensor, adam) -> th.Tensor:
+        """One whole `train_disc` minibatch (= batch) of `common.py:317-374` for this net: assemble, train-mode input
+        statistics (potential: next-state batch, then state batch, `reward_nets.py:708-710` order), then
+        `ia_airl_step_shaped` (forward, logits, BCE + statistics, deltas, weight-gradient GEMMs) and the split-K
+        reduction fused with Adam. Returns the logits `[R]`."""
+        base, pot = self._base, self.potential._potential_net
+        bm = base.mlp
+        R = sum(n for _, _, n in sources)
+        n_expert = sources[0][2]
+        dev = self.device
+        ws = self._aux.get(("fused", R))
+        if ws is None:
+            nblk = int(L.load().ia_airl_fused_slabs(R))
+            P = bm.n_params + pot.n_params
+            ws = dict(Xb=th.zeros(R, bm.ldx, device=dev), Sn=th.zeros(R, pot.ldx, device=dev),
+                      Sc=th.zeros(R, pot.ldx, device=dev), dones4=th.zeros(R, 4, device=dev), dones=th.empty(R, device=dev),
+                      Ab=th.empty(R, bm.ldx, device=dev), Db1=th.empty(R, 32, device=dev),
+                      Ap=th.empty(2 * R, pot.ldx, device=dev), H1=th.empty(2 * R, 32, device=dev),
+                      Dp1=th.empty(2 * R, 32, device=dev), Dp2=th.empty(2 * R, 32, device=dev),
+                      part=th.empty(nblk, P, device=dev), logits=th.empty(R, device=dev),
+                      bce_part=th.zeros(nblk * 8, device=dev), ticket=th.zeros(1, dtype=th.int32, device=dev),
+                      snapA=th.empty(2, pot.dims[0], device=dev), nblk=nblk)
+            self._aux[("fused", R)] = ws
+        row = 0
+        for table, idx, n in sources:
+            gather_concat(table, idx, n, base.obs_dim, base.act_dim, base.flags, ws["Xb"], bm.ldx, row)
+            gather_concat(table, idx, n, base.obs_dim, base.act_dim, (True, False, False, False), ws["Sn"], pot.ldx, row,
+                          state_from_next=True)
+            gather_concat(table, idx, n, base.obs_dim, base.act_dim, (True, False, False, False), ws["Sc"], pot.ldx, row)
+            gather_concat(table, idx, n, base.obs_dim, base.act_dim, (False, False, False, True), ws["dones4"], 4, row)
+            row += n
+        ws["dones"].copy_(ws["dones4"][:, 0])
+        bn, pn = bm.norm, pot.norm
+        if bn is not None and bm.training:
+            bn.update_stats(ws["Xb"], ldx=bm.ldx, rows=R)
+        A_mean = A_var = None
+        if pn is not None:
+            if pot.training:   # h(s') is normalised with the statistics after ITS update, h(s) after the second one
+                pn.update_stats(ws["Sn"], ldx=pot.ldx, rows=R)
+                ws["snapA"][0].copy_(pn.running_mean)
+                ws["snapA"][1].copy_(pn.running_var)
+                pn.update_stats(ws["Sc"], ldx=pot.ldx, rows=R)
+                A_mean, A_var = ws["snapA"][0], ws["snapA"][1]
+            else:
+                A_mean, A_var = pn.running_mean, pn.running_var
+        L.call("ia_airl_step_shaped", L.ptr(ws["Xb"]), bm.ldx, bm.dims[0], L.ptr(ws["Sn"]), L.ptr(ws["Sc"]), pot.ldx,
+               pot.dims[0], L.ptr(ws["dones"]), L.ptr(logp),
+               L.ptr(bn.running_mean) if bn is not None else None, L.ptr(bn.running_var) if bn is not None else None,
+               float(bn.eps) if bn is not None else 0.0,
+               L.ptr(A_mean), L.ptr(A_var), L.ptr(pn.running_mean) if pn is not None else None,
+               L.ptr(pn.running_var) if pn is not None else None, float(pn.eps) if pn is not None else 0.0,
+               L.ptr(bm.flat), L.ptr(pot.flat), self.discount_factor, float(scale), R, n_expert,
+               L.ptr(ws["Ab"]), bm.ldx, L.ptr(ws["Db1"]), L.ptr(ws["Ap"]), pot.ldx, L.ptr(ws["H1"]), L.ptr(ws["Dp1"]),
+               L.ptr(ws["Dp2"]), L.ptr(ws["part"]), L.ptr(ws["logits"]), L.ptr(stats_dev), L.ptr(ws["bce_part"]),
+               L.ptr(ws["ticket"]), L.stream())
+        assert adam.flat.data_ptr() == bm.flat.data_ptr() and adam.flat.numel() == bm.n_params + pot.n_params
+        adam.fused_reduce_step(ws["part"], ws["nblk"], 1.0)
+        return ws["logits"]
 
     def disc_backward(self, d_logits, accumulate, adam=None):
         wg, wn, wc, aux, R = self._last

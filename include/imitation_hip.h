@@ -202,6 +202,23 @@ int ia_airl_logits(const float* g, const float* h_cur, const float* h_next, cons
 int ia_airl_route_grad(const float* dlogits, const float* dones, float gamma, int R, float* dg, float* dh_cur,
                        float* dh_next, void* stream);
 
+/* ONE AIRL discriminator update for the scripts' default shaped reward net (adversarial/airl.py:99-132,
+ * rewards/reward_nets.py:674-809: reward MLP Db -> 32 -> 1 on [s | a | s' | done], potential MLP Dp -> 32 -> 32 -> 1 on
+ * s' and s, ReLU) without the ~40 launches of the stack-by-stack path (csrc/airl_fused.hip): one MFMA kernel over the
+ * rows (normalise with the given statistics -- potential: `A` after the next-state update, `B` after the state update
+ * -- three forwards, logits = g + gamma (1-done) h(s') - h(s) - log pi, BCE + statistics, deltas) and the three
+ * hidden-layer weight-gradient GEMMs. `partials` = [ia_airl_fused_slabs(R)][n_params] split-K slabs (base stack's
+ * parameters first, torch order) for ia_reduce_partials(_adam). Returns -2 for other geometries (ia_airl_fused_ok:
+ * widths 32, input widths <= 64). */
+int ia_airl_fused_ok(int Db, int Dp, int hb, int hp1, int hp2);
+int ia_airl_fused_slabs(int R);
+int ia_airl_step_shaped(const float* Xb, int ldb, int Db, const float* Sn, const float* Sc, int ldp, int Dp,
+                        const float* dones, const float* logp, const float* bmean, const float* bvar, float beps,
+                        const float* pmeanA, const float* pvarA, const float* pmeanB, const float* pvarB, float peps,
+                        const float* params_base, const float* params_pot, float gamma, float scale, int R, int n_expert,
+                        float* Ab, int ldab, float* Db1, float* Ap, int ldap, float* H1, float* Dp1, float* Dp2,
+                        float* partials, float* logits, float* stats, float* bce_part, unsigned* ticket, void* stream);
+
 /* rewards/reward_nets.py:637-671 `NormalizedRewardNet.predict_processed` applied once per env
  * step: out[t,:] = (raw[t,:]-mean)/sqrt(var+eps) with the statistics of steps < t, then (when
  * update_stats) the Chan update with raw[t,:]. mean/var are 1-element buffers, count int32. */

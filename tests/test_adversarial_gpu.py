@@ -132,6 +132,31 @@ def test_pipelined_rounds_are_bit_identical(tmp_path, case):
     assert len(logs[True]["progress.csv"]) == 4
 
 
+@pytest.mark.parametrize("over", [dict(), dict(demo_batch=300, n_demo=400, norm_disc=False),
+                                  dict(obs_dim=17, act_dim=6, demo_batch=640, n_demo=700)])
+def test_fused_airl_update_matches_the_general_schedule(over, tmp_path, monkeypatch):
+    """`ShapedRewardNet.disc_step_fused` (csrc/airl_fused.hip: one row-kernel + three split-K weight-gradient GEMMs +
+    reduce/Adam) against the layer-by-layer schedule it replaces, over whole training runs: same statistics, logits
+    and parameters up to fp32 summation order (one and several 256-row blocks, ragged last block, with and without
+    input normalisation)."""
+    from imitation_amd import reward_nets as rn
+
+    calls = []
+    orig = rn.ShapedRewardNet.disc_step_fused
+    monkeypatch.setattr(rn.ShapedRewardNet, "disc_step_fused",
+                        lambda self, *a, **k: (calls.append(1), orig(self, *a, **k))[1])
+    cfg = dict(harness.CASES["airl_box"], **over)
+    outs = {}
+    for fused in (True, False):
+        monkeypatch.setattr(rn, "FUSED_AIRL_STEP", fused)
+        tr, _ = harness.build_trainer("hip", cfg, str(tmp_path / str(fused)), device="cuda")
+        tr.train(cfg["rounds"] * cfg["n_envs"] * cfg["n_steps"])
+        outs[fused] = harness.snapshot(tr)
+    assert len(calls) == cfg["rounds"] * cfg["n_disc"]
+    worst = _compare(outs[True], outs[False], cfg)
+    print("fused AIRL vs general, max abs deviation:", max(worst.values()), max(worst, key=worst.get))
+
+
 def test_persistent_update_refuses_a_grid_that_cannot_be_resident(tmp_path):
     """`ia_ppo_update` meets at grid barriers, so every workgroup must be resident at once. The entry point checks
     occupancy x compute units against its grid and returns IA_ERR_UNSUPPORTED instead of launching; `PPO.train` then
