@@ -304,11 +304,10 @@ def run_image_variant(rounds=3, warm=2):
                       "minibatch 256 x 4 epochs, demo batch 512 x 2 updates"}
 
 
-def run_variant(name, rounds=4, warm=3):
+def build_variant(name):
+    """The trainer of one non-image variant, untrained."""
     import imitation_amd as p
     from imitation_amd.vec_env import SyntheticVecEnv
-    if name == "image_gail_64x16_cnn":
-        return run_image_variant()
     algo_name, n_envs, n_steps, od, ad, ppo_batch, n_epochs, demo_batch, n_disc, capacity, net_kw, ex = VARIANTS[name]
     discrete = ex.get("discrete", False)
     th.manual_seed(0)
@@ -339,7 +338,13 @@ def run_variant(name, rounds=4, warm=3):
     tr = cls(demonstrations=demos, demo_batch_size=demo_batch, venv=venv, gen_algo=algo, reward_net=net,
              n_disc_updates_per_round=n_disc, gen_replay_buffer_capacity=capacity,
              custom_logger=p.configure_logger(tempfile.mkdtemp(prefix="bench-var-"), []))
-    per = n_envs * n_steps
+    return tr, n_envs * n_steps
+
+
+def run_variant(name, rounds=4, warm=3):
+    if name == "image_gail_64x16_cnn":
+        return run_image_variant()
+    tr, per = build_variant(name)
     tr.train(warm * per)
     th.cuda.synchronize()
     t0 = time.perf_counter()

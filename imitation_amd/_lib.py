@@ -25,6 +25,12 @@ class MlpDesc(C.Structure):
     _fields_ = [("n_layers", C.c_int), ("dims", C.c_int * (IA_MAX_LAYERS + 1)), ("hidden_act", C.c_int)]
 
 
+class AdamArgs(C.Structure):
+    """Mirror of `ia_adam_args` (include/imitation_hip.h)."""
+    _fields_ = ([(n, C.c_void_p) for n in ("grads", "exp_avg", "exp_avg_sq")] +
+                [(n, C.c_float) for n in ("beta1", "beta2", "eps", "weight_decay", "step_size", "bc2_sqrt")])
+
+
 class PolicyDesc(C.Structure):
     _fields_ = [("obs_dim", C.c_int), ("act_dim", C.c_int), ("hidden", C.c_int), ("discrete", C.c_int),
                 ("has_norm", C.c_int), ("norm_eps", C.c_float)]
@@ -72,8 +78,11 @@ _SIGS = {
                                C.POINTER(C.c_int), _P, _P], C.c_int),
     "ia_airl_fused_ok": ([_I, _I, _I, _I, _I], C.c_int),
     "ia_airl_fused_slabs": ([_I], C.c_int),
+    "ia_airl_prepare": ([_P] * 6 + [_I] + [_P] * 6 + [_I] + [_I] * 6 + [_P, _I, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P],
+                        C.c_int),
+    "ia_airl_stats_merge": ([_P, _P, _P, _I, _I, _I] + [_P] * 9, C.c_int),
     "ia_airl_step_shaped": ([_P, _I, _I, _P, _P, _I, _I, _P, _P, _P, _P, _F, _P, _P, _P, _P, _F, _P, _P, _F, _F, _I, _I,
-                            _P, _I, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P], C.c_int),
+                            _P, _I, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P], C.c_int),
     "ia_conv1_u8_implicit_ok": ([_I, _I, _I, _I, _I, _I, _I], C.c_int),
     "ia_conv1_u8_forward": ([_P, _I, _I, _I, _P, _P, _F, _P, _P, _P], C.c_int),
     "ia_conv1_u8_wgrad_ws_floats": ([_I], C.c_longlong),
@@ -172,7 +181,15 @@ def ptr(t: Optional[th.Tensor]):
     return t.data_ptr()
 
 
+_raw_stream = getattr(th._C, "_cuda_getCurrentRawStream", None)
+_raw_device = getattr(th._C, "_cuda_getDevice", None)
+
+
 def stream():
+    """Raw handle of torch's current stream on the current device (the C-level getters when this torch has them:
+    `current_stream().cuda_stream` costs ~5 us of Python per call, and every launch asks)."""
+    if _raw_stream is not None and _raw_device is not None:
+        return _raw_stream(_raw_device())
     return th.cuda.current_stream().cuda_stream
 
 

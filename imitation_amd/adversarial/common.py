@@ -339,7 +339,7 @@ class AdversarialTrainer(abc.ABC):
                                                                                         self._discrete, self._device)
         return (e_tab, e_idx), (g_tab, g_idx)
 
-    def _policy_pass(self, sources, mb: int) -> Optional[th.Tensor]:
+    def _policy_pass(self, sources, mb: int, assembled: bool = False) -> Optional[th.Tensor]:
         """`common.py:606-615`: log pi(a|s) of the 2*mb rows under no_grad. For GAIL the value is
         discarded (`gail.py:157`) but the call still updates a train-mode feature RunningNorm
         (SURVEY App. C.2), so the statistics update is replayed even when logp is not needed."""
@@ -359,7 +359,7 @@ class AdversarialTrainer(abc.ABC):
                 self._quirk_item += 1
         R = 2 * mb
         row = 0
-        for table, idx, n in sources:
+        for table, idx, n in ([] if assembled else sources):   # (assembled: `_pol_obs` / `_pol_act` already hold the rows)
             networks.gather_concat(table, idx, n, pol.obs_dim, pol.act_dim, (True, False, False, False),
                                    self._pol_obs, pol.obs_dim, row)
             if self._needs_logp:
@@ -529,18 +529,23 @@ class AdversarialTrainer(abc.ABC):
                 if self.disc_grad_penalty_coef > 0.0:
                     raise NotImplementedError("disc_grad_penalty_coef > 0 is implemented for BasicRewardNet "
                                               "discriminators (GAIL; state-holder or imitation_amd.modules net)")
-                logp = None if (quirk_done and not self._needs_logp) else self._policy_pass(sources, mb)
-                if (isinstance(basic, reward_nets.ShapedRewardNet) and B == mb and fuse_adam is not None
-                        and logp is not None and basic.fused_step_ok()):
-                    # AIRL's default shaped net: forward, BCE, backward, reduction + Adam in five launches
-                    logits = basic.disc_step_fused(sources, logp, scale, stats_dev, fuse_adam)
+                if (self._needs_logp and isinstance(basic, reward_nets.ShapedRewardNet) and B == mb
+                        and fuse_adam is not None and self._torch_opt_params is None and basic.fused_step_ok()
+                        and hasattr(pol, "log_prob_rows")):
+                    # AIRL's default shaped net: one assembly launch for the net's and the policy's rows (+ one for the
+                    # input statistics), log pi(a|s), then forward, BCE, backward, reduction + Adam in five launches
+                    basic.fused_prepare(sources, self._pol_obs, self._pol_act)
+                    logp = self._policy_pass(sources, mb, assembled=True)
+                    logits = basic.fused_finish(logp, scale, stats_dev, fuse_adam)
                     fused_step = True
-                else:
-                    logits = net.disc_forward(sources, mb, logp)
-                    L.call("ia_bce_logits", L.ptr(logits), 2 * mb, mb, scale, L.ptr(self._dlogits),
-                           L.ptr(stats_dev), L.ptr(self._bce_ws), L.stream())
-                    fused_step = bool(net.disc_backward(self._dlogits, accumulate=not first,
-                                                        adam=fuse_adam if (B == mb) else None))
+                    first = False
+                    continue
+                logp = None if (quirk_done and not self._needs_logp) else self._policy_pass(sources, mb)
+                logits = net.disc_forward(sources, mb, logp)
+                L.call("ia_bce_logits", L.ptr(logits), 2 * mb, mb, scale, L.ptr(self._dlogits),
+                       L.ptr(stats_dev), L.ptr(self._bce_ws), L.stream())
+                fused_step = bool(net.disc_backward(self._dlogits, accumulate=not first,
+                                                    adam=fuse_adam if (B == mb) else None))
             first = False
         if self._dp is not None:  # one flat-bucket all-reduce per discriminator step
             self._dp.allreduce_mean_(net._store.grad)

@@ -24,7 +24,9 @@
 
 #include <cstdint>
 
+#include "../../include/imitation_hip.h"
 #include "common.h"
+#include "rn_common.h"
 
 namespace {
 
@@ -355,6 +357,186 @@ __global__ __launch_bounds__(A_THREADS) void airl_rows_kernel(AirlArgs a) {
   if (tid == 0) __hip_atomic_store(a.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+
+// ---- batch assembly + input statistics in one launch ---------------------------------------------------------------
+// One [expert | generator] source of a minibatch: rows `idx` (null: the first n) of a transition table.
+struct AirlSrc {
+  const float *obs, *act_f32;
+  const int64_t* act_i64;
+  const float* next_obs;
+  const uint8_t* dones;
+  const int64_t* idx;
+};
+
+struct AirlPrep {
+  AirlSrc s[2];
+  int n0, R, obs_dim, act_dim, use_state, use_action, use_next, use_done;
+  float *Xb; int ldb, Db;           // [R, ldb] = [state | action (one-hot) | next state | done] as flagged
+  float *Sn, *Sc; int ldp;          // [R, ldp] next observations, observations
+  float *dones;                     // [R] 0 / 1
+  float *ws_b, *ws_n, *ws_c;        // slab moments [slabs][2][D] of the three matrices (null: not wanted)
+  float *pol_obs, *pol_act;         // [R, obs_dim] observations, [R, act_dim] actions / [R] action index (null: not wanted)
+};
+
+// The workgroup's slab of one assembled matrix: element (row, c) comes from `val(k, c)` (k = the thread's k-th row),
+// is stored, and feeds the slab moments with rn_partial_kernel's thread mapping and summation order (mlp.hip:104),
+// so the statistics equal those of a stand-alone update of the stored matrix bit for bit.
+template <class F>
+__device__ __forceinline__ void assemble_slab(F val, float* __restrict__ X, int ldx, int D, int r0, int rows,
+                                              float* __restrict__ ws, float (&red)[8][33]) {
+  const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
+  constexpr int RPT = RN_ROWS_PER_BLOCK / 8;
+  for (int c0 = 0; c0 < D; c0 += 32) {
+    const int c = c0 + cl;
+    float v[RPT];
+#pragma unroll
+    for (int k = 0; k < RPT; ++k) v[k] = val(k, min(c, D - 1));
+#pragma unroll
+    for (int k = 0; k < RPT; ++k)
+      if (c < D && rl + 8 * k < rows) X[(long long)(r0 + rl + 8 * k) * ldx + c] = v[k];
+    if (ws == nullptr) continue;
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < RPT; ++k) s += (c < D && rl + 8 * k < rows) ? v[k] : 0.f;
+    red[rl][cl] = s;
+    __syncthreads();
+    float mean = 0.f;
+    if (rl == 0) {
+      float t = 0.f;
+      for (int k = 0; k < 8; ++k) t += red[k][cl];
+      mean = t / (float)rows;
+      red[0][cl] = mean;
+    }
+    __syncthreads();
+    mean = red[0][cl];
+    __syncthreads();
+    float q = 0.f;
+#pragma unroll
+    for (int k = 0; k < RPT; ++k) {
+      const float dlt = v[k] - mean;
+      q += (c < D && rl + 8 * k < rows) ? dlt * dlt : 0.f;
+    }
+    red[rl][cl] = q;
+    __syncthreads();
+    if (rl == 0 && c < D) {
+      float t = 0.f;
+      for (int k = 0; k < 8; ++k) t += red[k][cl];
+      ws[((long long)blockIdx.x * 2 + 0) * D + c] = mean;
+      ws[((long long)blockIdx.x * 2 + 1) * D + c] = t;
+    }
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(256) void airl_prepare_kernel(AirlPrep a) {
+  __shared__ float red[8][33];
+  constexpr int RPT = RN_ROWS_PER_BLOCK / 8;
+  const int r0 = blockIdx.x * RN_ROWS_PER_BLOCK;
+  const int rows = min(RN_ROWS_PER_BLOCK, a.R - r0);
+  const int rl = threadIdx.x >> 5;
+  // table row and source of the thread's rows (rows past the slab's end repeat its last one; never stored or summed)
+  long long src[RPT];
+  int which[RPT];
+#pragma unroll
+  for (int k = 0; k < RPT; ++k) {
+    const int i = r0 + min(rl + 8 * k, rows - 1);
+    const int w = i >= a.n0 ? 1 : 0, j = i - (w ? a.n0 : 0);
+    which[k] = w;
+    const int64_t* ix = w ? a.s[1].idx : a.s[0].idx;
+    src[k] = ix ? ix[j] : j;
+  }
+  for (int i = threadIdx.x; i < rows; i += 256) {
+    const int g = r0 + i, w = g >= a.n0 ? 1 : 0, j = g - (w ? a.n0 : 0);
+    const int64_t* ix = w ? a.s[1].idx : a.s[0].idx;
+    const long long sr = ix ? ix[j] : j;
+    a.dones[g] = (w ? a.s[1].dones : a.s[0].dones)[sr] ? 1.f : 0.f;
+  }
+  const int od = a.obs_dim, ad = a.act_dim;
+  const int e_state = a.use_state ? od : 0, e_act = e_state + (a.use_action ? ad : 0), e_next = e_act + (a.use_next ? od : 0);
+  // (per-row table pointers are SELECTED, not indexed: a lane-dependent index into the argument struct would put every
+  // access behind a second, dependent load)
+  const float *obs0 = a.s[0].obs, *obs1 = a.s[1].obs, *nxt0 = a.s[0].next_obs, *nxt1 = a.s[1].next_obs;
+  const float *af0 = a.s[0].act_f32, *af1 = a.s[1].act_f32;
+  const int64_t *ai0 = a.s[0].act_i64, *ai1 = a.s[1].act_i64;
+  const uint8_t *dn0 = a.s[0].dones, *dn1 = a.s[1].dones;
+  const bool disc = ai0 != nullptr;
+  auto obs_of = [&](int k) { return which[k] ? obs1 : obs0; };
+  auto nxt_of = [&](int k) { return which[k] ? nxt1 : nxt0; };
+  auto act_value = [&](int k, int o, bool onehot) -> float {
+    if (disc) {
+      const int64_t v = (which[k] ? ai1 : ai0)[src[k]];
+      return onehot ? (v == o ? 1.f : 0.f) : (float)v;
+    }
+    return (which[k] ? af1 : af0)[src[k] * ad + o];
+  };
+  assemble_slab([&](int k, int c) -> float {
+    const long long sr = src[k];
+    if (c < e_state) return obs_of(k)[sr * od + c];
+    if (c < e_act) return act_value(k, c - e_state, true);
+    if (c < e_next) return nxt_of(k)[sr * od + (c - e_act)];
+    return (which[k] ? dn1 : dn0)[sr] ? 1.f : 0.f;
+  }, a.Xb, a.ldb, a.Db, r0, rows, a.ws_b, red);
+  assemble_slab([&](int k, int c) -> float { return nxt_of(k)[src[k] * od + c]; }, a.Sn, a.ldp, od, r0, rows, a.ws_n, red);
+  assemble_slab([&](int k, int c) -> float { return obs_of(k)[src[k] * od + c]; }, a.Sc, a.ldp, od, r0, rows, a.ws_c, red);
+  if (a.pol_obs)   // the generator policy's inputs for log pi(a|s): the same rows, unpadded
+    assemble_slab([&](int k, int c) -> float { return obs_of(k)[src[k] * od + c]; }, a.pol_obs, od, od, r0, rows, nullptr,
+                  red);
+  if (a.pol_act) {
+    const int aw = disc ? 1 : ad;
+    assemble_slab([&](int k, int c) -> float { return act_value(k, c, false); }, a.pol_act, aw, aw, r0, rows, nullptr, red);
+  }
+}
+
+// The train-mode statistics updates of one forward (util/networks.py:111-134; reference order reward_nets.py:708-710):
+// base input norm with the assembled batch; potential input norm with the next-state batch -- the statistics h(s') is
+// normalised with, copied to `snapA` -- and then with the state batch. One wave per column; the workgroup that draws
+// the last ticket bumps the sample counts once every column has read them.
+__global__ __launch_bounds__(64) void airl_stats_merge_kernel(const float* __restrict__ ws_b, const float* __restrict__ ws_n,
+                                                              const float* __restrict__ ws_c, int R, int Db, int Dp,
+                                                              float* __restrict__ bmean, float* __restrict__ bvar,
+                                                              int32_t* __restrict__ bcount, float* __restrict__ pmean,
+                                                              float* __restrict__ pvar, int32_t* __restrict__ pcount,
+                                                              float* __restrict__ snapA, unsigned* __restrict__ ticket) {
+  const int lane = threadIdx.x;
+  const int nblocks = (R + RN_ROWS_PER_BLOCK - 1) / RN_ROWS_PER_BLOCK;
+  const int nbase = ws_b ? Db : 0;
+  if ((int)blockIdx.x < nbase) {
+    const int c = blockIdx.x, cnt = *bcount;
+    float bm, bq;
+    rn_wave_batch_moments(ws_b, nblocks, nblocks, R, Db, c, lane, bm, bq);
+    if (lane == 0) {
+      float mc = bmean[c], vc = bvar[c];
+      rn_absorb(mc, vc, cnt, R, bm, bq / (float)R);
+      bmean[c] = mc;
+      bvar[c] = vc;
+    }
+  } else {
+    const int c = blockIdx.x - nbase, cnt = *pcount;
+    float bm, bq, cm, cq;
+    rn_wave_batch_moments(ws_n, nblocks, nblocks, R, Dp, c, lane, bm, bq);
+    rn_wave_batch_moments(ws_c, nblocks, nblocks, R, Dp, c, lane, cm, cq);
+    if (lane == 0) {
+      float mc = pmean[c], vc = pvar[c];
+      rn_absorb(mc, vc, cnt, R, bm, bq / (float)R);
+      snapA[c] = mc;
+      snapA[Dp + c] = vc;
+      rn_absorb(mc, vc, rn_count_add(cnt, R), R, cm, cq / (float)R);
+      pmean[c] = mc;
+      pvar[c] = vc;
+    }
+  }
+  if (lane == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned tk = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tk == gridDim.x - 1) {
+      if (ws_b) *bcount = rn_count_add(*bcount, R);
+      if (ws_n) *pcount = rn_count_add(rn_count_add(*pcount, R), R);
+      __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -367,7 +549,9 @@ int ia_airl_fused_ok(int Db, int Dp, int hb, int hp1, int hp2) {
 /* Slabs of the split-K partial buffer (= workgroups of the rows kernel) an update of R rows uses. */
 int ia_airl_fused_slabs(int R) { return R > 0 ? (R + A_ROWS - 1) / A_ROWS : 0; }
 
-/* One discriminator update, device half: rows kernel + the three hidden-layer weight-gradient GEMMs; the caller then
+/* One discriminator update, device half: rows kernel + the three hidden-layer weight-gradient GEMMs; with `adam`
+ * given (parameters of the two stacks contiguous, base first), also the split-K reduction fused with the Adam step
+ * (ia_reduce_partials_adam) -- otherwise the caller
  * reduces `partials` ([ia_airl_fused_slabs(R)][n_params], base stack's parameters first) -- e.g. ia_reduce_partials_adam.
  * Inputs: assembled raw batches Xb[R, ldb] / Sn, Sc[R, ldp] ([expert | generator] rows), dones, log pi; statistics
  * as the train-mode updates left them (nullable: no input norm); flat parameters of the two stacks. Workspaces:
@@ -377,7 +561,8 @@ int ia_airl_step_shaped(const float* Xb, int ldb, int Db, const float* Sn, const
                         const float* pmeanA, const float* pvarA, const float* pmeanB, const float* pvarB, float peps,
                         const float* params_base, const float* params_pot, float gamma, float scale, int R, int n_expert,
                         float* Ab, int ldab, float* Db1, float* Ap, int ldap, float* H1, float* Dp1, float* Dp2,
-                        float* partials, float* logits, float* stats, float* bce_part, unsigned* ticket, void* stream) {
+                        float* partials, float* logits, float* stats, float* bce_part, unsigned* ticket,
+                        const ia_adam_args* adam, void* stream) {
   if (!Xb || !Sn || !Sc || !dones || !logp || !params_base || !params_pot || !Ab || !Db1 || !Ap || !H1 || !Dp1 || !Dp2 ||
       !partials || !logits || !stats || !bce_part || !ticket || R <= 0 || n_expert < 0 || n_expert > R)
     return IA_ERR_ARG;
@@ -412,7 +597,58 @@ int ia_airl_step_shaped(const float* Xb, int ldb, int Db, const float* Sn, const
   if (rc) return rc;
   rc = wgrad(Dp1, Ap, ldap, Dp, 2 * R, nb, (long long)nb + AH * Dp);
   if (rc) return rc;
-  return wgrad(Dp2, H1, AH, AH, 2 * R, (long long)nb + AH * Dp + AH, (long long)nb + AH * Dp + AH + AH * AH);
+  rc = wgrad(Dp2, H1, AH, AH, 2 * R, (long long)nb + AH * Dp + AH, (long long)nb + AH * Dp + AH + AH * AH);
+  if (rc || !adam) return rc;
+  if (!adam->grads || !adam->exp_avg || !adam->exp_avg_sq || params_pot != params_base + nb) return IA_ERR_ARG;
+  return ia_reduce_partials_adam(partials, nblk, ptot, 1.0f, adam->grads, const_cast<float*>(params_base), adam->exp_avg,
+                                 adam->exp_avg_sq, adam->beta1, adam->beta2, adam->eps, adam->weight_decay,
+                                 adam->step_size, adam->bc2_sqrt, stream);
+}
+
+/* Batch assembly of one update in ONE launch (adversarial/common.py:564-603, rewards/reward_nets.py:441-457): rows
+ * idx0 (n0 of them, expert) then idx1 (R - n0, generator) of the two transition tables -> Xb[R, ldb] ([state | action,
+ * one-hot when act_i64 | next state | done] as flagged), Sn / Sc[R, ldp] (next observations, observations) and
+ * dones[R]; with ws_* given, also the RunningNorm slab moments of each matrix ([ceil(R/256)][2][D], the layout and
+ * arithmetic of ia_running_norm_partial); with pol_obs / pol_act given, the unpadded observation and action rows the
+ * generator policy's log pi(a|s) reads. Padding columns of the outputs are not written. */
+int ia_airl_prepare(const float* obs0, const float* act0_f32, const int64_t* act0_i64, const float* next0,
+                    const uint8_t* done0, const int64_t* idx0, int n0, const float* obs1, const float* act1_f32,
+                    const int64_t* act1_i64, const float* next1, const uint8_t* done1, const int64_t* idx1, int n1,
+                    int obs_dim, int act_dim, int use_state, int use_action, int use_next_state, int use_done, float* Xb,
+                    int ldb, float* Sn, float* Sc, int ldp, float* dones, float* ws_b, float* ws_n, float* ws_c,
+                    float* pol_obs, float* pol_act, void* stream) {
+  const int Db = (use_state ? obs_dim : 0) + (use_action ? act_dim : 0) + (use_next_state ? obs_dim : 0) + (use_done ? 1 : 0);
+  if (!obs0 || !next0 || !done0 || !obs1 || !next1 || !done1 || n0 < 0 || n1 < 0 || n0 + n1 <= 0 || obs_dim <= 0 ||
+      act_dim <= 0 || Db <= 0 || !Xb || !Sn || !Sc || !dones || ldb < Db || ldp < obs_dim)
+    return IA_ERR_ARG;
+  if ((use_action || pol_act) && ((!act0_f32 && !act0_i64) || (!act1_f32 && !act1_i64))) return IA_ERR_ARG;
+  if ((act0_i64 != nullptr) != (act1_i64 != nullptr)) return IA_ERR_ARG;
+  AirlPrep a{};
+  a.s[0] = AirlSrc{obs0, act0_f32, act0_i64, next0, done0, idx0};
+  a.s[1] = AirlSrc{obs1, act1_f32, act1_i64, next1, done1, idx1};
+  a.n0 = n0; a.R = n0 + n1; a.obs_dim = obs_dim; a.act_dim = act_dim; a.use_state = use_state; a.use_action = use_action;
+  a.use_next = use_next_state; a.use_done = use_done; a.Xb = Xb; a.ldb = ldb; a.Db = Db; a.Sn = Sn; a.Sc = Sc; a.ldp = ldp;
+  a.dones = dones; a.ws_b = ws_b; a.ws_n = ws_n; a.ws_c = ws_c; a.pol_obs = pol_obs; a.pol_act = pol_act;
+  hipLaunchKernelGGL(airl_prepare_kernel, dim3((a.R + RN_ROWS_PER_BLOCK - 1) / RN_ROWS_PER_BLOCK), dim3(256), 0,
+                     (hipStream_t)stream, a);
+  IA_CHECK_LAUNCH();
+  return IA_OK;
+}
+
+/* The train-mode RunningNorm updates of one shaped-net forward from ia_airl_prepare's slab moments, one launch: base
+ * input norm (ws_b null: skipped); potential input norm (ws_n / ws_c null: skipped) with the next-state batch, its
+ * (mean, var) copied to snapA[2][Dp], then with the state batch. `ticket`: one zeroed word (left zeroed). */
+int ia_airl_stats_merge(const float* ws_b, const float* ws_n, const float* ws_c, int R, int Db, int Dp, float* bmean,
+                        float* bvar, int32_t* bcount, float* pmean, float* pvar, int32_t* pcount, float* snapA,
+                        unsigned* ticket, void* stream) {
+  if (R <= 0 || !ticket || (!ws_b && !ws_n) || (ws_b && (!bmean || !bvar || !bcount || Db <= 0)) || ((ws_n != nullptr) != (ws_c != nullptr)) ||
+      (ws_n && (!pmean || !pvar || !pcount || !snapA || Dp <= 0)))
+    return IA_ERR_ARG;
+  const int blocks = (ws_b ? Db : 0) + (ws_n ? Dp : 0);
+  hipLaunchKernelGGL(airl_stats_merge_kernel, dim3(blocks), dim3(64), 0, (hipStream_t)stream, ws_b, ws_n, ws_c, R, Db, Dp,
+                     bmean, bvar, bcount, pmean, pvar, pcount, snapA, ticket);
+  IA_CHECK_LAUNCH();
+  return IA_OK;
 }
 
 }  // extern "C"

@@ -338,6 +338,21 @@ class HipAdam:
                L.ptr(self.flat), L.ptr(self.exp_avg), L.ptr(self.exp_avg_sq), b1, b2, g["eps"], g["weight_decay"],
                g["lr"] / bc1, bc2 ** 0.5, L.stream())
 
+    def next_step_args(self):
+        """Counts one optimiser step and returns its `ia_adam_args` (by reference) for an entry point that finishes
+        with the reduction + Adam launch itself (`ia_airl_step_shaped`)."""
+        g = self.param_groups[0]
+        self.step_count += 1
+        b1, b2 = g["betas"]
+        a = getattr(self, "_c_args", None)
+        if a is None:
+            a = self._c_args = L.AdamArgs()
+        a.grads, a.exp_avg, a.exp_avg_sq = self.grad.data_ptr(), self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr()
+        a.beta1, a.beta2, a.eps, a.weight_decay = b1, b2, g["eps"], g["weight_decay"]
+        a.step_size = g["lr"] / (1.0 - b1 ** self.step_count)
+        a.bc2_sqrt = (1.0 - b2 ** self.step_count) ** 0.5
+        return C.byref(a)
+
     def state_dict(self):
         return {"state": {0: {"step": self.step_count, "exp_avg": self.exp_avg, "exp_avg_sq": self.exp_avg_sq}},
                 "param_groups": [dict(g, params=[0]) for g in self.param_groups]}

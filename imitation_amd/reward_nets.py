@@ -522,64 +522,77 @@ class ShapedRewardNet(ForwardWrapper):
             return False
         return bool(L.load().ia_airl_fused_ok(base.dims[0], pot.dims[0], base.dims[1], pot.dims[1], pot.dims[2]))
 
-    def disc_step_fused(self, sources, logp: th.Tensor, scale: float, stats_dev: th.Tensor, adam) -> th.Tensor:
-        """One whole `train_disc` minibatch (= batch) of `common.py:317-374` for this net: assemble, train-mode input
-        statistics (potential: next-state batch, then state batch, `reward_nets.py:708-710` order), then
-        `ia_airl_step_shaped` (forward, logits, BCE + statistics, deltas, weight-gradient GEMMs) and the split-K
-        reduction fused with Adam. Returns the logits `[R]`."""
+    def fused_prepare(self, sources, pol_obs: Optional[th.Tensor] = None, pol_act: Optional[th.Tensor] = None) -> None:
+        """First half of one whole `train_disc` minibatch (= batch) of `common.py:317-374` for this net: the batch
+        assembly (`ia_airl_prepare`: base inputs, next-state and state batches, dones -- and, when asked, the rows the
+        generator policy's log pi(a|s) reads) and the train-mode input statistics (`ia_airl_stats_merge`; potential:
+        next-state batch, then state batch, `reward_nets.py:708-710` order). Two launches."""
         base, pot = self._base, self.potential._potential_net
         bm = base.mlp
-        R = sum(n for _, _, n in sources)
-        n_expert = sources[0][2]
+        (t0, i0, n0), (t1, i1, n1) = sources
+        R = n0 + n1
         dev = self.device
         ws = self._aux.get(("fused", R))
         if ws is None:
             nblk = int(L.load().ia_airl_fused_slabs(R))
             P = bm.n_params + pot.n_params
+            nrn = -(-R // 256)
             ws = dict(Xb=th.zeros(R, bm.ldx, device=dev), Sn=th.zeros(R, pot.ldx, device=dev),
-                      Sc=th.zeros(R, pot.ldx, device=dev), dones4=th.zeros(R, 4, device=dev), dones=th.empty(R, device=dev),
+                      Sc=th.zeros(R, pot.ldx, device=dev), dones=th.empty(R, device=dev),
                       Ab=th.empty(R, bm.ldx, device=dev), Db1=th.empty(R, 32, device=dev),
                       Ap=th.empty(2 * R, pot.ldx, device=dev), H1=th.empty(2 * R, 32, device=dev),
                       Dp1=th.empty(2 * R, 32, device=dev), Dp2=th.empty(2 * R, 32, device=dev),
                       part=th.empty(nblk, P, device=dev), logits=th.empty(R, device=dev),
-                      bce_part=th.zeros(nblk * 8, device=dev), ticket=th.zeros(1, dtype=th.int32, device=dev),
-                      snapA=th.empty(2, pot.dims[0], device=dev), nblk=nblk)
+                      bce_part=th.zeros(nblk * 8, device=dev), ticket=th.zeros(2, dtype=th.int32, device=dev),
+                      snapA=th.empty(2, pot.dims[0], device=dev), nblk=nblk,
+                      ws_b=th.empty(nrn * 2 * bm.dims[0], device=dev), ws_n=th.empty(nrn * 2 * pot.dims[0], device=dev),
+                      ws_c=th.empty(nrn * 2 * pot.dims[0], device=dev))
+            ws["flags"] = [int(f) for f in base.flags]
+            ws["out"] = (ws["Xb"].data_ptr(), bm.ldx, ws["Sn"].data_ptr(), ws["Sc"].data_ptr(), pot.ldx,
+                         ws["dones"].data_ptr())
             self._aux[("fused", R)] = ws
-        row = 0
-        for table, idx, n in sources:
-            gather_concat(table, idx, n, base.obs_dim, base.act_dim, base.flags, ws["Xb"], bm.ldx, row)
-            gather_concat(table, idx, n, base.obs_dim, base.act_dim, (True, False, False, False), ws["Sn"], pot.ldx, row,
-                          state_from_next=True)
-            gather_concat(table, idx, n, base.obs_dim, base.act_dim, (True, False, False, False), ws["Sc"], pot.ldx, row)
-            gather_concat(table, idx, n, base.obs_dim, base.act_dim, (False, False, False, True), ws["dones4"], 4, row)
-            row += n
-        ws["dones"].copy_(ws["dones4"][:, 0])
         bn, pn = bm.norm, pot.norm
-        if bn is not None and bm.training:
-            bn.update_stats(ws["Xb"], ldx=bm.ldx, rows=R)
-        A_mean = A_var = None
+        upd_b = bn is not None and bm.training
+        upd_p = pn is not None and pot.training
+        pb = ws["ws_b"].data_ptr() if upd_b else None
+        pnx, pc = (ws["ws_n"].data_ptr(), ws["ws_c"].data_ptr()) if upd_p else (None, None)
+        acts = lambda t: (None, t.acts.data_ptr()) if t.discrete else (t.acts.data_ptr(), None)
+        st = L.stream()
+        L.call("ia_airl_prepare", t0.obs.data_ptr(), *acts(t0), t0.next_obs.data_ptr(), t0.dones.data_ptr(), L.ptr(i0), n0,
+               t1.obs.data_ptr(), *acts(t1), t1.next_obs.data_ptr(), t1.dones.data_ptr(), L.ptr(i1), n1, base.obs_dim,
+               base.act_dim, *ws["flags"], *ws["out"], pb, pnx, pc, L.ptr(pol_obs), L.ptr(pol_act), st)
+        if upd_b or upd_p:   # h(s') is normalised with the statistics after ITS update (snapA), h(s) after the second one
+            L.call("ia_airl_stats_merge", pb, pnx, pc, R, bm.dims[0], pot.dims[0],
+                   *((bn.running_mean.data_ptr(), bn.running_var.data_ptr(), bn.count.data_ptr()) if upd_b else (None,) * 3),
+                   *((pn.running_mean.data_ptr(), pn.running_var.data_ptr(), pn.count.data_ptr()) if upd_p else (None,) * 3),
+                   ws["snapA"].data_ptr(), ws["ticket"].data_ptr() + 4, st)
+        self._fused = (ws, R, n0, upd_p)
+
+    def fused_finish(self, logp: th.Tensor, scale: float, stats_dev: th.Tensor, adam) -> th.Tensor:
+        """Second half: `ia_airl_step_shaped` on the prepared batch (forward, logits, BCE + statistics, deltas,
+        weight-gradient GEMMs, split-K reduction fused with Adam: five launches). Returns the logits `[R]`."""
+        base, pot = self._base.mlp, self.potential._potential_net
+        ws, R, n_expert, upd_p = self._fused
+        bn, pn = base.norm, pot.norm
+        A = B = (None, None)
         if pn is not None:
-            if pot.training:   # h(s') is normalised with the statistics after ITS update, h(s) after the second one
-                pn.update_stats(ws["Sn"], ldx=pot.ldx, rows=R)
-                ws["snapA"][0].copy_(pn.running_mean)
-                ws["snapA"][1].copy_(pn.running_var)
-                pn.update_stats(ws["Sc"], ldx=pot.ldx, rows=R)
-                A_mean, A_var = ws["snapA"][0], ws["snapA"][1]
-            else:
-                A_mean, A_var = pn.running_mean, pn.running_var
-        L.call("ia_airl_step_shaped", L.ptr(ws["Xb"]), bm.ldx, bm.dims[0], L.ptr(ws["Sn"]), L.ptr(ws["Sc"]), pot.ldx,
-               pot.dims[0], L.ptr(ws["dones"]), L.ptr(logp),
-               L.ptr(bn.running_mean) if bn is not None else None, L.ptr(bn.running_var) if bn is not None else None,
-               float(bn.eps) if bn is not None else 0.0,
-               L.ptr(A_mean), L.ptr(A_var), L.ptr(pn.running_mean) if pn is not None else None,
-               L.ptr(pn.running_var) if pn is not None else None, float(pn.eps) if pn is not None else 0.0,
-               L.ptr(bm.flat), L.ptr(pot.flat), self.discount_factor, float(scale), R, n_expert,
-               L.ptr(ws["Ab"]), bm.ldx, L.ptr(ws["Db1"]), L.ptr(ws["Ap"]), pot.ldx, L.ptr(ws["H1"]), L.ptr(ws["Dp1"]),
-               L.ptr(ws["Dp2"]), L.ptr(ws["part"]), L.ptr(ws["logits"]), L.ptr(stats_dev), L.ptr(ws["bce_part"]),
-               L.ptr(ws["ticket"]), L.stream())
-        assert adam.flat.data_ptr() == bm.flat.data_ptr() and adam.flat.numel() == bm.n_params + pot.n_params
-        adam.fused_reduce_step(ws["part"], ws["nblk"], 1.0)
+            B = (pn.running_mean.data_ptr(), pn.running_var.data_ptr())
+            A = (ws["snapA"].data_ptr(), ws["snapA"].data_ptr() + 4 * pot.dims[0]) if upd_p else B
+        if adam.flat.data_ptr() != base.flat.data_ptr() or adam.flat.numel() != base.n_params + pot.n_params:
+            raise RuntimeError("the fused AIRL update needs the optimiser over the net's flat parameter buffer")
+        L.call("ia_airl_step_shaped", ws["out"][0], base.ldx, base.dims[0], ws["out"][2], ws["out"][3], pot.ldx,
+               pot.dims[0], ws["out"][5], L.ptr(logp),
+               *((bn.running_mean.data_ptr(), bn.running_var.data_ptr(), float(bn.eps)) if bn is not None else (None, None, 0.0)),
+               *A, *B, float(pn.eps) if pn is not None else 0.0,
+               base.flat.data_ptr(), pot.flat.data_ptr(), self.discount_factor, float(scale), R, n_expert,
+               ws["Ab"].data_ptr(), base.ldx, ws["Db1"].data_ptr(), ws["Ap"].data_ptr(), pot.ldx, ws["H1"].data_ptr(),
+               ws["Dp1"].data_ptr(), ws["Dp2"].data_ptr(), ws["part"].data_ptr(), ws["logits"].data_ptr(),
+               L.ptr(stats_dev), ws["bce_part"].data_ptr(), ws["ticket"].data_ptr(), adam.next_step_args(), L.stream())
         return ws["logits"]
+
+    def disc_step_fused(self, sources, logp: th.Tensor, scale: float, stats_dev: th.Tensor, adam) -> th.Tensor:
+        self.fused_prepare(sources)
+        return self.fused_finish(logp, scale, stats_dev, adam)
 
     def disc_backward(self, d_logits, accumulate, adam=None):
         wg, wn, wc, aux, R = self._last

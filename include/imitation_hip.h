@@ -210,6 +210,12 @@ int ia_airl_route_grad(const float* dlogits, const float* dones, float gamma, in
  * hidden-layer weight-gradient GEMMs. `partials` = [ia_airl_fused_slabs(R)][n_params] split-K slabs (base stack's
  * parameters first, torch order) for ia_reduce_partials(_adam). Returns -2 for other geometries (ia_airl_fused_ok:
  * widths 32, input widths <= 64). */
+typedef struct ia_adam_args {   /* torch.optim.Adam step over one flat buffer, see ia_adam_step */
+  float* grads;                 /* [n] receives the reduced gradient */
+  float* exp_avg;
+  float* exp_avg_sq;
+  float beta1, beta2, eps, weight_decay, step_size /* lr / (1 - b1^t) */, bc2_sqrt /* sqrt(1 - b2^t) */;
+} ia_adam_args;
 int ia_airl_fused_ok(int Db, int Dp, int hb, int hp1, int hp2);
 int ia_airl_fused_slabs(int R);
 int ia_airl_step_shaped(const float* Xb, int ldb, int Db, const float* Sn, const float* Sc, int ldp, int Dp,
@@ -217,7 +223,31 @@ int ia_airl_step_shaped(const float* Xb, int ldb, int Db, const float* Sn, const
                         const float* pmeanA, const float* pvarA, const float* pmeanB, const float* pvarB, float peps,
                         const float* params_base, const float* params_pot, float gamma, float scale, int R, int n_expert,
                         float* Ab, int ldab, float* Db1, float* Ap, int ldap, float* H1, float* Dp1, float* Dp2,
-                        float* partials, float* logits, float* stats, float* bce_part, unsigned* ticket, void* stream);
+                        float* partials, float* logits, float* stats, float* bce_part, unsigned* ticket,
+                        const ia_adam_args* adam /* nullable: reduce the slabs + Adam step in the same call */,
+                        void* stream);
+
+/* Batch assembly of one AIRL update in ONE launch (adversarial/common.py:564-603, rewards/reward_nets.py:441-457): rows
+ * idx0 (n0 of them, expert; null idx = the first n) then idx1 (n1, generator) of two transition tables -> Xb[n0+n1, ldb]
+ * ([state | action, one-hot when act_i64 | next state | done] as flagged), Sn / Sc[., ldp] (next observations,
+ * observations) and dones[.] as 0/1 floats; with ws_* given, also the RunningNorm slab moments of each matrix
+ * ([ceil(R/256)][2][D]: layout and arithmetic of ia_running_norm_partial); with pol_obs / pol_act given, the unpadded
+ * observation / action rows the generator policy's log pi(a|s) is evaluated on (common.py:606-615). Padding columns
+ * are not written. */
+int ia_airl_prepare(const float* obs0, const float* act0_f32, const int64_t* act0_i64, const float* next0,
+                    const uint8_t* done0, const int64_t* idx0, int n0, const float* obs1, const float* act1_f32,
+                    const int64_t* act1_i64, const float* next1, const uint8_t* done1, const int64_t* idx1, int n1,
+                    int obs_dim, int act_dim, int use_state, int use_action, int use_next_state, int use_done, float* Xb,
+                    int ldb, float* Sn, float* Sc, int ldp, float* dones, float* ws_b, float* ws_n, float* ws_c,
+                    float* pol_obs /*[R, obs_dim], nullable*/, float* pol_act /*[R, act_dim] or [R] index, nullable*/,
+                    void* stream);
+/* The train-mode RunningNorm updates of one shaped-net forward (util/networks.py:111-134 in reward_nets.py:708-710's
+ * order) from ia_airl_prepare's slab moments, one launch: base input norm (ws_b null: skipped); potential input norm
+ * (ws_n, ws_c null: skipped) with the next-state batch -- (mean, var) then copied to snapA[2][Dp] -- and with the state
+ * batch. `ticket`: one zeroed word (left zeroed). */
+int ia_airl_stats_merge(const float* ws_b, const float* ws_n, const float* ws_c, int R, int Db, int Dp, float* bmean,
+                        float* bvar, int32_t* bcount, float* pmean, float* pvar, int32_t* pcount, float* snapA,
+                        unsigned* ticket, void* stream);
 
 /* rewards/reward_nets.py:637-671 `NormalizedRewardNet.predict_processed` applied once per env
  * step: out[t,:] = (raw[t,:]-mean)/sqrt(var+eps) with the statistics of steps < t, then (when

@@ -135,15 +135,15 @@ def test_pipelined_rounds_are_bit_identical(tmp_path, case):
 @pytest.mark.parametrize("over", [dict(), dict(demo_batch=300, n_demo=400, norm_disc=False),
                                   dict(obs_dim=17, act_dim=6, demo_batch=640, n_demo=700)])
 def test_fused_airl_update_matches_the_general_schedule(over, tmp_path, monkeypatch):
-    """`ShapedRewardNet.disc_step_fused` (csrc/airl_fused.hip: one row-kernel + three split-K weight-gradient GEMMs +
+    """`ShapedRewardNet.fused_prepare / fused_finish` (csrc/airl_fused.hip: assembly + statistics, one row-kernel + three split-K weight-gradient GEMMs +
     reduce/Adam) against the layer-by-layer schedule it replaces, over whole training runs: same statistics, logits
     and parameters up to fp32 summation order (one and several 256-row blocks, ragged last block, with and without
     input normalisation)."""
     from imitation_amd import reward_nets as rn
 
     calls = []
-    orig = rn.ShapedRewardNet.disc_step_fused
-    monkeypatch.setattr(rn.ShapedRewardNet, "disc_step_fused",
+    orig = rn.ShapedRewardNet.fused_finish
+    monkeypatch.setattr(rn.ShapedRewardNet, "fused_finish",
                         lambda self, *a, **k: (calls.append(1), orig(self, *a, **k))[1])
     cfg = dict(harness.CASES["airl_box"], **over)
     outs = {}

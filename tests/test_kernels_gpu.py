@@ -220,6 +220,68 @@ def test_gather_concat_bit_exact():
             assert np.all(np.isnan(got[:100]))
 
 
+@pytest.mark.parametrize("n0,n1,discrete,use", [(200, 200, False, (1, 1, 0, 0)), (300, 213, True, (1, 1, 1, 1)),
+                                                (64, 64, False, (1, 1, 1, 0))])
+def test_airl_prepare_and_stats_merge_bit_exact(n0, n1, discrete, use):
+    """`ia_airl_prepare` (assembly of the base / next-state / state batches + their RunningNorm slab moments in one
+    launch) and `ia_airl_stats_merge` (the three train-mode updates in one launch) against the per-matrix kernels they
+    replace: every output bit for bit."""
+    rng = np.random.default_rng(1)
+    N, Do, Da = 700, 11, 5
+    R = n0 + n1
+    mk = lambda: dict(obs=dev(rng.standard_normal((N, Do)).astype(np.float32)),
+                      nxt=dev(rng.standard_normal((N, Do)).astype(np.float32) * 2 + 1),
+                      act=dev(rng.uniform(-1, 1, (N, Da)).astype(np.float32)),
+                      acti=dev(rng.integers(0, Da, N), th.int64), done=dev((rng.random(N) < 0.3).astype(np.uint8), th.uint8))
+    t0, t1 = mk(), mk()
+    i0, i1 = dev(rng.integers(0, N, n0), th.int64), None          # generator source: the first n1 rows (null index)
+    Db = use[0] * Do + use[1] * Da + use[2] * Do + use[3]
+    ldb, ldp = (Db + 3) // 4 * 4, (Do + 3) // 4 * 4
+    ref = dict(Xb=th.zeros(R, ldb, device=DEV), Sn=th.zeros(R, ldp, device=DEV), Sc=th.zeros(R, ldp, device=DEV),
+               d4=th.zeros(R, 4, device=DEV))
+    for t, idx, n, row in ((t0, i0, n0, 0), (t1, i1, n1, n0)):
+        af, ai = (None, L.ptr(t["acti"])) if discrete else (L.ptr(t["act"]), None)
+        for obs, flags, X, ld in ((t["obs"], use, ref["Xb"], ldb), (t["nxt"], (1, 0, 0, 0), ref["Sn"], ldp),
+                                  (t["obs"], (1, 0, 0, 0), ref["Sc"], ldp), (t["obs"], (0, 0, 0, 1), ref["d4"], 4)):
+            L.call("ia_gather_concat", L.ptr(obs), af, ai, L.ptr(t["nxt"]), L.ptr(t["done"]), L.ptr(idx), n, Do, Da,
+                   *flags, L.ptr(X), ld, row, L.stream())
+    nrn = -(-R // 256)
+    got = dict(Xb=th.zeros(R, ldb, device=DEV), Sn=th.zeros(R, ldp, device=DEV), Sc=th.zeros(R, ldp, device=DEV),
+               dones=th.empty(R, device=DEV))
+    wsg = {k: th.full((nrn * 2 * D,), float("nan"), device=DEV) for k, D in (("b", Db), ("n", Do), ("c", Do))}
+    acts = lambda t: (None, L.ptr(t["acti"])) if discrete else (L.ptr(t["act"]), None)
+    pol_obs = th.full((R, Do), float("nan"), device=DEV)
+    pol_act = th.full((R, 1 if discrete else Da), float("nan"), device=DEV)
+    L.call("ia_airl_prepare", L.ptr(t0["obs"]), *acts(t0), L.ptr(t0["nxt"]), L.ptr(t0["done"]), L.ptr(i0), n0,
+           L.ptr(t1["obs"]), *acts(t1), L.ptr(t1["nxt"]), L.ptr(t1["done"]), L.ptr(i1), n1, Do, Da, *use,
+           L.ptr(got["Xb"]), ldb, L.ptr(got["Sn"]), L.ptr(got["Sc"]), ldp, L.ptr(got["dones"]), L.ptr(wsg["b"]),
+           L.ptr(wsg["n"]), L.ptr(wsg["c"]), L.ptr(pol_obs), L.ptr(pol_act), L.stream())
+    for k in ("Xb", "Sn", "Sc"):
+        assert th.equal(got[k], ref[k]), k
+    assert th.equal(got["dones"], ref["d4"][:, 0])
+    assert th.equal(pol_obs, ref["Sc"][:, :Do])
+    rows = lambda t, idx, n: (t if idx is None else t[idx])[:n]
+    want_act = th.cat([rows(t0["acti" if discrete else "act"], i0, n0), rows(t1["acti" if discrete else "act"], i1, n1)])
+    assert th.equal(pol_act, want_act.float().reshape(R, -1))
+    # statistics: three stand-alone updates (base; potential with the next-state batch, then with the state batch)
+    st = lambda D: [th.linspace(-1, 1, D, device=DEV), th.linspace(0.5, 2, D, device=DEV),
+                    th.full((), 1000, dtype=th.int32, device=DEV)]
+    rb, rp, gb, gp = st(Db), st(Do), st(Db), st(Do)
+    for X, ld, D, (m, v, c) in ((ref["Xb"], ldb, Db, rb), (ref["Sn"], ldp, Do, rp)):
+        ws = th.empty(int(L.load().ia_running_norm_ws_floats(R, D)), device=DEV)
+        L.call("ia_running_norm_update", L.ptr(X), ld, R, D, L.ptr(m), L.ptr(v), L.ptr(c), L.ptr(ws), L.stream())
+    snap_ref = th.stack([rp[0].clone(), rp[1].clone()])
+    ws = th.empty(int(L.load().ia_running_norm_ws_floats(R, Do)), device=DEV)
+    L.call("ia_running_norm_update", L.ptr(ref["Sc"]), ldp, R, Do, L.ptr(rp[0]), L.ptr(rp[1]), L.ptr(rp[2]), L.ptr(ws),
+           L.stream())
+    snap, ticket = th.empty(2, Do, device=DEV), th.zeros(1, dtype=th.int32, device=DEV)
+    L.call("ia_airl_stats_merge", L.ptr(wsg["b"]), L.ptr(wsg["n"]), L.ptr(wsg["c"]), R, Db, Do, L.ptr(gb[0]), L.ptr(gb[1]),
+           L.ptr(gb[2]), L.ptr(gp[0]), L.ptr(gp[1]), L.ptr(gp[2]), L.ptr(snap), L.ptr(ticket), L.stream())
+    for a, b in zip(gb + gp + [snap], rb + rp + [snap_ref]):
+        assert th.equal(a, b)
+    assert int(ticket.item()) == 0 and int(gp[2].item()) == 1000 + 2 * R
+
+
 @pytest.mark.parametrize("R,ne", [(16384, 8192), (128, 64), (7, 0), (10, 10)])
 def test_bce_logits_and_stats(R, ne):
     from oracle.imitation_restated import compute_train_stats

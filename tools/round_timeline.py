@@ -1,6 +1,6 @@
 """Host and device timeline of overlapped GAIL rounds at config P: when the host finishes each
 enqueue step, and when each stream finishes its work (HIP events), relative to the round start.
-Usage: python tools/round_timeline.py [rounds] [world]"""
+Usage: python tools/round_timeline.py [rounds] [world] [variant]   (variant: a bench.py VARIANTS name instead of P)"""
 import os
 import sys
 import time
@@ -35,8 +35,11 @@ if world > 1:
             return 1234
 
     dp = NullDP(world)
-tr = bench.build_trainer(bench.hip_namespace(), cfg, "cuda", seed=0, dp=dp)
-per_round = cfg["n_envs"] * cfg["n_steps"]
+if len(sys.argv) > 3:
+    tr, per_round = bench.build_variant(sys.argv[3])
+else:
+    tr = bench.build_trainer(bench.hip_namespace(), cfg, "cuda", seed=0, dp=dp)
+    per_round = cfg["n_envs"] * cfg["n_steps"]
 tr.train(3 * per_round)
 th.cuda.synchronize()
 algo = tr.gen_algo
@@ -72,6 +75,8 @@ def wrap(obj, attr, name, dev=False, stream_of=None):
 wrap(algo, "collect_rollouts", "collect_rollouts returned", dev=True)
 wrap(algo, "train", "ppo train enqueued", dev=True)
 wrap(tr, "_disc_round", "disc round enqueued", dev=True)
+wrap(tr.venv_buffering, "pop_transitions_and_lens", "  pop_transitions returned")
+wrap(tr._gen_replay_buffer, "store", "  replay store returned")
 wrap(tr, "_replay_policy_norm_updates", "norm replay enqueued", dev=True)
 _orig_fin = tr._finish_disc_round
 
