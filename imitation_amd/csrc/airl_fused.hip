@@ -359,131 +359,103 @@ __global__ __launch_bounds__(A_THREADS) void airl_rows_kernel(AirlArgs a) {
 
 
 // ---- batch assembly + input statistics in one launch ---------------------------------------------------------------
-// One [expert | generator] source of a minibatch: rows `idx` (null: the first n) of a transition table.
-struct AirlSrc {
-  const float *obs, *act_f32;
-  const int64_t* act_i64;
-  const float* next_obs;
-  const uint8_t* dones;
-  const int64_t* idx;
+// One pass of the assembly: `ncols` consecutive columns of a destination matrix, all of one kind, taken from column
+// `off` on of a per-row source array (expert table for the slab's first rows, generator table for the rest).
+enum { AP_F32 = 0, AP_ONEHOT = 1, AP_DONE = 2, AP_INDEX = 3 };
+struct AirlPass {
+  const void *p0, *p1;   // the two tables' arrays: float [n, stride] (AP_F32), int64 [n] (AP_ONEHOT / AP_INDEX), uint8 [n] (AP_DONE)
+  int kind, stride, off, ncols;
+  float* X; int ldx, xcol;    // destination, its row stride, first destination column
+  float* ws; int wsD;         // slab moments [slabs][2][wsD] of the destination matrix (null: not wanted)
 };
+constexpr int AP_MAX = 12;
 
 struct AirlPrep {
-  AirlSrc s[2];
-  int n0, R, obs_dim, act_dim, use_state, use_action, use_next, use_done;
-  float *Xb; int ldb, Db;           // [R, ldb] = [state | action (one-hot) | next state | done] as flagged
-  float *Sn, *Sc; int ldp;          // [R, ldp] next observations, observations
-  float *dones;                     // [R] 0 / 1
-  float *ws_b, *ws_n, *ws_c;        // slab moments [slabs][2][D] of the three matrices (null: not wanted)
-  float *pol_obs, *pol_act;         // [R, obs_dim] observations, [R, act_dim] actions / [R] action index (null: not wanted)
+  const int64_t *idx0, *idx1;   // rows of the two tables (null: the first n)
+  int n0, R;
+  int n_pass;
+  AirlPass pass[AP_MAX];
 };
 
-// The workgroup's slab of one assembled matrix: element (row, c) comes from `val(k, c)` (k = the thread's k-th row),
-// is stored, and feeds the slab moments with rn_partial_kernel's thread mapping and summation order (mlp.hip:104),
-// so the statistics equal those of a stand-alone update of the stored matrix bit for bit.
-template <class F>
-__device__ __forceinline__ void assemble_slab(F val, float* __restrict__ X, int ldx, int D, int r0, int rows,
-                                              float* __restrict__ ws, float (&red)[8][33]) {
-  const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
-  constexpr int RPT = RN_ROWS_PER_BLOCK / 8;
-  for (int c0 = 0; c0 < D; c0 += 32) {
-    const int c = c0 + cl;
-    float v[RPT];
-#pragma unroll
-    for (int k = 0; k < RPT; ++k) v[k] = val(k, min(c, D - 1));
-#pragma unroll
-    for (int k = 0; k < RPT; ++k)
-      if (c < D && rl + 8 * k < rows) X[(long long)(r0 + rl + 8 * k) * ldx + c] = v[k];
-    if (ws == nullptr) continue;
-    float s = 0.f;
-#pragma unroll
-    for (int k = 0; k < RPT; ++k) s += (c < D && rl + 8 * k < rows) ? v[k] : 0.f;
-    red[rl][cl] = s;
-    __syncthreads();
-    float mean = 0.f;
-    if (rl == 0) {
-      float t = 0.f;
-      for (int k = 0; k < 8; ++k) t += red[k][cl];
-      mean = t / (float)rows;
-      red[0][cl] = mean;
-    }
-    __syncthreads();
-    mean = red[0][cl];
-    __syncthreads();
-    float q = 0.f;
-#pragma unroll
-    for (int k = 0; k < RPT; ++k) {
-      const float dlt = v[k] - mean;
-      q += (c < D && rl + 8 * k < rows) ? dlt * dlt : 0.f;
-    }
-    red[rl][cl] = q;
-    __syncthreads();
-    if (rl == 0 && c < D) {
-      float t = 0.f;
-      for (int k = 0; k < 8; ++k) t += red[k][cl];
-      ws[((long long)blockIdx.x * 2 + 0) * D + c] = mean;
-      ws[((long long)blockIdx.x * 2 + 1) * D + c] = t;
-    }
-    __syncthreads();
-  }
-}
-
 __global__ __launch_bounds__(256) void airl_prepare_kernel(AirlPrep a) {
+  // Workgroup (slab, pass): 256 rows of one pass. Element (row, c) is gathered once, stored, and feeds the slab moments
+  // with rn_partial_kernel's row partition and summation order (mlp.hip:104: 8 row lanes x 32 rows each, lanes folded
+  // in order), so the statistics equal those of a stand-alone update of the stored matrix bit for bit.
   __shared__ float red[8][33];
   constexpr int RPT = RN_ROWS_PER_BLOCK / 8;
   const int r0 = blockIdx.x * RN_ROWS_PER_BLOCK;
   const int rows = min(RN_ROWS_PER_BLOCK, a.R - r0);
-  const int rl = threadIdx.x >> 5;
+  const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
   // table row and source of the thread's rows (rows past the slab's end repeat its last one; never stored or summed)
-  long long src[RPT];
-  int which[RPT];
+  int src[RPT];                 // (tables have < 2^31 rows)
+  unsigned wmask = 0;           // bit k: the thread's k-th row comes from the generator source
+  static_assert(RPT <= 32, "one bit per row");
 #pragma unroll
   for (int k = 0; k < RPT; ++k) {
     const int i = r0 + min(rl + 8 * k, rows - 1);
     const int w = i >= a.n0 ? 1 : 0, j = i - (w ? a.n0 : 0);
-    which[k] = w;
-    const int64_t* ix = w ? a.s[1].idx : a.s[0].idx;
-    src[k] = ix ? ix[j] : j;
+    wmask |= (unsigned)w << k;
+    const int64_t* ix = w ? a.idx1 : a.idx0;
+    src[k] = ix ? (int)ix[j] : j;
   }
-  for (int i = threadIdx.x; i < rows; i += 256) {
-    const int g = r0 + i, w = g >= a.n0 ? 1 : 0, j = g - (w ? a.n0 : 0);
-    const int64_t* ix = w ? a.s[1].idx : a.s[0].idx;
-    const long long sr = ix ? ix[j] : j;
-    a.dones[g] = (w ? a.s[1].dones : a.s[0].dones)[sr] ? 1.f : 0.f;
-  }
-  const int od = a.obs_dim, ad = a.act_dim;
-  const int e_state = a.use_state ? od : 0, e_act = e_state + (a.use_action ? ad : 0), e_next = e_act + (a.use_next ? od : 0);
-  // (per-row table pointers are SELECTED, not indexed: a lane-dependent index into the argument struct would put every
-  // access behind a second, dependent load)
-  const float *obs0 = a.s[0].obs, *obs1 = a.s[1].obs, *nxt0 = a.s[0].next_obs, *nxt1 = a.s[1].next_obs;
-  const float *af0 = a.s[0].act_f32, *af1 = a.s[1].act_f32;
-  const int64_t *ai0 = a.s[0].act_i64, *ai1 = a.s[1].act_i64;
-  const uint8_t *dn0 = a.s[0].dones, *dn1 = a.s[1].dones;
-  const bool disc = ai0 != nullptr;
-  auto obs_of = [&](int k) { return which[k] ? obs1 : obs0; };
-  auto nxt_of = [&](int k) { return which[k] ? nxt1 : nxt0; };
-  auto act_value = [&](int k, int o, bool onehot) -> float {
-    if (disc) {
-      const int64_t v = (which[k] ? ai1 : ai0)[src[k]];
-      return onehot ? (v == o ? 1.f : 0.f) : (float)v;
+  {
+    const AirlPass& P = a.pass[blockIdx.y];
+    for (int c0 = 0; c0 < P.ncols; c0 += 32) {
+      const int c = c0 + cl, cc = min(c, P.ncols - 1);
+      const bool col_on = c < P.ncols;
+      float v[RPT];
+      if (P.kind == AP_F32) {
+        const float *q0 = (const float*)P.p0 + cc, *q1 = (const float*)P.p1 + cc;
+#pragma unroll
+        for (int k = 0; k < RPT; ++k) v[k] = (((wmask >> k) & 1u) ? q1 : q0)[(long long)src[k] * P.stride];
+      } else if (P.kind == AP_DONE) {
+        const uint8_t *q0 = (const uint8_t*)P.p0, *q1 = (const uint8_t*)P.p1;
+#pragma unroll
+        for (int k = 0; k < RPT; ++k) v[k] = (((wmask >> k) & 1u) ? q1 : q0)[src[k]] ? 1.f : 0.f;
+      } else {
+        const int64_t *q0 = (const int64_t*)P.p0, *q1 = (const int64_t*)P.p1;
+#pragma unroll
+        for (int k = 0; k < RPT; ++k) {
+          const int64_t t = (((wmask >> k) & 1u) ? q1 : q0)[src[k]];
+          v[k] = P.kind == AP_ONEHOT ? (t == cc ? 1.f : 0.f) : (float)t;
+        }
+      }
+      float* xp = P.X + (long long)r0 * P.ldx + P.xcol + c;
+#pragma unroll
+      for (int k = 0; k < RPT; ++k)
+        if (col_on && rl + 8 * k < rows) xp[(long long)(rl + 8 * k) * P.ldx] = v[k];
+      if (P.ws == nullptr) continue;
+      float sum = 0.f;
+#pragma unroll
+      for (int k = 0; k < RPT; ++k) sum += (col_on && rl + 8 * k < rows) ? v[k] : 0.f;
+      red[rl][cl] = sum;
+      __syncthreads();
+      float mean = 0.f;
+      if (rl == 0) {
+        float t = 0.f;
+        for (int k = 0; k < 8; ++k) t += red[k][cl];
+        mean = t / (float)rows;
+        red[0][cl] = mean;
+      }
+      __syncthreads();
+      mean = red[0][cl];
+      __syncthreads();
+      float q = 0.f;
+#pragma unroll
+      for (int k = 0; k < RPT; ++k) {
+        const float dlt = v[k] - mean;
+        q += (col_on && rl + 8 * k < rows) ? dlt * dlt : 0.f;
+      }
+      red[rl][cl] = q;
+      __syncthreads();
+      if (rl == 0 && col_on) {
+        float t = 0.f;
+        for (int k = 0; k < 8; ++k) t += red[k][cl];
+        P.ws[((long long)blockIdx.x * 2 + 0) * P.wsD + P.xcol + c] = mean;
+        P.ws[((long long)blockIdx.x * 2 + 1) * P.wsD + P.xcol + c] = t;
+      }
+      __syncthreads();
     }
-    return (which[k] ? af1 : af0)[src[k] * ad + o];
-  };
-  assemble_slab([&](int k, int c) -> float {
-    const long long sr = src[k];
-    if (c < e_state) return obs_of(k)[sr * od + c];
-    if (c < e_act) return act_value(k, c - e_state, true);
-    if (c < e_next) return nxt_of(k)[sr * od + (c - e_act)];
-    return (which[k] ? dn1 : dn0)[sr] ? 1.f : 0.f;
-  }, a.Xb, a.ldb, a.Db, r0, rows, a.ws_b, red);
-  assemble_slab([&](int k, int c) -> float { return nxt_of(k)[src[k] * od + c]; }, a.Sn, a.ldp, od, r0, rows, a.ws_n, red);
-  assemble_slab([&](int k, int c) -> float { return obs_of(k)[src[k] * od + c]; }, a.Sc, a.ldp, od, r0, rows, a.ws_c, red);
-  if (a.pol_obs)   // the generator policy's inputs for log pi(a|s): the same rows, unpadded
-    assemble_slab([&](int k, int c) -> float { return obs_of(k)[src[k] * od + c]; }, a.pol_obs, od, od, r0, rows, nullptr,
-                  red);
-  if (a.pol_act) {
-    const int aw = disc ? 1 : ad;
-    assemble_slab([&](int k, int c) -> float { return act_value(k, c, false); }, a.pol_act, aw, aw, r0, rows, nullptr, red);
   }
 }
 
@@ -624,12 +596,30 @@ int ia_airl_prepare(const float* obs0, const float* act0_f32, const int64_t* act
   if ((use_action || pol_act) && ((!act0_f32 && !act0_i64) || (!act1_f32 && !act1_i64))) return IA_ERR_ARG;
   if ((act0_i64 != nullptr) != (act1_i64 != nullptr)) return IA_ERR_ARG;
   AirlPrep a{};
-  a.s[0] = AirlSrc{obs0, act0_f32, act0_i64, next0, done0, idx0};
-  a.s[1] = AirlSrc{obs1, act1_f32, act1_i64, next1, done1, idx1};
-  a.n0 = n0; a.R = n0 + n1; a.obs_dim = obs_dim; a.act_dim = act_dim; a.use_state = use_state; a.use_action = use_action;
-  a.use_next = use_next_state; a.use_done = use_done; a.Xb = Xb; a.ldb = ldb; a.Db = Db; a.Sn = Sn; a.Sc = Sc; a.ldp = ldp;
-  a.dones = dones; a.ws_b = ws_b; a.ws_n = ws_n; a.ws_c = ws_c; a.pol_obs = pol_obs; a.pol_act = pol_act;
-  hipLaunchKernelGGL(airl_prepare_kernel, dim3((a.R + RN_ROWS_PER_BLOCK - 1) / RN_ROWS_PER_BLOCK), dim3(256), 0,
+  a.idx0 = idx0; a.idx1 = idx1; a.n0 = n0; a.R = n0 + n1;
+  const bool disc = act0_i64 != nullptr;
+  const int od = obs_dim, ad = act_dim;
+  int n = 0, col = 0;
+  auto add = [&](const void* p0, const void* p1, int kind, int stride, int ncols, float* X, int ldx, int xcol, float* ws,
+                 int wsD) { a.pass[n++] = AirlPass{p0, p1, kind, stride, 0, ncols, X, ldx, xcol, ws, wsD}; };
+  if (use_state) { add(obs0, obs1, AP_F32, od, od, Xb, ldb, col, ws_b, Db); col += od; }
+  if (use_action) {
+    if (disc) add(act0_i64, act1_i64, AP_ONEHOT, 1, ad, Xb, ldb, col, ws_b, Db);
+    else add(act0_f32, act1_f32, AP_F32, ad, ad, Xb, ldb, col, ws_b, Db);
+    col += ad;
+  }
+  if (use_next_state) { add(next0, next1, AP_F32, od, od, Xb, ldb, col, ws_b, Db); col += od; }
+  if (use_done) add(done0, done1, AP_DONE, 1, 1, Xb, ldb, col, ws_b, Db);
+  add(next0, next1, AP_F32, od, od, Sn, ldp, 0, ws_n, od);
+  add(obs0, obs1, AP_F32, od, od, Sc, ldp, 0, ws_c, od);
+  add(done0, done1, AP_DONE, 1, 1, dones, 1, 0, nullptr, 0);
+  if (pol_obs) add(obs0, obs1, AP_F32, od, od, pol_obs, od, 0, nullptr, 0);
+  if (pol_act) {
+    if (disc) add(act0_i64, act1_i64, AP_INDEX, 1, 1, pol_act, 1, 0, nullptr, 0);
+    else add(act0_f32, act1_f32, AP_F32, ad, ad, pol_act, ad, 0, nullptr, 0);
+  }
+  a.n_pass = n;
+  hipLaunchKernelGGL(airl_prepare_kernel, dim3((a.R + RN_ROWS_PER_BLOCK - 1) / RN_ROWS_PER_BLOCK, n), dim3(256), 0,
                      (hipStream_t)stream, a);
   IA_CHECK_LAUNCH();
   return IA_OK;
