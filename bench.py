@@ -261,6 +261,11 @@ VARIANTS = {
                             dict(gamma=0.95, clip_range=0.1)),
     "3_airl_ant_1024x16": ("airl", 1024, 16, 27, 8, 1024, 10, 8192, 16, 16384,
                            dict(reward_hid_sizes=(32,), potential_hid_sizes=(32, 32)), dict(normalize_output=True)),
+    # BASELINE config 3 as worded ("BasicShapedRewardNet + grad-penalty"): the opt-in penalty (no reference counterpart)
+    # on the shaped reward's input gradient; the update runs stack by stack + the penalty's two extra passes per stack
+    "3_airl_ant_1024x16_gp": ("airl", 1024, 16, 27, 8, 1024, 10, 8192, 16, 16384,
+                              dict(reward_hid_sizes=(32,), potential_hid_sizes=(32, 32)),
+                              dict(normalize_output=True, grad_penalty=10.0)),
     "1_cartpole_8x256_mlp64": ("gail", 8, 256, 4, 2, 64, 5, 1024, 4, 2048, dict(hid_sizes=(32, 32)),
                                dict(discrete=True, mlp64=True, gamma=0.95)),
     # policy towers outside the fused kernels' shapes (any SB3 `net_arch`): the general minibatch loop
@@ -337,7 +342,8 @@ def build_variant(name):
     demos = p.Transitions(obs=obs, acts=acts, next_obs=(0.9 * obs).astype(np.float32), dones=np.zeros(n, bool))
     tr = cls(demonstrations=demos, demo_batch_size=demo_batch, venv=venv, gen_algo=algo, reward_net=net,
              n_disc_updates_per_round=n_disc, gen_replay_buffer_capacity=capacity,
-             custom_logger=p.configure_logger(tempfile.mkdtemp(prefix="bench-var-"), []))
+             custom_logger=p.configure_logger(tempfile.mkdtemp(prefix="bench-var-"), []),
+             disc_grad_penalty_coef=ex.get("grad_penalty", 0.0))
     return tr, n_envs * n_steps
 
 

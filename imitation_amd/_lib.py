@@ -121,6 +121,8 @@ _SIGS = {
     "ia_disc_fused_prepare": ([C.POINTER(MlpDesc), _P, _I, _I, _P, _P], C.c_int),
     "ia_gp_interpolate": ([_P, _I, _I, _I, _P, _P, _P, _F, _P, _I, _P], C.c_int),
     "ia_gp_row_coeffs": ([_P, _I, _I, _I, _P, _F, _F, _F, _P, _P, _P], C.c_int),
+    "ia_gp_shaped_coeffs": ([_P, _I, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _P, _F, _P, _F, _F, _F, _F, _P, _P, _P, _P,
+                             _P], C.c_int),
     "ia_airl_logits": ([_P, _P, _P, _P, _P, _F, _I, _P, _P], C.c_int),
     "ia_airl_route_grad": ([_P, _P, _F, _I, _P, _P, _P, _P], C.c_int),
     "ia_gather_rows": ([_P, _P, _I, _I, _P, _P], C.c_int),

@@ -526,10 +526,12 @@ class AdversarialTrainer(abc.ABC):
                 logits = ws["out"].reshape(-1)
                 fused_step = fused_step or (last and fuse_adam is not None and not gp)
             else:
-                if self.disc_grad_penalty_coef > 0.0:
-                    raise NotImplementedError("disc_grad_penalty_coef > 0 is implemented for BasicRewardNet "
-                                              "discriminators (GAIL; state-holder or imitation_amd.modules net)")
-                if (self._needs_logp and isinstance(basic, reward_nets.ShapedRewardNet) and B == mb
+                gp = self.disc_grad_penalty_coef > 0.0
+                if gp and not isinstance(basic, reward_nets.ShapedRewardNet):
+                    raise NotImplementedError("disc_grad_penalty_coef > 0 is implemented for BasicRewardNet (GAIL; "
+                                              "state-holder or imitation_amd.modules net) and BasicShapedRewardNet "
+                                              "(AIRL; state-holder) discriminators")
+                if (not gp and self._needs_logp and isinstance(basic, reward_nets.ShapedRewardNet) and B == mb
                         and fuse_adam is not None and self._torch_opt_params is None and basic.fused_step_ok()
                         and hasattr(pol, "log_prob_rows")):
                     # AIRL's default shaped net: one assembly launch for the net's and the policy's rows (+ one for the
@@ -545,7 +547,9 @@ class AdversarialTrainer(abc.ABC):
                 L.call("ia_bce_logits", L.ptr(logits), 2 * mb, mb, scale, L.ptr(self._dlogits),
                        L.ptr(stats_dev), L.ptr(self._bce_ws), L.stream())
                 fused_step = bool(net.disc_backward(self._dlogits, accumulate=not first,
-                                                    adam=fuse_adam if (B == mb) else None))
+                                                    adam=fuse_adam if (B == mb and not gp) else None))
+                if gp:
+                    self._add_shaped_grad_penalty(basic, mb, scale)
             first = False
         if self._dp is not None:  # one flat-bucket all-reduce per discriminator step
             self._dp.allreduce_mean_(net._store.grad)
@@ -567,6 +571,25 @@ class AdversarialTrainer(abc.ABC):
                                                      var, eps, self.disc_grad_penalty_coef * scale,
                                                      self.disc_grad_penalty_target)
         L.call("ia_reduce_partials", L.ptr(g), 1, g.numel(), 1.0, 1, L.ptr(mlp.grad), L.stream())
+        self.last_grad_penalty = pen
+
+    def _add_shaped_grad_penalty(self, shaped, mb: int, scale: float) -> None:
+        """The same for AIRL's shaped net, on the batches its forward of this minibatch assembled
+        (`grad_penalty.shaped_penalty_and_param_grad`; input statistics as that forward left them, frozen)."""
+        from imitation_amd import grad_penalty
+        wg, wn, wc, aux, R = shaped._last
+        base, pot = shaped._base, shaped.potential._potential_net
+        bm = base.mlp
+        if pot.desc.hidden_act != bm.desc.hidden_act:
+            raise NotImplementedError("the gradient penalty needs the same activation in both stacks")
+        e = th.rand(mb).to(self._device)      # interpolation weights: torch's global CPU generator (only when enabled)
+        stats = lambda n: None if n is None else (n.running_mean, n.running_var, n.eps)
+        pen, gb, gpot = grad_penalty.shaped_penalty_and_param_grad(
+            bm.flat, bm.dims, pot.flat, pot.dims, bm.desc.hidden_act, wg["X"], bm.ldx, wn["X"], wc["X"], pot.ldx,
+            aux["dones"], mb, e, base.obs_dim, base.act_dim, base.flags, stats(bm.norm), stats(pot.norm),
+            shaped.discount_factor, self.disc_grad_penalty_coef * scale, self.disc_grad_penalty_target)
+        L.call("ia_reduce_partials", L.ptr(gb), 1, gb.numel(), 1.0, 1, L.ptr(bm.grad), L.stream())
+        L.call("ia_reduce_partials", L.ptr(gpot), 1, gpot.numel(), 1.0, 1, L.ptr(pot.grad), L.stream())
         self.last_grad_penalty = pen
 
     def _module_batch(self, sources):

@@ -458,6 +458,71 @@ __global__ __launch_bounds__(256) void gp_row_coeffs_kernel(const float* __restr
   if (lane == 0) pen[r] = (n - target) * (n - target);
 }
 
+// The same for AIRL's shaped reward f(s, a, s') = g([s | a | s' | d]) + gamma (1 - d) h(s') - h(s) (reward_nets.py:727-733;
+// d: the interpolated done flag, a constant of the row): the input gradient T over the blocks [s | a | s' | d] combines
+// the three stacks' input gradients, T_s = G_b[s] - G_c, T_a = G_b[a], T_s' = G_b[s'] + c G_n (c = gamma (1 - d)),
+// T_d = G_b[d] (base blocks as flagged; G = gn / sigma per stack). n = |T|_2, pen = (n - target)^2 and, with
+// Q = coef / B * 2 (n - target) / n * T, the coefficients each stack's second pass starts from:
+// Cn_b = Q[block] / sigma_b, Cn_n = c Q_s' / sigma_p, Cn_c = -Q_s / sigma_p. One wave per row.
+struct GpShaped {
+  const float *gn_b, *gn_n, *gn_c, *dhat, *var_b, *var_p;
+  int ldb, ldp, B, od, ad, use_state, use_action, use_next, use_done;
+  float eps_b, eps_p, gamma, coef, target;
+  float *Cn_b, *Cn_n, *Cn_c, *pen;
+};
+
+__global__ __launch_bounds__(256) void gp_shaped_coeffs_kernel(GpShaped a) {
+  const int lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= a.B) return;
+  const int od = a.od, ad = a.ad;
+  const int o_s = 0, o_a = o_s + (a.use_state ? od : 0), o_n = o_a + (a.use_action ? ad : 0), o_d = o_n + (a.use_next ? od : 0);
+  const float c = a.gamma * (1.f - a.dhat[r]);
+  const float* gb = a.gn_b + (long long)r * a.ldb;
+  const float* gnx = a.gn_n + (long long)r * a.ldp;
+  const float* gc = a.gn_c + (long long)r * a.ldp;
+  auto inv_b = [&](int col) { return a.var_b ? 1.f / sqrtf(a.var_b[col] + a.eps_b) : 1.f; };
+  auto inv_p = [&](int j) { return a.var_p ? 1.f / sqrtf(a.var_p[j] + a.eps_p) : 1.f; };
+  auto T_s = [&](int j) { return (a.use_state ? gb[o_s + j] * inv_b(o_s + j) : 0.f) - gc[j] * inv_p(j); };
+  auto T_a = [&](int j) { return a.use_action ? gb[o_a + j] * inv_b(o_a + j) : 0.f; };
+  auto T_n = [&](int j) { return (a.use_next ? gb[o_n + j] * inv_b(o_n + j) : 0.f) + c * (gnx[j] * inv_p(j)); };
+  float sq = 0.f;
+  for (int j = lane; j < od; j += 64) {
+    const float ts = T_s(j), tn = T_n(j);
+    sq += ts * ts + tn * tn;
+  }
+  for (int j = lane; j < ad; j += 64) {
+    const float ta = T_a(j);
+    sq += ta * ta;
+  }
+  if (a.use_done && lane == 0) {
+    const float td = gb[o_d] * inv_b(o_d);
+    sq += td * td;
+  }
+  for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o, 64);
+  const float n = sqrtf(sq);
+  const float k = n > 0.f ? a.coef / (float)a.B * 2.f * (n - a.target) / n : 0.f;
+  float* cb = a.Cn_b + (long long)r * a.ldb;
+  float* cn = a.Cn_n + (long long)r * a.ldp;
+  float* cc = a.Cn_c + (long long)r * a.ldp;
+  for (int j = lane; j < a.ldp; j += 64) {
+    const bool on = j < od;
+    const float qs = on ? k * T_s(j) : 0.f, qn = on ? k * T_n(j) : 0.f;
+    cn[j] = on ? c * qn * inv_p(j) : 0.f;
+    cc[j] = on ? -qs * inv_p(j) : 0.f;
+    if (on && a.use_state) cb[o_s + j] = qs * inv_b(o_s + j);
+    if (on && a.use_next) cb[o_n + j] = qn * inv_b(o_n + j);
+  }
+  if (a.use_action)
+    for (int j = lane; j < ad; j += 64) cb[o_a + j] = k * T_a(j) * inv_b(o_a + j);
+  const int Db = o_d + (a.use_done ? 1 : 0);
+  if (lane == 0) {
+    if (a.use_done) cb[o_d] = k * gb[o_d] * inv_b(o_d) * inv_b(o_d);
+    for (int col = Db; col < a.ldb; ++col) cb[col] = 0.f;
+    a.pen[r] = (n - a.target) * (n - a.target);
+  }
+}
+
 inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 
 }  // namespace
@@ -854,6 +919,21 @@ int ia_gp_row_coeffs(const float* gn, int ld, int B, int D, const float* var, fl
   if (!gn || !Cn || !pen || B <= 0 || D <= 0 || ld < D) return IA_ERR_ARG;
   hipLaunchKernelGGL(gp_row_coeffs_kernel, dim3(cdiv(B, 4)), dim3(256), 0, (hipStream_t)stream, gn, ld, B, D, var, eps,
                      coef, target, Cn, pen);
+  IA_CHECK_LAUNCH();
+  return IA_OK;
+}
+
+int ia_gp_shaped_coeffs(const float* gn_b, int ldb, const float* gn_n, const float* gn_c, int ldp, const float* dhat, int B,
+                        int obs_dim, int act_dim, int use_state, int use_action, int use_next_state, int use_done,
+                        const float* var_b, float eps_b, const float* var_p, float eps_p, float gamma, float coef,
+                        float target, float* Cn_b, float* Cn_n, float* Cn_c, float* pen, void* stream) {
+  const int Db = (use_state ? obs_dim : 0) + (use_action ? act_dim : 0) + (use_next_state ? obs_dim : 0) + (use_done ? 1 : 0);
+  if (!gn_b || !gn_n || !gn_c || !dhat || !Cn_b || !Cn_n || !Cn_c || !pen || B <= 0 || obs_dim <= 0 || act_dim <= 0 ||
+      Db <= 0 || ldb < Db || ldp < obs_dim)
+    return IA_ERR_ARG;
+  GpShaped a{gn_b, gn_n, gn_c, dhat, var_b, var_p, ldb, ldp, B, obs_dim, act_dim, use_state, use_action, use_next_state,
+             use_done, eps_b, eps_p, gamma, coef, target, Cn_b, Cn_n, Cn_c, pen};
+  hipLaunchKernelGGL(gp_shaped_coeffs_kernel, dim3(cdiv(B, 4)), dim3(256), 0, (hipStream_t)stream, a);
   IA_CHECK_LAUNCH();
   return IA_OK;
 }

@@ -194,6 +194,14 @@ int ia_gp_interpolate(const float* X, int ldx, int B, int D, const float* e, con
                       float eps, float* Xn, int ld, void* stream);
 int ia_gp_row_coeffs(const float* gn, int ld, int B, int D, const float* var, float eps, float coef, float target,
                      float* Cn, float* pen, void* stream);
+/* The same for AIRL's shaped reward f(s, a, s') = g([s | a | s' | d]) + gamma (1 - d) h(s') - h(s)
+ * (rewards/reward_nets.py:727-733; d = the interpolated done flag dhat[B], constant): from the three stacks' input
+ * gradients gn_b[B, ldb] (base, blocks as flagged), gn_n / gn_c[B, ldp] (potential at s' / at s) the penalty of
+ * |grad_(s, a, s', d) f|_2 per row and the coefficients Cn_b / Cn_n / Cn_c each stack's second pass starts from. */
+int ia_gp_shaped_coeffs(const float* gn_b, int ldb, const float* gn_n, const float* gn_c, int ldp, const float* dhat, int B,
+                        int obs_dim, int act_dim, int use_state, int use_action, int use_next_state, int use_done,
+                        const float* var_b, float eps_b, const float* var_p, float eps_p, float gamma, float coef,
+                        float target, float* Cn_b, float* Cn_n, float* Cn_c, float* pen, void* stream);
 
 /* adversarial/airl.py:118 + rewards/reward_nets.py:701-736:
  * logits = g + gamma*(1-done)*h_next - h_cur - logp ; and the matching dOut routing. */
