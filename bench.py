@@ -268,6 +268,8 @@ VARIANTS = {
                               dict(normalize_output=True, grad_penalty=10.0)),
     "1_cartpole_8x256_mlp64": ("gail", 8, 256, 4, 2, 64, 5, 1024, 4, 2048, dict(hid_sizes=(32, 32)),
                                dict(discrete=True, mlp64=True, gamma=0.95)),
+    # config P with SB3's default `MlpPolicy` (64 x 64 tanh towers) as the generator instead of FeedForward32Policy
+    "P_mlp64_1024x16": ("gail", 1024, 16, 17, 6, 1024, 10, 8192, 16, 16384, dict(hid_sizes=(256, 256)), dict(mlp64=True)),
     # policy towers outside the fused kernels' shapes (any SB3 `net_arch`): the general minibatch loop
     "towers_1024x16_pi128x64_vf256": ("gail", 1024, 16, 17, 6, 2048, 4, 8192, 4, 16384, dict(hid_sizes=(256, 256)),
                                       dict(net_arch=dict(pi=[128, 64], vf=[256]))),

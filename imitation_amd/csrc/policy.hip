@@ -16,6 +16,8 @@
 //    order (deterministic), applies clip_grad_norm_ + Adam and refreshes the transposed copies.
 #include "common.h"
 #include "rn_common.h"
+#include <algorithm>
+
 #include "../../include/imitation_hip.h"
 
 namespace {
@@ -567,6 +569,76 @@ __device__ void prepare_stats(const ia_policy_desc& d, const float* __restrict__
   prepare_stats_t<PREP_THREADS>(d, obs, adv, idx, batch, T, n_envs, update_norm, nm, nv, ncount, advstat, lds);
 }
 
+// Statistics of EVERY minibatch of an epoch in one launch, ahead of the per-minibatch kernels (`ia_ppo_epoch`): the
+// advantage mean / std and the train-mode feature RunningNorm update of a minibatch depend on its rows only, and the
+// running statistics are a sequential merge of per-minibatch moments. Workgroup b takes the raw moments of minibatch
+// b's (gathered, contiguous) rows (`prepare_stats_t`, partial form); the workgroup that draws the last ticket applies
+// the updates in order (util/networks.py:111-134, the expressions of `prepare_stats_t`) and leaves, per minibatch,
+// seq[b] = {adv mean, adv std, -, -, -, -, -, -, mean[MAXD], var[MAXD]} -- the statistics that minibatch's forward
+// normalises with. Before, the next minibatch's statistics were one 23 us workgroup inside every apply launch.
+constexpr int EPS_PART = 2 * MAXD + 8;       // raw moments of one minibatch (prepare_stats_t's partial layout)
+constexpr int EPS_SEQ = 8 + 2 * MAXD;        // published statistics of one minibatch
+__global__ __launch_bounds__(PREP_THREADS) void ppo_epoch_stats_kernel(ia_policy_desc d, const float* __restrict__ obs,
+                                                                       const float* __restrict__ adv, long long total,
+                                                                       int batch, int update_norm, float* __restrict__ nm,
+                                                                       float* __restrict__ nv, int32_t* __restrict__ ncount,
+                                                                       float* __restrict__ seq, float* __restrict__ part,
+                                                                       unsigned* __restrict__ ticket) {
+  extern __shared__ float lds[];
+  __shared__ int is_last;
+  const int tid = threadIdx.x, b = blockIdx.x, n_mb = gridDim.x;
+  const long long start = (long long)b * batch;
+  const int n = (int)((total - start) < batch ? (total - start) : batch);
+  prepare_stats_t<PREP_THREADS>(d, obs + start * d.obs_dim, adv + start, nullptr, n, 1, 1, update_norm, nm, nv, ncount,
+                                nullptr, lds, nullptr, part + (long long)b * EPS_PART);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (tid == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned tk = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    is_last = tk == (unsigned)n_mb - 1u;
+    if (is_last) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+  __syncthreads();
+  if (!is_last) return;
+  auto rows_of = [&](int k) { const long long s0 = (long long)k * batch; return (int)((total - s0) < batch ? (total - s0) : batch); };
+  for (int k = tid; k < n_mb; k += PREP_THREADS) {
+    const float* pk = part + (long long)k * EPS_PART;
+    const int nk = rows_of(k);
+    seq[(long long)k * EPS_SEQ + 0] = pk[2 * MAXD + 0];
+    seq[(long long)k * EPS_SEQ + 1] = nk > 1 ? sqrtf(pk[2 * MAXD + 1] / (float)(nk - 1)) : 0.f;
+  }
+  if (!(d.has_norm && update_norm)) return;
+  const int cnt0 = *ncount;
+  __syncthreads();
+  if (tid < d.obs_dim) {
+    float mean = nm[tid], var = nv[tid];
+    int cnt = cnt0;
+    for (int k = 0; k < n_mb; ++k) {
+      const float* pk = part + (long long)k * EPS_PART;
+      const int nk = rows_of(k);
+      const float bmean = pk[tid], bvar = pk[MAXD + tid] / (float)nk;
+      const float fcount = (float)cnt, fn = (float)nk, tot = (float)((long long)cnt + nk);
+      const float delta = bmean - mean;
+      mean = mean + delta * fn / tot;
+      float rv = var * fcount;
+      rv = rv + bvar * fn;
+      rv = rv + delta * delta * fcount * fn / tot;
+      var = rv / tot;
+      cnt = rn_count_add(cnt, nk);
+      seq[(long long)k * EPS_SEQ + 8 + tid] = mean;
+      seq[(long long)k * EPS_SEQ + 8 + MAXD + tid] = var;
+    }
+    nm[tid] = mean;
+    nv[tid] = var;
+    if (tid == 0) *ncount = cnt;
+  }
+}
+
 __global__ __launch_bounds__(PREP_THREADS) void ppo_prepare_kernel(ia_policy_desc d, const float* __restrict__ obs,
                                                                    const float* __restrict__ adv,
                                                                    const int64_t* __restrict__ idx, int batch, int T,
@@ -634,7 +706,8 @@ __global__ __launch_bounds__(512) void ppo_grad_kernel(ia_policy_desc d, const f
                                                        const int64_t* __restrict__ idx, int batch, int T, int n_envs,
                                                        int normalize_adv, float clip, float ent_coef, float vf_coef,
                                                        float* __restrict__ ws, int nblk,
-                                                       long long* __restrict__ tstamp /* optional phase clocks */) {
+                                                       long long* __restrict__ tstamp /* optional phase clocks */,
+                                                       const float* __restrict__ advstat_in) {
   using L = GLds<H>;
   constexpr int HQ = H / 4;
 #define IA_TS(slot) do { if (tstamp && blockIdx.x == 0 && threadIdx.x == 0) tstamp[slot] = clock64(); } while (0)
@@ -649,6 +722,7 @@ __global__ __launch_bounds__(512) void ppo_grad_kernel(ia_policy_desc d, const f
   const int i0 = blockIdx.x * ROWS;
   const int aw = d.discrete ? 1 : A;
   const float invB = 1.f / (float)batch;
+  if (blockIdx.x == 0 && tid == 0) reinterpret_cast<unsigned*>(ws)[7] = 0u;   // ticket of ppo_apply_split_kernel
 
   IA_TS(0);
   // ---- phase 0: cooperative, coalesced feature gather (+ normalisation) into LDS; clear pads
@@ -751,7 +825,8 @@ __global__ __launch_bounds__(512) void ppo_grad_kernel(ia_policy_desc d, const f
       }
     }
     float advn = adv[src];
-    if (normalize_adv && batch > 1) advn = (advn - w.advstat[0]) / (w.advstat[1] + 1e-8f);
+    const float* as = advstat_in ? advstat_in : w.advstat;
+    if (normalize_adv && batch > 1) advn = (advn - as[0]) / (as[1] + 1e-8f);
     const float log_ratio = logp - old_logp[src];
     const float ratio = expf(log_ratio);
     const float lo = 1.f - clip, hi = 1.f + clip;
@@ -916,8 +991,8 @@ struct UpdStage {
 // hidden = 32 without the persistent kernel, i.e. data-parallel runs): forward, losses, backward;
 // gradient partials -> `slab`, loss-statistic partials -> `statpart[0..4]`. LOAD_PARAMS: copy the flat
 // parameter vectors into LDS first.
-template <bool LOAD_PARAMS>
-__device__ __forceinline__ void mfma32_minibatch(
+template <int H, bool LOAD_PARAMS>
+__device__ __forceinline__ void mfma_minibatch(
     const ia_policy_desc& d, const float* __restrict__ P, const float* __restrict__ Pt, const float* __restrict__ nm,
     const float* __restrict__ nv, const float adv_mean, const float adv_std, const MbRows rows, const int vblk,
     const int normalize_adv, const float clip, const float ent_coef, const float vf_coef, float* __restrict__ slab,
@@ -929,8 +1004,8 @@ __device__ __forceinline__ void mfma32_minibatch(
   const float* __restrict__ ret = rows.ret;
   const int64_t* __restrict__ idx = rows.idx;
   const int batch = rows.batch, T = rows.T, n_envs = rows.n_envs;
-  constexpr int H = 32;
-  using L = GLds<32>;
+  constexpr int NC = H / 16, KS = H / 4;   // 16-column tiles of a layer output, MFMA steps over a hidden layer
+  using L = GLds<H>;
 #define IA_TS(slot) do { if (tstamp && vblk == 0 && threadIdx.x == 0) tstamp[slot] = clock64(); } while (0)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -978,9 +1053,13 @@ __device__ __forceinline__ void mfma32_minibatch(
   IA_TS(9);
   // ---- parameters: ONE cooperative, coalesced 16-byte copy of both flat vectors (torch layout P and
   // the transposed shadow copy Pt) into LDS; every weight fragment below is then an LDS read.
-  float* sP = lds + L::total;
-  float* sPt = sP + ((o.total + 3) & ~3);
-  if (LOAD_PARAMS) {
+  // (H = 64: the 64-wide activation tiles leave no room for parameter copies -- fragments come straight from the
+  // L2-resident flat vectors)
+  const float* sP = H == 32 ? lds + L::total : P;
+  const float* sPt = H == 32 ? sP + ((o.total + 3) & ~3) : Pt;
+  if (LOAD_PARAMS && H == 32) {
+    float* wP = lds + L::total;
+    float* wPt = wP + ((o.total + 3) & ~3);
     const int n4 = (o.total + 3) >> 2;
     const bool vec = ((reinterpret_cast<uintptr_t>(P) | reinterpret_cast<uintptr_t>(Pt)) & 15) == 0;
     for (int e = tid; e < n4; e += 512) {
@@ -999,8 +1078,8 @@ __device__ __forceinline__ void mfma32_minibatch(
         v0 = make_float4(t0[0], t0[1], t0[2], t0[3]);
         v1 = make_float4(t1[0], t1[1], t1[2], t1[3]);
       }
-      reinterpret_cast<float4*>(sP)[e] = v0;
-      reinterpret_cast<float4*>(sPt)[e] = v1;
+      reinterpret_cast<float4*>(wP)[e] = v0;
+      reinterpret_cast<float4*>(wPt)[e] = v1;
     }
   }
   IA_TS(10);
@@ -1020,39 +1099,59 @@ __device__ __forceinline__ void mfma32_minibatch(
   if (LOAD_PARAMS) stage_rows();
 
   IA_TS(11);
-  // weight fragments (LDS -> VGPR): B[k = 4s+lk][j = c*16+li]
-  float bW1[16][2], bW2[8][2], bW2o[8][2], bHead[8], bDa2[4][2], b1v[2], b2v[2], cwv[2];
+  // weight fragments -> VGPR: B[k = 4s+lk][j = CJ(c)]. H = 32: column tile c is columns c*16 + li (LDS reads). H = 64:
+  // tile c is columns li*NC + c, so the NC values a lane needs from one weight row are 16 contiguous bytes -- one
+  // global_load_dwordx4 instead of four scalar loads (144 -> 40 load instructions per wave; the fragments come from L2)
+  auto CJ = [&](int c) { return H == 32 ? c * 16 + li : li * NC + c; };
+  typedef float f32x4_u __attribute__((ext_vector_type(4), aligned(4)));
+  auto ldc = [&](const float* __restrict__ rowbase, float (&out)[NC]) {
+    if constexpr (H == 32) {
+#pragma unroll
+      for (int c = 0; c < NC; ++c) out[c] = rowbase[c * 16 + li];
+    } else {
+      const f32x4_u t = *reinterpret_cast<const f32x4_u*>(rowbase + li * NC);
+#pragma unroll
+      for (int c = 0; c < NC; ++c) out[c] = t[c];
+    }
+  };
+  float bW1[16][NC], bW2[KS][NC], bW2o[KS][NC], bHead[KS], bDa2[4][NC], b1v[NC], b2v[NC], cwv[NC];
 #pragma unroll
   for (int s = 0; s < 16; ++s) {
     const int kk = 4 * s + lk;
-    bW1[s][0] = bW1[s][1] = 0.f;
-    if (s < S1) {  // wave-uniform: steps beyond the observation width issue no LDS reads
 #pragma unroll
-      for (int c = 0; c < 2; ++c) bW1[s][c] = kk < D ? sPt[oW1 + kk * H + c * 16 + li] : 0.f;
+    for (int c = 0; c < NC; ++c) bW1[s][c] = 0.f;
+    if (s < S1) {  // wave-uniform: steps beyond the observation width issue no reads
+      ldc(sPt + oW1 + min(kk, D - 1) * H, bW1[s]);
+#pragma unroll
+      for (int c = 0; c < NC; ++c) bW1[s][c] = kk < D ? bW1[s][c] : 0.f;
     }
   }
 #pragma unroll
-  for (int s = 0; s < 8; ++s) {
+  for (int s = 0; s < KS; ++s) {
     const int kk = 4 * s + lk;
-#pragma unroll
-    for (int c = 0; c < 2; ++c) {
-      bW2[s][c] = sPt[oW2 + kk * H + c * 16 + li];   // W2^T[k][j]
-      bW2o[s][c] = sP[oW2 + kk * H + c * 16 + li];   // W2[j=k][k'] (row j contiguous)
-    }
+    ldc(sPt + oW2 + kk * H, bW2[s]);   // W2^T[k][j]
     bHead[s] = tw == 0 ? (li < A ? sP[o.aW + li * H + kk] : 0.f) : (li == 0 ? sP[o.cW + kk] : 0.f);
   }
+  // fragments of the backward phases: H = 32 takes them here (LDS reads, resident all along); H = 64 requests them
+  // from L2 after the forward chain, when the forward fragments' registers are free again
+  auto load_backward_fragments = [&]() {
 #pragma unroll
-  for (int s = 0; s < 4; ++s) {
-    const int aa = 4 * s + lk;
+    for (int s = 0; s < KS; ++s) {
+      const int kk = 4 * s + lk;
+      ldc(sP + oW2 + kk * H, bW2o[s]);   // W2[j=k][k'] (row j contiguous)
+    }
 #pragma unroll
-    for (int c = 0; c < 2; ++c) bDa2[s][c] = (tw == 0 && aa < A) ? sP[o.aW + aa * H + c * 16 + li] : 0.f;
-  }
+    for (int s = 0; s < 4; ++s) {
+      const int aa = 4 * s + lk;
+      ldc(sP + o.aW + min(aa, A - 1) * H, bDa2[s]);
 #pragma unroll
-  for (int c = 0; c < 2; ++c) {
-    b1v[c] = sP[ob1 + c * 16 + li];
-    b2v[c] = sP[ob2 + c * 16 + li];
-    cwv[c] = sP[o.cW + c * 16 + li];
-  }
+      for (int c = 0; c < NC; ++c) bDa2[s][c] = (tw == 0 && aa < A) ? bDa2[s][c] : 0.f;
+    }
+  };
+  if (H == 32) load_backward_fragments();
+  ldc(sP + ob1, b1v);
+  ldc(sP + ob2, b2v);
+  ldc(sP + o.cW, cwv);
   const float head_bias = tw == 0 ? (li < A ? sP[o.ab + li] : 0.f) : sP[o.cb];
   // per-action Gaussian constants (wave-uniform): sd = exp(log_std), var = sd^2, log sd
   float c_var[MAXA], c_logsd[MAXA];
@@ -1075,34 +1174,38 @@ __device__ __forceinline__ void mfma32_minibatch(
   IA_TS(1);
   // ---- phase 1: a1 = tanh(x W1^T + b1)
   {
-    f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    f32x4 acc[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int s = 0; s < 16; ++s)
       if (s < S1) {
         const float a = lds[L::x + arow * L::XS + 4 * s + lk];
-        acc[0] = mfma16(a, bW1[s][0], acc[0]);
-        acc[1] = mfma16(a, bW1[s][1], acc[1]);
+#pragma unroll
+        for (int c = 0; c < NC; ++c) acc[c] = mfma16(a, bW1[s][c], acc[c]);
       }
 #pragma unroll
-    for (int c = 0; c < 2; ++c)
+    for (int c = 0; c < NC; ++c)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) a1t[(q * 16 + lk * 4 + r) * L::HS + c * 16 + li] = fast_tanh(acc[c][r] + b1v[c]);
+      for (int r = 0; r < 4; ++r) a1t[(q * 16 + lk * 4 + r) * L::HS + CJ(c)] = fast_tanh(acc[c][r] + b1v[c]);
   }
   __syncthreads();
   IA_TS(2);
   // ---- phase 2: a2 = tanh(a1 W2^T + b2)
   {
-    f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    f32x4 acc[NC];
 #pragma unroll
-    for (int s = 0; s < 8; ++s) {
+    for (int c = 0; c < NC; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
       const float a = a1t[arow * L::HS + 4 * s + lk];
-      acc[0] = mfma16(a, bW2[s][0], acc[0]);
-      acc[1] = mfma16(a, bW2[s][1], acc[1]);
+#pragma unroll
+      for (int c = 0; c < NC; ++c) acc[c] = mfma16(a, bW2[s][c], acc[c]);
     }
 #pragma unroll
-    for (int c = 0; c < 2; ++c)
+    for (int c = 0; c < NC; ++c)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) a2t[(q * 16 + lk * 4 + r) * L::HS + c * 16 + li] = fast_tanh(acc[c][r] + b2v[c]);
+      for (int r = 0; r < 4; ++r) a2t[(q * 16 + lk * 4 + r) * L::HS + CJ(c)] = fast_tanh(acc[c][r] + b2v[c]);
   }
   __syncthreads();
   IA_TS(3);
@@ -1110,7 +1213,7 @@ __device__ __forceinline__ void mfma32_minibatch(
   {
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int s = 0; s < 8; ++s) acc = mfma16(a2t[arow * L::HS + 4 * s + lk], bHead[s], acc);
+    for (int s = 0; s < KS; ++s) acc = mfma16(a2t[arow * L::HS + 4 * s + lk], bHead[s], acc);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int row = q * 16 + lk * 4 + r;
@@ -1118,6 +1221,7 @@ __device__ __forceinline__ void mfma32_minibatch(
       else if (li == 0) lds[L::misc + row * L::MS + 0] = acc[r] + head_bias;
     }
   }
+  if (H != 32) load_backward_fragments();   // (in flight during the loss phase)
   __syncthreads();
   IA_TS(4);
   // ---- phase 4: per-row losses (wave 0: policy terms, wave 4: value term)
@@ -1192,23 +1296,25 @@ __device__ __forceinline__ void mfma32_minibatch(
   IA_TS(5);
   // ---- phase 5: dz2 = d(a2) * (1 - a2^2); head weight / bias gradients
   if (tw == 0) {
-    f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    f32x4 acc[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int s = 0; s < 4; ++s)
       if (s < SA) {
         const float a = lds[L::dout + arow * L::AS + 4 * s + lk];   // columns >= A are zero
-        acc[0] = mfma16(a, bDa2[s][0], acc[0]);
-        acc[1] = mfma16(a, bDa2[s][1], acc[1]);
+#pragma unroll
+        for (int c = 0; c < NC; ++c) acc[c] = mfma16(a, bDa2[s][c], acc[c]);
       }
 #pragma unroll
-    for (int c = 0; c < 2; ++c)
+    for (int c = 0; c < NC; ++c)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int e = (q * 16 + lk * 4 + r) * L::HS + c * 16 + li;
+        const int e = (q * 16 + lk * 4 + r) * L::HS + CJ(c);
         const float a = a2t[e];
         dzt[e] = acc[c][r] * (1.f - a * a);
       }
-    if (q < 2) {  // dWa[a][h] = sum_r dout[r][a] a2[r][h], tile of 16 h-columns per wave
+    if (q < NC) {  // dWa[a][h] = sum_r dout[r][a] a2[r][h], tile of 16 h-columns per wave
       f32x4 g = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int s = 0; s < 16; ++s)
@@ -1221,15 +1327,15 @@ __device__ __forceinline__ void mfma32_minibatch(
     if (q == 3 && !d.discrete) column_sum_store(lds + L::aux, L::AS, A, slab + o.log_std, lane);
   } else {
 #pragma unroll
-    for (int c = 0; c < 2; ++c)
+    for (int c = 0; c < NC; ++c)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int row = q * 16 + lk * 4 + r;
-        const int e = row * L::HS + c * 16 + li;
+        const int e = row * L::HS + CJ(c);
         const float a = a2t[e];
         dzt[e] = cwv[c] * lds[L::misc + row * L::MS + 1] * (1.f - a * a);
       }
-    if (q < 2) {  // dcW[h] = sum_r dv[r] a2[r][h]  (only output row 0 is meaningful)
+    if (q < NC) {  // dcW[h] = sum_r dv[r] a2[r][h]  (only output row 0 is meaningful)
       f32x4 g = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int s = 0; s < 16; ++s) {
@@ -1255,25 +1361,30 @@ __device__ __forceinline__ void mfma32_minibatch(
   IA_TS(6);
   // ---- phase 6: dW2 (one 16x16 tile per wave), db2, and dz1 = (dz2 W2) * (1 - a1^2) -> a2 tile
   {
-    const int jt = q >> 1, kt = q & 1;
-    f32x4 g = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int s = 0; s < 16; ++s)
-      g = mfma16(dzt[(4 * s + lk) * L::HS + jt * 16 + li], a1t[(4 * s + lk) * L::HS + kt * 16 + li], g);
+    for (int t = 0; t < NC * NC / 4; ++t) {   // NC x NC tiles of 16 x 16 over the tower's four waves
+      const int ti = q + 4 * t, jt = ti / NC, kt = ti % NC;
+      f32x4 g = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int r = 0; r < 4; ++r) slab[oW2 + (jt * 16 + lk * 4 + r) * H + kt * 16 + li] = g[r];
-    f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+      for (int s = 0; s < 16; ++s)
+        g = mfma16(dzt[(4 * s + lk) * L::HS + jt * 16 + li], a1t[(4 * s + lk) * L::HS + kt * 16 + li], g);
 #pragma unroll
-    for (int s = 0; s < 8; ++s) {
+      for (int r = 0; r < 4; ++r) slab[oW2 + (jt * 16 + lk * 4 + r) * H + kt * 16 + li] = g[r];
+    }
+    f32x4 acc[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
       const float a = dzt[arow * L::HS + 4 * s + lk];
-      acc[0] = mfma16(a, bW2o[s][0], acc[0]);
-      acc[1] = mfma16(a, bW2o[s][1], acc[1]);
+#pragma unroll
+      for (int c = 0; c < NC; ++c) acc[c] = mfma16(a, bW2o[s][c], acc[c]);
     }
 #pragma unroll
-    for (int c = 0; c < 2; ++c)
+    for (int c = 0; c < NC; ++c)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int e = (q * 16 + lk * 4 + r) * L::HS + c * 16 + li;
+        const int e = (q * 16 + lk * 4 + r) * L::HS + CJ(c);
         const float a = a1t[e];
         a2t[e] = acc[c][r] * (1.f - a * a);   // dz1 (the a2 tile is free from here on)
       }
@@ -1284,7 +1395,7 @@ __device__ __forceinline__ void mfma32_minibatch(
   // ---- phase 7: dW1 tiles (dz1^T x), db1
   {
     const int KT = (D + 15) >> 4;
-    for (int ti = q; ti < 2 * KT; ti += 4) {
+    for (int ti = q; ti < NC * KT; ti += 4) {
       const int jt = ti / KT, kt = ti - jt * KT;
       f32x4 g = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -1303,17 +1414,20 @@ __device__ __forceinline__ void mfma32_minibatch(
 }
 
 
-__global__ __launch_bounds__(512) void ppo_grad_mfma32_kernel(
+template <int H>
+__global__ __launch_bounds__(512) void ppo_grad_mfma_kernel(
     ia_policy_desc d, const float* __restrict__ P, const float* __restrict__ Pt, const float* __restrict__ nm,
     const float* __restrict__ nv, const float* __restrict__ obs, const float* __restrict__ actions,
     const float* __restrict__ old_logp, const float* __restrict__ adv, const float* __restrict__ ret,
     const int64_t* __restrict__ idx, int batch, int T, int n_envs, int normalize_adv, float clip, float ent_coef,
-    float vf_coef, float* __restrict__ ws, int nblk, long long* __restrict__ tstamp) {
+    float vf_coef, float* __restrict__ ws, int nblk, long long* __restrict__ tstamp, const float* __restrict__ advstat) {
   extern __shared__ float lds[];
-  const PolOff o = pol_offsets(d.obs_dim, d.act_dim, 32, d.discrete);
+  const PolOff o = pol_offsets(d.obs_dim, d.act_dim, H, d.discrete);
   const PpoWs w = ppo_ws(ws, nblk, o.total);
   const MbRows rows{obs, actions, old_logp, adv, ret, idx, batch, T, n_envs};
-  mfma32_minibatch<true>(d, P, Pt, nm, nv, w.advstat[0], w.advstat[1], rows, blockIdx.x, normalize_adv, clip, ent_coef,
+  if (blockIdx.x == 0 && threadIdx.x == 0) reinterpret_cast<unsigned*>(ws)[7] = 0u;   // ticket of ppo_apply_split_kernel
+  const float* as = advstat ? advstat : w.advstat;
+  mfma_minibatch<H, true>(d, P, Pt, nm, nv, as[0], as[1], rows, blockIdx.x, normalize_adv, clip, ent_coef,
                          vf_coef, w.slabs + (long long)blockIdx.x * o.total, w.statpart + blockIdx.x * 8, lds, tstamp);
 }
 
@@ -1399,6 +1513,131 @@ __global__ __launch_bounds__(PREP_THREADS) void ppo_apply_kernel(
     Pt[dst] = pn;
   }
   if (next_batch > 0 && gridDim.x == 1) {
+    __syncthreads();
+    prepare_stats(d, obs, adv, next_idx, next_batch, T, n_envs, update_norm, nm, nv, ncount, w.advstat, lds);
+  }
+}
+
+// The same step (slab reduction, clip_grad_norm_, Adam, transposed shadow copy, loss statistics) spread over `G`
+// workgroups: workgroup g reduces its contiguous chunk of the gradient and leaves the chunk's sum of squares; the one
+// that draws the last ticket folds the G partial sums in order, then applies clip + Adam to the whole vector (11 k
+// parameters at H = 64: a few per thread). The single-workgroup form above walks the slabs of ALL parameters in one
+// thread block -- 24 us at H = 64, as long as the gradient kernel itself. Workgroup G (launched when `stats_block`)
+// computes the next minibatch's statistics beside it. The ticket word is ws[7] (zeroed by the gradient kernels, reset
+// here); partial sums go to the unused slot 5 of the loss-statistic partials.
+__global__ __launch_bounds__(PREP_THREADS) void ppo_apply_split_kernel(
+    ia_policy_desc d, float* __restrict__ P, float* __restrict__ Pt, float* __restrict__ m, float* __restrict__ v,
+    float* __restrict__ ws, int nblk, int batch, float max_norm, float ent_coef, float vf_coef, float beta1,
+    float beta2, float eps, float step_size, float bc2_sqrt, float* __restrict__ stats, const float* __restrict__ obs,
+    const float* __restrict__ adv, const int64_t* __restrict__ next_idx, int next_batch, int T, int n_envs,
+    int update_norm, float* __restrict__ nm, float* __restrict__ nv, int32_t* __restrict__ ncount, int G,
+    int stats_block) {
+  extern __shared__ float lds[];
+  __shared__ float coef;
+  __shared__ int is_last;
+  const int H = d.hidden, D = d.obs_dim;
+  const PolOff o = pol_offsets(D, d.act_dim, H, d.discrete);
+  const PpoWs w = ppo_ws(ws, nblk, o.total);
+  const int tid = threadIdx.x;
+  if ((int)blockIdx.x == G) {
+    if (next_batch > 0)
+      prepare_stats(d, obs, adv, next_idx, next_batch, T, n_envs, update_norm, nm, nv, ncount, w.advstat, lds);
+    return;
+  }
+  const int chunk = (o.total + G - 1) / G;
+  const int i0 = blockIdx.x * chunk, i1 = min(o.total, i0 + chunk);
+  float sq = 0.f;
+  for (int i = i0 + tid; i < i1; i += PREP_THREADS) {
+    float g = 0.f;
+    int b = 0;
+    for (; b + 8 <= nblk; b += 8) {  // 8 independent loads in flight, then a fixed-order sum (as ppo_apply_kernel)
+      float t[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) t[u] = w.slabs[(long long)(b + u) * o.total + i];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) g += t[u];
+    }
+    for (; b < nblk; ++b) g += w.slabs[(long long)b * o.total + i];
+    w.grad[i] = g;
+    sq += g * g;
+  }
+  // hand-off per the gfx950 rules: every thread's gradient stores acknowledged, block barrier (inside the sum), then
+  // one lane's agent-scope release + relaxed ticket; the last workgroup acquires before reading the others' chunks
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  const float part = block_sum_1024(sq, lds);
+  unsigned* ticket = reinterpret_cast<unsigned*>(ws) + 7;
+  if (tid == 0) {
+    w.statpart[blockIdx.x * 8 + 5] = part;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned tk = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    is_last = tk == (unsigned)G - 1u;
+    if (is_last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  }
+  __syncthreads();
+  if (!is_last) return;
+  __shared__ float s_norm, s_st[5];
+  if (tid == 0) {
+    float total_sq = 0.f;
+    for (int g = 0; g < G; ++g) total_sq += w.statpart[g * 8 + 5];
+    const float total_norm = sqrtf(total_sq);
+    s_norm = total_norm;
+    coef = fminf(max_norm / (total_norm + 1e-6f), 1.0f);   // torch.nn.utils.clip_grad_norm_
+    __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  if (stats && tid >= 64 && tid < 69) {   // loss statistics: one lane of the second wave per statistic, beside the norm
+    const int k = tid - 64;
+    float st = 0.f;
+    for (int b = 0; b < nblk; ++b) st += w.statpart[b * 8 + k];
+    st *= 1.f / (float)batch;
+    stats[k] = st;
+    s_st[k] = st;
+  }
+  __syncthreads();
+  if (stats && tid == 0) {
+    stats[5] = s_st[0] + ent_coef * s_st[2] + vf_coef * s_st[1];  // loss
+    stats[6] = s_norm;
+    stats[7] = coef;
+  }
+  const float c = coef;
+  // Adam over the whole vector by this one workgroup: the loads of NPT parameters per thread are issued together (a
+  // loop with one parameter per trip is a chain of ~11 memory round trips at H = 64: 20 us)
+  constexpr int NPT = 12;
+  for (int base = 0; base < o.total; base += NPT * PREP_THREADS) {
+    float g_[NPT], m_[NPT], v_[NPT], p_[NPT];
+#pragma unroll
+    for (int k = 0; k < NPT; ++k) {
+      const int i = min(base + tid + k * PREP_THREADS, o.total - 1);
+      g_[k] = w.grad[i];
+      m_[k] = m[i];
+      v_[k] = v[i];
+      p_[k] = P[i];
+    }
+#pragma unroll
+    for (int k = 0; k < NPT; ++k) {
+      const int i = base + tid + k * PREP_THREADS;
+      if (i < o.total) {
+        const float g = g_[k] * c;
+        const float mi = m_[k] + (g - m_[k]) * (1.f - beta1);
+        const float vi = v_[k] * beta2 + (1.f - beta2) * g * g;
+        const float denom = sqrtf(vi) / bc2_sqrt + eps;
+        const float pn = p_[k] - step_size * (mi / denom);
+        P[i] = pn;
+        m[i] = mi;
+        v[i] = vi;
+        int dst = i;
+        auto tr = [&](int b0, int rows, int cols) {
+          if (i >= b0 && i < b0 + rows * cols) {
+            const int r = (i - b0) / cols, cc = (i - b0) % cols;
+            dst = b0 + cc * rows + r;
+          }
+        };
+        tr(o.pW1, H, D); tr(o.pW2, H, H); tr(o.vW1, H, D); tr(o.vW2, H, H);
+        Pt[dst] = pn;
+      }
+    }
+  }
+  if (next_batch > 0 && !stats_block) {
     __syncthreads();
     prepare_stats(d, obs, adv, next_idx, next_batch, T, n_envs, update_norm, nm, nv, ncount, w.advstat, lds);
   }
@@ -2928,7 +3167,9 @@ int64_t ia_ppo_ws_floats(const ia_policy_desc* d, int batch, int64_t gather_rows
   const int nblk = cdiv(batch, ROWS);
   const int P = pol_offsets(d->obs_dim, d->act_dim, d->hidden, d->discrete).total;
   const int aw = d->discrete ? 1 : d->act_dim;
-  return 8 + (int64_t)nblk * 8 + (int64_t)nblk * P + P + gather_rows * (d->obs_dim + aw + 3);
+  const int64_t n_mb = (gather_rows + batch - 1) / batch;
+  return 8 + (int64_t)nblk * 8 + (int64_t)nblk * P + P + gather_rows * (d->obs_dim + aw + 3) +
+         n_mb * (EPS_PART + EPS_SEQ);   // + ia_ppo_epoch's per-minibatch statistics (raw moments, published form)
 }
 
 }  // extern "C" (helpers below are C++)
@@ -2965,6 +3206,7 @@ struct PpoArgs {
   float beta1, beta2, adam_eps;
   float* ws;
   hipStream_t st;
+  const float* advstat = nullptr;   // {advantage mean, std} of this minibatch (null: ws[0..1], left by the previous launch)
 };
 
 int launch_gather(const PpoArgs& a, const int64_t* perm, long long rows, const Gathered& g) {
@@ -3007,21 +3249,22 @@ int launch_grad(const PpoArgs& a, const int64_t* idx, int batch) {
   static bool attr = false;
   const size_t bytes = GLds<H>::total * sizeof(float);
   const int nblk = cdiv(batch, ROWS);
-  if (H == 32 && !g_ppo_valu) {
-    const int P4 = (pol_offsets(a.d->obs_dim, a.d->act_dim, 32, a.d->discrete).total + 3) & ~3;
-    const size_t mbytes = (GLds<32>::total + 2 * P4) * sizeof(float);
+  if (!g_ppo_valu) {
+    // matrix-core gradient kernel: H = 32 with the parameters copied into LDS, H = 64 reading its fragments from L2
+    const int P4 = (pol_offsets(a.d->obs_dim, a.d->act_dim, H, a.d->discrete).total + 3) & ~3;
+    const size_t mbytes = (GLds<H>::total + (H == 32 ? 2 * P4 : 0)) * sizeof(float);
     static bool attr2 = false;
-    if (!attr2) { int rc = set_lds(ppo_grad_mfma32_kernel, 160 * 1024); if (rc) return rc; attr2 = true; }
-    hipLaunchKernelGGL(ppo_grad_mfma32_kernel, dim3(nblk), dim3(512), mbytes, a.st, *a.d, a.params, a.params_t,
+    if (!attr2) { int rc = set_lds(ppo_grad_mfma_kernel<H>, 160 * 1024); if (rc) return rc; attr2 = true; }
+    hipLaunchKernelGGL(ppo_grad_mfma_kernel<H>, dim3(nblk), dim3(512), mbytes, a.st, *a.d, a.params, a.params_t,
                        a.norm_mean, a.norm_var, a.obs, a.actions, a.old_logp, a.advantages, a.returns, idx, batch, a.T,
-                       a.n_envs, a.normalize_adv, a.clip_range, a.ent_coef, a.vf_coef, a.ws, nblk, g_tstamp);
+                       a.n_envs, a.normalize_adv, a.clip_range, a.ent_coef, a.vf_coef, a.ws, nblk, g_tstamp, a.advstat);
     IA_CHECK_LAUNCH();
     return IA_OK;
   }
   if (!attr) { int rc = set_lds(ppo_grad_kernel<H>, bytes); if (rc) return rc; attr = true; }
   hipLaunchKernelGGL(ppo_grad_kernel<H>, dim3(nblk), dim3(512), bytes, a.st, *a.d, a.params, a.params_t, a.norm_mean,
                      a.norm_var, a.obs, a.actions, a.old_logp, a.advantages, a.returns, idx, batch, a.T, a.n_envs,
-                     a.normalize_adv, a.clip_range, a.ent_coef, a.vf_coef, a.ws, nblk, g_tstamp);
+                     a.normalize_adv, a.clip_range, a.ent_coef, a.vf_coef, a.ws, nblk, g_tstamp, a.advstat);
   IA_CHECK_LAUNCH();
   return IA_OK;
 }
@@ -3032,19 +3275,28 @@ int launch_grad(const PpoArgs& a, const int64_t* idx, int batch) {
 int launch_minibatch_next(const PpoArgs& a, int batch, float step_size, float bc2_sqrt, float* stats,
                           const PpoArgs& nxt, int next_batch);
 
+// reduce + clip + Adam (+ the next minibatch's statistics: in an extra workgroup when `stats_block`, else behind Adam)
+int launch_apply_split(const PpoArgs& a, int batch, float step_size, float bc2_sqrt, float* stats, const float* nobs,
+                       const float* nadv, const int64_t* next_idx, int next_batch, int stats_block) {
+  static bool attr = false;
+  const size_t bytes = PREP_LDS_FLOATS * sizeof(float);
+  if (!attr) { int rc = set_lds(ppo_apply_split_kernel, bytes); if (rc) return rc; attr = true; }
+  const int nblk = cdiv(batch, ROWS);
+  const int total = pol_offsets(a.d->obs_dim, a.d->act_dim, a.d->hidden, a.d->discrete).total;
+  const int G = std::max(1, std::min(std::min(nblk, 16), cdiv(total, PREP_THREADS)));
+  hipLaunchKernelGGL(ppo_apply_split_kernel, dim3(G + (stats_block ? 1 : 0)), dim3(PREP_THREADS), bytes, a.st, *a.d,
+                     a.params, a.params_t, a.exp_avg, a.exp_avg_sq, a.ws, nblk, batch, a.max_grad_norm, a.ent_coef,
+                     a.vf_coef, a.beta1, a.beta2, a.adam_eps, step_size, bc2_sqrt, stats, nobs, nadv, next_idx, next_batch,
+                     a.T, a.n_envs, a.update_norm, a.norm_mean, a.norm_var, a.norm_count, G, stats_block);
+  IA_CHECK_LAUNCH();
+  return IA_OK;
+}
+
 int launch_minibatch(const PpoArgs& a, const int64_t* idx, int batch, float step_size, float bc2_sqrt, float* stats,
                      const int64_t* next_idx, int next_batch) {
   int rc = a.d->hidden == 32 ? launch_grad<32>(a, idx, batch) : launch_grad<64>(a, idx, batch);
   if (rc) return rc;
-  static bool attr = false;
-  const size_t bytes = PREP_LDS_FLOATS * sizeof(float);
-  if (!attr) { rc = set_lds(ppo_apply_kernel, bytes); if (rc) return rc; attr = true; }
-  hipLaunchKernelGGL(ppo_apply_kernel, dim3(1), dim3(PREP_THREADS), bytes, a.st, *a.d, a.params, a.params_t, a.exp_avg,
-                     a.exp_avg_sq, a.ws, cdiv(batch, ROWS), batch, a.max_grad_norm, a.ent_coef, a.vf_coef, a.beta1,
-                     a.beta2, a.adam_eps, step_size, bc2_sqrt, stats, a.obs, a.advantages, next_idx, next_batch, a.T,
-                     a.n_envs, a.update_norm, a.norm_mean, a.norm_var, a.norm_count, 3);
-  IA_CHECK_LAUNCH();
-  return IA_OK;
+  return launch_apply_split(a, batch, step_size, bc2_sqrt, stats, a.obs, a.advantages, next_idx, next_batch, 0);
 }
 
 // contiguous-rows form: `a` = this minibatch's rows, `nxt` = the next minibatch's rows (for its statistics)
@@ -3052,16 +3304,8 @@ int launch_minibatch_next(const PpoArgs& a, int batch, float step_size, float bc
                           const PpoArgs& nxt, int next_batch) {
   int rc = a.d->hidden == 32 ? launch_grad<32>(a, nullptr, batch) : launch_grad<64>(a, nullptr, batch);
   if (rc) return rc;
-  static bool attr = false;
-  const size_t bytes = PREP_LDS_FLOATS * sizeof(float);
-  if (!attr) { rc = set_lds(ppo_apply_kernel, bytes); if (rc) return rc; attr = true; }
-  hipLaunchKernelGGL(ppo_apply_kernel, dim3(next_batch > 0 ? 2 : 1), dim3(PREP_THREADS), bytes, a.st, *a.d, a.params,
-                     a.params_t, a.exp_avg,
-                     a.exp_avg_sq, a.ws, cdiv(batch, ROWS), batch, a.max_grad_norm, a.ent_coef, a.vf_coef, a.beta1,
-                     a.beta2, a.adam_eps, step_size, bc2_sqrt, stats, nxt.obs, nxt.advantages, nullptr, next_batch, a.T,
-                     a.n_envs, a.update_norm, a.norm_mean, a.norm_var, a.norm_count, 3);
-  IA_CHECK_LAUNCH();
-  return IA_OK;
+  return launch_apply_split(a, batch, step_size, bc2_sqrt, stats, nxt.obs, nxt.advantages, nullptr, next_batch,
+                            next_batch > 0 ? 1 : 0);
 }
 
 int launch_apply_phase(const PpoArgs& a, int batch, float step_size, float bc2_sqrt, float* stats, int phases) {
@@ -3172,19 +3416,36 @@ int ia_ppo_epoch(const ia_policy_desc* d, float* params, float* params_t, float*
   const Gathered g = gathered_region(d, ws, size_at(0), total);
   int rc = launch_gather(a, perm, total, g);
   if (rc) return rc;
-  rc = launch_prepare(at_rows(a, g, 0), nullptr, size_at(0));
-  if (rc) return rc;
+  // statistics of every minibatch of the epoch, one launch ahead of the chain (ppo_epoch_stats_kernel)
+  const int aw = d->discrete ? 1 : d->act_dim;
+  const int n_mb = (int)((total + batch_size - 1) / batch_size);
+  float* seq = g.ret + total;                       // [n_mb][EPS_SEQ]
+  float* part = seq + (long long)n_mb * EPS_SEQ;    // [n_mb][EPS_PART]
+  (void)aw;
+  {
+    static bool attr = false;
+    const size_t bytes = PREP_LDS_FLOATS * sizeof(float);
+    if (!attr) { rc = set_lds(ppo_epoch_stats_kernel, bytes); if (rc) return rc; attr = true; }
+    if (hipMemsetAsync(ws + 6, 0, sizeof(unsigned), a.st) != hipSuccess) return IA_ERR_ARG;   // its ticket (ws is not pre-zeroed)
+    hipLaunchKernelGGL(ppo_epoch_stats_kernel, dim3(n_mb), dim3(PREP_THREADS), bytes, a.st, *d, g.obs, g.adv, total,
+                       batch_size, update_norm, norm_mean, norm_var, norm_count, seq, part,
+                       reinterpret_cast<unsigned*>(ws) + 6);
+    IA_CHECK_LAUNCH();
+  }
+  const bool snap = d->has_norm && update_norm;
   for (long long start = 0; start < total; start += batch_size, ++mb) {
     const int b = size_at(start);
-    const long long nstart = start + batch_size;
-    const int nb = nstart < total ? size_at(nstart) : 0;
     ++step;
     const double bc1 = 1.0 - pow(beta1, (double)step);
     const double bc2 = 1.0 - pow(beta2, (double)step);
-    // the apply kernel prepares the NEXT minibatch: hand it that minibatch's rows
     PpoArgs v = at_rows(a, g, start);
-    rc = launch_minibatch_next(v, b, (float)(lr / bc1), (float)sqrt(bc2), stats ? stats + mb * 8 : nullptr,
-                               nb ? at_rows(a, g, nstart) : v, nb);
+    float* sq = seq + (long long)mb * EPS_SEQ;
+    v.advstat = sq;
+    if (snap) { v.norm_mean = sq + 8; v.norm_var = sq + 8 + MAXD; }
+    rc = d->hidden == 32 ? launch_grad<32>(v, nullptr, b) : launch_grad<64>(v, nullptr, b);
+    if (rc) return rc;
+    rc = launch_apply_split(v, b, (float)(lr / bc1), (float)sqrt(bc2), stats ? stats + mb * 8 : nullptr, nullptr, nullptr,
+                            nullptr, 0, 0);
     if (rc) return rc;
   }
   return IA_OK;

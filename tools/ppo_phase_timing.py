@@ -1,4 +1,5 @@
-"""Shader-clock timing of the ppo_grad kernel phases (block 0) at config P."""
+"""Shader-clock timing of the ppo_grad kernel phases (block 0) at config P.
+Usage: python tools/ppo_phase_timing.py [variant]   (e.g. P_mlp64_1024x16: the per-minibatch kernels of H = 64)"""
 import os, sys
 import numpy as np, torch as th
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -6,7 +7,7 @@ import bench
 from imitation_amd import _lib as L
 cfg = dict(bench.CFG_P)
 th.set_num_threads(1)
-tr = bench.build_trainer(bench.hip_namespace(), cfg, "cuda")
+tr = bench.build_variant(sys.argv[1])[0] if len(sys.argv) > 1 else bench.build_trainer(bench.hip_namespace(), cfg, "cuda")
 tr.train(2 * 16384)
 buf = th.zeros(16, dtype=th.int64, device="cuda")
 L.load().ia_ppo_debug_timing(buf.data_ptr())
