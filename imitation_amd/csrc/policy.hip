@@ -2191,8 +2191,9 @@ __device__ __forceinline__ void mfma32_minibatch_chain(
 // block -- wave (tower, q) takes rows q*16 .. q*16+15 through both layers and its head without block
 // barriers after the feature staging -- then lanes 0..15 of the policy waves sample / clip / score
 // their row exactly as the thread-per-row kernel does (same expression order), value waves store V.
+template <int H>
 struct ALds {
-  static constexpr int XS = MAXD + 1, HS = 33, AS = MAXA + 1;
+  static constexpr int XS = MAXD + 1, HS = H + 1, AS = MAXA + 1;
   static constexpr int x = 0;
   static constexpr int a1 = x + ROWS * XS;       // [2][ROWS][HS]
   static constexpr int a2 = a1 + 2 * ROWS * HS;
@@ -2203,14 +2204,14 @@ struct ALds {
 // EVAL = false: the rollout step (sample from `noise`, clip, log-prob of the sample).
 // EVAL = true: [SB3 evaluate_actions] -- `noise` holds the GIVEN actions, `clipped` receives the entropy;
 // `logp`, `values` and the entropy output may each be NULL (`ia_policy_evaluate`, hidden = 32).
-template <bool EVAL>
-__global__ __launch_bounds__(512) void policy_act_mfma32_kernel(
+template <int H, bool EVAL>
+__global__ __launch_bounds__(512) void policy_act_mfma_kernel(
     ia_policy_desc d, const float* __restrict__ P, const float* __restrict__ Pt, const float* __restrict__ nm,
     const float* __restrict__ nv, const float* __restrict__ obs, int n, const float* __restrict__ noise,
     const float* __restrict__ low, const float* __restrict__ high, float* __restrict__ actions,
     float* __restrict__ clipped, float* __restrict__ values, float* __restrict__ logp) {
-  constexpr int H = 32;
-  using L = ALds;
+  constexpr int NC = H / 16, KS = H / 4;
+  using L = ALds<H>;
   extern __shared__ float lds[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -2257,7 +2258,7 @@ __global__ __launch_bounds__(512) void policy_act_mfma32_kernel(
     }
   }
   // weight fragments straight from global memory (L2-resident, 14 KB): B[k = 4s+lk][j = c*16+li]
-  float bW1[16][2], bW2[8][2], bHead[8], b1v[2], b2v[2];
+  float bW1[16][NC], bW2[KS][NC], bHead[KS], b1v[NC], b2v[NC];
   // (all loads first, unconditional at clamped addresses, behind at most four wave-uniform branches; masks after)
 #pragma unroll
   for (int g = 0; g < 4; ++g) {
@@ -2265,22 +2266,24 @@ __global__ __launch_bounds__(512) void policy_act_mfma32_kernel(
 #pragma unroll
       for (int s = 4 * g; s < 4 * g + 4; ++s)
 #pragma unroll
-        for (int c = 0; c < 2; ++c) bW1[s][c] = Pt[oW1 + min(4 * s + lk, D - 1) * H + c * 16 + li];
+        for (int c = 0; c < NC; ++c) bW1[s][c] = Pt[oW1 + min(4 * s + lk, D - 1) * H + c * 16 + li];
     } else {
 #pragma unroll
-      for (int s = 4 * g; s < 4 * g + 4; ++s) bW1[s][0] = bW1[s][1] = 0.f;
+      for (int s = 4 * g; s < 4 * g + 4; ++s)
+#pragma unroll
+        for (int c = 0; c < NC; ++c) bW1[s][c] = 0.f;
     }
   }
   const int head_base = tw == 0 ? o.aW + min(li, A - 1) * H : o.cW;
 #pragma unroll
-  for (int s = 0; s < 8; ++s) {
+  for (int s = 0; s < KS; ++s) {
     const int kk = 4 * s + lk;
 #pragma unroll
-    for (int c = 0; c < 2; ++c) bW2[s][c] = Pt[oW2 + kk * H + c * 16 + li];
+    for (int c = 0; c < NC; ++c) bW2[s][c] = Pt[oW2 + kk * H + c * 16 + li];
     bHead[s] = P[head_base + kk];
   }
 #pragma unroll
-  for (int c = 0; c < 2; ++c) {
+  for (int c = 0; c < NC; ++c) {
     b1v[c] = P[ob1 + c * 16 + li];
     b2v[c] = P[ob2 + c * 16 + li];
   }
@@ -2297,11 +2300,11 @@ __global__ __launch_bounds__(512) void policy_act_mfma32_kernel(
 #pragma unroll
   for (int s = 0; s < 16; ++s)
 #pragma unroll
-    for (int c = 0; c < 2; ++c) bW1[s][c] = (4 * s + lk < D) ? bW1[s][c] : 0.f;
+    for (int c = 0; c < NC; ++c) bW1[s][c] = (4 * s + lk < D) ? bW1[s][c] : 0.f;
   {
     const bool head_on = tw == 0 ? li < A : li == 0;
 #pragma unroll
-    for (int s = 0; s < 8; ++s) bHead[s] = head_on ? bHead[s] : 0.f;
+    for (int s = 0; s < KS; ++s) bHead[s] = head_on ? bHead[s] : 0.f;
   }
   __syncthreads();
 
@@ -2309,30 +2312,34 @@ __global__ __launch_bounds__(512) void policy_act_mfma32_kernel(
   float* a2t = lds + L::a2 + tw * ROWS * L::HS;
   const int arow = q * 16 + li;
   {
-    f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    f32x4 acc[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int s = 0; s < 16; ++s)
       if (s < S1) {
         const float a = lds[L::x + arow * L::XS + 4 * s + lk];
-        acc[0] = mfma16(a, bW1[s][0], acc[0]);
-        acc[1] = mfma16(a, bW1[s][1], acc[1]);
+#pragma unroll
+        for (int c = 0; c < NC; ++c) acc[c] = mfma16(a, bW1[s][c], acc[c]);
       }
 #pragma unroll
-    for (int c = 0; c < 2; ++c)
+    for (int c = 0; c < NC; ++c)
 #pragma unroll
       for (int r = 0; r < 4; ++r) a1t[(q * 16 + lk * 4 + r) * L::HS + c * 16 + li] = fast_tanh(acc[c][r] + b1v[c]);
   }
   wave_sync_lds();
   {
-    f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    f32x4 acc[NC];
 #pragma unroll
-    for (int s = 0; s < 8; ++s) {
+    for (int c = 0; c < NC; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
       const float a = a1t[arow * L::HS + 4 * s + lk];
-      acc[0] = mfma16(a, bW2[s][0], acc[0]);
-      acc[1] = mfma16(a, bW2[s][1], acc[1]);
+#pragma unroll
+      for (int c = 0; c < NC; ++c) acc[c] = mfma16(a, bW2[s][c], acc[c]);
     }
 #pragma unroll
-    for (int c = 0; c < 2; ++c)
+    for (int c = 0; c < NC; ++c)
 #pragma unroll
       for (int r = 0; r < 4; ++r) a2t[(q * 16 + lk * 4 + r) * L::HS + c * 16 + li] = fast_tanh(acc[c][r] + b2v[c]);
   }
@@ -2340,7 +2347,7 @@ __global__ __launch_bounds__(512) void policy_act_mfma32_kernel(
   {
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int s = 0; s < 8; ++s) acc = mfma16(a2t[arow * L::HS + 4 * s + lk], bHead[s], acc);
+    for (int s = 0; s < KS; ++s) acc = mfma16(a2t[arow * L::HS + 4 * s + lk], bHead[s], acc);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int rr = q * 16 + lk * 4 + r;
@@ -3078,9 +3085,15 @@ int ia_policy_act(const ia_policy_desc* d, const float* params, const float* par
   int rc;
   if (d->hidden == 32 && !g_ppo_valu) {
     static bool attr = false;
-    const size_t bytes = ALds::total * sizeof(float);
-    if (!attr) { if ((rc = set_lds(policy_act_mfma32_kernel<false>, bytes))) return rc; attr = true; }
-    hipLaunchKernelGGL(policy_act_mfma32_kernel<false>, dim3(cdiv(n, ROWS)), dim3(512), bytes, (hipStream_t)stream, *d,
+    const size_t bytes = ALds<32>::total * sizeof(float);
+    if (!attr) { if ((rc = set_lds(policy_act_mfma_kernel<32, false>, bytes))) return rc; attr = true; }
+    hipLaunchKernelGGL((policy_act_mfma_kernel<32, false>), dim3(cdiv(n, ROWS)), dim3(512), bytes, (hipStream_t)stream, *d,
+                       params, params_t, norm_mean, norm_var, obs, n, noise, low, high, actions, clipped, values, logp);
+  } else if (d->hidden == 64 && !g_ppo_valu) {
+    static bool attr = false;
+    const size_t bytes = ALds<64>::total * sizeof(float);
+    if (!attr) { if ((rc = set_lds(policy_act_mfma_kernel<64, false>, bytes))) return rc; attr = true; }
+    hipLaunchKernelGGL((policy_act_mfma_kernel<64, false>), dim3(cdiv(n, ROWS)), dim3(512), bytes, (hipStream_t)stream, *d,
                        params, params_t, norm_mean, norm_var, obs, n, noise, low, high, actions, clipped, values, logp);
   } else if (d->hidden == 32) {
     if ((rc = set_lds(policy_act_kernel<32>, lds_bytes<32>()))) return rc;
@@ -3104,9 +3117,16 @@ int ia_policy_evaluate(const ia_policy_desc* d, const float* params, const float
   int rc;
   if (d->hidden == 32 && !g_ppo_valu && (actions != nullptr || logp == nullptr)) {
     static bool attr = false;   // the MFMA layer chain of the rollout step, given actions instead of sampling
-    const size_t bytes = ALds::total * sizeof(float);
-    if (!attr) { if ((rc = set_lds(policy_act_mfma32_kernel<true>, bytes))) return rc; attr = true; }
-    hipLaunchKernelGGL(policy_act_mfma32_kernel<true>, dim3(cdiv(n, ROWS)), dim3(512), bytes, (hipStream_t)stream, *d,
+    const size_t bytes = ALds<32>::total * sizeof(float);
+    if (!attr) { if ((rc = set_lds(policy_act_mfma_kernel<32, true>, bytes))) return rc; attr = true; }
+    hipLaunchKernelGGL((policy_act_mfma_kernel<32, true>), dim3(cdiv(n, ROWS)), dim3(512), bytes, (hipStream_t)stream, *d,
+                       params, params_t, norm_mean, norm_var, obs, n, actions, (const float*)nullptr,
+                       (const float*)nullptr, (float*)nullptr, entropy, values, logp);
+  } else if (d->hidden == 64 && !g_ppo_valu && (actions != nullptr || logp == nullptr)) {
+    static bool attr = false;
+    const size_t bytes = ALds<64>::total * sizeof(float);
+    if (!attr) { if ((rc = set_lds(policy_act_mfma_kernel<64, true>, bytes))) return rc; attr = true; }
+    hipLaunchKernelGGL((policy_act_mfma_kernel<64, true>), dim3(cdiv(n, ROWS)), dim3(512), bytes, (hipStream_t)stream, *d,
                        params, params_t, norm_mean, norm_var, obs, n, actions, (const float*)nullptr,
                        (const float*)nullptr, (float*)nullptr, entropy, values, logp);
   } else if (d->hidden == 32) {
