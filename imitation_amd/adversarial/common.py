@@ -531,15 +531,17 @@ class AdversarialTrainer(abc.ABC):
                     raise NotImplementedError("disc_grad_penalty_coef > 0 is implemented for BasicRewardNet (GAIL; "
                                               "state-holder or imitation_amd.modules net) and BasicShapedRewardNet "
                                               "(AIRL; state-holder) discriminators")
-                if (not gp and self._needs_logp and isinstance(basic, reward_nets.ShapedRewardNet) and B == mb
+                if (self._needs_logp and isinstance(basic, reward_nets.ShapedRewardNet) and B == mb
                         and fuse_adam is not None and self._torch_opt_params is None and basic.fused_step_ok()
                         and hasattr(pol, "log_prob_rows")):
                     # AIRL's default shaped net: one assembly launch for the net's and the policy's rows (+ one for the
                     # input statistics), log pi(a|s), then forward, BCE, backward, reduction + Adam in five launches
                     basic.fused_prepare(sources, self._pol_obs, self._pol_act)
                     logp = self._policy_pass(sources, mb, assembled=True)
-                    logits = basic.fused_finish(logp, scale, stats_dev, fuse_adam)
-                    fused_step = True
+                    logits = basic.fused_finish(logp, scale, stats_dev, None if gp else fuse_adam)
+                    fused_step = not gp
+                    if gp:   # penalty gradient on top of the reduced BCE gradient, then the optimiser step below
+                        self._add_shaped_grad_penalty(basic, mb, scale, basic.fused_batches())
                     first = False
                     continue
                 logp = None if (quirk_done and not self._needs_logp) else self._policy_pass(sources, mb)
@@ -573,11 +575,14 @@ class AdversarialTrainer(abc.ABC):
         L.call("ia_reduce_partials", L.ptr(g), 1, g.numel(), 1.0, 1, L.ptr(mlp.grad), L.stream())
         self.last_grad_penalty = pen
 
-    def _add_shaped_grad_penalty(self, shaped, mb: int, scale: float) -> None:
+    def _add_shaped_grad_penalty(self, shaped, mb: int, scale: float, batches=None) -> None:
         """The same for AIRL's shaped net, on the batches its forward of this minibatch assembled
         (`grad_penalty.shaped_penalty_and_param_grad`; input statistics as that forward left them, frozen)."""
         from imitation_amd import grad_penalty
-        wg, wn, wc, aux, R = shaped._last
+        if batches is None:
+            wg, wn, wc, aux, R = shaped._last
+            batches = (wg["X"], shaped._base.mlp.ldx, wn["X"], wc["X"], shaped.potential._potential_net.ldx, aux["dones"])
+        Xb, ldb, Sn, Sc, ldp, dones = batches
         base, pot = shaped._base, shaped.potential._potential_net
         bm = base.mlp
         if pot.desc.hidden_act != bm.desc.hidden_act:
@@ -585,8 +590,7 @@ class AdversarialTrainer(abc.ABC):
         e = th.rand(mb).to(self._device)      # interpolation weights: torch's global CPU generator (only when enabled)
         stats = lambda n: None if n is None else (n.running_mean, n.running_var, n.eps)
         pen, gb, gpot = grad_penalty.shaped_penalty_and_param_grad(
-            bm.flat, bm.dims, pot.flat, pot.dims, bm.desc.hidden_act, wg["X"], bm.ldx, wn["X"], wc["X"], pot.ldx,
-            aux["dones"], mb, e, base.obs_dim, base.act_dim, base.flags, stats(bm.norm), stats(pot.norm),
+            bm.flat, bm.dims, pot.flat, pot.dims, bm.desc.hidden_act, Xb, ldb, Sn, Sc, ldp, dones, mb, e, base.obs_dim, base.act_dim, base.flags, stats(bm.norm), stats(pot.norm),
             shaped.discount_factor, self.disc_grad_penalty_coef * scale, self.disc_grad_penalty_target)
         L.call("ia_reduce_partials", L.ptr(gb), 1, gb.numel(), 1.0, 1, L.ptr(bm.grad), L.stream())
         L.call("ia_reduce_partials", L.ptr(gpot), 1, gpot.numel(), 1.0, 1, L.ptr(pot.grad), L.stream())

@@ -570,7 +570,8 @@ class ShapedRewardNet(ForwardWrapper):
 
     def fused_finish(self, logp: th.Tensor, scale: float, stats_dev: th.Tensor, adam) -> th.Tensor:
         """Second half: `ia_airl_step_shaped` on the prepared batch (forward, logits, BCE + statistics, deltas,
-        weight-gradient GEMMs, split-K reduction fused with Adam: five launches). Returns the logits `[R]`."""
+        weight-gradient GEMMs, split-K reduction fused with Adam: five launches). Returns the logits `[R]`.
+        `adam=None`: the reduced gradient is left in the store's flat gradient buffer instead."""
         base, pot = self._base.mlp, self.potential._potential_net
         ws, R, n_expert, upd_p = self._fused
         bn, pn = base.norm, pot.norm
@@ -578,7 +579,8 @@ class ShapedRewardNet(ForwardWrapper):
         if pn is not None:
             B = (pn.running_mean.data_ptr(), pn.running_var.data_ptr())
             A = (ws["snapA"].data_ptr(), ws["snapA"].data_ptr() + 4 * pot.dims[0]) if upd_p else B
-        if adam.flat.data_ptr() != base.flat.data_ptr() or adam.flat.numel() != base.n_params + pot.n_params:
+        if adam is not None and (adam.flat.data_ptr() != base.flat.data_ptr()
+                                 or adam.flat.numel() != base.n_params + pot.n_params):
             raise RuntimeError("the fused AIRL update needs the optimiser over the net's flat parameter buffer")
         L.call("ia_airl_step_shaped", ws["out"][0], base.ldx, base.dims[0], ws["out"][2], ws["out"][3], pot.ldx,
                pot.dims[0], ws["out"][5], L.ptr(logp),
@@ -587,8 +589,17 @@ class ShapedRewardNet(ForwardWrapper):
                base.flat.data_ptr(), pot.flat.data_ptr(), self.discount_factor, float(scale), R, n_expert,
                ws["Ab"].data_ptr(), base.ldx, ws["Db1"].data_ptr(), ws["Ap"].data_ptr(), pot.ldx, ws["H1"].data_ptr(),
                ws["Dp1"].data_ptr(), ws["Dp2"].data_ptr(), ws["part"].data_ptr(), ws["logits"].data_ptr(),
-               L.ptr(stats_dev), ws["bce_part"].data_ptr(), ws["ticket"].data_ptr(), adam.next_step_args(), L.stream())
+               L.ptr(stats_dev), ws["bce_part"].data_ptr(), ws["ticket"].data_ptr(),
+               adam.next_step_args() if adam is not None else None, L.stream())
+        if adam is None:   # the caller adds to the gradient (gradient penalty) and steps the optimiser itself
+            g = self._store.grad
+            L.call("ia_reduce_partials", ws["part"].data_ptr(), ws["nblk"], g.numel(), 1.0, 0, g.data_ptr(), L.stream())
         return ws["logits"]
+
+    def fused_batches(self):
+        """(Xb, ldb, Sn, Sc, ldp, dones) of the batch `fused_prepare` assembled last."""
+        ws = self._fused[0]
+        return ws["Xb"], self._base.mlp.ldx, ws["Sn"], ws["Sc"], self.potential._potential_net.ldx, ws["dones"]
 
     def disc_step_fused(self, sources, logp: th.Tensor, scale: float, stats_dev: th.Tensor, adam) -> th.Tensor:
         self.fused_prepare(sources)
