@@ -81,6 +81,8 @@ _SIGS = {
     "ia_airl_prepare": ([_P] * 6 + [_I] + [_P] * 6 + [_I] + [_I] * 6 + [_P, _I, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P],
                         C.c_int),
     "ia_airl_stats_merge": ([_P, _P, _P, _I, _I, _I] + [_P] * 9, C.c_int),
+    "ia_airl_gp_shaped": ([_P, _I, _I, _P, _P, _I, _I, _P, _P, _P, _P, _F, _P, _P, _F, _P, _P, _I, _I, _I, _I, _I, _I, _F, _F,
+                           _F, _I] + [_P] * 12, C.c_int),
     "ia_airl_step_shaped": ([_P, _I, _I, _P, _P, _I, _I, _P, _P, _P, _P, _F, _P, _P, _P, _P, _F, _P, _P, _F, _F, _I, _I,
                             _P, _I, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P], C.c_int),
     "ia_conv1_u8_implicit_ok": ([_I, _I, _I, _I, _I, _I, _I], C.c_int),

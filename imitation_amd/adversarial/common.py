@@ -541,7 +541,9 @@ class AdversarialTrainer(abc.ABC):
                     logits = basic.fused_finish(logp, scale, stats_dev, None if gp else fuse_adam)
                     fused_step = not gp
                     if gp:   # penalty gradient on top of the reduced BCE gradient, then the optimiser step below
-                        self._add_shaped_grad_penalty(basic, mb, scale, basic.fused_batches())
+                        e = th.rand(mb).to(self._device)   # interpolation weights: torch's global CPU generator
+                        self.last_grad_penalty = basic.fused_grad_penalty(
+                            e, self.disc_grad_penalty_coef * scale, self.disc_grad_penalty_target)[0]
                     first = False
                     continue
                 logp = None if (quirk_done and not self._needs_logp) else self._policy_pass(sources, mb)

@@ -509,6 +509,355 @@ __global__ __launch_bounds__(64) void airl_stats_merge_kernel(const float* __res
   }
 }
 
+
+// ---- gradient penalty of the shaped reward (opt-in extension, imitation_amd/grad_penalty.py) on the same chains -------------
+// f(s, a, s') = g([s | a | s' | d]) + gamma (1 - d) h(s') - h(s) at x_hat = e x_expert + (1 - e) x_generator; penalty
+// coef * mean_i (|grad f|_2 - target)^2 over every input block. The stacks are ReLU, so with the masks of the forward
+// at x_hat fixed the input gradient is a product of the weight matrices, and so is the penalty's parameter gradient:
+//   forward (masks)            h = relu(.)                                   -- the forward chains of airl_rows_kernel
+//   input gradient, dOut = 1   u_L = w_out * m_L, u_l = m_l * (W_{l+1}^T u_{l+1}), gn = W_1^T u_1   (transposed chains)
+//   rows                       T = signed combination of the three gn / sigma, n = |T|, Q = coef/B 2 (n - t)/n T,
+//                              Cn = Q mapped back into each stack's normalised input (cross-stack columns via LDS tiles)
+//   second pass                dW_1 += u_1^T Cn, dV_1 = m_1 * (W_1 Cn), dW_2 += u_2^T dV_1, dV_2 = m_2 * (W_2 dV_1),
+//                              dw_out += column sums of dV_L; biases get nothing (the input gradient does not depend on them)
+// The row-contracting products (dW_1, dW_2) are split-K TN GEMMs on what this kernel writes, as in the update itself.
+constexpr int GP_TS = 68;                    // row stride of the per-wave exchange tiles (floats)
+struct AirlGpArgs {
+  const float *Xb, *Sn, *Sc; int ldb, Db, ldp, Dp;   // assembled [expert | generator] batches, 2B rows
+  const float *dones, *e;                            // [2B], [B]
+  const float *bmean, *bvar, *pmean, *pvar; float beps, peps;   // frozen statistics (null: none)
+  const float *Pb, *Pp;
+  int od, ad, use_state, use_action, use_next, use_done;
+  float gamma, coef, target; int B;
+  float *U1b, *Cb; int ldcb;          // [B, 32], [B, ldcb]
+  float *U1p, *Cp; int ldcp;          // [2B, 32], [2B, ldcp]: rows r (next) and B + r (current)
+  float *U2p, *V1p;                   // [2B, 32] each
+  float *part; long long part_stride; int off_b_wout, off_p_wout;
+  float *pen_part, *pen_out; unsigned* ticket;
+};
+
+struct GpLds {   // (carved from dynamic LDS)
+  f32x4 bW1f[A_CH * 64], pW1f[A_CH * 64], W2f[4 * 64], W2tf[4 * 64];
+  f32x4 bW1Tf[2 * 4 * 64], pW1Tf[2 * 4 * 64];     // A fragments of W1^T: [column tile][q][lane]
+  float vec[5 * AH + 4];
+  float bmean[A_D_MAX], bistd[A_D_MAX], pmean[A_D_MAX], pistd[A_D_MAX];
+  float red[A_WAVES][72];
+  float tiles[A_WAVES][3][32 * GP_TS];            // per wave: G_b, G_n, G_c (input gradients w.r.t. the raw inputs)
+  int is_last;
+};
+
+// interpolated, normalised chunks of one row pair (r, r + B)
+__device__ __forceinline__ void gp_mix(const f32x4 (&x0)[A_CH], const f32x4 (&x1)[A_CH], float w, int chunks,
+                                       const float* __restrict__ mean, const float* __restrict__ istd, int half,
+                                       f32x4 (&xn)[A_CH]) {
+#pragma unroll
+  for (int q = 0; q < A_CH; ++q) {
+    xn[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (q < chunks) {
+      const int k0 = 8 * q + 4 * half;
+      const f32x4 m = *reinterpret_cast<const f32x4*>(mean + k0);
+      const f32x4 is = *reinterpret_cast<const f32x4*>(istd + k0);
+      xn[q] = ((w * x0[q] + (1.f - w) * x1[q]) - m) * is;
+    }
+  }
+}
+
+// relu(b1 + W1 xn) of a stack's first layer (transposed chain; `xn` in chunk layout)
+__device__ __forceinline__ f32x16 gp_first(const f32x4 (&xn)[A_CH], int chunks, const f32x4* __restrict__ wf,
+                                           const float* __restrict__ b1, int half, bool relu) {
+  f32x16 acc = per_feature(b1, half);
+#pragma unroll
+  for (int q = 0; q < A_CH; ++q)
+    if (q < chunks) {
+      const f32x4 w = wf[q * 64];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) acc = mfma(w[u], xn[q][u], acc);
+    }
+  if (relu) {
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[j] = fmaxf(acc[j], 0.f);
+  }
+  return acc;
+}
+
+// gn = W1^T u for the column tiles of a stack (lane = row, registers = 16 of the tile's 32 columns)
+__device__ __forceinline__ void gp_input_grad(const f32x16& u, const f32x4* __restrict__ wtf, int tiles, f32x16 (&gn)[2]) {
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+#pragma unroll
+    for (int j = 0; j < 16; ++j) gn[t][j] = 0.f;
+    if (t < tiles) gn[t] = chain32(gn[t], u, wtf + t * 4 * 64);
+  }
+}
+
+__global__ __launch_bounds__(A_THREADS) void airl_gp_rows_kernel(AirlGpArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char gp_raw[];
+  GpLds& S = *reinterpret_cast<GpLds*>(gp_raw);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int half = lane >> 5, lrow = lane & 31;
+  const int Cb = (a.Db + 7) >> 3, Cp = (a.Dp + 7) >> 3;
+  const int Tb = (a.Db + 31) >> 5, Tp = (a.Dp + 31) >> 5;
+  const int r = blockIdx.x * A_ROWS + wave * 32 + lrow;
+  const bool live = r < a.B;
+  const int rr = live ? r : a.B - 1;
+  f32x4 b0[A_CH], b1[A_CH], n0[A_CH], n1[A_CH], c0[A_CH], c1[A_CH];
+  load_row(a.Xb + (long long)rr * a.ldb, a.ldb, Cb, half, b0);
+  load_row(a.Xb + (long long)(rr + a.B) * a.ldb, a.ldb, Cb, half, b1);
+  load_row(a.Sn + (long long)rr * a.ldp, a.ldp, Cp, half, n0);
+  load_row(a.Sn + (long long)(rr + a.B) * a.ldp, a.ldp, Cp, half, n1);
+  load_row(a.Sc + (long long)rr * a.ldp, a.ldp, Cp, half, c0);
+  load_row(a.Sc + (long long)(rr + a.B) * a.ldp, a.ldp, Cp, half, c1);
+  const float w = a.e[rr];
+  const float dhat = w * a.dones[rr] + (1.f - w) * a.dones[rr + a.B];
+
+  const float* Pb = a.Pb;
+  const float* Pp = a.Pp;
+  const int ob_b1 = AH * a.Db, ob_wout = ob_b1 + AH;
+  const int op_b1 = AH * a.Dp, op_W2 = op_b1 + AH, op_b2 = op_W2 + AH * AH, op_wout = op_b2 + AH;
+  for (int e = tid; e < A_CH * 64; e += A_THREADS) {
+    const int m = e & 31, k0 = 8 * (e >> 6) + 4 * ((e >> 5) & 1);
+    f32x4 wb, wp;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      wb[u] = k0 + u < a.Db ? Pb[m * a.Db + k0 + u] : 0.f;
+      wp[u] = k0 + u < a.Dp ? Pp[m * a.Dp + k0 + u] : 0.f;
+    }
+    S.bW1f[e] = wb;
+    S.pW1f[e] = wp;
+  }
+  for (int e = tid; e < 2 * 4 * 64; e += A_THREADS) {   // W1^T fragments: A[m = column 32 t + (lane & 31)][k = feature]
+    const int t = e >> 8, q = (e >> 6) & 3, m = e & 31, f0 = 8 * q + 4 * ((e >> 5) & 1), col = 32 * t + m;
+    f32x4 wb, wp;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      wb[u] = col < a.Db ? Pb[(f0 + u) * a.Db + col] : 0.f;
+      wp[u] = col < a.Dp ? Pp[(f0 + u) * a.Dp + col] : 0.f;
+    }
+    S.bW1Tf[e] = wb;
+    S.pW1Tf[e] = wp;
+  }
+  for (int e = tid; e < 4 * 64; e += A_THREADS) {
+    const int m = e & 31, k0 = 8 * (e >> 6) + 4 * ((e >> 5) & 1);
+    f32x4 wf, wt;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      wf[u] = Pp[op_W2 + m * AH + k0 + u];
+      wt[u] = Pp[op_W2 + (k0 + u) * AH + m];
+    }
+    S.W2f[e] = wf;
+    S.W2tf[e] = wt;
+  }
+  if (tid < AH) {
+    S.vec[tid] = Pb[ob_b1 + tid];
+    S.vec[AH + tid] = Pb[ob_wout + tid];
+    S.vec[2 * AH + tid] = Pp[op_b1 + tid];
+    S.vec[3 * AH + tid] = Pp[op_b2 + tid];
+    S.vec[4 * AH + tid] = Pp[op_wout + tid];
+  }
+  if (tid < A_D_MAX) {
+    const int k = tid;
+    const bool inb = k < a.Db, inp = k < a.Dp;
+    S.bmean[k] = (inb && a.bmean) ? a.bmean[k] : 0.f;
+    S.bistd[k] = inb ? (a.bmean ? 1.f / sqrtf(a.bvar[k] + a.beps) : 1.f) : 0.f;
+    S.pmean[k] = (inp && a.pmean) ? a.pmean[k] : 0.f;
+    S.pistd[k] = inp ? (a.pmean ? 1.f / sqrtf(a.pvar[k] + a.peps) : 1.f) : 0.f;
+  }
+  __syncthreads();
+  const f32x16 b_wout = per_feature(S.vec + AH, half), p_wout = per_feature(S.vec + 4 * AH, half);
+  const f32x16 p_b2 = per_feature(S.vec + 3 * AH, half);
+  const f32x4* bW1f = S.bW1f + lane;
+  const f32x4* pW1f = S.pW1f + lane;
+  const f32x4* W2f = S.W2f + lane;
+  const f32x4* W2tf = S.W2tf + lane;
+
+  // ---- forward at the interpolates (masks) and the input gradients with dOut = 1
+  f32x4 xb[A_CH], xn[A_CH], xc[A_CH];
+  gp_mix(b0, b1, w, Cb, S.bmean, S.bistd, half, xb);
+  gp_mix(n0, n1, w, Cp, S.pmean, S.pistd, half, xn);
+  gp_mix(c0, c1, w, Cp, S.pmean, S.pistd, half, xc);
+  const f32x16 hb = gp_first(xb, Cb, bW1f, S.vec, half, true);
+  const f32x16 h1n = gp_first(xn, Cp, pW1f, S.vec + 2 * AH, half, true);
+  const f32x16 h1c = gp_first(xc, Cp, pW1f, S.vec + 2 * AH, half, true);
+  const f32x16 h2n = chain32(p_b2, h1n, W2f), h2c = chain32(p_b2, h1c, W2f);   // (pre-activations: only the sign is used)
+  f32x16 u1b, u2n, u2c, z;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    u1b[j] = hb[j] > 0.f ? b_wout[j] : 0.f;
+    u2n[j] = h2n[j] > 0.f ? p_wout[j] : 0.f;
+    u2c[j] = h2c[j] > 0.f ? p_wout[j] : 0.f;
+    z[j] = 0.f;
+  }
+  f32x16 u1n = chain32(z, u2n, W2tf), u1c = chain32(z, u2c, W2tf);
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    u1n[j] = h1n[j] > 0.f ? u1n[j] : 0.f;
+    u1c[j] = h1c[j] > 0.f ? u1c[j] : 0.f;
+  }
+  f32x16 gb[2], gnx[2], gc[2];
+  gp_input_grad(u1b, S.bW1Tf + lane, Tb, gb);
+  gp_input_grad(u1n, S.pW1Tf + lane, Tp, gnx);
+  gp_input_grad(u1c, S.pW1Tf + lane, Tp, gc);
+  // G = gn / sigma (gradient w.r.t. the raw input); register (t, j) of a lane is column 32 t + 8 (j / 4) + 4 half + j % 4
+  auto colof = [&](int t, int j) { return 32 * t + 8 * (j >> 2) + 4 * half + (j & 3); };
+  float* Gb = S.tiles[wave][0] + lrow * GP_TS;
+  float* Gn = S.tiles[wave][1] + lrow * GP_TS;
+  float* Gc = S.tiles[wave][2] + lrow * GP_TS;
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int c0_ = 32 * t + 8 * q + 4 * half;
+      f32x4 vb, vn, vc;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        gb[t][4 * q + u] *= S.bistd[c0_ + u];
+        gnx[t][4 * q + u] *= S.pistd[c0_ + u];
+        gc[t][4 * q + u] *= S.pistd[c0_ + u];
+        vb[u] = gb[t][4 * q + u];
+        vn[u] = gnx[t][4 * q + u];
+        vc[u] = gc[t][4 * q + u];
+      }
+      *reinterpret_cast<f32x4*>(Gb + c0_) = vb;
+      *reinterpret_cast<f32x4*>(Gn + c0_) = vn;
+      *reinterpret_cast<f32x4*>(Gc + c0_) = vc;
+    }
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+
+  // ---- rows: T, |T|, coefficients. s' and s blocks are summed in the potential's column layout (own registers of
+  // gnx / gc + the base's entry from the tile), the action / done blocks in the base's.
+  const int od = a.od, ad = a.ad;
+  const int o_a = a.use_state ? od : 0, o_n = o_a + (a.use_action ? ad : 0), o_d = o_n + (a.use_next ? od : 0);
+  const float cdisc = a.gamma * (1.f - dhat);
+  f32x16 Ts[2], Tn[2];
+  float sq = 0.f;
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const int col = colof(t, j);
+      const bool on = col < od;
+      const float ts = on ? (a.use_state ? Gb[min(col, A_D_MAX - 1)] : 0.f) - gc[t][j] : 0.f;
+      const float tn = on ? (a.use_next ? Gb[min(o_n + col, A_D_MAX - 1)] : 0.f) + cdisc * gnx[t][j] : 0.f;
+      Ts[t][j] = ts;
+      Tn[t][j] = tn;
+      sq += ts * ts + tn * tn;
+      const bool in_a = a.use_action && col >= o_a && col < o_a + ad;
+      const bool in_d = a.use_done && col == o_d;
+      const float tb = (in_a || in_d) ? gb[t][j] : 0.f;
+      sq += tb * tb;
+    }
+  sq += __shfl_xor(sq, 32, 64);
+  const float nrm = sqrtf(sq);
+  const float kq = (live && nrm > 0.f) ? a.coef / (float)a.B * 2.f * (nrm - a.target) / nrm : 0.f;
+  const float pen_row = (live && half == 0) ? (nrm - a.target) * (nrm - a.target) : 0.f;
+  // Cn in each stack's chunk layout (= the B operand of the second pass)
+  f32x16 Cnb[2], Cnn[2], Cnc[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const int col = colof(t, j);
+      Cnn[t][j] = cdisc * kq * Tn[t][j] * S.pistd[col];
+      Cnc[t][j] = -kq * Ts[t][j] * S.pistd[col];
+      float tb;
+      if (a.use_state && col < od) tb = gb[t][j] - Gc[col];
+      else if (a.use_next && col >= o_n && col < o_n + od) tb = gb[t][j] + cdisc * Gn[min(max(col - o_n, 0), A_D_MAX - 1)];
+      else tb = gb[t][j];
+      Cnb[t][j] = col < a.Db ? kq * tb * S.bistd[col] : 0.f;
+    }
+
+  // ---- second pass
+  auto store_chunks = [&](float* dst, int ld, const f32x16 (&v)[2]) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int k0 = 32 * t + 8 * q + 4 * half;
+        if (k0 < ld) {
+          f32x4 o;
+#pragma unroll
+          for (int u = 0; u < 4; ++u) o[u] = v[t][4 * q + u];
+          *reinterpret_cast<f32x4*>(dst + k0) = o;
+        }
+      }
+  };
+  auto times_W1 = [&](const f32x16 (&cn)[2], const f32x4* wf, int chunks) {   // W1 . Cn  (32 features per row)
+    f32x16 acc = z;
+#pragma unroll
+    for (int q = 0; q < A_CH; ++q)
+      if (q < chunks) {
+        const f32x4 wv = wf[q * 64];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc = mfma(wv[u], cn[q >> 2][4 * (q & 3) + u], acc);
+      }
+    return acc;
+  };
+  f32x16 dV1b = times_W1(Cnb, bW1f, Cb);
+  f32x16 dV1n = times_W1(Cnn, pW1f, Cp), dV1c = times_W1(Cnc, pW1f, Cp);
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    dV1b[j] = hb[j] > 0.f ? dV1b[j] : 0.f;
+    dV1n[j] = h1n[j] > 0.f ? dV1n[j] : 0.f;
+    dV1c[j] = h1c[j] > 0.f ? dV1c[j] : 0.f;
+  }
+  f32x16 dV2n = chain32(z, dV1n, W2f), dV2c = chain32(z, dV1c, W2f);
+  f32x16 gwp, sc;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    gwp[j] = (h2n[j] > 0.f ? dV2n[j] : 0.f) + (h2c[j] > 0.f ? dV2c[j] : 0.f);
+    sc[j] = 0.f;
+  }
+  sc[0] = pen_row;
+  if (live) {
+    store_features(a.U1b + (long long)rr * AH, u1b, half);
+    store_chunks(a.Cb + (long long)rr * a.ldcb, a.ldcb, Cnb);
+    store_features(a.U1p + (long long)rr * AH, u1n, half);
+    store_features(a.U1p + (long long)(a.B + rr) * AH, u1c, half);
+    store_chunks(a.Cp + (long long)rr * a.ldcp, a.ldcp, Cnn);
+    store_chunks(a.Cp + (long long)(a.B + rr) * a.ldcp, a.ldcp, Cnc);
+    store_features(a.U2p + (long long)rr * AH, u2n, half);
+    store_features(a.U2p + (long long)(a.B + rr) * AH, u2c, half);
+    store_features(a.V1p + (long long)rr * AH, dV1n, half);
+    store_features(a.V1p + (long long)(a.B + rr) * AH, dV1c, half);
+  }
+  // (rows past the end: kq = 0, so every Cn and dV of theirs is zero)
+  const float s_b = half_sums16(dV1b, lane), s_p = half_sums16(gwp, lane), s_s = half_sums16(sc, lane);
+  {
+    const int j = ((lane >> 4) & 1) * 8 + ((lane >> 3) & 1) * 4 + ((lane >> 2) & 1) * 2 + ((lane >> 1) & 1);
+    const int feat = 8 * (j >> 2) + 4 * half + (j & 3);
+    if ((lane & 1) == 0) {
+      S.red[wave][feat] = s_b;
+      S.red[wave][AH + feat] = s_p;
+      if (half == 0 && j == 0) S.red[wave][2 * AH] = s_s;
+    }
+  }
+  __syncthreads();
+  if (tid < 2 * AH + 1) {
+    float tsum = S.red[0][tid];
+#pragma unroll
+    for (int wv = 1; wv < A_WAVES; ++wv) tsum += S.red[wv][tid];
+    float* slab = a.part + (long long)blockIdx.x * a.part_stride;
+    if (tid < AH) slab[a.off_b_wout + tid] = tsum;
+    else if (tid < 2 * AH) slab[a.off_p_wout + tid - AH] = tsum;
+    else a.pen_part[blockIdx.x] = tsum;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (tid == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned tk = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tk == gridDim.x - 1) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      float tsum = 0.f;
+      for (unsigned b = 0; b < gridDim.x; ++b) tsum += a.pen_part[b];
+      a.pen_out[0] = tsum / (float)a.B;
+      __hip_atomic_store(a.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -639,6 +988,63 @@ int ia_airl_stats_merge(const float* ws_b, const float* ws_n, const float* ws_c,
                      bmean, bvar, bcount, pmean, pvar, pcount, snapA, ticket);
   IA_CHECK_LAUNCH();
   return IA_OK;
+}
+
+/* Gradient penalty of AIRL's shaped reward (OPT-IN extension, no reference counterpart; imitation_amd/grad_penalty.py:
+ * coef * mean_i (|grad_(s,a,s',d) f|_2 - target)^2 at the interpolates e x_expert + (1-e) x_generator of the assembled
+ * batches, statistics frozen) for the geometry of ia_airl_fused_ok, its parameter gradient ADDED to `grads`
+ * ([base | potential] flat layout): one MFMA row kernel, three split-K weight-gradient GEMMs, one accumulate.
+ * Workspaces: U1b[B,32], Cb[B,ldb], U1p / U2p / V1p[2B,32], Cp[2B,ldp], partials [ia_airl_fused_slabs(B)][n_params]
+ * ZEROED once by the caller (bias entries are never written), pen_part[slabs], ticket (zeroed). pen_out[0] = the mean of
+ * (|grad f| - target)^2. */
+int ia_airl_gp_shaped(const float* Xb, int ldb, int Db, const float* Sn, const float* Sc, int ldp, int Dp,
+                      const float* dones, const float* e, const float* bmean, const float* bvar, float beps,
+                      const float* pmean, const float* pvar, float peps, const float* params_base,
+                      const float* params_pot, int obs_dim, int act_dim, int use_state, int use_action,
+                      int use_next_state, int use_done, float gamma, float coef, float target, int B, float* U1b,
+                      float* Cb, float* U1p, float* Cp, float* U2p, float* V1p, float* partials, float* pen_part,
+                      float* pen_out, unsigned* ticket, float* grads, void* stream) {
+  if (!Xb || !Sn || !Sc || !dones || !e || !params_base || !params_pot || !U1b || !Cb || !U1p || !Cp || !U2p || !V1p ||
+      !partials || !pen_part || !pen_out || !ticket || !grads || B <= 0)
+    return IA_ERR_ARG;
+  const int Dchk = (use_state ? obs_dim : 0) + (use_action ? act_dim : 0) + (use_next_state ? obs_dim : 0) + (use_done ? 1 : 0);
+  if (!ia_airl_fused_ok(Db, Dp, AH, AH, AH) || Dchk != Db || Dp != obs_dim || ldb % 4 || ldp % 4 || ldb < Db || ldp < Dp)
+    return IA_ERR_UNSUPPORTED;
+  const int nb = AH * Db + AH + AH + 1, np = AH * Dp + AH + AH * AH + AH + AH + 1;
+  const long long ptot = (long long)nb + np;
+  const int nblk = ia_airl_fused_slabs(B);
+  AirlGpArgs a{};
+  a.Xb = Xb; a.Sn = Sn; a.Sc = Sc; a.ldb = ldb; a.Db = Db; a.ldp = ldp; a.Dp = Dp; a.dones = dones; a.e = e;
+  a.bmean = bmean; a.bvar = bvar; a.pmean = pmean; a.pvar = pvar; a.beps = beps; a.peps = peps; a.Pb = params_base;
+  a.Pp = params_pot; a.od = obs_dim; a.ad = act_dim; a.use_state = use_state; a.use_action = use_action;
+  a.use_next = use_next_state; a.use_done = use_done; a.gamma = gamma; a.coef = coef; a.target = target; a.B = B;
+  a.U1b = U1b; a.Cb = Cb; a.ldcb = ldb; a.U1p = U1p; a.Cp = Cp; a.ldcp = ldp; a.U2p = U2p; a.V1p = V1p;
+  a.part = partials; a.part_stride = ptot; a.off_b_wout = AH * Db + AH; a.off_p_wout = nb + AH * Dp + AH + AH * AH + AH;
+  a.pen_part = pen_part; a.pen_out = pen_out; a.ticket = ticket;
+  static bool attr = false;
+  if (!attr) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(airl_gp_rows_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)sizeof(GpLds)) != hipSuccess)
+      return IA_ERR_ARG;
+    attr = true;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(airl_gp_rows_kernel, dim3(nblk), dim3(A_THREADS), sizeof(GpLds), st, a);
+  IA_CHECK_LAUNCH();
+  auto wgrad = [&](const float* u, const float* in, int ldin, int N, int K, long long w_off) {
+    IaGemm g{};
+    g.A = u; g.lda = AH; g.B = in; g.ldb = ldin; g.M = AH; g.N = N; g.K = K;
+    g.C = partials + w_off; g.ldc = N; g.splits = nblk; g.k_per_split = ((K + nblk - 1) / nblk + 31) / 32 * 32;
+    g.c_split_stride = ptot;
+    return ia_launch_gemm(IA_GEMM_TN, g, st);
+  };
+  int rc = wgrad(U1b, Cb, ldb, Db, B, 0);
+  if (rc) return rc;
+  rc = wgrad(U1p, Cp, ldp, Dp, 2 * B, nb);
+  if (rc) return rc;
+  rc = wgrad(U2p, V1p, AH, AH, 2 * B, (long long)nb + AH * Dp + AH);
+  if (rc) return rc;
+  return ia_reduce_partials(partials, nblk, ptot, 1.0f, 1, grads, stream);
 }
 
 }  // extern "C"

@@ -32,7 +32,9 @@ at the interpolated transition (d = the interpolated done flag, held constant; t
 input of the discriminator and carries no parameters), with the norm taken over the gradient w.r.t. EVERY input block.
 That gradient is a signed combination of the three stacks' input gradients (`ia_gp_shaped_coeffs`), each stack still
 piecewise linear: one first pass per stack evaluation, the row coefficients, one second pass per stack evaluation
-(`shaped_penalty_and_param_grad`).
+(`shaped_penalty_and_param_grad`). For the geometry of the fused AIRL update (widths 32, inputs <= 64 columns) the
+trainer uses `ShapedRewardNet.fused_grad_penalty` instead: the same arithmetic in one MFMA row kernel
+(`ia_airl_gp_shaped`, csrc/airl_fused.hip), checked against the same float64 graphs.
 """
 from __future__ import annotations
 

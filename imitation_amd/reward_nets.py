@@ -596,6 +596,35 @@ class ShapedRewardNet(ForwardWrapper):
             L.call("ia_reduce_partials", ws["part"].data_ptr(), ws["nblk"], g.numel(), 1.0, 0, g.data_ptr(), L.stream())
         return ws["logits"]
 
+    def fused_grad_penalty(self, e: th.Tensor, coef: float, target: float) -> th.Tensor:
+        """Opt-in gradient penalty (`grad_penalty.py`) of the shaped reward on the batch `fused_prepare` assembled last,
+        input statistics as they stand (frozen): `ia_airl_gp_shaped` ADDS the parameter gradient to the store's flat
+        gradient buffer. Returns the 1-element device tensor mean (|grad f| - target)^2."""
+        base, pot = self._base, self.potential._potential_net
+        bm = base.mlp
+        ws, R, n0, _ = self._fused
+        B = R // 2
+        if n0 != B or R != 2 * B:
+            raise ValueError("the gradient penalty interpolates expert and generator rows pairwise: equal halves needed")
+        gws = ws.get("gp")
+        if gws is None:
+            dev = self.device
+            nblk = int(L.load().ia_airl_fused_slabs(B))
+            gws = ws["gp"] = dict(U1b=th.empty(B, 32, device=dev), Cb=th.empty(B, bm.ldx, device=dev),
+                                  U1p=th.empty(2 * B, 32, device=dev), Cp=th.empty(2 * B, pot.ldx, device=dev),
+                                  U2p=th.empty(2 * B, 32, device=dev), V1p=th.empty(2 * B, 32, device=dev),
+                                  part=th.zeros(nblk, bm.n_params + pot.n_params, device=dev),
+                                  pen_part=th.empty(nblk, device=dev), pen=th.empty(1, device=dev),
+                                  ticket=th.zeros(1, dtype=th.int32, device=dev))
+        bn, pn = bm.norm, pot.norm
+        stat = lambda n: (n.running_mean.data_ptr(), n.running_var.data_ptr(), float(n.eps)) if n is not None else (None, None, 0.0)
+        L.call("ia_airl_gp_shaped", ws["out"][0], bm.ldx, bm.dims[0], ws["out"][2], ws["out"][3], pot.ldx, pot.dims[0],
+               ws["out"][5], L.ptr(e), *stat(bn), *stat(pn), bm.flat.data_ptr(), pot.flat.data_ptr(), base.obs_dim,
+               base.act_dim, *ws["flags"], self.discount_factor, float(coef), float(target), B,
+               *[gws[k].data_ptr() for k in ("U1b", "Cb", "U1p", "Cp", "U2p", "V1p", "part", "pen_part", "pen", "ticket")],
+               self._store.grad.data_ptr(), L.stream())
+        return gws["pen"]
+
     def fused_batches(self):
         """(Xb, ldb, Sn, Sc, ldp, dones) of the batch `fused_prepare` assembled last."""
         ws = self._fused[0]

@@ -257,6 +257,21 @@ int ia_airl_stats_merge(const float* ws_b, const float* ws_n, const float* ws_c,
                         float* bvar, int32_t* bcount, float* pmean, float* pvar, int32_t* pcount, float* snapA,
                         unsigned* ticket, void* stream);
 
+/* Gradient penalty of AIRL's shaped reward (OPT-IN extension, see ia_gp_shaped_coeffs) for the geometry of
+ * ia_airl_fused_ok, on the batches ia_airl_prepare assembled (Xb, Sn, Sc: [2B, ld] = [expert | generator] rows, dones[2B];
+ * e[B] interpolation weights; statistics frozen, null: none): coef * mean_i (|grad_(s,a,s',d) f|_2 - target)^2, its
+ * parameter gradient ADDED to grads ([base | potential] flat layout). One MFMA row kernel (forward masks, input
+ * gradients, row coefficients, second pass), three split-K weight-gradient GEMMs, one accumulate. Workspaces: U1b[B,32],
+ * Cb[B,ldb], U1p / U2p / V1p[2B,32], Cp[2B,ldp], partials[ia_airl_fused_slabs(B)][n_params] (ZEROED once by the caller),
+ * pen_part[slabs], ticket (one zeroed word). pen_out[0] = mean (|grad f| - target)^2. */
+int ia_airl_gp_shaped(const float* Xb, int ldb, int Db, const float* Sn, const float* Sc, int ldp, int Dp,
+                      const float* dones, const float* e, const float* bmean, const float* bvar, float beps,
+                      const float* pmean, const float* pvar, float peps, const float* params_base,
+                      const float* params_pot, int obs_dim, int act_dim, int use_state, int use_action,
+                      int use_next_state, int use_done, float gamma, float coef, float target, int B, float* U1b,
+                      float* Cb, float* U1p, float* Cp, float* U2p, float* V1p, float* partials, float* pen_part,
+                      float* pen_out, unsigned* ticket, float* grads, void* stream);
+
 /* rewards/reward_nets.py:637-671 `NormalizedRewardNet.predict_processed` applied once per env
  * step: out[t,:] = (raw[t,:]-mean)/sqrt(var+eps) with the statistics of steps < t, then (when
  * update_stats) the Chan update with raw[t,:]. mean/var are 1-element buffers, count int32. */

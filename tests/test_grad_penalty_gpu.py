@@ -112,6 +112,30 @@ def test_shaped_penalty_and_parameter_gradients_match_torch_double_backward(od, 
     for got, ref in ((gb, fb.grad), (gp, fp.grad)):
         scale = float(ref.abs().max())
         th.testing.assert_close(got.cpu().double(), ref, rtol=5e-4, atol=2e-5 * scale)
+    # ---- the one-kernel form for the fused geometry (csrc/airl_fused.hip: ia_airl_gp_shaped), ADDING to a gradient
+    lib = L.load()
+    assert lib.ia_airl_fused_ok(Db, od, 32, 32, 32)
+    nblk = int(lib.ia_airl_fused_slabs(B))
+    flat = th.cat([bflat, pflat]).to(DEV)
+    nbp = bflat.numel()
+    grads = th.full((flat.numel(),), 0.25, device=DEV)
+    ws = dict(U1b=th.empty(B, 32, device=DEV), Cb=th.empty(B, Xd.shape[1], device=DEV), U1p=th.empty(2 * B, 32, device=DEV),
+              Cp=th.empty(2 * B, Sn.shape[1], device=DEV), U2p=th.empty(2 * B, 32, device=DEV),
+              V1p=th.empty(2 * B, 32, device=DEV), part=th.zeros(nblk, flat.numel(), device=DEV),
+              pen_part=th.empty(nblk, device=DEV), pen=th.empty(1, device=DEV),
+              ticket=th.zeros(1, dtype=th.int32, device=DEV))
+    bn_, pn_ = todev(bnorm), todev(pnorm)
+    stat = lambda n: (L.ptr(n[0]), L.ptr(n[1]), float(n[2])) if n is not None else (None, None, 0.0)
+    dd, ed = done.to(DEV), e.to(DEV)
+    for _ in range(2):   # twice: the ticket / partial buffers must be reusable; the second call adds again
+        L.call("ia_airl_gp_shaped", L.ptr(Xd), Xd.shape[1], Db, L.ptr(Sn), L.ptr(Sc), Sn.shape[1], od, L.ptr(dd), L.ptr(ed),
+               *stat(bn_), *stat(pn_), L.ptr(flat), L.ptr(flat[nbp:]), od, ad, *flags, gamma, coef, target, B,
+               *[L.ptr(ws[k]) for k in ("U1b", "Cb", "U1p", "Cp", "U2p", "V1p", "part", "pen_part", "pen", "ticket")],
+               L.ptr(grads), L.stream())
+    th.testing.assert_close(ws["pen"][0].cpu().double(), pen_rows.mean().detach(), rtol=2e-5, atol=1e-6)
+    ref_all = th.cat([fb.grad, fp.grad])
+    scale = float(ref_all.abs().max())
+    th.testing.assert_close((grads.cpu().double() - 0.25) / 2, ref_all, rtol=5e-4, atol=3e-5 * scale)
 
 
 def test_airl_trainer_with_gradient_penalty(tmp_path):
