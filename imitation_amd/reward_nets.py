@@ -24,7 +24,7 @@ from imitation_amd.networks import (DenseStack, RunningNorm, TransitionTable, ev
 
 # tuning / tests: False forces the general (unfused) discriminator update even where the fused one applies
 FUSED_DISC_STEP = True
-FUSED_AIRL_STEP = True    # shaped reward nets of the default geometry take `ShapedRewardNet.disc_step_fused` (tests flip it)
+FUSED_AIRL_STEP = True    # shaped reward nets of the default geometry take `fused_prepare` / `fused_finish` (tests flip it)
 
 
 class ParamStore:

@@ -457,3 +457,46 @@ def test_one_rollout_noise_draw_equals_per_step_draws(n, A, T):
     th.manual_seed(3)
     one = th.empty(T, n, A).normal_()
     assert th.equal(seq, one) and th.equal(post_seq, th.get_rng_state())
+
+
+def test_adam_step_args_follow_torch_bias_corrections():
+    """`HipAdam.next_step_args` (the struct `ia_airl_step_shaped` finishes an update with): step counting and the
+    bias-correction scalars of `torch.optim.Adam` (`step_size = lr / (1 - b1^t)`, `sqrt(1 - b2^t)`), in double."""
+    import ctypes as C
+
+    from imitation_amd import _lib as L
+    from imitation_amd.networks import HipAdam
+
+    flat, grad = th.zeros(10), th.zeros(10)
+    opt = HipAdam(flat, grad, lr=3e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01)
+    for t in (1, 2, 3):
+        ref = opt.next_step_args()
+        a = C.cast(ref, C.POINTER(L.AdamArgs)).contents
+        assert opt.step_count == t
+        assert a.grads == grad.data_ptr() and a.exp_avg == opt.exp_avg.data_ptr() and a.exp_avg_sq == opt.exp_avg_sq.data_ptr()
+        assert a.step_size == np.float32(3e-4 / (1.0 - 0.9 ** t)) and a.bc2_sqrt == np.float32((1.0 - 0.999 ** t) ** 0.5)
+        assert (a.beta1, a.beta2, a.eps, a.weight_decay) == tuple(np.float32(v) for v in (0.9, 0.999, 1e-8, 0.01))
+    assert opt.state_dict()["state"][0]["step"] == 3
+
+
+def test_fused_airl_update_is_taken_only_for_its_geometry(monkeypatch):
+    """`ShapedRewardNet.fused_step_ok`: widths 32 / 32-32, ReLU, inputs the kernel covers, and the switch tests flip."""
+    import imitation_amd as p
+    from imitation_amd import reward_nets as rn, spaces
+
+    class _Lib:
+        @staticmethod
+        def ia_airl_fused_ok(Db, Dp, hb, hp1, hp2):
+            return int(hb == 32 and hp1 == 32 and hp2 == 32 and 1 <= Db <= 64 and 1 <= Dp <= 64)
+
+    monkeypatch.setattr(rn.L, "load", lambda: _Lib)
+    obs, act = spaces.Box(-1, 1, (11,), np.float32), spaces.Box(-1, 1, (3,), np.float32)
+    mk = lambda **kw: p.BasicShapedRewardNet(obs, act, **kw)
+    assert mk(reward_hid_sizes=(32,), potential_hid_sizes=(32, 32)).fused_step_ok()
+    assert not mk(reward_hid_sizes=(32, 32), potential_hid_sizes=(32, 32)).fused_step_ok()     # deeper reward net
+    assert not mk(reward_hid_sizes=(32,), potential_hid_sizes=(32,)).fused_step_ok()           # shallower potential
+    assert not mk(reward_hid_sizes=(64,), potential_hid_sizes=(32, 32)).fused_step_ok()        # other width
+    wide = spaces.Box(-1, 1, (70,), np.float32)
+    assert not p.BasicShapedRewardNet(wide, act, reward_hid_sizes=(32,), potential_hid_sizes=(32, 32)).fused_step_ok()
+    monkeypatch.setattr(rn, "FUSED_AIRL_STEP", False)
+    assert not mk(reward_hid_sizes=(32,), potential_hid_sizes=(32, 32)).fused_step_ok()
