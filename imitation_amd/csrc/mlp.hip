@@ -80,15 +80,25 @@ __global__ void reduce_adam_kernel(const float* __restrict__ partials, int split
   v[i] = vi;
 }
 
-__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
-                            float* __restrict__ v, long long n, float beta1, float beta2, float eps, float wd,
-                            float step_size, float bc2_sqrt) {
-  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
+// Step-dependent scalars of torch.optim.Adam from a DEVICE-resident step count, so that a captured launch sequence
+// (hipGraph replay of a whole PPO update, `GeneralTowers.ppo_update`) advances them without host arguments:
+// t = ++*step; scal = {lr / (1 - b1^t), sqrt(1 - b2^t)} in double like the host side of `ia_adam_step`'s callers.
+__global__ void adam_scalars_kernel(long long* __restrict__ step, double lr, double beta1, double beta2,
+                                    float* __restrict__ scal) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const long long t = *step + 1;
+  *step = t;
+  scal[0] = (float)(lr / (1.0 - pow(beta1, (double)t)));
+  scal[1] = (float)sqrt(1.0 - pow(beta2, (double)t));
+}
+
+// torch/optim/adam.py _single_tensor_adam for one element: lerp, mul+addcmul, sqrt/bc2_sqrt + eps, addcdiv
+__device__ __forceinline__ void adam_element(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                             float* __restrict__ v, long long i, float beta1, float beta2, float eps,
+                                             float wd, float step_size, float bc2_sqrt) {
   float grad = g[i];
   const float pi = p[i];
   if (wd != 0.f) grad = grad + wd * pi;
-  // torch/optim/adam.py _single_tensor_adam: lerp, mul+addcmul, sqrt/bc2_sqrt + eps, addcdiv
   float mi = m[i];
   mi = mi + (grad - mi) * (1.f - beta1);
   float vi = v[i] * beta2 + (1.f - beta2) * grad * grad;
@@ -96,6 +106,23 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
   p[i] = pi - step_size * (mi / denom);
   m[i] = mi;
   v[i] = vi;
+}
+
+__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                            float* __restrict__ v, long long n, float beta1, float beta2, float eps, float wd,
+                            float step_size, float bc2_sqrt) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  adam_element(p, g, m, v, i, beta1, beta2, eps, wd, step_size, bc2_sqrt);
+}
+
+// the same step with {step_size, bc2_sqrt} read from device memory (adam_scalars_kernel)
+__global__ void adam_dev_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                float* __restrict__ v, long long n, float beta1, float beta2, float eps, float wd,
+                                const float* __restrict__ scal) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  adam_element(p, g, m, v, i, beta1, beta2, eps, wd, scal[0], scal[1]);
 }
 
 // RunningNorm statistics. Stage 1: each block owns a contiguous slab of rows and produces, per
@@ -762,6 +789,23 @@ int ia_adam_step(float* params, const float* grads, float* exp_avg, float* exp_a
   if (n <= 0) return IA_ERR_ARG;
   hipLaunchKernelGGL(adam_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, params, grads, exp_avg,
                      exp_avg_sq, (long long)n, beta1, beta2, eps, weight_decay, step_size, bc2_sqrt);
+  IA_CHECK_LAUNCH();
+  return IA_OK;
+}
+
+int ia_adam_step_dev(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float beta1,
+                     float beta2, float eps, float weight_decay, const float* scalars, void* stream) {
+  if (n <= 0 || !scalars) return IA_ERR_ARG;
+  hipLaunchKernelGGL(adam_dev_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, params, grads, exp_avg,
+                     exp_avg_sq, (long long)n, beta1, beta2, eps, weight_decay, scalars);
+  IA_CHECK_LAUNCH();
+  return IA_OK;
+}
+
+int ia_adam_step_scalars(int64_t* step, double lr, double beta1, double beta2, float* scalars, void* stream) {
+  if (!step || !scalars) return IA_ERR_ARG;
+  hipLaunchKernelGGL(adam_scalars_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, reinterpret_cast<long long*>(step),
+                     lr, beta1, beta2, scalars);
   IA_CHECK_LAUNCH();
   return IA_OK;
 }

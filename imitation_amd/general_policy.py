@@ -65,6 +65,10 @@ def adopt(policy, pi, vf, activation_fn, ortho_init: bool, log_std_init: float) 
     policy._build_general(pi, vf, activation_fn, ortho_init, log_std_init)
 
 
+# tuning / tests: False keeps the PPO update of the generic stacks as individual launches (no hipGraph replay)
+GRAPH_UPDATES = True
+
+
 class GeneralTowers:
     fused = False
 
@@ -372,6 +376,52 @@ class GeneralTowers:
     def ppo_update(self, rb, perm_dev: th.Tensor, n_epochs: int, batch_size: int, normalize_advantage: bool,
                    clip_range: float, ent_coef: float, vf_coef: float, max_grad_norm: float, stats: th.Tensor,
                    dp=None) -> None:
+        """`_ppo_update_launches` (the ~35 launches per minibatch of the generic stacks are host-bound: ~250 us per
+        step of launch overhead against ~100 us of kernels), replayed as ONE hipGraph from the third update with the
+        same configuration on: the first runs eagerly (it also performs every kernel's one-time attribute set-up),
+        the second is captured -- Adam then takes its step-dependent scalars from a device-side step count
+        (`HipAdam.begin_device_steps`) -- and every later one is a single graph launch. Every buffer the sequence
+        touches is persistent (rollout tile, permutation, workspaces, parameters); the statistics land in a buffer
+        owned by the graph and are copied out. Not used under data parallelism (collectives between the launches)."""
+        opt = self.optimizer
+        n_steps = n_epochs * -(-(rb.buffer_size * rb.n_envs) // batch_size)
+        g0 = opt.param_groups[0] if isinstance(opt, HipAdam) else None
+        if not (GRAPH_UPDATES and g0 is not None and (dp is None or dp.world == 1) and self._flat.is_cuda):
+            return self._ppo_update_launches(rb, perm_dev, n_epochs, batch_size, normalize_advantage, clip_range,
+                                             ent_coef, vf_coef, max_grad_norm, stats, dp)
+        key = (rb.obs.data_ptr(), rb.acts.data_ptr(), rb.buffer_size, rb.n_envs, perm_dev.data_ptr(), n_epochs, batch_size,
+               bool(normalize_advantage), float(clip_range), float(ent_coef), float(vf_coef), float(max_grad_norm),
+               tuple(stats.shape), bool(self.training), float(g0["lr"]), tuple(g0["betas"]), float(g0["eps"]),
+               float(g0["weight_decay"]), th.cuda.current_device())
+        graphs = self.__dict__.setdefault("_update_graphs", {})
+        entry = graphs.get(key)
+        if entry is None:
+            if len(graphs) >= 4:     # (schedules that change every round would capture forever)
+                graphs.clear()
+            graphs[key] = "warm"
+            return self._ppo_update_launches(rb, perm_dev, n_epochs, batch_size, normalize_advantage, clip_range,
+                                             ent_coef, vf_coef, max_grad_norm, stats, dp)
+        if entry == "warm":
+            buf = th.zeros_like(stats)
+            graph = th.cuda.CUDAGraph()
+            opt.begin_device_steps()
+            try:
+                th.cuda.synchronize()
+                with th.cuda.graph(graph, capture_error_mode="thread_local"):
+                    self._ppo_update_launches(rb, perm_dev, n_epochs, batch_size, normalize_advantage, clip_range,
+                                              ent_coef, vf_coef, max_grad_norm, buf, None)
+            finally:
+                opt.end_device_steps(0)
+            entry = graphs[key] = (graph, buf)
+        graph, buf = entry
+        opt.sync_device_step()
+        graph.replay()
+        opt.step_count += n_steps
+        stats.copy_(buf)
+
+    def _ppo_update_launches(self, rb, perm_dev: th.Tensor, n_epochs: int, batch_size: int, normalize_advantage: bool,
+                             clip_range: float, ent_coef: float, vf_coef: float, max_grad_norm: float, stats: th.Tensor,
+                             dp=None) -> None:
         """All epochs x minibatches of one PPO update on the rollout tile `rb` (time-major `[T, n_envs, ...]`);
         `perm_dev[e]` = the epoch's `np.random.permutation(T * n_envs)` over SB3's env-major flattening
         ([SB3 RolloutBuffer.swap_and_flatten]: index i = env * T + t). `stats[e, mb, :8]` receives the minibatch

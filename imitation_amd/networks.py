@@ -318,8 +318,34 @@ class HipAdam:
     def zero_grad(self, set_to_none: bool = False) -> None:
         self.grad.zero_()
 
+    # ---- device-resident step count: for update loops that are captured once and replayed as a hipGraph ----------
+    def begin_device_steps(self) -> None:
+        """From here on `step()` takes its bias-correction scalars from a device-side step count (two launches per
+        step, no host-dependent kernel arguments), so a captured sequence of steps can be replayed; the host count is
+        advanced by the caller (`end_device_steps`)."""
+        if getattr(self, "_dev_step", None) is None:
+            self._dev_step = th.zeros(1, dtype=th.int64, device=self.flat.device)
+            self._dev_scal = th.zeros(2, device=self.flat.device)
+        self._dev_mode = True
+
+    def end_device_steps(self, steps_run: int = 0) -> None:
+        self._dev_mode = False
+        self.step_count += int(steps_run)
+
+    def sync_device_step(self) -> None:
+        """Sets the device-side count to the host's (before a replay)."""
+        self._dev_step.fill_(self.step_count)
+
     def step(self) -> None:
         g = self.param_groups[0]
+        if getattr(self, "_dev_mode", False):
+            b1, b2 = g["betas"]
+            s = L.stream()
+            L.call("ia_adam_step_scalars", L.ptr(self._dev_step), float(g["lr"]), float(b1), float(b2),
+                   L.ptr(self._dev_scal), s)
+            L.call("ia_adam_step_dev", L.ptr(self.flat), L.ptr(self.grad), L.ptr(self.exp_avg), L.ptr(self.exp_avg_sq),
+                   self.flat.numel(), b1, b2, g["eps"], g["weight_decay"], L.ptr(self._dev_scal), s)
+            return
         self.step_count += 1
         b1, b2 = g["betas"]
         bc1 = 1.0 - b1 ** self.step_count

@@ -90,6 +90,13 @@ int ia_reduce_partials_adam(const float* partials, int splits, int64_t n, float 
 int ia_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float beta1,
                  float beta2, float eps, float weight_decay, float step_size, float bc2_sqrt, void* stream);
 
+/* The same step with its step-dependent scalars kept on the DEVICE, for launch sequences that are captured once and
+ * replayed (hipGraph replay of a whole PPO update): `ia_adam_step_scalars` increments the int64 step count *step and
+ * writes scalars = {lr / (1 - b1^t), sqrt(1 - b2^t)} (double arithmetic); `ia_adam_step_dev` reads them. */
+int ia_adam_step_scalars(int64_t* step, double lr, double beta1, double beta2, float* scalars, void* stream);
+int ia_adam_step_dev(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float beta1,
+                     float beta2, float eps, float weight_decay, const float* scalars, void* stream);
+
 /* util/networks.py:111-134 `RunningNorm.update_stats` (Chan et al.), count is int32 on device.
  * ws: scratch of at least (2*D*blocks+...) floats, see ia_running_norm_ws_floats. */
 int64_t ia_running_norm_ws_floats(int R, int D);

@@ -160,6 +160,43 @@ def test_general_towers_agree_with_fused_kernels_on_a_shared_shape(discrete):
         np.testing.assert_allclose(y.cpu().numpy(), x.cpu().numpy(), rtol=1e-3, atol=1e-4)
 
 
+@pytest.mark.parametrize("discrete", [False, True])
+def test_general_towers_update_replayed_as_a_graph_equals_the_launch_sequence(discrete, monkeypatch):
+    """From the third update on `GeneralTowers.ppo_update` replays one captured hipGraph (Adam's step-dependent scalars
+    from a device-side count) instead of ~35 launches per minibatch: same parameters, optimiser state, step count and
+    logged statistics as the launch-by-launch run (device `pow` vs host `pow` may differ in the last bit of the step size)."""
+    import imitation_amd as ia
+    from imitation_amd import general_policy
+    from imitation_amd.vec_env import SyntheticVecEnv
+
+    outs = {}
+    for graphs in (True, False):
+        monkeypatch.setattr(general_policy, "GRAPH_UPDATES", graphs)
+        th.manual_seed(5)
+        np.random.seed(5)
+        venv = SyntheticVecEnv(num_envs=8, obs_dim=7, act_dim=3, horizon=9, seed=0, n_discrete=3 if discrete else None)
+        algo = ia.PPO(ia.ActorCriticPolicy, venv, n_steps=16, batch_size=48, n_epochs=2, ent_coef=0.02, seed=0,
+                      policy_kwargs=dict(net_arch=dict(pi=[24, 16], vf=[40]),
+                                         features_extractor_class=ia.NormalizeFeaturesExtractor,
+                                         features_extractor_kwargs=dict(normalize_class=ia.RunningNorm)), device="cuda")
+        assert not algo.policy.fused
+        algo.learn(16 * 8 * 6)       # six updates: eager, capture + replay, four replays
+        pol = algo.policy
+        used = [v for v in pol.__dict__.get("_update_graphs", {}).values() if v != "warm"]
+        assert (len(used) == 1) == graphs
+        outs[graphs] = ({k: v.detach().cpu().numpy().copy() for k, v in pol.state_dict().items()},
+                        pol.optimizer.exp_avg.cpu().numpy().copy(), pol.optimizer.step_count,
+                        {k: v for k, v in algo.logger.name_to_value.items() if k.startswith("train/")})
+    a, b = outs[True], outs[False]
+    assert a[2] == b[2] == 6 * 2 * 3
+    for k in a[0]:
+        np.testing.assert_allclose(a[0][k], b[0][k], rtol=2e-5, atol=2e-6, err_msg=k)
+    np.testing.assert_allclose(a[1], b[1], rtol=2e-5, atol=1e-7)
+    assert set(a[3]) == set(b[3])
+    for k in a[3]:
+        np.testing.assert_allclose(a[3][k], b[3][k], rtol=1e-4, atol=1e-6, err_msg=k)
+
+
 def test_general_towers_state_dict_checkpoint_and_bc(tmp_path):
     import imitation_amd as ia
     from imitation_amd import bc, spaces
