@@ -78,6 +78,7 @@ _SIGS = {
                                C.POINTER(C.c_int), _P, _P], C.c_int),
     "ia_airl_fused_ok": ([_I, _I, _I, _I, _I], C.c_int),
     "ia_airl_fused_slabs": ([_I], C.c_int),
+    "ia_airl_debug_timing": ([_P], C.c_int),
     "ia_airl_prepare": ([_P] * 6 + [_I] + [_P] * 6 + [_I] + [_I] * 6 + [_P, _I, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P],
                         C.c_int),
     "ia_airl_stats_merge": ([_P, _P, _P, _I, _I, _I] + [_P] * 9, C.c_int),

@@ -105,17 +105,51 @@ __device__ __forceinline__ float half_sums16(const f32x16& p, int lane) {
   return a1;
 }
 
+// Three independent vectors at once: each level's shuffles of all three are issued together, so the 16-step chain of
+// ~150-clock cross-lane operations is walked once, not three times.
+__device__ __forceinline__ void half_sums16x3(const f32x16& p0, const f32x16& p1, const f32x16& p2, int lane, float& r0,
+                                              float& r1, float& r2) {
+  const f32x16* p[3] = {&p0, &p1, &p2};
+  float a8[3][8], a4[3][4], a2[3][2], a1[3];
+  bool b = (lane & 16) != 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int v = 0; v < 3; ++v) a8[v][i] = (b ? (*p[v])[i + 8] : (*p[v])[i]) + __shfl_xor(b ? (*p[v])[i] : (*p[v])[i + 8], 16, 64);
+  b = (lane & 8) != 0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int v = 0; v < 3; ++v) a4[v][i] = (b ? a8[v][i + 4] : a8[v][i]) + __shfl_xor(b ? a8[v][i] : a8[v][i + 4], 8, 64);
+  b = (lane & 4) != 0;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int v = 0; v < 3; ++v) a2[v][i] = (b ? a4[v][i + 2] : a4[v][i]) + __shfl_xor(b ? a4[v][i] : a4[v][i + 2], 4, 64);
+  b = (lane & 2) != 0;
+#pragma unroll
+  for (int v = 0; v < 3; ++v) a1[v] = (b ? a2[v][1] : a2[v][0]) + __shfl_xor(b ? a2[v][0] : a2[v][1], 2, 64);
+#pragma unroll
+  for (int v = 0; v < 3; ++v) a1[v] += __shfl_xor(a1[v], 1, 64);
+  r0 = a1[0];
+  r1 = a1[1];
+  r2 = a1[2];
+}
+
 // All chunks of one input row, issued up front (the kernel's only HBM-latency exposure): chunk q of a lane in half h is
 // columns 8 q + 4 h .. + 3.
 __device__ __forceinline__ void load_row(const float* __restrict__ xrow, int ld, int chunks, int half, f32x4 (&raw)[A_CH]) {
+  // branch-free: behind a (wave-uniform) `if (q < chunks)` every load was followed by its own s_waitcnt at the end of the
+  // block -- 24 serial memory round trips, 5.4 us, before the kernel had done anything. Unused chunks re-read the row's
+  // last 16 bytes and are masked.
+  f32x4 v[A_CH];
+#pragma unroll
+  for (int q = 0; q < A_CH; ++q) v[q] = *reinterpret_cast<const f32x4*>(xrow + min(8 * q + 4 * half, ld - 4));
 #pragma unroll
   for (int q = 0; q < A_CH; ++q) {
-    raw[q] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (q < chunks) {
-      const int k0 = 8 * q + 4 * half;
-      const f32x4 v = *reinterpret_cast<const f32x4*>(xrow + min(k0, ld - 4));
-      if (k0 < ld) raw[q] = v;
-    }
+    const bool on = q < chunks && 8 * q + 4 * half < ld;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) raw[q][u] = on ? v[q][u] : 0.f;
   }
 }
 
@@ -161,6 +195,9 @@ __device__ __forceinline__ float dot_features(const f32x16& h, const f32x16& w) 
   return s + __shfl_xor(s, 32, 64);
 }
 
+long long* g_airl_tstamp = nullptr;   // debug: >= 16 shader clocks of workgroup 0's first wave (ia_airl_debug_timing)
+#define AIRL_TS(slot) do { if (ts && blockIdx.x == 0 && threadIdx.x == 0) ts[slot] = clock64(); } while (0)
+
 struct AirlLds {
   f32x4 bW1f[A_CH * 64], pW1f[A_CH * 64], W2f[4 * 64], W2tf[4 * 64];
   float vec[5 * AH + 4];            // b_b1, b_wout, p_b1, p_b2, p_wout, then bout_b, bout_p
@@ -169,8 +206,9 @@ struct AirlLds {
   int is_last;
 };
 
-__global__ __launch_bounds__(A_THREADS) void airl_rows_kernel(AirlArgs a) {
+__global__ __launch_bounds__(A_THREADS) void airl_rows_kernel(AirlArgs a, long long* __restrict__ ts) {
   __shared__ __attribute__((aligned(16))) AirlLds S;
+  AIRL_TS(0);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int half = lane >> 5;
   const int Cb = (a.Db + 7) >> 3, Cp = (a.Dp + 7) >> 3;
@@ -182,59 +220,83 @@ __global__ __launch_bounds__(A_THREADS) void airl_rows_kernel(AirlArgs a) {
   load_row(a.Sn + (long long)rr * a.ldp, a.ldp, Cp, half, rawn);
   load_row(a.Sc + (long long)rr * a.ldp, a.ldp, Cp, half, rawc);
   const float done = a.dones[rr], lp = a.logp[rr];
+  AIRL_TS(1);
 
   const float* Pb = a.Pb;
   const float* Pp = a.Pp;
   const int ob_b1 = AH * a.Db, ob_wout = ob_b1 + AH, ob_bout = ob_wout + AH;
   const int op_b1 = AH * a.Dp, op_W2 = op_b1 + AH, op_b2 = op_W2 + AH * AH, op_wout = op_b2 + AH, op_bout = op_wout + AH;
-  // weight fragments: entry (q, lane) = the four A values A[m = lane & 31][k = 8 q + 4 (lane >> 5) + u]
-  for (int e = tid; e < Cb * 64; e += A_THREADS) {
-    const int m = e & 31, k0 = 8 * (e >> 6) + 4 * ((e >> 5) & 1);
-    f32x4 w;
+  // weight fragments: entry (q, lane) = the four A values A[m = lane & 31][k = 8 q + 4 (lane >> 5) + u]. Staged
+  // branch-free -- every global load of a thread (clamped addresses, masked afterwards) is issued before its first LDS
+  // store: as loops with the loads inside, the staging was 14 serial memory round trips (3.3 us).
+  {
+    constexpr int NE = A_CH * 64 / A_THREADS;       // first-layer entries per thread and stack
+    static_assert(A_CH * 64 % A_THREADS == 0 && 4 * 64 == A_THREADS, "staging assumes 256 threads");
+    f32x4 wb[NE], wp[NE], w2, w2t;
 #pragma unroll
-    for (int u = 0; u < 4; ++u) w[u] = k0 + u < a.Db ? Pb[m * a.Db + k0 + u] : 0.f;
-    S.bW1f[e] = w;
-  }
-  for (int e = tid; e < Cp * 64; e += A_THREADS) {
-    const int m = e & 31, k0 = 8 * (e >> 6) + 4 * ((e >> 5) & 1);
-    f32x4 w;
+    for (int it = 0; it < NE; ++it) {
+      const int e = tid + it * A_THREADS;
+      const int m = e & 31, k0 = 8 * (e >> 6) + 4 * ((e >> 5) & 1);
 #pragma unroll
-    for (int u = 0; u < 4; ++u) w[u] = k0 + u < a.Dp ? Pp[m * a.Dp + k0 + u] : 0.f;
-    S.pW1f[e] = w;
-  }
-  for (int e = tid; e < 4 * 64; e += A_THREADS) {
-    const int m = e & 31, k0 = 8 * (e >> 6) + 4 * ((e >> 5) & 1);
-    f32x4 w, wt;
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      w[u] = Pp[op_W2 + m * AH + k0 + u];          // forward:  A[m = out][k = in]
-      wt[u] = Pp[op_W2 + (k0 + u) * AH + m];       // backward: A[m = in][k = out]
+      for (int u = 0; u < 4; ++u) {
+        wb[it][u] = Pb[m * a.Db + min(k0 + u, a.Db - 1)];
+        wp[it][u] = Pp[m * a.Dp + min(k0 + u, a.Dp - 1)];
+      }
     }
-    S.W2f[e] = w;
-    S.W2tf[e] = wt;
-  }
-  if (tid < AH) {
-    S.vec[tid] = Pb[ob_b1 + tid];
-    S.vec[AH + tid] = Pb[ob_wout + tid];
-    S.vec[2 * AH + tid] = Pp[op_b1 + tid];
-    S.vec[3 * AH + tid] = Pp[op_b2 + tid];
-    S.vec[4 * AH + tid] = Pp[op_wout + tid];
-  }
-  if (tid == 0) {
-    S.vec[5 * AH] = Pb[ob_bout];
-    S.vec[5 * AH + 1] = Pp[op_bout];
-  }
-  if (tid < A_D_MAX) {
-    const int k = tid;
-    const bool inb = k < a.Db, inp = k < a.Dp;
-    S.bmean[k] = (inb && a.bmean) ? a.bmean[k] : 0.f;
-    S.bistd[k] = inb ? (a.bmean ? 1.f / sqrtf(a.bvar[k] + a.beps) : 1.f) : 0.f;
-    S.pmA[k] = (inp && a.pmeanA) ? a.pmeanA[k] : 0.f;
-    S.piA[k] = inp ? (a.pmeanA ? 1.f / sqrtf(a.pvarA[k] + a.peps) : 1.f) : 0.f;
-    S.pmB[k] = (inp && a.pmeanA) ? a.pmeanB[k] : 0.f;
-    S.piB[k] = inp ? (a.pmeanA ? 1.f / sqrtf(a.pvarB[k] + a.peps) : 1.f) : 0.f;
+    {
+      const int m = tid & 31, k0 = 8 * (tid >> 6) + 4 * ((tid >> 5) & 1);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        w2[u] = Pp[op_W2 + m * AH + k0 + u];          // forward:  A[m = out][k = in]
+        w2t[u] = Pp[op_W2 + (k0 + u) * AH + m];       // backward: A[m = in][k = out]
+      }
+    }
+    const int vt = min(tid, AH - 1), kt = min(tid, A_D_MAX - 1);
+    const float v0 = Pb[ob_b1 + vt], v1 = Pb[ob_wout + vt], v2 = Pp[op_b1 + vt], v3 = Pp[op_b2 + vt], v4 = Pp[op_wout + vt];
+    const float vb0 = Pb[ob_bout], vb1 = Pp[op_bout];
+    const int kb = min(kt, a.Db - 1), kp = min(kt, a.Dp - 1);
+    const bool hb_ = a.bmean != nullptr, hp_ = a.pmeanA != nullptr;
+    const float sbm = hb_ ? a.bmean[kb] : 0.f, sbv = hb_ ? a.bvar[kb] : 1.f;
+    const float sam = hp_ ? a.pmeanA[kp] : 0.f, sav = hp_ ? a.pvarA[kp] : 1.f;
+    const float sqm = hp_ ? a.pmeanB[kp] : 0.f, sqv = hp_ ? a.pvarB[kp] : 1.f;
+#pragma unroll
+    for (int it = 0; it < NE; ++it) {
+      const int e = tid + it * A_THREADS;
+      const int k0 = 8 * (e >> 6) + 4 * ((e >> 5) & 1);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        wb[it][u] = k0 + u < a.Db ? wb[it][u] : 0.f;
+        wp[it][u] = k0 + u < a.Dp ? wp[it][u] : 0.f;
+      }
+      S.bW1f[e] = wb[it];
+      S.pW1f[e] = wp[it];
+    }
+    S.W2f[tid] = w2;
+    S.W2tf[tid] = w2t;
+    if (tid < AH) {
+      S.vec[tid] = v0;
+      S.vec[AH + tid] = v1;
+      S.vec[2 * AH + tid] = v2;
+      S.vec[3 * AH + tid] = v3;
+      S.vec[4 * AH + tid] = v4;
+    }
+    if (tid == 0) {
+      S.vec[5 * AH] = vb0;
+      S.vec[5 * AH + 1] = vb1;
+    }
+    if (tid < A_D_MAX) {
+      const int k = tid;
+      const bool inb = k < a.Db, inp = k < a.Dp;
+      S.bmean[k] = inb ? sbm : 0.f;
+      S.bistd[k] = inb ? (hb_ ? 1.f / sqrtf(sbv + a.beps) : 1.f) : 0.f;
+      S.pmA[k] = inp ? sam : 0.f;
+      S.piA[k] = inp ? (hp_ ? 1.f / sqrtf(sav + a.peps) : 1.f) : 0.f;
+      S.pmB[k] = inp ? sqm : 0.f;
+      S.piB[k] = inp ? (hp_ ? 1.f / sqrtf(sqv + a.peps) : 1.f) : 0.f;
+    }
   }
   __syncthreads();
+  AIRL_TS(2);
 
   const float* b_b1 = S.vec;
   const float* p_b1 = S.vec + 2 * AH;
@@ -259,6 +321,7 @@ __global__ __launch_bounds__(A_THREADS) void airl_rows_kernel(AirlArgs a) {
   }
   const float h_next = S.vec[5 * AH + 1] + dot_features(h2n, p_wout);
   const float h_cur = S.vec[5 * AH + 1] + dot_features(h2c, p_wout);
+  AIRL_TS(3);
 
   // logits (reward_nets.py:727-733 order, then airl.py:118) and BCE (bce_kernel's expressions); both halves hold them
   float f = g + a.gamma * ((1.f - done) * h_next);
@@ -310,9 +373,12 @@ __global__ __launch_bounds__(A_THREADS) void airl_rows_kernel(AirlArgs a) {
       store_features(a.H1 + row * AH, h1, half);
     }
   };
+  AIRL_TS(4);
   pot_back(h1n, h2n, dhn, (long long)rr);
   pot_back(h1c, h2c, dhc, (long long)(a.R + rr));
-  const float s_b = half_sums16(gb, lane), s_p = half_sums16(gp, lane), s_s = half_sums16(sc, lane);
+  AIRL_TS(5);
+  float s_b, s_p, s_s;
+  half_sums16x3(gb, gp, sc, lane, s_b, s_p, s_s);
   {
     const int j = ((lane >> 4) & 1) * 8 + ((lane >> 3) & 1) * 4 + ((lane >> 2) & 1) * 2 + ((lane >> 1) & 1);
     const int feat = 8 * (j >> 2) + 4 * half + (j & 3);
@@ -330,27 +396,45 @@ __global__ __launch_bounds__(A_THREADS) void airl_rows_kernel(AirlArgs a) {
     float* slab = a.part + (long long)blockIdx.x * a.part_stride;
     if (tid < AH) slab[a.off_b_wout + tid] = tsum;
     else if (tid < 2 * AH) slab[a.off_p_wout + tid - AH] = tsum;
-    else if (tid < 2 * AH + 6) a.bce_part[blockIdx.x * 8 + tid - 2 * AH] = tsum;
+    else if (tid < 2 * AH + 6)   // (written THROUGH to memory: the hand-off below then needs no L2 write-back)
+      __hip_atomic_store(a.bce_part + blockIdx.x * 8 + tid - 2 * AH, tsum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     else if (tid == 2 * AH + 6) slab[a.off_b_bout] = tsum;
     else slab[a.off_p_bout] = tsum;
   }
-  // statistics: the workgroup that draws the last ticket folds the partials in workgroup order (bce_kernel's hand-off)
+  // statistics: the workgroup that draws the last ticket folds the partials. Only the six partial sums cross
+  // workgroups inside this launch (everything else is read by the NEXT launches), so instead of an agent-scope release
+  // fence -- which writes back the ~160 KB of GEMM operands this workgroup has just stored: 5 us -- the partials go
+  // out as system-scope stores, are waited for (vmcnt), and are read back with system-scope loads.
+  AIRL_TS(6);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
+  AIRL_TS(7);
   if (tid == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const unsigned tk = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    AIRL_TS(8);
     S.is_last = (tk == gridDim.x - 1);
-    if (S.is_last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   }
   __syncthreads();
   if (!S.is_last) return;
-  if (tid < 6) {
-    float tsum = 0.f;
-    for (unsigned b = 0; b < gridDim.x; ++b) tsum += a.bce_part[b * 8 + tid];
-    if (tid == 0) tsum = tsum / (float)a.R * a.scale;
-    a.stats[tid] = tsum;
+  {
+    // fold: thread (k, j) sums workgroups j, j + 32, ... of statistic k with all its loads in flight, then lane j = 0
+    // adds the 32 partial sums in order -- fixed order, ~2 memory round trips instead of one per workgroup
+    const int k = tid >> 5, j = tid & 31;
+    float t = 0.f;
+    if (k < 6)
+      for (unsigned b = j; b < gridDim.x; b += 32)
+        t += __hip_atomic_load(a.bce_part + b * 8 + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    S.red[0][0] = 0.f;
+    __syncthreads();
+    float* fold = &S.red[0][0];          // (the block sums above are consumed: reuse 8 x 32 floats)
+    if (k < 8) fold[k * 32 + j] = t;
+    __syncthreads();
+    if (tid < 6) {
+      float tsum = 0.f;
+      for (int q = 0; q < 32; ++q) tsum += fold[tid * 32 + q];
+      if (tid == 0) tsum = tsum / (float)a.R * a.scale;
+      a.stats[tid] = tsum;
+    }
   }
   if (tid == 6) a.stats[6] = (float)a.n_expert;
   if (tid == 7) a.stats[7] = (float)(a.R - a.n_expert);
@@ -614,38 +698,49 @@ __global__ __launch_bounds__(A_THREADS) void airl_gp_rows_kernel(AirlGpArgs a) {
   const float* Pp = a.Pp;
   const int ob_b1 = AH * a.Db, ob_wout = ob_b1 + AH;
   const int op_b1 = AH * a.Dp, op_W2 = op_b1 + AH, op_b2 = op_W2 + AH * AH, op_wout = op_b2 + AH;
-  for (int e = tid; e < A_CH * 64; e += A_THREADS) {
-    const int m = e & 31, k0 = 8 * (e >> 6) + 4 * ((e >> 5) & 1);
-    f32x4 wb, wp;
+  {   // fragments, staged branch-free: all of a thread's global loads (clamped, masked afterwards) before its LDS stores
+    constexpr int NE = A_CH * 64 / A_THREADS;
+    f32x4 wb[NE], wp[NE], tb[NE], tp[NE], w2, w2t;
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      wb[u] = k0 + u < a.Db ? Pb[m * a.Db + k0 + u] : 0.f;
-      wp[u] = k0 + u < a.Dp ? Pp[m * a.Dp + k0 + u] : 0.f;
-    }
-    S.bW1f[e] = wb;
-    S.pW1f[e] = wp;
-  }
-  for (int e = tid; e < 2 * 4 * 64; e += A_THREADS) {   // W1^T fragments: A[m = column 32 t + (lane & 31)][k = feature]
-    const int t = e >> 8, q = (e >> 6) & 3, m = e & 31, f0 = 8 * q + 4 * ((e >> 5) & 1), col = 32 * t + m;
-    f32x4 wb, wp;
+    for (int it = 0; it < NE; ++it) {
+      const int e = tid + it * A_THREADS;
+      const int m = e & 31, k0 = 8 * (e >> 6) + 4 * ((e >> 5) & 1);
+      // W1^T entries: A[m = column 32 t + (lane & 31)][k = feature 8 q + 4 half + u]
+      const int t = e >> 8, f0 = 8 * ((e >> 6) & 3) + 4 * ((e >> 5) & 1), col = 32 * t + m;
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      wb[u] = col < a.Db ? Pb[(f0 + u) * a.Db + col] : 0.f;
-      wp[u] = col < a.Dp ? Pp[(f0 + u) * a.Dp + col] : 0.f;
+      for (int u = 0; u < 4; ++u) {
+        wb[it][u] = Pb[m * a.Db + min(k0 + u, a.Db - 1)];
+        wp[it][u] = Pp[m * a.Dp + min(k0 + u, a.Dp - 1)];
+        tb[it][u] = Pb[(f0 + u) * a.Db + min(col, a.Db - 1)];
+        tp[it][u] = Pp[(f0 + u) * a.Dp + min(col, a.Dp - 1)];
+      }
     }
-    S.bW1Tf[e] = wb;
-    S.pW1Tf[e] = wp;
-  }
-  for (int e = tid; e < 4 * 64; e += A_THREADS) {
-    const int m = e & 31, k0 = 8 * (e >> 6) + 4 * ((e >> 5) & 1);
-    f32x4 wf, wt;
+    {
+      const int m = tid & 31, k0 = 8 * (tid >> 6) + 4 * ((tid >> 5) & 1);
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      wf[u] = Pp[op_W2 + m * AH + k0 + u];
-      wt[u] = Pp[op_W2 + (k0 + u) * AH + m];
+      for (int u = 0; u < 4; ++u) {
+        w2[u] = Pp[op_W2 + m * AH + k0 + u];
+        w2t[u] = Pp[op_W2 + (k0 + u) * AH + m];
+      }
     }
-    S.W2f[e] = wf;
-    S.W2tf[e] = wt;
+#pragma unroll
+    for (int it = 0; it < NE; ++it) {
+      const int e = tid + it * A_THREADS;
+      const int k0 = 8 * (e >> 6) + 4 * ((e >> 5) & 1), col = 32 * (e >> 8) + (e & 31);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        wb[it][u] = k0 + u < a.Db ? wb[it][u] : 0.f;
+        wp[it][u] = k0 + u < a.Dp ? wp[it][u] : 0.f;
+        tb[it][u] = col < a.Db ? tb[it][u] : 0.f;
+        tp[it][u] = col < a.Dp ? tp[it][u] : 0.f;
+      }
+      S.bW1f[e] = wb[it];
+      S.pW1f[e] = wp[it];
+      S.bW1Tf[e] = tb[it];
+      S.pW1Tf[e] = tp[it];
+    }
+    S.W2f[tid] = w2;
+    S.W2tf[tid] = w2t;
   }
   if (tid < AH) {
     S.vec[tid] = Pb[ob_b1 + tid];
@@ -822,7 +917,8 @@ __global__ __launch_bounds__(A_THREADS) void airl_gp_rows_kernel(AirlGpArgs a) {
     store_features(a.V1p + (long long)(a.B + rr) * AH, dV1c, half);
   }
   // (rows past the end: kq = 0, so every Cn and dV of theirs is zero)
-  const float s_b = half_sums16(dV1b, lane), s_p = half_sums16(gwp, lane), s_s = half_sums16(sc, lane);
+  float s_b, s_p, s_s;
+  half_sums16x3(dV1b, gwp, sc, lane, s_b, s_p, s_s);
   {
     const int j = ((lane >> 4) & 1) * 8 + ((lane >> 3) & 1) * 4 + ((lane >> 2) & 1) * 2 + ((lane >> 1) & 1);
     const int feat = 8 * (j >> 2) + 4 * half + (j & 3);
@@ -840,18 +936,17 @@ __global__ __launch_bounds__(A_THREADS) void airl_gp_rows_kernel(AirlGpArgs a) {
     float* slab = a.part + (long long)blockIdx.x * a.part_stride;
     if (tid < AH) slab[a.off_b_wout + tid] = tsum;
     else if (tid < 2 * AH) slab[a.off_p_wout + tid - AH] = tsum;
-    else a.pen_part[blockIdx.x] = tsum;
+    else __hip_atomic_store(a.pen_part + blockIdx.x, tsum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
+  // (hand-off as in airl_rows_kernel: the one value that crosses workgroups goes out write-through, no L2 write-back)
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (tid == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const unsigned tk = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (tk == gridDim.x - 1) {
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
       float tsum = 0.f;
-      for (unsigned b = 0; b < gridDim.x; ++b) tsum += a.pen_part[b];
+      for (unsigned b = 0; b < gridDim.x; ++b)
+        tsum += __hip_atomic_load(a.pen_part + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       a.pen_out[0] = tsum / (float)a.B;
       __hip_atomic_store(a.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
@@ -861,6 +956,9 @@ __global__ __launch_bounds__(A_THREADS) void airl_gp_rows_kernel(AirlGpArgs a) {
 }  // namespace
 
 extern "C" {
+
+/* Debug / measurement: shader-clock stamps of the row kernel's phases (workgroup 0) into `buf` (>= 16 int64; null: off). */
+int ia_airl_debug_timing(long long* buf) { g_airl_tstamp = buf; return IA_OK; }
 
 /* Geometry the fused AIRL update covers: reward MLP Db -> 32 -> 1, potential MLP Dp -> 32 -> 32 -> 1 (ReLU). */
 int ia_airl_fused_ok(int Db, int Dp, int hb, int hp1, int hp2) {
@@ -903,7 +1001,7 @@ int ia_airl_step_shaped(const float* Xb, int ldb, int Db, const float* Sn, const
   a.off_p_wout = nb + AH * Dp + AH + AH * AH + AH; a.off_p_bout = a.off_p_wout + AH;
   a.logits = logits; a.stats = stats; a.bce_part = bce_part; a.ticket = ticket;
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(airl_rows_kernel, dim3(nblk), dim3(A_THREADS), 0, st, a);
+  hipLaunchKernelGGL(airl_rows_kernel, dim3(nblk), dim3(A_THREADS), 0, st, a, g_airl_tstamp);
   IA_CHECK_LAUNCH();
   // hidden-layer weight gradients: dW = delta^T . input over the rows, one split-K slab per 128 (256) rows; bias
   // gradients = column sums of delta. Slab s of `partials` is what workgroup s of the rows kernel wrote into.

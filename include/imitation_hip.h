@@ -233,6 +233,8 @@ typedef struct ia_adam_args {   /* torch.optim.Adam step over one flat buffer, s
 } ia_adam_args;
 int ia_airl_fused_ok(int Db, int Dp, int hb, int hp1, int hp2);
 int ia_airl_fused_slabs(int R);
+/* measurement: shader-clock stamps of the row kernel's phases (workgroup 0) into buf (>= 16 int64; NULL: off) */
+int ia_airl_debug_timing(long long* buf);
 int ia_airl_step_shaped(const float* Xb, int ldb, int Db, const float* Sn, const float* Sc, int ldp, int Dp,
                         const float* dones, const float* logp, const float* bmean, const float* bvar, float beps,
                         const float* pmeanA, const float* pvarA, const float* pmeanB, const float* pvarB, float peps,
