@@ -217,7 +217,7 @@ def build_trainer(impl: str, cfg, log_dir: str, device: str = "cpu", module_net:
     else:
         net = ns.BasicShapedRewardNet(venv.observation_space, venv.action_space,
                                       reward_hid_sizes=cfg["disc_hid"], potential_hid_sizes=(32, 32),
-                                      use_next_state=True, **kw)
+                                      use_next_state=cfg.get("use_next_state", True), **kw)
         if cfg.get("normalize_output"):
             net = ns.NormalizedRewardNet(net, disc_norm)
         cls = ns.AIRL

@@ -133,7 +133,9 @@ def test_pipelined_rounds_are_bit_identical(tmp_path, case):
 
 
 @pytest.mark.parametrize("over", [dict(), dict(demo_batch=300, n_demo=400, norm_disc=False),
-                                  dict(obs_dim=17, act_dim=6, demo_batch=640, n_demo=700)])
+                                  dict(obs_dim=17, act_dim=6, demo_batch=640, n_demo=700),
+                                  # > 32 potential inputs (two column tiles / five chunks), the scripts' default blocks
+                                  dict(obs_dim=40, act_dim=5, demo_batch=200, n_demo=300, use_next_state=False)])
 def test_fused_airl_update_matches_the_general_schedule(over, tmp_path, monkeypatch):
     """`ShapedRewardNet.fused_prepare / fused_finish` (csrc/airl_fused.hip: assembly + statistics, one row-kernel + three split-K weight-gradient GEMMs +
     reduce/Adam) against the layer-by-layer schedule it replaces, over whole training runs: same statistics, logits

@@ -57,7 +57,7 @@ def test_penalty_and_parameter_gradient_match_torch_double_backward(dims, B, nor
 
 
 @pytest.mark.parametrize("od,ad,flags,B,norm", [(11, 3, (1, 1, 0, 0), 200, True), (27, 8, (1, 1, 1, 1), 1024, True),
-                                                (5, 2, (0, 1, 1, 0), 77, False)])
+                                                (5, 2, (0, 1, 1, 0), 77, False), (40, 5, (1, 1, 0, 0), 300, True)])
 def test_shaped_penalty_and_parameter_gradients_match_torch_double_backward(od, ad, flags, B, norm):
     """AIRL's shaped reward f = g([s|a|s'|d]) + gamma (1 - d) h(s') - h(s): penalty on |grad_(s,a,s',d) f| at the
     interpolated transition, parameter gradients of both stacks, vs a float64 double-backward graph."""
