@@ -1010,13 +1010,13 @@ int ia_airl_step_shaped(const float* Xb, int ldb, int Db, const float* Sn, const
     w.A = delta; w.lda = AH; w.B = in; w.ldb = ldin; w.M = AH; w.N = N; w.K = K;
     w.C = partials + w_off; w.ldc = N; w.splits = nblk; w.k_per_split = ((K + nblk - 1) / nblk + 31) / 32 * 32;
     w.c_split_stride = ptot; w.dbias = partials + b_off; w.dbias_split_stride = ptot;
-    return ia_launch_gemm(IA_GEMM_TN, w, st);
+    return w;
   };
-  int rc = wgrad(Db1, Ab, ldab, Db, R, 0, (long long)AH * Db);
-  if (rc) return rc;
-  rc = wgrad(Dp1, Ap, ldap, Dp, 2 * R, nb, (long long)nb + AH * Dp);
-  if (rc) return rc;
-  rc = wgrad(Dp2, H1, AH, AH, 2 * R, (long long)nb + AH * Dp + AH, (long long)nb + AH * Dp + AH + AH * AH);
+  // (one grouped launch: 3 x nblk workgroups together instead of three latency-bound launches of nblk each)
+  const IaGemm ws3[3] = {wgrad(Db1, Ab, ldab, Db, R, 0, (long long)AH * Db),
+                         wgrad(Dp1, Ap, ldap, Dp, 2 * R, nb, (long long)nb + AH * Dp),
+                         wgrad(Dp2, H1, AH, AH, 2 * R, (long long)nb + AH * Dp + AH, (long long)nb + AH * Dp + AH + AH * AH)};
+  int rc = ia_launch_gemm_group_tn(ws3, 3, st);
   if (rc || !adam) return rc;
   if (!adam->grads || !adam->exp_avg || !adam->exp_avg_sq || params_pot != params_base + nb) return IA_ERR_ARG;
   return ia_reduce_partials_adam(partials, nblk, ptot, 1.0f, adam->grads, const_cast<float*>(params_base), adam->exp_avg,
@@ -1134,13 +1134,11 @@ int ia_airl_gp_shaped(const float* Xb, int ldb, int Db, const float* Sn, const f
     g.A = u; g.lda = AH; g.B = in; g.ldb = ldin; g.M = AH; g.N = N; g.K = K;
     g.C = partials + w_off; g.ldc = N; g.splits = nblk; g.k_per_split = ((K + nblk - 1) / nblk + 31) / 32 * 32;
     g.c_split_stride = ptot;
-    return ia_launch_gemm(IA_GEMM_TN, g, st);
+    return g;
   };
-  int rc = wgrad(U1b, Cb, ldb, Db, B, 0);
-  if (rc) return rc;
-  rc = wgrad(U1p, Cp, ldp, Dp, 2 * B, nb);
-  if (rc) return rc;
-  rc = wgrad(U2p, V1p, AH, AH, 2 * B, (long long)nb + AH * Dp + AH);
+  const IaGemm gs3[3] = {wgrad(U1b, Cb, ldb, Db, B, 0), wgrad(U1p, Cp, ldp, Dp, 2 * B, nb),
+                         wgrad(U2p, V1p, AH, AH, 2 * B, (long long)nb + AH * Dp + AH)};
+  int rc = ia_launch_gemm_group_tn(gs3, 3, st);
   if (rc) return rc;
   return ia_reduce_partials(partials, nblk, ptot, 1.0f, 1, grads, stream);
 }

@@ -61,6 +61,8 @@ struct IaGemm {
 };
 
 int ia_launch_gemm(int mode, const IaGemm& g, hipStream_t stream);
+// n <= 3 independent split-K TN GEMMs whose outputs have <= 32 rows, in one launch
+int ia_launch_gemm_group_tn(const IaGemm* gs, int n, hipStream_t stream);
 
 __device__ __forceinline__ float ia_softplus(float x) {
   return fmaxf(x, 0.0f) + log1pf(expf(-fabsf(x)));

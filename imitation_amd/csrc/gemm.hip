@@ -442,10 +442,10 @@ __device__ __forceinline__ void gemm_tile(const IaGemm& g, const TileCtx& tc, fl
   if (do_db && tid < BM && bm0 + tid < g.M) g.dbias[(long long)tc.split * g.dbias_split_stride + bm0 + tid] = dbacc;
 }
 
+// Workgroup `b` of `nb` of one GEMM (the body of ia_gemm_kernel; also run per problem by the grouped launch below).
 template <int WM, int WN, int TM, int TN, int MODE, bool IM = false>
-__global__ __launch_bounds__(WM* WN * 64) void ia_gemm_kernel(IaGemm g) {
+__device__ __forceinline__ void gemm_block(const IaGemm& g, float* smem, const int nb, const int b) {
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
-  extern __shared__ __attribute__((aligned(16))) float smem[];
 
   // XCD-aware block order: hardware places block b on XCD b%8. Give each XCD a CONTIGUOUS run of
   // (split, tile) work items: column tiles that share an A row-block -- and, for split-K, all the
@@ -454,8 +454,6 @@ __global__ __launch_bounds__(WM* WN * 64) void ia_gemm_kernel(IaGemm g) {
   const int tiles_n = (g.N + BN - 1) / BN;
   const int tiles_m = (g.M + BM - 1) / BM;
   const int tiles = tiles_m * tiles_n;
-  const int nb = gridDim.x;
-  const int b = blockIdx.x;
   const int q = nb >> 3, rmd = nb & 7, xcd = b & 7;
   const int lin = (xcd < rmd ? xcd * (q + 1) : rmd * (q + 1) + (xcd - rmd) * q) + (b >> 3);
   TileCtx tc;
@@ -479,6 +477,25 @@ __global__ __launch_bounds__(WM* WN * 64) void ia_gemm_kernel(IaGemm g) {
   } else {
     gemm_tile<WM, WN, TM, TN, MODE, false, IM>(g, tc, smem);
   }
+}
+
+template <int WM, int WN, int TM, int TN, int MODE, bool IM = false>
+__global__ __launch_bounds__(WM* WN * 64) void ia_gemm_kernel(IaGemm g) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  gemm_block<WM, WN, TM, TN, MODE, IM>(g, smem, gridDim.x, blockIdx.x);
+}
+
+// Up to three independent split-K TN GEMMs in ONE launch (32-row outputs: the hidden-layer weight gradients of the small
+// AIRL stacks, 10-16 us each when launched one after the other -- latency-bound with 128 workgroups; together they
+// fill the chip): workgroups [0, nb0) run problem 0, [nb0, nb0 + nb1) problem 1, the rest problem 2.
+struct IaGemm3 { IaGemm p[3]; int nb[3]; };
+template <int WM, int WN, int TM, int TN>
+__global__ __launch_bounds__(WM* WN * 64) void ia_gemm_group_tn_kernel(IaGemm3 gs) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int b = blockIdx.x;
+  if (b < gs.nb[0]) gemm_block<WM, WN, TM, TN, IA_GEMM_TN>(gs.p[0], smem, gs.nb[0], b);
+  else if (b < gs.nb[0] + gs.nb[1]) gemm_block<WM, WN, TM, TN, IA_GEMM_TN>(gs.p[1], smem, gs.nb[1], b - gs.nb[0]);
+  else gemm_block<WM, WN, TM, TN, IA_GEMM_TN>(gs.p[2], smem, gs.nb[2], b - gs.nb[0] - gs.nb[1]);
 }
 
 // ---- optional per-launch timing with HIP events on the launch stream (bench.py roofline) ----
@@ -560,6 +577,39 @@ int ia_launch_gemm(int mode, const IaGemm& g, hipStream_t stream) {
     case IA_GEMM_TN: return launch_mode<IA_GEMM_TN>(g, stream);
   }
   return IA_ERR_ARG;
+}
+
+// n <= 3 split-K TN GEMMs with M <= 32 in one launch (32 x 128 tiles)
+int ia_launch_gemm_group_tn(const IaGemm* gs, int n, hipStream_t stream) {
+  if (n < 1 || n > 3) return IA_ERR_ARG;
+  constexpr int WM = 1, WN = 4, TM = 1, TN = 1, NT = WM * WN * 64, BM = 32, BN = 128;
+  using AIO = TileIO<BM, NT, true>;
+  using BIO = TileIO<BN, NT, true>;
+  constexpr size_t smem = 2 * (AIO::ELEMS + BIO::ELEMS) * sizeof(float);
+  IaGemm3 a{};
+  int total = 0;
+  for (int i = 0; i < 3; ++i) {
+    if (i < n) {
+      const IaGemm& g = gs[i];
+      if (g.M <= 0 || g.M > BM || g.N <= 0 || g.K < 0 || g.im.on || g.splits < 1) return IA_ERR_ARG;
+      a.p[i] = g;
+      a.nb[i] = ((g.N + BN - 1) / BN) * g.splits;
+    } else {
+      a.nb[i] = 0;
+    }
+    total += a.nb[i];
+  }
+  auto kern = ia_gemm_group_tn_kernel<WM, WN, TM, TN>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)smem);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(total), dim3(NT), smem, stream, a);
+  IA_CHECK_LAUNCH();
+  return IA_OK;
 }
 
 extern "C" int ia_gemm_set_config(int cfg) { g_force_cfg = cfg; return IA_OK; }
