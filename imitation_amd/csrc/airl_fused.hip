@@ -424,9 +424,7 @@ __global__ __launch_bounds__(A_THREADS) void airl_rows_kernel(AirlArgs a, long l
     if (k < 6)
       for (unsigned b = j; b < gridDim.x; b += 32)
         t += __hip_atomic_load(a.bce_part + b * 8 + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    S.red[0][0] = 0.f;
-    __syncthreads();
-    float* fold = &S.red[0][0];          // (the block sums above are consumed: reuse 8 x 32 floats)
+    float* fold = &S.red[0][0];          // (the block sums above were consumed before the last barrier: reuse 8 x 32 floats)
     if (k < 8) fold[k * 32 + j] = t;
     __syncthreads();
     if (tid < 6) {

@@ -21,7 +21,7 @@ L.load().ia_airl_debug_timing(None)
 t = buf.cpu().numpy()
 names = ["row loads issued", "weights staged in LDS (+ barrier)", "three forwards + outputs", "logits / BCE / base deltas stored",
          "potential deltas (2 chains) + stores", "output-layer sums (shuffles) + slab", "stores acknowledged + barrier",
-         "release fence + ticket"]
+         "ticket (write-through hand-off)"]
 for n, d in zip(names, np.diff(t[:9])):
     print(f"  {n:44s} {d:8d} clk  ~{d / 2.4e3:6.2f} us @2.4GHz")
 print("  total", t[8] - t[0], "clk")
