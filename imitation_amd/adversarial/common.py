@@ -541,7 +541,7 @@ class AdversarialTrainer(abc.ABC):
                     logits = basic.fused_finish(logp, scale, stats_dev, None if gp else fuse_adam)
                     fused_step = not gp
                     if gp:   # penalty gradient on top of the reduced BCE gradient, then the optimiser step below
-                        e = th.rand(mb).to(self._device)   # interpolation weights: torch's global CPU generator
+                        e = self._gp_weights(mb)   # interpolation weights: torch's global CPU generator
                         self.last_grad_penalty = basic.fused_grad_penalty(
                             e, self.disc_grad_penalty_coef * scale, self.disc_grad_penalty_target)[0]
                     first = False
@@ -565,11 +565,32 @@ class AdversarialTrainer(abc.ABC):
         self._disc_step += 1
         self._last_disc_logits = logits
 
+    def _gp_weights(self, mb: int) -> th.Tensor:
+        """`th.rand(mb)` from torch's global CPU generator, on the device WITHOUT blocking the host: a plain
+        `.to(device)` of pageable memory is a synchronous copy in stream order, i.e. the host waits for every update
+        enqueued before it (250 us of host time per update measured with the penalty on). The draw goes into a ring of
+        pinned buffers and is copied asynchronously; a slot is reused only after its copy has been consumed."""
+        ring = getattr(self, "_gp_ring", None)
+        if ring is None or ring[0].shape[1] != mb:
+            n = 32
+            ring = self._gp_ring = (th.empty(n, mb).pin_memory(), th.empty(n, mb, device=self._device),
+                                    [None] * n, [0])
+        host, dev, events, counter = ring
+        k = counter[0] % host.shape[0]
+        counter[0] += 1
+        if events[k] is not None:
+            events[k].synchronize()
+        th.rand(mb, out=host[k])
+        dev[k].copy_(host[k], non_blocking=True)
+        events[k] = th.cuda.Event()
+        events[k].record()
+        return dev[k]
+
     def _add_grad_penalty(self, mlp, X: th.Tensor, norm, mb: int, scale: float) -> None:
         """Adds the gradient-penalty parameter gradient of one minibatch (`X[2*mb, ldx]` = [expert | generator] rows
         as assembled, `norm` = the (mean, var, eps) its forward normalised with, or None) to the flat gradient."""
         from imitation_amd import grad_penalty
-        e = th.rand(mb).to(self._device)      # interpolation weights: torch's global CPU generator (only when enabled)
+        e = self._gp_weights(mb)      # interpolation weights: torch's global CPU generator (only when enabled)
         mean, var, eps = norm if norm is not None else (None, None, 0.0)
         pen, g = grad_penalty.penalty_and_param_grad(mlp.flat, mlp.dims, mlp.desc.hidden_act, X, mlp.ldx, mb, e, mean,
                                                      var, eps, self.disc_grad_penalty_coef * scale,
@@ -589,7 +610,7 @@ class AdversarialTrainer(abc.ABC):
         bm = base.mlp
         if pot.desc.hidden_act != bm.desc.hidden_act:
             raise NotImplementedError("the gradient penalty needs the same activation in both stacks")
-        e = th.rand(mb).to(self._device)      # interpolation weights: torch's global CPU generator (only when enabled)
+        e = self._gp_weights(mb)      # interpolation weights: torch's global CPU generator (only when enabled)
         stats = lambda n: None if n is None else (n.running_mean, n.running_var, n.eps)
         pen, gb, gpot = grad_penalty.shaped_penalty_and_param_grad(
             bm.flat, bm.dims, pot.flat, pot.dims, bm.desc.hidden_act, Xb, ldb, Sn, Sc, ldp, dones, mb, e, base.obs_dim, base.act_dim, base.flags, stats(bm.norm), stats(pot.norm),
@@ -654,7 +675,7 @@ class AdversarialTrainer(abc.ABC):
         with th.no_grad():
             X = net.concat_inputs(state, action, next_state, done).contiguous()
             nrm = getattr(mlp, mlp._norm_name) if mlp._norm_name is not None else None
-            e = th.rand(mb).to(self._device)
+            e = self._gp_weights(mb)
             pen, g = grad_penalty.penalty_and_param_grad(
                 mlp.flat_parameters().contiguous(), mlp.dims, mlp.act, X, X.shape[1], mb, e,
                 None if nrm is None else nrm.running_mean, None if nrm is None else nrm.running_var,
