@@ -203,3 +203,17 @@ def test_gradient_penalty_on_the_fused_shape_and_unsupported_nets(tmp_path):
     at.train_gen()
     with pytest.raises(NotImplementedError, match="BasicRewardNet"):
         at.train_disc()
+
+
+def test_interpolation_weights_ring_reproduces_the_generator_stream(tmp_path):
+    """`_gp_weights`: the draws are `th.rand(mb)` of torch's global CPU generator, uploaded through a ring of pinned
+    buffers (no blocking copy in stream order); slots are reused (ring of 32) without clobbering pending uploads."""
+    tr, _ = harness.build_trainer("hip", harness.CASES["gail_box"], str(tmp_path), device="cuda")
+    th.manual_seed(7)
+    got = [tr._gp_weights(64) for _ in range(5)]
+    kept = [g.clone() for g in got]
+    got += [tr._gp_weights(64).clone() for _ in range(70)]
+    th.manual_seed(7)
+    ref = [th.rand(64) for _ in range(75)]
+    for g, r in zip(kept + got[5:], ref):
+        assert th.equal(g.cpu(), r)
