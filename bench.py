@@ -157,6 +157,7 @@ def disc_update_timing(trainer, cfg):
             e0.record()
             t_host = time.perf_counter()
             round_ws = trainer._assemble_round(drawn)   # one launch for all n batches + the ordered norm merges
+            fused = round_ws is not None
             for k in range(n):
                 with networks.training(trainer.reward_train):
                     trainer._disc_update(None, None, trainer._stats_ring[k], drawn=drawn[k], quirk_done=True,
@@ -177,7 +178,9 @@ def disc_update_timing(trainer, cfg):
     tf = flop / (best * 1e-6) / 1e12
     return {"kernel": "discriminator update (ia_disc_step_basic: assemble+moments+merge | tile forward+BCE+head "
                       "gradient | tile dgrad+first-layer wgrad | split-K wgrad | slab reduce+Adam+statistics)",
-            "bound": "mfma", "us": best, "host_enqueue_us": best_host, "launches_per_update": 4, "launches_per_round_shared": 4, "rows": R, "flop": flop,
+            "bound": "mfma", "us": best, "host_enqueue_us": best_host,
+            "path": "fused (round assembly + 4 launches per update)" if fused else "general (16 launches per update)",
+            "launches_per_update": 4 if fused else 16, "launches_per_round_shared": 4 if fused else 0, "rows": R, "flop": flop,
             "achieved": tf, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": tf / PEAK_F32_MFMA_TFLOPS,
             "algorithmic_bytes": alg_bytes, "achieved_hbm_gbs": alg_bytes / (best * 1e-6) / 1e9,
             "frac_hbm": alg_bytes / (best * 1e-6) / 8e12,

@@ -81,7 +81,7 @@ _SIGS = {
     "ia_airl_debug_timing": ([_P], C.c_int),
     "ia_airl_prepare": ([_P] * 6 + [_I] + [_P] * 6 + [_I] + [_I] * 6 + [_P, _I, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P],
                         C.c_int),
-    "ia_airl_stats_merge": ([_P, _P, _P, _I, _I, _I] + [_P] * 9, C.c_int),
+    "ia_airl_stats_merge": ([_P, _P, _P, _I, _L, _I, _I, _I] + [_P] * 9, C.c_int),
     "ia_airl_gp_shaped": ([_P, _I, _I, _P, _P, _I, _I, _P, _P, _P, _P, _F, _P, _P, _F, _P, _P, _I, _I, _I, _I, _I, _I, _F, _F,
                            _F, _I] + [_P] * 12, C.c_int),
     "ia_airl_step_shaped": ([_P, _I, _I, _P, _P, _I, _I, _P, _P, _P, _P, _F, _P, _P, _P, _P, _F, _P, _P, _F, _F, _I, _I,
@@ -124,6 +124,7 @@ _SIGS = {
     "ia_disc_fused_tile_rows": ([_I], C.c_int),
     "ia_disc_assemble_round": ([C.POINTER(DiscStepArgs), _I, _L, _L, _L, _P], C.c_int),
     "ia_disc_fused_prepare": ([C.POINTER(MlpDesc), _P, _I, _I, _P, _P], C.c_int),
+    "ia_disc_fused_adam": ([C.POINTER(MlpDesc), _P, _F, _I, _I, _P, _P, _P], C.c_int),
     "ia_gp_interpolate": ([_P, _I, _I, _I, _P, _P, _P, _F, _P, _I, _P], C.c_int),
     "ia_gp_row_coeffs": ([_P, _I, _I, _I, _P, _F, _F, _F, _P, _P, _P], C.c_int),
     "ia_gp_shaped_coeffs": ([_P, _I, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _P, _F, _P, _F, _F, _F, _F, _P, _P, _P, _P,

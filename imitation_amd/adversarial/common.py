@@ -166,7 +166,8 @@ class AdversarialTrainer(abc.ABC):
 
         # ---- data parallelism over env batches (extension; the reference is single-process) ----
         self._dp = data_parallel
-        if self._dp is not None and self._dp.world > 1:
+        self._dp_many = self._dp is not None and self._dp.world > 1
+        if self._dp_many:
             pol = self.gen_algo.policy
             self.gen_algo.dp = self._dp
             norms = [n for _, n in self.reward_train._named_norms()]
@@ -186,7 +187,7 @@ class AdversarialTrainer(abc.ABC):
         # the PPO update, exactly where the reference executes it).
         # Data-parallel runs keep it when the PPO update needs no per-step collective (global-minibatch
         # update): then only one stream at a time has collectives in flight, in the same order on all ranks.
-        dp_many = self._dp is not None and self._dp.world > 1
+        dp_many = self._dp_many
         self._overlap = (isinstance(self.gen_algo, ppo.PPO) and isinstance(self.policy, ActorCriticPolicy)
                          and (not dp_many or self.gen_algo._dp_global()) and not self._module_net)
         # AIRL's updates read log pi(a|s) of the policy PPO has just updated: they cannot run beside that
@@ -457,12 +458,12 @@ class AdversarialTrainer(abc.ABC):
     def _assemble_round(self, drawn):
         """Round-level batch assembly for the fused discriminator path (`BasicRewardNet.assemble_round`): every
         update's rows gathered by one launch, the input-norm updates applied in order by one more. None when it
-        does not apply (other nets / shapes, gradient accumulation, data parallelism, explicit samples)."""
+        does not apply (other nets / shapes, gradient accumulation, explicit samples). Under data parallelism every
+        rank assembles its own batches and the round's slab moments cross the ranks in one all-gather."""
         net = self._reward_net
         while isinstance(net, reward_nets.PredictProcessedWrapper):
             net = net.base
-        single = self._dp is None or self._dp.world == 1
-        if (self._module_net or not isinstance(net, reward_nets.BasicRewardNet) or self._needs_logp or not single
+        if (self._module_net or not isinstance(net, reward_nets.BasicRewardNet) or self._needs_logp
                 or self.disc_grad_penalty_coef > 0.0
                 or self._torch_opt_params is not None or self.demo_minibatch_size != self.demo_batch_size
                 or not isinstance(self._disc_opt, HipAdam) or len(drawn) > self._quirk_idx_dev.shape[0]):
@@ -471,7 +472,8 @@ class AdversarialTrainer(abc.ABC):
         if e_idx is None or g_idx is None:
             return None
         with networks.training(self.reward_train):
-            return net.assemble_round(e_tab, g_tab, self._quirk_idx_dev[:len(drawn)], len(drawn), self.demo_batch_size)
+            return net.assemble_round(e_tab, g_tab, self._quirk_idx_dev[:len(drawn)], len(drawn), self.demo_batch_size,
+                                      dp=self._dp if self._dp_many else None)
 
     def _disc_update(self, expert_samples, gen_samples, stats_dev: th.Tensor, drawn=None,
                      quirk_done: bool = False, pre=None) -> None:
@@ -489,13 +491,17 @@ class AdversarialTrainer(abc.ABC):
         first = True
         fused_step = False
         # single minibatch, HIP Adam, no cross-rank exchange: reduce + Adam in one launch
-        single = self._dp is None or self._dp.world == 1
+        single = not self._dp_many
         fuse_adam = self._disc_opt if (isinstance(self._disc_opt, HipAdam) and single) else None
         basic = net
         while isinstance(basic, reward_nets.PredictProcessedWrapper):
             basic = basic.base
-        c_path = (isinstance(basic, reward_nets.BasicRewardNet) and not self._needs_logp and single
-                  and self._torch_opt_params is None)
+        # data parallelism: the one-call update runs on batches the round-level assembly prepared (`pre`: rows gathered,
+        # input statistics merged over all ranks); its slab reduction leaves the rank's gradient, ONE all-reduce and
+        # the Adam + weight-image launch follow below. Updates outside such a round keep the general path.
+        c_path = (isinstance(basic, reward_nets.BasicRewardNet) and not self._needs_logp
+                  and (single or pre is not None) and self._torch_opt_params is None)
+        dp_fused = c_path and not single
         pol = self.policy
         prn = pol.features_extractor.normalize if isinstance(pol, ActorCriticPolicy) else None
         for start in range(0, B, mb):
@@ -532,14 +538,16 @@ class AdversarialTrainer(abc.ABC):
                                               "state-holder or imitation_amd.modules net) and BasicShapedRewardNet "
                                               "(AIRL; state-holder) discriminators")
                 if (self._needs_logp and isinstance(basic, reward_nets.ShapedRewardNet) and B == mb
-                        and fuse_adam is not None and self._torch_opt_params is None and basic.fused_step_ok()
-                        and hasattr(pol, "log_prob_rows")):
+                        and isinstance(self._disc_opt, HipAdam) and self._torch_opt_params is None
+                        and basic.fused_step_ok() and hasattr(pol, "log_prob_rows")):
                     # AIRL's default shaped net: one assembly launch for the net's and the policy's rows (+ one for the
-                    # input statistics), log pi(a|s), then forward, BCE, backward, reduction + Adam in five launches
-                    basic.fused_prepare(sources, self._pol_obs, self._pol_act)
+                    # input statistics), log pi(a|s), then forward, BCE, backward, reduction + Adam in five launches.
+                    # Data-parallel: the slab moments of the ranks are all-gathered between assembly and merge, the
+                    # reduced gradient is all-reduced below and the optimiser steps after it.
+                    basic.fused_prepare(sources, self._pol_obs, self._pol_act, dp=None if single else self._dp)
                     logp = self._policy_pass(sources, mb, assembled=True)
                     logits = basic.fused_finish(logp, scale, stats_dev, None if gp else fuse_adam)
-                    fused_step = not gp
+                    fused_step = not gp and fuse_adam is not None
                     if gp:   # penalty gradient on top of the reduced BCE gradient, then the optimiser step below
                         e = self._gp_weights(mb)   # interpolation weights: torch's global CPU generator
                         self.last_grad_penalty = basic.fused_grad_penalty(
@@ -555,7 +563,13 @@ class AdversarialTrainer(abc.ABC):
                 if gp:
                     self._add_shaped_grad_penalty(basic, mb, scale)
             first = False
-        if self._dp is not None:  # one flat-bucket all-reduce per discriminator step
+        if dp_fused and isinstance(self._disc_opt, HipAdam) and not gp:
+            # fused update under data parallelism: sum over the ranks, then 1 / world, Adam and the refresh of the weight
+            # images the next pre-assembled update's tile kernels read in ONE launch
+            self._dp.allreduce_sum_(net._store.grad)
+            basic.fused_adam_step(self._disc_opt, 2 * mb, 1.0 / self._dp.world)
+            fused_step = True
+        elif self._dp is not None:  # one flat-bucket all-reduce per discriminator step
             self._dp.allreduce_mean_(net._store.grad)
         if self._torch_opt_params is not None:
             for p, (_, gview) in zip(self._torch_opt_params, _named_grads(net)):
@@ -742,8 +756,9 @@ class AdversarialTrainer(abc.ABC):
             # the discriminator batches start with the observation columns and their slab moments were just taken
             # by the round assembly: the policy-feature-norm side effect (App. C.2) merges the same moments
             # (first obs_dim of D columns) -- no second gather
-            self._quirk_seq_merged = round_ws["rn_all"]
-            self._quirk_pending.append(("seq", len(drawn), round_ws["need"], 1, 2 * mb, basic.mlp.dims[0]))
+            self._quirk_seq_merged = round_ws["rn_seq"]   # (all ranks' moments under data parallelism)
+            self._quirk_pending.append(("seq", len(drawn), round_ws["rn_stride"], round_ws["rn_groups"], 2 * mb,
+                                        basic.mlp.dims[0]))
             return True
         need = int(L.load().ia_running_norm_ws_floats(2 * mb, pol.obs_dim))
         n_items = len(drawn) * len(range(0, B, mb))
@@ -818,10 +833,16 @@ class AdversarialTrainer(abc.ABC):
             self._train_pipelined(n_rounds)
             return
         for r in range(n_rounds):
+            # data-parallel GAIL: also the sequential schedules assemble a round's batches at once -- that is where the
+            # ranks' input statistics are exchanged for the fused updates (AIRL's fused update exchanges per update)
+            pre_dp = self._dp_many and not self._needs_logp
             if not self._overlap_beside_ppo:
                 self.train_gen(self.gen_train_timesteps)
                 self._overlap_k = 0
-                self._finish_disc_round(self._disc_round())
+                pending = self._disc_round(prepass=pre_dp)
+                if pre_dp:
+                    self._replay_policy_norm_updates()
+                self._finish_disc_round(pending)
             else:
                 main = th.cuda.current_stream()
                 self._in_overlap, self.gen_algo.defer_train_stats, self._overlap_k = True, True, 0
@@ -829,7 +850,7 @@ class AdversarialTrainer(abc.ABC):
                     self._disc_stream.wait_stream(main)
                     self.train_gen(self.gen_train_timesteps)       # rollout; PPO update enqueued on `main`
                     with th.cuda.stream(self._disc_stream):         # ... while the disc updates run here
-                        pending = self._disc_round()
+                        pending = self._disc_round(prepass=pre_dp)
                     main.wait_stream(self._disc_stream)
                     self._replay_policy_norm_updates()              # after the PPO update, in stream order
                     self._finish_disc_round(pending)

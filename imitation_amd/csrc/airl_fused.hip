@@ -546,35 +546,40 @@ __global__ __launch_bounds__(256) void airl_prepare_kernel(AirlPrep a) {
 // normalised with, copied to `snapA` -- and then with the state batch. One wave per column; the workgroup that draws
 // the last ticket bumps the sample counts once every column has read them.
 __global__ __launch_bounds__(64) void airl_stats_merge_kernel(const float* __restrict__ ws_b, const float* __restrict__ ws_n,
-                                                              const float* __restrict__ ws_c, int R, int Db, int Dp,
+                                                              const float* __restrict__ ws_c, int groups, long long gstride,
+                                                              int R, int Db, int Dp,
                                                               float* __restrict__ bmean, float* __restrict__ bvar,
                                                               int32_t* __restrict__ bcount, float* __restrict__ pmean,
                                                               float* __restrict__ pvar, int32_t* __restrict__ pcount,
                                                               float* __restrict__ snapA, unsigned* __restrict__ ticket) {
+  // `groups` data-parallel ranks contribute R rows each (slab moments `gstride` floats apart): every rank merges all of
+  // them in rank order, i.e. makes the update a single process would make on the concatenated batch
   const int lane = threadIdx.x;
-  const int nblocks = (R + RN_ROWS_PER_BLOCK - 1) / RN_ROWS_PER_BLOCK;
+  const int bpg = (R + RN_ROWS_PER_BLOCK - 1) / RN_ROWS_PER_BLOCK;
+  const int nblocks = groups * bpg;
+  const int Rt = groups * R;
   const int nbase = ws_b ? Db : 0;
   if ((int)blockIdx.x < nbase) {
     const int c = blockIdx.x, cnt = *bcount;
     float bm, bq;
-    rn_wave_batch_moments(ws_b, nblocks, nblocks, R, Db, c, lane, bm, bq);
+    rn_wave_batch_moments(ws_b, nblocks, bpg, R, Db, c, lane, bm, bq, gstride);
     if (lane == 0) {
       float mc = bmean[c], vc = bvar[c];
-      rn_absorb(mc, vc, cnt, R, bm, bq / (float)R);
+      rn_absorb(mc, vc, cnt, Rt, bm, bq / (float)Rt);
       bmean[c] = mc;
       bvar[c] = vc;
     }
   } else {
     const int c = blockIdx.x - nbase, cnt = *pcount;
     float bm, bq, cm, cq;
-    rn_wave_batch_moments(ws_n, nblocks, nblocks, R, Dp, c, lane, bm, bq);
-    rn_wave_batch_moments(ws_c, nblocks, nblocks, R, Dp, c, lane, cm, cq);
+    rn_wave_batch_moments(ws_n, nblocks, bpg, R, Dp, c, lane, bm, bq, gstride);
+    rn_wave_batch_moments(ws_c, nblocks, bpg, R, Dp, c, lane, cm, cq, gstride);
     if (lane == 0) {
       float mc = pmean[c], vc = pvar[c];
-      rn_absorb(mc, vc, cnt, R, bm, bq / (float)R);
+      rn_absorb(mc, vc, cnt, Rt, bm, bq / (float)Rt);
       snapA[c] = mc;
       snapA[Dp + c] = vc;
-      rn_absorb(mc, vc, rn_count_add(cnt, R), R, cm, cq / (float)R);
+      rn_absorb(mc, vc, rn_count_add(cnt, Rt), Rt, cm, cq / (float)Rt);
       pmean[c] = mc;
       pvar[c] = vc;
     }
@@ -584,8 +589,8 @@ __global__ __launch_bounds__(64) void airl_stats_merge_kernel(const float* __res
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const unsigned tk = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (tk == gridDim.x - 1) {
-      if (ws_b) *bcount = rn_count_add(*bcount, R);
-      if (ws_n) *pcount = rn_count_add(rn_count_add(*pcount, R), R);
+      if (ws_b) *bcount = rn_count_add(*bcount, Rt);
+      if (ws_n) *pcount = rn_count_add(rn_count_add(*pcount, Rt), Rt);
       __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
@@ -1072,16 +1077,18 @@ int ia_airl_prepare(const float* obs0, const float* act0_f32, const int64_t* act
 
 /* The train-mode RunningNorm updates of one shaped-net forward from ia_airl_prepare's slab moments, one launch: base
  * input norm (ws_b null: skipped); potential input norm (ws_n / ws_c null: skipped) with the next-state batch, its
- * (mean, var) copied to snapA[2][Dp], then with the state batch. `ticket`: one zeroed word (left zeroed). */
-int ia_airl_stats_merge(const float* ws_b, const float* ws_n, const float* ws_c, int R, int Db, int Dp, float* bmean,
-                        float* bvar, int32_t* bcount, float* pmean, float* pvar, int32_t* pcount, float* snapA,
-                        unsigned* ticket, void* stream) {
-  if (R <= 0 || !ticket || (!ws_b && !ws_n) || (ws_b && (!bmean || !bvar || !bcount || Db <= 0)) || ((ws_n != nullptr) != (ws_c != nullptr)) ||
-      (ws_n && (!pmean || !pvar || !pcount || !snapA || Dp <= 0)))
+ * (mean, var) copied to snapA[2][Dp], then with the state batch. `groups` > 1: the moments of that many data-parallel
+ * ranks (R rows each, `group_stride` floats apart, 0 = back to back), merged in rank order. `ticket`: one zeroed word
+ * (left zeroed). */
+int ia_airl_stats_merge(const float* ws_b, const float* ws_n, const float* ws_c, int groups, int64_t group_stride, int R,
+                        int Db, int Dp, float* bmean, float* bvar, int32_t* bcount, float* pmean, float* pvar,
+                        int32_t* pcount, float* snapA, unsigned* ticket, void* stream) {
+  if (R <= 0 || groups <= 0 || group_stride < 0 || !ticket || (!ws_b && !ws_n) || (ws_b && (!bmean || !bvar || !bcount || Db <= 0)) ||
+      ((ws_n != nullptr) != (ws_c != nullptr)) || (ws_n && (!pmean || !pvar || !pcount || !snapA || Dp <= 0)))
     return IA_ERR_ARG;
   const int blocks = (ws_b ? Db : 0) + (ws_n ? Dp : 0);
-  hipLaunchKernelGGL(airl_stats_merge_kernel, dim3(blocks), dim3(64), 0, (hipStream_t)stream, ws_b, ws_n, ws_c, R, Db, Dp,
-                     bmean, bvar, bcount, pmean, pvar, pcount, snapA, ticket);
+  hipLaunchKernelGGL(airl_stats_merge_kernel, dim3(blocks), dim3(64), 0, (hipStream_t)stream, ws_b, ws_n, ws_c, groups,
+                     (long long)group_stride, R, Db, Dp, bmean, bvar, bcount, pmean, pvar, pcount, snapA, ticket);
   IA_CHECK_LAUNCH();
   return IA_OK;
 }

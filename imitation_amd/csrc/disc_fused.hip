@@ -778,6 +778,43 @@ __global__ __launch_bounds__(256) void disc_reduce_kernel(ReduceArgs a) {
   }
 }
 
+// ------------------------------------------------------------------------------------------- K5b
+// Data-parallel form of the tail of K5: the slab reduction has left this rank's gradient in `grads` (K5 with adam = 0),
+// ONE all-reduce (sum) over the ranks has run on it, and this launch finishes the update: grads *= gscale (1 / world: the
+// rank mean, adversarial/common.py:352-373 on the concatenated batch), torch.optim.Adam's step, and the refresh of the
+// W2T / padded-W1 images the tile kernels of the NEXT pre-assembled update read.
+struct AdamRefreshArgs {
+  long long n; float* grads; float gscale;
+  float* p; float* m; float* v; float beta1, beta2, eps, wd, step_size, bc2_sqrt;
+  float* W2T; float* W1P; int H; int D;
+};
+
+__global__ __launch_bounds__(256) void disc_adam_refresh_kernel(AdamRefreshArgs a) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= a.n) return;
+  float grad = a.grads[i] * a.gscale;
+  a.grads[i] = grad;
+  // torch/optim/adam.py _single_tensor_adam: lerp, mul+addcmul, sqrt/bc2_sqrt + eps, addcdiv (K5's expressions)
+  const float pi = a.p[i];
+  if (a.wd != 0.f) grad = grad + a.wd * pi;
+  float mi = a.m[i];
+  mi = mi + (grad - mi) * (1.f - a.beta1);
+  const float vi = a.v[i] * a.beta2 + (1.f - a.beta2) * grad * grad;
+  const float denom = sqrtf(vi) / a.bc2_sqrt + a.eps;
+  const float pn = pi - a.step_size * (mi / denom);
+  a.p[i] = pn;
+  a.m[i] = mi;
+  a.v[i] = vi;
+  const long long nW1 = (long long)a.H * a.D, n1 = nW1 + a.H;
+  if (i < nW1) {
+    const int n = (int)(i / a.D), k = (int)(i - (long long)n * a.D);
+    a.W1P[n * XP + k] = pn;
+  } else if (i >= n1 && i < n1 + (long long)a.H * a.H) {
+    const int j = (int)(i - n1), r = j / a.H, c = j - r * a.H;
+    a.W2T[(long long)c * a.H + r] = pn;
+  }
+}
+
 inline int cdivi(long long a, long long b) { return (int)((a + b - 1) / b); }
 
 inline bool fused_shape_ok(const ia_mlp_desc* d, int ldx) {
@@ -889,6 +926,27 @@ extern "C" int ia_disc_fused_prepare(const ia_mlp_desc* d, const float* params, 
   as.W2 = params + (long long)H * D + H; as.W2T = w.W2T;
   as.W1 = params; as.W1P = w.W1P;
   hipLaunchKernelGGL(disc_assemble_kernel, dim3((H / 64) * (H / 64) + 1), dim3(AS_NT), 0, (hipStream_t)stream, as);
+  IA_CHECK_LAUNCH();
+  return IA_OK;
+}
+
+// Data-parallel tail of a fused update (see disc_adam_refresh_kernel): adam->grads holds the all-reduced (summed)
+// gradient; scaled by grad_scale in place, Adam step on `params`, W2T / W1 images of fused_ws refreshed.
+extern "C" int ia_disc_fused_adam(const ia_mlp_desc* d, float* params, float grad_scale, int R, int ldx, float* fused_ws,
+                                  const ia_adam_args* adam, void* stream) {
+  if (!fused_shape_ok(d, ldx) || !fused_ws || !params || !adam || !adam->grads || !adam->exp_avg || !adam->exp_avg_sq ||
+      R <= 0)
+    return IA_ERR_ARG;
+  const int D = d->dims[0], H = d->dims[1];
+  const FusedWs w = fused_ws_layout(d, R, fused_ws);
+  AdamRefreshArgs ra{};
+  ra.n = (long long)H * D + H + (long long)H * H + H + H + 1;
+  ra.grads = adam->grads; ra.gscale = grad_scale;
+  ra.p = params; ra.m = adam->exp_avg; ra.v = adam->exp_avg_sq;
+  ra.beta1 = adam->beta1; ra.beta2 = adam->beta2; ra.eps = adam->eps; ra.wd = adam->weight_decay;
+  ra.step_size = adam->step_size; ra.bc2_sqrt = adam->bc2_sqrt;
+  ra.W2T = w.W2T; ra.W1P = w.W1P; ra.H = H; ra.D = D;
+  hipLaunchKernelGGL(disc_adam_refresh_kernel, dim3(cdivi(ra.n, 256)), dim3(256), 0, (hipStream_t)stream, ra);
   IA_CHECK_LAUNCH();
   return IA_OK;
 }

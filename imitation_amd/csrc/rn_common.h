@@ -19,12 +19,18 @@ __device__ __forceinline__ void chan_combine(float& n, float& m, float& M2, floa
 // of `bpg`, each group covering `rpg` rows) and returns (batch mean, batch M2) in every lane: lane l
 // folds slabs l, l+64, ... sequentially, then a fixed butterfly (xor 32,16,...,1) combines the 64
 // partial triples -> deterministic.
+// `gstride` (floats; 0 = groups back to back): distance between the moment blocks of consecutive groups, for groups
+// that arrive inside a wider all-gathered record.
 __device__ __forceinline__ void rn_wave_batch_moments(const float* __restrict__ ws, int nblocks, int bpg, int rpg,
-                                                      int ws_ld, int c, int lane, float& b_mean, float& b_M2) {
+                                                      int ws_ld, int c, int lane, float& b_mean, float& b_M2,
+                                                      long long gstride = 0) {
   float n_acc = 0.f, m_acc = 0.f, M2 = 0.f;
+  const long long gs = gstride > 0 ? gstride : (long long)bpg * 2 * ws_ld;
   for (int b = lane; b < nblocks; b += 64) {
-    const float nb = (float)min(RN_ROWS_PER_BLOCK, rpg - (b % bpg) * RN_ROWS_PER_BLOCK);
-    chan_combine(n_acc, m_acc, M2, nb, ws[((long long)b * 2 + 0) * ws_ld + c], ws[((long long)b * 2 + 1) * ws_ld + c]);
+    const int g = b / bpg, bb = b - g * bpg;
+    const float nb = (float)min(RN_ROWS_PER_BLOCK, rpg - bb * RN_ROWS_PER_BLOCK);
+    const float* w = ws + g * gs + (long long)bb * 2 * ws_ld;
+    chan_combine(n_acc, m_acc, M2, nb, w[c], w[ws_ld + c]);
   }
   for (int o = 32; o > 0; o >>= 1) {
     const float nb = __shfl_xor(n_acc, o, 64), mb = __shfl_xor(m_acc, o, 64), qb = __shfl_xor(M2, o, 64);

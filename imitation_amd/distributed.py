@@ -47,6 +47,17 @@ class DataParallel:
             flat.mul_(1.0 / self.world)
         return flat
 
+    def allreduce_sum_(self, flat: th.Tensor) -> th.Tensor:
+        """In-place sum over ranks of one flat bucket (the caller folds 1 / world into its next kernel)."""
+        if self.world >= self._min_world:
+            if self._stage and flat.is_cuda:
+                h = flat.cpu()
+                dist.all_reduce(h, op=dist.ReduceOp.SUM, group=self.group)
+                flat.copy_(h)
+            else:
+                dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+        return flat
+
     def broadcast_(self, tensors: List[th.Tensor], src: int = 0) -> None:
         if self.world >= self._min_world:
             for t in tensors:

@@ -253,13 +253,15 @@ class BasicRewardNet(RewardNet):
         return fuse
 
     def assemble_round(self, e_tab: TransitionTable, g_tab: TransitionTable, idx_all: th.Tensor, n_updates: int,
-                       mb: int) -> Optional[Dict[str, th.Tensor]]:
+                       mb: int, dp=None) -> Optional[Dict[str, th.Tensor]]:
         """Batch assembly of a whole round's discriminator updates in ONE launch (fused shapes only; returns None
         otherwise): update k gathers expert rows `idx_all[k, 0]` and generator rows `idx_all[k, 1]` into its own
         X and leaves its RunningNorm slab moments; one `ia_running_norm_merge_seq` launch then applies the n
         updates of the input norm in order and keeps the statistics AFTER each one -- what update k's own forward
         normalises with (`util/networks.py:79-91`). The updates themselves (`disc_step_c(..., pre=(ws, k))`) are
-        four launches each."""
+        four launches each. `dp` (`distributed.DataParallel`, world > 1): every rank assembles its own batches; the
+        slab moments of the whole round are exchanged in ONE all-gather and every rank applies the same merges over
+        world x 2*mb rows per update -- the statistics of a single process on the concatenated batches."""
         import ctypes as C
         mlp, R = self.mlp, 2 * mb
         if FUSED_DISC_STEP is False or int(L.load().ia_disc_fused_ws_floats(C.byref(mlp.desc), R, mlp.ldx)) <= 0:
@@ -290,8 +292,13 @@ class BasicRewardNet(RewardNet):
         L.call("ia_disc_assemble_round", C.byref(a), n_updates, 2 * mb, R * mlp.ldx, rw["need"], L.stream())
         a.X, a.rn_ws = L.ptr(ws["X"]), L.ptr(ws["rn_ws"])
         rw["has_moments"] = update
+        rw["rn_seq"], rw["rn_stride"], rw["rn_groups"] = rw["rn_all"], rw["need"], 1
         if update:
-            L.call("ia_running_norm_merge_seq", L.ptr(rw["rn_all"]), n_updates, rw["need"], 1, R, D, D,
+            if dp is not None and dp.world > 1:   # [rank][update][moments] -> [update][rank][moments]
+                allm = dp.all_gather_flat(rw["rn_all"].reshape(-1))
+                rw["rn_seq"] = allm.view(dp.world, n_updates, rw["need"]).permute(1, 0, 2).contiguous()
+                rw["rn_stride"], rw["rn_groups"] = dp.world * rw["need"], dp.world
+            L.call("ia_running_norm_merge_seq", L.ptr(rw["rn_seq"]), n_updates, rw["rn_stride"], rw["rn_groups"], R, D, D,
                    L.ptr(nrm.running_mean), L.ptr(nrm.running_var), L.ptr(nrm.count), L.ptr(rw["snap"]), L.stream())
         L.call("ia_disc_fused_prepare", C.byref(mlp.desc), L.ptr(mlp.flat), R, mlp.ldx, L.ptr(ws["fused_ws"]), L.stream())
         return rw
@@ -386,6 +393,22 @@ class BasicRewardNet(RewardNet):
         else:
             ws["norm_used"] = (nrm.running_mean, nrm.running_var, nrm.eps)
         return ws
+
+
+    def fused_ws_of(self, R: int) -> Optional[th.Tensor]:
+        """The fused-update workspace of R-row updates (None: the general path runs this shape)."""
+        return self._step_workspace(R)["fused_ws"]
+
+    def fused_adam_step(self, adam, R: int, grad_scale: float) -> None:
+        """Data-parallel tail of a fused update: the flat gradient (already summed over the ranks) scaled by
+        `grad_scale`, Adam's step, and the refresh of the weight images the tile kernels read (`ia_disc_fused_adam`)."""
+        import ctypes as C
+        mlp = self.mlp
+        ws = self._step_workspace(R)
+        if adam.flat.data_ptr() != mlp.flat.data_ptr() or adam.flat.numel() != mlp.n_params:
+            raise RuntimeError("the fused update needs the optimiser over the net's flat parameter buffer")
+        L.call("ia_disc_fused_adam", C.byref(mlp.desc), L.ptr(mlp.flat), float(grad_scale), R, mlp.ldx,
+               L.ptr(ws["fused_ws"]), adam.next_step_args(), L.stream())
 
 
 class RewardNetWrapper(RewardNet):
@@ -522,11 +545,14 @@ class ShapedRewardNet(ForwardWrapper):
             return False
         return bool(L.load().ia_airl_fused_ok(base.dims[0], pot.dims[0], base.dims[1], pot.dims[1], pot.dims[2]))
 
-    def fused_prepare(self, sources, pol_obs: Optional[th.Tensor] = None, pol_act: Optional[th.Tensor] = None) -> None:
+    def fused_prepare(self, sources, pol_obs: Optional[th.Tensor] = None, pol_act: Optional[th.Tensor] = None,
+                      dp=None) -> None:
         """First half of one whole `train_disc` minibatch (= batch) of `common.py:317-374` for this net: the batch
         assembly (`ia_airl_prepare`: base inputs, next-state and state batches, dones -- and, when asked, the rows the
         generator policy's log pi(a|s) reads) and the train-mode input statistics (`ia_airl_stats_merge`; potential:
-        next-state batch, then state batch, `reward_nets.py:708-710` order). Two launches."""
+        next-state batch, then state batch, `reward_nets.py:708-710` order). Two launches. `dp` (world > 1): the three
+        moment sets of all ranks are exchanged in one all-gather in between and merged in rank order -- the statistics
+        update of one process on the concatenated batch."""
         base, pot = self._base, self.potential._potential_net
         bm = base.mlp
         (t0, i0, n0), (t1, i1, n1) = sources
@@ -545,8 +571,10 @@ class ShapedRewardNet(ForwardWrapper):
                       part=th.empty(nblk, P, device=dev), logits=th.empty(R, device=dev),
                       bce_part=th.zeros(nblk * 8, device=dev), ticket=th.zeros(2, dtype=th.int32, device=dev),
                       snapA=th.empty(2, pot.dims[0], device=dev), nblk=nblk,
-                      ws_b=th.empty(nrn * 2 * bm.dims[0], device=dev), ws_n=th.empty(nrn * 2 * pot.dims[0], device=dev),
-                      ws_c=th.empty(nrn * 2 * pot.dims[0], device=dev))
+                      ws_all=th.empty(nrn * 2 * (bm.dims[0] + 2 * pot.dims[0]), device=dev))
+            nb_, np_ = nrn * 2 * bm.dims[0], nrn * 2 * pot.dims[0]   # one record [base | next | current]: one all-gather
+            ws["ws_b"], ws["ws_n"], ws["ws_c"] = (ws["ws_all"][:nb_], ws["ws_all"][nb_:nb_ + np_],
+                                                  ws["ws_all"][nb_ + np_:])
             ws["flags"] = [int(f) for f in base.flags]
             ws["out"] = (ws["Xb"].data_ptr(), bm.ldx, ws["Sn"].data_ptr(), ws["Sc"].data_ptr(), pot.ldx,
                          ws["dones"].data_ptr())
@@ -562,7 +590,17 @@ class ShapedRewardNet(ForwardWrapper):
                t1.obs.data_ptr(), *acts(t1), t1.next_obs.data_ptr(), t1.dones.data_ptr(), L.ptr(i1), n1, base.obs_dim,
                base.act_dim, *ws["flags"], *ws["out"], pb, pnx, pc, L.ptr(pol_obs), L.ptr(pol_act), st)
         if upd_b or upd_p:   # h(s') is normalised with the statistics after ITS update (snapA), h(s) after the second one
-            L.call("ia_airl_stats_merge", pb, pnx, pc, R, bm.dims[0], pot.dims[0],
+            groups, gstride = 1, 0
+            if dp is not None and dp.world > 1:
+                rec = ws["ws_all"].numel()
+                allm = dp.all_gather_flat(ws["ws_all"])
+                groups, gstride = dp.world, rec
+                nb_, np_ = ws["ws_b"].numel(), ws["ws_n"].numel()
+                base_p = allm.data_ptr()
+                pb = base_p if upd_b else None
+                pnx, pc = (base_p + 4 * nb_, base_p + 4 * (nb_ + np_)) if upd_p else (None, None)
+                ws["_gathered"] = allm   # keeps the buffer alive until the merge has been enqueued (and beyond: reused)
+            L.call("ia_airl_stats_merge", pb, pnx, pc, groups, gstride, R, bm.dims[0], pot.dims[0],
                    *((bn.running_mean.data_ptr(), bn.running_var.data_ptr(), bn.count.data_ptr()) if upd_b else (None,) * 3),
                    *((pn.running_mean.data_ptr(), pn.running_var.data_ptr(), pn.count.data_ptr()) if upd_p else (None,) * 3),
                    ws["snapA"].data_ptr(), ws["ticket"].data_ptr() + 4, st)

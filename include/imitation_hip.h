@@ -231,6 +231,12 @@ typedef struct ia_adam_args {   /* torch.optim.Adam step over one flat buffer, s
   float* exp_avg_sq;
   float beta1, beta2, eps, weight_decay, step_size /* lr / (1 - b1^t) */, bc2_sqrt /* sqrt(1 - b2^t) */;
 } ia_adam_args;
+/* Data-parallel tail of a fused BasicRewardNet update (adversarial/common.py:352-373 on the union of the
+ * ranks' batches): ia_disc_step_basic with adam = 0 leaves this rank's reduced gradient in adam->grads, the caller sums it
+ * over the ranks with ONE all-reduce, then this launch scales it by grad_scale (1 / world) in place, applies
+ * torch.optim.Adam's step to `params` and refreshes the W2T / W1 images of fused_ws for the next pre_assembled update. */
+int ia_disc_fused_adam(const ia_mlp_desc* d, float* params, float grad_scale, int R, int ldx, float* fused_ws,
+                       const ia_adam_args* adam, void* stream);
 int ia_airl_fused_ok(int Db, int Dp, int hb, int hp1, int hp2);
 int ia_airl_fused_slabs(int R);
 /* measurement: shader-clock stamps of the row kernel's phases (workgroup 0) into buf (>= 16 int64; NULL: off) */
@@ -261,10 +267,12 @@ int ia_airl_prepare(const float* obs0, const float* act0_f32, const int64_t* act
 /* The train-mode RunningNorm updates of one shaped-net forward (util/networks.py:111-134 in reward_nets.py:708-710's
  * order) from ia_airl_prepare's slab moments, one launch: base input norm (ws_b null: skipped); potential input norm
  * (ws_n, ws_c null: skipped) with the next-state batch -- (mean, var) then copied to snapA[2][Dp] -- and with the state
- * batch. `ticket`: one zeroed word (left zeroed). */
-int ia_airl_stats_merge(const float* ws_b, const float* ws_n, const float* ws_c, int R, int Db, int Dp, float* bmean,
-                        float* bvar, int32_t* bcount, float* pmean, float* pvar, int32_t* pcount, float* snapA,
-                        unsigned* ticket, void* stream);
+ * batch. Data parallelism: `groups` ranks contribute R rows each, their slab moments `group_stride` floats
+ * apart inside the all-gathered buffer (0: back to back); all are merged in rank order, i.e. the update of ONE process on
+ * the concatenated batch. `ticket`: one zeroed word (left zeroed). */
+int ia_airl_stats_merge(const float* ws_b, const float* ws_n, const float* ws_c, int groups, int64_t group_stride, int R,
+                        int Db, int Dp, float* bmean, float* bvar, int32_t* bcount, float* pmean, float* pvar,
+                        int32_t* pcount, float* snapA, unsigned* ticket, void* stream);
 
 /* Gradient penalty of AIRL's shaped reward (OPT-IN extension, see ia_gp_shaped_coeffs) for the geometry of
  * ia_airl_fused_ok, on the batches ia_airl_prepare assembled (Xb, Sn, Sc: [2B, ld] = [expert | generator] rows, dones[2B];

@@ -362,3 +362,247 @@ def test_rccl_branches_execute_on_one_gpu(tmp_path):
     port = _free_port()
     mp.spawn(_rccl_worker, args=(1, port, str(tmp_path)), nprocs=1, join=True)
     assert os.path.exists(tmp_path / "rccl_ok")
+
+
+# ---------------------------------------------------------------------------------------------------
+# Round 3: the FUSED discriminator updates under data parallelism. GAIL's four-launch update
+# (`disc_fused.hip`, 256-wide) with the round's slab moments all-gathered once, slab reduce | all-reduce | Adam + weight
+# images; AIRL's fused update (`airl_fused.hip`) with the three moment sets all-gathered per update.
+
+def _fused_worker(rank, world, port, out_dir):
+    _init(rank, world, port)
+    th.cuda.set_device(0)
+    th.set_num_threads(1)
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import imitation_amd as p
+    from imitation_amd import reward_nets
+    from imitation_amd.distributed import DataParallel
+    from imitation_amd.vec_env import SyntheticVecEnv
+    from tests import harness
+    cfg = harness.CASES["gail_box"]
+    calls = {"gail": 0, "airl": 0}
+    orig_adam, orig_finish = reward_nets.BasicRewardNet.fused_adam_step, reward_nets.ShapedRewardNet.fused_finish
+
+    def counting_adam(self, *a, **k):
+        calls["gail"] += 1
+        return orig_adam(self, *a, **k)
+
+    def counting_finish(self, *a, **k):
+        calls["airl"] += 1
+        return orig_finish(self, *a, **k)
+
+    reward_nets.BasicRewardNet.fused_adam_step = counting_adam
+    reward_nets.ShapedRewardNet.fused_finish = counting_finish
+
+    def run(airl: bool, pipeline: bool, hid=(256, 256)):
+        th.manual_seed(100 + rank)
+        np.random.seed(100 + rank)
+        venv = SyntheticVecEnv(num_envs=cfg["n_envs"], obs_dim=17, act_dim=6, horizon=cfg["horizon"], seed=rank)
+        pk = dict(features_extractor_class=p.NormalizeFeaturesExtractor,
+                  features_extractor_kwargs=dict(normalize_class=p.RunningNorm))
+        algo = p.PPO(p.FeedForward32Policy, venv, n_steps=cfg["n_steps"], batch_size=cfg["ppo_batch"], n_epochs=2,
+                     ent_coef=0.1, policy_kwargs=pk, device="cuda")
+        if airl:
+            net = p.BasicShapedRewardNet(venv.observation_space, venv.action_space, reward_hid_sizes=(32,),
+                                         potential_hid_sizes=(32, 32), use_next_state=True,
+                                         normalize_input_layer=p.RunningNorm)
+        else:
+            net = p.BasicRewardNet(venv.observation_space, venv.action_space, hid_sizes=hid,
+                                   normalize_input_layer=p.RunningNorm)
+        demos = p.Transitions(**harness.make_demo_arrays(cfg, seed=1 + rank))
+        tr = (p.AIRL if airl else p.GAIL)(
+            demonstrations=demos, demo_batch_size=128, venv=venv, gen_algo=algo, reward_net=net,
+            n_disc_updates_per_round=3, custom_logger=p.configure_logger(tempfile.mkdtemp(), []),
+            data_parallel=DataParallel())
+        tr.pipeline_rounds = pipeline
+        tr.train(3 * cfg["n_envs"] * cfg["n_steps"])
+        th.cuda.synchronize()
+        sd = {f"disc/{k}": v.cpu() for k, v in tr._reward_net.state_dict().items()}
+        sd.update({f"pol/{k}": v.cpu() for k, v in algo.policy.state_dict().items()})
+        return sd
+
+    for name, kw in (("gail", dict(airl=False, pipeline=True)), ("gail_seq", dict(airl=False, pipeline=False)),
+                     ("gail128", dict(airl=False, pipeline=True, hid=(128, 128))),
+                     ("airl", dict(airl=True, pipeline=True)), ("airl_seq", dict(airl=True, pipeline=False))):
+        before = dict(calls)
+        sd = run(**kw)
+        sd["_fused_calls"] = th.tensor([calls["gail"] - before["gail"], calls["airl"] - before["airl"]])
+        th.save(sd, os.path.join(out_dir, f"fused{rank}_{name}.pt"))
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_fused_updates_under_data_parallelism_replicas_identical(tmp_path):
+    """Two ranks on one GPU (gloo): the fused GAIL update (H = 256 and 128) and the fused AIRL update keep their
+    kernels under data parallelism, replicas stay bit-identical, pipelined == sequential schedule."""
+    if not th.cuda.is_available():
+        pytest.skip("no GPU")
+    port = _free_port()
+    mp.spawn(_fused_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    ld = lambda r, n: th.load(tmp_path / f"fused{r}_{n}.pt")
+    for name in ("gail", "gail_seq", "gail128", "airl", "airl_seq"):
+        a, b = ld(0, name), ld(1, name)
+        calls = a.pop("_fused_calls"); b.pop("_fused_calls")
+        # 3 rounds x 3 updates, every one through the fused kernels
+        assert int(calls[1 if name.startswith("airl") else 0]) == 9, (name, calls)
+        for k in a:
+            assert th.equal(a[k], b[k]), (name, k)
+        assert all(bool(th.isfinite(v.float()).all()) for v in a.values())
+    for name in ("gail", "airl"):
+        a, s = ld(0, name), ld(0, name + "_seq")
+        for k in a:
+            if k != "_fused_calls":
+                assert th.equal(a[k], s[k]), (name, k)
+    # every rank contributed to the input statistics: world x (3 rounds x 3 updates x 256 rows)
+    assert int(ld(0, "gail")["disc/mlp.normalize_input.count"]) == 2 * 3 * 3 * 256
+
+
+def _fused_equiv_worker(rank, world, port, out_dir):
+    _init(rank, world, port)
+    th.cuda.set_device(0)
+    th.set_num_threads(1)
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import imitation_amd as p
+    from imitation_amd.distributed import DataParallel
+    from imitation_amd.vec_env import SyntheticVecEnv
+    from tests import harness
+    cfg = harness.CASES["gail_box"]
+    th.manual_seed(100 + rank)
+    np.random.seed(100 + rank)
+    venv = SyntheticVecEnv(num_envs=cfg["n_envs"], obs_dim=17, act_dim=6, horizon=cfg["horizon"], seed=rank)
+    pk = dict(features_extractor_class=p.NormalizeFeaturesExtractor,
+              features_extractor_kwargs=dict(normalize_class=p.RunningNorm))
+    algo = p.PPO(p.FeedForward32Policy, venv, n_steps=cfg["n_steps"], batch_size=cfg["ppo_batch"], n_epochs=2,
+                 ent_coef=0.1, policy_kwargs=pk, device="cuda")
+    net = p.BasicRewardNet(venv.observation_space, venv.action_space, hid_sizes=(256, 256),
+                           normalize_input_layer=p.RunningNorm)
+    demos = harness.make_demo_arrays(cfg, seed=1 + rank)
+    tr = p.GAIL(demonstrations=p.Transitions(**demos), demo_batch_size=128, venv=venv, gen_algo=algo, reward_net=net,
+                n_disc_updates_per_round=3, custom_logger=p.configure_logger(tempfile.mkdtemp(), []),
+                data_parallel=DataParallel())
+    tr.pipeline_rounds = False
+    tr.train_gen()                       # one rollout (+ the data-parallel PPO update): fills the replay ring
+    th.cuda.synchronize()
+    cpu = lambda sd: {k: v.detach().cpu().clone() for k, v in sd.items()}
+    out = dict(disc_pre=cpu(tr._reward_net.state_dict()),
+               pol_norm_pre=cpu(algo.policy.features_extractor.normalize.state_dict()),
+               demos=demos, ring={k: v.copy() for k, v in tr._gen_replay_buffer._arrays.items()},
+               ring_n=tr._gen_replay_buffer.size(), idx=[])
+    e_next, g_sample = tr._expert_stream.next_indices, tr._gen_replay_buffer.sample_indices
+
+    def rec_e():
+        i = e_next()
+        out["idx"].append(("e", np.array(i)))
+        return i
+
+    def rec_g(n):
+        i = g_sample(n)
+        out["idx"].append(("g", np.array(i)))
+        return i
+
+    tr._expert_stream.next_indices, tr._gen_replay_buffer.sample_indices = rec_e, rec_g
+    algo.policy.set_training_mode(True)   # as PPO.train leaves it (SURVEY App. C.2)
+    tr._overlap_k = 0
+    pending = tr._disc_round(prepass=True)      # the round-level assembly + three fused updates
+    tr._replay_policy_norm_updates()
+    tr._finish_disc_round(pending)
+    th.cuda.synchronize()
+    out["disc_post"] = cpu(tr._reward_net.state_dict())
+    out["pol_norm_post"] = cpu(algo.policy.features_extractor.normalize.state_dict())
+    th.save(out, os.path.join(out_dir, f"fequiv{rank}.pt"))
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_world_two_fused_updates_equal_single_process_on_the_concatenated_batch(tmp_path):
+    """The fused path (H = 256) under data parallelism == ONE process running the same fused round on the union of
+    the ranks' batches (expert / replay tables and index batches concatenated in rank order)."""
+    if not th.cuda.is_available():
+        pytest.skip("no GPU")
+    port = _free_port()
+    mp.spawn(_fused_equiv_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0 = th.load(tmp_path / "fequiv0.pt", weights_only=False)
+    r1 = th.load(tmp_path / "fequiv1.pt", weights_only=False)
+    for k in r0["disc_post"]:
+        assert th.equal(r0["disc_post"][k], r1["disc_post"][k]), k
+        assert th.equal(r0["disc_pre"][k], r1["disc_pre"][k]), k
+    assert not th.equal(r0["disc_post"]["mlp.dense0.weight"], r0["disc_pre"]["mlp.dense0.weight"])
+
+    import imitation_amd as p
+    from imitation_amd.vec_env import SyntheticVecEnv
+    from tests import harness
+    cfg = harness.CASES["gail_box"]
+    th.manual_seed(100)
+    np.random.seed(100)
+    venv = SyntheticVecEnv(num_envs=cfg["n_envs"], obs_dim=17, act_dim=6, horizon=cfg["horizon"], seed=0)
+    pk = dict(features_extractor_class=p.NormalizeFeaturesExtractor,
+              features_extractor_kwargs=dict(normalize_class=p.RunningNorm))
+    algo = p.PPO(p.FeedForward32Policy, venv, n_steps=cfg["n_steps"], batch_size=cfg["ppo_batch"], n_epochs=2,
+                 ent_coef=0.1, policy_kwargs=pk, device="cuda")
+    net = p.BasicRewardNet(venv.observation_space, venv.action_space, hid_sizes=(256, 256),
+                           normalize_input_layer=p.RunningNorm)
+    cat = lambda a, b: {k: np.concatenate([a[k], b[k]]) for k in a}
+    n_demo, cap = len(r0["demos"]["obs"]), r0["ring_n"]
+    assert cap == r1["ring_n"] == len(r0["ring"]["obs"])
+    tr = p.GAIL(demonstrations=p.Transitions(**cat(r0["demos"], r1["demos"])), demo_batch_size=256, venv=venv,
+                gen_algo=algo, reward_net=net, n_disc_updates_per_round=3, gen_replay_buffer_capacity=2 * cap,
+                custom_logger=p.configure_logger(str(tmp_path / "single"), []))
+    tr._reward_net.load_state_dict(r0["disc_pre"])
+    algo.policy.features_extractor.normalize.load_state_dict(r0["pol_norm_pre"])
+    tr._gen_replay_buffer.store(p.Transitions(**cat(r0["ring"], r1["ring"])))
+    stream = []
+    for (k0, i0), (k1, i1) in zip(r0["idx"], r1["idx"]):
+        assert k0 == k1
+        stream.append((k0, np.concatenate([i0, i1 + (n_demo if k0 == "e" else cap)])))
+    it = iter(stream)
+
+    def nxt(kind):
+        k, i = next(it)
+        assert k == kind
+        return i
+
+    tr._expert_stream.next_indices = lambda: nxt("e")
+    tr._gen_replay_buffer.sample_indices = lambda n: nxt("g")
+    algo.policy.set_training_mode(True)
+    tr._overlap_k = 0
+    pending = tr._disc_round(prepass=True)
+    assert pending is not None
+    tr._replay_policy_norm_updates()
+    tr._finish_disc_round(pending)
+    th.cuda.synchronize()
+    for kk, v in tr._reward_net.state_dict().items():
+        if kk.endswith("count"):
+            assert int(v) == int(r0["disc_post"][kk]) == 3 * 512, kk
+        else:
+            th.testing.assert_close(r0["disc_post"][kk], v.cpu(), rtol=2e-4, atol=5e-5, msg=kk)
+    for kk, v in algo.policy.features_extractor.normalize.state_dict().items():
+        if kk.endswith("count"):
+            assert int(v) == int(r0["pol_norm_post"][kk]), kk
+        else:
+            th.testing.assert_close(r0["pol_norm_post"][kk], v.cpu(), rtol=2e-4, atol=5e-5, msg=kk)
+
+
+@pytest.mark.gpu
+def test_bench_two_rank_launch_line_on_one_gpu(tmp_path):
+    """The driver's N > 1 command (`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...`) with two
+    ranks sharing the box's one GPU (`IA_BENCH_SHARE_GPU=1`: collectives through gloo): config P, data-parallel, fused
+    discriminator updates; one JSON line from rank 0."""
+    if not th.cuda.is_available():
+        pytest.skip("no GPU")
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, IA_BENCH_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3",
+           "--warmup", "2", "--prof-rounds", "1"]
+    res = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stderr[-4000:]
+    line = [l for l in res.stdout.splitlines() if l.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["value"] > 0
+    assert out["config"]["parallelism"] == "dp2"
+    assert out["roofline"]["disc_update"]["path"].startswith("fused")   # not the general 16-launch update
