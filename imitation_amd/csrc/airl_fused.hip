@@ -449,11 +449,13 @@ struct AirlPass {
   int kind, stride, off, ncols;
   float* X; int ldx, xcol;    // destination, its row stride, first destination column
   float* ws; int wsD;         // slab moments [slabs][2][wsD] of the destination matrix (null: not wanted)
+  long long x_stride, ws_stride;   // several batches in one launch (blockIdx.z = batch): element offsets per batch
 };
 constexpr int AP_MAX = 12;
 
 struct AirlPrep {
   const int64_t *idx0, *idx1;   // rows of the two tables (null: the first n)
+  long long idx_stride;         // ... of batch blockIdx.z: idx + z * idx_stride
   int n0, R;
   int n_pass;
   AirlPass pass[AP_MAX];
@@ -478,10 +480,12 @@ __global__ __launch_bounds__(256) void airl_prepare_kernel(AirlPrep a) {
     const int w = i >= a.n0 ? 1 : 0, j = i - (w ? a.n0 : 0);
     wmask |= (unsigned)w << k;
     const int64_t* ix = w ? a.idx1 : a.idx0;
-    src[k] = ix ? (int)ix[j] : j;
+    src[k] = ix ? (int)ix[(long long)blockIdx.z * a.idx_stride + j] : j;
   }
   {
-    const AirlPass& P = a.pass[blockIdx.y];
+    AirlPass P = a.pass[blockIdx.y];
+    P.X += (long long)blockIdx.z * P.x_stride;
+    if (P.ws != nullptr) P.ws += (long long)blockIdx.z * P.ws_stride;
     for (int c0 = 0; c0 < P.ncols; c0 += 32) {
       const int c = c0 + cl, cc = min(c, P.ncols - 1);
       const bool col_on = c < P.ncols;
@@ -956,6 +960,269 @@ __global__ __launch_bounds__(A_THREADS) void airl_gp_rows_kernel(AirlGpArgs a) {
   }
 }
 
+
+// ---- GAIL with the reference's DEFAULT discriminator: BasicRewardNet D -> 32 -> 32 -> 1 (ReLU) --------------------------------
+// rewards/reward_nets.py:394-397,430-457 (hid_sizes = (32, 32): what every tuned GAIL config of the reference trains) on
+// the same register-resident transposed chains as the potential stack above. One launch does the whole minibatch of
+// adversarial/common.py:352-373 short of the optimiser step: normalise (statistics as given), forward, BCE-with-logits +
+// the statistics of compute_train_stats, deltas -- and the WEIGHT GRADIENTS too: the workgroup's 128 rows of
+// (x_n, h1, delta1, delta2) go through LDS tiles, then wave 0 contracts delta2^T . h1 (dW2), waves 1 / 2 delta1^T . x_n
+// (dW1, 32 input columns each) over the 128 rows on the matrix cores and wave 3 takes the bias / output-layer sums. Each
+// workgroup leaves one slab of the flat gradient layout; ia_reduce_partials(_adam) finishes. Two launches per update.
+struct Disc32Args {
+  const float* X; int ldx, D, R, n_expert;
+  const float *mean, *var; float eps;     // null: no input normalisation
+  const float* P;                         // W1[32 x D] b1[32] W2[32 x 32] b2[32] W3[32] b3
+  float scale;
+  float* part; long long pstride;         // [workgroups][pstride] gradient slabs, torch parameter order
+  float *logits, *dlogits, *stats, *bce_part;
+  unsigned* ticket;
+};
+
+constexpr int D32_TX = 65, D32_TH = 33;   // LDS row strides (odd: conflict-free column walks)
+struct Disc32Lds {
+  f32x4 W1f[A_CH * 64], W2f[4 * 64], W2tf[4 * 64];
+  float vec[3 * AH + 4];                  // b1, b2, w3, then b3
+  float mean[A_D_MAX], istd[A_D_MAX];
+  float red[A_WAVES][40];                 // per wave: 32 dW3 partial sums + 8 scalars
+  float Tx[A_ROWS * D32_TX];              // normalised inputs of the workgroup's rows
+  float Th1[A_ROWS * D32_TH], Td1[A_ROWS * D32_TH], Td2[A_ROWS * D32_TH];
+  int is_last;
+};
+
+__device__ __forceinline__ void store_features_lds(float* __restrict__ row, const f32x16& v, int half) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+#pragma unroll
+    for (int u = 0; u < 4; ++u) row[8 * q + 4 * half + u] = v[4 * q + u];
+}
+
+// C[m][n] = sum over the workgroup's 128 rows of TA[row][m] * TB[row][n]: one wave, 64 k-steps of v_mfma_f32_32x32x2_f32
+// (A[m][k] from lane (m, k & 1), B[k][n] from lane (n, k & 1)); the 16 operand pairs of a quarter are requested together.
+__device__ __forceinline__ f32x16 rows_outer(const float* __restrict__ TA, int lda, const float* __restrict__ TB, int ldb,
+                                             int lane) {
+  f32x16 acc;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) acc[j] = 0.f;
+  const int c = lane & 31, h = lane >> 5;
+#pragma unroll
+  for (int s0 = 0; s0 < A_ROWS / 2; s0 += 16) {
+    float av[16], bv[16];
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      const int row = 2 * (s0 + s) + h;
+      av[s] = TA[row * lda + c];
+      bv[s] = TB[row * ldb + c];
+    }
+#pragma unroll
+    for (int s = 0; s < 16; ++s) acc = mfma(av[s], bv[s], acc);
+  }
+  return acc;
+}
+
+__global__ __launch_bounds__(A_THREADS) void disc32_rows_kernel(Disc32Args a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char d32_smem[];
+  Disc32Lds& S = *reinterpret_cast<Disc32Lds*>(d32_smem);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int half = lane >> 5;
+  const int D = a.D, C = (D + 7) >> 3;
+  const int rl = wave * 32 + (lane & 31);           // row inside the workgroup
+  const int r = blockIdx.x * A_ROWS + rl;
+  const bool live = r < a.R;
+  const int rr = live ? r : a.R - 1;                // (rows past the end recompute the last one with a zero delta)
+  f32x4 raw[A_CH];
+  load_row(a.X + (long long)rr * a.ldx, a.ldx, C, half, raw);
+
+  const float* P = a.P;
+  const int o_b1 = AH * D, o_W2 = o_b1 + AH, o_b2 = o_W2 + AH * AH, o_w3 = o_b2 + AH, o_b3 = o_w3 + AH;
+  {
+    // weight fragments (entry (q, lane) = A[m = lane & 31][k = 8 q + 4 (lane >> 5) + u]), vectors and statistics: every
+    // global load of a thread is issued before its first LDS store (clamped addresses, masked afterwards)
+    constexpr int NE = A_CH * 64 / A_THREADS;
+    f32x4 w1[NE], w2, w2t;
+#pragma unroll
+    for (int it = 0; it < NE; ++it) {
+      const int e = tid + it * A_THREADS;
+      const int m = e & 31, k0 = 8 * (e >> 6) + 4 * ((e >> 5) & 1);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) w1[it][u] = P[m * D + min(k0 + u, D - 1)];
+    }
+    {
+      const int m = tid & 31, k0 = 8 * (tid >> 6) + 4 * ((tid >> 5) & 1);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        w2[u] = P[o_W2 + m * AH + k0 + u];            // forward:  A[m = out][k = in]
+        w2t[u] = P[o_W2 + (k0 + u) * AH + m];         // backward: A[m = in][k = out]
+      }
+    }
+    const int vt = min(tid, AH - 1), kt = min(tid, D - 1);
+    const float v0 = P[o_b1 + vt], v1 = P[o_b2 + vt], v2 = P[o_w3 + vt], vb = P[o_b3];
+    const bool hn = a.mean != nullptr;
+    const float sm = hn ? a.mean[kt] : 0.f, sv = hn ? a.var[kt] : 1.f;
+#pragma unroll
+    for (int it = 0; it < NE; ++it) {
+      const int e = tid + it * A_THREADS;
+      const int k0 = 8 * (e >> 6) + 4 * ((e >> 5) & 1);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) w1[it][u] = k0 + u < D ? w1[it][u] : 0.f;
+      S.W1f[e] = w1[it];
+    }
+    S.W2f[tid] = w2;
+    S.W2tf[tid] = w2t;
+    if (tid < AH) {
+      S.vec[tid] = v0;
+      S.vec[AH + tid] = v1;
+      S.vec[2 * AH + tid] = v2;
+    }
+    if (tid == 0) S.vec[3 * AH] = vb;
+    if (tid < A_D_MAX) {
+      const bool in = tid < D;
+      S.mean[tid] = in ? sm : 0.f;
+      S.istd[tid] = in ? (hn ? 1.f / sqrtf(sv + a.eps) : 1.f) : 0.f;   // (x - mean) / sqrt(var + eps), networks.py:91
+    }
+  }
+  __syncthreads();
+
+  const f32x16 w3 = per_feature(S.vec + 2 * AH, half), b2 = per_feature(S.vec + AH, half);
+  const f32x4* W1f = S.W1f + lane;
+  const f32x4* W2f = S.W2f + lane;
+  const f32x4* W2tf = S.W2tf + lane;
+
+  // forward: h1 = relu(b1 + W1 xn) (xn into the LDS tile on the way), h2 = relu(b2 + W2 h1), logit = b3 + w3 . h2
+  f32x16 h1 = per_feature(S.vec, half);
+  {
+    float* xrow = S.Tx + rl * D32_TX;
+#pragma unroll
+    for (int q = 0; q < A_CH; ++q) {
+      if (q < C) {
+        const int k0 = 8 * q + 4 * half;
+        const f32x4 m = *reinterpret_cast<const f32x4*>(S.mean + k0);
+        const f32x4 is = *reinterpret_cast<const f32x4*>(S.istd + k0);
+        const f32x4 w = W1f[q * 64];
+        const f32x4 xn = (raw[q] - m) * is;          // (columns past the input width: istd = 0)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          xrow[k0 + u] = xn[u];
+          h1 = mfma(w[u], xn[u], h1);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 16; ++j) h1[j] = fmaxf(h1[j], 0.f);
+  f32x16 h2 = chain32(b2, h1, W2f);
+#pragma unroll
+  for (int j = 0; j < 16; ++j) h2[j] = fmaxf(h2[j], 0.f);
+  const float x = S.vec[3 * AH] + dot_features(h2, w3);
+
+  // BCE-with-logits, its gradient and the statistics (adversarial/common.py:27-92, 360-368; bce_kernel's expressions)
+  const float y = rr < a.n_expert ? 1.f : 0.f;
+  const float lse = log1pf(expf(-fabsf(x)));
+  const float p = 1.f / (1.f + expf(-x));
+  const float dlog = live ? (p - y) * (a.scale / (float)a.R) : 0.f;
+  f32x16 sc;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) sc[j] = 0.f;
+  if (live) {
+    if (half == 0) {
+      a.logits[r] = x;
+      if (a.dlogits) a.dlogits[r] = dlog;
+    }
+    const bool is_gen_pred = x < 0.f, is_gen_true = y == 0.f, ok = is_gen_pred == is_gen_true;
+    sc[0] = (1.f - y) * x - (fminf(x, 0.f) - lse);
+    sc[1] = ok ? 1.f : 0.f;
+    sc[2] = (ok && !is_gen_true) ? 1.f : 0.f;
+    sc[3] = (ok && is_gen_true) ? 1.f : 0.f;
+    sc[4] = is_gen_pred ? 1.f : 0.f;
+    sc[5] = (1.f - p) * x - (fminf(x, 0.f) - lse);
+    sc[6] = dlog;                                  // d b3
+  }
+
+  // backward: delta2 = relu'(h2) dlog w3, delta1 = relu'(h1) (W2^T delta2); output-layer gradient rows dlog * h2
+  f32x16 d2, g3, z;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    g3[j] = dlog * h2[j];
+    d2[j] = h2[j] > 0.f ? dlog * w3[j] : 0.f;
+    z[j] = 0.f;
+  }
+  f32x16 d1 = chain32(z, d2, W2tf);
+#pragma unroll
+  for (int j = 0; j < 16; ++j) d1[j] = h1[j] > 0.f ? d1[j] : 0.f;
+  store_features_lds(S.Th1 + rl * D32_TH, h1, half);
+  store_features_lds(S.Td1 + rl * D32_TH, d1, half);
+  store_features_lds(S.Td2 + rl * D32_TH, d2, half);
+  {
+    const float s_g = half_sums16(g3, lane), s_s = half_sums16(sc, lane);
+    const int j = ((lane >> 4) & 1) * 8 + ((lane >> 3) & 1) * 4 + ((lane >> 2) & 1) * 2 + ((lane >> 1) & 1);
+    const int feat = 8 * (j >> 2) + 4 * half + (j & 3);
+    if ((lane & 1) == 0) {
+      S.red[wave][feat] = s_g;
+      if (half == 0 && j < 8) S.red[wave][AH + j] = s_s;
+    }
+  }
+  __syncthreads();
+
+  // weight gradients of the workgroup's 128 rows, one role per wave; slab = [W1 | b1 | W2 | b2 | W3 | b3]
+  float* slab = a.part + (long long)blockIdx.x * a.pstride;
+  if (wave == 0) {
+    const f32x16 g = rows_outer(S.Td2, D32_TH, S.Th1, D32_TH, lane);
+#pragma unroll
+    for (int j = 0; j < 16; ++j) slab[o_W2 + (8 * (j >> 2) + 4 * half + (j & 3)) * AH + (lane & 31)] = g[j];
+  } else if (wave == 1 || (wave == 2 && D > 32)) {
+    const int c0 = (wave - 1) * 32, c = c0 + (lane & 31);
+    const f32x16 g = rows_outer(S.Td1, D32_TH, S.Tx + c0, D32_TX, lane);
+    if (c < D) {
+#pragma unroll
+      for (int j = 0; j < 16; ++j) slab[(8 * (j >> 2) + 4 * half + (j & 3)) * D + c] = g[j];
+    }
+  } else if (wave == 3) {
+    // bias gradients = column sums of the delta tiles (lanes 0..31: b2 from delta2, lanes 32..63: b1 from delta1)
+    const float* T = (half ? S.Td1 : S.Td2) + (lane & 31);
+    float s = 0.f;
+#pragma unroll 16
+    for (int row = 0; row < A_ROWS; ++row) s += T[row * D32_TH];
+    slab[(half ? o_b1 : o_b2) + (lane & 31)] = s;
+    if (lane < 40) {
+      float t = S.red[0][lane];
+#pragma unroll
+      for (int w = 1; w < A_WAVES; ++w) t += S.red[w][lane];
+      if (lane < AH) slab[o_w3 + lane] = t;
+      else if (lane < AH + 6)   // (written THROUGH to memory: the hand-off below then needs no L2 write-back)
+        __hip_atomic_store(a.bce_part + blockIdx.x * 8 + lane - AH, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      else if (lane == AH + 6) slab[o_b3] = t;
+    }
+  }
+  // statistics: the workgroup that draws the last ticket folds the partials (the hand-off of airl_rows_kernel)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (tid == 0) {
+    const unsigned tk = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    S.is_last = (tk == gridDim.x - 1);
+  }
+  __syncthreads();
+  if (!S.is_last) return;
+  {
+    const int k = tid >> 5, j = tid & 31;
+    float t = 0.f;
+    if (k < 6)
+      for (unsigned b = j; b < gridDim.x; b += 32)
+        t += __hip_atomic_load(a.bce_part + b * 8 + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    float* fold = S.Tx;                    // (the tiles were consumed before the last barriers)
+    if (k < 8) fold[k * 32 + j] = t;
+    __syncthreads();
+    if (tid < 6) {
+      float tsum = 0.f;
+      for (int q = 0; q < 32; ++q) tsum += fold[tid * 32 + q];
+      if (tid == 0) tsum = tsum / (float)a.R * a.scale;
+      a.stats[tid] = tsum;
+    }
+  }
+  if (tid == 6) a.stats[6] = (float)a.n_expert;
+  if (tid == 7) a.stats[7] = (float)(a.R - a.n_expert);
+  if (tid == 0) __hip_atomic_store(a.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 }  // namespace
 
 extern "C" {
@@ -1051,7 +1318,7 @@ int ia_airl_prepare(const float* obs0, const float* act0_f32, const int64_t* act
   const int od = obs_dim, ad = act_dim;
   int n = 0, col = 0;
   auto add = [&](const void* p0, const void* p1, int kind, int stride, int ncols, float* X, int ldx, int xcol, float* ws,
-                 int wsD) { a.pass[n++] = AirlPass{p0, p1, kind, stride, 0, ncols, X, ldx, xcol, ws, wsD}; };
+                 int wsD) { a.pass[n++] = AirlPass{p0, p1, kind, stride, 0, ncols, X, ldx, xcol, ws, wsD, 0, 0}; };
   if (use_state) { add(obs0, obs1, AP_F32, od, od, Xb, ldb, col, ws_b, Db); col += od; }
   if (use_action) {
     if (disc) add(act0_i64, act1_i64, AP_ONEHOT, 1, ad, Xb, ldb, col, ws_b, Db);
@@ -1149,3 +1416,110 @@ int ia_airl_gp_shaped(const float* Xb, int ldb, int Db, const float* Sn, const f
 }
 
 }  // extern "C"
+
+// ---- the 32-wide BasicRewardNet behind the fused entry points of disc_fused.hip (ia_disc_fused_ws_floats,
+//      ia_disc_assemble_round, ia_disc_step_basic -> ia_disc_step_fused, ia_disc_fused_adam dispatch here by shape) ----------
+bool ia_disc32_shape_ok(const ia_mlp_desc* d, int ldx) {
+  if (!d || d->n_layers != 3 || d->hidden_act != IA_ACT_RELU) return false;
+  const int D = d->dims[0];
+  return d->dims[1] == AH && d->dims[2] == AH && d->dims[3] == 1 && D >= 1 && D <= A_D_MAX && ldx >= D && ldx % 4 == 0 &&
+         ldx <= A_D_MAX;
+}
+
+namespace {
+struct D32Ws { float* part; float* bce_part; unsigned* ticket; long long total; int nblk; long long P; };
+inline D32Ws d32_layout(const ia_mlp_desc* d, int R, float* base) {
+  D32Ws w;
+  w.nblk = (R + A_ROWS - 1) / A_ROWS;
+  w.P = (long long)AH * d->dims[0] + AH + AH * AH + AH + AH + 1;
+  long long o = 0;
+  w.part = base + o; o += (long long)w.nblk * w.P;
+  w.bce_part = base + o; o += (long long)w.nblk * 8;
+  w.ticket = reinterpret_cast<unsigned*>(base + o); o += 4;
+  w.total = o;
+  return w;
+}
+}  // namespace
+
+int64_t ia_disc32_ws_floats(const ia_mlp_desc* d, int R) { return R > 0 ? d32_layout(d, R, nullptr).total : 0; }
+
+// Batch assembly of `n_updates` updates in one launch (update k: index rows idx + k * idx_stride -> X + k * x_stride, slab
+// moments -> rn_ws + k * rn_stride): adversarial/common.py:564-603 + rewards/reward_nets.py:441-457 through the pass kernel.
+int ia_disc32_assemble(const ia_disc_step_args* a, int n_updates, int64_t idx_stride, int64_t x_stride, int64_t rn_stride,
+                       float* rn_ws, hipStream_t stream) {
+  const int od = a->obs_dim, ad = a->act_dim, D = a->desc->dims[0];
+  const int Dchk = (a->use_state ? od : 0) + (a->use_action ? ad : 0) + (a->use_next_state ? od : 0) + (a->use_done ? 1 : 0);
+  if (Dchk != D || a->n0 < 0 || a->n1 < 0 || a->n0 + a->n1 <= 0 || !a->X || n_updates <= 0) return IA_ERR_ARG;
+  AirlPrep p{};
+  p.idx0 = a->idx0; p.idx1 = a->idx1; p.idx_stride = idx_stride; p.n0 = a->n0; p.R = a->n0 + a->n1;
+  // an empty side never selects its table: alias the other one so that no null pointer is formed into an address
+  const bool e0 = a->n0 == 0, e1 = a->n1 == 0;
+  const float *obs0 = e0 ? a->obs1 : a->obs0, *obs1 = e1 ? a->obs0 : a->obs1;
+  const float *nx0 = e0 ? a->next1 : a->next0, *nx1 = e1 ? a->next0 : a->next1;
+  const uint8_t *dn0 = e0 ? a->done1 : a->done0, *dn1 = e1 ? a->done0 : a->done1;
+  const float *af0 = e0 ? a->act1_f32 : a->act0_f32, *af1 = e1 ? a->act0_f32 : a->act1_f32;
+  const int64_t *ai0 = e0 ? a->act1_i64 : a->act0_i64, *ai1 = e1 ? a->act0_i64 : a->act1_i64;
+  const bool disc = ai0 != nullptr;
+  int n = 0, col = 0;
+  auto add = [&](const void* p0, const void* p1, int kind, int stride, int ncols) {
+    p.pass[n++] = AirlPass{p0, p1, kind, stride, 0, ncols, a->X, a->ldx, col, rn_ws, D, x_stride, rn_stride};
+    col += ncols;
+  };
+  if (a->use_state) add(obs0, obs1, AP_F32, od, od);
+  if (a->use_action) {
+    if (disc) add(ai0, ai1, AP_ONEHOT, 1, ad);
+    else add(af0, af1, AP_F32, ad, ad);
+  }
+  if (a->use_next_state) add(nx0, nx1, AP_F32, od, od);
+  if (a->use_done) add(dn0, dn1, AP_DONE, 1, 1);
+  p.n_pass = n;
+  hipLaunchKernelGGL(airl_prepare_kernel, dim3((p.R + RN_ROWS_PER_BLOCK - 1) / RN_ROWS_PER_BLOCK, n, n_updates), dim3(256),
+                     0, stream, p);
+  IA_CHECK_LAUNCH();
+  return IA_OK;
+}
+
+// One minibatch of train_disc for the 32-wide stack: the contract of ia_disc_step_basic (assemble unless pre_assembled,
+// train-mode statistics, forward + BCE + backward with the weight gradients in ONE launch, slab reduction (+ Adam)).
+int ia_disc32_step(const ia_disc_step_args* a, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  const ia_mlp_desc* d = a->desc;
+  const int R = a->n0 + a->n1, D = d->dims[0];
+  if (!ia_disc32_shape_ok(d, a->ldx) || !a->fused_ws || !a->X || !a->logits || !a->stats || !a->grads) return IA_ERR_ARG;
+  const D32Ws w = d32_layout(d, R, a->fused_ws);
+  int rc;
+  if (!a->pre_assembled) {
+    const bool upd = a->norm_mean != nullptr && a->update_norm;
+    if (upd && !a->rn_ws) return IA_ERR_ARG;
+    if ((rc = ia_disc32_assemble(a, 1, 0, 0, 0, upd ? a->rn_ws : nullptr, stream))) return rc;
+    if (upd) {
+      if ((rc = ia_running_norm_merge(a->rn_ws, 1, R, D, D, a->norm_mean, a->norm_var, a->norm_count, stream_))) return rc;
+      if (a->pnorm_mean && a->pnorm_dim > 0 && a->pnorm_dim <= D &&
+          (rc = ia_running_norm_merge(a->rn_ws, 1, R, a->pnorm_dim, D, a->pnorm_mean, a->pnorm_var, a->pnorm_count, stream_)))
+        return rc;
+    }
+  }
+  Disc32Args k{};
+  k.X = a->X; k.ldx = a->ldx; k.D = D; k.R = R; k.n_expert = a->n_expert;
+  k.mean = a->norm_mean; k.var = a->norm_var; k.eps = a->norm_eps;
+  k.P = a->params; k.scale = a->loss_scale;
+  k.part = w.part; k.pstride = w.P;
+  k.logits = a->logits; k.dlogits = a->dlogits; k.stats = a->stats; k.bce_part = w.bce_part; k.ticket = w.ticket;
+  static bool attr = false;
+  if (!attr) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(disc32_rows_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)sizeof(Disc32Lds)) != hipSuccess)
+      return IA_ERR_ARG;
+    attr = true;
+  }
+  hipLaunchKernelGGL(disc32_rows_kernel, dim3(w.nblk), dim3(A_THREADS), sizeof(Disc32Lds), stream, k);
+  IA_CHECK_LAUNCH();
+  if (a->adam && !a->accumulate)
+    return ia_reduce_partials_adam(w.part, w.nblk, w.P, 1.0f, a->grads, a->params, a->exp_avg, a->exp_avg_sq, a->beta1,
+                                   a->beta2, a->adam_eps, a->weight_decay, a->step_size, a->bc2_sqrt, stream_);
+  if ((rc = ia_reduce_partials(w.part, w.nblk, w.P, 1.0f, a->accumulate, a->grads, stream_))) return rc;
+  if (a->adam)
+    return ia_adam_step(a->params, a->grads, a->exp_avg, a->exp_avg_sq, w.P, a->beta1, a->beta2, a->adam_eps,
+                        a->weight_decay, a->step_size, a->bc2_sqrt, stream_);
+  return IA_OK;
+}

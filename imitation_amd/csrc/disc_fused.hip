@@ -871,6 +871,12 @@ int launch_fused_tiles(const FusedArgs& fa, int R, hipStream_t stream) {
 }  // namespace
 
 namespace { long long* g_fused_dbg = nullptr; }
+// the reference's default 32 x 32 stack takes the register-resident row kernel of airl_fused.hip behind the same entries
+bool ia_disc32_shape_ok(const ia_mlp_desc* d, int ldx);
+int64_t ia_disc32_ws_floats(const ia_mlp_desc* d, int R);
+int ia_disc32_assemble(const ia_disc_step_args* a, int n_updates, int64_t idx_stride, int64_t x_stride, int64_t rn_stride,
+                       float* rn_ws, hipStream_t stream);
+int ia_disc32_step(const ia_disc_step_args* a, void* stream);
 extern "C" int ia_disc_fused_tile_rows(int rows) { g_fused_bm = rows == 32 ? 32 : 64; return IA_OK; }
 extern "C" int ia_disc_fused_debug_timing(void* device_buffer_16xi64) {
   g_fused_dbg = static_cast<long long*>(device_buffer_16xi64);
@@ -878,6 +884,7 @@ extern "C" int ia_disc_fused_debug_timing(void* device_buffer_16xi64) {
 }
 
 extern "C" int64_t ia_disc_fused_ws_floats(const ia_mlp_desc* d, int R, int ldx) {
+  if (R > 0 && ia_disc32_shape_ok(d, ldx)) return ia_disc32_ws_floats(d, R);
   if (R <= 0 || !fused_shape_ok(d, ldx)) return 0;
   return fused_ws_layout(d, R, nullptr).total;
 }
@@ -900,6 +907,8 @@ void fill_assemble_sources(AssembleArgs& as, const ia_disc_step_args* a) {
 // rn_ws + k*rn_stride (no merge: ia_running_norm_merge_seq applies them in order and keeps per-update snapshots).
 extern "C" int ia_disc_assemble_round(const ia_disc_step_args* a, int n_updates, int64_t idx_stride, int64_t x_stride,
                                       int64_t rn_stride, void* stream) {
+  if (a && n_updates > 0 && ia_disc32_shape_ok(a->desc, a->ldx))
+    return ia_disc32_assemble(a, n_updates, idx_stride, x_stride, rn_stride, a->rn_ws, (hipStream_t)stream);
   if (!a || n_updates <= 0 || !fused_shape_ok(a->desc, a->ldx) || a->n0 + a->n1 <= 0) return IA_ERR_ARG;
   AssembleArgs as{};
   fill_assemble_sources(as, a);
@@ -918,6 +927,7 @@ extern "C" int ia_disc_assemble_round(const ia_disc_step_args* a, int n_updates,
 // pre-assembled updates; the updates' own Adam steps keep them current).
 extern "C" int ia_disc_fused_prepare(const ia_mlp_desc* d, const float* params, int R, int ldx, float* fused_ws,
                                      void* stream) {
+  if (fused_ws && R > 0 && ia_disc32_shape_ok(d, ldx)) return IA_OK;   // (its row kernel reads the parameters themselves)
   if (!fused_shape_ok(d, ldx) || !fused_ws || R <= 0) return IA_ERR_ARG;
   const int D = d->dims[0], H = d->dims[1];
   const FusedWs w = fused_ws_layout(d, R, fused_ws);
@@ -934,18 +944,20 @@ extern "C" int ia_disc_fused_prepare(const ia_mlp_desc* d, const float* params, 
 // gradient; scaled by grad_scale in place, Adam step on `params`, W2T / W1 images of fused_ws refreshed.
 extern "C" int ia_disc_fused_adam(const ia_mlp_desc* d, float* params, float grad_scale, int R, int ldx, float* fused_ws,
                                   const ia_adam_args* adam, void* stream) {
-  if (!fused_shape_ok(d, ldx) || !fused_ws || !params || !adam || !adam->grads || !adam->exp_avg || !adam->exp_avg_sq ||
-      R <= 0)
+  const bool narrow = ia_disc32_shape_ok(d, ldx);   // no weight images to refresh: H = D = 0 below
+  if ((!narrow && !fused_shape_ok(d, ldx)) || !fused_ws || !params || !adam || !adam->grads || !adam->exp_avg ||
+      !adam->exp_avg_sq || R <= 0)
     return IA_ERR_ARG;
   const int D = d->dims[0], H = d->dims[1];
-  const FusedWs w = fused_ws_layout(d, R, fused_ws);
+  FusedWs w{};
+  if (!narrow) w = fused_ws_layout(d, R, fused_ws);
   AdamRefreshArgs ra{};
   ra.n = (long long)H * D + H + (long long)H * H + H + H + 1;
   ra.grads = adam->grads; ra.gscale = grad_scale;
   ra.p = params; ra.m = adam->exp_avg; ra.v = adam->exp_avg_sq;
   ra.beta1 = adam->beta1; ra.beta2 = adam->beta2; ra.eps = adam->eps; ra.wd = adam->weight_decay;
   ra.step_size = adam->step_size; ra.bc2_sqrt = adam->bc2_sqrt;
-  ra.W2T = w.W2T; ra.W1P = w.W1P; ra.H = H; ra.D = D;
+  ra.W2T = w.W2T; ra.W1P = w.W1P; ra.H = narrow ? 0 : H; ra.D = narrow ? 1 : D;
   hipLaunchKernelGGL(disc_adam_refresh_kernel, dim3(cdivi(ra.n, 256)), dim3(256), 0, (hipStream_t)stream, ra);
   IA_CHECK_LAUNCH();
   return IA_OK;
@@ -957,6 +969,7 @@ int ia_disc_step_fused(const ia_disc_step_args* a, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   const ia_mlp_desc* d = a->desc;
   const int R = a->n0 + a->n1, D = d->dims[0], H = d->dims[1];
+  if (a->fused_ws && ia_disc32_shape_ok(d, a->ldx)) return ia_disc32_step(a, stream_);
   if (!fused_shape_ok(d, a->ldx) || !a->fused_ws) return IA_ERR_UNSUPPORTED;
   const FusedWs w = fused_ws_layout(d, R, a->fused_ws);
   const int bm = g_fused_bm == 64 ? 64 : 32;

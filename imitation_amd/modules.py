@@ -438,6 +438,27 @@ class RewardNetFromDiscriminatorLogit(RewardNet):
         return -th.nn.functional.logsigmoid(-logits)
 
 
+def bulk_relabel_ok(net: RewardNet) -> bool:
+    """True when `net.predict_processed(s, a, s', d)` is, row by row, `net.predict_th` of the same rows no matter how
+    the rows are split into calls -- i.e. every `predict_processed` / `predict` / `predict_th` along the wrapper chain
+    is one of THIS module's stateless implementations. A user net or wrapper that overrides any of them (custom
+    normalisation, clipping, counters) and `NormalizedRewardNet` (statistics updated per call) must be called once per
+    environment step like the reference does (`rewards/reward_wrapper.py:110-115`)."""
+    m = net
+    while True:
+        if isinstance(m, NormalizedRewardNet) or not isinstance(m, RewardNet):
+            return False
+        t = type(m)
+        own = PredictProcessedWrapper if isinstance(m, PredictProcessedWrapper) else RewardNet
+        if t.predict_processed is not RewardNet.predict_processed:
+            return False
+        if t.predict is not own.predict or t.predict_th is not own.predict_th:
+            return False
+        if not isinstance(m, PredictProcessedWrapper):
+            return True
+        m = m.base
+
+
 def build_mlp(*args, **kwargs) -> Mlp:
     """`util/networks.py:204-283` signature."""
     return Mlp(*args, **kwargs)

@@ -495,13 +495,14 @@ class PPO(OnPolicyAlgorithm):
             if isinstance(owner, RewardNet) and getattr(rw.reward_fn, "__name__", "") == "predict_processed":
                 fused_net = owner
         # an `nn.Module` reward net (operator boundary) whose prediction does not depend on the call sequence (no
-        # NormalizedRewardNet statistics update per call): relabel the whole tile behind the last step, in chunks,
-        # instead of one host round trip per environment step
+        # NormalizedRewardNet statistics update per call, no user override of predict_processed / predict / predict_th
+        # anywhere in the wrapper chain): relabel the whole tile behind the last step, in chunks, instead of one host
+        # round trip per environment step; anything else is called once per step like `RewardVecEnvWrapper` does
         module_net = None
         if rw is not None and fused_net is None:
             from imitation_amd import modules as _modules
             if (isinstance(owner, _modules.RewardNet) and getattr(rw.reward_fn, "__name__", "") == "predict_processed"
-                    and not any(isinstance(m_, _modules.NormalizedRewardNet) for m_ in owner.modules())):
+                    and _modules.bulk_relabel_ok(owner)):
                 module_net = owner
         T, n = rb.buffer_size, rb.n_envs
         assert n_rollout_steps == T

@@ -1,0 +1,196 @@
+"""The fused discriminator updates (`csrc/disc_fused.hip`: D -> H -> H -> 1 with H in {128, 256}; `csrc/airl_fused.hip`
+`disc32_rows_kernel`: the reference's default 32 x 32 stack with up to 64 inputs) through `BasicRewardNet.disc_step_c`
+against a float64 torch autograd restatement of one `train_disc` minibatch (`adversarial/common.py:352-373`,
+`rewards/reward_nets.py:441-457`, `util/networks.py:79-91,111-134`): logits, the statistics row, the flat gradient,
+the RunningNorm state, Adam's step. Tolerances: forward 1e-5 relative, gradients 2e-5 * sqrt(rows) absolute headroom
+for fp32 summation order; counts exact."""
+import numpy as np
+import pytest
+import torch as th
+
+import imitation_amd as p
+from imitation_amd import _lib as L
+from imitation_amd import networks, reward_nets, spaces
+from imitation_amd.networks import HipAdam, TransitionTable
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _need_gpu():
+    if not th.cuda.is_available():
+        pytest.skip("no GPU")
+    L.load()
+
+
+def _tables(n_tab, od, ad, discrete, seed):
+    g = np.random.default_rng(seed)
+    obs = g.standard_normal((n_tab, od)).astype(np.float32) * 1.7 + 0.3
+    nxt = g.standard_normal((n_tab, od)).astype(np.float32)
+    acts = g.integers(0, ad, n_tab).astype(np.int64) if discrete else g.uniform(-1, 1, (n_tab, ad)).astype(np.float32)
+    dones = (g.random(n_tab) < 0.3).astype(np.uint8)
+    t = TransitionTable(th.as_tensor(obs).to(DEV), th.as_tensor(acts).to(DEV), th.as_tensor(nxt).to(DEV),
+                        th.as_tensor(dones).to(DEV), discrete)
+    return t, dict(obs=obs, acts=acts, next_obs=nxt, dones=dones)
+
+
+def _concat(host, idx, flags, ad, discrete):
+    cols = []
+    if flags[0]:
+        cols.append(host["obs"][idx])
+    if flags[1]:
+        a = host["acts"][idx]
+        cols.append(np.eye(ad, dtype=np.float32)[a] if discrete else a)
+    if flags[2]:
+        cols.append(host["next_obs"][idx])
+    if flags[3]:
+        cols.append(host["dones"][idx].astype(np.float32)[:, None])
+    return np.concatenate(cols, axis=1)
+
+
+CASES = [
+    # (obs_dim, act_dim, discrete, flags (state, action, next_state, done), hid, n_expert, n_gen, norm)
+    (17, 6, False, (True, True, False, False), (32, 32), 64, 64, True),        # the reference default at HalfCheetah width
+    (17, 6, False, (True, True, True, True), (32, 32), 200, 200, True),        # use_next_state + use_done: 41 inputs
+    (27, 8, False, (True, True, False, False), (32, 32), 300, 211, True),      # Ant width (35), ragged: 511 rows
+    (4, 2, True, (True, True, False, False), (32, 32), 33, 31, True),          # CartPole: one-hot actions, 6 inputs
+    (29, 6, False, (True, True, True, False), (32, 32), 128, 128, False),      # 64 inputs (the maximum), no input norm
+    (17, 6, False, (True, True, False, False), (128, 128), 100, 92, True),
+    (17, 6, False, (True, True, False, False), (256, 256), 256, 256, True),
+]
+
+
+@pytest.mark.parametrize("od,ad,discrete,flags,hid,n0,n1,norm", CASES)
+def test_fused_disc_step_matches_float64_autograd(od, ad, discrete, flags, hid, n0, n1, norm):
+    th.manual_seed(3)
+    osp = spaces.Box(-np.inf, np.inf, (od,), np.float32)
+    asp = spaces.Discrete(ad) if discrete else spaces.Box(-1, 1, (ad,), np.float32)
+    kw = dict(normalize_input_layer=p.RunningNorm) if norm else {}
+    net = reward_nets.BasicRewardNet(osp, asp, use_state=flags[0], use_action=flags[1], use_next_state=flags[2],
+                                     use_done=flags[3], hid_sizes=hid, **kw).to(DEV)
+    mlp = net.mlp
+    R = n0 + n1
+    assert net.fused_ws_of(R) is not None, "this shape must take a fused path"
+    e_tab, e_host = _tables(700, od, ad, discrete, 1)
+    g_tab, g_host = _tables(500, od, ad, discrete, 2)
+    rng = np.random.default_rng(5)
+    e_idx, g_idx = rng.integers(0, 700, n0), rng.integers(0, 500, n1)
+    if norm:   # non-trivial running statistics before the update (an earlier batch of 77 rows)
+        warm = th.as_tensor(rng.standard_normal((77, mlp.dims[0])).astype(np.float32) * 0.5 + 0.2).to(DEV)
+        mlp.norm.update_stats(warm)
+    params0 = mlp.flat.detach().cpu().double().clone()
+    st0 = None if not norm else (mlp.norm.running_mean.cpu().double().clone(), mlp.norm.running_var.cpu().double().clone(),
+                                 int(mlp.norm.count))
+    opt = HipAdam(mlp.flat, mlp.grad, lr=1e-3)
+    stats = th.zeros(8, device=DEV)
+    bce_ws = th.zeros(int(L.load().ia_bce_ws_floats(R)), device=DEV)
+    src = [(e_tab, th.as_tensor(e_idx).to(DEV), n0), (g_tab, th.as_tensor(g_idx).to(DEV), n1)]
+    with networks.training(net):
+        ws = net.disc_step_c(src, n0, 0.5, stats, bce_ws, accumulate=False, adam=opt)
+    th.cuda.synchronize()
+
+    # ---- float64 restatement
+    X = th.as_tensor(np.concatenate([_concat(e_host, e_idx, flags, ad, discrete),
+                                     _concat(g_host, g_idx, flags, ad, discrete)])).double()
+    if norm:
+        mean, var, cnt = st0
+        bm, bv = X.mean(0), X.var(0, unbiased=False)
+        tot = cnt + R
+        delta = bm - mean
+        new_mean = mean + delta * R / tot
+        new_var = (var * cnt + bv * R + delta ** 2 * cnt * R / tot) / tot
+        assert int(mlp.norm.count) == tot
+        th.testing.assert_close(mlp.norm.running_mean.cpu().double(), new_mean, rtol=1e-5, atol=1e-6)
+        th.testing.assert_close(mlp.norm.running_var.cpu().double(), new_var, rtol=1e-5, atol=1e-6)
+        Xn = (X - new_mean) / th.sqrt(new_var + 1e-5)
+    else:
+        Xn = X
+    D, H1, H2 = mlp.dims[0], hid[0], hid[1]
+    P = params0.clone().requires_grad_(True)
+    o = 0
+    W1 = P[o:o + H1 * D].view(H1, D); o += H1 * D
+    b1 = P[o:o + H1]; o += H1
+    W2 = P[o:o + H2 * H1].view(H2, H1); o += H2 * H1
+    b2 = P[o:o + H2]; o += H2
+    W3 = P[o:o + H2].view(1, H2); o += H2
+    b3 = P[o:o + 1]
+    logits = (th.relu(th.relu(Xn @ W1.T + b1) @ W2.T + b2) @ W3.T + b3).reshape(-1)
+    y = th.cat([th.ones(n0), th.zeros(n1)]).double()
+    loss = th.nn.functional.binary_cross_entropy_with_logits(logits, y) * 0.5
+    loss.backward()
+    got_logits = ws["out"].reshape(-1).cpu().double()
+    th.testing.assert_close(got_logits, logits.detach(), rtol=1e-5, atol=2e-5)
+    gtol = 2e-5 * max(1.0, float(P.grad.abs().max()))
+    th.testing.assert_close(mlp.grad.cpu().double(), P.grad, rtol=2e-4, atol=gtol)
+    s = stats.cpu().double().numpy()
+    assert abs(s[0] - float(loss)) < 1e-5 * max(1.0, abs(float(loss)))
+    pred_gen, true_gen = logits.detach() < 0, y == 0
+    ok = pred_gen == true_gen
+    assert s[1] == float(ok.sum()) and s[2] == float((ok & ~true_gen).sum()) and s[3] == float((ok & true_gen).sum())
+    assert s[4] == float(pred_gen.sum()) and s[6] == n0 and s[7] == n1
+    pr = th.sigmoid(logits.detach())
+    ent = th.nn.functional.binary_cross_entropy_with_logits(logits.detach(), pr, reduction="sum")
+    assert abs(s[5] - float(ent)) < 1e-4 * max(1.0, abs(float(ent)))
+    # Adam's first step: p - lr * g / (|g| + eps) (bias-corrected moments of a single gradient)
+    g = P.grad
+    want = params0 - 1e-3 * g / (g.abs() + 1e-8)
+    moved = g.abs() > 1e-7   # (elements with a vanishing gradient take a step that depends on its last bits)
+    th.testing.assert_close(mlp.flat.cpu().double()[moved], want[moved], rtol=0, atol=2e-5)
+
+
+@pytest.mark.parametrize("hid", [(32, 32), (128, 128)])
+def test_round_assembly_equals_per_update_assembly(hid):
+    """`assemble_round` + pre-assembled updates (what a pipelined round runs) == one-call updates in sequence: same
+    parameters, statistics rows and RunningNorm state, bit for bit."""
+    od, ad, n_upd, mb = 17, 6, 3, 96
+    osp, asp = spaces.Box(-np.inf, np.inf, (od,), np.float32), spaces.Box(-1, 1, (ad,), np.float32)
+    e_tab, _ = _tables(400, od, ad, False, 1)
+    g_tab, _ = _tables(300, od, ad, False, 2)
+    rng = np.random.default_rng(9)
+    idx_all = th.as_tensor(np.stack([np.stack([rng.integers(0, 400, mb), rng.integers(0, 300, mb)])
+                                     for _ in range(n_upd)])).to(DEV).contiguous()
+    outs = []
+    for pre in (False, True):
+        th.manual_seed(11)
+        net = reward_nets.BasicRewardNet(osp, asp, hid_sizes=hid, normalize_input_layer=p.RunningNorm).to(DEV)
+        opt = HipAdam(net.mlp.flat, net.mlp.grad, lr=1e-3)
+        stats = th.zeros(n_upd, 8, device=DEV)
+        bce_ws = th.zeros(int(L.load().ia_bce_ws_floats(2 * mb)), device=DEV)
+        with networks.training(net):
+            rw = net.assemble_round(e_tab, g_tab, idx_all, n_upd, mb) if pre else None
+            assert (rw is not None) == pre
+            for k in range(n_upd):
+                src = [(e_tab, idx_all[k, 0], mb), (g_tab, idx_all[k, 1], mb)]
+                net.disc_step_c(src, mb, 1.0, stats[k], bce_ws, accumulate=False, adam=opt,
+                                pre=(rw, k) if pre else None)
+        th.cuda.synchronize()
+        outs.append((net.mlp.flat.cpu().clone(), stats.cpu().clone(), net.mlp.norm.running_mean.cpu().clone(),
+                     net.mlp.norm.running_var.cpu().clone(), int(net.mlp.norm.count)))
+    for a, b in zip(*outs):
+        assert (a == b) if isinstance(a, int) else th.equal(a, b)
+    assert outs[0][4] == n_upd * 2 * mb
+
+
+def test_gradient_accumulation_through_the_narrow_fused_step():
+    """Two half minibatches accumulated (`demo_minibatch_size < demo_batch_size`, `common.py:352-373`) == the gradient of
+    the whole batch under frozen statistics (eval-mode norm), within summation order."""
+    od, ad, mb = 11, 3, 80
+    osp, asp = spaces.Box(-np.inf, np.inf, (od,), np.float32), spaces.Box(-1, 1, (ad,), np.float32)
+    e_tab, _ = _tables(400, od, ad, False, 1)
+    g_tab, _ = _tables(300, od, ad, False, 2)
+    rng = np.random.default_rng(4)
+    ei, gi = th.as_tensor(rng.integers(0, 400, 2 * mb)).to(DEV), th.as_tensor(rng.integers(0, 300, 2 * mb)).to(DEV)
+    th.manual_seed(2)
+    net = reward_nets.BasicRewardNet(osp, asp, hid_sizes=(32, 32)).to(DEV)
+    stats = th.zeros(8, device=DEV)
+    bce_ws = th.zeros(int(L.load().ia_bce_ws_floats(4 * mb)), device=DEV)
+    with networks.training(net):
+        net.disc_step_c([(e_tab, ei, 2 * mb), (g_tab, gi, 2 * mb)], 2 * mb, 1.0, stats, bce_ws, accumulate=False)
+        whole = net.mlp.grad.cpu().clone()
+        for h in range(2):
+            sl = slice(h * mb, (h + 1) * mb)
+            net.disc_step_c([(e_tab, ei[sl].contiguous(), mb), (g_tab, gi[sl].contiguous(), mb)], mb, 0.5, stats, bce_ws,
+                            accumulate=h > 0)
+    th.cuda.synchronize()
+    th.testing.assert_close(net.mlp.grad.cpu(), whole, rtol=2e-4, atol=2e-6)

@@ -275,7 +275,7 @@ def test_airl_prepare_and_stats_merge_bit_exact(n0, n1, discrete, use):
     L.call("ia_running_norm_update", L.ptr(ref["Sc"]), ldp, R, Do, L.ptr(rp[0]), L.ptr(rp[1]), L.ptr(rp[2]), L.ptr(ws),
            L.stream())
     snap, ticket = th.empty(2, Do, device=DEV), th.zeros(1, dtype=th.int32, device=DEV)
-    L.call("ia_airl_stats_merge", L.ptr(wsg["b"]), L.ptr(wsg["n"]), L.ptr(wsg["c"]), R, Db, Do, L.ptr(gb[0]), L.ptr(gb[1]),
+    L.call("ia_airl_stats_merge", L.ptr(wsg["b"]), L.ptr(wsg["n"]), L.ptr(wsg["c"]), 1, 0, R, Db, Do, L.ptr(gb[0]), L.ptr(gb[1]),
            L.ptr(gb[2]), L.ptr(gp[0]), L.ptr(gp[1]), L.ptr(gp[2]), L.ptr(snap), L.ptr(ticket), L.stream())
     for a, b in zip(gb + gp + [snap], rb + rp + [snap_ref]):
         assert th.equal(a, b)
