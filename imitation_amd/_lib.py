@@ -106,7 +106,7 @@ _SIGS = {
     "ia_mlp_backward": ([C.POINTER(MlpDesc), _P, _P, _I, _I, _P, _P, _P, _P, _I, _P, _P], C.c_int),
     "ia_reduce_partials": ([_P, _I, _L, _F, _I, _P, _P], C.c_int),
     "ia_adam_step": ([_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _F, _P], C.c_int),
-    "ia_adam_step_scalars": ([_P, C.c_double, C.c_double, C.c_double, _P, _P], C.c_int),
+    "ia_adam_step_scalars": ([_P, C.c_double, _P, C.c_double, C.c_double, _P, _P], C.c_int),
     "ia_adam_step_dev": ([_P, _P, _P, _P, _L, _F, _F, _F, _F, _P, _P], C.c_int),
     "ia_running_norm_ws_floats": ([_I, _I], C.c_int64),
     "ia_running_norm_update": ([_P, _I, _I, _I, _P, _P, _P, _P, _P], C.c_int),

@@ -218,7 +218,9 @@ def save_checkpoint(trainer, path) -> None:
                 "_num_timesteps_at_start": getattr(algo, "_num_timesteps_at_start", 0),
                 "ep_info_buffer": list(getattr(algo, "ep_info_buffer", []) or [])},
         "ring": {"obs": ring._obs.cpu(), "acts": ring._acts.cpu(), "next": ring._next.cpu(), "dones": ring._dones.cpu(),
-                 "_idx": ring._idx, "_n_data": ring._n_data},
+                 "_idx": ring._idx, "_n_data": ring._n_data,
+                 # host ring of info dicts at the same positions (None: no stored transition carried any)
+                 "infos": None if ring._infos is None else list(ring._infos)},
         "expert_stream": None if es is None else {"perm": None if es._perm is None else es._perm.copy(), "pos": es._pos},
         "counters": {"_global_step": trainer._global_step, "_disc_step": trainer._disc_step},
         "buffering": {"_last_obs": np.array(trainer.venv_buffering._last_obs),
@@ -267,6 +269,8 @@ def load_checkpoint(trainer, path) -> None:
     ring._obs.copy_(r["obs"].to(dev)); ring._acts.copy_(r["acts"].to(dev))
     ring._next.copy_(r["next"].to(dev)); ring._dones.copy_(r["dones"].to(dev))
     ring._idx, ring._n_data = int(r["_idx"]), int(r["_n_data"])
+    infos = r.get("infos")
+    ring._infos = None if infos is None else np.array(list(infos) + [{}] * (ring.capacity - len(infos)), dtype=object)
     es = getattr(trainer, "_expert_stream", None)
     if es is not None and blob["expert_stream"] is not None:
         es._perm, es._pos = blob["expert_stream"]["perm"], int(blob["expert_stream"]["pos"])

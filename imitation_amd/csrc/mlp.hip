@@ -83,11 +83,12 @@ __global__ void reduce_adam_kernel(const float* __restrict__ partials, int split
 // Step-dependent scalars of torch.optim.Adam from a DEVICE-resident step count, so that a captured launch sequence
 // (hipGraph replay of a whole PPO update, `GeneralTowers.ppo_update`) advances them without host arguments:
 // t = ++*step; scal = {lr / (1 - b1^t), sqrt(1 - b2^t)} in double like the host side of `ia_adam_step`'s callers.
-__global__ void adam_scalars_kernel(long long* __restrict__ step, double lr, double beta1, double beta2,
-                                    float* __restrict__ scal) {
+__global__ void adam_scalars_kernel(long long* __restrict__ step, double lr, const double* __restrict__ lr_dev,
+                                    double beta1, double beta2, float* __restrict__ scal) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   const long long t = *step + 1;
   *step = t;
+  if (lr_dev != nullptr) lr = *lr_dev;   // a learning-rate schedule reaches a captured sequence through device memory
   scal[0] = (float)(lr / (1.0 - pow(beta1, (double)t)));
   scal[1] = (float)sqrt(1.0 - pow(beta2, (double)t));
 }
@@ -802,10 +803,11 @@ int ia_adam_step_dev(float* params, const float* grads, float* exp_avg, float* e
   return IA_OK;
 }
 
-int ia_adam_step_scalars(int64_t* step, double lr, double beta1, double beta2, float* scalars, void* stream) {
+int ia_adam_step_scalars(int64_t* step, double lr, const double* lr_dev, double beta1, double beta2, float* scalars,
+                         void* stream) {
   if (!step || !scalars) return IA_ERR_ARG;
   hipLaunchKernelGGL(adam_scalars_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, reinterpret_cast<long long*>(step),
-                     lr, beta1, beta2, scalars);
+                     lr, lr_dev, beta1, beta2, scalars);
   IA_CHECK_LAUNCH();
   return IA_OK;
 }

@@ -165,6 +165,7 @@ class GeneralTowers:
             else:
                 self._low = self._high = th.zeros(self.act_dim, device=device)
             self._ws = {}
+            self.__dict__.pop("_update_graphs", None)   # captured updates hold the old buffers' addresses
         return self
 
     def _sync_transposed(self) -> None:
@@ -389,9 +390,14 @@ class GeneralTowers:
         if not (GRAPH_UPDATES and g0 is not None and (dp is None or dp.world == 1) and self._flat.is_cuda):
             return self._ppo_update_launches(rb, perm_dev, n_epochs, batch_size, normalize_advantage, clip_range,
                                              ent_coef, vf_coef, max_grad_norm, stats, dp)
-        key = (rb.obs.data_ptr(), rb.acts.data_ptr(), rb.buffer_size, rb.n_envs, perm_dev.data_ptr(), n_epochs, batch_size,
-               bool(normalize_advantage), float(clip_range), float(ent_coef), float(vf_coef), float(max_grad_norm),
-               tuple(stats.shape), bool(self.training), float(g0["lr"]), tuple(g0["betas"]), float(g0["eps"]),
+        # every buffer the captured launches read or write is part of the key (a rebuilt rollout tile, a second `.to()`
+        # or a reloaded optimiser must not replay into freed memory); the learning rate is NOT: it reaches the captured
+        # Adam launches through device memory (`HipAdam.sync_device_step`), so a schedule keeps replaying
+        key = (rb.obs.data_ptr(), rb.acts.data_ptr(), rb.logp.data_ptr(), rb.adv.data_ptr(), rb.ret.data_ptr(),
+               rb.buffer_size, rb.n_envs, perm_dev.data_ptr(), self._flat.data_ptr(), self._pi_stack.data_ptr(),
+               self._vf_stack.data_ptr(), opt.exp_avg.data_ptr(), opt.exp_avg_sq.data_ptr(), opt.grad.data_ptr(), n_epochs,
+               batch_size, bool(normalize_advantage), float(clip_range), float(ent_coef), float(vf_coef),
+               float(max_grad_norm), tuple(stats.shape), bool(self.training), tuple(g0["betas"]), float(g0["eps"]),
                float(g0["weight_decay"]), th.cuda.current_device())
         graphs = self.__dict__.setdefault("_update_graphs", {})
         entry = graphs.get(key)

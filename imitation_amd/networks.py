@@ -326,6 +326,8 @@ class HipAdam:
         if getattr(self, "_dev_step", None) is None:
             self._dev_step = th.zeros(1, dtype=th.int64, device=self.flat.device)
             self._dev_scal = th.zeros(2, device=self.flat.device)
+            self._dev_lr = th.zeros(1, dtype=th.float64, device=self.flat.device)
+        self._dev_lr.fill_(float(self.param_groups[0]["lr"]))
         self._dev_mode = True
 
     def end_device_steps(self, steps_run: int = 0) -> None:
@@ -333,16 +335,17 @@ class HipAdam:
         self.step_count += int(steps_run)
 
     def sync_device_step(self) -> None:
-        """Sets the device-side count to the host's (before a replay)."""
+        """Sets the device-side count and learning rate to the host's (before a replay)."""
         self._dev_step.fill_(self.step_count)
+        self._dev_lr.fill_(float(self.param_groups[0]["lr"]))
 
     def step(self) -> None:
         g = self.param_groups[0]
         if getattr(self, "_dev_mode", False):
             b1, b2 = g["betas"]
             s = L.stream()
-            L.call("ia_adam_step_scalars", L.ptr(self._dev_step), float(g["lr"]), float(b1), float(b2),
-                   L.ptr(self._dev_scal), s)
+            L.call("ia_adam_step_scalars", L.ptr(self._dev_step), float(g["lr"]), L.ptr(self._dev_lr), float(b1),
+                   float(b2), L.ptr(self._dev_scal), s)
             L.call("ia_adam_step_dev", L.ptr(self.flat), L.ptr(self.grad), L.ptr(self.exp_avg), L.ptr(self.exp_avg_sq),
                    self.flat.numel(), b1, b2, g["eps"], g["weight_decay"], L.ptr(self._dev_scal), s)
             return

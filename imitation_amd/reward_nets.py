@@ -617,6 +617,10 @@ class ShapedRewardNet(ForwardWrapper):
         if pn is not None:
             B = (pn.running_mean.data_ptr(), pn.running_var.data_ptr())
             A = (ws["snapA"].data_ptr(), ws["snapA"].data_ptr() + 4 * pot.dims[0]) if upd_p else B
+        # the slabs are [base | potential] wide: the store must hold exactly these two stacks (also when the caller
+        # reduces into the store's gradient itself, `adam=None`)
+        if self._store.grad.numel() != base.n_params + pot.n_params or self._store.flat.data_ptr() != base.flat.data_ptr():
+            raise RuntimeError("the fused AIRL update needs a parameter store of exactly the reward and potential stacks")
         if adam is not None and (adam.flat.data_ptr() != base.flat.data_ptr()
                                  or adam.flat.numel() != base.n_params + pot.n_params):
             raise RuntimeError("the fused AIRL update needs the optimiser over the net's flat parameter buffer")

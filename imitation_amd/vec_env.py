@@ -143,6 +143,49 @@ class ArrayVecEnv(VecEnv):
         return obs, rews, dones, infos
 
 
+class GymStyleVecEnv(VecEnv):
+    """A plain SB3-protocol VecEnv around an array environment: ONLY `reset / step_async / step_wait`, the latter with
+    one info DICT per env -- `terminal_observation` and `TimeLimit.truncated` on episode ends (App. A.9) plus the
+    `episode = {"r", "l", "t"}` entry [SB3 Monitor] adds there (`util/util.py:150`, read by `data/rollout.py:536-547`
+    and SB3's `ep_info_buffer`). This is what a `DummyVecEnv` / `SubprocVecEnv` of Monitor-wrapped gym environments
+    hands the trainer; it is deliberately NOT an `ArrayVecEnv`, so the wrappers and the rollout collector take their
+    generic per-env branch (`wrappers.step_arrays`, `rewards/reward_wrapper.py:98-109`)."""
+
+    def __init__(self, env: "ArrayVecEnv"):
+        super().__init__(env.num_envs, env.observation_space, env.action_space)
+        self._env = env
+        self._ret = np.zeros(env.num_envs, dtype=np.float64)
+        self._len = np.zeros(env.num_envs, dtype=np.int64)
+        self._t = 0
+
+    def reset(self):
+        self._ret[:] = 0.0
+        self._len[:] = 0
+        return self._env.reset()
+
+    def seed(self, seed=None):
+        return self._env.seed(seed)
+
+    def step_async(self, actions):
+        self._env.step_async(actions)
+
+    def step_wait(self):
+        obs, rews, dones, nxt, trunc = self._env.step_wait_arrays()
+        self._ret += rews
+        self._len += 1
+        self._t += 1
+        infos: List[Dict[str, Any]] = [{} for _ in range(self.num_envs)]
+        for i in np.flatnonzero(dones):
+            infos[i]["terminal_observation"] = nxt[i].copy()
+            infos[i]["TimeLimit.truncated"] = bool(trunc[i])
+            infos[i]["episode"] = {"r": float(self._ret[i]), "l": int(self._len[i]), "t": float(self._t)}
+            self._ret[i], self._len[i] = 0.0, 0
+        return obs, rews, dones, infos
+
+    def close(self):
+        self._env.close()
+
+
 class SyntheticVecEnv(ArrayVecEnv):
     """HalfCheetah-shaped synthetic control environment.
 

@@ -45,14 +45,6 @@ def infos_from_arrays(dones, nxt, trunc) -> List[Dict[str, Any]]:
     return infos
 
 
-def _infos_have_content(infos) -> bool:
-    for info in infos:
-        for k in info:
-            if k not in ("terminal_observation", "TimeLimit.truncated"):
-                return True
-    return False
-
-
 class BufferingWrapper(VecEnvWrapper):
     """Saves transitions of the underlying VecEnv; `pop_*` return them in the reference's order."""
 
@@ -102,7 +94,9 @@ class BufferingWrapper(VecEnvWrapper):
         """State update of one `step_wait` given the step's arrays (`wrappers.py:69-91`)."""
         dones = np.asarray(dones, dtype=bool)
         self._steps.append((self._last_obs, np.array(acts, copy=True), next_fixed, np.asarray(rews), dones))
-        self._infos.append(list(infos) if infos is not None and _infos_have_content(infos) else None)
+        # the env's own dicts, verbatim, whenever it produced any (`data/wrappers.py:69-91` keeps every step's info);
+        # array envs (infos None) never pay for dict lists
+        self._infos.append(list(infos) if infos is not None else None)
         self._last_obs = new_obs
         self.n_transitions += self.num_envs
         self._timesteps += 1
@@ -115,8 +109,8 @@ class BufferingWrapper(VecEnvWrapper):
         return obs, acts, nxt, rews, dones
 
     def _infos_in_order(self, order: np.ndarray, n: int) -> Optional[np.ndarray]:
-        """`infos` of the recorded steps in emission order (time-major offsets `t*n + env`), `{}` where a step had
-        none; None when no step of the round carried any (`data/wrappers.py:69-91` keeps every step's dict)."""
+        """`infos` of the recorded steps in emission order (time-major offsets `t*n + env`): the env's own dicts
+        (`data/wrappers.py:69-91` keeps every step's dict verbatim); None for array envs, which produce none."""
         if not any(i is not None for i in self._infos):
             return None
         return np.array([self._infos[o // n][o % n] if self._infos[o // n] is not None else {} for o in order],

@@ -92,8 +92,10 @@ int ia_adam_step(float* params, const float* grads, float* exp_avg, float* exp_a
 
 /* The same step with its step-dependent scalars kept on the DEVICE, for launch sequences that are captured once and
  * replayed (hipGraph replay of a whole PPO update): `ia_adam_step_scalars` increments the int64 step count *step and
- * writes scalars = {lr / (1 - b1^t), sqrt(1 - b2^t)} (double arithmetic); `ia_adam_step_dev` reads them. */
-int ia_adam_step_scalars(int64_t* step, double lr, double beta1, double beta2, float* scalars, void* stream);
+ * writes scalars = {lr / (1 - b1^t), sqrt(1 - b2^t)} (double arithmetic; lr_dev, a device double, replaces `lr` when not
+ * NULL so that a learning-rate schedule needs no re-capture); `ia_adam_step_dev` reads them. */
+int ia_adam_step_scalars(int64_t* step, double lr, const double* lr_dev, double beta1, double beta2, float* scalars,
+                         void* stream);
 int ia_adam_step_dev(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float beta1,
                      float beta2, float eps, float weight_decay, const float* scalars, void* stream);
 

@@ -91,6 +91,46 @@ CASES: Dict[str, Dict[str, Any]] = {
                        n_steps=8, ppo_batch=16, n_epochs=2, ent_coef=0.01, disc_hid=None,
                        demo_batch=16, demo_minibatch=8, n_disc=2, capacity=None, n_demo=64, rounds=2,
                        norm_policy=False, norm_disc=False, obs_dtype="uint8", ppo_kwargs=dict(learning_rate=1e-4)),
+    # tuned_hps/gail_seals_half_cheetah_best_hp_eval.json:2-44 VERBATIM at reduced width (16 envs instead of the scripts'
+    # env count; every ratio kept: rl.batch_size / n_envs = 4 steps, replay capacity = 1/8 of a round, demo batches far
+    # larger than the ring, 8 updates per round): PPO clip 0.1, ent_coef 3.99e-6, gae_lambda 0.95, gamma 0.95, lr 2.625e-4,
+    # max_grad_norm 0.8, 5 epochs, vf_coef 0.1148; BasicRewardNet at its DEFAULT 32 x 32 with input RunningNorm, wrapped in
+    # NormalizedRewardNet (`reward.normalize_output_layer`: GAIL's processed reward bypasses it, gail.py:65-73).
+    "gail_tuned_hps": dict(algo="gail", n_envs=16, horizon=6, obs_dim=17, act_dim=6, n_discrete=None,
+                           n_steps=4, ppo_batch=8, n_epochs=5, ent_coef=3.992371122209408e-6, disc_hid=(32, 32),
+                           demo_batch=128, demo_minibatch=None, n_disc=8, capacity=8, n_demo=500, rounds=4,
+                           norm_policy=True, norm_disc=True, obs_dtype="float32", normalize_output=True,
+                           ppo_kwargs=dict(clip_range=0.1, gae_lambda=0.95, gamma=0.95,
+                                           learning_rate=0.00026250519057717037, max_grad_norm=0.8,
+                                           vf_coef=0.11483689492120866)),
+    # tuned_hps/airl_seals_ant_best_hp_eval.json:2-44 VERBATIM at reduced width (16 envs x 8 steps per round, Ant-shaped
+    # obs 27 / act 8): PPO minibatch 16 (as written), clip 0.3, ent_coef 3.28e-6, gae_lambda 0.8, gamma 0.995, lr 3.25e-5,
+    # max_grad_norm 0.9, 10 epochs, vf_coef 0.435; BasicShapedRewardNet defaults (reward 32, potential 32 x 32, no next
+    # state in the reward input) + input RunningNorm + NormalizedRewardNet; capacity = one round, 16 updates per round.
+    "airl_tuned_hps": dict(algo="airl", n_envs=16, horizon=12, obs_dim=27, act_dim=8, n_discrete=None,
+                           n_steps=8, ppo_batch=16, n_epochs=10, ent_coef=3.27750078482474e-6, disc_hid=(32,),
+                           demo_batch=64, demo_minibatch=None, n_disc=16, capacity=128, n_demo=400, rounds=2,
+                           norm_policy=True, norm_disc=True, obs_dtype="float32", normalize_output=True,
+                           use_next_state=False,
+                           ppo_kwargs=dict(clip_range=0.3, gae_lambda=0.8, gamma=0.995,
+                                           learning_rate=3.249429831179079e-5, max_grad_norm=0.9,
+                                           vf_coef=0.4351450387648799)),
+    # BASELINE config 1's plumbing ("CPU SubprocVecEnv"): the environment speaks ONLY the gym / SB3 VecEnv protocol --
+    # per-env info dicts with `terminal_observation`, `TimeLimit.truncated` and Monitor's `episode` entries
+    # (`vec_env.GymStyleVecEnv`) -- so the wrappers take their generic per-env branch (`rewards/reward_wrapper.py:98-109`,
+    # `data/wrappers.py:69-91`); CartPole-shaped, Discrete actions, SB3 MlpPolicy 64 x 64, variable-length bookkeeping.
+    "gail_generic_vecenv": dict(algo="gail", n_envs=8, horizon=9, obs_dim=4, act_dim=2, n_discrete=2,
+                                n_steps=16, ppo_batch=32, n_epochs=3, ent_coef=0.0, disc_hid=(32, 32),
+                                demo_batch=64, demo_minibatch=None, n_disc=3, capacity=96, n_demo=300, rounds=3,
+                                norm_policy=False, norm_disc=True, obs_dtype="float32", policy="mlp64",
+                                generic_vecenv=True, reward_scale=1.0, ppo_kwargs=dict(gamma=0.95, learning_rate=4e-4)),
+    # BasicRewardNet(use_next_state=True, use_done=True) (`rewards/reward_nets.py:441-457`): 17 + 6 + 17 + 1 = 41 inputs
+    # through the default 32 x 32 stack; episodes end inside the rollout so the done column is not constant.
+    "gail_next_done": dict(algo="gail", n_envs=8, horizon=5, obs_dim=17, act_dim=6, n_discrete=None,
+                           n_steps=16, ppo_batch=32, n_epochs=2, ent_coef=0.01, disc_hid=(32, 32),
+                           demo_batch=96, demo_minibatch=None, n_disc=3, capacity=None, n_demo=400, rounds=3,
+                           norm_policy=True, norm_disc=True, obs_dtype="float32",
+                           disc_kwargs=dict(use_next_state=True, use_done=True)),
     # AIRL, shaped reward net, NormalizedRewardNet output norm (script default), use_next_state.
     "airl_box": dict(algo="airl", n_envs=8, horizon=10, obs_dim=11, act_dim=3, n_discrete=None,
                      n_steps=16, ppo_batch=32, n_epochs=2, ent_coef=0.0, disc_hid=(32,),
@@ -192,7 +232,10 @@ def build_trainer(impl: str, cfg, log_dir: str, device: str = "cpu", module_net:
     else:
         venv = SyntheticVecEnv(num_envs=cfg["n_envs"], obs_dim=cfg["obs_dim"], act_dim=cfg["act_dim"],
                                horizon=cfg["horizon"], seed=0, obs_dtype=np.dtype(cfg["obs_dtype"]),
-                               n_discrete=cfg["n_discrete"])
+                               n_discrete=cfg["n_discrete"], reward_scale=cfg.get("reward_scale", 0.0))
+        if cfg.get("generic_vecenv"):
+            from imitation_amd.vec_env import GymStyleVecEnv
+            venv = GymStyleVecEnv(venv)
     pk = {}
     if cfg["norm_policy"]:
         pk = dict(features_extractor_class=ns.NormalizeFeaturesExtractor,
@@ -212,7 +255,10 @@ def build_trainer(impl: str, cfg, log_dir: str, device: str = "cpu", module_net:
         net = ns.CnnRewardNet(venv.observation_space, venv.action_space, hwc_format=False)
         cls = ns.GAIL if cfg["algo"] == "gail" else ns.AIRL
     elif cfg["algo"] == "gail":
-        net = ns.BasicRewardNet(venv.observation_space, venv.action_space, hid_sizes=cfg["disc_hid"], **kw)
+        net = ns.BasicRewardNet(venv.observation_space, venv.action_space, hid_sizes=cfg["disc_hid"], **kw,
+                                **cfg.get("disc_kwargs", {}))
+        if cfg.get("normalize_output"):
+            net = ns.NormalizedRewardNet(net, disc_norm)
         cls = ns.GAIL
     else:
         net = ns.BasicShapedRewardNet(venv.observation_space, venv.action_space,
@@ -253,6 +299,13 @@ def snapshot(trainer) -> Dict[str, np.ndarray]:
     for k in ("rewards", "values", "log_probs", "advantages", "returns", "actions", "observations"):
         out[f"rollout/{k}"] = _np(getattr(rb, k)).reshape(-1)
     out["counters"] = np.asarray([trainer._global_step, trainer._disc_step, trainer.gen_algo.num_timesteps])
+    eps = list(getattr(trainer.gen_algo, "ep_info_buffer", None) or [])
+    if eps:   # gym-style envs only: Monitor's episode entries as SB3 collects them ([SB3 collect_rollouts] App. A.4)
+        out["ep_info"] = np.asarray([[e["r"], e["l"]] for e in eps], dtype=np.float64)
+        infos = arrays["infos"] if "infos" in arrays else getattr(inner, "_infos", None)
+        out["replay/infos_episode_lens"] = np.asarray([i["episode"]["l"] if (i and "episode" in i) else 0
+                                                       for i in infos], dtype=np.int64)
+        out["replay/infos_has_terminal_obs"] = np.asarray([bool(i) and "terminal_observation" in i for i in infos])
     return out
 
 

@@ -62,7 +62,8 @@ def _compare(got, gold, cfg, skip=(), adam_outliers=None):
 
 @pytest.mark.parametrize("case", ["gail_box", "gail_f64", "gail_discrete", "airl_box", "gail_horizon", "gail_tuned",
                                   "gail_fused", "gail_cartpole", "gail_towers", "gail_discrete_towers",
-                                  "airl_towers", "gail_image", "airl_image"])
+                                  "airl_towers", "gail_image", "airl_image", "gail_tuned_hps", "airl_tuned_hps",
+                                  "gail_next_done", "gail_generic_vecenv"])
 def test_hip_trainer_matches_reference_golden(case, tmp_path):
     cfg = harness.CASES[case]
     gold = dict(np.load(os.path.join(GOLDEN, f"{case}.npz")))
