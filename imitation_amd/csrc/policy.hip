@@ -426,6 +426,34 @@ __device__ __forceinline__ float block_sum(float v, float* red /*>=17 floats*/) 
 }
 __device__ __forceinline__ float block_sum_1024(float v, float* red) { return block_sum<1024>(v, red); }
 
+// Wave sum on the DPP path (cross-lane operands of the VALU itself: ~10 clocks a step) instead of six ds_bpermute round
+// trips through the LDS pipe: quad swaps, row rotations, then row_bcast:15 / row_bcast:31 (GFX9). Lanes 48..63 end
+// with the total. Fixed order: deterministic, identical in every workgroup.
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ __forceinline__ float dpp_take(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, false));
+}
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+  v += dpp_take<0xb1>(v);          // quad_perm:[1,0,3,2]
+  v += dpp_take<0x4e>(v);          // quad_perm:[2,3,0,1]
+  v += dpp_take<0x124>(v);         // row_ror:4
+  v += dpp_take<0x128>(v);         // row_ror:8   -> every lane holds its row's sum
+  v += dpp_take<0x142, 0xa>(v);    // row_bcast:15 into rows 1 and 3
+  v += dpp_take<0x143, 0xc>(v);    // row_bcast:31 into rows 2 and 3 -> row 3 holds the wave's sum
+  return v;
+}
+// Sum over a 512-thread workgroup with ONE barrier: the wave sums go to the half of `red` (2 x 8 floats) selected by
+// `parity`, which the caller alternates between consecutive calls (the previous call's readers may still be reading).
+__device__ __forceinline__ float block_sum512_dpp(float v, float* red, int parity) {
+  v = wave_sum_dpp(v);
+  if ((threadIdx.x & 63) == 63) red[parity * 8 + (threadIdx.x >> 6)] = v;
+  __syncthreads();
+  float t = 0.f;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) t += red[parity * 8 + k];
+  return t;
+}
+
 // Minibatch statistics (SB3 PPO.train: advantage mean / unbiased std; train-mode RunningNorm
 // update of the feature extractor with the minibatch observations, util/networks.py:111-134).
 // Element-parallel gathers staged through LDS; all reductions in fixed order.
@@ -984,7 +1012,8 @@ struct UpdStage {
   static constexpr int src = ret + ROWS;                        // [ROWS] row offset into the rollout tile (as float bits)
   static constexpr int nxt = src + ROWS;                        // [ROWS] row offsets of the minibatch being prefetched
   static constexpr int ring = nxt + ROWS;                       // [UPD_RS_] copy of the minibatch's statistics-ring slot
-  static constexpr int act = ring + 2 * MAXD + 8;               // [ROWS][aw] the rows' actions, row-major, aw <= MAXA
+                                                                // (+ 56 floats: its 8-float tail arrives as one 64-lane LDS-direct load)
+  static constexpr int act = ring + 2 * MAXD + 64;              // [ROWS][aw] the rows' actions, row-major, aw <= MAXA
   __host__ __device__ static constexpr int total(int aw) { return act + ROWS * aw; }
 };
 // One minibatch of block `vblk` (64 rows), one launch per minibatch (`ia_ppo_minibatch*`, `ia_ppo_epoch`:
@@ -1695,6 +1724,9 @@ __device__ __forceinline__ void wave_sync_lds() {
 }
 
 // (`nv` = 1/sqrt(running_var + eps) per column, as the statistics block publishes it)
+// KS1 = k-steps (of 4 input columns) the first layer's fragments are sized for: 16 covers MAXD = 64 columns, 8 covers
+// observation widths <= 32 -- every reference environment of the path -- with 16 fragment registers less across the chain.
+template <int KS1>
 __device__ __forceinline__ void mfma32_minibatch_chain(
     const ia_policy_desc& d, const float* __restrict__ nm, const float* __restrict__ nv, const float adv_mean,
     const float adv_std, const MbRows rows, const int vblk, const int normalize_adv, const float clip,
@@ -1782,9 +1814,9 @@ __device__ __forceinline__ void mfma32_minibatch_chain(
   // addresses, grouped behind at most four wave-uniform branches -- then the masks: a guarded read (or a
   // select right behind its read) costs a branch and a full `lgkmcnt(0)` wait each, which made these ~70
   // reads a chain of ~50 serial LDS round trips.
-  float bW1[16][2], bW2[8][2], bW2o[8][2], bHead[8], bDa2[4][2], b1v[2], b2v[2], cwv[2];
+  float bW1[KS1][2], bW2[8][2], bW2o[8][2], bHead[8], bDa2[4][2], b1v[2], b2v[2], cwv[2];
 #pragma unroll
-  for (int g = 0; g < 4; ++g) {
+  for (int g = 0; g < KS1 / 4; ++g) {
     if (4 * g < S1) {
 #pragma unroll
       for (int s = 4 * g; s < 4 * g + 4; ++s)
@@ -1813,7 +1845,7 @@ __device__ __forceinline__ void mfma32_minibatch_chain(
   float my_sd = sP[o.log_std + min(lane, A - 1)];
   __builtin_amdgcn_sched_barrier(0);   // every read above is issued before the first value is touched
 #pragma unroll
-  for (int s = 0; s < 16; ++s)
+  for (int s = 0; s < KS1; ++s)
 #pragma unroll
     for (int c = 0; c < 2; ++c) bW1[s][c] = (4 * s + lk < D) ? bW1[s][c] : 0.f;
   {
@@ -1855,7 +1887,7 @@ __device__ __forceinline__ void mfma32_minibatch_chain(
     // A fragments in batches of four k-steps (one wave-uniform branch and one LDS wait per batch instead of
     // one per k-step); columns >= D of the x tile are zero
 #pragma unroll
-    for (int g = 0; g < 4; ++g)
+    for (int g = 0; g < KS1 / 4; ++g)
       if (4 * g < S1) {
         float xa[4];
 #pragma unroll
@@ -2505,7 +2537,7 @@ __device__ __forceinline__ bool spin_until(unsigned* p, unsigned target, unsigne
 
 // TIMING = false (production): the phase-clock accumulators (24 VGPRs of `tacc` alone) and every stamp are
 // compiled out -- the measurement build is a separate instantiation picked only while ia_ppo_debug_timing is on.
-template <int NPT, bool TIMING>
+template <int NPT, bool TIMING, int KS1>
 __global__ __launch_bounds__(512) void ppo_update_persistent_kernel(
     ia_policy_desc d, float* __restrict__ P, float* __restrict__ Pt, float* __restrict__ m, float* __restrict__ v,
     float* __restrict__ nm, float* __restrict__ nv, int32_t* __restrict__ ncount, int update_norm,
@@ -2842,7 +2874,6 @@ __global__ __launch_bounds__(512) void ppo_update_persistent_kernel(
   // copied into LDS behind barrier s (whose acquire fence covers it) and step s+1 starts without a
   // wait, a fence or a dependent global load. `have_ring`: the LDS copy holds this step's slot.
   bool have_ring = false;
-  float pf_r[3] = {0.f, 0.f, 0.f};
   if (tstamp && tid == 0) tprev = wall_clock64();
   for (int s = 0; s < n_steps; ++s) {
     const MbRows r = rows_of(s);
@@ -2858,7 +2889,11 @@ __global__ __launch_bounds__(512) void ppo_update_persistent_kernel(
       // (rare: the statistics block had not published this slot when the previous barrier was passed) copy it into
       // the LDS slot too, so that the chain below ALWAYS reads its statistics through LDS addresses -- a pointer that
       // may be global or LDS compiles to flat loads, 16 of them per lane in the staging phase
-      if (tid < 2 * MAXD + 8) stg[UpdStage::ring + tid] = *reinterpret_cast<const volatile float*>(slot + tid);
+      {
+        int sz;   // opaque zero: this rarely taken copy must not leave a hoisted (and spilled) address behind
+        asm volatile("s_mov_b32 %0, 0" : "=s"(sz));
+        if (tid < 2 * MAXD + 8) stg[UpdStage::ring + tid] = *reinterpret_cast<const volatile float*>(slot + tid + sz);
+      }
       __syncthreads();
     }
     slot = stg + UpdStage::ring;
@@ -2872,7 +2907,7 @@ __global__ __launch_bounds__(512) void ppo_update_persistent_kernel(
     float* stat_base = w.statpart + (s % UPD_SD) * nblk * 8;
     int oz;
     asm volatile("s_mov_b32 %0, 0" : "=s"(oz));
-    mfma32_minibatch_chain(d, slot, slot + MAXD, adv_mean, adv_std, r, vb, normalize_adv, clip, ent_coef, vf_coef,
+    mfma32_minibatch_chain<KS1>(d, slot, slot + MAXD, adv_mean, adv_std, r, vb, normalize_adv, clip, ent_coef, vf_coef,
                            slab_base + (long long)vb * w.P4, stat_base + vb * 8, lds, sP, stg, oz,
                            tstamp ? tstamp + 16 : nullptr);
     // (the minibatch ends with a block barrier: every slab store of this block has been issued)
@@ -2902,13 +2937,13 @@ __global__ __launch_bounds__(512) void ppo_update_persistent_kernel(
     __syncthreads();
     if (!s_ok) return;
     have_ring = (s + 1 < n_steps) && (s_pub >= s + 2);
-    if (have_ring) {  // issue now, park with the rows after the update
+    if (have_ring && wave < 3) {
+      // the next step's statistics slot: global -> LDS directly (waves 0 / 1: mean / 1 / std columns, wave 2: the
+      // advantage statistics -- 64 lanes wide, the staging slot has room), landed by prefetch_park's wait. Held in
+      // registers across the update instead, the first value was spilled right here behind a `vmcnt` wait.
       const float* nslot = w.ring + ((s + 1) % UPD_RING) * UPD_RS;
-      if (tid < MAXD) {
-        pf_r[0] = nslot[tid];
-        pf_r[1] = nslot[MAXD + tid];
-      }
-      if (tid < 8) pf_r[2] = nslot[2 * MAXD + tid];
+      __builtin_amdgcn_global_load_lds((glb_void_p)(nslot + wave * MAXD + lane),
+                                       (lds_void_p)(stg + UpdStage::ring + wave * MAXD), 4, 0, 0);
     }
     UPD_TS(2);
 
@@ -2924,7 +2959,9 @@ __global__ __launch_bounds__(512) void ppo_update_persistent_kernel(
     auto sum_vectors = [&](const float* __restrict__ base, int nsrc) {
 #pragma unroll
       for (int k = 0; k < NPT; ++k) g[k] = 0.f;
-      constexpr int KH = 4;  // 4 parameters x 8 vectors = 32 loads in flight per thread
+      constexpr int KH = 4;  // 4 parameters x 8 vectors = 32 loads in flight per thread (measured: 8 x 8 = 64 in flight
+                             // is SLOWER, 3.9 against 2.5 us for 16 slabs -- the phase runs at the CU's L1 fill rate,
+                             // 224 KB at 64 B / clock = 1.5 us, and deeper queues only add contention)
       int b = 0;
       for (; b + 8 <= nsrc; b += 8) {
 #pragma unroll
@@ -2935,10 +2972,12 @@ __global__ __launch_bounds__(512) void ppo_update_persistent_kernel(
             if (h * KH + k >= NPT) continue;  // (resolved at compile time)
             // clamped index: every load is unconditional (a guarded load costs a branch and a full
             // wait each, which serialises the whole batch); lanes past the end are discarded below
-            const int i = min(tid + (h * KH + k) * 512, o.total - 1);
+            // (unsigned 32-bit element offsets from the wave-uniform base: one address register per load, not two)
+            const unsigned i = (unsigned)min(tid + (h * KH + k) * 512, o.total - 1);
 #pragma unroll
-            for (int u = 0; u < 8; ++u) t[k][u] = base[(long long)(b + u) * w.P4 + i];
+            for (int u = 0; u < 8; ++u) t[k][u] = base[(unsigned)(b + u) * (unsigned)w.P4 + i];
           }
+          __builtin_amdgcn_sched_barrier(0);   // the whole batch is requested before its first value is consumed
 #pragma unroll
           for (int k = 0; k < KH; ++k) {
             if (h * KH + k >= NPT) continue;
@@ -2949,7 +2988,7 @@ __global__ __launch_bounds__(512) void ppo_update_persistent_kernel(
       }
       for (; b < nsrc; ++b) {
 #pragma unroll
-        for (int k = 0; k < NPT; ++k) g[k] += base[(long long)b * w.P4 + min(tid + k * 512, o.total - 1)];
+        for (int k = 0; k < NPT; ++k) g[k] += base[(unsigned)b * (unsigned)w.P4 + (unsigned)min(tid + k * 512, o.total - 1)];
       }
     };
     if (nblk <= 2 * UPD_GROUP) {
@@ -2990,7 +3029,7 @@ __global__ __launch_bounds__(512) void ppo_update_persistent_kernel(
     UPD_TS(4);
     int rz;   // opaque zero: the reduction scratch address is re-formed here instead of living in a (spilled) register
     asm volatile("s_mov_b32 %0, 0" : "=s"(rz));
-    const float total_sq = block_sum<512>(sq, lds + L::misc + ROWS * L::MS + rz);
+    const float total_sq = block_sum512_dpp(sq, lds + L::misc + ROWS * L::MS + rz, s & 1);
     UPD_TS(5);
     const float total_norm = sqrtf(total_sq);
     const float coef = fminf(max_norm / (total_norm + 1e-6f), 1.0f);  // torch clip_grad_norm_
@@ -3004,31 +3043,43 @@ __global__ __launch_bounds__(512) void ppo_update_persistent_kernel(
         write_loss_stats(s, total_norm, coef);
       }
     }
+    {
+      // torch.optim.Adam's step on the thread's NPT parameters. All LDS reads (parameter, index into the transposed
+      // copy) first, then the arithmetic, then all LDS writes: written element by element, every iteration's reads had to
+      // wait for the previous iteration's stores (the compiler cannot tell sPt[dstT[i]] from sP[i']) -- eight serial
+      // LDS round trips + eight undivided IEEE division / square-root chains, 1.6 us per step.
+      float pv[NPT];
+      int dt[NPT];
 #pragma unroll
-    for (int k = 0; k < NPT; ++k) {
-      const int i = tid + k * 512;
-      if (i < o.total) {
+      for (int k = 0; k < NPT; ++k) {
+        const int ic = min(tid + k * 512, o.total - 1);
+        pv[k] = sP[ic];
+        dt[k] = dstT[ic];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int k = 0; k < NPT; ++k) {
         const float gi = g[k] * coef;
         float mi = rm[k];
         mi = mi + (gi - mi) * (1.f - beta1);
         const float vi = rv[k] * beta2 + (1.f - beta2) * gi * gi;
         const float denom = sqrtf(vi) / bc2_sqrt + eps;
-        const float pn = sP[i] - step_size * (mi / denom);
-        rm[k] = mi;
+        pv[k] = pv[k] - step_size * (mi / denom);
+        rm[k] = mi;     // (threads past the parameter count carry zeros: g = 0 keeps m = v = 0; nothing of theirs is stored)
         rv[k] = vi;
-        sP[i] = pn;
-        sPt[dstT[i]] = pn;
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int k = 0; k < NPT; ++k) {
+        const int i = tid + k * 512;
+        if (i < o.total) {
+          sP[i] = pv[k];
+          sPt[dt[k]] = pv[k];
+        }
       }
     }
     UPD_TS(6);
-    if (s + 1 < n_steps) prefetch_park();
-    if (have_ring) {
-      if (tid < MAXD) {
-        stg[UpdStage::ring + tid] = pf_r[0];
-        stg[UpdStage::ring + MAXD + tid] = pf_r[1];
-      }
-      if (tid < 8) stg[UpdStage::ring + 2 * MAXD + tid] = pf_r[2];
-    }
+    if (s + 1 < n_steps) prefetch_park();   // (its vmcnt(0) also covers the statistics slot's LDS-direct loads)
     __syncthreads();
     UPD_TS(3);
   }
@@ -3521,13 +3572,22 @@ int ia_ppo_update(const ia_policy_desc* d, float* params, float* params_t, float
   const size_t bytes = grad_bytes > prep_bytes ? grad_bytes : prep_bytes;
   const bool wide = P > UPD_NPT * 512;
   const bool timing = g_tstamp != nullptr;
-  auto kernel = wide ? (timing ? ppo_update_persistent_kernel<UPD_NPT_WIDE, true> : ppo_update_persistent_kernel<UPD_NPT_WIDE, false>)
-                     : (timing ? ppo_update_persistent_kernel<UPD_NPT, true> : ppo_update_persistent_kernel<UPD_NPT, false>);
-  static size_t attr_bytes[4] = {0, 0, 0, 0};
-  if (bytes > attr_bytes[wide * 2 + timing]) {
+  // instantiations: {8, 9} parameters per thread x {production, phase clocks} x first-layer fragments for <= 32 / <= 64
+  // observation columns (the narrow form keeps 16 registers less across the chain)
+  const bool ks16 = d->obs_dim > 32;
+  using KernelT = decltype(&ppo_update_persistent_kernel<UPD_NPT, false, 8>);
+  static const KernelT kernels[8] = {
+      ppo_update_persistent_kernel<UPD_NPT, false, 8>,      ppo_update_persistent_kernel<UPD_NPT, false, 16>,
+      ppo_update_persistent_kernel<UPD_NPT, true, 8>,       ppo_update_persistent_kernel<UPD_NPT, true, 16>,
+      ppo_update_persistent_kernel<UPD_NPT_WIDE, false, 8>, ppo_update_persistent_kernel<UPD_NPT_WIDE, false, 16>,
+      ppo_update_persistent_kernel<UPD_NPT_WIDE, true, 8>,  ppo_update_persistent_kernel<UPD_NPT_WIDE, true, 16>};
+  const int vi_k = wide * 4 + timing * 2 + ks16;
+  const KernelT kernel = kernels[vi_k];
+  static size_t attr_bytes[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (bytes > attr_bytes[vi_k]) {
     const int rc = set_lds(kernel, bytes);
     if (rc) return rc;
-    attr_bytes[wide * 2 + timing] = bytes;
+    attr_bytes[vi_k] = bytes;
   }
   hipStream_t st = (hipStream_t)stream;
   const int steps_total = n_epochs * n_mb;
@@ -3578,9 +3638,9 @@ int ia_ppo_update(const ia_policy_desc* d, float* params, float* params_t, float
       // (and a cooperative launch costs +15-19 us per launch, MI355X_MICROARCH.md "coop-launch"), so the same
       // test is made here: workgroups per CU by the occupancy query (LDS-bound: one) times the CU count.
       // Not enough room -> IA_ERR_UNSUPPORTED, the caller runs ia_ppo_epoch (two launches per minibatch).
-      static int dev_cus = 0, per_cu[4] = {-1, -1, -1, -1};
-      static size_t per_cu_bytes[4] = {0, 0, 0, 0};
-      const int vi = wide * 2 + timing;
+      static int dev_cus = 0, per_cu[8] = {-1, -1, -1, -1, -1, -1, -1, -1};
+      static size_t per_cu_bytes[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      const int vi = vi_k;
       if (dev_cus == 0) {
         int dev = 0;
         if (hipGetDevice(&dev) != hipSuccess ||

@@ -11,23 +11,7 @@ import bench  # noqa: E402
 from imitation_amd import _lib as L  # noqa: E402
 
 
-class NullDP:
-    rank = 0
-
-    def __init__(self, world):
-        self.world = world
-
-    def allreduce_mean_(self, flat):
-        return flat
-
-    def broadcast_(self, tensors, src=0):
-        pass
-
-    def all_gather_flat(self, local):
-        return th.cat([local] * self.world)
-
-    def shared_seed(self):
-        return 1234
+from tools.dp_overhead import NullDP  # noqa: E402  (stand-in DataParallel: identity all-reduce, repeating all-gather)
 
 
 world = int(sys.argv[1]) if len(sys.argv) > 1 else 8
