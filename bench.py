@@ -197,13 +197,16 @@ def gemm_roofline(trainer, cfg, rounds):
     lib = L.load()
     lib.ia_prof_enable(1)
     algo = trainer.gen_algo
-    ppo_ms = []
+    ppo_ms, disc_in_rounds = [], []
     for _ in range(rounds):  # the persistent PPO update launch bracketed by events on its stream
         algo.update_events = (th.cuda.Event(enable_timing=True), th.cuda.Event(enable_timing=True))
         trainer.train(cfg["n_envs"] * cfg["n_steps"])
         th.cuda.synchronize()
-        if getattr(algo, "_upd_ws", None) is not None:
+        if getattr(algo, "_upd_ws", None) is not None or getattr(algo, "_dpg", None):
             ppo_ms.append(algo.update_events[0].elapsed_time(algo.update_events[1]))
+        t = getattr(trainer, "_disc_timing", None)   # (start, end, ran behind the PPO update?) of the round's updates, in situ
+        if t is not None and t[0] is not None:
+            disc_in_rounds.append((1e3 * t[0].elapsed_time(t[1]) / trainer.n_disc_updates_per_round, bool(t[2])))
     algo.update_events = None
     ms, fl = (C.c_double * 12)(), (C.c_double * 12)()
     cnt = (C.c_longlong * 12)()
@@ -227,6 +230,14 @@ def gemm_roofline(trainer, cfg, rounds):
                 "all_gemm_tflops": all_fl / all_ms if all_ms else None, "kernels": per[:6],
                 "note": "measured inside training rounds, i.e. BESIDE the persistent PPO kernel and the act kernels"}
     disc = disc_update_timing(trainer, cfg)
+    if disc_in_rounds:
+        # the same updates INSIDE training rounds: beside the persistent PPO kernel and the act kernels (or behind the PPO
+        # update, beside the next rollout's act kernels), events on the discriminator stream around the round's updates
+        us = sorted(u for u, _ in disc_in_rounds)[len(disc_in_rounds) // 2]
+        disc["us_in_rounds"] = us
+        disc["in_rounds_schedule"] = "behind the PPO update" if disc_in_rounds[-1][1] else "beside the PPO update"
+        disc["achieved_in_rounds"] = disc["flop"] / (us * 1e-6) / 1e12
+        disc["frac_in_rounds"] = disc["achieved_in_rounds"] / PEAK_F32_MFMA_TFLOPS
     ppo = None
     if ppo_ms:
         # forward + backward of both 32x32 towers ~ 3 x 2 x (weights touched) flops per row and step
@@ -237,13 +248,15 @@ def gemm_roofline(trainer, cfg, rounds):
         rows = world * min(algo.batch_size, cfg["n_envs"] * cfg["n_steps"])
         fl_ppo = per_row * rows * steps
         avg = sum(ppo_ms) / len(ppo_ms)
-        disc_ms_round = disc["us"] * 1e-3 * trainer.n_disc_updates_per_round
+        disc_ms_round = disc.get("us_in_rounds", disc["us"]) * 1e-3 * trainer.n_disc_updates_per_round
         ppo = {"kernel": "ppo_update_persistent_kernel (whole PPO.train, one launch)", "bound": "latency",
                "avg_launch_us": 1e3 * avg, "optimizer_steps_per_launch": steps, "us_per_step": 1e3 * avg / steps,
                "achieved": fl_ppo / (avg * 1e-3) / 1e12, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                "frac": fl_ppo / (avg * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS,
                "traffic": _pmc_traffic().get("ppo_update_persistent_kernel"),
-               "share_of_gpu_time": avg / (avg + disc_ms_round),
+               # of the two kernel families that own the round's GPU time (in-situ discriminator time); the share of ALL
+               # GPU time, act / relabel / GAE / copies included, is in the rocprofv3 summary under profiles/
+               "share_of_ppo_plus_disc_gpu_time": avg / (avg + disc_ms_round),
                "algorithmic_bytes_per_launch": steps * rows * (D + A + 4) * 4.0,
                "note": "largest kernel by GPU time: a chain of dependent 1024-row optimiser steps on nblk+3 workgroups "
                        "(the reference's minibatch semantics), bound by per-step latency (grid barrier, slab reduce, "
@@ -461,8 +474,8 @@ def run_variant(name, rounds=None, warm=None):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200)   # ~1 s of timed rounds at config P
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--prof-rounds", type=int, default=2)
     ap.add_argument("--no-variants", action="store_true")

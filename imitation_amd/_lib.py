@@ -133,6 +133,8 @@ _SIGS = {
     "ia_airl_route_grad": ([_P, _P, _F, _I, _P, _P, _P, _P], C.c_int),
     "ia_gather_rows": ([_P, _P, _I, _I, _P, _P], C.c_int),
     "ia_reward_norm_sequential": ([_P, _I, _I, _F, _I, _P, _P, _P, _P, _P], C.c_int),
+    "ia_reward_step_moments": ([_P, _I, _I, _P, _P], C.c_int),
+    "ia_reward_norm_sequential_groups": ([_P, _I, _I, _F, _I, _P, _I, _P, _P, _P, _P, _P], C.c_int),
     "ia_policy_param_count": ([C.POINTER(PolicyDesc)], C.c_int64),
     "ia_policy_transpose": ([C.POINTER(PolicyDesc), _P, _P, _P], C.c_int),
     "ia_policy_act": ([C.POINTER(PolicyDesc), _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P], C.c_int),

@@ -127,8 +127,6 @@ class AdversarialTrainer(abc.ABC):
         store = None if self._module_net else self._reward_net._store
         if self._module_net:
             from imitation_amd import ops
-            if data_parallel is not None and data_parallel.world > 1:
-                raise NotImplementedError("data parallelism is built for the fused state-holder reward nets")
             params = [p_ for p_ in self._reward_net.parameters() if p_.requires_grad]
             self._disc_opt = (ops.HipAdam(params, **self._disc_opt_kwargs) if disc_opt_cls is th.optim.Adam
                               else disc_opt_cls(params, **self._disc_opt_kwargs))
@@ -170,14 +168,26 @@ class AdversarialTrainer(abc.ABC):
         if self._dp_many:
             pol = self.gen_algo.policy
             self.gen_algo.dp = self._dp
-            norms = [n for _, n in self.reward_train._named_norms()]
-            norms += [s.norm for _, s in self._reward_net._named_stacks() if s.norm is not None]
+            if self._module_net:
+                # `nn.Module` reward nets: every RunningNorm merges the ranks' moments itself; parameters and buffers
+                # start from rank 0's; the gradients are averaged in one flat bucket per update (`_disc_update_module`)
+                from imitation_amd import modules as _modules
+                norms = [m_ for m_ in self._reward_net.modules() if isinstance(m_, _modules.RunningNorm)]
+                norms += [m_ for m_ in self.reward_train.modules() if isinstance(m_, _modules.RunningNorm)
+                          and all(m_ is not n_ for n_ in norms)]
+                heads = [p_.data for p_ in self._reward_net.parameters()]
+                heads += [b_ for b_ in self._reward_net.buffers() if all(b_ is not t for n_ in norms
+                                                                         for t in (n_.running_mean, n_.running_var, n_.count))]
+            else:
+                norms = [n for _, n in self.reward_train._named_norms()]
+                norms += [s.norm for _, s in self._reward_net._named_stacks() if s.norm is not None]
+                heads = [store.flat]
             if pol.features_extractor.normalize is not None:
                 norms.append(pol.features_extractor.normalize)
             for nrm in norms:
                 nrm.dp = self._dp
-            self._dp.broadcast_([store.flat, pol._flat] + [t for nrm in norms
-                                                           for t in (nrm.running_mean, nrm.running_var, nrm.count)])
+            self._dp.broadcast_(heads + [pol._flat] + [t for nrm in norms
+                                                       for t in (nrm.running_mean, nrm.running_var, nrm.count)])
             pol._sync_transposed()
 
         # ---- GAIL only: the discriminator update never reads the policy, so inside `train()` the
@@ -675,6 +685,15 @@ class AdversarialTrainer(abc.ABC):
             loss.backward()
             if self.disc_grad_penalty_coef > 0.0:
                 self._module_grad_penalty(state, action, next_state, done, mb, mb / B)
+        if self._dp_many:   # one flat bucket: the rank mean of the mean-reduced gradients = the gradient of the global mean
+            with th.no_grad():
+                grads = [p_.grad for g_ in self._disc_opt.param_groups for p_ in g_["params"] if p_.grad is not None]
+                flat = th.cat([g_.reshape(-1) for g_ in grads])
+                self._dp.allreduce_mean_(flat)
+                o = 0
+                for g_ in grads:
+                    g_.copy_(flat[o:o + g_.numel()].view_as(g_))
+                    o += g_.numel()
         self._disc_opt.step()
         stats_dev.copy_(stats)
         self._disc_step += 1

@@ -438,6 +438,66 @@ __global__ __launch_bounds__(256) void reward_norm_seq_kernel(const float* __res
   if (tid == 0 && update) { *mean = s_mean; *var = s_var; *count = s_cnt; }
 }
 
+// Data-parallel form (every rank relabels its own env batch, the statistics must be those of ONE process on
+// the env batches side by side). Pass 1, one block per step: (mean, M2) of the step's n raw rewards -- the two-pass
+// arithmetic of the kernel above.
+__global__ __launch_bounds__(256) void reward_step_moments_kernel(const float* __restrict__ raw, int n,
+                                                                   float* __restrict__ mom /*[T][2]*/) {
+  __shared__ float red[256];
+  const int tid = threadIdx.x, t = blockIdx.x;
+  float sum = 0.f;
+  for (int i = tid; i < n; i += 256) sum += raw[(long long)t * n + i];
+  red[tid] = sum;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) { if (tid < o) red[tid] += red[tid + o]; __syncthreads(); }
+  const float bmean = red[0] / (float)n;
+  __syncthreads();
+  float q = 0.f;
+  for (int i = tid; i < n; i += 256) {
+    const float dl = raw[(long long)t * n + i] - bmean;
+    q += dl * dl;
+  }
+  red[tid] = q;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) { if (tid < o) red[tid] += red[tid + o]; __syncthreads(); }
+  if (tid == 0) { mom[2 * t] = bmean; mom[2 * t + 1] = red[0]; }
+}
+
+// Pass 2 (after the all-gather of the ranks' [T][2] moments): walk the T steps in order -- normalise this rank's
+// rewards of step t with the statistics over steps < t, then absorb the step's batch over ALL ranks (Chan combination of
+// the `groups` per-rank moments in rank order: groups * n samples).
+__global__ __launch_bounds__(256) void reward_norm_seq_groups_kernel(const float* __restrict__ raw, int T, int n, float eps,
+                                                                      int update, const float* __restrict__ mom_all,
+                                                                      int groups, float* __restrict__ mean,
+                                                                      float* __restrict__ var, int32_t* __restrict__ count,
+                                                                      float* __restrict__ out) {
+  __shared__ float s_mean, s_var;
+  __shared__ int s_cnt;
+  const int tid = threadIdx.x;
+  if (tid == 0) { s_mean = *mean; s_var = *var; s_cnt = *count; }
+  __syncthreads();
+  for (int t = 0; t < T; ++t) {
+    const float m = s_mean, inv = 1.f / sqrtf(s_var + eps);
+    for (int i = tid; i < n; i += 256) out[(long long)t * n + i] = (raw[(long long)t * n + i] - m) * inv;
+    __syncthreads();
+    if (update && tid == 0) {
+      float na = 0.f, ma = 0.f, qa = 0.f;
+      for (int g = 0; g < groups; ++g) {
+        const float* p = mom_all + ((long long)g * T + t) * 2;
+        chan_combine(na, ma, qa, (float)n, p[0], p[1]);
+      }
+      const int R = groups * n;
+      float mc = s_mean, vc = s_var;
+      rn_absorb(mc, vc, s_cnt, R, ma, qa / (float)R);
+      s_mean = mc;
+      s_var = vc;
+      s_cnt = rn_count_add(s_cnt, R);
+    }
+    __syncthreads();
+  }
+  if (tid == 0 && update) { *mean = s_mean; *var = s_var; *count = s_cnt; }
+}
+
 // ---- gradient penalty (opt-in extension; BASELINE.json config 3 names it, the reference has none: SURVEY M1) ----
 // x_hat = e * x_expert + (1 - e) * x_gen per row pair, then the input normalisation with FROZEN statistics:
 // Xn[r, c] = (x_hat - mean[c]) / sqrt(var[c] + eps)  (mean == nullptr: x_hat itself); columns [D, ld) zero.
@@ -1007,6 +1067,22 @@ int ia_reward_norm_sequential(const float* raw, int T, int n, float eps, int upd
   if (T <= 0 || n <= 0) return IA_ERR_ARG;
   hipLaunchKernelGGL(reward_norm_seq_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, raw, T, n, eps, update_stats,
                      mean, var, count, out);
+  IA_CHECK_LAUNCH();
+  return IA_OK;
+}
+
+int ia_reward_step_moments(const float* raw, int T, int n, float* moments, void* stream) {
+  if (T <= 0 || n <= 0 || !raw || !moments) return IA_ERR_ARG;
+  hipLaunchKernelGGL(reward_step_moments_kernel, dim3(T), dim3(256), 0, (hipStream_t)stream, raw, n, moments);
+  IA_CHECK_LAUNCH();
+  return IA_OK;
+}
+
+int ia_reward_norm_sequential_groups(const float* raw, int T, int n, float eps, int update_stats, const float* moments_all,
+                                     int groups, float* mean, float* var, int32_t* count, float* out, void* stream) {
+  if (T <= 0 || n <= 0 || groups <= 0 || !moments_all) return IA_ERR_ARG;
+  hipLaunchKernelGGL(reward_norm_seq_groups_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, raw, T, n, eps,
+                     update_stats, moments_all, groups, mean, var, count, out);
   IA_CHECK_LAUNCH();
   return IA_OK;
 }

@@ -34,6 +34,7 @@ class RunningNorm(nn.Module):
         self.register_buffer("running_mean", th.zeros(num_features))
         self.register_buffer("running_var", th.ones(num_features))
         self.register_buffer("count", th.zeros((), dtype=th.int32))
+        self.dp = None   # imitation_amd.distributed.DataParallel (set by the trainer): merge the moments of all ranks
 
     def reset_running_stats(self) -> None:
         self.running_mean.zero_()
@@ -41,8 +42,19 @@ class RunningNorm(nn.Module):
         self.count.zero_()
 
     def update_stats(self, batch: th.Tensor) -> None:
-        th.ops.imitation_amd.running_norm_update(batch.detach().reshape(batch.shape[0], -1).float().contiguous(),
-                                                 self.running_mean, self.running_var, self.count)
+        x = batch.detach().reshape(batch.shape[0], -1).float().contiguous()
+        if self.dp is not None and self.dp.world > 1:
+            # every rank contributes its rows: slab moments all-gathered, the same Chan merge everywhere -- the update
+            # of one process on the concatenated batch, as `networks.RunningNorm` does it
+            from imitation_amd import _lib as L
+            R, F = x.shape
+            ws = th.empty(int(L.load().ia_running_norm_ws_floats(R, F)), device=x.device)
+            L.call("ia_running_norm_partial", L.ptr(x), F, R, F, L.ptr(ws), L.stream())
+            ws_all = self.dp.all_gather_flat(ws)
+            L.call("ia_running_norm_merge", L.ptr(ws_all), self.dp.world, R, F, F, L.ptr(self.running_mean),
+                   L.ptr(self.running_var), L.ptr(self.count), L.stream())
+            return
+        th.ops.imitation_amd.running_norm_update(x, self.running_mean, self.running_var, self.count)
 
     def forward(self, x: th.Tensor) -> th.Tensor:
         flat = x.reshape(x.shape[0], -1)

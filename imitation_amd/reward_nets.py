@@ -729,6 +729,16 @@ class NormalizedRewardNet(PredictProcessedWrapper):
         raw = self.base.predict_processed_rollout(table, T, n).contiguous()
         out = th.empty_like(raw)
         nl = self.normalize_output_layer
+        if nl.dp is not None and nl.dp.world > 1:
+            # data parallelism: this rank relabelled its own env batch; per step the statistics absorb the batch of ALL
+            # ranks (one all-gather of the [T, 2] per-step moments), so every rank keeps the statistics of one process on
+            # the env batches side by side
+            mom = th.empty(T, 2, device=raw.device)
+            L.call("ia_reward_step_moments", L.ptr(raw), T, n, L.ptr(mom), L.stream())
+            allm = nl.dp.all_gather_flat(mom.reshape(-1))
+            L.call("ia_reward_norm_sequential_groups", L.ptr(raw), T, n, nl.eps, int(update_stats), L.ptr(allm),
+                   nl.dp.world, L.ptr(nl.running_mean), L.ptr(nl.running_var), L.ptr(nl.count), L.ptr(out), L.stream())
+            return out
         L.call("ia_reward_norm_sequential", L.ptr(raw), T, n, nl.eps, int(update_stats), L.ptr(nl.running_mean),
                L.ptr(nl.running_var), L.ptr(nl.count), L.ptr(out), L.stream())
         return out

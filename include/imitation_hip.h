@@ -296,6 +296,13 @@ int ia_airl_gp_shaped(const float* Xb, int ldb, int Db, const float* Sn, const f
  * update_stats) the Chan update with raw[t,:]. mean/var are 1-element buffers, count int32. */
 int ia_reward_norm_sequential(const float* raw, int T, int n, float eps, int update_stats, float* mean, float* var,
                               int32_t* count, float* out, void* stream);
+/* Data-parallel form: every rank relabels its own env batch [T, n]; `ia_reward_step_moments` leaves the
+ * per-step (mean, M2) of its raw rewards in moments[T][2]; after an all-gather (rank-major [groups][T][2]),
+ * `ia_reward_norm_sequential_groups` walks the steps like ia_reward_norm_sequential but absorbs, per step, the batch of
+ * ALL ranks (groups * n samples) -- the statistics of one process on the env batches side by side. */
+int ia_reward_step_moments(const float* raw, int T, int n, float* moments, void* stream);
+int ia_reward_norm_sequential_groups(const float* raw, int T, int n, float eps, int update_stats, const float* moments_all,
+                                     int groups, float* mean, float* var, int32_t* count, float* out, void* stream);
 
 /* generic row gather: dst[i,:] = src[idx[i],:] (width floats) */
 int ia_gather_rows(const float* src, const int64_t* idx, int n, int width, float* dst, void* stream);

@@ -395,7 +395,7 @@ def _fused_worker(rank, world, port, out_dir):
     reward_nets.BasicRewardNet.fused_adam_step = counting_adam
     reward_nets.ShapedRewardNet.fused_finish = counting_finish
 
-    def run(airl: bool, pipeline: bool, hid=(256, 256)):
+    def run(airl: bool, pipeline: bool, hid=(256, 256), normalize_output: bool = False, module: bool = False):
         th.manual_seed(100 + rank)
         np.random.seed(100 + rank)
         venv = SyntheticVecEnv(num_envs=cfg["n_envs"], obs_dim=17, act_dim=6, horizon=cfg["horizon"], seed=rank)
@@ -407,9 +407,14 @@ def _fused_worker(rank, world, port, out_dir):
             net = p.BasicShapedRewardNet(venv.observation_space, venv.action_space, reward_hid_sizes=(32,),
                                          potential_hid_sizes=(32, 32), use_next_state=True,
                                          normalize_input_layer=p.RunningNorm)
+        elif module:   # autograd-capable nn.Module net on the custom ops (the operator boundary), general kernels
+            net = p.modules.BasicRewardNet(venv.observation_space, venv.action_space, hid_sizes=(32, 32),
+                                           normalize_input_layer=p.modules.RunningNorm)
         else:
             net = p.BasicRewardNet(venv.observation_space, venv.action_space, hid_sizes=hid,
                                    normalize_input_layer=p.RunningNorm)
+        if normalize_output:   # the scripts' default wrapper: output statistics over the env batches of ALL ranks
+            net = p.NormalizedRewardNet(net, p.RunningNorm)
         demos = p.Transitions(**harness.make_demo_arrays(cfg, seed=1 + rank))
         tr = (p.AIRL if airl else p.GAIL)(
             demonstrations=demos, demo_batch_size=128, venv=venv, gen_algo=algo, reward_net=net,
@@ -424,7 +429,10 @@ def _fused_worker(rank, world, port, out_dir):
 
     for name, kw in (("gail", dict(airl=False, pipeline=True)), ("gail_seq", dict(airl=False, pipeline=False)),
                      ("gail128", dict(airl=False, pipeline=True, hid=(128, 128))),
-                     ("airl", dict(airl=True, pipeline=True)), ("airl_seq", dict(airl=True, pipeline=False))):
+                     ("gail32", dict(airl=False, pipeline=True, hid=(32, 32))),
+                     ("airl", dict(airl=True, pipeline=True)), ("airl_seq", dict(airl=True, pipeline=False)),
+                     ("airl_norm", dict(airl=True, pipeline=True, normalize_output=True)),
+                     ("module", dict(airl=False, pipeline=True, module=True))):
         before = dict(calls)
         sd = run(**kw)
         sd["_fused_calls"] = th.tensor([calls["gail"] - before["gail"], calls["airl"] - before["airl"]])
@@ -441,11 +449,11 @@ def test_fused_updates_under_data_parallelism_replicas_identical(tmp_path):
     port = _free_port()
     mp.spawn(_fused_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     ld = lambda r, n: th.load(tmp_path / f"fused{r}_{n}.pt")
-    for name in ("gail", "gail_seq", "gail128", "airl", "airl_seq"):
+    for name in ("gail", "gail_seq", "gail128", "gail32", "airl", "airl_seq", "airl_norm", "module"):
         a, b = ld(0, name), ld(1, name)
         calls = a.pop("_fused_calls"); b.pop("_fused_calls")
-        # 3 rounds x 3 updates, every one through the fused kernels
-        assert int(calls[1 if name.startswith("airl") else 0]) == 9, (name, calls)
+        # 3 rounds x 3 updates, every one through the fused kernels (the nn.Module net: through the custom ops)
+        assert int(calls[1 if name.startswith("airl") else 0]) == (0 if name == "module" else 9), (name, calls)
         for k in a:
             assert th.equal(a[k], b[k]), (name, k)
         assert all(bool(th.isfinite(v.float()).all()) for v in a.values())
@@ -456,6 +464,9 @@ def test_fused_updates_under_data_parallelism_replicas_identical(tmp_path):
                 assert th.equal(a[k], s[k]), (name, k)
     # every rank contributed to the input statistics: world x (3 rounds x 3 updates x 256 rows)
     assert int(ld(0, "gail")["disc/mlp.normalize_input.count"]) == 2 * 3 * 3 * 256
+    assert int(ld(0, "module")["disc/mlp.normalize_input.count"]) == 2 * 3 * 3 * 256
+    # ... and to the output statistics of NormalizedRewardNet: world x (3 rollouts x 16 steps x 8 envs)
+    assert int(ld(0, "airl_norm")["disc/normalize_output_layer.count"]) == 2 * 3 * 16 * 8
 
 
 def _fused_equiv_worker(rank, world, port, out_dir):

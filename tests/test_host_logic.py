@@ -500,3 +500,29 @@ def test_fused_airl_update_is_taken_only_for_its_geometry(monkeypatch):
     assert not p.BasicShapedRewardNet(wide, act, reward_hid_sizes=(32,), potential_hid_sizes=(32, 32)).fused_step_ok()
     monkeypatch.setattr(rn, "FUSED_AIRL_STEP", False)
     assert not mk(reward_hid_sizes=(32,), potential_hid_sizes=(32, 32)).fused_step_ok()
+
+
+def test_production_kernels_do_not_spill():
+    """The built library's own notes (`llvm-readelf --notes` of its gfx950 code objects): the production instantiations
+    of the latency chains and the tile kernels keep every value in registers -- a spilled VGPR is a scratch access, and
+    every scratch access is a `vmcnt(0)` wait on the chain (round-2 verdict: DESIGN claimed zero, the binary had 4 / 52)."""
+    import shutil
+
+    if not os.path.exists("/opt/rocm/lib/llvm/bin/llvm-readelf") or shutil.which("c++filt") is None:
+        pytest.skip("llvm-readelf / c++filt not available")
+    from tools.kernel_resources import kernel_notes
+
+    notes = {k["name"]: k for k in kernel_notes()}
+    find = lambda sub: [k for n, k in notes.items() if sub in n]
+    # persistent PPO update: 8 and 9 parameters per thread, production build, observation widths <= 32 (every
+    # reference environment of the path): no spilled VGPR, no scratch at all
+    for inst in ("ppo_update_persistent_kernel<8, false, 8>", "ppo_update_persistent_kernel<9, false, 8>"):
+        ks = find(inst)
+        assert len(ks) == 1, inst
+        assert ks[0]["vgpr_spill"] == 0 and ks[0]["scratch"] == 0, (inst, ks[0])
+    for sub in ("disc_fwd_kernel", "disc_bwd_kernel", "airl_rows_kernel", "disc32_rows_kernel", "policy_act_mfma_kernel",
+                "ia_gemm_kernel", "conv1_fwd_kernel", "conv1_wgrad_kernel"):
+        ks = find(sub)
+        assert ks, sub
+        for k in ks:
+            assert k["vgpr_spill"] == 0, (sub, k)
