@@ -9,7 +9,7 @@ from imitation_amd.data_types import (ExpertIndexStream, Transitions, Transition
                                       TrajectoryWithRew, flatten_trajectories, segment_order,
                                       trajectories_from_legacy_npz)
 from imitation_amd.logger import HierarchicalLogger, configure as _configure_logger  # noqa: F401
-from imitation_amd.networks import RunningNorm, evaluating, training  # noqa: F401
+from imitation_amd.networks import EMANorm, RunningNorm, evaluating, training  # noqa: F401
 from imitation_amd.reward_nets import (BasicPotentialMLP, BasicRewardNet, BasicShapedRewardNet,  # noqa: F401
                                        ForwardWrapper, NormalizedRewardNet, PredictProcessedWrapper, RewardNet,
                                        RewardNetWrapper, ShapedRewardNet)

@@ -112,6 +112,7 @@ _SIGS = {
     "ia_running_norm_update": ([_P, _I, _I, _I, _P, _P, _P, _P, _P], C.c_int),
     "ia_running_norm_partial": ([_P, _I, _I, _I, _P, _P], C.c_int),
     "ia_running_norm_merge": ([_P, _I, _I, _I, _I, _P, _P, _P, _P], C.c_int),
+    "ia_ema_norm_merge": ([_P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _F, _P], C.c_int),
     "ia_running_norm_merge_seq": ([_P, _I, _L, _I, _I, _I, _I, _P, _P, _P, _P, _P], C.c_int),
     "ia_running_norm_apply": ([_P, _I, _I, _I, _P, _P, _F, _P, _I, _P], C.c_int),
     "ia_gather_concat": ([_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _I, _I, _P], C.c_int),

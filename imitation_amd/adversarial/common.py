@@ -510,7 +510,8 @@ class AdversarialTrainer(abc.ABC):
         # input statistics merged over all ranks); its slab reduction leaves the rank's gradient, ONE all-reduce and
         # the Adam + weight-image launch follow below. Updates outside such a round keep the general path.
         c_path = (isinstance(basic, reward_nets.BasicRewardNet) and not self._needs_logp
-                  and (single or pre is not None) and self._torch_opt_params is None)
+                  and (single or pre is not None) and self._torch_opt_params is None
+                  and (basic.mlp.norm is None or basic.mlp.norm.is_chan))   # (EMANorm: stack-by-stack path)
         dp_fused = c_path and not single
         pol = self.policy
         prn = pol.features_extractor.normalize if isinstance(pol, ActorCriticPolicy) else None

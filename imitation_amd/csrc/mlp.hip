@@ -239,6 +239,38 @@ __global__ __launch_bounds__(64 * RN_SEQ_WAVES) void rn_merge_seq_kernel(
   }
 }
 
+// EMANorm (util/networks.py:137-201): exponentially weighted statistics from the same slab moments. One wave per
+// column; every column reads the OLD inverse learning rate and batch counter, the follow-up kernel bumps them.
+//   inv_lr' = inv_lr + decay^num_batches;  lr = 1 / inv_lr';  d = b_mean - mean;  mean += lr d;
+//   var += lr (b_var + (1 - lr) d^2 - var)
+__global__ __launch_bounds__(64) void ema_merge_kernel(const float* __restrict__ ws, int nblocks, int bpg, int rpg, int R,
+                                                       int D, int ws_ld, float* __restrict__ mean,
+                                                       float* __restrict__ var, const float* __restrict__ inv_lr,
+                                                       const int32_t* __restrict__ num_batches, float decay) {
+  const int c = blockIdx.x, lane = threadIdx.x;
+  float b_mean, b_M2;
+  rn_wave_batch_moments(ws, nblocks, bpg, rpg, ws_ld, c, lane, b_mean, b_M2);
+  if (lane == 0) {
+    const float ilr = *inv_lr + powf(decay, (float)*num_batches);
+    const float lr = 1.f / ilr;
+    const float b_var = b_M2 / (float)R;
+    const float mc = mean[c], vc = var[c];
+    const float dm = b_mean - mc;
+    mean[c] = mc + lr * dm;
+    const float dv = b_var + (1.f - lr) * (dm * dm) - vc;
+    var[c] = vc + lr * dv;
+  }
+}
+
+__global__ void ema_count_kernel(int32_t* __restrict__ count, long long R, float* __restrict__ inv_lr,
+                                 int32_t* __restrict__ num_batches, float decay) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    *inv_lr = *inv_lr + powf(decay, (float)*num_batches);
+    *num_batches = *num_batches + 1;
+    *count = rn_count_add(*count, R);
+  }
+}
+
 __global__ void rn_count_kernel(int32_t* __restrict__ count, long long R) {
   if (threadIdx.x == 0 && blockIdx.x == 0) *count = rn_count_add(*count, R);
 }
@@ -906,6 +938,19 @@ int ia_running_norm_merge(const float* ws_all, int groups, int rows_per_group, i
                      rows_per_group, groups * rows_per_group, D, ws_ld, mean, var, count);
   IA_CHECK_LAUNCH();
   hipLaunchKernelGGL(rn_count_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, count, (long long)groups * rows_per_group);
+  IA_CHECK_LAUNCH();
+  return IA_OK;
+}
+
+int ia_ema_norm_merge(const float* ws_all, int groups, int rows_per_group, int D, int ws_ld, float* mean, float* var,
+                      int32_t* count, float* inv_learning_rate, int32_t* num_batches, float decay, void* stream) {
+  if (groups <= 0 || rows_per_group <= 0 || D <= 0 || ws_ld < D || !inv_learning_rate || !num_batches) return IA_ERR_ARG;
+  const int bpg = cdiv(rows_per_group, RN_ROWS_PER_BLOCK);
+  hipLaunchKernelGGL(ema_merge_kernel, dim3(D), dim3(64), 0, (hipStream_t)stream, ws_all, groups * bpg, bpg, rows_per_group,
+                     groups * rows_per_group, D, ws_ld, mean, var, inv_learning_rate, num_batches, decay);
+  IA_CHECK_LAUNCH();
+  hipLaunchKernelGGL(ema_count_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, count,
+                     (long long)groups * rows_per_group, inv_learning_rate, num_batches, decay);
   IA_CHECK_LAUNCH();
   return IA_OK;
 }

@@ -64,6 +64,35 @@ class RunningNorm(nn.Module):
         return ops.running_norm_apply_fn(flat, self.running_mean, self.running_var, self.eps).reshape(x.shape)
 
 
+class EMANorm(RunningNorm):
+    """`util/networks.py:137-201`: exponentially weighted statistics; buffers `inv_learning_rate`, `num_batches`."""
+
+    def __init__(self, num_features: int, decay: float = 0.99, eps: float = 1e-5):
+        super().__init__(num_features, eps=eps)
+        if not 0 < decay < 1:
+            raise ValueError("decay must be between 0 and 1")
+        self.decay = float(decay)
+        self.register_buffer("inv_learning_rate", th.zeros(()))
+        self.register_buffer("num_batches", th.zeros((), dtype=th.int32))
+
+    def reset_running_stats(self) -> None:
+        super().reset_running_stats()
+        self.inv_learning_rate.zero_()
+        self.num_batches.zero_()
+
+    def update_stats(self, batch: th.Tensor) -> None:
+        from imitation_amd import _lib as L
+        x = batch.detach().reshape(batch.shape[0], -1).float().contiguous()
+        R, F = x.shape
+        ws = th.empty(int(L.load().ia_running_norm_ws_floats(R, F)), device=x.device)
+        L.call("ia_running_norm_partial", L.ptr(x), F, R, F, L.ptr(ws), L.stream())
+        groups = 1
+        if self.dp is not None and self.dp.world > 1:
+            ws, groups = self.dp.all_gather_flat(ws), self.dp.world
+        L.call("ia_ema_norm_merge", L.ptr(ws), groups, R, F, F, L.ptr(self.running_mean), L.ptr(self.running_var),
+               L.ptr(self.count), L.ptr(self.inv_learning_rate), L.ptr(self.num_batches), self.decay, L.stream())
+
+
 _ACTS = {nn.ReLU: ops.ACT_RELU, nn.Tanh: ops.ACT_TANH}
 
 

@@ -58,6 +58,8 @@ class RunningNorm:
         self._ws: Optional[th.Tensor] = None
         self.dp = None  # imitation_amd.distributed.DataParallel: merge moments across ranks
 
+    is_chan = True   # Chan-merged statistics: what the fused updates' in-kernel merges implement (EMANorm: False)
+
     # -- nn.Module-like plumbing
     def train(self, mode: bool = True):
         self.training = mode
@@ -130,6 +132,60 @@ class RunningNorm:
     forward = __call__
 
 
+class EMANorm(RunningNorm):
+    """`util/networks.py:137-201`: exponentially weighted statistics (extra buffers `inv_learning_rate`,
+    `num_batches`). Same surface as `RunningNorm`; the fused one-call updates (which merge Chan statistics inside
+    their kernels) step aside for it and the stack-by-stack path runs (`RunningNorm.is_chan`)."""
+
+    is_chan = False
+
+    def __init__(self, num_features: int, decay: float = 0.99, eps: float = 1e-5):
+        super().__init__(num_features, eps=eps)
+        if not 0 < decay < 1:
+            raise ValueError("decay must be between 0 and 1")
+        self.decay = float(decay)
+        self.inv_learning_rate = th.zeros(())
+        self.num_batches = th.zeros((), dtype=th.int32)
+
+    def to(self, device):
+        super().to(device)
+        self.inv_learning_rate = self.inv_learning_rate.to(self.device)
+        self.num_batches = self.num_batches.to(self.device)
+        return self
+
+    def state_dict(self, prefix: str = "") -> Dict[str, th.Tensor]:
+        sd = super().state_dict(prefix)
+        sd.update({prefix + "inv_learning_rate": self.inv_learning_rate, prefix + "num_batches": self.num_batches})
+        return sd
+
+    def load_state_dict(self, sd, prefix: str = "") -> None:
+        super().load_state_dict(sd, prefix)
+        self.inv_learning_rate.copy_(th.as_tensor(sd[prefix + "inv_learning_rate"]))
+        self.num_batches.copy_(th.as_tensor(sd[prefix + "num_batches"]).to(th.int32))
+
+    def reset_running_stats(self) -> None:
+        super().reset_running_stats()
+        self.inv_learning_rate.zero_()
+        self.num_batches.zero_()
+
+    def update_stats(self, x: th.Tensor, ldx: Optional[int] = None, rows: Optional[int] = None) -> None:
+        require_device(self.device)
+        if x.dim() == 1:
+            x = x.reshape(-1, 1)
+        R = rows if rows is not None else x.shape[0]
+        ld = ldx if ldx is not None else x.shape[1]
+        need = int(L.load().ia_running_norm_ws_floats(R, self.num_features))
+        if self._ws is None or self._ws.numel() != need:
+            self._ws = th.empty(need, device=self.device)
+        L.call("ia_running_norm_partial", L.ptr(x), ld, R, self.num_features, L.ptr(self._ws), L.stream())
+        ws, groups = self._ws, 1
+        if self.dp is not None and self.dp.world > 1:
+            ws, groups = self.dp.all_gather_flat(self._ws), self.dp.world
+        L.call("ia_ema_norm_merge", L.ptr(ws), groups, R, self.num_features, self.num_features, L.ptr(self.running_mean),
+               L.ptr(self.running_var), L.ptr(self.count), L.ptr(self.inv_learning_rate), L.ptr(self.num_batches),
+               self.decay, L.stream())
+
+
 _ACT_CODES = {nn.ReLU: L.ACT_RELU, nn.Tanh: L.ACT_TANH, None: L.ACT_NONE}
 
 
@@ -159,9 +215,9 @@ class DenseStack:
         self.prefix = "" if name is None else f"{name}_"
         self.norm: Optional[RunningNorm] = None
         if normalize_input_layer is not None:
-            if normalize_input_layer is not RunningNorm:
-                raise NotImplementedError("only imitation_amd.RunningNorm is implemented as input normalisation")
-            self.norm = RunningNorm(in_size)
+            if not (isinstance(normalize_input_layer, type) and issubclass(normalize_input_layer, RunningNorm)):
+                raise NotImplementedError("input normalisation: imitation_amd.RunningNorm or imitation_amd.EMANorm")
+            self.norm = normalize_input_layer(in_size)
         self.desc = L.mlp_desc(self.dims, _ACT_CODES[activation])
         layers = [nn.Linear(self.dims[i], self.dims[i + 1]) for i in range(len(self.dims) - 1)]
         self.n_params = sum(l.weight.numel() + l.bias.numel() for l in layers)

@@ -39,7 +39,9 @@ class NormalizeFeaturesExtractor(FlattenExtractor):
     def __init__(self, observation_space, normalize_class=RunningNorm):
         super().__init__(observation_space)
         if normalize_class is not RunningNorm:
-            raise NotImplementedError("only imitation_amd.RunningNorm is implemented for feature normalisation")
+            raise NotImplementedError("feature normalisation of the HIP policies: imitation_amd.RunningNorm (the policy "
+                                      "kernels merge Chan statistics inside the PPO update; EMANorm is implemented for "
+                                      "reward nets only)")
         self.normalize = normalize_class(self.features_dim)
 
 

@@ -266,6 +266,8 @@ class BasicRewardNet(RewardNet):
         mlp, R = self.mlp, 2 * mb
         if FUSED_DISC_STEP is False or int(L.load().ia_disc_fused_ws_floats(C.byref(mlp.desc), R, mlp.ldx)) <= 0:
             return None
+        if mlp.norm is not None and not mlp.norm.is_chan:   # EMANorm: the fused kernels merge Chan statistics
+            return None
         if idx_all.shape[1:] != (2, mb) or not idx_all.is_contiguous():
             return None
         dev, D = mlp.flat.device, mlp.dims[0]
@@ -322,6 +324,8 @@ class BasicRewardNet(RewardNet):
             a.splits, a.rn_ws = ws["splits"], L.ptr(ws["rn_ws"])
             # D -> H -> H -> 1 stacks: workspace of the five-launch fused update (0 floats: general path)
             nf = 0 if FUSED_DISC_STEP is False else int(L.load().ia_disc_fused_ws_floats(C.byref(mlp.desc), R, mlp.ldx))
+            if mlp.norm is not None and not mlp.norm.is_chan:
+                nf = 0
             ws["fused_ws"] = th.zeros(nf, device=dev) if nf > 0 else None
             a.fused_ws = L.ptr(ws["fused_ws"])
             if nf > 0:  # 32 K-splits of the second layer's weight gradient: half the partial-slab traffic of 64
@@ -543,6 +547,8 @@ class ShapedRewardNet(ForwardWrapper):
             return False
         if base.desc.hidden_act != L.ACT_RELU or pot.desc.hidden_act != L.ACT_RELU or not FUSED_AIRL_STEP:
             return False
+        if any(n is not None and not n.is_chan for n in (base.norm, pot.norm)):   # EMANorm: stack-by-stack path
+            return False
         return bool(L.load().ia_airl_fused_ok(base.dims[0], pot.dims[0], base.dims[1], pot.dims[1], pot.dims[2]))
 
     def fused_prepare(self, sources, pol_obs: Optional[th.Tensor] = None, pol_act: Optional[th.Tensor] = None,
@@ -704,8 +710,8 @@ class NormalizedRewardNet(PredictProcessedWrapper):
 
     def __init__(self, base: RewardNet, normalize_output_layer: Type):
         super().__init__(base)
-        if normalize_output_layer is not RunningNorm:
-            raise NotImplementedError("only imitation_amd.RunningNorm is implemented as output normalisation")
+        if not (isinstance(normalize_output_layer, type) and issubclass(normalize_output_layer, RunningNorm)):
+            raise NotImplementedError("output normalisation: imitation_amd.RunningNorm or imitation_amd.EMANorm")
         self.normalize_output_layer = normalize_output_layer(1)
 
     def _named_norms(self):
@@ -729,6 +735,13 @@ class NormalizedRewardNet(PredictProcessedWrapper):
         raw = self.base.predict_processed_rollout(table, T, n).contiguous()
         out = th.empty_like(raw)
         nl = self.normalize_output_layer
+        if not nl.is_chan:   # EMANorm: step by step (normalise with the statistics so far, then update), like the wrapper
+            r2, o2 = raw.view(T, n, 1), out.view(T, n, 1)
+            for t in range(T):
+                nl.apply(r2[t], o2[t], 1, 1, n)
+                if update_stats:
+                    nl.update_stats(r2[t])
+            return out
         if nl.dp is not None and nl.dp.world > 1:
             # data parallelism: this rank relabelled its own env batch; per step the statistics absorb the batch of ALL
             # ranks (one all-gather of the [T, 2] per-step moments), so every rank keeps the statistics of one process on

@@ -113,6 +113,11 @@ int ia_running_norm_update(const float* X, int ldx, int R, int D, float* mean, f
 int ia_running_norm_partial(const float* X, int ldx, int R, int D, float* ws, void* stream);
 int ia_running_norm_merge(const float* ws_all, int groups, int rows_per_group, int D, int ws_ld, float* mean,
                           float* var, int32_t* count, void* stream);
+/* util/networks.py:137-201 `EMANorm.update_stats` from the same slab moments (ia_running_norm_partial; `groups` ranks of
+ * `rows_per_group` rows each under data parallelism): inv_learning_rate += decay^num_batches; lr = 1 / inv_learning_rate;
+ * mean += lr (b_mean - mean); var += lr (b_var + (1 - lr) (b_mean - mean_old)^2 - var); count += rows; num_batches += 1. */
+int ia_ema_norm_merge(const float* ws_all, int groups, int rows_per_group, int D, int ws_ld, float* mean, float* var,
+                      int32_t* count, float* inv_learning_rate, int32_t* num_batches, float decay, void* stream);
 /* n_seq consecutive ia_running_norm_merge updates (`groups` x `rows_per_group` rows each, moments
  * `seq_stride` floats apart) in order, in one launch: the deferred policy feature-norm updates of a
  * round (adversarial/common.py:606-615 side effect). snapshots (nullable): float

@@ -81,6 +81,33 @@ class RunningNorm(nn.Module):
         return (x - self.running_mean) / th.sqrt(self.running_var + self.eps)
 
 
+class EMANorm(RunningNorm):
+    """util/networks.py:137-201: exponentially weighted running statistics (batch EMA / EMV, "Algorithm 3" of the note
+    the reference cites); extra buffers `inv_learning_rate` (float) and `num_batches` (int)."""
+
+    def __init__(self, num_features: int, decay: float = 0.99, eps: float = 1e-5):
+        super().__init__(num_features, eps=eps)
+        if not 0 < decay < 1:
+            raise ValueError("decay must be between 0 and 1")
+        self.decay = decay
+        self.register_buffer("inv_learning_rate", th.zeros(()))
+        self.register_buffer("num_batches", th.zeros((), dtype=th.int))
+
+    def update_stats(self, batch: th.Tensor) -> None:  # networks.py:179-201
+        b_size = batch.shape[0]
+        if len(batch.shape) == 1:
+            batch = batch.reshape(b_size, 1)
+        self.inv_learning_rate += self.decay ** self.num_batches
+        learning_rate = 1 / self.inv_learning_rate
+        delta_mean = batch.mean(0) - self.running_mean
+        self.running_mean += learning_rate * delta_mean
+        batch_var = batch.var(0, unbiased=False)
+        delta_var = batch_var + (1 - learning_rate) * delta_mean ** 2 - self.running_var
+        self.running_var += learning_rate * delta_var
+        self.count += b_size
+        self.num_batches += 1
+
+
 class _Squeeze(nn.Module):
     def forward(self, x):
         return x.squeeze(1)

@@ -115,6 +115,12 @@ CASES: Dict[str, Dict[str, Any]] = {
                            ppo_kwargs=dict(clip_range=0.3, gae_lambda=0.8, gamma=0.995,
                                            learning_rate=3.249429831179079e-5, max_grad_norm=0.9,
                                            vf_coef=0.4351450387648799)),
+    # EMANorm (`util/networks.py:137-201`) wherever the reference takes a normalisation layer for the reward net: input
+    # norms of both stacks and the NormalizedRewardNet output layer (AIRL: the processed reward IS normalised).
+    "airl_ema": dict(algo="airl", n_envs=8, horizon=10, obs_dim=11, act_dim=3, n_discrete=None,
+                     n_steps=16, ppo_batch=32, n_epochs=2, ent_coef=0.0, disc_hid=(32,),
+                     demo_batch=64, demo_minibatch=None, n_disc=3, capacity=None, n_demo=300, rounds=3,
+                     norm_policy=True, norm_disc=True, obs_dtype="float32", normalize_output=True, disc_norm="ema"),
     # BASELINE config 1's plumbing ("CPU SubprocVecEnv"): the environment speaks ONLY the gym / SB3 VecEnv protocol --
     # per-env info dicts with `terminal_observation`, `TimeLimit.truncated` and Monitor's `episode` entries
     # (`vec_env.GymStyleVecEnv`) -- so the wrappers take their generic per-env branch (`rewards/reward_wrapper.py:98-109`,
@@ -172,7 +178,7 @@ def namespace(impl: str) -> pytypes.SimpleNamespace:
         from imitation.policies.base import FeedForward32Policy, NormalizeFeaturesExtractor
         from imitation.rewards import reward_nets as rn
         from imitation.util import logger as rlog
-        from imitation.util.networks import RunningNorm
+        from imitation.util.networks import EMANorm, RunningNorm
         from oracle import sb3_restated as sb
 
         def transitions(**kw):
@@ -183,7 +189,7 @@ def namespace(impl: str) -> pytypes.SimpleNamespace:
             GAIL=GAIL, AIRL=AIRL, PPO=sb.PPO, FeedForward32Policy=FeedForward32Policy,
             ActorCriticPolicy=sb.ActorCriticPolicy, ActorCriticCnnPolicy=sb.ActorCriticCnnPolicy,
             CnnRewardNet=rn.CnnRewardNet,
-            NormalizeFeaturesExtractor=NormalizeFeaturesExtractor, RunningNorm=RunningNorm,
+            NormalizeFeaturesExtractor=NormalizeFeaturesExtractor, RunningNorm=RunningNorm, EMANorm=EMANorm,
             BasicRewardNet=rn.BasicRewardNet, BasicShapedRewardNet=rn.BasicShapedRewardNet,
             NormalizedRewardNet=rn.NormalizedRewardNet, Transitions=transitions,
             configure_logger=lambda d: rlog.configure(d, []))
@@ -195,7 +201,7 @@ def namespace(impl: str) -> pytypes.SimpleNamespace:
             GAIL=o.GAIL, AIRL=o.AIRL, PPO=sb.PPO, FeedForward32Policy=o.FeedForward32Policy,
             ActorCriticPolicy=sb.ActorCriticPolicy, ActorCriticCnnPolicy=sb.ActorCriticCnnPolicy,
             CnnRewardNet=o.CnnRewardNet,
-            NormalizeFeaturesExtractor=o.NormalizeFeaturesExtractor, RunningNorm=o.RunningNorm,
+            NormalizeFeaturesExtractor=o.NormalizeFeaturesExtractor, RunningNorm=o.RunningNorm, EMANorm=o.EMANorm,
             BasicRewardNet=o.BasicRewardNet, BasicShapedRewardNet=o.BasicShapedRewardNet,
             NormalizedRewardNet=o.NormalizedRewardNet, Transitions=lambda **kw: o.Transitions(**kw),
             configure_logger=lambda d: o.configure_logger(d, []))
@@ -206,7 +212,7 @@ def namespace(impl: str) -> pytypes.SimpleNamespace:
             GAIL=p.GAIL, AIRL=p.AIRL, PPO=p.PPO, FeedForward32Policy=p.FeedForward32Policy,
             ActorCriticPolicy=p.ActorCriticPolicy, ActorCriticCnnPolicy=p.cnn_policy.ActorCriticCnnPolicy,
             CnnRewardNet=p.modules.CnnRewardNet,
-            NormalizeFeaturesExtractor=p.NormalizeFeaturesExtractor, RunningNorm=p.RunningNorm,
+            NormalizeFeaturesExtractor=p.NormalizeFeaturesExtractor, RunningNorm=p.RunningNorm, EMANorm=p.EMANorm,
             BasicRewardNet=p.BasicRewardNet, BasicShapedRewardNet=p.BasicShapedRewardNet,
             NormalizedRewardNet=p.NormalizedRewardNet, Transitions=lambda **kw: p.Transitions(**kw),
             configure_logger=lambda d: p.configure_logger(d, []))
@@ -220,9 +226,9 @@ def build_trainer(impl: str, cfg, log_dir: str, device: str = "cpu", module_net:
 
         ns.BasicRewardNet, ns.BasicShapedRewardNet, ns.NormalizedRewardNet = (m.BasicRewardNet, m.BasicShapedRewardNet,
                                                                              m.NormalizedRewardNet)
-        disc_norm = m.RunningNorm
+        disc_norm = m.EMANorm if cfg.get("disc_norm") == "ema" else m.RunningNorm
     else:
-        disc_norm = ns.RunningNorm
+        disc_norm = ns.EMANorm if cfg.get("disc_norm") == "ema" else ns.RunningNorm
     th.manual_seed(0)
     np.random.seed(0)
     if cfg.get("image"):

@@ -63,7 +63,7 @@ def _compare(got, gold, cfg, skip=(), adam_outliers=None):
 @pytest.mark.parametrize("case", ["gail_box", "gail_f64", "gail_discrete", "airl_box", "gail_horizon", "gail_tuned",
                                   "gail_fused", "gail_cartpole", "gail_towers", "gail_discrete_towers",
                                   "airl_towers", "gail_image", "airl_image", "gail_tuned_hps", "airl_tuned_hps",
-                                  "gail_next_done", "gail_generic_vecenv"])
+                                  "gail_next_done", "gail_generic_vecenv", "airl_ema"])
 def test_hip_trainer_matches_reference_golden(case, tmp_path):
     cfg = harness.CASES[case]
     gold = dict(np.load(os.path.join(GOLDEN, f"{case}.npz")))
@@ -382,10 +382,15 @@ def test_horizon_rollouts_match_live_oracle(n_steps, tmp_path):
 def test_bc_nature_cnn_84x84_matches_live_oracle(tmp_path):
     """BASELINE config 5's shape: `bc.BC` with the NatureCNN policy on uint8 4 x 84 x 84 frames, Discrete(6), batch 256
     (the full 4 096 is timed by bench.py's `5_bc_cnn_4096`; the CPU oracle needs seconds per step there): three
-    optimiser steps against the oracle's torch-CPU BC on the same frames, policy and loader stream. Every parameter
-    within rtol 2e-4 / atol 5e-5 except <= 1 % of a tensor's entries whose near-zero gradient takes a different early
-    Adam step (Adam normalises the step: a last-bit difference in a vanishing gradient is a +-lr step; bounded by
-    steps x lr; measured: 0.34 % of the first convolution's weights, worst 4.4e-4)."""
+    optimiser steps against the oracle's torch-CPU BC on the same frames, policy and loader stream. Every logged row
+    (loss, neglogp, entropy, prob_true_act, l2_norm ... of each step) within rtol 1e-4; every parameter within
+    steps x lr of the oracle's, and within rtol 2e-4 / atol 5e-5 for >= 97 % of each tensor's entries. Two fp32 effects
+    keep the rest apart without being errors: Adam normalises the step, so a last-bit difference in a vanishing gradient
+    is a +-lr step; and at this batch size a ReLU pre-activation within ~1e-6 of zero flips its mask between the two
+    fp32 summation orders (measured against a float64 graph: one unit of `linear.0` at batch 128, which moves that
+    unit's gradient row and, through the sample's feature gradient, every convolution gradient by ~0.3 % of its largest
+    entry; torch's own fp32 run happens not to flip). Gradients are checked entry by entry against torch autograd at
+    batch sizes without a flip in `test_cnn_policy_forward_and_gradient_match_torch` (same image shape)."""
     from imitation_amd import spaces
     shape, A, B, steps = (4, 84, 84), 6, 256, 3
     osp, asp = spaces.Box(0, 255, shape, np.uint8), spaces.Discrete(A)
@@ -403,17 +408,32 @@ def test_bc_nature_cnn_84x84_matches_live_oracle(tmp_path):
             pol = ns.ActorCriticCnnPolicy(observation_space=osp, action_space=asp, lr_schedule=lambda _: 1.0)
             demos = ns.Transitions(obs=obs, acts=acts, next_obs=obs.copy(), dones=np.zeros(2 * B, dtype=bool))
             kw = dict(device="cuda") if impl == "hip" else {}
+            logger = ns.configure_logger(str(tmp_path / impl))
+            rows, orig_dump = [], logger.dump
+
+            def dump(step=0, logger=logger, rows=rows, orig_dump=orig_dump):
+                kv = dict(logger.name_to_value) if hasattr(logger, "name_to_value") else {}
+                if not kv and hasattr(logger, "default_logger"):
+                    kv = dict(logger.default_logger.name_to_value)
+                rows.append([float(kv[k]) for k in sorted(kv) if k.startswith("bc/")])
+                return orig_dump(step)
+
+            logger.dump = dump
             tr = ns.BC(observation_space=osp, action_space=asp, rng=np.random.default_rng(0), policy=pol,
-                       demonstrations=demos, batch_size=B, custom_logger=ns.configure_logger(str(tmp_path / impl)), **kw)
-            tr.train(n_batches=steps, log_interval=10 ** 9, progress_bar=False)
+                       demonstrations=demos, batch_size=B, custom_logger=logger, **kw)
+            tr.train(n_batches=steps, log_interval=1, progress_bar=False)
             outs[impl] = {k: harness._np(v) for k, v in tr.policy.state_dict().items()
                           if not k.startswith(("pi_features_extractor.", "vf_features_extractor."))}
+            outs[impl]["_rows"] = np.asarray(rows, dtype=np.float64)
         finally:
             th.set_num_threads(threads)
     ref, got = outs["oracle"], outs["hip"]
     assert set(ref) == set(got)
+    rr, rg = ref.pop("_rows"), got.pop("_rows")
+    assert rr.shape == rg.shape and rr.shape[0] == steps and rr.shape[1] >= 5
+    np.testing.assert_allclose(rg, rr, rtol=1e-4, atol=1e-6)
     for k in ref:
         x, y = got[k].astype(np.float64), ref[k].astype(np.float64)
         err = np.abs(x - y)
         bad = err > 5e-5 + 2e-4 * np.abs(y)
-        assert bad.mean() <= 1e-2 and (not bad.any() or err[bad].max() <= steps * 1e-3 + 1e-4), (k, bad.mean(), err.max())
+        assert bad.sum() <= max(3, 0.03 * bad.size) and err.max() <= steps * 1e-3 + 1e-4, (k, bad.mean(), err.max())

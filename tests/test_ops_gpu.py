@@ -162,7 +162,7 @@ def test_module_reward_net_train_disc_matches_fused_path(tmp_path):
                                ta.reward_train.predict_processed(s, a, s, np.zeros(16, bool)), rtol=2e-4, atol=5e-5)
 
 
-@pytest.mark.parametrize("case", ["gail_box", "gail_discrete", "airl_box"])
+@pytest.mark.parametrize("case", ["gail_box", "gail_discrete", "airl_box", "airl_ema"])
 def test_module_reward_net_trainer_matches_reference_golden(case, tmp_path):
     """Full GAIL / AIRL runs with `nn.Module` reward nets (autograd through the HIP ops, gradient accumulation
     over minibatches by repeated `backward()`, per-step `predict_processed` relabelling) against the
