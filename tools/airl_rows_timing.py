@@ -11,7 +11,7 @@ import bench  # noqa: E402
 from imitation_amd import _lib as L  # noqa: E402
 
 th.set_num_threads(1)
-tr, per = bench.build_variant("3_airl_ant_1024x16")
+tr, per = bench.build_variant("3_airl_ant_1024x16_mb1024")
 tr.train(3 * per)
 buf = th.zeros(16, dtype=th.int64, device="cuda")
 L.load().ia_airl_debug_timing(buf.data_ptr())
