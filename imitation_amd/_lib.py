@@ -52,7 +52,9 @@ class DiscStepArgs(C.Structure):
                 [("accumulate", C.c_int), ("adam", C.c_int)] +
                 [(n, C.c_float) for n in ("beta1", "beta2", "adam_eps", "weight_decay", "step_size", "bc2_sqrt")] +
                 [(n, C.c_void_p) for n in ("pnorm_mean", "pnorm_var", "pnorm_count")] + [("pnorm_dim", C.c_int)] +
-                [("fused_ws", C.c_void_p), ("pre_assembled", C.c_int)])
+                [("fused_ws", C.c_void_p), ("pre_assembled", C.c_int)] +
+                [("gp_e", C.c_void_p), ("gp_coef", C.c_float), ("gp_target", C.c_float), ("gp_ws", C.c_void_p),
+                 ("gp_out", C.c_void_p)])
 
 
 class HipExtensionMissing(RuntimeError):
@@ -121,6 +123,7 @@ _SIGS = {
     "ia_reduce_partials_adam": ([_P, _I, _L, _F, _P, _P, _P, _P, _F, _F, _F, _F, _F, _F, _P], C.c_int),
     "ia_disc_step_basic": ([C.POINTER(DiscStepArgs), _P], C.c_int),
     "ia_disc_fused_ws_floats": ([C.POINTER(MlpDesc), _I, _I], C.c_int64),
+    "ia_disc_fused_gp_ws_floats": ([C.POINTER(MlpDesc), _I, _I], C.c_int64),
     "ia_disc_fused_debug_timing": ([_P], C.c_int),
     "ia_disc_fused_tile_rows": ([_I], C.c_int),
     "ia_disc_assemble_round": ([C.POINTER(DiscStepArgs), _I, _L, _L, _L, _P], C.c_int),

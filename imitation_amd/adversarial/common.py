@@ -474,7 +474,7 @@ class AdversarialTrainer(abc.ABC):
         while isinstance(net, reward_nets.PredictProcessedWrapper):
             net = net.base
         if (self._module_net or not isinstance(net, reward_nets.BasicRewardNet) or self._needs_logp
-                or self.disc_grad_penalty_coef > 0.0
+                or (self.disc_grad_penalty_coef > 0.0 and net.fused_gp_ws(self.demo_batch_size) is None)
                 or self._torch_opt_params is not None or self.demo_minibatch_size != self.demo_batch_size
                 or not isinstance(self._disc_opt, HipAdam) or len(drawn) > self._quirk_idx_dev.shape[0]):
             return None
@@ -531,10 +531,19 @@ class AdversarialTrainer(abc.ABC):
                     self._policy_pass(sources, mb)
                 inline = reuse and not self._in_overlap
                 gp = self.disc_grad_penalty_coef > 0.0
+                # 128 / 256-wide fused update: the penalty's three tile passes + one split-K product ride in the same call
+                # and share its slab reduction (+ Adam); other shapes add it stack by stack afterwards
+                gp_in = gp and basic.fused_gp_ws(mb) is not None
+                gp_arg = ((self._gp_weights(mb), self.disc_grad_penalty_coef * scale, self.disc_grad_penalty_target)
+                          if gp_in else None)   # interpolation weights: torch's global CPU generator (only when enabled)
                 ws = basic.disc_step_c(sources, mb, scale, stats_dev, self._bce_ws, accumulate=not first,
-                                       adam=fuse_adam if (last and not gp) else None, pnorm=prn if inline else None,
-                                       pnorm_dim=pol.obs_dim if inline else 0, pre=pre)
-                if gp:
+                                       adam=fuse_adam if (last and (not gp or gp_in)) else None,
+                                       pnorm=prn if inline else None, pnorm_dim=pol.obs_dim if inline else 0, pre=pre,
+                                       gp=gp_arg)
+                if gp_in:
+                    self.last_grad_penalty = ws["gp_out"][0]
+                    gp = False   # (nothing left to add; the optimiser step below follows the ordinary rules)
+                elif gp:
                     self._add_grad_penalty(basic.mlp, ws["X_used"], ws["norm_used"], mb, scale)
                 if reuse and self._in_overlap:  # replayed on the generator stream after the PPO update
                     slot = self._quirk_moment_slot(ws["rn_ws"].numel())

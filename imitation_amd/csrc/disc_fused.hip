@@ -56,23 +56,39 @@ struct FusedArgs {
   float* part;                                         // [tiles][8] statistics partials
   float* P1; float* P3;                                // per-tile partial slabs: [tiles][H*D+H], [tiles][H+1]
   long long* dbg;                                      // measurement only (ia_disc_fused_debug_timing): phase clocks of block 0
+  // gradient-penalty passes (MODE 1 / 2 of the tile kernels; R = interpolated rows, X = the [2R, ldx] assembled batch)
+  const float* gp_e;                                   // [R] weights: x_hat_i = e_i X[i] + (1 - e_i) X[R + i]
+  unsigned long long* h2mask;                          // ballot(h2 > 0), the layout of h1mask
+  float* gp_C;                                         // [R][ldx] row coefficients d(coef / R sum pen) / d xn
+  float* gp_pen;                                       // [tiles] partial sums of (|grad_x D| - target)^2
+  float gp_coef, gp_target;
 };
 
 // x tile of rows [row0, row0+64): raw X normalised on the fly -> xs[row][ld], columns >= D and rows >= R zero.
 // (X - mean) / sqrt(var + eps): util/networks.py:91 as ia_running_norm_apply computes it.
-template <int BM>
-__device__ __forceinline__ void load_x_tile(const FusedArgs& a, int row0, float* __restrict__ xs, int ld, int tid) {
+// HAT: the row is the interpolate e X[i] + (1 - e) X[R + i] (ia_gp_interpolate's expression), then normalised.
+// RAW: rows of `X` as they are (the penalty's row coefficients).
+template <int BM, bool HAT = false, bool RAW = false>
+__device__ __forceinline__ void load_x_tile(const FusedArgs& a, const float* __restrict__ X, int row0,
+                                            float* __restrict__ xs, int ld, int tid) {
   const int quads = a.ldx >> 2;
   if (tid < BM * quads) {
     const int row = tid / quads, q = tid - row * quads;
     const int gi = row0 + row;
-    const f4 v = *reinterpret_cast<const f4*>(a.X + (long long)min(gi, a.R - 1) * a.ldx + 4 * q);
+    const long long ro = (long long)min(gi, a.R - 1) * a.ldx + 4 * q;
+    f4 v = *reinterpret_cast<const f4*>(X + ro);
+    if constexpr (HAT) {
+      const f4 g = *reinterpret_cast<const f4*>(X + (long long)a.R * a.ldx + ro);
+      const float w = a.gp_e[min(gi, a.R - 1)];
+      v.x = w * v.x + (1.f - w) * g.x; v.y = w * v.y + (1.f - w) * g.y;
+      v.z = w * v.z + (1.f - w) * g.z; v.w = w * v.w + (1.f - w) * g.w;
+    }
     const float vv[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int c = 4 * q + j;
       float x = vv[j];
-      if (a.mean != nullptr) {
+      if (!RAW && a.mean != nullptr) {
         const int cc = min(c, a.D - 1);
         x = (x - a.mean[cc]) / sqrtf(a.var[cc] + a.eps);
       }
@@ -137,7 +153,12 @@ __device__ __forceinline__ void chunk_mma(f32x16 (&acc)[TN], const AAt& a_at, co
   __builtin_amdgcn_sched_barrier(0);
 }
 
-template <int H, int BM>
+// MODE 0: the BCE update's forward (above). MODE 1: first pass of the gradient penalty -- the same two layers at the
+// interpolated rows, ballots of both ReLU masks, u2 = relu'(h2) * w3 (= dD/dz2) into the dh2 buffer; no loss.
+// MODE 2: second pass -- x := the row coefficients C, v1 = relu'(h1) * (C . W1^T) (into the h1 buffer: the operand of
+// dW2 += u2^T v1), t = v1 . W2^T, dW3 partial = column sums of relu'(h2) * t (biases get no gradient: with the masks
+// fixed the input gradient does not depend on them).
+template <int H, int BM, int MODE = 0>
 __global__ __launch_bounds__(BM * 8) void disc_fwd_kernel(FusedArgs a) {
   constexpr int NT = BM * 8, NW = NT / 64;
   constexpr int TN = H / 128;          // 32-column MFMA tiles per wave
@@ -191,10 +212,19 @@ __global__ __launch_bounds__(BM * 8) void disc_fwd_kernel(FusedArgs a) {
 #pragma unroll
   for (int t = 0; t < TN; ++t) {
     const int col = wn * WC + t * 32 + li;
-    b1v[t] = b1[col]; b2v[t] = b2[col]; w3v[t] = w3[col];
+    b1v[t] = MODE == 2 ? 0.f : b1[col]; b2v[t] = MODE == 2 ? 0.f : b2[col]; w3v[t] = w3[col];
   }
   const float b3v = b3[0];
-  load_x_tile<BM>(a, row0, xs, XP, tid);
+  unsigned int hm_lo = 0u, hm_hi = 0u, h2_lo = 0u, h2_hi = 0u;   // MODE 2: the first pass's ballots (word (t, r) in lane t*16+r)
+  if constexpr (MODE == 2) {
+    const long long mo = ((long long)blockIdx.x * NW + wave) * (TN * 16) + min(lane, TN * 16 - 1);
+    const unsigned long long w1 = a.h1mask[mo], w2 = a.h2mask[mo];
+    hm_lo = (unsigned int)w1; hm_hi = (unsigned int)(w1 >> 32);
+    h2_lo = (unsigned int)w2; h2_hi = (unsigned int)(w2 >> 32);
+  }
+  if constexpr (MODE == 0) load_x_tile<BM>(a, a.X, row0, xs, XP, tid);
+  else if constexpr (MODE == 1) load_x_tile<BM, true>(a, a.X, row0, xs, XP, tid);
+  else load_x_tile<BM, false, true>(a, a.gp_C, row0, xs, XP, tid);
   for (int e = tid; e < BM * (24 - a.ldx); e += NT) {  // columns [ldx, 24) of the K = 24 operand
     const int w = 24 - a.ldx;
     const int row = e / w;
@@ -234,16 +264,22 @@ __global__ __launch_bounds__(BM * 8) void disc_fwd_kernel(FusedArgs a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int row = wm * 32 + 4 * lh + rowoff(r);
-      const float v = fmaxf(acc[t][r] + b1v[t], 0.f);
-      h1s[row * LDH + col] = v;
-      // relu'(h1) for the backward tile kernel: one 64-bit ballot per accumulator register instead of a
-      // re-read of the tile; lane (t*16 + r) keeps word (t, r) -> ONE coalesced store per wave below
-      const unsigned long long m = __ballot(v > 0.f);
-      if (lane == t * 16 + r) mword = m;
+      if constexpr (MODE == 2) {
+        const unsigned int wlo = __builtin_amdgcn_readlane(hm_lo, t * 16 + r), whi = __builtin_amdgcn_readlane(hm_hi, t * 16 + r);
+        const bool on = (((lh ? whi : wlo) >> li) & 1u) != 0u;
+        h1s[row * LDH + col] = on ? acc[t][r] : 0.f;
+      } else {
+        const float v = fmaxf(acc[t][r] + b1v[t], 0.f);
+        h1s[row * LDH + col] = v;
+        // relu'(h1) for the backward tile kernel: one 64-bit ballot per accumulator register instead of a
+        // re-read of the tile; lane (t*16 + r) keeps word (t, r) -> ONE coalesced store per wave below
+        const unsigned long long m = __ballot(v > 0.f);
+        if (lane == t * 16 + r) mword = m;
+      }
       acc[t][r] = 0.f;
     }
   }
-  if (lane < TN * 16) a.h1mask[((long long)blockIdx.x * NW + wave) * (TN * 16) + lane] = mword;
+  if (MODE != 2 && lane < TN * 16) a.h1mask[((long long)blockIdx.x * NW + wave) * (TN * 16) + lane] = mword;
   __syncthreads();   // every wave is done with the W1 image: the ring is the ring from here on
   bstore(0);
   if (NCH > 1) bload(1);
@@ -273,12 +309,66 @@ __global__ __launch_bounds__(BM * 8) void disc_fwd_kernel(FusedArgs a) {
       }
       auto a_at = [&](int ks) { return Ar[c * FB_K + 2 * ks]; };
       chunk_mma<H, TN>(acc, a_at, bs + (c % NS) * BST + boff, lh);
-      if (tid < HQ && row0 + hrow < a.R) *reinterpret_cast<f4*>(a.h1 + (long long)(row0 + hrow) * H + hcol) = hv;
+      if (MODE != 1 && tid < HQ && row0 + hrow < a.R)
+        *reinterpret_cast<f4*>(a.h1 + (long long)(row0 + hrow) * H + hcol) = hv;
       __syncthreads();
     }
   }
   FUSED_STAMP(a, 4);
 
+  if constexpr (MODE == 1) {
+    // ---- first penalty pass: u2 = relu'(h2) * w3 (rows past R: 0) -> the dh2 tile; ballots of relu'(h2)
+    unsigned long long m2w = 0ull;
+#pragma unroll
+    for (int t = 0; t < TN; ++t) {
+      const int col = wn * WC + t * 32 + li;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = wm * 32 + 4 * lh + rowoff(r);
+        const bool on = fmaxf(acc[t][r] + b2v[t], 0.f) > 0.f;
+        h1s[row * LDH + col] = (on && row0 + row < a.R) ? w3v[t] : 0.f;
+        const unsigned long long m = __ballot(on);
+        if (lane == t * 16 + r) m2w = m;
+      }
+    }
+    if (lane < TN * 16) a.h2mask[((long long)blockIdx.x * NW + wave) * (TN * 16) + lane] = m2w;
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < BM * H / 4 / NT; ++i) {
+      const int e4 = tid + i * NT;
+      const int row = e4 / (H / 4), c4 = (e4 % (H / 4)) * 4;
+      const float* hp = h1s + row * LDH + c4;
+      f4 v;
+      v.x = hp[0]; v.y = hp[1]; v.z = hp[2]; v.w = hp[3];
+      if (row0 + row < a.R) *reinterpret_cast<f4*>(a.dh2 + (long long)(row0 + row) * H + c4) = v;
+    }
+    return;
+  }
+  if constexpr (MODE == 2) {
+    // ---- second penalty pass: dW3 partial = column sums of relu'(h2) * t over the tile's rows; db3 = 0
+#pragma unroll
+    for (int t = 0; t < TN; ++t) {
+      const int col = wn * WC + t * 32 + li;
+      float s = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const unsigned int wlo = __builtin_amdgcn_readlane(h2_lo, t * 16 + r), whi = __builtin_amdgcn_readlane(h2_hi, t * 16 + r);
+        const bool on = (((lh ? whi : wlo) >> li) & 1u) != 0u;
+        s += on ? acc[t][r] : 0.f;
+      }
+      s += __shfl_xor(s, 32, 64);
+      if (lh == 0) w3red[wm * H + col] = s;
+    }
+    __syncthreads();
+    if (tid < H) {
+      float s = w3red[tid];
+#pragma unroll
+      for (int g = 1; g < BM / 32; ++g) s += w3red[g * H + tid];
+      a.P3[(long long)blockIdx.x * (H + 1) + tid] = s;
+    }
+    if (tid == 0) a.P3[(long long)blockIdx.x * (H + 1) + H] = 0.f;
+    return;
+  }
   // ---- epilogue: logit, BCE, dlogit, statistics, dW3/db3 partials, dh2
   float h2[TN][16];
   float p[16];
@@ -372,7 +462,12 @@ __global__ __launch_bounds__(BM * 8) void disc_fwd_kernel(FusedArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------- K3
-template <int H, int BM>
+// MODE 1 (gradient penalty, between the two passes; BM = 32): dh2 := u2, so the chain leaves u1 = relu'(h1) * (u2 . W2)
+// = dD/dz1 in the LDS tile; then gn = u1 . W1 (the input gradient w.r.t. the normalised row: K = H split over the four
+// waves, partial tiles summed in fixed order), the row coefficients of gp_row_coeffs_kernel (mlp.hip) -- g = gn / sigma,
+// n = |g|, pen = (n - target)^2, C = coef / R * 2 (n - target) / n * g / sigma -- into the x tile (and HBM, for the
+// second pass), and the same tile product as the BCE pass: dW1 partial = u1^T . C (no bias column).
+template <int H, int BM, int MODE = 0>
 __global__ __launch_bounds__(BM * 8) void disc_bwd_kernel(FusedArgs a) {
   constexpr int NT = BM * 8, NW = NT / 64;
   constexpr int TN = H / 128;
@@ -421,16 +516,18 @@ __global__ __launch_bounds__(BM * 8) void disc_bwd_kernel(FusedArgs a) {
   // (lane l < TN*16 holds word l: one coalesced load; word (t, r) is broadcast with readlane where it is used)
   const unsigned long long hmw = a.h1mask[((long long)blockIdx.x * NW + wave) * (TN * 16) + min(lane, TN * 16 - 1)];
   const unsigned int hm_lo = (unsigned int)hmw, hm_hi = (unsigned int)(hmw >> 32);
-  load_x_tile<BM>(a, row0, xs, XP3, tid);
-  for (int e = tid; e < BM * (XP3 - 1 - a.ldx); e += NT) {  // columns [ldx, 32) of the B operand
-    const int w = XP3 - 1 - a.ldx;
-    const int row = e / w, c = a.ldx + e - row * w;
-    xs[row * XP3 + c] = 0.f;
+  if constexpr (MODE == 0) {
+    load_x_tile<BM>(a, a.X, row0, xs, XP3, tid);
+    for (int e = tid; e < BM * (XP3 - 1 - a.ldx); e += NT) {  // columns [ldx, 32) of the B operand
+      const int w = XP3 - 1 - a.ldx;
+      const int row = e / w, c = a.ldx + e - row * w;
+      xs[row * XP3 + c] = 0.f;
+    }
   }
   lstore(0);
   if (NCH > 1) gload(1);
   __syncthreads();
-  if (tid < BM) xs[tid * XP3 + D] = 1.f;  // after the tile writes above (column D < 32 is a zero column there)
+  if (MODE == 0 && tid < BM) xs[tid * XP3 + D] = 1.f;  // after the tile writes above (column D < 32 is a zero column there)
   FUSED_STAMP(a, 9);
 
   f32x16 acc[TN];
@@ -461,6 +558,55 @@ __global__ __launch_bounds__(BM * 8) void disc_bwd_kernel(FusedArgs a) {
     }
   __syncthreads();
   FUSED_STAMP(a, 11);
+  if constexpr (MODE == 1) {
+    static_assert(MODE == 0 || BM == 32, "the penalty pass runs 32-row tiles (four waves split K)");
+    // gn partials: wave w multiplies u1[:, 64w' ...] by W1 rows of its K quarter; B fragment = W1[k][c] from the
+    // padded image (columns >= D are zero there up to XP; lanes past it read column 0 and are masked)
+    float* gpart = bs;                                   // [NW][32][33] (the rings are free by now)
+    static_assert(NW * 32 * 33 <= NS * BST + NS * AST, "gn partial tiles fit the two rings");
+    {
+      constexpr int KQ = H / NW;                         // k range of this wave
+      f32x16 accg;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) accg[r] = 0.f;
+      const bool cok = li < D;
+#pragma unroll 8
+      for (int s2 = 0; s2 < KQ / 2; ++s2) {
+        const int k = wave * KQ + 2 * s2 + lh;
+        const float af = d1s[li * LDH + k];
+        const float w1 = a.W1P[k * XP + min(li, XP - 1)];
+        accg = __builtin_amdgcn_mfma_f32_32x32x2f32(af, cok ? w1 : 0.f, accg, 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) gpart[(wave * 32 + 4 * lh + rowoff(r)) * 33 + li] = accg[r];
+    }
+    __syncthreads();
+    float pen_w = 0.f;
+    {
+      const float inv = (a.mean != nullptr && li < D) ? 1.f / sqrtf(a.var[min(li, D - 1)] + a.eps) : 1.f;
+#pragma unroll
+      for (int it = 0; it < 32 / (2 * NW); ++it) {
+        const int row = wave * (32 / NW) + 2 * it + lh;  // two rows per wave and iteration: lane half = row, li = column
+        const float gn = ((gpart[row * 33 + li] + gpart[(32 + row) * 33 + li]) + gpart[(64 + row) * 33 + li]) +
+                         gpart[(96 + row) * 33 + li];
+        const float g = li < D ? gn * inv : 0.f;
+        float sq = g * g;
+        sq += __shfl_xor(sq, 16, 64); sq += __shfl_xor(sq, 8, 64); sq += __shfl_xor(sq, 4, 64);
+        sq += __shfl_xor(sq, 2, 64); sq += __shfl_xor(sq, 1, 64);
+        const float n = sqrtf(sq);
+        const bool valid = row0 + row < a.R;
+        const float kk = (valid && n > 0.f) ? a.gp_coef / (float)a.R * 2.f * (n - a.gp_target) / n : 0.f;
+        const float cv = li < D ? kk * gn * inv * inv : 0.f;
+        xs[row * XP3 + li] = cv;
+        if (valid && li < a.ldx) a.gp_C[(long long)(row0 + row) * a.ldx + li] = cv;
+        const float pr = valid ? (n - a.gp_target) * (n - a.gp_target) : 0.f;
+        pen_w += __shfl(pr, 0, 64) + __shfl(pr, 32, 64);
+      }
+    }
+    if (lane == 0) xs[wave * XP3 + 32] = pen_w;          // (column 32 of the x tile is padding)
+    __syncthreads();
+    if (tid == 0) a.gp_pen[blockIdx.x] = ((xs[32] + xs[XP3 + 32]) + xs[2 * XP3 + 32]) + xs[3 * XP3 + 32];
+  }
 
   // ---- [dW1 | db1] partial [H, D + 1] = dh1^T . [xn | 1] over the tile's BM rows: one 32-unit M tile per wave
   //      and pass; the slab image [W1 grad [H][D] | b1 grad [H]] is assembled in LDS (the ring is free by now) ...
@@ -701,6 +847,9 @@ struct ReduceArgs {
   int adam; float* p; float* m; float* v; float beta1, beta2, eps, wd, step_size, bc2_sqrt;
   const float* part; int tiles; int R; int n_expert; float loss_scale; float* stats;
   float* W2T; float* W1P; int H; int D;   // images of W2 / W1 the tile kernels read: refreshed with the Adam step
+  // gradient penalty: a second slab set per segment, summed behind the first (cnt2 = 0: none), and the penalty's mean
+  const float* src2[3]; long long stride2[3]; int cnt2[3];
+  const float* pen; int pen_tiles; int gp_rows; float* gp_out;
 };
 
 // 64 parameters per block; wave q folds quarter q of the element's slabs in slab order, the four quarter
@@ -729,6 +878,15 @@ __global__ __launch_bounds__(256) void disc_reduce_kernel(ReduceArgs a) {
     }
     if (tid == 6) a.stats[6] = (float)a.n_expert;
     if (tid == 7) a.stats[7] = (float)(a.R - a.n_expert);
+    if (a.gp_out != nullptr) {   // mean_i (|grad_x D(x_hat_i)| - target)^2 from the tiles' partial sums, fixed order
+      float v = 0.f;
+      for (int t = tid; t < a.pen_tiles; t += 256) v += a.pen[t];
+      for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+      __syncthreads();
+      if (lane == 0) sred[0][q] = v;
+      __syncthreads();
+      if (tid == 0) a.gp_out[0] = (((sred[0][0] + sred[0][1]) + sred[0][2]) + sred[0][3]) / (float)a.gp_rows;
+    }
     return;
   }
   const long long i = (long long)blockIdx.x * 64 + lane;
@@ -749,6 +907,21 @@ __global__ __launch_bounds__(256) void disc_reduce_kernel(ReduceArgs a) {
     for (int u = 0; u < 8; ++u) s += t[u];
   }
   for (; k < hi; ++k) s += src[(long long)k * st];
+  if (a.cnt2[seg] > 0) {
+    const float* src2 = a.src2[seg] + (ic - base);
+    const long long st2 = a.stride2[seg];
+    const int cnt2 = a.cnt2[seg];
+    const int lo2 = (int)((long long)q * cnt2 / 4), hi2 = (int)((long long)(q + 1) * cnt2 / 4);
+    int k2 = lo2;
+    for (; k2 + 8 <= hi2; k2 += 8) {
+      float t[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) t[u] = src2[(long long)(k2 + u) * st2];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += t[u];
+    }
+    for (; k2 < hi2; ++k2) s += src2[(long long)k2 * st2];
+  }
   red[q][lane] = s;
   __syncthreads();
   if (q != 0 || i >= a.n) return;
@@ -844,6 +1017,64 @@ inline FusedWs fused_ws_layout(const ia_mlp_desc* d, int R, float* base) {
   return w;
 }
 
+// Workspace of the fused gradient penalty over B interpolated rows (32-row tiles): the second pass's operands
+// v1 / u2 [B, H], the row coefficients C [B, ldx], both passes' mask ballots, per-tile partial slabs of the first and
+// last layer, penalty partial sums, split-K slabs of dW2 (the bias entries of those slabs are never written: the
+// caller zeroes the workspace once and they stay zero).
+struct GpWs {
+  float* v1; float* u2; float* C; unsigned long long* m1; unsigned long long* m2; float* P1; float* P3; float* pen;
+  float* partials; int splits; long long total;
+};
+
+inline GpWs gp_ws_layout(const ia_mlp_desc* d, int B, int ldx, float* base) {
+  const long long D = d->dims[0], H = d->dims[1];
+  const long long tiles = cdivi(B, 32), tot = H * D + H + H * H + H + H + 1;
+  GpWs w;
+  long long o = 0;
+  w.v1 = base + o; o += (long long)B * H;
+  w.u2 = base + o; o += (long long)B * H;
+  w.C = base + o; o += (long long)B * ldx;
+  o = (o + 3) / 4 * 4;
+  w.m1 = reinterpret_cast<unsigned long long*>(base + o); o += tiles * 4 * (H / 128) * 16 * 2;
+  w.m2 = reinterpret_cast<unsigned long long*>(base + o); o += tiles * 4 * (H / 128) * 16 * 2;
+  w.P1 = base + o; o += tiles * (H * D + H);
+  w.P3 = base + o; o += tiles * (H + 1);
+  w.pen = base + o; o += tiles;
+  o = (o + 3) / 4 * 4;
+  w.splits = B >= 8192 ? 32 : (B >= 256 ? B / 256 : 1);
+  w.partials = base + o; o += w.splits * tot;
+  w.total = o;
+  return w;
+}
+
+template <int H>
+int launch_gp_tiles(const FusedArgs& ga, int B, hipStream_t stream) {
+  constexpr int BM = 32;
+  constexpr size_t smem_f = sizeof(float) * (BM * (H + 1) + NS * FB_K * H + 4 * BM + BM + (BM / 32) * H + BM * XP);
+  constexpr size_t smem_b = sizeof(float) * (BM * XP3 + BM * (H + 1) + NS * FB_K * H + NS * BM * A_LD);
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(disc_fwd_kernel<H, BM, 1>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_f);
+    if (e != hipSuccess) return (int)e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(disc_fwd_kernel<H, BM, 2>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_f);
+    if (e != hipSuccess) return (int)e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(disc_bwd_kernel<H, BM, 1>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_b);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  const int tiles = cdivi(B, BM);
+  hipLaunchKernelGGL((disc_fwd_kernel<H, BM, 1>), dim3(tiles), dim3(BM * 8), smem_f, stream, ga);
+  IA_CHECK_LAUNCH();
+  hipLaunchKernelGGL((disc_bwd_kernel<H, BM, 1>), dim3(tiles), dim3(BM * 8), smem_b, stream, ga);
+  IA_CHECK_LAUNCH();
+  hipLaunchKernelGGL((disc_fwd_kernel<H, BM, 2>), dim3(tiles), dim3(BM * 8), smem_f, stream, ga);
+  IA_CHECK_LAUNCH();
+  return IA_OK;
+}
+
 int g_fused_bm = 64;   // rows per tile workgroup (tuning: ia_disc_fused_tile_rows)
 
 template <int H, int BM>
@@ -881,6 +1112,11 @@ extern "C" int ia_disc_fused_tile_rows(int rows) { g_fused_bm = rows == 32 ? 32 
 extern "C" int ia_disc_fused_debug_timing(void* device_buffer_16xi64) {
   g_fused_dbg = static_cast<long long*>(device_buffer_16xi64);
   return IA_OK;
+}
+
+extern "C" int64_t ia_disc_fused_gp_ws_floats(const ia_mlp_desc* d, int B, int ldx) {
+  if (B <= 0 || !fused_shape_ok(d, ldx)) return 0;
+  return gp_ws_layout(d, B, ldx, nullptr).total;
 }
 
 extern "C" int64_t ia_disc_fused_ws_floats(const ia_mlp_desc* d, int R, int ldx) {
@@ -969,7 +1205,7 @@ int ia_disc_step_fused(const ia_disc_step_args* a, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   const ia_mlp_desc* d = a->desc;
   const int R = a->n0 + a->n1, D = d->dims[0], H = d->dims[1];
-  if (a->fused_ws && ia_disc32_shape_ok(d, a->ldx)) return ia_disc32_step(a, stream_);
+  if (a->fused_ws && ia_disc32_shape_ok(d, a->ldx)) return a->gp_e ? IA_ERR_UNSUPPORTED : ia_disc32_step(a, stream_);
   if (!fused_shape_ok(d, a->ldx) || !a->fused_ws) return IA_ERR_UNSUPPORTED;
   const FusedWs w = fused_ws_layout(d, R, a->fused_ws);
   const int bm = g_fused_bm == 64 ? 64 : 32;
@@ -1025,7 +1261,39 @@ int ia_disc_step_fused(const ia_disc_step_args* a, void* stream_) {
     if ((rc = ia_launch_gemm(IA_GEMM_TN, g, stream))) return rc;
   }
 
+  // opt-in gradient penalty (grad_penalty.py's definition) on the interpolates of the batch's expert / generator rows:
+  // three tile launches + the split-K product u2^T v1; its slabs join the reduction below
+  const bool gp = a->gp_e != nullptr;
+  GpWs gw{};
+  int gtiles = 0;
+  if (gp) {
+    const int B = a->n0;
+    if (!a->gp_ws || !a->gp_out || a->n1 != B || a->n_expert != B) return IA_ERR_ARG;
+    gw = gp_ws_layout(d, B, a->ldx, a->gp_ws);
+    gtiles = cdivi(B, 32);
+    FusedArgs ga = fa;
+    ga.R = B; ga.h1 = gw.v1; ga.dh2 = gw.u2; ga.h1mask = gw.m1; ga.h2mask = gw.m2; ga.P1 = gw.P1; ga.P3 = gw.P3;
+    ga.gp_e = a->gp_e; ga.gp_C = gw.C; ga.gp_pen = gw.pen; ga.gp_coef = a->gp_coef; ga.gp_target = a->gp_target;
+    ga.dbg = nullptr;
+    if ((rc = H == 256 ? launch_gp_tiles<256>(ga, B, stream) : launch_gp_tiles<128>(ga, B, stream))) return rc;
+    const int kps = (((B + gw.splits - 1) / gw.splits) + 31) / 32 * 32;
+    IaGemm g{};
+    g.A = gw.u2; g.lda = H;
+    g.B = gw.v1; g.ldb = H;
+    g.M = H; g.N = H; g.K = B;
+    g.C = gw.partials + n1; g.ldc = H;
+    g.splits = gw.splits; g.k_per_split = kps; g.c_split_stride = tot;
+    g.dbias = nullptr; g.dbias_split_stride = tot;
+    if ((rc = ia_launch_gemm(IA_GEMM_TN, g, stream))) return rc;
+  }
+
   ReduceArgs ra{};
+  if (gp) {
+    ra.src2[0] = gw.P1; ra.stride2[0] = n1; ra.cnt2[0] = gtiles;
+    ra.src2[1] = gw.partials + n1; ra.stride2[1] = tot; ra.cnt2[1] = gw.splits;
+    ra.src2[2] = gw.P3; ra.stride2[2] = n3; ra.cnt2[2] = gtiles;
+    ra.pen = gw.pen; ra.pen_tiles = gtiles; ra.gp_rows = a->n0; ra.gp_out = a->gp_out;
+  }
   ra.src[0] = w.P1; ra.stride[0] = n1; ra.cnt[0] = tiles; ra.seg_end[0] = n1;
   ra.src[1] = a->partials + n1; ra.stride[1] = tot; ra.cnt[1] = splits; ra.seg_end[1] = n1 + n2;
   ra.src[2] = w.P3; ra.stride[2] = n3; ra.cnt[2] = tiles; ra.seg_end[2] = tot;

@@ -1012,6 +1012,7 @@ int ia_disc_step_basic(const ia_disc_step_args* a, void* stream) {
   // D -> H -> H -> 1 ReLU stacks with a fused workspace take the five-launch path (disc_fused.hip)
   if (a->fused_ws != nullptr && ia_disc_fused_ws_floats(a->desc, a->n0 + a->n1, a->ldx) > 0)
     return ia_disc_step_fused(a, stream);
+  if (a->gp_e != nullptr) return IA_ERR_UNSUPPORTED;   // the fused penalty exists on the 128 / 256-wide tile path only
   const int R = a->n0 + a->n1;
   const int D = a->desc->dims[0];
   int rc;

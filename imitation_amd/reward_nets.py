@@ -333,11 +333,28 @@ class BasicRewardNet(RewardNet):
             ws["args"] = a
         return ws
 
+    def fused_gp_ws(self, mb: int) -> Optional[th.Tensor]:
+        """Workspace of the gradient penalty fused into the 128 / 256-wide tile update over `mb` interpolated rows
+        (None: the shape takes `grad_penalty.penalty_and_param_grad`, stack by stack)."""
+        import ctypes as C
+        mlp = self.mlp
+        ws = self._step_workspace(2 * mb)
+        if "gp_ws" not in ws:
+            nf = 0
+            if ws["fused_ws"] is not None:
+                nf = int(L.load().ia_disc_fused_gp_ws_floats(C.byref(mlp.desc), mb, mlp.ldx))
+            ws["gp_ws"] = th.zeros(nf, device=mlp.flat.device) if nf > 0 else None
+            ws["gp_out"] = th.zeros(1, device=mlp.flat.device)
+        return ws["gp_ws"]
+
     def disc_step_c(self, sources, n_expert: int, loss_scale: float, stats: th.Tensor, bce_ws: th.Tensor,
-                    accumulate: bool, adam=None, pnorm: Optional[RunningNorm] = None, pnorm_dim: int = 0, pre=None):
+                    accumulate: bool, adam=None, pnorm: Optional[RunningNorm] = None, pnorm_dim: int = 0, pre=None,
+                    gp=None):
         """One discriminator minibatch through the single C entry `ia_disc_step_basic` (assemble ->
         norm -> forward -> BCE -> backward -> reduce [-> Adam]): ONE host call instead of ~25.
-        Returns the workspace dict (logits in ws["out"], slab moments in ws["rn_ws"])."""
+        Returns the workspace dict (logits in ws["out"], slab moments in ws["rn_ws"]).
+        `gp = (e [n_expert] device weights, coef, target)`: the opt-in gradient penalty inside the same update
+        (`fused_gp_ws(n_expert)` must not be None); its mean lands in `ws["gp_out"]`."""
         import ctypes as C
         (t0, i0, n0), (t1, i1, n1) = sources
         R = n0 + n1
@@ -387,6 +404,15 @@ class BasicRewardNet(RewardNet):
         a.pnorm_var = L.ptr(pnorm.running_var) if use_p else None
         a.pnorm_count = L.ptr(pnorm.count) if use_p else None
         a.pnorm_dim = pnorm_dim if use_p else 0
+        a.gp_e = None
+        if gp is not None:
+            e, coef, target = gp
+            gws = self.fused_gp_ws(n_expert)
+            if gws is None or n0 != n1 or n0 != n_expert or e.numel() != n_expert:
+                raise RuntimeError("the fused gradient penalty needs equal expert / generator halves on the 128 / 256-wide "
+                                   "fused update")
+            a.gp_e, a.gp_coef, a.gp_target = L.ptr(e), float(coef), float(target)
+            a.gp_ws, a.gp_out = L.ptr(gws), L.ptr(ws["gp_out"])
         L.call("ia_disc_step_basic", C.byref(a), L.stream())
         # what this step read / normalised with (the opt-in gradient penalty evaluates the net at the same point)
         ws["X_used"] = ws["X"] if pre is None else pre[0]["X_all"][pre[1]]

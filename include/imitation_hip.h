@@ -179,10 +179,18 @@ typedef struct {
    * and fused_ws holds current W2T / W1 images (ia_disc_fused_prepare once, then kept by the Adam steps):
    * the update is four launches. */
   int pre_assembled;
+  /* fused path, H in {128, 256} only; OPT-IN extension (the reference has no gradient penalty): when gp_e is
+   * set (n0 == n1 == n_expert required) the update also carries coef * mean_i (|grad_x D(x_hat_i)|_2 - target)^2 with
+   * x_hat_i = e_i x_expert_i + (1 - e_i) x_gen_i (rows of X, normalised with the statistics the forward used), in three
+   * more tile launches + one split-K product whose slabs join the same reduction (+ Adam). gp_ws:
+   * ia_disc_fused_gp_ws_floats(desc, n0, ldx) floats ZEROED once by the caller; gp_out[0] = the mean penalty. */
+  const float* gp_e; float gp_coef; float gp_target; float* gp_ws; float* gp_out;
 } ia_disc_step_args;
 int ia_disc_step_basic(const ia_disc_step_args* a, void* stream);
 /* 0 when the fused path does not cover the shape (the call then runs the general path). */
 int64_t ia_disc_fused_ws_floats(const ia_mlp_desc* d, int R, int ldx);
+/* 0 when the fused gradient penalty does not cover the shape (B = interpolated rows = expert rows of an update). */
+int64_t ia_disc_fused_gp_ws_floats(const ia_mlp_desc* d, int B, int ldx);
 /* A whole round's batch assembly in ONE launch (fused shapes): for k < n_updates, rows idx0 + k*idx_stride /
  * idx1 + k*idx_stride of a's two tables -> X + k*x_stride, RunningNorm slab moments -> rn_ws + k*rn_stride
  * (strides in elements; no statistics are touched: apply them with ia_running_norm_merge_seq, whose snapshots

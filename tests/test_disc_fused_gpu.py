@@ -194,3 +194,76 @@ def test_gradient_accumulation_through_the_narrow_fused_step():
                             accumulate=h > 0)
     th.cuda.synchronize()
     th.testing.assert_close(net.mlp.grad.cpu(), whole, rtol=2e-4, atol=2e-6)
+
+
+@pytest.mark.parametrize("hid,B,norm,od", [((256, 256), 256, True, 17), ((128, 128), 200, True, 17),
+                                           ((256, 256), 1000, False, 11), ((256, 256), 4096, True, 17)])
+def test_fused_gradient_penalty_matches_float64_double_backward(hid, B, norm, od):
+    """The opt-in gradient penalty inside the 128 / 256-wide fused update (`disc_fwd_kernel` / `disc_bwd_kernel`
+    MODE 1 / 2): gradient of [BCE + coef * mean (|grad_x D(x_hat)| - target)^2] against a float64 double-backward graph,
+    the penalty's mean, and -- same call with the coefficient's passes switched off -- that the penalty is what
+    differs."""
+    th.manual_seed(11)
+    ad = 6
+    osp = spaces.Box(-np.inf, np.inf, (od,), np.float32)
+    asp = spaces.Box(-1, 1, (ad,), np.float32)
+    kw = dict(normalize_input_layer=p.RunningNorm) if norm else {}
+    net = reward_nets.BasicRewardNet(osp, asp, hid_sizes=hid, **kw).to(DEV)
+    mlp = net.mlp
+    with th.no_grad():   # small default-initialised weights leave the input gradient far below the target: scale up
+        mlp.flat.mul_(2.5)
+    R = 2 * B
+    assert net.fused_gp_ws(B) is not None
+    e_tab, e_host = _tables(5000, od, ad, False, 1)
+    g_tab, g_host = _tables(5000, od, ad, False, 2)
+    rng = np.random.default_rng(5)
+    e_idx, g_idx = rng.integers(0, 5000, B), rng.integers(0, 5000, B)
+    if norm:
+        warm = th.as_tensor(rng.standard_normal((77, mlp.dims[0])).astype(np.float32) * 0.5 + 0.2).to(DEV)
+        mlp.norm.update_stats(warm)
+    params0 = mlp.flat.detach().cpu().double().clone()
+    stats = th.zeros(8, device=DEV)
+    bce_ws = th.zeros(int(L.load().ia_bce_ws_floats(R)), device=DEV)
+    src = [(e_tab, th.as_tensor(e_idx).to(DEV), B), (g_tab, th.as_tensor(g_idx).to(DEV), B)]
+    e = th.rand(B)
+    coef, target = 3.0, 1.0
+    with networks.training(net):
+        ws = net.disc_step_c(src, B, 1.0, stats, bce_ws, accumulate=False, adam=None, gp=(e.to(DEV), coef, target))
+    th.cuda.synchronize()
+    got = mlp.grad.detach().cpu().double().clone()
+    pen_got = float(ws["gp_out"][0])
+    mean, var = (mlp.norm.running_mean.cpu().double(), mlp.norm.running_var.cpu().double()) if norm else (None, None)
+
+    flags = (True, True, False, False)
+    X = th.as_tensor(np.concatenate([_concat(e_host, e_idx, flags, ad, False),
+                                     _concat(g_host, g_idx, flags, ad, False)])).double()
+    D, H = mlp.dims[0], hid[0]
+    P = params0.clone().requires_grad_(True)
+    o = 0
+    W1 = P[o:o + H * D].view(H, D); o += H * D
+    b1 = P[o:o + H]; o += H
+    W2 = P[o:o + H * H].view(H, H); o += H * H
+    b2 = P[o:o + H]; o += H
+    W3 = P[o:o + H].view(1, H); o += H
+    b3 = P[o:o + 1]
+
+    def f(x):
+        xn = (x - mean) / th.sqrt(var + 1e-5) if norm else x
+        return (th.relu(th.relu(xn @ W1.T + b1) @ W2.T + b2) @ W3.T + b3).reshape(-1)
+
+    y = th.cat([th.ones(B), th.zeros(B)]).double()
+    bce = th.nn.functional.binary_cross_entropy_with_logits(f(X), y)
+    xh = (e.double()[:, None] * X[:B] + (1 - e.double()[:, None]) * X[B:]).requires_grad_(True)
+    (gx,) = th.autograd.grad(f(xh).sum(), xh, create_graph=True)
+    pen_rows = (gx.norm(dim=1) - target) ** 2
+    (g_bce,) = th.autograd.grad(bce, P, retain_graph=True)
+    (g_pen,) = th.autograd.grad(coef * pen_rows.mean(), P)
+    assert float(pen_rows.mean()) > 1e-3, "degenerate case: no penalty"
+    np.testing.assert_allclose(pen_got, float(pen_rows.mean()), rtol=5e-5)
+    scale = float(g_pen.abs().max())
+    # the penalty's share of the gradient, then the whole
+    th.testing.assert_close(got - g_bce, g_pen, rtol=2e-3, atol=3e-5 * scale)
+    th.testing.assert_close(got, g_bce + g_pen, rtol=5e-4, atol=2e-5 * max(scale, float(g_bce.abs().max())))
+    assert float((g_pen[o - H - H * H - H:o - H - H].abs()).max()) > 0     # W2 entries carry a penalty gradient
+    # bias entries get no penalty gradient (masks fixed): the float64 graph agrees
+    assert float(g_pen[H * D:H * D + H].abs().max()) == 0.0

@@ -194,7 +194,7 @@ def test_gradient_penalty_on_the_fused_shape_and_unsupported_nets(tmp_path):
     cfg = dict(harness.CASES["gail_fused"])
     tr, _ = harness.build_trainer("hip", cfg, str(tmp_path / "f"), device="cuda")
     tr.disc_grad_penalty_coef = 1.0
-    tr.train(2 * cfg["n_envs"] * cfg["n_steps"])        # pipelined rounds fall back to per-update assembly
+    tr.train(2 * cfg["n_envs"] * cfg["n_steps"])        # pipelined rounds, round-level assembly, penalty inside the update
     assert np.isfinite(float(tr.last_grad_penalty))
     assert all(bool(th.isfinite(v.float()).all()) for v in tr._reward_net.state_dict().values())
     # AIRL through an autograd `nn.Module` net: not built (the state-holder shaped net is, see the AIRL test above)
@@ -217,3 +217,31 @@ def test_interpolation_weights_ring_reproduces_the_generator_stream(tmp_path):
     ref = [th.rand(64) for _ in range(75)]
     for g, r in zip(kept + got[5:], ref):
         assert th.equal(g.cpu(), r)
+
+
+def test_fused_penalty_trainer_equals_the_stack_by_stack_penalty(tmp_path, monkeypatch):
+    """GAIL on the 256-wide fused update with the penalty on: the penalty computed inside the update (tile passes sharing
+    the slab reduction and Adam, round-level assembly kept) against the same trainer with the fused form switched off
+    (`grad_penalty.penalty_and_param_grad` after each update, then the optimiser step) -- same interpolation weights
+    from torch's generator, parameters within fp32 summation-order distance after two rounds."""
+    from imitation_amd import reward_nets
+
+    cfg = dict(harness.CASES["gail_fused"])
+    outs = {}
+    for name in ("fused", "stacks"):
+        if name == "stacks":
+            monkeypatch.setattr(reward_nets.BasicRewardNet, "fused_gp_ws", lambda self, mb: None)
+        tr, _ = harness.build_trainer("hip", cfg, str(tmp_path / name), device="cuda")
+        tr.disc_grad_penalty_coef = 4.0
+        th.manual_seed(123)
+        tr.train(2 * cfg["n_envs"] * cfg["n_steps"])
+        th.cuda.synchronize()
+        outs[name] = ({k: v.detach().cpu().numpy().copy() for k, v in tr._reward_net.state_dict().items()},
+                      float(tr.last_grad_penalty))
+    a, b = outs["fused"], outs["stacks"]
+    for k in a[0]:
+        if k.endswith("count"):
+            assert np.array_equal(a[0][k], b[0][k]), k
+        else:
+            np.testing.assert_allclose(a[0][k], b[0][k], rtol=2e-4, atol=5e-5, err_msg=k)
+    np.testing.assert_allclose(a[1], b[1], rtol=1e-3)
