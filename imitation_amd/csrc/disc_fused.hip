@@ -54,6 +54,7 @@ struct FusedArgs {
   unsigned long long* h1mask;                          // [tiles][8 waves][TN*16]: ballot(h1 > 0) per accumulator register
   float* logits; float* dlogits; int n_expert; float loss_scale;
   float* part;                                         // [tiles][8] statistics partials
+  float* dump;                                         // [1024]: where the slice stores of rows past R go (disc_fb_kernel)
   float* P1; float* P3;                                // per-tile partial slabs: [tiles][H*D+H], [tiles][H+1]
   long long* dbg;                                      // measurement only (ia_disc_fused_debug_timing): phase clocks of block 0
   // gradient-penalty passes (MODE 1 / 2 of the tile kernels; R = interpolated rows, X = the [2R, ldx] assembled batch)
@@ -158,6 +159,67 @@ __device__ __forceinline__ void chunk_mma(f32x16 (&acc)[TN], const AAt& a_at, co
 // MODE 2: second pass -- x := the row coefficients C, v1 = relu'(h1) * (C . W1^T) (into the h1 buffer: the operand of
 // dW2 += u2^T v1), t = v1 . W2^T, dW3 partial = column sums of relu'(h2) * t (biases get no gradient: with the masks
 // fixed the input gradient does not depend on them).
+// The same chunk in two halves, for loops that request chunk c+1's fragments BEFORE the MFMAs of chunk c issue (register
+// double buffering: the LDS round trip of a chunk hides behind the previous chunk's 1 024 matrix-pipe cycles instead of
+// relying on the SIMD's other wave being out of phase -- the per-chunk barrier puts the two back in phase every time).
+template <int H, int TN, class AAt>
+__device__ __forceinline__ void chunk_frags(float (&af)[FB_K / 2], float (&bf)[FB_K / 2][TN], const AAt& a_at,
+                                            const float* __restrict__ Bs, int lh) {
+#pragma unroll
+  for (int ks = 0; ks < FB_K / 2; ++ks) {
+    af[ks] = a_at(ks);
+#pragma unroll
+    for (int t = 0; t < TN; ++t) bf[ks][t] = Bs[(2 * ks + lh) * H + t * 32];
+  }
+  __builtin_amdgcn_sched_barrier(0);
+}
+template <int TN>
+__device__ __forceinline__ void chunk_mfmas(f32x16 (&acc)[TN], const float (&af)[FB_K / 2], const float (&bf)[FB_K / 2][TN]) {
+#pragma unroll
+  for (int ks = 0; ks < FB_K / 2; ++ks)
+#pragma unroll
+    for (int t = 0; t < TN; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[ks], bf[ks][t], acc[t], 0, 0, 0);
+  __builtin_amdgcn_sched_barrier(0);
+}
+// MFMAs of the chunk in flight with the NEXT chunk's fragment reads dealt between them: one MFMA (64 pipe cycles), then
+// two LDS reads, ... -- a wave can have 15 LDS operations outstanding, so 24 reads issued in one burst stall the issue of
+// the first MFMA until the first dozen return.
+template <int H, int TN, class AAt>
+__device__ __forceinline__ void chunk_mfmas_and_next_frags(f32x16 (&acc)[TN], const float (&af)[FB_K / 2],
+                                                           const float (&bf)[FB_K / 2][TN], float (&afn)[FB_K / 2],
+                                                           float (&bfn)[FB_K / 2][TN], const AAt& a_nx,
+                                                           const float* __restrict__ Bs, int lh) {
+#pragma unroll
+  for (int ks = 0; ks < FB_K / 2; ++ks) {
+    afn[ks] = a_nx(ks);
+#pragma unroll
+    for (int t = 0; t < TN; ++t) bfn[ks][t] = Bs[(2 * ks + lh) * H + t * 32];
+  }
+#pragma unroll
+  for (int ks = 0; ks < FB_K / 2; ++ks)
+#pragma unroll
+    for (int t = 0; t < TN; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[ks], bf[ks][t], acc[t], 0, 0, 0);
+}
+// Issue order of one loop iteration of disc_fb_kernel (everything between two barriers is one scheduling region): the
+// chunk's MFMAs lead -- their operands have been in registers since the previous iteration -- and the iteration's other
+// work is dealt between them: the ring write of chunk g+2 (NWR 16-byte LDS writes), the request of chunk g+3 (NWR
+// global loads), the LDS reads (next chunk's fragments + the 16-byte slice of the tile that trickles out to HBM), the
+// slice's store.
+template <int TN, int NWR>
+__device__ __forceinline__ void schedule_iteration() {
+  __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+  __builtin_amdgcn_sched_group_barrier(0x200, NWR, 0);
+  __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+  __builtin_amdgcn_sched_group_barrier(0x020, NWR, 0);
+#pragma unroll
+  for (int i = 2; i < (FB_K / 2) * TN; ++i) {
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // one MFMA
+    __builtin_amdgcn_sched_group_barrier(0x100, TN == 2 ? 2 : 3, 0);   // LDS reads
+  }
+  __builtin_amdgcn_sched_group_barrier(0x040, 1, 0);
+  __builtin_amdgcn_sched_barrier(0);
+}
+
 template <int H, int BM, int MODE = 0>
 __global__ __launch_bounds__(BM * 8) void disc_fwd_kernel(FusedArgs a) {
   constexpr int NT = BM * 8, NW = NT / 64;
@@ -293,24 +355,24 @@ __global__ __launch_bounds__(BM * 8) void disc_fwd_kernel(FusedArgs a) {
     const float* Ar = h1s + (wm * 32 + li) * LDH + lh;
     const int boff = wn * WC + li;
     // the tile's h1 goes out to HBM (for the weight gradients) in slices, one per chunk, read back from LDS
-    // row-major: 16-byte coalesced stores trickling beside the MFMAs instead of one burst of all workgroups
-    constexpr int HQ = BM * H / NCH / 4;     // 16-byte pieces per chunk
-    static_assert(HQ <= NT, "one 16-byte piece per thread and chunk at most");
+    // row-major: coalesced stores trickling beside the MFMAs instead of one burst of all workgroups. 8 bytes per
+    // thread and chunk, UNCONDITIONALLY (rows past R land in a dump slot): behind a branch the compiler cannot count
+    // the store in vmcnt and makes the next ring write wait for the store's acknowledgement (see disc_fb_kernel)
+    static_assert(BM * H / NCH / 2 == NT, "one 8-byte piece per thread and chunk");
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
       if (c + 1 < NCH) bstore(c + 1);
       if (c + 2 < NCH) bload(c + 2);
-      f4 hv;
-      const int e4 = c * HQ + min(tid, HQ - 1);
-      const int hrow = e4 / (H / 4), hcol = (e4 % (H / 4)) * 4;
-      {
-        const float* hp = h1s + hrow * LDH + hcol;
-        hv.x = hp[0]; hv.y = hp[1]; hv.z = hp[2]; hv.w = hp[3];
-      }
+      const int e2 = c * NT + tid;
+      const int hrow = e2 / (H / 2), hcol = (e2 % (H / 2)) * 2;
+      float2 hv;
+      if constexpr (MODE != 1) { hv.x = h1s[hrow * LDH + hcol]; hv.y = h1s[hrow * LDH + hcol + 1]; }
       auto a_at = [&](int ks) { return Ar[c * FB_K + 2 * ks]; };
       chunk_mma<H, TN>(acc, a_at, bs + (c % NS) * BST + boff, lh);
-      if (MODE != 1 && tid < HQ && row0 + hrow < a.R)
-        *reinterpret_cast<f4*>(a.h1 + (long long)(row0 + hrow) * H + hcol) = hv;
+      if constexpr (MODE != 1) {
+        float* dst = row0 + hrow < a.R ? a.h1 + (long long)(row0 + hrow) * H + hcol : a.dump + 2 * tid;
+        *reinterpret_cast<float2*>(dst) = hv;
+      }
       __syncthreads();
     }
   }
@@ -635,6 +697,329 @@ __global__ __launch_bounds__(BM * 8) void disc_bwd_kernel(FusedArgs a) {
   }
   __syncthreads();
   // ... and leaves in 16-byte coalesced stores (a dword-per-lane store of 23-float rows is store-issue bound)
+  for (int e = tid; e < (int)(n1 / 4); e += NT)
+    reinterpret_cast<f4*>(P1)[e] = reinterpret_cast<const f4*>(bs)[e];
+  FUSED_STAMP(a, 12);
+}
+
+// ------------------------------------------------------------------------------------------- K2 + K3 in one launch
+// The BCE update's forward AND backward of a tile in one workgroup (round 3; the two-launch form above stays for the
+// gradient penalty's passes and as `ia_disc_fused_split_tiles(1)`): after the forward epilogue the dh2 tile sits in LDS
+// where h1 was, so the input-gradient chain takes its A operand from there -- no dh2 re-read from HBM, no second
+// x / mask load, no second dispatch; dh2 trickles out to HBM beside the chain's MFMAs exactly as h1 does beside layer 2
+// (the weight-gradient GEMM needs both), W2's first chunks are requested while the BCE epilogue runs, and relu'(h1)
+// stays in the registers that took the ballots. Same arithmetic, same summation order as K2 + K3: bit-identical
+// outputs (tests/test_disc_fused_gpu.py compares the two forms).
+template <int H, int BM>
+__global__ __launch_bounds__(BM * 8) void disc_fb_kernel(FusedArgs a) {
+  constexpr int NT = BM * 8, NW = NT / 64;
+  constexpr int TN = H / 128;
+  constexpr int WC = TN * 32;
+  constexpr int LDH = H + 1;
+  constexpr int NCH = H / FB_K;
+  constexpr int BST = FB_K * H;
+  constexpr int BV = BST / 4 / NT;
+  static_assert(BST % (4 * NT) == 0, "B chunk must divide among the threads");
+  constexpr int NR = 3;                // ring stages: chunk g sits in stage g % 3 (g < NCH: W2T chunk g, then W2 chunk g - NCH)
+  static_assert(H * XP <= NR * BST, "the W1 image borrows the ring during layer 1");
+  static_assert(H * 24 + H <= NR * BST, "the first-layer slab image borrows the ring at the end");
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* h1s = smem;                   // [BM][LDH]   h1 tile -> dh2 tile -> dh1 tile
+  float* bs = h1s + BM * LDH;          // NR x [FB_K][H] ring (W2T chunks, then W2 chunks); W1 image during layer 1;
+                                       // the P1 slab image at the end
+  float* red = bs + NR * BST;          // [4][BM] logit partials per column group
+  float* dls = red + 4 * BM;           // [BM] dlogit of the tile's rows
+  float* w3red = dls + BM;             // [BM/32][H] dW3 partials per row group
+  float* xs = w3red + (BM / 32) * H;   // [BM][XP3]: xn | 0 ... (layer 1's A operand; later [xn | 1 | 0 ...] as dW1's B)
+  float* w1s = bs;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const int wm = wave >> 2, wn = wave & 3;
+  const int row0 = blockIdx.x * BM;
+  const int D = a.D;
+  const float* W1 = a.params;
+  const float* b1 = W1 + (long long)H * D;
+  const float* W2 = b1 + H;
+  const float* b2 = W2 + (long long)H * H;
+  const float* w3 = b2 + H;
+  const float* b3 = w3 + H;
+
+  // ---- prologue: every first-use operand is requested up front (coalesced 16-byte copies)
+  FUSED_STAMP(a, 0);
+  // chunk stream g = 0 .. 2 NCH - 1 through registers (requested three iterations ahead of its MFMAs) and the ring
+  f4 rb[BV], rb1[BV];
+  auto bload = [&](f4 (&r)[BV], int g) {
+    const float* src = g < NCH ? a.W2T + (long long)g * BST : W2 + (long long)(g - NCH) * BST;
+#pragma unroll
+    for (int i = 0; i < BV; ++i) r[i] = *reinterpret_cast<const f4*>(src + (long long)(tid + i * NT) * 4);
+  };
+  auto bstore = [&](const f4 (&r)[BV], int g) {
+    float* S = bs + (g % NR) * BST;
+#pragma unroll
+    for (int i = 0; i < BV; ++i) *reinterpret_cast<f4*>(S + (tid + i * NT) * 4) = r[i];
+  };
+  constexpr int W1Q = H * XP / 4;                      // float4 of the W1 image
+  constexpr int W1V = (W1Q + NT - 1) / NT;
+  f4 w1v[W1V];
+#pragma unroll
+  for (int i = 0; i < W1V; ++i) w1v[i] = reinterpret_cast<const f4*>(a.W1P)[min(tid + i * NT, W1Q - 1)];
+  float b1v[TN], b2v[TN], w3v[TN];
+#pragma unroll
+  for (int t = 0; t < TN; ++t) {
+    const int col = wn * WC + t * 32 + li;
+    b1v[t] = b1[col]; b2v[t] = b2[col]; w3v[t] = w3[col];
+  }
+  const float b3v = b3[0];
+  load_x_tile<BM>(a, a.X, row0, xs, XP3, tid);
+  for (int e = tid; e < BM * (XP3 - 1 - a.ldx); e += NT) {  // columns [ldx, 32)
+    const int w = XP3 - 1 - a.ldx;
+    const int row = e / w, c = a.ldx + e - row * w;
+    xs[row * XP3 + c] = 0.f;
+  }
+  bload(rb, 0);                                        // stay in registers until layer 1 is done with the ring
+  bload(rb1, 1);
+#pragma unroll
+  for (int i = 0; i < W1V; ++i)
+    if (tid + i * NT < W1Q) reinterpret_cast<f4*>(w1s)[tid + i * NT] = w1v[i];
+  __syncthreads();
+  FUSED_STAMP(a, 1);
+
+  // ---- layer 1: h1 = relu(xn . W1^T + b1), K = 24
+  f32x16 acc[TN];
+#pragma unroll
+  for (int t = 0; t < TN; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+  {
+    float af[12], bf[12][TN];
+#pragma unroll
+    for (int ks = 0; ks < 12; ++ks) {
+      af[ks] = xs[(wm * 32 + li) * XP3 + 2 * ks + lh];
+#pragma unroll
+      for (int t = 0; t < TN; ++t) bf[ks][t] = w1s[(wn * WC + t * 32 + li) * XP + 2 * ks + lh];
+    }
+#pragma unroll
+    for (int ks = 0; ks < 12; ++ks)
+#pragma unroll
+      for (int t = 0; t < TN; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[ks], bf[ks][t], acc[t], 0, 0, 0);
+  }
+  FUSED_STAMP(a, 2);
+  unsigned long long mword = 0ull;                     // relu'(h1): word (t, r) in lane t*16 + r, kept for the backward
+#pragma unroll
+  for (int t = 0; t < TN; ++t) {
+    const int col = wn * WC + t * 32 + li;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = wm * 32 + 4 * lh + rowoff(r);
+      const float v = fmaxf(acc[t][r] + b1v[t], 0.f);
+      h1s[row * LDH + col] = v;
+      const unsigned long long m = __ballot(v > 0.f);
+      if (lane == t * 16 + r) mword = m;
+      acc[t][r] = 0.f;
+    }
+  }
+  __syncthreads();   // every wave is done with the W1 image: the ring is the ring from here on
+  bstore(rb, 0);
+  bstore(rb1, 1);
+  bload(rb, 2);
+  __syncthreads();
+  FUSED_STAMP(a, 3);
+
+  // ---- layer 2 (see disc_fwd_kernel); its last iteration requests the backward chain's first W2 chunk
+  // the tile's h1 (layer 2) / dh2 (backward chain) leaves for HBM in slices, one per chunk: EVERY thread moves 8 bytes
+  // (read from LDS at the top of the iteration, stored behind the MFMAs) -- with 16-byte pieces only half of the waves
+  // had the LDS round trip + store at the end of their iteration, and the other half waited for them at the barrier
+  static_assert(BM * H / NCH / 2 == NT, "one 8-byte piece per thread and chunk");
+  const float* Ar = h1s + (wm * 32 + li) * LDH + lh;
+  const int boff = wn * WC + li;
+  float fa[2][FB_K / 2], fb[2][FB_K / 2][TN];          // fragments of the chunk in flight / the next one
+  {
+    auto a_at = [&](int ks) { return Ar[2 * ks]; };
+    chunk_frags<H, TN>(fa[0], fb[0], a_at, bs + boff, lh);
+  }
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    bstore(rb, c + 2);                                 // (c + 2 >= NCH: the backward chain's first W2 chunks)
+    bload(rb, c + 3);
+    const int e2 = c * NT + tid;
+    const int hrow = e2 / (H / 2), hcol = (e2 % (H / 2)) * 2;
+    const float hv0 = h1s[hrow * LDH + hcol], hv1 = h1s[hrow * LDH + hcol + 1];
+    if (c + 1 < NCH) {
+      auto a_nx = [&](int ks) { return Ar[(c + 1) * FB_K + 2 * ks]; };
+      chunk_mfmas_and_next_frags<H, TN>(acc, fa[c & 1], fb[c & 1], fa[(c + 1) & 1], fb[(c + 1) & 1], a_nx,
+                                        bs + ((c + 1) % NR) * BST + boff, lh);
+    } else {
+      chunk_mfmas<TN>(acc, fa[c & 1], fb[c & 1]);
+    }
+    {
+      // UNCONDITIONAL store (rows past R land in a dump slot): behind a branch the compiler cannot count the store in
+      // vmcnt and makes the next iteration's ring write wait for every outstanding operation -- i.e. for this store's
+      // acknowledgement, ~400 cycles per chunk
+      float2 hv; hv.x = hv0; hv.y = hv1;
+      float* dst = row0 + hrow < a.R ? a.h1 + (long long)(row0 + hrow) * H + hcol : a.dump + 2 * tid;
+      *reinterpret_cast<float2*>(dst) = hv;
+    }
+    schedule_iteration<TN, BV>();
+    __syncthreads();
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  FUSED_STAMP(a, 4);
+
+  // ---- epilogue: logit, BCE, dlogit, statistics, dW3/db3 partials, dh2 (into the h1 tile)
+  float h2[TN][16];
+  float p[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    float s = 0.f;
+#pragma unroll
+    for (int t = 0; t < TN; ++t) {
+      h2[t][r] = fmaxf(acc[t][r] + b2v[t], 0.f);
+      s += h2[t][r] * w3v[t];
+    }
+    p[r] = s;
+  }
+  {
+    const float tot = reduce16_in_half(p, lane);
+    const int r = ((lane >> 4) & 1) * 8 + ((lane >> 3) & 1) * 4 + ((lane >> 2) & 1) * 2 + ((lane >> 1) & 1);
+    if ((lane & 1) == 0) red[wn * BM + wm * 32 + 4 * lh + rowoff(r)] = tot;
+  }
+  __syncthreads();
+  FUSED_STAMP(a, 5);
+  if (wave == 0) {  // one row per lane (lanes >= BM idle but take part in the reduction)
+    const int row = min(lane, BM - 1);
+    const int gi = row0 + row;
+    const bool valid = lane < BM && gi < a.R;
+    const float x = ((red[row] + red[BM + row]) + red[2 * BM + row]) + red[3 * BM + row] + b3v;
+    // adversarial/common.py:360-368 + 27-92, the arithmetic of bce_kernel (mlp.hip)
+    const float y = gi < a.n_expert ? 1.f : 0.f;
+    const float lse = log1pf(expf(-fabsf(x)));
+    const float pr = 1.f / (1.f + expf(-x));
+    const float inv = a.loss_scale / (float)a.R;
+    const float dl = valid ? (pr - y) * inv : 0.f;
+    if (lane < BM) dls[lane] = dl;
+    if (valid) {
+      a.logits[gi] = x;
+      if (a.dlogits) a.dlogits[gi] = dl;
+    }
+    const bool is_gen_pred = x < 0.f, is_gen_true = y == 0.f;
+    const bool ok = is_gen_pred == is_gen_true;
+    float vals[8];
+    vals[0] = valid ? (1.f - y) * x - (fminf(x, 0.f) - lse) : 0.f;
+    vals[1] = (valid && ok) ? 1.f : 0.f;
+    vals[2] = (valid && ok && !is_gen_true) ? 1.f : 0.f;
+    vals[3] = (valid && ok && is_gen_true) ? 1.f : 0.f;
+    vals[4] = (valid && is_gen_pred) ? 1.f : 0.f;
+    vals[5] = valid ? (1.f - pr) * x - (fminf(x, 0.f) - lse) : 0.f;
+    vals[6] = dl;  // db3 partial
+    vals[7] = 0.f;
+    const float tot = reduce8_in_wave(vals, lane);
+    const int k = lane >> 3;
+    if ((lane & 7) == 0) {
+      if (k < 6) a.part[(long long)blockIdx.x * 8 + k] = tot;
+      else if (k == 6) a.P3[(long long)blockIdx.x * (H + 1) + H] = tot;
+    }
+  }
+  __syncthreads();
+  FUSED_STAMP(a, 6);
+  {
+    float dlr[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dlr[r] = dls[wm * 32 + 4 * lh + rowoff(r)];
+#pragma unroll
+    for (int t = 0; t < TN; ++t) {
+      const int col = wn * WC + t * 32 + li;
+      float s = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = wm * 32 + 4 * lh + rowoff(r);
+        s += dlr[r] * h2[t][r];
+        h1s[row * LDH + col] = h2[t][r] > 0.f ? dlr[r] * w3v[t] : 0.f;   // dh2 (the h1 tile is dead by now)
+        acc[t][r] = 0.f;
+      }
+      s += __shfl_xor(s, 32, 64);
+      if (lh == 0) w3red[wm * H + col] = s;
+    }
+  }
+  __syncthreads();
+  if (tid < H) {
+    float s = w3red[tid];
+#pragma unroll
+    for (int g = 1; g < BM / 32; ++g) s += w3red[g * H + tid];
+    a.P3[(long long)blockIdx.x * (H + 1) + tid] = s;
+  }
+  FUSED_STAMP(a, 7);
+
+  // ---- backward chain: dh1 = (dh2 . W2) * relu'(h1), A = the dh2 tile in LDS, B = W2 chunks through the ring; the
+  //      tile's dh2 goes out to HBM in slices beside the MFMAs
+  {
+    auto a_at = [&](int ks) { return Ar[2 * ks]; };
+    chunk_frags<H, TN>(fa[0], fb[0], a_at, bs + (NCH % NR) * BST + boff, lh);
+  }
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    if (c + 2 < NCH) bstore(rb, NCH + c + 2);
+    if (c + 3 < NCH) bload(rb, NCH + c + 3);
+    const int e2 = c * NT + tid;
+    const int hrow = e2 / (H / 2), hcol = (e2 % (H / 2)) * 2;
+    const float hv0 = h1s[hrow * LDH + hcol], hv1 = h1s[hrow * LDH + hcol + 1];
+    if (c + 1 < NCH) {
+      auto a_nx = [&](int ks) { return Ar[(c + 1) * FB_K + 2 * ks]; };
+      chunk_mfmas_and_next_frags<H, TN>(acc, fa[c & 1], fb[c & 1], fa[(c + 1) & 1], fb[(c + 1) & 1], a_nx,
+                                        bs + ((NCH + c + 1) % NR) * BST + boff, lh);
+    } else {
+      chunk_mfmas<TN>(acc, fa[c & 1], fb[c & 1]);
+    }
+    {
+      float2 hv; hv.x = hv0; hv.y = hv1;
+      float* dst = row0 + hrow < a.R ? a.dh2 + (long long)(row0 + hrow) * H + hcol : a.dump + 2 * tid;
+      *reinterpret_cast<float2*>(dst) = hv;
+    }
+    schedule_iteration<TN, BV>();
+    __syncthreads();
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  FUSED_STAMP(a, 10);
+  {
+    const unsigned int hm_lo = (unsigned int)mword, hm_hi = (unsigned int)(mword >> 32);
+#pragma unroll
+    for (int t = 0; t < TN; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const unsigned int wlo = __builtin_amdgcn_readlane(hm_lo, t * 16 + r), whi = __builtin_amdgcn_readlane(hm_hi, t * 16 + r);
+        const bool on = (((lh ? whi : wlo) >> li) & 1u) != 0u;
+        h1s[(wm * 32 + 4 * lh + rowoff(r)) * LDH + wn * WC + t * 32 + li] = on ? acc[t][r] : 0.f;
+      }
+  }
+  if (tid < BM) xs[tid * XP3 + D] = 1.f;  // the ones column makes db1 a column of dW1 (column D was a zero column so far)
+  __syncthreads();
+  FUSED_STAMP(a, 11);
+
+  // ---- [dW1 | db1] partial [H, D + 1] = dh1^T . [xn | 1] over the tile's BM rows (see disc_bwd_kernel)
+  const long long n1 = (long long)H * D + H;
+  float* P1 = a.P1 + (long long)blockIdx.x * n1;
+  for (int mt = wave; mt < H / 32; mt += NW) {
+    f32x16 acc1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc1[r] = 0.f;
+    float af[BM / 2], bf[BM / 2];
+#pragma unroll
+    for (int s = 0; s < BM / 2; ++s) {
+      const int k = 2 * s + lh;
+      af[s] = h1s[k * LDH + mt * 32 + li];
+      bf[s] = xs[k * XP3 + li];
+    }
+#pragma unroll
+    for (int s = 0; s < BM / 2; ++s) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(af[s], bf[s], acc1, 0, 0, 0);
+    if (li <= D) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int i = mt * 32 + 4 * lh + rowoff(r);
+        bs[li < D ? i * D + li : H * D + i] = acc1[r];
+      }
+    }
+  }
+  __syncthreads();
   for (int e = tid; e < (int)(n1 / 4); e += NT)
     reinterpret_cast<f4*>(P1)[e] = reinterpret_cast<const f4*>(bs)[e];
   FUSED_STAMP(a, 12);
@@ -998,7 +1383,7 @@ inline bool fused_shape_ok(const ia_mlp_desc* d, int ldx) {
   return D >= 1 && D <= 24 && ldx >= D && ldx <= 24 && ldx % 4 == 0;
 }
 
-struct FusedWs { float* P1; float* P3; float* part; float* W2T; float* W1P; unsigned long long* h1mask; unsigned int* ticket; long long total; };
+struct FusedWs { float* P1; float* P3; float* part; float* W2T; float* W1P; unsigned long long* h1mask; unsigned int* ticket; float* dump; long long total; };
 
 inline FusedWs fused_ws_layout(const ia_mlp_desc* d, int R, float* base) {
   const long long D = d->dims[0], H = d->dims[1];
@@ -1011,8 +1396,10 @@ inline FusedWs fused_ws_layout(const ia_mlp_desc* d, int R, float* base) {
   o = (o + 3) / 4 * 4;                     // 16-byte aligned W2T rows
   w.W2T = base + o; o += H * H;
   w.W1P = base + o; o += H * XP;
-  w.h1mask = reinterpret_cast<unsigned long long*>(base + o); o += tiles * 4 * (H / 128) * 16 * 2;
+  // (64-row tiles write 8 waves' words per tile: 2 * ceil(R / 64) half-tiles, one more than ceil(R / 32) when that is odd)
+  w.h1mask = reinterpret_cast<unsigned long long*>(base + o); o += 2 * (long long)cdivi(R, 64) * 4 * (H / 128) * 16 * 2;
   w.ticket = reinterpret_cast<unsigned int*>(base + o); o += 4;
+  w.dump = base + o; o += 1024;
   w.total = o;
   return w;
 }
@@ -1075,8 +1462,9 @@ int launch_gp_tiles(const FusedArgs& ga, int B, hipStream_t stream) {
   return IA_OK;
 }
 
-int g_fused_bm = 64;   // rows per tile workgroup (tuning: ia_disc_fused_tile_rows)
 
+int g_fused_bm = 64;   // rows per tile workgroup (tuning: ia_disc_fused_tile_rows)
+bool g_fused_split = false;   // forward and backward tile passes as two launches (ia_disc_fused_split_tiles)
 template <int H, int BM>
 int launch_fused_tiles(const FusedArgs& fa, int R, hipStream_t stream) {
   constexpr size_t smem_f = sizeof(float) * (BM * (H + 1) + NS * FB_K * H + 4 * BM + BM + (BM / 32) * H + BM * XP);
@@ -1091,7 +1479,20 @@ int launch_fused_tiles(const FusedArgs& fa, int R, hipStream_t stream) {
     if (e != hipSuccess) return (int)e;
     attr_set = true;
   }
+  constexpr size_t smem_fb = sizeof(float) * (BM * (H + 1) + 3 * FB_K * H + 4 * BM + BM + (BM / 32) * H + BM * XP3);
+  static bool attr_fb = false;
+  if (!attr_fb) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(disc_fb_kernel<H, BM>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_fb);
+    if (e != hipSuccess) return (int)e;
+    attr_fb = true;
+  }
   const int tiles = cdivi(R, BM);
+  if (!g_fused_split) {
+    hipLaunchKernelGGL((disc_fb_kernel<H, BM>), dim3(tiles), dim3(BM * 8), smem_fb, stream, fa);
+    IA_CHECK_LAUNCH();
+    return IA_OK;
+  }
   hipLaunchKernelGGL((disc_fwd_kernel<H, BM>), dim3(tiles), dim3(BM * 8), smem_f, stream, fa);
   IA_CHECK_LAUNCH();
   hipLaunchKernelGGL((disc_bwd_kernel<H, BM>), dim3(tiles), dim3(BM * 8), smem_b, stream, fa);
@@ -1109,6 +1510,7 @@ int ia_disc32_assemble(const ia_disc_step_args* a, int n_updates, int64_t idx_st
                        float* rn_ws, hipStream_t stream);
 int ia_disc32_step(const ia_disc_step_args* a, void* stream);
 extern "C" int ia_disc_fused_tile_rows(int rows) { g_fused_bm = rows == 32 ? 32 : 64; return IA_OK; }
+extern "C" int ia_disc_fused_split_tiles(int on) { g_fused_split = on != 0; return IA_OK; }
 extern "C" int ia_disc_fused_debug_timing(void* device_buffer_16xi64) {
   g_fused_dbg = static_cast<long long*>(device_buffer_16xi64);
   return IA_OK;
@@ -1236,7 +1638,7 @@ int ia_disc_step_fused(const ia_disc_step_args* a, void* stream_) {
   fa.h1 = a->hidden; fa.dh2 = a->hidden + (long long)R * H;
   fa.h1mask = w.h1mask;
   fa.logits = a->logits; fa.dlogits = a->dlogits; fa.n_expert = a->n_expert; fa.loss_scale = a->loss_scale;
-  fa.part = w.part; fa.P1 = w.P1; fa.P3 = w.P3;
+  fa.part = w.part; fa.P1 = w.P1; fa.P3 = w.P3; fa.dump = w.dump;
   fa.dbg = g_fused_dbg;
   int rc;
   if (bm == 64) rc = H == 256 ? launch_fused_tiles<256, 64>(fa, R, stream) : launch_fused_tiles<128, 64>(fa, R, stream);

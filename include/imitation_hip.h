@@ -205,6 +205,9 @@ int ia_disc_fused_debug_timing(void* device_buffer_16xi64);
 /* Tuning: rows per workgroup of the fused tile kernels, 64 (default: one 512-thread workgroup per CU) or 32
  * (two 256-thread workgroups per CU). */
 int ia_disc_fused_tile_rows(int rows);
+/* Tuning / measurement: 1 = the update's forward and backward tile passes as two launches (disc_fwd_kernel,
+ * disc_bwd_kernel); 0 (default) = both in one (disc_fb_kernel). Outputs are bit-identical. */
+int ia_disc_fused_split_tiles(int on);
 
 /* Gradient penalty on the discriminator (OPT-IN extension, default off: BASELINE.json config 3 / the north star name
  * it, the reference has none -- SURVEY M1): E[(|grad_x D(x_hat)|_2 - target)^2] at x_hat = e x_expert + (1-e) x_gen.

@@ -267,3 +267,49 @@ def test_fused_gradient_penalty_matches_float64_double_backward(hid, B, norm, od
     assert float((g_pen[o - H - H * H - H:o - H - H].abs()).max()) > 0     # W2 entries carry a penalty gradient
     # bias entries get no penalty gradient (masks fixed): the float64 graph agrees
     assert float(g_pen[H * D:H * D + H].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("hid,n0,n1,rows", [((256, 256), 1000, 1000, 64), ((128, 128), 300, 211, 64), ((256, 256), 200, 200, 32)])
+def test_one_launch_tile_pass_is_bit_identical_to_forward_plus_backward_launches(hid, n0, n1, rows):
+    """`disc_fb_kernel` (forward + backward of a tile in one workgroup) against `disc_fwd_kernel` + `disc_bwd_kernel`
+    (`ia_disc_fused_split_tiles(1)`): same arithmetic in the same order -> logits, statistics, gradient, parameters after
+    Adam and the saved activations bit for bit."""
+    od, ad = 17, 6
+    osp = spaces.Box(-np.inf, np.inf, (od,), np.float32)
+    asp = spaces.Box(-1, 1, (ad,), np.float32)
+    e_tab, _ = _tables(3000, od, ad, False, 1)
+    g_tab, _ = _tables(3000, od, ad, False, 2)
+    rng = np.random.default_rng(9)
+    e_idx, g_idx = th.as_tensor(rng.integers(0, 3000, n0)).to(DEV), th.as_tensor(rng.integers(0, 3000, n1)).to(DEV)
+    R = n0 + n1
+    outs = []
+    lib = L.load()
+    try:
+        lib.ia_disc_fused_tile_rows(rows)
+        for split in (1, 0):
+            lib.ia_disc_fused_split_tiles(split)
+            th.manual_seed(3)
+            net = reward_nets.BasicRewardNet(osp, asp, hid_sizes=hid, normalize_input_layer=p.RunningNorm).to(DEV)
+            mlp = net.mlp
+            opt = HipAdam(mlp.flat, mlp.grad, lr=1e-3)
+            stats = th.zeros(8, device=DEV)
+            bce_ws = th.zeros(int(lib.ia_bce_ws_floats(R)), device=DEV)
+            rows_out = []
+            for _ in range(2):
+                with networks.training(net):
+                    ws = net.disc_step_c([(e_tab, e_idx, n0), (g_tab, g_idx, n1)], n0, 1.0, stats, bce_ws,
+                                         accumulate=False, adam=opt)
+                th.cuda.synchronize()
+                rows_out.append((ws["out"].clone(), stats.clone(), mlp.grad.clone(), mlp.flat.clone(),
+                                 ws["hidden"][:2 * R * hid[0]].clone()))
+            outs.append(rows_out)
+    finally:
+        lib.ia_disc_fused_split_tiles(0)
+        lib.ia_disc_fused_tile_rows(64)
+    names = ("logits", "statistics", "gradient", "parameters", "saved activations")
+    for k, (a, b) in enumerate(zip(*outs)):
+        for name, x, y in zip(names, a, b):
+            if not th.equal(x, y):
+                ii = th.nonzero((x != y).reshape(-1)).reshape(-1)
+                raise AssertionError(f"update {k}: {name} differ at {ii.numel()} of {x.numel()} places, first {ii[:6].tolist()}, "
+                                     f"values {x.reshape(-1)[ii[:3]].tolist()} vs {y.reshape(-1)[ii[:3]].tolist()}")

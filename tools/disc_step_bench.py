@@ -45,6 +45,8 @@ def step(net, opt, e, g, ie, ig, stats, bce_ws, adam=True):
 
 if os.environ.get("TILE_ROWS"):
     L.load().ia_disc_fused_tile_rows(int(os.environ["TILE_ROWS"]))
+SPLIT = os.environ.get("SPLIT") == "1"     # forward and backward tile passes as two launches (the form before round 3)
+L.load().ia_disc_fused_split_tiles(int(SPLIT))
 e, g = tables(1)
 gi = th.Generator().manual_seed(2)
 ie = th.randint(0, NE, (mb,), generator=gi).to(dev)
@@ -134,5 +136,9 @@ L.load().ia_disc_fused_debug_timing(None)
 t = buf.cpu().numpy()
 names = ("prologue", "layer-1 MFMAs", "layer-1 epilogue", "layer-2 loop", "logit reduce", "BCE", "dh2/dW3 epilogue")
 print("fwd tile kernel, block 0 (cycles): " + ", ".join(f"{n} {int(t[i + 1] - t[i])}" for i, n in enumerate(names)) + f", total {int(t[7] - t[0])}")
-names = ("prologue", "dgrad loop", "mask -> LDS", "dW1/db1")
-print("bwd tile kernel, block 0 (cycles): " + ", ".join(f"{n} {int(t[9 + i] - t[8 + i])}" for i, n in enumerate(names)) + f", total {int(t[12] - t[8])}")
+if SPLIT:
+    names = ("prologue", "dgrad loop", "mask -> LDS", "dW1/db1")
+    print("bwd tile kernel, block 0 (cycles): " + ", ".join(f"{n} {int(t[9 + i] - t[8 + i])}" for i, n in enumerate(names)) + f", total {int(t[12] - t[8])}")
+else:
+    print(f"... the same workgroup's backward half (cycles): dgrad loop {int(t[10] - t[7])}, mask -> LDS {int(t[11] - t[10])}, "
+          f"dW1/db1 {int(t[12] - t[11])}; whole tile pass {int(t[12] - t[0])}")
