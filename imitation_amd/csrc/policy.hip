@@ -1726,15 +1726,26 @@ __device__ __forceinline__ void wave_sync_lds() {
 // (`nv` = 1/sqrt(running_var + eps) per column, as the statistics block publishes it)
 // KS1 = k-steps (of 4 input columns) the first layer's fragments are sized for: 16 covers MAXD = 64 columns, 8 covers
 // observation widths <= 32 -- every reference environment of the path -- with 16 fragment registers less across the chain.
-template <int KS1>
+// LOCAL (one gradient workgroup: minibatches <= 64 rows, both tuned configurations of the reference): the gradient
+// "slab" is an LDS image -- the part of the row staging area this minibatch has consumed by the time the gradient tiles
+// are formed -- that the caller reads straight back: no write-through stores to acknowledge, no release fence, no
+// grid wait, no re-read through L2. The loss-statistic partials (for the statistics workgroup) are stored write-through;
+// the caller drains them (`vmcnt(0)` in every wave) at the END of the step, where it waits for the prefetched rows
+// anyway, and arrives after that -- no release fence (cdna_hip_programming.md G16 R1), no acknowledgement on the chain.
+template <int KS1, bool LOCAL>
 __device__ __forceinline__ void mfma32_minibatch_chain(
     const ia_policy_desc& d, const float* __restrict__ nm, const float* __restrict__ nv, const float adv_mean,
     const float adv_std, const MbRows rows, const int vblk, const int normalize_adv, const float clip,
-    const float ent_coef, const float vf_coef, float* __restrict__ slab, float* __restrict__ statpart,
-    float* __restrict__ lds_in, const float* __restrict__ sP_in, const float* __restrict__ stg_in,
+    const float ent_coef, const float vf_coef, float* __restrict__ slab_g, float* __restrict__ statpart,
+    float* __restrict__ lds_in, const float* __restrict__ sP_in, float* __restrict__ stg_in,
     const int opaque_zero, long long* __restrict__ tstamp) {
   float* __restrict__ lds = lds_in + opaque_zero;
   const float* __restrict__ stg = stg_in + opaque_zero;
+  float* __restrict__ slab = LOCAL ? stg_in + opaque_zero + UpdStage::x : slab_g;
+  auto put = [&](float* p, float v) {
+    if constexpr (LOCAL) *p = v;
+    else slab_store(p, v);
+  };
   const int batch = rows.batch;
   constexpr int H = 32;
   using L = CLds;
@@ -2143,7 +2154,7 @@ __device__ __forceinline__ void mfma32_minibatch_chain(
     }
     s += __shfl_xor(s, 16, 64);
     s += __shfl_xor(s, 32, 64);
-    if (lane < ncols && lane < 16) slab_store(dst + lane, s);
+    if (lane < ncols && lane < 16) put(dst + lane, s);
   };
   auto colsum64_wide = [&](const float* __restrict__ tile, int stride, float* __restrict__ dst) {  // 32 columns
     const int c = lane & 31, part = lane >> 5;
@@ -2151,14 +2162,14 @@ __device__ __forceinline__ void mfma32_minibatch_chain(
 #pragma unroll
     for (int r = 0; r < 32; ++r) s += tile[(part * 32 + r) * stride + c];
     s += __shfl_xor(s, 32, 64);
-    if (lane < 32) slab_store(dst + lane, s);
+    if (lane < 32) put(dst + lane, s);
   };
   if (tw == 0) {
     if (q < 2) {  // dWa[a][h] = sum_r dout[r][a] a2[r][h], 16 h-columns per wave
       const f32x4 g = outer16(lds + L::dout, L::AS, li, a2t, L::HS, q * 16 + li);
 #pragma unroll
       for (int r = 0; r < 4; ++r)
-        if (lk * 4 + r < A) slab_store(slab + (o.aW + (lk * 4 + r) * H + q * 16 + li), g[r]);
+        if (lk * 4 + r < A) put(slab + (o.aW + (lk * 4 + r) * H + q * 16 + li), g[r]);
     }
     if (q == 2) colsum64(lds + L::dout, L::AS, A, slab + o.ab);
     if (q == 3 && !d.discrete) colsum64(lds + L::aux, L::AS, A, slab + o.log_std);
@@ -2174,7 +2185,7 @@ __device__ __forceinline__ void mfma32_minibatch_chain(
       f32x4 g = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int s = 0; s < 16; ++s) g = mfma16(li == 0 ? u[s] : 0.f, v[s], g);
-      if (lk == 0) slab_store(slab + (o.cW + q * 16 + li), g[0]);
+      if (lk == 0) put(slab + (o.cW + q * 16 + li), g[0]);
     }
     if (q == 2) {  // cb = sum_r dv[r]; statpart slots {0 pg, 2 ent, 3 kl, 4 clip, 1 value} <- misc columns 2..6
       // columns 1..6 of the misc tile summed together: lane c < 6 handles column 1 + c
@@ -2186,11 +2197,11 @@ __device__ __forceinline__ void mfma32_minibatch_chain(
       }
       sm += __shfl_xor(sm, 16, 64);
       sm += __shfl_xor(sm, 32, 64);
-      if (lane == 0) slab_store(slab + (o.cb), sm);
+      if (lane == 0) put(slab + (o.cb), sm);
       if (lane >= 1 && lane < 6) {
         const int m = lane - 1;                      // misc column 2 + m
         const int slot = m == 0 ? 0 : (m == 4 ? 1 : m + 1);
-        statpart[slot] = sm;
+        slab_store(statpart + slot, sm);   // (write-through in both forms; LOCAL drains it below)
       }
     }
   }
@@ -2198,7 +2209,7 @@ __device__ __forceinline__ void mfma32_minibatch_chain(
     const int jt = q >> 1, kt = q & 1;
     const f32x4 g = outer16(dz2t, L::HS, jt * 16 + li, a1t, L::HS, kt * 16 + li);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) slab_store(slab + (oW2 + (jt * 16 + lk * 4 + r) * H + kt * 16 + li), g[r]);
+    for (int r = 0; r < 4; ++r) put(slab + (oW2 + (jt * 16 + lk * 4 + r) * H + kt * 16 + li), g[r]);
     if (q == 3) colsum64_wide(dz2t, L::HS, slab + ob2);
   }
   {  // dW1 tiles (dz1^T x), db1
@@ -2209,7 +2220,7 @@ __device__ __forceinline__ void mfma32_minibatch_chain(
       const int col = kt * 16 + li;
       if (col < D)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) slab_store(slab + (oW1 + (jt * 16 + lk * 4 + r) * D + col), g[r]);
+        for (int r = 0; r < 4; ++r) put(slab + (oW1 + (jt * 16 + lk * 4 + r) * D + col), g[r]);
     }
     if (q == 2) colsum64_wide(dz1t, L::HS, slab + ob1);
   }
@@ -2537,7 +2548,7 @@ __device__ __forceinline__ bool spin_until(unsigned* p, unsigned target, unsigne
 
 // TIMING = false (production): the phase-clock accumulators (24 VGPRs of `tacc` alone) and every stamp are
 // compiled out -- the measurement build is a separate instantiation picked only while ia_ppo_debug_timing is on.
-template <int NPT, bool TIMING, int KS1>
+template <int NPT, bool TIMING, int KS1, bool LOCAL>
 __global__ __launch_bounds__(512) void ppo_update_persistent_kernel(
     ia_policy_desc d, float* __restrict__ P, float* __restrict__ Pt, float* __restrict__ m, float* __restrict__ v,
     float* __restrict__ nm, float* __restrict__ nv, int32_t* __restrict__ ncount, int update_norm,
@@ -2874,6 +2885,10 @@ __global__ __launch_bounds__(512) void ppo_update_persistent_kernel(
   // copied into LDS behind barrier s (whose acquire fence covers it) and step s+1 starts without a
   // wait, a fence or a dependent global load. `have_ring`: the LDS copy holds this step's slot.
   bool have_ring = false;
+  // one gradient workgroup: its gradient never leaves the CU (LDS image inside the consumed part of the staging area)
+  // (LOCAL is chosen by the host: nblk == 1 and the parameter vector fits the area; a kernel of its own, because both
+  // chain forms in one kernel cost 14 spilled registers in the 9-parameters-per-thread instantiation)
+  constexpr bool local = LOCAL;
   if (tstamp && tid == 0) tprev = wall_clock64();
   for (int s = 0; s < n_steps; ++s) {
     const MbRows r = rows_of(s);
@@ -2907,17 +2922,26 @@ __global__ __launch_bounds__(512) void ppo_update_persistent_kernel(
     float* stat_base = w.statpart + (s % UPD_SD) * nblk * 8;
     int oz;
     asm volatile("s_mov_b32 %0, 0" : "=s"(oz));
-    mfma32_minibatch_chain<KS1>(d, slot, slot + MAXD, adv_mean, adv_std, r, vb, normalize_adv, clip, ent_coef, vf_coef,
-                           slab_base + (long long)vb * w.P4, stat_base + vb * 8, lds, sP, stg, oz,
-                           tstamp ? tstamp + 16 : nullptr);
+    mfma32_minibatch_chain<KS1, LOCAL>(d, slot, slot + MAXD, adv_mean, adv_std, r, vb, normalize_adv, clip, ent_coef,
+                                       vf_coef, slab_base + (long long)vb * w.P4, stat_base + vb * 8, lds, sP, stg, oz,
+                                       tstamp ? tstamp + 16 : nullptr);
     // (the minibatch ends with a block barrier: every slab store of this block has been issued)
     UPD_TS(1);
-    if (tid == 0) {  // arrive first; the prefetch below overlaps the wait for the other blocks
+    if (!local && tid == 0) {  // arrive first; the prefetch below overlaps the wait for the other blocks
       __threadfence();
       UPD_TS(7);
       __hip_atomic_fetch_add(arrivals + 16 * (vb & (UPD_ARR - 1)), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     UPD_TS(8);
+    float g[NPT];
+    if (local) {
+      // the gradient image out of the staging area before the next minibatch's rows are loaded over it
+      int gz;
+      asm volatile("s_mov_b32 %0, 0" : "=s"(gz));
+#pragma unroll
+      for (int k = 0; k < NPT; ++k) g[k] = stg[UpdStage::x + gz + min(tid + k * 512, o.total - 1)];
+      __syncthreads();
+    }
     if (s + 1 < n_steps) {
       int pz;
       asm volatile("s_mov_b32 %0, 0" : "=s"(pz));
@@ -2925,7 +2949,7 @@ __global__ __launch_bounds__(512) void ppo_update_persistent_kernel(
     }
     UPD_TS(9);
     if (tid < 64) {
-      const bool ok = spin_arrivals(arrivals, (unsigned)(s + 1), nblk, err);
+      const bool ok = local ? true : spin_arrivals(arrivals, (unsigned)(s + 1), nblk, err);
       if (tid == 0) {
         s_ok = ok;
         s_pub = (int)__hip_atomic_load(published, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -2954,7 +2978,6 @@ __global__ __launch_bounds__(512) void ppo_update_persistent_kernel(
     // group g into a partial, one more grid barrier among the leaders' arrivals, then every block sums
     // the ngrp partials -- so a block never reads more than 16 vectors (128 slabs each would be 230 MB
     // of reads per step over all blocks).
-    float g[NPT];
     float sq = 0.f;
     auto sum_vectors = [&](const float* __restrict__ base, int nsrc) {
 #pragma unroll
@@ -2991,7 +3014,9 @@ __global__ __launch_bounds__(512) void ppo_update_persistent_kernel(
         for (int k = 0; k < NPT; ++k) g[k] += base[(unsigned)b * (unsigned)w.P4 + (unsigned)min(tid + k * 512, o.total - 1)];
       }
     };
-    if (nblk <= 2 * UPD_GROUP) {
+    if constexpr (LOCAL) {
+      // (g holds the workgroup's own gradient already)
+    } else if (nblk <= 2 * UPD_GROUP) {
       sum_vectors(slab_base, nblk);
     } else {
       // group size: 8 up to 64 blocks (both levels read 8 vectors: 6.7 us against 9.4 us with groups of 16),
@@ -3035,9 +3060,9 @@ __global__ __launch_bounds__(512) void ppo_update_persistent_kernel(
     const float coef = fminf(max_norm / (total_norm + 1e-6f), 1.0f);  // torch clip_grad_norm_
     if (vb == 0) {
       if (s + 1 < n_steps) {  // the statistics block writes this step's loss statistics later
-        if (tid == 0) {
-          w.normcoef[(s % UPD_SD) * 2] = total_norm;
-          w.normcoef[(s % UPD_SD) * 2 + 1] = coef;
+        if (tid == 0) {   // (write-through: the local form's arrive has no release fence ahead of it)
+          slab_store(w.normcoef + (s % UPD_SD) * 2, total_norm);
+          slab_store(w.normcoef + (s % UPD_SD) * 2 + 1, coef);
         }
       } else {
         write_loss_stats(s, total_norm, coef);
@@ -3080,7 +3105,11 @@ __global__ __launch_bounds__(512) void ppo_update_persistent_kernel(
     }
     UPD_TS(6);
     if (s + 1 < n_steps) prefetch_park();   // (its vmcnt(0) also covers the statistics slot's LDS-direct loads)
+    else if (local) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    if (local && tid == 0)   // only the statistics workgroup listens: this step's loss partials and norm / clip pair were
+                             // stored write-through and every wave has drained its stores ahead of the barrier above
+      __hip_atomic_fetch_add(arrivals + 16 * (vb & (UPD_ARR - 1)), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     UPD_TS(3);
   }
 #undef UPD_TS
@@ -3575,15 +3604,21 @@ int ia_ppo_update(const ia_policy_desc* d, float* params, float* params_t, float
   // instantiations: {8, 9} parameters per thread x {production, phase clocks} x first-layer fragments for <= 32 / <= 64
   // observation columns (the narrow form keeps 16 registers less across the chain)
   const bool ks16 = d->obs_dim > 32;
-  using KernelT = decltype(&ppo_update_persistent_kernel<UPD_NPT, false, 8>);
-  static const KernelT kernels[8] = {
-      ppo_update_persistent_kernel<UPD_NPT, false, 8>,      ppo_update_persistent_kernel<UPD_NPT, false, 16>,
-      ppo_update_persistent_kernel<UPD_NPT, true, 8>,       ppo_update_persistent_kernel<UPD_NPT, true, 16>,
-      ppo_update_persistent_kernel<UPD_NPT_WIDE, false, 8>, ppo_update_persistent_kernel<UPD_NPT_WIDE, false, 16>,
-      ppo_update_persistent_kernel<UPD_NPT_WIDE, true, 8>,  ppo_update_persistent_kernel<UPD_NPT_WIDE, true, 16>};
-  const int vi_k = wide * 4 + timing * 2 + ks16;
+  // one gradient workgroup whose parameter vector fits the consumed part of the staging area: the gradient stays in LDS
+  const bool local = nblk == 1 && P4 <= UpdStage::nxt;
+  using KernelT = decltype(&ppo_update_persistent_kernel<UPD_NPT, false, 8, false>);
+  static const KernelT kernels[16] = {
+      ppo_update_persistent_kernel<UPD_NPT, false, 8, false>,      ppo_update_persistent_kernel<UPD_NPT, false, 16, false>,
+      ppo_update_persistent_kernel<UPD_NPT, true, 8, false>,       ppo_update_persistent_kernel<UPD_NPT, true, 16, false>,
+      ppo_update_persistent_kernel<UPD_NPT_WIDE, false, 8, false>, ppo_update_persistent_kernel<UPD_NPT_WIDE, false, 16, false>,
+      ppo_update_persistent_kernel<UPD_NPT_WIDE, true, 8, false>,  ppo_update_persistent_kernel<UPD_NPT_WIDE, true, 16, false>,
+      ppo_update_persistent_kernel<UPD_NPT, false, 8, true>,       ppo_update_persistent_kernel<UPD_NPT, false, 16, true>,
+      ppo_update_persistent_kernel<UPD_NPT, true, 8, true>,        ppo_update_persistent_kernel<UPD_NPT, true, 16, true>,
+      ppo_update_persistent_kernel<UPD_NPT_WIDE, false, 8, true>,  ppo_update_persistent_kernel<UPD_NPT_WIDE, false, 16, true>,
+      ppo_update_persistent_kernel<UPD_NPT_WIDE, true, 8, true>,   ppo_update_persistent_kernel<UPD_NPT_WIDE, true, 16, true>};
+  const int vi_k = local * 8 + wide * 4 + timing * 2 + ks16;
   const KernelT kernel = kernels[vi_k];
-  static size_t attr_bytes[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  static size_t attr_bytes[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   if (bytes > attr_bytes[vi_k]) {
     const int rc = set_lds(kernel, bytes);
     if (rc) return rc;
@@ -3638,8 +3673,8 @@ int ia_ppo_update(const ia_policy_desc* d, float* params, float* params_t, float
       // (and a cooperative launch costs +15-19 us per launch, MI355X_MICROARCH.md "coop-launch"), so the same
       // test is made here: workgroups per CU by the occupancy query (LDS-bound: one) times the CU count.
       // Not enough room -> IA_ERR_UNSUPPORTED, the caller runs ia_ppo_epoch (two launches per minibatch).
-      static int dev_cus = 0, per_cu[8] = {-1, -1, -1, -1, -1, -1, -1, -1};
-      static size_t per_cu_bytes[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      static int dev_cus = 0, per_cu[16] = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1};
+      static size_t per_cu_bytes[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
       const int vi = vi_k;
       if (dev_cus == 0) {
         int dev = 0;

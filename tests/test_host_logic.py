@@ -516,11 +516,14 @@ def test_production_kernels_do_not_spill():
     find = lambda sub: [k for n, k in notes.items() if sub in n]
     # persistent PPO update: 8 and 9 parameters per thread, production build, observation widths <= 32 (every
     # reference environment of the path): no spilled VGPR, no scratch at all
-    for inst in ("ppo_update_persistent_kernel<8, false, 8>", "ppo_update_persistent_kernel<9, false, 8>"):
+    # (last argument: the one-gradient-workgroup form whose gradient stays in LDS -- the reference's tuned configurations)
+    for inst in ("ppo_update_persistent_kernel<8, false, 8, false>", "ppo_update_persistent_kernel<9, false, 8, false>",
+                 "ppo_update_persistent_kernel<8, false, 8, true>", "ppo_update_persistent_kernel<9, false, 8, true>",
+                 "ppo_update_persistent_kernel<8, false, 16, true>", "ppo_update_persistent_kernel<9, false, 16, true>"):
         ks = find(inst)
         assert len(ks) == 1, inst
         assert ks[0]["vgpr_spill"] == 0 and ks[0]["scratch"] == 0, (inst, ks[0])
-    for sub in ("disc_fwd_kernel", "disc_bwd_kernel", "airl_rows_kernel", "disc32_rows_kernel", "policy_act_mfma_kernel",
+    for sub in ("disc_fb_kernel", "disc_fwd_kernel", "disc_bwd_kernel", "airl_rows_kernel", "disc32_rows_kernel", "policy_act_mfma_kernel",
                 "ia_gemm_kernel", "conv1_fwd_kernel", "conv1_wgrad_kernel"):
         ks = find(sub)
         assert ks, sub

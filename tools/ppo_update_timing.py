@@ -1,6 +1,6 @@
-"""Where the persistent PPO update (ia_ppo_update) spends its time at config P: block 0 accumulates
+"""Where the persistent PPO update (ia_ppo_update) spends its time at config P (or a bench variant): block 0 accumulates
 100 MHz ticks per phase {wait for statistics, minibatch fwd/bwd, grid barrier, reduce+clip+Adam}.
-Usage: python tools/ppo_update_timing.py [xcd_pack 0|1]"""
+Usage: python tools/ppo_update_timing.py [xcd_pack 0|1] [bench variant, e.g. T_gail_half_cheetah_tuned_verbatim]"""
 import os
 import sys
 import time
@@ -13,9 +13,12 @@ from imitation_amd import _lib as L  # noqa: E402
 
 pack = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 th.set_num_threads(1)
-cfg = dict(bench.CFG_P)
-tr = bench.build_trainer(bench.hip_namespace(), cfg, "cuda")
-per_round = cfg["n_envs"] * cfg["n_steps"]
+if len(sys.argv) > 2:
+    tr, per_round = bench.build_variant(sys.argv[2])
+else:
+    cfg = dict(bench.CFG_P)
+    tr = bench.build_trainer(bench.hip_namespace(), cfg, "cuda")
+    per_round = cfg["n_envs"] * cfg["n_steps"]
 tr.train(2 * per_round)
 th.cuda.synchronize()
 algo = tr.gen_algo
