@@ -176,11 +176,11 @@ def disc_update_timing(trainer, cfg):
     n_par = D * H1 + H1 + H1 * H2 + H2 + H2 + 1
     alg_bytes = R * (D * 4 + 4) + 7 * 4 * n_par                            # rows in, logit out, parameter/Adam traffic
     tf = flop / (best * 1e-6) / 1e12
-    return {"kernel": "discriminator update (ia_disc_step_basic: assemble+moments+merge | tile forward+BCE+head "
-                      "gradient | tile dgrad+first-layer wgrad | split-K wgrad | slab reduce+Adam+statistics)",
+    return {"kernel": "discriminator update (ia_disc_step_basic: assemble+moments+merge | tile pass: forward+BCE+head "
+                      "gradient+dgrad+first-layer wgrad in one workgroup | split-K wgrad | slab reduce+Adam+statistics)",
             "bound": "mfma", "us": best, "host_enqueue_us": best_host,
-            "path": "fused (round assembly + 4 launches per update)" if fused else "general (16 launches per update)",
-            "launches_per_update": 4 if fused else 16, "launches_per_round_shared": 4 if fused else 0, "rows": R, "flop": flop,
+            "path": "fused (round assembly + 3 launches per update)" if fused else "general (16 launches per update)",
+            "launches_per_update": 3 if fused else 16, "launches_per_round_shared": 4 if fused else 0, "rows": R, "flop": flop,
             "achieved": tf, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": tf / PEAK_F32_MFMA_TFLOPS,
             "algorithmic_bytes": alg_bytes, "achieved_hbm_gbs": alg_bytes / (best * 1e-6) / 1e9,
             "frac_hbm": alg_bytes / (best * 1e-6) / 8e12,
