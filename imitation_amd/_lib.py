@@ -154,6 +154,8 @@ _SIGS = {
                                _F, _F, _F, _P, _P], C.c_int),
     "ia_ppo_debug_timing": ([_P], C.c_int),
     "ia_ppo_force_valu": ([_I], C.c_int),
+    "ia_ppo_epoch_split": ([_I], C.c_int),
+    "ia_ppo_epoch_debug_timing": ([_P], C.c_int),
     "ia_ppo_grad_offset": ([C.POINTER(PolicyDesc), _I], C.c_int64),
     "ia_ppo_minibatch_apply": ([C.POINTER(PolicyDesc), _P, _P, _I, _F, _F, _F, _P, _P, _F, _F, _F, _F, _F, _P, _P, _P],
                                C.c_int),

@@ -1025,7 +1025,10 @@ __device__ __forceinline__ void mfma_minibatch(
     const ia_policy_desc& d, const float* __restrict__ P, const float* __restrict__ Pt, const float* __restrict__ nm,
     const float* __restrict__ nv, const float adv_mean, const float adv_std, const MbRows rows, const int vblk,
     const int normalize_adv, const float clip, const float ent_coef, const float vf_coef, float* __restrict__ slab,
-    float* __restrict__ statpart, float* __restrict__ lds, long long* __restrict__ tstamp) {
+    float* __restrict__ statpart, float* __restrict__ lds_in, long long* __restrict__ tstamp, const int oz = 0) {
+  // `oz`: an opaque zero when the function sits inside a step loop (ppo_epoch_persistent_kernel): every per-lane offset is
+  // then re-derived per step instead of being hoisted out of the loop into (spilled) registers
+  float* __restrict__ lds = lds_in + oz;
   const float* __restrict__ obs = rows.obs;
   const float* __restrict__ actions = rows.actions;
   const float* __restrict__ old_logp = rows.old_logp;
@@ -1036,7 +1039,7 @@ __device__ __forceinline__ void mfma_minibatch(
   constexpr int NC = H / 16, KS = H / 4;   // 16-column tiles of a layer output, MFMA steps over a hidden layer
   using L = GLds<H>;
 #define IA_TS(slot) do { if (tstamp && vblk == 0 && threadIdx.x == 0) tstamp[slot] = clock64(); } while (0)
-  const int tid = threadIdx.x, lane = tid & 63;
+  const int tid = threadIdx.x + oz, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int tw = wv >> 2, q = wv & 3;
   const int li = lane & 15, lk = lane >> 4;
@@ -2546,6 +2549,189 @@ __device__ __forceinline__ bool spin_until(unsigned* p, unsigned target, unsigne
   return true;
 }
 
+// ---------------------------------------------------------------------------------------------
+// One launch per EPOCH for the towers the H = 32 persistent kernel does not cover ([64, 64]: SB3's default `MlpPolicy`):
+// the minibatch steps of `ia_ppo_epoch` -- gradient kernel + split apply kernel, two launches and ~6 us of dispatch
+// boundary each -- as phases of one co-resident grid of `nwg` workgroups separated by grid barriers:
+//   A  gradient of the minibatch (mfma_minibatch<H>, the device function the per-minibatch kernel runs; parameter
+//      fragments from L2), slabs + loss-statistic partials                                      | barrier
+//   B1 workgroup g sums chunk g of the slabs in slab order (registers) and leaves the chunk's sum of squares | barrier
+//   B2 every workgroup folds the G partial sums in order -> norm, clip coefficient; Adam on its own chunk (torch layout
+//      + transposed shadow copy); workgroup 0 writes the step's loss statistics                 | barrier
+// Same arithmetic as the two kernels (the chunking of the sum of squares differs: G = nwg chunks here). Barrier: every
+// thread's stores acknowledged, block barrier, one lane's agent-scope release + relaxed arrive on a monotonic counter,
+// bounded spin, acquire (the gfx950 hand-off rules of disc_fused.hip / the persistent H = 32 kernel).
+struct EpochSteps {
+  static constexpr int MAX = 64;
+  int n, first;                       // minibatches [first, first + n) of the epoch
+  float step_size[MAX], bc2_sqrt[MAX];
+};
+
+__device__ __forceinline__ bool epoch_grid_sync(unsigned* ctr, unsigned target, unsigned* err, int* s_flag) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const bool ok = spin_until(ctr, target, err);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    *s_flag = ok ? 1 : 0;
+  }
+  __syncthreads();
+  return *s_flag != 0;
+}
+
+template <int H>
+__global__ __launch_bounds__(512) void ppo_epoch_persistent_kernel(
+    ia_policy_desc d, float* __restrict__ P, float* __restrict__ Pt, float* __restrict__ m, float* __restrict__ v,
+    const float* __restrict__ nm_in, const float* __restrict__ nv_in, const float* __restrict__ obs,
+    const float* __restrict__ actions, const float* __restrict__ old_logp, const float* __restrict__ adv,
+    const float* __restrict__ ret, long long total_rows, int batch_size, int T, int n_envs, int normalize_adv,
+    float clip, float ent_coef, float vf_coef, float max_norm, float beta1, float beta2, float eps,
+    float* __restrict__ ws, const float* __restrict__ seq, int snap, float* __restrict__ stats, EpochSteps st,
+    long long* __restrict__ dbg /* measurement: [0..5] += 100 MHz ticks of workgroup 0 in {A, barrier, B1, barrier, B2, barrier} */) {
+  extern __shared__ float lds[];
+  __shared__ int s_flag;
+  long long tprev = 0;
+#define EP_TS(slot)                                                       \
+  do {                                                                    \
+    if (dbg != nullptr && blockIdx.x == 0 && threadIdx.x == 0) {          \
+      const long long tn = wall_clock64();                                \
+      dbg[slot] += tn - tprev;                                            \
+      tprev = tn;                                                         \
+    }                                                                     \
+  } while (0)
+  if (dbg != nullptr && blockIdx.x == 0 && threadIdx.x == 0) tprev = wall_clock64();
+  __shared__ float s_part[64];
+  const int bid = blockIdx.x, nwg = gridDim.x;
+  const int D = d.obs_dim, aw = d.discrete ? 1 : d.act_dim;
+  const PolOff o = pol_offsets(D, d.act_dim, H, d.discrete);
+  unsigned* ctr = reinterpret_cast<unsigned*>(ws) + 4;
+  unsigned* err = reinterpret_cast<unsigned*>(ws) + 5;
+  unsigned bar = 0;
+  const int chunk = (o.total + nwg - 1) / nwg;
+  constexpr int NPC = 4;   // parameters of the chunk per thread (chunk <= 2048)
+#pragma nounroll
+  for (int k = 0; k < st.n; ++k) {
+    const int mb = st.first + k;
+    const long long start = (long long)mb * batch_size;
+    const int b = (int)min((long long)batch_size, total_rows - start);
+    const int nblk = (b + ROWS - 1) / ROWS;
+    const PpoWs w = ppo_ws(ws, nblk, o.total);
+    const float* sq = seq + (long long)mb * EPS_SEQ;
+    // ---- A: gradient of this minibatch
+    if (bid < nblk) {
+      const MbRows rows{obs + start * D, actions + start * aw, old_logp + start, adv + start, ret + start, nullptr, b, T,
+                        n_envs};
+      // (opaque zero: inlined into the step loop, the chain's loop-invariant per-lane offsets are otherwise hoisted out of
+      //  it -- 278 spilled registers; 9 remain. As a real call (`noinline`) the ABI's saves cost 43.)
+      int oz;
+      asm volatile("s_mov_b32 %0, 0" : "=s"(oz));
+      mfma_minibatch<H, true>(d, P + oz, Pt + oz, snap ? sq + 8 : nm_in, snap ? sq + 8 + MAXD : nv_in, sq[0], sq[1], rows,
+                              bid + oz, normalize_adv, clip, ent_coef, vf_coef, w.slabs + (long long)bid * o.total,
+                              w.statpart + bid * 8, lds, nullptr, oz);
+    }
+    EP_TS(0);
+    if (!epoch_grid_sync(ctr, (++bar) * nwg, err, &s_flag)) return;
+    EP_TS(1);
+    // ---- B1: chunk `bid` of the slab sum (fixed slab order), the chunk's sum of squares
+    int oz2;   // (the apply phases' per-thread offsets are re-derived per step as well: nothing of theirs lives across A)
+    asm volatile("s_mov_b32 %0, 0" : "=s"(oz2));
+    const int tid = threadIdx.x + oz2;
+    const int i0 = bid * chunk + oz2, i1 = min(o.total, i0 + chunk);
+    float g[NPC];
+    float sqs = 0.f;
+#pragma unroll
+    for (int j = 0; j < NPC; ++j) {
+      const int i = i0 + tid + j * 512;
+      float acc = 0.f;
+      if (i < i1) {
+        int sb = 0;
+        for (; sb + 8 <= nblk; sb += 8) {   // 8 independent loads in flight, then a fixed-order sum (ppo_apply_split_kernel)
+          float t[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) t[u] = w.slabs[(long long)(sb + u) * o.total + i];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) acc += t[u];
+        }
+        for (; sb < nblk; ++sb) acc += w.slabs[(long long)sb * o.total + i];
+        sqs += acc * acc;
+      }
+      g[j] = acc;
+    }
+    {
+      const float part = block_sum<512>(sqs, lds);
+      if (tid == 0) w.statpart[bid * 8 + 5] = part;   // (slot 5 of the loss-statistic partials is unused by the gradient)
+    }
+    EP_TS(2);
+    if (!epoch_grid_sync(ctr, (++bar) * nwg, err, &s_flag)) return;
+    EP_TS(3);
+    // ---- B2: norm, clip, Adam on the own chunk; loss statistics
+    if (tid < 64) s_part[tid] = tid < nwg ? w.statpart[tid * 8 + 5] : 0.f;
+    __syncthreads();
+    float total_sq = 0.f;
+    for (int q = 0; q < nwg; ++q) total_sq += s_part[q];
+    const float total_norm = sqrtf(total_sq);
+    const float coef = fminf(max_norm / (total_norm + 1e-6f), 1.0f);   // torch.nn.utils.clip_grad_norm_
+    if (bid == 0 && stats != nullptr) {
+      __shared__ float s_st[5];
+      if (tid >= 64 && tid < 69) {   // one lane of the second wave per statistic (the order of ppo_apply_split_kernel)
+        const int kk = tid - 64;
+        float sv = 0.f;
+        for (int q = 0; q < nblk; ++q) sv += w.statpart[q * 8 + kk];
+        sv *= 1.f / (float)b;
+        stats[(long long)mb * 8 + kk] = sv;
+        s_st[kk] = sv;
+      }
+      __syncthreads();
+      if (tid == 0) {
+        stats[(long long)mb * 8 + 5] = s_st[0] + ent_coef * s_st[2] + vf_coef * s_st[1];  // loss
+        stats[(long long)mb * 8 + 6] = total_norm;
+        stats[(long long)mb * 8 + 7] = coef;
+      }
+    }
+    {
+      const float step_size = st.step_size[k], bc2_sqrt = st.bc2_sqrt[k];
+      float m_[NPC], v_[NPC], p_[NPC];
+#pragma unroll
+      for (int j = 0; j < NPC; ++j) {
+        const int i = min(i0 + tid + j * 512, o.total - 1);
+        m_[j] = m[i];
+        v_[j] = v[i];
+        p_[j] = P[i];
+      }
+#pragma unroll
+      for (int j = 0; j < NPC; ++j) {
+        const int i = i0 + tid + j * 512;
+        if (i < i1) {
+          const float gi = g[j] * coef;
+          const float mi = m_[j] + (gi - m_[j]) * (1.f - beta1);
+          const float vi = v_[j] * beta2 + (1.f - beta2) * gi * gi;
+          const float denom = sqrtf(vi) / bc2_sqrt + eps;
+          const float pn = p_[j] - step_size * (mi / denom);
+          P[i] = pn;
+          m[i] = mi;
+          v[i] = vi;
+          int dst = i;
+          auto tr = [&](int b0, int rows_, int cols) {
+            if (i >= b0 && i < b0 + rows_ * cols) {
+              const int r = (i - b0) / cols, cc = (i - b0) % cols;
+              dst = b0 + cc * rows_ + r;
+            }
+          };
+          tr(o.pW1, H, D); tr(o.pW2, H, H); tr(o.vW1, H, D); tr(o.vW2, H, H);
+          Pt[dst] = pn;
+        }
+      }
+    }
+    EP_TS(4);
+    if (!epoch_grid_sync(ctr, (++bar) * nwg, err, &s_flag)) return;
+    EP_TS(5);
+  }
+#undef EP_TS
+}
+
 // TIMING = false (production): the phase-clock accumulators (24 VGPRs of `tacc` alone) and every stamp are
 // compiled out -- the measurement build is a separate instantiation picked only while ia_ppo_debug_timing is on.
 template <int NPT, bool TIMING, int KS1, bool LOCAL>
@@ -3142,6 +3328,8 @@ int set_lds(K kern, size_t bytes) {
 }
 
 bool g_ppo_valu = false;  // tuning/debug: force the VALU kernels for H = 32 as well
+bool g_epoch_split = false;  // tuning/debug: two launches per minibatch for 64-wide towers too
+long long* g_epoch_dbg = nullptr;  // measurement: phase ticks of workgroup 0 of ppo_epoch_persistent_kernel
 }  // namespace
 
 extern "C" {
@@ -3477,6 +3665,18 @@ int ia_ppo_force_valu(int on) {
   return IA_OK;
 }
 
+// Tuning / measurement: 1 = ia_ppo_epoch launches the gradient and apply kernels per minibatch even where the
+// one-launch-per-epoch kernel applies (64-wide towers).
+int ia_ppo_epoch_split(int on) {
+  g_epoch_split = on != 0;
+  return IA_OK;
+}
+
+int ia_ppo_epoch_debug_timing(void* device_buffer_8xi64) {
+  g_epoch_dbg = (long long*)device_buffer_8xi64;
+  return IA_OK;
+}
+
 int64_t ia_ppo_grad_offset(const ia_policy_desc* d, int batch) {
   if (!pol_ok(d) || batch <= 0) return IA_ERR_ARG;
   const int nblk = cdiv(batch, ROWS);
@@ -3533,6 +3733,41 @@ int ia_ppo_epoch(const ia_policy_desc* d, float* params, float* params_t, float*
     IA_CHECK_LAUNCH();
   }
   const bool snap = d->has_norm && update_norm;
+  if (d->hidden == 64 && !g_ppo_valu && !g_epoch_split && g_tstamp == nullptr) {
+    // one launch per (<= 64 minibatches of the) epoch when every gradient workgroup can be resident at once
+    static int dev_cus = 0;
+    if (dev_cus == 0) {
+      int dev = 0;
+      if (hipGetDevice(&dev) != hipSuccess ||
+          hipDeviceGetAttribute(&dev_cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+        return IA_ERR_ARG;
+    }
+    const int nwg = cdiv(size_at(0), ROWS);
+    const int P = pol_offsets(d->obs_dim, d->act_dim, 64, d->discrete).total;
+    if (nwg <= dev_cus && nwg <= 64 && cdiv(P, nwg) <= 4 * 512) {
+      static bool attr = false;
+      const size_t mbytes = GLds<64>::total * sizeof(float);
+      if (!attr) { rc = set_lds(ppo_epoch_persistent_kernel<64>, mbytes); if (rc) return rc; attr = true; }
+      if (hipMemsetAsync(ws + 4, 0, 2 * sizeof(unsigned), a.st) != hipSuccess) return IA_ERR_ARG;   // barrier counter, error word
+      for (int first = 0; first < n_mb; first += EpochSteps::MAX) {
+        EpochSteps es{};
+        es.first = first;
+        es.n = std::min(EpochSteps::MAX, n_mb - first);
+        for (int k = 0; k < es.n; ++k) {
+          ++step;
+          es.step_size[k] = (float)(lr / (1.0 - pow(beta1, (double)step)));
+          es.bc2_sqrt[k] = (float)sqrt(1.0 - pow(beta2, (double)step));
+        }
+        if (first > 0 && hipMemsetAsync(ws + 4, 0, sizeof(unsigned), a.st) != hipSuccess) return IA_ERR_ARG;
+        hipLaunchKernelGGL(ppo_epoch_persistent_kernel<64>, dim3(nwg), dim3(512), mbytes, a.st, *d, params, params_t,
+                           exp_avg, exp_avg_sq, norm_mean, norm_var, g.obs, g.act, g.logp, g.adv, g.ret, total, batch_size,
+                           T, n_envs, normalize_adv, clip_range, ent_coef, vf_coef, max_grad_norm, (float)beta1,
+                           (float)beta2, adam_eps, ws, seq, snap ? 1 : 0, stats, es, g_epoch_dbg);
+        IA_CHECK_LAUNCH();
+      }
+      return IA_OK;
+    }
+  }
   for (long long start = 0; start < total; start += batch_size, ++mb) {
     const int b = size_at(start);
     ++step;

@@ -465,7 +465,12 @@ def test_timeout_bootstrap():
                                                         # large (data-parallel-sized) minibatches: 32 / 128
                                                         # gradient blocks, two-level slab reduction
                                                         (17, 6, 32, False, True, 16, 256, 2048),
-                                                        (17, 6, 32, False, True, 8, 2048, 8192)])
+                                                        (17, 6, 32, False, True, 8, 2048, 8192),
+                                                        # SB3's default MlpPolicy (64 x 64) at config-P minibatch size and
+                                                        # with a short last minibatch: the one-launch-per-epoch kernel
+                                                        # (minibatch steps as phases between grid barriers)
+                                                        (17, 6, 64, False, True, 16, 256, 1024),
+                                                        (4, 2, 64, True, True, 9, 100, 384)])
 @pytest.mark.parametrize("path", ["epoch", "update", "update_spread"])
 def test_ppo_epochs_match_oracle(D, A, H, discrete, norm, T, n, bs, path):
     """Two PPO epochs on a synthetic rollout: parameters, Adam state, RunningNorm state and the
