@@ -55,7 +55,7 @@ struct FusedArgs {
   float* logits; float* dlogits; int n_expert; float loss_scale;
   float* part;                                         // [tiles][8] statistics partials
   float* dump;                                         // [1024]: where the slice stores of rows past R go (disc_fb_kernel)
-  float* P1; float* P3;                                // per-tile partial slabs: [tiles][H*D+H], [tiles][H+1]
+  float* P1; float* P3;                                // per-tile partial slabs: [tiles][H*D+H], [tiles][2H+1] = [dW3 | db3 | db2]
   long long* dbg;                                      // measurement only (ia_disc_fused_debug_timing): phase clocks of block 0
   // gradient-penalty passes (MODE 1 / 2 of the tile kernels; R = interpolated rows, X = the [2R, ldx] assembled batch)
   const float* gp_e;                                   // [R] weights: x_hat_i = e_i X[i] + (1 - e_i) X[R + i]
@@ -236,8 +236,8 @@ __global__ __launch_bounds__(BM * 8) void disc_fwd_kernel(FusedArgs a) {
   float* bs = h1s + BM * LDH;          // NS x [FB_K][H] ring; holds the W1 image [H][XP] during layer 1
   float* red = bs + NS * BST;          // [4][BM] logit partials per column group
   float* dls = red + 4 * BM;           // [BM] dlogit of the tile's rows
-  float* w3red = dls + BM;             // [BM/32][H] dW3 partials per row group
-  float* xs = w3red + (BM / 32) * H;   // [BM][XP]
+  float* w3red = dls + BM;             // [2][BM/32][H] dW3 / db2 partials per row group
+  float* xs = w3red + 2 * (BM / 32) * H;   // [BM][XP]
   float* w1s = bs;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -426,9 +426,9 @@ __global__ __launch_bounds__(BM * 8) void disc_fwd_kernel(FusedArgs a) {
       float s = w3red[tid];
 #pragma unroll
       for (int g = 1; g < BM / 32; ++g) s += w3red[g * H + tid];
-      a.P3[(long long)blockIdx.x * (H + 1) + tid] = s;
+      a.P3[(long long)blockIdx.x * (2 * H + 1) + tid] = s;
     }
-    if (tid == 0) a.P3[(long long)blockIdx.x * (H + 1) + H] = 0.f;
+    if (tid == 0) a.P3[(long long)blockIdx.x * (2 * H + 1) + H] = 0.f;
     return;
   }
   // ---- epilogue: logit, BCE, dlogit, statistics, dW3/db3 partials, dh2
@@ -482,7 +482,7 @@ __global__ __launch_bounds__(BM * 8) void disc_fwd_kernel(FusedArgs a) {
     const int k = lane >> 3;
     if ((lane & 7) == 0) {
       if (k < 6) a.part[(long long)blockIdx.x * 8 + k] = tot;
-      else if (k == 6) a.P3[(long long)blockIdx.x * (H + 1) + H] = tot;
+      else if (k == 6) a.P3[(long long)blockIdx.x * (2 * H + 1) + H] = tot;
     }
   }
   __syncthreads();
@@ -493,22 +493,26 @@ __global__ __launch_bounds__(BM * 8) void disc_fwd_kernel(FusedArgs a) {
 #pragma unroll
   for (int t = 0; t < TN; ++t) {
     const int col = wn * WC + t * 32 + li;
-    float s = 0.f;
+    float s = 0.f, sb = 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int row = wm * 32 + 4 * lh + rowoff(r);
       s += dlr[r] * h2[t][r];
-      h1s[row * LDH + col] = h2[t][r] > 0.f ? dlr[r] * w3v[t] : 0.f;   // dh2 (the h1 tile is dead by now)
+      const float dv = h2[t][r] > 0.f ? dlr[r] * w3v[t] : 0.f;
+      h1s[row * LDH + col] = dv;   // dh2 (the h1 tile is dead by now)
+      sb += dv;                    // db2 = column sums of dh2 (the split-K product no longer carries them)
     }
     s += __shfl_xor(s, 32, 64);
-    if (lh == 0) w3red[wm * H + col] = s;
+    sb += __shfl_xor(sb, 32, 64);
+    if (lh == 0) { w3red[wm * H + col] = s; w3red[(BM / 32 + wm) * H + col] = sb; }
   }
   __syncthreads();
   if (tid < H) {
-    float s = w3red[tid];
+    float s = w3red[tid], sb = w3red[(BM / 32) * H + tid];
 #pragma unroll
-    for (int g = 1; g < BM / 32; ++g) s += w3red[g * H + tid];
-    a.P3[(long long)blockIdx.x * (H + 1) + tid] = s;
+    for (int g = 1; g < BM / 32; ++g) { s += w3red[g * H + tid]; sb += w3red[(BM / 32 + g) * H + tid]; }
+    a.P3[(long long)blockIdx.x * (2 * H + 1) + tid] = s;
+    a.P3[(long long)blockIdx.x * (2 * H + 1) + H + 1 + tid] = sb;
   }
   // dh2 tile -> HBM row-major in 16-byte stores (a dword-per-lane epilogue is store-issue bound)
 #pragma unroll
@@ -729,8 +733,8 @@ __global__ __launch_bounds__(BM * 8) void disc_fb_kernel(FusedArgs a) {
                                        // the P1 slab image at the end
   float* red = bs + NR * BST;          // [4][BM] logit partials per column group
   float* dls = red + 4 * BM;           // [BM] dlogit of the tile's rows
-  float* w3red = dls + BM;             // [BM/32][H] dW3 partials per row group
-  float* xs = w3red + (BM / 32) * H;   // [BM][XP3]: xn | 0 ... (layer 1's A operand; later [xn | 1 | 0 ...] as dW1's B)
+  float* w3red = dls + BM;             // [2][BM/32][H] dW3 / db2 partials per row group
+  float* xs = w3red + 2 * (BM / 32) * H;   // [BM][XP3]: xn | 0 ... (layer 1's A operand; later [xn | 1 | 0 ...] as dW1's B)
   float* w1s = bs;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -917,7 +921,7 @@ __global__ __launch_bounds__(BM * 8) void disc_fb_kernel(FusedArgs a) {
     const int k = lane >> 3;
     if ((lane & 7) == 0) {
       if (k < 6) a.part[(long long)blockIdx.x * 8 + k] = tot;
-      else if (k == 6) a.P3[(long long)blockIdx.x * (H + 1) + H] = tot;
+      else if (k == 6) a.P3[(long long)blockIdx.x * (2 * H + 1) + H] = tot;
     }
   }
   __syncthreads();
@@ -929,24 +933,28 @@ __global__ __launch_bounds__(BM * 8) void disc_fb_kernel(FusedArgs a) {
 #pragma unroll
     for (int t = 0; t < TN; ++t) {
       const int col = wn * WC + t * 32 + li;
-      float s = 0.f;
+      float s = 0.f, sb = 0.f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = wm * 32 + 4 * lh + rowoff(r);
         s += dlr[r] * h2[t][r];
-        h1s[row * LDH + col] = h2[t][r] > 0.f ? dlr[r] * w3v[t] : 0.f;   // dh2 (the h1 tile is dead by now)
+        const float dv = h2[t][r] > 0.f ? dlr[r] * w3v[t] : 0.f;
+        h1s[row * LDH + col] = dv;   // dh2 (the h1 tile is dead by now)
+        sb += dv;                    // db2 = column sums of dh2
         acc[t][r] = 0.f;
       }
       s += __shfl_xor(s, 32, 64);
-      if (lh == 0) w3red[wm * H + col] = s;
+      sb += __shfl_xor(sb, 32, 64);
+      if (lh == 0) { w3red[wm * H + col] = s; w3red[(BM / 32 + wm) * H + col] = sb; }
     }
   }
   __syncthreads();
   if (tid < H) {
-    float s = w3red[tid];
+    float s = w3red[tid], sb = w3red[(BM / 32) * H + tid];
 #pragma unroll
-    for (int g = 1; g < BM / 32; ++g) s += w3red[g * H + tid];
-    a.P3[(long long)blockIdx.x * (H + 1) + tid] = s;
+    for (int g = 1; g < BM / 32; ++g) { s += w3red[g * H + tid]; sb += w3red[(BM / 32 + g) * H + tid]; }
+    a.P3[(long long)blockIdx.x * (2 * H + 1) + tid] = s;
+    a.P3[(long long)blockIdx.x * (2 * H + 1) + H + 1 + tid] = sb;
   }
   FUSED_STAMP(a, 7);
 
@@ -1227,13 +1235,13 @@ __global__ __launch_bounds__(AS_NT) void disc_assemble_kernel(AssembleArgs a) {
 
 // ------------------------------------------------------------------------------------------- K5
 struct ReduceArgs {
-  const float* src[3]; long long stride[3]; int cnt[3]; long long seg_end[3];   // W1b1 | W2b2 | W3b3
+  const float* src[4]; long long stride[4]; int cnt[4]; long long seg_end[4];   // [W1 b1] | W2 | b2 | [W3 b3]
   long long n; int accumulate; float* grads;
   int adam; float* p; float* m; float* v; float beta1, beta2, eps, wd, step_size, bc2_sqrt;
   const float* part; int tiles; int R; int n_expert; float loss_scale; float* stats;
   float* W2T; float* W1P; int H; int D;   // images of W2 / W1 the tile kernels read: refreshed with the Adam step
   // gradient penalty: a second slab set per segment, summed behind the first (cnt2 = 0: none), and the penalty's mean
-  const float* src2[3]; long long stride2[3]; int cnt2[3];
+  const float* src2[4]; long long stride2[4]; int cnt2[4];
   const float* pen; int pen_tiles; int gp_rows; float* gp_out;
 };
 
@@ -1276,7 +1284,7 @@ __global__ __launch_bounds__(256) void disc_reduce_kernel(ReduceArgs a) {
   }
   const long long i = (long long)blockIdx.x * 64 + lane;
   const long long ic = i < a.n ? i : a.n - 1;
-  const int seg = ic < a.seg_end[0] ? 0 : (ic < a.seg_end[1] ? 1 : 2);
+  const int seg = ic < a.seg_end[0] ? 0 : (ic < a.seg_end[1] ? 1 : (ic < a.seg_end[2] ? 2 : 3));
   const long long base = seg == 0 ? 0 : a.seg_end[seg - 1];
   const float* src = a.src[seg] + (ic - base);
   const long long st = a.stride[seg];
@@ -1391,7 +1399,7 @@ inline FusedWs fused_ws_layout(const ia_mlp_desc* d, int R, float* base) {
   FusedWs w;
   long long o = 0;
   w.P1 = base + o; o += tiles * (H * D + H);
-  w.P3 = base + o; o += tiles * (H + 1);
+  w.P3 = base + o; o += tiles * (2 * H + 1);
   w.part = base + o; o += tiles * 8;
   o = (o + 3) / 4 * 4;                     // 16-byte aligned W2T rows
   w.W2T = base + o; o += H * H;
@@ -1425,7 +1433,7 @@ inline GpWs gp_ws_layout(const ia_mlp_desc* d, int B, int ldx, float* base) {
   w.m1 = reinterpret_cast<unsigned long long*>(base + o); o += tiles * 4 * (H / 128) * 16 * 2;
   w.m2 = reinterpret_cast<unsigned long long*>(base + o); o += tiles * 4 * (H / 128) * 16 * 2;
   w.P1 = base + o; o += tiles * (H * D + H);
-  w.P3 = base + o; o += tiles * (H + 1);
+  w.P3 = base + o; o += tiles * (2 * H + 1);
   w.pen = base + o; o += tiles;
   o = (o + 3) / 4 * 4;
   w.splits = B >= 8192 ? 32 : (B >= 256 ? B / 256 : 1);
@@ -1437,7 +1445,7 @@ inline GpWs gp_ws_layout(const ia_mlp_desc* d, int B, int ldx, float* base) {
 template <int H>
 int launch_gp_tiles(const FusedArgs& ga, int B, hipStream_t stream) {
   constexpr int BM = 32;
-  constexpr size_t smem_f = sizeof(float) * (BM * (H + 1) + NS * FB_K * H + 4 * BM + BM + (BM / 32) * H + BM * XP);
+  constexpr size_t smem_f = sizeof(float) * (BM * (H + 1) + NS * FB_K * H + 4 * BM + BM + 2 * (BM / 32) * H + BM * XP);
   constexpr size_t smem_b = sizeof(float) * (BM * XP3 + BM * (H + 1) + NS * FB_K * H + NS * BM * A_LD);
   static bool attr_set = false;
   if (!attr_set) {
@@ -1467,7 +1475,7 @@ int g_fused_bm = 64;   // rows per tile workgroup (tuning: ia_disc_fused_tile_ro
 bool g_fused_split = false;   // forward and backward tile passes as two launches (ia_disc_fused_split_tiles)
 template <int H, int BM>
 int launch_fused_tiles(const FusedArgs& fa, int R, hipStream_t stream) {
-  constexpr size_t smem_f = sizeof(float) * (BM * (H + 1) + NS * FB_K * H + 4 * BM + BM + (BM / 32) * H + BM * XP);
+  constexpr size_t smem_f = sizeof(float) * (BM * (H + 1) + NS * FB_K * H + 4 * BM + BM + 2 * (BM / 32) * H + BM * XP);
   constexpr size_t smem_b = sizeof(float) * (BM * XP3 + BM * (H + 1) + NS * FB_K * H + NS * BM * A_LD);
   static bool attr_set = false;
   if (!attr_set) {
@@ -1479,7 +1487,7 @@ int launch_fused_tiles(const FusedArgs& fa, int R, hipStream_t stream) {
     if (e != hipSuccess) return (int)e;
     attr_set = true;
   }
-  constexpr size_t smem_fb = sizeof(float) * (BM * (H + 1) + 3 * FB_K * H + 4 * BM + BM + (BM / 32) * H + BM * XP3);
+  constexpr size_t smem_fb = sizeof(float) * (BM * (H + 1) + 3 * FB_K * H + 4 * BM + BM + 2 * (BM / 32) * H + BM * XP3);
   static bool attr_fb = false;
   if (!attr_fb) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(disc_fb_kernel<H, BM>),
@@ -1659,7 +1667,7 @@ int ia_disc_step_fused(const ia_disc_step_args* a, void* stream_) {
     g.M = H; g.N = H; g.K = R;
     g.C = a->partials + n1; g.ldc = H;
     g.splits = splits; g.k_per_split = kps; g.c_split_stride = tot;
-    g.dbias = a->partials + n1 + (long long)H * H; g.dbias_split_stride = tot;
+    g.dbias = nullptr; g.dbias_split_stride = tot;   // (db2: column sums of dh2 in the tile pass -- 3.5 us less here)
     if ((rc = ia_launch_gemm(IA_GEMM_TN, g, stream))) return rc;
   }
 
@@ -1690,15 +1698,17 @@ int ia_disc_step_fused(const ia_disc_step_args* a, void* stream_) {
   }
 
   ReduceArgs ra{};
-  if (gp) {
+  const long long p3s = 2 * (long long)H + 1;   // tile slab of the last layer: [dW3 | db3 | db2]
+  if (gp) {   // (no bias gradients from the penalty: segment 2 has no second set)
     ra.src2[0] = gw.P1; ra.stride2[0] = n1; ra.cnt2[0] = gtiles;
     ra.src2[1] = gw.partials + n1; ra.stride2[1] = tot; ra.cnt2[1] = gw.splits;
-    ra.src2[2] = gw.P3; ra.stride2[2] = n3; ra.cnt2[2] = gtiles;
+    ra.src2[3] = gw.P3; ra.stride2[3] = p3s; ra.cnt2[3] = gtiles;
     ra.pen = gw.pen; ra.pen_tiles = gtiles; ra.gp_rows = a->n0; ra.gp_out = a->gp_out;
   }
   ra.src[0] = w.P1; ra.stride[0] = n1; ra.cnt[0] = tiles; ra.seg_end[0] = n1;
-  ra.src[1] = a->partials + n1; ra.stride[1] = tot; ra.cnt[1] = splits; ra.seg_end[1] = n1 + n2;
-  ra.src[2] = w.P3; ra.stride[2] = n3; ra.cnt[2] = tiles; ra.seg_end[2] = tot;
+  ra.src[1] = a->partials + n1; ra.stride[1] = tot; ra.cnt[1] = splits; ra.seg_end[1] = n1 + (long long)H * H;
+  ra.src[2] = w.P3 + H + 1; ra.stride[2] = p3s; ra.cnt[2] = tiles; ra.seg_end[2] = n1 + n2;
+  ra.src[3] = w.P3; ra.stride[3] = p3s; ra.cnt[3] = tiles; ra.seg_end[3] = tot;
   ra.n = tot; ra.accumulate = a->accumulate; ra.grads = a->grads;
   ra.adam = (a->adam && !a->accumulate) ? 1 : 0;
   ra.p = a->params; ra.m = a->exp_avg; ra.v = a->exp_avg_sq;
