@@ -395,7 +395,8 @@ def _fused_worker(rank, world, port, out_dir):
     reward_nets.BasicRewardNet.fused_adam_step = counting_adam
     reward_nets.ShapedRewardNet.fused_finish = counting_finish
 
-    def run(airl: bool, pipeline: bool, hid=(256, 256), normalize_output: bool = False, module: bool = False):
+    def run(airl: bool, pipeline: bool, hid=(256, 256), normalize_output: bool = False, module: bool = False,
+            gp: float = 0.0):
         th.manual_seed(100 + rank)
         np.random.seed(100 + rank)
         venv = SyntheticVecEnv(num_envs=cfg["n_envs"], obs_dim=17, act_dim=6, horizon=cfg["horizon"], seed=rank)
@@ -421,14 +422,18 @@ def _fused_worker(rank, world, port, out_dir):
             n_disc_updates_per_round=3, custom_logger=p.configure_logger(tempfile.mkdtemp(), []),
             data_parallel=DataParallel())
         tr.pipeline_rounds = pipeline
+        tr.disc_grad_penalty_coef = gp   # (opt-in; > 0: the penalty's tile passes inside the fused 256-wide update)
         tr.train(3 * cfg["n_envs"] * cfg["n_steps"])
         th.cuda.synchronize()
+        if gp > 0:
+            assert np.isfinite(float(tr.last_grad_penalty)) and float(tr.last_grad_penalty) >= 0
         sd = {f"disc/{k}": v.cpu() for k, v in tr._reward_net.state_dict().items()}
         sd.update({f"pol/{k}": v.cpu() for k, v in algo.policy.state_dict().items()})
         return sd
 
     for name, kw in (("gail", dict(airl=False, pipeline=True)), ("gail_seq", dict(airl=False, pipeline=False)),
                      ("gail128", dict(airl=False, pipeline=True, hid=(128, 128))),
+                     ("gail_gp", dict(airl=False, pipeline=True, gp=2.0)),
                      ("gail32", dict(airl=False, pipeline=True, hid=(32, 32))),
                      ("airl", dict(airl=True, pipeline=True)), ("airl_seq", dict(airl=True, pipeline=False)),
                      ("airl_norm", dict(airl=True, pipeline=True, normalize_output=True)),
@@ -449,7 +454,7 @@ def test_fused_updates_under_data_parallelism_replicas_identical(tmp_path):
     port = _free_port()
     mp.spawn(_fused_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     ld = lambda r, n: th.load(tmp_path / f"fused{r}_{n}.pt")
-    for name in ("gail", "gail_seq", "gail128", "gail32", "airl", "airl_seq", "airl_norm", "module"):
+    for name in ("gail", "gail_seq", "gail128", "gail_gp", "gail32", "airl", "airl_seq", "airl_norm", "module"):
         a, b = ld(0, name), ld(1, name)
         calls = a.pop("_fused_calls"); b.pop("_fused_calls")
         # 3 rounds x 3 updates, every one through the fused kernels (the nn.Module net: through the custom ops)
@@ -457,6 +462,8 @@ def test_fused_updates_under_data_parallelism_replicas_identical(tmp_path):
         for k in a:
             assert th.equal(a[k], b[k]), (name, k)
         assert all(bool(th.isfinite(v.float()).all()) for v in a.values())
+    # the penalty changed the parameters (same seeds otherwise) and went through the fused update + fused Adam launch
+    assert any(not th.equal(ld(0, "gail")[k], ld(0, "gail_gp")[k]) for k in ld(0, "gail") if k.startswith("disc/mlp.dense"))
     for name in ("gail", "airl"):
         a, s = ld(0, name), ld(0, name + "_seq")
         for k in a:
