@@ -1033,6 +1033,298 @@ __global__ __launch_bounds__(BM * 8) void disc_fb_kernel(FusedArgs a) {
   FUSED_STAMP(a, 12);
 }
 
+// ------------------------------------------------------------------------------------------- gradient penalty, one launch
+// The three penalty passes of a 32-row tile (disc_fwd_kernel<H,32,1>, disc_bwd_kernel<H,32,1>, disc_fwd_kernel<H,32,2>)
+// in ONE workgroup: what they hand from pass to pass -- relu'(h1), relu'(h2), u2, u1, the row coefficients C, v1 -- is
+// per tile, so the masks stay in the registers that took the ballots, C never leaves LDS, and the three chunk loops
+// (h1 W2^T, u2 W2, v1 W2^T: 3 NCH chunks of W2T | W2 | W2T) run as one stream through the 3-stage ring with the
+// register-double-buffered fragments of disc_fb_kernel. The W1 image stays resident (layer 1, the input gradient u1 W1
+// and C W1^T all read it). Only the second pass's GEMM operands u2 and v1 go to HBM, in slices beside the MFMAs of the
+// loop that reads them. Same arithmetic, same order as the three launches: bit-identical (`ia_disc_fused_split_tiles(1)`
+// keeps them; tests/test_disc_fused_gpu.py compares).
+template <int H>
+__global__ __launch_bounds__(256) void disc_gp_kernel(FusedArgs a) {
+  constexpr int BM = 32, NT = 256, NW = 4;
+  constexpr int TN = H / 128;
+  constexpr int WC = TN * 32;
+  constexpr int LDH = H + 1;
+  constexpr int NCH = H / FB_K;
+  constexpr int BST = FB_K * H;
+  constexpr int BV = BST / 4 / NT;
+  constexpr int NR = 3;
+  constexpr int SCR = (H * 25 > NW * 32 * 33) ? H * 25 : NW * 32 * 33;   // gn partial tiles, then the first-layer slab image
+  static_assert(BST % (4 * NT) == 0, "B chunk must divide among the threads");
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* h1s = smem;                   // [BM][LDH]   h1 -> u2 -> u1 -> v1
+  float* bs = h1s + BM * LDH;          // NR x [FB_K][H] ring
+  float* w1s = bs + NR * BST;          // [H][XP] W1 image, resident
+  float* scr = w1s + H * XP;           // [SCR]
+  float* w3red = scr + SCR;            // [H]
+  float* xs = w3red + H;               // [BM][XP3]: x_hat (normalised), later the row coefficients C
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const int wn = wave;
+  const int row0 = blockIdx.x * BM;
+  const int D = a.D;
+  const float* W1 = a.params;
+  const float* b1 = W1 + (long long)H * D;
+  const float* W2 = b1 + H;
+  const float* b2 = W2 + (long long)H * H;
+  const float* w3 = b2 + H;
+
+  f4 rb[BV], rb1[BV];
+  auto bload = [&](f4 (&r)[BV], int g) {
+    const float* src = g < NCH ? a.W2T + (long long)g * BST
+                               : (g < 2 * NCH ? W2 + (long long)(g - NCH) * BST : a.W2T + (long long)(g - 2 * NCH) * BST);
+#pragma unroll
+    for (int i = 0; i < BV; ++i) r[i] = *reinterpret_cast<const f4*>(src + (long long)(tid + i * NT) * 4);
+  };
+  auto bstore = [&](const f4 (&r)[BV], int g) {
+    float* S = bs + (g % NR) * BST;
+#pragma unroll
+    for (int i = 0; i < BV; ++i) *reinterpret_cast<f4*>(S + (tid + i * NT) * 4) = r[i];
+  };
+  constexpr int W1Q = H * XP / 4;
+  constexpr int W1V = (W1Q + NT - 1) / NT;
+  f4 w1v[W1V];
+#pragma unroll
+  for (int i = 0; i < W1V; ++i) w1v[i] = reinterpret_cast<const f4*>(a.W1P)[min(tid + i * NT, W1Q - 1)];
+  float b1v[TN], b2v[TN], w3v[TN];
+#pragma unroll
+  for (int t = 0; t < TN; ++t) {
+    const int col = wn * WC + t * 32 + li;
+    b1v[t] = b1[col]; b2v[t] = b2[col]; w3v[t] = w3[col];
+  }
+  load_x_tile<BM, true>(a, a.X, row0, xs, XP3, tid);
+  for (int e = tid; e < BM * (XP3 - 1 - a.ldx); e += NT) {  // columns [ldx, 32)
+    const int w = XP3 - 1 - a.ldx;
+    const int row = e / w, c = a.ldx + e - row * w;
+    xs[row * XP3 + c] = 0.f;
+  }
+  bload(rb, 0);
+  bload(rb1, 1);
+#pragma unroll
+  for (int i = 0; i < W1V; ++i)
+    if (tid + i * NT < W1Q) reinterpret_cast<f4*>(w1s)[tid + i * NT] = w1v[i];
+  bstore(rb, 0);
+  bstore(rb1, 1);
+  bload(rb, 2);
+  __syncthreads();
+
+  f32x16 acc[TN];
+  // layer-1 shaped product of the x tile with W1 (K = 24): at x_hat (first pass) and at C (second pass)
+  auto layer1 = [&]() {
+#pragma unroll
+    for (int t = 0; t < TN; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    float af[12], bf[12][TN];
+#pragma unroll
+    for (int ks = 0; ks < 12; ++ks) {
+      af[ks] = xs[li * XP3 + 2 * ks + lh];
+#pragma unroll
+      for (int t = 0; t < TN; ++t) bf[ks][t] = w1s[(wn * WC + t * 32 + li) * XP + 2 * ks + lh];
+    }
+#pragma unroll
+    for (int ks = 0; ks < 12; ++ks)
+#pragma unroll
+      for (int t = 0; t < TN; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[ks], bf[ks][t], acc[t], 0, 0, 0);
+  };
+  auto bit_of = [&](unsigned int lo, unsigned int hi, int idx) {
+    const unsigned int wlo = __builtin_amdgcn_readlane(lo, idx), whi = __builtin_amdgcn_readlane(hi, idx);
+    return (((lh ? whi : wlo) >> li) & 1u) != 0u;
+  };
+
+  // ---- h1 = relu(x_hat W1^T + b1); relu'(h1) ballots (word (t, r) in lane t*16 + r)
+  layer1();
+  unsigned long long mword1 = 0ull;
+#pragma unroll
+  for (int t = 0; t < TN; ++t) {
+    const int col = wn * WC + t * 32 + li;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = 4 * lh + rowoff(r);
+      const float v = fmaxf(acc[t][r] + b1v[t], 0.f);
+      h1s[row * LDH + col] = v;
+      const unsigned long long m = __ballot(v > 0.f);
+      if (lane == t * 16 + r) mword1 = m;
+      acc[t][r] = 0.f;
+    }
+  }
+  const unsigned int m1_lo = (unsigned int)mword1, m1_hi = (unsigned int)(mword1 >> 32);
+  __syncthreads();
+
+  // ---- one chunk loop of the stream: acc += tile(h1s) . chunk(g0 + c); the tile's rows go to `out` in slices (or not)
+  static_assert(BM * H / NCH / 2 == NT, "one 8-byte piece per thread and chunk");
+  const float* Ar = h1s + li * LDH + lh;
+  const int boff = wn * WC + li;
+  float fa[2][FB_K / 2], fb[2][FB_K / 2][TN];
+  auto chunk_loop = [&](const int g0, float* __restrict__ out) {
+    {
+      auto a_at = [&](int ks) { return Ar[2 * ks]; };
+      chunk_frags<H, TN>(fa[0], fb[0], a_at, bs + (g0 % NR) * BST + boff, lh);
+    }
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int g = g0 + c;
+      if (g + 2 < 3 * NCH) bstore(rb, g + 2);
+      if (g + 3 < 3 * NCH) bload(rb, g + 3);
+      const int e2 = c * NT + tid;
+      const int hrow = e2 / (H / 2), hcol = (e2 % (H / 2)) * 2;
+      float hv0 = 0.f, hv1 = 0.f;
+      if (out != nullptr) { hv0 = h1s[hrow * LDH + hcol]; hv1 = h1s[hrow * LDH + hcol + 1]; }
+      if (c + 1 < NCH) {
+        auto a_nx = [&](int ks) { return Ar[(c + 1) * FB_K + 2 * ks]; };
+        chunk_mfmas_and_next_frags<H, TN>(acc, fa[c & 1], fb[c & 1], fa[(c + 1) & 1], fb[(c + 1) & 1], a_nx,
+                                          bs + ((g + 1) % NR) * BST + boff, lh);
+      } else {
+        chunk_mfmas<TN>(acc, fa[c & 1], fb[c & 1]);
+      }
+      if (out != nullptr) {   // (wave-uniform; the store itself is unconditional: rows past R land in the dump slot)
+        float2 hv; hv.x = hv0; hv.y = hv1;
+        float* dst = row0 + hrow < a.R ? out + (long long)(row0 + hrow) * H + hcol : a.dump + 2 * tid;
+        *reinterpret_cast<float2*>(dst) = hv;
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      __syncthreads();
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+
+  // ---- z2 = h1 W2^T + b2: relu'(h2) ballots, u2 = relu'(h2) w3 (rows past R: 0) into the tile
+  chunk_loop(0, nullptr);
+  unsigned long long mword2 = 0ull;
+#pragma unroll
+  for (int t = 0; t < TN; ++t) {
+    const int col = wn * WC + t * 32 + li;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = 4 * lh + rowoff(r);
+      const bool on = fmaxf(acc[t][r] + b2v[t], 0.f) > 0.f;
+      h1s[row * LDH + col] = (on && row0 + row < a.R) ? w3v[t] : 0.f;
+      const unsigned long long m = __ballot(on);
+      if (lane == t * 16 + r) mword2 = m;
+      acc[t][r] = 0.f;
+    }
+  }
+  const unsigned int m2_lo = (unsigned int)mword2, m2_hi = (unsigned int)(mword2 >> 32);
+  __syncthreads();
+
+  // ---- u1 = relu'(h1) (u2 W2); u2 leaves for HBM beside the MFMAs
+  chunk_loop(NCH, a.dh2);
+#pragma unroll
+  for (int t = 0; t < TN; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const bool on = bit_of(m1_lo, m1_hi, t * 16 + r);
+      h1s[(4 * lh + rowoff(r)) * LDH + wn * WC + t * 32 + li] = on ? acc[t][r] : 0.f;
+    }
+  __syncthreads();
+
+  // ---- gn = u1 W1 (K = H split over the four waves), row coefficients -> xs := C, penalty partial (disc_bwd_kernel MODE 1)
+  {
+    constexpr int KQ = H / NW;
+    f32x16 accg;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) accg[r] = 0.f;
+    const bool cok = li < D;
+#pragma unroll 8
+    for (int s2 = 0; s2 < KQ / 2; ++s2) {
+      const int k = wave * KQ + 2 * s2 + lh;
+      const float af = h1s[li * LDH + k];
+      const float w1 = w1s[k * XP + min(li, XP - 1)];
+      accg = __builtin_amdgcn_mfma_f32_32x32x2f32(af, cok ? w1 : 0.f, accg, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) scr[(wave * 32 + 4 * lh + rowoff(r)) * 33 + li] = accg[r];
+  }
+  __syncthreads();
+  float pen_w = 0.f;
+  {
+    const float inv = (a.mean != nullptr && li < D) ? 1.f / sqrtf(a.var[min(li, D - 1)] + a.eps) : 1.f;
+#pragma unroll
+    for (int it = 0; it < 32 / (2 * NW); ++it) {
+      const int row = wave * (32 / NW) + 2 * it + lh;
+      const float gn = ((scr[row * 33 + li] + scr[(32 + row) * 33 + li]) + scr[(64 + row) * 33 + li]) +
+                       scr[(96 + row) * 33 + li];
+      const float g = li < D ? gn * inv : 0.f;
+      float sq = g * g;
+      sq += __shfl_xor(sq, 16, 64); sq += __shfl_xor(sq, 8, 64); sq += __shfl_xor(sq, 4, 64);
+      sq += __shfl_xor(sq, 2, 64); sq += __shfl_xor(sq, 1, 64);
+      const float n = sqrtf(sq);
+      const bool valid = row0 + row < a.R;
+      const float kk = (valid && n > 0.f) ? a.gp_coef / (float)a.R * 2.f * (n - a.gp_target) / n : 0.f;
+      xs[row * XP3 + li] = li < D ? kk * gn * inv * inv : 0.f;
+      const float pr = valid ? (n - a.gp_target) * (n - a.gp_target) : 0.f;
+      pen_w += __shfl(pr, 0, 64) + __shfl(pr, 32, 64);
+    }
+  }
+  if (lane == 0) xs[wave * XP3 + 32] = pen_w;
+  __syncthreads();
+  if (tid == 0) a.gp_pen[blockIdx.x] = ((xs[32] + xs[XP3 + 32]) + xs[2 * XP3 + 32]) + xs[3 * XP3 + 32];
+
+  // ---- first-layer slab [dW1 | 0] = u1^T . C (no bias column), image in `scr`
+  {
+    const long long n1 = (long long)H * D + H;
+    float* P1 = a.P1 + (long long)blockIdx.x * n1;
+    __syncthreads();   // (the gn partial tiles in `scr` have been read)
+    for (int mt = wave; mt < H / 32; mt += NW) {
+      f32x16 acc1;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc1[r] = 0.f;
+      float af[BM / 2], bf[BM / 2];
+#pragma unroll
+      for (int s = 0; s < BM / 2; ++s) {
+        const int k = 2 * s + lh;
+        af[s] = h1s[k * LDH + mt * 32 + li];
+        bf[s] = xs[k * XP3 + li];
+      }
+#pragma unroll
+      for (int s = 0; s < BM / 2; ++s) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(af[s], bf[s], acc1, 0, 0, 0);
+      if (li <= D) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int i = mt * 32 + 4 * lh + rowoff(r);
+          scr[li < D ? i * D + li : H * D + i] = acc1[r];
+        }
+      }
+    }
+    __syncthreads();
+    for (int e = tid; e < (int)(n1 / 4); e += NT)
+      reinterpret_cast<f4*>(P1)[e] = reinterpret_cast<const f4*>(scr)[e];
+  }
+
+  // ---- v1 = relu'(h1) (C W1^T) into the tile (every wave is past its reads of u1: the barrier above)
+  layer1();
+#pragma unroll
+  for (int t = 0; t < TN; ++t) {
+    const int col = wn * WC + t * 32 + li;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const bool on = bit_of(m1_lo, m1_hi, t * 16 + r);
+      h1s[(4 * lh + rowoff(r)) * LDH + col] = on ? acc[t][r] : 0.f;
+      acc[t][r] = 0.f;
+    }
+  }
+  __syncthreads();
+
+  // ---- t = v1 W2^T; v1 leaves for HBM beside the MFMAs; last-layer slab = column sums of relu'(h2) t
+  chunk_loop(2 * NCH, a.h1);
+#pragma unroll
+  for (int t = 0; t < TN; ++t) {
+    const int col = wn * WC + t * 32 + li;
+    float sum = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sum += bit_of(m2_lo, m2_hi, t * 16 + r) ? acc[t][r] : 0.f;
+    sum += __shfl_xor(sum, 32, 64);
+    if (lh == 0) w3red[col] = sum;
+  }
+  __syncthreads();
+  if (tid < H) a.P3[(long long)blockIdx.x * (2 * H + 1) + tid] = w3red[tid];
+  if (tid == 0) a.P3[(long long)blockIdx.x * (2 * H + 1) + H] = 0.f;
+}
+
 // ------------------------------------------------------------------------------------------- K1
 struct AssembleArgs {
   const float* obs[2]; const float* act_f32[2]; const int64_t* act_i64[2]; const float* next[2];
@@ -1442,6 +1734,8 @@ inline GpWs gp_ws_layout(const ia_mlp_desc* d, int B, int ldx, float* base) {
   return w;
 }
 
+int g_fused_bm = 64;   // rows per tile workgroup (tuning: ia_disc_fused_tile_rows)
+bool g_fused_split = false;   // forward and backward tile passes as two launches (ia_disc_fused_split_tiles)
 template <int H>
 int launch_gp_tiles(const FusedArgs& ga, int B, hipStream_t stream) {
   constexpr int BM = 32;
@@ -1461,6 +1755,20 @@ int launch_gp_tiles(const FusedArgs& ga, int B, hipStream_t stream) {
     attr_set = true;
   }
   const int tiles = cdivi(B, BM);
+  if (!g_fused_split) {
+    constexpr int SCR = (H * 25 > 4 * 32 * 33) ? H * 25 : 4 * 32 * 33;
+    constexpr size_t smem_g = sizeof(float) * (BM * (H + 1) + 3 * FB_K * H + H * XP + SCR + H + BM * XP3);
+    static bool attr_g = false;
+    if (!attr_g) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(disc_gp_kernel<H>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_g);
+      if (e != hipSuccess) return (int)e;
+      attr_g = true;
+    }
+    hipLaunchKernelGGL((disc_gp_kernel<H>), dim3(tiles), dim3(256), smem_g, stream, ga);
+    IA_CHECK_LAUNCH();
+    return IA_OK;
+  }
   hipLaunchKernelGGL((disc_fwd_kernel<H, BM, 1>), dim3(tiles), dim3(BM * 8), smem_f, stream, ga);
   IA_CHECK_LAUNCH();
   hipLaunchKernelGGL((disc_bwd_kernel<H, BM, 1>), dim3(tiles), dim3(BM * 8), smem_b, stream, ga);
@@ -1471,8 +1779,6 @@ int launch_gp_tiles(const FusedArgs& ga, int B, hipStream_t stream) {
 }
 
 
-int g_fused_bm = 64;   // rows per tile workgroup (tuning: ia_disc_fused_tile_rows)
-bool g_fused_split = false;   // forward and backward tile passes as two launches (ia_disc_fused_split_tiles)
 template <int H, int BM>
 int launch_fused_tiles(const FusedArgs& fa, int R, hipStream_t stream) {
   constexpr size_t smem_f = sizeof(float) * (BM * (H + 1) + NS * FB_K * H + 4 * BM + BM + 2 * (BM / 32) * H + BM * XP);

@@ -313,3 +313,45 @@ def test_one_launch_tile_pass_is_bit_identical_to_forward_plus_backward_launches
                 ii = th.nonzero((x != y).reshape(-1)).reshape(-1)
                 raise AssertionError(f"update {k}: {name} differ at {ii.numel()} of {x.numel()} places, first {ii[:6].tolist()}, "
                                      f"values {x.reshape(-1)[ii[:3]].tolist()} vs {y.reshape(-1)[ii[:3]].tolist()}")
+
+
+@pytest.mark.parametrize("hid,B,norm", [((256, 256), 1000, True), ((128, 128), 200, True), ((256, 256), 4096, False)])
+def test_one_launch_penalty_pass_is_bit_identical_to_its_three_launches(hid, B, norm):
+    """`disc_gp_kernel` (the penalty's three tile passes in one workgroup: masks in registers, C in LDS) against
+    `disc_fwd_kernel<.,32,1>` + `disc_bwd_kernel<.,32,1>` + `disc_fwd_kernel<.,32,2>` (`ia_disc_fused_split_tiles(1)`):
+    gradient (BCE + penalty), the penalty's mean and the second pass's GEMM operands bit for bit."""
+    od, ad = 17, 6
+    osp = spaces.Box(-np.inf, np.inf, (od,), np.float32)
+    asp = spaces.Box(-1, 1, (ad,), np.float32)
+    kw = dict(normalize_input_layer=p.RunningNorm) if norm else {}
+    e_tab, _ = _tables(6000, od, ad, False, 1)
+    g_tab, _ = _tables(6000, od, ad, False, 2)
+    rng = np.random.default_rng(9)
+    e_idx, g_idx = th.as_tensor(rng.integers(0, 6000, B)).to(DEV), th.as_tensor(rng.integers(0, 6000, B)).to(DEV)
+    e = th.rand(B, generator=th.Generator().manual_seed(4)).to(DEV)
+    R = 2 * B
+    outs = []
+    lib = L.load()
+    try:
+        for split in (1, 0):
+            lib.ia_disc_fused_split_tiles(split)
+            th.manual_seed(3)
+            net = reward_nets.BasicRewardNet(osp, asp, hid_sizes=hid, **kw).to(DEV)
+            with th.no_grad():
+                net.mlp.flat.mul_(2.5)
+            stats = th.zeros(8, device=DEV)
+            bce_ws = th.zeros(int(lib.ia_bce_ws_floats(R)), device=DEV)
+            with networks.training(net):
+                ws = net.disc_step_c([(e_tab, e_idx, B), (g_tab, g_idx, B)], B, 1.0, stats, bce_ws, accumulate=False,
+                                     adam=None, gp=(e, 3.0, 1.0))
+            th.cuda.synchronize()
+            n_act = 2 * B * hid[0]      # v1 | u2 at the head of the penalty workspace
+            outs.append((net.mlp.grad.clone(), ws["gp_out"].clone(), ws["gp_ws"][:n_act].clone(), stats.clone()))
+    finally:
+        lib.ia_disc_fused_split_tiles(0)
+    for name, x, y in zip(("gradient", "penalty", "v1 | u2", "statistics"), *outs):
+        if not th.equal(x, y):
+            ii = th.nonzero((x != y).reshape(-1)).reshape(-1)
+            raise AssertionError(f"{name} differ at {ii.numel()} of {x.numel()} places, first {ii[:6].tolist()}, values "
+                                 f"{x.reshape(-1)[ii[:3]].tolist()} vs {y.reshape(-1)[ii[:3]].tolist()}")
+    assert float(outs[0][1]) > 1e-3
