@@ -1,8 +1,10 @@
 // Host-side helpers of the C ABI (no device code): index draws that must reproduce NumPy's
 // legacy global generator bit for bit, runnable off the Python thread (ctypes drops the GIL).
+#include <chrono>
 #include <cstdint>
 #include <thread>
 #include <vector>
+#include <immintrin.h>
 
 #include "common.h"
 
@@ -110,4 +112,26 @@ extern "C" int ia_host_mt19937_permutations(uint32_t* key, int* pos, int64_t n, 
   for (int c = 0; c < count; ++c) legacy_permutation(key, p, n, out + (int64_t)c * n);
   *pos = p;
   return IA_OK;
+}
+
+// Host half of the rollout mailbox (policy_rollout_mailbox_kernel): spin until every one of the `n` flags the device
+// writes into pinned host memory has reached `target`. 0 = reached, 1 = timed out, -1 = a flag went negative (the
+// kernel gave up: aborted or its own time-out). Called through ctypes, i.e. without the GIL.
+extern "C" int ia_host_wait_i32(const volatile int32_t* flags, int n, int target, double timeout_s) {
+  if (!flags || n <= 0) return IA_ERR_ARG;
+  const auto t0 = std::chrono::steady_clock::now();
+  unsigned spins = 0;
+  for (;;) {
+    bool ok = true;
+    for (int i = 0; i < n; ++i) {
+      const int32_t v = flags[i];
+      if (v < 0) return -1;
+      if (v < target) { ok = false; break; }
+    }
+    if (ok) return 0;
+    _mm_pause();
+    if ((++spins & 4095u) == 0 &&
+        std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > timeout_s)
+      return 1;
+  }
 }

@@ -228,6 +228,10 @@ class GeneralTowers:
         return self.discrete
 
     # ---- rollout steps ---------------------------------------------------------------------------------------
+    def make_rollout_mailbox(self, *args, **kwargs):
+        """(the resident rollout kernel is the fused towers' act kernel: general towers launch per step)"""
+        return None
+
     def make_act_step(self, obs_tile: th.Tensor, noise_host: th.Tensor, acts: th.Tensor, clipped: th.Tensor,
                       val: th.Tensor, logp: th.Tensor):
         """Rollout-step launcher (Box heads): stage this step's observations and noise from the pinned host tiles,

@@ -263,6 +263,62 @@ class ActorCriticPolicy:
 
         return step
 
+    def make_rollout_mailbox(self, obs_tile: th.Tensor, noise_dev: th.Tensor, acts: th.Tensor, clipped: th.Tensor,
+                             val: th.Tensor, logp: th.Tensor, T: int, timeout_s: float = 120.0):
+        """The rollout's act steps as ONE resident launch (`ia_policy_rollout_mailbox`) on the current stream: returns
+        `(post, wait, close)` -- `post(t)` tells the device that step t's observations (and noise) are in their pinned
+        tiles, `wait(t)` returns True once every workgroup has acknowledged step t (its clipped actions are in host memory;
+        spins in C without the GIL) and False when the device has left the rollout (it waits `timeout_s` for a step, e.g.
+        an environment that took minutes: the caller then runs this and the remaining steps as per-step launches, which
+        rewrite the same values), `close()` aborts a kernel that has steps left (error paths) -- or None when the shape is
+        not covered (the caller launches `make_act_step`'s kernel per step). Same tiles, same values as `make_act_step`."""
+        assert not (self.training and self.features_extractor.normalize is not None), \
+            "the rollout step runs in eval mode (a train-mode forward would update the feature statistics)"
+        lib = L.load()
+        n = obs_tile.shape[1]
+        nblk = (n + 63) // 64
+        box = getattr(self, "_mailbox_flags", None)
+        if box is None or box[1].numel() != nblk:
+            box = self._mailbox_flags = (th.zeros(1, dtype=th.int32).pin_memory(), th.zeros(nblk, dtype=th.int32).pin_memory())
+        ready, done = box
+        ready.zero_()
+        done.zero_()
+        nm, nv = self._norm_ptrs()
+        stride = lambda t: t.stride(0)
+        rc = lib.ia_policy_rollout_mailbox(
+            C.byref(self.desc), L.ptr(self._flat), L.ptr(self._flat_t), nm, nv, n, L.ptr(self._low), L.ptr(self._high),
+            obs_tile.data_ptr(), stride(obs_tile), noise_dev.data_ptr(), stride(noise_dev) if noise_dev.dim() == 3 else 0,
+            acts.data_ptr(), stride(acts), clipped.data_ptr(), stride(clipped), val.data_ptr(), stride(val),
+            logp.data_ptr(), stride(logp), T, ready.data_ptr(), done.data_ptr(), float(timeout_s), L.stream())
+        if rc == L.ERR_UNSUPPORTED:
+            return None
+        L.check(rc, "ia_policy_rollout_mailbox")
+        ready_np = ready.numpy()
+        done_ptr = done.data_ptr()
+        wait_fn = lib.ia_host_wait_i32
+        state = {"posted": 0, "acked": 0}
+
+        def post(t: int) -> None:
+            ready_np[0] = t + 1
+            state["posted"] = t + 1
+
+        def wait(t: int) -> bool:
+            rc_ = wait_fn(done_ptr, nblk, t + 1, float(timeout_s) + 30.0)
+            if rc_ == 0:
+                state["acked"] = t + 1
+                return True
+            ready_np[0] = -1
+            if rc_ == 1:
+                raise RuntimeError(f"rollout mailbox: step {t} was neither acknowledged nor given up by the device")
+            state["acked"] = T          # (nothing left to abort)
+            return False
+
+        def close() -> None:
+            if state["acked"] < T:
+                ready_np[0] = -1   # the kernel's workgroups leave at their next poll
+
+        return post, wait, close
+
     @property
     def samples_on_host(self) -> bool:
         """Discrete head sampled by torch.multinomial on the host (the reference's RNG stream)."""

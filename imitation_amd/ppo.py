@@ -358,6 +358,10 @@ class PPO(OnPolicyAlgorithm):
         self._post_enqueue_work = []
         self._act_stream = None
         self.predraw_noise = os.environ.get("IA_PREDRAW_NOISE", "1") != "0"   # see `collect_rollouts`
+        # the rollout's act steps as one resident launch driven through flags in pinned host memory (`collect_rollouts`)
+        self.rollout_mailbox = os.environ.get("IA_ROLLOUT_MAILBOX", "1") != "0"
+        self.rollout_mailbox_timeout_s = 120.0   # how long the resident kernel waits for ONE environment step before it
+                                                 # leaves (the rollout then continues with per-step launches)
         self.rollout_window_ms = None
         self.rollout_profile = None
         self._dp_obs = th.zeros(min(self.batch_size, total), p.obs_dim, device=self.device)
@@ -534,6 +538,7 @@ class PPO(OnPolicyAlgorithm):
         act_stream.wait_stream(stream)     # parameters / statistics written by the previous update
         host_sampling = pol.samples_on_host  # Discrete head on the reference's torch.multinomial stream
         predrawn = False
+        mailbox = None
         with th.cuda.stream(act_stream):
             if host_sampling:
                 rb.ensure_host_sampling_tiles(pol.act_dim)
@@ -555,15 +560,45 @@ class PPO(OnPolicyAlgorithm):
                     pol.draw_noise_into(noise_tile)
                 predrawn = noise_tile.dim() == 3
                 act_step = pol.make_act_step(rb.h_obs, noise_tile, rb.acts, rb.h_clip, rb.val, rb.logp)  # eval mode: no norm update
+                # ONE resident launch for the rollout's T act steps, driven through flags in pinned host memory: a step
+                # then costs the host a flag write and a poll instead of a launch and a stream synchronisation
+                # (`ActorCriticPolicy.make_rollout_mailbox`; None: shapes its kernel does not cover)
+                if self.rollout_mailbox and hasattr(pol, "make_rollout_mailbox"):
+                    mailbox = pol.make_rollout_mailbox(rb.h_obs, noise_tile, rb.acts, rb.h_clip, rb.val, rb.logp, T,
+                                                       timeout_s=self.rollout_mailbox_timeout_s)
         h_clip_np = rb.h_clip.numpy()
+        try:
+            return self._rollout_steps(env, callback, rb, T, n, pol, rw, bw, base, fused_net, module_net, act_step, mailbox,
+                                       act_stream, host_sampling, predrawn, starts, per_step_rews, prof, tick, h_clip_np,
+                                       h_rew_np, h_dones_np, h_trunc_np, h_next_np, h_obs_np, h_starts_np, stream)
+        finally:
+            if mailbox is not None:
+                mailbox[2]()
+
+    def _rollout_steps(self, env, callback, rb, T, n, pol, rw, bw, base, fused_net, module_net, act_step, mailbox,
+                       act_stream, host_sampling, predrawn, starts, per_step_rews, prof, tick, h_clip_np, h_rew_np,
+                       h_dones_np, h_trunc_np, h_next_np, h_obs_np, h_starts_np, stream) -> bool:
+        """The step loop and the tail of `collect_rollouts` (its own function so that the rollout mailbox is closed on
+        every way out)."""
         for t in range(T):
             t0 = tick() if prof is not None else 0.0
             if not host_sampling and not predrawn:
                 pol.draw_noise_into(rb.h_noise)
             t1 = tick() if prof is not None else 0.0
-            act_step(t)
+            if mailbox is not None:
+                mailbox[0](t)
+            else:
+                act_step(t)
             t2 = tick() if prof is not None else 0.0
-            act_stream.synchronize()       # (so everything the act kernels wrote is complete before `stream` reads it)
+            if mailbox is not None and not mailbox[1](t):
+                # the resident kernel gave up waiting (an env step longer than its time-out): per-step launches from here
+                # on, this step included (the workgroups that did run it wrote the same values)
+                mailbox = None
+                act_stream.synchronize()
+                with th.cuda.stream(act_stream):
+                    act_step(t)
+            if mailbox is None:
+                act_stream.synchronize()   # (so everything the act kernels wrote is complete before `stream` reads it)
             if t == 0:
                 t_first_step = tick()      # the previous update has finished: the device is free from here on
                 self._check_update_error()

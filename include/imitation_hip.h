@@ -350,6 +350,21 @@ int ia_policy_transpose(const ia_policy_desc* d, const float* params, float* par
 int ia_policy_act(const ia_policy_desc* d, const float* params, const float* params_t, const float* norm_mean,
                   const float* norm_var, const float* obs, int n, const float* noise, const float* low,
                   const float* high, float* actions, float* clipped, float* values, float* logp, void* stream);
+/* [SB3 `collect_rollouts`'s per-step `policy.forward`] for a whole rollout in ONE resident launch: the workgroups take
+ * step t when `ready[0]` (int32 in pinned, device-mapped host memory) reaches t + 1 -- the host posts it after the
+ * step's observations / noise are in their pinned tiles --, run the body of `ia_policy_act` on the step's tiles (strides
+ * in floats between consecutive steps; 0 = the same tile every step) and acknowledge in `done[workgroup]` (pinned host
+ * memory, ceil(n / 64) ints) once the step's outputs, the clipped actions in host memory first of all, have left.
+ * Bounded: `ready[0] < 0` (abort) or `timeout_s` without a new step end the kernel; `done` then holds -(t + 1).
+ * IA_ERR_UNSUPPORTED (-> launch `ia_policy_act` per step) for shapes the matrix-core act kernel does not cover. */
+int ia_policy_rollout_mailbox(const ia_policy_desc* d, const float* params, const float* params_t, const float* norm_mean,
+                              const float* norm_var, int n, const float* low, const float* high, const float* obs,
+                              int64_t s_obs, const float* noise, int64_t s_noise, float* actions, int64_t s_act,
+                              float* clipped, int64_t s_clip, float* values, int64_t s_val, float* logp, int64_t s_lp,
+                              int T, const int32_t* ready, int32_t* done, double timeout_s, void* stream);
+/* Host half: spin (no GIL under ctypes) until all `n` flags have reached `target`. 0 reached, 1 timed out, -1 a flag is
+ * negative (the kernel gave up). */
+int ia_host_wait_i32(const volatile int32_t* flags, int n, int target, double timeout_s);
 
 /* [SB3 evaluate_actions / predict_values] without grad (adversarial/common.py:490-496): any of
  * logp/values/entropy may be NULL. actions: fp32 [n,act_dim] (Box) or fp32 action index [n]. */

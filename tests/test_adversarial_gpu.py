@@ -133,6 +133,53 @@ def test_pipelined_rounds_are_bit_identical(tmp_path, case):
     assert len(logs[True]["progress.csv"]) == 4
 
 
+@pytest.mark.parametrize("case", ["gail_box", "gail_f64", "airl_box", "gail_generic_vecenv", "gail_tuned_hps"])
+def test_rollout_mailbox_equals_per_step_launches(tmp_path, case):
+    """The rollout's act steps as one resident launch driven through flags in pinned host memory
+    (`ia_policy_rollout_mailbox`, default) against one `ia_policy_act` launch + stream synchronisation per step: every
+    array of the trainer snapshot bit for bit (small tiles: a step's observation tile shares cache lines with the next
+    step's -- the case the system-scope loads are there for)."""
+    if case not in harness.CASES:
+        pytest.skip(f"no case {case}")
+    outs = {}
+    for mode in (True, False):
+        cfg = harness.CASES[case]
+        tr, _ = harness.build_trainer("hip", cfg, str(tmp_path / f"m{mode}"), device="cuda")
+        tr.gen_algo.rollout_mailbox = mode
+        tr.train(3 * cfg["n_envs"] * cfg["n_steps"])
+        outs[mode] = harness.snapshot(tr)
+    for k in outs[True]:
+        assert np.array_equal(np.asarray(outs[True][k]), np.asarray(outs[False][k]), equal_nan=True), k
+
+
+def test_rollout_mailbox_survives_a_slow_environment_step(tmp_path):
+    """The resident act kernel waits a bounded time for each step; an environment step that takes longer makes it leave,
+    and the rollout continues with per-step launches from that step on -- same values as an undisturbed run."""
+    import time
+
+    cfg = harness.CASES["gail_box"]
+    outs = {}
+    for slow in (True, False):
+        tr, _ = harness.build_trainer("hip", cfg, str(tmp_path / f"s{slow}"), device="cuda")
+        algo = tr.gen_algo
+        if slow:
+            algo.rollout_mailbox_timeout_s = 0.05
+            base = algo._unwrap(algo.env)[2]
+            orig, calls = base.step_async, [0]
+
+            def step_async(actions, _orig=orig, _calls=calls):
+                _calls[0] += 1
+                if _calls[0] in (3, 21):     # inside the first and the second rollout
+                    time.sleep(0.3)
+                return _orig(actions)
+
+            base.step_async = step_async
+        tr.train(3 * cfg["n_envs"] * cfg["n_steps"])
+        outs[slow] = harness.snapshot(tr)
+    for k in outs[True]:
+        assert np.array_equal(np.asarray(outs[True][k]), np.asarray(outs[False][k]), equal_nan=True), k
+
+
 @pytest.mark.parametrize("over", [dict(), dict(demo_batch=300, n_demo=400, norm_disc=False),
                                   dict(obs_dim=17, act_dim=6, demo_batch=640, n_demo=700),
                                   # > 32 potential inputs (two column tiles / five chunks), the scripts' default blocks
