@@ -124,6 +124,11 @@ class _PermutationPredraw:
 
         self._thread = HostWorker.named("permutations").submit(work)
 
+    def ready(self) -> bool:
+        """The helper has filled `out` (whether the draw is ADOPTED is decided by `finish`)."""
+        t = self._thread
+        return t is not None and t.is_set() and self._rc == 0
+
     def finish(self, out: np.ndarray) -> bool:
         """True if `out` now holds the permutations and the global generator has advanced past them."""
         t, self._thread = self._thread, None
@@ -335,6 +340,7 @@ class PPO(OnPolicyAlgorithm):
         self._perm_host = th.zeros(self.n_epochs, total, dtype=th.int64).pin_memory()
         self._perm_dev = th.zeros(self.n_epochs, total, dtype=th.int64, device=self.device)
         self._perm_np = self._perm_host.numpy()
+        self._perm_uploaded = None     # event of an upload made beside the rollout (`_upload_permutations_early`)
         self._predraw = _PermutationPredraw(self.n_epochs, total)
         self.update_events = None  # optional (start, end) torch events around the persistent update launch
         self._stats_dev = th.zeros(self.n_epochs, self._n_mb, 8, device=self.device)
@@ -515,6 +521,7 @@ class PPO(OnPolicyAlgorithm):
         if self._dp_global():
             self._dpg["perms"].start(self._dpg["perm_np"])   # shared across ranks; consumed by the next train()
         else:
+            self._perm_uploaded = None
             self._predraw.start(self._perm_np)  # consumed by the `train()` that follows
         stream = th.cuda.current_stream()
         rb.h_obs[0].copy_(th.as_tensor(np.asarray(self._last_obs)).reshape(n, -1))
@@ -575,6 +582,20 @@ class PPO(OnPolicyAlgorithm):
             if mailbox is not None:
                 mailbox[2]()
 
+    def _upload_permutations_early(self, stream) -> None:
+        """The pre-drawn permutations of the update that follows this rollout go to the device as soon as the helper
+        thread has them (a side stream, beside the environment stepping). `train()` adopts the upload if it adopts the
+        draw (`_PermutationPredraw.finish`), else it draws and uploads in place as before."""
+        if self._perm_uploaded is not None or self._dp_global() or not self._predraw.ready():
+            return
+        up = L.side_stream(self.device, "upload")
+        up.wait_stream(stream)              # (the previous update, the last reader of the device copy, has been enqueued there)
+        with th.cuda.stream(up):
+            self._perm_dev.copy_(self._perm_host, non_blocking=True)
+            ev = th.cuda.Event()
+            ev.record()
+        self._perm_uploaded = ev
+
     def _rollout_steps(self, env, callback, rb, T, n, pol, rw, bw, base, fused_net, module_net, act_step, mailbox,
                        act_stream, host_sampling, predrawn, starts, per_step_rews, prof, tick, h_clip_np, h_rew_np,
                        h_dones_np, h_trunc_np, h_next_np, h_obs_np, h_starts_np, stream) -> bool:
@@ -634,6 +655,8 @@ class PPO(OnPolicyAlgorithm):
             else:
                 h_rew_np[t] = env_rews
             self._last_obs, starts = new_obs, np.asarray(dones, dtype=bool)
+            if t >= 1 and self._perm_uploaded is None:
+                self._upload_permutations_early(stream)
             if prof is not None:
                 prof["bookkeeping"] = prof.get("bookkeeping", 0.0) + tick() - prof.pop("_t_book")
         self._last_episode_starts = starts
@@ -837,10 +860,15 @@ class PPO(OnPolicyAlgorithm):
         dpg = self._dpg if self._dp_global() else None
         perm = self._perm_np
         if dpg is None:
+            early, self._perm_uploaded = self._perm_uploaded, None
             if not self._predraw.finish(perm):
+                early = None
                 for e in range(self.n_epochs):  # one global-NumPy draw per epoch, as RolloutBuffer.get does
                     perm[e] = np.random.permutation(T * n)
-            self._perm_dev.copy_(self._perm_host, non_blocking=True)
+            if early is not None:   # uploaded beside the rollout (`_upload_permutations_early`): 1.3 MB of PCIe time that
+                th.cuda.current_stream().wait_event(early)   # would sit between the last env step and the update
+            else:
+                self._perm_dev.copy_(self._perm_host, non_blocking=True)
         rn = pol.features_extractor.normalize
         g = pol.optimizer.param_groups[0]
         rec = None
@@ -850,8 +878,6 @@ class PPO(OnPolicyAlgorithm):
                 self._fin_stream = L.side_stream(self.device, "readback")
             rec = self._records[self._rec_i % 2]
             self._rec_i += 1
-            rec.val.copy_(rb.val)   # the tile is reused by the next rollout before the statistics are read
-            rec.ret.copy_(rb.ret)
         stats_dev = rec.stats if rec is not None else self._stats_dev
         if not pol.fused:
             # general towers: [SB3 PPO.train]'s minibatch loop on the generic stacks (one gradient all-reduce per
@@ -903,6 +929,10 @@ class PPO(OnPolicyAlgorithm):
             pol.optimizer.step_count += self._n_mb
         self._n_updates += self.n_epochs
         if rec is not None:
+            # (behind the update's launch, not ahead of it: the update neither writes these tiles nor do they change before
+            #  the next rollout's act kernels, which are ordered behind this stream)
+            rec.val.copy_(rb.val)   # the tile is reused by the next rollout before the statistics are read
+            rec.ret.copy_(rb.ret)
             if self.dp is not None and self.dp.world > 1 and dpg is None:   # that path wrote the shared statistics tile
                 rec.stats.copy_(self._stats_dev)
             if rec.log_std is not None:
