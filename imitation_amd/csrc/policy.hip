@@ -3472,6 +3472,18 @@ int ia_policy_rollout_mailbox(const ia_policy_desc* d, const float* params, cons
   if (!pol_ok(d) || n <= 0 || T <= 0 || !ready || !done || !obs || !actions || !clipped || !values || !logp)
     return IA_ERR_ARG;
   if (g_ppo_valu || (d->hidden != 32 && d->hidden != 64)) return IA_ERR_UNSUPPORTED;
+  {
+    // every workgroup stays resident for the whole rollout and the host waits for ALL of them at every step: more
+    // workgroups than the device can hold at once would leave the surplus waiting for the residents forever
+    static int dev_cus = 0;
+    if (dev_cus == 0) {
+      int dev = 0;
+      if (hipGetDevice(&dev) != hipSuccess ||
+          hipDeviceGetAttribute(&dev_cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+        return IA_ERR_ARG;
+    }
+    if (cdiv(n, ROWS) > dev_cus) return IA_ERR_UNSUPPORTED;   // (one workgroup per CU is always possible)
+  }
   ActMailbox mb{obs, s_obs, noise, s_noise, actions, s_act, clipped, s_clip, values, s_val, logp, s_lp, T,
                 reinterpret_cast<const int*>(ready), reinterpret_cast<int*>(done), (long long)(timeout_s * 1e8)};
   int rc;
