@@ -479,7 +479,7 @@ class ActorCriticCnnPolicy:
                 h_logits.copy_(d["logits"], non_blocking=True)
                 val[t].copy_(d["values"].reshape(n))
             stream_obj.synchronize()
-            dist = th.distributions.Categorical(logits=h_logits)
+            dist = th.distributions.Categorical(logits=h_logits, validate_args=False)
             a = dist.sample()
             h_logp[t].copy_(dist.log_prob(a))
             h_clip[t].copy_(a.reshape(n, 1))

@@ -270,7 +270,7 @@ class GeneralTowers:
                 h_logits.copy_(ws["out"], non_blocking=True)
                 val[t].copy_(ws["val"].reshape(n))
             stream_obj.synchronize()
-            dist = th.distributions.Categorical(logits=h_logits)
+            dist = th.distributions.Categorical(logits=h_logits, validate_args=False)
             a = dist.sample()
             h_logp[t].copy_(dist.log_prob(a))
             h_clip[t].copy_(a.reshape(n, 1))

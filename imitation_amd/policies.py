@@ -348,7 +348,8 @@ class ActorCriticPolicy:
             if rc != 0:
                 L.check(rc, "ia_policy_logits")
             stream_obj.synchronize()
-            dist = th.distributions.Categorical(logits=h_logits)
+            # (validate_args=False: same values, same draws from the generator; the argument checks are a fifth of a step)
+            dist = th.distributions.Categorical(logits=h_logits, validate_args=False)
             a = dist.sample()
             h_logp[t].copy_(dist.log_prob(a))
             h_clip[t].copy_(a.reshape(n, 1))

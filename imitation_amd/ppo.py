@@ -618,7 +618,7 @@ class PPO(OnPolicyAlgorithm):
                 act_stream.synchronize()
                 with th.cuda.stream(act_stream):
                     act_step(t)
-            if mailbox is None:
+            if mailbox is None and not host_sampling:   # (the host-sampling step has waited for its own launch already)
                 act_stream.synchronize()   # (so everything the act kernels wrote is complete before `stream` reads it)
             if t == 0:
                 t_first_step = tick()      # the previous update has finished: the device is free from here on
