@@ -479,9 +479,9 @@ class ActorCriticCnnPolicy:
                 h_logits.copy_(d["logits"], non_blocking=True)
                 val[t].copy_(d["values"].reshape(n))
             stream_obj.synchronize()
-            dist = th.distributions.Categorical(logits=h_logits, validate_args=False)
-            a = dist.sample()
-            h_logp[t].copy_(dist.log_prob(a))
+            from imitation_amd.policies import categorical_sample   # (local: policies imports this module)
+            a, lp = categorical_sample(h_logits)
+            h_logp[t].copy_(lp)
             h_clip[t].copy_(a.reshape(n, 1))
 
         return step

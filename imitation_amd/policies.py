@@ -45,6 +45,18 @@ class NormalizeFeaturesExtractor(FlattenExtractor):
         self.normalize = normalize_class(self.features_dim)
 
 
+def categorical_sample(logits: th.Tensor):
+    """`d = torch.distributions.Categorical(logits=logits); a = d.sample(); return a, d.log_prob(a)` op for op -- the
+    normalisation `logits - logsumexp`, `softmax` of that, ONE `torch.multinomial(probs, 1, True)` on the global
+    generator, a gather of the normalised logits -- without the distribution object (argument validation, lazy
+    properties, broadcasting helpers: 45 us of a 125 us rollout step at 8 environments). Same values, same draws
+    (`tests/test_host_logic.py::test_categorical_sample_equals_torch_distributions`)."""
+    lg = logits - logits.logsumexp(dim=-1, keepdim=True)
+    probs = th.nn.functional.softmax(lg, dim=-1)
+    a = th.multinomial(probs.reshape(-1, probs.shape[-1]), 1, True).T.reshape(probs.shape[:-1])
+    return a, lg.gather(-1, a.unsqueeze(-1)).squeeze(-1)
+
+
 class ActorCriticPolicy:
     fused = True   # False once `general_policy.adopt` re-classed the instance (towers outside the fused kernels)
 
@@ -348,10 +360,8 @@ class ActorCriticPolicy:
             if rc != 0:
                 L.check(rc, "ia_policy_logits")
             stream_obj.synchronize()
-            # (validate_args=False: same values, same draws from the generator; the argument checks are a fifth of a step)
-            dist = th.distributions.Categorical(logits=h_logits, validate_args=False)
-            a = dist.sample()
-            h_logp[t].copy_(dist.log_prob(a))
+            a, lp = categorical_sample(h_logits)
+            h_logp[t].copy_(lp)
             h_clip[t].copy_(a.reshape(n, 1))
 
         return step

@@ -529,3 +529,28 @@ def test_production_kernels_do_not_spill():
         assert ks, sub
         for k in ks:
             assert k["vgpr_spill"] == 0, (sub, k)
+
+
+@pytest.mark.parametrize("shape", [(8, 2), (1024, 6), (5, 13), (3, 1)])
+def test_categorical_sample_equals_torch_distributions(shape):
+    """`policies.categorical_sample` (the host-sampled Discrete rollout step): actions, log-probabilities and the global
+    generator's state after the draw equal `torch.distributions.Categorical(logits).sample()` / `.log_prob()` -- what
+    [SB3 CategoricalDistribution] composes -- bit for bit, over several consecutive steps."""
+    from imitation_amd.policies import categorical_sample
+
+    g = th.Generator().manual_seed(5)
+    for scale in (1.0, 8.0):
+        logits = [th.randn(*shape, generator=g) * scale for _ in range(4)]
+        th.manual_seed(9)
+        ref = []
+        for lg in logits:
+            d = th.distributions.Categorical(logits=lg)
+            a = d.sample()
+            ref.append((a, d.log_prob(a)))
+        ref_state = th.get_rng_state()
+        th.manual_seed(9)
+        got = [categorical_sample(lg) for lg in logits]
+        assert th.equal(th.get_rng_state(), ref_state)
+        for (a, lp), (ra, rlp) in zip(got, ref):
+            assert th.equal(a, ra) and a.dtype == ra.dtype and a.shape == ra.shape
+            assert th.equal(lp, rlp)
