@@ -266,14 +266,13 @@ __global__ __launch_bounds__(ROWS) void policy_eval_kernel(ia_policy_desc d, con
 // callers that sample on the host with the reference's own RNG call ([SB3 CategoricalDistribution.sample] =
 // torch.multinomial on torch's global CPU generator). Thread per row.
 template <int H>
-__global__ __launch_bounds__(ROWS) void policy_logits_kernel(ia_policy_desc d, const float* __restrict__ P,
-                                                             const float* __restrict__ Pt, const float* __restrict__ nm,
-                                                             const float* __restrict__ nv, const float* __restrict__ obs,
-                                                             int n, float* __restrict__ logits,
-                                                             float* __restrict__ values) {
+__device__ __forceinline__ void policy_logits_body(const ia_policy_desc& d, const float* __restrict__ P,
+                                                   const float* __restrict__ Pt, const float* __restrict__ nm,
+                                                   const float* __restrict__ nv, const float* __restrict__ obs, int n,
+                                                   float* __restrict__ logits, float* __restrict__ values, const int blk,
+                                                   float* __restrict__ lds) {
   using L = Lds<H>;
-  extern __shared__ float lds[];
-  const int tid = threadIdx.x, row = blockIdx.x * ROWS + tid;
+  const int tid = threadIdx.x, row = blk * ROWS + tid;
   const bool valid = row < n;
   const int D = d.obs_dim, A = d.act_dim;
   const PolOff o = pol_offsets(D, A, H, d.discrete);
@@ -292,6 +291,75 @@ __global__ __launch_bounds__(ROWS) void policy_logits_kernel(ia_policy_desc d, c
 #pragma unroll
     for (int k = 0; k < H; ++k) v = fmaf(P[o.cW + k], a2[k], v);
     if (valid) values[row] = v;
+  }
+}
+
+template <int H>
+__global__ __launch_bounds__(ROWS) void policy_logits_kernel(ia_policy_desc d, const float* __restrict__ P,
+                                                             const float* __restrict__ Pt, const float* __restrict__ nm,
+                                                             const float* __restrict__ nv, const float* __restrict__ obs,
+                                                             int n, float* __restrict__ logits,
+                                                             float* __restrict__ values) {
+  extern __shared__ float lds[];
+  policy_logits_body<H>(d, P, Pt, nm, nv, obs, n, logits, values, blockIdx.x, lds);
+}
+
+// Host <-> resident-kernel hand-off of the rollout mailboxes (policy_rollout_mailbox_kernel, policy_logits_mailbox_kernel):
+// `ready` is one int in pinned host memory (step t may run once it exceeds t; negative: abort), `done[workgroup]` the
+// acknowledgement. mailbox_wait: lane 0 polls with system-scope loads (bounded by `timeout_ticks` of the 100 MHz clock),
+// the verdict goes round the workgroup, and nothing of the step is read ahead of a system-scope acquire. mailbox_ack:
+// every thread has drained its stores, block barrier, one lane's system-scope release (the step's outputs in host memory
+// are ordinary L2-cached stores) and flag store.
+__device__ __forceinline__ bool mailbox_wait(const int* ready, int t, long long timeout_ticks, int* s_go) {
+  if (threadIdx.x == 0) {
+    const long long t0 = wall_clock64();
+    int go = 0;
+    for (;;) {
+      const int v = __hip_atomic_load(ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      if (v > t) { go = 1; break; }
+      if (v < 0 || wall_clock64() - t0 > timeout_ticks) break;
+      __builtin_amdgcn_s_sleep(8);
+    }
+    *s_go = go;
+  }
+  __syncthreads();
+  const bool go = *s_go != 0;
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+  return go;
+}
+__device__ __forceinline__ void mailbox_ack(int* done, int value) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+    __hip_atomic_store(done + blockIdx.x, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+
+// The host-sampled Discrete rollout step (`ia_policy_logits` per step + torch.multinomial on the host) with the launches
+// folded into one resident kernel: step t's logits land in the SAME pinned [n, A] tile every step (the host has sampled
+// from it before it posts the next step), the values in the device tile.
+struct LogitsMailbox {
+  const float* obs; long long s_obs;
+  float* logits;
+  float* values; long long s_val;
+  int T; const int* ready; int* done; long long timeout_ticks;
+};
+
+template <int H>
+__global__ __launch_bounds__(ROWS) void policy_logits_mailbox_kernel(ia_policy_desc d, const float* __restrict__ P,
+                                                                     const float* __restrict__ Pt,
+                                                                     const float* __restrict__ nm,
+                                                                     const float* __restrict__ nv, int n, LogitsMailbox mb) {
+  extern __shared__ float lds[];
+  __shared__ int s_go;
+  for (int t = 0; t < mb.T; ++t) {
+    if (!mailbox_wait(mb.ready, t, mb.timeout_ticks, &s_go)) {
+      if (threadIdx.x == 0) __hip_atomic_store(mb.done + blockIdx.x, -(t + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      return;
+    }
+    policy_logits_body<H>(d, P, Pt, nm, nv, mb.obs + t * mb.s_obs, n, mb.logits, mb.values + t * mb.s_val, blockIdx.x, lds);
+    mailbox_ack(mb.done, t + 1);
   }
 }
 
@@ -2522,36 +2590,14 @@ __global__ __launch_bounds__(512) void policy_rollout_mailbox_kernel(
   extern __shared__ float lds[];
   __shared__ int s_go;
   for (int t = 0; t < mb.T; ++t) {
-    if (threadIdx.x == 0) {
-      const long long t0 = wall_clock64();
-      int go = 0;
-      for (;;) {
-        const int v = __hip_atomic_load(mb.ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        if (v > t) { go = 1; break; }
-        if (v < 0 || wall_clock64() - t0 > mb.timeout_ticks) break;
-        __builtin_amdgcn_s_sleep(8);
-      }
-      s_go = go;
-    }
-    __syncthreads();
-    const int go = s_go;
-    if (!go) {
+    if (!mailbox_wait(mb.ready, t, mb.timeout_ticks, &s_go)) {
       if (threadIdx.x == 0) __hip_atomic_store(mb.done + blockIdx.x, -(t + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       return;
     }
-    __atomic_thread_fence(__ATOMIC_ACQUIRE);   // nothing of this step is read ahead of its flag (system scope)
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
     policy_act_body<H, false>(d, P, Pt, nm, nv, mb.obs + t * mb.s_obs, n, mb.noise ? mb.noise + t * mb.s_noise : nullptr,
                               low, high, mb.actions + t * mb.s_act, mb.clipped + t * mb.s_clip, mb.values + t * mb.s_val,
                               mb.logp + t * mb.s_lp, blockIdx.x, lds);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      // the clipped actions are ordinary (L2-cached) stores to host memory: one system-scope release writes this XCD's
-      // dirty lines back before the flag goes out (system-scope stores per element are one PCIe write each: 0.5 ms a step)
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
-      __hip_atomic_store(mb.done + blockIdx.x, t + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
+    mailbox_ack(mb.done, t + 1);
   }
 }
 
@@ -3499,6 +3545,36 @@ int ia_policy_rollout_mailbox(const ia_policy_desc* d, const float* params, cons
     if (!attr) { if ((rc = set_lds(policy_rollout_mailbox_kernel<64>, bytes))) return rc; attr = true; }
     hipLaunchKernelGGL((policy_rollout_mailbox_kernel<64>), dim3(cdiv(n, ROWS)), dim3(512), bytes, (hipStream_t)stream,
                        *d, params, params_t, norm_mean, norm_var, n, low, high, mb);
+  }
+  IA_CHECK_LAUNCH();
+  return IA_OK;
+}
+
+int ia_policy_logits_mailbox(const ia_policy_desc* d, const float* params, const float* params_t, const float* norm_mean,
+                             const float* norm_var, int n, const float* obs, int64_t s_obs, float* logits, float* values,
+                             int64_t s_val, int T, const int32_t* ready, int32_t* done, double timeout_s, void* stream) {
+  if (!pol_ok(d) || n <= 0 || T <= 0 || !ready || !done || !obs || !logits) return IA_ERR_ARG;
+  {
+    static int dev_cus = 0;
+    if (dev_cus == 0) {
+      int dev = 0;
+      if (hipGetDevice(&dev) != hipSuccess ||
+          hipDeviceGetAttribute(&dev_cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+        return IA_ERR_ARG;
+    }
+    if (cdiv(n, ROWS) > dev_cus) return IA_ERR_UNSUPPORTED;   // (every workgroup must be resident: see the act mailbox)
+  }
+  LogitsMailbox mb{obs, s_obs, logits, values, s_val, T, reinterpret_cast<const int*>(ready),
+                   reinterpret_cast<int*>(done), (long long)(timeout_s * 1e8)};
+  int rc;
+  if (d->hidden == 32) {
+    if ((rc = set_lds(policy_logits_mailbox_kernel<32>, lds_bytes<32>()))) return rc;
+    hipLaunchKernelGGL(policy_logits_mailbox_kernel<32>, dim3(cdiv(n, ROWS)), dim3(ROWS), lds_bytes<32>(),
+                       (hipStream_t)stream, *d, params, params_t, norm_mean, norm_var, n, mb);
+  } else {
+    if ((rc = set_lds(policy_logits_mailbox_kernel<64>, lds_bytes<64>()))) return rc;
+    hipLaunchKernelGGL(policy_logits_mailbox_kernel<64>, dim3(cdiv(n, ROWS)), dim3(ROWS), lds_bytes<64>(),
+                       (hipStream_t)stream, *d, params, params_t, norm_mean, norm_var, n, mb);
   }
   IA_CHECK_LAUNCH();
   return IA_OK;

@@ -232,6 +232,9 @@ class GeneralTowers:
         """(the resident rollout kernel is the fused towers' act kernel: general towers launch per step)"""
         return None
 
+    def make_multinomial_mailbox(self, *args, **kwargs):
+        return None
+
     def make_act_step(self, obs_tile: th.Tensor, noise_host: th.Tensor, acts: th.Tensor, clipped: th.Tensor,
                       val: th.Tensor, logp: th.Tensor):
         """Rollout-step launcher (Box heads): stage this step's observations and noise from the pinned host tiles,

@@ -289,12 +289,7 @@ class ActorCriticPolicy:
         lib = L.load()
         n = obs_tile.shape[1]
         nblk = (n + 63) // 64
-        box = getattr(self, "_mailbox_flags", None)
-        if box is None or box[1].numel() != nblk:
-            box = self._mailbox_flags = (th.zeros(1, dtype=th.int32).pin_memory(), th.zeros(nblk, dtype=th.int32).pin_memory())
-        ready, done = box
-        ready.zero_()
-        done.zero_()
+        ready, done = self._mailbox_flags_for(nblk)
         nm, nv = self._norm_ptrs()
         stride = lambda t: t.stride(0)
         rc = lib.ia_policy_rollout_mailbox(
@@ -365,6 +360,58 @@ class ActorCriticPolicy:
             h_clip[t].copy_(a.reshape(n, 1))
 
         return step
+
+    def _mailbox_flags_for(self, nblk: int):
+        box = getattr(self, "_mailbox_flags", None)
+        if box is None or box[1].numel() != nblk:
+            box = self._mailbox_flags = (th.zeros(1, dtype=th.int32).pin_memory(), th.zeros(nblk, dtype=th.int32).pin_memory())
+        box[0].zero_()
+        box[1].zero_()
+        return box
+
+    def make_multinomial_mailbox(self, obs_tile: th.Tensor, h_logits: th.Tensor, h_clip: th.Tensor, val: th.Tensor,
+                                 h_logp: th.Tensor, T: int, timeout_s: float = 120.0):
+        """`make_multinomial_step` with the T launches folded into ONE resident kernel (`ia_policy_logits_mailbox`):
+        `(post, wait, close)` as `make_rollout_mailbox`; `wait(t)` returns True after the step's logits have arrived in
+        the pinned tile AND the host has sampled from them exactly as `make_multinomial_step` does (actions in
+        `h_clip[t]`, log-probs in `h_logp[t]`). None: not covered."""
+        assert self.discrete and not (self.training and self.features_extractor.normalize is not None)
+        lib = L.load()
+        n = obs_tile.shape[1]
+        nblk = (n + 63) // 64
+        ready, done = self._mailbox_flags_for(nblk)
+        nm, nv = self._norm_ptrs()
+        rc = lib.ia_policy_logits_mailbox(C.byref(self.desc), L.ptr(self._flat), L.ptr(self._flat_t), nm, nv, n,
+                                          obs_tile.data_ptr(), obs_tile.stride(0), h_logits.data_ptr(), val.data_ptr(),
+                                          val.stride(0), T, ready.data_ptr(), done.data_ptr(), float(timeout_s), L.stream())
+        if rc == L.ERR_UNSUPPORTED:
+            return None
+        L.check(rc, "ia_policy_logits_mailbox")
+        ready_np, done_ptr, wait_fn = ready.numpy(), done.data_ptr(), lib.ia_host_wait_i32
+        state = {"acked": 0}
+
+        def post(t: int) -> None:
+            ready_np[0] = t + 1
+
+        def wait(t: int) -> bool:
+            rc_ = wait_fn(done_ptr, nblk, t + 1, float(timeout_s) + 30.0)
+            if rc_ != 0:
+                ready_np[0] = -1
+                if rc_ == 1:
+                    raise RuntimeError(f"rollout mailbox: step {t} was neither acknowledged nor given up by the device")
+                state["acked"] = T
+                return False
+            state["acked"] = t + 1
+            a, lp = categorical_sample(h_logits)
+            h_logp[t].copy_(lp)
+            h_clip[t].copy_(a.reshape(n, 1))
+            return True
+
+        def close() -> None:
+            if state["acked"] < T:
+                ready_np[0] = -1
+
+        return post, wait, close
 
     def act(self, obs_dev: th.Tensor, noise_dev: th.Tensor, actions: th.Tensor, clipped: th.Tensor,
             values: th.Tensor, logp: th.Tensor) -> None:

@@ -550,6 +550,9 @@ class PPO(OnPolicyAlgorithm):
             if host_sampling:
                 rb.ensure_host_sampling_tiles(pol.act_dim)
                 act_step = pol.make_multinomial_step(rb.h_obs, rb.h_logits, rb.h_clip, rb.val, rb.h_logp)
+                if self.rollout_mailbox and hasattr(pol, "make_multinomial_mailbox"):
+                    mailbox = pol.make_multinomial_mailbox(rb.h_obs, rb.h_logits, rb.h_clip, rb.val, rb.h_logp, T,
+                                                           timeout_s=self.rollout_mailbox_timeout_s)
             else:
                 # The rollout's T Gaussian noise tiles in ONE draw at its start, when that is the same stream:
                 # `normal_()` on a contiguous [T, n, A] tensor consumes torch's generator exactly as T draws of

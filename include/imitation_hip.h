@@ -362,6 +362,12 @@ int ia_policy_rollout_mailbox(const ia_policy_desc* d, const float* params, cons
                               int64_t s_obs, const float* noise, int64_t s_noise, float* actions, int64_t s_act,
                               float* clipped, int64_t s_clip, float* values, int64_t s_val, float* logp, int64_t s_lp,
                               int T, const int32_t* ready, int32_t* done, double timeout_s, void* stream);
+/* The same for the host-sampled Discrete step (`ia_policy_logits` per step + torch.multinomial on the host): step t's
+ * logits land in the SAME pinned [n, A] tile every step (the host samples from it before posting the next step), the
+ * values in `values + t * s_val`. */
+int ia_policy_logits_mailbox(const ia_policy_desc* d, const float* params, const float* params_t, const float* norm_mean,
+                             const float* norm_var, int n, const float* obs, int64_t s_obs, float* logits, float* values,
+                             int64_t s_val, int T, const int32_t* ready, int32_t* done, double timeout_s, void* stream);
 /* Host half: spin (no GIL under ctypes) until all `n` flags have reached `target`. 0 reached, 1 timed out, -1 a flag is
  * negative (the kernel gave up). */
 int ia_host_wait_i32(const volatile int32_t* flags, int n, int target, double timeout_s);

@@ -133,7 +133,8 @@ def test_pipelined_rounds_are_bit_identical(tmp_path, case):
     assert len(logs[True]["progress.csv"]) == 4
 
 
-@pytest.mark.parametrize("case", ["gail_box", "gail_f64", "airl_box", "gail_generic_vecenv", "gail_tuned_hps"])
+@pytest.mark.parametrize("case", ["gail_box", "gail_f64", "airl_box", "gail_generic_vecenv", "gail_tuned_hps", "gail_cartpole",
+                                  "gail_discrete"])
 def test_rollout_mailbox_equals_per_step_launches(tmp_path, case):
     """The rollout's act steps as one resident launch driven through flags in pinned host memory
     (`ia_policy_rollout_mailbox`, default) against one `ia_policy_act` launch + stream synchronisation per step: every
