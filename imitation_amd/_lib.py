@@ -144,7 +144,7 @@ _SIGS = {
     "ia_policy_transpose": ([C.POINTER(PolicyDesc), _P, _P, _P], C.c_int),
     "ia_policy_act": ([C.POINTER(PolicyDesc), _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P], C.c_int),
     "ia_policy_rollout_mailbox": ([C.POINTER(PolicyDesc), _P, _P, _P, _P, _I, _P, _P, _P, _L, _P, _L, _P, _L, _P, _L, _P, _L,
-                                   _P, _L, _I, _P, _P, _D, _P], C.c_int),
+                                   _P, _L, _P, _I, _P, _P, _D, _P], C.c_int),
     "ia_policy_logits_mailbox": ([C.POINTER(PolicyDesc), _P, _P, _P, _P, _I, _P, _L, _P, _P, _L, _I, _P, _P, _D, _P],
                                  C.c_int),
     "ia_host_wait_i32": ([_P, _I, _I, _D], C.c_int),

@@ -2582,6 +2582,7 @@ struct ActMailbox {
   float* clipped; long long s_clip;
   float* values; long long s_val;
   float* logp; long long s_lp;
+  float* last_val;                       // non-null: one more step, T, that only evaluates V(obs[T]) (the GAE bootstrap)
   int T; const int* ready; int* done; long long timeout_ticks;
 };
 
@@ -2606,6 +2607,14 @@ __global__ __launch_bounds__(512) void policy_rollout_mailbox_kernel(
                               mb.clipped + t * mb.s_clip, mb.values + t * mb.s_val, mb.logp + t * mb.s_lp,
                               blockIdx.x + oz, lds, oz);
     mailbox_ack(mb.done, t + 1);
+  }
+  if (mb.last_val != nullptr) {
+    // the value of the observation behind the last step ([SB3 collect_rollouts]: `predict_values(new_obs)` for the GAE
+    // bootstrap), posted by the host as step T: one launch and ~30 us less between the last env step and the update
+    if (!mailbox_wait(mb.ready, mb.T, mb.timeout_ticks, &s_go)) return;
+    policy_act_body<H, true>(d, P, Pt, nm, nv, mb.obs + mb.T * mb.s_obs, n, nullptr, nullptr, nullptr, nullptr, nullptr,
+                             mb.last_val, nullptr, blockIdx.x, lds);
+    mailbox_ack(mb.done, mb.T + 1);
   }
 }
 
@@ -3522,7 +3531,8 @@ int ia_policy_rollout_mailbox(const ia_policy_desc* d, const float* params, cons
                               const float* norm_var, int n, const float* low, const float* high, const float* obs,
                               int64_t s_obs, const float* noise, int64_t s_noise, float* actions, int64_t s_act,
                               float* clipped, int64_t s_clip, float* values, int64_t s_val, float* logp, int64_t s_lp,
-                              int T, const int32_t* ready, int32_t* done, double timeout_s, void* stream) {
+                              float* last_val, int T, const int32_t* ready, int32_t* done, double timeout_s,
+                              void* stream) {
   if (!pol_ok(d) || n <= 0 || T <= 0 || !ready || !done || !obs || !actions || !clipped || !values || !logp)
     return IA_ERR_ARG;
   if (g_ppo_valu || (d->hidden != 32 && d->hidden != 64)) return IA_ERR_UNSUPPORTED;
@@ -3538,7 +3548,7 @@ int ia_policy_rollout_mailbox(const ia_policy_desc* d, const float* params, cons
     }
     if (cdiv(n, ROWS) > dev_cus) return IA_ERR_UNSUPPORTED;   // (one workgroup per CU is always possible)
   }
-  ActMailbox mb{obs, s_obs, noise, s_noise, actions, s_act, clipped, s_clip, values, s_val, logp, s_lp, T,
+  ActMailbox mb{obs, s_obs, noise, s_noise, actions, s_act, clipped, s_clip, values, s_val, logp, s_lp, last_val, T,
                 reinterpret_cast<const int*>(ready), reinterpret_cast<int*>(done), (long long)(timeout_s * 1e8)};
   int rc;
   if (d->hidden == 32) {

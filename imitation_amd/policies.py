@@ -276,14 +276,17 @@ class ActorCriticPolicy:
         return step
 
     def make_rollout_mailbox(self, obs_tile: th.Tensor, noise_dev: th.Tensor, acts: th.Tensor, clipped: th.Tensor,
-                             val: th.Tensor, logp: th.Tensor, T: int, timeout_s: float = 120.0):
+                             val: th.Tensor, logp: th.Tensor, T: int, timeout_s: float = 120.0,
+                             last_val: Optional[th.Tensor] = None):
         """The rollout's act steps as ONE resident launch (`ia_policy_rollout_mailbox`) on the current stream: returns
         `(post, wait, close)` -- `post(t)` tells the device that step t's observations (and noise) are in their pinned
         tiles, `wait(t)` returns True once every workgroup has acknowledged step t (its clipped actions are in host memory;
         spins in C without the GIL) and False when the device has left the rollout (it waits `timeout_s` for a step, e.g.
         an environment that took minutes: the caller then runs this and the remaining steps as per-step launches, which
         rewrite the same values), `close()` aborts a kernel that has steps left (error paths) -- or None when the shape is
-        not covered (the caller launches `make_act_step`'s kernel per step). Same tiles, same values as `make_act_step`."""
+        not covered (the caller launches `make_act_step`'s kernel per step). Same tiles, same values as `make_act_step`.
+        `last_val`: the kernel also evaluates V(`obs_tile[T]`) into it when the host posts step T (`post(T)`, no wait
+        needed: the stream the kernel runs on is what later launches are ordered behind)."""
         assert not (self.training and self.features_extractor.normalize is not None), \
             "the rollout step runs in eval mode (a train-mode forward would update the feature statistics)"
         lib = L.load()
@@ -296,14 +299,16 @@ class ActorCriticPolicy:
             C.byref(self.desc), L.ptr(self._flat), L.ptr(self._flat_t), nm, nv, n, L.ptr(self._low), L.ptr(self._high),
             obs_tile.data_ptr(), stride(obs_tile), noise_dev.data_ptr(), stride(noise_dev) if noise_dev.dim() == 3 else 0,
             acts.data_ptr(), stride(acts), clipped.data_ptr(), stride(clipped), val.data_ptr(), stride(val),
-            logp.data_ptr(), stride(logp), T, ready.data_ptr(), done.data_ptr(), float(timeout_s), L.stream())
+            logp.data_ptr(), stride(logp), L.ptr(last_val), T, ready.data_ptr(), done.data_ptr(), float(timeout_s),
+            L.stream())
         if rc == L.ERR_UNSUPPORTED:
             return None
         L.check(rc, "ia_policy_rollout_mailbox")
         ready_np = ready.numpy()
         done_ptr = done.data_ptr()
         wait_fn = lib.ia_host_wait_i32
-        state = {"posted": 0, "acked": 0}
+        state = {"posted": 0, "gone": False}
+        total = T + 1 if last_val is not None else T    # steps the kernel stays for
 
         def post(t: int) -> None:
             ready_np[0] = t + 1
@@ -312,16 +317,15 @@ class ActorCriticPolicy:
         def wait(t: int) -> bool:
             rc_ = wait_fn(done_ptr, nblk, t + 1, float(timeout_s) + 30.0)
             if rc_ == 0:
-                state["acked"] = t + 1
                 return True
             ready_np[0] = -1
             if rc_ == 1:
                 raise RuntimeError(f"rollout mailbox: step {t} was neither acknowledged nor given up by the device")
-            state["acked"] = T          # (nothing left to abort)
+            state["gone"] = True        # (nothing left to abort)
             return False
 
         def close() -> None:
-            if state["acked"] < T:
+            if not state["gone"] and state["posted"] < total:
                 ready_np[0] = -1   # the kernel's workgroups leave at their next poll
 
         return post, wait, close

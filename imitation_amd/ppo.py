@@ -575,7 +575,7 @@ class PPO(OnPolicyAlgorithm):
                 # (`ActorCriticPolicy.make_rollout_mailbox`; None: shapes its kernel does not cover)
                 if self.rollout_mailbox and hasattr(pol, "make_rollout_mailbox"):
                     mailbox = pol.make_rollout_mailbox(rb.h_obs, noise_tile, rb.acts, rb.h_clip, rb.val, rb.logp, T,
-                                                       timeout_s=self.rollout_mailbox_timeout_s)
+                                                       timeout_s=self.rollout_mailbox_timeout_s, last_val=rb.last_val)
         h_clip_np = rb.h_clip.numpy()
         try:
             return self._rollout_steps(env, callback, rb, T, n, pol, rw, bw, base, fused_net, module_net, act_step, mailbox,
@@ -666,6 +666,11 @@ class PPO(OnPolicyAlgorithm):
         if self.update_events is not None:  # tools: device time from the last env step to the start of the update
             self.tail_event = th.cuda.Event(enable_timing=True)
             self.tail_event.record()
+        last_val_done = False
+        if mailbox is not None and not host_sampling:
+            mailbox[0](T)          # the observation behind the last step is in its pinned row: the resident kernel evaluates
+            last_val_done = True   # V of it (the GAE bootstrap) while the host goes on, and leaves
+            stream.wait_stream(act_stream)
         rb.h_last_done.copy_(th.as_tensor(starts.astype(np.float32)))
         rb.upload_host_tiles()
         if host_sampling:  # actions (= the clipped tile for Discrete heads) and log-probs were produced on the host
@@ -713,7 +718,8 @@ class PPO(OnPolicyAlgorithm):
             pol.values_rows(rb.next_fixed.reshape(T * n, -1), rb.term_val.reshape(T * n))
             L.call("ia_timeout_bootstrap", L.ptr(rb.rew), L.ptr(rb.term_val), L.ptr(rb.trunc), float(self.gamma),
                    T * n, L.stream())
-        pol.values_rows(rb.obs[T], rb.last_val)
+        if not last_val_done:
+            pol.values_rows(rb.obs[T], rb.last_val)
         L.call("ia_gae", L.ptr(rb.rew), L.ptr(rb.val), L.ptr(rb.starts), L.ptr(rb.last_val), L.ptr(rb.last_done), T,
                n, float(self.gamma), float(self.gae_lambda), L.ptr(rb.adv), L.ptr(rb.ret), L.stream())
         rb.full = True

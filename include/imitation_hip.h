@@ -356,12 +356,16 @@ int ia_policy_act(const ia_policy_desc* d, const float* params, const float* par
  * in floats between consecutive steps; 0 = the same tile every step) and acknowledge in `done[workgroup]` (pinned host
  * memory, ceil(n / 64) ints) once the step's outputs, the clipped actions in host memory first of all, have left.
  * Bounded: `ready[0] < 0` (abort) or `timeout_s` without a new step end the kernel; `done` then holds -(t + 1).
+ * last_val (may be NULL): when set, the host may post one more step, T (`ready[0] = T + 1` once `obs + T * s_obs`
+ * holds the observation behind the last step): the kernel then writes V of those rows there (the GAE bootstrap of
+ * [SB3 collect_rollouts]) and acknowledges with T + 1; nobody has to wait for that on the host.
  * IA_ERR_UNSUPPORTED (-> launch `ia_policy_act` per step) for shapes the matrix-core act kernel does not cover. */
 int ia_policy_rollout_mailbox(const ia_policy_desc* d, const float* params, const float* params_t, const float* norm_mean,
                               const float* norm_var, int n, const float* low, const float* high, const float* obs,
                               int64_t s_obs, const float* noise, int64_t s_noise, float* actions, int64_t s_act,
                               float* clipped, int64_t s_clip, float* values, int64_t s_val, float* logp, int64_t s_lp,
-                              int T, const int32_t* ready, int32_t* done, double timeout_s, void* stream);
+                              float* last_val, int T, const int32_t* ready, int32_t* done, double timeout_s,
+                              void* stream);
 /* The same for the host-sampled Discrete step (`ia_policy_logits` per step + torch.multinomial on the host): step t's
  * logits land in the SAME pinned [n, A] tile every step (the host samples from it before posting the next step), the
  * values in `values + t * s_val`. */
