@@ -36,6 +36,11 @@ constexpr int NS = 2;        // ring stages
 constexpr int XP = 25;       // padded row length of the x tile / W1 in LDS (D <= 24), odd -> conflict-free
 constexpr int XP3 = 33;      // x tile as a 32-wide B operand (K3)
 constexpr int A_LD = FB_K + 1;
+// Input widths: DW = 24 (D <= 24: K = 24 in layer 1, [xn | 1] as ONE 32-wide operand of the first-layer gradient) and
+// DW = 64 (D <= 63, X rows up to 64 floats: layer 1 in 16-column steps over the row length, [xn | 1] as two 32-wide
+// blocks). Row lengths of the W1 image / of the x tile in LDS, both odd:
+constexpr int xp_of(int DW) { return DW == 24 ? XP : 65; }
+constexpr int xp3_of(int DW) { return DW == 24 ? XP3 : 65; }
 
 __device__ __forceinline__ int rowoff(int r) { return (r & 3) + 8 * (r >> 2); }
 // phase clock of (block 0, thread 0) into dbg[slot] when measurement is switched on (scalar branch otherwise)
@@ -69,11 +74,11 @@ struct FusedArgs {
 // (X - mean) / sqrt(var + eps): util/networks.py:91 as ia_running_norm_apply computes it.
 // HAT: the row is the interpolate e X[i] + (1 - e) X[R + i] (ia_gp_interpolate's expression), then normalised.
 // RAW: rows of `X` as they are (the penalty's row coefficients).
-template <int BM, bool HAT = false, bool RAW = false>
+template <int BM, bool HAT = false, bool RAW = false, bool WIDE = false>
 __device__ __forceinline__ void load_x_tile(const FusedArgs& a, const float* __restrict__ X, int row0,
-                                            float* __restrict__ xs, int ld, int tid) {
+                                            float* __restrict__ xs, int ld, int tid0) {
   const int quads = a.ldx >> 2;
-  if (tid < BM * quads) {
+  auto piece = [&](int tid) {
     const int row = tid / quads, q = tid - row * quads;
     const int gi = row0 + row;
     const long long ro = (long long)min(gi, a.R - 1) * a.ldx + 4 * q;
@@ -95,6 +100,12 @@ __device__ __forceinline__ void load_x_tile(const FusedArgs& a, const float* __r
       }
       xs[row * ld + c] = (gi < a.R && c < a.D) ? x : 0.f;
     }
+  };
+  // rows of up to 24 floats: at most one 16-byte piece per thread of the BM * 8; WIDE (up to 64 floats): up to two
+  if constexpr (WIDE) {
+    for (int e = tid0; e < BM * quads; e += BM * 8) piece(e);
+  } else {
+    if (tid0 < BM * quads) piece(tid0);
   }
 }
 
@@ -714,9 +725,22 @@ __global__ __launch_bounds__(BM * 8) void disc_bwd_kernel(FusedArgs a) {
 // (the weight-gradient GEMM needs both), W2's first chunks are requested while the BCE epilogue runs, and relu'(h1)
 // stays in the registers that took the ballots. Same arithmetic, same summation order as K2 + K3: bit-identical
 // outputs (tests/test_disc_fused_gpu.py compares the two forms).
-template <int H, int BM>
+// LDS of disc_fb_kernel in floats: h1 tile | region R (ring, then the scratch rows, then padding) | x tile. Region R
+// holds the W1 image during layer 1 and the first-layer slab image at the end, whichever of the three is larger.
+template <int H, int BM, int DW>
+constexpr int fb_region_floats() {
+  constexpr int ring = 3 * FB_K * H + 4 * BM + BM + 2 * (BM / 32) * H;
+  constexpr int img = H * xp_of(DW) > H * (DW + 1) ? H * xp_of(DW) : H * (DW + 1);
+  return ring > img ? ring : img;
+}
+template <int H, int BM, int DW>
+constexpr int fb_lds_floats() { return BM * (H + 1) + fb_region_floats<H, BM, DW>() + BM * xp3_of(DW); }
+
+template <int H, int BM, int DW = 24>
 __global__ __launch_bounds__(BM * 8) void disc_fb_kernel(FusedArgs a) {
   constexpr int NT = BM * 8, NW = NT / 64;
+  constexpr int XPW = xp_of(DW), XP3W = xp3_of(DW);   // row lengths of the W1 image / the x tile
+  constexpr bool WIDE = DW != 24;
   constexpr int TN = H / 128;
   constexpr int WC = TN * 32;
   constexpr int LDH = H + 1;
@@ -725,16 +749,17 @@ __global__ __launch_bounds__(BM * 8) void disc_fb_kernel(FusedArgs a) {
   constexpr int BV = BST / 4 / NT;
   static_assert(BST % (4 * NT) == 0, "B chunk must divide among the threads");
   constexpr int NR = 3;                // ring stages: chunk g sits in stage g % 3 (g < NCH: W2T chunk g, then W2 chunk g - NCH)
-  static_assert(H * XP <= NR * BST, "the W1 image borrows the ring during layer 1");
-  static_assert(H * 24 + H <= NR * BST, "the first-layer slab image borrows the ring at the end");
+  static_assert(WIDE || H * XP <= NR * BST, "the W1 image borrows the ring during layer 1");
+  static_assert(WIDE || H * 24 + H <= NR * BST, "the first-layer slab image borrows the ring at the end");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* h1s = smem;                   // [BM][LDH]   h1 tile -> dh2 tile -> dh1 tile
   float* bs = h1s + BM * LDH;          // NR x [FB_K][H] ring (W2T chunks, then W2 chunks); W1 image during layer 1;
-                                       // the P1 slab image at the end
+                                       // the P1 slab image at the end (WIDE: both run on over the scratch rows below,
+                                       // which are idle at those times, and some padding)
   float* red = bs + NR * BST;          // [4][BM] logit partials per column group
   float* dls = red + 4 * BM;           // [BM] dlogit of the tile's rows
   float* w3red = dls + BM;             // [2][BM/32][H] dW3 / db2 partials per row group
-  float* xs = w3red + 2 * (BM / 32) * H;   // [BM][XP3]: xn | 0 ... (layer 1's A operand; later [xn | 1 | 0 ...] as dW1's B)
+  float* xs = bs + fb_region_floats<H, BM, DW>();   // [BM][XP3W]: xn | 0 ... (layer 1's A operand; later [xn | 1 | 0 ...] as dW1's B)
   float* w1s = bs;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -763,7 +788,8 @@ __global__ __launch_bounds__(BM * 8) void disc_fb_kernel(FusedArgs a) {
 #pragma unroll
     for (int i = 0; i < BV; ++i) *reinterpret_cast<f4*>(S + (tid + i * NT) * 4) = r[i];
   };
-  constexpr int W1Q = H * XP / 4;                      // float4 of the W1 image
+  static_assert(H * XPW % 4 == 0, "the W1 image is copied in 16-byte pieces");
+  constexpr int W1Q = H * XPW / 4;                     // float4 of the W1 image
   constexpr int W1V = (W1Q + NT - 1) / NT;
   f4 w1v[W1V];
 #pragma unroll
@@ -775,11 +801,11 @@ __global__ __launch_bounds__(BM * 8) void disc_fb_kernel(FusedArgs a) {
     b1v[t] = b1[col]; b2v[t] = b2[col]; w3v[t] = w3[col];
   }
   const float b3v = b3[0];
-  load_x_tile<BM>(a, a.X, row0, xs, XP3, tid);
-  for (int e = tid; e < BM * (XP3 - 1 - a.ldx); e += NT) {  // columns [ldx, 32)
-    const int w = XP3 - 1 - a.ldx;
+  load_x_tile<BM, false, false, WIDE>(a, a.X, row0, xs, XP3W, tid);
+  for (int e = tid; e < BM * (XP3W - 1 - a.ldx); e += NT) {  // columns [ldx, 32) (WIDE: [ldx, 64))
+    const int w = XP3W - 1 - a.ldx;
     const int row = e / w, c = a.ldx + e - row * w;
-    xs[row * XP3 + c] = 0.f;
+    xs[row * XP3W + c] = 0.f;
   }
   bload(rb, 0);                                        // stay in registers until layer 1 is done with the ring
   bload(rb1, 1);
@@ -789,13 +815,14 @@ __global__ __launch_bounds__(BM * 8) void disc_fb_kernel(FusedArgs a) {
   __syncthreads();
   FUSED_STAMP(a, 1);
 
-  // ---- layer 1: h1 = relu(xn . W1^T + b1), K = 24
+  // ---- layer 1: h1 = relu(xn . W1^T + b1), K = 24 (WIDE: 16 columns at a time over the row length; the columns from
+  //      D on are zero in both operands)
   f32x16 acc[TN];
 #pragma unroll
   for (int t = 0; t < TN; ++t)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-  {
+  if constexpr (!WIDE) {
     float af[12], bf[12][TN];
 #pragma unroll
     for (int ks = 0; ks < 12; ++ks) {
@@ -807,6 +834,24 @@ __global__ __launch_bounds__(BM * 8) void disc_fb_kernel(FusedArgs a) {
     for (int ks = 0; ks < 12; ++ks)
 #pragma unroll
       for (int t = 0; t < TN; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[ks], bf[ks][t], acc[t], 0, 0, 0);
+  } else {
+    const int nk16 = (a.ldx + 15) >> 4;
+    const float* xr = xs + (wm * 32 + li) * XP3W + lh;
+    const float* wr = w1s + (wn * WC + li) * XPW + lh;
+#pragma unroll 1
+    for (int kc = 0; kc < nk16; ++kc) {
+      float af[8], bf[8][TN];
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) {
+        af[ks] = xr[kc * 16 + 2 * ks];
+#pragma unroll
+        for (int t = 0; t < TN; ++t) bf[ks][t] = wr[t * 32 * XPW + kc * 16 + 2 * ks];
+      }
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks)
+#pragma unroll
+        for (int t = 0; t < TN; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[ks], bf[ks][t], acc[t], 0, 0, 0);
+    }
   }
   FUSED_STAMP(a, 2);
   unsigned long long mword = 0ull;                     // relu'(h1): word (t, r) in lane t*16 + r, kept for the backward
@@ -999,31 +1044,35 @@ __global__ __launch_bounds__(BM * 8) void disc_fb_kernel(FusedArgs a) {
         h1s[(wm * 32 + 4 * lh + rowoff(r)) * LDH + wn * WC + t * 32 + li] = on ? acc[t][r] : 0.f;
       }
   }
-  if (tid < BM) xs[tid * XP3 + D] = 1.f;  // the ones column makes db1 a column of dW1 (column D was a zero column so far)
+  if (tid < BM) xs[tid * XP3W + D] = 1.f;  // the ones column makes db1 a column of dW1 (column D was a zero column so far)
   __syncthreads();
   FUSED_STAMP(a, 11);
 
-  // ---- [dW1 | db1] partial [H, D + 1] = dh1^T . [xn | 1] over the tile's BM rows (see disc_bwd_kernel)
+  // ---- [dW1 | db1] partial [H, D + 1] = dh1^T . [xn | 1] over the tile's BM rows (see disc_bwd_kernel); WIDE: the
+  //      D + 1 <= 64 columns as two 32-wide blocks
   const long long n1 = (long long)H * D + H;
   float* P1 = a.P1 + (long long)blockIdx.x * n1;
   for (int mt = wave; mt < H / 32; mt += NW) {
-    f32x16 acc1;
+    float af[BM / 2];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc1[r] = 0.f;
-    float af[BM / 2], bf[BM / 2];
+    for (int s = 0; s < BM / 2; ++s) af[s] = h1s[(2 * s + lh) * LDH + mt * 32 + li];
 #pragma unroll
-    for (int s = 0; s < BM / 2; ++s) {
-      const int k = 2 * s + lh;
-      af[s] = h1s[k * LDH + mt * 32 + li];
-      bf[s] = xs[k * XP3 + li];
-    }
+    for (int nb = 0; nb < (WIDE ? 2 : 1); ++nb) {
+      f32x16 acc1;
 #pragma unroll
-    for (int s = 0; s < BM / 2; ++s) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(af[s], bf[s], acc1, 0, 0, 0);
-    if (li <= D) {
+      for (int r = 0; r < 16; ++r) acc1[r] = 0.f;
+      float bf[BM / 2];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int i = mt * 32 + 4 * lh + rowoff(r);
-        bs[li < D ? i * D + li : H * D + i] = acc1[r];
+      for (int s = 0; s < BM / 2; ++s) bf[s] = xs[(2 * s + lh) * XP3W + nb * 32 + li];
+#pragma unroll
+      for (int s = 0; s < BM / 2; ++s) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(af[s], bf[s], acc1, 0, 0, 0);
+      const int col = nb * 32 + li;
+      if (col <= D) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int i = mt * 32 + 4 * lh + rowoff(r);
+          bs[col < D ? i * D + col : H * D + i] = acc1[r];
+        }
       }
     }
   }
@@ -1337,7 +1386,7 @@ struct AssembleArgs {
   float* pmean; float* pvar; int32_t* pcount; int pdim;   // second norm over the first pdim columns
   unsigned int* ticket;
   const float* W2; float* W2T; int H;    // transposer blocks (blockIdx >= slabs)
-  const float* W1; float* W1P;           // last block: W1 [H][D] -> [H][XP], zero padded
+  const float* W1; float* W1P; int xp;   // last block: W1 [H][D] -> [H][xp], zero padded
   // a whole round in one launch: blockIdx.y = update k; its index rows / X / slab moments sit k strides further
   long long idx_stride, x_stride, rn_stride;
 };
@@ -1358,8 +1407,8 @@ __global__ __launch_bounds__(AS_NT) void disc_assemble_kernel(AssembleArgs a) {
     a.rn_ws += k * a.rn_stride;
   }
   if (a.W1P != nullptr && blockIdx.x == gridDim.x - 1) {
-    for (int e = tid; e < a.H * XP; e += AS_NT) {
-      const int n = e / XP, k = e - n * XP;
+    for (int e = tid; e < a.H * a.xp; e += AS_NT) {
+      const int n = e / a.xp, k = e - n * a.xp;
       a.W1P[e] = k < a.D ? a.W1[n * a.D + k] : 0.f;
     }
     return;
@@ -1531,7 +1580,7 @@ struct ReduceArgs {
   long long n; int accumulate; float* grads;
   int adam; float* p; float* m; float* v; float beta1, beta2, eps, wd, step_size, bc2_sqrt;
   const float* part; int tiles; int R; int n_expert; float loss_scale; float* stats;
-  float* W2T; float* W1P; int H; int D;   // images of W2 / W1 the tile kernels read: refreshed with the Adam step
+  float* W2T; float* W1P; int H; int D; int xp;   // images of W2 / W1 ([H][xp]) the tile kernels read: refreshed with the Adam step
   // gradient penalty: a second slab set per segment, summed behind the first (cnt2 = 0: none), and the penalty's mean
   const float* src2[4]; long long stride2[4]; int cnt2[4];
   const float* pen; int pen_tiles; int gp_rows; float* gp_out;
@@ -1629,7 +1678,7 @@ __global__ __launch_bounds__(256) void disc_reduce_kernel(ReduceArgs a) {
   const long long nW1 = (long long)a.H * a.D, n1 = nW1 + a.H;
   if (i < nW1) {
     const int n = (int)(i / a.D), k = (int)(i - (long long)n * a.D);
-    a.W1P[n * XP + k] = pn;
+    a.W1P[n * a.xp + k] = pn;
   } else if (i >= n1 && i < n1 + (long long)a.H * a.H) {
     const int j = (int)(i - n1), r = j / a.H, c = j - r * a.H;
     a.W2T[(long long)c * a.H + r] = pn;
@@ -1644,7 +1693,7 @@ __global__ __launch_bounds__(256) void disc_reduce_kernel(ReduceArgs a) {
 struct AdamRefreshArgs {
   long long n; float* grads; float gscale;
   float* p; float* m; float* v; float beta1, beta2, eps, wd, step_size, bc2_sqrt;
-  float* W2T; float* W1P; int H; int D;
+  float* W2T; float* W1P; int H; int D; int xp;
 };
 
 __global__ __launch_bounds__(256) void disc_adam_refresh_kernel(AdamRefreshArgs a) {
@@ -1666,7 +1715,7 @@ __global__ __launch_bounds__(256) void disc_adam_refresh_kernel(AdamRefreshArgs 
   const long long nW1 = (long long)a.H * a.D, n1 = nW1 + a.H;
   if (i < nW1) {
     const int n = (int)(i / a.D), k = (int)(i - (long long)n * a.D);
-    a.W1P[n * XP + k] = pn;
+    a.W1P[n * a.xp + k] = pn;
   } else if (i >= n1 && i < n1 + (long long)a.H * a.H) {
     const int j = (int)(i - n1), r = j / a.H, c = j - r * a.H;
     a.W2T[(long long)c * a.H + r] = pn;
@@ -1675,18 +1724,25 @@ __global__ __launch_bounds__(256) void disc_adam_refresh_kernel(AdamRefreshArgs 
 
 inline int cdivi(long long a, long long b) { return (int)((a + b - 1) / b); }
 
-inline bool fused_shape_ok(const ia_mlp_desc* d, int ldx) {
-  if (!d || d->n_layers != 3 || d->hidden_act != IA_ACT_RELU) return false;
+// The input width class of a stack the tile kernels cover: 24 (D <= 24, every kernel of this file incl. the penalty's),
+// 64 (D <= 63 in rows of up to 64 floats -- use_next_state / use_done nets, Ant-sized GAIL inputs: the one-launch tile
+// pass `disc_fb_kernel<H, 64, 64>`, assembled by the pass kernel of airl_fused.hip), 0: not covered.
+inline int fused_dw(const ia_mlp_desc* d, int ldx) {
+  if (!d || d->n_layers != 3 || d->hidden_act != IA_ACT_RELU) return 0;
   const int D = d->dims[0], H = d->dims[1];
-  if (d->dims[2] != H || d->dims[3] != 1) return false;
-  if (H != 128 && H != 256) return false;
-  return D >= 1 && D <= 24 && ldx >= D && ldx <= 24 && ldx % 4 == 0;
+  if (d->dims[2] != H || d->dims[3] != 1) return 0;
+  if (H != 128 && H != 256) return 0;
+  if (D < 1 || ldx < D || ldx % 4 != 0) return 0;
+  if (D <= 24 && ldx <= 24) return 24;
+  return (D <= 63 && ldx <= 64) ? 64 : 0;
 }
+inline bool fused_shape_ok(const ia_mlp_desc* d, int ldx) { return fused_dw(d, ldx) != 0; }
 
 struct FusedWs { float* P1; float* P3; float* part; float* W2T; float* W1P; unsigned long long* h1mask; unsigned int* ticket; float* dump; long long total; };
 
 inline FusedWs fused_ws_layout(const ia_mlp_desc* d, int R, float* base) {
   const long long D = d->dims[0], H = d->dims[1];
+  const int xp = D <= 24 ? XP : xp_of(64);
   const long long tiles = cdivi(R, 32);   // sized for 32-row tiles (64-row tiles use half of it)
   FusedWs w;
   long long o = 0;
@@ -1695,7 +1751,7 @@ inline FusedWs fused_ws_layout(const ia_mlp_desc* d, int R, float* base) {
   w.part = base + o; o += tiles * 8;
   o = (o + 3) / 4 * 4;                     // 16-byte aligned W2T rows
   w.W2T = base + o; o += H * H;
-  w.W1P = base + o; o += H * XP;
+  w.W1P = base + o; o += H * xp; o = (o + 3) / 4 * 4;
   // (64-row tiles write 8 waves' words per tile: 2 * ceil(R / 64) half-tiles, one more than ceil(R / 32) when that is odd)
   w.h1mask = reinterpret_cast<unsigned long long*>(base + o); o += 2 * (long long)cdivi(R, 64) * 4 * (H / 128) * 16 * 2;
   w.ticket = reinterpret_cast<unsigned int*>(base + o); o += 4;
@@ -1801,6 +1857,7 @@ int launch_fused_tiles(const FusedArgs& fa, int R, hipStream_t stream) {
     if (e != hipSuccess) return (int)e;
     attr_fb = true;
   }
+  static_assert(smem_fb == sizeof(float) * fb_lds_floats<H, BM, 24>(), "disc_fb_kernel's LDS map");
   const int tiles = cdivi(R, BM);
   if (!g_fused_split) {
     hipLaunchKernelGGL((disc_fb_kernel<H, BM>), dim3(tiles), dim3(BM * 8), smem_fb, stream, fa);
@@ -1810,6 +1867,23 @@ int launch_fused_tiles(const FusedArgs& fa, int R, hipStream_t stream) {
   hipLaunchKernelGGL((disc_fwd_kernel<H, BM>), dim3(tiles), dim3(BM * 8), smem_f, stream, fa);
   IA_CHECK_LAUNCH();
   hipLaunchKernelGGL((disc_bwd_kernel<H, BM>), dim3(tiles), dim3(BM * 8), smem_b, stream, fa);
+  IA_CHECK_LAUNCH();
+  return IA_OK;
+}
+
+// rows of 25 .. 64 floats: the one-launch tile pass only (64-row tiles)
+template <int H>
+int launch_fused_tiles_wide(const FusedArgs& fa, int R, hipStream_t stream) {
+  constexpr size_t smem = sizeof(float) * fb_lds_floats<H, 64, 64>();
+  static_assert(smem <= 160 * 1024, "one workgroup per CU");
+  static bool attr = false;
+  if (!attr) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(disc_fb_kernel<H, 64, 64>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (e != hipSuccess) return (int)e;
+    attr = true;
+  }
+  hipLaunchKernelGGL((disc_fb_kernel<H, 64, 64>), dim3(cdivi(R, 64)), dim3(512), smem, stream, fa);
   IA_CHECK_LAUNCH();
   return IA_OK;
 }
@@ -1831,7 +1905,7 @@ extern "C" int ia_disc_fused_debug_timing(void* device_buffer_16xi64) {
 }
 
 extern "C" int64_t ia_disc_fused_gp_ws_floats(const ia_mlp_desc* d, int B, int ldx) {
-  if (B <= 0 || !fused_shape_ok(d, ldx)) return 0;
+  if (B <= 0 || fused_dw(d, ldx) != 24) return 0;   // (the penalty's tile kernels: rows of up to 24 floats)
   return gp_ws_layout(d, B, ldx, nullptr).total;
 }
 
@@ -1859,7 +1933,7 @@ void fill_assemble_sources(AssembleArgs& as, const ia_disc_step_args* a) {
 // rn_ws + k*rn_stride (no merge: ia_running_norm_merge_seq applies them in order and keeps per-update snapshots).
 extern "C" int ia_disc_assemble_round(const ia_disc_step_args* a, int n_updates, int64_t idx_stride, int64_t x_stride,
                                       int64_t rn_stride, void* stream) {
-  if (a && n_updates > 0 && ia_disc32_shape_ok(a->desc, a->ldx))
+  if (a && n_updates > 0 && (ia_disc32_shape_ok(a->desc, a->ldx) || fused_dw(a->desc, a->ldx) == 64))
     return ia_disc32_assemble(a, n_updates, idx_stride, x_stride, rn_stride, a->rn_ws, (hipStream_t)stream);
   if (!a || n_updates <= 0 || !fused_shape_ok(a->desc, a->ldx) || a->n0 + a->n1 <= 0) return IA_ERR_ARG;
   AssembleArgs as{};
@@ -1886,7 +1960,7 @@ extern "C" int ia_disc_fused_prepare(const ia_mlp_desc* d, const float* params, 
   AssembleArgs as{};
   as.R = 0; as.D = D; as.ldx = ldx; as.H = H;
   as.W2 = params + (long long)H * D + H; as.W2T = w.W2T;
-  as.W1 = params; as.W1P = w.W1P;
+  as.W1 = params; as.W1P = w.W1P; as.xp = xp_of(fused_dw(d, ldx));
   hipLaunchKernelGGL(disc_assemble_kernel, dim3((H / 64) * (H / 64) + 1), dim3(AS_NT), 0, (hipStream_t)stream, as);
   IA_CHECK_LAUNCH();
   return IA_OK;
@@ -1910,6 +1984,7 @@ extern "C" int ia_disc_fused_adam(const ia_mlp_desc* d, float* params, float gra
   ra.beta1 = adam->beta1; ra.beta2 = adam->beta2; ra.eps = adam->eps; ra.wd = adam->weight_decay;
   ra.step_size = adam->step_size; ra.bc2_sqrt = adam->bc2_sqrt;
   ra.W2T = w.W2T; ra.W1P = w.W1P; ra.H = narrow ? 0 : H; ra.D = narrow ? 1 : D;
+  ra.xp = narrow ? XP : xp_of(fused_dw(d, ldx));
   hipLaunchKernelGGL(disc_adam_refresh_kernel, dim3(cdivi(ra.n, 256)), dim3(256), 0, (hipStream_t)stream, ra);
   IA_CHECK_LAUNCH();
   return IA_OK;
@@ -1922,9 +1997,11 @@ int ia_disc_step_fused(const ia_disc_step_args* a, void* stream_) {
   const ia_mlp_desc* d = a->desc;
   const int R = a->n0 + a->n1, D = d->dims[0], H = d->dims[1];
   if (a->fused_ws && ia_disc32_shape_ok(d, a->ldx)) return a->gp_e ? IA_ERR_UNSUPPORTED : ia_disc32_step(a, stream_);
-  if (!fused_shape_ok(d, a->ldx) || !a->fused_ws) return IA_ERR_UNSUPPORTED;
+  const int dw = fused_dw(d, a->ldx);
+  if (dw == 0 || !a->fused_ws || (dw != 24 && a->gp_e)) return IA_ERR_UNSUPPORTED;
+  const bool wide = dw != 24;
   const FusedWs w = fused_ws_layout(d, R, a->fused_ws);
-  const int bm = g_fused_bm == 64 ? 64 : 32;
+  const int bm = (g_fused_bm == 64 || wide) ? 64 : 32;
   const int tiles = cdivi(R, bm), slabs = cdivi(R, RN_ROWS_PER_BLOCK);
   const long long nW1 = (long long)H * D, n1 = nW1 + H, n2 = (long long)H * H + H, n3 = H + 1, tot = n1 + n2 + n3;
 
@@ -1938,11 +2015,24 @@ int ia_disc_step_fused(const ia_disc_step_args* a, void* stream_) {
   as.pdim = use_p ? a->pnorm_dim : 0;
   as.ticket = w.ticket;
   as.W2 = a->params + n1; as.W2T = w.W2T; as.H = H;
-  as.W1 = a->params; as.W1P = w.W1P;
-  if (!a->pre_assembled) {   // (pre-assembled: X / slab moments come from ia_disc_assemble_round, the statistics to
+  as.W1 = a->params; as.W1P = w.W1P; as.xp = xp_of(dw);
+  int rc;
+  if (!a->pre_assembled && !wide) {   // (pre-assembled: X / slab moments come from ia_disc_assemble_round, the statistics to
                              //  normalise with from the caller, W2T / W1P from ia_disc_fused_prepare + the Adam steps)
     hipLaunchKernelGGL(disc_assemble_kernel, dim3(slabs + (H / 64) * (H / 64) + 1), dim3(AS_NT), 0, stream, as);
     IA_CHECK_LAUNCH();
+  } else if (!a->pre_assembled) {
+    // wide rows: the pass kernel of airl_fused.hip assembles (any row length) and leaves the slab moments, the merges are
+    // their own launches (ia_disc32_step's sequence), and the weight images come from the transposer blocks
+    if (as.update_norm && !a->rn_ws) return IA_ERR_ARG;
+    if ((rc = ia_disc32_assemble(a, 1, 0, 0, 0, as.update_norm ? a->rn_ws : nullptr, stream))) return rc;
+    if (as.update_norm) {
+      if ((rc = ia_running_norm_merge(a->rn_ws, 1, R, D, D, a->norm_mean, a->norm_var, a->norm_count, stream_))) return rc;
+      if (use_p && (rc = ia_running_norm_merge(a->rn_ws, 1, R, a->pnorm_dim, D, a->pnorm_mean, a->pnorm_var,
+                                               a->pnorm_count, stream_)))
+        return rc;
+    }
+    if ((rc = ia_disc_fused_prepare(d, a->params, R, a->ldx, a->fused_ws, stream_))) return rc;
   }
 
   FusedArgs fa{};
@@ -1954,8 +2044,8 @@ int ia_disc_step_fused(const ia_disc_step_args* a, void* stream_) {
   fa.logits = a->logits; fa.dlogits = a->dlogits; fa.n_expert = a->n_expert; fa.loss_scale = a->loss_scale;
   fa.part = w.part; fa.P1 = w.P1; fa.P3 = w.P3; fa.dump = w.dump;
   fa.dbg = g_fused_dbg;
-  int rc;
-  if (bm == 64) rc = H == 256 ? launch_fused_tiles<256, 64>(fa, R, stream) : launch_fused_tiles<128, 64>(fa, R, stream);
+  if (wide) rc = H == 256 ? launch_fused_tiles_wide<256>(fa, R, stream) : launch_fused_tiles_wide<128>(fa, R, stream);
+  else if (bm == 64) rc = H == 256 ? launch_fused_tiles<256, 64>(fa, R, stream) : launch_fused_tiles<128, 64>(fa, R, stream);
   else rc = H == 256 ? launch_fused_tiles<256, 32>(fa, R, stream) : launch_fused_tiles<128, 32>(fa, R, stream);
   if (rc) return rc;
 
@@ -2022,7 +2112,7 @@ int ia_disc_step_fused(const ia_disc_step_args* a, void* stream_) {
   ra.step_size = a->step_size; ra.bc2_sqrt = a->bc2_sqrt;
   ra.part = w.part; ra.tiles = tiles; ra.R = R; ra.n_expert = a->n_expert; ra.loss_scale = a->loss_scale;
   ra.stats = a->stats;
-  ra.W2T = w.W2T; ra.W1P = w.W1P; ra.H = H; ra.D = D;
+  ra.W2T = w.W2T; ra.W1P = w.W1P; ra.H = H; ra.D = D; ra.xp = xp_of(dw);
   hipLaunchKernelGGL(disc_reduce_kernel, dim3(cdivi(tot, 64) + 1), dim3(256), 0, stream, ra);
   IA_CHECK_LAUNCH();
   if (a->adam && a->accumulate)

@@ -137,6 +137,15 @@ CASES: Dict[str, Dict[str, Any]] = {
                            demo_batch=96, demo_minibatch=None, n_disc=3, capacity=None, n_demo=400, rounds=3,
                            norm_policy=True, norm_disc=True, obs_dtype="float32",
                            disc_kwargs=dict(use_next_state=True, use_done=True)),
+    # 18 + 6 + 18 = 42 inputs (rows of 44 floats) through the wide fused update (128-wide stack, rows of 25 .. 64 floats:
+    # `disc_fb_kernel<H, 64, 64>`), pipelined rounds with the one-launch round assembly. (Without the done column: with it
+    # this configuration amplifies a 1e-6 parameter perturbation of the REFERENCE ITSELF to 2e-3 within three rounds --
+    # ReLU kinks; the column's assembly pass is covered by `gail_next_done` and by tests/test_disc_fused_gpu.py.)
+    "gail_fused_wide": dict(algo="gail", n_envs=8, horizon=5, obs_dim=18, act_dim=6, n_discrete=None,
+                            n_steps=16, ppo_batch=32, n_epochs=2, ent_coef=0.01, disc_hid=(128, 128),
+                            demo_batch=192, demo_minibatch=None, n_disc=3, capacity=None, n_demo=500, rounds=3,
+                            norm_policy=True, norm_disc=True, obs_dtype="float32",
+                            disc_kwargs=dict(use_next_state=True)),
     # AIRL, shaped reward net, NormalizedRewardNet output norm (script default), use_next_state.
     "airl_box": dict(algo="airl", n_envs=8, horizon=10, obs_dim=11, act_dim=3, n_discrete=None,
                      n_steps=16, ppo_batch=32, n_epochs=2, ent_coef=0.0, disc_hid=(32,),

@@ -63,7 +63,7 @@ def _compare(got, gold, cfg, skip=(), adam_outliers=None):
 @pytest.mark.parametrize("case", ["gail_box", "gail_f64", "gail_discrete", "airl_box", "gail_horizon", "gail_tuned",
                                   "gail_fused", "gail_cartpole", "gail_towers", "gail_discrete_towers",
                                   "airl_towers", "gail_image", "airl_image", "gail_tuned_hps", "airl_tuned_hps",
-                                  "gail_next_done", "gail_generic_vecenv", "airl_ema"])
+                                  "gail_next_done", "gail_generic_vecenv", "airl_ema", "gail_fused_wide"])
 def test_hip_trainer_matches_reference_golden(case, tmp_path):
     cfg = harness.CASES[case]
     gold = dict(np.load(os.path.join(GOLDEN, f"{case}.npz")))
@@ -101,7 +101,7 @@ def _csv_rows(path):
     return [{k: v for k, v in r.items() if not k.startswith(("time/", "mean/gen/time/", "raw/gen/time/"))} for r in rows]
 
 
-@pytest.mark.parametrize("case", ["gail_box", "airl_box", "gail_fused"])
+@pytest.mark.parametrize("case", ["gail_box", "airl_box", "gail_fused", "gail_fused_wide"])
 def test_pipelined_rounds_are_bit_identical(tmp_path, case):
     """Round r's discriminator updates run behind round r+1's environment stepping (GAIL; AIRL with the
     per-update feature statistics taken from the merge snapshots). Every array, every logged statistic

@@ -1,4 +1,4 @@
-"""The fused discriminator updates (`csrc/disc_fused.hip`: D -> H -> H -> 1 with H in {128, 256}; `csrc/airl_fused.hip`
+"""The fused discriminator updates (`csrc/disc_fused.hip`: D -> H -> H -> 1 with H in {128, 256}, D <= 63; `csrc/airl_fused.hip`
 `disc32_rows_kernel`: the reference's default 32 x 32 stack with up to 64 inputs) through `BasicRewardNet.disc_step_c`
 against a float64 torch autograd restatement of one `train_disc` minibatch (`adversarial/common.py:352-373`,
 `rewards/reward_nets.py:441-457`, `util/networks.py:79-91,111-134`): logits, the statistics row, the flat gradient,
@@ -58,6 +58,11 @@ CASES = [
     (29, 6, False, (True, True, True, False), (32, 32), 128, 128, False),      # 64 inputs (the maximum), no input norm
     (17, 6, False, (True, True, False, False), (128, 128), 100, 92, True),
     (17, 6, False, (True, True, False, False), (256, 256), 256, 256, True),
+    # rows of 25 .. 64 floats through the wide one-launch tile pass (`disc_fb_kernel<H, 64, 64>`)
+    (27, 8, False, (True, True, False, False), (256, 256), 300, 211, True),    # Ant GAIL: 35 inputs, ragged 511 rows
+    (17, 6, False, (True, True, True, True), (256, 256), 1000, 1000, True),    # use_next_state + use_done: 41 inputs
+    (28, 6, False, (True, True, True, True), (128, 128), 100, 93, True),       # 63 inputs (the maximum)
+    (11, 4, True, (True, True, True, False), (256, 256), 64, 64, False),       # one-hot actions, 26 inputs, no input norm
 ]
 
 
@@ -139,11 +144,11 @@ def test_fused_disc_step_matches_float64_autograd(od, ad, discrete, flags, hid, 
     th.testing.assert_close(mlp.flat.cpu().double()[moved], want[moved], rtol=0, atol=2e-5)
 
 
-@pytest.mark.parametrize("hid", [(32, 32), (128, 128)])
-def test_round_assembly_equals_per_update_assembly(hid):
+@pytest.mark.parametrize("hid,od", [((32, 32), 17), ((128, 128), 17), ((256, 256), 27)])
+def test_round_assembly_equals_per_update_assembly(hid, od):
     """`assemble_round` + pre-assembled updates (what a pipelined round runs) == one-call updates in sequence: same
     parameters, statistics rows and RunningNorm state, bit for bit."""
-    od, ad, n_upd, mb = 17, 6, 3, 96
+    ad, n_upd, mb = (8 if od == 27 else 6), 3, 96
     osp, asp = spaces.Box(-np.inf, np.inf, (od,), np.float32), spaces.Box(-1, 1, (ad,), np.float32)
     e_tab, _ = _tables(400, od, ad, False, 1)
     g_tab, _ = _tables(300, od, ad, False, 2)

@@ -396,7 +396,7 @@ def _fused_worker(rank, world, port, out_dir):
     reward_nets.ShapedRewardNet.fused_finish = counting_finish
 
     def run(airl: bool, pipeline: bool, hid=(256, 256), normalize_output: bool = False, module: bool = False,
-            gp: float = 0.0):
+            gp: float = 0.0, wide: bool = False):
         th.manual_seed(100 + rank)
         np.random.seed(100 + rank)
         venv = SyntheticVecEnv(num_envs=cfg["n_envs"], obs_dim=17, act_dim=6, horizon=cfg["horizon"], seed=rank)
@@ -413,7 +413,8 @@ def _fused_worker(rank, world, port, out_dir):
                                            normalize_input_layer=p.modules.RunningNorm)
         else:
             net = p.BasicRewardNet(venv.observation_space, venv.action_space, hid_sizes=hid,
-                                   normalize_input_layer=p.RunningNorm)
+                                   normalize_input_layer=p.RunningNorm,
+                                   **(dict(use_next_state=True, use_done=True) if wide else {}))   # wide: 41 inputs
         if normalize_output:   # the scripts' default wrapper: output statistics over the env batches of ALL ranks
             net = p.NormalizedRewardNet(net, p.RunningNorm)
         demos = p.Transitions(**harness.make_demo_arrays(cfg, seed=1 + rank))
@@ -434,6 +435,7 @@ def _fused_worker(rank, world, port, out_dir):
     for name, kw in (("gail", dict(airl=False, pipeline=True)), ("gail_seq", dict(airl=False, pipeline=False)),
                      ("gail128", dict(airl=False, pipeline=True, hid=(128, 128))),
                      ("gail_gp", dict(airl=False, pipeline=True, gp=2.0)),
+                     ("gail_wide", dict(airl=False, pipeline=True, wide=True)),
                      ("gail32", dict(airl=False, pipeline=True, hid=(32, 32))),
                      ("airl", dict(airl=True, pipeline=True)), ("airl_seq", dict(airl=True, pipeline=False)),
                      ("airl_norm", dict(airl=True, pipeline=True, normalize_output=True)),
@@ -454,7 +456,7 @@ def test_fused_updates_under_data_parallelism_replicas_identical(tmp_path):
     port = _free_port()
     mp.spawn(_fused_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     ld = lambda r, n: th.load(tmp_path / f"fused{r}_{n}.pt")
-    for name in ("gail", "gail_seq", "gail128", "gail_gp", "gail32", "airl", "airl_seq", "airl_norm", "module"):
+    for name in ("gail", "gail_seq", "gail128", "gail_gp", "gail_wide", "gail32", "airl", "airl_seq", "airl_norm", "module"):
         a, b = ld(0, name), ld(1, name)
         calls = a.pop("_fused_calls"); b.pop("_fused_calls")
         # 3 rounds x 3 updates, every one through the fused kernels (the nn.Module net: through the custom ops)

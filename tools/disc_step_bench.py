@@ -1,7 +1,7 @@
 """One discriminator update (C-ABI `ia_disc_step_basic`) at config-P shapes: the fused five-launch path
 against the general path and against torch autograd (float64) on the same inputs, then both timed
 back-to-back with HIP events on the launch stream.
-Usage: python tools/disc_step_bench.py [iters] [H] [R]"""
+Usage: [OD=27 AD=8] python tools/disc_step_bench.py [iters] [H] [R]"""
 import os
 import sys
 
@@ -16,7 +16,7 @@ from imitation_amd.networks import HipAdam, TransitionTable  # noqa: E402
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 50
 H = int(sys.argv[2]) if len(sys.argv) > 2 else 256
 R = int(sys.argv[3]) if len(sys.argv) > 3 else 16384
-OD, AD, NE, NG = 17, 6, 64000, 16384
+OD, AD, NE, NG = int(os.environ.get("OD", 17)), int(os.environ.get("AD", 6)), 64000, 16384   # OD=27 AD=8: Ant width (35 inputs)
 dev = "cuda"
 mb = R // 2
 
