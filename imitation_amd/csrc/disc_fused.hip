@@ -1,5 +1,6 @@
 // Fused discriminator update for BasicRewardNet-shaped stacks  D -> H -> H -> 1  (ReLU, H in {128, 256},
-// D <= 24): adversarial/common.py:352-373 (one minibatch of train_disc) in FIVE launches instead of 16,
+// D <= 24 in every kernel below; D <= 63 in rows of up to 64 floats through disc_fb_kernel<H, 64, 64>):
+// adversarial/common.py:352-373 (one minibatch of train_disc) in FIVE launches instead of 16,
 // with the hidden activations of a 64-row tile chained through LDS instead of round-tripping HBM.
 //
 //   K1 assemble : gather + concat (+ one-hot) of [expert | generator] rows -> X, RunningNorm slab moments
@@ -838,19 +839,27 @@ __global__ __launch_bounds__(BM * 8) void disc_fb_kernel(FusedArgs a) {
     const int nk16 = (a.ldx + 15) >> 4;
     const float* xr = xs + (wm * 32 + li) * XP3W + lh;
     const float* wr = w1s + (wn * WC + li) * XPW + lh;
-#pragma unroll 1
-    for (int kc = 0; kc < nk16; ++kc) {
-      float af[8], bf[8][TN];
+    float af[2][8], bf[2][8][TN];
+    auto frags = [&](float (&fa_)[8], float (&fb_)[8][TN], int kc) {
 #pragma unroll
       for (int ks = 0; ks < 8; ++ks) {
-        af[ks] = xr[kc * 16 + 2 * ks];
+        fa_[ks] = xr[kc * 16 + 2 * ks];
 #pragma unroll
-        for (int t = 0; t < TN; ++t) bf[ks][t] = wr[t * 32 * XPW + kc * 16 + 2 * ks];
+        for (int t = 0; t < TN; ++t) fb_[ks][t] = wr[t * 32 * XPW + kc * 16 + 2 * ks];
       }
+    };
+    frags(af[0], bf[0], 0);
+    // at most four steps (uniform guards); the next step's fragment reads are issued ahead of this step's MFMAs
 #pragma unroll
-      for (int ks = 0; ks < 8; ++ks)
+    for (int kc = 0; kc < 4; ++kc) {
+      if (kc < nk16) {
+        if (kc + 1 < 4) frags(af[(kc + 1) & 1], bf[(kc + 1) & 1], min(kc + 1, nk16 - 1));
 #pragma unroll
-        for (int t = 0; t < TN; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[ks], bf[ks][t], acc[t], 0, 0, 0);
+        for (int ks = 0; ks < 8; ++ks)
+#pragma unroll
+          for (int t = 0; t < TN; ++t)
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kc & 1][ks], bf[kc & 1][ks][t], acc[t], 0, 0, 0);
+      }
     }
   }
   FUSED_STAMP(a, 2);

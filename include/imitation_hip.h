@@ -169,7 +169,7 @@ typedef struct {
    * moments (the policy feature norm side effect); requires update_norm. */
   float* pnorm_mean; float* pnorm_var; int32_t* pnorm_count; int pnorm_dim;
   /* optional: ia_disc_fused_ws_floats(desc, n0+n1, ldx) floats, ZEROED once by the caller. When set and the
-   * stack is D -> H -> H -> 1 with ReLU, H in {128, 256}, D <= 24, the update runs as five fused launches
+   * stack is D -> H -> H -> 1 with ReLU, H in {128, 256}, D <= 63 (ldx <= 64), the update runs as fused launches
    * (assemble+moments+merge | forward+BCE+head gradient per 64-row tile | input gradient + first-layer weight
    * gradient per tile | second-layer weight gradient | slab reduction + Adam + statistics): the hidden
    * activations of a tile stay in LDS; `hidden` then holds h1 and dh2, `Xn` / `dhidden` are not touched. */

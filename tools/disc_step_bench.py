@@ -123,6 +123,28 @@ for fused in (False, True):
     print(f"{'fused  ' if fused else 'general'}: {us:8.2f} us per update  {flops / us / 1e6:7.2f} TFLOP/s  "
           f"({100 * flops / us / 1e6 / 157.3:5.1f}% of the fp32 MFMA peak), R={R} H={H}")
 
+# ---- the schedule of a pipelined round: ONE assembly launch for 16 updates, then the pre-assembled updates
+net, opt = build(True)
+stats = th.zeros(16, 8, device=dev)
+idx_all = th.stack([th.stack([ie, ig])] * 16).contiguous()
+ms = 0.0
+reps = max(1, iters // 16)
+for it in range(reps + 1):
+    e0, e1 = th.cuda.Event(enable_timing=True), th.cuda.Event(enable_timing=True)
+    e0.record()
+    with P.networks.training(net):
+        rw = net.assemble_round(e, g, idx_all, 16, mb)
+        for k in range(16):
+            net.disc_step_c([(e, idx_all[k, 0], mb), (g, idx_all[k, 1], mb)], mb, 1.0, stats[k], bce_ws, accumulate=False,
+                            adam=opt, pre=(rw, k))
+    e1.record()
+    th.cuda.synchronize()
+    if it:   # (the first pass warms up)
+        ms += e0.elapsed_time(e1)
+us = 1e3 * ms / (16 * reps)
+print(f"fused, round schedule (1 assembly launch per 16 updates + 3 launches per update): {us:8.2f} us per update  "
+      f"{flops / us / 1e6:7.2f} TFLOP/s ({100 * flops / us / 1e6 / 157.3:5.1f}% of the fp32 MFMA peak)")
+
 # ---- phase clocks of block 0 (fused tile kernels), shader cycles
 reward_nets.FUSED_DISC_STEP = True
 net, opt = build(True)
