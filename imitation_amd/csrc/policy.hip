@@ -778,14 +778,33 @@ __device__ __forceinline__ void column_sum_store(const float* tile, int stride, 
   }
 }
 
-template <int H>
-struct GLds {  // LDS carve-up of the 8-wave gradient kernel (floats)
+// The same sums (rows added in order 0 .. ROWS-1) with the reads issued sixteen at a time.
+__device__ __forceinline__ float column_sum_b(const float* col, int stride) {
+  float s = 0.f;
+#pragma unroll
+  for (int r0 = 0; r0 < ROWS; r0 += 16) {
+    float t[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) t[u] = col[(r0 + u) * stride];
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < 16; ++u) s += t[u];
+  }
+  return s;
+}
+__device__ __forceinline__ void column_sum_store_b(const float* tile, int stride, int ncols, float* __restrict__ dst,
+                                                   int lane) {
+  if (lane < ncols) dst[lane] = column_sum_b(tile + lane, stride);
+}
+
+template <int H, int NTOW = 2>
+struct GLds {  // LDS carve-up of the 8-wave gradient kernel (floats); NTOW = 1: one tower per workgroup (4 waves)
   static constexpr int XS = MAXD + 1, HS = H + 1, AS = MAXA + 1, MS = 9;
   static constexpr int x = 0;
-  static constexpr int a1 = x + ROWS * XS;             // [2 towers][ROWS][HS]
-  static constexpr int a2 = a1 + 2 * ROWS * HS;
-  static constexpr int dz = a2 + 2 * ROWS * HS;
-  static constexpr int out = dz + 2 * ROWS * HS;
+  static constexpr int a1 = x + ROWS * XS;             // [NTOW towers][ROWS][HS]
+  static constexpr int a2 = a1 + NTOW * ROWS * HS;
+  static constexpr int dz = a2 + NTOW * ROWS * HS;
+  static constexpr int out = dz + NTOW * ROWS * HS;
   static constexpr int dout = out + ROWS * AS;
   static constexpr int aux = dout + ROWS * AS;
   static constexpr int misc = aux + ROWS * AS;         // [ROWS][MS]: 0 = value, 1 = dvalue
@@ -1088,12 +1107,20 @@ struct UpdStage {
 // hidden = 32 without the persistent kernel, i.e. data-parallel runs): forward, losses, backward;
 // gradient partials -> `slab`, loss-statistic partials -> `statpart[0..4]`. LOAD_PARAMS: copy the flat
 // parameter vectors into LDS first.
-template <int H, bool LOAD_PARAMS>
+// SPLIT (H = 64, ppo_epoch_persistent_kernel<64, true>): the workgroup is FOUR waves and runs ONE tower (`tower`: 0 policy,
+// 1 value) of the block's 64 rows; the other tower of the same rows is another workgroup. One tower's tiles are 82 KB, so
+// that tower's parameters (both layouts, <= 71 KB) are resident in LDS like the H = 32 kernel's: every weight fragment is
+// an LDS read instead of a load from the memory-side cache, one wave per SIMD has the matrix pipe to itself, and the block
+// barriers are among four waves. The two workgroups of a row block write disjoint parts of the block's slab.
+template <int H, bool LOAD_PARAMS, bool SPLIT = false>
 __device__ __forceinline__ void mfma_minibatch(
     const ia_policy_desc& d, const float* __restrict__ P, const float* __restrict__ Pt, const float* __restrict__ nm,
     const float* __restrict__ nv, const float adv_mean, const float adv_std, const MbRows rows, const int vblk,
     const int normalize_adv, const float clip, const float ent_coef, const float vf_coef, float* __restrict__ slab,
-    float* __restrict__ statpart, float* __restrict__ lds_in, long long* __restrict__ tstamp, const int oz = 0) {
+    float* __restrict__ statpart, float* __restrict__ lds_in, long long* __restrict__ tstamp, const int oz = 0,
+    const int tower = 0) {
+  static_assert(!SPLIT || (H == 64 && LOAD_PARAMS), "the one-tower form is the 64-wide epoch kernel's");
+  constexpr int NT = SPLIT ? 256 : 512;
   // `oz`: an opaque zero when the function sits inside a step loop (ppo_epoch_persistent_kernel): every per-lane offset is
   // then re-derived per step instead of being hoisted out of the loop into (spilled) registers
   float* __restrict__ lds = lds_in + oz;
@@ -1105,11 +1132,13 @@ __device__ __forceinline__ void mfma_minibatch(
   const int64_t* __restrict__ idx = rows.idx;
   const int batch = rows.batch, T = rows.T, n_envs = rows.n_envs;
   constexpr int NC = H / 16, KS = H / 4;   // 16-column tiles of a layer output, MFMA steps over a hidden layer
-  using L = GLds<H>;
+  using L = GLds<H, SPLIT ? 1 : 2>;
 #define IA_TS(slot) do { if (tstamp && vblk == 0 && threadIdx.x == 0) tstamp[slot] = clock64(); } while (0)
   const int tid = threadIdx.x + oz, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int tw = wv >> 2, q = wv & 3;
+  const int tw = SPLIT ? tower : wv >> 2, q = SPLIT ? wv : wv & 3;
+  const bool pol_wave = SPLIT ? (tower == 0 && wv == 0) : wv == 0;   // the wave with the per-row policy loss terms
+  const bool val_wave = SPLIT ? (tower == 1 && wv == 0) : wv == 4;   // ... the value loss term
   const int li = lane & 15, lk = lane >> 4;
   const int D = d.obs_dim, A = d.act_dim;
   const PolOff o = pol_offsets(D, A, H, d.discrete);
@@ -1123,16 +1152,41 @@ __device__ __forceinline__ void mfma_minibatch(
 
   // ---- phase 0a: issue the feature-row loads FIRST (VMEM returns in order: the LDS stores below then
   // only wait for these, while the weight fragments requested next keep streaming in behind them)
-  constexpr int NIT = (ROWS * L::XS + 511) / 512;
+  // (the block's ROWS x D real elements, element e = row * D + column: one division per thread, then (row, column) advance
+  //  by NT elements per trip; trips past ROWS * D are skipped wave-uniformly)
+  constexpr int NIT = (ROWS * MAXD + NT - 1) / NT;
+  const int nel = ROWS * D;
   float xv[NIT], xm[NIT], xs_[NIT];
+  int xi[NIT];   // LDS offset of the element inside the x tile (-1: none)
+  {
+    // every load is UNCONDITIONAL at a clamped address (values selected afterwards): behind a divergent branch the
+    // compiler cannot count a load in vmcnt and each trip would wait for the one before -- a memory round trip per trip
+    int r = tid / D, k = tid - r * D;
+    const int dr = NT / D, dk = NT - dr * D;
+    const float* nmp = d.has_norm ? nm : obs;   // (no statistics: any readable address, the value is discarded)
+    const float* nvp = d.has_norm ? nv : obs;
+    unsigned okbits = 0u;   // bit it: the trip's element is a real row of the minibatch
+    // (no branch around a trip either, not even a uniform one: the merge of "loaded" and "not loaded" values is a copy
+    //  that waits for the load; trips past ROWS * D re-read the last row at clamped addresses and are discarded)
 #pragma unroll
-  for (int it = 0; it < NIT; ++it) {
-    const int e = tid + it * 512;
-    const int r = e / L::XS, k = e - r * L::XS;
-    const bool ok = e < ROWS * L::XS && k < D && i0 + r < batch;
-    xv[it] = ok ? obs[mb_row(idx, i0 + r, T, n_envs) * D + k] : 0.f;
-    xm[it] = (ok && d.has_norm) ? nm[k] : 0.f;
-    xs_[it] = (ok && d.has_norm) ? nv[k] : 1.f - d.norm_eps;
+    for (int it = 0; it < NIT; ++it) {
+      const bool on = tid + it * NT < nel;
+      okbits |= (on && i0 + r < batch) ? 1u << it : 0u;
+      xv[it] = obs[mb_row(idx, min(i0 + min(r, ROWS - 1), batch - 1), T, n_envs) * D + k];
+      xm[it] = nmp[k];
+      xs_[it] = nvp[k];
+      xi[it] = on ? r * L::XS + k : -1;
+      r += dr; k += dk;
+      if (k >= D) { k -= D; ++r; }
+    }
+    __builtin_amdgcn_sched_barrier(0);   // (the selects below consume the values: all the loads are issued before the first)
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const bool ok = (okbits >> it) & 1u;
+      xv[it] = ok ? xv[it] : 0.f;
+      xm[it] = (ok && d.has_norm) ? xm[it] : 0.f;
+      xs_[it] = (ok && d.has_norm) ? xs_[it] : 1.f - d.norm_eps;
+    }
   }
   // per-row scalars of the loss phase (wave 0: policy terms, wave 4: value term)
   const int i = i0 + lane;
@@ -1141,14 +1195,14 @@ __device__ __forceinline__ void mfma_minibatch(
   float r_oldlp = 0.f, r_adv = 0.f, r_ret = 0.f, r_act[MAXA];
 #pragma unroll
   for (int a = 0; a < MAXA; ++a) r_act[a] = 0.f;
-  if (wv == 0) {
+  if (pol_wave) {
     r_oldlp = old_logp[src];
     r_adv = adv[src];
 #pragma unroll
     for (int a = 0; a < MAXA; ++a)
       if (a < aw) r_act[a] = actions[src * aw + a];  // consumed in phase 4: the latency hides behind phases 1-3
   }
-  if (wv == 4) r_ret = ret[src];
+  if (val_wave) r_ret = ret[src];
 
   IA_TS(9);
   // ---- parameters: ONE cooperative, coalesced 16-byte copy of both flat vectors (torch layout P and
@@ -1157,12 +1211,64 @@ __device__ __forceinline__ void mfma_minibatch(
   // L2-resident flat vectors)
   const float* sP = H == 32 ? lds + L::total : P;
   const float* sPt = H == 32 ? sP + ((o.total + 3) & ~3) : Pt;
+  // SPLIT: images of the tower's two pieces of the flat vector -- A = its layers (policy: log_std, pW1 .. pb2; value:
+  // vW1 .. vb2), B = its head (aW, ab | cW, cb) -- in torch layout, and piece A of the transposed copy; each from the
+  // 4-float boundary below its first element, so that the copies are 16-byte pieces. sPA / sPB / sPt are biased so that
+  // the flat offsets of PolOff address them.
+  const float* sPA = sP;   // reads of the tower's layers / of its head (the same vector unless SPLIT)
+  const float* sPB = sP;
+  if constexpr (SPLIT) {
+    const int segA0 = tower ? o.vW1 : 0, segA1 = tower ? o.aW : o.vW1;
+    const int segB0 = tower ? o.cW : o.aW, segB1 = tower ? o.total : o.cW;
+    const int a0 = segA0 & ~3, lenA = ((segA1 + 3) & ~3) - a0;
+    const int b0 = segB0 & ~3, lenB = ((segB1 + 3) & ~3) - b0;
+    float* img = lds + ((L::total + 3) & ~3);
+    // all loads of the three pieces first (one round trip), then the LDS stores; a 16-byte piece that would run past the
+    // end of the flat vector (the last one of the value head at most) is read element by element
+    auto load_piece = [&](const float* __restrict__ srcv, int f0, int len4, int i) {
+      const int e = tid + i * NT, f = f0 + 4 * e;
+      float4 v4 = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (e < len4) {
+        if (f + 3 < o.total) {
+          v4 = *reinterpret_cast<const float4*>(srcv + f);
+        } else {
+          float t0[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) t0[u] = srcv[min(f + u, o.total - 1)];
+          v4 = make_float4(t0[0], t0[1], t0[2], t0[3]);
+        }
+      }
+      return v4;
+    };
+    constexpr int NA = (H * MAXD + H + H * H + H + MAXA + 8 + 4 * NT - 1) / (4 * NT);   // 16-byte pieces per thread, piece A
+    constexpr int NB = (MAXA * H + MAXA + 8 + 4 * NT - 1) / (4 * NT);                   // ... piece B
+    float4 va[NA], vb[NB], vt[NA];
+#pragma unroll
+    for (int i = 0; i < NA; ++i) va[i] = load_piece(P, a0, lenA >> 2, i);
+#pragma unroll
+    for (int i = 0; i < NB; ++i) vb[i] = load_piece(P, b0, lenB >> 2, i);
+#pragma unroll
+    for (int i = 0; i < NA; ++i) vt[i] = load_piece(Pt, a0, lenA >> 2, i);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < NA; ++i)
+      if (tid + i * NT < (lenA >> 2)) {
+        reinterpret_cast<float4*>(img)[tid + i * NT] = va[i];
+        reinterpret_cast<float4*>(img + lenA + lenB)[tid + i * NT] = vt[i];
+      }
+#pragma unroll
+    for (int i = 0; i < NB; ++i)
+      if (tid + i * NT < (lenB >> 2)) reinterpret_cast<float4*>(img + lenA)[tid + i * NT] = vb[i];
+    sPA = img - a0;
+    sPB = img + lenA - b0;
+    sPt = img + lenA + lenB - a0;
+  }
   if (LOAD_PARAMS && H == 32) {
     float* wP = lds + L::total;
     float* wPt = wP + ((o.total + 3) & ~3);
     const int n4 = (o.total + 3) >> 2;
     const bool vec = ((reinterpret_cast<uintptr_t>(P) | reinterpret_cast<uintptr_t>(Pt)) & 15) == 0;
-    for (int e = tid; e < n4; e += 512) {
+    for (int e = tid; e < n4; e += NT) {
       float4 v0, v1;
       if (vec && 4 * e + 3 < o.total) {
         v0 = reinterpret_cast<const float4*>(P)[e];
@@ -1186,12 +1292,18 @@ __device__ __forceinline__ void mfma_minibatch(
   // ---- phase 0b: normalise + stage the feature rows in LDS; clear the small tiles
   auto stage_rows = [&]() {
 #pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-      const int e = tid + it * 512;
-      if (e < ROWS * L::XS) lds[L::x + e] = (xv[it] - xm[it]) / sqrtf(xs_[it] + d.norm_eps);
+    for (int it = 0; it < NIT; ++it)
+      if (xi[it] >= 0) lds[L::x + xi[it]] = (xv[it] - xm[it]) / sqrtf(xs_[it] + d.norm_eps);
+    {
+      // columns D .. 4 * S1 - 1 feed layer 1's last MFMA step (against zero weight rows): they must be finite
+      const int padw = 4 * S1 - D;
+      for (int e = tid; e < ROWS * padw; e += NT) {
+        const int r = e / padw;
+        lds[L::x + r * L::XS + D + e - r * padw] = 0.f;
+      }
     }
-    for (int e = tid; e < ROWS * L::AS; e += 512) { lds[L::dout + e] = 0.f; lds[L::aux + e] = 0.f; lds[L::out + e] = 0.f; }
-    for (int e = tid; e < ROWS * L::MS; e += 512) lds[L::misc + e] = 0.f;
+    for (int e = tid; e < ROWS * L::AS; e += NT) { lds[L::dout + e] = 0.f; lds[L::aux + e] = 0.f; lds[L::out + e] = 0.f; }
+    for (int e = tid; e < ROWS * L::MS; e += NT) lds[L::misc + e] = 0.f;
     __syncthreads();
   };
   // With the parameters already resident in LDS the fragment reads below do not depend on this
@@ -1214,62 +1326,82 @@ __device__ __forceinline__ void mfma_minibatch(
       for (int c = 0; c < NC; ++c) out[c] = t[c];
     }
   };
+  // (Every batch of fragment / operand reads below is issued as a block, then a scheduling fence, then its consumers: in
+  //  source order "read, use, read, use" the compiler keeps that order in a kernel of this size and every use waits for its
+  //  own read -- ~100 cycles per MFMA. With the block form the waits are in-order counters behind one latency.)
+#define IA_FENCE() __builtin_amdgcn_sched_barrier(0)
   float bW1[16][NC], bW2[KS][NC], bW2o[KS][NC], bHead[KS], bDa2[4][NC], b1v[NC], b2v[NC], cwv[NC];
 #pragma unroll
   for (int s = 0; s < 16; ++s) {
-    const int kk = 4 * s + lk;
 #pragma unroll
     for (int c = 0; c < NC; ++c) bW1[s][c] = 0.f;
-    if (s < S1) {  // wave-uniform: steps beyond the observation width issue no reads
-      ldc(sPt + oW1 + min(kk, D - 1) * H, bW1[s]);
-#pragma unroll
-      for (int c = 0; c < NC; ++c) bW1[s][c] = kk < D ? bW1[s][c] : 0.f;
-    }
+    if (s < S1) ldc(sPt + oW1 + min(4 * s + lk, D - 1) * H, bW1[s]);  // wave-uniform: steps beyond the observation width issue no reads
   }
+  const int head_row = tw == 0 ? o.aW + min(li, A - 1) * H : o.cW;
+  const bool head_on = tw == 0 ? li < A : li == 0;
 #pragma unroll
   for (int s = 0; s < KS; ++s) {
     const int kk = 4 * s + lk;
     ldc(sPt + oW2 + kk * H, bW2[s]);   // W2^T[k][j]
-    bHead[s] = tw == 0 ? (li < A ? sP[o.aW + li * H + kk] : 0.f) : (li == 0 ? sP[o.cW + kk] : 0.f);
+    bHead[s] = sPB[head_row + kk];
   }
+  IA_FENCE();
+#pragma unroll
+  for (int s = 0; s < 16; ++s)
+    if (s < S1) {
+#pragma unroll
+      for (int c = 0; c < NC; ++c) bW1[s][c] = 4 * s + lk < D ? bW1[s][c] : 0.f;
+    }
+#pragma unroll
+  for (int s = 0; s < KS; ++s) bHead[s] = head_on ? bHead[s] : 0.f;
   // fragments of the backward phases: H = 32 takes them here (LDS reads, resident all along); H = 64 requests them
   // from L2 after the forward chain, when the forward fragments' registers are free again
   auto load_backward_fragments = [&]() {
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
       const int kk = 4 * s + lk;
-      ldc(sP + oW2 + kk * H, bW2o[s]);   // W2[j=k][k'] (row j contiguous)
+      ldc(sPA + oW2 + kk * H, bW2o[s]);   // W2[j=k][k'] (row j contiguous)
     }
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
       const int aa = 4 * s + lk;
-      ldc(sP + o.aW + min(aa, A - 1) * H, bDa2[s]);
 #pragma unroll
-      for (int c = 0; c < NC; ++c) bDa2[s][c] = (tw == 0 && aa < A) ? bDa2[s][c] : 0.f;
+      for (int c = 0; c < NC; ++c) bDa2[s][c] = 0.f;
+      if (!SPLIT || tw == 0) ldc(sPB + o.aW + min(aa, A - 1) * H, bDa2[s]);   // (SPLIT: the value tower holds no aW)
     }
+    IA_FENCE();
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int c = 0; c < NC; ++c) bDa2[s][c] = (tw == 0 && 4 * s + lk < A) ? bDa2[s][c] : 0.f;
   };
   if (H == 32) load_backward_fragments();
-  ldc(sP + ob1, b1v);
-  ldc(sP + ob2, b2v);
-  ldc(sP + o.cW, cwv);
-  const float head_bias = tw == 0 ? (li < A ? sP[o.ab + li] : 0.f) : sP[o.cb];
+  ldc(sPA + ob1, b1v);
+  ldc(sPA + ob2, b2v);
+#pragma unroll
+  for (int c = 0; c < NC; ++c) cwv[c] = 0.f;
+  if (!SPLIT || tw == 1) ldc(sPB + o.cW, cwv);   // (used by the value tower only)
+  const float head_bias = tw == 0 ? (li < A ? sPB[o.ab + li] : 0.f) : sPB[o.cb];
   // per-action Gaussian constants (wave-uniform): sd = exp(log_std), var = sd^2, log sd
   float c_var[MAXA], c_logsd[MAXA];
+  const bool need_sd = pol_wave && !d.discrete;   // only the loss wave needs them
+#pragma unroll
+  for (int a = 0; a < MAXA; ++a) c_logsd[a] = (need_sd && a < A) ? sPA[o.log_std + a] : 0.f;
+  IA_FENCE();
 #pragma unroll
   for (int a = 0; a < MAXA; ++a) {
     c_var[a] = 1.f;
-    c_logsd[a] = 0.f;
-    if (wv == 0 && !d.discrete && a < A) {  // only the loss wave needs them
-      const float sd = expf(sP[o.log_std + a]);
+    if (need_sd && a < A) {
+      const float sd = expf(c_logsd[a]);
       c_var[a] = sd * sd;
       c_logsd[a] = logf(sd);
     }
   }
 
   if (!LOAD_PARAMS) stage_rows();
-  float* a1t = lds + L::a1 + tw * ROWS * L::HS;
-  float* a2t = lds + L::a2 + tw * ROWS * L::HS;
-  float* dzt = lds + L::dz + tw * ROWS * L::HS;
+  float* a1t = lds + L::a1 + (SPLIT ? 0 : tw) * ROWS * L::HS;
+  float* a2t = lds + L::a2 + (SPLIT ? 0 : tw) * ROWS * L::HS;
+  float* dzt = lds + L::dz + (SPLIT ? 0 : tw) * ROWS * L::HS;
   const int arow = q * 16 + li;  // row whose A fragment this lane feeds
   IA_TS(1);
   // ---- phase 1: a1 = tanh(x W1^T + b1)
@@ -1277,12 +1409,15 @@ __device__ __forceinline__ void mfma_minibatch(
     f32x4 acc[NC];
 #pragma unroll
     for (int c = 0; c < NC; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float av[16];
+#pragma unroll
+    for (int s = 0; s < 16; ++s) av[s] = s < S1 ? lds[L::x + arow * L::XS + 4 * s + lk] : 0.f;
+    IA_FENCE();
 #pragma unroll
     for (int s = 0; s < 16; ++s)
       if (s < S1) {
-        const float a = lds[L::x + arow * L::XS + 4 * s + lk];
 #pragma unroll
-        for (int c = 0; c < NC; ++c) acc[c] = mfma16(a, bW1[s][c], acc[c]);
+        for (int c = 0; c < NC; ++c) acc[c] = mfma16(av[s], bW1[s][c], acc[c]);
       }
 #pragma unroll
     for (int c = 0; c < NC; ++c)
@@ -1296,12 +1431,14 @@ __device__ __forceinline__ void mfma_minibatch(
     f32x4 acc[NC];
 #pragma unroll
     for (int c = 0; c < NC; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float av[KS];
 #pragma unroll
-    for (int s = 0; s < KS; ++s) {
-      const float a = a1t[arow * L::HS + 4 * s + lk];
+    for (int s = 0; s < KS; ++s) av[s] = a1t[arow * L::HS + 4 * s + lk];
+    IA_FENCE();
 #pragma unroll
-      for (int c = 0; c < NC; ++c) acc[c] = mfma16(a, bW2[s][c], acc[c]);
-    }
+    for (int s = 0; s < KS; ++s)
+#pragma unroll
+      for (int c = 0; c < NC; ++c) acc[c] = mfma16(av[s], bW2[s][c], acc[c]);
 #pragma unroll
     for (int c = 0; c < NC; ++c)
 #pragma unroll
@@ -1312,8 +1449,12 @@ __device__ __forceinline__ void mfma_minibatch(
   // ---- phase 3: heads (policy: action_net -> out[row][a]; value: value_net -> misc[row][0])
   {
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    float av[KS];
 #pragma unroll
-    for (int s = 0; s < KS; ++s) acc = mfma16(a2t[arow * L::HS + 4 * s + lk], bHead[s], acc);
+    for (int s = 0; s < KS; ++s) av[s] = a2t[arow * L::HS + 4 * s + lk];
+    IA_FENCE();
+#pragma unroll
+    for (int s = 0; s < KS; ++s) acc = mfma16(av[s], bHead[s], acc);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int row = q * 16 + lk * 4 + r;
@@ -1325,7 +1466,7 @@ __device__ __forceinline__ void mfma_minibatch(
   __syncthreads();
   IA_TS(4);
   // ---- phase 4: per-row losses (wave 0: policy terms, wave 4: value term)
-  if (wv == 0) {
+  if (pol_wave) {
     const float* outrow = lds + L::out + lane * L::AS;
     float* doutrow = lds + L::dout + lane * L::AS;
     float* auxrow = lds + L::aux + lane * L::AS;
@@ -1386,7 +1527,7 @@ __device__ __forceinline__ void mfma_minibatch(
     mrow[3] = valid ? -entropy : 0.f;                                    // entropy_loss
     mrow[4] = valid ? (expf(log_ratio) - 1.f) - log_ratio : 0.f;         // approx_kl
     mrow[5] = valid ? (fabsf(ratio - 1.f) > clip ? 1.f : 0.f) : 0.f;     // clip_fraction
-  } else if (wv == 4) {
+  } else if (val_wave) {
     const float v = lds[L::misc + lane * L::MS + 0];
     const float verr = r_ret - v;
     lds[L::misc + lane * L::MS + 1] = valid ? vf_coef * 2.f * (v - r_ret) * invB : 0.f;
@@ -1399,96 +1540,131 @@ __device__ __forceinline__ void mfma_minibatch(
     f32x4 acc[NC];
 #pragma unroll
     for (int c = 0; c < NC; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float av[4], ae[NC][4], ua[16], ub[16];
 #pragma unroll
-    for (int s = 0; s < 4; ++s)
-      if (s < SA) {
-        const float a = lds[L::dout + arow * L::AS + 4 * s + lk];   // columns >= A are zero
-#pragma unroll
-        for (int c = 0; c < NC; ++c) acc[c] = mfma16(a, bDa2[s][c], acc[c]);
-      }
+    for (int s = 0; s < 4; ++s) av[s] = s < SA ? lds[L::dout + arow * L::AS + 4 * s + lk] : 0.f;   // columns >= A are zero
 #pragma unroll
     for (int c = 0; c < NC; ++c)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int e = (q * 16 + lk * 4 + r) * L::HS + CJ(c);
-        const float a = a2t[e];
-        dzt[e] = acc[c][r] * (1.f - a * a);
+      for (int r = 0; r < 4; ++r) ae[c][r] = a2t[(q * 16 + lk * 4 + r) * L::HS + CJ(c)];
+    if (q < NC) {
+#pragma unroll
+      for (int s = 0; s < 16; ++s) {
+        ua[s] = lds[L::dout + (4 * s + lk) * L::AS + li];
+        ub[s] = a2t[(4 * s + lk) * L::HS + q * 16 + li];
+      }
+    }
+    IA_FENCE();
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+      if (s < SA) {
+#pragma unroll
+        for (int c = 0; c < NC; ++c) acc[c] = mfma16(av[s], bDa2[s][c], acc[c]);
       }
     if (q < NC) {  // dWa[a][h] = sum_r dout[r][a] a2[r][h], tile of 16 h-columns per wave
       f32x4 g = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int s = 0; s < 16; ++s)
-        g = mfma16(lds[L::dout + (4 * s + lk) * L::AS + li], a2t[(4 * s + lk) * L::HS + q * 16 + li], g);
+      for (int s = 0; s < 16; ++s) g = mfma16(ua[s], ub[s], g);
 #pragma unroll
       for (int r = 0; r < 4; ++r)
         if (lk * 4 + r < A) slab[o.aW + (lk * 4 + r) * H + q * 16 + li] = g[r];
     }
-    if (q == 2) column_sum_store(lds + L::dout, L::AS, A, slab + o.ab, lane);
-    if (q == 3 && !d.discrete) column_sum_store(lds + L::aux, L::AS, A, slab + o.log_std, lane);
-  } else {
 #pragma unroll
     for (int c = 0; c < NC; ++c)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = q * 16 + lk * 4 + r;
-        const int e = row * L::HS + CJ(c);
-        const float a = a2t[e];
-        dzt[e] = cwv[c] * lds[L::misc + row * L::MS + 1] * (1.f - a * a);
+      for (int r = 0; r < 4; ++r) dzt[(q * 16 + lk * 4 + r) * L::HS + CJ(c)] = acc[c][r] * (1.f - ae[c][r] * ae[c][r]);
+    if (q == 2) column_sum_store_b(lds + L::dout, L::AS, A, slab + o.ab, lane);
+    if (q == 3 && !d.discrete) column_sum_store_b(lds + L::aux, L::AS, A, slab + o.log_std, lane);
+    if (SPLIT && q == 1 && lane < 4)   // this workgroup's loss statistics: misc columns 2..5 -> slots {0 pg, 2 ent, 3 kl, 4 clip}
+      statpart[lane == 0 ? 0 : lane + 1] = column_sum_b(lds + L::misc + 2 + lane, L::MS);
+  } else {
+    float ae[NC][4], dv[4], ua[16], ub[16];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) dv[r] = lds[L::misc + (q * 16 + lk * 4 + r) * L::MS + 1];
+#pragma unroll
+    for (int c = 0; c < NC; ++c)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) ae[c][r] = a2t[(q * 16 + lk * 4 + r) * L::HS + CJ(c)];
+    if (q < NC) {
+#pragma unroll
+      for (int s = 0; s < 16; ++s) {
+        ua[s] = lds[L::misc + (4 * s + lk) * L::MS + 1];
+        ub[s] = a2t[(4 * s + lk) * L::HS + q * 16 + li];
       }
+    }
+    IA_FENCE();
+#pragma unroll
+    for (int c = 0; c < NC; ++c)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        dzt[(q * 16 + lk * 4 + r) * L::HS + CJ(c)] = cwv[c] * dv[r] * (1.f - ae[c][r] * ae[c][r]);
     if (q < NC) {  // dcW[h] = sum_r dv[r] a2[r][h]  (only output row 0 is meaningful)
       f32x4 g = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int s = 0; s < 16; ++s) {
-        const float a = li == 0 ? lds[L::misc + (4 * s + lk) * L::MS + 1] : 0.f;
-        g = mfma16(a, a2t[(4 * s + lk) * L::HS + q * 16 + li], g);
-      }
+      for (int s = 0; s < 16; ++s) g = mfma16(li == 0 ? ua[s] : 0.f, ub[s], g);
       if (lk == 0) slab[o.cW + q * 16 + li] = g[0];
     }
-    if (q == 2 && lane == 0) {
-      float s = 0.f;
-      for (int r = 0; r < ROWS; ++r) s += lds[L::misc + r * L::MS + 1];
-      slab[o.cb] = s;
-    }
-    if (q == 3 && lane < 5) {  // statpart slots {0 pg, 2 ent, 3 kl, 4 clip, 1 value} <- misc columns 2..6
-      float s = 0.f;
-#pragma unroll 8
-      for (int r = 0; r < ROWS; ++r) s += lds[L::misc + r * L::MS + 2 + lane];
-      const int slot = lane == 0 ? 0 : (lane == 4 ? 1 : lane + 1);
-      statpart[slot] = s;
+    if (q == 2 && lane == 0) slab[o.cb] = column_sum_b(lds + L::misc + 1, L::MS);
+    if (q == 3 && lane < 5 && (!SPLIT || lane == 4)) {  // statpart slots {0 pg, 2 ent, 3 kl, 4 clip, 1 value} <- misc columns 2..6
+      const int slot = lane == 0 ? 0 : (lane == 4 ? 1 : lane + 1);   // (SPLIT: the policy workgroup sums its own four columns)
+      statpart[slot] = column_sum_b(lds + L::misc + 2 + lane, L::MS);
     }
   }
   __syncthreads();
   IA_TS(6);
   // ---- phase 6: dW2 (one 16x16 tile per wave), db2, and dz1 = (dz2 W2) * (1 - a1^2) -> a2 tile
   {
+    // NC x NC tiles of 16 x 16 over the tower's four waves, TWO at a time where a wave has several: their operand reads
+    // are one block and their (dependent) MFMA chains interleave
+    constexpr int NTW = NC * NC / 4, TP = NTW >= 2 ? 2 : 1;
 #pragma unroll
-    for (int t = 0; t < NC * NC / 4; ++t) {   // NC x NC tiles of 16 x 16 over the tower's four waves
-      const int ti = q + 4 * t, jt = ti / NC, kt = ti % NC;
-      f32x4 g = {0.f, 0.f, 0.f, 0.f};
+    for (int t0 = 0; t0 < NTW; t0 += TP) {
+      float ua[TP][16], ub[TP][16];
+#pragma unroll
+      for (int u = 0; u < TP; ++u) {
+        const int ti = q + 4 * (t0 + u), jt = ti / NC, kt = ti % NC;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+          ua[u][s] = dzt[(4 * s + lk) * L::HS + jt * 16 + li];
+          ub[u][s] = a1t[(4 * s + lk) * L::HS + kt * 16 + li];
+        }
+      }
+      IA_FENCE();
+      f32x4 g[TP];
+#pragma unroll
+      for (int u = 0; u < TP; ++u) g[u] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int s = 0; s < 16; ++s)
-        g = mfma16(dzt[(4 * s + lk) * L::HS + jt * 16 + li], a1t[(4 * s + lk) * L::HS + kt * 16 + li], g);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) slab[oW2 + (jt * 16 + lk * 4 + r) * H + kt * 16 + li] = g[r];
+        for (int u = 0; u < TP; ++u) g[u] = mfma16(ua[u][s], ub[u][s], g[u]);
+#pragma unroll
+      for (int u = 0; u < TP; ++u) {
+        const int ti = q + 4 * (t0 + u), jt = ti / NC, kt = ti % NC;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) slab[oW2 + (jt * 16 + lk * 4 + r) * H + kt * 16 + li] = g[u][r];
+      }
     }
     f32x4 acc[NC];
 #pragma unroll
     for (int c = 0; c < NC; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float av[KS], ae[NC][4];
 #pragma unroll
-    for (int s = 0; s < KS; ++s) {
-      const float a = dzt[arow * L::HS + 4 * s + lk];
-#pragma unroll
-      for (int c = 0; c < NC; ++c) acc[c] = mfma16(a, bW2o[s][c], acc[c]);
-    }
+    for (int s = 0; s < KS; ++s) av[s] = dzt[arow * L::HS + 4 * s + lk];
 #pragma unroll
     for (int c = 0; c < NC; ++c)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int e = (q * 16 + lk * 4 + r) * L::HS + CJ(c);
-        const float a = a1t[e];
-        a2t[e] = acc[c][r] * (1.f - a * a);   // dz1 (the a2 tile is free from here on)
-      }
-    if (q == 3) column_sum_store(dzt, L::HS, H, slab + ob2, lane);
+      for (int r = 0; r < 4; ++r) ae[c][r] = a1t[(q * 16 + lk * 4 + r) * L::HS + CJ(c)];
+    IA_FENCE();
+#pragma unroll
+    for (int s = 0; s < KS; ++s)
+#pragma unroll
+      for (int c = 0; c < NC; ++c) acc[c] = mfma16(av[s], bW2o[s][c], acc[c]);
+#pragma unroll
+    for (int c = 0; c < NC; ++c)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)   // dz1 (the a2 tile is free from here on)
+        a2t[(q * 16 + lk * 4 + r) * L::HS + CJ(c)] = acc[c][r] * (1.f - ae[c][r] * ae[c][r]);
+    if (q == 3) column_sum_store_b(dzt, L::HS, H, slab + ob2, lane);
   }
   __syncthreads();
   IA_TS(7);
@@ -1498,19 +1674,26 @@ __device__ __forceinline__ void mfma_minibatch(
     for (int ti = q; ti < NC * KT; ti += 4) {
       const int jt = ti / KT, kt = ti - jt * KT;
       f32x4 g = {0.f, 0.f, 0.f, 0.f};
+      float ua[16], ub[16];
 #pragma unroll
-      for (int s = 0; s < 16; ++s)
-        g = mfma16(a2t[(4 * s + lk) * L::HS + jt * 16 + li], lds[L::x + (4 * s + lk) * L::XS + kt * 16 + li], g);
+      for (int s = 0; s < 16; ++s) {
+        ua[s] = a2t[(4 * s + lk) * L::HS + jt * 16 + li];
+        ub[s] = lds[L::x + (4 * s + lk) * L::XS + kt * 16 + li];
+      }
+      IA_FENCE();
+#pragma unroll
+      for (int s = 0; s < 16; ++s) g = mfma16(ua[s], ub[s], g);
       const int col = kt * 16 + li;
       if (col < D)
 #pragma unroll
         for (int r = 0; r < 4; ++r) slab[oW1 + (jt * 16 + lk * 4 + r) * D + col] = g[r];
     }
-    if (q == 3) column_sum_store(a2t, L::HS, H, slab + ob1, lane);
+    if (q == 3) column_sum_store_b(a2t, L::HS, H, slab + ob1, lane);
   }
   __syncthreads();
   IA_TS(8);
 #undef IA_TS
+#undef IA_FENCE
 }
 
 
@@ -2232,11 +2415,16 @@ __device__ __forceinline__ void mfma32_minibatch_chain(
   };
   // a column sum over the 64 rows with four lanes per column (16 rows each) and a cross-lane add
   auto colsum64 = [&](const float* __restrict__ tile, int stride, int ncols, float* __restrict__ dst) {
+    // (the reads as one block, then the adds in row order: one LDS latency instead of sixteen)
     const int c = lane & 15, part = lane >> 4;
     float s = 0.f;
     if (c < ncols) {
+      float t[16];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) s += tile[(part * 16 + r) * stride + c];
+      for (int r = 0; r < 16; ++r) t[r] = tile[(part * 16 + r) * stride + c];
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s += t[r];
     }
     s += __shfl_xor(s, 16, 64);
     s += __shfl_xor(s, 32, 64);
@@ -2246,7 +2434,14 @@ __device__ __forceinline__ void mfma32_minibatch_chain(
     const int c = lane & 31, part = lane >> 5;
     float s = 0.f;
 #pragma unroll
-    for (int r = 0; r < 32; ++r) s += tile[(part * 32 + r) * stride + c];
+    for (int h = 0; h < 2; ++h) {   // (two blocks of sixteen reads: 32 staged values cost spills in the widest instantiation)
+      float t[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) t[r] = tile[(part * 32 + h * 16 + r) * stride + c];
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s += t[r];
+    }
     s += __shfl_xor(s, 32, 64);
     if (lane < 32) put(dst + lane, s);
   };
@@ -2278,8 +2473,12 @@ __device__ __forceinline__ void mfma32_minibatch_chain(
       const int c = lane & 15, part = lane >> 4;
       float sm = 0.f;
       if (c < 6) {
+        float t[16];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) sm += lds[L::misc + (part * 16 + r) * L::MS + 1 + c];
+        for (int r = 0; r < 16; ++r) t[r] = lds[L::misc + (part * 16 + r) * L::MS + 1 + c];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sm += t[r];
       }
       sm += __shfl_xor(sm, 16, 64);
       sm += __shfl_xor(sm, 32, 64);
@@ -2728,8 +2927,10 @@ __device__ __forceinline__ bool epoch_grid_sync(unsigned* ctr, unsigned target, 
   return *s_flag != 0;
 }
 
-template <int H>
-__global__ __launch_bounds__(512) void ppo_epoch_persistent_kernel(
+// SPLIT: two workgroups of four waves per row block, one per tower (mfma_minibatch<H, true, true>); the apply phases are
+// the same with 256 threads per workgroup and twice as many chunks.
+template <int H, bool SPLIT = false>
+__global__ __launch_bounds__(SPLIT ? 256 : 512) void ppo_epoch_persistent_kernel(
     ia_policy_desc d, float* __restrict__ P, float* __restrict__ Pt, float* __restrict__ m, float* __restrict__ v,
     const float* __restrict__ nm_in, const float* __restrict__ nv_in, const float* __restrict__ obs,
     const float* __restrict__ actions, const float* __restrict__ old_logp, const float* __restrict__ adv,
@@ -2750,7 +2951,9 @@ __global__ __launch_bounds__(512) void ppo_epoch_persistent_kernel(
   } while (0)
   if (dbg != nullptr && blockIdx.x == 0 && threadIdx.x == 0) tprev = wall_clock64();
   __shared__ float s_part[64];
+  constexpr int NT = SPLIT ? 256 : 512;
   const int bid = blockIdx.x, nwg = gridDim.x;
+  const int nrb = SPLIT ? nwg >> 1 : nwg;   // row blocks of a full minibatch: the workspace layout of every step
   const int D = d.obs_dim, aw = d.discrete ? 1 : d.act_dim;
   const PolOff o = pol_offsets(D, d.act_dim, H, d.discrete);
   unsigned* ctr = reinterpret_cast<unsigned*>(ws) + 4;
@@ -2764,19 +2967,23 @@ __global__ __launch_bounds__(512) void ppo_epoch_persistent_kernel(
     const long long start = (long long)mb * batch_size;
     const int b = (int)min((long long)batch_size, total_rows - start);
     const int nblk = (b + ROWS - 1) / ROWS;
-    const PpoWs w = ppo_ws(ws, nblk, o.total);
+    // (the layout of a FULL minibatch also for a short last one: the partial sums of squares of workgroups past its row
+    //  blocks must not land inside its slabs)
+    const PpoWs w = ppo_ws(ws, nrb, o.total);
     const float* sq = seq + (long long)mb * EPS_SEQ;
     // ---- A: gradient of this minibatch
-    if (bid < nblk) {
+    if ((SPLIT ? bid >> 1 : bid) < nblk) {
       const MbRows rows{obs + start * D, actions + start * aw, old_logp + start, adv + start, ret + start, nullptr, b, T,
                         n_envs};
       // (opaque zero: inlined into the step loop, the chain's loop-invariant per-lane offsets are otherwise hoisted out of
       //  it -- 278 spilled registers; 9 remain. As a real call (`noinline`) the ABI's saves cost 43.)
       int oz;
       asm volatile("s_mov_b32 %0, 0" : "=s"(oz));
-      mfma_minibatch<H, true>(d, P + oz, Pt + oz, snap ? sq + 8 : nm_in, snap ? sq + 8 + MAXD : nv_in, sq[0], sq[1], rows,
-                              bid + oz, normalize_adv, clip, ent_coef, vf_coef, w.slabs + (long long)bid * o.total,
-                              w.statpart + bid * 8, lds, nullptr, oz);
+      const int rb = SPLIT ? bid >> 1 : bid;
+      mfma_minibatch<H, true, SPLIT>(d, P + oz, Pt + oz, snap ? sq + 8 : nm_in, snap ? sq + 8 + MAXD : nv_in, sq[0], sq[1],
+                                     rows, rb + oz, normalize_adv, clip, ent_coef, vf_coef,
+                                     w.slabs + (long long)rb * o.total, w.statpart + rb * 8, lds,
+                                     dbg != nullptr ? dbg + 16 + (bid & 1) * 16 : nullptr, oz, bid & 1);
     }
     EP_TS(0);
     if (!epoch_grid_sync(ctr, (++bar) * nwg, err, &s_flag)) return;
@@ -2790,7 +2997,7 @@ __global__ __launch_bounds__(512) void ppo_epoch_persistent_kernel(
     float sqs = 0.f;
 #pragma unroll
     for (int j = 0; j < NPC; ++j) {
-      const int i = i0 + tid + j * 512;
+      const int i = i0 + tid + j * NT;
       float acc = 0.f;
       if (i < i1) {
         int sb = 0;
@@ -2807,14 +3014,15 @@ __global__ __launch_bounds__(512) void ppo_epoch_persistent_kernel(
       g[j] = acc;
     }
     {
-      const float part = block_sum<512>(sqs, lds);
-      if (tid == 0) w.statpart[bid * 8 + 5] = part;   // (slot 5 of the loss-statistic partials is unused by the gradient)
+      const float part = block_sum<NT>(sqs, lds);
+      // (slots 5 / 6 of the loss-statistic partials are unused by the gradient; SPLIT: one per tower workgroup)
+      if (tid == 0) w.statpart[SPLIT ? (bid >> 1) * 8 + 5 + (bid & 1) : bid * 8 + 5] = part;
     }
     EP_TS(2);
     if (!epoch_grid_sync(ctr, (++bar) * nwg, err, &s_flag)) return;
     EP_TS(3);
     // ---- B2: norm, clip, Adam on the own chunk; loss statistics
-    if (tid < 64) s_part[tid] = tid < nwg ? w.statpart[tid * 8 + 5] : 0.f;
+    if (tid < 64) s_part[tid] = tid < nwg ? w.statpart[SPLIT ? (tid >> 1) * 8 + 5 + (tid & 1) : tid * 8 + 5] : 0.f;
     __syncthreads();
     float total_sq = 0.f;
     for (int q = 0; q < nwg; ++q) total_sq += s_part[q];
@@ -2842,14 +3050,14 @@ __global__ __launch_bounds__(512) void ppo_epoch_persistent_kernel(
       float m_[NPC], v_[NPC], p_[NPC];
 #pragma unroll
       for (int j = 0; j < NPC; ++j) {
-        const int i = min(i0 + tid + j * 512, o.total - 1);
+        const int i = min(i0 + tid + j * NT, o.total - 1);
         m_[j] = m[i];
         v_[j] = v[i];
         p_[j] = P[i];
       }
 #pragma unroll
       for (int j = 0; j < NPC; ++j) {
-        const int i = i0 + tid + j * 512;
+        const int i = i0 + tid + j * NT;
         if (i < i1) {
           const float gi = g[j] * coef;
           const float mi = m_[j] + (gi - m_[j]) * (1.f - beta1);
@@ -3475,6 +3683,7 @@ int set_lds(K kern, size_t bytes) {
 
 bool g_ppo_valu = false;  // tuning/debug: force the VALU kernels for H = 32 as well
 bool g_epoch_split = false;  // tuning/debug: two launches per minibatch for 64-wide towers too
+bool g_epoch_whole = false;  // tuning/debug: the one-launch epoch with whole row-block workgroups (8 waves, both towers)
 long long* g_epoch_dbg = nullptr;  // measurement: phase ticks of workgroup 0 of ppo_epoch_persistent_kernel
 }  // namespace
 
@@ -3888,12 +4097,13 @@ int ia_ppo_force_valu(int on) {
 // Tuning / measurement: 1 = ia_ppo_epoch launches the gradient and apply kernels per minibatch even where the
 // one-launch-per-epoch kernel applies (64-wide towers).
 int ia_ppo_epoch_split(int on) {
-  g_epoch_split = on != 0;
+  g_epoch_split = on == 1;
+  g_epoch_whole = on == 2;
   return IA_OK;
 }
 
-int ia_ppo_epoch_debug_timing(void* device_buffer_8xi64) {
-  g_epoch_dbg = (long long*)device_buffer_8xi64;
+int ia_ppo_epoch_debug_timing(void* device_buffer_64xi64) {
+  g_epoch_dbg = (long long*)device_buffer_64xi64;
   return IA_OK;
 }
 
@@ -3962,12 +4172,26 @@ int ia_ppo_epoch(const ia_policy_desc* d, float* params, float* params_t, float*
           hipDeviceGetAttribute(&dev_cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
         return IA_ERR_ARG;
     }
-    const int nwg = cdiv(size_at(0), ROWS);
-    const int P = pol_offsets(d->obs_dim, d->act_dim, 64, d->discrete).total;
-    if (nwg <= dev_cus && nwg <= 64 && cdiv(P, nwg) <= 4 * 512) {
-      static bool attr = false;
-      const size_t mbytes = GLds<64>::total * sizeof(float);
-      if (!attr) { rc = set_lds(ppo_epoch_persistent_kernel<64>, mbytes); if (rc) return rc; attr = true; }
+    constexpr size_t EPOCH_SPLIT_LDS = 160 * 1024 - 1024;   // dynamic LDS the one-tower kernel may ask for (it has static LDS too)
+    const int nrb = cdiv(size_at(0), ROWS);
+    const PolOff po = pol_offsets(d->obs_dim, d->act_dim, 64, d->discrete);
+    const int P = po.total;
+    // one tower per workgroup (two workgroups of four waves per row block, the tower's parameters resident in LDS) when
+    // both fit: 2 nrb workgroups co-resident, chunks of <= 4 x 256 parameters, the larger tower's images beside its tiles
+    const int lenA = std::max(po.vW1, po.aW - po.vW1) + 6, lenB = std::max(po.cW - po.aW, P - po.cW) + 6;
+    const size_t sbytes = (size_t)(((GLds<64, 1>::total + 3) & ~3) + 2 * lenA + lenB) * sizeof(float);
+    const bool split = !g_epoch_whole && 2 * nrb <= dev_cus && 2 * nrb <= 64 && cdiv(P, 2 * nrb) <= 4 * 256 &&
+                       sbytes <= EPOCH_SPLIT_LDS;
+    const int nwg = split ? 2 * nrb : nrb;
+    if (nwg <= dev_cus && nwg <= 64 && cdiv(P, nwg) <= 4 * (split ? 256 : 512)) {
+      static bool attr = false, attr_s = false;
+      const size_t mbytes = split ? sbytes : GLds<64>::total * sizeof(float);
+      if (!split && !attr) { rc = set_lds(ppo_epoch_persistent_kernel<64>, mbytes); if (rc) return rc; attr = true; }
+      if (split && !attr_s) {
+        rc = set_lds(ppo_epoch_persistent_kernel<64, true>, EPOCH_SPLIT_LDS);
+        if (rc) return rc;
+        attr_s = true;
+      }
       if (hipMemsetAsync(ws + 4, 0, 2 * sizeof(unsigned), a.st) != hipSuccess) return IA_ERR_ARG;   // barrier counter, error word
       for (int first = 0; first < n_mb; first += EpochSteps::MAX) {
         EpochSteps es{};
@@ -3979,10 +4203,16 @@ int ia_ppo_epoch(const ia_policy_desc* d, float* params, float* params_t, float*
           es.bc2_sqrt[k] = (float)sqrt(1.0 - pow(beta2, (double)step));
         }
         if (first > 0 && hipMemsetAsync(ws + 4, 0, sizeof(unsigned), a.st) != hipSuccess) return IA_ERR_ARG;
-        hipLaunchKernelGGL(ppo_epoch_persistent_kernel<64>, dim3(nwg), dim3(512), mbytes, a.st, *d, params, params_t,
-                           exp_avg, exp_avg_sq, norm_mean, norm_var, g.obs, g.act, g.logp, g.adv, g.ret, total, batch_size,
-                           T, n_envs, normalize_adv, clip_range, ent_coef, vf_coef, max_grad_norm, (float)beta1,
-                           (float)beta2, adam_eps, ws, seq, snap ? 1 : 0, stats, es, g_epoch_dbg);
+        if (split)
+          hipLaunchKernelGGL((ppo_epoch_persistent_kernel<64, true>), dim3(nwg), dim3(256), mbytes, a.st, *d, params,
+                             params_t, exp_avg, exp_avg_sq, norm_mean, norm_var, g.obs, g.act, g.logp, g.adv, g.ret, total,
+                             batch_size, T, n_envs, normalize_adv, clip_range, ent_coef, vf_coef, max_grad_norm,
+                             (float)beta1, (float)beta2, adam_eps, ws, seq, snap ? 1 : 0, stats, es, g_epoch_dbg);
+        else
+          hipLaunchKernelGGL(ppo_epoch_persistent_kernel<64>, dim3(nwg), dim3(512), mbytes, a.st, *d, params, params_t,
+                             exp_avg, exp_avg_sq, norm_mean, norm_var, g.obs, g.act, g.logp, g.adv, g.ret, total, batch_size,
+                             T, n_envs, normalize_adv, clip_range, ent_coef, vf_coef, max_grad_norm, (float)beta1,
+                             (float)beta2, adam_eps, ws, seq, snap ? 1 : 0, stats, es, g_epoch_dbg);
         IA_CHECK_LAUNCH();
       }
       return IA_OK;

@@ -432,11 +432,14 @@ int ia_ppo_debug_timing(void* device_buffer_16xi64);
  * hidden = 32 instead of the MFMA 16x16x4 ones (hidden = 64 always uses the VALU kernels). */
 int ia_ppo_force_valu(int on);
 /* Tuning / measurement: 1 = `ia_ppo_epoch` keeps two launches per minibatch for 64-wide towers (default 0: one launch
- * per epoch, the minibatch steps as phases of a co-resident grid separated by grid barriers). */
+ * per epoch, the minibatch steps as phases of a co-resident grid separated by grid barriers; a row block's two towers
+ * are two four-wave workgroups with the tower's parameters resident in LDS when that fits); 2 = one launch per epoch
+ * with whole row-block workgroups (eight waves, both towers, weight fragments from memory: the form before). */
 int ia_ppo_epoch_split(int on);
-/* Measurement only: device buffer of 8 int64 (NULL: off); workgroup 0 of the one-launch-per-epoch kernel accumulates
- * 100 MHz ticks per phase in [0..5] = {gradient, barrier, slab sum, barrier, norm + Adam, barrier}. */
-int ia_ppo_epoch_debug_timing(void* device_buffer_8xi64);
+/* Measurement only: device buffer of 64 int64 (NULL: off); workgroup 0 of the one-launch-per-epoch kernel accumulates
+ * 100 MHz ticks per phase in [0..5] = {gradient, barrier, slab sum, barrier, norm + Adam, barrier}; [16..27] / [32..43]:
+ * shader-clock stamps inside the last step's gradient phase (row block 0; policy / value tower workgroup). */
+int ia_ppo_epoch_debug_timing(void* device_buffer_64xi64);
 int ia_ppo_minibatch_apply(const ia_policy_desc* d, float* params, float* params_t, int batch, float ent_coef,
                            float vf_coef, float max_grad_norm, float* exp_avg, float* exp_avg_sq, float beta1,
                            float beta2, float adam_eps, float step_size, float bc2_sqrt, float* ws, float* stats,

@@ -14,7 +14,7 @@ th.set_num_threads(1)
 tr, per = bench.build_variant(name)
 tr.train(3 * per)
 th.cuda.synchronize()
-buf = th.zeros(8, dtype=th.int64, device="cuda")
+buf = th.zeros(64, dtype=th.int64, device="cuda")
 L.load().ia_ppo_epoch_debug_timing(buf.data_ptr())
 rounds = 4
 tr.train(rounds * per)
@@ -26,3 +26,15 @@ t = buf.cpu().numpy()[:6] / 100.0 / steps
 names = ("gradient", "barrier", "slab sum + partial norm", "barrier", "norm + Adam + statistics", "barrier")
 print(f"{name}: per optimiser step (workgroup 0): " + ", ".join(f"{n} {v:.2f} us" for n, v in zip(names, t)) +
       f"; sum {t.sum():.2f} us")
+
+# shader-clock stamps of the LAST step's gradient phase (row block 0; [16..] policy-tower workgroup, [32..] value-tower
+# workgroup of the one-tower form; the whole-block form writes [16..] only)
+order = (0, 9, 10, 11, 1, 2, 3, 4, 5, 6, 7, 8)
+labels = ("row loads issued", "parameter copy issued", "rows staged (+ barrier)", "fragments", "layer 1", "layer 2", "heads",
+          "loss", "head gradients / dz2", "dW2 / dz1", "dW1")
+full = buf.cpu().numpy()
+for base, who in ((16, "tower 0 / whole block"), (32, "tower 1")):
+    st = [int(full[base + i]) for i in order]
+    if st[0] == 0:
+        continue
+    print(f"  {who}: " + ", ".join(f"{n} {st[i + 1] - st[i]}" for i, n in enumerate(labels)) + f"; total {st[-1] - st[0]} cycles")
