@@ -778,6 +778,12 @@ __device__ __forceinline__ void column_sum_store(const float* tile, int stride, 
   }
 }
 
+// Gradient-slab store of the persistent kernel: write-through (system-scope relaxed store = global_store sc0 sc1), so
+// the agent-scope release fence before the grid barrier finds no dirty L2 lines of the slab left to write back.
+__device__ __forceinline__ void slab_store(float* p, float v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // The same sums (rows added in order 0 .. ROWS-1) with the reads issued sixteen at a time.
 __device__ __forceinline__ float column_sum_b(const float* col, int stride) {
   float s = 0.f;
@@ -1137,8 +1143,6 @@ __device__ __forceinline__ void mfma_minibatch(
   const int tid = threadIdx.x + oz, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int tw = SPLIT ? tower : wv >> 2, q = SPLIT ? wv : wv & 3;
-  const bool pol_wave = SPLIT ? (tower == 0 && wv == 0) : wv == 0;   // the wave with the per-row policy loss terms
-  const bool val_wave = SPLIT ? (tower == 1 && wv == 0) : wv == 4;   // ... the value loss term
   const int li = lane & 15, lk = lane >> 4;
   const int D = d.obs_dim, A = d.act_dim;
   const PolOff o = pol_offsets(D, A, H, d.discrete);
@@ -1188,21 +1192,26 @@ __device__ __forceinline__ void mfma_minibatch(
       xs_[it] = (ok && d.has_norm) ? xs_[it] : 1.f - d.norm_eps;
     }
   }
-  // per-row scalars of the loss phase (wave 0: policy terms, wave 4: value term)
-  const int i = i0 + lane;
+  // per-row scalars of the loss phase: every wave takes the loss terms of ITS 16 rows (the rows whose head outputs it
+  // wrote) -- policy waves with four lanes per row (lane = 4 * row + part, actions part, part + 4, ...: the action loops are
+  // MAXA / 4 trips and the row sums two cross-lane adds), value waves with lanes 0 .. 15 (the form of the H = 32 chain)
+  const int lrow = tw == 0 ? q * 16 + (lane >> 2) : q * 16 + (lane & 15);
+  const int part = lane & 3;
+  const bool loss_lane = tw == 0 || lane < 16;
+  const int i = i0 + lrow;
   const bool valid = i < batch;
-  const long long src = valid ? mb_row(idx, i, T, n_envs) : 0;
-  float r_oldlp = 0.f, r_adv = 0.f, r_ret = 0.f, r_act[MAXA];
-#pragma unroll
-  for (int a = 0; a < MAXA; ++a) r_act[a] = 0.f;
-  if (pol_wave) {
+  const long long src = mb_row(idx, min(i, batch - 1), T, n_envs);
+  float r_oldlp = 0.f, r_adv = 0.f, r_ret = 0.f, r_act[4];
+  if (tw == 0) {   // (wave-uniform; consumed in phase 4: the latency hides behind phases 1-3)
     r_oldlp = old_logp[src];
     r_adv = adv[src];
 #pragma unroll
-    for (int a = 0; a < MAXA; ++a)
-      if (a < aw) r_act[a] = actions[src * aw + a];  // consumed in phase 4: the latency hides behind phases 1-3
+    for (int j = 0; j < 4; ++j) r_act[j] = actions[src * aw + min(part + 4 * j, aw - 1)];
+  } else {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) r_act[j] = 0.f;
+    r_ret = ret[src];
   }
-  if (val_wave) r_ret = ret[src];
 
   IA_TS(9);
   // ---- parameters: ONE cooperative, coalesced 16-byte copy of both flat vectors (torch layout P and
@@ -1211,58 +1220,72 @@ __device__ __forceinline__ void mfma_minibatch(
   // L2-resident flat vectors)
   const float* sP = H == 32 ? lds + L::total : P;
   const float* sPt = H == 32 ? sP + ((o.total + 3) & ~3) : Pt;
-  // SPLIT: images of the tower's two pieces of the flat vector -- A = its layers (policy: log_std, pW1 .. pb2; value:
-  // vW1 .. vb2), B = its head (aW, ab | cW, cb) -- in torch layout, and piece A of the transposed copy; each from the
-  // 4-float boundary below its first element, so that the copies are 16-byte pieces. sPA / sPB / sPt are biased so that
-  // the flat offsets of PolOff address them.
-  const float* sPA = sP;   // reads of the tower's layers / of its head (the same vector unless SPLIT)
+  // SPLIT: LDS images of what the tower reads -- A = its layers W1 b1 W2 b2 in torch layout, T = the same piece of the
+  // transposed copy, B = its head (aW, ab | cW, cb), C = log_std -- each image starting AT the piece's first element, so
+  // that every fragment row is 16-byte aligned in LDS (the pieces' sizes are multiples of H) and a lane's four values of
+  // a weight row are one ds_read_b128 (from the flat vector's own alignment they were four conflicted ds_read_b32). The
+  // global side of the copy reads 16 bytes at 4-byte alignment. sPA / sPt / sPB / sLS are biased so that the flat offsets
+  // of PolOff address the images. The loads are issued here, the LDS stores come behind the row staging below: the
+  // staging arithmetic runs while the parameters are on their way.
+  const float* sPA = sP;   // reads of the tower's layers / of its head / of log_std (the same vector unless SPLIT)
   const float* sPB = sP;
+  const float* sLS = sP;
+  typedef float f32x4_u __attribute__((ext_vector_type(4), aligned(4)));
+  constexpr int NA = SPLIT ? (H * MAXD + H + H * H + H + 4 * NT - 1) / (4 * NT) : 1;   // 16-byte pieces per thread, images A / T
+  constexpr int NB = SPLIT ? (MAXA * H + MAXA + 4 + 4 * NT - 1) / (4 * NT) : 1;        // ... image B
+  float4 va[NA], vb[NB], vt[NA];
+  float lsv = 0.f;
+  const int tlen = H * D + H + H * H + H, t0 = tower ? o.vW1 : o.pW1;
+  const int segB0 = tower ? o.cW : o.aW, lenB = ((tower ? o.total : o.cW) - segB0 + 3) & ~3;
+  float* imgA = lds + ((L::total + 3) & ~3);
+  float* imgT = imgA + tlen;
+  float* imgB = imgT + tlen;
+  float* imgC = imgB + lenB;
   if constexpr (SPLIT) {
-    const int segA0 = tower ? o.vW1 : 0, segA1 = tower ? o.aW : o.vW1;
-    const int segB0 = tower ? o.cW : o.aW, segB1 = tower ? o.total : o.cW;
-    const int a0 = segA0 & ~3, lenA = ((segA1 + 3) & ~3) - a0;
-    const int b0 = segB0 & ~3, lenB = ((segB1 + 3) & ~3) - b0;
-    float* img = lds + ((L::total + 3) & ~3);
-    // all loads of the three pieces first (one round trip), then the LDS stores; a 16-byte piece that would run past the
-    // end of the flat vector (the last one of the value head at most) is read element by element
+    // (a 16-byte piece that would run past the end of the flat vector -- the last one of the value head at most -- is read
+    //  element by element)
     auto load_piece = [&](const float* __restrict__ srcv, int f0, int len4, int i) {
       const int e = tid + i * NT, f = f0 + 4 * e;
       float4 v4 = make_float4(0.f, 0.f, 0.f, 0.f);
       if (e < len4) {
         if (f + 3 < o.total) {
-          v4 = *reinterpret_cast<const float4*>(srcv + f);
+          const f32x4_u t = *reinterpret_cast<const f32x4_u*>(srcv + f);
+          v4 = make_float4(t[0], t[1], t[2], t[3]);
         } else {
-          float t0[4];
+          float t0_[4];
 #pragma unroll
-          for (int u = 0; u < 4; ++u) t0[u] = srcv[min(f + u, o.total - 1)];
-          v4 = make_float4(t0[0], t0[1], t0[2], t0[3]);
+          for (int u = 0; u < 4; ++u) t0_[u] = srcv[min(f + u, o.total - 1)];
+          v4 = make_float4(t0_[0], t0_[1], t0_[2], t0_[3]);
         }
       }
       return v4;
     };
-    constexpr int NA = (H * MAXD + H + H * H + H + MAXA + 8 + 4 * NT - 1) / (4 * NT);   // 16-byte pieces per thread, piece A
-    constexpr int NB = (MAXA * H + MAXA + 8 + 4 * NT - 1) / (4 * NT);                   // ... piece B
-    float4 va[NA], vb[NB], vt[NA];
 #pragma unroll
-    for (int i = 0; i < NA; ++i) va[i] = load_piece(P, a0, lenA >> 2, i);
+    for (int i = 0; i < NA; ++i) va[i] = load_piece(P, t0, tlen >> 2, i);
 #pragma unroll
-    for (int i = 0; i < NB; ++i) vb[i] = load_piece(P, b0, lenB >> 2, i);
+    for (int i = 0; i < NB; ++i) vb[i] = load_piece(P, segB0, lenB >> 2, i);
 #pragma unroll
-    for (int i = 0; i < NA; ++i) vt[i] = load_piece(Pt, a0, lenA >> 2, i);
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int i = 0; i < NA; ++i)
-      if (tid + i * NT < (lenA >> 2)) {
-        reinterpret_cast<float4*>(img)[tid + i * NT] = va[i];
-        reinterpret_cast<float4*>(img + lenA + lenB)[tid + i * NT] = vt[i];
-      }
-#pragma unroll
-    for (int i = 0; i < NB; ++i)
-      if (tid + i * NT < (lenB >> 2)) reinterpret_cast<float4*>(img + lenA)[tid + i * NT] = vb[i];
-    sPA = img - a0;
-    sPB = img + lenA - b0;
-    sPt = img + lenA + lenB - a0;
+    for (int i = 0; i < NA; ++i) vt[i] = load_piece(Pt, t0, tlen >> 2, i);
+    lsv = P[d.discrete ? 0 : o.log_std + min(tid, A - 1)];
+    sPA = imgA - t0;
+    sPt = imgT - t0;
+    sPB = imgB - segB0;
+    sLS = imgC - (d.discrete ? 0 : o.log_std);
   }
+  auto store_images = [&]() {
+    if constexpr (SPLIT) {
+#pragma unroll
+      for (int i = 0; i < NA; ++i)
+        if (tid + i * NT < (tlen >> 2)) {
+          reinterpret_cast<float4*>(imgA)[tid + i * NT] = va[i];
+          reinterpret_cast<float4*>(imgT)[tid + i * NT] = vt[i];
+        }
+#pragma unroll
+      for (int i = 0; i < NB; ++i)
+        if (tid + i * NT < (lenB >> 2)) reinterpret_cast<float4*>(imgB)[tid + i * NT] = vb[i];
+      if (tid < MAXA) imgC[tid] = lsv;
+    }
+  };
   if (LOAD_PARAMS && H == 32) {
     float* wP = lds + L::total;
     float* wPt = wP + ((o.total + 3) & ~3);
@@ -1304,6 +1327,7 @@ __device__ __forceinline__ void mfma_minibatch(
     }
     for (int e = tid; e < ROWS * L::AS; e += NT) { lds[L::dout + e] = 0.f; lds[L::aux + e] = 0.f; lds[L::out + e] = 0.f; }
     for (int e = tid; e < ROWS * L::MS; e += NT) lds[L::misc + e] = 0.f;
+    store_images();   // (SPLIT: the parameter images, whose loads were issued ahead of this staging)
     __syncthreads();
   };
   // With the parameters already resident in LDS the fragment reads below do not depend on this
@@ -1315,7 +1339,6 @@ __device__ __forceinline__ void mfma_minibatch(
   // tile c is columns li*NC + c, so the NC values a lane needs from one weight row are 16 contiguous bytes -- one
   // global_load_dwordx4 instead of four scalar loads (144 -> 40 load instructions per wave; the fragments come from L2)
   auto CJ = [&](int c) { return H == 32 ? c * 16 + li : li * NC + c; };
-  typedef float f32x4_u __attribute__((ext_vector_type(4), aligned(4)));
   auto ldc = [&](const float* __restrict__ rowbase, float (&out)[NC]) {
     if constexpr (H == 32) {
 #pragma unroll
@@ -1330,6 +1353,12 @@ __device__ __forceinline__ void mfma_minibatch(
   //  source order "read, use, read, use" the compiler keeps that order in a kernel of this size and every use waits for its
   //  own read -- ~100 cycles per MFMA. With the block form the waits are in-order counters behind one latency.)
 #define IA_FENCE() __builtin_amdgcn_sched_barrier(0)
+  // slab / statistics stores: write-through in the one-tower form (the grid barrier's release fence then finds no dirty
+  // lines of the 44 KB slab to write back, as in the H = 32 persistent kernel), plain stores otherwise
+  auto sst = [&](float* __restrict__ p_, float v_) {
+    if constexpr (SPLIT) slab_store(p_, v_);
+    else *p_ = v_;
+  };
   float bW1[16][NC], bW2[KS][NC], bW2o[KS][NC], bHead[KS], bDa2[4][NC], b1v[NC], b2v[NC], cwv[NC];
 #pragma unroll
   for (int s = 0; s < 16; ++s) {
@@ -1383,18 +1412,19 @@ __device__ __forceinline__ void mfma_minibatch(
   if (!SPLIT || tw == 1) ldc(sPB + o.cW, cwv);   // (used by the value tower only)
   const float head_bias = tw == 0 ? (li < A ? sPB[o.ab + li] : 0.f) : sPB[o.cb];
   // per-action Gaussian constants (wave-uniform): sd = exp(log_std), var = sd^2, log sd
-  float c_var[MAXA], c_logsd[MAXA];
-  const bool need_sd = pol_wave && !d.discrete;   // only the loss wave needs them
+  // per-action Gaussian constants of the lane's actions (policy waves): 1 / sd^2, log sd with sd = exp(log_std)
+  float c_ivar[4], c_logsd[4];
+  const bool need_sd = tw == 0 && !d.discrete;
 #pragma unroll
-  for (int a = 0; a < MAXA; ++a) c_logsd[a] = (need_sd && a < A) ? sPA[o.log_std + a] : 0.f;
+  for (int j = 0; j < 4; ++j) c_logsd[j] = need_sd ? sLS[o.log_std + min(part + 4 * j, A - 1)] : 0.f;
   IA_FENCE();
 #pragma unroll
-  for (int a = 0; a < MAXA; ++a) {
-    c_var[a] = 1.f;
-    if (need_sd && a < A) {
-      const float sd = expf(c_logsd[a]);
-      c_var[a] = sd * sd;
-      c_logsd[a] = logf(sd);
+  for (int j = 0; j < 4; ++j) {
+    c_ivar[j] = 1.f;
+    if (need_sd) {
+      const float sd = expf(c_logsd[j]);
+      c_ivar[j] = 1.f / (sd * sd);
+      c_logsd[j] = logf(sd);
     }
   }
 
@@ -1465,73 +1495,99 @@ __device__ __forceinline__ void mfma_minibatch(
   if (H != 32) load_backward_fragments();   // (in flight during the loss phase)
   __syncthreads();
   IA_TS(4);
-  // ---- phase 4: per-row losses (wave 0: policy terms, wave 4: value term)
-  if (pol_wave) {
-    const float* outrow = lds + L::out + lane * L::AS;
-    float* doutrow = lds + L::dout + lane * L::AS;
-    float* auxrow = lds + L::aux + lane * L::AS;
-    float logp = 0.f, entropy = 0.f, lse = 0.f;
-    int act_i = 0;
-    if (!d.discrete) {
+  // ---- phase 4: per-row losses of the wave's 16 rows (see the loads above)
+  if (loss_lane) {
+    if (tw == 0) {
+      const float* outrow = lds + L::out + lrow * L::AS;
+      float* doutrow = lds + L::dout + lrow * L::AS;
+      float* auxrow = lds + L::aux + lrow * L::AS;
+      float logp = 0.f, entropy = 0.f, lse = 0.f;
+      int act_i = 0;
+      float o_[4];   // the head outputs of this lane's actions, read in one block (columns >= A hold zeros)
 #pragma unroll
-      for (int a = 0; a < MAXA; ++a)
-        if (a < A) {
-          const float diff = r_act[a] - outrow[a];
-          logp += -(diff * diff) / (2.f * c_var[a]) - c_logsd[a] - LOG_SQRT_2PI;
-          entropy += 0.5f + LOG_SQRT_2PI + c_logsd[a];
-        }
-    } else {
-      float mx = outrow[0];
-      for (int a = 1; a < A; ++a) mx = fmaxf(mx, outrow[a]);
-      float se = 0.f;
-      for (int a = 0; a < A; ++a) se += expf(outrow[a] - mx);
-      lse = mx + logf(se);
-      act_i = (int)r_act[0];
-      logp = outrow[act_i] - lse;
-      for (int a = 0; a < A; ++a) {
-        const float l = outrow[a] - lse;
-        entropy -= expf(l) * l;
-      }
-    }
-    float advn = r_adv;
-    if (normalize_adv && batch > 1) advn = (advn - adv_mean) / (adv_std + 1e-8f);
-    const float log_ratio = logp - r_oldlp;
-    const float ratio = expf(log_ratio);
-    const float lo = 1.f - clip, hi = 1.f + clip;
-    const float pl1 = advn * ratio;
-    const float pl2 = advn * fminf(fmaxf(ratio, lo), hi);
-    const float g1 = pl1 < pl2 ? 1.f : (pl1 == pl2 ? 0.5f : 0.f);
-    const float g2 = pl2 < pl1 ? 1.f : (pl1 == pl2 ? 0.5f : 0.f);
-    const float inrange = (ratio >= lo && ratio <= hi) ? 1.f : 0.f;
-    const float dlogp = valid ? -invB * advn * (g1 + g2 * inrange) * ratio : 0.f;
-    if (!d.discrete) {
+      for (int j = 0; j < 4; ++j) o_[j] = outrow[part + 4 * j];
+      if (d.discrete) act_i = (int)r_act[0];
+      const float o_act = outrow[act_i];
+      IA_FENCE();
+      auto quad_sum = [](float v) {
+        v += __shfl_xor(v, 1, 64);
+        v += __shfl_xor(v, 2, 64);
+        return v;
+      };
+      if (!d.discrete) {
 #pragma unroll
-      for (int a = 0; a < MAXA; ++a)
-        if (a < A) {
-          const float diff = r_act[a] - outrow[a];
-          doutrow[a] = dlogp * diff / c_var[a];
-          auxrow[a] = valid ? dlogp * (diff * diff / c_var[a] - 1.f) - ent_coef * invB : 0.f;
-        }
-    } else {
-      for (int a = 0; a < A; ++a) {
-        const float l = outrow[a] - lse, p = expf(l);
-        const float dH = -p * (l + entropy);
-        float g = dlogp * ((a == act_i ? 1.f : 0.f) - p);
-        g += valid ? -ent_coef * invB * dH : 0.f;
-        doutrow[a] = g;
+        for (int j = 0; j < 4; ++j)
+          if (part + 4 * j < A) {
+            const float diff = r_act[j] - o_[j];
+            logp += -(diff * diff) * (0.5f * c_ivar[j]) - c_logsd[j] - LOG_SQRT_2PI;
+            entropy += 0.5f + LOG_SQRT_2PI + c_logsd[j];
+          }
+        logp = quad_sum(logp);
+        entropy = quad_sum(entropy);
+      } else {
+        float mx = -3.0e38f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (part + 4 * j < A) mx = fmaxf(mx, o_[j]);
+        mx = fmaxf(mx, __shfl_xor(mx, 1, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 2, 64));
+        float se = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (part + 4 * j < A) se += expf(o_[j] - mx);
+        lse = mx + logf(quad_sum(se));
+        logp = o_act - lse;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (part + 4 * j < A) {
+            const float l = o_[j] - lse;
+            entropy -= expf(l) * l;
+          }
+        entropy = quad_sum(entropy);
       }
+      float advn = r_adv;
+      if (normalize_adv && batch > 1) advn = (advn - adv_mean) / (adv_std + 1e-8f);
+      const float log_ratio = logp - r_oldlp;
+      const float ratio = expf(log_ratio);
+      const float lo = 1.f - clip, hi = 1.f + clip;
+      const float pl1 = advn * ratio;
+      const float pl2 = advn * fminf(fmaxf(ratio, lo), hi);
+      const float g1 = pl1 < pl2 ? 1.f : (pl1 == pl2 ? 0.5f : 0.f);
+      const float g2 = pl2 < pl1 ? 1.f : (pl1 == pl2 ? 0.5f : 0.f);
+      const float inrange = (ratio >= lo && ratio <= hi) ? 1.f : 0.f;
+      const float dlogp = valid ? -invB * advn * (g1 + g2 * inrange) * ratio : 0.f;
+      if (!d.discrete) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (part + 4 * j < A) {
+            const float diff = r_act[j] - o_[j];
+            doutrow[part + 4 * j] = dlogp * diff * c_ivar[j];
+            auxrow[part + 4 * j] = valid ? dlogp * (diff * diff * c_ivar[j] - 1.f) - ent_coef * invB : 0.f;
+          }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (part + 4 * j < A) {
+            const float l = o_[j] - lse, p = expf(l);
+            const float dH = -p * (l + entropy);
+            float g = dlogp * ((part + 4 * j == act_i ? 1.f : 0.f) - p);
+            g += valid ? -ent_coef * invB * dH : 0.f;
+            doutrow[part + 4 * j] = g;
+          }
+      }
+      if (part == 0) {   // loss statistics: staged per row in the misc tile, summed in phase 5
+        float* mrow = lds + L::misc + lrow * L::MS;
+        mrow[2] = valid ? -fminf(pl1, pl2) : 0.f;                           // policy_gradient_loss
+        mrow[3] = valid ? -entropy : 0.f;                                    // entropy_loss
+        mrow[4] = valid ? (ratio - 1.f) - log_ratio : 0.f;                   // approx_kl
+        mrow[5] = valid ? (fabsf(ratio - 1.f) > clip ? 1.f : 0.f) : 0.f;     // clip_fraction
+      }
+    } else {
+      const float v = lds[L::misc + lrow * L::MS + 0];
+      const float verr = r_ret - v;
+      lds[L::misc + lrow * L::MS + 1] = valid ? vf_coef * 2.f * (v - r_ret) * invB : 0.f;
+      lds[L::misc + lrow * L::MS + 6] = valid ? verr * verr : 0.f;        // value_loss
     }
-    // loss statistics: staged per row in the misc tile, summed by an idle wave in phase 5
-    float* mrow = lds + L::misc + lane * L::MS;
-    mrow[2] = valid ? -fminf(pl1, pl2) : 0.f;                           // policy_gradient_loss
-    mrow[3] = valid ? -entropy : 0.f;                                    // entropy_loss
-    mrow[4] = valid ? (expf(log_ratio) - 1.f) - log_ratio : 0.f;         // approx_kl
-    mrow[5] = valid ? (fabsf(ratio - 1.f) > clip ? 1.f : 0.f) : 0.f;     // clip_fraction
-  } else if (val_wave) {
-    const float v = lds[L::misc + lane * L::MS + 0];
-    const float verr = r_ret - v;
-    lds[L::misc + lane * L::MS + 1] = valid ? vf_coef * 2.f * (v - r_ret) * invB : 0.f;
-    lds[L::misc + lane * L::MS + 6] = valid ? verr * verr : 0.f;        // value_loss
   }
   __syncthreads();
   IA_TS(5);
@@ -1567,16 +1623,16 @@ __device__ __forceinline__ void mfma_minibatch(
       for (int s = 0; s < 16; ++s) g = mfma16(ua[s], ub[s], g);
 #pragma unroll
       for (int r = 0; r < 4; ++r)
-        if (lk * 4 + r < A) slab[o.aW + (lk * 4 + r) * H + q * 16 + li] = g[r];
+        if (lk * 4 + r < A) sst(slab + o.aW + (lk * 4 + r) * H + q * 16 + li, g[r]);
     }
 #pragma unroll
     for (int c = 0; c < NC; ++c)
 #pragma unroll
       for (int r = 0; r < 4; ++r) dzt[(q * 16 + lk * 4 + r) * L::HS + CJ(c)] = acc[c][r] * (1.f - ae[c][r] * ae[c][r]);
-    if (q == 2) column_sum_store_b(lds + L::dout, L::AS, A, slab + o.ab, lane);
-    if (q == 3 && !d.discrete) column_sum_store_b(lds + L::aux, L::AS, A, slab + o.log_std, lane);
+    if (q == 2 && lane < A) sst(slab + o.ab + lane, column_sum_b(lds + L::dout + lane, L::AS));
+    if (q == 3 && !d.discrete && lane < A) sst(slab + o.log_std + lane, column_sum_b(lds + L::aux + lane, L::AS));
     if (SPLIT && q == 1 && lane < 4)   // this workgroup's loss statistics: misc columns 2..5 -> slots {0 pg, 2 ent, 3 kl, 4 clip}
-      statpart[lane == 0 ? 0 : lane + 1] = column_sum_b(lds + L::misc + 2 + lane, L::MS);
+      sst(statpart + (lane == 0 ? 0 : lane + 1), column_sum_b(lds + L::misc + 2 + lane, L::MS));
   } else {
     float ae[NC][4], dv[4], ua[16], ub[16];
 #pragma unroll
@@ -1602,12 +1658,12 @@ __device__ __forceinline__ void mfma_minibatch(
       f32x4 g = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int s = 0; s < 16; ++s) g = mfma16(li == 0 ? ua[s] : 0.f, ub[s], g);
-      if (lk == 0) slab[o.cW + q * 16 + li] = g[0];
+      if (lk == 0) sst(slab + o.cW + q * 16 + li, g[0]);
     }
-    if (q == 2 && lane == 0) slab[o.cb] = column_sum_b(lds + L::misc + 1, L::MS);
+    if (q == 2 && lane == 0) sst(slab + o.cb, column_sum_b(lds + L::misc + 1, L::MS));
     if (q == 3 && lane < 5 && (!SPLIT || lane == 4)) {  // statpart slots {0 pg, 2 ent, 3 kl, 4 clip, 1 value} <- misc columns 2..6
       const int slot = lane == 0 ? 0 : (lane == 4 ? 1 : lane + 1);   // (SPLIT: the policy workgroup sums its own four columns)
-      statpart[slot] = column_sum_b(lds + L::misc + 2 + lane, L::MS);
+      sst(statpart + slot, column_sum_b(lds + L::misc + 2 + lane, L::MS));
     }
   }
   __syncthreads();
@@ -1641,7 +1697,7 @@ __device__ __forceinline__ void mfma_minibatch(
       for (int u = 0; u < TP; ++u) {
         const int ti = q + 4 * (t0 + u), jt = ti / NC, kt = ti % NC;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) slab[oW2 + (jt * 16 + lk * 4 + r) * H + kt * 16 + li] = g[u][r];
+        for (int r = 0; r < 4; ++r) sst(slab + oW2 + (jt * 16 + lk * 4 + r) * H + kt * 16 + li, g[u][r]);
       }
     }
     f32x4 acc[NC];
@@ -1664,7 +1720,7 @@ __device__ __forceinline__ void mfma_minibatch(
 #pragma unroll
       for (int r = 0; r < 4; ++r)   // dz1 (the a2 tile is free from here on)
         a2t[(q * 16 + lk * 4 + r) * L::HS + CJ(c)] = acc[c][r] * (1.f - ae[c][r] * ae[c][r]);
-    if (q == 3) column_sum_store_b(dzt, L::HS, H, slab + ob2, lane);
+    if (q == 3 && lane < H) sst(slab + ob2 + lane, column_sum_b(dzt + lane, L::HS));
   }
   __syncthreads();
   IA_TS(7);
@@ -1686,9 +1742,9 @@ __device__ __forceinline__ void mfma_minibatch(
       const int col = kt * 16 + li;
       if (col < D)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) slab[oW1 + (jt * 16 + lk * 4 + r) * D + col] = g[r];
+        for (int r = 0; r < 4; ++r) sst(slab + oW1 + (jt * 16 + lk * 4 + r) * D + col, g[r]);
     }
-    if (q == 3) column_sum_store_b(a2t, L::HS, H, slab + ob1, lane);
+    if (q == 3 && lane < H) sst(slab + ob1 + lane, column_sum_b(a2t + lane, L::HS));
   }
   __syncthreads();
   IA_TS(8);
@@ -1963,12 +2019,6 @@ struct CLds {  // LDS carve-up (floats): activations of both towers plus separat
   static constexpr int misc = aux + ROWS * AS;         // [ROWS][MS]: 0 value, 1 dvalue, 2..6 loss statistics
   static constexpr int total = misc + ROWS * MS + 64;
 };
-
-// Gradient-slab store of the persistent kernel: write-through (system-scope relaxed store = global_store sc0 sc1), so
-// the agent-scope release fence before the grid barrier finds no dirty L2 lines of the slab left to write back.
-__device__ __forceinline__ void slab_store(float* p, float v) {
-  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-}
 
 __device__ __forceinline__ void wave_sync_lds() {
   // same-wave LDS hand-off: DS operations of one wave execute in issue order; this only stops the
@@ -2938,7 +2988,7 @@ __global__ __launch_bounds__(SPLIT ? 256 : 512) void ppo_epoch_persistent_kernel
     float clip, float ent_coef, float vf_coef, float max_norm, float beta1, float beta2, float eps,
     float* __restrict__ ws, const float* __restrict__ seq, int snap, float* __restrict__ stats, EpochSteps st,
     long long* __restrict__ dbg /* measurement: [0..5] += 100 MHz ticks of workgroup 0 in {A, barrier, B1, barrier, B2, barrier} */) {
-  extern __shared__ float lds[];
+  extern __shared__ __attribute__((aligned(16))) float lds[];
   __shared__ int s_flag;
   long long tprev = 0;
 #define EP_TS(slot)                                                       \
@@ -2961,6 +3011,20 @@ __global__ __launch_bounds__(SPLIT ? 256 : 512) void ppo_epoch_persistent_kernel
   unsigned bar = 0;
   const int chunk = (o.total + nwg - 1) / nwg;
   constexpr int NPC = 4;   // parameters of the chunk per thread (chunk <= 2048)
+  // SPLIT: the workgroup's chunk of the parameters and of Adam's moments lives in registers across the launch's steps (the
+  // chunk is the same every step and nobody else writes it): no loads in the apply phase, m / v go back to memory once at
+  // the end. (The eight-wave form has no registers to spare: it loads and stores them every step.)
+  float m_[NPC], v_[NPC], p_[NPC];
+#pragma unroll
+  for (int j = 0; j < NPC; ++j) {
+    m_[j] = 0.f; v_[j] = 0.f; p_[j] = 0.f;
+    if constexpr (SPLIT) {
+      const int i = min(bid * chunk + (int)threadIdx.x + j * NT, o.total - 1);
+      m_[j] = m[i];
+      v_[j] = v[i];
+      p_[j] = P[i];
+    }
+  }
 #pragma nounroll
   for (int k = 0; k < st.n; ++k) {
     const int mb = st.first + k;
@@ -3016,7 +3080,7 @@ __global__ __launch_bounds__(SPLIT ? 256 : 512) void ppo_epoch_persistent_kernel
     {
       const float part = block_sum<NT>(sqs, lds);
       // (slots 5 / 6 of the loss-statistic partials are unused by the gradient; SPLIT: one per tower workgroup)
-      if (tid == 0) w.statpart[SPLIT ? (bid >> 1) * 8 + 5 + (bid & 1) : bid * 8 + 5] = part;
+      if (tid == 0) slab_store(w.statpart + (SPLIT ? (bid >> 1) * 8 + 5 + (bid & 1) : bid * 8 + 5), part);
     }
     EP_TS(2);
     if (!epoch_grid_sync(ctr, (++bar) * nwg, err, &s_flag)) return;
@@ -3047,13 +3111,14 @@ __global__ __launch_bounds__(SPLIT ? 256 : 512) void ppo_epoch_persistent_kernel
     }
     {
       const float step_size = st.step_size[k], bc2_sqrt = st.bc2_sqrt[k];
-      float m_[NPC], v_[NPC], p_[NPC];
+      if constexpr (!SPLIT) {
 #pragma unroll
-      for (int j = 0; j < NPC; ++j) {
-        const int i = min(i0 + tid + j * NT, o.total - 1);
-        m_[j] = m[i];
-        v_[j] = v[i];
-        p_[j] = P[i];
+        for (int j = 0; j < NPC; ++j) {
+          const int i = min(i0 + tid + j * NT, o.total - 1);
+          m_[j] = m[i];
+          v_[j] = v[i];
+          p_[j] = P[i];
+        }
       }
 #pragma unroll
       for (int j = 0; j < NPC; ++j) {
@@ -3064,9 +3129,16 @@ __global__ __launch_bounds__(SPLIT ? 256 : 512) void ppo_epoch_persistent_kernel
           const float vi = v_[j] * beta2 + (1.f - beta2) * gi * gi;
           const float denom = sqrtf(vi) / bc2_sqrt + eps;
           const float pn = p_[j] - step_size * (mi / denom);
-          P[i] = pn;
-          m[i] = mi;
-          v[i] = vi;
+          if constexpr (SPLIT) {
+            slab_store(P + i, pn);   // (write-through: read by every workgroup behind the barrier)
+            p_[j] = pn;
+            m_[j] = mi;
+            v_[j] = vi;
+          } else {
+            P[i] = pn;
+            m[i] = mi;
+            v[i] = vi;
+          }
           int dst = i;
           auto tr = [&](int b0, int rows_, int cols) {
             if (i >= b0 && i < b0 + rows_ * cols) {
@@ -3075,13 +3147,24 @@ __global__ __launch_bounds__(SPLIT ? 256 : 512) void ppo_epoch_persistent_kernel
             }
           };
           tr(o.pW1, H, D); tr(o.pW2, H, H); tr(o.vW1, H, D); tr(o.vW2, H, H);
-          Pt[dst] = pn;
+          if constexpr (SPLIT) slab_store(Pt + dst, pn);
+          else Pt[dst] = pn;
         }
       }
     }
     EP_TS(4);
     if (!epoch_grid_sync(ctr, (++bar) * nwg, err, &s_flag)) return;
     EP_TS(5);
+  }
+  if constexpr (SPLIT) {
+#pragma unroll
+    for (int j = 0; j < NPC; ++j) {
+      const int i = bid * chunk + (int)threadIdx.x + j * NT;
+      if (i < min(o.total, (bid + 1) * chunk)) {
+        m[i] = m_[j];
+        v[i] = v_[j];
+      }
+    }
   }
 #undef EP_TS
 }
@@ -4178,8 +4261,8 @@ int ia_ppo_epoch(const ia_policy_desc* d, float* params, float* params_t, float*
     const int P = po.total;
     // one tower per workgroup (two workgroups of four waves per row block, the tower's parameters resident in LDS) when
     // both fit: 2 nrb workgroups co-resident, chunks of <= 4 x 256 parameters, the larger tower's images beside its tiles
-    const int lenA = std::max(po.vW1, po.aW - po.vW1) + 6, lenB = std::max(po.cW - po.aW, P - po.cW) + 6;
-    const size_t sbytes = (size_t)(((GLds<64, 1>::total + 3) & ~3) + 2 * lenA + lenB) * sizeof(float);
+    const int tlen = 64 * d->obs_dim + 64 + 64 * 64 + 64, lenB = std::max(po.cW - po.aW, P - po.cW) + 3;
+    const size_t sbytes = (size_t)(((GLds<64, 1>::total + 3) & ~3) + 2 * tlen + lenB + MAXA) * sizeof(float);
     const bool split = !g_epoch_whole && 2 * nrb <= dev_cus && 2 * nrb <= 64 && cdiv(P, 2 * nrb) <= 4 * 256 &&
                        sbytes <= EPOCH_SPLIT_LDS;
     const int nwg = split ? 2 * nrb : nrb;
