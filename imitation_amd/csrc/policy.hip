@@ -1232,40 +1232,33 @@ __device__ __forceinline__ void mfma_minibatch(
   const float* sLS = sP;
   typedef float f32x4_u __attribute__((ext_vector_type(4), aligned(4)));
   constexpr int NA = SPLIT ? (H * MAXD + H + H * H + H + 4 * NT - 1) / (4 * NT) : 1;   // 16-byte pieces per thread, images A / T
-  constexpr int NB = SPLIT ? (MAXA * H + MAXA + 4 + 4 * NT - 1) / (4 * NT) : 1;        // ... image B
-  float4 va[NA], vb[NB], vt[NA];
+  constexpr int NB = SPLIT ? (MAXA * H + MAXA + NT - 1) / NT : 1;                      // elements per thread, image B
+  float4 va[NA], vt[NA];
+  float vb[NB];
   float lsv = 0.f;
   const int tlen = H * D + H + H * H + H, t0 = tower ? o.vW1 : o.pW1;
-  const int segB0 = tower ? o.cW : o.aW, lenB = ((tower ? o.total : o.cW) - segB0 + 3) & ~3;
+  const int segB0 = tower ? o.cW : o.aW, nB = (tower ? o.total : o.cW) - segB0, lenB = (nB + 3) & ~3;
   float* imgA = lds + ((L::total + 3) & ~3);
   float* imgT = imgA + tlen;
   float* imgB = imgT + tlen;
   float* imgC = imgB + lenB;
   if constexpr (SPLIT) {
-    // (a 16-byte piece that would run past the end of the flat vector -- the last one of the value head at most -- is read
-    //  element by element)
-    auto load_piece = [&](const float* __restrict__ srcv, int f0, int len4, int i) {
-      const int e = tid + i * NT, f = f0 + 4 * e;
-      float4 v4 = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (e < len4) {
-        if (f + 3 < o.total) {
-          const f32x4_u t = *reinterpret_cast<const f32x4_u*>(srcv + f);
-          v4 = make_float4(t[0], t[1], t[2], t[3]);
-        } else {
-          float t0_[4];
+    // every load UNCONDITIONAL at a clamped index (see the row loads above); images A / T lie inside the flat vector whole,
+    // the head goes element by element (its last 16-byte piece could run past the vector's end)
 #pragma unroll
-          for (int u = 0; u < 4; ++u) t0_[u] = srcv[min(f + u, o.total - 1)];
-          v4 = make_float4(t0_[0], t0_[1], t0_[2], t0_[3]);
-        }
-      }
-      return v4;
-    };
+    for (int i = 0; i < NA; ++i) {
+      const int e = min(tid + i * NT, (tlen >> 2) - 1);
+      const f32x4_u t = *reinterpret_cast<const f32x4_u*>(P + t0 + 4 * e);
+      va[i] = make_float4(t[0], t[1], t[2], t[3]);
+    }
 #pragma unroll
-    for (int i = 0; i < NA; ++i) va[i] = load_piece(P, t0, tlen >> 2, i);
+    for (int i = 0; i < NB; ++i) vb[i] = P[segB0 + min(tid + i * NT, nB - 1)];
 #pragma unroll
-    for (int i = 0; i < NB; ++i) vb[i] = load_piece(P, segB0, lenB >> 2, i);
-#pragma unroll
-    for (int i = 0; i < NA; ++i) vt[i] = load_piece(Pt, t0, tlen >> 2, i);
+    for (int i = 0; i < NA; ++i) {
+      const int e = min(tid + i * NT, (tlen >> 2) - 1);
+      const f32x4_u t = *reinterpret_cast<const f32x4_u*>(Pt + t0 + 4 * e);
+      vt[i] = make_float4(t[0], t[1], t[2], t[3]);
+    }
     lsv = P[d.discrete ? 0 : o.log_std + min(tid, A - 1)];
     sPA = imgA - t0;
     sPt = imgT - t0;
@@ -1282,7 +1275,7 @@ __device__ __forceinline__ void mfma_minibatch(
         }
 #pragma unroll
       for (int i = 0; i < NB; ++i)
-        if (tid + i * NT < (lenB >> 2)) reinterpret_cast<float4*>(imgB)[tid + i * NT] = vb[i];
+        if (tid + i * NT < nB) imgB[tid + i * NT] = vb[i];
       if (tid < MAXA) imgC[tid] = lsv;
     }
   };
