@@ -471,13 +471,15 @@ def test_timeout_bootstrap():
                                                         # (minibatch steps as phases between grid barriers)
                                                         (17, 6, 64, False, True, 16, 256, 1024),
                                                         (4, 2, 64, True, True, 9, 100, 384)])
-@pytest.mark.parametrize("path", ["epoch", "update", "update_spread"])
+@pytest.mark.parametrize("path", ["epoch", "epoch_whole", "update", "update_spread"])
 def test_ppo_epochs_match_oracle(D, A, H, discrete, norm, T, n, bs, path):
     """Two PPO epochs on a synthetic rollout: parameters, Adam state, RunningNorm state and the
     logged loss statistics against SB3-restated `PPO.train` on the same permutations -- through
     one `ia_ppo_epoch` call per epoch, and through the single persistent `ia_ppo_update` launch
     (working blocks packed on one XCD, or spread over all of them)."""
-    if path != "epoch" and H != 32:
+    if path == "epoch_whole" and H != 64:
+        pytest.skip("64-wide towers: the one-launch epoch with whole row-block workgroups (default: one tower each)")
+    if path not in ("epoch", "epoch_whole") and H != 32:
         pytest.skip("the persistent update covers hidden = 32")
     from imitation_amd import spaces
     from oracle import imitation_restated as o
@@ -519,12 +521,17 @@ def test_ppo_epochs_match_oracle(D, A, H, discrete, norm, T, n, bs, path):
     ws = th.empty(int(L.load().ia_ppo_ws_floats(C.byref(dp.d), bs, T * n)), device=DEV)
     n_mb = -(-T * n // bs)
     stats = th.zeros(2, n_mb, 8, device=DEV)
-    if path == "epoch":
-        for e in range(2):
-            L.call("ia_ppo_epoch", C.byref(dp.d), L.ptr(dp.P), L.ptr(dp.Pt), L.ptr(dp.nm), L.ptr(dp.nv), L.ptr(dp.nc),
-                   int(norm), L.ptr(d_obs), L.ptr(d_act), L.ptr(d_lp), L.ptr(d_adv), L.ptr(d_ret),
-                   dptr(perms[e], th.int64), T, n, bs, 1, 0.2, 0.05, 0.5, 0.5, L.ptr(dp.m), L.ptr(dp.v), 3e-4, 0.9,
-                   0.999, 1e-5, e * n_mb, L.ptr(ws), L.ptr(stats[e]), L.stream())
+    if path in ("epoch", "epoch_whole"):
+        L.load().ia_ppo_epoch_split(2 if path == "epoch_whole" else 0)
+        try:
+            for e in range(2):
+                L.call("ia_ppo_epoch", C.byref(dp.d), L.ptr(dp.P), L.ptr(dp.Pt), L.ptr(dp.nm), L.ptr(dp.nv), L.ptr(dp.nc),
+                       int(norm), L.ptr(d_obs), L.ptr(d_act), L.ptr(d_lp), L.ptr(d_adv), L.ptr(d_ret),
+                       dptr(perms[e], th.int64), T, n, bs, 1, 0.2, 0.05, 0.5, 0.5, L.ptr(dp.m), L.ptr(dp.v), 3e-4, 0.9,
+                       0.999, 1e-5, e * n_mb, L.ptr(ws), L.ptr(stats[e]), L.stream())
+            th.cuda.synchronize()
+        finally:
+            L.load().ia_ppo_epoch_split(0)
     else:
         nws = int(L.load().ia_ppo_update_ws_floats(C.byref(dp.d), bs))
         if nws == 0:
