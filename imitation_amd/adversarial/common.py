@@ -233,6 +233,7 @@ class AdversarialTrainer(abc.ABC):
         B = self.demo_batch_size
         nq = max(1, self.n_disc_updates_per_round)
         self._quirk_idx_host = th.zeros(nq, 2, B, dtype=th.int64).pin_memory()
+        self._ring_rows_drawn = []
         self._quirk_idx_dev = th.zeros(nq, 2, B, dtype=th.int64, device=self._device)
         self._idx_host = th.zeros(2, B, dtype=th.int64).pin_memory()
         self._idx_dev = th.zeros(2, B, dtype=th.int64, device=self._device)
@@ -313,8 +314,10 @@ class AdversarialTrainer(abc.ABC):
             self._horizon = hs.pop()
 
     # ---- discriminator update (`common.py:317-389,521-632`) --------------------------------------
-    def _batch_sources(self, expert_samples, gen_samples):
-        """(expert_table, expert_idx_dev | None), (gen_table, gen_idx_dev | None) for one update."""
+    def _batch_sources(self, expert_samples, gen_samples, upload: bool = True):
+        """(expert_table, expert_idx_dev | None), (gen_table, gen_idx_dev | None) for one update. `upload=False` (ring
+        rows only): the index rows stay in their pinned ring row, the caller uploads the rows of all its updates in one
+        copy (`_upload_index_rows`) -- `self._ring_rows_drawn` collects the rows."""
         B = self.demo_batch_size
         e_idx = g_idx = None
         # inside an overlapped round every update gets its own (pinned, device) index rows so the
@@ -342,13 +345,29 @@ class AdversarialTrainer(abc.ABC):
             raise ValueError("Need to have exactly `demo_batch_size` number of expert and generator samples, each. "
                              f"(n_gen={n_gen} n_expert={n_exp} demo_batch_size={B})")
         if e_idx is not None or g_idx is not None:
-            idx_dev.copy_(idx_host, non_blocking=True)
+            if upload or k is None:
+                idx_dev.copy_(idx_host, non_blocking=True)
+            else:
+                self._ring_rows_drawn.append(k)
         obs_shape = self.venv.observation_space.shape
         e_tab = self._expert_table if expert_samples is None else _upload_table(expert_samples, obs_shape,
                                                                                 self._discrete, self._device)
         g_tab = self._gen_replay_buffer.table if gen_samples is None else _upload_table(gen_samples, obs_shape,
                                                                                         self._discrete, self._device)
         return (e_tab, e_idx), (g_tab, g_idx)
+
+    def _upload_index_rows(self) -> None:
+        """One host-to-device copy for the index rows of a round's updates (16 copies of 128 KB cost ~12 us of host time
+        each and sit between the round's first kernels in the stream)."""
+        rows, self._ring_rows_drawn = self._ring_rows_drawn, []
+        if not rows:
+            return
+        if rows == list(range(rows[0], rows[0] + len(rows))):
+            lo, hi = rows[0], rows[0] + len(rows)
+            self._quirk_idx_dev[lo:hi].copy_(self._quirk_idx_host[lo:hi], non_blocking=True)
+        else:
+            for k in rows:
+                self._quirk_idx_dev[k].copy_(self._quirk_idx_host[k], non_blocking=True)
 
     def _policy_pass(self, sources, mb: int, assembled: bool = False) -> Optional[th.Tensor]:
         """`common.py:606-615`: log pi(a|s) of the 2*mb rows under no_grad. For GAIL the value is
@@ -420,7 +439,9 @@ class AdversarialTrainer(abc.ABC):
             if prepass:
                 # all host index draws of the round first (same order as one per update), then the
                 # policy feature-norm moments of every update's batch, then the updates themselves
-                drawn = [self._batch_sources(None, None) for _ in range(n)]
+                self._ring_rows_drawn = []
+                drawn = [self._batch_sources(None, None, upload=False) for _ in range(n)]
+                self._upload_index_rows()
                 round_ws = self._assemble_round(drawn)   # fused shapes: ONE launch assembles all n batches
                 did = self._quirk_prepass(drawn, round_ws)
                 if self._needs_logp:
@@ -444,6 +465,11 @@ class AdversarialTrainer(abc.ABC):
                         self._disc_update(None, None, self._stats_ring[k], drawn=drawn[k], quirk_done=did,
                                           pre=None if round_ws is None else (round_ws, k))
                     steps.append(self._disc_step)
+                    if k == 0 and n > 1 and round_ws is not None and self.disc_grad_penalty_coef > 0.0:
+                        # the other updates' interpolation weights as one block, drawn while the device works on the
+                        # first update (whose own vector came through the per-update ring: nothing delays the round's
+                        # first kernels)
+                        self._gp_predraw_for_round(n - 1)
             else:
                 for k in range(n):
                     with networks.training(self.reward_train):
@@ -454,6 +480,7 @@ class AdversarialTrainer(abc.ABC):
         self._stats_ring_host.copy_(self._stats_ring, non_blocking=True)
         done = th.cuda.Event()
         done.record()
+        self._gp_block_done(done)
         return done, steps, self._global_step
 
     def _finish_disc_round(self, pending) -> None:
@@ -609,6 +636,10 @@ class AdversarialTrainer(abc.ABC):
             n = 32
             ring = self._gp_ring = (th.empty(n, mb).pin_memory(), th.empty(n, mb, device=self._device),
                                     [None] * n, [0])
+        blk = getattr(self, "_gp_block", None)
+        if blk is not None and blk[2] < blk[0].shape[0] and blk[0].shape[1] == mb:
+            blk[2] += 1                     # a round's weights, drawn and uploaded as ONE block (`_gp_predraw`)
+            return blk[0][blk[2] - 1]
         host, dev, events, counter = ring
         k = counter[0] % host.shape[0]
         counter[0] += 1
@@ -619,6 +650,43 @@ class AdversarialTrainer(abc.ABC):
         events[k] = th.cuda.Event()
         events[k].record()
         return dev[k]
+
+    def _gp_predraw_for_round(self, n_updates: int) -> None:
+        """Pre-draws the interpolation weights of a round of pre-assembled updates when every one of them will ask for
+        exactly one vector inside its fused update (single minibatch per update, fused penalty workspace available)."""
+        basic = self._reward_net
+        while isinstance(basic, reward_nets.PredictProcessedWrapper):
+            basic = basic.base
+        mb = self.demo_minibatch_size
+        if (isinstance(basic, reward_nets.BasicRewardNet) and mb == self.demo_batch_size
+                and basic.fused_gp_ws(mb) is not None):
+            self._gp_predraw(n_updates, mb)
+
+    def _gp_predraw(self, count: int, mb: int) -> None:
+        """The next `count` interpolation-weight vectors in ONE draw and ONE upload: `th.rand(count, mb)` consumes torch's
+        CPU generator exactly as `count` draws of `th.rand(mb)` do (one 32-bit draw per element, in order), nothing else
+        reads that generator while a round's updates are enqueued, and a copy per update inside the discriminator stream is
+        a ~20 us bubble between two updates' kernels plus ~25 us of host time. Four pinned / device blocks in rotation; a
+        block is reused only after the round that consumed it has completed (`_gp_block_done`)."""
+        blocks = getattr(self, "_gp_blocks", None)
+        if blocks is None or blocks[0][0].shape != (count, mb):
+            blocks = self._gp_blocks = [[th.empty(count, mb).pin_memory(), th.empty(count, mb, device=self._device), None]
+                                        for _ in range(4)]
+            self._gp_block_i = 0
+        b = blocks[self._gp_block_i % 4]
+        self._gp_block_i += 1
+        if b[2] is not None:
+            b[2].synchronize()
+        th.rand(count, mb, out=b[0])
+        b[1].copy_(b[0], non_blocking=True)
+        self._gp_block = [b[1], b, 0]
+
+    def _gp_block_done(self, event) -> None:
+        blk = getattr(self, "_gp_block", None)
+        if blk is not None:
+            assert blk[2] in (0, blk[0].shape[0]), "a round's pre-drawn interpolation weights were only partly consumed"
+            blk[1][2] = event
+            self._gp_block = None
 
     def _add_grad_penalty(self, mlp, X: th.Tensor, norm, mb: int, scale: float) -> None:
         """Adds the gradient-penalty parameter gradient of one minibatch (`X[2*mb, ldx]` = [expert | generator] rows

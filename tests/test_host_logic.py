@@ -555,3 +555,16 @@ def test_categorical_sample_equals_torch_distributions(shape):
         for (a, lp), (ra, rlp) in zip(got, ref):
             assert th.equal(a, ra) and a.dtype == ra.dtype and a.shape == ra.shape
             assert th.equal(lp, rlp)
+
+
+def test_block_draw_of_interpolation_weights_equals_per_update_draws():
+    """`AdversarialTrainer._gp_predraw`: a round's gradient-penalty interpolation weights are ONE `th.rand(n, mb)` draw;
+    torch's CPU generator hands out one 32-bit draw per element in order, so the block equals n draws of `th.rand(mb)`
+    (also for sizes that are no multiple of the vectorised kernels' 16-element blocks)."""
+    import torch as th
+    for n, mb in ((16, 8192), (5, 100), (3, 7), (4, 96)):
+        th.manual_seed(11)
+        block = th.rand(n, mb)
+        th.manual_seed(11)
+        seq = th.stack([th.rand(mb) for _ in range(n)])
+        assert th.equal(block, seq), (n, mb)
