@@ -465,7 +465,7 @@ class AdversarialTrainer(abc.ABC):
                         self._disc_update(None, None, self._stats_ring[k], drawn=drawn[k], quirk_done=did,
                                           pre=None if round_ws is None else (round_ws, k))
                     steps.append(self._disc_step)
-                    if k == 0 and n > 1 and round_ws is not None and self.disc_grad_penalty_coef > 0.0:
+                    if k == 0 and n > 1 and self.disc_grad_penalty_coef > 0.0:
                         # the other updates' interpolation weights as one block, drawn while the device works on the
                         # first update (whose own vector came through the per-update ring: nothing delays the round's
                         # first kernels)
@@ -652,14 +652,11 @@ class AdversarialTrainer(abc.ABC):
         return dev[k]
 
     def _gp_predraw_for_round(self, n_updates: int) -> None:
-        """Pre-draws the interpolation weights of a round of pre-assembled updates when every one of them will ask for
-        exactly one vector inside its fused update (single minibatch per update, fused penalty workspace available)."""
-        basic = self._reward_net
-        while isinstance(basic, reward_nets.PredictProcessedWrapper):
-            basic = basic.base
+        """Pre-draws the interpolation weights of the round's remaining updates when every update asks for exactly one
+        vector: a single minibatch per update (every penalty path -- fused GAIL / AIRL, stack by stack -- draws one
+        `th.rand(mb)` per minibatch; `_gp_block_done` checks that the block was consumed whole)."""
         mb = self.demo_minibatch_size
-        if (isinstance(basic, reward_nets.BasicRewardNet) and mb == self.demo_batch_size
-                and basic.fused_gp_ws(mb) is not None):
+        if mb == self.demo_batch_size:
             self._gp_predraw(n_updates, mb)
 
     def _gp_predraw(self, count: int, mb: int) -> None:
