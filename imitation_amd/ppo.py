@@ -363,6 +363,7 @@ class PPO(OnPolicyAlgorithm):
         self.after_enqueue = None
         self._post_enqueue_work = []
         self._act_stream = None
+        self.rollout_post_ahead = True   # (tuning / A-B: False posts a mailbox step only at the top of its own iteration)
         self.predraw_noise = os.environ.get("IA_PREDRAW_NOISE", "1") != "0"   # see `collect_rollouts`
         # the rollout's act steps as one resident launch driven through flags in pinned host memory (`collect_rollouts`)
         self.rollout_mailbox = os.environ.get("IA_ROLLOUT_MAILBOX", "1") != "0"
@@ -604,13 +605,21 @@ class PPO(OnPolicyAlgorithm):
                        h_dones_np, h_trunc_np, h_next_np, h_obs_np, h_starts_np, stream) -> bool:
         """The step loop and the tail of `collect_rollouts` (its own function so that the rollout mailbox is closed on
         every way out)."""
+        # Mailbox rollouts post step t + 1 AS SOON AS its observations are in their pinned row -- ahead of the rest of step
+        # t's bookkeeping (next-observation / done / reward rows, callbacks, the buffering wrapper), which then runs while
+        # the device computes the actions: ~10 us per env step off the host's critical path. (Needs the step's noise
+        # in place already: pre-drawn tiles or host-side sampling.)
+        post_ahead = self.rollout_post_ahead and (host_sampling or predrawn)
+        posted = -1   # the last step posted to the mailbox
         for t in range(T):
             t0 = tick() if prof is not None else 0.0
             if not host_sampling and not predrawn:
                 pol.draw_noise_into(rb.h_noise)
             t1 = tick() if prof is not None else 0.0
             if mailbox is not None:
-                mailbox[0](t)
+                if posted < t:
+                    mailbox[0](t)
+                    posted = t
             else:
                 act_step(t)
             t2 = tick() if prof is not None else 0.0
@@ -633,6 +642,10 @@ class PPO(OnPolicyAlgorithm):
             old_obs = self._last_obs
             base.step_async(acts_np)
             new_obs, env_rews, dones, nxt, trunc, infos = step_arrays(base)
+            h_obs_np[t + 1] = new_obs.reshape(n, -1)
+            if mailbox is not None and post_ahead and t + 1 < T:
+                mailbox[0](t + 1)
+                posted = t + 1
             if prof is not None:
                 t4 = tick()
                 for k, v in (("noise draw", t1 - t0), ("act launch", t2 - t1),
@@ -648,7 +661,6 @@ class PPO(OnPolicyAlgorithm):
                         self.ep_info_buffer.extend([info["episode"]])
             if bw is not None:
                 bw.record_step(acts_np, new_obs, nxt, env_rews, dones, infos)
-            h_obs_np[t + 1] = new_obs.reshape(n, -1)
             h_next_np[t] = nxt.reshape(n, -1)
             h_dones_np[t], h_trunc_np[t], h_starts_np[t] = dones, trunc, starts
             if rw is not None and fused_net is None and module_net is None:  # arbitrary host reward function: per-step call
