@@ -435,6 +435,7 @@ class AdversarialTrainer(abc.ABC):
             return None
         steps = []
         self._use_ring = True
+        self._gp_block = None   # (a block left over by a round that raised is dropped, not served)
         try:
             if prepass:
                 # all host index draws of the round first (same order as one per update), then the
