@@ -301,6 +301,16 @@ def test_missing_extension_fails_loudly(monkeypatch):
         _lib.load()
 
 
+# 3 x the worst deviation per state group measured on MI355X (round 4; `_assert_worst`), floored at 1e-5 (below that
+# the last bits of the host's torch-CPU build decide). Measured: config P {disc 9.4e-5, policy 7.6e-4, replay 4.7e-4,
+# rollout 6.1e-4}; AIRL Ant {disc 3.0e-4, policy 7.5e-7, replay 6e-8, rollout 2.9e-6}; tuned GAIL {disc 9.1e-7, policy
+# 1.3e-6, replay 4.3e-7, rollout 1.1e-5}; tuned AIRL Ant at 1 024 envs {disc 1.6e-4, policy 1.3e-6, replay 6e-8, rollout 1.4e-6}.
+CEIL_P = {"disc": 3e-4, "policy": 2.3e-3, "replay": 1.5e-3, "rollout": 1.9e-3, "*": 1e-5}
+CEIL_AIRL_ANT = {"disc": 9e-4, "policy": 1e-5, "replay": 1e-5, "rollout": 1e-5, "*": 1e-5}
+CEIL_TUNED_GAIL = {"disc": 1e-5, "policy": 1e-5, "replay": 1e-5, "rollout": 3.5e-5, "*": 1e-5}
+CEIL_TUNED_AIRL = {"disc": 5e-4, "policy": 1e-5, "replay": 1e-5, "rollout": 1e-5, "*": 1e-5}
+
+
 def test_full_size_config_p_matches_live_oracle():
     """BASELINE.json configs[1] at FULL size (1 024 envs x 16 steps, 256x256 discriminator on 16 384-row
     batches, 16 updates and 160 PPO minibatch steps per round): two rounds of the HIP trainer (pipelined
@@ -340,6 +350,7 @@ def test_full_size_config_p_matches_live_oracle():
     assert int(ref["counters"][2]) == 2 * per_round
     top = sorted(worst.items(), key=lambda kv: -kv[1])[:3]
     print("config P, 2 rounds, largest absolute deviations from the oracle:", top)
+    _assert_worst(worst, CEIL_P, "config P, 2 rounds:")
 
 
 def test_full_size_airl_ant_matches_live_oracle(tmp_path):
@@ -376,9 +387,30 @@ def test_full_size_airl_ant_matches_live_oracle(tmp_path):
             worst[key] = float(np.nanmax(np.abs(x.astype(np.float64) - y.astype(np.float64)))) if x.size else 0.0
     print("AIRL Ant-shaped, 1 round, largest absolute deviations from the oracle:",
           sorted(worst.items(), key=lambda kv: -kv[1])[:3])
+    _assert_worst(worst, CEIL_AIRL_ANT, "AIRL Ant-shaped, 1 round:")
 
 
-def _full_size_compare(cfg, rounds, k_steps, tmp_path, label, atol_per_step=1e-5):
+def _grouped_worst(worst):
+    """Largest absolute deviation per state group (disc/, policy/, rollout/, replay/, everything else)."""
+    out = {}
+    for key, v in worst.items():
+        g = key.split("/")[0] if "/" in key else "other"
+        out[g] = max(out.get(g, 0.0), v)
+    return out
+
+
+def _assert_worst(worst, ceilings, label):
+    """The tolerance envelope `atol = 5e-5 + k * 1e-5` is the reference's own accumulation rule scaled down; it would let a
+    several-fold regression through. So every full-size test also asserts its MEASURED worst deviation per state group
+    times three (`ceilings`: group -> 3 x the value measured on MI355X when the test was written)."""
+    got = _grouped_worst(worst)
+    print(label, "worst deviation per group:", {k: float(f"{v:.3g}") for k, v in sorted(got.items())})
+    for g, v in got.items():
+        lim = ceilings.get(g, ceilings.get("*"))
+        assert lim is None or v <= lim, (label, g, v, lim)
+
+
+def _full_size_compare(cfg, rounds, k_steps, tmp_path, label, atol_per_step=1e-5, ceilings=None):
     outs = {}
     for impl in ("oracle", "hip"):
         threads = th.get_num_threads()
@@ -402,6 +434,8 @@ def _full_size_compare(cfg, rounds, k_steps, tmp_path, label, atol_per_step=1e-5
                                        atol=5e-5 + k_steps * atol_per_step, equal_nan=True, err_msg=key)
             worst[key] = float(np.nanmax(np.abs(x.astype(np.float64) - y.astype(np.float64)))) if x.size else 0.0
     print(label, "largest absolute deviations from the oracle:", sorted(worst.items(), key=lambda kv: -kv[1])[:3])
+    _assert_worst(worst, ceilings or {}, label)
+    return worst
 
 
 def test_full_size_tuned_gail_matches_live_oracle(tmp_path):
@@ -412,7 +446,19 @@ def test_full_size_tuned_gail_matches_live_oracle(tmp_path):
     of the config-P test (atol 5e-5 + k * 1e-5 after k = 656 optimiser steps)."""
     cfg = dict(harness.CASES["gail_tuned_hps"], n_envs=1024, horizon=1000, ppo_batch=64, demo_batch=8192, capacity=512,
                n_demo=32768, rounds=2)
-    _full_size_compare(cfg, 2, 2 * (8 + 320), tmp_path, "tuned GAIL, 1024 envs, 2 rounds:")
+    _full_size_compare(cfg, 2, 2 * (8 + 320), tmp_path, "tuned GAIL, 1024 envs, 2 rounds:", ceilings=CEIL_TUNED_GAIL)
+
+
+def test_full_size_tuned_airl_matches_live_oracle(tmp_path):
+    """BASELINE.json configs[2] as the reference SHIPS it: `tuned_hps/airl_seals_ant_best_hp_eval.json:2-44` verbatim at
+    1 024 Ant-shaped envs (obs 27 / act 8): rl.batch_size 8 192 -> rounds of 8 steps, PPO minibatch 16 x 10 epochs = 5 120
+    optimiser steps per round on the one-workgroup (`LOCAL`) persistent kernel, clip 0.3, gae_lambda 0.8, gamma 0.995,
+    lr 3.25e-5, max_grad_norm 0.9, vf_coef 0.435; `BasicShapedRewardNet` defaults + input RunningNorm inside
+    `NormalizedRewardNet`, 8 192-row demo batches, ring capacity 8 192, 16 updates per round. One round against the CPU
+    oracle (k = 5 136 optimiser steps)."""
+    cfg = dict(harness.CASES["airl_tuned_hps"], n_envs=1024, horizon=1000, ppo_batch=16, demo_batch=8192, capacity=8192,
+               n_demo=32768, rounds=1)
+    _full_size_compare(cfg, 1, 16 + 5120, tmp_path, "tuned AIRL Ant, 1024 envs, 1 round:", ceilings=CEIL_TUNED_AIRL)
 
 
 @pytest.mark.parametrize("n_steps", [100] + ([1000] if os.environ.get("IA_SLOW_TESTS") == "1" else []))
@@ -427,10 +473,17 @@ def test_horizon_rollouts_match_live_oracle(n_steps, tmp_path):
     _full_size_compare(cfg, 1, 2 + n_steps, tmp_path, f"horizon variant 1024 x {n_steps}, 1 round:")
 
 
-def test_bc_nature_cnn_84x84_matches_live_oracle(tmp_path):
-    """BASELINE config 5's shape: `bc.BC` with the NatureCNN policy on uint8 4 x 84 x 84 frames, Discrete(6), batch 256
-    (the full 4 096 is timed by bench.py's `5_bc_cnn_4096`; the CPU oracle needs seconds per step there): three
-    optimiser steps against the oracle's torch-CPU BC on the same frames, policy and loader stream. Every logged row
+_BC_FULL = os.environ.get("IA_SLOW_TESTS") == "1" or (os.cpu_count() or 1) >= 32
+
+
+@pytest.mark.parametrize("B,steps,adam_eps", [(256, 3, None)] + ([(4096, 2, None), (4096, 2, 1e-3)] if _BC_FULL else []))
+def test_bc_nature_cnn_84x84_matches_live_oracle(B, steps, adam_eps, tmp_path):
+    """BASELINE config 5's shape: `bc.BC` with the NatureCNN policy on uint8 4 x 84 x 84 frames, Discrete(6): batch 256 x
+    three optimiser steps, and the FULL batch 4 096 x two steps (BASELINE.json configs[4] as worded; the torch-CPU oracle
+    needs ~50 s per 4 096-sample step on 8 threads, so those cases run when the host has >= 32 cores -- the oracle then
+    takes up to 64 threads: 2.5 s on the 256-core GPU box -- or with IA_SLOW_TESTS=1; once with the default Adam and once
+    with `optimizer_kwargs=dict(eps=1e-3)`, see `frac_ok` below) against the oracle's torch-CPU BC on the same frames,
+    policy and loader stream. Every logged row
     (loss, neglogp, entropy, prob_true_act, l2_norm ... of each step) within rtol 1e-4; every parameter within
     steps x lr of the oracle's, and within rtol 2e-4 / atol 5e-5 for >= 97 % of each tensor's entries. Two fp32 effects
     keep the rest apart without being errors: Adam normalises the step, so a last-bit difference in a vanishing gradient
@@ -440,7 +493,16 @@ def test_bc_nature_cnn_84x84_matches_live_oracle(tmp_path):
     entry; torch's own fp32 run happens not to flip). Gradients are checked entry by entry against torch autograd at
     batch sizes without a flip in `test_cnn_policy_forward_and_gradient_match_torch` (same image shape)."""
     from imitation_amd import spaces
-    shape, A, B, steps = (4, 84, 84), 6, 256, 3
+    shape, A = (4, 84, 84), 6
+    oracle_threads = 8 if B <= 256 else max(8, min(64, os.cpu_count() or 8))
+    # default Adam (eps 1e-8) normalises the step: an entry whose gradient is within rounding of zero moves by +-lr
+    # whichever sign the summation order leaves it -- 3 % of a tensor at batch 256, up to 6.3 % (4 of `cnn.4.bias`'s 64
+    # entries) at batch 4 096 where the mean gradients are smaller. With eps = 1e-3 >> |g| the step is LINEAR in the
+    # gradient (lr * g / eps = g), the amplification is gone and the parameters compare the full-size gradients directly:
+    # every entry inside the standard tolerance, measured worst deviation 1.3e-6 (asserted x 3).
+    frac_ok, worst_ok = (0.03 if B <= 256 else 0.08), steps * 1e-3 + 1e-4
+    if adam_eps is not None:
+        frac_ok, worst_ok = 0.0, 4e-6
     osp, asp = spaces.Box(0, 255, shape, np.uint8), spaces.Discrete(A)
     rng0 = np.random.default_rng(0)
     obs = rng0.integers(0, 256, (2 * B, *shape), dtype=np.uint8)
@@ -451,7 +513,7 @@ def test_bc_nature_cnn_84x84_matches_live_oracle(tmp_path):
         th.manual_seed(0)
         np.random.seed(0)
         threads = th.get_num_threads()
-        th.set_num_threads(8 if impl == "oracle" else 1)
+        th.set_num_threads(oracle_threads if impl == "oracle" else 1)
         try:
             pol = ns.ActorCriticCnnPolicy(observation_space=osp, action_space=asp, lr_schedule=lambda _: 1.0)
             demos = ns.Transitions(obs=obs, acts=acts, next_obs=obs.copy(), dones=np.zeros(2 * B, dtype=bool))
@@ -467,6 +529,8 @@ def test_bc_nature_cnn_84x84_matches_live_oracle(tmp_path):
                 return orig_dump(step)
 
             logger.dump = dump
+            if adam_eps is not None:
+                kw["optimizer_kwargs"] = dict(eps=adam_eps)
             tr = ns.BC(observation_space=osp, action_space=asp, rng=np.random.default_rng(0), policy=pol,
                        demonstrations=demos, batch_size=B, custom_logger=logger, **kw)
             tr.train(n_batches=steps, log_interval=1, progress_bar=False)
@@ -480,8 +544,16 @@ def test_bc_nature_cnn_84x84_matches_live_oracle(tmp_path):
     rr, rg = ref.pop("_rows"), got.pop("_rows")
     assert rr.shape == rg.shape and rr.shape[0] == steps and rr.shape[1] >= 5
     np.testing.assert_allclose(rg, rr, rtol=1e-4, atol=1e-6)
+    report = {}
     for k in ref:
         x, y = got[k].astype(np.float64), ref[k].astype(np.float64)
         err = np.abs(x - y)
         bad = err > 5e-5 + 2e-4 * np.abs(y)
-        assert bad.sum() <= max(3, 0.03 * bad.size) and err.max() <= steps * 1e-3 + 1e-4, (k, bad.mean(), err.max())
+        report[k] = (float(f"{bad.mean():.3g}"), float(f"{err.max():.3g}"))
+    print(f"BC NatureCNN batch {B} x {steps} steps, adam eps {adam_eps}, oracle threads {oracle_threads}: (fraction outside the standard "
+          f"tolerance, worst deviation) per tensor:", report)
+    for k in ref:
+        x, y = got[k].astype(np.float64), ref[k].astype(np.float64)
+        err = np.abs(x - y)
+        bad = err > 5e-5 + 2e-4 * np.abs(y)
+        assert bad.sum() <= (max(3, frac_ok * bad.size) if frac_ok else 0) and err.max() <= worst_ok, (k, bad.mean(), err.max())
