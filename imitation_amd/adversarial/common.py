@@ -186,8 +186,12 @@ class AdversarialTrainer(abc.ABC):
                 norms.append(pol.features_extractor.normalize)
             for nrm in norms:
                 nrm.dp = self._dp
+            # (EMANorm keeps two more state tensors, `inv_learning_rate` and `num_batches`: without them in the broadcast
+            #  ranks that loaded different checkpoints would diverge at the first update)
+            extra = [t for nrm in norms for t in (getattr(nrm, "inv_learning_rate", None), getattr(nrm, "num_batches", None))
+                     if isinstance(t, th.Tensor)]
             self._dp.broadcast_(heads + [pol._flat] + [t for nrm in norms
-                                                       for t in (nrm.running_mean, nrm.running_var, nrm.count)])
+                                                       for t in (nrm.running_mean, nrm.running_var, nrm.count)] + extra)
             pol._sync_transposed()
 
         # ---- GAIL only: the discriminator update never reads the policy, so inside `train()` the

@@ -36,6 +36,13 @@ class RunningNorm(nn.Module):
         self.register_buffer("count", th.zeros((), dtype=th.int32))
         self.dp = None   # imitation_amd.distributed.DataParallel (set by the trainer): merge the moments of all ranks
 
+    def __getstate__(self):
+        # `th.save(net)` (save_reward_net) must not pickle the process-group handle: a net reloaded in a single process
+        # would otherwise call collectives without a group; the trainer sets `dp` again when it adopts a net
+        state = dict(self.__dict__)
+        state["dp"] = None
+        return state
+
     def reset_running_stats(self) -> None:
         self.running_mean.zero_()
         self.running_var.fill_(1)

@@ -60,6 +60,11 @@ class RunningNorm:
 
     is_chan = True   # Chan-merged statistics: what the fused updates' in-kernel merges implement (EMANorm: False)
 
+    def __getstate__(self):
+        state = dict(self.__dict__)   # (never pickle the process-group handle, see modules.RunningNorm.__getstate__)
+        state["dp"] = None
+        return state
+
     # -- nn.Module-like plumbing
     def train(self, mode: bool = True):
         self.training = mode

@@ -309,6 +309,7 @@ class ActorCriticPolicy:
         wait_fn = lib.ia_host_wait_i32
         state = {"posted": 0, "gone": False}
         total = T + 1 if last_val is not None else T    # steps the kernel stays for
+        stream_obj = th.cuda.current_stream()
 
         def post(t: int) -> None:
             ready_np[0] = t + 1
@@ -318,15 +319,17 @@ class ActorCriticPolicy:
             rc_ = wait_fn(done_ptr, nblk, t + 1, float(timeout_s) + 30.0)
             if rc_ == 0:
                 return True
+            # rc -1: the device left on its own time-out. rc 1: the host's own (longer) time-out -- the device clock only
+            # starts once the kernel runs, so a kernel still queued behind other work ends up here: abort it and take the
+            # same per-step fallback (the caller synchronises the stream, where the kernel -- started or not -- sees -1)
             ready_np[0] = -1
-            if rc_ == 1:
-                raise RuntimeError(f"rollout mailbox: step {t} was neither acknowledged nor given up by the device")
             state["gone"] = True        # (nothing left to abort)
             return False
 
         def close() -> None:
             if not state["gone"] and state["posted"] < total:
                 ready_np[0] = -1   # the kernel's workgroups leave at their next poll
+                stream_obj.synchronize()   # ... and HAVE left before anybody can hand these flags to a new launch
 
         return post, wait, close
 
@@ -366,9 +369,16 @@ class ActorCriticPolicy:
         return step
 
     def _mailbox_flags_for(self, nblk: int):
-        box = getattr(self, "_mailbox_flags", None)
-        if box is None or box[1].numel() != nblk:
-            box = self._mailbox_flags = (th.zeros(1, dtype=th.int32).pin_memory(), th.zeros(nblk, dtype=th.int32).pin_memory())
+        """A (ready, done) pair in pinned host memory, zeroed. Pairs ROTATE over three slots: a kernel that was told to
+        abort (`ready = -1`) keeps seeing that value in ITS pair however soon the next rollout starts (`close()` also waits
+        for it to leave; the rotation covers a `close()` that raised)."""
+        ring = getattr(self, "_mailbox_ring", None)
+        if ring is None or ring[0][1].numel() != nblk:
+            ring = self._mailbox_ring = [(th.zeros(1, dtype=th.int32).pin_memory(), th.zeros(nblk, dtype=th.int32).pin_memory())
+                                         for _ in range(3)]
+            self._mailbox_next = 0
+        box = ring[self._mailbox_next]
+        self._mailbox_next = (self._mailbox_next + 1) % len(ring)
         box[0].zero_()
         box[1].zero_()
         return box
@@ -393,16 +403,15 @@ class ActorCriticPolicy:
         L.check(rc, "ia_policy_logits_mailbox")
         ready_np, done_ptr, wait_fn = ready.numpy(), done.data_ptr(), lib.ia_host_wait_i32
         state = {"acked": 0}
+        stream_obj = th.cuda.current_stream()
 
         def post(t: int) -> None:
             ready_np[0] = t + 1
 
         def wait(t: int) -> bool:
             rc_ = wait_fn(done_ptr, nblk, t + 1, float(timeout_s) + 30.0)
-            if rc_ != 0:
+            if rc_ != 0:    # -1: the device's time-out; 1: the host's (kernel never started) -- same fallback, see above
                 ready_np[0] = -1
-                if rc_ == 1:
-                    raise RuntimeError(f"rollout mailbox: step {t} was neither acknowledged nor given up by the device")
                 state["acked"] = T
                 return False
             state["acked"] = t + 1
@@ -414,6 +423,7 @@ class ActorCriticPolicy:
         def close() -> None:
             if state["acked"] < T:
                 ready_np[0] = -1
+                stream_obj.synchronize()
 
         return post, wait, close
 

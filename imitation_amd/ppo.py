@@ -20,6 +20,7 @@ import os
 import sys
 import threading
 import time
+import warnings
 from typing import Any, Dict, Optional
 
 import numpy as np
@@ -43,6 +44,15 @@ def set_random_seed(seed: int) -> None:
 
 def _schedule(v):
     return v if callable(v) else (lambda _progress, _v=float(v): _v)
+
+
+def _has_user_step_hook(callback) -> bool:
+    """True when user code runs inside the rollout's step loop through `callback.on_step` (anything but the built-in
+    no-op, the reward-logging callback of `RewardVecEnvWrapper`, or lists of those)."""
+    from imitation_amd.wrappers import WrappedRewardCallback
+    if isinstance(callback, _CallbackList):
+        return any(_has_user_step_hook(c) for c in callback.cbs)
+    return not (type(callback) is _NullCallback or isinstance(callback, WrappedRewardCallback))
 
 
 class _NullCallback:
@@ -369,6 +379,12 @@ class PPO(OnPolicyAlgorithm):
         self.rollout_mailbox = os.environ.get("IA_ROLLOUT_MAILBOX", "1") != "0"
         self.rollout_mailbox_timeout_s = 120.0   # how long the resident kernel waits for ONE environment step before it
                                                  # leaves (the rollout then continues with per-step launches)
+        # ... and how long when user code runs inside the step loop (a `callback` with its own `on_step`, an arbitrary
+        # host `reward_fn`): a DEVICE-WIDE wait made there (torch.cuda.synchronize(), empty_cache(), the caching
+        # allocator's out-of-memory retry) cannot return before the resident kernel has left, i.e. stalls for this long
+        # (INTEGRATION.md "The rollout mailbox and device-wide waits"). After ANY device-side time-out the mailbox stays
+        # off for the rest of training.
+        self.rollout_mailbox_hooked_timeout_s = 5.0
         self.rollout_window_ms = None
         self.rollout_profile = None
         self._dp_obs = th.zeros(min(self.batch_size, total), p.obs_dim, device=self.device)
@@ -547,13 +563,16 @@ class PPO(OnPolicyAlgorithm):
         host_sampling = pol.samples_on_host  # Discrete head on the reference's torch.multinomial stream
         predrawn = False
         mailbox = None
+        hooked = _has_user_step_hook(callback) or (rw is not None and fused_net is None and module_net is None)
+        mb_timeout = min(self.rollout_mailbox_timeout_s, self.rollout_mailbox_hooked_timeout_s) if hooked \
+            else self.rollout_mailbox_timeout_s
         with th.cuda.stream(act_stream):
             if host_sampling:
                 rb.ensure_host_sampling_tiles(pol.act_dim)
                 act_step = pol.make_multinomial_step(rb.h_obs, rb.h_logits, rb.h_clip, rb.val, rb.h_logp)
                 if self.rollout_mailbox and hasattr(pol, "make_multinomial_mailbox"):
                     mailbox = pol.make_multinomial_mailbox(rb.h_obs, rb.h_logits, rb.h_clip, rb.val, rb.h_logp, T,
-                                                           timeout_s=self.rollout_mailbox_timeout_s)
+                                                           timeout_s=mb_timeout)
             else:
                 # The rollout's T Gaussian noise tiles in ONE draw at its start, when that is the same stream:
                 # `normal_()` on a contiguous [T, n, A] tensor consumes torch's generator exactly as T draws of
@@ -576,7 +595,7 @@ class PPO(OnPolicyAlgorithm):
                 # (`ActorCriticPolicy.make_rollout_mailbox`; None: shapes its kernel does not cover)
                 if self.rollout_mailbox and hasattr(pol, "make_rollout_mailbox"):
                     mailbox = pol.make_rollout_mailbox(rb.h_obs, noise_tile, rb.acts, rb.h_clip, rb.val, rb.logp, T,
-                                                       timeout_s=self.rollout_mailbox_timeout_s, last_val=rb.last_val)
+                                                       timeout_s=mb_timeout, last_val=rb.last_val)
         h_clip_np = rb.h_clip.numpy()
         try:
             return self._rollout_steps(env, callback, rb, T, n, pol, rw, bw, base, fused_net, module_net, act_step, mailbox,
@@ -625,8 +644,15 @@ class PPO(OnPolicyAlgorithm):
             t2 = tick() if prof is not None else 0.0
             if mailbox is not None and not mailbox[1](t):
                 # the resident kernel gave up waiting (an env step longer than its time-out): per-step launches from here
-                # on, this step included (the workgroups that did run it wrote the same values)
+                # on, this step included (the workgroups that did run it wrote the same values) -- and for the rest of
+                # training: whatever was slow (or made a device-wide wait that could only return once the kernel had
+                # left) will be there again next rollout
                 mailbox = None
+                if self.rollout_mailbox:
+                    self.rollout_mailbox = False
+                    warnings.warn("rollout mailbox: the resident act kernel timed out waiting for an environment step; "
+                                  "continuing with per-step launches for the rest of training "
+                                  "(PPO.rollout_mailbox = True re-enables it)", RuntimeWarning)
                 act_stream.synchronize()
                 with th.cuda.stream(act_stream):
                     act_step(t)
@@ -883,6 +909,10 @@ class PPO(OnPolicyAlgorithm):
         if dpg is None:
             early, self._perm_uploaded = self._perm_uploaded, None
             if not self._predraw.finish(perm):
+                if early is not None:
+                    # the speculative upload may still be reading the pinned buffer (and writing the device copy) this
+                    # branch is about to overwrite: let it finish first
+                    early.synchronize()
                 early = None
                 for e in range(self.n_epochs):  # one global-NumPy draw per epoch, as RolloutBuffer.get does
                     perm[e] = np.random.permutation(T * n)

@@ -155,7 +155,8 @@ def test_rollout_mailbox_equals_per_step_launches(tmp_path, case):
 
 def test_rollout_mailbox_survives_a_slow_environment_step(tmp_path):
     """The resident act kernel waits a bounded time for each step; an environment step that takes longer makes it leave,
-    and the rollout continues with per-step launches from that step on -- same values as an undisturbed run."""
+    and the rollout -- and the rest of training -- continues with per-step launches from that step on: same values as an
+    undisturbed run."""
     import time
 
     cfg = harness.CASES["gail_box"]
@@ -175,7 +176,11 @@ def test_rollout_mailbox_survives_a_slow_environment_step(tmp_path):
                 return _orig(actions)
 
             base.step_async = step_async
-        tr.train(3 * cfg["n_envs"] * cfg["n_steps"])
+            with pytest.warns(RuntimeWarning, match="rollout mailbox"):
+                tr.train(3 * cfg["n_envs"] * cfg["n_steps"])
+            assert algo.rollout_mailbox is False   # after a device-side time-out the mailbox stays off (per-step launches)
+        else:
+            tr.train(3 * cfg["n_envs"] * cfg["n_steps"])
         outs[slow] = harness.snapshot(tr)
     for k in outs[True]:
         assert np.array_equal(np.asarray(outs[True][k]), np.asarray(outs[False][k]), equal_nan=True), k

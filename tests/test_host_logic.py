@@ -569,3 +569,37 @@ def test_block_draw_of_interpolation_weights_equals_per_update_draws():
         th.manual_seed(11)
         seq = th.stack([th.rand(mb) for _ in range(n)])
         assert th.equal(block, seq), (n, mb)
+
+
+def test_user_step_hooks_shorten_the_mailbox_timeout():
+    """A device-wide wait made by user code inside the rollout's step loop cannot return before the resident act kernel
+    has left: with a user `on_step` callback attached the kernel's time-out is the short one."""
+    from imitation_amd import ppo
+    from imitation_amd.wrappers import WrappedRewardCallback
+
+    class Mine(ppo._NullCallback):
+        def on_step(self):
+            return True
+
+    assert not ppo._has_user_step_hook(ppo._NullCallback())
+    assert not ppo._has_user_step_hook(WrappedRewardCallback([]))
+    assert not ppo._has_user_step_hook(ppo._CallbackList([ppo._NullCallback(), WrappedRewardCallback([])]))
+    assert ppo._has_user_step_hook(Mine())
+    assert ppo._has_user_step_hook(ppo._CallbackList([WrappedRewardCallback([]), Mine()]))
+
+
+def test_norm_layers_do_not_pickle_the_process_group():
+    """`save_reward_net` pickles whole nets: the data-parallel handle must not travel with them."""
+    import pickle
+    from imitation_amd import modules, networks
+
+    class Handle:
+        world = 2
+
+        def __reduce__(self):
+            raise RuntimeError("process groups cannot be pickled")
+
+    for nrm in (modules.RunningNorm(3), modules.EMANorm(3), networks.RunningNorm(3), networks.EMANorm(3)):
+        nrm.dp = Handle()
+        back = pickle.loads(pickle.dumps(nrm))
+        assert back.dp is None and nrm.dp is not None
