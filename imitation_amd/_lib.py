@@ -171,6 +171,17 @@ _SIGS = {
     "ia_ppo_update_assume_cus": ([_I], C.c_int),
     "ia_ppo_update": ([C.POINTER(PolicyDesc), _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F,
                        _F, _F, _F, _P, _P, _D, _D, _D, _F, _L, _P, _P, _P], C.c_int),
+    "ia_ppo_update_sharded_ws_floats": ([C.POINTER(PolicyDesc), _I, _I], C.c_int64),
+    "ia_ppo_shard_recv_bytes": ([C.POINTER(PolicyDesc), _I], C.c_int64),
+    "ia_ppo_update_sharded": ([C.POINTER(PolicyDesc), _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F,
+                               _F, _F, _F, _P, _P, _D, _D, _D, _F, _L, _P, _P,
+                               _I, _I, C.c_uint32, _P, _P, _I, _D, _P], C.c_int),
+    "ia_peer_alloc": ([C.c_size_t, C.POINTER(C.c_void_p), C.POINTER(C.c_int)], C.c_int),
+    "ia_peer_free": ([_P], C.c_int),
+    "ia_peer_ipc_export": ([_P, _P], C.c_int),
+    "ia_peer_ipc_open": ([_P, C.POINTER(C.c_void_p)], C.c_int),
+    "ia_peer_ipc_close": ([_P], C.c_int),
+    "ia_peer_handshake": ([_I, _I, C.c_uint32, _P, _P, _D, _P, _P], C.c_int),
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGS)

@@ -1,6 +1,7 @@
 // Host-side helpers of the C ABI (no device code): index draws that must reproduce NumPy's
 // legacy global generator bit for bit, runnable off the Python thread (ctypes drops the GIL).
 #include <chrono>
+#include <cstring>
 #include <cstdint>
 #include <thread>
 #include <vector>
@@ -134,4 +135,90 @@ extern "C" int ia_host_wait_i32(const volatile int32_t* flags, int n, int target
         std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > timeout_s)
       return 1;
   }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Peer-mapped device memory for the row-sharded data-parallel PPO update (ia_ppo_update_sharded): each rank (one process
+// per GPU) owns one block -- receive area + flags + handshake words -- that every other rank writes into directly from
+// inside its persistent kernel (xGMI between GPUs; the same protocol between two processes on one GPU, which is how it is
+// tested on one-GPU boxes). The block is fine-grained (coherent at system scope, never cached in a remote L2) when the
+// runtime grants it, plain device memory otherwise; it is shared through hipIpc handles the ranks exchange over
+// torch.distributed. These are the ONLY entries of the library that allocate / map / free device memory or synchronise.
+extern "C" int ia_peer_alloc(size_t bytes, void** out, int* fine_grained) {
+  if (!out || bytes == 0) return IA_ERR_ARG;
+  void* p = nullptr;
+  int fine = 1;
+  hipError_t e = hipExtMallocWithFlags(&p, bytes, hipDeviceMallocFinegrained);
+  if (e != hipSuccess || p == nullptr) {
+    (void)hipGetLastError();
+    fine = 0;
+    e = hipMalloc(&p, bytes);
+    if (e != hipSuccess) return (int)e;
+  }
+  e = hipMemset(p, 0, bytes);
+  if (e != hipSuccess) return (int)e;
+  e = hipDeviceSynchronize();
+  if (e != hipSuccess) return (int)e;
+  *out = p;
+  if (fine_grained) *fine_grained = fine;
+  return IA_OK;
+}
+extern "C" int ia_peer_free(void* p) { return p ? (int)hipFree(p) : IA_OK; }
+extern "C" int ia_peer_ipc_export(void* p, unsigned char* handle64) {
+  static_assert(sizeof(hipIpcMemHandle_t) == 64, "hipIpcMemHandle_t is 64 bytes");
+  if (!p || !handle64) return IA_ERR_ARG;
+  hipIpcMemHandle_t h;
+  const hipError_t e = hipIpcGetMemHandle(&h, p);
+  if (e != hipSuccess) return (int)e;
+  memcpy(handle64, &h, 64);
+  return IA_OK;
+}
+extern "C" int ia_peer_ipc_open(const unsigned char* handle64, void** out) {
+  if (!handle64 || !out) return IA_ERR_ARG;
+  hipIpcMemHandle_t h;
+  memcpy(&h, handle64, 64);
+  void* p = nullptr;
+  const hipError_t e = hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess);
+  if (e != hipSuccess) return (int)e;
+  *out = p;
+  return IA_OK;
+}
+extern "C" int ia_peer_ipc_close(void* p) { return p ? (int)hipIpcCloseMemHandle(p) : IA_OK; }
+
+namespace {
+struct HsPeers { uint32_t* p[8]; };
+// One wave: write `token` into word [rank] of every rank's handshake area, then wait until all `world` words of the own
+// area carry it. result: 1 = every peer's write arrived (mapping, peer writes and system-scope polling all work), 0 = not.
+__global__ void peer_handshake_kernel(int world, int rank, uint32_t token, uint32_t* own, HsPeers peers,
+                                      long long timeout_ticks, int* result) {
+  const int lane = threadIdx.x;
+  if (lane == 0)
+    for (int r = 0; r < world; ++r) __hip_atomic_store(peers.p[r] + rank, token, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  const long long t0 = wall_clock64();
+  int ok = 0;
+  for (;;) {
+    const uint32_t v = __hip_atomic_load(own + (lane < world ? lane : 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (__all(lane >= world || v == token)) { ok = 1; break; }
+    __builtin_amdgcn_s_sleep(8);
+    if (wall_clock64() - t0 > timeout_ticks) break;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+  if (lane == 0) __hip_atomic_store(result, ok, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+}  // namespace
+
+// Enqueues the handshake on `stream`; `result` is one int the device can write (device or pinned host memory).
+extern "C" int ia_peer_handshake(int world, int rank, uint32_t token, uint32_t* own_words, uint32_t* const* peer_words,
+                                 double timeout_s, int* result, void* stream) {
+  if (world < 1 || world > 8 || rank < 0 || rank >= world || !own_words || !peer_words || !result || token == 0)
+    return IA_ERR_ARG;
+  HsPeers pp;
+  for (int r = 0; r < 8; ++r) {
+    pp.p[r] = r < world ? peer_words[r] : nullptr;
+    if (r < world && !pp.p[r]) return IA_ERR_ARG;
+  }
+  hipLaunchKernelGGL(peer_handshake_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, world, rank, token, own_words, pp,
+                     (long long)(timeout_s * 1e8), result);
+  IA_CHECK_LAUNCH();
+  return IA_OK;
 }

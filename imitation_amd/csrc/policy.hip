@@ -17,6 +17,7 @@
 #include "common.h"
 #include "rn_common.h"
 #include <algorithm>
+#include <cstring>
 
 #include "../../include/imitation_hip.h"
 
@@ -2032,10 +2033,13 @@ __device__ __forceinline__ void wave_sync_lds() {
 template <int KS1, bool LOCAL>
 __device__ __forceinline__ void mfma32_minibatch_chain(
     const ia_policy_desc& d, const float* __restrict__ nm, const float* __restrict__ nv, const float adv_mean,
-    const float adv_std, const MbRows rows, const int vblk, const int normalize_adv, const float clip,
+    const float adv_std, const MbRows rows, const int i0_in, const int row_lim, const int normalize_adv, const float clip,
     const float ent_coef, const float vf_coef, float* __restrict__ slab_g, float* __restrict__ statpart,
     float* __restrict__ lds_in, const float* __restrict__ sP_in, float* __restrict__ stg_in,
     const int opaque_zero, long long* __restrict__ tstamp) {
+  // `i0_in`: first minibatch row of this workgroup; `row_lim`: rows at or beyond it are not this workgroup's (the
+  // minibatch size, or -- row-sharded data parallelism -- the end of this rank's row range inside the global minibatch);
+  // means are over `rows.batch`, the whole (global) minibatch, either way
   float* __restrict__ lds = lds_in + opaque_zero;
   const float* __restrict__ stg = stg_in + opaque_zero;
   float* __restrict__ slab = LOCAL ? stg_in + opaque_zero + UpdStage::x : slab_g;
@@ -2046,14 +2050,14 @@ __device__ __forceinline__ void mfma32_minibatch_chain(
   const int batch = rows.batch;
   constexpr int H = 32;
   using L = CLds;
-#define IA_TS(slot) do { if (tstamp && vblk == 0 && threadIdx.x == 0) tstamp[slot] = clock64(); } while (0)
+#define IA_TS(slot) do { if (tstamp && i0_in == 0 && threadIdx.x == 0) tstamp[slot] = clock64(); } while (0)
   const int tid = threadIdx.x + opaque_zero, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int tw = wv >> 2, q = wv & 3;
   const int li = lane & 15, lk = lane >> 4;
   const int D = d.obs_dim, A = d.act_dim;
   const PolOff o = pol_offsets(D, A, H, d.discrete);
-  const int i0 = vblk * ROWS;
+  const int i0 = i0_in;
   const int aw = d.discrete ? 1 : A;
   const float invB = 1.f / (float)batch;
   const int S1 = (D + 3) >> 2, SA = (A + 3) >> 2;
@@ -2069,7 +2073,7 @@ __device__ __forceinline__ void mfma32_minibatch_chain(
   const int part = lane & 3;
   const int lrow = tw == 0 ? q * 16 + (lane >> 2) : q * 16 + (lane & 15);   // local row of this lane in the loss phase
   const bool loss_lane = tw == 0 || lane < 16;
-  const bool valid = (i0 + lrow) < batch;
+  const bool valid = (i0 + lrow) < row_lim;
   float r_oldlp = 0.f, r_adv = 0.f, r_ret = 0.f, r_act[4] = {0.f, 0.f, 0.f, 0.f};
   if (tw == 0) {   // staged by the prefetch (LDS-direct loads); unconditional, clamped
     r_oldlp = stg[UpdStage::oldlp + lrow];
@@ -2092,7 +2096,7 @@ __device__ __forceinline__ void mfma32_minibatch_chain(
     const int s1r = (65536 + S1 - 1) / S1;   // wave-uniform
     for (int g = l128; g < 16 * S1; g += 128) {
       const int r = (g * s1r) >> 16, k0 = (g - r * S1) * 4;
-      const bool rok = (i0 + rbase + r) < batch;
+      const bool rok = (i0 + rbase + r) < row_lim;
       float raw[4], mu[4], vr[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
@@ -2430,7 +2434,7 @@ __device__ __forceinline__ void mfma32_minibatch_chain(
   // MFMA with its two reads and exposes an LDS round trip per step).
   // (minibatches of <= 16 rows -- the reference's tuned AIRL configuration -- contract over the first four row steps
   //  only: the gradient rows past the minibatch are exact zeros, so the remaining twelve steps add nothing)
-  const bool few_rows = batch - i0 <= 16;   // wave-uniform
+  const bool few_rows = row_lim - i0 <= 16;   // wave-uniform
   auto outer16 = [&](const float* __restrict__ U, int us, int ucol, const float* __restrict__ V, int vs, int vcol) {
     f32x4 g = {0.f, 0.f, 0.f, 0.f};
     if (few_rows) {
@@ -2882,6 +2886,28 @@ struct UpdSched {
   int n_steps, first, n_mb, batch_size;
   long long total;
 };
+// Row-sharded data parallelism (template parameter SHARD of the persistent kernel): every rank runs
+// the single-GPU kernel on ITS rows [rank * rows_per_rank, ...) of each GLOBAL minibatch (the rollout tile, permutations
+// and minibatch statistics are the global ones on every rank), reduces its workgroups' slabs in one level exactly like the
+// single-GPU update, and exchanges one record per optimiser step -- its partial gradient (P4 floats) + its loss-statistic
+// sums (8 floats) -- by writing it straight into every rank's receive area (peer-mapped device memory: xGMI between GPUs,
+// hipIpc between processes) and raising a per-(source, piece) flag there; every workgroup then sums the `world` records
+// in rank order (identical on all ranks: replicas stay bit-identical), clips by the GLOBAL norm and applies Adam. All
+// hand-offs are system-scope: write-through stores, `vmcnt(0)`, block barrier, release + relaxed flag store | relaxed
+// polling, acquire, loads that bypass the caches. Flags carry a sequence number that only grows over the exchange
+// context's life (never reset: a peer may already be writing the next launch's first step), records are double-buffered
+// by step parity (a sender cannot be two steps ahead of a receiver: it needs that receiver's record of the step between).
+constexpr int SHARD_WORLD_MAX = 8;
+constexpr int SHARD_PIECES_MAX = 8;
+constexpr int SHARD_RB = 2;             // records read per batch (registers: SHARD_RB x parameters per thread x 2)     // a record travels to a peer in <= 8 pieces, each sent by another workgroup
+struct ShardArgs {
+  int world, rank, rows_per_rank, pieces;
+  int loopback;                         // cost model on one process: this rank stands in for every source rank in turn
+  unsigned seq_base;                    // step s of this launch carries sequence number seq_base + s + 1
+  long long timeout_ticks;              // 100 MHz ticks a workgroup waits for the peers' records of one step
+  unsigned long long* recv;                        // this rank's receive area: [2][world][P4 + 8] (value, sequence) words
+  unsigned long long* peer_recv[SHARD_WORLD_MAX];  // every rank's receive area as mapped into this process (own included)
+};
 struct UpdWs {
   unsigned* ctrl;
   float *tab;   // [2][UPD_MAX_STEPS]: Adam step size lr/(1-b1^t) and sqrt(1-b2^t) per step (host doubles)
@@ -3164,7 +3190,7 @@ __global__ __launch_bounds__(SPLIT ? 256 : 512) void ppo_epoch_persistent_kernel
 
 // TIMING = false (production): the phase-clock accumulators (24 VGPRs of `tacc` alone) and every stamp are
 // compiled out -- the measurement build is a separate instantiation picked only while ia_ppo_debug_timing is on.
-template <int NPT, bool TIMING, int KS1, bool LOCAL>
+template <int NPT, bool TIMING, int KS1, bool LOCAL, bool SHARD = false>
 __global__ __launch_bounds__(512) void ppo_update_persistent_kernel(
     ia_policy_desc d, float* __restrict__ P, float* __restrict__ Pt, float* __restrict__ m, float* __restrict__ v,
     float* __restrict__ nm, float* __restrict__ nv, int32_t* __restrict__ ncount, int update_norm,
@@ -3172,7 +3198,8 @@ __global__ __launch_bounds__(512) void ppo_update_persistent_kernel(
     const float* __restrict__ adv, const float* __restrict__ ret, const int64_t* __restrict__ perm, int T, int n_envs,
     int normalize_adv, float clip, float ent_coef, float vf_coef, float max_norm, float beta1, float beta2, float eps,
     float* __restrict__ ws, int nblk, int n_slices, float* __restrict__ stats, UpdSched sch, int xcd_pack,
-    long long* __restrict__ tstamp /* debug: [0..3] += 100 MHz ticks in {stat wait, minibatch, barrier, update} */) {
+    long long* __restrict__ tstamp /* debug: [0..3] += 100 MHz ticks in {stat wait, minibatch, barrier, update} */,
+    ShardArgs sh) {
   constexpr int H = 32;
   using L = CLds;
   extern __shared__ float lds[];
@@ -3198,6 +3225,9 @@ __global__ __launch_bounds__(512) void ppo_update_persistent_kernel(
   // schedule scalars in registers; the per-step tables are read straight from the kernel arguments
   const int sch_first = sch.first, sch_nmb = sch.n_mb, sch_bs = sch.batch_size, n_steps = sch.n_steps;
   const long long sch_total = sch.total;
+  // row-sharded data parallelism: this rank's rows of a (global) minibatch are [row_lo, row_lim(r))
+  const int row_lo = SHARD ? sh.rank * sh.rows_per_rank : 0;
+  auto row_lim = [&](const MbRows& r) { return SHARD ? min(r.batch, row_lo + sh.rows_per_rank) : r.batch; };
   auto rows_of = [=](int s) {
     const int gs = sch_first + s;
     const int e = gs / sch_nmb, mb = gs - e * sch_nmb;
@@ -3242,6 +3272,7 @@ __global__ __launch_bounds__(512) void ppo_update_persistent_kernel(
     // step q's partials and its (norm, coef) pair are published by barrier q+1's release fences.
     int q = 0;
     auto drain = [&](int upto /* exclusive */) {
+      if constexpr (SHARD) return;   // (gradient workgroup 0 writes them itself: it holds every rank's sums)
       for (; q < upto; ++q)
         write_loss_stats(q, *reinterpret_cast<const volatile float*>(w.normcoef + (q % UPD_SD) * 2),
                          *reinterpret_cast<const volatile float*>(w.normcoef + (q % UPD_SD) * 2 + 1));
@@ -3409,9 +3440,9 @@ __global__ __launch_bounds__(512) void ppo_update_persistent_kernel(
       asm volatile("s_mov_b32 %0, 0" : "=s"(tz));
       const unsigned Tq = (unsigned)(T + tz);
       const MbRows r = rows_of(s);
-      const int i0 = vb * ROWS;
+      const int i0 = row_lo + vb * ROWS;
       int src = 0;
-      if (i0 + lane < r.batch) {
+      if (i0 + lane < row_lim(r)) {
         const long long flat = r.idx[i0 + lane];
         if (sch_total < (1ll << 31)) {  // 32-bit divide (the 64-bit one is a long software sequence)
           const unsigned f = (unsigned)flat, env = f / Tq, t = f - env * Tq;
@@ -3538,9 +3569,9 @@ __global__ __launch_bounds__(512) void ppo_update_persistent_kernel(
     float* stat_base = w.statpart + (s % UPD_SD) * nblk * 8;
     int oz;
     asm volatile("s_mov_b32 %0, 0" : "=s"(oz));
-    mfma32_minibatch_chain<KS1, LOCAL>(d, slot, slot + MAXD, adv_mean, adv_std, r, vb, normalize_adv, clip, ent_coef,
-                                       vf_coef, slab_base + (long long)vb * w.P4, stat_base + vb * 8, lds, sP, stg, oz,
-                                       tstamp ? tstamp + 16 : nullptr);
+    mfma32_minibatch_chain<KS1, LOCAL>(d, slot, slot + MAXD, adv_mean, adv_std, r, row_lo + vb * ROWS, row_lim(r),
+                                       normalize_adv, clip, ent_coef, vf_coef, slab_base + (long long)vb * w.P4,
+                                       stat_base + vb * 8, lds, sP, stg, oz, tstamp ? tstamp + 16 : nullptr);
     // (the minibatch ends with a block barrier: every slab store of this block has been issued)
     UPD_TS(1);
     if (!local && tid == 0) {  // arrive first; the prefetch below overlaps the wait for the other blocks
@@ -3556,6 +3587,7 @@ __global__ __launch_bounds__(512) void ppo_update_persistent_kernel(
       asm volatile("s_mov_b32 %0, 0" : "=s"(gz));
 #pragma unroll
       for (int k = 0; k < NPT; ++k) g[k] = stg[UpdStage::x + gz + min(tid + k * 512, o.total - 1)];
+      if constexpr (SHARD) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the loss-statistic partials go into the record
       __syncthreads();
     }
     if (s + 1 < n_steps) {
@@ -3662,6 +3694,92 @@ __global__ __launch_bounds__(512) void ppo_update_persistent_kernel(
       if (!s_ok) return;
       sum_vectors(part_base, ngrp);
     }
+    if constexpr (SHARD) {
+      // ---- exchange: g = this rank's partial gradient (identical in all of its workgroups) -> every rank's sum.
+      // Every value travels as ONE 8-byte word (float bits, sequence number of the step): a naturally aligned 8-byte store
+      // arrives whole, so the receiver needs no separate flag, the sender no acknowledgement wait, fence or flag store --
+      // one one-way trip per step (the LL protocol of RCCL, which relies on the same 8-byte atomicity over xGMI).
+      const int W = sh.world, J = sh.pieces;
+      const unsigned seq = sh.seq_base + (unsigned)s + 1u;
+      const int REC = w.P4 + 8;
+      const int kp = (NPT + J - 1) / J;              // per-thread parameter slots per piece
+      auto pack = [&](float v) { return ((unsigned long long)seq << 32) | (unsigned long long)__float_as_uint(v); };
+      // (1) send: pair (peer p, piece j) = index p * J + j, dealt round-robin over this rank's workgroups
+      for (int qi = vb; qi < W * J; qi += nblk) {    // (workgroup-uniform)
+        const int p = qi / J, j = qi - p * J;
+        const int src = sh.loopback ? p : sh.rank;
+        unsigned long long* dst = sh.peer_recv[p] + (long long)((s & 1) * W + src) * REC;
+#pragma unroll
+        for (int k = 0; k < NPT; ++k) {
+          const int i = tid + k * 512;
+          if (k / kp == j && i < o.total) __hip_atomic_store(dst + i, pack(g[k]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        if (j == 0 && tid < 64) {
+          // tail: this rank's loss-statistic sums (write-through partials of its workgroups). Lane (b8, k) = (lane >> 3,
+          // lane & 7) loads the partials of workgroups b8, b8 + 8, ... all at once (one L2 round trip per eight workgroups, not
+          // one per workgroup), then the eight lane groups fold in a fixed order.
+          float st = 0.f;
+          for (int b0 = 0; b0 < nblk; b0 += 8) {
+            const int b = b0 + (lane >> 3);
+            const float v = __hip_atomic_load(stat_base + min(b, nblk - 1) * 8 + (lane & 7), __ATOMIC_RELAXED,
+                                              __HIP_MEMORY_SCOPE_AGENT);
+            st += (b < nblk && (lane & 7) < 5) ? v : 0.f;
+          }
+          st += __shfl_down(st, 8, 64);
+          st += __shfl_down(st, 16, 64);
+          st += __shfl_down(st, 32, 64);
+          if (lane < 8) __hip_atomic_store(dst + w.P4 + lane, pack(st), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+      }
+      // (2) receive: the records in rank order, SHARD_RB at a time (SHARD_RB x NPT 8-byte loads in flight, all of them
+      // past the caches); a thread spins on its own elements until every one carries this step's sequence number. A peer can
+      // be one step ahead -- it then writes the OTHER parity's records -- never two (it needs this rank's record of the
+      // step between).
+      const unsigned long long* rbase = sh.recv + (long long)((s & 1) * W) * REC;
+#pragma unroll
+      for (int k = 0; k < NPT; ++k) g[k] = 0.f;
+      bool fail = false;
+      const long long t0 = wall_clock64();
+      for (int r0 = 0; r0 < W && !fail; r0 += SHARD_RB) {
+        unsigned long long t[SHARD_RB][NPT];
+        int ez;   // opaque zero: element offsets are re-formed per batch instead of living across the step
+        asm volatile("s_mov_b32 %0, 0" : "=s"(ez));
+        for (unsigned it = 0;;) {
+#pragma unroll
+          for (int u = 0; u < SHARD_RB; ++u)
+#pragma unroll
+            for (int k = 0; k < NPT; ++k)   // (unconditional loads at clamped record indices: see "a load behind a branch")
+              t[u][k] = __hip_atomic_load(rbase + (unsigned)min(r0 + u, W - 1) * (unsigned)REC +
+                                              (unsigned)min(tid + ez + k * 512, o.total - 1),
+                                          __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          __builtin_amdgcn_sched_barrier(0);
+          bool ok = true;
+#pragma unroll
+          for (int u = 0; u < SHARD_RB; ++u)
+#pragma unroll
+            for (int k = 0; k < NPT; ++k) ok = ok && (unsigned)(t[u][k] >> 32) == seq;
+          if (ok) break;
+          __builtin_amdgcn_s_sleep(1);
+          if ((++it & 255u) == 0 &&
+              (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) || wall_clock64() - t0 > sh.timeout_ticks)) {
+            fail = true;
+            break;
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < SHARD_RB; ++u)
+          if (r0 + u < W) {   // (workgroup-uniform)
+#pragma unroll
+            for (int k = 0; k < NPT; ++k) g[k] += __uint_as_float((unsigned)t[u][k]);
+          }
+      }
+      if (fail) {
+        __hip_atomic_store(err, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_ok = 0;
+      }
+      __syncthreads();   // (s_ok was set to 1 by the grid wait above -- or, one workgroup, is set here)
+      if (!s_ok) return;
+    }
 #pragma unroll
     for (int k = 0; k < NPT; ++k) {
       if (tid + k * 512 >= o.total) g[k] = 0.f;
@@ -3674,7 +3792,32 @@ __global__ __launch_bounds__(512) void ppo_update_persistent_kernel(
     UPD_TS(5);
     const float total_norm = sqrtf(total_sq);
     const float coef = fminf(max_norm / (total_norm + 1e-6f), 1.0f);  // torch clip_grad_norm_
-    if (vb == 0) {
+    if constexpr (SHARD) {
+      if (vb == 0 && tid < 64 && stats) {   // every rank's sums are in the step's records: same rows as write_loss_stats
+        const unsigned long long* rbase = sh.recv + (long long)((s & 1) * sh.world) * (w.P4 + 8) + w.P4;
+        const unsigned seq = sh.seq_base + (unsigned)s + 1u;
+        // lane (rank, k) = (lane >> 3, lane & 7) takes that rank's sum k: ONE round trip for all ranks (the tails travel
+        // with piece 0 of each record; the wait is bounded like every other), then the ranks fold in rank order
+        const int rk = min(lane >> 3, sh.world - 1);
+        unsigned long long tv;
+        const long long t0 = wall_clock64();
+        do {
+          tv = __hip_atomic_load(rbase + rk * (w.P4 + 8) + (lane & 7), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        } while (!__all((unsigned)(tv >> 32) == seq) && wall_clock64() - t0 < sh.timeout_ticks);
+        float st = (lane >> 3) < sh.world ? __uint_as_float((unsigned)tv) : 0.f;
+        {
+          float acc = __shfl(st, lane & 7, 64);
+          for (int r_ = 1; r_ < sh.world; ++r_) acc += __shfl(st, r_ * 8 + (lane & 7), 64);
+          st = acc * (1.f / (float)r.batch);
+        }
+        const float st0 = __shfl(st, 0, 64), st1 = __shfl(st, 1, 64), st2 = __shfl(st, 2, 64);
+        float* so = stats + (long long)(sch_first + s) * 8;
+        if (lane < 5) so[lane] = st;
+        if (lane == 5) so[5] = st0 + ent_coef * st2 + vf_coef * st1;
+        if (lane == 6) so[6] = total_norm;
+        if (lane == 7) so[7] = coef;
+      }
+    } else if (vb == 0) {
       if (s + 1 < n_steps) {  // the statistics block writes this step's loss statistics later
         if (tid == 0) {   // (write-through: the local form's arrive has no release fence ahead of it)
           slab_store(w.normcoef + (s % UPD_SD) * 2, total_norm);
@@ -4320,16 +4463,27 @@ inline size_t upd_grad_lds_bytes(int P4, int aw) {
 
 // Workspace of ia_ppo_update in floats; 0 when the persistent kernel does not cover the shape
 // (the caller then runs ia_ppo_epoch per epoch).
-int64_t ia_ppo_update_ws_floats(const ia_policy_desc* d, int batch_size) {
-  if (!pol_ok(d) || batch_size <= 0) return IA_ERR_ARG;
+static int64_t upd_ws_floats(const ia_policy_desc* d, int batch_size, int world) {
+  if (!pol_ok(d) || batch_size <= 0 || world < 1 || world > SHARD_WORLD_MAX) return IA_ERR_ARG;
   const int P = pol_offsets(d->obs_dim, d->act_dim, d->hidden, d->discrete).total;
   const int nblk = cdiv(batch_size, ROWS);
   const int P4 = (P + 3) & ~3;
   if (d->hidden != 32 || P > UPD_NPT_WIDE * 512 || upd_grad_lds_bytes(P4, d->discrete ? 1 : d->act_dim) > 160 * 1024 || nblk > UPD_NBLK_MAX ||
-      cdiv(batch_size, UPD_SLICE) > UPD_SLICES_MAX || g_ppo_valu)
+      cdiv((long long)batch_size * world, UPD_SLICE) > UPD_SLICES_MAX || g_ppo_valu)
     return 0;
   return UPD_CTRL + 2 * UPD_MAX_STEPS + UPD_RING * UPD_RS + UPD_SD * 2 + UPD_SD * (int64_t)nblk * 8 +
          2 * (int64_t)nblk * P4 + 2 * (int64_t)UPD_GROUPS_MAX * P4 + (int64_t)UPD_RING * UPD_SLICES_MAX * UPD_PRS;
+}
+int64_t ia_ppo_update_ws_floats(const ia_policy_desc* d, int batch_size) { return upd_ws_floats(d, batch_size, 1); }
+// Row-sharded data-parallel update (ia_ppo_update_sharded): workspace for `rows_per_rank` rows of each global minibatch of
+// world x rows_per_rank rows (0: shape not covered), and the size of a rank's receive area.
+int64_t ia_ppo_update_sharded_ws_floats(const ia_policy_desc* d, int rows_per_rank, int world) {
+  return upd_ws_floats(d, rows_per_rank, world);
+}
+int64_t ia_ppo_shard_recv_bytes(const ia_policy_desc* d, int world) {
+  if (!pol_ok(d) || world < 1 || world > SHARD_WORLD_MAX) return IA_ERR_ARG;
+  const int P = pol_offsets(d->obs_dim, d->act_dim, d->hidden, d->discrete).total;
+  return 2 * (int64_t)world * (((P + 3) & ~3) + 8) * (int64_t)sizeof(unsigned long long);
 }
 
 bool g_upd_xcd_pack = false;
@@ -4345,20 +4499,24 @@ int ia_ppo_update_assume_cus(int n) { g_upd_assume_cus = n; return IA_OK; }
 // RolloutBuffer.get order), in ONE persistent launch per <= UPD_MAX_STEPS optimiser steps.
 // stats: [n_epochs * n_minibatches][8] or NULL. ws must be zero-initialised once by the caller;
 // word 8 of it is a sticky error flag (non-zero: a grid wait timed out, results invalid).
-int ia_ppo_update(const ia_policy_desc* d, float* params, float* params_t, float* norm_mean, float* norm_var,
+// `shard` (ia_ppo_update_sharded): `batch_size` is the rank's rows per minibatch, `n_envs` the global tile's width; the
+// schedule (minibatch size world x batch_size, statistics slices) is the global one, the gradient workgroups are the rank's.
+static int ppo_update_launch(const ia_policy_desc* d, float* params, float* params_t, float* norm_mean, float* norm_var,
                   int32_t* norm_count, int update_norm, const float* obs, const float* actions, const float* old_logp,
                   const float* advantages, const float* returns, const int64_t* perm, int n_epochs, int T, int n_envs,
                   int batch_size, int normalize_adv, float clip_range, float ent_coef, float vf_coef,
                   float max_grad_norm, float* exp_avg, float* exp_avg_sq, double lr, double beta1, double beta2,
-                  float adam_eps, int64_t adam_steps_done, float* ws, float* stats, void* stream) {
-  if (!pol_ok(d) || batch_size <= 0 || n_epochs <= 0 || ia_ppo_update_ws_floats(d, batch_size) <= 0) return IA_ERR_ARG;
+                  float adam_eps, int64_t adam_steps_done, float* ws, float* stats, void* stream, const ShardArgs* shard) {
+  const int world = shard ? shard->world : 1;
+  if (!pol_ok(d) || batch_size <= 0 || n_epochs <= 0 || upd_ws_floats(d, batch_size, world) <= 0) return IA_ERR_ARG;
   const long long total = (long long)T * n_envs;
-  const int n_mb = cdiv(total, batch_size);
+  const int batch_global = batch_size * world;
+  const int n_mb = cdiv(total, batch_global);
   const int nblk = cdiv(batch_size, ROWS);
   const int P = pol_offsets(d->obs_dim, d->act_dim, 32, d->discrete).total;
   const int P4 = (P + 3) & ~3;
   const size_t grad_bytes = upd_grad_lds_bytes(P4, d->discrete ? 1 : d->act_dim);
-  const size_t prep_bytes = (PREP_LDS_FLOATS + (size_t)nblk * ROWS) * sizeof(float);  // + row offsets
+  const size_t prep_bytes = (PREP_LDS_FLOATS + (size_t)cdiv(batch_global, ROWS) * ROWS) * sizeof(float);  // + row offsets
   const size_t bytes = grad_bytes > prep_bytes ? grad_bytes : prep_bytes;
   const bool wide = P > UPD_NPT * 512;
   const bool timing = g_tstamp != nullptr;
@@ -4368,7 +4526,7 @@ int ia_ppo_update(const ia_policy_desc* d, float* params, float* params_t, float
   // one gradient workgroup whose parameter vector fits the consumed part of the staging area: the gradient stays in LDS
   const bool local = nblk == 1 && P4 <= UpdStage::nxt;
   using KernelT = decltype(&ppo_update_persistent_kernel<UPD_NPT, false, 8, false>);
-  static const KernelT kernels[16] = {
+  static const KernelT kernels[24] = {
       ppo_update_persistent_kernel<UPD_NPT, false, 8, false>,      ppo_update_persistent_kernel<UPD_NPT, false, 16, false>,
       ppo_update_persistent_kernel<UPD_NPT, true, 8, false>,       ppo_update_persistent_kernel<UPD_NPT, true, 16, false>,
       ppo_update_persistent_kernel<UPD_NPT_WIDE, false, 8, false>, ppo_update_persistent_kernel<UPD_NPT_WIDE, false, 16, false>,
@@ -4376,10 +4534,15 @@ int ia_ppo_update(const ia_policy_desc* d, float* params, float* params_t, float
       ppo_update_persistent_kernel<UPD_NPT, false, 8, true>,       ppo_update_persistent_kernel<UPD_NPT, false, 16, true>,
       ppo_update_persistent_kernel<UPD_NPT, true, 8, true>,        ppo_update_persistent_kernel<UPD_NPT, true, 16, true>,
       ppo_update_persistent_kernel<UPD_NPT_WIDE, false, 8, true>,  ppo_update_persistent_kernel<UPD_NPT_WIDE, false, 16, true>,
-      ppo_update_persistent_kernel<UPD_NPT_WIDE, true, 8, true>,   ppo_update_persistent_kernel<UPD_NPT_WIDE, true, 16, true>};
-  const int vi_k = local * 8 + wide * 4 + timing * 2 + ks16;
+      ppo_update_persistent_kernel<UPD_NPT_WIDE, true, 8, true>,   ppo_update_persistent_kernel<UPD_NPT_WIDE, true, 16, true>,
+      // row-sharded data parallelism (no phase-clock build): [16 + local * 4 + wide * 2 + ks16]
+      ppo_update_persistent_kernel<UPD_NPT, false, 8, false, true>,      ppo_update_persistent_kernel<UPD_NPT, false, 16, false, true>,
+      ppo_update_persistent_kernel<UPD_NPT_WIDE, false, 8, false, true>, ppo_update_persistent_kernel<UPD_NPT_WIDE, false, 16, false, true>,
+      ppo_update_persistent_kernel<UPD_NPT, false, 8, true, true>,       ppo_update_persistent_kernel<UPD_NPT, false, 16, true, true>,
+      ppo_update_persistent_kernel<UPD_NPT_WIDE, false, 8, true, true>,  ppo_update_persistent_kernel<UPD_NPT_WIDE, false, 16, true, true>};
+  const int vi_k = shard ? 16 + local * 4 + wide * 2 + ks16 : local * 8 + wide * 4 + timing * 2 + ks16;
   const KernelT kernel = kernels[vi_k];
-  static size_t attr_bytes[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  static size_t attr_bytes[24] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   if (bytes > attr_bytes[vi_k]) {
     const int rc = set_lds(kernel, bytes);
     if (rc) return rc;
@@ -4391,7 +4554,7 @@ int ia_ppo_update(const ia_policy_desc* d, float* params, float* params_t, float
   for (int first = 0; first < steps_total; first += UPD_MAX_STEPS) {
     UpdSched sch;
     sch.n_steps = steps_total - first < UPD_MAX_STEPS ? steps_total - first : UPD_MAX_STEPS;
-    sch.first = first; sch.n_mb = n_mb; sch.batch_size = batch_size; sch.total = total;
+    sch.first = first; sch.n_mb = n_mb; sch.batch_size = batch_global; sch.total = total;
     // Adam's per-step scalars, formed in double on the host exactly as torch.optim.Adam does, staged
     // through a small ring of pinned buffers (a slot is reused only after its copy has completed).
     HostTab& ht = g_host_tab[g_host_tab_next];
@@ -4426,7 +4589,7 @@ int ia_ppo_update(const ia_policy_desc* d, float* params, float* params_t, float
     // each, merged in order by the statistics block. (One block needs 22 us for the gathered moments of a
     // 1024-row minibatch -- as long as a whole gradient step, so the chain kept waiting 1-2 us per step for
     // it; two slices + merge take ~14 us and the ring runs ahead again.)
-    const int n_slices = (batch_size > UPD_SLICE && total < (1ll << 31)) ? cdiv(batch_size, UPD_SLICE) : 0;
+    const int n_slices = (batch_global > UPD_SLICE && total < (1ll << 31)) ? cdiv(batch_global, UPD_SLICE) : 0;
     const bool pack = g_upd_xcd_pack && nblk + 1 + n_slices <= 32;
     const int grid = (nblk + 1 + n_slices) * (pack ? 8 : 1);
     {
@@ -4434,8 +4597,9 @@ int ia_ppo_update(const ia_policy_desc* d, float* params, float* params_t, float
       // (and a cooperative launch costs +15-19 us per launch, MI355X_MICROARCH.md "coop-launch"), so the same
       // test is made here: workgroups per CU by the occupancy query (LDS-bound: one) times the CU count.
       // Not enough room -> IA_ERR_UNSUPPORTED, the caller runs ia_ppo_epoch (two launches per minibatch).
-      static int dev_cus = 0, per_cu[16] = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1};
-      static size_t per_cu_bytes[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+      static int dev_cus = 0, per_cu[24] = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1,
+                                            -1, -1, -1, -1, -1, -1, -1, -1};
+      static size_t per_cu_bytes[24] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
       const int vi = vi_k;
       if (dev_cus == 0) {
         int dev = 0;
@@ -4454,13 +4618,66 @@ int ia_ppo_update(const ia_policy_desc* d, float* params, float* params_t, float
       }
       if ((long long)per_cu[vi] * cu_count < (pack ? grid / 8 : grid)) return IA_ERR_UNSUPPORTED;
     }
+    ShardArgs sa;
+    if (shard) {
+      sa = *shard;
+      sa.seq_base = shard->seq_base + (unsigned)first;
+    } else {
+      memset(&sa, 0, sizeof(sa));
+    }
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(512), bytes, st, *d, params, params_t, exp_avg,
                        exp_avg_sq, norm_mean, norm_var, norm_count, update_norm, obs, actions, old_logp, advantages,
                        returns, perm, T, n_envs, normalize_adv, clip_range, ent_coef, vf_coef, max_grad_norm,
-                       (float)beta1, (float)beta2, adam_eps, ws, nblk, n_slices, stats, sch, pack ? 1 : 0, g_tstamp);
+                       (float)beta1, (float)beta2, adam_eps, ws, nblk, n_slices, stats, sch, pack ? 1 : 0, g_tstamp, sa);
     IA_CHECK_LAUNCH();
   }
   return IA_OK;
+}
+
+int ia_ppo_update(const ia_policy_desc* d, float* params, float* params_t, float* norm_mean, float* norm_var,
+                  int32_t* norm_count, int update_norm, const float* obs, const float* actions, const float* old_logp,
+                  const float* advantages, const float* returns, const int64_t* perm, int n_epochs, int T, int n_envs,
+                  int batch_size, int normalize_adv, float clip_range, float ent_coef, float vf_coef,
+                  float max_grad_norm, float* exp_avg, float* exp_avg_sq, double lr, double beta1, double beta2,
+                  float adam_eps, int64_t adam_steps_done, float* ws, float* stats, void* stream) {
+  return ppo_update_launch(d, params, params_t, norm_mean, norm_var, norm_count, update_norm, obs, actions, old_logp,
+                           advantages, returns, perm, n_epochs, T, n_envs, batch_size, normalize_adv, clip_range, ent_coef,
+                           vf_coef, max_grad_norm, exp_avg, exp_avg_sq, lr, beta1, beta2, adam_eps, adam_steps_done, ws,
+                           stats, stream, nullptr);
+}
+
+// The same [SB3 PPO.train] with each GLOBAL minibatch's rows sharded over `world` ranks (one process per GPU): `obs` ...
+// `returns` are the all-gathered rollout tile [T, n_envs] (n_envs = world x the rank's environments), `perm` the
+// permutations every rank shares, `rows_per_rank` the rank's rows of each minibatch of world x rows_per_rank rows.
+// `recv`: this rank's receive area (ia_ppo_shard_recv_bytes), zeroed once at allocation and never again; `peer_recv[r]`:
+// rank r's area as mapped into this process (own included). `seq_base`: optimiser steps exchanged through these areas so
+// far (the same on every rank; it must only ever grow). Every rank must launch the same sequence of updates. `loopback` (tools: the cost of a world-W step on one
+// process): every peer area is this process's own and the rank writes its record once per source rank.
+int ia_ppo_update_sharded(const ia_policy_desc* d, float* params, float* params_t, float* norm_mean, float* norm_var,
+                          int32_t* norm_count, int update_norm, const float* obs, const float* actions,
+                          const float* old_logp, const float* advantages, const float* returns, const int64_t* perm,
+                          int n_epochs, int T, int n_envs, int rows_per_rank, int normalize_adv, float clip_range,
+                          float ent_coef, float vf_coef, float max_grad_norm, float* exp_avg, float* exp_avg_sq, double lr,
+                          double beta1, double beta2, float adam_eps, int64_t adam_steps_done, float* ws, float* stats,
+                          int world, int rank, uint32_t seq_base, void* recv, void* const* peer_recv, int loopback,
+                          double timeout_s, void* stream) {
+  if (world < 1 || world > SHARD_WORLD_MAX || rank < 0 || rank >= world || !recv || !peer_recv) return IA_ERR_ARG;
+  ShardArgs sa;
+  sa.world = world; sa.rank = rank; sa.rows_per_rank = rows_per_rank; sa.loopback = loopback != 0;
+  const int nblk = cdiv(rows_per_rank, ROWS);
+  int J = nblk / world;
+  sa.pieces = J < 1 ? 1 : (J > SHARD_PIECES_MAX ? SHARD_PIECES_MAX : J);
+  sa.seq_base = seq_base;
+  sa.timeout_ticks = (long long)(timeout_s * 1e8);
+  sa.recv = static_cast<unsigned long long*>(recv);
+  for (int r = 0; r < SHARD_WORLD_MAX; ++r) {
+    sa.peer_recv[r] = r < world ? static_cast<unsigned long long*>(peer_recv[r]) : nullptr;
+    if (r < world && !sa.peer_recv[r]) return IA_ERR_ARG;
+  }
+  return ppo_update_launch(d, params, params_t, norm_mean, norm_var, norm_count, update_norm, obs, actions, old_logp,
+                           advantages, returns, perm, n_epochs, T, n_envs, rows_per_rank, normalize_adv, clip_range,
+                           ent_coef, vf_coef, max_grad_norm, exp_avg, exp_avg_sq, lr, beta1, beta2, adam_eps,
+                           adam_steps_done, ws, stats, stream, &sa);
 }
 
 }  // extern "C"

@@ -106,3 +106,107 @@ def merge_moments_reference(means: th.Tensor, m2s: th.Tensor, counts: th.Tensor)
         m_acc = m_acc + dlt * nb / tot
         n_acc = tot
     return m_acc, M2 / n_acc
+
+
+class PeerExchange:
+    """Peer-mapped exchange areas of the row-sharded data-parallel PPO update (`ia_ppo_update_sharded`).
+
+    Every rank owns ONE block of device memory -- receive area `[2][world][P4 + 8]` 8-byte (value, sequence) words,
+    16 handshake words -- that all ranks write into from inside their persistent PPO kernels: xGMI between
+    GPUs, the same protocol between processes sharing a GPU (how it is tested on one-GPU boxes). The ranks exchange
+    hipIpc handles of their blocks over `torch.distributed`, map each other's blocks, and prove the path with a
+    handshake kernel (every rank writes a token into every rank's block and waits for everybody's token in its own);
+    `ok` is the ranks' common verdict -- False sends the trainer back to the replicated update. `seq` counts the
+    optimiser steps exchanged so far (flags carry it; it never goes back).
+
+    `PeerExchange.loopback(world, ...)`: a single process standing in for `world` ranks (every "peer" is the own
+    block; the record is written `world` times and summed `world` times) -- the cost model of `tools/dp_overhead.py`."""
+
+    HS_WORDS = 16
+
+    def __init__(self, dp: Optional[DataParallel], desc, world: Optional[int] = None, rank: int = 0,
+                 handshake_timeout_s: float = 20.0):
+        import ctypes as C
+        from imitation_amd import _lib as L
+        lib = L.load()
+        self.dp = dp
+        self.loop = dp is None or world is not None
+        self.world = int(world if world is not None else dp.world)
+        self.rank = int(rank if self.loop else dp.rank)
+        self.recv_bytes = int(lib.ia_ppo_shard_recv_bytes(C.byref(desc), self.world))
+        self.base, self.fine_grained, self.seq, self._opened = 0, False, 0, []
+        # Every rank walks through the SAME collectives whatever fails locally (a rank that skipped one would hang the
+        # others); `good` collects the local verdict and the last all-reduce makes it common.
+        good = self.recv_bytes > 0
+        nbytes = max(self.recv_bytes, 0) + 4 * self.HS_WORDS
+        if good:
+            base, fine = C.c_void_p(), C.c_int(0)
+            good = lib.ia_peer_alloc(nbytes, C.byref(base), C.byref(fine)) == 0 and bool(base.value)
+            if good:
+                self.base, self.fine_grained = int(base.value), bool(fine.value)
+        bases = [self.base] * self.world
+        if not self.loop:
+            handle = (C.c_ubyte * 64)()
+            if good:
+                good = lib.ia_peer_ipc_export(self.base, handle) == 0
+            mine = th.tensor(list(handle) + [1 if good else 0], dtype=th.uint8)
+            allh = dp.all_gather_flat(mine if dp._stage else mine.cuda()).cpu().reshape(self.world, 65)
+            good = good and bool(allh[:, 64].all())
+            for r in range(self.world):
+                if r == self.rank or not good:
+                    continue
+                buf = (C.c_ubyte * 64)(*allh[r, :64].tolist())
+                out = C.c_void_p()
+                if lib.ia_peer_ipc_open(buf, C.byref(out)) != 0 or not out.value:
+                    good = False
+                    continue
+                bases[r] = int(out.value)
+                self._opened.append(bases[r])
+        off_hs = self.recv_bytes
+        arr = C.c_void_p * 8
+        self.recv = self.base
+        self.peer_recv = arr(*([b for b in bases] + [None] * (8 - self.world)))
+        self._peer_hs = arr(*([b + off_hs for b in bases] + [None] * (8 - self.world)))
+        self._hs = self.base + off_hs
+        self.ok = self._handshake(handshake_timeout_s, good)
+
+    @classmethod
+    def loopback(cls, world: int, desc) -> "PeerExchange":
+        return cls(None, desc, world=world, rank=0)
+
+    def _handshake(self, timeout_s: float, good: bool) -> bool:
+        from imitation_amd import _lib as L
+        if self.loop:
+            return good
+        import torch.distributed as dist_
+        # (1) everybody has mapped everybody (or given up) before anybody writes into a peer's block
+        ok = th.tensor([1 if good else 0], dtype=th.int32)
+        buf = ok if self.dp._stage else ok.cuda()
+        dist_.all_reduce(buf, op=dist_.ReduceOp.MIN, group=self.dp.group)
+        if int(buf.cpu()[0]) != 1:
+            return False
+        # (2) the handshake kernel on every rank, then the common verdict
+        res = th.zeros(1, dtype=th.int32).pin_memory()
+        rc = L.load().ia_peer_handshake(self.world, self.rank, 1, self._hs, self._peer_hs, float(timeout_s),
+                                        res.data_ptr(), L.stream())
+        th.cuda.current_stream().synchronize()
+        ok = th.tensor([1 if (rc == 0 and int(res[0]) == 1) else 0], dtype=th.int32)
+        buf = ok if self.dp._stage else ok.cuda()
+        dist_.all_reduce(buf, op=dist_.ReduceOp.MIN, group=self.dp.group)
+        return int(buf.cpu()[0]) == 1
+
+    def take_steps(self, n: int) -> int:
+        """Sequence base of a launch of `n` optimiser steps (every rank makes the same launches)."""
+        base = self.seq
+        self.seq += int(n)
+        return base
+
+    def close(self) -> None:
+        from imitation_amd import _lib as L
+        lib = L.load()
+        for p in self._opened:
+            lib.ia_peer_ipc_close(p)
+        self._opened = []
+        if self.base:
+            lib.ia_peer_free(self.base)
+            self.base = 0

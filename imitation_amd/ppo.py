@@ -395,6 +395,12 @@ class PPO(OnPolicyAlgorithm):
         self._fin_stream = None
         self.dp_batch_moments = True  # False: exchange the feature-norm moments once per minibatch (tests)
         self.dp_global_minibatch = True  # False: per-minibatch gradient all-reduce (`_train_data_parallel`)
+        # Data-parallel update on the global minibatch, ROWS SHARDED over the ranks (default): each rank's persistent kernel
+        # takes its `batch_size` rows of every world x batch_size-row minibatch and the ranks exchange one 14 KB record per
+        # optimiser step inside the kernels through peer-mapped memory (`distributed.PeerExchange`, `ia_ppo_update_sharded`).
+        # False -- or a failed peer handshake -- runs the whole global minibatch redundantly on every rank instead.
+        self.dp_row_sharded = os.environ.get("IA_DP_ROW_SHARDED", "1") != "0"
+        self.dp_exchange_timeout_s = 30.0   # a rank waits this long for a peer's record of ONE optimiser step
 
     @property
     def logger(self):
@@ -785,7 +791,20 @@ class PPO(OnPolicyAlgorithm):
             else:
                 dev, cols = self.device, pol.obs_dim + aw + 3
                 perm_host = th.zeros(self.n_epochs, W * T * n, dtype=th.int64).pin_memory()
+                shard = None
+                rows = bg // W
+                n_ws_s = int(L.load().ia_ppo_update_sharded_ws_floats(C.byref(pol.desc), rows, W)) if rows * W == bg else 0
+                if self.dp_row_sharded and n_ws_s > 0:
+                    from imitation_amd.distributed import PeerExchange
+                    make = getattr(dp, "make_peer_exchange", None)   # (stand-in DataParallel objects of the tools: loopback)
+                    ex = make(pol.desc) if make is not None else PeerExchange(dp, pol.desc)
+                    if ex.ok:   # (the ranks' COMMON verdict: mapping + peer writes + system-scope polling work everywhere)
+                        shard = dict(ex=ex, rows=rows, ws=th.zeros(n_ws_s, device=dev))
+                    else:
+                        warnings.warn("data-parallel PPO update: the peer-memory handshake failed; every rank runs the "
+                                      "whole global minibatch instead of its row shard", RuntimeWarning)
                 self._dpg = dict(
+                    shard=shard,
                     W=W, aw=aw, cols=cols, batch=bg, ws=th.zeros(n_ws, device=dev),
                     send=th.empty(T, n, cols, device=dev),
                     obs=th.empty(T, W * n, pol.obs_dim, device=dev), acts=th.empty(T, W * n, aw, device=dev),
@@ -820,14 +839,31 @@ class PPO(OnPolicyAlgorithm):
         og = pol.optimizer.param_groups[0]
         if self.update_events is not None:
             self.update_events[0].record()
-        L.call("ia_ppo_update", C.byref(pol.desc), L.ptr(pol._flat), L.ptr(pol._flat_t),
-               L.ptr(rn.running_mean) if rn else None, L.ptr(rn.running_var) if rn else None,
-               L.ptr(rn.count) if rn else None, int(rn is not None), L.ptr(g["obs"]), L.ptr(g["acts"]), L.ptr(g["logp"]),
-               L.ptr(g["adv"]), L.ptr(g["ret"]), L.ptr(g["perm_dev"]), self.n_epochs, T, W * n, g["batch"],
-               int(self.normalize_advantage), float(clip_range), float(self.ent_coef), float(self.vf_coef),
-               float(self.max_grad_norm), L.ptr(pol.optimizer.exp_avg), L.ptr(pol.optimizer.exp_avg_sq),
-               float(lr), float(og["betas"][0]), float(og["betas"][1]), float(og["eps"]), pol.optimizer.step_count,
-               L.ptr(g["ws"]), L.ptr(stats_dev), L.stream())
+        sh = g["shard"]
+        if sh is not None:
+            # rows sharded over the ranks, one record per optimiser step exchanged inside the kernels
+            ex = sh["ex"]
+            steps = self.n_epochs * (-(-(W * T * n) // g["batch"]))
+            L.call("ia_ppo_update_sharded", C.byref(pol.desc), L.ptr(pol._flat), L.ptr(pol._flat_t),
+                   L.ptr(rn.running_mean) if rn else None, L.ptr(rn.running_var) if rn else None,
+                   L.ptr(rn.count) if rn else None, int(rn is not None), L.ptr(g["obs"]), L.ptr(g["acts"]),
+                   L.ptr(g["logp"]), L.ptr(g["adv"]), L.ptr(g["ret"]), L.ptr(g["perm_dev"]), self.n_epochs, T, W * n,
+                   sh["rows"], int(self.normalize_advantage), float(clip_range), float(self.ent_coef),
+                   float(self.vf_coef), float(self.max_grad_norm), L.ptr(pol.optimizer.exp_avg),
+                   L.ptr(pol.optimizer.exp_avg_sq), float(lr), float(og["betas"][0]), float(og["betas"][1]),
+                   float(og["eps"]), pol.optimizer.step_count, L.ptr(sh["ws"]), L.ptr(stats_dev), ex.world, ex.rank,
+                   ex.take_steps(steps), ex.recv, ex.peer_recv, int(ex.loop),
+                   float(self.dp_exchange_timeout_s), L.stream())
+            self.dp_sharded_updates = getattr(self, "dp_sharded_updates", 0) + 1
+        else:
+            L.call("ia_ppo_update", C.byref(pol.desc), L.ptr(pol._flat), L.ptr(pol._flat_t),
+                   L.ptr(rn.running_mean) if rn else None, L.ptr(rn.running_var) if rn else None,
+                   L.ptr(rn.count) if rn else None, int(rn is not None), L.ptr(g["obs"]), L.ptr(g["acts"]), L.ptr(g["logp"]),
+                   L.ptr(g["adv"]), L.ptr(g["ret"]), L.ptr(g["perm_dev"]), self.n_epochs, T, W * n, g["batch"],
+                   int(self.normalize_advantage), float(clip_range), float(self.ent_coef), float(self.vf_coef),
+                   float(self.max_grad_norm), L.ptr(pol.optimizer.exp_avg), L.ptr(pol.optimizer.exp_avg_sq),
+                   float(lr), float(og["betas"][0]), float(og["betas"][1]), float(og["eps"]), pol.optimizer.step_count,
+                   L.ptr(g["ws"]), L.ptr(stats_dev), L.stream())
         if self.update_events is not None:
             self.update_events[1].record()
         pol.optimizer.step_count += self.n_epochs * self._n_mb
@@ -988,8 +1024,11 @@ class PPO(OnPolicyAlgorithm):
                 rec.stats.copy_(self._stats_dev)
             if rec.log_std is not None:
                 rec.log_std.copy_(pol.log_std)
-            if self._upd_ws is not None:
-                rec.err.copy_(self._upd_ws[8:9].view(th.int32))
+            err_ws = self._upd_ws
+            if dpg is not None:   # the data-parallel launch has its own workspace (word 8: 1 = a grid wait, 2 = a peer's
+                err_ws = dpg["shard"]["ws"] if dpg["shard"] is not None else dpg["ws"]   # record did not arrive in time)
+            if err_ws is not None:
+                rec.err.copy_(err_ws[8:9].view(th.int32))
             rec.ready.record()
             rec.clip_range, rec.n_updates = clip_range, self._n_updates
             self._pending_train = rec
@@ -1024,12 +1063,16 @@ class PPO(OnPolicyAlgorithm):
         else:
             clip_range, n_updates = pending, self._n_updates
             st = self._stats_dev.cpu().numpy()  # one synchronisation per train()
-            err = 0 if self._upd_ws is None else int(self._upd_ws[8:9].view(th.int32).item())
+            err_ws = self._upd_ws
+            if self._dpg:
+                err_ws = self._dpg["shard"]["ws"] if self._dpg["shard"] is not None else self._dpg["ws"]
+            err = 0 if err_ws is None else int(err_ws[8:9].view(th.int32).item())
             vals, rets = rb.val.cpu().numpy().reshape(-1), rb.ret.cpu().numpy().reshape(-1)
             std = None if pol.discrete else float(th.exp(pol.log_std.cpu()).mean().item())  # host exp, as on every schedule
         if err != 0:
-            raise RuntimeError("ia_ppo_update: a grid-wide wait timed out inside the persistent PPO kernel; "
-                               "the parameters of this update are invalid")
+            raise RuntimeError("ia_ppo_update: " + ("a peer rank's gradient record did not arrive in time"
+                                                    if err == 2 else "a grid-wide wait timed out")
+                               + " inside the persistent PPO kernel; the parameters of this update are invalid")
         var_y = np.var(rets)
         ev = np.nan if var_y == 0 else 1 - np.var(rets - vals) / var_y
         self.logger.record("train/entropy_loss", float(st[..., 2].mean()))

@@ -12,6 +12,7 @@
  */
 #ifndef IMITATION_HIP_H
 #define IMITATION_HIP_H
+#include <stddef.h>
 #include <stdint.h>
 #ifdef __cplusplus
 extern "C" {
@@ -564,6 +565,47 @@ int ia_ppo_update(const ia_policy_desc* d, float* params, float* params_t, float
                   int batch_size, int normalize_adv, float clip_range, float ent_coef, float vf_coef,
                   float max_grad_norm, float* exp_avg, float* exp_avg_sq, double lr, double beta1, double beta2,
                   float adam_eps, int64_t adam_steps_done, float* ws, float* stats, void* stream);
+
+/* Row-sharded data-parallel [SB3 PPO.train] (no reference counterpart: the reference is single-process, SURVEY section 5
+ * row "Distributed"; the partitioning is SURVEY 8e (1)-(3) / BASELINE.json north_star "sharded by env-batch ... all-reduce
+ * of ... policy grads"). One process per GPU; `obs` ... `returns` are the ALL-GATHERED rollout tile [T, n_envs] with
+ * n_envs = world x the rank's environments, `perm` the permutations every rank shares; each optimiser step works on a
+ * global minibatch of world x rows_per_rank rows of which this rank's workgroups take rows [rank * rows_per_rank, ...).
+ * The per-step exchange -- one record per rank: partial gradient + loss-statistic sums -- happens INSIDE the persistent
+ * kernel through peer-mapped device memory (xGMI between GPUs): every rank writes its record into every rank's receive
+ * area as 8-byte (value, step sequence number) words with system-scope stores -- an aligned 8-byte store arrives whole, so
+ * no flag, acknowledgement or fence is needed: the receiver spins on the words themselves --; all workgroups sum the
+ * records in rank order (bit-identical replicas), clip by the global norm (torch `clip_grad_norm_` after the sum) and
+ * apply Adam. Advantage statistics and the train-mode feature RunningNorm of a minibatch are computed over the global
+ * minibatch on every rank. `recv` (ia_ppo_shard_recv_bytes): this rank's area, zeroed ONCE at allocation; `peer_recv[r]`:
+ * rank r's area as mapped into this process (own rank included); `seq_base`: optimiser steps exchanged through these
+ * areas so far, identical on every rank, only ever growing. A rank that waits longer than
+ * `timeout_s` for a peer's record sets the sticky error word of `ws` (word 8: 2) and leaves. `loopback` != 0 (cost model
+ * on one process, tools/dp_overhead.py): all peer areas are the caller's own and it writes its record once per source rank. */
+int64_t ia_ppo_update_sharded_ws_floats(const ia_policy_desc* d, int rows_per_rank, int world);
+int64_t ia_ppo_shard_recv_bytes(const ia_policy_desc* d, int world);
+int ia_ppo_update_sharded(const ia_policy_desc* d, float* params, float* params_t, float* norm_mean, float* norm_var,
+                          int32_t* norm_count, int update_norm, const float* obs, const float* actions,
+                          const float* old_logp, const float* advantages, const float* returns, const int64_t* perm,
+                          int n_epochs, int T, int n_envs, int rows_per_rank, int normalize_adv, float clip_range,
+                          float ent_coef, float vf_coef, float max_grad_norm, float* exp_avg, float* exp_avg_sq, double lr,
+                          double beta1, double beta2, float adam_eps, int64_t adam_steps_done, float* ws, float* stats,
+                          int world, int rank, uint32_t seq_base, void* recv, void* const* peer_recv, int loopback,
+                          double timeout_s, void* stream);
+/* Peer-mapped device memory for the exchange above (the only entries that allocate, map, free or synchronise):
+ * ia_peer_alloc: `bytes` of zeroed device memory, fine-grained (system-scope coherent) when the runtime grants it
+ * (*fine_grained says which); ia_peer_ipc_export / _open / _close: the 64-byte hipIpc handle of a block and its mapping in
+ * another process (the ranks exchange handles over torch.distributed); ia_peer_handshake: one-wave kernel that writes
+ * `token` (non-zero, new for every call) into word [rank] of every rank's `peer_words[r]` and waits `timeout_s` for all
+ * `world` words of `own_words` to carry it -- *result = 1 when the mapping, peer writes and system-scope polling all work
+ * (the trainer falls back to the replicated update otherwise). */
+int ia_peer_alloc(size_t bytes, void** out, int* fine_grained);
+int ia_peer_free(void* p);
+int ia_peer_ipc_export(void* p, unsigned char* handle64);
+int ia_peer_ipc_open(const unsigned char* handle64, void** out);
+int ia_peer_ipc_close(void* p);
+int ia_peer_handshake(int world, int rank, uint32_t token, uint32_t* own_words, uint32_t* const* peer_words,
+                      double timeout_s, int* result, void* stream);
 
 #ifdef __cplusplus
 }

@@ -102,6 +102,10 @@ def _gpu_worker(rank, world, port, out_dir):
         sd.update({f"pol/{k}": v.cpu() for k, v in algo.policy.state_dict().items()})
         if global_mb:  # the gathered tile of the last update and this rank's own shard of it
             g, rb = algo._dpg, algo.rollout_buffer
+            # rows sharded over the ranks, records exchanged inside the kernels through hipIpc-mapped memory (two
+            # processes on one GPU): every update of this run took that path
+            assert g["shard"] is not None and g["shard"]["ex"].ok and not g["shard"]["ex"].loop
+            assert algo.dp_sharded_updates == cfg["rounds"] + 1
             sd["tile/obs_global"], sd["tile/adv_global"] = g["obs"].cpu(), g["adv"].cpu()
             sd["tile/obs_local"], sd["tile/adv_local"] = rb.obs[: rb.buffer_size].cpu(), rb.adv.cpu()
             sd["tile/perm"] = g["perm_dev"].cpu()
@@ -176,7 +180,14 @@ def test_two_ranks_one_gpu_replicas_identical(tmp_path):
 #           concatenated -- `train_disc` on that batch (mean-reduced BCE: the rank-mean of per-rank mean
 #           gradients IS the gradient of the global mean; moments merged over all rows).
 
-def _equiv_worker(rank, world, port, out_dir):
+# PPO geometries of the equivalence test: the harness case itself (one 64-row gradient workgroup per rank: the kernel form
+# whose gradient stays in LDS) and a wide one -- 64 envs x 16 steps per rank, PPO minibatch 512 per rank: eight gradient
+# workgroups per rank, global minibatches of 1 024 rows whose statistics are taken in 512-row slices, records travelling
+# in four pieces per peer
+_EQUIV_GEOM = {"one_workgroup": {}, "eight_workgroups": dict(n_envs=64, ppo_batch=512)}
+
+
+def _equiv_worker(rank, world, port, out_dir, geom="one_workgroup"):
     _init(rank, world, port)
     th.cuda.set_device(0)
     th.set_num_threads(1)
@@ -186,7 +197,7 @@ def _equiv_worker(rank, world, port, out_dir):
     from imitation_amd.distributed import DataParallel
     from imitation_amd.vec_env import SyntheticVecEnv
     from tests import harness
-    cfg = harness.CASES["gail_box"]
+    cfg = dict(harness.CASES["gail_box"], **_EQUIV_GEOM[geom])
     th.manual_seed(100 + rank)
     np.random.seed(100 + rank)
     venv = SyntheticVecEnv(num_envs=cfg["n_envs"], obs_dim=17, act_dim=6, horizon=cfg["horizon"], seed=rank)
@@ -230,19 +241,23 @@ def _equiv_worker(rank, world, port, out_dir):
     th.cuda.synchronize()
     out["pol_post"] = cpu(algo.policy.state_dict())
     g = algo._dpg
+    # the update above sharded each global minibatch's rows over the two ranks (records exchanged inside the kernels)
+    assert g["shard"] is not None and algo.dp_sharded_updates == 1
     out["tile"] = {k: g[k].cpu().clone() for k in ("obs", "acts", "logp", "adv", "ret")}
     out["perm"] = g["perm_dev"].cpu().clone()
+    out["stats"] = algo._stats_dev.cpu().clone() if algo._records is None else algo._records[(algo._rec_i - 1) % 2].stats.cpu().clone()
     out["hyper"] = dict(T=cfg["n_steps"], n=cfg["n_envs"], bs=cfg["ppo_batch"], n_epochs=2, ent_coef=0.1)
     th.save(out, os.path.join(out_dir, f"equiv{rank}.pt"))
     dist.destroy_process_group()
 
 
 @pytest.mark.gpu
-def test_world_two_equals_single_process_on_the_concatenated_batch(tmp_path):
+@pytest.mark.parametrize("geom", list(_EQUIV_GEOM))
+def test_world_two_equals_single_process_on_the_concatenated_batch(tmp_path, geom):
     if not th.cuda.is_available():
         pytest.skip("no GPU")
     port = _free_port()
-    mp.spawn(_equiv_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(_equiv_worker, args=(2, port, str(tmp_path), geom), nprocs=2, join=True)
     r0 = th.load(tmp_path / "equiv0.pt", weights_only=False)
     r1 = th.load(tmp_path / "equiv1.pt", weights_only=False)
     for k in r0["disc_post"]:
@@ -285,6 +300,13 @@ def test_world_two_equals_single_process_on_the_concatenated_batch(tmp_path):
     finally:
         np.random.permutation = real
     k = h["n_epochs"] * (T * n2 // (2 * h["bs"]))
+    # the logged loss statistics travel in the records' tails: both ranks hold the same rows, equal to the oracle's means
+    assert th.equal(r0["stats"], r1["stats"])
+    st, lg = r0["stats"].numpy().reshape(-1, 8), algo.logger.name_to_value
+    assert st[:, 0].mean() == pytest.approx(lg["train/policy_gradient_loss"], rel=2e-3, abs=2e-5)
+    assert st[:, 1].mean() == pytest.approx(lg["train/value_loss"], rel=2e-3)
+    assert st[:, 2].mean() == pytest.approx(lg["train/entropy_loss"], rel=2e-3)
+    assert st[-1, 5] == pytest.approx(lg["train/loss"], rel=2e-3, abs=2e-5)
     for name, ref in pol.state_dict().items():
         got = r0["pol_post"][name]
         if name.endswith("count"):

@@ -517,9 +517,10 @@ def test_production_kernels_do_not_spill():
     # persistent PPO update: 8 and 9 parameters per thread, production build, observation widths <= 32 (every
     # reference environment of the path): no spilled VGPR, no scratch at all
     # (last argument: the one-gradient-workgroup form whose gradient stays in LDS -- the reference's tuned configurations)
-    for inst in ("ppo_update_persistent_kernel<8, false, 8, false>", "ppo_update_persistent_kernel<9, false, 8, false>",
-                 "ppo_update_persistent_kernel<8, false, 8, true>", "ppo_update_persistent_kernel<9, false, 8, true>",
-                 "ppo_update_persistent_kernel<8, false, 16, true>", "ppo_update_persistent_kernel<9, false, 16, true>"):
+    # (fifth argument: the row-sharded data-parallel form, see below)
+    for inst in ("ppo_update_persistent_kernel<8, false, 8, false, false>", "ppo_update_persistent_kernel<9, false, 8, false, false>",
+                 "ppo_update_persistent_kernel<8, false, 8, true, false>", "ppo_update_persistent_kernel<9, false, 8, true, false>",
+                 "ppo_update_persistent_kernel<8, false, 16, true, false>", "ppo_update_persistent_kernel<9, false, 16, true, false>"):
         ks = find(inst)
         assert len(ks) == 1, inst
         assert ks[0]["vgpr_spill"] == 0 and ks[0]["scratch"] == 0, (inst, ks[0])

@@ -471,12 +471,15 @@ def test_timeout_bootstrap():
                                                         # (minibatch steps as phases between grid barriers)
                                                         (17, 6, 64, False, True, 16, 256, 1024),
                                                         (4, 2, 64, True, True, 9, 100, 384)])
-@pytest.mark.parametrize("path", ["epoch", "epoch_whole", "update", "update_spread"])
+@pytest.mark.parametrize("path", ["epoch", "epoch_whole", "update", "update_spread", "update_shard1"])
 def test_ppo_epochs_match_oracle(D, A, H, discrete, norm, T, n, bs, path):
     """Two PPO epochs on a synthetic rollout: parameters, Adam state, RunningNorm state and the
     logged loss statistics against SB3-restated `PPO.train` on the same permutations -- through
     one `ia_ppo_epoch` call per epoch, and through the single persistent `ia_ppo_update` launch
-    (working blocks packed on one XCD, or spread over all of them)."""
+    (working blocks packed on one XCD, or spread over all of them). `update_shard1`: the row-sharded data-parallel form
+    (`ia_ppo_update_sharded`) with a world of one -- the whole exchange machinery (8-byte value / sequence words through
+    the peer block, loss statistics through the record tails, two launches on a growing sequence base) on one process;
+    two ranks run in tests/test_distributed.py."""
     if path == "epoch_whole" and H != 64:
         pytest.skip("64-wide towers: the one-launch epoch with whole row-block workgroups (default: one tower each)")
     if path not in ("epoch", "epoch_whole") and H != 32:
@@ -532,6 +535,27 @@ def test_ppo_epochs_match_oracle(D, A, H, discrete, norm, T, n, bs, path):
             th.cuda.synchronize()
         finally:
             L.load().ia_ppo_epoch_split(0)
+    elif path == "update_shard1":
+        from imitation_amd.distributed import PeerExchange
+        nws = int(L.load().ia_ppo_update_sharded_ws_floats(C.byref(dp.d), bs, 1))
+        if nws == 0:
+            pytest.skip("shape not covered by the persistent kernel (parameter copies do not fit LDS)")
+        uws = th.zeros(nws, device=DEV)
+        d_perm = th.as_tensor(np.stack(perms)).to(DEV)
+        ex = PeerExchange.loopback(1, dp.d)
+        assert ex.ok
+        try:
+            for e in range(2):   # one launch per epoch: the sequence base carries over
+                L.call("ia_ppo_update_sharded", C.byref(dp.d), L.ptr(dp.P), L.ptr(dp.Pt), L.ptr(dp.nm), L.ptr(dp.nv),
+                       L.ptr(dp.nc), int(norm), L.ptr(d_obs), L.ptr(d_act), L.ptr(d_lp), L.ptr(d_adv), L.ptr(d_ret),
+                       L.ptr(d_perm[e:e + 1]), 1, T, n, bs, 1, 0.2, 0.05, 0.5, 0.5, L.ptr(dp.m), L.ptr(dp.v), 3e-4, 0.9, 0.999,
+                       1e-5, e * n_mb, L.ptr(uws), L.ptr(stats[e]), 1, 0, ex.take_steps(n_mb), ex.recv, ex.peer_recv, 1, 5.0,
+                       L.stream())
+            th.cuda.synchronize()
+            assert int(uws[8:9].view(th.int32).item()) == 0, "a wait timed out"
+        finally:
+            th.cuda.synchronize()
+            ex.close()
     else:
         nws = int(L.load().ia_ppo_update_ws_floats(C.byref(dp.d), bs))
         if nws == 0:

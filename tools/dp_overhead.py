@@ -43,6 +43,12 @@ class NullDP:
     def shared_seed(self):
         return 1234
 
+    def make_peer_exchange(self, desc):
+        """Row-sharded PPO update: this process stands in for every rank (its record is written and summed `world`
+        times through its own block, `PeerExchange.loopback`)."""
+        from imitation_amd.distributed import PeerExchange
+        return PeerExchange.loopback(self.world, desc)
+
 
 def main():
     rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 20
