@@ -87,20 +87,24 @@ def build_trainer(ns, cfg, device, seed=0, dp=None):
 def hip_namespace():
     import types
     import imitation_amd as p
-    return types.SimpleNamespace(GAIL=p.GAIL, PPO=p.PPO, FeedForward32Policy=p.FeedForward32Policy,
+    return types.SimpleNamespace(GAIL=p.GAIL, AIRL=p.AIRL, PPO=p.PPO, FeedForward32Policy=p.FeedForward32Policy,
+                                 ActorCriticPolicy=p.ActorCriticPolicy,
                                  NormalizeFeaturesExtractor=p.NormalizeFeaturesExtractor, RunningNorm=p.RunningNorm,
-                                 BasicRewardNet=p.BasicRewardNet, Transitions=lambda **kw: p.Transitions(**kw),
-                                 configure_logger=lambda d: p.configure_logger(d, []))
+                                 BasicRewardNet=p.BasicRewardNet, BasicShapedRewardNet=p.BasicShapedRewardNet,
+                                 NormalizedRewardNet=p.NormalizedRewardNet, Transitions=lambda **kw: p.Transitions(**kw),
+                                 configure_logger=lambda d: p.configure_logger(d, []), device="cuda")
 
 
 def oracle_namespace():
     import types
     from oracle import imitation_restated as o
     from oracle import sb3_restated as sb
-    return types.SimpleNamespace(GAIL=o.GAIL, PPO=sb.PPO, FeedForward32Policy=o.FeedForward32Policy,
+    return types.SimpleNamespace(GAIL=o.GAIL, AIRL=o.AIRL, PPO=sb.PPO, FeedForward32Policy=o.FeedForward32Policy,
+                                 ActorCriticPolicy=sb.ActorCriticPolicy,
                                  NormalizeFeaturesExtractor=o.NormalizeFeaturesExtractor, RunningNorm=o.RunningNorm,
-                                 BasicRewardNet=o.BasicRewardNet, Transitions=lambda **kw: o.Transitions(**kw),
-                                 configure_logger=lambda d: o.configure_logger(d, []))
+                                 BasicRewardNet=o.BasicRewardNet, BasicShapedRewardNet=o.BasicShapedRewardNet,
+                                 NormalizedRewardNet=o.NormalizedRewardNet, Transitions=lambda **kw: o.Transitions(**kw),
+                                 configure_logger=lambda d: o.configure_logger(d, []), device="cpu")
 
 
 def cpu_baseline(cfg, host_threads):
@@ -409,10 +413,10 @@ def run_bc_variant(batch=4096, steps=10):
             "config": "BC, NatureCNN ActorCriticCnnPolicy, uint8 4x84x84 frames, Discrete(6), batch 4096, Adam"}
 
 
-def build_variant(name):
-    """The trainer of one non-image variant, untrained."""
-    import imitation_amd as p
+def build_variant(name, p=None):
+    """The trainer of one non-image variant, untrained (`p`: namespace of an implementation, default the HIP product)."""
     from imitation_amd.vec_env import SyntheticVecEnv
+    p = p or hip_namespace()
     v = VARIANTS[name]
     n_envs, n_steps, od, ad = v["n_envs"], v["n_steps"], v["obs"], v["act"]
     discrete = v.get("discrete", False)
@@ -431,7 +435,7 @@ def build_variant(name):
         pk = dict(pk, net_arch=v["net_arch"])
     elif mlp64:
         pk = {}
-    algo = p.PPO(policy, venv, n_steps=n_steps, seed=0, policy_kwargs=pk, device="cuda", **v["ppo"])
+    algo = p.PPO(policy, venv, n_steps=n_steps, seed=0, policy_kwargs=pk, device=p.device, **v["ppo"])
     if v["algo"] == "gail":
         net = p.BasicRewardNet(venv.observation_space, venv.action_space, normalize_input_layer=p.RunningNorm, **v["net"])
         cls = p.GAIL
@@ -445,11 +449,30 @@ def build_variant(name):
     obs = rng.standard_normal((n, od)).astype(np.float32)
     acts = rng.integers(0, ad, n).astype(np.int64) if discrete else rng.uniform(-1, 1, (n, ad)).astype(np.float32)
     demos = p.Transitions(obs=obs, acts=acts, next_obs=(0.9 * obs).astype(np.float32), dones=np.zeros(n, bool))
+    extra = dict(disc_grad_penalty_coef=v["grad_penalty"]) if v.get("grad_penalty") else {}   # (opt-in extension, HIP only)
     tr = cls(demonstrations=demos, demo_batch_size=v["demo_batch"], venv=venv, gen_algo=algo, reward_net=net,
              n_disc_updates_per_round=v["n_disc"], gen_replay_buffer_capacity=v["capacity"],
-             custom_logger=p.configure_logger(tempfile.mkdtemp(prefix="bench-var-"), []),
-             disc_grad_penalty_coef=v.get("grad_penalty", 0.0))
+             custom_logger=p.configure_logger(tempfile.mkdtemp(prefix="bench-var-")), **extra)
     return tr, n_envs * n_steps
+
+
+# variants that get the CPU oracle timed beside them (one round each, after one warm-up round: the reference's shipped
+# configurations, for which the headline's cpu_baseline says nothing)
+CPU_VARIANTS = ("T_gail_half_cheetah_tuned_verbatim", "3_airl_ant_tuned_verbatim", "1_cartpole_8x256_mlp64")
+
+
+def variant_cpu_baseline(name, host_threads):
+    th.set_num_threads(min(8, host_threads))
+    try:
+        tr, per = build_variant(name, oracle_namespace())
+        tr.train(per)
+        t0 = time.perf_counter()
+        tr.train(per)
+        dt = time.perf_counter() - t0
+    finally:
+        th.set_num_threads(1)
+    return {"value": per / dt, "unit": "env-steps/s", "cores": min(8, host_threads), "kind": "port",
+            "sample": f"1 round = {per} env-steps after 1 warm-up round, {dt:.1f} s, torch threads={min(8, host_threads)}"}
 
 
 def run_variant(name, rounds=None, warm=None):
@@ -547,30 +570,71 @@ def main():
     base = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         base = cpu_baseline(cfg, host_threads)
+        if variants:
+            for name in CPU_VARIANTS:   # the oracle beside the reference's shipped configurations (one round each)
+                if name in variants and "error" not in variants[name]:
+                    try:
+                        cb = variant_cpu_baseline(name, host_threads)
+                        variants[name]["cpu_baseline"] = cb
+                        variants[name]["speedup_vs_cpu_baseline"] = variants[name]["env_steps_per_s"] / cb["value"]
+                    except Exception as e:
+                        variants[name]["cpu_baseline"] = {"error": f"{type(e).__name__}: {e}"}
     if world > 1:
         dist.barrier()
 
     if rank == 0:
         value = world * args.steps * per_round / dt
+        disc = (roof or {}).get("disc_update") or {}
+        ppo = (roof or {}).get("ppo_update") or {}
+        gemm = (roof or {}).get("gemm")
+        r3 = lambda x: None if x is None else float(f"{x:.4g}")
+        # compact record of everything a reader needs first (the driver keeps scalar fields and the END of the line):
+        summary = {
+            "headline_env_steps_per_s": r3(value), "ms_per_round": r3(1e3 * dt / args.steps), "n_gpus": world,
+            "ppo": {"us_per_step": r3(ppo.get("us_per_step")), "launch_us": r3(ppo.get("avg_launch_us")),
+                    "steps_per_launch": ppo.get("optimizer_steps_per_launch"), "frac_mfma": r3(ppo.get("frac")),
+                    "traffic": ppo.get("traffic"), "algorithmic_bytes": ppo.get("algorithmic_bytes_per_launch")},
+            "disc_update": {"us": r3(disc.get("us")), "us_in_rounds": r3(disc.get("us_in_rounds")),
+                            "frac": r3(disc.get("frac")), "frac_in_rounds": r3(disc.get("frac_in_rounds")),
+                            "traffic": disc.get("traffic"), "algorithmic_bytes": disc.get("algorithmic_bytes"),
+                            "path": (disc.get("path") or "").split(" ")[0]},
+            "cpu_env_steps_per_s": r3(base["value"]) if base else None,
+            "speedup_vs_cpu": r3(value / base["value"]) if base else None,
+            "variants_env_steps_per_s": ({k: r3(v.get("env_steps_per_s", v.get("samples_per_s"))) for k, v in variants.items()}
+                                         if variants else None),
+            "variants_cpu_env_steps_per_s": ({k: r3(v["cpu_baseline"].get("value")) for k, v in variants.items()
+                                              if isinstance(v.get("cpu_baseline"), dict)} if variants else None),
+        }
+        # `roofline`: the kernel with the largest share of GPU time, FLAT (scalars only), with the throughput family's
+        # figures beside it under disc_* names; the long-form records follow under `details`
+        flat = None
+        if roof:
+            flat = {k: v for k, v in roof.items() if not isinstance(v, (dict, list)) and k != "note"}
+            flat.update({"disc_update_us": disc.get("us"), "disc_update_us_in_rounds": disc.get("us_in_rounds"),
+                         "disc_update_frac": disc.get("frac"), "disc_update_frac_in_rounds": disc.get("frac_in_rounds"),
+                         "disc_update_traffic": disc.get("traffic"), "disc_update_bound": disc.get("bound"),
+                         "note": "dominant kernel by GPU time is a latency chain (read us_per_step); the MFMA-bound "
+                                 "family is disc_update_* (6.85 GFLOP per update vs 157.3 TFLOP/s)"})
         out = {
             "metric": "env-steps/sec (gen+disc round) GAIL HalfCheetah n_envs=1024",
             "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "summary": summary,
             "config": {"workload": "GAIL round, config P (BASELINE.json configs[1]): seals/HalfCheetah-shaped "
                                    "obs17/act6 synthetic VecEnv, n_envs=1024/GPU x n_steps=16, disc BasicRewardNet "
                                    "256x256+RunningNorm, demo_batch 8192, 16 disc updates/round, PPO 32x32 "
                                    "minibatch 1024 x 10 epochs", "env_steps_per_round_per_gpu": per_round,
-                       "parallelism": f"dp{world}" if world > 1 else "single"},
-            "roofline": roof, "cpu_baseline": base,
-            # siblings of `roofline` repeated at the top level (a parser that keeps only roofline's scalar fields
-            # still sees them): the whole discriminator update and the GEMM family
-            "roofline_disc_update": roof.get("disc_update") if roof else None,
-            "roofline_gemm": roof.get("gemm") if roof else None,
+                       "parallelism": f"dp{world}" if world > 1 else "single",
+                       "ppo_update": (("row-sharded, in-kernel exchange" if getattr(trainer.gen_algo, "dp_sharded_updates", 0)
+                                       else "replicated on the gathered tile") if world > 1 else "single GPU")},
+            "roofline": flat, "cpu_baseline": base,
+            "speedup_vs_cpu_baseline": (value / base["value"]) if base else None,
+            "details": {"roofline_disc_update": disc or None, "roofline_gemm": gemm, "roofline_ppo_update": ppo or None},
             "variants": variants,
+            # the same compact record once more at the END of the line (a reader that keeps only the tail still gets it)
+            "tail_summary": summary,
         }
-        if base:
-            out["speedup_vs_cpu_baseline"] = value / base["value"]
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

@@ -13,7 +13,8 @@ from typing import Optional
 import torch as th
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libimitation_hip.so")
+# (IA_LIB: another build of the same library -- same-box A / B runs of a kernel change, tools only)
+LIB_PATH = os.environ.get("IA_LIB") or os.path.join(_HERE, "libimitation_hip.so")
 
 IA_MAX_LAYERS = 8
 ACT_NONE, ACT_RELU, ACT_TANH, ACT_SOFTPLUS = 0, 1, 2, 3

@@ -388,25 +388,37 @@ __global__ void gae_kernel(const float* __restrict__ rewards, const float* __res
                            const float* __restrict__ last_dones, int T, int n, float gamma, float gl,
                            float* __restrict__ adv, float* __restrict__ ret) {
   // one lane per environment, reverse scan over T; every operation rounded separately in the
-  // order NumPy evaluates `r + gamma*nv*nnt - v` and `delta + gamma*lambda*nnt*last`.
+  // order NumPy evaluates `r + gamma*nv*nnt - v` and `delta + gamma*lambda*nnt*last` (bit-exact: the recurrence stays
+  // sequential in t). The loads do not depend on the recurrence, so they are requested GAE_U time steps at a time --
+  // the scan was one memory round trip per time step (472 us for 1 000 steps x 1 024 environments, 43 GB/s).
+  constexpr int GAE_U = 16;
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= n) return;
   float last = 0.f;
-  for (int t = T - 1; t >= 0; --t) {
-    float nnt, nv;
-    if (t == T - 1) {
-      nnt = __fsub_rn(1.0f, last_dones[e]);
-      nv = last_values[e];
-    } else {
-      nnt = __fsub_rn(1.0f, starts[(long long)(t + 1) * n + e]);
-      nv = values[(long long)(t + 1) * n + e];
+  float nv = last_values[e];                       // V of the step behind t (t = T - 1: the bootstrap value)
+  float nnt = __fsub_rn(1.0f, last_dones[e]);      // 1 - start flag of the step behind t
+  for (int t1 = T - 1; t1 >= 0; t1 -= GAE_U) {     // steps t1, t1 - 1, ..., t1 - GAE_U + 1 (clamped at 0)
+    float r[GAE_U], v[GAE_U], st[GAE_U];
+#pragma unroll
+    for (int u = 0; u < GAE_U; ++u) {
+      const long long o = (long long)max(t1 - u, 0) * n + e;   // clamped: unconditional loads, all in flight together
+      r[u] = rewards[o];
+      v[u] = values[o];
+      st[u] = starts[o];
     }
-    const float v = values[(long long)t * n + e];
-    const float delta =
-        __fsub_rn(__fadd_rn(rewards[(long long)t * n + e], __fmul_rn(__fmul_rn(gamma, nv), nnt)), v);
-    last = __fadd_rn(delta, __fmul_rn(__fmul_rn(gl, nnt), last));
-    adv[(long long)t * n + e] = last;
-    ret[(long long)t * n + e] = __fadd_rn(last, v);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < GAE_U; ++u) {
+      const int t = t1 - u;
+      if (t >= 0) {
+        const float delta = __fsub_rn(__fadd_rn(r[u], __fmul_rn(__fmul_rn(gamma, nv), nnt)), v[u]);
+        last = __fadd_rn(delta, __fmul_rn(__fmul_rn(gl, nnt), last));
+        adv[(long long)t * n + e] = last;
+        ret[(long long)t * n + e] = __fadd_rn(last, v[u]);
+        nv = v[u];                               // step t - 1 looks at values[t] and starts[t]
+        nnt = __fsub_rn(1.0f, st[u]);
+      }
+    }
   }
 }
 
@@ -2066,21 +2078,19 @@ __device__ __forceinline__ void mfma32_minibatch_chain(
   const float* __restrict__ sPt = sP + ((o.total + 3) & ~3);
   IA_TS(0);
 
-  // ---- per-row scalars of the loss. Policy waves (tw = 0): FOUR lanes per row -- lane = 4 * (row - 16 q) + part, part
-  // owns actions part, part + 4, part + 8, part + 12 (MAXA = 16) -- so the per-action work of a row is four
-  // iterations on 64 lanes instead of sixteen on 16 (the sums over actions are finished with two quad shuffles).
-  // Value waves (tw = 1): lanes 0..15 own row q*16 + lane.
-  const int part = lane & 3;
-  const int lrow = tw == 0 ? q * 16 + (lane >> 2) : q * 16 + (lane & 15);   // local row of this lane in the loss phase
-  const bool loss_lane = tw == 0 || lane < 16;
+  // ---- per-row scalars of the loss. The chain below runs TRANSPOSED -- features along the MFMA's M index, the wave's 16
+  // rows along N -- so a lane (lk, li) = (lane >> 4, lane & 15) ends every layer holding features 16 t + 4 lk + r
+  // (r = 0..3) of row li: four lanes per row, lane group lk owning actions 4 lk .. 4 lk + 3 in the loss phase (sums over
+  // actions finish with two cross-group shuffles). Value waves: every lane group carries the row's value; group 0 writes.
+  const int lrow = q * 16 + (lane & 15);   // local row of this lane
   const bool valid = (i0 + lrow) < row_lim;
   float r_oldlp = 0.f, r_adv = 0.f, r_ret = 0.f, r_act[4] = {0.f, 0.f, 0.f, 0.f};
   if (tw == 0) {   // staged by the prefetch (LDS-direct loads); unconditional, clamped
     r_oldlp = stg[UpdStage::oldlp + lrow];
     r_adv = stg[UpdStage::adv + lrow];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) r_act[j] = stg[UpdStage::act + lrow * aw + min(part + 4 * j, aw - 1)];
-  } else if (loss_lane) {
+    for (int j = 0; j < 4; ++j) r_act[j] = stg[UpdStage::act + lrow * aw + min(4 * (lane >> 4) + j, aw - 1)];
+  } else {
     r_ret = stg[UpdStage::ret + lrow];
   }
 
@@ -2115,61 +2125,57 @@ __device__ __forceinline__ void mfma32_minibatch_chain(
       for (int e = lane; e < 16 * L::AS; e += 64) {
         lds[L::dout + rbase * L::AS + e] = 0.f;
         lds[L::aux + rbase * L::AS + e] = 0.f;
-        lds[L::out + rbase * L::AS + e] = 0.f;
       }
     } else {
       for (int e = lane; e < 16 * L::MS; e += 64) lds[L::misc + rbase * L::MS + e] = 0.f;
     }
   }
   IA_TS(10);
-  // weight fragments (LDS -> VGPR): B[k = 4s+lk][j = c*16+li]. ALL reads first -- unconditional, at clamped
-  // addresses, grouped behind at most four wave-uniform branches -- then the masks: a guarded read (or a
-  // select right behind its read) costs a branch and a full `lgkmcnt(0)` wait each, which made these ~70
-  // reads a chain of ~50 serial LDS round trips.
-  float bW1[KS1][2], bW2[8][2], bW2o[8][2], bHead[8], bDa2[4][2], b1v[2], b2v[2], cwv[2];
+  // Weight fragments (LDS -> VGPR) as the MFMAs' A operand: A[m = li][k = lk] of k-step (kt, r) is W[out 16 t + li][in
+  // 16 kt + 4 lk + r] -- the k index of a step is PERMUTED (a step takes inputs 4 lk + r, lk = 0..3, of K tile kt) so
+  // that the accumulator of one layer (lane (lk, li) holds outputs 4 lk + r of row li) IS the B operand of the next:
+  // B[k = lk][n = li] of step (t, r) = output 16 t + 4 lk + r. Activations never leave the registers on the way
+  // x -> a1 -> a2 -> head -> loss -> d head -> dz2 -> dz1; the LDS tiles ([row][feature], as before) are written on the
+  // side for the weight-gradient tiles, which contract over rows. (Before: rows along M, one LDS write + wave sync + read
+  // between every two layers -- seven hand-offs of ~250 clocks on the chain.)
+  // ALL reads first -- unconditional, at clamped addresses -- then the masks: a guarded read (or a select right behind
+  // its read) costs a branch and a full `lgkmcnt(0)` wait each.
+  constexpr int KT1 = KS1 / 4;   // K tiles (16 input columns each) the first layer's fragments are sized for
+  float fW1[KT1][2][4], fW2[2][2][4], fW2T[2][2][4], fHead[2][4], fHeadT[2][4], b1c[2][4], b2c[2][4], hb[4];
+  // (biases: initial values of the layers' accumulators -- C layout, output 16 t + 4 lk + r -- dead once the layer starts)
 #pragma unroll
-  for (int g = 0; g < KS1 / 4; ++g) {
-    if (4 * g < S1) {
+  for (int kt = 0; kt < KT1; ++kt) {
+    if (4 * kt < S1) {
 #pragma unroll
-      for (int s = 4 * g; s < 4 * g + 4; ++s)
+      for (int t = 0; t < 2; ++t)
 #pragma unroll
-        for (int c = 0; c < 2; ++c) bW1[s][c] = sPt[oW1 + min(4 * s + lk, D - 1) * H + c * 16 + li];
+        for (int r = 0; r < 4; ++r) fW1[kt][t][r] = sPt[oW1 + min(16 * kt + 4 * lk + r, D - 1) * H + 16 * t + li];
     } else {
 #pragma unroll
-      for (int s = 4 * g; s < 4 * g + 4; ++s) bW1[s][0] = bW1[s][1] = 0.f;
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) fW1[kt][t][r] = 0.f;
     }
   }
   const int head_base = tw == 0 ? o.aW + min(li, A - 1) * H : o.cW;
+  // (the fragments of layer 2 and of the head are requested behind the previous layer's MFMAs -- their LDS latency
+  //  passes under that layer's tanh -- instead of here: 40 registers less across the first layer)
 #pragma unroll
-  for (int s = 0; s < 8; ++s) {
-    const int kk = 4 * s + lk;
+  for (int t = 0; t < 2; ++t)
 #pragma unroll
-    for (int c = 0; c < 2; ++c) bW2[s][c] = sPt[oW2 + kk * H + c * 16 + li];
-    bHead[s] = sP[head_base + kk];
-  }
-#pragma unroll
-  for (int c = 0; c < 2; ++c) {
-    b1v[c] = sP[ob1 + c * 16 + li];
-    b2v[c] = sP[ob2 + c * 16 + li];
-    cwv[c] = sP[o.cW + c * 16 + li];
-  }
-  float head_bias = sP[tw == 0 ? o.ab + min(li, A - 1) : o.cb];
+    for (int r = 0; r < 4; ++r) b1c[t][r] = sP[ob1 + 16 * t + 4 * lk + r];
   float my_sd = sP[o.log_std + min(lane, A - 1)];
   __builtin_amdgcn_sched_barrier(0);   // every read above is issued before the first value is touched
 #pragma unroll
-  for (int s = 0; s < KS1; ++s)
+  for (int kt = 0; kt < KT1; ++kt)
 #pragma unroll
-    for (int c = 0; c < 2; ++c) bW1[s][c] = (4 * s + lk < D) ? bW1[s][c] : 0.f;
-  {
-    const bool head_on = tw == 0 ? li < A : li == 0;
+    for (int t = 0; t < 2; ++t)
 #pragma unroll
-    for (int s = 0; s < 8; ++s) bHead[s] = head_on ? bHead[s] : 0.f;
-  }
-  head_bias = (tw == 0 && li >= A) ? 0.f : head_bias;
+      for (int r = 0; r < 4; ++r) fW1[kt][t][r] = (16 * kt + 4 * lk + r < D) ? fW1[kt][t][r] : 0.f;
   // per-action Gaussian constants; the reciprocal variance turns the ~3 IEEE divisions per action and
   // row of the loss into multiplications (<= 1 ulp away from dividing). Lane a computes action a's pair
-  // once (exp, division, log); every lane then picks the MAXA pairs up from the wave.
-  float c_ivar[4], c_logsd[4];   // of this lane's actions part + 4 j
+  // once (exp, division, log); every lane then picks its four actions' pairs up from the wave.
+  float c_ivar[4], c_logsd[4];   // of this lane's actions 4 lk + j
   {
     float my_ivar = 1.f, my_logsd = 0.f;
     if (tw == 0 && !d.discrete) {
@@ -2179,8 +2185,8 @@ __device__ __forceinline__ void mfma32_minibatch_chain(
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      c_ivar[j] = __shfl(my_ivar, part + 4 * j, 64);
-      c_logsd[j] = __shfl(my_logsd, part + 4 * j, 64);
+      c_ivar[j] = __shfl(my_ivar, 4 * lk + j, 64);
+      c_logsd[j] = __shfl(my_logsd, 4 * lk + j, 64);
     }
   }
   IA_TS(11);
@@ -2192,239 +2198,272 @@ __device__ __forceinline__ void mfma32_minibatch_chain(
   float* a2t = lds + L::a2 + tw * ROWS * L::HS;
   float* dz2t = lds + L::dz2 + tw * ROWS * L::HS;
   float* dz1t = lds + L::dz1 + tw * ROWS * L::HS;
-  const int arow = q * 16 + li;  // row whose A fragment this lane feeds
-  // ---- a1 = tanh(x W1^T + b1)
+  const int trow = (q * 16 + li) * L::HS + 4 * lk;   // this lane's four consecutive features of tile t start at trow + 16 t
+  // sum / max over the four lane groups of a row (the same bits in all four lanes): v_permlane16_swap / v_permlane32_swap
+  // with both operands the same register leave (even rows | odd rows) resp. (lower half | upper half) of it in both
+  // halves of the pair -- one VALU exchange per level instead of a ds_bpermute round trip
+  auto xchg16 = [](float v, float& a, float& b) {
+    const auto p2 = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    a = __uint_as_float(p2[0]);
+    b = __uint_as_float(p2[1]);
+  };
+  auto xchg32 = [](float v, float& a, float& b) {
+    const auto p2 = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    a = __uint_as_float(p2[0]);
+    b = __uint_as_float(p2[1]);
+  };
+  auto group_sum = [&](float v) {
+    float a, b;
+    xchg16(v, a, b);
+    v = a + b;
+    xchg32(v, a, b);
+    return a + b;
+  };
+  auto group_max = [&](float v) {
+    float a, b;
+    xchg16(v, a, b);
+    v = fmaxf(a, b);
+    xchg32(v, a, b);
+    return fmaxf(a, b);
+  };
+  // ---- a1^T = tanh(W1 x^T + b1): B operand = the wave's x rows, column 16 kt + 4 lk + r of row li
+  f32x4 a1[2], a2[2];
   {
-    f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-    // A fragments in batches of four k-steps (one wave-uniform branch and one LDS wait per batch instead of
-    // one per k-step); columns >= D of the x tile are zero
+    f32x4 acc[2][2] = {{{b1c[0][0], b1c[0][1], b1c[0][2], b1c[0][3]}, {0.f, 0.f, 0.f, 0.f}},
+                       {{b1c[1][0], b1c[1][1], b1c[1][2], b1c[1][3]}, {0.f, 0.f, 0.f, 0.f}}};
+    float xb[KT1][4];
 #pragma unroll
-    for (int g = 0; g < KS1 / 4; ++g)
-      if (4 * g < S1) {
-        float xa[4];
+    for (int kt = 0; kt < KT1; ++kt)
 #pragma unroll
-        for (int u = 0; u < 4; ++u) xa[u] = lds[L::x + arow * L::XS + 4 * (4 * g + u) + lk];
-        __builtin_amdgcn_sched_barrier(0);
+      for (int r = 0; r < 4; ++r) xb[kt][r] = lds[L::x + (q * 16 + li) * L::XS + min(16 * kt + 4 * lk + r, L::XS - 1)];
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          acc[0] = mfma16(xa[u], bW1[4 * g + u][0], acc[0]);
-          acc[1] = mfma16(xa[u], bW1[4 * g + u][1], acc[1]);
+    for (int kt = 0; kt < KT1; ++kt)
+      if (4 * kt < S1) {   // (wave-uniform; K tiles accumulate alternately into two chains per output tile)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          acc[0][kt & 1] = mfma16(fW1[kt][0][r], xb[kt][r], acc[0][kt & 1]);
+          acc[1][kt & 1] = mfma16(fW1[kt][1][r], xb[kt][r], acc[1][kt & 1]);
         }
       }
 #pragma unroll
-    for (int c = 0; c < 2; ++c)
+    for (int kt = 0; kt < 2; ++kt)   // layer 2's fragments and bias: in flight under the tanh below
 #pragma unroll
-      for (int r = 0; r < 4; ++r) a1t[(q * 16 + lk * 4 + r) * L::HS + c * 16 + li] = fast_tanh(acc[c][r] + b1v[c]);
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) fW2[kt][t][r] = sPt[oW2 + (16 * kt + 4 * lk + r) * H + 16 * t + li];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) b2c[t][r] = sP[ob2 + 16 * t + 4 * lk + r];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        a1[t][r] = fast_tanh(acc[t][0][r] + acc[t][1][r]);
+        a1t[trow + 16 * t + r] = a1[t][r];
+      }
   }
-  wave_sync_lds();
   IA_TS(2);
-  // ---- a2 = tanh(a1 W2^T + b2)
+  // ---- a2^T = tanh(W2 a1^T + b2)
   {
-    f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-    float aa[8];
+    f32x4 acc[2][2] = {{{b2c[0][0], b2c[0][1], b2c[0][2], b2c[0][3]}, {0.f, 0.f, 0.f, 0.f}},
+                       {{b2c[1][0], b2c[1][1], b2c[1][2], b2c[1][3]}, {0.f, 0.f, 0.f, 0.f}}};
 #pragma unroll
-    for (int s = 0; s < 8; ++s) aa[s] = a1t[arow * L::HS + 4 * s + lk];
-    __builtin_amdgcn_sched_barrier(0);
+    for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-    for (int s = 0; s < 8; ++s) {
-      acc[0] = mfma16(aa[s], bW2[s][0], acc[0]);
-      acc[1] = mfma16(aa[s], bW2[s][1], acc[1]);
-    }
+      for (int r = 0; r < 4; ++r) {
+        acc[0][kt] = mfma16(fW2[kt][0][r], a1[kt][r], acc[0][kt]);
+        acc[1][kt] = mfma16(fW2[kt][1][r], a1[kt][r], acc[1][kt]);
+      }
+    {   // the head's fragments and bias: in flight under the tanh below
+      const bool head_on = tw == 0 ? li < A : li == 0;
+      float hraw[2][4], braw[4];
 #pragma unroll
-    for (int c = 0; c < 2; ++c)
+      for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) a2t[(q * 16 + lk * 4 + r) * L::HS + c * 16 + li] = fast_tanh(acc[c][r] + b2v[c]);
-  }
-  wave_sync_lds();
-  IA_TS(3);
-  // ---- heads (policy: action_net -> out[row][a]; value: value_net -> misc[row][0])
-  {
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    float aa[8];
+        for (int r = 0; r < 4; ++r) hraw[kt][r] = sP[head_base + 16 * kt + 4 * lk + r];
 #pragma unroll
-    for (int s = 0; s < 8; ++s) aa[s] = a2t[arow * L::HS + 4 * s + lk];
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int s = 0; s < 8; ++s) acc = mfma16(aa[s], bHead[s], acc);
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int row = q * 16 + lk * 4 + r;
-      if (tw == 0) { if (li < A) lds[L::out + row * L::AS + li] = acc[r] + head_bias; }
-      else if (li == 0) lds[L::misc + row * L::MS + 0] = acc[r] + head_bias;
-    }
-  }
-  wave_sync_lds();
-  IA_TS(4);
-  // backward weight fragments (W2 in torch orientation, action_net rows): requested here, behind the forward pass
-  // (24 registers less across it), and landed by the time the loss phase below is through
-#pragma unroll
-  for (int s = 0; s < 8; ++s)
-#pragma unroll
-    for (int c = 0; c < 2; ++c) bW2o[s][c] = sP[oW2 + (4 * s + lk) * H + c * 16 + li];
-#pragma unroll
-  for (int s = 0; s < 4; ++s)
-#pragma unroll
-    for (int c = 0; c < 2; ++c) bDa2[s][c] = sP[o.aW + min(4 * s + lk, A - 1) * H + c * 16 + li];
-  // ---- per-row losses of this wave's 16 rows (policy waves: four lanes per row; value waves: lanes 0..15)
-  if (loss_lane) {
-    if (tw == 0) {
-      const float* outrow = lds + L::out + lrow * L::AS;
-      float* doutrow = lds + L::dout + lrow * L::AS;
-      float* auxrow = lds + L::aux + lrow * L::AS;
-      float logp = 0.f, entropy = 0.f, lse = 0.f;
-      int act_i = 0;
-      float o_[4];   // the head outputs of this lane's actions, read in one batch (columns >= A hold zeros)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) o_[j] = outrow[part + 4 * j];
-      if (d.discrete) act_i = (int)r_act[0];
-      const float o_act = outrow[act_i];
+      for (int r = 0; r < 4; ++r) braw[r] = sP[tw == 0 ? o.ab + min(4 * lk + r, A - 1) : o.cb];
       __builtin_amdgcn_sched_barrier(0);
-      IA_TS(12);
-      auto quad_sum = [](float v) {
-        v += __shfl_xor(v, 1, 64);
-        v += __shfl_xor(v, 2, 64);
-        return v;
-      };
-      if (!d.discrete) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-          if (part + 4 * j < A) {
-            const float diff = r_act[j] - o_[j];
-            logp += -(diff * diff) * (0.5f * c_ivar[j]) - c_logsd[j] - LOG_SQRT_2PI;
-            entropy += 0.5f + LOG_SQRT_2PI + c_logsd[j];
-          }
-        logp = quad_sum(logp);
-        entropy = quad_sum(entropy);
-      } else {
-        float mx = -3.0e38f;
+      for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-          if (part + 4 * j < A) mx = fmaxf(mx, o_[j]);
-        mx = fmaxf(mx, __shfl_xor(mx, 1, 64));
-        mx = fmaxf(mx, __shfl_xor(mx, 2, 64));
-        float se = 0.f;
+        for (int r = 0; r < 4; ++r) fHead[kt][r] = head_on ? hraw[kt][r] : 0.f;
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-          if (part + 4 * j < A) se += expf(o_[j] - mx);
-        lse = mx + logf(quad_sum(se));
-        logp = o_act - lse;
+      for (int r = 0; r < 4; ++r) hb[r] = (tw == 0 && 4 * lk + r >= A) ? 0.f : braw[r];
+    }
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-          if (part + 4 * j < A) {
-            const float l = o_[j] - lse;
-            entropy -= expf(l) * l;
-          }
-        entropy = quad_sum(entropy);
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        a2[t][r] = fast_tanh(acc[t][0][r] + acc[t][1][r]);
+        a2t[trow + 16 * t + r] = a2[t][r];
       }
-      IA_TS(13);
-      float advn = r_adv;
-      if (normalize_adv && batch > 1) advn = (advn - adv_mean) / (adv_std + 1e-8f);
-      const float log_ratio = logp - r_oldlp;
-      const float ratio = expf(log_ratio);
-      const float lo = 1.f - clip, hi = 1.f + clip;
-      const float pl1 = advn * ratio;
-      const float pl2 = advn * fminf(fmaxf(ratio, lo), hi);
-      const float g1 = pl1 < pl2 ? 1.f : (pl1 == pl2 ? 0.5f : 0.f);
-      const float g2 = pl2 < pl1 ? 1.f : (pl1 == pl2 ? 0.5f : 0.f);
-      const float inrange = (ratio >= lo && ratio <= hi) ? 1.f : 0.f;
-      const float dlogp = valid ? -invB * advn * (g1 + g2 * inrange) * ratio : 0.f;
-      IA_TS(14);
-      if (!d.discrete) {
+  }
+  IA_TS(3);
+  // ---- heads (policy: hout[r] = action_net output 4 lk + r of row li; value: hout[0] of lane group 0 = value_net output)
+  float hout[4];
+  {
+    f32x4 acc[2] = {{hb[0], hb[1], hb[2], hb[3]}, {0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-          if (part + 4 * j < A) {
-            const float diff = r_act[j] - o_[j];
-            doutrow[part + 4 * j] = dlogp * diff * c_ivar[j];
-            auxrow[part + 4 * j] = valid ? dlogp * (diff * diff * c_ivar[j] - 1.f) - ent_coef * invB : 0.f;
-          }
-      } else {
+    for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-          if (part + 4 * j < A) {
-            const float l = o_[j] - lse, p = expf(l);
-            const float dH = -p * (l + entropy);
-            float g = dlogp * ((part + 4 * j == act_i ? 1.f : 0.f) - p);
-            g += valid ? -ent_coef * invB * dH : 0.f;
-            doutrow[part + 4 * j] = g;
-          }
-      }
-      if (part == 0) {
-        float* mrow = lds + L::misc + lrow * L::MS;
-        mrow[2] = valid ? -fminf(pl1, pl2) : 0.f;                           // policy_gradient_loss
-        mrow[3] = valid ? -entropy : 0.f;                                    // entropy_loss
-        mrow[4] = valid ? (ratio - 1.f) - log_ratio : 0.f;                   // approx_kl
-        mrow[5] = valid ? (fabsf(ratio - 1.f) > clip ? 1.f : 0.f) : 0.f;     // clip_fraction
-      }
-      IA_TS(15);
+      for (int r = 0; r < 4; ++r) acc[kt] = mfma16(fHead[kt][r], a2[kt][r], acc[kt]);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) hout[r] = acc[0][r] + acc[1][r];
+  }
+  IA_TS(4);
+  // backward weight fragments (W2 in torch orientation, action_net rows as the A operand's k index): requested here,
+  // behind the forward pass (24 registers less across it), and landed by the time the loss phase below is through
+#pragma unroll
+  for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) fW2T[kt][t][r] = sP[oW2 + (16 * kt + 4 * lk + r) * H + 16 * t + li];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r)   // (value waves: value_net's weights of outputs 16 t + 4 lk + r in the same registers)
+      fHeadT[t][r] = sP[tw == 0 ? o.aW + min(4 * lk + r, A - 1) * H + 16 * t + li : o.cW + 16 * t + 4 * lk + r];
+  // ---- per-row losses of this wave's 16 rows; dout[r] = d loss / d head output 4 lk + r of row li (registers: the B
+  // operand of the backward pass; the LDS copy is for the head's weight gradient)
+  float dout[4] = {0.f, 0.f, 0.f, 0.f}, dvb = 0.f;
+  if (tw == 0) {
+    float logp = 0.f, entropy = 0.f, lse = 0.f;
+    int act_i = 0;
+    if (d.discrete) act_i = (int)r_act[0];
+    IA_TS(12);
+    if (!d.discrete) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (4 * lk + j < A) {
+          const float diff = r_act[j] - hout[j];
+          logp += -(diff * diff) * (0.5f * c_ivar[j]) - c_logsd[j] - LOG_SQRT_2PI;
+          entropy += 0.5f + LOG_SQRT_2PI + c_logsd[j];
+        }
+      logp = group_sum(logp);
+      entropy = group_sum(entropy);   // (the same for every row; two VALU exchanges)
     } else {
-      const float v = lds[L::misc + lrow * L::MS + 0];
-      const float verr = r_ret - v;
-      lds[L::misc + lrow * L::MS + 1] = valid ? vf_coef * 2.f * (v - r_ret) * invB : 0.f;
+      float mx = -3.0e38f, o_act = 0.f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (4 * lk + j < A) {
+          mx = fmaxf(mx, hout[j]);
+          o_act += (4 * lk + j == act_i) ? hout[j] : 0.f;
+        }
+      mx = group_max(mx);
+      o_act = group_sum(o_act);
+      float se = 0.f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (4 * lk + j < A) se += expf(hout[j] - mx);
+      lse = mx + logf(group_sum(se));
+      logp = o_act - lse;
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (4 * lk + j < A) {
+          const float l = hout[j] - lse;
+          entropy -= expf(l) * l;
+        }
+      entropy = group_sum(entropy);
+    }
+    IA_TS(13);
+    float advn = r_adv;
+    if (normalize_adv && batch > 1) advn = (advn - adv_mean) / (adv_std + 1e-8f);
+    const float log_ratio = logp - r_oldlp;
+    const float ratio = expf(log_ratio);
+    const float lo = 1.f - clip, hi = 1.f + clip;
+    const float pl1 = advn * ratio;
+    const float pl2 = advn * fminf(fmaxf(ratio, lo), hi);
+    const float g1 = pl1 < pl2 ? 1.f : (pl1 == pl2 ? 0.5f : 0.f);
+    const float g2 = pl2 < pl1 ? 1.f : (pl1 == pl2 ? 0.5f : 0.f);
+    const float inrange = (ratio >= lo && ratio <= hi) ? 1.f : 0.f;
+    const float dlogp = valid ? -invB * advn * (g1 + g2 * inrange) * ratio : 0.f;
+    IA_TS(14);
+    float* doutrow = lds + L::dout + lrow * L::AS;
+    float* auxrow = lds + L::aux + lrow * L::AS;
+    if (!d.discrete) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (4 * lk + j < A) {
+          const float diff = r_act[j] - hout[j];
+          dout[j] = dlogp * diff * c_ivar[j];
+          doutrow[4 * lk + j] = dout[j];
+          auxrow[4 * lk + j] = valid ? dlogp * (diff * diff * c_ivar[j] - 1.f) - ent_coef * invB : 0.f;
+        }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (4 * lk + j < A) {
+          const float l = hout[j] - lse, p = expf(l);
+          const float dH = -p * (l + entropy);
+          float g = dlogp * ((4 * lk + j == act_i ? 1.f : 0.f) - p);
+          g += valid ? -ent_coef * invB * dH : 0.f;
+          dout[j] = g;
+          doutrow[4 * lk + j] = g;
+        }
+    }
+    if (lk == 0) {
+      float* mrow = lds + L::misc + lrow * L::MS;
+      mrow[2] = valid ? -fminf(pl1, pl2) : 0.f;                           // policy_gradient_loss
+      mrow[3] = valid ? -entropy : 0.f;                                    // entropy_loss
+      mrow[4] = valid ? (ratio - 1.f) - log_ratio : 0.f;                   // approx_kl
+      mrow[5] = valid ? (fabsf(ratio - 1.f) > clip ? 1.f : 0.f) : 0.f;     // clip_fraction
+    }
+    IA_TS(15);
+  } else {
+    // value_net's only output row is m = 0: lane group 0, register 0 holds V(row li); every group needs its gradient
+    const float v = __shfl(hout[0], li, 64);
+    const float verr = r_ret - v;
+    dvb = valid ? vf_coef * 2.f * (v - r_ret) * invB : 0.f;
+    if (lk == 0) {
+      lds[L::misc + lrow * L::MS + 1] = dvb;
       lds[L::misc + lrow * L::MS + 6] = valid ? verr * verr : 0.f;        // value_loss
     }
   }
-  wave_sync_lds();
   IA_TS(5);
-  // ---- dz2 = d(a2) * (1 - a2^2) for this wave's rows
+  // ---- dz2^T = (W_head^T d head^T) * (1 - a2^2) for this wave's rows
+  f32x4 dz2[2];
   if (tw == 0) {
     f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-    float da[4], act[2][4];   // all operands of this phase in one batch (columns >= A of dout are zero)
 #pragma unroll
-    for (int s = 0; s < 4; ++s) da[s] = lds[L::dout + arow * L::AS + 4 * s + lk];
-#pragma unroll
-    for (int c = 0; c < 2; ++c)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) act[c][r] = a2t[(q * 16 + lk * 4 + r) * L::HS + c * 16 + li];
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int s = 0; s < 4; ++s)
-      if (s < SA) {
-        const bool on = 4 * s + lk < A;
-        acc[0] = mfma16(da[s], on ? bDa2[s][0] : 0.f, acc[0]);
-        acc[1] = mfma16(da[s], on ? bDa2[s][1] : 0.f, acc[1]);
+    for (int r = 0; r < 4; ++r)
+      if (r < A) {   // (k-step r carries actions r, 4 + r, 8 + r, 12 + r; rows of actions >= A are masked)
+        const bool on = 4 * lk + r < A;
+        acc[0] = mfma16(on ? fHeadT[0][r] : 0.f, dout[r], acc[0]);
+        acc[1] = mfma16(on ? fHeadT[1][r] : 0.f, dout[r], acc[1]);
       }
 #pragma unroll
-    for (int c = 0; c < 2; ++c)
+    for (int t = 0; t < 2; ++t)
 #pragma unroll
-      for (int r = 0; r < 4; ++r)
-        dz2t[(q * 16 + lk * 4 + r) * L::HS + c * 16 + li] = acc[c][r] * (1.f - act[c][r] * act[c][r]);
+      for (int r = 0; r < 4; ++r) dz2[t][r] = acc[t][r] * (1.f - a2[t][r] * a2[t][r]);
   } else {
-    float act[2][4], dv[4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      dv[r] = lds[L::misc + (q * 16 + lk * 4 + r) * L::MS + 1];
+    for (int t = 0; t < 2; ++t)
 #pragma unroll
-      for (int c = 0; c < 2; ++c) act[c][r] = a2t[(q * 16 + lk * 4 + r) * L::HS + c * 16 + li];
-    }
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int c = 0; c < 2; ++c)
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-        dz2t[(q * 16 + lk * 4 + r) * L::HS + c * 16 + li] = cwv[c] * dv[r] * (1.f - act[c][r] * act[c][r]);
+      for (int r = 0; r < 4; ++r) dz2[t][r] = fHeadT[t][r] * dvb * (1.f - a2[t][r] * a2[t][r]);
   }
-  wave_sync_lds();
-  // ---- dz1 = (dz2 W2) * (1 - a1^2) for this wave's rows
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) dz2t[trow + 16 * t + r] = dz2[t][r];
+  // ---- dz1^T = (W2^T dz2^T) * (1 - a1^2) for this wave's rows
   {
-    f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-    float dd[8], act[2][4];
+    f32x4 acc[2][2] = {{{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}};
 #pragma unroll
-    for (int s = 0; s < 8; ++s) dd[s] = dz2t[arow * L::HS + 4 * s + lk];
+    for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-    for (int c = 0; c < 2; ++c)
+      for (int r = 0; r < 4; ++r) {
+        acc[0][kt] = mfma16(fW2T[kt][0][r], dz2[kt][r], acc[0][kt]);
+        acc[1][kt] = mfma16(fW2T[kt][1][r], dz2[kt][r], acc[1][kt]);
+      }
 #pragma unroll
-      for (int r = 0; r < 4; ++r) act[c][r] = a1t[(q * 16 + lk * 4 + r) * L::HS + c * 16 + li];
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int s = 0; s < 8; ++s) {
-      acc[0] = mfma16(dd[s], bW2o[s][0], acc[0]);
-      acc[1] = mfma16(dd[s], bW2o[s][1], acc[1]);
-    }
-#pragma unroll
-    for (int c = 0; c < 2; ++c)
+    for (int t = 0; t < 2; ++t)
 #pragma unroll
       for (int r = 0; r < 4; ++r)
-        dz1t[(q * 16 + lk * 4 + r) * L::HS + c * 16 + li] = acc[c][r] * (1.f - act[c][r] * act[c][r]);
+        dz1t[trow + 16 * t + r] = (acc[t][0][r] + acc[t][1][r]) * (1.f - a1[t][r] * a1[t][r]);
   }
   __syncthreads();   // every row's activations and activation gradients are in LDS
   IA_TS(6);
@@ -2435,8 +2474,10 @@ __device__ __forceinline__ void mfma32_minibatch_chain(
   // (minibatches of <= 16 rows -- the reference's tuned AIRL configuration -- contract over the first four row steps
   //  only: the gradient rows past the minibatch are exact zeros, so the remaining twelve steps add nothing)
   const bool few_rows = row_lim - i0 <= 16;   // wave-uniform
+  // (two accumulator chains per tile -- even / odd row steps, added at the end: a chain of sixteen dependent MFMAs is
+  //  16 x 40 clocks of latency against 16 x 32 of issue; with two chains the pipe is the limit)
   auto outer16 = [&](const float* __restrict__ U, int us, int ucol, const float* __restrict__ V, int vs, int vcol) {
-    f32x4 g = {0.f, 0.f, 0.f, 0.f};
+    f32x4 g = {0.f, 0.f, 0.f, 0.f}, g2 = {0.f, 0.f, 0.f, 0.f};
     if (few_rows) {
       float u[4], v[4];
 #pragma unroll
@@ -2446,8 +2487,11 @@ __device__ __forceinline__ void mfma32_minibatch_chain(
       }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int s = 0; s < 4; ++s) g = mfma16(u[s], v[s], g);
-      return g;
+      for (int s = 0; s < 4; s += 2) {
+        g = mfma16(u[s], v[s], g);
+        g2 = mfma16(u[s + 1], v[s + 1], g2);
+      }
+      return g + g2;
     }
     float u[16], v[16];
 #pragma unroll
@@ -2457,8 +2501,54 @@ __device__ __forceinline__ void mfma32_minibatch_chain(
     }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int s = 0; s < 16; ++s) g = mfma16(u[s], v[s], g);
-    return g;
+    for (int s = 0; s < 16; s += 2) {
+      g = mfma16(u[s], v[s], g);
+      g2 = mfma16(u[s + 1], v[s + 1], g2);
+    }
+    return g + g2;
+  };
+  // two tiles at once: all 64 operands requested first, then four interleaved chains
+  auto outer16_pair = [&](const float* __restrict__ U0, int us0, int ucol0, const float* __restrict__ V0, int vs0, int vcol0,
+                          const float* __restrict__ U1, int us1, int ucol1, const float* __restrict__ V1, int vs1, int vcol1,
+                          f32x4& r0, f32x4& r1) {
+    f32x4 g0 = {0.f, 0.f, 0.f, 0.f}, g0b = {0.f, 0.f, 0.f, 0.f}, g1 = {0.f, 0.f, 0.f, 0.f}, g1b = {0.f, 0.f, 0.f, 0.f};
+    if (few_rows) {
+      float u0[4], v0[4], u1[4], v1[4];
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        u0[s] = U0[(4 * s + lk) * us0 + ucol0];
+        v0[s] = V0[(4 * s + lk) * vs0 + vcol0];
+        u1[s] = U1[(4 * s + lk) * us1 + ucol1];
+        v1[s] = V1[(4 * s + lk) * vs1 + vcol1];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int s = 0; s < 4; s += 2) {
+        g0 = mfma16(u0[s], v0[s], g0);
+        g1 = mfma16(u1[s], v1[s], g1);
+        g0b = mfma16(u0[s + 1], v0[s + 1], g0b);
+        g1b = mfma16(u1[s + 1], v1[s + 1], g1b);
+      }
+    } else {
+      float u0[16], v0[16], u1[16], v1[16];
+#pragma unroll
+      for (int s = 0; s < 16; ++s) {
+        u0[s] = U0[(4 * s + lk) * us0 + ucol0];
+        v0[s] = V0[(4 * s + lk) * vs0 + vcol0];
+        u1[s] = U1[(4 * s + lk) * us1 + ucol1];
+        v1[s] = V1[(4 * s + lk) * vs1 + vcol1];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int s = 0; s < 16; s += 2) {
+        g0 = mfma16(u0[s], v0[s], g0);
+        g1 = mfma16(u1[s], v1[s], g1);
+        g0b = mfma16(u0[s + 1], v0[s + 1], g0b);
+        g1b = mfma16(u1[s + 1], v1[s + 1], g1b);
+      }
+    }
+    r0 = g0 + g0b;
+    r1 = g1 + g1b;
   };
   // a column sum over the 64 rows with four lanes per column (16 rows each) and a cross-lane add
   auto colsum64 = [&](const float* __restrict__ tile, int stride, int ncols, float* __restrict__ dst) {
@@ -2537,22 +2627,32 @@ __device__ __forceinline__ void mfma32_minibatch_chain(
       }
     }
   }
-  {  // dW2 (one 16x16 tile per wave), db2
-    const int jt = q >> 1, kt = q & 1;
-    const f32x4 g = outer16(dz2t, L::HS, jt * 16 + li, a1t, L::HS, kt * 16 + li);
-#pragma unroll
-    for (int r = 0; r < 4; ++r) put(slab + (oW2 + (jt * 16 + lk * 4 + r) * H + kt * 16 + li), g[r]);
-    if (q == 3) colsum64_wide(dz2t, L::HS, slab + ob2);
-  }
-  {  // dW1 tiles (dz1^T x), db1
+  {  // dW2 (one 16x16 tile per wave) together with the wave's first dW1 tile (dz1^T x); db2, db1
     const int KT = (D + 15) >> 4;
-    for (int ti = q; ti < 2 * KT; ti += 4) {
+    const int jt2 = q >> 1, kt2 = q & 1;
+    auto store_w1 = [&](int ti, const f32x4& g) {
       const int jt = ti / KT, kt = ti - jt * KT;
-      const f32x4 g = outer16(dz1t, L::HS, jt * 16 + li, lds + L::x, L::XS, kt * 16 + li);
       const int col = kt * 16 + li;
       if (col < D)
 #pragma unroll
         for (int r = 0; r < 4; ++r) put(slab + (oW1 + (jt * 16 + lk * 4 + r) * D + col), g[r]);
+    };
+    f32x4 g2;
+    if (q < 2 * KT) {   // (wave-uniform)
+      const int jt = q / KT, kt = q - jt * KT;
+      f32x4 g1;
+      outer16_pair(dz2t, L::HS, jt2 * 16 + li, a1t, L::HS, kt2 * 16 + li, dz1t, L::HS, jt * 16 + li, lds + L::x, L::XS,
+                   kt * 16 + li, g2, g1);
+      store_w1(q, g1);
+    } else {
+      g2 = outer16(dz2t, L::HS, jt2 * 16 + li, a1t, L::HS, kt2 * 16 + li);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) put(slab + (oW2 + (jt2 * 16 + lk * 4 + r) * H + kt2 * 16 + li), g2[r]);
+    if (q == 3) colsum64_wide(dz2t, L::HS, slab + ob2);
+    for (int ti = q + 4; ti < 2 * KT; ti += 4) {   // observation widths beyond 32 columns: further dW1 tiles
+      const int jt = ti / KT, kt = ti - jt * KT;
+      store_w1(ti, outer16(dz1t, L::HS, jt * 16 + li, lds + L::x, L::XS, kt * 16 + li));
     }
     if (q == 2) colsum64_wide(dz1t, L::HS, slab + ob1);
   }

@@ -647,4 +647,8 @@ def test_bench_two_rank_launch_line_on_one_gpu(tmp_path):
     out = json.loads(line)
     assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["value"] > 0
     assert out["config"]["parallelism"] == "dp2"
-    assert out["roofline"]["disc_update"]["path"].startswith("fused")   # not the general 16-launch update
+    assert out["details"]["roofline_disc_update"]["path"].startswith("fused")   # not the general 16-launch update
+    assert out["summary"]["disc_update"]["path"] == "fused" and out["tail_summary"] == out["summary"]
+    # the PPO update sharded each global minibatch's rows over the ranks (in-kernel record exchange through hipIpc memory)
+    assert out["config"]["ppo_update"].startswith("row-sharded")
+    assert all(not isinstance(v, (dict, list)) for v in out["roofline"].values())   # flat: scalars survive any parser

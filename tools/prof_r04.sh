@@ -1,0 +1,21 @@
+# Round-4 measurements (run through gpurun; summaries are copied to profiles/ by hand):
+#  1 kernel trace of the headline command   2 HBM-traffic PMC passes (separate runs)   3 matrix-pipe counters for the
+#  discriminator update alone (SQ_VALU_MFMA_BUSY_CYCLES & friends, per MI355X_MICROARCH.md's counter notes)
+#  4 kernel trace of variant H (1 024 000-transition rounds): the bandwidth-bound kernels against 8 TB/s
+set -x
+cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp; O=gpurun_out/r04; mkdir -p $O
+rocprofv3 -L 2>/dev/null | grep -i -E "MFMA|SQ_BUSY_CU|GRBM_GUI_ACTIVE|SQ_WAVE_CYCLES|SQ_ACTIVE_INST_ANY|SQ_WAIT_INST_ANY" | cut -c1-160 | sort -u | head -40 > $O/counters_available.txt
+rocprofv3 --kernel-trace --stats -d $O/kt -- python bench.py --steps 20 --warmup 5 --no-variants --no-cpu-baseline > $O/kt_bench.json 2> $O/kt.log
+DB=$(find $O/kt -name "*results.db" | head -1); python tools/rocpd_stats.py $DB $O/kernel_stats_bench.md | head -16
+for c in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --kernel-trace --pmc $c -d $O/pmc_$c -- python bench.py --steps 8 --warmup 3 --no-variants --no-cpu-baseline --prof-rounds 0 > /dev/null 2> $O/pmc_$c.log
+  DB=$(find $O/pmc_$c -name "*results.db" | head -1); python tools/rocpd_pmc.py $DB > $O/pmc_$c.txt; grep -E "ppo_update_persistent|disc_fb|disc_reduce|ia_gemm_kernelILi2ELi2ELi1ELi1ELi2|disc_assemble|rn_merge_seq" $O/pmc_$c.txt | cut -c1-60,92-
+done
+for c in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES" "SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_WAVE_CYCLES" "GRBM_GUI_ACTIVE SQ_ACTIVE_INST_ANY"; do
+  n=$(echo $c | tr ' ' '_')
+  rocprofv3 --kernel-trace --pmc $c -d $O/pmc_$n -- python tools/disc_step_bench.py 8 > $O/pmc_$n.log 2>&1
+  DB=$(find $O/pmc_$n -name "*results.db" | head -1); python tools/rocpd_pmc.py $DB > $O/pmc_$n.txt 2>> $O/pmc_$n.log; grep -E "disc_fb|disc_reduce|ia_gemm_kernelILi2" $O/pmc_$n.txt | cut -c1-50,92-
+done
+rocprofv3 --kernel-trace --stats -d $O/kt_H -- python tools/variant_profile.py H_horizon_1024x1000 2 > $O/kt_H.log 2>&1
+DB=$(find $O/kt_H -name "*results.db" | head -1); python tools/rocpd_stats.py $DB $O/kernel_stats_H.md | head -30
+find $O -name "*.db" -delete; find $O -name "*.csv" -size +2M -delete; du -sh $O
