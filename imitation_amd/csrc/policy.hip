@@ -796,6 +796,17 @@ __device__ __forceinline__ void column_sum_store(const float* tile, int stride, 
 __device__ __forceinline__ void slab_store(float* p, float v) {
   __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
+// (value, sequence) words: one aligned 8-byte store / load each, past the caches of the other compute units (agent scope:
+// within the GPU; system scope: peer-mapped memory of another GPU)
+__device__ __forceinline__ unsigned long long ll_pack(float v, unsigned seq) {
+  return ((unsigned long long)seq << 32) | (unsigned long long)__float_as_uint(v);
+}
+__device__ __forceinline__ void ll_store_agent(unsigned long long* p, float v, unsigned seq) {
+  __hip_atomic_store(p, ll_pack(v, seq), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void ll_store_system(unsigned long long* p, float v, unsigned seq) {
+  __hip_atomic_store(p, ll_pack(v, seq), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 
 // The same sums (rows added in order 0 .. ROWS-1) with the reads issued sixteen at a time.
 __device__ __forceinline__ float column_sum_b(const float* col, int stride) {
@@ -2048,16 +2059,20 @@ __device__ __forceinline__ void mfma32_minibatch_chain(
     const float adv_std, const MbRows rows, const int i0_in, const int row_lim, const int normalize_adv, const float clip,
     const float ent_coef, const float vf_coef, float* __restrict__ slab_g, float* __restrict__ statpart,
     float* __restrict__ lds_in, const float* __restrict__ sP_in, float* __restrict__ stg_in,
-    const int opaque_zero, long long* __restrict__ tstamp) {
+    const int opaque_zero, long long* __restrict__ tstamp, const unsigned ll_seq) {
   // `i0_in`: first minibatch row of this workgroup; `row_lim`: rows at or beyond it are not this workgroup's (the
   // minibatch size, or -- row-sharded data parallelism -- the end of this rank's row range inside the global minibatch);
   // means are over `rows.batch`, the whole (global) minibatch, either way
   float* __restrict__ lds = lds_in + opaque_zero;
   const float* __restrict__ stg = stg_in + opaque_zero;
+  // Several gradient workgroups: `slab_g` is this workgroup's slab of 8-byte (value, sequence) words -- a naturally aligned
+  // 8-byte store arrives whole, so a reader needs no flag, the writer no acknowledgement, fence or barrier: the words are
+  // fire-and-forget and the consumers spin on the sequence number they carry (`ll_seq`: this step's).
   float* __restrict__ slab = LOCAL ? stg_in + opaque_zero + UpdStage::x : slab_g;
+  unsigned long long* __restrict__ slab64 = reinterpret_cast<unsigned long long*>(slab_g);
   auto put = [&](float* p, float v) {
     if constexpr (LOCAL) *p = v;
-    else slab_store(p, v);
+    else ll_store_agent(slab64 + (p - slab), v, ll_seq);
   };
   const int batch = rows.batch;
   constexpr int H = 32;
@@ -2072,7 +2087,7 @@ __device__ __forceinline__ void mfma32_minibatch_chain(
   const int i0 = i0_in;
   const int aw = d.discrete ? 1 : A;
   const float invB = 1.f / (float)batch;
-  const int S1 = (D + 3) >> 2, SA = (A + 3) >> 2;
+  const int S1 = (D + 3) >> 2;
   const int oW1 = tw ? o.vW1 : o.pW1, ob1 = tw ? o.vb1 : o.pb1, oW2 = tw ? o.vW2 : o.pW2, ob2 = tw ? o.vb2 : o.pb2;
   const float* __restrict__ sP = sP_in + opaque_zero;
   const float* __restrict__ sPt = sP + ((o.total + 3) & ~3);
@@ -2623,7 +2638,8 @@ __device__ __forceinline__ void mfma32_minibatch_chain(
       if (lane >= 1 && lane < 6) {
         const int m = lane - 1;                      // misc column 2 + m
         const int slot = m == 0 ? 0 : (m == 4 ? 1 : m + 1);
-        slab_store(statpart + slot, sm);   // (write-through in both forms; LOCAL drains it below)
+        if constexpr (LOCAL) slab_store(statpart + slot, sm);   // (write-through; the caller drains it)
+        else ll_store_agent(slab64 + (((o.total + 3) & ~3) + slot), sm, ll_seq);   // the slab's tail
       }
     }
   }
@@ -2979,8 +2995,6 @@ constexpr int UPD_SLICE = 512;                    // rows per statistics slice (
 constexpr int UPD_SLICES_MAX = 32;                // => minibatches up to 16 384 rows
 constexpr int UPD_PRS = 2 * MAXD + 4;             // slice partial: mean[MAXD], M2[MAXD], adv mean, adv M2, rows
 constexpr int UPD_SD = 8;                         // depth of the loss-statistic partial ring (> UPD_RING + 2)
-constexpr int UPD_GROUP = 16;                     // slabs summed per first-level group
-constexpr int UPD_GROUPS_MAX = 16;                // => up to 256 gradient blocks (16 384-row minibatches)
 constexpr int UPD_NBLK_MAX = 192;                 // co-residency: nblk + 1 workgroups on 256 CUs
 struct UpdSched {
   int n_steps, first, n_mb, batch_size;
@@ -3011,8 +3025,10 @@ struct ShardArgs {
 struct UpdWs {
   unsigned* ctrl;
   float *tab;   // [2][UPD_MAX_STEPS]: Adam step size lr/(1-b1^t) and sqrt(1-b2^t) per step (host doubles)
-  float *ring, *normcoef, *statpart, *slabs;   // normcoef: [UPD_SD][2] gradient norm, clip coefficient
-  float *partials;                             // [2][UPD_GROUPS_MAX][P4]: first reduction level when nblk > UPD_GROUP
+  float *ring, *normcoef, *statpart;           // normcoef: [UPD_SD][2] gradient norm, clip coefficient
+  unsigned long long *slabs64;                 // [2][nblk][P4 + 8] (value, sequence) words: the workgroups' gradient slabs,
+                                               // tail = their loss-statistic partials (several gradient workgroups only)
+  unsigned long long *sums64;                  // [2][P4 + 8]: the reduced vector, published slice by slice
   float *pring;                                // [UPD_RING][UPD_SLICES_MAX][UPD_PRS]: statistics slice partials
   int P4;
 };
@@ -3024,9 +3040,11 @@ __host__ __device__ inline UpdWs upd_ws(float* ws, int nblk, int P) {
   w.ring = w.tab + 2 * UPD_MAX_STEPS;
   w.normcoef = w.ring + UPD_RING * UPD_RS;
   w.statpart = w.normcoef + UPD_SD * 2;
-  w.slabs = w.statpart + UPD_SD * nblk * 8;
-  w.partials = w.slabs + 2 * (long long)nblk * w.P4;
-  w.pring = w.partials + 2 * (long long)UPD_GROUPS_MAX * w.P4;
+  float* slabs = w.statpart + UPD_SD * nblk * 8;
+  w.slabs64 = reinterpret_cast<unsigned long long*>(slabs);
+  float* sums = slabs + 4 * (long long)nblk * (w.P4 + 8);
+  w.sums64 = reinterpret_cast<unsigned long long*>(sums);
+  w.pring = sums + 4 * (long long)(w.P4 + 8);
   return w;
 }
 
@@ -3303,7 +3321,7 @@ __global__ __launch_bounds__(512) void ppo_update_persistent_kernel(
   constexpr int H = 32;
   using L = CLds;
   extern __shared__ float lds[];
-  __shared__ int s_ok, s_pub;
+  __shared__ int s_ok, s_pub, s_fail;
   if (!TIMING) tstamp = nullptr;
   long long tacc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   long long tprev = 0;
@@ -3318,9 +3336,12 @@ __global__ __launch_bounds__(512) void ppo_update_persistent_kernel(
   const UpdWs w = upd_ws(ws, nblk, o.total);
   unsigned* arrivals = w.ctrl + 64;   // UPD_ARR counters, 16 words apart
   unsigned* published = w.ctrl + 1;
-  unsigned* arrivals2 = w.ctrl + 2;   // second-level barrier (group leaders only)
   unsigned* sliced = w.ctrl + 16;     // [n_slices] steps whose partial moments slicer j has written
   unsigned* err = w.ctrl + 8;
+  // sequence numbers of the (value, sequence) words: they only ever grow over the workspace's life (word 9 of it, advanced
+  // by workgroup 0 when a launch ends) -- a word left by an earlier launch can never pass for this one's
+  const unsigned lseq_base = __hip_atomic_load(w.ctrl + 9, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (threadIdx.x == 0) s_fail = 0;
 
   // schedule scalars in registers; the per-step tables are read straight from the kernel arguments
   const int sch_first = sch.first, sch_nmb = sch.n_mb, sch_bs = sch.batch_size, n_steps = sch.n_steps;
@@ -3372,7 +3393,7 @@ __global__ __launch_bounds__(512) void ppo_update_persistent_kernel(
     // step q's partials and its (norm, coef) pair are published by barrier q+1's release fences.
     int q = 0;
     auto drain = [&](int upto /* exclusive */) {
-      if constexpr (SHARD) return;   // (gradient workgroup 0 writes them itself: it holds every rank's sums)
+      if constexpr (SHARD || !LOCAL) return;   // (gradient workgroup 0 writes them itself: it holds the sums)
       for (; q < upto; ++q)
         write_loss_stats(q, *reinterpret_cast<const volatile float*>(w.normcoef + (q % UPD_SD) * 2),
                          *reinterpret_cast<const volatile float*>(w.normcoef + (q % UPD_SD) * 2 + 1));
@@ -3382,7 +3403,7 @@ __global__ __launch_bounds__(512) void ppo_update_persistent_kernel(
     for (int s = 0; s < n_steps; ++s) {
       if (s >= UPD_RING) {  // the slot is free once every gradient block has arrived at barrier s - RING
         if (tid < 64) {
-          const bool ok = spin_arrivals(arrivals, (unsigned)(s - UPD_RING + 1), nblk, err);
+          const bool ok = spin_arrivals(arrivals, (unsigned)(s - UPD_RING + 1), 1, err);   // (workgroup 0's steps)
           if (tid == 0) {
             s_ok = ok;
             __threadfence();
@@ -3462,7 +3483,7 @@ __global__ __launch_bounds__(512) void ppo_update_persistent_kernel(
     if (tstamp && tid == 0) { tstamp[12] += sb_acc[0]; tstamp[13] += sb_acc[1]; tstamp[14] += sb_acc[2]; }
 #undef SB_TS
     if (tid < 64) {
-      const bool ok = spin_arrivals(arrivals, (unsigned)n_steps, nblk, err);
+      const bool ok = spin_arrivals(arrivals, (unsigned)n_steps, 1, err);
       if (tid == 0) {
         s_ok = ok;
         __threadfence();
@@ -3665,20 +3686,20 @@ __global__ __launch_bounds__(512) void ppo_update_persistent_kernel(
     // Adam's scalars of this step: requested now (a global load), consumed after the grid barrier
     const float step_size = w.tab[s], bc2_sqrt = w.tab[UPD_MAX_STEPS + s];
     if (s + 1 < n_steps) prefetch_resolve(s + 1);  // published by the block barriers inside the minibatch
-    float* slab_base = w.slabs + (long long)(s & 1) * nblk * w.P4;
+    const int P8 = w.P4 + 8;
+    const unsigned lseq = lseq_base + (unsigned)s + 1u;
+    unsigned long long* slabs_s = w.slabs64 + (long long)(s & 1) * nblk * P8;
     float* stat_base = w.statpart + (s % UPD_SD) * nblk * 8;
     int oz;
     asm volatile("s_mov_b32 %0, 0" : "=s"(oz));
     mfma32_minibatch_chain<KS1, LOCAL>(d, slot, slot + MAXD, adv_mean, adv_std, r, row_lo + vb * ROWS, row_lim(r),
-                                       normalize_adv, clip, ent_coef, vf_coef, slab_base + (long long)vb * w.P4,
-                                       stat_base + vb * 8, lds, sP, stg, oz, tstamp ? tstamp + 16 : nullptr);
-    // (the minibatch ends with a block barrier: every slab store of this block has been issued)
+                                       normalize_adv, clip, ent_coef, vf_coef,
+                                       reinterpret_cast<float*>(slabs_s + (long long)vb * P8), stat_base + vb * 8, lds, sP,
+                                       stg, oz, tstamp ? tstamp + 16 : nullptr, lseq);
+    // (the minibatch ends with a block barrier: the LDS tiles are free; several workgroups: the slab words are on their
+    //  way, nobody waits for them here)
     UPD_TS(1);
-    if (!local && tid == 0) {  // arrive first; the prefetch below overlaps the wait for the other blocks
-      __threadfence();
-      UPD_TS(7);
-      __hip_atomic_fetch_add(arrivals + 16 * (vb & (UPD_ARR - 1)), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
+    UPD_TS(7);
     UPD_TS(8);
     float g[NPT];
     if (local) {
@@ -3696,18 +3717,167 @@ __global__ __launch_bounds__(512) void ppo_update_persistent_kernel(
       prefetch_issue(s + 1, pz);
     }
     UPD_TS(9);
-    if (tid < 64) {
-      const bool ok = local ? true : spin_arrivals(arrivals, (unsigned)(s + 1), nblk, err);
+    if constexpr (LOCAL) {
       if (tid == 0) {
-        s_ok = ok;
+        s_ok = 1;
         s_pub = (int)__hip_atomic_load(published, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         UPD_TS(10);
         __threadfence();
         UPD_TS(11);
       }
+      __syncthreads();
+    } else {
+      // ---- Several gradient workgroups: the exchange of the step, without a grid barrier. Every workgroup's slab is on
+      // its way as (value, sequence) words; workgroup b owns SLICE b of the parameter range:
+      //   hop 1  it polls slice b of ALL slabs (nblk x SL words over its lanes, each lane spinning on its own words), sums
+      //          them in slab order through an LDS scratch, and publishes the slice of the sum vector (again as words);
+      //   hop 2  every workgroup polls the whole sum vector (its parameters-per-thread words per lane).
+      // Two one-way trips through memory; nobody waits for a store acknowledgement, a release fence or an arrival count
+      // (before: write-through stores acknowledged, fence, arrive, spin, acquire, then every workgroup read all nblk slabs --
+      // 224 KB through one CU's L1 per step at 16 slabs, two levels beyond 32). Slabs and sum vector are double-buffered by
+      // step parity: a word of step s + 2 can only be written after every workgroup has published (hence finished reading
+      // for) step s + 1. Row-sharded data parallelism adds one hop between the two: the slice of this RANK's sum goes to every
+      // rank's receive area, the slice's owner sums the ranks' words in rank order and publishes the global slice.
+      using u64 = unsigned long long;
+      const int SL = (P8 + nblk - 1) / nblk;   // slice length
+      const unsigned rcpSL = (unsigned)((0x100000000ull + (unsigned)SL - 1) / (unsigned)SL);
+      float* red = lds + L::a1;                // scratch [nblk][SL] (the activation tiles are free until the next minibatch)
+      auto valid_el = [&](int gi) { return gi < o.total || (gi >= w.P4 && gi < w.P4 + 5); };   // written elements only
+      bool fail = false;
+      const long long t0 = wall_clock64();
+      const long long local_timeout = 200000000ll;   // 2 s of the 100 MHz clock
+      {   // hop 1: this workgroup's slice of every slab
+        u64 t[NPT];
+        int gi_[NPT];
+        unsigned need = 0u;
+        int ez;
+        asm volatile("s_mov_b32 %0, 0" : "=s"(ez));
+#pragma unroll
+        for (int k = 0; k < NPT; ++k) {
+          const int f = tid + ez + k * 512;
+          const int j = (int)__umulhi((unsigned)f, rcpSL), e = f - j * SL;
+          const int gi = vb * SL + e;
+          gi_[k] = min(j, nblk - 1) * P8 + min(gi, P8 - 1);
+          if (f < nblk * SL && valid_el(gi)) need |= 1u << k;
+        }
+        for (unsigned it = 0;;) {
+#pragma unroll
+          for (int k = 0; k < NPT; ++k)   // (unconditional loads at clamped addresses, all in flight together)
+            t[k] = __hip_atomic_load(slabs_s + gi_[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __builtin_amdgcn_sched_barrier(0);
+          bool ok = true;
+#pragma unroll
+          for (int k = 0; k < NPT; ++k) ok = ok && (!((need >> k) & 1u) || (unsigned)(t[k] >> 32) == lseq);
+          if (ok) break;
+          __builtin_amdgcn_s_sleep(1);
+          if ((++it & 255u) == 0 &&
+              (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) || wall_clock64() - t0 > local_timeout)) {
+            fail = true;
+            break;
+          }
+        }
+#pragma unroll
+        for (int k = 0; k < NPT; ++k) {
+          const int f = tid + k * 512;
+          if (f < nblk * SL) red[f] = ((need >> k) & 1u) ? __uint_as_float((unsigned)t[k]) : 0.f;
+        }
+      }
+      UPD_TS(10);
+      if (tid == 0) s_pub = (int)__hip_atomic_load(published, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (fail) s_fail = 1;
+      __syncthreads();
+      if (s_fail) {
+        if (tid == 0) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+      }
+      u64* sums_s = w.sums64 + (long long)(s & 1) * P8;
+      for (int e = tid; e < SL; e += 512) {   // slice sums in slab order (reads eight at a time), then on their way
+        const int gi = vb * SL + e;
+        float part = 0.f;
+        int j = 0;
+        for (; j + 8 <= nblk; j += 8) {
+          float tt[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) tt[u] = red[(j + u) * SL + e];
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int u = 0; u < 8; ++u) part += tt[u];
+        }
+        for (; j < nblk; ++j) part += red[j * SL + e];
+        if (!valid_el(gi)) continue;
+        if constexpr (SHARD) {
+          const unsigned xseq = sh.seq_base + (unsigned)s + 1u;
+          for (int rr = 0; rr < sh.world; ++rr)   // this rank's slice sum into every rank's receive area
+            ll_store_system(sh.peer_recv[rr] + (long long)((s & 1) * sh.world + (sh.loopback ? rr : sh.rank)) * P8 + gi, part, xseq);
+        } else {
+          ll_store_agent(sums_s + gi, part, lseq);
+        }
+      }
+      if constexpr (SHARD) {   // the ranks' words of this slice, summed in rank order; the global slice published locally
+        const unsigned xseq = sh.seq_base + (unsigned)s + 1u;
+        const u64* rbase = sh.recv + (long long)((s & 1) * sh.world) * P8;
+        for (int e = tid; e < SL; e += 512) {
+          const int gi = vb * SL + e;
+          if (!valid_el(gi)) continue;
+          u64 t[SHARD_WORLD_MAX];
+          for (unsigned it = 0;;) {
+#pragma unroll
+            for (int rr = 0; rr < SHARD_WORLD_MAX; ++rr)
+              t[rr] = __hip_atomic_load(rbase + (long long)min(rr, sh.world - 1) * P8 + gi, __ATOMIC_RELAXED,
+                                        __HIP_MEMORY_SCOPE_SYSTEM);
+            __builtin_amdgcn_sched_barrier(0);
+            bool ok = true;
+#pragma unroll
+            for (int rr = 0; rr < SHARD_WORLD_MAX; ++rr) ok = ok && (rr >= sh.world || (unsigned)(t[rr] >> 32) == xseq);
+            if (ok) break;
+            __builtin_amdgcn_s_sleep(1);
+            if ((++it & 255u) == 0 && (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ||
+                                       wall_clock64() - t0 > sh.timeout_ticks)) {
+              fail = true;
+              break;
+            }
+          }
+          float part = 0.f;
+#pragma unroll
+          for (int rr = 0; rr < SHARD_WORLD_MAX; ++rr)
+            if (rr < sh.world) part += __uint_as_float((unsigned)t[rr]);
+          ll_store_agent(sums_s + gi, part, lseq);
+        }
+      }
+      UPD_TS(11);
+      {   // hop 2: the whole sum vector
+        u64 t[NPT];
+        int ez;
+        asm volatile("s_mov_b32 %0, 0" : "=s"(ez));
+        for (unsigned it = 0; !fail;) {
+#pragma unroll
+          for (int k = 0; k < NPT; ++k)
+            t[k] = __hip_atomic_load(sums_s + min(tid + ez + k * 512, o.total - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __builtin_amdgcn_sched_barrier(0);
+          bool ok = true;
+#pragma unroll
+          for (int k = 0; k < NPT; ++k) ok = ok && (unsigned)(t[k] >> 32) == lseq;
+          if (ok) break;
+          __builtin_amdgcn_s_sleep(1);
+          if ((++it & 255u) == 0 &&
+              (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ||
+               wall_clock64() - t0 > (SHARD ? sh.timeout_ticks : local_timeout))) {
+            fail = true;
+            break;
+          }
+        }
+#pragma unroll
+        for (int k = 0; k < NPT; ++k) g[k] = __uint_as_float((unsigned)t[k]);
+      }
+      if (fail) s_fail = 1;
+      __syncthreads();
+      if (s_fail) {
+        if (tid == 0) __hip_atomic_store(err, SHARD ? 2u : 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+      }
+      // (the statistics workgroup's ring follows workgroup 0's progress: every workgroup's minibatch s is behind it)
+      if (vb == 0 && tid == 0) __hip_atomic_fetch_add(arrivals, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    __syncthreads();
-    if (!s_ok) return;
     have_ring = (s + 1 < n_steps) && (s_pub >= s + 2);
     if (have_ring && wave < 3) {
       // the next step's statistics slot: global -> LDS directly (waves 0 / 1: mean / 1 / std columns, wave 2: the
@@ -3719,83 +3889,10 @@ __global__ __launch_bounds__(512) void ppo_update_persistent_kernel(
     }
     UPD_TS(2);
 
-    // reduce the slabs in fixed order, global norm, clip, Adam -- identical in every block. Up to
-    // 2 * UPD_GROUP blocks: every block sums all slabs itself (at 32 slabs still cheaper than a second
-    // grid barrier: 4.8 us against 7.3 us). More (large global minibatches, e.g. the
-    // data-parallel update on the all-gathered rollout): two levels -- block g < ngrp sums the slabs of
-    // group g into a partial, one more grid barrier among the leaders' arrivals, then every block sums
-    // the ngrp partials -- so a block never reads more than 16 vectors (128 slabs each would be 230 MB
-    // of reads per step over all blocks).
+    // global norm, clip, Adam -- identical in every workgroup (g: the summed gradient; one gradient workgroup: its own)
     float sq = 0.f;
-    auto sum_vectors = [&](const float* __restrict__ base, int nsrc) {
-#pragma unroll
-      for (int k = 0; k < NPT; ++k) g[k] = 0.f;
-      constexpr int KH = 4;  // 4 parameters x 8 vectors = 32 loads in flight per thread (measured: 8 x 8 = 64 in flight
-                             // is SLOWER, 3.9 against 2.5 us for 16 slabs -- the phase runs at the CU's L1 fill rate,
-                             // 224 KB at 64 B / clock = 1.5 us, and deeper queues only add contention)
-      int b = 0;
-      for (; b + 8 <= nsrc; b += 8) {
-#pragma unroll
-        for (int h = 0; h < (NPT + KH - 1) / KH; ++h) {
-          float t[KH][8];
-#pragma unroll
-          for (int k = 0; k < KH; ++k) {
-            if (h * KH + k >= NPT) continue;  // (resolved at compile time)
-            // clamped index: every load is unconditional (a guarded load costs a branch and a full
-            // wait each, which serialises the whole batch); lanes past the end are discarded below
-            // (unsigned 32-bit element offsets from the wave-uniform base: one address register per load, not two)
-            const unsigned i = (unsigned)min(tid + (h * KH + k) * 512, o.total - 1);
-#pragma unroll
-            for (int u = 0; u < 8; ++u) t[k][u] = base[(unsigned)(b + u) * (unsigned)w.P4 + i];
-          }
-          __builtin_amdgcn_sched_barrier(0);   // the whole batch is requested before its first value is consumed
-#pragma unroll
-          for (int k = 0; k < KH; ++k) {
-            if (h * KH + k >= NPT) continue;
-#pragma unroll
-            for (int u = 0; u < 8; ++u) g[h * KH + k] += t[k][u];
-          }
-        }
-      }
-      for (; b < nsrc; ++b) {
-#pragma unroll
-        for (int k = 0; k < NPT; ++k) g[k] += base[(unsigned)b * (unsigned)w.P4 + (unsigned)min(tid + k * 512, o.total - 1)];
-      }
-    };
-    if constexpr (LOCAL) {
-      // (g holds the workgroup's own gradient already)
-    } else if (nblk <= 2 * UPD_GROUP) {
-      sum_vectors(slab_base, nblk);
-    } else {
-      // group size: 8 up to 64 blocks (both levels read 8 vectors: 6.7 us against 9.4 us with groups of 16),
-      // 16 beyond (at 128 blocks 16 leaders + 16 partials measured slower than 8 + 16: 10.8 against 9.8 us)
-      const int gsz = nblk <= 64 ? 8 : UPD_GROUP;
-      const int ngrp = (nblk + gsz - 1) / gsz;
-      float* part_base = w.partials + (long long)(s & 1) * UPD_GROUPS_MAX * w.P4;
-      if (vb < ngrp) {
-        const int first = vb * gsz;
-        sum_vectors(slab_base + (long long)first * w.P4, min(gsz, nblk - first));
-#pragma unroll
-        for (int k = 0; k < NPT; ++k) {
-          const int i = tid + k * 512;
-          if (i < o.total) slab_store(part_base + (long long)vb * w.P4 + i, g[k]);
-        }
-      }
-      __syncthreads();
-      if (tid == 0) {
-        if (vb < ngrp) {
-          __threadfence();
-          __hip_atomic_fetch_add(arrivals2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        s_ok = spin_until(arrivals2, (unsigned)(s + 1) * ngrp, err);
-        __threadfence();
-      }
-      __syncthreads();
-      if (!s_ok) return;
-      sum_vectors(part_base, ngrp);
-    }
-    if constexpr (SHARD) {
-      // ---- exchange: g = this rank's partial gradient (identical in all of its workgroups) -> every rank's sum.
+    if constexpr (SHARD && LOCAL) {
+      // ---- exchange (one gradient workgroup per rank): g = this rank's partial gradient (identical in all of its workgroups) -> every rank's sum.
       // Every value travels as ONE 8-byte word (float bits, sequence number of the step): a naturally aligned 8-byte store
       // arrives whole, so the receiver needs no separate flag, the sender no acknowledgement wait, fence or flag store --
       // one one-way trip per step (the LL protocol of RCCL, which relies on the same 8-byte atomicity over xGMI).
@@ -3892,7 +3989,23 @@ __global__ __launch_bounds__(512) void ppo_update_persistent_kernel(
     UPD_TS(5);
     const float total_norm = sqrtf(total_sq);
     const float coef = fminf(max_norm / (total_norm + 1e-6f), 1.0f);  // torch clip_grad_norm_
-    if constexpr (SHARD) {
+    if constexpr (!LOCAL) {
+      if (vb == 0 && tid < 64 && stats) {   // the loss-statistic sums are the sum vector's tail: same rows as write_loss_stats
+        const unsigned long long* tb = w.sums64 + (long long)(s & 1) * P8 + w.P4;
+        unsigned long long tv;
+        const long long t0 = wall_clock64();
+        do {
+          tv = __hip_atomic_load(tb + min(lane, 4), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } while (!__all((unsigned)(tv >> 32) == lseq) && wall_clock64() - t0 < 200000000ll);
+        const float st = __uint_as_float((unsigned)tv) * (1.f / (float)r.batch);
+        const float st0 = __shfl(st, 0, 64), st1 = __shfl(st, 1, 64), st2 = __shfl(st, 2, 64);
+        float* so = stats + (long long)(sch_first + s) * 8;
+        if (lane < 5) so[lane] = st;
+        if (lane == 5) so[5] = st0 + ent_coef * st2 + vf_coef * st1;
+        if (lane == 6) so[6] = total_norm;
+        if (lane == 7) so[7] = coef;
+      }
+    } else if constexpr (SHARD) {
       if (vb == 0 && tid < 64 && stats) {   // every rank's sums are in the step's records: same rows as write_loss_stats
         const unsigned long long* rbase = sh.recv + (long long)((s & 1) * sh.world) * (w.P4 + 8) + w.P4;
         const unsigned seq = sh.seq_base + (unsigned)s + 1u;
@@ -3974,6 +4087,8 @@ __global__ __launch_bounds__(512) void ppo_update_persistent_kernel(
 #undef UPD_TS
   if (tstamp && vb == 0 && tid == 0)
     for (int k = 0; k < 12; ++k) tstamp[k] += tacc[k];
+  if (vb == 0 && tid == 0)
+    __hip_atomic_store(w.ctrl + 9, lseq_base + (unsigned)n_steps, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if (vb == 0) {
 #pragma unroll
     for (int k = 0; k < NPT; ++k) {
@@ -4571,8 +4686,10 @@ static int64_t upd_ws_floats(const ia_policy_desc* d, int batch_size, int world)
   if (d->hidden != 32 || P > UPD_NPT_WIDE * 512 || upd_grad_lds_bytes(P4, d->discrete ? 1 : d->act_dim) > 160 * 1024 || nblk > UPD_NBLK_MAX ||
       cdiv((long long)batch_size * world, UPD_SLICE) > UPD_SLICES_MAX || g_ppo_valu)
     return 0;
+  // (every gradient workgroup polls nblk x ceil((P4 + 8) / nblk) slab words with its parameters-per-thread x 512 lanes)
+  if (nblk > 1 && P4 + 8 + nblk - 1 > UPD_NPT_WIDE * 512) return 0;
   return UPD_CTRL + 2 * UPD_MAX_STEPS + UPD_RING * UPD_RS + UPD_SD * 2 + UPD_SD * (int64_t)nblk * 8 +
-         2 * (int64_t)nblk * P4 + 2 * (int64_t)UPD_GROUPS_MAX * P4 + (int64_t)UPD_RING * UPD_SLICES_MAX * UPD_PRS;
+         4 * (int64_t)nblk * (P4 + 8) + 4 * (int64_t)(P4 + 8) + (int64_t)UPD_RING * UPD_SLICES_MAX * UPD_PRS;
 }
 int64_t ia_ppo_update_ws_floats(const ia_policy_desc* d, int batch_size) { return upd_ws_floats(d, batch_size, 1); }
 // Row-sharded data-parallel update (ia_ppo_update_sharded): workspace for `rows_per_rank` rows of each global minibatch of
@@ -4618,7 +4735,7 @@ static int ppo_update_launch(const ia_policy_desc* d, float* params, float* para
   const size_t grad_bytes = upd_grad_lds_bytes(P4, d->discrete ? 1 : d->act_dim);
   const size_t prep_bytes = (PREP_LDS_FLOATS + (size_t)cdiv(batch_global, ROWS) * ROWS) * sizeof(float);  // + row offsets
   const size_t bytes = grad_bytes > prep_bytes ? grad_bytes : prep_bytes;
-  const bool wide = P > UPD_NPT * 512;
+  const bool wide = P > UPD_NPT * 512 || (nblk > 1 && P4 + 8 + nblk - 1 > UPD_NPT * 512);
   const bool timing = g_tstamp != nullptr;
   // instantiations: {8, 9} parameters per thread x {production, phase clocks} x first-layer fragments for <= 32 / <= 64
   // observation columns (the narrow form keeps 16 registers less across the chain)

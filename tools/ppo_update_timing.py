@@ -35,7 +35,7 @@ for rep in range(3):
     d = time.perf_counter() - t
     steps = algo.n_epochs * algo._n_mb
     ticks = buf.cpu().numpy()[:12]
-    names = ("wait statistics", "minibatch fwd/bwd", "grid barrier", "park+sync", "slab reduce", "norm (block sum)", "stats+Adam", "release fence", "atomic add", "prefetch issue", "spin", "acquire fence")
+    names = ("wait statistics", "minibatch fwd/bwd", "hop 2: poll the sum vector (+ barrier)", "park+sync", "(to the norm)", "norm (block sum)", "stats+Adam", "-", "-", "prefetch issue", "hop 1: poll the slice of all slabs", "slice sums + publish (+ barrier)")
     sb = buf.cpu().numpy()[12:15]
     print("statistics block per step: " + ", ".join(f"{n} {t_ / 100.0 / steps:.2f} us" for n, t_ in
                                                       zip(("wait for a free ring slot", "loss statistics of finished steps",
