@@ -2053,7 +2053,7 @@ __device__ __forceinline__ void wave_sync_lds() {
 // grid wait, no re-read through L2. The loss-statistic partials (for the statistics workgroup) are stored write-through;
 // the caller drains them (`vmcnt(0)` in every wave) at the END of the step, where it waits for the prefetched rows
 // anyway, and arrives after that -- no release fence (cdna_hip_programming.md G16 R1), no acknowledgement on the chain.
-template <int KS1, bool LOCAL>
+template <int KS1, bool LOCAL, bool SMALL = false>
 __device__ __forceinline__ void mfma32_minibatch_chain(
     const ia_policy_desc& d, const float* __restrict__ nm, const float* __restrict__ nv, const float adv_mean,
     const float adv_std, const MbRows rows, const int i0_in, const int row_lim, const int normalize_adv, const float clip,
@@ -2080,7 +2080,14 @@ __device__ __forceinline__ void mfma32_minibatch_chain(
 #define IA_TS(slot) do { if (tstamp && i0_in == 0 && threadIdx.x == 0) tstamp[slot] = clock64(); } while (0)
   const int tid = threadIdx.x + opaque_zero, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int tw = wv >> 2, q = wv & 3;
+  // wave w: tower w & 1, row quarter w >> 1 -- waves 0 and 1 (the two towers of rows 0..15) sit on different SIMDs, so a
+  // minibatch of <= 16 rows (the reference's tuned AIRL configuration) has a SIMD per tower to itself once the other six
+  // waves skip the layer chain (`idle` below); this numbering only then:
+  // (SMALL: an instantiation of its own, chosen by the host for minibatches of <= 16 rows. In the general kernel the
+  // uniform branch around the chain alone cost ~1 us per step at config P -- measured --, and full workgroups want the
+  // OTHER numbering: SIMD k then hosts (policy, k) and (value, k), complementary work, instead of two waves of one tower
+  // in lockstep)
+  const int tw = SMALL ? (wv & 1) : (wv >> 2), q = SMALL ? (wv >> 1) : (wv & 3);
   const int li = lane & 15, lk = lane >> 4;
   const int D = d.obs_dim, A = d.act_dim;
   const PolOff o = pol_offsets(D, A, H, d.discrete);
@@ -2110,8 +2117,10 @@ __device__ __forceinline__ void mfma32_minibatch_chain(
   }
 
   IA_TS(9);
+  // (SMALL: rows 16.. do not exist in any minibatch of the launch; the caller zeroed every tile once, their waves idle)
+  const bool idle = SMALL && q > 0;   // wave-uniform; compiled out of the general instantiations
   // ---- stage this wave's 16 feature rows (normalised) into the x tile; clear its rows of the small tiles
-  {
+  if (!idle) {
     const int rbase = q * 16;
     // the two waves that share q (tower 0 / tower 1) stage the 16 rows together, four consecutive columns per lane
     // and only the 4 * S1 columns the first layer reads with non-zero weights (the caller cleared the tile once: the
@@ -2242,6 +2251,9 @@ __device__ __forceinline__ void mfma32_minibatch_chain(
     return fmaxf(a, b);
   };
   // ---- a1^T = tanh(W1 x^T + b1): B operand = the wave's x rows, column 16 kt + 4 lk + r of row li
+  // (<= 16 rows in every minibatch of the launch: the waves of rows 16.. have nothing to run -- the weight-gradient tiles
+  //  below contract over rows 0..15 only, and the column sums over 64 rows find the zeros the caller left in the tiles)
+  if (!idle) {
   f32x4 a1[2], a2[2];
   {
     f32x4 acc[2][2] = {{{b1c[0][0], b1c[0][1], b1c[0][2], b1c[0][3]}, {0.f, 0.f, 0.f, 0.f}},
@@ -2480,6 +2492,7 @@ __device__ __forceinline__ void mfma32_minibatch_chain(
       for (int r = 0; r < 4; ++r)
         dz1t[trow + 16 * t + r] = (acc[t][0][r] + acc[t][1][r]) * (1.f - a1[t][r] * a1[t][r]);
   }
+  }   // (!idle)
   __syncthreads();   // every row's activations and activation gradients are in LDS
   IA_TS(6);
 
@@ -3308,7 +3321,7 @@ __global__ __launch_bounds__(SPLIT ? 256 : 512) void ppo_epoch_persistent_kernel
 
 // TIMING = false (production): the phase-clock accumulators (24 VGPRs of `tacc` alone) and every stamp are
 // compiled out -- the measurement build is a separate instantiation picked only while ia_ppo_debug_timing is on.
-template <int NPT, bool TIMING, int KS1, bool LOCAL, bool SHARD = false>
+template <int NPT, bool TIMING, int KS1, bool LOCAL, bool SHARD = false, bool SMALL = false>
 __global__ __launch_bounds__(512) void ppo_update_persistent_kernel(
     ia_policy_desc d, float* __restrict__ P, float* __restrict__ Pt, float* __restrict__ m, float* __restrict__ v,
     float* __restrict__ nm, float* __restrict__ nv, int32_t* __restrict__ ncount, int update_norm,
@@ -3521,6 +3534,7 @@ __global__ __launch_bounds__(512) void ppo_update_persistent_kernel(
   }
 
   // ---------------- gradient blocks
+  constexpr int PROWS = SMALL ? 16 : ROWS;   // rows a minibatch of this workgroup can have
   float* sP = lds + L::total;
   float* sPt = sP + w.P4;
   float* stg = sPt + w.P4;                    // UpdStage: the NEXT minibatch's rows of this block
@@ -3599,7 +3613,7 @@ __global__ __launch_bounds__(512) void ppo_update_persistent_kernel(
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
       const int e0 = it * 512 + wave * 64 + zero;  // wave-uniform
-      const int e = min(e0 + lane, ROWS * D - 1);
+      const int e = min(e0 + lane, PROWS * D - 1);
       const int rr = D == 1 ? e : (int)__umulhi((unsigned)e, rcpD);
       cols[it] = e - rr * D;
       srcs[it] = nxt[rr];
@@ -3610,7 +3624,7 @@ __global__ __launch_bounds__(512) void ppo_update_persistent_kernel(
     int asrc[NAT], acol[NAT];
 #pragma unroll
     for (int it = 0; it < NAT; ++it) {
-      const int e = min(it * 512 + wave * 64 + zero + lane, ROWS * aw_ - 1);
+      const int e = min(it * 512 + wave * 64 + zero + lane, PROWS * aw_ - 1);
       const int rr = e / aw_;
       acol[it] = e - rr * aw_;
       asrc[it] = nxt[rr];
@@ -3619,7 +3633,7 @@ __global__ __launch_bounds__(512) void ppo_update_persistent_kernel(
 #pragma unroll
     for (int it = 0; it < NAT; ++it) {
       const int e0 = it * 512 + wave * 64;  // wave-uniform
-      if (e0 < ROWS * aw_)
+      if (e0 < PROWS * aw_)
         __builtin_amdgcn_global_load_lds((glb_void_p)(r.actions + (long long)asrc[it] * aw_ + acol[it]),
                                          (lds_void_p)(stg + UpdStage::act + e0), 4, 0, 0);
     }
@@ -3631,7 +3645,7 @@ __global__ __launch_bounds__(512) void ppo_update_persistent_kernel(
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
       const int e0 = it * 512 + wave * 64;  // wave-uniform
-      if (e0 < ROWS * D)
+      if (e0 < PROWS * D)
         __builtin_amdgcn_global_load_lds((glb_void_p)(r.obs + (long long)srcs[it] * D + cols[it]),
                                          (lds_void_p)(stg + UpdStage::x + e0), 4, 0, 0);
     }
@@ -3640,7 +3654,8 @@ __global__ __launch_bounds__(512) void ppo_update_persistent_kernel(
     if (wave == 0) stg[UpdStage::src + lane] = stg[UpdStage::nxt + lane];
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the LDS-direct loads have landed
   };
-  for (int e = tid; e < ROWS * L::XS; e += 512) lds[L::x + e] = 0.f;   // (the chain only rewrites the columns it uses)
+  for (int e = tid; e < (SMALL ? L::total : ROWS * L::XS); e += 512) lds[L::x + e] = 0.f;   // (the chain only rewrites the columns
+                                                                                            // it uses; SMALL: rows 16.. of EVERY tile)
   if (n_steps > 0) {
     prefetch_resolve(0);
     __syncthreads();
@@ -3692,7 +3707,7 @@ __global__ __launch_bounds__(512) void ppo_update_persistent_kernel(
     float* stat_base = w.statpart + (s % UPD_SD) * nblk * 8;
     int oz;
     asm volatile("s_mov_b32 %0, 0" : "=s"(oz));
-    mfma32_minibatch_chain<KS1, LOCAL>(d, slot, slot + MAXD, adv_mean, adv_std, r, row_lo + vb * ROWS, row_lim(r),
+    mfma32_minibatch_chain<KS1, LOCAL, SMALL>(d, slot, slot + MAXD, adv_mean, adv_std, r, row_lo + vb * ROWS, row_lim(r),
                                        normalize_adv, clip, ent_coef, vf_coef,
                                        reinterpret_cast<float*>(slabs_s + (long long)vb * P8), stat_base + vb * 8, lds, sP,
                                        stg, oz, tstamp ? tstamp + 16 : nullptr, lseq);
@@ -4743,7 +4758,7 @@ static int ppo_update_launch(const ia_policy_desc* d, float* params, float* para
   // one gradient workgroup whose parameter vector fits the consumed part of the staging area: the gradient stays in LDS
   const bool local = nblk == 1 && P4 <= UpdStage::nxt;
   using KernelT = decltype(&ppo_update_persistent_kernel<UPD_NPT, false, 8, false>);
-  static const KernelT kernels[24] = {
+  static const KernelT kernels[32] = {
       ppo_update_persistent_kernel<UPD_NPT, false, 8, false>,      ppo_update_persistent_kernel<UPD_NPT, false, 16, false>,
       ppo_update_persistent_kernel<UPD_NPT, true, 8, false>,       ppo_update_persistent_kernel<UPD_NPT, true, 16, false>,
       ppo_update_persistent_kernel<UPD_NPT_WIDE, false, 8, false>, ppo_update_persistent_kernel<UPD_NPT_WIDE, false, 16, false>,
@@ -4756,10 +4771,18 @@ static int ppo_update_launch(const ia_policy_desc* d, float* params, float* para
       ppo_update_persistent_kernel<UPD_NPT, false, 8, false, true>,      ppo_update_persistent_kernel<UPD_NPT, false, 16, false, true>,
       ppo_update_persistent_kernel<UPD_NPT_WIDE, false, 8, false, true>, ppo_update_persistent_kernel<UPD_NPT_WIDE, false, 16, false, true>,
       ppo_update_persistent_kernel<UPD_NPT, false, 8, true, true>,       ppo_update_persistent_kernel<UPD_NPT, false, 16, true, true>,
-      ppo_update_persistent_kernel<UPD_NPT_WIDE, false, 8, true, true>,  ppo_update_persistent_kernel<UPD_NPT_WIDE, false, 16, true, true>};
-  const int vi_k = shard ? 16 + local * 4 + wide * 2 + ks16 : local * 8 + wide * 4 + timing * 2 + ks16;
+      ppo_update_persistent_kernel<UPD_NPT_WIDE, false, 8, true, true>,  ppo_update_persistent_kernel<UPD_NPT_WIDE, false, 16, true, true>,
+      // one gradient workgroup, minibatches of <= 16 rows (the tuned AIRL file): six of the eight waves skip the layer chain,
+      // each tower's one wave has a SIMD to itself: [24 + shard * 4 + wide * 2 + ks16]
+      ppo_update_persistent_kernel<UPD_NPT, false, 8, true, false, true>,       ppo_update_persistent_kernel<UPD_NPT, false, 16, true, false, true>,
+      ppo_update_persistent_kernel<UPD_NPT_WIDE, false, 8, true, false, true>,  ppo_update_persistent_kernel<UPD_NPT_WIDE, false, 16, true, false, true>,
+      ppo_update_persistent_kernel<UPD_NPT, false, 8, true, true, true>,        ppo_update_persistent_kernel<UPD_NPT, false, 16, true, true, true>,
+      ppo_update_persistent_kernel<UPD_NPT_WIDE, false, 8, true, true, true>,   ppo_update_persistent_kernel<UPD_NPT_WIDE, false, 16, true, true, true>};
+  const bool small = local && batch_size <= 16 && !timing;
+  const int vi_k = small ? 24 + (shard ? 4 : 0) + wide * 2 + ks16
+                         : (shard ? 16 + local * 4 + wide * 2 + ks16 : local * 8 + wide * 4 + timing * 2 + ks16);
   const KernelT kernel = kernels[vi_k];
-  static size_t attr_bytes[24] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  static size_t attr_bytes[32] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   if (bytes > attr_bytes[vi_k]) {
     const int rc = set_lds(kernel, bytes);
     if (rc) return rc;
@@ -4814,9 +4837,9 @@ static int ppo_update_launch(const ia_policy_desc* d, float* params, float* para
       // (and a cooperative launch costs +15-19 us per launch, MI355X_MICROARCH.md "coop-launch"), so the same
       // test is made here: workgroups per CU by the occupancy query (LDS-bound: one) times the CU count.
       // Not enough room -> IA_ERR_UNSUPPORTED, the caller runs ia_ppo_epoch (two launches per minibatch).
-      static int dev_cus = 0, per_cu[24] = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1,
-                                            -1, -1, -1, -1, -1, -1, -1, -1};
-      static size_t per_cu_bytes[24] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+      static int dev_cus = 0, per_cu[32] = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1,
+                                            -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1};
+      static size_t per_cu_bytes[32] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
       const int vi = vi_k;
       if (dev_cus == 0) {
         int dev = 0;

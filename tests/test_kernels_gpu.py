@@ -470,7 +470,12 @@ def test_timeout_bootstrap():
                                                         # with a short last minibatch: the one-launch-per-epoch kernel
                                                         # (minibatch steps as phases between grid barriers)
                                                         (17, 6, 64, False, True, 16, 256, 1024),
-                                                        (4, 2, 64, True, True, 9, 100, 384)])
+                                                        (4, 2, 64, True, True, 9, 100, 384),
+                                                        # minibatches of <= 16 rows (the reference's tuned AIRL file): the
+                                                        # one-workgroup kernel whose waves of rows 16.. idle; Ant width,
+                                                        # and a Discrete head with a short last minibatch
+                                                        (27, 8, 32, False, True, 4, 12, 16),
+                                                        (4, 3, 32, True, True, 4, 10, 16)])
 @pytest.mark.parametrize("path", ["epoch", "epoch_whole", "update", "update_spread", "update_shard1"])
 def test_ppo_epochs_match_oracle(D, A, H, discrete, norm, T, n, bs, path):
     """Two PPO epochs on a synthetic rollout: parameters, Adam state, RunningNorm state and the
