@@ -2044,6 +2044,55 @@ __device__ __forceinline__ void wave_sync_lds() {
   __builtin_amdgcn_wave_barrier();
 }
 
+// Rows of the minibatch (raw, packed, prefetched into the staging area) -> normalised rows in the x tile; this wave's rows
+// of the small tiles cleared. Wave (tower tw, quarter q) and its twin of the other tower share the quarter's 16 rows.
+// Depends on the minibatch and its statistics only -- NOT on the parameters -- so the persistent kernel runs it for the
+// next minibatch while this minibatch's sum vector is still on its way (`STAGED` chain).
+template <bool SMALL>
+__device__ __forceinline__ void chain_stage_rows(const ia_policy_desc& d, const float* __restrict__ nm,
+                                                 const float* __restrict__ nv, const int i0, const int row_lim,
+                                                 float* __restrict__ lds, const float* __restrict__ stg, const int tw,
+                                                 const int q, const int lane) {
+  using L = CLds;
+  const int D = d.obs_dim;
+  const int S1 = (D + 3) >> 2;
+  const bool idle = SMALL && q > 0;   // wave-uniform; compiled out of the general instantiations
+  if (!idle) {
+    const int rbase = q * 16;
+    // the two waves that share q (tower 0 / tower 1) stage the 16 rows together, four consecutive columns per lane
+    // and only the 4 * S1 columns the first layer reads with non-zero weights (the caller cleared the tile once: the
+    // columns beyond are never written). Group g = row * S1 + column group; the row comes from a multiply-shift
+    // (S1 <= 16, g < 256). All 12 loads of a group (raw value, mean, 1 / std) are in flight together.
+    const int l128 = lane + 64 * tw;
+    const int s1r = (65536 + S1 - 1) / S1;   // wave-uniform
+    for (int g = l128; g < 16 * S1; g += 128) {
+      const int r = (g * s1r) >> 16, k0 = (g - r * S1) * 4;
+      const bool rok = (i0 + rbase + r) < row_lim;
+      float raw[4], mu[4], vr[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        raw[j] = stg[UpdStage::x + (rbase + r) * D + k0 + j];   // (packed rows; columns >= D are masked below)
+        mu[j] = nm[k0 + j];          // slot arrays hold MAXD entries each
+        vr[j] = nv[k0 + j];
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const bool ok = rok && k0 + j < D;
+        const bool nrm = ok && d.has_norm;          // (`nv` carries 1/sqrt(var + eps), see the statistics block)
+        lds[L::x + (rbase + r) * L::XS + k0 + j] = ok ? (nrm ? (raw[j] - mu[j]) * vr[j] : raw[j]) : 0.f;
+      }
+    }
+    if (tw == 0) {
+      for (int e = lane; e < 16 * L::AS; e += 64) {
+        lds[L::dout + rbase * L::AS + e] = 0.f;
+        lds[L::aux + rbase * L::AS + e] = 0.f;
+      }
+    } else {
+      for (int e = lane; e < 16 * L::MS; e += 64) lds[L::misc + rbase * L::MS + e] = 0.f;
+    }
+  }
+}
+
 // (`nv` = 1/sqrt(running_var + eps) per column, as the statistics block publishes it)
 // KS1 = k-steps (of 4 input columns) the first layer's fragments are sized for: 16 covers MAXD = 64 columns, 8 covers
 // observation widths <= 32 -- every reference environment of the path -- with 16 fragment registers less across the chain.
@@ -2053,7 +2102,7 @@ __device__ __forceinline__ void wave_sync_lds() {
 // grid wait, no re-read through L2. The loss-statistic partials (for the statistics workgroup) are stored write-through;
 // the caller drains them (`vmcnt(0)` in every wave) at the END of the step, where it waits for the prefetched rows
 // anyway, and arrives after that -- no release fence (cdna_hip_programming.md G16 R1), no acknowledgement on the chain.
-template <int KS1, bool LOCAL, bool SMALL = false>
+template <int KS1, bool LOCAL, bool SMALL = false, bool STAGED = false>
 __device__ __forceinline__ void mfma32_minibatch_chain(
     const ia_policy_desc& d, const float* __restrict__ nm, const float* __restrict__ nv, const float adv_mean,
     const float adv_std, const MbRows rows, const int i0_in, const int row_lim, const int normalize_adv, const float clip,
@@ -2119,41 +2168,9 @@ __device__ __forceinline__ void mfma32_minibatch_chain(
   IA_TS(9);
   // (SMALL: rows 16.. do not exist in any minibatch of the launch; the caller zeroed every tile once, their waves idle)
   const bool idle = SMALL && q > 0;   // wave-uniform; compiled out of the general instantiations
-  // ---- stage this wave's 16 feature rows (normalised) into the x tile; clear its rows of the small tiles
-  if (!idle) {
-    const int rbase = q * 16;
-    // the two waves that share q (tower 0 / tower 1) stage the 16 rows together, four consecutive columns per lane
-    // and only the 4 * S1 columns the first layer reads with non-zero weights (the caller cleared the tile once: the
-    // columns beyond are never written). Group g = row * S1 + column group; the row comes from a multiply-shift
-    // (S1 <= 16, g < 256). All 12 loads of a group (raw value, mean, 1 / std) are in flight together.
-    const int l128 = lane + 64 * tw;
-    const int s1r = (65536 + S1 - 1) / S1;   // wave-uniform
-    for (int g = l128; g < 16 * S1; g += 128) {
-      const int r = (g * s1r) >> 16, k0 = (g - r * S1) * 4;
-      const bool rok = (i0 + rbase + r) < row_lim;
-      float raw[4], mu[4], vr[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        raw[j] = stg[UpdStage::x + (rbase + r) * D + k0 + j];   // (packed rows; columns >= D are masked below)
-        mu[j] = nm[k0 + j];          // slot arrays hold MAXD entries each
-        vr[j] = nv[k0 + j];
-      }
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const bool ok = rok && k0 + j < D;
-        const bool nrm = ok && d.has_norm;          // (`nv` carries 1/sqrt(var + eps), see the statistics block)
-        lds[L::x + (rbase + r) * L::XS + k0 + j] = ok ? (nrm ? (raw[j] - mu[j]) * vr[j] : raw[j]) : 0.f;
-      }
-    }
-    if (tw == 0) {
-      for (int e = lane; e < 16 * L::AS; e += 64) {
-        lds[L::dout + rbase * L::AS + e] = 0.f;
-        lds[L::aux + rbase * L::AS + e] = 0.f;
-      }
-    } else {
-      for (int e = lane; e < 16 * L::MS; e += 64) lds[L::misc + rbase * L::MS + e] = 0.f;
-    }
-  }
+  // ---- stage this wave's 16 feature rows (normalised) into the x tile; clear its rows of the small tiles (STAGED: the
+  // caller did that already -- several gradient workgroups stage the NEXT minibatch while the sum vector is in flight)
+  if constexpr (!STAGED) chain_stage_rows<SMALL>(d, nm, nv, i0, row_lim, lds, stg, tw, q, lane);
   IA_TS(10);
   // Weight fragments (LDS -> VGPR) as the MFMAs' A operand: A[m = li][k = lk] of k-step (kt, r) is W[out 16 t + li][in
   // 16 kt + 4 lk + r] -- the k index of a step is PERMUTED (a step takes inputs 4 lk + r, lk = 0..3, of K tile kt) so
@@ -3334,7 +3351,7 @@ __global__ __launch_bounds__(512) void ppo_update_persistent_kernel(
   constexpr int H = 32;
   using L = CLds;
   extern __shared__ float lds[];
-  __shared__ int s_ok, s_pub, s_fail;
+  __shared__ int s_ok, s_pub, s_fail, s_pubw[4];
   if (!TIMING) tstamp = nullptr;
   long long tacc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   long long tprev = 0;
@@ -3715,8 +3732,19 @@ __global__ __launch_bounds__(512) void ppo_update_persistent_kernel(
         if (tid < 2 * MAXD + 8) stg[UpdStage::ring + tid] = *reinterpret_cast<const volatile float*>(slot + tid + sz);
       }
       __syncthreads();
+      if constexpr (!LOCAL) {   // (several workgroups stage ahead, see below: here only step 0 or late statistics)
+        int zz;
+        asm volatile("s_mov_b32 %0, 0" : "=s"(zz));
+        const int wv_ = __builtin_amdgcn_readfirstlane((tid + zz) >> 6);
+        chain_stage_rows<false>(d, stg + UpdStage::ring, stg + UpdStage::ring + MAXD, row_lo + vb * ROWS, row_lim(r), lds, stg,
+                                wv_ >> 2, wv_ & 3, lane);
+      }
     }
     slot = stg + UpdStage::ring;
+    // (several workgroups: how far the statistics workgroup is, read HERE -- before the statistics slot of step s + 1 is
+    //  requested below, so a slot it calls published was published when its load was issued)
+    int pub_early = 0;
+    if constexpr (!LOCAL) pub_early = (int)__hip_atomic_load(published, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     adv_mean = slot[2 * MAXD];
     adv_std = slot[2 * MAXD + 1];
     UPD_TS(0);
@@ -3729,7 +3757,7 @@ __global__ __launch_bounds__(512) void ppo_update_persistent_kernel(
     float* stat_base = w.statpart + (s % UPD_SD) * nblk * 8;
     int oz;
     asm volatile("s_mov_b32 %0, 0" : "=s"(oz));
-    mfma32_minibatch_chain<KS1, LOCAL, SMALL>(d, slot, slot + MAXD, adv_mean, adv_std, r, row_lo + vb * ROWS, row_lim(r),
+    mfma32_minibatch_chain<KS1, LOCAL, SMALL, !LOCAL>(d, slot, slot + MAXD, adv_mean, adv_std, r, row_lo + vb * ROWS, row_lim(r),
                                        normalize_adv, clip, ent_coef, vf_coef,
                                        reinterpret_cast<float*>(slabs_s + (long long)vb * P8), stat_base + vb * 8, lds, sP,
                                        stg, oz, tstamp ? tstamp + 16 : nullptr, lseq);
@@ -3752,6 +3780,16 @@ __global__ __launch_bounds__(512) void ppo_update_persistent_kernel(
       int pz;
       asm volatile("s_mov_b32 %0, 0" : "=s"(pz));
       prefetch_issue(s + 1, pz);
+    }
+    if constexpr (!LOCAL) {
+      if (s + 1 < n_steps && wave < 3) {
+        if (pub_early >= s + 2) {
+          const float* nslot = w.ring + ((s + 1) % UPD_RING) * UPD_RS;
+          __builtin_amdgcn_global_load_lds((glb_void_p)(nslot + wave * MAXD + lane),
+                                           (lds_void_p)(stg + UpdStage::ring + wave * MAXD), 4, 0, 0);
+        }
+        if (lane == 0) s_pubw[wave] = pub_early;
+      }
     }
     UPD_TS(9);
     if constexpr (LOCAL) {
@@ -3889,6 +3927,22 @@ __global__ __launch_bounds__(512) void ppo_update_persistent_kernel(
         }
       }
       UPD_TS(11);
+      // ---- while the sum vector is on its way: the NEXT minibatch's rows are normalised into the x tile -- 1.3 us of
+      // the next chain that depends on the data only, not on the parameters Adam is about to write. Its rows (prefetched
+      // behind this minibatch's chain) and its statistics slot (requested with them by waves 0-2, each if ITS early look at
+      // the statistics workgroup's progress said published) HAVE landed: loads return in order and hop 1's polls, issued
+      // after them, have returned in every wave ahead of hop 1's barrier -- no wait here (a `vmcnt(0)` would also wait for
+      // the acknowledgement of the slice words just sent).
+      const bool stage_ahead = (s + 1 < n_steps) && min(min(s_pubw[0], s_pubw[1]), s_pubw[2]) >= s + 2;   // workgroup-uniform
+      if (stage_ahead) {
+        const MbRows rn = rows_of(s + 1);
+        int zz;
+        asm volatile("s_mov_b32 %0, 0" : "=s"(zz));
+        const int wv_ = __builtin_amdgcn_readfirstlane((tid + zz) >> 6);
+        chain_stage_rows<false>(d, stg + UpdStage::ring, stg + UpdStage::ring + MAXD, row_lo + vb * ROWS, row_lim(rn), lds, stg,
+                                wv_ >> 2, wv_ & 3, lane);
+      }
+      if (tid == 0) s_pub = stage_ahead ? s + 2 : 0;   // (what `have_ring` is formed from below)
       {   // hop 2: the whole sum vector
         u64 t[NPT];
         int ez;
@@ -3923,7 +3977,7 @@ __global__ __launch_bounds__(512) void ppo_update_persistent_kernel(
       if (vb == 0 && tid == 0) __hip_atomic_fetch_add(arrivals, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     have_ring = (s + 1 < n_steps) && (s_pub >= s + 2);
-    if (have_ring && wave < 3) {
+    if (LOCAL && have_ring && wave < 3) {
       // the next step's statistics slot: global -> LDS directly (waves 0 / 1: mean / 1 / std columns, wave 2: the
       // advantage statistics -- 64 lanes wide, the staging slot has room), landed by prefetch_park's wait. Held in
       // registers across the update instead, the first value was spilled right here behind a `vmcnt` wait.
@@ -4120,7 +4174,8 @@ __global__ __launch_bounds__(512) void ppo_update_persistent_kernel(
       }
     }
     UPD_TS(6);
-    if (s + 1 < n_steps) prefetch_park();   // (its vmcnt(0) also covers the statistics slot's LDS-direct loads)
+    if (s + 1 < n_steps && (LOCAL || !have_ring)) prefetch_park();   // (its vmcnt(0) also covers the statistics slot's LDS-direct loads;
+                                                                     //  several workgroups: staged ahead, nothing left to land)
     else if (local) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (local && tid == 0)   // only the statistics workgroup listens: this step's loss partials and norm / clip pair were
