@@ -2023,18 +2023,24 @@ __global__ __launch_bounds__(PREP_THREADS) void ppo_apply_split_kernel(
 // then ONE block barrier, then all weight-gradient tiles, bias column sums and loss-statistic sums --
 // the only parts that contract over all 64 rows -- run independently per wave. Three block barriers
 // per minibatch instead of eight. Parameters are resident in LDS (sP / sPt), rows are staged (stg).
-struct CLds {  // LDS carve-up (floats): activations of both towers plus separate dz2 / dz1 tiles
-  static constexpr int XS = MAXD + 1, HS = 33, AS = MAXA + 1, MS = 9;
-  static constexpr int x = 0;
-  static constexpr int a1 = x + ROWS * XS;             // [2 towers][ROWS][HS]
-  static constexpr int a2 = a1 + 2 * ROWS * HS;
-  static constexpr int dz2 = a2 + 2 * ROWS * HS;
-  static constexpr int dz1 = dz2 + 2 * ROWS * HS;
-  static constexpr int out = dz1 + 2 * ROWS * HS;
-  static constexpr int dout = out + ROWS * AS;
-  static constexpr int aux = dout + ROWS * AS;
-  static constexpr int misc = aux + ROWS * AS;         // [ROWS][MS]: 0 value, 1 dvalue, 2..6 loss statistics
-  static constexpr int total = misc + ROWS * MS + 64;
+struct CLds {  // LDS carve-up (floats) of the persistent update's minibatch tiles
+  // Every tile is TRANSPOSED: [feature / column][row], rows contiguous, row stride RS = 68 floats (272 bytes: 16-byte
+  // aligned, = 4 mod 32 banks). The chain's lanes (lk, li) -- features 16 t + 4 lk + r of row li -- then write a tile with
+  // 16 consecutive rows per lane group 16 banks apart (conflict-free), and the weight-gradient tiles, which contract over
+  // ROWS, read four consecutive rows of a feature in ONE ds_read_b128 (row steps permuted: step s of lane group lk is row
+  // 16 (s >> 2) + 4 lk + (s & 3)) -- 8 wide reads per 16 x 16 x 64 tile instead of 32 two-way conflicted ds_read_b32.
+  static constexpr int RS = 68;
+  static constexpr int XS = MAXD + 1;                 // (width bound of a staged raw row: sizes the row prefetch)
+  static constexpr int x = 0;                         // [MAXD][RS] normalised observations
+  static constexpr int a1 = x + MAXD * RS;            // [2 towers][32][RS]
+  static constexpr int a2 = a1 + 2 * 32 * RS;
+  static constexpr int dz2 = a2 + 2 * 32 * RS;
+  static constexpr int dz1 = dz2 + 2 * 32 * RS;
+  static constexpr int dout = dz1 + 2 * 32 * RS;      // [MAXA][RS] d loss / d head output
+  static constexpr int aux = dout + MAXA * RS;        // [MAXA][RS] log_std gradient terms
+  static constexpr int misc = aux + MAXA * RS;        // [8][RS]: 1 dvalue, 2..6 loss statistics
+  static constexpr int scratch = misc + 8 * RS;       // 64 floats: block reductions
+  static constexpr int total = scratch + 64;
 };
 
 __device__ __forceinline__ void wave_sync_lds() {
@@ -2079,16 +2085,16 @@ __device__ __forceinline__ void chain_stage_rows(const ia_policy_desc& d, const 
       for (int j = 0; j < 4; ++j) {
         const bool ok = rok && k0 + j < D;
         const bool nrm = ok && d.has_norm;          // (`nv` carries 1/sqrt(var + eps), see the statistics block)
-        lds[L::x + (rbase + r) * L::XS + k0 + j] = ok ? (nrm ? (raw[j] - mu[j]) * vr[j] : raw[j]) : 0.f;
+        lds[L::x + (k0 + j) * L::RS + rbase + r] = ok ? (nrm ? (raw[j] - mu[j]) * vr[j] : raw[j]) : 0.f;
       }
     }
     if (tw == 0) {
-      for (int e = lane; e < 16 * L::AS; e += 64) {
-        lds[L::dout + rbase * L::AS + e] = 0.f;
-        lds[L::aux + rbase * L::AS + e] = 0.f;
+      for (int e = lane; e < 16 * MAXA; e += 64) {   // (e >> 4: action, e & 15: row of this wave)
+        lds[L::dout + (e >> 4) * L::RS + rbase + (e & 15)] = 0.f;
+        lds[L::aux + (e >> 4) * L::RS + rbase + (e & 15)] = 0.f;
       }
     } else {
-      for (int e = lane; e < 16 * L::MS; e += 64) lds[L::misc + rbase * L::MS + e] = 0.f;
+      for (int e = lane; e < 16 * 8; e += 64) lds[L::misc + (e >> 4) * L::RS + rbase + (e & 15)] = 0.f;
     }
   }
 }
@@ -2235,11 +2241,11 @@ __device__ __forceinline__ void mfma32_minibatch_chain(
   __syncthreads();
   IA_TS(1);
 
-  float* a1t = lds + L::a1 + tw * ROWS * L::HS;
-  float* a2t = lds + L::a2 + tw * ROWS * L::HS;
-  float* dz2t = lds + L::dz2 + tw * ROWS * L::HS;
-  float* dz1t = lds + L::dz1 + tw * ROWS * L::HS;
-  const int trow = (q * 16 + li) * L::HS + 4 * lk;   // this lane's four consecutive features of tile t start at trow + 16 t
+  float* a1t = lds + L::a1 + tw * 32 * L::RS;
+  float* a2t = lds + L::a2 + tw * 32 * L::RS;
+  float* dz2t = lds + L::dz2 + tw * 32 * L::RS;
+  float* dz1t = lds + L::dz1 + tw * 32 * L::RS;
+  const int trow = 4 * lk * L::RS + q * 16 + li;   // feature 16 t + 4 lk + r of this lane's row: trow + (16 t + r) * RS
   // sum / max over the four lane groups of a row (the same bits in all four lanes): v_permlane16_swap / v_permlane32_swap
   // with both operands the same register leave (even rows | odd rows) resp. (lower half | upper half) of it in both
   // halves of the pair -- one VALU exchange per level instead of a ds_bpermute round trip
@@ -2279,7 +2285,7 @@ __device__ __forceinline__ void mfma32_minibatch_chain(
 #pragma unroll
     for (int kt = 0; kt < KT1; ++kt)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) xb[kt][r] = lds[L::x + (q * 16 + li) * L::XS + min(16 * kt + 4 * lk + r, L::XS - 1)];
+      for (int r = 0; r < 4; ++r) xb[kt][r] = lds[L::x + min(16 * kt + 4 * lk + r, MAXD - 1) * L::RS + q * 16 + li];
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int kt = 0; kt < KT1; ++kt)
@@ -2305,7 +2311,7 @@ __device__ __forceinline__ void mfma32_minibatch_chain(
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         a1[t][r] = fast_tanh(acc[t][0][r] + acc[t][1][r]);
-        a1t[trow + 16 * t + r] = a1[t][r];
+        a1t[trow + (16 * t + r) * L::RS] = a1[t][r];
       }
   }
   IA_TS(2);
@@ -2342,7 +2348,7 @@ __device__ __forceinline__ void mfma32_minibatch_chain(
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         a2[t][r] = fast_tanh(acc[t][0][r] + acc[t][1][r]);
-        a2t[trow + 16 * t + r] = a2[t][r];
+        a2t[trow + (16 * t + r) * L::RS] = a2[t][r];
       }
   }
   IA_TS(3);
@@ -2426,16 +2432,16 @@ __device__ __forceinline__ void mfma32_minibatch_chain(
     const float inrange = (ratio >= lo && ratio <= hi) ? 1.f : 0.f;
     const float dlogp = valid ? -invB * advn * (g1 + g2 * inrange) * ratio : 0.f;
     IA_TS(14);
-    float* doutrow = lds + L::dout + lrow * L::AS;
-    float* auxrow = lds + L::aux + lrow * L::AS;
+    float* doutrow = lds + L::dout + lrow;   // (column a of this lane's row: [a * RS])
+    float* auxrow = lds + L::aux + lrow;
     if (!d.discrete) {
 #pragma unroll
       for (int j = 0; j < 4; ++j)
         if (4 * lk + j < A) {
           const float diff = r_act[j] - hout[j];
           dout[j] = dlogp * diff * c_ivar[j];
-          doutrow[4 * lk + j] = dout[j];
-          auxrow[4 * lk + j] = valid ? dlogp * (diff * diff * c_ivar[j] - 1.f) - ent_coef * invB : 0.f;
+          doutrow[(4 * lk + j) * L::RS] = dout[j];
+          auxrow[(4 * lk + j) * L::RS] = valid ? dlogp * (diff * diff * c_ivar[j] - 1.f) - ent_coef * invB : 0.f;
         }
     } else {
 #pragma unroll
@@ -2446,15 +2452,15 @@ __device__ __forceinline__ void mfma32_minibatch_chain(
           float g = dlogp * ((4 * lk + j == act_i ? 1.f : 0.f) - p);
           g += valid ? -ent_coef * invB * dH : 0.f;
           dout[j] = g;
-          doutrow[4 * lk + j] = g;
+          doutrow[(4 * lk + j) * L::RS] = g;
         }
     }
     if (lk == 0) {
-      float* mrow = lds + L::misc + lrow * L::MS;
-      mrow[2] = valid ? -fminf(pl1, pl2) : 0.f;                           // policy_gradient_loss
-      mrow[3] = valid ? -entropy : 0.f;                                    // entropy_loss
-      mrow[4] = valid ? (ratio - 1.f) - log_ratio : 0.f;                   // approx_kl
-      mrow[5] = valid ? (fabsf(ratio - 1.f) > clip ? 1.f : 0.f) : 0.f;     // clip_fraction
+      float* mrow = lds + L::misc + lrow;
+      mrow[2 * L::RS] = valid ? -fminf(pl1, pl2) : 0.f;                           // policy_gradient_loss
+      mrow[3 * L::RS] = valid ? -entropy : 0.f;                                    // entropy_loss
+      mrow[4 * L::RS] = valid ? (ratio - 1.f) - log_ratio : 0.f;                   // approx_kl
+      mrow[5 * L::RS] = valid ? (fabsf(ratio - 1.f) > clip ? 1.f : 0.f) : 0.f;     // clip_fraction
     }
     IA_TS(15);
   } else {
@@ -2463,8 +2469,8 @@ __device__ __forceinline__ void mfma32_minibatch_chain(
     const float verr = r_ret - v;
     dvb = valid ? vf_coef * 2.f * (v - r_ret) * invB : 0.f;
     if (lk == 0) {
-      lds[L::misc + lrow * L::MS + 1] = dvb;
-      lds[L::misc + lrow * L::MS + 6] = valid ? verr * verr : 0.f;        // value_loss
+      lds[L::misc + 1 * L::RS + lrow] = dvb;
+      lds[L::misc + 6 * L::RS + lrow] = valid ? verr * verr : 0.f;        // value_loss
     }
   }
   IA_TS(5);
@@ -2492,7 +2498,7 @@ __device__ __forceinline__ void mfma32_minibatch_chain(
 #pragma unroll
   for (int t = 0; t < 2; ++t)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) dz2t[trow + 16 * t + r] = dz2[t][r];
+    for (int r = 0; r < 4; ++r) dz2t[trow + (16 * t + r) * L::RS] = dz2[t][r];
   // ---- dz1^T = (W2^T dz2^T) * (1 - a1^2) for this wave's rows
   {
     f32x4 acc[2][2] = {{{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}};
@@ -2507,7 +2513,7 @@ __device__ __forceinline__ void mfma32_minibatch_chain(
     for (int t = 0; t < 2; ++t)
 #pragma unroll
       for (int r = 0; r < 4; ++r)
-        dz1t[trow + 16 * t + r] = (acc[t][0][r] + acc[t][1][r]) * (1.f - a1[t][r] * a1[t][r]);
+        dz1t[trow + (16 * t + r) * L::RS] = (acc[t][0][r] + acc[t][1][r]) * (1.f - a1[t][r] * a1[t][r]);
   }
   }   // (!idle)
   __syncthreads();   // every row's activations and activation gradients are in LDS
@@ -2519,149 +2525,136 @@ __device__ __forceinline__ void mfma32_minibatch_chain(
   // (minibatches of <= 16 rows -- the reference's tuned AIRL configuration -- contract over the first four row steps
   //  only: the gradient rows past the minibatch are exact zeros, so the remaining twelve steps add nothing)
   const bool few_rows = row_lim - i0 <= 16;   // wave-uniform
-  // (two accumulator chains per tile -- even / odd row steps, added at the end: a chain of sixteen dependent MFMAs is
-  //  16 x 40 clocks of latency against 16 x 32 of issue; with two chains the pipe is the limit)
-  auto outer16 = [&](const float* __restrict__ U, int us, int ucol, const float* __restrict__ V, int vs, int vcol) {
+  // A tile = 16 features of U (the MFMA's M index) x 16 features of V (N), contracted over the rows (K). A lane reads
+  // four consecutive rows of its feature per ds_read_b128: row steps 4 sq .. 4 sq + 3 of lane group lk are rows
+  // 16 sq + 4 lk .. + 3 -- the same permutation on both operands. Two accumulator chains per tile (a chain of sixteen
+  // dependent MFMAs is 16 x 40 clocks of latency against 16 x 32 of issue); `few_rows`: rows 0..15 only.
+  auto rd4 = [&](const float* p) { return *reinterpret_cast<const f32x4*>(p); };
+  auto outer16 = [&](const float* __restrict__ U, int ufeat, const float* __restrict__ V, int vfeat) {
+    const float* up = U + ufeat * L::RS + 4 * lk;
+    const float* vp = V + vfeat * L::RS + 4 * lk;
     f32x4 g = {0.f, 0.f, 0.f, 0.f}, g2 = {0.f, 0.f, 0.f, 0.f};
     if (few_rows) {
-      float u[4], v[4];
-#pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        u[s] = U[(4 * s + lk) * us + ucol];
-        v[s] = V[(4 * s + lk) * vs + vcol];
-      }
+      const f32x4 u = rd4(up), v = rd4(vp);
       __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int s = 0; s < 4; s += 2) {
-        g = mfma16(u[s], v[s], g);
-        g2 = mfma16(u[s + 1], v[s + 1], g2);
-      }
+      g = mfma16(u[0], v[0], g);
+      g2 = mfma16(u[1], v[1], g2);
+      g = mfma16(u[2], v[2], g);
+      g2 = mfma16(u[3], v[3], g2);
       return g + g2;
     }
-    float u[16], v[16];
+    f32x4 u[4], v[4];
 #pragma unroll
-    for (int s = 0; s < 16; ++s) {
-      u[s] = U[(4 * s + lk) * us + ucol];
-      v[s] = V[(4 * s + lk) * vs + vcol];
+    for (int sq = 0; sq < 4; ++sq) {
+      u[sq] = rd4(up + 16 * sq);
+      v[sq] = rd4(vp + 16 * sq);
     }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int s = 0; s < 16; s += 2) {
-      g = mfma16(u[s], v[s], g);
-      g2 = mfma16(u[s + 1], v[s + 1], g2);
+    for (int sq = 0; sq < 4; ++sq) {
+      g = mfma16(u[sq][0], v[sq][0], g);
+      g2 = mfma16(u[sq][1], v[sq][1], g2);
+      g = mfma16(u[sq][2], v[sq][2], g);
+      g2 = mfma16(u[sq][3], v[sq][3], g2);
     }
     return g + g2;
   };
-  // two tiles at once: all 64 operands requested first, then four interleaved chains
-  auto outer16_pair = [&](const float* __restrict__ U0, int us0, int ucol0, const float* __restrict__ V0, int vs0, int vcol0,
-                          const float* __restrict__ U1, int us1, int ucol1, const float* __restrict__ V1, int vs1, int vcol1,
-                          f32x4& r0, f32x4& r1) {
+  // two tiles at once: all operands requested first, then four interleaved chains
+  auto outer16_pair = [&](const float* __restrict__ U0, int uf0, const float* __restrict__ V0, int vf0,
+                          const float* __restrict__ U1, int uf1, const float* __restrict__ V1, int vf1, f32x4& r0, f32x4& r1) {
+    const float* up0 = U0 + uf0 * L::RS + 4 * lk;
+    const float* vp0 = V0 + vf0 * L::RS + 4 * lk;
+    const float* up1 = U1 + uf1 * L::RS + 4 * lk;
+    const float* vp1 = V1 + vf1 * L::RS + 4 * lk;
     f32x4 g0 = {0.f, 0.f, 0.f, 0.f}, g0b = {0.f, 0.f, 0.f, 0.f}, g1 = {0.f, 0.f, 0.f, 0.f}, g1b = {0.f, 0.f, 0.f, 0.f};
     if (few_rows) {
-      float u0[4], v0[4], u1[4], v1[4];
-#pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        u0[s] = U0[(4 * s + lk) * us0 + ucol0];
-        v0[s] = V0[(4 * s + lk) * vs0 + vcol0];
-        u1[s] = U1[(4 * s + lk) * us1 + ucol1];
-        v1[s] = V1[(4 * s + lk) * vs1 + vcol1];
-      }
+      const f32x4 u0 = rd4(up0), v0 = rd4(vp0), u1 = rd4(up1), v1 = rd4(vp1);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int s = 0; s < 4; s += 2) {
-        g0 = mfma16(u0[s], v0[s], g0);
-        g1 = mfma16(u1[s], v1[s], g1);
-        g0b = mfma16(u0[s + 1], v0[s + 1], g0b);
-        g1b = mfma16(u1[s + 1], v1[s + 1], g1b);
+      for (int i = 0; i < 4; i += 2) {
+        g0 = mfma16(u0[i], v0[i], g0);
+        g1 = mfma16(u1[i], v1[i], g1);
+        g0b = mfma16(u0[i + 1], v0[i + 1], g0b);
+        g1b = mfma16(u1[i + 1], v1[i + 1], g1b);
       }
     } else {
-      float u0[16], v0[16], u1[16], v1[16];
+      f32x4 u0[4], v0[4], u1[4], v1[4];
 #pragma unroll
-      for (int s = 0; s < 16; ++s) {
-        u0[s] = U0[(4 * s + lk) * us0 + ucol0];
-        v0[s] = V0[(4 * s + lk) * vs0 + vcol0];
-        u1[s] = U1[(4 * s + lk) * us1 + ucol1];
-        v1[s] = V1[(4 * s + lk) * vs1 + vcol1];
+      for (int sq = 0; sq < 4; ++sq) {
+        u0[sq] = rd4(up0 + 16 * sq);
+        v0[sq] = rd4(vp0 + 16 * sq);
+        u1[sq] = rd4(up1 + 16 * sq);
+        v1[sq] = rd4(vp1 + 16 * sq);
       }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int s = 0; s < 16; s += 2) {
-        g0 = mfma16(u0[s], v0[s], g0);
-        g1 = mfma16(u1[s], v1[s], g1);
-        g0b = mfma16(u0[s + 1], v0[s + 1], g0b);
-        g1b = mfma16(u1[s + 1], v1[s + 1], g1b);
-      }
+      for (int sq = 0; sq < 4; ++sq)
+#pragma unroll
+        for (int i = 0; i < 4; i += 2) {
+          g0 = mfma16(u0[sq][i], v0[sq][i], g0);
+          g1 = mfma16(u1[sq][i], v1[sq][i], g1);
+          g0b = mfma16(u0[sq][i + 1], v0[sq][i + 1], g0b);
+          g1b = mfma16(u1[sq][i + 1], v1[sq][i + 1], g1b);
+        }
     }
     r0 = g0 + g0b;
     r1 = g1 + g1b;
   };
-  // a column sum over the 64 rows with four lanes per column (16 rows each) and a cross-lane add
-  auto colsum64 = [&](const float* __restrict__ tile, int stride, int ncols, float* __restrict__ dst) {
-    // (the reads as one block, then the adds in row order: one LDS latency instead of sixteen)
+  // a column's sum over the 64 rows: four lanes per column (16 rows each: four ds_read_b128) and a cross-lane add
+  auto colsum64 = [&](const float* __restrict__ tile, int ncols, float* __restrict__ dst) {
     const int c = lane & 15, part = lane >> 4;
+    const float* cp = tile + min(c, MAXA - 1) * L::RS + part * 16;
+    f32x4 t[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) t[i] = rd4(cp + 4 * i);
+    __builtin_amdgcn_sched_barrier(0);
     float s = 0.f;
-    if (c < ncols) {
-      float t[16];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) t[r] = tile[(part * 16 + r) * stride + c];
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int r = 0; r < 16; ++r) s += t[r];
-    }
+    for (int i = 0; i < 4; ++i) s += (t[i][0] + t[i][1]) + (t[i][2] + t[i][3]);
+    s = c < ncols ? s : 0.f;
     s += __shfl_xor(s, 16, 64);
     s += __shfl_xor(s, 32, 64);
     if (lane < ncols && lane < 16) put(dst + lane, s);
   };
-  auto colsum64_wide = [&](const float* __restrict__ tile, int stride, float* __restrict__ dst) {  // 32 columns
+  auto colsum64_wide = [&](const float* __restrict__ tile, float* __restrict__ dst) {  // 32 columns, two lanes each
     const int c = lane & 31, part = lane >> 5;
+    const float* cp = tile + c * L::RS + part * 32;
+    f32x4 t[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) t[i] = rd4(cp + 4 * i);
+    __builtin_amdgcn_sched_barrier(0);
     float s = 0.f;
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {   // (two blocks of sixteen reads: 32 staged values cost spills in the widest instantiation)
-      float t[16];
-#pragma unroll
-      for (int r = 0; r < 16; ++r) t[r] = tile[(part * 32 + h * 16 + r) * stride + c];
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int r = 0; r < 16; ++r) s += t[r];
-    }
+    for (int i = 0; i < 8; ++i) s += (t[i][0] + t[i][1]) + (t[i][2] + t[i][3]);
     s += __shfl_xor(s, 32, 64);
     if (lane < 32) put(dst + lane, s);
   };
   if (tw == 0) {
     if (q < 2) {  // dWa[a][h] = sum_r dout[r][a] a2[r][h], 16 h-columns per wave
-      const f32x4 g = outer16(lds + L::dout, L::AS, li, a2t, L::HS, q * 16 + li);
+      const f32x4 g = outer16(lds + L::dout, li, a2t, q * 16 + li);
 #pragma unroll
       for (int r = 0; r < 4; ++r)
         if (lk * 4 + r < A) put(slab + (o.aW + (lk * 4 + r) * H + q * 16 + li), g[r]);
     }
-    if (q == 2) colsum64(lds + L::dout, L::AS, A, slab + o.ab);
-    if (q == 3 && !d.discrete) colsum64(lds + L::aux, L::AS, A, slab + o.log_std);
+    if (q == 2) colsum64(lds + L::dout, A, slab + o.ab);
+    if (q == 3 && !d.discrete) colsum64(lds + L::aux, A, slab + o.log_std);
   } else {
-    if (q < 2) {  // dcW[h] = sum_r dv[r] a2[r][h]  (only output row 0 is meaningful)
-      float u[16], v[16];
-#pragma unroll
-      for (int s = 0; s < 16; ++s) {
-        u[s] = lds[L::misc + (4 * s + lk) * L::MS + 1];   // (unconditional; masked behind the barrier)
-        v[s] = a2t[(4 * s + lk) * L::HS + q * 16 + li];
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      f32x4 g = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int s = 0; s < 16; ++s) g = mfma16(li == 0 ? u[s] : 0.f, v[s], g);
+    if (q < 2) {  // dcW[h] = sum_r dv[r] a2[r][h]  (only output row 0 is meaningful: the dvalue column feeds M index 0)
+      const f32x4 g = outer16(lds + L::misc + L::RS, 0, a2t, q * 16 + li);   // (every lane reads column 1; rows m > 0 unused)
       if (lk == 0) put(slab + (o.cW + q * 16 + li), g[0]);
     }
     if (q == 2) {  // cb = sum_r dv[r]; statpart slots {0 pg, 2 ent, 3 kl, 4 clip, 1 value} <- misc columns 2..6
       // columns 1..6 of the misc tile summed together: lane c < 6 handles column 1 + c
       const int c = lane & 15, part = lane >> 4;
+      const float* cp = lds + L::misc + (1 + min(c, 5)) * L::RS + part * 16;
+      f32x4 t[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) t[i] = rd4(cp + 4 * i);
+      __builtin_amdgcn_sched_barrier(0);
       float sm = 0.f;
-      if (c < 6) {
-        float t[16];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) t[r] = lds[L::misc + (part * 16 + r) * L::MS + 1 + c];
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) sm += t[r];
-      }
+      for (int i = 0; i < 4; ++i) sm += (t[i][0] + t[i][1]) + (t[i][2] + t[i][3]);
+      sm = c < 6 ? sm : 0.f;
       sm += __shfl_xor(sm, 16, 64);
       sm += __shfl_xor(sm, 32, 64);
       if (lane == 0) put(slab + (o.cb), sm);
@@ -2673,6 +2666,7 @@ __device__ __forceinline__ void mfma32_minibatch_chain(
       }
     }
   }
+  IA_TS(7);
   {  // dW2 (one 16x16 tile per wave) together with the wave's first dW1 tile (dz1^T x); db2, db1
     const int KT = (D + 15) >> 4;
     const int jt2 = q >> 1, kt2 = q & 1;
@@ -2687,20 +2681,19 @@ __device__ __forceinline__ void mfma32_minibatch_chain(
     if (q < 2 * KT) {   // (wave-uniform)
       const int jt = q / KT, kt = q - jt * KT;
       f32x4 g1;
-      outer16_pair(dz2t, L::HS, jt2 * 16 + li, a1t, L::HS, kt2 * 16 + li, dz1t, L::HS, jt * 16 + li, lds + L::x, L::XS,
-                   kt * 16 + li, g2, g1);
+      outer16_pair(dz2t, jt2 * 16 + li, a1t, kt2 * 16 + li, dz1t, jt * 16 + li, lds + L::x, kt * 16 + li, g2, g1);
       store_w1(q, g1);
     } else {
-      g2 = outer16(dz2t, L::HS, jt2 * 16 + li, a1t, L::HS, kt2 * 16 + li);
+      g2 = outer16(dz2t, jt2 * 16 + li, a1t, kt2 * 16 + li);
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) put(slab + (oW2 + (jt2 * 16 + lk * 4 + r) * H + kt2 * 16 + li), g2[r]);
-    if (q == 3) colsum64_wide(dz2t, L::HS, slab + ob2);
+    if (q == 3) colsum64_wide(dz2t, slab + ob2);
     for (int ti = q + 4; ti < 2 * KT; ti += 4) {   // observation widths beyond 32 columns: further dW1 tiles
       const int jt = ti / KT, kt = ti - jt * KT;
-      store_w1(ti, outer16(dz1t, L::HS, jt * 16 + li, lds + L::x, L::XS, kt * 16 + li));
+      store_w1(ti, outer16(dz1t, jt * 16 + li, lds + L::x, kt * 16 + li));
     }
-    if (q == 2) colsum64_wide(dz1t, L::HS, slab + ob1);
+    if (q == 2) colsum64_wide(dz1t, slab + ob1);
   }
   __syncthreads();
   IA_TS(8);
@@ -3350,7 +3343,11 @@ __global__ __launch_bounds__(512) void ppo_update_persistent_kernel(
     ShardArgs sh) {
   constexpr int H = 32;
   using L = CLds;
-  extern __shared__ float lds[];
+  // The tiles are read with ds_read_b128: their base must be 16-byte aligned. The dynamic part of the LDS starts right
+  // behind the static part -- 8 or 28 bytes here, depending on the instantiation -- and every wide read was split (2.4x
+  // the gradient-tile phase) until the base was rounded up (the host allocates 16 bytes more).
+  extern __shared__ float lds_raw[];
+  float* lds = lds_raw + (((16u - (__builtin_amdgcn_groupstaticsize() & 15u)) & 15u) >> 2);
   __shared__ int s_ok, s_pub, s_fail, s_pubw[4];
   if (!TIMING) tstamp = nullptr;
   long long tacc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -3578,7 +3575,7 @@ __global__ __launch_bounds__(512) void ppo_update_persistent_kernel(
   float* sPt = sP + w.P4;
   float* stg = sPt + w.P4;                    // UpdStage: the NEXT minibatch's rows of this block
   unsigned short* dstT = reinterpret_cast<unsigned short*>(stg + UpdStage::total(d.discrete ? 1 : d.act_dim));  // [P4] index of parameter i in the transposed copy
-  // (64 spare floats behind the misc tile, lds + L::misc + ROWS * L::MS, are the block reductions' scratch)
+  // (the 64 floats at lds + L::scratch are the block reductions' scratch)
   const int lane = tid & 63;
   float rm[NPT], rv[NPT];
 #pragma unroll
@@ -3693,7 +3690,7 @@ __global__ __launch_bounds__(512) void ppo_update_persistent_kernel(
     if (wave == 0) stg[UpdStage::src + lane] = stg[UpdStage::nxt + lane];
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the LDS-direct loads have landed
   };
-  for (int e = tid; e < (SMALL ? L::total : ROWS * L::XS); e += 512) lds[L::x + e] = 0.f;   // (the chain only rewrites the columns
+  for (int e = tid; e < (SMALL ? L::total : MAXD * L::RS); e += 512) lds[L::x + e] = 0.f;   // (the chain only rewrites the columns
                                                                                             // it uses; SMALL: rows 16.. of EVERY tile)
   if (n_steps > 0) {
     prefetch_resolve(0);
@@ -4083,7 +4080,7 @@ __global__ __launch_bounds__(512) void ppo_update_persistent_kernel(
     UPD_TS(4);
     int rz;   // opaque zero: the reduction scratch address is re-formed here instead of living in a (spilled) register
     asm volatile("s_mov_b32 %0, 0" : "=s"(rz));
-    const float total_sq = block_sum512_dpp(sq, lds + L::misc + ROWS * L::MS + rz, s & 1);
+    const float total_sq = block_sum512_dpp(sq, lds + L::scratch + rz, s & 1);
     UPD_TS(5);
     const float total_norm = sqrtf(total_sq);
     const float coef = fminf(max_norm / (total_norm + 1e-6f), 1.0f);  // torch clip_grad_norm_
@@ -4772,7 +4769,8 @@ int ia_ppo_epoch(const ia_policy_desc* d, float* params, float* params_t, float*
 
 // LDS of a gradient block: minibatch tiles, both parameter copies, the staged next minibatch, the transpose map
 inline size_t upd_grad_lds_bytes(int P4, int aw) {
-  return (CLds::total + 2 * (size_t)P4 + UpdStage::total(aw)) * sizeof(float) + P4 * sizeof(unsigned short);
+  return 16 /* base rounded up to 16 bytes */ + (CLds::total + 2 * (size_t)P4 + UpdStage::total(aw)) * sizeof(float) +
+         P4 * sizeof(unsigned short);
 }
 
 // Workspace of ia_ppo_update in floats; 0 when the persistent kernel does not cover the shape

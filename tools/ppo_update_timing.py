@@ -47,7 +47,7 @@ import numpy as np  # noqa: E402
 d = np.diff(np.concatenate([t[:7], t[8:9]]))   # (slot 7 is not stamped: the gradient tiles are one phase)
 names = ["0 stage/fragments", "1 layer1", "2 layer2", "3 heads", "4 loss", "5 head grads, dz2, dz1 + barrier",
          "6 gradient tiles (dW*, db*, statistics) + barrier"]
-print("shader clocks per minibatch phase (last step, block 0):")
+print("shader clocks per minibatch phase (last step, block 0):"); print("  tile phase: head tiles / column sums", t[7] - t[6], "clk, dW2 / dW1 tiles + bias sums + barrier", t[8] - t[7], "clk")
 for n_, v in zip(names, d):
     print(f"  {n_:18s} {v:8d} clk  ~{v / 2.4e3:6.2f} us @2.4GHz")
 print(f"  loss detail (clk): fragment requests + head outputs read {t[12] - t[4]}, log-prob / entropy over the actions "
