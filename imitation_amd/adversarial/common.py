@@ -117,7 +117,11 @@ class AdversarialTrainer(abc.ABC):
         self._reward_net = reward_net.to(self._device)
         self._log_dir = str(log_dir)
         if init_tensorboard:
-            raise NotImplementedError("tensorboard is not installed in this image; use csv/json logger formats")
+            # reference `common.py:223-227,343,386-387`: a histogram of the logits every 20th update. tensorboard is not
+            # part of this image: say so and train on (every scalar still goes through the logger's csv / json formats)
+            import warnings
+            warnings.warn("init_tensorboard=True: no tensorboard writer in this build -- the discriminator-logit "
+                          "histograms are skipped, all scalars are logged as usual", RuntimeWarning)
         self._disc_opt_cls = disc_opt_cls
         self._disc_opt_kwargs = dict(disc_opt_kwargs or {})
         # An `nn.Module` reward net (imitation_amd.modules, or any user subclass of its `RewardNet`): the

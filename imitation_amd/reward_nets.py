@@ -203,8 +203,29 @@ def _dims_of(space) -> int:
     return spaces.flatdim(space)
 
 
+def _module_twin(cls_name: str, args, kwargs):
+    """`dropout_prob > 0` (`util/networks.py:270-271`; off in every shipped GAIL / AIRL configuration): the fused
+    state-holder stacks have no dropout, the `nn.Module` reward nets of `imitation_amd.modules` do (layer by layer on the
+    HIP ops, masks from the device generator) -- so the constructor hands back the module net of the same name and
+    arguments, which `AdversarialTrainer` trains through `loss.backward()`. Normalisation layer classes are mapped to
+    their module counterparts."""
+    from imitation_amd import modules, networks
+    kw = dict(kwargs)
+    nl = kw.get("normalize_input_layer")
+    if nl is networks.EMANorm:
+        kw["normalize_input_layer"] = modules.EMANorm
+    elif nl is networks.RunningNorm:
+        kw["normalize_input_layer"] = modules.RunningNorm
+    return getattr(modules, cls_name)(*args, **kw)
+
+
 class BasicRewardNet(RewardNet):
     """`rewards/reward_nets.py:383-457`: MLP over the concatenation of the enabled inputs."""
+
+    def __new__(cls, *args, **kwargs):
+        if cls is BasicRewardNet and float(kwargs.get("dropout_prob", 0.0) or 0.0) > 0.0:
+            return _module_twin("BasicRewardNet", args, kwargs)   # (not an instance of cls: __init__ is not run on it)
+        return super().__new__(cls)
 
     def __init__(self, observation_space, action_space, use_state: bool = True, use_action: bool = True,
                  use_next_state: bool = False, use_done: bool = False, **kwargs):

@@ -605,3 +605,17 @@ def test_norm_layers_do_not_pickle_the_process_group():
         nrm.dp = Handle()
         back = pickle.loads(pickle.dumps(nrm))
         assert back.dp is None and nrm.dp is not None
+
+
+def test_dropout_routes_to_the_module_net_and_tensorboard_warns(tmp_path):
+    """Surface guards that used to raise: `BasicRewardNet(..., dropout_prob > 0)` (`util/networks.py:210,270-271`) hands
+    back the `nn.Module` reward net of the same arguments (the fused state-holder stacks have no dropout);
+    `init_tensorboard=True` (`common.py:223-227`) warns and trains on."""
+    from imitation_amd import modules, spaces
+
+    obs, act = spaces.Box(-np.inf, np.inf, (5,), np.float32), spaces.Box(-1, 1, (2,), np.float32)
+    net = p.BasicRewardNet(obs, act, hid_sizes=(16, 16), dropout_prob=0.25, normalize_input_layer=p.RunningNorm)
+    assert isinstance(net, modules.BasicRewardNet) and net.mlp.dropout_prob == 0.25
+    assert isinstance(net.mlp.normalize_input, modules.RunningNorm)
+    plain = p.BasicRewardNet(obs, act, hid_sizes=(16, 16))
+    assert type(plain) is p.BasicRewardNet and not isinstance(plain, modules.BasicRewardNet)

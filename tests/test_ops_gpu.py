@@ -336,3 +336,32 @@ def test_conv2d_nhwc_op_matches_torch(B, H, W, Cin, Cout, k, s, p, relu):
     for name, a_, r_ in (("y", y, yr), ("dx", x.grad, xr.grad), ("dw", w.grad, wr.grad), ("db", b.grad, br.grad)):
         scale = float(r_.abs().max()) + 1e-12
         assert float((a_ - r_).abs().max()) <= 5e-5 * scale, (name, float((a_ - r_).abs().max()), scale)
+
+
+def test_dropout_net_and_tensorboard_flag_train_through_gail(tmp_path):
+    """What used to raise now runs: a `BasicRewardNet(dropout_prob > 0)` built through the state-holder constructor is the
+    `nn.Module` net and trains through `GAIL.train` (module path: `loss.backward()` on the HIP ops); `init_tensorboard=True`
+    (`common.py:223-227`) warns and trains on."""
+    import imitation_amd as p
+    from imitation_amd import modules
+    from imitation_amd.vec_env import SyntheticVecEnv
+
+    cfg = harness.CASES["gail_box"]
+    th.manual_seed(0)
+    np.random.seed(0)
+    venv = SyntheticVecEnv(num_envs=cfg["n_envs"], obs_dim=17, act_dim=6, horizon=cfg["horizon"], seed=0)
+    algo = p.PPO(p.FeedForward32Policy, venv, n_steps=cfg["n_steps"], batch_size=cfg["ppo_batch"], n_epochs=2, seed=0,
+                 device="cuda")
+    net = p.BasicRewardNet(venv.observation_space, venv.action_space, hid_sizes=(32, 32), dropout_prob=0.2,
+                           normalize_input_layer=p.RunningNorm)
+    assert isinstance(net, modules.BasicRewardNet)
+    demos = p.Transitions(**harness.make_demo_arrays(cfg))
+    with pytest.warns(RuntimeWarning, match="init_tensorboard"):
+        tr = p.GAIL(demonstrations=demos, demo_batch_size=64, venv=venv, gen_algo=algo, reward_net=net,
+                    n_disc_updates_per_round=2, custom_logger=p.configure_logger(str(tmp_path), []), init_tensorboard=True)
+    before = {k: v.detach().clone() for k, v in net.state_dict().items()}
+    tr.train(2 * cfg["n_envs"] * cfg["n_steps"])
+    th.cuda.synchronize()
+    after = net.state_dict()
+    assert any(not th.equal(before[k], after[k]) for k in before if k.endswith("weight"))
+    assert all(bool(th.isfinite(v.float()).all()) for v in after.values())
