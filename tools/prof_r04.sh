@@ -1,7 +1,9 @@
 # Round-4 measurements (run through gpurun; summaries are copied to profiles/ by hand):
 #  1 kernel trace of the headline command   2 HBM-traffic PMC passes (separate runs)   3 matrix-pipe counters for the
 #  discriminator update alone (SQ_VALU_MFMA_BUSY_CYCLES & friends, per MI355X_MICROARCH.md's counter notes)
-#  4 kernel trace of variant H (1 024 000-transition rounds): the bandwidth-bound kernels against 8 TB/s
+#  4 kernel traces of variant H (1 024 000-transition rounds: the bandwidth-bound kernels against 8 TB/s) and of the two
+#  tuned files   5 phase clocks of the persistent PPO update   6 data-parallel round, stub collectives (row-sharded and
+#  replicated)   7 the full bench line   8 the slow parity tests
 set -x
 cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp; O=gpurun_out/r04; mkdir -p $O
 rocprofv3 -L 2>/dev/null | grep -i -E "MFMA|SQ_BUSY_CU|GRBM_GUI_ACTIVE|SQ_WAVE_CYCLES|SQ_ACTIVE_INST_ANY|SQ_WAIT_INST_ANY" | cut -c1-160 | sort -u | head -40 > $O/counters_available.txt
@@ -16,6 +18,16 @@ for c in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES" "SQ_INSTS_VALU_MFMA_MOPS_F
   rocprofv3 --kernel-trace --pmc $c -d $O/pmc_$n -- python tools/disc_step_bench.py 8 > $O/pmc_$n.log 2>&1
   DB=$(find $O/pmc_$n -name "*results.db" | head -1); python tools/rocpd_pmc.py $DB > $O/pmc_$n.txt 2>> $O/pmc_$n.log; grep -E "disc_fb|disc_reduce|ia_gemm_kernelILi2" $O/pmc_$n.txt | cut -c1-50,92-
 done
-rocprofv3 --kernel-trace --stats -d $O/kt_H -- python tools/variant_profile.py H_horizon_1024x1000 2 > $O/kt_H.log 2>&1
-DB=$(find $O/kt_H -name "*results.db" | head -1); python tools/rocpd_stats.py $DB $O/kernel_stats_H.md | head -30
+for v in H_horizon_1024x1000:2 T_gail_half_cheetah_tuned_verbatim:8 3_airl_ant_tuned_verbatim:3; do
+  n=${v%%:*}; r=${v##*:}
+  rocprofv3 --kernel-trace --stats -d $O/kt_$n -- python tools/variant_profile.py $n $r > $O/kt_$n.log 2>&1
+  DB=$(find $O/kt_$n -name "*results.db" | head -1); python tools/rocpd_stats.py $DB $O/kernel_stats_$n.md | head -14
+done
+python tools/ppo_update_timing.py 0 > $O/ppo_timing_P.txt 2>&1; tail -14 $O/ppo_timing_P.txt | cut -c1-400
+python tools/ppo_update_timing.py 0 T_gail_half_cheetah_tuned_verbatim > $O/ppo_timing_T.txt 2>&1; tail -3 $O/ppo_timing_T.txt | cut -c1-400
+for v in "" T_gail_half_cheetah_tuned_verbatim 3_airl_ant_tuned_verbatim 3_airl_ant_1024x16_mb1024; do python tools/ppo_step_us.py 0 8 $v 2>&1 | tail -1; done > $O/ppo_step_us.txt; cat $O/ppo_step_us.txt
+python tools/dp_overhead.py 20 > $O/dp_overhead_sharded.txt 2>&1; head -8 $O/dp_overhead_sharded.txt
+IA_DP_ROW_SHARDED=0 python tools/dp_overhead.py 20 > $O/dp_overhead_replicated.txt 2>&1; head -8 $O/dp_overhead_replicated.txt
+python bench.py > $O/bench_full.json 2> $O/bench_full.log; python tools/show_bench.py $O/bench_full.json 2>/dev/null | cut -c1-300 | head -24
+IA_SLOW_TESTS=1 python -m pytest tests/test_adversarial_gpu.py -q -s -m gpu -k "horizon_rollouts or bc_nature or full_size" > $O/slow_tests.txt 2>&1; grep -E "worst deviation|fraction outside|passed|failed" $O/slow_tests.txt | cut -c1-600
 find $O -name "*.db" -delete; find $O -name "*.csv" -size +2M -delete; du -sh $O
