@@ -315,6 +315,12 @@ VARIANTS = {
     # GAIL at Ant width (35 inputs) with use_next_state + use_done on top (63 inputs), default 32 x 32 net
     "P_ant_gail_d35": _v(algo="gail", n_envs=1024, n_steps=16, obs=27, act=8, ppo=_PPO_P, demo_batch=8192, n_disc=16,
                          capacity=16384, net=dict(), rounds=12, warm=3),
+    # ... the 256 x 256 discriminator at Ant width (rows of 36 floats: the wide tile kernels), without and with the
+    # opt-in gradient penalty (`disc_gp_kernel<256, 64>` inside the update)
+    "P_ant_gail_d35_h256": _v(algo="gail", n_envs=1024, n_steps=16, obs=27, act=8, ppo=_PPO_P, demo_batch=8192, n_disc=16,
+                              capacity=16384, net=dict(hid_sizes=(256, 256)), rounds=12, warm=3),
+    "P_ant_gail_d35_gp10": _v(algo="gail", n_envs=1024, n_steps=16, obs=27, act=8, ppo=_PPO_P, demo_batch=8192, n_disc=16,
+                              capacity=16384, net=dict(hid_sizes=(256, 256)), grad_penalty=10.0, rounds=12, warm=3),
     "P_ant_gail_d63_next_done": _v(algo="gail", n_envs=1024, n_steps=16, obs=27, act=8, ppo=_PPO_P, demo_batch=8192, n_disc=16,
                                    capacity=16384, net=dict(use_next_state=True, use_done=True), rounds=12, warm=3),
     # BASELINE config 1 in its canonical library form (docs/algorithms/gail.rst:36-91): 8 envs, SB3 MlpPolicy 64 x 64,

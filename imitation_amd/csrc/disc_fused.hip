@@ -21,6 +21,7 @@
 // fixed order.
 #include "common.h"
 #include "rn_common.h"
+#include "disc_reduce.h"
 #include "../../include/imitation_hip.h"
 
 namespace {
@@ -1100,9 +1101,16 @@ __global__ __launch_bounds__(BM * 8) void disc_fb_kernel(FusedArgs a) {
 // and C W1^T all read it). Only the second pass's GEMM operands u2 and v1 go to HBM, in slices beside the MFMAs of the
 // loop that reads them. Same arithmetic, same order as the three launches: bit-identical (`ia_disc_fused_split_tiles(1)`
 // keeps them; tests/test_disc_fused_gpu.py compares).
-template <int H>
+// DW = 64 (rows of up to 64 floats, D <= 63 -- Ant-width GAIL nets, `use_next_state` / `use_done`): layer 1 over K = 64,
+// the input gradient and the row coefficients as two 32-column blocks (the four waves: K halves x column blocks, two
+// columns per lane in the norm), the first-layer slab straight to HBM (its image would not fit beside the 65-float W1
+// rows), and the input gradient's partial tiles in the ring slot the second chunk loop has just finished with.
+template <int H, int DW = 24>
 __global__ __launch_bounds__(256) void disc_gp_kernel(FusedArgs a) {
   constexpr int BM = 32, NT = 256, NW = 4;
+  constexpr bool WIDE = DW == 64;
+  constexpr int XP = xp_of(DW), XP3 = xp3_of(DW);   // (shadow the narrow row lengths of the file scope)
+  constexpr int KS1 = WIDE ? 32 : 12;               // layer 1: k steps of 2
   constexpr int TN = H / 128;
   constexpr int WC = TN * 32;
   constexpr int LDH = H + 1;
@@ -1110,14 +1118,17 @@ __global__ __launch_bounds__(256) void disc_gp_kernel(FusedArgs a) {
   constexpr int BST = FB_K * H;
   constexpr int BV = BST / 4 / NT;
   constexpr int NR = 3;
-  constexpr int SCR = (H * 25 > NW * 32 * 33) ? H * 25 : NW * 32 * 33;   // gn partial tiles, then the first-layer slab image
+  constexpr bool SCR_IN_RING = WIDE && BST >= 2 * 32 * 64;
+  // gn partial tiles, then (narrow) the first-layer slab image; WIDE: 2 K halves x [32][64] partial tiles only
+  constexpr int SCR = WIDE ? (SCR_IN_RING ? 0 : 2 * 32 * 64) : ((H * 25 > NW * 32 * 33) ? H * 25 : NW * 32 * 33);
   static_assert(BST % (4 * NT) == 0, "B chunk must divide among the threads");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* h1s = smem;                   // [BM][LDH]   h1 -> u2 -> u1 -> v1
   float* bs = h1s + BM * LDH;          // NR x [FB_K][H] ring
   float* w1s = bs + NR * BST;          // [H][XP] W1 image, resident
-  float* scr = w1s + H * XP;           // [SCR]
-  float* w3red = scr + SCR;            // [H]
+  float* scr = SCR_IN_RING ? bs + ((2 * NCH - 1) % NR) * BST : w1s + H * XP;   // [SCR] (WIDE, H = 256: the slot of the
+                                                                               //  second loop's last chunk)
+  float* w3red = w1s + H * XP + SCR;   // [H]
   float* xs = w3red + H;               // [BM][XP3]: x_hat (normalised), later the row coefficients C
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1154,8 +1165,8 @@ __global__ __launch_bounds__(256) void disc_gp_kernel(FusedArgs a) {
     const int col = wn * WC + t * 32 + li;
     b1v[t] = b1[col]; b2v[t] = b2[col]; w3v[t] = w3[col];
   }
-  load_x_tile<BM, true>(a, a.X, row0, xs, XP3, tid);
-  for (int e = tid; e < BM * (XP3 - 1 - a.ldx); e += NT) {  // columns [ldx, 32)
+  load_x_tile<BM, true, false, WIDE>(a, a.X, row0, xs, XP3, tid);
+  for (int e = tid; e < BM * (XP3 - 1 - a.ldx); e += NT) {  // columns [ldx, 32) (WIDE: [ldx, 64))
     const int w = XP3 - 1 - a.ldx;
     const int row = e / w, c = a.ldx + e - row * w;
     xs[row * XP3 + c] = 0.f;
@@ -1171,21 +1182,21 @@ __global__ __launch_bounds__(256) void disc_gp_kernel(FusedArgs a) {
   __syncthreads();
 
   f32x16 acc[TN];
-  // layer-1 shaped product of the x tile with W1 (K = 24): at x_hat (first pass) and at C (second pass)
+  // layer-1 shaped product of the x tile with W1 (K = 24 / 64): at x_hat (first pass) and at C (second pass)
   auto layer1 = [&]() {
 #pragma unroll
     for (int t = 0; t < TN; ++t)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-    float af[12], bf[12][TN];
+    float af[KS1], bf[KS1][TN];
 #pragma unroll
-    for (int ks = 0; ks < 12; ++ks) {
+    for (int ks = 0; ks < KS1; ++ks) {
       af[ks] = xs[li * XP3 + 2 * ks + lh];
 #pragma unroll
       for (int t = 0; t < TN; ++t) bf[ks][t] = w1s[(wn * WC + t * 32 + li) * XP + 2 * ks + lh];
     }
 #pragma unroll
-    for (int ks = 0; ks < 12; ++ks)
+    for (int ks = 0; ks < KS1; ++ks)
 #pragma unroll
       for (int t = 0; t < TN; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[ks], bf[ks][t], acc[t], 0, 0, 0);
   };
@@ -1281,7 +1292,23 @@ __global__ __launch_bounds__(256) void disc_gp_kernel(FusedArgs a) {
   __syncthreads();
 
   // ---- gn = u1 W1 (K = H split over the four waves), row coefficients -> xs := C, penalty partial (disc_bwd_kernel MODE 1)
-  {
+  if constexpr (WIDE) {
+    constexpr int KH = H / 2;
+    const int kh = wave >> 1, col = (wave & 1) * 32 + li;
+    f32x16 accg;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) accg[r] = 0.f;
+    const bool cok = col < D;
+#pragma unroll 8
+    for (int s2 = 0; s2 < KH / 2; ++s2) {
+      const int k = kh * KH + 2 * s2 + lh;
+      const float af = h1s[li * LDH + k];
+      const float w1 = w1s[k * XP + col];
+      accg = __builtin_amdgcn_mfma_f32_32x32x2f32(af, cok ? w1 : 0.f, accg, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) scr[(kh * 32 + 4 * lh + rowoff(r)) * 64 + col] = accg[r];
+  } else {
     constexpr int KQ = H / NW;
     f32x16 accg;
 #pragma unroll
@@ -1299,7 +1326,28 @@ __global__ __launch_bounds__(256) void disc_gp_kernel(FusedArgs a) {
   }
   __syncthreads();
   float pen_w = 0.f;
-  {
+  if constexpr (WIDE) {
+    const int c1 = 32 + li;
+    const float inv0 = (a.mean != nullptr && li < D) ? 1.f / sqrtf(a.var[min(li, D - 1)] + a.eps) : 1.f;
+    const float inv1 = (a.mean != nullptr && c1 < D) ? 1.f / sqrtf(a.var[min(c1, D - 1)] + a.eps) : 1.f;
+#pragma unroll
+    for (int it = 0; it < 32 / (2 * NW); ++it) {
+      const int row = wave * (32 / NW) + 2 * it + lh;
+      const float gn0 = scr[row * 64 + li] + scr[(32 + row) * 64 + li];
+      const float gn1 = scr[row * 64 + c1] + scr[(32 + row) * 64 + c1];
+      const float g0 = li < D ? gn0 * inv0 : 0.f, g1 = c1 < D ? gn1 * inv1 : 0.f;
+      float sq = g0 * g0 + g1 * g1;
+      sq += __shfl_xor(sq, 16, 64); sq += __shfl_xor(sq, 8, 64); sq += __shfl_xor(sq, 4, 64);
+      sq += __shfl_xor(sq, 2, 64); sq += __shfl_xor(sq, 1, 64);
+      const float n = sqrtf(sq);
+      const bool valid = row0 + row < a.R;
+      const float kk = (valid && n > 0.f) ? a.gp_coef / (float)a.R * 2.f * (n - a.gp_target) / n : 0.f;
+      xs[row * XP3 + li] = li < D ? kk * gn0 * inv0 * inv0 : 0.f;
+      xs[row * XP3 + c1] = c1 < D ? kk * gn1 * inv1 * inv1 : 0.f;
+      const float pr = valid ? (n - a.gp_target) * (n - a.gp_target) : 0.f;
+      pen_w += __shfl(pr, 0, 64) + __shfl(pr, 32, 64);
+    }
+  } else {
     const float inv = (a.mean != nullptr && li < D) ? 1.f / sqrtf(a.var[min(li, D - 1)] + a.eps) : 1.f;
 #pragma unroll
     for (int it = 0; it < 32 / (2 * NW); ++it) {
@@ -1318,9 +1366,10 @@ __global__ __launch_bounds__(256) void disc_gp_kernel(FusedArgs a) {
       pen_w += __shfl(pr, 0, 64) + __shfl(pr, 32, 64);
     }
   }
-  if (lane == 0) xs[wave * XP3 + 32] = pen_w;
+  constexpr int PC = XP3 - 1;   // the spare last column of the tile
+  if (lane == 0) xs[wave * XP3 + PC] = pen_w;
   __syncthreads();
-  if (tid == 0) a.gp_pen[blockIdx.x] = ((xs[32] + xs[XP3 + 32]) + xs[2 * XP3 + 32]) + xs[3 * XP3 + 32];
+  if (tid == 0) a.gp_pen[blockIdx.x] = ((xs[PC] + xs[XP3 + PC]) + xs[2 * XP3 + PC]) + xs[3 * XP3 + PC];
 
   // ---- first-layer slab [dW1 | 0] = u1^T . C (no bias column), image in `scr`
   {
@@ -1328,29 +1377,34 @@ __global__ __launch_bounds__(256) void disc_gp_kernel(FusedArgs a) {
     float* P1 = a.P1 + (long long)blockIdx.x * n1;
     __syncthreads();   // (the gn partial tiles in `scr` have been read)
     for (int mt = wave; mt < H / 32; mt += NW) {
-      f32x16 acc1;
+      float af[BM / 2];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc1[r] = 0.f;
-      float af[BM / 2], bf[BM / 2];
+      for (int s = 0; s < BM / 2; ++s) af[s] = h1s[(2 * s + lh) * LDH + mt * 32 + li];
 #pragma unroll
-      for (int s = 0; s < BM / 2; ++s) {
-        const int k = 2 * s + lh;
-        af[s] = h1s[k * LDH + mt * 32 + li];
-        bf[s] = xs[k * XP3 + li];
-      }
+      for (int nb = 0; nb < (WIDE ? 2 : 1); ++nb) {
+        f32x16 acc1;
 #pragma unroll
-      for (int s = 0; s < BM / 2; ++s) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(af[s], bf[s], acc1, 0, 0, 0);
-      if (li <= D) {
+        for (int r = 0; r < 16; ++r) acc1[r] = 0.f;
+        float bf[BM / 2];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int i = mt * 32 + 4 * lh + rowoff(r);
-          scr[li < D ? i * D + li : H * D + i] = acc1[r];
+        for (int s = 0; s < BM / 2; ++s) bf[s] = xs[(2 * s + lh) * XP3 + nb * 32 + li];
+#pragma unroll
+        for (int s = 0; s < BM / 2; ++s) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(af[s], bf[s], acc1, 0, 0, 0);
+        const int col = nb * 32 + li;
+        if (col <= D) {   // (column D: the bias column of the slab, 0 here -- column D of C is 0)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int i = mt * 32 + 4 * lh + rowoff(r);
+            (WIDE ? P1 : scr)[col < D ? i * D + col : H * D + i] = acc1[r];
+          }
         }
       }
     }
-    __syncthreads();
-    for (int e = tid; e < (int)(n1 / 4); e += NT)
-      reinterpret_cast<f4*>(P1)[e] = reinterpret_cast<const f4*>(scr)[e];
+    if constexpr (!WIDE) {
+      __syncthreads();
+      for (int e = tid; e < (int)(n1 / 4); e += NT)
+        reinterpret_cast<f4*>(P1)[e] = reinterpret_cast<const f4*>(scr)[e];
+    }
   }
 
   // ---- v1 = relu'(h1) (C W1^T) into the tile (every wave is past its reads of u1: the barrier above)
@@ -1584,115 +1638,8 @@ __global__ __launch_bounds__(AS_NT) void disc_assemble_kernel(AssembleArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------- K5
-struct ReduceArgs {
-  const float* src[4]; long long stride[4]; int cnt[4]; long long seg_end[4];   // [W1 b1] | W2 | b2 | [W3 b3]
-  long long n; int accumulate; float* grads;
-  int adam; float* p; float* m; float* v; float beta1, beta2, eps, wd, step_size, bc2_sqrt;
-  const float* part; int tiles; int R; int n_expert; float loss_scale; float* stats;
-  float* W2T; float* W1P; int H; int D; int xp;   // images of W2 / W1 ([H][xp]) the tile kernels read: refreshed with the Adam step
-  // gradient penalty: a second slab set per segment, summed behind the first (cnt2 = 0: none), and the penalty's mean
-  const float* src2[4]; long long stride2[4]; int cnt2[4];
-  const float* pen; int pen_tiles; int gp_rows; float* gp_out;
-};
-
-// 64 parameters per block; wave q folds quarter q of the element's slabs in slab order, the four quarter
-// sums are combined in fixed order -> deterministic. The last block folds the statistics partials.
-__global__ __launch_bounds__(256) void disc_reduce_kernel(ReduceArgs a) {
-  __shared__ float red[4][64];
-  const int tid = threadIdx.x, lane = tid & 63, q = tid >> 6;
-  if (blockIdx.x == gridDim.x - 1) {
-    float vals[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    for (int t = tid; t < a.tiles; t += 256) {
-#pragma unroll
-      for (int k = 0; k < 6; ++k) vals[k] += a.part[(long long)t * 8 + k];
-    }
-    __shared__ float sred[6][4];
-#pragma unroll
-    for (int k = 0; k < 6; ++k) {
-      float v = vals[k];
-      for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
-      if (lane == 0) sred[k][q] = v;
-    }
-    __syncthreads();
-    if (tid < 6) {
-      float t = ((sred[tid][0] + sred[tid][1]) + sred[tid][2]) + sred[tid][3];
-      if (tid == 0) t = t / (float)a.R * a.loss_scale;
-      a.stats[tid] = t;
-    }
-    if (tid == 6) a.stats[6] = (float)a.n_expert;
-    if (tid == 7) a.stats[7] = (float)(a.R - a.n_expert);
-    if (a.gp_out != nullptr) {   // mean_i (|grad_x D(x_hat_i)| - target)^2 from the tiles' partial sums, fixed order
-      float v = 0.f;
-      for (int t = tid; t < a.pen_tiles; t += 256) v += a.pen[t];
-      for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
-      __syncthreads();
-      if (lane == 0) sred[0][q] = v;
-      __syncthreads();
-      if (tid == 0) a.gp_out[0] = (((sred[0][0] + sred[0][1]) + sred[0][2]) + sred[0][3]) / (float)a.gp_rows;
-    }
-    return;
-  }
-  const long long i = (long long)blockIdx.x * 64 + lane;
-  const long long ic = i < a.n ? i : a.n - 1;
-  const int seg = ic < a.seg_end[0] ? 0 : (ic < a.seg_end[1] ? 1 : (ic < a.seg_end[2] ? 2 : 3));
-  const long long base = seg == 0 ? 0 : a.seg_end[seg - 1];
-  const float* src = a.src[seg] + (ic - base);
-  const long long st = a.stride[seg];
-  const int cnt = a.cnt[seg];
-  const int lo = (int)((long long)q * cnt / 4), hi = (int)((long long)(q + 1) * cnt / 4);
-  float s = 0.f;
-  int k = lo;
-  for (; k + 8 <= hi; k += 8) {
-    float t[8];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) t[u] = src[(long long)(k + u) * st];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) s += t[u];
-  }
-  for (; k < hi; ++k) s += src[(long long)k * st];
-  if (a.cnt2[seg] > 0) {
-    const float* src2 = a.src2[seg] + (ic - base);
-    const long long st2 = a.stride2[seg];
-    const int cnt2 = a.cnt2[seg];
-    const int lo2 = (int)((long long)q * cnt2 / 4), hi2 = (int)((long long)(q + 1) * cnt2 / 4);
-    int k2 = lo2;
-    for (; k2 + 8 <= hi2; k2 += 8) {
-      float t[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) t[u] = src2[(long long)(k2 + u) * st2];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) s += t[u];
-    }
-    for (; k2 < hi2; ++k2) s += src2[(long long)k2 * st2];
-  }
-  red[q][lane] = s;
-  __syncthreads();
-  if (q != 0 || i >= a.n) return;
-  float grad = ((red[0][lane] + red[1][lane]) + red[2][lane]) + red[3][lane];
-  if (a.accumulate) grad = a.grads[i] + grad;
-  a.grads[i] = grad;
-  if (!a.adam) return;
-  // torch/optim/adam.py _single_tensor_adam: lerp, mul+addcmul, sqrt/bc2_sqrt + eps, addcdiv
-  const float pi = a.p[i];
-  if (a.wd != 0.f) grad = grad + a.wd * pi;
-  float mi = a.m[i];
-  mi = mi + (grad - mi) * (1.f - a.beta1);
-  const float vi = a.v[i] * a.beta2 + (1.f - a.beta2) * grad * grad;
-  const float denom = sqrtf(vi) / a.bc2_sqrt + a.eps;
-  const float pn = pi - a.step_size * (mi / denom);
-  a.p[i] = pn;
-  a.m[i] = mi;
-  a.v[i] = vi;
-  // the next update may skip the assemble launch (pre-assembled rounds): W2T / the padded W1 image follow here
-  const long long nW1 = (long long)a.H * a.D, n1 = nW1 + a.H;
-  if (i < nW1) {
-    const int n = (int)(i / a.D), k = (int)(i - (long long)n * a.D);
-    a.W1P[n * a.xp + k] = pn;
-  } else if (i >= n1 && i < n1 + (long long)a.H * a.H) {
-    const int j = (int)(i - n1), r = j / a.H, c = j - r * a.H;
-    a.W2T[(long long)c * a.H + r] = pn;
-  }
-}
+// (disc_reduce.h: ReduceArgs, disc_reduce_block)
+__global__ __launch_bounds__(256) void disc_reduce_kernel(ReduceArgs a) { disc_reduce_block(a, blockIdx.x, gridDim.x); }
 
 // ------------------------------------------------------------------------------------------- K5b
 // Data-parallel form of the tail of K5: the slab reduction has left this rank's gradient in `grads` (K5 with adam = 0),
@@ -1801,6 +1748,25 @@ inline GpWs gp_ws_layout(const ia_mlp_desc* d, int B, int ldx, float* base) {
 
 int g_fused_bm = 64;   // rows per tile workgroup (tuning: ia_disc_fused_tile_rows)
 bool g_fused_split = false;   // forward and backward tile passes as two launches (ia_disc_fused_split_tiles)
+bool g_side_reduce = true;    // the product-independent part of the closing reduction inside the split-K product's launch
+template <int H>
+int launch_gp_tiles_wide(const FusedArgs& ga, int B, hipStream_t stream) {
+  constexpr int BM = 32, XPW = xp_of(64), XP3W = xp3_of(64);
+  constexpr int SCR = FB_K * H >= 2 * 32 * 64 ? 0 : 2 * 32 * 64;
+  constexpr size_t smem_g = sizeof(float) * (BM * (H + 1) + 3 * FB_K * H + H * XPW + SCR + H + BM * XP3W);
+  static_assert(smem_g <= 160 * 1024, "the wide penalty tile must fit one CU's LDS");
+  static bool attr_g = false;
+  if (!attr_g) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(disc_gp_kernel<H, 64>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_g);
+    if (e != hipSuccess) return (int)e;
+    attr_g = true;
+  }
+  hipLaunchKernelGGL((disc_gp_kernel<H, 64>), dim3(cdivi(B, BM)), dim3(256), smem_g, stream, ga);
+  IA_CHECK_LAUNCH();
+  return IA_OK;
+}
+
 template <int H>
 int launch_gp_tiles(const FusedArgs& ga, int B, hipStream_t stream) {
   constexpr int BM = 32;
@@ -1908,13 +1874,14 @@ int ia_disc32_assemble(const ia_disc_step_args* a, int n_updates, int64_t idx_st
 int ia_disc32_step(const ia_disc_step_args* a, void* stream);
 extern "C" int ia_disc_fused_tile_rows(int rows) { g_fused_bm = rows == 32 ? 32 : 64; return IA_OK; }
 extern "C" int ia_disc_fused_split_tiles(int on) { g_fused_split = on != 0; return IA_OK; }
+extern "C" int ia_disc_fused_side_reduce(int on) { g_side_reduce = on != 0; return IA_OK; }
 extern "C" int ia_disc_fused_debug_timing(void* device_buffer_16xi64) {
   g_fused_dbg = static_cast<long long*>(device_buffer_16xi64);
   return IA_OK;
 }
 
 extern "C" int64_t ia_disc_fused_gp_ws_floats(const ia_mlp_desc* d, int B, int ldx) {
-  if (B <= 0 || fused_dw(d, ldx) != 24) return 0;   // (the penalty's tile kernels: rows of up to 24 floats)
+  if (B <= 0 || fused_dw(d, ldx) == 0) return 0;   // (the penalty's tile kernel: rows of up to 24 / up to 64 floats)
   return gp_ws_layout(d, B, ldx, nullptr).total;
 }
 
@@ -2007,7 +1974,7 @@ int ia_disc_step_fused(const ia_disc_step_args* a, void* stream_) {
   const int R = a->n0 + a->n1, D = d->dims[0], H = d->dims[1];
   if (a->fused_ws && ia_disc32_shape_ok(d, a->ldx)) return a->gp_e ? IA_ERR_UNSUPPORTED : ia_disc32_step(a, stream_);
   const int dw = fused_dw(d, a->ldx);
-  if (dw == 0 || !a->fused_ws || (dw != 24 && a->gp_e)) return IA_ERR_UNSUPPORTED;
+  if (dw == 0 || !a->fused_ws) return IA_ERR_UNSUPPORTED;
   const bool wide = dw != 24;
   const FusedWs w = fused_ws_layout(d, R, a->fused_ws);
   const int bm = (g_fused_bm == 64 || wide) ? 64 : 32;
@@ -2064,6 +2031,7 @@ int ia_disc_step_fused(const ia_disc_step_args* a, void* stream_) {
   //  vector-memory pipe per instruction, and fragments need one per operand and k-step; the LDS-staged GEMM
   //  moves the same data in 16-byte loads.)
   const int splits = a->splits;
+  IaGemm g_main{};
   {
     const int kps = (((R + splits - 1) / splits) + 31) / 32 * 32;
     IaGemm g{};
@@ -2073,14 +2041,21 @@ int ia_disc_step_fused(const ia_disc_step_args* a, void* stream_) {
     g.C = a->partials + n1; g.ldc = H;
     g.splits = splits; g.k_per_split = kps; g.c_split_stride = tot;
     g.dbias = nullptr; g.dbias_split_stride = tot;   // (db2: column sums of dh2 in the tile pass -- 3.5 us less here)
-    if ((rc = ia_launch_gemm(IA_GEMM_TN, g, stream))) return rc;
+    g_main = g;
+  }
+  const bool gp = a->gp_e != nullptr;
+  // What of the closing reduction does not depend on a split-K product rides in the LAST product's launch (the penalty's
+  // tile passes read the parameters: not in the first one then).
+  const bool side = g_side_reduce && H * (D + 1) % 64 == 0;
+  if (gp || !side) {
+    if ((rc = ia_launch_gemm(IA_GEMM_TN, g_main, stream))) return rc;
   }
 
   // opt-in gradient penalty (grad_penalty.py's definition) on the interpolates of the batch's expert / generator rows:
   // three tile launches + the split-K product u2^T v1; its slabs join the reduction below
-  const bool gp = a->gp_e != nullptr;
   GpWs gw{};
   int gtiles = 0;
+  IaGemm g_pen{};
   if (gp) {
     const int B = a->n0;
     if (!a->gp_ws || !a->gp_out || a->n1 != B || a->n_expert != B) return IA_ERR_ARG;
@@ -2090,7 +2065,9 @@ int ia_disc_step_fused(const ia_disc_step_args* a, void* stream_) {
     ga.R = B; ga.h1 = gw.v1; ga.dh2 = gw.u2; ga.h1mask = gw.m1; ga.h2mask = gw.m2; ga.P1 = gw.P1; ga.P3 = gw.P3;
     ga.gp_e = a->gp_e; ga.gp_C = gw.C; ga.gp_pen = gw.pen; ga.gp_coef = a->gp_coef; ga.gp_target = a->gp_target;
     ga.dbg = nullptr;
-    if ((rc = H == 256 ? launch_gp_tiles<256>(ga, B, stream) : launch_gp_tiles<128>(ga, B, stream))) return rc;
+    if (wide) rc = H == 256 ? launch_gp_tiles_wide<256>(ga, B, stream) : launch_gp_tiles_wide<128>(ga, B, stream);
+    else rc = H == 256 ? launch_gp_tiles<256>(ga, B, stream) : launch_gp_tiles<128>(ga, B, stream);
+    if (rc) return rc;
     const int kps = (((B + gw.splits - 1) / gw.splits) + 31) / 32 * 32;
     IaGemm g{};
     g.A = gw.u2; g.lda = H;
@@ -2099,7 +2076,8 @@ int ia_disc_step_fused(const ia_disc_step_args* a, void* stream_) {
     g.C = gw.partials + n1; g.ldc = H;
     g.splits = gw.splits; g.k_per_split = kps; g.c_split_stride = tot;
     g.dbias = nullptr; g.dbias_split_stride = tot;
-    if ((rc = ia_launch_gemm(IA_GEMM_TN, g, stream))) return rc;
+    g_pen = g;
+    if (!side && (rc = ia_launch_gemm(IA_GEMM_TN, g, stream))) return rc;
   }
 
   ReduceArgs ra{};
@@ -2122,7 +2100,18 @@ int ia_disc_step_fused(const ia_disc_step_args* a, void* stream_) {
   ra.part = w.part; ra.tiles = tiles; ra.R = R; ra.n_expert = a->n_expert; ra.loss_scale = a->loss_scale;
   ra.stats = a->stats;
   ra.W2T = w.W2T; ra.W1P = w.W1P; ra.H = H; ra.D = D; ra.xp = xp_of(dw);
-  hipLaunchKernelGGL(disc_reduce_kernel, dim3(cdivi(tot, 64) + 1), dim3(256), 0, stream, ra);
+  if (side) {
+    // first / last layer, b2, the statistics row: beside the product; dW2's split slabs: behind it
+    ra.r_begin[0] = 0; ra.r_end[0] = n1; ra.nb0 = (int)(n1 / 64);
+    ra.r_begin[1] = n1 + (long long)H * H; ra.r_end[1] = tot; ra.do_stats = 1;
+    if ((rc = ia_launch_gemm_tn_side(gp ? g_pen : g_main, ra, stream))) return rc;
+    ra.r_begin[0] = n1; ra.r_end[0] = n1 + (long long)H * H; ra.nb0 = H * H / 64;
+    ra.r_begin[1] = 0; ra.r_end[1] = 0; ra.do_stats = 0;
+  } else {
+    ra.r_begin[0] = 0; ra.r_end[0] = tot; ra.nb0 = cdivi(tot, 64);
+    ra.r_begin[1] = 0; ra.r_end[1] = 0; ra.do_stats = 1;
+  }
+  hipLaunchKernelGGL(disc_reduce_kernel, dim3(disc_reduce_blocks(ra)), dim3(256), 0, stream, ra);
   IA_CHECK_LAUNCH();
   if (a->adam && a->accumulate)
     return ia_adam_step(a->params, a->grads, a->exp_avg, a->exp_avg_sq, tot, a->beta1, a->beta2, a->adam_eps,

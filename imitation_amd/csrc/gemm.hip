@@ -13,6 +13,7 @@
 // Global->LDS goes through registers (float4 loads issued one chunk ahead, written to the
 // other LDS buffer after the MFMAs: one barrier per 32-deep K chunk).
 #include "common.h"
+#include "disc_reduce.h"
 
 namespace {
 
@@ -485,6 +486,20 @@ __global__ __launch_bounds__(WM* WN * 64) void ia_gemm_kernel(IaGemm g) {
   gemm_block<WM, WN, TM, TN, MODE, IM>(g, smem, gridDim.x, blockIdx.x);
 }
 
+// The split-K TN product of the fused discriminator update with a SIDE JOB in front: workgroups [0, side_blocks) run the
+// part of the update's slab reduction + Adam step that does not depend on this product (disc_reduce.h) -- ~7 MB of slab
+// reads that used to wait for the product to finish, now under its MFMAs; the rest are the product's own workgroups.
+template <int WM, int WN, int TM, int TN>
+__global__ __launch_bounds__(WM* WN * 64) void ia_gemm_tn_side_kernel(IaGemm g, ReduceArgs side, int side_blocks) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  static_assert(WM * WN * 64 == 256, "disc_reduce_block is written for 256 threads");
+  if ((int)blockIdx.x < side_blocks) {
+    disc_reduce_block(side, blockIdx.x, side_blocks);
+    return;
+  }
+  gemm_block<WM, WN, TM, TN, IA_GEMM_TN>(g, smem, gridDim.x - side_blocks, blockIdx.x - side_blocks);
+}
+
 // Up to three independent split-K TN GEMMs in ONE launch (32-row outputs: the hidden-layer weight gradients of the small
 // AIRL stacks, 10-16 us each when launched one after the other -- latency-bound with 128 workgroups; together they
 // fill the chip): workgroups [0, nb0) run problem 0, [nb0, nb0 + nb1) problem 1, the rest problem 2.
@@ -577,6 +592,35 @@ int ia_launch_gemm(int mode, const IaGemm& g, hipStream_t stream) {
     case IA_GEMM_TN: return launch_mode<IA_GEMM_TN>(g, stream);
   }
   return IA_ERR_ARG;
+}
+
+int ia_launch_gemm_tn_side(const IaGemm& g, const ReduceArgs& side, hipStream_t stream) {
+  if (g.M <= 0 || g.N <= 0 || g.K < 0 || g.im.on || g.splits < 1) return IA_ERR_ARG;
+  constexpr int WM = 2, WN = 2, TM = 1, TN = 1, NT = 256, BM = 64, BN = 64;   // launch_mode's choice for these shapes
+  using AIO = TileIO<BM, NT, true>;
+  using BIO = TileIO<BN, NT, true>;
+  constexpr size_t smem = 2 * (AIO::ELEMS + BIO::ELEMS) * sizeof(float);
+  auto kern = ia_gemm_tn_side_kernel<WM, WN, TM, TN>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  const int side_blocks = disc_reduce_blocks(side);
+  const int tiles = ((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN);
+  const bool prof = g_prof_on && g_prof_n < PROF_POOL;
+  if (prof) (void)hipEventRecord(g_prof_ev[g_prof_n][0], stream);
+  hipLaunchKernelGGL(kern, dim3(side_blocks + tiles * g.splits), dim3(NT), smem, stream, g, side, side_blocks);
+  IA_CHECK_LAUNCH();
+  if (prof) {
+    (void)hipEventRecord(g_prof_ev[g_prof_n][1], stream);
+    g_prof_kid[g_prof_n] = IA_GEMM_TN * 4 + 1;
+    g_prof_fl[g_prof_n] = 2.0 * (double)g.M * (double)g.N * (double)g.K;
+    ++g_prof_n;
+  }
+  return IA_OK;
 }
 
 // n <= 3 split-K TN GEMMs with M <= 32 in one launch (32 x 128 tiles)

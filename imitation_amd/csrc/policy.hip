@@ -3846,7 +3846,8 @@ __global__ __launch_bounds__(512) void ppo_update_persistent_kernel(
           gi_[k] = min(j, nblk - 1) * P8 + min(gi, P8 - 1);
           if (f < nblk * SL && valid_el(gi)) need |= 1u << k;
         }
-        for (unsigned it = 0;;) {
+        unsigned it = 0;
+        for (;; ) {
 #pragma unroll
           for (int k = 0; k < NPT; ++k)   // (unconditional loads at clamped addresses, all in flight together)
             t[k] = __hip_atomic_load(slabs_s + gi_[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -3862,6 +3863,7 @@ __global__ __launch_bounds__(512) void ppo_update_persistent_kernel(
             break;
           }
         }
+        if (tstamp && tid == 0) tstamp[40] += it;   // (measurement build: hop 1's unsuccessful polls of thread 0)
 #pragma unroll
         for (int k = 0; k < NPT; ++k) {
           const int f = tid + k * 512;
@@ -3944,7 +3946,8 @@ __global__ __launch_bounds__(512) void ppo_update_persistent_kernel(
         u64 t[NPT];
         int ez;
         asm volatile("s_mov_b32 %0, 0" : "=s"(ez));
-        for (unsigned it = 0; !fail;) {
+        unsigned it = 0;
+        for (; !fail;) {
 #pragma unroll
           for (int k = 0; k < NPT; ++k)
             t[k] = __hip_atomic_load(sums_s + min(tid + ez + k * 512, o.total - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -3961,6 +3964,7 @@ __global__ __launch_bounds__(512) void ppo_update_persistent_kernel(
             break;
           }
         }
+        if (tstamp && tid == 0) tstamp[41] += it;   // (hop 2's unsuccessful polls)
 #pragma unroll
         for (int k = 0; k < NPT; ++k) g[k] = __uint_as_float((unsigned)t[k]);
       }

@@ -209,6 +209,10 @@ int ia_disc_fused_tile_rows(int rows);
 /* Tuning / measurement: 1 = the update's forward and backward tile passes as two launches (disc_fwd_kernel,
  * disc_bwd_kernel); 0 (default) = both in one (disc_fb_kernel). Outputs are bit-identical. */
 int ia_disc_fused_split_tiles(int on);
+/* Tuning / measurement: 1 (default) = the part of the update's closing slab reduction + Adam step that does not depend
+ * on the split-K product dW2 (first / last layer, b2, the statistics row) runs as the leading workgroups of that
+ * product's launch; 0 = the whole reduction in its own launch behind the product. Outputs are bit-identical. */
+int ia_disc_fused_side_reduce(int on);
 
 /* Gradient penalty on the discriminator (OPT-IN extension, default off: BASELINE.json config 3 / the north star name
  * it, the reference has none -- SURVEY M1): E[(|grad_x D(x_hat)|_2 - target)^2] at x_hat = e x_expert + (1-e) x_gen.

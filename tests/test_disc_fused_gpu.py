@@ -202,7 +202,11 @@ def test_gradient_accumulation_through_the_narrow_fused_step():
 
 
 @pytest.mark.parametrize("hid,B,norm,od", [((256, 256), 256, True, 17), ((128, 128), 200, True, 17),
-                                           ((256, 256), 1000, False, 11), ((256, 256), 4096, True, 17)])
+                                           ((256, 256), 1000, False, 11), ((256, 256), 4096, True, 17),
+                                           # rows of up to 64 floats (`disc_gp_kernel<H, 64>`): D = 35 (Ant-width), D = 63
+                                           ((256, 256), 1000, True, 29), ((256, 256), 500, True, 57),
+                                           ((128, 128), 200, False, 29), ((256, 256), 4096, True, 29),
+                                           ((128, 128), 333, True, 57)])
 def test_fused_gradient_penalty_matches_float64_double_backward(hid, B, norm, od):
     """The opt-in gradient penalty inside the 128 / 256-wide fused update (`disc_fwd_kernel` / `disc_bwd_kernel`
     MODE 1 / 2): gradient of [BCE + coef * mean (|grad_x D(x_hat)| - target)^2] against a float64 double-backward graph,
@@ -293,6 +297,7 @@ def test_one_launch_tile_pass_is_bit_identical_to_forward_plus_backward_launches
         lib.ia_disc_fused_tile_rows(rows)
         for split in (1, 0):
             lib.ia_disc_fused_split_tiles(split)
+            lib.ia_disc_fused_side_reduce(1 - split)   # (the closing reduction: one launch / split around the product)
             th.manual_seed(3)
             net = reward_nets.BasicRewardNet(osp, asp, hid_sizes=hid, normalize_input_layer=p.RunningNorm).to(DEV)
             mlp = net.mlp
@@ -310,6 +315,7 @@ def test_one_launch_tile_pass_is_bit_identical_to_forward_plus_backward_launches
             outs.append(rows_out)
     finally:
         lib.ia_disc_fused_split_tiles(0)
+        lib.ia_disc_fused_side_reduce(1)
         lib.ia_disc_fused_tile_rows(64)
     names = ("logits", "statistics", "gradient", "parameters", "saved activations")
     for k, (a, b) in enumerate(zip(*outs)):
@@ -340,6 +346,7 @@ def test_one_launch_penalty_pass_is_bit_identical_to_its_three_launches(hid, B, 
     try:
         for split in (1, 0):
             lib.ia_disc_fused_split_tiles(split)
+            lib.ia_disc_fused_side_reduce(1 - split)   # (the closing reduction: one launch / split around the product)
             th.manual_seed(3)
             net = reward_nets.BasicRewardNet(osp, asp, hid_sizes=hid, **kw).to(DEV)
             with th.no_grad():
@@ -354,6 +361,7 @@ def test_one_launch_penalty_pass_is_bit_identical_to_its_three_launches(hid, B, 
             outs.append((net.mlp.grad.clone(), ws["gp_out"].clone(), ws["gp_ws"][:n_act].clone(), stats.clone()))
     finally:
         lib.ia_disc_fused_split_tiles(0)
+        lib.ia_disc_fused_side_reduce(1)
     for name, x, y in zip(("gradient", "penalty", "v1 | u2", "statistics"), *outs):
         if not th.equal(x, y):
             ii = th.nonzero((x != y).reshape(-1)).reshape(-1)

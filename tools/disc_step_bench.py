@@ -47,6 +47,8 @@ if os.environ.get("TILE_ROWS"):
     L.load().ia_disc_fused_tile_rows(int(os.environ["TILE_ROWS"]))
 SPLIT = os.environ.get("SPLIT") == "1"     # forward and backward tile passes as two launches (the form before round 3)
 L.load().ia_disc_fused_split_tiles(int(SPLIT))
+if os.environ.get("SIDE"):   # SIDE=0: the whole closing reduction in its own launch behind the split-K product
+    L.load().ia_disc_fused_side_reduce(int(os.environ["SIDE"]))
 e, g = tables(1)
 gi = th.Generator().manual_seed(2)
 ie = th.randint(0, NE, (mb,), generator=gi).to(dev)

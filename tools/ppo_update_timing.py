@@ -24,7 +24,7 @@ th.cuda.synchronize()
 algo = tr.gen_algo
 algo.defer_train_stats = True
 L.load().ia_ppo_update_xcd_pack(pack)
-buf = th.zeros(32, dtype=th.int64, device="cuda")
+buf = th.zeros(64, dtype=th.int64, device="cuda")
 L.load().ia_ppo_debug_timing(buf.data_ptr())
 for rep in range(3):
     buf.zero_()
@@ -40,6 +40,8 @@ for rep in range(3):
     print("statistics block per step: " + ", ".join(f"{n} {t_ / 100.0 / steps:.2f} us" for n, t_ in
                                                       zip(("wait for a free ring slot", "loss statistics of finished steps",
                                                            "minibatch statistics + publish"), sb)))
+    polls = buf.cpu().numpy()[40:42]
+    print(f"unsuccessful polls per step (thread 0 of workgroup 0): hop 1 {polls[0] / steps:.2f}, hop 2 {polls[1] / steps:.2f}")
     print(f"xcd_pack={pack}: train() {1e3 * d:.2f} ms for {steps} steps; per step: " +
           ", ".join(f"{n} {t_ / 100.0 / steps:.2f} us" for n, t_ in zip(names, ticks)))
 t = buf.cpu().numpy()[16:32]
