@@ -442,6 +442,7 @@ __global__ void bootstrap_kernel(float* __restrict__ rewards, const float* __res
 //                       (advantage mean/std, feature RunningNorm update), so no separate
 //                       "prepare" launch is needed except for the first minibatch of an epoch.
 
+__host__ __device__ inline long long epoch_ll_words(int nrb, int P);   // (ppo_epoch_ll_kernel's word areas)
 // ws layout (floats): [0..7] adv stats {mean, std}; [8..8+nblk*8) loss-stat partials;
 // then gradient slabs [nblk][P]; then reduced gradient [P].
 struct PpoWs {
@@ -476,9 +477,13 @@ __global__ void ppo_epoch_gather_kernel(const float* __restrict__ obs, const flo
                                         const float* __restrict__ ret, const int64_t* __restrict__ perm,
                                         long long total, int T, int n_envs, int D, int aw, float* __restrict__ gobs,
                                         float* __restrict__ gact, float* __restrict__ glogp, float* __restrict__ gadv,
-                                        float* __restrict__ gret) {
+                                        float* __restrict__ gret, unsigned long long* __restrict__ zero_words,
+                                        long long n_zero, unsigned* __restrict__ zero_ctl) {
   const int W = D + aw + 3;
   const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  // (the word-exchange epoch kernel's areas and control words are cleared here instead of by three fill launches per epoch)
+  for (long long z = e; z < n_zero; z += (long long)gridDim.x * blockDim.x) zero_words[z] = 0ull;
+  if (zero_ctl != nullptr && e < 3) zero_ctl[e] = 0u;
   if (e >= total * W) return;
   const long long p = e / W;
   const int c = (int)(e - p * W);
@@ -1142,14 +1147,24 @@ struct UpdStage {
 // that tower's parameters (both layouts, <= 71 KB) are resident in LDS like the H = 32 kernel's: every weight fragment is
 // an LDS read instead of a load from the memory-side cache, one wave per SIMD has the matrix pipe to itself, and the block
 // barriers are among four waves. The two workgroups of a row block write disjoint parts of the block's slab.
-template <int H, bool LOAD_PARAMS, bool SPLIT = false>
+// NLL > 0 (SPLIT only; ppo_epoch_ll_kernel): the word-exchange form. The tower's parameters arrive as 8-byte (value,
+// sequence) words `ll.par` -- every thread polls its NLL words of the tower's layers (+ head, log_std) until all carry
+// `ll.par_seq` -- and every gradient / statistics entry LEAVES as such a word with `ll.out_seq`: `slab` / `statpart` are
+// then word arrays (pointers to 8-byte words in float* clothing: only used for offsets). A poll that times out raises
+// `*ll.fail` (LDS) and `*ll.err`; the caller returns behind this function's closing barrier.
+struct MbLl {
+  const unsigned long long* par; unsigned par_seq, out_seq; int* fail; unsigned* err;
+};
+template <int H, bool LOAD_PARAMS, bool SPLIT = false, int NLL = 0>
 __device__ __forceinline__ void mfma_minibatch(
     const ia_policy_desc& d, const float* __restrict__ P, const float* __restrict__ Pt, const float* __restrict__ nm,
     const float* __restrict__ nv, const float adv_mean, const float adv_std, const MbRows rows, const int vblk,
     const int normalize_adv, const float clip, const float ent_coef, const float vf_coef, float* __restrict__ slab,
     float* __restrict__ statpart, float* __restrict__ lds_in, long long* __restrict__ tstamp, const int oz = 0,
-    const int tower = 0) {
+    const int tower = 0, const MbLl ll = MbLl{}) {
   static_assert(!SPLIT || (H == 64 && LOAD_PARAMS), "the one-tower form is the 64-wide epoch kernel's");
+  static_assert(NLL == 0 || SPLIT, "the word-exchange form is the one-tower kernel's");
+  constexpr bool LLX = NLL > 0;
   constexpr int NT = SPLIT ? 256 : 512;
   // `oz`: an opaque zero when the function sits inside a step loop (ppo_epoch_persistent_kernel): every per-lane offset is
   // then re-derived per step instead of being hoisted out of the loop into (spilled) registers
@@ -1182,7 +1197,10 @@ __device__ __forceinline__ void mfma_minibatch(
   // only wait for these, while the weight fragments requested next keep streaming in behind them)
   // (the block's ROWS x D real elements, element e = row * D + column: one division per thread, then (row, column) advance
   //  by NT elements per trip; trips past ROWS * D are skipped wave-uniformly)
-  constexpr int NIT = (ROWS * MAXD + NT - 1) / NT;
+  // (the word-exchange form is instantiated per observation-width class -- NLL = 20: D <= 14, 24: D <= 30 -- and takes
+  //  its row-load trips from the class: at D = 11 three of MAXD's sixteen trips carry elements)
+  constexpr int DMAX = NLL == 20 ? 14 : (NLL == 24 ? 30 : MAXD);
+  constexpr int NIT = (ROWS * DMAX + NT - 1) / NT;
   const int nel = ROWS * D;
   float xv[NIT], xm[NIT], xs_[NIT];
   int xi[NIT];   // LDS offset of the element inside the x tile (-1: none)
@@ -1255,18 +1273,105 @@ __device__ __forceinline__ void mfma_minibatch(
   const float* sPB = sP;
   const float* sLS = sP;
   typedef float f32x4_u __attribute__((ext_vector_type(4), aligned(4)));
-  constexpr int NA = SPLIT ? (H * MAXD + H + H * H + H + 4 * NT - 1) / (4 * NT) : 1;   // 16-byte pieces per thread, images A / T
+  constexpr int NA = (SPLIT && !LLX) ? (H * MAXD + H + H * H + H + 4 * NT - 1) / (4 * NT) : 1;   // 16-byte pieces per thread, images A / T
   constexpr int NB = SPLIT ? (MAXA * H + MAXA + NT - 1) / NT : 1;                      // elements per thread, image B
+  constexpr int NLA = LLX ? NLL : 1;                                                   // words per thread, image A
   float4 va[NA], vt[NA];
   float vb[NB];
+  float wa[NLA];
   float lsv = 0.f;
   const int tlen = H * D + H + H * H + H, t0 = tower ? o.vW1 : o.pW1;
   const int segB0 = tower ? o.cW : o.aW, nB = (tower ? o.total : o.cW) - segB0, lenB = (nB + 3) & ~3;
+  // (word-exchange form: image T holds W1^T and W2^T only, rows H + 4 floats apart -- the polled words go straight to
+  //  their transposed places, and with that row distance the 64 columns of a W2 row land in 16 banks instead of one)
+  constexpr int TS = LLX ? H + 4 : H;
   float* imgA = lds + ((L::total + 3) & ~3);
   float* imgT = imgA + tlen;
-  float* imgB = imgT + tlen;
+  float* imgB = imgT + (LLX ? (D + H) * TS : tlen);
   float* imgC = imgB + lenB;
-  if constexpr (SPLIT) {
+  auto stage_x = [&]() {
+#pragma unroll
+    for (int it = 0; it < NIT; ++it)
+      if (xi[it] >= 0) lds[L::x + xi[it]] = (xv[it] - xm[it]) / sqrtf(xs_[it] + d.norm_eps);
+    {
+      // columns D .. 4 * S1 - 1 feed layer 1's last MFMA step (against zero weight rows): they must be finite
+      const int padw = 4 * S1 - D;
+      for (int e = tid; e < ROWS * padw; e += NT) {
+        const int r = e / padw;
+        lds[L::x + r * L::XS + D + e - r * padw] = 0.f;
+      }
+    }
+    for (int e = tid; e < ROWS * L::AS; e += NT) { lds[L::dout + e] = 0.f; lds[L::aux + e] = 0.f; lds[L::out + e] = 0.f; }
+    for (int e = tid; e < ROWS * L::MS; e += NT) lds[L::misc + e] = 0.f;
+  };
+  if constexpr (LLX) {
+    // (the rows are normalised into the x tile FIRST: the owners publish the parameters at about the same moment everywhere,
+    //  and their flight -- plus the row loads' -- passes under this work instead of under a spin)
+    stage_x();
+    // the parameters as the chunk owners published them (this step's sequence number): all words requested together, the
+    // whole set again until every one has arrived (the row loads above are in flight meanwhile)
+    typedef unsigned long long u64;
+    const u64* pa = ll.par + t0;
+    const u64* pb = ll.par + segB0;
+    const u64* pc = ll.par + (d.discrete ? 0 : o.log_std + min(tid, A - 1));
+    u64 ta[NLA], tb[NB], tc;
+    unsigned it = 0;
+    for (;;) {
+#pragma unroll
+      for (int i = 0; i < NLA; ++i)
+        ta[i] = __hip_atomic_load(pa + min(tid + i * NT, tlen - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+      for (int i = 0; i < NB; ++i)
+        tb[i] = __hip_atomic_load(pb + min(tid + i * NT, nB - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      tc = __hip_atomic_load(pc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      bool ok = (unsigned)(tc >> 32) == ll.par_seq;
+#pragma unroll
+      for (int i = 0; i < NLA; ++i) ok = ok && (unsigned)(ta[i] >> 32) == ll.par_seq;
+#pragma unroll
+      for (int i = 0; i < NB; ++i) ok = ok && (unsigned)(tb[i] >> 32) == ll.par_seq;
+      if (__all(ok)) break;
+      __builtin_amdgcn_s_sleep(1);
+      if (++it > (1u << 22) || ((it & 255u) == 0 && __hip_atomic_load(ll.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+        if (lane == 0) {
+          __hip_atomic_store(ll.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          *ll.fail = 1;
+        }
+        break;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NLA; ++i) wa[i] = __uint_as_float((unsigned)ta[i]);
+#pragma unroll
+    for (int i = 0; i < NB; ++i) vb[i] = __uint_as_float((unsigned)tb[i]);
+    lsv = __uint_as_float((unsigned)tc);
+    sPA = imgA - t0;
+    sPt = imgT - t0;
+    sPB = imgB - segB0;
+    sLS = imgC - (d.discrete ? 0 : o.log_std);
+    // image A (torch layout) and, for the two weight matrices, the transposed places of image T; the head and log_std
+    {
+      const int nW1 = H * D, oW2i = nW1 + H;
+      const float invD = 1.f / (float)D;
+#pragma unroll
+      for (int i = 0; i < NLA; ++i) {
+        const int e = tid + i * NT;
+        if (e < tlen) {
+          imgA[e] = wa[i];
+          if (e < nW1) {
+            const int r = (int)(((float)e + 0.5f) * invD), c = e - r * D;   // (exact: e < 4096, D <= 64)
+            imgT[c * TS + r] = wa[i];
+          } else if (e >= oW2i && e < oW2i + H * H) {
+            const int j = e - oW2i;
+            imgT[(D + (j & (H - 1))) * TS + (j >> 6)] = wa[i];
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i)
+      if (tid + i * NT < nB) imgB[tid + i * NT] = vb[i];
+    if (tid < MAXA) imgC[tid] = lsv;
+  } else if constexpr (SPLIT) {
     // every load UNCONDITIONAL at a clamped index (see the row loads above); images A / T lie inside the flat vector whole,
     // the head goes element by element (its last 16-byte piece could run past the vector's end)
 #pragma unroll
@@ -1290,7 +1395,9 @@ __device__ __forceinline__ void mfma_minibatch(
     sLS = imgC - (d.discrete ? 0 : o.log_std);
   }
   auto store_images = [&]() {
-    if constexpr (SPLIT) {
+    if constexpr (LLX) {
+      // (nothing left: the poll wrote every image)
+    } else if constexpr (SPLIT) {
 #pragma unroll
       for (int i = 0; i < NA; ++i)
         if (tid + i * NT < (tlen >> 2)) {
@@ -1331,19 +1438,7 @@ __device__ __forceinline__ void mfma_minibatch(
   IA_TS(10);
   // ---- phase 0b: normalise + stage the feature rows in LDS; clear the small tiles
   auto stage_rows = [&]() {
-#pragma unroll
-    for (int it = 0; it < NIT; ++it)
-      if (xi[it] >= 0) lds[L::x + xi[it]] = (xv[it] - xm[it]) / sqrtf(xs_[it] + d.norm_eps);
-    {
-      // columns D .. 4 * S1 - 1 feed layer 1's last MFMA step (against zero weight rows): they must be finite
-      const int padw = 4 * S1 - D;
-      for (int e = tid; e < ROWS * padw; e += NT) {
-        const int r = e / padw;
-        lds[L::x + r * L::XS + D + e - r * padw] = 0.f;
-      }
-    }
-    for (int e = tid; e < ROWS * L::AS; e += NT) { lds[L::dout + e] = 0.f; lds[L::aux + e] = 0.f; lds[L::out + e] = 0.f; }
-    for (int e = tid; e < ROWS * L::MS; e += NT) lds[L::misc + e] = 0.f;
+    if constexpr (!LLX) stage_x();   // (word-exchange form: done ahead of the parameter poll, see there)
     store_images();   // (SPLIT: the parameter images, whose loads were issued ahead of this staging)
     __syncthreads();
   };
@@ -1373,22 +1468,25 @@ __device__ __forceinline__ void mfma_minibatch(
   // slab / statistics stores: write-through in the one-tower form (the grid barrier's release fence then finds no dirty
   // lines of the 44 KB slab to write back, as in the H = 32 persistent kernel), plain stores otherwise
   auto sst = [&](float* __restrict__ p_, float v_) {
-    if constexpr (SPLIT) slab_store(p_, v_);
+    if constexpr (LLX) ll_store_agent(reinterpret_cast<unsigned long long*>(slab) + (p_ - slab), v_, ll.out_seq);
+    else if constexpr (SPLIT) slab_store(p_, v_);
     else *p_ = v_;
   };
+  const float* tW1 = LLX ? imgT : sPt + oW1;          // rows of W1^T / W2^T, TS floats apart
+  const float* tW2 = LLX ? imgT + D * TS : sPt + oW2;
   float bW1[16][NC], bW2[KS][NC], bW2o[KS][NC], bHead[KS], bDa2[4][NC], b1v[NC], b2v[NC], cwv[NC];
 #pragma unroll
   for (int s = 0; s < 16; ++s) {
 #pragma unroll
     for (int c = 0; c < NC; ++c) bW1[s][c] = 0.f;
-    if (s < S1) ldc(sPt + oW1 + min(4 * s + lk, D - 1) * H, bW1[s]);  // wave-uniform: steps beyond the observation width issue no reads
+    if (s < S1) ldc(tW1 + min(4 * s + lk, D - 1) * TS, bW1[s]);  // wave-uniform: steps beyond the observation width issue no reads
   }
   const int head_row = tw == 0 ? o.aW + min(li, A - 1) * H : o.cW;
   const bool head_on = tw == 0 ? li < A : li == 0;
 #pragma unroll
   for (int s = 0; s < KS; ++s) {
     const int kk = 4 * s + lk;
-    ldc(sPt + oW2 + kk * H, bW2[s]);   // W2^T[k][j]
+    ldc(tW2 + kk * TS, bW2[s]);   // W2^T[k][j]
     bHead[s] = sPB[head_row + kk];
   }
   IA_FENCE();
@@ -1400,6 +1498,7 @@ __device__ __forceinline__ void mfma_minibatch(
     }
 #pragma unroll
   for (int s = 0; s < KS; ++s) bHead[s] = head_on ? bHead[s] : 0.f;
+  IA_TS(12);
   // fragments of the backward phases: H = 32 takes them here (LDS reads, resident all along); H = 64 requests them
   // from L2 after the forward chain, when the forward fragments' registers are free again
   auto load_backward_fragments = [&]() {
@@ -1428,7 +1527,7 @@ __device__ __forceinline__ void mfma_minibatch(
   for (int c = 0; c < NC; ++c) cwv[c] = 0.f;
   if (!SPLIT || tw == 1) ldc(sPB + o.cW, cwv);   // (used by the value tower only)
   const float head_bias = tw == 0 ? (li < A ? sPB[o.ab + li] : 0.f) : sPB[o.cb];
-  // per-action Gaussian constants (wave-uniform): sd = exp(log_std), var = sd^2, log sd
+  IA_TS(13);
   // per-action Gaussian constants of the lane's actions (policy waves): 1 / sd^2, log sd with sd = exp(log_std)
   float c_ivar[4], c_logsd[4];
   const bool need_sd = tw == 0 && !d.discrete;
@@ -3329,6 +3428,251 @@ __global__ __launch_bounds__(SPLIT ? 256 : 512) void ppo_epoch_persistent_kernel
 #undef EP_TS
 }
 
+// ---------------------------------------------------------------------------------------------
+// The one-tower epoch kernel WITHOUT grid barriers: the three hand-offs of a step travel as 8-byte (value, sequence) words
+// (the exchange of the H = 32 persistent kernel: no flags, no fences, nothing to reset -- a word is valid when its upper
+// half carries the step's sequence number; two buffers by sequence parity):
+//   A   gradient of the minibatch (mfma_minibatch<H, true, true, NLL>): the tower's parameters are POLLED from the
+//       parameter words (`par`, published by the chunk owners at the end of the previous step), the gradient entries and
+//       the loss-statistic partials leave as words of the row block's slab
+//   B1  workgroup g polls chunk g of every slab and sums it in slab order; its sum of squares leaves as ONE word (`sq`)
+//   B2  every workgroup polls the G partial sums of squares and folds them in order -> norm, clip coefficient; Adam on
+//       its own chunk (parameters and moments in registers across the launch); the new parameters leave as words.
+// Same arithmetic in the same order as ppo_epoch_persistent_kernel<H, true>: bit-identical results
+// (`ia_ppo_epoch_split(3)` keeps that kernel; tests compare). Who may overwrite what: a workgroup writes step s + 2's slab
+// words (same buffer as step s's) only behind its poll of step s + 1's parameters, which every chunk owner publishes
+// behind ITS poll of all sums of squares of step s + 1, which every workgroup publishes behind its slab poll of step
+// s + 1 -- so every reader of step s's slab words is long done; the same chain covers `sq` and `par`.
+// Sequence numbers: `seq0` + k for "the parameters step k of this launch reads", `seq0` + k + 1 for what it produces;
+// the host passes 1 + Adam steps done (never 0) and clears the word areas once per call (the workspace arrives
+// uninitialised and a caller may restart its step count).
+struct EpochLl {
+  unsigned long long* base;   // slabs [2][nrb][P + 8] | sq [2][64] | par [2][P]   (8-byte words)
+  unsigned seq0;
+};
+__host__ __device__ inline long long epoch_ll_words(int nrb, int P) { return 2LL * nrb * (P + 8) + 2 * 64 + 2LL * P; }
+
+template <int H, int NLL>
+__global__ __launch_bounds__(256) void ppo_epoch_ll_kernel(
+    ia_policy_desc d, float* __restrict__ P, float* __restrict__ Pt, float* __restrict__ m, float* __restrict__ v,
+    const float* __restrict__ nm_in, const float* __restrict__ nv_in, const float* __restrict__ obs,
+    const float* __restrict__ actions, const float* __restrict__ old_logp, const float* __restrict__ adv,
+    const float* __restrict__ ret, long long total_rows, int batch_size, int T, int n_envs, int normalize_adv,
+    float clip, float ent_coef, float vf_coef, float max_norm, float beta1, float beta2, float eps,
+    float* __restrict__ ws, EpochLl ll, const float* __restrict__ seq, int snap, float* __restrict__ stats, EpochSteps st,
+    long long* __restrict__ dbg /* measurement: [0..5] += 100 MHz ticks of workgroup 0 in {A, slab poll + sum, sum of squares
+                                   published, poll of the sums of squares, Adam + publish, -} */) {
+  typedef unsigned long long u64;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  __shared__ int s_fail;
+  __shared__ float s_part[64];
+  __shared__ float s_stat[32 * 8];
+  long long tprev = 0;
+#define EP_TS(slot)                                                       \
+  do {                                                                    \
+    if (dbg != nullptr && blockIdx.x == 0 && threadIdx.x == 0) {          \
+      const long long tn = wall_clock64();                                \
+      dbg[slot] += tn - tprev;                                            \
+      tprev = tn;                                                         \
+    }                                                                     \
+  } while (0)
+  if (dbg != nullptr && blockIdx.x == 0 && threadIdx.x == 0) tprev = wall_clock64();
+  constexpr int NT = 256;
+  const int bid = blockIdx.x, nwg = gridDim.x, nrb = nwg >> 1;
+  const int D = d.obs_dim, aw = d.discrete ? 1 : d.act_dim;
+  const PolOff o = pol_offsets(D, d.act_dim, H, d.discrete);
+  const int SW = o.total + 8;
+  u64* slabs64 = ll.base;
+  u64* sq64 = slabs64 + 2LL * nrb * SW;
+  u64* par64 = sq64 + 2 * 64;
+  unsigned* err = reinterpret_cast<unsigned*>(ws) + 5;
+  const int chunk = (o.total + nwg - 1) / nwg;
+  constexpr int NPC = 4;   // parameters of the chunk per thread (chunk <= 1024)
+  if (threadIdx.x == 0) s_fail = 0;
+  // the workgroup's chunk of the parameters and of Adam's moments: registers across the launch (nobody else writes it)
+  float m_[NPC], v_[NPC], p_[NPC];
+#pragma unroll
+  for (int j = 0; j < NPC; ++j) {
+    const int i = min(bid * chunk + (int)threadIdx.x + j * NT, o.total - 1);
+    m_[j] = m[i];
+    v_[j] = v[i];
+    p_[j] = P[i];
+  }
+  {   // the parameters the first step reads
+    u64* dst = par64 + (long long)(ll.seq0 & 1u) * o.total;
+#pragma unroll
+    for (int j = 0; j < NPC; ++j) {
+      const int i = bid * chunk + (int)threadIdx.x + j * NT;
+      if (i < min(o.total, (bid + 1) * chunk)) ll_store_agent(dst + i, p_[j], ll.seq0);
+    }
+  }
+  __syncthreads();
+#pragma nounroll
+  for (int k = 0; k < st.n; ++k) {
+    const unsigned seq_par = ll.seq0 + (unsigned)k, seq_out = seq_par + 1u;
+    const int mb = st.first + k;
+    const long long start = (long long)mb * batch_size;
+    const int b = (int)min((long long)batch_size, total_rows - start);
+    const int nblk = (b + ROWS - 1) / ROWS;
+    const float* sq = seq + (long long)mb * EPS_SEQ;
+    u64* slabs_s = slabs64 + (long long)(seq_out & 1u) * nrb * SW;
+    // ---- A: gradient of this minibatch
+    if ((bid >> 1) < nblk) {
+      const MbRows rows{obs + start * D, actions + start * aw, old_logp + start, adv + start, ret + start, nullptr, b, T,
+                        n_envs};
+      int oz;   // (opaque zero: see ppo_epoch_persistent_kernel)
+      asm volatile("s_mov_b32 %0, 0" : "=s"(oz));
+      const int rb = bid >> 1;
+      float* slab = reinterpret_cast<float*>(slabs_s + (long long)rb * SW);   // (a word array: offsets only)
+      const MbLl mll{par64 + (long long)(seq_par & 1u) * o.total, seq_par, seq_out, &s_fail, err};
+      mfma_minibatch<H, true, true, NLL>(d, P + oz, Pt + oz, snap ? sq + 8 : nm_in, snap ? sq + 8 + MAXD : nv_in, sq[0], sq[1],
+                                         rows, rb + oz, normalize_adv, clip, ent_coef, vf_coef, slab, slab + o.total, lds,
+                                         dbg != nullptr ? dbg + 16 + (bid & 1) * 16 : nullptr, oz, bid & 1, mll);
+    }
+    if (s_fail) return;   // (behind the function's closing barrier; workgroups without rows never set it)
+    EP_TS(0);
+    // ---- B1: chunk `bid` of every slab, summed in slab order; workgroup 0 also collects the loss-statistic partials
+    int oz2;
+    asm volatile("s_mov_b32 %0, 0" : "=s"(oz2));
+    const int tid = threadIdx.x + oz2, lane = tid & 63;
+    const int i0 = bid * chunk + oz2, i1 = min(o.total, i0 + chunk);
+    bool fail = false;
+    auto timed_out = [&](unsigned& it) {
+      __builtin_amdgcn_s_sleep(1);
+      if (++it > (1u << 22) || ((it & 255u) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+        if (lane == 0) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return true;
+      }
+      return false;
+    };
+    float g[NPC];
+    float sqs = 0.f;
+#pragma unroll
+    for (int j = 0; j < NPC; ++j) {
+      const int i = i0 + tid + j * NT;
+      float acc = 0.f;
+      if (i0 + (tid & ~63) + j * NT < i1) {   // (wave-uniform: some lane of the wave has an element)
+        const u64* col = slabs_s + min(i, o.total - 1);
+        for (int sb = 0; sb < nblk && !fail; sb += 8) {
+          u64 t[8];
+          unsigned it = 0;
+          for (;;) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+              t[u] = __hip_atomic_load(col + (long long)min(sb + u, nblk - 1) * SW, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            bool ok = true;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) ok = ok && (unsigned)(t[u] >> 32) == seq_out;
+            if (__all(ok)) break;
+            if (timed_out(it)) { fail = true; break; }
+          }
+#pragma unroll
+          for (int u = 0; u < 8; ++u)
+            if (sb + u < nblk) acc += __uint_as_float((unsigned)t[u]);
+        }
+        if (i < i1) sqs += acc * acc;
+      }
+      g[j] = acc;
+    }
+    if (bid == 0 && stats != nullptr && (tid & ~63) < nblk * 8) {   // (wave-uniform) slab q's statistics slot: word P + slot
+      const int q = min(tid >> 3, nblk - 1), slot = tid & 7;
+      const bool mine = tid < nblk * 8 && slot < 5;
+      const u64* wp = slabs_s + (long long)q * SW + o.total + (mine ? slot : 0);
+      u64 t;
+      unsigned it = 0;
+      for (;;) {
+        t = __hip_atomic_load(wp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (__all(!mine || (unsigned)(t >> 32) == seq_out)) break;
+        if (timed_out(it)) { fail = true; break; }
+      }
+      if (tid < nblk * 8) s_stat[tid] = __uint_as_float((unsigned)t);
+    }
+    EP_TS(1);
+    {
+      const float part = block_sum<NT>(sqs, lds);
+      if (tid == 0) ll_store_agent(sq64 + (seq_out & 1u) * 64 + bid, part, seq_out);
+    }
+    EP_TS(2);
+    // ---- B2: the G partial sums of squares -> norm, clip coefficient; Adam on the own chunk; loss statistics
+    if (tid < 64) {
+      const u64* wp = sq64 + (seq_out & 1u) * 64 + min(tid, nwg - 1);
+      u64 t;
+      unsigned it = 0;
+      for (;;) {
+        t = __hip_atomic_load(wp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (__all((unsigned)(t >> 32) == seq_out)) break;
+        if (timed_out(it)) { fail = true; break; }
+      }
+      s_part[tid] = tid < nwg ? __uint_as_float((unsigned)t) : 0.f;
+    }
+    if (__any(fail) && lane == 0) s_fail = 1;
+    __syncthreads();
+    if (s_fail) return;
+    EP_TS(3);
+    float total_sq = 0.f;
+    for (int q = 0; q < nwg; ++q) total_sq += s_part[q];
+    const float total_norm = sqrtf(total_sq);
+    const float coef = fminf(max_norm / (total_norm + 1e-6f), 1.0f);   // torch.nn.utils.clip_grad_norm_
+    {
+      const float step_size = st.step_size[k], bc2_sqrt = st.bc2_sqrt[k];
+      u64* dst = par64 + (long long)(seq_out & 1u) * o.total;
+#pragma unroll
+      for (int j = 0; j < NPC; ++j) {
+        const int i = i0 + tid + j * NT;
+        if (i < i1) {
+          const float gi = g[j] * coef;
+          const float mi = m_[j] + (gi - m_[j]) * (1.f - beta1);
+          const float vi = v_[j] * beta2 + (1.f - beta2) * gi * gi;
+          const float denom = sqrtf(vi) / bc2_sqrt + eps;
+          const float pn = p_[j] - step_size * (mi / denom);
+          ll_store_agent(dst + i, pn, seq_out);
+          p_[j] = pn;
+          m_[j] = mi;
+          v_[j] = vi;
+        }
+      }
+    }
+    if (bid == 0 && stats != nullptr) {
+      __shared__ float s_st[5];
+      if (tid >= 64 && tid < 69) {   // one lane of the second wave per statistic, partials in row-block order
+        const int kk = tid - 64;
+        float sv = 0.f;
+        for (int q = 0; q < nblk; ++q) sv += s_stat[q * 8 + kk];
+        sv *= 1.f / (float)b;
+        stats[(long long)mb * 8 + kk] = sv;
+        s_st[kk] = sv;
+      }
+      __syncthreads();
+      if (tid == 0) {
+        stats[(long long)mb * 8 + 5] = s_st[0] + ent_coef * s_st[2] + vf_coef * s_st[1];  // loss
+        stats[(long long)mb * 8 + 6] = total_norm;
+        stats[(long long)mb * 8 + 7] = coef;
+      }
+    }
+    EP_TS(4);
+  }
+  // the launch's last parameters and moments back to memory (torch layout + the transposed shadow copy)
+#pragma unroll
+  for (int j = 0; j < NPC; ++j) {
+    const int i = bid * chunk + (int)threadIdx.x + j * NT;
+    if (i < min(o.total, (bid + 1) * chunk)) {
+      m[i] = m_[j];
+      v[i] = v_[j];
+      P[i] = p_[j];
+      int dst = i;
+      auto tr = [&](int b0, int rows_, int cols) {
+        if (i >= b0 && i < b0 + rows_ * cols) {
+          const int r = (i - b0) / cols, cc = (i - b0) % cols;
+          dst = b0 + cc * rows_ + r;
+        }
+      };
+      tr(o.pW1, H, D); tr(o.pW2, H, H); tr(o.vW1, H, D); tr(o.vW2, H, H);
+      Pt[dst] = p_[j];
+    }
+  }
+#undef EP_TS
+}
+
 // TIMING = false (production): the phase-clock accumulators (24 VGPRs of `tacc` alone) and every stamp are
 // compiled out -- the measurement build is a separate instantiation picked only while ia_ppo_debug_timing is on.
 template <int NPT, bool TIMING, int KS1, bool LOCAL, bool SHARD = false, bool SMALL = false>
@@ -4218,6 +4562,7 @@ int set_lds(K kern, size_t bytes) {
 bool g_ppo_valu = false;  // tuning/debug: force the VALU kernels for H = 32 as well
 bool g_epoch_split = false;  // tuning/debug: two launches per minibatch for 64-wide towers too
 bool g_epoch_whole = false;  // tuning/debug: the one-launch epoch with whole row-block workgroups (8 waves, both towers)
+bool g_epoch_barriers = false;   // tuning/debug: the one-tower epoch kernel with grid barriers instead of the word exchange
 long long* g_epoch_dbg = nullptr;  // measurement: phase ticks of workgroup 0 of ppo_epoch_persistent_kernel
 }  // namespace
 
@@ -4413,14 +4758,22 @@ int ia_timeout_bootstrap(float* rewards, const float* terminal_values, const uin
   return IA_OK;
 }
 
-int64_t ia_ppo_ws_floats(const ia_policy_desc* d, int batch, int64_t gather_rows) {
-  if (!pol_ok(d) || batch <= 0 || gather_rows < batch) return IA_ERR_ARG;
+// (everything but the word areas of ppo_epoch_ll_kernel, which follow at the next 8-byte boundary)
+static int64_t ppo_ws_plain_floats(const ia_policy_desc* d, int batch, int64_t gather_rows) {
   const int nblk = cdiv(batch, ROWS);
   const int P = pol_offsets(d->obs_dim, d->act_dim, d->hidden, d->discrete).total;
   const int aw = d->discrete ? 1 : d->act_dim;
   const int64_t n_mb = (gather_rows + batch - 1) / batch;
-  return 8 + (int64_t)nblk * 8 + (int64_t)nblk * P + P + gather_rows * (d->obs_dim + aw + 3) +
-         n_mb * (EPS_PART + EPS_SEQ);   // + ia_ppo_epoch's per-minibatch statistics (raw moments, published form)
+  const int64_t n = 8 + (int64_t)nblk * 8 + (int64_t)nblk * P + P + gather_rows * (d->obs_dim + aw + 3) +
+                    n_mb * (EPS_PART + EPS_SEQ);   // + ia_ppo_epoch's per-minibatch statistics (raw moments, published form)
+  return (n + 1) & ~(int64_t)1;
+}
+
+int64_t ia_ppo_ws_floats(const ia_policy_desc* d, int batch, int64_t gather_rows) {
+  if (!pol_ok(d) || batch <= 0 || gather_rows < batch) return IA_ERR_ARG;
+  const int P = pol_offsets(d->obs_dim, d->act_dim, d->hidden, d->discrete).total;
+  const int64_t ll = d->hidden == 64 ? 2 * epoch_ll_words(cdiv(batch, ROWS), P) : 0;   // (64-wide towers: the word exchange)
+  return ppo_ws_plain_floats(d, batch, gather_rows) + ll;
 }
 
 }  // extern "C" (helpers below are C++)
@@ -4460,12 +4813,13 @@ struct PpoArgs {
   const float* advstat = nullptr;   // {advantage mean, std} of this minibatch (null: ws[0..1], left by the previous launch)
 };
 
-int launch_gather(const PpoArgs& a, const int64_t* perm, long long rows, const Gathered& g) {
+int launch_gather(const PpoArgs& a, const int64_t* perm, long long rows, const Gathered& g,
+                  unsigned long long* zero_words = nullptr, long long n_zero = 0, unsigned* zero_ctl = nullptr) {
   const int aw = a.d->discrete ? 1 : a.d->act_dim;
   const long long elems = rows * (a.d->obs_dim + aw + 3);
   hipLaunchKernelGGL(ppo_epoch_gather_kernel, dim3(cdiv(elems, 256)), dim3(256), 0, a.st, a.obs, a.actions, a.old_logp,
                      a.advantages, a.returns, perm, rows, a.T, a.n_envs, a.d->obs_dim, aw, g.obs, g.act, g.logp, g.adv,
-                     g.ret);
+                     g.ret, zero_words, n_zero, zero_ctl);
   IA_CHECK_LAUNCH();
   return IA_OK;
 }
@@ -4633,6 +4987,7 @@ int ia_ppo_force_valu(int on) {
 int ia_ppo_epoch_split(int on) {
   g_epoch_split = on == 1;
   g_epoch_whole = on == 2;
+  g_epoch_barriers = on == 3;
   return IA_OK;
 }
 
@@ -4678,7 +5033,32 @@ int ia_ppo_epoch(const ia_policy_desc* d, float* params, float* params_t, float*
   int mb = 0;
   auto size_at = [&](long long start) { return (int)((total - start) < batch_size ? (total - start) : batch_size); };
   const Gathered g = gathered_region(d, ws, size_at(0), total);
-  int rc = launch_gather(a, perm, total, g);
+  // which epoch kernel (64-wide towers; see below): the word-exchange form has its areas and control words cleared by
+  // the gather launch
+  static int dev_cus = 0;
+  if (dev_cus == 0) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&dev_cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+      return IA_ERR_ARG;
+  }
+  constexpr size_t EPOCH_SPLIT_LDS = 160 * 1024 - 1024;   // dynamic LDS the one-tower kernel may ask for (it has static LDS too)
+  constexpr size_t EPOCH_LL_LDS = 160 * 1024 - 2048;
+  const bool one_launch = d->hidden == 64 && !g_ppo_valu && !g_epoch_split && g_tstamp == nullptr;
+  const int nrb = cdiv(size_at(0), ROWS);
+  const PolOff po = pol_offsets(d->obs_dim, d->act_dim, d->hidden, d->discrete);
+  const int P = po.total;
+  // one tower per workgroup (two workgroups of four waves per row block, the tower's parameters resident in LDS) when
+  // both fit: 2 nrb workgroups co-resident, chunks of <= 4 x 256 parameters, the larger tower's images beside its tiles
+  const int tlen = 64 * d->obs_dim + 64 + 64 * 64 + 64, lenB = std::max(po.cW - po.aW, P - po.cW) + 3;
+  const size_t sbytes = (size_t)(((GLds<64, 1>::total + 3) & ~3) + 2 * tlen + 4 * d->obs_dim + 128 + lenB + MAXA) * sizeof(float);
+  const bool split = one_launch && !g_epoch_whole && 2 * nrb <= dev_cus && 2 * nrb <= 64 && cdiv(P, 2 * nrb) <= 4 * 256 &&
+                     sbytes <= EPOCH_SPLIT_LDS;
+  // the word-exchange form of the one-tower kernel (no grid barriers); its word areas sit behind everything else in ws
+  const bool llx = split && !g_epoch_barriers && sbytes <= EPOCH_LL_LDS && nrb <= 32;
+  unsigned long long* ll_base = llx ? reinterpret_cast<unsigned long long*>(ws + ppo_ws_plain_floats(d, size_at(0), total)) : nullptr;
+  int rc = launch_gather(a, perm, total, g, ll_base, llx ? epoch_ll_words(nrb, P) : 0,
+                         llx ? reinterpret_cast<unsigned*>(ws) + 4 : nullptr);   // (words 4, 5, 6: counter, error word, ticket)
   if (rc) return rc;
   // statistics of every minibatch of the epoch, one launch ahead of the chain (ppo_epoch_stats_kernel)
   const int aw = d->discrete ? 1 : d->act_dim;
@@ -4690,36 +5070,48 @@ int ia_ppo_epoch(const ia_policy_desc* d, float* params, float* params_t, float*
     static bool attr = false;
     const size_t bytes = PREP_LDS_FLOATS * sizeof(float);
     if (!attr) { rc = set_lds(ppo_epoch_stats_kernel, bytes); if (rc) return rc; attr = true; }
-    if (hipMemsetAsync(ws + 6, 0, sizeof(unsigned), a.st) != hipSuccess) return IA_ERR_ARG;   // its ticket (ws is not pre-zeroed)
+    if (!llx && hipMemsetAsync(ws + 6, 0, sizeof(unsigned), a.st) != hipSuccess) return IA_ERR_ARG;   // its ticket (ws is not pre-zeroed)
     hipLaunchKernelGGL(ppo_epoch_stats_kernel, dim3(n_mb), dim3(PREP_THREADS), bytes, a.st, *d, g.obs, g.adv, total,
                        batch_size, update_norm, norm_mean, norm_var, norm_count, seq, part,
                        reinterpret_cast<unsigned*>(ws) + 6);
     IA_CHECK_LAUNCH();
   }
   const bool snap = d->has_norm && update_norm;
-  if (d->hidden == 64 && !g_ppo_valu && !g_epoch_split && g_tstamp == nullptr) {
+  if (one_launch) {
     // one launch per (<= 64 minibatches of the) epoch when every gradient workgroup can be resident at once
-    static int dev_cus = 0;
-    if (dev_cus == 0) {
-      int dev = 0;
-      if (hipGetDevice(&dev) != hipSuccess ||
-          hipDeviceGetAttribute(&dev_cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
-        return IA_ERR_ARG;
-    }
-    constexpr size_t EPOCH_SPLIT_LDS = 160 * 1024 - 1024;   // dynamic LDS the one-tower kernel may ask for (it has static LDS too)
-    const int nrb = cdiv(size_at(0), ROWS);
-    const PolOff po = pol_offsets(d->obs_dim, d->act_dim, 64, d->discrete);
-    const int P = po.total;
-    // one tower per workgroup (two workgroups of four waves per row block, the tower's parameters resident in LDS) when
-    // both fit: 2 nrb workgroups co-resident, chunks of <= 4 x 256 parameters, the larger tower's images beside its tiles
-    const int tlen = 64 * d->obs_dim + 64 + 64 * 64 + 64, lenB = std::max(po.cW - po.aW, P - po.cW) + 3;
-    const size_t sbytes = (size_t)(((GLds<64, 1>::total + 3) & ~3) + 2 * tlen + lenB + MAXA) * sizeof(float);
-    const bool split = !g_epoch_whole && 2 * nrb <= dev_cus && 2 * nrb <= 64 && cdiv(P, 2 * nrb) <= 4 * 256 &&
-                       sbytes <= EPOCH_SPLIT_LDS;
     const int nwg = split ? 2 * nrb : nrb;
     if (nwg <= dev_cus && nwg <= 64 && cdiv(P, nwg) <= 4 * (split ? 256 : 512)) {
       static bool attr = false, attr_s = false;
       const size_t mbytes = split ? sbytes : GLds<64>::total * sizeof(float);
+      if (llx) {
+        const int nll = tlen <= 20 * 256 ? 20 : (tlen <= 24 * 256 ? 24 : 33);
+        static bool attr_l[3] = {false, false, false};
+        auto k20 = ppo_epoch_ll_kernel<64, 20>;
+        auto k24 = ppo_epoch_ll_kernel<64, 24>;
+        auto k33 = ppo_epoch_ll_kernel<64, 33>;
+        auto kern = nll == 20 ? k20 : (nll == 24 ? k24 : k33);
+        const int ai = nll == 20 ? 0 : (nll == 24 ? 1 : 2);
+        if (!attr_l[ai]) { rc = set_lds(kern, EPOCH_LL_LDS); if (rc) return rc; attr_l[ai] = true; }
+        EpochLl el{};
+        el.base = ll_base;   // (cleared, like the error word, by the gather launch above)
+        for (int first = 0; first < n_mb; first += EpochSteps::MAX) {
+          EpochSteps es{};
+          es.first = first;
+          es.n = std::min(EpochSteps::MAX, n_mb - first);
+          el.seq0 = (unsigned)(adam_steps_done + first + 1);
+          for (int k = 0; k < es.n; ++k) {
+            ++step;
+            es.step_size[k] = (float)(lr / (1.0 - pow(beta1, (double)step)));
+            es.bc2_sqrt[k] = (float)sqrt(1.0 - pow(beta2, (double)step));
+          }
+          hipLaunchKernelGGL(kern, dim3(nwg), dim3(256), sbytes, a.st, *d, params, params_t, exp_avg, exp_avg_sq, norm_mean,
+                             norm_var, g.obs, g.act, g.logp, g.adv, g.ret, total, batch_size, T, n_envs, normalize_adv,
+                             clip_range, ent_coef, vf_coef, max_grad_norm, (float)beta1, (float)beta2, adam_eps, ws, el, seq,
+                             snap ? 1 : 0, stats, es, g_epoch_dbg);
+          IA_CHECK_LAUNCH();
+        }
+        return IA_OK;
+      }
       if (!split && !attr) { rc = set_lds(ppo_epoch_persistent_kernel<64>, mbytes); if (rc) return rc; attr = true; }
       if (split && !attr_s) {
         rc = set_lds(ppo_epoch_persistent_kernel<64, true>, EPOCH_SPLIT_LDS);

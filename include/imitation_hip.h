@@ -437,9 +437,11 @@ int ia_ppo_debug_timing(void* device_buffer_16xi64);
  * hidden = 32 instead of the MFMA 16x16x4 ones (hidden = 64 always uses the VALU kernels). */
 int ia_ppo_force_valu(int on);
 /* Tuning / measurement: 1 = `ia_ppo_epoch` keeps two launches per minibatch for 64-wide towers (default 0: one launch
- * per epoch, the minibatch steps as phases of a co-resident grid separated by grid barriers; a row block's two towers
+ * per epoch, the minibatch steps as phases of a co-resident grid; a row block's two towers
  * are two four-wave workgroups with the tower's parameters resident in LDS when that fits); 2 = one launch per epoch
- * with whole row-block workgroups (eight waves, both towers, weight fragments from memory: the form before). */
+ * with whole row-block workgroups (eight waves, both towers, weight fragments from memory: the form before);
+ * 3 = the one-tower kernel with grid barriers between the phases (default 0 hands the slabs, the partial sums of
+ * squares and the new parameters over as 8-byte value / sequence words instead: no barrier; bit-identical results). */
 int ia_ppo_epoch_split(int on);
 /* Measurement only: device buffer of 64 int64 (NULL: off); workgroup 0 of the one-launch-per-epoch kernel accumulates
  * 100 MHz ticks per phase in [0..5] = {gradient, barrier, slab sum, barrier, norm + Adam, barrier}; [16..27] / [32..43]:

@@ -476,7 +476,7 @@ def test_timeout_bootstrap():
                                                         # and a Discrete head with a short last minibatch
                                                         (27, 8, 32, False, True, 4, 12, 16),
                                                         (4, 3, 32, True, True, 4, 10, 16)])
-@pytest.mark.parametrize("path", ["epoch", "epoch_whole", "update", "update_spread", "update_shard1"])
+@pytest.mark.parametrize("path", ["epoch", "epoch_whole", "epoch_barriers", "update", "update_spread", "update_shard1"])
 def test_ppo_epochs_match_oracle(D, A, H, discrete, norm, T, n, bs, path):
     """Two PPO epochs on a synthetic rollout: parameters, Adam state, RunningNorm state and the
     logged loss statistics against SB3-restated `PPO.train` on the same permutations -- through
@@ -485,9 +485,10 @@ def test_ppo_epochs_match_oracle(D, A, H, discrete, norm, T, n, bs, path):
     (`ia_ppo_update_sharded`) with a world of one -- the whole exchange machinery (8-byte value / sequence words through
     the peer block, loss statistics through the record tails, two launches on a growing sequence base) on one process;
     two ranks run in tests/test_distributed.py."""
-    if path == "epoch_whole" and H != 64:
-        pytest.skip("64-wide towers: the one-launch epoch with whole row-block workgroups (default: one tower each)")
-    if path not in ("epoch", "epoch_whole") and H != 32:
+    if path in ("epoch_whole", "epoch_barriers") and H != 64:
+        pytest.skip("64-wide towers: the one-launch epoch with whole row-block workgroups / with grid barriers (default: one "
+                    "tower per workgroup, hand-offs as 8-byte value / sequence words)")
+    if path not in ("epoch", "epoch_whole", "epoch_barriers") and H != 32:
         pytest.skip("the persistent update covers hidden = 32")
     from imitation_amd import spaces
     from oracle import imitation_restated as o
@@ -529,8 +530,8 @@ def test_ppo_epochs_match_oracle(D, A, H, discrete, norm, T, n, bs, path):
     ws = th.empty(int(L.load().ia_ppo_ws_floats(C.byref(dp.d), bs, T * n)), device=DEV)
     n_mb = -(-T * n // bs)
     stats = th.zeros(2, n_mb, 8, device=DEV)
-    if path in ("epoch", "epoch_whole"):
-        L.load().ia_ppo_epoch_split(2 if path == "epoch_whole" else 0)
+    if path in ("epoch", "epoch_whole", "epoch_barriers"):
+        L.load().ia_ppo_epoch_split({"epoch": 0, "epoch_whole": 2, "epoch_barriers": 3}[path])
         try:
             for e in range(2):
                 L.call("ia_ppo_epoch", C.byref(dp.d), L.ptr(dp.P), L.ptr(dp.Pt), L.ptr(dp.nm), L.ptr(dp.nv), L.ptr(dp.nc),
@@ -598,6 +599,46 @@ def test_ppo_epochs_match_oracle(D, A, H, discrete, norm, T, n, bs, path):
     Pt2 = th.empty_like(dp.P)
     L.call("ia_policy_transpose", C.byref(dp.d), L.ptr(dp.P), L.ptr(Pt2), L.stream())
     assert th.equal(Pt2, dp.Pt)
+
+
+@pytest.mark.parametrize("D,A,discrete,T,n,bs", [(17, 6, False, 16, 256, 1024), (4, 2, True, 9, 100, 384),
+                                                  (27, 8, False, 8, 512, 2048), (40, 3, False, 10, 100, 448)])
+def test_word_exchange_epoch_is_bit_identical_to_the_barrier_form(D, A, discrete, T, n, bs):
+    """64-wide towers: `ppo_epoch_ll_kernel` (slabs, partial sums of squares and new parameters handed over as 8-byte
+    value / sequence words, no grid barrier) against `ppo_epoch_persistent_kernel<64, true>` (`ia_ppo_epoch_split(3)`):
+    the same sums in the same order -> parameters, transposed copy, Adam moments and logged statistics bit for bit over
+    three epochs (the sequence numbers continue from call to call; observation widths of all three poll-size classes)."""
+    pol_ref = _oracle_policy(D, A, 64, discrete, True, seed=5)
+    rng = np.random.default_rng(1)
+    aw = 1 if discrete else A
+    obs = rng.standard_normal((T, n, D)).astype(np.float32)
+    acts = (rng.integers(0, A, (T, n, 1)) if discrete else rng.standard_normal((T, n, A))).astype(np.float32)
+    lp, adv = rng.standard_normal((T, n)).astype(np.float32) * 0.1 - 1.0, rng.standard_normal((T, n)).astype(np.float32)
+    ret = rng.standard_normal((T, n)).astype(np.float32)
+    d_obs, d_act, d_lp, d_adv, d_ret = dev(obs), dev(acts), dev(lp), dev(adv), dev(ret)
+    n_mb = -(-T * n // bs)
+    perms = [rng.permutation(T * n) for _ in range(3)]
+    outs = []
+    try:
+        for mode in (3, 0):
+            dp = DevPolicy(pol_ref, D, A, 64, discrete, True)
+            ws = th.empty(int(L.load().ia_ppo_ws_floats(C.byref(dp.d), bs, T * n)), device=DEV)
+            ws.uniform_(-1e30, 1e30)   # (the workspace arrives uninitialised)
+            stats = th.zeros(3, n_mb, 8, device=DEV)
+            L.load().ia_ppo_epoch_split(mode)
+            for e in range(3):
+                L.call("ia_ppo_epoch", C.byref(dp.d), L.ptr(dp.P), L.ptr(dp.Pt), L.ptr(dp.nm), L.ptr(dp.nv), L.ptr(dp.nc),
+                       1, L.ptr(d_obs), L.ptr(d_act), L.ptr(d_lp), L.ptr(d_adv), L.ptr(d_ret),
+                       dptr(perms[e], th.int64), T, n, bs, 1, 0.2, 0.05, 0.5, 0.5, L.ptr(dp.m), L.ptr(dp.v), 3e-4, 0.9,
+                       0.999, 1e-5, e * n_mb, L.ptr(ws), L.ptr(stats[e]), L.stream())
+            th.cuda.synchronize()
+            assert int(ws[5:6].view(th.int32).item()) == 0, "a wait timed out"
+            outs.append((dp.P.clone(), dp.Pt.clone(), dp.m.clone(), dp.v.clone(), stats.clone(), dp.nm.clone(), dp.nv.clone()))
+    finally:
+        L.load().ia_ppo_epoch_split(0)
+    for name, x, y in zip(("parameters", "transposed copy", "exp_avg", "exp_avg_sq", "statistics", "norm mean", "norm var"), *outs):
+        assert th.equal(x, y), f"{name}: {int((x != y).sum())} of {x.numel()} differ, max {float((x - y).abs().max()):.3e}"
+    assert float(outs[0][0].abs().sum()) > 0 and bool(th.isfinite(outs[1][0]).all())
 
 
 @pytest.mark.parametrize("shape,B,A", [((4, 36, 36), 8, 6), ((3, 44, 52), 5, 4), ((1, 36, 40), 33, 18),

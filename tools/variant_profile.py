@@ -8,5 +8,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench  # noqa: E402
 
 th.set_num_threads(1)
+if os.environ.get("IA_EPOCH_SPLIT"):   # A/B of the 64-wide epoch kernels (include/imitation_hip.h: ia_ppo_epoch_split)
+    from imitation_amd import _lib as L
+    L.load().ia_ppo_epoch_split(int(os.environ["IA_EPOCH_SPLIT"]))
 name = sys.argv[1] if len(sys.argv) > 1 else "3_airl_ant_1024x16_mb1024"
 print(name, bench.run_variant(name, rounds=int(sys.argv[2]) if len(sys.argv) > 2 else 6))
