@@ -123,6 +123,7 @@ _SIGS = {
     "ia_bce_logits": ([_P, _I, _I, _F, _P, _P, _P, _P], C.c_int),
     "ia_reduce_partials_adam": ([_P, _I, _L, _F, _P, _P, _P, _P, _F, _F, _F, _F, _F, _F, _P], C.c_int),
     "ia_disc_step_basic": ([C.POINTER(DiscStepArgs), _P], C.c_int),
+    "ia_disc_round_basic": ([C.POINTER(DiscStepArgs), _I, _P], C.c_int),
     "ia_disc_fused_ws_floats": ([C.POINTER(MlpDesc), _I, _I], C.c_int64),
     "ia_disc_fused_gp_ws_floats": ([C.POINTER(MlpDesc), _I, _I], C.c_int64),
     "ia_disc_fused_debug_timing": ([_P], C.c_int),

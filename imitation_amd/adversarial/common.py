@@ -214,6 +214,7 @@ class AdversarialTrainer(abc.ABC):
         self._overlap_beside_ppo = self._overlap and not self._needs_logp
         self._disc_stream = L.side_stream(self._device, "disc") if self._overlap else None
         self._in_overlap = False
+        self._gen_stored_early = False
         self._overlap_k = 0
         self._quirk_ready = None
         self._quirk_seq = None
@@ -233,6 +234,15 @@ class AdversarialTrainer(abc.ABC):
         # into the rollout's host time, beside otherwise. Pure scheduling: values are identical either way.
         # AIRL's updates read the updated policy and always wait.
         self.disc_behind_ppo: Optional[bool] = None
+        # pre-assembled rounds on the fused update: all n updates through one C call (False: one call per update)
+        self.disc_round_one_call = True
+        # pipelined rounds: write round r-1's log row behind round r's enqueue instead of ahead of it -- None: only when
+        # round r-1's updates are still running at that point (waiting would delay round r's); True / False: always / never
+        # (tests). The rows are the same either way.
+        self.disc_log_late: Optional[bool] = None
+        # pipelined rounds: enqueue round r's updates right behind the PPO launch, ahead of the iteration's host-side waits
+        # and logging (False: behind them, after `learn` has returned -- the schedule before; tests compare)
+        self.disc_enqueue_early = True
         self._disc_ms_behind = None   # device time of a round's updates, measured while they ran alone
         self._disc_mode_behind = True
         self._quirk_pending = []
@@ -249,7 +259,9 @@ class AdversarialTrainer(abc.ABC):
         # one statistics row per update of a round: `train()` enqueues all n_disc updates before it
         # reads any of them back (the host prepares update k+1 while the GPU runs update k)
         self._stats_ring = th.zeros(nq, 8, device=self._device)
-        self._stats_ring_host = th.zeros(nq, 8).pin_memory()
+        # (two host copies, used in turn: a round's rows may be read back only after the NEXT round has been enqueued)
+        self._stats_ring_hosts = [th.zeros(nq, 8).pin_memory(), th.zeros(nq, 8).pin_memory()]
+        self._stats_ring_turn = 0
         self._use_ring = False
         self._bce_ws = th.zeros(int(L.load().ia_bce_ws_floats(2 * self.demo_minibatch_size)), device=self._device)
         self._dlogits = th.zeros(2 * self.demo_minibatch_size, device=self._device)
@@ -431,7 +443,7 @@ class AdversarialTrainer(abc.ABC):
             self.logger.dump(disc_step)
         return train_stats
 
-    def _disc_round(self, prepass: bool = False, after=None):
+    def _disc_round(self, prepass: bool = False, after=None, global_step: Optional[int] = None):
         """Enqueues the n_disc updates of one round without reading their statistics back; returns
         what `_finish_disc_round` needs to log them afterwards, in order. A `train_disc` replaced by
         the user (subclass or instance attribute) is honoured: then the updates run one by one."""
@@ -469,6 +481,12 @@ class AdversarialTrainer(abc.ABC):
                         th.cuda.current_stream().wait_event(after)
                     self._disc_t0 = th.cuda.Event(enable_timing=True)
                     self._disc_t0.record()
+                if self._round_one_call_ok(round_ws, did):
+                    # every update of the round in ONE C call (`ia_disc_round_basic`): the launches of the loop below, its
+                    # per-update host work (~110 us of Python each -- the round was bound by it) paid once
+                    self._disc_round_one_call(round_ws, n)
+                    steps.extend(range(self._disc_step - n + 1, self._disc_step + 1))
+                    n = 0
                 for k in range(n):
                     with networks.training(self.reward_train):
                         self._disc_update(None, None, self._stats_ring[k], drawn=drawn[k], quirk_done=did,
@@ -486,18 +504,55 @@ class AdversarialTrainer(abc.ABC):
                     steps.append(self._disc_step)
         finally:
             self._use_ring = False
-        self._stats_ring_host.copy_(self._stats_ring, non_blocking=True)
+        self._stats_ring_turn ^= 1
+        host_rows = self._stats_ring_hosts[self._stats_ring_turn]
+        host_rows.copy_(self._stats_ring, non_blocking=True)
         done = th.cuda.Event()
         done.record()
         self._gp_block_done(done)
-        return done, steps, self._global_step
+        return done, steps, self._global_step if global_step is None else global_step, host_rows
+
+    def _round_one_call_ok(self, round_ws, quirk_done: bool) -> bool:
+        """The conditions under which `_disc_update` would take, for EVERY update of a pre-assembled round, the one-call
+        fused update with the optimiser step inside and no host work between the updates."""
+        if round_ws is None or not self.disc_round_one_call or self._dp is not None or self._module_net:
+            return False   # (`_assemble_round` has checked the net, the optimiser, minibatch == batch and the penalty's shape)
+        basic = self._reward_net
+        while isinstance(basic, reward_nets.PredictProcessedWrapper):
+            basic = basic.base
+        if basic.mlp.norm is not None and not basic.mlp.norm.is_chan:
+            return False
+        pol = self.policy
+        prn = pol.features_extractor.normalize if isinstance(pol, ActorCriticPolicy) else None
+        return prn is None or not pol.training or bool(quirk_done)   # (else: a policy pass / moment copy per update)
+
+    def _disc_round_one_call(self, round_ws, n: int) -> None:
+        basic = self._reward_net
+        while isinstance(basic, reward_nets.PredictProcessedWrapper):
+            basic = basic.base
+        mb = self.demo_batch_size
+        gp = None
+        if self.disc_grad_penalty_coef > 0.0:
+            # interpolation weights: torch's global CPU generator, one `th.rand(mb)` per update in update order (the first
+            # through the per-update ring, the rest as one block -- the draws of the per-update loop)
+            es = [self._gp_weights(mb)]
+            if n > 1:
+                self._gp_predraw_for_round(n - 1)
+                es += [self._gp_weights(mb) for _ in range(n - 1)]
+            gp = (es, self.disc_grad_penalty_coef, self.disc_grad_penalty_target)
+        with networks.training(self.reward_train):
+            ws = basic.disc_round_c(n, mb, 1.0, self._stats_ring, self._bce_ws, self._disc_opt, round_ws, gp=gp)
+        if gp is not None:
+            self.last_grad_penalty = ws["gp_out"][0]
+        self._disc_step += n
+        self._last_disc_logits = ws["out"].reshape(-1)
 
     def _finish_disc_round(self, pending) -> None:
         if pending is None:
             return
-        done, steps, global_step = pending
+        done, steps, global_step, host_rows = pending
         done.synchronize()
-        rows = self._stats_ring_host.numpy()
+        rows = host_rows.numpy()
         for k, step in enumerate(steps):
             self._log_disc_stats(rows[k], step, global_step)
 
@@ -810,6 +865,13 @@ class AdversarialTrainer(abc.ABC):
             self.gen_algo.learn(total_timesteps=total_timesteps, reset_num_timesteps=False,
                                 callback=self.gen_callback, **learn_kwargs)
             self._global_step += 1
+        if self._gen_stored_early:   # (pipelined rounds: done behind the PPO launch, see `_train_pipelined`)
+            self._gen_stored_early = False
+            return
+        self._store_gen_rollout()
+
+    def _store_gen_rollout(self) -> None:
+        """The tail of `train_gen` (`common.py:407-420`): the rollout's transitions go to the replay buffer."""
         rb = getattr(self.gen_algo, "rollout_buffer", None)
         device_rows = (isinstance(self.gen_algo, ppo.PPO) and rb is not None and rb.full
                        and self.venv_buffering.n_transitions == rb.buffer_size * rb.n_envs)
@@ -1004,45 +1066,98 @@ class AdversarialTrainer(abc.ABC):
             if previous:
                 main.wait_event(previous[-1][1])
 
-        def drain():  # host side: read the previous round's statistics back and write its log rows
+        late = []   # root-level records of the previous round's generator statistics, when its log row is written late
+
+        def drain(final: bool = False):  # host side: read the previous round's statistics back and write its log rows
             if not previous:
                 return
-            pend, done, stash, gstep, train_rec = previous.pop()
+            pend, done, stash, gstep, train_rec = previous[-1]
+            root = self.logger.default_logger
+            defer = (not done.query()) if self.disc_log_late is None else bool(self.disc_log_late)
+            if not final and not late and defer:
+                # The previous round's updates are still running (long rounds, e.g. with the gradient penalty): waiting
+                # here would hold back THIS round's updates by as long -- they are enqueued right after this hook. Only
+                # what this iteration's own log row needs is done now: the generator's train statistics of the previous
+                # round go to the raw/gen logger; their root-level means are kept and entered, in the same order,
+                # when the round's row is written behind this round's enqueue (`drain_late`). Same rows either way.
+                root.record_mean = lambda key, value, exclude=None: late.append((key, value, exclude))
+                try:
+                    with self.logger.replaying(stash), self.logger.accumulate_means("gen"):
+                        algo._pending_train, keep = train_rec, algo._pending_train
+                        algo.finalize_train()
+                        algo._pending_train = keep
+                finally:
+                    del root.record_mean
+                late.append(None)   # (marks "taken", also when nothing was recorded)
+                return
+            previous.pop()
             done.synchronize()
             with self.logger.replaying(stash):
                 self._finish_disc_round(pend)
-                with self.logger.accumulate_means("gen"):
-                    algo._pending_train, keep = train_rec, algo._pending_train
-                    algo.finalize_train()
-                    algo._pending_train = keep
+                if late:
+                    for rec in late[:-1]:
+                        root.record_mean(*rec)
+                    late.clear()
+                else:
+                    with self.logger.accumulate_means("gen"):
+                        algo._pending_train, keep = train_rec, algo._pending_train
+                        algo.finalize_train()
+                        algo._pending_train = keep
                 self.logger.dump(gstep)
+
+        early = []   # (pend, done) of the round enqueued from inside `learn`
+
+        def enqueue_disc_round(global_step: int):
+            ppo_done = th.cuda.Event()
+            ppo_done.record()
+            with th.cuda.stream(self._disc_stream):
+                # ring store and moment pre-pass run beside the PPO update; the 16 updates wait for it,
+                # so they execute while the host steps the environments of the next round instead of
+                # competing with the latency-bound PPO chain for the memory system
+                behind = self._choose_disc_behind_ppo()
+                pend = self._disc_round(prepass=True, after=ppo_done if behind else None, global_step=global_step)
+                done = th.cuda.Event(enable_timing=True)
+                done.record()
+                self._disc_timing = (self._disc_t0, done, behind)
+            return pend, done
+
+        calls = [0]
+
+        def after_train_enqueued(last: bool):
+            # Right behind the PPO launch, AHEAD of the iteration's host-side waits (the reward bookkeeping waits for the
+            # relabelled rewards, i.e. for the previous round's updates; then the previous round's rows are logged): the
+            # rollout goes to the replay buffer and this round's updates are enqueued -- what `train_gen`'s tail and the
+            # loop below do otherwise, in the same order among themselves (same index draws, same launches). Only for the
+            # single-iteration `learn` of a round.
+            calls[0] += 1
+            if not last or calls[0] != 1:
+                return
+            self._store_gen_rollout()
+            self._gen_stored_early = True
+            early.append(enqueue_disc_round(self._global_step + 1))
 
         self._in_overlap, algo.defer_train_stats = True, True
         algo.before_relabel, algo.after_enqueue, algo.enqueue_first = gate, drain, True
+        algo.after_train_enqueued = after_train_enqueued if self.disc_enqueue_early else None
         try:
             for _ in range(n_rounds):
                 self._overlap_k = 0
+                calls[0] = 0
                 self.train_gen(self.gen_train_timesteps)          # drains the previous round before relabelling
-                ppo_done = th.cuda.Event()
-                ppo_done.record()
-                with th.cuda.stream(self._disc_stream):
-                    # ring store and moment pre-pass run beside the PPO update; the 16 updates wait for it,
-                    # so they execute while the host steps the environments of the next round instead of
-                    # competing with the latency-bound PPO chain for the memory system
-                    behind = self._choose_disc_behind_ppo()
-                    pend = self._disc_round(prepass=True, after=ppo_done if behind else None)
-                    done = th.cuda.Event(enable_timing=True)
-                    done.record()
-                    self._disc_timing = (self._disc_t0, done, behind)
+                pend, done = early.pop() if early else enqueue_disc_round(self._global_step)
                 main.wait_event(self._quirk_ready)
                 self._replay_policy_norm_updates()                 # behind the PPO update, ahead of the next rollout
+                if late:   # the previous round's row, held back above
+                    drain(final=True)
                 train_rec, algo._pending_train = algo._pending_train, None
                 previous.append((pend, done, self.logger.detach_pending(), self._global_step, train_rec))
-            drain()
+            drain(final=True)
             main.wait_stream(self._disc_stream)
         finally:
             self._in_overlap, algo.defer_train_stats = False, False
             algo.before_relabel, algo.after_enqueue, algo.enqueue_first = None, None, False
+            algo.after_train_enqueued = None
+            self._gen_stored_early = False
 
 
 def _slice_table(t: TransitionTable, start: int, n: int) -> TransitionTable:

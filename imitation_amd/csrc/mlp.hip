@@ -1057,6 +1057,20 @@ int ia_disc_step_basic(const ia_disc_step_args* a, void* stream) {
   return IA_OK;
 }
 
+// A round's updates in ONE host call: update k runs with a[k] (the caller has filled every struct: batch rows, statistics
+// snapshots, Adam scalars of step k, statistics row k). The launches are exactly those of n calls of ia_disc_step_basic
+// in order; what this entry removes is the per-update host work of the binding above it (the reference's
+// `for _ in range(n_disc_updates_per_round): train_disc()`, adversarial/common.py:454-458, costs ~110 us of Python per
+// update on the fused path -- more than the update's kernels take to enqueue).
+int ia_disc_round_basic(const ia_disc_step_args* a, int n, void* stream) {
+  if (!a || n <= 0) return IA_ERR_ARG;
+  for (int k = 0; k < n; ++k) {
+    const int rc = ia_disc_step_basic(a + k, stream);
+    if (rc) return rc;
+  }
+  return IA_OK;
+}
+
 int ia_gp_interpolate(const float* X, int ldx, int B, int D, const float* e, const float* mean, const float* var,
                       float eps, float* Xn, int ld, void* stream) {
   if (!X || !e || !Xn || B <= 0 || D <= 0 || ld < D) return IA_ERR_ARG;

@@ -371,6 +371,9 @@ class PPO(OnPolicyAlgorithm):
         # are made in the same order as always. Set by the pipelined adversarial trainer.
         self.enqueue_first = False
         self.after_enqueue = None
+        # ... and, ahead of both (right behind the update's launch): `after_train_enqueued(last_iteration)` -- the pipelined
+        # adversarial trainer enqueues the round's discriminator updates there, before any host-side wait of this iteration
+        self.after_train_enqueued = None
         self._post_enqueue_work = []
         self._act_stream = None
         self.rollout_post_ahead = True   # (tuning / A-B: False posts a mailbox step only at the top of its own iteration)
@@ -481,6 +484,8 @@ class PPO(OnPolicyAlgorithm):
             lr_later = None
             if self.enqueue_first:
                 lr_later = self.train(record_lr=False)
+                if self.after_train_enqueued is not None:
+                    self.after_train_enqueued(self.num_timesteps >= total_timesteps)
                 for work in self._post_enqueue_work:
                     work()
                 self._post_enqueue_work = []

@@ -377,11 +377,37 @@ class BasicRewardNet(RewardNet):
         `gp = (e [n_expert] device weights, coef, target)`: the opt-in gradient penalty inside the same update
         (`fused_gp_ws(n_expert)` must not be None); its mean lands in `ws["gp_out"]`."""
         import ctypes as C
-        (t0, i0, n0), (t1, i1, n1) = sources
-        R = n0 + n1
-        mlp = self.mlp
-        ws = self._step_workspace(R)
+        ws = self._step_workspace(sources[0][2] + sources[1][2])
         a = ws["args"]
+        self._fill_step_args(a, ws, sources, n_expert, loss_scale, stats, bce_ws, accumulate, adam, pnorm, pnorm_dim, pre, gp)
+        L.call("ia_disc_step_basic", C.byref(a), L.stream())
+        return self._step_used(ws, pre)
+
+    def disc_round_c(self, n: int, mb: int, loss_scale: float, stats_rows: th.Tensor, bce_ws: th.Tensor, adam, rw,
+                     gp=None):
+        """The n pre-assembled updates of one round (`rw` = `assemble_round`'s workspace) through ONE C call
+        (`ia_disc_round_basic`): the same launches in the same order as n `disc_step_c(..., pre=(rw, k))` calls with
+        the optimiser step fused -- the per-update Python (argument structs, ~110 us each, more than the update's
+        kernels take to enqueue) is paid once per round. `gp = ([n] list of device weight vectors, coef, target)`."""
+        import ctypes as C
+        ws = self._step_workspace(2 * mb)
+        arr = ws.get("round_args")
+        if arr is None or len(arr) < n:
+            arr = ws["round_args"] = (type(ws["args"]) * n)()
+        base = ws["args"]
+        src = [(None, None, mb), (None, None, mb)]
+        for k in range(n):
+            a = arr[k]
+            C.memmove(C.byref(a), C.byref(base), C.sizeof(base))   # (the fields no update changes: desc, work areas, ...)
+            self._fill_step_args(a, ws, src, mb, loss_scale, stats_rows[k], bce_ws, False, adam, None, 0, (rw, k),
+                                 None if gp is None else (gp[0][k], gp[1], gp[2]))
+        L.call("ia_disc_round_basic", arr, n, L.stream())
+        return self._step_used(ws, (rw, n - 1))
+
+    def _fill_step_args(self, a, ws, sources, n_expert, loss_scale, stats, bce_ws, accumulate, adam, pnorm, pnorm_dim,
+                        pre, gp) -> None:
+        (t0, i0, n0), (t1, i1, n1) = sources
+        mlp = self.mlp
         a.params, a.grads = L.ptr(mlp.flat), L.ptr(mlp.grad)
         nrm = mlp.norm
         a.norm_mean = L.ptr(nrm.running_mean) if nrm is not None else None
@@ -434,8 +460,10 @@ class BasicRewardNet(RewardNet):
                                    "fused update")
             a.gp_e, a.gp_coef, a.gp_target = L.ptr(e), float(coef), float(target)
             a.gp_ws, a.gp_out = L.ptr(gws), L.ptr(ws["gp_out"])
-        L.call("ia_disc_step_basic", C.byref(a), L.stream())
+
+    def _step_used(self, ws, pre):
         # what this step read / normalised with (the opt-in gradient penalty evaluates the net at the same point)
+        nrm = self.mlp.norm
         ws["X_used"] = ws["X"] if pre is None else pre[0]["X_all"][pre[1]]
         if nrm is None:
             ws["norm_used"] = None

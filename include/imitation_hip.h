@@ -188,6 +188,9 @@ typedef struct {
   const float* gp_e; float gp_coef; float gp_target; float* gp_ws; float* gp_out;
 } ia_disc_step_args;
 int ia_disc_step_basic(const ia_disc_step_args* a, void* stream);
+/* The n updates of one round (`for _ in range(n_disc_updates_per_round): train_disc()`, adversarial/common.py:454-458)
+ * in one host call: update k = ia_disc_step_basic(&a[k], stream), in order; stops at the first error. */
+int ia_disc_round_basic(const ia_disc_step_args* a, int n, void* stream);
 /* 0 when the fused path does not cover the shape (the call then runs the general path). */
 int64_t ia_disc_fused_ws_floats(const ia_mlp_desc* d, int R, int ldx);
 /* 0 when the fused gradient penalty does not cover the shape (B = interpolated rows = expert rows of an update). */

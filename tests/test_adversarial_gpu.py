@@ -112,25 +112,72 @@ def test_pipelined_rounds_are_bit_identical(tmp_path, case):
     import imitation_amd as p
 
     outs, logs = {}, {}
-    for mode in (True, False):
+    # (pipelined; pipelined with every round's log row written late -- behind the next round's enqueue, as happens by itself
+    #  when a round's updates outlast the next PPO enqueue; strictly sequential)
+    #  "behind": the updates enqueued after `learn` has returned instead of right behind the PPO launch
+    for mode in (True, "late", "behind", False):
         cfg = harness.CASES[case]
         d = str(tmp_path / f"log_{mode}")
         tr, _ = harness.build_trainer("hip", cfg, d, device="cuda")
         tr._logger = p.configure_logger(d, ["csv"])
         tr.gen_algo.set_logger(tr.logger)
-        tr.pipeline_rounds = mode
+        tr.pipeline_rounds = bool(mode)
+        tr.disc_log_late = True if mode == "late" else (False if mode is True else None)
+        tr.disc_enqueue_early = mode != "behind"
         assert tr._overlap, "the overlapped schedules must be available for this case"
         tr.train(4 * cfg["n_envs"] * cfg["n_steps"])
         outs[mode] = harness.snapshot(tr)
         tr.logger.close()
         logs[mode] = {os.path.relpath(f, d): _csv_rows(f) for f in sorted(glob.glob(os.path.join(d, "**", "*.csv"),
                                                                                 recursive=True))}
+    for mode in (True, "late", "behind"):
+        for k in outs[mode]:
+            assert np.array_equal(np.asarray(outs[mode][k]), np.asarray(outs[False][k]), equal_nan=True), (mode, k)
+        assert set(logs[mode]) == set(logs[False]) and len(logs[mode]) == 3      # root, raw/gen, raw/disc
+        for f in logs[mode]:
+            assert logs[mode][f] == logs[False][f], (mode, f)
+        assert len(logs[mode]["progress.csv"]) == 4
+
+
+@pytest.mark.parametrize("case,penalty", [("gail_fused", 0.0), ("gail_fused", 4.0), ("gail_box", 0.0)])
+def test_round_of_updates_in_one_call_is_bit_identical(tmp_path, case, penalty):
+    """A pre-assembled round's n discriminator updates through ONE C call (`ia_disc_round_basic`, default) against one
+    `ia_disc_step_basic` call per update: same launches in the same order -> every array of the trainer snapshot, the
+    penalty's mean and every logged row bit for bit (with the penalty: the same `th.rand` draws in the same order)."""
+    import glob
+
+    import imitation_amd as p
+
+    if case not in harness.CASES:
+        pytest.skip(f"no case {case}")
+    outs, logs, used = {}, {}, {}
+    for mode in (True, False):
+        cfg = harness.CASES[case]
+        d = str(tmp_path / f"log_{mode}")
+        tr, _ = harness.build_trainer("hip", cfg, d, device="cuda")
+        tr._logger = p.configure_logger(d, ["csv"])
+        tr.gen_algo.set_logger(tr.logger)
+        tr.disc_round_one_call = mode
+        tr.disc_grad_penalty_coef = penalty
+        calls = []
+        orig = tr._disc_round_one_call
+        tr._disc_round_one_call = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+        th.manual_seed(77)
+        tr.train(3 * cfg["n_envs"] * cfg["n_steps"])
+        th.cuda.synchronize()
+        outs[mode] = harness.snapshot(tr)
+        if penalty:
+            outs[mode]["last_grad_penalty"] = float(tr.last_grad_penalty)
+        used[mode] = len(calls)
+        tr.logger.close()
+        logs[mode] = {os.path.relpath(f, d): _csv_rows(f) for f in sorted(glob.glob(os.path.join(d, "**", "*.csv"),
+                                                                                recursive=True))}
+    if case == "gail_fused":
+        assert used[True] >= 2 and used[False] == 0, used   # (the fused shape takes the one-call round)
     for k in outs[True]:
         assert np.array_equal(np.asarray(outs[True][k]), np.asarray(outs[False][k]), equal_nan=True), k
-    assert set(logs[True]) == set(logs[False]) and len(logs[True]) == 3      # root, raw/gen, raw/disc
     for f in logs[True]:
         assert logs[True][f] == logs[False][f], f
-    assert len(logs[True]["progress.csv"]) == 4
 
 
 @pytest.mark.parametrize("case", ["gail_box", "gail_f64", "airl_box", "gail_generic_vecenv", "gail_tuned_hps", "gail_cartpole",
