@@ -169,6 +169,8 @@ _SIGS = {
                                C.c_int),
     "ia_ppo_epoch": ([C.POINTER(PolicyDesc), _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _F,
                       _F, _F, _P, _P, _D, _D, _D, _F, _L, _P, _P, _P], C.c_int),
+    "ia_ppo_epochs": ([C.POINTER(PolicyDesc), _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _F,
+                       _F, _F, _P, _P, _D, _D, _D, _F, _L, _P, _P, _P], C.c_int),
     "ia_ppo_update_ws_floats": ([C.POINTER(PolicyDesc), _I], C.c_int64),
     "ia_ppo_update_xcd_pack": ([_I], C.c_int),
     "ia_ppo_update_assume_cus": ([_I], C.c_int),

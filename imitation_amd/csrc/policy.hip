@@ -3216,8 +3216,8 @@ __device__ __forceinline__ bool spin_until(unsigned* p, unsigned target, unsigne
 // thread's stores acknowledged, block barrier, one lane's agent-scope release + relaxed arrive on a monotonic counter,
 // bounded spin, acquire (the gfx950 hand-off rules of disc_fused.hip / the persistent H = 32 kernel).
 struct EpochSteps {
-  static constexpr int MAX = 64;
-  int n, first;                       // minibatches [first, first + n) of the epoch
+  static constexpr int MAX = 192;     // (1.5 KB of kernel arguments: a round's 160 steps in one launch)
+  int n, first;                       // minibatches [first, first + n) of the sequence
   float step_size[MAX], bc2_sqrt[MAX];
 };
 
@@ -5018,17 +5018,21 @@ int ia_ppo_minibatch_apply(const ia_policy_desc* d, float* params, float* params
 // np.random.permutation(T*n_envs) already resident on the device; minibatches are consecutive
 // slices of it (the last one may be short). Adam's bias corrections are formed in double per step.
 // Launches: 1 prepare + 2 per minibatch.
-int ia_ppo_epoch(const ia_policy_desc* d, float* params, float* params_t, float* norm_mean, float* norm_var,
+// `n_epochs` consecutive epochs as ONE sequence of minibatches (`perm` = the epochs' permutations back to back): valid when
+// the rollout divides into whole minibatches (no minibatch then straddles two epochs and every minibatch is the one the
+// per-epoch call makes); gather, statistics and the epoch kernels run over n_epochs x T x n_envs rows.
+static int ppo_epochs_impl(const ia_policy_desc* d, float* params, float* params_t, float* norm_mean, float* norm_var,
                  int32_t* norm_count, int update_norm, const float* obs, const float* actions, const float* old_logp,
-                 const float* advantages, const float* returns, const int64_t* perm, int T, int n_envs,
+                 const float* advantages, const float* returns, const int64_t* perm, int n_epochs, int T, int n_envs,
                  int batch_size, int normalize_adv, float clip_range, float ent_coef, float vf_coef,
                  float max_grad_norm, float* exp_avg, float* exp_avg_sq, double lr, double beta1, double beta2,
                  float adam_eps, int64_t adam_steps_done, float* ws, float* stats, void* stream) {
-  if (!pol_ok(d) || batch_size <= 0) return IA_ERR_ARG;
+  if (!pol_ok(d) || batch_size <= 0 || n_epochs < 1) return IA_ERR_ARG;
+  if (n_epochs > 1 && ((long long)T * n_envs) % batch_size != 0) return IA_ERR_UNSUPPORTED;
   PpoArgs a{d, params, params_t, norm_mean, norm_var, norm_count, update_norm, obs, actions, old_logp, advantages,
             returns, T, n_envs, normalize_adv, clip_range, ent_coef, vf_coef, max_grad_norm, exp_avg, exp_avg_sq,
             (float)beta1, (float)beta2, adam_eps, ws, (hipStream_t)stream};
-  const long long total = (long long)T * n_envs;
+  const long long total = (long long)T * n_envs * n_epochs;
   int64_t step = adam_steps_done;
   int mb = 0;
   auto size_at = [&](long long start) { return (int)((total - start) < batch_size ? (total - start) : batch_size); };
@@ -5162,6 +5166,29 @@ int ia_ppo_epoch(const ia_policy_desc* d, float* params, float* params_t, float*
   return IA_OK;
 }
 
+
+int ia_ppo_epoch(const ia_policy_desc* d, float* params, float* params_t, float* norm_mean, float* norm_var,
+                 int32_t* norm_count, int update_norm, const float* obs, const float* actions, const float* old_logp,
+                 const float* advantages, const float* returns, const int64_t* perm, int T, int n_envs,
+                 int batch_size, int normalize_adv, float clip_range, float ent_coef, float vf_coef,
+                 float max_grad_norm, float* exp_avg, float* exp_avg_sq, double lr, double beta1, double beta2,
+                 float adam_eps, int64_t adam_steps_done, float* ws, float* stats, void* stream) {
+  return ppo_epochs_impl(d, params, params_t, norm_mean, norm_var, norm_count, update_norm, obs, actions, old_logp,
+                         advantages, returns, perm, 1, T, n_envs, batch_size, normalize_adv, clip_range, ent_coef, vf_coef,
+                         max_grad_norm, exp_avg, exp_avg_sq, lr, beta1, beta2, adam_eps, adam_steps_done, ws, stats, stream);
+}
+
+int ia_ppo_epochs(const ia_policy_desc* d, float* params, float* params_t, float* norm_mean, float* norm_var,
+                  int32_t* norm_count, int update_norm, const float* obs, const float* actions, const float* old_logp,
+                  const float* advantages, const float* returns, const int64_t* perms, int n_epochs, int T, int n_envs,
+                  int batch_size, int normalize_adv, float clip_range, float ent_coef, float vf_coef,
+                  float max_grad_norm, float* exp_avg, float* exp_avg_sq, double lr, double beta1, double beta2,
+                  float adam_eps, int64_t adam_steps_done, float* ws, float* stats, void* stream) {
+  return ppo_epochs_impl(d, params, params_t, norm_mean, norm_var, norm_count, update_norm, obs, actions, old_logp,
+                         advantages, returns, perms, n_epochs, T, n_envs, batch_size, normalize_adv, clip_range, ent_coef,
+                         vf_coef, max_grad_norm, exp_avg, exp_avg_sq, lr, beta1, beta2, adam_eps, adam_steps_done, ws, stats,
+                         stream);
+}
 
 // LDS of a gradient block: minibatch tiles, both parameter copies, the staged next minibatch, the transpose map
 inline size_t upd_grad_lds_bytes(int P4, int aw) {

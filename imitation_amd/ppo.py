@@ -345,7 +345,11 @@ class PPO(OnPolicyAlgorithm):
         total = self.n_steps * self.n_envs
         self._n_mb = -(-total // self.batch_size)
         # policies outside the fused kernels' shapes (`general_policy.GeneralTowers`) run their own minibatch loop
-        self._ppo_ws = th.empty(int(L.load().ia_ppo_ws_floats(C.byref(p.desc), min(self.batch_size, total), total)),
+        # (whole minibatches per epoch: room for every epoch's gathered rows, `ia_ppo_epochs` runs them as one sequence)
+        self._ppo_ws_epochs = self.n_epochs if (p.fused and total % self.batch_size == 0) else 1
+        self.epochs_one_call = True   # (tuning / tests: False = one `ia_ppo_epoch` call per epoch)
+        self._ppo_ws = th.empty(int(L.load().ia_ppo_ws_floats(C.byref(p.desc), min(self.batch_size, total),
+                                                              self._ppo_ws_epochs * total)),
                                 device=self.device) if p.fused else None
         self._perm_host = th.zeros(self.n_epochs, total, dtype=th.int64).pin_memory()
         self._perm_dev = th.zeros(self.n_epochs, total, dtype=th.int64, device=self.device)
@@ -1009,7 +1013,24 @@ class PPO(OnPolicyAlgorithm):
                     self._h_upd_err = th.zeros(1, dtype=th.int32).pin_memory()
                 self._h_upd_err.copy_(self._upd_ws[8:9].view(th.int32), non_blocking=True)
                 self._upd_err_pending = True
-        for e in range(self.n_epochs if (single and self._upd_ws is None) else 0):
+        per_epoch = single and self._upd_ws is None
+        if per_epoch and self.n_epochs > 1 and self._ppo_ws_epochs == self.n_epochs and self.epochs_one_call:
+            # every epoch of the update as one sequence of minibatches (the rollout divides into whole minibatches): gather
+            # and statistics of all epochs in one launch each, the epoch kernels back to back
+            rc = L.load().ia_ppo_epochs(
+                C.byref(pol.desc), L.ptr(pol._flat), L.ptr(pol._flat_t),
+                L.ptr(rn.running_mean) if rn else None, L.ptr(rn.running_var) if rn else None,
+                L.ptr(rn.count) if rn else None, int(rn is not None), L.ptr(rb.obs), L.ptr(rb.acts), L.ptr(rb.logp),
+                L.ptr(rb.adv), L.ptr(rb.ret), L.ptr(self._perm_dev), self.n_epochs, T, n, self.batch_size,
+                int(self.normalize_advantage), float(clip_range), float(self.ent_coef), float(self.vf_coef),
+                float(self.max_grad_norm), L.ptr(pol.optimizer.exp_avg), L.ptr(pol.optimizer.exp_avg_sq),
+                float(lr), float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]), pol.optimizer.step_count,
+                L.ptr(self._ppo_ws), L.ptr(stats_dev), L.stream())
+            if rc != L.ERR_UNSUPPORTED:
+                L.check(rc, "ia_ppo_epochs")
+                pol.optimizer.step_count += self.n_epochs * self._n_mb
+                per_epoch = False
+        for e in range(self.n_epochs if per_epoch else 0):
             L.call("ia_ppo_epoch", C.byref(pol.desc), L.ptr(pol._flat), L.ptr(pol._flat_t),
                    L.ptr(rn.running_mean) if rn else None, L.ptr(rn.running_var) if rn else None,
                    L.ptr(rn.count) if rn else None, int(rn is not None), L.ptr(rb.obs), L.ptr(rb.acts), L.ptr(rb.logp),

@@ -551,6 +551,17 @@ int ia_ppo_epoch(const ia_policy_desc* d, float* params, float* params_t, float*
                  int batch_size, int normalize_adv, float clip_range, float ent_coef, float vf_coef,
                  float max_grad_norm, float* exp_avg, float* exp_avg_sq, double lr, double beta1, double beta2,
                  float adam_eps, int64_t adam_steps_done, float* ws, float* stats, void* stream);
+/* `n_epochs` consecutive epochs (the `for epoch in range(n_epochs)` loop of SB3's PPO.train) in one call: `perms` =
+ * the epochs' permutations back to back [n_epochs][T*n_envs], stats [n_epochs][n_minibatches][8] or NULL,
+ * ws: ia_ppo_ws_floats(d, batch, n_epochs * T * n_envs). The epochs run as ONE sequence of minibatches (gather and
+ * statistics of every epoch in one launch each, the epoch kernels back to back): needs T*n_envs % batch_size == 0 --
+ * IA_ERR_UNSUPPORTED otherwise, nothing launched (call ia_ppo_epoch per epoch). Same values as n_epochs ia_ppo_epoch calls. */
+int ia_ppo_epochs(const ia_policy_desc* d, float* params, float* params_t, float* norm_mean, float* norm_var,
+                 int32_t* norm_count, int update_norm, const float* obs, const float* actions, const float* old_logp,
+                 const float* advantages, const float* returns, const int64_t* perms, int n_epochs, int T, int n_envs,
+                 int batch_size, int normalize_adv, float clip_range, float ent_coef, float vf_coef,
+                 float max_grad_norm, float* exp_avg, float* exp_avg_sq, double lr, double beta1, double beta2,
+                 float adam_eps, int64_t adam_steps_done, float* ws, float* stats, void* stream);
 
 /* A whole [SB3 PPO.train]: n_epochs passes over consecutive minibatches of perm[n_epochs][T*n_envs]
  * in ONE persistent launch (hidden = 32): nblk gradient blocks keep the parameters in LDS and

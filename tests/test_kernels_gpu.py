@@ -476,7 +476,8 @@ def test_timeout_bootstrap():
                                                         # and a Discrete head with a short last minibatch
                                                         (27, 8, 32, False, True, 4, 12, 16),
                                                         (4, 3, 32, True, True, 4, 10, 16)])
-@pytest.mark.parametrize("path", ["epoch", "epoch_whole", "epoch_barriers", "update", "update_spread", "update_shard1"])
+@pytest.mark.parametrize("path", ["epoch", "epochs_one_call", "epoch_whole", "epoch_barriers", "update", "update_spread",
+                                  "update_shard1"])
 def test_ppo_epochs_match_oracle(D, A, H, discrete, norm, T, n, bs, path):
     """Two PPO epochs on a synthetic rollout: parameters, Adam state, RunningNorm state and the
     logged loss statistics against SB3-restated `PPO.train` on the same permutations -- through
@@ -488,7 +489,9 @@ def test_ppo_epochs_match_oracle(D, A, H, discrete, norm, T, n, bs, path):
     if path in ("epoch_whole", "epoch_barriers") and H != 64:
         pytest.skip("64-wide towers: the one-launch epoch with whole row-block workgroups / with grid barriers (default: one "
                     "tower per workgroup, hand-offs as 8-byte value / sequence words)")
-    if path not in ("epoch", "epoch_whole", "epoch_barriers") and H != 32:
+    if path == "epochs_one_call" and (T * n) % bs != 0:
+        pytest.skip("`ia_ppo_epochs` runs the epochs as one sequence of minibatches: whole minibatches per epoch only")
+    if path not in ("epoch", "epochs_one_call", "epoch_whole", "epoch_barriers") and H != 32:
         pytest.skip("the persistent update covers hidden = 32")
     from imitation_amd import spaces
     from oracle import imitation_restated as o
@@ -527,10 +530,18 @@ def test_ppo_epochs_match_oracle(D, A, H, discrete, norm, T, n, bs, path):
     np.random.seed(123)
     algo.train()  # oracle: 2 epochs
 
-    ws = th.empty(int(L.load().ia_ppo_ws_floats(C.byref(dp.d), bs, T * n)), device=DEV)
+    ws = th.empty(int(L.load().ia_ppo_ws_floats(C.byref(dp.d), bs, (2 if path == "epochs_one_call" else 1) * T * n)),
+                  device=DEV)
     n_mb = -(-T * n // bs)
     stats = th.zeros(2, n_mb, 8, device=DEV)
-    if path in ("epoch", "epoch_whole", "epoch_barriers"):
+    if path == "epochs_one_call":   # both epochs as one sequence of minibatches (`ia_ppo_epochs`)
+        d_perm = th.as_tensor(np.stack(perms)).to(DEV)
+        L.call("ia_ppo_epochs", C.byref(dp.d), L.ptr(dp.P), L.ptr(dp.Pt), L.ptr(dp.nm), L.ptr(dp.nv), L.ptr(dp.nc),
+               int(norm), L.ptr(d_obs), L.ptr(d_act), L.ptr(d_lp), L.ptr(d_adv), L.ptr(d_ret), L.ptr(d_perm), 2, T, n, bs,
+               1, 0.2, 0.05, 0.5, 0.5, L.ptr(dp.m), L.ptr(dp.v), 3e-4, 0.9, 0.999, 1e-5, 0, L.ptr(ws), L.ptr(stats),
+               L.stream())
+        th.cuda.synchronize()
+    elif path in ("epoch", "epoch_whole", "epoch_barriers"):
         L.load().ia_ppo_epoch_split({"epoch": 0, "epoch_whole": 2, "epoch_barriers": 3}[path])
         try:
             for e in range(2):
