@@ -1161,7 +1161,9 @@ __device__ __forceinline__ void mfma_minibatch(
     const float* __restrict__ nv, const float adv_mean, const float adv_std, const MbRows rows, const int vblk,
     const int normalize_adv, const float clip, const float ent_coef, const float vf_coef, float* __restrict__ slab,
     float* __restrict__ statpart, float* __restrict__ lds_in, long long* __restrict__ tstamp, const int oz = 0,
-    const int tower = 0, const MbLl ll = MbLl{}) {
+    const int tower = 0, const MbLl ll = MbLl{}, const int* __restrict__ tdst = nullptr) {
+  // (`tdst`, word-exchange form: where in the transposed image each of the thread's NLL parameter words goes, -1: nowhere
+  //  -- the same every step, so the caller works it out once per launch and keeps it in registers)
   static_assert(!SPLIT || (H == 64 && LOAD_PARAMS), "the one-tower form is the 64-wide epoch kernel's");
   static_assert(NLL == 0 || SPLIT, "the word-exchange form is the one-tower kernel's");
   constexpr bool LLX = NLL > 0;
@@ -1349,23 +1351,11 @@ __device__ __forceinline__ void mfma_minibatch(
     sPB = imgB - segB0;
     sLS = imgC - (d.discrete ? 0 : o.log_std);
     // image A (torch layout) and, for the two weight matrices, the transposed places of image T; the head and log_std
-    {
-      const int nW1 = H * D, oW2i = nW1 + H;
-      const float invD = 1.f / (float)D;
 #pragma unroll
-      for (int i = 0; i < NLA; ++i) {
-        const int e = tid + i * NT;
-        if (e < tlen) {
-          imgA[e] = wa[i];
-          if (e < nW1) {
-            const int r = (int)(((float)e + 0.5f) * invD), c = e - r * D;   // (exact: e < 4096, D <= 64)
-            imgT[c * TS + r] = wa[i];
-          } else if (e >= oW2i && e < oW2i + H * H) {
-            const int j = e - oW2i;
-            imgT[(D + (j & (H - 1))) * TS + (j >> 6)] = wa[i];
-          }
-        }
-      }
+    for (int i = 0; i < NLA; ++i) {
+      const int e = tid + i * NT;
+      if (e < tlen) imgA[e] = wa[i];
+      if (tdst[i] >= 0) imgT[tdst[i]] = wa[i];
     }
 #pragma unroll
     for (int i = 0; i < NB; ++i)
@@ -3489,6 +3479,26 @@ __global__ __launch_bounds__(256) void ppo_epoch_ll_kernel(
   const int chunk = (o.total + nwg - 1) / nwg;
   constexpr int NPC = 4;   // parameters of the chunk per thread (chunk <= 1024)
   if (threadIdx.x == 0) s_fail = 0;
+  // where each of the thread's polled parameter words goes in the transposed LDS image (mfma_minibatch: rows of W1^T, then
+  // of W2^T, H + 4 floats apart); the same every step
+  int tdst[NLL];
+  {
+    constexpr int TS = H + 4;
+    const int nW1 = H * D, oW2i = nW1 + H;
+#pragma unroll
+    for (int i = 0; i < NLL; ++i) {
+      const int e = (int)threadIdx.x + i * NT;
+      int t = -1;
+      if (e < nW1) {
+        const int r = e / D;
+        t = (e - r * D) * TS + r;
+      } else if (e >= oW2i && e < oW2i + H * H) {
+        const int j = e - oW2i;
+        t = (D + (j & (H - 1))) * TS + (j >> 6);
+      }
+      tdst[i] = t;
+    }
+  }
   // the workgroup's chunk of the parameters and of Adam's moments: registers across the launch (nobody else writes it)
   float m_[NPC], v_[NPC], p_[NPC];
 #pragma unroll
@@ -3520,14 +3530,15 @@ __global__ __launch_bounds__(256) void ppo_epoch_ll_kernel(
     if ((bid >> 1) < nblk) {
       const MbRows rows{obs + start * D, actions + start * aw, old_logp + start, adv + start, ret + start, nullptr, b, T,
                         n_envs};
-      int oz;   // (opaque zero: see ppo_epoch_persistent_kernel)
+      int oz;   // (opaque zero: see ppo_epoch_persistent_kernel. Without it the loop-invariant offsets are hoisted into 495-512
+                //  registers -- spills in two of the three width classes -- for 0.4 us per step: measured, not taken)
       asm volatile("s_mov_b32 %0, 0" : "=s"(oz));
       const int rb = bid >> 1;
       float* slab = reinterpret_cast<float*>(slabs_s + (long long)rb * SW);   // (a word array: offsets only)
       const MbLl mll{par64 + (long long)(seq_par & 1u) * o.total, seq_par, seq_out, &s_fail, err};
       mfma_minibatch<H, true, true, NLL>(d, P + oz, Pt + oz, snap ? sq + 8 : nm_in, snap ? sq + 8 + MAXD : nv_in, sq[0], sq[1],
                                          rows, rb + oz, normalize_adv, clip, ent_coef, vf_coef, slab, slab + o.total, lds,
-                                         dbg != nullptr ? dbg + 16 + (bid & 1) * 16 : nullptr, oz, bid & 1, mll);
+                                         dbg != nullptr ? dbg + 16 + (bid & 1) * 16 : nullptr, oz, bid & 1, mll, tdst);
     }
     if (s_fail) return;   // (behind the function's closing barrier; workgroups without rows never set it)
     EP_TS(0);
