@@ -1445,6 +1445,12 @@ __device__ __forceinline__ void mfma_minibatch(
     if constexpr (H == 32) {
 #pragma unroll
       for (int c = 0; c < NC; ++c) out[c] = rowbase[c * 16 + li];
+    } else if constexpr (LLX) {
+      // (word-exchange form: every image starts on a 16-byte boundary of LDS -- the caller rounds the dynamic area's base --
+      //  and every fragment row is a multiple of four floats into its image: one ds_read_b128 per fragment)
+      const f32x4 t = *reinterpret_cast<const f32x4*>(rowbase + li * NC);
+#pragma unroll
+      for (int c = 0; c < NC; ++c) out[c] = t[c];
     } else {
       const f32x4_u t = *reinterpret_cast<const f32x4_u*>(rowbase + li * NC);
 #pragma unroll
@@ -3453,7 +3459,10 @@ __global__ __launch_bounds__(256) void ppo_epoch_ll_kernel(
     long long* __restrict__ dbg /* measurement: [0..5] += 100 MHz ticks of workgroup 0 in {A, slab poll + sum, sum of squares
                                    published, poll of the sums of squares, Adam + publish, -} */) {
   typedef unsigned long long u64;
-  extern __shared__ __attribute__((aligned(16))) float lds[];
+  extern __shared__ __attribute__((aligned(16))) float lds_raw[];
+  // (the dynamic area starts where the static one ends -- not a 16-byte boundary here: rounded up, the launch asks for 16
+  //  bytes more; the images' ds_read_b128 fragment reads would otherwise be split)
+  float* lds = lds_raw + (((16 - (__builtin_amdgcn_groupstaticsize() & 15)) & 15) >> 2);
   __shared__ int s_fail;
   __shared__ float s_part[64];
   __shared__ float s_stat[32 * 8];
@@ -5070,7 +5079,7 @@ static int ppo_epochs_impl(const ia_policy_desc* d, float* params, float* params
   const bool split = one_launch && !g_epoch_whole && 2 * nrb <= dev_cus && 2 * nrb <= 64 && cdiv(P, 2 * nrb) <= 4 * 256 &&
                      sbytes <= EPOCH_SPLIT_LDS;
   // the word-exchange form of the one-tower kernel (no grid barriers); its word areas sit behind everything else in ws
-  const bool llx = split && !g_epoch_barriers && sbytes <= EPOCH_LL_LDS && nrb <= 32;
+  const bool llx = split && !g_epoch_barriers && sbytes + 16 <= EPOCH_LL_LDS && nrb <= 32;
   unsigned long long* ll_base = llx ? reinterpret_cast<unsigned long long*>(ws + ppo_ws_plain_floats(d, size_at(0), total)) : nullptr;
   int rc = launch_gather(a, perm, total, g, ll_base, llx ? epoch_ll_words(nrb, P) : 0,
                          llx ? reinterpret_cast<unsigned*>(ws) + 4 : nullptr);   // (words 4, 5, 6: counter, error word, ticket)
@@ -5119,7 +5128,7 @@ static int ppo_epochs_impl(const ia_policy_desc* d, float* params, float* params
             es.step_size[k] = (float)(lr / (1.0 - pow(beta1, (double)step)));
             es.bc2_sqrt[k] = (float)sqrt(1.0 - pow(beta2, (double)step));
           }
-          hipLaunchKernelGGL(kern, dim3(nwg), dim3(256), sbytes, a.st, *d, params, params_t, exp_avg, exp_avg_sq, norm_mean,
+          hipLaunchKernelGGL(kern, dim3(nwg), dim3(256), sbytes + 16, a.st, *d, params, params_t, exp_avg, exp_avg_sq, norm_mean,
                              norm_var, g.obs, g.act, g.logp, g.adv, g.ret, total, batch_size, T, n_envs, normalize_adv,
                              clip_range, ent_coef, vf_coef, max_grad_norm, (float)beta1, (float)beta2, adam_eps, ws, el, seq,
                              snap ? 1 : 0, stats, es, g_epoch_dbg);
