@@ -1527,16 +1527,20 @@ __device__ __forceinline__ void mfma_minibatch(
   // per-action Gaussian constants of the lane's actions (policy waves): 1 / sd^2, log sd with sd = exp(log_std)
   float c_ivar[4], c_logsd[4];
   const bool need_sd = tw == 0 && !d.discrete;
-#pragma unroll
-  for (int j = 0; j < 4; ++j) c_logsd[j] = need_sd ? sLS[o.log_std + min(part + 4 * j, A - 1)] : 0.f;
-  IA_FENCE();
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    c_ivar[j] = 1.f;
+  {
+    // lane l works out the pair of action (l & 15) -- one exp, one division, one log per lane instead of four -- and the
+    // lanes pick theirs up by shuffle (the form of the H = 32 chain; same expressions, same values)
+    float my_ivar = 1.f, my_logsd = need_sd ? sLS[o.log_std + min(lane & 15, A - 1)] : 0.f;
+    IA_FENCE();
     if (need_sd) {
-      const float sd = expf(c_logsd[j]);
-      c_ivar[j] = 1.f / (sd * sd);
-      c_logsd[j] = logf(sd);
+      const float sd = expf(my_logsd);
+      my_ivar = 1.f / (sd * sd);
+      my_logsd = logf(sd);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      c_ivar[j] = __shfl(my_ivar, part + 4 * j, 64);
+      c_logsd[j] = __shfl(my_logsd, part + 4 * j, 64);
     }
   }
 
