@@ -3969,7 +3969,7 @@ __global__ __launch_bounds__(512) void ppo_update_persistent_kernel(
   // Row prefetch: the gathers of step s+1 (two dependent global loads per element) are issued
   // before the grid barrier of step s and land in registers behind the barrier wait and the
   // update; they are parked in the LDS staging area just before step s+1 starts.
-  constexpr int NIT = (ROWS * L::XS + 511) / 512;
+  constexpr int NIT = (PROWS * L::XS + 511) / 512;   // (SMALL: 3 passes can hold its 16 rows, not 9)
   // (i) one step ahead of (ii): wave 7 resolves permutation entry -> rollout-tile row offset for the
   // block's 64 rows of minibatch s (a dependent global load plus a division) and leaves them in LDS;
   // any later block barrier publishes them. (ii) every thread then issues its row gathers at once.
@@ -4024,7 +4024,7 @@ __global__ __launch_bounds__(512) void ppo_update_persistent_kernel(
     }
     // actions: element e = row * aw + column of the block's [ROWS][aw] tile, 512 elements per pass
     const int aw_ = d.discrete ? 1 : d.act_dim;
-    constexpr int NAT = ROWS * MAXA / 512;
+    constexpr int NAT = (PROWS * MAXA + 511) / 512;
     int asrc[NAT], acol[NAT];
 #pragma unroll
     for (int it = 0; it < NAT; ++it) {
