@@ -139,6 +139,24 @@ def test_pipelined_rounds_are_bit_identical(tmp_path, case):
         assert len(logs[mode]["progress.csv"]) == 4
 
 
+def test_all_epochs_in_one_call_equal_one_call_per_epoch(tmp_path):
+    """64-wide towers (`gail_cartpole`: 128-row rollouts, PPO minibatch 32, five epochs): `PPO.train` through ONE
+    `ia_ppo_epochs` call (the epochs as one sequence of minibatches: one gather, one statistics and one epoch launch) against
+    one `ia_ppo_epoch` call per epoch -- the same minibatches, the same sums in the same order: every array bit for bit."""
+    outs, calls = {}, {}
+    for mode in (True, False):
+        cfg = harness.CASES["gail_cartpole"]
+        tr, _ = harness.build_trainer("hip", cfg, str(tmp_path / f"m{mode}"), device="cuda")
+        algo = tr.gen_algo
+        assert algo._ppo_ws_epochs == cfg["n_epochs"] and algo._upd_ws is None   # (whole minibatches; the per-epoch kernels)
+        algo.epochs_one_call = mode
+        tr.train(cfg["rounds"] * cfg["n_envs"] * cfg["n_steps"])
+        th.cuda.synchronize()
+        outs[mode] = harness.snapshot(tr)
+    for k in outs[True]:
+        assert np.array_equal(np.asarray(outs[True][k]), np.asarray(outs[False][k]), equal_nan=True), k
+
+
 @pytest.mark.parametrize("case,penalty", [("gail_fused", 0.0), ("gail_fused", 4.0), ("gail_box", 0.0)])
 def test_round_of_updates_in_one_call_is_bit_identical(tmp_path, case, penalty):
     """A pre-assembled round's n discriminator updates through ONE C call (`ia_disc_round_basic`, default) against one
