@@ -809,6 +809,11 @@ __device__ __forceinline__ unsigned long long ll_pack(float v, unsigned seq) {
 __device__ __forceinline__ void ll_store_agent(unsigned long long* p, float v, unsigned seq) {
   __hip_atomic_store(p, ll_pack(v, seq), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+// ... for readers on the SAME XCD only (workgroup-scope store: the line stays in that XCD's L2, which is the point of
+// coherence for its compute units -- no fabric write per word; agent-scope polls bypass L1 and are served by that L2)
+__device__ __forceinline__ void ll_store_xcd(unsigned long long* p, float v, unsigned seq) {
+  __hip_atomic_store(p, ll_pack(v, seq), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
 __device__ __forceinline__ void ll_store_system(unsigned long long* p, float v, unsigned seq) {
   __hip_atomic_store(p, ll_pack(v, seq), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
@@ -2213,7 +2218,9 @@ __device__ __forceinline__ void mfma32_minibatch_chain(
     const float adv_std, const MbRows rows, const int i0_in, const int row_lim, const int normalize_adv, const float clip,
     const float ent_coef, const float vf_coef, float* __restrict__ slab_g, float* __restrict__ statpart,
     float* __restrict__ lds_in, const float* __restrict__ sP_in, float* __restrict__ stg_in,
-    const int opaque_zero, long long* __restrict__ tstamp, const unsigned ll_seq) {
+    const int opaque_zero, long long* __restrict__ tstamp, const unsigned ll_seq, const bool ll_xcd = false) {
+  // `ll_xcd` (wave-uniform): every gradient workgroup of the launch sits on this XCD (the kernel has checked): the slab
+  // words are stored at workgroup scope -- they stay in the XCD's L2 instead of costing a fabric write each.
   // `i0_in`: first minibatch row of this workgroup; `row_lim`: rows at or beyond it are not this workgroup's (the
   // minibatch size, or -- row-sharded data parallelism -- the end of this rank's row range inside the global minibatch);
   // means are over `rows.batch`, the whole (global) minibatch, either way
@@ -2226,6 +2233,7 @@ __device__ __forceinline__ void mfma32_minibatch_chain(
   unsigned long long* __restrict__ slab64 = reinterpret_cast<unsigned long long*>(slab_g);
   auto put = [&](float* p, float v) {
     if constexpr (LOCAL) *p = v;
+    else if (ll_xcd) ll_store_xcd(slab64 + (p - slab), v, ll_seq);
     else ll_store_agent(slab64 + (p - slab), v, ll_seq);
   };
   const int batch = rows.batch;
@@ -2761,7 +2769,8 @@ __device__ __forceinline__ void mfma32_minibatch_chain(
         const int m = lane - 1;                      // misc column 2 + m
         const int slot = m == 0 ? 0 : (m == 4 ? 1 : m + 1);
         if constexpr (LOCAL) slab_store(statpart + slot, sm);   // (write-through; the caller drains it)
-        else ll_store_agent(slab64 + (((o.total + 3) & ~3) + slot), sm, ll_seq);   // the slab's tail
+        else if (ll_xcd) ll_store_xcd(slab64 + (((o.total + 3) & ~3) + slot), sm, ll_seq);   // the slab's tail
+        else ll_store_agent(slab64 + (((o.total + 3) & ~3) + slot), sm, ll_seq);
       }
     }
   }
@@ -3737,6 +3746,52 @@ __global__ __launch_bounds__(512) void ppo_update_persistent_kernel(
   // by workgroup 0 when a launch ends) -- a word left by an earlier launch can never pass for this one's
   const unsigned lseq_base = __hip_atomic_load(w.ctrl + 9, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if (threadIdx.x == 0) s_fail = 0;
+  // Packed launches: do ALL gradient workgroups sit on one XCD? Each publishes the id of its XCC (an ordinary word of the
+  // exchange, in the unused last tail word of its slab, under a sequence number no step uses) and reads everybody's; if
+  // they agree -- the same answer in every workgroup --, the step's words are stored at workgroup scope (`ll_store_xcd`):
+  // they stay in the XCD's L2, the coherence point of its compute units, and the polls (agent scope: past L1) find them
+  // there. One exchange per launch; any other placement keeps the agent-scope stores.
+  bool ll_xcd = false;
+  if constexpr (!LOCAL) {
+    if (xcd_pack && vb < nblk && nblk <= 64) {
+      __shared__ int s_xcd;
+      unsigned xcc;
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+      xcc &= 0xfu;
+      const unsigned aseq = ~lseq_base;
+      unsigned long long* aw = w.slabs64 + w.P4 + 7;
+      const long long P8a = w.P4 + 8;
+      if (tid == 0) ll_store_agent(aw + (long long)vb * P8a, __uint_as_float(xcc), aseq);
+      if (tid < 64) {
+        const unsigned long long* wp = aw + (long long)min(tid, nblk - 1) * P8a;
+        unsigned long long t;
+        bool bad = false;
+        const long long t0a = wall_clock64();
+        for (unsigned it = 0;;) {
+          t = __hip_atomic_load(wp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (__all((unsigned)(t >> 32) == aseq)) break;
+          __builtin_amdgcn_s_sleep(1);
+          if ((++it & 255u) == 0 &&
+              (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) || wall_clock64() - t0a > 200000000ll)) {
+            bad = true;
+            break;
+          }
+        }
+        if (tid == 0) {
+          s_xcd = 0;
+          if (bad) s_fail = 1;
+        }
+        if (!bad && __all((unsigned)t == xcc) && tid == 0) s_xcd = 1;
+      }
+      __syncthreads();
+      if (s_fail) {
+        if (tid == 0) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+      }
+      ll_xcd = s_xcd != 0;
+      if (tstamp && tid == 0 && vb < 8) tstamp[42 + vb] = (long long)xcc * 2 + (ll_xcd ? 1 : 0);   // (measurement build)
+    }
+  }
 
   // schedule scalars in registers; the per-step tables are read straight from the kernel arguments
   const int sch_first = sch.first, sch_nmb = sch.n_mb, sch_bs = sch.batch_size, n_steps = sch.n_steps;
@@ -4125,7 +4180,7 @@ __global__ __launch_bounds__(512) void ppo_update_persistent_kernel(
     mfma32_minibatch_chain<KS1, LOCAL, SMALL, !LOCAL>(d, slot, slot + MAXD, adv_mean, adv_std, r, row_lo + vb * ROWS, row_lim(r),
                                        normalize_adv, clip, ent_coef, vf_coef,
                                        reinterpret_cast<float*>(slabs_s + (long long)vb * P8), stat_base + vb * 8, lds, sP,
-                                       stg, oz, tstamp ? tstamp + 16 : nullptr, lseq);
+                                       stg, oz, tstamp ? tstamp + 16 : nullptr, lseq, ll_xcd);
     // (the minibatch ends with a block barrier: the LDS tiles are free; several workgroups: the slab words are on their
     //  way, nobody waits for them here)
     UPD_TS(1);
@@ -4193,6 +4248,8 @@ __global__ __launch_bounds__(512) void ppo_update_persistent_kernel(
           const unsigned xseq = sh.seq_base + (unsigned)s + 1u;
           for (int rr = 0; rr < sh.world; ++rr)
             ll_store_system(sh.peer_recv[rr] + (long long)((s & 1) * sh.world + (sh.loopback ? rr : sh.rank)) * P8 + gi, part, xseq);
+        } else if (ll_xcd) {
+          ll_store_xcd(sums_s + gi, part, lseq);
         } else {
           ll_store_agent(sums_s + gi, part, lseq);
         }
@@ -4290,7 +4347,8 @@ __global__ __launch_bounds__(512) void ppo_update_persistent_kernel(
 #pragma unroll
           for (int rr = 0; rr < SHARD_WORLD_MAX; ++rr)
             if (rr < sh.world) part += __uint_as_float((unsigned)t[rr]);
-          ll_store_agent(sums_s + gi, part, lseq);
+          if (ll_xcd) ll_store_xcd(sums_s + gi, part, lseq);
+          else ll_store_agent(sums_s + gi, part, lseq);
         }
       }
       UPD_TS(11);
@@ -5247,7 +5305,7 @@ int64_t ia_ppo_shard_recv_bytes(const ia_policy_desc* d, int world) {
   return 2 * (int64_t)world * (((P + 3) & ~3) + 8) * (int64_t)sizeof(unsigned long long);
 }
 
-bool g_upd_xcd_pack = false;
+bool g_upd_xcd_pack = true;   // several gradient workgroups that fit one XCD: packed there (ia_ppo_update_xcd_pack)
 constexpr int HOST_TAB_SLOTS = 8;
 struct HostTab { float* buf = nullptr; hipEvent_t done; };
 HostTab g_host_tab[HOST_TAB_SLOTS];
@@ -5359,7 +5417,7 @@ static int ppo_update_launch(const ia_policy_desc* d, float* params, float* para
     // 1024-row minibatch -- as long as a whole gradient step, so the chain kept waiting 1-2 us per step for
     // it; two slices + merge take ~14 us and the ring runs ahead again.)
     const int n_slices = (batch_global > UPD_SLICE && total < (1ll << 31)) ? cdiv(batch_global, UPD_SLICE) : 0;
-    const bool pack = g_upd_xcd_pack && nblk + 1 + n_slices <= 32;
+    const bool pack = g_upd_xcd_pack && nblk > 1 && nblk + 1 + n_slices <= 32;
     const int grid = (nblk + 1 + n_slices) * (pack ? 8 : 1);
     {
       // The grid barriers inside need every workgroup resident at once. A plain launch performs no such check

@@ -2,7 +2,8 @@
 alternating, and times `rounds` rounds of `train()` after a warm-up.
 Usage: python tools/ab_rounds.py <bench variant | P> <attribute>=<a>,<b>[,<c>] [rounds] [repeats]
   attribute: an attribute of the trainer (`disc_behind_ppo`, `disc_round_one_call`, `disc_enqueue_early`) or, with the prefix
-  `gen.`, of its PPO (`gen.epochs_one_call`); values: None / True / False / numbers.
+  `gen.`, of its PPO (`gen.epochs_one_call`), or `lib.<toggle>`: an integer switch of the library
+  (`lib.ia_ppo_update_xcd_pack`, `lib.ia_ppo_epoch_split`, `lib.ia_disc_fused_side_reduce`); values: None / True / False / numbers.
   e.g.  python tools/ab_rounds.py P disc_behind_ppo=None,True,False 100
         python tools/ab_rounds.py P_mlp64_1024x16 gen.epochs_one_call=True,False 60 3"""
 import ast
@@ -27,9 +28,13 @@ for v in vals * repeats:
         tr, per = bench.build_trainer(bench.hip_namespace(), cfg, "cuda"), cfg["n_envs"] * cfg["n_steps"]
     else:
         tr, per = bench.build_variant(name)
-    obj, a = (tr.gen_algo, attr[4:]) if attr.startswith("gen.") else (tr, attr)
-    assert hasattr(obj, a), attr
-    setattr(obj, a, v)
+    if attr.startswith("lib."):
+        from imitation_amd import _lib as L
+        getattr(L.load(), attr[4:])(int(v))
+    else:
+        obj, a = (tr.gen_algo, attr[4:]) if attr.startswith("gen.") else (tr, attr)
+        assert hasattr(obj, a), attr
+        setattr(obj, a, v)
     tr.train(5 * per)
     th.cuda.synchronize()
     t = time.perf_counter()

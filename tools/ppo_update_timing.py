@@ -40,6 +40,9 @@ for rep in range(3):
     print("statistics block per step: " + ", ".join(f"{n} {t_ / 100.0 / steps:.2f} us" for n, t_ in
                                                       zip(("wait for a free ring slot", "loss statistics of finished steps",
                                                            "minibatch statistics + publish"), sb)))
+    place = buf.cpu().numpy()[42:50]
+    print("packed launch: (XCC id, words stored at workgroup scope) of gradient workgroups 0-7:",
+          [(int(v) >> 1, bool(int(v) & 1)) for v in place])
     polls = buf.cpu().numpy()[40:42]
     print(f"unsuccessful polls per step (thread 0 of workgroup 0): hop 1 {polls[0] / steps:.2f}, hop 2 {polls[1] / steps:.2f}")
     print(f"xcd_pack={pack}: train() {1e3 * d:.2f} ms for {steps} steps; per step: " +
