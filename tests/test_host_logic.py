@@ -527,8 +527,8 @@ def test_production_kernels_do_not_spill():
         assert k["vgpr_spill"] == 0 and k["scratch"] <= (32 if sharded else 0), k
     for sub in ("disc_fb_kernel", "disc_gp_kernel", "policy_rollout_mailbox_kernel", "policy_logits_mailbox_kernel",
                 "disc_fwd_kernel", "disc_bwd_kernel", "airl_rows_kernel", "disc32_rows_kernel", "policy_act_mfma_kernel",
-                "ia_gemm_kernel", "conv1_fwd_kernel", "conv1_wgrad_kernel", "ppo_epoch_persistent_kernel",
-                "ppo_grad_mfma_kernel"):
+                "ia_gemm_kernel", "ia_gemm_tn_side_kernel", "conv1_fwd_kernel", "conv1_wgrad_kernel",
+                "ppo_epoch_persistent_kernel", "ppo_epoch_ll_kernel", "ppo_grad_mfma_kernel", "disc_reduce_kernel"):
         ks = find(sub)
         assert ks, sub
         for k in ks:
