@@ -443,6 +443,7 @@ __global__ void bootstrap_kernel(float* __restrict__ rewards, const float* __res
 //                       "prepare" launch is needed except for the first minibatch of an epoch.
 
 __host__ __device__ inline long long epoch_ll_words(int nrb, int P);   // (ppo_epoch_ll_kernel's word areas)
+__host__ __device__ inline int epoch_ll_row_blocks(int nrb, int P);
 // ws layout (floats): [0..7] adv stats {mean, std}; [8..8+nblk*8) loss-stat partials;
 // then gradient slabs [nblk][P]; then reduced gradient [P].
 struct PpoWs {
@@ -3460,6 +3461,11 @@ struct EpochLl {
   unsigned seq0;
 };
 __host__ __device__ inline long long epoch_ll_words(int nrb, int P) { return 2LL * nrb * (P + 8) + 2 * 64 + 2LL * P; }
+// row blocks the launch is laid out for: the minibatch's own, or as many as it takes for chunks of <= 1 024 parameters
+__host__ __device__ inline int epoch_ll_row_blocks(int nrb, int P) {
+  const int owners = (P + 1023) / 1024;
+  return nrb > (owners + 1) / 2 ? nrb : (owners + 1) / 2;
+}
 
 template <int H, int NLL>
 __global__ __launch_bounds__(256) void ppo_epoch_ll_kernel(
@@ -3499,7 +3505,8 @@ __global__ __launch_bounds__(256) void ppo_epoch_ll_kernel(
   u64* par64 = sq64 + 2 * 64;
   unsigned* err = reinterpret_cast<unsigned*>(ws) + 5;
   const int chunk = (o.total + nwg - 1) / nwg;
-  constexpr int NPC = 4;   // parameters of the chunk per thread (chunk <= 1024)
+  constexpr int NPC = 4;   // parameters of the chunk per thread (chunk <= 1024: the host launches enough workgroups -- those
+                           // beyond the minibatch's row blocks have no gradient phase, they only own a chunk)
   if (threadIdx.x == 0) s_fail = 0;
   // where each of the thread's polled parameter words goes in the transposed LDS image (mfma_minibatch: rows of W1^T, then
   // of W2^T, H + 4 floats apart); the same every step
@@ -4854,7 +4861,7 @@ static int64_t ppo_ws_plain_floats(const ia_policy_desc* d, int batch, int64_t g
 int64_t ia_ppo_ws_floats(const ia_policy_desc* d, int batch, int64_t gather_rows) {
   if (!pol_ok(d) || batch <= 0 || gather_rows < batch) return IA_ERR_ARG;
   const int P = pol_offsets(d->obs_dim, d->act_dim, d->hidden, d->discrete).total;
-  const int64_t ll = d->hidden == 64 ? 2 * epoch_ll_words(cdiv(batch, ROWS), P) : 0;   // (64-wide towers: the word exchange)
+  const int64_t ll = d->hidden == 64 ? 2 * epoch_ll_words(epoch_ll_row_blocks(cdiv(batch, ROWS), P), P) : 0;   // (64-wide towers: the word exchange)
   return ppo_ws_plain_floats(d, batch, gather_rows) + ll;
 }
 
@@ -5138,12 +5145,16 @@ static int ppo_epochs_impl(const ia_policy_desc* d, float* params, float* params
   // both fit: 2 nrb workgroups co-resident, chunks of <= 4 x 256 parameters, the larger tower's images beside its tiles
   const int tlen = 64 * d->obs_dim + 64 + 64 * 64 + 64, lenB = std::max(po.cW - po.aW, P - po.cW) + 3;
   const size_t sbytes = (size_t)(((GLds<64, 1>::total + 3) & ~3) + 2 * tlen + 4 * d->obs_dim + 128 + lenB + MAXA) * sizeof(float);
-  const bool split = one_launch && !g_epoch_whole && 2 * nrb <= dev_cus && 2 * nrb <= 64 && cdiv(P, 2 * nrb) <= 4 * 256 &&
-                     sbytes <= EPOCH_SPLIT_LDS;
-  // the word-exchange form of the one-tower kernel (no grid barriers); its word areas sit behind everything else in ws
-  const bool llx = split && !g_epoch_barriers && sbytes + 16 <= EPOCH_LL_LDS && nrb <= 32;
+  const bool towers_fit = one_launch && !g_epoch_whole && 2 * nrb <= dev_cus && 2 * nrb <= 64;
+  // the word-exchange form of the one-tower kernel (no grid barriers); its word areas sit behind everything else in ws.
+  // Small minibatches (down to ONE row block: SB3's default batch_size = 64): the launch has as many workgroups as it takes
+  // for chunks of <= 1 024 parameters -- those beyond the row blocks run no gradient phase, they sum, clip and step their
+  // chunk (`epoch_ll_row_blocks`)
+  const int nrb_l = epoch_ll_row_blocks(nrb, P);
+  const bool llx = towers_fit && !g_epoch_barriers && sbytes + 16 <= EPOCH_LL_LDS && nrb_l <= 32 && 2 * nrb_l <= dev_cus;
+  const bool split = towers_fit && sbytes <= EPOCH_SPLIT_LDS && (llx || cdiv(P, 2 * nrb) <= 4 * 256);
   unsigned long long* ll_base = llx ? reinterpret_cast<unsigned long long*>(ws + ppo_ws_plain_floats(d, size_at(0), total)) : nullptr;
-  int rc = launch_gather(a, perm, total, g, ll_base, llx ? epoch_ll_words(nrb, P) : 0,
+  int rc = launch_gather(a, perm, total, g, ll_base, llx ? epoch_ll_words(nrb_l, P) : 0,
                          llx ? reinterpret_cast<unsigned*>(ws) + 4 : nullptr);   // (words 4, 5, 6: counter, error word, ticket)
   if (rc) return rc;
   // statistics of every minibatch of the epoch, one launch ahead of the chain (ppo_epoch_stats_kernel)
@@ -5166,7 +5177,7 @@ static int ppo_epochs_impl(const ia_policy_desc* d, float* params, float* params
   if (one_launch) {
     // one launch per (<= 64 minibatches of the) epoch when every gradient workgroup can be resident at once
     const int nwg = split ? 2 * nrb : nrb;
-    if (nwg <= dev_cus && nwg <= 64 && cdiv(P, nwg) <= 4 * (split ? 256 : 512)) {
+    if (llx || (nwg <= dev_cus && nwg <= 64 && cdiv(P, nwg) <= 4 * (split ? 256 : 512))) {
       static bool attr = false, attr_s = false;
       const size_t mbytes = split ? sbytes : GLds<64>::total * sizeof(float);
       if (llx) {
@@ -5190,7 +5201,7 @@ static int ppo_epochs_impl(const ia_policy_desc* d, float* params, float* params
             es.step_size[k] = (float)(lr / (1.0 - pow(beta1, (double)step)));
             es.bc2_sqrt[k] = (float)sqrt(1.0 - pow(beta2, (double)step));
           }
-          hipLaunchKernelGGL(kern, dim3(nwg), dim3(256), sbytes + 16, a.st, *d, params, params_t, exp_avg, exp_avg_sq, norm_mean,
+          hipLaunchKernelGGL(kern, dim3(2 * nrb_l), dim3(256), sbytes + 16, a.st, *d, params, params_t, exp_avg, exp_avg_sq, norm_mean,
                              norm_var, g.obs, g.act, g.logp, g.adv, g.ret, total, batch_size, T, n_envs, normalize_adv,
                              clip_range, ent_coef, vf_coef, max_grad_norm, (float)beta1, (float)beta2, adam_eps, ws, el, seq,
                              snap ? 1 : 0, stats, es, g_epoch_dbg);

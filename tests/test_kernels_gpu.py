@@ -471,6 +471,11 @@ def test_timeout_bootstrap():
                                                         # (minibatch steps as phases between grid barriers)
                                                         (17, 6, 64, False, True, 16, 256, 1024),
                                                         (4, 2, 64, True, True, 9, 100, 384),
+                                                        # ... down to ONE row block per minibatch (SB3's default batch_size
+                                                        # = 64: two workgroups, each owning half the parameters -- the
+                                                        # 20-per-thread chunk form) and two row blocks
+                                                        (4, 2, 64, True, True, 16, 8, 64),
+                                                        (17, 6, 64, False, True, 8, 32, 128),
                                                         # minibatches of <= 16 rows (the reference's tuned AIRL file): the
                                                         # one-workgroup kernel whose waves of rows 16.. idle; Ant width,
                                                         # and a Discrete head with a short last minibatch
