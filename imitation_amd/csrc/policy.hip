@@ -2833,7 +2833,9 @@ __device__ __forceinline__ void policy_act_body(
     const float* __restrict__ nv, const float* __restrict__ obs, int n, const float* __restrict__ noise,
     const float* __restrict__ low, const float* __restrict__ high, float* __restrict__ actions,
     float* __restrict__ clipped, float* __restrict__ values, float* __restrict__ logp, const int blk,
-    float* __restrict__ lds, const int oz = 0) {
+    float* __restrict__ lds, const int oz = 0, float* __restrict__ logits_out = nullptr) {
+  // `logits_out` (host-sampled Discrete rollout step, `ia_policy_logits*`): the head outputs [n, A] and the values are all
+  // that is wanted -- nothing is sampled.
   // `oz`: an opaque zero when the body sits inside the mailbox kernel's step loop -- its per-lane offsets and the weight
   // fragments are then re-derived per step instead of being hoisted out of the loop (71 spilled registers at H = 64)
   constexpr int NC = H / 16, KS = H / 4;
@@ -2985,6 +2987,10 @@ __device__ __forceinline__ void policy_act_body(
   const int row = i0 + q * 16 + lane;
   if (lane >= 16 || row >= n) return;
   const float* outrow = lds + L::out + (q * 16 + lane) * L::AS;
+  if (logits_out != nullptr) {
+    for (int a = 0; a < A; ++a) logits_out[(long long)row * A + a] = outrow[a];
+    return;
+  }
   if constexpr (EVAL) {
     float* entropy = clipped;
     if (!d.discrete) {
@@ -3109,6 +3115,39 @@ __global__ __launch_bounds__(512) void policy_rollout_mailbox_kernel(
     policy_act_body<H, true>(d, P, Pt, nm, nv, mb.obs + mb.T * mb.s_obs, n, nullptr, nullptr, nullptr, nullptr, nullptr,
                              mb.last_val, nullptr, blockIdx.x, lds);
     mailbox_ack(mb.done, mb.T + 1);
+  }
+}
+
+// The host-sampled Discrete step on the MFMA body (one 512-thread workgroup per 64 rows, both towers at once): logits
+// [n, A] + values. The thread-per-row kernels above (policy_logits_kernel / policy_logits_mailbox_kernel) take ~30 us for
+// a 64-wide policy -- 2 x 4 500 dependent FMAs per row with every weight a load -- which was HALF of an 8-environment
+// rollout step (BASELINE config 1); kept behind `ia_ppo_force_valu`.
+template <int H>
+__global__ __launch_bounds__(512) void policy_logits_mfma_kernel(
+    ia_policy_desc d, const float* __restrict__ P, const float* __restrict__ Pt, const float* __restrict__ nm,
+    const float* __restrict__ nv, const float* __restrict__ obs, int n, float* __restrict__ logits,
+    float* __restrict__ values) {
+  extern __shared__ float lds[];
+  policy_act_body<H, false>(d, P, Pt, nm, nv, obs, n, nullptr, nullptr, nullptr, nullptr, nullptr, values, nullptr,
+                            blockIdx.x, lds, 0, logits);
+}
+
+template <int H>
+__global__ __launch_bounds__(512) void policy_logits_mailbox_mfma_kernel(
+    ia_policy_desc d, const float* __restrict__ P, const float* __restrict__ Pt, const float* __restrict__ nm,
+    const float* __restrict__ nv, int n, LogitsMailbox mb) {
+  extern __shared__ float lds[];
+  __shared__ int s_go;
+  for (int t = 0; t < mb.T; ++t) {
+    if (!mailbox_wait(mb.ready, t, mb.timeout_ticks, &s_go)) {
+      if (threadIdx.x == 0) __hip_atomic_store(mb.done + blockIdx.x, -(t + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      return;
+    }
+    int oz = 0;   // (H = 64: see policy_rollout_mailbox_kernel)
+    if constexpr (H == 64) asm volatile("s_mov_b32 %0, 0" : "=s"(oz));
+    policy_act_body<H, false>(d, P + oz, Pt + oz, nm, nv, mb.obs + t * mb.s_obs, n, nullptr, nullptr, nullptr, nullptr, nullptr,
+                              mb.values + t * mb.s_val, nullptr, blockIdx.x + oz, lds, oz, mb.logits);
+    mailbox_ack(mb.done, t + 1);
   }
 }
 
@@ -4762,6 +4801,21 @@ int ia_policy_logits_mailbox(const ia_policy_desc* d, const float* params, const
   LogitsMailbox mb{obs, s_obs, logits, values, s_val, T, reinterpret_cast<const int*>(ready),
                    reinterpret_cast<int*>(done), (long long)(timeout_s * 1e8)};
   int rc;
+  if (!g_ppo_valu) {   // the MFMA body (both towers of 64 rows per 512-thread workgroup)
+    if (d->hidden == 32) {
+      const size_t bytes = ALds<32>::total * sizeof(float);
+      if ((rc = set_lds(policy_logits_mailbox_mfma_kernel<32>, bytes))) return rc;
+      hipLaunchKernelGGL(policy_logits_mailbox_mfma_kernel<32>, dim3(cdiv(n, ROWS)), dim3(512), bytes, (hipStream_t)stream, *d,
+                         params, params_t, norm_mean, norm_var, n, mb);
+    } else {
+      const size_t bytes = ALds<64>::total * sizeof(float);
+      if ((rc = set_lds(policy_logits_mailbox_mfma_kernel<64>, bytes))) return rc;
+      hipLaunchKernelGGL(policy_logits_mailbox_mfma_kernel<64>, dim3(cdiv(n, ROWS)), dim3(512), bytes, (hipStream_t)stream, *d,
+                         params, params_t, norm_mean, norm_var, n, mb);
+    }
+    IA_CHECK_LAUNCH();
+    return IA_OK;
+  }
   if (d->hidden == 32) {
     if ((rc = set_lds(policy_logits_mailbox_kernel<32>, lds_bytes<32>()))) return rc;
     hipLaunchKernelGGL(policy_logits_mailbox_kernel<32>, dim3(cdiv(n, ROWS)), dim3(ROWS), lds_bytes<32>(),
@@ -4813,6 +4867,21 @@ int ia_policy_logits(const ia_policy_desc* d, const float* params, const float* 
                      const float* norm_var, const float* obs, int n, float* logits, float* values, void* stream) {
   if (!pol_ok(d) || n <= 0 || !logits) return IA_ERR_ARG;
   int rc;
+  if (!g_ppo_valu) {   // the MFMA body: the same arithmetic as the mailbox kernel's steps
+    if (d->hidden == 32) {
+      const size_t bytes = ALds<32>::total * sizeof(float);
+      if ((rc = set_lds(policy_logits_mfma_kernel<32>, bytes))) return rc;
+      hipLaunchKernelGGL(policy_logits_mfma_kernel<32>, dim3(cdiv(n, ROWS)), dim3(512), bytes, (hipStream_t)stream, *d, params,
+                         params_t, norm_mean, norm_var, obs, n, logits, values);
+    } else {
+      const size_t bytes = ALds<64>::total * sizeof(float);
+      if ((rc = set_lds(policy_logits_mfma_kernel<64>, bytes))) return rc;
+      hipLaunchKernelGGL(policy_logits_mfma_kernel<64>, dim3(cdiv(n, ROWS)), dim3(512), bytes, (hipStream_t)stream, *d, params,
+                         params_t, norm_mean, norm_var, obs, n, logits, values);
+    }
+    IA_CHECK_LAUNCH();
+    return IA_OK;
+  }
   if (d->hidden == 32) {
     if ((rc = set_lds(policy_logits_kernel<32>, lds_bytes<32>()))) return rc;
     hipLaunchKernelGGL(policy_logits_kernel<32>, dim3(cdiv(n, ROWS)), dim3(ROWS), lds_bytes<32>(),
