@@ -37,6 +37,27 @@ class PolicyDesc(C.Structure):
                 ("has_norm", C.c_int), ("norm_eps", C.c_float)]
 
 
+class AirlUpdateArgs(C.Structure):
+    """Mirror of `ia_airl_update_args` (include/imitation_hip.h): one AIRL update of the fused shaped-net path."""
+    _fields_ = ([(n, C.c_void_p) for n in ("obs0", "act0_f32", "act0_i64", "next0", "done0", "idx0")] + [("n0", C.c_int)] +
+                [(n, C.c_void_p) for n in ("obs1", "act1_f32", "act1_i64", "next1", "done1", "idx1")] + [("n1", C.c_int)] +
+                [(n, C.c_int) for n in ("obs_dim", "act_dim", "use_state", "use_action", "use_next_state", "use_done")] +
+                [("Xb", C.c_void_p), ("ldb", C.c_int), ("Sn", C.c_void_p), ("Sc", C.c_void_p), ("ldp", C.c_int),
+                 ("dones", C.c_void_p)] +
+                [(n, C.c_void_p) for n in ("ws_b", "ws_n", "ws_c", "pol_obs", "pol_act")] +
+                [("Db", C.c_int), ("Dp", C.c_int)] +
+                [(n, C.c_void_p) for n in ("bmean", "bvar", "bcount", "pmean", "pvar", "pcount", "snapA", "merge_ticket")] +
+                [("pol", C.POINTER(PolicyDesc))] +
+                [(n, C.c_void_p) for n in ("pol_params", "pol_params_t", "pol_norm_mean", "pol_norm_var", "logp")] +
+                [("f_bmean", C.c_void_p), ("f_bvar", C.c_void_p), ("beps", C.c_float)] +
+                [(n, C.c_void_p) for n in ("pmeanA", "pvarA", "pmeanB", "pvarB")] + [("peps", C.c_float)] +
+                [("params_base", C.c_void_p), ("params_pot", C.c_void_p), ("gamma", C.c_float), ("scale", C.c_float),
+                 ("n_expert", C.c_int)] +
+                [("Ab", C.c_void_p), ("ldab", C.c_int), ("Db1", C.c_void_p), ("Ap", C.c_void_p), ("ldap", C.c_int)] +
+                [(n, C.c_void_p) for n in ("H1", "Dp1", "Dp2", "partials", "logits", "stats", "bce_part", "ticket")] +
+                [("adam", AdamArgs)])
+
+
 class DiscStepArgs(C.Structure):
     """Mirror of `ia_disc_step_args` (include/imitation_hip.h)."""
     _fields_ = ([("desc", C.POINTER(MlpDesc))] +
@@ -85,6 +106,7 @@ _SIGS = {
     "ia_airl_prepare": ([_P] * 6 + [_I] + [_P] * 6 + [_I] + [_I] * 6 + [_P, _I, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P],
                         C.c_int),
     "ia_airl_stats_merge": ([_P, _P, _P, _I, _L, _I, _I, _I] + [_P] * 9, C.c_int),
+    "ia_airl_round": ([C.POINTER(AirlUpdateArgs), _I, _P], C.c_int),
     "ia_airl_gp_shaped": ([_P, _I, _I, _P, _P, _I, _I, _P, _P, _P, _P, _F, _P, _P, _F, _P, _P, _I, _I, _I, _I, _I, _I, _F, _F,
                            _F, _I] + [_P] * 12, C.c_int),
     "ia_airl_step_shaped": ([_P, _I, _I, _P, _P, _I, _I, _P, _P, _P, _P, _F, _P, _P, _P, _P, _F, _P, _P, _F, _F, _I, _I,

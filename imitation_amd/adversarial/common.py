@@ -481,7 +481,12 @@ class AdversarialTrainer(abc.ABC):
                         th.cuda.current_stream().wait_event(after)
                     self._disc_t0 = th.cuda.Event(enable_timing=True)
                     self._disc_t0.record()
-                if self._round_one_call_ok(round_ws, did):
+                if self._airl_round_ok(drawn, did):
+                    # AIRL's fused shaped-net update: the round's updates in ONE C call too (`ia_airl_round`)
+                    self._airl_round_one_call(drawn, n, did)
+                    steps.extend(range(self._disc_step - n + 1, self._disc_step + 1))
+                    n = 0
+                elif self._round_one_call_ok(round_ws, did):
                     # every update of the round in ONE C call (`ia_disc_round_basic`): the launches of the loop below, its
                     # per-update host work (~110 us of Python each -- the round was bound by it) paid once
                     self._disc_round_one_call(round_ws, n)
@@ -525,6 +530,42 @@ class AdversarialTrainer(abc.ABC):
         pol = self.policy
         prn = pol.features_extractor.normalize if isinstance(pol, ActorCriticPolicy) else None
         return prn is None or not pol.training or bool(quirk_done)   # (else: a policy pass / moment copy per update)
+
+    def _airl_round_ok(self, drawn, quirk_done: bool) -> bool:
+        """The conditions under which `_disc_update` would take, for EVERY update of the round, AIRL's fused shaped-net update
+        (`fused_prepare` + `log_prob_rows` + `fused_finish` with the optimiser step inside) with nothing else in between."""
+        if (not self._needs_logp or not self.disc_round_one_call or self._dp is not None or self._module_net
+                or self.disc_grad_penalty_coef > 0.0 or self._torch_opt_params is not None
+                or self.demo_minibatch_size != self.demo_batch_size or not isinstance(self._disc_opt, HipAdam)):
+            return False
+        basic = self._reward_net
+        while isinstance(basic, reward_nets.PredictProcessedWrapper):
+            basic = basic.base
+        pol = self.policy
+        if (not isinstance(basic, reward_nets.ShapedRewardNet) or not basic.fused_step_ok()
+                or not isinstance(pol, ActorCriticPolicy) or not getattr(pol, "fused", False)):
+            return False
+        if any(e_idx is None or g_idx is None for (_, e_idx), (_, g_idx) in drawn):
+            return False
+        rn = pol.features_extractor.normalize
+        # a train-mode feature norm: every update's log pi(a|s) needs ITS snapshot of the statistics (the merge launch's)
+        return rn is None or not pol.training or (bool(quirk_done) and self._quirk_snap is not None)
+
+    def _airl_round_one_call(self, drawn, n: int, quirk_done: bool) -> None:
+        basic = self._reward_net
+        while isinstance(basic, reward_nets.PredictProcessedWrapper):
+            basic = basic.base
+        pol = self.policy
+        rn = pol.features_extractor.normalize
+        snaps = None
+        if rn is not None and pol.training:
+            snaps = self._quirk_snap[self._quirk_item:self._quirk_item + n]
+            self._quirk_item += n
+        with networks.training(self.reward_train):
+            logits = basic.airl_round_c(drawn, self.demo_batch_size, pol, self._pol_obs, self._pol_act, self._logp, snaps,
+                                        1.0, self._stats_ring, self._disc_opt)
+        self._disc_step += n
+        self._last_disc_logits = logits
 
     def _disc_round_one_call(self, round_ws, n: int) -> None:
         basic = self._reward_net

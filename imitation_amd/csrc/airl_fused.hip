@@ -1415,6 +1415,37 @@ int ia_airl_gp_shaped(const float* Xb, int ldb, int Db, const float* Sn, const f
   return ia_reduce_partials(partials, nblk, ptot, 1.0f, 1, grads, stream);
 }
 
+// A round's AIRL updates in ONE host call (`for _ in range(n_disc_updates_per_round): train_disc()`,
+// adversarial/common.py:454-458): update k = the four entries an update is made of, with a[k]'s arguments, in order. What
+// this removes is the per-update Python of the binding (four calls and their argument marshalling: ~150 us per update,
+// which made the AIRL round host-bound).
+int ia_airl_round(const ia_airl_update_args* a, int n, void* stream) {
+  if (!a || n <= 0) return IA_ERR_ARG;
+  for (int k = 0; k < n; ++k) {
+    const ia_airl_update_args& u = a[k];
+    const int R = u.n0 + u.n1;
+    int rc = ia_airl_prepare(u.obs0, u.act0_f32, u.act0_i64, u.next0, u.done0, u.idx0, u.n0, u.obs1, u.act1_f32, u.act1_i64,
+                             u.next1, u.done1, u.idx1, u.n1, u.obs_dim, u.act_dim, u.use_state, u.use_action, u.use_next_state,
+                             u.use_done, u.Xb, u.ldb, u.Sn, u.Sc, u.ldp, u.dones, u.ws_b, u.ws_n, u.ws_c, u.pol_obs, u.pol_act,
+                             stream);
+    if (rc) return rc;
+    if (u.ws_b || u.ws_n || u.ws_c) {
+      rc = ia_airl_stats_merge(u.ws_b, u.ws_n, u.ws_c, 1, 0, R, u.Db, u.Dp, u.bmean, u.bvar, u.bcount, u.pmean, u.pvar,
+                               u.pcount, u.snapA, u.merge_ticket, stream);
+      if (rc) return rc;
+    }
+    rc = ia_policy_evaluate(u.pol, u.pol_params, u.pol_params_t, u.pol_norm_mean, u.pol_norm_var, u.pol_obs, u.pol_act, R,
+                            u.logp, nullptr, nullptr, stream);
+    if (rc) return rc;
+    rc = ia_airl_step_shaped(u.Xb, u.ldb, u.Db, u.Sn, u.Sc, u.ldp, u.Dp, u.dones, u.logp, u.f_bmean, u.f_bvar, u.beps, u.pmeanA,
+                             u.pvarA, u.pmeanB, u.pvarB, u.peps, u.params_base, u.params_pot, u.gamma, u.scale, R, u.n_expert,
+                             u.Ab, u.ldab, u.Db1, u.Ap, u.ldap, u.H1, u.Dp1, u.Dp2, u.partials, u.logits, u.stats, u.bce_part,
+                             u.ticket, &u.adam, stream);
+    if (rc) return rc;
+  }
+  return IA_OK;
+}
+
 }  // extern "C"
 
 // ---- the 32-wide BasicRewardNet behind the fused entry points of disc_fused.hip (ia_disc_fused_ws_floats,

@@ -627,7 +627,7 @@ class ShapedRewardNet(ForwardWrapper):
         return bool(L.load().ia_airl_fused_ok(base.dims[0], pot.dims[0], base.dims[1], pot.dims[1], pot.dims[2]))
 
     def fused_prepare(self, sources, pol_obs: Optional[th.Tensor] = None, pol_act: Optional[th.Tensor] = None,
-                      dp=None) -> None:
+                      dp=None, _args_only: bool = False) -> None:
         """First half of one whole `train_disc` minibatch (= batch) of `common.py:317-374` for this net: the batch
         assembly (`ia_airl_prepare`: base inputs, next-state and state batches, dones -- and, when asked, the rows the
         generator policy's log pi(a|s) reads) and the train-mode input statistics (`ia_airl_stats_merge`; potential:
@@ -665,6 +665,9 @@ class ShapedRewardNet(ForwardWrapper):
         upd_p = pn is not None and pot.training
         pb = ws["ws_b"].data_ptr() if upd_b else None
         pnx, pc = (ws["ws_n"].data_ptr(), ws["ws_c"].data_ptr()) if upd_p else (None, None)
+        if _args_only:   # (`airl_round_c`: the workspace and what this call would have left in `_fused`, no launch)
+            self._fused = (ws, R, n0, upd_p)
+            return
         acts = lambda t: (None, t.acts.data_ptr()) if t.discrete else (t.acts.data_ptr(), None)
         st = L.stream()
         L.call("ia_airl_prepare", t0.obs.data_ptr(), *acts(t0), t0.next_obs.data_ptr(), t0.dones.data_ptr(), L.ptr(i0), n0,
@@ -686,6 +689,87 @@ class ShapedRewardNet(ForwardWrapper):
                    *((pn.running_mean.data_ptr(), pn.running_var.data_ptr(), pn.count.data_ptr()) if upd_p else (None,) * 3),
                    ws["snapA"].data_ptr(), ws["ticket"].data_ptr() + 4, st)
         self._fused = (ws, R, n0, upd_p)
+
+    def airl_round_c(self, drawn, mb: int, pol, pol_obs: th.Tensor, pol_act: th.Tensor, logp: th.Tensor, snaps,
+                     scale: float, stats_rows: th.Tensor, adam) -> th.Tensor:
+        """The n updates of one round (`drawn[k]` = ((expert table, index rows), (generator table, index rows)), `mb` rows
+        each) through ONE C call (`ia_airl_round`): per update the calls `fused_prepare` + `policy.log_prob_rows` +
+        `fused_finish` make, in their order, with the optimiser step fused. `snaps` `[n, 2, obs_dim]` (or None: the
+        policy's live statistics, which no update changes): the statistics update k's log pi(a|s) is normalised with.
+        Returns the logits of the last update."""
+        import ctypes as C
+        base, pot = self._base, self.potential._potential_net
+        bm = base.mlp
+        (t0, i0), (t1, i1) = drawn[0]
+        self.fused_prepare([(t0, i0, mb), (t1, i1, mb)], pol_obs, pol_act, _args_only=True)   # (workspace of this batch size)
+        ws, R, n0, upd_p = self._fused
+        bn, pn = bm.norm, pot.norm
+        upd_b = bn is not None and bm.training
+        if self._store.grad.numel() != bm.n_params + pot.n_params or self._store.flat.data_ptr() != bm.flat.data_ptr():
+            raise RuntimeError("the fused AIRL update needs a parameter store of exactly the reward and potential stacks")
+        if adam.flat.data_ptr() != bm.flat.data_ptr() or adam.flat.numel() != bm.n_params + pot.n_params:
+            raise RuntimeError("the fused AIRL update needs the optimiser over the net's flat parameter buffer")
+        t = L.AirlUpdateArgs()   # what no update of the round changes
+        for k, tb in enumerate((t0, t1)):
+            setattr(t, f"obs{k}", tb.obs.data_ptr())
+            setattr(t, f"act{k}_f32", None if tb.discrete else tb.acts.data_ptr())
+            setattr(t, f"act{k}_i64", tb.acts.data_ptr() if tb.discrete else None)
+            setattr(t, f"next{k}", tb.next_obs.data_ptr())
+            setattr(t, f"done{k}", tb.dones.data_ptr())
+            setattr(t, f"n{k}", mb)
+        t.obs_dim, t.act_dim = base.obs_dim, base.act_dim
+        t.use_state, t.use_action, t.use_next_state, t.use_done = ws["flags"]
+        t.Xb, t.ldb, t.Sn, t.Sc, t.ldp, t.dones = ws["out"]
+        t.ws_b = ws["ws_b"].data_ptr() if upd_b else None
+        t.ws_n, t.ws_c = (ws["ws_n"].data_ptr(), ws["ws_c"].data_ptr()) if upd_p else (None, None)
+        t.pol_obs, t.pol_act = L.ptr(pol_obs), L.ptr(pol_act)
+        t.Db, t.Dp = bm.dims[0], pot.dims[0]
+        if upd_b:
+            t.bmean, t.bvar, t.bcount = bn.running_mean.data_ptr(), bn.running_var.data_ptr(), bn.count.data_ptr()
+        if upd_p:
+            t.pmean, t.pvar, t.pcount = pn.running_mean.data_ptr(), pn.running_var.data_ptr(), pn.count.data_ptr()
+        t.snapA, t.merge_ticket = ws["snapA"].data_ptr(), ws["ticket"].data_ptr() + 4
+        t.pol = C.pointer(pol.desc)
+        t.pol_params, t.pol_params_t, t.logp = L.ptr(pol._flat), L.ptr(pol._flat_t), L.ptr(logp)
+        live_nm, live_nv = pol._norm_ptrs()
+        if bn is not None:
+            t.f_bmean, t.f_bvar, t.beps = bn.running_mean.data_ptr(), bn.running_var.data_ptr(), float(bn.eps)
+        if pn is not None:
+            t.pmeanB, t.pvarB, t.peps = pn.running_mean.data_ptr(), pn.running_var.data_ptr(), float(pn.eps)
+            t.pmeanA, t.pvarA = ((ws["snapA"].data_ptr(), ws["snapA"].data_ptr() + 4 * pot.dims[0]) if upd_p
+                                 else (t.pmeanB, t.pvarB))
+        t.params_base, t.params_pot = bm.flat.data_ptr(), pot.flat.data_ptr()
+        t.gamma, t.scale, t.n_expert = self.discount_factor, float(scale), mb
+        t.Ab, t.ldab, t.Db1, t.Ap, t.ldap = ws["Ab"].data_ptr(), bm.ldx, ws["Db1"].data_ptr(), ws["Ap"].data_ptr(), pot.ldx
+        t.H1, t.Dp1, t.Dp2 = ws["H1"].data_ptr(), ws["Dp1"].data_ptr(), ws["Dp2"].data_ptr()
+        t.partials, t.logits = ws["part"].data_ptr(), ws["logits"].data_ptr()
+        t.bce_part, t.ticket = ws["bce_part"].data_ptr(), ws["ticket"].data_ptr()
+        g = adam.param_groups[0]
+        b1, b2 = g["betas"]
+        t.adam.grads, t.adam.exp_avg, t.adam.exp_avg_sq = adam.grad.data_ptr(), adam.exp_avg.data_ptr(), adam.exp_avg_sq.data_ptr()
+        t.adam.beta1, t.adam.beta2, t.adam.eps, t.adam.weight_decay = b1, b2, g["eps"], g["weight_decay"]
+        n = len(drawn)
+        arr = ws.get("round_args")
+        if arr is None or len(arr) < n:
+            arr = ws["round_args"] = (L.AirlUpdateArgs * n)()
+        so = pol.obs_dim * 4
+        stats_base, stats_stride = stats_rows.data_ptr(), stats_rows.stride(0) * 4
+        snap_base = None if snaps is None else snaps.data_ptr()
+        for k in range(n):
+            a = arr[k]
+            C.memmove(C.byref(a), C.byref(t), C.sizeof(t))
+            (_, e_idx), (_, g_idx) = drawn[k]
+            a.idx0, a.idx1 = L.ptr(e_idx), L.ptr(g_idx)
+            a.stats = stats_base + k * stats_stride
+            if snap_base is None:
+                a.pol_norm_mean, a.pol_norm_var = live_nm, live_nv
+            else:
+                a.pol_norm_mean, a.pol_norm_var = snap_base + k * 2 * so, snap_base + k * 2 * so + so
+            adam.step_count += 1
+            a.adam.step_size = g["lr"] / (1.0 - b1 ** adam.step_count)
+            a.adam.bc2_sqrt = (1.0 - b2 ** adam.step_count) ** 0.5
+        L.call("ia_airl_round", arr, n, L.stream())
+        return ws["logits"]
 
     def fused_finish(self, logp: th.Tensor, scale: float, stats_dev: th.Tensor, adam) -> th.Tensor:
         """Second half: `ia_airl_step_shaped` on the prepared batch (forward, logits, BCE + statistics, deltas,

@@ -390,6 +390,41 @@ int ia_policy_evaluate(const ia_policy_desc* d, const float* params, const float
                        const float* norm_var, const float* obs, const float* actions, int n, float* logp,
                        float* values, float* entropy, void* stream);
 
+/* One AIRL discriminator update on the fused shaped-net path as ONE record -- the arguments of the four calls it is made
+ * of, in their order: ia_airl_prepare (batch assembly incl. the policy's rows), ia_airl_stats_merge (train-mode input
+ * statistics; skipped when ws_b, ws_n and ws_c are all NULL), ia_policy_evaluate (log pi(a|s) of the assembled rows under the
+ * statistics pol_norm_mean / pol_norm_var: common.py:606-615), ia_airl_step_shaped (forward, BCE, backward, reduction,
+ * Adam). Field names are the parameters' names of those entries. */
+typedef struct {
+  /* ia_airl_prepare */
+  const float* obs0; const float* act0_f32; const int64_t* act0_i64; const float* next0; const uint8_t* done0;
+  const int64_t* idx0; int n0;
+  const float* obs1; const float* act1_f32; const int64_t* act1_i64; const float* next1; const uint8_t* done1;
+  const int64_t* idx1; int n1;
+  int obs_dim, act_dim, use_state, use_action, use_next_state, use_done;
+  float* Xb; int ldb; float* Sn; float* Sc; int ldp; float* dones;
+  float* ws_b; float* ws_n; float* ws_c; float* pol_obs; float* pol_act;
+  /* ia_airl_stats_merge (one rank: groups = 1) */
+  int Db, Dp;
+  float* bmean; float* bvar; int32_t* bcount; float* pmean; float* pvar; int32_t* pcount; float* snapA;
+  unsigned* merge_ticket;
+  /* ia_policy_evaluate */
+  const ia_policy_desc* pol; const float* pol_params; const float* pol_params_t; const float* pol_norm_mean;
+  const float* pol_norm_var; float* logp;
+  /* ia_airl_step_shaped (Xb ... dones, logp as above) */
+  const float* f_bmean; const float* f_bvar; float beps;
+  const float* pmeanA; const float* pvarA; const float* pmeanB; const float* pvarB; float peps;
+  const float* params_base; const float* params_pot; float gamma; float scale; int n_expert;
+  float* Ab; int ldab; float* Db1; float* Ap; int ldap; float* H1; float* Dp1; float* Dp2;
+  float* partials; float* logits; float* stats; float* bce_part; unsigned* ticket;
+  ia_adam_args adam;   /* the reduction + Adam step of this update (its step_size / bc2_sqrt) */
+} ia_airl_update_args;
+/* The n updates of one round (`for _ in range(n_disc_updates_per_round): train_disc()`, adversarial/common.py:454-458)
+ * for AIRL's fused shaped-net update, in one host call: update k = the four calls above with a[k], in order; stops at the
+ * first error. */
+int ia_airl_round(const ia_airl_update_args* a, int n, void* stream);
+
+
 /* Head outputs only: logits[n, act_dim] = action_net(latent_pi) (Categorical logits / Gaussian means) and,
  * when values != NULL, the value head. For host-side sampling with the reference's own RNG call:
  * [SB3 CategoricalDistribution.sample] = torch.multinomial on torch's global CPU generator

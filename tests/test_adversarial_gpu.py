@@ -157,7 +157,8 @@ def test_all_epochs_in_one_call_equal_one_call_per_epoch(tmp_path):
         assert np.array_equal(np.asarray(outs[True][k]), np.asarray(outs[False][k]), equal_nan=True), k
 
 
-@pytest.mark.parametrize("case,penalty", [("gail_fused", 0.0), ("gail_fused", 4.0), ("gail_box", 0.0)])
+@pytest.mark.parametrize("case,penalty", [("gail_fused", 0.0), ("gail_fused", 4.0), ("gail_box", 0.0), ("airl_box", 0.0),
+                                          ("airl_towers", 0.0)])
 def test_round_of_updates_in_one_call_is_bit_identical(tmp_path, case, penalty):
     """A pre-assembled round's n discriminator updates through ONE C call (`ia_disc_round_basic`, default) against one
     `ia_disc_step_basic` call per update: same launches in the same order -> every array of the trainer snapshot, the
@@ -178,8 +179,9 @@ def test_round_of_updates_in_one_call_is_bit_identical(tmp_path, case, penalty):
         tr.disc_round_one_call = mode
         tr.disc_grad_penalty_coef = penalty
         calls = []
-        orig = tr._disc_round_one_call
+        orig, orig_airl = tr._disc_round_one_call, tr._airl_round_one_call
         tr._disc_round_one_call = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+        tr._airl_round_one_call = lambda *a, **k: (calls.append(1), orig_airl(*a, **k))[1]
         th.manual_seed(77)
         tr.train(3 * cfg["n_envs"] * cfg["n_steps"])
         th.cuda.synchronize()
@@ -190,8 +192,8 @@ def test_round_of_updates_in_one_call_is_bit_identical(tmp_path, case, penalty):
         tr.logger.close()
         logs[mode] = {os.path.relpath(f, d): _csv_rows(f) for f in sorted(glob.glob(os.path.join(d, "**", "*.csv"),
                                                                                 recursive=True))}
-    if case == "gail_fused":
-        assert used[True] >= 2 and used[False] == 0, used   # (the fused shape takes the one-call round)
+    if case in ("gail_fused", "airl_box"):
+        assert used[True] >= 2 and used[False] == 0, used   # (the fused shapes take the one-call round)
     for k in outs[True]:
         assert np.array_equal(np.asarray(outs[True][k]), np.asarray(outs[False][k]), equal_nan=True), k
     for f in logs[True]:
