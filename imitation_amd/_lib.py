@@ -107,6 +107,7 @@ _SIGS = {
                         C.c_int),
     "ia_airl_stats_merge": ([_P, _P, _P, _I, _L, _I, _I, _I] + [_P] * 9, C.c_int),
     "ia_airl_round": ([C.POINTER(AirlUpdateArgs), _I, _P], C.c_int),
+    "ia_obs_moments_round": ([_P, _P, _I, _P, _P, _I, _I, _I, _L, _P, _I, _P, _L, _P], C.c_int),
     "ia_airl_gp_shaped": ([_P, _I, _I, _P, _P, _I, _I, _P, _P, _P, _P, _F, _P, _P, _F, _P, _P, _I, _I, _I, _I, _I, _I, _F, _F,
                            _F, _I] + [_P] * 12, C.c_int),
     "ia_airl_step_shaped": ([_P, _I, _I, _P, _P, _I, _I, _P, _P, _P, _P, _F, _P, _P, _P, _P, _F, _P, _P, _F, _F, _I, _I,

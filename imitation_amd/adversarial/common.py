@@ -971,6 +971,8 @@ class AdversarialTrainer(abc.ABC):
         if self._quirk_seq is None or self._quirk_seq.shape != (n_items, need):
             self._quirk_seq = th.empty(n_items, need, device=self._device)
         k = 0
+        if self._quirk_prepass_one_launch(drawn, need):
+            drawn = ()   # (every batch's moments are in `_quirk_seq`: nothing left for the per-update launches below)
         for (e_tab, e_idx), (g_tab, g_idx) in drawn:
             for start in range(0, B, mb):
                 row = 0
@@ -993,6 +995,33 @@ class AdversarialTrainer(abc.ABC):
             stride = groups * need
         self._quirk_seq_merged = seq
         self._quirk_pending.append(("seq", n_items, stride, groups, 2 * mb, pol.obs_dim))
+        return True
+
+    def _quirk_prepass_one_launch(self, drawn, need: int) -> bool:
+        """The observation-column moments of ALL the round's batches in one launch (`ia_obs_moments_round`) instead of two
+        gathers + one moment launch per update -- when every update is one minibatch on the same two tables and its index
+        rows are the round's contiguous ring rows (the pipelined schedule). Same layout, same arithmetic."""
+        B, mb = self.demo_batch_size, self.demo_minibatch_size
+        if mb != B or not drawn:
+            return False
+        (e_tab, e0), (g_tab, g0) = drawn[0]
+        if e0 is None or g0 is None:
+            return False
+        base, step = e0.data_ptr(), 2 * B * 8
+        for k, ((et, ei), (gt, gi)) in enumerate(drawn):
+            if (et is not e_tab or gt is not g_tab or ei is None or gi is None or ei.data_ptr() != base + k * step
+                    or gi.data_ptr() != base + k * step + B * 8):
+                return False
+        od = self.policy.obs_dim
+        if (e_tab.obs.dtype != th.float32 or g_tab.obs.dtype != th.float32 or e_tab.obs.shape[1:] != (od,)
+                or g_tab.obs.shape[1:] != (od,) or not e_tab.obs.is_contiguous() or not g_tab.obs.is_contiguous()):
+            return False
+        n, ldx = len(drawn), (od + 3) // 4 * 4
+        x = getattr(self, "_quirk_rows", None)
+        if x is None or x.numel() < n * 2 * B * ldx:
+            x = self._quirk_rows = th.empty(n * 2 * B * ldx, device=self._device)
+        L.call("ia_obs_moments_round", L.ptr(e_tab.obs), base, B, L.ptr(g_tab.obs), base + B * 8, B, od, n, 2 * B, L.ptr(x), ldx,
+               L.ptr(self._quirk_seq), need, L.stream())
         return True
 
     def _replay_policy_norm_updates(self, snapshots: bool = False) -> None:

@@ -1510,6 +1510,29 @@ int ia_disc32_assemble(const ia_disc_step_args* a, int n_updates, int64_t idx_st
   return IA_OK;
 }
 
+// Slab moments of the OBSERVATION columns of a round's batches in ONE launch: what the policy's train-mode feature
+// RunningNorm absorbs when `train_disc` evaluates log pi(a|s) on a batch (common.py:606-615) depends on the
+// sampled rows only, so the moments of all n_updates batches are taken ahead of the updates (ia_running_norm_merge_seq
+// then applies them in order and keeps the per-update snapshots). Batch k = rows idx0 + k*idx_stride (n0, first table) then
+// idx1 + k*idx_stride (n1, second table); X [n_updates][n0+n1][ldx] is scratch for the gathered rows; rn_ws + k*rn_stride
+// receives batch k's moments in ia_running_norm_partial's layout and arithmetic. (Before: two gathers and one moment
+// launch per update.)
+extern "C" int ia_obs_moments_round(const float* obs0, const int64_t* idx0, int n0, const float* obs1, const int64_t* idx1,
+                                    int n1, int obs_dim, int n_updates, int64_t idx_stride, float* X, int ldx, float* rn_ws,
+                                    int64_t rn_stride, void* stream) {
+  if (!obs0 || !obs1 || !idx0 || !idx1 || !X || !rn_ws || obs_dim < 1 || ldx < obs_dim) return IA_ERR_ARG;
+  ia_mlp_desc d{};
+  d.n_layers = 1;
+  d.dims[0] = obs_dim;
+  ia_disc_step_args a{};
+  a.desc = &d;
+  a.obs0 = obs0; a.idx0 = idx0; a.n0 = n0;
+  a.obs1 = obs1; a.idx1 = idx1; a.n1 = n1;
+  a.obs_dim = obs_dim; a.act_dim = 0; a.use_state = 1;
+  a.X = X; a.ldx = ldx;
+  return ia_disc32_assemble(&a, n_updates, idx_stride, (int64_t)(n0 + n1) * ldx, rn_stride, rn_ws, (hipStream_t)stream);
+}
+
 // One minibatch of train_disc for the 32-wide stack: the contract of ia_disc_step_basic (assemble unless pre_assembled,
 // train-mode statistics, forward + BCE + backward with the weight gradients in ONE launch, slab reduction (+ Adam)).
 int ia_disc32_step(const ia_disc_step_args* a, void* stream_) {

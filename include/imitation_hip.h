@@ -390,6 +390,15 @@ int ia_policy_evaluate(const ia_policy_desc* d, const float* params, const float
                        const float* norm_var, const float* obs, const float* actions, int n, float* logp,
                        float* values, float* entropy, void* stream);
 
+/* Slab moments of the observation columns of a round's n_updates batches in one launch (the policy's train-mode feature
+ * RunningNorm side effect of train_disc's log pi(a|s) evaluation, common.py:606-615, taken ahead of the updates): batch k =
+ * rows idx0 + k*idx_stride (n0 of the first table) then idx1 + k*idx_stride (n1 of the second); X [n_updates][n0+n1][ldx]
+ * scratch; rn_ws + k*rn_stride <- batch k's moments (ia_running_norm_partial's layout and arithmetic; feed
+ * ia_running_norm_merge_seq). */
+int ia_obs_moments_round(const float* obs0, const int64_t* idx0, int n0, const float* obs1, const int64_t* idx1, int n1,
+                         int obs_dim, int n_updates, int64_t idx_stride, float* X, int ldx, float* rn_ws, int64_t rn_stride,
+                         void* stream);
+
 /* One AIRL discriminator update on the fused shaped-net path as ONE record -- the arguments of the four calls it is made
  * of, in their order: ia_airl_prepare (batch assembly incl. the policy's rows), ia_airl_stats_merge (train-mode input
  * statistics; skipped when ws_b, ws_n and ws_c are all NULL), ia_policy_evaluate (log pi(a|s) of the assembled rows under the
