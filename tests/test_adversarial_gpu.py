@@ -264,10 +264,12 @@ def test_fused_airl_update_matches_the_general_schedule(over, tmp_path, monkeypa
     input normalisation)."""
     from imitation_amd import reward_nets as rn
 
-    calls = []
-    orig = rn.ShapedRewardNet.fused_finish
+    calls = []   # fused updates made: one per `fused_finish`, a round's worth per `airl_round_c` (the one-call round)
+    orig, orig_round = rn.ShapedRewardNet.fused_finish, rn.ShapedRewardNet.airl_round_c
     monkeypatch.setattr(rn.ShapedRewardNet, "fused_finish",
                         lambda self, *a, **k: (calls.append(1), orig(self, *a, **k))[1])
+    monkeypatch.setattr(rn.ShapedRewardNet, "airl_round_c",
+                        lambda self, drawn, *a, **k: (calls.extend([1] * len(drawn)), orig_round(self, drawn, *a, **k))[1])
     cfg = dict(harness.CASES["airl_box"], **over)
     outs = {}
     for fused in (True, False):
