@@ -55,7 +55,11 @@ class AirlUpdateArgs(C.Structure):
                  ("n_expert", C.c_int)] +
                 [("Ab", C.c_void_p), ("ldab", C.c_int), ("Db1", C.c_void_p), ("Ap", C.c_void_p), ("ldap", C.c_int)] +
                 [(n, C.c_void_p) for n in ("H1", "Dp1", "Dp2", "partials", "logits", "stats", "bce_part", "ticket")] +
-                [("adam", AdamArgs)])
+                [("adam", AdamArgs)] +
+                [("gp_e", C.c_void_p), ("gp_coef", C.c_float), ("gp_target", C.c_float), ("n_slabs", C.c_int),
+                 ("n_params", C.c_int64)] +
+                [(n, C.c_void_p) for n in ("U1b", "Cb", "U1p", "Cp", "U2p", "V1p", "gp_partials", "pen_part", "pen_out",
+                                           "gp_ticket")])
 
 
 class DiscStepArgs(C.Structure):

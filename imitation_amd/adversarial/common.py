@@ -535,7 +535,7 @@ class AdversarialTrainer(abc.ABC):
         """The conditions under which `_disc_update` would take, for EVERY update of the round, AIRL's fused shaped-net update
         (`fused_prepare` + `log_prob_rows` + `fused_finish` with the optimiser step inside) with nothing else in between."""
         if (not self._needs_logp or not self.disc_round_one_call or self._dp is not None or self._module_net
-                or self.disc_grad_penalty_coef > 0.0 or self._torch_opt_params is not None
+                or self._torch_opt_params is not None
                 or self.demo_minibatch_size != self.demo_batch_size or not isinstance(self._disc_opt, HipAdam)):
             return False
         basic = self._reward_net
@@ -561,9 +561,21 @@ class AdversarialTrainer(abc.ABC):
         if rn is not None and pol.training:
             snaps = self._quirk_snap[self._quirk_item:self._quirk_item + n]
             self._quirk_item += n
+        gp = None
+        if self.disc_grad_penalty_coef > 0.0:
+            # interpolation weights: torch's global CPU generator, one `th.rand(mb)` per update in update order (the draws of
+            # the per-update loop: the first through the ring, the rest as one block)
+            mb = self.demo_batch_size
+            es = [self._gp_weights(mb)]
+            if n > 1:
+                self._gp_predraw_for_round(n - 1)
+                es += [self._gp_weights(mb) for _ in range(n - 1)]
+            gp = (es, self.disc_grad_penalty_coef, self.disc_grad_penalty_target)
         with networks.training(self.reward_train):
             logits = basic.airl_round_c(drawn, self.demo_batch_size, pol, self._pol_obs, self._pol_act, self._logp, snaps,
-                                        1.0, self._stats_ring, self._disc_opt)
+                                        1.0, self._stats_ring, self._disc_opt, gp=gp)
+        if gp is not None:
+            self.last_grad_penalty = basic._fused[0]["gp"]["pen"][0]
         self._disc_step += n
         self._last_disc_logits = logits
 

@@ -1437,11 +1437,24 @@ int ia_airl_round(const ia_airl_update_args* a, int n, void* stream) {
     rc = ia_policy_evaluate(u.pol, u.pol_params, u.pol_params_t, u.pol_norm_mean, u.pol_norm_var, u.pol_obs, u.pol_act, R,
                             u.logp, nullptr, nullptr, stream);
     if (rc) return rc;
+    const bool gp = u.gp_e != nullptr;
     rc = ia_airl_step_shaped(u.Xb, u.ldb, u.Db, u.Sn, u.Sc, u.ldp, u.Dp, u.dones, u.logp, u.f_bmean, u.f_bvar, u.beps, u.pmeanA,
                              u.pvarA, u.pmeanB, u.pvarB, u.peps, u.params_base, u.params_pot, u.gamma, u.scale, R, u.n_expert,
                              u.Ab, u.ldab, u.Db1, u.Ap, u.ldap, u.H1, u.Dp1, u.Dp2, u.partials, u.logits, u.stats, u.bce_part,
-                             u.ticket, &u.adam, stream);
+                             u.ticket, gp ? nullptr : &u.adam, stream);
     if (rc) return rc;
+    if (gp) {   // the penalty's gradient on top of the reduced BCE gradient, then the optimiser step
+      if (u.n0 != u.n1) return IA_ERR_ARG;
+      if ((rc = ia_reduce_partials(u.partials, u.n_slabs, u.n_params, 1.0f, 0, u.adam.grads, stream))) return rc;
+      rc = ia_airl_gp_shaped(u.Xb, u.ldb, u.Db, u.Sn, u.Sc, u.ldp, u.Dp, u.dones, u.gp_e, u.f_bmean, u.f_bvar, u.beps, u.pmeanB,
+                             u.pvarB, u.peps, u.params_base, u.params_pot, u.obs_dim, u.act_dim, u.use_state, u.use_action,
+                             u.use_next_state, u.use_done, u.gamma, u.gp_coef, u.gp_target, u.n0, u.U1b, u.Cb, u.U1p, u.Cp,
+                             u.U2p, u.V1p, u.gp_partials, u.pen_part, u.pen_out, u.gp_ticket, u.adam.grads, stream);
+      if (rc) return rc;
+      rc = ia_adam_step(const_cast<float*>(u.params_base), u.adam.grads, u.adam.exp_avg, u.adam.exp_avg_sq, u.n_params,
+                        u.adam.beta1, u.adam.beta2, u.adam.eps, u.adam.weight_decay, u.adam.step_size, u.adam.bc2_sqrt, stream);
+      if (rc) return rc;
+    }
   }
   return IA_OK;
 }

@@ -691,11 +691,13 @@ class ShapedRewardNet(ForwardWrapper):
         self._fused = (ws, R, n0, upd_p)
 
     def airl_round_c(self, drawn, mb: int, pol, pol_obs: th.Tensor, pol_act: th.Tensor, logp: th.Tensor, snaps,
-                     scale: float, stats_rows: th.Tensor, adam) -> th.Tensor:
+                     scale: float, stats_rows: th.Tensor, adam, gp=None) -> th.Tensor:
         """The n updates of one round (`drawn[k]` = ((expert table, index rows), (generator table, index rows)), `mb` rows
         each) through ONE C call (`ia_airl_round`): per update the calls `fused_prepare` + `policy.log_prob_rows` +
         `fused_finish` make, in their order, with the optimiser step fused. `snaps` `[n, 2, obs_dim]` (or None: the
         policy's live statistics, which no update changes): the statistics update k's log pi(a|s) is normalised with.
+        `gp = ([n] device weight vectors, coef, target)`: the opt-in gradient penalty of every update (`fused_grad_penalty`
+        between the slab reduction and the optimiser step; its mean of the last update is in `self._fused[0]["gp"]["pen"]`).
         Returns the logits of the last update."""
         import ctypes as C
         base, pot = self._base, self.potential._potential_net
@@ -748,6 +750,12 @@ class ShapedRewardNet(ForwardWrapper):
         b1, b2 = g["betas"]
         t.adam.grads, t.adam.exp_avg, t.adam.exp_avg_sq = adam.grad.data_ptr(), adam.exp_avg.data_ptr(), adam.exp_avg_sq.data_ptr()
         t.adam.beta1, t.adam.beta2, t.adam.eps, t.adam.weight_decay = b1, b2, g["eps"], g["weight_decay"]
+        if gp is not None:
+            gws = self._gp_workspace(ws, mb)
+            t.gp_coef, t.gp_target, t.n_slabs, t.n_params = float(gp[1]), float(gp[2]), ws["nblk"], bm.n_params + pot.n_params
+            for fld, key in (("U1b", "U1b"), ("Cb", "Cb"), ("U1p", "U1p"), ("Cp", "Cp"), ("U2p", "U2p"), ("V1p", "V1p"),
+                             ("gp_partials", "part"), ("pen_part", "pen_part"), ("pen_out", "pen"), ("gp_ticket", "ticket")):
+                setattr(t, fld, gws[key].data_ptr())
         n = len(drawn)
         arr = ws.get("round_args")
         if arr is None or len(arr) < n:
@@ -768,8 +776,25 @@ class ShapedRewardNet(ForwardWrapper):
             adam.step_count += 1
             a.adam.step_size = g["lr"] / (1.0 - b1 ** adam.step_count)
             a.adam.bc2_sqrt = (1.0 - b2 ** adam.step_count) ** 0.5
+            if gp is not None:
+                a.gp_e = L.ptr(gp[0][k])
         L.call("ia_airl_round", arr, n, L.stream())
         return ws["logits"]
+
+    def _gp_workspace(self, ws, B: int):
+        """Work areas of `ia_airl_gp_shaped` for B interpolated rows (kept with the fused workspace of 2 B rows)."""
+        gws = ws.get("gp")
+        if gws is None:
+            bm, pot = self._base.mlp, self.potential._potential_net
+            dev = self.device
+            nblk = int(L.load().ia_airl_fused_slabs(B))
+            gws = ws["gp"] = dict(U1b=th.empty(B, 32, device=dev), Cb=th.empty(B, bm.ldx, device=dev),
+                                  U1p=th.empty(2 * B, 32, device=dev), Cp=th.empty(2 * B, pot.ldx, device=dev),
+                                  U2p=th.empty(2 * B, 32, device=dev), V1p=th.empty(2 * B, 32, device=dev),
+                                  part=th.zeros(nblk, bm.n_params + pot.n_params, device=dev),
+                                  pen_part=th.empty(nblk, device=dev), pen=th.empty(1, device=dev),
+                                  ticket=th.zeros(1, dtype=th.int32, device=dev))
+        return gws
 
     def fused_finish(self, logp: th.Tensor, scale: float, stats_dev: th.Tensor, adam) -> th.Tensor:
         """Second half: `ia_airl_step_shaped` on the prepared batch (forward, logits, BCE + statistics, deltas,
@@ -813,16 +838,7 @@ class ShapedRewardNet(ForwardWrapper):
         B = R // 2
         if n0 != B or R != 2 * B:
             raise ValueError("the gradient penalty interpolates expert and generator rows pairwise: equal halves needed")
-        gws = ws.get("gp")
-        if gws is None:
-            dev = self.device
-            nblk = int(L.load().ia_airl_fused_slabs(B))
-            gws = ws["gp"] = dict(U1b=th.empty(B, 32, device=dev), Cb=th.empty(B, bm.ldx, device=dev),
-                                  U1p=th.empty(2 * B, 32, device=dev), Cp=th.empty(2 * B, pot.ldx, device=dev),
-                                  U2p=th.empty(2 * B, 32, device=dev), V1p=th.empty(2 * B, 32, device=dev),
-                                  part=th.zeros(nblk, bm.n_params + pot.n_params, device=dev),
-                                  pen_part=th.empty(nblk, device=dev), pen=th.empty(1, device=dev),
-                                  ticket=th.zeros(1, dtype=th.int32, device=dev))
+        gws = self._gp_workspace(ws, B)
         bn, pn = bm.norm, pot.norm
         stat = lambda n: (n.running_mean.data_ptr(), n.running_var.data_ptr(), float(n.eps)) if n is not None else (None, None, 0.0)
         L.call("ia_airl_gp_shaped", ws["out"][0], bm.ldx, bm.dims[0], ws["out"][2], ws["out"][3], pot.ldx, pot.dims[0],

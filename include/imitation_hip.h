@@ -403,7 +403,8 @@ int ia_obs_moments_round(const float* obs0, const int64_t* idx0, int n0, const f
  * of, in their order: ia_airl_prepare (batch assembly incl. the policy's rows), ia_airl_stats_merge (train-mode input
  * statistics; skipped when ws_b, ws_n and ws_c are all NULL), ia_policy_evaluate (log pi(a|s) of the assembled rows under the
  * statistics pol_norm_mean / pol_norm_var: common.py:606-615), ia_airl_step_shaped (forward, BCE, backward, reduction,
- * Adam). Field names are the parameters' names of those entries. */
+ * Adam) -- with the opt-in gradient penalty: reduction, ia_airl_gp_shaped and the Adam step as three more calls. Field
+ * names are the parameters' names of those entries. */
 typedef struct {
   /* ia_airl_prepare */
   const float* obs0; const float* act0_f32; const int64_t* act0_i64; const float* next0; const uint8_t* done0;
@@ -427,6 +428,12 @@ typedef struct {
   float* Ab; int ldab; float* Db1; float* Ap; int ldap; float* H1; float* Dp1; float* Dp2;
   float* partials; float* logits; float* stats; float* bce_part; unsigned* ticket;
   ia_adam_args adam;   /* the reduction + Adam step of this update (its step_size / bc2_sqrt) */
+  /* opt-in gradient penalty (gp_e != NULL; n0 == n1 required): ia_airl_step_shaped then leaves the slabs, they are
+   * reduced into adam.grads (ia_reduce_partials), ia_airl_gp_shaped ADDS the penalty's gradient (its parameters' names
+   * below), and ia_adam_step over the n_params parameters at params_base closes the update */
+  const float* gp_e; float gp_coef; float gp_target; int n_slabs; int64_t n_params;
+  float* U1b; float* Cb; float* U1p; float* Cp; float* U2p; float* V1p; float* gp_partials; float* pen_part; float* pen_out;
+  unsigned* gp_ticket;
 } ia_airl_update_args;
 /* The n updates of one round (`for _ in range(n_disc_updates_per_round): train_disc()`, adversarial/common.py:454-458)
  * for AIRL's fused shaped-net update, in one host call: update k = the four calls above with a[k], in order; stops at the

@@ -158,7 +158,7 @@ def test_all_epochs_in_one_call_equal_one_call_per_epoch(tmp_path):
 
 
 @pytest.mark.parametrize("case,penalty", [("gail_fused", 0.0), ("gail_fused", 4.0), ("gail_box", 0.0), ("airl_box", 0.0),
-                                          ("airl_towers", 0.0)])
+                                          ("airl_box", 3.0), ("airl_towers", 0.0)])
 def test_round_of_updates_in_one_call_is_bit_identical(tmp_path, case, penalty):
     """A pre-assembled round's n discriminator updates through ONE C call (`ia_disc_round_basic`, default) against one
     `ia_disc_step_basic` call per update: same launches in the same order -> every array of the trainer snapshot, the
