@@ -346,7 +346,9 @@ class PPO(OnPolicyAlgorithm):
         self._n_mb = -(-total // self.batch_size)
         # policies outside the fused kernels' shapes (`general_policy.GeneralTowers`) run their own minibatch loop
         # (whole minibatches per epoch: room for every epoch's gathered rows, `ia_ppo_epochs` runs them as one sequence)
-        self._ppo_ws_epochs = self.n_epochs if (p.fused and total % self.batch_size == 0) else 1
+        # (... up to 4 M gathered rows: beyond that the per-epoch calls keep the workspace at one epoch's size)
+        self._ppo_ws_epochs = (self.n_epochs if (p.fused and total % self.batch_size == 0
+                                                 and self.n_epochs * total <= (1 << 22)) else 1)
         self.epochs_one_call = True   # (tuning / tests: False = one `ia_ppo_epoch` call per epoch)
         self._ppo_ws = th.empty(int(L.load().ia_ppo_ws_floats(C.byref(p.desc), min(self.batch_size, total),
                                                               self._ppo_ws_epochs * total)),
