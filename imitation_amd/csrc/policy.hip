@@ -5385,7 +5385,7 @@ int64_t ia_ppo_shard_recv_bytes(const ia_policy_desc* d, int world) {
   return 2 * (int64_t)world * (((P + 3) & ~3) + 8) * (int64_t)sizeof(unsigned long long);
 }
 
-bool g_upd_xcd_pack = true;   // several gradient workgroups that fit one XCD: packed there (ia_ppo_update_xcd_pack)
+bool g_upd_xcd_pack = false;   // opt-in (ia_ppo_update_xcd_pack): several gradient workgroups that fit one XCD packed there
 constexpr int HOST_TAB_SLOTS = 8;
 struct HostTab { float* buf = nullptr; hipEvent_t done; };
 HostTab g_host_tab[HOST_TAB_SLOTS];

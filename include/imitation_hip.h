@@ -622,10 +622,11 @@ int ia_ppo_epochs(const ia_policy_desc* d, float* params, float* params_t, float
  * ia_ppo_update_ws_floats returns 0 when the shape is not covered (use ia_ppo_epoch per epoch);
  * ws must be zeroed once by the caller, word 8 of it is a sticky error flag (a bounded grid wait
  * timed out: results invalid). stats: [n_epochs*n_minibatches][8] or NULL.
- * ia_ppo_update_xcd_pack(1) (default when there are several gradient workgroups and they fit one XCD's 32 CUs) launches
- * 8x the blocks so that the working ones share one XCD; the gradient workgroups then check their placement against each
- * other (XCC ids, one word exchange per launch) and, when they do sit on one XCD, store the step's (value, sequence) words at
- * workgroup scope -- L2-resident instead of one fabric write per word; 0 spreads the workgroups over all XCDs. */
+ * ia_ppo_update_xcd_pack(1) (several gradient workgroups that fit one XCD's 32 CUs) launches 8x the blocks so that the
+ * working ones share one XCD; the gradient workgroups then check their placement against each other (XCC ids, one word
+ * exchange per launch) and, when they do sit on one XCD, store the step's (value, sequence) words at workgroup scope --
+ * L2-resident instead of one fabric write per word. Default 0 (spread over all XCDs): packed measured +1-2 % at config P
+ * on one box, nothing on another, and -3 ... -5 % where the row gathers dominate (1 000-step rollouts, Ant-width rows). */
 int64_t ia_ppo_update_ws_floats(const ia_policy_desc* d, int batch_size);
 int ia_ppo_update_xcd_pack(int on);
 /* ia_ppo_update returns IA_ERR_UNSUPPORTED (-2) without launching when its workgroups (which meet at grid
