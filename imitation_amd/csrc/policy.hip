@@ -4114,7 +4114,7 @@ __global__ __launch_bounds__(512) void ppo_update_persistent_kernel(
     // observations: staged PACKED, element e = row * D + column (only the D columns that exist: at D = 17 three
     // 512-element passes instead of the nine a 65-wide row stride took); row = e / D by reciprocal multiplication
     int srcs[NIT], cols[NIT];
-    const unsigned rcpD = (unsigned)((0x100000000ull + (unsigned)D - 1) / (unsigned)D);   // wave-uniform
+    const unsigned rcpD = 0xffffffffu / (unsigned)D + 1u;   // = ceil(2^32 / D) mod 2^32, by a 32-bit divide (the 64-bit one: ~100 scalar instructions per step)
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
       const int e0 = it * 512 + wave * 64 + zero;  // wave-uniform
@@ -4233,6 +4233,8 @@ __global__ __launch_bounds__(512) void ppo_update_persistent_kernel(
     UPD_TS(7);
     UPD_TS(8);
     float g[NPT];
+    unsigned long long tail_w = 0ull;                                  // (several workgroups: the sum vector's tail, see hop 2)
+    const bool want_tail = !LOCAL && vb == 0 && tid < 64 && stats;
     if (local) {
       // the gradient image out of the staging area before the next minibatch's rows are loaded over it
       int gz;
@@ -4281,7 +4283,7 @@ __global__ __launch_bounds__(512) void ppo_update_persistent_kernel(
       // rank's receive area, the slice's owner sums the ranks' words in rank order and publishes the global slice.
       using u64 = unsigned long long;
       const int SL = (P8 + nblk - 1) / nblk;   // slice length
-      const unsigned rcpSL = (unsigned)((0x100000000ull + (unsigned)SL - 1) / (unsigned)SL);
+      const unsigned rcpSL = 0xffffffffu / (unsigned)SL + 1u;   // = ceil(2^32 / SL), 32-bit divide
       float* red = lds + L::a1;                // scratch [nblk][SL] (the activation tiles are free until the next minibatch)
       auto valid_el = [&](int gi) { return gi < o.total || (gi >= w.P4 && gi < w.P4 + 5); };   // written elements only
       bool fail = false;
@@ -4414,7 +4416,9 @@ __global__ __launch_bounds__(512) void ppo_update_persistent_kernel(
                                 wv_ >> 2, wv_ & 3, lane);
       }
       if (tid == 0) s_pub = stage_ahead ? s + 2 : 0;   // (what `have_ring` is formed from below)
-      {   // hop 2: the whole sum vector
+      {   // hop 2: the whole sum vector. Wave 0 of workgroup 0 also takes the vector's TAIL (the loss-statistic sums it
+          // writes out after the norm) in the same trip: polled behind the norm, it was one more round trip through the
+          // fabric per step in the one workgroup every other workgroup's hop 1 then waits for.
         u64 t[NPT];
         int ez;
         asm volatile("s_mov_b32 %0, 0" : "=s"(ez));
@@ -4423,8 +4427,9 @@ __global__ __launch_bounds__(512) void ppo_update_persistent_kernel(
 #pragma unroll
           for (int k = 0; k < NPT; ++k)
             t[k] = __hip_atomic_load(sums_s + min(tid + ez + k * 512, o.total - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          tail_w = __hip_atomic_load(sums_s + w.P4 + ez + min(lane, 4), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           __builtin_amdgcn_sched_barrier(0);
-          bool ok = true;
+          bool ok = !want_tail || (unsigned)(tail_w >> 32) == lseq;
 #pragma unroll
           for (int k = 0; k < NPT; ++k) ok = ok && (unsigned)(t[k] >> 32) == lseq;
           if (ok) break;
@@ -4562,13 +4567,7 @@ __global__ __launch_bounds__(512) void ppo_update_persistent_kernel(
     const float coef = fminf(max_norm / (total_norm + 1e-6f), 1.0f);  // torch clip_grad_norm_
     if constexpr (!LOCAL) {
       if (vb == 0 && tid < 64 && stats) {   // the loss-statistic sums are the sum vector's tail: same rows as write_loss_stats
-        const unsigned long long* tb = w.sums64 + (long long)(s & 1) * P8 + w.P4;
-        unsigned long long tv;
-        const long long t0 = wall_clock64();
-        do {
-          tv = __hip_atomic_load(tb + min(lane, 4), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        } while (!__all((unsigned)(tv >> 32) == lseq) && wall_clock64() - t0 < 200000000ll);
-        const float st = __uint_as_float((unsigned)tv) * (1.f / (float)r.batch);
+        const float st = __uint_as_float((unsigned)tail_w) * (1.f / (float)r.batch);   // (arrived with hop 2)
         const float st0 = __shfl(st, 0, 64), st1 = __shfl(st, 1, 64), st2 = __shfl(st, 2, 64);
         float* so = stats + (long long)(sch_first + s) * 8;
         if (lane < 5) so[lane] = st;
