@@ -3845,6 +3845,14 @@ __global__ __launch_bounds__(512) void ppo_update_persistent_kernel(
   // row-sharded data parallelism: this rank's rows of a (global) minibatch are [row_lo, row_lim(r))
   const int row_lo = SHARD ? sh.rank * sh.rows_per_rank : 0;
   auto row_lim = [&](const MbRows& r) { return SHARD ? min(r.batch, row_lo + sh.rows_per_rank) : r.batch; };
+  // (epoch, minibatch) -> rows; the gradient workgroups carry the pair from step to step instead of dividing every time
+  auto rows_at = [=](int e, int mb) {
+    const long long start = (long long)mb * sch_bs;
+    const long long left = sch_total - start;
+    MbRows r{obs, actions, old_logp, adv, ret, perm + (long long)e * sch_total + start,
+             (int)(left < sch_bs ? left : sch_bs), T, n_envs};
+    return r;
+  };
   auto rows_of = [=](int s) {
     const int gs = sch_first + s;
     const int e = gs / sch_nmb, mb = gs - e * sch_nmb;
@@ -4074,12 +4082,11 @@ __global__ __launch_bounds__(512) void ppo_update_persistent_kernel(
   // (i) one step ahead of (ii): wave 7 resolves permutation entry -> rollout-tile row offset for the
   // block's 64 rows of minibatch s (a dependent global load plus a division) and leaves them in LDS;
   // any later block barrier publishes them. (ii) every thread then issues its row gathers at once.
-  auto prefetch_resolve = [&](int s) {
+  auto prefetch_resolve = [&](const MbRows& r) {
     if (tid >= 448) {
       int tz;   // opaque zero: the reciprocal of T behind `f / T` is re-derived per step instead of being spilled
       asm volatile("s_mov_b32 %0, 0" : "=s"(tz));
       const unsigned Tq = (unsigned)(T + tz);
-      const MbRows r = rows_of(s);
       const int i0 = row_lo + vb * ROWS;
       int src = 0;
       if (i0 + lane < row_lim(r)) {
@@ -4106,8 +4113,7 @@ __global__ __launch_bounds__(512) void ppo_update_persistent_kernel(
   // gathers of a wave nine serial round trips to memory (3.6 us per step on the barrier path). `zero` is an opaque
   // 0 refreshed every step, so the element -> (row, column) arithmetic is redone here (a dozen VALU operations)
   // instead of being hoisted out of the step loop into 27 spilled registers.
-  auto prefetch_issue = [&](int s, int zero) {
-    const MbRows r = rows_of(s);
+  auto prefetch_issue = [&](const MbRows& r, int zero) {
     const int* nxt = reinterpret_cast<const int*>(stg) + UpdStage::nxt;
     int src0 = 0;
     if (wave == 0) src0 = nxt[lane];
@@ -4118,21 +4124,29 @@ __global__ __launch_bounds__(512) void ppo_update_persistent_kernel(
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
       const int e0 = it * 512 + wave * 64 + zero;  // wave-uniform
-      const int e = min(e0 + lane, PROWS * D - 1);
-      const int rr = D == 1 ? e : (int)__umulhi((unsigned)e, rcpD);
-      cols[it] = e - rr * D;
-      srcs[it] = nxt[rr];
+      cols[it] = srcs[it] = 0;
+      if (e0 < PROWS * D) {   // (the passes this observation width fills: 3 of 9 at D = 17)
+        const int e = min(e0 + lane, PROWS * D - 1);
+        const int rr = D == 1 ? e : (int)__umulhi((unsigned)e, rcpD);
+        cols[it] = e - rr * D;
+        srcs[it] = nxt[rr];
+      }
     }
     // actions: element e = row * aw + column of the block's [ROWS][aw] tile, 512 elements per pass
     const int aw_ = d.discrete ? 1 : d.act_dim;
     constexpr int NAT = (PROWS * MAXA + 511) / 512;
     int asrc[NAT], acol[NAT];
+    const unsigned rcpA = 0xffffffffu / (unsigned)aw_ + 1u;   // (aw_ = 1: 0, not used)
 #pragma unroll
     for (int it = 0; it < NAT; ++it) {
-      const int e = min(it * 512 + wave * 64 + zero + lane, PROWS * aw_ - 1);
-      const int rr = e / aw_;
-      acol[it] = e - rr * aw_;
-      asrc[it] = nxt[rr];
+      const int e0 = it * 512 + wave * 64 + zero;  // wave-uniform
+      acol[it] = asrc[it] = 0;
+      if (e0 < PROWS * aw_) {
+        const int e = min(e0 + lane, PROWS * aw_ - 1);
+        const int rr = aw_ == 1 ? e : (int)__umulhi((unsigned)e, rcpA);
+        acol[it] = e - rr * aw_;
+        asrc[it] = nxt[rr];
+      }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
@@ -4161,10 +4175,11 @@ __global__ __launch_bounds__(512) void ppo_update_persistent_kernel(
   };
   for (int e = tid; e < (SMALL ? L::total : MAXD * L::RS); e += 512) lds[L::x + e] = 0.f;   // (the chain only rewrites the columns
                                                                                             // it uses; SMALL: rows 16.. of EVERY tile)
+  int cur_e = sch_first / sch_nmb, cur_mb = sch_first - cur_e * sch_nmb;   // (epoch, minibatch) of step s
   if (n_steps > 0) {
-    prefetch_resolve(0);
+    prefetch_resolve(rows_at(cur_e, cur_mb));
     __syncthreads();
-    prefetch_issue(0, 0);
+    prefetch_issue(rows_at(cur_e, cur_mb), 0);
     prefetch_park();
   }
   __syncthreads();
@@ -4179,7 +4194,11 @@ __global__ __launch_bounds__(512) void ppo_update_persistent_kernel(
   constexpr bool local = LOCAL;
   if (tstamp && tid == 0) tprev = wall_clock64();
   for (int s = 0; s < n_steps; ++s) {
-    const MbRows r = rows_of(s);
+    const MbRows r = rows_at(cur_e, cur_mb);
+    const bool wrap = cur_mb + 1 == sch_nmb;
+    const int nxt_e = wrap ? cur_e + 1 : cur_e, nxt_mb = wrap ? 0 : cur_mb + 1;   // step s + 1
+    cur_e = nxt_e;
+    cur_mb = nxt_mb;
     const float* slot = w.ring + (s % UPD_RING) * UPD_RS;
     float adv_mean, adv_std;
     if (!have_ring) {
@@ -4216,7 +4235,7 @@ __global__ __launch_bounds__(512) void ppo_update_persistent_kernel(
     UPD_TS(0);
     // Adam's scalars of this step: requested now (a global load), consumed after the grid barrier
     const float step_size = w.tab[s], bc2_sqrt = w.tab[UPD_MAX_STEPS + s];
-    if (s + 1 < n_steps) prefetch_resolve(s + 1);  // published by the block barriers inside the minibatch
+    if (s + 1 < n_steps) prefetch_resolve(rows_at(nxt_e, nxt_mb));  // published by the block barriers inside the minibatch
     const int P8 = w.P4 + 8;
     const unsigned lseq = lseq_base + (unsigned)s + 1u;
     unsigned long long* slabs_s = w.slabs64 + (long long)(s & 1) * nblk * P8;
@@ -4247,7 +4266,7 @@ __global__ __launch_bounds__(512) void ppo_update_persistent_kernel(
     if (s + 1 < n_steps) {
       int pz;
       asm volatile("s_mov_b32 %0, 0" : "=s"(pz));
-      prefetch_issue(s + 1, pz);
+      prefetch_issue(rows_at(nxt_e, nxt_mb), pz);
     }
     if constexpr (!LOCAL) {
       if (s + 1 < n_steps && wave < 3) {
@@ -4408,7 +4427,7 @@ __global__ __launch_bounds__(512) void ppo_update_persistent_kernel(
       // the acknowledgement of the slice words just sent).
       const bool stage_ahead = (s + 1 < n_steps) && min(min(s_pubw[0], s_pubw[1]), s_pubw[2]) >= s + 2;   // workgroup-uniform
       if (stage_ahead) {
-        const MbRows rn = rows_of(s + 1);
+        const MbRows rn = rows_at(nxt_e, nxt_mb);
         int zz;
         asm volatile("s_mov_b32 %0, 0" : "=s"(zz));
         const int wv_ = __builtin_amdgcn_readfirstlane((tid + zz) >> 6);
