@@ -4363,7 +4363,8 @@ __global__ __launch_bounds__(512) void ppo_update_persistent_kernel(
         }
       }
       UPD_TS(10);
-      if (tid == 0) s_pub = (int)__hip_atomic_load(published, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      // (thread 0 used to read `published` into s_pub here: a round trip through the fabric ahead of this barrier in every
+      //  workgroup, for a value that is overwritten below before anybody reads it)
       if (fail) s_fail = 1;
       __syncthreads();
       if (s_fail) {
@@ -4464,16 +4465,11 @@ __global__ __launch_bounds__(512) void ppo_update_persistent_kernel(
 #pragma unroll
         for (int k = 0; k < NPT; ++k) g[k] = __uint_as_float((unsigned)t[k]);
       }
-      if (fail) s_fail = 1;
-      __syncthreads();
-      if (s_fail) {
-        if (tid == 0) __hip_atomic_store(err, SHARD ? 2u : 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        return;
-      }
+      if (fail) s_fail = 1;   // (no barrier of its own: s_fail and s_pub are read behind the norm's block barrier below)
       // (the statistics workgroup's ring follows workgroup 0's progress: every workgroup's minibatch s is behind it)
       if (vb == 0 && tid == 0) __hip_atomic_fetch_add(arrivals, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    have_ring = (s + 1 < n_steps) && (s_pub >= s + 2);
+    if constexpr (LOCAL) have_ring = (s + 1 < n_steps) && (s_pub >= s + 2);
     if (LOCAL && have_ring && wave < 3) {
       // the next step's statistics slot: global -> LDS directly (waves 0 / 1: mean / 1 / std columns, wave 2: the
       // advantage statistics -- 64 lanes wide, the staging slot has room), landed by prefetch_park's wait. Held in
@@ -4581,6 +4577,13 @@ __global__ __launch_bounds__(512) void ppo_update_persistent_kernel(
     int rz;   // opaque zero: the reduction scratch address is re-formed here instead of living in a (spilled) register
     asm volatile("s_mov_b32 %0, 0" : "=s"(rz));
     const float total_sq = block_sum512_dpp(sq, lds + L::scratch + rz, s & 1);
+    if constexpr (!LOCAL) {   // (the block sum's barrier published hop 2's verdict and thread 0's s_pub)
+      if (s_fail) {
+        if (tid == 0) __hip_atomic_store(err, SHARD ? 2u : 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+      }
+      have_ring = (s + 1 < n_steps) && (s_pub >= s + 2);
+    }
     UPD_TS(5);
     const float total_norm = sqrtf(total_sq);
     const float coef = fminf(max_norm / (total_norm + 1e-6f), 1.0f);  // torch clip_grad_norm_
