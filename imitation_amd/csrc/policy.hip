@@ -4228,8 +4228,11 @@ __global__ __launch_bounds__(512) void ppo_update_persistent_kernel(
     slot = stg + UpdStage::ring;
     // (several workgroups: how far the statistics workgroup is, read HERE -- before the statistics slot of step s + 1 is
     //  requested below, so a slot it calls published was published when its load was issued)
-    int pub_early = 0;
-    if constexpr (!LOCAL) pub_early = (int)__hip_atomic_load(published, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // (one gradient workgroup: read here too. It used to be read behind the minibatch by thread 0, followed by a full fence
+    //  and a barrier of its own: a round trip through the fabric plus the wait for the wave's row gathers, ~0.8 us per step
+    //  with every wave waiting. The value of the step's start says "published" almost always -- the statistics workgroup
+    //  runs a ring ahead --, and the acquire half of the fence is all the slot's loads need.)
+    const int pub_early = (int)__hip_atomic_load(published, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     adv_mean = slot[2 * MAXD];
     adv_std = slot[2 * MAXD + 1];
     UPD_TS(0);
@@ -4261,6 +4264,14 @@ __global__ __launch_bounds__(512) void ppo_update_persistent_kernel(
 #pragma unroll
       for (int k = 0; k < NPT; ++k) g[k] = stg[UpdStage::x + gz + min(tid + k * 512, o.total - 1)];
       if constexpr (SHARD) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the loss-statistic partials go into the record
+      if (tid == 0) {
+        s_ok = 1;
+        s_pub = pub_early;
+        // acquire, by hand: the LDS store above has waited for the counter's load; the CU's L1 is invalidated before any
+        // wave requests the slot below. (The fence builtin also waits for this wave's write-through stores of the
+        // minibatch -- a trip to memory and back -- with every other wave at the barrier.)
+        asm volatile("buffer_inv sc1" ::: "memory");
+      }
       __syncthreads();
     }
     if (s + 1 < n_steps) {
@@ -4280,14 +4291,8 @@ __global__ __launch_bounds__(512) void ppo_update_persistent_kernel(
     }
     UPD_TS(9);
     if constexpr (LOCAL) {
-      if (tid == 0) {
-        s_ok = 1;
-        s_pub = (int)__hip_atomic_load(published, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        UPD_TS(10);
-        __threadfence();
-        UPD_TS(11);
-      }
-      __syncthreads();
+      UPD_TS(10);
+      UPD_TS(11);
     } else {
       // ---- Several gradient workgroups: the exchange of the step, without a grid barrier. Every workgroup's slab is on
       // its way as (value, sequence) words; workgroup b owns SLICE b of the parameter range:
