@@ -92,7 +92,8 @@ def hip_namespace():
                                  NormalizeFeaturesExtractor=p.NormalizeFeaturesExtractor, RunningNorm=p.RunningNorm,
                                  BasicRewardNet=p.BasicRewardNet, BasicShapedRewardNet=p.BasicShapedRewardNet,
                                  NormalizedRewardNet=p.NormalizedRewardNet, Transitions=lambda **kw: p.Transitions(**kw),
-                                 configure_logger=lambda d: p.configure_logger(d, []), device="cuda")
+                                 configure_logger=lambda d: p.configure_logger(d, []), device="cuda",
+                                 CnnPolicy="CnnPolicy", CnnRewardNet=p.modules.CnnRewardNet)
 
 
 def oracle_namespace():
@@ -104,7 +105,8 @@ def oracle_namespace():
                                  NormalizeFeaturesExtractor=o.NormalizeFeaturesExtractor, RunningNorm=o.RunningNorm,
                                  BasicRewardNet=o.BasicRewardNet, BasicShapedRewardNet=o.BasicShapedRewardNet,
                                  NormalizedRewardNet=o.NormalizedRewardNet, Transitions=lambda **kw: o.Transitions(**kw),
-                                 configure_logger=lambda d: o.configure_logger(d, []), device="cpu")
+                                 configure_logger=lambda d: o.configure_logger(d, []), device="cpu",
+                                 CnnPolicy=sb.ActorCriticCnnPolicy, CnnRewardNet=o.CnnRewardNet)
 
 
 def cpu_baseline(cfg, host_threads):
@@ -127,6 +129,9 @@ def cpu_baseline(cfg, host_threads):
     rounds, dt = res[best]
     one = res.get(1, res[best])
     return {"value": rounds * per_round / dt, "unit": "env-steps/s", "cores": best, "kind": "port",
+            "note": "oracle/ restatement, bit-identical to the reference's own modules run under oracle/ref_shim.py (CPU "
+                    "suite); /root/reference does not exist on the GPU box, so the verbatim modules were timed once, in "
+                    "the build container: profiles/r01_phase_compare.md (the oracle is not faster than they are)",
             "sample": f"{rounds} rounds = {rounds * per_round} env-steps incl. {rounds * cfg['n_disc']} disc updates + "
                       f"{rounds * 160} PPO minibatch steps, {dt:.1f} s, torch threads={best} (fastest setting), "
                       f"os.cpu_count()={os.cpu_count()}",
@@ -334,6 +339,13 @@ VARIANTS = {
                                                 policy="mlp64", generic_vecenv=True,
                                                 ppo=dict(batch_size=64, n_epochs=5, ent_coef=0.0, learning_rate=4e-4, gamma=0.95),
                                                 demo_batch=1024, n_disc=4, capacity=2048, net=dict(), rounds=4, warm=3),
+    # config P stepped through a generic SB3-protocol VecEnv at WIDTH (what a 1 024-env DummyVecEnv / SubprocVecEnv of
+    # Monitor-wrapped environments hands the trainer, `util/util.py:158-166`): one info dict per env and step,
+    # `terminal_observation` / `TimeLimit.truncated` / `episode` on the (staggered) episode ends -- the wrappers' per-env
+    # branch (`rewards/reward_wrapper.py:92-133`, `data/wrappers.py:69-91`) instead of `ArrayVecEnv.step_wait_arrays`
+    "P_generic_vecenv_1024": _v(algo="gail", n_envs=1024, n_steps=16, obs=17, act=6, ppo=_PPO_P, demo_batch=8192, n_disc=16,
+                                capacity=16384, net=dict(hid_sizes=(256, 256)), generic_vecenv=True, stagger=True,
+                                rounds=12, warm=3),
     # config P with SB3's default `MlpPolicy` (64 x 64 tanh towers) as the generator instead of FeedForward32Policy
     "P_mlp64_1024x16": _v(algo="gail", n_envs=1024, n_steps=16, obs=17, act=6, policy="mlp64", ppo=dict(_PPO_P, ent_coef=0.01),
                           demo_batch=8192, n_disc=16, capacity=16384, net=dict(hid_sizes=(256, 256)), rounds=12, warm=3),
@@ -349,26 +361,31 @@ VARIANTS = {
 }
 
 
-def run_image_variant(rounds=3, warm=2):
+def build_image_variant(p=None):
     """GAIL on image observations end to end: uint8 [4, 84, 84] frames, `PPO("CnnPolicy")` generator
-    (NatureCNN, Categorical head), `modules.CnnRewardNet` discriminator trained through the operator boundary."""
-    import imitation_amd as p
+    (NatureCNN, Categorical head), `CnnRewardNet` discriminator (HIP: `modules.CnnRewardNet`, trained through the operator
+    boundary; `p`: namespace of another implementation, e.g. the oracle for the CPU figure)."""
     from imitation_amd.vec_env import SyntheticImageVecEnv
+    p = p or hip_namespace()
     n_envs, n_steps, shape, n_act = 64, 16, (4, 84, 84), 6
     th.manual_seed(0)
     np.random.seed(0)
     venv = SyntheticImageVecEnv(num_envs=n_envs, shape=shape, act_dim=3, horizon=500, seed=0, n_discrete=n_act)
-    algo = p.PPO("CnnPolicy", venv, n_steps=n_steps, batch_size=256, n_epochs=4, ent_coef=0.01, learning_rate=1e-4, seed=0,
-                 device="cuda")
-    net = p.modules.CnnRewardNet(venv.observation_space, venv.action_space, hwc_format=False)
+    algo = p.PPO(p.CnnPolicy, venv, n_steps=n_steps, batch_size=256, n_epochs=4, ent_coef=0.01, learning_rate=1e-4, seed=0,
+                 device=p.device)
+    net = p.CnnRewardNet(venv.observation_space, venv.action_space, hwc_format=False)
     rng = np.random.default_rng(1)
     n = 2048
     frames = rng.integers(0, 256, (n + 1, *shape)).astype(np.uint8)
     demos = p.Transitions(obs=frames[:-1], acts=rng.integers(0, n_act, n).astype(np.int64), next_obs=frames[1:],
                           dones=np.zeros(n, bool))
     tr = p.GAIL(demonstrations=demos, demo_batch_size=512, venv=venv, gen_algo=algo, reward_net=net,
-                n_disc_updates_per_round=2, custom_logger=p.configure_logger(tempfile.mkdtemp(prefix="bench-var-"), []))
-    per = n_envs * n_steps
+                n_disc_updates_per_round=2, custom_logger=p.configure_logger(tempfile.mkdtemp(prefix="bench-var-")))
+    return tr, n_envs * n_steps
+
+
+def run_image_variant(rounds=3, warm=2):
+    tr, per = build_image_variant()
     tr.train(warm * per)
     th.cuda.synchronize()
     t0 = time.perf_counter()
@@ -382,46 +399,11 @@ def run_image_variant(rounds=3, warm=2):
                       "minibatch 256 x 4 epochs, demo batch 512 x 2 updates"}
 
 
-def run_bc_variant(batch=4096, steps=10):
-    """BASELINE config 5: `bc.BC` supervised steps (`algorithms/bc.py:94-156,464-510`) with the NatureCNN policy on
-    synthetic uint8 4 x 84 x 84 frames, Discrete(6), batch 4096: samples/s and the GEMM work rate of a step."""
-    import imitation_amd as p
-    from imitation_amd import spaces
-    shape, A = (4, 84, 84), 6
-    osp, asp = spaces.Box(0, 255, shape, np.uint8), spaces.Discrete(A)
-    rng = np.random.default_rng(0)
-    n = 2 * batch
-    obs = rng.integers(0, 256, (n, *shape), dtype=np.uint8)
-    acts = rng.integers(0, A, n).astype(np.int64)
-    demos = p.Transitions(obs=obs, acts=acts, next_obs=obs, dones=np.zeros(n, bool))
-    th.manual_seed(0)
-    pol = p.cnn_policy.ActorCriticCnnPolicy(osp, asp, lambda _: 1.0)
-    tr = p.bc.BC(observation_space=osp, action_space=asp, rng=rng, policy=pol, demonstrations=demos, batch_size=batch,
-                 device="cuda", custom_logger=p.configure_logger(tempfile.mkdtemp(prefix="bench-bc-"), []))
-    tr.train(n_batches=2, log_interval=10 ** 9)
-    th.cuda.synchronize()
-    dt = None
-    for _ in range(2):   # best of two timed passes (one pass in twenty ran at half speed on a busy host: 115 MB of frames
-        t0 = time.perf_counter()   # per batch are gathered on the host)
-        tr.train(n_batches=steps, log_interval=10 ** 9)
-        th.cuda.synchronize()
-        d = (time.perf_counter() - t0) / steps
-        dt = d if dt is None else min(dt, d)
-    g = pol.geom
-    fwd = sum(2.0 * batch * oh * ow * (cin * k * k) * cout for cin, _, _, cout, k, _, oh, ow in g) \
-        + 2.0 * batch * pol.n_flatten * 512 + 2.0 * batch * 512 * (A + 1)
-    dgrad = sum(2.0 * batch * oh * ow * (cin * k * k) * cout for cin, _, _, cout, k, _, oh, ow in g[1:]) \
-        + 2.0 * batch * pol.n_flatten * 512 + 2.0 * batch * 512 * A
-    flops = 2 * fwd + dgrad
-    finite = all(bool(th.isfinite(v.float()).all()) for v in pol.state_dict().values())
-    return {"samples_per_s": batch / dt, "ms_per_step": 1e3 * dt, "steps": steps, "batch": batch, "finite": finite,
-            "gemm_tflops": flops / dt / 1e12, "frac_of_fp32_mfma_peak": flops / dt / 1e12 / PEAK_F32_MFMA_TFLOPS,
-            "config": "BC, NatureCNN ActorCriticCnnPolicy, uint8 4x84x84 frames, Discrete(6), batch 4096, Adam"}
-
-
 def build_variant(name, p=None):
     """The trainer of one non-image variant, untrained (`p`: namespace of an implementation, default the HIP product)."""
     from imitation_amd.vec_env import SyntheticVecEnv
+    if name == "image_gail_64x16_cnn":
+        return build_image_variant(p)
     p = p or hip_namespace()
     v = VARIANTS[name]
     n_envs, n_steps, od, ad = v["n_envs"], v["n_steps"], v["obs"], v["act"]
@@ -429,7 +411,7 @@ def build_variant(name, p=None):
     th.manual_seed(0)
     np.random.seed(0)
     venv = SyntheticVecEnv(num_envs=n_envs, obs_dim=od, act_dim=ad, horizon=1000 if n_envs > 8 else 500, seed=0,
-                           n_discrete=ad if discrete else None)
+                           n_discrete=ad if discrete else None, stagger=bool(v.get("stagger")))
     if v.get("generic_vecenv"):
         from imitation_amd.vec_env import GymStyleVecEnv
         venv = GymStyleVecEnv(venv)
@@ -458,27 +440,34 @@ def build_variant(name, p=None):
     extra = dict(disc_grad_penalty_coef=v["grad_penalty"]) if v.get("grad_penalty") else {}   # (opt-in extension, HIP only)
     tr = cls(demonstrations=demos, demo_batch_size=v["demo_batch"], venv=venv, gen_algo=algo, reward_net=net,
              n_disc_updates_per_round=v["n_disc"], gen_replay_buffer_capacity=v["capacity"],
-             custom_logger=p.configure_logger(tempfile.mkdtemp(prefix="bench-var-")), **extra)
+             custom_logger=p.configure_logger(tempfile.mkdtemp(prefix="bench-var-")),
+             allow_variable_horizon=bool(v.get("stagger")), **extra)   # (staggered first episodes are shorter)
     return tr, n_envs * n_steps
 
 
 # variants that get the CPU oracle timed beside them (one round each, after one warm-up round: the reference's shipped
 # configurations, for which the headline's cpu_baseline says nothing)
-CPU_VARIANTS = ("T_gail_half_cheetah_tuned_verbatim", "3_airl_ant_tuned_verbatim", "1_cartpole_8x256_mlp64")
+CPU_VARIANTS = ("T_gail_half_cheetah_tuned_verbatim", "3_airl_ant_tuned_verbatim", "1_cartpole_8x256_mlp64",
+                "P_generic_vecenv_1024", "image_gail_64x16_cnn")
 
 
 def variant_cpu_baseline(name, host_threads):
     th.set_num_threads(min(8, host_threads))
     try:
         tr, per = build_variant(name, oracle_namespace())
-        tr.train(per)
+        warm = 0 if name == "image_gail_64x16_cnn" else 1   # (a CPU round of 1 024 frames through two NatureCNNs: tens of seconds)
+        if warm:
+            tr.train(per)
         t0 = time.perf_counter()
         tr.train(per)
         dt = time.perf_counter() - t0
     finally:
         th.set_num_threads(1)
     return {"value": per / dt, "unit": "env-steps/s", "cores": min(8, host_threads), "kind": "port",
-            "sample": f"1 round = {per} env-steps after 1 warm-up round, {dt:.1f} s, torch threads={min(8, host_threads)}"}
+            "sample": f"1 round = {per} env-steps after {warm} warm-up round(s), {dt:.1f} s, torch threads={min(8, host_threads)}",
+            "note": "oracle/ restatement (bit-identical to the reference's modules under oracle/ref_shim.py, which cannot "
+                    "travel to the GPU box); the reference's own modules were timed once, in the build container: "
+                    "profiles/r01_phase_compare.md"}
 
 
 def run_variant(name, rounds=None, warm=None):
@@ -620,7 +609,9 @@ def main():
                          "disc_update_frac": disc.get("frac"), "disc_update_frac_in_rounds": disc.get("frac_in_rounds"),
                          "disc_update_traffic": disc.get("traffic"), "disc_update_bound": disc.get("bound"),
                          "note": "dominant kernel by GPU time is a latency chain (read us_per_step); the MFMA-bound "
-                                 "family is disc_update_* (6.85 GFLOP per update vs 157.3 TFLOP/s)"})
+                                 "family is disc_update_*" +
+                                 (f" ({disc['flop'] / 1e9:.3g} GFLOP per update vs {disc.get('peak', 157.3)} TFLOP/s)"
+                                  if disc.get("flop") else "")})
         out = {
             "metric": "env-steps/sec (gen+disc round) GAIL HalfCheetah n_envs=1024",
             "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

@@ -78,12 +78,19 @@ class ReplayBuffer:
             return
         if self._infos is None:
             self._infos = np.array([{} for _ in range(self.capacity)], dtype=object)
-        self._infos[lo:lo + m] = [{} for _ in range(m)] if infos is None else list(infos)
+        if infos is None:
+            self._infos[lo:lo + m] = [{} for _ in range(m)]
+        elif isinstance(infos, np.ndarray) and infos.dtype == object:
+            self._infos[lo:lo + m] = infos          # (object rows copy as references: no Python loop)
+        else:
+            self._infos[lo:lo + m] = list(infos)
 
     @staticmethod
     def _meaningful(infos) -> Optional[np.ndarray]:
         if infos is None:
             return None
+        if isinstance(infos, np.ndarray) and infos.dtype == object:
+            return infos if any(infos.tolist()) else None   # (a dict is true iff it is non-empty)
         return np.asarray(infos, dtype=object) if any(len(i) for i in infos) else None
 
     def store(self, transitions, truncate_ok: bool = True) -> None:

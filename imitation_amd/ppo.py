@@ -698,8 +698,8 @@ class PPO(OnPolicyAlgorithm):
             self.num_timesteps += n
             if not callback.on_step():
                 return False
-            if infos is not None:
-                for info in infos:
+            if infos is not None:   # [SB3 _update_info_buffer]; only non-empty dicts can carry an `episode` entry
+                for info in filter(None, infos):
                     if info.get("episode") is not None:
                         self.ep_info_buffer.extend([info["episode"]])
             if bw is not None:

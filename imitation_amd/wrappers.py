@@ -31,9 +31,10 @@ def step_arrays(venv: VecEnv):
     dones = np.asarray(dones, dtype=bool)
     nxt = np.array(obs, copy=True)
     trunc = np.zeros(len(dones), dtype=bool)
-    for i in np.flatnonzero(dones):  # `reward_wrapper.py:98-109`, SB3 collect_rollouts timeout rule
-        nxt[i] = infos[i]["terminal_observation"]
-        trunc[i] = bool(infos[i].get("TimeLimit.truncated", False))
+    ended = np.flatnonzero(dones)    # `reward_wrapper.py:98-109`, SB3 collect_rollouts timeout rule: ended envs only
+    if len(ended):
+        nxt[ended] = np.stack([infos[i]["terminal_observation"] for i in ended]).reshape(len(ended), *nxt.shape[1:])
+        trunc[ended] = [bool(infos[i].get("TimeLimit.truncated", False)) for i in ended]
     return obs, rews, dones, nxt, trunc, infos
 
 
@@ -96,7 +97,7 @@ class BufferingWrapper(VecEnvWrapper):
         self._steps.append((self._last_obs, np.array(acts, copy=True), next_fixed, np.asarray(rews), dones))
         # the env's own dicts, verbatim, whenever it produced any (`data/wrappers.py:69-91` keeps every step's info);
         # array envs (infos None) never pay for dict lists
-        self._infos.append(list(infos) if infos is not None else None)
+        self._infos.append((infos if isinstance(infos, list) else list(infos)) if infos is not None else None)
         self._last_obs = new_obs
         self.n_transitions += self.num_envs
         self._timesteps += 1
@@ -113,8 +114,13 @@ class BufferingWrapper(VecEnvWrapper):
         (`data/wrappers.py:69-91` keeps every step's dict verbatim); None for array envs, which produce none."""
         if not any(i is not None for i in self._infos):
             return None
-        return np.array([self._infos[o // n][o % n] if self._infos[o // n] is not None else {} for o in order],
-                        dtype=object)
+        # one object row per step (`np.fromiter`: no shape discovery inside the dicts) and ONE fancy index for the whole
+        # round, instead of a Python loop over its 16 384 entries
+        tile = np.empty((len(self._infos), n), dtype=object)
+        for t, row in enumerate(self._infos):
+            # (steps recorded without dicts between steps with them: an empty dict each, as before)
+            tile[t] = np.fromiter(row if row is not None else ({} for _ in range(n)), dtype=object, count=n)
+        return tile.reshape(-1)[order]
 
     def pop_transitions_and_lens(self) -> Tuple[Optional[dt.TransitionsWithRew], List[int]]:
         """Fast path of `pop_trajectories` + `flatten_trajectories_with_rew`

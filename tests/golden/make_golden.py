@@ -41,6 +41,15 @@ def dump_sb3_fixture_layout():
         "optimizer": {"betas": list(pg["betas"]), "eps": pg["eps"], "weight_decay": pg["weight_decay"],
                       "n_params": len(pg["params"])},
         "hyperparameter_fields": {k: data[k] for k in keys},
+        # bookkeeping of a finished `learn(100_000)` as SB3 itself stored it: one `_n_updates` per EPOCH, one Adam
+        # step per minibatch, progress taken BEFORE `train()`, the linear schedule applied to the param group
+        "bookkeeping": {
+            "n_envs": data["n_envs"], "num_timesteps": data["num_timesteps"],
+            "_total_timesteps": data["_total_timesteps"], "_n_updates": data["_n_updates"],
+            "_current_progress_remaining": data["_current_progress_remaining"],
+            "adam_step": sorted({float(v["step"]) for v in opt["state"].values()}),
+            "param_group_lr": pg["lr"],
+        },
     }
     path = os.path.join(HERE, "sb3_fixture_layout.json")
     with open(path, "w") as f:

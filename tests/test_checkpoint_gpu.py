@@ -117,3 +117,36 @@ def test_sb3_trained_expert_runs_on_the_hip_policy():
     np.testing.assert_allclose(vals.reshape(-1).cpu().numpy(), g["values"], rtol=2e-4, atol=2e-4)
     np.testing.assert_allclose(logp.cpu().numpy(), g["logp"], rtol=2e-4, atol=2e-5)
     np.testing.assert_allclose(ent.cpu().numpy(), g["entropy"], rtol=2e-4, atol=2e-5)
+
+
+def test_ppo_bookkeeping_matches_the_sb3_fixture_zip(tmp_path):
+    """The product's `PPO.learn(100_000)` under the fixture's hyper-parameters leaves -- and `save` writes -- the five
+    bookkeeping numbers SB3 2.2.0a3 itself stored in the reference's `cartpole_0/policies/final/model.zip`
+    (`tests/golden/sb3_fixture_layout.json: bookkeeping`; the oracle's twin: `test_sb3_bookkeeping_matches_the_fixture_zip`):
+    whole rollouts past the budget, `_n_updates` per epoch, Adam steps per minibatch, progress before `train()`, the
+    linear schedule's (negative) last learning rate in the param group."""
+    import imitation_amd as p
+    from imitation_amd.vec_env import SyntheticVecEnv
+
+    lay = json.load(open(os.path.join(GOLDEN, "sb3_fixture_layout.json")))
+    hp, bk = lay["hyperparameter_fields"], lay["bookkeeping"]
+    th.manual_seed(0)
+    np.random.seed(0)
+    venv = SyntheticVecEnv(num_envs=bk["n_envs"], obs_dim=4, act_dim=1, horizon=50, n_discrete=2, seed=3)
+    algo = p.PPO(p.ActorCriticPolicy, venv, learning_rate=lambda progress: progress * 1e-3, n_steps=hp["n_steps"],
+                 batch_size=hp["batch_size"], n_epochs=hp["n_epochs"], gamma=hp["gamma"], gae_lambda=hp["gae_lambda"],
+                 ent_coef=hp["ent_coef"], vf_coef=hp["vf_coef"], max_grad_norm=hp["max_grad_norm"], seed=0,
+                 device="cuda")
+    algo.learn(bk["_total_timesteps"])
+    algo.save(tmp_path / "model.zip")
+    z = zipfile.ZipFile(tmp_path / "model.zip")
+    data = json.loads(z.read("data"))
+    for k in ("num_timesteps", "_total_timesteps", "_n_updates", "_current_progress_remaining", "n_envs"):
+        assert data[k] == bk[k], (k, data[k], bk[k])
+    opt = th.load(io.BytesIO(z.read("policy.optimizer.pth")), weights_only=False)
+    assert sorted({float(s["step"]) for s in opt["state"].values()}) == bk["adam_step"]
+    assert opt["param_groups"][0]["lr"] == bk["param_group_lr"]
+    assert len(opt["state"]) == lay["optimizer"]["n_params"]
+    sd = th.load(io.BytesIO(z.read("policy.pth")), weights_only=False)
+    assert {k: list(v.shape) for k, v in sd.items()} == lay["state_dict"]
+    assert all(bool(th.isfinite(v).all()) for v in sd.values())

@@ -262,3 +262,43 @@ def test_cnn_reward_net_matches_golden():
     net.load_state_dict({k[3:]: th.as_tensor(v) for k, v in g.items() if k.startswith("sd/")})
     got = net.predict_processed(g["obs"], g["acts"], g["next_obs"], g["dones"])
     np.testing.assert_allclose(got, g["rews"], rtol=1e-5, atol=1e-6)
+
+
+def _linear_schedule(initial: float):
+    """`imitation.util.util` / rl-zoo style linear schedule: lr = progress_remaining * initial."""
+    return lambda progress: progress * initial
+
+
+def test_sb3_bookkeeping_matches_the_fixture_zip():
+    """[SB3 OnPolicyAlgorithm.learn / PPO.train] bookkeeping, pinned to what SB3 2.2.0a3 ITSELF stored in
+    `/root/reference/tests/testdata/expert_models/cartpole_0/policies/final/model.zip` (`data`,
+    `policy.optimizer.pth`; extracted by `tests/golden/make_golden.py:dump_sb3_fixture_layout`): after
+    `learn(100_000)` with `n_steps 32 x n_envs 8`, `batch_size 256`, `n_epochs 20` and a linear learning rate of
+    1e-3 the file holds `num_timesteps 100096` (the loop runs whole rollouts past the budget), `_n_updates 7820`
+    (+1 per EPOCH), Adam `step 7820` (one per MINIBATCH: 391 rollouts x 20 epochs x 1), progress
+    `-0.00096...` (taken after the last rollout, BEFORE `train()`) and a param-group `lr` of `-9.6e-07` (the
+    schedule applied through `_update_learning_rate` at the head of `train()`, negative in the overshoot)."""
+    from imitation_amd.vec_env import SyntheticVecEnv
+    lay = json.load(open(os.path.join(GOLDEN, "sb3_fixture_layout.json")))
+    hp, bk = lay["hyperparameter_fields"], lay["bookkeeping"]
+    th.manual_seed(0)
+    np.random.seed(0)
+    threads = th.get_num_threads()
+    th.set_num_threads(1)   # 12 512 eight-row forwards + 7 820 256-row steps: thread hand-offs dominate otherwise
+    venv = SyntheticVecEnv(num_envs=bk["n_envs"], obs_dim=4, act_dim=1, horizon=50, n_discrete=2, seed=3)
+    algo = sb.PPO(sb.ActorCriticPolicy, venv, learning_rate=_linear_schedule(1e-3), n_steps=hp["n_steps"],
+                  batch_size=hp["batch_size"], n_epochs=hp["n_epochs"], gamma=hp["gamma"],
+                  gae_lambda=hp["gae_lambda"], ent_coef=hp["ent_coef"], vf_coef=hp["vf_coef"],
+                  max_grad_norm=hp["max_grad_norm"], seed=0)
+    try:
+        algo.learn(bk["_total_timesteps"])
+    finally:
+        th.set_num_threads(threads)
+    assert algo.num_timesteps == bk["num_timesteps"] == 100096
+    assert algo._total_timesteps == bk["_total_timesteps"]
+    assert algo._n_updates == bk["_n_updates"] == 7820
+    assert algo._current_progress_remaining == bk["_current_progress_remaining"]   # same float64 expression
+    opt = algo.policy.optimizer
+    assert sorted({float(s["step"]) for s in opt.state.values()}) == bk["adam_step"] == [7820.0]
+    assert opt.param_groups[0]["lr"] == bk["param_group_lr"]
+    assert len(opt.state) == lay["optimizer"]["n_params"]
