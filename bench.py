@@ -399,6 +399,43 @@ def run_image_variant(rounds=3, warm=2):
                       "minibatch 256 x 4 epochs, demo batch 512 x 2 updates"}
 
 
+def run_bc_variant(batch=4096, steps=10):
+    """BASELINE config 5: `bc.BC` supervised steps (`algorithms/bc.py:94-156,464-510`) with the NatureCNN policy on
+    synthetic uint8 4 x 84 x 84 frames, Discrete(6), batch 4096: samples/s and the GEMM work rate of a step."""
+    import imitation_amd as p
+    from imitation_amd import spaces
+    shape, A = (4, 84, 84), 6
+    osp, asp = spaces.Box(0, 255, shape, np.uint8), spaces.Discrete(A)
+    rng = np.random.default_rng(0)
+    n = 2 * batch
+    obs = rng.integers(0, 256, (n, *shape), dtype=np.uint8)
+    acts = rng.integers(0, A, n).astype(np.int64)
+    demos = p.Transitions(obs=obs, acts=acts, next_obs=obs, dones=np.zeros(n, bool))
+    th.manual_seed(0)
+    pol = p.cnn_policy.ActorCriticCnnPolicy(osp, asp, lambda _: 1.0)
+    tr = p.bc.BC(observation_space=osp, action_space=asp, rng=rng, policy=pol, demonstrations=demos, batch_size=batch,
+                 device="cuda", custom_logger=p.configure_logger(tempfile.mkdtemp(prefix="bench-bc-"), []))
+    tr.train(n_batches=2, log_interval=10 ** 9)
+    th.cuda.synchronize()
+    dt = None
+    for _ in range(2):   # best of two timed passes (one pass in twenty ran at half speed on a busy host: 115 MB of frames
+        t0 = time.perf_counter()   # per batch are gathered on the host)
+        tr.train(n_batches=steps, log_interval=10 ** 9)
+        th.cuda.synchronize()
+        d = (time.perf_counter() - t0) / steps
+        dt = d if dt is None else min(dt, d)
+    g = pol.geom
+    fwd = sum(2.0 * batch * oh * ow * (cin * k * k) * cout for cin, _, _, cout, k, _, oh, ow in g) \
+        + 2.0 * batch * pol.n_flatten * 512 + 2.0 * batch * 512 * (A + 1)
+    dgrad = sum(2.0 * batch * oh * ow * (cin * k * k) * cout for cin, _, _, cout, k, _, oh, ow in g[1:]) \
+        + 2.0 * batch * pol.n_flatten * 512 + 2.0 * batch * 512 * A
+    flops = 2 * fwd + dgrad
+    finite = all(bool(th.isfinite(v.float()).all()) for v in pol.state_dict().values())
+    return {"samples_per_s": batch / dt, "ms_per_step": 1e3 * dt, "steps": steps, "batch": batch, "finite": finite,
+            "gemm_tflops": flops / dt / 1e12, "frac_of_fp32_mfma_peak": flops / dt / 1e12 / PEAK_F32_MFMA_TFLOPS,
+            "config": "BC, NatureCNN ActorCriticCnnPolicy, uint8 4x84x84 frames, Discrete(6), batch 4096, Adam"}
+
+
 def build_variant(name, p=None):
     """The trainer of one non-image variant, untrained (`p`: namespace of an implementation, default the HIP product)."""
     from imitation_amd.vec_env import SyntheticVecEnv

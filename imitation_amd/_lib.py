@@ -123,7 +123,8 @@ _SIGS = {
     "ia_gauss_act": ([_P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P], C.c_int),
     "ia_gauss_eval": ([_P, _P, _P, _I, _I, _P, _P, _P], C.c_int),
     "ia_adv_moments": ([_P, _I, _P, _P], C.c_int),
-    "ia_clip_grad_norm": ([_P, C.c_longlong, _F, _P, _P], C.c_int),
+    "ia_clip_grad_norm_ws_floats": ([], C.c_longlong),
+    "ia_clip_grad_norm": ([_P, C.c_longlong, _F, _P, _P, _P], C.c_int),
     "ia_ppo_head_loss_ws_floats": ([_I], C.c_longlong),
     "ia_ppo_head_loss": ([_I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _F, _F, _F, _P, _P, _P, _P, _P, _P], C.c_int),
     "ia_mlp_param_count": ([C.POINTER(MlpDesc)], C.c_int64),

@@ -524,6 +524,9 @@ class ActorCriticCnnPolicy:
         opt = self.optimizer
         grad = opt.grad
         dev = self.device
+        if getattr(self, "_clip_ws", None) is None:   # partials of the grid-wide gradient norm (long gradients)
+            self._clip_ws = th.empty(int(L.load().ia_clip_grad_norm_ws_floats()), device=self.device)
+        clip_ws = self._clip_ws
         for e in range(n_epochs):
             for mb, start in enumerate(range(0, total, batch_size)):
                 b = min(batch_size, total - start)
@@ -550,7 +553,7 @@ class ActorCriticCnnPolicy:
                 self.backward(b, grad, with_values=True)
                 if dp is not None and dp.world > 1:
                     dp.allreduce_mean_(grad)
-                L.call("ia_clip_grad_norm", L.ptr(grad), grad.numel(), float(max_grad_norm), None, s)
+                L.call("ia_clip_grad_norm", L.ptr(grad), grad.numel(), float(max_grad_norm), None, L.ptr(clip_ws), s)
                 opt.step()
 
     # ---- acting --------------------------------------------------------------------------------------------

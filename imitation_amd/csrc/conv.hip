@@ -261,11 +261,59 @@ __global__ void relu_backward_kernel(const float* __restrict__ dy, const float* 
 }
 
 // out[b, c] = mean over the HW positions of y[b, :, c] (AdaptiveAvgPool2d(1) on channel-last activations): one
-// block per image, threads over channels (consecutive c: coalesced rows), positions summed in order.
+// block per image. Channel QUADS across the threads (consecutive threads read consecutive 16-byte pieces of a position's
+// channel row: a wave instruction covers 1 KB), the positions dealt over G = 256 / (C / 4) thread groups; every thread
+// sums its positions in order in four interleaved chains (loads of four positions in flight), the groups are folded in
+// group order through LDS -- a fixed summation order, whatever the grid. (The first form -- one thread per channel walking
+// all HW positions with a stride of C floats, 32 of 256 threads busy at C = 32 -- took 2.7 ms per 1 024 x 84 x 84 x 32
+// call: 16 of the image-GAIL round's 93 ms of GPU time, `profiles/r05_image_gail.md`.)
 __global__ __launch_bounds__(256) void avgpool_nhwc_kernel(const float* __restrict__ y, int HW, int C,
                                                            float* __restrict__ out) {
+  __shared__ float4 red[256];
   const long long b = blockIdx.x;
-  for (int c = threadIdx.x; c < C; c += 256) {
+  const int tid = threadIdx.x;
+  const int Q = C >> 2;                      // channel quads
+  if ((C & 3) == 0 && Q <= 256) {
+    const int G = 256 / Q;                   // position groups
+    const int q = tid % Q, g = tid / Q;
+    float4 acc[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    if (g < G) {
+      const float4* src = reinterpret_cast<const float4*>(y + b * HW * C) + q;
+      int p = g;
+      for (; p + 3 * G < HW; p += 4 * G) {
+        float4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = src[(long long)(p + u * G) * Q];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          acc[u].x += v[u].x; acc[u].y += v[u].y; acc[u].z += v[u].z; acc[u].w += v[u].w;
+        }
+      }
+      for (int u = 0; p < HW; p += G, ++u) {
+        const float4 v = src[(long long)p * Q];
+        acc[u].x += v.x; acc[u].y += v.y; acc[u].z += v.z; acc[u].w += v.w;
+      }
+    }
+    float4 s;
+    s.x = (acc[0].x + acc[1].x) + (acc[2].x + acc[3].x);
+    s.y = (acc[0].y + acc[1].y) + (acc[2].y + acc[3].y);
+    s.z = (acc[0].z + acc[1].z) + (acc[2].z + acc[3].z);
+    s.w = (acc[0].w + acc[1].w) + (acc[2].w + acc[3].w);
+    red[tid] = s;
+    __syncthreads();
+    if (tid < Q) {
+      float4 t = red[tid];
+      for (int g2 = 1; g2 < G; ++g2) {
+        const float4 v = red[g2 * Q + tid];
+        t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
+      }
+      const float inv = (float)HW;
+      float* o = out + b * C + 4 * tid;
+      o[0] = t.x / inv; o[1] = t.y / inv; o[2] = t.z / inv; o[3] = t.w / inv;
+    }
+    return;
+  }
+  for (int c = tid; c < C; c += 256) {       // other channel counts: a thread per channel, positions in order
     const float* src = y + b * HW * C + c;
     float s = 0.f;
     for (int p = 0; p < HW; ++p) s += src[(long long)p * C];

@@ -449,6 +449,9 @@ class GeneralTowers:
         rn = self.features_extractor.normalize
         opt = self.optimizer
         grad = opt.grad
+        if getattr(self, "_clip_ws", None) is None:   # partials of the grid-wide gradient norm (long gradients)
+            self._clip_ws = th.empty(int(L.load().ia_clip_grad_norm_ws_floats()), device=self.device)
+        clip_ws = self._clip_ws
         for e in range(n_epochs):
             for mb, start in enumerate(range(0, total, batch_size)):
                 b = min(batch_size, total - start)
@@ -485,7 +488,7 @@ class GeneralTowers:
                     grad[o1:o1 + n1].copy_(g[n0:])
                 if dp is not None and dp.world > 1:
                     dp.allreduce_mean_(grad)
-                L.call("ia_clip_grad_norm", L.ptr(grad), grad.numel(), float(max_grad_norm), None, s)
+                L.call("ia_clip_grad_norm", L.ptr(grad), grad.numel(), float(max_grad_norm), None, L.ptr(clip_ws), s)
                 opt.step()
                 self._sync_transposed()
 

@@ -224,7 +224,16 @@ def conv2d_nhwc_backward(dy: Tensor, y: Tensor, col: Tensor, x: Tensor, w: Tenso
     L.call("ia_reduce_partials", L.ptr(part), splits, Cout * K, 1.0, 0, L.ptr(dw), L.stream())
     L.call("ia_reduce_partials", L.ptr(dbp), splits, Cout, 1.0, 0, L.ptr(db), L.stream())
     dx = th.zeros(B, in_h, in_w, Cin, device=dy.device) if not need_dx else th.empty(B, in_h, in_w, Cin, device=dy.device)
-    if need_dx:
+    if need_dx and stride == 1 and KH - 1 - pad >= 0 and KH == KW and conv_is_implicit(Cout, KW, dz.numel()):
+        # d loss / d input of a stride-1 convolution = the padded (KH - 1 - pad) stride-1 convolution of `dz` with the
+        # flipped / transposed kernel Wd[c, i, j, co] = W[co, KH-1-i, KW-1-j, c]: again an implicit GEMM over the im2col VIEW
+        # of dz -- no [M, KH*KW*Cin] column-gradient buffer (8.3 GB per call at 1 024 frames of 84 x 84 x 32) and no col2im
+        # pass over it (`ia_gemm_f32_im2col_pad`, the form `cnn_policy._dgrad_implicit` uses for NatureCNN)
+        wd = w.flip(1, 2).permute(3, 1, 2, 0).contiguous()
+        Kd = KH * KW * Cout
+        L.call("ia_gemm_f32_im2col_pad", L.GEMM_NT, L.ptr(dz), Kd, L.ptr(wd), Kd, L.ptr(dx), Cin, B * in_h * in_w, Cin, Kd,
+               None, ACT_NONE, 1, None, OH, OW, Cout, KH, KW, 1, KH - 1 - pad, None, None, L.stream())
+    elif need_dx:
         dcol = th.empty(M, K, device=dy.device)
         L.call("ia_gemm_f32", L.GEMM_NN, L.ptr(dz), Cout, L.ptr(w), K, L.ptr(dcol), K, M, K, Cout, None, 0, None, 0, 1,
                None, L.stream())

@@ -582,8 +582,11 @@ int ia_gauss_eval(const float* mean, const float* log_std, const float* actions,
                   void* stream);
 /* out2 = (mean, unbiased std) of x[n] -- the minibatch advantage normalisation of PPO.train; one block, fixed order */
 int ia_adv_moments(const float* x, int n, float* out2, void* stream);
-/* torch.nn.utils.clip_grad_norm_ on one flat gradient (in place); norm_out (nullable) receives the total norm */
-int ia_clip_grad_norm(float* grad, long long n, float max_norm, float* norm_out, void* stream);
+/* torch.nn.utils.clip_grad_norm_ on one flat gradient (in place); norm_out (nullable) receives the total norm.
+ * ws (nullable): ia_clip_grad_norm_ws_floats() floats -- with it, gradients of >= 65 536 entries are reduced by a grid of
+ * blocks (partials folded in a fixed order) instead of one block. */
+long long ia_clip_grad_norm_ws_floats(void);
+int ia_clip_grad_norm(float* grad, long long n, float max_norm, float* norm_out, float* ws, void* stream);
 /* One PPO minibatch at the heads: `out` = Gaussian means or Categorical logits [B, A] (A <= 64), `actions` [B, A]
  * (Box) or [B] fp32 indices (Discrete), adv_ms = ia_adv_moments of `adv` or NULL (no normalisation).
  * Writes d loss / d out, d loss / d values, d loss / d log_std (Box) and stats[8] = {policy_gradient_loss,

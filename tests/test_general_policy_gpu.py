@@ -105,15 +105,17 @@ def test_gauss_act_and_clip_grad_norm():
     np.testing.assert_allclose(lp2.cpu().numpy(), lp.cpu().numpy(), rtol=1e-6, atol=1e-6)
     np.testing.assert_allclose(ent.cpu().numpy(), dist.entropy().sum(1).numpy(), rtol=1e-6)
 
-    for scale in (0.01, 10.0):   # below / above the clipping threshold
-        gr = th.randn(5000, generator=g) * scale
-        gd, norm = d(gr), th.empty(1, device="cuda")
-        L.call("ia_clip_grad_norm", L.ptr(gd), gd.numel(), 0.5, L.ptr(norm), L.stream())
-        p = nn.Parameter(th.zeros(5000))
-        p.grad = gr.clone()
-        total = th.nn.utils.clip_grad_norm_([p], 0.5)
-        np.testing.assert_allclose(norm.item(), total.item(), rtol=1e-5)
-        np.testing.assert_allclose(gd.cpu().numpy(), p.grad.numpy(), rtol=1e-5, atol=1e-9)
+    cws = th.empty(int(L.load().ia_clip_grad_norm_ws_floats()), device="cuda")
+    for numel, ws in ((5000, None), (5000, cws), (1_700_003, cws), (65_536, cws)):   # one block / the grid form (NatureCNN length)
+        for scale in (0.01 / (numel / 5000) ** 0.5, 10.0):   # below / above the clipping threshold
+            gr = th.randn(numel, generator=g) * scale
+            gd, norm = d(gr), th.empty(1, device="cuda")
+            L.call("ia_clip_grad_norm", L.ptr(gd), gd.numel(), 0.5, L.ptr(norm), None if ws is None else L.ptr(ws), L.stream())
+            p = nn.Parameter(th.zeros(numel))
+            p.grad = gr.clone()
+            total = th.nn.utils.clip_grad_norm_([p], 0.5)
+            np.testing.assert_allclose(norm.item(), total.item(), rtol=1e-5)
+            np.testing.assert_allclose(gd.cpu().numpy(), p.grad.numpy(), rtol=1e-5, atol=1e-9)
 
 
 @pytest.mark.parametrize("discrete", [False, True])
