@@ -23,6 +23,16 @@
 
 namespace {
 
+// Same-box A/B switches of round 5's changes to the persistent PPO update (tools/ab_libs.sh builds one library per switch):
+#ifndef IA_PF16
+#define IA_PF16 1        // row prefetch of the next minibatch as 16-byte LDS-direct loads (rows staged 4 ceil(D / 4) floats apart)
+#endif
+#ifndef IA_ADAM_FAST
+#define IA_ADAM_FAST 1   // Adam's sqrt / two divisions on v_sqrt_f32 / v_rcp_f32 (+ one Newton step) instead of the IEEE expansions
+#endif
+#ifndef IA_TILES_V2
+#define IA_TILES_V2 1    // weight-gradient tiles with one useful row / column (value head, a <= 4-column last K tile) as VALU dots
+#endif
 constexpr int MAXD = 64;   // max observation width
 constexpr int MAXA = 16;   // max action width / number of discrete actions
 constexpr int ROWS = 64;   // rows per block (one wave)
@@ -2180,12 +2190,27 @@ __device__ __forceinline__ void chain_stage_rows(const ia_policy_desc& d, const 
       const int r = (g * s1r) >> 16, k0 = (g - r * S1) * 4;
       const bool rok = (i0 + rbase + r) < row_lim;
       float raw[4], mu[4], vr[4];
+#if IA_PF16
+      {   // rows staged 4 S1 floats apart (16-byte pieces, as the LDS-direct loads left them): group g's piece is slot
+          // rbase S1 + g of the area -- ONE ds_read_b128 each for the raw values, the means and 1 / std
+        const f32x4 rq = *reinterpret_cast<const f32x4*>(stg + UpdStage::x + (rbase * S1 + g) * 4);
+        const f32x4 mq = *reinterpret_cast<const f32x4*>(nm + k0);
+        const f32x4 vq = *reinterpret_cast<const f32x4*>(nv + k0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          raw[j] = rq[j];   // (columns >= D hold the next row's first values: masked below)
+          mu[j] = mq[j];
+          vr[j] = vq[j];
+        }
+      }
+#else
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         raw[j] = stg[UpdStage::x + (rbase + r) * D + k0 + j];   // (packed rows; columns >= D are masked below)
         mu[j] = nm[k0 + j];          // slot arrays hold MAXD entries each
         vr[j] = nv[k0 + j];
       }
+#endif
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const bool ok = rok && k0 + j < D;

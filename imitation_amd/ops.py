@@ -211,7 +211,9 @@ def conv2d_nhwc_backward(dy: Tensor, y: Tensor, col: Tensor, x: Tensor, w: Tenso
     if relu:
         dz = th.empty_like(dy)
         L.call("ia_relu_backward", L.ptr(dy), L.ptr(y), dy.numel(), L.ptr(dz), L.stream())
-    splits = int(min(64, max(1, M // 2048)))
+    # split-K over the rows: 64 splits left the weight gradient of a 1 024-frame 84 x 84 batch (7.2 M rows against a 32 x 288
+    # output: 5 tiles) on 320 workgroups of 113 k rows each -- 7.7 ms per call, 17 TFLOP/s (`profiles/r05_image_gail.md`)
+    splits = int(min(1024, max(1, M // 2048)))
     part = th.empty(splits, Cout, K, device=dy.device)
     dbp = th.empty(splits, Cout, device=dy.device)
     if col.shape[0] == 0:

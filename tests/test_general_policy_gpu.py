@@ -114,8 +114,14 @@ def test_gauss_act_and_clip_grad_norm():
             p = nn.Parameter(th.zeros(numel))
             p.grad = gr.clone()
             total = th.nn.utils.clip_grad_norm_([p], 0.5)
-            np.testing.assert_allclose(norm.item(), total.item(), rtol=1e-5)
-            np.testing.assert_allclose(gd.cpu().numpy(), p.grad.numpy(), rtol=1e-5, atol=1e-9)
+            if numel <= 5000:
+                np.testing.assert_allclose(norm.item(), total.item(), rtol=1e-5)
+                np.testing.assert_allclose(gd.cpu().numpy(), p.grad.numpy(), rtol=1e-5, atol=1e-9)
+            # long vectors: torch-CPU's own float32 accumulation is 2e-5 off at 1.7 M entries -- the float64 norm decides
+            total64 = float(gr.double().norm())
+            np.testing.assert_allclose(norm.item(), total64, rtol=2e-6)
+            want = gr.double() * min(1.0, 0.5 / (total64 + 1e-6))
+            np.testing.assert_allclose(gd.cpu().numpy(), want.float().numpy(), rtol=2e-6, atol=1e-9)
 
 
 @pytest.mark.parametrize("discrete", [False, True])
