@@ -2762,6 +2762,52 @@ __device__ __forceinline__ void mfma32_minibatch_chain(
     s += __shfl_xor(s, 32, 64);
     if (lane < 32) put(dst + lane, s);
   };
+#if IA_TILES_V2
+  // Round 5: six of the twenty 16 x 16 x 64 tiles of a step produced ONE useful row or column (the value head's weight
+  // gradient: two tiles for 32 numbers; at obs 17 the second K tile of both towers' first layer: four tiles for 2 x 32
+  // numbers) and the two SIMDs that hosted the head tiles issued 96 MFMAs against 64 on the others. Those products are
+  // now VALU dots -- a lane per (feature, row half): sixteen ds_read_b128 and 32 fused multiply-adds --, the policy head's
+  // two tiles sit on the waves whose first-layer tile went away (q = 1, 3): <= 64 MFMAs on every SIMD.
+  const int KTg = (D + 15) >> 4;
+  const bool narrow = KTg == 2 && D - 16 <= 4;   // (launch-constant) the first layer's second K tile holds <= 4 columns
+  auto dot32 = [&](const float* __restrict__ U /* [32 features][RS] */, const float* __restrict__ vrow /* [RS] */) {
+    const float* up = U + (lane & 31) * L::RS + (lane >> 5) * 32;
+    const float* vp = vrow + (lane >> 5) * 32;
+    f32x4 u[8], w[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      u[i] = rd4(up + 4 * i);
+      w[i] = rd4(vp + 4 * i);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      s0 = __builtin_fmaf(u[i][0], w[i][0], s0);
+      s1 = __builtin_fmaf(u[i][1], w[i][1], s1);
+      s0 = __builtin_fmaf(u[i][2], w[i][2], s0);
+      s1 = __builtin_fmaf(u[i][3], w[i][3], s1);
+    }
+    float sm = s0 + s1;
+    sm += __shfl_xor(sm, 32, 64);
+    return sm;   // (lanes j and j + 32: feature j's sum over the 64 rows)
+  };
+  if (tw == 0) {
+    if (q & 1) {  // dWa[a][h] = sum_r dout[r][a] a2[r][h], 16 h-columns per wave (waves 1 and 3)
+      const int ht = q >> 1;
+      const f32x4 g = outer16(lds + L::dout, li, a2t, ht * 16 + li);
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (lk * 4 + r < A) put(slab + (o.aW + (lk * 4 + r) * H + ht * 16 + li), g[r]);
+    }
+    if (q == 2) colsum64(lds + L::dout, A, slab + o.ab);
+    if (q == 0 && !d.discrete) colsum64(lds + L::aux, A, slab + o.log_std);
+  } else {
+    if (q == 1) {  // dcW[h] = sum_r dv[r] a2[r][h]: 32 numbers
+      const float sm = dot32(a2t, lds + L::misc + L::RS);
+      if (lane < 32) put(slab + (o.cW + lane), sm);
+    }
+#else
   if (tw == 0) {
     if (q < 2) {  // dWa[a][h] = sum_r dout[r][a] a2[r][h], 16 h-columns per wave
       const f32x4 g = outer16(lds + L::dout, li, a2t, q * 16 + li);
@@ -2776,6 +2822,7 @@ __device__ __forceinline__ void mfma32_minibatch_chain(
       const f32x4 g = outer16(lds + L::misc + L::RS, 0, a2t, q * 16 + li);   // (every lane reads column 1; rows m > 0 unused)
       if (lk == 0) put(slab + (o.cW + q * 16 + li), g[0]);
     }
+#endif
     if (q == 2) {  // cb = sum_r dv[r]; statpart slots {0 pg, 2 ent, 3 kl, 4 clip, 1 value} <- misc columns 2..6
       // columns 1..6 of the misc tile summed together: lane c < 6 handles column 1 + c
       const int c = lane & 15, part = lane >> 4;
@@ -2812,7 +2859,12 @@ __device__ __forceinline__ void mfma32_minibatch_chain(
         for (int r = 0; r < 4; ++r) put(slab + (oW1 + (jt * 16 + lk * 4 + r) * D + col), g[r]);
     };
     f32x4 g2;
-    if (q < 2 * KT) {   // (wave-uniform)
+#if IA_TILES_V2
+    const bool pair_w1 = q < 2 * KT && !(narrow && (q & 1));   // (narrow: tiles (jt, kt = 1) are the VALU dots below)
+#else
+    const bool pair_w1 = q < 2 * KT;
+#endif
+    if (pair_w1) {   // (wave-uniform)
       const int jt = q / KT, kt = q - jt * KT;
       f32x4 g1;
       outer16_pair(dz2t, jt2 * 16 + li, a1t, kt2 * 16 + li, dz1t, jt * 16 + li, lds + L::x, kt * 16 + li, g2, g1);
@@ -2822,6 +2874,13 @@ __device__ __forceinline__ void mfma32_minibatch_chain(
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) put(slab + (oW2 + (jt2 * 16 + lk * 4 + r) * H + kt2 * 16 + li), g2[r]);
+#if IA_TILES_V2
+    if (narrow && q == 1)   // dW1[j][16 + c] = sum_r dz1[r][j] x[r][16 + c], c < D - 16 <= 4: all 32 rows j of the tower at once
+      for (int c = 16; c < D; ++c) {
+        const float sm = dot32(dz1t, lds + L::x + c * L::RS);
+        if (lane < 32) put(slab + (oW1 + lane * D + c), sm);
+      }
+#endif
     if (q == 3) colsum64_wide(dz2t, slab + ob2);
     for (int ti = q + 4; ti < 2 * KT; ti += 4) {   // observation widths beyond 32 columns: further dW1 tiles
       const int jt = ti / KT, kt = ti - jt * KT;
@@ -4138,6 +4197,70 @@ __global__ __launch_bounds__(512) void ppo_update_persistent_kernel(
   // gathers of a wave nine serial round trips to memory (3.6 us per step on the barrier path). `zero` is an opaque
   // 0 refreshed every step, so the element -> (row, column) arithmetic is redone here (a dozen VALU operations)
   // instead of being hoisted out of the step loop into 27 spilled registers.
+#if IA_PF16
+  // Round 5: the observation rows travel as 16-BYTE pieces (`global_load_lds` width 16: LDS destination = wave-uniform base +
+  // 16 x lane). Slot e = row * Q + piece, Q = ceil(D / 4): the rows land 4 Q floats apart in slot order -- exactly the order
+  // `chain_stage_rows` walks them (one ds_read_b128 per slot) --, ONE pass of five waves at D = 17 instead of three passes of
+  // all eight, a third of the address arithmetic. A row's last piece runs up to 12 bytes into the next row of the rollout
+  // tile (masked when the slot is read; the tile's last time slice T is never a minibatch row, so the tensor is not left).
+  // The per-row scalars are loaded by wave 7 (the x pieces occupy the low waves).
+  auto prefetch_issue = [&](const MbRows& r, int zero) {
+    const int* nxt = reinterpret_cast<const int*>(stg) + UpdStage::nxt;
+    constexpr int SCW = 7;   // wave that loads the per-row scalars
+    int src0 = 0;
+    if (wave == SCW) src0 = nxt[lane];
+    const int Q = (D + 3) >> 2;
+    constexpr int NQT = (PROWS * (MAXD / 4) + 511) / 512;
+    int qsrc[NQT], qoff[NQT];
+    const unsigned rcpQ = 0xffffffffu / (unsigned)Q + 1u;
+#pragma unroll
+    for (int it = 0; it < NQT; ++it) {
+      const int e0 = it * 512 + wave * 64 + zero;  // wave-uniform
+      qsrc[it] = qoff[it] = 0;
+      if (e0 < PROWS * Q) {
+        const int e = min(e0 + lane, PROWS * Q - 1);
+        const int rr = Q == 1 ? e : (int)__umulhi((unsigned)e, rcpQ);
+        qoff[it] = 4 * (e - rr * Q);
+        qsrc[it] = nxt[rr];
+      }
+    }
+    const int aw_ = d.discrete ? 1 : d.act_dim;
+    constexpr int NAT = (PROWS * MAXA + 511) / 512;
+    int asrc[NAT], acol[NAT];
+    const unsigned rcpA = 0xffffffffu / (unsigned)aw_ + 1u;   // (aw_ = 1: 0, not used)
+#pragma unroll
+    for (int it = 0; it < NAT; ++it) {
+      const int e0 = it * 512 + wave * 64 + zero;  // wave-uniform
+      acol[it] = asrc[it] = 0;
+      if (e0 < PROWS * aw_) {
+        const int e = min(e0 + lane, PROWS * aw_ - 1);
+        const int rr = aw_ == 1 ? e : (int)__umulhi((unsigned)e, rcpA);
+        acol[it] = e - rr * aw_;
+        asrc[it] = nxt[rr];
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int it = 0; it < NQT; ++it) {
+      const int e0 = it * 512 + wave * 64;  // wave-uniform
+      if (e0 < PROWS * Q)
+        __builtin_amdgcn_global_load_lds((glb_void_p)(r.obs + (long long)qsrc[it] * D + qoff[it]),
+                                         (lds_void_p)(stg + UpdStage::x + 4 * e0), 16, 0, 0);
+    }
+#pragma unroll
+    for (int it = 0; it < NAT; ++it) {
+      const int e0 = it * 512 + wave * 64;  // wave-uniform
+      if (e0 < PROWS * aw_)
+        __builtin_amdgcn_global_load_lds((glb_void_p)(r.actions + (long long)asrc[it] * aw_ + acol[it]),
+                                         (lds_void_p)(stg + UpdStage::act + e0), 4, 0, 0);
+    }
+    if (wave == SCW) {
+      __builtin_amdgcn_global_load_lds((glb_void_p)(r.old_logp + src0), (lds_void_p)(stg + UpdStage::oldlp), 4, 0, 0);
+      __builtin_amdgcn_global_load_lds((glb_void_p)(r.adv + src0), (lds_void_p)(stg + UpdStage::adv), 4, 0, 0);
+      __builtin_amdgcn_global_load_lds((glb_void_p)(r.ret + src0), (lds_void_p)(stg + UpdStage::ret), 4, 0, 0);
+    }
+  };
+#else
   auto prefetch_issue = [&](const MbRows& r, int zero) {
     const int* nxt = reinterpret_cast<const int*>(stg) + UpdStage::nxt;
     int src0 = 0;
@@ -4194,6 +4317,7 @@ __global__ __launch_bounds__(512) void ppo_update_persistent_kernel(
                                          (lds_void_p)(stg + UpdStage::x + e0), 4, 0, 0);
     }
   };
+#endif
   auto prefetch_park = [&]() {  // row offsets of the staged minibatch (its action loads use them)
     if (wave == 0) stg[UpdStage::src + lane] = stg[UpdStage::nxt + lane];
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the LDS-direct loads have landed
@@ -4676,6 +4800,27 @@ __global__ __launch_bounds__(512) void ppo_update_persistent_kernel(
         dt[k] = dstT[ic];
       }
       __builtin_amdgcn_sched_barrier(0);
+#if IA_ADAM_FAST
+      // Round 5: torch's `sqrt(v) / sqrt(bc2) + eps` and `m / denom` on the hardware's v_sqrt_f32 / v_rcp_f32 (1 ulp each) with
+      // one Newton step on the reciprocal, the division by sqrt(bc2) as a multiplication by its reciprocal (formed once per
+      // step): ~9 VALU operations per parameter instead of ~35 (two IEEE division expansions and a square-root expansion --
+      // ~400 instructions per wave and step in EVERY workgroup). The step differs from torch's by <= ~2 ulp of lr * m / denom
+      // (~1e-10 absolute at lr = 3e-4); the full-size parity tests re-measured: `profiles/r05_ppo_ab.md`.
+      const float inv_bc2 = 1.f / bc2_sqrt;
+#pragma unroll
+      for (int k = 0; k < NPT; ++k) {
+        const float gi = g[k] * coef;
+        float mi = rm[k];
+        mi = mi + (gi - mi) * (1.f - beta1);
+        const float vi = rv[k] * beta2 + (1.f - beta2) * gi * gi;
+        const float denom = __builtin_amdgcn_sqrtf(vi) * inv_bc2 + eps;
+        float rd = __builtin_amdgcn_rcpf(denom);
+        rd = __builtin_fmaf(rd, __builtin_fmaf(-denom, rd, 1.f), rd);
+        pv[k] = pv[k] - step_size * (mi * rd);
+        rm[k] = mi;     // (threads past the parameter count carry zeros: g = 0 keeps m = v = 0; nothing of theirs is stored)
+        rv[k] = vi;
+      }
+#else
 #pragma unroll
       for (int k = 0; k < NPT; ++k) {
         const float gi = g[k] * coef;
@@ -4687,6 +4832,7 @@ __global__ __launch_bounds__(512) void ppo_update_persistent_kernel(
         rm[k] = mi;     // (threads past the parameter count carry zeros: g = 0 keeps m = v = 0; nothing of theirs is stored)
         rv[k] = vi;
       }
+#endif
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int k = 0; k < NPT; ++k) {
