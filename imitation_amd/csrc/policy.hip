@@ -23,16 +23,6 @@
 
 namespace {
 
-// Same-box A/B switches of round 5's changes to the persistent PPO update (tools/ab_libs.sh builds one library per switch):
-#ifndef IA_PF16
-#define IA_PF16 1        // row prefetch of the next minibatch as 16-byte LDS-direct loads (rows staged 4 ceil(D / 4) floats apart)
-#endif
-#ifndef IA_ADAM_FAST
-#define IA_ADAM_FAST 1   // Adam's sqrt / two divisions on v_sqrt_f32 / v_rcp_f32 (+ one Newton step) instead of the IEEE expansions
-#endif
-#ifndef IA_TILES_V2
-#define IA_TILES_V2 1    // weight-gradient tiles with one useful row / column (value head, a <= 4-column last K tile) as VALU dots
-#endif
 constexpr int MAXD = 64;   // max observation width
 constexpr int MAXA = 16;   // max action width / number of discrete actions
 constexpr int ROWS = 64;   // rows per block (one wave)
@@ -2145,7 +2135,6 @@ struct CLds {  // LDS carve-up (floats) of the persistent update's minibatch til
   // ROWS, read four consecutive rows of a feature in ONE ds_read_b128 (row steps permuted: step s of lane group lk is row
   // 16 (s >> 2) + 4 lk + (s & 3)) -- 8 wide reads per 16 x 16 x 64 tile instead of 32 two-way conflicted ds_read_b32.
   static constexpr int RS = 68;
-  static constexpr int XS = MAXD + 1;                 // (width bound of a staged raw row: sizes the row prefetch)
   static constexpr int x = 0;                         // [MAXD][RS] normalised observations
   static constexpr int a1 = x + MAXD * RS;            // [2 towers][32][RS]
   static constexpr int a2 = a1 + 2 * 32 * RS;
@@ -2190,7 +2179,6 @@ __device__ __forceinline__ void chain_stage_rows(const ia_policy_desc& d, const 
       const int r = (g * s1r) >> 16, k0 = (g - r * S1) * 4;
       const bool rok = (i0 + rbase + r) < row_lim;
       float raw[4], mu[4], vr[4];
-#if IA_PF16
       {   // rows staged 4 S1 floats apart (16-byte pieces, as the LDS-direct loads left them): group g's piece is slot
           // rbase S1 + g of the area -- ONE ds_read_b128 each for the raw values, the means and 1 / std
         const f32x4 rq = *reinterpret_cast<const f32x4*>(stg + UpdStage::x + (rbase * S1 + g) * 4);
@@ -2203,14 +2191,6 @@ __device__ __forceinline__ void chain_stage_rows(const ia_policy_desc& d, const 
           vr[j] = vq[j];
         }
       }
-#else
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        raw[j] = stg[UpdStage::x + (rbase + r) * D + k0 + j];   // (packed rows; columns >= D are masked below)
-        mu[j] = nm[k0 + j];          // slot arrays hold MAXD entries each
-        vr[j] = nv[k0 + j];
-      }
-#endif
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const bool ok = rok && k0 + j < D;
@@ -2652,6 +2632,10 @@ __device__ __forceinline__ void mfma32_minibatch_chain(
   __syncthreads();   // every row's activations and activation gradients are in LDS
   IA_TS(6);
 
+  // (Round 5, measured and dropped: the six tiles of a step with ONE useful row / column -- value head, second first-layer
+  //  K tile at obs 17 -- as VALU dots with the head tiles moved to the waves that lost a tile, <= 64 MFMAs per SIMD instead
+  //  of 96: 15.50 -> 15.50 us per step at config P, +1-2 % on the one-workgroup forms. The phase is bound by its LDS reads
+  //  and dependent chains, not by MFMA issue: `profiles/r05_ppo_ab.md`.)
   // ---- gradient tiles: contractions over all 64 rows, independent per wave. Every tile requests its
   // 32 LDS operands first and then runs its 16 dependent MFMAs (the compiler otherwise pairs each
   // MFMA with its two reads and exposes an LDS round trip per step).
@@ -2762,52 +2746,6 @@ __device__ __forceinline__ void mfma32_minibatch_chain(
     s += __shfl_xor(s, 32, 64);
     if (lane < 32) put(dst + lane, s);
   };
-#if IA_TILES_V2
-  // Round 5: six of the twenty 16 x 16 x 64 tiles of a step produced ONE useful row or column (the value head's weight
-  // gradient: two tiles for 32 numbers; at obs 17 the second K tile of both towers' first layer: four tiles for 2 x 32
-  // numbers) and the two SIMDs that hosted the head tiles issued 96 MFMAs against 64 on the others. Those products are
-  // now VALU dots -- a lane per (feature, row half): sixteen ds_read_b128 and 32 fused multiply-adds --, the policy head's
-  // two tiles sit on the waves whose first-layer tile went away (q = 1, 3): <= 64 MFMAs on every SIMD.
-  const int KTg = (D + 15) >> 4;
-  const bool narrow = KTg == 2 && D - 16 <= 4;   // (launch-constant) the first layer's second K tile holds <= 4 columns
-  auto dot32 = [&](const float* __restrict__ U /* [32 features][RS] */, const float* __restrict__ vrow /* [RS] */) {
-    const float* up = U + (lane & 31) * L::RS + (lane >> 5) * 32;
-    const float* vp = vrow + (lane >> 5) * 32;
-    f32x4 u[8], w[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      u[i] = rd4(up + 4 * i);
-      w[i] = rd4(vp + 4 * i);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    float s0 = 0.f, s1 = 0.f;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      s0 = __builtin_fmaf(u[i][0], w[i][0], s0);
-      s1 = __builtin_fmaf(u[i][1], w[i][1], s1);
-      s0 = __builtin_fmaf(u[i][2], w[i][2], s0);
-      s1 = __builtin_fmaf(u[i][3], w[i][3], s1);
-    }
-    float sm = s0 + s1;
-    sm += __shfl_xor(sm, 32, 64);
-    return sm;   // (lanes j and j + 32: feature j's sum over the 64 rows)
-  };
-  if (tw == 0) {
-    if (q & 1) {  // dWa[a][h] = sum_r dout[r][a] a2[r][h], 16 h-columns per wave (waves 1 and 3)
-      const int ht = q >> 1;
-      const f32x4 g = outer16(lds + L::dout, li, a2t, ht * 16 + li);
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-        if (lk * 4 + r < A) put(slab + (o.aW + (lk * 4 + r) * H + ht * 16 + li), g[r]);
-    }
-    if (q == 2) colsum64(lds + L::dout, A, slab + o.ab);
-    if (q == 0 && !d.discrete) colsum64(lds + L::aux, A, slab + o.log_std);
-  } else {
-    if (q == 1) {  // dcW[h] = sum_r dv[r] a2[r][h]: 32 numbers
-      const float sm = dot32(a2t, lds + L::misc + L::RS);
-      if (lane < 32) put(slab + (o.cW + lane), sm);
-    }
-#else
   if (tw == 0) {
     if (q < 2) {  // dWa[a][h] = sum_r dout[r][a] a2[r][h], 16 h-columns per wave
       const f32x4 g = outer16(lds + L::dout, li, a2t, q * 16 + li);
@@ -2822,7 +2760,6 @@ __device__ __forceinline__ void mfma32_minibatch_chain(
       const f32x4 g = outer16(lds + L::misc + L::RS, 0, a2t, q * 16 + li);   // (every lane reads column 1; rows m > 0 unused)
       if (lk == 0) put(slab + (o.cW + q * 16 + li), g[0]);
     }
-#endif
     if (q == 2) {  // cb = sum_r dv[r]; statpart slots {0 pg, 2 ent, 3 kl, 4 clip, 1 value} <- misc columns 2..6
       // columns 1..6 of the misc tile summed together: lane c < 6 handles column 1 + c
       const int c = lane & 15, part = lane >> 4;
@@ -2859,12 +2796,7 @@ __device__ __forceinline__ void mfma32_minibatch_chain(
         for (int r = 0; r < 4; ++r) put(slab + (oW1 + (jt * 16 + lk * 4 + r) * D + col), g[r]);
     };
     f32x4 g2;
-#if IA_TILES_V2
-    const bool pair_w1 = q < 2 * KT && !(narrow && (q & 1));   // (narrow: tiles (jt, kt = 1) are the VALU dots below)
-#else
-    const bool pair_w1 = q < 2 * KT;
-#endif
-    if (pair_w1) {   // (wave-uniform)
+    if (q < 2 * KT) {   // (wave-uniform)
       const int jt = q / KT, kt = q - jt * KT;
       f32x4 g1;
       outer16_pair(dz2t, jt2 * 16 + li, a1t, kt2 * 16 + li, dz1t, jt * 16 + li, lds + L::x, kt * 16 + li, g2, g1);
@@ -2874,13 +2806,6 @@ __device__ __forceinline__ void mfma32_minibatch_chain(
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) put(slab + (oW2 + (jt2 * 16 + lk * 4 + r) * H + kt2 * 16 + li), g2[r]);
-#if IA_TILES_V2
-    if (narrow && q == 1)   // dW1[j][16 + c] = sum_r dz1[r][j] x[r][16 + c], c < D - 16 <= 4: all 32 rows j of the tower at once
-      for (int c = 16; c < D; ++c) {
-        const float sm = dot32(dz1t, lds + L::x + c * L::RS);
-        if (lane < 32) put(slab + (oW1 + lane * D + c), sm);
-      }
-#endif
     if (q == 3) colsum64_wide(dz2t, slab + ob2);
     for (int ti = q + 4; ti < 2 * KT; ti += 4) {   // observation widths beyond 32 columns: further dW1 tiles
       const int jt = ti / KT, kt = ti - jt * KT;
@@ -4162,7 +4087,6 @@ __global__ __launch_bounds__(512) void ppo_update_persistent_kernel(
   // Row prefetch: the gathers of step s+1 (two dependent global loads per element) are issued
   // before the grid barrier of step s and land in registers behind the barrier wait and the
   // update; they are parked in the LDS staging area just before step s+1 starts.
-  constexpr int NIT = (PROWS * L::XS + 511) / 512;   // (SMALL: 3 passes can hold its 16 rows, not 9)
   // (i) one step ahead of (ii): wave 7 resolves permutation entry -> rollout-tile row offset for the
   // block's 64 rows of minibatch s (a dependent global load plus a division) and leaves them in LDS;
   // any later block barrier publishes them. (ii) every thread then issues its row gathers at once.
@@ -4197,7 +4121,6 @@ __global__ __launch_bounds__(512) void ppo_update_persistent_kernel(
   // gathers of a wave nine serial round trips to memory (3.6 us per step on the barrier path). `zero` is an opaque
   // 0 refreshed every step, so the element -> (row, column) arithmetic is redone here (a dozen VALU operations)
   // instead of being hoisted out of the step loop into 27 spilled registers.
-#if IA_PF16
   // Round 5: the observation rows travel as 16-BYTE pieces (`global_load_lds` width 16: LDS destination = wave-uniform base +
   // 16 x lane). Slot e = row * Q + piece, Q = ceil(D / 4): the rows land 4 Q floats apart in slot order -- exactly the order
   // `chain_stage_rows` walks them (one ds_read_b128 per slot) --, ONE pass of five waves at D = 17 instead of three passes of
@@ -4260,64 +4183,6 @@ __global__ __launch_bounds__(512) void ppo_update_persistent_kernel(
       __builtin_amdgcn_global_load_lds((glb_void_p)(r.ret + src0), (lds_void_p)(stg + UpdStage::ret), 4, 0, 0);
     }
   };
-#else
-  auto prefetch_issue = [&](const MbRows& r, int zero) {
-    const int* nxt = reinterpret_cast<const int*>(stg) + UpdStage::nxt;
-    int src0 = 0;
-    if (wave == 0) src0 = nxt[lane];
-    // observations: staged PACKED, element e = row * D + column (only the D columns that exist: at D = 17 three
-    // 512-element passes instead of the nine a 65-wide row stride took); row = e / D by reciprocal multiplication
-    int srcs[NIT], cols[NIT];
-    const unsigned rcpD = 0xffffffffu / (unsigned)D + 1u;   // = ceil(2^32 / D) mod 2^32, by a 32-bit divide (the 64-bit one: ~100 scalar instructions per step)
-#pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-      const int e0 = it * 512 + wave * 64 + zero;  // wave-uniform
-      cols[it] = srcs[it] = 0;
-      if (e0 < PROWS * D) {   // (the passes this observation width fills: 3 of 9 at D = 17)
-        const int e = min(e0 + lane, PROWS * D - 1);
-        const int rr = D == 1 ? e : (int)__umulhi((unsigned)e, rcpD);
-        cols[it] = e - rr * D;
-        srcs[it] = nxt[rr];
-      }
-    }
-    // actions: element e = row * aw + column of the block's [ROWS][aw] tile, 512 elements per pass
-    const int aw_ = d.discrete ? 1 : d.act_dim;
-    constexpr int NAT = (PROWS * MAXA + 511) / 512;
-    int asrc[NAT], acol[NAT];
-    const unsigned rcpA = 0xffffffffu / (unsigned)aw_ + 1u;   // (aw_ = 1: 0, not used)
-#pragma unroll
-    for (int it = 0; it < NAT; ++it) {
-      const int e0 = it * 512 + wave * 64 + zero;  // wave-uniform
-      acol[it] = asrc[it] = 0;
-      if (e0 < PROWS * aw_) {
-        const int e = min(e0 + lane, PROWS * aw_ - 1);
-        const int rr = aw_ == 1 ? e : (int)__umulhi((unsigned)e, rcpA);
-        acol[it] = e - rr * aw_;
-        asrc[it] = nxt[rr];
-      }
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-    for (int it = 0; it < NAT; ++it) {
-      const int e0 = it * 512 + wave * 64;  // wave-uniform
-      if (e0 < PROWS * aw_)
-        __builtin_amdgcn_global_load_lds((glb_void_p)(r.actions + (long long)asrc[it] * aw_ + acol[it]),
-                                         (lds_void_p)(stg + UpdStage::act + e0), 4, 0, 0);
-    }
-    if (wave == 0) {
-      __builtin_amdgcn_global_load_lds((glb_void_p)(r.old_logp + src0), (lds_void_p)(stg + UpdStage::oldlp), 4, 0, 0);
-      __builtin_amdgcn_global_load_lds((glb_void_p)(r.adv + src0), (lds_void_p)(stg + UpdStage::adv), 4, 0, 0);
-      __builtin_amdgcn_global_load_lds((glb_void_p)(r.ret + src0), (lds_void_p)(stg + UpdStage::ret), 4, 0, 0);
-    }
-#pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-      const int e0 = it * 512 + wave * 64;  // wave-uniform
-      if (e0 < PROWS * D)
-        __builtin_amdgcn_global_load_lds((glb_void_p)(r.obs + (long long)srcs[it] * D + cols[it]),
-                                         (lds_void_p)(stg + UpdStage::x + e0), 4, 0, 0);
-    }
-  };
-#endif
   auto prefetch_park = [&]() {  // row offsets of the staged minibatch (its action loads use them)
     if (wave == 0) stg[UpdStage::src + lane] = stg[UpdStage::nxt + lane];
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the LDS-direct loads have landed
@@ -4800,7 +4665,6 @@ __global__ __launch_bounds__(512) void ppo_update_persistent_kernel(
         dt[k] = dstT[ic];
       }
       __builtin_amdgcn_sched_barrier(0);
-#if IA_ADAM_FAST
       // Round 5: torch's `sqrt(v) / sqrt(bc2) + eps` and `m / denom` on the hardware's v_sqrt_f32 / v_rcp_f32 (1 ulp each) with
       // one Newton step on the reciprocal, the division by sqrt(bc2) as a multiplication by its reciprocal (formed once per
       // step): ~9 VALU operations per parameter instead of ~35 (two IEEE division expansions and a square-root expansion --
@@ -4820,19 +4684,6 @@ __global__ __launch_bounds__(512) void ppo_update_persistent_kernel(
         rm[k] = mi;     // (threads past the parameter count carry zeros: g = 0 keeps m = v = 0; nothing of theirs is stored)
         rv[k] = vi;
       }
-#else
-#pragma unroll
-      for (int k = 0; k < NPT; ++k) {
-        const float gi = g[k] * coef;
-        float mi = rm[k];
-        mi = mi + (gi - mi) * (1.f - beta1);
-        const float vi = rv[k] * beta2 + (1.f - beta2) * gi * gi;
-        const float denom = sqrtf(vi) / bc2_sqrt + eps;
-        pv[k] = pv[k] - step_size * (mi / denom);
-        rm[k] = mi;     // (threads past the parameter count carry zeros: g = 0 keeps m = v = 0; nothing of theirs is stored)
-        rv[k] = vi;
-      }
-#endif
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int k = 0; k < NPT; ++k) {

@@ -116,7 +116,9 @@ class _PermutationPredraw:
     def _same(a, b) -> bool:
         return a[0] == b[0] and a[2:] == b[2:] and np.array_equal(a[1], b[1])
 
-    def start(self, out: np.ndarray) -> None:
+    def start(self, out: np.ndarray, then=None) -> None:
+        """`then(key, pos, state0)` (optional) is called in the helper's thread once the permutations are drawn, with the
+        generator state BEHIND them (the trainer's discriminator index draws continue from there)."""
         assert out.dtype == np.int64 and out.flags.c_contiguous and out.shape == (self.n_epochs, self.size)
         st = np.random.get_state()
         if st[0] != "MT19937":
@@ -131,6 +133,8 @@ class _PermutationPredraw:
         def work():
             self._rc = lib.ia_host_mt19937_permutations(self._key.ctypes.data, C.byref(self._pos), self.size,
                                                         self.n_epochs, out.ctypes.data)
+            if then is not None and self._rc == 0:
+                then(self._key, int(self._pos.value), st)
 
         self._thread = HostWorker.named("permutations").submit(work)
 
@@ -380,6 +384,10 @@ class PPO(OnPolicyAlgorithm):
         # ... and, ahead of both (right behind the update's launch): `after_train_enqueued(last_iteration)` -- the pipelined
         # adversarial trainer enqueues the round's discriminator updates there, before any host-side wait of this iteration
         self.after_train_enqueued = None
+        # hooks of the adversarial trainer's index predraws (`adversarial/common.py: _DiscIndexPredraw`): called right behind
+        # the rollout's one noise draw; factory of the continuation of the permutation helper (argument: rows of the rollout)
+        self.after_noise_drawn = None
+        self.perm_continuation = None
         self._post_enqueue_work = []
         self._act_stream = None
         self.rollout_post_ahead = True   # (tuning / A-B: False posts a mailbox step only at the top of its own iteration)
@@ -556,7 +564,8 @@ class PPO(OnPolicyAlgorithm):
             self._dpg["perms"].start(self._dpg["perm_np"])   # shared across ranks; consumed by the next train()
         else:
             self._perm_uploaded = None
-            self._predraw.start(self._perm_np)  # consumed by the `train()` that follows
+            cont = self.perm_continuation(T * n) if self.perm_continuation is not None else None
+            self._predraw.start(self._perm_np, then=cont)  # consumed by the `train()` that follows
         stream = th.cuda.current_stream()
         rb.h_obs[0].copy_(th.as_tensor(np.asarray(self._last_obs)).reshape(n, -1))
         starts = np.asarray(self._last_episode_starts, dtype=bool)
@@ -605,6 +614,8 @@ class PPO(OnPolicyAlgorithm):
                         rb.h_noise_tile = th.zeros(T, n, width).pin_memory()
                     noise_tile = rb.h_noise_tile
                     pol.draw_noise_into(noise_tile)
+                    if self.after_noise_drawn is not None:   # torch's global generator rests until the round's updates
+                        self.after_noise_drawn()
                 predrawn = noise_tile.dim() == 3
                 act_step = pol.make_act_step(rb.h_obs, noise_tile, rb.acts, rb.h_clip, rb.val, rb.logp)  # eval mode: no norm update
                 # ONE resident launch for the rollout's T act steps, driven through flags in pinned host memory: a step
