@@ -91,6 +91,8 @@ _P, _I, _L, _F, _D = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_double
 _SIGS = {
     "ia_version": ([], C.c_int),
     "ia_host_mt19937_permutations": ([_P, C.POINTER(C.c_int), _L, _I, _P], C.c_int),
+    "ia_host_mt19937_permutations_then_randint": ([_P, C.POINTER(C.c_int), _L, _I, _P, _L, _L, _L, _P, _P,
+                                                   C.POINTER(C.c_int)], C.c_int),
     "ia_host_mt19937_seeded_permutations": ([_P, _I, _L, _I, _P], C.c_int),
     "ia_im2col_u8_nchw": ([_P, _I, _I, _I, _I, _I, _I, _I, _F, _P, _P], C.c_int),
     "ia_im2col_f32_nhwc": ([_P, _I, _I, _I, _I, _I, _I, _I, _P, _P], C.c_int),

@@ -25,7 +25,6 @@ from imitation_amd import _lib as L
 from imitation_amd import buffer, data_types as dt
 from imitation_amd import logger as imit_logger
 from imitation_amd import networks, ppo, reward_nets, wrappers
-from imitation_amd.host_worker import HostWorker
 from imitation_amd.networks import HipAdam, TransitionTable, require_device
 from imitation_amd.policies import ActorCriticPolicy
 
@@ -77,111 +76,6 @@ def _upload_table(samples: Mapping, obs_shape, discrete: bool, device) -> Transi
                            th.from_numpy(np.ascontiguousarray(arr("dones"), dtype=np.uint8)).to(device), discrete)
 
 
-class _DiscIndexPredraw:
-    """The host index draws of a round's discriminator updates -- the expert loader's epoch seeds + `torch.randperm`
-    (`data_types.ExpertIndexStream`) and the replay ring's `np.random.randint` rows (`buffer.sample_indices`), 0.7 ms of the
-    host path behind the PPO launch at config P -- made DURING the rollout, by helper threads, on COPIES of the two global
-    generators:
-
-    * torch: right behind the rollout's one noise draw (`PPO.after_noise_drawn`) nothing reads torch's global CPU generator
-      until the round's updates; a clone of its state serves the round's `next_indices` calls (the `torch.randperm` of an
-      epoch start runs without the GIL);
-    * NumPy: the permutation helper of the PPO update (`ppo._PermutationPredraw`) leaves the generator state BEHIND the
-      epoch permutations; `RandomState.randint` on that state is what `np.random.randint` will do.
-
-    `adopt` (at the start of `_disc_round`, which makes exactly n draws of each kind) hands the rows over only if the global
-    generators are, at that point, in the states the copies started from and the ring holds as many rows as was assumed; the
-    global states then jump behind the draws -- values and generator states are those of drawing in place, which is what
-    happens otherwise (`tests/test_host_logic.py::test_disc_index_predraw_*`)."""
-
-    def __init__(self, trainer):
-        self.tr = trainer
-        self._expert = None      # (event, box) of the running / finished torch-side job
-        self._replay = None
-        self.adopted = [0, 0]    # rounds whose (expert, replay) rows came from a predraw (tests, profiles)
-
-    # ---- torch side ------------------------------------------------------------------------------
-    def start_expert(self) -> None:
-        tr = self.tr
-        st = getattr(tr, "_expert_stream", None)
-        self._expert = None
-        if st is None or getattr(tr, "_expert_batches", None) is not None or not tr.predraw_disc_indices:
-            return
-        n = tr.n_disc_updates_per_round
-        snap = th.get_rng_state()
-        perm, pos = st._perm, st._pos
-        box = {}
-
-        def work():
-            g = th.Generator()
-            g.set_state(snap)
-            draw = lambda: int(th.empty((), dtype=th.int64).random_(generator=g).item())   # noqa: E731
-            p, q, rows = perm, pos, []
-            for _ in range(n):
-                if p is None or q >= st.batches_per_epoch:
-                    draw()                      # iter(loader): base seed
-                    pg = th.Generator()
-                    pg.manual_seed(draw())      # first next(): sampler seed
-                    p, q = th.randperm(st.n, generator=pg).numpy(), 0
-                rows.append(p[q * st.batch_size:(q + 1) * st.batch_size])
-                q += 1
-            box.update(snap=snap, post=g.get_state(), rows=rows, perm=p, pos=q, n=n)
-
-        self._expert = (HostWorker.named("expert-draws").submit(work), box)
-
-    # ---- NumPy side (runs in the permutation helper's thread, behind the permutations) -----------------
-    def replay_continuation(self, rows_in_rollout: int):
-        tr = self.tr
-        self._replay = None
-        buf = getattr(tr, "_gen_replay_buffer", None)
-        if not tr.predraw_disc_indices or buf is None:
-            return None
-        n, B = tr.n_disc_updates_per_round, tr.demo_batch_size
-        size = min(buf.size() + rows_in_rollout, buf.capacity)
-        box = {}
-        self._replay = box
-
-        def then(key: np.ndarray, pos: int, state0) -> None:
-            # (called in the permutation helper's thread when the permutations are done; the draws go to a worker of their
-            #  own so that `PPO.train`, which waits for the permutations, never waits for them)
-            key = key.copy()
-
-            def draw():
-                rs = np.random.RandomState()
-                rs.set_state((state0[0], key, pos, state0[3], state0[4]))
-                box.update(pre=(key, pos), rows=[rs.randint(size, size=B) for _ in range(n)], post=rs.get_state(),
-                           size=size, n=n)
-
-            box["event"] = HostWorker.named("replay-draws").submit(draw)
-
-        return then
-
-    # ---- hand-over -------------------------------------------------------------------------------
-    def adopt(self, n: int):
-        """`(expert rows | None, replay rows | None)` for the n updates about to be drawn."""
-        tr = self.tr
-        e_rows = g_rows = None
-        job, self._expert = self._expert, None
-        if job is not None:
-            job[0].wait()
-            box = job[1]
-            if box.get("n") == n and th.equal(th.get_rng_state(), box["snap"]):
-                th.set_rng_state(box["post"])
-                tr._expert_stream._perm, tr._expert_stream._pos = box["perm"], box["pos"]
-                e_rows = list(box["rows"])
-                self.adopted[0] += 1
-        box, self._replay = self._replay, None
-        if box and box.get("event") is not None:
-            box["event"].wait()
-        if box and box.get("n") == n and box["size"] == tr._gen_replay_buffer.size():
-            st = np.random.get_state()
-            if st[0] == "MT19937" and int(st[2]) == box["pre"][1] and np.array_equal(st[1], box["pre"][0]):
-                np.random.set_state(box["post"])
-                g_rows = list(box["rows"])
-                self.adopted[1] += 1
-        return e_rows, g_rows
-
-
 class AdversarialTrainer(abc.ABC):
     """Base class for adversarial imitation learning algorithms like GAIL and AIRL."""
 
@@ -207,13 +101,13 @@ class AdversarialTrainer(abc.ABC):
         self._horizon = None
         self.venv = venv
         self.gen_algo = gen_algo
-        # the discriminator updates' index rows, drawn by helper threads during the rollout (`_DiscIndexPredraw`)
+        # the replay ring's index rows of a round's discriminator updates are drawn by the PPO permutation helper's C call,
+        # behind the epoch permutations, on a copy of NumPy's global generator (`_replay_rows_spec`, `_disc_round`)
         self.predraw_disc_indices = True
-        self._idx_predraw = _DiscIndexPredraw(self)
-        self._pre_expert_rows, self._pre_replay_rows = [], []
+        self.replay_rows_predrawn = 0    # rounds whose rows came from the helper (tests, profiles)
+        self._pre_replay_rows = []
         if isinstance(gen_algo, ppo.PPO):
-            gen_algo.after_noise_drawn = self._idx_predraw.start_expert
-            gen_algo.perm_continuation = self._idx_predraw.replay_continuation
+            gen_algo.randint_spec_for_round = self._replay_rows_spec
         self._device = th.device(gen_algo.device)
         require_device(self._device)
         L.load()  # fail loudly here if the HIP extension is missing
@@ -446,6 +340,15 @@ class AdversarialTrainer(abc.ABC):
         if len(hs) == 1:
             self._horizon = hs.pop()
 
+    def _replay_rows_spec(self, rows_in_rollout: int):
+        """(high, rows, row_len) of the `np.random.randint` draws the next `_disc_round` will make (`buffer.sample_indices`:
+        one row of `demo_batch_size` indices below the ring's fill per update), given that the rollout about to be collected
+        adds `rows_in_rollout` rows to the ring first; None: do not predraw."""
+        buf = getattr(self, "_gen_replay_buffer", None)
+        if not self.predraw_disc_indices or buf is None:
+            return None
+        return (min(buf.size() + rows_in_rollout, buf.capacity), self.n_disc_updates_per_round, self.demo_batch_size)
+
     # ---- discriminator update (`common.py:317-389,521-632`) --------------------------------------
     def _batch_sources(self, expert_samples, gen_samples, upload: bool = True):
         """(expert_table, expert_idx_dev | None), (gen_table, gen_idx_dev | None) for one update. `upload=False` (ring
@@ -465,8 +368,7 @@ class AdversarialTrainer(abc.ABC):
             if self._expert_batches is not None:
                 expert_samples = next(self._expert_batches)
             else:
-                rows = self._pre_expert_rows.pop(0) if self._pre_expert_rows else self._expert_stream.next_indices()
-                idx_host[0].copy_(th.from_numpy(rows))
+                idx_host[0].copy_(th.from_numpy(self._expert_stream.next_indices()))
                 e_idx = idx_dev[0]
         if gen_samples is None:
             if self._gen_replay_buffer.size() == 0:
@@ -571,9 +473,18 @@ class AdversarialTrainer(abc.ABC):
         steps = []
         self._use_ring = True
         self._gp_block = None   # (a block left over by a round that raised is dropped, not served)
-        # index rows drawn during the rollout by the helper threads, if the generators are where the helpers started
-        e_rows, g_rows = self._idx_predraw.adopt(n)
-        self._pre_expert_rows, self._pre_replay_rows = e_rows or [], g_rows or []
+        # the ring's index rows, if the permutation helper drew them for exactly this round and NumPy's global generator is
+        # still where `PPO.train` left it (then it moves behind them: values and state of drawing in place)
+        self._pre_replay_rows = []
+        pre = getattr(self.gen_algo, "_predraw", None)
+        ring = self._gen_replay_buffer
+        plain_ring = (type(ring).sample_indices is buffer.ReplayBuffer.sample_indices
+                      and "sample_indices" not in ring.__dict__)   # (a replaced sampler is asked, not bypassed)
+        if self.predraw_disc_indices and plain_ring and pre is not None and hasattr(pre, "take_randint"):
+            rows = pre.take_randint(self._gen_replay_buffer.size(), n, self.demo_batch_size)
+            if rows is not None:
+                self._pre_replay_rows = list(rows)
+                self.replay_rows_predrawn += 1
         try:
             if prepass:
                 # all host index draws of the round first (same order as one per update), then the
@@ -627,7 +538,7 @@ class AdversarialTrainer(abc.ABC):
                     steps.append(self._disc_step)
         finally:
             self._use_ring = False
-            self._pre_expert_rows, self._pre_replay_rows = [], []
+            self._pre_replay_rows = []
         self._stats_ring_turn ^= 1
         host_rows = self._stats_ring_hosts[self._stats_ring_turn]
         host_rows.copy_(self._stats_ring, non_blocking=True)

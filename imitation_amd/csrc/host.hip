@@ -115,6 +115,30 @@ extern "C" int ia_host_mt19937_permutations(uint32_t* key, int* pos, int64_t n, 
   return IA_OK;
 }
 
+// The same, followed -- on a COPY of the generator -- by `rows` x `row_len` draws of `np.random.randint(high, size=row_len)`
+// (legacy `RandomState.randint`, int64: `_rand_int64` -> `random_bounded_uint64_fill` with use_masked = 1, i.e. for
+// high - 1 < 2^32 - 1 one masked rejection loop over 32-bit draws per element; high == 1: zeros, no draw). key / pos are
+// left BEHIND THE PERMUTATIONS (what `PPO.train` installs as the global state when it adopts them); key_post / pos_post
+// receive the state behind the randint rows (what the discriminator round installs when it adopts those: the replay
+// ring's sixteen `sample_indices` calls of a round, `algorithms/adversarial/common.py:557-575` through
+// `data/buffer.py:366-377`). One call, no GIL in between: the helper thread never competes with the rollout loop.
+extern "C" int ia_host_mt19937_permutations_then_randint(uint32_t* key, int* pos, int64_t n, int count, int64_t* out,
+                                                         int64_t high, int64_t rows, int64_t row_len, int64_t* out_rows,
+                                                         uint32_t* key_post, int* pos_post) {
+  const int rc = ia_host_mt19937_permutations(key, pos, n, count, out);
+  if (rc != IA_OK) return rc;
+  if (rows <= 0) return IA_OK;
+  if (out_rows == nullptr || key_post == nullptr || pos_post == nullptr || high < 1 || high > 0x100000000LL || row_len < 0)
+    return IA_ERR_ARG;
+  for (int i = 0; i < MT_N; ++i) key_post[i] = key[i];
+  int p = *pos;
+  const uint64_t rng = (uint64_t)(high - 1);
+  for (int64_t i = 0; i < rows * row_len; ++i)
+    out_rows[i] = rng == 0xffffffffULL ? (int64_t)mt_next32(key_post, p) : (int64_t)legacy_interval(key_post, p, rng);
+  *pos_post = p;
+  return IA_OK;
+}
+
 // Host half of the rollout mailbox (policy_rollout_mailbox_kernel): spin until every one of the `n` flags the device
 // writes into pinned host memory has reached `target`. 0 = reached, 1 = timed out, -1 = a flag went negative (the
 // kernel gave up: aborted or its own time-out). Called through ctypes, i.e. without the GIL.

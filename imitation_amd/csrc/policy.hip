@@ -443,6 +443,9 @@ __global__ void bootstrap_kernel(float* __restrict__ rewards, const float* __res
 //                       "prepare" launch is needed except for the first minibatch of an epoch.
 
 __host__ __device__ inline long long epoch_ll_words(int nrb, int P);   // (ppo_epoch_ll_kernel's word areas)
+__host__ __device__ inline long long t64_words(int nrb, int TWp);       // (ppo_epoch_t64_kernel's)
+struct PolOff;
+__host__ __device__ inline int t64_twp(const PolOff& o, int D, int A, int discrete);
 __host__ __device__ inline int epoch_ll_row_blocks(int nrb, int P);
 // ws layout (floats): [0..7] adv stats {mean, std}; [8..8+nblk*8) loss-stat partials;
 // then gradient slabs [nblk][P]; then reduced gradient [P].
@@ -3761,6 +3764,938 @@ __global__ __launch_bounds__(256) void ppo_epoch_ll_kernel(
 #undef EP_TS
 }
 
+// ---------------------------------------------------------------------------------------------
+// 64-wide towers (SB3's default `MlpPolicy`), round 5: TOWER-RESIDENT parameters and the transposed, register-resident
+// chain of the 32-wide persistent kernel.
+//
+//   grid = 2 nrb workgroups of FOUR waves: workgroup (rb, tw) = (bid >> 1, bid & 1) runs tower tw (0 policy, 1 value) of
+//   row block rb (64 rows) of every minibatch; wave q owns rows 16 q .. 16 q + 15 for the whole activation chain
+//       x -> a1 -> a2 -> head -> per-row loss -> d head -> dz2 -> dz1
+//   with features along the MFMA's M index, the wave's rows along N and the k index of a step permuted so that the
+//   accumulator of one layer IS the B operand of the next (`mfma32_minibatch_chain`): activations never leave the
+//   registers; the `[feature][row]` LDS tiles are written on the side for the weight-gradient tiles (ds_read_b128 of four
+//   consecutive rows). One wave per SIMD: the matrix pipe and the VALU are the wave's own.
+//   The tower's parameters LIVE in LDS for the whole launch -- W1 / W2 in torch layout with padded rows (a forward
+//   fragment = the four consecutive INPUTS of an output row: one ds_read_b128), W2 transposed likewise for the backward
+//   pass, the head in both orientations -- and Adam's moments of the WHOLE tower in the registers of each of its nrb
+//   workgroups: every workgroup of a tower applies the same clip + Adam step to its own copy, so there is NO parameter
+//   hand-off (`ppo_epoch_ll_kernel`: chunk owners publish 5.3 k parameter words per tower and step, every tower workgroup
+//   polls them, rebuilds two LDS images and re-reads every fragment: 5.3 of its 26.5 us per step).
+//   Exchange per step, as in the 32-wide kernel: (value, sequence) words, two hops. Hop 1: workgroup (rb, tw) polls slice
+//   rb of the nrb slabs of ITS tower, sums them in slab order, publishes the slice and the slice's sum of squares (one
+//   word); hop 2: it polls its tower's whole sum vector and the 2 nrb sums of squares (both towers: the clip is by the
+//   GLOBAL norm), folds those in a fixed order, clips, steps. The next minibatch's rows are loaded (plain loads of the
+//   gathered, contiguous rows) at the top of a step, parked in LDS behind the chain's barrier and normalised into the x
+//   tile between the two hops.
+struct T64Geo {   // LDS carve-up (floats; every offset a multiple of 4) of one tower workgroup
+  static constexpr int RS = 68;    // row stride of the [feature][row] tiles and of the 64-wide weight images
+  static constexpr int HT = 20;    // row stride of the transposed head image [64 hidden][16 actions + 4]
+  int DP;                          // padded first-layer row: multiple of 4 with DP / 4 odd (eight lanes' b128 reads hit 32 banks)
+  int x, a1, a2, dz2, dz1, dout, aux, misc, scratch;   // tiles
+  int W1, W2, W2T, b1, b2, HW, HWT, hb, ls;            // images
+  int sx, sact, soldlp, sadv, sret, ring;              // staging of the next minibatch's rows; its statistics slot
+  int total;
+};
+__host__ __device__ inline T64Geo t64_geo(int D, int aw, int KT1) {
+  constexpr int RS = T64Geo::RS;
+  T64Geo g;
+  int S1 = (D + 3) >> 2;
+  if (!(S1 & 1)) ++S1;
+  g.DP = 4 * S1;
+  int p = 0;
+  g.x = p; p += 16 * KT1 * RS;
+  g.a1 = p; p += 64 * RS;
+  g.a2 = p; p += 64 * RS;
+  g.dz2 = p; p += 64 * RS;
+  g.dz1 = p; p += 64 * RS;
+  g.dout = p; p += 16 * RS;
+  g.aux = p; p += 16 * RS;
+  g.misc = p; p += 8 * RS;
+  g.scratch = p; p += 64;
+  g.W1 = p; p += 64 * g.DP;
+  g.W2 = p; p += 64 * RS;
+  g.W2T = p; p += 64 * RS;
+  g.b1 = p; p += 64;
+  g.b2 = p; p += 64;
+  g.HW = p; p += 16 * RS;
+  g.HWT = p; p += 64 * T64Geo::HT;
+  g.hb = p; p += 16;
+  g.ls = p; p += 16;
+  g.sx = p; p += (64 * D + 3) & ~3;
+  g.sact = p; p += (64 * aw + 3) & ~3;
+  g.soldlp = p; p += 64;
+  g.sadv = p; p += 64;
+  g.sret = p; p += 64;
+  g.ring = p; p += 2 * MAXD + 8;
+  g.total = p;
+  return g;
+}
+// Tower-local parameter order: W1 [64][D], b1, W2 [64][64], b2, head weights (action_net [A][64] | value_net [64]),
+// head bias, log_std (policy tower of a Box space).
+struct T64Loc {
+  int lb1, lW2, lb2, lHW, lHb, lLS, TW;   // local offsets; TW: the tower's parameter count
+  int fbase, fhead, fls;                  // flat offsets of the three pieces in the parameter vector
+};
+__host__ __device__ inline T64Loc t64_loc(const PolOff& o, int D, int A, int discrete, int tw) {
+  T64Loc l;
+  l.lb1 = 64 * D;
+  l.lW2 = l.lb1 + 64;
+  l.lb2 = l.lW2 + 64 * 64;
+  l.lHW = l.lb2 + 64;
+  l.lHb = l.lHW + (tw ? 64 : A * 64);
+  l.lLS = l.lHb + (tw ? 1 : A);
+  l.TW = l.lLS + ((tw == 0 && !discrete) ? A : 0);
+  l.fbase = tw ? o.vW1 : o.pW1;
+  l.fhead = tw ? o.cW : o.aW;
+  l.fls = discrete ? 0 : o.log_std;
+  return l;
+}
+__host__ __device__ inline int t64_flat(const T64Loc& l, int i) {
+  return i < l.lHW ? l.fbase + i : (i < l.lLS ? l.fhead + (i - l.lHW) : l.fls + (i - l.lLS));
+}
+__host__ __device__ inline int t64_twp(const PolOff& o, int D, int A, int discrete) {
+  const int t0 = t64_loc(o, D, A, discrete, 0).TW, t1 = t64_loc(o, D, A, discrete, 1).TW;
+  return ((t0 > t1 ? t0 : t1) + 3) & ~3;
+}
+// word areas (8-byte words): slabs [2 parities][2 towers][nrb][TWp + 8] | sums [2][2][TWp + 8] | sums of squares [2][2][32]
+__host__ __device__ inline long long t64_words(int nrb, int TWp) {
+  return 4LL * nrb * (TWp + 8) + 4LL * (TWp + 8) + 4 * 32;
+}
+
+// The chain + weight-gradient tiles of one tower workgroup for one minibatch. `row0`: first minibatch row of the block,
+// `b`: rows of the minibatch; `slab`: this workgroup's slab (words); `mid()`: called by every wave behind the barrier that
+// ends the activation chain (the caller parks the next minibatch's prefetched rows there).
+template <int KT1, class Mid>
+__device__ __forceinline__ void t64_tower_minibatch(
+    const ia_policy_desc& d, const T64Geo& G, const T64Loc& Lc, const int tw, float* __restrict__ lds, const int row0,
+    const int b, const float adv_mean, const float adv_std, const int normalize_adv, const float clip, const float ent_coef,
+    const float vf_coef, unsigned long long* __restrict__ slab, const int tail0, const unsigned seq, Mid&& mid) {
+  constexpr int RS = T64Geo::RS;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int q = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 15, lk = lane >> 4;
+  const int D = d.obs_dim, A = d.act_dim;
+  const int aw = d.discrete ? 1 : A;
+  const float invB = 1.f / (float)b;
+  auto rd4 = [&](const float* p) { return *reinterpret_cast<const f32x4*>(p); };
+  auto put = [&](int idx, float v) { ll_store_agent(slab + idx, v, seq); };
+  const int lrow = q * 16 + li;
+  const bool valid = row0 + lrow < b;
+  // per-row scalars of the loss (staged by the prefetch)
+  float r_oldlp = 0.f, r_adv = 0.f, r_ret = 0.f, r_act[4] = {0.f, 0.f, 0.f, 0.f};
+  if (tw == 0) {
+    r_oldlp = lds[G.soldlp + lrow];
+    r_adv = lds[G.sadv + lrow];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) r_act[j] = lds[G.sact + lrow * aw + min(4 * lk + j, aw - 1)];
+  } else {
+    r_ret = lds[G.sret + lrow];
+  }
+  // ---- layer 1: a1^T = tanh(W1 x^T + b1). A operand: W1[out 16 t + li][in 16 kt + 4 lk + r], r = 0..3 one ds_read_b128 of the
+  // padded torch-layout image; B operand: the wave's x rows, column 16 kt + 4 lk + r of row li
+  f32x4 a1[4], a2[4];
+  {
+    f32x4 fW1[KT1][4], b1c[4];
+    float xb[KT1][4];
+#pragma unroll
+    for (int kt = 0; kt < KT1; ++kt)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) fW1[kt][t] = rd4(lds + G.W1 + (16 * t + li) * G.DP + min(16 * kt + 4 * lk, G.DP - 4));
+#pragma unroll
+    for (int t = 0; t < 4; ++t) b1c[t] = rd4(lds + G.b1 + 16 * t + 4 * lk);
+#pragma unroll
+    for (int kt = 0; kt < KT1; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) xb[kt][r] = lds[G.x + (16 * kt + 4 * lk + r) * RS + q * 16 + li];
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int kt = 0; kt < KT1; ++kt) {
+      const bool on = 16 * kt + 4 * lk < G.DP;   // (quads past the padded row: the clamped read returned other columns)
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) fW1[kt][t][r] = on ? fW1[kt][t][r] : 0.f;
+    }
+    f32x4 acc[4][2];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      acc[t][0] = b1c[t];
+      acc[t][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int kt = 0; kt < KT1; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[t][(kt * 4 + r) & 1] = mfma16(fW1[kt][t][r], xb[kt][r], acc[t][(kt * 4 + r) & 1]);
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        a1[t][r] = fast_tanh(acc[t][0][r] + acc[t][1][r]);
+        lds[G.a1 + (16 * t + 4 * lk + r) * RS + q * 16 + li] = a1[t][r];
+      }
+  }
+  // ---- layer 2: a2^T = tanh(W2 a1^T + b2): the accumulators of layer 1 are the B operands
+  {
+    f32x4 fW2[4][4], b2c[4];
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) fW2[kt][t] = rd4(lds + G.W2 + (16 * t + li) * RS + 16 * kt + 4 * lk);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) b2c[t] = rd4(lds + G.b2 + 16 * t + 4 * lk);
+    __builtin_amdgcn_sched_barrier(0);
+    f32x4 acc[4][2];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      acc[t][0] = b2c[t];
+      acc[t][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[t][r & 1] = mfma16(fW2[kt][t][r], a1[kt][r], acc[t][r & 1]);
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        a2[t][r] = fast_tanh(acc[t][0][r] + acc[t][1][r]);
+        lds[G.a2 + (16 * t + 4 * lk + r) * RS + q * 16 + li] = a2[t][r];
+      }
+  }
+  // ---- head. The head image holds action_net's rows (rows >= A zero) resp. value_net's row in row 0 (rows 1.. zero): the M
+  // index li picks the row; hout[r] = output 4 lk + r of row li (value: lane group 0, register 0)
+  float hout[4];
+  {
+    f32x4 fHead[4];
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) fHead[kt] = rd4(lds + G.HW + li * RS + 16 * kt + 4 * lk);
+    const f32x4 hb = rd4(lds + G.hb + 4 * lk);
+    __builtin_amdgcn_sched_barrier(0);
+    f32x4 acc[2] = {hb, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[r & 1] = mfma16(fHead[kt][r], a2[kt][r], acc[r & 1]);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) hout[r] = acc[0][r] + acc[1][r];
+  }
+  // backward fragments: the head's weights of the lane's outputs 16 t + 4 lk + r here (landed by the time the loss phase is
+  // through); W2 transposed (A[m = in 16 t + li][k = out 16 kt + 4 lk + r]) behind the loss phase
+  f32x4 fHeadT[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+    fHeadT[t] = tw == 0 ? rd4(lds + G.HWT + (16 * t + li) * T64Geo::HT + 4 * lk) : rd4(lds + G.HW + 16 * t + 4 * lk);
+  // ---- per-row losses (the expressions of `mfma32_minibatch_chain`): four lanes per row, lane group lk = actions 4 lk ..
+  auto xchg16 = [](float v, float& a, float& bq) {
+    const auto p2 = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    a = __uint_as_float(p2[0]);
+    bq = __uint_as_float(p2[1]);
+  };
+  auto xchg32 = [](float v, float& a, float& bq) {
+    const auto p2 = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    a = __uint_as_float(p2[0]);
+    bq = __uint_as_float(p2[1]);
+  };
+  auto group_sum = [&](float v) {
+    float a, bq;
+    xchg16(v, a, bq);
+    v = a + bq;
+    xchg32(v, a, bq);
+    return a + bq;
+  };
+  auto group_max = [&](float v) {
+    float a, bq;
+    xchg16(v, a, bq);
+    v = fmaxf(a, bq);
+    xchg32(v, a, bq);
+    return fmaxf(a, bq);
+  };
+  float dout[4] = {0.f, 0.f, 0.f, 0.f}, dvb = 0.f;
+  if (tw == 0) {
+    float c_ivar[4] = {1.f, 1.f, 1.f, 1.f}, c_logsd[4] = {0.f, 0.f, 0.f, 0.f};
+    if (!d.discrete) {   // lane a: action a's (1 / sd^2, log sd); every lane picks its four actions' pairs up from the wave
+      const float sd = expf(lds[G.ls + min(lane, A - 1)]);
+      const float my_ivar = lane < A ? 1.f / (sd * sd) : 1.f;
+      const float my_logsd = lane < A ? logf(sd) : 0.f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        c_ivar[j] = __shfl(my_ivar, 4 * lk + j, 64);
+        c_logsd[j] = __shfl(my_logsd, 4 * lk + j, 64);
+      }
+    }
+    float logp = 0.f, entropy = 0.f, lse = 0.f;
+    int act_i = 0;
+    if (d.discrete) act_i = (int)r_act[0];
+    if (!d.discrete) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (4 * lk + j < A) {
+          const float diff = r_act[j] - hout[j];
+          logp += -(diff * diff) * (0.5f * c_ivar[j]) - c_logsd[j] - LOG_SQRT_2PI;
+          entropy += 0.5f + LOG_SQRT_2PI + c_logsd[j];
+        }
+      logp = group_sum(logp);
+      entropy = group_sum(entropy);
+    } else {
+      float mx = -3.0e38f, o_act = 0.f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (4 * lk + j < A) {
+          mx = fmaxf(mx, hout[j]);
+          o_act += (4 * lk + j == act_i) ? hout[j] : 0.f;
+        }
+      mx = group_max(mx);
+      o_act = group_sum(o_act);
+      float se = 0.f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (4 * lk + j < A) se += expf(hout[j] - mx);
+      lse = mx + logf(group_sum(se));
+      logp = o_act - lse;
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (4 * lk + j < A) {
+          const float l = hout[j] - lse;
+          entropy -= expf(l) * l;
+        }
+      entropy = group_sum(entropy);
+    }
+    float advn = r_adv;
+    if (normalize_adv && b > 1) advn = (advn - adv_mean) / (adv_std + 1e-8f);
+    const float log_ratio = logp - r_oldlp;
+    const float ratio = expf(log_ratio);
+    const float lo = 1.f - clip, hi = 1.f + clip;
+    const float pl1 = advn * ratio;
+    const float pl2 = advn * fminf(fmaxf(ratio, lo), hi);
+    const float g1 = pl1 < pl2 ? 1.f : (pl1 == pl2 ? 0.5f : 0.f);
+    const float g2 = pl2 < pl1 ? 1.f : (pl1 == pl2 ? 0.5f : 0.f);
+    const float inrange = (ratio >= lo && ratio <= hi) ? 1.f : 0.f;
+    const float dlogp = valid ? -invB * advn * (g1 + g2 * inrange) * ratio : 0.f;
+    float* doutrow = lds + G.dout + lrow;   // (column a of this lane's row: [a * RS])
+    float* auxrow = lds + G.aux + lrow;
+    if (!d.discrete) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (4 * lk + j < A) {
+          const float diff = r_act[j] - hout[j];
+          dout[j] = dlogp * diff * c_ivar[j];
+          doutrow[(4 * lk + j) * RS] = dout[j];
+          auxrow[(4 * lk + j) * RS] = valid ? dlogp * (diff * diff * c_ivar[j] - 1.f) - ent_coef * invB : 0.f;
+        }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (4 * lk + j < A) {
+          const float l = hout[j] - lse, p = expf(l);
+          const float dH = -p * (l + entropy);
+          float g = dlogp * ((4 * lk + j == act_i ? 1.f : 0.f) - p);
+          g += valid ? -ent_coef * invB * dH : 0.f;
+          dout[j] = g;
+          doutrow[(4 * lk + j) * RS] = g;
+        }
+    }
+    if (lk == 0) {
+      float* mrow = lds + G.misc + lrow;
+      mrow[2 * RS] = valid ? -fminf(pl1, pl2) : 0.f;                           // policy_gradient_loss
+      mrow[3 * RS] = valid ? -entropy : 0.f;                                    // entropy_loss
+      mrow[4 * RS] = valid ? (ratio - 1.f) - log_ratio : 0.f;                   // approx_kl
+      mrow[5 * RS] = valid ? (fabsf(ratio - 1.f) > clip ? 1.f : 0.f) : 0.f;     // clip_fraction
+    }
+  } else {
+    const float v = __shfl(hout[0], li, 64);   // (lane group 0, register 0 holds V(row li))
+    const float verr = r_ret - v;
+    dvb = valid ? vf_coef * 2.f * (v - r_ret) * invB : 0.f;
+    if (lk == 0) {
+      lds[G.misc + 1 * RS + lrow] = dvb;
+      lds[G.misc + 6 * RS + lrow] = valid ? verr * verr : 0.f;        // value_loss
+    }
+  }
+  // ---- dz2^T = (W_head^T d head^T) * (1 - a2^2), dz1^T = (W2^T dz2^T) * (1 - a1^2)
+  {
+    f32x4 fW2T[4][4];   // (requested here: in flight under dz2's MFMAs / products)
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) fW2T[kt][t] = rd4(lds + G.W2T + (16 * t + li) * RS + 16 * kt + 4 * lk);
+    f32x4 dz2[4];
+    if (tw == 0) {
+      f32x4 acc[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int r = 0; r < 4; ++r)   // (k-step r carries actions r, 4 + r, 8 + r, 12 + r; the image's columns >= A are zero)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[t] = mfma16(fHeadT[t][r], dout[r], acc[t]);
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dz2[t][r] = acc[t][r] * (1.f - a2[t][r] * a2[t][r]);
+    } else {
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dz2[t][r] = fHeadT[t][r] * dvb * (1.f - a2[t][r] * a2[t][r]);
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) lds[G.dz2 + (16 * t + 4 * lk + r) * RS + q * 16 + li] = dz2[t][r];
+    f32x4 acc[4][2];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[t][0] = acc[t][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[t][r & 1] = mfma16(fW2T[kt][t][r], dz2[kt][r], acc[t][r & 1]);
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        lds[G.dz1 + (16 * t + 4 * lk + r) * RS + q * 16 + li] = (acc[t][0][r] + acc[t][1][r]) * (1.f - a1[t][r] * a1[t][r]);
+  }
+  __syncthreads();   // every row's activations and activation gradients are in LDS
+  mid();
+  // ---- weight-gradient tiles: contractions over the 64 rows, independent per wave. Tile = 16 features of U (the MFMA's M
+  // index) x 16 features of V (N); a lane reads four consecutive rows of its feature per ds_read_b128 (row steps 4 sq .. + 3
+  // of lane group lk are rows 16 sq + 4 lk ..: the same permutation on both operands); two accumulator chains per tile.
+  auto tile2 = [&](const f32x4 (&u)[4], const float* __restrict__ V0, const float* __restrict__ V1, f32x4& r0, f32x4& r1) {
+    const float* vp0 = V0 + li * RS + 4 * lk;
+    const float* vp1 = V1 + li * RS + 4 * lk;
+    f32x4 v0[4], v1[4];
+#pragma unroll
+    for (int sq = 0; sq < 4; ++sq) {
+      v0[sq] = rd4(vp0 + 16 * sq);
+      v1[sq] = rd4(vp1 + 16 * sq);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    f32x4 g0 = {0.f, 0.f, 0.f, 0.f}, g0b = g0, g1 = g0, g1b = g0;
+#pragma unroll
+    for (int sq = 0; sq < 4; ++sq)
+#pragma unroll
+      for (int i = 0; i < 4; i += 2) {
+        g0 = mfma16(u[sq][i], v0[sq][i], g0);
+        g1 = mfma16(u[sq][i], v1[sq][i], g1);
+        g0b = mfma16(u[sq][i + 1], v0[sq][i + 1], g0b);
+        g1b = mfma16(u[sq][i + 1], v1[sq][i + 1], g1b);
+      }
+    r0 = g0 + g0b;
+    r1 = g1 + g1b;
+  };
+  auto load_u = [&](const float* __restrict__ U, f32x4 (&u)[4]) {
+    const float* up = U + li * RS + 4 * lk;
+#pragma unroll
+    for (int sq = 0; sq < 4; ++sq) u[sq] = rd4(up + 16 * sq);
+  };
+  // a feature's sum over the 64 rows (optionally weighted by a row vector): lane (j, quarter) = (lane & 15, lane >> 4)
+  auto colsum16 = [&](const float* __restrict__ tile /* 16 features */, const float* __restrict__ wrow /* nullable */) {
+    const float* cp = tile + (lane & 15) * RS + (lane >> 4) * 16;
+    f32x4 t[4], w[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      t[i] = rd4(cp + 4 * i);
+      w[i] = wrow ? rd4(wrow + (lane >> 4) * 16 + 4 * i) : f32x4{1.f, 1.f, 1.f, 1.f};
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    float s = 0.f;
+    if (wrow) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) s += (t[i][0] * w[i][0] + t[i][1] * w[i][1]) + (t[i][2] * w[i][2] + t[i][3] * w[i][3]);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) s += (t[i][0] + t[i][1]) + (t[i][2] + t[i][3]);
+    }
+    s += __shfl_xor(s, 16, 64);
+    s += __shfl_xor(s, 32, 64);
+    return s;   // (all four lanes of feature j hold the sum)
+  };
+  {   // dW2[j][i] = sum_r dz2[r][j] a1[r][i]: wave q takes output rows j = 16 q .. 16 q + 15, all four input tiles
+    f32x4 u[4];
+    load_u(lds + G.dz2 + 16 * q * RS, u);
+#pragma unroll
+    for (int it = 0; it < 4; it += 2) {
+      f32x4 g0, g1;
+      tile2(u, lds + G.a1 + 16 * it * RS, lds + G.a1 + 16 * (it + 1) * RS, g0, g1);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        put(Lc.lW2 + (16 * q + 4 * lk + r) * 64 + 16 * it + li, g0[r]);
+        put(Lc.lW2 + (16 * q + 4 * lk + r) * 64 + 16 * (it + 1) + li, g1[r]);
+      }
+    }
+    const float sb2 = colsum16(lds + G.dz2 + 16 * q * RS, nullptr);
+    if (lane < 16) put(Lc.lb2 + 16 * q + lane, sb2);
+  }
+  {   // dW1[j][c] = sum_r dz1[r][j] x[r][c]; head weights: dWa[a][h] = sum_r dout[r][a] a2[r][h] (policy: one tile per wave)
+    f32x4 u[4];
+    load_u(lds + G.dz1 + 16 * q * RS, u);
+    f32x4 g0, g1;
+    if (KT1 == 2) {
+      tile2(u, lds + G.x, lds + G.x + 16 * RS, g0, g1);
+    } else {
+      tile2(u, lds + G.x, lds + G.x, g0, g1);   // (one K tile: the second product is discarded)
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      if (li < D) put((16 * q + 4 * lk + r) * D + li, g0[r]);
+      if (KT1 == 2 && 16 + li < D) put((16 * q + 4 * lk + r) * D + 16 + li, g1[r]);
+    }
+    const float sb1 = colsum16(lds + G.dz1 + 16 * q * RS, nullptr);
+    if (lane < 16) put(Lc.lb1 + 16 * q + lane, sb1);
+  }
+  if (tw == 0) {
+    f32x4 u[4];
+    load_u(lds + G.dout, u);
+    f32x4 g0, g1;
+    tile2(u, lds + G.a2 + 16 * q * RS, lds + G.a2 + 16 * q * RS, g0, g1);
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      if (4 * lk + r < A) put(Lc.lHW + (4 * lk + r) * 64 + 16 * q + li, g0[r]);
+    if (q == 0) {   // action_net bias
+      const float s = colsum16(lds + G.dout, nullptr);
+      if (lane < A) put(Lc.lHb + lane, s);
+    } else if (q == 1) {   // log_std
+      if (!d.discrete) {
+        const float s = colsum16(lds + G.aux, nullptr);
+        if (lane < A) put(Lc.lLS + lane, s);
+      }
+    } else if (q == 2) {   // loss statistics: misc columns 2..5 -> tail slots {0 pg, 2 ent, 3 kl, 4 clip}
+      const float s = colsum16(lds + G.misc, nullptr);   // (features 0..7 of the misc tile; 8..15 read the next tile: unused)
+      if (lane >= 2 && lane < 6) put(tail0 + (lane == 2 ? 0 : lane - 1), s);
+    } else {
+      if (lane < 4) put(tail0 + (lane == 0 ? 1 : lane + 4), 0.f);   // (slots 1, 5, 6, 7: not this tower's)
+    }
+  } else {
+    // value_net: dcW[h] = sum_r dv[r] a2[r][h] -- one useful row of a tile: a weighted column sum instead
+    const float s = colsum16(lds + G.a2 + 16 * q * RS, lds + G.misc + 1 * RS);
+    if (lane < 16) put(Lc.lHW + 16 * q + lane, s);
+    if (q == 0) {   // value_net bias = sum_r dv[r]; value_loss -> tail slot 1
+      const float sm = colsum16(lds + G.misc, nullptr);
+      if (lane == 1) put(Lc.lHb, sm);
+      if (lane == 6) put(tail0 + 1, sm);
+    } else if (q == 1) {
+      if (lane < 7) put(tail0 + (lane == 0 ? 0 : lane + 1), 0.f);   // (slots 0, 2..7: not this tower's)
+    }
+  }
+  __syncthreads();
+}
+
+template <int KT1>
+__global__ __launch_bounds__(256) void ppo_epoch_t64_kernel(
+    ia_policy_desc d, float* __restrict__ P, float* __restrict__ Pt, float* __restrict__ m, float* __restrict__ v,
+    const float* __restrict__ nm_in, const float* __restrict__ nv_in, const float* __restrict__ obs,
+    const float* __restrict__ actions, const float* __restrict__ old_logp, const float* __restrict__ adv,
+    const float* __restrict__ ret, long long total_rows, int batch_size, int normalize_adv, float clip, float ent_coef,
+    float vf_coef, float max_norm, float beta1, float beta2, float eps, float* __restrict__ ws,
+    unsigned long long* __restrict__ wbase, unsigned seq0, const float* __restrict__ seq, int snap,
+    float* __restrict__ stats, EpochSteps st, long long* __restrict__ dbg /* measurement: [0..5] += 100 MHz ticks of workgroup 0
+    in {chain + tiles, hop 1, slice sums, staging + hop 2, norm + Adam, -} */) {
+  typedef unsigned long long u64;
+  constexpr int NT = 256, RS = T64Geo::RS;
+  // Parameter SLOTS of a thread (Adam's moments in registers, the hop-2 words it polls): per piece of the tower its own
+  // thread-linear numbering, so that a slot's parameter, its places in the LDS images and its word are plain arithmetic
+  // on (slot, thread) -- no per-slot index registers: W1 (64 D elements: 4 KT1 slots), the two hidden biases (one slot:
+  // threads 0..127), W2 (16 slots: element tid + 256 kk = row (tid >> 6) + 4 kk, column tid & 63), head weights (4 slots),
+  // head bias + log_std (one slot).
+  constexpr int SW1 = 4 * KT1, NPT = SW1 + 1 + 16 + 4 + 1;
+  constexpr int NH1 = (64 * 16 * KT1 + 64 + 64 * 64 + 64 + 16 * 64 + 32 + 8 + 32 + NT - 1) / NT + 1;   // words polled in hop 1
+  extern __shared__ __attribute__((aligned(16))) float lds_raw[];
+  float* lds = lds_raw + (((16 - (__builtin_amdgcn_groupstaticsize() & 15)) & 15) >> 2);
+  __shared__ int s_fail;
+  __shared__ float s_part[64];
+  __shared__ float s_tail[16];
+  const int bid = blockIdx.x, nrb = gridDim.x >> 1, rb = bid >> 1, tw = bid & 1;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int D = d.obs_dim, A = d.act_dim, aw = d.discrete ? 1 : A;
+  const PolOff o = pol_offsets(D, A, 64, d.discrete);
+  const T64Geo G = t64_geo(D, aw, KT1);
+  const T64Loc Lc = t64_loc(o, D, A, d.discrete, tw);
+  const int TWp = t64_twp(o, D, A, d.discrete), SWW = TWp + 8;
+  u64* slabs64 = wbase;
+  u64* sums64 = slabs64 + 4LL * nrb * SWW;
+  u64* sq64 = sums64 + 4LL * SWW;
+  unsigned* err = reinterpret_cast<unsigned*>(ws) + 5;
+  long long tprev = 0;
+#define T64_TS(slot)                                                      \
+  do {                                                                    \
+    if (dbg != nullptr && bid == 0 && tid == 0) {                         \
+      const long long tn = wall_clock64();                                \
+      dbg[slot] += tn - tprev;                                            \
+      tprev = tn;                                                         \
+    }                                                                     \
+  } while (0)
+  if (tid == 0) s_fail = 0;
+  for (int e = tid; e < G.total; e += NT) lds[e] = 0.f;
+  __syncthreads();
+  // ---- slot -> (tower-local index | -1, first / second place in the LDS images | -1)
+  const unsigned rcpD = 0xffffffffu / (unsigned)D + 1u;
+  auto slot_of = [&](const int sidx, int& i, int& da, int& db) {
+    i = da = db = -1;
+    if (sidx < SW1) {
+      const int e = tid + sidx * NT;
+      if (e < 64 * D) {
+        const int r = D == 1 ? e : (int)__umulhi((unsigned)e, rcpD);
+        i = e;
+        da = G.W1 + r * G.DP + (e - r * D);
+      }
+    } else if (sidx == SW1) {
+      if (tid < 64) {
+        i = Lc.lb1 + tid;
+        da = G.b1 + tid;
+      } else if (tid < 128) {
+        i = Lc.lb2 + tid - 64;
+        da = G.b2 + tid - 64;
+      }
+    } else if (sidx < SW1 + 17) {
+      const int kk = sidx - SW1 - 1, r = (tid >> 6) + 4 * kk, c = tid & 63;
+      i = Lc.lW2 + tid + NT * kk;
+      da = G.W2 + r * RS + c;
+      db = G.W2T + c * RS + r;
+    } else if (sidx < SW1 + 21) {
+      const int j = tid + NT * (sidx - SW1 - 17);
+      if (tw == 0) {
+        if ((j >> 6) < A) {
+          i = Lc.lHW + j;
+          da = G.HW + (j >> 6) * RS + (j & 63);
+          db = G.HWT + (j & 63) * T64Geo::HT + (j >> 6);
+        }
+      } else if (j < 64) {
+        i = Lc.lHW + j;
+        da = G.HW + j;
+      }
+    } else {
+      const int j = Lc.lHb + tid;
+      if (j < Lc.TW) {
+        i = j;
+        da = j < Lc.lLS ? G.hb + (j - Lc.lHb) : G.ls + (j - Lc.lLS);
+      }
+    }
+  };
+  // ---- the tower's parameters into the LDS images; Adam's moments of the whole tower in registers for the launch
+  float rm[NPT], rv[NPT];
+#pragma unroll
+  for (int k = 0; k < NPT; ++k) {
+    int i, da, db;
+    slot_of(k, i, da, db);
+    rm[k] = rv[k] = 0.f;
+    if (i >= 0) {
+      const int f = t64_flat(Lc, i);
+      rm[k] = m[f];
+      rv[k] = v[f];
+      const float p = P[f];
+      lds[da] = p;
+      if (db >= 0) lds[db] = p;
+    }
+  }
+  // ---- rows of a minibatch: gathered and contiguous. `load_rows` requests block rb's rows of minibatch `mbi` (plain loads,
+  // clamped inside the sequence; rows past the minibatch are masked when staged), `park_rows` leaves them in the staging area
+  constexpr int NXR = (64 * 32 + NT - 1) / NT;   // observation elements per thread (D <= 32)
+  constexpr int NAR = (64 * MAXA + NT - 1) / NT;
+  float pf_x[NXR], pf_a[NAR], pf_s = 0.f, pf_r = 0.f;
+  auto load_rows = [&](int mbi) {
+    const long long start = (long long)mbi * batch_size + 64 * rb;
+    const long long last = total_rows - 1;
+    const int nx = 64 * D, na = 64 * aw;
+#pragma unroll
+    for (int it = 0; it < NXR; ++it) {
+      const int e = min(tid + it * NT, nx - 1);
+      const int r = e / D;
+      const long long row = start + r < last ? start + r : last;
+      pf_x[it] = obs[row * D + (e - r * D)];
+    }
+#pragma unroll
+    for (int it = 0; it < NAR; ++it) {
+      const int e = min(tid + it * NT, na - 1);
+      const int r = e / aw;
+      const long long row = start + r < last ? start + r : last;
+      pf_a[it] = actions[row * aw + (e - r * aw)];
+    }
+    {   // per-row scalars: threads 0..63 old log-prob, 64..127 advantage, 128..191 return; 192..: the statistics slot
+      const int r = tid & 63;
+      const long long row = start + r < last ? start + r : last;
+      const float* src = tid < 64 ? old_logp : (tid < 128 ? adv : ret);
+      pf_s = src[row];
+    }
+    {   // statistics of the minibatch: adv mean / std, feature mean / variance (snapshot of the running statistics AFTER
+        // this minibatch's update when the call updates them, the running statistics themselves otherwise)
+      const float* sq = seq + (long long)mbi * EPS_SEQ;
+      const int e = tid;   // 0, 1: adv mean / std; 8 + c: mean; 8 + MAXD + c: variance
+      float val = 0.f;
+      if (e < 2) val = sq[e];
+      else if (e >= 8 && e < 8 + 2 * MAXD) {
+        const int c = (e - 8) & (MAXD - 1);
+        const bool var = e >= 8 + MAXD;
+        if (d.has_norm && c < D) val = snap ? sq[e] : (var ? nv_in[c] : nm_in[c]);
+      }
+      pf_r = val;
+    }
+  };
+  auto park_rows = [&]() {
+    const int nx = 64 * D, na = 64 * aw;
+#pragma unroll
+    for (int it = 0; it < NXR; ++it)
+      if (tid + it * NT < nx) lds[G.sx + tid + it * NT] = pf_x[it];
+#pragma unroll
+    for (int it = 0; it < NAR; ++it)
+      if (tid + it * NT < na) lds[G.sact + tid + it * NT] = pf_a[it];
+    if (tid < 192) lds[G.soldlp + tid] = pf_s;   // (soldlp, sadv, sret are consecutive 64-float areas)
+    if (tid < 2 * MAXD + 8) lds[G.ring + tid] = pf_r;
+  };
+  // normalised rows of the staged minibatch -> x tile (transposed); `bn`: rows of that minibatch
+  auto stage_rows = [&](int bn) {
+    const int S1 = (D + 3) >> 2;
+    const int s1r = (65536 + S1 - 1) / S1;
+    for (int g = tid; g < 64 * S1; g += NT) {
+      const int r = (g * s1r) >> 16, k0 = (g - r * S1) * 4;
+      const bool rok = 64 * rb + r < bn;
+      float raw[4], mu[4], vr[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int c = min(k0 + j, D - 1);
+        raw[j] = lds[G.sx + r * D + c];
+        mu[j] = lds[G.ring + 8 + c];
+        vr[j] = lds[G.ring + 8 + MAXD + c];
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const bool ok = rok && k0 + j < D;
+        float val = raw[j];
+        if (d.has_norm) val = (raw[j] - mu[j]) * __builtin_amdgcn_rsqf(vr[j] + d.norm_eps);
+        lds[G.x + (k0 + j) * RS + r] = ok ? val : 0.f;
+      }
+    }
+  };
+  auto timed_out = [&](unsigned& it) {
+    __builtin_amdgcn_s_sleep(1);
+    if (++it > (1u << 22) || ((it & 255u) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+      __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      return true;
+    }
+    return false;
+  };
+  if (st.n > 0) {
+    load_rows(st.first);
+    park_rows();
+    __syncthreads();
+    const long long start0 = (long long)st.first * batch_size;
+    stage_rows((int)min((long long)batch_size, total_rows - start0));
+  }
+  __syncthreads();
+  if (dbg != nullptr && bid == 0 && tid == 0) tprev = wall_clock64();
+#pragma nounroll
+  for (int k = 0; k < st.n; ++k) {
+    const unsigned sq_ = seq0 + (unsigned)k + 1u;   // sequence number of everything this step publishes
+    const int par = (int)(sq_ & 1u);
+    const int mb = st.first + k;
+    const long long start = (long long)mb * batch_size;
+    const int b = (int)min((long long)batch_size, total_rows - start);
+    const int nblk = (b + ROWS - 1) / ROWS;
+    const bool more = k + 1 < st.n;
+    const int bnext = more ? (int)min((long long)batch_size, total_rows - (start + batch_size)) : 0;
+    const float adv_mean = lds[G.ring + 0], adv_std = lds[G.ring + 1];
+    const float step_size = st.step_size[k], bc2_sqrt = st.bc2_sqrt[k];
+    if (more) load_rows(mb + 1);   // (in flight under the chain; parked behind its barrier)
+    u64* slab = slabs64 + ((long long)(par * 2 + tw) * nrb + rb) * SWW;
+    if (rb < nblk) {
+      t64_tower_minibatch<KT1>(d, G, Lc, tw, lds, 64 * rb, b, adv_mean, adv_std, normalize_adv, clip, ent_coef, vf_coef, slab,
+                               TWp, sq_, [&]() { if (more) park_rows(); });
+    } else {
+      __syncthreads();
+      if (more) park_rows();
+      __syncthreads();
+    }
+    T64_TS(0);
+    // ---- hop 1: slice rb of the tower's nblk slabs, summed in slab order
+    const int SL = (SWW + nrb - 1) / nrb;
+    const unsigned rcpSL = 0xffffffffu / (unsigned)SL + 1u;
+    float* red = lds + G.a1;   // scratch [nblk][SL] (the activation tiles are free until the next chain)
+    auto written = [&](int gi) { return gi < Lc.TW || (gi >= TWp && gi < SWW); };
+    bool fail = false;
+    {
+      const u64* tslabs = slabs64 + (long long)(par * 2 + tw) * nrb * SWW;
+      u64 t[NH1];
+      int off[NH1];
+      unsigned need = 0u;
+#pragma unroll
+      for (int u = 0; u < NH1; ++u) {
+        const int f = tid + u * NT;
+        const int j = (int)__umulhi((unsigned)f, rcpSL), e = f - j * SL;
+        const int gi = rb * SL + e;
+        off[u] = min(j, nblk - 1) * SWW + min(gi, SWW - 1);
+        if (j < nblk && gi < SWW && written(gi)) need |= 1u << u;
+      }
+      unsigned it = 0;
+      for (;;) {
+#pragma unroll
+        for (int u = 0; u < NH1; ++u) t[u] = __hip_atomic_load(tslabs + off[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __builtin_amdgcn_sched_barrier(0);
+        bool ok = true;
+#pragma unroll
+        for (int u = 0; u < NH1; ++u) ok = ok && (!((need >> u) & 1u) || (unsigned)(t[u] >> 32) == sq_);
+        if (ok) break;
+        if (timed_out(it)) { fail = true; break; }
+      }
+#pragma unroll
+      for (int u = 0; u < NH1; ++u) {
+        const int f = tid + u * NT;
+        if (f < nblk * SL) red[f] = ((need >> u) & 1u) ? __uint_as_float((unsigned)t[u]) : 0.f;
+      }
+    }
+    if (fail) s_fail = 1;
+    __syncthreads();
+    if (s_fail) return;
+    T64_TS(1);
+    {
+      u64* tsum = sums64 + (long long)(par * 2 + tw) * SWW;
+      float sqs = 0.f;
+      for (int e = tid; e < SL; e += NT) {
+        const int gi = rb * SL + e;
+        float part = 0.f;
+        int j = 0;
+        for (; j + 8 <= nblk; j += 8) {
+          float tt[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) tt[u] = red[(j + u) * SL + e];
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int u = 0; u < 8; ++u) part += tt[u];
+        }
+        for (; j < nblk; ++j) part += red[j * SL + e];
+        if (gi < SWW && written(gi)) ll_store_agent(tsum + gi, part, sq_);
+        if (gi < Lc.TW) sqs += part * part;
+      }
+      const float tot = block_sum<NT>(sqs, lds + G.scratch);
+      if (tid == 0) ll_store_agent(sq64 + (par * 2 + tw) * 32 + rb, tot, sq_);
+    }
+    T64_TS(2);
+    // ---- while the slice sums travel: the next minibatch's rows are normalised into the x tile
+    if (more) stage_rows(bnext);
+    // ---- hop 2: the tower's whole sum vector; the 2 nrb sums of squares; workgroup 0: both towers' loss-statistic sums
+    float g[NPT];
+    {
+      const u64* tsum = sums64 + (long long)(par * 2 + tw) * SWW;
+      u64 t[NPT], tq = 0ull, tt = 0ull;
+      const bool want_q = tid < 2 * nrb;             // lane -> (tower tid / nrb, block tid % nrb)
+      const bool want_t = bid == 0 && tid >= 64 && tid < 80 && stats != nullptr;   // second wave: tails of tower (tid - 64) >> 3
+      const u64* qp = sq64 + (par * 2 + (want_q ? tid / nrb : 0)) * 32 + (want_q ? tid % nrb : 0);
+      const u64* tp = sums64 + (long long)(par * 2 + (want_t ? (tid - 64) >> 3 : 0)) * SWW + TWp + (want_t ? (tid & 7) : 0);
+      int hoff[NPT];      // word of each slot (slots without a parameter: word 0, not waited for)
+      unsigned hneed = 0u;
+#pragma unroll
+      for (int kk = 0; kk < NPT; ++kk) {
+        int i, da, db;
+        slot_of(kk, i, da, db);
+        hoff[kk] = i < 0 ? 0 : i;
+        if (i >= 0) hneed |= 1u << kk;
+      }
+      unsigned it = 0;
+      for (; !fail;) {
+#pragma unroll
+        for (int kk = 0; kk < NPT; ++kk)
+          t[kk] = __hip_atomic_load(tsum + hoff[kk], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        tq = __hip_atomic_load(qp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        tt = __hip_atomic_load(tp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __builtin_amdgcn_sched_barrier(0);
+        bool ok = (!want_q || (unsigned)(tq >> 32) == sq_) && (!want_t || (unsigned)(tt >> 32) == sq_);
+#pragma unroll
+        for (int kk = 0; kk < NPT; ++kk) ok = ok && (!((hneed >> kk) & 1u) || (unsigned)(t[kk] >> 32) == sq_);
+        if (ok) break;
+        if (timed_out(it)) { fail = true; break; }
+      }
+#pragma unroll
+      for (int kk = 0; kk < NPT; ++kk) g[kk] = ((hneed >> kk) & 1u) ? __uint_as_float((unsigned)t[kk]) : 0.f;
+      if (tid < 64) s_part[tid] = want_q ? __uint_as_float((unsigned)tq) : 0.f;
+      if (want_t) s_tail[tid - 64] = __uint_as_float((unsigned)tt);
+    }
+    if (fail) s_fail = 1;
+    __syncthreads();
+    if (s_fail) return;
+    T64_TS(3);
+    float total_sq = 0.f;
+    for (int qq = 0; qq < 2 * nrb; ++qq) total_sq += s_part[qq];   // (policy tower's blocks, then the value tower's)
+    const float total_norm = sqrtf(total_sq);
+    const float coef = fminf(max_norm / (total_norm + 1e-6f), 1.0f);   // torch.nn.utils.clip_grad_norm_
+    {
+      // torch.optim.Adam's step on the thread's parameters of the tower (the arithmetic of the 32-wide kernel: hardware
+      // square root and reciprocal + one Newton step); all LDS reads first, then the arithmetic, then the writes
+      float pv[NPT];
+#pragma unroll
+      for (int kk = 0; kk < NPT; ++kk) {
+        int i, da, db;
+        slot_of(kk, i, da, db);
+        pv[kk] = lds[da < 0 ? 0 : da];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      const float inv_bc2 = 1.f / bc2_sqrt;
+#pragma unroll
+      for (int kk = 0; kk < NPT; ++kk) {
+        const float gi = g[kk] * coef;
+        float mi = rm[kk];
+        mi = mi + (gi - mi) * (1.f - beta1);
+        const float vi = rv[kk] * beta2 + (1.f - beta2) * gi * gi;
+        const float denom = __builtin_amdgcn_sqrtf(vi) * inv_bc2 + eps;
+        float rd = __builtin_amdgcn_rcpf(denom);
+        rd = __builtin_fmaf(rd, __builtin_fmaf(-denom, rd, 1.f), rd);
+        pv[kk] = pv[kk] - step_size * (mi * rd);
+        rm[kk] = mi;
+        rv[kk] = vi;
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int kk = 0; kk < NPT; ++kk) {
+        int i, da, db;
+        slot_of(kk, i, da, db);
+        if (da >= 0) lds[da] = pv[kk];
+        if (db >= 0) lds[db] = pv[kk];
+      }
+    }
+    if (bid == 0 && stats != nullptr && tid == 0) {   // tails: tower 0 slots {0 pg, 2 ent, 3 kl, 4 clip}, tower 1 slot 1 (value)
+      const float inv = 1.f / (float)b;
+      const float pg = s_tail[0] * inv, vl = s_tail[8 + 1] * inv, en = s_tail[2] * inv;
+      float* so = stats + (long long)mb * 8;
+      so[0] = pg;
+      so[1] = vl;
+      so[2] = en;
+      so[3] = s_tail[3] * inv;
+      so[4] = s_tail[4] * inv;
+      so[5] = pg + ent_coef * en + vf_coef * vl;
+      so[6] = total_norm;
+      so[7] = coef;
+    }
+    __syncthreads();   // the images hold the new parameters; x tile and staging area belong to the next step
+    T64_TS(4);
+  }
+  // ---- the launch's last parameters and moments back to memory (torch layout + the transposed shadow copy): row block 0
+  if (rb == 0) {
+#pragma unroll
+    for (int k = 0; k < NPT; ++k) {
+      int i, da, db;
+      slot_of(k, i, da, db);
+      if (i >= 0) {
+        const int f = t64_flat(Lc, i);
+        const float p = lds[da];
+        m[f] = rm[k];
+        v[f] = rv[k];
+        P[f] = p;
+        int dt_ = f;
+        auto tr = [&](int b0, int rows_, int cols) {
+          if (f >= b0 && f < b0 + rows_ * cols) {
+            const int r = (f - b0) / cols, cc = (f - b0) % cols;
+            dt_ = b0 + cc * rows_ + r;
+          }
+        };
+        tr(o.pW1, 64, D); tr(o.pW2, 64, 64); tr(o.vW1, 64, D); tr(o.vW2, 64, 64);
+        Pt[dt_] = p;
+      }
+    }
+  }
+#undef T64_TS
+}
+
 // TIMING = false (production): the phase-clock accumulators (24 VGPRs of `tacc` alone) and every stamp are
 // compiled out -- the measurement build is a separate instantiation picked only while ia_ppo_debug_timing is on.
 template <int NPT, bool TIMING, int KS1, bool LOCAL, bool SHARD = false, bool SMALL = false>
@@ -4739,6 +5674,7 @@ bool g_ppo_valu = false;  // tuning/debug: force the VALU kernels for H = 32 as 
 bool g_epoch_split = false;  // tuning/debug: two launches per minibatch for 64-wide towers too
 bool g_epoch_whole = false;  // tuning/debug: the one-launch epoch with whole row-block workgroups (8 waves, both towers)
 bool g_epoch_barriers = false;   // tuning/debug: the one-tower epoch kernel with grid barriers instead of the word exchange
+bool g_epoch_t64 = true;         // the tower-resident epoch kernel (round 5) where it applies; false: round 4's word-exchange kernel
 long long* g_epoch_dbg = nullptr;  // measurement: phase ticks of workgroup 0 of ppo_epoch_persistent_kernel
 }  // namespace
 
@@ -4978,7 +5914,12 @@ static int64_t ppo_ws_plain_floats(const ia_policy_desc* d, int batch, int64_t g
 int64_t ia_ppo_ws_floats(const ia_policy_desc* d, int batch, int64_t gather_rows) {
   if (!pol_ok(d) || batch <= 0 || gather_rows < batch) return IA_ERR_ARG;
   const int P = pol_offsets(d->obs_dim, d->act_dim, d->hidden, d->discrete).total;
-  const int64_t ll = d->hidden == 64 ? 2 * epoch_ll_words(epoch_ll_row_blocks(cdiv(batch, ROWS), P), P) : 0;   // (64-wide towers: the word exchange)
+  int64_t ll = d->hidden == 64 ? 2 * epoch_ll_words(epoch_ll_row_blocks(cdiv(batch, ROWS), P), P) : 0;   // (64-wide towers: the word exchange)
+  if (d->hidden == 64) {   // ... or the tower-resident kernel's areas
+    const PolOff po = pol_offsets(d->obs_dim, d->act_dim, d->hidden, d->discrete);
+    const int64_t t64 = 2 * t64_words(cdiv(batch, ROWS), t64_twp(po, d->obs_dim, d->act_dim, d->discrete));
+    ll = t64 > ll ? t64 : ll;
+  }
   return ppo_ws_plain_floats(d, batch, gather_rows) + ll;
 }
 
@@ -5194,6 +6135,7 @@ int ia_ppo_epoch_split(int on) {
   g_epoch_split = on == 1;
   g_epoch_whole = on == 2;
   g_epoch_barriers = on == 3;
+  g_epoch_t64 = on != 4;   // 4: the word-exchange kernel with chunk owners (round 4) where the tower-resident one applies
   return IA_OK;
 }
 
@@ -5270,9 +6212,17 @@ static int ppo_epochs_impl(const ia_policy_desc* d, float* params, float* params
   const int nrb_l = epoch_ll_row_blocks(nrb, P);
   const bool llx = towers_fit && !g_epoch_barriers && sbytes + 16 <= EPOCH_LL_LDS && nrb_l <= 32 && 2 * nrb_l <= dev_cus;
   const bool split = towers_fit && sbytes <= EPOCH_SPLIT_LDS && (llx || cdiv(P, 2 * nrb) <= 4 * 256);
-  unsigned long long* ll_base = llx ? reinterpret_cast<unsigned long long*>(ws + ppo_ws_plain_floats(d, size_at(0), total)) : nullptr;
-  int rc = launch_gather(a, perm, total, g, ll_base, llx ? epoch_ll_words(nrb_l, P) : 0,
-                         llx ? reinterpret_cast<unsigned*>(ws) + 4 : nullptr);   // (words 4, 5, 6: counter, error word, ticket)
+  // the tower-resident kernel (round 5): observation widths up to 32 (both layouts of W2, W1 and the tiles beside the staging
+  // area in 160 KB), <= 32 row blocks; every tower workgroup steps its whole tower
+  const T64Geo tgeo = t64_geo(d->obs_dim, d->discrete ? 1 : d->act_dim, d->obs_dim <= 16 ? 1 : 2);
+  const int t64_TWp = t64_twp(po, d->obs_dim, d->act_dim, d->discrete);
+  constexpr size_t T64_LDS = 160 * 1024 - 1024;
+  const bool t64 = one_launch && g_epoch_t64 && !g_epoch_whole && !g_epoch_barriers && d->obs_dim <= 32 && nrb <= 32 &&
+                   2 * nrb <= dev_cus && (size_t)tgeo.total * sizeof(float) + 16 <= T64_LDS &&
+                   g_epoch_dbg == nullptr;
+  unsigned long long* ll_base = (llx || t64) ? reinterpret_cast<unsigned long long*>(ws + ppo_ws_plain_floats(d, size_at(0), total)) : nullptr;
+  int rc = launch_gather(a, perm, total, g, ll_base, t64 ? t64_words(nrb, t64_TWp) : (llx ? epoch_ll_words(nrb_l, P) : 0),
+                         (llx || t64) ? reinterpret_cast<unsigned*>(ws) + 4 : nullptr);   // (words 4, 5, 6: counter, error word, ticket)
   if (rc) return rc;
   // statistics of every minibatch of the epoch, one launch ahead of the chain (ppo_epoch_stats_kernel)
   const int aw = d->discrete ? 1 : d->act_dim;
@@ -5284,13 +6234,39 @@ static int ppo_epochs_impl(const ia_policy_desc* d, float* params, float* params
     static bool attr = false;
     const size_t bytes = PREP_LDS_FLOATS * sizeof(float);
     if (!attr) { rc = set_lds(ppo_epoch_stats_kernel, bytes); if (rc) return rc; attr = true; }
-    if (!llx && hipMemsetAsync(ws + 6, 0, sizeof(unsigned), a.st) != hipSuccess) return IA_ERR_ARG;   // its ticket (ws is not pre-zeroed)
+    if (!llx && !t64 && hipMemsetAsync(ws + 6, 0, sizeof(unsigned), a.st) != hipSuccess) return IA_ERR_ARG;   // its ticket (ws is not pre-zeroed)
     hipLaunchKernelGGL(ppo_epoch_stats_kernel, dim3(n_mb), dim3(PREP_THREADS), bytes, a.st, *d, g.obs, g.adv, total,
                        batch_size, update_norm, norm_mean, norm_var, norm_count, seq, part,
                        reinterpret_cast<unsigned*>(ws) + 6);
     IA_CHECK_LAUNCH();
   }
   const bool snap = d->has_norm && update_norm;
+  if (t64) {
+    const int kt1 = d->obs_dim <= 16 ? 1 : 2;
+    auto k1 = ppo_epoch_t64_kernel<1>;
+    auto k2 = ppo_epoch_t64_kernel<2>;
+    auto kern = kt1 == 1 ? k1 : k2;
+    static bool attr_t[2] = {false, false};
+    if (!attr_t[kt1 - 1]) { rc = set_lds(kern, T64_LDS); if (rc) return rc; attr_t[kt1 - 1] = true; }
+    const size_t tbytes = (size_t)tgeo.total * sizeof(float) + 16;
+    for (int first = 0; first < n_mb; first += EpochSteps::MAX) {
+      EpochSteps es{};
+      es.first = first;
+      es.n = std::min(EpochSteps::MAX, n_mb - first);
+      const unsigned seq0 = (unsigned)(adam_steps_done + first);
+      for (int k = 0; k < es.n; ++k) {
+        ++step;
+        es.step_size[k] = (float)(lr / (1.0 - pow(beta1, (double)step)));
+        es.bc2_sqrt[k] = (float)sqrt(1.0 - pow(beta2, (double)step));
+      }
+      hipLaunchKernelGGL(kern, dim3(2 * nrb), dim3(256), tbytes, a.st, *d, params, params_t, exp_avg, exp_avg_sq, norm_mean,
+                         norm_var, g.obs, g.act, g.logp, g.adv, g.ret, total, batch_size, normalize_adv, clip_range, ent_coef,
+                         vf_coef, max_grad_norm, (float)beta1, (float)beta2, adam_eps, ws, ll_base, seq0, seq, snap ? 1 : 0, stats,
+                         es, (long long*)nullptr);
+      IA_CHECK_LAUNCH();
+    }
+    return IA_OK;
+  }
   if (one_launch) {
     // one launch per (<= 64 minibatches of the) epoch when every gradient workgroup can be resident at once
     const int nwg = split ? 2 * nrb : nrb;

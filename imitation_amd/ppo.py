@@ -111,15 +111,18 @@ class _PermutationPredraw:
         self._pos = C.c_int(0)
         self._rc = 0
         self._out: Optional[np.ndarray] = None
+        self._rr = self._rr_armed = None
 
     @staticmethod
     def _same(a, b) -> bool:
         return a[0] == b[0] and a[2:] == b[2:] and np.array_equal(a[1], b[1])
 
-    def start(self, out: np.ndarray, then=None) -> None:
-        """`then(key, pos, state0)` (optional) is called in the helper's thread once the permutations are drawn, with the
-        generator state BEHIND them (the trainer's discriminator index draws continue from there)."""
+    def start(self, out: np.ndarray, randint_spec=None) -> None:
+        """`randint_spec = (high, rows, row_len)` (optional): behind the permutations the SAME C call draws, on a copy of the
+        generator, `rows` x `np.random.randint(high, size=row_len)` -- the replay ring's index rows of the round's
+        discriminator updates (`take_randint`)."""
         assert out.dtype == np.int64 and out.flags.c_contiguous and out.shape == (self.n_epochs, self.size)
+        self._rr = None
         st = np.random.get_state()
         if st[0] != "MT19937":
             self._thread = None
@@ -129,12 +132,20 @@ class _PermutationPredraw:
         self._pos = C.c_int(int(st[2]))
         self._out = out
         lib = L.load()
+        if randint_spec is not None:
+            high, rows, row_len = (int(x) for x in randint_spec)
+            rr = dict(spec=(high, rows, row_len), rows=np.empty((rows, row_len), dtype=np.int64),
+                      key=np.empty(624, dtype=np.uint32), pos=C.c_int(0))
+            self._rr = rr
 
-        def work():
-            self._rc = lib.ia_host_mt19937_permutations(self._key.ctypes.data, C.byref(self._pos), self.size,
-                                                        self.n_epochs, out.ctypes.data)
-            if then is not None and self._rc == 0:
-                then(self._key, int(self._pos.value), st)
+            def work():
+                self._rc = lib.ia_host_mt19937_permutations_then_randint(
+                    self._key.ctypes.data, C.byref(self._pos), self.size, self.n_epochs, out.ctypes.data, high, rows, row_len,
+                    rr["rows"].ctypes.data, rr["key"].ctypes.data, C.byref(rr["pos"]))
+        else:
+            def work():
+                self._rc = lib.ia_host_mt19937_permutations(self._key.ctypes.data, C.byref(self._pos), self.size,
+                                                            self.n_epochs, out.ctypes.data)
 
         self._thread = HostWorker.named("permutations").submit(work)
 
@@ -153,7 +164,21 @@ class _PermutationPredraw:
             return False
         s0 = self._state0
         np.random.set_state((s0[0], self._key, int(self._pos.value), s0[3], s0[4]))
+        self._rr_armed = self._rr   # (valid while the global generator stays where this call has just put it)
         return True
+
+    def take_randint(self, high: int, rows: int, row_len: int):
+        """The `rows` x `np.random.randint(high, size=row_len)` rows drawn behind the adopted permutations -- handed over
+        (and the global generator moved behind them) only if the request is the one they were drawn for and the global
+        generator is still where `finish` left it; None otherwise (the caller draws in place)."""
+        rr, self._rr_armed = getattr(self, "_rr_armed", None), None
+        if rr is None or rr["spec"] != (int(high), int(rows), int(row_len)):
+            return None
+        st = np.random.get_state()
+        if st[0] != "MT19937" or int(st[2]) != int(self._pos.value) or not np.array_equal(st[1], self._key):
+            return None
+        np.random.set_state((st[0], rr["key"], int(rr["pos"].value), st[3], st[4]))
+        return rr["rows"]
 
 
 class _SharedPermutations:
@@ -384,10 +409,10 @@ class PPO(OnPolicyAlgorithm):
         # ... and, ahead of both (right behind the update's launch): `after_train_enqueued(last_iteration)` -- the pipelined
         # adversarial trainer enqueues the round's discriminator updates there, before any host-side wait of this iteration
         self.after_train_enqueued = None
-        # hooks of the adversarial trainer's index predraws (`adversarial/common.py: _DiscIndexPredraw`): called right behind
-        # the rollout's one noise draw; factory of the continuation of the permutation helper (argument: rows of the rollout)
-        self.after_noise_drawn = None
-        self.perm_continuation = None
+        # hook of the adversarial trainer (`adversarial/common.py: _replay_rows_spec`): (high, rows, row_len) of the
+        # `np.random.randint` rows its discriminator round will draw behind this update's permutations (argument: rows of
+        # the rollout) -- the permutation helper's C call draws them too, on a copy of the generator
+        self.randint_spec_for_round = None
         self._post_enqueue_work = []
         self._act_stream = None
         self.rollout_post_ahead = True   # (tuning / A-B: False posts a mailbox step only at the top of its own iteration)
@@ -564,8 +589,8 @@ class PPO(OnPolicyAlgorithm):
             self._dpg["perms"].start(self._dpg["perm_np"])   # shared across ranks; consumed by the next train()
         else:
             self._perm_uploaded = None
-            cont = self.perm_continuation(T * n) if self.perm_continuation is not None else None
-            self._predraw.start(self._perm_np, then=cont)  # consumed by the `train()` that follows
+            spec = self.randint_spec_for_round(T * n) if self.randint_spec_for_round is not None else None
+            self._predraw.start(self._perm_np, randint_spec=spec)  # consumed by the `train()` that follows
         stream = th.cuda.current_stream()
         rb.h_obs[0].copy_(th.as_tensor(np.asarray(self._last_obs)).reshape(n, -1))
         starts = np.asarray(self._last_episode_starts, dtype=bool)
@@ -614,8 +639,6 @@ class PPO(OnPolicyAlgorithm):
                         rb.h_noise_tile = th.zeros(T, n, width).pin_memory()
                     noise_tile = rb.h_noise_tile
                     pol.draw_noise_into(noise_tile)
-                    if self.after_noise_drawn is not None:   # torch's global generator rests until the round's updates
-                        self.after_noise_drawn()
                 predrawn = noise_tile.dim() == 3
                 act_step = pol.make_act_step(rb.h_obs, noise_tile, rb.acts, rb.h_clip, rb.val, rb.logp)  # eval mode: no norm update
                 # ONE resident launch for the rollout's T act steps, driven through flags in pinned host memory: a step

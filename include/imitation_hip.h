@@ -40,6 +40,13 @@ int ia_version(void);
  * per-epoch minibatch order of [SB3 RolloutBuffer.get] (adversarial/common.py:391-403 -> PPO.train).
  * Lets the host draw them off the Python thread while the rollout runs. out: int64 [count, n]. */
 int ia_host_mt19937_permutations(uint32_t* key, int* pos, int64_t n, int count, int64_t* out);
+/* ... followed, on a copy of the generator, by `rows` draws of np.random.randint(high, size=row_len) (legacy int64
+ * masked rejection): the replay ring's index rows of the round's discriminator updates (`data/buffer.py:366-377`,
+ * `algorithms/adversarial/common.py:557-575`). key / pos stay BEHIND THE PERMUTATIONS, key_post / pos_post receive the
+ * state behind the rows. */
+int ia_host_mt19937_permutations_then_randint(uint32_t* key, int* pos, int64_t n, int count, int64_t* out, int64_t high,
+                                              int64_t rows, int64_t row_len, int64_t* out_rows, uint32_t* key_post,
+                                              int* pos_post);
 /* HOST helper: out[c] = np.random.RandomState(seeds[c, 0:seed_len]).permutation(n) for c < count, each on
  * its own host thread. No reference counterpart (the reference is single-process): the shared-seed
  * minibatch order of the data-parallel PPO update. seeds: uint32 [count, seed_len]. */
@@ -495,7 +502,11 @@ int ia_ppo_force_valu(int on);
  * are two four-wave workgroups with the tower's parameters resident in LDS when that fits); 2 = one launch per epoch
  * with whole row-block workgroups (eight waves, both towers, weight fragments from memory: the form before);
  * 3 = the one-tower kernel with grid barriers between the phases (default 0 hands the slabs, the partial sums of
- * squares and the new parameters over as 8-byte value / sequence words instead: no barrier; bit-identical results). */
+ * squares and the new parameters over as 8-byte value / sequence words instead: no barrier; bit-identical results);
+ * 4 = that word-exchange kernel with chunk owners (round 4's default) also where round 5's default applies: observation
+ * widths <= 32 run `ppo_epoch_t64_kernel` -- every tower workgroup keeps its tower's parameters in LDS and Adam's moments
+ * in registers for the launch and steps the whole tower itself (no parameter hand-off), the layer chain transposed and
+ * register-resident as in the 32-wide persistent kernel ([SB3 PPO.train] on the default MlpPolicy). */
 int ia_ppo_epoch_split(int on);
 /* Measurement only: device buffer of 64 int64 (NULL: off); workgroup 0 of the one-launch-per-epoch kernel accumulates
  * 100 MHz ticks per phase in [0..5] = {gradient, barrier, slab sum, barrier, norm + Adam, barrier}; [16..27] / [32..43]:

@@ -621,78 +621,52 @@ def test_dropout_routes_to_the_module_net_and_tensorboard_warns(tmp_path):
     assert type(plain) is p.BasicRewardNet and not isinstance(plain, modules.BasicRewardNet)
 
 
-class _FakeRing:
-    capacity = 16384
-
-    def __init__(self, n):
-        self._n = n
-
-    def size(self):
-        return self._n
-
-
-def _fake_trainer(n_updates=16, batch=256, n_demo=1000, ring_rows=900):
-    import types
-    from imitation_amd import data_types as dt
-    from imitation_amd.adversarial.common import _DiscIndexPredraw
-    tr = types.SimpleNamespace(n_disc_updates_per_round=n_updates, demo_batch_size=batch, predraw_disc_indices=True,
-                               _expert_batches=None, _expert_stream=dt.ExpertIndexStream(n_demo, batch),
-                               _gen_replay_buffer=_FakeRing(ring_rows))
-    return tr, _DiscIndexPredraw(tr)
-
-
-def test_disc_index_predraw_equals_drawing_in_place():
-    """The helper threads' index rows and the generator states they leave are those of the in-place draws
-    (`ExpertIndexStream.next_indices` on torch's global generator incl. epoch starts; `np.random.randint` on NumPy's)."""
-    import copy
-    n, B, rollout_rows = 16, 256, 64
-    th.manual_seed(11)
-    np.random.seed(12)
-    tr, pre = _fake_trainer(n, B)
-    for _ in range(3):   # three rounds: the expert epoch boundary (3 batches per epoch) is crossed many times
-        t0, n0 = th.get_rng_state(), np.random.get_state()
-        st0 = copy.deepcopy((tr._expert_stream._perm, tr._expert_stream._pos))
-        # --- in place
-        want_e = [tr._expert_stream.next_indices().copy() for _ in range(n)]
-        tr._gen_replay_buffer._n = min(tr._gen_replay_buffer._n + rollout_rows, tr._gen_replay_buffer.capacity)
-        want_g = [np.random.randint(tr._gen_replay_buffer.size(), size=B) for _ in range(n)]
-        t1, n1, st1 = th.get_rng_state(), np.random.get_state(), (tr._expert_stream._perm, tr._expert_stream._pos)
-        # --- rewind, predraw, adopt
-        th.set_rng_state(t0)
-        np.random.set_state(n0)
-        tr._expert_stream._perm, tr._expert_stream._pos = st0
-        tr._gen_replay_buffer._n -= rollout_rows
-        pre.start_expert()
-        then = pre.replay_continuation(rollout_rows)
-        then(np.ascontiguousarray(n0[1], dtype=np.uint32).copy(), int(n0[2]), n0)   # (what the permutation helper calls)
-        tr._gen_replay_buffer._n += rollout_rows                                    # (the rollout has been stored)
-        e_rows, g_rows = pre.adopt(n)
-        assert e_rows is not None and g_rows is not None
-        assert all(np.array_equal(a, b) for a, b in zip(e_rows, want_e))
-        assert all(np.array_equal(a, b) and a.dtype == b.dtype for a, b in zip(g_rows, want_g))
-        assert th.equal(th.get_rng_state(), t1)
+def test_permutation_predraw_with_randint_rows_equals_drawing_in_place():
+    """`ppo._PermutationPredraw` with a randint spec (the C helper `ia_host_mt19937_permutations_then_randint`): the epoch
+    permutations AND the replay ring's index rows equal `np.random.permutation` x n_epochs followed by
+    `np.random.randint(high, size=row_len)` x rows drawn in place, and so does the generator state after each hand-over."""
+    from imitation_amd.ppo import _PermutationPredraw
+    for seed, (n_epochs, size, high, rows, row_len) in enumerate([(10, 16384, 16384, 16, 8192), (3, 100, 1, 2, 5),
+                                                                  (2, 7, 3000, 4, 33), (1, 64, 2 ** 32, 2, 9)]):
+        np.random.seed(100 + seed)
+        s0 = np.random.get_state()
+        want_p = np.stack([np.random.permutation(size) for _ in range(n_epochs)])
+        s_mid = np.random.get_state()
+        want_r = np.stack([np.random.randint(high, size=row_len) for _ in range(rows)])
+        s_post = np.random.get_state()
+        np.random.set_state(s0)
+        pre = _PermutationPredraw(n_epochs, size)
+        out = np.empty((n_epochs, size), dtype=np.int64)
+        pre.start(out, randint_spec=(high, rows, row_len))
+        assert pre.finish(out)
+        assert np.array_equal(out, want_p)
         got = np.random.get_state()
-        assert got[0] == n1[0] and np.array_equal(got[1], n1[1]) and got[2:] == n1[2:]
-        assert np.array_equal(tr._expert_stream._perm, st1[0]) and tr._expert_stream._pos == st1[1]
-    assert pre.adopted == [3, 3]
+        assert np.array_equal(got[1], s_mid[1]) and got[2:] == s_mid[2:]
+        assert pre.take_randint(high + 1, rows, row_len) is None          # another request than the one drawn for
+        pre._rr_armed = pre._rr
+        r = pre.take_randint(high, rows, row_len)
+        assert r is not None and r.dtype == want_r.dtype and np.array_equal(r, want_r)
+        got = np.random.get_state()
+        assert np.array_equal(got[1], s_post[1]) and got[2:] == s_post[2:]
+        assert pre.take_randint(high, rows, row_len) is None              # handed over once
 
 
-def test_disc_index_predraw_is_dropped_when_a_generator_moved():
-    """Somebody drew from a global generator between the copy and the hand-over (an env using torch's RNG, a user callback
-    calling np.random): the speculation is dropped, the global states stay as they are, the draws happen in place."""
-    n, B = 4, 128
-    th.manual_seed(3)
-    np.random.seed(4)
-    tr, pre = _fake_trainer(n, B)
-    n0 = np.random.get_state()
-    pre.start_expert()
-    pre.replay_continuation(0)(np.ascontiguousarray(n0[1], dtype=np.uint32).copy(), int(n0[2]), n0)
-    th.rand(1)
+def test_randint_rows_are_dropped_when_the_generator_moved():
+    """Somebody drew from NumPy's global generator between `PPO.train` (which adopted the permutations) and the
+    discriminator round: the rows are not handed over and the global state stays as it is."""
+    from imitation_amd.ppo import _PermutationPredraw
+    np.random.seed(5)
+    pre = _PermutationPredraw(2, 50)
+    out = np.empty((2, 50), dtype=np.int64)
+    pre.start(out, randint_spec=(40, 3, 10))
+    assert pre.finish(out)
     np.random.rand()
-    t, s = th.get_rng_state(), np.random.get_state()
-    assert pre.adopt(n) == (None, None)
-    assert th.equal(th.get_rng_state(), t) and np.array_equal(np.random.get_state()[1], s[1])
-    # ... and when the ring does not hold the number of rows the helper assumed
-    n0 = np.random.get_state()
-    pre.replay_continuation(64)(np.ascontiguousarray(n0[1], dtype=np.uint32).copy(), int(n0[2]), n0)
-    assert pre.adopt(n)[1] is None
+    st = np.random.get_state()
+    assert pre.take_randint(40, 3, 10) is None
+    got = np.random.get_state()
+    assert np.array_equal(got[1], st[1]) and got[2:] == st[2:]
+    # ... and when the permutations themselves were not adopted (the generator moved during the rollout)
+    pre.start(out, randint_spec=(40, 3, 10))
+    np.random.rand()
+    assert not pre.finish(out)
+    assert pre.take_randint(40, 3, 10) is None

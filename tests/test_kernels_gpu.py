@@ -481,8 +481,8 @@ def test_timeout_bootstrap():
                                                         # and a Discrete head with a short last minibatch
                                                         (27, 8, 32, False, True, 4, 12, 16),
                                                         (4, 3, 32, True, True, 4, 10, 16)])
-@pytest.mark.parametrize("path", ["epoch", "epochs_one_call", "epoch_whole", "epoch_barriers", "update", "update_spread",
-                                  "update_shard1"])
+@pytest.mark.parametrize("path", ["epoch", "epochs_one_call", "epoch_whole", "epoch_barriers", "epoch_ll", "update",
+                                  "update_spread", "update_shard1"])
 def test_ppo_epochs_match_oracle(D, A, H, discrete, norm, T, n, bs, path):
     """Two PPO epochs on a synthetic rollout: parameters, Adam state, RunningNorm state and the
     logged loss statistics against SB3-restated `PPO.train` on the same permutations -- through
@@ -491,12 +491,12 @@ def test_ppo_epochs_match_oracle(D, A, H, discrete, norm, T, n, bs, path):
     (`ia_ppo_update_sharded`) with a world of one -- the whole exchange machinery (8-byte value / sequence words through
     the peer block, loss statistics through the record tails, two launches on a growing sequence base) on one process;
     two ranks run in tests/test_distributed.py."""
-    if path in ("epoch_whole", "epoch_barriers") and H != 64:
-        pytest.skip("64-wide towers: the one-launch epoch with whole row-block workgroups / with grid barriers (default: one "
-                    "tower per workgroup, hand-offs as 8-byte value / sequence words)")
+    if path in ("epoch_whole", "epoch_barriers", "epoch_ll") and H != 64:
+        pytest.skip("64-wide towers: the one-launch epoch with whole row-block workgroups / with grid barriers / with chunk "
+                    "owners and parameter words (default: the tower-resident kernel, `ppo_epoch_t64_kernel`)")
     if path == "epochs_one_call" and (T * n) % bs != 0:
         pytest.skip("`ia_ppo_epochs` runs the epochs as one sequence of minibatches: whole minibatches per epoch only")
-    if path not in ("epoch", "epochs_one_call", "epoch_whole", "epoch_barriers") and H != 32:
+    if path not in ("epoch", "epochs_one_call", "epoch_whole", "epoch_barriers", "epoch_ll") and H != 32:
         pytest.skip("the persistent update covers hidden = 32")
     from imitation_amd import spaces
     from oracle import imitation_restated as o
@@ -546,8 +546,8 @@ def test_ppo_epochs_match_oracle(D, A, H, discrete, norm, T, n, bs, path):
                1, 0.2, 0.05, 0.5, 0.5, L.ptr(dp.m), L.ptr(dp.v), 3e-4, 0.9, 0.999, 1e-5, 0, L.ptr(ws), L.ptr(stats),
                L.stream())
         th.cuda.synchronize()
-    elif path in ("epoch", "epoch_whole", "epoch_barriers"):
-        L.load().ia_ppo_epoch_split({"epoch": 0, "epoch_whole": 2, "epoch_barriers": 3}[path])
+    elif path in ("epoch", "epoch_whole", "epoch_barriers", "epoch_ll"):
+        L.load().ia_ppo_epoch_split({"epoch": 0, "epoch_whole": 2, "epoch_barriers": 3, "epoch_ll": 4}[path])
         try:
             for e in range(2):
                 L.call("ia_ppo_epoch", C.byref(dp.d), L.ptr(dp.P), L.ptr(dp.Pt), L.ptr(dp.nm), L.ptr(dp.nv), L.ptr(dp.nc),
@@ -620,8 +620,8 @@ def test_ppo_epochs_match_oracle(D, A, H, discrete, norm, T, n, bs, path):
 @pytest.mark.parametrize("D,A,discrete,T,n,bs", [(17, 6, False, 16, 256, 1024), (4, 2, True, 9, 100, 384),
                                                   (27, 8, False, 8, 512, 2048), (40, 3, False, 10, 100, 448)])
 def test_word_exchange_epoch_is_bit_identical_to_the_barrier_form(D, A, discrete, T, n, bs):
-    """64-wide towers: `ppo_epoch_ll_kernel` (slabs, partial sums of squares and new parameters handed over as 8-byte
-    value / sequence words, no grid barrier) against `ppo_epoch_persistent_kernel<64, true>` (`ia_ppo_epoch_split(3)`):
+    """64-wide towers: `ppo_epoch_ll_kernel` (`ia_ppo_epoch_split(4)`: slabs, partial sums of squares and new parameters handed
+    over as 8-byte value / sequence words, no grid barrier) against `ppo_epoch_persistent_kernel<64, true>` (`ia_ppo_epoch_split(3)`):
     the same sums in the same order -> parameters, transposed copy, Adam moments and logged statistics bit for bit over
     three epochs (the sequence numbers continue from call to call; observation widths of all three poll-size classes)."""
     pol_ref = _oracle_policy(D, A, 64, discrete, True, seed=5)
@@ -636,7 +636,7 @@ def test_word_exchange_epoch_is_bit_identical_to_the_barrier_form(D, A, discrete
     perms = [rng.permutation(T * n) for _ in range(3)]
     outs = []
     try:
-        for mode in (3, 0):
+        for mode in (3, 4, 0):
             dp = DevPolicy(pol_ref, D, A, 64, discrete, True)
             ws = th.empty(int(L.load().ia_ppo_ws_floats(C.byref(dp.d), bs, T * n)), device=DEV)
             ws.uniform_(-1e30, 1e30)   # (the workspace arrives uninitialised)
@@ -652,9 +652,16 @@ def test_word_exchange_epoch_is_bit_identical_to_the_barrier_form(D, A, discrete
             outs.append((dp.P.clone(), dp.Pt.clone(), dp.m.clone(), dp.v.clone(), stats.clone(), dp.nm.clone(), dp.nv.clone()))
     finally:
         L.load().ia_ppo_epoch_split(0)
-    for name, x, y in zip(("parameters", "transposed copy", "exp_avg", "exp_avg_sq", "statistics", "norm mean", "norm var"), *outs):
+    names = ("parameters", "transposed copy", "exp_avg", "exp_avg_sq", "statistics", "norm mean", "norm var")
+    for name, x, y in zip(names, outs[0], outs[1]):
         assert th.equal(x, y), f"{name}: {int((x != y).sum())} of {x.numel()} differ, max {float((x - y).abs().max()):.3e}"
     assert float(outs[0][0].abs().sum()) > 0 and bool(th.isfinite(outs[1][0]).all())
+    # the default kernel (tower-resident parameters, transposed chain: other summation orders; observation widths up to 32,
+    # beyond them the word-exchange kernel again) agrees within the tolerance of the oracle comparison
+    k = 3 * n_mb
+    for name, x, y in zip(names, outs[0], outs[2]):
+        th.testing.assert_close(x, y, rtol=(1 + k) * 1e-5, atol=(1 + k) * 2e-6, msg=lambda m, name=name: f"{name}: {m}")
+    assert th.equal(outs[2][0], outs[2][0]) and bool(th.isfinite(outs[2][0]).all())
 
 
 @pytest.mark.parametrize("shape,B,A", [((4, 36, 36), 8, 6), ((3, 44, 52), 5, 4), ((1, 36, 40), 33, 18),
