@@ -17,6 +17,7 @@
 #include "common.h"
 #include "rn_common.h"
 #include <algorithm>
+#include <type_traits>
 #include <cstring>
 
 #include "../../include/imitation_hip.h"
@@ -443,9 +444,6 @@ __global__ void bootstrap_kernel(float* __restrict__ rewards, const float* __res
 //                       "prepare" launch is needed except for the first minibatch of an epoch.
 
 __host__ __device__ inline long long epoch_ll_words(int nrb, int P);   // (ppo_epoch_ll_kernel's word areas)
-__host__ __device__ inline long long t64_words(int nrb, int TWp);       // (ppo_epoch_t64_kernel's)
-struct PolOff;
-__host__ __device__ inline int t64_twp(const PolOff& o, int D, int A, int discrete);
 __host__ __device__ inline int epoch_ll_row_blocks(int nrb, int P);
 // ws layout (floats): [0..7] adv stats {mean, std}; [8..8+nblk*8) loss-stat partials;
 // then gradient slabs [nblk][P]; then reduced gradient [P].
@@ -3765,113 +3763,72 @@ __global__ __launch_bounds__(256) void ppo_epoch_ll_kernel(
 }
 
 // ---------------------------------------------------------------------------------------------
-// 64-wide towers (SB3's default `MlpPolicy`), round 5: TOWER-RESIDENT parameters and the transposed, register-resident
-// chain of the 32-wide persistent kernel.
-//
-//   grid = 2 nrb workgroups of FOUR waves: workgroup (rb, tw) = (bid >> 1, bid & 1) runs tower tw (0 policy, 1 value) of
-//   row block rb (64 rows) of every minibatch; wave q owns rows 16 q .. 16 q + 15 for the whole activation chain
+// 64-wide towers (SB3's default `MlpPolicy`), round 5: the transposed, register-resident chain of the 32-wide persistent
+// kernel for ONE tower per four-wave workgroup (`ppo_epoch_ll2_kernel` below). Wave q owns rows 16 q .. 16 q + 15 of the
+// block for the whole activation chain
 //       x -> a1 -> a2 -> head -> per-row loss -> d head -> dz2 -> dz1
-//   with features along the MFMA's M index, the wave's rows along N and the k index of a step permuted so that the
-//   accumulator of one layer IS the B operand of the next (`mfma32_minibatch_chain`): activations never leave the
-//   registers; the `[feature][row]` LDS tiles are written on the side for the weight-gradient tiles (ds_read_b128 of four
-//   consecutive rows). One wave per SIMD: the matrix pipe and the VALU are the wave's own.
-//   The tower's parameters LIVE in LDS for the whole launch -- W1 / W2 in torch layout with padded rows (a forward
-//   fragment = the four consecutive INPUTS of an output row: one ds_read_b128), W2 transposed likewise for the backward
-//   pass, the head in both orientations -- and Adam's moments of the WHOLE tower in the registers of each of its nrb
-//   workgroups: every workgroup of a tower applies the same clip + Adam step to its own copy, so there is NO parameter
-//   hand-off (`ppo_epoch_ll_kernel`: chunk owners publish 5.3 k parameter words per tower and step, every tower workgroup
-//   polls them, rebuilds two LDS images and re-reads every fragment: 5.3 of its 26.5 us per step).
-//   Exchange per step, as in the 32-wide kernel: (value, sequence) words, two hops. Hop 1: workgroup (rb, tw) polls slice
-//   rb of the nrb slabs of ITS tower, sums them in slab order, publishes the slice and the slice's sum of squares (one
-//   word); hop 2: it polls its tower's whole sum vector and the 2 nrb sums of squares (both towers: the clip is by the
-//   GLOBAL norm), folds those in a fixed order, clips, steps. The next minibatch's rows are loaded (plain loads of the
-//   gathered, contiguous rows) at the top of a step, parked in LDS behind the chain's barrier and normalised into the x
-//   tile between the two hops.
-struct T64Geo {   // LDS carve-up (floats; every offset a multiple of 4) of one tower workgroup
+// with features along the MFMA's M index, the wave's rows along N and the k index of a step permuted so that the
+// accumulator of one layer IS the B operand of the next (`mfma32_minibatch_chain`): activations never leave the registers;
+// the `[feature][row]` LDS tiles are written on the side for the weight-gradient tiles (ds_read_b128 of four consecutive
+// rows). One wave per SIMD: the matrix pipe and the VALU are the wave's own. The tower's parameters are read from LDS
+// images: W1 / W2 in torch layout with padded rows (a forward fragment = the four consecutive INPUTS of an output row: one
+// ds_read_b128), W2 transposed likewise for the backward pass, the head in both orientations.
+template <int KT1>
+struct T64Geo {   // LDS carve-up (floats; every offset a multiple of 4) of one tower workgroup: compile-time but for the
+                  // staging area's pieces, whose sizes follow the observation / action widths
   static constexpr int RS = 68;    // row stride of the [feature][row] tiles and of the 64-wide weight images
   static constexpr int HT = 20;    // row stride of the transposed head image [64 hidden][16 actions + 4]
-  int DP;                          // padded first-layer row: multiple of 4 with DP / 4 odd (eight lanes' b128 reads hit 32 banks)
-  int x, a1, a2, dz2, dz1, dout, aux, misc, scratch;   // tiles
-  int W1, W2, W2T, b1, b2, HW, HWT, hb, ls;            // images
-  int sx, sact, soldlp, sadv, sret, ring;              // staging of the next minibatch's rows; its statistics slot
-  int total;
+  static constexpr int DP = 16 * KT1 + 4;   // first-layer image row: a whole number of K tiles + one quad -- an odd number of
+                                            // quads (eight lanes' b128 reads hit 32 banks); columns >= D stay zero
+  // tiles
+  static constexpr int x = 0;
+  static constexpr int a1 = x + 16 * KT1 * RS;
+  static constexpr int a2 = a1 + 64 * RS;
+  static constexpr int dz2 = a2 + 64 * RS;
+  static constexpr int dz1 = dz2 + 64 * RS;
+  static constexpr int dout = dz1 + 64 * RS;
+  static constexpr int aux = dout + 16 * RS;
+  static constexpr int misc = aux + 16 * RS;
+  static constexpr int scratch = misc + 8 * RS;
+  // images
+  static constexpr int W1 = scratch + 64;
+  static constexpr int W2 = W1 + 64 * DP;
+  static constexpr int W2T = W2 + 64 * RS;
+  static constexpr int b1 = W2T + 64 * RS;
+  static constexpr int b2 = b1 + 64;
+  static constexpr int HW = b2 + 64;
+  static constexpr int HWT = HW + 16 * RS;
+  static constexpr int hb = HWT + 64 * HT;
+  static constexpr int ls = hb + 16;       // log_std [16] | 1 / sd^2 [16] | log sd [16] (policy tower of a Box space)
+  // staging of the next minibatch's rows; its statistics slot
+  static constexpr int ring = ls + 48;
+  static constexpr int soldlp = ring + 2 * MAXD + 8;   // old log-prob | advantage | return: three consecutive 64-float areas
+  static constexpr int sadv = soldlp + 64;
+  static constexpr int sret = sadv + 64;
+  static constexpr int sx = sret + 64;                 // [64][D] raw rows, packed
+  int sact, total;                                     // [64][aw]
+  __host__ __device__ T64Geo(int D, int aw) {
+    sact = sx + ((64 * D + 3) & ~3);
+    total = sact + ((64 * aw + 3) & ~3);
+  }
 };
-__host__ __device__ inline T64Geo t64_geo(int D, int aw, int KT1) {
-  constexpr int RS = T64Geo::RS;
-  T64Geo g;
-  int S1 = (D + 3) >> 2;
-  if (!(S1 & 1)) ++S1;
-  g.DP = 4 * S1;
-  int p = 0;
-  g.x = p; p += 16 * KT1 * RS;
-  g.a1 = p; p += 64 * RS;
-  g.a2 = p; p += 64 * RS;
-  g.dz2 = p; p += 64 * RS;
-  g.dz1 = p; p += 64 * RS;
-  g.dout = p; p += 16 * RS;
-  g.aux = p; p += 16 * RS;
-  g.misc = p; p += 8 * RS;
-  g.scratch = p; p += 64;
-  g.W1 = p; p += 64 * g.DP;
-  g.W2 = p; p += 64 * RS;
-  g.W2T = p; p += 64 * RS;
-  g.b1 = p; p += 64;
-  g.b2 = p; p += 64;
-  g.HW = p; p += 16 * RS;
-  g.HWT = p; p += 64 * T64Geo::HT;
-  g.hb = p; p += 16;
-  g.ls = p; p += 16;
-  g.sx = p; p += (64 * D + 3) & ~3;
-  g.sact = p; p += (64 * aw + 3) & ~3;
-  g.soldlp = p; p += 64;
-  g.sadv = p; p += 64;
-  g.sret = p; p += 64;
-  g.ring = p; p += 2 * MAXD + 8;
-  g.total = p;
-  return g;
-}
-// Tower-local parameter order: W1 [64][D], b1, W2 [64][64], b2, head weights (action_net [A][64] | value_net [64]),
-// head bias, log_std (policy tower of a Box space).
-struct T64Loc {
-  int lb1, lW2, lb2, lHW, lHb, lLS, TW;   // local offsets; TW: the tower's parameter count
-  int fbase, fhead, fls;                  // flat offsets of the three pieces in the parameter vector
+struct T64Out {   // word index (inside the workgroup's slab) of each piece of the tower's gradient; the loss-statistic tail
+  int W1, b1, W2, b2, HW, Hb, LS, tail;
+  bool zero_tail;   // the slab is this tower's alone: the tail slots of the other tower's statistics are written as zeros
 };
-__host__ __device__ inline T64Loc t64_loc(const PolOff& o, int D, int A, int discrete, int tw) {
-  T64Loc l;
-  l.lb1 = 64 * D;
-  l.lW2 = l.lb1 + 64;
-  l.lb2 = l.lW2 + 64 * 64;
-  l.lHW = l.lb2 + 64;
-  l.lHb = l.lHW + (tw ? 64 : A * 64);
-  l.lLS = l.lHb + (tw ? 1 : A);
-  l.TW = l.lLS + ((tw == 0 && !discrete) ? A : 0);
-  l.fbase = tw ? o.vW1 : o.pW1;
-  l.fhead = tw ? o.cW : o.aW;
-  l.fls = discrete ? 0 : o.log_std;
-  return l;
-}
-__host__ __device__ inline int t64_flat(const T64Loc& l, int i) {
-  return i < l.lHW ? l.fbase + i : (i < l.lLS ? l.fhead + (i - l.lHW) : l.fls + (i - l.lLS));
-}
-__host__ __device__ inline int t64_twp(const PolOff& o, int D, int A, int discrete) {
-  const int t0 = t64_loc(o, D, A, discrete, 0).TW, t1 = t64_loc(o, D, A, discrete, 1).TW;
-  return ((t0 > t1 ? t0 : t1) + 3) & ~3;
-}
-// word areas (8-byte words): slabs [2 parities][2 towers][nrb][TWp + 8] | sums [2][2][TWp + 8] | sums of squares [2][2][32]
-__host__ __device__ inline long long t64_words(int nrb, int TWp) {
-  return 4LL * nrb * (TWp + 8) + 4LL * (TWp + 8) + 4 * 32;
-}
-
-// The chain + weight-gradient tiles of one tower workgroup for one minibatch. `row0`: first minibatch row of the block,
-// `b`: rows of the minibatch; `slab`: this workgroup's slab (words); `mid()`: called by every wave behind the barrier that
-// ends the activation chain (the caller parks the next minibatch's prefetched rows there).
 template <int KT1, class Mid>
 __device__ __forceinline__ void t64_tower_minibatch(
-    const ia_policy_desc& d, const T64Geo& G, const T64Loc& Lc, const int tw, float* __restrict__ lds, const int row0,
+    const ia_policy_desc& d, const T64Geo<KT1>& G, const T64Out& Lc, const int tw, float* __restrict__ lds_in, const int row0,
     const int b, const float adv_mean, const float adv_std, const int normalize_adv, const float clip, const float ent_coef,
-    const float vf_coef, unsigned long long* __restrict__ slab, const int tail0, const unsigned seq, Mid&& mid) {
-  constexpr int RS = T64Geo::RS;
-  const int tid = threadIdx.x, lane = tid & 63;
+    const float vf_coef, unsigned long long* __restrict__ slab, const unsigned seq, Mid&& mid,
+    long long* __restrict__ ts /* measurement (nullable): shader clocks of the phases, thread 0 */, const int oz) {
+  // (`oz`: an opaque zero refreshed by the caller every step: the per-lane tile / image offsets below are then re-derived
+  //  per step -- a handful of VALU operations -- instead of being hoisted out of the step loop into spilled registers)
+  constexpr int RS = T64Geo<KT1>::RS;
+#define T64C_TS(slot) do { if (ts != nullptr && threadIdx.x == 0) ts[slot] = clock64(); } while (0)
+  T64C_TS(0);
+  float* __restrict__ lds = lds_in + oz;
+  const int tid = threadIdx.x + oz, lane = tid & 63;
   const int q = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 15, lk = lane >> 4;
   const int D = d.obs_dim, A = d.act_dim;
@@ -3900,7 +3857,7 @@ __device__ __forceinline__ void t64_tower_minibatch(
 #pragma unroll
     for (int kt = 0; kt < KT1; ++kt)
 #pragma unroll
-      for (int t = 0; t < 4; ++t) fW1[kt][t] = rd4(lds + G.W1 + (16 * t + li) * G.DP + min(16 * kt + 4 * lk, G.DP - 4));
+      for (int t = 0; t < 4; ++t) fW1[kt][t] = rd4(lds + G.W1 + (16 * t + li) * G.DP + 16 * kt + 4 * lk);
 #pragma unroll
     for (int t = 0; t < 4; ++t) b1c[t] = rd4(lds + G.b1 + 16 * t + 4 * lk);
 #pragma unroll
@@ -3908,14 +3865,6 @@ __device__ __forceinline__ void t64_tower_minibatch(
 #pragma unroll
       for (int r = 0; r < 4; ++r) xb[kt][r] = lds[G.x + (16 * kt + 4 * lk + r) * RS + q * 16 + li];
     __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int kt = 0; kt < KT1; ++kt) {
-      const bool on = 16 * kt + 4 * lk < G.DP;   // (quads past the padded row: the clamped read returned other columns)
-#pragma unroll
-      for (int t = 0; t < 4; ++t)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) fW1[kt][t][r] = on ? fW1[kt][t][r] : 0.f;
-    }
     f32x4 acc[4][2];
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
@@ -3926,8 +3875,10 @@ __device__ __forceinline__ void t64_tower_minibatch(
     for (int kt = 0; kt < KT1; ++kt)
 #pragma unroll
       for (int r = 0; r < 4; ++r)
+        if (16 * kt + r < D) {   // (wave-uniform: k-step (kt, r) carries columns 16 kt + r + {0, 4, 8, 12})
 #pragma unroll
-        for (int t = 0; t < 4; ++t) acc[t][(kt * 4 + r) & 1] = mfma16(fW1[kt][t][r], xb[kt][r], acc[t][(kt * 4 + r) & 1]);
+          for (int t = 0; t < 4; ++t) acc[t][(kt * 4 + r) & 1] = mfma16(fW1[kt][t][r], xb[kt][r], acc[t][(kt * 4 + r) & 1]);
+        }
 #pragma unroll
     for (int t = 0; t < 4; ++t)
 #pragma unroll
@@ -3936,6 +3887,7 @@ __device__ __forceinline__ void t64_tower_minibatch(
         lds[G.a1 + (16 * t + 4 * lk + r) * RS + q * 16 + li] = a1[t][r];
       }
   }
+  T64C_TS(1);
   // ---- layer 2: a2^T = tanh(W2 a1^T + b2): the accumulators of layer 1 are the B operands
   {
     f32x4 fW2[4][4], b2c[4];
@@ -3966,6 +3918,7 @@ __device__ __forceinline__ void t64_tower_minibatch(
         lds[G.a2 + (16 * t + 4 * lk + r) * RS + q * 16 + li] = a2[t][r];
       }
   }
+  T64C_TS(2);
   // ---- head. The head image holds action_net's rows (rows >= A zero) resp. value_net's row in row 0 (rows 1.. zero): the M
   // index li picks the row; hout[r] = output 4 lk + r of row li (value: lane group 0, register 0)
   float hout[4];
@@ -3983,12 +3936,13 @@ __device__ __forceinline__ void t64_tower_minibatch(
 #pragma unroll
     for (int r = 0; r < 4; ++r) hout[r] = acc[0][r] + acc[1][r];
   }
+  T64C_TS(3);
   // backward fragments: the head's weights of the lane's outputs 16 t + 4 lk + r here (landed by the time the loss phase is
   // through); W2 transposed (A[m = in 16 t + li][k = out 16 kt + 4 lk + r]) behind the loss phase
   f32x4 fHeadT[4];
 #pragma unroll
   for (int t = 0; t < 4; ++t)
-    fHeadT[t] = tw == 0 ? rd4(lds + G.HWT + (16 * t + li) * T64Geo::HT + 4 * lk) : rd4(lds + G.HW + 16 * t + 4 * lk);
+    fHeadT[t] = tw == 0 ? rd4(lds + G.HWT + (16 * t + li) * T64Geo<KT1>::HT + 4 * lk) : rd4(lds + G.HW + 16 * t + 4 * lk);
   // ---- per-row losses (the expressions of `mfma32_minibatch_chain`): four lanes per row, lane group lk = actions 4 lk ..
   auto xchg16 = [](float v, float& a, float& bq) {
     const auto p2 = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
@@ -4016,17 +3970,9 @@ __device__ __forceinline__ void t64_tower_minibatch(
   };
   float dout[4] = {0.f, 0.f, 0.f, 0.f}, dvb = 0.f;
   if (tw == 0) {
-    float c_ivar[4] = {1.f, 1.f, 1.f, 1.f}, c_logsd[4] = {0.f, 0.f, 0.f, 0.f};
-    if (!d.discrete) {   // lane a: action a's (1 / sd^2, log sd); every lane picks its four actions' pairs up from the wave
-      const float sd = expf(lds[G.ls + min(lane, A - 1)]);
-      const float my_ivar = lane < A ? 1.f / (sd * sd) : 1.f;
-      const float my_logsd = lane < A ? logf(sd) : 0.f;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        c_ivar[j] = __shfl(my_ivar, 4 * lk + j, 64);
-        c_logsd[j] = __shfl(my_logsd, 4 * lk + j, 64);
-      }
-    }
+    // per-action Gaussian constants 1 / sd^2 and log sd of the lane's actions 4 lk ..: worked out once per step by the thread
+    // that steps log_std (`gauss_constants`) and left behind the log_std image
+    const f32x4 c_ivar = rd4(lds + G.ls + 16 + 4 * lk), c_logsd = rd4(lds + G.ls + 32 + 4 * lk);
     float logp = 0.f, entropy = 0.f, lse = 0.f;
     int act_i = 0;
     if (d.discrete) act_i = (int)r_act[0];
@@ -4114,6 +4060,7 @@ __device__ __forceinline__ void t64_tower_minibatch(
       lds[G.misc + 6 * RS + lrow] = valid ? verr * verr : 0.f;        // value_loss
     }
   }
+  T64C_TS(4);
   // ---- dz2^T = (W_head^T d head^T) * (1 - a2^2), dz1^T = (W2^T dz2^T) * (1 - a1^2)
   {
     f32x4 fW2T[4][4];   // (requested here: in flight under dz2's MFMAs / products)
@@ -4159,8 +4106,10 @@ __device__ __forceinline__ void t64_tower_minibatch(
       for (int r = 0; r < 4; ++r)
         lds[G.dz1 + (16 * t + 4 * lk + r) * RS + q * 16 + li] = (acc[t][0][r] + acc[t][1][r]) * (1.f - a1[t][r] * a1[t][r]);
   }
+  T64C_TS(5);
   __syncthreads();   // every row's activations and activation gradients are in LDS
   mid();
+  T64C_TS(6);
   // ---- weight-gradient tiles: contractions over the 64 rows, independent per wave. Tile = 16 features of U (the MFMA's M
   // index) x 16 features of V (N); a lane reads four consecutive rows of its feature per ds_read_b128 (row steps 4 sq .. + 3
   // of lane group lk are rows 16 sq + 4 lk ..: the same permutation on both operands); two accumulator chains per tile.
@@ -4223,13 +4172,14 @@ __device__ __forceinline__ void t64_tower_minibatch(
       tile2(u, lds + G.a1 + 16 * it * RS, lds + G.a1 + 16 * (it + 1) * RS, g0, g1);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        put(Lc.lW2 + (16 * q + 4 * lk + r) * 64 + 16 * it + li, g0[r]);
-        put(Lc.lW2 + (16 * q + 4 * lk + r) * 64 + 16 * (it + 1) + li, g1[r]);
+        put(Lc.W2 + (16 * q + 4 * lk + r) * 64 + 16 * it + li, g0[r]);
+        put(Lc.W2 + (16 * q + 4 * lk + r) * 64 + 16 * (it + 1) + li, g1[r]);
       }
     }
     const float sb2 = colsum16(lds + G.dz2 + 16 * q * RS, nullptr);
-    if (lane < 16) put(Lc.lb2 + 16 * q + lane, sb2);
+    if (lane < 16) put(Lc.b2 + 16 * q + lane, sb2);
   }
+  T64C_TS(7);
   {   // dW1[j][c] = sum_r dz1[r][j] x[r][c]; head weights: dWa[a][h] = sum_r dout[r][a] a2[r][h] (policy: one tile per wave)
     f32x4 u[4];
     load_u(lds + G.dz1 + 16 * q * RS, u);
@@ -4241,12 +4191,13 @@ __device__ __forceinline__ void t64_tower_minibatch(
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      if (li < D) put((16 * q + 4 * lk + r) * D + li, g0[r]);
-      if (KT1 == 2 && 16 + li < D) put((16 * q + 4 * lk + r) * D + 16 + li, g1[r]);
+      if (li < D) put(Lc.W1 + (16 * q + 4 * lk + r) * D + li, g0[r]);
+      if (KT1 == 2 && 16 + li < D) put(Lc.W1 + (16 * q + 4 * lk + r) * D + 16 + li, g1[r]);
     }
     const float sb1 = colsum16(lds + G.dz1 + 16 * q * RS, nullptr);
-    if (lane < 16) put(Lc.lb1 + 16 * q + lane, sb1);
+    if (lane < 16) put(Lc.b1 + 16 * q + lane, sb1);
   }
+  T64C_TS(8);
   if (tw == 0) {
     f32x4 u[4];
     load_u(lds + G.dout, u);
@@ -4254,185 +4205,190 @@ __device__ __forceinline__ void t64_tower_minibatch(
     tile2(u, lds + G.a2 + 16 * q * RS, lds + G.a2 + 16 * q * RS, g0, g1);
 #pragma unroll
     for (int r = 0; r < 4; ++r)
-      if (4 * lk + r < A) put(Lc.lHW + (4 * lk + r) * 64 + 16 * q + li, g0[r]);
+      if (4 * lk + r < A) put(Lc.HW + (4 * lk + r) * 64 + 16 * q + li, g0[r]);
     if (q == 0) {   // action_net bias
       const float s = colsum16(lds + G.dout, nullptr);
-      if (lane < A) put(Lc.lHb + lane, s);
+      if (lane < A) put(Lc.Hb + lane, s);
     } else if (q == 1) {   // log_std
       if (!d.discrete) {
         const float s = colsum16(lds + G.aux, nullptr);
-        if (lane < A) put(Lc.lLS + lane, s);
+        if (lane < A) put(Lc.LS + lane, s);
       }
     } else if (q == 2) {   // loss statistics: misc columns 2..5 -> tail slots {0 pg, 2 ent, 3 kl, 4 clip}
       const float s = colsum16(lds + G.misc, nullptr);   // (features 0..7 of the misc tile; 8..15 read the next tile: unused)
-      if (lane >= 2 && lane < 6) put(tail0 + (lane == 2 ? 0 : lane - 1), s);
+      if (lane >= 2 && lane < 6) put(Lc.tail + (lane == 2 ? 0 : lane - 1), s);
     } else {
-      if (lane < 4) put(tail0 + (lane == 0 ? 1 : lane + 4), 0.f);   // (slots 1, 5, 6, 7: not this tower's)
+      if (Lc.zero_tail && lane < 4) put(Lc.tail + (lane == 0 ? 1 : lane + 4), 0.f);   // (slots 1, 5, 6, 7: not this tower's)
     }
   } else {
     // value_net: dcW[h] = sum_r dv[r] a2[r][h] -- one useful row of a tile: a weighted column sum instead
     const float s = colsum16(lds + G.a2 + 16 * q * RS, lds + G.misc + 1 * RS);
-    if (lane < 16) put(Lc.lHW + 16 * q + lane, s);
+    if (lane < 16) put(Lc.HW + 16 * q + lane, s);
     if (q == 0) {   // value_net bias = sum_r dv[r]; value_loss -> tail slot 1
       const float sm = colsum16(lds + G.misc, nullptr);
-      if (lane == 1) put(Lc.lHb, sm);
-      if (lane == 6) put(tail0 + 1, sm);
+      if (lane == 1) put(Lc.Hb, sm);
+      if (lane == 6) put(Lc.tail + 1, sm);
     } else if (q == 1) {
-      if (lane < 7) put(tail0 + (lane == 0 ? 0 : lane + 1), 0.f);   // (slots 0, 2..7: not this tower's)
+      if (Lc.zero_tail && lane < 7) put(Lc.tail + (lane == 0 ? 0 : lane + 1), 0.f);   // (slots 0, 2..7: not this tower's)
     }
   }
+  T64C_TS(9);
   __syncthreads();
+  T64C_TS(10);
+#undef T64C_TS
 }
 
+// ---------------------------------------------------------------------------------------------
+// Round 5: the word-exchange epoch kernel with the TRANSPOSED, REGISTER-RESIDENT chain (`t64_tower_minibatch`) as its
+// gradient phase -- observation widths up to 32. Exchange, sequence numbers, chunk owners and Adam are those of
+// `ppo_epoch_ll_kernel` (same word areas, same sums in the same order in phases B1 / B2); what changed is phase A:
+//   * the tower's polled parameter words go straight to their places in the chain's LDS images (W1 / W2 in torch layout
+//     with padded rows, W2 transposed, the head in both orientations: every weight fragment one ds_read_b128), places
+//     worked out once per launch;
+//   * the minibatch's rows are plain loads of the gathered, contiguous rows issued a step AHEAD (parked in LDS behind the
+//     chain's barrier, normalised into the `[feature][row]` x tile while the partial sums of squares travel);
+//   * activations stay in registers through x -> a1 -> a2 -> head -> loss -> dz2 -> dz1; four tiles of a wave's weight
+//     gradient share their first operand; one-row products (value head) are weighted column sums.
+// A tower workgroup that was tried in between -- parameters resident in LDS for the launch, every workgroup stepping its
+// whole tower, two hops -- lost: Adam on 5.7 k parameters by 256 threads and 22-30 words per thread in both hops cost more
+// than the parameter hand-off saves (28.2 against 26.5 us per step; `profiles/r05_mlp64.md`).
 template <int KT1>
-__global__ __launch_bounds__(256) void ppo_epoch_t64_kernel(
+__global__ __launch_bounds__(256) void ppo_epoch_ll2_kernel(
     ia_policy_desc d, float* __restrict__ P, float* __restrict__ Pt, float* __restrict__ m, float* __restrict__ v,
     const float* __restrict__ nm_in, const float* __restrict__ nv_in, const float* __restrict__ obs,
     const float* __restrict__ actions, const float* __restrict__ old_logp, const float* __restrict__ adv,
-    const float* __restrict__ ret, long long total_rows, int batch_size, int normalize_adv, float clip, float ent_coef,
-    float vf_coef, float max_norm, float beta1, float beta2, float eps, float* __restrict__ ws,
-    unsigned long long* __restrict__ wbase, unsigned seq0, const float* __restrict__ seq, int snap,
-    float* __restrict__ stats, EpochSteps st, long long* __restrict__ dbg /* measurement: [0..5] += 100 MHz ticks of workgroup 0
-    in {chain + tiles, hop 1, slice sums, staging + hop 2, norm + Adam, -} */) {
+    const float* __restrict__ ret, long long total_rows, int batch_size, int T, int n_envs, int normalize_adv,
+    float clip, float ent_coef, float vf_coef, float max_norm, float beta1, float beta2, float eps,
+    float* __restrict__ ws, EpochLl ll, const float* __restrict__ seq, int snap, float* __restrict__ stats, EpochSteps st,
+    long long* __restrict__ dbg /* measurement: [0..5] += 100 MHz ticks of workgroup 0 in {A, slab poll + sum, sum of squares
+                                   published, poll of the sums of squares, Adam + publish, -}; [16..], [32..]: shader clocks of
+                                   the chain's phases (policy / value tower of row block 0, last step) */) {
   typedef unsigned long long u64;
-  constexpr int NT = 256, RS = T64Geo::RS;
-  // Parameter SLOTS of a thread (Adam's moments in registers, the hop-2 words it polls): per piece of the tower its own
-  // thread-linear numbering, so that a slot's parameter, its places in the LDS images and its word are plain arithmetic
-  // on (slot, thread) -- no per-slot index registers: W1 (64 D elements: 4 KT1 slots), the two hidden biases (one slot:
-  // threads 0..127), W2 (16 slots: element tid + 256 kk = row (tid >> 6) + 4 kk, column tid & 63), head weights (4 slots),
-  // head bias + log_std (one slot).
-  constexpr int SW1 = 4 * KT1, NPT = SW1 + 1 + 16 + 4 + 1;
-  constexpr int NH1 = (64 * 16 * KT1 + 64 + 64 * 64 + 64 + 16 * 64 + 32 + 8 + 32 + NT - 1) / NT + 1;   // words polled in hop 1
+  constexpr int H = 64, NT = 256;
+  constexpr int RS = T64Geo<KT1>::RS;
+  constexpr int NLL = KT1 == 1 ? 21 : 25;                    // words of the tower's layers per thread (64 D + 64 + 4096 + 64)
+  constexpr int NB = (MAXA * H + MAXA + NT - 1) / NT;        // words of its head per thread
   extern __shared__ __attribute__((aligned(16))) float lds_raw[];
-  float* lds = lds_raw + (((16 - (__builtin_amdgcn_groupstaticsize() & 15)) & 15) >> 2);
+  float* const lds0 = lds_raw + (((16 - (__builtin_amdgcn_groupstaticsize() & 15)) & 15) >> 2);
+  float* lds = lds0;
   __shared__ int s_fail;
   __shared__ float s_part[64];
-  __shared__ float s_tail[16];
-  const int bid = blockIdx.x, nrb = gridDim.x >> 1, rb = bid >> 1, tw = bid & 1;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int D = d.obs_dim, A = d.act_dim, aw = d.discrete ? 1 : A;
-  const PolOff o = pol_offsets(D, A, 64, d.discrete);
-  const T64Geo G = t64_geo(D, aw, KT1);
-  const T64Loc Lc = t64_loc(o, D, A, d.discrete, tw);
-  const int TWp = t64_twp(o, D, A, d.discrete), SWW = TWp + 8;
-  u64* slabs64 = wbase;
-  u64* sums64 = slabs64 + 4LL * nrb * SWW;
-  u64* sq64 = sums64 + 4LL * SWW;
-  unsigned* err = reinterpret_cast<unsigned*>(ws) + 5;
+  __shared__ float s_stat[32 * 8];
   long long tprev = 0;
-#define T64_TS(slot)                                                      \
+#define EP_TS(slot)                                                       \
   do {                                                                    \
-    if (dbg != nullptr && bid == 0 && tid == 0) {                         \
+    if (dbg != nullptr && blockIdx.x == 0 && threadIdx.x == 0) {          \
       const long long tn = wall_clock64();                                \
       dbg[slot] += tn - tprev;                                            \
       tprev = tn;                                                         \
     }                                                                     \
   } while (0)
+  if (dbg != nullptr && blockIdx.x == 0 && threadIdx.x == 0) tprev = wall_clock64();
+  const int bid = blockIdx.x, nwg = gridDim.x, nrb = nwg >> 1, rb = bid >> 1, tower = bid & 1;
+  const int D = d.obs_dim, A = d.act_dim, aw = d.discrete ? 1 : A;
+  const PolOff o = pol_offsets(D, A, H, d.discrete);
+  const T64Geo<KT1> G(D, aw);
+  const int SW = o.total + 8;
+  u64* slabs64 = ll.base;
+  u64* sq64 = slabs64 + 2LL * nrb * SW;
+  u64* par64 = sq64 + 2 * 64;
+  unsigned* err = reinterpret_cast<unsigned*>(ws) + 5;
+  const int chunk = (o.total + nwg - 1) / nwg;
+  constexpr int NPC = 4;   // parameters of the chunk per thread (chunk <= 1024)
+  int tid = threadIdx.x, lane = tid & 63;   // (re-formed every step behind an opaque zero: see the step loop)
   if (tid == 0) s_fail = 0;
   for (int e = tid; e < G.total; e += NT) lds[e] = 0.f;
-  __syncthreads();
-  // ---- slot -> (tower-local index | -1, first / second place in the LDS images | -1)
-  const unsigned rcpD = 0xffffffffu / (unsigned)D + 1u;
-  auto slot_of = [&](const int sidx, int& i, int& da, int& db) {
-    i = da = db = -1;
-    if (sidx < SW1) {
-      const int e = tid + sidx * NT;
-      if (e < 64 * D) {
-        const int r = D == 1 ? e : (int)__umulhi((unsigned)e, rcpD);
-        i = e;
-        da = G.W1 + r * G.DP + (e - r * D);
-      }
-    } else if (sidx == SW1) {
-      if (tid < 64) {
-        i = Lc.lb1 + tid;
-        da = G.b1 + tid;
-      } else if (tid < 128) {
-        i = Lc.lb2 + tid - 64;
-        da = G.b2 + tid - 64;
-      }
-    } else if (sidx < SW1 + 17) {
-      const int kk = sidx - SW1 - 1, r = (tid >> 6) + 4 * kk, c = tid & 63;
-      i = Lc.lW2 + tid + NT * kk;
+  // ---- the tower's pieces of the parameter vector and where each of the thread's polled words goes in the LDS images
+  // (first place | second place << 16, 0xffff: none): the same every step
+  const int tlen = H * D + H + H * H + H, t0 = tower ? o.vW1 : o.pW1;
+  const int segB0 = tower ? o.cW : o.aW, nB = (tower ? o.total : o.cW) - segB0;
+  unsigned dA[NLL], dB[NB];
+#pragma unroll
+  for (int i = 0; i < NLL; ++i) {
+    const int e = tid + i * NT;
+    unsigned da = 0xffffu, db = 0xffffu;
+    if (e < H * D) {
+      const int r = e / D;
+      da = G.W1 + r * G.DP + (e - r * D);
+    } else if (e < H * D + H) {
+      da = G.b1 + (e - H * D);
+    } else if (e < H * D + H + H * H) {
+      const int j = e - (H * D + H), r = j >> 6, c = j & 63;
       da = G.W2 + r * RS + c;
       db = G.W2T + c * RS + r;
-    } else if (sidx < SW1 + 21) {
-      const int j = tid + NT * (sidx - SW1 - 17);
-      if (tw == 0) {
-        if ((j >> 6) < A) {
-          i = Lc.lHW + j;
-          da = G.HW + (j >> 6) * RS + (j & 63);
-          db = G.HWT + (j & 63) * T64Geo::HT + (j >> 6);
-        }
-      } else if (j < 64) {
-        i = Lc.lHW + j;
-        da = G.HW + j;
-      }
-    } else {
-      const int j = Lc.lHb + tid;
-      if (j < Lc.TW) {
-        i = j;
-        da = j < Lc.lLS ? G.hb + (j - Lc.lHb) : G.ls + (j - Lc.lLS);
-      }
+    } else if (e < tlen) {
+      da = G.b2 + (e - (H * D + H + H * H));
     }
-  };
-  // ---- the tower's parameters into the LDS images; Adam's moments of the whole tower in registers for the launch
-  float rm[NPT], rv[NPT];
+    dA[i] = da | (db << 16);
+  }
 #pragma unroll
-  for (int k = 0; k < NPT; ++k) {
-    int i, da, db;
-    slot_of(k, i, da, db);
-    rm[k] = rv[k] = 0.f;
-    if (i >= 0) {
-      const int f = t64_flat(Lc, i);
-      rm[k] = m[f];
-      rv[k] = v[f];
-      const float p = P[f];
-      lds[da] = p;
-      if (db >= 0) lds[db] = p;
+  for (int i = 0; i < NB; ++i) {
+    const int j = tid + i * NT;
+    unsigned da = 0xffffu, db = 0xffffu;
+    if (tower == 0) {
+      if (j < A * H) {
+        da = G.HW + (j >> 6) * RS + (j & 63);
+        db = G.HWT + (j & 63) * T64Geo<KT1>::HT + (j >> 6);
+      } else if (j < nB) {
+        da = G.hb + (j - A * H);
+      }
+    } else if (j < H) {
+      da = G.HW + j;
+    } else if (j < nB) {
+      da = G.hb;
+    }
+    dB[i] = da | (db << 16);
+  }
+  const T64Out out{tower ? o.vW1 : o.pW1, tower ? o.vb1 : o.pb1, tower ? o.vW2 : o.pW2, tower ? o.vb2 : o.pb2,
+                   tower ? o.cW : o.aW,   tower ? o.cb : o.ab,   d.discrete ? 0 : o.log_std, o.total, false};
+  // the workgroup's chunk of the parameters and of Adam's moments: registers across the launch (nobody else writes it)
+  float m_[NPC], v_[NPC], p_[NPC];
+#pragma unroll
+  for (int j = 0; j < NPC; ++j) {
+    const int i = min(bid * chunk + tid + j * NT, o.total - 1);
+    m_[j] = m[i];
+    v_[j] = v[i];
+    p_[j] = P[i];
+  }
+  {   // the parameters the first step reads
+    u64* dst = par64 + (long long)(ll.seq0 & 1u) * o.total;
+#pragma unroll
+    for (int j = 0; j < NPC; ++j) {
+      const int i = bid * chunk + tid + j * NT;
+      if (i < min(o.total, (bid + 1) * chunk)) ll_store_agent(dst + i, p_[j], ll.seq0);
     }
   }
-  // ---- rows of a minibatch: gathered and contiguous. `load_rows` requests block rb's rows of minibatch `mbi` (plain loads,
-  // clamped inside the sequence; rows past the minibatch are masked when staged), `park_rows` leaves them in the staging area
-  constexpr int NXR = (64 * 32 + NT - 1) / NT;   // observation elements per thread (D <= 32)
+  // ---- rows of a minibatch: gathered and contiguous. `load_rows`: plain loads of block rb's rows of minibatch `mbi`, every
+  // one UNCONDITIONAL at a clamped 32-bit offset from a uniform base (a load behind a branch is merged with the "not
+  // loaded" value by a copy that waits for it; a per-thread choice of pointer makes the load a flat one behind 64-bit
+  // address arithmetic); `park_rows` leaves them in the staging area; `stage_rows` normalises them into the x tile
+  constexpr int NXR = (64 * 16 * KT1 + NT - 1) / NT;
   constexpr int NAR = (64 * MAXA + NT - 1) / NT;
-  float pf_x[NXR], pf_a[NAR], pf_s = 0.f, pf_r = 0.f;
+  float pf_x[NXR], pf_a[NAR], pf_s[3], pf_r[3];
   auto load_rows = [&](int mbi) {
-    const long long start = (long long)mbi * batch_size + 64 * rb;
-    const long long last = total_rows - 1;
-    const int nx = 64 * D, na = 64 * aw;
+    long long start = (long long)mbi * batch_size + 64 * rb;
+    start = start < total_rows - 1 ? start : total_rows - 1;
+    const float* xb0 = obs + start * D;
+    const float* ab0 = actions + start * aw;
+    const int rrem = (int)(total_rows - 1 - start);            // rows behind the block's first
+    const int xrem = rrem * D + D - 1, arem = rrem * aw + aw - 1;
 #pragma unroll
-    for (int it = 0; it < NXR; ++it) {
-      const int e = min(tid + it * NT, nx - 1);
-      const int r = e / D;
-      const long long row = start + r < last ? start + r : last;
-      pf_x[it] = obs[row * D + (e - r * D)];
-    }
+    for (int it = 0; it < NXR; ++it) pf_x[it] = xb0[min(tid + it * NT, xrem)];
 #pragma unroll
-    for (int it = 0; it < NAR; ++it) {
-      const int e = min(tid + it * NT, na - 1);
-      const int r = e / aw;
-      const long long row = start + r < last ? start + r : last;
-      pf_a[it] = actions[row * aw + (e - r * aw)];
-    }
-    {   // per-row scalars: threads 0..63 old log-prob, 64..127 advantage, 128..191 return; 192..: the statistics slot
-      const int r = tid & 63;
-      const long long row = start + r < last ? start + r : last;
-      const float* src = tid < 64 ? old_logp : (tid < 128 ? adv : ret);
-      pf_s = src[row];
-    }
-    {   // statistics of the minibatch: adv mean / std, feature mean / variance (snapshot of the running statistics AFTER
-        // this minibatch's update when the call updates them, the running statistics themselves otherwise)
-      const float* sq = seq + (long long)mbi * EPS_SEQ;
-      const int e = tid;   // 0, 1: adv mean / std; 8 + c: mean; 8 + MAXD + c: variance
-      float val = 0.f;
-      if (e < 2) val = sq[e];
-      else if (e >= 8 && e < 8 + 2 * MAXD) {
-        const int c = (e - 8) & (MAXD - 1);
-        const bool var = e >= 8 + MAXD;
-        if (d.has_norm && c < D) val = snap ? sq[e] : (var ? nv_in[c] : nm_in[c]);
-      }
-      pf_r = val;
-    }
+    for (int it = 0; it < NAR; ++it) pf_a[it] = ab0[min(tid + it * NT, arem)];
+    const int r = min(tid & 63, rrem);
+    pf_s[0] = (old_logp + start)[r];
+    pf_s[1] = (adv + start)[r];
+    pf_s[2] = (ret + start)[r];
+    // statistics of the minibatch: [0] adv mean, [1] adv std, [8 + c] feature mean, [8 + MAXD + c] feature variance (the
+    // snapshot of the running statistics AFTER this minibatch's update when the call updates them, else the running ones)
+    const float* sqp = seq + (long long)mbi * EPS_SEQ;
+    const int e = min(tid, 2 * MAXD + 7), c = (max(e, 8) - 8) & (MAXD - 1);
+    const float* nmp = d.has_norm ? nm_in : sqp;
+    const float* nvp = d.has_norm ? nv_in : sqp;
+    pf_r[0] = sqp[e];
+    pf_r[1] = nmp[min(c, D - 1)];
+    pf_r[2] = nvp[min(c, D - 1)];
   };
   auto park_rows = [&]() {
     const int nx = 64 * D, na = 64 * aw;
@@ -4442,11 +4398,18 @@ __global__ __launch_bounds__(256) void ppo_epoch_t64_kernel(
 #pragma unroll
     for (int it = 0; it < NAR; ++it)
       if (tid + it * NT < na) lds[G.sact + tid + it * NT] = pf_a[it];
-    if (tid < 192) lds[G.soldlp + tid] = pf_s;   // (soldlp, sadv, sret are consecutive 64-float areas)
-    if (tid < 2 * MAXD + 8) lds[G.ring + tid] = pf_r;
+    if (tid < 192) lds[G.soldlp + tid] = tid < 64 ? pf_s[0] : (tid < 128 ? pf_s[1] : pf_s[2]);   // (three consecutive areas)
+    if (tid < 2 * MAXD + 8) {
+      const bool var = tid >= 8 + MAXD;
+      float val = (snap || tid < 8) ? pf_r[0] : (var ? pf_r[2] : pf_r[1]);
+      // (variance columns: 1 / sqrt(var + eps) once per column here -- the product below is within 1 ulp of the quotient
+      //  `util/networks.py:91` forms, as in the 32-wide kernel -- instead of a square root and a division per element)
+      if (var) val = 1.f / sqrtf(val + d.norm_eps);
+      if (tid >= 8 && (!d.has_norm || ((tid - 8) & (MAXD - 1)) >= D)) val = 0.f;
+      lds[G.ring + tid] = val;
+    }
   };
-  // normalised rows of the staged minibatch -> x tile (transposed); `bn`: rows of that minibatch
-  auto stage_rows = [&](int bn) {
+  auto stage_rows = [&](int bn) {   // `bn`: rows of the staged minibatch
     const int S1 = (D + 3) >> 2;
     const int s1r = (65536 + S1 - 1) / S1;
     for (int g = tid; g < 64 * S1; g += NT) {
@@ -4464,236 +4427,240 @@ __global__ __launch_bounds__(256) void ppo_epoch_t64_kernel(
       for (int j = 0; j < 4; ++j) {
         const bool ok = rok && k0 + j < D;
         float val = raw[j];
-        if (d.has_norm) val = (raw[j] - mu[j]) * __builtin_amdgcn_rsqf(vr[j] + d.norm_eps);
+        if (d.has_norm) val = (raw[j] - mu[j]) * vr[j];   // (`vr`: 1 / sqrt(var + eps), see park_rows)
         lds[G.x + (k0 + j) * RS + r] = ok ? val : 0.f;
       }
     }
   };
-  auto timed_out = [&](unsigned& it) {
-    __builtin_amdgcn_s_sleep(1);
-    if (++it > (1u << 22) || ((it & 255u) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
-      __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      return true;
-    }
-    return false;
-  };
-  if (st.n > 0) {
+  auto rows_of = [&](int mbi) { return (int)min((long long)batch_size, total_rows - (long long)mbi * batch_size); };
+  __syncthreads();
+  if (st.n > 0 && rb < (rows_of(st.first) + ROWS - 1) / ROWS) {   // (block-uniform)
     load_rows(st.first);
     park_rows();
     __syncthreads();
-    const long long start0 = (long long)st.first * batch_size;
-    stage_rows((int)min((long long)batch_size, total_rows - start0));
+    stage_rows(rows_of(st.first));
   }
   __syncthreads();
-  if (dbg != nullptr && bid == 0 && tid == 0) tprev = wall_clock64();
 #pragma nounroll
   for (int k = 0; k < st.n; ++k) {
-    const unsigned sq_ = seq0 + (unsigned)k + 1u;   // sequence number of everything this step publishes
-    const int par = (int)(sq_ & 1u);
+    int oz;   // opaque zero, refreshed every step: per-lane offsets are re-derived per step instead of being hoisted out of the
+              // loop into spilled registers
+    asm volatile("s_mov_b32 %0, 0" : "=s"(oz));
+    tid = (int)threadIdx.x + oz;
+    lane = tid & 63;
+    lds = lds0 + oz;
+    const unsigned seq_par = ll.seq0 + (unsigned)k, seq_out = seq_par + 1u;
     const int mb = st.first + k;
-    const long long start = (long long)mb * batch_size;
-    const int b = (int)min((long long)batch_size, total_rows - start);
+    const int b = rows_of(mb);
     const int nblk = (b + ROWS - 1) / ROWS;
     const bool more = k + 1 < st.n;
-    const int bnext = more ? (int)min((long long)batch_size, total_rows - (start + batch_size)) : 0;
-    const float adv_mean = lds[G.ring + 0], adv_std = lds[G.ring + 1];
-    const float step_size = st.step_size[k], bc2_sqrt = st.bc2_sqrt[k];
-    if (more) load_rows(mb + 1);   // (in flight under the chain; parked behind its barrier)
-    u64* slab = slabs64 + ((long long)(par * 2 + tw) * nrb + rb) * SWW;
-    if (rb < nblk) {
-      t64_tower_minibatch<KT1>(d, G, Lc, tw, lds, 64 * rb, b, adv_mean, adv_std, normalize_adv, clip, ent_coef, vf_coef, slab,
-                               TWp, sq_, [&]() { if (more) park_rows(); });
-    } else {
+    const int bnext = more ? rows_of(mb + 1) : 0;
+    const bool have = rb < nblk, have_next = more && rb < (bnext + ROWS - 1) / ROWS;   // (block-uniform)
+    u64* slabs_s = slabs64 + (long long)(seq_out & 1u) * nrb * SW;
+    bool fail = false;
+    auto timed_out = [&](unsigned& it) {
+      __builtin_amdgcn_s_sleep(1);
+      if (++it > (1u << 22) || ((it & 255u) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+        if (lane == 0) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return true;
+      }
+      return false;
+    };
+    // ---- A: gradient of this minibatch
+    if (have_next) load_rows(mb + 1);   // (in flight under the poll and the chain; parked behind the chain's barrier)
+    if (have) {
+      const float adv_mean = lds[G.ring + 0], adv_std = lds[G.ring + 1];
+      {   // the tower's parameters as the chunk owners published them: all words requested together, the whole set again
+          // until every one carries this step's number; then straight to their places in the images
+        const u64* par = par64 + (long long)(seq_par & 1u) * o.total;
+        const u64* pa = par + t0;
+        const u64* pb = par + segB0;
+        const u64* pc = par + (d.discrete ? 0 : o.log_std + min(tid, A - 1));
+        u64 ta[NLL], tb[NB], tc;
+        unsigned it = 0;
+        for (;;) {
+#pragma unroll
+          for (int i = 0; i < NLL; ++i)
+            ta[i] = __hip_atomic_load(pa + min(tid + i * NT, tlen - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+          for (int i = 0; i < NB; ++i)
+            tb[i] = __hip_atomic_load(pb + min(tid + i * NT, nB - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          tc = __hip_atomic_load(pc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __builtin_amdgcn_sched_barrier(0);
+          bool ok = (unsigned)(tc >> 32) == seq_par;
+#pragma unroll
+          for (int i = 0; i < NLL; ++i) ok = ok && (unsigned)(ta[i] >> 32) == seq_par;
+#pragma unroll
+          for (int i = 0; i < NB; ++i) ok = ok && (unsigned)(tb[i] >> 32) == seq_par;
+          if (__all(ok)) break;
+          if (timed_out(it)) { fail = true; break; }
+        }
+#pragma unroll
+        for (int i = 0; i < NLL; ++i) {
+          const float w = __uint_as_float((unsigned)ta[i]);
+          const unsigned da = dA[i] & 0xffffu, db = dA[i] >> 16;
+          if (da != 0xffffu) lds[da] = w;
+          if (db != 0xffffu) lds[db] = w;
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+          const float w = __uint_as_float((unsigned)tb[i]);
+          const unsigned da = dB[i] & 0xffffu, db = dB[i] >> 16;
+          if (da != 0xffffu) lds[da] = w;
+          if (db != 0xffffu) lds[db] = w;
+        }
+        if (tower == 0 && !d.discrete && tid < A) {   // log_std[a] and the loss phase's constants 1 / sd^2, log sd
+          const float lsv = __uint_as_float((unsigned)tc);
+          const float sd = expf(lsv);
+          lds[G.ls + tid] = lsv;
+          lds[G.ls + 16 + tid] = 1.f / (sd * sd);
+          lds[G.ls + 32 + tid] = logf(sd);
+        }
+      }
+      if (fail) s_fail = 1;
       __syncthreads();
-      if (more) park_rows();
+      u64* slab = slabs_s + (long long)rb * SW;
+      t64_tower_minibatch<KT1>(d, G, out, tower, lds, 64 * rb, b, adv_mean, adv_std, normalize_adv, clip, ent_coef, vf_coef, slab,
+                               seq_out, [&]() { if (have_next) park_rows(); },
+                               (dbg != nullptr && bid < 2) ? dbg + 16 + 16 * bid : nullptr, oz);
+    } else if (have_next) {
+      __syncthreads();
+      park_rows();
       __syncthreads();
     }
-    T64_TS(0);
-    // ---- hop 1: slice rb of the tower's nblk slabs, summed in slab order
-    const int SL = (SWW + nrb - 1) / nrb;
-    const unsigned rcpSL = 0xffffffffu / (unsigned)SL + 1u;
-    float* red = lds + G.a1;   // scratch [nblk][SL] (the activation tiles are free until the next chain)
-    auto written = [&](int gi) { return gi < Lc.TW || (gi >= TWp && gi < SWW); };
-    bool fail = false;
-    {
-      const u64* tslabs = slabs64 + (long long)(par * 2 + tw) * nrb * SWW;
-      u64 t[NH1];
-      int off[NH1];
-      unsigned need = 0u;
+    if (s_fail) return;   // (behind a block barrier; workgroups without rows never set it)
+    EP_TS(0);
+    // ---- B1: chunk `bid` of every slab, summed in slab order; workgroup 0 also collects the loss-statistic partials
+    const int i0 = bid * chunk + oz, i1 = min(o.total, i0 + chunk);
+    float g[NPC];
+    float sqs = 0.f;
 #pragma unroll
-      for (int u = 0; u < NH1; ++u) {
-        const int f = tid + u * NT;
-        const int j = (int)__umulhi((unsigned)f, rcpSL), e = f - j * SL;
-        const int gi = rb * SL + e;
-        off[u] = min(j, nblk - 1) * SWW + min(gi, SWW - 1);
-        if (j < nblk && gi < SWW && written(gi)) need |= 1u << u;
+    for (int j = 0; j < NPC; ++j) {
+      const int i = i0 + tid + j * NT;
+      float acc = 0.f;
+      if (i0 + (tid & ~63) + j * NT < i1) {   // (wave-uniform: some lane of the wave has an element)
+        const u64* col = slabs_s + min(i, o.total - 1);
+        for (int sb = 0; sb < nblk && !fail; sb += 8) {
+          u64 t[8];
+          unsigned it = 0;
+          for (;;) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+              t[u] = __hip_atomic_load(col + (long long)min(sb + u, nblk - 1) * SW, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            bool ok = true;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) ok = ok && (unsigned)(t[u] >> 32) == seq_out;
+            if (__all(ok)) break;
+            if (timed_out(it)) { fail = true; break; }
+          }
+#pragma unroll
+          for (int u = 0; u < 8; ++u)
+            if (sb + u < nblk) acc += __uint_as_float((unsigned)t[u]);
+        }
+        if (i < i1) sqs += acc * acc;
       }
+      g[j] = acc;
+    }
+    if (bid == 0 && stats != nullptr && (tid & ~63) < nblk * 8) {   // (wave-uniform) slab q's statistics slot: word P + slot
+      const int q = min(tid >> 3, nblk - 1), slot = tid & 7;
+      const bool mine = tid < nblk * 8 && slot < 5;
+      const u64* wp = slabs_s + (long long)q * SW + o.total + (mine ? slot : 0);
+      u64 t;
       unsigned it = 0;
       for (;;) {
-#pragma unroll
-        for (int u = 0; u < NH1; ++u) t[u] = __hip_atomic_load(tslabs + off[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __builtin_amdgcn_sched_barrier(0);
-        bool ok = true;
-#pragma unroll
-        for (int u = 0; u < NH1; ++u) ok = ok && (!((need >> u) & 1u) || (unsigned)(t[u] >> 32) == sq_);
-        if (ok) break;
+        t = __hip_atomic_load(wp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (__all(!mine || (unsigned)(t >> 32) == seq_out)) break;
         if (timed_out(it)) { fail = true; break; }
       }
-#pragma unroll
-      for (int u = 0; u < NH1; ++u) {
-        const int f = tid + u * NT;
-        if (f < nblk * SL) red[f] = ((need >> u) & 1u) ? __uint_as_float((unsigned)t[u]) : 0.f;
-      }
+      if (tid < nblk * 8) s_stat[tid] = __uint_as_float((unsigned)t);
     }
-    if (fail) s_fail = 1;
-    __syncthreads();
-    if (s_fail) return;
-    T64_TS(1);
+    EP_TS(1);
     {
-      u64* tsum = sums64 + (long long)(par * 2 + tw) * SWW;
-      float sqs = 0.f;
-      for (int e = tid; e < SL; e += NT) {
-        const int gi = rb * SL + e;
-        float part = 0.f;
-        int j = 0;
-        for (; j + 8 <= nblk; j += 8) {
-          float tt[8];
-#pragma unroll
-          for (int u = 0; u < 8; ++u) tt[u] = red[(j + u) * SL + e];
-          __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-          for (int u = 0; u < 8; ++u) part += tt[u];
-        }
-        for (; j < nblk; ++j) part += red[j * SL + e];
-        if (gi < SWW && written(gi)) ll_store_agent(tsum + gi, part, sq_);
-        if (gi < Lc.TW) sqs += part * part;
-      }
-      const float tot = block_sum<NT>(sqs, lds + G.scratch);
-      if (tid == 0) ll_store_agent(sq64 + (par * 2 + tw) * 32 + rb, tot, sq_);
+      const float part = block_sum<NT>(sqs, lds + G.scratch);
+      if (tid == 0) ll_store_agent(sq64 + (seq_out & 1u) * 64 + bid, part, seq_out);
     }
-    T64_TS(2);
-    // ---- while the slice sums travel: the next minibatch's rows are normalised into the x tile
-    if (more) stage_rows(bnext);
-    // ---- hop 2: the tower's whole sum vector; the 2 nrb sums of squares; workgroup 0: both towers' loss-statistic sums
-    float g[NPT];
-    {
-      const u64* tsum = sums64 + (long long)(par * 2 + tw) * SWW;
-      u64 t[NPT], tq = 0ull, tt = 0ull;
-      const bool want_q = tid < 2 * nrb;             // lane -> (tower tid / nrb, block tid % nrb)
-      const bool want_t = bid == 0 && tid >= 64 && tid < 80 && stats != nullptr;   // second wave: tails of tower (tid - 64) >> 3
-      const u64* qp = sq64 + (par * 2 + (want_q ? tid / nrb : 0)) * 32 + (want_q ? tid % nrb : 0);
-      const u64* tp = sums64 + (long long)(par * 2 + (want_t ? (tid - 64) >> 3 : 0)) * SWW + TWp + (want_t ? (tid & 7) : 0);
-      int hoff[NPT];      // word of each slot (slots without a parameter: word 0, not waited for)
-      unsigned hneed = 0u;
-#pragma unroll
-      for (int kk = 0; kk < NPT; ++kk) {
-        int i, da, db;
-        slot_of(kk, i, da, db);
-        hoff[kk] = i < 0 ? 0 : i;
-        if (i >= 0) hneed |= 1u << kk;
-      }
+    EP_TS(2);
+    // ---- while the partial sums of squares travel: the next minibatch's rows are normalised into the x tile
+    if (have_next) stage_rows(bnext);
+    // ---- B2: the G partial sums of squares -> norm, clip coefficient; Adam on the own chunk; loss statistics
+    if (tid < 64) {
+      const u64* wp = sq64 + (seq_out & 1u) * 64 + min(tid, nwg - 1);
+      u64 t;
       unsigned it = 0;
-      for (; !fail;) {
-#pragma unroll
-        for (int kk = 0; kk < NPT; ++kk)
-          t[kk] = __hip_atomic_load(tsum + hoff[kk], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        tq = __hip_atomic_load(qp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        tt = __hip_atomic_load(tp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __builtin_amdgcn_sched_barrier(0);
-        bool ok = (!want_q || (unsigned)(tq >> 32) == sq_) && (!want_t || (unsigned)(tt >> 32) == sq_);
-#pragma unroll
-        for (int kk = 0; kk < NPT; ++kk) ok = ok && (!((hneed >> kk) & 1u) || (unsigned)(t[kk] >> 32) == sq_);
-        if (ok) break;
+      for (;;) {
+        t = __hip_atomic_load(wp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (__all((unsigned)(t >> 32) == seq_out)) break;
         if (timed_out(it)) { fail = true; break; }
       }
-#pragma unroll
-      for (int kk = 0; kk < NPT; ++kk) g[kk] = ((hneed >> kk) & 1u) ? __uint_as_float((unsigned)t[kk]) : 0.f;
-      if (tid < 64) s_part[tid] = want_q ? __uint_as_float((unsigned)tq) : 0.f;
-      if (want_t) s_tail[tid - 64] = __uint_as_float((unsigned)tt);
+      s_part[tid] = tid < nwg ? __uint_as_float((unsigned)t) : 0.f;
     }
-    if (fail) s_fail = 1;
+    if (__any(fail) && lane == 0) s_fail = 1;
     __syncthreads();
     if (s_fail) return;
-    T64_TS(3);
+    EP_TS(3);
     float total_sq = 0.f;
-    for (int qq = 0; qq < 2 * nrb; ++qq) total_sq += s_part[qq];   // (policy tower's blocks, then the value tower's)
+    for (int q = 0; q < nwg; ++q) total_sq += s_part[q];
     const float total_norm = sqrtf(total_sq);
     const float coef = fminf(max_norm / (total_norm + 1e-6f), 1.0f);   // torch.nn.utils.clip_grad_norm_
     {
-      // torch.optim.Adam's step on the thread's parameters of the tower (the arithmetic of the 32-wide kernel: hardware
-      // square root and reciprocal + one Newton step); all LDS reads first, then the arithmetic, then the writes
-      float pv[NPT];
+      const float step_size = st.step_size[k], bc2_sqrt = st.bc2_sqrt[k];
+      u64* dst = par64 + (long long)(seq_out & 1u) * o.total;
 #pragma unroll
-      for (int kk = 0; kk < NPT; ++kk) {
-        int i, da, db;
-        slot_of(kk, i, da, db);
-        pv[kk] = lds[da < 0 ? 0 : da];
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      const float inv_bc2 = 1.f / bc2_sqrt;
-#pragma unroll
-      for (int kk = 0; kk < NPT; ++kk) {
-        const float gi = g[kk] * coef;
-        float mi = rm[kk];
-        mi = mi + (gi - mi) * (1.f - beta1);
-        const float vi = rv[kk] * beta2 + (1.f - beta2) * gi * gi;
-        const float denom = __builtin_amdgcn_sqrtf(vi) * inv_bc2 + eps;
-        float rd = __builtin_amdgcn_rcpf(denom);
-        rd = __builtin_fmaf(rd, __builtin_fmaf(-denom, rd, 1.f), rd);
-        pv[kk] = pv[kk] - step_size * (mi * rd);
-        rm[kk] = mi;
-        rv[kk] = vi;
-      }
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int kk = 0; kk < NPT; ++kk) {
-        int i, da, db;
-        slot_of(kk, i, da, db);
-        if (da >= 0) lds[da] = pv[kk];
-        if (db >= 0) lds[db] = pv[kk];
+      for (int j = 0; j < NPC; ++j) {
+        const int i = i0 + tid + j * NT;
+        if (i < i1) {
+          const float gi = g[j] * coef;
+          const float mi = m_[j] + (gi - m_[j]) * (1.f - beta1);
+          const float vi = v_[j] * beta2 + (1.f - beta2) * gi * gi;
+          const float denom = sqrtf(vi) / bc2_sqrt + eps;
+          const float pn = p_[j] - step_size * (mi / denom);
+          ll_store_agent(dst + i, pn, seq_out);
+          p_[j] = pn;
+          m_[j] = mi;
+          v_[j] = vi;
+        }
       }
     }
-    if (bid == 0 && stats != nullptr && tid == 0) {   // tails: tower 0 slots {0 pg, 2 ent, 3 kl, 4 clip}, tower 1 slot 1 (value)
-      const float inv = 1.f / (float)b;
-      const float pg = s_tail[0] * inv, vl = s_tail[8 + 1] * inv, en = s_tail[2] * inv;
-      float* so = stats + (long long)mb * 8;
-      so[0] = pg;
-      so[1] = vl;
-      so[2] = en;
-      so[3] = s_tail[3] * inv;
-      so[4] = s_tail[4] * inv;
-      so[5] = pg + ent_coef * en + vf_coef * vl;
-      so[6] = total_norm;
-      so[7] = coef;
+    if (bid == 0 && stats != nullptr) {
+      __shared__ float s_st[5];
+      if (tid >= 64 && tid < 69) {   // one lane of the second wave per statistic, partials in row-block order
+        const int kk = tid - 64;
+        float sv = 0.f;
+        for (int q = 0; q < nblk; ++q) sv += s_stat[q * 8 + kk];
+        sv *= 1.f / (float)b;
+        stats[(long long)mb * 8 + kk] = sv;
+        s_st[kk] = sv;
+      }
+      __syncthreads();
+      if (tid == 0) {
+        stats[(long long)mb * 8 + 5] = s_st[0] + ent_coef * s_st[2] + vf_coef * s_st[1];  // loss
+        stats[(long long)mb * 8 + 6] = total_norm;
+        stats[(long long)mb * 8 + 7] = coef;
+      }
     }
-    __syncthreads();   // the images hold the new parameters; x tile and staging area belong to the next step
-    T64_TS(4);
+    EP_TS(4);
   }
-  // ---- the launch's last parameters and moments back to memory (torch layout + the transposed shadow copy): row block 0
-  if (rb == 0) {
+  // the launch's last parameters and moments back to memory (torch layout + the transposed shadow copy)
+  tid = threadIdx.x;
 #pragma unroll
-    for (int k = 0; k < NPT; ++k) {
-      int i, da, db;
-      slot_of(k, i, da, db);
-      if (i >= 0) {
-        const int f = t64_flat(Lc, i);
-        const float p = lds[da];
-        m[f] = rm[k];
-        v[f] = rv[k];
-        P[f] = p;
-        int dt_ = f;
-        auto tr = [&](int b0, int rows_, int cols) {
-          if (f >= b0 && f < b0 + rows_ * cols) {
-            const int r = (f - b0) / cols, cc = (f - b0) % cols;
-            dt_ = b0 + cc * rows_ + r;
-          }
-        };
-        tr(o.pW1, 64, D); tr(o.pW2, 64, 64); tr(o.vW1, 64, D); tr(o.vW2, 64, 64);
-        Pt[dt_] = p;
-      }
+  for (int j = 0; j < NPC; ++j) {
+    const int i = bid * chunk + tid + j * NT;
+    if (i < min(o.total, (bid + 1) * chunk)) {
+      m[i] = m_[j];
+      v[i] = v_[j];
+      P[i] = p_[j];
+      int dst = i;
+      auto tr = [&](int b0, int rows_, int cols) {
+        if (i >= b0 && i < b0 + rows_ * cols) {
+          const int r = (i - b0) / cols, cc = (i - b0) % cols;
+          dst = b0 + cc * rows_ + r;
+        }
+      };
+      tr(o.pW1, H, D); tr(o.pW2, H, H); tr(o.vW1, H, D); tr(o.vW2, H, H);
+      Pt[dst] = p_[j];
     }
   }
-#undef T64_TS
+#undef EP_TS
 }
 
 // TIMING = false (production): the phase-clock accumulators (24 VGPRs of `tacc` alone) and every stamp are
@@ -5674,7 +5641,8 @@ bool g_ppo_valu = false;  // tuning/debug: force the VALU kernels for H = 32 as 
 bool g_epoch_split = false;  // tuning/debug: two launches per minibatch for 64-wide towers too
 bool g_epoch_whole = false;  // tuning/debug: the one-launch epoch with whole row-block workgroups (8 waves, both towers)
 bool g_epoch_barriers = false;   // tuning/debug: the one-tower epoch kernel with grid barriers instead of the word exchange
-bool g_epoch_t64 = true;         // the tower-resident epoch kernel (round 5) where it applies; false: round 4's word-exchange kernel
+bool g_epoch_chain2 = true;      // the word-exchange epoch kernel with round 5's transposed register-resident chain (observation
+                                 // widths <= 32); false: round 4's gradient body everywhere
 long long* g_epoch_dbg = nullptr;  // measurement: phase ticks of workgroup 0 of ppo_epoch_persistent_kernel
 }  // namespace
 
@@ -5914,12 +5882,7 @@ static int64_t ppo_ws_plain_floats(const ia_policy_desc* d, int batch, int64_t g
 int64_t ia_ppo_ws_floats(const ia_policy_desc* d, int batch, int64_t gather_rows) {
   if (!pol_ok(d) || batch <= 0 || gather_rows < batch) return IA_ERR_ARG;
   const int P = pol_offsets(d->obs_dim, d->act_dim, d->hidden, d->discrete).total;
-  int64_t ll = d->hidden == 64 ? 2 * epoch_ll_words(epoch_ll_row_blocks(cdiv(batch, ROWS), P), P) : 0;   // (64-wide towers: the word exchange)
-  if (d->hidden == 64) {   // ... or the tower-resident kernel's areas
-    const PolOff po = pol_offsets(d->obs_dim, d->act_dim, d->hidden, d->discrete);
-    const int64_t t64 = 2 * t64_words(cdiv(batch, ROWS), t64_twp(po, d->obs_dim, d->act_dim, d->discrete));
-    ll = t64 > ll ? t64 : ll;
-  }
+  const int64_t ll = d->hidden == 64 ? 2 * epoch_ll_words(epoch_ll_row_blocks(cdiv(batch, ROWS), P), P) : 0;   // (64-wide towers: the word exchange)
   return ppo_ws_plain_floats(d, batch, gather_rows) + ll;
 }
 
@@ -6135,7 +6098,7 @@ int ia_ppo_epoch_split(int on) {
   g_epoch_split = on == 1;
   g_epoch_whole = on == 2;
   g_epoch_barriers = on == 3;
-  g_epoch_t64 = on != 4;   // 4: the word-exchange kernel with chunk owners (round 4) where the tower-resident one applies
+  g_epoch_chain2 = on != 4;   // 4: round 4's gradient body in the word-exchange kernel also where round 5's chain applies
   return IA_OK;
 }
 
@@ -6212,17 +6175,9 @@ static int ppo_epochs_impl(const ia_policy_desc* d, float* params, float* params
   const int nrb_l = epoch_ll_row_blocks(nrb, P);
   const bool llx = towers_fit && !g_epoch_barriers && sbytes + 16 <= EPOCH_LL_LDS && nrb_l <= 32 && 2 * nrb_l <= dev_cus;
   const bool split = towers_fit && sbytes <= EPOCH_SPLIT_LDS && (llx || cdiv(P, 2 * nrb) <= 4 * 256);
-  // the tower-resident kernel (round 5): observation widths up to 32 (both layouts of W2, W1 and the tiles beside the staging
-  // area in 160 KB), <= 32 row blocks; every tower workgroup steps its whole tower
-  const T64Geo tgeo = t64_geo(d->obs_dim, d->discrete ? 1 : d->act_dim, d->obs_dim <= 16 ? 1 : 2);
-  const int t64_TWp = t64_twp(po, d->obs_dim, d->act_dim, d->discrete);
-  constexpr size_t T64_LDS = 160 * 1024 - 1024;
-  const bool t64 = one_launch && g_epoch_t64 && !g_epoch_whole && !g_epoch_barriers && d->obs_dim <= 32 && nrb <= 32 &&
-                   2 * nrb <= dev_cus && (size_t)tgeo.total * sizeof(float) + 16 <= T64_LDS &&
-                   g_epoch_dbg == nullptr;
-  unsigned long long* ll_base = (llx || t64) ? reinterpret_cast<unsigned long long*>(ws + ppo_ws_plain_floats(d, size_at(0), total)) : nullptr;
-  int rc = launch_gather(a, perm, total, g, ll_base, t64 ? t64_words(nrb, t64_TWp) : (llx ? epoch_ll_words(nrb_l, P) : 0),
-                         (llx || t64) ? reinterpret_cast<unsigned*>(ws) + 4 : nullptr);   // (words 4, 5, 6: counter, error word, ticket)
+  unsigned long long* ll_base = llx ? reinterpret_cast<unsigned long long*>(ws + ppo_ws_plain_floats(d, size_at(0), total)) : nullptr;
+  int rc = launch_gather(a, perm, total, g, ll_base, llx ? epoch_ll_words(nrb_l, P) : 0,
+                         llx ? reinterpret_cast<unsigned*>(ws) + 4 : nullptr);   // (words 4, 5, 6: counter, error word, ticket)
   if (rc) return rc;
   // statistics of every minibatch of the epoch, one launch ahead of the chain (ppo_epoch_stats_kernel)
   const int aw = d->discrete ? 1 : d->act_dim;
@@ -6234,45 +6189,50 @@ static int ppo_epochs_impl(const ia_policy_desc* d, float* params, float* params
     static bool attr = false;
     const size_t bytes = PREP_LDS_FLOATS * sizeof(float);
     if (!attr) { rc = set_lds(ppo_epoch_stats_kernel, bytes); if (rc) return rc; attr = true; }
-    if (!llx && !t64 && hipMemsetAsync(ws + 6, 0, sizeof(unsigned), a.st) != hipSuccess) return IA_ERR_ARG;   // its ticket (ws is not pre-zeroed)
+    if (!llx && hipMemsetAsync(ws + 6, 0, sizeof(unsigned), a.st) != hipSuccess) return IA_ERR_ARG;   // its ticket (ws is not pre-zeroed)
     hipLaunchKernelGGL(ppo_epoch_stats_kernel, dim3(n_mb), dim3(PREP_THREADS), bytes, a.st, *d, g.obs, g.adv, total,
                        batch_size, update_norm, norm_mean, norm_var, norm_count, seq, part,
                        reinterpret_cast<unsigned*>(ws) + 6);
     IA_CHECK_LAUNCH();
   }
   const bool snap = d->has_norm && update_norm;
-  if (t64) {
-    const int kt1 = d->obs_dim <= 16 ? 1 : 2;
-    auto k1 = ppo_epoch_t64_kernel<1>;
-    auto k2 = ppo_epoch_t64_kernel<2>;
-    auto kern = kt1 == 1 ? k1 : k2;
-    static bool attr_t[2] = {false, false};
-    if (!attr_t[kt1 - 1]) { rc = set_lds(kern, T64_LDS); if (rc) return rc; attr_t[kt1 - 1] = true; }
-    const size_t tbytes = (size_t)tgeo.total * sizeof(float) + 16;
-    for (int first = 0; first < n_mb; first += EpochSteps::MAX) {
-      EpochSteps es{};
-      es.first = first;
-      es.n = std::min(EpochSteps::MAX, n_mb - first);
-      const unsigned seq0 = (unsigned)(adam_steps_done + first);
-      for (int k = 0; k < es.n; ++k) {
-        ++step;
-        es.step_size[k] = (float)(lr / (1.0 - pow(beta1, (double)step)));
-        es.bc2_sqrt[k] = (float)sqrt(1.0 - pow(beta2, (double)step));
-      }
-      hipLaunchKernelGGL(kern, dim3(2 * nrb), dim3(256), tbytes, a.st, *d, params, params_t, exp_avg, exp_avg_sq, norm_mean,
-                         norm_var, g.obs, g.act, g.logp, g.adv, g.ret, total, batch_size, normalize_adv, clip_range, ent_coef,
-                         vf_coef, max_grad_norm, (float)beta1, (float)beta2, adam_eps, ws, ll_base, seq0, seq, snap ? 1 : 0, stats,
-                         es, (long long*)nullptr);
-      IA_CHECK_LAUNCH();
-    }
-    return IA_OK;
-  }
   if (one_launch) {
     // one launch per (<= 64 minibatches of the) epoch when every gradient workgroup can be resident at once
     const int nwg = split ? 2 * nrb : nrb;
     if (llx || (nwg <= dev_cus && nwg <= 64 && cdiv(P, nwg) <= 4 * (split ? 256 : 512))) {
       static bool attr = false, attr_s = false;
       const size_t mbytes = split ? sbytes : GLds<64>::total * sizeof(float);
+      const int aw_ = d->discrete ? 1 : d->act_dim;
+      const size_t l2bytes = (size_t)(d->obs_dim <= 16 ? T64Geo<1>(d->obs_dim, aw_).total : T64Geo<2>(d->obs_dim, aw_).total) *
+                                 sizeof(float) + 16;
+      if (llx && g_epoch_chain2 && d->obs_dim <= 32 && l2bytes <= EPOCH_LL_LDS) {
+        // round 5's gradient phase (transposed register-resident chain, images with ds_read_b128 fragments)
+        auto k1 = ppo_epoch_ll2_kernel<1>;
+        auto k2 = ppo_epoch_ll2_kernel<2>;
+        const int ki = d->obs_dim <= 16 ? 0 : 1;
+        auto kern = ki == 0 ? k1 : k2;
+        static bool attr_2[2] = {false, false};
+        if (!attr_2[ki]) { rc = set_lds(kern, EPOCH_LL_LDS); if (rc) return rc; attr_2[ki] = true; }
+        EpochLl el{};
+        el.base = ll_base;   // (cleared, like the error word, by the gather launch above)
+        for (int first = 0; first < n_mb; first += EpochSteps::MAX) {
+          EpochSteps es{};
+          es.first = first;
+          es.n = std::min(EpochSteps::MAX, n_mb - first);
+          el.seq0 = (unsigned)(adam_steps_done + first + 1);
+          for (int k = 0; k < es.n; ++k) {
+            ++step;
+            es.step_size[k] = (float)(lr / (1.0 - pow(beta1, (double)step)));
+            es.bc2_sqrt[k] = (float)sqrt(1.0 - pow(beta2, (double)step));
+          }
+          hipLaunchKernelGGL(kern, dim3(2 * nrb_l), dim3(256), l2bytes, a.st, *d, params, params_t, exp_avg, exp_avg_sq, norm_mean,
+                             norm_var, g.obs, g.act, g.logp, g.adv, g.ret, total, batch_size, T, n_envs, normalize_adv,
+                             clip_range, ent_coef, vf_coef, max_grad_norm, (float)beta1, (float)beta2, adam_eps, ws, el, seq,
+                             snap ? 1 : 0, stats, es, g_epoch_dbg);
+          IA_CHECK_LAUNCH();
+        }
+        return IA_OK;
+      }
       if (llx) {
         const int nll = tlen <= 20 * 256 ? 20 : (tlen <= 24 * 256 ? 24 : 33);
         static bool attr_l[3] = {false, false, false};

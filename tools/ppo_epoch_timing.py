@@ -27,6 +27,7 @@ L.load().ia_ppo_epoch_debug_timing(None)
 algo = tr.gen_algo
 steps = rounds * algo.n_epochs * algo._n_mb
 t = buf.cpu().numpy()[:6] / 100.0 / steps
+chain2 = mode == 0 and tr.gen_algo.policy.obs_dim <= 32   # round 5's gradient phase (ppo_epoch_ll2_kernel)
 names = (("gradient", "barrier", "slab sum + partial norm", "barrier", "norm + Adam + statistics", "barrier") if mode == 3 else
          ("gradient (incl. parameter poll)", "slab poll + sum", "partial norm published", "poll of the partial norms",
           "norm + Adam + publish + statistics", "-"))
@@ -35,6 +36,15 @@ print(f"{name}: per optimiser step (workgroup 0): " + ", ".join(f"{n} {v:.2f} us
 
 # shader-clock stamps of the LAST step's gradient phase (row block 0; [16..] policy-tower workgroup, [32..] value-tower
 # workgroup of the one-tower form; the whole-block form writes [16..] only)
+if chain2:
+    full = buf.cpu().numpy()
+    lab = ("layer 1", "layer 2", "head", "loss", "dz2 / dz1", "barrier + park", "dW2 + db2", "dW1 + db1", "head gradient + sums",
+           "closing barrier")
+    for base, who in ((16, "policy tower"), (32, "value tower")):
+        st = [int(full[base + i]) for i in range(11)]
+        print(f"  {who} (row block 0, last step): " + ", ".join(f"{n} {st[i + 1] - st[i]}" for i, n in enumerate(lab)) +
+              f"; total {st[-1] - st[0]} cycles")
+    sys.exit(0)
 order = (0, 9, 10, 11, 1, 2, 3, 4, 5, 6, 7, 8)
 labels = (("row loads issued", "parameter copy issued", "rows staged (+ barrier)") if mode == 3 else
           ("row loads issued", "rows normalised + parameter poll + images", "block barrier")) + ("fragments", "layer 1", "layer 2", "heads",
