@@ -3871,21 +3871,31 @@ __device__ __forceinline__ void t64_tower_minibatch(
       acc[t][0] = b1c[t];
       acc[t][1] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
+    // tile by tile (two accumulator chains each): the tanh of tile t issues between the MFMAs of tile t + 1
+    auto l1_tile = [&](const int t) {
 #pragma unroll
-    for (int kt = 0; kt < KT1; ++kt)
+      for (int kt = 0; kt < KT1; ++kt)
 #pragma unroll
-      for (int r = 0; r < 4; ++r)
-        if (16 * kt + r < D) {   // (wave-uniform: k-step (kt, r) carries columns 16 kt + r + {0, 4, 8, 12})
-#pragma unroll
-          for (int t = 0; t < 4; ++t) acc[t][(kt * 4 + r) & 1] = mfma16(fW1[kt][t][r], xb[kt][r], acc[t][(kt * 4 + r) & 1]);
-        }
-#pragma unroll
-    for (int t = 0; t < 4; ++t)
+        for (int r = 0; r < 4; ++r)   // (all k-steps, no branch around the ones past the observation width: the image's columns
+                                      //  >= D are zero, and a branch here keeps the tanh of the tile before from issuing
+                                      //  between these MFMAs)
+          acc[t][(kt * 4 + r) & 1] = mfma16(fW1[kt][t][r], xb[kt][r], acc[t][(kt * 4 + r) & 1]);
+    };
+    auto l1_tanh = [&](const int t) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         a1[t][r] = fast_tanh(acc[t][0][r] + acc[t][1][r]);
         lds[G.a1 + (16 * t + 4 * lk + r) * RS + q * 16 + li] = a1[t][r];
       }
+    };
+    l1_tile(0);
+    l1_tile(1);
+    l1_tanh(0);
+    l1_tile(2);
+    l1_tanh(1);
+    l1_tile(3);
+    l1_tanh(2);
+    l1_tanh(3);
   }
   T64C_TS(1);
   // ---- layer 2: a2^T = tanh(W2 a1^T + b2): the accumulators of layer 1 are the B operands
@@ -3904,19 +3914,27 @@ __device__ __forceinline__ void t64_tower_minibatch(
       acc[t][0] = b2c[t];
       acc[t][1] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
+    auto l2_tile = [&](const int t) {
 #pragma unroll
-    for (int kt = 0; kt < 4; ++kt)
+      for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
-      for (int r = 0; r < 4; ++r)
-#pragma unroll
-        for (int t = 0; t < 4; ++t) acc[t][r & 1] = mfma16(fW2[kt][t][r], a1[kt][r], acc[t][r & 1]);
-#pragma unroll
-    for (int t = 0; t < 4; ++t)
+        for (int r = 0; r < 4; ++r) acc[t][r & 1] = mfma16(fW2[kt][t][r], a1[kt][r], acc[t][r & 1]);
+    };
+    auto l2_tanh = [&](const int t) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         a2[t][r] = fast_tanh(acc[t][0][r] + acc[t][1][r]);
         lds[G.a2 + (16 * t + 4 * lk + r) * RS + q * 16 + li] = a2[t][r];
       }
+    };
+    l2_tile(0);
+    l2_tile(1);
+    l2_tanh(0);
+    l2_tile(2);
+    l2_tanh(1);
+    l2_tile(3);
+    l2_tanh(2);
+    l2_tanh(3);
   }
   T64C_TS(2);
   // ---- head. The head image holds action_net's rows (rows >= A zero) resp. value_net's row in row 0 (rows 1.. zero): the M
@@ -4094,17 +4112,25 @@ __device__ __forceinline__ void t64_tower_minibatch(
     f32x4 acc[4][2];
 #pragma unroll
     for (int t = 0; t < 4; ++t) acc[t][0] = acc[t][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    auto d1_tile = [&](const int t) {
 #pragma unroll
-    for (int kt = 0; kt < 4; ++kt)
+      for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
-      for (int r = 0; r < 4; ++r)
-#pragma unroll
-        for (int t = 0; t < 4; ++t) acc[t][r & 1] = mfma16(fW2T[kt][t][r], dz2[kt][r], acc[t][r & 1]);
-#pragma unroll
-    for (int t = 0; t < 4; ++t)
+        for (int r = 0; r < 4; ++r) acc[t][r & 1] = mfma16(fW2T[kt][t][r], dz2[kt][r], acc[t][r & 1]);
+    };
+    auto d1_out = [&](const int t) {
 #pragma unroll
       for (int r = 0; r < 4; ++r)
         lds[G.dz1 + (16 * t + 4 * lk + r) * RS + q * 16 + li] = (acc[t][0][r] + acc[t][1][r]) * (1.f - a1[t][r] * a1[t][r]);
+    };
+    d1_tile(0);
+    d1_tile(1);
+    d1_out(0);
+    d1_tile(2);
+    d1_out(1);
+    d1_tile(3);
+    d1_out(2);
+    d1_out(3);
   }
   T64C_TS(5);
   __syncthreads();   // every row's activations and activation gradients are in LDS
@@ -4534,32 +4560,59 @@ __global__ __launch_bounds__(256) void ppo_epoch_ll2_kernel(
     const int i0 = bid * chunk + oz, i1 = min(o.total, i0 + chunk);
     float g[NPC];
     float sqs = 0.f;
+    // (the slabs' words of an element are requested TOGETHER, two elements at a time: up to 32 loads in flight and one trip
+    //  through the fabric where eight-slab batches per element took four -- 3.6 of the step's 21 us; same sums, same order)
 #pragma unroll
-    for (int j = 0; j < NPC; ++j) {
-      const int i = i0 + tid + j * NT;
-      float acc = 0.f;
-      if (i0 + (tid & ~63) + j * NT < i1) {   // (wave-uniform: some lane of the wave has an element)
-        const u64* col = slabs_s + min(i, o.total - 1);
-        for (int sb = 0; sb < nblk && !fail; sb += 8) {
-          u64 t[8];
+    for (int j0 = 0; j0 < NPC; j0 += 2) {
+      float acc[2] = {0.f, 0.f};
+      if (i0 + (tid & ~63) + j0 * NT < i1) {   // (wave-uniform: some lane of the wave has an element of this pair)
+        const bool two = i0 + (tid & ~63) + (j0 + 1) * NT < i1;   // (wave-uniform)
+        const u64* col0 = slabs_s + min(i0 + tid + j0 * NT, o.total - 1);
+        const u64* col1 = slabs_s + min(i0 + tid + (j0 + 1) * NT, o.total - 1);
+        for (int sb = 0; sb < nblk && !fail; sb += 16) {
+          u64 t0[16], t1[16];
           unsigned it = 0;
+          const bool full = nblk - sb >= 16;   // (block-uniform: sixteen real slabs -- no clamps, no conditional sums)
+          const unsigned sw = (unsigned)SW;
+          const u64* c0 = col0 + (long long)sb * SW;
+          const u64* c1 = col1 + (long long)sb * SW;
           for (;;) {
 #pragma unroll
-            for (int u = 0; u < 8; ++u)
-              t[u] = __hip_atomic_load(col + (long long)min(sb + u, nblk - 1) * SW, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int u = 0; u < 16; ++u)
+              t0[u] = __hip_atomic_load(c0 + (full ? (unsigned)u : (unsigned)min(u, nblk - 1 - sb)) * sw, __ATOMIC_RELAXED,
+                                        __HIP_MEMORY_SCOPE_AGENT);
+            if (two) {
+#pragma unroll
+              for (int u = 0; u < 16; ++u)
+                t1[u] = __hip_atomic_load(c1 + (full ? (unsigned)u : (unsigned)min(u, nblk - 1 - sb)) * sw, __ATOMIC_RELAXED,
+                                          __HIP_MEMORY_SCOPE_AGENT);
+            }
             bool ok = true;
 #pragma unroll
-            for (int u = 0; u < 8; ++u) ok = ok && (unsigned)(t[u] >> 32) == seq_out;
+            for (int u = 0; u < 16; ++u) ok = ok && (unsigned)(t0[u] >> 32) == seq_out && (!two || (unsigned)(t1[u] >> 32) == seq_out);
             if (__all(ok)) break;
             if (timed_out(it)) { fail = true; break; }
           }
+          if (full) {
 #pragma unroll
-          for (int u = 0; u < 8; ++u)
-            if (sb + u < nblk) acc += __uint_as_float((unsigned)t[u]);
+            for (int u = 0; u < 16; ++u) {
+              acc[0] += __uint_as_float((unsigned)t0[u]);
+              acc[1] += two ? __uint_as_float((unsigned)t1[u]) : 0.f;
+            }
+          } else {
+#pragma unroll
+            for (int u = 0; u < 16; ++u)
+              if (sb + u < nblk) {
+                acc[0] += __uint_as_float((unsigned)t0[u]);
+                if (two) acc[1] += __uint_as_float((unsigned)t1[u]);
+              }
+          }
         }
-        if (i < i1) sqs += acc * acc;
+        if (i0 + tid + j0 * NT < i1) sqs += acc[0] * acc[0];
+        if (two && i0 + tid + (j0 + 1) * NT < i1) sqs += acc[1] * acc[1];
       }
-      g[j] = acc;
+      g[j0] = acc[0];
+      g[j0 + 1] = acc[1];
     }
     if (bid == 0 && stats != nullptr && (tid & ~63) < nblk * 8) {   // (wave-uniform) slab q's statistics slot: word P + slot
       const int q = min(tid >> 3, nblk - 1), slot = tid & 7;
