@@ -529,6 +529,22 @@ def run_variant(name, rounds=None, warm=None):
             "env_steps_per_round": per, "ppo_optimizer_steps_per_round": steps, "finite": finite, "config": cfg}
 
 
+def _dp_form_text(algo):
+    """Which data-parallel form of the persistent PPO update the run used, and on what grounds (`PPO.dp_update_form`)."""
+    names = {"sharded": "row-sharded, in-kernel exchange", "replicated": "replicated on the gathered tile"}
+    ch = getattr(algo, "dp_choice", None)
+    if ch is not None:
+        return (f"{names[ch['chosen']]} -- measured on this node during the warm-up rounds: row-sharded "
+                f"{ch['sharded_ms']:.3f} ms, replicated {ch['replicated_ms']:.3f} ms per update (slowest rank)")
+    g = algo._dpg if isinstance(getattr(algo, "_dpg", None), dict) else None
+    if g is None:
+        return "per-minibatch gradient all-reduce"
+    if algo.dp_update_form in g["forms"] or len(g["forms"]) == 1:
+        form = algo.dp_update_form if algo.dp_update_form in g["forms"] else g["forms"][0]
+        return f"{names[form]} ({'asked for' if algo.dp_update_form == form else 'the only form available'})"
+    return "row-sharded / replicated alternating (the timed trials were not over)"
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -660,8 +676,8 @@ def main():
                                    "256x256+RunningNorm, demo_batch 8192, 16 disc updates/round, PPO 32x32 "
                                    "minibatch 1024 x 10 epochs", "env_steps_per_round_per_gpu": per_round,
                        "parallelism": f"dp{world}" if world > 1 else "single",
-                       "ppo_update": (("row-sharded, in-kernel exchange" if getattr(trainer.gen_algo, "dp_sharded_updates", 0)
-                                       else "replicated on the gathered tile") if world > 1 else "single GPU")},
+                       "ppo_update": _dp_form_text(trainer.gen_algo) if world > 1 else "single GPU",
+                       "ppo_update_choice": getattr(trainer.gen_algo, "dp_choice", None) if world > 1 else None},
             "roofline": flat, "cpu_baseline": base,
             "speedup_vs_cpu_baseline": (value / base["value"]) if base else None,
             "details": {"roofline_disc_update": disc or None, "roofline_gemm": gemm, "roofline_ppo_update": ppo or None},

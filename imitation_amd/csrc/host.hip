@@ -180,9 +180,11 @@ extern "C" int ia_peer_alloc(size_t bytes, void** out, int* fine_grained) {
     if (e != hipSuccess) return (int)e;
   }
   e = hipMemset(p, 0, bytes);
-  if (e != hipSuccess) return (int)e;
-  e = hipDeviceSynchronize();
-  if (e != hipSuccess) return (int)e;
+  if (e == hipSuccess) e = hipDeviceSynchronize();
+  if (e != hipSuccess) {
+    (void)hipFree(p);
+    return (int)e;
+  }
   *out = p;
   if (fine_grained) *fine_grained = fine;
   return IA_OK;

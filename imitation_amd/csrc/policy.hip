@@ -5210,6 +5210,11 @@ __global__ __launch_bounds__(512) void ppo_update_persistent_kernel(
     if (s + 1 < n_steps) prefetch_resolve(rows_at(nxt_e, nxt_mb));  // published by the block barriers inside the minibatch
     const int P8 = w.P4 + 8;
     const unsigned lseq = lseq_base + (unsigned)s + 1u;
+    // row-sharded exchange: the receive areas are double-buffered by the parity of the GLOBAL sequence number (the exchange
+    // context's counter, which only grows), not of this launch's step index: a launch with an odd number of steps would
+    // otherwise end and the next one begin on the same buffer, and a fast rank could overwrite a record a slow peer has not
+    // read yet (the ranks are only ordered by the words themselves)
+    const int xpar = SHARD ? (int)((sh.seq_base + (unsigned)s) & 1u) : 0;
     unsigned long long* slabs_s = w.slabs64 + (long long)(s & 1) * nblk * P8;
     float* stat_base = w.statpart + (s % UPD_SD) * nblk * 8;
     int oz;
@@ -5288,7 +5293,7 @@ __global__ __launch_bounds__(512) void ppo_update_persistent_kernel(
         if constexpr (SHARD) {
           const unsigned xseq = sh.seq_base + (unsigned)s + 1u;
           for (int rr = 0; rr < sh.world; ++rr)
-            ll_store_system(sh.peer_recv[rr] + (long long)((s & 1) * sh.world + (sh.loopback ? rr : sh.rank)) * P8 + gi, part, xseq);
+            ll_store_system(sh.peer_recv[rr] + (long long)(xpar * sh.world + (sh.loopback ? rr : sh.rank)) * P8 + gi, part, xseq);
         } else if (ll_xcd) {
           ll_store_xcd(sums_s + gi, part, lseq);
         } else {
@@ -5363,7 +5368,7 @@ __global__ __launch_bounds__(512) void ppo_update_persistent_kernel(
       }
       if constexpr (SHARD) {   // the ranks' words of this slice, summed in rank order; the global slice published locally
         const unsigned xseq = sh.seq_base + (unsigned)s + 1u;
-        const u64* rbase = sh.recv + (long long)((s & 1) * sh.world) * P8;
+        const u64* rbase = sh.recv + (long long)(xpar * sh.world) * P8;
         for (int e = tid; e < SL; e += 512) {
           const int gi = vb * SL + e;
           if (!valid_el(gi)) continue;
@@ -5384,6 +5389,11 @@ __global__ __launch_bounds__(512) void ppo_update_persistent_kernel(
               fail = true;
               break;
             }
+          }
+          if (fail) {   // a peer's record never came: NO word leaves under this step's number (a sibling workgroup would take it
+                        // for the global slice and step its parameters before the error word is seen)
+            __hip_atomic_store(err, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            break;
           }
           float part = 0.f;
 #pragma unroll
@@ -5470,7 +5480,7 @@ __global__ __launch_bounds__(512) void ppo_update_persistent_kernel(
       for (int qi = vb; qi < W * J; qi += nblk) {    // (workgroup-uniform)
         const int p = qi / J, j = qi - p * J;
         const int src = sh.loopback ? p : sh.rank;
-        unsigned long long* dst = sh.peer_recv[p] + (long long)((s & 1) * W + src) * REC;
+        unsigned long long* dst = sh.peer_recv[p] + (long long)(xpar * W + src) * REC;
 #pragma unroll
         for (int k = 0; k < NPT; ++k) {
           const int i = tid + k * 512;
@@ -5497,7 +5507,7 @@ __global__ __launch_bounds__(512) void ppo_update_persistent_kernel(
       // past the caches); a thread spins on its own elements until every one carries this step's sequence number. A peer can
       // be one step ahead -- it then writes the OTHER parity's records -- never two (it needs this rank's record of the
       // step between).
-      const unsigned long long* rbase = sh.recv + (long long)((s & 1) * W) * REC;
+      const unsigned long long* rbase = sh.recv + (long long)(xpar * W) * REC;
 #pragma unroll
       for (int k = 0; k < NPT; ++k) g[k] = 0.f;
       bool fail = false;
@@ -5573,16 +5583,20 @@ __global__ __launch_bounds__(512) void ppo_update_persistent_kernel(
       }
     } else if constexpr (SHARD) {
       if (vb == 0 && tid < 64 && stats) {   // every rank's sums are in the step's records: same rows as write_loss_stats
-        const unsigned long long* rbase = sh.recv + (long long)((s & 1) * sh.world) * (w.P4 + 8) + w.P4;
+        const unsigned long long* rbase = sh.recv + (long long)(xpar * sh.world) * (w.P4 + 8) + w.P4;
         const unsigned seq = sh.seq_base + (unsigned)s + 1u;
         // lane (rank, k) = (lane >> 3, lane & 7) takes that rank's sum k: ONE round trip for all ranks (the tails travel
         // with piece 0 of each record; the wait is bounded like every other), then the ranks fold in rank order
         const int rk = min(lane >> 3, sh.world - 1);
         unsigned long long tv;
         const long long t0 = wall_clock64();
+        bool late = false;
         do {
           tv = __hip_atomic_load(rbase + rk * (w.P4 + 8) + (lane & 7), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        } while (!__all((unsigned)(tv >> 32) == seq) && wall_clock64() - t0 < sh.timeout_ticks);
+          late = !__all((unsigned)(tv >> 32) == seq);
+        } while (late && wall_clock64() - t0 < sh.timeout_ticks);
+        if (late && lane == 0)   // (stale tail words would be logged as this step's statistics: the host raises instead)
+          __hip_atomic_store(err, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         float st = (lane >> 3) < sh.world ? __uint_as_float((unsigned)tv) : 0.f;
         {
           float acc = __shfl(st, lane & 7, 64);

@@ -4,12 +4,16 @@ The reference has no distributed code at all; this is the MI3
 scale-out of the same round: every rank owns `n_envs` environments, its own expert
 index stream and replay ring, and a full replica of policy + discriminator. Exchanges:
 
-* one flat-bucket all-reduce (mean) of the discriminator gradient per `train_disc`
-  (289 KB at 256x256) and of the policy gradient per PPO minibatch (14 KB) -- latency-bound
-  messages, so ONE collective per optimiser step on a persistent flat buffer;
-* an all-gather of RunningNorm slab moments whenever a normalisation layer updates, followed by
-  the same Chan merge on every rank (identical statistics everywhere, exactly the update a
-  single process would have made on the concatenated batch);
+* discriminator: one flat-bucket all-reduce of the gradient per `train_disc` (289 KB at 256x256) between the fused
+  update's reduction and its Adam step; the RunningNorm slab moments of ALL the round's updates cross the ranks in one
+  all-gather and are merged in order, with per-update snapshots, by one launch (exactly the statistics a single
+  process would have formed on the concatenated batches);
+* PPO update (`ppo.PPO._train_dp_global`): ONE all-gather of the round's rollout shards, then the persistent update on
+  the global tile -- either row-sharded (each rank its rows of every global minibatch; one record per optimiser step
+  crosses the ranks INSIDE the kernels through peer-mapped memory, `PeerExchange` below: no collective on the chain) or
+  replicated (every rank the whole global minibatch, no per-step exchange at all); which of the two runs is MEASURED on
+  the node during the first updates (`PPO.dp_update_form = "auto"`, `PPO.dp_choice`). Policies outside the persistent
+  kernel fall back to one all-reduce of the flat policy gradient per optimiser step (`_train_data_parallel`);
 * a parameter broadcast from rank 0 at construction.
 Replicas therefore stay bit-identical; global-norm clipping happens after the all-reduce.
 """

@@ -442,6 +442,14 @@ class PPO(OnPolicyAlgorithm):
         # optimiser step inside the kernels through peer-mapped memory (`distributed.PeerExchange`, `ia_ppo_update_sharded`).
         # False -- or a failed peer handshake -- runs the whole global minibatch redundantly on every rank instead.
         self.dp_row_sharded = os.environ.get("IA_DP_ROW_SHARDED", "1") != "0"
+        # Which data-parallel form of the persistent update runs: "sharded" (each rank its rows of the global minibatch,
+        # one record per optimiser step exchanged inside the kernels), "replicated" (every rank the whole global
+        # minibatch, no per-step exchange) or "auto" (default): both are TIMED on the node during the first updates of a
+        # run -- alternating, the first launch of each form discarded -- and the form whose slowest rank is faster is kept
+        # on all ranks (one all-gather of two numbers). `dp_choice` records both timings and the verdict (`bench.py`
+        # prints it). `IA_DP_ROW_SHARDED=0` still means "replicated".
+        self.dp_update_form = os.environ.get("IA_DP_UPDATE_FORM", "auto") if self.dp_row_sharded else "replicated"
+        self.dp_choice = None
         self.dp_exchange_timeout_s = 30.0   # a rank waits this long for a peer's record of ONE optimiser step
 
     @property
@@ -830,27 +838,32 @@ class PPO(OnPolicyAlgorithm):
             T, n, W = rb.buffer_size, rb.n_envs, dp.world
             aw = 1 if pol.discrete else pol.act_dim
             bg = min(W * self.batch_size, W * T * n)
+            rows = bg // W
+            # the row-sharded form is asked for FIRST: it is the one that still fits when the global minibatch has more row
+            # blocks than one GPU's persistent kernel takes; the replicated form only where its shape is supported
+            n_ws_s = int(L.load().ia_ppo_update_sharded_ws_floats(C.byref(pol.desc), rows, W)) if rows * W == bg else 0
             n_ws = int(L.load().ia_ppo_update_ws_floats(C.byref(pol.desc), bg))
-            if n_ws <= 0:
+            dev, cols = self.device, pol.obs_dim + aw + 3
+            shard = None
+            if self.dp_update_form != "replicated" and n_ws_s > 0:
+                from imitation_amd.distributed import PeerExchange
+                make = getattr(dp, "make_peer_exchange", None)   # (stand-in DataParallel objects of the tools: loopback)
+                ex = make(pol.desc) if make is not None else PeerExchange(dp, pol.desc)
+                if ex.ok:   # (the ranks' COMMON verdict: mapping + peer writes + system-scope polling work everywhere)
+                    shard = dict(ex=ex, rows=rows, ws=th.zeros(n_ws_s, device=dev))
+                else:
+                    ex.close()
+                    warnings.warn("data-parallel PPO update: the peer-memory handshake failed; every rank runs the "
+                                  "whole global minibatch instead of its row shard", RuntimeWarning)
+            if shard is None and n_ws <= 0:
                 self._dpg = False
             else:
-                dev, cols = self.device, pol.obs_dim + aw + 3
                 perm_host = th.zeros(self.n_epochs, W * T * n, dtype=th.int64).pin_memory()
-                shard = None
-                rows = bg // W
-                n_ws_s = int(L.load().ia_ppo_update_sharded_ws_floats(C.byref(pol.desc), rows, W)) if rows * W == bg else 0
-                if self.dp_row_sharded and n_ws_s > 0:
-                    from imitation_amd.distributed import PeerExchange
-                    make = getattr(dp, "make_peer_exchange", None)   # (stand-in DataParallel objects of the tools: loopback)
-                    ex = make(pol.desc) if make is not None else PeerExchange(dp, pol.desc)
-                    if ex.ok:   # (the ranks' COMMON verdict: mapping + peer writes + system-scope polling work everywhere)
-                        shard = dict(ex=ex, rows=rows, ws=th.zeros(n_ws_s, device=dev))
-                    else:
-                        warnings.warn("data-parallel PPO update: the peer-memory handshake failed; every rank runs the "
-                                      "whole global minibatch instead of its row shard", RuntimeWarning)
+                forms = (["sharded"] if shard is not None else []) + (["replicated"] if n_ws > 0 else [])
                 self._dpg = dict(
-                    shard=shard,
-                    W=W, aw=aw, cols=cols, batch=bg, ws=th.zeros(n_ws, device=dev),
+                    shard=shard, forms=forms, n_ws=n_ws, ws=None,   # (the replicated form's workspace: on first use)
+                    auto=dict(k=0, events=[], ms={"sharded": [], "replicated": []}, chosen=None),
+                    W=W, aw=aw, cols=cols, batch=bg,
                     send=th.empty(T, n, cols, device=dev),
                     obs=th.empty(T, W * n, pol.obs_dim, device=dev), acts=th.empty(T, W * n, aw, device=dev),
                     logp=th.empty(T, W * n, device=dev), adv=th.empty(T, W * n, device=dev),
@@ -884,7 +897,13 @@ class PPO(OnPolicyAlgorithm):
         og = pol.optimizer.param_groups[0]
         if self.update_events is not None:
             self.update_events[0].record()
-        sh = g["shard"]
+        form, timed = self._dp_pick_form(g)
+        ev = (th.cuda.Event(enable_timing=True), th.cuda.Event(enable_timing=True)) if timed else None
+        if ev is not None:
+            ev[0].record()
+        sh = g["shard"] if form == "sharded" else None
+        if sh is None and g["ws"] is None:
+            g["ws"] = th.zeros(g["n_ws"], device=self.device)
         if sh is not None:
             # rows sharded over the ranks, one record per optimiser step exchanged inside the kernels
             ex = sh["ex"]
@@ -909,9 +928,50 @@ class PPO(OnPolicyAlgorithm):
                    float(self.max_grad_norm), L.ptr(pol.optimizer.exp_avg), L.ptr(pol.optimizer.exp_avg_sq),
                    float(lr), float(og["betas"][0]), float(og["betas"][1]), float(og["eps"]), pol.optimizer.step_count,
                    L.ptr(g["ws"]), L.ptr(stats_dev), L.stream())
+        if ev is not None:
+            ev[1].record()
+            g["auto"]["events"].append((form, ev))
         if self.update_events is not None:
             self.update_events[1].record()
         pol.optimizer.step_count += self.n_epochs * self._n_mb
+
+    _DP_AUTO_TRIALS = 4   # timed updates of the "auto" choice: sharded / replicated alternating, the first of each discarded
+                          # (the driver's five warm-up rounds hold the trials and the verdict)
+
+    def _dp_pick_form(self, g):
+        """(form of this update, whether it is timed). One form available, or one asked for: that one. "auto": the first
+        `_DP_AUTO_TRIALS` updates alternate between the forms under HIP events; then every rank takes the minimum of its
+        kept timings per form, the ranks' MAXIMA (one all-gather of two numbers: a step is as slow as the slowest rank)
+        decide for all of them alike, and `dp_choice` keeps the record."""
+        forms, auto = g["forms"], g["auto"]
+        if len(forms) == 1 or self.dp_update_form in forms:
+            return (self.dp_update_form if self.dp_update_form in forms else forms[0]), False
+        if auto["chosen"] is not None:
+            return auto["chosen"], False
+        k = auto["k"]
+        auto["k"] = k + 1
+        if k < self._DP_AUTO_TRIALS:
+            return forms[k % 2], True
+        for form, (e0, e1) in auto["events"]:
+            e1.synchronize()
+            auto["ms"][form].append(e0.elapsed_time(e1))
+        mine = [min(auto["ms"][f][1:]) for f in ("sharded", "replicated")]
+        allr = self.dp.all_gather_flat(th.tensor(mine, dtype=th.float32, device=self.device)).view(-1, 2).cpu()
+        worst = allr.max(dim=0).values.tolist()
+        auto["chosen"] = "sharded" if worst[0] <= worst[1] else "replicated"
+        auto["events"] = []
+        self.dp_choice = dict(sharded_ms=worst[0], replicated_ms=worst[1], chosen=auto["chosen"],
+                              trials={f: [round(x, 4) for x in v] for f, v in auto["ms"].items()})
+        return auto["chosen"], False
+
+    def close(self) -> None:
+        """Releases what the data-parallel update holds outside torch's allocator: the peer-mapped exchange block and the
+        hipIpc mappings of the other ranks' blocks (`distributed.PeerExchange`)."""
+        g = self._dpg if isinstance(self._dpg, dict) else None
+        if g is not None and g.get("shard") is not None:
+            g["shard"]["ex"].close()
+            g["shard"] = None
+            g["forms"] = [f for f in g["forms"] if f != "sharded"]
 
     def _train_data_parallel(self, perm: np.ndarray, lr: float, clip_range: float) -> None:
         """Minibatch loop with one RCCL all-reduce of the flat policy gradient per optimiser step

@@ -82,6 +82,7 @@ def _gpu_worker(rank, world, port, out_dir):
                      batch_size=cfg["ppo_batch"], n_epochs=2, ent_coef=0.1, policy_kwargs=pk, device="cuda")
         algo.dp_batch_moments = batch_moments
         algo.dp_global_minibatch = global_mb
+        algo.dp_update_form = "sharded"   # (the default, "auto", times both forms first: its own test below)
         if airl:
             net = p.BasicShapedRewardNet(venv.observation_space, venv.action_space, reward_hid_sizes=(32,),
                                          potential_hid_sizes=(32, 32), use_next_state=True,
@@ -206,6 +207,7 @@ def _equiv_worker(rank, world, port, out_dir, geom="one_workgroup"):
     algo = p.PPO(p.FeedForward32Policy, venv, n_steps=cfg["n_steps"], batch_size=cfg["ppo_batch"], n_epochs=2,
                  ent_coef=0.1, policy_kwargs=pk, device="cuda")
     algo.dp_global_minibatch = True
+    algo.dp_update_form = "sharded"
     net = p.BasicRewardNet(venv.observation_space, venv.action_space, hid_sizes=(32, 32),
                            normalize_input_layer=p.RunningNorm)
     demos = p.Transitions(**harness.make_demo_arrays(cfg, seed=1 + rank))
@@ -649,6 +651,9 @@ def test_bench_two_rank_launch_line_on_one_gpu(tmp_path):
     assert out["config"]["parallelism"] == "dp2"
     assert out["details"]["roofline_disc_update"]["path"].startswith("fused")   # not the general 16-launch update
     assert out["summary"]["disc_update"]["path"] == "fused" and out["tail_summary"] == out["summary"]
-    # the PPO update sharded each global minibatch's rows over the ranks (in-kernel record exchange through hipIpc memory)
-    assert out["config"]["ppo_update"].startswith("row-sharded")
+    # the data-parallel form of the PPO update was a MEASURED choice: both forms ran during the warm-up rounds (rows sharded
+    # over the ranks with the in-kernel record exchange through hipIpc memory; the whole global minibatch on every rank)
+    ch = out["config"]["ppo_update_choice"]
+    assert ch is not None and ch["chosen"] in ("sharded", "replicated") and ch["sharded_ms"] > 0 and ch["replicated_ms"] > 0
+    assert out["config"]["ppo_update"].startswith("row-sharded" if ch["chosen"] == "sharded" else "replicated")
     assert all(not isinstance(v, (dict, list)) for v in out["roofline"].values())   # flat: scalars survive any parser

@@ -59,6 +59,9 @@ def main():
     for world in (1, 2, 4, 8):
         dp = None if world == 1 else NullDP(world)
         tr = bench.build_trainer(bench.hip_namespace(), cfg, "cuda", seed=0, dp=dp)
+        # (the stub world measures ONE form per run: IA_DP_ROW_SHARDED=0 the replicated one, else the row-sharded one -- the
+        #  product's default, "auto", times both on the real node and keeps the faster)
+        tr.gen_algo.dp_update_form = "replicated" if os.environ.get("IA_DP_ROW_SHARDED", "1") == "0" else "sharded"
         tr.train(4 * per_round)
         th.cuda.synchronize()
         if dp is not None:
