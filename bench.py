@@ -343,6 +343,10 @@ VARIANTS = {
     # Monitor-wrapped environments hands the trainer, `util/util.py:158-166`): one info dict per env and step,
     # `terminal_observation` / `TimeLimit.truncated` / `episode` on the (staggered) episode ends -- the wrappers' per-env
     # branch (`rewards/reward_wrapper.py:92-133`, `data/wrappers.py:69-91`) instead of `ArrayVecEnv.step_wait_arrays`
+    # ... and the SAME environment (staggered episode ends, variable-horizon flag) through the array protocol: the pair
+    # isolates what the dict protocol costs -- the env's own 1 024 dicts per step and the trainer's per-env branch
+    "P_stagger_arrays_1024": _v(algo="gail", n_envs=1024, n_steps=16, obs=17, act=6, ppo=_PPO_P, demo_batch=8192, n_disc=16,
+                                capacity=16384, net=dict(hid_sizes=(256, 256)), stagger=True, rounds=12, warm=3),
     "P_generic_vecenv_1024": _v(algo="gail", n_envs=1024, n_steps=16, obs=17, act=6, ppo=_PPO_P, demo_batch=8192, n_disc=16,
                                 capacity=16384, net=dict(hid_sizes=(256, 256)), generic_vecenv=True, stagger=True,
                                 rounds=12, warm=3),

@@ -191,7 +191,6 @@ _SIGS = {
     "ia_ppo_minibatch_grad": ([C.POINTER(PolicyDesc), _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I,
                                _F, _F, _F, _P, _P], C.c_int),
     "ia_ppo_debug_timing": ([_P], C.c_int),
-    "ia_ppo_force_valu": ([_I], C.c_int),
     "ia_ppo_epoch_split": ([_I], C.c_int),
     "ia_ppo_epoch_debug_timing": ([_P], C.c_int),
     "ia_ppo_grad_offset": ([C.POINTER(PolicyDesc), _I], C.c_int64),

@@ -146,70 +146,6 @@ __device__ __forceinline__ float gauss_logp_term(float a, float mu, float log_st
 // ------------------------------------------------------------------------------- inference
 
 template <int H>
-__global__ __launch_bounds__(ROWS) void policy_act_kernel(ia_policy_desc d, const float* __restrict__ P,
-                                                          const float* __restrict__ Pt, const float* __restrict__ nm,
-                                                          const float* __restrict__ nv, const float* __restrict__ obs,
-                                                          int n, const float* __restrict__ noise,
-                                                          const float* __restrict__ low, const float* __restrict__ high,
-                                                          float* __restrict__ actions, float* __restrict__ clipped,
-                                                          float* __restrict__ values, float* __restrict__ logp) {
-  using L = Lds<H>;
-  extern __shared__ float lds[];
-  const int tid = threadIdx.x, row = blockIdx.x * ROWS + tid;
-  const bool valid = row < n;
-  const int D = d.obs_dim, A = d.act_dim;
-  const PolOff o = pol_offsets(D, A, H, d.discrete);
-  float* xrow = lds + L::x + tid * L::XS;
-  float* a1row = lds + L::a1 + tid * L::HS;
-  float* outrow = lds + L::out + tid * L::AS;
-  load_features(d, obs + (long long)(valid ? row : 0) * D, nm, nv, valid, xrow);
-  float a2[H];
-  tower_forward<H>(Pt + o.pW1, P + o.pb1, Pt + o.pW2, P + o.pb2, D, xrow, a1row, nullptr, a2);
-  head_forward<H>(P + o.aW, P + o.ab, A, a2, outrow);
-  tower_forward<H>(Pt + o.vW1, P + o.vb1, Pt + o.vW2, P + o.vb2, D, xrow, a1row, nullptr, a2);
-  float v = P[o.cb];
-#pragma unroll
-  for (int k = 0; k < H; ++k) v = fmaf(P[o.cW + k], a2[k], v);
-  if (!valid) return;
-  values[row] = v;
-  if (!d.discrete) {
-    float lp = 0.f;
-    for (int a = 0; a < A; ++a) {
-      const float ls = P[o.log_std + a];
-      const float mu = outrow[a];
-      // Normal.rsample: loc + eps * scale  (two roundings, as on the host)
-      const float act = __fadd_rn(mu, __fmul_rn(noise[(long long)row * A + a], expf(ls)));
-      actions[(long long)row * A + a] = act;
-      clipped[(long long)row * A + a] = fminf(fmaxf(act, low[a]), high[a]);
-      lp += gauss_logp_term(act, mu, ls);
-    }
-    logp[row] = lp;
-  } else {
-    float mx = outrow[0];
-    for (int a = 1; a < A; ++a) mx = fmaxf(mx, outrow[a]);
-    float se = 0.f;
-    for (int a = 0; a < A; ++a) se += expf(outrow[a] - mx);
-    const float lse = mx + logf(se);
-    const float u = noise[row];
-    float c = 0.f;
-    int pick = A - 1;
-    if (u < 0.f) {  // mode of the Categorical ([SB3 CategoricalDistribution.mode] = argmax, first index on ties)
-      pick = 0;
-      for (int a = 1; a < A; ++a)
-        if (outrow[a] > outrow[pick]) pick = a;
-    } else {
-      for (int a = 0; a < A; ++a) {
-        c += expf(outrow[a] - lse);
-        if (u < c) { pick = a; break; }
-      }
-    }
-    actions[row] = (float)pick;
-    clipped[row] = (float)pick;
-    logp[row] = outrow[pick] - lse;
-  }
-}
-
-template <int H>
 __global__ __launch_bounds__(ROWS) void policy_eval_kernel(ia_policy_desc d, const float* __restrict__ P,
                                                            const float* __restrict__ Pt, const float* __restrict__ nm,
                                                            const float* __restrict__ nv, const float* __restrict__ obs,
@@ -267,45 +203,6 @@ __global__ __launch_bounds__(ROWS) void policy_eval_kernel(ia_policy_desc d, con
 // Raw head outputs: action_net(latent_pi) (Categorical logits / Gaussian means) and the value head, for
 // callers that sample on the host with the reference's own RNG call ([SB3 CategoricalDistribution.sample] =
 // torch.multinomial on torch's global CPU generator). Thread per row.
-template <int H>
-__device__ __forceinline__ void policy_logits_body(const ia_policy_desc& d, const float* __restrict__ P,
-                                                   const float* __restrict__ Pt, const float* __restrict__ nm,
-                                                   const float* __restrict__ nv, const float* __restrict__ obs, int n,
-                                                   float* __restrict__ logits, float* __restrict__ values, const int blk,
-                                                   float* __restrict__ lds) {
-  using L = Lds<H>;
-  const int tid = threadIdx.x, row = blk * ROWS + tid;
-  const bool valid = row < n;
-  const int D = d.obs_dim, A = d.act_dim;
-  const PolOff o = pol_offsets(D, A, H, d.discrete);
-  float* xrow = lds + L::x + tid * L::XS;
-  float* a1row = lds + L::a1 + tid * L::HS;
-  float* outrow = lds + L::out + tid * L::AS;
-  load_features(d, obs + (long long)(valid ? row : 0) * D, nm, nv, valid, xrow);
-  float a2[H];
-  tower_forward<H>(Pt + o.pW1, P + o.pb1, Pt + o.pW2, P + o.pb2, D, xrow, a1row, nullptr, a2);
-  head_forward<H>(P + o.aW, P + o.ab, A, a2, outrow);
-  if (valid)
-    for (int a = 0; a < A; ++a) logits[(long long)row * A + a] = outrow[a];
-  if (values) {
-    tower_forward<H>(Pt + o.vW1, P + o.vb1, Pt + o.vW2, P + o.vb2, D, xrow, a1row, nullptr, a2);
-    float v = P[o.cb];
-#pragma unroll
-    for (int k = 0; k < H; ++k) v = fmaf(P[o.cW + k], a2[k], v);
-    if (valid) values[row] = v;
-  }
-}
-
-template <int H>
-__global__ __launch_bounds__(ROWS) void policy_logits_kernel(ia_policy_desc d, const float* __restrict__ P,
-                                                             const float* __restrict__ Pt, const float* __restrict__ nm,
-                                                             const float* __restrict__ nv, const float* __restrict__ obs,
-                                                             int n, float* __restrict__ logits,
-                                                             float* __restrict__ values) {
-  extern __shared__ float lds[];
-  policy_logits_body<H>(d, P, Pt, nm, nv, obs, n, logits, values, blockIdx.x, lds);
-}
-
 // Host <-> resident-kernel hand-off of the rollout mailboxes (policy_rollout_mailbox_kernel, policy_logits_mailbox_kernel):
 // `ready` is one int in pinned host memory (step t may run once it exceeds t; negative: abort), `done[workgroup]` the
 // acknowledgement. mailbox_wait: lane 0 polls with system-scope loads (bounded by `timeout_ticks` of the 100 MHz clock),
@@ -347,23 +244,6 @@ struct LogitsMailbox {
   float* values; long long s_val;
   int T; const int* ready; int* done; long long timeout_ticks;
 };
-
-template <int H>
-__global__ __launch_bounds__(ROWS) void policy_logits_mailbox_kernel(ia_policy_desc d, const float* __restrict__ P,
-                                                                     const float* __restrict__ Pt,
-                                                                     const float* __restrict__ nm,
-                                                                     const float* __restrict__ nv, int n, LogitsMailbox mb) {
-  extern __shared__ float lds[];
-  __shared__ int s_go;
-  for (int t = 0; t < mb.T; ++t) {
-    if (!mailbox_wait(mb.ready, t, mb.timeout_ticks, &s_go)) {
-      if (threadIdx.x == 0) __hip_atomic_store(mb.done + blockIdx.x, -(t + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-      return;
-    }
-    policy_logits_body<H>(d, P, Pt, nm, nv, mb.obs + t * mb.s_obs, n, mb.logits, mb.values + t * mb.s_val, blockIdx.x, lds);
-    mailbox_ack(mb.done, t + 1);
-  }
-}
 
 __global__ void transpose_params_kernel(ia_policy_desc d, const float* __restrict__ P, float* __restrict__ Pt) {
   const int H = d.hidden, D = d.obs_dim;
@@ -852,267 +732,6 @@ struct GLds {  // LDS carve-up of the 8-wave gradient kernel (floats); NTOW = 1:
   static constexpr int misc = aux + ROWS * AS;         // [ROWS][MS]: 0 = value, 1 = dvalue
   static constexpr int total = misc + ROWS * MS + 64;
 };
-
-template <int H>
-__global__ __launch_bounds__(512) void ppo_grad_kernel(ia_policy_desc d, const float* __restrict__ P,
-                                                       const float* __restrict__ Pt, const float* __restrict__ nm,
-                                                       const float* __restrict__ nv, const float* __restrict__ obs,
-                                                       const float* __restrict__ actions,
-                                                       const float* __restrict__ old_logp,
-                                                       const float* __restrict__ adv, const float* __restrict__ ret,
-                                                       const int64_t* __restrict__ idx, int batch, int T, int n_envs,
-                                                       int normalize_adv, float clip, float ent_coef, float vf_coef,
-                                                       float* __restrict__ ws, int nblk,
-                                                       long long* __restrict__ tstamp /* optional phase clocks */,
-                                                       const float* __restrict__ advstat_in) {
-  using L = GLds<H>;
-  constexpr int HQ = H / 4;
-#define IA_TS(slot) do { if (tstamp && blockIdx.x == 0 && threadIdx.x == 0) tstamp[slot] = clock64(); } while (0)
-  extern __shared__ float lds[];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int tw = wv >> 2, q = wv & 3;          // tower (0 = policy, 1 = value), output quarter
-  const int D = d.obs_dim, A = d.act_dim;
-  const PolOff o = pol_offsets(D, A, H, d.discrete);
-  const PpoWs w = ppo_ws(ws, nblk, o.total);
-  float* slab = w.slabs + (long long)blockIdx.x * o.total;
-  const int i0 = blockIdx.x * ROWS;
-  const int aw = d.discrete ? 1 : A;
-  const float invB = 1.f / (float)batch;
-  if (blockIdx.x == 0 && tid == 0) reinterpret_cast<unsigned*>(ws)[7] = 0u;   // ticket of ppo_apply_split_kernel
-
-  IA_TS(0);
-  // ---- phase 0: cooperative, coalesced feature gather (+ normalisation) into LDS; clear pads
-  for (int e = tid; e < ROWS * L::XS; e += 512) {
-    const int r = e / L::XS, k = e - r * L::XS;
-    float v = 0.f;
-    if (k < D && i0 + r < batch) {
-      v = obs[mb_row(idx, i0 + r, T, n_envs) * D + k];
-      if (d.has_norm) v = (v - nm[k]) / sqrtf(nv[k] + d.norm_eps);
-    }
-    lds[L::x + e] = v;
-  }
-  for (int e = tid; e < ROWS * L::AS; e += 512) { lds[L::dout + e] = 0.f; lds[L::aux + e] = 0.f; lds[L::out + e] = 0.f; }
-  for (int e = tid; e < ROWS * L::MS; e += 512) lds[L::misc + e] = 0.f;
-  __syncthreads();
-
-  const int oW1 = tw ? o.vW1 : o.pW1, ob1 = tw ? o.vb1 : o.pb1, oW2 = tw ? o.vW2 : o.pW2, ob2 = tw ? o.vb2 : o.pb2;
-  const float* xrow = lds + L::x + lane * L::XS;
-  float* a1row = lds + L::a1 + (tw * ROWS + lane) * L::HS;
-  float* a2row = lds + L::a2 + (tw * ROWS + lane) * L::HS;
-  float* dzrow = lds + L::dz + (tw * ROWS + lane) * L::HS;
-  const int c0 = q * HQ;  // first output column owned by this wave
-
-  IA_TS(1);
-  // ---- phase 1: layer 1 (quarter of the outputs)
-  {
-    float acc[HQ];
-#pragma unroll
-    for (int j = 0; j < HQ; ++j) acc[j] = P[ob1 + c0 + j];
-#pragma unroll 4
-    for (int k = 0; k < D; ++k) {
-      const float xk = xrow[k];
-#pragma unroll
-      for (int j = 0; j < HQ; ++j) acc[j] = fmaf(Pt[oW1 + k * H + c0 + j], xk, acc[j]);
-    }
-#pragma unroll
-    for (int j = 0; j < HQ; ++j) a1row[c0 + j] = fast_tanh(acc[j]);
-  }
-  __syncthreads();
-  IA_TS(2);
-  // ---- phase 2: layer 2
-  {
-    float acc[HQ];
-#pragma unroll
-    for (int j = 0; j < HQ; ++j) acc[j] = P[ob2 + c0 + j];
-#pragma unroll 4
-    for (int k = 0; k < H; ++k) {
-      const float ak = a1row[k];
-#pragma unroll
-      for (int j = 0; j < HQ; ++j) acc[j] = fmaf(Pt[oW2 + k * H + c0 + j], ak, acc[j]);
-    }
-#pragma unroll
-    for (int j = 0; j < HQ; ++j) a2row[c0 + j] = fast_tanh(acc[j]);
-  }
-  __syncthreads();
-  IA_TS(3);
-  // ---- phase 3: heads
-  if (tw == 0) {
-    for (int a = q; a < A; a += 4) {
-      float s = P[o.ab + a];
-#pragma unroll 8
-      for (int k = 0; k < H; ++k) s = fmaf(P[o.aW + a * H + k], a2row[k], s);
-      lds[L::out + lane * L::AS + a] = s;
-    }
-  } else if (q == 0) {
-    float v = P[o.cb];
-#pragma unroll 8
-    for (int k = 0; k < H; ++k) v = fmaf(P[o.cW + k], a2row[k], v);
-    lds[L::misc + lane * L::MS + 0] = v;
-  }
-  __syncthreads();
-  IA_TS(4);
-  // ---- phase 4: per-row losses (wave 0: policy terms, wave 4: value term)
-  const int i = i0 + lane;
-  const bool valid = i < batch;
-  if (wv == 0) {
-    const long long src = valid ? mb_row(idx, i, T, n_envs) : 0;
-    const float* outrow = lds + L::out + lane * L::AS;
-    float* doutrow = lds + L::dout + lane * L::AS;
-    float* auxrow = lds + L::aux + lane * L::AS;
-    float logp = 0.f, entropy = 0.f, lse = 0.f;
-    int act_i = 0;
-    if (!d.discrete) {
-      for (int a = 0; a < A; ++a) {
-        const float ls = P[o.log_std + a];
-        logp += gauss_logp_term(actions[src * aw + a], outrow[a], ls);
-        entropy += 0.5f + LOG_SQRT_2PI + logf(expf(ls));
-      }
-    } else {
-      float mx = outrow[0];
-      for (int a = 1; a < A; ++a) mx = fmaxf(mx, outrow[a]);
-      float se = 0.f;
-      for (int a = 0; a < A; ++a) se += expf(outrow[a] - mx);
-      lse = mx + logf(se);
-      act_i = (int)actions[src];
-      logp = outrow[act_i] - lse;
-      for (int a = 0; a < A; ++a) {
-        const float l = outrow[a] - lse;
-        entropy -= expf(l) * l;
-      }
-    }
-    float advn = adv[src];
-    const float* as = advstat_in ? advstat_in : w.advstat;
-    if (normalize_adv && batch > 1) advn = (advn - as[0]) / (as[1] + 1e-8f);
-    const float log_ratio = logp - old_logp[src];
-    const float ratio = expf(log_ratio);
-    const float lo = 1.f - clip, hi = 1.f + clip;
-    const float pl1 = advn * ratio;
-    const float pl2 = advn * fminf(fmaxf(ratio, lo), hi);
-    // d(-mean(min(pl1,pl2)))/d ratio with torch's tie rule (equal -> half to each branch)
-    const float g1 = pl1 < pl2 ? 1.f : (pl1 == pl2 ? 0.5f : 0.f);
-    const float g2 = pl2 < pl1 ? 1.f : (pl1 == pl2 ? 0.5f : 0.f);
-    const float inrange = (ratio >= lo && ratio <= hi) ? 1.f : 0.f;
-    const float dlogp = valid ? -invB * advn * (g1 + g2 * inrange) * ratio : 0.f;
-    if (!d.discrete) {
-      for (int a = 0; a < A; ++a) {
-        const float ls = P[o.log_std + a];
-        const float sd = expf(ls), var = sd * sd;
-        const float diff = actions[src * aw + a] - outrow[a];
-        doutrow[a] = dlogp * diff / var;
-        // d logp/d log_std = diff^2/var - 1 ; entropy_loss = -mean(entropy) -> -ent_coef/B per row
-        auxrow[a] = valid ? dlogp * (diff * diff / var - 1.f) - ent_coef * invB : 0.f;
-      }
-    } else {
-      for (int a = 0; a < A; ++a) {
-        const float l = outrow[a] - lse, p = expf(l);
-        const float dH = -p * (l + entropy);  // d entropy / d logit_a
-        float g = dlogp * ((a == act_i ? 1.f : 0.f) - p);
-        g += valid ? -ent_coef * invB * dH : 0.f;
-        doutrow[a] = g;
-      }
-    }
-    float st[4];
-    st[0] = valid ? -fminf(pl1, pl2) : 0.f;                         // policy_gradient_loss
-    st[1] = valid ? -entropy : 0.f;                                  // entropy_loss
-    st[2] = valid ? (expf(log_ratio) - 1.f) - log_ratio : 0.f;       // approx_kl
-    st[3] = valid ? (fabsf(ratio - 1.f) > clip ? 1.f : 0.f) : 0.f;   // clip_fraction
-    const int slot[4] = {0, 2, 3, 4};
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      float x = st[k];
-      for (int s = 32; s > 0; s >>= 1) x += __shfl_down(x, s, 64);
-      if (lane == 0) w.statpart[blockIdx.x * 8 + slot[k]] = x;
-    }
-  } else if (wv == 4) {
-    const long long src = valid ? mb_row(idx, i, T, n_envs) : 0;
-    const float v = lds[L::misc + lane * L::MS + 0];
-    const float verr = ret[src] - v;
-    lds[L::misc + lane * L::MS + 1] = valid ? vf_coef * 2.f * (v - ret[src]) * invB : 0.f;  // F.mse_loss
-    float x = valid ? verr * verr : 0.f;
-    for (int s = 32; s > 0; s >>= 1) x += __shfl_down(x, s, 64);
-    if (lane == 0) w.statpart[blockIdx.x * 8 + 1] = x;
-  }
-  __syncthreads();
-  IA_TS(5);
-  // ---- phase 5: d(a2) -> dz2 for this wave's quarter; head weight/bias gradients
-  if (tw == 0) {
-    float da2[HQ];
-#pragma unroll
-    for (int k = 0; k < HQ; ++k) da2[k] = 0.f;
-    const float* doutrow = lds + L::dout + lane * L::AS;
-    for (int a = 0; a < A; ++a) {
-      const float g = doutrow[a];
-#pragma unroll
-      for (int k = 0; k < HQ; ++k) da2[k] = fmaf(P[o.aW + a * H + c0 + k], g, da2[k]);
-    }
-#pragma unroll
-    for (int k = 0; k < HQ; ++k) {
-      const float a = a2row[c0 + k];
-      dzrow[c0 + k] = da2[k] * (1.f - a * a);
-    }
-    if (q * 32 < H)  // dWa[a][k] = sum_r dout[r][a] a2[r][k]
-      mfma_outer_store(lds + L::dout, L::AS, lds + L::a2, L::HS, 0, q * 32, A, H, slab + o.aW, H, lane);
-    if (q == 2) column_sum_store(lds + L::dout, L::AS, A, slab + o.ab, lane);
-    if (q == 3 && !d.discrete) column_sum_store(lds + L::aux, L::AS, A, slab + o.log_std, lane);
-  } else {
-    const float dv = lds[L::misc + lane * L::MS + 1];
-#pragma unroll
-    for (int k = 0; k < HQ; ++k) {
-      const float a = a2row[c0 + k];
-      dzrow[c0 + k] = P[o.cW + c0 + k] * dv * (1.f - a * a);
-    }
-    if (q * 32 < H)  // dcW[k] = sum_r dv[r] a2[r][k]   (U = misc column 1, only row j=0 stored)
-      mfma_outer_store(lds + L::misc + 1, L::MS, lds + L::a2 + ROWS * L::HS, L::HS, 0, q * 32, 1, H, slab + o.cW, H,
-                       lane);
-    if (q == 2 && lane == 0) {
-      float s = 0.f;
-      for (int r = 0; r < ROWS; ++r) s += lds[L::misc + r * L::MS + 1];
-      slab[o.cb] = s;
-    }
-  }
-  __syncthreads();
-  IA_TS(6);
-  // ---- phase 6: dW2 / db2 from (dz2, a1); d(a1) -> dz1 (stored in the now-free a2 tile)
-  {
-    const float* dzt = lds + L::dz + tw * ROWS * L::HS;
-    const float* a1t = lds + L::a1 + tw * ROWS * L::HS;
-    constexpr int NT2 = (H / 32) * (H / 32);
-    if (q < NT2) {
-      const int j0 = (q / (H / 32)) * 32, k0 = (q % (H / 32)) * 32;
-      mfma_outer_store(dzt, L::HS, a1t, L::HS, j0, k0, H, H, slab + oW2, H, lane);
-    }
-    if (q == 3) column_sum_store(dzt, L::HS, H, slab + ob2, lane);
-    float da1[HQ];
-#pragma unroll
-    for (int k = 0; k < HQ; ++k) da1[k] = 0.f;
-#pragma unroll 4
-    for (int j = 0; j < H; ++j) {
-      const float g = dzrow[j];
-#pragma unroll
-      for (int k = 0; k < HQ; ++k) da1[k] = fmaf(P[oW2 + j * H + c0 + k], g, da1[k]);
-    }
-#pragma unroll
-    for (int k = 0; k < HQ; ++k) {
-      const float a = a1row[c0 + k];
-      a2row[c0 + k] = da1[k] * (1.f - a * a);  // dz1
-    }
-  }
-  __syncthreads();
-  IA_TS(7);
-  // ---- phase 7: dW1 / db1 from (dz1, x)
-  {
-    const float* dz1 = lds + L::a2 + tw * ROWS * L::HS;
-    const int kt = (D + 31) / 32;
-    const int ntile = (H / 32) * kt;
-    for (int ti = q; ti < ntile; ti += 4)
-      mfma_outer_store(dz1, L::HS, lds + L::x, L::XS, (ti / kt) * 32, (ti % kt) * 32, H, D, slab + oW1, D, lane);
-    if (q == 3) column_sum_store(dz1, L::HS, H, slab + ob1, lane);
-  }
-  __syncthreads();
-  IA_TS(8);
-#undef IA_TS
-}
 
 // ---------------------------------------------------------------------------------------------
 // H = 32 specialisation built on v_mfma_f32_16x16x4_f32 (lane l: li = l&15, lk = l>>4; A[i=li][k=lk],
@@ -3129,9 +2748,9 @@ __global__ __launch_bounds__(512) void policy_rollout_mailbox_kernel(
 }
 
 // The host-sampled Discrete step on the MFMA body (one 512-thread workgroup per 64 rows, both towers at once): logits
-// [n, A] + values. The thread-per-row kernels above (policy_logits_kernel / policy_logits_mailbox_kernel) take ~30 us for
-// a 64-wide policy -- 2 x 4 500 dependent FMAs per row with every weight a load -- which was HALF of an 8-environment
-// rollout step (BASELINE config 1); kept behind `ia_ppo_force_valu`.
+// [n, A] + values. (The thread-per-row kernels this replaced took ~30 us for a 64-wide policy -- 2 x 4 500 dependent FMAs
+// per row with every weight a load --, HALF of an 8-environment rollout step of BASELINE config 1; they and the other
+// thread-per-row forms behind `ia_ppo_force_valu` were retired in round 5: no production path reached them.)
 template <int H>
 __global__ __launch_bounds__(512) void policy_logits_mfma_kernel(
     ia_policy_desc d, const float* __restrict__ P, const float* __restrict__ Pt, const float* __restrict__ nm,
@@ -5704,7 +5323,6 @@ int set_lds(K kern, size_t bytes) {
   return e == hipSuccess ? IA_OK : (int)e;
 }
 
-bool g_ppo_valu = false;  // tuning/debug: force the VALU kernels for H = 32 as well
 bool g_epoch_split = false;  // tuning/debug: two launches per minibatch for 64-wide towers too
 bool g_epoch_whole = false;  // tuning/debug: the one-launch epoch with whole row-block workgroups (8 waves, both towers)
 bool g_epoch_barriers = false;   // tuning/debug: the one-tower epoch kernel with grid barriers instead of the word exchange
@@ -5732,28 +5350,20 @@ int ia_policy_act(const ia_policy_desc* d, const float* params, const float* par
                   const float* high, float* actions, float* clipped, float* values, float* logp, void* stream) {
   if (!pol_ok(d) || n <= 0) return IA_ERR_ARG;
   int rc;
-  if (d->hidden == 32 && !g_ppo_valu) {
+  if (d->hidden == 32) {
     static bool attr = false;
     const size_t bytes = ALds<32>::total * sizeof(float);
     if (!attr) { if ((rc = set_lds(policy_act_mfma_kernel<32, false>, bytes))) return rc; attr = true; }
     hipLaunchKernelGGL((policy_act_mfma_kernel<32, false>), dim3(cdiv(n, ROWS)), dim3(512), bytes, (hipStream_t)stream, *d,
                        params, params_t, norm_mean, norm_var, obs, n, noise, low, high, actions, clipped, values, logp);
-  } else if (d->hidden == 64 && !g_ppo_valu) {
+  } else if (d->hidden == 64) {
     static bool attr = false;
     const size_t bytes = ALds<64>::total * sizeof(float);
     if (!attr) { if ((rc = set_lds(policy_act_mfma_kernel<64, false>, bytes))) return rc; attr = true; }
     hipLaunchKernelGGL((policy_act_mfma_kernel<64, false>), dim3(cdiv(n, ROWS)), dim3(512), bytes, (hipStream_t)stream, *d,
                        params, params_t, norm_mean, norm_var, obs, n, noise, low, high, actions, clipped, values, logp);
-  } else if (d->hidden == 32) {
-    if ((rc = set_lds(policy_act_kernel<32>, lds_bytes<32>()))) return rc;
-    hipLaunchKernelGGL(policy_act_kernel<32>, dim3(cdiv(n, ROWS)), dim3(ROWS), lds_bytes<32>(), (hipStream_t)stream,
-                       *d, params, params_t, norm_mean, norm_var, obs, n, noise, low, high, actions, clipped, values,
-                       logp);
   } else {
-    if ((rc = set_lds(policy_act_kernel<64>, lds_bytes<64>()))) return rc;
-    hipLaunchKernelGGL(policy_act_kernel<64>, dim3(cdiv(n, ROWS)), dim3(ROWS), lds_bytes<64>(), (hipStream_t)stream,
-                       *d, params, params_t, norm_mean, norm_var, obs, n, noise, low, high, actions, clipped, values,
-                       logp);
+    return IA_ERR_UNSUPPORTED;
   }
   IA_CHECK_LAUNCH();
   return IA_OK;
@@ -5770,7 +5380,7 @@ int ia_policy_rollout_mailbox(const ia_policy_desc* d, const float* params, cons
                               void* stream) {
   if (!pol_ok(d) || n <= 0 || T <= 0 || !ready || !done || !obs || !actions || !clipped || !values || !logp)
     return IA_ERR_ARG;
-  if (g_ppo_valu || (d->hidden != 32 && d->hidden != 64)) return IA_ERR_UNSUPPORTED;
+  if (d->hidden != 32 && d->hidden != 64) return IA_ERR_UNSUPPORTED;
   {
     // every workgroup stays resident for the whole rollout and the host waits for ALL of them at every step: more
     // workgroups than the device can hold at once would leave the surplus waiting for the residents forever
@@ -5820,7 +5430,7 @@ int ia_policy_logits_mailbox(const ia_policy_desc* d, const float* params, const
   LogitsMailbox mb{obs, s_obs, logits, values, s_val, T, reinterpret_cast<const int*>(ready),
                    reinterpret_cast<int*>(done), (long long)(timeout_s * 1e8)};
   int rc;
-  if (!g_ppo_valu) {   // the MFMA body (both towers of 64 rows per 512-thread workgroup)
+  {   // the MFMA body (both towers of 64 rows per 512-thread workgroup)
     if (d->hidden == 32) {
       const size_t bytes = ALds<32>::total * sizeof(float);
       if ((rc = set_lds(policy_logits_mailbox_mfma_kernel<32>, bytes))) return rc;
@@ -5835,17 +5445,7 @@ int ia_policy_logits_mailbox(const ia_policy_desc* d, const float* params, const
     IA_CHECK_LAUNCH();
     return IA_OK;
   }
-  if (d->hidden == 32) {
-    if ((rc = set_lds(policy_logits_mailbox_kernel<32>, lds_bytes<32>()))) return rc;
-    hipLaunchKernelGGL(policy_logits_mailbox_kernel<32>, dim3(cdiv(n, ROWS)), dim3(ROWS), lds_bytes<32>(),
-                       (hipStream_t)stream, *d, params, params_t, norm_mean, norm_var, n, mb);
-  } else {
-    if ((rc = set_lds(policy_logits_mailbox_kernel<64>, lds_bytes<64>()))) return rc;
-    hipLaunchKernelGGL(policy_logits_mailbox_kernel<64>, dim3(cdiv(n, ROWS)), dim3(ROWS), lds_bytes<64>(),
-                       (hipStream_t)stream, *d, params, params_t, norm_mean, norm_var, n, mb);
-  }
-  IA_CHECK_LAUNCH();
-  return IA_OK;
+  return IA_ERR_UNSUPPORTED;
 }
 
 int ia_policy_evaluate(const ia_policy_desc* d, const float* params, const float* params_t, const float* norm_mean,
@@ -5853,14 +5453,14 @@ int ia_policy_evaluate(const ia_policy_desc* d, const float* params, const float
                        float* values, float* entropy, void* stream) {
   if (!pol_ok(d) || n <= 0) return IA_ERR_ARG;
   int rc;
-  if (d->hidden == 32 && !g_ppo_valu && (actions != nullptr || logp == nullptr)) {
+  if (d->hidden == 32 && (actions != nullptr || logp == nullptr)) {
     static bool attr = false;   // the MFMA layer chain of the rollout step, given actions instead of sampling
     const size_t bytes = ALds<32>::total * sizeof(float);
     if (!attr) { if ((rc = set_lds(policy_act_mfma_kernel<32, true>, bytes))) return rc; attr = true; }
     hipLaunchKernelGGL((policy_act_mfma_kernel<32, true>), dim3(cdiv(n, ROWS)), dim3(512), bytes, (hipStream_t)stream, *d,
                        params, params_t, norm_mean, norm_var, obs, n, actions, (const float*)nullptr,
                        (const float*)nullptr, (float*)nullptr, entropy, values, logp);
-  } else if (d->hidden == 64 && !g_ppo_valu && (actions != nullptr || logp == nullptr)) {
+  } else if (d->hidden == 64 && (actions != nullptr || logp == nullptr)) {
     static bool attr = false;
     const size_t bytes = ALds<64>::total * sizeof(float);
     if (!attr) { if ((rc = set_lds(policy_act_mfma_kernel<64, true>, bytes))) return rc; attr = true; }
@@ -5886,7 +5486,7 @@ int ia_policy_logits(const ia_policy_desc* d, const float* params, const float* 
                      const float* norm_var, const float* obs, int n, float* logits, float* values, void* stream) {
   if (!pol_ok(d) || n <= 0 || !logits) return IA_ERR_ARG;
   int rc;
-  if (!g_ppo_valu) {   // the MFMA body: the same arithmetic as the mailbox kernel's steps
+  {   // the MFMA body: the same arithmetic as the mailbox kernel's steps
     if (d->hidden == 32) {
       const size_t bytes = ALds<32>::total * sizeof(float);
       if ((rc = set_lds(policy_logits_mfma_kernel<32>, bytes))) return rc;
@@ -5901,17 +5501,7 @@ int ia_policy_logits(const ia_policy_desc* d, const float* params, const float* 
     IA_CHECK_LAUNCH();
     return IA_OK;
   }
-  if (d->hidden == 32) {
-    if ((rc = set_lds(policy_logits_kernel<32>, lds_bytes<32>()))) return rc;
-    hipLaunchKernelGGL(policy_logits_kernel<32>, dim3(cdiv(n, ROWS)), dim3(ROWS), lds_bytes<32>(),
-                       (hipStream_t)stream, *d, params, params_t, norm_mean, norm_var, obs, n, logits, values);
-  } else {
-    if ((rc = set_lds(policy_logits_kernel<64>, lds_bytes<64>()))) return rc;
-    hipLaunchKernelGGL(policy_logits_kernel<64>, dim3(cdiv(n, ROWS)), dim3(ROWS), lds_bytes<64>(),
-                       (hipStream_t)stream, *d, params, params_t, norm_mean, norm_var, obs, n, logits, values);
-  }
-  IA_CHECK_LAUNCH();
-  return IA_OK;
+  return IA_ERR_UNSUPPORTED;
 }
 
 int ia_gae(const float* rewards, const float* values, const float* episode_starts, const float* last_values,
@@ -6028,25 +5618,15 @@ int launch_prepare(const PpoArgs& a, const int64_t* idx, int batch) {
 
 template <int H>
 int launch_grad(const PpoArgs& a, const int64_t* idx, int batch) {
-  static bool attr = false;
-  const size_t bytes = GLds<H>::total * sizeof(float);
   const int nblk = cdiv(batch, ROWS);
-  if (!g_ppo_valu) {
-    // matrix-core gradient kernel: H = 32 with the parameters copied into LDS, H = 64 reading its fragments from L2
-    const int P4 = (pol_offsets(a.d->obs_dim, a.d->act_dim, H, a.d->discrete).total + 3) & ~3;
-    const size_t mbytes = (GLds<H>::total + (H == 32 ? 2 * P4 : 0)) * sizeof(float);
-    static bool attr2 = false;
-    if (!attr2) { int rc = set_lds(ppo_grad_mfma_kernel<H>, 160 * 1024); if (rc) return rc; attr2 = true; }
-    hipLaunchKernelGGL(ppo_grad_mfma_kernel<H>, dim3(nblk), dim3(512), mbytes, a.st, *a.d, a.params, a.params_t,
-                       a.norm_mean, a.norm_var, a.obs, a.actions, a.old_logp, a.advantages, a.returns, idx, batch, a.T,
-                       a.n_envs, a.normalize_adv, a.clip_range, a.ent_coef, a.vf_coef, a.ws, nblk, g_tstamp, a.advstat);
-    IA_CHECK_LAUNCH();
-    return IA_OK;
-  }
-  if (!attr) { int rc = set_lds(ppo_grad_kernel<H>, bytes); if (rc) return rc; attr = true; }
-  hipLaunchKernelGGL(ppo_grad_kernel<H>, dim3(nblk), dim3(512), bytes, a.st, *a.d, a.params, a.params_t, a.norm_mean,
-                     a.norm_var, a.obs, a.actions, a.old_logp, a.advantages, a.returns, idx, batch, a.T, a.n_envs,
-                     a.normalize_adv, a.clip_range, a.ent_coef, a.vf_coef, a.ws, nblk, g_tstamp, a.advstat);
+  // matrix-core gradient kernel: H = 32 with the parameters copied into LDS, H = 64 reading its fragments from L2
+  const int P4 = (pol_offsets(a.d->obs_dim, a.d->act_dim, H, a.d->discrete).total + 3) & ~3;
+  const size_t mbytes = (GLds<H>::total + (H == 32 ? 2 * P4 : 0)) * sizeof(float);
+  static bool attr2 = false;
+  if (!attr2) { int rc = set_lds(ppo_grad_mfma_kernel<H>, 160 * 1024); if (rc) return rc; attr2 = true; }
+  hipLaunchKernelGGL(ppo_grad_mfma_kernel<H>, dim3(nblk), dim3(512), mbytes, a.st, *a.d, a.params, a.params_t,
+                     a.norm_mean, a.norm_var, a.obs, a.actions, a.old_logp, a.advantages, a.returns, idx, batch, a.T,
+                     a.n_envs, a.normalize_adv, a.clip_range, a.ent_coef, a.vf_coef, a.ws, nblk, g_tstamp, a.advstat);
   IA_CHECK_LAUNCH();
   return IA_OK;
 }
@@ -6154,11 +5734,6 @@ int ia_ppo_debug_timing(void* device_buffer_16xi64) {
   return IA_OK;
 }
 
-int ia_ppo_force_valu(int on) {
-  g_ppo_valu = on != 0;
-  return IA_OK;
-}
-
 // Tuning / measurement: 1 = ia_ppo_epoch launches the gradient and apply kernels per minibatch even where the
 // one-launch-per-epoch kernel applies (64-wide towers).
 int ia_ppo_epoch_split(int on) {
@@ -6226,7 +5801,7 @@ static int ppo_epochs_impl(const ia_policy_desc* d, float* params, float* params
   }
   constexpr size_t EPOCH_SPLIT_LDS = 160 * 1024 - 1024;   // dynamic LDS the one-tower kernel may ask for (it has static LDS too)
   constexpr size_t EPOCH_LL_LDS = 160 * 1024 - 2048;
-  const bool one_launch = d->hidden == 64 && !g_ppo_valu && !g_epoch_split && g_tstamp == nullptr;
+  const bool one_launch = d->hidden == 64 && !g_epoch_split && g_tstamp == nullptr;
   const int nrb = cdiv(size_at(0), ROWS);
   const PolOff po = pol_offsets(d->obs_dim, d->act_dim, d->hidden, d->discrete);
   const int P = po.total;
@@ -6417,7 +5992,7 @@ static int64_t upd_ws_floats(const ia_policy_desc* d, int batch_size, int world)
   const int nblk = cdiv(batch_size, ROWS);
   const int P4 = (P + 3) & ~3;
   if (d->hidden != 32 || P > UPD_NPT_WIDE * 512 || upd_grad_lds_bytes(P4, d->discrete ? 1 : d->act_dim) > 160 * 1024 || nblk > UPD_NBLK_MAX ||
-      cdiv((long long)batch_size * world, UPD_SLICE) > UPD_SLICES_MAX || g_ppo_valu)
+      cdiv((long long)batch_size * world, UPD_SLICE) > UPD_SLICES_MAX)
     return 0;
   // (every gradient workgroup polls nblk x ceil((P4 + 8) / nblk) slab words with its parameters-per-thread x 512 lanes)
   if (nblk > 1 && P4 + 8 + nblk - 1 > UPD_NPT_WIDE * 512) return 0;

@@ -494,9 +494,6 @@ int64_t ia_ppo_grad_offset(const ia_policy_desc* d, int batch);
  * stores the shader clock at its phase boundaries in [0..11]; ia_ppo_update accumulates 100 MHz ticks
  * per step phase in [0..7] and stores the last step's phase clocks in [16..27] (NULL switches it off). */
 int ia_ppo_debug_timing(void* device_buffer_16xi64);
-/* Tuning/tests: 1 = use the VALU (thread-per-row) gradient and rollout-step kernels also for
- * hidden = 32 instead of the MFMA 16x16x4 ones (hidden = 64 always uses the VALU kernels). */
-int ia_ppo_force_valu(int on);
 /* Tuning / measurement: 1 = `ia_ppo_epoch` keeps two launches per minibatch for 64-wide towers (default 0: one launch
  * per epoch, the minibatch steps as phases of a co-resident grid; a row block's two towers
  * are two four-wave workgroups with the tower's parameters resident in LDS when that fits); 2 = one launch per epoch

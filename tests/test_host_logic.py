@@ -525,7 +525,7 @@ def test_production_kernels_do_not_spill():
         # (the one-workgroup row-sharded forms keep a handful of kernel-argument SGPRs -- the peers' receive areas -- in
         #  20 bytes of scratch: scalar traffic once per step, no vector register among it)
         assert k["vgpr_spill"] == 0 and k["scratch"] <= (32 if sharded else 0), k
-    for sub in ("disc_fb_kernel", "disc_gp_kernel", "policy_rollout_mailbox_kernel", "policy_logits_mailbox_kernel",
+    for sub in ("disc_fb_kernel", "disc_gp_kernel", "policy_rollout_mailbox_kernel", "policy_logits_mailbox_mfma_kernel",
                 "disc_fwd_kernel", "disc_bwd_kernel", "airl_rows_kernel", "disc32_rows_kernel", "policy_act_mfma_kernel",
                 "ia_gemm_kernel", "ia_gemm_tn_side_kernel", "conv1_fwd_kernel", "conv1_wgrad_kernel",
                 "ppo_epoch_persistent_kernel", "ppo_epoch_ll_kernel", "ppo_grad_mfma_kernel", "disc_reduce_kernel"):
@@ -533,6 +533,12 @@ def test_production_kernels_do_not_spill():
         assert ks, sub
         for k in ks:
             assert k["vgpr_spill"] == 0, (sub, k)
+    # round 5's 64-wide epoch kernel (one wave per SIMD, up to 512 registers): one value moves to an accumulator register and
+    # back (the notes count that as a spill) -- what matters is that nothing goes to scratch MEMORY
+    ks = find("ppo_epoch_ll2_kernel")
+    assert len(ks) == 2
+    for k in ks:
+        assert k["scratch"] == 0 and k["vgpr_spill"] <= 2, k
 
 
 @pytest.mark.parametrize("shape", [(8, 2), (1024, 6), (5, 13), (3, 1)])
