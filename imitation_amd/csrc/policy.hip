@@ -2252,10 +2252,6 @@ __device__ __forceinline__ void mfma32_minibatch_chain(
   __syncthreads();   // every row's activations and activation gradients are in LDS
   IA_TS(6);
 
-  // (Round 5, measured and dropped: the six tiles of a step with ONE useful row / column -- value head, second first-layer
-  //  K tile at obs 17 -- as VALU dots with the head tiles moved to the waves that lost a tile, <= 64 MFMAs per SIMD instead
-  //  of 96: 15.50 -> 15.50 us per step at config P, +1-2 % on the one-workgroup forms. The phase is bound by its LDS reads
-  //  and dependent chains, not by MFMA issue: `profiles/r05_ppo_ab.md`.)
   // ---- gradient tiles: contractions over all 64 rows, independent per wave. Every tile requests its
   // 32 LDS operands first and then runs its 16 dependent MFMAs (the compiler otherwise pairs each
   // MFMA with its two reads and exposes an LDS round trip per step).
@@ -2366,19 +2362,60 @@ __device__ __forceinline__ void mfma32_minibatch_chain(
     s += __shfl_xor(s, 32, 64);
     if (lane < 32) put(dst + lane, s);
   };
+  // Round 5: six of the twenty 16 x 16 x 64 tiles of a step produce ONE useful row or column (the value head's weight
+  // gradient: two tiles for 32 numbers; at obs 17 the second K tile of both towers' first layer: four tiles for 2 x 32
+  // numbers). With several gradient workgroups (TILES2) those products are VALU dots -- a lane per (feature, row half):
+  // sixteen ds_read_b128 and 32 fused multiply-adds -- and the policy head's two tiles sit on the waves whose first-layer
+  // tile went away (q = 1, 3): <= 64 MFMAs on every SIMD instead of 96 on two of them. Same-box bisect over the round's
+  // versions (`profiles/r05_ppo_ab.md`): together with the 16-byte prefetch and the fast Adam 15.61 -> 15.13 us per step at
+  // config P, those two alone 15.55; the one-workgroup forms measure 1-2 % SLOWER with the dots and keep the tiles.
+  constexpr bool TILES2 = !LOCAL;
+  const int KTg = (D + 15) >> 4;
+  const bool narrow = TILES2 && KTg == 2 && D - 16 <= 4;   // (launch-constant) the first layer's second K tile holds <= 4 columns
+  auto dot32 = [&](const float* __restrict__ U /* [32 features][RS] */, const float* __restrict__ vrow /* [RS] */) {
+    const float* up = U + (lane & 31) * L::RS + (lane >> 5) * 32;
+    const float* vp = vrow + (lane >> 5) * 32;
+    f32x4 u[8], w[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      u[i] = rd4(up + 4 * i);
+      w[i] = rd4(vp + 4 * i);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      s0 = __builtin_fmaf(u[i][0], w[i][0], s0);
+      s1 = __builtin_fmaf(u[i][1], w[i][1], s1);
+      s0 = __builtin_fmaf(u[i][2], w[i][2], s0);
+      s1 = __builtin_fmaf(u[i][3], w[i][3], s1);
+    }
+    float sm = s0 + s1;
+    sm += __shfl_xor(sm, 32, 64);
+    return sm;   // (lanes j and j + 32: feature j's sum over the 64 rows)
+  };
   if (tw == 0) {
-    if (q < 2) {  // dWa[a][h] = sum_r dout[r][a] a2[r][h], 16 h-columns per wave
-      const f32x4 g = outer16(lds + L::dout, li, a2t, q * 16 + li);
+    const bool head_tile = TILES2 ? (q & 1) != 0 : q < 2;   // dWa[a][h] = sum_r dout[r][a] a2[r][h], 16 h-columns per wave
+    if (head_tile) {
+      const int ht = TILES2 ? q >> 1 : q;
+      const f32x4 g = outer16(lds + L::dout, li, a2t, ht * 16 + li);
 #pragma unroll
       for (int r = 0; r < 4; ++r)
-        if (lk * 4 + r < A) put(slab + (o.aW + (lk * 4 + r) * H + q * 16 + li), g[r]);
+        if (lk * 4 + r < A) put(slab + (o.aW + (lk * 4 + r) * H + ht * 16 + li), g[r]);
     }
     if (q == 2) colsum64(lds + L::dout, A, slab + o.ab);
-    if (q == 3 && !d.discrete) colsum64(lds + L::aux, A, slab + o.log_std);
+    if (q == (TILES2 ? 0 : 3) && !d.discrete) colsum64(lds + L::aux, A, slab + o.log_std);
   } else {
-    if (q < 2) {  // dcW[h] = sum_r dv[r] a2[r][h]  (only output row 0 is meaningful: the dvalue column feeds M index 0)
-      const f32x4 g = outer16(lds + L::misc + L::RS, 0, a2t, q * 16 + li);   // (every lane reads column 1; rows m > 0 unused)
-      if (lk == 0) put(slab + (o.cW + q * 16 + li), g[0]);
+    if constexpr (TILES2) {
+      if (q == 1) {  // dcW[h] = sum_r dv[r] a2[r][h]: 32 numbers
+        const float sm = dot32(a2t, lds + L::misc + L::RS);
+        if (lane < 32) put(slab + (o.cW + lane), sm);
+      }
+    } else {
+      if (q < 2) {  // dcW[h] = sum_r dv[r] a2[r][h]  (only output row 0 is meaningful: the dvalue column feeds M index 0)
+        const f32x4 g = outer16(lds + L::misc + L::RS, 0, a2t, q * 16 + li);   // (every lane reads column 1; rows m > 0 unused)
+        if (lk == 0) put(slab + (o.cW + q * 16 + li), g[0]);
+      }
     }
     if (q == 2) {  // cb = sum_r dv[r]; statpart slots {0 pg, 2 ent, 3 kl, 4 clip, 1 value} <- misc columns 2..6
       // columns 1..6 of the misc tile summed together: lane c < 6 handles column 1 + c
@@ -2416,7 +2453,7 @@ __device__ __forceinline__ void mfma32_minibatch_chain(
         for (int r = 0; r < 4; ++r) put(slab + (oW1 + (jt * 16 + lk * 4 + r) * D + col), g[r]);
     };
     f32x4 g2;
-    if (q < 2 * KT) {   // (wave-uniform)
+    if (q < 2 * KT && !(narrow && (q & 1))) {   // (wave-uniform; narrow: tiles (jt, kt = 1) are the VALU dots below)
       const int jt = q / KT, kt = q - jt * KT;
       f32x4 g1;
       outer16_pair(dz2t, jt2 * 16 + li, a1t, kt2 * 16 + li, dz1t, jt * 16 + li, lds + L::x, kt * 16 + li, g2, g1);
@@ -2426,6 +2463,11 @@ __device__ __forceinline__ void mfma32_minibatch_chain(
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) put(slab + (oW2 + (jt2 * 16 + lk * 4 + r) * H + kt2 * 16 + li), g2[r]);
+    if (narrow && q == 1)   // dW1[j][16 + c] = sum_r dz1[r][j] x[r][16 + c], c < D - 16 <= 4: all 32 rows j of the tower at once
+      for (int c = 16; c < D; ++c) {
+        const float sm = dot32(dz1t, lds + L::x + c * L::RS);
+        if (lane < 32) put(slab + (oW1 + lane * D + c), sm);
+      }
     if (q == 3) colsum64_wide(dz2t, slab + ob2);
     for (int ti = q + 4; ti < 2 * KT; ti += 4) {   // observation widths beyond 32 columns: further dW1 tiles
       const int jt = ti / KT, kt = ti - jt * KT;

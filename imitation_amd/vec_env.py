@@ -166,6 +166,12 @@ class GymStyleVecEnv(VecEnv):
     def seed(self, seed=None):
         return self._env.seed(seed)
 
+    def set_lookahead(self, steps: int) -> None:
+        # (the synthetic env's own draw-ahead horizon: forwarded so that BOTH protocols step the same environment at the
+        #  same cost -- what differs between them is then the dict protocol alone)
+        if hasattr(self._env, "set_lookahead"):
+            self._env.set_lookahead(steps)
+
     def step_async(self, actions):
         self._env.step_async(actions)
 
