@@ -413,6 +413,12 @@ class PPO(OnPolicyAlgorithm):
         # `np.random.randint` rows its discriminator round will draw behind this update's permutations (argument: rows of
         # the rollout) -- the permutation helper's C call draws them too, on a copy of the generator
         self.randint_spec_for_round = None
+        # hook of the pipelined adversarial trainer (`adversarial/common.py: _round_predraw`), called right behind the
+        # rollout's noise draw -- where the host waits for the previous update anyway: what the coming discriminator round
+        # will take from torch's global CPU generator (expert index rows, interpolation weights) is drawn THERE, in the order
+        # the round itself draws it, when the whole rollout's noise has been taken in one draw (nothing else reads that
+        # generator until the round: the condition `predraw_noise` states)
+        self.after_noise_predraw = None
         self._post_enqueue_work = []
         self._act_stream = None
         self.rollout_post_ahead = True   # (tuning / A-B: False posts a mailbox step only at the top of its own iteration)
@@ -647,6 +653,8 @@ class PPO(OnPolicyAlgorithm):
                         rb.h_noise_tile = th.zeros(T, n, width).pin_memory()
                     noise_tile = rb.h_noise_tile
                     pol.draw_noise_into(noise_tile)
+                    if self.after_noise_predraw is not None and not hooked:   # (no user code inside the step loop)
+                        self.after_noise_predraw()
                 predrawn = noise_tile.dim() == 3
                 act_step = pol.make_act_step(rb.h_obs, noise_tile, rb.acts, rb.h_clip, rb.val, rb.logp)  # eval mode: no norm update
                 # ONE resident launch for the rollout's T act steps, driven through flags in pinned host memory: a step
@@ -794,7 +802,7 @@ class PPO(OnPolicyAlgorithm):
         else:
             rb.rew.copy_(rb.h_rew, non_blocking=True)
         if rw is not None:
-            if fused_net is not None and self.enqueue_first:
+            if (fused_net is not None or module_net is not None) and self.enqueue_first:
                 # episode-return bookkeeping needs the relabelled rewards on the host but nothing on the
                 # device needs it: copy now, consume after the PPO update has been enqueued
                 rb.h_rew.copy_(rb.rew, non_blocking=True)

@@ -101,7 +101,7 @@ def _csv_rows(path):
     return [{k: v for k, v in r.items() if not k.startswith(("time/", "mean/gen/time/", "raw/gen/time/"))} for r in rows]
 
 
-@pytest.mark.parametrize("case", ["gail_box", "airl_box", "gail_fused", "gail_fused_wide"])
+@pytest.mark.parametrize("case", ["gail_box", "airl_box", "gail_fused", "gail_fused_wide", "gail_image", "gail_box+module"])
 def test_pipelined_rounds_are_bit_identical(tmp_path, case):
     """Round r's discriminator updates run behind round r+1's environment stepping (GAIL; AIRL with the
     per-update feature statistics taken from the merge snapshots). Every array, every logged statistic
@@ -115,10 +115,13 @@ def test_pipelined_rounds_are_bit_identical(tmp_path, case):
     # (pipelined; pipelined with every round's log row written late -- behind the next round's enqueue, as happens by itself
     #  when a round's updates outlast the next PPO enqueue; strictly sequential)
     #  "behind": the updates enqueued after `learn` has returned instead of right behind the PPO launch
+    # "+module": the `nn.Module` reward nets (operator boundary) -- they and the image policy (GAIL) joined the overlapped
+    # schedules in round 5
+    case, module_net = case.split("+")[0], case.endswith("+module")
     for mode in (True, "late", "behind", False):
         cfg = harness.CASES[case]
         d = str(tmp_path / f"log_{mode}")
-        tr, _ = harness.build_trainer("hip", cfg, d, device="cuda")
+        tr, _ = harness.build_trainer("hip", cfg, d, device="cuda", module_net=module_net)
         tr._logger = p.configure_logger(d, ["csv"])
         tr.gen_algo.set_logger(tr.logger)
         tr.pipeline_rounds = bool(mode)
@@ -198,6 +201,46 @@ def test_round_of_updates_in_one_call_is_bit_identical(tmp_path, case, penalty):
         assert np.array_equal(np.asarray(outs[True][k]), np.asarray(outs[False][k]), equal_nan=True), k
     for f in logs[True]:
         assert logs[True][f] == logs[False][f], f
+
+
+@pytest.mark.parametrize("case,penalty", [("gail_fused", 0.0), ("gail_fused", 4.0), ("gail_box", 0.0), ("airl_tuned_hps", 3.0)])
+def test_round_draws_behind_the_rollout_noise_are_bit_identical(tmp_path, case, penalty):
+    """Pipelined rounds whose discriminator updates are what the next relabelling waits for take the round's draws from
+    torch's global CPU generator (expert index rows, interpolation weights) right behind the rollout's noise draw instead of
+    between the PPO launch and the round's enqueue (`AdversarialTrainer._round_predraw`): same draws, same order -> every
+    array, the penalty's mean and every log row bit for bit."""
+    import glob
+
+    import imitation_amd as p
+
+    outs, logs, pre = {}, {}, {}
+    for mode in ("always", False):
+        cfg = harness.CASES[case]
+        d = str(tmp_path / f"log_{mode}")
+        tr, _ = harness.build_trainer("hip", cfg, d, device="cuda")
+        tr._logger = p.configure_logger(d, ["csv"])
+        tr.gen_algo.set_logger(tr.logger)
+        tr.predraw_round_draws = mode
+        tr.disc_grad_penalty_coef = penalty
+        th.manual_seed(78)
+        tr.train(4 * cfg["n_envs"] * cfg["n_steps"])
+        th.cuda.synchronize()
+        outs[mode] = harness.snapshot(tr)
+        if penalty:
+            outs[mode]["last_grad_penalty"] = float(tr.last_grad_penalty)
+        pre[mode] = tr.round_draws_predrawn
+        assert not tr._pre_expert_rows and tr._gp_round_pre is None
+        tr.logger.close()
+        logs[mode] = {os.path.relpath(f, d): _csv_rows(f) for f in sorted(glob.glob(os.path.join(d, "**", "*.csv"),
+                                                                                recursive=True))}
+    cfg = harness.CASES[case]
+    assert (cfg["n_envs"] * cfg["act_dim"]) % 16 == 0   # (the rollout's noise is one draw: the hook's condition)
+    if True:
+        assert pre["always"] >= 3 and pre[False] == 0, pre   # (every round but the first: no update before its rollout)
+    for k in outs["always"]:
+        assert np.array_equal(np.asarray(outs["always"][k]), np.asarray(outs[False][k]), equal_nan=True), k
+    for f in logs["always"]:
+        assert logs["always"][f] == logs[False][f], f
 
 
 @pytest.mark.parametrize("case", ["gail_box", "gail_f64", "airl_box", "gail_generic_vecenv", "gail_tuned_hps", "gail_cartpole",
