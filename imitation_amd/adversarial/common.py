@@ -248,6 +248,10 @@ class AdversarialTrainer(abc.ABC):
         # update's own `evaluate_actions` would have seen taken from the merge snapshots.
         self._overlap_beside_ppo = self._overlap and not self._needs_logp
         self._disc_stream = L.side_stream(self._device, "disc") if self._overlap else None
+        # (Measured and dropped for the image policy, whose rollout step is a chain of ~10 ordinary launches that queue behind
+        #  the reward CNN's millisecond kernels: a CU-masked discriminator stream -- hipExtStreamCreateWithCUMask, 32 or 64 CUs
+        #  left free. The updates ran 30 % slower on it (23.3 -> 30.4 ms per round's updates) for 12-25 % fewer CUs and the
+        #  round lost more than the act steps gained: profiles/r05_image_gail.md.)
         self._in_overlap = False
         self._gen_stored_early = False
         self._overlap_k = 0
