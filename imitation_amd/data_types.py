@@ -188,6 +188,9 @@ class ExpertIndexStream:
         return b
 
 
+_NO_DONE_ORDER: dict = {}
+
+
 def segment_order(dones: np.ndarray) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
     """Row order of a rollout's transitions after `pop_trajectories` + flatten.
 
@@ -202,6 +205,17 @@ def segment_order(dones: np.ndarray) -> Tuple[np.ndarray, np.ndarray, np.ndarray
     """
     dones = np.asarray(dones, dtype=bool)
     T, n = dones.shape
+    if not dones.any():
+        # no episode ended inside the rollout (15 rounds of 16 at the reference's 1 000-step horizons): only in-progress
+        # fragments, by env index, each in time order -- the same array every time, kept per shape
+        order = _NO_DONE_ORDER.get((T, n))
+        if order is None:
+            if len(_NO_DONE_ORDER) > 8:
+                _NO_DONE_ORDER.clear()
+            order = (np.arange(T, dtype=np.int64)[None, :] * n + np.arange(n, dtype=np.int64)[:, None]).reshape(-1)
+            _NO_DONE_ORDER[(T, n)] = order
+        empty = np.zeros(0, dtype=np.int64)
+        return order.copy(), empty, empty   # (callers own their array)
     t_idx, e_idx = np.nonzero(dones)               # sorted by t then e: exactly the completion order
     # start step of each completed segment = previous done step of the same env + 1
     prev_done = np.full((T, n), -1, dtype=np.int64)

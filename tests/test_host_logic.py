@@ -128,7 +128,7 @@ def test_segment_order_random_done_patterns():
     rng = np.random.default_rng(3)
     for _ in range(20):
         T, n = int(rng.integers(1, 12)), int(rng.integers(1, 9))
-        dones = rng.random((T, n)) < 0.3
+        dones = rng.random((T, n)) < (0.3 if _ % 4 else 0.0)   # (every fourth pattern: no episode end -- the cached order)
         order, _, _ = dt.segment_order(dones)
         assert sorted(order.tolist()) == list(range(T * n))
         # brute-force reference order
