@@ -112,10 +112,29 @@ class _PermutationPredraw:
         self._rc = 0
         self._out: Optional[np.ndarray] = None
         self._rr = self._rr_armed = None
+        self._bg = None
+
+    # The state of NumPy's global generator is read, compared and moved DIRECTLY in the bit generator's `mt19937_state`
+    # (`uint32 key[624]; int pos;` at `_bit_generator.ctypes.state_address`): `np.random.get_state()` / `set_state()` cost
+    # ~20-45 us each (tuple + array copies, validation) and sat between the last environment step and the PPO launch
+    # (`finish`), ahead of the discriminator round's enqueue (`take_randint`) and at the top of the rollout (`start`).
+    _STATE_BYTES = 624 * 4 + 4
 
     @staticmethod
-    def _same(a, b) -> bool:
-        return a[0] == b[0] and a[2:] == b[2:] and np.array_equal(a[1], b[1])
+    def _global_mt():
+        """(bit generator, address of its mt19937_state) of NumPy's global `RandomState`, or None when it is not MT19937."""
+        bg = getattr(np.random.mtrand._rand, "_bit_generator", None)
+        if type(bg).__name__ != "MT19937":
+            return None
+        return bg, int(bg.ctypes.state_address)
+
+    def _raw_state(self, addr: int) -> bytes:
+        return C.string_at(addr, self._STATE_BYTES)
+
+    @staticmethod
+    def _move_global(addr: int, key: np.ndarray, pos: int) -> None:
+        C.memmove(addr, key.ctypes.data, 624 * 4)
+        C.c_int.from_address(addr + 624 * 4).value = int(pos)
 
     def start(self, out: np.ndarray, randint_spec=None) -> None:
         """`randint_spec = (high, rows, row_len)` (optional): behind the permutations the SAME C call draws, on a copy of the
@@ -123,13 +142,15 @@ class _PermutationPredraw:
         discriminator updates (`take_randint`)."""
         assert out.dtype == np.int64 and out.flags.c_contiguous and out.shape == (self.n_epochs, self.size)
         self._rr = None
-        st = np.random.get_state()
-        if st[0] != "MT19937":
+        mt = self._global_mt()
+        if mt is None:
             self._thread = None
             return
-        self._state0 = st
-        self._key = np.ascontiguousarray(st[1], dtype=np.uint32).copy()
-        self._pos = C.c_int(int(st[2]))
+        self._bg, addr = mt
+        raw = self._raw_state(addr)
+        self._state0 = raw
+        self._key = np.frombuffer(raw, dtype=np.uint32, count=624).copy()
+        self._pos = C.c_int(int.from_bytes(raw[624 * 4:], sys.byteorder, signed=True))
         self._out = out
         lib = L.load()
         if randint_spec is not None:
@@ -160,10 +181,11 @@ class _PermutationPredraw:
         if t is None:
             return False
         t.wait()
-        if self._rc != 0 or out is not self._out or not self._same(np.random.get_state(), self._state0):
+        mt = self._global_mt()
+        if (self._rc != 0 or out is not self._out or mt is None or mt[0] is not self._bg
+                or self._raw_state(mt[1]) != self._state0):
             return False
-        s0 = self._state0
-        np.random.set_state((s0[0], self._key, int(self._pos.value), s0[3], s0[4]))
+        self._move_global(mt[1], self._key, self._pos.value)
         self._rr_armed = self._rr   # (valid while the global generator stays where this call has just put it)
         return True
 
@@ -174,10 +196,14 @@ class _PermutationPredraw:
         rr, self._rr_armed = getattr(self, "_rr_armed", None), None
         if rr is None or rr["spec"] != (int(high), int(rows), int(row_len)):
             return None
-        st = np.random.get_state()
-        if st[0] != "MT19937" or int(st[2]) != int(self._pos.value) or not np.array_equal(st[1], self._key):
+        mt = self._global_mt()
+        if mt is None or mt[0] is not self._bg:
             return None
-        np.random.set_state((st[0], rr["key"], int(rr["pos"].value), st[3], st[4]))
+        raw = self._raw_state(mt[1])
+        if (int.from_bytes(raw[624 * 4:], sys.byteorder, signed=True) != int(self._pos.value)
+                or raw[:624 * 4] != self._key.tobytes()):
+            return None
+        self._move_global(mt[1], rr["key"], rr["pos"].value)
         return rr["rows"]
 
 

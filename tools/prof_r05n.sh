@@ -1,7 +1,12 @@
 set -x
 cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp; O=gpurun_out/r05n; mkdir -p $O; rm -f $O/*.txt
-timeout 900 python -m pytest tests/test_disc_fused_gpu.py tests/test_grad_penalty_gpu.py tests/test_adversarial_gpu.py -m gpu -q -x -k "penalty or gp or one_call or round_draws" > $O/pytest.txt 2>&1; tail -4 $O/pytest.txt | cut -c1-200
-for V in P_gp10 P_ant_gail_d35_gp10; do python tools/ab_rounds.py $V lib.ia_disc_fused_tn_pair=1,0 100 3 2>&1 | grep ms/round | cut -c1-100; done > $O/ab_pair.txt; cat $O/ab_pair.txt
-rocprofv3 --kernel-trace --stats -d $O/kt_gp -- python tools/variant_profile.py P_gp10 6 > $O/kt_gp.log 2>&1
-DB=$(find $O/kt_gp -name "*results.db" | head -1); python tools/rocpd_stats.py $DB $O/kernel_stats_P_gp10.md | head -12 | cut -c1-200
-find $O -name "*.db" -delete
+timeout 900 python -m pytest tests/test_adversarial_gpu.py tests/test_kernels_gpu.py -m gpu -q -x -k "mailbox or golden or act" > $O/pytest.txt 2>&1; tail -4 $O/pytest.txt | cut -c1-200
+for V in P_gp10 P 1_cartpole_8x256_mlp64; do python tools/ab_rounds.py $V lib.ia_rollout_mailbox_sys_out=1,0 100 3 2>&1 | grep ms/round | cut -c1-100; done > $O/ab_sys.txt; cat $O/ab_sys.txt
+for S in 1 0; do python - <<EOF
+import sys; sys.path.insert(0, '.')
+from imitation_amd import _lib as L
+L.load().ia_rollout_mailbox_sys_out($S)
+sys.argv = ['x', '20']
+exec(open('tools/rollout_sections.py').read().split("# device time between")[0])
+EOF
+done 2>&1 | grep -E "us/step|sum" | cut -c1-120
