@@ -160,6 +160,8 @@ _SIGS = {
     "ia_disc_fused_tile_rows": ([_I], C.c_int),
     "ia_disc_fused_split_tiles": ([_I], C.c_int),
     "ia_disc_fused_side_reduce": ([_I], C.c_int),
+    "ia_disc_fused_predict_ws_floats": ([C.POINTER(MlpDesc), _I], C.c_int64),
+    "ia_disc_fused_predict": ([C.POINTER(MlpDesc), _P, _P, _I, _I, _P, _P, _F, _I, _P, _P, _P], C.c_int),
     "ia_disc_assemble_round": ([C.POINTER(DiscStepArgs), _I, _L, _L, _L, _P], C.c_int),
     "ia_disc_fused_prepare": ([C.POINTER(MlpDesc), _P, _I, _I, _P, _P], C.c_int),
     "ia_disc_fused_adam": ([C.POINTER(MlpDesc), _P, _F, _I, _I, _P, _P, _P], C.c_int),

@@ -70,6 +70,7 @@ struct FusedArgs {
   float* gp_C;                                         // [R][ldx] row coefficients d(coef / R sum pen) / d xn
   float* gp_pen;                                       // [tiles] partial sums of (|grad_x D| - target)^2
   float gp_coef, gp_target;
+  int out_act;                                         // disc_fwd_kernel MODE 3 (prediction): activation of the output
 };
 
 // x tile of rows [row0, row0+64): raw X normalised on the fly -> xs[row][ld], columns >= D and rows >= R zero.
@@ -297,7 +298,7 @@ __global__ __launch_bounds__(BM * 8) void disc_fwd_kernel(FusedArgs a) {
     hm_lo = (unsigned int)w1; hm_hi = (unsigned int)(w1 >> 32);
     h2_lo = (unsigned int)w2; h2_hi = (unsigned int)(w2 >> 32);
   }
-  if constexpr (MODE == 0) load_x_tile<BM>(a, a.X, row0, xs, XP, tid);
+  if constexpr (MODE == 0 || MODE == 3) load_x_tile<BM>(a, a.X, row0, xs, XP, tid);
   else if constexpr (MODE == 1) load_x_tile<BM, true>(a, a.X, row0, xs, XP, tid);
   else load_x_tile<BM, false, true>(a, a.gp_C, row0, xs, XP, tid);
   for (int e = tid; e < BM * (24 - a.ldx); e += NT) {  // columns [ldx, 24) of the K = 24 operand
@@ -348,13 +349,15 @@ __global__ __launch_bounds__(BM * 8) void disc_fwd_kernel(FusedArgs a) {
         h1s[row * LDH + col] = v;
         // relu'(h1) for the backward tile kernel: one 64-bit ballot per accumulator register instead of a
         // re-read of the tile; lane (t*16 + r) keeps word (t, r) -> ONE coalesced store per wave below
-        const unsigned long long m = __ballot(v > 0.f);
-        if (lane == t * 16 + r) mword = m;
+        if constexpr (MODE != 3) {
+          const unsigned long long m = __ballot(v > 0.f);
+          if (lane == t * 16 + r) mword = m;
+        }
       }
       acc[t][r] = 0.f;
     }
   }
-  if (MODE != 2 && lane < TN * 16) a.h1mask[((long long)blockIdx.x * NW + wave) * (TN * 16) + lane] = mword;
+  if (MODE != 2 && MODE != 3 && lane < TN * 16) a.h1mask[((long long)blockIdx.x * NW + wave) * (TN * 16) + lane] = mword;
   __syncthreads();   // every wave is done with the W1 image: the ring is the ring from here on
   bstore(0);
   if (NCH > 1) bload(1);
@@ -379,10 +382,10 @@ __global__ __launch_bounds__(BM * 8) void disc_fwd_kernel(FusedArgs a) {
       const int e2 = c * NT + tid;
       const int hrow = e2 / (H / 2), hcol = (e2 % (H / 2)) * 2;
       float2 hv;
-      if constexpr (MODE != 1) { hv.x = h1s[hrow * LDH + hcol]; hv.y = h1s[hrow * LDH + hcol + 1]; }
+      if constexpr (MODE != 1 && MODE != 3) { hv.x = h1s[hrow * LDH + hcol]; hv.y = h1s[hrow * LDH + hcol + 1]; }
       auto a_at = [&](int ks) { return Ar[c * FB_K + 2 * ks]; };
       chunk_mma<H, TN>(acc, a_at, bs + (c % NS) * BST + boff, lh);
-      if constexpr (MODE != 1) {
+      if constexpr (MODE != 1 && MODE != 3) {
         float* dst = row0 + hrow < a.R ? a.h1 + (long long)(row0 + hrow) * H + hcol : a.dump + 2 * tid;
         *reinterpret_cast<float2*>(dst) = hv;
       }
@@ -464,6 +467,15 @@ __global__ __launch_bounds__(BM * 8) void disc_fwd_kernel(FusedArgs a) {
   }
   __syncthreads();
   FUSED_STAMP(a, 5);
+  if constexpr (MODE == 3) {
+    // ---- prediction (`RewardNet.predict_th` of the rows, `rewards/reward_nets.py:176-204`): the output, through its
+    //      activation (GAIL's generator reward: softplus, `gail.py:75-83`), is all that leaves the tile
+    if (wave == 0 && lane < BM && row0 + lane < a.R) {
+      const float x = ((red[lane] + red[BM + lane]) + red[2 * BM + lane]) + red[3 * BM + lane] + b3v;
+      a.logits[row0 + lane] = ia_apply_act(x, a.out_act);
+    }
+    return;
+  }
   if (wave == 0) {  // one row per lane (lanes >= BM idle but take part in the reduction)
     const int row = min(lane, BM - 1);
     const int gi = row0 + row;
@@ -1940,6 +1952,55 @@ extern "C" int ia_disc_fused_prepare(const ia_mlp_desc* d, const float* params, 
   hipLaunchKernelGGL(disc_assemble_kernel, dim3((H / 64) * (H / 64) + 1), dim3(AS_NT), 0, (hipStream_t)stream, as);
   IA_CHECK_LAUNCH();
   return IA_OK;
+}
+
+// PREDICTION on the tile kernel: out[r] = act(MLP(normalise(X[r]))) for R assembled rows -- `RewardNet.predict_th` of a
+// whole rollout tile (`rewards/reward_nets.py:176-204`; the relabelling behind the rollout's last step,
+// `rewards/reward_wrapper.py:110-115`) as TWO launches (weight images of the current parameters, then the forward pass of
+// 64-row tiles with the hidden activations chained through LDS: disc_fwd_kernel<H, 64, 3>) instead of the five of
+// ia_running_norm_apply + ia_mlp_forward, and without the [R, H] activations going out to HBM twice. D <= 24 stacks
+// D -> H -> H -> 1 (ReLU, H = 128 / 256) only: 0 floats of workspace = shape not covered (use ia_mlp_forward).
+extern "C" int64_t ia_disc_fused_predict_ws_floats(const ia_mlp_desc* d, int ldx) {
+  if (fused_dw(d, ldx) != 24 || ia_disc32_shape_ok(d, ldx)) return 0;
+  return fused_ws_layout(d, 64, nullptr).total;
+}
+namespace {
+template <int H>
+int launch_predict_tiles(const FusedArgs& fa, int R, hipStream_t stream) {
+  constexpr int BM = 64;
+  constexpr size_t smem_f = sizeof(float) * (BM * (H + 1) + NS * FB_K * H + 4 * BM + BM + 2 * (BM / 32) * H + BM * XP);
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(disc_fwd_kernel<H, BM, 3>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_f);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((disc_fwd_kernel<H, BM, 3>), dim3(cdivi(R, BM)), dim3(BM * 8), smem_f, stream, fa);
+  IA_CHECK_LAUNCH();
+  return IA_OK;
+}
+}  // namespace
+extern "C" int ia_disc_fused_predict(const ia_mlp_desc* d, const float* params, const float* X, int ldx, int R,
+                                     const float* norm_mean, const float* norm_var, float norm_eps, int out_act,
+                                     float* predict_ws, float* out, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!d || !params || !X || !predict_ws || !out || R <= 0) return IA_ERR_ARG;
+  if (fused_dw(d, ldx) != 24 || ia_disc32_shape_ok(d, ldx)) return IA_ERR_UNSUPPORTED;
+  const int D = d->dims[0], H = d->dims[1];
+  const FusedWs w = fused_ws_layout(d, 64, predict_ws);
+  AssembleArgs as{};
+  as.R = 0; as.D = D; as.ldx = ldx; as.H = H;
+  as.W2 = params + (long long)H * D + H; as.W2T = w.W2T;
+  as.W1 = params; as.W1P = w.W1P; as.xp = XP;
+  hipLaunchKernelGGL(disc_assemble_kernel, dim3((H / 64) * (H / 64) + 1), dim3(AS_NT), 0, stream, as);
+  IA_CHECK_LAUNCH();
+  FusedArgs fa{};
+  fa.X = X; fa.ldx = ldx; fa.R = R; fa.D = D;
+  fa.mean = norm_mean; fa.var = norm_var; fa.eps = norm_eps;
+  fa.params = params; fa.W2T = w.W2T; fa.W1P = w.W1P;
+  fa.logits = out; fa.dump = w.dump; fa.out_act = out_act;
+  return H == 256 ? launch_predict_tiles<256>(fa, R, stream) : launch_predict_tiles<128>(fa, R, stream);
 }
 
 // Data-parallel tail of a fused update (see disc_adam_refresh_kernel): adam->grads holds the all-reduced (summed)

@@ -9,6 +9,7 @@ from __future__ import annotations
 
 import contextlib
 import ctypes as C
+import os
 from typing import Dict, Iterator, List, Optional, Sequence, Tuple
 
 import numpy as np
@@ -308,8 +309,31 @@ class DenseStack:
             ws["partials"] = th.empty(ws["splits"], self.n_params, device=dev)
         return ws
 
-    def forward_rows(self, ws: Dict[str, th.Tensor], R: int, out_act: int = L.ACT_NONE) -> th.Tensor:
-        """Runs the stack on `ws["X"][:R]` (already assembled). Returns `ws["out"]` `[R, out]`."""
+    # prediction of whole tiles (the reward relabelling behind a rollout) on the fused tile kernel where its shape is covered
+    # (`ia_disc_fused_predict`: D <= 24 -> H -> H -> 1, ReLU, H = 128 / 256); False: always the layer-by-layer launches
+    FUSED_PREDICT = os.environ.get("IA_FUSED_PREDICT", "1") != "0"
+
+    def _predict_ws(self) -> Optional[th.Tensor]:
+        ws = getattr(self, "_pred_ws", False)
+        if ws is False:
+            n = 0
+            if len(self.dims) == 4 and self.dims[-1] == 1 and (self.norm is None or self.norm.is_chan):
+                n = int(L.load().ia_disc_fused_predict_ws_floats(C.byref(self.desc), self.ldx))
+            ws = self._pred_ws = th.zeros(n, device=self.flat.device) if n > 0 else None
+        return ws
+
+    def forward_rows(self, ws: Dict[str, th.Tensor], R: int, out_act: int = L.ACT_NONE, keep_hidden: bool = True) -> th.Tensor:
+        """Runs the stack on `ws["X"][:R]` (already assembled). Returns `ws["out"]` `[R, out]`. `keep_hidden=False`: the
+        caller will not back-propagate through this pass (predictions): covered shapes take the two-launch tile kernel,
+        which keeps the hidden activations in LDS."""
+        if not keep_hidden and self.FUSED_PREDICT and not (self.norm is not None and self.training):
+            pws = self._predict_ws()
+            if pws is not None:
+                nrm = self.norm
+                L.call("ia_disc_fused_predict", C.byref(self.desc), L.ptr(self.flat), L.ptr(ws["X"]), self.ldx, R,
+                       L.ptr(nrm.running_mean) if nrm is not None else None, L.ptr(nrm.running_var) if nrm is not None else None,
+                       float(nrm.eps) if nrm is not None else 0.0, out_act, L.ptr(pws), L.ptr(ws["out"]), L.stream())
+                return ws["out"]
         x = ws["X"]
         if self.norm is not None:
             if self.training:

@@ -259,7 +259,7 @@ class BasicRewardNet(RewardNet):
         R = sum(n for _, _, n in sources)
         ws = self.mlp.workspace(R, tag)
         self._assemble(sources, ws)
-        return self.mlp.forward_rows(ws, R, out_act).reshape(R)
+        return self.mlp.forward_rows(ws, R, out_act, keep_hidden=False).reshape(R)
 
     def disc_forward(self, sources, mb_rows, logp):
         R = sum(n for _, _, n in sources)

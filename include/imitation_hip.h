@@ -223,6 +223,16 @@ int ia_disc_fused_split_tiles(int on);
  * on the split-K product dW2 (first / last layer, b2, the statistics row) runs as the leading workgroups of that
  * product's launch; 0 = the whole reduction in its own launch behind the product. Outputs are bit-identical. */
 int ia_disc_fused_side_reduce(int on);
+/* Prediction on the fused tile kernel: out[r] = out_act(MLP(normalise(X[r, :D]))) for R assembled rows of a D -> H -> H -> 1
+ * ReLU stack (D <= 24, H = 128 / 256) -- `RewardNet.predict_th` of a whole rollout tile (rewards/reward_nets.py:176-204),
+ * i.e. the reward relabelling behind a rollout's last step (rewards/reward_wrapper.py:110-115; GAIL: out_act = IA_ACT_SOFTPLUS,
+ * algorithms/adversarial/gail.py:75-83) -- in two launches, the hidden activations never leaving LDS; replaces
+ * ia_running_norm_apply + ia_mlp_forward on these shapes (the same fp32 MFMA products; the values differ from that path's by
+ * <= 1e-7 relative, tests/test_disc_fused_gpu.py). norm_mean == NULL: no input
+ * normalisation. predict_ws: ia_disc_fused_predict_ws_floats(d, ldx) floats (0 = shape not covered; IA_ERR_UNSUPPORTED). */
+int64_t ia_disc_fused_predict_ws_floats(const ia_mlp_desc* d, int ldx);
+int ia_disc_fused_predict(const ia_mlp_desc* d, const float* params, const float* X, int ldx, int R, const float* norm_mean,
+                          const float* norm_var, float norm_eps, int out_act, float* predict_ws, float* out, void* stream);
 
 /* Gradient penalty on the discriminator (OPT-IN extension, default off: BASELINE.json config 3 / the north star name
  * it, the reference has none -- SURVEY M1): E[(|grad_x D(x_hat)|_2 - target)^2] at x_hat = e x_expert + (1-e) x_gen.
