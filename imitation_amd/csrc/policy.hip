@@ -75,12 +75,25 @@ struct Lds {
 
 // Branch-free tanh: odd polynomial for |x| <= 0.1 (rel. error < 1e-9), 1 - 2/(exp(2|x|)+1) otherwise
 // (v_exp_f32 / v_rcp_f32: ~1 ulp each). libm's tanhf costs ~45 instructions and divergent branches.
+// Written with explicit fused multiply-adds (the file is built with -ffp-contract=off: as plain expressions the
+// polynomial was 3 mul + 3 add, the exponent (|x| + |x|) * log2(e) an add + a mul, 1 - 2 r a mul + a sub -- 16 VALU
+// instructions + the two transcendentals per value, 8 values per lane and layer on the PPO chain): 11 + 2. The exponent
+// and 1 - 2 r are the same bits as before (scaling by two is exact); the polynomial rounds three times less.
+#ifndef IA_TANH_FMA
+#define IA_TANH_FMA 1
+#endif
 __device__ __forceinline__ float fast_tanh(float x) {
   const float ax = fabsf(x);
   const float x2 = x * x;
+#if IA_TANH_FMA
+  const float poly = x * __builtin_fmaf(x2, __builtin_fmaf(x2, __builtin_fmaf(x2, -0.05396825f, 0.13333334f), -0.33333334f), 1.f);
+  const float e = __builtin_amdgcn_exp2f(ax * 2.8853900817779268f);   // = exp2((|x| + |x|) * log2(e)), bit for bit
+  const float big = copysignf(__builtin_fmaf(-2.f, __builtin_amdgcn_rcpf(e + 1.f), 1.f), x);
+#else
   const float poly = x * (1.f + x2 * (-0.33333334f + x2 * (0.13333334f + x2 * -0.05396825f)));
   const float e = __expf(2.f * ax);
   const float big = copysignf(1.f - 2.f * __builtin_amdgcn_rcpf(e + 1.f), x);
+#endif
   return ax <= 0.1f ? poly : big;
 }
 
