@@ -197,6 +197,10 @@ def save_checkpoint(trainer, path) -> None:
     algo = trainer.gen_algo
     if trainer.venv_buffering.n_transitions:
         raise RuntimeError("checkpoint only at a round boundary (the buffering wrapper still holds transitions)")
+    if getattr(trainer, "_pre_expert_rows", None) or getattr(trainer, "_gp_round_pre", None) is not None:
+        # (draws taken ahead for a round that did not run to its end -- `AdversarialTrainer._round_predraw`: the generator
+        #  is already behind them, a resumed run would draw them a second time)
+        raise RuntimeError("checkpoint only at a round boundary (a round's index rows are drawn but not consumed)")
     th.cuda.synchronize()
     net, opt, ring = trainer._reward_net, trainer._disc_opt, trainer._gen_replay_buffer
     es = getattr(trainer, "_expert_stream", None)
