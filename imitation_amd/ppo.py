@@ -123,10 +123,13 @@ class _PermutationPredraw:
     @staticmethod
     def _global_mt():
         """(bit generator, address of its mt19937_state) of NumPy's global `RandomState`, or None when it is not MT19937."""
-        bg = getattr(np.random.mtrand._rand, "_bit_generator", None)
-        if type(bg).__name__ != "MT19937":
+        try:   # (private attributes of NumPy: without them the speculation is off and every draw happens in place)
+            bg = getattr(np.random.mtrand._rand, "_bit_generator", None)
+            if type(bg).__name__ != "MT19937":
+                return None
+            return bg, int(bg.ctypes.state_address)
+        except AttributeError:
             return None
-        return bg, int(bg.ctypes.state_address)
 
     def _raw_state(self, addr: int) -> bytes:
         return C.string_at(addr, self._STATE_BYTES)
