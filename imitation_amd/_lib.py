@@ -62,6 +62,18 @@ class AirlUpdateArgs(C.Structure):
                                            "gp_ticket")])
 
 
+class RolloutTailArgs(C.Structure):
+    """Mirror of `ia_rollout_tail_args` (include/imitation_hip.h)."""
+    _fields_ = ([(n, C.c_void_p) for n in ("obs", "act_f32", "act_i64", "next_obs", "dones")] +
+                [(n, C.c_int) for n in ("obs_dim", "act_dim", "use_state", "use_action", "use_next_state", "use_done")] +
+                [("X", C.c_void_p), ("ldx", C.c_int), ("desc", C.POINTER(MlpDesc))] +
+                [(n, C.c_void_p) for n in ("params", "norm_mean", "norm_var")] + [("norm_eps", C.c_float), ("out_act", C.c_int)] +
+                [(n, C.c_void_p) for n in ("predict_ws", "rewards", "rewards_host", "values", "episode_starts", "last_values",
+                                           "last_dones")] +
+                [("T", C.c_int), ("n", C.c_int), ("gamma", C.c_float), ("gae_lambda", C.c_float)] +
+                [("advantages", C.c_void_p), ("returns", C.c_void_p)])
+
+
 class DiscStepArgs(C.Structure):
     """Mirror of `ia_disc_step_args` (include/imitation_hip.h)."""
     _fields_ = ([("desc", C.POINTER(MlpDesc))] +
@@ -160,6 +172,7 @@ _SIGS = {
     "ia_disc_fused_tile_rows": ([_I], C.c_int),
     "ia_disc_fused_split_tiles": ([_I], C.c_int),
     "ia_disc_fused_side_reduce": ([_I], C.c_int),
+    "ia_rollout_tail": ([C.POINTER(RolloutTailArgs), _P], C.c_int),
     "ia_disc_fused_predict_ws_floats": ([C.POINTER(MlpDesc), _I], C.c_int64),
     "ia_disc_fused_predict": ([C.POINTER(MlpDesc), _P, _P, _I, _I, _P, _P, _F, _I, _P, _P, _P], C.c_int),
     "ia_disc_assemble_round": ([C.POINTER(DiscStepArgs), _I, _L, _L, _L, _P], C.c_int),

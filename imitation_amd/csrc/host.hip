@@ -8,6 +8,7 @@
 #include <immintrin.h>
 
 #include "common.h"
+#include "../../include/imitation_hip.h"
 
 namespace {
 
@@ -247,4 +248,29 @@ extern "C" int ia_peer_handshake(int world, int rank, uint32_t token, uint32_t* 
                      (long long)(timeout_s * 1e8), result);
   IA_CHECK_LAUNCH();
   return IA_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The tail of a rollout in ONE host call: relabelling of the whole [T, n] tile by the discriminator-based reward
+// (`rewards/reward_wrapper.py:110-115` per step == once on the tile, since nothing on this path changes between steps:
+// assembly `ia_gather_concat`, prediction `ia_disc_fused_predict`), the rewards' copy to the pinned host tile (episode-return
+// bookkeeping, `rewards/reward_wrapper.py:117-133`), and [SB3 RolloutBuffer.compute_returns_and_advantage] (`ia_gae`) -- the
+// launches of those four calls in their order, nothing else: the Python between them (argument marshalling of ~60 scalars,
+// table views, context managers: ~75 us) sat on the critical path between the last environment step and the PPO launch.
+extern "C" int ia_rollout_tail(const ia_rollout_tail_args* a, void* stream) {
+  if (!a || !a->desc || !a->X || !a->rewards || a->T <= 0 || a->n <= 0) return IA_ERR_ARG;
+  const int rows = a->T * a->n;
+  int rc = ia_gather_concat(a->obs, a->act_f32, a->act_i64, a->next_obs, a->dones, nullptr, rows, a->obs_dim, a->act_dim,
+                            a->use_state, a->use_action, a->use_next_state, a->use_done, a->X, a->ldx, 0, stream);
+  if (rc) return rc;
+  rc = ia_disc_fused_predict(a->desc, a->params, a->X, a->ldx, rows, a->norm_mean, a->norm_var, a->norm_eps, a->out_act,
+                             a->predict_ws, a->rewards, stream);
+  if (rc) return rc;
+  if (a->rewards_host) {
+    hipError_t e = hipMemcpyAsync(a->rewards_host, a->rewards, sizeof(float) * (size_t)rows, hipMemcpyDeviceToHost,
+                                  (hipStream_t)stream);
+    if (e != hipSuccess) return (int)e;
+  }
+  return ia_gae(a->rewards, a->values, a->episode_starts, a->last_values, a->last_dones, a->T, a->n, a->gamma,
+                a->gae_lambda, a->advantages, a->returns, stream);
 }

@@ -448,6 +448,10 @@ class PPO(OnPolicyAlgorithm):
         # the round itself draws it, when the whole rollout's noise has been taken in one draw (nothing else reads that
         # generator until the round: the condition `predraw_noise` states)
         self.after_noise_predraw = None
+        # relabelling + reward copy + GAE behind a rollout's last step as one host call where the reward net allows it
+        # (`_rollout_tail_args`; False: the general path, call by call -- tests compare)
+        self.rollout_tail_one_call = True
+        self._tail_args = None
         self._post_enqueue_work = []
         self._act_stream = None
         self.rollout_post_ahead = True   # (tuning / A-B: False posts a mailbox step only at the top of its own iteration)
@@ -701,6 +705,40 @@ class PPO(OnPolicyAlgorithm):
             if mailbox is not None:
                 mailbox[2]()
 
+    def _rollout_tail_args(self, fused_net, rb, T: int, n: int):
+        """The argument block of `ia_rollout_tail` for this rollout buffer and reward net (built once, re-used while nothing
+        it points at has moved), or None when the reward is not one fused-shape stack (`RewardNet.rollout_tail_plan`)."""
+        plan = fused_net.rollout_tail_plan()
+        if plan is None:
+            return None
+        basic, out_act = plan
+        mlp, nrm = basic.mlp, basic.mlp.norm
+        ws = mlp.workspace(T * n, "rollout")
+        pws = mlp._predict_ws()
+        key = (id(basic), out_act, T, n, basic.flags, ws["X"].data_ptr(), pws.data_ptr(), mlp.flat.data_ptr(),
+               None if nrm is None else (nrm.running_mean.data_ptr(), nrm.running_var.data_ptr(), float(nrm.eps)),
+               rb.obs.data_ptr(), rb.clipped.data_ptr(), rb.next_fixed.data_ptr(), rb.dones.data_ptr(), rb.rew.data_ptr(),
+               rb.h_rew.data_ptr(), rb.val.data_ptr(), rb.starts.data_ptr(), rb.last_val.data_ptr(), rb.last_done.data_ptr(),
+               rb.adv.data_ptr(), rb.ret.data_ptr(), float(self.gamma), float(self.gae_lambda))
+        if self._tail_args is None or self._tail_args[0] != key:
+            a = L.RolloutTailArgs()
+            a.obs, a.act_f32, a.act_i64 = rb.obs.data_ptr(), rb.clipped.data_ptr(), None
+            a.next_obs, a.dones = rb.next_fixed.data_ptr(), rb.dones.data_ptr()
+            a.obs_dim, a.act_dim = basic.obs_dim, basic.act_dim
+            a.use_state, a.use_action, a.use_next_state, a.use_done = (int(f) for f in basic.flags)
+            a.X, a.ldx, a.desc = ws["X"].data_ptr(), mlp.ldx, C.pointer(mlp.desc)
+            a.params = mlp.flat.data_ptr()
+            a.norm_mean = None if nrm is None else nrm.running_mean.data_ptr()
+            a.norm_var = None if nrm is None else nrm.running_var.data_ptr()
+            a.norm_eps, a.out_act = (0.0 if nrm is None else float(nrm.eps)), int(out_act)
+            a.predict_ws, a.rewards, a.rewards_host = pws.data_ptr(), rb.rew.data_ptr(), rb.h_rew.data_ptr()
+            a.values, a.episode_starts = rb.val.data_ptr(), rb.starts.data_ptr()
+            a.last_values, a.last_dones = rb.last_val.data_ptr(), rb.last_done.data_ptr()
+            a.T, a.n, a.gamma, a.gae_lambda = T, n, float(self.gamma), float(self.gae_lambda)
+            a.advantages, a.returns = rb.adv.data_ptr(), rb.ret.data_ptr()
+            self._tail_args = (key, a, mlp.desc)   # (the descriptor object stays alive with its pointer)
+        return self._tail_args[1]
+
     def _upload_permutations_early(self, stream) -> None:
         """The pre-drawn permutations of the update that follows this rollout go to the device as soon as the helper
         thread has them (a side stream, beside the environment stepping). `train()` adopts the upload if it adopts the
@@ -815,6 +853,29 @@ class PPO(OnPolicyAlgorithm):
         self.rollout_window_ms = 1e3 * (tick() - t_first_step)
         if self.before_relabel is not None:
             self.before_relabel()
+        tail = None
+        if (fused_net is not None and rw is not None and self.enqueue_first and self.rollout_tail_one_call and last_val_done
+                and not pol.discrete and not h_trunc_np.any()):
+            tail = self._rollout_tail_args(fused_net, rb, T, n)
+        if tail is not None:
+            # relabelling of the tile, the rewards' copy to the pinned host tile and GAE as ONE host call (`ia_rollout_tail`:
+            # the launches of the general path below, in its order; ~75 us of Python between the last environment step and
+            # the PPO launch otherwise)
+            L.call("ia_rollout_tail", C.byref(tail), L.stream())
+            copied = th.cuda.Event()
+            copied.record()
+            last_obs, dones_host = self._last_obs, h_dones_np.astype(bool)
+
+            def bookkeeping():
+                copied.synchronize()
+                rw.record_rewards(rb.h_rew.numpy().copy(), dones_host, last_obs)
+
+            self._post_enqueue_work.append(bookkeeping)
+            rb.full = True
+            self.rollout_done_event = th.cuda.Event()
+            self.rollout_done_event.record()
+            callback.on_rollout_end()
+            return True
         if fused_net is not None:  # discriminator reward relabelling on the whole [T, n] tile
             acts_tbl = rb.clipped.reshape(T * n).long() if pol.discrete else rb.clipped.reshape(T * n, -1)
             table = TransitionTable(rb.obs[:T].reshape(T * n, -1), acts_tbl, rb.next_fixed.reshape(T * n, -1),

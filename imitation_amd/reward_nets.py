@@ -191,6 +191,12 @@ class RewardNet(abc.ABC):
         with evaluating(self):
             return self._forward_table([(table, None, T * n)], "rollout")
 
+    def rollout_tail_plan(self):
+        """`(BasicRewardNet, output activation)` when `predict_processed_rollout` of this net is, row by row, ONE stack
+        the fused tile kernel covers followed by that activation -- the rollout collector then relabels, copies the
+        rewards out and runs GAE in one host call (`ia_rollout_tail`, `PPO._rollout_tail_args`); None: the general path."""
+        return None
+
     def disc_forward(self, sources, mb_rows: int, logp: Optional[th.Tensor]) -> th.Tensor:
         raise NotImplementedError(f"{type(self).__name__} cannot be trained as a discriminator on the HIP path")
 
@@ -260,6 +266,11 @@ class BasicRewardNet(RewardNet):
         ws = self.mlp.workspace(R, tag)
         self._assemble(sources, ws)
         return self.mlp.forward_rows(ws, R, out_act, keep_hidden=False).reshape(R)
+
+    def rollout_tail_plan(self):
+        if type(self) is not BasicRewardNet or not self.mlp.FUSED_PREDICT or self.mlp._predict_ws() is None:
+            return None   # (a subclass may have its own forward; shapes outside the tile kernel)
+        return self, L.ACT_NONE
 
     def disc_forward(self, sources, mb_rows, logp):
         R = sum(n for _, _, n in sources)

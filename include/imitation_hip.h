@@ -470,6 +470,23 @@ int ia_gae(const float* rewards, const float* values, const float* episode_start
            const float* last_dones, int T, int n, float gamma, float gae_lambda, float* advantages,
            float* returns, void* stream);
 
+/* The tail of a rollout whose reward is a fused-shape discriminator (GAIL: softplus of the logit) in ONE host call: the
+ * launches of ia_gather_concat (identity rows of the [T, n] tile) + ia_disc_fused_predict + the rewards' copy to a pinned
+ * host tile (rewards/reward_wrapper.py:117-133 reads them there; may be NULL) + ia_gae, in that order -- what
+ * [SB3 collect_rollouts] does behind its last step (rewards/reward_wrapper.py:110-115 once per step == once on the tile)
+ * followed by [SB3 RolloutBuffer.compute_returns_and_advantage]. Replaces four host calls and the Python between them. */
+typedef struct {
+  const float* obs; const float* act_f32; const int64_t* act_i64; const float* next_obs; const uint8_t* dones;
+  int obs_dim, act_dim, use_state, use_action, use_next_state, use_done;
+  float* X; int ldx;                                   /* assembled rows [T * n, ldx] */
+  const ia_mlp_desc* desc; const float* params; const float* norm_mean; const float* norm_var; float norm_eps; int out_act;
+  float* predict_ws;                                   /* ia_disc_fused_predict_ws_floats(desc, ldx) floats */
+  float* rewards; float* rewards_host;                 /* [T, n] device tile; pinned host copy or NULL */
+  const float* values; const float* episode_starts; const float* last_values; const float* last_dones;
+  int T, n; float gamma, gae_lambda; float* advantages; float* returns;
+} ia_rollout_tail_args;
+int ia_rollout_tail(const ia_rollout_tail_args* a, void* stream);
+
 /* [SB3 collect_rollouts] rewards[i] += gamma * V(terminal_obs_i) where truncated[i]. */
 int ia_timeout_bootstrap(float* rewards, const float* terminal_values, const uint8_t* truncated, float gamma,
                          int64_t n, void* stream);

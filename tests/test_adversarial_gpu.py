@@ -203,6 +203,41 @@ def test_round_of_updates_in_one_call_is_bit_identical(tmp_path, case, penalty):
         assert logs[True][f] == logs[False][f], f
 
 
+@pytest.mark.parametrize("case", ["gail_fused", "gail_fused_wide", "gail_box"])
+def test_rollout_tail_in_one_call_is_bit_identical(tmp_path, case):
+    """Relabelling of the rollout tile, the rewards' copy to the pinned host tile and GAE through ONE host call
+    (`ia_rollout_tail`, `PPO._rollout_tail_args`: reward nets that are one fused-shape stack + GAIL's softplus) against the
+    general path call by call: the same launches in the same order -> every array and every log row bit for bit. Cases whose
+    net the tile kernel does not cover (`gail_box`: 32 x 32; `gail_fused_wide`: rows of more than 24 floats) must simply not
+    take it."""
+    import glob
+
+    import imitation_amd as p
+
+    outs, logs, took = {}, {}, {}
+    for mode in (True, False):
+        # (episodes of 50 steps against rollouts of 16: three rollouts without an episode end, the fourth with the time-limit
+        #  bootstrap, which takes the general path in both modes)
+        cfg = dict(harness.CASES[case], horizon=50)
+        d = str(tmp_path / f"log_{mode}")
+        tr, _ = harness.build_trainer("hip", cfg, d, device="cuda")
+        tr._logger = p.configure_logger(d, ["csv"])
+        tr.gen_algo.set_logger(tr.logger)
+        tr.gen_algo.rollout_tail_one_call = mode
+        tr.train(4 * cfg["n_envs"] * cfg["n_steps"])
+        th.cuda.synchronize()
+        outs[mode] = harness.snapshot(tr)
+        took[mode] = tr.gen_algo._tail_args is not None
+        tr.logger.close()
+        logs[mode] = {os.path.relpath(f, d): _csv_rows(f) for f in sorted(glob.glob(os.path.join(d, "**", "*.csv"),
+                                                                                recursive=True))}
+    assert took[True] == (case == "gail_fused") and not took[False], took
+    for k in outs[True]:
+        assert np.array_equal(np.asarray(outs[True][k]), np.asarray(outs[False][k]), equal_nan=True), k
+    for f in logs[True]:
+        assert logs[True][f] == logs[False][f], f
+
+
 @pytest.mark.parametrize("case,penalty", [("gail_fused", 0.0), ("gail_fused", 4.0), ("gail_box", 0.0), ("airl_tuned_hps", 3.0)])
 def test_round_draws_behind_the_rollout_noise_are_bit_identical(tmp_path, case, penalty):
     """Pipelined rounds whose discriminator updates are what the next relabelling waits for take the round's draws from

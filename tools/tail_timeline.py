@@ -67,4 +67,6 @@ keys = ["upload_host_tiles returned", "relabel (predict_processed_rollout) enter
         "collect_rollouts returned", "PPO.train entered", "ia_ppo_update entered", "ia_ppo_update returned"]
 print(f"host, us after the last environment step returned (median of {len(marks)} rounds):")
 for k in keys:
+    if not all(k in m for m in marks):   # (the one-call tail has no separate relabelling call)
+        continue
     print(f"  {k:52s} {1e6 * statistics.median(m[k] - m['last env step returned'] for m in marks):8.1f}")
