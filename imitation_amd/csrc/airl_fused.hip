@@ -977,6 +977,7 @@ struct Disc32Args {
   float* part; long long pstride;         // [workgroups][pstride] gradient slabs, torch parameter order
   float *logits, *dlogits, *stats, *bce_part;
   unsigned* ticket;
+  float* pred_out; int out_act;           // prediction (ia_disc32_predict): out_act(logit) of every row is all that is wanted
 };
 
 constexpr int D32_TX = 65, D32_TH = 33;   // LDS row strides (odd: conflict-free column walks)
@@ -1114,6 +1115,10 @@ __global__ __launch_bounds__(A_THREADS) void disc32_rows_kernel(Disc32Args a) {
 #pragma unroll
   for (int j = 0; j < 16; ++j) h2[j] = fmaxf(h2[j], 0.f);
   const float x = S.vec[3 * AH] + dot_features(h2, w3);
+  if (a.pred_out != nullptr) {   // (kernel argument: uniform) `RewardNet.predict_th` of the rows, rewards/reward_nets.py:176-204
+    if (live && half == 0) a.pred_out[r] = ia_apply_act(x, a.out_act);
+    return;
+  }
 
   // BCE-with-logits, its gradient and the statistics (adversarial/common.py:27-92, 360-368; bce_kernel's expressions)
   const float y = rr < a.n_expert ? 1.f : 0.f;
@@ -1468,6 +1473,27 @@ bool ia_disc32_shape_ok(const ia_mlp_desc* d, int ldx) {
   const int D = d->dims[0];
   return d->dims[1] == AH && d->dims[2] == AH && d->dims[3] == 1 && D >= 1 && D <= A_D_MAX && ldx >= D && ldx % 4 == 0 &&
          ldx <= A_D_MAX;
+}
+
+// Prediction on the row kernel (the reference's default 32 x 32 stack, up to 64 inputs): one launch, see ia_disc_fused_predict.
+int ia_disc32_predict(const ia_mlp_desc* d, const float* params, const float* X, int ldx, int R, const float* mean,
+                      const float* var, float eps, int out_act, float* out, hipStream_t stream) {
+  if (!ia_disc32_shape_ok(d, ldx) || !params || !X || !out || R <= 0) return IA_ERR_ARG;
+  Disc32Args k{};
+  k.X = X; k.ldx = ldx; k.D = d->dims[0]; k.R = R; k.n_expert = 0;
+  k.mean = mean; k.var = var; k.eps = eps;
+  k.P = params; k.scale = 0.f;
+  k.pred_out = out; k.out_act = out_act;
+  static bool attr = false;
+  if (!attr) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(disc32_rows_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)sizeof(Disc32Lds)) != hipSuccess)
+      return IA_ERR_ARG;
+    attr = true;
+  }
+  hipLaunchKernelGGL(disc32_rows_kernel, dim3((R + A_ROWS - 1) / A_ROWS), dim3(A_THREADS), sizeof(Disc32Lds), stream, k);
+  IA_CHECK_LAUNCH();
+  return IA_OK;
 }
 
 namespace {

@@ -1884,6 +1884,8 @@ int64_t ia_disc32_ws_floats(const ia_mlp_desc* d, int R);
 int ia_disc32_assemble(const ia_disc_step_args* a, int n_updates, int64_t idx_stride, int64_t x_stride, int64_t rn_stride,
                        float* rn_ws, hipStream_t stream);
 int ia_disc32_step(const ia_disc_step_args* a, void* stream);
+int ia_disc32_predict(const ia_mlp_desc* d, const float* params, const float* X, int ldx, int R, const float* mean,
+                      const float* var, float eps, int out_act, float* out, hipStream_t stream);
 extern "C" int ia_disc_fused_tile_rows(int rows) { g_fused_bm = rows == 32 ? 32 : 64; return IA_OK; }
 extern "C" int ia_disc_fused_split_tiles(int on) { g_fused_split = on != 0; return IA_OK; }
 extern "C" int ia_disc_fused_side_reduce(int on) { g_side_reduce = on != 0; return IA_OK; }
@@ -1959,9 +1961,11 @@ extern "C" int ia_disc_fused_prepare(const ia_mlp_desc* d, const float* params, 
 // `rewards/reward_wrapper.py:110-115`) as TWO launches (weight images of the current parameters, then the forward pass of
 // 64-row tiles with the hidden activations chained through LDS: disc_fwd_kernel<H, 64, 3>) instead of the five of
 // ia_running_norm_apply + ia_mlp_forward, and without the [R, H] activations going out to HBM twice. D <= 24 stacks
-// D -> H -> H -> 1 (ReLU, H = 128 / 256) only: 0 floats of workspace = shape not covered (use ia_mlp_forward).
+// D -> H -> H -> 1 (ReLU, H = 128 / 256), and the reference's default D <= 64 -> 32 -> 32 -> 1 stack on the register-resident row
+// kernel of airl_fused.hip (ONE launch); 0 floats of workspace = shape not covered (use ia_mlp_forward).
 extern "C" int64_t ia_disc_fused_predict_ws_floats(const ia_mlp_desc* d, int ldx) {
-  if (fused_dw(d, ldx) != 24 || ia_disc32_shape_ok(d, ldx)) return 0;
+  if (ia_disc32_shape_ok(d, ldx)) return 4;   // (the 32 x 32 row kernel needs no workspace: a token size)
+  if (fused_dw(d, ldx) != 24) return 0;
   return fused_ws_layout(d, 64, nullptr).total;
 }
 namespace {
@@ -1986,7 +1990,9 @@ extern "C" int ia_disc_fused_predict(const ia_mlp_desc* d, const float* params, 
                                      float* predict_ws, float* out, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (!d || !params || !X || !predict_ws || !out || R <= 0) return IA_ERR_ARG;
-  if (fused_dw(d, ldx) != 24 || ia_disc32_shape_ok(d, ldx)) return IA_ERR_UNSUPPORTED;
+  if (ia_disc32_shape_ok(d, ldx))   // the reference's default 32 x 32 stack (<= 64 inputs): the register-resident row kernel
+    return ia_disc32_predict(d, params, X, ldx, R, norm_mean, norm_var, norm_eps, out_act, out, stream);
+  if (fused_dw(d, ldx) != 24) return IA_ERR_UNSUPPORTED;
   const int D = d->dims[0], H = d->dims[1];
   const FusedWs w = fused_ws_layout(d, 64, predict_ws);
   AssembleArgs as{};

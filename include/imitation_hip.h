@@ -224,7 +224,7 @@ int ia_disc_fused_split_tiles(int on);
  * product's launch; 0 = the whole reduction in its own launch behind the product. Outputs are bit-identical. */
 int ia_disc_fused_side_reduce(int on);
 /* Prediction on the fused tile kernel: out[r] = out_act(MLP(normalise(X[r, :D]))) for R assembled rows of a D -> H -> H -> 1
- * ReLU stack (D <= 24, H = 128 / 256) -- `RewardNet.predict_th` of a whole rollout tile (rewards/reward_nets.py:176-204),
+ * ReLU stack (D <= 24, H = 128 / 256; or the reference's default H = 32 with D <= 64: the row kernel, one launch) -- `RewardNet.predict_th` of a whole rollout tile (rewards/reward_nets.py:176-204),
  * i.e. the reward relabelling behind a rollout's last step (rewards/reward_wrapper.py:110-115; GAIL: out_act = IA_ACT_SOFTPLUS,
  * algorithms/adversarial/gail.py:75-83) -- in two launches, the hidden activations never leaving LDS; replaces
  * ia_running_norm_apply + ia_mlp_forward on these shapes (the same fp32 MFMA products; the values differ from that path's by

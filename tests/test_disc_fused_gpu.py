@@ -376,7 +376,10 @@ def test_one_launch_penalty_pass_is_bit_identical_to_its_three_launches(hid, B, 
     ((128, 128), 4, 2, True, 333, True, True),         # CartPole width (one-hot actions: 6 inputs)
     ((256, 256), 11, 3, False, 64, True, False),
     ((128, 128), 11, 3, False, 1, True, True),         # a single transition (`predict_th` of one row)
-    ((256, 256), 17, 6, False, 65, False, True)])      # one row into the second tile
+    ((256, 256), 17, 6, False, 65, False, True),       # one row into the second tile
+    ((32, 32), 17, 6, False, 16384, True, True),       # the reference's default discriminator: the row kernel's prediction mode
+    ((32, 32), 29, 6, False, 500, True, False),        # ... at 35 inputs (rows of 36 floats), ragged last workgroup
+    ((32, 32), 4, 2, True, 33, False, True)])
 def test_fused_prediction_matches_the_layer_by_layer_forward(hid, od, ad, discrete, R, norm, softplus):
     """`ia_disc_fused_predict` (`DenseStack.forward_rows(keep_hidden=False)`: the relabelling of a rollout tile,
     `rewards/reward_wrapper.py:110-115` / `rewards/reward_nets.py:176-204`) against `ia_running_norm_apply` + `ia_mlp_forward`
