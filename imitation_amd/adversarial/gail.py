@@ -31,8 +31,8 @@ class RewardNetFromDiscriminatorLogit(reward_nets.RewardNet):
     def _forward_table(self, sources, tag, out_act=L.ACT_NONE):
         return self.base._forward_table(sources, tag, L.ACT_SOFTPLUS)
 
-    def rollout_tail_plan(self):
-        plan = self.base.rollout_tail_plan() if type(self) is RewardNetFromDiscriminatorLogit else None
+    def forward_plan(self):
+        plan = self.base.forward_plan() if type(self) is RewardNetFromDiscriminatorLogit else None
         return None if plan is None or plan[1] != L.ACT_NONE else (plan[0], L.ACT_SOFTPLUS)
 
 

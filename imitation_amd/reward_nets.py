@@ -191,11 +191,19 @@ class RewardNet(abc.ABC):
         with evaluating(self):
             return self._forward_table([(table, None, T * n)], "rollout")
 
-    def rollout_tail_plan(self):
-        """`(BasicRewardNet, output activation)` when `predict_processed_rollout` of this net is, row by row, ONE stack
-        the fused tile kernel covers followed by that activation -- the rollout collector then relabels, copies the
-        rewards out and runs GAE in one host call (`ia_rollout_tail`, `PPO._rollout_tail_args`); None: the general path."""
+    def forward_plan(self):
+        """`(BasicRewardNet, output activation)` when `_forward_table` of this net is, row by row, ONE stack the fused
+        prediction kernels cover followed by that activation; None otherwise."""
         return None
+
+    def rollout_tail_plan(self):
+        """`forward_plan()` when `predict_processed_rollout` of this net IS its `_forward_table` (the default; a wrapper that
+        post-processes the tile -- `NormalizedRewardNet` as the outermost net -- is not): the rollout collector then relabels,
+        copies the rewards out and runs GAE in one host call (`ia_rollout_tail`, `PPO._rollout_tail_args`); None: the
+        general path."""
+        if type(self).predict_processed_rollout is not RewardNet.predict_processed_rollout:
+            return None
+        return self.forward_plan()
 
     def disc_forward(self, sources, mb_rows: int, logp: Optional[th.Tensor]) -> th.Tensor:
         raise NotImplementedError(f"{type(self).__name__} cannot be trained as a discriminator on the HIP path")
@@ -267,9 +275,9 @@ class BasicRewardNet(RewardNet):
         self._assemble(sources, ws)
         return self.mlp.forward_rows(ws, R, out_act, keep_hidden=False).reshape(R)
 
-    def rollout_tail_plan(self):
+    def forward_plan(self):
         if type(self) is not BasicRewardNet or not self.mlp.FUSED_PREDICT or self.mlp._predict_ws() is None:
-            return None   # (a subclass may have its own forward; shapes outside the tile kernel)
+            return None   # (a subclass may have its own forward; shapes outside the prediction kernels)
         return self, L.ACT_NONE
 
     def disc_forward(self, sources, mb_rows, logp):
@@ -568,6 +576,13 @@ class PredictProcessedWrapper(RewardNetWrapper):
 
     def _forward_table(self, sources, tag, out_act=L.ACT_NONE):
         return self.base._forward_table(sources, tag, out_act)
+
+    def forward_plan(self):
+        # (`forward` passes through: `rewards/reward_nets.py:303-353` -- also for NormalizedRewardNet, which normalises in
+        #  `predict_processed` only; a subclass may have changed `_forward_table`)
+        if type(self)._forward_table is not PredictProcessedWrapper._forward_table:
+            return None
+        return self.base.forward_plan()
 
     def predict(self, state, action, next_state, done):
         return self.base.predict(state, action, next_state, done)

@@ -203,7 +203,7 @@ def test_round_of_updates_in_one_call_is_bit_identical(tmp_path, case, penalty):
         assert logs[True][f] == logs[False][f], f
 
 
-@pytest.mark.parametrize("case", ["gail_fused", "gail_fused_wide", "gail_box"])
+@pytest.mark.parametrize("case", ["gail_fused", "gail_fused_wide", "gail_box", "gail_tuned_hps", "airl_box"])
 def test_rollout_tail_in_one_call_is_bit_identical(tmp_path, case):
     """Relabelling of the rollout tile, the rewards' copy to the pinned host tile and GAE through ONE host call
     (`ia_rollout_tail`, `PPO._rollout_tail_args`: reward nets that are one fused-shape stack + GAIL's softplus) against the
@@ -231,7 +231,10 @@ def test_rollout_tail_in_one_call_is_bit_identical(tmp_path, case):
         tr.logger.close()
         logs[mode] = {os.path.relpath(f, d): _csv_rows(f) for f in sorted(glob.glob(os.path.join(d, "**", "*.csv"),
                                                                                 recursive=True))}
-    assert took[True] == (case in ("gail_fused", "gail_box")) and not took[False], took
+    # (`gail_tuned_hps`: FromDiscriminatorLogit(NormalizedRewardNet(Basic 32 x 32)) -- the normalisation layer acts in
+    #  `predict_processed` of ITS OWN level only, so the training reward passes through it: covered; `airl_box`: the
+    #  NormalizedRewardNet is the outermost net and normalises the tile: general path)
+    assert took[True] == (case in ("gail_fused", "gail_box", "gail_tuned_hps")) and not took[False], took
     for k in outs[True]:
         assert np.array_equal(np.asarray(outs[True][k]), np.asarray(outs[False][k]), equal_nan=True), k
     for f in logs[True]:
