@@ -172,6 +172,7 @@ _SIGS = {
     "ia_disc_fused_tile_rows": ([_I], C.c_int),
     "ia_disc_fused_split_tiles": ([_I], C.c_int),
     "ia_disc_fused_side_reduce": ([_I], C.c_int),
+    "ia_disc_fused_gp_groups": ([_I], C.c_int),
     "ia_rollout_tail": ([C.POINTER(RolloutTailArgs), _P], C.c_int),
     "ia_disc_fused_predict_ws_floats": ([C.POINTER(MlpDesc), _I], C.c_int64),
     "ia_disc_fused_predict": ([C.POINTER(MlpDesc), _P, _P, _I, _I, _P, _P, _F, _I, _P, _P, _P], C.c_int),

@@ -1117,36 +1117,58 @@ __global__ __launch_bounds__(BM * 8) void disc_fb_kernel(FusedArgs a) {
 // the input gradient and the row coefficients as two 32-column blocks (the four waves: K halves x column blocks, two
 // columns per lane in the norm), the first-layer slab straight to HBM (its image would not fit beside the 65-float W1
 // rows), and the input gradient's partial tiles in the ring slot the second chunk loop has just finished with.
-template <int H, int DW = 24>
-__global__ __launch_bounds__(256) void disc_gp_kernel(FusedArgs a) {
-  constexpr int BM = 32, NT = 256, NW = 4;
+// G = 2 (H = 256, DW = 24: config P's penalty): TWO 32-row tiles per workgroup -- 512 threads, two waves per SIMD -- that
+// share the chunk stream's ring and the W1 image and have their own tile, x tile and partial sums; per tile the same
+// instructions in the same order as G = 1 (bit-identical). The input-gradient partial tiles of ONE group at a time sit in the
+// ring stage the second chunk loop has just left (rows 32 floats apart to fit its 4 096), the first-layer slab goes straight
+// to HBM: 151 KB of LDS. With one 256-thread workgroup per CU (138 KB) the kernel ran at one wave per SIMD, 58 TFLOP/s
+// against the BCE tile kernel's 80.
+// NWC = 8 (same shape): ONE tile per workgroup, its columns split over EIGHT waves (32 columns each instead of 64) -- 512
+// threads, two waves per SIMD, and still one workgroup per tile: B = 8 192 interpolates fill all 256 CUs, where G = 2 leaves
+// half of them idle (measured: 80 us per launch against 60-66 for G = 1). The input gradient's four K quarters and the row
+// norms stay with waves 0-3 (the same partial tiles, the same sums); every other phase divides by columns or by slab tiles.
+template <int H, int DW = 24, int G = 1, int NWC = 4>
+__global__ __launch_bounds__(64 * NWC * G) void disc_gp_kernel(FusedArgs a) {
+  constexpr int BM = 32, NW = 4, NTG = 64 * NWC, NT = NTG * G;   // NW: waves that share the input-gradient phase; NTG: threads of a row group
+  static_assert(G == 1 || (G == 2 && DW == 24 && H == 256 && NWC == 4), "two row groups: the 256-wide narrow-row shape only");
+  static_assert(NWC == 4 || (NWC == 8 && G == 1 && DW == 24 && H == 256), "eight column groups: the 256-wide narrow-row shape only");
   constexpr bool WIDE = DW == 64;
   constexpr int XP = xp_of(DW), XP3 = xp3_of(DW);   // (shadow the narrow row lengths of the file scope)
   constexpr int KS1 = WIDE ? 32 : 12;               // layer 1: k steps of 2
-  constexpr int TN = H / 128;
+  constexpr int TN = H / (32 * NWC);                  // 32-column MFMA tiles per wave
   constexpr int WC = TN * 32;
   constexpr int LDH = H + 1;
   constexpr int NCH = H / FB_K;
   constexpr int BST = FB_K * H;
   constexpr int BV = BST / 4 / NT;
   constexpr int NR = 3;
-  constexpr bool SCR_IN_RING = WIDE && BST >= 2 * 32 * 64;
+  constexpr bool SCR_IN_RING = (WIDE && BST >= 2 * 32 * 64) || G == 2;
+  constexpr int GS = G == 2 ? 32 : 33;                // row length of an input-gradient partial tile (narrow rows)
   // gn partial tiles, then (narrow) the first-layer slab image; WIDE: 2 K halves x [32][64] partial tiles only
-  constexpr int SCR = WIDE ? (SCR_IN_RING ? 0 : 2 * 32 * 64) : ((H * 25 > NW * 32 * 33) ? H * 25 : NW * 32 * 33);
+  constexpr int SCR = SCR_IN_RING ? 0 : (WIDE ? 2 * 32 * 64 : ((H * 25 > NW * 32 * 33) ? H * 25 : NW * 32 * 33));
+  static_assert(!SCR_IN_RING || WIDE || NW * 32 * GS <= BST, "a group's partial tiles must fit one ring stage");
   static_assert(BST % (4 * NT) == 0, "B chunk must divide among the threads");
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* h1s = smem;                   // [BM][LDH]   h1 -> u2 -> u1 -> v1
-  float* bs = h1s + BM * LDH;          // NR x [FB_K][H] ring
+  float* h1s = smem;                   // G x [BM][LDH]   h1 -> u2 -> u1 -> v1 (this wave's group: below)
+  float* bs = h1s + G * BM * LDH;      // NR x [FB_K][H] ring
   float* w1s = bs + NR * BST;          // [H][XP] W1 image, resident
   float* scr = SCR_IN_RING ? bs + ((2 * NCH - 1) % NR) * BST : w1s + H * XP;   // [SCR] (WIDE, H = 256: the slot of the
                                                                                //  second loop's last chunk)
-  float* w3red = w1s + H * XP + SCR;   // [H]
-  float* xs = w3red + H;               // [BM][XP3]: x_hat (normalised), later the row coefficients C
+  float* w3red = w1s + H * XP + SCR;   // G x [H]
+  float* xs = w3red + G * H;           // G x [BM][XP3]: x_hat (normalised), later the row coefficients C
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wg = G == 1 ? 0 : (tid >> 8);        // row group of this wave
+  const int wave = (tid >> 6) % NWC;             // wave inside its group
+  const int tg = tid & (NTG - 1);                // thread inside its group
   const int li = lane & 31, lh = lane >> 5;
   const int wn = wave;
-  const int row0 = blockIdx.x * BM;
+  const int tile = blockIdx.x * G + wg;          // the 32-row tile of this group
+  const bool tile_ok = G == 1 || tile * BM < a.R;   // (an odd tile count leaves the last workgroup's second group idle)
+  const int row0 = tile * BM;
+  h1s += wg * BM * LDH;
+  w3red += wg * H;
+  xs += wg * BM * XP3;
   const int D = a.D;
   const float* W1 = a.params;
   const float* b1 = W1 + (long long)H * D;
@@ -1177,8 +1199,8 @@ __global__ __launch_bounds__(256) void disc_gp_kernel(FusedArgs a) {
     const int col = wn * WC + t * 32 + li;
     b1v[t] = b1[col]; b2v[t] = b2[col]; w3v[t] = w3[col];
   }
-  load_x_tile<BM, true, false, WIDE>(a, a.X, row0, xs, XP3, tid);
-  for (int e = tid; e < BM * (XP3 - 1 - a.ldx); e += NT) {  // columns [ldx, 32) (WIDE: [ldx, 64))
+  load_x_tile<BM, true, false, WIDE>(a, a.X, row0, xs, XP3, tg);
+  for (int e = tg; e < BM * (XP3 - 1 - a.ldx); e += NTG) {  // columns [ldx, 32) (WIDE: [ldx, 64))
     const int w = XP3 - 1 - a.ldx;
     const int row = e / w, c = a.ldx + e - row * w;
     xs[row * XP3 + c] = 0.f;
@@ -1237,7 +1259,8 @@ __global__ __launch_bounds__(256) void disc_gp_kernel(FusedArgs a) {
   __syncthreads();
 
   // ---- one chunk loop of the stream: acc += tile(h1s) . chunk(g0 + c); the tile's rows go to `out` in slices (or not)
-  static_assert(BM * H / NCH / 2 == NT, "one 8-byte piece per thread and chunk");
+  constexpr int PW = BM * H / NCH / NTG;            // floats of the tile a thread sends to HBM per chunk (2; 8 waves: 1)
+  static_assert(PW * NTG * NCH == BM * H && (PW == 1 || PW == 2), "the tile leaves in NCH slices of PW floats per thread");
   const float* Ar = h1s + li * LDH + lh;
   const int boff = wn * WC + li;
   float fa[2][FB_K / 2], fb[2][FB_K / 2][TN];
@@ -1251,10 +1274,10 @@ __global__ __launch_bounds__(256) void disc_gp_kernel(FusedArgs a) {
       const int g = g0 + c;
       if (g + 2 < 3 * NCH) bstore(rb, g + 2);
       if (g + 3 < 3 * NCH) bload(rb, g + 3);
-      const int e2 = c * NT + tid;
-      const int hrow = e2 / (H / 2), hcol = (e2 % (H / 2)) * 2;
+      const int e2 = c * NTG + tg;
+      const int hrow = e2 / (H / PW), hcol = (e2 % (H / PW)) * PW;
       float hv0 = 0.f, hv1 = 0.f;
-      if (out != nullptr) { hv0 = h1s[hrow * LDH + hcol]; hv1 = h1s[hrow * LDH + hcol + 1]; }
+      if (out != nullptr) { hv0 = h1s[hrow * LDH + hcol]; if constexpr (PW == 2) hv1 = h1s[hrow * LDH + hcol + 1]; }
       if (c + 1 < NCH) {
         auto a_nx = [&](int ks) { return Ar[(c + 1) * FB_K + 2 * ks]; };
         chunk_mfmas_and_next_frags<H, TN>(acc, fa[c & 1], fb[c & 1], fa[(c + 1) & 1], fb[(c + 1) & 1], a_nx,
@@ -1263,9 +1286,9 @@ __global__ __launch_bounds__(256) void disc_gp_kernel(FusedArgs a) {
         chunk_mfmas<TN>(acc, fa[c & 1], fb[c & 1]);
       }
       if (out != nullptr) {   // (wave-uniform; the store itself is unconditional: rows past R land in the dump slot)
-        float2 hv; hv.x = hv0; hv.y = hv1;
-        float* dst = row0 + hrow < a.R ? out + (long long)(row0 + hrow) * H + hcol : a.dump + 2 * tid;
-        *reinterpret_cast<float2*>(dst) = hv;
+        float* dst = row0 + hrow < a.R ? out + (long long)(row0 + hrow) * H + hcol : a.dump + PW * tid;
+        if constexpr (PW == 2) { float2 hv; hv.x = hv0; hv.y = hv1; *reinterpret_cast<float2*>(dst) = hv; }
+        else *dst = hv0;
       }
       __builtin_amdgcn_sched_barrier(0);
       __syncthreads();
@@ -1320,7 +1343,9 @@ __global__ __launch_bounds__(256) void disc_gp_kernel(FusedArgs a) {
     }
 #pragma unroll
     for (int r = 0; r < 16; ++r) scr[(kh * 32 + 4 * lh + rowoff(r)) * 64 + col] = accg[r];
-  } else {
+  }
+  // narrow rows: the four K quarters of a group's input gradient as partial tiles in `scr` (rows GS floats apart) ...
+  auto gn_partials = [&]() {
     constexpr int KQ = H / NW;
     f32x16 accg;
 #pragma unroll
@@ -1334,9 +1359,10 @@ __global__ __launch_bounds__(256) void disc_gp_kernel(FusedArgs a) {
       accg = __builtin_amdgcn_mfma_f32_32x32x2f32(af, cok ? w1 : 0.f, accg, 0, 0, 0);
     }
 #pragma unroll
-    for (int r = 0; r < 16; ++r) scr[(wave * 32 + 4 * lh + rowoff(r)) * 33 + li] = accg[r];
-  }
-  __syncthreads();
+    for (int r = 0; r < 16; ++r) scr[(wave * 32 + 4 * lh + rowoff(r)) * GS + li] = accg[r];
+  };
+  if constexpr (!WIDE && G == 1) { if (NWC == NW || wave < NW) gn_partials(); }
+  if constexpr (G == 1) __syncthreads();
   float pen_w = 0.f;
   if constexpr (WIDE) {
     const int c1 = 32 + li;
@@ -1359,13 +1385,16 @@ __global__ __launch_bounds__(256) void disc_gp_kernel(FusedArgs a) {
       const float pr = valid ? (n - a.gp_target) * (n - a.gp_target) : 0.f;
       pen_w += __shfl(pr, 0, 64) + __shfl(pr, 32, 64);
     }
-  } else {
+  }
+  // ... and the rows' norms, coefficients C (into the x tile) and penalty terms from the partial tiles' fixed-order sums
+  auto gn_rows = [&]() {
+    float pw = 0.f;
     const float inv = (a.mean != nullptr && li < D) ? 1.f / sqrtf(a.var[min(li, D - 1)] + a.eps) : 1.f;
 #pragma unroll
     for (int it = 0; it < 32 / (2 * NW); ++it) {
       const int row = wave * (32 / NW) + 2 * it + lh;
-      const float gn = ((scr[row * 33 + li] + scr[(32 + row) * 33 + li]) + scr[(64 + row) * 33 + li]) +
-                       scr[(96 + row) * 33 + li];
+      const float gn = ((scr[row * GS + li] + scr[(32 + row) * GS + li]) + scr[(64 + row) * GS + li]) +
+                       scr[(96 + row) * GS + li];
       const float g = li < D ? gn * inv : 0.f;
       float sq = g * g;
       sq += __shfl_xor(sq, 16, 64); sq += __shfl_xor(sq, 8, 64); sq += __shfl_xor(sq, 4, 64);
@@ -1375,20 +1404,32 @@ __global__ __launch_bounds__(256) void disc_gp_kernel(FusedArgs a) {
       const float kk = (valid && n > 0.f) ? a.gp_coef / (float)a.R * 2.f * (n - a.gp_target) / n : 0.f;
       xs[row * XP3 + li] = li < D ? kk * gn * inv * inv : 0.f;
       const float pr = valid ? (n - a.gp_target) * (n - a.gp_target) : 0.f;
-      pen_w += __shfl(pr, 0, 64) + __shfl(pr, 32, 64);
+      pw += __shfl(pr, 0, 64) + __shfl(pr, 32, 64);
+    }
+    return pw;
+  };
+  if constexpr (!WIDE && G == 1) { if (NWC == NW || wave < NW) pen_w = gn_rows(); }
+  if constexpr (G > 1) {
+    // one group at a time through the one free ring stage (every barrier is the whole workgroup's)
+#pragma unroll
+    for (int gsel = 0; gsel < G; ++gsel) {
+      if (wg == gsel) gn_partials();
+      __syncthreads();
+      if (wg == gsel) pen_w = gn_rows();
+      __syncthreads();
     }
   }
   constexpr int PC = XP3 - 1;   // the spare last column of the tile
-  if (lane == 0) xs[wave * XP3 + PC] = pen_w;
+  if (lane == 0 && (NWC == NW || wave < NW)) xs[wave * XP3 + PC] = pen_w;
   __syncthreads();
-  if (tid == 0) a.gp_pen[blockIdx.x] = ((xs[PC] + xs[XP3 + PC]) + xs[2 * XP3 + PC]) + xs[3 * XP3 + PC];
+  if (tg == 0 && tile_ok) a.gp_pen[tile] = ((xs[PC] + xs[XP3 + PC]) + xs[2 * XP3 + PC]) + xs[3 * XP3 + PC];
 
   // ---- first-layer slab [dW1 | 0] = u1^T . C (no bias column), image in `scr`
   {
     const long long n1 = (long long)H * D + H;
-    float* P1 = a.P1 + (long long)blockIdx.x * n1;
+    float* P1 = a.P1 + (long long)tile * n1;
     __syncthreads();   // (the gn partial tiles in `scr` have been read)
-    for (int mt = wave; mt < H / 32; mt += NW) {
+    for (int mt = wave; mt < H / 32; mt += NWC) {
       float af[BM / 2];
 #pragma unroll
       for (int s = 0; s < BM / 2; ++s) af[s] = h1s[(2 * s + lh) * LDH + mt * 32 + li];
@@ -1403,19 +1444,21 @@ __global__ __launch_bounds__(256) void disc_gp_kernel(FusedArgs a) {
 #pragma unroll
         for (int s = 0; s < BM / 2; ++s) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(af[s], bf[s], acc1, 0, 0, 0);
         const int col = nb * 32 + li;
-        if (col <= D) {   // (column D: the bias column of the slab, 0 here -- column D of C is 0)
+        if (col <= D && tile_ok) {   // (column D: the bias column of the slab, 0 here -- column D of C is 0)
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             const int i = mt * 32 + 4 * lh + rowoff(r);
-            (WIDE ? P1 : scr)[col < D ? i * D + col : H * D + i] = acc1[r];
+            ((WIDE || G > 1) ? P1 : scr)[col < D ? i * D + col : H * D + i] = acc1[r];
           }
         }
       }
     }
-    if constexpr (!WIDE) {
+    if constexpr (!WIDE && G == 1) {
       __syncthreads();
       for (int e = tid; e < (int)(n1 / 4); e += NT)
         reinterpret_cast<f4*>(P1)[e] = reinterpret_cast<const f4*>(scr)[e];
+    } else {
+      __syncthreads();   // (the slab went straight to HBM: every wave is past its reads of u1 before v1 overwrites the tile)
     }
   }
 
@@ -1445,8 +1488,8 @@ __global__ __launch_bounds__(256) void disc_gp_kernel(FusedArgs a) {
     if (lh == 0) w3red[col] = sum;
   }
   __syncthreads();
-  if (tid < H) a.P3[(long long)blockIdx.x * (2 * H + 1) + tid] = w3red[tid];
-  if (tid == 0) a.P3[(long long)blockIdx.x * (2 * H + 1) + H] = 0.f;
+  if (tg < H && tile_ok) a.P3[(long long)tile * (2 * H + 1) + tg] = w3red[tg];
+  if (tg == 0 && tile_ok) a.P3[(long long)tile * (2 * H + 1) + H] = 0.f;
 }
 
 // ------------------------------------------------------------------------------------------- K1
@@ -1761,6 +1804,8 @@ inline GpWs gp_ws_layout(const ia_mlp_desc* d, int B, int ldx, float* base) {
 int g_fused_bm = 64;   // rows per tile workgroup (tuning: ia_disc_fused_tile_rows)
 bool g_fused_split = false;   // forward and backward tile passes as two launches (ia_disc_fused_split_tiles)
 bool g_side_reduce = true;    // the product-independent part of the closing reduction inside the split-K product's launch
+int g_gp_groups = 8;          // form of the one-launch penalty pass at H = 256 (ia_disc_fused_gp_groups): 8 = one tile, eight column
+                              // waves; 2 = two tiles per workgroup; 1 = one tile, four waves
 template <int H>
 int launch_gp_tiles_wide(const FusedArgs& ga, int B, hipStream_t stream) {
   constexpr int BM = 32, XPW = xp_of(64), XP3W = xp3_of(64);
@@ -1798,6 +1843,36 @@ int launch_gp_tiles(const FusedArgs& ga, int B, hipStream_t stream) {
     attr_set = true;
   }
   const int tiles = cdivi(B, BM);
+  if constexpr (H == 256) {
+    if (!g_fused_split && g_gp_groups == 8) {   // one tile per 512-thread workgroup, columns over eight waves (disc_gp_kernel)
+      constexpr int SCR8 = (H * 25 > 4 * 32 * 33) ? H * 25 : 4 * 32 * 33;
+      constexpr size_t smem_g8 = sizeof(float) * (BM * (H + 1) + 3 * FB_K * H + H * XP + SCR8 + H + BM * XP3);
+      static bool attr_g8 = false;
+      if (!attr_g8) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(disc_gp_kernel<H, 24, 1, 8>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_g8);
+        if (e != hipSuccess) return (int)e;
+        attr_g8 = true;
+      }
+      hipLaunchKernelGGL((disc_gp_kernel<H, 24, 1, 8>), dim3(tiles), dim3(512), smem_g8, stream, ga);
+      IA_CHECK_LAUNCH();
+      return IA_OK;
+    }
+    if (!g_fused_split && g_gp_groups == 2) {   // two 32-row tiles per 512-thread workgroup: two waves per SIMD (disc_gp_kernel)
+      constexpr size_t smem_g2 = sizeof(float) * (2 * BM * (H + 1) + 3 * FB_K * H + H * XP + 2 * H + 2 * BM * XP3);
+      static_assert(smem_g2 <= 160 * 1024, "the two-group penalty workgroup must fit one CU's LDS");
+      static bool attr_g2 = false;
+      if (!attr_g2) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(disc_gp_kernel<H, 24, 2>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_g2);
+        if (e != hipSuccess) return (int)e;
+        attr_g2 = true;
+      }
+      hipLaunchKernelGGL((disc_gp_kernel<H, 24, 2>), dim3(cdivi(tiles, 2)), dim3(512), smem_g2, stream, ga);
+      IA_CHECK_LAUNCH();
+      return IA_OK;
+    }
+  }
   if (!g_fused_split) {
     constexpr int SCR = (H * 25 > 4 * 32 * 33) ? H * 25 : 4 * 32 * 33;
     constexpr size_t smem_g = sizeof(float) * (BM * (H + 1) + 3 * FB_K * H + H * XP + SCR + H + BM * XP3);
@@ -1889,6 +1964,7 @@ int ia_disc32_predict(const ia_mlp_desc* d, const float* params, const float* X,
 extern "C" int ia_disc_fused_tile_rows(int rows) { g_fused_bm = rows == 32 ? 32 : 64; return IA_OK; }
 extern "C" int ia_disc_fused_split_tiles(int on) { g_fused_split = on != 0; return IA_OK; }
 extern "C" int ia_disc_fused_side_reduce(int on) { g_side_reduce = on != 0; return IA_OK; }
+extern "C" int ia_disc_fused_gp_groups(int groups) { g_gp_groups = (groups == 1 || groups == 2) ? groups : 8; return IA_OK; }
 extern "C" int ia_disc_fused_debug_timing(void* device_buffer_16xi64) {
   g_fused_dbg = static_cast<long long*>(device_buffer_16xi64);
   return IA_OK;

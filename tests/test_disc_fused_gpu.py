@@ -326,11 +326,16 @@ def test_one_launch_tile_pass_is_bit_identical_to_forward_plus_backward_launches
                                      f"values {x.reshape(-1)[ii[:3]].tolist()} vs {y.reshape(-1)[ii[:3]].tolist()}")
 
 
-@pytest.mark.parametrize("hid,B,norm", [((256, 256), 1000, True), ((128, 128), 200, True), ((256, 256), 4096, False)])
-def test_one_launch_penalty_pass_is_bit_identical_to_its_three_launches(hid, B, norm):
+@pytest.mark.parametrize("hid,B,norm,form", [((256, 256), 1000, True, 8), ((128, 128), 200, True, 8), ((256, 256), 4096, False, 8),
+                                             ((256, 256), 1100, True, 8), ((256, 256), 1000, True, 1),
+                                             ((256, 256), 1100, True, 2),   # 35 tiles: the last two-tile workgroup is half idle
+                                             ((256, 256), 4096, False, 2)])
+def test_one_launch_penalty_pass_is_bit_identical_to_its_three_launches(hid, B, norm, form):
     """`disc_gp_kernel` (the penalty's three tile passes in one workgroup: masks in registers, C in LDS) against
     `disc_fwd_kernel<.,32,1>` + `disc_bwd_kernel<.,32,1>` + `disc_fwd_kernel<.,32,2>` (`ia_disc_fused_split_tiles(1)`):
-    gradient (BCE + penalty), the penalty's mean and the second pass's GEMM operands bit for bit."""
+    gradient (BCE + penalty), the penalty's mean and the second pass's GEMM operands bit for bit. `form`: the 256-wide pass as
+    one tile per workgroup with eight column waves (8, default), two tiles per workgroup (2), or four waves (1):
+    `ia_disc_fused_gp_groups`."""
     od, ad = 17, 6
     osp = spaces.Box(-np.inf, np.inf, (od,), np.float32)
     asp = spaces.Box(-1, 1, (ad,), np.float32)
@@ -344,6 +349,7 @@ def test_one_launch_penalty_pass_is_bit_identical_to_its_three_launches(hid, B, 
     outs = []
     lib = L.load()
     try:
+        lib.ia_disc_fused_gp_groups(form)
         for split in (1, 0):
             lib.ia_disc_fused_split_tiles(split)
             lib.ia_disc_fused_side_reduce(1 - split)   # (the closing reduction: one launch / split around the product)
@@ -362,6 +368,7 @@ def test_one_launch_penalty_pass_is_bit_identical_to_its_three_launches(hid, B, 
     finally:
         lib.ia_disc_fused_split_tiles(0)
         lib.ia_disc_fused_side_reduce(1)
+        lib.ia_disc_fused_gp_groups(8)
     for name, x, y in zip(("gradient", "penalty", "v1 | u2", "statistics"), *outs):
         if not th.equal(x, y):
             ii = th.nonzero((x != y).reshape(-1)).reshape(-1)
