@@ -1131,7 +1131,7 @@ template <int H, int DW = 24, int G = 1, int NWC = 4>
 __global__ __launch_bounds__(64 * NWC * G) void disc_gp_kernel(FusedArgs a) {
   constexpr int BM = 32, NW = 4, NTG = 64 * NWC, NT = NTG * G;   // NW: waves that share the input-gradient phase; NTG: threads of a row group
   static_assert(G == 1 || (G == 2 && DW == 24 && H == 256 && NWC == 4), "two row groups: the 256-wide narrow-row shape only");
-  static_assert(NWC == 4 || (NWC == 8 && G == 1 && DW == 24 && H == 256), "eight column groups: the 256-wide narrow-row shape only");
+  static_assert(NWC == 4 || (NWC == 8 && G == 1 && H == 256), "eight column groups: the 256-wide shapes only");
   constexpr bool WIDE = DW == 64;
   constexpr int XP = xp_of(DW), XP3 = xp3_of(DW);   // (shadow the narrow row lengths of the file scope)
   constexpr int KS1 = WIDE ? 32 : 12;               // layer 1: k steps of 2
@@ -1328,6 +1328,7 @@ __global__ __launch_bounds__(64 * NWC * G) void disc_gp_kernel(FusedArgs a) {
 
   // ---- gn = u1 W1 (K = H split over the four waves), row coefficients -> xs := C, penalty partial (disc_bwd_kernel MODE 1)
   if constexpr (WIDE) {
+   if (NWC == NW || wave < NW) {   // (eight column waves: the two K halves x two column blocks stay with waves 0-3)
     constexpr int KH = H / 2;
     const int kh = wave >> 1, col = (wave & 1) * 32 + li;
     f32x16 accg;
@@ -1343,6 +1344,7 @@ __global__ __launch_bounds__(64 * NWC * G) void disc_gp_kernel(FusedArgs a) {
     }
 #pragma unroll
     for (int r = 0; r < 16; ++r) scr[(kh * 32 + 4 * lh + rowoff(r)) * 64 + col] = accg[r];
+   }
   }
   // narrow rows: the four K quarters of a group's input gradient as partial tiles in `scr` (rows GS floats apart) ...
   auto gn_partials = [&]() {
@@ -1365,6 +1367,7 @@ __global__ __launch_bounds__(64 * NWC * G) void disc_gp_kernel(FusedArgs a) {
   if constexpr (G == 1) __syncthreads();
   float pen_w = 0.f;
   if constexpr (WIDE) {
+   if (NWC == NW || wave < NW) {
     const int c1 = 32 + li;
     const float inv0 = (a.mean != nullptr && li < D) ? 1.f / sqrtf(a.var[min(li, D - 1)] + a.eps) : 1.f;
     const float inv1 = (a.mean != nullptr && c1 < D) ? 1.f / sqrtf(a.var[min(c1, D - 1)] + a.eps) : 1.f;
@@ -1385,6 +1388,7 @@ __global__ __launch_bounds__(64 * NWC * G) void disc_gp_kernel(FusedArgs a) {
       const float pr = valid ? (n - a.gp_target) * (n - a.gp_target) : 0.f;
       pen_w += __shfl(pr, 0, 64) + __shfl(pr, 32, 64);
     }
+   }
   }
   // ... and the rows' norms, coefficients C (into the x tile) and penalty terms from the partial tiles' fixed-order sums
   auto gn_rows = [&]() {
@@ -1818,6 +1822,20 @@ int launch_gp_tiles_wide(const FusedArgs& ga, int B, hipStream_t stream) {
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_g);
     if (e != hipSuccess) return (int)e;
     attr_g = true;
+  }
+  if constexpr (H == 256) {
+    if (g_gp_groups == 8) {   // columns over eight waves (two waves per SIMD), as the narrow-row pass
+      static bool attr_g8 = false;
+      if (!attr_g8) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(disc_gp_kernel<H, 64, 1, 8>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_g);
+        if (e != hipSuccess) return (int)e;
+        attr_g8 = true;
+      }
+      hipLaunchKernelGGL((disc_gp_kernel<H, 64, 1, 8>), dim3(cdivi(B, BM)), dim3(512), smem_g, stream, ga);
+      IA_CHECK_LAUNCH();
+      return IA_OK;
+    }
   }
   hipLaunchKernelGGL((disc_gp_kernel<H, 64>), dim3(cdivi(B, BM)), dim3(256), smem_g, stream, ga);
   IA_CHECK_LAUNCH();

@@ -377,6 +377,45 @@ def test_one_launch_penalty_pass_is_bit_identical_to_its_three_launches(hid, B, 
     assert float(outs[0][1]) > 1e-3
 
 
+@pytest.mark.parametrize("od,ad,B", [(29, 6, 1000), (27, 8, 333)])
+def test_wide_row_penalty_pass_forms_are_bit_identical(od, ad, B):
+    """`disc_gp_kernel<256, 64>` (rows of up to 64 floats: Ant-width nets) with its columns over eight waves (default, two
+    waves per SIMD) against the four-wave form (`ia_disc_fused_gp_groups(1)`): gradient, penalty mean, the second pass's GEMM
+    operands and the statistics bit for bit (the float64 double-backward tests of tests/test_grad_penalty_gpu.py cover the
+    values themselves)."""
+    osp = spaces.Box(-np.inf, np.inf, (od,), np.float32)
+    asp = spaces.Box(-1, 1, (ad,), np.float32)
+    e_tab, _ = _tables(6000, od, ad, False, 1)
+    g_tab, _ = _tables(6000, od, ad, False, 2)
+    rng = np.random.default_rng(9)
+    e_idx, g_idx = th.as_tensor(rng.integers(0, 6000, B)).to(DEV), th.as_tensor(rng.integers(0, 6000, B)).to(DEV)
+    e = th.rand(B, generator=th.Generator().manual_seed(4)).to(DEV)
+    R = 2 * B
+    outs = []
+    lib = L.load()
+    try:
+        for form in (8, 1):
+            lib.ia_disc_fused_gp_groups(form)
+            th.manual_seed(3)
+            net = reward_nets.BasicRewardNet(osp, asp, hid_sizes=(256, 256), normalize_input_layer=p.RunningNorm).to(DEV)
+            with th.no_grad():
+                net.mlp.flat.mul_(2.5)
+            assert net.mlp.ldx > 24 and net.fused_gp_ws(B) is not None   # the wide-row fused penalty
+            stats = th.zeros(8, device=DEV)
+            bce_ws = th.zeros(int(lib.ia_bce_ws_floats(R)), device=DEV)
+            with networks.training(net):
+                ws = net.disc_step_c([(e_tab, e_idx, B), (g_tab, g_idx, B)], B, 1.0, stats, bce_ws, accumulate=False,
+                                     adam=None, gp=(e, 3.0, 1.0))
+            th.cuda.synchronize()
+            n_act = 2 * B * 256
+            outs.append((net.mlp.grad.clone(), ws["gp_out"].clone(), ws["gp_ws"][:n_act].clone(), stats.clone()))
+    finally:
+        lib.ia_disc_fused_gp_groups(8)
+    for name, x, y in zip(("gradient", "penalty", "v1 | u2", "statistics"), *outs):
+        assert th.equal(x, y), name
+    assert float(outs[0][1]) > 1e-3
+
+
 @pytest.mark.parametrize("hid,od,ad,discrete,R,norm,softplus", [
     ((256, 256), 17, 6, False, 16384, True, True),     # config P's relabelling tile
     ((256, 256), 17, 6, False, 1000, False, False),    # ragged last tile, no input norm, raw logits
