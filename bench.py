@@ -295,7 +295,7 @@ VARIANTS = {
         algo="gail", n_envs=1024, n_steps=4, obs=17, act=6,
         ppo=dict(batch_size=64, clip_range=0.1, ent_coef=3.992371122209408e-6, gae_lambda=0.95, gamma=0.95,
                  learning_rate=0.00026250519057717037, max_grad_norm=0.8, n_epochs=5, vf_coef=0.11483689492120866),
-        demo_batch=8192, n_disc=8, capacity=512, net=dict(), normalize_output=True, rounds=12, warm=3),
+        demo_batch=8192, n_disc=8, capacity=512, net=dict(), normalize_output=True, rounds=30, warm=5),
     # scripts/config/tuned_hps/airl_seals_ant_best_hp_eval.json:2-44 verbatim (rl.batch_size 8192 -> n_steps 8; PPO
     # minibatch 16: 5 120 optimiser steps per round)
     "3_airl_ant_tuned_verbatim": _v(
@@ -306,28 +306,28 @@ VARIANTS = {
     # BASELINE config 3's shape with config P's generator schedule (PPO minibatch 1024): the fused AIRL update
     "3_airl_ant_1024x16_mb1024": _v(algo="airl", n_envs=1024, n_steps=16, obs=27, act=8, ppo=dict(_PPO_P, ent_coef=0.01),
                                     demo_batch=8192, n_disc=16, capacity=16384, net=dict(), normalize_output=True,
-                                    rounds=12, warm=3),
+                                    rounds=30, warm=5),
     # ... "+ grad-penalty" as BASELINE words config 3 (opt-in extension, no reference counterpart: coefficient 10)
     "3_airl_ant_1024x16_mb1024_gp10": _v(algo="airl", n_envs=1024, n_steps=16, obs=27, act=8, ppo=dict(_PPO_P, ent_coef=0.01),
                                          demo_batch=8192, n_disc=16, capacity=16384, net=dict(), normalize_output=True,
-                                         grad_penalty=10.0, rounds=12, warm=3),
+                                         grad_penalty=10.0, rounds=30, warm=5),
     # config P with the opt-in gradient penalty on the 256 x 256 discriminator
     "P_gp10": _v(algo="gail", n_envs=1024, n_steps=16, obs=17, act=6, ppo=_PPO_P, demo_batch=8192, n_disc=16, capacity=16384,
-                 net=dict(hid_sizes=(256, 256)), grad_penalty=10.0, rounds=12, warm=3),
+                 net=dict(hid_sizes=(256, 256)), grad_penalty=10.0, rounds=30, warm=5),
     # config P with the reference's DEFAULT discriminator (BasicRewardNet 32 x 32)
     "P_disc32": _v(algo="gail", n_envs=1024, n_steps=16, obs=17, act=6, ppo=_PPO_P, demo_batch=8192, n_disc=16, capacity=16384,
-                   net=dict(), rounds=12, warm=3),
+                   net=dict(), rounds=30, warm=5),
     # GAIL at Ant width (35 inputs) with use_next_state + use_done on top (63 inputs), default 32 x 32 net
     "P_ant_gail_d35": _v(algo="gail", n_envs=1024, n_steps=16, obs=27, act=8, ppo=_PPO_P, demo_batch=8192, n_disc=16,
-                         capacity=16384, net=dict(), rounds=12, warm=3),
+                         capacity=16384, net=dict(), rounds=30, warm=5),
     # ... the 256 x 256 discriminator at Ant width (rows of 36 floats: the wide tile kernels), without and with the
     # opt-in gradient penalty (`disc_gp_kernel<256, 64>` inside the update)
     "P_ant_gail_d35_h256": _v(algo="gail", n_envs=1024, n_steps=16, obs=27, act=8, ppo=_PPO_P, demo_batch=8192, n_disc=16,
-                              capacity=16384, net=dict(hid_sizes=(256, 256)), rounds=12, warm=3),
+                              capacity=16384, net=dict(hid_sizes=(256, 256)), rounds=30, warm=5),
     "P_ant_gail_d35_gp10": _v(algo="gail", n_envs=1024, n_steps=16, obs=27, act=8, ppo=_PPO_P, demo_batch=8192, n_disc=16,
-                              capacity=16384, net=dict(hid_sizes=(256, 256)), grad_penalty=10.0, rounds=12, warm=3),
+                              capacity=16384, net=dict(hid_sizes=(256, 256)), grad_penalty=10.0, rounds=30, warm=5),
     "P_ant_gail_d63_next_done": _v(algo="gail", n_envs=1024, n_steps=16, obs=27, act=8, ppo=_PPO_P, demo_batch=8192, n_disc=16,
-                                   capacity=16384, net=dict(use_next_state=True, use_done=True), rounds=12, warm=3),
+                                   capacity=16384, net=dict(use_next_state=True, use_done=True), rounds=30, warm=5),
     # BASELINE config 1 in its canonical library form (docs/algorithms/gail.rst:36-91): 8 envs, SB3 MlpPolicy 64 x 64,
     # Discrete head on the reference's sampling stream
     "1_cartpole_8x256_mlp64": _v(algo="gail", n_envs=8, n_steps=256, obs=4, act=2, discrete=True, policy="mlp64",
@@ -346,18 +346,18 @@ VARIANTS = {
     # ... and the SAME environment (staggered episode ends, variable-horizon flag) through the array protocol: the pair
     # isolates what the dict protocol costs -- the env's own 1 024 dicts per step and the trainer's per-env branch
     "P_stagger_arrays_1024": _v(algo="gail", n_envs=1024, n_steps=16, obs=17, act=6, ppo=_PPO_P, demo_batch=8192, n_disc=16,
-                                capacity=16384, net=dict(hid_sizes=(256, 256)), stagger=True, rounds=12, warm=3),
+                                capacity=16384, net=dict(hid_sizes=(256, 256)), stagger=True, rounds=30, warm=5),
     "P_generic_vecenv_1024": _v(algo="gail", n_envs=1024, n_steps=16, obs=17, act=6, ppo=_PPO_P, demo_batch=8192, n_disc=16,
                                 capacity=16384, net=dict(hid_sizes=(256, 256)), generic_vecenv=True, stagger=True,
-                                rounds=12, warm=3),
+                                rounds=30, warm=5),
     # config P with SB3's default `MlpPolicy` (64 x 64 tanh towers) as the generator instead of FeedForward32Policy
     "P_mlp64_1024x16": _v(algo="gail", n_envs=1024, n_steps=16, obs=17, act=6, policy="mlp64", ppo=dict(_PPO_P, ent_coef=0.01),
-                          demo_batch=8192, n_disc=16, capacity=16384, net=dict(hid_sizes=(256, 256)), rounds=12, warm=3),
+                          demo_batch=8192, n_disc=16, capacity=16384, net=dict(hid_sizes=(256, 256)), rounds=30, warm=5),
     # policy towers outside the fused kernels' shapes (any SB3 `net_arch`): the general minibatch loop
     "towers_1024x16_pi128x64_vf256": _v(algo="gail", n_envs=1024, n_steps=16, obs=17, act=6, policy="mlp64",
                                         net_arch=dict(pi=[128, 64], vf=[256]),
                                         ppo=dict(batch_size=2048, n_epochs=4, ent_coef=0.01), demo_batch=8192, n_disc=4,
-                                        capacity=16384, net=dict(hid_sizes=(256, 256)), rounds=12, warm=3),
+                                        capacity=16384, net=dict(hid_sizes=(256, 256)), rounds=30, warm=5),
     # GAIL on uint8 image observations: CnnPolicy generator + CnnRewardNet discriminator (run_image_variant)
     "image_gail_64x16_cnn": None,
     # BASELINE config 5: BC supervised step, NatureCNN policy on 84 x 84 x 4 uint8 frames, batch 4096 (run_bc_variant)
