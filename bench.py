@@ -74,6 +74,10 @@ def build_trainer(ns, cfg, device, seed=0, dp=None):
     algo = ns.PPO(ns.FeedForward32Policy, venv, n_steps=cfg["n_steps"], batch_size=cfg["ppo_batch"],
                   n_epochs=cfg["n_epochs"], ent_coef=cfg["ent_coef"], learning_rate=cfg["lr"], seed=seed,
                   policy_kwargs=pk, device=device)
+    if dp is not None:
+        # the benchmark MEASURES which data-parallel form of the PPO update is faster on this node during its warm-up
+        # rounds (the library's default is the row-sharded form, deterministic; see `PPO.dp_update_form`)
+        algo.dp_update_form = os.environ.get("IA_DP_UPDATE_FORM", "auto") if algo.dp_row_sharded else "replicated"
     net = ns.BasicRewardNet(venv.observation_space, venv.action_space, hid_sizes=cfg["disc_hid"],
                             normalize_input_layer=ns.RunningNorm)
     demos = ns.Transitions(**make_demos(cfg))
@@ -545,8 +549,29 @@ def _dp_form_text(algo):
         return "per-minibatch gradient all-reduce"
     if algo.dp_update_form in g["forms"] or len(g["forms"]) == 1:
         form = algo.dp_update_form if algo.dp_update_form in g["forms"] else g["forms"][0]
-        return f"{names[form]} ({'asked for' if algo.dp_update_form == form else 'the only form available'})"
+        why = "asked for" if algo.dp_update_form == form else "the only form available"
+        if getattr(algo, "dp_handshake_failed", False):
+            why = "the peer-memory handshake failed on at least one rank: every rank fell back to this form"
+        return f"{names[form]} ({why})"
     return "row-sharded / replicated alternating (the timed trials were not over)"
+
+
+def _self_launch(n_gpus: int) -> int:
+    """`python bench.py --gpus N` without a launcher's environment: re-runs this file under
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1` with the same arguments
+    (the driver's own N > 1 command shape) and returns its exit status. Rank 0 prints the one JSON line."""
+    import socket
+    import subprocess
+    if os.environ.get("IA_BENCH_SHARE_GPU") != "1" and th.cuda.device_count() < n_gpus:
+        raise SystemExit(f"bench.py: --gpus {n_gpus} but this node shows {th.cuda.device_count()} GPU(s)")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n_gpus) // n_gpus)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
 
 
 def main():
@@ -559,10 +584,17 @@ def main():
     ap.add_argument("--no-variants", action="store_true")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # bare `python bench.py --gpus N`: become the launcher -- one rank per GPU under torch.distributed.run on this
+        # node, the ranks' stdout (rank 0's ONE JSON line) and exit status passed through
+        sys.exit(_self_launch(args.gpus))
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run)"
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU "
+                         f"(`python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py --gpus {args.gpus}`), "
+                         "or run `python bench.py --gpus N` bare and it launches the ranks itself")
     # Test hook for boxes with fewer GPUs than ranks (not a benchmark mode): IA_BENCH_SHARE_GPU=1 puts
     # every rank on cuda:0 and moves the collectives through gloo (RCCL refuses two ranks on one GPU).
     share = os.environ.get("IA_BENCH_SHARE_GPU") == "1"
@@ -631,7 +663,19 @@ def main():
                         variants[name]["speedup_vs_cpu_baseline"] = variants[name]["env_steps_per_s"] / cb["value"]
                     except Exception as e:
                         variants[name]["cpu_baseline"] = {"error": f"{type(e).__name__}: {e}"}
+    by_rank = None
     if world > 1:
+        # what every rank actually ran (the form is the ranks' COMMON verdict by construction; the line shows it per rank)
+        g = trainer.gen_algo._dpg if isinstance(getattr(trainer.gen_algo, "_dpg", None), dict) else None
+        ch = getattr(trainer.gen_algo, "dp_choice", None)
+        mine = {"rank": rank,
+                "form": (ch["chosen"] if ch else (trainer.gen_algo.dp_update_form
+                                                  if g and trainer.gen_algo.dp_update_form in g["forms"]
+                                                  else (g["forms"][0] if g else "per-minibatch all-reduce"))),
+                "handshake_failed": bool(getattr(trainer.gen_algo, "dp_handshake_failed", False)),
+                "sharded_updates": int(getattr(trainer.gen_algo, "dp_sharded_updates", 0))}
+        by_rank = [None] * world
+        dist.all_gather_object(by_rank, mine)
         dist.barrier()
 
     if rank == 0:
@@ -681,7 +725,8 @@ def main():
                                    "minibatch 1024 x 10 epochs", "env_steps_per_round_per_gpu": per_round,
                        "parallelism": f"dp{world}" if world > 1 else "single",
                        "ppo_update": _dp_form_text(trainer.gen_algo) if world > 1 else "single GPU",
-                       "ppo_update_choice": getattr(trainer.gen_algo, "dp_choice", None) if world > 1 else None},
+                       "ppo_update_choice": getattr(trainer.gen_algo, "dp_choice", None) if world > 1 else None,
+                       "ppo_update_by_rank": by_rank},
             "roofline": flat, "cpu_baseline": base,
             "speedup_vs_cpu_baseline": (value / base["value"]) if base else None,
             "details": {"roofline_disc_update": disc or None, "roofline_gemm": gemm, "roofline_ppo_update": ppo or None},

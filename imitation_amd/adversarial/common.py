@@ -870,8 +870,10 @@ class AdversarialTrainer(abc.ABC):
         b[1].copy_(b[0], non_blocking=True)
         self._gp_block = [b[1], b, 0]
 
-    def _round_predraw(self) -> None:
-        """`PPO.after_noise_predraw` of the pipelined schedule: the coming discriminator round's draws from torch's global
+    def _round_predraw(self, last_rollout: bool = True) -> None:
+        """`PPO.after_noise_predraw` of the pipelined schedule (`last_rollout`: False behind any but the last rollout of a
+        round of several PPO iterations, `gen_train_timesteps > n_steps * n_envs` -- the sequential schedule draws the
+        noise of the remaining rollouts first, so nothing is taken here): the coming discriminator round's draws from torch's global
         CPU generator -- its n expert index rows (`ExpertIndexStream`: two 64-bit draws per epoch of the expert table), then
         its n interpolation-weight vectors as one block -- taken HERE, right behind the rollout's noise, in the order the
         round takes them (`_disc_round`, prepass form: all index rows first, then the weights). Nothing else reads that
@@ -881,6 +883,8 @@ class AdversarialTrainer(abc.ABC):
         drawn in place as before, continuing the same sequence."""
         ev = self._ppo_done_event
         force = self.predraw_round_draws == "always"   # (tests: regardless of what the device is doing)
+        if not last_rollout:
+            return
         if (not self.predraw_round_draws or not (self._disc_critical or force) or ev is None or self._expert_stream is None
                 or self._pre_expert_rows or self._gp_round_pre is not None):
             return

@@ -19,6 +19,7 @@ Replicas therefore stay bit-identical; global-norm clipping happens after the al
 """
 from __future__ import annotations
 
+import os
 from typing import List, Optional
 
 import torch as th
@@ -148,6 +149,11 @@ class PeerExchange:
             good = lib.ia_peer_alloc(nbytes, C.byref(base), C.byref(fine)) == 0 and bool(base.value)
             if good:
                 self.base, self.fine_grained = int(base.value), bool(fine.value)
+        # test-only switch: the rank named by IA_PEER_FAIL_RANK reports that it could not export / map peer memory (what a
+        # node without peer access between two of its GPUs looks like) -- every rank must land on the replicated update
+        self.forced_failure = (not self.loop) and os.environ.get("IA_PEER_FAIL_RANK", "") == str(self.rank)
+        if self.forced_failure:
+            good = False
         bases = [self.base] * self.world
         if not self.loop:
             handle = (C.c_ubyte * 64)()

@@ -118,33 +118,101 @@ class _PermutationPredraw:
     # (`uint32 key[624]; int pos;` at `_bit_generator.ctypes.state_address`): `np.random.get_state()` / `set_state()` cost
     # ~20-45 us each (tuple + array copies, validation) and sat between the last environment step and the PPO launch
     # (`finish`), ahead of the discriminator round's enqueue (`take_randint`) and at the top of the rollout (`start`).
+    # That layout is NumPy-private, so it is PROVEN once per process on a private `np.random.MT19937` instance (`_raw_ok`:
+    # the bytes at the address equal the public `.state` before and after draws, and a state written through the address
+    # reads back through `.state`); when the proof fails -- another NumPy lays the struct out differently -- the same
+    # protocol runs on the public `get_state` / `set_state` instead (slower, same draws, same post-states:
+    # `tests/test_host_logic.py::test_permutation_predraw_falls_back_to_public_state_api`).
     _STATE_BYTES = 624 * 4 + 4
+    _KEY_OFFSET = 0          # of `key[624]` from `state_address` (tests move it to trip the proof)
+    _raw_proof: Optional[bool] = None
 
-    @staticmethod
-    def _global_mt():
-        """(bit generator, address of its mt19937_state) of NumPy's global `RandomState`, or None when it is not MT19937."""
-        try:   # (private attributes of NumPy: without them the speculation is off and every draw happens in place)
+    @classmethod
+    def _raw_ok(cls) -> bool:
+        if cls._raw_proof is None:
+            ok = False
+            try:
+                bg = np.random.MT19937(20260930)
+                addr = int(bg.ctypes.state_address) + cls._KEY_OFFSET
+
+                def same():
+                    st = bg.state["state"]
+                    raw = C.string_at(addr, cls._STATE_BYTES)
+                    return (raw[:624 * 4] == np.ascontiguousarray(st["key"], dtype=np.uint32).tobytes()
+                            and int.from_bytes(raw[624 * 4:], sys.byteorder, signed=True) == int(st["pos"]))
+
+                ok = same()
+                bg.random_raw(7)          # pos moves inside the block
+                ok = ok and same()
+                bg.random_raw(700)        # the block is regenerated
+                ok = ok and same()
+                other = np.random.MT19937(7).state["state"]
+                key = np.ascontiguousarray(other["key"], dtype=np.uint32)
+                C.memmove(addr, key.ctypes.data, 624 * 4)
+                C.c_int.from_address(addr + 624 * 4).value = 321
+                st = bg.state["state"]
+                ok = ok and np.array_equal(st["key"], key) and int(st["pos"]) == 321
+                want = np.random.MT19937(7)
+                want.state = dict(want.state, state=dict(key=key, pos=321))
+                ok = ok and bool(np.array_equal(bg.random_raw(5), want.random_raw(5)))
+            except Exception:   # (anything missing or different: the public API)
+                ok = False
+            cls._raw_proof = ok
+        return cls._raw_proof
+
+    @classmethod
+    def _global_mt(cls):
+        """(bit generator, address of its mt19937_state -- or None: go through `get_state` / `set_state`) of NumPy's global
+        `RandomState`, or None when it is not MT19937 (no speculation: every draw happens in place)."""
+        try:
             bg = getattr(np.random.mtrand._rand, "_bit_generator", None)
-            if type(bg).__name__ != "MT19937":
-                return None
-            return bg, int(bg.ctypes.state_address)
         except AttributeError:
+            bg = None
+        if bg is None:
+            try:
+                if np.random.get_state()[0] != "MT19937":
+                    return None
+            except Exception:
+                return None
+            return None, None
+        if type(bg).__name__ != "MT19937":
             return None
+        if cls._raw_ok():
+            try:
+                return bg, int(bg.ctypes.state_address) + cls._KEY_OFFSET
+            except AttributeError:
+                pass
+        return bg, None
 
-    def _raw_state(self, addr: int) -> bytes:
+    def _raw_state(self, addr) -> bytes:
+        """`key[624]` + `pos` of the global generator as bytes (address None: through the public API)."""
+        if addr is None:
+            st = np.random.get_state()
+            return (np.ascontiguousarray(st[1], dtype=np.uint32).tobytes()
+                    + int(st[2]).to_bytes(4, sys.byteorder, signed=True))
         return C.string_at(addr, self._STATE_BYTES)
 
     @staticmethod
-    def _move_global(addr: int, key: np.ndarray, pos: int) -> None:
-        C.memmove(addr, key.ctypes.data, 624 * 4)
-        C.c_int.from_address(addr + 624 * 4).value = int(pos)
+    def _move_global(addr, key: np.ndarray, pos: int, bg=None) -> None:
+        if addr is None:   # public API: the Gaussian cache of the legacy state stays as it is (no draw here touches it)
+            st = np.random.get_state()
+            np.random.set_state((st[0], np.array(key, dtype=np.uint32), int(pos)) + tuple(st[3:]))
+            return
+        lock = getattr(bg, "lock", None)   # (the bit generator's own lock: another thread's draw never sees half a state)
+        if lock is not None:
+            with lock:
+                C.memmove(addr, key.ctypes.data, 624 * 4)
+                C.c_int.from_address(addr + 624 * 4).value = int(pos)
+        else:
+            C.memmove(addr, key.ctypes.data, 624 * 4)
+            C.c_int.from_address(addr + 624 * 4).value = int(pos)
 
     def start(self, out: np.ndarray, randint_spec=None) -> None:
         """`randint_spec = (high, rows, row_len)` (optional): behind the permutations the SAME C call draws, on a copy of the
         generator, `rows` x `np.random.randint(high, size=row_len)` -- the replay ring's index rows of the round's
         discriminator updates (`take_randint`)."""
         assert out.dtype == np.int64 and out.flags.c_contiguous and out.shape == (self.n_epochs, self.size)
-        self._rr = None
+        self._rr = self._rr_armed = None   # (rows armed by an earlier round belong to an earlier generator state)
         mt = self._global_mt()
         if mt is None:
             self._thread = None
@@ -181,6 +249,7 @@ class _PermutationPredraw:
     def finish(self, out: np.ndarray) -> bool:
         """True if `out` now holds the permutations and the global generator has advanced past them."""
         t, self._thread = self._thread, None
+        self._rr_armed = None
         if t is None:
             return False
         t.wait()
@@ -188,7 +257,7 @@ class _PermutationPredraw:
         if (self._rc != 0 or out is not self._out or mt is None or mt[0] is not self._bg
                 or self._raw_state(mt[1]) != self._state0):
             return False
-        self._move_global(mt[1], self._key, self._pos.value)
+        self._move_global(mt[1], self._key, self._pos.value, mt[0])
         self._rr_armed = self._rr   # (valid while the global generator stays where this call has just put it)
         return True
 
@@ -206,7 +275,7 @@ class _PermutationPredraw:
         if (int.from_bytes(raw[624 * 4:], sys.byteorder, signed=True) != int(self._pos.value)
                 or raw[:624 * 4] != self._key.tobytes()):
             return None
-        self._move_global(mt[1], rr["key"], rr["pos"].value)
+        self._move_global(mt[1], rr["key"], rr["pos"].value, mt[0])
         return rr["rows"]
 
 
@@ -446,7 +515,8 @@ class PPO(OnPolicyAlgorithm):
         # rollout's noise draw -- where the host waits for the previous update anyway: what the coming discriminator round
         # will take from torch's global CPU generator (expert index rows, interpolation weights) is drawn THERE, in the order
         # the round itself draws it, when the whole rollout's noise has been taken in one draw (nothing else reads that
-        # generator until the round: the condition `predraw_noise` states)
+        # generator until the round: the condition `predraw_noise` states). Argument: whether this is the last rollout of
+        # the running `learn()` -- only then is the round's first draw the next thing the sequential schedule takes
         self.after_noise_predraw = None
         # relabelling + reward copy + GAE behind a rollout's last step as one host call where the reward net allows it
         # (`_rollout_tail_args`; False: the general path, call by call -- tests compare)
@@ -481,14 +551,18 @@ class PPO(OnPolicyAlgorithm):
         # optimiser step inside the kernels through peer-mapped memory (`distributed.PeerExchange`, `ia_ppo_update_sharded`).
         # False -- or a failed peer handshake -- runs the whole global minibatch redundantly on every rank instead.
         self.dp_row_sharded = os.environ.get("IA_DP_ROW_SHARDED", "1") != "0"
-        # Which data-parallel form of the persistent update runs: "sharded" (each rank its rows of the global minibatch,
-        # one record per optimiser step exchanged inside the kernels), "replicated" (every rank the whole global
-        # minibatch, no per-step exchange) or "auto" (default): both are TIMED on the node during the first updates of a
-        # run -- alternating, the first launch of each form discarded -- and the form whose slowest rank is faster is kept
-        # on all ranks (one all-gather of two numbers). `dp_choice` records both timings and the verdict (`bench.py`
-        # prints it). `IA_DP_ROW_SHARDED=0` still means "replicated".
-        self.dp_update_form = os.environ.get("IA_DP_UPDATE_FORM", "auto") if self.dp_row_sharded else "replicated"
+        # Which data-parallel form of the persistent update runs: "sharded" (default: each rank its rows of the global
+        # minibatch, one record per optimiser step exchanged inside the kernels; a failed peer handshake -> "replicated" on
+        # every rank, `dp_handshake_failed`), "replicated" (every rank the whole global minibatch, no per-step exchange) or
+        # "auto" (opt-in; `bench.py` asks for it): both are TIMED on the node during the first updates of a run --
+        # alternating, the first launch of each form discarded -- and the form whose slowest rank is faster is kept on all
+        # ranks (one all-gather of two numbers); `dp_choice` records both timings and the verdict. The two forms sum the
+        # gradient slabs in different orders (same values, last bits differ), so a choice that depends on measured time
+        # is NOT the default: a seeded run on a given node always takes the same form. `IA_DP_ROW_SHARDED=0` still means
+        # "replicated".
+        self.dp_update_form = os.environ.get("IA_DP_UPDATE_FORM", "sharded") if self.dp_row_sharded else "replicated"
         self.dp_choice = None
+        self.dp_handshake_failed = False
         self.dp_exchange_timeout_s = 30.0   # a rank waits this long for a peer's record of ONE optimiser step
 
     @property
@@ -687,7 +761,9 @@ class PPO(OnPolicyAlgorithm):
                     noise_tile = rb.h_noise_tile
                     pol.draw_noise_into(noise_tile)
                     if self.after_noise_predraw is not None and not hooked:   # (no user code inside the step loop)
-                        self.after_noise_predraw()
+                        # is this the LAST rollout of the running `learn()`? (a round of k > 1 rollouts draws the noise of
+                        # rollouts 2..k from the same generator before the discriminator round draws anything)
+                        self.after_noise_predraw(self.num_timesteps + n * T >= self._total_timesteps)
                 predrawn = noise_tile.dim() == 3
                 act_step = pol.make_act_step(rb.h_obs, noise_tile, rb.acts, rb.h_clip, rb.val, rb.logp)  # eval mode: no norm update
                 # ONE resident launch for the rollout's T act steps, driven through flags in pinned host memory: a step
@@ -951,6 +1027,7 @@ class PPO(OnPolicyAlgorithm):
                     shard = dict(ex=ex, rows=rows, ws=th.zeros(n_ws_s, device=dev))
                 else:
                     ex.close()
+                    self.dp_handshake_failed = True   # (the ranks' common verdict: the same on every rank)
                     warnings.warn("data-parallel PPO update: the peer-memory handshake failed; every rank runs the "
                                   "whole global minibatch instead of its row shard", RuntimeWarning)
             if shard is None and n_ws <= 0:
@@ -1070,6 +1147,8 @@ class PPO(OnPolicyAlgorithm):
             g["shard"]["ex"].close()
             g["shard"] = None
             g["forms"] = [f for f in g["forms"] if f != "sharded"]
+            if not g["forms"]:
+                self._dpg = None   # nothing left to run: the next update builds the state (and its exchange) again
 
     def _train_data_parallel(self, perm: np.ndarray, lr: float, clip_range: float) -> None:
         """Minibatch loop with one RCCL all-reduce of the flat policy gradient per optimiser step

@@ -97,7 +97,8 @@ class BufferingWrapper(VecEnvWrapper):
         self._steps.append((self._last_obs, np.array(acts, copy=True), next_fixed, np.asarray(rews), dones))
         # the env's own dicts, verbatim, whenever it produced any (`data/wrappers.py:69-91` keeps every step's info);
         # array envs (infos None) never pay for dict lists
-        self._infos.append((infos if isinstance(infos, list) else list(infos)) if infos is not None else None)
+        # (a shallow copy of the LIST: an env may refill the same list object every step)
+        self._infos.append(list(infos) if infos is not None else None)
         self._last_obs = new_obs
         self.n_transitions += self.num_envs
         self._timesteps += 1
@@ -119,7 +120,12 @@ class BufferingWrapper(VecEnvWrapper):
         tile = np.empty((len(self._infos), n), dtype=object)
         for t, row in enumerate(self._infos):
             # (steps recorded without dicts between steps with them: an empty dict each, as before)
-            tile[t] = np.fromiter(row if row is not None else ({} for _ in range(n)), dtype=object, count=n)
+            it = row if row is not None else ({} for _ in range(n))
+            try:
+                tile[t] = np.fromiter(it, dtype=object, count=n)
+            except (TypeError, ValueError):   # NumPy < 1.23: no object dtype in `fromiter`
+                for j, d in enumerate(row if row is not None else ({} for _ in range(n))):
+                    tile[t, j] = d
         return tile.reshape(-1)[order]
 
     def pop_transitions_and_lens(self) -> Tuple[Optional[dt.TransitionsWithRew], List[int]]:

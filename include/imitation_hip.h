@@ -532,10 +532,12 @@ int ia_ppo_debug_timing(void* device_buffer_16xi64);
  * with whole row-block workgroups (eight waves, both towers, weight fragments from memory: the form before);
  * 3 = the one-tower kernel with grid barriers between the phases (default 0 hands the slabs, the partial sums of
  * squares and the new parameters over as 8-byte value / sequence words instead: no barrier; bit-identical results);
- * 4 = that word-exchange kernel with chunk owners (round 4's default) also where round 5's default applies: observation
- * widths <= 32 run `ppo_epoch_t64_kernel` -- every tower workgroup keeps its tower's parameters in LDS and Adam's moments
- * in registers for the launch and steps the whole tower itself (no parameter hand-off), the layer chain transposed and
- * register-resident as in the 32-wide persistent kernel ([SB3 PPO.train] on the default MlpPolicy). */
+ * 4 = that word-exchange kernel with round 4's gradient body (`ppo_epoch_ll_kernel`) also where the default applies:
+ * observation widths <= 32 run `ppo_epoch_ll2_kernel` -- the same word exchange (chunk owners sum, clip and step their
+ * chunk of the parameters and hand the new words on), with the gradient phase on the transposed register-resident layer
+ * chain of the 32-wide persistent kernel (activations in registers from x to dz1, weight fragments as one ds_read_b128
+ * of a padded LDS image; [SB3 PPO.train] on the default MlpPolicy). Wider observations keep `ppo_epoch_ll_kernel`;
+ * minibatches of more than 32 row blocks (or towers whose images do not fit in LDS) the barrier form (3). */
 int ia_ppo_epoch_split(int on);
 /* Measurement only: device buffer of 64 int64 (NULL: off); workgroup 0 of the one-launch-per-epoch kernel accumulates
  * 100 MHz ticks per phase in [0..5] = {gradient, barrier, slab sum, barrier, norm + Adam, barrier}; [16..27] / [32..43]:

@@ -286,7 +286,8 @@ def build_trainer(impl: str, cfg, log_dir: str, device: str = "cpu", module_net:
     trainer = cls(demonstrations=demos, demo_batch_size=cfg["demo_batch"], venv=venv, gen_algo=algo,
                   reward_net=net, demo_minibatch_size=cfg["demo_minibatch"],
                   n_disc_updates_per_round=cfg["n_disc"], gen_replay_buffer_capacity=cfg["capacity"],
-                  custom_logger=ns.configure_logger(log_dir), allow_variable_horizon=False)
+                  custom_logger=ns.configure_logger(log_dir), allow_variable_horizon=False,
+                  **({"gen_train_timesteps": cfg["gen_train_timesteps"]} if cfg.get("gen_train_timesteps") else {}))
     return trainer, venv
 
 

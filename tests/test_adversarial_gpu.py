@@ -241,12 +241,15 @@ def test_rollout_tail_in_one_call_is_bit_identical(tmp_path, case):
         assert logs[True][f] == logs[False][f], f
 
 
-@pytest.mark.parametrize("case,penalty", [("gail_fused", 0.0), ("gail_fused", 4.0), ("gail_box", 0.0), ("airl_tuned_hps", 3.0)])
-def test_round_draws_behind_the_rollout_noise_are_bit_identical(tmp_path, case, penalty):
+@pytest.mark.parametrize("case,penalty,iters", [("gail_fused", 0.0, 1), ("gail_fused", 4.0, 1), ("gail_box", 0.0, 1),
+                                                ("airl_tuned_hps", 3.0, 1), ("gail_fused", 4.0, 2), ("gail_box", 0.0, 3)])
+def test_round_draws_behind_the_rollout_noise_are_bit_identical(tmp_path, case, penalty, iters):
     """Pipelined rounds whose discriminator updates are what the next relabelling waits for take the round's draws from
     torch's global CPU generator (expert index rows, interpolation weights) right behind the rollout's noise draw instead of
     between the PPO launch and the round's enqueue (`AdversarialTrainer._round_predraw`): same draws, same order -> every
-    array, the penalty's mean and every log row bit for bit."""
+    array, the penalty's mean and every log row bit for bit. `iters` > 1: rounds of several PPO iterations
+    (`gen_train_timesteps = iters x n_steps x n_envs`) -- the draws are taken behind the LAST rollout's noise only (the
+    sequential schedule draws the other rollouts' noise first)."""
     import glob
 
     import imitation_amd as p
@@ -254,6 +257,8 @@ def test_round_draws_behind_the_rollout_noise_are_bit_identical(tmp_path, case, 
     outs, logs, pre = {}, {}, {}
     for mode in ("always", False):
         cfg = harness.CASES[case]
+        if iters > 1:
+            cfg = dict(cfg, gen_train_timesteps=iters * cfg["n_envs"] * cfg["n_steps"])
         d = str(tmp_path / f"log_{mode}")
         tr, _ = harness.build_trainer("hip", cfg, d, device="cuda")
         tr._logger = p.configure_logger(d, ["csv"])
@@ -261,7 +266,7 @@ def test_round_draws_behind_the_rollout_noise_are_bit_identical(tmp_path, case, 
         tr.predraw_round_draws = mode
         tr.disc_grad_penalty_coef = penalty
         th.manual_seed(78)
-        tr.train(4 * cfg["n_envs"] * cfg["n_steps"])
+        tr.train(4 * iters * cfg["n_envs"] * cfg["n_steps"])
         th.cuda.synchronize()
         outs[mode] = harness.snapshot(tr)
         if penalty:

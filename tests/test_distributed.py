@@ -185,10 +185,22 @@ def test_two_ranks_one_gpu_replicas_identical(tmp_path):
 # whose gradient stays in LDS) and a wide one -- 64 envs x 16 steps per rank, PPO minibatch 512 per rank: eight gradient
 # workgroups per rank, global minibatches of 1 024 rows whose statistics are taken in 512-row slices, records travelling
 # in four pieces per peer
-_EQUIV_GEOM = {"one_workgroup": {}, "eight_workgroups": dict(n_envs=64, ppo_batch=512)}
+# ... and config P's own per-rank geometry (bench.py: 1 024 envs x 16 steps, PPO minibatch 1 024 = sixteen gradient
+# workgroups + three per rank, global minibatches of world x 1 024 rows)
+_EQUIV_GEOM = {"one_workgroup": {}, "eight_workgroups": dict(n_envs=64, ppo_batch=512),
+               "config_p": dict(n_envs=1024, ppo_batch=1024)}
+# (world, geometry, data-parallel form of the PPO update): world 4 is the first time more than two writers meet in the
+# exchange's parity slots and the rank-order slice sums (4 x 11 resident workgroups sharded, 4 x 35 replicated: co-resident
+# on one GPU)
+_EQUIV_RUNS = [(2, "one_workgroup", "sharded"), (2, "eight_workgroups", "sharded"), (2, "config_p", "sharded"),
+               (2, "config_p", "replicated"), (4, "eight_workgroups", "sharded"), (4, "eight_workgroups", "replicated"),
+               (4, "one_workgroup", "sharded"),
+               # the last rank reports that it cannot map peer memory (test-only `IA_PEER_FAIL_RANK`): all four ranks must
+               # land on the replicated update and still equal the single process
+               (4, "one_workgroup", "handshake_fails")]
 
 
-def _equiv_worker(rank, world, port, out_dir, geom="one_workgroup"):
+def _equiv_worker(rank, world, port, out_dir, geom="one_workgroup", form="sharded"):
     _init(rank, world, port)
     th.cuda.set_device(0)
     th.set_num_threads(1)
@@ -207,7 +219,9 @@ def _equiv_worker(rank, world, port, out_dir, geom="one_workgroup"):
     algo = p.PPO(p.FeedForward32Policy, venv, n_steps=cfg["n_steps"], batch_size=cfg["ppo_batch"], n_epochs=2,
                  ent_coef=0.1, policy_kwargs=pk, device="cuda")
     algo.dp_global_minibatch = True
-    algo.dp_update_form = "sharded"
+    algo.dp_update_form = "sharded" if form == "handshake_fails" else form
+    if form == "handshake_fails":
+        os.environ["IA_PEER_FAIL_RANK"] = str(world - 1)
     net = p.BasicRewardNet(venv.observation_space, venv.action_space, hid_sizes=(32, 32),
                            normalize_input_layer=p.RunningNorm)
     demos = p.Transitions(**harness.make_demo_arrays(cfg, seed=1 + rank))
@@ -243,8 +257,12 @@ def _equiv_worker(rank, world, port, out_dir, geom="one_workgroup"):
     th.cuda.synchronize()
     out["pol_post"] = cpu(algo.policy.state_dict())
     g = algo._dpg
-    # the update above sharded each global minibatch's rows over the two ranks (records exchanged inside the kernels)
-    assert g["shard"] is not None and algo.dp_sharded_updates == 1
+    if form == "sharded":
+        # the update above sharded each global minibatch's rows over the ranks (records exchanged inside the kernels)
+        assert g["shard"] is not None and algo.dp_sharded_updates == 1 and not algo.dp_handshake_failed
+    else:
+        assert g["shard"] is None and getattr(algo, "dp_sharded_updates", 0) == 0   # whole global minibatch on every rank
+        assert algo.dp_handshake_failed == (form == "handshake_fails") and g["forms"] == ["replicated"]
     out["tile"] = {k: g[k].cpu().clone() for k in ("obs", "acts", "logp", "adv", "ret")}
     out["perm"] = g["perm_dev"].cpu().clone()
     out["stats"] = algo._stats_dev.cpu().clone() if algo._records is None else algo._records[(algo._rec_i - 1) % 2].stats.cpu().clone()
@@ -254,30 +272,35 @@ def _equiv_worker(rank, world, port, out_dir, geom="one_workgroup"):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("geom", list(_EQUIV_GEOM))
-def test_world_two_equals_single_process_on_the_concatenated_batch(tmp_path, geom):
+@pytest.mark.parametrize("world,geom,form", _EQUIV_RUNS, ids=[f"w{w}-{g}-{f}" for w, g, f in _EQUIV_RUNS])
+def test_world_n_equals_single_process_on_the_concatenated_batch(tmp_path, world, geom, form):
+    """`world` ranks sharing the box's one GPU (gloo collectives, hipIpc-mapped exchange areas) == ONE process on the
+    ranks' batches side by side: the PPO update against [SB3 PPO.train] restated on the concatenated rollout, the
+    discriminator against a single-process `train_disc` on the concatenated batches. Unmeasured on multi-GPU hardware."""
     if not th.cuda.is_available():
         pytest.skip("no GPU")
     port = _free_port()
-    mp.spawn(_equiv_worker, args=(2, port, str(tmp_path), geom), nprocs=2, join=True)
-    r0 = th.load(tmp_path / "equiv0.pt", weights_only=False)
-    r1 = th.load(tmp_path / "equiv1.pt", weights_only=False)
-    for k in r0["disc_post"]:
-        assert th.equal(r0["disc_post"][k], r1["disc_post"][k]), k
-    for k in r0["pol_post"]:
-        assert th.equal(r0["pol_post"][k], r1["pol_post"][k]), k
+    W = world
+    mp.spawn(_equiv_worker, args=(W, port, str(tmp_path), geom, form), nprocs=W, join=True)
+    rs = [th.load(tmp_path / f"equiv{r}.pt", weights_only=False) for r in range(W)]
+    r0 = rs[0]
+    for r1 in rs[1:]:
+        for k in r0["disc_post"]:
+            assert th.equal(r0["disc_post"][k], r1["disc_post"][k]), k
+        for k in r0["pol_post"]:
+            assert th.equal(r0["pol_post"][k], r1["pol_post"][k]), k
 
-    # ---- (1) PPO: world 2 == [SB3 PPO.train] restated, single process, on the side-by-side env batch with
-    #          batch_size 2 x 32 and the data-parallel run's permutations
+    # ---- (1) PPO: world W == [SB3 PPO.train] restated, single process, on the side-by-side env batch with
+    #          batch_size W x (per-rank batch) and the data-parallel run's permutations
     from imitation_amd import spaces
     from oracle import imitation_restated as o
     from oracle import sb3_restated as sb
     h = r0["hyper"]
-    T, n2, D, A = h["T"], 2 * h["n"], 17, 6
+    T, n2, D, A = h["T"], W * h["n"], 17, 6
     os_, as_ = spaces.Box(-np.inf, np.inf, (D,), np.float32), spaces.Box(-1, 1, (A,), np.float32)
     pol = sb.ActorCriticPolicy(os_, as_, lambda _: 3e-4, net_arch=[32, 32], features_extractor_class=o.NormalizeFeaturesExtractor)
     pol.load_state_dict(r0["pol_pre"])
-    algo = sb.PPO(sb.ActorCriticPolicy, None, n_steps=T, batch_size=2 * h["bs"], n_epochs=h["n_epochs"],
+    algo = sb.PPO(sb.ActorCriticPolicy, None, n_steps=T, batch_size=W * h["bs"], n_epochs=h["n_epochs"],
                   ent_coef=h["ent_coef"], _init_setup_model=False)
     algo.observation_space, algo.action_space, algo.n_envs = os_, as_, n2
     algo.policy = pol
@@ -301,9 +324,10 @@ def test_world_two_equals_single_process_on_the_concatenated_batch(tmp_path, geo
         algo.train()
     finally:
         np.random.permutation = real
-    k = h["n_epochs"] * (T * n2 // (2 * h["bs"]))
-    # the logged loss statistics travel in the records' tails: both ranks hold the same rows, equal to the oracle's means
-    assert th.equal(r0["stats"], r1["stats"])
+    k = h["n_epochs"] * (T * n2 // (W * h["bs"]))
+    # the logged loss statistics travel in the records' tails: all ranks hold the same rows, equal to the oracle's means
+    for r1 in rs[1:]:
+        assert th.equal(r0["stats"], r1["stats"])
     st, lg = r0["stats"].numpy().reshape(-1, 8), algo.logger.name_to_value
     assert st[:, 0].mean() == pytest.approx(lg["train/policy_gradient_loss"], rel=2e-3, abs=2e-5)
     assert st[:, 1].mean() == pytest.approx(lg["train/value_loss"], rel=2e-3)
@@ -316,7 +340,7 @@ def test_world_two_equals_single_process_on_the_concatenated_batch(tmp_path, geo
         else:
             th.testing.assert_close(got.float(), ref.float(), rtol=(1 + k) * 1e-5, atol=(1 + k) * 2e-6, msg=name)
 
-    # ---- (2) discriminator: world 2 == one process with demo_batch_size 2 x 64 on the concatenated batches
+    # ---- (2) discriminator: world W == one process with demo_batch_size W x 64 on the concatenated batches
     import imitation_amd as p
     from imitation_amd.vec_env import SyntheticVecEnv
     from tests import harness
@@ -330,14 +354,14 @@ def test_world_two_equals_single_process_on_the_concatenated_batch(tmp_path, geo
                ent_coef=0.1, policy_kwargs=pk, device="cuda")
     net = p.BasicRewardNet(venv.observation_space, venv.action_space, hid_sizes=(32, 32),
                            normalize_input_layer=p.RunningNorm)
-    tr = p.GAIL(demonstrations=p.Transitions(**harness.make_demo_arrays(cfg, seed=1)), demo_batch_size=128, venv=venv,
+    tr = p.GAIL(demonstrations=p.Transitions(**harness.make_demo_arrays(cfg, seed=1)), demo_batch_size=W * 64, venv=venv,
                 gen_algo=a1, reward_net=net, n_disc_updates_per_round=2,
                 custom_logger=p.configure_logger(str(tmp_path / "single"), []))
     for kk, v in tr._reward_net.state_dict().items():
         assert th.equal(v.cpu(), r0["disc_pre"][kk]), kk          # same starting point
-    cat = lambda a, b: {kk: np.concatenate([a[kk], b[kk]]) for kk in a}
-    for (e0, g0), (e1, g1) in zip(r0["batches"], r1["batches"]):
-        tr.train_disc(expert_samples=cat(e0, e1), gen_samples=cat(g0, g1))
+    cat = lambda parts: {kk: np.concatenate([a[kk] for a in parts]) for kk in parts[0]}
+    for per_rank in zip(*[r["batches"] for r in rs]):
+        tr.train_disc(expert_samples=cat([e for e, _ in per_rank]), gen_samples=cat([g_ for _, g_ in per_rank]))
     for kk, v in tr._reward_net.state_dict().items():
         if kk.endswith("count"):
             assert int(v) == int(r0["disc_post"][kk]), kk
@@ -502,7 +526,12 @@ def test_fused_updates_under_data_parallelism_replicas_identical(tmp_path):
     assert int(ld(0, "airl_norm")["disc/normalize_output_layer.count"]) == 2 * 3 * 16 * 8
 
 
-def _fused_equiv_worker(rank, world, port, out_dir):
+# geometry of the fused-update equivalence test: the harness case (8 envs, 128-row expert batches) and config P's per-rank
+# geometry (bench.py: 1 024 envs x 16 steps in the ring, 8 192-row expert batches = 16 384-row updates per rank)
+_FUSED_GEOM = {"gail_box": dict(demo_batch=128), "config_p": dict(n_envs=1024, demo_batch=8192, n_demo=20000)}
+
+
+def _fused_equiv_worker(rank, world, port, out_dir, geom="gail_box"):
     _init(rank, world, port)
     th.cuda.set_device(0)
     th.set_num_threads(1)
@@ -512,7 +541,7 @@ def _fused_equiv_worker(rank, world, port, out_dir):
     from imitation_amd.distributed import DataParallel
     from imitation_amd.vec_env import SyntheticVecEnv
     from tests import harness
-    cfg = harness.CASES["gail_box"]
+    cfg = dict(harness.CASES["gail_box"], **_FUSED_GEOM[geom])
     th.manual_seed(100 + rank)
     np.random.seed(100 + rank)
     venv = SyntheticVecEnv(num_envs=cfg["n_envs"], obs_dim=17, act_dim=6, horizon=cfg["horizon"], seed=rank)
@@ -523,8 +552,8 @@ def _fused_equiv_worker(rank, world, port, out_dir):
     net = p.BasicRewardNet(venv.observation_space, venv.action_space, hid_sizes=(256, 256),
                            normalize_input_layer=p.RunningNorm)
     demos = harness.make_demo_arrays(cfg, seed=1 + rank)
-    tr = p.GAIL(demonstrations=p.Transitions(**demos), demo_batch_size=128, venv=venv, gen_algo=algo, reward_net=net,
-                n_disc_updates_per_round=3, custom_logger=p.configure_logger(tempfile.mkdtemp(), []),
+    tr = p.GAIL(demonstrations=p.Transitions(**demos), demo_batch_size=cfg["demo_batch"], venv=venv, gen_algo=algo,
+                reward_net=net, n_disc_updates_per_round=3, custom_logger=p.configure_logger(tempfile.mkdtemp(), []),
                 data_parallel=DataParallel())
     tr.pipeline_rounds = False
     tr.train_gen()                       # one rollout (+ the data-parallel PPO update): fills the replay ring
@@ -560,13 +589,14 @@ def _fused_equiv_worker(rank, world, port, out_dir):
 
 
 @pytest.mark.gpu
-def test_world_two_fused_updates_equal_single_process_on_the_concatenated_batch(tmp_path):
+@pytest.mark.parametrize("geom", list(_FUSED_GEOM))
+def test_world_two_fused_updates_equal_single_process_on_the_concatenated_batch(tmp_path, geom):
     """The fused path (H = 256) under data parallelism == ONE process running the same fused round on the union of
     the ranks' batches (expert / replay tables and index batches concatenated in rank order)."""
     if not th.cuda.is_available():
         pytest.skip("no GPU")
     port = _free_port()
-    mp.spawn(_fused_equiv_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(_fused_equiv_worker, args=(2, port, str(tmp_path), geom), nprocs=2, join=True)
     r0 = th.load(tmp_path / "fequiv0.pt", weights_only=False)
     r1 = th.load(tmp_path / "fequiv1.pt", weights_only=False)
     for k in r0["disc_post"]:
@@ -577,7 +607,7 @@ def test_world_two_fused_updates_equal_single_process_on_the_concatenated_batch(
     import imitation_amd as p
     from imitation_amd.vec_env import SyntheticVecEnv
     from tests import harness
-    cfg = harness.CASES["gail_box"]
+    cfg = dict(harness.CASES["gail_box"], **_FUSED_GEOM[geom])
     th.manual_seed(100)
     np.random.seed(100)
     venv = SyntheticVecEnv(num_envs=cfg["n_envs"], obs_dim=17, act_dim=6, horizon=cfg["horizon"], seed=0)
@@ -590,7 +620,7 @@ def test_world_two_fused_updates_equal_single_process_on_the_concatenated_batch(
     cat = lambda a, b: {k: np.concatenate([a[k], b[k]]) for k in a}
     n_demo, cap = len(r0["demos"]["obs"]), r0["ring_n"]
     assert cap == r1["ring_n"] == len(r0["ring"]["obs"])
-    tr = p.GAIL(demonstrations=p.Transitions(**cat(r0["demos"], r1["demos"])), demo_batch_size=256, venv=venv,
+    tr = p.GAIL(demonstrations=p.Transitions(**cat(r0["demos"], r1["demos"])), demo_batch_size=2 * cfg["demo_batch"], venv=venv,
                 gen_algo=algo, reward_net=net, n_disc_updates_per_round=3, gen_replay_buffer_capacity=2 * cap,
                 custom_logger=p.configure_logger(str(tmp_path / "single"), []))
     tr._reward_net.load_state_dict(r0["disc_pre"])
@@ -618,7 +648,7 @@ def test_world_two_fused_updates_equal_single_process_on_the_concatenated_batch(
     th.cuda.synchronize()
     for kk, v in tr._reward_net.state_dict().items():
         if kk.endswith("count"):
-            assert int(v) == int(r0["disc_post"][kk]) == 3 * 512, kk
+            assert int(v) == int(r0["disc_post"][kk]) == 3 * 2 * 2 * cfg["demo_batch"], kk
         else:
             th.testing.assert_close(r0["disc_post"][kk], v.cpu(), rtol=2e-4, atol=5e-5, msg=kk)
     for kk, v in algo.policy.features_extractor.normalize.state_dict().items():
@@ -657,3 +687,56 @@ def test_bench_two_rank_launch_line_on_one_gpu(tmp_path):
     assert ch is not None and ch["chosen"] in ("sharded", "replicated") and ch["sharded_ms"] > 0 and ch["replicated_ms"] > 0
     assert out["config"]["ppo_update"].startswith("row-sharded" if ch["chosen"] == "sharded" else "replicated")
     assert all(not isinstance(v, (dict, list)) for v in out["roofline"].values())   # flat: scalars survive any parser
+
+
+def _bench_line(tmp_path, cmd, extra_env=None):
+    import json
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, IA_BENCH_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0", **(extra_env or {}))
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    res = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stderr[-4000:]
+    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, lines          # ONE JSON line, from rank 0
+    return json.loads(lines[0])
+
+
+@pytest.mark.gpu
+def test_bench_bare_command_launches_its_own_ranks(tmp_path):
+    """`python bench.py --gpus 2 ...` with no launcher environment (the shape of the driver's N = 1 command with another N):
+    the script re-runs itself under `torch.distributed.run`, one rank per GPU (here: two ranks on the one GPU), and rank 0
+    prints the one JSON line."""
+    if not th.cuda.is_available():
+        pytest.skip("no GPU")
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = _bench_line(tmp_path, [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup",
+                                 "5", "--prof-rounds", "1"])
+    assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["value"] > 0 and out["config"]["parallelism"] == "dp2"
+    ch = out["config"]["ppo_update_choice"]   # five warm-up rounds: the four timed trials and the verdict
+    assert ch is not None and ch["chosen"] in ("sharded", "replicated")
+    by_rank = out["config"]["ppo_update_by_rank"]
+    assert [b["rank"] for b in by_rank] == [0, 1] and {b["form"] for b in by_rank} == {ch["chosen"]}
+    assert not any(b["handshake_failed"] for b in by_rank)
+
+
+@pytest.mark.gpu
+def test_bench_failed_peer_handshake_lands_every_rank_on_the_replicated_update(tmp_path):
+    """One rank cannot export / map peer memory (test-only switch `IA_PEER_FAIL_RANK`): the ranks' common verdict sends
+    ALL of them to the replicated update -- no rank runs the sharded kernel against peers that are not there -- and the
+    line says so."""
+    if not th.cuda.is_available():
+        pytest.skip("no GPU")
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = _bench_line(tmp_path, [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup",
+                                 "2", "--prof-rounds", "1"], extra_env={"IA_PEER_FAIL_RANK": "1"})
+    assert out["n_gpus"] == 2 and out["value"] > 0
+    by_rank = out["config"]["ppo_update_by_rank"]
+    assert len(by_rank) == 2
+    for b in by_rank:
+        assert b["form"] == "replicated" and b["handshake_failed"] and b["sharded_updates"] == 0, b
+    assert out["config"]["ppo_update"].startswith("replicated") and "handshake failed" in out["config"]["ppo_update"]
+    assert out["config"]["ppo_update_choice"] is None

@@ -676,3 +676,74 @@ def test_randint_rows_are_dropped_when_the_generator_moved():
     np.random.rand()
     assert not pre.finish(out)
     assert pre.take_randint(40, 3, 10) is None
+
+
+def test_permutation_predraw_falls_back_to_public_state_api(monkeypatch):
+    """The speculation reads and moves NumPy's global MT19937 state inside the bit generator's own struct only after it has
+    PROVEN the struct's layout on a private generator (`_PermutationPredraw._raw_ok`). With the layout assumption wrong
+    (here: the key array looked for 8 bytes off) the proof trips and the same protocol runs through `np.random.get_state` /
+    `set_state`: identical permutations, identical index rows, identical generator states after each hand-over."""
+    from imitation_amd.ppo import _PermutationPredraw as P
+
+    monkeypatch.setattr(P, "_raw_proof", None)
+    assert P._raw_ok() is True          # this NumPy: the fast path is proven
+    assert P._global_mt()[1] is not None
+    n_epochs, size, high, rows, row_len = 3, 1000, 900, 4, 77
+
+    def run():
+        np.random.seed(11)
+        np.random.standard_normal(3)            # a cached Gaussian in the legacy state: must survive the hand-overs
+        pre = P(n_epochs, size)
+        out = np.empty((n_epochs, size), dtype=np.int64)
+        pre.start(out, randint_spec=(high, rows, row_len))
+        assert pre.finish(out)
+        mid = np.random.get_state()
+        r = pre.take_randint(high, rows, row_len)
+        assert r is not None
+        post = np.random.get_state()
+        return out.copy(), r.copy(), mid, post, np.random.standard_normal(2)
+
+    fast = run()
+    monkeypatch.setattr(P, "_KEY_OFFSET", 8)
+    monkeypatch.setattr(P, "_raw_proof", None)
+    assert P._raw_ok() is False         # the guard trips ...
+    bg, addr = P._global_mt()
+    assert bg is not None and addr is None   # ... and the public API takes over
+    slow = run()
+    np.random.seed(11)
+    np.random.standard_normal(3)
+    want_p = np.stack([np.random.permutation(size) for _ in range(n_epochs)])
+    want_mid = np.random.get_state()
+    want_r = np.stack([np.random.randint(high, size=row_len) for _ in range(rows)])
+    want_post = np.random.get_state()
+    want_g = np.random.standard_normal(2)
+    same_state = lambda a, b: a[0] == b[0] and np.array_equal(a[1], b[1]) and tuple(a[2:]) == tuple(b[2:])
+    for got in (fast, slow):
+        assert np.array_equal(got[0], want_p) and np.array_equal(got[1], want_r)
+        assert same_state(got[2], want_mid) and same_state(got[3], want_post)
+        assert np.array_equal(got[4], want_g)
+    # a foreign draw during the speculation window is still noticed on the public path
+    pre = P(2, 50)
+    out = np.empty((2, 50), dtype=np.int64)
+    pre.start(out)
+    np.random.rand()
+    assert not pre.finish(out)
+    monkeypatch.setattr(P, "_KEY_OFFSET", 0)
+    monkeypatch.setattr(P, "_raw_proof", None)
+    assert P._raw_ok() is True
+
+
+def test_stale_armed_rows_are_never_handed_over():
+    """Rows armed by one round must not survive into a later one: `start` and a failing `finish` both disarm them (the
+    generator state they were drawn from is gone)."""
+    from imitation_amd.ppo import _PermutationPredraw as P
+    np.random.seed(21)
+    pre = P(2, 64)
+    out = np.empty((2, 64), dtype=np.int64)
+    pre.start(out, randint_spec=(50, 2, 9))
+    assert pre.finish(out) and pre._rr_armed is not None
+    pre.start(out, randint_spec=(50, 2, 9))            # the next round starts without the rows having been taken
+    assert pre._rr_armed is None
+    np.random.rand()
+    assert not pre.finish(out) and pre._rr_armed is None
+    assert pre.take_randint(50, 2, 9) is None
