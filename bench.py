@@ -582,6 +582,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--prof-rounds", type=int, default=2)
     ap.add_argument("--no-variants", action="store_true")
+    ap.add_argument("--long-rounds", type=int, default=200)   # total rounds of the longer sample behind the timed region
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -627,15 +628,43 @@ def main():
             dist.barrier()
             th.cuda.synchronize()
 
+    def over_ranks(x):   # the slowest rank's time
+        if world > 1:
+            tmax = th.tensor([x], device="cuda", dtype=th.float64)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            x = float(tmax.item())
+        return x
+
     barrier()
+    trainer.round_wall_stamps = stamps = []   # (a host time stamp per round: the spread inside the timed call)
     t0 = time.perf_counter()
     trainer.train(args.steps * per_round)
     barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        tmax = th.tensor([dt], device="cuda", dtype=th.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
+    dt = over_ranks(time.perf_counter() - t0)
+    trainer.round_wall_stamps = None
+    # spread of the timed rounds (rank 0's host stamps; the first interval starts at t0) ...
+    gaps = np.diff(np.array([t0] + stamps)) * 1e3
+    spread = None
+    if len(gaps) >= 2:
+        spread = {"ms_per_step_median": float(np.median(gaps)), "ms_per_step_p10": float(np.percentile(gaps, 10)),
+                  "ms_per_step_p90": float(np.percentile(gaps, 90)), "ms_per_step_min": float(gaps.min()),
+                  "ms_per_step_max": float(gaps.max()), "rounds": int(len(gaps)),
+                  "note": "host time stamps at the end of each round's iteration inside the ONE timed train() call; "
+                          "under the pipelined schedule a stamp leads the device by up to one round's updates, so single "
+                          "gaps are indicative and their sum is what `ms_per_step` measures"}
+    # ... and a longer sample right behind the timed region, so that K x 3.8 ms is never the only number: the same call
+    # over `--long-rounds` rounds (default 200 minus K), timed the same way; `value_long` covers both regions together
+    long_rounds = max(0, args.long_rounds - args.steps)
+    value_long = None
+    if long_rounds > 0:
+        barrier()
+        t1 = time.perf_counter()
+        trainer.train(long_rounds * per_round)
+        barrier()
+        dt_long = over_ranks(time.perf_counter() - t1)
+        value_long = {"value": world * (args.steps + long_rounds) * per_round / (dt + dt_long), "unit": "env-steps/s",
+                      "rounds": args.steps + long_rounds, "ms_per_step": 1e3 * (dt + dt_long) / (args.steps + long_rounds),
+                      "value_extra_rounds_only": world * long_rounds * per_round / dt_long}
 
     # the profiled rounds are training rounds too: under data parallelism EVERY rank must take part in
     # their collectives (only rank 0's measurement is reported)
@@ -687,6 +716,9 @@ def main():
         # compact record of everything a reader needs first (the driver keeps scalar fields and the END of the line):
         summary = {
             "headline_env_steps_per_s": r3(value), "ms_per_round": r3(1e3 * dt / args.steps), "n_gpus": world,
+            "ms_per_round_p10_median_p90": ([r3(spread["ms_per_step_p10"]), r3(spread["ms_per_step_median"]),
+                                             r3(spread["ms_per_step_p90"])] if spread else None),
+            "env_steps_per_s_over_200_rounds": r3(value_long["value"]) if value_long else None,
             "ppo": {"us_per_step": r3(ppo.get("us_per_step")), "launch_us": r3(ppo.get("avg_launch_us")),
                     "steps_per_launch": ppo.get("optimizer_steps_per_launch"), "frac_mfma": r3(ppo.get("frac")),
                     "traffic": ppo.get("traffic"), "algorithmic_bytes": ppo.get("algorithmic_bytes_per_launch")},
@@ -718,6 +750,9 @@ def main():
             "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            **({k: v for k, v in spread.items() if k.startswith("ms_per_step_")} if spread else {}),
+            "value_200": (value_long["value"] if value_long and value_long["rounds"] == 200 else None),
+            "spread": spread, "value_long": value_long,
             "summary": summary,
             "config": {"workload": "GAIL round, config P (BASELINE.json configs[1]): seals/HalfCheetah-shaped "
                                    "obs17/act6 synthetic VecEnv, n_envs=1024/GPU x n_steps=16, disc BasicRewardNet "

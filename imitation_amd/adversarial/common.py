@@ -14,6 +14,7 @@ from __future__ import annotations
 import abc
 import contextlib
 import os
+import time
 from typing import Callable, Dict, Iterable, Mapping, Optional, Type
 
 import numpy as np
@@ -113,6 +114,10 @@ class AdversarialTrainer(abc.ABC):
         # (`_round_predraw`; same draws, same order). False: always in place; "always": whatever the device is doing (tests).
         self.predraw_round_draws = True
         self.round_draws_predrawn = 0    # rounds that found all their expert rows drawn ahead (tests, profiles)
+        # measurement (`bench.py`): a list here collects `time.perf_counter()` at the end of every round's host iteration --
+        # the spread of the rounds inside one `train()` call, on every schedule, without a callback (which would switch
+        # the pipelined schedule off)
+        self.round_wall_stamps: Optional[list] = None
         self._pre_expert_rows = []
         self._gp_round_pre = None
         self._disc_critical = False
@@ -1215,6 +1220,8 @@ class AdversarialTrainer(abc.ABC):
             if callback:
                 callback(r)
             self.logger.dump(self._global_step)
+            if self.round_wall_stamps is not None:
+                self.round_wall_stamps.append(time.perf_counter())
 
     def _choose_disc_behind_ppo(self) -> bool:
         if self._needs_logp:
@@ -1350,6 +1357,8 @@ class AdversarialTrainer(abc.ABC):
                     drain(final=True)
                 train_rec, algo._pending_train = algo._pending_train, None
                 previous.append((pend, done, self.logger.detach_pending(), self._global_step, train_rec))
+                if self.round_wall_stamps is not None:
+                    self.round_wall_stamps.append(time.perf_counter())
             drain(final=True)
             main.wait_stream(self._disc_stream)
         finally:
