@@ -1791,6 +1791,20 @@ __device__ __forceinline__ void wave_sync_lds() {
 // of the small tiles cleared. Wave (tower tw, quarter q) and its twin of the other tower share the quarter's 16 rows.
 // Depends on the minibatch and its statistics only -- NOT on the parameters -- so the persistent kernel runs it for the
 // next minibatch while this minibatch's sum vector is still on its way (`STAGED` chain).
+// The transposed towers' LDS image of the persistent update (`sPt`): rows TSTR = 36 floats apart instead of H = 32, every
+// matrix at `upd_tbase(its offset in the parameter vector)` (36/32 of it: a matrix of n = 32 c floats grows to 36 c, so the
+// scaled intervals stay disjoint). Why: Adam writes parameter i of thread tid + 512 k to the transposed copy as well; with
+// rows 32 apart consecutive lanes (consecutive input columns of one output row) hit ONE bank -- a 32-way conflict on W2,
+// 17-way on W1 at 17 observation columns: ~2 600 LDS cycles per step = 1.1 of the Adam phase's 1.3 us in every gradient
+// workgroup. 36 = 4 (mod 32): the writes spread over 8 banks (4-way: 2x a conflict-free ds_write_b32, guide's LDS table),
+// and the chain's fragment reads (lane group lk = rows 4 lk + r: 4 x 36 = 16 mod 32) become conflict-free (2-way before).
+#ifndef IA_UPD_TSTR
+#define IA_UPD_TSTR 36   // (32: the unpadded image, for same-box A/Bs -- tools/ab_libs.sh)
+#endif
+constexpr int UPD_TSTR = IA_UPD_TSTR;
+__host__ __device__ inline int upd_tbase(int off) { return (off * UPD_TSTR + 31) >> 5; }
+__host__ __device__ inline int upd_pt4(int P4) { return (upd_tbase(P4) + 3) & ~3; }   // floats of the padded image
+
 template <bool SMALL>
 __device__ __forceinline__ void chain_stage_rows(const ia_policy_desc& d, const float* __restrict__ nm,
                                                  const float* __restrict__ nv, const int i0, const int row_lim,
@@ -1898,7 +1912,9 @@ __device__ __forceinline__ void mfma32_minibatch_chain(
   const int S1 = (D + 3) >> 2;
   const int oW1 = tw ? o.vW1 : o.pW1, ob1 = tw ? o.vb1 : o.pb1, oW2 = tw ? o.vW2 : o.pW2, ob2 = tw ? o.vb2 : o.pb2;
   const float* __restrict__ sP = sP_in + opaque_zero;
-  const float* __restrict__ sPt = sP + ((o.total + 3) & ~3);
+  const float* __restrict__ sPt = sP + ((o.total + 3) & ~3);   // padded image: rows UPD_TSTR apart, bases upd_tbase(.)
+  constexpr int TS_ = UPD_TSTR;
+  const int tW1 = upd_tbase(oW1), tW2 = upd_tbase(oW2);
   IA_TS(0);
 
   // ---- per-row scalars of the loss. The chain below runs TRANSPOSED -- features along the MFMA's M index, the wave's 16
@@ -1942,7 +1958,7 @@ __device__ __forceinline__ void mfma32_minibatch_chain(
 #pragma unroll
       for (int t = 0; t < 2; ++t)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) fW1[kt][t][r] = sPt[oW1 + min(16 * kt + 4 * lk + r, D - 1) * H + 16 * t + li];
+        for (int r = 0; r < 4; ++r) fW1[kt][t][r] = sPt[tW1 + min(16 * kt + 4 * lk + r, D - 1) * TS_ + 16 * t + li];
     } else {
 #pragma unroll
       for (int t = 0; t < 2; ++t)
@@ -2047,7 +2063,7 @@ __device__ __forceinline__ void mfma32_minibatch_chain(
 #pragma unroll
       for (int r = 0; r < 4; ++r)
 #pragma unroll
-        for (int t = 0; t < 2; ++t) fW2[kt][t][r] = sPt[oW2 + (16 * kt + 4 * lk + r) * H + 16 * t + li];
+        for (int t = 0; t < 2; ++t) fW2[kt][t][r] = sPt[tW2 + (16 * kt + 4 * lk + r) * TS_ + 16 * t + li];
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -4687,8 +4703,8 @@ __global__ __launch_bounds__(512) void ppo_update_persistent_kernel(
   // ---------------- gradient blocks
   constexpr int PROWS = SMALL ? 16 : ROWS;   // rows a minibatch of this workgroup can have
   float* sP = lds + L::total;
-  float* sPt = sP + w.P4;
-  float* stg = sPt + w.P4;                    // UpdStage: the NEXT minibatch's rows of this block
+  float* sPt = sP + w.P4;                     // transposed towers, padded rows (UPD_TSTR; see there)
+  float* stg = sPt + upd_pt4(w.P4);           // UpdStage: the NEXT minibatch's rows of this block
   unsigned short* dstT = reinterpret_cast<unsigned short*>(stg + UpdStage::total(d.discrete ? 1 : d.act_dim));  // [P4] index of parameter i in the transposed copy
   // (the 64 floats at lds + L::scratch are the block reductions' scratch)
   const int lane = tid & 63;
@@ -4698,19 +4714,20 @@ __global__ __launch_bounds__(512) void ppo_update_persistent_kernel(
     const int i = tid + k * 512;
     rm[k] = rv[k] = 0.f;
     if (i < o.total) {
-      sP[i] = P[i];
-      sPt[i] = Pt[i];
+      const float pi_ = P[i];
+      sP[i] = pi_;
       rm[k] = m[i];
       rv[k] = v[i];
-      int dst = i;
+      int dst = 0xffff;   // (not a tower matrix: no transposed copy inside this kernel)
       auto tr = [&](int base, int rows, int cols) {
         if (i >= base && i < base + rows * cols) {
           const int rr = (i - base) / cols, cc = (i - base) % cols;
-          dst = base + cc * rows + rr;
+          dst = upd_tbase(base) + cc * UPD_TSTR + rr;
         }
       };
       tr(o.pW1, H, D); tr(o.pW2, H, H); tr(o.vW1, H, D); tr(o.vW2, H, H);
       dstT[i] = (unsigned short)dst;
+      if (dst != 0xffff) sPt[dst] = pi_;   // (= Pt's value of that element: the global copy is rewritten when the launch ends)
     }
   }
   // Row prefetch: the gathers of step s+1 (two dependent global loads per element) are issued
@@ -5333,7 +5350,7 @@ __global__ __launch_bounds__(512) void ppo_update_persistent_kernel(
         const int i = tid + k * 512;
         if (i < o.total) {
           sP[i] = pv[k];
-          sPt[dt[k]] = pv[k];
+          if (dt[k] != 0xffff) sPt[dt[k]] = pv[k];
         }
       }
     }
@@ -5357,8 +5374,17 @@ __global__ __launch_bounds__(512) void ppo_update_persistent_kernel(
     for (int k = 0; k < NPT; ++k) {
       const int i = tid + k * 512;
       if (i < o.total) {
-        P[i] = sP[i];
-        Pt[i] = sPt[i];
+        const float pi_ = sP[i];
+        P[i] = pi_;
+        int dst = i;   // element i's place in the global transposed copy (`transpose_params_kernel`'s layout)
+        auto tr = [&](int base, int rows, int cols) {
+          if (i >= base && i < base + rows * cols) {
+            const int rr = (i - base) / cols, cc = (i - base) % cols;
+            dst = base + cc * rows + rr;
+          }
+        };
+        tr(o.pW1, H, D); tr(o.pW2, H, H); tr(o.vW1, H, D); tr(o.vW2, H, H);
+        Pt[dst] = pi_;
         m[i] = rm[k];
         v[i] = rv[k];
       }
@@ -6035,7 +6061,7 @@ int ia_ppo_epochs(const ia_policy_desc* d, float* params, float* params_t, float
 
 // LDS of a gradient block: minibatch tiles, both parameter copies, the staged next minibatch, the transpose map
 inline size_t upd_grad_lds_bytes(int P4, int aw) {
-  return 16 /* base rounded up to 16 bytes */ + (CLds::total + 2 * (size_t)P4 + UpdStage::total(aw)) * sizeof(float) +
+  return 16 /* base rounded up to 16 bytes */ + (CLds::total + (size_t)P4 + upd_pt4(P4) + UpdStage::total(aw)) * sizeof(float) +
          P4 * sizeof(unsigned short);
 }
 
