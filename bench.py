@@ -271,6 +271,7 @@ def gemm_roofline(trainer, cfg, rounds):
                # GPU time, act / relabel / GAE / copies included, is in the rocprofv3 summary under profiles/
                "share_of_ppo_plus_disc_gpu_time": avg / (avg + disc_ms_round),
                "algorithmic_bytes_per_launch": steps * rows * (D + A + 4) * 4.0,
+               **_ppo_floor(D, A, rows, 1e3 * avg / steps),
                "note": "largest kernel by GPU time: a chain of dependent 1024-row optimiser steps on nblk+3 workgroups "
                        "(the reference's minibatch semantics), bound by per-step latency (grid barrier, slab reduce, "
                        "Adam), not by MFMA or HBM throughput: read us_per_step, not frac. The throughput kernels are "
@@ -280,6 +281,18 @@ def gemm_roofline(trainer, cfg, rounds):
     top["gemm"] = gemm
     top["ppo_update"] = ppo
     return top
+
+
+def _ppo_floor(D, A, rows, us_per_step):
+    """The computed floor of one optimiser step (`tools/ppo_step_floor.py`: longest dependent path priced with the guide's
+    issue / MFMA / LDS / fabric constants, nothing measured) beside the measured step, so the latency kernel's number has a
+    denominator: `us_per_step_over_floor` is the figure to read, not `frac`."""
+    try:
+        from tools.ppo_step_floor import model
+        m = model(D, A, rows)
+        return {"floor_us": m["floor_us"], "floor_chain_us": m["chain_us"], "us_per_step_over_floor": us_per_step / m["floor_us"]}
+    except Exception as e:   # the figure is a derived annotation: never take the line down
+        return {"floor_us": None, "floor_error": f"{type(e).__name__}: {e}"}
 
 
 # ---- the other BASELINE.json / SURVEY 8d configurations, driver-timed under `variants` -----------------
@@ -719,7 +732,8 @@ def main():
             "ms_per_round_p10_median_p90": ([r3(spread["ms_per_step_p10"]), r3(spread["ms_per_step_median"]),
                                              r3(spread["ms_per_step_p90"])] if spread else None),
             "env_steps_per_s_over_200_rounds": r3(value_long["value"]) if value_long else None,
-            "ppo": {"us_per_step": r3(ppo.get("us_per_step")), "launch_us": r3(ppo.get("avg_launch_us")),
+            "ppo": {"us_per_step": r3(ppo.get("us_per_step")), "floor_us": r3(ppo.get("floor_us")),
+                    "us_per_step_over_floor": r3(ppo.get("us_per_step_over_floor")), "launch_us": r3(ppo.get("avg_launch_us")),
                     "steps_per_launch": ppo.get("optimizer_steps_per_launch"), "frac_mfma": r3(ppo.get("frac")),
                     "traffic": ppo.get("traffic"), "algorithmic_bytes": ppo.get("algorithmic_bytes_per_launch")},
             "disc_update": {"us": r3(disc.get("us")), "us_in_rounds": r3(disc.get("us_in_rounds")),

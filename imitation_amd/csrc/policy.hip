@@ -1924,14 +1924,24 @@ __device__ __forceinline__ void mfma32_minibatch_chain(
   const int lrow = q * 16 + (lane & 15);   // local row of this lane
   const bool valid = (i0 + lrow) < row_lim;
   float r_oldlp = 0.f, r_adv = 0.f, r_ret = 0.f, r_act[4] = {0.f, 0.f, 0.f, 0.f};
+  // Round 6, minibatches of <= 16 rows (SMALL: the value wave has a SIMD to itself and reaches the barrier below early): what
+  // the policy wave's loss needs but the towers do not -- the rows' NORMALISED advantages (one IEEE division per row) and the
+  // per-action Gaussian constants (exp, IEEE division, log of `log_std`) -- is formed by the VALUE wave and handed over through
+  // LDS (the staged advantages in place; the constants in the upper half of the block-reduction scratch, free during the
+  // chain): same operations on the same inputs, bit for bit (`tools/ppo_bits.py`), ~70 instructions and their dependent
+  // latencies off the policy wave's path: 7.53 -> 7.40 us per step on the tuned AIRL file. With full workgroups the two towers
+  // of a row quarter SHARE a SIMD and the hand-over measures 2-4 % slower (`profiles/r06_ppo_ab.md`): they keep the old split.
+  constexpr bool HANDOVER = SMALL;
   if (tw == 0) {   // staged by the prefetch (LDS-direct loads); unconditional, clamped
     r_oldlp = stg[UpdStage::oldlp + lrow];
-    r_adv = stg[UpdStage::adv + lrow];
+    if constexpr (!HANDOVER) r_adv = stg[UpdStage::adv + lrow];
 #pragma unroll
     for (int j = 0; j < 4; ++j) r_act[j] = stg[UpdStage::act + lrow * aw + min(4 * (lane >> 4) + j, aw - 1)];
   } else {
     r_ret = stg[UpdStage::ret + lrow];
+    if constexpr (HANDOVER) r_adv = stg[UpdStage::adv + lrow];
   }
+  float* gconst = lds + L::scratch + 32;   // (HANDOVER) [16] 1 / sd^2, [16] log sd, of actions 0..15
 
   IA_TS(9);
   // (SMALL: rows 16.. do not exist in any minibatch of the launch; the caller zeroed every tile once, their waves idle)
@@ -1981,11 +1991,28 @@ __device__ __forceinline__ void mfma32_minibatch_chain(
     for (int t = 0; t < 2; ++t)
 #pragma unroll
       for (int r = 0; r < 4; ++r) fW1[kt][t][r] = (16 * kt + 4 * lk + r < D) ? fW1[kt][t][r] : 0.f;
-  // per-action Gaussian constants; the reciprocal variance turns the ~3 IEEE divisions per action and
-  // row of the loss into multiplications (<= 1 ulp away from dividing). Lane a computes action a's pair
-  // once (exp, division, log); every lane then picks its four actions' pairs up from the wave.
-  float c_ivar[4], c_logsd[4];   // of this lane's actions 4 lk + j
-  {
+  float c_ivar[4] = {1.f, 1.f, 1.f, 1.f}, c_logsd[4] = {0.f, 0.f, 0.f, 0.f};   // of this lane's actions 4 lk + j (policy waves; read behind the barrier)
+  if constexpr (HANDOVER) {
+    if (tw != 0) {
+      if (!idle) {   // this wave's 16 rows: the advantage as the loss uses it
+        float advn = r_adv;
+        if (normalize_adv && batch > 1) advn = (advn - adv_mean) / (adv_std + 1e-8f);
+        if (lk == 0) stg_in[opaque_zero + UpdStage::adv + lrow] = advn;
+      }
+      if (q == 0 && !d.discrete) {
+        const float sd = expf(my_sd);
+        const float my_ivar = lane < A ? 1.f / (sd * sd) : 1.f;
+        const float my_logsd = lane < A ? logf(sd) : 0.f;
+        if (lane < 16) {
+          gconst[lane] = my_ivar;
+          gconst[16 + lane] = my_logsd;
+        }
+      }
+    }
+  } else {
+    // per-action Gaussian constants; the reciprocal variance turns the ~3 IEEE divisions per action and row of the loss into
+    // multiplications (<= 1 ulp away from dividing). Lane a computes action a's pair once (exp, division, log); every lane
+    // then picks its four actions' pairs up from the wave.
     float my_ivar = 1.f, my_logsd = 0.f;
     if (tw == 0 && !d.discrete) {
       const float sd = expf(my_sd);
@@ -2048,6 +2075,14 @@ __device__ __forceinline__ void mfma32_minibatch_chain(
     for (int kt = 0; kt < KT1; ++kt)
 #pragma unroll
       for (int r = 0; r < 4; ++r) xb[kt][r] = lds[L::x + min(16 * kt + 4 * lk + r, MAXD - 1) * L::RS + q * 16 + li];
+    if (HANDOVER && tw == 0) {   // the value wave's hand-over (landed long before the loss phase reads the registers)
+      r_adv = stg_in[opaque_zero + UpdStage::adv + lrow];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        c_ivar[j] = gconst[4 * lk + j];
+        c_logsd[j] = gconst[16 + 4 * lk + j];
+      }
+    }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int kt = 0; kt < KT1; ++kt)
@@ -2182,8 +2217,9 @@ __device__ __forceinline__ void mfma32_minibatch_chain(
       entropy = group_sum(entropy);
     }
     IA_TS(13);
-    float advn = r_adv;
-    if (normalize_adv && batch > 1) advn = (advn - adv_mean) / (adv_std + 1e-8f);
+    float advn = r_adv;   // (HANDOVER: normalised by the value wave of these rows, see the top of the chain)
+    if constexpr (!HANDOVER)
+      if (normalize_adv && batch > 1) advn = (advn - adv_mean) / (adv_std + 1e-8f);
     const float log_ratio = logp - r_oldlp;
     const float ratio = expf(log_ratio);
     const float lo = 1.f - clip, hi = 1.f + clip;
