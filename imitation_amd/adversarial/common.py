@@ -836,10 +836,27 @@ class AdversarialTrainer(abc.ABC):
         if events[k] is not None:
             events[k].synchronize()
         th.rand(mb, out=host[k])
-        dev[k].copy_(host[k], non_blocking=True)
+        self._h2d_off_stream(dev[k], host[k])
         events[k] = th.cuda.Event()
         events[k].record()
         return dev[k]
+
+    def _h2d_off_stream(self, dst: th.Tensor, src: th.Tensor) -> None:
+        """Pinned -> device copy on the upload side stream, the current stream waiting for it -- instead of a copy IN the
+        current stream. AIRL's discriminator stream waits for the PPO update (its log pi needs the updated policy); a copy
+        enqueued behind that wait sits in the copy engine's queue until the PPO kernel ends, and every later copy of ANY
+        stream queues behind it: with the penalty on, the read-back of the previous round's generator statistics
+        (`PPO.finalize_train`, its own side stream) took 1.28 ms instead of 0.14 and the next rollout began that much
+        later (`tools/drain_probe.py`, `profiles/r06_airl_gp.md`)."""
+        up, cur = L.side_stream(self._device, "upload"), th.cuda.current_stream()
+        if up == cur:
+            dst.copy_(src, non_blocking=True)
+            return
+        with th.cuda.stream(up):
+            dst.copy_(src, non_blocking=True)
+            ev = th.cuda.Event()
+            ev.record()
+        cur.wait_event(ev)
 
     def _gp_predraw_for_round(self, n_updates: int) -> None:
         """Pre-draws the interpolation weights of the round's remaining updates when every update asks for exactly one
@@ -872,7 +889,7 @@ class AdversarialTrainer(abc.ABC):
         if b[2] is not None:
             b[2].synchronize()
         th.rand(count, mb, out=b[0])
-        b[1].copy_(b[0], non_blocking=True)
+        self._h2d_off_stream(b[1], b[0])
         self._gp_block = [b[1], b, 0]
 
     def _round_predraw(self, last_rollout: bool = True) -> None:

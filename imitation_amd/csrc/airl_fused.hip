@@ -196,7 +196,7 @@ __device__ __forceinline__ float dot_features(const f32x16& h, const f32x16& w) 
 }
 
 long long* g_airl_tstamp = nullptr;   // debug: >= 16 shader clocks of workgroup 0's first wave (ia_airl_debug_timing)
-#define AIRL_TS(slot) do { if (ts && blockIdx.x == 0 && threadIdx.x == 0) ts[slot] = clock64(); } while (0)
+#define AIRL_TS(slot) do { if (ts && bid == 0 && threadIdx.x == 0) ts[slot] = clock64(); } while (0)
 
 struct AirlLds {
   f32x4 bW1f[A_CH * 64], pW1f[A_CH * 64], W2f[4 * 64], W2tf[4 * 64];
@@ -206,13 +206,15 @@ struct AirlLds {
   int is_last;
 };
 
-__global__ __launch_bounds__(A_THREADS) void airl_rows_kernel(AirlArgs a, long long* __restrict__ ts) {
-  __shared__ __attribute__((aligned(16))) AirlLds S;
+// (`bid` of `nblocks`: this workgroup's place among the launch's workgroups of THIS body -- the update's rows and the
+//  gradient penalty's rows can share one launch, `airl_rows_gp_kernel`)
+__device__ __forceinline__ void airl_rows_body(const AirlArgs& a, long long* __restrict__ ts, AirlLds& S, const int bid,
+                                               const unsigned nblocks) {
   AIRL_TS(0);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int half = lane >> 5;
   const int Cb = (a.Db + 7) >> 3, Cp = (a.Dp + 7) >> 3;
-  const int r = blockIdx.x * A_ROWS + wave * 32 + (lane & 31);
+  const int r = bid * A_ROWS + wave * 32 + (lane & 31);
   const bool live = r < a.R;
   const int rr = live ? r : a.R - 1;             // (rows past the end recompute the last one; nothing of theirs is stored or summed)
   f32x4 rawb[A_CH], rawn[A_CH], rawc[A_CH];
@@ -393,11 +395,11 @@ __global__ __launch_bounds__(A_THREADS) void airl_rows_kernel(AirlArgs a, long l
     float tsum = S.red[0][tid];
 #pragma unroll
     for (int w = 1; w < A_WAVES; ++w) tsum += S.red[w][tid];
-    float* slab = a.part + (long long)blockIdx.x * a.part_stride;
+    float* slab = a.part + (long long)bid * a.part_stride;
     if (tid < AH) slab[a.off_b_wout + tid] = tsum;
     else if (tid < 2 * AH) slab[a.off_p_wout + tid - AH] = tsum;
     else if (tid < 2 * AH + 6)   // (written THROUGH to memory: the hand-off below then needs no L2 write-back)
-      __hip_atomic_store(a.bce_part + blockIdx.x * 8 + tid - 2 * AH, tsum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      __hip_atomic_store(a.bce_part + bid * 8 + tid - 2 * AH, tsum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     else if (tid == 2 * AH + 6) slab[a.off_b_bout] = tsum;
     else slab[a.off_p_bout] = tsum;
   }
@@ -412,7 +414,7 @@ __global__ __launch_bounds__(A_THREADS) void airl_rows_kernel(AirlArgs a, long l
   if (tid == 0) {
     const unsigned tk = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     AIRL_TS(8);
-    S.is_last = (tk == gridDim.x - 1);
+    S.is_last = (tk == nblocks - 1);
   }
   __syncthreads();
   if (!S.is_last) return;
@@ -422,7 +424,7 @@ __global__ __launch_bounds__(A_THREADS) void airl_rows_kernel(AirlArgs a, long l
     const int k = tid >> 5, j = tid & 31;
     float t = 0.f;
     if (k < 6)
-      for (unsigned b = j; b < gridDim.x; b += 32)
+      for (unsigned b = j; b < nblocks; b += 32)
         t += __hip_atomic_load(a.bce_part + b * 8 + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     float* fold = &S.red[0][0];          // (the block sums above were consumed before the last barrier: reuse 8 x 32 floats)
     if (k < 8) fold[k * 32 + j] = t;
@@ -437,6 +439,11 @@ __global__ __launch_bounds__(A_THREADS) void airl_rows_kernel(AirlArgs a, long l
   if (tid == 6) a.stats[6] = (float)a.n_expert;
   if (tid == 7) a.stats[7] = (float)(a.R - a.n_expert);
   if (tid == 0) __hip_atomic_store(a.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__global__ __launch_bounds__(A_THREADS) void airl_rows_kernel(AirlArgs a, long long* __restrict__ ts) {
+  __shared__ __attribute__((aligned(16))) AirlLds S;
+  airl_rows_body(a, ts, S, blockIdx.x, gridDim.x);
 }
 
 
@@ -681,14 +688,12 @@ __device__ __forceinline__ void gp_input_grad(const f32x16& u, const f32x4* __re
   }
 }
 
-__global__ __launch_bounds__(A_THREADS) void airl_gp_rows_kernel(AirlGpArgs a) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char gp_raw[];
-  GpLds& S = *reinterpret_cast<GpLds*>(gp_raw);
+__device__ __forceinline__ void airl_gp_rows_body(const AirlGpArgs& a, GpLds& S, const int bid, const unsigned nblocks) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int half = lane >> 5, lrow = lane & 31;
   const int Cb = (a.Db + 7) >> 3, Cp = (a.Dp + 7) >> 3;
   const int Tb = (a.Db + 31) >> 5, Tp = (a.Dp + 31) >> 5;
-  const int r = blockIdx.x * A_ROWS + wave * 32 + lrow;
+  const int r = bid * A_ROWS + wave * 32 + lrow;
   const bool live = r < a.B;
   const int rr = live ? r : a.B - 1;
   f32x4 b0[A_CH], b1[A_CH], n0[A_CH], n1[A_CH], c0[A_CH], c1[A_CH];
@@ -940,24 +945,39 @@ __global__ __launch_bounds__(A_THREADS) void airl_gp_rows_kernel(AirlGpArgs a) {
     float tsum = S.red[0][tid];
 #pragma unroll
     for (int wv = 1; wv < A_WAVES; ++wv) tsum += S.red[wv][tid];
-    float* slab = a.part + (long long)blockIdx.x * a.part_stride;
+    float* slab = a.part + (long long)bid * a.part_stride;
     if (tid < AH) slab[a.off_b_wout + tid] = tsum;
     else if (tid < 2 * AH) slab[a.off_p_wout + tid - AH] = tsum;
-    else __hip_atomic_store(a.pen_part + blockIdx.x, tsum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    else __hip_atomic_store(a.pen_part + bid, tsum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
   // (hand-off as in airl_rows_kernel: the one value that crosses workgroups goes out write-through, no L2 write-back)
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (tid == 0) {
     const unsigned tk = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (tk == gridDim.x - 1) {
+    if (tk == nblocks - 1) {
       float tsum = 0.f;
-      for (unsigned b = 0; b < gridDim.x; ++b)
+      for (unsigned b = 0; b < nblocks; ++b)
         tsum += __hip_atomic_load(a.pen_part + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       a.pen_out[0] = tsum / (float)a.B;
       __hip_atomic_store(a.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
+}
+
+__global__ __launch_bounds__(A_THREADS) void airl_gp_rows_kernel(AirlGpArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char gp_raw[];
+  airl_gp_rows_body(a, *reinterpret_cast<GpLds*>(gp_raw), blockIdx.x, gridDim.x);
+}
+
+// The update's rows AND its gradient penalty's rows in ONE launch: the penalty's pass reads the assembled batches, the frozen
+// statistics and the parameters -- nothing the update's row pass writes -- so the two passes (64 workgroups each at
+// 8 192 + 8 192 rows: a quarter of the chip, 21 and 42 us) run side by side instead of one behind the other. The penalty's
+// workgroups, the longer ones, take the first block ids.
+__global__ __launch_bounds__(A_THREADS) void airl_rows_gp_kernel(AirlArgs a, AirlGpArgs g, int nb_gp, long long* __restrict__ ts) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char both_raw[];
+  if ((int)blockIdx.x < nb_gp) airl_gp_rows_body(g, *reinterpret_cast<GpLds*>(both_raw), blockIdx.x, nb_gp);
+  else airl_rows_body(a, ts, *reinterpret_cast<AirlLds*>(both_raw), blockIdx.x - nb_gp, gridDim.x - nb_gp);
 }
 
 
@@ -1228,6 +1248,99 @@ __global__ __launch_bounds__(A_THREADS) void disc32_rows_kernel(Disc32Args a) {
   if (tid == 0) __hip_atomic_store(a.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+
+// ---- host side: argument blocks of the two row passes and of their split-K weight-gradient products --------------------------
+struct AirlStepPlan { AirlArgs a; IaGemm ws3[3]; int nblk, nb; long long ptot; };
+int airl_plan_step(const float* Xb, int ldb, int Db, const float* Sn, const float* Sc, int ldp, int Dp, const float* dones,
+                   const float* logp, const float* bmean, const float* bvar, float beps, const float* pmeanA,
+                   const float* pvarA, const float* pmeanB, const float* pvarB, float peps, const float* params_base,
+                   const float* params_pot, float gamma, float scale, int R, int n_expert, float* Ab, int ldab, float* Db1,
+                   float* Ap, int ldap, float* H1, float* Dp1, float* Dp2, float* partials, float* logits, float* stats,
+                   float* bce_part, unsigned* ticket, AirlStepPlan& pl) {
+  if (!Xb || !Sn || !Sc || !dones || !logp || !params_base || !params_pot || !Ab || !Db1 || !Ap || !H1 || !Dp1 || !Dp2 ||
+      !partials || !logits || !stats || !bce_part || !ticket || R <= 0 || n_expert < 0 || n_expert > R)
+    return IA_ERR_ARG;
+  if (!ia_airl_fused_ok(Db, Dp, AH, AH, AH) || ldb % 4 || ldp % 4 || ldab % 4 || ldap % 4 || ldb < Db || ldp < Dp ||
+      ldab < ((Db + 3) & ~3) || ldap < ((Dp + 3) & ~3))
+    return IA_ERR_UNSUPPORTED;
+  const int nb = AH * Db + AH + AH + 1, np = AH * Dp + AH + AH * AH + AH + AH + 1;
+  const long long ptot = (long long)nb + np;
+  const int nblk = ia_airl_fused_slabs(R);
+  AirlArgs a{};
+  a.Xb = Xb; a.Sn = Sn; a.Sc = Sc; a.ldb = ldb; a.Db = Db; a.ldp = ldp; a.Dp = Dp; a.dones = dones; a.logp = logp;
+  a.bmean = bmean; a.bvar = bvar; a.pmeanA = pmeanA; a.pvarA = pvarA; a.pmeanB = pmeanB; a.pvarB = pvarB;
+  a.beps = beps; a.peps = peps; a.Pb = params_base; a.Pp = params_pot; a.gamma = gamma; a.scale = scale; a.R = R;
+  a.n_expert = n_expert; a.Ab = Ab; a.ldab = ldab; a.Db1 = Db1; a.Ap = Ap; a.ldap = ldap; a.H1 = H1; a.Dp1 = Dp1; a.Dp2 = Dp2;
+  a.part = partials; a.part_stride = ptot;
+  a.off_b_wout = AH * Db + AH; a.off_b_bout = a.off_b_wout + AH;
+  a.off_p_wout = nb + AH * Dp + AH + AH * AH + AH; a.off_p_bout = a.off_p_wout + AH;
+  a.logits = logits; a.stats = stats; a.bce_part = bce_part; a.ticket = ticket;
+  // hidden-layer weight gradients: dW = delta^T . input over the rows, one split-K slab per 128 (256) rows; bias
+  // gradients = column sums of delta. Slab s of `partials` is what workgroup s of the rows kernel wrote into.
+  auto wgrad = [&](const float* delta, const float* in, int ldin, int N, int K, long long w_off, long long b_off) {
+    IaGemm w{};
+    w.A = delta; w.lda = AH; w.B = in; w.ldb = ldin; w.M = AH; w.N = N; w.K = K;
+    w.C = partials + w_off; w.ldc = N; w.splits = nblk; w.k_per_split = ((K + nblk - 1) / nblk + 31) / 32 * 32;
+    w.c_split_stride = ptot; w.dbias = partials + b_off; w.dbias_split_stride = ptot;
+    return w;
+  };
+  pl.a = a; pl.nblk = nblk; pl.nb = nb; pl.ptot = ptot;
+  pl.ws3[0] = wgrad(Db1, Ab, ldab, Db, R, 0, (long long)AH * Db);
+  pl.ws3[1] = wgrad(Dp1, Ap, ldap, Dp, 2 * R, nb, (long long)nb + AH * Dp);
+  pl.ws3[2] = wgrad(Dp2, H1, AH, AH, 2 * R, (long long)nb + AH * Dp + AH, (long long)nb + AH * Dp + AH + AH * AH);
+  return IA_OK;
+}
+
+struct AirlGpPlan { AirlGpArgs a; IaGemm gs3[3]; int nblk; long long ptot; };
+int airl_plan_gp(const float* Xb, int ldb, int Db, const float* Sn, const float* Sc, int ldp, int Dp, const float* dones,
+                 const float* e, const float* bmean, const float* bvar, float beps, const float* pmean, const float* pvar,
+                 float peps, const float* params_base, const float* params_pot, int obs_dim, int act_dim, int use_state,
+                 int use_action, int use_next_state, int use_done, float gamma, float coef, float target, int B, float* U1b,
+                 float* Cb, float* U1p, float* Cp, float* U2p, float* V1p, float* partials, float* pen_part, float* pen_out,
+                 unsigned* ticket, AirlGpPlan& pl) {
+  if (!Xb || !Sn || !Sc || !dones || !e || !params_base || !params_pot || !U1b || !Cb || !U1p || !Cp || !U2p || !V1p ||
+      !partials || !pen_part || !pen_out || !ticket || B <= 0)
+    return IA_ERR_ARG;
+  const int Dchk = (use_state ? obs_dim : 0) + (use_action ? act_dim : 0) + (use_next_state ? obs_dim : 0) + (use_done ? 1 : 0);
+  if (!ia_airl_fused_ok(Db, Dp, AH, AH, AH) || Dchk != Db || Dp != obs_dim || ldb % 4 || ldp % 4 || ldb < Db || ldp < Dp)
+    return IA_ERR_UNSUPPORTED;
+  const int nb = AH * Db + AH + AH + 1, np = AH * Dp + AH + AH * AH + AH + AH + 1;
+  const long long ptot = (long long)nb + np;
+  const int nblk = ia_airl_fused_slabs(B);
+  AirlGpArgs a{};
+  a.Xb = Xb; a.Sn = Sn; a.Sc = Sc; a.ldb = ldb; a.Db = Db; a.ldp = ldp; a.Dp = Dp; a.dones = dones; a.e = e;
+  a.bmean = bmean; a.bvar = bvar; a.pmean = pmean; a.pvar = pvar; a.beps = beps; a.peps = peps; a.Pb = params_base;
+  a.Pp = params_pot; a.od = obs_dim; a.ad = act_dim; a.use_state = use_state; a.use_action = use_action;
+  a.use_next = use_next_state; a.use_done = use_done; a.gamma = gamma; a.coef = coef; a.target = target; a.B = B;
+  a.U1b = U1b; a.Cb = Cb; a.ldcb = ldb; a.U1p = U1p; a.Cp = Cp; a.ldcp = ldp; a.U2p = U2p; a.V1p = V1p;
+  a.part = partials; a.part_stride = ptot; a.off_b_wout = AH * Db + AH; a.off_p_wout = nb + AH * Dp + AH + AH * AH + AH;
+  a.pen_part = pen_part; a.pen_out = pen_out; a.ticket = ticket;
+  auto wgrad = [&](const float* u, const float* in, int ldin, int N, int K, long long w_off) {
+    IaGemm g{};
+    g.A = u; g.lda = AH; g.B = in; g.ldb = ldin; g.M = AH; g.N = N; g.K = K;
+    g.C = partials + w_off; g.ldc = N; g.splits = nblk; g.k_per_split = ((K + nblk - 1) / nblk + 31) / 32 * 32;
+    g.c_split_stride = ptot;
+    return g;
+  };
+  pl.a = a; pl.nblk = nblk; pl.ptot = ptot;
+  pl.gs3[0] = wgrad(U1b, Cb, ldb, Db, B, 0);
+  pl.gs3[1] = wgrad(U1p, Cp, ldp, Dp, 2 * B, nb);
+  pl.gs3[2] = wgrad(U2p, V1p, AH, AH, 2 * B, (long long)nb + AH * Dp + AH);
+  return IA_OK;
+}
+
+int airl_gp_lds_attr() {   // the penalty's row pass (alone, or sharing a launch with the update's) needs > 64 KB of LDS
+  static bool attr = false;
+  if (!attr) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(airl_gp_rows_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)sizeof(GpLds)) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(airl_rows_gp_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)(sizeof(GpLds) > sizeof(AirlLds) ? sizeof(GpLds) : sizeof(AirlLds))) != hipSuccess)
+      return IA_ERR_ARG;
+    attr = true;
+  }
+  return IA_OK;
+}
 }  // namespace
 
 extern "C" {
@@ -1257,44 +1370,19 @@ int ia_airl_step_shaped(const float* Xb, int ldb, int Db, const float* Sn, const
                         float* Ab, int ldab, float* Db1, float* Ap, int ldap, float* H1, float* Dp1, float* Dp2,
                         float* partials, float* logits, float* stats, float* bce_part, unsigned* ticket,
                         const ia_adam_args* adam, void* stream) {
-  if (!Xb || !Sn || !Sc || !dones || !logp || !params_base || !params_pot || !Ab || !Db1 || !Ap || !H1 || !Dp1 || !Dp2 ||
-      !partials || !logits || !stats || !bce_part || !ticket || R <= 0 || n_expert < 0 || n_expert > R)
-    return IA_ERR_ARG;
-  if (!ia_airl_fused_ok(Db, Dp, AH, AH, AH) || ldb % 4 || ldp % 4 || ldab % 4 || ldap % 4 || ldb < Db || ldp < Dp ||
-      ldab < ((Db + 3) & ~3) || ldap < ((Dp + 3) & ~3))
-    return IA_ERR_UNSUPPORTED;
-  const int nb = AH * Db + AH + AH + 1, np = AH * Dp + AH + AH * AH + AH + AH + 1;
-  const long long ptot = (long long)nb + np;
-  const int nblk = ia_airl_fused_slabs(R);
-  AirlArgs a{};
-  a.Xb = Xb; a.Sn = Sn; a.Sc = Sc; a.ldb = ldb; a.Db = Db; a.ldp = ldp; a.Dp = Dp; a.dones = dones; a.logp = logp;
-  a.bmean = bmean; a.bvar = bvar; a.pmeanA = pmeanA; a.pvarA = pvarA; a.pmeanB = pmeanB; a.pvarB = pvarB;
-  a.beps = beps; a.peps = peps; a.Pb = params_base; a.Pp = params_pot; a.gamma = gamma; a.scale = scale; a.R = R;
-  a.n_expert = n_expert; a.Ab = Ab; a.ldab = ldab; a.Db1 = Db1; a.Ap = Ap; a.ldap = ldap; a.H1 = H1; a.Dp1 = Dp1; a.Dp2 = Dp2;
-  a.part = partials; a.part_stride = ptot;
-  a.off_b_wout = AH * Db + AH; a.off_b_bout = a.off_b_wout + AH;
-  a.off_p_wout = nb + AH * Dp + AH + AH * AH + AH; a.off_p_bout = a.off_p_wout + AH;
-  a.logits = logits; a.stats = stats; a.bce_part = bce_part; a.ticket = ticket;
+  AirlStepPlan pl;
+  int rc = airl_plan_step(Xb, ldb, Db, Sn, Sc, ldp, Dp, dones, logp, bmean, bvar, beps, pmeanA, pvarA, pmeanB, pvarB, peps,
+                          params_base, params_pot, gamma, scale, R, n_expert, Ab, ldab, Db1, Ap, ldap, H1, Dp1, Dp2, partials,
+                          logits, stats, bce_part, ticket, pl);
+  if (rc) return rc;
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(airl_rows_kernel, dim3(nblk), dim3(A_THREADS), 0, st, a, g_airl_tstamp);
+  hipLaunchKernelGGL(airl_rows_kernel, dim3(pl.nblk), dim3(A_THREADS), 0, st, pl.a, g_airl_tstamp);
   IA_CHECK_LAUNCH();
-  // hidden-layer weight gradients: dW = delta^T . input over the rows, one split-K slab per 128 (256) rows; bias
-  // gradients = column sums of delta. Slab s of `partials` is what workgroup s of the rows kernel wrote into.
-  auto wgrad = [&](const float* delta, const float* in, int ldin, int N, int K, long long w_off, long long b_off) {
-    IaGemm w{};
-    w.A = delta; w.lda = AH; w.B = in; w.ldb = ldin; w.M = AH; w.N = N; w.K = K;
-    w.C = partials + w_off; w.ldc = N; w.splits = nblk; w.k_per_split = ((K + nblk - 1) / nblk + 31) / 32 * 32;
-    w.c_split_stride = ptot; w.dbias = partials + b_off; w.dbias_split_stride = ptot;
-    return w;
-  };
   // (one grouped launch: 3 x nblk workgroups together instead of three latency-bound launches of nblk each)
-  const IaGemm ws3[3] = {wgrad(Db1, Ab, ldab, Db, R, 0, (long long)AH * Db),
-                         wgrad(Dp1, Ap, ldap, Dp, 2 * R, nb, (long long)nb + AH * Dp),
-                         wgrad(Dp2, H1, AH, AH, 2 * R, (long long)nb + AH * Dp + AH, (long long)nb + AH * Dp + AH + AH * AH)};
-  int rc = ia_launch_gemm_group_tn(ws3, 3, st);
+  rc = ia_launch_gemm_group_tn(pl.ws3, 3, st);
   if (rc || !adam) return rc;
-  if (!adam->grads || !adam->exp_avg || !adam->exp_avg_sq || params_pot != params_base + nb) return IA_ERR_ARG;
-  return ia_reduce_partials_adam(partials, nblk, ptot, 1.0f, adam->grads, const_cast<float*>(params_base), adam->exp_avg,
+  if (!adam->grads || !adam->exp_avg || !adam->exp_avg_sq || params_pot != params_base + pl.nb) return IA_ERR_ARG;
+  return ia_reduce_partials_adam(partials, pl.nblk, pl.ptot, 1.0f, adam->grads, const_cast<float*>(params_base), adam->exp_avg,
                                  adam->exp_avg_sq, adam->beta1, adam->beta2, adam->eps, adam->weight_decay,
                                  adam->step_size, adam->bc2_sqrt, stream);
 }
@@ -1379,45 +1467,19 @@ int ia_airl_gp_shaped(const float* Xb, int ldb, int Db, const float* Sn, const f
                       int use_next_state, int use_done, float gamma, float coef, float target, int B, float* U1b,
                       float* Cb, float* U1p, float* Cp, float* U2p, float* V1p, float* partials, float* pen_part,
                       float* pen_out, unsigned* ticket, float* grads, void* stream) {
-  if (!Xb || !Sn || !Sc || !dones || !e || !params_base || !params_pot || !U1b || !Cb || !U1p || !Cp || !U2p || !V1p ||
-      !partials || !pen_part || !pen_out || !ticket || !grads || B <= 0)
-    return IA_ERR_ARG;
-  const int Dchk = (use_state ? obs_dim : 0) + (use_action ? act_dim : 0) + (use_next_state ? obs_dim : 0) + (use_done ? 1 : 0);
-  if (!ia_airl_fused_ok(Db, Dp, AH, AH, AH) || Dchk != Db || Dp != obs_dim || ldb % 4 || ldp % 4 || ldb < Db || ldp < Dp)
-    return IA_ERR_UNSUPPORTED;
-  const int nb = AH * Db + AH + AH + 1, np = AH * Dp + AH + AH * AH + AH + AH + 1;
-  const long long ptot = (long long)nb + np;
-  const int nblk = ia_airl_fused_slabs(B);
-  AirlGpArgs a{};
-  a.Xb = Xb; a.Sn = Sn; a.Sc = Sc; a.ldb = ldb; a.Db = Db; a.ldp = ldp; a.Dp = Dp; a.dones = dones; a.e = e;
-  a.bmean = bmean; a.bvar = bvar; a.pmean = pmean; a.pvar = pvar; a.beps = beps; a.peps = peps; a.Pb = params_base;
-  a.Pp = params_pot; a.od = obs_dim; a.ad = act_dim; a.use_state = use_state; a.use_action = use_action;
-  a.use_next = use_next_state; a.use_done = use_done; a.gamma = gamma; a.coef = coef; a.target = target; a.B = B;
-  a.U1b = U1b; a.Cb = Cb; a.ldcb = ldb; a.U1p = U1p; a.Cp = Cp; a.ldcp = ldp; a.U2p = U2p; a.V1p = V1p;
-  a.part = partials; a.part_stride = ptot; a.off_b_wout = AH * Db + AH; a.off_p_wout = nb + AH * Dp + AH + AH * AH + AH;
-  a.pen_part = pen_part; a.pen_out = pen_out; a.ticket = ticket;
-  static bool attr = false;
-  if (!attr) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(airl_gp_rows_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)sizeof(GpLds)) != hipSuccess)
-      return IA_ERR_ARG;
-    attr = true;
-  }
-  hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(airl_gp_rows_kernel, dim3(nblk), dim3(A_THREADS), sizeof(GpLds), st, a);
-  IA_CHECK_LAUNCH();
-  auto wgrad = [&](const float* u, const float* in, int ldin, int N, int K, long long w_off) {
-    IaGemm g{};
-    g.A = u; g.lda = AH; g.B = in; g.ldb = ldin; g.M = AH; g.N = N; g.K = K;
-    g.C = partials + w_off; g.ldc = N; g.splits = nblk; g.k_per_split = ((K + nblk - 1) / nblk + 31) / 32 * 32;
-    g.c_split_stride = ptot;
-    return g;
-  };
-  const IaGemm gs3[3] = {wgrad(U1b, Cb, ldb, Db, B, 0), wgrad(U1p, Cp, ldp, Dp, 2 * B, nb),
-                         wgrad(U2p, V1p, AH, AH, 2 * B, (long long)nb + AH * Dp + AH)};
-  int rc = ia_launch_gemm_group_tn(gs3, 3, st);
+  if (!grads) return IA_ERR_ARG;
+  AirlGpPlan pl;
+  int rc = airl_plan_gp(Xb, ldb, Db, Sn, Sc, ldp, Dp, dones, e, bmean, bvar, beps, pmean, pvar, peps, params_base, params_pot,
+                        obs_dim, act_dim, use_state, use_action, use_next_state, use_done, gamma, coef, target, B, U1b, Cb, U1p,
+                        Cp, U2p, V1p, partials, pen_part, pen_out, ticket, pl);
   if (rc) return rc;
-  return ia_reduce_partials(partials, nblk, ptot, 1.0f, 1, grads, stream);
+  if ((rc = airl_gp_lds_attr())) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(airl_gp_rows_kernel, dim3(pl.nblk), dim3(A_THREADS), sizeof(GpLds), st, pl.a);
+  IA_CHECK_LAUNCH();
+  rc = ia_launch_gemm_group_tn(pl.gs3, 3, st);
+  if (rc) return rc;
+  return ia_reduce_partials(partials, pl.nblk, pl.ptot, 1.0f, 1, grads, stream);
 }
 
 // A round's AIRL updates in ONE host call (`for _ in range(n_disc_updates_per_round): train_disc()`,
@@ -1442,24 +1504,46 @@ int ia_airl_round(const ia_airl_update_args* a, int n, void* stream) {
     rc = ia_policy_evaluate(u.pol, u.pol_params, u.pol_params_t, u.pol_norm_mean, u.pol_norm_var, u.pol_obs, u.pol_act, R,
                             u.logp, nullptr, nullptr, stream);
     if (rc) return rc;
-    const bool gp = u.gp_e != nullptr;
-    rc = ia_airl_step_shaped(u.Xb, u.ldb, u.Db, u.Sn, u.Sc, u.ldp, u.Dp, u.dones, u.logp, u.f_bmean, u.f_bvar, u.beps, u.pmeanA,
-                             u.pvarA, u.pmeanB, u.pvarB, u.peps, u.params_base, u.params_pot, u.gamma, u.scale, R, u.n_expert,
-                             u.Ab, u.ldab, u.Db1, u.Ap, u.ldap, u.H1, u.Dp1, u.Dp2, u.partials, u.logits, u.stats, u.bce_part,
-                             u.ticket, gp ? nullptr : &u.adam, stream);
-    if (rc) return rc;
-    if (gp) {   // the penalty's gradient on top of the reduced BCE gradient, then the optimiser step
-      if (u.n0 != u.n1) return IA_ERR_ARG;
-      if ((rc = ia_reduce_partials(u.partials, u.n_slabs, u.n_params, 1.0f, 0, u.adam.grads, stream))) return rc;
-      rc = ia_airl_gp_shaped(u.Xb, u.ldb, u.Db, u.Sn, u.Sc, u.ldp, u.Dp, u.dones, u.gp_e, u.f_bmean, u.f_bvar, u.beps, u.pmeanB,
-                             u.pvarB, u.peps, u.params_base, u.params_pot, u.obs_dim, u.act_dim, u.use_state, u.use_action,
-                             u.use_next_state, u.use_done, u.gamma, u.gp_coef, u.gp_target, u.n0, u.U1b, u.Cb, u.U1p, u.Cp,
-                             u.U2p, u.V1p, u.gp_partials, u.pen_part, u.pen_out, u.gp_ticket, u.adam.grads, stream);
+    if (u.gp_e == nullptr) {
+      rc = ia_airl_step_shaped(u.Xb, u.ldb, u.Db, u.Sn, u.Sc, u.ldp, u.Dp, u.dones, u.logp, u.f_bmean, u.f_bvar, u.beps, u.pmeanA,
+                               u.pvarA, u.pmeanB, u.pvarB, u.peps, u.params_base, u.params_pot, u.gamma, u.scale, R, u.n_expert,
+                               u.Ab, u.ldab, u.Db1, u.Ap, u.ldap, u.H1, u.Dp1, u.Dp2, u.partials, u.logits, u.stats, u.bce_part,
+                               u.ticket, &u.adam, stream);
       if (rc) return rc;
-      rc = ia_adam_step(const_cast<float*>(u.params_base), u.adam.grads, u.adam.exp_avg, u.adam.exp_avg_sq, u.n_params,
-                        u.adam.beta1, u.adam.beta2, u.adam.eps, u.adam.weight_decay, u.adam.step_size, u.adam.bc2_sqrt, stream);
-      if (rc) return rc;
+      continue;
     }
+    // With the gradient penalty (round 6): the update's row pass and the penalty's in ONE launch (independent: the penalty
+    // reads the assembled batches, the statistics as the merge left them and the parameters), their six split-K
+    // weight-gradient products in ONE grouped launch, and both slab sets reduced inside the optimiser step's launch --
+    // three launches where there were seven (rows, products, reduce | penalty rows, products, reduce + add | Adam), the
+    // same kernels' bodies on the same operands and the same order of every sum: bit-identical (tools/ppo_bits.py).
+    if (u.n0 != u.n1) return IA_ERR_ARG;
+    AirlStepPlan sp;
+    AirlGpPlan gp;
+    rc = airl_plan_step(u.Xb, u.ldb, u.Db, u.Sn, u.Sc, u.ldp, u.Dp, u.dones, u.logp, u.f_bmean, u.f_bvar, u.beps, u.pmeanA, u.pvarA,
+                        u.pmeanB, u.pvarB, u.peps, u.params_base, u.params_pot, u.gamma, u.scale, R, u.n_expert, u.Ab, u.ldab,
+                        u.Db1, u.Ap, u.ldap, u.H1, u.Dp1, u.Dp2, u.partials, u.logits, u.stats, u.bce_part, u.ticket, sp);
+    if (rc) return rc;
+    rc = airl_plan_gp(u.Xb, u.ldb, u.Db, u.Sn, u.Sc, u.ldp, u.Dp, u.dones, u.gp_e, u.f_bmean, u.f_bvar, u.beps, u.pmeanB, u.pvarB,
+                      u.peps, u.params_base, u.params_pot, u.obs_dim, u.act_dim, u.use_state, u.use_action, u.use_next_state,
+                      u.use_done, u.gamma, u.gp_coef, u.gp_target, u.n0, u.U1b, u.Cb, u.U1p, u.Cp, u.U2p, u.V1p, u.gp_partials,
+                      u.pen_part, u.pen_out, u.gp_ticket, gp);
+    if (rc) return rc;
+    if (!u.adam.grads || !u.adam.exp_avg || !u.adam.exp_avg_sq || u.params_pot != u.params_base + sp.nb ||
+        sp.nblk != u.n_slabs || sp.ptot != u.n_params)
+      return IA_ERR_ARG;
+    if ((rc = airl_gp_lds_attr())) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    constexpr size_t lds_both = sizeof(GpLds) > sizeof(AirlLds) ? sizeof(GpLds) : sizeof(AirlLds);
+    hipLaunchKernelGGL(airl_rows_gp_kernel, dim3(gp.nblk + sp.nblk), dim3(A_THREADS), lds_both, st, sp.a, gp.a, gp.nblk,
+                       g_airl_tstamp);
+    IA_CHECK_LAUNCH();
+    const IaGemm six[6] = {gp.gs3[0], gp.gs3[1], gp.gs3[2], sp.ws3[0], sp.ws3[1], sp.ws3[2]};
+    if ((rc = ia_launch_gemm_group_tn(six, 6, st))) return rc;
+    rc = ia_reduce2_partials_adam(u.partials, sp.nblk, u.gp_partials, gp.nblk, sp.ptot, 1.0f, u.adam.grads,
+                                  const_cast<float*>(u.params_base), u.adam.exp_avg, u.adam.exp_avg_sq, u.adam.beta1,
+                                  u.adam.beta2, u.adam.eps, u.adam.weight_decay, u.adam.step_size, u.adam.bc2_sqrt, st);
+    if (rc) return rc;
   }
   return IA_OK;
 }

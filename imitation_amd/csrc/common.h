@@ -61,8 +61,12 @@ struct IaGemm {
 };
 
 int ia_launch_gemm(int mode, const IaGemm& g, hipStream_t stream);
-// n <= 3 independent split-K TN GEMMs whose outputs have <= 32 rows, in one launch
+// n <= 6 independent split-K TN GEMMs whose outputs have <= 32 rows, in one launch
 int ia_launch_gemm_group_tn(const IaGemm* gs, int n, hipStream_t stream);
+// mlp.hip: grads = scale * sum(slabs of `partials`) + sum(slabs of `partials2`), then torch's Adam step -- one launch
+int ia_reduce2_partials_adam(const float* partials, int splits, const float* partials2, int splits2, int64_t n, float scale,
+                             float* grads, float* params, float* exp_avg, float* exp_avg_sq, float beta1, float beta2,
+                             float eps, float weight_decay, float step_size, float bc2_sqrt, hipStream_t stream);
 
 __device__ __forceinline__ float ia_softplus(float x) {
   return fmaxf(x, 0.0f) + log1pf(expf(-fabsf(x)));

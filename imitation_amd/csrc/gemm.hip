@@ -500,17 +500,24 @@ __global__ __launch_bounds__(WM* WN * 64) void ia_gemm_tn_side_kernel(IaGemm g, 
   gemm_block<WM, WN, TM, TN, IA_GEMM_TN>(g, smem, gridDim.x - side_blocks, blockIdx.x - side_blocks);
 }
 
-// Up to three independent split-K TN GEMMs in ONE launch (32-row outputs: the hidden-layer weight gradients of the small
+// Up to six independent split-K TN GEMMs in ONE launch (32-row outputs: the hidden-layer weight gradients of the small
 // AIRL stacks, 10-16 us each when launched one after the other -- latency-bound with 128 workgroups; together they
-// fill the chip): workgroups [0, nb0) run problem 0, [nb0, nb0 + nb1) problem 1, the rest problem 2.
-struct IaGemm3 { IaGemm p[3]; int nb[3]; };
+// fill the chip): workgroups [0, nb0) run problem 0, [nb0, nb0 + nb1) problem 1, ... (three problems: an update's weight
+// gradients; six: those and the gradient penalty's, whose row kernel ran in the same launch as the update's).
+constexpr int GEMM_GROUP_MAX = 6;
+struct IaGemmGroup { IaGemm p[GEMM_GROUP_MAX]; int nb[GEMM_GROUP_MAX]; };
 template <int WM, int WN, int TM, int TN>
-__global__ __launch_bounds__(WM* WN * 64) void ia_gemm_group_tn_kernel(IaGemm3 gs) {
+__global__ __launch_bounds__(WM* WN * 64) void ia_gemm_group_tn_kernel(IaGemmGroup gs) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int b = blockIdx.x;
-  if (b < gs.nb[0]) gemm_block<WM, WN, TM, TN, IA_GEMM_TN>(gs.p[0], smem, gs.nb[0], b);
-  else if (b < gs.nb[0] + gs.nb[1]) gemm_block<WM, WN, TM, TN, IA_GEMM_TN>(gs.p[1], smem, gs.nb[1], b - gs.nb[0]);
-  else gemm_block<WM, WN, TM, TN, IA_GEMM_TN>(gs.p[2], smem, gs.nb[2], b - gs.nb[0] - gs.nb[1]);
+  int b = blockIdx.x;
+#pragma unroll
+  for (int i = 0; i < GEMM_GROUP_MAX; ++i) {   // (workgroup-uniform)
+    if (b < gs.nb[i]) {
+      gemm_block<WM, WN, TM, TN, IA_GEMM_TN>(gs.p[i], smem, gs.nb[i], b);
+      return;
+    }
+    b -= gs.nb[i];
+  }
 }
 
 // ---- optional per-launch timing with HIP events on the launch stream (bench.py roofline) ----
@@ -623,16 +630,16 @@ int ia_launch_gemm_tn_side(const IaGemm& g, const ReduceArgs& side, hipStream_t 
   return IA_OK;
 }
 
-// n <= 3 split-K TN GEMMs with M <= 32 in one launch (32 x 128 tiles)
+// n <= 6 split-K TN GEMMs with M <= 32 in one launch (32 x 128 tiles)
 int ia_launch_gemm_group_tn(const IaGemm* gs, int n, hipStream_t stream) {
-  if (n < 1 || n > 3) return IA_ERR_ARG;
+  if (n < 1 || n > GEMM_GROUP_MAX) return IA_ERR_ARG;
   constexpr int WM = 1, WN = 4, TM = 1, TN = 1, NT = WM * WN * 64, BM = 32, BN = 128;
   using AIO = TileIO<BM, NT, true>;
   using BIO = TileIO<BN, NT, true>;
   constexpr size_t smem = 2 * (AIO::ELEMS + BIO::ELEMS) * sizeof(float);
-  IaGemm3 a{};
+  IaGemmGroup a{};
   int total = 0;
-  for (int i = 0; i < 3; ++i) {
+  for (int i = 0; i < GEMM_GROUP_MAX; ++i) {
     if (i < n) {
       const IaGemm& g = gs[i];
       if (g.M <= 0 || g.M > BM || g.N <= 0 || g.K < 0 || g.im.on || g.splits < 1) return IA_ERR_ARG;

@@ -51,12 +51,10 @@ __global__ void reduce_partials_kernel(const float* __restrict__ partials, int s
 
 // split-K slab reduction fused with the Adam step (single minibatch, single GPU): the reduced
 // gradient is also written out (it is the flat gradient the API exposes).
-__global__ void reduce_adam_kernel(const float* __restrict__ partials, int splits, long long n, float scale,
-                                   float* __restrict__ grads, float* __restrict__ p, float* __restrict__ m,
-                                   float* __restrict__ v, float beta1, float beta2, float eps, float wd,
-                                   float step_size, float bc2_sqrt) {
-  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
+// (`partials2`: a second set of slabs -- the gradient penalty's -- whose fixed-order sum is ADDED to the first set's scaled sum:
+// the arithmetic of `reduce_partials_kernel` (accumulate = 0), `reduce_partials_kernel` (accumulate = 1, scale 1) and
+// `adam_kernel` in one launch, bit for bit)
+__device__ __forceinline__ float slab_sum(const float* __restrict__ partials, int splits, long long n, long long i) {
   float s = 0.f;
   int k = 0;
   for (; k + 8 <= splits; k += 8) {
@@ -67,7 +65,17 @@ __global__ void reduce_adam_kernel(const float* __restrict__ partials, int split
     for (int u = 0; u < 8; ++u) s += t[u];
   }
   for (; k < splits; ++k) s += partials[(long long)k * n + i];
-  float grad = s * scale;
+  return s;
+}
+
+__global__ void reduce_adam_kernel(const float* __restrict__ partials, int splits, long long n, float scale,
+                                   float* __restrict__ grads, float* __restrict__ p, float* __restrict__ m,
+                                   float* __restrict__ v, float beta1, float beta2, float eps, float wd,
+                                   float step_size, float bc2_sqrt, const float* __restrict__ partials2, int splits2) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float grad = slab_sum(partials, splits, n, i) * scale;
+  if (partials2 != nullptr) grad = grad + slab_sum(partials2, splits2, n, i) * 1.0f;
   grads[i] = grad;
   const float pi = p[i];
   if (wd != 0.f) grad = grad + wd * pi;
@@ -872,7 +880,7 @@ int ia_reduce_partials_adam(const float* partials, int splits, int64_t n, float 
   if (n <= 0 || splits < 1) return IA_ERR_ARG;
   hipLaunchKernelGGL(reduce_adam_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, partials, splits,
                      (long long)n, scale, grads, params, exp_avg, exp_avg_sq, beta1, beta2, eps, weight_decay, step_size,
-                     bc2_sqrt);
+                     bc2_sqrt, (const float*)nullptr, 0);
   IA_CHECK_LAUNCH();
   return IA_OK;
 }
@@ -1156,3 +1164,15 @@ int ia_gather_rows(const float* src, const int64_t* idx, int n, int width, float
 }
 
 }  // extern "C"
+
+// reduce (first slabs, scaled) + reduce (second slabs, added) + Adam in one launch (internal: airl_fused.hip)
+int ia_reduce2_partials_adam(const float* partials, int splits, const float* partials2, int splits2, int64_t n, float scale,
+                             float* grads, float* params, float* exp_avg, float* exp_avg_sq, float beta1, float beta2,
+                             float eps, float weight_decay, float step_size, float bc2_sqrt, hipStream_t stream) {
+  if (n <= 0 || splits < 1 || splits2 < 1 || !partials || !partials2) return IA_ERR_ARG;
+  hipLaunchKernelGGL(reduce_adam_kernel, dim3(cdiv(n, 256)), dim3(256), 0, stream, partials, splits, (long long)n, scale,
+                     grads, params, exp_avg, exp_avg_sq, beta1, beta2, eps, weight_decay, step_size, bc2_sqrt, partials2,
+                     splits2);
+  IA_CHECK_LAUNCH();
+  return IA_OK;
+}

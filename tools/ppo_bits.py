@@ -1,5 +1,4 @@
-"""Bit fingerprint of a few training rounds (config P or a bench variant): sha256 over the generator's parameter vector and
-Adam moments after `rounds` rounds from the bench's fixed seeds. Two libraries (IA_LIB=...) that print the same line compute
+"""Bit fingerprint of a few training rounds (config P or a bench variant): sha256 over the generator's and the reward net's state after `rounds` rounds from the bench's fixed seeds. Two libraries (IA_LIB=...) that print the same line compute
 the same bits -- the check behind every "same operations, moved" kernel change (tools/ab_libs.sh builds the libraries).
 Usage: python tools/ppo_bits.py [rounds] [bench variant]"""
 import hashlib
@@ -26,4 +25,9 @@ pol = tr.gen_algo.policy
 for name, t in sorted(pol.state_dict().items()):
     h.update(name.encode())
     h.update(t.detach().cpu().contiguous().numpy().tobytes())
-print((sys.argv[2] if len(sys.argv) > 2 else "P"), f"rounds={rounds}", "policy sha256", h.hexdigest()[:24])
+hr = hashlib.sha256()
+for name, t in sorted(tr._reward_net.state_dict().items()):   # the discriminator's parameters and running statistics
+    hr.update(name.encode())
+    hr.update(t.detach().cpu().contiguous().numpy().tobytes())
+print((sys.argv[2] if len(sys.argv) > 2 else "P"), f"rounds={rounds}", "policy sha256", h.hexdigest()[:24],
+      "reward net sha256", hr.hexdigest()[:24])
