@@ -1,0 +1,229 @@
+// The reward CNN's 3 x 3 "same" convolutions at FULL image resolution (`rewards/reward_nets.py:460-610` -> `util/networks.py:286-357`:
+// Conv2d(3, stride 1, padding "same") - ReLU per hidden channel count, 32 channels by default, AdaptiveAvgPool2d(1)): kernels
+// written for THAT geometry instead of the general im2col GEMMs of gemm.hip / conv.hip, which the image-GAIL round ran at 0.19 of
+// the fp32-MFMA peak (`profiles/r05_image_gail.md`).
+//
+//   conv3x3_c32_wgrad_kernel   dW[co][ky][kx][ci] = sum over (b, oy, ox) of dz[b, oy, ox, co] * x[b, oy+ky-1, ox+kx-1, ci], Cin = Cout = 32.
+//       A 7.2 M-row x 32 x 288 TN product at 1 024 frames of 84 x 84. The split-K GEMM cut it into 1 024 row slabs x 5 tiles of
+//       64 x 64 and re-read the im2col view of x nine times over (3.6 ms, 36 TFLOP/s). Here a workgroup owns whole IMAGES: it walks the
+//       output rows of an image with the three input rows an output row needs resident in LDS (every input row is loaded once and
+//       used by three output rows), the WHOLE 32 x 288 gradient in the accumulators of its waves (wave (ky, half): taps (ky, 0..2),
+//       three 32 x 32 tiles, over one half of a row's positions; the halves are added in a fixed order when the workgroup is
+//       through with its images), positions along the MFMA's K index: A[m = co][k = position] and B[k = position][n = ci] are both
+//       conflict-free ds_read_b32 of channel-last rows. HBM traffic: x and dz once each.
+//   avgpool_relu_backward_kernel   dz[b, p, c] = y[b, p, c] > 0 ? dout[b, c] / HW : 0 -- the backward of "ReLU then global average
+//       pool" in one pass (read y, write dz) instead of the pool's broadcast (write) + relu_backward (read, read, write).
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "common.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int C3_C = 32;          // channels in and out
+constexpr int C3_WMAX = 128;      // widest image row the LDS rows are sized for
+constexpr int C3_THREADS = 384;   // six waves: (kernel row ky = wave % 3) x (half of the positions of a row = wave / 3)
+
+// LDS: a ring of FOUR input rows (three in use + the one being loaded), each [W + 2 pixels][32] with a zero pixel at either
+// end (the "same" padding in x), and TWO dz rows [W (+1 when odd)][32].
+struct C3Geo {
+  int W, H, Wp;            // Wp = W rounded up to even: positions go through the MFMA in pairs
+  int xrow, zrow;          // floats per LDS row
+  __host__ __device__ C3Geo(int H_, int W_) : W(W_), H(H_), Wp((W_ + 1) & ~1), xrow((((W_ + 1) & ~1) + 2) * C3_C), zrow(((W_ + 1) & ~1) * C3_C) {}
+  __host__ __device__ int total() const { return 4 * xrow + 2 * zrow; }
+};
+
+__global__ __launch_bounds__(C3_THREADS) void conv3x3_c32_wgrad_kernel(const float* __restrict__ dz, const float* __restrict__ x,
+                                                                       int B, int H, int W, float* __restrict__ part,
+                                                                       float* __restrict__ dbp) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const C3Geo g(H, W);
+  float* xr = lds;                    // [4][xrow]
+  float* zr = lds + 4 * g.xrow;       // [2][zrow]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ky = wv % 3, half = wv / 3;
+  const int m = lane & 31, kk = lane >> 5;
+  const int row_f4 = W * C3_C / 4;    // float4 pieces of one image row
+  constexpr int NLD = (C3_WMAX * C3_C / 4 + C3_THREADS - 1) / C3_THREADS;   // pieces per thread and row
+
+  f32x16 acc[3];
+#pragma unroll
+  for (int t = 0; t < 3; ++t)
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[t][j] = 0.f;
+  float bsum = 0.f;
+
+  // zero pixels of every x row (never overwritten) and the odd-width tail of the dz rows
+  for (int e = tid; e < 4 * 2 * C3_C; e += C3_THREADS) {
+    const int r = e / (2 * C3_C), q = e - r * 2 * C3_C;
+    xr[r * g.xrow + (q < C3_C ? q : (g.Wp + 1) * C3_C + (q - C3_C))] = 0.f;
+  }
+  if (g.Wp != W) {
+    for (int e = tid; e < 4 * C3_C; e += C3_THREADS) xr[(e / C3_C) * g.xrow + (W + 1) * C3_C + (e % C3_C)] = 0.f;
+    for (int e = tid; e < 2 * C3_C; e += C3_THREADS) zr[(e / C3_C) * g.zrow + W * C3_C + (e % C3_C)] = 0.f;
+  }
+
+  auto load_row = [&](const float* __restrict__ src, f32x4 (&v)[NLD]) {   // one image row, global -> registers (all in flight)
+    const f32x4* s4 = reinterpret_cast<const f32x4*>(src);
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      const int e = tid + i * C3_THREADS;
+      v[i] = s4[min(e, row_f4 - 1)];
+    }
+  };
+  auto store_row = [&](float* __restrict__ dst, const f32x4 (&v)[NLD]) {
+    f32x4* d4 = reinterpret_cast<f32x4*>(dst);
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      const int e = tid + i * C3_THREADS;
+      if (e < row_f4) d4[e] = v[i];
+    }
+  };
+  auto zero_row = [&](float* __restrict__ dst) {
+    f32x4* d4 = reinterpret_cast<f32x4*>(dst);
+    for (int e = tid; e < row_f4; e += C3_THREADS) d4[e] = f32x4{0.f, 0.f, 0.f, 0.f};
+  };
+  const int steps = g.Wp >> 1;                                   // position pairs of a row
+  const int s_lo = half ? (steps + 1) >> 1 : 0, s_hi = half ? steps : (steps + 1) >> 1;
+
+  for (int b = blockIdx.x; b < B; b += gridDim.x) {
+    const float* xb = x + (long long)b * H * W * C3_C;
+    const float* zb = dz + (long long)b * H * W * C3_C;
+    // Ring slot of input row r: (r + 1) & 3 (row -1 -- zeros -- in slot 0). Output row oy reads rows oy - 1 .. oy + 1 =
+    // slots oy & 3 .. (oy + 2) & 3; row oy + 2 goes to the FREE slot (oy + 3) & 3 and dz row oy + 1 to the other dz slot while
+    // row oy is being contracted (both were last read for output row oy - 1): one barrier per output row.
+    __syncthreads();   // (the previous image's last reads)
+    zero_row(xr + 0 * g.xrow + C3_C);
+    {
+      f32x4 v0[NLD], v1[NLD], vz[NLD];
+      load_row(xb, v0);
+      if (H > 1) load_row(xb + (long long)W * C3_C, v1);
+      load_row(zb, vz);
+      store_row(xr + 1 * g.xrow + C3_C, v0);
+      if (H > 1) store_row(xr + 2 * g.xrow + C3_C, v1);
+      else zero_row(xr + 2 * g.xrow + C3_C);
+      store_row(zr, vz);
+    }
+    __syncthreads();
+    for (int oy = 0; oy < H; ++oy) {
+      f32x4 vx[NLD], vz[NLD];
+      const bool have_x = oy + 2 < H, have_z = oy + 1 < H;
+      if (have_x) load_row(xb + (long long)(oy + 2) * W * C3_C, vx);
+      if (have_z) load_row(zb + (long long)(oy + 1) * W * C3_C, vz);
+      const float* xrow = xr + ((oy + ky) & 3) * g.xrow;   // this wave's input row oy + ky - 1
+      const float* zrow = zr + (oy & 1) * g.zrow;
+      // positions in pairs along K: A[m = co][k] = dz[ox0 + k][co], B[k][n = ci] = x[ox0 + k + kx - 1][ci] (LDS pixel ox0 + k + kx)
+      const float* ap = zrow + kk * C3_C + m;
+      const float* bp = xrow + kk * C3_C + m;
+      for (int s = s_lo; s < s_hi; ++s) {
+        const float a = ap[s * 2 * C3_C];
+        const float b0 = bp[s * 2 * C3_C], b1 = bp[s * 2 * C3_C + C3_C], b2 = bp[s * 2 * C3_C + 2 * C3_C];
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc[1], 0, 0, 0);
+        acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b2, acc[2], 0, 0, 0);
+        if (ky == 1) bsum += a;   // (wave-uniform) bias gradient: sum of dz over the positions
+      }
+      if (have_x) store_row(xr + ((oy + 3) & 3) * g.xrow + C3_C, vx);
+      else zero_row(xr + ((oy + 3) & 3) * g.xrow + C3_C);
+      if (have_z) store_row(zr + ((oy + 1) & 1) * g.zrow, vz);
+      __syncthreads();
+    }
+  }
+  // the two halves of the positions: the upper half's accumulators through LDS (the rows are free), added by the lower half's
+  // wave of the same ky -- a fixed order
+  float* ex = lds;   // [3 ky][3 kx][16][64]
+  if (half == 1) {
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+      for (int j = 0; j < 16; ++j) ex[((ky * 3 + kx) * 16 + j) * 64 + lane] = acc[kx][j];
+    if (ky == 1) ex[9 * 16 * 64 + lane] = bsum;
+  }
+  __syncthreads();
+  if (half == 1) return;
+#pragma unroll
+  for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[kx][j] += ex[((ky * 3 + kx) * 16 + j) * 64 + lane];
+  if (ky == 1) bsum += ex[9 * 16 * 64 + lane];
+  // slab of this workgroup: part[wg][co][(ky * 3 + kx) * 32 + ci]; accumulator register j of lane (n = lane & 31, half = lane >> 5)
+  // is row m = 8 (j / 4) + 4 half + j % 4, column n
+  float* slab = part + (long long)blockIdx.x * C3_C * 9 * C3_C;
+#pragma unroll
+  for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const int co = 8 * (j >> 2) + 4 * kk + (j & 3);
+      slab[co * 9 * C3_C + (ky * 3 + kx) * C3_C + m] = acc[kx][j];
+    }
+  if (ky == 1) {
+    bsum += __shfl_xor(bsum, 32, 64);
+    if (lane < 32) dbp[(long long)blockIdx.x * C3_C + lane] = bsum;
+  }
+}
+
+__global__ __launch_bounds__(256) void avgpool_relu_backward_kernel(const float* __restrict__ dout, const float* __restrict__ y,
+                                                                    int HW, int C, float* __restrict__ dz, long long total4) {
+  const int Q = C >> 2;
+  const float inv = (float)HW;
+  const f32x4* y4 = reinterpret_cast<const f32x4*>(y);
+  f32x4* z4 = reinterpret_cast<f32x4*>(dz);
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total4; e += (long long)gridDim.x * blockDim.x) {
+    const int q = (int)(e % Q);
+    const long long b = e / ((long long)HW * Q);
+    const f32x4 v = y4[e];
+    const f32x4 gq = *reinterpret_cast<const f32x4*>(dout + b * C + 4 * q);
+    f32x4 o;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) o[u] = v[u] > 0.f ? gq[u] / inv : 0.f;   // (the pool's own quotient, then the mask)
+    z4[e] = o;
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+/* Weight and bias gradient of a 3 x 3, stride-1, "same"-padded convolution with 32 input and 32 output channels on channel-last
+ * tensors (dz[B, H, W, 32], x[B, H, W, 32]) as `ia_conv3x3_c32_wgrad_slabs(B)` slabs: part[slabs][32][3][3][32] (torch's
+ * [Cout, KH, KW, Cin] weight layout per slab), dbp[slabs][32]; reduce with ia_reduce_partials. IA_ERR_UNSUPPORTED (-2) for
+ * W > 128. */
+int ia_conv3x3_c32_wgrad_slabs(int B) { return B < 1 ? 0 : (B < 1024 ? B : 1024); }
+
+int ia_conv3x3_c32_wgrad(const float* dz, const float* x, int B, int H, int W, float* part, float* dbp, void* stream) {
+  if (!dz || !x || !part || !dbp || B <= 0 || H <= 0 || W <= 0) return IA_ERR_ARG;
+  if (W > C3_WMAX) return IA_ERR_UNSUPPORTED;
+  const C3Geo g(H, W);
+  constexpr int EX_FLOATS = 9 * 16 * 64 + 64;   // the position halves' exchange at the end (narrow images: more than the rows)
+  const size_t bytes = (size_t)(g.total() > EX_FLOATS ? g.total() : EX_FLOATS) * sizeof(float);
+  static size_t attr_bytes = 0;
+  if (bytes > attr_bytes) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_c32_wgrad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)bytes) != hipSuccess)
+      return IA_ERR_ARG;
+    attr_bytes = bytes;
+  }
+  hipLaunchKernelGGL(conv3x3_c32_wgrad_kernel, dim3(ia_conv3x3_c32_wgrad_slabs(B)), dim3(C3_THREADS), bytes, (hipStream_t)stream,
+                     dz, x, B, H, W, part, dbp);
+  IA_CHECK_LAUNCH();
+  return IA_OK;
+}
+
+/* Backward of "ReLU, then AdaptiveAvgPool2d(1)" on channel-last y[B, HW, C] (C % 4 == 0): dz = y > 0 ? dout[b, c] / HW : 0. */
+int ia_avgpool_relu_backward(const float* dout, const float* y, int B, int HW, int C, float* dz, void* stream) {
+  if (!dout || !y || !dz || B <= 0 || HW <= 0 || C <= 0) return IA_ERR_ARG;
+  if (C % 4) return IA_ERR_UNSUPPORTED;
+  const long long total4 = (long long)B * HW * (C / 4);
+  const long long blocks = (total4 + 255) / 256;
+  hipLaunchKernelGGL(avgpool_relu_backward_kernel, dim3((unsigned)(blocks < 65536 * 4 ? blocks : 65536 * 4)), dim3(256), 0,
+                     (hipStream_t)stream, dout, y, HW, C, dz, total4);
+  IA_CHECK_LAUNCH();
+  return IA_OK;
+}
+
+}  // extern "C"

@@ -306,10 +306,15 @@ class Cnn(nn.Module):
 
     def forward(self, x: th.Tensor) -> th.Tensor:
         h = x.permute(0, 2, 3, 1).contiguous()                  # [B, C, H, W] -> channel-last
-        for n in self._convs:
+        for n in self._convs[:-1]:
             conv = getattr(self, n)
             h = ops.conv2d_nhwc(h, conv.weight.permute(0, 2, 3, 1).contiguous(), conv.bias, self.stride, self.pad, relu=True)
-        pooled = ops.avgpool_nhwc_fn(h)
+        if self._convs:   # the last convolution, its ReLU and the pool as one autograd node (fused backward)
+            conv = getattr(self, self._convs[-1])
+            pooled = ops.conv2d_relu_avgpool_nhwc(h, conv.weight.permute(0, 2, 3, 1).contiguous(), conv.bias, self.stride,
+                                                  self.pad)
+        else:
+            pooled = ops.avgpool_nhwc_fn(h)
         fin = getattr(self, self._final)
         out = ops.mlp(pooled, th.cat([fin.weight.reshape(-1), fin.bias.reshape(-1)]), self.dims_final, ops.ACT_NONE)
         return out.squeeze(-1) if self.squeeze_output else out

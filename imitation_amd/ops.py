@@ -211,6 +211,15 @@ def conv2d_nhwc_backward(dy: Tensor, y: Tensor, col: Tensor, x: Tensor, w: Tenso
     if relu:
         dz = th.empty_like(dy)
         L.call("ia_relu_backward", L.ptr(dy), L.ptr(y), dy.numel(), L.ptr(dz), L.stream())
+    if (col.shape[0] == 0 and KH == KW == 3 and stride == 1 and pad == 1 and Cin == 32 and Cout == 32 and in_w <= 128
+            and (OH, OW) == (in_h, in_w)):
+        # the reward CNN's own geometry: whole images per workgroup, the 32 x 288 gradient in its accumulators, x and dz read
+        # once (`csrc/conv3x3.hip`; the split-K GEMM below ran this 7.2 M-row product at 36 TFLOP/s)
+        splits = int(L.load().ia_conv3x3_c32_wgrad_slabs(B))
+        part = th.empty(splits, Cout, K, device=dy.device)
+        dbp = th.empty(splits, Cout, device=dy.device)
+        L.call("ia_conv3x3_c32_wgrad", L.ptr(dz), L.ptr(x), B, in_h, in_w, L.ptr(part), L.ptr(dbp), L.stream())
+        return _conv_backward_tail(dz, w, part, dbp, splits, B, in_h, in_w, OH, OW, Cin, Cout, KH, KW, K, M, stride, pad, need_dx)
     # split-K over the rows: 64 splits left the weight gradient of a 1 024-frame 84 x 84 batch (7.2 M rows against a 32 x 288
     # output: 5 tiles) on 320 workgroups of 113 k rows each -- 7.7 ms per call, 17 TFLOP/s (`profiles/r05_image_gail.md`)
     splits = int(min(1024, max(1, M // 2048)))
@@ -222,6 +231,12 @@ def conv2d_nhwc_backward(dy: Tensor, y: Tensor, col: Tensor, x: Tensor, w: Tenso
     else:
         L.call("ia_gemm_f32", L.GEMM_TN, L.ptr(dz), Cout, L.ptr(col), K, L.ptr(part), K, Cout, K, M, None, 0, None, 0,
                splits, L.ptr(dbp), L.stream())
+    return _conv_backward_tail(dz, w, part, dbp, splits, B, in_h, in_w, OH, OW, Cin, Cout, KH, KW, K, M, stride, pad, need_dx)
+
+
+def _conv_backward_tail(dz, w, part, dbp, splits, B, in_h, in_w, OH, OW, Cin, Cout, KH, KW, K, M, stride, pad, need_dx):
+    """Slab reduction of the weight / bias gradient (fixed order) and the input gradient of `conv2d_nhwc_backward`."""
+    dy = dz
     dw, db = th.empty(Cout, KH, KW, Cin, device=dy.device), th.empty(Cout, device=dy.device)
     L.call("ia_reduce_partials", L.ptr(part), splits, Cout * K, 1.0, 0, L.ptr(dw), L.stream())
     L.call("ia_reduce_partials", L.ptr(dbp), splits, Cout, 1.0, 0, L.ptr(db), L.stream())
@@ -315,6 +330,52 @@ class _AvgPool(th.autograd.Function):
 
 def avgpool_nhwc_fn(y: Tensor) -> Tensor:
     return _AvgPool.apply(_dev(y, "y"))
+
+
+@th.library.custom_op("imitation_amd::avgpool_relu_backward", mutates_args=(), device_types="cuda")
+def avgpool_relu_backward(dout: Tensor, y: Tensor) -> Tensor:
+    """Backward of "ReLU, then `AdaptiveAvgPool2d(1)`" through the saved post-activation `y[B, H, W, C]`: the pool's
+    `dout / (H W)` under the ReLU's mask in ONE pass (read y, write dz) -- apart, the broadcast writes a full-resolution
+    tensor that `ia_relu_backward` reads back together with `y` (2.8 GB moved per 1 024 x 84 x 84 x 32 call instead of 1.85)."""
+    dout, y = _dev(dout, "dout"), _dev(y, "y")
+    B, H, W, Cc = y.shape
+    dz = th.empty_like(y)
+    L.call("ia_avgpool_relu_backward", L.ptr(dout), L.ptr(y), B, H * W, Cc, L.ptr(dz), L.stream())
+    return dz
+
+
+@avgpool_relu_backward.register_fake
+def _(dout, y):
+    return th.empty_like(y)
+
+
+class _ConvReluPool(th.autograd.Function):
+    """`Conv2d - ReLU - AdaptiveAvgPool2d(1) - Flatten` (the tail of `build_cnn`, `util/networks.py:340-349`) as one node: the same
+    two forward launches as `conv2d_nhwc(relu=True)` + `avgpool_nhwc_fn`, a backward that forms the convolution's
+    pre-activation gradient in one pass."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, stride, pad):
+        y, col = th.ops.imitation_amd.conv2d_nhwc_forward(x, w, b, stride, pad, True)
+        ctx.save_for_backward(y, col, x, w)
+        ctx.cfg = (x.shape[1], x.shape[2], stride, pad)
+        return th.ops.imitation_amd.avgpool_nhwc(y)
+
+    @staticmethod
+    def backward(ctx, dout):
+        y, col, x, w = ctx.saved_tensors
+        in_h, in_w, stride, pad = ctx.cfg
+        dz = th.ops.imitation_amd.avgpool_relu_backward(dout.contiguous(), y)
+        dx, dw, db = th.ops.imitation_amd.conv2d_nhwc_backward(dz, y, col, x, w, in_h, in_w, stride, pad, False,
+                                                               bool(ctx.needs_input_grad[0]))
+        return (dx if ctx.needs_input_grad[0] else None), dw, db, None, None
+
+
+def conv2d_relu_avgpool_nhwc(x: Tensor, w: Tensor, b: Tensor, stride: int = 1, pad: int = 0) -> Tensor:
+    """`avgpool_nhwc_fn(conv2d_nhwc(x, w, b, stride, pad, relu=True))` with the fused backward (C % 4 == 0)."""
+    if w.shape[0] % 4:
+        return avgpool_nhwc_fn(conv2d_nhwc(x, w, b, stride, pad, relu=True))
+    return _ConvReluPool.apply(_dev(x, "x"), w, b, int(stride), int(pad))
 
 
 class _Mlp(th.autograd.Function):

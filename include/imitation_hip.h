@@ -572,6 +572,16 @@ int ia_relu_backward(const float* dy, const float* y, int64_t n, float* out, voi
 /* nn.AdaptiveAvgPool2d(1) on channel-last activations y[B, HW, C] -> out[B, C], and its backward (dy = dout / HW). */
 int ia_avgpool_nhwc(const float* y, int B, int HW, int C, float* out, void* stream);
 int ia_avgpool_nhwc_backward(const float* dout, int B, int HW, int C, float* dy, void* stream);
+/* The reward CNN's geometry (3 x 3, stride 1, "same" padding, 32 -> 32 channels; `rewards/reward_nets.py:460-610` with
+ * `util/networks.py:286-357`'s defaults), channel-last tensors dz[B, H, W, 32], x[B, H, W, 32]: weight and bias gradient as
+ * ia_conv3x3_c32_wgrad_slabs(B) slabs part[slabs][32][3][3][32] (torch's [Cout, KH, KW, Cin] per slab), dbp[slabs][32] -- reduce
+ * with ia_reduce_partials. A workgroup owns whole images, the 32 x 288 gradient stays in its accumulators, x and dz are read
+ * once. -2 (IA_ERR_UNSUPPORTED) for W > 128. */
+int ia_conv3x3_c32_wgrad_slabs(int B);
+int ia_conv3x3_c32_wgrad(const float* dz, const float* x, int B, int H, int W, float* part, float* dbp, void* stream);
+/* Backward of "ReLU, then AdaptiveAvgPool2d(1)" on channel-last y[B, HW, C] in one pass: dz = y > 0 ? dout[b, c] / HW : 0
+ * (C % 4 == 0; else -2). */
+int ia_avgpool_relu_backward(const float* dout, const float* y, int B, int HW, int C, float* dz, void* stream);
 /* ia_gemm_f32 with the [rows, KH*KW*Cin] operand of a convolution given implicitly as the im2col view of the
  * channel-last activation tensor x[Bn, H, W, Cin] (`torch.nn.Conv2d` forward / weight gradient without a column
  * buffer; [SB3 torch_layers.NatureCNN] cnn.2 / cnn.4). mode 0 (NT): A = x, C[M = Bn*OH*OW, N = Cout] =

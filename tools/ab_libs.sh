@@ -5,7 +5,7 @@ set -e
 cd "$(dirname "$0")/../imitation_amd/csrc"
 mkdir -p ../_ab
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wall -Wno-unused-function -Wno-unused-variable"
-OTHERS="gemm.o mlp.o disc_fused.o airl_fused.o ppo_general.o host.o conv.o conv1_implicit.o"
+OTHERS="gemm.o mlp.o disc_fused.o airl_fused.o ppo_general.o host.o conv.o conv1_implicit.o conv3x3.o"
 for spec in "$@"; do
   name="${spec%%:*}"; defs="${spec#*:}"
   ( /opt/rocm/bin/hipcc $FLAGS $defs -c policy.hip -o ../_ab/policy_$name.o &&
