@@ -167,6 +167,195 @@ __global__ __launch_bounds__(C3_THREADS) void conv3x3_c32_wgrad_kernel(const flo
   }
 }
 
+// ---- the reward CNN's FIRST convolution: 4 input channels (the frame stack), 32 output channels, 3 x 3 "same" -----------------------
+// K = 36 is no 32-deep chunk of a kernel row, so the general path materialised the im2col matrix (1 024 x 7 056 x 36 floats = 1 GB
+// written, read by the forward GEMM and read again by the weight gradient: 2.8 ms of an update's 11). Both products straight from
+// the 4-channel rows instead:
+//   conv3x3_c4_fwd_kernel    y = relu(b + W x): a workgroup takes a band of output rows of one image, its input rows (+ halo, zero
+//       pixels at the borders) in LDS; per 32 positions 18 MFMAs 32x32x2 with A[m = co][k = (tap, ci)] = the weights (registers) and
+//       B[k][n = position] gathered from the LDS rows; bias and ReLU on the accumulators, 16-byte stores. Bound by the 925 MB of y.
+//   conv3x3_c4_wgrad_kernel  dW[co][(tap, ci)] and db over the positions of whole images per workgroup: A[m = co][k = position] = dz
+//       (LDS row), B[k = position][n = (tap, ci)] from the LDS rows of x, two 32-wide column tiles (36 columns). Reads dz once.
+constexpr int C4_CI = 4, C4_K = 36;
+constexpr int C4_BAND = 12;        // output rows per forward workgroup
+constexpr int C4_THREADS = 256;
+
+__global__ __launch_bounds__(C4_THREADS) void conv3x3_c4_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                                    const float* __restrict__ bias, int H, int W, int bands,
+                                                                    int relu, float* __restrict__ y) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];   // [(BAND + 2) rows][(W + 2) pixels][4]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n = lane & 31, kk = lane >> 5;
+  const int b = blockIdx.x / bands, band = blockIdx.x - b * bands;
+  const int oy0 = band * C4_BAND, rows = min(C4_BAND, H - oy0);
+  const int rs = (W + 2) * C4_CI;   // floats per LDS row
+  // weights as the A operand: A[m = co][k] of step j is W[co][2 j + k] (torch layout [co][ky][kx][ci] = [co][36])
+  float wa[C4_K / 2];
+#pragma unroll
+  for (int j = 0; j < C4_K / 2; ++j) wa[j] = w[n * C4_K + 2 * j + kk];
+  // B operand: element e = 2 j + k = (tap, ci) of position p sits at LDS offset p_base + (ky * rs + kx * 4 + ci)
+  int boff[C4_K / 2];
+#pragma unroll
+  for (int j = 0; j < C4_K / 2; ++j) {
+    const int e = 2 * j + kk, tap = e >> 2, ci = e & 3;
+    boff[j] = (tap / 3) * rs + (tap % 3) * C4_CI + ci;
+  }
+  float bv[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) bv[j] = bias[8 * (j >> 2) + 4 * kk + (j & 3)];
+  // input rows oy0 - 1 .. oy0 + rows (zero outside the image), pixels -1 .. W
+  const float* xb = x + (long long)b * H * W * C4_CI;
+  const int px = W + 2;
+  for (int e = tid; e < (rows + 2) * px; e += C4_THREADS) {
+    const int r = e / px, p = e - r * px;
+    const int iy = oy0 - 1 + r, ix = p - 1;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (iy >= 0 && iy < H && ix >= 0 && ix < W) v = *reinterpret_cast<const f32x4*>(xb + ((long long)iy * W + ix) * C4_CI);
+    *reinterpret_cast<f32x4*>(lds + (r * px + p) * C4_CI) = v;
+  }
+  __syncthreads();
+  const int npos = rows * W;
+  float* yb = y + ((long long)b * H + oy0) * W * C3_C;
+  for (int t0 = wave * 32; t0 < npos; t0 += 4 * 32) {
+    const int p = min(t0 + n, npos - 1);
+    const int r = p / W, ox = p - r * W;
+    const float* base = lds + (r * px + ox) * C4_CI;
+    float bq[C4_K / 2];
+#pragma unroll
+    for (int j = 0; j < C4_K / 2; ++j) bq[j] = base[boff[j]];
+    f32x16 acc;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[j] = bv[j];
+#pragma unroll
+    for (int j = 0; j < C4_K / 2; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[j], bq[j], acc, 0, 0, 0);
+    if (t0 + n < npos) {
+      float* o = yb + (long long)p * C3_C + 4 * kk;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        f32x4 v;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = relu ? fmaxf(acc[4 * q + u], 0.f) : acc[4 * q + u];
+        *reinterpret_cast<f32x4*>(o + 8 * q) = v;
+      }
+    }
+  }
+}
+
+constexpr int C4W_THREADS = 256;   // four waves: quarters of a row's position pairs; each wave both column tiles
+__global__ __launch_bounds__(C4W_THREADS) void conv3x3_c4_wgrad_kernel(const float* __restrict__ dz, const float* __restrict__ x,
+                                                                       int B, int H, int W, float* __restrict__ part,
+                                                                       float* __restrict__ dbp) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  // LDS: ring of four x rows [(Wp + 2) pixels][4] (zero pixels at either end) + two dz rows [Wp][32]
+  const int Wp = (W + 1) & ~1;
+  const int xrow = (Wp + 2) * C4_CI, zrow = Wp * C3_C;
+  float* xr = lds;
+  float* zr = lds + 4 * xrow;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int m = lane & 31, kk = lane >> 5;
+  // B[k = position][n = e]: e = 32 t + m (t = 0, 1; e < 36) -> (ky, kx, ci); the wave's rows differ by ky PER LANE here
+  int boff[2];
+  bool bon[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const int e = 32 * t + m;
+    bon[t] = e < C4_K;
+    const int ec = bon[t] ? e : 0, tap = ec >> 2, ci = ec & 3;
+    boff[t] = (tap / 3) * 4 * xrow /* ring slot stride, resolved per output row below */ + (tap % 3) * C4_CI + ci;
+  }
+  f32x16 acc[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[t][j] = 0.f;
+  float bsum = 0.f;
+  for (int e = tid; e < 4 * xrow; e += C4W_THREADS) xr[e] = 0.f;
+  for (int e = tid; e < 2 * zrow; e += C4W_THREADS) zr[e] = 0.f;
+  const int zf4 = W * C3_C / 4, xf4 = W;   // float4 pieces of a dz row / an x row (one pixel each)
+  constexpr int NZ = (C3_WMAX * C3_C / 4 + C4W_THREADS - 1) / C4W_THREADS;
+  const int steps = Wp >> 1;
+  const int s_lo = (steps * wv) >> 2, s_hi = (steps * (wv + 1)) >> 2;
+  for (int b = blockIdx.x; b < B; b += gridDim.x) {
+    const float* xb = x + (long long)b * H * W * C4_CI;
+    const float* zb = dz + (long long)b * H * W * C3_C;
+    __syncthreads();
+    // ring slot of input row r: (r + 1) & 3; row -1 = zeros
+    for (int e = tid; e < W; e += C4W_THREADS) *reinterpret_cast<f32x4*>(xr + 0 * xrow + (e + 1) * C4_CI) = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int e = tid; e < 2 * xf4; e += C4W_THREADS) {
+      const int r = e / xf4, p = e - r * xf4;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (r < H) v = *reinterpret_cast<const f32x4*>(xb + ((long long)r * W + p) * C4_CI);
+      *reinterpret_cast<f32x4*>(xr + (r + 1) * xrow + (p + 1) * C4_CI) = v;
+    }
+    for (int e = tid; e < zf4; e += C4W_THREADS) reinterpret_cast<f32x4*>(zr)[e] = reinterpret_cast<const f32x4*>(zb)[e];
+    __syncthreads();
+    for (int oy = 0; oy < H; ++oy) {
+      f32x4 vz[NZ], vx = {0.f, 0.f, 0.f, 0.f};
+      const bool have_x = oy + 2 < H, have_z = oy + 1 < H;
+      if (have_z) {
+        const f32x4* s4 = reinterpret_cast<const f32x4*>(zb + (long long)(oy + 1) * W * C3_C);
+#pragma unroll
+        for (int i = 0; i < NZ; ++i) vz[i] = s4[min(tid + i * C4W_THREADS, zf4 - 1)];
+      }
+      if (have_x && tid < xf4) vx = *reinterpret_cast<const f32x4*>(xb + ((long long)(oy + 2) * W + tid) * C4_CI);
+      // x row oy + ky - 1 is in slot (oy + ky) & 3: the lane's tap decides
+      const float* zrow_p = zr + (oy & 1) * zrow + kk * C3_C + m;
+      const float* bp[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const int ky = boff[t] / (4 * xrow), rest = boff[t] - ky * 4 * xrow;
+        bp[t] = xr + ((oy + ky) & 3) * xrow + rest + kk * C4_CI;
+      }
+      for (int s = s_lo; s < s_hi; ++s) {
+        const float a = zrow_p[s * 2 * C3_C];
+        const float b0 = bp[0][s * 2 * C4_CI];
+        const float b1 = bon[1] ? bp[1][s * 2 * C4_CI] : 0.f;
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc[1], 0, 0, 0);
+        bsum += a;
+      }
+      if (tid < xf4) *reinterpret_cast<f32x4*>(xr + ((oy + 3) & 3) * xrow + (tid + 1) * C4_CI) = vx;   // (zeros past the image)
+      if (have_z) {
+        f32x4* d4 = reinterpret_cast<f32x4*>(zr + ((oy + 1) & 1) * zrow);
+#pragma unroll
+        for (int i = 0; i < NZ; ++i)
+          if (tid + i * C4W_THREADS < zf4) d4[tid + i * C4W_THREADS] = vz[i];
+      }
+      __syncthreads();
+    }
+  }
+  // the four waves' partial sums through LDS, added in wave order by wave 0
+  __syncthreads();
+  float* ex = lds;   // [3 waves][2][16][64] + [3][64]
+  if (wv > 0) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int j = 0; j < 16; ++j) ex[(((wv - 1) * 2 + t) * 16 + j) * 64 + lane] = acc[t][j];
+    ex[3 * 2 * 16 * 64 + (wv - 1) * 64 + lane] = bsum;
+  }
+  __syncthreads();
+  if (wv > 0) return;
+  for (int w2 = 0; w2 < 3; ++w2) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int j = 0; j < 16; ++j) acc[t][j] += ex[((w2 * 2 + t) * 16 + j) * 64 + lane];
+    bsum += ex[3 * 2 * 16 * 64 + w2 * 64 + lane];
+  }
+  float* slab = part + (long long)blockIdx.x * C3_C * C4_K;
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const int e = 32 * t + m;
+    if (e < C4_K)
+#pragma unroll
+      for (int j = 0; j < 16; ++j) slab[(8 * (j >> 2) + 4 * kk + (j & 3)) * C4_K + e] = acc[t][j];
+  }
+  bsum += __shfl_xor(bsum, 32, 64);
+  if (lane < 32) dbp[(long long)blockIdx.x * C3_C + lane] = bsum;
+}
+
 __global__ __launch_bounds__(256) void avgpool_relu_backward_kernel(const float* __restrict__ dout, const float* __restrict__ y,
                                                                     int HW, int C, float* __restrict__ dz, long long total4) {
   const int Q = C >> 2;
@@ -210,6 +399,32 @@ int ia_conv3x3_c32_wgrad(const float* dz, const float* x, int B, int H, int W, f
   }
   hipLaunchKernelGGL(conv3x3_c32_wgrad_kernel, dim3(ia_conv3x3_c32_wgrad_slabs(B)), dim3(C3_THREADS), bytes, (hipStream_t)stream,
                      dz, x, B, H, W, part, dbp);
+  IA_CHECK_LAUNCH();
+  return IA_OK;
+}
+
+/* The same for the reward CNN's FIRST convolution (4 input channels: the frame stack): forward y[B, H, W, 32] = act(b + W x) of
+ * x[B, H, W, 4] with w[32][3][3][4] (`relu` != 0: ReLU), and its weight / bias gradient as ia_conv3x3_c32_wgrad_slabs(B) slabs
+ * part[slabs][32][36], dbp[slabs][32] -- no [B H W, 36] column matrix. -2 for W > 128. */
+int ia_conv3x3_c4_forward(const float* x, const float* w, const float* bias, int B, int H, int W, int relu, float* y, void* stream) {
+  if (!x || !w || !bias || !y || B <= 0 || H <= 0 || W <= 0) return IA_ERR_ARG;
+  if (W > C3_WMAX) return IA_ERR_UNSUPPORTED;
+  const int bands = (H + C4_BAND - 1) / C4_BAND;
+  const size_t bytes = (size_t)(C4_BAND + 2) * (W + 2) * C4_CI * sizeof(float);
+  hipLaunchKernelGGL(conv3x3_c4_fwd_kernel, dim3((unsigned)((long long)B * bands)), dim3(C4_THREADS), bytes, (hipStream_t)stream, x, w,
+                     bias, H, W, bands, relu, y);
+  IA_CHECK_LAUNCH();
+  return IA_OK;
+}
+
+int ia_conv3x3_c4_wgrad(const float* dz, const float* x, int B, int H, int W, float* part, float* dbp, void* stream) {
+  if (!dz || !x || !part || !dbp || B <= 0 || H <= 0 || W <= 0) return IA_ERR_ARG;
+  if (W > C3_WMAX) return IA_ERR_UNSUPPORTED;
+  const int Wp = (W + 1) & ~1;
+  const int rows_f = 4 * (Wp + 2) * C4_CI + 2 * Wp * C3_C, ex_f = 3 * 2 * 16 * 64 + 3 * 64;
+  const size_t bytes = (size_t)(rows_f > ex_f ? rows_f : ex_f) * sizeof(float);
+  hipLaunchKernelGGL(conv3x3_c4_wgrad_kernel, dim3(ia_conv3x3_c32_wgrad_slabs(B)), dim3(C4W_THREADS), bytes, (hipStream_t)stream, dz,
+                     x, B, H, W, part, dbp);
   IA_CHECK_LAUNCH();
   return IA_OK;
 }

@@ -163,6 +163,12 @@ def conv_is_implicit(cin: int, kw: int, x_numel: int) -> bool:
     return cin % 4 == 0 and (kw * cin) % 32 == 0 and x_numel < 2 ** 31
 
 
+def conv_is_direct_c4(cin: int, cout: int, kh: int, kw: int, stride: int, pad: int, w_in: int) -> bool:
+    """The reward CNN's first convolution (`csrc/conv3x3.hip`): 3 x 3 "same" from the 4-channel frame stack to 32 channels --
+    forward and weight gradient straight from the 4-channel rows, no column matrix."""
+    return cin == 4 and cout == 32 and kh == kw == 3 and stride == 1 and pad == 1 and w_in <= 128
+
+
 @th.library.custom_op("imitation_amd::conv2d_nhwc_forward", mutates_args=(), device_types="cuda")
 def conv2d_nhwc_forward(x: Tensor, w: Tensor, b: Tensor, stride: int, pad: int, relu: bool) -> Tuple[Tensor, Tensor]:
     """Convolution of channel-last activations `x[B, H, W, Cin]` with `w[Cout, KH, KW, Cin]`, bias `b[Cout]`, zero
@@ -174,6 +180,9 @@ def conv2d_nhwc_forward(x: Tensor, w: Tensor, b: Tensor, stride: int, pad: int, 
     OH, OW = (H + 2 * pad - KH) // stride + 1, (W + 2 * pad - KW) // stride + 1
     K, M = KH * KW * Cin, B * OH * OW
     y = th.empty(B, OH, OW, Cout, device=x.device)
+    if conv_is_direct_c4(Cin, Cout, KH, KW, stride, pad, W):
+        L.call("ia_conv3x3_c4_forward", L.ptr(x), L.ptr(w), L.ptr(b), B, H, W, int(relu), L.ptr(y), L.stream())
+        return y, th.empty(0, K, device=x.device)
     if conv_is_implicit(Cin, KW, B * H * W * Cin):
         # the GEMM reads its operand through the padded im2col view of `x`: no column buffer (`col` comes back empty;
         # the backward op takes `x` instead)
@@ -192,7 +201,7 @@ def _(x, w, b, stride, pad, relu):
     B, H, W, Cin = x.shape
     Cout, KH, KW, _ = w.shape
     OH, OW = (H + 2 * pad - KH) // stride + 1, (W + 2 * pad - KW) // stride + 1
-    rows = 0 if conv_is_implicit(Cin, KW, B * H * W * Cin) else B * OH * OW
+    rows = 0 if (conv_is_implicit(Cin, KW, B * H * W * Cin) or conv_is_direct_c4(Cin, Cout, KH, KW, stride, pad, W)) else B * OH * OW
     return x.new_empty(B, OH, OW, Cout), x.new_empty(rows, KH * KW * Cin)
 
 
@@ -219,6 +228,12 @@ def conv2d_nhwc_backward(dy: Tensor, y: Tensor, col: Tensor, x: Tensor, w: Tenso
         part = th.empty(splits, Cout, K, device=dy.device)
         dbp = th.empty(splits, Cout, device=dy.device)
         L.call("ia_conv3x3_c32_wgrad", L.ptr(dz), L.ptr(x), B, in_h, in_w, L.ptr(part), L.ptr(dbp), L.stream())
+        return _conv_backward_tail(dz, w, part, dbp, splits, B, in_h, in_w, OH, OW, Cin, Cout, KH, KW, K, M, stride, pad, need_dx)
+    if col.shape[0] == 0 and conv_is_direct_c4(Cin, Cout, KH, KW, stride, pad, in_w):
+        splits = int(L.load().ia_conv3x3_c32_wgrad_slabs(B))
+        part = th.empty(splits, Cout, K, device=dy.device)
+        dbp = th.empty(splits, Cout, device=dy.device)
+        L.call("ia_conv3x3_c4_wgrad", L.ptr(dz), L.ptr(x), B, in_h, in_w, L.ptr(part), L.ptr(dbp), L.stream())
         return _conv_backward_tail(dz, w, part, dbp, splits, B, in_h, in_w, OH, OW, Cin, Cout, KH, KW, K, M, stride, pad, need_dx)
     # split-K over the rows: 64 splits left the weight gradient of a 1 024-frame 84 x 84 batch (7.2 M rows against a 32 x 288
     # output: 5 tiles) on 320 workgroups of 113 k rows each -- 7.7 ms per call, 17 TFLOP/s (`profiles/r05_image_gail.md`)

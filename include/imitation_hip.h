@@ -579,6 +579,11 @@ int ia_avgpool_nhwc_backward(const float* dout, int B, int HW, int C, float* dy,
  * once. -2 (IA_ERR_UNSUPPORTED) for W > 128. */
 int ia_conv3x3_c32_wgrad_slabs(int B);
 int ia_conv3x3_c32_wgrad(const float* dz, const float* x, int B, int H, int W, float* part, float* dbp, void* stream);
+/* The same net's FIRST convolution (4 input channels: the frame stack; w[32][3][3][4]): forward y[B, H, W, 32] = act(b + W x)
+ * (relu != 0: ReLU) and weight / bias gradient (slabs part[slabs][32][36], dbp[slabs][32], slabs as above) straight from the
+ * 4-channel rows -- no [B H W, 36] column matrix. -2 for W > 128. */
+int ia_conv3x3_c4_forward(const float* x, const float* w, const float* bias, int B, int H, int W, int relu, float* y, void* stream);
+int ia_conv3x3_c4_wgrad(const float* dz, const float* x, int B, int H, int W, float* part, float* dbp, void* stream);
 /* Backward of "ReLU, then AdaptiveAvgPool2d(1)" on channel-last y[B, HW, C] in one pass: dz = y > 0 ? dout[b, c] / HW : 0
  * (C % 4 == 0; else -2). */
 int ia_avgpool_relu_backward(const float* dout, const float* y, int B, int HW, int C, float* dz, void* stream);

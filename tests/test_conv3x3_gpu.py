@@ -72,3 +72,24 @@ def test_avgpool_relu_backward_equals_its_two_passes_bit_for_bit(B, HW, C):
     got = th.full_like(y, float("nan"))
     L.call("ia_avgpool_relu_backward", L.ptr(dout), L.ptr(y), B, HW, C, L.ptr(got), L.stream())
     assert th.equal(got, want)
+
+
+@pytest.mark.parametrize("B,H,W", [(1, 1, 1), (3, 5, 7), (2, 13, 16), (4, 25, 31), (2, 84, 84), (1030, 3, 4)])
+def test_conv3x3_c4_forward_and_gradient_match_float64_autograd(B, H, W):
+    """The reward CNN's first convolution straight from the 4-channel rows (no column matrix), through the public op."""
+    g = th.Generator().manual_seed(7 * B + H + W)
+    x = th.randn(B, H, W, 4, generator=g).cuda()
+    w = (0.3 * th.randn(32, 3, 3, 4, generator=g)).cuda()
+    b = (0.3 * th.randn(32, generator=g)).cuda()
+    wr, br = w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    y = ops.conv2d_nhwc(x, wr, br, 1, 1, relu=True)
+    coef = th.randn(B, H, W, 32, generator=g).cuda()
+    (y * coef).sum().backward()
+    w64 = w.double().cpu().permute(0, 3, 1, 2).contiguous().requires_grad_(True)
+    b64 = b.double().cpu().requires_grad_(True)
+    y64 = th.relu(th.nn.functional.conv2d(x.double().cpu().permute(0, 3, 1, 2), w64, b64, padding=1))
+    (y64 * coef.double().cpu().permute(0, 3, 1, 2)).sum().backward()
+    assert th.allclose(y.double().cpu(), y64.detach().permute(0, 2, 3, 1), rtol=1e-5, atol=1e-5)
+    tol = 2e-5 * max(1.0, np.sqrt(B * H * W / 64.0))
+    assert float((wr.grad.double().cpu() - w64.grad.permute(0, 2, 3, 1)).abs().max()) <= tol * (float(w64.grad.abs().max()) + 1e-12)
+    assert float((br.grad.double().cpu() - b64.grad).abs().max()) <= tol * (float(b64.grad.abs().max()) + 1e-12)
