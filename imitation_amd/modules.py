@@ -306,13 +306,15 @@ class Cnn(nn.Module):
 
     def forward(self, x: th.Tensor) -> th.Tensor:
         h = x.permute(0, 2, 3, 1).contiguous()                  # [B, C, H, W] -> channel-last
-        for n in self._convs[:-1]:
+        # every layer's ReLU backward rides in the NEXT layer's input-gradient epilogue (`ops.conv2d_nhwc`)
+        for i, n in enumerate(self._convs[:-1]):
             conv = getattr(self, n)
-            h = ops.conv2d_nhwc(h, conv.weight.permute(0, 2, 3, 1).contiguous(), conv.bias, self.stride, self.pad, relu=True)
+            h = ops.conv2d_nhwc(h, conv.weight.permute(0, 2, 3, 1).contiguous(), conv.bias, self.stride, self.pad, relu=True,
+                                x_is_relu=i > 0, dy_is_masked=True)
         if self._convs:   # the last convolution, its ReLU and the pool as one autograd node (fused backward)
             conv = getattr(self, self._convs[-1])
             pooled = ops.conv2d_relu_avgpool_nhwc(h, conv.weight.permute(0, 2, 3, 1).contiguous(), conv.bias, self.stride,
-                                                  self.pad)
+                                                  self.pad, x_is_relu=len(self._convs) > 1)
         else:
             pooled = ops.avgpool_nhwc_fn(h)
         fin = getattr(self, self._final)

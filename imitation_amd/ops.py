@@ -207,11 +207,12 @@ def _(x, w, b, stride, pad, relu):
 
 @th.library.custom_op("imitation_amd::conv2d_nhwc_backward", mutates_args=(), device_types="cuda")
 def conv2d_nhwc_backward(dy: Tensor, y: Tensor, col: Tensor, x: Tensor, w: Tensor, in_h: int, in_w: int, stride: int,
-                         pad: int, relu: bool, need_dx: bool) -> Tuple[Tensor, Tensor, Tensor]:
+                         pad: int, relu: bool, need_dx: bool, mask_dx: bool = False) -> Tuple[Tensor, Tensor, Tensor]:
     """Backward of `conv2d_nhwc_forward`: `(dx[B, H, W, Cin] (zeros when not needed), dw, db)`. ReLU backward from
     the saved output, weight gradient = split-K TN GEMM on the kept columns -- or, when the forward ran without a
     column buffer (`col` empty), on the implicit view of the input `x` -- slabs reduced in fixed order; input gradient =
-    NN GEMM + gather-form col2im."""
+    NN GEMM + gather-form col2im. `mask_dx`: the input `x` is itself a ReLU output whose backward the caller wants applied to
+    `dx` here (zero where x <= 0: in the input-gradient GEMM's epilogue, instead of a pass of its own over the tensor)."""
     dy, y, col, x, w = _dev(dy, "dy"), _dev(y, "y"), _dev(col, "col"), _dev(x, "x"), _dev(w, "w")
     B, OH, OW, Cout = y.shape
     _, KH, KW, Cin = w.shape
@@ -228,13 +229,15 @@ def conv2d_nhwc_backward(dy: Tensor, y: Tensor, col: Tensor, x: Tensor, w: Tenso
         part = th.empty(splits, Cout, K, device=dy.device)
         dbp = th.empty(splits, Cout, device=dy.device)
         L.call("ia_conv3x3_c32_wgrad", L.ptr(dz), L.ptr(x), B, in_h, in_w, L.ptr(part), L.ptr(dbp), L.stream())
-        return _conv_backward_tail(dz, w, part, dbp, splits, B, in_h, in_w, OH, OW, Cin, Cout, KH, KW, K, M, stride, pad, need_dx)
+        return _conv_backward_tail(dz, w, part, dbp, splits, B, in_h, in_w, OH, OW, Cin, Cout, KH, KW, K, M, stride, pad, need_dx,
+                                   x if mask_dx else None)
     if col.shape[0] == 0 and conv_is_direct_c4(Cin, Cout, KH, KW, stride, pad, in_w):
         splits = int(L.load().ia_conv3x3_c32_wgrad_slabs(B))
         part = th.empty(splits, Cout, K, device=dy.device)
         dbp = th.empty(splits, Cout, device=dy.device)
         L.call("ia_conv3x3_c4_wgrad", L.ptr(dz), L.ptr(x), B, in_h, in_w, L.ptr(part), L.ptr(dbp), L.stream())
-        return _conv_backward_tail(dz, w, part, dbp, splits, B, in_h, in_w, OH, OW, Cin, Cout, KH, KW, K, M, stride, pad, need_dx)
+        return _conv_backward_tail(dz, w, part, dbp, splits, B, in_h, in_w, OH, OW, Cin, Cout, KH, KW, K, M, stride, pad, need_dx,
+                                   x if mask_dx else None)
     # split-K over the rows: 64 splits left the weight gradient of a 1 024-frame 84 x 84 batch (7.2 M rows against a 32 x 288
     # output: 5 tiles) on 320 workgroups of 113 k rows each -- 7.7 ms per call, 17 TFLOP/s (`profiles/r05_image_gail.md`)
     splits = int(min(1024, max(1, M // 2048)))
@@ -246,11 +249,13 @@ def conv2d_nhwc_backward(dy: Tensor, y: Tensor, col: Tensor, x: Tensor, w: Tenso
     else:
         L.call("ia_gemm_f32", L.GEMM_TN, L.ptr(dz), Cout, L.ptr(col), K, L.ptr(part), K, Cout, K, M, None, 0, None, 0,
                splits, L.ptr(dbp), L.stream())
-    return _conv_backward_tail(dz, w, part, dbp, splits, B, in_h, in_w, OH, OW, Cin, Cout, KH, KW, K, M, stride, pad, need_dx)
+    return _conv_backward_tail(dz, w, part, dbp, splits, B, in_h, in_w, OH, OW, Cin, Cout, KH, KW, K, M, stride, pad, need_dx,
+                                   x if mask_dx else None)
 
 
-def _conv_backward_tail(dz, w, part, dbp, splits, B, in_h, in_w, OH, OW, Cin, Cout, KH, KW, K, M, stride, pad, need_dx):
-    """Slab reduction of the weight / bias gradient (fixed order) and the input gradient of `conv2d_nhwc_backward`."""
+def _conv_backward_tail(dz, w, part, dbp, splits, B, in_h, in_w, OH, OW, Cin, Cout, KH, KW, K, M, stride, pad, need_dx, mask=None):
+    """Slab reduction of the weight / bias gradient (fixed order) and the input gradient of `conv2d_nhwc_backward`
+    (`mask`: zero it where that tensor -- the convolution's input, a ReLU output -- is <= 0)."""
     dy = dz
     dw, db = th.empty(Cout, KH, KW, Cin, device=dy.device), th.empty(Cout, device=dy.device)
     L.call("ia_reduce_partials", L.ptr(part), splits, Cout * K, 1.0, 0, L.ptr(dw), L.stream())
@@ -264,17 +269,19 @@ def _conv_backward_tail(dz, w, part, dbp, splits, B, in_h, in_w, OH, OW, Cin, Co
         wd = w.flip(1, 2).permute(3, 1, 2, 0).contiguous()
         Kd = KH * KW * Cout
         L.call("ia_gemm_f32_im2col_pad", L.GEMM_NT, L.ptr(dz), Kd, L.ptr(wd), Kd, L.ptr(dx), Cin, B * in_h * in_w, Cin, Kd,
-               None, ACT_NONE, 1, None, OH, OW, Cout, KH, KW, 1, KH - 1 - pad, None, None, L.stream())
+               None, ACT_NONE, 1, None, OH, OW, Cout, KH, KW, 1, KH - 1 - pad, None, L.ptr(mask), L.stream())
     elif need_dx:
         dcol = th.empty(M, K, device=dy.device)
         L.call("ia_gemm_f32", L.GEMM_NN, L.ptr(dz), Cout, L.ptr(w), K, L.ptr(dcol), K, M, K, Cout, None, 0, None, 0, 1,
                None, L.stream())
         L.call("ia_col2im_nhwc_pad", L.ptr(dcol), B, in_h, in_w, Cin, KH, KW, stride, pad, L.ptr(dx), L.stream())
+        if mask is not None:
+            L.call("ia_relu_backward", L.ptr(dx), L.ptr(mask), dx.numel(), L.ptr(dx), L.stream())
     return dx, dw, db
 
 
 @conv2d_nhwc_backward.register_fake
-def _(dy, y, col, x, w, in_h, in_w, stride, pad, relu, need_dx):
+def _(dy, y, col, x, w, in_h, in_w, stride, pad, relu, need_dx, mask_dx=False):
     B = y.shape[0]
     return y.new_empty(B, in_h, in_w, w.shape[3]), th.empty_like(w), y.new_empty(w.shape[0])
 
@@ -312,24 +319,28 @@ def _(dout, h, w):
 
 class _Conv(th.autograd.Function):
     @staticmethod
-    def forward(ctx, x, w, b, stride, pad, relu):
+    def forward(ctx, x, w, b, stride, pad, relu, x_is_relu, dy_is_masked):
         y, col = th.ops.imitation_amd.conv2d_nhwc_forward(x, w, b, stride, pad, relu)
         ctx.save_for_backward(y, col, x, w)
-        ctx.cfg = (x.shape[1], x.shape[2], stride, pad, relu)
+        ctx.cfg = (x.shape[1], x.shape[2], stride, pad, relu and not dy_is_masked, x_is_relu)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         y, col, x, w = ctx.saved_tensors
-        in_h, in_w, stride, pad, relu = ctx.cfg
+        in_h, in_w, stride, pad, relu, x_is_relu = ctx.cfg
         dx, dw, db = th.ops.imitation_amd.conv2d_nhwc_backward(dy.contiguous(), y, col, x, w, in_h, in_w, stride, pad,
-                                                               relu, bool(ctx.needs_input_grad[0]))
-        return (dx if ctx.needs_input_grad[0] else None), dw, db, None, None, None
+                                                               relu, bool(ctx.needs_input_grad[0]), x_is_relu)
+        return (dx if ctx.needs_input_grad[0] else None), dw, db, None, None, None, None, None
 
 
-def conv2d_nhwc(x: Tensor, w: Tensor, b: Tensor, stride: int = 1, pad: int = 0, relu: bool = False) -> Tensor:
-    """Differentiable channel-last convolution (+ fused ReLU): `x[B, H, W, Cin]`, `w[Cout, KH, KW, Cin]`."""
-    return _Conv.apply(_dev(x, "x"), w, b, int(stride), int(pad), bool(relu))
+def conv2d_nhwc(x: Tensor, w: Tensor, b: Tensor, stride: int = 1, pad: int = 0, relu: bool = False, x_is_relu: bool = False,
+                dy_is_masked: bool = False) -> Tensor:
+    """Differentiable channel-last convolution (+ fused ReLU): `x[B, H, W, Cin]`, `w[Cout, KH, KW, Cin]`.
+    A chain of ReLU convolutions can hand the ReLU backward of layer i to layer i + 1's input-gradient GEMM (its epilogue
+    zeroes dx where its input -- layer i's ReLU output -- is <= 0): layer i + 1 is built with `x_is_relu=True`, layer i with
+    `dy_is_masked=True` (the gradient it receives already carries its own mask: no `ia_relu_backward` pass). Same values."""
+    return _Conv.apply(_dev(x, "x"), w, b, int(stride), int(pad), bool(relu), bool(x_is_relu), bool(dy_is_masked))
 
 
 class _AvgPool(th.autograd.Function):
@@ -370,27 +381,28 @@ class _ConvReluPool(th.autograd.Function):
     pre-activation gradient in one pass."""
 
     @staticmethod
-    def forward(ctx, x, w, b, stride, pad):
+    def forward(ctx, x, w, b, stride, pad, x_is_relu):
         y, col = th.ops.imitation_amd.conv2d_nhwc_forward(x, w, b, stride, pad, True)
         ctx.save_for_backward(y, col, x, w)
-        ctx.cfg = (x.shape[1], x.shape[2], stride, pad)
+        ctx.cfg = (x.shape[1], x.shape[2], stride, pad, x_is_relu)
         return th.ops.imitation_amd.avgpool_nhwc(y)
 
     @staticmethod
     def backward(ctx, dout):
         y, col, x, w = ctx.saved_tensors
-        in_h, in_w, stride, pad = ctx.cfg
+        in_h, in_w, stride, pad, x_is_relu = ctx.cfg
         dz = th.ops.imitation_amd.avgpool_relu_backward(dout.contiguous(), y)
         dx, dw, db = th.ops.imitation_amd.conv2d_nhwc_backward(dz, y, col, x, w, in_h, in_w, stride, pad, False,
-                                                               bool(ctx.needs_input_grad[0]))
-        return (dx if ctx.needs_input_grad[0] else None), dw, db, None, None
+                                                               bool(ctx.needs_input_grad[0]), x_is_relu)
+        return (dx if ctx.needs_input_grad[0] else None), dw, db, None, None, None
 
 
-def conv2d_relu_avgpool_nhwc(x: Tensor, w: Tensor, b: Tensor, stride: int = 1, pad: int = 0) -> Tensor:
-    """`avgpool_nhwc_fn(conv2d_nhwc(x, w, b, stride, pad, relu=True))` with the fused backward (C % 4 == 0)."""
+def conv2d_relu_avgpool_nhwc(x: Tensor, w: Tensor, b: Tensor, stride: int = 1, pad: int = 0, x_is_relu: bool = False) -> Tensor:
+    """`avgpool_nhwc_fn(conv2d_nhwc(x, w, b, stride, pad, relu=True))` with the fused backward (C % 4 == 0); `x_is_relu` as
+    in `conv2d_nhwc`."""
     if w.shape[0] % 4:
-        return avgpool_nhwc_fn(conv2d_nhwc(x, w, b, stride, pad, relu=True))
-    return _ConvReluPool.apply(_dev(x, "x"), w, b, int(stride), int(pad))
+        return avgpool_nhwc_fn(conv2d_nhwc(x, w, b, stride, pad, relu=True, x_is_relu=x_is_relu))
+    return _ConvReluPool.apply(_dev(x, "x"), w, b, int(stride), int(pad), bool(x_is_relu))
 
 
 class _Mlp(th.autograd.Function):
