@@ -1245,14 +1245,27 @@ class AdversarialTrainer(abc.ABC):
             return True
         if self.disc_behind_ppo is not None:
             return bool(self.disc_behind_ppo)
+        self._disc_choose_calls = calls = getattr(self, "_disc_choose_calls", 0) + 1
         t = getattr(self, "_disc_timing", None)
-        if t is not None and t[0] is not None and t[2] and t[1].query():  # a finished round measured while alone
+        # a finished round measured while alone -- but not one of a trainer's first rounds: they carry one-off costs (code
+        # objects loaded on first launch, first-touch allocations). A cold measurement used to put the image variant on
+        # "beside" for good -- the updates' time is only measured in "behind" rounds -- where its round is 63-68 ms
+        # instead of 56-58 (`profiles/r06_image_gail.md`).
+        if t is not None and t[0] is not None and t[2] and t[1].query() and calls > 3:
             self._disc_ms_behind = t[0].elapsed_time(t[1])
         window = self.gen_algo.rollout_window_ms
         if self._disc_ms_behind is not None and window is not None:
             # hysteresis: switching costs nothing, but do not flap around the break-even point
             fits = self._disc_ms_behind < (0.95 if self._disc_mode_behind else 0.8) * window
+            if not fits and self._disc_mode_behind:
+                self._disc_probe_at = calls + 32
             self._disc_mode_behind = fits
+        if not self._disc_mode_behind and calls >= getattr(self, "_disc_probe_at", 1 << 62):
+            # every 32 rounds of "beside": one round "behind", to measure the updates alone again (both schedules compute the
+            # same values: `test_pipelined_rounds_are_bit_identical`)
+            self._disc_probe_at = calls + 32
+            self._disc_ms_behind = None
+            self._disc_mode_behind = True
         return self._disc_mode_behind
 
     def _train_pipelined(self, n_rounds: int) -> None:

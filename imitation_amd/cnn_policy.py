@@ -276,7 +276,8 @@ class ActorCriticCnnPolicy:
             raise TypeError("image observations must be uint8 (the policy applies [SB3 preprocess_obs]: x / 255)")
         return t.to(self.device).reshape(-1, *self.observation_space.shape).contiguous()
 
-    def _forward(self, obs_u8: th.Tensor) -> Dict[str, th.Tensor]:
+    def _forward(self, obs_u8: th.Tensor, values_out: Optional[th.Tensor] = None) -> Dict[str, th.Tensor]:
+        """`values_out` (contiguous [B] device row): the value head writes there instead of into the batch buffer."""
         require_device(self.device)
         B = obs_u8.shape[0]
         d = self._buffers(B)
@@ -304,7 +305,8 @@ class ActorCriticCnnPolicy:
                    self.n_flatten, bias=self.b(3), act=1)
         F_ = self.features_dim
         self._gemm(0, d["feat"], F_, self.w(4), F_, d["logits"], self.n_actions, B, self.n_actions, F_, bias=self.b(4))
-        self._gemm(0, d["feat"], F_, self.w(5), F_, d["values"], 1, B, 1, F_, bias=self.b(5))
+        self._gemm(0, d["feat"], F_, self.w(5), F_, d["values"] if values_out is None else values_out, 1, B, 1, F_,
+                   bias=self.b(5))
         return d
 
     def evaluate_actions(self, obs, actions, logp_coef: float = 0.0, ent_coef: float = 0.0, want_grad: bool = False):
@@ -474,23 +476,62 @@ class ActorCriticCnnPolicy:
         """Rollout-step launcher for Discrete heads on the reference's sampling stream: logits to the pinned host
         tile, then `torch.distributions.Categorical(logits).sample()` / `.log_prob()` as SB3 composes them."""
         assert self.discrete
-        n = obs_tile.shape[1]
-        obs_d = th.empty(n, self.obs_dim, device=self.device)
-        stream_obj = th.cuda.current_stream()
+        launch, finish = self._multinomial_launch_finish(obs_tile, h_logits, h_clip, val, h_logp)
 
         def step(t: int) -> None:
+            launch(t)
+            finish(t)
+
+        return step
+
+    def make_multinomial_mailbox(self, obs_tile: th.Tensor, h_logits: th.Tensor, h_clip: th.Tensor, val: th.Tensor,
+                                 h_logp: th.Tensor, T: int, timeout_s: float = 120.0):
+        """`(post, wait, close)` as `ActorCriticPolicy.make_multinomial_mailbox`, with the step's launches as `post(t)` and
+        the wait for them + the host-side sampling as `wait(t)`: the rollout loop posts step t + 1 as soon as its frames are in
+        place and does step t's bookkeeping (the fp32 copy of the frames into the rollout tile, replay rows, callbacks) while
+        the device runs the ~8 launches of NatureCNN -- which queue for workgroup slots beside the discriminator's kernels
+        (`profiles/r05_image_gail.md`: 0.25 -> 1.5 ms per step, all of it host-visible before)."""
+        assert self.discrete
+        launch, finish = self._multinomial_launch_finish(obs_tile, h_logits, h_clip, val, h_logp)
+
+        def wait(t: int) -> bool:
+            finish(t)
+            return True
+
+        return launch, wait, (lambda: None)
+
+    def _multinomial_launch_finish(self, obs_tile, h_logits, h_clip, val, h_logp):
+        n = obs_tile.shape[1]
+        obs_d = th.empty(n, self.obs_dim, device=self.device)
+        # the step's frames as the environment hands them over (uint8): a pinned staging row the rollout loop fills
+        # (`PPO._rollout_steps`: `act_frames_u8` / `act_frames_u8_step`) -- a quarter of the fp32 row's bytes over PCIe and no
+        # conversion launch; the fp32 row of the rollout tile is used when the loop has not filled it for this step
+        if getattr(self, "act_frames_u8", None) is None or self.act_frames_u8.shape != (n, self.obs_dim):
+            self.act_frames_u8 = th.empty(n, self.obs_dim, dtype=th.uint8).pin_memory()
+            self.act_frames_u8_step = -1
+        u8_h = self.act_frames_u8
+        u8_d = th.empty(n, self.obs_dim, dtype=th.uint8, device=self.device)
+        stream_obj = th.cuda.current_stream()
+
+        def launch(t: int) -> None:
             with th.cuda.stream(stream_obj):
-                obs_d.copy_(obs_tile[t], non_blocking=True)
-                d = self._forward(self._rows_u8(obs_d))
+                if self.act_frames_u8_step == t:
+                    u8_d.copy_(u8_h, non_blocking=True)
+                    frames = u8_d.view(-1, *self.observation_space.shape)
+                else:
+                    obs_d.copy_(obs_tile[t], non_blocking=True)
+                    frames = self._rows_u8(obs_d)
+                d = self._forward(frames, values_out=val[t])
                 h_logits.copy_(d["logits"], non_blocking=True)
-                val[t].copy_(d["values"].reshape(n))
+
+        def finish(t: int) -> None:
             stream_obj.synchronize()
             from imitation_amd.policies import categorical_sample   # (local: policies imports this module)
             a, lp = categorical_sample(h_logits)
             h_logp[t].copy_(lp)
             h_clip[t].copy_(a.reshape(n, 1))
 
-        return step
+        return launch, finish
 
     _CHUNK = 512   # rows per forward when a whole tile is evaluated (bootstrap values, log pi of replay rows)
 

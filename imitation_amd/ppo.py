@@ -840,6 +840,15 @@ class PPO(OnPolicyAlgorithm):
         # in place already: pre-drawn tiles or host-side sampling.)
         post_ahead = self.rollout_post_ahead and (host_sampling or predrawn)
         posted = -1   # the last step posted to the mailbox
+        u8_t = getattr(pol, "act_frames_u8", None)   # (image policies: pinned uint8 staging row of the act step)
+        u8_np = None if u8_t is None else u8_t.numpy()
+        if u8_np is not None:
+            first = np.asarray(self._last_obs)
+            if first.dtype == np.uint8:
+                u8_np[...] = first.reshape(n, -1)
+                pol.act_frames_u8_step = 0
+            else:
+                u8_np, pol.act_frames_u8_step = None, -1
         for t in range(T):
             t0 = tick() if prof is not None else 0.0
             if not host_sampling and not predrawn:
@@ -878,8 +887,14 @@ class PPO(OnPolicyAlgorithm):
             old_obs = self._last_obs
             base.step_async(acts_np)
             new_obs, env_rews, dones, nxt, trunc, infos = step_arrays(base)
+            if u8_np is not None and new_obs.dtype == np.uint8:   # image policies take the next step's frames as they come
+                u8_np[...] = new_obs.reshape(n, -1)
+                pol.act_frames_u8_step = t + 1
+                if mailbox is not None and post_ahead and t + 1 < T:   # (posted ahead of the fp32 copy into the rollout tile)
+                    mailbox[0](t + 1)
+                    posted = t + 1
             h_obs_np[t + 1] = new_obs.reshape(n, -1)
-            if mailbox is not None and post_ahead and t + 1 < T:
+            if mailbox is not None and post_ahead and t + 1 < T and posted < t + 1:
                 mailbox[0](t + 1)
                 posted = t + 1
             if prof is not None:
