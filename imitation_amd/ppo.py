@@ -1055,7 +1055,9 @@ class PPO(OnPolicyAlgorithm):
                     auto=dict(k=0, events=[], ms={"sharded": [], "replicated": []}, chosen=None),
                     W=W, aw=aw, cols=cols, batch=bg,
                     send=th.empty(T, n, cols, device=dev),
-                    obs=th.empty(T, W * n, pol.obs_dim, device=dev), acts=th.empty(T, W * n, aw, device=dev),
+                    # (one slice more than the T the kernels index: `ia_ppo_update*` fetch observation rows as 16-byte
+                    #  pieces, the last piece of a row runs up to 12 bytes past it -- include/imitation_hip.h)
+                    obs=th.empty(T + 1, W * n, pol.obs_dim, device=dev)[:T], acts=th.empty(T, W * n, aw, device=dev),
                     logp=th.empty(T, W * n, device=dev), adv=th.empty(T, W * n, device=dev),
                     ret=th.empty(T, W * n, device=dev), perm_host=perm_host, perm_np=perm_host.numpy(),
                     perm_dev=th.zeros(self.n_epochs, W * T * n, dtype=th.int64, device=dev),

@@ -682,6 +682,9 @@ int ia_ppo_epochs(const ia_policy_desc* d, float* params, float* params_t, float
  * ia_ppo_update_ws_floats returns 0 when the shape is not covered (use ia_ppo_epoch per epoch);
  * ws must be zeroed once by the caller, word 8 of it is a sticky error flag (a bounded grid wait
  * timed out: results invalid). stats: [n_epochs*n_minibatches][8] or NULL.
+ * `obs` is read in 16-byte pieces, a row's last piece up to 12 bytes past the row when obs_dim % 4 != 0: the ALLOCATION behind
+ * `obs` must extend at least 12 bytes past row T*n_envs - 1 (SB3's rollout tile has T + 1 time slices -- the observation behind
+ * the last step -- and satisfies this by construction; a tile of exactly T slices at the end of a mapped region faults).
  * ia_ppo_update_xcd_pack(1) (several gradient workgroups that fit one XCD's 32 CUs) launches 8x the blocks so that the
  * working ones share one XCD; the gradient workgroups then check their placement against each other (XCC ids, one word
  * exchange per launch) and, when they do sit on one XCD, store the step's (value, sequence) words at workgroup scope --

@@ -527,7 +527,10 @@ def test_ppo_epochs_match_oracle(D, A, H, discrete, norm, T, n, bs, path):
     buf.log_probs[:] = (lp.numpy() + 0.1 * rng.standard_normal(T * n)).reshape(T, n)
     buf.full = True
     algo.rollout_buffer = buf
-    d_obs, d_act = dev(buf.observations), dev(buf.actions)
+    # (one time slice more than T behind the observations, as the rollout tile has: `ia_ppo_update*` read rows in 16-byte pieces,
+    #  up to 12 bytes past the last row -- include/imitation_hip.h; an exact-size tensor at the end of a mapped region faulted)
+    d_obs = dev(np.concatenate([buf.observations, np.zeros_like(buf.observations[:1])]))[:T]
+    d_act = dev(buf.actions)
     d_lp, d_adv, d_ret = dev(buf.log_probs), dev(buf.advantages), dev(buf.returns)
 
     np.random.seed(123)
