@@ -546,8 +546,45 @@ def run_variant(name, rounds=None, warm=None):
     cfg = {k: (list(x) if isinstance(x, tuple) else x) for k, x in v.items() if k not in ("rounds", "warm")}
     cfg["net"] = {k: (list(x) if isinstance(x, tuple) else x) for k, x in v["net"].items()}
     steps = tr.gen_algo.n_epochs * tr.gen_algo._n_mb
-    return {"env_steps_per_s": rounds * per / dt, "ms_per_round": 1e3 * dt / rounds, "rounds": rounds,
-            "env_steps_per_round": per, "ppo_optimizer_steps_per_round": steps, "finite": finite, "config": cfg}
+    out = {"env_steps_per_s": rounds * per / dt, "ms_per_round": 1e3 * dt / rounds, "rounds": rounds,
+           "env_steps_per_round": per, "ppo_optimizer_steps_per_round": steps, "finite": finite, "config": cfg}
+    out.update(_variant_disc_record(tr, v))
+    return out
+
+
+def _variant_disc_record(tr, v):
+    """The LAST timed round's discriminator updates by the events on their stream (`AdversarialTrainer._disc_timing`): us per
+    update inside the round and, for the two-hidden-layer stacks, the fp32-MFMA fraction of the update's flops -- BCE update
+    2 R (3 (D H1 + H1 H2 + H2) - D H1) over R = 2 x demo_batch rows (forward, weight gradient, input gradient but the first
+    layer's) plus, with the opt-in penalty, 2 B (4 D H1 + 4 H1 H2 + H2) over B = demo_batch interpolates (forward, input
+    gradient, the second pass through both layers and the two weight-gradient products); AIRL: the base stack on R rows and
+    the potential stack on 2 R (next state, state), the penalty likewise on B and 2 B."""
+    t = getattr(tr, "_disc_timing", None)
+    if t is None or t[0] is None:
+        return {}
+    try:
+        th.cuda.synchronize()
+        us = 1e3 * t[0].elapsed_time(t[1]) / tr.n_disc_updates_per_round
+    except Exception:
+        return {}
+    rec = {"disc_update_us_in_rounds": us, "disc_updates_schedule": "behind the PPO update" if t[2] else "beside the PPO update"}
+    hid = tuple(v["net"].get("hid_sizes", (32, 32)))
+    if len(hid) != 2:
+        return rec
+    H1, H2 = hid
+    B, gp = v["demo_batch"], v.get("grad_penalty", 0.0) > 0.0
+    R = 2 * B
+    upd = lambda rows, D: 2.0 * rows * (3 * (D * H1 + H1 * H2 + H2) - D * H1)
+    pen = lambda rows, D: 2.0 * rows * (4 * D * H1 + 4 * H1 * H2 + H2)
+    if v["algo"] == "gail":
+        D = v["obs"] + v["act"] + (v["obs"] if v["net"].get("use_next_state") else 0) + (1 if v["net"].get("use_done") else 0)
+        flop = upd(R, D) + (pen(B, D) if gp else 0.0)
+    else:   # AIRL's shaped net (defaults: base on [s | a | s'] ... as flagged; potential 32 x 32 on s', s)
+        Db = v["obs"] + v["act"]
+        flop = upd(R, Db) + upd(2 * R, v["obs"]) + ((pen(B, Db) + pen(2 * B, v["obs"])) if gp else 0.0)
+    rec["disc_update_flop"] = flop
+    rec["disc_update_frac_in_rounds"] = flop / (us * 1e-6) / 1e12 / PEAK_F32_MFMA_TFLOPS
+    return rec
 
 
 def _dp_form_text(algo):
@@ -744,6 +781,9 @@ def main():
             "speedup_vs_cpu": r3(value / base["value"]) if base else None,
             "variants_env_steps_per_s": ({k: r3(v.get("env_steps_per_s", v.get("samples_per_s"))) for k, v in variants.items()}
                                          if variants else None),
+            "variants_disc_update_us_frac_in_rounds": ({k: [r3(v.get("disc_update_us_in_rounds")), r3(v.get("disc_update_frac_in_rounds"))]
+                                                        for k, v in variants.items() if v.get("disc_update_us_in_rounds")}
+                                                       if variants else None),
             "variants_cpu_env_steps_per_s": ({k: r3(v["cpu_baseline"].get("value")) for k, v in variants.items()
                                               if isinstance(v.get("cpu_baseline"), dict)} if variants else None),
         }
