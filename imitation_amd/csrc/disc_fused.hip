@@ -750,8 +750,8 @@ constexpr int fb_region_floats() {
 template <int H, int BM, int DW>
 constexpr int fb_lds_floats() { return BM * (H + 1) + fb_region_floats<H, BM, DW>() + BM * xp3_of(DW); }
 
-template <int H, int BM, int DW = 24>
-__global__ __launch_bounds__(BM * 8) void disc_fb_kernel(FusedArgs a) {
+template <int H, int BM, int DW>
+__device__ __forceinline__ void disc_fb_body(const FusedArgs& a, const int bid) {
   constexpr int NT = BM * 8, NW = NT / 64;
   constexpr int XPW = xp_of(DW), XP3W = xp3_of(DW);   // row lengths of the W1 image / the x tile
   constexpr bool WIDE = DW != 24;
@@ -779,7 +779,7 @@ __global__ __launch_bounds__(BM * 8) void disc_fb_kernel(FusedArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, lh = lane >> 5;
   const int wm = wave >> 2, wn = wave & 3;
-  const int row0 = blockIdx.x * BM;
+  const int row0 = bid * BM;
   const int D = a.D;
   const float* W1 = a.params;
   const float* b1 = W1 + (long long)H * D;
@@ -987,8 +987,8 @@ __global__ __launch_bounds__(BM * 8) void disc_fb_kernel(FusedArgs a) {
     const float tot = reduce8_in_wave(vals, lane);
     const int k = lane >> 3;
     if ((lane & 7) == 0) {
-      if (k < 6) a.part[(long long)blockIdx.x * 8 + k] = tot;
-      else if (k == 6) a.P3[(long long)blockIdx.x * (2 * H + 1) + H] = tot;
+      if (k < 6) a.part[(long long)bid * 8 + k] = tot;
+      else if (k == 6) a.P3[(long long)bid * (2 * H + 1) + H] = tot;
     }
   }
   __syncthreads();
@@ -1020,8 +1020,8 @@ __global__ __launch_bounds__(BM * 8) void disc_fb_kernel(FusedArgs a) {
     float s = w3red[tid], sb = w3red[(BM / 32) * H + tid];
 #pragma unroll
     for (int g = 1; g < BM / 32; ++g) { s += w3red[g * H + tid]; sb += w3red[(BM / 32 + g) * H + tid]; }
-    a.P3[(long long)blockIdx.x * (2 * H + 1) + tid] = s;
-    a.P3[(long long)blockIdx.x * (2 * H + 1) + H + 1 + tid] = sb;
+    a.P3[(long long)bid * (2 * H + 1) + tid] = s;
+    a.P3[(long long)bid * (2 * H + 1) + H + 1 + tid] = sb;
   }
   FUSED_STAMP(a, 7);
 
@@ -1073,7 +1073,7 @@ __global__ __launch_bounds__(BM * 8) void disc_fb_kernel(FusedArgs a) {
   // ---- [dW1 | db1] partial [H, D + 1] = dh1^T . [xn | 1] over the tile's BM rows (see disc_bwd_kernel); WIDE: the
   //      D + 1 <= 64 columns as two 32-wide blocks
   const long long n1 = (long long)H * D + H;
-  float* P1 = a.P1 + (long long)blockIdx.x * n1;
+  float* P1 = a.P1 + (long long)bid * n1;
   for (int mt = wave; mt < H / 32; mt += NW) {
     float af[BM / 2];
 #pragma unroll
@@ -1104,6 +1104,9 @@ __global__ __launch_bounds__(BM * 8) void disc_fb_kernel(FusedArgs a) {
   FUSED_STAMP(a, 12);
 }
 
+template <int H, int BM, int DW = 24>
+__global__ __launch_bounds__(BM * 8) void disc_fb_kernel(FusedArgs a) { disc_fb_body<H, BM, DW>(a, blockIdx.x); }
+
 // ------------------------------------------------------------------------------------------- gradient penalty, one launch
 // The three penalty passes of a 32-row tile (disc_fwd_kernel<H,32,1>, disc_bwd_kernel<H,32,1>, disc_fwd_kernel<H,32,2>)
 // in ONE workgroup: what they hand from pass to pass -- relu'(h1), relu'(h2), u2, u1, the row coefficients C, v1 -- is
@@ -1127,8 +1130,8 @@ __global__ __launch_bounds__(BM * 8) void disc_fb_kernel(FusedArgs a) {
 // threads, two waves per SIMD, and still one workgroup per tile: B = 8 192 interpolates fill all 256 CUs, where G = 2 leaves
 // half of them idle (measured: 80 us per launch against 60-66 for G = 1). The input gradient's four K quarters and the row
 // norms stay with waves 0-3 (the same partial tiles, the same sums); every other phase divides by columns or by slab tiles.
-template <int H, int DW = 24, int G = 1, int NWC = 4>
-__global__ __launch_bounds__(64 * NWC * G) void disc_gp_kernel(FusedArgs a) {
+template <int H, int DW, int G, int NWC>
+__device__ __forceinline__ void disc_gp_body(const FusedArgs& a, const int bid) {
   constexpr int BM = 32, NW = 4, NTG = 64 * NWC, NT = NTG * G;   // NW: waves that share the input-gradient phase; NTG: threads of a row group
   static_assert(G == 1 || (G == 2 && DW == 24 && H == 256 && NWC == 4), "two row groups: the 256-wide narrow-row shape only");
   static_assert(NWC == 4 || (NWC == 8 && G == 1 && H == 256), "eight column groups: the 256-wide shapes only");
@@ -1163,7 +1166,7 @@ __global__ __launch_bounds__(64 * NWC * G) void disc_gp_kernel(FusedArgs a) {
   const int tg = tid & (NTG - 1);                // thread inside its group
   const int li = lane & 31, lh = lane >> 5;
   const int wn = wave;
-  const int tile = blockIdx.x * G + wg;          // the 32-row tile of this group
+  const int tile = bid * G + wg;          // the 32-row tile of this group
   const bool tile_ok = G == 1 || tile * BM < a.R;   // (an odd tile count leaves the last workgroup's second group idle)
   const int row0 = tile * BM;
   h1s += wg * BM * LDH;
@@ -1494,6 +1497,21 @@ __global__ __launch_bounds__(64 * NWC * G) void disc_gp_kernel(FusedArgs a) {
   __syncthreads();
   if (tg < H && tile_ok) a.P3[(long long)tile * (2 * H + 1) + tg] = w3red[tg];
   if (tg == 0 && tile_ok) a.P3[(long long)tile * (2 * H + 1) + H] = 0.f;
+}
+
+template <int H, int DW = 24, int G = 1, int NWC = 4>
+__global__ __launch_bounds__(64 * NWC * G) void disc_gp_kernel(FusedArgs a) { disc_gp_body<H, DW, G, NWC>(a, blockIdx.x); }
+
+// The update's tile pass AND the penalty's in ONE launch (256-wide stack, rows of up to 24 or up to 64 floats, 64-row update tiles,
+// the penalty's eight-column-wave form: both bodies are 512-thread workgroups of one tile). The penalty's pass reads the batch, the
+// statistics and the parameters -- nothing the update's pass writes. Each pass is about ONE wave of 256 workgroups on a chip
+// where the PPO kernel holds 19 compute units: as launches of their own each pays for a second, nearly empty wave (alone
+// 51 / 48 us, beside the PPO kernel 65 / 61); in one launch the stragglers of one fill the other's gaps. The penalty's
+// tiles take the first block ids. Same bodies, same operands: bit-identical per tile.
+template <int H, int DW>
+__global__ __launch_bounds__(512) void disc_fb_gp_kernel(FusedArgs fa, FusedArgs ga, int n_gp) {
+  if ((int)blockIdx.x < n_gp) disc_gp_body<H, DW, 1, 8>(ga, blockIdx.x);
+  else disc_fb_body<H, 64, DW>(fa, blockIdx.x - n_gp);
 }
 
 // ------------------------------------------------------------------------------------------- K1
@@ -1951,6 +1969,35 @@ int launch_fused_tiles(const FusedArgs& fa, int R, hipStream_t stream) {
   return IA_OK;
 }
 
+// the update's tile pass and the penalty's in one launch (`disc_fb_gp_kernel`): 256-wide stack, narrow rows, 64-row update
+// tiles, the penalty's eight-column-wave form. `false`: this configuration is not it (the caller launches them apart).
+bool g_fb_gp_merged = true;   // (ia_disc_fused_gp_merged: same-box A/Bs)
+inline bool fb_gp_merged_ok(int H, bool wide, int bm) {
+  return g_fb_gp_merged && H == 256 && bm == 64 && !g_fused_split && g_gp_groups == 8;
+}
+template <int DW>
+int launch_fb_gp_merged(const FusedArgs& fa, const FusedArgs& ga, int R, int B, hipStream_t stream) {
+  constexpr int H = 256, BMG = 32;
+  constexpr bool WIDE = DW == 64;
+  constexpr int XPW = xp_of(DW), XP3W = xp3_of(DW);
+  constexpr int SCR8 = WIDE ? (FB_K * H >= 2 * 32 * 64 ? 0 : 2 * 32 * 64) : ((H * 25 > 4 * 32 * 33) ? H * 25 : 4 * 32 * 33);
+  constexpr size_t smem_g8 = sizeof(float) * (BMG * (H + 1) + 3 * FB_K * H + H * XPW + SCR8 + H + BMG * XP3W);
+  constexpr size_t smem_fb = sizeof(float) * fb_lds_floats<H, 64, DW>();
+  constexpr size_t smem = smem_g8 > smem_fb ? smem_g8 : smem_fb;
+  static_assert(smem <= 160 * 1024, "one workgroup per CU");
+  static bool attr = false;
+  if (!attr) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(disc_fb_gp_kernel<H, DW>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (e != hipSuccess) return (int)e;
+    attr = true;
+  }
+  const int n_gp = cdivi(B, BMG), n_fb = cdivi(R, 64);
+  hipLaunchKernelGGL((disc_fb_gp_kernel<H, DW>), dim3(n_gp + n_fb), dim3(512), smem, stream, fa, ga, n_gp);
+  IA_CHECK_LAUNCH();
+  return IA_OK;
+}
+
 // rows of 25 .. 64 floats: the one-launch tile pass only (64-row tiles)
 template <int H>
 int launch_fused_tiles_wide(const FusedArgs& fa, int R, hipStream_t stream) {
@@ -1982,7 +2029,11 @@ int ia_disc32_predict(const ia_mlp_desc* d, const float* params, const float* X,
 extern "C" int ia_disc_fused_tile_rows(int rows) { g_fused_bm = rows == 32 ? 32 : 64; return IA_OK; }
 extern "C" int ia_disc_fused_split_tiles(int on) { g_fused_split = on != 0; return IA_OK; }
 extern "C" int ia_disc_fused_side_reduce(int on) { g_side_reduce = on != 0; return IA_OK; }
-extern "C" int ia_disc_fused_gp_groups(int groups) { g_gp_groups = (groups == 1 || groups == 2) ? groups : 8; return IA_OK; }
+extern "C" int ia_disc_fused_gp_groups(int groups) {
+  g_gp_groups = (groups == 1 || groups == 2) ? groups : 8;
+  g_fb_gp_merged = groups != 80;   // 80: eight column waves, but the penalty's pass as a launch of its own (A/Bs, tests)
+  return IA_OK;
+}
 extern "C" int ia_disc_fused_debug_timing(void* device_buffer_16xi64) {
   g_fused_dbg = static_cast<long long*>(device_buffer_16xi64);
   return IA_OK;
@@ -2181,7 +2232,10 @@ int ia_disc_step_fused(const ia_disc_step_args* a, void* stream_) {
   fa.logits = a->logits; fa.dlogits = a->dlogits; fa.n_expert = a->n_expert; fa.loss_scale = a->loss_scale;
   fa.part = w.part; fa.P1 = w.P1; fa.P3 = w.P3; fa.dump = w.dump;
   fa.dbg = g_fused_dbg;
-  if (wide) rc = H == 256 ? launch_fused_tiles_wide<256>(fa, R, stream) : launch_fused_tiles_wide<128>(fa, R, stream);
+  // (with the penalty, where both passes are one-tile 512-thread workgroups: ONE launch for the two of them, below)
+  const bool merged = a->gp_e != nullptr && fb_gp_merged_ok(H, wide, bm);
+  if (merged) rc = IA_OK;
+  else if (wide) rc = H == 256 ? launch_fused_tiles_wide<256>(fa, R, stream) : launch_fused_tiles_wide<128>(fa, R, stream);
   else if (bm == 64) rc = H == 256 ? launch_fused_tiles<256, 64>(fa, R, stream) : launch_fused_tiles<128, 64>(fa, R, stream);
   else rc = H == 256 ? launch_fused_tiles<256, 32>(fa, R, stream) : launch_fused_tiles<128, 32>(fa, R, stream);
   if (rc) return rc;
@@ -2208,7 +2262,7 @@ int ia_disc_step_fused(const ia_disc_step_args* a, void* stream_) {
   // What of the closing reduction does not depend on a split-K product rides in the LAST product's launch (the penalty's
   // tile passes read the parameters: not in the first one then).
   const bool side = g_side_reduce && H * (D + 1) % 64 == 0;
-  if (gp || !side) {
+  if ((gp || !side) && !merged) {
     if ((rc = ia_launch_gemm(IA_GEMM_TN, g_main, stream))) return rc;
   }
 
@@ -2226,8 +2280,14 @@ int ia_disc_step_fused(const ia_disc_step_args* a, void* stream_) {
     ga.R = B; ga.h1 = gw.v1; ga.dh2 = gw.u2; ga.h1mask = gw.m1; ga.h2mask = gw.m2; ga.P1 = gw.P1; ga.P3 = gw.P3;
     ga.gp_e = a->gp_e; ga.gp_C = gw.C; ga.gp_pen = gw.pen; ga.gp_coef = a->gp_coef; ga.gp_target = a->gp_target;
     ga.dbg = nullptr;
-    if (wide) rc = H == 256 ? launch_gp_tiles_wide<256>(ga, B, stream) : launch_gp_tiles_wide<128>(ga, B, stream);
-    else rc = H == 256 ? launch_gp_tiles<256>(ga, B, stream) : launch_gp_tiles<128>(ga, B, stream);
+    if (merged) {   // both tile passes, then the update's split-K product (which the first branch above left for here)
+      if ((rc = wide ? launch_fb_gp_merged<64>(fa, ga, R, B, stream) : launch_fb_gp_merged<24>(fa, ga, R, B, stream))) return rc;
+      rc = ia_launch_gemm(IA_GEMM_TN, g_main, stream);
+    } else if (wide) {
+      rc = H == 256 ? launch_gp_tiles_wide<256>(ga, B, stream) : launch_gp_tiles_wide<128>(ga, B, stream);
+    } else {
+      rc = H == 256 ? launch_gp_tiles<256>(ga, B, stream) : launch_gp_tiles<128>(ga, B, stream);
+    }
     if (rc) return rc;
     const int kps = (((B + gw.splits - 1) / gw.splits) + 31) / 32 * 32;
     IaGemm g{};

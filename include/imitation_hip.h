@@ -226,7 +226,9 @@ int ia_disc_fused_side_reduce(int on);
 /* Tuning / measurement: form of the one-launch gradient-penalty pass on the 256-wide stack with rows of up to 24 floats: 8
  * (default: one 32-row tile per 512-thread workgroup, its columns over eight waves -- two waves per SIMD, one workgroup per tile),
  * 2 (two tiles per 512-thread workgroup sharing the weight stream: half as many workgroups) or 1 (one tile, four waves: one
- * wave per SIMD, the form before round 5). Same values. */
+ * wave per SIMD, the form before round 5). Same values. With 8 the penalty's pass shares ONE launch with the update's own
+ * tile pass (64-row tiles: two independent one-tile 512-thread workgroup bodies, `disc_fb_gp_kernel`); 80 = the eight-wave
+ * form as a launch of its own. */
 int ia_disc_fused_gp_groups(int groups);
 /* Prediction on the fused tile kernel: out[r] = out_act(MLP(normalise(X[r, :D]))) for R assembled rows of a D -> H -> H -> 1
  * ReLU stack (D <= 24, H = 128 / 256; or the reference's default H = 32 with D <= 64: the row kernel, one launch) -- `RewardNet.predict_th` of a whole rollout tile (rewards/reward_nets.py:176-204),

@@ -327,14 +327,15 @@ def test_one_launch_tile_pass_is_bit_identical_to_forward_plus_backward_launches
 
 
 @pytest.mark.parametrize("hid,B,norm,form", [((256, 256), 1000, True, 8), ((128, 128), 200, True, 8), ((256, 256), 4096, False, 8),
-                                             ((256, 256), 1100, True, 8), ((256, 256), 1000, True, 1),
+                                             ((256, 256), 1100, True, 8), ((256, 256), 1100, True, 80), ((256, 256), 1000, True, 1),
                                              ((256, 256), 1100, True, 2),   # 35 tiles: the last two-tile workgroup is half idle
                                              ((256, 256), 4096, False, 2)])
 def test_one_launch_penalty_pass_is_bit_identical_to_its_three_launches(hid, B, norm, form):
     """`disc_gp_kernel` (the penalty's three tile passes in one workgroup: masks in registers, C in LDS) against
     `disc_fwd_kernel<.,32,1>` + `disc_bwd_kernel<.,32,1>` + `disc_fwd_kernel<.,32,2>` (`ia_disc_fused_split_tiles(1)`):
     gradient (BCE + penalty), the penalty's mean and the second pass's GEMM operands bit for bit. `form`: the 256-wide pass as
-    one tile per workgroup with eight column waves (8, default), two tiles per workgroup (2), or four waves (1):
+    one tile per workgroup with eight column waves (8, default -- since round 6 in ONE launch with the update's own tile pass,
+    `disc_fb_gp_kernel`; 80: the same form as a launch of its own), two tiles per workgroup (2), or four waves (1):
     `ia_disc_fused_gp_groups`."""
     od, ad = 17, 6
     osp = spaces.Box(-np.inf, np.inf, (od,), np.float32)
@@ -394,7 +395,7 @@ def test_wide_row_penalty_pass_forms_are_bit_identical(od, ad, B):
     outs = []
     lib = L.load()
     try:
-        for form in (8, 1):
+        for form in (8, 80, 1):
             lib.ia_disc_fused_gp_groups(form)
             th.manual_seed(3)
             net = reward_nets.BasicRewardNet(osp, asp, hid_sizes=(256, 256), normalize_input_layer=p.RunningNorm).to(DEV)
@@ -411,8 +412,9 @@ def test_wide_row_penalty_pass_forms_are_bit_identical(od, ad, B):
             outs.append((net.mlp.grad.clone(), ws["gp_out"].clone(), ws["gp_ws"][:n_act].clone(), stats.clone()))
     finally:
         lib.ia_disc_fused_gp_groups(8)
-    for name, x, y in zip(("gradient", "penalty", "v1 | u2", "statistics"), *outs):
-        assert th.equal(x, y), name
+    for other in outs[1:]:   # (8: in one launch with the update's tile pass; 80: the same form apart; 1: four waves)
+        for name, x, y in zip(("gradient", "penalty", "v1 | u2", "statistics"), outs[0], other):
+            assert th.equal(x, y), name
     assert float(outs[0][1]) > 1e-3
 
 
