@@ -270,6 +270,8 @@ class ActorCriticCnnPolicy:
         L.call("ia_gemm_f32", mode, L.ptr(A), lda, L.ptr(Bm), ldb, L.ptr(Cm), ldc, M, N, K, L.ptr(bias), act,
                L.ptr(P), ldp, splits, L.ptr(dbias), L.stream())
 
+    takes_uint8_frames = True   # (`PPO`: the rollout tile's host rows and their transfer are uint8 for this policy)
+
     def _obs_u8(self, obs) -> th.Tensor:
         t = obs if isinstance(obs, th.Tensor) else th.as_tensor(np.ascontiguousarray(obs))
         if t.dtype != th.uint8:
@@ -456,14 +458,16 @@ class ActorCriticCnnPolicy:
         assert not self.discrete
         n, A = obs_tile.shape[1], self.act_dim
         dev = self.device
-        obs_d, noise_d, clip_d = th.empty(n, self.obs_dim, device=dev), th.empty(n, A, device=dev), th.empty(n, A, device=dev)
+        u8_tile = obs_tile.dtype == th.uint8   # (`RolloutBuffer(obs_u8=True)`: the frames as the environment hands them over)
+        obs_d = th.empty(n, self.obs_dim, dtype=obs_tile.dtype, device=dev)
+        noise_d, clip_d = th.empty(n, A, device=dev), th.empty(n, A, device=dev)
         stream_obj = th.cuda.current_stream()
 
         def step(t: int) -> None:
             with th.cuda.stream(stream_obj):
                 obs_d.copy_(obs_tile[t], non_blocking=True)
                 noise_d.copy_((noise_host[t] if noise_host.dim() == 3 else noise_host).reshape(n, A), non_blocking=True)
-                d = self._forward(self._rows_u8(obs_d))
+                d = self._forward(obs_d.view(-1, *self.observation_space.shape) if u8_tile else self._rows_u8(obs_d))
                 L.call("ia_gauss_act", L.ptr(d["logits"]), L.ptr(self._flat), L.ptr(noise_d), L.ptr(self._low),
                        L.ptr(self._high), n, A, L.ptr(acts[t]), L.ptr(clip_d), L.ptr(logp[t]), L.stream())
                 val[t].copy_(d["values"].reshape(n))
@@ -502,25 +506,17 @@ class ActorCriticCnnPolicy:
 
     def _multinomial_launch_finish(self, obs_tile, h_logits, h_clip, val, h_logp):
         n = obs_tile.shape[1]
-        obs_d = th.empty(n, self.obs_dim, device=self.device)
-        # the step's frames as the environment hands them over (uint8): a pinned staging row the rollout loop fills
-        # (`PPO._rollout_steps`: `act_frames_u8` / `act_frames_u8_step`) -- a quarter of the fp32 row's bytes over PCIe and no
-        # conversion launch; the fp32 row of the rollout tile is used when the loop has not filled it for this step
-        if getattr(self, "act_frames_u8", None) is None or self.act_frames_u8.shape != (n, self.obs_dim):
-            self.act_frames_u8 = th.empty(n, self.obs_dim, dtype=th.uint8).pin_memory()
-            self.act_frames_u8_step = -1
-        u8_h = self.act_frames_u8
-        u8_d = th.empty(n, self.obs_dim, dtype=th.uint8, device=self.device)
+        # the rollout tile's pinned rows are uint8 for image observations (`RolloutBuffer(obs_u8=True)`: the frames as the
+        # environment hands them over -- a quarter of an fp32 row's bytes over PCIe and no conversion launch); an fp32 tile
+        # (a caller's own) is converted on the device as before
+        u8_tile = obs_tile.dtype == th.uint8
+        obs_d = th.empty(n, self.obs_dim, dtype=obs_tile.dtype, device=self.device)
         stream_obj = th.cuda.current_stream()
 
         def launch(t: int) -> None:
             with th.cuda.stream(stream_obj):
-                if self.act_frames_u8_step == t:
-                    u8_d.copy_(u8_h, non_blocking=True)
-                    frames = u8_d.view(-1, *self.observation_space.shape)
-                else:
-                    obs_d.copy_(obs_tile[t], non_blocking=True)
-                    frames = self._rows_u8(obs_d)
+                obs_d.copy_(obs_tile[t], non_blocking=True)
+                frames = obs_d.view(-1, *self.observation_space.shape) if u8_tile else self._rows_u8(obs_d)
                 d = self._forward(frames, values_out=val[t])
                 h_logits.copy_(d["logits"], non_blocking=True)
 

@@ -346,27 +346,36 @@ class RolloutBuffer:
     staging the env loop writes into. Properties named like SB3's `RolloutBuffer` fields return
     host copies in SB3's layout (post-`get()`: env-major flattened; `rewards`: `[T, n]`)."""
 
-    def __init__(self, T: int, n: int, obs_dim: int, act_width: int, device):
+    def __init__(self, T: int, n: int, obs_dim: int, act_width: int, device, obs_u8: bool = False):
+        """`obs_u8` (image observations, uint8 frames): the pinned tiles the env loop writes (`h_obs`, `h_next`) and their twins
+        in the transfer block are uint8 -- the frames as the environment hands them over --; the fp32 device tiles every consumer
+        reads (`obs`, `next_fixed`: relabelling, replay rows, PPO's row gathers) are filled from them by two conversion kernels
+        behind the one copy. At 64 envs x 16 steps of 4 x 84 x 84 frames: 60 MB over PCIe instead of 240 MB, and no uint8 ->
+        fp32 pass over 3.6 M elements per env step on the host (`profiles/r06_image_gail.md`)."""
         self.buffer_size, self.n_envs, self.obs_dim, self.act_width = T, n, obs_dim, act_width
+        self.obs_u8 = bool(obs_u8)
         f = lambda *s: th.zeros(*s, device=device)
         # Everything the env loop produces on the host goes to the device in ONE copy after the last step:
         # the host-written tiles are views into one pinned block, their device twins views into one device
         # block with the same layout (seven separate copies cost ~10 us of copy-engine latency each, on the
         # critical path between the last env step and the PPO update).
-        spec = [("obs", (T + 1, n, obs_dim), th.float32), ("clipped", (T, n, act_width), th.float32),
-                ("next_fixed", (T, n, obs_dim), th.float32), ("starts", (T, n), th.float32),
+        frame_dt = th.uint8 if self.obs_u8 else th.float32
+        spec = [("_obs_x" if self.obs_u8 else "obs", (T + 1, n, obs_dim), frame_dt), ("clipped", (T, n, act_width), th.float32),
+                ("_next_x" if self.obs_u8 else "next_fixed", (T, n, obs_dim), frame_dt), ("starts", (T, n), th.float32),
                 ("last_done", (n,), th.float32), ("dones", (T, n), th.uint8), ("trunc", (T, n), th.uint8)]
         nbytes = sum(-(-int(np.prod(shape)) * th.empty(0, dtype=dt).element_size() // 256) * 256 for _, shape, dt in spec)
         self._dev_block = th.zeros(nbytes, dtype=th.uint8, device=device)
         self._host_block = th.zeros(nbytes, dtype=th.uint8).pin_memory()
         off = 0
         host_names = dict(obs="h_obs", clipped="h_clip", next_fixed="h_next", starts="h_starts",
-                          last_done="h_last_done", dones="h_dones", trunc="h_trunc")
+                          last_done="h_last_done", dones="h_dones", trunc="h_trunc", _obs_x="h_obs", _next_x="h_next")
         for name, shape, dt in spec:
             size = int(np.prod(shape)) * th.empty(0, dtype=dt).element_size()
             setattr(self, name, self._dev_block[off:off + size].view(dt).view(*shape))
             setattr(self, host_names[name], self._host_block[off:off + size].view(dt).view(*shape))
             off += -(-size // 256) * 256
+        if self.obs_u8:   # (one slice more than T: `ia_ppo_update*`'s 16-byte row pieces, include/imitation_hip.h)
+            self.obs, self.next_fixed = f(T + 1, n, obs_dim), f(T, n, obs_dim)
         self.acts = f(T, n, act_width)
         self.rew, self.val, self.logp, self.adv, self.ret = (f(T, n) for _ in range(5))
         self.term_val, self.last_val = f(T, n), f(n)
@@ -384,8 +393,11 @@ class RolloutBuffer:
             self.h_logp = th.zeros(self.buffer_size, self.n_envs).pin_memory()
 
     def upload_host_tiles(self) -> None:
-        """One H2D copy of everything the env loop wrote on the host (current stream)."""
+        """One H2D copy of everything the env loop wrote on the host (current stream); uint8 frames -> the fp32 tiles."""
         self._dev_block.copy_(self._host_block, non_blocking=True)
+        if self.obs_u8:
+            self.obs.copy_(self._obs_x)
+            self.next_fixed.copy_(self._next_x)
 
     def reset(self) -> None:
         self.full = False
@@ -467,8 +479,10 @@ class PPO(OnPolicyAlgorithm):
         if self.device.type != "cuda":
             return
         p = self.policy
+        osp_ = self.observation_space   # image observations (uint8 frames, an image policy): uint8 transport tiles
+        frames_u8 = (getattr(p, "takes_uint8_frames", False) and getattr(osp_, "dtype", None) == np.uint8)
         self.rollout_buffer = RolloutBuffer(self.n_steps, self.n_envs, p.obs_dim, 1 if p.discrete else p.act_dim,
-                                            self.device)
+                                            self.device, obs_u8=frames_u8)
         total = self.n_steps * self.n_envs
         self._n_mb = -(-total // self.batch_size)
         # policies outside the fused kernels' shapes (`general_policy.GeneralTowers`) run their own minibatch loop
@@ -840,15 +854,6 @@ class PPO(OnPolicyAlgorithm):
         # in place already: pre-drawn tiles or host-side sampling.)
         post_ahead = self.rollout_post_ahead and (host_sampling or predrawn)
         posted = -1   # the last step posted to the mailbox
-        u8_t = getattr(pol, "act_frames_u8", None)   # (image policies: pinned uint8 staging row of the act step)
-        u8_np = None if u8_t is None else u8_t.numpy()
-        if u8_np is not None:
-            first = np.asarray(self._last_obs)
-            if first.dtype == np.uint8:
-                u8_np[...] = first.reshape(n, -1)
-                pol.act_frames_u8_step = 0
-            else:
-                u8_np, pol.act_frames_u8_step = None, -1
         for t in range(T):
             t0 = tick() if prof is not None else 0.0
             if not host_sampling and not predrawn:
@@ -887,14 +892,8 @@ class PPO(OnPolicyAlgorithm):
             old_obs = self._last_obs
             base.step_async(acts_np)
             new_obs, env_rews, dones, nxt, trunc, infos = step_arrays(base)
-            if u8_np is not None and new_obs.dtype == np.uint8:   # image policies take the next step's frames as they come
-                u8_np[...] = new_obs.reshape(n, -1)
-                pol.act_frames_u8_step = t + 1
-                if mailbox is not None and post_ahead and t + 1 < T:   # (posted ahead of the fp32 copy into the rollout tile)
-                    mailbox[0](t + 1)
-                    posted = t + 1
             h_obs_np[t + 1] = new_obs.reshape(n, -1)
-            if mailbox is not None and post_ahead and t + 1 < T and posted < t + 1:
+            if mailbox is not None and post_ahead and t + 1 < T:
                 mailbox[0](t + 1)
                 posted = t + 1
             if prof is not None:
