@@ -1258,12 +1258,15 @@ class AdversarialTrainer(abc.ABC):
             # hysteresis: switching costs nothing, but do not flap around the break-even point
             fits = self._disc_ms_behind < (0.95 if self._disc_mode_behind else 0.8) * window
             if not fits and self._disc_mode_behind:
-                self._disc_probe_at = calls + 32
+                # (the probing gap doubles every time a probe ends on "beside" again -- 32, 64, ... 1 024 rounds: a probing round
+                #  costs config P ~0.5 ms, and its answer there does not change)
+                self._disc_probe_gap = min(1024, 2 * getattr(self, "_disc_probe_gap", 16))
+                self._disc_probe_at = calls + self._disc_probe_gap
             self._disc_mode_behind = fits
         if not self._disc_mode_behind and calls >= getattr(self, "_disc_probe_at", 1 << 62):
-            # every 32 rounds of "beside": one round "behind", to measure the updates alone again (both schedules compute the
+            # after a while of "beside": one round "behind", to measure the updates alone again (both schedules compute the
             # same values: `test_pipelined_rounds_are_bit_identical`)
-            self._disc_probe_at = calls + 32
+            self._disc_probe_at = 1 << 62
             self._disc_ms_behind = None
             self._disc_mode_behind = True
         return self._disc_mode_behind

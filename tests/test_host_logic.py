@@ -747,3 +747,35 @@ def test_stale_armed_rows_are_never_handed_over():
     np.random.rand()
     assert not pre.finish(out) and pre._rr_armed is None
     assert pre.take_randint(50, 2, 9) is None
+
+
+def test_update_schedule_chooser_ignores_cold_rounds_and_probes_with_backoff():
+    """`AdversarialTrainer._choose_disc_behind_ppo`: the updates' device time is only measured in "behind" rounds, so a
+    measurement taken during a trainer's first rounds (code objects loaded at first launch) must not park the schedule on
+    "beside" for good (it did: the image variant ran 63-68 ms per round instead of 56-58) -- the first three calls are
+    ignored, and "beside" goes back to one "behind" round after 32, 64, ... 1 024 rounds to measure again."""
+    from imitation_amd.adversarial.common import AdversarialTrainer
+
+    class Ev:
+        def __init__(self, ms): self.ms = ms
+        def query(self): return True
+        def elapsed_time(self, other): return other.ms
+
+    class Fake:
+        _needs_logp, disc_behind_ppo = False, None
+        _disc_ms_behind, _disc_mode_behind = None, True
+
+    f = Fake()
+    f.gen_algo = type("A", (), {"rollout_window_ms": 10.0})()
+    choose = lambda ms: (setattr(f, "_disc_timing", (Ev(0.0), Ev(ms), f._disc_mode_behind)),
+                         AdversarialTrainer._choose_disc_behind_ppo(f))[1]
+    assert [choose(500.0) for _ in range(3)] == [True, True, True]        # cold rounds: 500 ms of "updates" are not believed
+    assert choose(4.0) is True and f._disc_ms_behind == 4.0                  # warm: fits the 10 ms window
+    assert choose(9.9) is False                                              # does not fit any more -> "beside"
+    seen = [choose(9.9) for _ in range(200)]                                 # ("beside" rounds measure nothing)
+    probes = [i for i, b in enumerate(seen) if b]
+    assert probes[:2] == [31, 96] and all(not seen[i + 1] for i in probes[:2])   # a probe after 32 rounds, the next 64 rounds behind its verdict
+    f.gen_algo.rollout_window_ms = 100.0                                     # the window grows: the next probe stays "behind"
+    nxt = [choose(9.9) for _ in range(200)]
+    first = nxt.index(True)
+    assert all(nxt[first:])
