@@ -93,3 +93,27 @@ def test_conv3x3_c4_forward_and_gradient_match_float64_autograd(B, H, W):
     tol = 2e-5 * max(1.0, np.sqrt(B * H * W / 64.0))
     assert float((wr.grad.double().cpu() - w64.grad.permute(0, 2, 3, 1)).abs().max()) <= tol * (float(w64.grad.abs().max()) + 1e-12)
     assert float((br.grad.double().cpu() - b64.grad).abs().max()) <= tol * (float(b64.grad.abs().max()) + 1e-12)
+
+
+def test_rollout_tiles_carry_image_frames_as_uint8_and_fill_the_fp32_tiles():
+    """`RolloutBuffer(obs_u8=True)`: the pinned tiles the env loop writes and their twins in the transfer block are uint8, the
+    fp32 device tiles every consumer reads are filled behind the one copy -- the same values as the fp32 transport, exactly."""
+    from imitation_amd.ppo import RolloutBuffer
+    T, n, D = 3, 5, 4 * 6 * 6
+    rng = np.random.default_rng(0)
+    frames = rng.integers(0, 256, (T + 1, n, D), dtype=np.uint8)
+    nxt = rng.integers(0, 256, (T, n, D), dtype=np.uint8)
+    outs = []
+    for u8 in (True, False):
+        rb = RolloutBuffer(T, n, D, 1, th.device("cuda"), obs_u8=u8)
+        assert rb.h_obs.dtype == (th.uint8 if u8 else th.float32) and rb.obs.dtype == th.float32
+        assert rb.obs.shape == (T + 1, n, D) and rb.next_fixed.shape == (T, n, D)
+        rb.h_obs.numpy()[...] = frames
+        rb.h_next.numpy()[...] = nxt
+        rb.h_dones.numpy()[...] = 1
+        rb.upload_host_tiles()
+        th.cuda.synchronize()
+        outs.append((rb.obs.clone(), rb.next_fixed.clone(), rb.dones.clone()))
+    for a, b in zip(*outs):
+        assert th.equal(a, b)
+    assert th.equal(outs[0][0].cpu(), th.as_tensor(frames).float())
