@@ -118,6 +118,7 @@ _SIGS = {
     "ia_conv3x3_c32_wgrad": ([_P, _P, _I, _I, _I, _P, _P, _P], C.c_int),
     "ia_avgpool_relu_backward": ([_P, _P, _I, _I, _I, _P, _P], C.c_int),
     "ia_conv3x3_c4_forward": ([_P, _P, _P, _I, _I, _I, _I, _P, _P], C.c_int),
+    "ia_conv3x3_c32_conv": ([_P, _P, _P, _P, _I, _I, _I, _I, _P, _P], C.c_int),
     "ia_conv3x3_c4_wgrad": ([_P, _P, _I, _I, _I, _P, _P, _P], C.c_int),
     "ia_categorical_loss": ([_P, _I, _P, _I, _I, _F, _F, _P, _P, _P, _P], C.c_int),
     "ia_gemm_f32_im2col": ([_I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _P, _I, _I, _P, _I, _I, _I, _I, _I, _I, _P], C.c_int),

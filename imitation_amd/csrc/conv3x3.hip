@@ -167,6 +167,89 @@ __global__ __launch_bounds__(C3_THREADS) void conv3x3_c32_wgrad_kernel(const flo
   }
 }
 
+// ---- conv3x3_c32_conv_kernel: y = act(bias + W * x) [* (mask > 0)] for 32 -> 32 channels, the forward of the reward CNN's second
+// convolution AND -- with the flipped / transposed weights Wd[ci][ky][kx][co] = W[co][2 - ky][2 - kx][ci] -- its input gradient (then
+// `mask` = the layer below's ReLU output: its backward in the epilogue). The implicit GEMM of gemm.hip ran these 133 GFLOP calls at
+// 66-71 TFLOP/s (128 x 32 tiles, K = 288 in nine 32-deep chunks, the operand gathered chunk by chunk).
+// A workgroup takes a BAND of 8 output rows of one image: 8 x W positions (672 = 21 tiles of 32 at W = 84), their 10 input rows in LDS
+// with a zero pixel at either end and a pixel stride of 33 floats (B[k = (tap, ci)][n = position]: lanes walk positions -> 33 n + ci:
+// conflict-free), the weights as [k][co] (A[m = co][k]: lanes walk co: conflict-free); per tile 144 MFMAs 32x32x2 whose A / B
+// fragments are one ds_read_b32 each; bias, activation and mask on the accumulators, 16-byte stores.
+constexpr int CV_BAND = 8, CV_PS = 33;
+constexpr int CV_THREADS = 512;
+
+__global__ __launch_bounds__(CV_THREADS) void conv3x3_c32_conv_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                                      const float* __restrict__ bias, const float* __restrict__ mask,
+                                                                      int H, int W, int bands, int relu, float* __restrict__ y) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int px = W + 2;
+  float* ws = lds;                           // [288][32]: ws[k * 32 + co] = w[co][k]
+  float* xs = lds + 9 * C3_C * C3_C;         // [(BAND + 2) rows][px][33]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n = lane & 31, kk = lane >> 5;
+  const int b = blockIdx.x / bands, band = blockIdx.x - b * bands;
+  const int oy0 = band * CV_BAND, rows = min(CV_BAND, H - oy0);
+  // weights: global [co][288] -> LDS [k][co] (coalesced reads along k, conflict-light scatter)
+  for (int e = tid; e < C3_C * 9 * C3_C; e += CV_THREADS) {
+    const int co = e / (9 * C3_C), k = e - co * 9 * C3_C;
+    ws[k * C3_C + co] = w[e];
+  }
+  // input rows oy0 - 1 .. oy0 + rows (zeros outside the image), pixels -1 .. W, 16-byte loads, pixel stride 33 in LDS
+  const float* xb = x + (long long)b * H * W * C3_C;
+  const int n4 = (rows + 2) * px * (C3_C / 4);
+  for (int e = tid; e < n4; e += CV_THREADS) {
+    const int q = e & 7, pp = e >> 3;
+    const int r = pp / px, p = pp - r * px;
+    const int iy = oy0 - 1 + r, ix = p - 1;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (iy >= 0 && iy < H && ix >= 0 && ix < W) v = *reinterpret_cast<const f32x4*>(xb + ((long long)iy * W + ix) * C3_C + 4 * q);
+    float* d = xs + (r * px + p) * CV_PS + 4 * q;
+    d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3];
+  }
+  __syncthreads();
+  float bv[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) bv[j] = bias ? bias[8 * (j >> 2) + 4 * kk + (j & 3)] : 0.f;
+  const int npos = rows * W;
+  const long long out0 = ((long long)b * H + oy0) * W;
+  for (int t0 = wave * 32; t0 < npos; t0 += (CV_THREADS / 64) * 32) {
+    const int p = min(t0 + n, npos - 1);
+    const int r = p / W, ox = p - r * W;
+    const float* bbase = xs + (r * px + ox) * CV_PS + kk;   // element (tap, ci = 2 j' + kk)
+    const float* abase = ws + kk * C3_C + n;
+    f32x16 acc;   // (the bias joins in the epilogue, as in the GEMM this replaces: the same sums in the same order, bit for bit --
+                  //  pre-activations within an ulp of zero keep their sign, and with it the ReLU mask of the backward pass)
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[j] = 0.f;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const float* bt = bbase + ((tap / 3) * px + (tap % 3)) * CV_PS;
+      const float* at = abase + tap * C3_C * C3_C;
+#pragma unroll
+      for (int c2 = 0; c2 < C3_C / 2; ++c2)   // k-step: channels 2 c2 + kk of this tap
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(at[2 * c2 * C3_C], bt[2 * c2], acc, 0, 0, 0);
+    }
+    if (t0 + n < npos) {
+      const long long o = (out0 + p) * C3_C + 4 * kk;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        f32x4 v;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const float pre = acc[4 * q + u] + bv[4 * q + u];
+          v[u] = relu ? fmaxf(pre, 0.f) : pre;
+        }
+        if (mask != nullptr) {
+          const f32x4 mq = *reinterpret_cast<const f32x4*>(mask + o + 8 * q);
+#pragma unroll
+          for (int u = 0; u < 4; ++u) v[u] = mq[u] > 0.f ? v[u] : 0.f;
+        }
+        *reinterpret_cast<f32x4*>(y + o + 8 * q) = v;
+      }
+    }
+  }
+}
+
 // ---- the reward CNN's FIRST convolution: 4 input channels (the frame stack), 32 output channels, 3 x 3 "same" -----------------------
 // K = 36 is no 32-deep chunk of a kernel row, so the general path materialised the im2col matrix (1 024 x 7 056 x 36 floats = 1 GB
 // written, read by the forward GEMM and read again by the weight gradient: 2.8 ms of an update's 11). Both products straight from
@@ -223,9 +306,9 @@ __global__ __launch_bounds__(C4_THREADS) void conv3x3_c4_fwd_kernel(const float*
     float bq[C4_K / 2];
 #pragma unroll
     for (int j = 0; j < C4_K / 2; ++j) bq[j] = base[boff[j]];
-    f32x16 acc;
+    f32x16 acc;   // (bias in the epilogue: the sums of the GEMM this replaces, bit for bit)
 #pragma unroll
-    for (int j = 0; j < 16; ++j) acc[j] = bv[j];
+    for (int j = 0; j < 16; ++j) acc[j] = 0.f;
 #pragma unroll
     for (int j = 0; j < C4_K / 2; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[j], bq[j], acc, 0, 0, 0);
     if (t0 + n < npos) {
@@ -234,7 +317,10 @@ __global__ __launch_bounds__(C4_THREADS) void conv3x3_c4_fwd_kernel(const float*
       for (int q = 0; q < 4; ++q) {
         f32x4 v;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) v[u] = relu ? fmaxf(acc[4 * q + u], 0.f) : acc[4 * q + u];
+        for (int u = 0; u < 4; ++u) {
+          const float pre = acc[4 * q + u] + bv[4 * q + u];
+          v[u] = relu ? fmaxf(pre, 0.f) : pre;
+        }
         *reinterpret_cast<f32x4*>(o + 8 * q) = v;
       }
     }
@@ -399,6 +485,28 @@ int ia_conv3x3_c32_wgrad(const float* dz, const float* x, int B, int H, int W, f
   }
   hipLaunchKernelGGL(conv3x3_c32_wgrad_kernel, dim3(ia_conv3x3_c32_wgrad_slabs(B)), dim3(C3_THREADS), bytes, (hipStream_t)stream,
                      dz, x, B, H, W, part, dbp);
+  IA_CHECK_LAUNCH();
+  return IA_OK;
+}
+
+/* y[B, H, W, 32] = act(bias + conv3x3(x[B, H, W, 32], w[32][3][3][32])) on channel-last tensors, stride 1, "same" padding; `bias`
+ * nullable; `relu` != 0: ReLU; `mask` (nullable, laid out like y): outputs zeroed where mask <= 0. With the flipped / transposed
+ * weights this is the convolution's input gradient (mask: the ReLU output below). -2 for W > 126. */
+int ia_conv3x3_c32_conv(const float* x, const float* w, const float* bias, const float* mask, int B, int H, int W, int relu, float* y,
+                        void* stream) {
+  if (!x || !w || !y || B <= 0 || H <= 0 || W <= 0) return IA_ERR_ARG;
+  const size_t bytes = ((size_t)9 * C3_C * C3_C + (size_t)(CV_BAND + 2) * (W + 2) * CV_PS) * sizeof(float);
+  if (bytes > 160 * 1024) return IA_ERR_UNSUPPORTED;
+  static size_t attr_bytes = 0;
+  if (bytes > attr_bytes) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_c32_conv_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)bytes) != hipSuccess)
+      return IA_ERR_ARG;
+    attr_bytes = bytes;
+  }
+  const int bands = (H + CV_BAND - 1) / CV_BAND;
+  hipLaunchKernelGGL(conv3x3_c32_conv_kernel, dim3((unsigned)((long long)B * bands)), dim3(CV_THREADS), bytes, (hipStream_t)stream, x, w,
+                     bias, mask, H, W, bands, relu, y);
   IA_CHECK_LAUNCH();
   return IA_OK;
 }

@@ -169,6 +169,12 @@ def conv_is_direct_c4(cin: int, cout: int, kh: int, kw: int, stride: int, pad: i
     return cin == 4 and cout == 32 and kh == kw == 3 and stride == 1 and pad == 1 and w_in <= 128
 
 
+def conv_is_direct_c32(cin: int, cout: int, kh: int, kw: int, stride: int, pad: int, w_in: int) -> bool:
+    """The reward CNN's second convolution (`csrc/conv3x3.hip`, `conv3x3_c32_conv_kernel`): 3 x 3 "same", 32 -> 32 channels, image
+    rows that fit the kernel's LDS band (10 rows of W + 2 pixels at 33 floats + the weights in 160 KB)."""
+    return cin == 32 and cout == 32 and kh == kw == 3 and stride == 1 and pad == 1 and (9 * 1024 + 10 * (w_in + 2) * 33) * 4 <= 160 * 1024
+
+
 @th.library.custom_op("imitation_amd::conv2d_nhwc_forward", mutates_args=(), device_types="cuda")
 def conv2d_nhwc_forward(x: Tensor, w: Tensor, b: Tensor, stride: int, pad: int, relu: bool) -> Tuple[Tensor, Tensor]:
     """Convolution of channel-last activations `x[B, H, W, Cin]` with `w[Cout, KH, KW, Cin]`, bias `b[Cout]`, zero
@@ -182,6 +188,9 @@ def conv2d_nhwc_forward(x: Tensor, w: Tensor, b: Tensor, stride: int, pad: int, 
     y = th.empty(B, OH, OW, Cout, device=x.device)
     if conv_is_direct_c4(Cin, Cout, KH, KW, stride, pad, W):
         L.call("ia_conv3x3_c4_forward", L.ptr(x), L.ptr(w), L.ptr(b), B, H, W, int(relu), L.ptr(y), L.stream())
+        return y, th.empty(0, K, device=x.device)
+    if conv_is_direct_c32(Cin, Cout, KH, KW, stride, pad, W):
+        L.call("ia_conv3x3_c32_conv", L.ptr(x), L.ptr(w), L.ptr(b), None, B, H, W, int(relu), L.ptr(y), L.stream())
         return y, th.empty(0, K, device=x.device)
     if conv_is_implicit(Cin, KW, B * H * W * Cin):
         # the GEMM reads its operand through the padded im2col view of `x`: no column buffer (`col` comes back empty;
@@ -201,7 +210,8 @@ def _(x, w, b, stride, pad, relu):
     B, H, W, Cin = x.shape
     Cout, KH, KW, _ = w.shape
     OH, OW = (H + 2 * pad - KH) // stride + 1, (W + 2 * pad - KW) // stride + 1
-    rows = 0 if (conv_is_implicit(Cin, KW, B * H * W * Cin) or conv_is_direct_c4(Cin, Cout, KH, KW, stride, pad, W)) else B * OH * OW
+    rows = 0 if (conv_is_implicit(Cin, KW, B * H * W * Cin) or conv_is_direct_c4(Cin, Cout, KH, KW, stride, pad, W)
+                 or conv_is_direct_c32(Cin, Cout, KH, KW, stride, pad, W)) else B * OH * OW
     return x.new_empty(B, OH, OW, Cout), x.new_empty(rows, KH * KW * Cin)
 
 
@@ -261,7 +271,12 @@ def _conv_backward_tail(dz, w, part, dbp, splits, B, in_h, in_w, OH, OW, Cin, Co
     L.call("ia_reduce_partials", L.ptr(part), splits, Cout * K, 1.0, 0, L.ptr(dw), L.stream())
     L.call("ia_reduce_partials", L.ptr(dbp), splits, Cout, 1.0, 0, L.ptr(db), L.stream())
     dx = th.zeros(B, in_h, in_w, Cin, device=dy.device) if not need_dx else th.empty(B, in_h, in_w, Cin, device=dy.device)
-    if need_dx and stride == 1 and KH - 1 - pad >= 0 and KH == KW and conv_is_implicit(Cout, KW, dz.numel()):
+    if need_dx and (OH, OW) == (in_h, in_w) and conv_is_direct_c32(Cout, Cin, KH, KW, stride, pad, in_w):
+        # the same geometry read backwards: the convolution of `dz` with the flipped / transposed kernel, the layer below's ReLU
+        # mask in the epilogue (`conv3x3_c32_conv_kernel`)
+        wd = w.flip(1, 2).permute(3, 1, 2, 0).contiguous()
+        L.call("ia_conv3x3_c32_conv", L.ptr(dz), L.ptr(wd), None, L.ptr(mask), B, in_h, in_w, 0, L.ptr(dx), L.stream())
+    elif need_dx and stride == 1 and KH - 1 - pad >= 0 and KH == KW and conv_is_implicit(Cout, KW, dz.numel()):
         # d loss / d input of a stride-1 convolution = the padded (KH - 1 - pad) stride-1 convolution of `dz` with the
         # flipped / transposed kernel Wd[c, i, j, co] = W[co, KH-1-i, KW-1-j, c]: again an implicit GEMM over the im2col VIEW
         # of dz -- no [M, KH*KW*Cin] column-gradient buffer (8.3 GB per call at 1 024 frames of 84 x 84 x 32) and no col2im

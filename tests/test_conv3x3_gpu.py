@@ -117,3 +117,31 @@ def test_rollout_tiles_carry_image_frames_as_uint8_and_fill_the_fp32_tiles():
     for a, b in zip(*outs):
         assert th.equal(a, b)
     assert th.equal(outs[0][0].cpu(), th.as_tensor(frames).float())
+
+
+@pytest.mark.parametrize("B,H,W", [(1, 1, 1), (2, 5, 7), (3, 9, 16), (2, 17, 31), (2, 84, 84), (5, 8, 90)])
+def test_conv3x3_c32_forward_and_input_gradient_match_float64_autograd(B, H, W):
+    """The 32 -> 32 layer's forward and input gradient on `conv3x3_c32_conv_kernel` (bands of 8 output rows, partial last band,
+    odd widths), through a two-layer chain of the public op so that the ReLU mask in the input gradient's epilogue is used."""
+    g = th.Generator().manual_seed(11 * B + H + W)
+    x = th.randn(B, H, W, 32, generator=g).cuda()
+    w1 = (0.1 * th.randn(32, 3, 3, 32, generator=g)).cuda()
+    w2 = (0.1 * th.randn(32, 3, 3, 32, generator=g)).cuda()
+    b1, b2 = (0.1 * th.randn(32, generator=g)).cuda(), (0.1 * th.randn(32, generator=g)).cuda()
+    xr = x.clone().requires_grad_(True)
+    w1r, w2r = w1.clone().requires_grad_(True), w2.clone().requires_grad_(True)
+    h = ops.conv2d_nhwc(xr, w1r, b1, 1, 1, relu=True, dy_is_masked=True)
+    y = ops.conv2d_nhwc(h, w2r, b2, 1, 1, relu=True, x_is_relu=True)
+    coef = th.randn(B, H, W, 32, generator=g).cuda()
+    (y * coef).sum().backward()
+    x64 = x.double().cpu().permute(0, 3, 1, 2).requires_grad_(True)
+    w164 = w1.double().cpu().permute(0, 3, 1, 2).contiguous().requires_grad_(True)
+    w264 = w2.double().cpu().permute(0, 3, 1, 2).contiguous().requires_grad_(True)
+    h64 = th.relu(th.nn.functional.conv2d(x64, w164, b1.double().cpu(), padding=1))
+    y64 = th.relu(th.nn.functional.conv2d(h64, w264, b2.double().cpu(), padding=1))
+    (y64 * coef.double().cpu().permute(0, 3, 1, 2)).sum().backward()
+    assert th.allclose(y.double().cpu(), y64.detach().permute(0, 2, 3, 1), rtol=2e-5, atol=2e-5)
+    tol = 3e-5 * max(1.0, np.sqrt(B * H * W / 64.0))
+    for got, want in ((xr.grad, x64.grad), (w1r.grad, w164.grad), (w2r.grad, w264.grad)):
+        want = want.permute(0, 2, 3, 1)
+        assert float((got.double().cpu() - want).abs().max()) <= tol * (float(want.abs().max()) + 1e-12)
