@@ -183,28 +183,49 @@ __global__ __launch_bounds__(CV_THREADS) void conv3x3_c32_conv_kernel(const floa
                                                                       int H, int W, int bands, int relu, float* __restrict__ y) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int px = W + 2;
-  float* ws = lds;                           // [288][32]: ws[k * 32 + co] = w[co][k]
+  float* ws = lds;                           // [288][32]: ws[k * 32 + co]
   float* xs = lds + 9 * C3_C * C3_C;         // [(BAND + 2) rows][px][33]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n = lane & 31, kk = lane >> 5;
   const int b = blockIdx.x / bands, band = blockIdx.x - b * bands;
   const int oy0 = band * CV_BAND, rows = min(CV_BAND, H - oy0);
-  // weights: global [co][288] -> LDS [k][co] (coalesced reads along k, conflict-light scatter)
-  for (int e = tid; e < C3_C * 9 * C3_C; e += CV_THREADS) {
-    const int co = e / (9 * C3_C), k = e - co * 9 * C3_C;
-    ws[k * C3_C + co] = w[e];
+  // weights: `w` arrives as [k = (tap, ci)][co] (the caller transposes the 36 KB once per call): 16-byte copies, all of a thread's
+  // loads in flight before its stores (element by element the prologue -- one workgroup per CU, nothing to hide it behind -- was a
+  // third of the kernel: 32 serial round trips to L2 per thread and 64-way conflicted LDS scatters)
+  {
+    constexpr int NWQ = (9 * C3_C * C3_C / 4 + CV_THREADS - 1) / CV_THREADS;   // 5
+    f32x4 wv[NWQ];
+#pragma unroll
+    for (int i = 0; i < NWQ; ++i) wv[i] = reinterpret_cast<const f32x4*>(w)[min(tid + i * CV_THREADS, 9 * C3_C * C3_C / 4 - 1)];
+#pragma unroll
+    for (int i = 0; i < NWQ; ++i)
+      if (tid + i * CV_THREADS < 9 * C3_C * C3_C / 4) reinterpret_cast<f32x4*>(ws)[tid + i * CV_THREADS] = wv[i];
   }
-  // input rows oy0 - 1 .. oy0 + rows (zeros outside the image), pixels -1 .. W, 16-byte loads, pixel stride 33 in LDS
+  // input rows oy0 - 1 .. oy0 + rows (zeros outside the image), pixels -1 .. W, 16-byte loads (seven in flight per thread and
+  // pass), pixel stride 33 in LDS
   const float* xb = x + (long long)b * H * W * C3_C;
   const int n4 = (rows + 2) * px * (C3_C / 4);
-  for (int e = tid; e < n4; e += CV_THREADS) {
-    const int q = e & 7, pp = e >> 3;
-    const int r = pp / px, p = pp - r * px;
-    const int iy = oy0 - 1 + r, ix = p - 1;
-    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    if (iy >= 0 && iy < H && ix >= 0 && ix < W) v = *reinterpret_cast<const f32x4*>(xb + ((long long)iy * W + ix) * C3_C + 4 * q);
-    float* d = xs + (r * px + p) * CV_PS + 4 * q;
-    d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3];
+  constexpr int NB = 7;
+  for (int e0 = 0; e0 < n4; e0 += NB * CV_THREADS) {
+    f32x4 v[NB];
+    int dst[NB];
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      const int e = e0 + tid + i * CV_THREADS;
+      const int q = e & 7, pp = e >> 3;
+      const int r = pp / px, p = pp - r * px;
+      const int iy = oy0 - 1 + r, ix = p - 1;
+      const bool in = e < n4 && iy >= 0 && iy < H && ix >= 0 && ix < W;
+      dst[i] = e < n4 ? (r * px + p) * CV_PS + 4 * q : -1;
+      v[i] = *reinterpret_cast<const f32x4*>(xb + ((long long)min(max(iy, 0), H - 1) * W + min(max(ix, 0), W - 1)) * C3_C + 4 * q);
+      if (!in) v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i)
+      if (dst[i] >= 0) {
+        float* d = xs + dst[i];
+        d[0] = v[i][0]; d[1] = v[i][1]; d[2] = v[i][2]; d[3] = v[i][3];
+      }
   }
   __syncthreads();
   float bv[16];
@@ -489,9 +510,10 @@ int ia_conv3x3_c32_wgrad(const float* dz, const float* x, int B, int H, int W, f
   return IA_OK;
 }
 
-/* y[B, H, W, 32] = act(bias + conv3x3(x[B, H, W, 32], w[32][3][3][32])) on channel-last tensors, stride 1, "same" padding; `bias`
- * nullable; `relu` != 0: ReLU; `mask` (nullable, laid out like y): outputs zeroed where mask <= 0. With the flipped / transposed
- * weights this is the convolution's input gradient (mask: the ReLU output below). -2 for W > 126. */
+/* y[B, H, W, 32] = act(bias + conv3x3(x[B, H, W, 32], w)) on channel-last tensors, stride 1, "same" padding. `wt`: the weights
+ * TRANSPOSED, [ky][kx][ci][co] (= torch's [co][ky][kx][ci] with co moved last); `bias` nullable; `relu` != 0: ReLU; `mask` (nullable,
+ * laid out like y): outputs zeroed where mask <= 0. With wt[ky][kx][co][ci] = W[co][2 - ky][2 - kx][ci] on dz this is the convolution's
+ * input gradient (mask: the ReLU output below). -2 when a band of rows does not fit 160 KB of LDS (W > 94). */
 int ia_conv3x3_c32_conv(const float* x, const float* w, const float* bias, const float* mask, int B, int H, int W, int relu, float* y,
                         void* stream) {
   if (!x || !w || !y || B <= 0 || H <= 0 || W <= 0) return IA_ERR_ARG;

@@ -190,7 +190,8 @@ def conv2d_nhwc_forward(x: Tensor, w: Tensor, b: Tensor, stride: int, pad: int, 
         L.call("ia_conv3x3_c4_forward", L.ptr(x), L.ptr(w), L.ptr(b), B, H, W, int(relu), L.ptr(y), L.stream())
         return y, th.empty(0, K, device=x.device)
     if conv_is_direct_c32(Cin, Cout, KH, KW, stride, pad, W):
-        L.call("ia_conv3x3_c32_conv", L.ptr(x), L.ptr(w), L.ptr(b), None, B, H, W, int(relu), L.ptr(y), L.stream())
+        wt = w.permute(1, 2, 3, 0).contiguous()   # [ky][kx][ci][co]: the kernel's LDS image, 36 KB
+        L.call("ia_conv3x3_c32_conv", L.ptr(x), L.ptr(wt), L.ptr(b), None, B, H, W, int(relu), L.ptr(y), L.stream())
         return y, th.empty(0, K, device=x.device)
     if conv_is_implicit(Cin, KW, B * H * W * Cin):
         # the GEMM reads its operand through the padded im2col view of `x`: no column buffer (`col` comes back empty;
@@ -274,7 +275,7 @@ def _conv_backward_tail(dz, w, part, dbp, splits, B, in_h, in_w, OH, OW, Cin, Co
     if need_dx and (OH, OW) == (in_h, in_w) and conv_is_direct_c32(Cout, Cin, KH, KW, stride, pad, in_w):
         # the same geometry read backwards: the convolution of `dz` with the flipped / transposed kernel, the layer below's ReLU
         # mask in the epilogue (`conv3x3_c32_conv_kernel`)
-        wd = w.flip(1, 2).permute(3, 1, 2, 0).contiguous()
+        wd = w.flip(1, 2).permute(1, 2, 0, 3).contiguous()   # [ky][kx][co][ci] of the flipped kernel: contraction index first
         L.call("ia_conv3x3_c32_conv", L.ptr(dz), L.ptr(wd), None, L.ptr(mask), B, in_h, in_w, 0, L.ptr(dx), L.stream())
     elif need_dx and stride == 1 and KH - 1 - pad >= 0 and KH == KW and conv_is_implicit(Cout, KW, dz.numel()):
         # d loss / d input of a stride-1 convolution = the padded (KH - 1 - pad) stride-1 convolution of `dz` with the

@@ -581,13 +581,13 @@ int ia_avgpool_nhwc_backward(const float* dout, int B, int HW, int C, float* dy,
  * once. -2 (IA_ERR_UNSUPPORTED) for W > 128. */
 int ia_conv3x3_c32_wgrad_slabs(int B);
 int ia_conv3x3_c32_wgrad(const float* dz, const float* x, int B, int H, int W, float* part, float* dbp, void* stream);
-/* Forward of that 32 -> 32 layer, y[B, H, W, 32] = act(bias + conv3x3(x, w[32][3][3][32])) (`bias` nullable; relu != 0: ReLU; `mask`
- * nullable, laid out like y: outputs zeroed where mask <= 0) -- and, called with the flipped / transposed weights
- * Wd[ci][ky][kx][co] = W[co][2 - ky][2 - kx][ci] on dz, its input gradient (mask: the ReLU output of the layer below). A workgroup
+/* Forward of that 32 -> 32 layer, y[B, H, W, 32] = act(bias + conv3x3(x, w)) with the weights handed over TRANSPOSED,
+ * wt[ky][kx][ci][co] (`bias` nullable; relu != 0: ReLU; `mask` nullable, laid out like y: outputs zeroed where mask <= 0) -- and,
+ * called with wt[ky][kx][co][ci] = W[co][2 - ky][2 - kx][ci] on dz, its input gradient (mask: the ReLU output of the layer below). A workgroup
  * takes 8 output rows of one image with their 10 input rows and the weights in LDS. -2 when a row band does not fit 160 KB of LDS
  * (W > 94). */
-int ia_conv3x3_c32_conv(const float* x, const float* w, const float* bias, const float* mask, int B, int H, int W, int relu, float* y,
-                        void* stream);
+int ia_conv3x3_c32_conv(const float* x, const float* wt, const float* bias, const float* mask, int B, int H, int W, int relu,
+                        float* y, void* stream);
 /* The same net's FIRST convolution (4 input channels: the frame stack; w[32][3][3][4]): forward y[B, H, W, 32] = act(b + W x)
  * (relu != 0: ReLU) and weight / bias gradient (slabs part[slabs][32][36], dbp[slabs][32], slabs as above) straight from the
  * 4-channel rows -- no [B H W, 36] column matrix. -2 for W > 128. */
