@@ -530,7 +530,7 @@ def variant_cpu_baseline(name, host_threads):
 
 def run_variant(name, rounds=None, warm=None):
     if name == "image_gail_64x16_cnn":
-        return run_image_variant()
+        return run_image_variant(rounds or 3, warm or 2)
     if name == "5_bc_cnn_4096":
         return run_bc_variant()
     v = VARIANTS[name]

@@ -3499,23 +3499,24 @@ __global__ __launch_bounds__(256) void ppo_epoch_ll_kernel(
 // rows). One wave per SIMD: the matrix pipe and the VALU are the wave's own. The tower's parameters are read from LDS
 // images: W1 / W2 in torch layout with padded rows (a forward fragment = the four consecutive INPUTS of an output row: one
 // ds_read_b128), W2 transposed likewise for the backward pass, the head in both orientations.
-template <int KT1>
+template <int KT1, int RB = 64>
 struct T64Geo {   // LDS carve-up (floats; every offset a multiple of 4) of one tower workgroup: compile-time but for the
-                  // staging area's pieces, whose sizes follow the observation / action widths
-  static constexpr int RS = 68;    // row stride of the [feature][row] tiles and of the 64-wide weight images
+                  // staging area's pieces, whose sizes follow the observation / action widths. RB = rows of the block
+  static constexpr int RS = 68;    // row stride of the 64-wide weight images
+  static constexpr int TS = RB + 4;   // row stride of the [feature][row] tiles (68 at 64 rows: the images' stride)
   static constexpr int HT = 20;    // row stride of the transposed head image [64 hidden][16 actions + 4]
   static constexpr int DP = 16 * KT1 + 4;   // first-layer image row: a whole number of K tiles + one quad -- an odd number of
                                             // quads (eight lanes' b128 reads hit 32 banks); columns >= D stay zero
   // tiles
   static constexpr int x = 0;
-  static constexpr int a1 = x + 16 * KT1 * RS;
-  static constexpr int a2 = a1 + 64 * RS;
-  static constexpr int dz2 = a2 + 64 * RS;
-  static constexpr int dz1 = dz2 + 64 * RS;
-  static constexpr int dout = dz1 + 64 * RS;
-  static constexpr int aux = dout + 16 * RS;
-  static constexpr int misc = aux + 16 * RS;
-  static constexpr int scratch = misc + 8 * RS;
+  static constexpr int a1 = x + 16 * KT1 * TS;
+  static constexpr int a2 = a1 + 64 * TS;
+  static constexpr int dz2 = a2 + 64 * TS;
+  static constexpr int dz1 = dz2 + 64 * TS;
+  static constexpr int dout = dz1 + 64 * TS;
+  static constexpr int aux = dout + 16 * TS;
+  static constexpr int misc = aux + 16 * TS;
+  static constexpr int scratch = misc + 8 * TS;
   // images
   static constexpr int W1 = scratch + 64;
   static constexpr int W2 = W1 + 64 * DP;
@@ -3531,11 +3532,11 @@ struct T64Geo {   // LDS carve-up (floats; every offset a multiple of 4) of one 
   static constexpr int soldlp = ring + 2 * MAXD + 8;   // old log-prob | advantage | return: three consecutive 64-float areas
   static constexpr int sadv = soldlp + 64;
   static constexpr int sret = sadv + 64;
-  static constexpr int sx = sret + 64;                 // [64][D] raw rows, packed
-  int sact, total;                                     // [64][aw]
+  static constexpr int sx = sret + 64;                 // [RB][D] raw rows, packed
+  int sact, total;                                     // [RB][aw]
   __host__ __device__ T64Geo(int D, int aw) {
-    sact = sx + ((64 * D + 3) & ~3);
-    total = sact + ((64 * aw + 3) & ~3);
+    sact = sx + ((RB * D + 3) & ~3);
+    total = sact + ((RB * aw + 3) & ~3);
   }
 };
 struct T64Out {   // word index (inside the workgroup's slab) of each piece of the tower's gradient; the loss-statistic tail
@@ -3991,6 +3992,572 @@ __device__ __forceinline__ void t64_tower_minibatch(
 }
 
 // ---------------------------------------------------------------------------------------------
+// Round 6: the same chain on EIGHT waves per tower -- two per SIMD. Wave w = (q, h) = (w & 3, w >> 2) owns rows 16 q .. of the
+// block like wave q above, but only the output tiles 2 h, 2 h + 1 of every layer (features 32 h .. 32 h + 31): half the MFMAs
+// and half the tanh / store work per wave, the SIMD's second wave issuing under the first one's latencies. The k index of a
+// layer runs over all 64 features of the layer below: a wave's own half is in its registers, its partner's half comes from the
+// `[feature][row]` tile the partner writes anyway (one workgroup barrier per layer; the next layer's weight fragments are
+// requested ahead of it). Head and per-row losses (16 MFMAs, no weights to split) are computed by both waves of a pair. Every
+// tile is accumulated by the same MFMAs in the same order as in the four-wave form: the gradients are bit-identical.
+// Weight-gradient tiles: dW2's four input tiles go two per wave; h = 0 takes dW1's first tile and its bias, h = 1 dW1's second
+// tile (observation widths > 16), the second layer's bias, the head's tile and the small column sums.
+template <int KT1, int RB, int NW, class Mid>
+__device__ __forceinline__ void t64h_tower_minibatch(
+    const ia_policy_desc& d, const T64Geo<KT1, RB>& G, const T64Out& Lc, const int tw, float* __restrict__ lds_in, const int row0,
+    const int b, const float adv_mean, const float adv_std, const int normalize_adv, const float clip, const float ent_coef,
+    const float vf_coef, unsigned long long* __restrict__ slab, const unsigned seq, Mid&& mid,
+    long long* __restrict__ ts /* measurement (nullable): shader clocks of the phases, thread 0 */, const int oz) {
+  constexpr int RS = T64Geo<KT1, RB>::RS, TS = T64Geo<KT1, RB>::TS;   // strides of the weight images / of the row tiles
+  constexpr int NQ = RB / 16, SQ = RB / 16;                           // row groups of the block = waves per feature half
+  static_assert(NW == 2 * NQ, "two waves (feature halves) per group of 16 rows");
+#define T64C_TS(slot) do { if (ts != nullptr && threadIdx.x == 0) ts[slot] = clock64(); } while (0)
+  T64C_TS(0);
+  float* __restrict__ lds = lds_in + oz;
+  const int tid = threadIdx.x + oz, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int q = w % NQ, h = w / NQ;
+  const bool hi = h != 0;
+  const int li = lane & 15, lk = lane >> 4;
+  const int D = d.obs_dim, A = d.act_dim;
+  const int aw = d.discrete ? 1 : A;
+  const float invB = 1.f / (float)b;
+  auto rd4 = [&](const float* p) { return *reinterpret_cast<const f32x4*>(p); };
+  auto put = [&](int idx, float v) { ll_store_agent(slab + idx, v, seq); };
+  auto sel4 = [&](const f32x4& own, const f32x4& other, bool own_first) {
+    f32x4 o;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) o[r] = own_first ? own[r] : other[r];
+    return o;
+  };
+  const int lrow = q * 16 + li;
+  const bool valid = row0 + lrow < b;
+  const int T0 = 32 * h;               // first feature of the wave's tiles
+  const int P0 = 32 - T0;              // ... of its partner's
+  float* const colp = lds + q * 16 + li;   // column (row of the minibatch) of the lane in every [feature][row] tile
+  // per-row scalars of the loss (staged by the prefetch)
+  float r_oldlp = 0.f, r_adv = 0.f, r_ret = 0.f, r_act[4] = {0.f, 0.f, 0.f, 0.f};
+  if (tw == 0) {
+    r_oldlp = lds[G.soldlp + lrow];
+    r_adv = lds[G.sadv + lrow];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) r_act[j] = lds[G.sact + lrow * aw + min(4 * lk + j, aw - 1)];
+  } else {
+    r_ret = lds[G.sret + lrow];
+  }
+  // the partner's half of a [feature][row] tile (features P0 + 16 j + 4 lk + r of the lane's row), and the four k tiles of a
+  // layer in feature order from the two halves
+  auto partner = [&](int tile, f32x4 (&o)[2]) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) o[j][r] = colp[tile + (P0 + 16 * j + 4 * lk + r) * TS];
+  };
+  auto whole = [&](const f32x4 (&own)[2], const f32x4 (&oth)[2], f32x4 (&o)[4]) {
+    o[0] = sel4(own[0], oth[0], !hi);
+    o[1] = sel4(own[1], oth[1], !hi);
+    o[2] = sel4(own[0], oth[0], hi);
+    o[3] = sel4(own[1], oth[1], hi);
+  };
+  // ---- layer 1: tiles 2 h, 2 h + 1 of a1^T = tanh(W1 x^T + b1)
+  f32x4 a1o[2], a2o[2], a1[4], a2[4];
+  f32x4 fW2[4][2], b2c[2];
+  {
+    f32x4 fW1[KT1][2], b1c[2];
+    float xb[KT1][4];
+#pragma unroll
+    for (int kt = 0; kt < KT1; ++kt)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) fW1[kt][j] = rd4(lds + G.W1 + (T0 + 16 * j + li) * G.DP + 16 * kt + 4 * lk);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) b1c[j] = rd4(lds + G.b1 + T0 + 16 * j + 4 * lk);
+#pragma unroll
+    for (int kt = 0; kt < KT1; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) xb[kt][r] = colp[G.x + (16 * kt + 4 * lk + r) * TS];
+    __builtin_amdgcn_sched_barrier(0);
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      acc[j][0] = b1c[j];
+      acc[j][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    auto l1_tile = [&](const int j) {
+#pragma unroll
+      for (int kt = 0; kt < KT1; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[j][(kt * 4 + r) & 1] = mfma16(fW1[kt][j][r], xb[kt][r], acc[j][(kt * 4 + r) & 1]);
+    };
+    auto l1_tanh = [&](const int j) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        a1o[j][r] = fast_tanh(acc[j][0][r] + acc[j][1][r]);
+        colp[G.a1 + (T0 + 16 * j + 4 * lk + r) * TS] = a1o[j][r];
+      }
+    };
+    l1_tile(0);
+    l1_tile(1);
+    // (the second layer's fragments of the wave's output rows: in flight under the tanh and the barrier)
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) fW2[kt][j] = rd4(lds + G.W2 + (T0 + 16 * j + li) * RS + 16 * kt + 4 * lk);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) b2c[j] = rd4(lds + G.b2 + T0 + 16 * j + 4 * lk);
+    l1_tanh(0);
+    l1_tanh(1);
+  }
+  __syncthreads();
+  T64C_TS(1);
+  {
+    f32x4 a1p[2];
+    partner(G.a1, a1p);
+    whole(a1o, a1p, a1);
+  }
+  // ---- layer 2: tiles 2 h, 2 h + 1 of a2^T = tanh(W2 a1^T + b2)
+  f32x4 fHead[4], hbias;
+  {
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      acc[j][0] = b2c[j];
+      acc[j][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    auto l2_tile = [&](const int j) {
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[j][r & 1] = mfma16(fW2[kt][j][r], a1[kt][r], acc[j][r & 1]);
+    };
+    auto l2_tanh = [&](const int j) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        a2o[j][r] = fast_tanh(acc[j][0][r] + acc[j][1][r]);
+        colp[G.a2 + (T0 + 16 * j + 4 * lk + r) * TS] = a2o[j][r];
+      }
+    };
+    l2_tile(0);
+    l2_tile(1);
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) fHead[kt] = rd4(lds + G.HW + li * RS + 16 * kt + 4 * lk);
+    hbias = rd4(lds + G.hb + 4 * lk);
+    l2_tanh(0);
+    l2_tanh(1);
+  }
+  __syncthreads();
+  T64C_TS(2);
+  {
+    f32x4 a2p[2];
+    partner(G.a2, a2p);
+    whole(a2o, a2p, a2);
+  }
+  // ---- head (both waves of a pair): hout[r] = output 4 lk + r of row li (value: lane group 0, register 0)
+  float hout[4];
+  {
+    f32x4 acc[2] = {hbias, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[r & 1] = mfma16(fHead[kt][r], a2[kt][r], acc[r & 1]);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) hout[r] = acc[0][r] + acc[1][r];
+  }
+  T64C_TS(3);
+  // backward fragments of the wave's tiles: the head's weights of the lane's outputs T0 + 16 j + 4 lk + r; W2 transposed
+  f32x4 fHeadT[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+    fHeadT[j] = tw == 0 ? rd4(lds + G.HWT + (T0 + 16 * j + li) * T64Geo<KT1, RB>::HT + 4 * lk) : rd4(lds + G.HW + T0 + 16 * j + 4 * lk);
+  f32x4 fW2T[4][2];
+#pragma unroll
+  for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) fW2T[kt][j] = rd4(lds + G.W2T + (T0 + 16 * j + li) * RS + 16 * kt + 4 * lk);
+  // ---- per-row losses (the expressions of `t64_tower_minibatch`; the pair's first wave leaves the rows' pieces in LDS)
+  auto xchg16 = [](float v, float& a, float& bq) {
+    const auto p2 = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    a = __uint_as_float(p2[0]);
+    bq = __uint_as_float(p2[1]);
+  };
+  auto xchg32 = [](float v, float& a, float& bq) {
+    const auto p2 = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    a = __uint_as_float(p2[0]);
+    bq = __uint_as_float(p2[1]);
+  };
+  auto group_sum = [&](float v) {
+    float a, bq;
+    xchg16(v, a, bq);
+    v = a + bq;
+    xchg32(v, a, bq);
+    return a + bq;
+  };
+  auto group_max = [&](float v) {
+    float a, bq;
+    xchg16(v, a, bq);
+    v = fmaxf(a, bq);
+    xchg32(v, a, bq);
+    return fmaxf(a, bq);
+  };
+  float dout[4] = {0.f, 0.f, 0.f, 0.f}, dvb = 0.f;
+  if (tw == 0) {
+    const f32x4 c_ivar = rd4(lds + G.ls + 16 + 4 * lk), c_logsd = rd4(lds + G.ls + 32 + 4 * lk);
+    float logp = 0.f, entropy = 0.f, lse = 0.f;
+    int act_i = 0;
+    if (d.discrete) act_i = (int)r_act[0];
+    if (!d.discrete) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (4 * lk + j < A) {
+          const float diff = r_act[j] - hout[j];
+          logp += -(diff * diff) * (0.5f * c_ivar[j]) - c_logsd[j] - LOG_SQRT_2PI;
+          entropy += 0.5f + LOG_SQRT_2PI + c_logsd[j];
+        }
+      logp = group_sum(logp);
+      entropy = group_sum(entropy);
+    } else {
+      float mx = -3.0e38f, o_act = 0.f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (4 * lk + j < A) {
+          mx = fmaxf(mx, hout[j]);
+          o_act += (4 * lk + j == act_i) ? hout[j] : 0.f;
+        }
+      mx = group_max(mx);
+      o_act = group_sum(o_act);
+      float se = 0.f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (4 * lk + j < A) se += expf(hout[j] - mx);
+      lse = mx + logf(group_sum(se));
+      logp = o_act - lse;
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (4 * lk + j < A) {
+          const float l = hout[j] - lse;
+          entropy -= expf(l) * l;
+        }
+      entropy = group_sum(entropy);
+    }
+    float advn = r_adv;
+    if (normalize_adv && b > 1) advn = (advn - adv_mean) / (adv_std + 1e-8f);
+    const float log_ratio = logp - r_oldlp;
+    const float ratio = expf(log_ratio);
+    const float lo = 1.f - clip, hi_ = 1.f + clip;
+    const float pl1 = advn * ratio;
+    const float pl2 = advn * fminf(fmaxf(ratio, lo), hi_);
+    const float g1 = pl1 < pl2 ? 1.f : (pl1 == pl2 ? 0.5f : 0.f);
+    const float g2 = pl2 < pl1 ? 1.f : (pl1 == pl2 ? 0.5f : 0.f);
+    const float inrange = (ratio >= lo && ratio <= hi_) ? 1.f : 0.f;
+    const float dlogp = valid ? -invB * advn * (g1 + g2 * inrange) * ratio : 0.f;
+    float* doutrow = lds + G.dout + lrow;   // (column a of this lane's row: [a * RS])
+    float* auxrow = lds + G.aux + lrow;
+    if (!d.discrete) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (4 * lk + j < A) {
+          const float diff = r_act[j] - hout[j];
+          dout[j] = dlogp * diff * c_ivar[j];
+          if (!hi) {
+            doutrow[(4 * lk + j) * TS] = dout[j];
+            auxrow[(4 * lk + j) * TS] = valid ? dlogp * (diff * diff * c_ivar[j] - 1.f) - ent_coef * invB : 0.f;
+          }
+        }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (4 * lk + j < A) {
+          const float l = hout[j] - lse, p = expf(l);
+          const float dH = -p * (l + entropy);
+          float g = dlogp * ((4 * lk + j == act_i ? 1.f : 0.f) - p);
+          g += valid ? -ent_coef * invB * dH : 0.f;
+          dout[j] = g;
+          if (!hi) doutrow[(4 * lk + j) * TS] = g;
+        }
+    }
+    if (lk == 0 && !hi) {
+      float* mrow = lds + G.misc + lrow;
+      mrow[2 * TS] = valid ? -fminf(pl1, pl2) : 0.f;                           // policy_gradient_loss
+      mrow[3 * TS] = valid ? -entropy : 0.f;                                    // entropy_loss
+      mrow[4 * TS] = valid ? (ratio - 1.f) - log_ratio : 0.f;                   // approx_kl
+      mrow[5 * TS] = valid ? (fabsf(ratio - 1.f) > clip ? 1.f : 0.f) : 0.f;     // clip_fraction
+    }
+  } else {
+    const float v = __shfl(hout[0], li, 64);   // (lane group 0, register 0 holds V(row li))
+    const float verr = r_ret - v;
+    dvb = valid ? vf_coef * 2.f * (v - r_ret) * invB : 0.f;
+    if (lk == 0 && !hi) {
+      lds[G.misc + 1 * TS + lrow] = dvb;
+      lds[G.misc + 6 * TS + lrow] = valid ? verr * verr : 0.f;        // value_loss
+    }
+  }
+  T64C_TS(4);
+  // ---- tiles 2 h, 2 h + 1 of dz2^T = (W_head^T d head^T) * (1 - a2^2), then of dz1^T = (W2^T dz2^T) * (1 - a1^2)
+  f32x4 dz2o[2];
+  if (tw == 0) {
+    f32x4 acc[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int r = 0; r < 4; ++r)   // (k-step r carries actions r, 4 + r, 8 + r, 12 + r; the image's columns >= A are zero)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) acc[j] = mfma16(fHeadT[j][r], dout[r], acc[j]);
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) dz2o[j][r] = acc[j][r] * (1.f - a2o[j][r] * a2o[j][r]);
+  } else {
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) dz2o[j][r] = fHeadT[j][r] * dvb * (1.f - a2o[j][r] * a2o[j][r]);
+  }
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) colp[G.dz2 + (T0 + 16 * j + 4 * lk + r) * TS] = dz2o[j][r];
+  __syncthreads();
+  {
+    f32x4 dz2p[2], dz2[4];
+    partner(G.dz2, dz2p);
+    whole(dz2o, dz2p, dz2);
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[j][0] = acc[j][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    auto d1_tile = [&](const int j) {
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[j][r & 1] = mfma16(fW2T[kt][j][r], dz2[kt][r], acc[j][r & 1]);
+    };
+    auto d1_out = [&](const int j) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        colp[G.dz1 + (T0 + 16 * j + 4 * lk + r) * TS] = (acc[j][0][r] + acc[j][1][r]) * (1.f - a1o[j][r] * a1o[j][r]);
+    };
+    d1_tile(0);
+    d1_tile(1);
+    d1_out(0);
+    d1_out(1);
+  }
+  T64C_TS(5);
+  __syncthreads();   // every row's activations and activation gradients are in LDS
+  mid();
+  T64C_TS(6);
+  // ---- weight-gradient tiles (see `t64_tower_minibatch`): the same tiles, MFMAs and accumulation order; contractions over the
+  // block's RB rows (SQ steps of 16)
+  auto tile2 = [&](const f32x4 (&u)[SQ], const float* __restrict__ V0, const float* __restrict__ V1, f32x4& r0, f32x4& r1) {
+    const float* vp0 = V0 + li * TS + 4 * lk;
+    const float* vp1 = V1 + li * TS + 4 * lk;
+    f32x4 v0[SQ], v1[SQ];
+#pragma unroll
+    for (int sq = 0; sq < SQ; ++sq) {
+      v0[sq] = rd4(vp0 + 16 * sq);
+      v1[sq] = rd4(vp1 + 16 * sq);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    f32x4 g0 = {0.f, 0.f, 0.f, 0.f}, g0b = g0, g1 = g0, g1b = g0;
+#pragma unroll
+    for (int sq = 0; sq < SQ; ++sq)
+#pragma unroll
+      for (int i = 0; i < 4; i += 2) {
+        g0 = mfma16(u[sq][i], v0[sq][i], g0);
+        g1 = mfma16(u[sq][i], v1[sq][i], g1);
+        g0b = mfma16(u[sq][i + 1], v0[sq][i + 1], g0b);
+        g1b = mfma16(u[sq][i + 1], v1[sq][i + 1], g1b);
+      }
+    r0 = g0 + g0b;
+    r1 = g1 + g1b;
+  };
+  auto tile1 = [&](const f32x4 (&u)[SQ], const float* __restrict__ V0, f32x4& r0) {
+    const float* vp0 = V0 + li * TS + 4 * lk;
+    f32x4 v0[SQ];
+#pragma unroll
+    for (int sq = 0; sq < SQ; ++sq) v0[sq] = rd4(vp0 + 16 * sq);
+    __builtin_amdgcn_sched_barrier(0);
+    f32x4 g0 = {0.f, 0.f, 0.f, 0.f}, g0b = g0;
+#pragma unroll
+    for (int sq = 0; sq < SQ; ++sq)
+#pragma unroll
+      for (int i = 0; i < 4; i += 2) {
+        g0 = mfma16(u[sq][i], v0[sq][i], g0);
+        g0b = mfma16(u[sq][i + 1], v0[sq][i + 1], g0b);
+      }
+    r0 = g0 + g0b;
+  };
+  auto load_u = [&](const float* __restrict__ U, f32x4 (&u)[SQ]) {
+    const float* up = U + li * TS + 4 * lk;
+#pragma unroll
+    for (int sq = 0; sq < SQ; ++sq) u[sq] = rd4(up + 16 * sq);
+  };
+  // a feature's sum over the block's rows (optionally weighted by a row vector): lane (j, quarter) = (lane & 15, lane >> 4)
+  auto colsum16 = [&](const float* __restrict__ tile /* 16 features */, const float* __restrict__ wrow /* nullable */) {
+    const float* cp = tile + (lane & 15) * TS + (lane >> 4) * (RB / 4);
+    f32x4 t[SQ], wv[SQ];
+#pragma unroll
+    for (int i = 0; i < SQ; ++i) {
+      t[i] = rd4(cp + 4 * i);
+      wv[i] = wrow ? rd4(wrow + (lane >> 4) * (RB / 4) + 4 * i) : f32x4{1.f, 1.f, 1.f, 1.f};
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    float s = 0.f;
+    if (wrow) {
+#pragma unroll
+      for (int i = 0; i < SQ; ++i) s += (t[i][0] * wv[i][0] + t[i][1] * wv[i][1]) + (t[i][2] * wv[i][2] + t[i][3] * wv[i][3]);
+    } else {
+#pragma unroll
+      for (int i = 0; i < SQ; ++i) s += (t[i][0] + t[i][1]) + (t[i][2] + t[i][3]);
+    }
+    s += __shfl_xor(s, 16, 64);
+    s += __shfl_xor(s, 32, 64);
+    return s;   // (all four lanes of feature j hold the sum)
+  };
+  if constexpr (NW == 8) {
+    // eight waves: dW2's four input tiles go two per wave; h = 0 takes dW1's first K tile and its bias, h = 1 dW1's second K
+    // tile (observation widths > 16), the second layer's bias, the head's tile; the small column sums ride with h = 0
+    {   // dW2[j][i] = sum_r dz2[r][j] a1[r][i]: wave (q, h) takes output rows j = 16 q .., input tiles 2 h and 2 h + 1
+      f32x4 u[SQ];
+      load_u(lds + G.dz2 + 16 * q * TS, u);
+      f32x4 g0, g1;
+      tile2(u, lds + G.a1 + T0 * TS, lds + G.a1 + (T0 + 16) * TS, g0, g1);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        put(Lc.W2 + (16 * q + 4 * lk + r) * 64 + T0 + li, g0[r]);
+        put(Lc.W2 + (16 * q + 4 * lk + r) * 64 + T0 + 16 + li, g1[r]);
+      }
+    }
+    T64C_TS(7);
+    if (!hi) {   // dW1[j][c] = sum_r dz1[r][j] x[r][c], first K tile; the first layer's bias
+      f32x4 u[SQ], g0;
+      load_u(lds + G.dz1 + 16 * q * TS, u);
+      tile1(u, lds + G.x, g0);
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (li < D) put(Lc.W1 + (16 * q + 4 * lk + r) * D + li, g0[r]);
+      const float sb1 = colsum16(lds + G.dz1 + 16 * q * TS, nullptr);
+      if (lane < 16) put(Lc.b1 + 16 * q + lane, sb1);
+    } else {     // second K tile; the second layer's bias
+      if (KT1 == 2) {
+        f32x4 u[SQ], g1;
+        load_u(lds + G.dz1 + 16 * q * TS, u);
+        tile1(u, lds + G.x + 16 * TS, g1);
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (16 + li < D) put(Lc.W1 + (16 * q + 4 * lk + r) * D + 16 + li, g1[r]);
+      }
+      const float sb2 = colsum16(lds + G.dz2 + 16 * q * TS, nullptr);
+      if (lane < 16) put(Lc.b2 + 16 * q + lane, sb2);
+    }
+    T64C_TS(8);
+    if (tw == 0) {
+      if (hi) {   // head weights: dWa[a][h] = sum_r dout[r][a] a2[r][h], hidden tile q
+        f32x4 u[SQ], g0;
+        load_u(lds + G.dout, u);
+        tile1(u, lds + G.a2 + 16 * q * TS, g0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (4 * lk + r < A) put(Lc.HW + (4 * lk + r) * 64 + 16 * q + li, g0[r]);
+      } else if (q == 0) {   // action_net bias
+        const float s = colsum16(lds + G.dout, nullptr);
+        if (lane < A) put(Lc.Hb + lane, s);
+      } else if (q == 1) {   // log_std
+        if (!d.discrete) {
+          const float s = colsum16(lds + G.aux, nullptr);
+          if (lane < A) put(Lc.LS + lane, s);
+        }
+      } else if (q == 2) {   // loss statistics: misc columns 2..5 -> tail slots {0 pg, 2 ent, 3 kl, 4 clip}
+        const float s = colsum16(lds + G.misc, nullptr);   // (features 0..7 of the misc tile; 8..15 read the next tile: unused)
+        if (lane >= 2 && lane < 6) put(Lc.tail + (lane == 2 ? 0 : lane - 1), s);
+      } else {
+        if (Lc.zero_tail && lane < 4) put(Lc.tail + (lane == 0 ? 1 : lane + 4), 0.f);   // (slots 1, 5, 6, 7: not this tower's)
+      }
+    } else {
+      if (hi) {   // value_net: dcW[h] = sum_r dv[r] a2[r][h] -- one useful row of a tile: a weighted column sum instead
+        const float s = colsum16(lds + G.a2 + 16 * q * TS, lds + G.misc + 1 * TS);
+        if (lane < 16) put(Lc.HW + 16 * q + lane, s);
+      } else if (q == 0) {   // value_net bias = sum_r dv[r]; value_loss -> tail slot 1
+        const float sm = colsum16(lds + G.misc, nullptr);
+        if (lane == 1) put(Lc.Hb, sm);
+        if (lane == 6) put(Lc.tail + 1, sm);
+      } else if (q == 1) {
+        if (Lc.zero_tail && lane < 7) put(Lc.tail + (lane == 0 ? 0 : lane + 1), 0.f);   // (slots 0, 2..7: not this tower's)
+      }
+    }
+  } else {
+    // four waves (32-row blocks): wave w takes output tile w of every product, as wave q of `t64_tower_minibatch` does
+    {
+      f32x4 u[SQ];
+      load_u(lds + G.dz2 + 16 * w * TS, u);
+#pragma unroll
+      for (int it = 0; it < 4; it += 2) {
+        f32x4 g0, g1;
+        tile2(u, lds + G.a1 + 16 * it * TS, lds + G.a1 + 16 * (it + 1) * TS, g0, g1);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          put(Lc.W2 + (16 * w + 4 * lk + r) * 64 + 16 * it + li, g0[r]);
+          put(Lc.W2 + (16 * w + 4 * lk + r) * 64 + 16 * (it + 1) + li, g1[r]);
+        }
+      }
+      const float sb2 = colsum16(lds + G.dz2 + 16 * w * TS, nullptr);
+      if (lane < 16) put(Lc.b2 + 16 * w + lane, sb2);
+    }
+    T64C_TS(7);
+    {
+      f32x4 u[SQ], g0;
+      load_u(lds + G.dz1 + 16 * w * TS, u);
+      tile1(u, lds + G.x, g0);
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (li < D) put(Lc.W1 + (16 * w + 4 * lk + r) * D + li, g0[r]);
+      if (KT1 == 2) {
+        f32x4 g1;
+        tile1(u, lds + G.x + 16 * TS, g1);
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (16 + li < D) put(Lc.W1 + (16 * w + 4 * lk + r) * D + 16 + li, g1[r]);
+      }
+      const float sb1 = colsum16(lds + G.dz1 + 16 * w * TS, nullptr);
+      if (lane < 16) put(Lc.b1 + 16 * w + lane, sb1);
+    }
+    T64C_TS(8);
+    if (tw == 0) {
+      f32x4 u[SQ], g0;
+      load_u(lds + G.dout, u);
+      tile1(u, lds + G.a2 + 16 * w * TS, g0);
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (4 * lk + r < A) put(Lc.HW + (4 * lk + r) * 64 + 16 * w + li, g0[r]);
+      if (w == 0) {   // action_net bias
+        const float s = colsum16(lds + G.dout, nullptr);
+        if (lane < A) put(Lc.Hb + lane, s);
+      } else if (w == 1) {   // log_std
+        if (!d.discrete) {
+          const float s = colsum16(lds + G.aux, nullptr);
+          if (lane < A) put(Lc.LS + lane, s);
+        }
+      } else if (w == 2) {   // loss statistics: misc columns 2..5 -> tail slots {0 pg, 2 ent, 3 kl, 4 clip}
+        const float s = colsum16(lds + G.misc, nullptr);
+        if (lane >= 2 && lane < 6) put(Lc.tail + (lane == 2 ? 0 : lane - 1), s);
+      } else {
+        if (Lc.zero_tail && lane < 4) put(Lc.tail + (lane == 0 ? 1 : lane + 4), 0.f);
+      }
+    } else {
+      const float s = colsum16(lds + G.a2 + 16 * w * TS, lds + G.misc + 1 * TS);
+      if (lane < 16) put(Lc.HW + 16 * w + lane, s);
+      if (w == 0) {   // value_net bias = sum_r dv[r]; value_loss -> tail slot 1
+        const float sm = colsum16(lds + G.misc, nullptr);
+        if (lane == 1) put(Lc.Hb, sm);
+        if (lane == 6) put(Lc.tail + 1, sm);
+      } else if (w == 1) {
+        if (Lc.zero_tail && lane < 7) put(Lc.tail + (lane == 0 ? 0 : lane + 1), 0.f);
+      }
+    }
+  }
+  T64C_TS(9);
+  __syncthreads();
+  T64C_TS(10);
+#undef T64C_TS
+}
+
+// ---------------------------------------------------------------------------------------------
 // Round 5: the word-exchange epoch kernel with the TRANSPOSED, REGISTER-RESIDENT chain (`t64_tower_minibatch`) as its
 // gradient phase -- observation widths up to 32. Exchange, sequence numbers, chunk owners and Adam are those of
 // `ppo_epoch_ll_kernel` (same word areas, same sums in the same order in phases B1 / B2); what changed is phase A:
@@ -4004,8 +4571,8 @@ __device__ __forceinline__ void t64_tower_minibatch(
 // A tower workgroup that was tried in between -- parameters resident in LDS for the launch, every workgroup stepping its
 // whole tower, two hops -- lost: Adam on 5.7 k parameters by 256 threads and 22-30 words per thread in both hops cost more
 // than the parameter hand-off saves (28.2 against 26.5 us per step; `profiles/r05_mlp64.md`).
-template <int KT1>
-__global__ __launch_bounds__(256) void ppo_epoch_ll2_kernel(
+template <int KT1, int NW, int RB>
+__global__ __launch_bounds__(64 * NW) void ppo_epoch_ll2_kernel(
     ia_policy_desc d, float* __restrict__ P, float* __restrict__ Pt, float* __restrict__ m, float* __restrict__ v,
     const float* __restrict__ nm_in, const float* __restrict__ nv_in, const float* __restrict__ obs,
     const float* __restrict__ actions, const float* __restrict__ old_logp, const float* __restrict__ adv,
@@ -4016,9 +4583,9 @@ __global__ __launch_bounds__(256) void ppo_epoch_ll2_kernel(
                                    published, poll of the sums of squares, Adam + publish, -}; [16..], [32..]: shader clocks of
                                    the chain's phases (policy / value tower of row block 0, last step) */) {
   typedef unsigned long long u64;
-  constexpr int H = 64, NT = 256;
-  constexpr int RS = T64Geo<KT1>::RS;
-  constexpr int NLL = KT1 == 1 ? 21 : 25;                    // words of the tower's layers per thread (64 D + 64 + 4096 + 64)
+  constexpr int H = 64, NT = 64 * NW;                        // NW = 4: round 5's chain, one wave per SIMD; 8: two (`t64h_...`)
+  constexpr int RS = T64Geo<KT1, RB>::RS, TS = T64Geo<KT1, RB>::TS;
+  constexpr int NLL = (64 * 16 * KT1 + 64 + 4096 + 64 + NT - 1) / NT;   // words of the tower's layers per thread (64 D + 64 + 4096 + 64)
   constexpr int NB = (MAXA * H + MAXA + NT - 1) / NT;        // words of its head per thread
   extern __shared__ __attribute__((aligned(16))) float lds_raw[];
   float* const lds0 = lds_raw + (((16 - (__builtin_amdgcn_groupstaticsize() & 15)) & 15) >> 2);
@@ -4039,14 +4606,14 @@ __global__ __launch_bounds__(256) void ppo_epoch_ll2_kernel(
   const int bid = blockIdx.x, nwg = gridDim.x, nrb = nwg >> 1, rb = bid >> 1, tower = bid & 1;
   const int D = d.obs_dim, A = d.act_dim, aw = d.discrete ? 1 : A;
   const PolOff o = pol_offsets(D, A, H, d.discrete);
-  const T64Geo<KT1> G(D, aw);
+  const T64Geo<KT1, RB> G(D, aw);
   const int SW = o.total + 8;
   u64* slabs64 = ll.base;
   u64* sq64 = slabs64 + 2LL * nrb * SW;
   u64* par64 = sq64 + 2 * 64;
   unsigned* err = reinterpret_cast<unsigned*>(ws) + 5;
   const int chunk = (o.total + nwg - 1) / nwg;
-  constexpr int NPC = 4;   // parameters of the chunk per thread (chunk <= 1024)
+  constexpr int NPC = 1024 / NT;   // parameters of the chunk per thread (chunk <= 1024)
   int tid = threadIdx.x, lane = tid & 63;   // (re-formed every step behind an opaque zero: see the step loop)
   if (tid == 0) s_fail = 0;
   for (int e = tid; e < G.total; e += NT) lds[e] = 0.f;
@@ -4080,7 +4647,7 @@ __global__ __launch_bounds__(256) void ppo_epoch_ll2_kernel(
     if (tower == 0) {
       if (j < A * H) {
         da = G.HW + (j >> 6) * RS + (j & 63);
-        db = G.HWT + (j & 63) * T64Geo<KT1>::HT + (j >> 6);
+        db = G.HWT + (j & 63) * T64Geo<KT1, RB>::HT + (j >> 6);
       } else if (j < nB) {
         da = G.hb + (j - A * H);
       }
@@ -4114,11 +4681,11 @@ __global__ __launch_bounds__(256) void ppo_epoch_ll2_kernel(
   // one UNCONDITIONAL at a clamped 32-bit offset from a uniform base (a load behind a branch is merged with the "not
   // loaded" value by a copy that waits for it; a per-thread choice of pointer makes the load a flat one behind 64-bit
   // address arithmetic); `park_rows` leaves them in the staging area; `stage_rows` normalises them into the x tile
-  constexpr int NXR = (64 * 16 * KT1 + NT - 1) / NT;
-  constexpr int NAR = (64 * MAXA + NT - 1) / NT;
+  constexpr int NXR = (RB * 16 * KT1 + NT - 1) / NT;
+  constexpr int NAR = (RB * MAXA + NT - 1) / NT;
   float pf_x[NXR], pf_a[NAR], pf_s[3], pf_r[3];
   auto load_rows = [&](int mbi) {
-    long long start = (long long)mbi * batch_size + 64 * rb;
+    long long start = (long long)mbi * batch_size + RB * rb;
     start = start < total_rows - 1 ? start : total_rows - 1;
     const float* xb0 = obs + start * D;
     const float* ab0 = actions + start * aw;
@@ -4128,7 +4695,7 @@ __global__ __launch_bounds__(256) void ppo_epoch_ll2_kernel(
     for (int it = 0; it < NXR; ++it) pf_x[it] = xb0[min(tid + it * NT, xrem)];
 #pragma unroll
     for (int it = 0; it < NAR; ++it) pf_a[it] = ab0[min(tid + it * NT, arem)];
-    const int r = min(tid & 63, rrem);
+    const int r = min(tid & (RB - 1), rrem);
     pf_s[0] = (old_logp + start)[r];
     pf_s[1] = (adv + start)[r];
     pf_s[2] = (ret + start)[r];
@@ -4143,14 +4710,15 @@ __global__ __launch_bounds__(256) void ppo_epoch_ll2_kernel(
     pf_r[2] = nvp[min(c, D - 1)];
   };
   auto park_rows = [&]() {
-    const int nx = 64 * D, na = 64 * aw;
+    const int nx = RB * D, na = RB * aw;
 #pragma unroll
     for (int it = 0; it < NXR; ++it)
       if (tid + it * NT < nx) lds[G.sx + tid + it * NT] = pf_x[it];
 #pragma unroll
     for (int it = 0; it < NAR; ++it)
       if (tid + it * NT < na) lds[G.sact + tid + it * NT] = pf_a[it];
-    if (tid < 192) lds[G.soldlp + tid] = tid < 64 ? pf_s[0] : (tid < 128 ? pf_s[1] : pf_s[2]);   // (three consecutive areas)
+    if (tid < 3 * RB)   // (three consecutive 64-float areas)
+      lds[G.soldlp + 64 * (tid / RB) + (tid & (RB - 1))] = tid < RB ? pf_s[0] : (tid < 2 * RB ? pf_s[1] : pf_s[2]);
     if (tid < 2 * MAXD + 8) {
       const bool var = tid >= 8 + MAXD;
       float val = (snap || tid < 8) ? pf_r[0] : (var ? pf_r[2] : pf_r[1]);
@@ -4164,9 +4732,9 @@ __global__ __launch_bounds__(256) void ppo_epoch_ll2_kernel(
   auto stage_rows = [&](int bn) {   // `bn`: rows of the staged minibatch
     const int S1 = (D + 3) >> 2;
     const int s1r = (65536 + S1 - 1) / S1;
-    for (int g = tid; g < 64 * S1; g += NT) {
+    for (int g = tid; g < RB * S1; g += NT) {
       const int r = (g * s1r) >> 16, k0 = (g - r * S1) * 4;
-      const bool rok = 64 * rb + r < bn;
+      const bool rok = RB * rb + r < bn;
       float raw[4], mu[4], vr[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
@@ -4180,13 +4748,13 @@ __global__ __launch_bounds__(256) void ppo_epoch_ll2_kernel(
         const bool ok = rok && k0 + j < D;
         float val = raw[j];
         if (d.has_norm) val = (raw[j] - mu[j]) * vr[j];   // (`vr`: 1 / sqrt(var + eps), see park_rows)
-        lds[G.x + (k0 + j) * RS + r] = ok ? val : 0.f;
+        lds[G.x + (k0 + j) * TS + r] = ok ? val : 0.f;
       }
     }
   };
   auto rows_of = [&](int mbi) { return (int)min((long long)batch_size, total_rows - (long long)mbi * batch_size); };
   __syncthreads();
-  if (st.n > 0 && rb < (rows_of(st.first) + ROWS - 1) / ROWS) {   // (block-uniform)
+  if (st.n > 0 && rb < (rows_of(st.first) + RB - 1) / RB) {   // (block-uniform)
     load_rows(st.first);
     park_rows();
     __syncthreads();
@@ -4204,10 +4772,10 @@ __global__ __launch_bounds__(256) void ppo_epoch_ll2_kernel(
     const unsigned seq_par = ll.seq0 + (unsigned)k, seq_out = seq_par + 1u;
     const int mb = st.first + k;
     const int b = rows_of(mb);
-    const int nblk = (b + ROWS - 1) / ROWS;
+    const int nblk = (b + RB - 1) / RB;
     const bool more = k + 1 < st.n;
     const int bnext = more ? rows_of(mb + 1) : 0;
-    const bool have = rb < nblk, have_next = more && rb < (bnext + ROWS - 1) / ROWS;   // (block-uniform)
+    const bool have = rb < nblk, have_next = more && rb < (bnext + RB - 1) / RB;   // (block-uniform)
     u64* slabs_s = slabs64 + (long long)(seq_out & 1u) * nrb * SW;
     bool fail = false;
     auto timed_out = [&](unsigned& it) {
@@ -4272,9 +4840,14 @@ __global__ __launch_bounds__(256) void ppo_epoch_ll2_kernel(
       if (fail) s_fail = 1;
       __syncthreads();
       u64* slab = slabs_s + (long long)rb * SW;
-      t64_tower_minibatch<KT1>(d, G, out, tower, lds, 64 * rb, b, adv_mean, adv_std, normalize_adv, clip, ent_coef, vf_coef, slab,
-                               seq_out, [&]() { if (have_next) park_rows(); },
-                               (dbg != nullptr && bid < 2) ? dbg + 16 + 16 * bid : nullptr, oz);
+      if constexpr (NW == 8 || RB != 64)
+        t64h_tower_minibatch<KT1, RB, NW>(d, G, out, tower, lds, RB * rb, b, adv_mean, adv_std, normalize_adv, clip, ent_coef, vf_coef,
+                                  slab, seq_out, [&]() { if (have_next) park_rows(); },
+                                  (dbg != nullptr && bid < 2) ? dbg + 16 + 16 * bid : nullptr, oz);
+      else
+        t64_tower_minibatch<KT1>(d, G, out, tower, lds, RB * rb, b, adv_mean, adv_std, normalize_adv, clip, ent_coef, vf_coef,
+                                 slab, seq_out, [&]() { if (have_next) park_rows(); },
+                                 (dbg != nullptr && bid < 2) ? dbg + 16 + 16 * bid : nullptr, oz);
     } else if (have_next) {
       __syncthreads();
       park_rows();
@@ -4288,6 +4861,35 @@ __global__ __launch_bounds__(256) void ppo_epoch_ll2_kernel(
     float sqs = 0.f;
     // (the slabs' words of an element are requested TOGETHER, two elements at a time: up to 32 loads in flight and one trip
     //  through the fabric where eight-slab batches per element took four -- 3.6 of the step's 21 us; same sums, same order)
+    if (NW == 4 && nblk > 16) {
+      // more than sixteen slabs (32-row blocks of a 1 024-row minibatch): ALL words of one element requested together -- one
+      // trip through the fabric where two batches of sixteen took two (same sums in the same slab order)
+#pragma unroll
+      for (int j = 0; j < NPC; ++j) {
+        float acc = 0.f;
+        if (i0 + (tid & ~63) + j * NT < i1) {   // (wave-uniform)
+          const u64* col = slabs_s + min(i0 + tid + j * NT, o.total - 1);
+          const unsigned sw = (unsigned)SW;
+          u64 t[32];
+          unsigned it = 0;
+          for (;;) {
+#pragma unroll
+            for (int u = 0; u < 32; ++u)
+              t[u] = __hip_atomic_load(col + (unsigned)min(u, nblk - 1) * sw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            bool ok = true;
+#pragma unroll
+            for (int u = 0; u < 32; ++u) ok = ok && (unsigned)(t[u] >> 32) == seq_out;
+            if (__all(ok)) break;
+            if (timed_out(it)) { fail = true; break; }
+          }
+#pragma unroll
+          for (int u = 0; u < 32; ++u)
+            if (u < nblk) acc += __uint_as_float((unsigned)t[u]);
+          if (i0 + tid + j * NT < i1) sqs += acc * acc;
+        }
+        g[j] = acc;
+      }
+    } else
 #pragma unroll
     for (int j0 = 0; j0 < NPC; j0 += 2) {
       float acc[2] = {0.f, 0.f};
@@ -5445,6 +6047,8 @@ bool g_epoch_whole = false;  // tuning/debug: the one-launch epoch with whole ro
 bool g_epoch_barriers = false;   // tuning/debug: the one-tower epoch kernel with grid barriers instead of the word exchange
 bool g_epoch_chain2 = true;      // the word-exchange epoch kernel with round 5's transposed register-resident chain (observation
                                  // widths <= 32); false: round 4's gradient body everywhere
+bool g_epoch_waves8 = true;      // round 6: that kernel with eight waves per tower workgroup, two per SIMD (false: round 5's four)
+bool g_epoch_rows32 = true;      // round 6: ... on 32-row blocks (four waves: two row groups x two feature halves) where they fit
 long long* g_epoch_dbg = nullptr;  // measurement: phase ticks of workgroup 0 of ppo_epoch_persistent_kernel
 }  // namespace
 
@@ -5656,7 +6260,9 @@ static int64_t ppo_ws_plain_floats(const ia_policy_desc* d, int batch, int64_t g
 int64_t ia_ppo_ws_floats(const ia_policy_desc* d, int batch, int64_t gather_rows) {
   if (!pol_ok(d) || batch <= 0 || gather_rows < batch) return IA_ERR_ARG;
   const int P = pol_offsets(d->obs_dim, d->act_dim, d->hidden, d->discrete).total;
-  const int64_t ll = d->hidden == 64 ? 2 * epoch_ll_words(epoch_ll_row_blocks(cdiv(batch, ROWS), P), P) : 0;   // (64-wide towers: the word exchange)
+  // (64-wide towers: the word exchange, laid out for 32-row blocks where they apply -- twice the slabs)
+  const int r64 = epoch_ll_row_blocks(cdiv(batch, ROWS), P), r32 = epoch_ll_row_blocks(cdiv(batch, 32), P);
+  const int64_t ll = d->hidden == 64 ? 2 * epoch_ll_words(r32 <= 32 ? r32 : r64, P) : 0;
   return ppo_ws_plain_floats(d, batch, gather_rows) + ll;
 }
 
@@ -5857,6 +6463,8 @@ int ia_ppo_epoch_split(int on) {
   g_epoch_split = on == 1;
   g_epoch_whole = on == 2;
   g_epoch_barriers = on == 3;
+  g_epoch_waves8 = on != 5;   // 5: round 5's four-wave tower workgroups (one wave per SIMD) in `ppo_epoch_ll2_kernel`
+  g_epoch_rows32 = on != 5 && on != 6;   // 6: 64-row blocks on eight waves also where the 32-row blocks apply
   g_epoch_chain2 = on != 4;   // 4: round 4's gradient body in the word-exchange kernel also where round 5's chain applies
   return IA_OK;
 }
@@ -5934,8 +6542,14 @@ static int ppo_epochs_impl(const ia_policy_desc* d, float* params, float* params
   const int nrb_l = epoch_ll_row_blocks(nrb, P);
   const bool llx = towers_fit && !g_epoch_barriers && sbytes + 16 <= EPOCH_LL_LDS && nrb_l <= 32 && 2 * nrb_l <= dev_cus;
   const bool split = towers_fit && sbytes <= EPOCH_SPLIT_LDS && (llx || cdiv(P, 2 * nrb) <= 4 * 256);
+  // round 6: the transposed-chain kernel on 32-ROW blocks (twice the workgroups, half the chain and half the weight-gradient
+  // tiles per compute unit) where its 2 x ceil(b / 32) workgroups and slabs fit the exchange's limits (minibatches <= 1 024 rows)
+  const int nrb32_l = epoch_ll_row_blocks(cdiv(size_at(0), 32), P);
+  const bool rows32 = llx && g_epoch_chain2 && g_epoch_rows32 && d->obs_dim <= 32 && nrb32_l <= 32 && 2 * nrb32_l <= dev_cus &&
+                      2 * nrb32_l <= 64;
+  const int nrb_x = rows32 ? nrb32_l : nrb_l;   // row blocks the word areas are laid out for
   unsigned long long* ll_base = llx ? reinterpret_cast<unsigned long long*>(ws + ppo_ws_plain_floats(d, size_at(0), total)) : nullptr;
-  int rc = launch_gather(a, perm, total, g, ll_base, llx ? epoch_ll_words(nrb_l, P) : 0,
+  int rc = launch_gather(a, perm, total, g, ll_base, llx ? epoch_ll_words(nrb_x, P) : 0,
                          llx ? reinterpret_cast<unsigned*>(ws) + 4 : nullptr);   // (words 4, 5, 6: counter, error word, ticket)
   if (rc) return rc;
   // statistics of every minibatch of the epoch, one launch ahead of the chain (ppo_epoch_stats_kernel)
@@ -5966,11 +6580,16 @@ static int ppo_epochs_impl(const ia_policy_desc* d, float* params, float* params
                                  sizeof(float) + 16;
       if (llx && g_epoch_chain2 && d->obs_dim <= 32 && l2bytes <= EPOCH_LL_LDS) {
         // round 5's gradient phase (transposed register-resident chain, images with ds_read_b128 fragments)
-        auto k1 = ppo_epoch_ll2_kernel<1>;
-        auto k2 = ppo_epoch_ll2_kernel<2>;
-        const int ki = d->obs_dim <= 16 ? 0 : 1;
-        auto kern = ki == 0 ? k1 : k2;
-        static bool attr_2[2] = {false, false};
+        auto k1 = ppo_epoch_ll2_kernel<1, 4, 64>;
+        auto k2 = ppo_epoch_ll2_kernel<2, 4, 64>;
+        auto k1h = ppo_epoch_ll2_kernel<1, 8, 64>;   // round 6: two waves per SIMD per tower
+        auto k2h = ppo_epoch_ll2_kernel<2, 8, 64>;
+        auto k1r = ppo_epoch_ll2_kernel<1, 4, 32>;   // round 6: 32-row blocks
+        auto k2r = ppo_epoch_ll2_kernel<2, 4, 32>;
+        const int nw = rows32 ? 4 : (g_epoch_waves8 ? 8 : 4);
+        const int ki = (d->obs_dim <= 16 ? 0 : 1) + (rows32 ? 4 : (nw == 8 ? 2 : 0));
+        auto kern = ki == 0 ? k1 : (ki == 1 ? k2 : (ki == 2 ? k1h : (ki == 3 ? k2h : (ki == 4 ? k1r : k2r))));
+        static bool attr_2[6] = {false, false, false, false, false, false};
         if (!attr_2[ki]) { rc = set_lds(kern, EPOCH_LL_LDS); if (rc) return rc; attr_2[ki] = true; }
         EpochLl el{};
         el.base = ll_base;   // (cleared, like the error word, by the gather launch above)
@@ -5984,7 +6603,7 @@ static int ppo_epochs_impl(const ia_policy_desc* d, float* params, float* params
             es.step_size[k] = (float)(lr / (1.0 - pow(beta1, (double)step)));
             es.bc2_sqrt[k] = (float)sqrt(1.0 - pow(beta2, (double)step));
           }
-          hipLaunchKernelGGL(kern, dim3(2 * nrb_l), dim3(256), l2bytes, a.st, *d, params, params_t, exp_avg, exp_avg_sq, norm_mean,
+          hipLaunchKernelGGL(kern, dim3(2 * nrb_x), dim3(64 * nw), l2bytes, a.st, *d, params, params_t, exp_avg, exp_avg_sq, norm_mean,
                              norm_var, g.obs, g.act, g.logp, g.adv, g.ret, total, batch_size, T, n_envs, normalize_adv,
                              clip_range, ent_coef, vf_coef, max_grad_norm, (float)beta1, (float)beta2, adam_eps, ws, el, seq,
                              snap ? 1 : 0, stats, es, g_epoch_dbg);

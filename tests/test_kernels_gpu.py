@@ -671,6 +671,66 @@ def test_word_exchange_epoch_is_bit_identical_to_the_barrier_form(D, A, discrete
         assert th.equal(x, y), f"default form, run to run, {name}: {int((x != y).sum())} of {x.numel()} differ"
 
 
+@pytest.mark.parametrize("D,A,discrete,T,n,bs", [(17, 6, False, 16, 256, 1024), (4, 2, True, 9, 100, 384),
+                                                  (27, 8, False, 8, 512, 2048), (11, 3, False, 8, 32, 64),
+                                                  (16, 16, False, 5, 77, 200), (32, 5, True, 6, 64, 128)])
+def test_two_waves_per_simd_epoch_equals_the_four_wave_form(D, A, discrete, T, n, bs):
+    """64-wide towers, `ppo_epoch_ll2_kernel`: eight waves per tower workgroup (`ia_ppo_epoch_split(6)`: every wave half of a
+    layer's output tiles, its partner's half of the activations through LDS) against round 5's four (`ia_ppo_epoch_split(5)`):
+    every tile is accumulated by the same MFMAs in the same order, so with a clip threshold nothing reaches (the sum of squares
+    is folded by twice as many waves: the norm may differ in its last bit) parameters, transposed copy, Adam moments and the
+    loss statistics are bit-identical over three epochs; with the default threshold they agree to the last few bits. The
+    default form (0: 32-row blocks up to 1 024-row minibatches -- the rows' contraction in two slabs instead of one) agrees
+    within the tolerance of the oracle comparison and is deterministic."""
+    pol_ref = _oracle_policy(D, A, 64, discrete, True, seed=5)
+    rng = np.random.default_rng(1)
+    obs = rng.standard_normal((T, n, D)).astype(np.float32)
+    acts = (rng.integers(0, A, (T, n, 1)) if discrete else rng.standard_normal((T, n, A))).astype(np.float32)
+    lp, adv = rng.standard_normal((T, n)).astype(np.float32) * 0.1 - 1.0, rng.standard_normal((T, n)).astype(np.float32)
+    ret = rng.standard_normal((T, n)).astype(np.float32)
+    d_obs, d_act, d_lp, d_adv, d_ret = dev(obs), dev(acts), dev(lp), dev(adv), dev(ret)
+    n_mb = -(-T * n // bs)
+    perms = [rng.permutation(T * n) for _ in range(3)]
+    names = ("parameters", "transposed copy", "exp_avg", "exp_avg_sq", "norm mean", "norm var")
+    k = 3 * n_mb
+    for max_norm in (1e9, 0.5):
+        outs = []
+        try:
+            for mode in (5, 6, 0, 0):
+                dp = DevPolicy(pol_ref, D, A, 64, discrete, True)
+                ws = th.empty(int(L.load().ia_ppo_ws_floats(C.byref(dp.d), bs, T * n)), device=DEV)
+                ws.uniform_(-1e30, 1e30)   # (the workspace arrives uninitialised)
+                stats = th.zeros(3, n_mb, 8, device=DEV)
+                L.load().ia_ppo_epoch_split(mode)
+                for e in range(3):
+                    L.call("ia_ppo_epoch", C.byref(dp.d), L.ptr(dp.P), L.ptr(dp.Pt), L.ptr(dp.nm), L.ptr(dp.nv), L.ptr(dp.nc),
+                           1, L.ptr(d_obs), L.ptr(d_act), L.ptr(d_lp), L.ptr(d_adv), L.ptr(d_ret),
+                           dptr(perms[e], th.int64), T, n, bs, 1, 0.2, 0.05, 0.5, max_norm, L.ptr(dp.m), L.ptr(dp.v), 3e-4, 0.9,
+                           0.999, 1e-5, e * n_mb, L.ptr(ws), L.ptr(stats[e]), L.stream())
+                th.cuda.synchronize()
+                assert int(ws[5:6].view(th.int32).item()) == 0, "a wait timed out"
+                outs.append(((dp.P.clone(), dp.Pt.clone(), dp.m.clone(), dp.v.clone(), dp.nm.clone(), dp.nv.clone()), stats.clone()))
+        finally:
+            L.load().ia_ppo_epoch_split(0)
+        (xs, st_x), (ys, st_y), (zs, st_z), (zs2, st_z2) = outs
+        assert float(ys[0].abs().sum()) > 0 and bool(th.isfinite(ys[0]).all()) and bool(th.isfinite(zs[0]).all())
+        if max_norm > 1e8:
+            for name, x, y in zip(names, xs, ys):
+                assert th.equal(x, y), f"{name}: {int((x != y).sum())} of {x.numel()} differ, max {float((x - y).abs().max()):.3e}"
+            assert th.equal(st_x[..., :6], st_y[..., :6]) and th.equal(st_x[..., 7], st_y[..., 7])
+            th.testing.assert_close(st_x[..., 6], st_y[..., 6], rtol=1e-6, atol=0)
+        else:
+            for name, x, y in zip(names, xs, ys):
+                th.testing.assert_close(x, y, rtol=(1 + k) * 1e-6, atol=(1 + k) * 2e-7, msg=lambda m, name=name: f"{name}: {m}")
+            th.testing.assert_close(st_x, st_y, rtol=1e-5, atol=1e-6)
+        for name, x, z in zip(names, xs, zs):   # the default form: other slabs, same gradient within rounding
+            th.testing.assert_close(x, z, rtol=(1 + k) * 1e-5, atol=(1 + k) * 2e-6, msg=lambda m, name=name: f"default form, {name}: {m}")
+        th.testing.assert_close(st_x, st_z, rtol=1e-4, atol=1e-5)
+        for name, z, z2 in zip(names, zs, zs2):
+            assert th.equal(z, z2), f"default form, run to run, {name}"
+        assert th.equal(st_z, st_z2)
+
+
 @pytest.mark.parametrize("shape,B,A", [((4, 36, 36), 8, 6), ((3, 44, 52), 5, 4), ((1, 36, 40), 33, 18),
                                        ((4, 84, 84), 5, 6), ((4, 44, 60), 3, 4)])
 def test_cnn_policy_forward_and_gradient_match_torch(shape, B, A):

@@ -11,5 +11,8 @@ th.set_num_threads(1)
 if os.environ.get("IA_EPOCH_SPLIT"):   # A/B of the 64-wide epoch kernels (include/imitation_hip.h: ia_ppo_epoch_split)
     from imitation_amd import _lib as L
     L.load().ia_ppo_epoch_split(int(os.environ["IA_EPOCH_SPLIT"]))
+if os.environ.get("IA_GRAPH") == "0":   # A/B of the graph-replayed module-policy updates
+    from imitation_amd import general_policy
+    general_policy.GRAPH_UPDATES = False
 name = sys.argv[1] if len(sys.argv) > 1 else "3_airl_ant_1024x16_mb1024"
 print(name, bench.run_variant(name, rounds=int(sys.argv[2]) if len(sys.argv) > 2 else 6))
