@@ -3992,15 +3992,22 @@ __device__ __forceinline__ void t64_tower_minibatch(
 }
 
 // ---------------------------------------------------------------------------------------------
-// Round 6: the same chain on EIGHT waves per tower -- two per SIMD. Wave w = (q, h) = (w & 3, w >> 2) owns rows 16 q .. of the
-// block like wave q above, but only the output tiles 2 h, 2 h + 1 of every layer (features 32 h .. 32 h + 31): half the MFMAs
-// and half the tanh / store work per wave, the SIMD's second wave issuing under the first one's latencies. The k index of a
-// layer runs over all 64 features of the layer below: a wave's own half is in its registers, its partner's half comes from the
-// `[feature][row]` tile the partner writes anyway (one workgroup barrier per layer; the next layer's weight fragments are
-// requested ahead of it). Head and per-row losses (16 MFMAs, no weights to split) are computed by both waves of a pair. Every
-// tile is accumulated by the same MFMAs in the same order as in the four-wave form: the gradients are bit-identical.
-// Weight-gradient tiles: dW2's four input tiles go two per wave; h = 0 takes dW1's first tile and its bias, h = 1 dW1's second
-// tile (observation widths > 16), the second layer's bias, the head's tile and the small column sums.
+// Round 6: the same chain with every layer's output tiles split between TWO waves per group of 16 rows. Wave w = (q, h) =
+// (w % NQ, w / NQ), NQ = RB / 16 row groups, owns rows 16 q .. of the block like wave q above, but only the output tiles 2 h,
+// 2 h + 1 of every layer (features 32 h .. 32 h + 31): half the MFMAs and half the tanh / store work per wave. The k index of
+// a layer runs over all 64 features of the layer below: a wave's own half is in its registers, its partner's half comes from
+// the `[feature][row]` tile the partner writes anyway (one workgroup barrier per layer; the next layer's weight fragments are
+// requested ahead of it). Head and per-row losses (16 MFMAs, no weights to split) are computed by both waves of a pair. Two
+// forms:
+//   * RB = 64, eight waves (two per SIMD, the second one issuing under the first one's latencies). Every tile is accumulated
+//     by the same MFMAs in the same order as in the four-wave form: the gradients are bit-identical. Weight-gradient tiles:
+//     dW2's four input tiles go two per wave; h = 0 takes dW1's first K tile and its bias, h = 1 dW1's second K tile
+//     (observation widths > 16), the second layer's bias and the head's tile.
+//   * RB = 32, four waves (one per SIMD): twice the workgroups per minibatch, each with half the chain AND half the
+//     weight-gradient MFMAs (contractions over 32 rows) per compute unit -- at the price of twice the slabs in phase B1 and
+//     twice the readers of the parameter words. Wave w takes output tile w of every weight-gradient product.
+// The row tiles' stride is TS = RB + 4 floats (an odd number of quads: sixteen lanes' ds_read_b128 of consecutive features hit
+// distinct bank quads), the 64-wide weight images keep RS = 68.
 template <int KT1, int RB, int NW, class Mid>
 __device__ __forceinline__ void t64h_tower_minibatch(
     const ia_policy_desc& d, const T64Geo<KT1, RB>& G, const T64Out& Lc, const int tw, float* __restrict__ lds_in, const int row0,
