@@ -405,7 +405,7 @@ def build_image_variant(p=None):
     return tr, n_envs * n_steps
 
 
-def run_image_variant(rounds=3, warm=2):
+def run_image_variant(rounds=10, warm=3):   # (45-50 ms rounds on the host's clock: three-round samples spread by 8 %)
     tr, per = build_image_variant()
     tr.train(warm * per)
     th.cuda.synchronize()
@@ -530,7 +530,7 @@ def variant_cpu_baseline(name, host_threads):
 
 def run_variant(name, rounds=None, warm=None):
     if name == "image_gail_64x16_cnn":
-        return run_image_variant(rounds or 3, warm or 2)
+        return run_image_variant(rounds or 10, warm or 3)
     if name == "5_bc_cnn_4096":
         return run_bc_variant()
     v = VARIANTS[name]
