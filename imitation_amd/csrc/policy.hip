@@ -1813,9 +1813,16 @@ __device__ __forceinline__ void chain_stage_rows(const ia_policy_desc& d, const 
   using L = CLds;
   const int D = d.obs_dim;
   const int S1 = (D + 3) >> 2;
-  const bool idle = SMALL && q > 0;   // wave-uniform; compiled out of the general instantiations
+#ifndef IA_SMALL_STAGE_ASIDE
+#define IA_SMALL_STAGE_ASIDE 1   // (0: the chain waves stage their rows themselves, for same-box A/Bs -- tools/ab_libs.sh)
+#endif
+  // SMALL (minibatches of <= 16 rows: only the waves of row quarter 0 run the chain): the rows are staged by the waves of row
+  // quarter 1 -- idle otherwise -- WHILE the chain waves request their weight fragments; both meet at the caller's barrier.
+  // Same values into the same places (~1 100 clocks of the chain waves' path per step on the tuned AIRL file).
+  constexpr int QS = (SMALL && IA_SMALL_STAGE_ASIDE) ? 1 : 0;
+  const bool idle = SMALL && q != QS;   // wave-uniform; compiled out of the general instantiations
   if (!idle) {
-    const int rbase = q * 16;
+    const int rbase = SMALL ? 0 : q * 16;
     // the two waves that share q (tower 0 / tower 1) stage the 16 rows together, four consecutive columns per lane
     // and only the 4 * S1 columns the first layer reads with non-zero weights (the caller cleared the tile once: the
     // columns beyond are never written). Group g = row * S1 + column group; the row comes from a multiply-shift
