@@ -4022,8 +4022,9 @@ __device__ __forceinline__ void t64h_tower_minibatch(
     const float vf_coef, unsigned long long* __restrict__ slab, const unsigned seq, Mid&& mid,
     long long* __restrict__ ts /* measurement (nullable): shader clocks of the phases, thread 0 */, const int oz) {
   constexpr int RS = T64Geo<KT1, RB>::RS, TS = T64Geo<KT1, RB>::TS;   // strides of the weight images / of the row tiles
-  constexpr int NQ = RB / 16, SQ = RB / 16;                           // row groups of the block = waves per feature half
-  static_assert(NW == 2 * NQ, "two waves (feature halves) per group of 16 rows");
+  constexpr int NQ = RB / 16, SQ = RB / 16;                           // row groups of the block; 16-row steps of a contraction
+  constexpr int NH = NW / NQ, TPW = 4 / NH;                           // waves per row group (feature parts); output tiles per wave
+  static_assert(NW == NH * NQ && (NH == 2 || NH == 4), "two or four waves (feature halves / quarters) per group of 16 rows");
 #define T64C_TS(slot) do { if (ts != nullptr && threadIdx.x == 0) ts[slot] = clock64(); } while (0)
   T64C_TS(0);
   float* __restrict__ lds = lds_in + oz;
@@ -4045,8 +4046,9 @@ __device__ __forceinline__ void t64h_tower_minibatch(
   };
   const int lrow = q * 16 + li;
   const bool valid = row0 + lrow < b;
-  const int T0 = 32 * h;               // first feature of the wave's tiles
-  const int P0 = 32 - T0;              // ... of its partner's
+  const int T0 = 16 * TPW * h;         // first feature of the wave's tiles
+  const int P0 = 32 - T0;              // ... of its partner's (feature halves)
+  const bool headw = NH == 2 || h == 0;   // (wave-uniform) this wave runs the head and the per-row losses
   float* const colp = lds + q * 16 + li;   // column (row of the minibatch) of the lane in every [feature][row] tile
   // per-row scalars of the loss (staged by the prefetch)
   float r_oldlp = 0.f, r_adv = 0.f, r_ret = 0.f, r_act[4] = {0.f, 0.f, 0.f, 0.f};
@@ -4072,26 +4074,40 @@ __device__ __forceinline__ void t64h_tower_minibatch(
     o[2] = sel4(own[0], oth[0], hi);
     o[3] = sel4(own[1], oth[1], hi);
   };
+  // all four k tiles of a layer below (behind the workgroup barrier that follows its tiles' stores). Halves: the own two from
+  // the registers, the partner's two from the tile; quarters: all four from the tile (16 conflict-free ds_read_b32)
+  auto gather4 = [&](int tile, const f32x4 (&own)[TPW], f32x4 (&o)[4]) {
+    if constexpr (NH == 2) {
+      f32x4 oth[2];
+      partner(tile, oth);
+      whole(own, oth, o);
+    } else {
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[kt][r] = colp[tile + (16 * kt + 4 * lk + r) * TS];
+    }
+  };
   // ---- layer 1: tiles 2 h, 2 h + 1 of a1^T = tanh(W1 x^T + b1)
-  f32x4 a1o[2], a2o[2], a1[4], a2[4];
-  f32x4 fW2[4][2], b2c[2];
+  f32x4 a1o[TPW], a2o[TPW], a1[4], a2[4];
+  f32x4 fW2[4][TPW], b2c[TPW];
   {
-    f32x4 fW1[KT1][2], b1c[2];
+    f32x4 fW1[KT1][TPW], b1c[TPW];
     float xb[KT1][4];
 #pragma unroll
     for (int kt = 0; kt < KT1; ++kt)
 #pragma unroll
-      for (int j = 0; j < 2; ++j) fW1[kt][j] = rd4(lds + G.W1 + (T0 + 16 * j + li) * G.DP + 16 * kt + 4 * lk);
+      for (int j = 0; j < TPW; ++j) fW1[kt][j] = rd4(lds + G.W1 + (T0 + 16 * j + li) * G.DP + 16 * kt + 4 * lk);
 #pragma unroll
-    for (int j = 0; j < 2; ++j) b1c[j] = rd4(lds + G.b1 + T0 + 16 * j + 4 * lk);
+    for (int j = 0; j < TPW; ++j) b1c[j] = rd4(lds + G.b1 + T0 + 16 * j + 4 * lk);
 #pragma unroll
     for (int kt = 0; kt < KT1; ++kt)
 #pragma unroll
       for (int r = 0; r < 4; ++r) xb[kt][r] = colp[G.x + (16 * kt + 4 * lk + r) * TS];
     __builtin_amdgcn_sched_barrier(0);
-    f32x4 acc[2][2];
+    f32x4 acc[TPW][2];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
+    for (int j = 0; j < TPW; ++j) {
       acc[j][0] = b1c[j];
       acc[j][1] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
@@ -4108,31 +4124,27 @@ __device__ __forceinline__ void t64h_tower_minibatch(
         colp[G.a1 + (T0 + 16 * j + 4 * lk + r) * TS] = a1o[j][r];
       }
     };
-    l1_tile(0);
-    l1_tile(1);
+#pragma unroll
+    for (int j = 0; j < TPW; ++j) l1_tile(j);
     // (the second layer's fragments of the wave's output rows: in flight under the tanh and the barrier)
 #pragma unroll
     for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
-      for (int j = 0; j < 2; ++j) fW2[kt][j] = rd4(lds + G.W2 + (T0 + 16 * j + li) * RS + 16 * kt + 4 * lk);
+      for (int j = 0; j < TPW; ++j) fW2[kt][j] = rd4(lds + G.W2 + (T0 + 16 * j + li) * RS + 16 * kt + 4 * lk);
 #pragma unroll
-    for (int j = 0; j < 2; ++j) b2c[j] = rd4(lds + G.b2 + T0 + 16 * j + 4 * lk);
-    l1_tanh(0);
-    l1_tanh(1);
+    for (int j = 0; j < TPW; ++j) b2c[j] = rd4(lds + G.b2 + T0 + 16 * j + 4 * lk);
+#pragma unroll
+    for (int j = 0; j < TPW; ++j) l1_tanh(j);
   }
   __syncthreads();
   T64C_TS(1);
-  {
-    f32x4 a1p[2];
-    partner(G.a1, a1p);
-    whole(a1o, a1p, a1);
-  }
+  gather4(G.a1, a1o, a1);
   // ---- layer 2: tiles 2 h, 2 h + 1 of a2^T = tanh(W2 a1^T + b2)
   f32x4 fHead[4], hbias;
   {
-    f32x4 acc[2][2];
+    f32x4 acc[TPW][2];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
+    for (int j = 0; j < TPW; ++j) {
       acc[j][0] = b2c[j];
       acc[j][1] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
@@ -4149,24 +4161,20 @@ __device__ __forceinline__ void t64h_tower_minibatch(
         colp[G.a2 + (T0 + 16 * j + 4 * lk + r) * TS] = a2o[j][r];
       }
     };
-    l2_tile(0);
-    l2_tile(1);
+#pragma unroll
+    for (int j = 0; j < TPW; ++j) l2_tile(j);
 #pragma unroll
     for (int kt = 0; kt < 4; ++kt) fHead[kt] = rd4(lds + G.HW + li * RS + 16 * kt + 4 * lk);
     hbias = rd4(lds + G.hb + 4 * lk);
-    l2_tanh(0);
-    l2_tanh(1);
+#pragma unroll
+    for (int j = 0; j < TPW; ++j) l2_tanh(j);
   }
   __syncthreads();
   T64C_TS(2);
-  {
-    f32x4 a2p[2];
-    partner(G.a2, a2p);
-    whole(a2o, a2p, a2);
-  }
+  if (headw) gather4(G.a2, a2o, a2);
   // ---- head (both waves of a pair): hout[r] = output 4 lk + r of row li (value: lane group 0, register 0)
-  float hout[4];
-  {
+  float hout[4] = {0.f, 0.f, 0.f, 0.f};
+  if (headw) {
     f32x4 acc[2] = {hbias, {0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
     for (int kt = 0; kt < 4; ++kt)
@@ -4177,15 +4185,15 @@ __device__ __forceinline__ void t64h_tower_minibatch(
   }
   T64C_TS(3);
   // backward fragments of the wave's tiles: the head's weights of the lane's outputs T0 + 16 j + 4 lk + r; W2 transposed
-  f32x4 fHeadT[2];
+  f32x4 fHeadT[TPW];
 #pragma unroll
-  for (int j = 0; j < 2; ++j)
+  for (int j = 0; j < TPW; ++j)
     fHeadT[j] = tw == 0 ? rd4(lds + G.HWT + (T0 + 16 * j + li) * T64Geo<KT1, RB>::HT + 4 * lk) : rd4(lds + G.HW + T0 + 16 * j + 4 * lk);
-  f32x4 fW2T[4][2];
+  f32x4 fW2T[4][TPW];
 #pragma unroll
   for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) fW2T[kt][j] = rd4(lds + G.W2T + (T0 + 16 * j + li) * RS + 16 * kt + 4 * lk);
+    for (int j = 0; j < TPW; ++j) fW2T[kt][j] = rd4(lds + G.W2T + (T0 + 16 * j + li) * RS + 16 * kt + 4 * lk);
   // ---- per-row losses (the expressions of `t64_tower_minibatch`; the pair's first wave leaves the rows' pieces in LDS)
   auto xchg16 = [](float v, float& a, float& bq) {
     const auto p2 = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
@@ -4212,7 +4220,9 @@ __device__ __forceinline__ void t64h_tower_minibatch(
     return fmaxf(a, bq);
   };
   float dout[4] = {0.f, 0.f, 0.f, 0.f}, dvb = 0.f;
-  if (tw == 0) {
+  if (!headw) {
+    // (feature quarters: the row group's first wave runs head and losses alone and leaves d head / dv in LDS, see below)
+  } else if (tw == 0) {
     const f32x4 c_ivar = rd4(lds + G.ls + 16 + 4 * lk), c_logsd = rd4(lds + G.ls + 32 + 4 * lk);
     float logp = 0.f, entropy = 0.f, lse = 0.f;
     int act_i = 0;
@@ -4303,39 +4313,47 @@ __device__ __forceinline__ void t64h_tower_minibatch(
       lds[G.misc + 6 * TS + lrow] = valid ? verr * verr : 0.f;        // value_loss
     }
   }
+  if constexpr (NH == 4) {   // d head^T (policy: the [action][row] tile, zero beyond the actions) / dv of the lane's row
+    __syncthreads();
+    if (tw == 0) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) dout[r] = colp[G.dout + (4 * lk + r) * TS];
+    } else {
+      dvb = lds[G.misc + 1 * TS + lrow];
+    }
+  }
   T64C_TS(4);
   // ---- tiles 2 h, 2 h + 1 of dz2^T = (W_head^T d head^T) * (1 - a2^2), then of dz1^T = (W2^T dz2^T) * (1 - a1^2)
-  f32x4 dz2o[2];
+  f32x4 dz2o[TPW];
   if (tw == 0) {
-    f32x4 acc[2];
+    f32x4 acc[TPW];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < TPW; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int r = 0; r < 4; ++r)   // (k-step r carries actions r, 4 + r, 8 + r, 12 + r; the image's columns >= A are zero)
 #pragma unroll
-      for (int j = 0; j < 2; ++j) acc[j] = mfma16(fHeadT[j][r], dout[r], acc[j]);
+      for (int j = 0; j < TPW; ++j) acc[j] = mfma16(fHeadT[j][r], dout[r], acc[j]);
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < TPW; ++j)
 #pragma unroll
       for (int r = 0; r < 4; ++r) dz2o[j][r] = acc[j][r] * (1.f - a2o[j][r] * a2o[j][r]);
   } else {
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < TPW; ++j)
 #pragma unroll
       for (int r = 0; r < 4; ++r) dz2o[j][r] = fHeadT[j][r] * dvb * (1.f - a2o[j][r] * a2o[j][r]);
   }
 #pragma unroll
-  for (int j = 0; j < 2; ++j)
+  for (int j = 0; j < TPW; ++j)
 #pragma unroll
     for (int r = 0; r < 4; ++r) colp[G.dz2 + (T0 + 16 * j + 4 * lk + r) * TS] = dz2o[j][r];
   __syncthreads();
   {
-    f32x4 dz2p[2], dz2[4];
-    partner(G.dz2, dz2p);
-    whole(dz2o, dz2p, dz2);
-    f32x4 acc[2][2];
+    f32x4 dz2[4];
+    gather4(G.dz2, dz2o, dz2);
+    f32x4 acc[TPW][2];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) acc[j][0] = acc[j][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < TPW; ++j) acc[j][0] = acc[j][1] = f32x4{0.f, 0.f, 0.f, 0.f};
     auto d1_tile = [&](const int j) {
 #pragma unroll
       for (int kt = 0; kt < 4; ++kt)
@@ -4347,10 +4365,10 @@ __device__ __forceinline__ void t64h_tower_minibatch(
       for (int r = 0; r < 4; ++r)
         colp[G.dz1 + (T0 + 16 * j + 4 * lk + r) * TS] = (acc[j][0][r] + acc[j][1][r]) * (1.f - a1o[j][r] * a1o[j][r]);
     };
-    d1_tile(0);
-    d1_tile(1);
-    d1_out(0);
-    d1_out(1);
+#pragma unroll
+    for (int j = 0; j < TPW; ++j) d1_tile(j);
+#pragma unroll
+    for (int j = 0; j < TPW; ++j) d1_out(j);
   }
   T64C_TS(5);
   __syncthreads();   // every row's activations and activation gradients are in LDS
@@ -4425,73 +4443,75 @@ __device__ __forceinline__ void t64h_tower_minibatch(
     return s;   // (all four lanes of feature j hold the sum)
   };
   if constexpr (NW == 8) {
+    const int jw = w & 3, iw = w >> 2, I0 = 32 * iw;   // output tile and pair of input tiles of this wave's dW2 products
+    const bool second = iw != 0;
     // eight waves: dW2's four input tiles go two per wave; h = 0 takes dW1's first K tile and its bias, h = 1 dW1's second K
     // tile (observation widths > 16), the second layer's bias, the head's tile; the small column sums ride with h = 0
-    {   // dW2[j][i] = sum_r dz2[r][j] a1[r][i]: wave (q, h) takes output rows j = 16 q .., input tiles 2 h and 2 h + 1
+    {   // dW2[j][i] = sum_r dz2[r][j] a1[r][i]: wave w takes output rows j = 16 (w & 3) .., input tiles 2 (w >> 2) and 2 (w >> 2) + 1
       f32x4 u[SQ];
-      load_u(lds + G.dz2 + 16 * q * TS, u);
+      load_u(lds + G.dz2 + 16 * jw * TS, u);
       f32x4 g0, g1;
-      tile2(u, lds + G.a1 + T0 * TS, lds + G.a1 + (T0 + 16) * TS, g0, g1);
+      tile2(u, lds + G.a1 + I0 * TS, lds + G.a1 + (I0 + 16) * TS, g0, g1);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        put(Lc.W2 + (16 * q + 4 * lk + r) * 64 + T0 + li, g0[r]);
-        put(Lc.W2 + (16 * q + 4 * lk + r) * 64 + T0 + 16 + li, g1[r]);
+        put(Lc.W2 + (16 * jw + 4 * lk + r) * 64 + I0 + li, g0[r]);
+        put(Lc.W2 + (16 * jw + 4 * lk + r) * 64 + I0 + 16 + li, g1[r]);
       }
     }
     T64C_TS(7);
-    if (!hi) {   // dW1[j][c] = sum_r dz1[r][j] x[r][c], first K tile; the first layer's bias
+    if (!second) {   // dW1[j][c] = sum_r dz1[r][j] x[r][c], first K tile; the first layer's bias
       f32x4 u[SQ], g0;
-      load_u(lds + G.dz1 + 16 * q * TS, u);
+      load_u(lds + G.dz1 + 16 * jw * TS, u);
       tile1(u, lds + G.x, g0);
 #pragma unroll
       for (int r = 0; r < 4; ++r)
-        if (li < D) put(Lc.W1 + (16 * q + 4 * lk + r) * D + li, g0[r]);
-      const float sb1 = colsum16(lds + G.dz1 + 16 * q * TS, nullptr);
-      if (lane < 16) put(Lc.b1 + 16 * q + lane, sb1);
+        if (li < D) put(Lc.W1 + (16 * jw + 4 * lk + r) * D + li, g0[r]);
+      const float sb1 = colsum16(lds + G.dz1 + 16 * jw * TS, nullptr);
+      if (lane < 16) put(Lc.b1 + 16 * jw + lane, sb1);
     } else {     // second K tile; the second layer's bias
       if (KT1 == 2) {
         f32x4 u[SQ], g1;
-        load_u(lds + G.dz1 + 16 * q * TS, u);
+        load_u(lds + G.dz1 + 16 * jw * TS, u);
         tile1(u, lds + G.x + 16 * TS, g1);
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-          if (16 + li < D) put(Lc.W1 + (16 * q + 4 * lk + r) * D + 16 + li, g1[r]);
+          if (16 + li < D) put(Lc.W1 + (16 * jw + 4 * lk + r) * D + 16 + li, g1[r]);
       }
-      const float sb2 = colsum16(lds + G.dz2 + 16 * q * TS, nullptr);
-      if (lane < 16) put(Lc.b2 + 16 * q + lane, sb2);
+      const float sb2 = colsum16(lds + G.dz2 + 16 * jw * TS, nullptr);
+      if (lane < 16) put(Lc.b2 + 16 * jw + lane, sb2);
     }
     T64C_TS(8);
     if (tw == 0) {
-      if (hi) {   // head weights: dWa[a][h] = sum_r dout[r][a] a2[r][h], hidden tile q
+      if (second) {   // head weights: dWa[a][h] = sum_r dout[r][a] a2[r][h], hidden tile q
         f32x4 u[SQ], g0;
         load_u(lds + G.dout, u);
-        tile1(u, lds + G.a2 + 16 * q * TS, g0);
+        tile1(u, lds + G.a2 + 16 * jw * TS, g0);
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-          if (4 * lk + r < A) put(Lc.HW + (4 * lk + r) * 64 + 16 * q + li, g0[r]);
-      } else if (q == 0) {   // action_net bias
+          if (4 * lk + r < A) put(Lc.HW + (4 * lk + r) * 64 + 16 * jw + li, g0[r]);
+      } else if (jw == 0) {   // action_net bias
         const float s = colsum16(lds + G.dout, nullptr);
         if (lane < A) put(Lc.Hb + lane, s);
-      } else if (q == 1) {   // log_std
+      } else if (jw == 1) {   // log_std
         if (!d.discrete) {
           const float s = colsum16(lds + G.aux, nullptr);
           if (lane < A) put(Lc.LS + lane, s);
         }
-      } else if (q == 2) {   // loss statistics: misc columns 2..5 -> tail slots {0 pg, 2 ent, 3 kl, 4 clip}
+      } else if (jw == 2) {   // loss statistics: misc columns 2..5 -> tail slots {0 pg, 2 ent, 3 kl, 4 clip}
         const float s = colsum16(lds + G.misc, nullptr);   // (features 0..7 of the misc tile; 8..15 read the next tile: unused)
         if (lane >= 2 && lane < 6) put(Lc.tail + (lane == 2 ? 0 : lane - 1), s);
       } else {
         if (Lc.zero_tail && lane < 4) put(Lc.tail + (lane == 0 ? 1 : lane + 4), 0.f);   // (slots 1, 5, 6, 7: not this tower's)
       }
     } else {
-      if (hi) {   // value_net: dcW[h] = sum_r dv[r] a2[r][h] -- one useful row of a tile: a weighted column sum instead
-        const float s = colsum16(lds + G.a2 + 16 * q * TS, lds + G.misc + 1 * TS);
-        if (lane < 16) put(Lc.HW + 16 * q + lane, s);
-      } else if (q == 0) {   // value_net bias = sum_r dv[r]; value_loss -> tail slot 1
+      if (second) {   // value_net: dcW[h] = sum_r dv[r] a2[r][h] -- one useful row of a tile: a weighted column sum instead
+        const float s = colsum16(lds + G.a2 + 16 * jw * TS, lds + G.misc + 1 * TS);
+        if (lane < 16) put(Lc.HW + 16 * jw + lane, s);
+      } else if (jw == 0) {   // value_net bias = sum_r dv[r]; value_loss -> tail slot 1
         const float sm = colsum16(lds + G.misc, nullptr);
         if (lane == 1) put(Lc.Hb, sm);
         if (lane == 6) put(Lc.tail + 1, sm);
-      } else if (q == 1) {
+      } else if (jw == 1) {
         if (Lc.zero_tail && lane < 7) put(Lc.tail + (lane == 0 ? 0 : lane + 1), 0.f);   // (slots 0, 2..7: not this tower's)
       }
     }
@@ -4875,7 +4895,7 @@ __global__ __launch_bounds__(64 * NW) void ppo_epoch_ll2_kernel(
     float sqs = 0.f;
     // (the slabs' words of an element are requested TOGETHER, two elements at a time: up to 32 loads in flight and one trip
     //  through the fabric where eight-slab batches per element took four -- 3.6 of the step's 21 us; same sums, same order)
-    if (NW == 4 && nblk > 16) {
+    if ((NW == 4 || RB == 32) && nblk > 16) {
       // more than sixteen slabs (32-row blocks of a 1 024-row minibatch): ALL words of one element requested together -- one
       // trip through the fabric where two batches of sixteen took two (same sums in the same slab order)
 #pragma unroll
@@ -6063,6 +6083,7 @@ bool g_epoch_chain2 = true;      // the word-exchange epoch kernel with round 5'
                                  // widths <= 32); false: round 4's gradient body everywhere
 bool g_epoch_waves8 = true;      // round 6: that kernel with eight waves per tower workgroup, two per SIMD (false: round 5's four)
 bool g_epoch_rows32 = true;      // round 6: ... on 32-row blocks (four waves: two row groups x two feature halves) where they fit
+bool g_epoch_quarters = true;    // round 6: ... with eight waves per 32-row block (two row groups x four feature quarters)
 long long* g_epoch_dbg = nullptr;  // measurement: phase ticks of workgroup 0 of ppo_epoch_persistent_kernel
 }  // namespace
 
@@ -6479,6 +6500,7 @@ int ia_ppo_epoch_split(int on) {
   g_epoch_barriers = on == 3;
   g_epoch_waves8 = on != 5;   // 5: round 5's four-wave tower workgroups (one wave per SIMD) in `ppo_epoch_ll2_kernel`
   g_epoch_rows32 = on != 5 && on != 6;   // 6: 64-row blocks on eight waves also where the 32-row blocks apply
+  g_epoch_quarters = on != 7;            // 7: 32-row blocks on four waves (feature halves) instead of eight (quarters)
   g_epoch_chain2 = on != 4;   // 4: round 4's gradient body in the word-exchange kernel also where round 5's chain applies
   return IA_OK;
 }
@@ -6598,12 +6620,15 @@ static int ppo_epochs_impl(const ia_policy_desc* d, float* params, float* params
         auto k2 = ppo_epoch_ll2_kernel<2, 4, 64>;
         auto k1h = ppo_epoch_ll2_kernel<1, 8, 64>;   // round 6: two waves per SIMD per tower
         auto k2h = ppo_epoch_ll2_kernel<2, 8, 64>;
-        auto k1r = ppo_epoch_ll2_kernel<1, 4, 32>;   // round 6: 32-row blocks
+        auto k1r = ppo_epoch_ll2_kernel<1, 4, 32>;   // round 6: 32-row blocks, feature halves
         auto k2r = ppo_epoch_ll2_kernel<2, 4, 32>;
-        const int nw = rows32 ? 4 : (g_epoch_waves8 ? 8 : 4);
-        const int ki = (d->obs_dim <= 16 ? 0 : 1) + (rows32 ? 4 : (nw == 8 ? 2 : 0));
-        auto kern = ki == 0 ? k1 : (ki == 1 ? k2 : (ki == 2 ? k1h : (ki == 3 ? k2h : (ki == 4 ? k1r : k2r))));
-        static bool attr_2[6] = {false, false, false, false, false, false};
+        auto k1q = ppo_epoch_ll2_kernel<1, 8, 32>;   // round 6: 32-row blocks, feature quarters (two waves per SIMD)
+        auto k2q = ppo_epoch_ll2_kernel<2, 8, 32>;
+        const int nw = rows32 ? (g_epoch_quarters ? 8 : 4) : (g_epoch_waves8 ? 8 : 4);
+        const int ki = (d->obs_dim <= 16 ? 0 : 1) + (rows32 ? (nw == 8 ? 6 : 4) : (nw == 8 ? 2 : 0));
+        decltype(k1) kerns[8] = {k1, k2, k1h, k2h, k1r, k2r, k1q, k2q};
+        auto kern = kerns[ki];
+        static bool attr_2[8] = {false, false, false, false, false, false, false, false};
         if (!attr_2[ki]) { rc = set_lds(kern, EPOCH_LL_LDS); if (rc) return rc; attr_2[ki] = true; }
         EpochLl el{};
         el.base = ll_base;   // (cleared, like the error word, by the gather launch above)

@@ -680,8 +680,9 @@ def test_two_waves_per_simd_epoch_equals_the_four_wave_form(D, A, discrete, T, n
     every tile is accumulated by the same MFMAs in the same order, so with a clip threshold nothing reaches (the sum of squares
     is folded by twice as many waves: the norm may differ in its last bit) parameters, transposed copy, Adam moments and the
     loss statistics are bit-identical over three epochs; with the default threshold they agree to the last few bits. The
-    default form (0: 32-row blocks up to 1 024-row minibatches -- the rows' contraction in two slabs instead of one) agrees
-    within the tolerance of the oracle comparison and is deterministic."""
+    default form (0: 32-row blocks up to 1 024-row minibatches -- the rows' contraction in two slabs instead of one --, eight
+    waves = two row groups x four feature QUARTERS) agrees within the tolerance of the oracle comparison, is deterministic, and
+    is bit-identical in the same sense to its four-wave form (7: feature halves)."""
     pol_ref = _oracle_policy(D, A, 64, discrete, True, seed=5)
     rng = np.random.default_rng(1)
     obs = rng.standard_normal((T, n, D)).astype(np.float32)
@@ -696,7 +697,7 @@ def test_two_waves_per_simd_epoch_equals_the_four_wave_form(D, A, discrete, T, n
     for max_norm in (1e9, 0.5):
         outs = []
         try:
-            for mode in (5, 6, 0, 0):
+            for mode in (5, 6, 0, 0, 7):
                 dp = DevPolicy(pol_ref, D, A, 64, discrete, True)
                 ws = th.empty(int(L.load().ia_ppo_ws_floats(C.byref(dp.d), bs, T * n)), device=DEV)
                 ws.uniform_(-1e30, 1e30)   # (the workspace arrives uninitialised)
@@ -712,7 +713,7 @@ def test_two_waves_per_simd_epoch_equals_the_four_wave_form(D, A, discrete, T, n
                 outs.append(((dp.P.clone(), dp.Pt.clone(), dp.m.clone(), dp.v.clone(), dp.nm.clone(), dp.nv.clone()), stats.clone()))
         finally:
             L.load().ia_ppo_epoch_split(0)
-        (xs, st_x), (ys, st_y), (zs, st_z), (zs2, st_z2) = outs
+        (xs, st_x), (ys, st_y), (zs, st_z), (zs2, st_z2), (hs, st_h) = outs
         assert float(ys[0].abs().sum()) > 0 and bool(th.isfinite(ys[0]).all()) and bool(th.isfinite(zs[0]).all())
         if max_norm > 1e8:
             for name, x, y in zip(names, xs, ys):
@@ -729,6 +730,13 @@ def test_two_waves_per_simd_epoch_equals_the_four_wave_form(D, A, discrete, T, n
         for name, z, z2 in zip(names, zs, zs2):
             assert th.equal(z, z2), f"default form, run to run, {name}"
         assert th.equal(st_z, st_z2)
+        if max_norm > 1e8:   # quarters against halves on the same 32-row blocks (64-row blocks when they do not apply: 6 == 6)
+            for name, z, hh in zip(names, zs, hs):
+                assert th.equal(z, hh), f"quarters / halves, {name}: {int((z != hh).sum())} of {z.numel()} differ"
+            assert th.equal(st_z[..., :6], st_h[..., :6])
+        else:
+            for name, z, hh in zip(names, zs, hs):
+                th.testing.assert_close(z, hh, rtol=(1 + k) * 1e-6, atol=(1 + k) * 2e-7, msg=lambda m, name=name: f"quarters / halves, {name}: {m}")
 
 
 @pytest.mark.parametrize("shape,B,A", [((4, 36, 36), 8, 6), ((3, 44, 52), 5, 4), ((1, 36, 40), 33, 18),
