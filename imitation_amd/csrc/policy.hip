@@ -3999,9 +3999,10 @@ __device__ __forceinline__ void t64_tower_minibatch(
 }
 
 // ---------------------------------------------------------------------------------------------
-// Round 6: the same chain with every layer's output tiles split between TWO waves per group of 16 rows. Wave w = (q, h) =
-// (w % NQ, w / NQ), NQ = RB / 16 row groups, owns rows 16 q .. of the block like wave q above, but only the output tiles 2 h,
-// 2 h + 1 of every layer (features 32 h .. 32 h + 31): half the MFMAs and half the tanh / store work per wave. The k index of
+// Round 6: the same chain with every layer's output tiles split between the NH = 2 (or 4) waves of a group of 16 rows. Wave
+// w = (q, h) = (w % NQ, w / NQ), NQ = RB / 16 row groups, owns rows 16 q .. of the block like wave q above, but only the output
+// tiles 2 h, 2 h + 1 of every layer (features 32 h .. 32 h + 31; quarters: tile h): half the MFMAs and half the tanh / store
+// work per wave. The k index of
 // a layer runs over all 64 features of the layer below: a wave's own half is in its registers, its partner's half comes from
 // the `[feature][row]` tile the partner writes anyway (one workgroup barrier per layer; the next layer's weight fragments are
 // requested ahead of it). Head and per-row losses (16 MFMAs, no weights to split) are computed by both waves of a pair. Two
@@ -4013,6 +4014,10 @@ __device__ __forceinline__ void t64_tower_minibatch(
 //   * RB = 32, four waves (one per SIMD): twice the workgroups per minibatch, each with half the chain AND half the
 //     weight-gradient MFMAs (contractions over 32 rows) per compute unit -- at the price of twice the slabs in phase B1 and
 //     twice the readers of the parameter words. Wave w takes output tile w of every weight-gradient product.
+//   * RB = 32, EIGHT waves = two row groups x four feature QUARTERS (NH = 4; the default up to 1 024-row minibatches): one
+//     output tile per wave and layer, all four k tiles of the layer below read from the `[feature][row]` tile behind the
+//     barrier; head and per-row losses by the row group's first wave alone, d head / dv handed to the other three through LDS
+//     behind one more barrier; weight-gradient tiles by the wave's number as in the 64-row eight-wave form.
 // The row tiles' stride is TS = RB + 4 floats (an odd number of quads: sixteen lanes' ds_read_b128 of consecutive features hit
 // distinct bank quads), the 64-wide weight images keep RS = 68.
 template <int KT1, int RB, int NW, class Mid>

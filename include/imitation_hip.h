@@ -540,11 +540,12 @@ int ia_ppo_debug_timing(void* device_buffer_16xi64);
  * chain of the 32-wide persistent kernel (activations in registers from x to dz1, weight fragments as one ds_read_b128
  * of a padded LDS image; [SB3 PPO.train] on the default MlpPolicy). Wider observations keep `ppo_epoch_ll_kernel`;
  * minibatches of more than 32 row blocks (or towers whose images do not fit in LDS) the barrier form (3).
- * Round 6, inside `ppo_epoch_ll2_kernel`: minibatches of up to 1 024 rows run on 32-ROW blocks (four waves: two row groups x
- * two halves of every layer's output features; twice the workgroups, half the chain and half the weight-gradient tiles per
- * compute unit), larger ones on 64-row blocks with eight waves per tower workgroup (two per SIMD);
+ * Round 6, inside `ppo_epoch_ll2_kernel`: minibatches of up to 1 024 rows run on 32-ROW blocks (eight waves: two row groups x
+ * four quarters of every layer's output features; twice the workgroups, half the chain and half the weight-gradient tiles per
+ * compute unit), larger ones on 64-row blocks with eight waves per tower workgroup (feature halves, two waves per SIMD);
  * 5 = round 5's form (64-row blocks, four waves, every wave all output features); 6 = the eight-wave 64-row form also where
- * the 32-row blocks apply (its gradients are bit-identical to 5's: same MFMAs in the same order per tile). */
+ * the 32-row blocks apply (its gradients are bit-identical to 5's: same MFMAs in the same order per tile); 7 = 32-row blocks
+ * on four waves (feature halves; bit-identical to the default's quarters in the same sense). */
 int ia_ppo_epoch_split(int on);
 /* Measurement only: device buffer of 64 int64 (NULL: off); workgroup 0 of the one-launch-per-epoch kernel accumulates
  * 100 MHz ticks per phase in [0..5] = {gradient, barrier, slab sum, barrier, norm + Adam, barrier}; [16..27] / [32..43]:
