@@ -150,6 +150,7 @@ _SIGS = {
     "ia_mlp_param_count": ([C.POINTER(MlpDesc)], C.c_int64),
     "ia_mlp_hidden_floats_per_row": ([C.POINTER(MlpDesc)], C.c_int64),
     "ia_gemm_f32": ([_I, _P, _I, _P, _I, _P, _I, _I, _I, _I, _P, _I, _P, _I, _I, _P, _P], C.c_int),
+    "ia_gemm_f32_nt_splitk": ([_P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _P, _I, _I, _P], C.c_int),
     "ia_gemm_set_config": ([_I], C.c_int),
     "ia_prof_enable": ([_I], C.c_int),
     "ia_prof_collect": ([_P, _P, _P], C.c_int),

@@ -272,6 +272,22 @@ class ActorCriticCnnPolicy:
 
     takes_uint8_frames = True   # (`PPO`: the rollout tile's host rows and their transfer are uint8 for this policy)
 
+    # rows of a weight gradient's contraction per K split (<= 64 splits): a convolution's [64 x 512] gradient is 8 output tiles
+    # -- at 2 048 rows per split a 256-frame minibatch (20 736 rows) ran on 80 workgroups of 64 K chunks each
+    WGRAD_ROWS_PER_SPLIT = 512
+    LINEAR_SPLIT_K = True   # (False: the feature layer's product unsplit at every batch size -- same-box A/Bs)
+
+    def _linear_splits(self, B: int) -> int:
+        """K splits of the `linear` layer's forward product at batch `B`: 1 once its 64 x 64 output tiles alone fill the
+        device (BC's batches), else as many slabs of >= 8 K chunks as bring the launch to ~256 workgroups."""
+        if not self.LINEAR_SPLIT_K or self.features_dim % 4:
+            return 1
+        tiles = -(-B // 64) * -(-self.features_dim // 64)
+        if tiles >= 128:
+            return 1
+        chunks = self.n_flatten // 32
+        return int(max(1, min(chunks // 8, 256 // tiles)))
+
     def _obs_u8(self, obs) -> th.Tensor:
         t = obs if isinstance(obs, th.Tensor) else th.as_tensor(np.ascontiguousarray(obs))
         if t.dtype != th.uint8:
@@ -303,8 +319,18 @@ class ActorCriticCnnPolicy:
                 L.call("ia_im2col_f32_nhwc", L.ptr(d[f"act{li - 1}"]), B, h, w_, cin, k, k, s, L.ptr(d[f"col{li}"]), L.stream())
             self._gemm(0, d[f"col{li}"], K, self.w(li), K, d[f"act{li}"], cout, B * oh * ow, cout, K, bias=self.b(li), act=1)
         flat = d["act2"].view(B, self.n_flatten)     # (h, w, c) order: linear.0's columns are stored to match
-        self._gemm(0, flat, self.n_flatten, self.w(3), self.n_flatten, d["feat"], self.features_dim, B, self.features_dim,
-                   self.n_flatten, bias=self.b(3), act=1)
+        sk = self._linear_splits(B)
+        if sk > 1:
+            # few output tiles, long K (rollout steps and PPO minibatches: 8 - 32 tiles of 64 x 64 with 98 K chunks each on as
+            # many of the 256 compute units): the product split along K, bias + ReLU behind the ordered sum of the slabs
+            if "feat_parts" not in d:
+                d["feat_parts"] = th.empty(sk, B, self.features_dim, device=self.device)
+            L.call("ia_gemm_f32_nt_splitk", L.ptr(flat), self.n_flatten, L.ptr(self.w(3)), self.n_flatten,
+                   L.ptr(d["feat_parts"]), L.ptr(d["feat"]), self.features_dim, B, self.features_dim, self.n_flatten,
+                   L.ptr(self.b(3)), 1, sk, L.stream())
+        else:
+            self._gemm(0, flat, self.n_flatten, self.w(3), self.n_flatten, d["feat"], self.features_dim, B,
+                       self.features_dim, self.n_flatten, bias=self.b(3), act=1)
         F_ = self.features_dim
         self._gemm(0, d["feat"], F_, self.w(4), F_, d["logits"], self.n_actions, B, self.n_actions, F_, bias=self.b(4))
         self._gemm(0, d["feat"], F_, self.w(5), F_, d["values"] if values_out is None else values_out, 1, B, 1, F_,
@@ -340,7 +366,7 @@ class ActorCriticCnnPolicy:
         """grad[w_li] += dout^T . inp ; grad[b_li] += column sums of dout   (split-K TN GEMM + ordered reduction).
         `im = (H, W, Cin, k, stride)`: `inp` is the layer's channel-last INPUT and the [rows, K] operand its implicit
         im2col view."""
-        splits = int(min(64, max(1, rows // 2048)))
+        splits = int(min(64, max(1, rows // self.WGRAD_ROWS_PER_SPLIT)))
         part = th.empty(splits, n_out, K, device=self.device)
         db = th.empty(splits, n_out, device=self.device)
         if im is not None:

@@ -53,6 +53,7 @@ struct IaGemm {
   int act;              // NT: epilogue activation; NN: derivative kind applied with P
   const float* P;       // NN: post-activation values of the layer whose input-grad this is
   int ldp;
+  int nt_split;         // NT only: the K splits below apply, slab s of C receives split s's products WITHOUT bias / activation
   int splits;           // TN: number of K splits (grid.z)
   int k_per_split;      // TN: rows of K handled by one split (multiple of 32)
   long long c_split_stride;   // TN: elements between consecutive split slabs of C

@@ -402,7 +402,8 @@ __device__ __forceinline__ void gemm_tile(const IaGemm& g, const TileCtx& tc, fl
     __syncthreads();
   }
   float* C = g.C;
-  if (MODE == IA_GEMM_TN) C += (long long)tc.split * g.c_split_stride;
+  const bool nt_part = MODE == IA_GEMM_NT && !IM && g.nt_split != 0;   // (block-uniform) slab of a split-K forward product
+  if (MODE == IA_GEMM_TN || nt_part) C += (long long)tc.split * g.c_split_stride;
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -417,7 +418,7 @@ __device__ __forceinline__ void gemm_tile(const IaGemm& g, const TileCtx& tc, fl
         if (FAST || (row < g.M && col < g.N)) {
           float v = acc[i][j][r];
           if (MODE == IA_GEMM_NT) {
-            v = ia_apply_act(v + bcol, g.act);
+            if (!nt_part) v = ia_apply_act(v + bcol, g.act);
           } else if (MODE == IA_GEMM_NN) {
             if (g.P != nullptr)
               v *= ia_act_grad_from_post(PREP ? pv[PREP ? i : 0][PREP ? j : 0][r] : g.P[(long long)row * g.ldp + col], g.act);
@@ -464,7 +465,7 @@ __device__ __forceinline__ void gemm_block(const IaGemm& g, float* smem, const i
   tc.bn0 = (t % tiles_n) * BN;
   tc.k_begin = 0;
   tc.k_end = g.K;
-  if (MODE == IA_GEMM_TN) {
+  if (MODE == IA_GEMM_TN || (MODE == IA_GEMM_NT && !IM && g.nt_split != 0)) {
     tc.k_begin = tc.split * g.k_per_split;
     tc.k_end = min(g.K, tc.k_begin + g.k_per_split);
   }
@@ -548,7 +549,7 @@ int launch_cfg(const IaGemm& g, hipStream_t stream) {
     attr_set = true;
   }
   const int tiles = ((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN);
-  dim3 grid(tiles * (MODE == IA_GEMM_TN ? g.splits : 1));
+  dim3 grid(tiles * ((MODE == IA_GEMM_TN || (MODE == IA_GEMM_NT && !IM && g.nt_split != 0)) ? g.splits : 1));
   const bool prof = g_prof_on && g_prof_n < PROF_POOL;
   if (prof) (void)hipEventRecord(g_prof_ev[g_prof_n][0], stream);
   hipLaunchKernelGGL(kern, grid, dim3(NT), smem, stream, g);
@@ -709,6 +710,52 @@ extern "C" int ia_gemm_f32(int mode, const float* A, int lda, const float* B, in
   g.c_split_stride = (long long)M * ldc;
   g.dbias_split_stride = M;
   return ia_launch_gemm(mode, g, (hipStream_t)stream);
+}
+
+// Forward product of a layer with FEW output tiles and a long K (the NatureCNN's 3 136 -> 512 linear layer at rollout / minibatch
+// sizes: 8 - 32 tiles of 64 x 64, 98 K chunks each on 8 - 32 of 256 compute units): split along K into `splits` slabs of
+// `partials` [splits][M][N] (one launch), then C = act(sum of the slabs in split order + bias) (`reduce_bias_act_kernel`).
+// Deterministic; the sum order differs from the unsplit product's (fp32 rounding).
+namespace {
+__global__ void reduce_bias_act_kernel(const float* __restrict__ partials, int splits, int M, int N, const float* __restrict__ bias,
+                                       int act, float* __restrict__ C, int ldc) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;   // element quad
+  const long long n = (long long)M * N;
+  if (4 * i >= n) return;
+  const int row = (int)((4 * i) / N), col = (int)((4 * i) - (long long)row * N);
+  f4 s = {0.f, 0.f, 0.f, 0.f};
+  for (int k = 0; k < splits; ++k) {
+    const f4 t = *reinterpret_cast<const f4*>(partials + (long long)k * n + 4 * i);
+    s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+  }
+  if (bias != nullptr) {
+    const f4 b = *reinterpret_cast<const f4*>(bias + col);
+    s.x += b.x; s.y += b.y; s.z += b.z; s.w += b.w;
+  }
+  f4 o = {ia_apply_act(s.x, act), ia_apply_act(s.y, act), ia_apply_act(s.z, act), ia_apply_act(s.w, act)};
+  *reinterpret_cast<f4*>(C + (long long)row * ldc + col) = o;
+}
+}  // namespace
+
+extern "C" int ia_gemm_f32_nt_splitk(const float* A, int lda, const float* B, int ldb, float* partials, float* C, int ldc, int M,
+                                     int N, int K, const float* bias, int act, int splits, void* stream) {
+  if (splits < 1 || M <= 0 || N <= 0 || K <= 0 || (N & 3) || (ldc & 3) || partials == nullptr ||
+      ((reinterpret_cast<uintptr_t>(partials) | reinterpret_cast<uintptr_t>(C) | reinterpret_cast<uintptr_t>(bias)) & 15))
+    return IA_ERR_ARG;
+  IaGemm g{};
+  g.A = A; g.B = B; g.C = partials; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = N;
+  g.bias = nullptr; g.act = 0;
+  g.nt_split = 1;
+  g.splits = splits;
+  g.k_per_split = ((K + splits - 1) / splits + BK - 1) / BK * BK;
+  g.c_split_stride = (long long)M * N;
+  int rc = ia_launch_gemm(IA_GEMM_NT, g, (hipStream_t)stream);
+  if (rc) return rc;
+  const long long quads = ((long long)M * N) >> 2;
+  hipLaunchKernelGGL(reduce_bias_act_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, (hipStream_t)stream, partials,
+                     splits, M, N, bias, act, C, ldc);
+  IA_CHECK_LAUNCH();
+  return IA_OK;
 }
 
 // ia_gemm_f32 with the k-contiguous [rows, KH*KW*Cin] operand of a convolution given IMPLICITLY as the im2col view of

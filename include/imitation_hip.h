@@ -60,6 +60,12 @@ int64_t ia_mlp_hidden_floats_per_row(const ia_mlp_desc* d);
 int ia_gemm_f32(int mode, const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N,
                 int K, const float* bias, int act, const float* P, int ldp, int splits, float* dbias,
                 void* stream);
+/* mode 0 with the product split along K: slab s of `partials` [splits][M][N] receives split s's products, then
+ * C = act(sum of the slabs in split order + bias) -- for layers with few output tiles and a long K (the NatureCNN's
+ * 3 136 -> 512 `linear` at rollout / minibatch sizes: [SB3 NatureCNN.linear], `/root/reference/src/imitation/policies/base.py`
+ * builds it through SB3's `ActorCriticCnnPolicy`). N and ldc multiples of 4, pointers 16-byte aligned. Deterministic. */
+int ia_gemm_f32_nt_splitk(const float* A, int lda, const float* B, int ldb, float* partials, float* C, int ldc, int M, int N,
+                          int K, const float* bias, int act, int splits, void* stream);
 
 /* Measurement only (bench.py): when enabled every GEMM launch is bracketed by hipEvents on its
  * launch stream; collect() returns per-kernel totals for the 12 kernels (id = mode*4 + tile

@@ -71,6 +71,28 @@ def test_gemm_nt(M, N, K):
         th.testing.assert_close(got[0].cpu(), ref, rtol=2e-5, atol=2e-5 * math.sqrt(K))
 
 
+@pytest.mark.parametrize("M,N,K,splits", [(64, 512, 3136, 12), (256, 512, 3136, 8), (5, 512, 3136, 12), (70, 36, 100, 3),
+                                          (33, 64, 64, 1), (64, 128, 96, 7)])
+def test_gemm_nt_split_along_k(M, N, K, splits):
+    """`ia_gemm_f32_nt_splitk` (the NatureCNN `linear` layer at rollout / minibatch sizes): C = act(A . B^T + bias) with the
+    product in `splits` K slabs (empty trailing slabs included), bias and activation behind their ordered sum; float64 reference."""
+    A, B, b = rnd(M, K, seed=1), rnd(N, K, seed=2), rnd(N, seed=3)
+    dA, dB, db = dev(A), dev(B), dev(b)   # (kept alive across the launches)
+    for act, f in [(0, lambda x: x), (1, th.relu)]:
+        parts = th.full((splits, M, N), float("nan"), device=DEV)
+        out = th.full((M, N), float("nan"), device=DEV)
+        L.call("ia_gemm_f32_nt_splitk", L.ptr(dA), K, L.ptr(dB), K, L.ptr(parts), L.ptr(out), N, M, N, K, L.ptr(db), act, splits,
+               L.stream())
+        th.cuda.synchronize()
+        ref = f(A.double() @ B.double().T + b.double()).float()
+        th.testing.assert_close(out.cpu(), ref, rtol=2e-5, atol=2e-5 * math.sqrt(K))
+        got2 = th.empty_like(out)   # deterministic
+        L.call("ia_gemm_f32_nt_splitk", L.ptr(dA), K, L.ptr(dB), K, L.ptr(parts), L.ptr(got2), N, M, N, K, L.ptr(db), act, splits,
+               L.stream())
+        th.cuda.synchronize()
+        assert th.equal(out, got2)
+
+
 @pytest.mark.parametrize("M,N,K", [(128, 128, 32), (1000, 23, 256), (16384, 256, 256), (70, 33, 1), (513, 64, 32)])
 def test_gemm_nn_with_activation_grad(M, N, K):
     A, B = rnd(M, K, seed=1), rnd(K, N, seed=2)

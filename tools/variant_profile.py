@@ -14,5 +14,9 @@ if os.environ.get("IA_EPOCH_SPLIT"):   # A/B of the 64-wide epoch kernels (inclu
 if os.environ.get("IA_GRAPH") == "0":   # A/B of the graph-replayed module-policy updates
     from imitation_amd import general_policy
     general_policy.GRAPH_UPDATES = False
+if os.environ.get("IA_IMG_OLD"):   # A/B of the NatureCNN policy's launch shapes (round 5's: unsplit linear layer, 2 048-row splits)
+    from imitation_amd import cnn_policy
+    cnn_policy.ActorCriticCnnPolicy.LINEAR_SPLIT_K = False
+    cnn_policy.ActorCriticCnnPolicy.WGRAD_ROWS_PER_SPLIT = 2048
 name = sys.argv[1] if len(sys.argv) > 1 else "3_airl_ant_1024x16_mb1024"
 print(name, bench.run_variant(name, rounds=int(sys.argv[2]) if len(sys.argv) > 2 else 6))
