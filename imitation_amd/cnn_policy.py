@@ -589,6 +589,10 @@ class ActorCriticCnnPolicy:
         s = L.stream()
         offs = (perm_dev % T) * n + perm_dev // T          # time-major row of every permuted index
         obs_rows, act_rows = rb.obs.reshape((T + 1) * n, D), rb.acts.reshape(total, aw)
+        rows_x = getattr(rb, "_obs_x", None) if getattr(rb, "obs_u8", False) else None
+        if rows_x is not None and not (rows_x.dtype == th.uint8 and rows_x.is_contiguous() and D % 4 == 0 and
+                                       rows_x.numel() == (T + 1) * n * D):
+            rows_x = None
         vecs = ((rb.logp.reshape(total, 1), "old"), (rb.adv.reshape(total, 1), "adv"), (rb.ret.reshape(total, 1), "ret"))
         opt = self.optimizer
         grad = opt.grad
@@ -600,9 +604,16 @@ class ActorCriticCnnPolicy:
             for mb, start in enumerate(range(0, total, batch_size)):
                 b = min(batch_size, total - start)
                 idx = offs[e, start:start + b]
-                rows = th.empty(b, D, device=dev)
-                L.call("ia_gather_rows", L.ptr(obs_rows), L.ptr(idx), b, D, L.ptr(rows), s)
-                d = self._forward(self._rows_u8(rows))
+                if rows_x is not None:
+                    # the rollout tile's uint8 transport copy (`RolloutBuffer(obs_u8=True)`): the rows are gathered as they
+                    # are -- four frame bytes per 4-byte element -- instead of as fp32 rows converted back to uint8
+                    rows = th.empty(b, D, dtype=th.uint8, device=dev)
+                    L.call("ia_gather_rows", L.ptr(rows_x), L.ptr(idx), b, D // 4, L.ptr(rows), s)
+                    d = self._forward(rows.view(b, *self.observation_space.shape))
+                else:
+                    rows = th.empty(b, D, device=dev)
+                    L.call("ia_gather_rows", L.ptr(obs_rows), L.ptr(idx), b, D, L.ptr(rows), s)
+                    d = self._forward(self._rows_u8(rows))
                 if "old" not in d:
                     d.update(old=th.empty(b, device=dev), adv=th.empty(b, device=dev), ret=th.empty(b, device=dev),
                              ms=th.empty(2, device=dev),
