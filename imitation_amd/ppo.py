@@ -360,9 +360,12 @@ class RolloutBuffer:
         # block with the same layout (seven separate copies cost ~10 us of copy-engine latency each, on the
         # critical path between the last env step and the PPO update).
         frame_dt = th.uint8 if self.obs_u8 else th.float32
-        spec = [("_obs_x" if self.obs_u8 else "obs", (T + 1, n, obs_dim), frame_dt), ("clipped", (T, n, act_width), th.float32),
-                ("_next_x" if self.obs_u8 else "next_fixed", (T, n, obs_dim), frame_dt), ("starts", (T, n), th.float32),
-                ("last_done", (n,), th.float32), ("dones", (T, n), th.uint8), ("trunc", (T, n), th.uint8)]
+        # (the two frame tiles first, the small tiles contiguous behind them: `upload_host_tiles(from_step=)` takes the frames'
+        #  tails and the small tiles as three copies)
+        spec = [("_obs_x" if self.obs_u8 else "obs", (T + 1, n, obs_dim), frame_dt),
+                ("_next_x" if self.obs_u8 else "next_fixed", (T, n, obs_dim), frame_dt), ("clipped", (T, n, act_width), th.float32),
+                ("starts", (T, n), th.float32), ("last_done", (n,), th.float32), ("dones", (T, n), th.uint8),
+                ("trunc", (T, n), th.uint8)]
         nbytes = sum(-(-int(np.prod(shape)) * th.empty(0, dtype=dt).element_size() // 256) * 256 for _, shape, dt in spec)
         self._dev_block = th.zeros(nbytes, dtype=th.uint8, device=device)
         self._host_block = th.zeros(nbytes, dtype=th.uint8).pin_memory()
@@ -373,6 +376,8 @@ class RolloutBuffer:
             size = int(np.prod(shape)) * th.empty(0, dtype=dt).element_size()
             setattr(self, name, self._dev_block[off:off + size].view(dt).view(*shape))
             setattr(self, host_names[name], self._host_block[off:off + size].view(dt).view(*shape))
+            if name == "clipped":
+                self._small_off = off   # (first byte of the small tiles)
             off += -(-size // 256) * 256
         if self.obs_u8:   # (one slice more than T: `ia_ppo_update*`'s 16-byte row pieces, include/imitation_hip.h)
             self.obs, self.next_fixed = f(T + 1, n, obs_dim), f(T, n, obs_dim)
@@ -392,12 +397,32 @@ class RolloutBuffer:
             self.h_logits = th.zeros(self.n_envs, n_actions).pin_memory()
             self.h_logp = th.zeros(self.buffer_size, self.n_envs).pin_memory()
 
-    def upload_host_tiles(self) -> None:
-        """One H2D copy of everything the env loop wrote on the host (current stream); uint8 frames -> the fp32 tiles."""
-        self._dev_block.copy_(self._host_block, non_blocking=True)
+    def upload_host_tiles(self, from_step: int = 0) -> None:
+        """One H2D copy of everything the env loop wrote on the host (current stream); uint8 frames -> the fp32 tiles.
+        `from_step` > 0: the frame rows of steps < from_step are on the device already (`upload_host_steps`): the frames'
+        tails and the small tiles, three copies."""
+        ox, nx = (self._obs_x, self._next_x) if self.obs_u8 else (self.obs, self.next_fixed)
+        if from_step <= 0:
+            self._dev_block.copy_(self._host_block, non_blocking=True)
+        else:
+            ox[from_step:].copy_(self.h_obs[from_step:], non_blocking=True)
+            nx[from_step:].copy_(self.h_next[from_step:], non_blocking=True)
+            self._dev_block[self._small_off:].copy_(self._host_block[self._small_off:], non_blocking=True)
         if self.obs_u8:
-            self.obs.copy_(self._obs_x)
-            self.next_fixed.copy_(self._next_x)
+            self.obs[from_step:].copy_(self._obs_x[from_step:])
+            self.next_fixed[from_step:].copy_(self._next_x[from_step:])
+
+    def upload_host_steps(self, t1: int) -> None:
+        """Steps [0, t1) of what a reward net reads (observations, next observations, clipped actions, dones) ahead of the whole
+        upload -- the rows are final once their steps are done (current stream)."""
+        ox, nx = (self._obs_x, self._next_x) if self.obs_u8 else (self.obs, self.next_fixed)
+        ox[:t1].copy_(self.h_obs[:t1], non_blocking=True)
+        nx[:t1].copy_(self.h_next[:t1], non_blocking=True)
+        self.clipped[:t1].copy_(self.h_clip[:t1], non_blocking=True)
+        self.dones[:t1].copy_(self.h_dones[:t1], non_blocking=True)
+        if self.obs_u8:
+            self.obs[:t1].copy_(self._obs_x[:t1])
+            self.next_fixed[:t1].copy_(self._next_x[:t1])
 
     def reset(self) -> None:
         self.full = False
@@ -535,6 +560,11 @@ class PPO(OnPolicyAlgorithm):
         # relabelling + reward copy + GAE behind a rollout's last step as one host call where the reward net allows it
         # (`_rollout_tail_args`; False: the general path, call by call -- tests compare)
         self.rollout_tail_one_call = True
+        # `nn.Module` reward nets relabelled in bulk behind the rollout: the rows of the rollout's first three quarters are
+        # uploaded and relabelled WHILE the host steps the environments through the last quarter (rows are independent; the
+        # reward net is final once the previous round's updates are through -- `before_relabel` -- and those run behind the
+        # first part of the rollout). False: everything behind the last step (tests compare)
+        self.relabel_early = True
         self._tail_args = None
         self._post_enqueue_work = []
         self._act_stream = None
@@ -843,6 +873,18 @@ class PPO(OnPolicyAlgorithm):
             ev.record()
         self._perm_uploaded = ev
 
+    def _relabel_module_rows(self, rb, module_net, pol, row_lo: int, row_hi: int, T: int, n: int) -> None:
+        """`rb.rew` rows [row_lo, row_hi) (time-major) <- `module_net.predict_th` of the rollout tile's rows (current stream)."""
+        osp = self.observation_space
+        S, NS = rb.obs[:T].reshape(T * n, *osp.shape), rb.next_fixed.reshape(T * n, *osp.shape)
+        A_ = rb.clipped.reshape(T * n).long() if pol.discrete else rb.clipped.reshape((T * n, *self.action_space.shape))
+        D_, out = rb.dones.reshape(T * n), rb.rew.view(-1)
+        # (chunks of 1 024 rows: rows are independent, the chunk size only bounds the transient activations -- 1.9 GB for the
+        #  default CnnRewardNet on 84 x 84 frames -- and a 256-row chunk left the convolutions' launches four times as many)
+        for lo in range(row_lo, row_hi, 1024):
+            hi = min(row_hi, lo + 1024)
+            out[lo:hi] = module_net.predict_th(S[lo:hi], A_[lo:hi], NS[lo:hi], D_[lo:hi])
+
     def _rollout_steps(self, env, callback, rb, T, n, pol, rw, bw, base, fused_net, module_net, act_step, mailbox,
                        act_stream, host_sampling, predrawn, starts, per_step_rews, prof, tick, h_clip_np, h_rew_np,
                        h_dones_np, h_trunc_np, h_next_np, h_obs_np, h_starts_np, stream) -> bool:
@@ -854,6 +896,8 @@ class PPO(OnPolicyAlgorithm):
         # in place already: pre-drawn tiles or host-side sampling.)
         post_ahead = self.rollout_post_ahead and (host_sampling or predrawn)
         posted = -1   # the last step posted to the mailbox
+        early_at = (3 * T) // 4 if (module_net is not None and self.relabel_early and T >= 8) else 0
+        early_T = 0   # steps whose rows are relabelled already
         for t in range(T):
             t0 = tick() if prof is not None else 0.0
             if not host_sampling and not predrawn:
@@ -922,6 +966,13 @@ class PPO(OnPolicyAlgorithm):
             self._last_obs, starts = new_obs, np.asarray(dones, dtype=bool)
             if t >= 1 and self._perm_uploaded is None:
                 self._upload_permutations_early(stream)
+            if t + 1 == early_at:
+                # (the copies first: a copy enqueued behind the stream's wait for the updates would hold back every later copy)
+                rb.upload_host_steps(early_at)
+                if self.before_relabel is not None:
+                    self.before_relabel()
+                self._relabel_module_rows(rb, module_net, pol, 0, early_at * n, T, n)
+                early_T = early_at
             if prof is not None:
                 prof["bookkeeping"] = prof.get("bookkeeping", 0.0) + tick() - prof.pop("_t_book")
         self._last_episode_starts = starts
@@ -934,14 +985,14 @@ class PPO(OnPolicyAlgorithm):
             last_val_done = True   # V of it (the GAE bootstrap) while the host goes on, and leaves
             stream.wait_stream(act_stream)
         rb.h_last_done.copy_(th.as_tensor(starts.astype(np.float32)))
-        rb.upload_host_tiles()
+        rb.upload_host_tiles(from_step=early_T)
         if host_sampling:  # actions (= the clipped tile for Discrete heads) and log-probs were produced on the host
             rb.acts.copy_(rb.clipped)
             rb.logp.copy_(rb.h_logp, non_blocking=True)
         # host time the device had to itself for other streams' work during this rollout (see
         # `AdversarialTrainer._train_pipelined`: where the discriminator updates are scheduled)
         self.rollout_window_ms = 1e3 * (tick() - t_first_step)
-        if self.before_relabel is not None:
+        if self.before_relabel is not None and early_T == 0:   # (else: the stream has waited for the updates already)
             self.before_relabel()
         tail = None
         if (fused_net is not None and rw is not None and self.enqueue_first and self.rollout_tail_one_call and last_val_done
@@ -972,15 +1023,7 @@ class PPO(OnPolicyAlgorithm):
                                     rb.dones.reshape(T * n), pol.discrete)
             rb.rew.copy_(fused_net.predict_processed_rollout(table, T, n).reshape(T, n))
         elif module_net is not None:
-            osp = self.observation_space
-            S, NS = rb.obs[:T].reshape(T * n, *osp.shape), rb.next_fixed.reshape(T * n, *osp.shape)
-            A_ = rb.clipped.reshape(T * n).long() if pol.discrete else rb.clipped.reshape((T * n, *self.action_space.shape))
-            D_, out = rb.dones.reshape(T * n), rb.rew.view(-1)
-            # (chunks of 1 024 rows: rows are independent, the chunk size only bounds the transient activations -- 1.9 GB for the
-            #  default CnnRewardNet on 84 x 84 frames -- and a 256-row chunk left the convolutions' launches four times as many)
-            for lo in range(0, T * n, 1024):
-                hi = min(T * n, lo + 1024)
-                out[lo:hi] = module_net.predict_th(S[lo:hi], A_[lo:hi], NS[lo:hi], D_[lo:hi])
+            self._relabel_module_rows(rb, module_net, pol, early_T * n, T * n, T, n)
         else:
             rb.rew.copy_(rb.h_rew, non_blocking=True)
         if rw is not None:

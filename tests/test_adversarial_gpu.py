@@ -142,6 +142,25 @@ def test_pipelined_rounds_are_bit_identical(tmp_path, case):
         assert len(logs[mode]["progress.csv"]) == 4
 
 
+@pytest.mark.parametrize("case", ["gail_image", "airl_image", "gail_box+module"])
+def test_relabelling_ahead_of_the_last_step_is_bit_identical(tmp_path, case):
+    """`PPO.relabel_early`: an `nn.Module` reward net relabels the rows of the rollout's first three quarters while the host
+    still steps the environments through the last one (partial upload of the host tiles, the stream's wait for the previous
+    round's updates, the net on those rows; the rest behind the last step). Rows are independent: every array equals the
+    schedule that relabels everything behind the last step."""
+    case, module_net = case.split("+")[0], case.endswith("+module")
+    outs = {}
+    for early in (True, False):
+        cfg = harness.CASES[case]
+        tr, _ = harness.build_trainer("hip", cfg, str(tmp_path / f"log_{early}"), device="cuda", module_net=module_net)
+        tr.gen_algo.relabel_early = early
+        assert cfg["n_steps"] >= 8
+        tr.train(3 * cfg["n_envs"] * cfg["n_steps"])
+        outs[early] = harness.snapshot(tr)
+    for k in outs[True]:
+        assert np.array_equal(np.asarray(outs[True][k]), np.asarray(outs[False][k]), equal_nan=True), k
+
+
 def test_all_epochs_in_one_call_equal_one_call_per_epoch(tmp_path):
     """64-wide towers (`gail_cartpole`: 128-row rollouts, PPO minibatch 32, five epochs): `PPO.train` through ONE
     `ia_ppo_epochs` call (the epochs as one sequence of minibatches: one gather, one statistics and one epoch launch) against

@@ -18,5 +18,12 @@ if os.environ.get("IA_IMG_OLD"):   # A/B of the NatureCNN policy's launch shapes
     from imitation_amd import cnn_policy
     cnn_policy.ActorCriticCnnPolicy.LINEAR_SPLIT_K = False
     cnn_policy.ActorCriticCnnPolicy.WGRAD_ROWS_PER_SPLIT = 2048
+if os.environ.get("IA_RELABEL_LATE"):   # A/B: module reward nets relabel the whole rollout behind its last step
+    from imitation_amd import ppo as _ppo
+    _init = _ppo.PPO.__init__
+    def _late(self, *a, **k):
+        _init(self, *a, **k)
+        self.relabel_early = False
+    _ppo.PPO.__init__ = _late
 name = sys.argv[1] if len(sys.argv) > 1 else "3_airl_ant_1024x16_mb1024"
 print(name, bench.run_variant(name, rounds=int(sys.argv[2]) if len(sys.argv) > 2 else 6))
