@@ -32,7 +32,8 @@ inline bool desc_ok(const ia_mlp_desc* d) {
 // ---------------------------------------------------------------- reductions / elementwise
 
 __global__ void reduce_partials_kernel(const float* __restrict__ partials, int splits, long long n, float scale,
-                                       int accumulate, float* __restrict__ grads) {
+                                       int accumulate, float* __restrict__ grads, long long stride) {
+  // (`stride`: elements between consecutive slabs -- n for whole slabs, more when a PIECE of every slab is reduced)
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   float s = 0.f;
@@ -40,11 +41,11 @@ __global__ void reduce_partials_kernel(const float* __restrict__ partials, int s
   for (; k + 8 <= splits; k += 8) {  // 8 independent loads in flight, then a fixed-order sum
     float t[8];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) t[u] = partials[(long long)(k + u) * n + i];
+    for (int u = 0; u < 8; ++u) t[u] = partials[(long long)(k + u) * stride + i];
 #pragma unroll
     for (int u = 0; u < 8; ++u) s += t[u];
   }
-  for (; k < splits; ++k) s += partials[(long long)k * n + i];  // fixed order: deterministic
+  for (; k < splits; ++k) s += partials[(long long)k * stride + i];  // fixed order: deterministic
   s *= scale;
   grads[i] = accumulate ? grads[i] + s : s;
 }
@@ -869,7 +870,46 @@ int ia_reduce_partials(const float* partials, int splits, int64_t n, float scale
                        void* stream) {
   if (n <= 0 || splits < 1) return IA_ERR_ARG;
   hipLaunchKernelGGL(reduce_partials_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, partials,
-                     splits, (long long)n, scale, accumulate, grads);
+                     splits, (long long)n, scale, accumulate, grads, (long long)n);
+  IA_CHECK_LAUNCH();
+  return IA_OK;
+}
+
+int ia_reduce_partials_strided(const float* partials, int splits, int64_t n, int64_t stride, float scale, int accumulate,
+                               float* grads, void* stream) {
+  if (n <= 0 || splits < 1 || stride < n) return IA_ERR_ARG;
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, partials,
+                     splits, (long long)n, scale, accumulate, grads, (long long)stride);
+  IA_CHECK_LAUNCH();
+  return IA_OK;
+}
+
+namespace {
+struct CopyPieces { const float* src[4]; float* dst[4]; long long n[4]; long long start[5]; };
+__global__ void copy_pieces_kernel(CopyPieces c) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= c.start[4]) return;
+  const int p = i >= c.start[2] ? (i >= c.start[3] ? 3 : 2) : (i >= c.start[1] ? 1 : 0);
+  const long long j = i - c.start[p];
+  c.dst[p][j] = c.src[p][j];
+}
+}  // namespace
+
+int ia_copy_pieces(int n_pieces, const float* const* src, float* const* dst, const int64_t* n, void* stream) {
+  if (n_pieces < 1 || n_pieces > 4) return IA_ERR_ARG;
+  CopyPieces c{};
+  long long total = 0;
+  for (int p = 0; p < 4; ++p) {
+    c.start[p] = total;
+    if (p < n_pieces) {
+      if (n[p] < 0) return IA_ERR_ARG;
+      c.src[p] = src[p]; c.dst[p] = dst[p]; c.n[p] = n[p];
+      total += n[p];
+    }
+  }
+  c.start[4] = total;
+  if (total == 0) return IA_OK;
+  hipLaunchKernelGGL(copy_pieces_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, c);
   IA_CHECK_LAUNCH();
   return IA_OK;
 }

@@ -173,6 +173,17 @@ class GeneralTowers:
         if self._pi_stack is None:
             return
         f = self._flat
+        if f.is_cuda:   # the four pieces in one launch (four device-to-device copies per optimiser step before)
+            key = (f.data_ptr(), self._pi_stack.data_ptr(), self._vf_stack.data_ptr())
+            if getattr(self, "_sync_args", (None,))[0] != key:
+                offs = (self._o_pi, self._o_an, self._o_vf, self._o_vn)
+                dsts = (self._pi_stack.data_ptr(), self._pi_stack.data_ptr() + 4 * self._n_pi,
+                        self._vf_stack.data_ptr(), self._vf_stack.data_ptr() + 4 * self._n_vf)
+                self._sync_args = (key, (C.c_void_p * 4)(*(f.data_ptr() + 4 * o for o in offs)), (C.c_void_p * 4)(*dsts),
+                                   (C.c_int64 * 4)(self._n_pi, self._n_an, self._n_vf, self._n_vn))
+            _, src, dst, ns = self._sync_args
+            L.call("ia_copy_pieces", 4, src, dst, ns, L.stream())
+            return
         self._pi_stack[: self._n_pi].copy_(f[self._o_pi:self._o_pi + self._n_pi])
         self._pi_stack[self._n_pi:].copy_(f[self._o_an:self._o_an + self._n_an])
         self._vf_stack[: self._n_vf].copy_(f[self._o_vf:self._o_vf + self._n_vf])
@@ -482,10 +493,12 @@ class GeneralTowers:
                     part = ws["part"].reshape(-1)[: sp * P]
                     L.call("ia_mlp_backward", C.byref(desc), L.ptr(stack), L.ptr(ws["x"]), D, b, L.ptr(hid), L.ptr(dout),
                            L.ptr(ws["dhid"]), L.ptr(part), sp, None, s)
-                    L.call("ia_reduce_partials", L.ptr(part), sp, P, 1.0, 0, L.ptr(g), s)
+                    # the tower's slabs reduced straight into the two pieces of the flat gradient (its layers | its head): the
+                    # same sums as one reduction of the whole stack followed by two copies
                     (o0, n0), (o1, n1) = pieces
-                    grad[o0:o0 + n0].copy_(g[:n0])
-                    grad[o1:o1 + n1].copy_(g[n0:])
+                    if n0:   # (a tower without hidden layers has no first piece)
+                        L.call("ia_reduce_partials_strided", L.ptr(part), sp, n0, P, 1.0, 0, L.ptr(grad[o0:o0 + n0]), s)
+                    L.call("ia_reduce_partials_strided", L.ptr(part[n0:]), sp, n1, P, 1.0, 0, L.ptr(grad[o1:o1 + n1]), s)
                 if dp is not None and dp.world > 1:
                     dp.allreduce_mean_(grad)
                 L.call("ia_clip_grad_norm", L.ptr(grad), grad.numel(), float(max_grad_norm), None, L.ptr(clip_ws), s)

@@ -92,6 +92,14 @@ int ia_mlp_backward(const ia_mlp_desc* d, const float* params, const float* X, i
  * adversarial/common.py:352-369) */
 int ia_reduce_partials(const float* partials, int splits, int64_t n, float scale, int accumulate, float* grads,
                        void* stream);
+/* ... of a PIECE of every slab: element i of slab k at partials[k * stride + i], i < n <= stride (the generic towers' per-tower
+ * gradient stacks reduced straight into the pieces of the flat gradient: [SB3 ActorCriticPolicy] keeps `mlp_extractor.policy_net`,
+ * `.value_net`, `action_net`, `value_net` in that order, the kernels want each tower's layers contiguous). */
+int ia_reduce_partials_strided(const float* partials, int splits, int64_t n, int64_t stride, float scale, int accumulate,
+                               float* grads, void* stream);
+/* dst[p][0 .. n[p]) = src[p][0 .. n[p]) for p < n_pieces <= 4 in ONE launch (the towers' contiguous parameter stacks
+ * refreshed from the flat parameter vector behind an optimiser step: four device-to-device copies before). */
+int ia_copy_pieces(int n_pieces, const float* const* src, float* const* dst, const int64_t* n, void* stream);
 
 /* ia_reduce_partials (accumulate = 0) fused with ia_adam_step: one launch per discriminator update
  * when there is a single minibatch and no cross-rank all-reduce in between. */
