@@ -502,6 +502,22 @@ def test_fused_airl_update_is_taken_only_for_its_geometry(monkeypatch):
     assert not mk(reward_hid_sizes=(32,), potential_hid_sizes=(32, 32)).fused_step_ok()
 
 
+def test_nature_cnn_linear_layer_split_rule():
+    """`ActorCriticCnnPolicy._linear_splits`: the 3 136 -> 512 layer's forward product is split along K only while its 64 x 64
+    output tiles alone leave most of the 256 compute units idle -- rollout steps and PPO minibatches, not BC's batches --, never
+    into slabs of fewer than 8 K chunks, and not at all when the switch is off."""
+    from imitation_amd import spaces
+    from imitation_amd.cnn_policy import ActorCriticCnnPolicy
+    pol = ActorCriticCnnPolicy(spaces.Box(0, 255, (4, 84, 84), np.uint8), spaces.Discrete(6), lambda _: 1e-3)
+    assert pol.n_flatten == 3136 and pol.features_dim == 512
+    assert [pol._linear_splits(b) for b in (1, 64, 65, 256, 1024, 4096)] == [12, 12, 12, 8, 1, 1]
+    for b in (1, 64, 256):   # every slab at least 8 chunks of 32, the launch at most ~256 workgroups
+        sk = pol._linear_splits(b)
+        assert 3136 // 32 // sk >= 8 and sk * -(-b // 64) * 8 <= 256
+    pol.LINEAR_SPLIT_K = False
+    assert pol._linear_splits(64) == 1
+
+
 def test_production_kernels_do_not_spill():
     """The built library's own notes (`llvm-readelf --notes` of its gfx950 code objects): the production instantiations
     of the latency chains and the tile kernels keep every value in registers -- a spilled VGPR is a scratch access, and
