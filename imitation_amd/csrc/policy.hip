@@ -3496,16 +3496,17 @@ __global__ __launch_bounds__(256) void ppo_epoch_ll_kernel(
 }
 
 // ---------------------------------------------------------------------------------------------
-// 64-wide towers (SB3's default `MlpPolicy`), round 5: the transposed, register-resident chain of the 32-wide persistent
-// kernel for ONE tower per four-wave workgroup (`ppo_epoch_ll2_kernel` below). Wave q owns rows 16 q .. 16 q + 15 of the
-// block for the whole activation chain
+// 64-wide towers (SB3's default `MlpPolicy`): the transposed chain of the 32-wide persistent kernel for ONE tower per workgroup
+// (`ppo_epoch_ll2_kernel` below). A group of 16 rows runs the activation chain
 //       x -> a1 -> a2 -> head -> per-row loss -> d head -> dz2 -> dz1
-// with features along the MFMA's M index, the wave's rows along N and the k index of a step permuted so that the
-// accumulator of one layer IS the B operand of the next (`mfma32_minibatch_chain`): activations never leave the registers;
-// the `[feature][row]` LDS tiles are written on the side for the weight-gradient tiles (ds_read_b128 of four consecutive
-// rows). One wave per SIMD: the matrix pipe and the VALU are the wave's own. The tower's parameters are read from LDS
-// images: W1 / W2 in torch layout with padded rows (a forward fragment = the four consecutive INPUTS of an output row: one
-// ds_read_b128), W2 transposed likewise for the backward pass, the head in both orientations.
+// with features along the MFMA's M index, the rows along N and the k index of a step permuted so that the accumulator of one
+// layer has the B operand's layout of the next (`mfma32_minibatch_chain`); the `[feature][row]` LDS tiles serve the
+// weight-gradient tiles (ds_read_b128 of four consecutive rows) and hand a layer's outputs from the wave that formed them to
+// the others of its row group. The tower's parameters are read from LDS images: W1 / W2 in torch layout with padded rows (a
+// forward fragment = the four consecutive INPUTS of an output row: one ds_read_b128), W2 transposed likewise for the backward
+// pass, the head in both orientations. (Round 5's form -- one wave per SIMD, every wave all 64 output features of its rows,
+// activations in registers from x to dz1: 20.6 us per step -- was retired in round 6 once the eight-wave form below, bit-identical
+// to it, had replaced it everywhere: `profiles/r06_mlp64.md`, DESIGN_HISTORY.md.)
 template <int KT1, int RB = 64>
 struct T64Geo {   // LDS carve-up (floats; every offset a multiple of 4) of one tower workgroup: compile-time but for the
                   // staging area's pieces, whose sizes follow the observation / action widths. RB = rows of the block
@@ -3550,465 +3551,16 @@ struct T64Out {   // word index (inside the workgroup's slab) of each piece of t
   int W1, b1, W2, b2, HW, Hb, LS, tail;
   bool zero_tail;   // the slab is this tower's alone: the tail slots of the other tower's statistics are written as zeros
 };
-template <int KT1, class Mid>
-__device__ __forceinline__ void t64_tower_minibatch(
-    const ia_policy_desc& d, const T64Geo<KT1>& G, const T64Out& Lc, const int tw, float* __restrict__ lds_in, const int row0,
-    const int b, const float adv_mean, const float adv_std, const int normalize_adv, const float clip, const float ent_coef,
-    const float vf_coef, unsigned long long* __restrict__ slab, const unsigned seq, Mid&& mid,
-    long long* __restrict__ ts /* measurement (nullable): shader clocks of the phases, thread 0 */, const int oz) {
-  // (`oz`: an opaque zero refreshed by the caller every step: the per-lane tile / image offsets below are then re-derived
-  //  per step -- a handful of VALU operations -- instead of being hoisted out of the step loop into spilled registers)
-  constexpr int RS = T64Geo<KT1>::RS;
-#define T64C_TS(slot) do { if (ts != nullptr && threadIdx.x == 0) ts[slot] = clock64(); } while (0)
-  T64C_TS(0);
-  float* __restrict__ lds = lds_in + oz;
-  const int tid = threadIdx.x + oz, lane = tid & 63;
-  const int q = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int li = lane & 15, lk = lane >> 4;
-  const int D = d.obs_dim, A = d.act_dim;
-  const int aw = d.discrete ? 1 : A;
-  const float invB = 1.f / (float)b;
-  auto rd4 = [&](const float* p) { return *reinterpret_cast<const f32x4*>(p); };
-  auto put = [&](int idx, float v) { ll_store_agent(slab + idx, v, seq); };
-  const int lrow = q * 16 + li;
-  const bool valid = row0 + lrow < b;
-  // per-row scalars of the loss (staged by the prefetch)
-  float r_oldlp = 0.f, r_adv = 0.f, r_ret = 0.f, r_act[4] = {0.f, 0.f, 0.f, 0.f};
-  if (tw == 0) {
-    r_oldlp = lds[G.soldlp + lrow];
-    r_adv = lds[G.sadv + lrow];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) r_act[j] = lds[G.sact + lrow * aw + min(4 * lk + j, aw - 1)];
-  } else {
-    r_ret = lds[G.sret + lrow];
-  }
-  // ---- layer 1: a1^T = tanh(W1 x^T + b1). A operand: W1[out 16 t + li][in 16 kt + 4 lk + r], r = 0..3 one ds_read_b128 of the
-  // padded torch-layout image; B operand: the wave's x rows, column 16 kt + 4 lk + r of row li
-  f32x4 a1[4], a2[4];
-  {
-    f32x4 fW1[KT1][4], b1c[4];
-    float xb[KT1][4];
-#pragma unroll
-    for (int kt = 0; kt < KT1; ++kt)
-#pragma unroll
-      for (int t = 0; t < 4; ++t) fW1[kt][t] = rd4(lds + G.W1 + (16 * t + li) * G.DP + 16 * kt + 4 * lk);
-#pragma unroll
-    for (int t = 0; t < 4; ++t) b1c[t] = rd4(lds + G.b1 + 16 * t + 4 * lk);
-#pragma unroll
-    for (int kt = 0; kt < KT1; ++kt)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) xb[kt][r] = lds[G.x + (16 * kt + 4 * lk + r) * RS + q * 16 + li];
-    __builtin_amdgcn_sched_barrier(0);
-    f32x4 acc[4][2];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      acc[t][0] = b1c[t];
-      acc[t][1] = f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-    // tile by tile (two accumulator chains each): the tanh of tile t issues between the MFMAs of tile t + 1
-    auto l1_tile = [&](const int t) {
-#pragma unroll
-      for (int kt = 0; kt < KT1; ++kt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r)   // (all k-steps, no branch around the ones past the observation width: the image's columns
-                                      //  >= D are zero, and a branch here keeps the tanh of the tile before from issuing
-                                      //  between these MFMAs)
-          acc[t][(kt * 4 + r) & 1] = mfma16(fW1[kt][t][r], xb[kt][r], acc[t][(kt * 4 + r) & 1]);
-    };
-    auto l1_tanh = [&](const int t) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        a1[t][r] = fast_tanh(acc[t][0][r] + acc[t][1][r]);
-        lds[G.a1 + (16 * t + 4 * lk + r) * RS + q * 16 + li] = a1[t][r];
-      }
-    };
-    l1_tile(0);
-    l1_tile(1);
-    l1_tanh(0);
-    l1_tile(2);
-    l1_tanh(1);
-    l1_tile(3);
-    l1_tanh(2);
-    l1_tanh(3);
-  }
-  T64C_TS(1);
-  // ---- layer 2: a2^T = tanh(W2 a1^T + b2): the accumulators of layer 1 are the B operands
-  {
-    f32x4 fW2[4][4], b2c[4];
-#pragma unroll
-    for (int kt = 0; kt < 4; ++kt)
-#pragma unroll
-      for (int t = 0; t < 4; ++t) fW2[kt][t] = rd4(lds + G.W2 + (16 * t + li) * RS + 16 * kt + 4 * lk);
-#pragma unroll
-    for (int t = 0; t < 4; ++t) b2c[t] = rd4(lds + G.b2 + 16 * t + 4 * lk);
-    __builtin_amdgcn_sched_barrier(0);
-    f32x4 acc[4][2];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      acc[t][0] = b2c[t];
-      acc[t][1] = f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-    auto l2_tile = [&](const int t) {
-#pragma unroll
-      for (int kt = 0; kt < 4; ++kt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) acc[t][r & 1] = mfma16(fW2[kt][t][r], a1[kt][r], acc[t][r & 1]);
-    };
-    auto l2_tanh = [&](const int t) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        a2[t][r] = fast_tanh(acc[t][0][r] + acc[t][1][r]);
-        lds[G.a2 + (16 * t + 4 * lk + r) * RS + q * 16 + li] = a2[t][r];
-      }
-    };
-    l2_tile(0);
-    l2_tile(1);
-    l2_tanh(0);
-    l2_tile(2);
-    l2_tanh(1);
-    l2_tile(3);
-    l2_tanh(2);
-    l2_tanh(3);
-  }
-  T64C_TS(2);
-  // ---- head. The head image holds action_net's rows (rows >= A zero) resp. value_net's row in row 0 (rows 1.. zero): the M
-  // index li picks the row; hout[r] = output 4 lk + r of row li (value: lane group 0, register 0)
-  float hout[4];
-  {
-    f32x4 fHead[4];
-#pragma unroll
-    for (int kt = 0; kt < 4; ++kt) fHead[kt] = rd4(lds + G.HW + li * RS + 16 * kt + 4 * lk);
-    const f32x4 hb = rd4(lds + G.hb + 4 * lk);
-    __builtin_amdgcn_sched_barrier(0);
-    f32x4 acc[2] = {hb, {0.f, 0.f, 0.f, 0.f}};
-#pragma unroll
-    for (int kt = 0; kt < 4; ++kt)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) acc[r & 1] = mfma16(fHead[kt][r], a2[kt][r], acc[r & 1]);
-#pragma unroll
-    for (int r = 0; r < 4; ++r) hout[r] = acc[0][r] + acc[1][r];
-  }
-  T64C_TS(3);
-  // backward fragments: the head's weights of the lane's outputs 16 t + 4 lk + r here (landed by the time the loss phase is
-  // through); W2 transposed (A[m = in 16 t + li][k = out 16 kt + 4 lk + r]) behind the loss phase
-  f32x4 fHeadT[4];
-#pragma unroll
-  for (int t = 0; t < 4; ++t)
-    fHeadT[t] = tw == 0 ? rd4(lds + G.HWT + (16 * t + li) * T64Geo<KT1>::HT + 4 * lk) : rd4(lds + G.HW + 16 * t + 4 * lk);
-  // ---- per-row losses (the expressions of `mfma32_minibatch_chain`): four lanes per row, lane group lk = actions 4 lk ..
-  auto xchg16 = [](float v, float& a, float& bq) {
-    const auto p2 = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-    a = __uint_as_float(p2[0]);
-    bq = __uint_as_float(p2[1]);
-  };
-  auto xchg32 = [](float v, float& a, float& bq) {
-    const auto p2 = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-    a = __uint_as_float(p2[0]);
-    bq = __uint_as_float(p2[1]);
-  };
-  auto group_sum = [&](float v) {
-    float a, bq;
-    xchg16(v, a, bq);
-    v = a + bq;
-    xchg32(v, a, bq);
-    return a + bq;
-  };
-  auto group_max = [&](float v) {
-    float a, bq;
-    xchg16(v, a, bq);
-    v = fmaxf(a, bq);
-    xchg32(v, a, bq);
-    return fmaxf(a, bq);
-  };
-  float dout[4] = {0.f, 0.f, 0.f, 0.f}, dvb = 0.f;
-  if (tw == 0) {
-    // per-action Gaussian constants 1 / sd^2 and log sd of the lane's actions 4 lk ..: worked out once per step by the thread
-    // that steps log_std (`gauss_constants`) and left behind the log_std image
-    const f32x4 c_ivar = rd4(lds + G.ls + 16 + 4 * lk), c_logsd = rd4(lds + G.ls + 32 + 4 * lk);
-    float logp = 0.f, entropy = 0.f, lse = 0.f;
-    int act_i = 0;
-    if (d.discrete) act_i = (int)r_act[0];
-    if (!d.discrete) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-        if (4 * lk + j < A) {
-          const float diff = r_act[j] - hout[j];
-          logp += -(diff * diff) * (0.5f * c_ivar[j]) - c_logsd[j] - LOG_SQRT_2PI;
-          entropy += 0.5f + LOG_SQRT_2PI + c_logsd[j];
-        }
-      logp = group_sum(logp);
-      entropy = group_sum(entropy);
-    } else {
-      float mx = -3.0e38f, o_act = 0.f;
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-        if (4 * lk + j < A) {
-          mx = fmaxf(mx, hout[j]);
-          o_act += (4 * lk + j == act_i) ? hout[j] : 0.f;
-        }
-      mx = group_max(mx);
-      o_act = group_sum(o_act);
-      float se = 0.f;
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-        if (4 * lk + j < A) se += expf(hout[j] - mx);
-      lse = mx + logf(group_sum(se));
-      logp = o_act - lse;
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-        if (4 * lk + j < A) {
-          const float l = hout[j] - lse;
-          entropy -= expf(l) * l;
-        }
-      entropy = group_sum(entropy);
-    }
-    float advn = r_adv;
-    if (normalize_adv && b > 1) advn = (advn - adv_mean) / (adv_std + 1e-8f);
-    const float log_ratio = logp - r_oldlp;
-    const float ratio = expf(log_ratio);
-    const float lo = 1.f - clip, hi = 1.f + clip;
-    const float pl1 = advn * ratio;
-    const float pl2 = advn * fminf(fmaxf(ratio, lo), hi);
-    const float g1 = pl1 < pl2 ? 1.f : (pl1 == pl2 ? 0.5f : 0.f);
-    const float g2 = pl2 < pl1 ? 1.f : (pl1 == pl2 ? 0.5f : 0.f);
-    const float inrange = (ratio >= lo && ratio <= hi) ? 1.f : 0.f;
-    const float dlogp = valid ? -invB * advn * (g1 + g2 * inrange) * ratio : 0.f;
-    float* doutrow = lds + G.dout + lrow;   // (column a of this lane's row: [a * RS])
-    float* auxrow = lds + G.aux + lrow;
-    if (!d.discrete) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-        if (4 * lk + j < A) {
-          const float diff = r_act[j] - hout[j];
-          dout[j] = dlogp * diff * c_ivar[j];
-          doutrow[(4 * lk + j) * RS] = dout[j];
-          auxrow[(4 * lk + j) * RS] = valid ? dlogp * (diff * diff * c_ivar[j] - 1.f) - ent_coef * invB : 0.f;
-        }
-    } else {
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-        if (4 * lk + j < A) {
-          const float l = hout[j] - lse, p = expf(l);
-          const float dH = -p * (l + entropy);
-          float g = dlogp * ((4 * lk + j == act_i ? 1.f : 0.f) - p);
-          g += valid ? -ent_coef * invB * dH : 0.f;
-          dout[j] = g;
-          doutrow[(4 * lk + j) * RS] = g;
-        }
-    }
-    if (lk == 0) {
-      float* mrow = lds + G.misc + lrow;
-      mrow[2 * RS] = valid ? -fminf(pl1, pl2) : 0.f;                           // policy_gradient_loss
-      mrow[3 * RS] = valid ? -entropy : 0.f;                                    // entropy_loss
-      mrow[4 * RS] = valid ? (ratio - 1.f) - log_ratio : 0.f;                   // approx_kl
-      mrow[5 * RS] = valid ? (fabsf(ratio - 1.f) > clip ? 1.f : 0.f) : 0.f;     // clip_fraction
-    }
-  } else {
-    const float v = __shfl(hout[0], li, 64);   // (lane group 0, register 0 holds V(row li))
-    const float verr = r_ret - v;
-    dvb = valid ? vf_coef * 2.f * (v - r_ret) * invB : 0.f;
-    if (lk == 0) {
-      lds[G.misc + 1 * RS + lrow] = dvb;
-      lds[G.misc + 6 * RS + lrow] = valid ? verr * verr : 0.f;        // value_loss
-    }
-  }
-  T64C_TS(4);
-  // ---- dz2^T = (W_head^T d head^T) * (1 - a2^2), dz1^T = (W2^T dz2^T) * (1 - a1^2)
-  {
-    f32x4 fW2T[4][4];   // (requested here: in flight under dz2's MFMAs / products)
-#pragma unroll
-    for (int kt = 0; kt < 4; ++kt)
-#pragma unroll
-      for (int t = 0; t < 4; ++t) fW2T[kt][t] = rd4(lds + G.W2T + (16 * t + li) * RS + 16 * kt + 4 * lk);
-    f32x4 dz2[4];
-    if (tw == 0) {
-      f32x4 acc[4];
-#pragma unroll
-      for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int r = 0; r < 4; ++r)   // (k-step r carries actions r, 4 + r, 8 + r, 12 + r; the image's columns >= A are zero)
-#pragma unroll
-        for (int t = 0; t < 4; ++t) acc[t] = mfma16(fHeadT[t][r], dout[r], acc[t]);
-#pragma unroll
-      for (int t = 0; t < 4; ++t)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) dz2[t][r] = acc[t][r] * (1.f - a2[t][r] * a2[t][r]);
-    } else {
-#pragma unroll
-      for (int t = 0; t < 4; ++t)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) dz2[t][r] = fHeadT[t][r] * dvb * (1.f - a2[t][r] * a2[t][r]);
-    }
-#pragma unroll
-    for (int t = 0; t < 4; ++t)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) lds[G.dz2 + (16 * t + 4 * lk + r) * RS + q * 16 + li] = dz2[t][r];
-    f32x4 acc[4][2];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) acc[t][0] = acc[t][1] = f32x4{0.f, 0.f, 0.f, 0.f};
-    auto d1_tile = [&](const int t) {
-#pragma unroll
-      for (int kt = 0; kt < 4; ++kt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) acc[t][r & 1] = mfma16(fW2T[kt][t][r], dz2[kt][r], acc[t][r & 1]);
-    };
-    auto d1_out = [&](const int t) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-        lds[G.dz1 + (16 * t + 4 * lk + r) * RS + q * 16 + li] = (acc[t][0][r] + acc[t][1][r]) * (1.f - a1[t][r] * a1[t][r]);
-    };
-    d1_tile(0);
-    d1_tile(1);
-    d1_out(0);
-    d1_tile(2);
-    d1_out(1);
-    d1_tile(3);
-    d1_out(2);
-    d1_out(3);
-  }
-  T64C_TS(5);
-  __syncthreads();   // every row's activations and activation gradients are in LDS
-  mid();
-  T64C_TS(6);
-  // ---- weight-gradient tiles: contractions over the 64 rows, independent per wave. Tile = 16 features of U (the MFMA's M
-  // index) x 16 features of V (N); a lane reads four consecutive rows of its feature per ds_read_b128 (row steps 4 sq .. + 3
-  // of lane group lk are rows 16 sq + 4 lk ..: the same permutation on both operands); two accumulator chains per tile.
-  auto tile2 = [&](const f32x4 (&u)[4], const float* __restrict__ V0, const float* __restrict__ V1, f32x4& r0, f32x4& r1) {
-    const float* vp0 = V0 + li * RS + 4 * lk;
-    const float* vp1 = V1 + li * RS + 4 * lk;
-    f32x4 v0[4], v1[4];
-#pragma unroll
-    for (int sq = 0; sq < 4; ++sq) {
-      v0[sq] = rd4(vp0 + 16 * sq);
-      v1[sq] = rd4(vp1 + 16 * sq);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    f32x4 g0 = {0.f, 0.f, 0.f, 0.f}, g0b = g0, g1 = g0, g1b = g0;
-#pragma unroll
-    for (int sq = 0; sq < 4; ++sq)
-#pragma unroll
-      for (int i = 0; i < 4; i += 2) {
-        g0 = mfma16(u[sq][i], v0[sq][i], g0);
-        g1 = mfma16(u[sq][i], v1[sq][i], g1);
-        g0b = mfma16(u[sq][i + 1], v0[sq][i + 1], g0b);
-        g1b = mfma16(u[sq][i + 1], v1[sq][i + 1], g1b);
-      }
-    r0 = g0 + g0b;
-    r1 = g1 + g1b;
-  };
-  auto load_u = [&](const float* __restrict__ U, f32x4 (&u)[4]) {
-    const float* up = U + li * RS + 4 * lk;
-#pragma unroll
-    for (int sq = 0; sq < 4; ++sq) u[sq] = rd4(up + 16 * sq);
-  };
-  // a feature's sum over the 64 rows (optionally weighted by a row vector): lane (j, quarter) = (lane & 15, lane >> 4)
-  auto colsum16 = [&](const float* __restrict__ tile /* 16 features */, const float* __restrict__ wrow /* nullable */) {
-    const float* cp = tile + (lane & 15) * RS + (lane >> 4) * 16;
-    f32x4 t[4], w[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      t[i] = rd4(cp + 4 * i);
-      w[i] = wrow ? rd4(wrow + (lane >> 4) * 16 + 4 * i) : f32x4{1.f, 1.f, 1.f, 1.f};
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    float s = 0.f;
-    if (wrow) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) s += (t[i][0] * w[i][0] + t[i][1] * w[i][1]) + (t[i][2] * w[i][2] + t[i][3] * w[i][3]);
-    } else {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) s += (t[i][0] + t[i][1]) + (t[i][2] + t[i][3]);
-    }
-    s += __shfl_xor(s, 16, 64);
-    s += __shfl_xor(s, 32, 64);
-    return s;   // (all four lanes of feature j hold the sum)
-  };
-  {   // dW2[j][i] = sum_r dz2[r][j] a1[r][i]: wave q takes output rows j = 16 q .. 16 q + 15, all four input tiles
-    f32x4 u[4];
-    load_u(lds + G.dz2 + 16 * q * RS, u);
-#pragma unroll
-    for (int it = 0; it < 4; it += 2) {
-      f32x4 g0, g1;
-      tile2(u, lds + G.a1 + 16 * it * RS, lds + G.a1 + 16 * (it + 1) * RS, g0, g1);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        put(Lc.W2 + (16 * q + 4 * lk + r) * 64 + 16 * it + li, g0[r]);
-        put(Lc.W2 + (16 * q + 4 * lk + r) * 64 + 16 * (it + 1) + li, g1[r]);
-      }
-    }
-    const float sb2 = colsum16(lds + G.dz2 + 16 * q * RS, nullptr);
-    if (lane < 16) put(Lc.b2 + 16 * q + lane, sb2);
-  }
-  T64C_TS(7);
-  {   // dW1[j][c] = sum_r dz1[r][j] x[r][c]; head weights: dWa[a][h] = sum_r dout[r][a] a2[r][h] (policy: one tile per wave)
-    f32x4 u[4];
-    load_u(lds + G.dz1 + 16 * q * RS, u);
-    f32x4 g0, g1;
-    if (KT1 == 2) {
-      tile2(u, lds + G.x, lds + G.x + 16 * RS, g0, g1);
-    } else {
-      tile2(u, lds + G.x, lds + G.x, g0, g1);   // (one K tile: the second product is discarded)
-    }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      if (li < D) put(Lc.W1 + (16 * q + 4 * lk + r) * D + li, g0[r]);
-      if (KT1 == 2 && 16 + li < D) put(Lc.W1 + (16 * q + 4 * lk + r) * D + 16 + li, g1[r]);
-    }
-    const float sb1 = colsum16(lds + G.dz1 + 16 * q * RS, nullptr);
-    if (lane < 16) put(Lc.b1 + 16 * q + lane, sb1);
-  }
-  T64C_TS(8);
-  if (tw == 0) {
-    f32x4 u[4];
-    load_u(lds + G.dout, u);
-    f32x4 g0, g1;
-    tile2(u, lds + G.a2 + 16 * q * RS, lds + G.a2 + 16 * q * RS, g0, g1);
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-      if (4 * lk + r < A) put(Lc.HW + (4 * lk + r) * 64 + 16 * q + li, g0[r]);
-    if (q == 0) {   // action_net bias
-      const float s = colsum16(lds + G.dout, nullptr);
-      if (lane < A) put(Lc.Hb + lane, s);
-    } else if (q == 1) {   // log_std
-      if (!d.discrete) {
-        const float s = colsum16(lds + G.aux, nullptr);
-        if (lane < A) put(Lc.LS + lane, s);
-      }
-    } else if (q == 2) {   // loss statistics: misc columns 2..5 -> tail slots {0 pg, 2 ent, 3 kl, 4 clip}
-      const float s = colsum16(lds + G.misc, nullptr);   // (features 0..7 of the misc tile; 8..15 read the next tile: unused)
-      if (lane >= 2 && lane < 6) put(Lc.tail + (lane == 2 ? 0 : lane - 1), s);
-    } else {
-      if (Lc.zero_tail && lane < 4) put(Lc.tail + (lane == 0 ? 1 : lane + 4), 0.f);   // (slots 1, 5, 6, 7: not this tower's)
-    }
-  } else {
-    // value_net: dcW[h] = sum_r dv[r] a2[r][h] -- one useful row of a tile: a weighted column sum instead
-    const float s = colsum16(lds + G.a2 + 16 * q * RS, lds + G.misc + 1 * RS);
-    if (lane < 16) put(Lc.HW + 16 * q + lane, s);
-    if (q == 0) {   // value_net bias = sum_r dv[r]; value_loss -> tail slot 1
-      const float sm = colsum16(lds + G.misc, nullptr);
-      if (lane == 1) put(Lc.Hb, sm);
-      if (lane == 6) put(Lc.tail + 1, sm);
-    } else if (q == 1) {
-      if (Lc.zero_tail && lane < 7) put(Lc.tail + (lane == 0 ? 0 : lane + 1), 0.f);   // (slots 0, 2..7: not this tower's)
-    }
-  }
-  T64C_TS(9);
-  __syncthreads();
-  T64C_TS(10);
-#undef T64C_TS
-}
-
 // ---------------------------------------------------------------------------------------------
-// Round 6: the same chain with every layer's output tiles split between the NH = 2 (or 4) waves of a group of 16 rows. Wave
-// w = (q, h) = (w % NQ, w / NQ), NQ = RB / 16 row groups, owns rows 16 q .. of the block like wave q above, but only the output
-// tiles 2 h, 2 h + 1 of every layer (features 32 h .. 32 h + 31; quarters: tile h): half the MFMAs and half the tanh / store
-// work per wave. The k index of
+// The chain: every layer's four output tiles are split between the NH = 2 (or 4) waves of a group of 16 rows. Wave
+// w = (q, h) = (w % NQ, w / NQ), NQ = RB / 16 row groups, owns rows 16 q .. of the block and the output tiles 2 h, 2 h + 1 of
+// every layer (features 32 h .. 32 h + 31; quarters: tile h). The k index of
 // a layer runs over all 64 features of the layer below: a wave's own half is in its registers, its partner's half comes from
 // the `[feature][row]` tile the partner writes anyway (one workgroup barrier per layer; the next layer's weight fragments are
 // requested ahead of it). Head and per-row losses (16 MFMAs, no weights to split) are computed by both waves of a pair. Two
 // forms:
 //   * RB = 64, eight waves (two per SIMD, the second one issuing under the first one's latencies). Every tile is accumulated
-//     by the same MFMAs in the same order as in the four-wave form: the gradients are bit-identical. Weight-gradient tiles:
+//     by the same MFMAs in the same order as in round 5's four-wave form: the gradients were bit-identical. Weight-gradient tiles:
 //     dW2's four input tiles go two per wave; h = 0 takes dW1's first K tile and its bias, h = 1 dW1's second K tile
 //     (observation widths > 16), the second layer's bias and the head's tile.
 //   * RB = 32, four waves (one per SIMD): twice the workgroups per minibatch, each with half the chain AND half the
@@ -4199,7 +3751,7 @@ __device__ __forceinline__ void t64h_tower_minibatch(
   for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
     for (int j = 0; j < TPW; ++j) fW2T[kt][j] = rd4(lds + G.W2T + (T0 + 16 * j + li) * RS + 16 * kt + 4 * lk);
-  // ---- per-row losses (the expressions of `t64_tower_minibatch`; the pair's first wave leaves the rows' pieces in LDS)
+  // ---- per-row losses (the expressions of `mfma32_minibatch_chain`; the group's first wave leaves the rows' pieces in LDS)
   auto xchg16 = [](float v, float& a, float& bq) {
     const auto p2 = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
     a = __uint_as_float(p2[0]);
@@ -4379,8 +3931,10 @@ __device__ __forceinline__ void t64h_tower_minibatch(
   __syncthreads();   // every row's activations and activation gradients are in LDS
   mid();
   T64C_TS(6);
-  // ---- weight-gradient tiles (see `t64_tower_minibatch`): the same tiles, MFMAs and accumulation order; contractions over the
-  // block's RB rows (SQ steps of 16)
+  // ---- weight-gradient tiles: contractions over the block's RB rows (SQ steps of 16), independent per wave. Tile = 16 features
+  // of U (the MFMA's M index) x 16 features of V (N); a lane reads four consecutive rows of its feature per ds_read_b128 (row
+  // steps 4 sq .. + 3 of lane group lk are rows 16 sq + 4 lk ..: the same permutation on both operands); two accumulator
+  // chains per tile
   auto tile2 = [&](const f32x4 (&u)[SQ], const float* __restrict__ V0, const float* __restrict__ V1, f32x4& r0, f32x4& r1) {
     const float* vp0 = V0 + li * TS + 4 * lk;
     const float* vp1 = V1 + li * TS + 4 * lk;
@@ -4521,7 +4075,7 @@ __device__ __forceinline__ void t64h_tower_minibatch(
       }
     }
   } else {
-    // four waves (32-row blocks): wave w takes output tile w of every product, as wave q of `t64_tower_minibatch` does
+    // four waves (32-row blocks): wave w takes output tile w of every product
     {
       f32x4 u[SQ];
       load_u(lds + G.dz2 + 16 * w * TS, u);
@@ -4597,7 +4151,7 @@ __device__ __forceinline__ void t64h_tower_minibatch(
 }
 
 // ---------------------------------------------------------------------------------------------
-// Round 5: the word-exchange epoch kernel with the TRANSPOSED, REGISTER-RESIDENT chain (`t64_tower_minibatch`) as its
+// Round 5: the word-exchange epoch kernel with the TRANSPOSED chain (`t64h_tower_minibatch`) as its
 // gradient phase -- observation widths up to 32. Exchange, sequence numbers, chunk owners and Adam are those of
 // `ppo_epoch_ll_kernel` (same word areas, same sums in the same order in phases B1 / B2); what changed is phase A:
 //   * the tower's polled parameter words go straight to their places in the chain's LDS images (W1 / W2 in torch layout
@@ -4605,8 +4159,11 @@ __device__ __forceinline__ void t64h_tower_minibatch(
 //     worked out once per launch;
 //   * the minibatch's rows are plain loads of the gathered, contiguous rows issued a step AHEAD (parked in LDS behind the
 //     chain's barrier, normalised into the `[feature][row]` x tile while the partial sums of squares travel);
-//   * activations stay in registers through x -> a1 -> a2 -> head -> loss -> dz2 -> dz1; four tiles of a wave's weight
-//     gradient share their first operand; one-row products (value head) are weighted column sums.
+//   * a wave's own output tiles stay in its registers through x -> a1 -> a2 -> head -> loss -> dz2 -> dz1 (the other tiles of a
+//     layer come from the row tiles); the tiles of a wave's weight gradient share their first operand; one-row products
+//     (value head) are weighted column sums;
+//   * round 6: NW waves per tower workgroup on RB-row blocks (`t64h_tower_minibatch`'s three forms); phase B1 requests ALL slabs'
+//     words of an element together when there are more than sixteen (32-row blocks of a 1 024-row minibatch).
 // A tower workgroup that was tried in between -- parameters resident in LDS for the launch, every workgroup stepping its
 // whole tower, two hops -- lost: Adam on 5.7 k parameters by 256 threads and 22-30 words per thread in both hops cost more
 // than the parameter hand-off saves (28.2 against 26.5 us per step; `profiles/r05_mlp64.md`).
@@ -4879,14 +4436,9 @@ __global__ __launch_bounds__(64 * NW) void ppo_epoch_ll2_kernel(
       if (fail) s_fail = 1;
       __syncthreads();
       u64* slab = slabs_s + (long long)rb * SW;
-      if constexpr (NW == 8 || RB != 64)
-        t64h_tower_minibatch<KT1, RB, NW>(d, G, out, tower, lds, RB * rb, b, adv_mean, adv_std, normalize_adv, clip, ent_coef, vf_coef,
-                                  slab, seq_out, [&]() { if (have_next) park_rows(); },
-                                  (dbg != nullptr && bid < 2) ? dbg + 16 + 16 * bid : nullptr, oz);
-      else
-        t64_tower_minibatch<KT1>(d, G, out, tower, lds, RB * rb, b, adv_mean, adv_std, normalize_adv, clip, ent_coef, vf_coef,
-                                 slab, seq_out, [&]() { if (have_next) park_rows(); },
-                                 (dbg != nullptr && bid < 2) ? dbg + 16 + 16 * bid : nullptr, oz);
+      t64h_tower_minibatch<KT1, RB, NW>(d, G, out, tower, lds, RB * rb, b, adv_mean, adv_std, normalize_adv, clip, ent_coef, vf_coef,
+                                        slab, seq_out, [&]() { if (have_next) park_rows(); },
+                                        (dbg != nullptr && bid < 2) ? dbg + 16 + 16 * bid : nullptr, oz);
     } else if (have_next) {
       __syncthreads();
       park_rows();
@@ -6086,8 +5638,7 @@ bool g_epoch_whole = false;  // tuning/debug: the one-launch epoch with whole ro
 bool g_epoch_barriers = false;   // tuning/debug: the one-tower epoch kernel with grid barriers instead of the word exchange
 bool g_epoch_chain2 = true;      // the word-exchange epoch kernel with round 5's transposed register-resident chain (observation
                                  // widths <= 32); false: round 4's gradient body everywhere
-bool g_epoch_waves8 = true;      // round 6: that kernel with eight waves per tower workgroup, two per SIMD (false: round 5's four)
-bool g_epoch_rows32 = true;      // round 6: ... on 32-row blocks (four waves: two row groups x two feature halves) where they fit
+bool g_epoch_rows32 = true;      // round 6: that kernel on 32-row blocks where they fit (false: 64-row blocks, eight waves, everywhere)
 bool g_epoch_quarters = true;    // round 6: ... with eight waves per 32-row block (two row groups x four feature quarters)
 long long* g_epoch_dbg = nullptr;  // measurement: phase ticks of workgroup 0 of ppo_epoch_persistent_kernel
 }  // namespace
@@ -6503,8 +6054,7 @@ int ia_ppo_epoch_split(int on) {
   g_epoch_split = on == 1;
   g_epoch_whole = on == 2;
   g_epoch_barriers = on == 3;
-  g_epoch_waves8 = on != 5;   // 5: round 5's four-wave tower workgroups (one wave per SIMD) in `ppo_epoch_ll2_kernel`
-  g_epoch_rows32 = on != 5 && on != 6;   // 6: 64-row blocks on eight waves also where the 32-row blocks apply
+  g_epoch_rows32 = on != 6;   // 6: 64-row blocks on eight waves also where the 32-row blocks apply
   g_epoch_quarters = on != 7;            // 7: 32-row blocks on four waves (feature halves) instead of eight (quarters)
   g_epoch_chain2 = on != 4;   // 4: round 4's gradient body in the word-exchange kernel also where round 5's chain applies
   return IA_OK;
@@ -6621,19 +6171,17 @@ static int ppo_epochs_impl(const ia_policy_desc* d, float* params, float* params
                                  sizeof(float) + 16;
       if (llx && g_epoch_chain2 && d->obs_dim <= 32 && l2bytes <= EPOCH_LL_LDS) {
         // round 5's gradient phase (transposed register-resident chain, images with ds_read_b128 fragments)
-        auto k1 = ppo_epoch_ll2_kernel<1, 4, 64>;
-        auto k2 = ppo_epoch_ll2_kernel<2, 4, 64>;
-        auto k1h = ppo_epoch_ll2_kernel<1, 8, 64>;   // round 6: two waves per SIMD per tower
+        auto k1h = ppo_epoch_ll2_kernel<1, 8, 64>;   // 64-row blocks: eight waves (feature halves), two per SIMD
         auto k2h = ppo_epoch_ll2_kernel<2, 8, 64>;
         auto k1r = ppo_epoch_ll2_kernel<1, 4, 32>;   // round 6: 32-row blocks, feature halves
         auto k2r = ppo_epoch_ll2_kernel<2, 4, 32>;
         auto k1q = ppo_epoch_ll2_kernel<1, 8, 32>;   // round 6: 32-row blocks, feature quarters (two waves per SIMD)
         auto k2q = ppo_epoch_ll2_kernel<2, 8, 32>;
-        const int nw = rows32 ? (g_epoch_quarters ? 8 : 4) : (g_epoch_waves8 ? 8 : 4);
-        const int ki = (d->obs_dim <= 16 ? 0 : 1) + (rows32 ? (nw == 8 ? 6 : 4) : (nw == 8 ? 2 : 0));
-        decltype(k1) kerns[8] = {k1, k2, k1h, k2h, k1r, k2r, k1q, k2q};
+        const int nw = rows32 ? (g_epoch_quarters ? 8 : 4) : 8;
+        const int ki = (d->obs_dim <= 16 ? 0 : 1) + (rows32 ? (nw == 8 ? 4 : 2) : 0);
+        decltype(k1h) kerns[6] = {k1h, k2h, k1r, k2r, k1q, k2q};
         auto kern = kerns[ki];
-        static bool attr_2[8] = {false, false, false, false, false, false, false, false};
+        static bool attr_2[6] = {false, false, false, false, false, false};
         if (!attr_2[ki]) { rc = set_lds(kern, EPOCH_LL_LDS); if (rc) return rc; attr_2[ki] = true; }
         EpochLl el{};
         el.base = ll_base;   // (cleared, like the error word, by the gather launch above)

@@ -557,9 +557,9 @@ int ia_ppo_debug_timing(void* device_buffer_16xi64);
  * Round 6, inside `ppo_epoch_ll2_kernel`: minibatches of up to 1 024 rows run on 32-ROW blocks (eight waves: two row groups x
  * four quarters of every layer's output features; twice the workgroups, half the chain and half the weight-gradient tiles per
  * compute unit), larger ones on 64-row blocks with eight waves per tower workgroup (feature halves, two waves per SIMD);
- * 5 = round 5's form (64-row blocks, four waves, every wave all output features); 6 = the eight-wave 64-row form also where
- * the 32-row blocks apply (its gradients are bit-identical to 5's: same MFMAs in the same order per tile); 7 = 32-row blocks
- * on four waves (feature halves; bit-identical to the default's quarters in the same sense). */
+ * 6 = the eight-wave 64-row form also where the 32-row blocks apply; 7 = 32-row blocks on four waves (feature halves: the same
+ * MFMAs in the same order per tile as the default's quarters -- bit-identical gradients). (Round 5's four-wave 64-row form, to
+ * which 6 was bit-identical in that sense, was retired in round 6.) */
 int ia_ppo_epoch_split(int on);
 /* Measurement only: device buffer of 64 int64 (NULL: off); workgroup 0 of the one-launch-per-epoch kernel accumulates
  * 100 MHz ticks per phase in [0..5] = {gradient, barrier, slab sum, barrier, norm + Adam, barrier}; [16..27] / [32..43]:

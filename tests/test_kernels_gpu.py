@@ -493,6 +493,9 @@ def test_timeout_bootstrap():
                                                         # (minibatch steps as phases between grid barriers)
                                                         (17, 6, 64, False, True, 16, 256, 1024),
                                                         (4, 2, 64, True, True, 9, 100, 384),
+                                                        # ... and beyond 1 024 rows (64-row blocks on eight waves; up to 1 024:
+                                                        # 32-row blocks), second observation-width class
+                                                        (27, 8, 64, False, True, 8, 512, 2048),
                                                         # ... down to ONE row block per minibatch (SB3's default batch_size
                                                         # = 64: two workgroups, each owning half the parameters -- the
                                                         # 20-per-thread chunk form) and two row blocks
@@ -696,15 +699,15 @@ def test_word_exchange_epoch_is_bit_identical_to_the_barrier_form(D, A, discrete
 @pytest.mark.parametrize("D,A,discrete,T,n,bs", [(17, 6, False, 16, 256, 1024), (4, 2, True, 9, 100, 384),
                                                   (27, 8, False, 8, 512, 2048), (11, 3, False, 8, 32, 64),
                                                   (16, 16, False, 5, 77, 200), (32, 5, True, 6, 64, 128)])
-def test_two_waves_per_simd_epoch_equals_the_four_wave_form(D, A, discrete, T, n, bs):
-    """64-wide towers, `ppo_epoch_ll2_kernel`: eight waves per tower workgroup (`ia_ppo_epoch_split(6)`: every wave half of a
-    layer's output tiles, its partner's half of the activations through LDS) against round 5's four (`ia_ppo_epoch_split(5)`):
-    every tile is accumulated by the same MFMAs in the same order, so with a clip threshold nothing reaches (the sum of squares
-    is folded by twice as many waves: the norm may differ in its last bit) parameters, transposed copy, Adam moments and the
-    loss statistics are bit-identical over three epochs; with the default threshold they agree to the last few bits. The
-    default form (0: 32-row blocks up to 1 024-row minibatches -- the rows' contraction in two slabs instead of one --, eight
-    waves = two row groups x four feature QUARTERS) agrees within the tolerance of the oracle comparison, is deterministic, and
-    is bit-identical in the same sense to its four-wave form (7: feature halves)."""
+def test_epoch_chain_forms_agree(D, A, discrete, T, n, bs):
+    """64-wide towers, `ppo_epoch_ll2_kernel`'s forms: 64-row blocks on eight waves (`ia_ppo_epoch_split(6)`: every wave half of
+    a layer's output tiles, two waves per SIMD; the form of 1 025 - 2 048-row minibatches), 32-row blocks on four waves (7:
+    feature halves) and on eight (0, the default up to 1 024 rows: feature QUARTERS). Every tile is accumulated by the same MFMAs
+    in the same order in 7 and 0, so with a clip threshold nothing reaches (the sum of squares is folded by twice as many waves:
+    the norm may differ in its last bit) parameters, transposed copy, Adam moments and the loss statistics are bit-identical over
+    three epochs, and agree to the last few bits with the default threshold. The 64-row form (the rows' contraction in one slab
+    per 64 rows instead of two) agrees with them within the tolerance of the oracle comparison; the default is deterministic.
+    (Round 5's four-wave 64-row form, to which 6 was bit-identical in the same sense, was retired: `profiles/r06_mlp64.md`.)"""
     pol_ref = _oracle_policy(D, A, 64, discrete, True, seed=5)
     rng = np.random.default_rng(1)
     obs = rng.standard_normal((T, n, D)).astype(np.float32)
@@ -719,7 +722,7 @@ def test_two_waves_per_simd_epoch_equals_the_four_wave_form(D, A, discrete, T, n
     for max_norm in (1e9, 0.5):
         outs = []
         try:
-            for mode in (5, 6, 0, 0, 7):
+            for mode in (6, 0, 0, 7):
                 dp = DevPolicy(pol_ref, D, A, 64, discrete, True)
                 ws = th.empty(int(L.load().ia_ppo_ws_floats(C.byref(dp.d), bs, T * n)), device=DEV)
                 ws.uniform_(-1e30, 1e30)   # (the workspace arrives uninitialised)
@@ -735,19 +738,10 @@ def test_two_waves_per_simd_epoch_equals_the_four_wave_form(D, A, discrete, T, n
                 outs.append(((dp.P.clone(), dp.Pt.clone(), dp.m.clone(), dp.v.clone(), dp.nm.clone(), dp.nv.clone()), stats.clone()))
         finally:
             L.load().ia_ppo_epoch_split(0)
-        (xs, st_x), (ys, st_y), (zs, st_z), (zs2, st_z2), (hs, st_h) = outs
-        assert float(ys[0].abs().sum()) > 0 and bool(th.isfinite(ys[0]).all()) and bool(th.isfinite(zs[0]).all())
-        if max_norm > 1e8:
-            for name, x, y in zip(names, xs, ys):
-                assert th.equal(x, y), f"{name}: {int((x != y).sum())} of {x.numel()} differ, max {float((x - y).abs().max()):.3e}"
-            assert th.equal(st_x[..., :6], st_y[..., :6]) and th.equal(st_x[..., 7], st_y[..., 7])
-            th.testing.assert_close(st_x[..., 6], st_y[..., 6], rtol=1e-6, atol=0)
-        else:
-            for name, x, y in zip(names, xs, ys):
-                th.testing.assert_close(x, y, rtol=(1 + k) * 1e-6, atol=(1 + k) * 2e-7, msg=lambda m, name=name: f"{name}: {m}")
-            th.testing.assert_close(st_x, st_y, rtol=1e-5, atol=1e-6)
-        for name, x, z in zip(names, xs, zs):   # the default form: other slabs, same gradient within rounding
-            th.testing.assert_close(x, z, rtol=(1 + k) * 1e-5, atol=(1 + k) * 2e-6, msg=lambda m, name=name: f"default form, {name}: {m}")
+        (xs, st_x), (zs, st_z), (zs2, st_z2), (hs, st_h) = outs
+        assert float(xs[0].abs().sum()) > 0 and bool(th.isfinite(xs[0]).all()) and bool(th.isfinite(zs[0]).all())
+        for name, x, z in zip(names, xs, zs):   # 64-row blocks against the default: other slabs, same gradient within rounding
+            th.testing.assert_close(x, z, rtol=(1 + k) * 1e-5, atol=(1 + k) * 2e-6, msg=lambda m, name=name: f"64-row form, {name}: {m}")
         th.testing.assert_close(st_x, st_z, rtol=1e-4, atol=1e-5)
         for name, z, z2 in zip(names, zs, zs2):
             assert th.equal(z, z2), f"default form, run to run, {name}"

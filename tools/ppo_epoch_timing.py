@@ -27,7 +27,7 @@ L.load().ia_ppo_epoch_debug_timing(None)
 algo = tr.gen_algo
 steps = rounds * algo.n_epochs * algo._n_mb
 t = buf.cpu().numpy()[:6] / 100.0 / steps
-chain2 = mode in (0, 5) and tr.gen_algo.policy.obs_dim <= 32   # round 5's gradient phase (ppo_epoch_ll2_kernel)
+chain2 = mode in (0, 6, 7) and tr.gen_algo.policy.obs_dim <= 32   # round 5's gradient phase (ppo_epoch_ll2_kernel)
 names = (("gradient", "barrier", "slab sum + partial norm", "barrier", "norm + Adam + statistics", "barrier") if mode == 3 else
          ("gradient (incl. parameter poll)", "slab poll + sum", "partial norm published", "poll of the partial norms",
           "norm + Adam + publish + statistics", "-"))
