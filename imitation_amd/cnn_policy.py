@@ -546,12 +546,12 @@ class ActorCriticCnnPolicy:
                 d = self._forward(frames, values_out=val[t])
                 h_logits.copy_(d["logits"], non_blocking=True)
 
+        h_logp_np, h_clip_np, rows_np = h_logp.numpy(), h_clip.numpy().reshape(h_clip.shape[0], n), np.arange(n)
+
         def finish(t: int) -> None:
             stream_obj.synchronize()
-            from imitation_amd.policies import categorical_sample   # (local: policies imports this module)
-            a, lp = categorical_sample(h_logits)
-            h_logp[t].copy_(lp)
-            h_clip[t].copy_(a.reshape(n, 1))
+            from imitation_amd.policies import categorical_sample_into   # (local: policies imports this module)
+            categorical_sample_into(h_logits, h_logp_np[t], h_clip_np[t], rows_np)
 
         return launch, finish
 

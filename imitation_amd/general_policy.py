@@ -276,6 +276,7 @@ class GeneralTowers:
         n = obs_tile.shape[1]
         ws = self._buffers("step", n)
         stream_obj = th.cuda.current_stream()
+        h_logp_np, h_clip_np, rows_np = h_logp.numpy(), h_clip.numpy().reshape(h_clip.shape[0], n), np.arange(n)
 
         def step(t: int) -> None:
             with th.cuda.stream(stream_obj):
@@ -284,10 +285,8 @@ class GeneralTowers:
                 h_logits.copy_(ws["out"], non_blocking=True)
                 val[t].copy_(ws["val"].reshape(n))
             stream_obj.synchronize()
-            from imitation_amd.policies import categorical_sample   # (local: policies imports this module)
-            a, lp = categorical_sample(h_logits)
-            h_logp[t].copy_(lp)
-            h_clip[t].copy_(a.reshape(n, 1))
+            from imitation_amd.policies import categorical_sample_into   # (local: policies imports this module)
+            categorical_sample_into(h_logits, h_logp_np[t], h_clip_np[t], rows_np)
 
         return step
 

@@ -582,6 +582,16 @@ def test_categorical_sample_equals_torch_distributions(shape):
         for (a, lp), (ra, rlp) in zip(got, ref):
             assert th.equal(a, ra) and a.dtype == ra.dtype and a.shape == ra.shape
             assert th.equal(lp, rlp)
+        if len(shape) == 2:   # the rollout steps' form: results straight into the pinned tiles' NumPy rows
+            from imitation_amd.policies import categorical_sample_into
+            n = shape[0]
+            lp_rows, act_rows = np.full((4, n), np.nan, np.float32), np.full((4, n, 1), np.nan, np.float32)
+            th.manual_seed(9)
+            for t, lg in enumerate(logits):
+                categorical_sample_into(lg, lp_rows[t], act_rows.reshape(4, n)[t], np.arange(n))
+            assert th.equal(th.get_rng_state(), ref_state)
+            for t, (ra, rlp) in enumerate(ref):
+                assert np.array_equal(lp_rows[t], rlp.numpy()) and np.array_equal(act_rows[t, :, 0], ra.numpy().astype(np.float32))
 
 
 def test_block_draw_of_interpolation_weights_equals_per_update_draws():
