@@ -57,6 +57,37 @@ def categorical_sample(logits: th.Tensor):
     return a, lg.gather(-1, a.unsqueeze(-1)).squeeze(-1)
 
 
+_RACE_OK = None   # does `_multinomial_one` reproduce `torch.multinomial(p, 1, True)` on this torch build? (checked on first use)
+
+
+def _multinomial_one(probs: th.Tensor, generator=None) -> np.ndarray:
+    """`torch.multinomial(probs, 1, True)[:, 0]` of a 2-D float32 tile as torch itself forms it (ATen `multinomial`, one sample
+    per row: `q = empty_like(p).exponential_(1)`, `argmax(p / q)` -- the exponential race): the ONE generator call is the same
+    call on the same tensor, the division and the argmax are NumPy's (IEEE division; first maximum). torch's own entry spends
+    most of its ~10 us per 8 x 2 tile on argument checks (`max`, `min`, `sum`, `any` reductions of the probabilities) that a
+    softmax's output does not need."""
+    q = th.empty_like(probs).exponential_(1.0, generator=generator)
+    return np.argmax(probs.numpy() / q.numpy(), axis=-1)
+
+
+def _race_reproduces_multinomial() -> bool:
+    """The guard of `_multinomial_one`: on private generators, the same actions AND the same generator state as
+    `torch.multinomial` over several shapes and draws -- an ATen that samples differently fails it and the rollout step keeps
+    calling `torch.multinomial`."""
+    global _RACE_OK
+    if _RACE_OK is None:
+        ok = True
+        gp = th.Generator().manual_seed(11)
+        for shape in ((8, 2), (64, 6), (1024, 6), (5, 13), (1, 3)):
+            g1, g2 = th.Generator().manual_seed(7), th.Generator().manual_seed(7)
+            for _ in range(12):
+                p = th.softmax(th.randn(*shape, generator=gp) * 3.0, -1)
+                ref = th.multinomial(p, 1, True, generator=g1)[:, 0].numpy()
+                ok = ok and np.array_equal(ref, _multinomial_one(p, g2)) and th.equal(g1.get_state(), g2.get_state())
+        _RACE_OK = bool(ok)
+    return _RACE_OK
+
+
 def categorical_sample_into(logits: th.Tensor, logp_row: np.ndarray, act_row: np.ndarray, rows: np.ndarray) -> None:
     """`categorical_sample` of a host `[n, A]` logits tile with the results written straight into NumPy rows (the pinned rollout
     tiles' views): `logp_row[n]` float32, `act_row[n]` float32 (the action indices; exact), `rows = np.arange(n)`. The three
@@ -64,7 +95,10 @@ def categorical_sample_into(logits: th.Tensor, logp_row: np.ndarray, act_row: np
     3-5 us each per environment step at 8 environments -- are NumPy indexing."""
     lg = logits - logits.logsumexp(dim=-1, keepdim=True)
     probs = th.nn.functional.softmax(lg, dim=-1)
-    a = th.multinomial(probs, 1, True).numpy()[:, 0]
+    if probs.dtype == th.float32 and probs.dim() == 2 and _race_reproduces_multinomial():
+        a = _multinomial_one(probs)
+    else:
+        a = th.multinomial(probs, 1, True).numpy()[:, 0]
     logp_row[:] = lg.numpy()[rows, a]
     act_row[:] = a
 

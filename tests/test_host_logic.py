@@ -583,7 +583,9 @@ def test_categorical_sample_equals_torch_distributions(shape):
             assert th.equal(a, ra) and a.dtype == ra.dtype and a.shape == ra.shape
             assert th.equal(lp, rlp)
         if len(shape) == 2:   # the rollout steps' form: results straight into the pinned tiles' NumPy rows
+            from imitation_amd import policies
             from imitation_amd.policies import categorical_sample_into
+            assert policies._race_reproduces_multinomial(), "this torch build samples `multinomial` differently: the guard must trip"
             n = shape[0]
             lp_rows, act_rows = np.full((4, n), np.nan, np.float32), np.full((4, n, 1), np.nan, np.float32)
             th.manual_seed(9)
@@ -592,6 +594,28 @@ def test_categorical_sample_equals_torch_distributions(shape):
             assert th.equal(th.get_rng_state(), ref_state)
             for t, (ra, rlp) in enumerate(ref):
                 assert np.array_equal(lp_rows[t], rlp.numpy()) and np.array_equal(act_rows[t, :, 0], ra.numpy().astype(np.float32))
+
+
+def test_multinomial_race_guard_trips_and_falls_back(monkeypatch):
+    """`policies._multinomial_one` stands on how ATen samples one action per row; `_race_reproduces_multinomial` is what stands
+    between another torch build and silently different rollouts: with a sampler that draws differently the guard says no, and
+    `categorical_sample_into` then produces `torch.multinomial`'s draws through torch itself."""
+    from imitation_amd import policies
+    monkeypatch.setattr(policies, "_RACE_OK", None)
+    monkeypatch.setattr(policies, "_multinomial_one",
+                        lambda p, generator=None: np.argmax(p.numpy() / th.empty_like(p).uniform_(generator=generator).numpy(), -1))
+    assert policies._race_reproduces_multinomial() is False
+    logits = th.randn(8, 3, generator=th.Generator().manual_seed(2))
+    th.manual_seed(4)
+    d = th.distributions.Categorical(logits=logits)
+    ra = d.sample()
+    rlp, ref_state = d.log_prob(ra), th.get_rng_state()
+    lp, act = np.zeros(8, np.float32), np.zeros(8, np.float32)
+    th.manual_seed(4)
+    policies.categorical_sample_into(logits, lp, act, np.arange(8))
+    assert th.equal(th.get_rng_state(), ref_state) and np.array_equal(act, ra.numpy().astype(np.float32))
+    assert np.array_equal(lp, rlp.numpy())
+    monkeypatch.setattr(policies, "_RACE_OK", None)   # (the next user checks the real sampler again)
 
 
 def test_block_draw_of_interpolation_weights_equals_per_update_draws():
