@@ -275,6 +275,7 @@ class ActorCriticCnnPolicy:
     # rows of a weight gradient's contraction per K split (<= 64 splits): a convolution's [64 x 512] gradient is 8 output tiles
     # -- at 2 048 rows per split a 256-frame minibatch (20 736 rows) ran on 80 workgroups of 64 K chunks each
     WGRAD_ROWS_PER_SPLIT = 512
+    ACT_ZERO_COPY = True   # (False: the rollout step's frames go through a device copy first -- same-box A/Bs)
     LINEAR_SPLIT_K = True   # (False: the feature layer's product unsplit at every batch size -- same-box A/Bs)
 
     def _linear_splits(self, B: int) -> int:
@@ -539,10 +540,17 @@ class ActorCriticCnnPolicy:
         obs_d = th.empty(n, self.obs_dim, dtype=obs_tile.dtype, device=self.device)
         stream_obj = th.cuda.current_stream()
 
+        zero_copy = self.ACT_ZERO_COPY and u8_tile and obs_tile.is_pinned() and self.implicit_conv1
+
         def launch(t: int) -> None:
             with th.cuda.stream(stream_obj):
-                obs_d.copy_(obs_tile[t], non_blocking=True)
-                frames = obs_d.view(-1, *self.observation_space.shape) if u8_tile else self._rows_u8(obs_d)
+                if zero_copy:
+                    # the first convolution reads the step's frames straight from their pinned (device-mapped) row: no copy-engine
+                    # hop of 1.8 MB in front of the step's eight launches
+                    frames = obs_tile[t].view(-1, *self.observation_space.shape)
+                else:
+                    obs_d.copy_(obs_tile[t], non_blocking=True)
+                    frames = obs_d.view(-1, *self.observation_space.shape) if u8_tile else self._rows_u8(obs_d)
                 d = self._forward(frames, values_out=val[t])
                 h_logits.copy_(d["logits"], non_blocking=True)
 

@@ -25,5 +25,8 @@ if os.environ.get("IA_RELABEL_LATE"):   # A/B: module reward nets relabel the wh
         _init(self, *a, **k)
         self.relabel_early = False
     _ppo.PPO.__init__ = _late
+if os.environ.get("IA_ACT_COPY"):   # A/B: the image act step's frames through a device copy (before: zero-copy reads of the pinned row)
+    from imitation_amd import cnn_policy as _cp
+    _cp.ActorCriticCnnPolicy.ACT_ZERO_COPY = False
 name = sys.argv[1] if len(sys.argv) > 1 else "3_airl_ant_1024x16_mb1024"
 print(name, bench.run_variant(name, rounds=int(sys.argv[2]) if len(sys.argv) > 2 else 6))
