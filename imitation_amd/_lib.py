@@ -159,6 +159,7 @@ _SIGS = {
     "ia_reduce_partials": ([_P, _I, _L, _F, _I, _P, _P], C.c_int),
     "ia_reduce_partials_strided": ([_P, _I, _L, _L, _F, _I, _P, _P], C.c_int),
     "ia_copy_pieces": ([_I, _P, _P, _P, _P], C.c_int),
+    "ia_reduce_partials_multi": ([_I, _P, _P, _P, _P, _P], C.c_int),
     "ia_adam_step": ([_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _F, _P], C.c_int),
     "ia_adam_step_scalars": ([_P, C.c_double, _P, C.c_double, C.c_double, _P, _P], C.c_int),
     "ia_adam_step_dev": ([_P, _P, _P, _P, _L, _F, _F, _F, _F, _P, _P], C.c_int),

@@ -136,6 +136,7 @@ class ActorCriticCnnPolicy:
         self.device = th.device("cpu")
         self._lr0 = float(lr_schedule(1))
         self._bufs: Dict[int, Dict[str, th.Tensor]] = {}
+        self._pending_reduce: list = []   # (slabs, splits, n, destination piece of the flat gradient) queued by `_wgrad`
 
     # ---- layouts ---------------------------------------------------------------------------------------
     def _to_device_layout(self, i: int, w: th.Tensor) -> th.Tensor:
@@ -275,6 +276,7 @@ class ActorCriticCnnPolicy:
     # rows of a weight gradient's contraction per K split (<= 64 splits): a convolution's [64 x 512] gradient is 8 output tiles
     # -- at 2 048 rows per split a 256-frame minibatch (20 736 rows) ran on 80 workgroups of 64 K chunks each
     WGRAD_ROWS_PER_SPLIT = 512
+    REDUCE_IN_ONE_LAUNCH = True
     ACT_ZERO_COPY = True   # (False: the rollout step's frames go through a device copy first -- same-box A/Bs)
     LINEAR_SPLIT_K = True   # (False: the feature layer's product unsplit at every batch size -- same-box A/Bs)
 
@@ -377,8 +379,24 @@ class ActorCriticCnnPolicy:
         else:
             self._gemm(2, dout, n_out, inp, K, part, K, n_out, K, rows, splits=splits, dbias=db)
         ow_, nw, ob_, nb = self._offsets[li]
-        L.call("ia_reduce_partials", L.ptr(part), splits, nw, 1.0, 1, L.ptr(grad[ow_:ow_ + nw]), L.stream())
-        L.call("ia_reduce_partials", L.ptr(db), splits, nb, 1.0, 1, L.ptr(grad[ob_:ob_ + nb]), L.stream())
+        # (the slabs' ordered sums are added to the flat gradient by ONE launch at the end of `backward`: `_flush_reduces`)
+        self._pending_reduce.append((part, splits, nw, grad[ow_:ow_ + nw]))
+        self._pending_reduce.append((db, splits, nb, grad[ob_:ob_ + nb]))
+
+    def _flush_reduces(self) -> None:
+        """`grad[piece] += ordered sum of the piece's slabs` for every weight / bias piece `_wgrad` queued: one launch per <= 16
+        pieces (a launch per piece before: twelve per optimiser step of ~6 us each at minibatch sizes)."""
+        pend, self._pending_reduce = self._pending_reduce, []
+        if not self.REDUCE_IN_ONE_LAUNCH:   # (same-box A/Bs: a launch per piece, the same sums)
+            for part, splits, n, dst in pend:
+                L.call("ia_reduce_partials", L.ptr(part), splits, n, 1.0, 1, L.ptr(dst), L.stream())
+            return
+        for lo in range(0, len(pend), 16):
+            seg = pend[lo:lo + 16]
+            k = len(seg)
+            L.call("ia_reduce_partials_multi", k, (C.c_void_p * k)(*(t[0].data_ptr() for t in seg)),
+                   (C.c_int * k)(*(t[1] for t in seg)), (C.c_int64 * k)(*(t[2] for t in seg)),
+                   (C.c_void_p * k)(*(t[3].data_ptr() for t in seg)), L.stream())
 
     def _dcol(self, d, li: int, rows: int, K: int) -> th.Tensor:
         """Column-gradient buffer of the explicit input-gradient path (allocated on first use)."""
@@ -466,6 +484,7 @@ class ActorCriticCnnPolicy:
                 L.call("ia_col2im_nhwc", L.ptr(d[f"dcol{li}"]), B, h, w_, cin, k, k, s, L.ptr(d[f"act{li - 1}"]),
                        L.ptr(d[f"dact{li - 1}"]), L.stream())
             dout = d[f"dact{li - 1}"]
+        self._flush_reduces()
 
     # ---- PPO generator protocol (the surface `ppo.PPO` and the adversarial trainer drive; same as
     # `general_policy.GeneralTowers`) ---------------------------------------------------------------------------

@@ -885,6 +885,51 @@ int ia_reduce_partials_strided(const float* partials, int splits, int64_t n, int
 }
 
 namespace {
+// up to 16 slab reductions in ONE launch: segment g's element i = scale-free sum over its `splits[g]` slabs (stride n[g]) in
+// slab order, ADDED to dst[g][i] -- `reduce_partials_kernel(accumulate = 1, scale = 1)`'s arithmetic per element
+struct ReduceSegs { const float* part[16]; float* dst[16]; long long n[16]; long long start[17]; int splits[16]; int count; };
+__global__ void reduce_segments_kernel(ReduceSegs c) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= c.start[c.count]) return;
+  int g = 0;
+  while (g + 1 < c.count && i >= c.start[g + 1]) ++g;
+  const long long j = i - c.start[g], n = c.n[g];
+  const float* __restrict__ partials = c.part[g];
+  const int splits = c.splits[g];
+  float s = 0.f;
+  int k = 0;
+  for (; k + 8 <= splits; k += 8) {
+    float t[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) t[u] = partials[(long long)(k + u) * n + j];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s += t[u];
+  }
+  for (; k < splits; ++k) s += partials[(long long)k * n + j];
+  s *= 1.0f;   // (the single reduction's `scale`)
+  c.dst[g][j] = c.dst[g][j] + s;
+}
+}  // namespace
+
+int ia_reduce_partials_multi(int n_segs, const float* const* partials, const int* splits, const int64_t* n, float* const* dst,
+                             void* stream) {
+  if (n_segs < 1 || n_segs > 16) return IA_ERR_ARG;
+  ReduceSegs c{};
+  long long total = 0;
+  for (int g = 0; g < n_segs; ++g) {
+    if (n[g] <= 0 || splits[g] < 1) return IA_ERR_ARG;
+    c.part[g] = partials[g]; c.dst[g] = dst[g]; c.n[g] = n[g]; c.splits[g] = splits[g];
+    c.start[g] = total;
+    total += n[g];
+  }
+  c.start[n_segs] = total;
+  c.count = n_segs;
+  hipLaunchKernelGGL(reduce_segments_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, c);
+  IA_CHECK_LAUNCH();
+  return IA_OK;
+}
+
+namespace {
 struct CopyPieces { const float* src[4]; float* dst[4]; long long n[4]; long long start[5]; };
 __global__ void copy_pieces_kernel(CopyPieces c) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;

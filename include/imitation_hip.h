@@ -97,6 +97,10 @@ int ia_reduce_partials(const float* partials, int splits, int64_t n, float scale
  * `.value_net`, `action_net`, `value_net` in that order, the kernels want each tower's layers contiguous). */
 int ia_reduce_partials_strided(const float* partials, int splits, int64_t n, int64_t stride, float scale, int accumulate,
                                float* grads, void* stream);
+/* n_segs <= 16 reductions `ia_reduce_partials(partials[g], splits[g], n[g], 1.0, accumulate = 1, dst[g])` in ONE launch (the
+ * NatureCNN policy's backward pass: weight and bias slabs of its six layers -- twelve launches per optimiser step before). */
+int ia_reduce_partials_multi(int n_segs, const float* const* partials, const int* splits, const int64_t* n, float* const* dst,
+                             void* stream);
 /* dst[p][0 .. n[p]) = src[p][0 .. n[p]) for p < n_pieces <= 4 in ONE launch (the towers' contiguous parameter stacks
  * refreshed from the flat parameter vector behind an optimiser step: four device-to-device copies before). */
 int ia_copy_pieces(int n_pieces, const float* const* src, float* const* dst, const int64_t* n, void* stream);

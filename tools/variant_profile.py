@@ -28,5 +28,8 @@ if os.environ.get("IA_RELABEL_LATE"):   # A/B: module reward nets relabel the wh
 if os.environ.get("IA_ACT_COPY"):   # A/B: the image act step's frames through a device copy (before: zero-copy reads of the pinned row)
     from imitation_amd import cnn_policy as _cp
     _cp.ActorCriticCnnPolicy.ACT_ZERO_COPY = False
+if os.environ.get("IA_REDUCE_EACH"):   # A/B: the NatureCNN policy's slab reductions one launch per piece
+    from imitation_amd import cnn_policy as _cp2
+    _cp2.ActorCriticCnnPolicy.REDUCE_IN_ONE_LAUNCH = False
 name = sys.argv[1] if len(sys.argv) > 1 else "3_airl_ant_1024x16_mb1024"
 print(name, bench.run_variant(name, rounds=int(sys.argv[2]) if len(sys.argv) > 2 else 6))
